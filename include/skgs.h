@@ -1,0 +1,186 @@
+/*
+ * skgs.h -- C ABI of libskgs_hip.so: the MI355X (gfx950) implementation of SK_GS's per-frame hot path
+ *           (LBS deform of every Gaussian + differentiable 3DGS tile rasterizer, forward and backward).
+ *
+ * Boundary: every entry point below replaces one pybind11 function of the reference's CUDA extension
+ * `my_ext/_C` (resolved in Python through get_C_function(name), my_ext/_C/__init__.py:17-48), or -- for the
+ * deform -- the torch/lietorch op sequence of networks/sk_gs.py.  Signatures carry only plain pointers, sizes
+ * and a HIP stream: no torch types.  All tensors are fp32, contiguous, device memory unless stated; index
+ * tensors are int32 (`radii`, `n_contrib`, top-k ids) or int64 (KNN indices, as pytorch3d returns them).
+ *
+ * Reference interface replaced (file:line relative to the reference root):
+ *   skgs_rasterize_forward*      <- rasterize_gaussians               my_ext/_C/src/nerf/gaussian_rasterizer_forward.cu:260-317
+ *   skgs_rasterize_backward      <- rasterize_gaussians_backward      my_ext/_C/src/nerf/gaussian_rasterizer_backwrad.cu:200-261,333
+ *   skgs_rasterize_extra_forward <- gaussian_rasterize_extra_forward  my_ext/_C/src/nerf/gaussian_rasterizer_extra.cu:222-246
+ *   skgs_rasterize_extra_backward<- gaussian_rasterize_extra_backward my_ext/_C/src/nerf/gaussian_rasterizer_extra.cu:248-277
+ *   skgs_topk_weights            <- gaussian_topk_weights             my_ext/_C/src/nerf/gaussian_topk.cu:98-121
+ *   skgs_mark_visible            <- mark_visible (commented out)      my_ext/_C/src/nerf/gaussian_rasterizer_imp.cu:75-103
+ *   skgs_lbs_deform_forward/backward <- networks/sk_gs.py:1143-1150,1162,1192-1203 (+ lietorch SE3.act, lie.h:59-64,246)
+ *   skgs_knn_bones               <- pytorch3d.ops.knn_points call     networks/sk_gs.py:757
+ *
+ * Opaque buffers (the reference's geomBuffer / binningBuffer / imgBuffer uint8 tensors, gaussian_render.h:118-158):
+ * the caller allocates them with the sizes returned by skgs_*_buffer_bytes() and hands the same bytes back to the
+ * backward / extra / top-k calls.  Their internal layout is private to this library (DESIGN.md "Data layout").
+ *
+ * Host synchronisation: the reference copies num_rendered to the host in the middle of the forward
+ * (gaussian_rasterizer_forward.cu:209).  Here the forward is split so the caller decides:
+ *   (a) skgs_rasterize_forward_stage1 -> sync -> read *host_num_rendered -> allocate binning buffer exactly ->
+ *       skgs_rasterize_forward_stage2                     (reference behaviour, one sync)
+ *   (b) skgs_rasterize_forward with a binning capacity the caller guessed; no sync; device-side overflow flag
+ *       (skgs_read_status) tells later whether the guess was too small.       (hipGraph-capturable)
+ *
+ * Every function returns 0 on success, non-zero on error; skgs_last_error() returns the message of the last
+ * failure on the calling thread (the reference raises through AT_ERROR -> Python RuntimeError).
+ */
+#ifndef SKGS_H_
+#define SKGS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKGS_VERSION 1
+#define SKGS_TILE 16             /* BLOCK_X = BLOCK_Y, gaussian_render.h:29-30 */
+#define SKGS_MAX_RENDER_EXTRA 4  /* E <= 4 in renderCUDA_{forward,backward}, gaussian_render.cu:117-139 */
+
+typedef void* skgs_stream_t; /* hipStream_t */
+
+/* Inputs of rasterize_gaussians / rasterize_gaussians_backward (same meaning, same order as the pybind args). */
+typedef struct skgs_raster_inputs {
+  int32_t P;          /* number of Gaussians */
+  int32_t sh_degree;  /* active SH degree D (0..3) */
+  int32_t sh_coeffs;  /* allocated SH coefficients per Gaussian M (sh is [P, M, 3]); 0 when colors_precomp is used */
+  int32_t E;          /* extra channels blended with the colour (0..4) */
+  int32_t image_height, image_width;
+  float tanfovx, tanfovy, scale_modifier;
+  int32_t prefiltered, debug, colmap;
+  const float* viewmatrix; /* [4,4] colmap=1: transposed (column-major) world->view; colmap=0: row-major */
+  const float* projmatrix; /* [4,4] same convention, full projection */
+  const float* campos;     /* [3] */
+  const float* means3D;    /* [P,3] */
+  const float* opacity;    /* [P,1] */
+  const float* sh;         /* [P,M,3] or NULL */
+  const float* scales;     /* [P,3] or NULL */
+  const float* rotations;  /* [P,4] xyzw, not normalised by the kernels (ops_3d.h:93-103) or NULL */
+  const float* extras;     /* [P,E] or NULL */
+  const float* colors_precomp; /* [P,3] or NULL */
+  const float* cov3D_precomp;  /* [P,6] or NULL */
+} skgs_raster_inputs;
+
+typedef struct skgs_raster_buffers {
+  void* geom;    size_t geom_bytes;
+  void* binning; size_t binning_bytes;
+  void* img;     size_t img_bytes;
+} skgs_raster_buffers;
+
+/* status words kept in the geom buffer header, readable asynchronously */
+typedef struct skgs_status {
+  int32_t num_rendered;   /* R = sum of tiles touched (what the reference returns) */
+  int32_t overflow;       /* 1 if R exceeded the binning capacity given to stage 2 */
+  int32_t max_tile_count; /* longest per-tile list */
+  int32_t reserved;
+} skgs_status;
+
+size_t skgs_geom_buffer_bytes(int32_t P);
+size_t skgs_img_buffer_bytes(int32_t image_width, int32_t image_height);
+size_t skgs_binning_buffer_bytes(int64_t capacity /* tile instances */);
+int64_t skgs_binning_capacity(size_t binning_bytes);
+
+/* Forward, stage 1: per-Gaussian preprocess (cull, project, Sigma3D/2D, conic, radius, SH->RGB), per-tile counts,
+ * exclusive scan.  Writes radii[P].  If host_num_rendered != NULL (pinned host memory) R is copied there
+ * asynchronously on `stream`. */
+int skgs_rasterize_forward_stage1(const skgs_raster_inputs* in, const skgs_raster_buffers* buf, int32_t* radii,
+    int32_t* host_num_rendered, skgs_stream_t stream);
+/* Forward, stage 2: scatter tile instances, per-tile depth sort, alpha-blend.  out_color [3,H,W], out_opacity [H,W]
+ * (= 1 - T, no background: gaussian_render.cu:106-108), out_extra [E,H,W] or NULL. */
+int skgs_rasterize_forward_stage2(const skgs_raster_inputs* in, const skgs_raster_buffers* buf, float* out_color,
+    float* out_opacity, float* out_extra, skgs_stream_t stream);
+/* Both stages back to back, no host synchronisation. */
+int skgs_rasterize_forward(const skgs_raster_inputs* in, const skgs_raster_buffers* buf, int32_t* radii,
+    float* out_color, float* out_opacity, float* out_extra, int32_t* host_num_rendered, skgs_stream_t stream);
+/* Copies the status words to host memory (async on stream). */
+int skgs_read_status(const skgs_raster_buffers* buf, skgs_status* host_status, skgs_stream_t stream);
+
+typedef struct skgs_raster_grads {
+  /* grad_outputs */
+  const float* dL_dout_color;   /* [3,H,W] */
+  const float* dL_dout_opacity; /* [H,W] */
+  const float* dL_dout_extra;   /* [E,H,W] or NULL */
+  /* optional gradients chained in from gaussian_rasterize_extra_backward: added to the results (NULL = none) */
+  const float* grad_means2D_in; /* [P,3] */
+  const float* grad_conic_in;   /* [P,2,2] */
+  const float* grad_opacity_in; /* [P,1] */
+  /* outputs, all written completely (rows of culled Gaussians are zero) */
+  float* dL_dmeans2D;   /* [P,3]  (NDC-scaled, z = 0) */
+  float* dL_dconic;     /* [P,2,2] or NULL */
+  float* dL_dcolors;    /* [P,3] */
+  float* dL_dopacity;   /* [P,1] */
+  float* dL_dmeans3D;   /* [P,3] */
+  float* dL_dcov3D;     /* [P,6] */
+  float* dL_dsh;        /* [P,M,3] or NULL when M == 0 */
+  float* dL_dscales;    /* [P,3] */
+  float* dL_drotations; /* [P,4] */
+  float* dL_dextras;    /* [P,E] or NULL */
+  /* scratch: P*16 floats, contents undefined on entry and exit */
+  float* workspace; size_t workspace_bytes;
+} skgs_raster_grads;
+size_t skgs_backward_workspace_bytes(int32_t P);
+
+int skgs_rasterize_backward(const skgs_raster_inputs* in, const skgs_raster_buffers* buf, const int32_t* radii,
+    const float* out_opacity, const skgs_raster_grads* g, skgs_stream_t stream);
+
+/* Blend arbitrary per-Gaussian features with the saved buffers. extra [P,E]; pixel_extra [H*W, E] (pixel-major,
+ * the reference labels this tensor {W,H,E}). */
+int skgs_rasterize_extra_forward(int32_t W, int32_t H, int32_t P, int32_t E, const float* extra,
+    const skgs_raster_buffers* buf, float* pixel_extra, skgs_stream_t stream);
+/* grad_means2D [P,3], grad_conic [P,2,2], grad_opacity [P,1] are accumulated INTO (caller zero-fills fresh ones);
+ * dL_dextra [P,E] is overwritten. */
+int skgs_rasterize_extra_backward(int32_t W, int32_t H, int32_t P, int32_t E, const float* extra,
+    const float* out_opacity, const float* grad_pixel_extra, const skgs_raster_buffers* buf, float* grad_means2D,
+    float* grad_conic, float* grad_opacity, float* dL_dextra, skgs_stream_t stream);
+/* top_indices [H,W,k] int32 (-1 fill), top_weights [H,W,k] */
+int skgs_topk_weights(int32_t topk, int32_t W, int32_t H, int32_t P, const skgs_raster_buffers* buf,
+    int32_t* top_indices, float* top_weights, skgs_stream_t stream);
+/* present [P] bytes (0/1): near-plane test of in_frustum{,_colmap} */
+int skgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, int32_t colmap, uint8_t* present,
+    skgs_stream_t stream);
+
+/* ---- LBS deform + activation epilogue (networks/sk_gs.py:1143-1150,1162,1192-1203) ---- */
+typedef struct skgs_deform_inputs {
+  int32_t P, K, M;
+  const float* points;        /* [P,3] detached copy of xyz (may alias xyz) */
+  const float* weights;       /* [P,K] */
+  const int64_t* indices;     /* [P,K] bone ids */
+  const float* bone_T;        /* [M,7] tx,ty,tz,qx,qy,qz,qw */
+  const float* bone_drot;     /* [M,4] */
+  const float* bone_dscale;   /* [M,3] */
+  const float* xyz;           /* [P,3] */
+  const float* log_scale;     /* [P,3] */
+  const float* rot;           /* [P,4] */
+  const float* opacity_logit; /* [P,1] */
+} skgs_deform_inputs;
+/* means [P,3], scales [P,3], rotations [P,4] (normalised), opacity [P,1]; d_xyz/d_rot/d_scale optional (NULL) */
+int skgs_lbs_deform_forward(const skgs_deform_inputs* in, float* means, float* scales, float* rotations,
+    float* opacity, float* d_xyz, float* d_rot, float* d_scale, skgs_stream_t stream);
+/* g_bone_* must be zero-filled by the caller (they are accumulated with atomics). */
+int skgs_lbs_deform_backward(const skgs_deform_inputs* in, const float* g_means, const float* g_scales,
+    const float* g_rotations, const float* g_opacity, float* g_weights, float* g_bone_T, float* g_bone_drot,
+    float* g_bone_dscale, float* g_xyz, float* g_log_scale, float* g_rot, float* g_opacity_logit,
+    skgs_stream_t stream);
+/* K (<= 16) nearest bones by squared L2 in `dim` dimensions, ascending, ties to the lower index. */
+int skgs_knn_bones(int32_t P, int32_t M, int32_t K, int32_t dim, const float* points, const float* joints,
+    float* out_dist, int64_t* out_idx, skgs_stream_t stream);
+
+/* Tuning knob of the blend kernels: pixels handled per lane (1, 2 or 4); 0 = heuristic on the tile count. */
+void skgs_set_pixels_per_lane(int ppl);
+
+const char* skgs_last_error(void);
+int skgs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKGS_H_ */

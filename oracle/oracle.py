@@ -1,0 +1,301 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/skgs_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Imported by tests/, by bench.py's ``cpu_baseline`` leg and by
+``__graft_entry__.smoke()`` as the checker -- never by the product package ``sk_gs_amd``.
+
+Every method mirrors one reference kernel / host function (file:line in the C source).  Inputs are numpy
+arrays (anything ``np.asarray`` accepts); outputs are freshly allocated numpy arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+BLOCK = 16
+
+
+def build(out_dir: Optional[str] = None, native: bool = False) -> str:
+    """Compile the oracle with gcc (idempotent). Returns the directory holding the .so files."""
+    out = out_dir or os.path.join(_HERE, '_build')
+    args = ['make', '-s', '-C', _HERE, f'OUT={out}']
+    if native:
+        args.append('native')
+    subprocess.run(args, check=True)
+    return out
+
+
+def _lib_path(name: str, out_dir: Optional[str] = None) -> str:
+    out = out_dir or os.path.join(_HERE, '_build')
+    path = os.path.join(out, name)
+    if not os.path.exists(path):
+        build(out_dir)
+    return path
+
+
+def _p(a: Optional[np.ndarray]):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """fp32 oracle (``dtype='f32'``) or its fp64 twin (``dtype='f64'``)."""
+
+    def __init__(self, dtype: str = 'f32', lib_path: Optional[str] = None):
+        assert dtype in ('f32', 'f64')
+        self.dtype = np.float32 if dtype == 'f32' else np.float64
+        self.prefix = 'skgs_oracle_' if dtype == 'f32' else 'skgs_oracle64_'
+        self.creal = C.c_float if dtype == 'f32' else C.c_double
+        name = 'libskgs_oracle.so' if dtype == 'f32' else 'libskgs_oracle64.so'
+        self.lib = C.CDLL(lib_path or _lib_path(name))
+        self._fn('bin_and_sort').restype = C.c_int64
+        self._fn('getHigherMsb').restype = C.c_uint32
+        self._fn('num_threads').restype = C.c_int
+
+    # ------------------------------------------------------------------ helpers
+    def _fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def r(self, a, shape=None) -> Optional[np.ndarray]:
+        """to contiguous REAL array; empty / None -> None (the reference's null-pointer convention)"""
+        if a is None:
+            return None
+        a = np.ascontiguousarray(np.asarray(a), dtype=self.dtype)
+        if a.size == 0:
+            return None
+        if shape is not None:
+            a = a.reshape(shape)
+        return a
+
+    def num_threads(self) -> int:
+        return int(self._fn('num_threads')())
+
+    # ------------------------------------------------------------------ stages
+    def preprocess_forward(self, means3D, scales, rotations, opacities, shs, viewmatrix, projmatrix, campos, W, H,
+                           tanfovx, tanfovy, sh_degree, scale_modifier=1.0, colmap=True, cov3D_precomp=None,
+                           colors_precomp=None):
+        """preprocessCUDA{,_colmap}: gaussian_preprocess{,_colmap}.cu"""
+        means3D = self.r(means3D)
+        P = means3D.shape[0]
+        scales, rotations = self.r(scales), self.r(rotations)
+        opacities = self.r(opacities).reshape(-1)
+        shs = self.r(shs)
+        M = 0 if shs is None else shs.shape[1]
+        cov3D_precomp, colors_precomp = self.r(cov3D_precomp), self.r(colors_precomp)
+        out = dict(
+            radii=np.zeros(P, np.int32), means2D=np.zeros((P, 2), self.dtype), depths=np.zeros(P, self.dtype),
+            cov3D=np.zeros((P, 6), self.dtype), rgb=np.zeros((P, 3), self.dtype),
+            conic_opacity=np.zeros((P, 4), self.dtype), tiles_touched=np.zeros(P, np.uint32),
+            clamped=np.zeros((P, 3), np.uint8))
+        self._fn('preprocess_forward')(
+            C.c_int(P), C.c_int(sh_degree), C.c_int(M), _p(means3D), _p(scales), self.creal(scale_modifier),
+            _p(rotations), _p(opacities), _p(shs), _p(cov3D_precomp), _p(colors_precomp),
+            _p(self.r(viewmatrix)), _p(self.r(projmatrix)), _p(self.r(campos)), C.c_int(W), C.c_int(H),
+            self.creal(tanfovx), self.creal(tanfovy), C.c_int(int(colmap)),
+            _p(out['radii']), _p(out['means2D']), _p(out['depths']), _p(out['cov3D']), _p(out['rgb']),
+            _p(out['conic_opacity']), _p(out['tiles_touched']), _p(out['clamped']))
+        return out
+
+    def bin_and_sort(self, W, H, geom):
+        """InclusiveSum + duplicateWithKeys + SortPairs + identifyTileRanges: gaussian_rasterizer_forward.cu:45-94"""
+        P = geom['radii'].shape[0]
+        T = ((W + BLOCK - 1) // BLOCK) * ((H + BLOCK - 1) // BLOCK)
+        offsets = np.zeros(P, np.uint32)
+        ranges = np.zeros((T, 2), np.uint32)
+        fn = self._fn('bin_and_sort')
+        args = [C.c_int(P), C.c_int(W), C.c_int(H), _p(geom['means2D']), _p(geom['depths']), _p(geom['radii']),
+                _p(geom['tiles_touched']), _p(offsets)]
+        R = int(fn(*args, C.c_int64(0), None, None, _p(ranges)))
+        keys = np.zeros(max(R, 1), np.uint64)
+        plist = np.zeros(max(R, 1), np.uint32)
+        R2 = int(fn(*args, C.c_int64(R), _p(keys), _p(plist), _p(ranges)))
+        assert R2 == R
+        return dict(num_rendered=R, point_offsets=offsets, point_list_keys=keys[:R], point_list=plist[:R],
+                    ranges=ranges)
+
+    def render_forward(self, W, H, geom, binning, colors=None, extra=None):
+        """renderCUDA_forward: gaussian_render.cu:16-112"""
+        colors = geom['rgb'] if colors is None else self.r(colors)
+        extra = self.r(extra)
+        E = 0 if extra is None else extra.shape[1]
+        out = dict(color=np.zeros((3, H, W), self.dtype), opacity=np.zeros((H, W), self.dtype),
+                   n_contrib=np.zeros((H, W), np.uint32),
+                   out_extra=np.zeros((E, H, W), self.dtype) if E else None)
+        self._fn('render_forward')(
+            C.c_int(W), C.c_int(H), C.c_int(E), _p(binning['ranges']), _p(binning['point_list']),
+            _p(geom['means2D']), _p(colors), _p(geom['conic_opacity']), _p(extra), _p(out['n_contrib']),
+            _p(out['color']), _p(out['opacity']), _p(out['out_extra']))
+        return out
+
+    def render_backward(self, W, H, geom, binning, img, dL_dcolor, dL_dopacity, colors=None, extra=None,
+                        dL_dextra=None, grad_means2D=None, grad_conic=None, grad_opacity=None):
+        """renderCUDA_backward: gaussian_render.cu:182-341 (accumulates into the optional grad_* inputs)"""
+        P = geom['radii'].shape[0]
+        colors = geom['rgb'] if colors is None else self.r(colors)
+        extra = self.r(extra)
+        dL_dextra = self.r(dL_dextra)
+        E = extra.shape[1] if (extra is not None and dL_dextra is not None) else 0
+        g = dict(
+            dL_dmean2D=np.zeros((P, 3), self.dtype) if grad_means2D is None else self.r(grad_means2D).copy(),
+            dL_dconic=np.zeros((P, 4), self.dtype) if grad_conic is None else self.r(grad_conic).reshape(P, 4).copy(),
+            dL_dopacity=np.zeros((P, 1), self.dtype) if grad_opacity is None else self.r(grad_opacity).reshape(P, 1).copy(),
+            dL_dcolors=np.zeros((P, 3), self.dtype),
+            dL_dextras=np.zeros((P, E), self.dtype) if E else None)
+        self._fn('render_backward')(
+            C.c_int(P), C.c_int(W), C.c_int(H), C.c_int(E), _p(binning['ranges']), _p(binning['point_list']),
+            _p(geom['means2D']), _p(geom['conic_opacity']), _p(colors), _p(extra), _p(self.r(img['opacity'])),
+            _p(img['n_contrib']), _p(self.r(dL_dcolor)), _p(dL_dextra), _p(self.r(dL_dopacity)),
+            _p(g['dL_dmean2D']), _p(g['dL_dconic']), _p(g['dL_dopacity']), _p(g['dL_dcolors']), _p(g['dL_dextras']))
+        return g
+
+    def preprocess_backward(self, means3D, scales, rotations, shs, viewmatrix, projmatrix, campos, W, H, tanfovx,
+                            tanfovy, sh_degree, geom, dL_dmean2D, dL_dconic, dL_dcolors, scale_modifier=1.0,
+                            colmap=True, cov3D_precomp=None):
+        """computeCov2DCUDA + preprocessCUDA_backward: gaussian_preprocess{,_colmap}.cu"""
+        means3D = self.r(means3D)
+        P = means3D.shape[0]
+        shs = self.r(shs)
+        M = 0 if shs is None else shs.shape[1]
+        scales, rotations = self.r(scales), self.r(rotations)
+        cov3D_precomp = self.r(cov3D_precomp)
+        cov3Ds = geom['cov3D'] if cov3D_precomp is None else cov3D_precomp
+        g = dict(dL_dmeans3D=np.zeros((P, 3), self.dtype), dL_dcov3D=np.zeros((P, 6), self.dtype),
+                 dL_dsh=np.zeros((P, M, 3), self.dtype), dL_dscales=np.zeros((P, 3), self.dtype),
+                 dL_drotations=np.zeros((P, 4), self.dtype))
+        dL_dcolors = self.r(dL_dcolors).copy()
+        self._fn('preprocess_backward')(
+            C.c_int(P), C.c_int(sh_degree), C.c_int(M), _p(means3D), _p(geom['radii']), _p(shs), _p(geom['clamped']),
+            _p(scales), _p(rotations), self.creal(scale_modifier), _p(cov3Ds), _p(self.r(viewmatrix)),
+            _p(self.r(projmatrix)), C.c_int(W), C.c_int(H), self.creal(tanfovx), self.creal(tanfovy),
+            _p(self.r(campos)), C.c_int(int(colmap)), _p(self.r(dL_dmean2D)), _p(self.r(dL_dconic).reshape(P, 4)),
+            _p(g['dL_dmeans3D']), _p(dL_dcolors), _p(g['dL_dcov3D']), _p(g['dL_dsh']), _p(g['dL_dscales']),
+            _p(g['dL_drotations']))
+        return g
+
+    # ------------------------------------------------------------------ whole-op (mirrors the pybind entry points)
+    def rasterize_forward(self, H, W, tanfovx, tanfovy, sh_degree, scale_modifier, colmap, viewmatrix, projmatrix,
+                          campos, means3D, opacity, sh=None, scales=None, rotations=None, extras=None, colors=None,
+                          cov3D_precomp=None):
+        """RasterizeGaussiansCUDA / Rasterizer::forward: gaussian_rasterizer_forward.cu:157-315"""
+        geom = self.preprocess_forward(means3D, scales, rotations, opacity, sh, viewmatrix, projmatrix, campos, W, H,
+                                       tanfovx, tanfovy, sh_degree, scale_modifier, colmap, cov3D_precomp, colors)
+        binning = self.bin_and_sort(W, H, geom)
+        colors_r = self.r(colors)
+        img = self.render_forward(W, H, geom, binning, colors_r, extras)
+        return dict(num_rendered=binning['num_rendered'], color=img['color'], opacity=img['opacity'],
+                    radii=geom['radii'], out_extra=img['out_extra'], geom=geom, binning=binning, img=img)
+
+    def rasterize_backward(self, fwd, H, W, tanfovx, tanfovy, sh_degree, scale_modifier, colmap, viewmatrix,
+                           projmatrix, campos, means3D, sh, scales, rotations, dL_dcolor, dL_dopacity, extras=None,
+                           dL_dextra=None, colors=None, cov3D_precomp=None, grad_means2D=None, grad_conic=None,
+                           grad_opacity=None):
+        """RasterizeGaussiansBackwardCUDA / Rasterizer::backward: gaussian_rasterizer_backwrad.cu:148-261"""
+        g1 = self.render_backward(W, H, fwd['geom'], fwd['binning'], fwd['img'], dL_dcolor, dL_dopacity, colors, extras,
+                                  dL_dextra, grad_means2D, grad_conic, grad_opacity)
+        g2 = self.preprocess_backward(means3D, scales, rotations, sh, viewmatrix, projmatrix, campos, W, H, tanfovx,
+                                      tanfovy, sh_degree, fwd['geom'], g1['dL_dmean2D'], g1['dL_dconic'],
+                                      g1['dL_dcolors'], scale_modifier, colmap, cov3D_precomp)
+        out = dict(g1)
+        out.update(g2)
+        return out
+
+    # ------------------------------------------------------------------ extras / top-k
+    def extra_forward(self, W, H, fwd, extra):
+        extra = self.r(extra)
+        E = extra.shape[1]
+        out = np.zeros((H * W, E), self.dtype)
+        self._fn('render_extra_forward')(
+            C.c_int(W), C.c_int(H), C.c_int(E), _p(fwd['binning']['ranges']), _p(fwd['binning']['point_list']),
+            _p(fwd['geom']['means2D']), _p(fwd['geom']['conic_opacity']), _p(fwd['img']['n_contrib']), _p(extra),
+            _p(out))
+        return out
+
+    def extra_backward(self, W, H, fwd, extra, grad_pixel_extra, grad_means2D=None, grad_conic=None,
+                       grad_opacity=None):
+        extra = self.r(extra)
+        P, E = extra.shape
+        g = dict(
+            dL_dmean2D=np.zeros((P, 3), self.dtype) if grad_means2D is None else self.r(grad_means2D).copy(),
+            dL_dconic=np.zeros((P, 4), self.dtype) if grad_conic is None else self.r(grad_conic).reshape(P, 4).copy(),
+            dL_dopacity=np.zeros((P, 1), self.dtype) if grad_opacity is None else self.r(grad_opacity).reshape(P, 1).copy(),
+            dL_dextra=np.zeros((P, E), self.dtype))
+        self._fn('render_extra_backward')(
+            C.c_int(P), C.c_int(W), C.c_int(H), C.c_int(E), _p(fwd['binning']['ranges']),
+            _p(fwd['binning']['point_list']), _p(fwd['geom']['means2D']), _p(fwd['geom']['conic_opacity']),
+            _p(self.r(fwd['img']['opacity'])), _p(fwd['img']['n_contrib']), _p(extra),
+            _p(self.r(grad_pixel_extra).reshape(H * W, E)), _p(g['dL_dmean2D']), _p(g['dL_dconic']),
+            _p(g['dL_dopacity']), _p(g['dL_dextra']))
+        return g
+
+    def topk_weights(self, topk, W, H, fwd):
+        idx = np.full((H, W, topk), -1, np.int32)
+        w = np.zeros((H, W, topk), self.dtype)
+        self._fn('topk_weights')(
+            C.c_int(topk), C.c_int(W), C.c_int(H), _p(fwd['binning']['ranges']), _p(fwd['binning']['point_list']),
+            _p(fwd['geom']['means2D']), _p(fwd['geom']['conic_opacity']), _p(fwd['img']['n_contrib']), _p(idx), _p(w))
+        return idx, w
+
+    def mark_visible(self, means3D, viewmatrix, colmap=True):
+        means3D = self.r(means3D)
+        out = np.zeros(means3D.shape[0], np.uint8)
+        self._fn('mark_visible')(C.c_int(means3D.shape[0]), _p(means3D), _p(self.r(viewmatrix)), C.c_int(int(colmap)),
+                                 _p(out))
+        return out.astype(bool)
+
+    # ------------------------------------------------------------------ deform
+    def lbs_deform_forward(self, points, weights, indices, bone_T, bone_drot, bone_dscale, xyz, log_scale, rot,
+                           opacity_logit):
+        """sk_gs.py:1147-1149,1162,1192-1203 + lie.h SE3 act"""
+        points = self.r(points)
+        P = points.shape[0]
+        weights = self.r(weights)
+        K = weights.shape[1]
+        indices = np.ascontiguousarray(indices, dtype=np.int64)
+        bone_T = self.r(bone_T)
+        M = bone_T.shape[0]
+        o = dict(means=np.zeros((P, 3), self.dtype), scales=np.zeros((P, 3), self.dtype),
+                 rotations=np.zeros((P, 4), self.dtype), opacity=np.zeros((P, 1), self.dtype),
+                 d_xyz=np.zeros((P, 3), self.dtype), d_rot=np.zeros((P, 4), self.dtype),
+                 d_scale=np.zeros((P, 3), self.dtype))
+        self._fn('lbs_deform_forward')(
+            C.c_int(P), C.c_int(K), C.c_int(M), _p(points), _p(weights), _p(indices), _p(bone_T),
+            _p(self.r(bone_drot)), _p(self.r(bone_dscale)), _p(self.r(xyz)), _p(self.r(log_scale)), _p(self.r(rot)),
+            _p(self.r(opacity_logit).reshape(-1)), _p(o['means']), _p(o['scales']), _p(o['rotations']),
+            _p(o['opacity']), _p(o['d_xyz']), _p(o['d_rot']), _p(o['d_scale']))
+        return o
+
+    def lbs_deform_backward(self, points, weights, indices, bone_T, bone_drot, bone_dscale, log_scale, rot,
+                            opacity_logit, g_means, g_scales, g_rotations, g_opacity):
+        points = self.r(points)
+        P = points.shape[0]
+        weights = self.r(weights)
+        K = weights.shape[1]
+        indices = np.ascontiguousarray(indices, dtype=np.int64)
+        bone_T = self.r(bone_T)
+        M = bone_T.shape[0]
+        g = dict(g_weights=np.zeros((P, K), self.dtype), g_bone_T=np.zeros((M, 7), self.dtype),
+                 g_bone_drot=np.zeros((M, 4), self.dtype), g_bone_dscale=np.zeros((M, 3), self.dtype),
+                 g_xyz=np.zeros((P, 3), self.dtype), g_log_scale=np.zeros((P, 3), self.dtype),
+                 g_rot=np.zeros((P, 4), self.dtype), g_opacity_logit=np.zeros((P, 1), self.dtype))
+        self._fn('lbs_deform_backward')(
+            C.c_int(P), C.c_int(K), C.c_int(M), _p(points), _p(weights), _p(indices), _p(bone_T),
+            _p(self.r(bone_drot)), _p(self.r(bone_dscale)), _p(self.r(log_scale)), _p(self.r(rot)),
+            _p(self.r(opacity_logit).reshape(-1)), _p(self.r(g_means)), _p(self.r(g_scales)), _p(self.r(g_rotations)),
+            _p(self.r(g_opacity).reshape(-1)), _p(g['g_weights']), _p(g['g_bone_T']), _p(g['g_bone_drot']),
+            _p(g['g_bone_dscale']), _p(g['g_xyz']), _p(g['g_log_scale']), _p(g['g_rot']), _p(g['g_opacity_logit']))
+        return g
+
+    def knn_bones(self, points, joints, K):
+        points, joints = self.r(points), self.r(joints)
+        P, dim = points.shape
+        M = joints.shape[0]
+        dist = np.zeros((P, K), self.dtype)
+        idx = np.zeros((P, K), np.int64)
+        self._fn('knn_bones')(C.c_int(P), C.c_int(M), C.c_int(K), C.c_int(dim), _p(points), _p(joints), _p(dist),
+                              _p(idx))
+        return dist, idx

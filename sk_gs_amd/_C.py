@@ -1,0 +1,549 @@
+"""Host binding of ``libskgs_hip.so`` (C ABI in ``include/skgs.h``) under the reference's extension surface.
+
+The reference resolves its CUDA ops by name through ``my_ext._C.get_C_function(name)`` (my_ext/_C/__init__.py:17-48)
+and calls them with torch tensors.  This module offers the same names with the same positional arguments and the same
+returned tuples, implemented by passing raw device pointers + the current HIP stream to the C ABI.  PyTorch is used
+for device memory and streams only.
+
+There is NO fallback: if the shared library is missing (or a tensor is not on a HIP device) the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, 'libskgs_hip.so')
+_lib = None
+_lock = threading.Lock()
+
+
+class SkgsError(RuntimeError):
+    pass
+
+
+class _RasterInputs(C.Structure):
+    _fields_ = [
+        ('P', C.c_int32), ('sh_degree', C.c_int32), ('sh_coeffs', C.c_int32), ('E', C.c_int32),
+        ('image_height', C.c_int32), ('image_width', C.c_int32),
+        ('tanfovx', C.c_float), ('tanfovy', C.c_float), ('scale_modifier', C.c_float),
+        ('prefiltered', C.c_int32), ('debug', C.c_int32), ('colmap', C.c_int32),
+        ('viewmatrix', C.c_void_p), ('projmatrix', C.c_void_p), ('campos', C.c_void_p),
+        ('means3D', C.c_void_p), ('opacity', C.c_void_p), ('sh', C.c_void_p), ('scales', C.c_void_p),
+        ('rotations', C.c_void_p), ('extras', C.c_void_p), ('colors_precomp', C.c_void_p),
+        ('cov3D_precomp', C.c_void_p),
+    ]
+
+
+class _RasterBuffers(C.Structure):
+    _fields_ = [('geom', C.c_void_p), ('geom_bytes', C.c_size_t), ('binning', C.c_void_p),
+                ('binning_bytes', C.c_size_t), ('img', C.c_void_p), ('img_bytes', C.c_size_t)]
+
+
+class _Status(C.Structure):
+    _fields_ = [('num_rendered', C.c_int32), ('overflow', C.c_int32), ('max_tile_count', C.c_int32),
+                ('reserved', C.c_int32)]
+
+
+class _RasterGrads(C.Structure):
+    _fields_ = [
+        ('dL_dout_color', C.c_void_p), ('dL_dout_opacity', C.c_void_p), ('dL_dout_extra', C.c_void_p),
+        ('grad_means2D_in', C.c_void_p), ('grad_conic_in', C.c_void_p), ('grad_opacity_in', C.c_void_p),
+        ('dL_dmeans2D', C.c_void_p), ('dL_dconic', C.c_void_p), ('dL_dcolors', C.c_void_p),
+        ('dL_dopacity', C.c_void_p), ('dL_dmeans3D', C.c_void_p), ('dL_dcov3D', C.c_void_p), ('dL_dsh', C.c_void_p),
+        ('dL_dscales', C.c_void_p), ('dL_drotations', C.c_void_p), ('dL_dextras', C.c_void_p),
+        ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t),
+    ]
+
+
+class _DeformInputs(C.Structure):
+    _fields_ = [
+        ('P', C.c_int32), ('K', C.c_int32), ('M', C.c_int32),
+        ('points', C.c_void_p), ('weights', C.c_void_p), ('indices', C.c_void_p), ('bone_T', C.c_void_p),
+        ('bone_drot', C.c_void_p), ('bone_dscale', C.c_void_p), ('xyz', C.c_void_p), ('log_scale', C.c_void_p),
+        ('rot', C.c_void_p), ('opacity_logit', C.c_void_p),
+    ]
+
+
+EXPORTED_SYMBOLS = [
+    'skgs_geom_buffer_bytes', 'skgs_img_buffer_bytes', 'skgs_binning_buffer_bytes', 'skgs_binning_capacity',
+    'skgs_rasterize_forward_stage1', 'skgs_rasterize_forward_stage2', 'skgs_rasterize_forward', 'skgs_read_status',
+    'skgs_backward_workspace_bytes', 'skgs_rasterize_backward', 'skgs_rasterize_extra_forward',
+    'skgs_rasterize_extra_backward', 'skgs_topk_weights', 'skgs_mark_visible', 'skgs_lbs_deform_forward',
+    'skgs_lbs_deform_backward', 'skgs_knn_bones', 'skgs_last_error', 'skgs_version',
+]
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen libskgs_hip.so (once). Raises SkgsError with build instructions when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(_LIB_PATH):
+            raise SkgsError(
+                f'{_LIB_PATH} not found: the HIP extension is not built. Run `python -c "import __graft_entry__ as g; '
+                f'g.build()"` or `make -C sk_gs_amd/csrc`. There is no CPU / PyTorch fallback for this path.')
+        lib = C.CDLL(_LIB_PATH)
+        for name in ('skgs_geom_buffer_bytes', 'skgs_img_buffer_bytes', 'skgs_binning_buffer_bytes',
+                     'skgs_backward_workspace_bytes'):
+            getattr(lib, name).restype = C.c_size_t
+        lib.skgs_binning_capacity.restype = C.c_int64
+        lib.skgs_binning_capacity.argtypes = [C.c_size_t]
+        lib.skgs_binning_buffer_bytes.argtypes = [C.c_int64]
+        lib.skgs_last_error.restype = C.c_char_p
+        _lib = lib
+    return _lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise SkgsError(load_library().skgs_last_error().decode())
+
+
+def _ptr(t: Optional[Tensor]):
+    """device pointer or NULL for None / empty tensors (the reference's null-data_ptr convention)"""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def _f32c(t: Optional[Tensor], device=None) -> Optional[Tensor]:
+    if t is None:
+        return None
+    if t.numel() == 0:
+        return t
+    if device is not None and t.device != device:
+        t = t.to(device)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _require_gpu(t: Tensor, name: str):
+    if not t.is_cuda:
+        raise SkgsError(f'{name} must live on a HIP device (got {t.device}); sk_gs_amd has no CPU path')
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ----------------------------------------------------------------------------------------------- configuration
+class _Config:
+    #: True  -> reference behaviour: one host sync per forward to size the binning buffer exactly and return R
+    #: False -> no sync: binning capacity is predicted from the previous call (x growth) and checked lazily
+    sync_num_rendered: bool = True
+    capacity_growth: float = 1.5
+    min_capacity: int = 1 << 16
+
+
+config = _Config()
+_capacity_hint = {}  # (P, W, H) -> last capacity
+_pinned = {}
+
+
+def _pinned_i32(device, n=4) -> Tensor:
+    key = (device.index, n)
+    t = _pinned.get(key)
+    if t is None:
+        t = torch.zeros(n, dtype=torch.int32).pin_memory()
+        _pinned[key] = t
+    return t
+
+
+def set_pixels_per_lane(ppl: int):
+    """tuning knob of the blend kernels: 1, 2 or 4 pixels per lane; 0 = heuristic"""
+    load_library().skgs_set_pixels_per_lane(C.c_int(ppl))
+
+
+def _make_inputs(H, W, tanfovx, tanfovy, degree, scale_modifier, prefiltered, debug, colmap, viewmatrix, projmatrix,
+                 campos, means3D, opacity, sh, scales, rotations, extras, colors, cov3D_precomp):
+    dev = means3D.device
+    keep = []
+
+    def prep(t):
+        t = _f32c(t, dev)
+        keep.append(t)
+        return t
+
+    means3D = prep(means3D)
+    P = means3D.shape[0]
+    if means3D.ndim != 2 or means3D.shape[1] != 3:
+        raise SkgsError('means3D must have dimensions (num_points, 3)')
+    sh = prep(sh)
+    M = sh.shape[1] if (sh is not None and sh.numel() > 0) else 0
+    extras = prep(extras)
+    E = extras.shape[-1] if (extras is not None and extras.numel() > 0) else 0
+    a = _RasterInputs()
+    a.P, a.sh_degree, a.sh_coeffs, a.E = P, int(degree), M, E
+    a.image_height, a.image_width = int(H), int(W)
+    a.tanfovx, a.tanfovy, a.scale_modifier = float(tanfovx), float(tanfovy), float(scale_modifier)
+    a.prefiltered, a.debug, a.colmap = int(bool(prefiltered)), int(bool(debug)), int(bool(colmap))
+    a.viewmatrix, a.projmatrix, a.campos = _ptr(prep(viewmatrix)), _ptr(prep(projmatrix)), _ptr(prep(campos))
+    a.means3D, a.opacity, a.sh = _ptr(means3D), _ptr(prep(opacity)), _ptr(sh)
+    a.scales, a.rotations, a.extras = _ptr(prep(scales)), _ptr(prep(rotations)), _ptr(extras)
+    a.colors_precomp, a.cov3D_precomp = _ptr(prep(colors)), _ptr(prep(cov3D_precomp))
+    return a, keep, P, M, E
+
+
+def _buffers(geom: Tensor, binning: Tensor, img: Tensor) -> _RasterBuffers:
+    b = _RasterBuffers()
+    b.geom, b.geom_bytes = geom.data_ptr(), geom.numel()
+    b.binning, b.binning_bytes = (binning.data_ptr() if binning.numel() else None), binning.numel()
+    b.img, b.img_bytes = img.data_ptr(), img.numel()
+    return b
+
+
+# =============================================================================================== rasterize_gaussians
+def rasterize_gaussians(image_height: int, image_width: int, tanfovx: float, tanfovy: float, degree: int,
+                        scale_modifier: float, prefiltered: bool, debug: bool, colmap: bool, viewmatrix: Tensor,
+                        projmatrix: Tensor, campos: Tensor, means3D: Tensor, opacity: Tensor, sh: Tensor,
+                        scales: Tensor, rotations: Tensor, extras: Optional[Tensor], colors: Tensor,
+                        cov3D_precomp: Tensor):
+    """Drop-in for ``_C.rasterize_gaussians`` (gaussian_rasterizer_forward.cu:260-317).
+
+    Returns ``(num_rendered, color[3,H,W], opacity[H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer,
+    out_extras[E,H,W] | None)``.
+    """
+    lib = load_library()
+    _require_gpu(means3D, 'means3D')
+    dev = means3D.device
+    H, W = int(image_height), int(image_width)
+    with torch.cuda.device(dev):
+        a, keep, P, M, E = _make_inputs(H, W, tanfovx, tanfovy, degree, scale_modifier, prefiltered, debug, colmap,
+                                        viewmatrix, projmatrix, campos, means3D, opacity, sh, scales, rotations,
+                                        extras, colors, cov3D_precomp)
+        f32 = dict(dtype=torch.float32, device=dev)
+        out_color = torch.empty((3, H, W), **f32)
+        out_opacity = torch.empty((H, W), **f32)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        out_extras = torch.empty((E, H, W), **f32) if extras is not None and E > 0 else None
+        geom = torch.empty((lib.skgs_geom_buffer_bytes(C.c_int32(P)),), dtype=torch.uint8, device=dev)
+        img = torch.empty((lib.skgs_img_buffer_bytes(C.c_int32(W), C.c_int32(H)),), dtype=torch.uint8, device=dev)
+        if P == 0:
+            out_color.zero_(), out_opacity.zero_()
+            if out_extras is not None:
+                out_extras.zero_()
+            binning = torch.empty((0,), dtype=torch.uint8, device=dev)
+            geom[:256].zero_()
+            return 0, out_color, out_opacity, radii, geom, binning, img, out_extras
+        stream = _stream()
+        if config.sync_num_rendered:
+            host_r = _pinned_i32(dev)
+            bufs = _buffers(geom, torch.empty((0,), dtype=torch.uint8, device=dev), img)
+            _check(lib.skgs_rasterize_forward_stage1(C.byref(a), C.byref(bufs), C.c_void_p(radii.data_ptr()),
+                                                     C.c_void_p(host_r.data_ptr()), stream))
+            torch.cuda.current_stream().synchronize()
+            num_rendered = int(host_r[0])
+            binning = torch.empty((lib.skgs_binning_buffer_bytes(C.c_int64(num_rendered)),), dtype=torch.uint8,
+                                  device=dev)
+            bufs = _buffers(geom, binning, img)
+            _check(lib.skgs_rasterize_forward_stage2(C.byref(a), C.byref(bufs), C.c_void_p(out_color.data_ptr()),
+                                                     C.c_void_p(out_opacity.data_ptr()),
+                                                     C.c_void_p(_ptr(out_extras)), stream))
+        else:
+            key = (P, W, H)
+            cap = _capacity_hint.get(key, max(config.min_capacity, 8 * P))
+            binning = torch.empty((lib.skgs_binning_buffer_bytes(C.c_int64(cap)),), dtype=torch.uint8, device=dev)
+            bufs = _buffers(geom, binning, img)
+            _check(lib.skgs_rasterize_forward(C.byref(a), C.byref(bufs), C.c_void_p(radii.data_ptr()),
+                                              C.c_void_p(out_color.data_ptr()), C.c_void_p(out_opacity.data_ptr()),
+                                              C.c_void_p(_ptr(out_extras)), None, stream))
+            num_rendered = -1  # unknown without a sync: see read_status()
+    return num_rendered, out_color, out_opacity, radii, geom, binning, img, out_extras
+
+
+def read_status(geomBuffer: Tensor) -> dict:
+    """(synchronising) status words of a forward: num_rendered, overflow flag, longest tile list"""
+    hdr = geomBuffer[:16].cpu().view(torch.int32)
+    return dict(num_rendered=int(hdr[0]), overflow=int(hdr[1]), max_tile_count=int(hdr[2]))
+
+
+def unpack_buffers(W: int, H: int, P: int, geomBuffer: Tensor, binningBuffer: Tensor, imgBuffer: Tensor) -> dict:
+    """Diagnostic view of the opaque buffers (layout: csrc/skgs_common.h). Used by tests and tools only."""
+    def a256(x):
+        return (x + 255) & ~255
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    hdr = geomBuffer[:16].view(torch.int32)
+    recs = geomBuffer[256:256 + P * 48].view(torch.float32).view(P, 12)
+    o = 0
+    n_contrib = imgBuffer[o:o + W * H * 4].view(torch.int32).view(H, W)
+    o += a256(W * H * 4)
+    tile_counts = imgBuffer[o:o + T * 4].view(torch.int32)
+    o += a256(T * 4)
+    tile_offsets = imgBuffer[o:o + (T + 1) * 4].view(torch.int32)
+    cap = int(load_library().skgs_binning_capacity(C.c_size_t(binningBuffer.numel())))
+    keys = binningBuffer[:cap * 8].view(torch.int64)
+    plo = a256(cap * 8)
+    point_list = binningBuffer[plo:plo + cap * 4].view(torch.int32)
+    return dict(num_rendered=hdr[0], overflow=hdr[1], max_tile_count=hdr[2], recs=recs, n_contrib=n_contrib,
+                tile_counts=tile_counts, tile_offsets=tile_offsets, keys=keys, point_list=point_list, capacity=cap)
+
+
+def update_capacity_hint(P: int, W: int, H: int, num_rendered: int):
+    _capacity_hint[(P, W, H)] = max(config.min_capacity, int(num_rendered * config.capacity_growth) + 1024)
+
+
+# ====================================================================================== rasterize_gaussians_backward
+def rasterize_gaussians_backward(scale_modifier: float, tanfovx: float, tanfovy: float, degree: int, debug: bool,
+                                 colmap: bool, viewmatrix: Tensor, projmatrix: Tensor, campos: Tensor,
+                                 means3D: Tensor, colors: Tensor, extras: Optional[Tensor], scales: Tensor,
+                                 rotations: Tensor, cov3D_precomp: Tensor, sh: Tensor, R: int, radii: Tensor,
+                                 out_opacity: Tensor, dL_dout_color: Tensor, dL_dout_opacity: Tensor,
+                                 dL_dout_extra: Optional[Tensor], grad_means2D: Optional[Tensor],
+                                 grad_conic: Optional[Tensor], grad_opacity: Optional[Tensor], geomBuffer: Tensor,
+                                 binningBuffer: Tensor, imgBuffer: Tensor):
+    """Drop-in for ``_C.rasterize_gaussians_backward`` (gaussian_rasterizer_backwrad.cu:200-261).
+
+    Returns ``(dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
+    dL_dscales[P,3], dL_drotations[P,4], dL_dextras[P,E] | None)``.
+    """
+    lib = load_library()
+    _require_gpu(means3D, 'means3D')
+    dev = means3D.device
+    H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])
+    with torch.cuda.device(dev):
+        # opacity is not an input of the backward: the blend kernels read it from the saved records
+        dummy_op = means3D  # any non-null pointer satisfies the input check; never dereferenced in the backward
+        a, keep, P, M, E = _make_inputs(H, W, tanfovx, tanfovy, degree, scale_modifier, False, debug, colmap,
+                                        viewmatrix, projmatrix, campos, means3D, dummy_op, sh, scales, rotations,
+                                        extras, colors, cov3D_precomp)
+        f32 = dict(dtype=torch.float32, device=dev)
+        use_extra = extras is not None and dL_dout_extra is not None and E > 0
+        g = _RasterGrads()
+        dL_dout_color = _f32c(dL_dout_color, dev)
+        dL_dout_opacity = _f32c(dL_dout_opacity, dev)
+        dL_dout_extra = _f32c(dL_dout_extra, dev) if use_extra else None
+        gm_in, gc_in, go_in = _f32c(grad_means2D, dev), _f32c(grad_conic, dev), _f32c(grad_opacity, dev)
+        out_opacity = _f32c(out_opacity, dev)
+        radii = radii.contiguous()
+        dL_dmeans2D = torch.empty((P, 3), **f32)
+        dL_dcolors = torch.empty((P, 3), **f32)
+        dL_dopacity = torch.empty((P, 1), **f32)
+        dL_dmeans3D = torch.empty((P, 3), **f32)
+        dL_dcov3D = torch.empty((P, 6), **f32)
+        dL_dsh = torch.empty((P, M, 3), **f32)
+        dL_dscales = torch.empty((P, 3), **f32)
+        dL_drot = torch.empty((P, 4), **f32)
+        dL_dextras = torch.empty((P, E), **f32) if use_extra else None
+        if P == 0:
+            return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drot,
+                    dL_dextras)
+        ws_bytes = lib.skgs_backward_workspace_bytes(C.c_int32(P))
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        g.dL_dout_color, g.dL_dout_opacity, g.dL_dout_extra = _ptr(dL_dout_color), _ptr(dL_dout_opacity), _ptr(dL_dout_extra)
+        g.grad_means2D_in, g.grad_conic_in, g.grad_opacity_in = _ptr(gm_in), _ptr(gc_in), _ptr(go_in)
+        g.dL_dmeans2D, g.dL_dconic, g.dL_dcolors, g.dL_dopacity = _ptr(dL_dmeans2D), None, _ptr(dL_dcolors), _ptr(dL_dopacity)
+        g.dL_dmeans3D, g.dL_dcov3D, g.dL_dsh = _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh)
+        g.dL_dscales, g.dL_drotations, g.dL_dextras = _ptr(dL_dscales), _ptr(dL_drot), _ptr(dL_dextras)
+        g.workspace, g.workspace_bytes = ws.data_ptr(), ws_bytes
+        if not use_extra:
+            a.extras, a.E = None, 0
+        bufs = _buffers(geomBuffer, binningBuffer, imgBuffer)
+        _check(lib.skgs_rasterize_backward(C.byref(a), C.byref(bufs), C.c_void_p(radii.data_ptr()),
+                                           C.c_void_p(out_opacity.data_ptr()), C.byref(g), _stream()))
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drot, dL_dextras
+
+
+# ======================================================================================================= extras / topk
+def gaussian_rasterize_extra_forward(W: int, H: int, R: int, extra: Tensor, geomBuffer: Tensor,
+                                     binningBuffer: Tensor, imgBuffer: Tensor) -> Tensor:
+    """Drop-in for ``_C.gaussian_rasterize_extra_forward`` (gaussian_rasterizer_extra.cu:222-246).
+    Returns a tensor labelled ``[W, H, E]`` whose memory is pixel-major ``[H*W, E]`` -- exactly like the reference."""
+    lib = load_library()
+    _require_gpu(extra, 'extras')
+    if extra.ndim != 2:
+        raise SkgsError('Error shape for extras')
+    dev = extra.device
+    with torch.cuda.device(dev):
+        extra = _f32c(extra, dev)
+        P, E = extra.shape
+        out = torch.zeros((W, H, E), dtype=torch.float32, device=dev)
+        if P == 0:
+            return out
+        bufs = _buffers(geomBuffer, binningBuffer, imgBuffer)
+        _check(lib.skgs_rasterize_extra_forward(C.c_int32(W), C.c_int32(H), C.c_int32(P), C.c_int32(E),
+                                                C.c_void_p(extra.data_ptr()), C.byref(bufs),
+                                                C.c_void_p(out.data_ptr()), _stream()))
+    return out
+
+
+def gaussian_rasterize_extra_backward(W: int, H: int, R: int, extra: Tensor, out_opacity: Tensor,
+                                      grad_pixel_extras: Tensor, geomBuffer: Tensor, binningBuffer: Tensor,
+                                      imgBuffer: Tensor, grad_means2D: Optional[Tensor], grad_conic: Optional[Tensor],
+                                      grad_opacity: Optional[Tensor]):
+    """Drop-in for ``_C.gaussian_rasterize_extra_backward`` (gaussian_rasterizer_extra.cu:248-277).
+    Returns ``(dL_dextra[P,E], dL_dmeans2D[P,3], dL_dconic[P,2,2], dL_dopacity[P,1])``; the three optional inputs are
+    accumulated into in place."""
+    lib = load_library()
+    _require_gpu(extra, 'extras')
+    dev = extra.device
+    with torch.cuda.device(dev):
+        extra = _f32c(extra, dev)
+        P, E = extra.shape
+        f32 = dict(dtype=torch.float32, device=dev)
+        gm = grad_means2D if grad_means2D is not None else torch.zeros((P, 3), **f32)
+        gc = grad_conic if grad_conic is not None else torch.zeros((P, 2, 2), **f32)
+        go = grad_opacity if grad_opacity is not None else torch.zeros((P, 1), **f32)
+        ge = torch.empty((P, E), **f32)
+        if P == 0:
+            return ge, gm, gc, go
+        out_opacity = _f32c(out_opacity, dev)
+        gpe = _f32c(grad_pixel_extras, dev)
+        bufs = _buffers(geomBuffer, binningBuffer, imgBuffer)
+        _check(lib.skgs_rasterize_extra_backward(
+            C.c_int32(W), C.c_int32(H), C.c_int32(P), C.c_int32(E), C.c_void_p(extra.data_ptr()),
+            C.c_void_p(out_opacity.data_ptr()), C.c_void_p(gpe.data_ptr()), C.byref(bufs), C.c_void_p(gm.data_ptr()),
+            C.c_void_p(gc.data_ptr()), C.c_void_p(go.data_ptr()), C.c_void_p(ge.data_ptr()), _stream()))
+    return ge, gm, gc, go
+
+
+def gaussian_topk_weights(topk: int, W: int, H: int, P: int, R: int, geomBuffer: Tensor, binningBuffer: Tensor,
+                          imgBuffer: Tensor) -> Tuple[Tensor, Tensor]:
+    """Drop-in for ``_C.gaussian_topk_weights`` (gaussian_topk.cu:98-121): ``(idx[H,W,k] int32, w[H,W,k])``."""
+    lib = load_library()
+    _require_gpu(geomBuffer, 'geomBuffer')
+    dev = geomBuffer.device
+    with torch.cuda.device(dev):
+        idx = torch.full((H, W, topk), -1, dtype=torch.int32, device=dev)
+        w = torch.zeros((H, W, topk), dtype=torch.float32, device=dev)
+        if P == 0:
+            return idx, w
+        bufs = _buffers(geomBuffer, binningBuffer, imgBuffer)
+        _check(lib.skgs_topk_weights(C.c_int32(topk), C.c_int32(W), C.c_int32(H), C.c_int32(P), C.byref(bufs),
+                                     C.c_void_p(idx.data_ptr()), C.c_void_p(w.data_ptr()), _stream()))
+    return idx, w
+
+
+def mark_visible(positions: Tensor, viewmatrix: Tensor, projmatrix: Tensor, colmap: bool = False) -> Tensor:
+    """The reference left ``mark_visible`` commented out (gaussian_rasterizer_imp.cu:75-103) although
+    ``GaussianRasterizer.markVisible`` calls it; provided here with the near-plane test of ``in_frustum``."""
+    lib = load_library()
+    _require_gpu(positions, 'positions')
+    dev = positions.device
+    with torch.cuda.device(dev):
+        positions = _f32c(positions, dev)
+        viewmatrix = _f32c(viewmatrix, dev)
+        P = positions.shape[0]
+        out = torch.empty((P,), dtype=torch.uint8, device=dev)
+        _check(lib.skgs_mark_visible(C.c_int32(P), C.c_void_p(_ptr(positions)), C.c_void_p(viewmatrix.data_ptr()),
+                                     C.c_int32(int(colmap)), C.c_void_p(_ptr(out)), _stream()))
+    return out.bool()
+
+
+# ============================================================================================================= deform
+def _deform_inputs(points, weights, indices, bone_T, bone_drot, bone_dscale, xyz, log_scale, rot, opacity_logit):
+    dev = points.device
+    ts = [_f32c(t, dev) for t in (points, weights)]
+    indices = indices.to(device=dev, dtype=torch.int64).contiguous()
+    rest = [_f32c(t, dev) for t in (bone_T, bone_drot, bone_dscale, xyz, log_scale, rot, opacity_logit)]
+    a = _DeformInputs()
+    a.P, a.K, a.M = ts[0].shape[0], ts[1].shape[1], rest[0].shape[0]
+    a.points, a.weights, a.indices = _ptr(ts[0]), _ptr(ts[1]), _ptr(indices)
+    (a.bone_T, a.bone_drot, a.bone_dscale, a.xyz, a.log_scale, a.rot, a.opacity_logit) = [_ptr(t) for t in rest]
+    return a, ts + [indices] + rest
+
+
+def lbs_deform_forward(points, weights, indices, bone_T, bone_drot, bone_dscale, xyz, log_scale, rot, opacity_logit,
+                       need_deltas: bool = False):
+    """Fused LBS deform + activation epilogue (sk_gs.py:1143-1150,1162,1192-1203).
+    Returns ``(means[P,3], scales[P,3], rotations[P,4], opacity[P,1], d_xyz, d_rot, d_scale)`` (deltas None unless
+    ``need_deltas``)."""
+    lib = load_library()
+    _require_gpu(points, 'points')
+    dev = points.device
+    with torch.cuda.device(dev):
+        a, keep = _deform_inputs(points, weights, indices, bone_T, bone_drot, bone_dscale, xyz, log_scale, rot,
+                                 opacity_logit)
+        P = a.P
+        f32 = dict(dtype=torch.float32, device=dev)
+        means, scales = torch.empty((P, 3), **f32), torch.empty((P, 3), **f32)
+        rotations, opacity = torch.empty((P, 4), **f32), torch.empty((P, 1), **f32)
+        d_xyz = torch.empty((P, 3), **f32) if need_deltas else None
+        d_rot = torch.empty((P, 4), **f32) if need_deltas else None
+        d_scale = torch.empty((P, 3), **f32) if need_deltas else None
+        _check(lib.skgs_lbs_deform_forward(C.byref(a), C.c_void_p(_ptr(means)), C.c_void_p(_ptr(scales)),
+                                           C.c_void_p(_ptr(rotations)), C.c_void_p(_ptr(opacity)),
+                                           C.c_void_p(_ptr(d_xyz)), C.c_void_p(_ptr(d_rot)),
+                                           C.c_void_p(_ptr(d_scale)), _stream()))
+    return means, scales, rotations, opacity, d_xyz, d_rot, d_scale
+
+
+def lbs_deform_backward(points, weights, indices, bone_T, bone_drot, bone_dscale, log_scale, rot, opacity_logit,
+                        g_means, g_scales, g_rotations, g_opacity):
+    """Returns ``(g_weights[P,K], g_bone_T[M,7], g_bone_drot[M,4], g_bone_dscale[M,3], g_xyz, g_log_scale, g_rot,
+    g_opacity_logit)``."""
+    lib = load_library()
+    _require_gpu(points, 'points')
+    dev = points.device
+    with torch.cuda.device(dev):
+        a, keep = _deform_inputs(points, weights, indices, bone_T, bone_drot, bone_dscale, points, log_scale, rot,
+                                 opacity_logit)
+        P, K, M = a.P, a.K, a.M
+        f32 = dict(dtype=torch.float32, device=dev)
+        gs = [_f32c(t, dev) for t in (g_means, g_scales, g_rotations, g_opacity)]
+        g_weights = torch.empty((P, K), **f32)
+        # the three atomically accumulated outputs are dense views of ONE zeroed block (one memset)
+        blk = torch.zeros((M * 14,), **f32)
+        g_bone_T, g_bone_drot, g_bone_dscale = blk[:M * 7].view(M, 7), blk[M * 7:M * 11].view(M, 4), blk[M * 11:].view(M, 3)
+        g_xyz, g_log_scale = torch.empty((P, 3), **f32), torch.empty((P, 3), **f32)
+        g_rot, g_op = torch.empty((P, 4), **f32), torch.empty((P, 1), **f32)
+        _check(lib.skgs_lbs_deform_backward(
+            C.byref(a), C.c_void_p(_ptr(gs[0])), C.c_void_p(_ptr(gs[1])), C.c_void_p(_ptr(gs[2])),
+            C.c_void_p(_ptr(gs[3])), C.c_void_p(_ptr(g_weights)), C.c_void_p(g_bone_T.data_ptr()),
+            C.c_void_p(g_bone_drot.data_ptr()), C.c_void_p(g_bone_dscale.data_ptr()), C.c_void_p(_ptr(g_xyz)),
+            C.c_void_p(_ptr(g_log_scale)), C.c_void_p(_ptr(g_rot)), C.c_void_p(_ptr(g_op)), _stream()))
+    return g_weights, g_bone_T, g_bone_drot, g_bone_dscale, g_xyz, g_log_scale, g_rot, g_op
+
+
+def knn_bones(points: Tensor, joints: Tensor, K: int) -> Tuple[Tensor, Tensor]:
+    """K nearest bones (squared L2 ascending) -- the ``pytorch3d.ops.knn_points`` call of sk_gs.py:757.
+    Returns ``(dist2[P,K] float32, idx[P,K] int64)``."""
+    lib = load_library()
+    _require_gpu(points, 'points')
+    dev = points.device
+    with torch.cuda.device(dev):
+        points, joints = _f32c(points, dev), _f32c(joints, dev)
+        P, dim = points.shape
+        M = joints.shape[0]
+        dist = torch.empty((P, K), dtype=torch.float32, device=dev)
+        idx = torch.empty((P, K), dtype=torch.int64, device=dev)
+        _check(lib.skgs_knn_bones(C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(dim),
+                                  C.c_void_p(_ptr(points)), C.c_void_p(joints.data_ptr()), C.c_void_p(_ptr(dist)),
+                                  C.c_void_p(_ptr(idx)), _stream()))
+    return dist, idx
+
+
+_FUNCTIONS = {
+    'rasterize_gaussians': rasterize_gaussians,
+    'rasterize_gaussians_backward': rasterize_gaussians_backward,
+    'gaussian_rasterize_extra_forward': gaussian_rasterize_extra_forward,
+    'gaussian_rasterize_extra_backward': gaussian_rasterize_extra_backward,
+    'gaussian_topk_weights': gaussian_topk_weights,
+    'mark_visible': mark_visible,
+    'lbs_deform_forward': lbs_deform_forward,
+    'lbs_deform_backward': lbs_deform_backward,
+    'knn_bones': knn_bones,
+}
+
+
+def get_C_function(name: str):
+    """Same contract as ``my_ext._C.get_C_function`` (my_ext/_C/__init__.py:39-48) except that an unknown name or a
+    missing library raises instead of silently returning None."""
+    load_library()
+    try:
+        return _FUNCTIONS[name]
+    except KeyError:
+        raise SkgsError(f'sk_gs_amd._C has no function named {name!r}') from None

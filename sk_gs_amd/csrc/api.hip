@@ -1,0 +1,206 @@
+// api.hip -- C ABI of libskgs_hip.so (declared in include/skgs.h): argument checks, buffer carving, launch order.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "skgs_common.h"
+
+namespace skgs {
+static thread_local char g_err[512] = "";
+int set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return 1;
+}
+
+static int check_inputs(const skgs_raster_inputs* in) {
+  SKGS_REQUIRE(in != nullptr, "inputs struct is NULL");
+  SKGS_REQUIRE(in->P >= 0, "P must be >= 0");
+  SKGS_REQUIRE(in->image_width > 0 && in->image_height > 0, "image size must be positive");
+  if (in->P == 0) return 0;
+  SKGS_REQUIRE(in->means3D != nullptr, "means3D must have dimensions (num_points, 3)");
+  SKGS_REQUIRE(in->opacity != nullptr, "opacity is required");
+  SKGS_REQUIRE(in->viewmatrix && in->projmatrix && in->campos, "viewmatrix / projmatrix / campos are required");
+  SKGS_REQUIRE((in->sh != nullptr) != (in->colors_precomp != nullptr),
+      "Please provide excatly one of either SHs or precomputed colors!");
+  SKGS_REQUIRE(((in->scales != nullptr) && (in->rotations != nullptr)) != (in->cov3D_precomp != nullptr),
+      "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+  if (in->sh) {
+    SKGS_REQUIRE(in->sh_degree >= 0 && in->sh_degree <= 3, "sh_degree must be in [0,3]");
+    SKGS_REQUIRE(in->sh_coeffs >= (in->sh_degree + 1) * (in->sh_degree + 1), "sh has too few coefficients for sh_degree");
+  }
+  SKGS_REQUIRE(in->E >= 0 && in->E <= SKGS_MAX_RENDER_EXTRA, "Only Support 0,1,2,3,4 extra features");
+  return 0;
+}
+static int check_buffers(const skgs_raster_inputs* in, const skgs_raster_buffers* buf, bool need_binning) {
+  SKGS_REQUIRE(buf != nullptr && buf->geom && buf->img, "geom / img buffers are required");
+  SKGS_REQUIRE(buf->geom_bytes >= geom_bytes(in->P), "geom buffer too small");
+  SKGS_REQUIRE(buf->img_bytes >= img_bytes(in->image_width, in->image_height), "img buffer too small");
+  if (need_binning) SKGS_REQUIRE(buf->binning != nullptr || buf->binning_bytes == 0, "binning buffer is NULL");
+  return 0;
+}
+}  // namespace skgs
+
+using namespace skgs;
+
+extern "C" {
+
+const char* skgs_last_error(void) { return g_err; }
+int skgs_version(void) { return SKGS_VERSION; }
+
+size_t skgs_geom_buffer_bytes(int32_t P) { return geom_bytes(P); }
+size_t skgs_img_buffer_bytes(int32_t W, int32_t H) { return img_bytes(W, H); }
+size_t skgs_binning_buffer_bytes(int64_t capacity) { return bin_bytes(capacity < 0 ? 0 : capacity); }
+int64_t skgs_binning_capacity(size_t bytes) { return bin_capacity(bytes); }
+size_t skgs_backward_workspace_bytes(int32_t P) { return (size_t) P * GRAD_ROW * 4 + 256; }
+
+int skgs_rasterize_forward_stage1(const skgs_raster_inputs* in, const skgs_raster_buffers* buf, int32_t* radii,
+    int32_t* host_num_rendered, skgs_stream_t stream) {
+  if (check_inputs(in) || check_buffers(in, buf, false)) return 1;
+  SKGS_REQUIRE(radii != nullptr || in->P == 0, "radii output is required");
+  hipStream_t s = (hipStream_t) stream;
+  GeomView g    = geom_view(buf->geom);
+  ImgView im    = img_view(buf->img, in->image_width, in->image_height);
+  if (launch_preprocess_forward(*in, g, im, radii, s)) return 1;
+  if (launch_scan_tiles(g, im, 0, s)) return 1;
+  if (host_num_rendered)
+    SKGS_CHECK_HIP(hipMemcpyAsync(host_num_rendered, &g.hdr->num_rendered, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
+int skgs_rasterize_forward_stage2(const skgs_raster_inputs* in, const skgs_raster_buffers* buf, float* out_color,
+    float* out_opacity, float* out_extra, skgs_stream_t stream) {
+  if (check_inputs(in) || check_buffers(in, buf, true)) return 1;
+  SKGS_REQUIRE(out_color && out_opacity, "out_color / out_opacity are required");
+  SKGS_REQUIRE(!(in->extras && in->E > 0) || out_extra, "out_extra is required when extras are given");
+  hipStream_t s = (hipStream_t) stream;
+  GeomView g    = geom_view(buf->geom);
+  ImgView im    = img_view(buf->img, in->image_width, in->image_height);
+  BinView b     = bin_view(buf->binning, buf->binning_bytes);
+  if (launch_scatter_sort(*in, g, im, b, s)) return 1;
+  return launch_render_forward(*in, g, im, b, out_color, out_opacity, out_extra, s);
+}
+
+int skgs_rasterize_forward(const skgs_raster_inputs* in, const skgs_raster_buffers* buf, int32_t* radii, float* out_color,
+    float* out_opacity, float* out_extra, int32_t* host_num_rendered, skgs_stream_t stream) {
+  if (skgs_rasterize_forward_stage1(in, buf, radii, host_num_rendered, stream)) return 1;
+  return skgs_rasterize_forward_stage2(in, buf, out_color, out_opacity, out_extra, stream);
+}
+
+int skgs_read_status(const skgs_raster_buffers* buf, skgs_status* host_status, skgs_stream_t stream) {
+  SKGS_REQUIRE(buf && buf->geom && host_status, "read_status: NULL argument");
+  SKGS_CHECK_HIP(hipMemcpyAsync(host_status, buf->geom, sizeof(skgs_status), hipMemcpyDeviceToHost, (hipStream_t) stream));
+  return 0;
+}
+
+int skgs_rasterize_backward(const skgs_raster_inputs* in, const skgs_raster_buffers* buf, const int32_t* radii,
+    const float* out_opacity, const skgs_raster_grads* gr, skgs_stream_t stream) {
+  if (check_inputs(in) || check_buffers(in, buf, true)) return 1;
+  SKGS_REQUIRE(gr != nullptr, "grads struct is NULL");
+  if (in->P == 0) return 0;
+  SKGS_REQUIRE(radii && out_opacity, "radii / out_opacity are required");
+  SKGS_REQUIRE(gr->dL_dout_color && gr->dL_dout_opacity, "dL_dout_color / dL_dout_opacity are required");
+  SKGS_REQUIRE(gr->dL_dmeans2D && gr->dL_dcolors && gr->dL_dopacity && gr->dL_dmeans3D && gr->dL_dcov3D &&
+                   gr->dL_dscales && gr->dL_drotations,
+      "gradient outputs are required");
+  SKGS_REQUIRE(!(in->sh && in->sh_coeffs > 0) || gr->dL_dsh, "dL_dsh is required when sh is given");
+  SKGS_REQUIRE(gr->workspace && gr->workspace_bytes >= skgs_backward_workspace_bytes(in->P), "workspace too small");
+  hipStream_t s = (hipStream_t) stream;
+  GeomView g    = geom_view(buf->geom);
+  ImgView im    = img_view(buf->img, in->image_width, in->image_height);
+  BinView b     = bin_view(buf->binning, buf->binning_bytes);
+  SKGS_CHECK_HIP(hipMemsetAsync(gr->workspace, 0, (size_t) in->P * GRAD_ROW * 4, s));
+  if (launch_render_backward(*in, g, im, b, out_opacity, gr->dL_dout_color, gr->dL_dout_opacity, gr->dL_dout_extra,
+          gr->workspace, s))
+    return 1;
+  return launch_preprocess_backward(*in, g, radii, *gr, s);
+}
+
+int skgs_rasterize_extra_forward(int32_t W, int32_t H, int32_t P, int32_t E, const float* extra,
+    const skgs_raster_buffers* buf, float* pixel_extra, skgs_stream_t stream) {
+  SKGS_REQUIRE(buf && buf->geom && buf->img, "buffers are required");
+  SKGS_REQUIRE(E > 0 && extra && pixel_extra, "Error shape for extras");
+  if (P == 0) return 0;
+  GeomView g = geom_view(buf->geom);
+  ImgView im = img_view(buf->img, W, H);
+  BinView b  = bin_view(buf->binning, buf->binning_bytes);
+  return launch_extra_forward(W, H, P, E, extra, g, im, b, pixel_extra, (hipStream_t) stream);
+}
+
+int skgs_rasterize_extra_backward(int32_t W, int32_t H, int32_t P, int32_t E, const float* extra, const float* out_opacity,
+    const float* grad_pixel_extra, const skgs_raster_buffers* buf, float* grad_means2D, float* grad_conic,
+    float* grad_opacity, float* dL_dextra, skgs_stream_t stream) {
+  SKGS_REQUIRE(buf && buf->geom && buf->img, "buffers are required");
+  SKGS_REQUIRE(E > 0 && extra && grad_pixel_extra && out_opacity, "Error shape for extras");
+  SKGS_REQUIRE(grad_means2D && grad_conic && grad_opacity && dL_dextra, "gradient outputs are required");
+  if (P == 0) return 0;
+  hipStream_t s = (hipStream_t) stream;
+  GeomView g = geom_view(buf->geom);
+  ImgView im = img_view(buf->img, W, H);
+  BinView b  = bin_view(buf->binning, buf->binning_bytes);
+  SKGS_CHECK_HIP(hipMemsetAsync(dL_dextra, 0, (size_t) P * E * 4, s));
+  return launch_extra_backward(W, H, P, E, extra, out_opacity, grad_pixel_extra, g, im, b, grad_means2D, grad_conic,
+      grad_opacity, dL_dextra, s);
+}
+
+int skgs_topk_weights(int32_t topk, int32_t W, int32_t H, int32_t P, const skgs_raster_buffers* buf, int32_t* top_indices,
+    float* top_weights, skgs_stream_t stream) {
+  SKGS_REQUIRE(buf && buf->geom && buf->img, "buffers are required");
+  SKGS_REQUIRE(topk > 0 && top_indices && top_weights, "topk outputs are required");
+  hipStream_t s = (hipStream_t) stream;
+  if (P == 0) {
+    SKGS_CHECK_HIP(hipMemsetAsync(top_indices, 0xff, (size_t) W * H * topk * 4, s));
+    SKGS_CHECK_HIP(hipMemsetAsync(top_weights, 0, (size_t) W * H * topk * 4, s));
+    return 0;
+  }
+  GeomView g = geom_view(buf->geom);
+  ImgView im = img_view(buf->img, W, H);
+  BinView b  = bin_view(buf->binning, buf->binning_bytes);
+  return launch_topk(topk, W, H, g, im, b, top_indices, top_weights, s);
+}
+
+int skgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, int32_t colmap, uint8_t* present,
+    skgs_stream_t stream) {
+  SKGS_REQUIRE(P == 0 || (means3D && viewmatrix && present), "mark_visible: NULL argument");
+  return launch_mark_visible(P, means3D, viewmatrix, colmap, present, (hipStream_t) stream);
+}
+
+static int check_deform(const skgs_deform_inputs* in) {
+  SKGS_REQUIRE(in != nullptr, "deform inputs struct is NULL");
+  SKGS_REQUIRE(in->P >= 0 && in->K >= 1 && in->M >= 1, "deform: need P >= 0, K >= 1, M >= 1");
+  if (in->P == 0) return 0;
+  SKGS_REQUIRE(in->points && in->weights && in->indices && in->bone_T && in->bone_drot && in->bone_dscale,
+      "deform: points / weights / indices / bone tensors are required");
+  SKGS_REQUIRE(in->log_scale && in->rot && in->opacity_logit, "deform: Gaussian parameter tensors are required");
+  return 0;
+}
+
+int skgs_lbs_deform_forward(const skgs_deform_inputs* in, float* means, float* scales, float* rotations, float* opacity,
+    float* d_xyz, float* d_rot, float* d_scale, skgs_stream_t stream) {
+  if (check_deform(in)) return 1;
+  SKGS_REQUIRE(in->P == 0 || (in->xyz && means && scales && rotations && opacity), "deform: outputs are required");
+  return launch_deform_forward(*in, means, scales, rotations, opacity, d_xyz, d_rot, d_scale, (hipStream_t) stream);
+}
+
+int skgs_lbs_deform_backward(const skgs_deform_inputs* in, const float* g_means, const float* g_scales,
+    const float* g_rotations, const float* g_opacity, float* g_weights, float* g_bone_T, float* g_bone_drot,
+    float* g_bone_dscale, float* g_xyz, float* g_log_scale, float* g_rot, float* g_opacity_logit,
+    skgs_stream_t stream) {
+  if (check_deform(in)) return 1;
+  SKGS_REQUIRE(in->P == 0 || (g_means && g_scales && g_rotations && g_opacity), "deform: upstream gradients are required");
+  SKGS_REQUIRE(in->P == 0 || (g_weights && g_bone_T && g_bone_drot && g_bone_dscale && g_xyz && g_log_scale && g_rot &&
+                                 g_opacity_logit),
+      "deform: gradient outputs are required");
+  return launch_deform_backward(*in, g_means, g_scales, g_rotations, g_opacity, g_weights, g_bone_T, g_bone_drot,
+      g_bone_dscale, g_xyz, g_log_scale, g_rot, g_opacity_logit, (hipStream_t) stream);
+}
+
+int skgs_knn_bones(int32_t P, int32_t M, int32_t K, int32_t dim, const float* points, const float* joints,
+    float* out_dist, int64_t* out_idx, skgs_stream_t stream) {
+  SKGS_REQUIRE(P == 0 || (points && joints && out_dist && out_idx), "knn_bones: NULL argument");
+  SKGS_REQUIRE(M >= 1 && dim >= 1, "knn_bones: M and dim must be >= 1");
+  return launch_knn_bones(P, M, K, dim, points, joints, out_dist, out_idx, (hipStream_t) stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,734 @@
+// preprocess.hip -- per-Gaussian kernels of the rasterizer (gfx950).
+//
+//   preprocess_forward_kernel : cull, project, Sigma3D -> Sigma2D -> conic, screen radius, tile rect, SH -> RGB,
+//                               per-tile instance counts.            (reference: gaussian_preprocess.cu:99-168,
+//                               gaussian_preprocess_colmap.cu:155-224, gaussian_rasterizer_forward.cu:97-137)
+//   preprocess_backward_kernel: conic -> Sigma2D -> Sigma3D/mean, projection, SH and Sigma3D -> scale/rotation
+//                               gradients in ONE pass (reference runs computeCov2DCUDA + preprocessCUDA_backward:
+//                               gaussian_preprocess.cu:183-400, gaussian_preprocess_colmap.cu:240-481,
+//                               gaussian_rasterizer_backwrad.cu:26-127)
+//
+// HBM-bound streaming kernels, one lane per Gaussian.  The arithmetic is written in the reference's evaluation
+// order and compiled without FMA contraction so that every discrete decision (cull, radius = ceil(..), tile
+// rectangle, SH clamp) is bit-identical to the CPU oracle; these kernels move ~0.3 KB per Gaussian, the extra
+// VALU work is free.
+#include "skgs_common.h"
+
+#pragma clang fp contract(off)
+
+namespace skgs {
+namespace {
+
+__device__ const float SH_C0   = 0.28209479177387814f;
+__device__ const float SH_C1   = 0.4886025119029199f;
+__device__ const float SH_C2[] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+    -1.0925484305920792f, 0.5462742152960396f};
+__device__ const float SH_C3[] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+    0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+struct Cam {
+  float view[16];
+  float proj[16];
+  float campos[3];
+};
+
+// A 3x3 held as m[c][r] (column-major) with the product order  r[c][w] = a[0][w]*b[c][0] + a[1][w]*b[c][1] + a[2][w]*b[c][2]
+struct M3 {
+  float m[3][3];
+};
+__device__ __forceinline__ M3 m3_mul(const M3& a, const M3& b) {
+  M3 r;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int w = 0; w < 3; ++w) r.m[c][w] = a.m[0][w] * b.m[c][0] + a.m[1][w] * b.m[c][1] + a.m[2][w] * b.m[c][2];
+  return r;
+}
+__device__ __forceinline__ M3 m3_t(const M3& a) {
+  M3 r;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int w = 0; w < 3; ++w) r.m[c][w] = a.m[w][c];
+  return r;
+}
+__device__ __forceinline__ M3 m3_sym(const float* c6) {
+  M3 v;
+  v.m[0][0] = c6[0], v.m[0][1] = c6[1], v.m[0][2] = c6[2];
+  v.m[1][0] = c6[1], v.m[1][1] = c6[3], v.m[1][2] = c6[4];
+  v.m[2][0] = c6[2], v.m[2][1] = c6[4], v.m[2][2] = c6[5];
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------- colmap = 1
+__device__ __forceinline__ void xf3_cm(const float* p, const float* m, float* o) {
+  o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+  o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+  o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+}
+__device__ __forceinline__ void xf4_cm(const float* p, const float* m, float* o) {
+  o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+  o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+  o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+  o[3] = m[3] * p[0] + m[7] * p[1] + m[11] * p[2] + m[15];
+}
+__device__ __forceinline__ M3 rot_cm(const float* q) {
+  const float x = q[0], y = q[1], z = q[2], r = q[3];
+  M3 R;
+  R.m[0][0] = 1.f - 2.f * (y * y + z * z), R.m[0][1] = 2.f * (x * y - r * z), R.m[0][2] = 2.f * (x * z + r * y);
+  R.m[1][0] = 2.f * (x * y + r * z), R.m[1][1] = 1.f - 2.f * (x * x + z * z), R.m[1][2] = 2.f * (y * z - r * x);
+  R.m[2][0] = 2.f * (x * z - r * y), R.m[2][1] = 2.f * (y * z + r * x), R.m[2][2] = 1.f - 2.f * (x * x + y * y);
+  return R;
+}
+__device__ __forceinline__ M3 scale_rot_cm(const float* s /*already * mod*/, const M3& R) {
+  M3 S;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int w = 0; w < 3; ++w) S.m[c][w] = (c == w) ? s[c] : 0.f;
+  return m3_mul(S, R);
+}
+__device__ __forceinline__ void cov3d_cm(const float* scale, float mod, const float* q, float* c6) {
+  const float s[3] = {mod * scale[0], mod * scale[1], mod * scale[2]};
+  M3 Mm            = scale_rot_cm(s, rot_cm(q));
+  M3 Sg            = m3_mul(m3_t(Mm), Mm);
+  c6[0] = Sg.m[0][0], c6[1] = Sg.m[0][1], c6[2] = Sg.m[0][2], c6[3] = Sg.m[1][1], c6[4] = Sg.m[1][2], c6[5] = Sg.m[2][2];
+}
+// T = W*J and the clamped view-space point; shared by forward and backward
+struct ProjCM {
+  M3 T, W, V;
+  float t[3];
+  float xm, ym;
+};
+__device__ __forceinline__ ProjCM proj_cm(const float* mean, float fx, float fy, float tfx, float tfy, const float* c6,
+    const float* vm) {
+  ProjCM o;
+  xf3_cm(mean, vm, o.t);
+  const float limx = 1.3f * tfx, limy = 1.3f * tfy;
+  const float txtz = o.t[0] / o.t[2], tytz = o.t[1] / o.t[2];
+  o.t[0]           = fminf(limx, fmaxf(-limx, txtz)) * o.t[2];
+  o.t[1]           = fminf(limy, fmaxf(-limy, tytz)) * o.t[2];
+  o.xm             = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+  o.ym             = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+  M3 J;
+  J.m[0][0] = fx / o.t[2], J.m[0][1] = 0.f, J.m[0][2] = -(fx * o.t[0]) / (o.t[2] * o.t[2]);
+  J.m[1][0] = 0.f, J.m[1][1] = fy / o.t[2], J.m[1][2] = -(fy * o.t[1]) / (o.t[2] * o.t[2]);
+  J.m[2][0] = 0.f, J.m[2][1] = 0.f, J.m[2][2] = 0.f;
+  o.W.m[0][0] = vm[0], o.W.m[0][1] = vm[4], o.W.m[0][2] = vm[8];
+  o.W.m[1][0] = vm[1], o.W.m[1][1] = vm[5], o.W.m[1][2] = vm[9];
+  o.W.m[2][0] = vm[2], o.W.m[2][1] = vm[6], o.W.m[2][2] = vm[10];
+  o.T = m3_mul(o.W, J);
+  o.V = m3_sym(c6);
+  return o;
+}
+
+// ---------------------------------------------------------------------------------------------- colmap = 0
+__device__ __forceinline__ void xf3_rm(const float* p, const float* m, float* o) {
+  o[0] = m[0] * p[0] + m[1] * p[1] + m[2] * p[2] + m[3];
+  o[1] = m[4] * p[0] + m[5] * p[1] + m[6] * p[2] + m[7];
+  o[2] = m[8] * p[0] + m[9] * p[1] + m[10] * p[2] + m[11];
+}
+__device__ __forceinline__ void xf4_rm(const float* p, const float* m, float* o) {
+  o[0] = m[0] * p[0] + m[1] * p[1] + m[2] * p[2] + m[3];
+  o[1] = m[4] * p[0] + m[5] * p[1] + m[6] * p[2] + m[7];
+  o[2] = m[8] * p[0] + m[9] * p[1] + m[10] * p[2] + m[11];
+  o[3] = m[12] * p[0] + m[13] * p[1] + m[14] * p[2] + m[15];
+}
+__device__ __forceinline__ void q2R_rm(const float* q, float* R) {
+  const float x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0] = 1 - 2 * (y * y + z * z), R[1] = 2 * (x * y - z * w), R[2] = 2 * (y * w + x * z);
+  R[3] = 2 * (x * y + z * w), R[4] = 1 - 2 * (x * x + z * z), R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w), R[7] = 2 * (x * w + y * z), R[8] = 1 - 2 * (x * x + y * y);
+}
+__device__ __forceinline__ void mm_rm(const float* A, const float* B, float* C) {  // C += A*B, k innermost
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) C[i * 3 + j] += A[i * 3 + k] * B[k * 3 + j];
+}
+__device__ __forceinline__ void mm_tn_rm(const float* At, const float* B, float* C) {  // C += At^T * B
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) C[i * 3 + j] += At[k * 3 + i] * B[k * 3 + j];
+}
+__device__ __forceinline__ void cov3d_rm(const float* s, const float* q, float* c6) {
+  float R[9];
+  q2R_rm(q, R);
+  const float sx2 = s[0] * s[0], sy2 = s[1] * s[1], sz2 = s[2] * s[2];
+  c6[0] = R[0] * R[0] * sx2 + R[1] * R[1] * sy2 + R[2] * R[2] * sz2;
+  c6[1] = R[0] * R[3] * sx2 + R[1] * R[4] * sy2 + R[2] * R[5] * sz2;
+  c6[2] = R[0] * R[6] * sx2 + R[1] * R[7] * sy2 + R[2] * R[8] * sz2;
+  c6[3] = R[3] * R[3] * sx2 + R[4] * R[4] * sy2 + R[5] * R[5] * sz2;
+  c6[4] = R[3] * R[6] * sx2 + R[4] * R[7] * sy2 + R[5] * R[8] * sz2;
+  c6[5] = R[6] * R[6] * sx2 + R[7] * R[7] * sy2 + R[8] * R[8] * sz2;
+}
+struct ProjRM {
+  float T[9], W[9];
+  float t[3];
+  float xm, ym;
+};
+__device__ __forceinline__ ProjRM proj_rm(const float* mean, float fx, float fy, float tfx, float tfy, const float* vm) {
+  ProjRM o;
+  xf3_rm(mean, vm, o.t);
+  const float limx = 1.3f * tfx, limy = 1.3f * tfy;
+  const float txtz = o.t[0] / o.t[2], tytz = o.t[1] / o.t[2];
+  o.t[0]           = fminf(fmaxf(txtz, -limx), limx) * o.t[2];
+  o.t[1]           = fminf(fmaxf(tytz, -limy), limy) * o.t[2];
+  o.xm             = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+  o.ym             = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+  const float J[9] = {fx / o.t[2], 0.f, -(fx * o.t[0]) / (o.t[2] * o.t[2]), 0.f, fy / o.t[2],
+      -(fy * o.t[1]) / (o.t[2] * o.t[2]), 0.f, 0.f, 0.f};
+  o.W[0] = vm[0], o.W[1] = vm[1], o.W[2] = vm[2], o.W[3] = vm[4], o.W[4] = vm[5], o.W[5] = vm[6];
+  o.W[6] = vm[8], o.W[7] = vm[9], o.W[8] = vm[10];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) o.T[i] = 0.f;
+  mm_rm(o.W, J, o.T);
+  return o;
+}
+__device__ __forceinline__ void cov2d_rm(const ProjRM& pr, const float* c6, float* cov) {
+  const float V[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
+  float tmp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  mm_tn_rm(pr.T, V, tmp);
+  mm_rm(tmp, pr.T, c);
+  cov[0] = c[0] + 0.3f, cov[1] = c[1], cov[2] = c[4] + 0.3f;
+}
+
+// ---------------------------------------------------------------------------------------------- shared
+__device__ __forceinline__ float ndc2pix(float v, int S) { return (float) ((((double) v + 1.0) * S - 1.0) * 0.5); }
+
+// SH basis * coefficients for one Gaussian; sh points at [M][3].
+__device__ __forceinline__ void sh_to_rgb(int deg, const float* mean, const float* campos, const float* sh, float* rgb,
+    uint32_t* clamp_bits) {
+  float d[3]      = {mean[0] - campos[0], mean[1] - campos[1], mean[2] - campos[2]};
+  const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  const float x = d[0] / len, y = d[1] / len, z = d[2] / len;
+  uint32_t bits = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float r = SH_C0 * sh[c];
+    if (deg > 0) {
+      r = r - SH_C1 * y * sh[3 + c] + SH_C1 * z * sh[6 + c] - SH_C1 * x * sh[9 + c];
+      if (deg > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        r = r + SH_C2[0] * xy * sh[12 + c] + SH_C2[1] * yz * sh[15 + c] + SH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + c] +
+            SH_C2[3] * xz * sh[21 + c] + SH_C2[4] * (xx - yy) * sh[24 + c];
+        if (deg > 2) {
+          r = r + SH_C3[0] * y * (3.0f * xx - yy) * sh[27 + c] + SH_C3[1] * xy * z * sh[30 + c] +
+              SH_C3[2] * y * (4.0f * zz - xx - yy) * sh[33 + c] + SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + c] +
+              SH_C3[4] * x * (4.0f * zz - xx - yy) * sh[39 + c] + SH_C3[5] * z * (xx - yy) * sh[42 + c] +
+              SH_C3[6] * x * (xx - 3.0f * yy) * sh[45 + c];
+        }
+      }
+    }
+    r += 0.5f;
+    if (r < 0.f) bits |= (1u << c);
+    rgb[c] = fmaxf(r, 0.0f);
+  }
+  *clamp_bits = bits;
+}
+
+template <bool COLMAP>
+__global__ void __launch_bounds__(256) preprocess_forward_kernel(int P, int D, int M, const float* __restrict__ means3D,
+    const float* __restrict__ scales, float scale_modifier, const float* __restrict__ rotations,
+    const float* __restrict__ opacities, const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
+    const float* __restrict__ colors_precomp, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
+    const float* __restrict__ campos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
+    int gx, int gy, int32_t* __restrict__ radii, float4* __restrict__ recs, uint32_t* __restrict__ tile_counts) {
+  __shared__ Cam cam;
+  if (threadIdx.x < 16) {
+    cam.view[threadIdx.x] = viewmatrix[threadIdx.x];
+    cam.proj[threadIdx.x] = projmatrix[threadIdx.x];
+  }
+  if (threadIdx.x < 3) cam.campos[threadIdx.x] = campos[threadIdx.x];
+  __syncthreads();
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P) return;
+
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;  // culled Gaussians get an all-zero record
+  int radius = 0;
+  uint32_t tiles = 0, clamp_bits = 0;
+  int mn[2] = {0, 0}, mx[2] = {0, 0};
+  const float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+  float pv[3], ph[4];
+  bool ok;
+  if (COLMAP) {
+    xf3_cm(p, cam.view, pv);
+    ok = !(pv[2] <= 0.2f);
+  } else {
+    xf3_rm(p, cam.view, pv);
+    ok = !(pv[2] <= -1.0f);
+  }
+  if (ok) {
+    if (COLMAP)
+      xf4_cm(p, cam.proj, ph);
+    else
+      xf4_rm(p, cam.proj, ph);
+    const float p_w = 1.0f / (ph[3] + 0.0000001f);
+    const float ppx = ph[0] * p_w, ppy = ph[1] * p_w;
+    float c6[6];
+    if (cov3D_precomp != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) c6[i] = cov3D_precomp[6 * idx + i];
+    } else {
+      const float s[3] = {scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]};
+      const float4 qv  = reinterpret_cast<const float4*>(rotations)[idx];
+      const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+      if (COLMAP)
+        cov3d_cm(s, scale_modifier, q, c6);
+      else
+        cov3d_rm(s, q, c6);
+    }
+    float cov[3];
+    if (COLMAP) {
+      ProjCM pr = proj_cm(p, focal_x, focal_y, tan_fovx, tan_fovy, c6, cam.view);
+      M3 c      = m3_mul(m3_mul(m3_t(pr.T), m3_t(pr.V)), pr.T);
+      cov[0] = c.m[0][0] + 0.3f, cov[1] = c.m[0][1], cov[2] = c.m[1][1] + 0.3f;
+    } else {
+      ProjRM pr = proj_rm(p, focal_x, focal_y, tan_fovx, tan_fovy, cam.view);
+      cov2d_rm(pr, c6, cov);
+    }
+    const float det = (cov[0] * cov[2] - cov[1] * cov[1]);
+    if (det != 0.0f) {
+      const float det_inv = 1.f / det;
+      const float conic[3] = {cov[2] * det_inv, -cov[1] * det_inv, cov[0] * det_inv};
+      const float mid      = 0.5f * (cov[0] + cov[2]);
+      const float lambda1  = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+      const float lambda2  = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+      const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+      const float pix[2]    = {ndc2pix(ppx, W), ndc2pix(ppy, H)};
+      tile_rect(pix[0], pix[1], (int) my_radius, gx, gy, mn, mx);
+      const uint32_t area = (uint32_t) (mx[0] - mn[0]) * (uint32_t) (mx[1] - mn[1]);
+      if (area != 0) {
+        float rgb[3];
+        if (colors_precomp == nullptr) {
+          sh_to_rgb(D, p, cam.campos, shs + (size_t) idx * M * 3, rgb, &clamp_bits);
+        } else {
+          rgb[0] = colors_precomp[3 * idx], rgb[1] = colors_precomp[3 * idx + 1], rgb[2] = colors_precomp[3 * idx + 2];
+        }
+        radius = (int) my_radius;
+        tiles  = area;
+        r0     = make_float4(pix[0], pix[1], conic[0], conic[1]);
+        r1     = make_float4(conic[2], opacities[idx], rgb[0], rgb[1]);
+        r2     = make_float4(rgb[2], pv[2], __int_as_float(radius), __uint_as_float(tiles | (clamp_bits << 29)));
+      }
+    }
+  }
+  radii[idx]        = radius;
+  recs[3 * idx + 0] = r0;
+  recs[3 * idx + 1] = r1;
+  recs[3 * idx + 2] = r2;
+  // per-tile instance counts (replaces the reference's per-Gaussian InclusiveSum: offsets are per TILE here)
+  for (int y = mn[1]; y < mx[1] && tiles; ++y)
+    for (int x = mn[0]; x < mx[0]; ++x) atomicAdd(&tile_counts[y * gx + x], 1u);
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// dL_dmeans += through dir = normalize(mean - campos)
+__device__ __forceinline__ void dnormvdv3(const float* v, const float* dv, float* o) {
+  const float sum2     = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+  const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+  o[0] = ((+sum2 - v[0] * v[0]) * dv[0] - v[1] * v[0] * dv[1] - v[2] * v[0] * dv[2]) * invsum32;
+  o[1] = (-v[0] * v[1] * dv[0] + (sum2 - v[1] * v[1]) * dv[1] - v[2] * v[1] * dv[2]) * invsum32;
+  o[2] = (-v[0] * v[2] * dv[0] - v[1] * v[2] * dv[1] + (sum2 - v[2] * v[2]) * dv[2]) * invsum32;
+}
+
+// SH backward: writes dL_dsh[M][3] for this Gaussian and returns dL_dmean contribution.
+__device__ __forceinline__ void sh_backward(int deg, int M, const float* mean, const float* campos, const float* sh,
+    uint32_t clamp_bits, const float* dL_dcolor, float* dL_dsh, float* dL_dmean_out) {
+  const float dir_orig[3] = {mean[0] - campos[0], mean[1] - campos[1], mean[2] - campos[2]};
+  const float len = sqrtf(dir_orig[0] * dir_orig[0] + dir_orig[1] * dir_orig[1] + dir_orig[2] * dir_orig[2]);
+  const float x = dir_orig[0] / len, y = dir_orig[1] / len, z = dir_orig[2] / len;
+  float g[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) g[c] = dL_dcolor[c] * (((clamp_bits >> c) & 1u) ? 0.f : 1.f);
+  float dx[3] = {0, 0, 0}, dy[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
+#define SHV(i, c) sh[(i) *3 + (c)]
+#define SETSH(i, coef)                                             \
+  {                                                                \
+    const float _k = (coef);                                       \
+    _Pragma("unroll") for (int c = 0; c < 3; ++c) dL_dsh[(i) *3 + c] = _k * g[c]; \
+  }
+  SETSH(0, SH_C0);
+  if (deg > 0) {
+    SETSH(1, -SH_C1 * y);
+    SETSH(2, SH_C1 * z);
+    SETSH(3, -SH_C1 * x);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      dx[c] = -SH_C1 * SHV(3, c);
+      dy[c] = -SH_C1 * SHV(1, c);
+      dz[c] = SH_C1 * SHV(2, c);
+    }
+    if (deg > 1) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      SETSH(4, SH_C2[0] * xy);
+      SETSH(5, SH_C2[1] * yz);
+      SETSH(6, SH_C2[2] * (2.f * zz - xx - yy));
+      SETSH(7, SH_C2[3] * xz);
+      SETSH(8, SH_C2[4] * (xx - yy));
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        dx[c] += SH_C2[0] * y * SHV(4, c) + SH_C2[2] * 2.f * -x * SHV(6, c) + SH_C2[3] * z * SHV(7, c) + SH_C2[4] * 2.f * x * SHV(8, c);
+        dy[c] += SH_C2[0] * x * SHV(4, c) + SH_C2[1] * z * SHV(5, c) + SH_C2[2] * 2.f * -y * SHV(6, c) + SH_C2[4] * 2.f * -y * SHV(8, c);
+        dz[c] += SH_C2[1] * y * SHV(5, c) + SH_C2[2] * 2.f * 2.f * z * SHV(6, c) + SH_C2[3] * x * SHV(7, c);
+      }
+      if (deg > 2) {
+        SETSH(9, SH_C3[0] * y * (3.f * xx - yy));
+        SETSH(10, SH_C3[1] * xy * z);
+        SETSH(11, SH_C3[2] * y * (4.f * zz - xx - yy));
+        SETSH(12, SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+        SETSH(13, SH_C3[4] * x * (4.f * zz - xx - yy));
+        SETSH(14, SH_C3[5] * z * (xx - yy));
+        SETSH(15, SH_C3[6] * x * (xx - 3.f * yy));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          dx[c] += (SH_C3[0] * SHV(9, c) * 3.f * 2.f * xy + SH_C3[1] * SHV(10, c) * yz + SH_C3[2] * SHV(11, c) * -2.f * xy +
+                    SH_C3[3] * SHV(12, c) * -3.f * 2.f * xz + SH_C3[4] * SHV(13, c) * (-3.f * xx + 4.f * zz - yy) +
+                    SH_C3[5] * SHV(14, c) * 2.f * xz + SH_C3[6] * SHV(15, c) * 3.f * (xx - yy));
+          dy[c] += (SH_C3[0] * SHV(9, c) * 3.f * (xx - yy) + SH_C3[1] * SHV(10, c) * xz +
+                    SH_C3[2] * SHV(11, c) * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * SHV(12, c) * -3.f * 2.f * yz +
+                    SH_C3[4] * SHV(13, c) * -2.f * xy + SH_C3[5] * SHV(14, c) * -2.f * yz + SH_C3[6] * SHV(15, c) * -3.f * 2.f * xy);
+          dz[c] += (SH_C3[1] * SHV(10, c) * xy + SH_C3[2] * SHV(11, c) * 4.f * 2.f * yz +
+                    SH_C3[3] * SHV(12, c) * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * SHV(13, c) * 4.f * 2.f * xz +
+                    SH_C3[5] * SHV(14, c) * (xx - yy));
+        }
+      }
+    }
+  }
+#undef SHV
+#undef SETSH
+  const float dL_ddir[3] = {dx[0] * g[0] + dx[1] * g[1] + dx[2] * g[2], dy[0] * g[0] + dy[1] * g[1] + dy[2] * g[2],
+      dz[0] * g[0] + dz[1] * g[1] + dz[2] * g[2]};
+  dnormvdv3(dir_orig, dL_ddir, dL_dmean_out);
+  // coefficients above the active degree stay zero
+  const int used = (deg + 1) * (deg + 1);
+  for (int i = used; i < M; ++i) dL_dsh[i * 3] = 0.f, dL_dsh[i * 3 + 1] = 0.f, dL_dsh[i * 3 + 2] = 0.f;
+}
+
+template <bool COLMAP>
+__global__ void __launch_bounds__(256) preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3D,
+    const int32_t* __restrict__ radii, const float* __restrict__ shs, const float* __restrict__ scales,
+    const float* __restrict__ rotations, float scale_modifier, const float* __restrict__ cov3D_precomp,
+    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos, int W,
+    int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, const float4* __restrict__ recs,
+    const float* __restrict__ gradacc /*[P][16]*/, const float* __restrict__ gin_means2D,
+    const float* __restrict__ gin_conic, const float* __restrict__ gin_opacity, int E, float* __restrict__ dL_dmeans2D,
+    float* __restrict__ dL_dconic_out, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
+    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
+    float* __restrict__ dL_dscales, float* __restrict__ dL_drot, float* __restrict__ dL_dextras) {
+  __shared__ Cam cam;
+  if (threadIdx.x < 16) {
+    cam.view[threadIdx.x] = viewmatrix[threadIdx.x];
+    cam.proj[threadIdx.x] = projmatrix[threadIdx.x];
+  }
+  if (threadIdx.x < 3) cam.campos[threadIdx.x] = campos[threadIdx.x];
+  __syncthreads();
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P) return;
+
+  // gradients accumulated by the blend backward (+ the optional chained-in ones)
+  float gm2[2] = {0.f, 0.f}, gcon[3] = {0.f, 0.f, 0.f}, gop = 0.f, gcol[3] = {0.f, 0.f, 0.f}, gex[4] = {0, 0, 0, 0};
+  const bool visible = radii[idx] > 0;
+  {
+    const float4* row = reinterpret_cast<const float4*>(gradacc + (size_t) idx * GRAD_ROW);
+    float4 a = make_float4(0, 0, 0, 0), b = a, c = a, d = a;
+    if (visible) a = row[0], b = row[1], c = row[2], d = row[3];
+    gm2[0] = a.x, gm2[1] = a.y, gcon[0] = a.z, gcon[1] = a.w, gcon[2] = b.x, gop = b.y, gcol[0] = b.z, gcol[1] = b.w;
+    gcol[2] = c.x, gex[0] = c.y, gex[1] = c.z, gex[2] = c.w, gex[3] = d.x;
+  }
+  if (gin_means2D) gm2[0] += gin_means2D[3 * idx], gm2[1] += gin_means2D[3 * idx + 1];
+  if (gin_conic) gcon[0] += gin_conic[4 * idx], gcon[1] += gin_conic[4 * idx + 1], gcon[2] += gin_conic[4 * idx + 3];
+  if (gin_opacity) gop += gin_opacity[idx];
+  dL_dmeans2D[3 * idx] = gm2[0], dL_dmeans2D[3 * idx + 1] = gm2[1];
+  dL_dmeans2D[3 * idx + 2] = gin_means2D ? gin_means2D[3 * idx + 2] : 0.f;
+  if (dL_dconic_out) {
+    dL_dconic_out[4 * idx] = gcon[0], dL_dconic_out[4 * idx + 1] = gcon[1];
+    dL_dconic_out[4 * idx + 2] = gin_conic ? gin_conic[4 * idx + 2] : 0.f;
+    dL_dconic_out[4 * idx + 3] = gcon[2];
+  }
+  dL_dopacity[idx] = gop;
+  dL_dcolors[3 * idx] = gcol[0], dL_dcolors[3 * idx + 1] = gcol[1], dL_dcolors[3 * idx + 2] = gcol[2];
+  for (int e = 0; e < E; ++e) dL_dextras[(size_t) idx * E + e] = gex[e];
+
+  float gmean[3] = {0.f, 0.f, 0.f}, gcov[6] = {0, 0, 0, 0, 0, 0}, gscale[3] = {0, 0, 0}, grot[4] = {0, 0, 0, 0};
+  float* gsh_row = dL_dsh ? dL_dsh + (size_t) idx * M * 3 : nullptr;
+  if (!visible) {
+    if (gsh_row)
+      for (int i = 0; i < M * 3; ++i) gsh_row[i] = 0.f;
+  } else {
+    const float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+    float c6[6];
+    float s[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1};
+    if (scales) {
+      s[0] = scales[3 * idx], s[1] = scales[3 * idx + 1], s[2] = scales[3 * idx + 2];
+      const float4 qv = reinterpret_cast<const float4*>(rotations)[idx];
+      q[0] = qv.x, q[1] = qv.y, q[2] = qv.z, q[3] = qv.w;
+    }
+    if (cov3D_precomp) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) c6[i] = cov3D_precomp[6 * idx + i];
+    } else if (COLMAP) {
+      cov3d_cm(s, scale_modifier, q, c6);  // recomputed (same arithmetic as the forward) instead of stored
+    } else {
+      cov3d_rm(s, q, c6);
+    }
+    const float h_x = focal_x, h_y = focal_y;
+    // ---- conic -> cov2D -> cov3D, mean (part 1: ASSIGNED) ----
+    if (COLMAP) {
+      ProjCM pr = proj_cm(p, h_x, h_y, tan_fovx, tan_fovy, c6, cam.view);
+      M3 c2     = m3_mul(m3_mul(m3_t(pr.T), m3_t(pr.V)), pr.T);
+      const float a = c2.m[0][0] + 0.3f, b = c2.m[0][1], c = c2.m[1][1] + 0.3f;
+      const float denom = a * c - b * b;
+      float dL_da = 0, dL_db = 0, dL_dc = 0;
+      const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+#define TT(i, j) pr.T.m[i][j]
+#define VV(i, j) pr.V.m[i][j]
+#define WW(i, j) pr.W.m[i][j]
+      if (denom2inv != 0) {
+        dL_da = denom2inv * (-c * c * gcon[0] + 2 * b * c * gcon[1] + (denom - a * c) * gcon[2]);
+        dL_dc = denom2inv * (-a * a * gcon[2] + 2 * a * b * gcon[1] + (denom - a * c) * gcon[0]);
+        dL_db = denom2inv * 2 * (b * c * gcon[0] - (denom + 2 * b * b) * gcon[1] + a * b * gcon[2]);
+        gcov[0] = (TT(0, 0) * TT(0, 0) * dL_da + TT(0, 0) * TT(1, 0) * dL_db + TT(1, 0) * TT(1, 0) * dL_dc);
+        gcov[3] = (TT(0, 1) * TT(0, 1) * dL_da + TT(0, 1) * TT(1, 1) * dL_db + TT(1, 1) * TT(1, 1) * dL_dc);
+        gcov[5] = (TT(0, 2) * TT(0, 2) * dL_da + TT(0, 2) * TT(1, 2) * dL_db + TT(1, 2) * TT(1, 2) * dL_dc);
+        gcov[1] = 2 * TT(0, 0) * TT(0, 1) * dL_da + (TT(0, 0) * TT(1, 1) + TT(0, 1) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 1) * dL_dc;
+        gcov[2] = 2 * TT(0, 0) * TT(0, 2) * dL_da + (TT(0, 0) * TT(1, 2) + TT(0, 2) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 2) * dL_dc;
+        gcov[4] = 2 * TT(0, 2) * TT(0, 1) * dL_da + (TT(0, 1) * TT(1, 2) + TT(0, 2) * TT(1, 1)) * dL_db + 2 * TT(1, 1) * TT(1, 2) * dL_dc;
+      }
+      const float dT00 = 2 * (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_da +
+                         (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_db;
+      const float dT01 = 2 * (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_da +
+                         (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_db;
+      const float dT02 = 2 * (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_da +
+                         (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_db;
+      const float dT10 = 2 * (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_dc +
+                         (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_db;
+      const float dT11 = 2 * (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_dc +
+                         (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_db;
+      const float dT12 = 2 * (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_dc +
+                         (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_db;
+      const float dJ00 = WW(0, 0) * dT00 + WW(0, 1) * dT01 + WW(0, 2) * dT02;
+      const float dJ02 = WW(2, 0) * dT00 + WW(2, 1) * dT01 + WW(2, 2) * dT02;
+      const float dJ11 = WW(1, 0) * dT10 + WW(1, 1) * dT11 + WW(1, 2) * dT12;
+      const float dJ12 = WW(2, 0) * dT10 + WW(2, 1) * dT11 + WW(2, 2) * dT12;
+#undef TT
+#undef VV
+#undef WW
+      const float tz = 1.f / pr.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+      const float dt[3] = {pr.xm * -h_x * tz2 * dJ02, pr.ym * -h_y * tz2 * dJ12,
+          -h_x * tz2 * dJ00 - h_y * tz2 * dJ11 + (2 * h_x * pr.t[0]) * tz3 * dJ02 + (2 * h_y * pr.t[1]) * tz3 * dJ12};
+      const float* vm = cam.view;
+      gmean[0] = vm[0] * dt[0] + vm[1] * dt[1] + vm[2] * dt[2];
+      gmean[1] = vm[4] * dt[0] + vm[5] * dt[1] + vm[6] * dt[2];
+      gmean[2] = vm[8] * dt[0] + vm[9] * dt[1] + vm[10] * dt[2];
+    } else {
+      // literal restatement of the row-major variant INCLUDING its self-inconsistencies
+      // (gaussian_preprocess.cu:241 uses T[1]; dL_dT2/5/8 = 0 so dL_dtx = dL_dty = 0)
+      ProjRM pr = proj_rm(p, h_x, h_y, tan_fovx, tan_fovy, cam.view);
+      float cov[3];
+      cov2d_rm(pr, c6, cov);
+      const float* T = pr.T;
+      const float* Wm = pr.W;
+      const float a = cov[0], b = cov[1], c = cov[2];
+      const float denom = a * c - b * b;
+      float dL_da = 0, dL_db = 0, dL_dc = 0;
+      const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+      if (denom2inv != 0) {
+        dL_da = denom2inv * (-c * c * gcon[0] + 2 * b * c * gcon[1] + (denom - a * c) * gcon[2]);
+        dL_dc = denom2inv * (-a * a * gcon[2] + 2 * a * b * gcon[1] + (denom - a * c) * gcon[0]);
+        dL_db = denom2inv * 2 * (b * c * gcon[0] - (denom + 2 * b * b) * gcon[1] + a * b * gcon[2]);
+        gcov[0] = (T[0] * T[0] * dL_da + T[0] * T[1] * dL_db + T[1] * T[1] * dL_dc);
+        gcov[3] = (T[1] * T[1] * dL_da + T[1] * T[4] * dL_db + T[4] * T[4] * dL_dc);
+        gcov[5] = (T[6] * T[6] * dL_da + T[6] * T[7] * dL_db + T[7] * T[7] * dL_dc);
+        gcov[1] = 2 * T[0] * T[3] * dL_da + (T[0] * T[4] + T[3] * T[1]) * dL_db + 2 * T[1] * T[4] * dL_dc;
+        gcov[2] = 2 * T[0] * T[6] * dL_da + (T[0] * T[7] + T[6] * T[1]) * dL_db + 2 * T[1] * T[7] * dL_dc;
+        gcov[4] = 2 * T[6] * T[3] * dL_da + (T[3] * T[7] + T[6] * T[4]) * dL_db + 2 * T[4] * T[7] * dL_dc;
+      }
+      const float dT0 = 2 * (T[0] * c6[0] + T[3] * c6[1] + T[6] * c6[2]) * dL_da + (T[1] * c6[0] + T[4] * c6[1] + T[7] * c6[2]) * dL_db;
+      const float dT1 = 2 * (T[1] * c6[0] + T[4] * c6[1] + T[7] * c6[2]) * dL_dc + (T[0] * c6[0] + T[3] * c6[1] + T[6] * c6[2]) * dL_db;
+      const float dT2 = 0;
+      const float dT3 = 2 * (T[0] * c6[1] + T[3] * c6[3] + T[6] * c6[4]) * dL_da + (T[1] * c6[1] + T[4] * c6[3] + T[7] * c6[4]) * dL_db;
+      const float dT4 = 2 * (T[1] * c6[1] + T[4] * c6[3] + T[7] * c6[4]) * dL_dc + (T[0] * c6[3] + T[3] * c6[4] + T[6] * c6[5]) * dL_db;
+      const float dT5 = 0;
+      const float dT6 = 2 * (T[0] * c6[2] + T[3] * c6[4] + T[6] * c6[5]) * dL_da + (T[1] * c6[2] + T[4] * c6[4] + T[7] * c6[5]) * dL_db;
+      const float dT7 = 2 * (T[1] * c6[2] + T[4] * c6[4] + T[7] * c6[5]) * dL_dc + (T[0] * c6[2] + T[3] * c6[4] + T[6] * c6[5]) * dL_db;
+      const float dT8 = 0;
+      const float dJ00 = Wm[0] * dT0 + Wm[3] * dT3 + Wm[6] * dT6;
+      const float dJ02 = Wm[0] * dT2 + Wm[3] * dT5 + Wm[6] * dT8;
+      const float dJ11 = Wm[1] * dT1 + Wm[4] * dT4 + Wm[7] * dT7;
+      const float dJ12 = Wm[1] * dT2 + Wm[4] * dT5 + Wm[7] * dT8;
+      const float tz = 1.f / pr.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+      const float dt[3] = {pr.xm * -h_x * tz2 * dJ02, pr.ym * -h_y * tz2 * dJ12,
+          -h_x * tz2 * dJ00 - h_y * tz2 * dJ11 + (2 * h_x * pr.t[0]) * tz3 * dJ02 + (2 * h_y * pr.t[1]) * tz3 * dJ12};
+      const float* vm = cam.view;
+      gmean[0] = vm[0] * dt[0] + vm[4] * dt[1] + vm[8] * dt[2];
+      gmean[1] = vm[1] * dt[0] + vm[5] * dt[1] + vm[9] * dt[2];
+      gmean[2] = vm[2] * dt[0] + vm[6] * dt[1] + vm[10] * dt[2];
+    }
+    // ---- projection of the 2D mean (part 2: +=) ----
+    {
+      const float* proj = cam.proj;
+      float mh[4], d2[3];
+      if (COLMAP) {
+        xf4_cm(p, proj, mh);
+        const float m_w  = 1.0f / (mh[3] + 0.0000001f);
+        const float mul1 = (proj[0] * p[0] + proj[4] * p[1] + proj[8] * p[2] + proj[12]) * m_w * m_w;
+        const float mul2 = (proj[1] * p[0] + proj[5] * p[1] + proj[9] * p[2] + proj[13]) * m_w * m_w;
+        d2[0] = (proj[0] * m_w - proj[3] * mul1) * gm2[0] + (proj[1] * m_w - proj[3] * mul2) * gm2[1];
+        d2[1] = (proj[4] * m_w - proj[7] * mul1) * gm2[0] + (proj[5] * m_w - proj[7] * mul2) * gm2[1];
+        d2[2] = (proj[8] * m_w - proj[11] * mul1) * gm2[0] + (proj[9] * m_w - proj[11] * mul2) * gm2[1];
+      } else {
+        xf4_rm(p, proj, mh);
+        const float m_w  = 1.0f / (mh[3] + 0.0000001f);
+        const float mul1 = (proj[0] * p[0] + proj[1] * p[1] + proj[2] * p[2] + proj[3]) * m_w * m_w;
+        const float mul2 = (proj[4] * p[0] + proj[5] * p[1] + proj[6] * p[2] + proj[7]) * m_w * m_w;
+        d2[0] = (proj[0] * m_w - proj[12] * mul1) * gm2[0] + (proj[4] * m_w - proj[12] * mul2) * gm2[1];
+        d2[1] = (proj[1] * m_w - proj[13] * mul1) * gm2[0] + (proj[5] * m_w - proj[13] * mul2) * gm2[1];
+        d2[2] = (proj[2] * m_w - proj[14] * mul1) * gm2[0] + (proj[6] * m_w - proj[14] * mul2) * gm2[1];
+      }
+      gmean[0] += d2[0], gmean[1] += d2[1], gmean[2] += d2[2];
+    }
+    // ---- SH (part 3: +=) ----
+    if (shs) {
+      const uint32_t clamp_bits = __float_as_uint(recs[3 * idx + 2].w) >> 29;
+      float dm[3];
+      sh_backward(D, M, p, cam.campos, shs + (size_t) idx * M * 3, clamp_bits, gcol, gsh_row, dm);
+      gmean[0] += dm[0], gmean[1] += dm[1], gmean[2] += dm[2];
+    }
+    // ---- Sigma3D -> scale, rotation ----
+    if (scales) {
+      if (COLMAP) {
+        const float x = q[0], y = q[1], z = q[2], r = q[3];
+        M3 R           = rot_cm(q);
+        const float sm[3] = {scale_modifier * s[0], scale_modifier * s[1], scale_modifier * s[2]};
+        M3 Mm          = scale_rot_cm(sm, R);
+        M3 dSg;
+        dSg.m[0][0] = gcov[0], dSg.m[0][1] = 0.5f * gcov[1], dSg.m[0][2] = 0.5f * gcov[2];
+        dSg.m[1][0] = 0.5f * gcov[1], dSg.m[1][1] = gcov[3], dSg.m[1][2] = 0.5f * gcov[4];
+        dSg.m[2][0] = 0.5f * gcov[2], dSg.m[2][1] = 0.5f * gcov[4], dSg.m[2][2] = gcov[5];
+        M3 M2;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int w = 0; w < 3; ++w) M2.m[c][w] = Mm.m[c][w] * 2.0f;
+        M3 dM  = m3_mul(M2, dSg);
+        M3 Rt  = m3_t(R);
+        M3 dMt = m3_t(dM);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gscale[k] = Rt.m[k][0] * dMt.m[k][0] + Rt.m[k][1] * dMt.m[k][1] + Rt.m[k][2] * dMt.m[k][2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int w = 0; w < 3; ++w) dMt.m[k][w] *= sm[k];
+#define DD(i, j) dMt.m[i][j]
+        grot[0] = 2 * y * (DD(1, 0) + DD(0, 1)) + 2 * z * (DD(2, 0) + DD(0, 2)) + 2 * r * (DD(1, 2) - DD(2, 1)) - 4 * x * (DD(2, 2) + DD(1, 1));
+        grot[1] = 2 * x * (DD(1, 0) + DD(0, 1)) + 2 * r * (DD(2, 0) - DD(0, 2)) + 2 * z * (DD(1, 2) + DD(2, 1)) - 4 * y * (DD(2, 2) + DD(0, 0));
+        grot[2] = 2 * r * (DD(0, 1) - DD(1, 0)) + 2 * x * (DD(2, 0) + DD(0, 2)) + 2 * y * (DD(1, 2) + DD(2, 1)) - 4 * z * (DD(1, 1) + DD(0, 0));
+        grot[3] = 2 * z * (DD(0, 1) - DD(1, 0)) + 2 * y * (DD(2, 0) - DD(0, 2)) + 2 * x * (DD(1, 2) - DD(2, 1));
+#undef DD
+      } else {
+        float R[9];
+        q2R_rm(q, R);
+        const float* g = gcov;
+        gscale[0] = R[0] * R[0] * g[0] + R[0] * R[3] * g[1] + R[0] * R[6] * g[2] + R[3] * R[3] * g[3] + R[3] * R[6] * g[4] + R[6] * R[6] * g[5];
+        gscale[1] = R[1] * R[1] * g[0] + R[1] * R[4] * g[1] + R[1] * R[7] * g[2] + R[4] * R[4] * g[3] + R[4] * R[7] * g[4] + R[7] * R[7] * g[5];
+        gscale[2] = R[2] * R[2] * g[0] + R[2] * R[5] * g[1] + R[2] * R[8] * g[2] + R[5] * R[5] * g[3] + R[5] * R[8] * g[4] + R[8] * R[8] * g[5];
+        gscale[0] *= 2 * s[0], gscale[1] *= 2 * s[1], gscale[2] *= 2 * s[2];
+        const float sx2 = s[0] * s[0], sy2 = s[1] * s[1], sz2 = s[2] * s[2];
+        float dR[9];
+        dR[0] = (2 * R[0] * g[0] + R[3] * g[1] + R[6] * g[2]) * sx2;
+        dR[1] = (2 * R[1] * g[0] + R[4] * g[1] + R[7] * g[2]) * sy2;
+        dR[2] = (2 * R[2] * g[0] + R[5] * g[1] + R[8] * g[2]) * sz2;
+        dR[3] = (2 * R[3] * g[3] + R[0] * g[1] + R[6] * g[4]) * sx2;
+        dR[4] = (2 * R[4] * g[3] + R[1] * g[1] + R[7] * g[4]) * sy2;
+        dR[5] = (2 * R[5] * g[3] + R[2] * g[1] + R[8] * g[4]) * sz2;
+        dR[6] = (2 * R[6] * g[5] + R[0] * g[2] + R[3] * g[4]) * sx2;
+        dR[7] = (2 * R[7] * g[5] + R[1] * g[2] + R[4] * g[4]) * sy2;
+        dR[8] = (2 * R[8] * g[5] + R[2] * g[2] + R[5] * g[4]) * sz2;
+        const float x = q[0], y = q[1], z = q[2], w = q[3];
+        grot[0] = 2 * (-2 * x * (dR[4] + dR[8]) + y * (dR[1] + dR[3]) + z * (dR[2] + dR[6]) + w * (dR[7] - dR[5]));
+        grot[1] = 2 * (x * (dR[1] + dR[3]) - 2 * y * (dR[0] + dR[8]) + z * (dR[5] + dR[7]) + w * (dR[2] - dR[6]));
+        grot[2] = 2 * (x * (dR[2] + dR[6]) + y * (dR[5] + dR[7]) - 2 * z * (dR[0] + dR[4]) + w * (dR[3] - dR[1]));
+        grot[3] = 2 * (x * (dR[7] - dR[5]) + y * (dR[2] - dR[6]) + z * (dR[3] - dR[1]));
+      }
+    }
+  }
+  dL_dmeans3D[3 * idx] = gmean[0], dL_dmeans3D[3 * idx + 1] = gmean[1], dL_dmeans3D[3 * idx + 2] = gmean[2];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dL_dcov3D[6 * idx + i] = gcov[i];
+  dL_dscales[3 * idx] = gscale[0], dL_dscales[3 * idx + 1] = gscale[1], dL_dscales[3 * idx + 2] = gscale[2];
+  reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(grot[0], grot[1], grot[2], grot[3]);
+}
+
+__global__ void mark_visible_kernel(int P, const float* means, const float* view, int colmap, uint8_t* present) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P) return;
+  const float p[3] = {means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]};
+  float pv[3];
+  if (colmap) {
+    xf3_cm(p, view, pv);
+    present[idx] = !(pv[2] <= 0.2f);
+  } else {
+    xf3_rm(p, view, pv);
+    present[idx] = !(pv[2] <= -1.0f);
+  }
+}
+
+}  // namespace
+
+int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, int32_t* radii, hipStream_t s) {
+  const int P = in.P;
+  const float focal_y = in.image_height / (2.0f * in.tanfovy);
+  const float focal_x = in.image_width / (2.0f * in.tanfovx);
+  SKGS_CHECK_HIP(hipMemsetAsync(im.tile_counts, 0, (size_t) im.T * 4, s));
+  if (P == 0) return 0;
+  dim3 grid((P + 255) / 256), block(256);
+  if (in.colmap)
+    hipLaunchKernelGGL(preprocess_forward_kernel<true>, grid, block, 0, s, P, in.sh_degree, in.sh_coeffs, in.means3D,
+        in.scales, in.scale_modifier, in.rotations, in.opacity, in.sh, in.cov3D_precomp, in.colors_precomp, in.viewmatrix,
+        in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y, im.tiles_x,
+        im.tiles_y, radii, g.recs, im.tile_counts);
+  else
+    hipLaunchKernelGGL(preprocess_forward_kernel<false>, grid, block, 0, s, P, in.sh_degree, in.sh_coeffs, in.means3D,
+        in.scales, in.scale_modifier, in.rotations, in.opacity, in.sh, in.cov3D_precomp, in.colors_precomp, in.viewmatrix,
+        in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y, im.tiles_x,
+        im.tiles_y, radii, g.recs, im.tile_counts);
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const int32_t* radii, const skgs_raster_grads& gr,
+    hipStream_t s) {
+  const int P = in.P;
+  if (P == 0) return 0;
+  const float focal_y = in.image_height / (2.0f * in.tanfovy);
+  const float focal_x = in.image_width / (2.0f * in.tanfovx);
+  dim3 grid((P + 255) / 256), block(256);
+  const int E = (in.extras && gr.dL_dout_extra && gr.dL_dextras) ? in.E : 0;
+#define SKGS_PB_ARGS                                                                                                    \
+  P, in.sh_degree, in.sh_coeffs, in.means3D, radii, in.sh, in.scales, in.rotations, in.scale_modifier, in.cov3D_precomp, \
+      in.viewmatrix, in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y, \
+      g.recs, gr.workspace, gr.grad_means2D_in, gr.grad_conic_in, gr.grad_opacity_in, E, gr.dL_dmeans2D, gr.dL_dconic,    \
+      gr.dL_dcolors, gr.dL_dopacity, gr.dL_dmeans3D, gr.dL_dcov3D, gr.dL_dsh, gr.dL_dscales, gr.dL_drotations, gr.dL_dextras
+  if (in.colmap)
+    hipLaunchKernelGGL(preprocess_backward_kernel<true>, grid, block, 0, s, SKGS_PB_ARGS);
+  else
+    hipLaunchKernelGGL(preprocess_backward_kernel<false>, grid, block, 0, s, SKGS_PB_ARGS);
+#undef SKGS_PB_ARGS
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_mark_visible(int P, const float* means, const float* view, int colmap, uint8_t* present, hipStream_t s) {
+  if (P == 0) return 0;
+  hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means, view, colmap, present);
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace skgs

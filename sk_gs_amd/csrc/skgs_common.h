@@ -1,0 +1,177 @@
+// skgs_common.h -- private layouts and device helpers shared by the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/skgs.h"
+
+namespace skgs {
+
+constexpr int TILE      = SKGS_TILE;  // 16x16 pixel tiles (reference BLOCK_X/BLOCK_Y)
+constexpr int WAVE      = 64;         // CDNA wavefront
+constexpr int REC_F4    = 3;          // one Gaussian record = 3 x float4 = 48 B
+constexpr int GRAD_ROW  = 16;         // one gradient-accumulator row = 16 floats = one 64-B line
+
+// ---- geom buffer ---------------------------------------------------------------------------------------
+// [0,256)   GeomHeader
+// [256, ..) GaussRec[P]   (48 B each, 16-B aligned)
+//   f[0] x_pix  f[1] y_pix  f[2] conic.a  f[3] conic.b | f[4] conic.c  f[5] opacity  f[6] r  f[7] g |
+//   f[8] b      f[9] depth  i[10] radius  u[11] tiles_touched | clamped_bits << 29
+struct GeomHeader {
+  int32_t num_rendered;
+  int32_t overflow;
+  int32_t max_tile_count;
+  int32_t reserved;
+  int32_t P;
+  int32_t pad[59];
+};
+static_assert(sizeof(GeomHeader) == 256, "header");
+
+struct GeomView {
+  GeomHeader* hdr;
+  float4* recs;
+};
+__host__ __device__ inline GeomView geom_view(void* base) {
+  GeomView v;
+  v.hdr  = reinterpret_cast<GeomHeader*>(base);
+  v.recs = reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + 256);
+  return v;
+}
+inline size_t geom_bytes(int32_t P) { return 256 + (size_t) P * 48 + 256; }
+
+// ---- img buffer ----------------------------------------------------------------------------------------
+// n_contrib[H*W] u32 | tile_counts[T] | tile_offsets[T+1] | cursors[T]       (each 256-B aligned)
+struct ImgView {
+  uint32_t* n_contrib;
+  uint32_t* tile_counts;
+  uint32_t* tile_offsets;
+  uint32_t* cursors;
+  int tiles_x, tiles_y, T;
+};
+inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+__host__ __device__ inline size_t align256_hd(size_t x) { return (x + 255) & ~size_t(255); }
+inline ImgView img_view(void* base, int W, int H) {
+  ImgView v;
+  v.tiles_x = (W + TILE - 1) / TILE;
+  v.tiles_y = (H + TILE - 1) / TILE;
+  v.T       = v.tiles_x * v.tiles_y;
+  char* p   = reinterpret_cast<char*>(base);
+  v.n_contrib = reinterpret_cast<uint32_t*>(p);
+  p += align256((size_t) W * H * 4);
+  v.tile_counts = reinterpret_cast<uint32_t*>(p);
+  p += align256((size_t) v.T * 4);
+  v.tile_offsets = reinterpret_cast<uint32_t*>(p);
+  p += align256((size_t) (v.T + 1) * 4);
+  v.cursors = reinterpret_cast<uint32_t*>(p);
+  return v;
+}
+inline size_t img_bytes(int W, int H) {
+  int T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+  return align256((size_t) W * H * 4) + align256((size_t) T * 4) + align256((size_t) (T + 1) * 4) +
+         align256((size_t) T * 4) + 256;
+}
+
+// ---- binning buffer ------------------------------------------------------------------------------------
+// keys[cap] u64 (depth_bits << 32 | gaussian id; sorted in place per tile) | point_list[cap] u32
+struct BinView {
+  uint64_t* keys;
+  uint32_t* point_list;
+  int64_t capacity;
+};
+inline int64_t bin_capacity(size_t bytes) {
+  if (bytes < 512) return 0;
+  return (int64_t) ((bytes - 512) / 12);
+}
+inline size_t bin_bytes(int64_t cap) { return (size_t) cap * 12 + 512; }
+inline BinView bin_view(void* base, size_t bytes) {
+  BinView v;
+  v.capacity   = bin_capacity(bytes);
+  char* p      = reinterpret_cast<char*>(base);
+  v.keys       = reinterpret_cast<uint64_t*>(p);
+  v.point_list = reinterpret_cast<uint32_t*>(p + align256((size_t) v.capacity * 8));
+  return v;
+}
+
+// ---- XCD-aware block -> work remap -------------------------------------------------------------------
+// Blocks are dealt round-robin over the 8 XCDs (block b and b+8 share an XCD/L2). Give every XCD one contiguous
+// span of work items so neighbouring tiles (which share Gaussians) hit the same L2.  Pure performance: any
+// placement gives the same results.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+  const int per = (n + 7) >> 3;
+  const int v   = (b & 7) * per + (b >> 3);
+  return v;  // may be >= n for the tail: caller must bounds-check
+}
+
+// ---- wave-level sum over 64 lanes using DPP (result valid in lane 63) --------------------------------
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND_CTRL = false>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, BOUND_CTRL));
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v += dpp_mov<0x111, 0xf, 0xf, true>(v);  // row_shr:1
+  v += dpp_mov<0x112, 0xf, 0xf, true>(v);  // row_shr:2
+  v += dpp_mov<0x114, 0xf, 0xf, true>(v);  // row_shr:4  (lanes 3.. hold sums of 4; after this lane 7,15 hold 8)
+  v += dpp_mov<0x118, 0xf, 0xf, true>(v);  // row_shr:8  -> lane 15 of each row = row sum
+  v += dpp_mov<0x142, 0xa, 0xf, false>(v); // row_bcast:15 into rows 1,3
+  v += dpp_mov<0x143, 0xc, 0xf, false>(v); // row_bcast:31 into rows 2,3 -> lane 63 = total
+  return v;
+}
+
+// Tile rectangle of a splat (reference getRect, gaussian_render.h:42-47). Used by the preprocess AND the scatter
+// kernel: both must produce the identical rectangle.  No multiply feeds an add here, so FMA contraction settings
+// of the including file cannot change the result.
+__device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int gy, int* mn, int* mx) {
+  mn[0] = min(gx, max(0, (int) ((px - r) / TILE)));
+  mn[1] = min(gy, max(0, (int) ((py - r) / TILE)));
+  mx[0] = min(gx, max(0, (int) ((px + r + TILE - 1) / TILE)));
+  mx[1] = min(gy, max(0, (int) ((py + r + TILE - 1) / TILE)));
+}
+
+__device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+}  // namespace skgs
+
+// host-side launch declarations (one per TU)
+namespace skgs {
+int set_error(const char* fmt, ...);
+#define SKGS_CHECK_HIP(expr)                                                                 \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) return skgs::set_error("%s failed: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+#define SKGS_REQUIRE(cond, ...) \
+  do {                          \
+    if (!(cond)) return skgs::set_error(__VA_ARGS__); \
+  } while (0)
+
+// preprocess.hip
+int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, int32_t* radii, hipStream_t s);
+int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const int32_t* radii,
+    const skgs_raster_grads& gr, hipStream_t s);
+int launch_mark_visible(int P, const float* means, const float* view, int colmap, uint8_t* present, hipStream_t s);
+// binning.hip
+int launch_scan_tiles(GeomView g, ImgView im, int64_t capacity_hint, hipStream_t s);
+int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, BinView b, hipStream_t s);
+// render.hip
+int launch_render_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, BinView b, float* out_color,
+    float* out_opacity, float* out_extra, hipStream_t s);
+int launch_render_backward(const skgs_raster_inputs& in, GeomView g, ImgView im, BinView b, const float* out_opacity,
+    const float* dL_dcolor, const float* dL_dopacity, const float* dL_dextra, float* gradacc, hipStream_t s);
+int launch_extra_forward(int W, int H, int P, int E, const float* extra, GeomView g, ImgView im, BinView b,
+    float* pixel_extra, hipStream_t s);
+int launch_extra_backward(int W, int H, int P, int E, const float* extra, const float* out_opacity,
+    const float* grad_pixel_extra, GeomView g, ImgView im, BinView b, float* grad_means2D, float* grad_conic,
+    float* grad_opacity, float* dL_dextra, hipStream_t s);
+int launch_topk(int topk, int W, int H, GeomView g, ImgView im, BinView b, int32_t* top_idx, float* top_w,
+    hipStream_t s);
+// deform.hip
+int launch_deform_forward(const skgs_deform_inputs& in, float* means, float* scales, float* rotations, float* opacity,
+    float* d_xyz, float* d_rot, float* d_scale, hipStream_t s);
+int launch_deform_backward(const skgs_deform_inputs& in, const float* g_means, const float* g_scales,
+    const float* g_rotations, const float* g_opacity, float* g_weights, float* g_bone_T, float* g_bone_drot,
+    float* g_bone_dscale, float* g_xyz, float* g_log_scale, float* g_rot, float* g_opacity_logit, hipStream_t s);
+int launch_knn_bones(int P, int M, int K, int dim, const float* points, const float* joints, float* out_dist,
+    int64_t* out_idx, hipStream_t s);
+}  // namespace skgs

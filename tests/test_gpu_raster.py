@@ -1,0 +1,257 @@
+"""GPU parity tests of the rasterizer: HIP kernels (through the C ABI / reference-named functions) vs the CPU oracle
+on identical seeded inputs.
+
+Tolerances (written here, as the task requires):
+  * integer outputs (radii, num_rendered, per-tile ranges, sorted point lists): bit-exact;
+  * per-Gaussian floats produced by the preprocess kernel (pixel position, conic, depth, rgb): bit-exact -- the kernel
+    is compiled without FMA contraction in the oracle's evaluation order;
+  * blended image / opacity and every gradient: max-norm relative error (the reference's get_rel_error,
+    my_ext/utils/test_utils.py:6-21) <= 1e-4, the north-star tolerance.  The blend uses the hardware exp, so a
+    (pixel, Gaussian) pair sitting within an ulp of the alpha<1/255 or T<1e-4 thresholds may flip; such flips are
+    bounded separately: n_contrib may differ on <= 1e-4 of the pixels.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import frac_outliers, oracle_backward, oracle_forward, rel_err, scene_inputs, to_np
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _C():
+    from sk_gs_amd import _C
+    return _C
+
+
+def hip_forward(act, rs, extras=None, colors=None, cov3D=None):
+    C = _C()
+    e = torch.Tensor([])
+    use_sh = colors is None
+    out = C.rasterize_gaussians(
+        rs.image_height, rs.image_width, rs.tanfovx, rs.tanfovy, rs.sh_degree, rs.scale_modifier, rs.prefiltered,
+        rs.debug, rs.colmap, rs.viewmatrix, rs.projmatrix, rs.campos, act['means3D'], act['opacity'],
+        act['sh'] if use_sh else e, act['scales'] if cov3D is None else e, act['rotations'] if cov3D is None else e,
+        extras, e if use_sh else colors, e if cov3D is None else cov3D)
+    return out
+
+
+def hip_backward(fwd, act, rs, dL_dcolor, dL_dopacity, extras=None, dL_dextra=None, colors=None, cov3D=None, gm=None,
+                 gc=None, go=None):
+    C = _C()
+    e = torch.Tensor([])
+    use_sh = colors is None
+    R, color, opacity, radii, geom, binning, img, out_extra = fwd
+    return C.rasterize_gaussians_backward(
+        rs.scale_modifier, rs.tanfovx, rs.tanfovy, rs.sh_degree, rs.debug, rs.colmap, rs.viewmatrix, rs.projmatrix,
+        rs.campos, act['means3D'], e if use_sh else colors, extras, act['scales'] if cov3D is None else e,
+        act['rotations'] if cov3D is None else e, e if cov3D is None else cov3D, act['sh'] if use_sh else e, R, radii,
+        opacity, dL_dcolor, dL_dopacity, dL_dextra, gm, gc, go, geom, binning, img)
+
+
+def check_forward(o, act, rs, extras=None, colors=None, cov3D=None):
+    W, H = rs.image_width, rs.image_height
+    P = act['means3D'].shape[0]
+    ref = oracle_forward(o, act, rs, extras, colors, cov3D)
+    fwd = hip_forward(act, rs, extras, colors, cov3D)
+    R, color, opacity, radii, geom, binning, img, out_extra = fwd
+    assert R == ref['num_rendered']
+    np.testing.assert_array_equal(to_np(radii), ref['radii'])
+    bufs = _C().unpack_buffers(W, H, P, geom, binning, img)
+    vis = ref['radii'] > 0
+    recs = to_np(bufs['recs'])
+    # per-Gaussian records: bit-exact for visible Gaussians
+    np.testing.assert_array_equal(recs[vis, 0:2], ref['geom']['means2D'][vis])
+    np.testing.assert_array_equal(recs[vis, 2:5], ref['geom']['conic_opacity'][vis, 0:3])
+    np.testing.assert_array_equal(recs[vis, 9], ref['geom']['depths'][vis])
+    if colors is None:
+        np.testing.assert_array_equal(recs[vis, 6:9], ref['geom']['rgb'][vis])
+    # tile ranges and sorted lists: bit-exact
+    offs = to_np(bufs['tile_offsets']).astype(np.int64)
+    ranges = ref['binning']['ranges'].astype(np.int64)
+    nonempty = ranges[:, 1] > ranges[:, 0]
+    np.testing.assert_array_equal((offs[1:] - offs[:-1])[nonempty], (ranges[:, 1] - ranges[:, 0])[nonempty])
+    np.testing.assert_array_equal(offs[:-1][nonempty], ranges[nonempty, 0])
+    np.testing.assert_array_equal(to_np(bufs['point_list'])[:R].astype(np.uint32), ref['binning']['point_list'])
+    # image
+    assert rel_err(color, ref['color']) <= TOL, rel_err(color, ref['color'])
+    assert rel_err(opacity, ref['opacity']) <= TOL
+    nc = to_np(bufs['n_contrib']).astype(np.int64)
+    assert (nc != ref['img']['n_contrib'].astype(np.int64)).mean() <= 1e-4
+    if extras is not None:
+        assert rel_err(out_extra, ref['out_extra']) <= TOL
+    return ref, fwd
+
+
+@pytest.mark.parametrize('ppl', [1, 2, 4])
+@pytest.mark.parametrize('colmap', [True, False])
+@pytest.mark.parametrize('P,W,H,seed,scale_mult', [(5000, 256, 256, 0, 2.0), (3000, 200, 136, 1, 3.0)])
+def test_forward_backward_parity(oracle32, colmap, P, W, H, seed, scale_mult, ppl):
+    _C().set_pixels_per_lane(ppl)
+    try:
+        act, rs, cam = scene_inputs(P, W, H, seed=seed, colmap=colmap, scale_mult=scale_mult, device='cuda')
+        ref, fwd = check_forward(oracle32, act, rs)
+        g = torch.Generator().manual_seed(seed + 7)
+        dL_dcolor = torch.randn(3, H, W, generator=g).cuda()
+        dL_dopacity = torch.randn(H, W, generator=g).cuda()
+        gref = oracle_backward(oracle32, ref, act, rs, dL_dcolor, dL_dopacity)
+        got = hip_backward(fwd, act, rs, dL_dcolor, dL_dopacity)
+        names = ['dL_dmean2D', 'dL_dcolors', 'dL_dopacity', 'dL_dmeans3D', 'dL_dcov3D', 'dL_dsh', 'dL_dscales',
+                 'dL_drotations']
+        for name, t in zip(names, got[:8]):
+            err = rel_err(t, gref[name].reshape(to_np(t).shape))
+            assert err <= TOL, (name, err)
+        assert got[8] is None
+    finally:
+        _C().set_pixels_per_lane(0)
+
+
+@pytest.mark.parametrize('E', [1, 4])
+def test_extras_in_main_pass(oracle32, E):
+    P, W, H = 3000, 160, 160
+    act, rs, cam = scene_inputs(P, W, H, seed=3, colmap=True, scale_mult=3.0, device='cuda')
+    g = torch.Generator().manual_seed(11)
+    extras = torch.randn(P, E, generator=g).cuda()
+    ref, fwd = check_forward(oracle32, act, rs, extras=extras)
+    dL_dcolor = torch.randn(3, H, W, generator=g).cuda()
+    dL_dopacity = torch.randn(H, W, generator=g).cuda()
+    dL_dextra = torch.randn(E, H, W, generator=g).cuda()
+    gref = oracle_backward(oracle32, ref, act, rs, dL_dcolor, dL_dopacity, extras, dL_dextra)
+    got = hip_backward(fwd, act, rs, dL_dcolor, dL_dopacity, extras, dL_dextra)
+    assert rel_err(got[8], gref['dL_dextras']) <= TOL
+    assert rel_err(got[0], gref['dL_dmean2D']) <= TOL
+    assert rel_err(got[5], gref['dL_dsh']) <= TOL
+
+
+def test_precomputed_colors_and_cov(oracle32):
+    P, W, H = 2000, 128, 128
+    act, rs, cam = scene_inputs(P, W, H, seed=4, colmap=True, scale_mult=3.0, device='cuda')
+    g = torch.Generator().manual_seed(5)
+    colors = torch.rand(P, 3, generator=g).cuda()
+    # covariance from the oracle's own forward (scale/rot path) reused as cov3D_precomp
+    ref0 = oracle_forward(oracle32, act, rs)
+    cov3D = torch.from_numpy(ref0['geom']['cov3D']).cuda()
+    ref, fwd = check_forward(oracle32, act, rs, colors=colors, cov3D=cov3D)
+    dL_dcolor = torch.randn(3, H, W, generator=g).cuda()
+    dL_dopacity = torch.randn(H, W, generator=g).cuda()
+    gref = oracle_backward(oracle32, ref, act, rs, dL_dcolor, dL_dopacity, colors=colors, cov3D=cov3D)
+    got = hip_backward(fwd, act, rs, dL_dcolor, dL_dopacity, colors=colors, cov3D=cov3D)
+    assert rel_err(got[1], gref['dL_dcolors']) <= TOL
+    assert rel_err(got[4], gref['dL_dcov3D']) <= TOL
+    assert rel_err(got[3], gref['dL_dmeans3D']) <= TOL
+    assert float(got[6].abs().max()) == 0.0 and float(got[7].abs().max()) == 0.0
+
+
+def test_chained_input_grads(oracle32):
+    """grad_means2D / grad_conic / grad_opacity handed in (from extra passes) are added to the results"""
+    P, W, H = 1500, 96, 96
+    act, rs, cam = scene_inputs(P, W, H, seed=6, colmap=True, scale_mult=3.0, device='cuda')
+    ref, fwd = check_forward(oracle32, act, rs)
+    g = torch.Generator().manual_seed(9)
+    dL_dcolor = torch.randn(3, H, W, generator=g).cuda()
+    dL_dopacity = torch.randn(H, W, generator=g).cuda()
+    gm = torch.randn(P, 3, generator=g).cuda()
+    gc = torch.randn(P, 2, 2, generator=g).cuda()
+    go = torch.randn(P, 1, generator=g).cuda()
+    gref = oracle_backward(oracle32, ref, act, rs, dL_dcolor, dL_dopacity, grad_means2D=gm, grad_conic=gc,
+                           grad_opacity=go)
+    got = hip_backward(fwd, act, rs, dL_dcolor, dL_dopacity, gm=gm.clone(), gc=gc.clone(), go=go.clone())
+    assert rel_err(got[0], gref['dL_dmean2D']) <= TOL
+    assert rel_err(got[2], gref['dL_dopacity']) <= TOL
+    assert rel_err(got[3], gref['dL_dmeans3D']) <= TOL
+    assert rel_err(got[6], gref['dL_dscales']) <= TOL
+
+
+def test_other_extras_and_topk(oracle32):
+    C = _C()
+    P, W, H, E = 2000, 112, 80, 20
+    act, rs, cam = scene_inputs(P, W, H, seed=8, colmap=True, scale_mult=3.0, device='cuda')
+    ref, fwd = check_forward(oracle32, act, rs)
+    R, color, opacity, radii, geom, binning, img, _ = fwd
+    g = torch.Generator().manual_seed(13)
+    extra = torch.randn(P, E, generator=g).cuda()
+    pe = C.gaussian_rasterize_extra_forward(W, H, R, extra, geom, binning, img)
+    assert tuple(pe.shape) == (W, H, E)
+    pe_ref = oracle32.extra_forward(W, H, ref, to_np(extra))
+    assert rel_err(pe.reshape(H * W, E), pe_ref) <= TOL
+    gpe = torch.randn(W, H, E, generator=g).cuda()
+    ge, gm, gc, go = C.gaussian_rasterize_extra_backward(W, H, R, extra, opacity, gpe, geom, binning, img, None, None,
+                                                         None)
+    gref = oracle32.extra_backward(W, H, ref, to_np(extra), to_np(gpe))
+    assert rel_err(ge, gref['dL_dextra']) <= TOL
+    assert rel_err(gm, gref['dL_dmean2D']) <= TOL
+    assert rel_err(gc.reshape(P, 4), gref['dL_dconic']) <= TOL
+    assert rel_err(go, gref['dL_dopacity']) <= TOL
+    idx, w = C.gaussian_topk_weights(3, W, H, P, R, geom, binning, img)
+    idx_ref, w_ref = oracle32.topk_weights(3, W, H, ref)
+    assert rel_err(w, w_ref) <= TOL
+    assert (to_np(idx) != idx_ref).mean() <= 1e-3
+    vis = C.mark_visible(act['means3D'], rs.viewmatrix, rs.projmatrix, True)
+    np.testing.assert_array_equal(to_np(vis), oracle32.mark_visible(to_np(act['means3D']), to_np(rs.viewmatrix), True))
+
+
+def test_empty_and_culled(oracle32):
+    C = _C()
+    W, H = 64, 48
+    act, rs, cam = scene_inputs(16, W, H, seed=0, colmap=True, device='cuda')
+    # P = 0
+    act0 = {k: v[:0] for k, v in act.items()}
+    out = hip_forward(act0, rs)
+    assert out[0] == 0 and float(out[1].abs().max()) == 0 and float(out[2].abs().max()) == 0
+    # everything behind the camera
+    act_b = dict(act)
+    act_b['means3D'] = act['means3D'] + rs.campos * 3
+    out = hip_forward(act_b, rs)
+    assert out[0] == 0 and int(out[3].abs().max()) == 0 and float(out[1].abs().max()) == 0
+    got = hip_backward(out, act_b, rs, torch.randn(3, H, W).cuda(), torch.randn(H, W).cuda())
+    for t in got[:8]:
+        assert float(t.abs().max()) == 0.0
+
+
+def test_async_capacity_overflow_flag():
+    C = _C()
+    P, W, H = 4000, 128, 128
+    act, rs, cam = scene_inputs(P, W, H, seed=2, colmap=True, scale_mult=4.0, device='cuda')
+    ref = hip_forward(act, rs)
+    R = ref[0]
+    C.config.sync_num_rendered = False
+    try:
+        C._capacity_hint[(P, W, H)] = R + 100
+        out = hip_forward(act, rs)
+        st = C.read_status(out[4])
+        assert st['num_rendered'] == R and st['overflow'] == 0
+        assert torch.equal(out[1], ref[1]) or rel_err(out[1], ref[1]) < 1e-6
+        C._capacity_hint[(P, W, H)] = R // 2
+        out = hip_forward(act, rs)
+        st = C.read_status(out[4])
+        assert st['num_rendered'] == R and st['overflow'] == 1
+    finally:
+        C.config.sync_num_rendered = True
+        C._capacity_hint.clear()
+
+
+def test_single_gaussian_closed_form():
+    """one isotropic Gaussian at the image centre: alpha(x) = o * exp(-r^2 / (2 s^2)) with s^2 = (f*sigma/z)^2 + 0.3"""
+    import math
+    from sk_gs_amd import scene
+    W = H = 64
+    cam = scene.make_camera(W, H, eye=torch.tensor([0., 0., -4.]))
+    rs = scene.raster_settings_from_camera(cam, sh_degree=0, colmap=True, device='cuda')
+    sigma, op = 0.05, 0.8
+    act = dict(means3D=torch.zeros(1, 3).cuda(), scales=torch.full((1, 3), sigma).cuda(),
+               rotations=torch.tensor([[0., 0., 0., 1.]]).cuda(), opacity=torch.tensor([[op]]).cuda(),
+               sh=torch.zeros(1, 1, 3).cuda())
+    act['sh'][0, 0] = torch.tensor([1.0, 0.5, -0.2])
+    out = hip_forward(act, rs)
+    opacity = to_np(out[2])
+    focal = W / (2 * rs.tanfovx)
+    s2 = (focal * sigma / 4.0) ** 2 + 0.3
+    ys, xs = np.mgrid[0:H, 0:W]
+    cx = ((0 + 1.0) * W - 1.0) * 0.5
+    r2 = (xs - cx) ** 2 + (ys - cx) ** 2
+    alpha = np.minimum(0.99, op * np.exp(-0.5 * r2 / s2))
+    alpha[alpha < 1 / 255] = 0
+    assert np.abs(opacity - alpha).max() < 2e-5
+    rgb = np.maximum(0.28209479177387814 * np.array([1.0, 0.5, -0.2]) + 0.5, 0)
+    assert np.abs(to_np(out[1]) - rgb[:, None, None] * alpha[None]).max() < 2e-5
