@@ -75,6 +75,16 @@ class Oracle:
     def num_threads(self) -> int:
         return int(self._fn('num_threads')())
 
+    def set_exp_mode(self, mode: int):
+        """0: libm exp (literal restatement); 1: reproducible double-arithmetic exp shared with the strict HIP build"""
+        self._fn('set_exp_mode')(C.c_int(mode))
+
+    def exp_array(self, x):
+        x = self.r(x)
+        out = np.zeros_like(x)
+        self._fn('exp_array')(C.c_int(x.size), _p(x), _p(out))
+        return out
+
     # ------------------------------------------------------------------ stages
     def preprocess_forward(self, means3D, scales, rotations, opacities, shs, viewmatrix, projmatrix, campos, W, H,
                            tanfovx, tanfovy, sh_degree, scale_modifier=1.0, colmap=True, cov3D_precomp=None,

@@ -52,6 +52,42 @@ typedef float REAL;
 #define BLOCK_SIZE 256
 #define NUM_CHANNELS 3
 
+/* exp used by the blend kernels.  exp_mode 0: libm (expf for the fp32 build) -- the literal restatement.
+ * exp_mode 1 (fp32 build only): a reproducible exp made of IEEE double multiplies/adds, one operation per
+ * statement; the HIP library's strict-math build (skgs_set_strict_math(1)) evaluates the very same sequence, so the
+ * two sides can be compared bit for bit, threshold decisions included. */
+static int g_exp_mode = 0;
+void ORACLE(set_exp_mode)(int mode) { g_exp_mode = mode; }
+static inline REAL oexp(REAL x) {
+#ifndef SKGS_F64
+  if (g_exp_mode == 1) {
+    const double xd = (double) x;
+    const double t  = xd * 1.4426950408889634;
+    const double n  = rint(t);
+    const double a  = n * 0.6931471803691238;
+    const double b  = n * 1.9082149292705877e-10;
+    double r        = xd - a;
+    r               = r - b;
+    double p        = r * (1.0 / 5040.0);
+    p               = p + (1.0 / 720.0);
+    p               = p * r;
+    p               = p + (1.0 / 120.0);
+    p               = p * r;
+    p               = p + (1.0 / 24.0);
+    p               = p * r;
+    p               = p + (1.0 / 6.0);
+    p               = p * r;
+    p               = p + 0.5;
+    p               = p * r;
+    p               = p + 1.0;
+    p               = p * r;
+    p               = p + 1.0;
+    return (float) ldexp(p, (int) n);
+  }
+#endif
+  return R_EXP(x);
+}
+
 static inline REAL r_min(REAL a, REAL b) { return a < b ? a : b; }
 static inline REAL r_max(REAL a, REAL b) { return a > b ? a : b; }
 static inline int i_min(int a, int b) { return a < b ? a : b; }
@@ -587,7 +623,7 @@ void ORACLE(render_forward)(int W, int H, int E, const uint32_t* ranges, const u
           const REAL* con_o = conic_opacity + 4 * id;
           REAL power        = RC(-0.5) * (con_o[0] * dx * dx + con_o[2] * dy * dy) - con_o[1] * dx * dy;
           if (power > RC(0.0)) continue;
-          REAL alpha = r_min(RC(0.99f), con_o[3] * R_EXP(power));
+          REAL alpha = r_min(RC(0.99f), con_o[3] * oexp(power));
           if (alpha < RC(1.0f / 255.0f)) continue;
           REAL test_T = T * (1 - alpha);
           if (test_T < RC(0.0001f)) break; /* done = true */
@@ -662,7 +698,7 @@ void ORACLE(render_backward)(int P, int W, int H, int E, const uint32_t* ranges,
             const REAL* con_o = conic_opacity + 4 * id;
             const REAL power  = RC(-0.5) * (con_o[0] * dx * dx + con_o[2] * dy * dy) - con_o[1] * dx * dy;
             if (power > RC(0.0)) continue;
-            const REAL G     = R_EXP(power);
+            const REAL G     = oexp(power);
             const REAL alpha = r_min(RC(0.99f), con_o[3] * G);
             if (alpha < RC(1.0f / 255.0f)) continue;
             T                          = T / (RC(1.) - alpha);
@@ -1025,7 +1061,7 @@ void ORACLE(render_extra_forward)(int W, int H, int E, const uint32_t* ranges, c
           const REAL* con_o = conic_opacity + 4 * id;
           REAL power        = RC(-0.5) * (con_o[0] * dx * dx + con_o[2] * dy * dy) - con_o[1] * dx * dy;
           if (power > RC(0.0)) continue;
-          REAL alpha = r_min(RC(0.99f), con_o[3] * R_EXP(power));
+          REAL alpha = r_min(RC(0.99f), con_o[3] * oexp(power));
           if (alpha < RC(1.0f / 255.0f)) continue;
           REAL test_T = T * (1 - alpha);
           if (test_T < RC(0.0001f)) break;
@@ -1072,7 +1108,7 @@ void ORACLE(render_extra_backward)(int P, int W, int H, int E, const uint32_t* r
             const REAL* con_o = conic_opacity + 4 * id;
             const REAL power  = RC(-0.5) * (con_o[0] * dx * dx + con_o[2] * dy * dy) - con_o[1] * dx * dy;
             if (power > RC(0.0)) continue;
-            const REAL G     = R_EXP(power);
+            const REAL G     = oexp(power);
             const REAL alpha = r_min(RC(0.99f), con_o[3] * G);
             if (alpha < RC(1.0f / 255.0f)) continue;
             T                          = T / (RC(1.) - alpha);
@@ -1135,7 +1171,7 @@ void ORACLE(topk_weights)(int topk, int W, int H, const uint32_t* ranges, const 
           const REAL* con_o = conic_opacity + 4 * id;
           REAL power        = RC(-0.5) * (con_o[0] * dx * dx + con_o[2] * dy * dy) - con_o[1] * dx * dy;
           if (power > RC(0.0)) continue;
-          REAL alpha = r_min(RC(0.99f), con_o[3] * R_EXP(power));
+          REAL alpha = r_min(RC(0.99f), con_o[3] * oexp(power));
           if (alpha < RC(1.0f / 255.0f)) continue;
           REAL test_T = T * (1 - alpha);
           if (test_T < RC(0.0001f)) break;
@@ -1338,6 +1374,11 @@ void ORACLE(mark_visible)(int P, const REAL* means3D, const REAL* viewmatrix, in
       present[idx] = !(pv[2] <= RC(-1.0f));
     }
   }
+}
+
+/* test hook: out[i] = the blend exp (current exp_mode) of x[i] */
+void ORACLE(exp_array)(int n, const REAL* x, REAL* out) {
+  for (int i = 0; i < n; ++i) out[i] = oexp(x[i]);
 }
 
 int ORACLE(num_threads)(void) {

@@ -168,6 +168,12 @@ def set_pixels_per_lane(ppl: int):
     load_library().skgs_set_pixels_per_lane(C.c_int(ppl))
 
 
+def set_strict_math(on: bool):
+    """parity-test switch: blend kernels built without FMA contraction, in the oracle's operation order, with the
+    reproducible double-arithmetic exp (bit-comparable with the oracle's exp_mode=1). Slower; never used by bench."""
+    load_library().skgs_set_strict_math(C.c_int(int(bool(on))))
+
+
 def _make_inputs(H, W, tanfovx, tanfovy, degree, scale_modifier, prefiltered, debug, colmap, viewmatrix, projmatrix,
                  campos, means3D, opacity, sh, scales, rotations, extras, colors, cov3D_precomp):
     dev = means3D.device

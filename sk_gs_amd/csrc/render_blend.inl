@@ -1,0 +1,287 @@
+// render_blend.inl -- forward / backward blend kernels. Included TWICE by render.hip:
+//   namespace blend_fast   : FMA contraction on, hardware exp (v_exp_f32)            -> the product path
+//   namespace blend_strict : contraction off, the oracle's literal operation order and the reproducible
+//                            double-precision exp of skgs_exp_strict()                  -> bit-comparable with the
+//                            oracle built with exp_mode = 1 (parity tests; skgs_set_strict_math(1))
+// SKGS_STRICT (0/1) and SKGS_BLEND_NS are defined by the includer.
+namespace SKGS_BLEND_NS {
+
+__device__ __forceinline__ float blend_exp(float x) {
+#if SKGS_STRICT
+  return skgs_exp_strict(x);
+#else
+  return __expf(x);
+#endif
+}
+
+// ====================================================================================================== forward
+template <int PPL, int E>
+__global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx, int T, const uint32_t* __restrict__ offsets,
+    int64_t capacity, const uint32_t* __restrict__ point_list, const float4* __restrict__ recs,
+    const float* __restrict__ extra, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+    float* __restrict__ out_opacity, float* __restrict__ out_extra) {
+  constexpr int SUBS = 4 / PPL;
+  const int v        = xcd_remap(blockIdx.x, T * SUBS);
+  if (v >= T * SUBS) return;
+  const int tile = v / SUBS, sub = v % SUBS;
+  const int lane = threadIdx.x;
+  const Pix<PPL> pix = pixel_setup<PPL>(tile, sub, lane, gx, W, H);
+
+  __shared__ float4 s_a[WAVE];  // x, y, conic a, conic b
+  __shared__ float4 s_b[WAVE];  // conic c, opacity, r, g
+  __shared__ float s_c[WAVE];   // b
+  __shared__ float s_e[E > 0 ? WAVE * E : 1];
+
+  const int64_t start = offsets[tile];
+  const int64_t end   = min<int64_t>((int64_t) offsets[tile + 1], capacity);
+
+  float Tr[PPL], C[PPL][3], Ex[PPL][E > 0 ? E : 1];
+  uint32_t last[PPL];
+  bool done[PPL];
+#pragma unroll
+  for (int i = 0; i < PPL; ++i) {
+    Tr[i] = 1.0f, last[i] = 0, done[i] = !pix.inside[i];
+    C[i][0] = C[i][1] = C[i][2] = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) Ex[i][e] = 0.f;
+  }
+
+  for (int64_t base = start; base < end; base += WAVE) {
+    bool all_done = true;
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) all_done = all_done && done[i];
+    if (__all(all_done)) break;
+    const int n = (int) min<int64_t>(WAVE, end - base);
+    __syncthreads();  // single-wave workgroup: orders the LDS reads of the previous batch before these writes
+    if (lane < n) {
+      const uint32_t id = point_list[base + lane];
+      const float4 a = recs[3 * id], b = recs[3 * id + 1], c = recs[3 * id + 2];
+      s_a[lane] = a, s_b[lane] = b, s_c[lane] = c.x;
+#pragma unroll
+      for (int e = 0; e < E; ++e) s_e[lane * (E > 0 ? E : 1) + e] = extra[(size_t) id * E + e];
+    }
+    __syncthreads();
+    const uint32_t contrib0 = (uint32_t) (base - start);
+    for (int j = 0; j < n; ++j) {
+      const float4 a = s_a[j];
+      const float4 b = s_b[j];
+      bool hit[PPL];
+      float wgt[PPL], al[PPL], Tp[PPL];
+      bool any = false;
+#pragma unroll
+      for (int i = 0; i < PPL; ++i) {
+        hit[i] = false;
+        wgt[i] = 0.f, al[i] = 0.f, Tp[i] = 0.f;
+        if (!done[i]) {
+          const float dx = a.x - pix.x[i], dy = a.y - pix.y[i];
+          const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+          if (power <= 0.0f) {
+            const float alpha = fminf(0.99f, b.y * blend_exp(power));
+            if (alpha >= ALPHA_MIN) {
+              const float test_T = Tr[i] * (1.f - alpha);
+              if (test_T < T_MIN) {
+                done[i] = true;
+              } else {
+                hit[i]  = true;
+                al[i]   = alpha;
+                Tp[i]   = Tr[i];
+                wgt[i]  = alpha * Tr[i];
+                Tr[i]   = test_T;
+                last[i] = contrib0 + j + 1;
+              }
+            }
+          }
+        }
+        any = any || hit[i];
+      }
+      if (__any(any)) {
+        const float cb = s_c[j];
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) {
+          // hit[i] false -> wgt 0: adds an exact +0
+#if SKGS_STRICT
+          // reference order: features * alpha * T, left to right (gaussian_render.cu:93-95)
+          if (hit[i]) {
+            C[i][0] += b.z * al[i] * Tp[i];
+            C[i][1] += b.w * al[i] * Tp[i];
+            C[i][2] += cb * al[i] * Tp[i];
+#pragma unroll
+            for (int e = 0; e < E; ++e) Ex[i][e] += s_e[j * (E > 0 ? E : 1) + e] * al[i] * Tp[i];
+          }
+#else
+          C[i][0] += b.z * wgt[i];
+          C[i][1] += b.w * wgt[i];
+          C[i][2] += cb * wgt[i];
+#pragma unroll
+          for (int e = 0; e < E; ++e) Ex[i][e] += s_e[j * (E > 0 ? E : 1) + e] * wgt[i];
+#endif
+        }
+      }
+    }
+  }
+  const size_t HW = (size_t) H * W;
+#pragma unroll
+  for (int i = 0; i < PPL; ++i) {
+    if (pix.inside[i]) {
+      out_opacity[pix.id[i]] = 1.f - Tr[i];
+      n_contrib[pix.id[i]]   = last[i];
+      out_color[pix.id[i]]          = C[i][0];
+      out_color[HW + pix.id[i]]     = C[i][1];
+      out_color[2 * HW + pix.id[i]] = C[i][2];
+#pragma unroll
+      for (int e = 0; e < E; ++e) out_extra[e * HW + pix.id[i]] = Ex[i][e];
+    }
+  }
+}
+
+// ===================================================================================================== backward
+// gradacc row layout (16 floats = 64 B per Gaussian):
+//   0 mean2D.x  1 mean2D.y  2 conic.x  3 conic.y  4 conic.w  5 opacity  6..8 colour  9..12 extras  13..15 unused
+template <int PPL, int E>
+__global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int gx, int T, const uint32_t* __restrict__ offsets,
+    int64_t capacity, const uint32_t* __restrict__ point_list, const float4* __restrict__ recs,
+    const float* __restrict__ extra, const float* __restrict__ out_opacity, const uint32_t* __restrict__ n_contrib,
+    const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dout_extra,
+    const float* __restrict__ dL_dout_opacity, float* __restrict__ gradacc) {
+  constexpr int SUBS = 4 / PPL;
+  constexpr int NV   = 9 + E;
+  const int v        = xcd_remap(blockIdx.x, T * SUBS);
+  if (v >= T * SUBS) return;
+  const int tile = v / SUBS, sub = v % SUBS;
+  const int lane = threadIdx.x;
+  const Pix<PPL> pix = pixel_setup<PPL>(tile, sub, lane, gx, W, H);
+
+  __shared__ float4 s_a[WAVE];
+  __shared__ float4 s_b[WAVE];
+  __shared__ float s_c[WAVE];
+  __shared__ uint32_t s_id[WAVE];
+  __shared__ float s_e[E > 0 ? WAVE * E : 1];
+  __shared__ float s_acc[WAVE][GRAD_ROW];
+  __shared__ uint32_t s_acc_id[WAVE];
+
+  const int64_t start = offsets[tile];
+  const int64_t end   = min<int64_t>((int64_t) offsets[tile + 1], capacity);
+  const size_t HW     = (size_t) H * W;
+
+  float T_final[PPL], Tr[PPL], dL_dT[PPL], dpix[PPL][3], dex[PPL][E > 0 ? E : 1];
+  float accum[PPL][3], lastc[PPL][3], accum_e[PPL][E > 0 ? E : 1], last_e[PPL][E > 0 ? E : 1], last_alpha[PPL];
+  uint32_t lastk[PPL];
+  uint32_t maxk = 0;
+#pragma unroll
+  for (int i = 0; i < PPL; ++i) {
+    const bool in = pix.inside[i];
+    T_final[i]    = in ? 1.0f - out_opacity[pix.id[i]] : 0.f;
+    Tr[i]         = T_final[i];
+    dL_dT[i]      = in ? -dL_dout_opacity[pix.id[i]] : 0.f;
+    lastk[i]      = in ? n_contrib[pix.id[i]] : 0u;
+    maxk          = max(maxk, lastk[i]);
+    last_alpha[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      dpix[i][c]  = in ? dL_dpixels[c * HW + pix.id[i]] : 0.f;
+      accum[i][c] = 0.f, lastc[i][c] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      dex[i][e]     = in ? dL_dout_extra[e * HW + pix.id[i]] : 0.f;
+      accum_e[i][e] = 0.f, last_e[i][e] = 0.f;
+    }
+  }
+  // wave-wide maximum of the last contributor: nothing behind it can matter to this wave
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) maxk = max(maxk, (uint32_t) __shfl_xor((int) maxk, d));
+  if (maxk == 0) return;
+  const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+
+  // walk the list back to front: entry at list position k (0-based) has "contributor" index k
+  for (int64_t hi = start + (int64_t) min<int64_t>(maxk, end - start); hi > start; hi -= WAVE) {
+    const int n = (int) min<int64_t>(WAVE, hi - start);
+    __syncthreads();
+    if (lane < n) {
+      const uint32_t id = point_list[hi - 1 - lane];
+      const float4 a = recs[3 * id], b = recs[3 * id + 1], c = recs[3 * id + 2];
+      s_a[lane] = a, s_b[lane] = b, s_c[lane] = c.x, s_id[lane] = id;
+#pragma unroll
+      for (int e = 0; e < E; ++e) s_e[lane * (E > 0 ? E : 1) + e] = extra[(size_t) id * E + e];
+    }
+    __syncthreads();
+    int nact = 0;  // wave-uniform count of LDS rows in use
+    for (int j = 0; j < n; ++j) {
+      const uint32_t k = (uint32_t) (hi - 1 - j - start);
+      const float4 a = s_a[j];
+      const float4 b = s_b[j];
+      float g[NV];
+#pragma unroll
+      for (int q = 0; q < NV; ++q) g[q] = 0.f;
+      bool any = false;
+      float col[3] = {b.z, b.w, 0.f};
+      bool col_loaded = false;
+#pragma unroll
+      for (int i = 0; i < PPL; ++i) {
+        if (k < lastk[i]) {
+          const float dx = a.x - pix.x[i], dy = a.y - pix.y[i];
+          const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+          if (power <= 0.0f) {
+            const float G     = blend_exp(power);
+            const float alpha = fminf(0.99f, b.y * G);
+            if (alpha >= ALPHA_MIN) {
+              any = true;
+              if (!col_loaded) col[2] = s_c[j], col_loaded = true;
+              const float Tn = Tr[i] / (1.f - alpha);
+              Tr[i]          = Tn;
+              const float dchannel_dcolor = alpha * Tn;
+              float dL_dalpha = 0.0f;
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                accum[i][c] = last_alpha[i] * lastc[i][c] + (1.f - last_alpha[i]) * accum[i][c];
+                lastc[i][c] = col[c];
+                dL_dalpha += (col[c] - accum[i][c]) * dpix[i][c];
+                g[6 + c] += dchannel_dcolor * dpix[i][c];
+              }
+#pragma unroll
+              for (int e = 0; e < E; ++e) {
+                const float ce = s_e[j * (E > 0 ? E : 1) + e];
+                accum_e[i][e]  = last_alpha[i] * last_e[i][e] + (1.f - last_alpha[i]) * accum_e[i][e];
+                last_e[i][e]   = ce;
+                dL_dalpha += (ce - accum_e[i][e]) * dex[i][e];
+                g[9 + e] += dchannel_dcolor * dex[i][e];
+              }
+              dL_dalpha *= Tn;
+              last_alpha[i] = alpha;
+              dL_dalpha += (-T_final[i] / (1.f - alpha)) * dL_dT[i];
+              const float dL_dG    = b.y * dL_dalpha;
+              const float gdx      = G * dx;
+              const float gdy      = G * dy;
+              const float dG_ddelx = -gdx * a.z - gdy * a.w;
+              const float dG_ddely = -gdy * b.x - gdx * a.w;
+              g[0] += dL_dG * dG_ddelx * ddelx_dx;
+              g[1] += dL_dG * dG_ddely * ddely_dy;
+              g[2] += -0.5f * gdx * dx * dL_dG;
+              g[3] += -0.5f * gdx * dy * dL_dG;
+              g[4] += -0.5f * gdy * dy * dL_dG;
+              g[5] += G * dL_dalpha;
+            }
+          }
+        }
+      }
+      if (__any(any)) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) g[q] = wave_sum_to_lane63(g[q]);
+        if (lane == 63) {
+#pragma unroll
+          for (int q = 0; q < NV; ++q) s_acc[nact][q] = g[q];
+          s_acc_id[nact] = s_id[j];
+        }
+        ++nact;
+      }
+    }
+    // flush: 4 rows (4 x 64-B lines) per wave-wide atomic instruction
+    __syncthreads();
+    for (int r0 = 0; r0 < nact; r0 += 4) {
+      const int row = r0 + (lane >> 4), colx = lane & 15;
+      if (row < nact && colx < NV) atomicAdd(&gradacc[(size_t) s_acc_id[row] * GRAD_ROW + colx], s_acc[row][colx]);
+    }
+  }
+}
+
+}  // namespace SKGS_BLEND_NS

@@ -27,6 +27,23 @@ def frac_outliers(a, b, rtol, atol) -> float:
     return float((np.abs(a - b) > atol + rtol * np.abs(b)).mean())
 
 
+def assert_close_robust(a, b, tol=1e-4, outlier_frac=1e-4, hard=3e-2, name=''):
+    """max-norm-relative comparison that tolerates threshold flips.
+
+    The blend uses the hardware exp; a (pixel, Gaussian) pair whose alpha sits within an ulp of the 1/255 cut, or
+    whose transmittance sits within an ulp of the 1e-4 stop, may take the other branch than the oracle (any two
+    implementations with different exp rounding do that, the CUDA reference included).  Such flips are rare and
+    bounded: at most `outlier_frac` of the elements may exceed `tol`, none may exceed `hard`."""
+    a, b = to_np(a).astype(np.float64), to_np(b).astype(np.float64).reshape(to_np(a).shape)
+    if b.size == 0:
+        return
+    scale = max(np.abs(b).max(), 1e-30)
+    d = np.abs(a - b) / scale
+    frac = float((d > tol).mean())
+    assert frac <= outlier_frac, f'{name}: {frac:.2e} of the elements exceed {tol} (max {d.max():.2e})'
+    assert d.max() <= hard, f'{name}: max rel err {d.max():.2e} > {hard}'
+
+
 def scene_inputs(P, W, H, seed=0, colmap=True, sh_degree=3, scale_mult=1.0, device='cpu'):
     from sk_gs_amd import scene
     g = scene.make_gaussians(P, seed=seed, sh_degree=3, scale_mult=scale_mult)
