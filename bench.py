@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""Benchmark of the SK_GS hot path on MI355X: train iters/s (deform -> rasterize -> 0.8 L1 + 0.2 (1-SSIM) -> backward ->
+[all-reduce] -> Adam(eps=1e-15)) for BASELINE.json config #1: 100k Gaussians, 20 bones, K=5, SH degree 3, 800x800.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  A "step" is one training iteration of ONE view per rank (the reference trains with
+batch = 1 view, data_loader/build.py:26); with N ranks N views are processed per step (weak scaling) and `value` is
+the whole-job rate N*K / t.  Inputs (Gaussians, cameras, bones, target images) are synthetic, seeded and resident in
+HBM before the timed region.  Extra objects on the line:
+  roofline      dominant kernel (render_backward): algorithmic bytes (40 R + 24 W H + 44 P) / HIP-event time
+  kernels       per-kernel HIP-event time and algorithmic GB/s (separate short pass after the timed region)
+  cpu_baseline  the CPU oracle (restatement of the reference kernels; the reference has no CPU path) on the host cores
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CONFIGS = {
+    0: dict(name='static-10k-400', P=10_000, M=0, K=0, W=400, H=400),
+    1: dict(name='hook-like-100k-800', P=100_000, M=20, K=5, W=800, H=800),
+    2: dict(name='atlas-like-200k-512', P=200_000, M=32, K=5, W=512, H=512),
+    3: dict(name='mutant-like-300k-800', P=300_000, M=20, K=5, W=800, H=800),
+    4: dict(name='zju-like-500k-1024', P=500_000, M=24, K=5, W=1024, H=1024),
+}
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def alg_bytes(name, P, M, K, W, H, R):
+    """algorithmic bytes per launch, SURVEY.md section 8(d)"""
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    return {
+        'deform_forward': P * (88 + 4 * M),
+        'deform_backward': P * (40 + 4 * K),
+        'knn_bones': P * (12 + 8 * K + 4 * K),
+        'preprocess_forward': 311 * P,
+        'scan_tiles': 8 * T,
+        'scatter': 28 * P + 12 * R,
+        'tile_sort': 16 * R,
+        'render_forward': 40 * R + 20 * W * H,
+        'render_backward': 40 * R + 24 * W * H + 44 * P,
+        'preprocess_backward': 627 * P,
+    }.get(name)
+
+
+def cpu_baseline(cfg, seconds_budget=20.0):
+    """time the CPU oracle on the same workload (bounded sample); returns the cpu_baseline object"""
+    import numpy as np
+    import tempfile
+    from oracle import oracle as om
+    from sk_gs_amd import scene, skeleton
+    lib = None
+    try:
+        out = om.build(tempfile.mkdtemp(prefix='skgs_oracle_native_'), native=True)
+        lib = os.path.join(out, 'libskgs_oracle_native.so')
+        if not os.path.exists(lib):
+            lib = None
+    except Exception:
+        lib = None
+    o = om.Oracle('f32', lib_path=lib)
+    P, M, K, W, H = cfg['P'], cfg['M'], cfg['K'], cfg['W'], cfg['H']
+    g = scene.make_gaussians(P, seed=0)
+    cam = scene.make_camera(W, H, seed=0)
+    rs = scene.raster_settings_from_camera(cam, colmap=True)
+    n = lambda t: t.numpy()  # noqa: E731
+    gen = torch.Generator().manual_seed(5)
+    if M > 0:
+        b = scene.make_bones(M, seed=0)
+        table, _ = skeleton.build_ancestor_table(b['parents'], 0)
+        sk_T = skeleton.kinematic(b['joints'], skeleton.axis_angle_to_quat(b['axis_angle']), None, table, 0)
+        w = torch.softmax(torch.randn(P, K, generator=gen), -1)
+    gcol = torch.randn(3, H, W, generator=gen).numpy()
+    gop = torch.randn(H, W, generator=gen).numpy()
+
+    def one_iter():
+        if M > 0:
+            _, idx = o.knn_bones(n(g['xyz']), n(b['joints']), K)
+            d = o.lbs_deform_forward(n(g['xyz']), n(w), idx, n(sk_T), n(b['d_rot']), n(b['d_scale']), n(g['xyz']),
+                                     n(g['log_scale']), n(g['rot']), n(g['opacity_logit']))
+        else:
+            act = scene.activate(g)
+            d = dict(means=n(act['means3D']), scales=n(act['scales']), rotations=n(act['rotations']),
+                     opacity=n(act['opacity']))
+        fwd = o.rasterize_forward(H, W, rs.tanfovx, rs.tanfovy, 3, 1.0, True, n(rs.viewmatrix), n(rs.projmatrix),
+                                  n(rs.campos), d['means'], d['opacity'], n(g['sh']), d['scales'], d['rotations'])
+        gr = o.rasterize_backward(fwd, H, W, rs.tanfovx, rs.tanfovy, 3, 1.0, True, n(rs.viewmatrix), n(rs.projmatrix),
+                                  n(rs.campos), d['means'], n(g['sh']), d['scales'], d['rotations'], gcol, gop)
+        if M > 0:
+            o.lbs_deform_backward(n(g['xyz']), n(w), idx, n(sk_T), n(b['d_rot']), n(b['d_scale']), n(g['log_scale']),
+                                  n(g['rot']), n(g['opacity_logit']), gr['dL_dmeans3D'], gr['dL_dscales'],
+                                  gr['dL_drotations'], gr['dL_dopacity'])
+        return fwd['num_rendered']
+
+    one_iter()  # warm-up
+    t0 = time.perf_counter()
+    iters = 0
+    while True:
+        one_iter()
+        iters += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or iters >= 50:
+            break
+    return dict(value=round(iters / el, 4), unit='iters/s', cores=o.num_threads(), kind='port',
+                sample=f'{iters} iterations of deform+rasterize forward+backward (no loss/Adam) of the same workload, '
+                       f'{el:.1f} s, oracle built {"-march=native" if lib else "portable"}, OpenMP')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--config', type=int, default=1)
+    ap.add_argument('--views', type=int, default=8)
+    ap.add_argument('--ppl', type=int, default=0, help='pixels per lane of the blend kernels (0 = heuristic)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--ms-per-render', action='store_true', help='also time rasterizer fwd+bwd alone (fixed grads)')
+    args = ap.parse_args()
+
+    from sk_gs_amd import _C, scene
+    from sk_gs_amd.losses import image_loss
+    from sk_gs_amd.model import SkinnedGaussians
+    from sk_gs_amd.view_parallel import ViewParallel, init_distributed
+
+    rank, world, local_rank = init_distributed()
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    _C.load_library()
+    cfg = CONFIGS[args.config]
+    P, M, K, W, H = cfg['P'], cfg['M'], cfg['K'], cfg['W'], cfg['H']
+    if args.ppl:
+        _C.set_pixels_per_lane(args.ppl)
+
+    # ---------------------------------------------------------------- synthetic scene, resident in HBM
+    frames = args.views
+    model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=0).to(dev)
+    cams = [scene.make_camera(W, H, seed=i) for i in range(args.views)]
+    settings = [scene.raster_settings_from_camera(c, sh_degree=3, colmap=True, device=dev) for c in cams]
+    gen = torch.Generator().manual_seed(77)
+    targets = [torch.rand(3, H, W, generator=gen).to(dev) for _ in range(args.views)]
+    background = torch.ones(3, device=dev)
+    opt = torch.optim.Adam(model.param_groups(lr=1e-3), eps=1e-15, betas=(0.9, 0.999), fused=True)
+    vp = ViewParallel(model.parameters(), average=True)
+    overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def train_step(i):
+        v = vp.view_index(i, args.views)
+        vp.grads.zero_()
+        out = model.render(settings[v], time_id=v % frames, background=background)
+        loss = image_loss(out['images'], targets[v])
+        loss.backward()
+        vp.allreduce_grads()
+        opt.step()
+        overflow.add_(out['buffer'].geomBuffer[4:8].view(torch.int32))
+        return out
+
+    # ---------------------------------------------------------------- learn R per view with the synchronising path
+    _C.config.sync_num_rendered = True
+    Rs = []
+    for v in range(args.views):
+        out = model.render(settings[v], time_id=v % frames, background=background)
+        Rs.append(out['buffer'].R)
+    R_mean, R_max = sum(Rs) / len(Rs), max(Rs)
+    _C.config.sync_num_rendered = False
+    _C.update_capacity_hint(P, W, H, int(R_max * 1.25))
+
+    for i in range(args.warmup):
+        train_step(i)
+    torch.cuda.synchronize()
+    _C.profile_enable(['render_backward'])
+    _C.profile_collect()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        train_step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = _C.profile_collect()
+    _C.profile_enable([])
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert int(overflow.item()) == 0, 'binning capacity overflow during the timed region: result invalid'
+
+    # ---------------------------------------------------------------- per-kernel breakdown (short separate pass)
+    kernels = {}
+    _C.profile_enable(None)
+    for i in range(min(args.steps, 20)):
+        train_step(args.warmup + args.steps + i)
+    torch.cuda.synchronize()
+    for name, (ms, n) in _C.profile_collect().items():
+        us = ms / n * 1e3
+        b = alg_bytes(name, P, M, K, W, H, R_mean)
+        kernels[name] = dict(us=round(us, 2), launches_per_step=round(n / min(args.steps, 20), 2),
+                             alg_MB=round(b / 1e6, 2) if b else None,
+                             GBps=round(b / (us * 1e-6) / 1e9, 1) if b else None)
+    _C.profile_enable([])
+
+    ms_render = None
+    if args.ms_per_render:
+        from sk_gs_amd.renderer.gaussian_render import render
+        with torch.no_grad():
+            net = {k: v.detach() for k, v in model(0).items()}
+        gcol, gop = torch.randn(3, H, W, device=dev), torch.randn(H, W, device=dev)
+        ins = {k: v.clone().requires_grad_(True) for k, v in net.items()}
+        times = []
+        for i in range(60):
+            torch.cuda.synchronize()
+            s = time.perf_counter()
+            o = render(**ins, raster_settings=settings[0])
+            torch.autograd.backward([o['images'], o['opacity']], [gcol, gop])
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - s) * 1e3)
+        times = sorted(times[10:])
+        ms_render = dict(median=round(times[len(times) // 2], 4), p10=round(times[len(times) // 10], 4),
+                         p90=round(times[9 * len(times) // 10], 4))
+
+    if rank == 0:
+        rb_ms, rb_n = prof.get('render_backward', (0.0, 0))
+        rb_us = rb_ms / max(rb_n, 1) * 1e3
+        rb_bytes = alg_bytes('render_backward', P, M, K, W, H, R_mean)
+        achieved = rb_bytes / (rb_us * 1e-6) / 1e9 if rb_us > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_render_backward.json')
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get('config') == cfg['name']:
+                    traffic = rec.get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        line = {
+            'metric': 'train iters/sec (deform + rasterize fwd+bwd + L1/SSIM loss + Adam), 100k Gaussians @800x800',
+            'value': round(world * args.steps / elapsed, 3), 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{cfg["name"]}: {P} Gaussians, {M} bones, K={K}, SH degree 3, {W}x{H}, '
+                                   f'{args.views} synthetic views, colmap=True, 1 view per rank per step',
+                       'num_rendered_mean': round(R_mean), 'num_rendered_max': R_max,
+                       'parallelism': f'view-parallel x{world}, flat-buffer grad all-reduce '
+                                      f'({vp.grads.nbytes / 1e6:.1f} MB)'},
+            'roofline': {'bound': 'hbm', 'kernel': 'render_backward', 'achieved': round(achieved, 2),
+                         'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 5),
+                         'traffic': traffic, 'avg_us': round(rb_us, 2), 'launches': rb_n,
+                         'alg_bytes_per_launch': int(rb_bytes),
+                         'note': 'blend kernels are VALU/LDS/atomic-bound, not HBM-bound (SURVEY 8d caveat); '
+                                 'streaming kernels are listed under "kernels"'},
+            'kernels': kernels,
+        }
+        if ms_render:
+            line['ms_per_render_fwd_bwd'] = ms_render
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(cfg, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -176,6 +176,16 @@ int skgs_knn_bones(int32_t P, int32_t M, int32_t K, int32_t dim, const float* po
 
 /* Tuning knob of the blend kernels: pixels handled per lane (1, 2 or 4); 0 = heuristic on the tile count. */
 void skgs_set_pixels_per_lane(int ppl);
+/* Parity-test switch: blend kernels without FMA contraction, in the oracle's operation order, reproducible exp. */
+void skgs_set_strict_math(int on);
+
+/* Per-kernel timing with HIP events recorded on the launch stream (bit k of the mask enables kernel id k; ids are
+ * 0..skgs_profile_kernel_count()-1, names via skgs_profile_kernel_name). skgs_profile_collect waits for the events
+ * recorded since the previous collect and returns their summed duration [ms] and the number of launches. */
+void skgs_profile_enable(uint32_t kernel_mask);
+int skgs_profile_kernel_count(void);
+const char* skgs_profile_kernel_name(int kernel_id);
+int skgs_profile_collect(int kernel_id, double* total_ms, int32_t* launches);
 
 const char* skgs_last_error(void);
 int skgs_version(void);

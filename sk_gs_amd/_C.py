@@ -168,6 +168,34 @@ def set_pixels_per_lane(ppl: int):
     load_library().skgs_set_pixels_per_lane(C.c_int(ppl))
 
 
+def profile_kernels() -> dict:
+    """name -> kernel id of the kernels the library can time with HIP events"""
+    lib = load_library()
+    lib.skgs_profile_kernel_name.restype = C.c_char_p
+    return {lib.skgs_profile_kernel_name(C.c_int(i)).decode(): i for i in range(lib.skgs_profile_kernel_count())}
+
+
+def profile_enable(names=None):
+    """enable HIP-event timing for the named kernels (None = all, [] = off)"""
+    ids = profile_kernels()
+    mask = 0
+    for n in (ids.keys() if names is None else names):
+        mask |= 1 << ids[n]
+    load_library().skgs_profile_enable(C.c_uint32(mask))
+
+
+def profile_collect() -> dict:
+    """name -> (total_ms, launches) since the last collect (synchronises on the recorded events)"""
+    lib = load_library()
+    out = {}
+    for name, kid in profile_kernels().items():
+        ms, n = C.c_double(0), C.c_int32(0)
+        _check(lib.skgs_profile_collect(C.c_int(kid), C.byref(ms), C.byref(n)))
+        if n.value:
+            out[name] = (ms.value, n.value)
+    return out
+
+
 def set_strict_math(on: bool):
     """parity-test switch: blend kernels built without FMA contraction, in the oracle's operation order, with the
     reproducible double-arithmetic exp (bit-comparable with the oracle's exp_mode=1). Slower; never used by bench."""

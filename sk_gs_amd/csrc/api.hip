@@ -14,6 +14,41 @@ int set_error(const char* fmt, ...) {
   return 1;
 }
 
+// ---- per-kernel event timing ---------------------------------------------------------------------------------
+namespace {
+constexpr int PROF_RING = 4096;
+struct ProfSlot {
+  hipEvent_t start[PROF_RING], stop[PROF_RING];
+  bool created = false;
+  int used     = 0;     // pairs recorded since the last collect
+  bool open    = false; // begin recorded, end pending
+};
+ProfSlot g_prof[K_COUNT];
+uint32_t g_prof_mask = 0;
+const char* const g_prof_names[K_COUNT] = {"preprocess_forward", "scan_tiles", "scatter", "tile_sort", "render_forward",
+    "render_backward", "preprocess_backward", "deform_forward", "deform_backward", "knn_bones"};
+}  // namespace
+
+void prof_begin(int kid, hipStream_t s) {
+  if (!((g_prof_mask >> kid) & 1u)) return;
+  ProfSlot& p = g_prof[kid];
+  if (!p.created) {
+    for (int i = 0; i < PROF_RING; ++i) {
+      if (hipEventCreate(&p.start[i]) != hipSuccess || hipEventCreate(&p.stop[i]) != hipSuccess) return;
+    }
+    p.created = true;
+  }
+  if (p.used >= PROF_RING) return;  // ring full: stop sampling until collected
+  p.open = hipEventRecord(p.start[p.used], s) == hipSuccess;
+}
+void prof_end(int kid, hipStream_t s) {
+  if (!((g_prof_mask >> kid) & 1u)) return;
+  ProfSlot& p = g_prof[kid];
+  if (!p.open) return;
+  if (hipEventRecord(p.stop[p.used], s) == hipSuccess) p.used++;
+  p.open = false;
+}
+
 static int check_inputs(const skgs_raster_inputs* in) {
   SKGS_REQUIRE(in != nullptr, "inputs struct is NULL");
   SKGS_REQUIRE(in->P >= 0, "P must be >= 0");
@@ -45,6 +80,26 @@ static int check_buffers(const skgs_raster_inputs* in, const skgs_raster_buffers
 using namespace skgs;
 
 extern "C" {
+
+void skgs_profile_enable(uint32_t kernel_mask) { g_prof_mask = kernel_mask; }
+int skgs_profile_kernel_count(void) { return K_COUNT; }
+const char* skgs_profile_kernel_name(int kid) { return (kid >= 0 && kid < K_COUNT) ? g_prof_names[kid] : ""; }
+/* Waits for the recorded events of kernel `kid`, returns their summed duration and count, and resets the ring. */
+int skgs_profile_collect(int kid, double* total_ms, int32_t* launches) {
+  SKGS_REQUIRE(kid >= 0 && kid < K_COUNT && total_ms && launches, "profile_collect: bad argument");
+  ProfSlot& p = g_prof[kid];
+  double sum  = 0.0;
+  for (int i = 0; i < p.used; ++i) {
+    SKGS_CHECK_HIP(hipEventSynchronize(p.stop[i]));
+    float ms = 0.f;
+    SKGS_CHECK_HIP(hipEventElapsedTime(&ms, p.start[i], p.stop[i]));
+    sum += ms;
+  }
+  *total_ms = sum;
+  *launches = p.used;
+  p.used    = 0;
+  return 0;
+}
 
 const char* skgs_last_error(void) { return g_err; }
 int skgs_version(void) { return SKGS_VERSION; }

@@ -148,6 +148,7 @@ __global__ void __launch_bounds__(SORT_THREADS) tile_sort_kernel(int T, const ui
 }  // namespace
 
 int launch_scan_tiles(GeomView g, ImgView im, int64_t /*capacity_hint*/, hipStream_t s) {
+  ProfScope prof(K_SCAN, s);
   hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, im.T, im.tile_counts, im.tile_offsets,
       im.cursors, g.hdr);
   SKGS_CHECK_HIP(hipGetLastError());
@@ -157,11 +158,17 @@ int launch_scan_tiles(GeomView g, ImgView im, int64_t /*capacity_hint*/, hipStre
 int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, BinView b, hipStream_t s) {
   const int P = in.P;
   if (P == 0) return 0;
-  hipLaunchKernelGGL(scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, im.tiles_x, im.tiles_y, g.recs,
-      im.tile_offsets, im.cursors, b.keys, b.capacity, g.hdr);
+  {
+    ProfScope prof(K_SCATTER, s);
+    hipLaunchKernelGGL(scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, im.tiles_x, im.tiles_y, g.recs,
+        im.tile_offsets, im.cursors, b.keys, b.capacity, g.hdr);
+  }
   SKGS_CHECK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(tile_sort_kernel, dim3(im.T), dim3(SORT_THREADS), 0, s, im.T, im.tile_offsets, b.keys, b.point_list,
-      b.capacity);
+  {
+    ProfScope prof(K_SORT, s);
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(im.T), dim3(SORT_THREADS), 0, s, im.T, im.tile_offsets, b.keys, b.point_list,
+        b.capacity);
+  }
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

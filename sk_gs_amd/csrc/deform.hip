@@ -268,6 +268,7 @@ __global__ void __launch_bounds__(256) knn_bones_kernel(int P, int M, int K, int
 int launch_deform_forward(const skgs_deform_inputs& in, float* means, float* scales, float* rotations, float* opacity,
     float* d_xyz, float* d_rot, float* d_scale, hipStream_t s) {
   if (in.P == 0) return 0;
+  ProfScope prof(K_DEFORM_FWD, s);
   dim3 grid((in.P + DEFORM_THREADS - 1) / DEFORM_THREADS), block(DEFORM_THREADS);
   if (in.M <= MAX_LDS_BONES)
     hipLaunchKernelGGL(deform_forward_kernel<true>, grid, block, (size_t) in.M * BONE_F * 4, s, in.P, in.K, in.M, in.points,
@@ -285,6 +286,7 @@ int launch_deform_backward(const skgs_deform_inputs& in, const float* g_means, c
     const float* g_rotations, const float* g_opacity, float* g_weights, float* g_bone_T, float* g_bone_drot,
     float* g_bone_dscale, float* g_xyz, float* g_log_scale, float* g_rot, float* g_opacity_logit, hipStream_t s) {
   if (in.P == 0) return 0;
+  ProfScope prof(K_DEFORM_BWD, s);
   dim3 grid((in.P + DEFORM_THREADS - 1) / DEFORM_THREADS), block(DEFORM_THREADS);
   if (in.M <= MAX_LDS_BONES / 2)
     hipLaunchKernelGGL(deform_backward_kernel<true>, grid, block, (size_t) in.M * BONE_F * 4 * 2, s, in.P, in.K, in.M,
@@ -305,7 +307,8 @@ int launch_knn_bones(int P, int M, int K, int dim, const float* points, const fl
   if (P == 0) return 0;
   if (K > KNN_MAXK || K < 1) return set_error("knn_bones: K must be in [1,%d] (got %d)", KNN_MAXK, K);
   const size_t lds = (size_t) M * dim * 4;
-  const int use_lds = lds <= 96 * 1024;
+  const int use_lds = lds <= 48 * 1024;
+  ProfScope prof(K_KNN, s);
   hipLaunchKernelGGL(knn_bones_kernel, dim3((P + 255) / 256), dim3(256), use_lds ? lds : 0, s, P, M, K, dim, points, joints,
       out_dist, out_idx, use_lds);
   SKGS_CHECK_HIP(hipGetLastError());

@@ -687,6 +687,7 @@ int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView 
   const float focal_x = in.image_width / (2.0f * in.tanfovx);
   SKGS_CHECK_HIP(hipMemsetAsync(im.tile_counts, 0, (size_t) im.T * 4, s));
   if (P == 0) return 0;
+  ProfScope prof(K_PREPROCESS_FWD, s);
   dim3 grid((P + 255) / 256), block(256);
   if (in.colmap)
     hipLaunchKernelGGL(preprocess_forward_kernel<true>, grid, block, 0, s, P, in.sh_degree, in.sh_coeffs, in.means3D,
@@ -708,6 +709,7 @@ int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const i
   if (P == 0) return 0;
   const float focal_y = in.image_height / (2.0f * in.tanfovy);
   const float focal_x = in.image_width / (2.0f * in.tanfovx);
+  ProfScope prof(K_PREPROCESS_BWD, s);
   dim3 grid((P + 255) / 256), block(256);
   const int E = (in.extras && gr.dL_dout_extra && gr.dL_dextras) ? in.E : 0;
 #define SKGS_PB_ARGS                                                                                                    \

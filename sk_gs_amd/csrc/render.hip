@@ -266,6 +266,7 @@ int launch_render_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, 
   const int W = in.image_width, H = in.image_height;
   const int E = in.extras ? in.E : 0;
   const int ppl = g_ppl_override ? g_ppl_override : choose_ppl(im.T);
+  ProfScope prof(K_RENDER_FWD, s);
 #define FWD(E_, PPL_)                                                                                                   \
   {                                                                                                                     \
     const int nblk = ((im.T * (4 / PPL_) + 7) / 8) * 8;                                                                 \
@@ -295,6 +296,7 @@ int launch_render_backward(const skgs_raster_inputs& in, GeomView g, ImgView im,
   const int W = in.image_width, H = in.image_height;
   const int E = (in.extras && dL_dextra) ? in.E : 0;
   const int ppl = g_ppl_override ? g_ppl_override : choose_ppl(im.T);
+  ProfScope prof(K_RENDER_BWD, s);
 #define BWD(E_, PPL_)                                                                                                  \
   {                                                                                                                    \
     const int nblk = ((im.T * (4 / PPL_) + 7) / 8) * 8;                                                                \

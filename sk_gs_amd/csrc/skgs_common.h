@@ -146,6 +146,21 @@ int set_error(const char* fmt, ...);
     if (!(cond)) return skgs::set_error(__VA_ARGS__); \
   } while (0)
 
+// ---- optional per-kernel HIP-event timing (api.hip). Off by default; bench.py turns it on for the kernels it
+// reports.  Events are recorded on the stream the kernel is launched on.
+enum KernelId {
+  K_PREPROCESS_FWD = 0, K_SCAN, K_SCATTER, K_SORT, K_RENDER_FWD, K_RENDER_BWD, K_PREPROCESS_BWD, K_DEFORM_FWD,
+  K_DEFORM_BWD, K_KNN, K_COUNT
+};
+void prof_begin(int kid, hipStream_t s);
+void prof_end(int kid, hipStream_t s);
+struct ProfScope {
+  int kid;
+  hipStream_t s;
+  ProfScope(int k, hipStream_t st) : kid(k), s(st) { prof_begin(kid, s); }
+  ~ProfScope() { prof_end(kid, s); }
+};
+
 // preprocess.hip
 int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, int32_t* radii, hipStream_t s);
 int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const int32_t* radii,

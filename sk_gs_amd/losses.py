@@ -1,0 +1,52 @@
+"""Image loss of the training step: ``0.8 * L1 + 0.2 * (1 - SSIM)`` (exps/default.yaml:83-84,
+networks/sk_gs.py:1524-1529, networks/losses/image_loss.py:6-32, networks/losses/ssim.py:20-62).
+
+Plain torch restatement (11x11 Gaussian window, sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2). This is the
+"next" row (f)-1 of the scope table: a fused HIP version replaces it once the hot path meets its bar.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+_window_cache = {}
+
+
+def gaussian_window(window_size: int = 11, sigma: float = 1.5, channels: int = 3, device=None) -> Tensor:
+    key = (window_size, sigma, channels, str(device))
+    w = _window_cache.get(key)
+    if w is None:
+        g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
+        g = (g / g.sum()).unsqueeze(1)
+        w2 = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)
+        w = w2.expand(channels, 1, window_size, window_size).contiguous().to(device)
+        _window_cache[key] = w
+    return w
+
+
+def ssim_map(img1: Tensor, img2: Tensor, window_size: int = 11) -> Tensor:
+    """img*: [B, C, H, W]"""
+    C = img1.shape[-3]
+    window = gaussian_window(window_size, 1.5, C, img1.device).type_as(img1)
+    pad = window_size // 2
+    mu1 = F.conv2d(img1, window, padding=pad, groups=C)
+    mu2 = F.conv2d(img2, window, padding=pad, groups=C)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    sigma1_sq = F.conv2d(img1 * img1, window, padding=pad, groups=C) - mu1_sq
+    sigma2_sq = F.conv2d(img2 * img2, window, padding=pad, groups=C) - mu2_sq
+    sigma12 = F.conv2d(img1 * img2, window, padding=pad, groups=C) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    return ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
+
+
+def ssim_loss(img1_chw: Tensor, img2_chw: Tensor) -> Tensor:
+    """1 - mean SSIM, images [C,H,W] or [B,C,H,W]"""
+    if img1_chw.ndim == 3:
+        img1_chw, img2_chw = img1_chw[None], img2_chw[None]
+    return 1.0 - ssim_map(img1_chw, img2_chw).mean()
+
+
+def image_loss(pred_chw: Tensor, gt_chw: Tensor, lambda_l1: float = 0.8, lambda_ssim: float = 0.2) -> Tensor:
+    l1 = (pred_chw - gt_chw).abs().mean()
+    return lambda_l1 * l1 + lambda_ssim * ssim_loss(pred_chw, gt_chw)

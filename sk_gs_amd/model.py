@@ -1,0 +1,97 @@
+"""Minimal skinned-Gaussian module: the part of ``SkeletonGaussianSplatting`` that sits on the hot path.
+
+It owns the six Gaussian parameter tensors with the reference's names (networks/gaussian_splatting.py:134-139), the
+skeleton (joints, ancestor table), the LBS logits ``sp_W`` and a per-frame table of joint rotations (what the
+reference caches in ``sk_cache``, sk_gs.py:1077-1085; the 8x256 deform MLP that fills it is out of scope),
+and reproduces the call sequence of ``forward`` / ``render`` in stage ``sk`` (sk_gs.py:1160-1242):
+
+    kinematic -> calc_LBS_weight -> [lbs_deform: skin + activations] -> render(**net_out, raster_settings)
+
+Used by tests, bench.py and smoke(); it is NOT a re-implementation of the reference's training policy.
+"""
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor, nn
+import torch.nn.functional as F
+
+from sk_gs_amd import scene, skeleton
+from sk_gs_amd.deform import calc_lbs_weight, lbs_deform
+from sk_gs_amd.renderer.gaussian_render import GaussianRasterizationSettings, render
+
+
+class SkinnedGaussians(nn.Module):
+    def __init__(self, P: int, M: int, K: int = 5, sh_degree: int = 3, num_frames: int = 8, seed: int = 0,
+                 scale_mult: float = 1.0):
+        super().__init__()
+        g = scene.make_gaussians(P, seed=seed, sh_degree=sh_degree, scale_mult=scale_mult)
+        b = scene.make_bones(max(M, 1), seed=seed)
+        self.P, self.M, self.K = P, M, min(K, max(M, 1))
+        self.max_sh_degree = sh_degree
+        self.active_sh_degree = sh_degree
+        self._xyz = nn.Parameter(g['xyz'])
+        self._features_dc = nn.Parameter(g['sh'][:, :1].contiguous())
+        self._features_rest = nn.Parameter(g['sh'][:, 1:].contiguous())
+        self._scaling = nn.Parameter(g['log_scale'])
+        self._rotation = nn.Parameter(g['rot'])
+        self._opacity = nn.Parameter(g['opacity_logit'])
+        gen = torch.Generator().manual_seed(3000 + seed)
+        self.sp_W = nn.Parameter(torch.randn(P, max(M, 1), generator=gen))
+        self.register_buffer('joints', b['joints'])
+        table, depth = skeleton.build_ancestor_table(b['parents'], 0)
+        self.register_buffer('joint_parents', table)
+        self.joint_root = 0
+        # per-frame joint rotations (pre-normalisation, added to [0,0,0,1]: sk_gs.py:1076), d_rot, d_scale
+        frames = max(num_frames, 1)
+        rot0 = torch.stack([skeleton.axis_angle_to_quat(0.2 * torch.randn(max(M, 1), 3, generator=gen))
+                            for _ in range(frames)])
+        self.sk_r = nn.Parameter(rot0 - rot0.new_tensor([0, 0, 0, 1.]))
+        self.sk_d_rot = nn.Parameter(b['d_rot'][None].repeat(frames, 1, 1))
+        self.sk_d_scale = nn.Parameter(b['d_scale'][None].repeat(frames, 1, 1))
+        self.global_tr = nn.Parameter(torch.tensor([0, 0, 0, 0, 0, 0, 1.]).repeat(frames, 1))
+        self.static = M == 0
+
+    # ------------------------------------------------------------------------------------------------ parameters
+    def param_groups(self, lr: float = 1e-3, spatial_scale: float = 1.0):
+        """the six Gaussian groups of ``get_params`` (gaussian_splatting.py:443-453) + the skinning parameters"""
+        groups = [
+            {'params': [self._xyz], 'lr': lr * 0.16 * spatial_scale, 'name': 'xyz'},
+            {'params': [self._features_dc], 'lr': lr * 2.5, 'name': 'f_dc'},
+            {'params': [self._features_rest], 'lr': lr * 2.5 / 20, 'name': 'f_rest'},
+            {'params': [self._opacity], 'lr': lr * 50., 'name': 'opacity'},
+            {'params': [self._scaling], 'lr': lr * 5.0, 'name': 'scaling'},
+            {'params': [self._rotation], 'lr': lr * 1.0, 'name': 'rotation'},
+        ]
+        if not self.static:
+            groups.append({'params': [self.sp_W, self.sk_r, self.sk_d_rot, self.sk_d_scale, self.global_tr],
+                           'lr': lr, 'name': 'skinning'})
+        return groups
+
+    # --------------------------------------------------------------------------------------------------- forward
+    def bone_transforms(self, time_id: int):
+        sk_r = F.normalize(self.sk_r[time_id] + self.sk_r.new_tensor([0., 0., 0., 1.]), dim=-1)
+        sk_T = skeleton.kinematic(self.joints, sk_r, self.global_tr[time_id], self.joint_parents, self.joint_root)
+        return sk_T, self.sk_d_rot[time_id], self.sk_d_scale[time_id]
+
+    def forward(self, time_id: int = 0) -> Dict[str, Tensor]:
+        sh_features = torch.cat((self._features_dc, self._features_rest), dim=1)
+        if self.static:  # stage 'static': d_xyz = d_rot = d_scale = 0 (sk_gs.py:1167-1168)
+            return dict(points=self._xyz, opacity=torch.sigmoid(self._opacity), scales=torch.exp(self._scaling),
+                        rotations=F.normalize(self._rotation, dim=-1), sh_features=sh_features)
+        points = self._xyz.detach()
+        sk_T, sk_d_rot, sk_d_scale = self.bone_transforms(time_id)
+        weights, indices = calc_lbs_weight(points, self.joints, self.K, sp_W=self.sp_W)
+        means, scales, rotations, opacity = lbs_deform(points, weights, indices, sk_T, sk_d_rot, sk_d_scale,
+                                                       self._xyz, self._scaling, self._rotation, self._opacity)
+        return dict(points=means, opacity=opacity, scales=scales, rotations=rotations, sh_features=sh_features)
+
+    def render(self, raster_settings: GaussianRasterizationSettings, time_id: int = 0,
+               background: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        """one view: ``render()`` of sk_gs.py:1206-1242 for the in-tree rasterizer (background composited here)"""
+        net_out = self(time_id)
+        out = render(**net_out, raster_settings=raster_settings)
+        images = out['images']  # [3,H,W]
+        if background is not None:
+            images = images + (1 - out['opacity'][None]) * background.view(3, 1, 1)
+        out['images'] = images
+        return out

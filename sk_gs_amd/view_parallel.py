@@ -1,0 +1,103 @@
+"""View-parallel training: one process per GPU, every rank holds a full replica of the Gaussians, renders a different
+training view, and the parameter gradients are summed with ONE all-reduce over RCCL/xGMI.
+
+The reference has no working multi-GPU path for this model (its DDP wrapper breaks on the first densification,
+my_ext/framework.py:339-357; scripts/run_all_dnerf.sh runs one scene per GPU), so this is new work, not a port:
+  * all parameter gradients live in ONE flat fp32 buffer (``FlatGradBuffer``): ``p.grad`` are views into it, so a
+    single collective moves everything -- on the 8-GPU fully connected xGMI box RCCL splits a large buffer over all
+    7 links, which per-tensor all-reduces of the small tensors (opacity, rotation, ...) would not;
+  * densification statistics (sum of screen-space gradient norms, visit counts: SUM; max radii: MAX,
+    gaussian_splatting.py:503-513) are reduced the same way so prune/split decisions stay identical on every rank.
+Backend: ``nccl`` (= RCCL on ROCm) on GPUs, ``gloo`` on CPU (tests).
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+def init_distributed(backend: Optional[str] = None) -> tuple:
+    """(rank, world, local_rank) from the torchrun environment; initialises the default group when world > 1."""
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+class FlatGradBuffer:
+    """All gradients of ``params`` as views of one contiguous buffer."""
+
+    def __init__(self, params: Iterable[Tensor]):
+        self.params: List[Tensor] = [p for p in params if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else 'cpu'
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def zero_(self):
+        self.flat.zero_()
+
+    def rebind(self):
+        """re-attach the views (needed if something replaced p.grad, e.g. zero_grad(set_to_none=True))"""
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.flat[off:off + n].data_ptr():
+                p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    @property
+    def nbytes(self) -> int:
+        return self.flat.numel() * 4
+
+
+class ViewParallel:
+    """Gradient (and densification-statistic) reduction over the ranks of the default process group."""
+
+    def __init__(self, params: Iterable[Tensor], average: bool = True):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.grads = FlatGradBuffer(params)
+        self.average = average
+
+    def view_index(self, step: int, num_views: int) -> int:
+        """rank r renders view (step * world + r) mod num_views"""
+        return (step * self.world + self.rank) % num_views
+
+    def allreduce_grads(self, async_op: bool = False):
+        if self.world == 1:
+            return None
+        if self.average:
+            self.grads.flat.div_(self.world)
+        return dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+
+    def allreduce_densify_stats(self, xyz_gradient_accum: Tensor, denom: Tensor, max_radii2D: Tensor):
+        if self.world == 1:
+            return
+        packed = torch.stack([xyz_gradient_accum.view(-1).float(), denom.view(-1).float()])
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+        xyz_gradient_accum.view(-1).copy_(packed[0])
+        denom.view(-1).copy_(packed[1])
+        dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX)
+
+    def broadcast_params(self, params: Iterable[Tensor], src: int = 0):
+        if self.world == 1:
+            return
+        for p in params:
+            dist.broadcast(p.data, src=src)

@@ -1,0 +1,137 @@
+"""GPU parity tests of the LBS deform, the bone KNN and the end-to-end model step against the CPU oracle.
+
+Tolerances: KNN indices bit-exact; deform forward outputs <= 2e-6 max-norm relative (same operation order, only
+expf differs by an ulp); deform backward <= 1e-5 (bone gradients are summed in a different order); end-to-end
+parameter gradients of one training view <= 1e-4 (north star) with the threshold-flip allowance of helpers.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import assert_close_robust, rel_err, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(P, M, K, seed):
+    from sk_gs_amd import scene
+    g = scene.make_gaussians(P, seed=seed)
+    b = scene.make_bones(M, seed=seed)
+    gen = torch.Generator().manual_seed(seed + 100)
+    bone_T = torch.cat([0.3 * torch.randn(M, 3, generator=gen), torch.randn(M, 4, generator=gen)], -1)  # un-normalised q
+    w = torch.softmax(torch.randn(P, K, generator=gen), -1)
+    idx = torch.stack([torch.randperm(M, generator=gen)[:K] for _ in range(P)]).long()
+    return g, b, bone_T, w, idx
+
+
+@pytest.mark.parametrize('P,M,K', [(5000, 20, 5), (3000, 1, 1), (2000, 600, 4), (1000, 1500, 3)])
+def test_deform_forward_backward(oracle32, P, M, K):
+    from sk_gs_amd import _C
+    g, b, bone_T, w, idx = _inputs(P, M, K, seed=P)
+    n = to_np
+    ref = oracle32.lbs_deform_forward(n(g['xyz']), n(w), n(idx), n(bone_T), n(b['d_rot']), n(b['d_scale']), n(g['xyz']),
+                                      n(g['log_scale']), n(g['rot']), n(g['opacity_logit']))
+    c = lambda t: t.cuda()  # noqa: E731
+    out = _C.lbs_deform_forward(c(g['xyz']), c(w), c(idx), c(bone_T), c(b['d_rot']), c(b['d_scale']), c(g['xyz']),
+                                c(g['log_scale']), c(g['rot']), c(g['opacity_logit']), need_deltas=True)
+    for name, t in zip(['means', 'scales', 'rotations', 'opacity', 'd_xyz', 'd_rot', 'd_scale'], out):
+        assert rel_err(t, ref[name]) <= 2e-6, name
+    gen = torch.Generator().manual_seed(1)
+    gm, gs, gr, go = (torch.randn(P, 3, generator=gen), torch.randn(P, 3, generator=gen),
+                      torch.randn(P, 4, generator=gen), torch.randn(P, 1, generator=gen))
+    gref = oracle32.lbs_deform_backward(n(g['xyz']), n(w), n(idx), n(bone_T), n(b['d_rot']), n(b['d_scale']),
+                                        n(g['log_scale']), n(g['rot']), n(g['opacity_logit']), n(gm), n(gs), n(gr), n(go))
+    got = _C.lbs_deform_backward(c(g['xyz']), c(w), c(idx), c(bone_T), c(b['d_rot']), c(b['d_scale']),
+                                 c(g['log_scale']), c(g['rot']), c(g['opacity_logit']), c(gm), c(gs), c(gr), c(go))
+    names = ['g_weights', 'g_bone_T', 'g_bone_drot', 'g_bone_dscale', 'g_xyz', 'g_log_scale', 'g_rot',
+             'g_opacity_logit']
+    for name, t in zip(names, got):
+        assert rel_err(t, gref[name]) <= 1e-5, (name, rel_err(t, gref[name]))
+
+
+@pytest.mark.parametrize('P,M,K,dim', [(4000, 20, 5, 3), (1000, 512, 5, 11), (500, 3, 5, 3)])
+def test_knn_bones(oracle32, P, M, K, dim):
+    from sk_gs_amd import _C
+    gen = torch.Generator().manual_seed(P + M)
+    pts, jts = torch.randn(P, dim, generator=gen), torch.randn(M, dim, generator=gen)
+    d_ref, i_ref = oracle32.knn_bones(to_np(pts), to_np(jts), K)
+    d, i = _C.knn_bones(pts.cuda(), jts.cuda(), K)
+    np.testing.assert_array_equal(to_np(i), i_ref)
+    assert rel_err(d, d_ref) <= 1e-6
+
+
+def test_autograd_op_matches_torch_reference():
+    """lbs_deform (HIP, autograd.Function) vs the same math written with differentiable torch ops"""
+    from sk_gs_amd import skeleton
+    from sk_gs_amd.deform import lbs_deform
+    P, M, K = 3000, 12, 4
+    g, b, bone_T, w, idx = _inputs(P, M, K, seed=3)
+    dev = 'cuda'
+    leaves = {k: v.to(dev).requires_grad_(True) for k, v in dict(
+        w=w, bone_T=bone_T, drot=b['d_rot'], dscale=b['d_scale'], xyz=g['xyz'], ls=g['log_scale'], rot=g['rot'],
+        op=g['opacity_logit']).items()}
+    idx = idx.to(dev)
+
+    def torch_ref(L):
+        p = L['xyz'].detach()
+        y = skeleton.se3_act(L['bone_T'][idx], p[:, None])
+        d_xyz = (y * L['w'][..., None]).sum(1) - p
+        d_rot = (L['drot'][idx] * L['w'][..., None]).sum(1)
+        d_scale = (L['dscale'][idx] * L['w'][..., None]).sum(1)
+        return (L['xyz'] + d_xyz, torch.exp(L['ls']) + d_scale, F.normalize(L['rot'] + d_rot, dim=-1),
+                torch.sigmoid(L['op']))
+
+    gen = torch.Generator().manual_seed(9)
+    cot = [torch.randn(P, c, generator=gen).to(dev) for c in (3, 3, 4, 1)]
+    outs_ref = torch_ref(leaves)
+    grads_ref = torch.autograd.grad(outs_ref, list(leaves.values()), cot)
+    outs = lbs_deform(leaves['xyz'].detach(), leaves['w'], idx, leaves['bone_T'], leaves['drot'], leaves['dscale'],
+                      leaves['xyz'], leaves['ls'], leaves['rot'], leaves['op'])
+    grads = torch.autograd.grad(outs, list(leaves.values()), cot)
+    for a, r in zip(outs, outs_ref):
+        assert rel_err(a, r) <= 1e-5
+    for name, a, r in zip(leaves.keys(), grads, grads_ref):
+        assert rel_err(a, r) <= 2e-5, (name, rel_err(a, r))
+
+
+def test_model_step_matches_oracle(oracle32):
+    """one full view: bone chain -> KNN weights -> deform -> render -> fixed cotangents -> grads of the six Gaussian
+    parameter tensors, vs the oracle pipeline fed with the same bones"""
+    from sk_gs_amd import scene
+    from sk_gs_amd.model import SkinnedGaussians
+    P, M, K, W, H = 6000, 10, 5, 160, 128
+    model = SkinnedGaussians(P, M, K, num_frames=2, seed=1, scale_mult=2.5).cuda()
+    cam = scene.make_camera(W, H, seed=4)
+    rs = scene.raster_settings_from_camera(cam, colmap=True, device='cuda')
+    out = model.render(rs, time_id=1)
+    gen = torch.Generator().manual_seed(2)
+    gcol, gop = torch.randn(3, H, W, generator=gen).cuda(), torch.randn(H, W, generator=gen).cuda()
+    torch.autograd.backward([out['images'], out['opacity']], [gcol, gop])
+    n = to_np
+    with torch.no_grad():
+        sk_T, d_rot, d_scale = model.bone_transforms(1)
+        from sk_gs_amd.deform import calc_lbs_weight
+        w, idx = calc_lbs_weight(model._xyz, model.joints, K, sp_W=model.sp_W)
+        sh = torch.cat([model._features_dc, model._features_rest], 1)
+    d = oracle32.lbs_deform_forward(n(model._xyz), n(w), n(idx), n(sk_T), n(d_rot), n(d_scale), n(model._xyz),
+                                    n(model._scaling), n(model._rotation), n(model._opacity))
+    fwd = oracle32.rasterize_forward(H, W, rs.tanfovx, rs.tanfovy, 3, 1.0, True, n(rs.viewmatrix), n(rs.projmatrix),
+                                     n(rs.campos), d['means'], d['opacity'], n(sh), d['scales'], d['rotations'])
+    assert_close_robust(out['images'], fwd['color'], 1e-4, name='image')
+    gr = oracle32.rasterize_backward(fwd, H, W, rs.tanfovx, rs.tanfovy, 3, 1.0, True, n(rs.viewmatrix),
+                                     n(rs.projmatrix), n(rs.campos), d['means'], n(sh), d['scales'], d['rotations'],
+                                     n(gcol), n(gop))
+    gd = oracle32.lbs_deform_backward(n(model._xyz), n(w), n(idx), n(sk_T), n(d_rot), n(d_scale), n(model._scaling),
+                                      n(model._rotation), n(model._opacity), gr['dL_dmeans3D'], gr['dL_dscales'],
+                                      gr['dL_drotations'], gr['dL_dopacity'])
+    assert_close_robust(model._xyz.grad, gd['g_xyz'], 1e-4, 1e-3, name='xyz')
+    assert_close_robust(model._scaling.grad, gd['g_log_scale'], 1e-4, 1e-3, name='scaling')
+    assert_close_robust(model._rotation.grad, gd['g_rot'], 1e-4, 1e-3, name='rotation')
+    assert_close_robust(model._opacity.grad, gd['g_opacity_logit'], 1e-4, 1e-3, name='opacity')
+    assert_close_robust(model._features_dc.grad, gr['dL_dsh'][:, :1], 1e-4, 1e-3, name='f_dc')
+    assert_close_robust(model._features_rest.grad, gr['dL_dsh'][:, 1:], 1e-4, 1e-3, name='f_rest')
+    # densification statistic: viewspace gradient populated
+    vs = out['viewspace_points'].grad
+    assert vs is not None
+    assert_close_robust(vs, gr['dL_dmean2D'], 1e-4, 1e-3, name='viewspace grad')
