@@ -127,6 +127,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--ms-per-render', action='store_true', help='also time rasterizer fwd+bwd alone (fixed grads)')
+    ap.add_argument('--lr', type=float, default=1e-4, help='base lr (reference 1e-3); small keeps the workload stationary')
+    ap.add_argument('--eager', action='store_true', help='issue every launch eagerly instead of replaying hipGraphs')
     args = ap.parse_args()
 
     from sk_gs_amd import _C, scene
@@ -150,38 +152,64 @@ def main():
     model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=0).to(dev)
     cams = [scene.make_camera(W, H, seed=i) for i in range(args.views)]
     settings = [scene.raster_settings_from_camera(c, sh_degree=3, colmap=True, device=dev) for c in cams]
-    gen = torch.Generator().manual_seed(77)
-    targets = [torch.rand(3, H, W, generator=gen).to(dev) for _ in range(args.views)]
     background = torch.ones(3, device=dev)
-    opt = torch.optim.Adam(model.param_groups(lr=1e-3), eps=1e-15, betas=(0.9, 0.999), fused=True)
+    # targets = the model's own initial renders + noise: a plausible fitting problem whose gradients stay small, so
+    # the workload (num_rendered, tile lists) is stationary over the run instead of drifting with a random target
+    gen = torch.Generator().manual_seed(77)
+    targets = []
+    with torch.no_grad():
+        for v in range(args.views):
+            img = model.render(settings[v], time_id=v % frames, background=background)['images']
+            targets.append((img + 0.05 * torch.randn(3, H, W, generator=gen).to(dev)).clamp(0, 1).contiguous())
+    opt = torch.optim.Adam(model.param_groups(lr=args.lr), eps=1e-15, betas=(0.9, 0.999), fused=True,
+                           capturable=not args.eager)
     vp = ViewParallel(model.parameters(), average=True)
     overflow = torch.zeros(1, dtype=torch.int32, device=dev)
 
-    def train_step(i):
-        v = vp.view_index(i, args.views)
+    def fwd_bwd(v):
         vp.grads.zero_()
         out = model.render(settings[v], time_id=v % frames, background=background)
         loss = image_loss(out['images'], targets[v])
         loss.backward()
+        overflow.add_(out['buffer'].geomBuffer[4:8].view(torch.int32))
+
+    def eager_step(i):
+        fwd_bwd(vp.view_index(i, args.views))
         vp.allreduce_grads()
         opt.step()
-        overflow.add_(out['buffer'].geomBuffer[4:8].view(torch.int32))
-        return out
+
+    from sk_gs_amd.train_step import GraphedSteps
+    if world == 1:  # whole step (fwd + bwd + Adam) is one graph per view
+        g_step = GraphedSteps(lambda v: (fwd_bwd(v), opt.step()))
+        g_opt = None
+    else:           # the RCCL all-reduce stays between two graphs
+        g_step = GraphedSteps(fwd_bwd)
+        g_opt = GraphedSteps(lambda _: opt.step())
+
+    def graph_step(i):
+        g_step(vp.view_index(i, args.views))
+        if g_opt is not None:
+            vp.allreduce_grads()
+            g_opt(0)
+
+    train_step = eager_step if args.eager else graph_step
 
     # ---------------------------------------------------------------- learn R per view with the synchronising path
     _C.config.sync_num_rendered = True
     Rs = []
-    for v in range(args.views):
-        out = model.render(settings[v], time_id=v % frames, background=background)
-        Rs.append(out['buffer'].R)
+    with torch.no_grad():  # no autograd graph may stay alive across a capture (see sk_gs_amd/train_step.py)
+        for v in range(args.views):
+            Rs.append(model.render(settings[v], time_id=v % frames, background=background)['buffer'].R)
     R_mean, R_max = sum(Rs) / len(Rs), max(Rs)
     _C.config.sync_num_rendered = False
     _C.update_capacity_hint(P, W, H, int(R_max * 1.25))
 
+    eager_step(0)  # initialises optimizer state before any capture
     for i in range(args.warmup):
         train_step(i)
     torch.cuda.synchronize()
-    _C.profile_enable(['render_backward'])
+    if args.eager:
+        _C.profile_enable(['render_backward'])
     _C.profile_collect()
     if world > 1:
         dist.barrier()
@@ -201,13 +229,17 @@ def main():
         elapsed = float(t.item())
     assert int(overflow.item()) == 0, 'binning capacity overflow during the timed region: result invalid'
 
-    # ---------------------------------------------------------------- per-kernel breakdown (short separate pass)
+    # ------------------------------------------------ per-kernel HIP-event timing: eager pass over the same steps
+    # (events cannot be read back from inside a replayed graph; the kernels and their inputs are the same)
     kernels = {}
     _C.profile_enable(None)
     for i in range(min(args.steps, 20)):
-        train_step(args.warmup + args.steps + i)
+        eager_step(args.warmup + args.steps + i)
     torch.cuda.synchronize()
-    for name, (ms, n) in _C.profile_collect().items():
+    prof_all = _C.profile_collect()
+    if 'render_backward' not in prof:
+        prof = prof_all
+    for name, (ms, n) in prof_all.items():
         us = ms / n * 1e3
         b = alg_bytes(name, P, M, K, W, H, R_mean)
         kernels[name] = dict(us=round(us, 2), launches_per_step=round(n / min(args.steps, 20), 2),
@@ -257,7 +289,8 @@ def main():
                                    f'{args.views} synthetic views, colmap=True, 1 view per rank per step',
                        'num_rendered_mean': round(R_mean), 'num_rendered_max': R_max,
                        'parallelism': f'view-parallel x{world}, flat-buffer grad all-reduce '
-                                      f'({vp.grads.nbytes / 1e6:.1f} MB)'},
+                                      f'({vp.grads.nbytes / 1e6:.1f} MB)',
+                       'launch': 'eager' if args.eager else 'one hipGraph replay per view step'},
             'roofline': {'bound': 'hbm', 'kernel': 'render_backward', 'achieved': round(achieved, 2),
                          'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 5),
                          'traffic': traffic, 'avg_us': round(rb_us, 2), 'launches': rb_n,

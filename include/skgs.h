@@ -174,6 +174,18 @@ int skgs_lbs_deform_backward(const skgs_deform_inputs* in, const float* g_means,
 int skgs_knn_bones(int32_t P, int32_t M, int32_t K, int32_t dim, const float* points, const float* joints,
     float* out_dist, int64_t* out_idx, skgs_stream_t stream);
 
+/* ---- fused training-image loss (scope row (f)-1): lambda_l1 * mean|x-y| + lambda_ssim * (1 - mean SSIM(x,y)) ----
+ * Replaces networks/losses/ssim.py:20-62 + image_loss.py:6-32 as composed at networks/sk_gs.py:1524-1529 (11x11
+ * Gaussian window, sigma 1.5, zero padding).  pred, gt: [C,H,W].  loss3 (device, 3 floats) = {total, L1 mean, SSIM
+ * mean}.  The workspace (skgs_image_loss_workspace_bytes) carries the SSIM derivative maps from forward to
+ * backward.  grad_loss: device scalar dL/dloss, or NULL for 1. */
+size_t skgs_image_loss_workspace_bytes(int32_t C, int32_t H, int32_t W);
+int skgs_image_loss_forward(int32_t C, int32_t H, int32_t W, const float* pred, const float* gt, float lambda_l1,
+    float lambda_ssim, float* loss3, void* workspace, size_t workspace_bytes, skgs_stream_t stream);
+int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred, const float* gt, float lambda_l1,
+    float lambda_ssim, const float* grad_loss, const void* workspace, size_t workspace_bytes, float* dL_dpred,
+    skgs_stream_t stream);
+
 /* Tuning knob of the blend kernels: pixels handled per lane (1, 2 or 4); 0 = heuristic on the tile count. */
 void skgs_set_pixels_per_lane(int ppl);
 /* Parity-test switch: blend kernels without FMA contraction, in the oracle's operation order, reproducible exp. */

@@ -9,6 +9,7 @@ There is NO fallback: if the shared library is missing (or a tensor is not on a 
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import threading
@@ -136,6 +137,17 @@ def _require_gpu(t: Tensor, name: str):
         raise SkgsError(f'{name} must live on a HIP device (got {t.device}); sk_gs_amd has no CPU path')
 
 
+_NULLCTX = contextlib.nullcontext()
+
+
+def _on_device(dev):
+    """device guard that is a no-op when `dev` already is the current device: switching devices (hipSetDevice)
+    inside a stream capture is not safe on ROCm, and the common single-device-per-process case never needs it"""
+    if dev.index is None or dev.index == torch.cuda.current_device():
+        return _NULLCTX
+    return torch.cuda.device(dev)
+
+
 def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -255,7 +267,7 @@ def rasterize_gaussians(image_height: int, image_width: int, tanfovx: float, tan
     _require_gpu(means3D, 'means3D')
     dev = means3D.device
     H, W = int(image_height), int(image_width)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         a, keep, P, M, E = _make_inputs(H, W, tanfovx, tanfovy, degree, scale_modifier, prefiltered, debug, colmap,
                                         viewmatrix, projmatrix, campos, means3D, opacity, sh, scales, rotations,
                                         extras, colors, cov3D_precomp)
@@ -348,7 +360,7 @@ def rasterize_gaussians_backward(scale_modifier: float, tanfovx: float, tanfovy:
     _require_gpu(means3D, 'means3D')
     dev = means3D.device
     H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         # opacity is not an input of the backward: the blend kernels read it from the saved records
         dummy_op = means3D  # any non-null pointer satisfies the input check; never dereferenced in the backward
         a, keep, P, M, E = _make_inputs(H, W, tanfovx, tanfovy, degree, scale_modifier, False, debug, colmap,
@@ -401,7 +413,7 @@ def gaussian_rasterize_extra_forward(W: int, H: int, R: int, extra: Tensor, geom
     if extra.ndim != 2:
         raise SkgsError('Error shape for extras')
     dev = extra.device
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         extra = _f32c(extra, dev)
         P, E = extra.shape
         out = torch.zeros((W, H, E), dtype=torch.float32, device=dev)
@@ -424,7 +436,7 @@ def gaussian_rasterize_extra_backward(W: int, H: int, R: int, extra: Tensor, out
     lib = load_library()
     _require_gpu(extra, 'extras')
     dev = extra.device
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         extra = _f32c(extra, dev)
         P, E = extra.shape
         f32 = dict(dtype=torch.float32, device=dev)
@@ -450,7 +462,7 @@ def gaussian_topk_weights(topk: int, W: int, H: int, P: int, R: int, geomBuffer:
     lib = load_library()
     _require_gpu(geomBuffer, 'geomBuffer')
     dev = geomBuffer.device
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         idx = torch.full((H, W, topk), -1, dtype=torch.int32, device=dev)
         w = torch.zeros((H, W, topk), dtype=torch.float32, device=dev)
         if P == 0:
@@ -467,7 +479,7 @@ def mark_visible(positions: Tensor, viewmatrix: Tensor, projmatrix: Tensor, colm
     lib = load_library()
     _require_gpu(positions, 'positions')
     dev = positions.device
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         positions = _f32c(positions, dev)
         viewmatrix = _f32c(viewmatrix, dev)
         P = positions.shape[0]
@@ -498,7 +510,7 @@ def lbs_deform_forward(points, weights, indices, bone_T, bone_drot, bone_dscale,
     lib = load_library()
     _require_gpu(points, 'points')
     dev = points.device
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         a, keep = _deform_inputs(points, weights, indices, bone_T, bone_drot, bone_dscale, xyz, log_scale, rot,
                                  opacity_logit)
         P = a.P
@@ -522,7 +534,7 @@ def lbs_deform_backward(points, weights, indices, bone_T, bone_drot, bone_dscale
     lib = load_library()
     _require_gpu(points, 'points')
     dev = points.device
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         a, keep = _deform_inputs(points, weights, indices, bone_T, bone_drot, bone_dscale, points, log_scale, rot,
                                  opacity_logit)
         P, K, M = a.P, a.K, a.M
@@ -548,7 +560,7 @@ def knn_bones(points: Tensor, joints: Tensor, K: int) -> Tuple[Tensor, Tensor]:
     lib = load_library()
     _require_gpu(points, 'points')
     dev = points.device
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         points, joints = _f32c(points, dev), _f32c(joints, dev)
         P, dim = points.shape
         M = joints.shape[0]
@@ -558,6 +570,41 @@ def knn_bones(points: Tensor, joints: Tensor, K: int) -> Tuple[Tensor, Tensor]:
                                   C.c_void_p(_ptr(points)), C.c_void_p(joints.data_ptr()), C.c_void_p(_ptr(dist)),
                                   C.c_void_p(_ptr(idx)), _stream()))
     return dist, idx
+
+
+def image_loss_forward(pred: Tensor, gt: Tensor, lambda_l1: float, lambda_ssim: float):
+    """fused ``lambda_l1 * L1 + lambda_ssim * (1 - SSIM)`` of [C,H,W] images.
+    Returns ``(loss3[3] = {total, l1_mean, ssim_mean}, workspace)``."""
+    lib = load_library()
+    _require_gpu(pred, 'pred')
+    dev = pred.device
+    with _on_device(dev):
+        pred, gt = _f32c(pred, dev), _f32c(gt, dev)
+        Cc, H, W = pred.shape
+        nbytes = lib.skgs_image_loss_workspace_bytes(C.c_int32(Cc), C.c_int32(H), C.c_int32(W))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        loss3 = torch.empty((3,), dtype=torch.float32, device=dev)
+        _check(lib.skgs_image_loss_forward(C.c_int32(Cc), C.c_int32(H), C.c_int32(W), C.c_void_p(pred.data_ptr()),
+                                           C.c_void_p(gt.data_ptr()), C.c_float(lambda_l1), C.c_float(lambda_ssim),
+                                           C.c_void_p(loss3.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                           C.c_size_t(nbytes), _stream()))
+    return loss3, ws
+
+
+def image_loss_backward(pred: Tensor, gt: Tensor, lambda_l1: float, lambda_ssim: float, grad_loss: Optional[Tensor],
+                        workspace: Tensor) -> Tensor:
+    lib = load_library()
+    dev = pred.device
+    with _on_device(dev):
+        pred, gt = _f32c(pred, dev), _f32c(gt, dev)
+        Cc, H, W = pred.shape
+        out = torch.empty_like(pred)
+        gl = _f32c(grad_loss, dev) if grad_loss is not None else None
+        _check(lib.skgs_image_loss_backward(C.c_int32(Cc), C.c_int32(H), C.c_int32(W), C.c_void_p(pred.data_ptr()),
+                                            C.c_void_p(gt.data_ptr()), C.c_float(lambda_l1), C.c_float(lambda_ssim),
+                                            C.c_void_p(_ptr(gl)), C.c_void_p(workspace.data_ptr()),
+                                            C.c_size_t(workspace.numel()), C.c_void_p(out.data_ptr()), _stream()))
+    return out
 
 
 _FUNCTIONS = {

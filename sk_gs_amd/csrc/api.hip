@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <algorithm>
+
 #include "skgs_common.h"
 
 namespace skgs {
@@ -12,6 +14,19 @@ int set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return 1;
+}
+
+// ---- fill kernel: used instead of hipMemsetAsync so that every node of a captured hipGraph is a plain kernel node
+__global__ void fill_u32_kernel(uint32_t* __restrict__ p, uint32_t v, size_t n) {
+  const size_t stride = (size_t) gridDim.x * blockDim.x;
+  for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+int fill_u32(void* p, uint32_t v, size_t n_words, hipStream_t s) {
+  if (n_words == 0) return 0;
+  const int blocks = (int) std::min<size_t>((n_words + 255) / 256, 2048);
+  hipLaunchKernelGGL(fill_u32_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p), v, n_words);
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 
 // ---- per-kernel event timing ---------------------------------------------------------------------------------
@@ -165,7 +180,7 @@ int skgs_rasterize_backward(const skgs_raster_inputs* in, const skgs_raster_buff
   GeomView g    = geom_view(buf->geom);
   ImgView im    = img_view(buf->img, in->image_width, in->image_height);
   BinView b     = bin_view(buf->binning, buf->binning_bytes);
-  SKGS_CHECK_HIP(hipMemsetAsync(gr->workspace, 0, (size_t) in->P * GRAD_ROW * 4, s));
+  if (fill_u32(gr->workspace, 0u, (size_t) in->P * GRAD_ROW, s)) return 1;
   if (launch_render_backward(*in, g, im, b, out_opacity, gr->dL_dout_color, gr->dL_dout_opacity, gr->dL_dout_extra,
           gr->workspace, s))
     return 1;
@@ -194,7 +209,7 @@ int skgs_rasterize_extra_backward(int32_t W, int32_t H, int32_t P, int32_t E, co
   GeomView g = geom_view(buf->geom);
   ImgView im = img_view(buf->img, W, H);
   BinView b  = bin_view(buf->binning, buf->binning_bytes);
-  SKGS_CHECK_HIP(hipMemsetAsync(dL_dextra, 0, (size_t) P * E * 4, s));
+  if (fill_u32(dL_dextra, 0u, (size_t) P * E, s)) return 1;
   return launch_extra_backward(W, H, P, E, extra, out_opacity, grad_pixel_extra, g, im, b, grad_means2D, grad_conic,
       grad_opacity, dL_dextra, s);
 }
@@ -205,8 +220,8 @@ int skgs_topk_weights(int32_t topk, int32_t W, int32_t H, int32_t P, const skgs_
   SKGS_REQUIRE(topk > 0 && top_indices && top_weights, "topk outputs are required");
   hipStream_t s = (hipStream_t) stream;
   if (P == 0) {
-    SKGS_CHECK_HIP(hipMemsetAsync(top_indices, 0xff, (size_t) W * H * topk * 4, s));
-    SKGS_CHECK_HIP(hipMemsetAsync(top_weights, 0, (size_t) W * H * topk * 4, s));
+    if (fill_u32(top_indices, 0xffffffffu, (size_t) W * H * topk, s)) return 1;
+    if (fill_u32(top_weights, 0u, (size_t) W * H * topk, s)) return 1;
     return 0;
   }
   GeomView g = geom_view(buf->geom);

@@ -1,0 +1,226 @@
+// image_loss.hip -- fused training-image loss  lambda_l1 * mean|x - y| + lambda_ssim * (1 - mean SSIM(x, y))
+// forward and backward (gfx950).  Scope-table row (f)-1: "fused image loss".
+//
+// Reference: networks/losses/ssim.py:20-62 (11x11 Gaussian window sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2,
+// five depth-wise conv2d + ~15 element-wise torch kernels forward, as many again backward), networks/losses/
+// image_loss.py:6-32 (L1 mean), weights exps/default.yaml:83-84.  On MI355X the depth-wise convs run in MIOpen at
+// ~0.4 ms each -- 3.5 ms per training step, more than the whole rasterizer.
+//
+// Here: the window is separable, so each 16x16 output tile stages a 26x26 halo of x and y in LDS, runs the 11-tap
+// horizontal pass for the 5 moments (x, y, xx, yy, xy) into LDS and the vertical pass into registers, evaluates the
+// SSIM map and its partial derivatives w.r.t. (mu1, E[xx], E[xy]) in place, and block-reduces the SSIM and L1 sums.
+// Backward = the same separable convolution applied to the three derivative maps:
+//     dL/dx = gs * (w * dmu1 + 2 x (w * dExx) + y (w * dExy)) + gl * sign(x - y).
+// HBM traffic: forward reads 2 and writes 3 image planes, backward reads 5 and writes 1 (vs ~60 plane passes in
+// the torch graph).  Per-tile partial sums are reduced in a fixed order: the loss value is bitwise reproducible.
+#include "skgs_common.h"
+
+namespace skgs {
+namespace {
+
+constexpr int LT   = 16;           // tile edge
+constexpr int HALO = 5;            // window radius
+constexpr int LW   = LT + 2 * HALO;  // 26
+struct Win {
+  float g[11];
+};
+
+__device__ __forceinline__ float block_sum_256(float v, float* s_red) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+  const int wid = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) s_red[wid] = v;
+  __syncthreads();
+  const float r = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  __syncthreads();
+  return r;
+}
+
+__global__ void __launch_bounds__(256) image_loss_forward_kernel(int C, int H, int W, const float* __restrict__ pred,
+    const float* __restrict__ gt, Win win, float* __restrict__ dmaps /*[3][C][H][W]*/, float* __restrict__ partials) {
+  __shared__ float s_x[LW][LW + 1];
+  __shared__ float s_y[LW][LW + 1];
+  __shared__ float s_h[5][LW][LT + 1];
+  __shared__ float s_red[4];
+  const int c  = blockIdx.z;
+  const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
+  const int tid = threadIdx.x;
+  const size_t plane = (size_t) H * W;
+  const float* px = pred + c * plane;
+  const float* py = gt + c * plane;
+  for (int i = tid; i < LW * LW; i += 256) {
+    const int r = i / LW, q = i - r * LW;
+    const int gy = y0 + r - HALO, gx = x0 + q - HALO;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    s_x[r][q] = in ? px[(size_t) gy * W + gx] : 0.f;
+    s_y[r][q] = in ? py[(size_t) gy * W + gx] : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < LW * LT; i += 256) {
+    const int r = i / LT, q = i - r * LT;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float w = win.g[k], xv = s_x[r][q + k], yv = s_y[r][q + k];
+      a0 += w * xv, a1 += w * yv, a2 += w * xv * xv, a3 += w * yv * yv, a4 += w * xv * yv;
+    }
+    s_h[0][r][q] = a0, s_h[1][r][q] = a1, s_h[2][r][q] = a2, s_h[3][r][q] = a3, s_h[4][r][q] = a4;
+  }
+  __syncthreads();
+  const int tx = tid & 15, ty = tid >> 4;
+  const int gx = x0 + tx, gy = y0 + ty;
+  const bool inside = gx < W && gy < H;
+  float mu1 = 0.f, mu2 = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
+#pragma unroll
+  for (int k = 0; k < 11; ++k) {
+    const float w = win.g[k];
+    mu1 += w * s_h[0][ty + k][tx], mu2 += w * s_h[1][ty + k][tx], exx += w * s_h[2][ty + k][tx];
+    eyy += w * s_h[3][ty + k][tx], exy += w * s_h[4][ty + k][tx];
+  }
+  float ssim = 0.f, l1 = 0.f;
+  if (inside) {
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+    const float s1 = exx - mu1_sq, s2 = eyy - mu2_sq, s12 = exy - mu12;
+    const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = s1 + s2 + C2;
+    const float inv = 1.f / (B1 * B2);
+    ssim            = A1 * A2 * inv;
+    // partial derivatives of ssim w.r.t. the window moments of x (mu1, E[xx], E[xy]) as independent variables
+    const float d_mu1 = (2.f * mu2 * (A2 - A1) * inv) - ssim * (2.f * mu1 * (B2 - B1)) * inv;
+    const float d_exx = -ssim / B2;
+    const float d_exy = 2.f * A1 * inv;
+    const size_t o   = (size_t) c * plane + (size_t) gy * W + gx;
+    const size_t CHW = (size_t) C * plane;
+    dmaps[o] = d_mu1, dmaps[CHW + o] = d_exx, dmaps[2 * CHW + o] = d_exy;
+    l1 = fabsf(s_x[ty + HALO][tx + HALO] - s_y[ty + HALO][tx + HALO]);
+  }
+  const float ssum = block_sum_256(ssim, s_red);
+  const float lsum = block_sum_256(l1, s_red);
+  if (tid == 0) {
+    const int b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    partials[2 * b] = ssum, partials[2 * b + 1] = lsum;
+  }
+}
+
+__global__ void __launch_bounds__(256) image_loss_finalize_kernel(int nblocks, double inv_n, float lambda_l1,
+    float lambda_ssim, const float* __restrict__ partials, float* __restrict__ loss /*[3]*/) {
+  __shared__ double s_a[256], s_b[256];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) a += partials[2 * i], b += partials[2 * i + 1];
+  s_a[threadIdx.x] = a, s_b[threadIdx.x] = b;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if (threadIdx.x < d) s_a[threadIdx.x] += s_a[threadIdx.x + d], s_b[threadIdx.x] += s_b[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float ssim_mean = (float) (s_a[0] * inv_n), l1_mean = (float) (s_b[0] * inv_n);
+    loss[0] = lambda_l1 * l1_mean + lambda_ssim * (1.0f - ssim_mean);
+    loss[1] = l1_mean;
+    loss[2] = ssim_mean;
+  }
+}
+
+__global__ void __launch_bounds__(256) image_loss_backward_kernel(int C, int H, int W, const float* __restrict__ pred,
+    const float* __restrict__ gt, Win win, const float* __restrict__ dmaps, const float* __restrict__ grad_loss,
+    float scale_l1, float scale_ssim, float* __restrict__ dL_dpred) {
+  __shared__ float s_m[3][LW][LW + 1];
+  __shared__ float s_h[3][LW][LT + 1];
+  const int c  = blockIdx.z;
+  const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
+  const int tid = threadIdx.x;
+  const size_t plane = (size_t) H * W, CHW = (size_t) C * plane;
+  for (int i = tid; i < LW * LW; i += 256) {
+    const int r = i / LW, q = i - r * LW;
+    const int gy = y0 + r - HALO, gx = x0 + q - HALO;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const size_t o = (size_t) c * plane + (size_t) gy * W + gx;
+    s_m[0][r][q] = in ? dmaps[o] : 0.f;
+    s_m[1][r][q] = in ? dmaps[CHW + o] : 0.f;
+    s_m[2][r][q] = in ? dmaps[2 * CHW + o] : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < LW * LT; i += 256) {
+    const int r = i / LT, q = i - r * LT;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float w = win.g[k];
+      a0 += w * s_m[0][r][q + k], a1 += w * s_m[1][r][q + k], a2 += w * s_m[2][r][q + k];
+    }
+    s_h[0][r][q] = a0, s_h[1][r][q] = a1, s_h[2][r][q] = a2;
+  }
+  __syncthreads();
+  const int tx = tid & 15, ty = tid >> 4;
+  const int gx = x0 + tx, gy = y0 + ty;
+  if (!(gx < W && gy < H)) return;
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 11; ++k) {
+    const float w = win.g[k];
+    c0 += w * s_h[0][ty + k][tx], c1 += w * s_h[1][ty + k][tx], c2 += w * s_h[2][ty + k][tx];
+  }
+  const size_t o = (size_t) c * plane + (size_t) gy * W + gx;
+  const float x = pred[o], y = gt[o];
+  const float g = grad_loss ? grad_loss[0] : 1.0f;
+  const float d = x - y;
+  const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+  dL_dpred[o] = g * (scale_ssim * (c0 + 2.f * x * c1 + y * c2) + scale_l1 * sgn);
+}
+
+Win make_window() {
+  // torch: gauss = Tensor([exp(-(x - 5)^2 / (2 sigma^2))]) (fp32), gauss / gauss.sum()   (ssim.py:8-10)
+  Win w;
+  float s = 0.f;
+  for (int i = 0; i < 11; ++i) {
+    w.g[i] = (float) exp(-(double) ((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5));
+    s += w.g[i];
+  }
+  for (int i = 0; i < 11; ++i) w.g[i] = w.g[i] / s;
+  return w;
+}
+
+}  // namespace
+}  // namespace skgs
+
+using namespace skgs;
+
+extern "C" {
+
+size_t skgs_image_loss_workspace_bytes(int32_t C, int32_t H, int32_t W) {
+  const size_t tiles = (size_t) ((W + LT - 1) / LT) * ((H + LT - 1) / LT) * C;
+  return (size_t) 3 * C * H * W * 4 + align256(tiles * 2 * 4) + 256;
+}
+
+int skgs_image_loss_forward(int32_t C, int32_t H, int32_t W, const float* pred, const float* gt, float lambda_l1,
+    float lambda_ssim, float* loss3, void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
+  SKGS_REQUIRE(C > 0 && H > 0 && W > 0 && pred && gt && loss3 && workspace, "image_loss_forward: bad argument");
+  SKGS_REQUIRE(workspace_bytes >= skgs_image_loss_workspace_bytes(C, H, W), "image_loss_forward: workspace too small");
+  hipStream_t s   = (hipStream_t) stream;
+  float* dmaps    = reinterpret_cast<float*>(workspace);
+  float* partials = dmaps + (size_t) 3 * C * H * W;
+  dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, C);
+  hipLaunchKernelGGL(image_loss_forward_kernel, grid, dim3(256), 0, s, C, H, W, pred, gt, make_window(), dmaps, partials);
+  SKGS_CHECK_HIP(hipGetLastError());
+  const int nblocks = grid.x * grid.y * grid.z;
+  hipLaunchKernelGGL(image_loss_finalize_kernel, dim3(1), dim3(256), 0, s, nblocks, 1.0 / ((double) C * H * W), lambda_l1,
+      lambda_ssim, partials, loss3);
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred, const float* gt, float lambda_l1,
+    float lambda_ssim, const float* grad_loss /*device scalar or NULL (=1)*/, const void* workspace,
+    size_t workspace_bytes, float* dL_dpred, skgs_stream_t stream) {
+  SKGS_REQUIRE(C > 0 && H > 0 && W > 0 && pred && gt && workspace && dL_dpred, "image_loss_backward: bad argument");
+  SKGS_REQUIRE(workspace_bytes >= skgs_image_loss_workspace_bytes(C, H, W), "image_loss_backward: workspace too small");
+  const float* dmaps = reinterpret_cast<const float*>(workspace);
+  const float n      = (float) ((double) C * H * W);
+  dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, C);
+  hipLaunchKernelGGL(image_loss_backward_kernel, grid, dim3(256), 0, (hipStream_t) stream, C, H, W, pred, gt, make_window(),
+      dmaps, grad_loss, lambda_l1 / n, -lambda_ssim / n, dL_dpred);
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -685,7 +685,7 @@ int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView 
   const int P = in.P;
   const float focal_y = in.image_height / (2.0f * in.tanfovy);
   const float focal_x = in.image_width / (2.0f * in.tanfovx);
-  SKGS_CHECK_HIP(hipMemsetAsync(im.tile_counts, 0, (size_t) im.T * 4, s));
+  if (fill_u32(im.tile_counts, 0u, (size_t) im.T, s)) return 1;
   if (P == 0) return 0;
   ProfScope prof(K_PREPROCESS_FWD, s);
   dim3 grid((P + 255) / 256), block(256);

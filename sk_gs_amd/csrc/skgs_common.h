@@ -161,6 +161,9 @@ struct ProfScope {
   ~ProfScope() { prof_end(kid, s); }
 };
 
+// api.hip: p[0..n_words) = v  (kernel, not hipMemsetAsync: keeps captured graphs to kernel nodes only)
+int fill_u32(void* p, uint32_t v, size_t n_words, hipStream_t s);
+
 // preprocess.hip
 int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, int32_t* radii, hipStream_t s);
 int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const int32_t* radii,

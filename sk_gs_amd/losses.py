@@ -47,6 +47,31 @@ def ssim_loss(img1_chw: Tensor, img2_chw: Tensor) -> Tensor:
     return 1.0 - ssim_map(img1_chw, img2_chw).mean()
 
 
-def image_loss(pred_chw: Tensor, gt_chw: Tensor, lambda_l1: float = 0.8, lambda_ssim: float = 0.2) -> Tensor:
+def image_loss_torch(pred_chw: Tensor, gt_chw: Tensor, lambda_l1: float = 0.8, lambda_ssim: float = 0.2) -> Tensor:
+    """plain-torch restatement (reference graph): used as the fp32 numerics reference of the fused kernel"""
     l1 = (pred_chw - gt_chw).abs().mean()
     return lambda_l1 * l1 + lambda_ssim * ssim_loss(pred_chw, gt_chw)
+
+
+class _FusedImageLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt, lambda_l1, lambda_ssim):
+        from sk_gs_amd import _C
+        loss3, ws = _C.image_loss_forward(pred, gt, lambda_l1, lambda_ssim)
+        ctx.save_for_backward(pred, gt, ws)
+        ctx.lambdas = (lambda_l1, lambda_ssim)
+        return loss3[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_loss):
+        from sk_gs_amd import _C
+        pred, gt, ws = ctx.saved_tensors
+        g = _C.image_loss_backward(pred, gt, ctx.lambdas[0], ctx.lambdas[1], grad_loss.reshape(1), ws)
+        return g, None, None, None
+
+
+def image_loss(pred_chw: Tensor, gt_chw: Tensor, lambda_l1: float = 0.8, lambda_ssim: float = 0.2) -> Tensor:
+    """``lambda_l1 * L1 + lambda_ssim * (1 - SSIM)``: one fused HIP kernel per direction (csrc/image_loss.hip).
+    GPU tensors only -- there is no fallback; ``image_loss_torch`` is the explicit torch reference used by tests."""
+    return _FusedImageLoss.apply(pred_chw, gt_chw, float(lambda_l1), float(lambda_ssim))

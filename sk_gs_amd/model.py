@@ -41,6 +41,10 @@ class SkinnedGaussians(nn.Module):
         table, depth = skeleton.build_ancestor_table(b['parents'], 0)
         self.register_buffer('joint_parents', table)
         self.joint_root = 0
+        ident, mask = skeleton.root_constants(max(M, 1), 0)
+        self.register_buffer('_ident7', ident)
+        self.register_buffer('_root_mask', mask)
+        self.register_buffer('_rot_bias', torch.tensor([0., 0., 0., 1.]))
         # per-frame joint rotations (pre-normalisation, added to [0,0,0,1]: sk_gs.py:1076), d_rot, d_scale
         frames = max(num_frames, 1)
         rot0 = torch.stack([skeleton.axis_angle_to_quat(0.2 * torch.randn(max(M, 1), 3, generator=gen))
@@ -69,8 +73,9 @@ class SkinnedGaussians(nn.Module):
 
     # --------------------------------------------------------------------------------------------------- forward
     def bone_transforms(self, time_id: int):
-        sk_r = F.normalize(self.sk_r[time_id] + self.sk_r.new_tensor([0., 0., 0., 1.]), dim=-1)
-        sk_T = skeleton.kinematic(self.joints, sk_r, self.global_tr[time_id], self.joint_parents, self.joint_root)
+        sk_r = F.normalize(self.sk_r[time_id] + self._rot_bias, dim=-1)
+        sk_T = skeleton.kinematic(self.joints, sk_r, self.global_tr[time_id], self.joint_parents, self.joint_root,
+                                  (self._ident7, self._root_mask))
         return sk_T, self.sk_d_rot[time_id], self.sk_d_scale[time_id]
 
     def forward(self, time_id: int = 0) -> Dict[str, Tensor]:

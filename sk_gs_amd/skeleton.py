@@ -76,12 +76,19 @@ def build_ancestor_table(parents: Tensor, root: int) -> Tuple[Tensor, int]:
     return table, max_depth
 
 
-def skeleton_warp_se3(local_T: Tensor, global_T: Optional[Tensor], ancestors: Tensor, root: int) -> Tensor:
+def root_constants(M: int, root: int, device=None) -> Tuple[Tensor, Tensor]:
+    """(identity 7-vector, [M,1] bool mask of the root): built once, outside any graph capture (H2D copies)"""
+    ident = torch.tensor([0, 0, 0, 0, 0, 0, 1.], device=device)
+    mask = torch.zeros(M, 1, dtype=torch.bool)
+    mask[root] = True
+    return ident, mask.to(device)
+
+
+def skeleton_warp_se3(local_T: Tensor, global_T: Optional[Tensor], ancestors: Tensor, root: int,
+                      consts: Optional[Tuple[Tensor, Tensor]] = None) -> Tensor:
     """global bone transforms T_i = G * prod_{a in path(root -> i)} T_a; the root's own transform is forced to identity"""
     M, L = ancestors.shape
-    ident = local_T.new_tensor([0, 0, 0, 0, 0, 0, 1.])
-    mask = torch.zeros(M, 1, dtype=torch.bool, device=local_T.device)
-    mask[root] = True
+    ident, mask = consts if consts is not None else root_constants(M, root, local_T.device)
     out = torch.where(mask, ident.expand(M, 7), local_T)
     for level in range(L):
         out = se3_mul(out[ancestors[:, level]], out)
@@ -91,8 +98,9 @@ def skeleton_warp_se3(local_T: Tensor, global_T: Optional[Tensor], ancestors: Te
     return se3_mul(global_T.view(1, 7).expand(M, 7), out)
 
 
-def kinematic(joints: Tensor, sk_r: Tensor, g_tr: Optional[Tensor], ancestors: Tensor, root: int) -> Tensor:
+def kinematic(joints: Tensor, sk_r: Tensor, g_tr: Optional[Tensor], ancestors: Tensor, root: int,
+              consts: Optional[Tuple[Tensor, Tensor]] = None) -> Tensor:
     """joint rotations (unit xyzw quaternions [M,4]) about their joint positions -> global SE3 [M,7]
     (sk_gs.py:1090-1106): sk_t = joints + R(-joints)"""
     sk_t = joints + quat_act(sk_r, -joints)
-    return skeleton_warp_se3(torch.cat([sk_t, sk_r], dim=-1), g_tr, ancestors, root)
+    return skeleton_warp_se3(torch.cat([sk_t, sk_r], dim=-1), g_tr, ancestors, root, consts)

@@ -1,0 +1,54 @@
+"""hipGraph capture of the per-view training step.
+
+One training iteration is ~15 of our kernels plus the torch glue around them (bone chain, softmax of the LBS logits,
+concatenations, Adam) -- a few hundred short launches, i.e. launch-bound when issued eagerly.  The step has static
+shapes and, with the capacity-based binning (``_C.config.sync_num_rendered = False``), no host synchronisation, so
+the whole thing replays as ONE hipGraph per training view.  (The reference cannot do this: its forward blocks on a
+D2H copy of ``num_rendered``, gaussian_rasterizer_forward.cu:209.)
+"""
+import gc
+from typing import Callable, Dict, Hashable
+
+import torch
+
+
+class GraphedSteps:
+    """Captures ``fn(key)`` once per key into a ``torch.cuda.CUDAGraph`` and replays it afterwards.
+
+    ``fn`` must be free of host synchronisation and must only touch tensors that live across calls (parameters,
+    optimizer state, static inputs) or that it allocates itself (those come from the graph's private pool).
+
+    Pitfall (found the hard way on ROCm 7.2): no autograd graph built on ANOTHER stream may still be alive when a
+    capture starts.  A parameter's AccumulateGrad node is cached while any graph references it and remembers the
+    stream it was created on; a backward captured on the side stream would then synchronise with that foreign
+    (legacy default) stream, which drags it into the capture and crashes hipStreamEndCapture.  Drop such outputs
+    (or run those forwards under ``torch.no_grad()``) before capturing; ``capture`` runs ``gc.collect()`` first."""
+
+    def __init__(self, fn: Callable[[Hashable], None], warmup: int = 2):
+        self.fn = fn
+        self.warmup = warmup
+        self.graphs: Dict[Hashable, torch.cuda.CUDAGraph] = {}
+        self.pool = None
+
+    def capture(self, key: Hashable):
+        gc.collect()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):
+                self.fn(key)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.pool):
+            self.fn(key)
+        if self.pool is None:
+            self.pool = g.pool()
+        self.graphs[key] = g
+        return g
+
+    def __call__(self, key: Hashable):
+        g = self.graphs.get(key)
+        if g is None:
+            g = self.capture(key)
+        g.replay()
