@@ -174,6 +174,21 @@ int skgs_lbs_deform_backward(const skgs_deform_inputs* in, const float* g_means,
 int skgs_knn_bones(int32_t P, int32_t M, int32_t K, int32_t dim, const float* points, const float* joints,
     float* out_dist, int64_t* out_idx, skgs_stream_t stream);
 
+/* ---- bone chain (scope row a-3): joint rotations -> global bone transforms, one launch per direction ----
+ * Replaces kinematic() + skeleton_warp_SE3() (networks/sk_gs.py:1069-1107,193-206; lietorch SE3 product lie.h:242-246).
+ *   sk_r_raw [M,4]  network output BEFORE "+[0,0,0,1], normalize" (sk_gs.py:1076)      joints [M,3]
+ *   global_T [7] or NULL (identity)                                                     bone_T  [M,7] out
+ * Skeleton topology as three int32 device arrays: parents[M] (direct parent; parents[root] = root), the bones sorted
+ * by depth (level_nodes[M]) and level_start[num_levels+1] (level 0 = {root}).  chain_A [M,7] is written by the forward
+ * (may be NULL for inference) and consumed by the backward.  g_joints / g_global_T may be NULL. */
+int skgs_bone_chain_forward(int32_t M, int32_t root, const int32_t* parents, const int32_t* level_nodes,
+    const int32_t* level_start, int32_t num_levels, const float* sk_r_raw, const float* joints, const float* global_T,
+    float* bone_T, float* chain_A, skgs_stream_t stream);
+int skgs_bone_chain_backward(int32_t M, int32_t root, const int32_t* parents, const int32_t* level_nodes,
+    const int32_t* level_start, int32_t num_levels, const float* sk_r_raw, const float* joints, const float* global_T,
+    const float* chain_A, const float* g_bone_T, float* g_sk_r_raw, float* g_joints, float* g_global_T,
+    skgs_stream_t stream);
+
 /* ---- fused training-image loss (scope row (f)-1): lambda_l1 * mean|x-y| + lambda_ssim * (1 - mean SSIM(x,y)) ----
  * Replaces networks/losses/ssim.py:20-62 + image_loss.py:6-32 as composed at networks/sk_gs.py:1524-1529 (11x11
  * Gaussian window, sigma 1.5, zero padding).  pred, gt: [C,H,W].  loss3 (device, 3 floats) = {total, L1 mean, SSIM

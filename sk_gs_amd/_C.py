@@ -572,6 +572,48 @@ def knn_bones(points: Tensor, joints: Tensor, K: int) -> Tuple[Tensor, Tensor]:
     return dist, idx
 
 
+def bone_chain_forward(sk_r_raw: Tensor, joints: Tensor, global_T: Optional[Tensor], topo: dict,
+                       save_chain: bool = True):
+    """``kinematic`` + ``skeleton_warp_SE3`` (sk_gs.py:1069-1107,193-206) in one launch.
+    ``topo`` = dict(parents, level_nodes, level_start: int32 device tensors; root, num_levels: int).
+    Returns ``(bone_T[M,7], chain_A[M,7] | None)``."""
+    lib = load_library()
+    _require_gpu(sk_r_raw, 'sk_r_raw')
+    dev = sk_r_raw.device
+    with _on_device(dev):
+        sk_r_raw, joints, global_T = _f32c(sk_r_raw, dev), _f32c(joints, dev), _f32c(global_T, dev)
+        M = sk_r_raw.shape[0]
+        bone_T = torch.empty((M, 7), dtype=torch.float32, device=dev)
+        chain = torch.empty((M, 7), dtype=torch.float32, device=dev) if save_chain else None
+        _check(lib.skgs_bone_chain_forward(
+            C.c_int32(M), C.c_int32(topo['root']), C.c_void_p(topo['parents'].data_ptr()),
+            C.c_void_p(topo['level_nodes'].data_ptr()), C.c_void_p(topo['level_start'].data_ptr()),
+            C.c_int32(topo['num_levels']), C.c_void_p(sk_r_raw.data_ptr()), C.c_void_p(joints.data_ptr()),
+            C.c_void_p(_ptr(global_T)), C.c_void_p(bone_T.data_ptr()), C.c_void_p(_ptr(chain)), _stream()))
+    return bone_T, chain
+
+
+def bone_chain_backward(sk_r_raw: Tensor, joints: Tensor, global_T: Optional[Tensor], topo: dict, chain_A: Tensor,
+                        g_bone_T: Tensor, need_joints: bool = False):
+    """Returns ``(g_sk_r_raw[M,4], g_joints[M,3] | None, g_global_T[7] | None)``."""
+    lib = load_library()
+    dev = sk_r_raw.device
+    with _on_device(dev):
+        sk_r_raw, joints, global_T = _f32c(sk_r_raw, dev), _f32c(joints, dev), _f32c(global_T, dev)
+        g_bone_T = _f32c(g_bone_T, dev)
+        M = sk_r_raw.shape[0]
+        g_raw = torch.empty((M, 4), dtype=torch.float32, device=dev)
+        g_j = torch.empty((M, 3), dtype=torch.float32, device=dev) if need_joints else None
+        g_g = torch.empty((7,), dtype=torch.float32, device=dev) if global_T is not None else None
+        _check(lib.skgs_bone_chain_backward(
+            C.c_int32(M), C.c_int32(topo['root']), C.c_void_p(topo['parents'].data_ptr()),
+            C.c_void_p(topo['level_nodes'].data_ptr()), C.c_void_p(topo['level_start'].data_ptr()),
+            C.c_int32(topo['num_levels']), C.c_void_p(sk_r_raw.data_ptr()), C.c_void_p(joints.data_ptr()),
+            C.c_void_p(_ptr(global_T)), C.c_void_p(chain_A.data_ptr()), C.c_void_p(g_bone_T.data_ptr()),
+            C.c_void_p(g_raw.data_ptr()), C.c_void_p(_ptr(g_j)), C.c_void_p(_ptr(g_g)), _stream()))
+    return g_raw, g_j, g_g
+
+
 def image_loss_forward(pred: Tensor, gt: Tensor, lambda_l1: float, lambda_ssim: float):
     """fused ``lambda_l1 * L1 + lambda_ssim * (1 - SSIM)`` of [C,H,W] images.
     Returns ``(loss3[3] = {total, l1_mean, ssim_mean}, workspace)``."""

@@ -45,6 +45,9 @@ class SkinnedGaussians(nn.Module):
         self.register_buffer('_ident7', ident)
         self.register_buffer('_root_mask', mask)
         self.register_buffer('_rot_bias', torch.tensor([0., 0., 0., 1.]))
+        self._topo_cpu = skeleton.build_topology(b['parents'], 0)
+        self._topo = None
+        self.fused_bone_chain = True
         # per-frame joint rotations (pre-normalisation, added to [0,0,0,1]: sk_gs.py:1076), d_rot, d_scale
         frames = max(num_frames, 1)
         rot0 = torch.stack([skeleton.axis_angle_to_quat(0.2 * torch.randn(max(M, 1), 3, generator=gen))
@@ -72,10 +75,19 @@ class SkinnedGaussians(nn.Module):
         return groups
 
     # --------------------------------------------------------------------------------------------------- forward
+    def topology(self) -> dict:
+        if self._topo is None or self._topo['parents'].device != self.joints.device:
+            self._topo = {k: (v.to(self.joints.device) if isinstance(v, Tensor) else v)
+                          for k, v in self._topo_cpu.items()}
+        return self._topo
+
     def bone_transforms(self, time_id: int):
-        sk_r = F.normalize(self.sk_r[time_id] + self._rot_bias, dim=-1)
-        sk_T = skeleton.kinematic(self.joints, sk_r, self.global_tr[time_id], self.joint_parents, self.joint_root,
-                                  (self._ident7, self._root_mask))
+        if self.fused_bone_chain and self.joints.is_cuda:
+            sk_T = skeleton.bone_chain(self.sk_r[time_id], self.joints, self.global_tr[time_id], self.topology())
+        else:  # plain-torch restatement (the numerics reference of the fused kernel)
+            sk_r = F.normalize(self.sk_r[time_id] + self._rot_bias, dim=-1)
+            sk_T = skeleton.kinematic(self.joints, sk_r, self.global_tr[time_id], self.joint_parents,
+                                      self.joint_root, (self._ident7, self._root_mask))
         return sk_T, self.sk_d_rot[time_id], self.sk_d_scale[time_id]
 
     def forward(self, time_id: int = 0) -> Dict[str, Tensor]:

@@ -104,3 +104,55 @@ def kinematic(joints: Tensor, sk_r: Tensor, g_tr: Optional[Tensor], ancestors: T
     (sk_gs.py:1090-1106): sk_t = joints + R(-joints)"""
     sk_t = joints + quat_act(sk_r, -joints)
     return skeleton_warp_se3(torch.cat([sk_t, sk_r], dim=-1), g_tr, ancestors, root, consts)
+
+
+# ------------------------------------------------------------------------------------------------ fused HIP path
+def build_topology(parents: Tensor, root: int, device=None) -> dict:
+    """Skeleton topology in the form the ``bone_chain`` kernels walk: direct parents, bones sorted by depth and the
+    start of every depth level (level 0 = {root}).  Built on the host once per skeleton (the reference rebuilds its
+    ancestor table in ``joint_discovery`` every 1000 iterations, sk_gs.py:1245-1265)."""
+    M = parents.shape[0]
+    par = parents.clone().long().cpu()
+    par[root] = root
+    depth = torch.zeros(M, dtype=torch.long)
+    for i in range(M):
+        d, f = 0, i
+        while f != root:
+            f = int(par[f])
+            d += 1
+            assert d <= M, 'parents do not form a tree rooted at `root`'
+        depth[i] = d
+    order = torch.argsort(depth, stable=True)
+    num_levels = int(depth.max()) + 1 if M > 0 else 1
+    counts = torch.bincount(depth, minlength=num_levels)
+    level_start = torch.zeros(num_levels + 1, dtype=torch.long)
+    level_start[1:] = torch.cumsum(counts, 0)
+    i32 = dict(dtype=torch.int32, device=device)
+    return dict(parents=par.to(**i32), level_nodes=order.to(**i32), level_start=level_start.to(**i32), root=int(root),
+                num_levels=num_levels)
+
+
+class _BoneChain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sk_r_raw, joints, global_T, topo):
+        from sk_gs_amd import _C
+        bone_T, chain = _C.bone_chain_forward(sk_r_raw, joints, global_T, topo, save_chain=True)
+        ctx.topo = topo
+        ctx.has_global = global_T is not None
+        ctx.save_for_backward(sk_r_raw, joints, global_T, chain)
+        return bone_T
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_bone_T):
+        from sk_gs_amd import _C
+        sk_r_raw, joints, global_T, chain = ctx.saved_tensors
+        need_j = ctx.needs_input_grad[1]
+        g_raw, g_j, g_g = _C.bone_chain_backward(sk_r_raw, joints, global_T, ctx.topo, chain, g_bone_T, need_joints=need_j)
+        return g_raw, g_j, g_g, None
+
+
+def bone_chain(sk_r_raw: Tensor, joints: Tensor, global_T: Optional[Tensor], topo: dict) -> Tensor:
+    """Fused ``normalize(raw + [0,0,0,1]) -> kinematic -> skeleton_warp_SE3`` on the GPU (csrc/bone_chain.hip):
+    global bone transforms [M,7] from the raw joint-rotation outputs; one kernel per direction instead of ~450."""
+    return _BoneChain.apply(sk_r_raw, joints, global_T, topo)

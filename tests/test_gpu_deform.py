@@ -135,3 +135,41 @@ def test_model_step_matches_oracle(oracle32):
     vs = out['viewspace_points'].grad
     assert vs is not None
     assert_close_robust(vs, gr['dL_dmean2D'], 1e-4, 1e-3, name='viewspace grad')
+
+
+@pytest.mark.parametrize('M,shape', [(20, 'random'), (64, 'chain'), (33, 'star'), (1, 'single'), (500, 'random')])
+@pytest.mark.parametrize('with_global', [True, False])
+def test_bone_chain_matches_torch(M, shape, with_global):
+    """fused bone-chain kernel vs the torch restatement of kinematic + skeleton_warp_SE3 (values and gradients)"""
+    from sk_gs_amd import skeleton
+    gen = torch.Generator().manual_seed(M)
+    if shape == 'chain':
+        parents = torch.arange(-1, M - 1).clamp_min(0)
+    elif shape == 'star':
+        parents = torch.zeros(M, dtype=torch.long)
+    else:
+        parents = torch.zeros(M, dtype=torch.long)
+        for i in range(1, M):
+            parents[i] = int(torch.randint(0, i, (1,), generator=gen))
+    joints = (torch.rand(M, 3, generator=gen) * 2 - 1).cuda()
+    raw = (0.3 * torch.randn(M, 4, generator=gen)).cuda().requires_grad_(True)
+    gT = torch.cat([0.2 * torch.randn(3, generator=gen), torch.randn(4, generator=gen)]).cuda().requires_grad_(True)
+    joints_g = joints.clone().requires_grad_(True)
+    table, _ = skeleton.build_ancestor_table(parents, 0)
+    table = table.cuda()
+    consts = skeleton.root_constants(M, 0, 'cuda')
+    bias = torch.tensor([0., 0., 0., 1.]).cuda()
+    sk_r = F.normalize(raw + bias, dim=-1)
+    ref = skeleton.kinematic(joints_g, sk_r, gT if with_global else None, table, 0, consts)
+    cot = torch.randn(M, 7, generator=gen).cuda()
+    # cotangent orthogonal to q, as the deform backward produces it
+    qn = F.normalize(ref[:, 3:].detach(), dim=-1)
+    cot[:, 3:] -= qn * (qn * cot[:, 3:]).sum(-1, keepdim=True)
+    inputs = [raw, joints_g] + ([gT] if with_global else [])
+    gref = torch.autograd.grad(ref, inputs, cot)
+    topo = skeleton.build_topology(parents, 0, device='cuda')
+    out = skeleton.bone_chain(raw, joints_g, gT if with_global else None, topo)
+    got = torch.autograd.grad(out, inputs, cot)
+    assert rel_err(out, ref) <= 5e-6
+    for a, r in zip(got, gref):
+        assert rel_err(a, r) <= 5e-5, rel_err(a, r)
