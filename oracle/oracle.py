@@ -85,6 +85,39 @@ class Oracle:
         self._fn('exp_array')(C.c_int(x.size), _p(x), _p(out))
         return out
 
+    # ------------------------------------------------------------------ sub-step hooks (pinned by tests/golden)
+    def cov3d_array(self, scales, rots, mod=1.0, colmap=True):
+        scales, rots = self.r(scales), self.r(rots)
+        out = np.zeros((scales.shape[0], 6), self.dtype)
+        self._fn('cov3d_array')(C.c_int(scales.shape[0]), _p(scales), self.creal(mod), _p(rots), C.c_int(int(colmap)),
+                                _p(out))
+        return out
+
+    def cov2d_array(self, means, cov3D, viewmatrix, fx, fy, tanfovx, tanfovy, colmap=True):
+        means, cov3D = self.r(means), self.r(cov3D)
+        out = np.zeros((means.shape[0], 3), self.dtype)
+        self._fn('cov2d_array')(C.c_int(means.shape[0]), _p(means), _p(cov3D), _p(self.r(viewmatrix)), self.creal(fx),
+                                self.creal(fy), self.creal(tanfovx), self.creal(tanfovy), C.c_int(int(colmap)), _p(out))
+        return out
+
+    def sh_array(self, deg, means, campos, shs):
+        means, shs = self.r(means), self.r(shs)
+        P, M = shs.shape[0], shs.shape[1]
+        rgb = np.zeros((P, 3), self.dtype)
+        clamped = np.zeros((P, 3), np.uint8)
+        self._fn('sh_array')(C.c_int(P), C.c_int(deg), C.c_int(M), _p(means), _p(self.r(campos)), _p(shs), _p(rgb),
+                             _p(clamped))
+        return rgb, clamped
+
+    def bone_chain_forward(self, ancestors, root, sk_r, joints, global_T=None):
+        """kinematic + skeleton_warp_SE3, literal pointer jumping (sk_gs.py:1069-1107,193-206)"""
+        ancestors = np.ascontiguousarray(ancestors, dtype=np.int64)
+        M, L = ancestors.shape
+        out = np.zeros((M, 7), self.dtype)
+        self._fn('bone_chain_forward')(C.c_int(M), C.c_int(L), C.c_int(root), _p(ancestors), _p(self.r(sk_r)),
+                                       _p(self.r(joints)), _p(self.r(global_T)), _p(out))
+        return out
+
     # ------------------------------------------------------------------ stages
     def preprocess_forward(self, means3D, scales, rotations, opacities, shs, viewmatrix, projmatrix, campos, W, H,
                            tanfovx, tanfovy, sh_degree, scale_modifier=1.0, colmap=True, cov3D_precomp=None,

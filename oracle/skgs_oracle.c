@@ -1376,6 +1376,79 @@ void ORACLE(mark_visible)(int P, const REAL* means3D, const REAL* viewmatrix, in
   }
 }
 
+/* ---- test hooks that expose sub-steps so they can be pinned against the reference's pure-torch helpers -------- */
+/* Sigma3D [P,6] from scale/rotation, both modes (computeCov3D{,_colmap}) */
+void ORACLE(cov3d_array)(int P, const REAL* scales, REAL mod, const REAL* rots, int colmap, REAL* out) {
+  for (int i = 0; i < P; ++i) {
+    if (colmap)
+      computeCov3D_colmap(scales + 3 * i, mod, rots + 4 * i, out + 6 * i);
+    else
+      computeCov3D_rowmajor(scales + 3 * i, rots + 4 * i, out + 6 * i);
+  }
+}
+/* Sigma2D (+0.3 low-pass) [P,3] = (xx, xy, yy), both modes (computeCov2D{,_colmap}) */
+void ORACLE(cov2d_array)(int P, const REAL* means, const REAL* cov3D, const REAL* viewmatrix, REAL fx, REAL fy,
+    REAL tan_fovx, REAL tan_fovy, int colmap, REAL* out) {
+  for (int i = 0; i < P; ++i) {
+    if (colmap)
+      computeCov2D_colmap(means + 3 * i, fx, fy, tan_fovx, tan_fovy, cov3D + 6 * i, viewmatrix, out + 3 * i);
+    else
+      computeCov2D_rowmajor(means + 3 * i, fx, fy, tan_fovx, tan_fovy, cov3D + 6 * i, viewmatrix, out + 3 * i);
+  }
+}
+/* SH -> RGB [P,3] (with the +0.5 and the clamp) and the clamp flags */
+void ORACLE(sh_array)(int P, int deg, int M, const REAL* means, const REAL* campos, const REAL* shs, REAL* rgb,
+    uint8_t* clamped) {
+  for (int i = 0; i < P; ++i) computeColorFromSH_fwd(i, deg, M, means, campos, shs, clamped, rgb + 3 * i);
+}
+
+/* Bone chain, literal restatement of kinematic() + skeleton_warp_SE3() (networks/sk_gs.py:1069-1107,193-206) with the
+ * SE3 product of lie.h:45-47,242-246: pointer jumping over the [M,L] ancestor table, root forced to identity.
+ * sk_r [M,4] are the (already normalised) joint rotations; global_T may be NULL. */
+static void se3_mul_o(const REAL* a, const REAL* b, REAL* o) {
+  REAL qa[4] = {a[3], a[4], a[5], a[6]}, qb[4] = {b[3], b[4], b[5], b[6]};
+  REAL na = R_SQRT(qa[0] * qa[0] + qa[1] * qa[1] + qa[2] * qa[2] + qa[3] * qa[3]);
+  REAL nb = R_SQRT(qb[0] * qb[0] + qb[1] * qb[1] + qb[2] * qb[2] + qb[3] * qb[3]);
+  for (int c = 0; c < 4; ++c) qa[c] /= na, qb[c] /= nb;
+  /* Eigen quaternion product (x,y,z,w) */
+  REAL q[4] = {qa[3] * qb[0] + qa[0] * qb[3] + qa[1] * qb[2] - qa[2] * qb[1],
+      qa[3] * qb[1] + qa[1] * qb[3] + qa[2] * qb[0] - qa[0] * qb[2],
+      qa[3] * qb[2] + qa[2] * qb[3] + qa[0] * qb[1] - qa[1] * qb[0],
+      qa[3] * qb[3] - qa[0] * qb[0] - qa[1] * qb[1] - qa[2] * qb[2]};
+  REAL nq = R_SQRT(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  REAL ta[7] = {0, 0, 0, qa[0], qa[1], qa[2], qa[3]}, y[3];
+  se3_act(ta, b, y); /* R(qa) * t_b */
+  o[0] = a[0] + y[0], o[1] = a[1] + y[1], o[2] = a[2] + y[2];
+  for (int c = 0; c < 4; ++c) o[3 + c] = q[c] / nq;
+}
+void ORACLE(bone_chain_forward)(int M, int L, int root, const int64_t* ancestors /*[M,L]*/, const REAL* sk_r,
+    const REAL* joints, const REAL* global_T, REAL* bone_T) {
+  REAL* cur = (REAL*) malloc(sizeof(REAL) * 7 * M);
+  REAL* nxt = (REAL*) malloc(sizeof(REAL) * 7 * M);
+  for (int i = 0; i < M; ++i) {
+    REAL rot7[7] = {0, 0, 0, sk_r[4 * i], sk_r[4 * i + 1], sk_r[4 * i + 2], sk_r[4 * i + 3]};
+    REAL mj[3]   = {-joints[3 * i], -joints[3 * i + 1], -joints[3 * i + 2]}, y[3];
+    se3_act(rot7, mj, y); /* sk_t = joints + sk_r.act(-joints), sk_gs.py:1090 */
+    for (int c = 0; c < 3; ++c) cur[7 * i + c] = joints[3 * i + c] + y[c];
+    for (int c = 0; c < 4; ++c) cur[7 * i + 3 + c] = sk_r[4 * i + c];
+  }
+  for (int c = 0; c < 7; ++c) cur[7 * root + c] = (c == 6) ? RC(1) : RC(0); /* out[root] = identity, :196 */
+  for (int l = 0; l < L; ++l) {                                             /* out = out[parents[:, l]] * out, :199 */
+    for (int i = 0; i < M; ++i) se3_mul_o(cur + 7 * ancestors[(size_t) i * L + l], cur + 7 * i, nxt + 7 * i);
+    REAL* t = cur;
+    cur     = nxt;
+    nxt     = t;
+  }
+  for (int i = 0; i < M; ++i) {
+    if (global_T)
+      se3_mul_o(global_T, cur + 7 * i, bone_T + 7 * i);
+    else
+      for (int c = 0; c < 7; ++c) bone_T[7 * i + c] = cur[7 * i + c];
+  }
+  free(cur);
+  free(nxt);
+}
+
 /* test hook: out[i] = the blend exp (current exp_mode) of x[i] */
 void ORACLE(exp_array)(int n, const REAL* x, REAL* out) {
   for (int i = 0; i < n; ++i) out[i] = oexp(x[i]);

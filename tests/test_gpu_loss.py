@@ -22,6 +22,21 @@ def test_fused_image_loss_matches_torch(H, W):
     assert rel_err(got, gref) <= 1e-4
 
 
+def test_fused_image_loss_matches_reference_golden():
+    """fused kernel vs values/gradients produced by the reference's own SSIM_Loss + ImageLoss (tests/golden/ssim.npz)"""
+    import os
+    import numpy as np
+    from sk_gs_amd.losses import image_loss
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ssim.npz'))
+    for k in range(3):
+        x = torch.from_numpy(g[f'x{k}'])[0].permute(2, 0, 1).contiguous().cuda().requires_grad_(True)
+        y = torch.from_numpy(g[f'y{k}'])[0].permute(2, 0, 1).contiguous().cuda()
+        out = image_loss(x, y)
+        (grad,) = torch.autograd.grad(out, x)
+        assert abs(float(out.detach()) - float(g[f'total{k}'])) <= 1e-5 * float(g[f'total{k}'])
+        assert rel_err(grad.permute(1, 2, 0), g[f'grad{k}'][0]) <= 1e-4
+
+
 def test_fused_image_loss_identical_images():
     from sk_gs_amd.losses import image_loss
     x = torch.rand(3, 48, 48).cuda().requires_grad_(True)

@@ -1,0 +1,136 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/skgs.h declares (no compute
+without a GPU), the product path fails loudly off-GPU, and the view-parallel gradient all-reduce works across two
+processes (gloo)."""
+import ctypes
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, 'include', 'skgs.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(skgs_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from sk_gs_amd import _C
+    path = _C.lib_path()
+    if not os.path.exists(path):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(path)
+    declared = _header_functions()
+    assert len(declared) >= 25
+    missing = [f for f in declared if not hasattr(lib, f)]
+    assert not missing, missing
+    for f in _C.EXPORTED_SYMBOLS:
+        assert f in declared
+    lib.skgs_version.restype = ctypes.c_int
+    assert lib.skgs_version() == 1
+    lib.skgs_geom_buffer_bytes.restype = ctypes.c_size_t
+    assert lib.skgs_geom_buffer_bytes(ctypes.c_int32(1000)) >= 1000 * 48
+    lib.skgs_binning_capacity.restype = ctypes.c_int64
+    lib.skgs_binning_capacity.argtypes = [ctypes.c_size_t]
+    lib.skgs_binning_buffer_bytes.restype = ctypes.c_size_t
+    lib.skgs_binning_buffer_bytes.argtypes = [ctypes.c_int64]
+    assert lib.skgs_binning_capacity(lib.skgs_binning_buffer_bytes(12345)) >= 12345
+
+
+def test_argument_errors_are_reported_not_crashed():
+    from sk_gs_amd import _C
+    lib = _C.load_library()
+    rc = lib.skgs_rasterize_forward_stage1(None, None, None, None, None)
+    assert rc != 0 and b'NULL' in lib.skgs_last_error()
+    with pytest.raises(_C.SkgsError):
+        _C.get_C_function('no_such_function')
+
+
+def test_product_path_refuses_cpu_tensors():
+    """no CPU fallback: the reference-named entry points raise for CPU tensors instead of computing something"""
+    from sk_gs_amd import _C
+    e = torch.Tensor([])
+    with pytest.raises(_C.SkgsError):
+        _C.rasterize_gaussians(32, 32, 0.5, 0.5, 0, 1.0, False, False, True, torch.eye(4), torch.eye(4), torch.zeros(3),
+                               torch.zeros(4, 3), torch.ones(4, 1), torch.zeros(4, 1, 3), torch.ones(4, 3),
+                               torch.tensor([[0, 0, 0, 1.]]).repeat(4, 1), None, e, e)
+    with pytest.raises(_C.SkgsError):
+        _C.knn_bones(torch.zeros(4, 3), torch.zeros(2, 3), 1)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'sk_gs_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.inl')):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert 'import oracle' not in txt and 'from oracle' not in txt and 'skgs_oracle_' not in txt, f
+
+
+def test_topology_and_flat_grad_buffer():
+    from sk_gs_amd import skeleton
+    from sk_gs_amd.view_parallel import FlatGradBuffer
+    parents = torch.tensor([0, 0, 1, 1, 3, 0])
+    topo = skeleton.build_topology(parents, 0)
+    assert topo['num_levels'] == 4
+    assert topo['level_start'].tolist() == [0, 1, 3, 5, 6]
+    assert sorted(topo['level_nodes'].tolist()) == list(range(6))
+    a, b = torch.nn.Parameter(torch.zeros(3, 2)), torch.nn.Parameter(torch.zeros(5))
+    fb = FlatGradBuffer([a, b])
+    (a.sum() * 2 + (b * torch.arange(5.)).sum()).backward()
+    assert fb.flat.tolist() == [2.] * 6 + [0., 1., 2., 3., 4.]
+    fb.zero_()
+    assert a.grad.abs().sum() == 0 and a.grad.data_ptr() == fb.flat.data_ptr()
+
+
+_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, os.environ['SKGS_ROOT'])
+import torch.distributed as dist
+from sk_gs_amd.view_parallel import ViewParallel, init_distributed
+rank, world, _ = init_distributed('gloo')
+torch.manual_seed(0)
+p1, p2 = torch.nn.Parameter(torch.ones(4, 3)), torch.nn.Parameter(torch.ones(7))
+vp = ViewParallel([p1, p2], average=True)
+assert vp.world == 2 and vp.view_index(3, 8) == (3 * 2 + rank) % 8
+((p1 * (rank + 1)).sum() + (p2 * (10 * (rank + 1))).sum()).backward()
+vp.allreduce_grads()
+assert torch.allclose(p1.grad, torch.full((4, 3), 1.5)), p1.grad
+assert torch.allclose(p2.grad, torch.full((7,), 15.0)), p2.grad
+acc, den, rad = torch.full((5, 1), float(rank + 1)), torch.ones(5, 1), torch.tensor([1., 5., 2., 0., 3.]) * (rank + 1)
+vp.allreduce_densify_stats(acc, den, rad)
+assert torch.allclose(acc, torch.full((5, 1), 3.0)) and torch.allclose(den, torch.full((5, 1), 2.0))
+assert torch.allclose(rad, torch.tensor([2., 10., 4., 0., 6.]))
+w = torch.nn.Parameter(torch.full((3,), float(rank)))
+vp.broadcast_params([w], src=1)
+assert torch.allclose(w.data, torch.ones(3))
+dist.barrier()
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_view_parallel_allreduce_two_processes_gloo(tmp_path):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), SKGS_ROOT=ROOT, OMP_NUM_THREADS='1')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f'rank {r} ok' in o
