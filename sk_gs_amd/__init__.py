@@ -11,3 +11,25 @@ Layout (only what the path needs):
   view_parallel.py          one-process-per-GPU view-parallel gradient all-reduce (RCCL)
 """
 __version__ = '0.1.0'
+
+
+def install_as_my_ext_C():
+    """Make ``from my_ext._C import get_C_function`` (networks/renderer/gaussian_render.py:12) resolve to this package's
+    binding, so the reference's own renderer module runs unchanged on top of libskgs_hip.so."""
+    import sys
+    import types
+    from sk_gs_amd import _C
+    pkg = sys.modules.get('my_ext')
+    if pkg is None:
+        pkg = types.ModuleType('my_ext')
+        pkg.__path__ = []
+        sys.modules['my_ext'] = pkg
+    sys.modules['my_ext._C'] = _C
+    pkg._C = _C
+
+
+def install_as_diff_gaussian_rasterization():
+    """Make ``from diff_gaussian_rasterization import GaussianRasterizer, GaussianRasterizationSettings``
+    (networks/renderer/gaussian_render_origin.py:7, networks/gaussian_splatting.py) resolve to this package."""
+    from sk_gs_amd import diff_gaussian_rasterization as m
+    m.install()
