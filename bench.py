@@ -128,6 +128,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--ms-per-render', action='store_true', help='also time rasterizer fwd+bwd alone (fixed grads)')
     ap.add_argument('--lr', type=float, default=1e-4, help='base lr (reference 1e-3); small keeps the workload stationary')
+    ap.add_argument('--torch-adam', action='store_true', help='use torch.optim.Adam(fused=True) instead of the one-launch kernel')
     ap.add_argument('--eager', action='store_true', help='issue every launch eagerly instead of replaying hipGraphs')
     args = ap.parse_args()
 
@@ -161,9 +162,13 @@ def main():
         for v in range(args.views):
             img = model.render(settings[v], time_id=v % frames, background=background)['images']
             targets.append((img + 0.05 * torch.randn(3, H, W, generator=gen).to(dev)).clamp(0, 1).contiguous())
-    opt = torch.optim.Adam(model.param_groups(lr=args.lr), eps=1e-15, betas=(0.9, 0.999), fused=True,
-                           capturable=not args.eager)
     vp = ViewParallel(model.parameters(), average=True)
+    if args.torch_adam:
+        opt = torch.optim.Adam(model.param_groups(lr=args.lr), eps=1e-15, betas=(0.9, 0.999), fused=True,
+                               capturable=not args.eager)
+    else:
+        from sk_gs_amd.optim import FusedAdam
+        opt = FusedAdam(model.param_groups(lr=args.lr), eps=1e-15, betas=(0.9, 0.999))
     overflow = torch.zeros(1, dtype=torch.int32, device=dev)
 
     def fwd_bwd(v):

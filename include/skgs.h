@@ -201,6 +201,18 @@ int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred,
     float lambda_ssim, const float* grad_loss, const void* workspace, size_t workspace_bytes, float* dL_dpred,
     skgs_stream_t stream);
 
+/* ---- multi-tensor Adam step in one launch (scope row (f)-2) ----
+ * Replaces torch.optim.Adam(eps=1e-15) as configured by exps/default.yaml:122-125 over the parameter groups of
+ * networks/gaussian_splatting.py:443-453 (amsgrad off, no weight decay).  `tensors` is a DEVICE array of descriptors
+ *   struct { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; int64_t n; int64_t chunk0; float lr;
+ *            float pad; }   (skgs_adam_tensor_bytes() = 56)
+ * with chunk0 = running sum of ceil(n / skgs_adam_chunk_elems()) and total_chunks the final sum.  step_count is a
+ * device float holding the number of steps taken so far; the call increments it (hipGraph-capturable). */
+size_t skgs_adam_tensor_bytes(void);
+int64_t skgs_adam_chunk_elems(void);
+int skgs_adam_step(int32_t n_tensors, const void* tensors, int64_t total_chunks, double beta1, double beta2, double eps,
+    float* step_count, skgs_stream_t stream);
+
 /* Tuning knob of the blend kernels: pixels handled per lane (1, 2 or 4); 0 = heuristic on the tile count. */
 void skgs_set_pixels_per_lane(int ppl);
 /* Parity-test switch: blend kernels without FMA contraction, in the oracle's operation order, reproducible exp. */

@@ -1,0 +1,108 @@
+// adam.hip -- multi-tensor Adam step in ONE launch (scope row (f)-2).
+//
+// Reference: torch.optim.Adam(eps=1e-15, betas=(0.9, 0.999)) over the six Gaussian parameter groups with per-group
+// learning rates (exps/default.yaml:122-125, networks/gaussian_splatting.py:443-453), stepped by
+// my_ext/framework.py:264-306.  torch's fused path issues one multi_tensor_apply launch per group and state list
+// (7 launches, ~300 us per step for config #1 on MI355X = 0.5 TB/s).  The update is a pure stream:
+// 16 B read + 12 B written per element.  Here every tensor of every group is walked by one grid with float4 accesses;
+// the step counter lives on the device so the launch can sit inside a captured hipGraph.
+//
+// Math (identical to torch, amsgrad = False, weight_decay = 0, maximize = False):
+//   m = b1 m + (1 - b1) g ;  v = b2 v + (1 - b2) g^2 ;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+#include <algorithm>
+
+#include "skgs_common.h"
+
+namespace skgs {
+namespace {
+
+struct AdamTensor {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t n;        // elements
+  int64_t chunk0;   // first chunk index of this tensor in the flattened chunk space
+  float lr;
+  float pad;
+};
+static_assert(sizeof(AdamTensor) == 56, "layout shared with the host binding");
+constexpr int ADAM_THREADS = 256;
+constexpr int ADAM_CHUNK   = ADAM_THREADS * 4 * 4;  // elements per workgroup iteration (4 float4 per lane)
+
+__global__ void __launch_bounds__(ADAM_THREADS) adam_step_kernel(int n_tensors, const AdamTensor* __restrict__ tensors,
+    int64_t total_chunks, double beta1d, double beta2d, float eps, const float* __restrict__ step_count) {
+  // hyper-parameters arrive as doubles and (1 - beta) is formed in double, as torch does: 1.0f - 0.999f is off by 1.3e-5
+  const double t   = (double) step_count[0] + 1.0;
+  const float bc1  = (float) (1.0 - pow(beta1d, t));
+  const float inv_sqrt_bc2 = (float) (1.0 / sqrt(1.0 - pow(beta2d, t)));
+  const float beta1 = (float) beta1d, beta2 = (float) beta2d;
+  const float omb1 = (float) (1.0 - beta1d), omb2 = (float) (1.0 - beta2d);
+  for (int64_t chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
+    int ti = 0;
+    while (ti + 1 < n_tensors && tensors[ti + 1].chunk0 <= chunk) ++ti;
+    const AdamTensor T = tensors[ti];
+    const float step_size = T.lr / bc1;
+    const int64_t base = (chunk - T.chunk0) * ADAM_CHUNK;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(T.param) | reinterpret_cast<uintptr_t>(T.grad) |
+                           reinterpret_cast<uintptr_t>(T.exp_avg) | reinterpret_cast<uintptr_t>(T.exp_avg_sq)) & 15) == 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t i = base + ((int64_t) r * ADAM_THREADS + threadIdx.x) * 4;
+      if (aligned && i + 3 < T.n) {
+        const float4 g = *reinterpret_cast<const float4*>(T.grad + i);
+        float4 m = *reinterpret_cast<float4*>(T.exp_avg + i);
+        float4 v = *reinterpret_cast<float4*>(T.exp_avg_sq + i);
+        float4 p = *reinterpret_cast<float4*>(T.param + i);
+#define SKGS_ADAM1(c)                                         \
+  m.c = beta1 * m.c + omb1 * g.c;                             \
+  v.c = beta2 * v.c + omb2 * g.c * g.c;                       \
+  p.c -= step_size * m.c / (sqrtf(v.c) * inv_sqrt_bc2 + eps);
+        SKGS_ADAM1(x) SKGS_ADAM1(y) SKGS_ADAM1(z) SKGS_ADAM1(w)
+        *reinterpret_cast<float4*>(T.exp_avg + i)    = m;
+        *reinterpret_cast<float4*>(T.exp_avg_sq + i) = v;
+        *reinterpret_cast<float4*>(T.param + i)      = p;
+      } else {
+        for (int64_t k = i; k < T.n && k < i + 4; ++k) {
+          const float g = T.grad[k];
+          const float m = beta1 * T.exp_avg[k] + omb1 * g;
+          const float v = beta2 * T.exp_avg_sq[k] + omb2 * g * g;
+          T.exp_avg[k] = m, T.exp_avg_sq[k] = v;
+          T.param[k] -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
+        }
+      }
+    }
+  }
+}
+#undef SKGS_ADAM1
+
+__global__ void adam_bump_kernel(float* step_count) { step_count[0] += 1.0f; }
+
+}  // namespace
+}  // namespace skgs
+
+using namespace skgs;
+
+extern "C" {
+
+size_t skgs_adam_tensor_bytes(void) { return sizeof(AdamTensor); }
+int64_t skgs_adam_chunk_elems(void) { return ADAM_CHUNK; }
+
+/* tensors: DEVICE array of n_tensors descriptors {param, grad, exp_avg, exp_avg_sq, n, chunk0, lr} (56 B each, every
+ * pointer 16-B aligned; chunk0 = running sum of ceil(n / skgs_adam_chunk_elems())). step_count: device float, the
+ * number of steps taken so far; incremented by the call. */
+int skgs_adam_step(int32_t n_tensors, const void* tensors, int64_t total_chunks, double beta1, double beta2, double eps,
+    float* step_count, skgs_stream_t stream) {
+  SKGS_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || (tensors && step_count)), "adam_step: NULL argument");
+  if (n_tensors == 0 || total_chunks == 0) return 0;
+  hipStream_t s   = (hipStream_t) stream;
+  const int grid  = (int) std::min<int64_t>(total_chunks, 256 * 16);
+  hipLaunchKernelGGL(adam_step_kernel, dim3(grid), dim3(ADAM_THREADS), 0, s, n_tensors,
+      reinterpret_cast<const AdamTensor*>(tensors), total_chunks, beta1, beta2, (float) eps, step_count);
+  SKGS_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, s, step_count);
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -227,7 +227,14 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
             if (alpha >= ALPHA_MIN) {
               any = true;
               if (!col_loaded) col[2] = s_c[j], col_loaded = true;
+#if SKGS_STRICT
               const float Tn = Tr[i] / (1.f - alpha);
+              const float tf_over = -T_final[i] / (1.f - alpha);
+#else
+              const float rinv    = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp; the IEEE divide is ~10 instructions
+              const float Tn      = Tr[i] * rinv;
+              const float tf_over = -T_final[i] * rinv;
+#endif
               Tr[i]          = Tn;
               const float dchannel_dcolor = alpha * Tn;
               float dL_dalpha = 0.0f;
@@ -248,7 +255,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
               }
               dL_dalpha *= Tn;
               last_alpha[i] = alpha;
-              dL_dalpha += (-T_final[i] / (1.f - alpha)) * dL_dT[i];
+              dL_dalpha += tf_over * dL_dT[i];
               const float dL_dG    = b.y * dL_dalpha;
               const float gdx      = G * dx;
               const float gdy      = G * dy;
@@ -266,7 +273,9 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
       }
       if (__any(any)) {
 #pragma unroll
-        for (int q = 0; q < NV; ++q) g[q] = wave_sum_to_lane63(g[q]);
+        for (int q = 0; q + 2 < 9; q += 3) wave_sum3_to_lane63(g[q], g[q + 1], g[q + 2]);
+#pragma unroll
+        for (int q = 9; q < NV; ++q) g[q] = wave_sum_to_lane63(g[q]);
         if (lane == 63) {
 #pragma unroll
           for (int q = 0; q < NV; ++q) s_acc[nact][q] = g[q];

@@ -118,6 +118,27 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   return v;
 }
 
+// Three independent wave sums at once, as hand-placed v_add_f32_dpp (one instruction per step and value: hipcc's
+// DPP-combine leaves most update_dpp + add pairs un-fused, doubling the instruction count of the reduction).
+// A VALU write -> DPP read of the same VGPR needs 2 wait states on gfx9-family parts: inside the statement the
+// three chains are interleaved, so each value's next step is exactly two instructions after its previous one; the
+// leading s_nop covers values produced by compiler code just before the statement.  Totals land in lane 63.
+#define SKGS_DPP3_STEP(CTRL)                                   \
+  "v_add_f32_dpp %0, %0, %0 " CTRL "\n\t"                      \
+  "v_add_f32_dpp %1, %1, %1 " CTRL "\n\t"                      \
+  "v_add_f32_dpp %2, %2, %2 " CTRL "\n\t"
+__device__ __forceinline__ void wave_sum3_to_lane63(float& a, float& b, float& c) {
+  asm volatile("s_nop 1\n\t"
+      SKGS_DPP3_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+      SKGS_DPP3_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+      SKGS_DPP3_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+      SKGS_DPP3_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+      SKGS_DPP3_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+      SKGS_DPP3_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+      "s_nop 0"
+      : "+v"(a), "+v"(b), "+v"(c));
+}
+
 // Tile rectangle of a splat (reference getRect, gaussian_render.h:42-47). Used by the preprocess AND the scatter
 // kernel: both must produce the identical rectangle.  No multiply feeds an add here, so FMA contraction settings
 // of the including file cannot change the result.

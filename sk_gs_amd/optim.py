@@ -1,0 +1,79 @@
+"""Fused multi-tensor Adam (scope row (f)-2): every parameter of every group is updated by ONE kernel launch
+(csrc/adam.hip) instead of torch's per-group ``multi_tensor_apply`` launches.
+
+Semantics = ``torch.optim.Adam(params, betas, eps, amsgrad=False, weight_decay=0)`` as the reference configures it
+(exps/default.yaml:122-125: eps 1e-15, betas (0.9, 0.999); per-group learning rates networks/gaussian_splatting.py:
+443-453).  The step counter and the descriptor table live on the device, so ``step()`` is hipGraph-capturable;
+learning-rate changes (``update_learning_rate``, gaussian_splatting.py:455-465) are pushed with ``set_lr`` outside
+the graph.
+"""
+import ctypes as C
+import struct
+from typing import Iterable, List
+
+import torch
+
+from sk_gs_amd import _C
+
+
+class FusedAdam:
+    def __init__(self, param_groups: Iterable[dict], betas=(0.9, 0.999), eps: float = 1e-15):
+        lib = _C.load_library()
+        lib.skgs_adam_chunk_elems.restype = C.c_int64
+        lib.skgs_adam_tensor_bytes.restype = C.c_size_t
+        self.param_groups: List[dict] = [dict(g) for g in param_groups]
+        self.betas, self.eps = betas, eps
+        self._chunk = int(lib.skgs_adam_chunk_elems())
+        assert int(lib.skgs_adam_tensor_bytes()) == 56
+        self.params, self._lr_index = [], []
+        for gi, g in enumerate(self.param_groups):
+            g['params'] = [p for p in g['params']]
+            for p in g['params']:
+                if p.requires_grad:
+                    assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+                    self.params.append(p)
+                    self._lr_index.append(gi)
+        dev = self.params[0].device
+        self.state = {p: dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p)) for p in self.params}
+        self.step_count = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._table = torch.zeros(len(self.params) * 56, dtype=torch.uint8, device=dev)
+        self._total_chunks = 0
+        self._bound_grads = None
+        self._upload()
+
+    # ---------------------------------------------------------------------------------------------------------
+    def _upload(self):
+        """(re)build the device descriptor table; must run outside graph capture (H2D copy)"""
+        blob, chunk0 = bytearray(), 0
+        grads = []
+        for p, gi in zip(self.params, self._lr_index):
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            st = self.state[p]
+            n = p.numel()
+            blob += struct.pack('<QQQQqqff', p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(),
+                                st['exp_avg_sq'].data_ptr(), n, chunk0, float(self.param_groups[gi]['lr']), 0.0)
+            chunk0 += (n + self._chunk - 1) // self._chunk
+            grads.append(p.grad.data_ptr())
+        self._total_chunks = chunk0
+        self._bound_grads = grads
+        self._table.copy_(torch.frombuffer(bytes(blob), dtype=torch.uint8))
+
+    def set_lr(self, group_index: int, lr: float):
+        self.param_groups[group_index]['lr'] = lr
+        self._upload()
+
+    def zero_grad(self, set_to_none: bool = False):
+        for p in self.params:
+            if p.grad is not None:
+                p.grad.zero_()
+
+    def step(self):
+        if not torch.cuda.is_current_stream_capturing():
+            # the table holds raw gradient pointers: refresh it if autograd replaced a .grad tensor
+            if any(p.grad is None or p.grad.data_ptr() != g for p, g in zip(self.params, self._bound_grads)):
+                self._upload()
+        lib = _C.load_library()
+        _C._check(lib.skgs_adam_step(C.c_int32(len(self.params)), C.c_void_p(self._table.data_ptr()),
+                                     C.c_int64(self._total_chunks), C.c_double(self.betas[0]), C.c_double(self.betas[1]),
+                                     C.c_double(self.eps), C.c_void_p(self.step_count.data_ptr()), _C._stream()))
