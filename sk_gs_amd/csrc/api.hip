@@ -133,7 +133,7 @@ int skgs_rasterize_forward_stage1(const skgs_raster_inputs* in, const skgs_raste
   GeomView g    = geom_view(buf->geom);
   ImgView im    = img_view(buf->img, in->image_width, in->image_height);
   if (launch_preprocess_forward(*in, g, im, radii, s)) return 1;
-  if (launch_scan_tiles(g, im, 0, s)) return 1;
+  if (launch_scan_tiles(g, im, in->P, s)) return 1;
   if (host_num_rendered)
     SKGS_CHECK_HIP(hipMemcpyAsync(host_num_rendered, &g.hdr->num_rendered, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   return 0;

@@ -64,12 +64,35 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(int T, const u
   }
 }
 
-// One lane per Gaussian: write (depth_bits<<32 | id) into every touched tile's range.
+// Tile counting and scatter: LPG lanes per Gaussian.  A Gaussian touches ~5 tiles on average but the loops of a
+// one-lane-per-Gaussian kernel are serial chains of (returning) atomics on a grid of only ~1.5 waves per SIMD, i.e.
+// pure latency (measured: 84 us for 5e5 atomics).  With 16 lanes per Gaussian every (Gaussian, tile) pair is its own
+// lane, all atomics of a wave are in flight together and there are 16x more waves to hide their latency.
+constexpr int LPG = 16;
+
+// Adds 1 to tile_counts[t] for every tile the splat's rectangle covers.
+__global__ void __launch_bounds__(256) count_tiles_kernel(int P, int gx, int gy, const float4* __restrict__ recs,
+    uint32_t* __restrict__ tile_counts) {
+  const int64_t tid = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  const int idx     = (int) (tid / LPG);
+  if (idx >= P) return;
+  const float4 r2  = recs[3 * idx + 2];
+  const int radius = __float_as_int(r2.z);
+  if (radius <= 0) return;
+  const float4 r0 = recs[3 * idx];
+  int mn[2], mx[2];
+  tile_rect(r0.x, r0.y, radius, gx, gy, mn, mx);
+  const int w = mx[0] - mn[0], n = w * (mx[1] - mn[1]);
+  for (int k = (int) (tid % LPG); k < n; k += LPG) atomicAdd(&tile_counts[(mn[1] + k / w) * gx + mn[0] + k % w], 1u);
+}
+
+// Writes (depth_bits<<32 | id) into every touched tile's range.
 __global__ void __launch_bounds__(256) scatter_kernel(int P, int gx, int gy, const float4* __restrict__ recs,
     const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursors, uint64_t* __restrict__ keys, int64_t capacity,
     GeomHeader* hdr) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx == 0 && (int64_t) hdr->num_rendered > capacity) hdr->overflow = 1;
+  const int64_t tid = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid == 0 && (int64_t) hdr->num_rendered > capacity) hdr->overflow = 1;
+  const int idx = (int) (tid / LPG);
   if (idx >= P) return;
   const float4 r2  = recs[3 * idx + 2];
   const int radius = __float_as_int(r2.z);
@@ -78,12 +101,91 @@ __global__ void __launch_bounds__(256) scatter_kernel(int P, int gx, int gy, con
   int mn[2], mx[2];
   tile_rect(r0.x, r0.y, radius, gx, gy, mn, mx);
   const uint64_t key = ((uint64_t) __float_as_uint(r2.y) << 32) | (uint32_t) idx;
-  for (int y = mn[1]; y < mx[1]; ++y)
-    for (int x = mn[0]; x < mx[0]; ++x) {
-      const int t        = y * gx + x;
-      const uint32_t pos = offsets[t] + atomicAdd(&cursors[t], 1u);
+  const int w = mx[0] - mn[0], n = w * (mx[1] - mn[1]);
+  for (int k = (int) (tid % LPG); k < n; k += LPG) {
+    const int t        = (mn[1] + k / w) * gx + mn[0] + k % w;
+    const uint32_t pos = offsets[t] + atomicAdd(&cursors[t], 1u);
+    if ((int64_t) pos < capacity) keys[pos] = key;
+  }
+}
+
+// LDS-privatised variants (T <= BIN_LDS_TILES).  Device-scope atomics execute at the memory side on MI355X (the
+// per-XCD L2s are not coherent): 5e5 scattered single-dword atomics cost ~45 us whatever the launch shape.  Here a few
+// large workgroups histogram their share of the (Gaussian, tile) pairs in LDS (ds_add is ~1 lane/clk) and touch global
+// memory once per non-empty bin: ~BIN_GROUPS x T global atomics instead of R.
+constexpr int BIN_LDS_TILES = 8192;
+constexpr int BIN_THREADS   = 1024;
+constexpr int BIN_GROUPS    = 48;
+
+__device__ __forceinline__ bool splat_rect(const float4* __restrict__ recs, int idx, int gx, int gy, int* mn, int& w, int& n,
+    uint32_t& depth_bits) {
+  const float4 r2  = recs[3 * idx + 2];
+  const int radius = __float_as_int(r2.z);
+  if (radius <= 0) return false;
+  const float4 r0 = recs[3 * idx];
+  int mx[2];
+  tile_rect(r0.x, r0.y, radius, gx, gy, mn, mx);
+  w          = mx[0] - mn[0];
+  n          = w * (mx[1] - mn[1]);
+  depth_bits = __float_as_uint(r2.y);
+  return n > 0;
+}
+
+__global__ void __launch_bounds__(BIN_THREADS) count_tiles_lds_kernel(int P, int gx, int gy, int T,
+    const float4* __restrict__ recs, uint32_t* __restrict__ tile_counts) {
+  extern __shared__ uint32_t s_cnt[];  // [T]
+  for (int i = threadIdx.x; i < T; i += BIN_THREADS) s_cnt[i] = 0;
+  __syncthreads();
+  const int64_t lanes = (int64_t) P * LPG;
+  for (int64_t tid = (int64_t) blockIdx.x * BIN_THREADS + threadIdx.x; tid < lanes; tid += (int64_t) gridDim.x * BIN_THREADS) {
+    int mn[2], w, n;
+    uint32_t db;
+    if (!splat_rect(recs, (int) (tid / LPG), gx, gy, mn, w, n, db)) continue;
+    for (int k = (int) (tid % LPG); k < n; k += LPG) atomicAdd(&s_cnt[(mn[1] + k / w) * gx + mn[0] + k % w], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < T; i += BIN_THREADS) {
+    const uint32_t c = s_cnt[i];
+    if (c) atomicAdd(&tile_counts[i], c);
+  }
+}
+
+__global__ void __launch_bounds__(BIN_THREADS) scatter_lds_kernel(int P, int gx, int gy, int T, const float4* __restrict__ recs,
+    const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursors, uint64_t* __restrict__ keys, int64_t capacity,
+    GeomHeader* hdr) {
+  extern __shared__ uint32_t s_mem[];
+  uint32_t* s_cnt  = s_mem;      // [T] entries of this workgroup per tile, then the running local rank
+  uint32_t* s_base = s_mem + T;  // [T] offsets[t] + slots reserved for this workgroup
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (int64_t) hdr->num_rendered > capacity) hdr->overflow = 1;
+  for (int i = threadIdx.x; i < T; i += BIN_THREADS) s_cnt[i] = 0;
+  __syncthreads();
+  const int64_t lanes  = (int64_t) P * LPG;
+  const int64_t stride = (int64_t) gridDim.x * BIN_THREADS;
+  for (int64_t tid = (int64_t) blockIdx.x * BIN_THREADS + threadIdx.x; tid < lanes; tid += stride) {
+    int mn[2], w, n;
+    uint32_t db;
+    if (!splat_rect(recs, (int) (tid / LPG), gx, gy, mn, w, n, db)) continue;
+    for (int k = (int) (tid % LPG); k < n; k += LPG) atomicAdd(&s_cnt[(mn[1] + k / w) * gx + mn[0] + k % w], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < T; i += BIN_THREADS) {
+    const uint32_t c = s_cnt[i];
+    s_base[i]        = c ? offsets[i] + atomicAdd(&cursors[i], c) : 0u;
+    s_cnt[i]         = 0;
+  }
+  __syncthreads();
+  for (int64_t tid = (int64_t) blockIdx.x * BIN_THREADS + threadIdx.x; tid < lanes; tid += stride) {
+    int mn[2], w, n;
+    uint32_t db;
+    const int idx = (int) (tid / LPG);
+    if (!splat_rect(recs, idx, gx, gy, mn, w, n, db)) continue;
+    const uint64_t key = ((uint64_t) db << 32) | (uint32_t) idx;
+    for (int k = (int) (tid % LPG); k < n; k += LPG) {
+      const int t        = (mn[1] + k / w) * gx + mn[0] + k % w;
+      const uint32_t pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
       if ((int64_t) pos < capacity) keys[pos] = key;
     }
+  }
 }
 
 // Per-tile sort. Ascending-only bitonic network with virtual +inf padding (works for any length).
@@ -147,8 +249,18 @@ __global__ void __launch_bounds__(SORT_THREADS) tile_sort_kernel(int T, const ui
 
 }  // namespace
 
-int launch_scan_tiles(GeomView g, ImgView im, int64_t /*capacity_hint*/, hipStream_t s) {
+int launch_scan_tiles(GeomView g, ImgView im, int64_t P, hipStream_t s) {
   ProfScope prof(K_SCAN, s);
+  if (P > 0) {
+    const int64_t lanes = P * LPG;
+    if (im.T <= BIN_LDS_TILES)
+      hipLaunchKernelGGL(count_tiles_lds_kernel, dim3(BIN_GROUPS), dim3(BIN_THREADS), (size_t) im.T * 4, s, (int) P,
+          im.tiles_x, im.tiles_y, im.T, g.recs, im.tile_counts);
+    else
+      hipLaunchKernelGGL(count_tiles_kernel, dim3((unsigned) ((lanes + 255) / 256)), dim3(256), 0, s, (int) P, im.tiles_x,
+          im.tiles_y, g.recs, im.tile_counts);
+    SKGS_CHECK_HIP(hipGetLastError());
+  }
   hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, im.T, im.tile_counts, im.tile_offsets,
       im.cursors, g.hdr);
   SKGS_CHECK_HIP(hipGetLastError());
@@ -160,8 +272,13 @@ int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, Bi
   if (P == 0) return 0;
   {
     ProfScope prof(K_SCATTER, s);
-    hipLaunchKernelGGL(scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, im.tiles_x, im.tiles_y, g.recs,
-        im.tile_offsets, im.cursors, b.keys, b.capacity, g.hdr);
+    const int64_t lanes = (int64_t) P * LPG;
+    if (im.T <= BIN_LDS_TILES)
+      hipLaunchKernelGGL(scatter_lds_kernel, dim3(BIN_GROUPS), dim3(BIN_THREADS), (size_t) im.T * 8, s, P, im.tiles_x,
+          im.tiles_y, im.T, g.recs, im.tile_offsets, im.cursors, b.keys, b.capacity, g.hdr);
+    else
+      hipLaunchKernelGGL(scatter_kernel, dim3((unsigned) ((lanes + 255) / 256)), dim3(256), 0, s, P, im.tiles_x, im.tiles_y,
+          g.recs, im.tile_offsets, im.cursors, b.keys, b.capacity, g.hdr);
   }
   SKGS_CHECK_HIP(hipGetLastError());
   {

@@ -7,6 +7,8 @@
 //   Backward scatter-adds bone gradients into an LDS copy of the bone table (ds_add_f32) and flushes it with one
 //   global atomic per (bone, component, workgroup).
 // HBM-bound: ~(88 + 12K) B per Gaussian forward, arithmetic in the oracle's order without contraction.
+#include <algorithm>
+
 #include "skgs_common.h"
 
 #pragma clang fp contract(off)
@@ -16,6 +18,7 @@ namespace {
 
 constexpr int DEFORM_THREADS = 256;
 constexpr int BONE_F         = 14;    // qx qy qz qw tx ty tz | drot[4] | dscale[3]
+constexpr int PREF_K         = 8;     // neighbour slots prefetched into registers (K is 5 in every shipped config)
 constexpr int MAX_LDS_BONES  = 1024;  // 56 KB of dynamic LDS (backward keeps a gradient copy too: 512 bones)
 
 __device__ __forceinline__ void load_bone(const float* T7, const float* drot, const float* dscale, int j, float* b) {
@@ -97,22 +100,32 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_kernel(int P, 
     const float* __restrict__ g_scales, const float* __restrict__ g_rotations, const float* __restrict__ g_opacity,
     float* __restrict__ g_weights, float* __restrict__ g_bone_T, float* __restrict__ g_bone_drot,
     float* __restrict__ g_bone_dscale, float* __restrict__ g_xyz, float* __restrict__ g_log_scale,
-    float* __restrict__ g_rot, float* __restrict__ g_opacity_logit) {
+    float* __restrict__ g_rot, float* __restrict__ g_opacity_logit, int ncopy) {
   extern __shared__ float s_mem[];
   float* s_bones = s_mem;                                   // [M][14] (LDS_BONES only)
-  float* s_grad  = s_mem + (LDS_BONES ? M * BONE_F : 0);    // [M][14] (LDS_BONES only)
+  float* s_grad  = s_mem + (LDS_BONES ? M * BONE_F : 0);    // [ncopy][M][14] (LDS_BONES only)
+  // With few bones, neighbouring lanes hit the same LDS row and ds_add_f32 serialises per conflicting lane (measured
+  // ~5 cycles per lane-atomic at M = 20).  ncopy (power of two) private copies of the table, chosen by lane id, cut the
+  // conflict degree by ncopy; they are summed at the flush.
+  float* s_my = s_grad + (size_t) (threadIdx.x & (ncopy - 1)) * M * BONE_F;
   if (LDS_BONES) {
     for (int j = threadIdx.x; j < M; j += DEFORM_THREADS) load_bone(bone_T, bone_drot, bone_dscale, j, s_bones + j * BONE_F);
-    for (int i = threadIdx.x; i < M * BONE_F; i += DEFORM_THREADS) s_grad[i] = 0.f;
+    for (int i = threadIdx.x; i < ncopy * M * BONE_F; i += DEFORM_THREADS) s_grad[i] = 0.f;
     __syncthreads();
   }
-  const int n = blockIdx.x * DEFORM_THREADS + threadIdx.x;
-  if (n < P) {
+  for (int n = blockIdx.x * DEFORM_THREADS + threadIdx.x; n < P; n += gridDim.x * DEFORM_THREADS) {
     const float p[3] = {points[3 * n], points[3 * n + 1], points[3 * n + 2]};
+    // All neighbour ids / weights are fetched up front (static registers, loads in flight together): with ~1.5 waves
+    // per SIMD at P = 1e5 a load-use chain per k was pure HBM latency (measured 30 us for this loop alone).
+    int jj[PREF_K];
+    float ww[PREF_K];
+#pragma unroll
+    for (int k = 0; k < PREF_K; ++k) {
+      jj[k] = k < K ? (int) indices[(size_t) n * K + k] : 0;
+      ww[k] = k < K ? weights[(size_t) n * K + k] : 0.f;
+    }
     float sr[4] = {0, 0, 0, 0};
-    for (int k = 0; k < K; ++k) {
-      const int j   = (int) indices[(size_t) n * K + k];
-      const float w = weights[(size_t) n * K + k];
+    auto acc_sr = [&](int j, float w) {
       if (LDS_BONES) {
         const float* b = s_bones + j * BONE_F;
         sr[0] += b[7] * w, sr[1] += b[8] * w, sr[2] += b[9] * w, sr[3] += b[10] * w;
@@ -120,7 +133,11 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_kernel(int P, 
         sr[0] += bone_drot[4 * j] * w, sr[1] += bone_drot[4 * j + 1] * w, sr[2] += bone_drot[4 * j + 2] * w,
             sr[3] += bone_drot[4 * j + 3] * w;
       }
-    }
+    };
+#pragma unroll
+    for (int k = 0; k < PREF_K; ++k)
+      if (k < K) acc_sr(jj[k], ww[k]);
+    for (int k = PREF_K; k < K; ++k) acc_sr((int) indices[(size_t) n * K + k], weights[(size_t) n * K + k]);
     const float4 r4  = reinterpret_cast<const float4*>(rot)[n];
     const float4 gr4 = reinterpret_cast<const float4*>(g_rotations)[n];
     const float v[4] = {r4.x + sr[0], r4.y + sr[1], r4.z + sr[2], r4.w + sr[3]};
@@ -146,9 +163,7 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_kernel(int P, 
     reinterpret_cast<float4*>(g_rot)[n] = make_float4(g_v[0], g_v[1], g_v[2], g_v[3]);
     const float sg     = 1.0f / (1.0f + expf(-opacity_logit[n]));
     g_opacity_logit[n] = g_opacity[n] * sg * (1.0f - sg);
-    for (int k = 0; k < K; ++k) {
-      const int j   = (int) indices[(size_t) n * K + k];
-      const float w = weights[(size_t) n * K + k];
+    auto bone_body = [&](int k, int j, float w) {
       float bl[BONE_F];
       const float* b;
       if (LDS_BONES) {
@@ -190,7 +205,7 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_kernel(int P, 
       for (int c = 0; c < 3; ++c) out[11 + c] = w * g_ds[c];
       if (LDS_BONES) {
 #pragma unroll
-        for (int c = 0; c < BONE_F; ++c) atomicAdd(&s_grad[j * BONE_F + c], out[c]);
+        for (int c = 0; c < BONE_F; ++c) atomicAdd(&s_my[j * BONE_F + c], out[c]);
       } else {
 #pragma unroll
         for (int c = 0; c < 7; ++c) atomicAdd(&g_bone_T[7 * j + c], out[c]);
@@ -199,12 +214,17 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_kernel(int P, 
 #pragma unroll
         for (int c = 0; c < 3; ++c) atomicAdd(&g_bone_dscale[3 * j + c], out[11 + c]);
       }
-    }
+    };
+#pragma unroll
+    for (int k = 0; k < PREF_K; ++k)
+      if (k < K) bone_body(k, jj[k], ww[k]);
+    for (int k = PREF_K; k < K; ++k) bone_body(k, (int) indices[(size_t) n * K + k], weights[(size_t) n * K + k]);
   }
   if (LDS_BONES) {
     __syncthreads();
     for (int i = threadIdx.x; i < M * BONE_F; i += DEFORM_THREADS) {
-      const float val = s_grad[i];
+      float val = 0.f;
+      for (int cpy = 0; cpy < ncopy; ++cpy) val += s_grad[(size_t) cpy * M * BONE_F + i];
       if (val != 0.f) {
         const int j = i / BONE_F, c = i % BONE_F;
         if (c < 7)
@@ -220,6 +240,8 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_kernel(int P, 
 
 // K nearest bones (squared L2, ascending, ties -> lower index). joints staged in LDS.
 constexpr int KNN_MAXK = 16;
+// KCAP = compile-time capacity of the per-lane top-K list (>= K): the insertion network is KCAP steps per bone
+template <int KCAP>
 __global__ void __launch_bounds__(256) knn_bones_kernel(int P, int M, int K, int dim, const float* __restrict__ points,
     const float* __restrict__ joints, float* __restrict__ out_dist, int64_t* __restrict__ out_idx, int lds_joints) {
   extern __shared__ float s_j[];
@@ -230,23 +252,30 @@ __global__ void __launch_bounds__(256) knn_bones_kernel(int P, int M, int K, int
   const float* jt = lds_joints ? s_j : joints;
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= P) return;
-  float bd[KNN_MAXK];
-  int bi[KNN_MAXK];
+  float bd[KCAP];
+  int bi[KCAP];
 #pragma unroll
-  for (int k = 0; k < KNN_MAXK; ++k) bd[k] = __builtin_inff(), bi[k] = -1;
-  float pt[16];
-  for (int c = 0; c < dim && c < 16; ++c) pt[c] = points[(size_t) n * dim + c];
+  for (int k = 0; k < KCAP; ++k) bd[k] = __builtin_inff(), bi[k] = -1;
+  const float* pn = points + (size_t) n * dim;
+  const float p0 = pn[0], p1 = dim > 1 ? pn[1] : 0.f, p2 = dim > 2 ? pn[2] : 0.f;
   for (int j = 0; j < M; ++j) {
     float d = 0.f;
-    for (int c = 0; c < dim; ++c) {
-      const float df = (c < 16 ? pt[c] : points[(size_t) n * dim + c]) - jt[(size_t) j * dim + c];
-      d += df * df;
+    if (dim == 3) {  // the sk stage: xyz only (no runtime-indexed per-thread array: those live in scratch memory)
+      const float d0 = p0 - jt[3 * j], d1 = p1 - jt[3 * j + 1], d2 = p2 - jt[3 * j + 2];
+      d += d0 * d0;
+      d += d1 * d1;
+      d += d2 * d2;
+    } else {
+      for (int c = 0; c < dim; ++c) {
+        const float df = pn[c] - jt[(size_t) j * dim + c];
+        d += df * df;
+      }
     }
     // insert (d, j) keeping ascending order; equal distances stay behind earlier (lower) indices
     float cd = d;
     int ci   = j;
 #pragma unroll
-    for (int k = 0; k < KNN_MAXK; ++k) {
+    for (int k = 0; k < KCAP; ++k) {
       if (k < K && cd < bd[k]) {
         const float td = bd[k];
         const int ti   = bi[k];
@@ -256,7 +285,7 @@ __global__ void __launch_bounds__(256) knn_bones_kernel(int P, int M, int K, int
     }
   }
 #pragma unroll
-  for (int k = 0; k < KNN_MAXK; ++k)
+  for (int k = 0; k < KCAP; ++k)
     if (k < K) {
       out_dist[(size_t) n * K + k] = bi[k] >= 0 ? bd[k] : 0.f;
       out_idx[(size_t) n * K + k]  = bi[k];
@@ -288,16 +317,20 @@ int launch_deform_backward(const skgs_deform_inputs& in, const float* g_means, c
   if (in.P == 0) return 0;
   ProfScope prof(K_DEFORM_BWD, s);
   dim3 grid((in.P + DEFORM_THREADS - 1) / DEFORM_THREADS), block(DEFORM_THREADS);
-  if (in.M <= MAX_LDS_BONES / 2)
-    hipLaunchKernelGGL(deform_backward_kernel<true>, grid, block, (size_t) in.M * BONE_F * 4 * 2, s, in.P, in.K, in.M,
-        in.points, in.weights, in.indices, in.bone_T, in.bone_drot, in.bone_dscale, in.log_scale, in.rot, in.opacity_logit,
-        g_means, g_scales, g_rotations, g_opacity, g_weights, g_bone_T, g_bone_drot, g_bone_dscale, g_xyz, g_log_scale,
-        g_rot, g_opacity_logit);
-  else
+  if (in.M <= MAX_LDS_BONES / 2) {
+    const size_t table = (size_t) in.M * BONE_F * 4;
+    int ncopy = 1;
+    while (ncopy < 16 && table * (1 + 2 * ncopy) <= 56 * 1024) ncopy *= 2;
+    hipLaunchKernelGGL(deform_backward_kernel<true>, grid, block, table * (1 + ncopy), s, in.P, in.K, in.M, in.points,
+        in.weights, in.indices, in.bone_T, in.bone_drot, in.bone_dscale, in.log_scale, in.rot, in.opacity_logit, g_means,
+        g_scales, g_rotations, g_opacity, g_weights, g_bone_T, g_bone_drot, g_bone_dscale, g_xyz, g_log_scale, g_rot,
+        g_opacity_logit, ncopy);
+  } else {
     hipLaunchKernelGGL(deform_backward_kernel<false>, grid, block, 0, s, in.P, in.K, in.M, in.points, in.weights,
         in.indices, in.bone_T, in.bone_drot, in.bone_dscale, in.log_scale, in.rot, in.opacity_logit, g_means, g_scales,
         g_rotations, g_opacity, g_weights, g_bone_T, g_bone_drot, g_bone_dscale, g_xyz, g_log_scale, g_rot,
-        g_opacity_logit);
+        g_opacity_logit, 1);
+  }
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -309,8 +342,16 @@ int launch_knn_bones(int P, int M, int K, int dim, const float* points, const fl
   const size_t lds = (size_t) M * dim * 4;
   const int use_lds = lds <= 48 * 1024;
   ProfScope prof(K_KNN, s);
-  hipLaunchKernelGGL(knn_bones_kernel, dim3((P + 255) / 256), dim3(256), use_lds ? lds : 0, s, P, M, K, dim, points, joints,
-      out_dist, out_idx, use_lds);
+#define SKGS_KNN(KCAP_)                                                                                                  \
+  hipLaunchKernelGGL(knn_bones_kernel<KCAP_>, dim3((P + 255) / 256), dim3(256), use_lds ? lds : 0, s, P, M, K, dim, points, \
+      joints, out_dist, out_idx, use_lds)
+  if (K <= 4)
+    SKGS_KNN(4);
+  else if (K <= 8)
+    SKGS_KNN(8);
+  else
+    SKGS_KNN(KNN_MAXK);
+#undef SKGS_KNN
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

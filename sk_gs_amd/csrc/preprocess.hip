@@ -322,9 +322,7 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(int P, int D, i
   recs[3 * idx + 0] = r0;
   recs[3 * idx + 1] = r1;
   recs[3 * idx + 2] = r2;
-  // per-tile instance counts (replaces the reference's per-Gaussian InclusiveSum: offsets are per TILE here)
-  for (int y = mn[1]; y < mx[1] && tiles; ++y)
-    for (int x = mn[0]; x < mx[0]; ++x) atomicAdd(&tile_counts[y * gx + x], 1u);
+  // (per-tile instance counts are accumulated by binning.hip::count_tiles_kernel, 16 lanes per Gaussian)
 }
 
 // ------------------------------------------------------------------------------------------------ backward

@@ -191,7 +191,7 @@ int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const i
     const skgs_raster_grads& gr, hipStream_t s);
 int launch_mark_visible(int P, const float* means, const float* view, int colmap, uint8_t* present, hipStream_t s);
 // binning.hip
-int launch_scan_tiles(GeomView g, ImgView im, int64_t capacity_hint, hipStream_t s);
+int launch_scan_tiles(GeomView g, ImgView im, int64_t P, hipStream_t s);  // count tiles (16 lanes / Gaussian) + scan
 int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, BinView b, hipStream_t s);
 // render.hip
 int launch_render_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, BinView b, float* out_color,
