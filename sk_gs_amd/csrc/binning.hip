@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) count_tiles_kernel(int P, int gx, int gy,
   const int idx     = (int) (tid / LPG);
   if (idx >= P) return;
   const float4 r2  = recs[3 * idx + 2];
-  const int radius = __float_as_int(r2.z);
+  const int radius = __float_as_int(r2.z) & 0x0fffffff;
   if (radius <= 0) return;
   const float4 r0 = recs[3 * idx];
   int mn[2], mx[2];
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256) scatter_kernel(int P, int gx, int gy, con
   const int idx = (int) (tid / LPG);
   if (idx >= P) return;
   const float4 r2  = recs[3 * idx + 2];
-  const int radius = __float_as_int(r2.z);
+  const int radius = __float_as_int(r2.z) & 0x0fffffff;
   if (radius <= 0) return;
   const float4 r0 = recs[3 * idx];
   int mn[2], mx[2];
@@ -120,7 +120,7 @@ constexpr int BIN_GROUPS    = 48;
 __device__ __forceinline__ bool splat_rect(const float4* __restrict__ recs, int idx, int gx, int gy, int* mn, int& w, int& n,
     uint32_t& depth_bits) {
   const float4 r2  = recs[3 * idx + 2];
-  const int radius = __float_as_int(r2.z);
+  const int radius = __float_as_int(r2.z) & 0x0fffffff;
   if (radius <= 0) return false;
   const float4 r0 = recs[3 * idx];
   int mx[2];

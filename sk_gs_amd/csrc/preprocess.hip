@@ -314,7 +314,14 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(int P, int D, i
         tiles  = area;
         r0     = make_float4(pix[0], pix[1], conic[0], conic[1]);
         r1     = make_float4(conic[2], opacities[idx], rgb[0], rgb[1]);
-        r2     = make_float4(rgb[2], pv[2], __int_as_float(radius), __uint_as_float(tiles | (clamp_bits << 29)));
+        // Squared pixel radius outside which alpha = min(0.99, o * exp(power)) < 1/255 for certain:
+        //   alpha >= 1/255  <=>  d^T Q d <= 2 ln(255 o)  and  d^T Q d >= |d|^2 / lambda_max(cov)
+        // (lambda1 >= the true largest eigenvalue because of the max(0.1, .) under the root).  The blend kernels skip a
+        // splat for a whole wave when its centre is farther than this from the wave's pixel rectangle -- the pairs
+        // skipped are exactly pairs the reference `continue`s on.  +1 % margin for fp32 rounding of either side.
+        const float o255  = 255.0f * opacities[idx];
+        const float rcut2 = o255 > 1.0f ? 2.02f * logf(o255) * fmaxf(lambda1, lambda2) + 0.25f : -1.0f;
+        r2 = make_float4(rgb[2], pv[2], __int_as_float(radius | (int) (clamp_bits << 28)), rcut2);
       }
     }
   }
@@ -593,7 +600,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(int P, int D, 
     }
     // ---- SH (part 3: +=) ----
     if (shs) {
-      const uint32_t clamp_bits = __float_as_uint(recs[3 * idx + 2].w) >> 29;
+      const uint32_t clamp_bits = (__float_as_uint(recs[3 * idx + 2].z) >> 28) & 7u;
       float dm[3];
       sh_backward(D, M, p, cam.campos, shs + (size_t) idx * M * 3, clamp_bits, gcol, gsh_row, dm);
       gmean[0] += dm[0], gmean[1] += dm[1], gmean[2] += dm[2];

@@ -51,6 +51,31 @@ __device__ __forceinline__ Pix<PPL> pixel_setup(int tile, int sub, int lane, int
   return p;
 }
 
+// Pixel rectangle (inclusive, pixel-centre coordinates) covered by one wave: PPL 8x8 quadrants of a 16x16 tile.
+struct WaveRect {
+  float x0, y0, x1, y1;
+};
+template <int PPL>
+__device__ __forceinline__ WaveRect wave_rect(int tile, int sub, int gx) {
+  const int tx = (tile % gx) * TILE, ty = (tile / gx) * TILE;
+  WaveRect r;
+  if (PPL == 4) {
+    r.x0 = (float) tx, r.y0 = (float) ty, r.x1 = (float) (tx + 15), r.y1 = (float) (ty + 15);
+  } else if (PPL == 2) {  // quadrants 2*sub, 2*sub+1: one 16x8 strip
+    r.x0 = (float) tx, r.y0 = (float) (ty + sub * 8), r.x1 = (float) (tx + 15), r.y1 = (float) (ty + sub * 8 + 7);
+  } else {
+    r.x0 = (float) (tx + (sub & 1) * 8), r.y0 = (float) (ty + (sub >> 1) * 8);
+    r.x1 = r.x0 + 7.f, r.y1 = r.y0 + 7.f;
+  }
+  return r;
+}
+// false only if NO pixel of the rectangle can get alpha >= 1/255 from this splat (rcut2: preprocess.hip)
+__device__ __forceinline__ bool splat_reaches_rect(float cx, float cy, float rcut2, const WaveRect& r) {
+  const float dx = fmaxf(fmaxf(r.x0 - cx, cx - r.x1), 0.f);
+  const float dy = fmaxf(fmaxf(r.y0 - cy, cy - r.y1), 0.f);
+  return dx * dx + dy * dy <= rcut2;
+}
+
 // Reproducible exp for the strict (parity) build: every step is an IEEE double multiply or add, written one
 // operation per statement and compiled without contraction, so the CPU oracle (exp_mode = 1) gets the same bits.
 __device__ __forceinline__ float skgs_exp_strict(float x) {

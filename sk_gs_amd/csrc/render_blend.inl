@@ -34,6 +34,7 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
 
   const int64_t start = offsets[tile];
   const int64_t end   = min<int64_t>((int64_t) offsets[tile + 1], capacity);
+  const WaveRect rect = wave_rect<PPL>(tile, sub, gx);
 
   float Tr[PPL], C[PPL][3], Ex[PPL][E > 0 ? E : 1];
   uint32_t last[PPL];
@@ -53,16 +54,20 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
     if (__all(all_done)) break;
     const int n = (int) min<int64_t>(WAVE, end - base);
     __syncthreads();  // single-wave workgroup: orders the LDS reads of the previous batch before these writes
+    bool relevant = false;
     if (lane < n) {
       const uint32_t id = point_list[base + lane];
       const float4 a = recs[3 * id], b = recs[3 * id + 1], c = recs[3 * id + 2];
       s_a[lane] = a, s_b[lane] = b, s_c[lane] = c.x;
 #pragma unroll
       for (int e = 0; e < E; ++e) s_e[lane * (E > 0 ? E : 1) + e] = extra[(size_t) id * E + e];
+      relevant = splat_reaches_rect(a.x, a.y, c.w, rect);
     }
     __syncthreads();
     const uint32_t contrib0 = (uint32_t) (base - start);
-    for (int j = 0; j < n; ++j) {
+    // only the splats whose 1/255 iso-contour can reach this wave's pixel rectangle are visited (wave-uniform list)
+    for (unsigned long long todo = __ballot(relevant); todo; todo &= todo - 1) {
+      const int j    = __builtin_ctzll(todo);
       const float4 a = s_a[j];
       const float4 b = s_b[j];
       bool hit[PPL];
@@ -163,6 +168,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
   const int64_t end   = min<int64_t>((int64_t) offsets[tile + 1], capacity);
   const size_t HW     = (size_t) H * W;
 
+  const WaveRect rect = wave_rect<PPL>(tile, sub, gx);
   float T_final[PPL], Tr[PPL], dL_dT[PPL], dpix[PPL][3], dex[PPL][E > 0 ? E : 1];
   float accum[PPL][3], lastc[PPL][3], accum_e[PPL][E > 0 ? E : 1], last_e[PPL][E > 0 ? E : 1], last_alpha[PPL];
   uint32_t lastk[PPL];
@@ -197,16 +203,19 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
   for (int64_t hi = start + (int64_t) min<int64_t>(maxk, end - start); hi > start; hi -= WAVE) {
     const int n = (int) min<int64_t>(WAVE, hi - start);
     __syncthreads();
+    bool relevant = false;
     if (lane < n) {
       const uint32_t id = point_list[hi - 1 - lane];
       const float4 a = recs[3 * id], b = recs[3 * id + 1], c = recs[3 * id + 2];
       s_a[lane] = a, s_b[lane] = b, s_c[lane] = c.x, s_id[lane] = id;
 #pragma unroll
       for (int e = 0; e < E; ++e) s_e[lane * (E > 0 ? E : 1) + e] = extra[(size_t) id * E + e];
+      relevant = splat_reaches_rect(a.x, a.y, c.w, rect);
     }
     __syncthreads();
     int nact = 0;  // wave-uniform count of LDS rows in use
-    for (int j = 0; j < n; ++j) {
+    for (unsigned long long todo = __ballot(relevant); todo; todo &= todo - 1) {
+      const int j      = __builtin_ctzll(todo);
       const uint32_t k = (uint32_t) (hi - 1 - j - start);
       const float4 a = s_a[j];
       const float4 b = s_b[j];

@@ -16,7 +16,7 @@ constexpr int GRAD_ROW  = 16;         // one gradient-accumulator row = 16 float
 // [0,256)   GeomHeader
 // [256, ..) GaussRec[P]   (48 B each, 16-B aligned)
 //   f[0] x_pix  f[1] y_pix  f[2] conic.a  f[3] conic.b | f[4] conic.c  f[5] opacity  f[6] r  f[7] g |
-//   f[8] b      f[9] depth  i[10] radius  u[11] tiles_touched | clamped_bits << 29
+//   f[8] b      f[9] depth  i[10] radius | clamped_bits << 28   f[11] rcut2 (squared cut-off radius, see preprocess)
 struct GeomHeader {
   int32_t num_rendered;
   int32_t overflow;
