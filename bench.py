@@ -132,12 +132,20 @@ def main():
     ap.add_argument('--eager', action='store_true', help='issue every launch eagerly instead of replaying hipGraphs')
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: everything else that any library prints to fd 1 (RCCL's version banner,
+    # MIOpen notes) is diverted to stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     from sk_gs_amd import _C, scene
     from sk_gs_amd.losses import image_loss
     from sk_gs_amd.model import SkinnedGaussians
     from sk_gs_amd.view_parallel import ViewParallel, init_distributed
 
-    rank, world, local_rank = init_distributed()
+    # SKGS_FORCE_DIST=1: create a (1-rank) RCCL group so a single GPU exercises the multi-GPU code path
+    rank, world, local_rank = init_distributed(force=bool(os.environ.get('SKGS_FORCE_DIST')))
+    use_dist = dist.is_initialized()
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
     torch.cuda.set_device(local_rank)
@@ -184,7 +192,7 @@ def main():
         opt.step()
 
     from sk_gs_amd.train_step import GraphedSteps
-    if world == 1:  # whole step (fwd + bwd + Adam) is one graph per view
+    if not use_dist:  # whole step (fwd + bwd + Adam) is one graph per view
         g_step = GraphedSteps(lambda v: (fwd_bwd(v), opt.step()))
         g_opt = None
     else:           # the RCCL all-reduce stays between two graphs
@@ -210,25 +218,30 @@ def main():
     _C.update_capacity_hint(P, W, H, int(R_max * 1.25))
 
     eager_step(0)  # initialises optimizer state before any capture
+    if not args.eager:  # every graph exists before the timed region, whatever --warmup is
+        for v in range(args.views):
+            g_step.capture(v)
+        if g_opt is not None:
+            g_opt.capture(0)
     for i in range(args.warmup):
         train_step(i)
     torch.cuda.synchronize()
     if args.eager:
         _C.profile_enable(['render_backward'])
     _C.profile_collect()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         train_step(args.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     prof = _C.profile_collect()
     _C.profile_enable([])
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -308,8 +321,8 @@ def main():
             line['ms_per_render_fwd_bwd'] = ms_render
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg, args.cpu_seconds)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        os.write(json_fd, (json.dumps(line) + '\n').encode())
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

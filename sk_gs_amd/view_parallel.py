@@ -20,12 +20,13 @@ import torch.distributed as dist
 from torch import Tensor
 
 
-def init_distributed(backend: Optional[str] = None) -> tuple:
-    """(rank, world, local_rank) from the torchrun environment; initialises the default group when world > 1."""
+def init_distributed(backend: Optional[str] = None, force: bool = False) -> tuple:
+    """(rank, world, local_rank) from the torchrun environment; initialises the default group when world > 1
+    (or, with ``force``, even for a single rank: lets one GPU exercise the collective code path)."""
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -71,8 +72,9 @@ class ViewParallel:
     """Gradient (and densification-statistic) reduction over the ranks of the default process group."""
 
     def __init__(self, params: Iterable[Tensor], average: bool = True):
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.active = dist.is_initialized()  # collectives are issued whenever a process group exists (even world 1)
+        self.world = dist.get_world_size() if self.active else 1
+        self.rank = dist.get_rank() if self.active else 0
         self.grads = FlatGradBuffer(params)
         self.average = average
 
@@ -81,14 +83,14 @@ class ViewParallel:
         return (step * self.world + self.rank) % num_views
 
     def allreduce_grads(self, async_op: bool = False):
-        if self.world == 1:
+        if not self.active:
             return None
-        if self.average:
+        if self.average and self.world > 1:
             self.grads.flat.div_(self.world)
         return dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM, async_op=async_op)
 
     def allreduce_densify_stats(self, xyz_gradient_accum: Tensor, denom: Tensor, max_radii2D: Tensor):
-        if self.world == 1:
+        if not self.active:
             return
         packed = torch.stack([xyz_gradient_accum.view(-1).float(), denom.view(-1).float()])
         dist.all_reduce(packed, op=dist.ReduceOp.SUM)
@@ -97,7 +99,7 @@ class ViewParallel:
         dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX)
 
     def broadcast_params(self, params: Iterable[Tensor], src: int = 0):
-        if self.world == 1:
+        if not self.active:
             return
         for p in params:
             dist.broadcast(p.data, src=src)
