@@ -19,7 +19,8 @@ import torch
 from torch import Tensor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, 'libskgs_hip.so')
+# SKGS_HIP_LIB: another build of the same library (kernel experiments, tools/); there is no non-HIP implementation
+_LIB_PATH = os.environ.get('SKGS_HIP_LIB') or os.path.join(_HERE, 'libskgs_hip.so')
 _lib = None
 _lock = threading.Lock()
 

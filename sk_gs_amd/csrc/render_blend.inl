@@ -198,6 +198,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
   for (int d = 32; d > 0; d >>= 1) maxk = max(maxk, (uint32_t) __shfl_xor((int) maxk, d));
   if (maxk == 0) return;
   const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+  const int holder_q = transposed_holder_value(lane >> 3);
 
   // walk the list back to front: entry at list position k (0-based) has "contributor" index k
   for (int64_t hi = start + (int64_t) min<int64_t>(maxk, end - start); hi > start; hi -= WAVE) {
@@ -281,13 +282,14 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
         }
       }
       if (__any(any)) {
-#pragma unroll
-        for (int q = 0; q + 2 < 9; q += 3) wave_sum3_to_lane63(g[q], g[q + 1], g[q + 2]);
+        // 8 sums land one per lane in lanes 0, 8, .., 56 (one ds_write for all of them); the ninth in lane 63
+        wave_sum9_transposed(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], 0xff00ff00ff00ff00ull);
 #pragma unroll
         for (int q = 9; q < NV; ++q) g[q] = wave_sum_to_lane63(g[q]);
+        if ((lane & 7) == 0) s_acc[nact][holder_q] = g[1];
         if (lane == 63) {
 #pragma unroll
-          for (int q = 0; q < NV; ++q) s_acc[nact][q] = g[q];
+          for (int q = 8; q < NV; ++q) s_acc[nact][q] = g[q];
           s_acc_id[nact] = s_id[j];
         }
         ++nact;

@@ -139,6 +139,56 @@ __device__ __forceinline__ void wave_sum3_to_lane63(float& a, float& b, float& c
       : "+v"(a), "+v"(b), "+v"(c));
 }
 
+// Nine wave sums at once by "transposing" the reduction (gfx950: v_permlane32_swap / v_permlane16_swap).
+// Each swap+add halves the lane span of TWO values and packs them into one register, so eight values need
+// 4+2 swap/add pairs, one select pair and four DPP adds (~20 VALU) instead of 8 x 6 DPP adds.  The ninth value runs
+// the ordinary DPP chain, interleaved so that it fills the wait states the other chain needs (a VALU write followed
+// by a DPP / permlane read of the same VGPR needs 2 wait states; the compiler cannot see inside the statement).
+// All 64 lanes must be active.  On return
+//     lane 8*m (m = 0..7) of `v1` holds the total of value bitrev3(m)  (m: 0 1 2 3 4 5 6 7 -> v0 v4 v2 v6 v1 v5 v3 v7)
+//     lane 63 of `v8` holds the total of v8;  v0, v2..v7 are clobbered.
+// `m8` is the lane mask of lanes with bit 3 set (0xff00ff00ff00ff00), passed in so it lives in SGPRs across calls.
+#define SKGS_DPP_ALL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+__device__ __forceinline__ void wave_sum9_transposed(float& v0, float& v1, float& v2, float& v3, float& v4, float& v5,
+                                                     float& v6, float& v7, float& v8, unsigned long long m8) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_permlane32_swap_b32 %0, %1\n\t"
+      "v_permlane32_swap_b32 %2, %3\n\t"
+      "v_permlane32_swap_b32 %4, %5\n\t"
+      "v_permlane32_swap_b32 %6, %7\n\t"
+      "v_add_f32_dpp %8, %8, %8 row_shr:1" SKGS_DPP_ALL
+      "v_add_f32 %0, %0, %1\n\t"
+      "v_add_f32 %2, %2, %3\n\t"
+      "v_add_f32_dpp %8, %8, %8 row_shr:2" SKGS_DPP_ALL
+      "v_add_f32 %4, %4, %5\n\t"
+      "v_add_f32 %6, %6, %7\n\t"
+      "v_permlane16_swap_b32 %0, %2\n\t"
+      "v_add_f32_dpp %8, %8, %8 row_shr:4" SKGS_DPP_ALL
+      "v_permlane16_swap_b32 %4, %6\n\t"
+      "v_add_f32 %0, %0, %2\n\t"
+      "v_add_f32 %4, %4, %6\n\t"
+      "v_add_f32_dpp %8, %8, %8 row_shr:8" SKGS_DPP_ALL
+      "s_nop 0\n\t"
+      "v_cndmask_b32_e64 %1, %0, %4, %9\n\t"
+      "v_cndmask_b32_e64 %3, %4, %0, %9\n\t"
+      "v_add_f32_dpp %8, %8, %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %1, %3, %1 row_ror:8" SKGS_DPP_ALL
+      "v_add_f32_dpp %8, %8, %8 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_shl:4" SKGS_DPP_ALL
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_shl:2" SKGS_DPP_ALL
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_shl:1" SKGS_DPP_ALL
+      "s_nop 0"
+      : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8)
+      : "s"(m8));
+}
+// value index held by lane 8*m after wave_sum9_transposed
+__device__ __forceinline__ int transposed_holder_value(int m) { return ((m & 1) << 2) | (m & 2) | ((m >> 2) & 1); }
+
 // Tile rectangle of a splat (reference getRect, gaussian_render.h:42-47). Used by the preprocess AND the scatter
 // kernel: both must produce the identical rectangle.  No multiply feeds an add here, so FMA contraction settings
 // of the including file cannot change the result.

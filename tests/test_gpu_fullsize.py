@@ -1,0 +1,177 @@
+"""GPU tests at BASELINE.json's full sizes: size-independent properties of the binning and the blend, and one full-size
+parity run against the oracle (the oracle needs ~1 s per forward+backward of config #1 on the GPU box's host cores).
+
+Properties (any size):
+  * conservation: sum of per-tile counts == num_rendered == sum over Gaussians of their tile-rectangle area;
+  * every tile's list is strictly increasing in (depth bits, Gaussian id) and holds exactly the Gaussians whose
+    rectangle covers the tile (checked through a checksum of ids per tile);
+  * the forward is bitwise deterministic run to run, and identical for 1 / 2 / 4 pixels per lane;
+  * the backward is linear in the cotangent;
+  * strict and fast blend builds agree to the north-star tolerance.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close_robust, oracle_backward, oracle_forward, rel_err, scene_inputs, to_np
+from test_gpu_raster import GRAD_NAMES, hip_backward, hip_forward
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {  # BASELINE.json configs (synthetic recipe of SURVEY 8d)
+    1: dict(P=100_000, W=800, H=800),
+    2: dict(P=200_000, W=512, H=512),
+    4: dict(P=500_000, W=1024, H=1024),
+}
+
+
+def _C():
+    from sk_gs_amd import _C
+    return _C
+
+
+@pytest.mark.parametrize('cfg', [1, 2, 4])
+def test_binning_invariants_full_size(cfg):
+    c = CONFIGS[cfg]
+    P, W, H = c['P'], c['W'], c['H']
+    act, rs, cam = scene_inputs(P, W, H, seed=cfg, colmap=True, device='cuda')
+    R, color, opacity, radii, geom, binning, img, _ = hip_forward(act, rs)
+    bufs = _C().unpack_buffers(W, H, P, geom, binning, img)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    T = gx * gy
+    counts, offs = bufs['tile_counts'].long(), bufs['tile_offsets'].long()
+    assert int(counts.sum()) == R == int(offs[T]) == int(bufs['num_rendered'])
+    assert torch.equal(offs[1:] - offs[:-1], counts)
+    # rectangle areas recomputed from the records (reference getRect) must add up to R
+    recs = bufs['recs']
+    rad = (recs[:, 10].contiguous().view(torch.int32) & 0x0fffffff).float()
+    x, y = recs[:, 0], recs[:, 1]
+    vis = rad > 0
+    mnx = ((x - rad) / 16).int().clamp(0, gx)
+    mxx = ((x + rad + 16 - 1) / 16).int().clamp(0, gx)  # C evaluation order ((x + r) + 16) - 1
+    mny = ((y - rad) / 16).int().clamp(0, gy)
+    mxy = ((y + rad + 16 - 1) / 16).int().clamp(0, gy)
+    area = ((mxx - mnx) * (mxy - mny)).long() * vis.long()
+    assert int(area.sum()) == R
+    assert torch.equal(vis, radii > 0)
+    # sortedness inside every tile: keys strictly increasing except at tile boundaries
+    keys = bufs['keys'][:R]
+    inc = keys[1:] > keys[:-1]
+    boundary = torch.zeros(R - 1, dtype=torch.bool, device=keys.device)
+    b = offs[1:T][(offs[1:T] > 0) & (offs[1:T] < R)] - 1
+    boundary[b] = True
+    assert bool((inc | boundary).all())
+    # membership checksum: sum of Gaussian ids per tile == the same sum built from the rectangles
+    plist = bufs['point_list'][:R].long()
+    tile_of_entry = torch.searchsorted(offs[1:].contiguous(), torch.arange(R, device=plist.device), right=True)
+    got = torch.zeros(T, dtype=torch.long, device=plist.device).index_add_(0, tile_of_entry, plist)
+    want = torch.zeros(T, dtype=torch.long, device=plist.device)
+    ids = torch.nonzero(vis).flatten()
+    for dy in range(int((mxy - mny).max())):
+        for dx in range(int((mxx - mnx).max())):
+            m = ((mnx[ids] + dx) < mxx[ids]) & ((mny[ids] + dy) < mxy[ids])
+            t = (mny[ids] + dy) * gx + (mnx[ids] + dx)
+            want.index_add_(0, t[m].long(), ids[m])
+    assert torch.equal(got, want)
+    # low 32 bits of every key are the point list
+    assert torch.equal((keys & 0xffffffff).long(), plist)
+    # image sanity
+    assert float(opacity.min()) >= 0.0 and float(opacity.max()) <= 1.0
+    nc = bufs['n_contrib'].long()
+    tiles_len = counts.view(gy, gx).repeat_interleave(16, 0).repeat_interleave(16, 1)[:H, :W]
+    assert bool((nc <= tiles_len).all())
+
+
+def test_forward_is_deterministic_and_ppl_invariant_full_size():
+    """run-to-run bitwise determinism (both builds); the strict build is also bitwise independent of the
+    pixels-per-lane mapping (the fast build lets the compiler contract FMAs differently per mapping: <= 1e-5)"""
+    P, W, H = CONFIGS[1]['P'], CONFIGS[1]['W'], CONFIGS[1]['H']
+    act, rs, cam = scene_inputs(P, W, H, seed=0, colmap=True, device='cuda')
+    try:
+        for strict in (False, True):
+            _C().set_strict_math(strict)
+            _C().set_pixels_per_lane(0)
+            ref = hip_forward(act, rs)
+            again = hip_forward(act, rs)
+            assert torch.equal(ref[1], again[1]) and torch.equal(ref[2], again[2])
+            for ppl in (1, 2, 4):
+                _C().set_pixels_per_lane(ppl)
+                out = hip_forward(act, rs)
+                if strict:
+                    assert torch.equal(out[1], ref[1]) and torch.equal(out[2], ref[2]), ppl
+                else:
+                    assert_close_robust(out[1], ref[1], 1e-5, name=f'color ppl={ppl}')
+                    assert_close_robust(out[2], ref[2], 1e-5, name=f'opacity ppl={ppl}')
+    finally:
+        _C().set_pixels_per_lane(0)
+        _C().set_strict_math(False)
+
+
+def test_backward_is_linear_in_the_cotangent_full_size():
+    P, W, H = CONFIGS[1]['P'], CONFIGS[1]['W'], CONFIGS[1]['H']
+    act, rs, cam = scene_inputs(P, W, H, seed=1, colmap=True, device='cuda')
+    fwd = hip_forward(act, rs)
+    g = torch.Generator().manual_seed(3)
+    c1, o1 = torch.randn(3, H, W, generator=g).cuda(), torch.randn(H, W, generator=g).cuda()
+    c2, o2 = torch.randn(3, H, W, generator=g).cuda(), torch.randn(H, W, generator=g).cuda()
+    a, b = 0.75, -1.5
+    g1 = hip_backward(fwd, act, rs, c1, o1)
+    g2 = hip_backward(fwd, act, rs, c2, o2)
+    g12 = hip_backward(fwd, act, rs, a * c1 + b * c2, a * o1 + b * o2)
+    for name, x1, x2, x12 in zip(GRAD_NAMES, g1, g2, g12):
+        assert rel_err(x12, a * x1 + b * x2) <= 2e-5, name
+
+
+def test_strict_and_fast_builds_agree_full_size():
+    P, W, H = CONFIGS[1]['P'], CONFIGS[1]['W'], CONFIGS[1]['H']
+    act, rs, cam = scene_inputs(P, W, H, seed=2, colmap=True, device='cuda')
+    g = torch.Generator().manual_seed(5)
+    gc, go = torch.randn(3, H, W, generator=g).cuda(), torch.randn(H, W, generator=g).cuda()
+    fast = hip_forward(act, rs)
+    gfast = hip_backward(fast, act, rs, gc, go)
+    try:
+        _C().set_strict_math(True)
+        strict = hip_forward(act, rs)
+        gstrict = hip_backward(strict, act, rs, gc, go)
+    finally:
+        _C().set_strict_math(False)
+    assert fast[0] == strict[0] and torch.equal(fast[3], strict[3])
+    assert_close_robust(fast[1], strict[1], 1e-4, name='color')
+    assert_close_robust(fast[2], strict[2], 1e-4, name='opacity')
+    for name, a, b in zip(GRAD_NAMES, gfast, gstrict):
+        assert_close_robust(a, b, 1e-4, 1e-3, name=name)
+
+
+def test_config1_full_size_parity_with_oracle(oracle32):
+    """BASELINE config #1 (100k Gaussians, 800x800): strict build bit-exact forward, gradients <= 1e-5; fast build
+    within the north-star 1e-4 (threshold-flip allowance of helpers.assert_close_robust)"""
+    P, W, H = CONFIGS[1]['P'], CONFIGS[1]['W'], CONFIGS[1]['H']
+    act, rs, cam = scene_inputs(P, W, H, seed=0, colmap=True, device='cuda')
+    g = torch.Generator().manual_seed(11)
+    gc, go = torch.randn(3, H, W, generator=g).cuda(), torch.randn(H, W, generator=g).cuda()
+    # literal oracle (libm exp) vs the product build
+    ref = oracle_forward(oracle32, act, rs)
+    fwd = hip_forward(act, rs)
+    assert fwd[0] == ref['num_rendered']
+    np.testing.assert_array_equal(to_np(fwd[3]), ref['radii'])
+    assert_close_robust(fwd[1], ref['color'], 1e-4, name='color')
+    assert_close_robust(fwd[2], ref['opacity'], 1e-4, name='opacity')
+    gref = oracle_backward(oracle32, ref, act, rs, gc, go)
+    got = hip_backward(fwd, act, rs, gc, go)
+    for name, t in zip(GRAD_NAMES, got[:8]):
+        assert_close_robust(t, gref[name], 1e-4, 1e-3, name=name)
+    # reproducible-exp oracle vs the strict build: bit-exact image
+    oracle32.set_exp_mode(1)
+    _C().set_strict_math(True)
+    try:
+        ref_s = oracle_forward(oracle32, act, rs)
+        fwd_s = hip_forward(act, rs)
+        np.testing.assert_array_equal(to_np(fwd_s[1]), ref_s['color'])
+        np.testing.assert_array_equal(to_np(fwd_s[2]), ref_s['opacity'])
+        gref_s = oracle_backward(oracle32, ref_s, act, rs, gc, go)
+        got_s = hip_backward(fwd_s, act, rs, gc, go)
+        for name, t in zip(GRAD_NAMES, got_s[:8]):
+            assert rel_err(t, gref_s[name].reshape(to_np(t).shape)) <= 2e-5, name
+    finally:
+        oracle32.set_exp_mode(0)
+        _C().set_strict_math(False)
