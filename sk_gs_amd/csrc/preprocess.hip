@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(int P, int D, i
 
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;  // culled Gaussians get an all-zero record
   int radius = 0;
-  uint32_t tiles = 0, clamp_bits = 0;
+  uint32_t clamp_bits = 0;
   int mn[2] = {0, 0}, mx[2] = {0, 0};
   const float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
   float pv[3], ph[4];
@@ -311,17 +311,14 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(int P, int D, i
           rgb[0] = colors_precomp[3 * idx], rgb[1] = colors_precomp[3 * idx + 1], rgb[2] = colors_precomp[3 * idx + 2];
         }
         radius = (int) my_radius;
-        tiles  = area;
         r0     = make_float4(pix[0], pix[1], conic[0], conic[1]);
         r1     = make_float4(conic[2], opacities[idx], rgb[0], rgb[1]);
-        // Squared pixel radius outside which alpha = min(0.99, o * exp(power)) < 1/255 for certain:
-        //   alpha >= 1/255  <=>  d^T Q d <= 2 ln(255 o)  and  d^T Q d >= |d|^2 / lambda_max(cov)
-        // (lambda1 >= the true largest eigenvalue because of the max(0.1, .) under the root).  The blend kernels skip a
-        // splat for a whole wave when its centre is farther than this from the wave's pixel rectangle -- the pairs
-        // skipped are exactly pairs the reference `continue`s on.  +1 % margin for fp32 rounding of either side.
-        const float o255  = 255.0f * opacities[idx];
-        const float rcut2 = o255 > 1.0f ? 2.02f * logf(o255) * fmaxf(lambda1, lambda2) + 0.25f : -1.0f;
-        r2 = make_float4(rgb[2], pv[2], __int_as_float(radius | (int) (clamp_bits << 28)), rcut2);
+        // qmax = 2 ln(255 o): a pixel can reach alpha = min(0.99, o * exp(-q/2)) >= 1/255 only where the conic form
+        // q(d) <= qmax.  The blend kernels skip a splat for a whole wave when the minimum of q over the wave's pixel
+        // rectangle exceeds it (render.hip: splat_reaches_rect); +0.01 absorbs logf / exp rounding.
+        const float o255 = 255.0f * opacities[idx];
+        const float qmax = o255 > 1.0f ? 2.0f * logf(o255) + 0.01f : -1.0f;
+        r2 = make_float4(rgb[2], pv[2], __int_as_float(radius | (int) (clamp_bits << 28)), qmax);
       }
     }
   }

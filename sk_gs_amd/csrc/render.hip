@@ -69,11 +69,26 @@ __device__ __forceinline__ WaveRect wave_rect(int tile, int sub, int gx) {
   }
   return r;
 }
-// false only if NO pixel of the rectangle can get alpha >= 1/255 from this splat (rcut2: preprocess.hip)
-__device__ __forceinline__ bool splat_reaches_rect(float cx, float cy, float rcut2, const WaveRect& r) {
-  const float dx = fmaxf(fmaxf(r.x0 - cx, cx - r.x1), 0.f);
-  const float dy = fmaxf(fmaxf(r.y0 - cy, cy - r.y1), 0.f);
-  return dx * dx + dy * dy <= rcut2;
+// false only if NO pixel of the rectangle can get alpha >= 1/255 from this splat.
+// alpha >= 1/255  <=>  q(d) = a dx^2 + 2 b dx dy + c dy^2 <= 2 ln(255 o) =: qmax (record slot, preprocess.hip).  The
+// minimum of the convex q over the rectangle (in centre-relative coordinates) is 0 if the centre is inside, else it
+// lies on a face visible from the centre: the nearer vertical and/or horizontal edge, where q is a 1-D parabola.
+// Every pair skipped is a pair the reference `continue`s on: the rectangle is taken in the kernel's own rounded
+// differences (fl is monotonic), and `slack` bounds the fp32 evaluation error of `power` anywhere in the rectangle.
+__device__ __forceinline__ bool splat_reaches_rect(float cx, float cy, float qa, float qb, float qc, float qmax,
+                                                   const WaveRect& r) {
+  const float X0 = r.x0 - cx, X1 = r.x1 - cx, Y0 = r.y0 - cy, Y1 = r.y1 - cy;
+  const bool inx = X0 <= 0.f && X1 >= 0.f, iny = Y0 <= 0.f && Y1 >= 0.f;
+  const float Xn = X0 > 0.f ? X0 : X1, Yn = Y0 > 0.f ? Y0 : Y1;  // nearest edges (meaningful when !inx / !iny)
+  const float dyv = fminf(fmaxf(-qb * Xn * __builtin_amdgcn_rcpf(qc), Y0), Y1);
+  const float dxh = fminf(fmaxf(-qb * Yn * __builtin_amdgcn_rcpf(qa), X0), X1);
+  const float qv  = qa * Xn * Xn + 2.f * qb * Xn * dyv + qc * dyv * dyv;
+  const float qh  = qa * dxh * dxh + 2.f * qb * dxh * Yn + qc * Yn * Yn;
+  float qmin      = fminf(inx ? qh : qv, iny ? qv : qh);
+  if (inx && iny) qmin = 0.f;
+  const float mx = fmaxf(fabsf(X0), fabsf(X1)), my = fmaxf(fabsf(Y0), fabsf(Y1));
+  const float slack = 4e-6f * (qa * mx * mx + qc * my * my + 2.f * fabsf(qb) * mx * my);
+  return !(qmin > qmax + slack) || !(qa > 0.f && qc > 0.f);  // NaN / degenerate conic: never skip
 }
 
 // Reproducible exp for the strict (parity) build: every step is an IEEE double multiply or add, written one

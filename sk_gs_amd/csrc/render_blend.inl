@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
       s_a[lane] = a, s_b[lane] = b, s_c[lane] = c.x;
 #pragma unroll
       for (int e = 0; e < E; ++e) s_e[lane * (E > 0 ? E : 1) + e] = extra[(size_t) id * E + e];
-      relevant = splat_reaches_rect(a.x, a.y, c.w, rect);
+      relevant = splat_reaches_rect(a.x, a.y, a.z, a.w, b.x, c.w, rect);
     }
     __syncthreads();
     const uint32_t contrib0 = (uint32_t) (base - start);
@@ -70,13 +70,15 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
       const int j    = __builtin_ctzll(todo);
       const float4 a = s_a[j];
       const float4 b = s_b[j];
+#if SKGS_STRICT
+      // literal control flow and operation order of the reference (gaussian_render.cu:66-100)
       bool hit[PPL];
-      float wgt[PPL], al[PPL], Tp[PPL];
+      float al[PPL], Tp[PPL];
       bool any = false;
 #pragma unroll
       for (int i = 0; i < PPL; ++i) {
         hit[i] = false;
-        wgt[i] = 0.f, al[i] = 0.f, Tp[i] = 0.f;
+        al[i] = 0.f, Tp[i] = 0.f;
         if (!done[i]) {
           const float dx = a.x - pix.x[i], dy = a.y - pix.y[i];
           const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
@@ -90,7 +92,6 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
                 hit[i]  = true;
                 al[i]   = alpha;
                 Tp[i]   = Tr[i];
-                wgt[i]  = alpha * Tr[i];
                 Tr[i]   = test_T;
                 last[i] = contrib0 + j + 1;
               }
@@ -99,12 +100,10 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
         }
         any = any || hit[i];
       }
-      if (__any(any)) {
+      if (__ballot(any) != 0) {
         const float cb = s_c[j];
 #pragma unroll
         for (int i = 0; i < PPL; ++i) {
-          // hit[i] false -> wgt 0: adds an exact +0
-#if SKGS_STRICT
           // reference order: features * alpha * T, left to right (gaussian_render.cu:93-95)
           if (hit[i]) {
             C[i][0] += b.z * al[i] * Tp[i];
@@ -113,15 +112,33 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
 #pragma unroll
             for (int e = 0; e < E; ++e) Ex[i][e] += s_e[j * (E > 0 ? E : 1) + e] * al[i] * Tp[i];
           }
-#else
-          C[i][0] += b.z * wgt[i];
-          C[i][1] += b.w * wgt[i];
-          C[i][2] += cb * wgt[i];
-#pragma unroll
-          for (int e = 0; e < E; ++e) Ex[i][e] += s_e[j * (E > 0 ? E : 1) + e] * wgt[i];
-#endif
         }
       }
+#else
+      // Same decisions, branch-free: after the wave-level cull nearly every visit has a contributing lane, so the
+      // nested exec-mask regions only cost SALU work and serialise the LDS reads.  Lanes that do not contribute
+      // carry weight 0 (adds an exact +0).
+      const float cb = s_c[j];
+#pragma unroll
+      for (int i = 0; i < PPL; ++i) {
+        const float dx = a.x - pix.x[i], dy = a.y - pix.y[i];
+        const float power  = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+        const float alpha  = fminf(0.99f, b.y * blend_exp(power));
+        const float test_T = Tr[i] * (1.f - alpha);
+        const bool valid   = !done[i] && power <= 0.0f && alpha >= ALPHA_MIN;
+        const bool stop    = valid && test_T < T_MIN;
+        const bool hit     = valid && !stop;
+        const float wgt    = hit ? alpha * Tr[i] : 0.f;
+        done[i]            = done[i] || stop;
+        Tr[i]              = hit ? test_T : Tr[i];
+        last[i]            = hit ? contrib0 + j + 1 : last[i];
+        C[i][0] += b.z * wgt;
+        C[i][1] += b.w * wgt;
+        C[i][2] += cb * wgt;
+#pragma unroll
+        for (int e = 0; e < E; ++e) Ex[i][e] += s_e[j * (E > 0 ? E : 1) + e] * wgt;
+      }
+#endif
     }
   }
   const size_t HW = (size_t) H * W;
@@ -161,8 +178,6 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
   __shared__ float s_c[WAVE];
   __shared__ uint32_t s_id[WAVE];
   __shared__ float s_e[E > 0 ? WAVE * E : 1];
-  __shared__ float s_acc[WAVE][GRAD_ROW];
-  __shared__ uint32_t s_acc_id[WAVE];
 
   const int64_t start = offsets[tile];
   const int64_t end   = min<int64_t>((int64_t) offsets[tile + 1], capacity);
@@ -198,7 +213,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
   for (int d = 32; d > 0; d >>= 1) maxk = max(maxk, (uint32_t) __shfl_xor((int) maxk, d));
   if (maxk == 0) return;
   const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-  const int holder_q = transposed_holder_value(lane >> 3);
+  const bool holder  = (lane & 7) == 0 || lane == 63;
+  const int holder_q = lane == 63 ? 8 : transposed_holder_value(lane >> 3);
 
   // walk the list back to front: entry at list position k (0-based) has "contributor" index k
   for (int64_t hi = start + (int64_t) min<int64_t>(maxk, end - start); hi > start; hi -= WAVE) {
@@ -211,10 +227,9 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
       s_a[lane] = a, s_b[lane] = b, s_c[lane] = c.x, s_id[lane] = id;
 #pragma unroll
       for (int e = 0; e < E; ++e) s_e[lane * (E > 0 ? E : 1) + e] = extra[(size_t) id * E + e];
-      relevant = splat_reaches_rect(a.x, a.y, c.w, rect);
+      relevant = splat_reaches_rect(a.x, a.y, a.z, a.w, b.x, c.w, rect);
     }
     __syncthreads();
-    int nact = 0;  // wave-uniform count of LDS rows in use
     for (unsigned long long todo = __ballot(relevant); todo; todo &= todo - 1) {
       const int j      = __builtin_ctzll(todo);
       const uint32_t k = (uint32_t) (hi - 1 - j - start);
@@ -281,25 +296,19 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
           }
         }
       }
-      if (__any(any)) {
-        // 8 sums land one per lane in lanes 0, 8, .., 56 (one ds_write for all of them); the ninth in lane 63
+      if (__ballot(any) != 0) {
+        // 8 sums land one per lane in lanes 0, 8, .., 56, the ninth in lane 63: ONE atomic instruction adds the nine
+        // values into the Gaussian's 64-B gradient row (a single memory-side request)
         wave_sum9_transposed(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], 0xff00ff00ff00ff00ull);
 #pragma unroll
         for (int q = 9; q < NV; ++q) g[q] = wave_sum_to_lane63(g[q]);
-        if ((lane & 7) == 0) s_acc[nact][holder_q] = g[1];
+        float* row = gradacc + (size_t) s_id[j] * GRAD_ROW;
+        if (holder) atomicAdd(row + holder_q, lane == 63 ? g[8] : g[1]);
         if (lane == 63) {
 #pragma unroll
-          for (int q = 8; q < NV; ++q) s_acc[nact][q] = g[q];
-          s_acc_id[nact] = s_id[j];
+          for (int q = 9; q < NV; ++q) atomicAdd(row + q, g[q]);
         }
-        ++nact;
       }
-    }
-    // flush: 4 rows (4 x 64-B lines) per wave-wide atomic instruction
-    __syncthreads();
-    for (int r0 = 0; r0 < nact; r0 += 4) {
-      const int row = r0 + (lane >> 4), colx = lane & 15;
-      if (row < nact && colx < NV) atomicAdd(&gradacc[(size_t) s_acc_id[row] * GRAD_ROW + colx], s_acc[row][colx]);
     }
   }
 }
