@@ -130,6 +130,9 @@ def main():
     ap.add_argument('--lr', type=float, default=1e-4, help='base lr (reference 1e-3); small keeps the workload stationary')
     ap.add_argument('--torch-adam', action='store_true', help='use torch.optim.Adam(fused=True) instead of the one-launch kernel')
     ap.add_argument('--eager', action='store_true', help='issue every launch eagerly instead of replaying hipGraphs')
+    ap.add_argument('--autograd', action='store_true',
+                    help='run the step through the torch-autograd operator path (model.render + image_loss + backward) '
+                         'instead of sk_gs_amd.fused_step.FusedViewStep (same kernels, no autograd glue)')
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line: everything else that any library prints to fd 1 (RCCL's version banner,
@@ -177,14 +180,33 @@ def main():
     else:
         from sk_gs_amd.optim import FusedAdam
         opt = FusedAdam(model.param_groups(lr=args.lr), eps=1e-15, betas=(0.9, 0.999))
+    # ---------------------------------------------------------------- learn R per view with the synchronising path
+    _C.config.sync_num_rendered = True
+    Rs = []
+    with torch.no_grad():  # no autograd graph may stay alive across a capture (see sk_gs_amd/train_step.py)
+        for v in range(args.views):
+            Rs.append(model.render(settings[v], time_id=v % frames, background=background)['buffer'].R)
+    R_mean, R_max = sum(Rs) / len(Rs), max(Rs)
+    _C.config.sync_num_rendered = False
+    _C.update_capacity_hint(P, W, H, int(R_max * 1.25))
+
     overflow = torch.zeros(1, dtype=torch.int32, device=dev)
 
-    def fwd_bwd(v):
-        vp.grads.zero_()
-        out = model.render(settings[v], time_id=v % frames, background=background)
-        loss = image_loss(out['images'], targets[v])
-        loss.backward()
-        overflow.add_(out['buffer'].geomBuffer[4:8].view(torch.int32))
+    if args.autograd:
+        def fwd_bwd(v):
+            vp.grads.zero_()
+            out = model.render(settings[v], time_id=v % frames, background=background)
+            loss = image_loss(out['images'], targets[v])
+            loss.backward()
+            overflow.add_(out['buffer'].geomBuffer[4:8].view(torch.int32))
+    else:
+        from sk_gs_amd.fused_step import FusedViewStep
+        fstep = FusedViewStep(model, W, H, capacity=int(R_max * 1.25 * _C.config.capacity_growth) + 1024,
+                              background=background)
+
+        def fwd_bwd(v):  # every gradient is overwritten in place: no zero fill of the flat buffer
+            fstep.forward_backward(settings[v], v % frames, targets[v])
+            overflow.add_(fstep.geom[4:8].view(torch.int32))
 
     def eager_step(i):
         fwd_bwd(vp.view_index(i, args.views))
@@ -206,16 +228,6 @@ def main():
             g_opt(0)
 
     train_step = eager_step if args.eager else graph_step
-
-    # ---------------------------------------------------------------- learn R per view with the synchronising path
-    _C.config.sync_num_rendered = True
-    Rs = []
-    with torch.no_grad():  # no autograd graph may stay alive across a capture (see sk_gs_amd/train_step.py)
-        for v in range(args.views):
-            Rs.append(model.render(settings[v], time_id=v % frames, background=background)['buffer'].R)
-    R_mean, R_max = sum(Rs) / len(Rs), max(Rs)
-    _C.config.sync_num_rendered = False
-    _C.update_capacity_hint(P, W, H, int(R_max * 1.25))
 
     eager_step(0)  # initialises optimizer state before any capture
     if not args.eager:  # every graph exists before the timed region, whatever --warmup is
@@ -308,7 +320,8 @@ def main():
                        'num_rendered_mean': round(R_mean), 'num_rendered_max': R_max,
                        'parallelism': f'view-parallel x{world}, flat-buffer grad all-reduce '
                                       f'({vp.grads.nbytes / 1e6:.1f} MB)',
-                       'launch': 'eager' if args.eager else 'one hipGraph replay per view step'},
+                       'launch': 'eager' if args.eager else 'one hipGraph replay per view step',
+                       'step': 'autograd operator path' if args.autograd else 'FusedViewStep (direct C-ABI calls)'},
             'roofline': {'bound': 'hbm', 'kernel': 'render_backward', 'achieved': round(achieved, 2),
                          'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 5),
                          'traffic': traffic, 'avg_us': round(rb_us, 2), 'launches': rb_n,

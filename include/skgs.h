@@ -68,6 +68,12 @@ typedef struct skgs_raster_inputs {
   const float* extras;     /* [P,E] or NULL */
   const float* colors_precomp; /* [P,3] or NULL */
   const float* cov3D_precomp;  /* [P,6] or NULL */
+  /* ---- optional fused-epilogue inputs (NULL = the in-tree reference behaviour) ---- */
+  const float* sh_rest;    /* split SH storage: `sh` is then the DC term [P,1,3] and sh_rest [P,M-1,3] (the reference's
+                              _features_dc / _features_rest, concatenated by get_features, gaussian_splatting.py:170-173) */
+  const float* background; /* [3]: out_color = C + T * bg inside the blend kernel (upstream diff_gaussian_rasterization
+                              forward.cu renderCUDA epilogue; the in-tree variant composites in torch, sk_gs.py:1236) and
+                              its dL/dT term in the backward */
 } skgs_raster_inputs;
 
 typedef struct skgs_raster_buffers {
@@ -107,7 +113,7 @@ int skgs_read_status(const skgs_raster_buffers* buf, skgs_status* host_status, s
 typedef struct skgs_raster_grads {
   /* grad_outputs */
   const float* dL_dout_color;   /* [3,H,W] */
-  const float* dL_dout_opacity; /* [H,W] */
+  const float* dL_dout_opacity; /* [H,W] or NULL (= 0) */
   const float* dL_dout_extra;   /* [E,H,W] or NULL */
   /* optional gradients chained in from gaussian_rasterize_extra_backward: added to the results (NULL = none) */
   const float* grad_means2D_in; /* [P,3] */
@@ -124,6 +130,7 @@ typedef struct skgs_raster_grads {
   float* dL_dscales;    /* [P,3] */
   float* dL_drotations; /* [P,4] */
   float* dL_dextras;    /* [P,E] or NULL */
+  float* dL_dsh_rest;   /* with skgs_raster_inputs::sh_rest: dL_dsh is [P,1,3] and this [P,M-1,3]; else NULL */
   /* scratch: P*16 floats, contents undefined on entry and exit */
   float* workspace; size_t workspace_bytes;
 } skgs_raster_grads;
@@ -165,14 +172,23 @@ typedef struct skgs_deform_inputs {
 /* means [P,3], scales [P,3], rotations [P,4] (normalised), opacity [P,1]; d_xyz/d_rot/d_scale optional (NULL) */
 int skgs_lbs_deform_forward(const skgs_deform_inputs* in, float* means, float* scales, float* rotations,
     float* opacity, float* d_xyz, float* d_rot, float* d_scale, skgs_stream_t stream);
-/* g_bone_* must be zero-filled by the caller (they are accumulated with atomics). */
+/* Every output is written completely (no zero-fill needed; the bone gradients are reduced without atomics, in a
+ * fixed order, when M <= 64).  workspace: skgs_lbs_deform_backward_workspace_bytes(P, M) bytes of scratch. */
+size_t skgs_lbs_deform_backward_workspace_bytes(int32_t P, int32_t M);
 int skgs_lbs_deform_backward(const skgs_deform_inputs* in, const float* g_means, const float* g_scales,
     const float* g_rotations, const float* g_opacity, float* g_weights, float* g_bone_T, float* g_bone_drot,
-    float* g_bone_dscale, float* g_xyz, float* g_log_scale, float* g_rot, float* g_opacity_logit,
-    skgs_stream_t stream);
+    float* g_bone_dscale, float* g_xyz, float* g_log_scale, float* g_rot, float* g_opacity_logit, void* workspace,
+    size_t workspace_bytes, skgs_stream_t stream);
 /* K (<= 16) nearest bones by squared L2 in `dim` dimensions, ascending, ties to the lower index. */
 int skgs_knn_bones(int32_t P, int32_t M, int32_t K, int32_t dim, const float* points, const float* joints,
     float* out_dist, int64_t* out_idx, skgs_stream_t stream);
+/* LBS weights from the per-Gaussian logits, the `sp_W` branch of calc_LBS_weight (networks/sk_gs.py:769-770):
+ * weights[P,K] = softmax_k(sp_W[p, indices[p,k]]).  The backward writes the DENSE gradient g_sp_W[P,M] (zeros for the
+ * bones outside the K nearest), i.e. what autograd's gather backward accumulates into a zero tensor. */
+int skgs_lbs_weights_forward(int32_t P, int32_t M, int32_t K, const float* sp_W, const int64_t* indices, float* weights,
+    skgs_stream_t stream);
+int skgs_lbs_weights_backward(int32_t P, int32_t M, int32_t K, const float* weights, const int64_t* indices,
+    const float* g_weights, float* g_sp_W, skgs_stream_t stream);
 
 /* ---- bone chain (scope row a-3): joint rotations -> global bone transforms, one launch per direction ----
  * Replaces kinematic() + skeleton_warp_SE3() (networks/sk_gs.py:1069-1107,193-206; lietorch SE3 product lie.h:242-246).

@@ -38,7 +38,7 @@ class _RasterInputs(C.Structure):
         ('viewmatrix', C.c_void_p), ('projmatrix', C.c_void_p), ('campos', C.c_void_p),
         ('means3D', C.c_void_p), ('opacity', C.c_void_p), ('sh', C.c_void_p), ('scales', C.c_void_p),
         ('rotations', C.c_void_p), ('extras', C.c_void_p), ('colors_precomp', C.c_void_p),
-        ('cov3D_precomp', C.c_void_p),
+        ('cov3D_precomp', C.c_void_p), ('sh_rest', C.c_void_p), ('background', C.c_void_p),
     ]
 
 
@@ -59,7 +59,7 @@ class _RasterGrads(C.Structure):
         ('dL_dmeans2D', C.c_void_p), ('dL_dconic', C.c_void_p), ('dL_dcolors', C.c_void_p),
         ('dL_dopacity', C.c_void_p), ('dL_dmeans3D', C.c_void_p), ('dL_dcov3D', C.c_void_p), ('dL_dsh', C.c_void_p),
         ('dL_dscales', C.c_void_p), ('dL_drotations', C.c_void_p), ('dL_dextras', C.c_void_p),
-        ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t),
+        ('dL_dsh_rest', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t),
     ]
 
 
@@ -77,7 +77,8 @@ EXPORTED_SYMBOLS = [
     'skgs_rasterize_forward_stage1', 'skgs_rasterize_forward_stage2', 'skgs_rasterize_forward', 'skgs_read_status',
     'skgs_backward_workspace_bytes', 'skgs_rasterize_backward', 'skgs_rasterize_extra_forward',
     'skgs_rasterize_extra_backward', 'skgs_topk_weights', 'skgs_mark_visible', 'skgs_lbs_deform_forward',
-    'skgs_lbs_deform_backward', 'skgs_knn_bones', 'skgs_last_error', 'skgs_version',
+    'skgs_lbs_deform_backward', 'skgs_lbs_deform_backward_workspace_bytes', 'skgs_knn_bones',
+    'skgs_lbs_weights_forward', 'skgs_lbs_weights_backward', 'skgs_last_error', 'skgs_version',
 ]
 
 
@@ -99,7 +100,8 @@ def load_library():
                 f'g.build()"` or `make -C sk_gs_amd/csrc`. There is no CPU / PyTorch fallback for this path.')
         lib = C.CDLL(_LIB_PATH)
         for name in ('skgs_geom_buffer_bytes', 'skgs_img_buffer_bytes', 'skgs_binning_buffer_bytes',
-                     'skgs_backward_workspace_bytes'):
+                     'skgs_backward_workspace_bytes', 'skgs_lbs_deform_backward_workspace_bytes',
+                     'skgs_image_loss_workspace_bytes'):
             getattr(lib, name).restype = C.c_size_t
         lib.skgs_binning_capacity.restype = C.c_int64
         lib.skgs_binning_capacity.argtypes = [C.c_size_t]
@@ -542,16 +544,19 @@ def lbs_deform_backward(points, weights, indices, bone_T, bone_drot, bone_dscale
         f32 = dict(dtype=torch.float32, device=dev)
         gs = [_f32c(t, dev) for t in (g_means, g_scales, g_rotations, g_opacity)]
         g_weights = torch.empty((P, K), **f32)
-        # the three atomically accumulated outputs are dense views of ONE zeroed block (one memset)
-        blk = torch.zeros((M * 14,), **f32)
-        g_bone_T, g_bone_drot, g_bone_dscale = blk[:M * 7].view(M, 7), blk[M * 7:M * 11].view(M, 4), blk[M * 11:].view(M, 3)
+        g_bone_T, g_bone_drot = torch.empty((M, 7), **f32), torch.empty((M, 4), **f32)
+        g_bone_dscale = torch.empty((M, 3), **f32)
         g_xyz, g_log_scale = torch.empty((P, 3), **f32), torch.empty((P, 3), **f32)
         g_rot, g_op = torch.empty((P, 4), **f32), torch.empty((P, 1), **f32)
+        lib.skgs_lbs_deform_backward_workspace_bytes.restype = C.c_size_t
+        ws = torch.empty((lib.skgs_lbs_deform_backward_workspace_bytes(C.c_int32(P), C.c_int32(M)),), dtype=torch.uint8,
+                         device=dev)
         _check(lib.skgs_lbs_deform_backward(
             C.byref(a), C.c_void_p(_ptr(gs[0])), C.c_void_p(_ptr(gs[1])), C.c_void_p(_ptr(gs[2])),
             C.c_void_p(_ptr(gs[3])), C.c_void_p(_ptr(g_weights)), C.c_void_p(g_bone_T.data_ptr()),
             C.c_void_p(g_bone_drot.data_ptr()), C.c_void_p(g_bone_dscale.data_ptr()), C.c_void_p(_ptr(g_xyz)),
-            C.c_void_p(_ptr(g_log_scale)), C.c_void_p(_ptr(g_rot)), C.c_void_p(_ptr(g_op)), _stream()))
+            C.c_void_p(_ptr(g_log_scale)), C.c_void_p(_ptr(g_rot)), C.c_void_p(_ptr(g_op)),
+            C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()), _stream()))
     return g_weights, g_bone_T, g_bone_drot, g_bone_dscale, g_xyz, g_log_scale, g_rot, g_op
 
 

@@ -79,6 +79,9 @@ static int check_inputs(const skgs_raster_inputs* in) {
   if (in->sh) {
     SKGS_REQUIRE(in->sh_degree >= 0 && in->sh_degree <= 3, "sh_degree must be in [0,3]");
     SKGS_REQUIRE(in->sh_coeffs >= (in->sh_degree + 1) * (in->sh_degree + 1), "sh has too few coefficients for sh_degree");
+    SKGS_REQUIRE(!in->sh_rest || in->sh_coeffs >= 2, "sh_rest given but sh_coeffs < 2");
+  } else {
+    SKGS_REQUIRE(!in->sh_rest, "sh_rest given without sh");
   }
   SKGS_REQUIRE(in->E >= 0 && in->E <= SKGS_MAX_RENDER_EXTRA, "Only Support 0,1,2,3,4 extra features");
   return 0;
@@ -170,11 +173,12 @@ int skgs_rasterize_backward(const skgs_raster_inputs* in, const skgs_raster_buff
   SKGS_REQUIRE(gr != nullptr, "grads struct is NULL");
   if (in->P == 0) return 0;
   SKGS_REQUIRE(radii && out_opacity, "radii / out_opacity are required");
-  SKGS_REQUIRE(gr->dL_dout_color && gr->dL_dout_opacity, "dL_dout_color / dL_dout_opacity are required");
+  SKGS_REQUIRE(gr->dL_dout_color, "dL_dout_color is required");
   SKGS_REQUIRE(gr->dL_dmeans2D && gr->dL_dcolors && gr->dL_dopacity && gr->dL_dmeans3D && gr->dL_dcov3D &&
                    gr->dL_dscales && gr->dL_drotations,
       "gradient outputs are required");
   SKGS_REQUIRE(!(in->sh && in->sh_coeffs > 0) || gr->dL_dsh, "dL_dsh is required when sh is given");
+  SKGS_REQUIRE((in->sh_rest != nullptr) == (gr->dL_dsh_rest != nullptr), "dL_dsh_rest goes with sh_rest (split SH storage)");
   SKGS_REQUIRE(gr->workspace && gr->workspace_bytes >= skgs_backward_workspace_bytes(in->P), "workspace too small");
   hipStream_t s = (hipStream_t) stream;
   GeomView g    = geom_view(buf->geom);
@@ -253,17 +257,23 @@ int skgs_lbs_deform_forward(const skgs_deform_inputs* in, float* means, float* s
   return launch_deform_forward(*in, means, scales, rotations, opacity, d_xyz, d_rot, d_scale, (hipStream_t) stream);
 }
 
+size_t skgs_lbs_deform_backward_workspace_bytes(int32_t P, int32_t M) {
+  return deform_backward_workspace_bytes(P < 0 ? 0 : P, M < 0 ? 0 : M);
+}
+
 int skgs_lbs_deform_backward(const skgs_deform_inputs* in, const float* g_means, const float* g_scales,
     const float* g_rotations, const float* g_opacity, float* g_weights, float* g_bone_T, float* g_bone_drot,
-    float* g_bone_dscale, float* g_xyz, float* g_log_scale, float* g_rot, float* g_opacity_logit,
-    skgs_stream_t stream) {
+    float* g_bone_dscale, float* g_xyz, float* g_log_scale, float* g_rot, float* g_opacity_logit, void* workspace,
+    size_t workspace_bytes, skgs_stream_t stream) {
   if (check_deform(in)) return 1;
   SKGS_REQUIRE(in->P == 0 || (g_means && g_scales && g_rotations && g_opacity), "deform: upstream gradients are required");
-  SKGS_REQUIRE(in->P == 0 || (g_weights && g_bone_T && g_bone_drot && g_bone_dscale && g_xyz && g_log_scale && g_rot &&
-                                 g_opacity_logit),
+  SKGS_REQUIRE(g_bone_T && g_bone_drot && g_bone_dscale, "deform: bone gradient outputs are required");
+  SKGS_REQUIRE(in->P == 0 || (g_weights && g_xyz && g_log_scale && g_rot && g_opacity_logit),
       "deform: gradient outputs are required");
+  SKGS_REQUIRE(in->P == 0 || (workspace && workspace_bytes >= deform_backward_workspace_bytes(in->P, in->M)),
+      "deform backward: workspace too small (skgs_lbs_deform_backward_workspace_bytes)");
   return launch_deform_backward(*in, g_means, g_scales, g_rotations, g_opacity, g_weights, g_bone_T, g_bone_drot,
-      g_bone_dscale, g_xyz, g_log_scale, g_rot, g_opacity_logit, (hipStream_t) stream);
+      g_bone_dscale, g_xyz, g_log_scale, g_rot, g_opacity_logit, workspace, (hipStream_t) stream);
 }
 
 int skgs_knn_bones(int32_t P, int32_t M, int32_t K, int32_t dim, const float* points, const float* joints,
@@ -271,6 +281,20 @@ int skgs_knn_bones(int32_t P, int32_t M, int32_t K, int32_t dim, const float* po
   SKGS_REQUIRE(P == 0 || (points && joints && out_dist && out_idx), "knn_bones: NULL argument");
   SKGS_REQUIRE(M >= 1 && dim >= 1, "knn_bones: M and dim must be >= 1");
   return launch_knn_bones(P, M, K, dim, points, joints, out_dist, out_idx, (hipStream_t) stream);
+}
+
+int skgs_lbs_weights_forward(int32_t P, int32_t M, int32_t K, const float* sp_W, const int64_t* indices, float* weights,
+    skgs_stream_t stream) {
+  SKGS_REQUIRE(P == 0 || (sp_W && indices && weights), "lbs_weights_forward: NULL argument");
+  SKGS_REQUIRE(M >= 1, "lbs_weights_forward: M must be >= 1");
+  return launch_lbs_weights_forward(P, M, K, sp_W, indices, weights, (hipStream_t) stream);
+}
+
+int skgs_lbs_weights_backward(int32_t P, int32_t M, int32_t K, const float* weights, const int64_t* indices,
+    const float* g_weights, float* g_sp_W, skgs_stream_t stream) {
+  SKGS_REQUIRE(P == 0 || (weights && indices && g_weights && g_sp_W), "lbs_weights_backward: NULL argument");
+  SKGS_REQUIRE(M >= 1 && K >= 1, "lbs_weights_backward: M and K must be >= 1");
+  return launch_lbs_weights_backward(P, M, K, weights, indices, g_weights, g_sp_W, (hipStream_t) stream);
 }
 
 }  // extern "C"

@@ -238,6 +238,159 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_kernel(int P, 
   }
 }
 
+// ------------------------------------------------------------------------------ bone gradients by moments
+// Every bone gradient is linear in quantities that do not depend on the bone:
+//     u_p = [ g_dx (3) | g_dx p^T (9, row-major S[a][b] = g_dx[a] p[b]) | g_v (4) | g_ds (3) ]          (19 floats)
+//     Mom[b] = sum_{p,k : idx[p,k] = b} w[p,k] u_p            i.e.  Mom = W^T U  with the dense [P,M] weight matrix
+//     g_T.t = Mom[0:3],  g_T.q = (I - q q^T) Q(q) Mom[3:12] / |q_raw|,  g_drot = Mom[12:16],  g_dscale = Mom[16:19]
+// (Q(q) S is the quaternion gradient of sum w g.(R(q) p) written on the moment matrix, lie.h:59-64.)  So the scatter
+// of 14 values per (Gaussian, neighbour) -- LDS atomics that serialise on the few bones neighbouring Gaussians share,
+// 60 us at P = 1e5 -- becomes a small dense contraction: each wave stages its 64 weight rows and u vectors in LDS and
+// every lane owns (bone, component) outputs, summing over the wave's Gaussians with conflict-free broadcast reads.
+// Per-workgroup partial moments go to a workspace; a second tiny kernel reduces them in a fixed order and applies
+// the per-bone linear maps.  No atomics: the bone gradients are deterministic.
+constexpr int MOM_F         = 19;
+constexpr int MOM_U         = 20;  // padded row of U
+constexpr int MOM_MAX_BONES = 64;
+
+__global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_moments_kernel(int P, int K, int M,
+    const float* __restrict__ points, const float* __restrict__ weights, const int64_t* __restrict__ indices,
+    const float* __restrict__ bone_T, const float* __restrict__ bone_drot, const float* __restrict__ bone_dscale,
+    const float* __restrict__ log_scale, const float* __restrict__ rot, const float* __restrict__ opacity_logit,
+    const float* __restrict__ g_means, const float* __restrict__ g_scales, const float* __restrict__ g_rotations,
+    const float* __restrict__ g_opacity, float* __restrict__ g_weights, float* __restrict__ g_xyz,
+    float* __restrict__ g_log_scale, float* __restrict__ g_rot, float* __restrict__ g_opacity_logit,
+    float* __restrict__ partials /* [gridDim.x][M][19] */) {
+  extern __shared__ float s_mem[];
+  const int Mp    = (M + 3) & ~3;                 // weight rows padded to float4
+  float* s_bones  = s_mem;                        // [M][14]
+  float* s_w      = s_bones + M * BONE_F;         // [4 waves][64][Mp]
+  float* s_u      = s_w + 4 * 64 * Mp;            // [4 waves][64][20]
+  float* s_part   = s_u + 4 * 64 * MOM_U;         // [4 waves][M*19]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* my_w = s_w + (size_t) (wave * 64 + lane) * Mp;
+  float* my_u = s_u + (size_t) (wave * 64 + lane) * MOM_U;
+  for (int j = threadIdx.x; j < M; j += DEFORM_THREADS) load_bone(bone_T, bone_drot, bone_dscale, j, s_bones + j * BONE_F);
+  for (int i = 0; i < Mp; i += 4) *reinterpret_cast<float4*>(my_w + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const int n = blockIdx.x * DEFORM_THREADS + threadIdx.x;
+  float u[MOM_U];
+#pragma unroll
+  for (int c = 0; c < MOM_U; ++c) u[c] = 0.f;
+  if (n < P) {
+    const float p[3] = {points[3 * n], points[3 * n + 1], points[3 * n + 2]};
+    float sr[4] = {0, 0, 0, 0};
+    for (int k = 0; k < K; ++k) {
+      const int j   = (int) indices[(size_t) n * K + k];
+      const float w = weights[(size_t) n * K + k];
+      const float* b = s_bones + j * BONE_F;
+      sr[0] += b[7] * w, sr[1] += b[8] * w, sr[2] += b[9] * w, sr[3] += b[10] * w;
+      my_w[j] += w;  // own row: plain read-modify-write (KNN ids are distinct, += keeps it right if they are not)
+    }
+    const float4 r4  = reinterpret_cast<const float4*>(rot)[n];
+    const float4 gr4 = reinterpret_cast<const float4*>(g_rotations)[n];
+    const float v[4] = {r4.x + sr[0], r4.y + sr[1], r4.z + sr[2], r4.w + sr[3]};
+    const float gr[4] = {gr4.x, gr4.y, gr4.z, gr4.w};
+    const float nv    = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+    float g_v[4];
+    if (nv > 1e-12f) {
+      const float uq[4] = {v[0] / nv, v[1] / nv, v[2] / nv, v[3] / nv};
+      const float dot   = uq[0] * gr[0] + uq[1] * gr[1] + uq[2] * gr[2] + uq[3] * gr[3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) g_v[c] = (gr[c] - uq[c] * dot) / nv;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) g_v[c] = gr[c] / 1e-12f;
+    }
+    const float g_dx[3] = {g_means[3 * n], g_means[3 * n + 1], g_means[3 * n + 2]};
+    const float g_ds[3] = {g_scales[3 * n], g_scales[3 * n + 1], g_scales[3 * n + 2]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      g_xyz[3 * n + c]       = g_dx[c];
+      g_log_scale[3 * n + c] = g_ds[c] * expf(log_scale[3 * n + c]);
+    }
+    reinterpret_cast<float4*>(g_rot)[n] = make_float4(g_v[0], g_v[1], g_v[2], g_v[3]);
+    const float sg     = 1.0f / (1.0f + expf(-opacity_logit[n]));
+    g_opacity_logit[n] = g_opacity[n] * sg * (1.0f - sg);
+    for (int k = 0; k < K; ++k) {  // dL/dw[p,k] = g_dx . (T_j p) + g_v . d_rot_j + g_ds . d_scale_j
+      const float* b = s_bones + (int) indices[(size_t) n * K + k] * BONE_F;
+      float y[3];
+      se3_act(b, p, y);
+      float gw = g_dx[0] * y[0] + g_dx[1] * y[1] + g_dx[2] * y[2];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) gw += g_v[c] * b[7 + c];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gw += g_ds[c] * b[11 + c];
+      g_weights[(size_t) n * K + k] = gw;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      u[a] = g_dx[a];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) u[3 + 3 * a + c] = g_dx[a] * p[c];
+      u[16 + a] = g_ds[a];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) u[12 + c] = g_v[c];
+  }
+#pragma unroll
+  for (int c = 0; c < MOM_U; c += 4) *reinterpret_cast<float4*>(my_u + c) = make_float4(u[c], u[c + 1], u[c + 2], u[c + 3]);
+  __syncthreads();  // (only the own wave's rows are read below; the barrier also orders the LDS traffic)
+  // ---- each lane owns outputs o = (bone, component): Mom_wave[o] = sum over the wave's 64 Gaussians
+  const int n_out   = M * MOM_F;
+  const float* w0   = s_w + (size_t) wave * 64 * Mp;
+  const float* u0   = s_u + (size_t) wave * 64 * MOM_U;
+  float* part       = s_part + (size_t) wave * n_out;
+  for (int o = lane; o < n_out; o += 64) {
+    const int b = o / MOM_F, c = o - b * MOM_F;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int q = 0; q < 64; ++q) acc += w0[q * Mp + b] * u0[q * MOM_U + c];
+    part[o] = acc;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < n_out; o += DEFORM_THREADS)
+    partials[(size_t) blockIdx.x * n_out + o] = (s_part[o] + s_part[n_out + o]) + (s_part[2 * n_out + o] + s_part[3 * n_out + o]);
+}
+
+// one workgroup per bone: fixed-order reduction of the per-workgroup partial moments, then the per-bone linear maps
+__global__ void __launch_bounds__(256) deform_backward_finalize_kernel(int M, int nblk, const float* __restrict__ partials,
+    const float* __restrict__ bone_T, float* __restrict__ g_bone_T, float* __restrict__ g_bone_drot,
+    float* __restrict__ g_bone_dscale) {
+  __shared__ float s_red[8][32];
+  const int b = blockIdx.x, c = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  float acc = 0.f;
+  if (c < MOM_F)
+    for (int w = slice; w < nblk; w += 8) acc += partials[((size_t) w * M + b) * MOM_F + c];
+  s_red[slice][c] = acc;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  float m[MOM_F];
+  for (int i = 0; i < MOM_F; ++i)
+    m[i] = ((s_red[0][i] + s_red[1][i]) + (s_red[2][i] + s_red[3][i])) + ((s_red[4][i] + s_red[5][i]) + (s_red[6][i] + s_red[7][i]));
+  const float q0 = bone_T[7 * b + 3], q1 = bone_T[7 * b + 4], q2 = bone_T[7 * b + 5], q3 = bone_T[7 * b + 6];
+  const float qn = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+  const float vq[4] = {q0 / qn, q1 / qn, q2 / qn, q3 / qn};
+  const float* S = m + 3;  // S[a][c] = sum w g[a] p[c]
+#define SM(a, c) S[3 * (a) + (c)]
+  const float pxg[3] = {SM(2, 1) - SM(1, 2), SM(0, 2) - SM(2, 0), SM(1, 0) - SM(0, 1)};  // sum p x g
+  const float tr     = SM(0, 0) + SM(1, 1) + SM(2, 2);                                 // sum g . p
+  float gqh[4];
+  for (int i = 0; i < 3; ++i) {
+    const float vdp_g = vq[0] * SM(i, 0) + vq[1] * SM(i, 1) + vq[2] * SM(i, 2);  // sum (q.p) g[i]
+    const float gdv_p = vq[0] * SM(0, i) + vq[1] * SM(1, i) + vq[2] * SM(2, i);  // sum (g.q) p[i]
+    gqh[i] = 2.0f * vq[3] * pxg[i] + 2.0f * (vdp_g + gdv_p - 2.0f * tr * vq[i]);
+  }
+  gqh[3] = 2.0f * ((vq[1] * SM(0, 2) - vq[2] * SM(0, 1)) + (vq[2] * SM(1, 0) - vq[0] * SM(1, 2)) +
+                   (vq[0] * SM(2, 1) - vq[1] * SM(2, 0)));  // sum g . (q x p)
+#undef SM
+  const float dotq = vq[0] * gqh[0] + vq[1] * gqh[1] + vq[2] * gqh[2] + vq[3] * gqh[3];
+  g_bone_T[7 * b] = m[0], g_bone_T[7 * b + 1] = m[1], g_bone_T[7 * b + 2] = m[2];
+  for (int i = 0; i < 4; ++i) g_bone_T[7 * b + 3 + i] = (gqh[i] - vq[i] * dotq) / qn;
+  for (int i = 0; i < 4; ++i) g_bone_drot[4 * b + i] = m[12 + i];
+  for (int i = 0; i < 3; ++i) g_bone_dscale[3 * b + i] = m[16 + i];
+}
+
 // K nearest bones (squared L2, ascending, ties -> lower index). joints staged in LDS.
 constexpr int KNN_MAXK = 16;
 // KCAP = compile-time capacity of the per-lane top-K list (>= K): the insertion network is KCAP steps per bone
@@ -292,6 +445,44 @@ __global__ void __launch_bounds__(256) knn_bones_kernel(int P, int M, int K, int
     }
 }
 
+// --------------------------------------------------------------------------------- LBS weights from logits
+// weights = softmax_k( sp_W[p, indices[p, k]] )  -- the `sp_W` branch of calc_LBS_weight (sk_gs.py:769-770:
+// torch.gather(sp_W, 1, indices).softmax(-1)); one lane per Gaussian, K <= 16.
+__global__ void __launch_bounds__(256) lbs_weights_forward_kernel(int P, int M, int K, const float* __restrict__ sp_W,
+    const int64_t* __restrict__ indices, float* __restrict__ weights) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  float l[KNN_MAXK];
+  float mx = -INFINITY;
+  for (int k = 0; k < K; ++k) {
+    l[k] = sp_W[(size_t) p * M + (int) indices[(size_t) p * K + k]];
+    mx   = fmaxf(mx, l[k]);
+  }
+  float sum = 0.f;
+  for (int k = 0; k < K; ++k) {
+    l[k] = expf(l[k] - mx);
+    sum += l[k];
+  }
+  for (int k = 0; k < K; ++k) weights[(size_t) p * K + k] = l[k] / sum;
+}
+
+// g_logit[k] = w[k] * (g_w[k] - sum_j w[j] g_w[j]), scattered back through the gather into a DENSE row of g_sp_W
+// (every element of the [P,M] gradient is written: zeros where the bone is not among the K nearest), one element
+// per lane so the 4*P*M bytes are stored coalesced.
+__global__ void __launch_bounds__(256) lbs_weights_backward_kernel(int P, int M, int K, const float* __restrict__ weights,
+    const int64_t* __restrict__ indices, const float* __restrict__ g_weights, float* __restrict__ g_sp_W) {
+  const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t) P * M) return;
+  const int p = (int) (i / M), m = (int) (i - (size_t) p * M);
+  float dot = 0.f, hit_w = 0.f, hit_g = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float w = weights[(size_t) p * K + k], g = g_weights[(size_t) p * K + k];
+    dot += w * g;
+    if ((int) indices[(size_t) p * K + k] == m) hit_w += w, hit_g += w * g;  // KNN indices are distinct
+  }
+  g_sp_W[i] = hit_g - hit_w * dot;
+}
+
 }  // namespace
 
 int launch_deform_forward(const skgs_deform_inputs& in, float* means, float* scales, float* rotations, float* opacity,
@@ -311,12 +502,44 @@ int launch_deform_forward(const skgs_deform_inputs& in, float* means, float* sca
   return 0;
 }
 
+size_t deform_backward_workspace_bytes(int P, int M) {
+  if (M > MOM_MAX_BONES) return 256;
+  const size_t nblk = (size_t) (P + DEFORM_THREADS - 1) / DEFORM_THREADS;
+  return align256(nblk * (size_t) M * MOM_F * 4) + 256;
+}
+
 int launch_deform_backward(const skgs_deform_inputs& in, const float* g_means, const float* g_scales,
     const float* g_rotations, const float* g_opacity, float* g_weights, float* g_bone_T, float* g_bone_drot,
-    float* g_bone_dscale, float* g_xyz, float* g_log_scale, float* g_rot, float* g_opacity_logit, hipStream_t s) {
-  if (in.P == 0) return 0;
-  ProfScope prof(K_DEFORM_BWD, s);
+    float* g_bone_dscale, float* g_xyz, float* g_log_scale, float* g_rot, float* g_opacity_logit, void* workspace,
+    hipStream_t s) {
+  if (in.P == 0) {  // outputs are always written completely
+    if (fill_u32(g_bone_T, 0u, (size_t) in.M * 7, s) || fill_u32(g_bone_drot, 0u, (size_t) in.M * 4, s) ||
+        fill_u32(g_bone_dscale, 0u, (size_t) in.M * 3, s))
+      return 1;
+    return 0;
+  }
   dim3 grid((in.P + DEFORM_THREADS - 1) / DEFORM_THREADS), block(DEFORM_THREADS);
+  if (in.M <= MOM_MAX_BONES) {
+    const int Mp     = (in.M + 3) & ~3;
+    const size_t lds = ((size_t) in.M * BONE_F + 4 * 64 * (size_t) Mp + 4 * 64 * MOM_U + 4 * (size_t) in.M * MOM_F) * 4;
+    float* partials  = reinterpret_cast<float*>(workspace);
+    {
+      ProfScope prof(K_DEFORM_BWD, s);
+      hipLaunchKernelGGL(deform_backward_moments_kernel, grid, block, lds, s, in.P, in.K, in.M, in.points, in.weights,
+          in.indices, in.bone_T, in.bone_drot, in.bone_dscale, in.log_scale, in.rot, in.opacity_logit, g_means, g_scales,
+          g_rotations, g_opacity, g_weights, g_xyz, g_log_scale, g_rot, g_opacity_logit, partials);
+    }
+    SKGS_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(deform_backward_finalize_kernel, dim3(in.M), dim3(256), 0, s, in.M, (int) grid.x, partials, in.bone_T,
+        g_bone_T, g_bone_drot, g_bone_dscale);
+    SKGS_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
+  // many bones (superpoint stage): scatter with atomics into zeroed outputs
+  if (fill_u32(g_bone_T, 0u, (size_t) in.M * 7, s) || fill_u32(g_bone_drot, 0u, (size_t) in.M * 4, s) ||
+      fill_u32(g_bone_dscale, 0u, (size_t) in.M * 3, s))
+    return 1;
+  ProfScope prof(K_DEFORM_BWD, s);
   if (in.M <= MAX_LDS_BONES / 2) {
     const size_t table = (size_t) in.M * BONE_F * 4;
     int ncopy = 1;
@@ -352,6 +575,24 @@ int launch_knn_bones(int P, int M, int K, int dim, const float* points, const fl
   else
     SKGS_KNN(KNN_MAXK);
 #undef SKGS_KNN
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_lbs_weights_forward(int P, int M, int K, const float* sp_W, const int64_t* indices, float* weights, hipStream_t s) {
+  if (P == 0) return 0;
+  if (K > KNN_MAXK || K < 1) return set_error("lbs_weights: K must be in [1,%d] (got %d)", KNN_MAXK, K);
+  hipLaunchKernelGGL(lbs_weights_forward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, M, K, sp_W, indices, weights);
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_lbs_weights_backward(int P, int M, int K, const float* weights, const int64_t* indices, const float* g_weights,
+    float* g_sp_W, hipStream_t s) {
+  if (P == 0 || M == 0) return 0;
+  const size_t n = (size_t) P * M;
+  hipLaunchKernelGGL(lbs_weights_backward_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, P, M, K, weights,
+      indices, g_weights, g_sp_W);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -201,8 +201,10 @@ __device__ __forceinline__ void cov2d_rm(const ProjRM& pr, const float* c6, floa
 // ---------------------------------------------------------------------------------------------- shared
 __device__ __forceinline__ float ndc2pix(float v, int S) { return (float) ((((double) v + 1.0) * S - 1.0) * 0.5); }
 
-// SH basis * coefficients for one Gaussian; sh points at [M][3].
-__device__ __forceinline__ void sh_to_rgb(int deg, const float* mean, const float* campos, const float* sh, float* rgb,
+// SH basis * coefficients for one Gaussian.  Coefficient 0 is read through `dc`, coefficients 1.. through `sh`
+// (indexed from coefficient 0): one [M][3] row has dc == sh; split DC / rest storage (skgs_raster_inputs::sh_rest)
+// passes two rows, the second biased by -3 floats.
+__device__ __forceinline__ void sh_to_rgb(int deg, const float* mean, const float* campos, const float* dc, const float* sh, float* rgb,
     uint32_t* clamp_bits) {
   float d[3]      = {mean[0] - campos[0], mean[1] - campos[1], mean[2] - campos[2]};
   const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
@@ -210,7 +212,7 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const float* mean, const floa
   uint32_t bits = 0;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    float r = SH_C0 * sh[c];
+    float r = SH_C0 * dc[c];
     if (deg > 0) {
       r = r - SH_C1 * y * sh[3 + c] + SH_C1 * z * sh[6 + c] - SH_C1 * x * sh[9 + c];
       if (deg > 1) {
@@ -235,7 +237,8 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const float* mean, const floa
 template <bool COLMAP>
 __global__ void __launch_bounds__(256) preprocess_forward_kernel(int P, int D, int M, const float* __restrict__ means3D,
     const float* __restrict__ scales, float scale_modifier, const float* __restrict__ rotations,
-    const float* __restrict__ opacities, const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
+    const float* __restrict__ opacities, const float* __restrict__ shs, const float* __restrict__ shs_rest,
+    const float* __restrict__ cov3D_precomp,
     const float* __restrict__ colors_precomp, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
     const float* __restrict__ campos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
     int gx, int gy, int32_t* __restrict__ radii, float4* __restrict__ recs, uint32_t* __restrict__ tile_counts) {
@@ -306,7 +309,10 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(int P, int D, i
       if (area != 0) {
         float rgb[3];
         if (colors_precomp == nullptr) {
-          sh_to_rgb(D, p, cam.campos, shs + (size_t) idx * M * 3, rgb, &clamp_bits);
+          if (shs_rest)
+            sh_to_rgb(D, p, cam.campos, shs + (size_t) idx * 3, shs_rest + (size_t) idx * (M - 1) * 3 - 3, rgb, &clamp_bits);
+          else
+            sh_to_rgb(D, p, cam.campos, shs + (size_t) idx * M * 3, shs + (size_t) idx * M * 3, rgb, &clamp_bits);
         } else {
           rgb[0] = colors_precomp[3 * idx], rgb[1] = colors_precomp[3 * idx + 1], rgb[2] = colors_precomp[3 * idx + 2];
         }
@@ -339,9 +345,10 @@ __device__ __forceinline__ void dnormvdv3(const float* v, const float* dv, float
   o[2] = (-v[0] * v[2] * dv[0] - v[1] * v[2] * dv[1] + (sum2 - v[2] * v[2]) * dv[2]) * invsum32;
 }
 
-// SH backward: writes dL_dsh[M][3] for this Gaussian and returns dL_dmean contribution.
+// SH backward: writes dL_dsh[M][3] for this Gaussian and returns dL_dmean contribution.  `sh` and (dL_ddc, dL_dsh)
+// follow the convention of sh_to_rgb (coefficient 0 through the first pointer; only coefficients >= 1 of sh are read).
 __device__ __forceinline__ void sh_backward(int deg, int M, const float* mean, const float* campos, const float* sh,
-    uint32_t clamp_bits, const float* dL_dcolor, float* dL_dsh, float* dL_dmean_out) {
+    uint32_t clamp_bits, const float* dL_dcolor, float* dL_ddc, float* dL_dsh, float* dL_dmean_out) {
   const float dir_orig[3] = {mean[0] - campos[0], mean[1] - campos[1], mean[2] - campos[2]};
   const float len = sqrtf(dir_orig[0] * dir_orig[0] + dir_orig[1] * dir_orig[1] + dir_orig[2] * dir_orig[2]);
   const float x = dir_orig[0] / len, y = dir_orig[1] / len, z = dir_orig[2] / len;
@@ -353,7 +360,7 @@ __device__ __forceinline__ void sh_backward(int deg, int M, const float* mean, c
 #define SETSH(i, coef)                                             \
   {                                                                \
     const float _k = (coef);                                       \
-    _Pragma("unroll") for (int c = 0; c < 3; ++c) dL_dsh[(i) *3 + c] = _k * g[c]; \
+    _Pragma("unroll") for (int c = 0; c < 3; ++c) ((i) == 0 ? dL_ddc : dL_dsh)[(i) *3 + c] = _k * g[c]; \
   }
   SETSH(0, SH_C0);
   if (deg > 0) {
@@ -414,7 +421,8 @@ __device__ __forceinline__ void sh_backward(int deg, int M, const float* mean, c
 
 template <bool COLMAP>
 __global__ void __launch_bounds__(256) preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3D,
-    const int32_t* __restrict__ radii, const float* __restrict__ shs, const float* __restrict__ scales,
+    const int32_t* __restrict__ radii, const float* __restrict__ shs, const float* __restrict__ shs_rest,
+    const float* __restrict__ scales,
     const float* __restrict__ rotations, float scale_modifier, const float* __restrict__ cov3D_precomp,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos, int W,
     int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, const float4* __restrict__ recs,
@@ -422,6 +430,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(int P, int D, 
     const float* __restrict__ gin_conic, const float* __restrict__ gin_opacity, int E, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_dconic_out, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
+    float* __restrict__ dL_dsh_rest,
     float* __restrict__ dL_dscales, float* __restrict__ dL_drot, float* __restrict__ dL_dextras) {
   __shared__ Cam cam;
   if (threadIdx.x < 16) {
@@ -458,10 +467,14 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(int P, int D, 
   for (int e = 0; e < E; ++e) dL_dextras[(size_t) idx * E + e] = gex[e];
 
   float gmean[3] = {0.f, 0.f, 0.f}, gcov[6] = {0, 0, 0, 0, 0, 0}, gscale[3] = {0, 0, 0}, grot[4] = {0, 0, 0, 0};
-  float* gsh_row = dL_dsh ? dL_dsh + (size_t) idx * M * 3 : nullptr;
+  // gradient rows of the SH coefficients: one [M][3] row, or split DC [1][3] / rest [M-1][3] rows (rest biased by -3)
+  float* gsh_dc  = dL_dsh ? dL_dsh + (size_t) idx * (dL_dsh_rest ? 1 : M) * 3 : nullptr;
+  float* gsh_row = dL_dsh_rest ? dL_dsh_rest + (size_t) idx * (M - 1) * 3 - 3 : gsh_dc;
   if (!visible) {
-    if (gsh_row)
-      for (int i = 0; i < M * 3; ++i) gsh_row[i] = 0.f;
+    if (gsh_dc) {
+      for (int i = 0; i < 3; ++i) gsh_dc[i] = 0.f;
+      for (int i = 3; i < M * 3; ++i) gsh_row[i] = 0.f;
+    }
   } else {
     const float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
     float c6[6];
@@ -599,7 +612,10 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(int P, int D, 
     if (shs) {
       const uint32_t clamp_bits = (__float_as_uint(recs[3 * idx + 2].z) >> 28) & 7u;
       float dm[3];
-      sh_backward(D, M, p, cam.campos, shs + (size_t) idx * M * 3, clamp_bits, gcol, gsh_row, dm);
+      if (shs_rest)
+        sh_backward(D, M, p, cam.campos, shs_rest + (size_t) idx * (M - 1) * 3 - 3, clamp_bits, gcol, gsh_dc, gsh_row, dm);
+      else
+        sh_backward(D, M, p, cam.campos, shs + (size_t) idx * M * 3, clamp_bits, gcol, gsh_dc, gsh_row, dm);
       gmean[0] += dm[0], gmean[1] += dm[1], gmean[2] += dm[2];
     }
     // ---- Sigma3D -> scale, rotation ----
@@ -693,12 +709,14 @@ int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView 
   dim3 grid((P + 255) / 256), block(256);
   if (in.colmap)
     hipLaunchKernelGGL(preprocess_forward_kernel<true>, grid, block, 0, s, P, in.sh_degree, in.sh_coeffs, in.means3D,
-        in.scales, in.scale_modifier, in.rotations, in.opacity, in.sh, in.cov3D_precomp, in.colors_precomp, in.viewmatrix,
+        in.scales, in.scale_modifier, in.rotations, in.opacity, in.sh, in.sh_rest, in.cov3D_precomp, in.colors_precomp,
+        in.viewmatrix,
         in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y, im.tiles_x,
         im.tiles_y, radii, g.recs, im.tile_counts);
   else
     hipLaunchKernelGGL(preprocess_forward_kernel<false>, grid, block, 0, s, P, in.sh_degree, in.sh_coeffs, in.means3D,
-        in.scales, in.scale_modifier, in.rotations, in.opacity, in.sh, in.cov3D_precomp, in.colors_precomp, in.viewmatrix,
+        in.scales, in.scale_modifier, in.rotations, in.opacity, in.sh, in.sh_rest, in.cov3D_precomp, in.colors_precomp,
+        in.viewmatrix,
         in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y, im.tiles_x,
         im.tiles_y, radii, g.recs, im.tile_counts);
   SKGS_CHECK_HIP(hipGetLastError());
@@ -715,10 +733,12 @@ int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const i
   dim3 grid((P + 255) / 256), block(256);
   const int E = (in.extras && gr.dL_dout_extra && gr.dL_dextras) ? in.E : 0;
 #define SKGS_PB_ARGS                                                                                                    \
-  P, in.sh_degree, in.sh_coeffs, in.means3D, radii, in.sh, in.scales, in.rotations, in.scale_modifier, in.cov3D_precomp, \
+  P, in.sh_degree, in.sh_coeffs, in.means3D, radii, in.sh, in.sh_rest, in.scales, in.rotations, in.scale_modifier,       \
+      in.cov3D_precomp,                                                                                                \
       in.viewmatrix, in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y, \
       g.recs, gr.workspace, gr.grad_means2D_in, gr.grad_conic_in, gr.grad_opacity_in, E, gr.dL_dmeans2D, gr.dL_dconic,    \
-      gr.dL_dcolors, gr.dL_dopacity, gr.dL_dmeans3D, gr.dL_dcov3D, gr.dL_dsh, gr.dL_dscales, gr.dL_drotations, gr.dL_dextras
+      gr.dL_dcolors, gr.dL_dopacity, gr.dL_dmeans3D, gr.dL_dcov3D, gr.dL_dsh, gr.dL_dsh_rest, gr.dL_dscales, gr.dL_drotations, \
+      gr.dL_dextras
   if (in.colmap)
     hipLaunchKernelGGL(preprocess_backward_kernel<true>, grid, block, 0, s, SKGS_PB_ARGS);
   else

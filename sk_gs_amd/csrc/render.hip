@@ -312,12 +312,12 @@ int launch_render_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, 
     const int nblk = ((im.T * (4 / PPL_) + 7) / 8) * 8;                                                                 \
     if (g_strict)                                                                                                       \
       hipLaunchKernelGGL((blend_strict::render_forward_kernel<PPL_, E_>), dim3(nblk), dim3(64), 0, s, W, H, im.tiles_x, \
-          im.T, im.tile_offsets, b.capacity, b.point_list, g.recs, in.extras, im.n_contrib, out_color, out_opacity,     \
-          out_extra);                                                                                                   \
+          im.T, im.tile_offsets, b.capacity, b.point_list, g.recs, in.extras, in.background, im.n_contrib, out_color,   \
+          out_opacity, out_extra);                                                                                      \
     else                                                                                                                \
       hipLaunchKernelGGL((blend_fast::render_forward_kernel<PPL_, E_>), dim3(nblk), dim3(64), 0, s, W, H, im.tiles_x,   \
-          im.T, im.tile_offsets, b.capacity, b.point_list, g.recs, in.extras, im.n_contrib, out_color, out_opacity,     \
-          out_extra);                                                                                                   \
+          im.T, im.tile_offsets, b.capacity, b.point_list, g.recs, in.extras, in.background, im.n_contrib, out_color,   \
+          out_opacity, out_extra);                                                                                      \
   }
   if (ppl == 4) {
     SKGS_DISPATCH_E(E, FWD, 4)
@@ -342,12 +342,12 @@ int launch_render_backward(const skgs_raster_inputs& in, GeomView g, ImgView im,
     const int nblk = ((im.T * (4 / PPL_) + 7) / 8) * 8;                                                                \
     if (g_strict)                                                                                                      \
       hipLaunchKernelGGL((blend_strict::render_backward_kernel<PPL_, E_>), dim3(nblk), dim3(64), 0, s, W, H,           \
-          im.tiles_x, im.T, im.tile_offsets, b.capacity, b.point_list, g.recs, in.extras, out_opacity, im.n_contrib,   \
-          dL_dcolor, dL_dextra, dL_dopacity, gradacc);                                                                 \
+ im.tiles_x, im.T, im.tile_offsets, b.capacity, b.point_list, g.recs, in.extras, in.background, out_opacity,       \
+          im.n_contrib, dL_dcolor, dL_dextra, dL_dopacity, gradacc);                                                               \
     else                                                                                                               \
       hipLaunchKernelGGL((blend_fast::render_backward_kernel<PPL_, E_>), dim3(nblk), dim3(64), 0, s, W, H, im.tiles_x, \
-          im.T, im.tile_offsets, b.capacity, b.point_list, g.recs, in.extras, out_opacity, im.n_contrib, dL_dcolor,    \
-          dL_dextra, dL_dopacity, gradacc);                                                                            \
+          im.T, im.tile_offsets, b.capacity, b.point_list, g.recs, in.extras, in.background, out_opacity, im.n_contrib,   \
+          dL_dcolor, dL_dextra, dL_dopacity, gradacc);                                                                           \
   }
   if (ppl == 4) {
     SKGS_DISPATCH_E(E, BWD, 4)

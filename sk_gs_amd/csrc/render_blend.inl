@@ -18,8 +18,8 @@ __device__ __forceinline__ float blend_exp(float x) {
 template <int PPL, int E>
 __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx, int T, const uint32_t* __restrict__ offsets,
     int64_t capacity, const uint32_t* __restrict__ point_list, const float4* __restrict__ recs,
-    const float* __restrict__ extra, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-    float* __restrict__ out_opacity, float* __restrict__ out_extra) {
+    const float* __restrict__ extra, const float* __restrict__ bg, uint32_t* __restrict__ n_contrib,
+    float* __restrict__ out_color, float* __restrict__ out_opacity, float* __restrict__ out_extra) {
   constexpr int SUBS = 4 / PPL;
   const int v        = xcd_remap(blockIdx.x, T * SUBS);
   if (v >= T * SUBS) return;
@@ -147,9 +147,10 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
     if (pix.inside[i]) {
       out_opacity[pix.id[i]] = 1.f - Tr[i];
       n_contrib[pix.id[i]]   = last[i];
-      out_color[pix.id[i]]          = C[i][0];
-      out_color[HW + pix.id[i]]     = C[i][1];
-      out_color[2 * HW + pix.id[i]] = C[i][2];
+      // optional background: C + T * bg (upstream diff_gaussian_rasterization epilogue; NULL = in-tree variant)
+      out_color[pix.id[i]]          = bg ? C[i][0] + Tr[i] * bg[0] : C[i][0];
+      out_color[HW + pix.id[i]]     = bg ? C[i][1] + Tr[i] * bg[1] : C[i][1];
+      out_color[2 * HW + pix.id[i]] = bg ? C[i][2] + Tr[i] * bg[2] : C[i][2];
 #pragma unroll
       for (int e = 0; e < E; ++e) out_extra[e * HW + pix.id[i]] = Ex[i][e];
     }
@@ -162,9 +163,10 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
 template <int PPL, int E>
 __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int gx, int T, const uint32_t* __restrict__ offsets,
     int64_t capacity, const uint32_t* __restrict__ point_list, const float4* __restrict__ recs,
-    const float* __restrict__ extra, const float* __restrict__ out_opacity, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dout_extra,
-    const float* __restrict__ dL_dout_opacity, float* __restrict__ gradacc) {
+    const float* __restrict__ extra, const float* __restrict__ bg, const float* __restrict__ out_opacity,
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
+    const float* __restrict__ dL_dout_extra, const float* __restrict__ dL_dout_opacity /* may be NULL */,
+    float* __restrict__ gradacc) {
   constexpr int SUBS = 4 / PPL;
   constexpr int NV   = 9 + E;
   const int v        = xcd_remap(blockIdx.x, T * SUBS);
@@ -193,7 +195,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
     const bool in = pix.inside[i];
     T_final[i]    = in ? 1.0f - out_opacity[pix.id[i]] : 0.f;
     Tr[i]         = T_final[i];
-    dL_dT[i]      = in ? -dL_dout_opacity[pix.id[i]] : 0.f;
+    dL_dT[i]      = (in && dL_dout_opacity) ? -dL_dout_opacity[pix.id[i]] : 0.f;
     lastk[i]      = in ? n_contrib[pix.id[i]] : 0u;
     maxk          = max(maxk, lastk[i]);
     last_alpha[i] = 0.f;
@@ -202,6 +204,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
       dpix[i][c]  = in ? dL_dpixels[c * HW + pix.id[i]] : 0.f;
       accum[i][c] = 0.f, lastc[i][c] = 0.f;
     }
+    // out_color = C + T_final * bg: the background adds bg . dL_dpixel to dL/dT_final
+    if (bg) dL_dT[i] += bg[0] * dpix[i][0] + bg[1] * dpix[i][1] + bg[2] * dpix[i][2];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       dex[i][e]     = in ? dL_dout_extra[e * HW + pix.id[i]] : 0.f;

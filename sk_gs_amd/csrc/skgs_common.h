@@ -258,9 +258,14 @@ int launch_topk(int topk, int W, int H, GeomView g, ImgView im, BinView b, int32
 // deform.hip
 int launch_deform_forward(const skgs_deform_inputs& in, float* means, float* scales, float* rotations, float* opacity,
     float* d_xyz, float* d_rot, float* d_scale, hipStream_t s);
+size_t deform_backward_workspace_bytes(int P, int M);
 int launch_deform_backward(const skgs_deform_inputs& in, const float* g_means, const float* g_scales,
     const float* g_rotations, const float* g_opacity, float* g_weights, float* g_bone_T, float* g_bone_drot,
-    float* g_bone_dscale, float* g_xyz, float* g_log_scale, float* g_rot, float* g_opacity_logit, hipStream_t s);
+    float* g_bone_dscale, float* g_xyz, float* g_log_scale, float* g_rot, float* g_opacity_logit, void* workspace,
+    hipStream_t s);
 int launch_knn_bones(int P, int M, int K, int dim, const float* points, const float* joints, float* out_dist,
     int64_t* out_idx, hipStream_t s);
+int launch_lbs_weights_forward(int P, int M, int K, const float* sp_W, const int64_t* indices, float* weights, hipStream_t s);
+int launch_lbs_weights_backward(int P, int M, int K, const float* weights, const int64_t* indices, const float* g_weights,
+    float* g_sp_W, hipStream_t s);
 }  // namespace skgs

@@ -1,0 +1,202 @@
+"""The per-view training step as a straight line of C-ABI calls on persistent buffers.
+
+``SkinnedGaussians.render`` + ``image_loss`` + ``loss.backward()`` run the hot path through torch autograd: every
+operator of include/skgs.h is one autograd node, and autograd adds its own kernels around them -- ``torch.cat`` of
+the two SH parameters and the split of its gradient, gather / softmax / scatter for the LBS logits, index-select of the
+per-frame tables and the zero-filled tables of their backward, one ``AccumulateGrad`` add per parameter, zero fills for
+every freshly allocated gradient.  On one MI355X (config #1) that glue is ~40 short launches and ~0.2 ms of a 0.85 ms
+step.  ``FusedViewStep`` issues the SAME library calls in the same order, but
+
+  * reads the parameters in place (split SH storage: ``skgs_raster_inputs.sh_rest``; per-frame rows by pointer),
+  * composites the background inside the blend kernels (``skgs_raster_inputs.background``),
+  * lets every backward kernel write its result straight into the parameter's ``.grad`` storage (the views of
+    ``view_parallel.FlatGradBuffer``), overwriting instead of accumulating,
+
+so a step is ~22 kernels of ours and one tiny fill, with no autograd graph at all.  It computes exactly what the autograd
+path computes (tests/test_gpu_fused_step.py compares every gradient); the autograd path stays the drop-in operator
+surface.
+
+Reference call sequence: networks/sk_gs.py:1160-1242 (forward / render), :1524-1529 (loss), train.py:179-250.
+"""
+import ctypes as C
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from sk_gs_amd import _C
+from sk_gs_amd.model import SkinnedGaussians
+from sk_gs_amd.renderer.gaussian_render import GaussianRasterizationSettings
+
+
+def _p(t: Optional[Tensor]) -> C.c_void_p:
+    return C.c_void_p(None if t is None else t.data_ptr())
+
+
+class FusedViewStep:
+    """forward + loss + backward of one view for a ``SkinnedGaussians`` model (stage ``sk``, sp_W weights).
+
+    After ``forward_backward(rs, time_id, target)``:
+      * every parameter's ``.grad`` holds the gradient of ``lambda_l1 * L1 + lambda_ssim * (1 - SSIM)`` (overwritten),
+      * ``loss3`` (device, 3 floats) = total, L1 mean, SSIM mean; ``grad_means2D`` [P,3] is the screen-space gradient
+        the densification statistics use (``viewspace_points.grad``, gaussian_splatting.py:503-513);
+      * ``image`` [3,H,W], ``out_opacity`` [H,W], ``radii`` [P] are the forward results.
+    No host synchronisation: the binning buffer has a fixed ``capacity`` (tile instances); ``status()`` reads the
+    device-side overflow flag.  hipGraph-capturable.
+    """
+
+    def __init__(self, model: SkinnedGaussians, W: int, H: int, capacity: int, lambda_dssim: float = 0.2,
+                 background: Optional[Tensor] = None):
+        assert not model.static, 'FusedViewStep covers the skinned stage (M >= 1)'
+        self.model, self.W, self.H = model, int(W), int(H)
+        self.lambda_l1, self.lambda_ssim = 1.0 - lambda_dssim, lambda_dssim
+        lib = self.lib = _C.load_library()
+        dev = model._xyz.device
+        if not model._xyz.is_cuda:
+            raise _C.SkgsError('FusedViewStep needs the model on a HIP device; sk_gs_amd has no CPU path')
+        P, M, K = model.P, model.M, model.K
+        self.P, self.M, self.K = P, M, K
+        f32 = dict(dtype=torch.float32, device=dev)
+        u8 = dict(dtype=torch.uint8, device=dev)
+        self.background = None if background is None else background.to(**f32).contiguous()
+        for p in model.parameters():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            assert p.is_contiguous() and p.grad.is_contiguous() and p.dtype == torch.float32
+        # ---- persistent intermediates -------------------------------------------------------------------------
+        self.bone_T, self.chain_A = torch.empty((M, 7), **f32), torch.empty((M, 7), **f32)
+        self.knn_dist = torch.empty((P, K), **f32)
+        self.indices = torch.empty((P, K), dtype=torch.int64, device=dev)
+        self.weights = torch.empty((P, K), **f32)
+        self.means, self.scales = torch.empty((P, 3), **f32), torch.empty((P, 3), **f32)
+        self.rotations, self.opacity = torch.empty((P, 4), **f32), torch.empty((P, 1), **f32)
+        self.image, self.out_opacity = torch.empty((3, H, W), **f32), torch.empty((H, W), **f32)
+        self.radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        self.geom = torch.empty((lib.skgs_geom_buffer_bytes(C.c_int32(P)),), **u8)
+        self.img = torch.empty((lib.skgs_img_buffer_bytes(C.c_int32(W), C.c_int32(H)),), **u8)
+        self.binning = torch.empty((lib.skgs_binning_buffer_bytes(C.c_int64(int(capacity))),), **u8)
+        self.loss3 = torch.zeros(3, **f32)
+        self.loss_ws = torch.empty((lib.skgs_image_loss_workspace_bytes(C.c_int32(3), C.c_int32(H), C.c_int32(W)),), **u8)
+        self.dL_dimage = torch.empty((3, H, W), **f32)
+        self.grad_means2D = torch.empty((P, 3), **f32)
+        self.g_colors, self.g_cov3D = torch.empty((P, 3), **f32), torch.empty((P, 6), **f32)
+        self.g_means, self.g_scales = torch.empty((P, 3), **f32), torch.empty((P, 3), **f32)
+        self.g_rotations, self.g_opacity = torch.empty((P, 4), **f32), torch.empty((P, 1), **f32)
+        self.g_weights = torch.empty((P, K), **f32)
+        self.g_bone_T = torch.empty((M, 7), **f32)
+        self.deform_ws = torch.empty((lib.skgs_lbs_deform_backward_workspace_bytes(C.c_int32(P), C.c_int32(M)),), **u8)
+        self.bwd_ws = torch.empty((lib.skgs_backward_workspace_bytes(C.c_int32(P)),), **u8)
+        topo = model.topology()
+        self._topo = topo
+        self._bufs = _C._buffers(self.geom, self.binning, self.img)
+
+    # ------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _zero_table_grads(self):
+        """per-frame tables: only row ``time_id`` gets a gradient, every other row must read zero.  With a
+        FlatGradBuffer the four tables are adjacent: one fill."""
+        m = self.model
+        tabs = [m.sk_r.grad, m.sk_d_rot.grad, m.sk_d_scale.grad, m.global_tr.grad]
+        lo = min(t.data_ptr() for t in tabs)
+        total = sum(t.numel() for t in tabs)
+        first = min(tabs, key=lambda t: t.data_ptr())
+        contiguous = (max(t.data_ptr() + t.numel() * 4 for t in tabs) - lo == total * 4
+                      and first.untyped_storage().data_ptr() == tabs[-1].untyped_storage().data_ptr())
+        if contiguous:
+            torch.as_strided(first, (total,), (1,)).zero_()
+        else:
+            for t in tabs:
+                t.zero_()
+
+    def _raster_inputs(self, rs: GaussianRasterizationSettings) -> '_C._RasterInputs':
+        m = self.model
+        a = _C._RasterInputs()
+        a.P, a.sh_degree, a.sh_coeffs, a.E = self.P, int(rs.sh_degree), (m.max_sh_degree + 1) ** 2, 0
+        a.image_height, a.image_width = self.H, self.W
+        a.tanfovx, a.tanfovy, a.scale_modifier = float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier)
+        a.prefiltered, a.debug, a.colmap = int(bool(rs.prefiltered)), int(bool(rs.debug)), int(bool(rs.colmap))
+        for name in ('viewmatrix', 'projmatrix', 'campos'):
+            t = getattr(rs, name)
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), name
+            setattr(a, name, t.data_ptr())
+        a.means3D, a.opacity = self.means.data_ptr(), self.opacity.data_ptr()
+        a.scales, a.rotations = self.scales.data_ptr(), self.rotations.data_ptr()
+        a.sh, a.sh_rest = m._features_dc.data_ptr(), m._features_rest.data_ptr()
+        a.background = None if self.background is None else self.background.data_ptr()
+        return a
+
+    def _deform_inputs(self, time_id: int) -> '_C._DeformInputs':
+        m = self.model
+        a = _C._DeformInputs()
+        a.P, a.K, a.M = self.P, self.K, self.M
+        a.points = a.xyz = m._xyz.data_ptr()  # points = xyz.detach() (sk_gs.py:1113): same storage
+        a.weights, a.indices, a.bone_T = self.weights.data_ptr(), self.indices.data_ptr(), self.bone_T.data_ptr()
+        a.bone_drot, a.bone_dscale = m.sk_d_rot[time_id].data_ptr(), m.sk_d_scale[time_id].data_ptr()
+        a.log_scale, a.rot, a.opacity_logit = m._scaling.data_ptr(), m._rotation.data_ptr(), m._opacity.data_ptr()
+        return a
+
+    # ------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, rs: GaussianRasterizationSettings, time_id: int):
+        """bone chain -> KNN + LBS weights -> skin + activations -> rasterize.  Fills ``image`` / ``out_opacity``."""
+        lib, m, st, chk = self.lib, self.model, _C._stream(), _C._check
+        t = self._topo
+        P, M, K = self.P, self.M, self.K
+        chk(lib.skgs_bone_chain_forward(
+            C.c_int32(M), C.c_int32(t['root']), _p(t['parents']), _p(t['level_nodes']), _p(t['level_start']),
+            C.c_int32(t['num_levels']), _p(m.sk_r[time_id]), _p(m.joints), _p(m.global_tr[time_id]), _p(self.bone_T),
+            _p(self.chain_A), st))
+        chk(lib.skgs_knn_bones(C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(3), _p(m._xyz), _p(m.joints),
+                               _p(self.knn_dist), _p(self.indices), st))
+        chk(lib.skgs_lbs_weights_forward(C.c_int32(P), C.c_int32(M), C.c_int32(K), _p(m.sp_W), _p(self.indices),
+                                         _p(self.weights), st))
+        d = self._deform_inputs(time_id)
+        chk(lib.skgs_lbs_deform_forward(C.byref(d), _p(self.means), _p(self.scales), _p(self.rotations),
+                                        _p(self.opacity), None, None, None, st))
+        a = self._raster_inputs(rs)
+        chk(lib.skgs_rasterize_forward(C.byref(a), C.byref(self._bufs), _p(self.radii), _p(self.image),
+                                       _p(self.out_opacity), None, None, st))
+        return a, d
+
+    @torch.no_grad()
+    def forward_backward(self, rs: GaussianRasterizationSettings, time_id: int, target: Tensor):
+        lib, m, st, chk = self.lib, self.model, _C._stream(), _C._check
+        t = self._topo
+        P, M, K, W, H = self.P, self.M, self.K, self.W, self.H
+        assert target.is_cuda and target.dtype == torch.float32 and target.is_contiguous()
+        self._zero_table_grads()
+        a, d = self.forward(rs, time_id)
+        # ---- loss and dL/dimage
+        chk(lib.skgs_image_loss_forward(C.c_int32(3), C.c_int32(H), C.c_int32(W), _p(self.image), _p(target),
+                                        C.c_float(self.lambda_l1), C.c_float(self.lambda_ssim), _p(self.loss3),
+                                        _p(self.loss_ws), C.c_size_t(self.loss_ws.numel()), st))
+        chk(lib.skgs_image_loss_backward(C.c_int32(3), C.c_int32(H), C.c_int32(W), _p(self.image), _p(target),
+                                         C.c_float(self.lambda_l1), C.c_float(self.lambda_ssim), None,
+                                         _p(self.loss_ws), C.c_size_t(self.loss_ws.numel()), _p(self.dL_dimage), st))
+        # ---- rasterize backward: SH gradients land in the parameters' .grad, the rest feeds the skinning backward
+        g = _C._RasterGrads()
+        g.dL_dout_color = self.dL_dimage.data_ptr()  # dL_dout_opacity = NULL: the background term is in-kernel
+        g.dL_dmeans2D, g.dL_dcolors, g.dL_dopacity = (self.grad_means2D.data_ptr(), self.g_colors.data_ptr(),
+                                                      self.g_opacity.data_ptr())
+        g.dL_dmeans3D, g.dL_dcov3D = self.g_means.data_ptr(), self.g_cov3D.data_ptr()
+        g.dL_dsh, g.dL_dsh_rest = m._features_dc.grad.data_ptr(), m._features_rest.grad.data_ptr()
+        g.dL_dscales, g.dL_drotations = self.g_scales.data_ptr(), self.g_rotations.data_ptr()
+        g.workspace, g.workspace_bytes = self.bwd_ws.data_ptr(), self.bwd_ws.numel()
+        chk(lib.skgs_rasterize_backward(C.byref(a), C.byref(self._bufs), _p(self.radii), _p(self.out_opacity),
+                                        C.byref(g), st))
+        # ---- skinning backward: Gaussian parameters' gradients written in place
+        chk(lib.skgs_lbs_deform_backward(
+            C.byref(d), _p(self.g_means), _p(self.g_scales), _p(self.g_rotations), _p(self.g_opacity),
+            _p(self.g_weights), _p(self.g_bone_T), _p(m.sk_d_rot.grad[time_id]), _p(m.sk_d_scale.grad[time_id]),
+            _p(m._xyz.grad), _p(m._scaling.grad), _p(m._rotation.grad), _p(m._opacity.grad), _p(self.deform_ws),
+            C.c_size_t(self.deform_ws.numel()), st))
+        chk(lib.skgs_lbs_weights_backward(C.c_int32(P), C.c_int32(M), C.c_int32(K), _p(self.weights), _p(self.indices),
+                                          _p(self.g_weights), _p(m.sp_W.grad), st))
+        chk(lib.skgs_bone_chain_backward(
+            C.c_int32(M), C.c_int32(t['root']), _p(t['parents']), _p(t['level_nodes']), _p(t['level_start']),
+            C.c_int32(t['num_levels']), _p(m.sk_r[time_id]), _p(m.joints), _p(m.global_tr[time_id]), _p(self.chain_A),
+            _p(self.g_bone_T), _p(m.sk_r.grad[time_id]), None, _p(m.global_tr.grad[time_id]), st))
+
+    def status(self) -> dict:
+        """(synchronising) num_rendered / overflow / longest tile list of the last forward"""
+        return _C.read_status(self.geom)
