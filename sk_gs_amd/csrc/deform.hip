@@ -353,21 +353,35 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_moments_kernel
     partials[(size_t) blockIdx.x * n_out + o] = (s_part[o] + s_part[n_out + o]) + (s_part[2 * n_out + o] + s_part[3 * n_out + o]);
 }
 
-// one workgroup per bone: fixed-order reduction of the per-workgroup partial moments, then the per-bone linear maps
+// one workgroup per bone: fixed-order reduction of the per-workgroup partial moments, then the per-bone linear maps.
+// Thread t owns the partial rows w = t, t + 256, ...: its 19 loads per row are independent (all in flight together;
+// a per-component loop over w was a 49-deep dependent load chain, 15 us), then an LDS tree over the 256 threads.
 __global__ void __launch_bounds__(256) deform_backward_finalize_kernel(int M, int nblk, const float* __restrict__ partials,
     const float* __restrict__ bone_T, float* __restrict__ g_bone_T, float* __restrict__ g_bone_drot,
     float* __restrict__ g_bone_dscale) {
-  __shared__ float s_red[8][32];
-  const int b = blockIdx.x, c = threadIdx.x & 31, slice = threadIdx.x >> 5;
-  float acc = 0.f;
-  if (c < MOM_F)
-    for (int w = slice; w < nblk; w += 8) acc += partials[((size_t) w * M + b) * MOM_F + c];
-  s_red[slice][c] = acc;
+  __shared__ float s_red[256][MOM_F + 1];
+  const int b = blockIdx.x, t = threadIdx.x;
+  float acc[MOM_F];
+#pragma unroll
+  for (int c = 0; c < MOM_F; ++c) acc[c] = 0.f;
+  for (int w = t; w < nblk; w += 256) {
+    const float* row = partials + ((size_t) w * M + b) * MOM_F;
+#pragma unroll
+    for (int c = 0; c < MOM_F; ++c) acc[c] += row[c];
+  }
+#pragma unroll
+  for (int c = 0; c < MOM_F; ++c) s_red[t][c] = acc[c];
   __syncthreads();
-  if (threadIdx.x != 0) return;
+  for (int d = 128; d > 0; d >>= 1) {
+    if (t < d) {
+#pragma unroll
+      for (int c = 0; c < MOM_F; ++c) s_red[t][c] += s_red[t + d][c];
+    }
+    __syncthreads();
+  }
+  if (t != 0) return;
   float m[MOM_F];
-  for (int i = 0; i < MOM_F; ++i)
-    m[i] = ((s_red[0][i] + s_red[1][i]) + (s_red[2][i] + s_red[3][i])) + ((s_red[4][i] + s_red[5][i]) + (s_red[6][i] + s_red[7][i]));
+  for (int i = 0; i < MOM_F; ++i) m[i] = s_red[0][i];
   const float q0 = bone_T[7 * b + 3], q1 = bone_T[7 * b + 4], q2 = bone_T[7 * b + 5], q3 = bone_T[7 * b + 6];
   const float qn = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
   const float vq[4] = {q0 / qn, q1 / qn, q2 / qn, q3 / qn};

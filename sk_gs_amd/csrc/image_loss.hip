@@ -6,9 +6,10 @@
 // image_loss.py:6-32 (L1 mean), weights exps/default.yaml:83-84.  On MI355X the depth-wise convs run in MIOpen at
 // ~0.4 ms each -- 3.5 ms per training step, more than the whole rasterizer.
 //
-// Here: the window is separable, so each 16x16 output tile stages a 26x26 halo of x and y in LDS, runs the 11-tap
-// horizontal pass for the 5 moments (x, y, xx, yy, xy) into LDS and the vertical pass into registers, evaluates the
-// SSIM map and its partial derivatives w.r.t. (mu1, E[xx], E[xy]) in place, and block-reduces the SSIM and L1 sums.
+// Here: the window is separable, so each 32x32 output tile stages a 42x42 halo of x and y in LDS, runs the 11-tap
+// horizontal pass for the 5 moments (x, y, xx, yy, xy) into LDS and the vertical pass into registers (both passes
+// register-blocked: a thread slides the window over 18 / 14 inputs for 8 / 4 outputs), evaluates the SSIM map and its
+// partial derivatives w.r.t. (mu1, E[xx], E[xy]) in place, and block-reduces the SSIM and L1 sums.
 // Backward = the same separable convolution applied to the three derivative maps:
 //     dL/dx = gs * (w * dmu1 + 2 x (w * dExx) + y (w * dExy)) + gl * sign(x - y).
 // HBM traffic: forward reads 2 and writes 3 image planes, backward reads 5 and writes 1 (vs ~60 plane passes in
@@ -18,9 +19,15 @@
 namespace skgs {
 namespace {
 
-constexpr int LT   = 16;           // tile edge
-constexpr int HALO = 5;            // window radius
-constexpr int LW   = LT + 2 * HALO;  // 26
+constexpr int TW   = 32, TH = 32;      // output tile of one workgroup
+constexpr int HALO = 5;                // window radius
+constexpr int IW   = TW + 2 * HALO;    // 42 staged columns
+constexpr int IH   = TH + 2 * HALO;    // 42 staged rows
+constexpr int IP   = IW + 2;           // LDS pitch of the staged inputs (16-B aligned 8-column segments)
+constexpr int HP   = TW + 1;           // LDS pitch of the horizontally filtered rows
+constexpr int SEG  = 8;                // horizontal pass: outputs per thread (18 inputs -> 8 outputs)
+constexpr int VSEG = 4;                // vertical pass: outputs per thread (14 inputs -> 4 outputs)
+static_assert(TW % SEG == 0 && (TH / VSEG) * TW == 256 && IH * (TW / SEG) <= 256, "tile / thread mapping");
 struct Win {
   float g[11];
 };
@@ -36,66 +43,102 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red) {
   return r;
 }
 
+// Register-blocked separable filter: a thread of the horizontal pass slides the 11-tap window over 18 staged inputs
+// for 8 adjacent outputs (2.25 LDS reads per output and moment pair instead of 22), a thread of the vertical pass
+// over 14 rows for 4 outputs (3.5 reads per output instead of 11).  The kernel was LDS-issue bound before.
 __global__ void __launch_bounds__(256) image_loss_forward_kernel(int C, int H, int W, const float* __restrict__ pred,
     const float* __restrict__ gt, Win win, float* __restrict__ dmaps /*[3][C][H][W]*/, float* __restrict__ partials) {
-  __shared__ float s_x[LW][LW + 1];
-  __shared__ float s_y[LW][LW + 1];
-  __shared__ float s_h[5][LW][LT + 1];
+  __shared__ float s_x[IH][IP];
+  __shared__ float s_y[IH][IP];
+  __shared__ float s_h[5][IH][HP];
   __shared__ float s_red[4];
   const int c  = blockIdx.z;
-  const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const int tid = threadIdx.x;
   const size_t plane = (size_t) H * W;
   const float* px = pred + c * plane;
   const float* py = gt + c * plane;
-  for (int i = tid; i < LW * LW; i += 256) {
-    const int r = i / LW, q = i - r * LW;
+  for (int i = tid; i < IH * IW; i += 256) {
+    const int r = i / IW, q = i - r * IW;
     const int gy = y0 + r - HALO, gx = x0 + q - HALO;
     const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
     s_x[r][q] = in ? px[(size_t) gy * W + gx] : 0.f;
     s_y[r][q] = in ? py[(size_t) gy * W + gx] : 0.f;
   }
   __syncthreads();
-  for (int i = tid; i < LW * LT; i += 256) {
-    const int r = i / LT, q = i - r * LT;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+  if (tid < IH * (TW / SEG)) {
+    const int r = tid / (TW / SEG), q0 = (tid % (TW / SEG)) * SEG;
+    float a[SEG][5];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const float w = win.g[k], xv = s_x[r][q + k], yv = s_y[r][q + k];
-      a0 += w * xv, a1 += w * yv, a2 += w * xv * xv, a3 += w * yv * yv, a4 += w * xv * yv;
+    for (int o = 0; o < SEG; ++o)
+#pragma unroll
+      for (int m = 0; m < 5; ++m) a[o][m] = 0.f;
+#pragma unroll
+    for (int i = 0; i < SEG + 10; ++i) {
+      const float xv = s_x[r][q0 + i], yv = s_y[r][q0 + i];
+      const float xx = xv * xv, yy = yv * yv, xy = xv * yv;
+#pragma unroll
+      for (int o = 0; o < SEG; ++o) {
+        const int k = i - o;  // compile-time after unrolling
+        if (k >= 0 && k < 11) {
+          const float w = win.g[k];
+          a[o][0] += w * xv, a[o][1] += w * yv, a[o][2] += w * xx, a[o][3] += w * yy, a[o][4] += w * xy;
+        }
+      }
     }
-    s_h[0][r][q] = a0, s_h[1][r][q] = a1, s_h[2][r][q] = a2, s_h[3][r][q] = a3, s_h[4][r][q] = a4;
+#pragma unroll
+    for (int o = 0; o < SEG; ++o)
+#pragma unroll
+      for (int m = 0; m < 5; ++m) s_h[m][r][q0 + o] = a[o][m];
   }
   __syncthreads();
-  const int tx = tid & 15, ty = tid >> 4;
-  const int gx = x0 + tx, gy = y0 + ty;
-  const bool inside = gx < W && gy < H;
-  float mu1 = 0.f, mu2 = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
+  const int tx = tid % TW, ty0 = (tid / TW) * VSEG;
+  float v[VSEG][5];
 #pragma unroll
-  for (int k = 0; k < 11; ++k) {
-    const float w = win.g[k];
-    mu1 += w * s_h[0][ty + k][tx], mu2 += w * s_h[1][ty + k][tx], exx += w * s_h[2][ty + k][tx];
-    eyy += w * s_h[3][ty + k][tx], exy += w * s_h[4][ty + k][tx];
+  for (int o = 0; o < VSEG; ++o)
+#pragma unroll
+    for (int m = 0; m < 5; ++m) v[o][m] = 0.f;
+#pragma unroll
+  for (int i = 0; i < VSEG + 10; ++i) {
+    float hv[5];
+#pragma unroll
+    for (int m = 0; m < 5; ++m) hv[m] = s_h[m][ty0 + i][tx];
+#pragma unroll
+    for (int o = 0; o < VSEG; ++o) {
+      const int k = i - o;
+      if (k >= 0 && k < 11) {
+        const float w = win.g[k];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) v[o][m] += w * hv[m];
+      }
+    }
   }
-  float ssim = 0.f, l1 = 0.f;
-  if (inside) {
-    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-    const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-    const float s1 = exx - mu1_sq, s2 = eyy - mu2_sq, s12 = exy - mu12;
-    const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = s1 + s2 + C2;
-    const float inv = 1.f / (B1 * B2);
-    ssim            = A1 * A2 * inv;
-    // partial derivatives of ssim w.r.t. the window moments of x (mu1, E[xx], E[xy]) as independent variables
-    const float d_mu1 = (2.f * mu2 * (A2 - A1) * inv) - ssim * (2.f * mu1 * (B2 - B1)) * inv;
-    const float d_exx = -ssim / B2;
-    const float d_exy = 2.f * A1 * inv;
-    const size_t o   = (size_t) c * plane + (size_t) gy * W + gx;
-    const size_t CHW = (size_t) C * plane;
-    dmaps[o] = d_mu1, dmaps[CHW + o] = d_exx, dmaps[2 * CHW + o] = d_exy;
-    l1 = fabsf(s_x[ty + HALO][tx + HALO] - s_y[ty + HALO][tx + HALO]);
+  float ssim_sum = 0.f, l1_sum = 0.f;
+  const int gx = x0 + tx;
+#pragma unroll
+  for (int o = 0; o < VSEG; ++o) {
+    const int gy = y0 + ty0 + o;
+    if (gx < W && gy < H) {
+      const float mu1 = v[o][0], mu2 = v[o][1], exx = v[o][2], eyy = v[o][3], exy = v[o][4];
+      const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+      const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+      const float s1 = exx - mu1_sq, s2 = eyy - mu2_sq, s12 = exy - mu12;
+      const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = s1 + s2 + C2;
+      const float inv  = 1.f / (B1 * B2);
+      const float ssim = A1 * A2 * inv;
+      // partial derivatives of ssim w.r.t. the window moments of x (mu1, E[xx], E[xy]) as independent variables
+      const float d_mu1 = (2.f * mu2 * (A2 - A1) * inv) - ssim * (2.f * mu1 * (B2 - B1)) * inv;
+      const float d_exx = -ssim / B2;
+      const float d_exy = 2.f * A1 * inv;
+      const size_t oo  = (size_t) c * plane + (size_t) gy * W + gx;
+      const size_t CHW = (size_t) C * plane;
+      dmaps[oo] = d_mu1, dmaps[CHW + oo] = d_exx, dmaps[2 * CHW + oo] = d_exy;
+      ssim_sum += ssim;
+      l1_sum += fabsf(s_x[ty0 + o + HALO][tx + HALO] - s_y[ty0 + o + HALO][tx + HALO]);
+    }
   }
-  const float ssum = block_sum_256(ssim, s_red);
-  const float lsum = block_sum_256(l1, s_red);
+  const float ssum = block_sum_256(ssim_sum, s_red);
+  const float lsum = block_sum_256(l1_sum, s_red);
   if (tid == 0) {
     const int b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     partials[2 * b] = ssum, partials[2 * b + 1] = lsum;
@@ -124,14 +167,14 @@ __global__ void __launch_bounds__(256) image_loss_finalize_kernel(int nblocks, d
 __global__ void __launch_bounds__(256) image_loss_backward_kernel(int C, int H, int W, const float* __restrict__ pred,
     const float* __restrict__ gt, Win win, const float* __restrict__ dmaps, const float* __restrict__ grad_loss,
     float scale_l1, float scale_ssim, float* __restrict__ dL_dpred) {
-  __shared__ float s_m[3][LW][LW + 1];
-  __shared__ float s_h[3][LW][LT + 1];
+  __shared__ float s_m[3][IH][IP];
+  __shared__ float s_h[3][IH][HP];
   const int c  = blockIdx.z;
-  const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const int tid = threadIdx.x;
   const size_t plane = (size_t) H * W, CHW = (size_t) C * plane;
-  for (int i = tid; i < LW * LW; i += 256) {
-    const int r = i / LW, q = i - r * LW;
+  for (int i = tid; i < IH * IW; i += 256) {
+    const int r = i / IW, q = i - r * IW;
     const int gy = y0 + r - HALO, gx = x0 + q - HALO;
     const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
     const size_t o = (size_t) c * plane + (size_t) gy * W + gx;
@@ -140,32 +183,56 @@ __global__ void __launch_bounds__(256) image_loss_backward_kernel(int C, int H, 
     s_m[2][r][q] = in ? dmaps[2 * CHW + o] : 0.f;
   }
   __syncthreads();
-  for (int i = tid; i < LW * LT; i += 256) {
-    const int r = i / LT, q = i - r * LT;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  if (tid < IH * (TW / SEG)) {
+    const int r = tid / (TW / SEG), q0 = (tid % (TW / SEG)) * SEG;
+    float a[SEG][3];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const float w = win.g[k];
-      a0 += w * s_m[0][r][q + k], a1 += w * s_m[1][r][q + k], a2 += w * s_m[2][r][q + k];
+    for (int o = 0; o < SEG; ++o) a[o][0] = a[o][1] = a[o][2] = 0.f;
+#pragma unroll
+    for (int i = 0; i < SEG + 10; ++i) {
+      const float m0 = s_m[0][r][q0 + i], m1 = s_m[1][r][q0 + i], m2 = s_m[2][r][q0 + i];
+#pragma unroll
+      for (int o = 0; o < SEG; ++o) {
+        const int k = i - o;
+        if (k >= 0 && k < 11) {
+          const float w = win.g[k];
+          a[o][0] += w * m0, a[o][1] += w * m1, a[o][2] += w * m2;
+        }
+      }
     }
-    s_h[0][r][q] = a0, s_h[1][r][q] = a1, s_h[2][r][q] = a2;
+#pragma unroll
+    for (int o = 0; o < SEG; ++o) s_h[0][r][q0 + o] = a[o][0], s_h[1][r][q0 + o] = a[o][1], s_h[2][r][q0 + o] = a[o][2];
   }
   __syncthreads();
-  const int tx = tid & 15, ty = tid >> 4;
-  const int gx = x0 + tx, gy = y0 + ty;
-  if (!(gx < W && gy < H)) return;
-  float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+  const int tx = tid % TW, ty0 = (tid / TW) * VSEG;
+  float v[VSEG][3];
 #pragma unroll
-  for (int k = 0; k < 11; ++k) {
-    const float w = win.g[k];
-    c0 += w * s_h[0][ty + k][tx], c1 += w * s_h[1][ty + k][tx], c2 += w * s_h[2][ty + k][tx];
+  for (int o = 0; o < VSEG; ++o) v[o][0] = v[o][1] = v[o][2] = 0.f;
+#pragma unroll
+  for (int i = 0; i < VSEG + 10; ++i) {
+    const float h0 = s_h[0][ty0 + i][tx], h1 = s_h[1][ty0 + i][tx], h2 = s_h[2][ty0 + i][tx];
+#pragma unroll
+    for (int o = 0; o < VSEG; ++o) {
+      const int k = i - o;
+      if (k >= 0 && k < 11) {
+        const float w = win.g[k];
+        v[o][0] += w * h0, v[o][1] += w * h1, v[o][2] += w * h2;
+      }
+    }
   }
-  const size_t o = (size_t) c * plane + (size_t) gy * W + gx;
-  const float x = pred[o], y = gt[o];
+  const int gx = x0 + tx;
   const float g = grad_loss ? grad_loss[0] : 1.0f;
-  const float d = x - y;
-  const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-  dL_dpred[o] = g * (scale_ssim * (c0 + 2.f * x * c1 + y * c2) + scale_l1 * sgn);
+#pragma unroll
+  for (int o = 0; o < VSEG; ++o) {
+    const int gy = y0 + ty0 + o;
+    if (gx < W && gy < H) {
+      const size_t oo = (size_t) c * plane + (size_t) gy * W + gx;
+      const float x = pred[oo], y = gt[oo];
+      const float d = x - y;
+      const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      dL_dpred[oo] = g * (scale_ssim * (v[o][0] + 2.f * x * v[o][1] + y * v[o][2]) + scale_l1 * sgn);
+    }
+  }
 }
 
 Win make_window() {
@@ -188,7 +255,7 @@ using namespace skgs;
 extern "C" {
 
 size_t skgs_image_loss_workspace_bytes(int32_t C, int32_t H, int32_t W) {
-  const size_t tiles = (size_t) ((W + LT - 1) / LT) * ((H + LT - 1) / LT) * C;
+  const size_t tiles = (size_t) ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * C;
   return (size_t) 3 * C * H * W * 4 + align256(tiles * 2 * 4) + 256;
 }
 
@@ -199,7 +266,7 @@ int skgs_image_loss_forward(int32_t C, int32_t H, int32_t W, const float* pred, 
   hipStream_t s   = (hipStream_t) stream;
   float* dmaps    = reinterpret_cast<float*>(workspace);
   float* partials = dmaps + (size_t) 3 * C * H * W;
-  dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, C);
+  dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, C);
   hipLaunchKernelGGL(image_loss_forward_kernel, grid, dim3(256), 0, s, C, H, W, pred, gt, make_window(), dmaps, partials);
   SKGS_CHECK_HIP(hipGetLastError());
   const int nblocks = grid.x * grid.y * grid.z;
@@ -216,7 +283,7 @@ int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred,
   SKGS_REQUIRE(workspace_bytes >= skgs_image_loss_workspace_bytes(C, H, W), "image_loss_backward: workspace too small");
   const float* dmaps = reinterpret_cast<const float*>(workspace);
   const float n      = (float) ((double) C * H * W);
-  dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, C);
+  dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, C);
   hipLaunchKernelGGL(image_loss_backward_kernel, grid, dim3(256), 0, (hipStream_t) stream, C, H, W, pred, gt, make_window(),
       dmaps, grad_loss, lambda_l1 / n, -lambda_ssim / n, dL_dpred);
   SKGS_CHECK_HIP(hipGetLastError());

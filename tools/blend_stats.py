@@ -79,6 +79,17 @@ for t in range(gx * gy):
         tot['any_bwd'] += int(anyh.sum())
         tot['pairs_bwd'] += int(h.sum())
         tile_cost += int((circ & walked).sum())
+    for strip in range(2):
+        sl = (slice(None), slice(strip * 8, strip * 8 + 8), slice(None))
+        maxk = nc[sl[1:]].max()
+        if maxk == 0:
+            continue
+        h = hit[sl] & live[sl]
+        tot['any_strip'] = tot.get('any_strip', 0) + int(h.reshape(n, -1).any(1).sum())
+        lanes = (h[:, :, :8] | h[:, :, 8:]).reshape(n, -1).sum(1)
+        tot['lanes_strip'] = tot.get('lanes_strip', 0) + int(lanes.sum())
+    h = hit & live
+    tot['any_tile'] = tot.get('any_tile', 0) + int(h.reshape(n, -1).any(1).sum())
     per_tile_cost.append(tile_cost)
 print('P', P, 'R', R, tot)
 pc = np.array(per_tile_cost)
