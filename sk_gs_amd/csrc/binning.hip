@@ -10,6 +10,8 @@
 // instances are scattered into their tile's range, and each tile then sorts its own short list in LDS on the
 // 64-bit key depth_bits<<32 | id  -- the same total order, with 1 pass over the R instances instead of ~6 radix
 // passes, no host round trip and nothing whose launch shape depends on R (hipGraph-capturable).
+#include <cstdlib>
+
 #include "skgs_common.h"
 
 namespace skgs {
@@ -115,7 +117,15 @@ __global__ void __launch_bounds__(256) scatter_kernel(int P, int gx, int gy, con
 // memory once per non-empty bin: ~BIN_GROUPS x T global atomics instead of R.
 constexpr int BIN_LDS_TILES = 8192;
 constexpr int BIN_THREADS   = 1024;
-constexpr int BIN_GROUPS    = 48;
+constexpr int BIN_GROUPS    = 256;  // one per CU (measured: 48 -> 82 us, 256 -> 42 us for count + scatter); SKGS_BIN_GROUPS overrides
+static int bin_groups() {
+  static int v = [] {
+    const char* e = getenv("SKGS_BIN_GROUPS");
+    const int n   = e ? atoi(e) : 0;
+    return n > 0 ? n : BIN_GROUPS;
+  }();
+  return v;
+}
 
 __device__ __forceinline__ bool splat_rect(const float4* __restrict__ recs, int idx, int gx, int gy, int* mn, int& w, int& n,
     uint32_t& depth_bits) {
@@ -254,7 +264,7 @@ int launch_scan_tiles(GeomView g, ImgView im, int64_t P, hipStream_t s) {
   if (P > 0) {
     const int64_t lanes = P * LPG;
     if (im.T <= BIN_LDS_TILES)
-      hipLaunchKernelGGL(count_tiles_lds_kernel, dim3(BIN_GROUPS), dim3(BIN_THREADS), (size_t) im.T * 4, s, (int) P,
+      hipLaunchKernelGGL(count_tiles_lds_kernel, dim3(bin_groups()), dim3(BIN_THREADS), (size_t) im.T * 4, s, (int) P,
           im.tiles_x, im.tiles_y, im.T, g.recs, im.tile_counts);
     else
       hipLaunchKernelGGL(count_tiles_kernel, dim3((unsigned) ((lanes + 255) / 256)), dim3(256), 0, s, (int) P, im.tiles_x,
@@ -274,7 +284,7 @@ int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, Bi
     ProfScope prof(K_SCATTER, s);
     const int64_t lanes = (int64_t) P * LPG;
     if (im.T <= BIN_LDS_TILES)
-      hipLaunchKernelGGL(scatter_lds_kernel, dim3(BIN_GROUPS), dim3(BIN_THREADS), (size_t) im.T * 8, s, P, im.tiles_x,
+      hipLaunchKernelGGL(scatter_lds_kernel, dim3(bin_groups()), dim3(BIN_THREADS), (size_t) im.T * 8, s, P, im.tiles_x,
           im.tiles_y, im.T, g.recs, im.tile_offsets, im.cursors, b.keys, b.capacity, g.hdr);
     else
       hipLaunchKernelGGL(scatter_kernel, dim3((unsigned) ((lanes + 255) / 256)), dim3(256), 0, s, P, im.tiles_x, im.tiles_y,

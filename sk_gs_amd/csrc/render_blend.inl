@@ -187,7 +187,10 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
 
   const WaveRect rect = wave_rect<PPL>(tile, sub, gx);
   float T_final[PPL], Tr[PPL], dL_dT[PPL], dpix[PPL][3], dex[PPL][E > 0 ? E : 1];
-  float accum[PPL][3], lastc[PPL][3], accum_e[PPL][E > 0 ? E : 1], last_e[PPL][E > 0 ? E : 1], last_alpha[PPL];
+  // accum = colour blended behind the current splat.  The reference updates it lazily at the next contributor
+  // (accum = last_alpha * last_color + (1 - last_alpha) * accum, gaussian_render.cu:281-287); here the same expression
+  // is evaluated right after the contributor itself -- identical operands and rounding, 4 + E fewer state registers.
+  float accum[PPL][3], accum_e[PPL][E > 0 ? E : 1];
   uint32_t lastk[PPL];
   uint32_t maxk = 0;
 #pragma unroll
@@ -198,18 +201,17 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
     dL_dT[i]      = (in && dL_dout_opacity) ? -dL_dout_opacity[pix.id[i]] : 0.f;
     lastk[i]      = in ? n_contrib[pix.id[i]] : 0u;
     maxk          = max(maxk, lastk[i]);
-    last_alpha[i] = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       dpix[i][c]  = in ? dL_dpixels[c * HW + pix.id[i]] : 0.f;
-      accum[i][c] = 0.f, lastc[i][c] = 0.f;
+      accum[i][c] = 0.f;
     }
     // out_color = C + T_final * bg: the background adds bg . dL_dpixel to dL/dT_final
     if (bg) dL_dT[i] += bg[0] * dpix[i][0] + bg[1] * dpix[i][1] + bg[2] * dpix[i][2];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       dex[i][e]     = in ? dL_dout_extra[e * HW + pix.id[i]] : 0.f;
-      accum_e[i][e] = 0.f, last_e[i][e] = 0.f;
+      accum_e[i][e] = 0.f;
     }
   }
   // wave-wide maximum of the last contributor: nothing behind it can matter to this wave
@@ -269,21 +271,18 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
               float dL_dalpha = 0.0f;
 #pragma unroll
               for (int c = 0; c < 3; ++c) {
-                accum[i][c] = last_alpha[i] * lastc[i][c] + (1.f - last_alpha[i]) * accum[i][c];
-                lastc[i][c] = col[c];
                 dL_dalpha += (col[c] - accum[i][c]) * dpix[i][c];
                 g[6 + c] += dchannel_dcolor * dpix[i][c];
+                accum[i][c] = alpha * col[c] + (1.f - alpha) * accum[i][c];
               }
 #pragma unroll
               for (int e = 0; e < E; ++e) {
                 const float ce = s_e[j * (E > 0 ? E : 1) + e];
-                accum_e[i][e]  = last_alpha[i] * last_e[i][e] + (1.f - last_alpha[i]) * accum_e[i][e];
-                last_e[i][e]   = ce;
                 dL_dalpha += (ce - accum_e[i][e]) * dex[i][e];
                 g[9 + e] += dchannel_dcolor * dex[i][e];
+                accum_e[i][e] = alpha * ce + (1.f - alpha) * accum_e[i][e];
               }
               dL_dalpha *= Tn;
-              last_alpha[i] = alpha;
               dL_dalpha += tf_over * dL_dT[i];
               const float dL_dG    = b.y * dL_dalpha;
               const float gdx      = G * dx;
