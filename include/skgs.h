@@ -87,7 +87,8 @@ typedef struct skgs_status {
   int32_t num_rendered;   /* R = sum of tiles touched (what the reference returns) */
   int32_t overflow;       /* 1 if R exceeded the binning capacity given to stage 2 */
   int32_t max_tile_count; /* longest per-tile list */
-  int32_t reserved;
+  int32_t overflow_events; /* sticky: incremented by every forward that overflowed; the library never resets it, so
+                              it counts overflows since the caller last zeroed the first 16 bytes of the geom buffer */
 } skgs_status;
 
 size_t skgs_geom_buffer_bytes(int32_t P);
@@ -187,6 +188,9 @@ int skgs_knn_bones(int32_t P, int32_t M, int32_t K, int32_t dim, const float* po
  * bones outside the K nearest), i.e. what autograd's gather backward accumulates into a zero tensor. */
 int skgs_lbs_weights_forward(int32_t P, int32_t M, int32_t K, const float* sp_W, const int64_t* indices, float* weights,
     skgs_stream_t stream);
+/* skgs_knn_bones (dim = 3) + skgs_lbs_weights_forward in one launch: out_idx [P,K] int64, out_weights [P,K]. */
+int skgs_knn_lbs_weights(int32_t P, int32_t M, int32_t K, const float* points, const float* joints, const float* sp_W,
+    int64_t* out_idx, float* out_weights, skgs_stream_t stream);
 int skgs_lbs_weights_backward(int32_t P, int32_t M, int32_t K, const float* weights, const int64_t* indices,
     const float* g_weights, float* g_sp_W, skgs_stream_t stream);
 

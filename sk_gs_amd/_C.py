@@ -49,7 +49,7 @@ class _RasterBuffers(C.Structure):
 
 class _Status(C.Structure):
     _fields_ = [('num_rendered', C.c_int32), ('overflow', C.c_int32), ('max_tile_count', C.c_int32),
-                ('reserved', C.c_int32)]
+                ('overflow_events', C.c_int32)]
 
 
 class _RasterGrads(C.Structure):
@@ -317,7 +317,8 @@ def rasterize_gaussians(image_height: int, image_width: int, tanfovx: float, tan
 def read_status(geomBuffer: Tensor) -> dict:
     """(synchronising) status words of a forward: num_rendered, overflow flag, longest tile list"""
     hdr = geomBuffer[:16].cpu().view(torch.int32)
-    return dict(num_rendered=int(hdr[0]), overflow=int(hdr[1]), max_tile_count=int(hdr[2]))
+    return dict(num_rendered=int(hdr[0]), overflow=int(hdr[1]), max_tile_count=int(hdr[2]),
+                overflow_events=int(hdr[3]))  # sticky counter: meaningful when the caller zeroed the header once
 
 
 def unpack_buffers(W: int, H: int, P: int, geomBuffer: Tensor, binningBuffer: Tensor, imgBuffer: Tensor) -> dict:

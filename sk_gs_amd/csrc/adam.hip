@@ -76,6 +76,8 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_step_kernel(int n_tensors, 
 }
 #undef SKGS_ADAM1
 
+// (A last-workgroup-out ticket inside adam_step_kernel was tried instead of this launch: 4096 same-address atomics
+// next to the counter every workgroup reads cost 70 us.)
 __global__ void adam_bump_kernel(float* step_count) { step_count[0] += 1.0f; }
 
 }  // namespace

@@ -283,6 +283,13 @@ int skgs_knn_bones(int32_t P, int32_t M, int32_t K, int32_t dim, const float* po
   return launch_knn_bones(P, M, K, dim, points, joints, out_dist, out_idx, (hipStream_t) stream);
 }
 
+int skgs_knn_lbs_weights(int32_t P, int32_t M, int32_t K, const float* points, const float* joints, const float* sp_W,
+    int64_t* out_idx, float* out_weights, skgs_stream_t stream) {
+  SKGS_REQUIRE(P == 0 || (points && joints && sp_W && out_idx && out_weights), "knn_lbs_weights: NULL argument");
+  SKGS_REQUIRE(M >= 1, "knn_lbs_weights: M must be >= 1");
+  return launch_knn_lbs_weights(P, M, K, points, joints, sp_W, out_idx, out_weights, (hipStream_t) stream);
+}
+
 int skgs_lbs_weights_forward(int32_t P, int32_t M, int32_t K, const float* sp_W, const int64_t* indices, float* weights,
     skgs_stream_t stream) {
   SKGS_REQUIRE(P == 0 || (sp_W && indices && weights), "lbs_weights_forward: NULL argument");

@@ -10,6 +10,7 @@
 // instances are scattered into their tile's range, and each tile then sorts its own short list in LDS on the
 // 64-bit key depth_bits<<32 | id  -- the same total order, with 1 pass over the R instances instead of ~6 radix
 // passes, no host round trip and nothing whose launch shape depends on R (hipGraph-capturable).
+#include <algorithm>
 #include <cstdlib>
 
 #include "skgs_common.h"
@@ -93,7 +94,7 @@ __global__ void __launch_bounds__(256) scatter_kernel(int P, int gx, int gy, con
     const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursors, uint64_t* __restrict__ keys, int64_t capacity,
     GeomHeader* hdr) {
   const int64_t tid = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid == 0 && (int64_t) hdr->num_rendered > capacity) hdr->overflow = 1;
+  if (tid == 0 && (int64_t) hdr->num_rendered > capacity) hdr->overflow = 1, hdr->overflow_events += 1;
   const int idx = (int) (tid / LPG);
   if (idx >= P) return;
   const float4 r2  = recs[3 * idx + 2];
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(BIN_THREADS) scatter_lds_kernel(int P, int gx,
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_cnt  = s_mem;      // [T] entries of this workgroup per tile, then the running local rank
   uint32_t* s_base = s_mem + T;  // [T] offsets[t] + slots reserved for this workgroup
-  if (blockIdx.x == 0 && threadIdx.x == 0 && (int64_t) hdr->num_rendered > capacity) hdr->overflow = 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (int64_t) hdr->num_rendered > capacity) hdr->overflow = 1, hdr->overflow_events += 1;
   for (int i = threadIdx.x; i < T; i += BIN_THREADS) s_cnt[i] = 0;
   __syncthreads();
   const int64_t lanes  = (int64_t) P * LPG;
@@ -229,32 +230,116 @@ __device__ __forceinline__ void bitonic_any(KeyPtr k, int L, int n /*pow2 >= L*/
   }
 }
 
-__global__ void __launch_bounds__(SORT_THREADS) tile_sort_kernel(int T, const uint32_t* __restrict__ offsets,
-    uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list, int64_t capacity) {
+__global__ void __launch_bounds__(SORT_THREADS) tile_sort_kernel(int T, int min_len, const GeomHeader* __restrict__ hdr,
+    const uint32_t* __restrict__ offsets, uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list,
+    int64_t capacity) {
   __shared__ uint64_t sk[SORT_LDS_MAX];
+  const int tid = threadIdx.x;
+  if (hdr->max_tile_count <= min_len) return;  // the usual case: every list was sorted by tile_sort_wave_kernel
+  for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {  // grid-stride: only lists longer than min_len are sorted here
+    const int64_t s64 = offsets[tile], e64 = min<int64_t>((int64_t) offsets[tile + 1], capacity);
+    const int L = (int) (e64 - s64);
+    if (L <= min_len) continue;
+    uint64_t* gk = keys + s64;
+    int n = 1;
+    while (n < L) n <<= 1;
+    if (L <= SORT_LDS_MAX) {
+      for (int i = tid; i < L; i += SORT_THREADS) sk[i] = gk[i];
+      __syncthreads();
+      if (L > 1) bitonic_any(sk, L, n, tid);
+      for (int i = tid; i < L; i += SORT_THREADS) {
+        const uint64_t v    = sk[i];
+        gk[i]               = v;
+        point_list[s64 + i] = (uint32_t) v;
+      }
+      __syncthreads();
+    } else {
+      // rare: list longer than the LDS window -> same network on global memory (one workgroup, L1/L2 resident)
+      bitonic_any(gk, L, n, tid);
+      for (int i = tid; i < L; i += SORT_THREADS) point_list[s64 + i] = (uint32_t) gk[i];
+    }
+  }
+}
+
+// Lists of up to 64 * E keys (E <= 16: 1024 keys, i.e. nearly every tile): ONE wave sorts the list entirely in
+// registers.  Blocked layout -- lane l holds keys l*E .. l*E+E-1 -- so a bitonic compare-exchange at distance j < E is
+// a swap between two registers of the same lane and only distances j >= E need one cross-lane read (lane ^ (j/E),
+// ds_bpermute): 21 of the 36 steps for 256 keys.  No LDS array, no barriers.  The LDS network above needed a
+// workgroup barrier per step and 32 KB of LDS per tile.  Padding keys are ~0 (above every real key: the low word is a
+// Gaussian id < 2^31).
+constexpr int WSORT_MAX_E = 16;
+
+template <int E>
+__device__ __forceinline__ void wave_bitonic(uint64_t (&k)[E], int lane) {
+  constexpr int N = 64 * E;
+#pragma unroll
+  for (int size = 2; size <= N; size <<= 1) {
+#pragma unroll
+    for (int j = size >> 1; j > 0; j >>= 1) {
+      if (j < E) {  // partner in another register of the same lane (index bits below E)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          if ((e & j) == 0) {
+            // ascending iff bit `size` of the global index lane*E + e is clear
+            const bool asc   = size < E ? ((e & size) == 0) : (((lane * E) & size) == 0);
+            const uint64_t a = k[e], b = k[e | j];
+            const bool sw = asc ? (a > b) : (a < b);
+            k[e]          = sw ? b : a;
+            k[e | j]      = sw ? a : b;
+          }
+        }
+      } else {  // partner in lane ^ (j / E), same register
+        constexpr int dummy = 0;
+        (void) dummy;
+        const int jl     = j / E;
+        const bool upper = (lane & jl) != 0;
+        const bool asc   = ((lane * E) & size) == 0;  // size > j >= E: a lane bit
+        const bool keep_min = asc != upper;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const uint64_t a  = k[e];
+          const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) a, jl), hi = (uint32_t) __shfl_xor((int) (uint32_t) (a >> 32), jl);
+          const uint64_t b  = ((uint64_t) hi << 32) | lo;
+          k[e] = keep_min ? (a < b ? a : b) : (a > b ? a : b);
+        }
+      }
+    }
+  }
+}
+
+template <int E>
+__device__ __forceinline__ void wave_sort_tile(uint64_t* __restrict__ gk, uint32_t* __restrict__ pl, int L, int lane) {
+  uint64_t k[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) k[e] = (lane * E + e) < L ? gk[lane * E + e] : ~0ull;
+  wave_bitonic<E>(k, lane);
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = lane * E + e;
+    if (i < L) gk[i] = k[e], pl[i] = (uint32_t) k[e];
+  }
+}
+
+__global__ void __launch_bounds__(64) tile_sort_wave_kernel(int T, const uint32_t* __restrict__ offsets,
+    uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list, int64_t capacity) {
   const int tile = blockIdx.x;
   if (tile >= T) return;
   const int64_t s64 = offsets[tile], e64 = min<int64_t>((int64_t) offsets[tile + 1], capacity);
-  if (e64 <= s64) return;
   const int L = (int) (e64 - s64);
+  if (L <= 0 || L > 64 * WSORT_MAX_E) return;  // longer lists: tile_sort_kernel
   uint64_t* gk = keys + s64;
-  const int tid = threadIdx.x;
-  int n = 1;
-  while (n < L) n <<= 1;
-  if (L <= SORT_LDS_MAX) {
-    for (int i = tid; i < L; i += SORT_THREADS) sk[i] = gk[i];
-    __syncthreads();
-    if (L > 1) bitonic_any(sk, L, n, tid);
-    for (int i = tid; i < L; i += SORT_THREADS) {
-      const uint64_t v    = sk[i];
-      gk[i]               = v;
-      point_list[s64 + i] = (uint32_t) v;
-    }
-  } else {
-    // rare: list longer than the LDS window -> same network on global memory (one workgroup, L1/L2 resident)
-    bitonic_any(gk, L, n, tid);
-    for (int i = tid; i < L; i += SORT_THREADS) point_list[s64 + i] = (uint32_t) gk[i];
-  }
+  uint32_t* pl = point_list + s64;
+  const int lane = threadIdx.x;
+  if (L <= 64)
+    wave_sort_tile<1>(gk, pl, L, lane);
+  else if (L <= 128)
+    wave_sort_tile<2>(gk, pl, L, lane);
+  else if (L <= 256)
+    wave_sort_tile<4>(gk, pl, L, lane);
+  else if (L <= 512)
+    wave_sort_tile<8>(gk, pl, L, lane);
+  else
+    wave_sort_tile<16>(gk, pl, L, lane);
 }
 
 }  // namespace
@@ -293,8 +378,11 @@ int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, Bi
   SKGS_CHECK_HIP(hipGetLastError());
   {
     ProfScope prof(K_SORT, s);
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(im.T), dim3(SORT_THREADS), 0, s, im.T, im.tile_offsets, b.keys, b.point_list,
+    hipLaunchKernelGGL(tile_sort_wave_kernel, dim3(im.T), dim3(64), 0, s, im.T, im.tile_offsets, b.keys, b.point_list,
         b.capacity);
+    // lists longer than 1024 keys (rare): a few workgroups scan the tile table and sort those in LDS / global memory
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(std::min(im.T, 128)), dim3(SORT_THREADS), 0, s, im.T, 64 * WSORT_MAX_E, g.hdr,
+        im.tile_offsets, b.keys, b.point_list, b.capacity);
   }
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;

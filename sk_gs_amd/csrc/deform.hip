@@ -481,20 +481,89 @@ __global__ void __launch_bounds__(256) lbs_weights_forward_kernel(int P, int M, 
 }
 
 // g_logit[k] = w[k] * (g_w[k] - sum_j w[j] g_w[j]), scattered back through the gather into a DENSE row of g_sp_W
-// (every element of the [P,M] gradient is written: zeros where the bone is not among the K nearest), one element
-// per lane so the 4*P*M bytes are stored coalesced.
+// (every element of the [P,M] gradient is written: zeros where the bone is not among the K nearest).  One lane per
+// Gaussian builds its row in LDS; the workgroup then stores its 256 consecutive rows as one contiguous span.
 __global__ void __launch_bounds__(256) lbs_weights_backward_kernel(int P, int M, int K, const float* __restrict__ weights,
     const int64_t* __restrict__ indices, const float* __restrict__ g_weights, float* __restrict__ g_sp_W) {
-  const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
-  if (i >= (size_t) P * M) return;
-  const int p = (int) (i / M), m = (int) (i - (size_t) p * M);
-  float dot = 0.f, hit_w = 0.f, hit_g = 0.f;
-  for (int k = 0; k < K; ++k) {
-    const float w = weights[(size_t) p * K + k], g = g_weights[(size_t) p * K + k];
-    dot += w * g;
-    if ((int) indices[(size_t) p * K + k] == m) hit_w += w, hit_g += w * g;  // KNN indices are distinct
+  extern __shared__ float s_rows[];  // [256][M]
+  const int p0 = blockIdx.x * 256, p = p0 + threadIdx.x;
+  float* row = s_rows + (size_t) threadIdx.x * M;
+  for (int m = 0; m < M; ++m) row[m] = 0.f;
+  if (p < P) {
+    float dot = 0.f;
+    for (int k = 0; k < K; ++k) dot += weights[(size_t) p * K + k] * g_weights[(size_t) p * K + k];
+    for (int k = 0; k < K; ++k) {
+      const float w = weights[(size_t) p * K + k];
+      row[(int) indices[(size_t) p * K + k]] += w * (g_weights[(size_t) p * K + k] - dot);  // KNN indices are distinct
+    }
   }
-  g_sp_W[i] = hit_g - hit_w * dot;
+  __syncthreads();
+  const size_t n = (size_t) min(256, P - p0) * M;
+  float* dst     = g_sp_W + (size_t) p0 * M;
+  for (size_t i = threadIdx.x; i < n; i += 256) dst[i] = s_rows[i];
+}
+
+// K nearest bones + LBS weights in one pass (the two calls of calc_LBS_weight, sk_gs.py:757,769-770): top-K as
+// knn_bones_kernel (dim = 3), then softmax of the gathered logits; indices and weights leave through LDS so that a
+// workgroup stores contiguous spans instead of K strided 8-byte pieces per lane.
+template <int KCAP>
+__global__ void __launch_bounds__(256) knn_weights_kernel(int P, int M, int K, const float* __restrict__ points,
+    const float* __restrict__ joints, const float* __restrict__ sp_W, int64_t* __restrict__ out_idx,
+    float* __restrict__ out_weights) {
+  extern __shared__ float s_dyn[];
+  float* s_j       = s_dyn;                                                  // [M][3]
+  float* s_w       = s_dyn + ((M * 3 + 3) & ~3);                             // [256][K]
+  int64_t* s_idx   = reinterpret_cast<int64_t*>(s_w + ((256 * K + 3) & ~3));  // [256][K]
+  for (int i = threadIdx.x; i < M * 3; i += 256) s_j[i] = joints[i];
+  __syncthreads();
+  const int p0 = blockIdx.x * 256, n = p0 + threadIdx.x;
+  if (n < P) {
+    float bd[KCAP];
+    int bi[KCAP];
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) bd[k] = __builtin_inff(), bi[k] = 0;
+    const float p0x = points[3 * (size_t) n], p1 = points[3 * (size_t) n + 1], p2 = points[3 * (size_t) n + 2];
+    for (int j = 0; j < M; ++j) {
+      const float d0 = p0x - s_j[3 * j], d1 = p1 - s_j[3 * j + 1], d2 = p2 - s_j[3 * j + 2];
+      float d = 0.f;
+      d += d0 * d0;
+      d += d1 * d1;
+      d += d2 * d2;
+      float cd = d;
+      int ci   = j;
+#pragma unroll
+      for (int k = 0; k < KCAP; ++k) {
+        if (k < K && cd < bd[k]) {
+          const float td = bd[k];
+          const int ti   = bi[k];
+          bd[k] = cd, bi[k] = ci;
+          cd = td, ci = ti;
+        }
+      }
+    }
+    float l[KCAP];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) {
+      l[k] = k < K ? sp_W[(size_t) n * M + bi[k]] : -INFINITY;
+      mx   = fmaxf(mx, l[k]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) {
+      l[k] = k < K ? expf(l[k] - mx) : 0.f;
+      sum += l[k];
+    }
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k)
+      if (k < K) s_w[threadIdx.x * K + k] = l[k] / sum, s_idx[threadIdx.x * K + k] = bi[k];
+  }
+  __syncthreads();
+  const int cnt = min(256, P - p0) * K;
+  for (int i = threadIdx.x; i < cnt; i += 256) {
+    out_weights[(size_t) p0 * K + i] = s_w[i];
+    out_idx[(size_t) p0 * K + i]     = s_idx[i];
+  }
 }
 
 }  // namespace
@@ -604,9 +673,30 @@ int launch_lbs_weights_forward(int P, int M, int K, const float* sp_W, const int
 int launch_lbs_weights_backward(int P, int M, int K, const float* weights, const int64_t* indices, const float* g_weights,
     float* g_sp_W, hipStream_t s) {
   if (P == 0 || M == 0) return 0;
-  const size_t n = (size_t) P * M;
-  hipLaunchKernelGGL(lbs_weights_backward_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, P, M, K, weights,
+  if ((size_t) M * 256 * 4 > 60 * 1024) return set_error("lbs_weights_backward: M = %d too large (<= 60)", M);
+  hipLaunchKernelGGL(lbs_weights_backward_kernel, dim3((P + 255) / 256), dim3(256), (size_t) M * 256 * 4, s, P, M, K, weights,
       indices, g_weights, g_sp_W);
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_knn_lbs_weights(int P, int M, int K, const float* points, const float* joints, const float* sp_W, int64_t* out_idx,
+    float* out_weights, hipStream_t s) {
+  if (P == 0) return 0;
+  if (K > KNN_MAXK || K < 1 || K > M) return set_error("knn_lbs_weights: K must be in [1,min(%d,M)] (got %d)", KNN_MAXK, K);
+  const size_t lds = ((size_t) ((M * 3 + 3) & ~3) + ((256 * K + 3) & ~3)) * 4 + (size_t) 256 * K * 8;
+  if (lds > 60 * 1024) return set_error("knn_lbs_weights: M = %d too large for the LDS joint table", M);
+  ProfScope prof(K_KNN, s);
+#define SKGS_KNNW(KCAP_)                                                                                            \
+  hipLaunchKernelGGL(knn_weights_kernel<KCAP_>, dim3((P + 255) / 256), dim3(256), lds, s, P, M, K, points, joints, sp_W, \
+      out_idx, out_weights)
+  if (K <= 4)
+    SKGS_KNNW(4);
+  else if (K <= 8)
+    SKGS_KNNW(8);
+  else
+    SKGS_KNNW(KNN_MAXK);
+#undef SKGS_KNNW
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -250,6 +250,8 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(int P, int D, i
   if (threadIdx.x < 3) cam.campos[threadIdx.x] = campos[threadIdx.x];
   __syncthreads();
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  // the per-tile counters of the next kernel (binning.hip: count_tiles) start from zero: cleared here, not by a fill launch
+  for (int t = idx; t < gx * gy; t += gridDim.x * blockDim.x) tile_counts[t] = 0u;
   if (idx >= P) return;
 
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;  // culled Gaussians get an all-zero record
@@ -703,8 +705,7 @@ int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView 
   const int P = in.P;
   const float focal_y = in.image_height / (2.0f * in.tanfovy);
   const float focal_x = in.image_width / (2.0f * in.tanfovx);
-  if (fill_u32(im.tile_counts, 0u, (size_t) im.T, s)) return 1;
-  if (P == 0) return 0;
+  if (P == 0) return fill_u32(im.tile_counts, 0u, (size_t) im.T, s);
   ProfScope prof(K_PREPROCESS_FWD, s);
   dim3 grid((P + 255) / 256), block(256);
   if (in.colmap)

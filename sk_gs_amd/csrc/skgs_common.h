@@ -21,7 +21,7 @@ struct GeomHeader {
   int32_t num_rendered;
   int32_t overflow;
   int32_t max_tile_count;
-  int32_t reserved;
+  int32_t overflow_events;  // never reset by the library: forwards whose R exceeded the capacity since the caller zeroed it
   int32_t P;
   int32_t pad[59];
 };
@@ -265,6 +265,8 @@ int launch_deform_backward(const skgs_deform_inputs& in, const float* g_means, c
     hipStream_t s);
 int launch_knn_bones(int P, int M, int K, int dim, const float* points, const float* joints, float* out_dist,
     int64_t* out_idx, hipStream_t s);
+int launch_knn_lbs_weights(int P, int M, int K, const float* points, const float* joints, const float* sp_W, int64_t* out_idx,
+    float* out_weights, hipStream_t s);
 int launch_lbs_weights_forward(int P, int M, int K, const float* sp_W, const int64_t* indices, float* weights, hipStream_t s);
 int launch_lbs_weights_backward(int P, int M, int K, const float* weights, const int64_t* indices, const float* g_weights,
     float* g_sp_W, hipStream_t s);

@@ -65,7 +65,6 @@ class FusedViewStep:
             assert p.is_contiguous() and p.grad.is_contiguous() and p.dtype == torch.float32
         # ---- persistent intermediates -------------------------------------------------------------------------
         self.bone_T, self.chain_A = torch.empty((M, 7), **f32), torch.empty((M, 7), **f32)
-        self.knn_dist = torch.empty((P, K), **f32)
         self.indices = torch.empty((P, K), dtype=torch.int64, device=dev)
         self.weights = torch.empty((P, K), **f32)
         self.means, self.scales = torch.empty((P, 3), **f32), torch.empty((P, 3), **f32)
@@ -73,6 +72,7 @@ class FusedViewStep:
         self.image, self.out_opacity = torch.empty((3, H, W), **f32), torch.empty((H, W), **f32)
         self.radii = torch.empty((P,), dtype=torch.int32, device=dev)
         self.geom = torch.empty((lib.skgs_geom_buffer_bytes(C.c_int32(P)),), **u8)
+        self.geom[:256].zero_()  # status words; `overflow_events` counts overflowing forwards from here on
         self.img = torch.empty((lib.skgs_img_buffer_bytes(C.c_int32(W), C.c_int32(H)),), **u8)
         self.binning = torch.empty((lib.skgs_binning_buffer_bytes(C.c_int64(int(capacity))),), **u8)
         self.loss3 = torch.zeros(3, **f32)
@@ -146,10 +146,8 @@ class FusedViewStep:
             C.c_int32(M), C.c_int32(t['root']), _p(t['parents']), _p(t['level_nodes']), _p(t['level_start']),
             C.c_int32(t['num_levels']), _p(m.sk_r[time_id]), _p(m.joints), _p(m.global_tr[time_id]), _p(self.bone_T),
             _p(self.chain_A), st))
-        chk(lib.skgs_knn_bones(C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(3), _p(m._xyz), _p(m.joints),
-                               _p(self.knn_dist), _p(self.indices), st))
-        chk(lib.skgs_lbs_weights_forward(C.c_int32(P), C.c_int32(M), C.c_int32(K), _p(m.sp_W), _p(self.indices),
-                                         _p(self.weights), st))
+        chk(lib.skgs_knn_lbs_weights(C.c_int32(P), C.c_int32(M), C.c_int32(K), _p(m._xyz), _p(m.joints), _p(m.sp_W),
+                                     _p(self.indices), _p(self.weights), st))
         d = self._deform_inputs(time_id)
         chk(lib.skgs_lbs_deform_forward(C.byref(d), _p(self.means), _p(self.scales), _p(self.rotations),
                                         _p(self.opacity), None, None, None, st))
@@ -198,5 +196,6 @@ class FusedViewStep:
             _p(self.g_bone_T), _p(m.sk_r.grad[time_id]), None, _p(m.global_tr.grad[time_id]), st))
 
     def status(self) -> dict:
-        """(synchronising) num_rendered / overflow / longest tile list of the last forward"""
+        """(synchronising) num_rendered / overflow / longest tile list of the last forward, and the number of
+        forwards since construction whose tile lists did not fit ``capacity`` (``overflow_events``)"""
         return _C.read_status(self.geom)

@@ -228,6 +228,22 @@ def test_empty_and_culled(oracle32):
         assert float(t.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('P,W,H,scale_mult', [(6000, 64, 64, 6.0), (20000, 96, 96, 5.0)])
+def test_long_tile_lists_all_sort_paths(oracle32, P, W, H, scale_mult):
+    """tile lists of 1k..4.5k entries: the LDS bitonic (> 1024 keys) and the global-memory network (> 4096 keys)
+    behind the one-wave register sort; sorted lists and the strict image stay bit-exact"""
+    _C().set_strict_math(True)
+    oracle32.set_exp_mode(1)
+    try:
+        act, rs, cam = scene_inputs(P, W, H, seed=3, colmap=True, scale_mult=scale_mult, device='cuda')
+        ref, fwd = check_forward(oracle32, act, rs, strict=True)
+        r = ref['binning']['ranges'].astype(np.int64)
+        assert (r[:, 1] - r[:, 0]).max() > 1024
+    finally:
+        _C().set_strict_math(False)
+        oracle32.set_exp_mode(0)
+
+
 def test_async_capacity_overflow_flag():
     C = _C()
     P, W, H = 4000, 128, 128
