@@ -302,13 +302,14 @@ def main():
         rb_us = rb_ms / max(rb_n, 1) * 1e3
         rb_bytes = alg_bytes('render_backward', P, M, K, W, H, R_mean)
         achieved = rb_bytes / (rb_us * 1e-6) / 1e9 if rb_us > 0 else 0.0
-        traffic = None
+        traffic, valu_busy = None, None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_render_backward.json')
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
                 if rec.get('config') == cfg['name']:
                     traffic = rec.get('hbm_bytes_per_launch')
+                    valu_busy = rec.get('valubusy')
             except Exception:
                 traffic = None
         line = {
@@ -327,6 +328,7 @@ def main():
                          'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 5),
                          'traffic': traffic, 'avg_us': round(rb_us, 2), 'launches': rb_n,
                          'alg_bytes_per_launch': int(rb_bytes),
+                         'valu_busy_pct': round(valu_busy, 1) if valu_busy else None,
                          'note': 'blend kernels are VALU/LDS/atomic-bound, not HBM-bound (SURVEY 8d caveat); '
                                  'streaming kernels are listed under "kernels"'},
             'kernels': kernels,
