@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(int P, int D, 
     const float* __restrict__ rotations, float scale_modifier, const float* __restrict__ cov3D_precomp,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos, int W,
     int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, const float4* __restrict__ recs,
-    const float* __restrict__ gradacc /*[P][16]*/, const float* __restrict__ gin_means2D,
+    const float* __restrict__ gradacc /*[P][16]*/, int moments, const float* __restrict__ gin_means2D,
     const float* __restrict__ gin_conic, const float* __restrict__ gin_opacity, int E, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_dconic_out, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
@@ -453,6 +453,16 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(int P, int D, 
     if (visible) a = row[0], b = row[1], c = row[2], d = row[3];
     gm2[0] = a.x, gm2[1] = a.y, gcon[0] = a.z, gcon[1] = a.w, gcon[2] = b.x, gop = b.y, gcol[0] = b.z, gcol[1] = b.w;
     gcol[2] = c.x, gex[0] = c.y, gex[1] = c.z, gex[2] = c.w, gex[3] = d.x;
+    if (moments) {
+      // fast blend build: slots 0..4 are sum w {dx, dy, dx^2, dx dy, dy^2} over all pixels (render_blend.inl);
+      // dL/dmean2D = -(conic . [m1, m2]) * 0.5 * (W, H), dL/dconic = -0.5 * [m3, m4, m5]
+      const float4 q0 = recs[3 * idx], q1 = recs[3 * idx + 1];
+      const float cx = q0.z, cy = q0.w, cz = q1.x;
+      const float m1 = a.x, m2 = a.y;
+      gm2[0]  = -(cx * m1 + cy * m2) * (0.5f * W);
+      gm2[1]  = -(cz * m2 + cy * m1) * (0.5f * H);
+      gcon[0] = -0.5f * a.z, gcon[1] = -0.5f * a.w, gcon[2] = -0.5f * b.x;
+    }
   }
   if (gin_means2D) gm2[0] += gin_means2D[3 * idx], gm2[1] += gin_means2D[3 * idx + 1];
   if (gin_conic) gcon[0] += gin_conic[4 * idx], gcon[1] += gin_conic[4 * idx + 1], gcon[2] += gin_conic[4 * idx + 3];
@@ -737,7 +747,8 @@ int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const i
   P, in.sh_degree, in.sh_coeffs, in.means3D, radii, in.sh, in.sh_rest, in.scales, in.rotations, in.scale_modifier,       \
       in.cov3D_precomp,                                                                                                \
       in.viewmatrix, in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y, \
-      g.recs, gr.workspace, gr.grad_means2D_in, gr.grad_conic_in, gr.grad_opacity_in, E, gr.dL_dmeans2D, gr.dL_dconic,    \
+      g.recs, gr.workspace, (int) gradacc_rows_hold_moments(), gr.grad_means2D_in, gr.grad_conic_in, gr.grad_opacity_in, E,  \
+      gr.dL_dmeans2D, gr.dL_dconic,                                                                                      \
       gr.dL_dcolors, gr.dL_dopacity, gr.dL_dmeans3D, gr.dL_dcov3D, gr.dL_dsh, gr.dL_dsh_rest, gr.dL_dscales, gr.dL_drotations, \
       gr.dL_dextras
   if (in.colmap)

@@ -290,6 +290,8 @@ int g_strict        = 0;
 
 extern "C" void skgs_set_pixels_per_lane(int ppl) { g_ppl_override = (ppl == 1 || ppl == 2 || ppl == 4) ? ppl : 0; }
 extern "C" void skgs_set_strict_math(int on) { g_strict = on ? 1 : 0; }
+// layout of slots 0..4 of the gradient rows written by render_backward (render_blend.inl): moments in the fast build
+bool gradacc_rows_hold_moments() { return g_strict == 0; }
 
 #define SKGS_DISPATCH_E(E_, FN, ...)     \
   switch (E_) {                          \

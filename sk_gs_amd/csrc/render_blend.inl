@@ -160,6 +160,7 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
 // ===================================================================================================== backward
 // gradacc row layout (16 floats = 64 B per Gaussian):
 //   0 mean2D.x  1 mean2D.y  2 conic.x  3 conic.y  4 conic.w  5 opacity  6..8 colour  9..12 extras  13..15 unused
+// (fast build: slots 0..4 hold the moments sum w {dx, dy, dx^2, dx dy, dy^2} instead, see the kernel body)
 template <int PPL, int E>
 __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int gx, int T, const uint32_t* __restrict__ offsets,
     int64_t capacity, const uint32_t* __restrict__ point_list, const float4* __restrict__ recs,
@@ -284,6 +285,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
               }
               dL_dalpha *= Tn;
               dL_dalpha += tf_over * dL_dT[i];
+#if SKGS_STRICT
+              // the reference's expressions, term by term (gaussian_render.cu:300-318)
               const float dL_dG    = b.y * dL_dalpha;
               const float gdx      = G * dx;
               const float gdy      = G * dy;
@@ -295,6 +298,21 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
               g[3] += -0.5f * gdx * dy * dL_dG;
               g[4] += -0.5f * gdy * dy * dL_dG;
               g[5] += G * dL_dalpha;
+#else
+              // All five geometric gradients are linear in the moments of w = G * dL/dG over the pixels:
+              //   dL/dmean2D = -(conic . [sum w dx, sum w dy]) * 0.5 * (W, H),   dL/dconic = -0.5 * sum w [dx^2, dx dy, dy^2]
+              // so the row accumulates the five moments and preprocess_backward applies the per-Gaussian coefficients
+              // once (7 multiplies per pair here instead of 17).
+              const float gA = G * dL_dalpha;
+              const float w  = b.y * gA;
+              const float m1 = w * dx, m2 = w * dy;
+              g[0] += m1;
+              g[1] += m2;
+              g[2] += m1 * dx;
+              g[3] += m1 * dy;
+              g[4] += m2 * dy;
+              g[5] += gA;
+#endif
             }
           }
         }

@@ -244,6 +244,7 @@ int launch_mark_visible(int P, const float* means, const float* view, int colmap
 int launch_scan_tiles(GeomView g, ImgView im, int64_t P, hipStream_t s);  // count tiles (16 lanes / Gaussian) + scan
 int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, BinView b, hipStream_t s);
 // render.hip
+bool gradacc_rows_hold_moments();
 int launch_render_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, BinView b, float* out_color,
     float* out_opacity, float* out_extra, hipStream_t s);
 int launch_render_backward(const skgs_raster_inputs& in, GeomView g, ImgView im, BinView b, const float* out_opacity,
