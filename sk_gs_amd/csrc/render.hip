@@ -16,7 +16,8 @@
 //    row shifts/broadcasts, parked in an LDS row per contributing Gaussian, and flushed with one 64-byte-row
 //    atomic per (Gaussian, wave) -- the shape the MI355X memory-side float atomic unit likes -- instead of 9
 //    scattered atomics per pair;
-//  * blockIdx -> tile mapping is XCD-aware (xcd_remap) so neighbouring tiles share an L2.
+//  * blockIdx -> tile mapping is XCD-aware (xcd_remap): small groups of neighbouring tiles share an L2, all XCDs get
+//    the same mix of image regions.
 // Per-pixel arithmetic follows the reference's sequence (power, alpha clamp 0.99, 1/255 and 1e-4 tests, T/(1-a)
 // recurrence seeded from 1 - out_opacity); exp is the hardware v_exp_f32 path.
 #include "skgs_common.h"
@@ -311,7 +312,7 @@ int launch_render_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, 
   ProfScope prof(K_RENDER_FWD, s);
 #define FWD(E_, PPL_)                                                                                                   \
   {                                                                                                                     \
-    const int nblk = ((im.T * (4 / PPL_) + 7) / 8) * 8;                                                                 \
+    const int nblk = xcd_grid(im.T * (4 / PPL_));                                                                       \
     if (g_strict)                                                                                                       \
       hipLaunchKernelGGL((blend_strict::render_forward_kernel<PPL_, E_>), dim3(nblk), dim3(64), 0, s, W, H, im.tiles_x, \
           im.T, im.tile_offsets, b.capacity, b.point_list, g.recs, in.extras, in.background, im.n_contrib, out_color,   \
@@ -344,7 +345,7 @@ int launch_render_backward(const skgs_raster_inputs& in, GeomView g, ImgView im,
   ProfScope prof(K_RENDER_BWD, s);
 #define BWD(E_, PPL_)                                                                                                  \
   {                                                                                                                    \
-    const int nblk = ((im.T * (4 / PPL_) + 7) / 8) * 8;                                                                \
+    const int nblk = xcd_grid(im.T * (4 / PPL_));                                                                      \
     if (g_strict)                                                                                                      \
       hipLaunchKernelGGL((blend_strict::render_backward_kernel<PPL_, E_>), dim3(nblk), dim3(64), 0, s, W, H,           \
  im.tiles_x, im.T, im.tile_offsets, b.capacity, b.point_list, g.recs, in.extras, in.background, out_opacity,       \

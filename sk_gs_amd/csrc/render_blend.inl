@@ -209,6 +209,9 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
     }
     // out_color = C + T_final * bg: the background adds bg . dL_dpixel to dL/dT_final
     if (bg) dL_dT[i] += bg[0] * dpix[i][0] + bg[1] * dpix[i][1] + bg[2] * dpix[i][2];
+#if !SKGS_STRICT
+    dL_dT[i] *= -T_final[i];  // the walk only needs K = -T_final * dL/dT_final
+#endif
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       dex[i][e]     = in ? dL_dout_extra[e * HW + pix.id[i]] : 0.f;
@@ -263,11 +266,11 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
               const float Tn = Tr[i] / (1.f - alpha);
               const float tf_over = -T_final[i] / (1.f - alpha);
 #else
-              const float rinv    = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp; the IEEE divide is ~10 instructions
-              const float Tn      = Tr[i] * rinv;
-              const float tf_over = -T_final[i] * rinv;
+              const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp; the IEEE divide is ~10 instructions
+              const float Tn   = Tr[i] * rinv;
 #endif
-              Tr[i]          = Tn;
+              const float Tprev = Tr[i];
+              Tr[i]             = Tn;
               const float dchannel_dcolor = alpha * Tn;
               float dL_dalpha = 0.0f;
 #if SKGS_STRICT
@@ -299,11 +302,14 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
                 D += s_e[j * (E > 0 ? E : 1) + e] * dex[i][e];
                 g[9 + e] += dchannel_dcolor * dex[i][e];
               }
-              dL_dalpha   = D - accum[i][0];
+              // (D - S) * T_next - T_final / (1 - alpha) * dL/dT  =  ((D - S) * T_prev + K) / (1 - alpha),  K = -T_final dL/dT
+              dL_dalpha   = ((D - accum[i][0]) * Tprev + dL_dT[i]) * rinv;
               accum[i][0] = alpha * D + (1.f - alpha) * accum[i][0];
 #endif
+#if SKGS_STRICT
               dL_dalpha *= Tn;
               dL_dalpha += tf_over * dL_dT[i];
+#endif
 #if SKGS_STRICT
               // the reference's expressions, term by term (gaussian_render.cu:300-318)
               const float dL_dG    = b.y * dL_dalpha;
