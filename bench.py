@@ -202,14 +202,16 @@ def main():
     else:
         from sk_gs_amd.fused_step import FusedViewStep
         fstep = FusedViewStep(model, W, H, capacity=int(R_max * 1.25 * _C.config.capacity_growth) + 1024,
-                              background=background)
+                              background=background, grad_scale=1.0 / world)
 
         def fwd_bwd(v):  # every gradient is overwritten in place: no zero fill of the flat buffer
             fstep.forward_backward(settings[v], v % frames, targets[v])
 
+    prescaled = not args.autograd  # FusedViewStep seeds the backward with 1/world
+
     def eager_step(i):
         fwd_bwd(vp.view_index(i, args.views))
-        vp.allreduce_grads()
+        vp.allreduce_grads(prescaled=prescaled)
         opt.step()
 
     from sk_gs_amd.train_step import GraphedSteps
@@ -223,7 +225,7 @@ def main():
     def graph_step(i):
         g_step(vp.view_index(i, args.views))
         if g_opt is not None:
-            vp.allreduce_grads()
+            vp.allreduce_grads(prescaled=prescaled)
             g_opt(0)
 
     train_step = eager_step if args.eager else graph_step

@@ -132,8 +132,11 @@ typedef struct skgs_raster_grads {
   float* dL_drotations; /* [P,4] */
   float* dL_dextras;    /* [P,E] or NULL */
   float* dL_dsh_rest;   /* with skgs_raster_inputs::sh_rest: dL_dsh is [P,1,3] and this [P,M-1,3]; else NULL */
-  /* scratch: P*16 floats, contents undefined on entry and exit */
+  /* scratch: P*16 floats, contents undefined on entry and exit ... */
   float* workspace; size_t workspace_bytes;
+  /* ... unless workspace_is_zero != 0: the caller guarantees the scratch is all zero on entry and the library leaves
+   * it all zero on exit (saves the clearing launch when the same scratch serves every step) */
+  int32_t workspace_is_zero;
 } skgs_raster_grads;
 size_t skgs_backward_workspace_bytes(int32_t P);
 

@@ -184,7 +184,7 @@ int skgs_rasterize_backward(const skgs_raster_inputs* in, const skgs_raster_buff
   GeomView g    = geom_view(buf->geom);
   ImgView im    = img_view(buf->img, in->image_width, in->image_height);
   BinView b     = bin_view(buf->binning, buf->binning_bytes);
-  if (fill_u32(gr->workspace, 0u, (size_t) in->P * GRAD_ROW, s)) return 1;
+  if (!gr->workspace_is_zero && fill_u32(gr->workspace, 0u, (size_t) in->P * GRAD_ROW, s)) return 1;
   if (launch_render_backward(*in, g, im, b, out_opacity, gr->dL_dout_color, gr->dL_dout_opacity, gr->dL_dout_extra,
           gr->workspace, s))
     return 1;

@@ -58,26 +58,59 @@ __device__ __forceinline__ Q4 qrot_grad_q(const Q4& q, const V3& p, const V3& g)
 __device__ __forceinline__ V3 qrot_T(const Q4& q, const V3& g) { return qrot(qconj(q), g); }
 
 constexpr int CHAIN_THREADS = 256;
+constexpr int LOC_F         = 12;  // staged per-bone local data: q[4] (unit), tL[3], j[3], |raw|, pad
+
+// Per-bone local transform L_i = (j + R(q)(-j), q) and the topology, staged in LDS by all threads at once: the
+// level loops then touch LDS only.  (Reading parents / level_nodes / raw / joints from global memory inside the loop
+// made every tree level a chain of three dependent global loads: 13 us for a 20-bone skeleton.)
+struct Staged {
+  const float* loc;  // [M][LOC_F]
+  const int* par;    // [M]
+  const int* ln;     // [M]
+  const int* ls;     // [num_levels + 1]
+};
+__device__ __forceinline__ Staged stage_skeleton(float* s_base, int M, int num_levels, const int32_t* parents,
+    const int32_t* level_nodes, const int32_t* level_start, const float* sk_r_raw, const float* joints) {
+  float* loc = s_base;
+  int* par   = reinterpret_cast<int*>(s_base + (size_t) M * LOC_F);
+  int* ln    = par + M;
+  int* ls    = ln + M;
+  for (int i = threadIdx.x; i < M; i += CHAIN_THREADS) {
+    const float raw[4] = {sk_r_raw[4 * i], sk_r_raw[4 * i + 1], sk_r_raw[4 * i + 2], sk_r_raw[4 * i + 3] + 1.0f};
+    const float nraw   = fmaxf(sqrtf(raw[0] * raw[0] + raw[1] * raw[1] + raw[2] * raw[2] + raw[3] * raw[3]), 1e-12f);
+    const Q4 q  = {raw[0] / nraw, raw[1] / nraw, raw[2] / nraw, raw[3] / nraw};
+    const V3 j  = {joints[3 * i], joints[3 * i + 1], joints[3 * i + 2]};
+    const V3 rj = qrot(q, {-j.x, -j.y, -j.z});
+    float* o    = loc + (size_t) i * LOC_F;
+    o[0] = q.x, o[1] = q.y, o[2] = q.z, o[3] = q.w;
+    o[4] = j.x + rj.x, o[5] = j.y + rj.y, o[6] = j.z + rj.z;
+    o[7] = j.x, o[8] = j.y, o[9] = j.z, o[10] = nraw, o[11] = 0.f;
+    par[i] = parents[i], ln[i] = level_nodes[i];
+  }
+  for (int l = threadIdx.x; l <= num_levels; l += CHAIN_THREADS) ls[l] = level_start[l];
+  return {loc, par, ln, ls};
+}
+inline size_t staged_bytes(int M, int num_levels) { return ((size_t) M * LOC_F + 2 * (size_t) M + num_levels + 2) * 4; }
 // LDS layout per bone: A = (t[3], q[4]) -> 7 floats (forward) + gA 7 floats (backward)
 
 __global__ void __launch_bounds__(CHAIN_THREADS) bone_chain_forward_kernel(int M, int root, const int32_t* __restrict__ parents,
     const int32_t* __restrict__ level_nodes, const int32_t* __restrict__ level_start, int num_levels,
     const float* __restrict__ sk_r_raw, const float* __restrict__ joints, const float* __restrict__ global_T,
     float* __restrict__ bone_T, float* __restrict__ chain_A /*[M,7] saved for backward*/) {
-  extern __shared__ float s_A[];  // [M][7]
+  extern __shared__ float s_A[];  // [M][7] | staged skeleton
   const int tid = threadIdx.x;
+  const Staged sk = stage_skeleton(s_A + 7 * (size_t) M, M, num_levels, parents, level_nodes, level_start, sk_r_raw, joints);
   if (tid == 0) {
     float* a = s_A + 7 * root;
     a[0] = a[1] = a[2] = a[3] = a[4] = a[5] = 0.f, a[6] = 1.f;
   }
   __syncthreads();
   for (int lv = 1; lv < num_levels; ++lv) {
-    for (int k = level_start[lv] + tid; k < level_start[lv + 1]; k += CHAIN_THREADS) {
-      const int i = level_nodes[k], p = parents[i];
-      const Q4 q  = qnormalize({sk_r_raw[4 * i], sk_r_raw[4 * i + 1], sk_r_raw[4 * i + 2], sk_r_raw[4 * i + 3] + 1.0f});
-      const V3 j  = {joints[3 * i], joints[3 * i + 1], joints[3 * i + 2]};
-      const V3 rj = qrot(q, {-j.x, -j.y, -j.z});
-      const V3 tL = {j.x + rj.x, j.y + rj.y, j.z + rj.z};
+    for (int k = sk.ls[lv] + tid; k < sk.ls[lv + 1]; k += CHAIN_THREADS) {
+      const int i = sk.ln[k], p = sk.par[i];
+      const float* lo = sk.loc + (size_t) i * LOC_F;
+      const Q4 q  = {lo[0], lo[1], lo[2], lo[3]};
+      const V3 tL = {lo[4], lo[5], lo[6]};
       const float* ap = s_A + 7 * p;
       const Q4 qp = {ap[3], ap[4], ap[5], ap[6]};
       const V3 rt = qrot(qp, tL);
@@ -123,6 +156,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) bone_chain_backward_kernel(int 
   float* s_gA = s_mem + 7 * M;  // [M][7]
   __shared__ float s_gG[7];
   const int tid = threadIdx.x;
+  const Staged sk = stage_skeleton(s_mem + 14 * (size_t) M, M, num_levels, parents, level_nodes, level_start, sk_r_raw, joints);
   for (int i = tid; i < 7 * M; i += CHAIN_THREADS) s_A[i] = chain_A[i];
   if (tid < 7) s_gG[tid] = 0.f;
   __syncthreads();
@@ -154,15 +188,13 @@ __global__ void __launch_bounds__(CHAIN_THREADS) bone_chain_backward_kernel(int 
   __syncthreads();
   // A_i = A_p o L_i, deepest level first
   for (int lv = num_levels - 1; lv >= 1; --lv) {
-    for (int k = level_start[lv] + tid; k < level_start[lv + 1]; k += CHAIN_THREADS) {
-      const int i = level_nodes[k], p = parents[i];
-      const float raw[4] = {sk_r_raw[4 * i], sk_r_raw[4 * i + 1], sk_r_raw[4 * i + 2], sk_r_raw[4 * i + 3] + 1.0f};
-      const float nraw   = fmaxf(sqrtf(raw[0] * raw[0] + raw[1] * raw[1] + raw[2] * raw[2] + raw[3] * raw[3]), 1e-12f);
-      const Q4 q  = {raw[0] / nraw, raw[1] / nraw, raw[2] / nraw, raw[3] / nraw};
-      const V3 j  = {joints[3 * i], joints[3 * i + 1], joints[3 * i + 2]};
-      const V3 mj = {-j.x, -j.y, -j.z};
-      const V3 rj = qrot(q, mj);
-      const V3 tL = {j.x + rj.x, j.y + rj.y, j.z + rj.z};
+    for (int k = sk.ls[lv] + tid; k < sk.ls[lv + 1]; k += CHAIN_THREADS) {
+      const int i = sk.ln[k], p = sk.par[i];
+      const float* lo  = sk.loc + (size_t) i * LOC_F;
+      const Q4 q       = {lo[0], lo[1], lo[2], lo[3]};
+      const V3 tL      = {lo[4], lo[5], lo[6]};
+      const V3 mj      = {-lo[7], -lo[8], -lo[9]};
+      const float nraw = lo[10];
       const float* ap = s_A + 7 * p;
       const Q4 qp = {ap[3], ap[4], ap[5], ap[6]};
       const float* ga = s_gA + 7 * i;
@@ -225,8 +257,9 @@ int skgs_bone_chain_forward(int32_t M, int32_t root, const int32_t* parents, con
     float* bone_T, float* chain_A, skgs_stream_t stream) {
   SKGS_REQUIRE(M >= 1 && root >= 0 && root < M && num_levels >= 1, "bone_chain: bad skeleton sizes");
   SKGS_REQUIRE(parents && level_nodes && level_start && sk_r_raw && joints && bone_T, "bone_chain: NULL argument");
-  SKGS_REQUIRE((size_t) M * 7 * 4 <= 60 * 1024, "bone_chain: at most 2194 bones");
-  hipLaunchKernelGGL(bone_chain_forward_kernel, dim3(1), dim3(CHAIN_THREADS), (size_t) M * 7 * 4, (hipStream_t) stream, M, root,
+  const size_t lds = (size_t) M * 7 * 4 + staged_bytes(M, num_levels);
+  SKGS_REQUIRE(lds <= 64 * 1024, "bone_chain: skeleton too large for the LDS staging (about 740 bones)");
+  hipLaunchKernelGGL(bone_chain_forward_kernel, dim3(1), dim3(CHAIN_THREADS), lds, (hipStream_t) stream, M, root,
       parents, level_nodes, level_start, num_levels, sk_r_raw, joints, global_T, bone_T, chain_A);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
@@ -239,8 +272,9 @@ int skgs_bone_chain_backward(int32_t M, int32_t root, const int32_t* parents, co
   SKGS_REQUIRE(M >= 1 && root >= 0 && root < M && num_levels >= 1, "bone_chain: bad skeleton sizes");
   SKGS_REQUIRE(parents && level_nodes && level_start && sk_r_raw && joints && chain_A && g_bone_T && g_sk_r_raw,
       "bone_chain: NULL argument");
-  SKGS_REQUIRE((size_t) M * 14 * 4 <= 60 * 1024, "bone_chain backward: at most 1097 bones");
-  hipLaunchKernelGGL(bone_chain_backward_kernel, dim3(1), dim3(CHAIN_THREADS), (size_t) M * 14 * 4, (hipStream_t) stream, M,
+  const size_t lds = (size_t) M * 14 * 4 + staged_bytes(M, num_levels);
+  SKGS_REQUIRE(lds <= 64 * 1024, "bone_chain backward: skeleton too large for the LDS staging (about 560 bones)");
+  hipLaunchKernelGGL(bone_chain_backward_kernel, dim3(1), dim3(CHAIN_THREADS), lds, (hipStream_t) stream, M,
       root, parents, level_nodes, level_start, num_levels, sk_r_raw, joints, global_T, chain_A, g_bone_T, g_sk_r_raw,
       g_joints, g_global_T);
   SKGS_CHECK_HIP(hipGetLastError());

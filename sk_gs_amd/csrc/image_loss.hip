@@ -23,7 +23,7 @@ constexpr int TW   = 32, TH = 32;      // output tile of one workgroup
 constexpr int HALO = 5;                // window radius
 constexpr int IW   = TW + 2 * HALO;    // 42 staged columns
 constexpr int IH   = TH + 2 * HALO;    // 42 staged rows
-constexpr int IP   = IW + 2;           // LDS pitch of the staged inputs (16-B aligned 8-column segments)
+constexpr int IP   = IW + 2;           // LDS pitch of staged inputs (backward)
 constexpr int HP   = TW + 1;           // LDS pitch of the horizontally filtered rows
 constexpr int SEG  = 8;                // horizontal pass: outputs per thread (18 inputs -> 8 outputs)
 constexpr int VSEG = 4;                // vertical pass: outputs per thread (14 inputs -> 4 outputs)
@@ -43,31 +43,49 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red) {
   return r;
 }
 
-// Register-blocked separable filter: a thread of the horizontal pass slides the 11-tap window over 18 staged inputs
-// for 8 adjacent outputs (2.25 LDS reads per output and moment pair instead of 22), a thread of the vertical pass
-// over 14 rows for 4 outputs (3.5 reads per output instead of 11).  The kernel was LDS-issue bound before.
+// Register-blocked separable filter: a thread of the horizontal pass slides the 11-tap window over 18 inputs for 8
+// adjacent outputs, a thread of the vertical pass over 14 filtered rows for 4 outputs (3.5 LDS reads per output and
+// moment instead of 11).  The inputs go from global memory straight into the registers of the horizontal pass (the
+// overlap between neighbouring segments and tiles is served by L1/L2): only the filtered rows live in LDS (27 KB per
+// workgroup, 5 workgroups per CU).  Interior tiles skip the zero-padding tests.
+template <int NMAP>
+__device__ __forceinline__ void load_row18(const float* const (&plane)[NMAP], int W, int H, int gy, int gx0, bool interior,
+    float (&v)[NMAP][SEG + 10]) {
+  if (interior) {
+#pragma unroll
+    for (int m = 0; m < NMAP; ++m) {
+      const float* row = plane[m] + (size_t) gy * W + gx0;
+#pragma unroll
+      for (int i = 0; i < SEG + 10; ++i) v[m][i] = row[i];
+    }
+  } else {
+    const bool row_ok = gy >= 0 && gy < H;
+    const size_t ro   = (size_t) (row_ok ? gy : 0) * W;
+#pragma unroll
+    for (int i = 0; i < SEG + 10; ++i) {
+      const int gx  = gx0 + i;
+      const bool ok = row_ok && gx >= 0 && gx < W;
+      const size_t o = ro + (ok ? gx : 0);
+#pragma unroll
+      for (int m = 0; m < NMAP; ++m) v[m][i] = ok ? plane[m][o] : 0.f;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) image_loss_forward_kernel(int C, int H, int W, const float* __restrict__ pred,
     const float* __restrict__ gt, Win win, float* __restrict__ dmaps /*[3][C][H][W]*/, float* __restrict__ partials) {
-  __shared__ float s_x[IH][IP];
-  __shared__ float s_y[IH][IP];
   __shared__ float s_h[5][IH][HP];
   __shared__ float s_red[4];
   const int c  = blockIdx.z;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const int tid = threadIdx.x;
   const size_t plane = (size_t) H * W;
-  const float* px = pred + c * plane;
-  const float* py = gt + c * plane;
-  for (int i = tid; i < IH * IW; i += 256) {
-    const int r = i / IW, q = i - r * IW;
-    const int gy = y0 + r - HALO, gx = x0 + q - HALO;
-    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-    s_x[r][q] = in ? px[(size_t) gy * W + gx] : 0.f;
-    s_y[r][q] = in ? py[(size_t) gy * W + gx] : 0.f;
-  }
-  __syncthreads();
+  const float* const planes[2] = {pred + c * plane, gt + c * plane};
+  const bool interior = x0 >= HALO && y0 >= HALO && x0 + TW + HALO <= W && y0 + TH + HALO <= H;
   if (tid < IH * (TW / SEG)) {
     const int r = tid / (TW / SEG), q0 = (tid % (TW / SEG)) * SEG;
+    float in[2][SEG + 10];
+    load_row18<2>(planes, W, H, y0 + r - HALO, x0 + q0 - HALO, interior, in);
     float a[SEG][5];
 #pragma unroll
     for (int o = 0; o < SEG; ++o)
@@ -75,7 +93,7 @@ __global__ void __launch_bounds__(256) image_loss_forward_kernel(int C, int H, i
       for (int m = 0; m < 5; ++m) a[o][m] = 0.f;
 #pragma unroll
     for (int i = 0; i < SEG + 10; ++i) {
-      const float xv = s_x[r][q0 + i], yv = s_y[r][q0 + i];
+      const float xv = in[0][i], yv = in[1][i];
       const float xx = xv * xv, yy = yv * yv, xy = xv * yv;
 #pragma unroll
       for (int o = 0; o < SEG; ++o) {
@@ -130,11 +148,12 @@ __global__ void __launch_bounds__(256) image_loss_forward_kernel(int C, int H, i
       const float d_mu1 = (2.f * mu2 * (A2 - A1) * inv) - ssim * (2.f * mu1 * (B2 - B1)) * inv;
       const float d_exx = -ssim / B2;
       const float d_exy = 2.f * A1 * inv;
-      const size_t oo  = (size_t) c * plane + (size_t) gy * W + gx;
+      const size_t po  = (size_t) gy * W + gx;
+      const size_t oo  = (size_t) c * plane + po;
       const size_t CHW = (size_t) C * plane;
       dmaps[oo] = d_mu1, dmaps[CHW + oo] = d_exx, dmaps[2 * CHW + oo] = d_exy;
       ssim_sum += ssim;
-      l1_sum += fabsf(s_x[ty0 + o + HALO][tx + HALO] - s_y[ty0 + o + HALO][tx + HALO]);
+      l1_sum += fabsf(planes[0][po] - planes[1][po]);
     }
   }
   const float ssum = block_sum_256(ssim_sum, s_red);

@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(int P, int D, 
     const float* __restrict__ rotations, float scale_modifier, const float* __restrict__ cov3D_precomp,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos, int W,
     int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, const float4* __restrict__ recs,
-    const float* __restrict__ gradacc /*[P][16]*/, int moments, const float* __restrict__ gin_means2D,
+    float* __restrict__ gradacc /*[P][16]*/, int moments, int rezero, const float* __restrict__ gin_means2D,
     const float* __restrict__ gin_conic, const float* __restrict__ gin_opacity, int E, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_dconic_out, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
@@ -448,9 +448,13 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(int P, int D, 
   float gm2[2] = {0.f, 0.f}, gcon[3] = {0.f, 0.f, 0.f}, gop = 0.f, gcol[3] = {0.f, 0.f, 0.f}, gex[4] = {0, 0, 0, 0};
   const bool visible = radii[idx] > 0;
   {
-    const float4* row = reinterpret_cast<const float4*>(gradacc + (size_t) idx * GRAD_ROW);
+    float4* row = reinterpret_cast<float4*>(gradacc + (size_t) idx * GRAD_ROW);
     float4 a = make_float4(0, 0, 0, 0), b = a, c = a, d = a;
-    if (visible) a = row[0], b = row[1], c = row[2], d = row[3];
+    if (visible) {
+      a = row[0], b = row[1], c = row[2], d = row[3];
+      // skgs_raster_grads::workspace_is_zero: hand the scratch back all zero (rows of culled Gaussians are never touched)
+      if (rezero) row[0] = row[1] = row[2] = row[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     gm2[0] = a.x, gm2[1] = a.y, gcon[0] = a.z, gcon[1] = a.w, gcon[2] = b.x, gop = b.y, gcol[0] = b.z, gcol[1] = b.w;
     gcol[2] = c.x, gex[0] = c.y, gex[1] = c.z, gex[2] = c.w, gex[3] = d.x;
     if (moments) {
@@ -743,13 +747,12 @@ int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const i
   ProfScope prof(K_PREPROCESS_BWD, s);
   dim3 grid((P + 255) / 256), block(256);
   const int E = (in.extras && gr.dL_dout_extra && gr.dL_dextras) ? in.E : 0;
-#define SKGS_PB_ARGS                                                                                                    \
-  P, in.sh_degree, in.sh_coeffs, in.means3D, radii, in.sh, in.sh_rest, in.scales, in.rotations, in.scale_modifier,       \
-      in.cov3D_precomp,                                                                                                \
-      in.viewmatrix, in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y, \
-      g.recs, gr.workspace, (int) gradacc_rows_hold_moments(), gr.grad_means2D_in, gr.grad_conic_in, gr.grad_opacity_in, E,  \
-      gr.dL_dmeans2D, gr.dL_dconic,                                                                                      \
-      gr.dL_dcolors, gr.dL_dopacity, gr.dL_dmeans3D, gr.dL_dcov3D, gr.dL_dsh, gr.dL_dsh_rest, gr.dL_dscales, gr.dL_drotations, \
+#define SKGS_PB_ARGS                                                                                                     \
+  P, in.sh_degree, in.sh_coeffs, in.means3D, radii, in.sh, in.sh_rest, in.scales, in.rotations, in.scale_modifier,        \
+      in.cov3D_precomp, in.viewmatrix, in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, \
+      focal_x, focal_y, g.recs, gr.workspace, (int) gradacc_rows_hold_moments(), (int) (gr.workspace_is_zero != 0),       \
+      gr.grad_means2D_in, gr.grad_conic_in, gr.grad_opacity_in, E, gr.dL_dmeans2D, gr.dL_dconic, gr.dL_dcolors,           \
+      gr.dL_dopacity, gr.dL_dmeans3D, gr.dL_dcov3D, gr.dL_dsh, gr.dL_dsh_rest, gr.dL_dscales, gr.dL_drotations,           \
       gr.dL_dextras
   if (in.colmap)
     hipLaunchKernelGGL(preprocess_backward_kernel<true>, grid, block, 0, s, SKGS_PB_ARGS);

@@ -46,7 +46,7 @@ class FusedViewStep:
     """
 
     def __init__(self, model: SkinnedGaussians, W: int, H: int, capacity: int, lambda_dssim: float = 0.2,
-                 background: Optional[Tensor] = None):
+                 background: Optional[Tensor] = None, grad_scale: float = 1.0):
         assert not model.static, 'FusedViewStep covers the skinned stage (M >= 1)'
         self.model, self.W, self.H = model, int(W), int(H)
         self.lambda_l1, self.lambda_ssim = 1.0 - lambda_dssim, lambda_dssim
@@ -59,6 +59,9 @@ class FusedViewStep:
         f32 = dict(dtype=torch.float32, device=dev)
         u8 = dict(dtype=torch.uint8, device=dev)
         self.background = None if background is None else background.to(**f32).contiguous()
+        # dL/dloss seed: 1/world_size makes the gradients arrive pre-averaged for a SUM all-reduce (view-parallel
+        # training), instead of a separate division pass over the whole flat gradient buffer
+        self.grad_scale = None if grad_scale == 1.0 else torch.full((1,), float(grad_scale), **f32)
         for p in model.parameters():
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
@@ -85,7 +88,7 @@ class FusedViewStep:
         self.g_weights = torch.empty((P, K), **f32)
         self.g_bone_T = torch.empty((M, 7), **f32)
         self.deform_ws = torch.empty((lib.skgs_lbs_deform_backward_workspace_bytes(C.c_int32(P), C.c_int32(M)),), **u8)
-        self.bwd_ws = torch.empty((lib.skgs_backward_workspace_bytes(C.c_int32(P)),), **u8)
+        self.bwd_ws = torch.zeros((lib.skgs_backward_workspace_bytes(C.c_int32(P)),), **u8)  # kept zero between steps
         topo = model.topology()
         self._topo = topo
         self._bufs = _C._buffers(self.geom, self.binning, self.img)
@@ -169,7 +172,7 @@ class FusedViewStep:
                                         C.c_float(self.lambda_l1), C.c_float(self.lambda_ssim), _p(self.loss3),
                                         _p(self.loss_ws), C.c_size_t(self.loss_ws.numel()), st))
         chk(lib.skgs_image_loss_backward(C.c_int32(3), C.c_int32(H), C.c_int32(W), _p(self.image), _p(target),
-                                         C.c_float(self.lambda_l1), C.c_float(self.lambda_ssim), None,
+                                         C.c_float(self.lambda_l1), C.c_float(self.lambda_ssim), _p(self.grad_scale),
                                          _p(self.loss_ws), C.c_size_t(self.loss_ws.numel()), _p(self.dL_dimage), st))
         # ---- rasterize backward: SH gradients land in the parameters' .grad, the rest feeds the skinning backward
         g = _C._RasterGrads()
@@ -180,6 +183,7 @@ class FusedViewStep:
         g.dL_dsh, g.dL_dsh_rest = m._features_dc.grad.data_ptr(), m._features_rest.grad.data_ptr()
         g.dL_dscales, g.dL_drotations = self.g_scales.data_ptr(), self.g_rotations.data_ptr()
         g.workspace, g.workspace_bytes = self.bwd_ws.data_ptr(), self.bwd_ws.numel()
+        g.workspace_is_zero = 1
         chk(lib.skgs_rasterize_backward(C.byref(a), C.byref(self._bufs), _p(self.radii), _p(self.out_opacity),
                                         C.byref(g), st))
         # ---- skinning backward: Gaussian parameters' gradients written in place

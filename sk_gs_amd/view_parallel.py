@@ -82,10 +82,12 @@ class ViewParallel:
         """rank r renders view (step * world + r) mod num_views"""
         return (step * self.world + self.rank) % num_views
 
-    def allreduce_grads(self, async_op: bool = False):
+    def allreduce_grads(self, async_op: bool = False, prescaled: bool = False):
+        """SUM all-reduce of the flat gradient buffer.  ``prescaled``: the gradients were already multiplied by
+        1/world at their source (``FusedViewStep(grad_scale=1/world)``), so the averaging pass is skipped."""
         if not self.active:
             return None
-        if self.average and self.world > 1:
+        if self.average and self.world > 1 and not prescaled:
             self.grads.flat.div_(self.world)
         return dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM, async_op=async_op)
 

@@ -104,6 +104,11 @@ assert vp.world == 2 and vp.view_index(3, 8) == (3 * 2 + rank) % 8
 vp.allreduce_grads()
 assert torch.allclose(p1.grad, torch.full((4, 3), 1.5)), p1.grad
 assert torch.allclose(p2.grad, torch.full((7,), 15.0)), p2.grad
+# gradients seeded with 1/world at their source (FusedViewStep(grad_scale=1/world)): SUM without the averaging pass
+vp.grads.zero_()
+((p1 * (rank + 1)).sum() / world + (p2 * (10 * (rank + 1))).sum() / world).backward()
+vp.allreduce_grads(prescaled=True)
+assert torch.allclose(p1.grad, torch.full((4, 3), 1.5)) and torch.allclose(p2.grad, torch.full((7,), 15.0))
 acc, den, rad = torch.full((5, 1), float(rank + 1)), torch.ones(5, 1), torch.tensor([1., 5., 2., 0., 3.]) * (rank + 1)
 vp.allreduce_densify_stats(acc, den, rad)
 assert torch.allclose(acc, torch.full((5, 1), 3.0)) and torch.allclose(den, torch.full((5, 1), 2.0))
