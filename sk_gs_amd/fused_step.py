@@ -145,6 +145,8 @@ class FusedViewStep:
         lib, m, st, chk = self.lib, self.model, _C._stream(), _C._check
         t = self._topo
         P, M, K = self.P, self.M, self.K
+        # (running the single-workgroup bone-chain kernels on a forked stream beside the wide kernels was measured:
+        # the fork/join edges of the captured graph cost more (+12 us per step) than the ~10 us of overlap)
         chk(lib.skgs_bone_chain_forward(
             C.c_int32(M), C.c_int32(t['root']), _p(t['parents']), _p(t['level_nodes']), _p(t['level_start']),
             C.c_int32(t['num_levels']), _p(m.sk_r[time_id]), _p(m.joints), _p(m.global_tr[time_id]), _p(self.bone_T),
