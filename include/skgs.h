@@ -236,6 +236,13 @@ int64_t skgs_adam_chunk_elems(void);
 int skgs_adam_step(int32_t n_tensors, const void* tensors, int64_t total_chunks, double beta1, double beta2, double eps,
     float* step_count, skgs_stream_t stream);
 
+/* ---- densification statistics of one training view (scope row (f)-4) ----
+ * networks/sk_gs.py:1990-1997 + networks/gaussian_splatting.py:503-513: for every Gaussian with radii > 0
+ *   max_radii2D = max(max_radii2D, radii); xyz_gradient_accum += |grad_means2D[:, :2]|; denom += 1.
+ * grad_means2D [P,3] is dL_dmeans2D of skgs_rasterize_backward (`viewspace_points.grad`); accum, denom [P,1]. */
+int skgs_densify_stats(int32_t P, const int32_t* radii, const float* grad_means2D, float* xyz_gradient_accum, float* denom,
+    float* max_radii2D, skgs_stream_t stream);
+
 /* Tuning knob of the blend kernels: pixels handled per lane (1, 2 or 4); 0 = heuristic on the tile count. */
 void skgs_set_pixels_per_lane(int ppl);
 /* Parity-test switch: blend kernels without FMA contraction, in the oracle's operation order, reproducible exp. */

@@ -342,3 +342,25 @@ class Oracle:
         self._fn('knn_bones')(C.c_int(P), C.c_int(M), C.c_int(K), C.c_int(dim), _p(points), _p(joints), _p(dist),
                               _p(idx))
         return dist, idx
+
+    # ------------------------------------------------------------------------------------- per-iteration bookkeeping
+    def densify_stats(self, radii, grad_means2D, xyz_gradient_accum, denom, max_radii2D):
+        """numpy restatement of the densification statistics of one view (networks/sk_gs.py:1990-1997:
+        ``mask = radii > 0; max_radii2D[mask] = max(max_radii2D[mask], radii[mask])``; networks/gaussian_splatting.py:
+        503-513: ``xyz_gradient_accum[mask] += norm(grad[mask, :2]); denom[mask] += 1``).  Returns the three updated
+        arrays (inputs untouched)."""
+        radii = np.asarray(radii)
+        g = self.r(grad_means2D).reshape(-1, 3)
+        acc, den, mr = (self.r(x).copy() for x in (xyz_gradient_accum, denom, max_radii2D))
+        mask = radii > 0
+        mr[mask] = np.maximum(mr[mask], radii[mask].astype(self.dtype))
+        nrm = np.sqrt(g[:, 0] * g[:, 0] + g[:, 1] * g[:, 1]).astype(self.dtype)
+        acc.reshape(-1)[mask] += nrm[mask]
+        den.reshape(-1)[mask] += 1
+        return acc, den, mr
+
+    def lbs_weights(self, sp_W, indices):
+        """``torch.gather(sp_W, 1, indices).softmax(-1)`` (networks/sk_gs.py:769-770) in numpy"""
+        l = np.take_along_axis(self.r(sp_W), np.asarray(indices), axis=1)
+        e = np.exp(l - l.max(axis=1, keepdims=True))
+        return (e / e.sum(axis=1, keepdims=True)).astype(self.dtype)

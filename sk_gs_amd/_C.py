@@ -212,6 +212,22 @@ def profile_collect() -> dict:
     return out
 
 
+def densify_stats(radii: Tensor, grad_means2D: Tensor, xyz_gradient_accum: Tensor, denom: Tensor, max_radii2D: Tensor):
+    """In-place densification statistics of one view (``add_densification_stats`` + the ``max_radii2D`` update,
+    networks/gaussian_splatting.py:503-513, networks/sk_gs.py:1990-1997) in one launch."""
+    lib = load_library()
+    _require_gpu(radii, 'radii')
+    P = radii.shape[0]
+    for t, n in ((radii, P), (grad_means2D, 3 * P), (xyz_gradient_accum, P), (denom, P), (max_radii2D, P)):
+        if not (t.is_cuda and t.is_contiguous() and t.numel() == n):
+            raise SkgsError('densify_stats: tensors must be contiguous device tensors of P rows')
+    if radii.dtype != torch.int32 or any(t.dtype != torch.float32 for t in (grad_means2D, xyz_gradient_accum, denom, max_radii2D)):
+        raise SkgsError('densify_stats: radii int32, the others float32')
+    _check(lib.skgs_densify_stats(C.c_int32(P), C.c_void_p(_ptr(radii)), C.c_void_p(_ptr(grad_means2D)),
+                                  C.c_void_p(_ptr(xyz_gradient_accum)), C.c_void_p(_ptr(denom)),
+                                  C.c_void_p(_ptr(max_radii2D)), _stream()))
+
+
 def set_strict_math(on: bool):
     """parity-test switch: blend kernels built without FMA contraction, in the oracle's operation order, with the
     reproducible double-arithmetic exp (bit-comparable with the oracle's exp_mode=1). Slower; never used by bench."""

@@ -46,7 +46,7 @@ class FusedViewStep:
     """
 
     def __init__(self, model: SkinnedGaussians, W: int, H: int, capacity: int, lambda_dssim: float = 0.2,
-                 background: Optional[Tensor] = None, grad_scale: float = 1.0):
+                 background: Optional[Tensor] = None, grad_scale: float = 1.0, densify_stats: bool = False):
         assert not model.static, 'FusedViewStep covers the skinned stage (M >= 1)'
         self.model, self.W, self.H = model, int(W), int(H)
         self.lambda_l1, self.lambda_ssim = 1.0 - lambda_dssim, lambda_dssim
@@ -89,6 +89,10 @@ class FusedViewStep:
         self.g_bone_T = torch.empty((M, 7), **f32)
         self.deform_ws = torch.empty((lib.skgs_lbs_deform_backward_workspace_bytes(C.c_int32(P), C.c_int32(M)),), **u8)
         self.bwd_ws = torch.zeros((lib.skgs_backward_workspace_bytes(C.c_int32(P)),), **u8)  # kept zero between steps
+        # densification statistics (gaussian_splatting.py:503-513, sk_gs.py:1990-1997), updated by every step if asked
+        self.densify_stats = bool(densify_stats)
+        self.xyz_gradient_accum, self.denom = torch.zeros((P, 1), **f32), torch.zeros((P, 1), **f32)
+        self.max_radii2D = torch.zeros((P,), **f32)
         topo = model.topology()
         self._topo = topo
         self._bufs = _C._buffers(self.geom, self.binning, self.img)
@@ -200,6 +204,15 @@ class FusedViewStep:
             C.c_int32(M), C.c_int32(t['root']), _p(t['parents']), _p(t['level_nodes']), _p(t['level_start']),
             C.c_int32(t['num_levels']), _p(m.sk_r[time_id]), _p(m.joints), _p(m.global_tr[time_id]), _p(self.chain_A),
             _p(self.g_bone_T), _p(m.sk_r.grad[time_id]), None, _p(m.global_tr.grad[time_id]), st))
+        if self.densify_stats:
+            self.add_densification_stats()
+
+    @torch.no_grad()
+    def add_densification_stats(self):
+        """accumulate this view's statistics (one launch); ``forward_backward`` calls it when ``densify_stats`` is set"""
+        _C._check(self.lib.skgs_densify_stats(C.c_int32(self.P), _p(self.radii), _p(self.grad_means2D),
+                                             _p(self.xyz_gradient_accum), _p(self.denom), _p(self.max_radii2D),
+                                             _C._stream()))
 
     def status(self) -> dict:
         """(synchronising) num_rendered / overflow / longest tile list of the last forward, and the number of

@@ -173,3 +173,31 @@ def test_bone_chain_matches_torch(M, shape, with_global):
     assert rel_err(out, ref) <= 5e-6
     for a, r in zip(got, gref):
         assert rel_err(a, r) <= 5e-5, rel_err(a, r)
+
+
+def test_densify_stats_and_lbs_weights_kernels(oracle32):
+    """(f)-4 densification statistics and the sp_W weighting against their numpy restatements"""
+    from sk_gs_amd import _C
+    g = torch.Generator().manual_seed(9)
+    P, M, K = 5000, 12, 4
+    radii = (torch.randint(-2, 30, (P,), generator=g)).clamp(min=0).int()
+    grad = torch.randn(P, 3, generator=g)
+    acc, den, mr = torch.rand(P, 1, generator=g), torch.randint(0, 5, (P, 1), generator=g).float(), torch.rand(P, generator=g) * 20
+    ref = oracle32.densify_stats(radii.numpy(), grad.numpy(), acc.numpy(), den.numpy(), mr.numpy())
+    a, d, m = acc.cuda(), den.cuda(), mr.cuda()
+    _C.densify_stats(radii.cuda(), grad.cuda(), a, d, m)
+    assert rel_err(a, ref[0]) <= 1e-6 and np.array_equal(to_np(d), ref[1]) and np.array_equal(to_np(m), ref[2])
+    # KNN + softmax of the gathered logits in one launch vs knn_bones + numpy
+    pts, joints, sp_W = torch.randn(P, 3, generator=g), torch.randn(M, 3, generator=g), torch.randn(P, M, generator=g)
+    lib = _C.load_library()
+    idx = torch.empty((P, K), dtype=torch.int64, device='cuda')
+    w = torch.empty((P, K), device='cuda')
+    import ctypes as C
+    pts_d, joints_d, sp_W_d = pts.cuda(), joints.cuda(), sp_W.cuda()
+    _C._check(lib.skgs_knn_lbs_weights(C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_void_p(pts_d.data_ptr()),
+                                       C.c_void_p(joints_d.data_ptr()), C.c_void_p(sp_W_d.data_ptr()),
+                                       C.c_void_p(idx.data_ptr()), C.c_void_p(w.data_ptr()), _C._stream()))
+    torch.cuda.synchronize()
+    _, idx_ref = oracle32.knn_bones(pts.numpy(), joints.numpy(), K)
+    assert np.array_equal(to_np(idx), idx_ref)
+    assert rel_err(w, oracle32.lbs_weights(sp_W.numpy(), idx_ref)) <= 2e-6

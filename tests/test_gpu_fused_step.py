@@ -45,7 +45,7 @@ def test_fused_step_matches_autograd(use_bg, flat):
     else:
         for p in model.parameters():
             p.grad = torch.full_like(p, 123.0)
-    step = FusedViewStep(model, W, H, capacity=int(R * 1.2) + 1024, background=bg)
+    step = FusedViewStep(model, W, H, capacity=int(R * 1.2) + 1024, background=bg, densify_stats=True)
     step.forward_backward(rs, tid, target)
     st = step.status()
     assert st['overflow'] == 0 and st['num_rendered'] == R
@@ -55,6 +55,10 @@ def test_fused_step_matches_autograd(use_bg, flat):
         assert_close_robust(p.grad, ref[n], 1e-4, 1e-4, name=n)  # atomics order + in-kernel background rounding
     vs = out['viewspace_points'].grad
     assert_close_robust(step.grad_means2D, vs, 1e-4, 1e-4, name='means2D')
+    # densification statistics of this view (gaussian_splatting.py:503-513, sk_gs.py:1990-1997)
+    vis = step.radii > 0
+    assert torch.equal(step.denom.view(-1), vis.float()) and torch.equal(step.max_radii2D, step.radii.float() * vis)
+    assert rel_err(step.xyz_gradient_accum.view(-1), step.grad_means2D[:, :2].norm(dim=-1) * vis) <= 1e-6
     # a second call on another frame leaves no stale rows in the per-frame tables
     step.forward_backward(rs, 2, target)
     assert float(model.sk_r.grad[tid].abs().max()) == 0.0 and float(model.sk_r.grad[2].abs().max()) > 0.0
