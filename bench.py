@@ -130,6 +130,12 @@ def main():
     ap.add_argument('--lr', type=float, default=1e-4, help='base lr (reference 1e-3); small keeps the workload stationary')
     ap.add_argument('--torch-adam', action='store_true', help='use torch.optim.Adam(fused=True) instead of the one-launch kernel')
     ap.add_argument('--eager', action='store_true', help='issue every launch eagerly instead of replaying hipGraphs')
+    ap.add_argument('--pipeline', action='store_true',
+                    help='world > 1: two gradient buckets, the SH bucket on the wire during the skinning backward and the '
+                         'second one during the Adam update of the first (4 graphs per step instead of 2: measured +58 us '
+                         'of launch / stream-join overhead per step on one GPU, so it only pays when the all-reduce is slow)')
+    ap.add_argument('--dense-spw-grad', action='store_true',
+                    help='world > 1: all-reduce the dense [P,M] sp_W gradient instead of the compact [P,K] logit gradient')
     ap.add_argument('--autograd', action='store_true',
                     help='run the step through the torch-autograd operator path (model.render + image_loss + backward) '
                          'instead of sk_gs_amd.fused_step.FusedViewStep (same kernels, no autograd glue)')
@@ -173,13 +179,25 @@ def main():
         for v in range(args.views):
             img = model.render(settings[v], time_id=v % frames, background=background)['images']
             targets.append((img + 0.05 * torch.randn(3, H, W, generator=gen).to(dev)).clamp(0, 1).contiguous())
-    vp = ViewParallel(model.parameters(), average=True)
-    if args.torch_adam:
-        opt = torch.optim.Adam(model.param_groups(lr=args.lr), eps=1e-15, betas=(0.9, 0.999), fused=True,
-                               capturable=not args.eager)
+    fused_dist = use_dist and not args.autograd and not args.torch_adam
+    pipelined = fused_dist and args.pipeline
+    compact = fused_dist and (pipelined or not args.dense_spw_grad)
+    groups = model.param_groups(lr=args.lr)
+    if compact:
+        # the dense [P,M] sp_W gradient never goes on the wire: the ranks all-reduce the compact [P,K] logit gradient
+        # (their KNN indices are identical) and expand it afterwards
+        from sk_gs_amd.view_parallel import BucketedGradReducer
+        bucket0 = [model._features_dc, model._features_rest]   # final after the rasterizer backward
+        bucket1 = [model._xyz, model._scaling, model._rotation, model._opacity, model.sk_r, model.sk_d_rot,
+                   model.sk_d_scale, model.global_tr]          # final after the skinning backward
+        if pipelined:
+            vp = BucketedGradReducer([bucket0, bucket1], extras=[0, P * model.K])
+        else:
+            vp = BucketedGradReducer([bucket0 + bucket1], extras=[P * model.K])
+        comm_bytes = vp.nbytes
     else:
-        from sk_gs_amd.optim import FusedAdam
-        opt = FusedAdam(model.param_groups(lr=args.lr), eps=1e-15, betas=(0.9, 0.999))
+        vp = ViewParallel(model.parameters(), average=True)
+        comm_bytes = vp.grads.nbytes
     # ---------------------------------------------------------------- learn R per view with the synchronising path
     _C.config.sync_num_rendered = True
     Rs = []
@@ -191,51 +209,113 @@ def main():
     _C.update_capacity_hint(P, W, H, int(R_max * 1.25))
 
     overflow = torch.zeros(1, dtype=torch.int32, device=dev)
-
-    if args.autograd:
-        def fwd_bwd(v):
-            vp.grads.zero_()
-            out = model.render(settings[v], time_id=v % frames, background=background)
-            loss = image_loss(out['images'], targets[v])
-            loss.backward()
-            overflow.add_(out['buffer'].geomBuffer[4:8].view(torch.int32))
-    else:
+    from sk_gs_amd.train_step import GraphedSteps
+    if not args.autograd:
         from sk_gs_amd.fused_step import FusedViewStep
         fstep = FusedViewStep(model, W, H, capacity=int(R_max * 1.25 * _C.config.capacity_growth) + 1024,
-                              background=background, grad_scale=1.0 / world)
+                              background=background, grad_scale=1.0 / world,
+                              spw_logit_grad=vp.extra_views[-1] if compact else None)
 
-        def fwd_bwd(v):  # every gradient is overwritten in place: no zero fill of the flat buffer
-            fstep.forward_backward(settings[v], v % frames, targets[v])
+    if pipelined:
+        # ---- world > 1: bucket 0 is on the wire while the skinning backward runs, bucket 1 while Adam updates bucket 0
+        from sk_gs_amd.optim import FusedAdam
+        optA = FusedAdam([g for g in groups if g['name'] in ('f_dc', 'f_rest')], eps=1e-15, betas=(0.9, 0.999))
+        optB = FusedAdam([g for g in groups if g['name'] not in ('f_dc', 'f_rest')], eps=1e-15, betas=(0.9, 0.999))
 
-    prescaled = not args.autograd  # FusedViewStep seeds the backward with 1/world
+        def part_a(v):
+            fstep.backward_raster(settings[v], v % frames, targets[v])
 
-    def eager_step(i):
-        fwd_bwd(vp.view_index(i, args.views))
-        vp.allreduce_grads(prescaled=prescaled)
-        opt.step()
+        def part_b(v):
+            fstep.backward_skinning(v % frames)
 
-    from sk_gs_amd.train_step import GraphedSteps
-    if not use_dist:  # whole step (fwd + bwd + Adam) is one graph per view
-        g_step = GraphedSteps(lambda v: (fwd_bwd(v), opt.step()))
-        g_opt = None
-    else:           # the RCCL all-reduce stays between two graphs
-        g_step = GraphedSteps(fwd_bwd)
-        g_opt = GraphedSteps(lambda _: opt.step())
+        def part_c2(_):
+            fstep.scatter_spw_grad()
+            optB.step()
 
-    def graph_step(i):
-        g_step(vp.view_index(i, args.views))
-        if g_opt is not None:
-            vp.allreduce_grads(prescaled=prescaled)
-            g_opt(0)
+        gA, gB = GraphedSteps(part_a), GraphedSteps(part_b)
+        gC1, gC2 = GraphedSteps(lambda _: optA.step()), GraphedSteps(part_c2)
+
+        def run_step(i, fa, fb, fc1, fc2):
+            v = vp.view_index(i, args.views)
+            fa(v)
+            w0 = vp.allreduce(0)
+            fb(v)
+            w1 = vp.allreduce(1)
+            w0.wait()
+            fc1(0)
+            w1.wait()
+            fc2(0)
+
+        def eager_step(i):
+            run_step(i, part_a, part_b, lambda _: optA.step(), part_c2)
+
+        def graph_step(i):
+            run_step(i, gA, gB, gC1, gC2)
+
+        def capture_all():
+            for v in range(args.views):
+                gA.capture(v)
+                gB.capture(v)
+            gC1.capture(0)
+            gC2.capture(0)
+    else:
+        if args.torch_adam:
+            opt = torch.optim.Adam(groups, eps=1e-15, betas=(0.9, 0.999), fused=True, capturable=not args.eager)
+        else:
+            from sk_gs_amd.optim import FusedAdam
+            opt = FusedAdam(groups, eps=1e-15, betas=(0.9, 0.999))
+        if args.autograd:
+            def fwd_bwd(v):
+                vp.grads.zero_()
+                out = model.render(settings[v], time_id=v % frames, background=background)
+                loss = image_loss(out['images'], targets[v])
+                loss.backward()
+                overflow.add_(out['buffer'].geomBuffer[4:8].view(torch.int32))
+        else:
+            def fwd_bwd(v):  # every gradient is overwritten in place: no zero fill of the flat buffer
+                fstep.forward_backward(settings[v], v % frames, targets[v])
+        prescaled = not args.autograd  # FusedViewStep seeds the backward with 1/world
+
+        def reduce_grads():
+            if compact:
+                vp.allreduce(0, async_op=False)
+            else:
+                vp.allreduce_grads(prescaled=prescaled)
+
+        def update(_=0):
+            if compact:
+                fstep.scatter_spw_grad()
+            opt.step()
+
+        def eager_step(i):
+            fwd_bwd(vp.view_index(i, args.views))
+            reduce_grads()
+            update()
+
+        if not use_dist:  # whole step (fwd + bwd + Adam) is one graph per view
+            g_step = GraphedSteps(lambda v: (fwd_bwd(v), opt.step()))
+            g_opt = None
+        else:           # the RCCL all-reduce stays between two graphs
+            g_step = GraphedSteps(fwd_bwd)
+            g_opt = GraphedSteps(update)
+
+        def graph_step(i):
+            g_step(vp.view_index(i, args.views))
+            if g_opt is not None:
+                reduce_grads()
+                g_opt(0)
+
+        def capture_all():
+            for v in range(args.views):
+                g_step.capture(v)
+            if g_opt is not None:
+                g_opt.capture(0)
 
     train_step = eager_step if args.eager else graph_step
 
     eager_step(0)  # initialises optimizer state before any capture
     if not args.eager:  # every graph exists before the timed region, whatever --warmup is
-        for v in range(args.views):
-            g_step.capture(v)
-        if g_opt is not None:
-            g_opt.capture(0)
+        capture_all()
     for i in range(args.warmup):
         train_step(i)
     torch.cuda.synchronize()
@@ -322,8 +402,11 @@ def main():
             'config': {'workload': f'{cfg["name"]}: {P} Gaussians, {M} bones, K={K}, SH degree 3, {W}x{H}, '
                                    f'{args.views} synthetic views, colmap=True, 1 view per rank per step',
                        'num_rendered_mean': round(R_mean), 'num_rendered_max': R_max,
-                       'parallelism': f'view-parallel x{world}, flat-buffer grad all-reduce '
-                                      f'({vp.grads.nbytes / 1e6:.1f} MB)',
+                       'parallelism': f'view-parallel x{world}, ' + (
+                           f'2-bucket grad all-reduce ({comm_bytes / 1e6:.1f} MB, SH bucket overlapped with the skinning '
+                           f'backward, second bucket with Adam)' if pipelined else
+                           f'flat-buffer grad all-reduce ({comm_bytes / 1e6:.1f} MB'
+                           + (', compact LBS-logit gradient' if compact else '') + ')'),
                        'launch': 'eager' if args.eager else 'one hipGraph replay per view step',
                        'step': 'autograd operator path' if args.autograd else 'FusedViewStep (direct C-ABI calls)'},
             'roofline': {'bound': 'hbm', 'kernel': 'render_backward', 'achieved': round(achieved, 2),

@@ -191,6 +191,12 @@ int skgs_knn_bones(int32_t P, int32_t M, int32_t K, int32_t dim, const float* po
  * bones outside the K nearest), i.e. what autograd's gather backward accumulates into a zero tensor. */
 int skgs_lbs_weights_forward(int32_t P, int32_t M, int32_t K, const float* sp_W, const int64_t* indices, float* weights,
     skgs_stream_t stream);
+/* skgs_lbs_weights_backward in two halves (view-parallel training all-reduces the compact half: the KNN indices are the
+ * same on every rank): g_logits [P,K] = w * (g_w - sum_j w_j g_w_j), then its expansion into the dense g_sp_W [P,M]. */
+int skgs_lbs_weights_backward_compact(int32_t P, int32_t K, const float* weights, const float* g_weights, float* g_logits,
+    skgs_stream_t stream);
+int skgs_lbs_logits_scatter(int32_t P, int32_t M, int32_t K, const int64_t* indices, const float* g_logits, float* g_sp_W,
+    skgs_stream_t stream);
 /* skgs_knn_bones (dim = 3) + skgs_lbs_weights_forward in one launch: out_idx [P,K] int64, out_weights [P,K]. */
 int skgs_knn_lbs_weights(int32_t P, int32_t M, int32_t K, const float* points, const float* joints, const float* sp_W,
     int64_t* out_idx, float* out_weights, skgs_stream_t stream);

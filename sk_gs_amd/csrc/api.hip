@@ -283,6 +283,20 @@ int skgs_knn_bones(int32_t P, int32_t M, int32_t K, int32_t dim, const float* po
   return launch_knn_bones(P, M, K, dim, points, joints, out_dist, out_idx, (hipStream_t) stream);
 }
 
+int skgs_lbs_weights_backward_compact(int32_t P, int32_t K, const float* weights, const float* g_weights, float* g_logits,
+    skgs_stream_t stream) {
+  SKGS_REQUIRE(P == 0 || (weights && g_weights && g_logits), "lbs_weights_backward_compact: NULL argument");
+  SKGS_REQUIRE(K >= 1, "lbs_weights_backward_compact: K must be >= 1");
+  return launch_lbs_weights_backward_compact(P, K, weights, g_weights, g_logits, (hipStream_t) stream);
+}
+
+int skgs_lbs_logits_scatter(int32_t P, int32_t M, int32_t K, const int64_t* indices, const float* g_logits, float* g_sp_W,
+    skgs_stream_t stream) {
+  SKGS_REQUIRE(P == 0 || (indices && g_logits && g_sp_W), "lbs_logits_scatter: NULL argument");
+  SKGS_REQUIRE(M >= 1 && K >= 1, "lbs_logits_scatter: M and K must be >= 1");
+  return launch_lbs_logits_scatter(P, M, K, indices, g_logits, g_sp_W, (hipStream_t) stream);
+}
+
 int skgs_knn_lbs_weights(int32_t P, int32_t M, int32_t K, const float* points, const float* joints, const float* sp_W,
     int64_t* out_idx, float* out_weights, skgs_stream_t stream) {
   SKGS_REQUIRE(P == 0 || (points && joints && sp_W && out_idx && out_weights), "knn_lbs_weights: NULL argument");

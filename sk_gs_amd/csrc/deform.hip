@@ -503,6 +503,30 @@ __global__ void __launch_bounds__(256) lbs_weights_backward_kernel(int P, int M,
   for (size_t i = threadIdx.x; i < n; i += 256) dst[i] = s_rows[i];
 }
 
+// The same backward in two halves, for view-parallel training: g_logits [P,K] (compact: what the ranks all-reduce,
+// K/M of the dense size -- the KNN indices are identical on every rank) and its expansion into the dense [P,M] rows.
+__global__ void __launch_bounds__(256) lbs_weights_backward_compact_kernel(int P, int K, const float* __restrict__ weights,
+    const float* __restrict__ g_weights, float* __restrict__ g_logits) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  float dot = 0.f;
+  for (int k = 0; k < K; ++k) dot += weights[(size_t) p * K + k] * g_weights[(size_t) p * K + k];
+  for (int k = 0; k < K; ++k) g_logits[(size_t) p * K + k] = weights[(size_t) p * K + k] * (g_weights[(size_t) p * K + k] - dot);
+}
+__global__ void __launch_bounds__(256) lbs_logits_scatter_kernel(int P, int M, int K, const int64_t* __restrict__ indices,
+    const float* __restrict__ g_logits, float* __restrict__ g_sp_W) {
+  extern __shared__ float s_rows[];  // [256][M]
+  const int p0 = blockIdx.x * 256, p = p0 + threadIdx.x;
+  float* row = s_rows + (size_t) threadIdx.x * M;
+  for (int m = 0; m < M; ++m) row[m] = 0.f;
+  if (p < P)
+    for (int k = 0; k < K; ++k) row[(int) indices[(size_t) p * K + k]] += g_logits[(size_t) p * K + k];
+  __syncthreads();
+  const size_t n = (size_t) min(256, P - p0) * M;
+  float* dst     = g_sp_W + (size_t) p0 * M;
+  for (size_t i = threadIdx.x; i < n; i += 256) dst[i] = s_rows[i];
+}
+
 // K nearest bones + LBS weights in one pass (the two calls of calc_LBS_weight, sk_gs.py:757,769-770): top-K as
 // knn_bones_kernel (dim = 3), then softmax of the gathered logits; indices and weights leave through LDS so that a
 // workgroup stores contiguous spans instead of K strided 8-byte pieces per lane.
@@ -697,6 +721,25 @@ int launch_knn_lbs_weights(int P, int M, int K, const float* points, const float
   else
     SKGS_KNNW(KNN_MAXK);
 #undef SKGS_KNNW
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_lbs_weights_backward_compact(int P, int K, const float* weights, const float* g_weights, float* g_logits,
+    hipStream_t s) {
+  if (P == 0) return 0;
+  hipLaunchKernelGGL(lbs_weights_backward_compact_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, K, weights, g_weights,
+      g_logits);
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_lbs_logits_scatter(int P, int M, int K, const int64_t* indices, const float* g_logits, float* g_sp_W,
+    hipStream_t s) {
+  if (P == 0 || M == 0) return 0;
+  if ((size_t) M * 256 * 4 > 60 * 1024) return set_error("lbs_logits_scatter: M = %d too large (<= 60)", M);
+  hipLaunchKernelGGL(lbs_logits_scatter_kernel, dim3((P + 255) / 256), dim3(256), (size_t) M * 256 * 4, s, P, M, K, indices,
+      g_logits, g_sp_W);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -46,7 +46,8 @@ class FusedViewStep:
     """
 
     def __init__(self, model: SkinnedGaussians, W: int, H: int, capacity: int, lambda_dssim: float = 0.2,
-                 background: Optional[Tensor] = None, grad_scale: float = 1.0, densify_stats: bool = False):
+                 background: Optional[Tensor] = None, grad_scale: float = 1.0, densify_stats: bool = False,
+                 spw_logit_grad: Optional[Tensor] = None):
         assert not model.static, 'FusedViewStep covers the skinned stage (M >= 1)'
         self.model, self.W, self.H = model, int(W), int(H)
         self.lambda_l1, self.lambda_ssim = 1.0 - lambda_dssim, lambda_dssim
@@ -89,6 +90,9 @@ class FusedViewStep:
         self.g_bone_T = torch.empty((M, 7), **f32)
         self.deform_ws = torch.empty((lib.skgs_lbs_deform_backward_workspace_bytes(C.c_int32(P), C.c_int32(M)),), **u8)
         self.bwd_ws = torch.zeros((lib.skgs_backward_workspace_bytes(C.c_int32(P)),), **u8)  # kept zero between steps
+        # view-parallel training: [P*K] float32 view that receives the compact LBS-logit gradient (see backward_skinning)
+        self.spw_logit_grad = spw_logit_grad
+        assert spw_logit_grad is None or (spw_logit_grad.numel() == P * K and spw_logit_grad.is_contiguous())
         # densification statistics (gaussian_splatting.py:503-513, sk_gs.py:1990-1997), updated by every step if asked
         self.densify_stats = bool(densify_stats)
         self.xyz_gradient_accum, self.denom = torch.zeros((P, 1), **f32), torch.zeros((P, 1), **f32)
@@ -167,8 +171,14 @@ class FusedViewStep:
 
     @torch.no_grad()
     def forward_backward(self, rs: GaussianRasterizationSettings, time_id: int, target: Tensor):
+        self.backward_raster(rs, time_id, target)
+        self.backward_skinning(time_id)
+
+    @torch.no_grad()
+    def backward_raster(self, rs: GaussianRasterizationSettings, time_id: int, target: Tensor):
+        """first half of the step: forward, loss, rasterizer backward.  On return the SH gradients
+        (``_features_dc.grad``, ``_features_rest.grad``) are final; the skinning backward has not run yet."""
         lib, m, st, chk = self.lib, self.model, _C._stream(), _C._check
-        t = self._topo
         P, M, K, W, H = self.P, self.M, self.K, self.W, self.H
         assert target.is_cuda and target.dtype == torch.float32 and target.is_contiguous()
         self._zero_table_grads()
@@ -192,20 +202,40 @@ class FusedViewStep:
         g.workspace_is_zero = 1
         chk(lib.skgs_rasterize_backward(C.byref(a), C.byref(self._bufs), _p(self.radii), _p(self.out_opacity),
                                         C.byref(g), st))
-        # ---- skinning backward: Gaussian parameters' gradients written in place
+
+    @torch.no_grad()
+    def backward_skinning(self, time_id: int):
+        """second half: skinning backward (Gaussian parameters' gradients written in place), LBS logits, bone chain.
+        With ``spw_logit_grad`` set, the logit gradient is left compact ([P,K], for the all-reduce) and
+        ``scatter_spw_grad`` expands it into ``sp_W.grad`` later."""
+        lib, m, st, chk = self.lib, self.model, _C._stream(), _C._check
+        t = self._topo
+        P, M, K = self.P, self.M, self.K
+        d = self._deform_inputs(time_id)
         chk(lib.skgs_lbs_deform_backward(
             C.byref(d), _p(self.g_means), _p(self.g_scales), _p(self.g_rotations), _p(self.g_opacity),
             _p(self.g_weights), _p(self.g_bone_T), _p(m.sk_d_rot.grad[time_id]), _p(m.sk_d_scale.grad[time_id]),
             _p(m._xyz.grad), _p(m._scaling.grad), _p(m._rotation.grad), _p(m._opacity.grad), _p(self.deform_ws),
             C.c_size_t(self.deform_ws.numel()), st))
-        chk(lib.skgs_lbs_weights_backward(C.c_int32(P), C.c_int32(M), C.c_int32(K), _p(self.weights), _p(self.indices),
-                                          _p(self.g_weights), _p(m.sp_W.grad), st))
+        if self.spw_logit_grad is None:
+            chk(lib.skgs_lbs_weights_backward(C.c_int32(P), C.c_int32(M), C.c_int32(K), _p(self.weights),
+                                              _p(self.indices), _p(self.g_weights), _p(m.sp_W.grad), st))
+        else:
+            chk(lib.skgs_lbs_weights_backward_compact(C.c_int32(P), C.c_int32(K), _p(self.weights), _p(self.g_weights),
+                                                      _p(self.spw_logit_grad), st))
         chk(lib.skgs_bone_chain_backward(
             C.c_int32(M), C.c_int32(t['root']), _p(t['parents']), _p(t['level_nodes']), _p(t['level_start']),
             C.c_int32(t['num_levels']), _p(m.sk_r[time_id]), _p(m.joints), _p(m.global_tr[time_id]), _p(self.chain_A),
             _p(self.g_bone_T), _p(m.sk_r.grad[time_id]), None, _p(m.global_tr.grad[time_id]), st))
         if self.densify_stats:
             self.add_densification_stats()
+
+    @torch.no_grad()
+    def scatter_spw_grad(self):
+        """expand the (all-reduced) compact logit gradient into the dense ``sp_W.grad``"""
+        _C._check(self.lib.skgs_lbs_logits_scatter(C.c_int32(self.P), C.c_int32(self.M), C.c_int32(self.K),
+                                                   _p(self.indices), _p(self.spw_logit_grad), _p(self.model.sp_W.grad),
+                                                   _C._stream()))
 
     @torch.no_grad()
     def add_densification_stats(self):

@@ -105,3 +105,49 @@ class ViewParallel:
             return
         for p in params:
             dist.broadcast(p.data, src=src)
+
+
+class BucketedGradReducer:
+    """Gradients in ONE flat fp32 buffer cut into contiguous *buckets* that are all-reduced separately.
+
+    View-parallel schedule (bench.py, world > 1): the backward produces its gradients in two waves -- the SH
+    coefficients (60 % of the bytes) are final once the rasterizer backward has run, everything else once the skinning
+    backward has run.  Bucket 0 is handed to RCCL while the skinning backward still executes, bucket 1 afterwards, and
+    the Adam update of bucket 0 runs while bucket 1 is on the wire.  ``extras[i]`` appends plain float32 scratch to
+    bucket i (used for the compact LBS-logit gradient, which replaces the 4x larger dense ``sp_W`` gradient on the wire).
+
+    ``buckets``: list of lists of parameters; every parameter gets ``.grad`` = a view into the flat buffer."""
+
+    def __init__(self, buckets: List[List[Tensor]], extras: Optional[List[int]] = None):
+        self.active = dist.is_initialized()
+        self.world = dist.get_world_size() if self.active else 1
+        self.rank = dist.get_rank() if self.active else 0
+        extras = list(extras) if extras is not None else [0] * len(buckets)
+        assert len(extras) == len(buckets)
+        sizes = [sum(p.numel() for p in b) + e for b, e in zip(buckets, extras)]
+        dev = buckets[0][0].device
+        self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        self.bucket_views: List[Tensor] = []
+        self.extra_views: List[Optional[Tensor]] = []
+        off = 0
+        for b, e, n in zip(buckets, extras, sizes):
+            self.bucket_views.append(self.flat[off:off + n])
+            o = off
+            for p in b:
+                p.grad = self.flat[o:o + p.numel()].view_as(p)
+                o += p.numel()
+            self.extra_views.append(self.flat[o:o + e] if e else None)
+            off += n
+
+    def view_index(self, step: int, num_views: int) -> int:
+        return (step * self.world + self.rank) % num_views
+
+    def allreduce(self, i: int, async_op: bool = True):
+        """SUM all-reduce of bucket i (gradients are expected pre-scaled by 1/world at their source)"""
+        if not self.active:
+            return None
+        return dist.all_reduce(self.bucket_views[i], op=dist.ReduceOp.SUM, async_op=async_op)
+
+    @property
+    def nbytes(self) -> int:
+        return self.flat.numel() * 4

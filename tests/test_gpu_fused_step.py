@@ -92,3 +92,37 @@ def test_fused_step_is_graph_capturable_and_trains():
     torch.cuda.synchronize()
     assert step.status()['overflow'] == 0
     assert float(step.loss3[0]) < 0.9 * first
+
+
+def test_split_step_with_compact_logit_gradient_matches_the_single_call():
+    """view-parallel schedule: rasterizer half, skinning half with the compact [P,K] logit gradient, then its
+    expansion -- same gradients as forward_backward() with the dense sp_W gradient"""
+    from sk_gs_amd import _C
+    from sk_gs_amd.fused_step import FusedViewStep
+    from sk_gs_amd.view_parallel import BucketedGradReducer
+    P, M, K, W, H, frames, tid = 4000, 12, 4, 160, 120, 3, 1
+    model, rs, target = _setup(P, M, K, W, H, frames)
+    with torch.no_grad():
+        _C.config.sync_num_rendered = True
+        R = model.render(rs, time_id=tid)['buffer'].R
+    ref_step = FusedViewStep(model, W, H, capacity=int(R * 1.2) + 1024)
+    ref_step.forward_backward(rs, tid, target)
+    ref = {n: p.grad.clone() for n, p in model.named_parameters()}
+    for p in model.parameters():
+        p.grad = None
+    b0 = [model._features_dc, model._features_rest]
+    b1 = [model._xyz, model._scaling, model._rotation, model._opacity, model.sk_r, model.sk_d_rot, model.sk_d_scale,
+          model.global_tr]
+    red = BucketedGradReducer([b0, b1], extras=[0, P * K])
+    red.flat.fill_(7.0)
+    assert red.nbytes == 4 * (sum(p.numel() for p in b0 + b1) + P * K) and model.sp_W.grad is None
+    step = FusedViewStep(model, W, H, capacity=int(R * 1.2) + 1024, spw_logit_grad=red.extra_views[1])
+    model.sp_W.grad.fill_(7.0)
+    step.backward_raster(rs, tid, target)
+    for n in ('_features_dc', '_features_rest'):  # final after the first half
+        assert_close_robust(getattr(model, n).grad, ref[n], 1e-4, 1e-4, name=n)
+    step.backward_skinning(tid)
+    step.scatter_spw_grad()
+    for n, p in model.named_parameters():
+        assert_close_robust(p.grad, ref[n], 1e-4, 1e-4, name=n)
+    assert red.allreduce(0) is None  # no process group: nothing to do

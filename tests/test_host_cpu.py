@@ -113,6 +113,18 @@ acc, den, rad = torch.full((5, 1), float(rank + 1)), torch.ones(5, 1), torch.ten
 vp.allreduce_densify_stats(acc, den, rad)
 assert torch.allclose(acc, torch.full((5, 1), 3.0)) and torch.allclose(den, torch.full((5, 1), 2.0))
 assert torch.allclose(rad, torch.tensor([2., 10., 4., 0., 6.]))
+# two-bucket reducer with an extra scratch span (the compact LBS-logit gradient of the view-parallel schedule)
+from sk_gs_amd.view_parallel import BucketedGradReducer
+q1, q2, q3 = (torch.nn.Parameter(torch.ones(n)) for n in (5, 3, 4))
+red = BucketedGradReducer([[q1], [q2, q3]], extras=[0, 6])
+assert red.flat.numel() == 5 + 3 + 4 + 6 and red.extra_views[0] is None and red.extra_views[1].numel() == 6
+assert q1.grad.data_ptr() == red.flat.data_ptr() and red.bucket_views[1].numel() == 13
+q1.grad.fill_(rank + 1.0), q2.grad.fill_(10.0 * (rank + 1)), q3.grad.fill_(-1.0), red.extra_views[1].fill_(rank)
+w0 = red.allreduce(0)
+w1 = red.allreduce(1)
+w0.wait(), w1.wait()
+assert torch.allclose(q1.grad, torch.full((5,), 3.0)) and torch.allclose(q2.grad, torch.full((3,), 30.0))
+assert torch.allclose(q3.grad, torch.full((4,), -2.0)) and torch.allclose(red.extra_views[1], torch.full((6,), 1.0))
 w = torch.nn.Parameter(torch.full((3,), float(rank)))
 vp.broadcast_params([w], src=1)
 assert torch.allclose(w.data, torch.ones(3))
