@@ -278,12 +278,10 @@ __global__ void __launch_bounds__(256) topk_kernel(int topk, int W, int H, int g
   }
 }
 
-// pixels-per-lane heuristic: keep >= ~4 waves per SIMD in flight (1024 SIMDs on MI355X)
-inline int choose_ppl(int T) {
-  if (T >= 8192) return 4;
-  if (T >= 3072) return 2;
-  return 1;
-}
+// pixels per lane: 1 everywhere.  Measured (tools/ppl_sweep.py, fwd / bwd us): 500k Gaussians @1024^2: 171/461 (1),
+// 278/564 (2), 380/702 (4); 200k @512^2: 76/186, 128/305, 253/586; 300k @1600x1200: 167/499, 242/544, 286/603.
+// The 2- and 4-pixel variants stay for skgs_set_pixels_per_lane() experiments and as test cases.
+inline int choose_ppl(int /*T*/) { return 1; }
 int g_ppl_override = 0;
 int g_strict        = 0;
 
