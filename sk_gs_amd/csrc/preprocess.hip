@@ -234,8 +234,62 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const float* mean, const floa
   *clamp_bits = bits;
 }
 
+// SH rows of a workgroup, staged through LDS.  A lane needs its own row of RL floats (45 for the split "rest" storage,
+// 48 for one [16][3] row): read directly, every load instruction of a wave touches 64 different rows and the L1 cannot
+// hold the workgroup's span, so each 64-B line is fetched from L2 many times.  Here the waves copy whole rows with
+// consecutive lanes on consecutive floats (the span of a workgroup is contiguous in memory); rows get an odd pitch so
+// that the per-lane reads afterwards are bank-conflict free.
+constexpr int PRE_THREADS = 128;
+__device__ __forceinline__ int sh_pitch(int RL) { return RL | 1; }
+// Both copies keep all of a thread's global accesses in flight at once (up to STAGE_V float4 per thread): a loop of
+// load -> LDS store per row serialised on the load latency and was slower than no staging at all.
+constexpr int STAGE_V = 12;  // PRE_THREADS rows x 48 floats / 4 / PRE_THREADS
+__device__ __forceinline__ int stage_lds_index(int e, int RL, int pitch) {  // float index e of the span -> LDS index
+  if (pitch == RL) return e;
+  const int r = e / RL;
+  return r * pitch + (e - r * RL);
+}
+__device__ __forceinline__ void stage_rows_in(float* s_dst, const float* __restrict__ src, int nrows, int RL) {
+  const int pitch = sh_pitch(RL), n = nrows * RL;
+  const bool vec  = (RL % 4 == 0 || pitch == RL) && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+  const int n4    = vec ? n >> 2 : 0;
+  float4 v[STAGE_V];
+#pragma unroll
+  for (int k = 0; k < STAGE_V; ++k) {
+    const int i = threadIdx.x + k * PRE_THREADS;
+    if (i < n4) v[k] = reinterpret_cast<const float4*>(src)[i];
+  }
+#pragma unroll
+  for (int k = 0; k < STAGE_V; ++k) {
+    const int i = threadIdx.x + k * PRE_THREADS;
+    if (i < n4) {
+      if (pitch == RL) {
+        s_dst[4 * i] = v[k].x, s_dst[4 * i + 1] = v[k].y, s_dst[4 * i + 2] = v[k].z, s_dst[4 * i + 3] = v[k].w;
+      } else {  // RL % 4 == 0: the four floats stay in one row
+        const int o = stage_lds_index(4 * i, RL, pitch);
+        s_dst[o] = v[k].x, s_dst[o + 1] = v[k].y, s_dst[o + 2] = v[k].z, s_dst[o + 3] = v[k].w;
+      }
+    }
+  }
+  for (int e = 4 * n4 + threadIdx.x; e < n; e += PRE_THREADS) s_dst[stage_lds_index(e, RL, pitch)] = src[e];
+}
+__device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, const float* s_src, int nrows, int RL) {
+  const int pitch = sh_pitch(RL), n = nrows * RL;
+  const bool vec  = (RL % 4 == 0 || pitch == RL) && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+  const int n4    = vec ? n >> 2 : 0;
+#pragma unroll
+  for (int k = 0; k < STAGE_V; ++k) {
+    const int i = threadIdx.x + k * PRE_THREADS;
+    if (i < n4) {
+      const int o = pitch == RL ? 4 * i : stage_lds_index(4 * i, RL, pitch);
+      reinterpret_cast<float4*>(dst)[i] = make_float4(s_src[o], s_src[o + 1], s_src[o + 2], s_src[o + 3]);
+    }
+  }
+  for (int e = 4 * n4 + threadIdx.x; e < n; e += PRE_THREADS) dst[e] = s_src[stage_lds_index(e, RL, pitch)];
+}
+
 template <bool COLMAP>
-__global__ void __launch_bounds__(256) preprocess_forward_kernel(int P, int D, int M, const float* __restrict__ means3D,
+__global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, int D, int M, const float* __restrict__ means3D,
     const float* __restrict__ scales, float scale_modifier, const float* __restrict__ rotations,
     const float* __restrict__ opacities, const float* __restrict__ shs, const float* __restrict__ shs_rest,
     const float* __restrict__ cov3D_precomp,
@@ -252,6 +306,24 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(int P, int D, i
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   // the per-tile counters of the next kernel (binning.hip: count_tiles) start from zero: cleared here, not by a fill launch
   for (int t = idx; t < gx * gy; t += gridDim.x * blockDim.x) tile_counts[t] = 0u;
+  // this workgroup's SH rows -> LDS (coefficient 0 through my_dc, coefficients >= 1 through my_sh, see sh_to_rgb)
+  extern __shared__ float s_sh[];
+  const float *my_dc = nullptr, *my_sh = nullptr;
+  if (shs != nullptr && colors_precomp == nullptr) {
+    const int base = blockIdx.x * blockDim.x, nrows = min((int) blockDim.x, P - base);
+    if (shs_rest) {
+      const int RL = (M - 1) * 3;
+      float* s_dc  = s_sh + blockDim.x * sh_pitch(RL);
+      stage_rows_in(s_sh, shs_rest + (size_t) base * RL, nrows, RL);
+      for (int i = threadIdx.x; i < nrows * 3; i += blockDim.x) s_dc[i] = shs[(size_t) base * 3 + i];
+      my_dc = s_dc + threadIdx.x * 3, my_sh = s_sh + threadIdx.x * sh_pitch(RL) - 3;
+    } else {
+      const int RL = M * 3;
+      stage_rows_in(s_sh, shs + (size_t) base * RL, nrows, RL);
+      my_dc = my_sh = s_sh + threadIdx.x * sh_pitch(RL);
+    }
+    __syncthreads();
+  }
   if (idx >= P) return;
 
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;  // culled Gaussians get an all-zero record
@@ -311,10 +383,7 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(int P, int D, i
       if (area != 0) {
         float rgb[3];
         if (colors_precomp == nullptr) {
-          if (shs_rest)
-            sh_to_rgb(D, p, cam.campos, shs + (size_t) idx * 3, shs_rest + (size_t) idx * (M - 1) * 3 - 3, rgb, &clamp_bits);
-          else
-            sh_to_rgb(D, p, cam.campos, shs + (size_t) idx * M * 3, shs + (size_t) idx * M * 3, rgb, &clamp_bits);
+          sh_to_rgb(D, p, cam.campos, my_dc, my_sh, rgb, &clamp_bits);
         } else {
           rgb[0] = colors_precomp[3 * idx], rgb[1] = colors_precomp[3 * idx + 1], rgb[2] = colors_precomp[3 * idx + 2];
         }
@@ -349,26 +418,21 @@ __device__ __forceinline__ void dnormvdv3(const float* v, const float* dv, float
 
 // SH backward: writes dL_dsh[M][3] for this Gaussian and returns dL_dmean contribution.  `sh` and (dL_ddc, dL_dsh)
 // follow the convention of sh_to_rgb (coefficient 0 through the first pointer; only coefficients >= 1 of sh are read).
+// Every read of `sh` happens before the first write to dL_dsh, so the two may be the SAME row (the kernel keeps the
+// coefficients and their gradients in one LDS row per lane).
 __device__ __forceinline__ void sh_backward(int deg, int M, const float* mean, const float* campos, const float* sh,
     uint32_t clamp_bits, const float* dL_dcolor, float* dL_ddc, float* dL_dsh, float* dL_dmean_out) {
   const float dir_orig[3] = {mean[0] - campos[0], mean[1] - campos[1], mean[2] - campos[2]};
   const float len = sqrtf(dir_orig[0] * dir_orig[0] + dir_orig[1] * dir_orig[1] + dir_orig[2] * dir_orig[2]);
   const float x = dir_orig[0] / len, y = dir_orig[1] / len, z = dir_orig[2] / len;
+  const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
   float g[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) g[c] = dL_dcolor[c] * (((clamp_bits >> c) & 1u) ? 0.f : 1.f);
+  // ---- reads: d(colour)/d(direction)
   float dx[3] = {0, 0, 0}, dy[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
 #define SHV(i, c) sh[(i) *3 + (c)]
-#define SETSH(i, coef)                                             \
-  {                                                                \
-    const float _k = (coef);                                       \
-    _Pragma("unroll") for (int c = 0; c < 3; ++c) ((i) == 0 ? dL_ddc : dL_dsh)[(i) *3 + c] = _k * g[c]; \
-  }
-  SETSH(0, SH_C0);
   if (deg > 0) {
-    SETSH(1, -SH_C1 * y);
-    SETSH(2, SH_C1 * z);
-    SETSH(3, -SH_C1 * x);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       dx[c] = -SH_C1 * SHV(3, c);
@@ -376,12 +440,6 @@ __device__ __forceinline__ void sh_backward(int deg, int M, const float* mean, c
       dz[c] = SH_C1 * SHV(2, c);
     }
     if (deg > 1) {
-      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-      SETSH(4, SH_C2[0] * xy);
-      SETSH(5, SH_C2[1] * yz);
-      SETSH(6, SH_C2[2] * (2.f * zz - xx - yy));
-      SETSH(7, SH_C2[3] * xz);
-      SETSH(8, SH_C2[4] * (xx - yy));
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         dx[c] += SH_C2[0] * y * SHV(4, c) + SH_C2[2] * 2.f * -x * SHV(6, c) + SH_C2[3] * z * SHV(7, c) + SH_C2[4] * 2.f * x * SHV(8, c);
@@ -389,13 +447,6 @@ __device__ __forceinline__ void sh_backward(int deg, int M, const float* mean, c
         dz[c] += SH_C2[1] * y * SHV(5, c) + SH_C2[2] * 2.f * 2.f * z * SHV(6, c) + SH_C2[3] * x * SHV(7, c);
       }
       if (deg > 2) {
-        SETSH(9, SH_C3[0] * y * (3.f * xx - yy));
-        SETSH(10, SH_C3[1] * xy * z);
-        SETSH(11, SH_C3[2] * y * (4.f * zz - xx - yy));
-        SETSH(12, SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
-        SETSH(13, SH_C3[4] * x * (4.f * zz - xx - yy));
-        SETSH(14, SH_C3[5] * z * (xx - yy));
-        SETSH(15, SH_C3[6] * x * (xx - 3.f * yy));
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           dx[c] += (SH_C3[0] * SHV(9, c) * 3.f * 2.f * xy + SH_C3[1] * SHV(10, c) * yz + SH_C3[2] * SHV(11, c) * -2.f * xy +
@@ -412,17 +463,45 @@ __device__ __forceinline__ void sh_backward(int deg, int M, const float* mean, c
     }
   }
 #undef SHV
-#undef SETSH
   const float dL_ddir[3] = {dx[0] * g[0] + dx[1] * g[1] + dx[2] * g[2], dy[0] * g[0] + dy[1] * g[1] + dy[2] * g[2],
       dz[0] * g[0] + dz[1] * g[1] + dz[2] * g[2]};
   dnormvdv3(dir_orig, dL_ddir, dL_dmean_out);
+  // ---- writes: d(colour)/d(coefficient i) = basis_i(direction)
+#define SETSH(i, coef)                                             \
+  {                                                                \
+    const float _k = (coef);                                       \
+    _Pragma("unroll") for (int c = 0; c < 3; ++c) ((i) == 0 ? dL_ddc : dL_dsh)[(i) *3 + c] = _k * g[c]; \
+  }
+  SETSH(0, SH_C0);
+  if (deg > 0) {
+    SETSH(1, -SH_C1 * y);
+    SETSH(2, SH_C1 * z);
+    SETSH(3, -SH_C1 * x);
+    if (deg > 1) {
+      SETSH(4, SH_C2[0] * xy);
+      SETSH(5, SH_C2[1] * yz);
+      SETSH(6, SH_C2[2] * (2.f * zz - xx - yy));
+      SETSH(7, SH_C2[3] * xz);
+      SETSH(8, SH_C2[4] * (xx - yy));
+      if (deg > 2) {
+        SETSH(9, SH_C3[0] * y * (3.f * xx - yy));
+        SETSH(10, SH_C3[1] * xy * z);
+        SETSH(11, SH_C3[2] * y * (4.f * zz - xx - yy));
+        SETSH(12, SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+        SETSH(13, SH_C3[4] * x * (4.f * zz - xx - yy));
+        SETSH(14, SH_C3[5] * z * (xx - yy));
+        SETSH(15, SH_C3[6] * x * (xx - 3.f * yy));
+      }
+    }
+  }
+#undef SETSH
   // coefficients above the active degree stay zero
   const int used = (deg + 1) * (deg + 1);
   for (int i = used; i < M; ++i) dL_dsh[i * 3] = 0.f, dL_dsh[i * 3 + 1] = 0.f, dL_dsh[i * 3 + 2] = 0.f;
 }
 
 template <bool COLMAP>
-__global__ void __launch_bounds__(256) preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3D,
+__global__ void __launch_bounds__(PRE_THREADS) preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3D,
     const int32_t* __restrict__ radii, const float* __restrict__ shs, const float* __restrict__ shs_rest,
     const float* __restrict__ scales,
     const float* __restrict__ rotations, float scale_modifier, const float* __restrict__ cov3D_precomp,
@@ -440,9 +519,16 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(int P, int D, 
     cam.proj[threadIdx.x] = projmatrix[threadIdx.x];
   }
   if (threadIdx.x < 3) cam.campos[threadIdx.x] = campos[threadIdx.x];
-  __syncthreads();
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= P) return;
+  // SH rows of this workgroup -> LDS; the gradient rows are built in the same LDS rows (sh_backward reads before it
+  // writes) and leave as one contiguous span at the end.  The DC term is not read by the backward.
+  extern __shared__ float s_sh[];
+  const bool staged = shs != nullptr && dL_dsh != nullptr;
+  const int RL      = shs_rest ? (M - 1) * 3 : M * 3;
+  const int base = blockIdx.x * blockDim.x, nrows = min((int) blockDim.x, P - base);
+  if (staged) stage_rows_in(s_sh, (shs_rest ? shs_rest : shs) + (size_t) base * RL, nrows, RL);
+  __syncthreads();
+  if (idx < P) {
 
   // gradients accumulated by the blend backward (+ the optional chained-in ones)
   float gm2[2] = {0.f, 0.f}, gcon[3] = {0.f, 0.f, 0.f}, gop = 0.f, gcol[3] = {0.f, 0.f, 0.f}, gex[4] = {0, 0, 0, 0};
@@ -484,8 +570,9 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(int P, int D, 
 
   float gmean[3] = {0.f, 0.f, 0.f}, gcov[6] = {0, 0, 0, 0, 0, 0}, gscale[3] = {0, 0, 0}, grot[4] = {0, 0, 0, 0};
   // gradient rows of the SH coefficients: one [M][3] row, or split DC [1][3] / rest [M-1][3] rows (rest biased by -3)
-  float* gsh_dc  = dL_dsh ? dL_dsh + (size_t) idx * (dL_dsh_rest ? 1 : M) * 3 : nullptr;
-  float* gsh_row = dL_dsh_rest ? dL_dsh_rest + (size_t) idx * (M - 1) * 3 - 3 : gsh_dc;
+  float* my_row  = s_sh + threadIdx.x * sh_pitch(RL);
+  float* gsh_dc  = !dL_dsh ? nullptr : (dL_dsh_rest ? dL_dsh + (size_t) idx * 3 : my_row);
+  float* gsh_row = dL_dsh_rest ? my_row - 3 : gsh_dc;
   if (!visible) {
     if (gsh_dc) {
       for (int i = 0; i < 3; ++i) gsh_dc[i] = 0.f;
@@ -628,10 +715,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(int P, int D, 
     if (shs) {
       const uint32_t clamp_bits = (__float_as_uint(recs[3 * idx + 2].z) >> 28) & 7u;
       float dm[3];
-      if (shs_rest)
-        sh_backward(D, M, p, cam.campos, shs_rest + (size_t) idx * (M - 1) * 3 - 3, clamp_bits, gcol, gsh_dc, gsh_row, dm);
-      else
-        sh_backward(D, M, p, cam.campos, shs + (size_t) idx * M * 3, clamp_bits, gcol, gsh_dc, gsh_row, dm);
+      sh_backward(D, M, p, cam.campos, gsh_row, clamp_bits, gcol, gsh_dc, gsh_row, dm);  // coefficients and gradients share the row
       gmean[0] += dm[0], gmean[1] += dm[1], gmean[2] += dm[2];
     }
     // ---- Sigma3D -> scale, rotation ----
@@ -697,6 +781,11 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(int P, int D, 
   for (int i = 0; i < 6; ++i) dL_dcov3D[6 * idx + i] = gcov[i];
   dL_dscales[3 * idx] = gscale[0], dL_dscales[3 * idx + 1] = gscale[1], dL_dscales[3 * idx + 2] = gscale[2];
   reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(grot[0], grot[1], grot[2], grot[3]);
+  }  // idx < P
+  if (staged) {
+    __syncthreads();
+    stage_rows_out((dL_dsh_rest ? dL_dsh_rest : dL_dsh) + (size_t) base * RL, s_sh, nrows, RL);
+  }
 }
 
 __global__ void mark_visible_kernel(int P, const float* means, const float* view, int colmap, uint8_t* present) {
@@ -721,19 +810,23 @@ int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView 
   const float focal_x = in.image_width / (2.0f * in.tanfovx);
   if (P == 0) return fill_u32(im.tile_counts, 0u, (size_t) im.T, s);
   ProfScope prof(K_PREPROCESS_FWD, s);
-  dim3 grid((P + 255) / 256), block(256);
+  dim3 grid((P + PRE_THREADS - 1) / PRE_THREADS), block(PRE_THREADS);
+  size_t lds = 0;
+  if (in.sh && !in.colors_precomp) {
+    const int M = in.sh_coeffs;
+    lds = in.sh_rest ? ((size_t) PRE_THREADS * (((M - 1) * 3) | 1) + (size_t) PRE_THREADS * 3) * 4
+                     : (size_t) PRE_THREADS * ((M * 3) | 1) * 4;
+  }
   if (in.colmap)
-    hipLaunchKernelGGL(preprocess_forward_kernel<true>, grid, block, 0, s, P, in.sh_degree, in.sh_coeffs, in.means3D,
+    hipLaunchKernelGGL(preprocess_forward_kernel<true>, grid, block, lds, s, P, in.sh_degree, in.sh_coeffs, in.means3D,
         in.scales, in.scale_modifier, in.rotations, in.opacity, in.sh, in.sh_rest, in.cov3D_precomp, in.colors_precomp,
-        in.viewmatrix,
-        in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y, im.tiles_x,
-        im.tiles_y, radii, g.recs, im.tile_counts);
+        in.viewmatrix, in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y,
+        im.tiles_x, im.tiles_y, radii, g.recs, im.tile_counts);
   else
-    hipLaunchKernelGGL(preprocess_forward_kernel<false>, grid, block, 0, s, P, in.sh_degree, in.sh_coeffs, in.means3D,
+    hipLaunchKernelGGL(preprocess_forward_kernel<false>, grid, block, lds, s, P, in.sh_degree, in.sh_coeffs, in.means3D,
         in.scales, in.scale_modifier, in.rotations, in.opacity, in.sh, in.sh_rest, in.cov3D_precomp, in.colors_precomp,
-        in.viewmatrix,
-        in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y, im.tiles_x,
-        im.tiles_y, radii, g.recs, im.tile_counts);
+        in.viewmatrix, in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y,
+        im.tiles_x, im.tiles_y, radii, g.recs, im.tile_counts);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -745,7 +838,8 @@ int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const i
   const float focal_y = in.image_height / (2.0f * in.tanfovy);
   const float focal_x = in.image_width / (2.0f * in.tanfovx);
   ProfScope prof(K_PREPROCESS_BWD, s);
-  dim3 grid((P + 255) / 256), block(256);
+  dim3 grid((P + PRE_THREADS - 1) / PRE_THREADS), block(PRE_THREADS);
+  const size_t lds = (in.sh && gr.dL_dsh) ? (size_t) PRE_THREADS * (((in.sh_rest ? in.sh_coeffs - 1 : in.sh_coeffs) * 3) | 1) * 4 : 0;
   const int E = (in.extras && gr.dL_dout_extra && gr.dL_dextras) ? in.E : 0;
 #define SKGS_PB_ARGS                                                                                                     \
   P, in.sh_degree, in.sh_coeffs, in.means3D, radii, in.sh, in.sh_rest, in.scales, in.rotations, in.scale_modifier,        \
@@ -755,9 +849,9 @@ int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const i
       gr.dL_dopacity, gr.dL_dmeans3D, gr.dL_dcov3D, gr.dL_dsh, gr.dL_dsh_rest, gr.dL_dscales, gr.dL_drotations,           \
       gr.dL_dextras
   if (in.colmap)
-    hipLaunchKernelGGL(preprocess_backward_kernel<true>, grid, block, 0, s, SKGS_PB_ARGS);
+    hipLaunchKernelGGL(preprocess_backward_kernel<true>, grid, block, lds, s, SKGS_PB_ARGS);
   else
-    hipLaunchKernelGGL(preprocess_backward_kernel<false>, grid, block, 0, s, SKGS_PB_ARGS);
+    hipLaunchKernelGGL(preprocess_backward_kernel<false>, grid, block, lds, s, SKGS_PB_ARGS);
 #undef SKGS_PB_ARGS
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
