@@ -136,6 +136,9 @@ def main():
                          'of launch / stream-join overhead per step on one GPU, so it only pays when the all-reduce is slow)')
     ap.add_argument('--dense-spw-grad', action='store_true',
                     help='world > 1: all-reduce the dense [P,M] sp_W gradient instead of the compact [P,K] logit gradient')
+    ap.add_argument('--deform-net', action='store_true',
+                    help='produce the joint rotations / d_rot / d_scale with the 8x256 deform network inside every step '
+                         '(scope row (f)-3: +24 launches, +0.5M parameters in Adam) instead of the per-frame tables')
     ap.add_argument('--autograd', action='store_true',
                     help='run the step through the torch-autograd operator path (model.render + image_loss + backward) '
                          'instead of sk_gs_amd.fused_step.FusedViewStep (same kernels, no autograd glue)')
@@ -167,7 +170,7 @@ def main():
 
     # ---------------------------------------------------------------- synthetic scene, resident in HBM
     frames = args.views
-    model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=0).to(dev)
+    model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=0, deform_net=args.deform_net).to(dev)
     cams = [scene.make_camera(W, H, seed=i) for i in range(args.views)]
     settings = [scene.raster_settings_from_camera(c, sh_degree=3, colmap=True, device=dev) for c in cams]
     background = torch.ones(3, device=dev)
@@ -188,8 +191,10 @@ def main():
         # (their KNN indices are identical) and expand it afterwards
         from sk_gs_amd.view_parallel import BucketedGradReducer
         bucket0 = [model._features_dc, model._features_rest]   # final after the rasterizer backward
-        bucket1 = [model._xyz, model._scaling, model._rotation, model._opacity, model.sk_r, model.sk_d_rot,
-                   model.sk_d_scale, model.global_tr]          # final after the skinning backward
+        bucket1 = [model._xyz, model._scaling, model._rotation, model._opacity]  # final after the skinning backward
+        bucket1 += [t for t in (model.sk_r, model.sk_d_rot, model.sk_d_scale, model.global_tr) if t is not None]
+        if model.sk_deform_net is not None:
+            bucket1 += list(model.sk_deform_net.parameters())
         if pipelined:
             vp = BucketedGradReducer([bucket0, bucket1], extras=[0, P * model.K])
         else:
@@ -408,6 +413,8 @@ def main():
                            f'flat-buffer grad all-reduce ({comm_bytes / 1e6:.1f} MB'
                            + (', compact LBS-logit gradient' if compact else '') + ')'),
                        'launch': 'eager' if args.eager else 'one hipGraph replay per view step',
+                       'joint_rotations': 'deform network (8x256 MLP) inside the step' if args.deform_net
+                       else 'per-frame tables (the reference\'s sk_cache)',
                        'step': 'autograd operator path' if args.autograd else 'FusedViewStep (direct C-ABI calls)'},
             'roofline': {'bound': 'hbm', 'kernel': 'render_backward', 'achieved': round(achieved, 2),
                          'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 5),

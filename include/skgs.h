@@ -242,6 +242,25 @@ int64_t skgs_adam_chunk_elems(void);
 int skgs_adam_step(int32_t n_tensors, const void* tensors, int64_t total_chunks, double beta1, double beta2, double eps,
     float* step_count, skgs_stream_t stream);
 
+/* ---- bone-transform producer of the skeleton stage (scope row (f)-3) ----
+ * SimpleDeformationNetwork (networks/sk_gs.py:134-164): FreqEncoder (my_ext/_C/src/nerf/freqencoder.cu:7-60) +
+ * MLP_with_skips (my_ext/blocks/mlp.py:43-85), evaluated on one row per bone.  One launch per linear layer and direction:
+ *   forward : Y[B,out] = act([X1 | X2] W^T + bias),  W [out, in1 + in2] (torch.nn.Linear layout), X2 optional (skip input)
+ *   backward: gZ = gY * (Y > 0) when relu;  gW = gZ^T [X1 | X2];  gb = sum_b gZ;  gX1 = gZ W[:, :in1] (written);
+ *             gX2 = gZ W[:, in1:]; accumulate_gx bit 0 / bit 1: add to gX1 / gX2 instead of writing.  gb, gX1, gX2 may be
+ *             NULL.
+ * freq encode: out[b, :] = [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(deg-1) x), cos(..)] grouped per frequency (C = D + 2 D deg
+ * columns written at row stride ld_out). */
+int skgs_freq_encode_forward(int32_t B, int32_t D, int32_t degree, const float* x, int32_t ld_x /* 0: one input row
+    for all B output rows */, float* out, int32_t ld_out, skgs_stream_t stream);
+int skgs_freq_encode_backward(int32_t B, int32_t D, int32_t degree, const float* grad_out, const float* out, int32_t ld_out,
+    float* grad_x, skgs_stream_t stream);
+int skgs_linear_forward(int32_t B, int32_t in1, int32_t in2, int32_t out, const float* X1, int32_t ldx1, const float* X2,
+    int32_t ldx2, const float* W, const float* bias, float* Y, int32_t ldy, int32_t relu, skgs_stream_t stream);
+int skgs_linear_backward(int32_t B, int32_t in1, int32_t in2, int32_t out, const float* X1, int32_t ldx1, const float* X2,
+    int32_t ldx2, const float* W, const float* Y, const float* gY, int32_t ldy, int32_t relu, float* gW, float* gb,
+    float* gX1, int32_t ldg1, float* gX2, int32_t ldg2, int32_t accumulate_gx, skgs_stream_t stream);
+
 /* ---- densification statistics of one training view (scope row (f)-4) ----
  * networks/sk_gs.py:1990-1997 + networks/gaussian_splatting.py:503-513: for every Gaussian with radii > 0
  *   max_radii2D = max(max_radii2D, radii); xyz_gradient_accum += |grad_means2D[:, :2]|; denom += 1.

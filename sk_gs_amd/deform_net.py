@@ -1,0 +1,214 @@
+"""Bone-transform producer of the skeleton stage (scope row (f)-3).
+
+``DeformMLP`` mirrors ``SimpleDeformationNetwork`` (networks/sk_gs.py:134-164): frequency encoding of the joint
+positions (degree 10) and of the time (degree 6), ``MLP_with_skips`` (my_ext/blocks/mlp.py:43-85: 8 x 256, ReLU, the
+input concatenated again after layer 4) and three linear heads (4 | 4 | 3 = raw joint rotation, d_rot, d_scale,
+``sk_dims``).  The parameter names match the reference's ``state_dict`` (``dynamic_net.net.{i}.weight``,
+``dynamic_net.last.{j}.weight`` ...), the three heads are stored as one [11, 256] matrix so that a forward or backward
+pass is one launch per layer (csrc/mlp.hip) instead of ~65 torch launches for 20 rows.
+
+``forward`` runs the HIP kernels (device tensors only, no fallback); ``reference_forward`` is the same network in
+plain torch ops -- the numerics reference of the kernels and the CPU restatement used by the host tests.
+"""
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor, nn
+import torch.nn.functional as F
+
+from sk_gs_amd import _C
+
+
+def freq_encode_torch(x: Tensor, degree: int) -> Tensor:
+    """[x, sin(2^0 x), cos(2^0 x), ..., sin(2^(deg-1) x), cos(2^(deg-1) x)] (freqencoder.cu:7-33: cos as sin(. + pi/2))"""
+    outs = [x]
+    for f in range(degree):
+        outs.append(torch.sin(x * (2.0 ** f)))
+        outs.append(torch.sin(x * (2.0 ** f) + torch.pi / 2))
+    return torch.cat(outs, dim=-1)
+
+
+class _MLPWithSkips(nn.Module):
+    """parameter container with the reference's names: ``net`` (hidden layers) and ``last`` (heads, stored fused)"""
+
+    def __init__(self, in_channels: int, dim_hidden: int, out_channels: Sequence[int], num_layers: int, skips: Sequence[int]):
+        super().__init__()
+        self.in_channels, self.dim_hidden, self.num_layers = in_channels, dim_hidden, num_layers
+        self.out_channels, self.skips = tuple(out_channels), tuple(skips)
+        net, c = [], in_channels
+        for i in range(num_layers):
+            net.append(nn.Linear(c, dim_hidden))
+            c = dim_hidden + (in_channels if i in self.skips else 0)
+        self.net = nn.ModuleList(net)
+        self.head_in = c
+        heads = [nn.Linear(c, oc) for oc in self.out_channels]  # same initialisation as three separate nn.Linear
+        self.last_weight = nn.Parameter(torch.cat([h.weight.data for h in heads], dim=0))
+        self.last_bias = nn.Parameter(torch.cat([h.bias.data for h in heads], dim=0))
+
+    # ---- the reference stores the heads as ``last.{j}.weight`` / ``last.{j}.bias``
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        w, b = destination.pop(prefix + 'last_weight'), destination.pop(prefix + 'last_bias')
+        o = 0
+        for j, oc in enumerate(self.out_channels):
+            destination[f'{prefix}last.{j}.weight'], destination[f'{prefix}last.{j}.bias'] = w[o:o + oc], b[o:o + oc]
+            o += oc
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        keys = [f'{prefix}last.{j}.weight' for j in range(len(self.out_channels))]
+        if all(k in state_dict for k in keys):
+            state_dict[prefix + 'last_weight'] = torch.cat([state_dict.pop(k) for k in keys], dim=0)
+            state_dict[prefix + 'last_bias'] = torch.cat(
+                [state_dict.pop(f'{prefix}last.{j}.bias') for j in range(len(self.out_channels))], dim=0)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def layer_dims(self) -> List[Tuple[int, int]]:
+        """(in1, in2) per hidden layer: in2 = width of the re-injected input"""
+        dims, skip_in = [], 0
+        for i in range(self.num_layers):
+            dims.append((self.in_channels if i == 0 else self.dim_hidden, skip_in))
+            skip_in = self.in_channels if i in self.skips else 0
+        return dims + [(self.dim_hidden, skip_in)]  # last entry: the heads
+
+
+class DeformMLP(nn.Module):
+    def __init__(self, p_in_channels: int = 3, t_in_channels: int = 1, out_channels: Sequence[int] = (4, 4, 3),
+                 width: int = 256, depth: int = 8, skips: Sequence[int] = (4,), p_degree: int = 10, t_degree: int = 6):
+        super().__init__()
+        self.p_in, self.t_in, self.p_degree, self.t_degree = p_in_channels, t_in_channels, p_degree, t_degree
+        self.p_dim = p_in_channels * (1 + 2 * p_degree)
+        self.t_dim = t_in_channels * (1 + 2 * t_degree)
+        self.dynamic_net = _MLPWithSkips(self.p_dim + self.t_dim, width, out_channels, depth, skips)
+
+    # ------------------------------------------------------------------------------------------------ plain torch
+    def reference_forward(self, points: Tensor, t: Tensor) -> List[Tensor]:
+        net = self.dynamic_net
+        p_embed = freq_encode_torch(points, self.p_degree)
+        t_embed = freq_encode_torch(t.view(-1, self.t_in), self.t_degree).expand(points.shape[0], -1)
+        x0 = torch.cat([p_embed, t_embed], dim=-1)
+        x = x0
+        for i in range(net.num_layers):
+            x = F.relu(net.net[i](x))
+            if i in net.skips:
+                x = torch.cat([x, x0], dim=-1)
+        out = F.linear(x, net.last_weight, net.last_bias)
+        return list(out.split(net.out_channels, dim=-1))
+
+    # ------------------------------------------------------------------------------------------------ HIP kernels
+    def forward(self, points: Tensor, t: Tensor) -> List[Tensor]:
+        net = self.dynamic_net
+        params = [p for l in net.net for p in (l.weight, l.bias)] + [net.last_weight, net.last_bias]
+        out = _DeformMLPFn.apply(self, points, t, *params)
+        return list(out.split(net.out_channels, dim=-1))
+
+
+def _lin_fwd(lib, B, in1, in2, out, X1, ldx1, X2, ldx2, W, b, Y, ldy, relu):
+    _C._check(lib.skgs_linear_forward(C.c_int32(B), C.c_int32(in1), C.c_int32(in2), C.c_int32(out), C.c_void_p(X1),
+                                      C.c_int32(ldx1), C.c_void_p(X2), C.c_int32(ldx2), C.c_void_p(W), C.c_void_p(b),
+                                      C.c_void_p(Y), C.c_int32(ldy), C.c_int32(relu), _C._stream()))
+
+
+def _lin_bwd(lib, B, in1, in2, out, X1, ldx1, X2, ldx2, W, Y, gY, ldy, relu, gW, gb, gX1, ldg1, gX2, ldg2, acc2):
+    _C._check(lib.skgs_linear_backward(C.c_int32(B), C.c_int32(in1), C.c_int32(in2), C.c_int32(out), C.c_void_p(X1),
+                                       C.c_int32(ldx1), C.c_void_p(X2), C.c_int32(ldx2), C.c_void_p(W), C.c_void_p(Y),
+                                       C.c_void_p(gY), C.c_int32(ldy), C.c_int32(relu), C.c_void_p(gW), C.c_void_p(gb),
+                                       C.c_void_p(gX1), C.c_int32(ldg1), C.c_void_p(gX2), C.c_int32(ldg2),
+                                       C.c_int32(acc2), _C._stream()))
+
+
+class DeformMLPRunner:
+    """The launch sequence of one forward / backward on caller-provided buffers (shared by the autograd Function and by
+    ``FusedViewStep``).  ``x0`` [B, IN], ``acts`` [L, B, H], ``out`` [B, OUT]; gradients are WRITTEN to the given tensors."""
+
+    def __init__(self, mlp: DeformMLP):
+        self.mlp, self.lib = mlp, _C.load_library()
+
+    def encode(self, points: Tensor, t: Tensor, x0: Tensor):
+        m, lib = self.mlp, self.lib
+        B, ld = points.shape[0], x0.shape[1]
+        _C._check(lib.skgs_freq_encode_forward(C.c_int32(B), C.c_int32(m.p_in), C.c_int32(m.p_degree),
+                                               C.c_void_p(points.data_ptr()), C.c_int32(m.p_in),
+                                               C.c_void_p(x0.data_ptr()), C.c_int32(ld), _C._stream()))
+        # the time embedding is the same for every row (ld_x = 0)
+        _C._check(lib.skgs_freq_encode_forward(C.c_int32(B), C.c_int32(m.t_in), C.c_int32(m.t_degree),
+                                               C.c_void_p(t.data_ptr()), C.c_int32(0),
+                                               C.c_void_p(x0[:, m.p_dim:].data_ptr()), C.c_int32(ld), _C._stream()))
+
+    def forward_hidden(self, x0: Tensor, acts: Tensor):
+        net, lib = self.mlp.dynamic_net, self.lib
+        B, IN, H = x0.shape[0], net.in_channels, net.dim_hidden
+        dims = net.layer_dims()
+        prev, ldp = x0.data_ptr(), IN
+        for i, layer in enumerate(net.net):
+            in1, in2 = dims[i]
+            _lin_fwd(lib, B, in1, in2, H, prev, ldp, x0.data_ptr() if in2 else None, IN, layer.weight.data_ptr(),
+                     layer.bias.data_ptr(), acts[i].data_ptr(), H, 1)
+            prev, ldp = acts[i].data_ptr(), H
+
+    def forward(self, x0: Tensor, acts: Tensor, out: Tensor):
+        net, lib = self.mlp.dynamic_net, self.lib
+        self.forward_hidden(x0, acts)
+        in1, in2 = net.layer_dims()[-1]
+        _lin_fwd(lib, x0.shape[0], in1, in2, out.shape[1], acts[-1].data_ptr(), net.dim_hidden,
+                 x0.data_ptr() if in2 else None, net.in_channels, net.last_weight.data_ptr(), net.last_bias.data_ptr(),
+                 out.data_ptr(), out.shape[1], 0)
+
+    def backward_hidden(self, x0: Tensor, acts: Tensor, grads: List[Tensor], g_act: Tensor):
+        """hidden layers, last to first; ``g_act[0]`` holds dL/d(last activation) on entry.  ``grads``: [gW0, gb0, ...]
+        (written).  The encoded input gets no gradient: joints and time are inputs of the skeleton stage."""
+        net, lib = self.mlp.dynamic_net, self.lib
+        B, IN, H, L = x0.shape[0], net.in_channels, net.dim_hidden, net.num_layers
+        dims = net.layer_dims()
+        x0p = x0.data_ptr()
+        cur = 0
+        for i in range(L - 1, -1, -1):
+            in1, in2 = dims[i]
+            layer = net.net[i]
+            x1, ld1 = (acts[i - 1].data_ptr(), H) if i > 0 else (x0p, IN)
+            gx1 = g_act[1 - cur].data_ptr() if i > 0 else None
+            _lin_bwd(lib, B, in1, in2, H, x1, ld1, x0p if in2 else None, IN, layer.weight.data_ptr(), acts[i].data_ptr(),
+                     g_act[cur].data_ptr(), H, 1, grads[2 * i].data_ptr(), grads[2 * i + 1].data_ptr(), gx1, H, None, IN, 0)
+            cur = 1 - cur
+
+    def backward(self, x0: Tensor, acts: Tensor, out: Tensor, g_out: Tensor, grads: List[Tensor], g_act: Tensor):
+        """``grads``: [gW0, gb0, ..., gW_last, gb_last] (written); ``g_act`` [2, B, H] ping-pong scratch"""
+        net, lib = self.mlp.dynamic_net, self.lib
+        B, IN, H, L = x0.shape[0], net.in_channels, net.dim_hidden, net.num_layers
+        in1, in2 = net.layer_dims()[-1]
+        _lin_bwd(lib, B, in1, in2, out.shape[1], acts[L - 1].data_ptr(), H, x0.data_ptr() if in2 else None, IN,
+                 net.last_weight.data_ptr(), None, g_out.data_ptr(), out.shape[1], 0, grads[-2].data_ptr(),
+                 grads[-1].data_ptr(), g_act[0].data_ptr(), H, None, IN, 0)
+        self.backward_hidden(x0, acts, grads[:-2], g_act)
+
+
+class _DeformMLPFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mlp: DeformMLP, points: Tensor, t: Tensor, *params):
+        _C._require_gpu(points, 'points')
+        net = mlp.dynamic_net
+        points = points.detach().float().contiguous()
+        t = t.detach().float().reshape(-1).contiguous().to(points.device)
+        B = points.shape[0]
+        f32 = dict(dtype=torch.float32, device=points.device)
+        x0 = torch.empty((B, net.in_channels), **f32)
+        acts = torch.empty((net.num_layers, B, net.dim_hidden), **f32)
+        out = torch.empty((B, sum(net.out_channels)), **f32)
+        run = DeformMLPRunner(mlp)
+        run.encode(points, t, x0)
+        run.forward(x0, acts, out)
+        ctx.mlp = mlp
+        ctx.save_for_backward(x0, acts, out)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_out):
+        x0, acts, out = ctx.saved_tensors
+        mlp = ctx.mlp
+        net = mlp.dynamic_net
+        params = [p for l in net.net for p in (l.weight, l.bias)] + [net.last_weight, net.last_bias]
+        grads = [torch.empty_like(p) for p in params]
+        g_act = torch.empty((2,) + tuple(acts.shape[1:]), dtype=torch.float32, device=acts.device)
+        DeformMLPRunner(mlp).backward(x0, acts, out, g_out.contiguous(), grads, g_act)
+        return (None, None, None) + tuple(grads)  # joints / time are inputs of the skeleton stage, not learned here

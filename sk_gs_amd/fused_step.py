@@ -97,6 +97,18 @@ class FusedViewStep:
         self.densify_stats = bool(densify_stats)
         self.xyz_gradient_accum, self.denom = torch.zeros((P, 1), **f32), torch.zeros((P, 1), **f32)
         self.max_radii2D = torch.zeros((P,), **f32)
+        # bone-transform producer (scope row (f)-3): the MLP runs inside the step, its weight gradients are written in place
+        self.deform_net = model.sk_deform_net
+        if self.deform_net is not None:
+            from sk_gs_amd.deform_net import DeformMLPRunner
+            net = self.deform_net.dynamic_net
+            self._mlp = DeformMLPRunner(self.deform_net)
+            self._x0 = torch.empty((M, net.in_channels), **f32)
+            self._acts = torch.empty((net.num_layers, M, net.dim_hidden), **f32)
+            self._g_act = torch.empty((2, M, net.dim_hidden), **f32)
+            self._sk_r_raw, self._d_rot, self._d_scale = (torch.empty((M, 4), **f32), torch.empty((M, 4), **f32),
+                                                          torch.empty((M, 3), **f32))
+            self._g_heads = [torch.empty((M, 4), **f32), torch.empty((M, 4), **f32), torch.empty((M, 3), **f32)]
         topo = model.topology()
         self._topo = topo
         self._bufs = _C._buffers(self.geom, self.binning, self.img)
@@ -107,7 +119,7 @@ class FusedViewStep:
         """per-frame tables: only row ``time_id`` gets a gradient, every other row must read zero.  With a
         FlatGradBuffer the four tables are adjacent: one fill."""
         m = self.model
-        tabs = [m.sk_r.grad, m.sk_d_rot.grad, m.sk_d_scale.grad, m.global_tr.grad]
+        tabs = [t.grad for t in (m.sk_r, m.sk_d_rot, m.sk_d_scale, m.global_tr) if t is not None]
         lo = min(t.data_ptr() for t in tabs)
         total = sum(t.numel() for t in tabs)
         first = min(tabs, key=lambda t: t.data_ptr())
@@ -142,7 +154,10 @@ class FusedViewStep:
         a.P, a.K, a.M = self.P, self.K, self.M
         a.points = a.xyz = m._xyz.data_ptr()  # points = xyz.detach() (sk_gs.py:1113): same storage
         a.weights, a.indices, a.bone_T = self.weights.data_ptr(), self.indices.data_ptr(), self.bone_T.data_ptr()
-        a.bone_drot, a.bone_dscale = m.sk_d_rot[time_id].data_ptr(), m.sk_d_scale[time_id].data_ptr()
+        if self.deform_net is None:
+            a.bone_drot, a.bone_dscale = m.sk_d_rot[time_id].data_ptr(), m.sk_d_scale[time_id].data_ptr()
+        else:
+            a.bone_drot, a.bone_dscale = self._d_rot.data_ptr(), self._d_scale.data_ptr()
         a.log_scale, a.rot, a.opacity_logit = m._scaling.data_ptr(), m._rotation.data_ptr(), m._opacity.data_ptr()
         return a
 
@@ -153,11 +168,12 @@ class FusedViewStep:
         lib, m, st, chk = self.lib, self.model, _C._stream(), _C._check
         t = self._topo
         P, M, K = self.P, self.M, self.K
+        sk_r_raw = self._joint_rotations(time_id)
         # (running the single-workgroup bone-chain kernels on a forked stream beside the wide kernels was measured:
         # the fork/join edges of the captured graph cost more (+12 us per step) than the ~10 us of overlap)
         chk(lib.skgs_bone_chain_forward(
             C.c_int32(M), C.c_int32(t['root']), _p(t['parents']), _p(t['level_nodes']), _p(t['level_start']),
-            C.c_int32(t['num_levels']), _p(m.sk_r[time_id]), _p(m.joints), _p(m.global_tr[time_id]), _p(self.bone_T),
+            C.c_int32(t['num_levels']), _p(sk_r_raw), _p(m.joints), _p(m.global_tr[time_id]), _p(self.bone_T),
             _p(self.chain_A), st))
         chk(lib.skgs_knn_lbs_weights(C.c_int32(P), C.c_int32(M), C.c_int32(K), _p(m._xyz), _p(m.joints), _p(m.sp_W),
                                      _p(self.indices), _p(self.weights), st))
@@ -212,9 +228,14 @@ class FusedViewStep:
         t = self._topo
         P, M, K = self.P, self.M, self.K
         d = self._deform_inputs(time_id)
+        if self.deform_net is None:
+            sk_r_raw, g_raw = m.sk_r[time_id], m.sk_r.grad[time_id]
+            g_drot, g_dscale = m.sk_d_rot.grad[time_id], m.sk_d_scale.grad[time_id]
+        else:  # the three heads of the producer network: their gradients feed its backward below
+            sk_r_raw, (g_raw, g_drot, g_dscale) = self._sk_r_raw, self._g_heads
         chk(lib.skgs_lbs_deform_backward(
             C.byref(d), _p(self.g_means), _p(self.g_scales), _p(self.g_rotations), _p(self.g_opacity),
-            _p(self.g_weights), _p(self.g_bone_T), _p(m.sk_d_rot.grad[time_id]), _p(m.sk_d_scale.grad[time_id]),
+            _p(self.g_weights), _p(self.g_bone_T), _p(g_drot), _p(g_dscale),
             _p(m._xyz.grad), _p(m._scaling.grad), _p(m._rotation.grad), _p(m._opacity.grad), _p(self.deform_ws),
             C.c_size_t(self.deform_ws.numel()), st))
         if self.spw_logit_grad is None:
@@ -225,10 +246,46 @@ class FusedViewStep:
                                                       _p(self.spw_logit_grad), st))
         chk(lib.skgs_bone_chain_backward(
             C.c_int32(M), C.c_int32(t['root']), _p(t['parents']), _p(t['level_nodes']), _p(t['level_start']),
-            C.c_int32(t['num_levels']), _p(m.sk_r[time_id]), _p(m.joints), _p(m.global_tr[time_id]), _p(self.chain_A),
-            _p(self.g_bone_T), _p(m.sk_r.grad[time_id]), None, _p(m.global_tr.grad[time_id]), st))
+            C.c_int32(t['num_levels']), _p(sk_r_raw), _p(m.joints), _p(m.global_tr[time_id]), _p(self.chain_A),
+            _p(self.g_bone_T), _p(g_raw), None, _p(m.global_tr.grad[time_id]), st))
+        if self.deform_net is not None:
+            self._deform_net_backward()
         if self.densify_stats:
             self.add_densification_stats()
+
+    def _joint_rotations(self, time_id: int) -> Tensor:
+        """raw joint rotations of the frame: a row of the per-frame table, or the producer network's first head (the
+        network also fills d_rot / d_scale): 2 encode + 8 layer + 3 head launches (csrc/mlp.hip)"""
+        m = self.model
+        if self.deform_net is None:
+            return m.sk_r[time_id]
+        from sk_gs_amd.deform_net import _lin_fwd
+        net, run = self.deform_net.dynamic_net, self._mlp
+        run.encode(m.joints, m.frame_times[time_id], self._x0)
+        run.forward_hidden(self._x0, self._acts)
+        M, H, IN = self.M, net.dim_hidden, net.in_channels
+        in1, in2 = net.layer_dims()[-1]
+        o = 0
+        for buf, oc in zip((self._sk_r_raw, self._d_rot, self._d_scale), net.out_channels):
+            _lin_fwd(self.lib, M, in1, in2, oc, self._acts[-1].data_ptr(), H, self._x0.data_ptr() if in2 else None, IN,
+                     net.last_weight[o:].data_ptr(), net.last_bias[o:].data_ptr(), buf.data_ptr(), oc, 0)
+            o += oc
+        return self._sk_r_raw
+
+    def _deform_net_backward(self):
+        """weight gradients of the producer network, written into the parameters' .grad: 3 head + 8 layer launches"""
+        from sk_gs_amd.deform_net import _lin_bwd
+        net, run = self.deform_net.dynamic_net, self._mlp
+        M, H, IN = self.M, net.dim_hidden, net.in_channels
+        in1, in2 = net.layer_dims()[-1]
+        o = 0
+        for j, (g_head, oc) in enumerate(zip(self._g_heads, net.out_channels)):
+            _lin_bwd(self.lib, M, in1, in2, oc, self._acts[-1].data_ptr(), H, self._x0.data_ptr() if in2 else None, IN,
+                     net.last_weight[o:].data_ptr(), None, g_head.data_ptr(), oc, 0, net.last_weight.grad[o:].data_ptr(),
+                     net.last_bias.grad[o:].data_ptr(), self._g_act[0].data_ptr(), H, None, IN, 1 if j > 0 else 0)
+            o += oc
+        grads = [g for l in net.net for g in (l.weight.grad, l.bias.grad)]
+        run.backward_hidden(self._x0, self._acts, grads, self._g_act)
 
     @torch.no_grad()
     def scatter_spw_grad(self):

@@ -22,7 +22,7 @@ from sk_gs_amd.renderer.gaussian_render import GaussianRasterizationSettings, re
 
 class SkinnedGaussians(nn.Module):
     def __init__(self, P: int, M: int, K: int = 5, sh_degree: int = 3, num_frames: int = 8, seed: int = 0,
-                 scale_mult: float = 1.0):
+                 scale_mult: float = 1.0, deform_net: bool = False):
         super().__init__()
         g = scene.make_gaussians(P, seed=seed, sh_degree=sh_degree, scale_mult=scale_mult)
         b = scene.make_bones(max(M, 1), seed=seed)
@@ -52,9 +52,22 @@ class SkinnedGaussians(nn.Module):
         frames = max(num_frames, 1)
         rot0 = torch.stack([skeleton.axis_angle_to_quat(0.2 * torch.randn(max(M, 1), 3, generator=gen))
                             for _ in range(frames)])
-        self.sk_r = nn.Parameter(rot0 - rot0.new_tensor([0, 0, 0, 1.]))
-        self.sk_d_rot = nn.Parameter(b['d_rot'][None].repeat(frames, 1, 1))
-        self.sk_d_scale = nn.Parameter(b['d_scale'][None].repeat(frames, 1, 1))
+        # joint rotations / d_rot / d_scale per frame: either the cached table (what the reference keeps in sk_cache) or
+        # the producer network itself (sk_deform_net: SimpleDeformationNetwork, sk_gs.py:520-522,1069-1085)
+        self.sk_deform_net = None
+        if deform_net:
+            from sk_gs_amd.deform_net import DeformMLP
+            torch.manual_seed(4000 + seed)
+            self.sk_deform_net = DeformMLP()
+            with torch.no_grad():  # start of the skeleton stage: rotations near identity, small d_rot / d_scale
+                self.sk_deform_net.dynamic_net.last_weight.mul_(0.01)
+                self.sk_deform_net.dynamic_net.last_bias.zero_()
+            self.register_buffer('frame_times', torch.linspace(0., 1., frames).view(frames, 1))
+            self.sk_r = self.sk_d_rot = self.sk_d_scale = None
+        else:
+            self.sk_r = nn.Parameter(rot0 - rot0.new_tensor([0, 0, 0, 1.]))
+            self.sk_d_rot = nn.Parameter(b['d_rot'][None].repeat(frames, 1, 1))
+            self.sk_d_scale = nn.Parameter(b['d_scale'][None].repeat(frames, 1, 1))
         self.global_tr = nn.Parameter(torch.tensor([0, 0, 0, 0, 0, 0, 1.]).repeat(frames, 1))
         self.static = M == 0
 
@@ -70,8 +83,12 @@ class SkinnedGaussians(nn.Module):
             {'params': [self._rotation], 'lr': lr * 1.0, 'name': 'rotation'},
         ]
         if not self.static:
-            groups.append({'params': [self.sp_W, self.sk_r, self.sk_d_rot, self.sk_d_scale, self.global_tr],
-                           'lr': lr, 'name': 'skinning'})
+            if self.sk_deform_net is None:
+                groups.append({'params': [self.sp_W, self.sk_r, self.sk_d_rot, self.sk_d_scale, self.global_tr],
+                               'lr': lr, 'name': 'skinning'})
+            else:
+                groups.append({'params': [self.sp_W, self.global_tr], 'lr': lr, 'name': 'skinning'})
+                groups.append({'params': list(self.sk_deform_net.parameters()), 'lr': lr, 'name': 'deform_net'})
         return groups
 
     # --------------------------------------------------------------------------------------------------- forward
@@ -81,14 +98,24 @@ class SkinnedGaussians(nn.Module):
                           for k, v in self._topo_cpu.items()}
         return self._topo
 
+    def joint_outputs(self, time_id: int):
+        """(raw joint rotations [M,4], d_rot [M,4], d_scale [M,3]) of a frame"""
+        if self.sk_deform_net is None:
+            return self.sk_r[time_id], self.sk_d_rot[time_id], self.sk_d_scale[time_id]
+        t = self.frame_times[time_id]
+        if self.joints.is_cuda:
+            return tuple(self.sk_deform_net(self.joints, t))
+        return tuple(self.sk_deform_net.reference_forward(self.joints, t))
+
     def bone_transforms(self, time_id: int):
+        sk_r_raw, d_rot, d_scale = self.joint_outputs(time_id)
         if self.fused_bone_chain and self.joints.is_cuda:
-            sk_T = skeleton.bone_chain(self.sk_r[time_id], self.joints, self.global_tr[time_id], self.topology())
+            sk_T = skeleton.bone_chain(sk_r_raw, self.joints, self.global_tr[time_id], self.topology())
         else:  # plain-torch restatement (the numerics reference of the fused kernel)
-            sk_r = F.normalize(self.sk_r[time_id] + self._rot_bias, dim=-1)
+            sk_r = F.normalize(sk_r_raw + self._rot_bias, dim=-1)
             sk_T = skeleton.kinematic(self.joints, sk_r, self.global_tr[time_id], self.joint_parents,
                                       self.joint_root, (self._ident7, self._root_mask))
-        return sk_T, self.sk_d_rot[time_id], self.sk_d_scale[time_id]
+        return sk_T, d_rot, d_scale
 
     def forward(self, time_id: int = 0) -> Dict[str, Tensor]:
         sh_features = torch.cat((self._features_dc, self._features_rest), dim=1)

@@ -57,7 +57,7 @@ class FusedAdam:
             grads.append(p.grad.data_ptr())
         self._total_chunks = chunk0
         self._bound_grads = grads
-        self._table.copy_(torch.frombuffer(bytes(blob), dtype=torch.uint8))
+        self._table.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
 
     def set_lr(self, group_index: int, lr: float):
         self.param_groups[group_index]['lr'] = lr

@@ -17,6 +17,8 @@ What is pinned (reference file:line of the function that produced the expected v
   skeleton.npz    networks/sk_gs.py:167-190 skeleton_warp_v0 / skeleton_warp on 4x4 matrices; xfm.py:60-79 apply
   ssim.npz        networks/losses/ssim.py:20-62 SSIM_Loss, networks/losses/image_loss.py:6-32 ImageLoss('l1'):
                   loss values and d(0.8 L1 + 0.2 SSIM)/d image
+  mlp.npz         my_ext/blocks/mlp.py:43-85 MLP_with_skips (4 x 16, skip after layer 2, heads 4|4|3): parameters by their
+                  state_dict names, outputs and parameter gradients for fixed cotangents
 """
 import importlib.abc
 import importlib.machinery
@@ -187,6 +189,19 @@ def main():
         rec.update({f'x{k}': f32(x), f'y{k}': f32(y), f'ssim{k}': np.float64(ls.item()), f'l1{k}': np.float64(ll.item()),
                     f'total{k}': np.float64(total.item()), f'grad{k}': f32(grad)})
     np.savez(os.path.join(HERE, 'ssim.npz'), **rec)
+
+    # ---- deform MLP (skeleton stage): MLP_with_skips as configured by SimpleDeformationNetwork -----------------------
+    from my_ext.blocks.mlp import MLP_with_skips
+    torch.manual_seed(20240502)
+    net = MLP_with_skips(in_channels=12, dim_hidden=16, out_channels=(4, 4, 3), num_layers=4, skips=(2,))
+    x = torch.randn(6, 12, generator=g, requires_grad=True)
+    outs = net(x)
+    gy = [torch.randn(o.shape, generator=g) for o in outs]
+    grads = torch.autograd.grad(outs, list(net.parameters()), gy)
+    rec = {'x': f32(x), **{f'out{j}': f32(o) for j, o in enumerate(outs)}, **{f'gy{j}': f32(v) for j, v in enumerate(gy)}}
+    for (n, p), gr in zip(net.named_parameters(), grads):
+        rec['param.' + n], rec['grad.' + n] = f32(p), f32(gr)
+    np.savez(os.path.join(HERE, 'mlp.npz'), **rec)
     print('golden fixtures written to', HERE)
     for f in sorted(os.listdir(HERE)):
         print(f'  {f:<20} {os.path.getsize(os.path.join(HERE, f)):>8} B')

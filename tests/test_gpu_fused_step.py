@@ -126,3 +126,33 @@ def test_split_step_with_compact_logit_gradient_matches_the_single_call():
     for n, p in model.named_parameters():
         assert_close_robust(p.grad, ref[n], 1e-4, 1e-4, name=n)
     assert red.allreduce(0) is None  # no process group: nothing to do
+
+
+def test_fused_step_with_the_deform_network_matches_autograd():
+    """stage sk with the bone-transform producer network inside the step (scope row (f)-3): its weight gradients from
+    FusedViewStep equal those of the autograd path (DeformMLP -> bone_chain -> lbs_deform -> render -> loss)"""
+    from sk_gs_amd import _C, scene
+    from sk_gs_amd.fused_step import FusedViewStep
+    from sk_gs_amd.losses import image_loss
+    from sk_gs_amd.model import SkinnedGaussians
+    P, M, K, W, H, frames, tid = 3000, 10, 4, 128, 96, 3, 2
+    dev = torch.device('cuda')
+    model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=2, scale_mult=2.0, deform_net=True).to(dev)
+    assert model.sk_r is None and any(n.startswith('sk_deform_net.') for n, _ in model.named_parameters())
+    cam = scene.make_camera(W, H, seed=2)
+    rs = scene.raster_settings_from_camera(cam, sh_degree=3, colmap=True, device=dev)
+    target = torch.rand(3, H, W, generator=torch.Generator().manual_seed(3)).to(dev)
+    _C.config.sync_num_rendered = True
+    out = model.render(rs, time_id=tid)
+    loss = image_loss(out['images'], target)
+    loss.backward()
+    ref = {n: p.grad.clone() for n, p in model.named_parameters()}
+    assert float(ref['sk_deform_net.dynamic_net.net.0.weight'].abs().max()) > 0
+    R = out['buffer'].R
+    for p in model.parameters():
+        p.grad = torch.full_like(p, 5.0)
+    step = FusedViewStep(model, W, H, capacity=int(R * 1.2) + 1024)
+    step.forward_backward(rs, tid, target)
+    assert rel_err(step.image, out['images'].detach()) <= 5e-6
+    for n, p in model.named_parameters():
+        assert_close_robust(p.grad, ref[n], 2e-4, 1e-3, name=n)

@@ -157,3 +157,38 @@ def test_image_loss_restatement_matches_reference():
         assert abs(float(total) - float(g[f'total{k}'])) < 1e-6
         (grad,) = torch.autograd.grad(total, x)
         np.testing.assert_allclose(grad.permute(1, 2, 0).numpy(), g[f'grad{k}'][0], atol=1e-8, rtol=1e-4)
+
+
+def test_deform_mlp_matches_reference_modules():
+    """sk_gs_amd.deform_net: the plain-torch restatement (reference_forward) and the parameter naming against
+    my_ext/blocks/mlp.py:43-85 MLP_with_skips (fixture mlp.npz: parameters by state_dict name, outputs, gradients)"""
+    import torch
+    from sk_gs_amd.deform_net import DeformMLP
+    z = np.load(os.path.join(GOLD, 'mlp.npz'))
+    # in = 12 = 3 * (1 + 2 * 1) + 1 * (1 + 2 * 1): feed the fixture's input in place of the encoded one
+    mlp = DeformMLP(p_in_channels=3, t_in_channels=1, out_channels=(4, 4, 3), width=16, depth=4, skips=(2,), p_degree=1,
+                    t_degree=1)
+    state = {'dynamic_net.' + k[len('param.'):]: torch.tensor(z[k]) for k in z.files if k.startswith('param.')}
+    assert set(state) == set(mlp.state_dict())  # same names as the reference's state_dict
+    mlp.load_state_dict(state)
+    net = mlp.dynamic_net
+    x0 = torch.tensor(z['x'], requires_grad=True)
+    x = x0
+    for i in range(net.num_layers):
+        x = torch.relu(net.net[i](x))
+        if i in net.skips:
+            x = torch.cat([x, x0], dim=-1)
+    out = torch.nn.functional.linear(x, net.last_weight, net.last_bias)
+    ref_out = np.concatenate([z['out0'], z['out1'], z['out2']], axis=1)
+    assert np.abs(out.detach().numpy() - ref_out).max() <= 1e-6
+    out.backward(torch.tensor(np.concatenate([z['gy0'], z['gy1'], z['gy2']], axis=1)))
+    saved = mlp.state_dict(keep_vars=True)
+    for k in z.files:
+        if k.startswith('grad.net.'):
+            p = dict(mlp.named_parameters())['dynamic_net.' + k[len('grad.'):]]
+            assert np.abs(p.grad.numpy() - z[k]).max() <= 1e-5, k
+    gl = np.concatenate([z[f'grad.last.{j}.weight'] for j in range(3)], axis=0)
+    assert np.abs(net.last_weight.grad.numpy() - gl).max() <= 1e-5
+    # and the module's own forward path in plain torch (encoder + net) runs and has the reference's output split
+    outs = mlp.reference_forward(torch.randn(5, 3), torch.tensor([0.25]))
+    assert [tuple(o.shape) for o in outs] == [(5, 4), (5, 4), (5, 3)] and saved is not None
