@@ -220,12 +220,18 @@ def main():
         fstep = FusedViewStep(model, W, H, capacity=int(R_max * 1.25 * _C.config.capacity_growth) + 1024,
                               background=background, grad_scale=1.0 / world,
                               spw_logit_grad=vp.extra_views[-1] if compact else None)
+        # the per-frame table gradients (one row written per step) are cleared by the Adam launch itself
+        table_span = None if args.torch_adam else fstep.table_grad_span()
+        fstep.tables_zeroed_by_optimizer = table_span is not None
+    else:
+        table_span = None
 
     if pipelined:
         # ---- world > 1: bucket 0 is on the wire while the skinning backward runs, bucket 1 while Adam updates bucket 0
         from sk_gs_amd.optim import FusedAdam
         optA = FusedAdam([g for g in groups if g['name'] in ('f_dc', 'f_rest')], eps=1e-15, betas=(0.9, 0.999))
-        optB = FusedAdam([g for g in groups if g['name'] not in ('f_dc', 'f_rest')], eps=1e-15, betas=(0.9, 0.999))
+        optB = FusedAdam([g for g in groups if g['name'] not in ('f_dc', 'f_rest')], eps=1e-15, betas=(0.9, 0.999),
+                         zero_after_step=table_span)
 
         def part_a(v):
             fstep.backward_raster(settings[v], v % frames, targets[v])
@@ -268,7 +274,7 @@ def main():
             opt = torch.optim.Adam(groups, eps=1e-15, betas=(0.9, 0.999), fused=True, capturable=not args.eager)
         else:
             from sk_gs_amd.optim import FusedAdam
-            opt = FusedAdam(groups, eps=1e-15, betas=(0.9, 0.999))
+            opt = FusedAdam(groups, eps=1e-15, betas=(0.9, 0.999), zero_after_step=table_span)
         if args.autograd:
             def fwd_bwd(v):
                 vp.grads.zero_()

@@ -225,10 +225,13 @@ int skgs_bone_chain_backward(int32_t M, int32_t root, const int32_t* parents, co
  * backward.  grad_loss: device scalar dL/dloss, or NULL for 1. */
 size_t skgs_image_loss_workspace_bytes(int32_t C, int32_t H, int32_t W);
 int skgs_image_loss_forward(int32_t C, int32_t H, int32_t W, const float* pred, const float* gt, float lambda_l1,
-    float lambda_ssim, float* loss3, void* workspace, size_t workspace_bytes, skgs_stream_t stream);
+    float lambda_ssim, float* loss3 /* may be NULL: see the backward */, void* workspace, size_t workspace_bytes,
+    skgs_stream_t stream);
+/* loss3: NULL, or where this call puts {total, L1 mean, SSIM mean} of the forward that filled `workspace` (a forward
+ * called with loss3 = NULL skips its one-workgroup summation launch; one workgroup of the backward does it instead). */
 int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred, const float* gt, float lambda_l1,
     float lambda_ssim, const float* grad_loss, const void* workspace, size_t workspace_bytes, float* dL_dpred,
-    skgs_stream_t stream);
+    float* loss3, skgs_stream_t stream);
 
 /* ---- multi-tensor Adam step in one launch (scope row (f)-2) ----
  * Replaces torch.optim.Adam(eps=1e-15) as configured by exps/default.yaml:122-125 over the parameter groups of
@@ -240,7 +243,8 @@ int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred,
 size_t skgs_adam_tensor_bytes(void);
 int64_t skgs_adam_chunk_elems(void);
 int skgs_adam_step(int32_t n_tensors, const void* tensors, int64_t total_chunks, double beta1, double beta2, double eps,
-    float* step_count, skgs_stream_t stream);
+    float* step_count, float* zero_after /* NULL, or zero_n floats cleared after the update (with the counter bump) */,
+    int64_t zero_n, skgs_stream_t stream);
 
 /* ---- bone-transform producer of the skeleton stage (scope row (f)-3) ----
  * SimpleDeformationNetwork (networks/sk_gs.py:134-164): FreqEncoder (my_ext/_C/src/nerf/freqencoder.cu:7-60) +

@@ -669,7 +669,7 @@ def image_loss_backward(pred: Tensor, gt: Tensor, lambda_l1: float, lambda_ssim:
         _check(lib.skgs_image_loss_backward(C.c_int32(Cc), C.c_int32(H), C.c_int32(W), C.c_void_p(pred.data_ptr()),
                                             C.c_void_p(gt.data_ptr()), C.c_float(lambda_l1), C.c_float(lambda_ssim),
                                             C.c_void_p(_ptr(gl)), C.c_void_p(workspace.data_ptr()),
-                                            C.c_size_t(workspace.numel()), C.c_void_p(out.data_ptr()), _stream()))
+                                            C.c_size_t(workspace.numel()), C.c_void_p(out.data_ptr()), None, _stream()))
     return out
 
 

@@ -78,7 +78,13 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_step_kernel(int n_tensors, 
 
 // (A last-workgroup-out ticket inside adam_step_kernel was tried instead of this launch: 4096 same-address atomics
 // next to the counter every workgroup reads cost 70 us.)
-__global__ void adam_bump_kernel(float* step_count) { step_count[0] += 1.0f; }
+// ... and, in the same launch, clears `zero_after` (gradient storage that must read zero when the next backward starts:
+// the per-frame tables of which a step writes one row -- instead of a fill launch at the start of every step)
+__global__ void __launch_bounds__(256) adam_bump_kernel(float* step_count, float* __restrict__ zero_after, int64_t zero_n) {
+  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) step_count[0] += 1.0f;
+  if (i < zero_n) zero_after[i] = 0.f;
+}
 
 }  // namespace
 }  // namespace skgs
@@ -94,7 +100,7 @@ int64_t skgs_adam_chunk_elems(void) { return ADAM_CHUNK; }
  * pointer 16-B aligned; chunk0 = running sum of ceil(n / skgs_adam_chunk_elems())). step_count: device float, the
  * number of steps taken so far; incremented by the call. */
 int skgs_adam_step(int32_t n_tensors, const void* tensors, int64_t total_chunks, double beta1, double beta2, double eps,
-    float* step_count, skgs_stream_t stream) {
+    float* step_count, float* zero_after, int64_t zero_n, skgs_stream_t stream) {
   SKGS_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || (tensors && step_count)), "adam_step: NULL argument");
   if (n_tensors == 0 || total_chunks == 0) return 0;
   hipStream_t s   = (hipStream_t) stream;
@@ -102,7 +108,9 @@ int skgs_adam_step(int32_t n_tensors, const void* tensors, int64_t total_chunks,
   hipLaunchKernelGGL(adam_step_kernel, dim3(grid), dim3(ADAM_THREADS), 0, s, n_tensors,
       reinterpret_cast<const AdamTensor*>(tensors), total_chunks, beta1, beta2, (float) eps, step_count);
   SKGS_CHECK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, s, step_count);
+  const int64_t zn = zero_after ? std::max<int64_t>(zero_n, 0) : 0;
+  hipLaunchKernelGGL(adam_bump_kernel, dim3((unsigned) std::max<int64_t>(1, (zn + 255) / 256)), dim3(256), 0, s, step_count,
+      zero_after, zn);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -164,9 +164,9 @@ __global__ void __launch_bounds__(256) image_loss_forward_kernel(int C, int H, i
   }
 }
 
-__global__ void __launch_bounds__(256) image_loss_finalize_kernel(int nblocks, double inv_n, float lambda_l1,
-    float lambda_ssim, const float* __restrict__ partials, float* __restrict__ loss /*[3]*/) {
-  __shared__ double s_a[256], s_b[256];
+// fixed-order sum of the per-tile partials (256 threads of one workgroup) -> loss[3] = {total, L1 mean, SSIM mean}
+__device__ __forceinline__ void finalize_loss(int nblocks, double inv_n, float lambda_l1, float lambda_ssim,
+    const float* __restrict__ partials, float* __restrict__ loss, double* s_a, double* s_b) {
   double a = 0.0, b = 0.0;
   for (int i = threadIdx.x; i < nblocks; i += 256) a += partials[2 * i], b += partials[2 * i + 1];
   s_a[threadIdx.x] = a, s_b[threadIdx.x] = b;
@@ -183,9 +183,16 @@ __global__ void __launch_bounds__(256) image_loss_finalize_kernel(int nblocks, d
   }
 }
 
+__global__ void __launch_bounds__(256) image_loss_finalize_kernel(int nblocks, double inv_n, float lambda_l1,
+    float lambda_ssim, const float* __restrict__ partials, float* __restrict__ loss /*[3]*/) {
+  __shared__ double s_a[256], s_b[256];
+  finalize_loss(nblocks, inv_n, lambda_l1, lambda_ssim, partials, loss, s_a, s_b);
+}
+
 __global__ void __launch_bounds__(256) image_loss_backward_kernel(int C, int H, int W, const float* __restrict__ pred,
     const float* __restrict__ gt, Win win, const float* __restrict__ dmaps, const float* __restrict__ grad_loss,
-    float scale_l1, float scale_ssim, float* __restrict__ dL_dpred) {
+    float scale_l1, float scale_ssim, float* __restrict__ dL_dpred, const float* __restrict__ partials, int nblocks,
+    double inv_n, float lambda_l1, float lambda_ssim, float* __restrict__ loss3) {
   __shared__ float s_m[3][IH][IP];
   __shared__ float s_h[3][IH][HP];
   const int c  = blockIdx.z;
@@ -252,6 +259,12 @@ __global__ void __launch_bounds__(256) image_loss_backward_kernel(int C, int H, 
       dL_dpred[oo] = g * (scale_ssim * (v[o][0] + 2.f * x * v[o][1] + y * v[o][2]) + scale_l1 * sgn);
     }
   }
+  // the loss value itself, when the forward left it to this launch (one workgroup, off everybody else's critical path)
+  if (loss3 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    __syncthreads();
+    double* s_a = reinterpret_cast<double*>(&s_m[0][0][0]);  // 2 x 256 doubles fit the first staging plane
+    finalize_loss(nblocks, inv_n, lambda_l1, lambda_ssim, partials, loss3, s_a, s_a + 256);
+  }
 }
 
 Win make_window() {
@@ -280,7 +293,7 @@ size_t skgs_image_loss_workspace_bytes(int32_t C, int32_t H, int32_t W) {
 
 int skgs_image_loss_forward(int32_t C, int32_t H, int32_t W, const float* pred, const float* gt, float lambda_l1,
     float lambda_ssim, float* loss3, void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
-  SKGS_REQUIRE(C > 0 && H > 0 && W > 0 && pred && gt && loss3 && workspace, "image_loss_forward: bad argument");
+  SKGS_REQUIRE(C > 0 && H > 0 && W > 0 && pred && gt && workspace, "image_loss_forward: bad argument");
   SKGS_REQUIRE(workspace_bytes >= skgs_image_loss_workspace_bytes(C, H, W), "image_loss_forward: workspace too small");
   hipStream_t s   = (hipStream_t) stream;
   float* dmaps    = reinterpret_cast<float*>(workspace);
@@ -288,23 +301,28 @@ int skgs_image_loss_forward(int32_t C, int32_t H, int32_t W, const float* pred, 
   dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, C);
   hipLaunchKernelGGL(image_loss_forward_kernel, grid, dim3(256), 0, s, C, H, W, pred, gt, make_window(), dmaps, partials);
   SKGS_CHECK_HIP(hipGetLastError());
-  const int nblocks = grid.x * grid.y * grid.z;
-  hipLaunchKernelGGL(image_loss_finalize_kernel, dim3(1), dim3(256), 0, s, nblocks, 1.0 / ((double) C * H * W), lambda_l1,
-      lambda_ssim, partials, loss3);
-  SKGS_CHECK_HIP(hipGetLastError());
+  if (loss3) {  // NULL: the caller asks skgs_image_loss_backward for the value (saves this launch)
+    const int nblocks = grid.x * grid.y * grid.z;
+    hipLaunchKernelGGL(image_loss_finalize_kernel, dim3(1), dim3(256), 0, s, nblocks, 1.0 / ((double) C * H * W), lambda_l1,
+        lambda_ssim, partials, loss3);
+    SKGS_CHECK_HIP(hipGetLastError());
+  }
   return 0;
 }
 
 int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred, const float* gt, float lambda_l1,
     float lambda_ssim, const float* grad_loss /*device scalar or NULL (=1)*/, const void* workspace,
-    size_t workspace_bytes, float* dL_dpred, skgs_stream_t stream) {
+    size_t workspace_bytes, float* dL_dpred, float* loss3 /*NULL, or where to put the forward's loss values*/,
+    skgs_stream_t stream) {
   SKGS_REQUIRE(C > 0 && H > 0 && W > 0 && pred && gt && workspace && dL_dpred, "image_loss_backward: bad argument");
   SKGS_REQUIRE(workspace_bytes >= skgs_image_loss_workspace_bytes(C, H, W), "image_loss_backward: workspace too small");
   const float* dmaps = reinterpret_cast<const float*>(workspace);
   const float n      = (float) ((double) C * H * W);
   dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, C);
+  const float* partials = dmaps + (size_t) 3 * C * H * W;
   hipLaunchKernelGGL(image_loss_backward_kernel, grid, dim3(256), 0, (hipStream_t) stream, C, H, W, pred, gt, make_window(),
-      dmaps, grad_loss, lambda_l1 / n, -lambda_ssim / n, dL_dpred);
+      dmaps, grad_loss, lambda_l1 / n, -lambda_ssim / n, dL_dpred, partials, (int) (grid.x * grid.y * grid.z),
+      1.0 / ((double) C * H * W), lambda_l1, lambda_ssim, loss3);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -47,7 +47,7 @@ class FusedViewStep:
 
     def __init__(self, model: SkinnedGaussians, W: int, H: int, capacity: int, lambda_dssim: float = 0.2,
                  background: Optional[Tensor] = None, grad_scale: float = 1.0, densify_stats: bool = False,
-                 spw_logit_grad: Optional[Tensor] = None):
+                 spw_logit_grad: Optional[Tensor] = None, tables_zeroed_by_optimizer: bool = False):
         assert not model.static, 'FusedViewStep covers the skinned stage (M >= 1)'
         self.model, self.W, self.H = model, int(W), int(H)
         self.lambda_l1, self.lambda_ssim = 1.0 - lambda_dssim, lambda_dssim
@@ -90,6 +90,9 @@ class FusedViewStep:
         self.g_bone_T = torch.empty((M, 7), **f32)
         self.deform_ws = torch.empty((lib.skgs_lbs_deform_backward_workspace_bytes(C.c_int32(P), C.c_int32(M)),), **u8)
         self.bwd_ws = torch.zeros((lib.skgs_backward_workspace_bytes(C.c_int32(P)),), **u8)  # kept zero between steps
+        # the optimizer clears the per-frame table gradients after its update (FusedAdam(zero_after_step=
+        # step.table_grad_span())): no fill launch at the start of the step
+        self.tables_zeroed_by_optimizer = bool(tables_zeroed_by_optimizer)
         # view-parallel training: [P*K] float32 view that receives the compact LBS-logit gradient (see backward_skinning)
         self.spw_logit_grad = spw_logit_grad
         assert spw_logit_grad is None or (spw_logit_grad.numel() == P * K and spw_logit_grad.is_contiguous())
@@ -114,8 +117,23 @@ class FusedViewStep:
         self._bufs = _C._buffers(self.geom, self.binning, self.img)
 
     # ------------------------------------------------------------------------------------------------------------
+    def table_grad_span(self) -> Optional[Tensor]:
+        """the per-frame tables' gradients as ONE contiguous float32 view (they are adjacent in a flat gradient buffer),
+        or None when they are not adjacent"""
+        m = self.model
+        tabs = [t.grad for t in (m.sk_r, m.sk_d_rot, m.sk_d_scale, m.global_tr) if t is not None]
+        lo = min(t.data_ptr() for t in tabs)
+        total = sum(t.numel() for t in tabs)
+        first = min(tabs, key=lambda t: t.data_ptr())
+        same = all(t.untyped_storage().data_ptr() == first.untyped_storage().data_ptr() for t in tabs)
+        if same and max(t.data_ptr() + t.numel() * 4 for t in tabs) - lo == total * 4:
+            return torch.as_strided(first, (total,), (1,))
+        return None
+
     @torch.no_grad()
     def _zero_table_grads(self):
+        if self.tables_zeroed_by_optimizer:
+            return
         """per-frame tables: only row ``time_id`` gets a gradient, every other row must read zero.  With a
         FlatGradBuffer the four tables are adjacent: one fill."""
         m = self.model
@@ -201,11 +219,12 @@ class FusedViewStep:
         a, d = self.forward(rs, time_id)
         # ---- loss and dL/dimage
         chk(lib.skgs_image_loss_forward(C.c_int32(3), C.c_int32(H), C.c_int32(W), _p(self.image), _p(target),
-                                        C.c_float(self.lambda_l1), C.c_float(self.lambda_ssim), _p(self.loss3),
+                                        C.c_float(self.lambda_l1), C.c_float(self.lambda_ssim), None,  # value: backward
                                         _p(self.loss_ws), C.c_size_t(self.loss_ws.numel()), st))
         chk(lib.skgs_image_loss_backward(C.c_int32(3), C.c_int32(H), C.c_int32(W), _p(self.image), _p(target),
                                          C.c_float(self.lambda_l1), C.c_float(self.lambda_ssim), _p(self.grad_scale),
-                                         _p(self.loss_ws), C.c_size_t(self.loss_ws.numel()), _p(self.dL_dimage), st))
+                                         _p(self.loss_ws), C.c_size_t(self.loss_ws.numel()), _p(self.dL_dimage),
+                                         _p(self.loss3), st))
         # ---- rasterize backward: SH gradients land in the parameters' .grad, the rest feeds the skinning backward
         g = _C._RasterGrads()
         g.dL_dout_color = self.dL_dimage.data_ptr()  # dL_dout_opacity = NULL: the background term is in-kernel

@@ -17,12 +17,16 @@ from sk_gs_amd import _C
 
 
 class FusedAdam:
-    def __init__(self, param_groups: Iterable[dict], betas=(0.9, 0.999), eps: float = 1e-15):
+    def __init__(self, param_groups: Iterable[dict], betas=(0.9, 0.999), eps: float = 1e-15,
+                 zero_after_step: 'torch.Tensor' = None):
         lib = _C.load_library()
         lib.skgs_adam_chunk_elems.restype = C.c_int64
         lib.skgs_adam_tensor_bytes.restype = C.c_size_t
         self.param_groups: List[dict] = [dict(g) for g in param_groups]
         self.betas, self.eps = betas, eps
+        # contiguous float32 gradient storage cleared by the step itself (see FusedViewStep(tables_zeroed_by_optimizer))
+        self.zero_after_step = zero_after_step
+        assert zero_after_step is None or (zero_after_step.is_contiguous() and zero_after_step.dtype == torch.float32)
         self._chunk = int(lib.skgs_adam_chunk_elems())
         assert int(lib.skgs_adam_tensor_bytes()) == 56
         self.params, self._lr_index = [], []
@@ -74,6 +78,9 @@ class FusedAdam:
             if any(p.grad is None or p.grad.data_ptr() != g for p, g in zip(self.params, self._bound_grads)):
                 self._upload()
         lib = _C.load_library()
+        z = self.zero_after_step
         _C._check(lib.skgs_adam_step(C.c_int32(len(self.params)), C.c_void_p(self._table.data_ptr()),
                                      C.c_int64(self._total_chunks), C.c_double(self.betas[0]), C.c_double(self.betas[1]),
-                                     C.c_double(self.eps), C.c_void_p(self.step_count.data_ptr()), _C._stream()))
+                                     C.c_double(self.eps), C.c_void_p(self.step_count.data_ptr()),
+                                     C.c_void_p(z.data_ptr() if z is not None else None),
+                                     C.c_int64(z.numel() if z is not None else 0), _C._stream()))

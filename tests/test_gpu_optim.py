@@ -35,3 +35,17 @@ def test_fused_adam_matches_torch():
     before = b[0].detach().clone()
     opt.step()
     assert float((b[0] - before).abs().max()) > 1e-3
+
+
+def test_fused_adam_clears_the_requested_gradient_span_after_the_update():
+    """zero_after_step: the launch that bumps the step counter also clears a gradient span (FusedViewStep's per-frame
+    table gradients), after the update has consumed it"""
+    from sk_gs_amd.optim import FusedAdam
+    flat = torch.ones(10 + 37, device='cuda')
+    a, b = torch.nn.Parameter(torch.zeros(10, device='cuda')), torch.nn.Parameter(torch.zeros(37, device='cuda'))
+    a.grad, b.grad = flat[:10], flat[10:]
+    opt = FusedAdam([{'params': [a, b], 'lr': 0.1}], zero_after_step=flat[10:])
+    opt.step()
+    torch.cuda.synchronize()
+    assert float(a.grad.min()) == 1.0 and float(b.grad.abs().max()) == 0.0
+    assert float(b.data.max()) < 0.0 and float(opt.step_count.item()) == 1.0  # b was updated with the gradient first
