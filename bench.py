@@ -164,6 +164,8 @@ def main():
     dev = torch.device('cuda', local_rank)
     _C.load_library()
     cfg = CONFIGS[args.config]
+    if cfg['M'] == 0:  # static stage (config #0): no skinning, the operator path runs it
+        args.autograd = True
     P, M, K, W, H = cfg['P'], cfg['M'], cfg['K'], cfg['W'], cfg['H']
     if args.ppl:
         _C.set_pixels_per_lane(args.ppl)

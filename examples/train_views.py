@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Minimal training loop on a synthetic skinned scene: what a user of the reference's `train.py` loop looks like on
+sk_gs_amd.  One process per GPU (`python -m torch.distributed.run --nproc-per-node N examples/train_views.py`) or a
+single process.
+
+    FusedViewStep   : bone chain -> KNN / LBS weights -> skinning -> rasterize -> 0.8 L1 + 0.2 (1 - SSIM) -> backward,
+                      all as direct calls into libskgs_hip.so, gradients written into the parameters' .grad
+    FusedAdam       : every parameter group in one launch (eps = 1e-15, the reference's learning-rate ratios)
+    GraphedSteps    : the whole step replayed as one hipGraph per training view (two per view with > 1 rank)
+    ViewParallel    : one flat gradient buffer, one RCCL all-reduce per step
+"""
+import argparse
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gaussians', type=int, default=20000)
+    ap.add_argument('--bones', type=int, default=12)
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--views', type=int, default=8)
+    ap.add_argument('--iters', type=int, default=400)
+    ap.add_argument('--lr', type=float, default=1e-3)
+    args = ap.parse_args()
+
+    from sk_gs_amd import _C, scene
+    from sk_gs_amd.fused_step import FusedViewStep
+    from sk_gs_amd.model import SkinnedGaussians
+    from sk_gs_amd.optim import FusedAdam
+    from sk_gs_amd.train_step import GraphedSteps
+    from sk_gs_amd.view_parallel import ViewParallel, init_distributed
+
+    rank, world, local_rank = init_distributed()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    P, M, W = args.gaussians, args.bones, args.size
+    # "ground truth": a scene rendered from a second, perturbed set of parameters
+    teacher = SkinnedGaussians(P, M, 4, num_frames=args.views, seed=1).to(dev)
+    model = SkinnedGaussians(P, M, 4, num_frames=args.views, seed=1).to(dev)
+    with torch.no_grad():
+        model._features_dc.mul_(0.5)
+        model._opacity.sub_(0.5)
+    cams = [scene.make_camera(W, W, seed=i) for i in range(args.views)]
+    views = [scene.raster_settings_from_camera(c, sh_degree=3, colmap=True, device=dev) for c in cams]
+    bg = torch.ones(3, device=dev)
+    _C.config.sync_num_rendered = True
+    with torch.no_grad():
+        outs = [teacher.render(views[v], time_id=v, background=bg) for v in range(args.views)]
+    targets = [o['images'].contiguous() for o in outs]
+    capacity = int(max(o['buffer'].R for o in outs) * 2.5) + 4096
+
+    vp = ViewParallel(model.parameters())                       # p.grad -> views of one flat buffer
+    step = FusedViewStep(model, W, W, capacity=capacity, background=bg, grad_scale=1.0 / world, densify_stats=True)
+    opt = FusedAdam(model.param_groups(lr=args.lr), eps=1e-15)
+    if world == 1:
+        graphs = GraphedSteps(lambda v: (step.forward_backward(views[v], v, targets[v]), opt.step()))
+        run = graphs
+    else:
+        g_fb = GraphedSteps(lambda v: step.forward_backward(views[v], v, targets[v]))
+        g_opt = GraphedSteps(lambda _: opt.step())
+
+        def run(v):
+            g_fb(v)
+            vp.allreduce_grads(prescaled=True)
+            g_opt(0)
+
+    step.forward_backward(views[0], 0, targets[0])                # warm-up outside any capture
+    opt.step()
+    for it in range(args.iters):
+        run(vp.view_index(it, args.views))
+        if rank == 0 and (it % 100 == 0 or it == args.iters - 1):
+            l = step.loss3.tolist()                               # synchronises
+            print(f'iter {it:5d}  loss {l[0]:.5f}  (L1 {l[1]:.5f}, SSIM {l[2]:.4f})  {step.status()}')
+    if rank == 0:
+        print('visible at least once:', int((step.denom > 0).sum()), 'of', P, 'Gaussians; max screen radius',
+              float(step.max_radii2D.max()))
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
