@@ -136,6 +136,9 @@ def main():
                          'of launch / stream-join overhead per step on one GPU, so it only pays when the all-reduce is slow)')
     ap.add_argument('--dense-spw-grad', action='store_true',
                     help='world > 1: all-reduce the dense [P,M] sp_W gradient instead of the compact [P,K] logit gradient')
+    ap.add_argument('--compact-lists', action='store_true',
+                    help='count -> scan -> scatter into compact tile lists (the reference layout) instead of fixed per-tile '
+                         'buckets (no counting / scan launch)')
     ap.add_argument('--deform-net', action='store_true',
                     help='produce the joint rotations / d_rot / d_scale with the 8x256 deform network inside every step '
                          '(scope row (f)-3: +24 launches, +0.5M parameters in Adam) instead of the per-frame tables')
@@ -207,11 +210,15 @@ def main():
         comm_bytes = vp.grads.nbytes
     # ---------------------------------------------------------------- learn R per view with the synchronising path
     _C.config.sync_num_rendered = True
-    Rs = []
+    Rs, longest = [], 0
     with torch.no_grad():  # no autograd graph may stay alive across a capture (see sk_gs_amd/train_step.py)
         for v in range(args.views):
-            Rs.append(model.render(settings[v], time_id=v % frames, background=background)['buffer'].R)
+            buf = model.render(settings[v], time_id=v % frames, background=background)['buffer']
+            Rs.append(buf.R)
+            longest = max(longest, _C.read_status(buf.geomBuffer)['max_tile_count'])
     R_mean, R_max = sum(Rs) / len(Rs), max(Rs)
+    # fixed slots per tile for the bucket layout: 1.5x the longest list seen, rounded up to 64
+    tile_bucket = 0 if args.compact_lists else ((int(longest * 1.5) + 63) // 64) * 64
     _C.config.sync_num_rendered = False
     _C.update_capacity_hint(P, W, H, int(R_max * 1.25))
 
@@ -221,7 +228,7 @@ def main():
         from sk_gs_amd.fused_step import FusedViewStep
         fstep = FusedViewStep(model, W, H, capacity=int(R_max * 1.25 * _C.config.capacity_growth) + 1024,
                               background=background, grad_scale=1.0 / world,
-                              spw_logit_grad=vp.extra_views[-1] if compact else None)
+                              spw_logit_grad=vp.extra_views[-1] if compact else None, tile_bucket=tile_bucket)
         # the per-frame table gradients (one row written per step) are cleared by the Adam launch itself
         table_span = None if args.torch_adam else fstep.table_grad_span()
         fstep.tables_zeroed_by_optimizer = table_span is not None
@@ -421,6 +428,8 @@ def main():
                            f'flat-buffer grad all-reduce ({comm_bytes / 1e6:.1f} MB'
                            + (', compact LBS-logit gradient' if compact else '') + ')'),
                        'launch': 'eager' if args.eager else 'one hipGraph replay per view step',
+                       'tile_lists': 'compact (count, scan, scatter)' if (args.autograd or args.compact_lists)
+                       else f'buckets of {tile_bucket} slots per tile (longest list {longest})',
                        'joint_rotations': 'deform network (8x256 MLP) inside the step' if args.deform_net
                        else 'per-frame tables (the reference\'s sk_cache)',
                        'step': 'autograd operator path' if args.autograd else 'FusedViewStep (direct C-ABI calls)'},

@@ -74,6 +74,11 @@ typedef struct skgs_raster_inputs {
   const float* background; /* [3]: out_color = C + T * bg inside the blend kernel (upstream diff_gaussian_rasterization
                               forward.cu renderCUDA epilogue; the in-tree variant composites in torch, sk_gs.py:1236) and
                               its dL/dT term in the backward */
+  int32_t tile_bucket_capacity; /* 0: the reference's compact tile lists (count -> scan -> scatter).  Lcap > 0 ("bucket"
+                              layout, skgs_rasterize_forward only): tile t owns the fixed slots [t Lcap, (t+1) Lcap) of a
+                              binning buffer of T * Lcap instances, so the counting and scan launches disappear; a tile
+                              with more than Lcap instances drops the excess and sets the overflow flag; num_rendered
+                              and max_tile_count of skgs_status read -1. */
 } skgs_raster_inputs;
 
 typedef struct skgs_raster_buffers {

@@ -39,6 +39,7 @@ class _RasterInputs(C.Structure):
         ('means3D', C.c_void_p), ('opacity', C.c_void_p), ('sh', C.c_void_p), ('scales', C.c_void_p),
         ('rotations', C.c_void_p), ('extras', C.c_void_p), ('colors_precomp', C.c_void_p),
         ('cov3D_precomp', C.c_void_p), ('sh_rest', C.c_void_p), ('background', C.c_void_p),
+        ('tile_bucket_capacity', C.c_int32),
     ]
 
 

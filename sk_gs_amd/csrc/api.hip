@@ -131,6 +131,7 @@ size_t skgs_backward_workspace_bytes(int32_t P) { return (size_t) P * GRAD_ROW *
 int skgs_rasterize_forward_stage1(const skgs_raster_inputs* in, const skgs_raster_buffers* buf, int32_t* radii,
     int32_t* host_num_rendered, skgs_stream_t stream) {
   if (check_inputs(in) || check_buffers(in, buf, false)) return 1;
+  SKGS_REQUIRE(in->tile_bucket_capacity <= 0, "tile_bucket_capacity: use skgs_rasterize_forward (no two-stage form)");
   SKGS_REQUIRE(radii != nullptr || in->P == 0, "radii output is required");
   hipStream_t s = (hipStream_t) stream;
   GeomView g    = geom_view(buf->geom);
@@ -157,6 +158,24 @@ int skgs_rasterize_forward_stage2(const skgs_raster_inputs* in, const skgs_raste
 
 int skgs_rasterize_forward(const skgs_raster_inputs* in, const skgs_raster_buffers* buf, int32_t* radii, float* out_color,
     float* out_opacity, float* out_extra, int32_t* host_num_rendered, skgs_stream_t stream) {
+  if (in && in->tile_bucket_capacity > 0) {
+    // bucket layout: preprocess (clears the per-tile cursors) -> scatter into the tiles' fixed slots -> sort -> blend
+    if (check_inputs(in) || check_buffers(in, buf, true)) return 1;
+    SKGS_REQUIRE(radii != nullptr || in->P == 0, "radii output is required");
+    SKGS_REQUIRE(out_color && out_opacity, "out_color / out_opacity are required");
+    SKGS_REQUIRE(!(in->extras && in->E > 0) || out_extra, "out_extra is required when extras are given");
+    SKGS_REQUIRE(host_num_rendered == nullptr, "the bucket layout does not compute num_rendered");
+    hipStream_t s = (hipStream_t) stream;
+    GeomView g    = geom_view(buf->geom);
+    ImgView im    = img_view(buf->img, in->image_width, in->image_height);
+    BinView b     = bin_view(buf->binning, buf->binning_bytes);
+    SKGS_REQUIRE(b.capacity >= (int64_t) im.T * in->tile_bucket_capacity,
+        "binning buffer too small for tiles x tile_bucket_capacity instances");
+    SKGS_REQUIRE((int64_t) im.T * in->tile_bucket_capacity < (int64_t) 1 << 32, "tiles x tile_bucket_capacity must fit 32 bits");
+    if (launch_preprocess_forward(*in, g, im, radii, s)) return 1;
+    if (launch_scatter_sort(*in, g, im, b, s)) return 1;
+    return launch_render_forward(*in, g, im, b, out_color, out_opacity, out_extra, s);
+  }
   if (skgs_rasterize_forward_stage1(in, buf, radii, host_num_rendered, stream)) return 1;
   return skgs_rasterize_forward_stage2(in, buf, out_color, out_opacity, out_extra, stream);
 }

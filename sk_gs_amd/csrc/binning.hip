@@ -22,7 +22,8 @@ constexpr int SCAN_THREADS = 1024;
 
 // Single-workgroup exclusive scan of tile_counts[T] -> tile_offsets[T+1]; zeroes cursors; publishes R.
 __global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(int T, const uint32_t* __restrict__ counts,
-    uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursors, GeomHeader* hdr) {
+    uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursors, uint32_t* __restrict__ tile_begin,
+    uint32_t* __restrict__ tile_end, GeomHeader* hdr) {
   __shared__ uint32_t wave_tot[SCAN_THREADS / WAVE];
   __shared__ uint32_t wave_max[SCAN_THREADS / WAVE];
   __shared__ uint32_t carry_s;
@@ -48,6 +49,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(int T, const u
     if (i < T) {
       offsets[i] = carry + wprefix + v - c;
       cursors[i] = 0;
+      tile_begin[i] = carry + wprefix + v - c, tile_end[i] = carry + wprefix + v;
     }
     __syncthreads();
     if (tid == SCAN_THREADS - 1) carry_s = carry + wprefix + v;
@@ -64,6 +66,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(int T, const u
     hdr->num_rendered   = (int32_t) carry_s;
     hdr->max_tile_count = (int32_t) m;
     hdr->overflow       = 0;
+    hdr->big_tiles      = 0;
   }
 }
 
@@ -92,9 +95,9 @@ __global__ void __launch_bounds__(256) count_tiles_kernel(int P, int gx, int gy,
 // Writes (depth_bits<<32 | id) into every touched tile's range.
 __global__ void __launch_bounds__(256) scatter_kernel(int P, int gx, int gy, const float4* __restrict__ recs,
     const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursors, uint64_t* __restrict__ keys, int64_t capacity,
-    GeomHeader* hdr) {
+    GeomHeader* hdr, int bucket) {
   const int64_t tid = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid == 0 && (int64_t) hdr->num_rendered > capacity) hdr->overflow = 1, hdr->overflow_events += 1;
+  if (!bucket && tid == 0 && (int64_t) hdr->num_rendered > capacity) hdr->overflow = 1, hdr->overflow_events += 1;
   const int idx = (int) (tid / LPG);
   if (idx >= P) return;
   const float4 r2  = recs[3 * idx + 2];
@@ -107,8 +110,12 @@ __global__ void __launch_bounds__(256) scatter_kernel(int P, int gx, int gy, con
   const int w = mx[0] - mn[0], n = w * (mx[1] - mn[1]);
   for (int k = (int) (tid % LPG); k < n; k += LPG) {
     const int t        = (mn[1] + k / w) * gx + mn[0] + k % w;
-    const uint32_t pos = offsets[t] + atomicAdd(&cursors[t], 1u);
-    if ((int64_t) pos < capacity) keys[pos] = key;
+    const uint32_t slot = atomicAdd(&cursors[t], 1u);
+    if (bucket) {
+      if (slot < (uint32_t) bucket) keys[(size_t) t * bucket + slot] = key;
+    } else if ((int64_t) offsets[t] + slot < capacity) {
+      keys[offsets[t] + slot] = key;
+    }
   }
 }
 
@@ -163,11 +170,12 @@ __global__ void __launch_bounds__(BIN_THREADS) count_tiles_lds_kernel(int P, int
 
 __global__ void __launch_bounds__(BIN_THREADS) scatter_lds_kernel(int P, int gx, int gy, int T, const float4* __restrict__ recs,
     const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursors, uint64_t* __restrict__ keys, int64_t capacity,
-    GeomHeader* hdr) {
+    GeomHeader* hdr, int bucket /* 0: compact lists at offsets[]; > 0: tile t owns slots [t * bucket, (t + 1) * bucket) */) {
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_cnt  = s_mem;      // [T] entries of this workgroup per tile, then the running local rank
   uint32_t* s_base = s_mem + T;  // [T] offsets[t] + slots reserved for this workgroup
-  if (blockIdx.x == 0 && threadIdx.x == 0 && (int64_t) hdr->num_rendered > capacity) hdr->overflow = 1, hdr->overflow_events += 1;
+  if (!bucket && blockIdx.x == 0 && threadIdx.x == 0 && (int64_t) hdr->num_rendered > capacity)
+    hdr->overflow = 1, hdr->overflow_events += 1;
   for (int i = threadIdx.x; i < T; i += BIN_THREADS) s_cnt[i] = 0;
   __syncthreads();
   const int64_t lanes  = (int64_t) P * LPG;
@@ -181,7 +189,7 @@ __global__ void __launch_bounds__(BIN_THREADS) scatter_lds_kernel(int P, int gx,
   __syncthreads();
   for (int i = threadIdx.x; i < T; i += BIN_THREADS) {
     const uint32_t c = s_cnt[i];
-    s_base[i]        = c ? offsets[i] + atomicAdd(&cursors[i], c) : 0u;
+    s_base[i]        = c ? (bucket ? 0u : offsets[i]) + atomicAdd(&cursors[i], c) : 0u;  // bucket: index inside the tile
     s_cnt[i]         = 0;
   }
   __syncthreads();
@@ -194,7 +202,11 @@ __global__ void __launch_bounds__(BIN_THREADS) scatter_lds_kernel(int P, int gx,
     for (int k = (int) (tid % LPG); k < n; k += LPG) {
       const int t        = (mn[1] + k / w) * gx + mn[0] + k % w;
       const uint32_t pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
-      if ((int64_t) pos < capacity) keys[pos] = key;
+      if (bucket) {
+        if (pos < (uint32_t) bucket) keys[(size_t) t * bucket + pos] = key;  // entries beyond the bucket are dropped (flagged)
+      } else if ((int64_t) pos < capacity) {
+        keys[pos] = key;
+      }
     }
   }
 }
@@ -230,23 +242,25 @@ __device__ __forceinline__ void bitonic_any(KeyPtr k, int L, int n /*pow2 >= L*/
   }
 }
 
-__global__ void __launch_bounds__(SORT_THREADS) tile_sort_kernel(int T, int min_len, const GeomHeader* __restrict__ hdr,
-    const uint32_t* __restrict__ offsets, uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list,
-    int64_t capacity) {
+// Lists longer than the one-wave register sort handles (rare): the wave kernel below queues them in `worklist`.
+__global__ void __launch_bounds__(SORT_THREADS) tile_sort_kernel(const GeomHeader* __restrict__ hdr,
+    const uint32_t* __restrict__ worklist, const uint32_t* __restrict__ tile_begin, const uint32_t* __restrict__ tile_end,
+    uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list, int64_t capacity) {
   __shared__ uint64_t sk[SORT_LDS_MAX];
   const int tid = threadIdx.x;
-  if (hdr->max_tile_count <= min_len) return;  // the usual case: every list was sorted by tile_sort_wave_kernel
-  for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {  // grid-stride: only lists longer than min_len are sorted here
-    const int64_t s64 = offsets[tile], e64 = min<int64_t>((int64_t) offsets[tile + 1], capacity);
+  const int nbig = hdr->big_tiles;  // the usual case: 0
+  for (int w = blockIdx.x; w < nbig; w += gridDim.x) {
+    const int tile    = (int) worklist[w];
+    const int64_t s64 = tile_begin[tile], e64 = min<int64_t>((int64_t) tile_end[tile], capacity);
     const int L = (int) (e64 - s64);
-    if (L <= min_len) continue;
+    if (L <= 1) continue;
     uint64_t* gk = keys + s64;
     int n = 1;
     while (n < L) n <<= 1;
     if (L <= SORT_LDS_MAX) {
       for (int i = tid; i < L; i += SORT_THREADS) sk[i] = gk[i];
       __syncthreads();
-      if (L > 1) bitonic_any(sk, L, n, tid);
+      bitonic_any(sk, L, n, tid);
       for (int i = tid; i < L; i += SORT_THREADS) {
         const uint64_t v    = sk[i];
         gk[i]               = v;
@@ -254,7 +268,7 @@ __global__ void __launch_bounds__(SORT_THREADS) tile_sort_kernel(int T, int min_
       }
       __syncthreads();
     } else {
-      // rare: list longer than the LDS window -> same network on global memory (one workgroup, L1/L2 resident)
+      // list longer than the LDS window -> same network on global memory (one workgroup, L1/L2 resident)
       bitonic_any(gk, L, n, tid);
       for (int i = tid; i < L; i += SORT_THREADS) point_list[s64 + i] = (uint32_t) gk[i];
     }
@@ -320,16 +334,31 @@ __device__ __forceinline__ void wave_sort_tile(uint64_t* __restrict__ gk, uint32
   }
 }
 
-__global__ void __launch_bounds__(64) tile_sort_wave_kernel(int T, const uint32_t* __restrict__ offsets,
+__global__ void __launch_bounds__(64) tile_sort_wave_kernel(int T, int bucket, const uint32_t* __restrict__ cursors,
+    uint32_t* __restrict__ tile_begin, uint32_t* __restrict__ tile_end, uint32_t* __restrict__ worklist, GeomHeader* hdr,
     uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list, int64_t capacity) {
   const int tile = blockIdx.x;
   if (tile >= T) return;
-  const int64_t s64 = offsets[tile], e64 = min<int64_t>((int64_t) offsets[tile + 1], capacity);
+  const int lane = threadIdx.x;
+  int64_t s64, e64;
+  if (bucket) {  // bucket layout: the per-tile cursor is the count; this kernel publishes the tile's range
+    const uint32_t cnt = cursors[tile];
+    s64 = (int64_t) tile * bucket, e64 = s64 + min(cnt, (uint32_t) bucket);
+    if (lane == 0) {
+      tile_begin[tile] = (uint32_t) s64, tile_end[tile] = (uint32_t) e64;
+      if (cnt > (uint32_t) bucket) hdr->overflow = 1, atomicAdd(&hdr->overflow_events, 1);
+    }
+  } else {
+    s64 = tile_begin[tile], e64 = min<int64_t>((int64_t) tile_end[tile], capacity);
+  }
   const int L = (int) (e64 - s64);
-  if (L <= 0 || L > 64 * WSORT_MAX_E) return;  // longer lists: tile_sort_kernel
+  if (L <= 0) return;
+  if (L > 64 * WSORT_MAX_E) {  // tile_sort_kernel
+    if (lane == 0) worklist[atomicAdd(&hdr->big_tiles, 1)] = (uint32_t) tile;
+    return;
+  }
   uint64_t* gk = keys + s64;
   uint32_t* pl = point_list + s64;
-  const int lane = threadIdx.x;
   if (L <= 64)
     wave_sort_tile<1>(gk, pl, L, lane);
   else if (L <= 128)
@@ -357,7 +386,7 @@ int launch_scan_tiles(GeomView g, ImgView im, int64_t P, hipStream_t s) {
     SKGS_CHECK_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, im.T, im.tile_counts, im.tile_offsets,
-      im.cursors, g.hdr);
+      im.cursors, im.tile_begin, im.tile_end, g.hdr);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -365,24 +394,25 @@ int launch_scan_tiles(GeomView g, ImgView im, int64_t P, hipStream_t s) {
 int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, BinView b, hipStream_t s) {
   const int P = in.P;
   if (P == 0) return 0;
+  const int bucket = in.tile_bucket_capacity > 0 ? in.tile_bucket_capacity : 0;
   {
     ProfScope prof(K_SCATTER, s);
     const int64_t lanes = (int64_t) P * LPG;
     if (im.T <= BIN_LDS_TILES)
       hipLaunchKernelGGL(scatter_lds_kernel, dim3(bin_groups()), dim3(BIN_THREADS), (size_t) im.T * 8, s, P, im.tiles_x,
-          im.tiles_y, im.T, g.recs, im.tile_offsets, im.cursors, b.keys, b.capacity, g.hdr);
+          im.tiles_y, im.T, g.recs, im.tile_offsets, im.cursors, b.keys, b.capacity, g.hdr, bucket);
     else
       hipLaunchKernelGGL(scatter_kernel, dim3((unsigned) ((lanes + 255) / 256)), dim3(256), 0, s, P, im.tiles_x, im.tiles_y,
-          g.recs, im.tile_offsets, im.cursors, b.keys, b.capacity, g.hdr);
+          g.recs, im.tile_offsets, im.cursors, b.keys, b.capacity, g.hdr, bucket);
   }
   SKGS_CHECK_HIP(hipGetLastError());
   {
     ProfScope prof(K_SORT, s);
-    hipLaunchKernelGGL(tile_sort_wave_kernel, dim3(im.T), dim3(64), 0, s, im.T, im.tile_offsets, b.keys, b.point_list,
-        b.capacity);
-    // lists longer than 1024 keys (rare): a few workgroups scan the tile table and sort those in LDS / global memory
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(std::min(im.T, 128)), dim3(SORT_THREADS), 0, s, im.T, 64 * WSORT_MAX_E, g.hdr,
-        im.tile_offsets, b.keys, b.point_list, b.capacity);
+    hipLaunchKernelGGL(tile_sort_wave_kernel, dim3(im.T), dim3(64), 0, s, im.T, bucket, im.cursors, im.tile_begin,
+        im.tile_end, im.worklist, g.hdr, b.keys, b.point_list, b.capacity);
+    // lists longer than 1024 keys (rare): a few workgroups drain the worklist, sorting in LDS / global memory
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(std::min(im.T, 128)), dim3(SORT_THREADS), 0, s, g.hdr, im.worklist,
+        im.tile_begin, im.tile_end, b.keys, b.point_list, b.capacity);
   }
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;

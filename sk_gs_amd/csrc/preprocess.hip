@@ -295,7 +295,8 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
     const float* __restrict__ cov3D_precomp,
     const float* __restrict__ colors_precomp, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
     const float* __restrict__ campos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
-    int gx, int gy, int32_t* __restrict__ radii, float4* __restrict__ recs, uint32_t* __restrict__ tile_counts) {
+    int gx, int gy, int32_t* __restrict__ radii, float4* __restrict__ recs, uint32_t* __restrict__ tile_counts,
+    GeomHeader* hdr_bucket /* bucket layout: tile_counts are the per-tile cursors and the status words start here */) {
   __shared__ Cam cam;
   if (threadIdx.x < 16) {
     cam.view[threadIdx.x] = viewmatrix[threadIdx.x];
@@ -306,6 +307,9 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   // the per-tile counters of the next kernel (binning.hip: count_tiles) start from zero: cleared here, not by a fill launch
   for (int t = idx; t < gx * gy; t += gridDim.x * blockDim.x) tile_counts[t] = 0u;
+  if (hdr_bucket && idx == 0) {  // no scan kernel in the bucket layout: R and the longest list are not computed
+    hdr_bucket->num_rendered = -1, hdr_bucket->max_tile_count = -1, hdr_bucket->overflow = 0, hdr_bucket->big_tiles = 0;
+  }
   // this workgroup's SH rows -> LDS (coefficient 0 through my_dc, coefficients >= 1 through my_sh, see sh_to_rgb)
   extern __shared__ float s_sh[];
   const float *my_dc = nullptr, *my_sh = nullptr;
@@ -808,8 +812,9 @@ int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView 
   const int P = in.P;
   const float focal_y = in.image_height / (2.0f * in.tanfovy);
   const float focal_x = in.image_width / (2.0f * in.tanfovx);
-  if (P == 0) return fill_u32(im.tile_counts, 0u, (size_t) im.T, s);
+  if (P == 0) return fill_u32(im.tile_counts, 0u, (size_t) im.T, s) || fill_u32(im.cursors, 0u, (size_t) im.T, s);
   ProfScope prof(K_PREPROCESS_FWD, s);
+  const bool bucket = in.tile_bucket_capacity > 0;
   dim3 grid((P + PRE_THREADS - 1) / PRE_THREADS), block(PRE_THREADS);
   size_t lds = 0;
   if (in.sh && !in.colors_precomp) {
@@ -821,12 +826,12 @@ int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView 
     hipLaunchKernelGGL(preprocess_forward_kernel<true>, grid, block, lds, s, P, in.sh_degree, in.sh_coeffs, in.means3D,
         in.scales, in.scale_modifier, in.rotations, in.opacity, in.sh, in.sh_rest, in.cov3D_precomp, in.colors_precomp,
         in.viewmatrix, in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y,
-        im.tiles_x, im.tiles_y, radii, g.recs, im.tile_counts);
+        im.tiles_x, im.tiles_y, radii, g.recs, bucket ? im.cursors : im.tile_counts, bucket ? g.hdr : nullptr);
   else
     hipLaunchKernelGGL(preprocess_forward_kernel<false>, grid, block, lds, s, P, in.sh_degree, in.sh_coeffs, in.means3D,
         in.scales, in.scale_modifier, in.rotations, in.opacity, in.sh, in.sh_rest, in.cov3D_precomp, in.colors_precomp,
         in.viewmatrix, in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y,
-        im.tiles_x, im.tiles_y, radii, g.recs, im.tile_counts);
+        im.tiles_x, im.tiles_y, radii, g.recs, bucket ? im.cursors : im.tile_counts, bucket ? g.hdr : nullptr);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -145,14 +145,14 @@ __device__ __forceinline__ bool blend_alpha(const float4& a, const float4& b, fl
   return alpha >= ALPHA_MIN;
 }
 
-__global__ void __launch_bounds__(256) extra_forward_kernel(int W, int H, int gx, int E, const uint32_t* __restrict__ offsets,
+__global__ void __launch_bounds__(256) extra_forward_kernel(int W, int H, int gx, int E, TileRanges ranges,
     int64_t capacity, const uint32_t* __restrict__ point_list, const float4* __restrict__ recs,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ point_extra, float* __restrict__ pixel_extra) {
   const int tile = blockIdx.x;
   const int px = (tile % gx) * TILE + (threadIdx.x & 15), py = (tile / gx) * TILE + (threadIdx.x >> 4);
   if (!(px < W && py < H)) return;
   const uint32_t pid = (uint32_t) W * py + px;
-  const int64_t start = offsets[tile], end = min<int64_t>((int64_t) offsets[tile + 1], capacity);
+  const int64_t start = ranges.begin[tile], end = min<int64_t>((int64_t) ranges.end[tile], capacity);
   const uint32_t lastk = n_contrib[pid];
   float* out = pixel_extra + (size_t) pid * E;
   for (int es = 0; es < E; es += 16) {
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256) extra_forward_kernel(int W, int H, int gx
   }
 }
 
-__global__ void __launch_bounds__(256) extra_backward_kernel(int W, int H, int gx, int E, const uint32_t* __restrict__ offsets,
+__global__ void __launch_bounds__(256) extra_backward_kernel(int W, int H, int gx, int E, TileRanges ranges,
     int64_t capacity, const uint32_t* __restrict__ point_list, const float4* __restrict__ recs,
     const float* __restrict__ out_opacity, const uint32_t* __restrict__ n_contrib, const float* __restrict__ point_extra,
     const float* __restrict__ dL_dpixel_extra, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(256) extra_backward_kernel(int W, int H, int g
   const int px = (tile % gx) * TILE + (threadIdx.x & 15), py = (tile / gx) * TILE + (threadIdx.x >> 4);
   if (!(px < W && py < H)) return;
   const uint32_t pid = (uint32_t) W * py + px;
-  const int64_t start = offsets[tile], end = min<int64_t>((int64_t) offsets[tile + 1], capacity);
+  const int64_t start = ranges.begin[tile], end = min<int64_t>((int64_t) ranges.end[tile], capacity);
   const uint32_t lastk = n_contrib[pid];
   const float T_final = 1.0f - out_opacity[pid];
   const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
@@ -237,14 +237,14 @@ __global__ void __launch_bounds__(256) extra_backward_kernel(int W, int H, int g
   }
 }
 
-__global__ void __launch_bounds__(256) topk_kernel(int topk, int W, int H, int gx, const uint32_t* __restrict__ offsets,
+__global__ void __launch_bounds__(256) topk_kernel(int topk, int W, int H, int gx, TileRanges ranges,
     int64_t capacity, const uint32_t* __restrict__ point_list, const float4* __restrict__ recs,
     const uint32_t* __restrict__ n_contrib, int32_t* __restrict__ top_indices, float* __restrict__ top_weights) {
   const int tile = blockIdx.x;
   const int px = (tile % gx) * TILE + (threadIdx.x & 15), py = (tile / gx) * TILE + (threadIdx.x >> 4);
   if (!(px < W && py < H)) return;
   const uint32_t pid = (uint32_t) W * py + px;
-  const int64_t start = offsets[tile], end = min<int64_t>((int64_t) offsets[tile + 1], capacity);
+  const int64_t start = ranges.begin[tile], end = min<int64_t>((int64_t) ranges.end[tile], capacity);
   const uint32_t lastk = n_contrib[pid];
   float* tw   = top_weights + (size_t) pid * topk;
   int32_t* ti = top_indices + (size_t) pid * topk;
@@ -313,11 +313,11 @@ int launch_render_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, 
     const int nblk = xcd_grid(im.T * (4 / PPL_));                                                                       \
     if (g_strict)                                                                                                       \
       hipLaunchKernelGGL((blend_strict::render_forward_kernel<PPL_, E_>), dim3(nblk), dim3(64), 0, s, W, H, im.tiles_x, \
-          im.T, im.tile_offsets, b.capacity, b.point_list, g.recs, in.extras, in.background, im.n_contrib, out_color,   \
+          im.T, TileRanges{im.tile_begin, im.tile_end}, b.capacity, b.point_list, g.recs, in.extras, in.background, im.n_contrib, out_color,   \
           out_opacity, out_extra);                                                                                      \
     else                                                                                                                \
       hipLaunchKernelGGL((blend_fast::render_forward_kernel<PPL_, E_>), dim3(nblk), dim3(64), 0, s, W, H, im.tiles_x,   \
-          im.T, im.tile_offsets, b.capacity, b.point_list, g.recs, in.extras, in.background, im.n_contrib, out_color,   \
+          im.T, TileRanges{im.tile_begin, im.tile_end}, b.capacity, b.point_list, g.recs, in.extras, in.background, im.n_contrib, out_color,   \
           out_opacity, out_extra);                                                                                      \
   }
   if (ppl == 4) {
@@ -346,11 +346,11 @@ int launch_render_backward(const skgs_raster_inputs& in, GeomView g, ImgView im,
     const int nblk = xcd_grid(im.T * (4 / PPL_));                                                                      \
     if (g_strict)                                                                                                      \
       hipLaunchKernelGGL((blend_strict::render_backward_kernel<PPL_, E_>), dim3(nblk), dim3(64), 0, s, W, H,           \
- im.tiles_x, im.T, im.tile_offsets, b.capacity, b.point_list, g.recs, in.extras, in.background, out_opacity,       \
+ im.tiles_x, im.T, TileRanges{im.tile_begin, im.tile_end}, b.capacity, b.point_list, g.recs, in.extras, in.background, out_opacity,       \
           im.n_contrib, dL_dcolor, dL_dextra, dL_dopacity, gradacc);                                                               \
     else                                                                                                               \
       hipLaunchKernelGGL((blend_fast::render_backward_kernel<PPL_, E_>), dim3(nblk), dim3(64), 0, s, W, H, im.tiles_x, \
-          im.T, im.tile_offsets, b.capacity, b.point_list, g.recs, in.extras, in.background, out_opacity, im.n_contrib,   \
+          im.T, TileRanges{im.tile_begin, im.tile_end}, b.capacity, b.point_list, g.recs, in.extras, in.background, out_opacity, im.n_contrib,   \
           dL_dcolor, dL_dextra, dL_dopacity, gradacc);                                                                           \
   }
   if (ppl == 4) {
@@ -367,7 +367,7 @@ int launch_render_backward(const skgs_raster_inputs& in, GeomView g, ImgView im,
 
 int launch_extra_forward(int W, int H, int /*P*/, int E, const float* extra, GeomView g, ImgView im, BinView b,
     float* pixel_extra, hipStream_t s) {
-  hipLaunchKernelGGL(extra_forward_kernel, dim3(im.T), dim3(256), 0, s, W, H, im.tiles_x, E, im.tile_offsets, b.capacity,
+  hipLaunchKernelGGL(extra_forward_kernel, dim3(im.T), dim3(256), 0, s, W, H, im.tiles_x, E, TileRanges{im.tile_begin, im.tile_end}, b.capacity,
       b.point_list, g.recs, im.n_contrib, extra, pixel_extra);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
@@ -376,7 +376,7 @@ int launch_extra_forward(int W, int H, int /*P*/, int E, const float* extra, Geo
 int launch_extra_backward(int W, int H, int /*P*/, int E, const float* extra, const float* out_opacity,
     const float* grad_pixel_extra, GeomView g, ImgView im, BinView b, float* grad_means2D, float* grad_conic,
     float* grad_opacity, float* dL_dextra, hipStream_t s) {
-  hipLaunchKernelGGL(extra_backward_kernel, dim3(im.T), dim3(256), 0, s, W, H, im.tiles_x, E, im.tile_offsets, b.capacity,
+  hipLaunchKernelGGL(extra_backward_kernel, dim3(im.T), dim3(256), 0, s, W, H, im.tiles_x, E, TileRanges{im.tile_begin, im.tile_end}, b.capacity,
       b.point_list, g.recs, out_opacity, im.n_contrib, extra, grad_pixel_extra, grad_means2D, grad_conic, grad_opacity,
       dL_dextra);
   SKGS_CHECK_HIP(hipGetLastError());
@@ -384,7 +384,7 @@ int launch_extra_backward(int W, int H, int /*P*/, int E, const float* extra, co
 }
 
 int launch_topk(int topk, int W, int H, GeomView g, ImgView im, BinView b, int32_t* top_idx, float* top_w, hipStream_t s) {
-  hipLaunchKernelGGL(topk_kernel, dim3(im.T), dim3(256), 0, s, topk, W, H, im.tiles_x, im.tile_offsets, b.capacity,
+  hipLaunchKernelGGL(topk_kernel, dim3(im.T), dim3(256), 0, s, topk, W, H, im.tiles_x, TileRanges{im.tile_begin, im.tile_end}, b.capacity,
       b.point_list, g.recs, im.n_contrib, top_idx, top_w);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;

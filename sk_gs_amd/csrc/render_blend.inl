@@ -16,7 +16,7 @@ __device__ __forceinline__ float blend_exp(float x) {
 
 // ====================================================================================================== forward
 template <int PPL, int E>
-__global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx, int T, const uint32_t* __restrict__ offsets,
+__global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx, int T, TileRanges ranges,
     int64_t capacity, const uint32_t* __restrict__ point_list, const float4* __restrict__ recs,
     const float* __restrict__ extra, const float* __restrict__ bg, uint32_t* __restrict__ n_contrib,
     float* __restrict__ out_color, float* __restrict__ out_opacity, float* __restrict__ out_extra) {
@@ -32,8 +32,8 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
   __shared__ float s_c[WAVE];   // b
   __shared__ float s_e[E > 0 ? WAVE * E : 1];
 
-  const int64_t start = offsets[tile];
-  const int64_t end   = min<int64_t>((int64_t) offsets[tile + 1], capacity);
+  const int64_t start = ranges.begin[tile];
+  const int64_t end   = min<int64_t>((int64_t) ranges.end[tile], capacity);
   const WaveRect rect = wave_rect<PPL>(tile, sub, gx);
 
   float Tr[PPL], C[PPL][3], Ex[PPL][E > 0 ? E : 1];
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
 //   0 mean2D.x  1 mean2D.y  2 conic.x  3 conic.y  4 conic.w  5 opacity  6..8 colour  9..12 extras  13..15 unused
 // (fast build: slots 0..4 hold the moments sum w {dx, dy, dx^2, dx dy, dy^2} instead, see the kernel body)
 template <int PPL, int E>
-__global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int gx, int T, const uint32_t* __restrict__ offsets,
+__global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int gx, int T, TileRanges ranges,
     int64_t capacity, const uint32_t* __restrict__ point_list, const float4* __restrict__ recs,
     const float* __restrict__ extra, const float* __restrict__ bg, const float* __restrict__ out_opacity,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
@@ -182,8 +182,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
   __shared__ uint32_t s_id[WAVE];
   __shared__ float s_e[E > 0 ? WAVE * E : 1];
 
-  const int64_t start = offsets[tile];
-  const int64_t end   = min<int64_t>((int64_t) offsets[tile + 1], capacity);
+  const int64_t start = ranges.begin[tile];
+  const int64_t end   = min<int64_t>((int64_t) ranges.end[tile], capacity);
   const size_t HW     = (size_t) H * W;
 
   const WaveRect rect = wave_rect<PPL>(tile, sub, gx);

@@ -23,7 +23,8 @@ struct GeomHeader {
   int32_t max_tile_count;
   int32_t overflow_events;  // never reset by the library: forwards whose R exceeded the capacity since the caller zeroed it
   int32_t P;
-  int32_t pad[59];
+  int32_t big_tiles;        // tiles whose list is longer than the one-wave sort handles (worklist length, per forward)
+  int32_t pad[58];
 };
 static_assert(sizeof(GeomHeader) == 256, "header");
 
@@ -40,13 +41,23 @@ __host__ __device__ inline GeomView geom_view(void* base) {
 inline size_t geom_bytes(int32_t P) { return 256 + (size_t) P * 48 + 256; }
 
 // ---- img buffer ----------------------------------------------------------------------------------------
-// n_contrib[H*W] u32 | tile_counts[T] | tile_offsets[T+1] | cursors[T]       (each 256-B aligned)
+// n_contrib[H*W] u32 | tile_counts[T] | tile_offsets[T+1] | cursors[T] | tile_begin[T] | tile_end[T] | worklist[T]
+// (each 256-B aligned).  tile_begin / tile_end are what every consumer of the lists reads: the compact layout fills
+// them from the scan (begin = offsets[t], end = offsets[t+1]), the bucket layout (skgs_raster_inputs::
+// tile_bucket_capacity) from the per-tile cursors (begin = t * Lcap).
 struct ImgView {
   uint32_t* n_contrib;
   uint32_t* tile_counts;
   uint32_t* tile_offsets;
   uint32_t* cursors;
+  uint32_t* tile_begin;
+  uint32_t* tile_end;
+  uint32_t* worklist;
   int tiles_x, tiles_y, T;
+};
+struct TileRanges {
+  const uint32_t* begin;
+  const uint32_t* end;
 };
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 __host__ __device__ inline size_t align256_hd(size_t x) { return (x + 255) & ~size_t(255); }
@@ -63,12 +74,18 @@ inline ImgView img_view(void* base, int W, int H) {
   v.tile_offsets = reinterpret_cast<uint32_t*>(p);
   p += align256((size_t) (v.T + 1) * 4);
   v.cursors = reinterpret_cast<uint32_t*>(p);
+  p += align256((size_t) v.T * 4);
+  v.tile_begin = reinterpret_cast<uint32_t*>(p);
+  p += align256((size_t) v.T * 4);
+  v.tile_end = reinterpret_cast<uint32_t*>(p);
+  p += align256((size_t) v.T * 4);
+  v.worklist = reinterpret_cast<uint32_t*>(p);
   return v;
 }
 inline size_t img_bytes(int W, int H) {
   int T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
   return align256((size_t) W * H * 4) + align256((size_t) T * 4) + align256((size_t) (T + 1) * 4) +
-         align256((size_t) T * 4) + 256;
+         4 * align256((size_t) T * 4) + 256;
 }
 
 // ---- binning buffer ------------------------------------------------------------------------------------

@@ -47,7 +47,8 @@ class FusedViewStep:
 
     def __init__(self, model: SkinnedGaussians, W: int, H: int, capacity: int, lambda_dssim: float = 0.2,
                  background: Optional[Tensor] = None, grad_scale: float = 1.0, densify_stats: bool = False,
-                 spw_logit_grad: Optional[Tensor] = None, tables_zeroed_by_optimizer: bool = False):
+                 spw_logit_grad: Optional[Tensor] = None, tables_zeroed_by_optimizer: bool = False,
+                 tile_bucket: int = 0):
         assert not model.static, 'FusedViewStep covers the skinned stage (M >= 1)'
         self.model, self.W, self.H = model, int(W), int(H)
         self.lambda_l1, self.lambda_ssim = 1.0 - lambda_dssim, lambda_dssim
@@ -78,6 +79,11 @@ class FusedViewStep:
         self.geom = torch.empty((lib.skgs_geom_buffer_bytes(C.c_int32(P)),), **u8)
         self.geom[:256].zero_()  # status words; `overflow_events` counts overflowing forwards from here on
         self.img = torch.empty((lib.skgs_img_buffer_bytes(C.c_int32(W), C.c_int32(H)),), **u8)
+        # tile_bucket = Lcap > 0: every tile owns Lcap fixed slots (skgs_raster_inputs.tile_bucket_capacity): no counting
+        # and no scan launch; `capacity` is then ignored
+        self.tile_bucket = int(tile_bucket)
+        if self.tile_bucket > 0:
+            capacity = ((W + 15) // 16) * ((H + 15) // 16) * self.tile_bucket
         self.binning = torch.empty((lib.skgs_binning_buffer_bytes(C.c_int64(int(capacity))),), **u8)
         self.loss3 = torch.zeros(3, **f32)
         self.loss_ws = torch.empty((lib.skgs_image_loss_workspace_bytes(C.c_int32(3), C.c_int32(H), C.c_int32(W)),), **u8)
@@ -164,6 +170,7 @@ class FusedViewStep:
         a.scales, a.rotations = self.scales.data_ptr(), self.rotations.data_ptr()
         a.sh, a.sh_rest = m._features_dc.data_ptr(), m._features_rest.data_ptr()
         a.background = None if self.background is None else self.background.data_ptr()
+        a.tile_bucket_capacity = self.tile_bucket
         return a
 
     def _deform_inputs(self, time_id: int) -> '_C._DeformInputs':

@@ -156,3 +156,32 @@ def test_fused_step_with_the_deform_network_matches_autograd():
     assert rel_err(step.image, out['images'].detach()) <= 5e-6
     for n, p in model.named_parameters():
         assert_close_robust(p.grad, ref[n], 2e-4, 1e-3, name=n)
+
+
+def test_bucket_tile_layout_matches_compact_lists_and_flags_overflow():
+    """skgs_raster_inputs.tile_bucket_capacity: fixed slots per tile instead of count -> scan -> scatter; same image and
+    gradients; a bucket smaller than the longest list sets the overflow flag"""
+    from sk_gs_amd import _C
+    from sk_gs_amd.fused_step import FusedViewStep
+    P, M, K, W, H, frames, tid = 6000, 12, 4, 200, 136, 3, 1
+    model, rs, target = _setup(P, M, K, W, H, frames)
+    with torch.no_grad():
+        _C.config.sync_num_rendered = True
+        buf = model.render(rs, time_id=tid)['buffer']
+        R, longest = buf.R, _C.read_status(buf.geomBuffer)['max_tile_count']
+    ref = FusedViewStep(model, W, H, capacity=int(R * 1.2) + 1024)
+    ref.forward_backward(rs, tid, target)
+    gref = {n: p.grad.clone() for n, p in model.named_parameters()}
+    img_ref = ref.image.clone()
+    for p in model.parameters():
+        p.grad = torch.full_like(p, 3.0)
+    step = FusedViewStep(model, W, H, capacity=0, tile_bucket=((longest + 63) // 64) * 64)
+    step.forward_backward(rs, tid, target)
+    st = step.status()
+    assert st['overflow'] == 0 and st['num_rendered'] == -1
+    assert torch.equal(step.image, img_ref) and torch.equal(step.radii, ref.radii)
+    for n, p in model.named_parameters():
+        assert_close_robust(p.grad, gref[n], 2e-5, 1e-4, name=n)
+    small = FusedViewStep(model, W, H, capacity=0, tile_bucket=max(longest // 2, 1))
+    small.forward_backward(rs, tid, target)
+    assert small.status()['overflow'] == 1 and small.status()['overflow_events'] >= 1
