@@ -221,6 +221,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
   // wave-wide maximum of the last contributor: nothing behind it can matter to this wave
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) maxk = max(maxk, (uint32_t) __shfl_xor((int) maxk, d));
+  maxk = (uint32_t) __builtin_amdgcn_readfirstlane((int) maxk);  // wave-uniform: the walk's bounds and k live in SGPRs
   if (maxk == 0) return;
   const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
   const bool holder  = (lane & 7) == 0 || lane == 63;
@@ -246,11 +247,13 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
       const float4 a = s_a[j];
       const float4 b = s_b[j];
       float g[NV];
-#pragma unroll
-      for (int q = 0; q < NV; ++q) g[q] = 0.f;
       bool any = false;
       float col[3] = {b.z, b.w, 0.f};
       bool col_loaded = false;
+#if SKGS_STRICT
+      // ---- the reference's expressions, term by term (gaussian_render.cu:252-318)
+#pragma unroll
+      for (int q = 0; q < NV; ++q) g[q] = 0.f;
 #pragma unroll
       for (int i = 0; i < PPL; ++i) {
         if (k < lastk[i]) {
@@ -262,18 +265,11 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
             if (alpha >= ALPHA_MIN) {
               any = true;
               if (!col_loaded) col[2] = s_c[j], col_loaded = true;
-#if SKGS_STRICT
               const float Tn = Tr[i] / (1.f - alpha);
               const float tf_over = -T_final[i] / (1.f - alpha);
-#else
-              const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp; the IEEE divide is ~10 instructions
-              const float Tn   = Tr[i] * rinv;
-#endif
-              const float Tprev = Tr[i];
-              Tr[i]             = Tn;
+              Tr[i]          = Tn;
               const float dchannel_dcolor = alpha * Tn;
               float dL_dalpha = 0.0f;
-#if SKGS_STRICT
 #pragma unroll
               for (int c = 0; c < 3; ++c) {
                 dL_dalpha += (col[c] - accum[i][c]) * dpix[i][c];
@@ -287,31 +283,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
                 g[9 + e] += dchannel_dcolor * dex[i][e];
                 accum_e[i][e] = alpha * ce + (1.f - alpha) * accum_e[i][e];
               }
-#else
-              // sum_c (colour_c - behind_c) * dpix_c = D - S with D = colour . dpix and the scalar S = behind . dpix,
-              // which obeys the same recurrence as the behind-colour itself (S <- alpha D + (1 - alpha) S): one state
-              // register per pixel instead of 3 + E, 6 instead of 12 operations.
-              float D = 0.f;
-#pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                D += col[c] * dpix[i][c];
-                g[6 + c] += dchannel_dcolor * dpix[i][c];
-              }
-#pragma unroll
-              for (int e = 0; e < E; ++e) {
-                D += s_e[j * (E > 0 ? E : 1) + e] * dex[i][e];
-                g[9 + e] += dchannel_dcolor * dex[i][e];
-              }
-              // (D - S) * T_next - T_final / (1 - alpha) * dL/dT  =  ((D - S) * T_prev + K) / (1 - alpha),  K = -T_final dL/dT
-              dL_dalpha   = ((D - accum[i][0]) * Tprev + dL_dT[i]) * rinv;
-              accum[i][0] = alpha * D + (1.f - alpha) * accum[i][0];
-#endif
-#if SKGS_STRICT
               dL_dalpha *= Tn;
               dL_dalpha += tf_over * dL_dT[i];
-#endif
-#if SKGS_STRICT
-              // the reference's expressions, term by term (gaussian_render.cu:300-318)
               const float dL_dG    = b.y * dL_dalpha;
               const float gdx      = G * dx;
               const float gdy      = G * dy;
@@ -323,25 +296,63 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
               g[3] += -0.5f * gdx * dy * dL_dG;
               g[4] += -0.5f * gdy * dy * dL_dG;
               g[5] += G * dL_dalpha;
-#else
-              // All five geometric gradients are linear in the moments of w = G * dL/dG over the pixels:
-              //   dL/dmean2D = -(conic . [sum w dx, sum w dy]) * 0.5 * (W, H),   dL/dconic = -0.5 * sum w [dx^2, dx dy, dy^2]
-              // so the row accumulates the five moments and preprocess_backward applies the per-Gaussian coefficients
-              // once (7 multiplies per pair here instead of 17).
-              const float gA = G * dL_dalpha;
-              const float w  = b.y * gA;
-              const float m1 = w * dx, m2 = w * dy;
-              g[0] += m1;
-              g[1] += m2;
-              g[2] += m1 * dx;
-              g[3] += m1 * dy;
-              g[4] += m2 * dy;
-              g[5] += gA;
-#endif
             }
           }
         }
       }
+#else
+      // ---- product build.  Inside the divergent region only the per-pixel state and two scalars are produced:
+      //   gA  = G * dL/dalpha                      (0 for a pixel the splat does not touch)
+      //   dch = alpha * T_next = dC/dcolour        (0 likewise)
+      // with  sum_c (colour_c - behind_c) dpix_c = D - S,  D = colour . dpix,  S = behind . dpix  (S obeys the recurrence
+      // of the behind-colour: one state register instead of 3 + E)  and
+      //   (D - S) T_next - T_final / (1 - alpha) dL/dT = ((D - S) T_prev + K) / (1 - alpha),  K = -T_final dL/dT.
+      // The nine partials are plain products of gA / dch formed by ALL lanes afterwards (no zero-initialisation of
+      // nine registers per visit): the five geometric ones are the moments of w = o gA = G dL/dG,
+      //   sum w {dx, dy, dx^2, dx dy, dy^2}
+      // to which preprocess_backward applies the conic coefficients once per Gaussian.
+      float gA[PPL], dch[PPL], dxs[PPL], dys[PPL];
+#pragma unroll
+      for (int i = 0; i < PPL; ++i) {
+        const float dx = a.x - pix.x[i], dy = a.y - pix.y[i];
+        dxs[i] = dx, dys[i] = dy, gA[i] = 0.f, dch[i] = 0.f;
+        if (k < lastk[i]) {
+          const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+          if (power <= 0.0f) {
+            const float G     = blend_exp(power);
+            const float alpha = fminf(0.99f, b.y * G);
+            if (alpha >= ALPHA_MIN) {
+              any = true;
+              if (!col_loaded) col[2] = s_c[j], col_loaded = true;
+              const float rinv  = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp; the IEEE divide is ~10 instructions
+              const float Tprev = Tr[i];
+              const float Tn    = Tprev * rinv;
+              Tr[i]             = Tn;
+              float D = col[0] * dpix[i][0] + col[1] * dpix[i][1] + col[2] * dpix[i][2];
+#pragma unroll
+              for (int e = 0; e < E; ++e) D += s_e[j * (E > 0 ? E : 1) + e] * dex[i][e];
+              const float dL_dalpha = ((D - accum[i][0]) * Tprev + dL_dT[i]) * rinv;
+              accum[i][0] = alpha * D + (1.f - alpha) * accum[i][0];
+              gA[i]  = G * dL_dalpha;
+              dch[i] = alpha * Tn;
+            }
+          }
+        }
+      }
+      if (__ballot(any) != 0) {
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) {
+          const float w  = b.y * gA[i];
+          const float m1 = w * dxs[i], m2 = w * dys[i];
+          const float v[9] = {m1, m2, m1 * dxs[i], m1 * dys[i], m2 * dys[i], gA[i], dch[i] * dpix[i][0], dch[i] * dpix[i][1],
+              dch[i] * dpix[i][2]};
+#pragma unroll
+          for (int q = 0; q < 9; ++q) g[q] = i == 0 ? v[q] : g[q] + v[q];
+#pragma unroll
+          for (int e = 0; e < E; ++e) g[9 + e] = i == 0 ? dch[i] * dex[i][e] : g[9 + e] + dch[i] * dex[i][e];
+        }
+      }
+#endif
       if (__ballot(any) != 0) {
         // 8 sums land one per lane in lanes 0, 8, .., 56, the ninth in lane 63: ONE atomic instruction adds the nine
         // values into the Gaussian's 64-B gradient row (a single memory-side request)
