@@ -339,7 +339,9 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
           }
         }
       }
+#endif
       if (__ballot(any) != 0) {
+#if !SKGS_STRICT
 #pragma unroll
         for (int i = 0; i < PPL; ++i) {
           const float w  = b.y * gA[i];
@@ -351,9 +353,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
 #pragma unroll
           for (int e = 0; e < E; ++e) g[9 + e] = i == 0 ? dch[i] * dex[i][e] : g[9 + e] + dch[i] * dex[i][e];
         }
-      }
 #endif
-      if (__ballot(any) != 0) {
         // 8 sums land one per lane in lanes 0, 8, .., 56, the ninth in lane 63: ONE atomic instruction adds the nine
         // values into the Gaussian's 64-B gradient row (a single memory-side request)
         wave_sum9_transposed(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], 0xff00ff00ff00ff00ull);
