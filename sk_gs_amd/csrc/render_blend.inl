@@ -312,35 +312,41 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
       //   sum w {dx, dy, dx^2, dx dy, dy^2}
       // to which preprocess_backward applies the conic coefficients once per Gaussian.
       float gA[PPL], dch[PPL], dxs[PPL], dys[PPL];
+      unsigned long long any_mask = 0ull;
+      col[2] = s_c[j];  // all three LDS reads of the record are issued together, none inside the divergent region
 #pragma unroll
       for (int i = 0; i < PPL; ++i) {
         const float dx = a.x - pix.x[i], dy = a.y - pix.y[i];
         dxs[i] = dx, dys[i] = dy, gA[i] = 0.f, dch[i] = 0.f;
-        if (k < lastk[i]) {
-          const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-          if (power <= 0.0f) {
-            const float G     = blend_exp(power);
-            const float alpha = fminf(0.99f, b.y * G);
-            if (alpha >= ALPHA_MIN) {
-              any = true;
-              if (!col_loaded) col[2] = s_c[j], col_loaded = true;
-              const float rinv  = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp; the IEEE divide is ~10 instructions
-              const float Tprev = Tr[i];
-              const float Tn    = Tprev * rinv;
-              Tr[i]             = Tn;
-              float D = col[0] * dpix[i][0] + col[1] * dpix[i][1] + col[2] * dpix[i][2];
+        float D = col[0] * dpix[i][0] + col[1] * dpix[i][1] + col[2] * dpix[i][2];  // colour . dL/dpixel (all lanes)
 #pragma unroll
-              for (int e = 0; e < E; ++e) D += s_e[j * (E > 0 ? E : 1) + e] * dex[i][e];
-              const float dL_dalpha = ((D - accum[i][0]) * Tprev + dL_dT[i]) * rinv;
-              accum[i][0] = alpha * D + (1.f - alpha) * accum[i][0];
-              gA[i]  = G * dL_dalpha;
-              dch[i] = alpha * Tn;
-            }
-          }
+        for (int e = 0; e < E; ++e) D += s_e[j * (E > 0 ? E : 1) + e] * dex[i][e];
+        asm volatile("" : "+v"(D));  // keep D (and the LDS reads behind it) in front of the branch
+        // the three tests as one lane mask (the region below is entered by exactly the lanes the reference blends)
+        const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+        const float G     = blend_exp(power);
+        const float alpha = fminf(0.99f, b.y * G);
+        const bool valid  = (k < lastk[i]) & (power <= 0.0f) & (alpha >= ALPHA_MIN);
+        // wave-level "does any lane blend this splat": the AND of the three compare masks, kept in SGPRs (a ballot of
+        // the combined bool is lowered through a VGPR select + compare)
+        any_mask |= __builtin_amdgcn_ballot_w64(k < lastk[i]) & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
+                    __builtin_amdgcn_ballot_w64(alpha >= ALPHA_MIN);
+        if (valid) {
+          const float rinv  = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp; the IEEE divide is ~10 instructions
+          const float Tprev = Tr[i];
+          const float Tn    = Tprev * rinv;
+          Tr[i]             = Tn;
+          const float dL_dalpha = ((D - accum[i][0]) * Tprev + dL_dT[i]) * rinv;
+          accum[i][0] = alpha * D + (1.f - alpha) * accum[i][0];
+          gA[i]  = G * dL_dalpha;
+          dch[i] = alpha * Tn;
         }
       }
 #endif
-      if (__ballot(any) != 0) {
+#if SKGS_STRICT
+      const unsigned long long any_mask = __builtin_amdgcn_ballot_w64(any);
+#endif
+      if (any_mask != 0) {
 #if !SKGS_STRICT
 #pragma unroll
         for (int i = 0; i < PPL; ++i) {
