@@ -58,7 +58,12 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
     if (lane < n) {
       const uint32_t id = point_list[base + lane];
       const float4 a = recs[3 * id], b = recs[3 * id + 1], c = recs[3 * id + 2];
+#if SKGS_STRICT
       s_a[lane] = a, s_b[lane] = b, s_c[lane] = c.x;
+#else
+      // the staged record carries the conic pre-scaled: power = dx (p dx + q dy) + (r dy) dy with p = -A/2, q = -B, r = -C/2
+      s_a[lane] = make_float4(a.x, a.y, -0.5f * a.z, -a.w), s_b[lane] = make_float4(-0.5f * b.x, b.y, b.z, b.w), s_c[lane] = c.x;
+#endif
 #pragma unroll
       for (int e = 0; e < E; ++e) s_e[lane * (E > 0 ? E : 1) + e] = extra[(size_t) id * E + e];
       relevant = splat_reaches_rect(a.x, a.y, a.z, a.w, b.x, c.w, rect);
@@ -122,7 +127,7 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
 #pragma unroll
       for (int i = 0; i < PPL; ++i) {
         const float dx = a.x - pix.x[i], dy = a.y - pix.y[i];
-        const float power  = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+        const float power  = dx * (a.z * dx + a.w * dy) + (b.x * dy) * dy;  // pre-scaled conic, see the staging
         const float alpha  = fminf(0.99f, b.y * blend_exp(power));
         const float test_T = Tr[i] * (1.f - alpha);
         const bool valid   = !done[i] && power <= 0.0f && alpha >= ALPHA_MIN;
@@ -235,7 +240,12 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
     if (lane < n) {
       const uint32_t id = point_list[hi - 1 - lane];
       const float4 a = recs[3 * id], b = recs[3 * id + 1], c = recs[3 * id + 2];
+#if SKGS_STRICT
       s_a[lane] = a, s_b[lane] = b, s_c[lane] = c.x, s_id[lane] = id;
+#else
+      s_a[lane] = make_float4(a.x, a.y, -0.5f * a.z, -a.w), s_b[lane] = make_float4(-0.5f * b.x, b.y, b.z, b.w);
+      s_c[lane] = c.x, s_id[lane] = id;
+#endif
 #pragma unroll
       for (int e = 0; e < E; ++e) s_e[lane * (E > 0 ? E : 1) + e] = extra[(size_t) id * E + e];
       relevant = splat_reaches_rect(a.x, a.y, a.z, a.w, b.x, c.w, rect);
@@ -313,7 +323,9 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
       // to which preprocess_backward applies the conic coefficients once per Gaussian.
       float gA[PPL], dch[PPL], dxs[PPL], dys[PPL];
       unsigned long long any_mask = 0ull;
-      col[2] = s_c[j];  // all three LDS reads of the record are issued together, none inside the divergent region
+      col[2] = s_c[j];
+      uint32_t gid = s_id[j];  // (read here, with the record, not after the reduction where its latency is exposed)
+      asm volatile("" : "+v"(gid));  // all three LDS reads of the record are issued together, none inside the divergent region
 #pragma unroll
       for (int i = 0; i < PPL; ++i) {
         const float dx = a.x - pix.x[i], dy = a.y - pix.y[i];
@@ -323,7 +335,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
         for (int e = 0; e < E; ++e) D += s_e[j * (E > 0 ? E : 1) + e] * dex[i][e];
         asm volatile("" : "+v"(D));  // keep D (and the LDS reads behind it) in front of the branch
         // the three tests as one lane mask (the region below is entered by exactly the lanes the reference blends)
-        const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+        const float power = dx * (a.z * dx + a.w * dy) + (b.x * dy) * dy;  // pre-scaled conic, see the staging
         const float G     = blend_exp(power);
         const float alpha = fminf(0.99f, b.y * G);
         const bool valid  = (k < lastk[i]) & (power <= 0.0f) & (alpha >= ALPHA_MIN);
@@ -365,7 +377,10 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
         wave_sum9_transposed(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], 0xff00ff00ff00ff00ull);
 #pragma unroll
         for (int q = 9; q < NV; ++q) g[q] = wave_sum_to_lane63(g[q]);
-        float* row = gradacc + (size_t) s_id[j] * GRAD_ROW;
+#if SKGS_STRICT
+        const uint32_t gid = s_id[j];
+#endif
+        float* row = gradacc + (size_t) gid * GRAD_ROW;
         if (holder) atomicAdd(row + holder_q, lane == 63 ? g[8] : g[1]);
         if (lane == 63) {
 #pragma unroll
