@@ -25,7 +25,7 @@ def _inputs(P, M, K, seed):
     return g, b, bone_T, w, idx
 
 
-@pytest.mark.parametrize('P,M,K', [(5000, 20, 5), (3000, 1, 1), (2000, 600, 4), (1000, 1500, 3)])
+@pytest.mark.parametrize('P,M,K', [(5000, 20, 5), (3000, 1, 1), (2500, 64, 8), (700, 65, 3), (2000, 600, 4), (1000, 1500, 3)])
 def test_deform_forward_backward(oracle32, P, M, K):
     from sk_gs_amd import _C
     g, b, bone_T, w, idx = _inputs(P, M, K, seed=P)
