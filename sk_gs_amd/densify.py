@@ -1,0 +1,134 @@
+"""Adaptive density control on top of ``FusedAdam`` -- the caller side of the hot path (scope row (f)-2 / (f)-4: the
+optimizer-state surgery of ``change_optimizer`` and the clone / split / prune operations that use it).
+
+Restated from ``GaussianSplatting`` (networks/gaussian_splatting.py): ``prune_points`` :565-576, ``densification_postfix``
+:578-587, ``densify_and_split`` :589-620, ``densify_and_clone`` :622-634, ``densify`` :636-641, ``prune`` :643-650,
+``reset_opacity`` :652-655.  Plain torch: these run every ~100 iterations, not per step.  Every per-Gaussian parameter
+of the model -- the reference's ``param_names_map`` plus the LBS logits ``sp_W`` -- is pruned / extended together with
+its Adam moments.  After any of them the number of Gaussians has changed: rebuild ``FusedViewStep`` / flat gradient
+buffers / captured graphs (their buffers are sized by P), as the reference re-creates its tensors.
+"""
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+
+from sk_gs_amd.optim import FusedAdam
+
+# module attribute -> optimizer group name (gaussian_splatting.py:89-96 + the per-Gaussian LBS logits)
+PARAM_NAMES_MAP = {'_xyz': 'xyz', '_features_dc': 'f_dc', '_features_rest': 'f_rest', '_opacity': 'opacity',
+                   '_scaling': 'scaling', '_rotation': 'rotation', 'sp_W': 'sp_W'}
+
+
+class DensifyStats:
+    """xyz_gradient_accum [P,1], denom [P,1], max_radii2D [P] (gaussian_splatting.py:495-501); ``FusedViewStep`` has the
+    same three attributes and can be passed wherever ``stats`` is expected."""
+
+    def __init__(self, P: int, device):
+        self.xyz_gradient_accum = torch.zeros((P, 1), device=device)
+        self.denom = torch.zeros((P, 1), device=device)
+        self.max_radii2D = torch.zeros((P,), device=device)
+
+
+def _names(model) -> Dict[str, str]:
+    return {a: n for a, n in PARAM_NAMES_MAP.items() if getattr(model, a, None) is not None}
+
+
+def quaternion_to_R(q: Tensor) -> Tensor:
+    """xyzw quaternion (normalised first) -> rotation matrix, my_ext/ops_3d/quaternion.py:162-172"""
+    x, y, z, w = torch.nn.functional.normalize(q, dim=-1).unbind(-1)
+    return torch.stack([1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * w * z, 2 * w * y + 2 * x * z,
+                        2 * x * y + 2 * w * z, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * w * x,
+                        2 * x * z - 2 * w * y, 2 * w * x + 2 * y * z, 1 - 2 * x * x - 2 * y * y],
+                       dim=-1).reshape(*x.shape, 3, 3)
+
+
+def _rebind(model, new: Dict[str, torch.nn.Parameter]):
+    for attr, name in _names(model).items():
+        if name in new:
+            setattr(model, attr, new[name])
+    model.P = model._xyz.shape[0]
+
+
+@torch.no_grad()
+def prune_points(model, opt: FusedAdam, mask: Tensor, stats=None):
+    """remove the Gaussians where ``mask`` is True (gaussian_splatting.py:565-576)"""
+    keep = ~mask
+    _rebind(model, opt.change_optimizer(keep, list(_names(model).values()), op='prune'))
+    if stats is not None:
+        stats.xyz_gradient_accum = stats.xyz_gradient_accum[keep]
+        stats.denom = stats.denom[keep]
+        stats.max_radii2D = stats.max_radii2D[keep]
+
+
+@torch.no_grad()
+def densification_postfix(model, opt: FusedAdam, new_params: Dict[str, Tensor], stats=None):
+    """append rows (by optimizer group name) and restart the statistics (gaussian_splatting.py:578-587)"""
+    _rebind(model, opt.change_optimizer(new_params, op='concat'))
+    if stats is not None:
+        P, dev = model._xyz.shape[0], model._xyz.device
+        stats.xyz_gradient_accum = torch.zeros((P, 1), device=dev)
+        stats.denom = torch.zeros((P, 1), device=dev)
+        stats.max_radii2D = torch.zeros((P,), device=dev)
+
+
+@torch.no_grad()
+def densify_and_split(model, opt: FusedAdam, grads: Tensor, grad_threshold: float, scene_extent: float, N: int = 2,
+                      stats=None, generator: Optional[torch.Generator] = None):
+    """large Gaussians with a large screen-space gradient are replaced by N samples of themselves (:589-620)"""
+    n_init = model._xyz.shape[0]
+    padded = torch.zeros((n_init,), device=model._xyz.device)
+    padded[:grads.shape[0]] = grads.squeeze()
+    scaling = torch.exp(model._scaling)
+    sel = (padded >= grad_threshold) & (scaling.amax(dim=1) > scene_extent)
+    stds = scaling[sel].repeat(N, 1)
+    samples = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=generator)
+    rots = quaternion_to_R(model._rotation[sel]).repeat(N, 1, 1)
+    new = {}
+    for attr, name in _names(model).items():
+        p = getattr(model, attr)
+        if attr == '_xyz':
+            new[name] = torch.bmm(rots, samples[..., None]).squeeze(-1) + p[sel].repeat(N, 1)
+        elif attr == '_scaling':
+            new[name] = torch.log(scaling[sel].repeat(N, 1) / (0.8 * N))
+        else:
+            new[name] = p[sel].repeat(N, *[1] * (p.ndim - 1))
+    densification_postfix(model, opt, new, stats)
+    prune_points(model, opt, torch.cat((sel, sel.new_zeros(N * int(sel.sum())))), stats)
+
+
+@torch.no_grad()
+def densify_and_clone(model, opt: FusedAdam, grads: Tensor, grad_threshold: float, scene_extent: float, stats=None):
+    """small Gaussians with a large screen-space gradient are duplicated (:622-634)"""
+    sel = (torch.norm(grads, dim=-1) >= grad_threshold) & (torch.exp(model._scaling).amax(dim=1) <= scene_extent)
+    new = {name: getattr(model, attr)[sel] for attr, name in _names(model).items()}
+    densification_postfix(model, opt, new, stats)
+
+
+@torch.no_grad()
+def densify(model, opt: FusedAdam, stats, max_grad: float, extent: float, densify_percent_dense: float = 0.01,
+            generator: Optional[torch.Generator] = None):
+    """clone, then split, by the mean screen-space gradient accumulated in ``stats`` (:636-641)"""
+    grads = stats.xyz_gradient_accum / stats.denom
+    grads[grads.isnan()] = 0.0
+    densify_and_clone(model, opt, grads, max_grad, densify_percent_dense * extent, stats)
+    densify_and_split(model, opt, grads, max_grad, densify_percent_dense * extent, stats=stats, generator=generator)
+
+
+@torch.no_grad()
+def prune(model, opt: FusedAdam, stats, min_opacity: float, extent: float, max_screen_size: float,
+          prune_percent_dense: float = 0.1):
+    """drop transparent, screen-filling and world-size outliers (:643-650)"""
+    mask = (torch.sigmoid(model._opacity) < min_opacity).squeeze(-1)
+    if max_screen_size:
+        big_vs = stats.max_radii2D > max_screen_size
+        big_ws = torch.exp(model._scaling).amax(dim=1) > prune_percent_dense * extent
+        mask = mask | big_vs | big_ws
+    prune_points(model, opt, mask, stats)
+
+
+@torch.no_grad()
+def reset_opacity(model, opt: FusedAdam):
+    """opacity <- min(opacity, 0.01) in logit space, with fresh Adam moments (:652-655)"""
+    o = torch.minimum(torch.sigmoid(model._opacity), torch.full_like(model._opacity, 0.01))
+    _rebind(model, opt.change_optimizer(torch.log(o / (1 - o)), name='opacity', op='replace'))

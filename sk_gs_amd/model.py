@@ -83,11 +83,12 @@ class SkinnedGaussians(nn.Module):
             {'params': [self._rotation], 'lr': lr * 1.0, 'name': 'rotation'},
         ]
         if not self.static:
+            groups.append({'params': [self.sp_W], 'lr': lr, 'name': 'sp_W'})  # per Gaussian: pruned / extended with them
             if self.sk_deform_net is None:
-                groups.append({'params': [self.sp_W, self.sk_r, self.sk_d_rot, self.sk_d_scale, self.global_tr],
+                groups.append({'params': [self.sk_r, self.sk_d_rot, self.sk_d_scale, self.global_tr],
                                'lr': lr, 'name': 'skinning'})
             else:
-                groups.append({'params': [self.sp_W, self.global_tr], 'lr': lr, 'name': 'skinning'})
+                groups.append({'params': [self.global_tr], 'lr': lr, 'name': 'skinning'})
                 groups.append({'params': list(self.sk_deform_net.parameters()), 'lr': lr, 'name': 'deform_net'})
         return groups
 

@@ -63,6 +63,56 @@ class FusedAdam:
         self._bound_grads = grads
         self._table.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
 
+    # ---------------------------------------------------------------------------------------------------------
+    def change_optimizer(self, tensor, name=None, op: str = 'replace', dim: int = 0) -> dict:
+        """Replace, prune or extend the parameter of the named group(s) together with its Adam state -- the optimizer
+        surgery of densification, ``GaussianSplatting.change_optimizer`` (networks/gaussian_splatting.py:515-563):
+
+          replace : the group's parameter becomes ``tensor``; exp_avg / exp_avg_sq restart from zero
+          prune   : ``tensor`` is a boolean keep-mask along ``dim``; parameter and state keep the selected rows
+          concat  : ``tensor`` is appended along ``dim``; the new rows' state starts from zero
+
+        ``tensor`` may be a dict name -> tensor.  Like the reference, a named group holds ONE parameter.  Returns
+        name -> new ``nn.Parameter`` (the caller re-binds its module attributes, rebuilds any flat gradient buffer and
+        re-captures graphs: every shape changed)."""
+        from torch import nn
+        assert op in ('replace', 'prune', 'concat')
+        names = ([name] if isinstance(name, str) else list(name)) if name is not None else list(tensor.keys())
+        out = {}
+        for g in self.param_groups:
+            if g.get('name') not in names:
+                continue
+            assert len(g['params']) == 1, f"group {g['name']!r}: change_optimizer handles one parameter per group"
+            old = g['params'][0]
+            new_t = tensor[g['name']] if isinstance(tensor, dict) else tensor
+            st = self.state.pop(old)
+            with torch.no_grad():
+                if op == 'concat':
+                    new_t = new_t.to(old.device, torch.float32)
+                    data = torch.cat([old.data, new_t], dim)
+                    st = {k: torch.cat([v, torch.zeros_like(new_t)], dim) for k, v in st.items()}
+                elif op == 'prune':
+                    idx = (slice(None),) * dim + (new_t,)
+                    data = old.data[idx]
+                    st = {k: v[idx] for k, v in st.items()}
+                else:
+                    data = new_t.detach().to(old.device, torch.float32)
+                    st = {k: torch.zeros_like(data) for k in st}
+            p = nn.Parameter(data.contiguous().requires_grad_(True))
+            g['params'][0] = p
+            self.state[p] = {k: v.contiguous() for k, v in st.items()}
+            out[g['name']] = p
+        self.params, self._lr_index = [], []
+        for gi, g in enumerate(self.param_groups):
+            for p in g['params']:
+                if p.requires_grad:
+                    self.params.append(p)
+                    self._lr_index.append(gi)
+        if self._table.numel() != len(self.params) * 56:
+            self._table = torch.zeros(len(self.params) * 56, dtype=torch.uint8, device=self._table.device)
+        self._upload()
+        return out
+
     def set_lr(self, group_index: int, lr: float):
         self.param_groups[group_index]['lr'] = lr
         self._upload()
