@@ -27,9 +27,10 @@ def main():
     ap.add_argument('--views', type=int, default=8)
     ap.add_argument('--iters', type=int, default=400)
     ap.add_argument('--lr', type=float, default=1e-3)
+    ap.add_argument('--densify-every', type=int, default=0, help='clone / split / prune every N iterations (0: never)')
     args = ap.parse_args()
 
-    from sk_gs_amd import _C, scene
+    from sk_gs_amd import _C, densify, scene
     from sk_gs_amd.fused_step import FusedViewStep
     from sk_gs_amd.model import SkinnedGaussians
     from sk_gs_amd.optim import FusedAdam
@@ -55,30 +56,44 @@ def main():
     targets = [o['images'].contiguous() for o in outs]
     capacity = int(max(o['buffer'].R for o in outs) * 2.5) + 4096
 
-    vp = ViewParallel(model.parameters())                       # p.grad -> views of one flat buffer
-    step = FusedViewStep(model, W, W, capacity=capacity, background=bg, grad_scale=1.0 / world, densify_stats=True)
     opt = FusedAdam(model.param_groups(lr=args.lr), eps=1e-15)
-    if world == 1:
-        graphs = GraphedSteps(lambda v: (step.forward_backward(views[v], v, targets[v]), opt.step()))
-        run = graphs
-    else:
-        g_fb = GraphedSteps(lambda v: step.forward_backward(views[v], v, targets[v]))
-        g_opt = GraphedSteps(lambda _: opt.step())
 
-        def run(v):
-            g_fb(v)
-            vp.allreduce_grads(prescaled=True)
-            g_opt(0)
+    def build_runtime():
+        """everything sized by the number of Gaussians: flat gradient buffer, step workspaces, captured graphs"""
+        vp = ViewParallel(model.parameters())                   # p.grad -> views of one flat buffer
+        step = FusedViewStep(model, W, W, capacity=capacity * model.P // P + 4096, background=bg, grad_scale=1.0 / world, densify_stats=True)
+        step.forward_backward(views[0], 0, targets[0])            # warm-up outside any capture
+        opt.rebind()                                              # the .grad tensors moved
+        if world == 1:
+            run = GraphedSteps(lambda v: (step.forward_backward(views[v], v, targets[v]), opt.step()))
+        else:
+            g_fb = GraphedSteps(lambda v: step.forward_backward(views[v], v, targets[v]))
+            g_opt = GraphedSteps(lambda _: opt.step())
 
-    step.forward_backward(views[0], 0, targets[0])                # warm-up outside any capture
-    opt.step()
+            def run(v):
+                g_fb(v)
+                vp.allreduce_grads(prescaled=True)
+                g_opt(0)
+        step.xyz_gradient_accum.zero_(), step.denom.zero_(), step.max_radii2D.zero_()
+        return vp, step, run
+
+    vp, step, run = build_runtime()
+    gen = torch.Generator(device=dev).manual_seed(1234)          # same samples on every rank
     for it in range(args.iters):
         run(vp.view_index(it, args.views))
+        if args.densify_every and it > 0 and it % args.densify_every == 0 and it < args.iters - 1:
+            vp.allreduce_densify_stats(step.xyz_gradient_accum, step.denom, step.max_radii2D)
+            before = model.P
+            densify.densify(model, opt, step, max_grad=2e-4, extent=4.0, generator=gen)
+            densify.prune(model, opt, step, min_opacity=0.005, extent=4.0, max_screen_size=0.25 * W)
+            vp, step, run = build_runtime()                      # P changed
+            if rank == 0:
+                print(f'iter {it:5d}  densify: {before} -> {model.P} Gaussians')
         if rank == 0 and (it % 100 == 0 or it == args.iters - 1):
             l = step.loss3.tolist()                               # synchronises
             print(f'iter {it:5d}  loss {l[0]:.5f}  (L1 {l[1]:.5f}, SSIM {l[2]:.4f})  {step.status()}')
     if rank == 0:
-        print('visible at least once:', int((step.denom > 0).sum()), 'of', P, 'Gaussians; max screen radius',
+        print('visible at least once:', int((step.denom > 0).sum()), 'of', model.P, 'Gaussians; max screen radius',
               float(step.max_radii2D.max()))
     if dist.is_initialized():
         dist.barrier()

@@ -63,6 +63,11 @@ class FusedAdam:
         self._bound_grads = grads
         self._table.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
 
+    def rebind(self):
+        """re-read every parameter's / gradient's address (after ``ViewParallel`` moved the ``.grad`` tensors into a flat
+        buffer, or before capturing ``step`` into a graph: the refresh in ``step`` cannot run during capture)"""
+        self._upload()
+
     # ---------------------------------------------------------------------------------------------------------
     def change_optimizer(self, tensor, name=None, op: str = 'replace', dim: int = 0) -> dict:
         """Replace, prune or extend the parameter of the named group(s) together with its Adam state -- the optimizer
