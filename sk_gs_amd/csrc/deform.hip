@@ -407,7 +407,23 @@ __global__ void __launch_bounds__(256) deform_backward_finalize_kernel(int M, in
 
 // K nearest bones (squared L2, ascending, ties -> lower index). joints staged in LDS.
 constexpr int KNN_MAXK = 16;
-// KCAP = compile-time capacity of the per-lane top-K list (>= K): the insertion network is KCAP steps per bone
+// KCAP = compile-time capacity of the per-lane top-K list (>= K): the insertion network is KCAP steps per bone.
+// One bubble step per slot as selects (v_cndmask), no branches and no array copies: a candidate displaces the first entry it
+// is strictly smaller than and the displaced entry moves on, so equal distances stay behind earlier (lower) indices.  Slots
+// beyond K just collect the overflow; the first K are the top-K.
+template <int KCAP>
+__device__ __forceinline__ void topk_insert(float (&bd)[KCAP], int (&bi)[KCAP], float cd, int ci) {
+#pragma unroll
+  for (int k = 0; k < KCAP; ++k) {
+    const bool lt  = cd < bd[k];
+    const float td = bd[k];
+    const int ti   = bi[k];
+    bd[k] = lt ? cd : td;
+    bi[k] = lt ? ci : ti;
+    cd    = lt ? td : cd;
+    ci    = lt ? ti : ci;
+  }
+}
 template <int KCAP>
 __global__ void __launch_bounds__(256) knn_bones_kernel(int P, int M, int K, int dim, const float* __restrict__ points,
     const float* __restrict__ joints, float* __restrict__ out_dist, int64_t* __restrict__ out_idx, int lds_joints) {
@@ -441,15 +457,7 @@ __global__ void __launch_bounds__(256) knn_bones_kernel(int P, int M, int K, int
     // insert (d, j) keeping ascending order; equal distances stay behind earlier (lower) indices
     float cd = d;
     int ci   = j;
-#pragma unroll
-    for (int k = 0; k < KCAP; ++k) {
-      if (k < K && cd < bd[k]) {
-        const float td = bd[k];
-        const int ti   = bi[k];
-        bd[k] = cd, bi[k] = ci;
-        cd = td, ci = ti;
-      }
-    }
+    topk_insert<KCAP>(bd, bi, cd, ci);
   }
 #pragma unroll
   for (int k = 0; k < KCAP; ++k)
@@ -555,15 +563,7 @@ __global__ void __launch_bounds__(256) knn_weights_kernel(int P, int M, int K, c
       d += d2 * d2;
       float cd = d;
       int ci   = j;
-#pragma unroll
-      for (int k = 0; k < KCAP; ++k) {
-        if (k < K && cd < bd[k]) {
-          const float td = bd[k];
-          const int ti   = bi[k];
-          bd[k] = cd, bi[k] = ci;
-          cd = td, ci = ti;
-        }
-      }
+      topk_insert<KCAP>(bd, bi, cd, ci);
     }
     float l[KCAP];
     float mx = -INFINITY;
@@ -716,6 +716,8 @@ int launch_knn_lbs_weights(int P, int M, int K, const float* points, const float
       out_idx, out_weights)
   if (K <= 4)
     SKGS_KNNW(4);
+  else if (K <= 5)
+    SKGS_KNNW(5);
   else if (K <= 8)
     SKGS_KNNW(8);
   else
