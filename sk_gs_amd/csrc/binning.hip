@@ -410,8 +410,10 @@ int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, Bi
     ProfScope prof(K_SORT, s);
     hipLaunchKernelGGL(tile_sort_wave_kernel, dim3(im.T), dim3(64), 0, s, im.T, bucket, im.cursors, im.tile_begin,
         im.tile_end, im.worklist, g.hdr, b.keys, b.point_list, b.capacity);
-    // lists longer than 1024 keys (rare): a few workgroups drain the worklist, sorting in LDS / global memory
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(std::min(im.T, 128)), dim3(SORT_THREADS), 0, s, g.hdr, im.worklist,
+    // lists longer than 1024 keys (rare): a few workgroups drain the worklist, sorting in LDS / global memory.  A bucket
+    // layout whose buckets hold no more than the register sort takes cannot produce one: no launch
+    if (bucket == 0 || bucket > 64 * WSORT_MAX_E)
+      hipLaunchKernelGGL(tile_sort_kernel, dim3(std::min(im.T, 128)), dim3(SORT_THREADS), 0, s, g.hdr, im.worklist,
         im.tile_begin, im.tile_end, b.keys, b.point_list, b.capacity);
   }
   SKGS_CHECK_HIP(hipGetLastError());

@@ -72,12 +72,37 @@ __device__ __forceinline__ void load_row18(const float* const (&plane)[NMAP], in
   }
 }
 
+// Workgroup -> tile.  The dispatcher deals consecutive workgroups round-robin to the 8 XCDs, each with its own L2; a tile
+// shares its 5-pixel halo with its neighbours, so every XCD gets ONE contiguous run of the row-major (channel, tile row,
+// tile column) order (~9 tile rows at 800x800): neighbours meet in the same L2 instead of each XCD fetching its own copy
+// of every halo from the fabric.
+struct TileId {
+  int tx, ty, c, linear;
+};
+__device__ __forceinline__ bool tile_of_block(int tiles_x, int tiles_y, int C, TileId& t) {
+  const int n = tiles_x * tiles_y * C, chunk = (n + 7) >> 3;
+  const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+  const int w = xcd * chunk + i;
+  if (i >= chunk || w >= n) return false;
+  t.linear = w;
+  t.tx     = w % tiles_x;
+  t.ty     = (w / tiles_x) % tiles_y;
+  t.c      = w / (tiles_x * tiles_y);
+  return true;
+}
+inline dim3 tile_grid(int C, int H, int W) {
+  const int n = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * C;
+  return dim3((unsigned) (((n + 7) / 8) * 8));
+}
+
 __global__ void __launch_bounds__(256) image_loss_forward_kernel(int C, int H, int W, const float* __restrict__ pred,
     const float* __restrict__ gt, Win win, float* __restrict__ dmaps /*[3][C][H][W]*/, float* __restrict__ partials) {
   __shared__ float s_h[5][IH][HP];
   __shared__ float s_red[4];
-  const int c  = blockIdx.z;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  TileId tile;
+  if (!tile_of_block((W + TW - 1) / TW, (H + TH - 1) / TH, C, tile)) return;
+  const int c  = tile.c;
+  const int x0 = tile.tx * TW, y0 = tile.ty * TH;
   const int tid = threadIdx.x;
   const size_t plane = (size_t) H * W;
   const float* const planes[2] = {pred + c * plane, gt + c * plane};
@@ -159,7 +184,7 @@ __global__ void __launch_bounds__(256) image_loss_forward_kernel(int C, int H, i
   const float ssum = block_sum_256(ssim_sum, s_red);
   const float lsum = block_sum_256(l1_sum, s_red);
   if (tid == 0) {
-    const int b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int b = tile.linear;
     partials[2 * b] = ssum, partials[2 * b + 1] = lsum;
   }
 }
@@ -195,8 +220,10 @@ __global__ void __launch_bounds__(256) image_loss_backward_kernel(int C, int H, 
     double inv_n, float lambda_l1, float lambda_ssim, float* __restrict__ loss3) {
   __shared__ float s_m[3][IH][IP];
   __shared__ float s_h[3][IH][HP];
-  const int c  = blockIdx.z;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  TileId tile;
+  if (!tile_of_block((W + TW - 1) / TW, (H + TH - 1) / TH, C, tile)) return;
+  const int c  = tile.c;
+  const int x0 = tile.tx * TW, y0 = tile.ty * TH;
   const int tid = threadIdx.x;
   const size_t plane = (size_t) H * W, CHW = (size_t) C * plane;
   for (int i = tid; i < IH * IW; i += 256) {
@@ -260,7 +287,7 @@ __global__ void __launch_bounds__(256) image_loss_backward_kernel(int C, int H, 
     }
   }
   // the loss value itself, when the forward left it to this launch (one workgroup, off everybody else's critical path)
-  if (loss3 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+  if (loss3 && tile.linear == 0) {
     __syncthreads();
     double* s_a = reinterpret_cast<double*>(&s_m[0][0][0]);  // 2 x 256 doubles fit the first staging plane
     finalize_loss(nblocks, inv_n, lambda_l1, lambda_ssim, partials, loss3, s_a, s_a + 256);
@@ -298,11 +325,11 @@ int skgs_image_loss_forward(int32_t C, int32_t H, int32_t W, const float* pred, 
   hipStream_t s   = (hipStream_t) stream;
   float* dmaps    = reinterpret_cast<float*>(workspace);
   float* partials = dmaps + (size_t) 3 * C * H * W;
-  dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, C);
-  hipLaunchKernelGGL(image_loss_forward_kernel, grid, dim3(256), 0, s, C, H, W, pred, gt, make_window(), dmaps, partials);
+  hipLaunchKernelGGL(image_loss_forward_kernel, tile_grid(C, H, W), dim3(256), 0, s, C, H, W, pred, gt, make_window(), dmaps,
+      partials);
   SKGS_CHECK_HIP(hipGetLastError());
   if (loss3) {  // NULL: the caller asks skgs_image_loss_backward for the value (saves this launch)
-    const int nblocks = grid.x * grid.y * grid.z;
+    const int nblocks = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * C;
     hipLaunchKernelGGL(image_loss_finalize_kernel, dim3(1), dim3(256), 0, s, nblocks, 1.0 / ((double) C * H * W), lambda_l1,
         lambda_ssim, partials, loss3);
     SKGS_CHECK_HIP(hipGetLastError());
@@ -318,10 +345,10 @@ int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred,
   SKGS_REQUIRE(workspace_bytes >= skgs_image_loss_workspace_bytes(C, H, W), "image_loss_backward: workspace too small");
   const float* dmaps = reinterpret_cast<const float*>(workspace);
   const float n      = (float) ((double) C * H * W);
-  dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, C);
   const float* partials = dmaps + (size_t) 3 * C * H * W;
-  hipLaunchKernelGGL(image_loss_backward_kernel, grid, dim3(256), 0, (hipStream_t) stream, C, H, W, pred, gt, make_window(),
-      dmaps, grad_loss, lambda_l1 / n, -lambda_ssim / n, dL_dpred, partials, (int) (grid.x * grid.y * grid.z),
+  const int nblocks     = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * C;
+  hipLaunchKernelGGL(image_loss_backward_kernel, tile_grid(C, H, W), dim3(256), 0, (hipStream_t) stream, C, H, W, pred, gt,
+      make_window(), dmaps, grad_loss, lambda_l1 / n, -lambda_ssim / n, dL_dpred, partials, nblocks,
       1.0 / ((double) C * H * W), lambda_l1, lambda_ssim, loss3);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;

@@ -79,6 +79,10 @@ for t in range(gx * gy):
         tot['any_bwd'] += int(anyh.sum())
         tot['pairs_bwd'] += int(h.sum())
         tile_cost += int((circ & walked).sum())
+        # 4x4 quads of the wave: list length per quad if every quad walked its own compacted list
+        qany = [h[:, (qd // 2) * 4:(qd // 2) * 4 + 4, (qd % 2) * 4:(qd % 2) * 4 + 4].reshape(n, -1).any(1).sum() for qd in range(4)]
+        tot['quad_max'] = tot.get('quad_max', 0) + int(max(qany))
+        tot['quad_sum'] = tot.get('quad_sum', 0) + int(sum(qany))
     for strip in range(2):
         sl = (slice(None), slice(strip * 8, strip * 8 + 8), slice(None))
         maxk = nc[sl[1:]].max()
