@@ -242,7 +242,7 @@ __device__ __forceinline__ void bitonic_any(KeyPtr k, int L, int n /*pow2 >= L*/
   }
 }
 
-// Lists longer than the one-wave register sort handles (rare): the wave kernel below queues them in `worklist`.
+// Lists longer than the register sort below handles (> 1024 keys, rare): that kernel queues them in `worklist`.
 __global__ void __launch_bounds__(SORT_THREADS) tile_sort_kernel(const GeomHeader* __restrict__ hdr,
     const uint32_t* __restrict__ worklist, const uint32_t* __restrict__ tile_begin, const uint32_t* __restrict__ tile_end,
     uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list, int64_t capacity) {
@@ -275,17 +275,65 @@ __global__ void __launch_bounds__(SORT_THREADS) tile_sort_kernel(const GeomHeade
   }
 }
 
-// Lists of up to 64 * E keys (E <= 16: 1024 keys, i.e. nearly every tile): ONE wave sorts the list entirely in
+// Lists of up to 64 * E keys (E <= 8: 512 keys, nearly every tile): ONE wave sorts the list entirely in
 // registers.  Blocked layout -- lane l holds keys l*E .. l*E+E-1 -- so a bitonic compare-exchange at distance j < E is
 // a swap between two registers of the same lane and only distances j >= E need one cross-lane read (lane ^ (j/E),
 // ds_bpermute): 21 of the 36 steps for 256 keys.  No LDS array, no barriers.  The LDS network above needed a
 // workgroup barrier per step and 32 KB of LDS per tile.  Padding keys are ~0 (above every real key: the low word is a
 // Gaussian id < 2^31).
-constexpr int WSORT_MAX_E = 16;
+constexpr int WSORT_WAVE_MAX = 512;   // longest list one wave sorts on its own (E = 8)
+constexpr int WSORT_TEAM_MAX = 1024;  // longest list the four waves of a workgroup sort together (E = 4 each)
 
-template <int E>
-__device__ __forceinline__ void wave_bitonic(uint64_t (&k)[E], int lane) {
-  constexpr int N = 64 * E;
+// Value of lane ^ J for J in {1, 2, 4, 8, 16, 32} without the LDS crossbar (ds_bpermute: ~100 cycles of latency per step,
+// and the sort is a chain of dependent steps at ~2.5 waves per SIMD): DPP quad_perm (1, 2), two bank-masked row shifts
+// (4), row_ror:8 (8: +8 and -8 coincide in a row of 16), and the gfx950 v_permlane16/32_swap on two copies (16, 32).
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v, int lane) {
+  const int x = (int) v;
+  if constexpr (J == 1) {
+    return (uint32_t) __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false);  // quad_perm:[1,0,3,2]
+  } else if constexpr (J == 2) {
+    return (uint32_t) __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false);  // quad_perm:[2,3,0,1]
+  } else if constexpr (J == 4) {
+    int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xf, 0x5, false);  // row_shl:4 -> lanes 0-3, 8-11 of a row read l+4
+    t     = __builtin_amdgcn_update_dpp(t, x, 0x114, 0xf, 0xa, false);  // row_shr:4 -> lanes 4-7, 12-15 read l-4
+    return (uint32_t) t;
+  } else if constexpr (J == 8) {
+    return (uint32_t) __builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false);  // row_ror:8
+  } else if constexpr (J == 16) {
+    uint32_t a = v, b = v;
+    // odd rows of a <-> even rows of b:  a = [r0 r0 r2 r2], b = [r1 r1 r3 r3]
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return (lane & 16) ? a : b;
+  } else {
+    static_assert(J == 32, "lane_xor: J must be a power of two <= 32");
+    uint32_t a = v, b = v;
+    // upper half of a <-> lower half of b:  a = [lo lo], b = [hi hi]
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return (lane & 32) ? a : b;
+  }
+}
+
+// jl is a constant once the network's loops are unrolled: the switch folds away
+__device__ __forceinline__ uint32_t lane_xor_any(uint32_t v, int jl, int lane) {
+  switch (jl) {
+    case 1: return lane_xor<1>(v, lane);
+    case 2: return lane_xor<2>(v, lane);
+    case 4: return lane_xor<4>(v, lane);
+    case 8: return lane_xor<8>(v, lane);
+    case 16: return lane_xor<16>(v, lane);
+    default: return lane_xor<32>(v, lane);
+  }
+}
+
+// WAVES = 1: the one-wave network.  WAVES = 4: the same network over the 256 lanes of a workgroup -- "virtual lane"
+// vlane = wave * 64 + lane holds keys vlane*E .. vlane*E+E-1; the only steps that leave the wave are the ones at distance
+// >= 64*E (3 of the 55 steps for 1024 keys), done as an exchange through LDS (sx: WAVES*64*E keys) with two barriers.
+// A 1024-key list costs a wave 4 keys per step instead of 16.
+template <int E, int WAVES>
+__device__ __forceinline__ void bitonic_blocked(uint64_t (&k)[E], int lane, int wave, uint64_t* __restrict__ sx) {
+  constexpr int N = 64 * E * WAVES;
+  const int vlane = wave * 64 + lane;
 #pragma unroll
   for (int size = 2; size <= N; size <<= 1) {
 #pragma unroll
@@ -294,81 +342,116 @@ __device__ __forceinline__ void wave_bitonic(uint64_t (&k)[E], int lane) {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           if ((e & j) == 0) {
-            // ascending iff bit `size` of the global index lane*E + e is clear
-            const bool asc   = size < E ? ((e & size) == 0) : (((lane * E) & size) == 0);
+            // ascending iff bit `size` of the global index vlane*E + e is clear
+            const bool asc   = size < E ? ((e & size) == 0) : (((vlane * E) & size) == 0);
             const uint64_t a = k[e], b = k[e | j];
-            const bool sw = asc ? (a > b) : (a < b);
+            const bool sw = (a > b) == asc;  // one 64-bit compare; equal keys (padding) may swap freely
             k[e]          = sw ? b : a;
             k[e | j]      = sw ? a : b;
           }
         }
-      } else {  // partner in lane ^ (j / E), same register
-        constexpr int dummy = 0;
-        (void) dummy;
+      } else if (j < 64 * E) {  // partner in lane ^ (j / E), same register
         const int jl     = j / E;
         const bool upper = (lane & jl) != 0;
-        const bool asc   = ((lane * E) & size) == 0;  // size > j >= E: a lane bit
+        const bool asc   = ((vlane * E) & size) == 0;  // size > j >= E: a lane bit
         const bool keep_min = asc != upper;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           const uint64_t a  = k[e];
-          const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) a, jl), hi = (uint32_t) __shfl_xor((int) (uint32_t) (a >> 32), jl);
+          const uint32_t lo = lane_xor_any((uint32_t) a, jl, lane), hi = lane_xor_any((uint32_t) (a >> 32), jl, lane);
           const uint64_t b  = ((uint64_t) hi << 32) | lo;
-          k[e] = keep_min ? (a < b ? a : b) : (a > b ? a : b);
+          k[e] = ((b < a) == keep_min) ? b : a;  // one 64-bit compare per key and step
         }
+      } else {  // partner in wave ^ (j / (64 E)), same lane and register
+        const int jw     = j / (64 * E);
+        const bool upper = (wave & jw) != 0;
+        const bool asc   = ((vlane * E) & size) == 0;
+        const bool keep_min = asc != upper;
+#pragma unroll
+        for (int e = 0; e < E; ++e) sx[(wave * E + e) * 64 + lane] = k[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const uint64_t a = k[e], b = sx[((wave ^ jw) * E + e) * 64 + lane];
+          k[e] = ((b < a) == keep_min) ? b : a;  // one 64-bit compare per key and step
+        }
+        __syncthreads();
       }
     }
   }
 }
 
-template <int E>
-__device__ __forceinline__ void wave_sort_tile(uint64_t* __restrict__ gk, uint32_t* __restrict__ pl, int L, int lane) {
+template <int E, int WAVES>
+__device__ __forceinline__ void sort_tile_blocked(uint64_t* __restrict__ gk, uint32_t* __restrict__ pl, int L, int lane,
+    int wave, uint64_t* __restrict__ sx) {
+  const int vlane = wave * 64 + lane;
   uint64_t k[E];
 #pragma unroll
-  for (int e = 0; e < E; ++e) k[e] = (lane * E + e) < L ? gk[lane * E + e] : ~0ull;
-  wave_bitonic<E>(k, lane);
+  for (int e = 0; e < E; ++e) k[e] = (vlane * E + e) < L ? gk[vlane * E + e] : ~0ull;
+#ifndef SKGS_EXP_NOSORT
+  bitonic_blocked<E, WAVES>(k, lane, wave, sx);
+#endif
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    const int i = lane * E + e;
+    const int i = vlane * E + e;
     if (i < L) gk[i] = k[e], pl[i] = (uint32_t) k[e];
   }
 }
 
-__global__ void __launch_bounds__(64) tile_sort_wave_kernel(int T, int bucket, const uint32_t* __restrict__ cursors,
+// One workgroup = 4 waves = 4 consecutive tiles.  Each wave first sorts its own list if that is at most 512 keys (the
+// steps are latency-bound: four waves side by side beat four team sorts in a row); lists of 513..1024 keys are then sorted one after the other by all four waves together; longer ones go to the worklist.
+__global__ void __launch_bounds__(256) tile_sort_wave_kernel(int T, int bucket, const uint32_t* __restrict__ cursors,
     uint32_t* __restrict__ tile_begin, uint32_t* __restrict__ tile_end, uint32_t* __restrict__ worklist, GeomHeader* hdr,
     uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list, int64_t capacity) {
-  const int tile = blockIdx.x;
-  if (tile >= T) return;
-  const int lane = threadIdx.x;
-  int64_t s64, e64;
-  if (bucket) {  // bucket layout: the per-tile cursor is the count; this kernel publishes the tile's range
-    const uint32_t cnt = cursors[tile];
-    s64 = (int64_t) tile * bucket, e64 = s64 + min(cnt, (uint32_t) bucket);
-    if (lane == 0) {
-      tile_begin[tile] = (uint32_t) s64, tile_end[tile] = (uint32_t) e64;
-      if (cnt > (uint32_t) bucket) hdr->overflow = 1, atomicAdd(&hdr->overflow_events, 1);
+  __shared__ uint64_t s_x[4 * 4 * 64];
+  __shared__ int s_len[4];
+  __shared__ long long s_beg[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + wave;
+  int64_t s64 = 0;
+  int L       = 0;
+  if (tile < T) {
+    int64_t e64;
+    if (bucket) {  // bucket layout: the per-tile cursor is the count; this kernel publishes the tile's range
+      const uint32_t cnt = cursors[tile];
+      s64 = (int64_t) tile * bucket, e64 = s64 + min(cnt, (uint32_t) bucket);
+      if (lane == 0) {
+        tile_begin[tile] = (uint32_t) s64, tile_end[tile] = (uint32_t) e64;
+        if (cnt > (uint32_t) bucket) hdr->overflow = 1, atomicAdd(&hdr->overflow_events, 1);
+      }
+    } else {
+      s64 = tile_begin[tile], e64 = min<int64_t>((int64_t) tile_end[tile], capacity);
     }
-  } else {
-    s64 = tile_begin[tile], e64 = min<int64_t>((int64_t) tile_end[tile], capacity);
+    L = max((int) (e64 - s64), 0);
+    if (L > WSORT_TEAM_MAX) {  // tile_sort_kernel
+      if (lane == 0) worklist[atomicAdd(&hdr->big_tiles, 1)] = (uint32_t) tile;
+      L = 0;
+    }
   }
-  const int L = (int) (e64 - s64);
-  if (L <= 0) return;
-  if (L > 64 * WSORT_MAX_E) {  // tile_sort_kernel
-    if (lane == 0) worklist[atomicAdd(&hdr->big_tiles, 1)] = (uint32_t) tile;
-    return;
+  if (lane == 0) s_len[wave] = L > WSORT_WAVE_MAX ? L : 0, s_beg[wave] = s64;
+  if (L > 1 && L <= WSORT_WAVE_MAX) {
+    uint64_t* gk = keys + s64;
+    uint32_t* pl = point_list + s64;
+    if (L <= 64)
+      sort_tile_blocked<1, 1>(gk, pl, L, lane, 0, nullptr);
+    else if (L <= 128)
+      sort_tile_blocked<2, 1>(gk, pl, L, lane, 0, nullptr);
+    else if (L <= 256)
+      sort_tile_blocked<4, 1>(gk, pl, L, lane, 0, nullptr);
+    else
+      sort_tile_blocked<8, 1>(gk, pl, L, lane, 0, nullptr);
+  } else if (L == 1 && lane == 0) {
+    point_list[s64] = (uint32_t) keys[s64];
   }
-  uint64_t* gk = keys + s64;
-  uint32_t* pl = point_list + s64;
-  if (L <= 64)
-    wave_sort_tile<1>(gk, pl, L, lane);
-  else if (L <= 128)
-    wave_sort_tile<2>(gk, pl, L, lane);
-  else if (L <= 256)
-    wave_sort_tile<4>(gk, pl, L, lane);
-  else if (L <= 512)
-    wave_sort_tile<8>(gk, pl, L, lane);
-  else
-    wave_sort_tile<16>(gk, pl, L, lane);
+  __syncthreads();
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+    const int Lw = s_len[w];  // workgroup-uniform
+    if (Lw == 0) continue;
+    uint64_t* gk = keys + s_beg[w];
+    uint32_t* pl = point_list + s_beg[w];
+    sort_tile_blocked<4, 4>(gk, pl, Lw, lane, wave, s_x);
+  }
 }
 
 }  // namespace
@@ -408,11 +491,11 @@ int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, Bi
   SKGS_CHECK_HIP(hipGetLastError());
   {
     ProfScope prof(K_SORT, s);
-    hipLaunchKernelGGL(tile_sort_wave_kernel, dim3(im.T), dim3(64), 0, s, im.T, bucket, im.cursors, im.tile_begin,
+    hipLaunchKernelGGL(tile_sort_wave_kernel, dim3((im.T + 3) / 4), dim3(256), 0, s, im.T, bucket, im.cursors, im.tile_begin,
         im.tile_end, im.worklist, g.hdr, b.keys, b.point_list, b.capacity);
     // lists longer than 1024 keys (rare): a few workgroups drain the worklist, sorting in LDS / global memory.  A bucket
     // layout whose buckets hold no more than the register sort takes cannot produce one: no launch
-    if (bucket == 0 || bucket > 64 * WSORT_MAX_E)
+    if (bucket == 0 || bucket > WSORT_TEAM_MAX)
       hipLaunchKernelGGL(tile_sort_kernel, dim3(std::min(im.T, 128)), dim3(SORT_THREADS), 0, s, g.hdr, im.worklist,
         im.tile_begin, im.tile_end, b.keys, b.point_list, b.capacity);
   }
