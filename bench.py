@@ -210,12 +210,14 @@ def main():
         comm_bytes = vp.grads.nbytes
     # ---------------------------------------------------------------- learn R per view with the synchronising path
     _C.config.sync_num_rendered = True
-    Rs, longest = [], 0
+    Rs, longest, walked = [], 0, []
     with torch.no_grad():  # no autograd graph may stay alive across a capture (see sk_gs_amd/train_step.py)
         for v in range(args.views):
             buf = model.render(settings[v], time_id=v % frames, background=background)['buffer']
             Rs.append(buf.R)
             longest = max(longest, _C.read_status(buf.geomBuffer)['max_tile_count'])
+            # n_contrib[H, W] heads the image buffer: per pixel, how far down its tile's list the blend walked
+            walked.append(int(buf.imgBuffer[:W * H * 4].view(torch.int32).sum(dtype=torch.int64)))
     R_mean, R_max = sum(Rs) / len(Rs), max(Rs)
     # fixed slots per tile for the bucket layout: 1.5x the longest list seen, rounded up to 64
     tile_bucket = 0 if args.compact_lists else ((int(longest * 1.5) + 63) // 64) * 64
@@ -422,6 +424,8 @@ def main():
             'config': {'workload': f'{cfg["name"]}: {P} Gaussians, {M} bones, K={K}, SH degree 3, {W}x{H}, '
                                    f'{args.views} synthetic views, colmap=True, 1 view per rank per step',
                        'num_rendered_mean': round(R_mean), 'num_rendered_max': R_max,
+                       'tile_list_mean': round(R_mean / (((W + 15) // 16) * ((H + 15) // 16)), 1), 'tile_list_max': longest,
+                       'walked_pairs_mean': round(sum(walked) / len(walked)),
                        'parallelism': f'view-parallel x{world}, ' + (
                            f'2-bucket grad all-reduce ({comm_bytes / 1e6:.1f} MB, SH bucket overlapped with the skinning '
                            f'backward, second bucket with Adam)' if pipelined else
