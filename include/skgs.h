@@ -207,6 +207,14 @@ int skgs_knn_lbs_weights(int32_t P, int32_t M, int32_t K, const float* points, c
     int64_t* out_idx, float* out_weights, skgs_stream_t stream);
 int skgs_lbs_weights_backward(int32_t P, int32_t M, int32_t K, const float* weights, const int64_t* indices,
     const float* g_weights, float* g_sp_W, skgs_stream_t stream);
+/* skgs_knn_lbs_weights + skgs_lbs_deform_forward in one launch (stage `sk`: calc_LBS_weight sk_gs.py:757-770 followed by
+ * the skinning and activation epilogue :1143-1150,1192-1203 on the same Gaussians).  out_idx / out_weights [P,K] are
+ * written for the backward; means / scales / rotations / opacity as skgs_lbs_deform_forward.  Bit-identical to the two
+ * separate calls. */
+int skgs_knn_lbs_deform_forward(int32_t P, int32_t M, int32_t K, const float* points, const float* joints, const float* sp_W,
+    const float* bone_T, const float* bone_drot, const float* bone_dscale, const float* xyz, const float* log_scale,
+    const float* rot, const float* opacity_logit, int64_t* out_idx, float* out_weights, float* means, float* scales,
+    float* rotations, float* opacity, skgs_stream_t stream);
 
 /* ---- bone chain (scope row a-3): joint rotations -> global bone transforms, one launch per direction ----
  * Replaces kinematic() + skeleton_warp_SE3() (networks/sk_gs.py:1069-1107,193-206; lietorch SE3 product lie.h:242-246).

@@ -590,6 +590,89 @@ __global__ void __launch_bounds__(256) knn_weights_kernel(int P, int M, int K, c
   }
 }
 
+
+// knn_weights_kernel + deform_forward_kernel<true> in one launch (the sk stage runs them back to back on the same
+// Gaussians, sk_gs.py:757-770 then :1143-1150): the K (index, weight) pairs stay in registers between the two halves, so
+// the weights / indices are written for the backward but never re-read, and one launch disappears.  Same arithmetic, in
+// the same order, as the two kernels (the tests compare the three entry points bit for bit).
+template <int KCAP>
+__global__ void __launch_bounds__(256) knn_deform_forward_kernel(int P, int M, int K, const float* __restrict__ points,
+    const float* __restrict__ joints, const float* __restrict__ sp_W, const float* __restrict__ bone_T,
+    const float* __restrict__ bone_drot, const float* __restrict__ bone_dscale, const float* __restrict__ xyz,
+    const float* __restrict__ log_scale, const float* __restrict__ rot, const float* __restrict__ opacity_logit,
+    int64_t* __restrict__ out_idx, float* __restrict__ out_weights, float* __restrict__ means, float* __restrict__ scales,
+    float* __restrict__ rotations, float* __restrict__ opacity) {
+  extern __shared__ float s_dyn[];
+  float* s_j       = s_dyn;                                                  // [M][3]
+  float* s_bones   = s_dyn + ((M * 3 + 3) & ~3);                             // [M][14]
+  float* s_w       = s_bones + ((M * BONE_F + 3) & ~3);                      // [256][K]
+  int64_t* s_idx   = reinterpret_cast<int64_t*>(s_w + ((256 * K + 3) & ~3));  // [256][K]
+  for (int i = threadIdx.x; i < M * 3; i += 256) s_j[i] = joints[i];
+  for (int j = threadIdx.x; j < M; j += 256) load_bone(bone_T, bone_drot, bone_dscale, j, s_bones + j * BONE_F);
+  __syncthreads();
+  const int p0 = blockIdx.x * 256, n = p0 + threadIdx.x;
+  if (n < P) {
+    float bd[KCAP];
+    int bi[KCAP];
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) bd[k] = __builtin_inff(), bi[k] = 0;
+    const float p[3] = {points[3 * (size_t) n], points[3 * (size_t) n + 1], points[3 * (size_t) n + 2]};
+    for (int j = 0; j < M; ++j) {
+      const float d0 = p[0] - s_j[3 * j], d1 = p[1] - s_j[3 * j + 1], d2 = p[2] - s_j[3 * j + 2];
+      float d = 0.f;
+      d += d0 * d0;
+      d += d1 * d1;
+      d += d2 * d2;
+      topk_insert<KCAP>(bd, bi, d, j);
+    }
+    float l[KCAP];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) {
+      l[k] = k < K ? sp_W[(size_t) n * M + bi[k]] : -INFINITY;
+      mx   = fmaxf(mx, l[k]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) {
+      l[k] = k < K ? expf(l[k] - mx) : 0.f;
+      sum += l[k];
+    }
+    float sx[3] = {0, 0, 0}, sr[4] = {0, 0, 0, 0}, ss[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) {
+      if (k < K) {
+        const float w = l[k] / sum;
+        s_w[threadIdx.x * K + k] = w, s_idx[threadIdx.x * K + k] = bi[k];
+        const float* b = s_bones + bi[k] * BONE_F;
+        float y[3];
+        se3_act(b, p, y);
+        sx[0] += y[0] * w, sx[1] += y[1] * w, sx[2] += y[2] * w;
+        sr[0] += b[7] * w, sr[1] += b[8] * w, sr[2] += b[9] * w, sr[3] += b[10] * w;
+        ss[0] += b[11] * w, ss[1] += b[12] * w, ss[2] += b[13] * w;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float dx = sx[c] - p[c];
+      means[3 * n + c]  = xyz[3 * n + c] + dx;
+      scales[3 * n + c] = expf(log_scale[3 * n + c]) + ss[c];
+    }
+    const float4 r4 = reinterpret_cast<const float4*>(rot)[n];
+    const float v[4] = {r4.x + sr[0], r4.y + sr[1], r4.z + sr[2], r4.w + sr[3]};
+    float nv = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+    nv       = fmaxf(nv, 1e-12f);
+    reinterpret_cast<float4*>(rotations)[n] = make_float4(v[0] / nv, v[1] / nv, v[2] / nv, v[3] / nv);
+    opacity[n] = 1.0f / (1.0f + expf(-opacity_logit[n]));
+  }
+  __syncthreads();
+  const int cnt = min(256, P - p0) * K;
+  for (int i = threadIdx.x; i < cnt; i += 256) {
+    out_weights[(size_t) p0 * K + i] = s_w[i];
+    out_idx[(size_t) p0 * K + i]     = s_idx[i];
+  }
+}
+
 }  // namespace
 
 int launch_deform_forward(const skgs_deform_inputs& in, float* means, float* scales, float* rotations, float* opacity,
@@ -723,6 +806,32 @@ int launch_knn_lbs_weights(int P, int M, int K, const float* points, const float
   else
     SKGS_KNNW(KNN_MAXK);
 #undef SKGS_KNNW
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_knn_deform_forward(int P, int M, int K, const float* points, const float* joints, const float* sp_W,
+    const float* bone_T, const float* bone_drot, const float* bone_dscale, const float* xyz, const float* log_scale,
+    const float* rot, const float* opacity_logit, int64_t* out_idx, float* out_weights, float* means, float* scales,
+    float* rotations, float* opacity, hipStream_t s) {
+  if (P == 0) return 0;
+  if (K > KNN_MAXK || K < 1 || K > M) return set_error("knn_deform_forward: K must be in [1,min(%d,M)] (got %d)", KNN_MAXK, K);
+  const size_t lds = ((size_t) ((M * 3 + 3) & ~3) + ((M * BONE_F + 3) & ~3) + ((256 * K + 3) & ~3)) * 4 + (size_t) 256 * K * 8;
+  if (lds > 60 * 1024) return set_error("knn_deform_forward: M = %d too large for the LDS tables", M);
+  ProfScope prof(K_DEFORM_FWD, s);
+#define SKGS_KNND(KCAP_)                                                                                                 \
+  hipLaunchKernelGGL(knn_deform_forward_kernel<KCAP_>, dim3((P + 255) / 256), dim3(256), lds, s, P, M, K, points, joints, \
+      sp_W, bone_T, bone_drot, bone_dscale, xyz, log_scale, rot, opacity_logit, out_idx, out_weights, means, scales,      \
+      rotations, opacity)
+  if (K <= 4)
+    SKGS_KNND(4);
+  else if (K <= 5)
+    SKGS_KNND(5);
+  else if (K <= 8)
+    SKGS_KNND(8);
+  else
+    SKGS_KNND(KNN_MAXK);
+#undef SKGS_KNND
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

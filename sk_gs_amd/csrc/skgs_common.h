@@ -293,6 +293,10 @@ int launch_knn_bones(int P, int M, int K, int dim, const float* points, const fl
     int64_t* out_idx, hipStream_t s);
 int launch_knn_lbs_weights(int P, int M, int K, const float* points, const float* joints, const float* sp_W, int64_t* out_idx,
     float* out_weights, hipStream_t s);
+int launch_knn_deform_forward(int P, int M, int K, const float* points, const float* joints, const float* sp_W,
+    const float* bone_T, const float* bone_drot, const float* bone_dscale, const float* xyz, const float* log_scale,
+    const float* rot, const float* opacity_logit, int64_t* out_idx, float* out_weights, float* means, float* scales,
+    float* rotations, float* opacity, hipStream_t s);
 int launch_lbs_weights_backward_compact(int P, int K, const float* weights, const float* g_weights, float* g_logits,
     hipStream_t s);
 int launch_lbs_logits_scatter(int P, int M, int K, const int64_t* indices, const float* g_logits, float* g_sp_W,

@@ -200,11 +200,13 @@ class FusedViewStep:
             C.c_int32(M), C.c_int32(t['root']), _p(t['parents']), _p(t['level_nodes']), _p(t['level_start']),
             C.c_int32(t['num_levels']), _p(sk_r_raw), _p(m.joints), _p(m.global_tr[time_id]), _p(self.bone_T),
             _p(self.chain_A), st))
-        chk(lib.skgs_knn_lbs_weights(C.c_int32(P), C.c_int32(M), C.c_int32(K), _p(m._xyz), _p(m.joints), _p(m.sp_W),
-                                     _p(self.indices), _p(self.weights), st))
         d = self._deform_inputs(time_id)
-        chk(lib.skgs_lbs_deform_forward(C.byref(d), _p(self.means), _p(self.scales), _p(self.rotations),
-                                        _p(self.opacity), None, None, None, st))
+        # K nearest bones + softmax weights + skinning + activations: one launch (weights / indices kept for the backward)
+        chk(lib.skgs_knn_lbs_deform_forward(
+            C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_void_p(d.points), _p(m.joints), _p(m.sp_W), C.c_void_p(d.bone_T),
+            C.c_void_p(d.bone_drot), C.c_void_p(d.bone_dscale), C.c_void_p(d.xyz), C.c_void_p(d.log_scale), C.c_void_p(d.rot),
+            C.c_void_p(d.opacity_logit), _p(self.indices), _p(self.weights), _p(self.means), _p(self.scales),
+            _p(self.rotations), _p(self.opacity), st))
         a = self._raster_inputs(rs)
         chk(lib.skgs_rasterize_forward(C.byref(a), C.byref(self._bufs), _p(self.radii), _p(self.image),
                                        _p(self.out_opacity), None, None, st))

@@ -201,3 +201,39 @@ def test_densify_stats_and_lbs_weights_kernels(oracle32):
     _, idx_ref = oracle32.knn_bones(pts.numpy(), joints.numpy(), K)
     assert np.array_equal(to_np(idx), idx_ref)
     assert rel_err(w, oracle32.lbs_weights(sp_W.numpy(), idx_ref)) <= 2e-6
+
+
+@pytest.mark.parametrize('P,M,K', [(5000, 20, 5), (3001, 7, 4), (900, 33, 8), (400, 3, 1)])
+def test_knn_weights_deform_in_one_launch_is_bit_identical_to_the_separate_calls(oracle32, P, M, K):
+    """skgs_knn_lbs_deform_forward == skgs_knn_lbs_weights followed by skgs_lbs_deform_forward (and the oracle)"""
+    import ctypes as C
+    from sk_gs_amd import _C
+    g, b, bone_T, _, _ = _inputs(P, M, K, seed=P + 1)
+    gen = torch.Generator().manual_seed(P)
+    joints, sp_W = torch.randn(M, 3, generator=gen), torch.randn(P, M, generator=gen)
+    d = {k: v.cuda().contiguous() for k, v in dict(xyz=g['xyz'], ls=g['log_scale'], rot=g['rot'], op=g['opacity_logit'],
+                                                   joints=joints, sp_W=sp_W, bone_T=bone_T, drot=b['d_rot'],
+                                                   dscale=b['d_scale']).items()}
+    lib, st, p = _C.load_library(), _C._stream(), (lambda t: C.c_void_p(t.data_ptr()))
+    idx1 = torch.empty((P, K), dtype=torch.int64, device='cuda')
+    w1 = torch.empty((P, K), device='cuda')
+    _C._check(lib.skgs_knn_lbs_weights(C.c_int32(P), C.c_int32(M), C.c_int32(K), p(d['xyz']), p(d['joints']), p(d['sp_W']),
+                                       p(idx1), p(w1), st))
+    sep = _C.lbs_deform_forward(d['xyz'], w1, idx1, d['bone_T'], d['drot'], d['dscale'], d['xyz'], d['ls'], d['rot'], d['op'])
+    idx2, w2 = torch.empty_like(idx1), torch.empty_like(w1)
+    outs = [torch.empty((P, c), device='cuda') for c in (3, 3, 4, 1)]
+    _C._check(lib.skgs_knn_lbs_deform_forward(
+        C.c_int32(P), C.c_int32(M), C.c_int32(K), p(d['xyz']), p(d['joints']), p(d['sp_W']), p(d['bone_T']), p(d['drot']),
+        p(d['dscale']), p(d['xyz']), p(d['ls']), p(d['rot']), p(d['op']), p(idx2), p(w2), *[p(o) for o in outs], st))
+    torch.cuda.synchronize()
+    assert torch.equal(idx1, idx2) and torch.equal(w1, w2)
+    for name, a, r in zip(['means', 'scales', 'rotations', 'opacity'], outs, sep):
+        assert torch.equal(a, r.view_as(a)), name
+    n = to_np
+    _, idx_ref = oracle32.knn_bones(n(g['xyz']), n(joints), K)
+    w_ref = oracle32.lbs_weights(n(sp_W), idx_ref)
+    ref = oracle32.lbs_deform_forward(n(g['xyz']), w_ref, idx_ref, n(bone_T), n(b['d_rot']), n(b['d_scale']), n(g['xyz']),
+                                      n(g['log_scale']), n(g['rot']), n(g['opacity_logit']))
+    assert np.array_equal(n(idx2), idx_ref)
+    for name, a in zip(['means', 'scales', 'rotations', 'opacity'], outs):
+        assert rel_err(a, ref[name]) <= 3e-6, name
