@@ -188,6 +188,14 @@ int skgs_lbs_deform_backward(const skgs_deform_inputs* in, const float* g_means,
     const float* g_rotations, const float* g_opacity, float* g_weights, float* g_bone_T, float* g_bone_drot,
     float* g_bone_dscale, float* g_xyz, float* g_log_scale, float* g_rot, float* g_opacity_logit, void* workspace,
     size_t workspace_bytes, skgs_stream_t stream);
+/* skgs_lbs_deform_backward with the softmax backward of the `sp_W` weighting folded in (skgs_lbs_weights_backward /
+ * _compact, networks/sk_gs.py:769-770): writes the dense logit gradient g_sp_W [P,M] and / or the compact one g_logits
+ * [P,K] (either may be NULL, not both); g_weights may be NULL.  Needs M <= 64 and K <= 8.  Same values as the
+ * two-call sequence. */
+int skgs_lbs_deform_backward_logits(const skgs_deform_inputs* in, const float* g_means, const float* g_scales,
+    const float* g_rotations, const float* g_opacity, float* g_weights, float* g_bone_T, float* g_bone_drot,
+    float* g_bone_dscale, float* g_xyz, float* g_log_scale, float* g_rot, float* g_opacity_logit, float* g_sp_W,
+    float* g_logits, void* workspace, size_t workspace_bytes, skgs_stream_t stream);
 /* K (<= 16) nearest bones by squared L2 in `dim` dimensions, ascending, ties to the lower index. */
 int skgs_knn_bones(int32_t P, int32_t M, int32_t K, int32_t dim, const float* points, const float* joints,
     float* out_dist, int64_t* out_idx, skgs_stream_t stream);

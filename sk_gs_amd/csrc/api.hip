@@ -295,6 +295,21 @@ int skgs_lbs_deform_backward(const skgs_deform_inputs* in, const float* g_means,
       g_bone_dscale, g_xyz, g_log_scale, g_rot, g_opacity_logit, workspace, (hipStream_t) stream);
 }
 
+int skgs_lbs_deform_backward_logits(const skgs_deform_inputs* in, const float* g_means, const float* g_scales,
+    const float* g_rotations, const float* g_opacity, float* g_weights, float* g_bone_T, float* g_bone_drot,
+    float* g_bone_dscale, float* g_xyz, float* g_log_scale, float* g_rot, float* g_opacity_logit, float* g_sp_W,
+    float* g_logits, void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
+  if (check_deform(in)) return 1;
+  SKGS_REQUIRE(in->P == 0 || (g_means && g_scales && g_rotations && g_opacity), "deform: upstream gradients are required");
+  SKGS_REQUIRE(g_bone_T && g_bone_drot && g_bone_dscale, "deform: bone gradient outputs are required");
+  SKGS_REQUIRE(in->P == 0 || (g_xyz && g_log_scale && g_rot && g_opacity_logit), "deform: gradient outputs are required");
+  SKGS_REQUIRE(g_sp_W || g_logits, "deform backward (logits): one of g_sp_W / g_logits is required");
+  SKGS_REQUIRE(in->P == 0 || (workspace && workspace_bytes >= deform_backward_workspace_bytes(in->P, in->M)),
+      "deform backward: workspace too small (skgs_lbs_deform_backward_workspace_bytes)");
+  return launch_deform_backward(*in, g_means, g_scales, g_rotations, g_opacity, g_weights, g_bone_T, g_bone_drot,
+      g_bone_dscale, g_xyz, g_log_scale, g_rot, g_opacity_logit, workspace, (hipStream_t) stream, g_sp_W, g_logits);
+}
+
 int skgs_knn_bones(int32_t P, int32_t M, int32_t K, int32_t dim, const float* points, const float* joints,
     float* out_dist, int64_t* out_idx, skgs_stream_t stream) {
   SKGS_REQUIRE(P == 0 || (points && joints && out_dist && out_idx), "knn_bones: NULL argument");

@@ -260,7 +260,8 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_moments_kernel
     const float* __restrict__ g_means, const float* __restrict__ g_scales, const float* __restrict__ g_rotations,
     const float* __restrict__ g_opacity, float* __restrict__ g_weights, float* __restrict__ g_xyz,
     float* __restrict__ g_log_scale, float* __restrict__ g_rot, float* __restrict__ g_opacity_logit,
-    float* __restrict__ partials /* [gridDim.x][M][19] */) {
+    float* __restrict__ partials /* [gridDim.x][M][19] */,
+    float* __restrict__ g_sp_W /* [P,M] or NULL */, float* __restrict__ g_logits /* [P,K] or NULL; both need K <= PREF_K */) {
   extern __shared__ float s_mem[];
   const int Mp    = (M + 3) & ~3;                 // weight rows padded to float4
   float* s_bones  = s_mem;                        // [M][14]
@@ -274,6 +275,11 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_moments_kernel
   for (int i = 0; i < Mp; i += 4) *reinterpret_cast<float4*>(my_w + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   const int n = blockIdx.x * DEFORM_THREADS + threadIdx.x;
+  const bool want_logits = g_sp_W != nullptr || g_logits != nullptr;
+  float lw[PREF_K], lg[PREF_K];
+  int lj[PREF_K];
+#pragma unroll
+  for (int q = 0; q < PREF_K; ++q) lw[q] = 0.f, lg[q] = 0.f, lj[q] = 0;
   float u[MOM_U];
 #pragma unroll
   for (int c = 0; c < MOM_U; ++c) u[c] = 0.f;
@@ -312,8 +318,10 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_moments_kernel
     reinterpret_cast<float4*>(g_rot)[n] = make_float4(g_v[0], g_v[1], g_v[2], g_v[3]);
     const float sg     = 1.0f / (1.0f + expf(-opacity_logit[n]));
     g_opacity_logit[n] = g_opacity[n] * sg * (1.0f - sg);
+    float dot = 0.f;
     for (int k = 0; k < K; ++k) {  // dL/dw[p,k] = g_dx . (T_j p) + g_v . d_rot_j + g_ds . d_scale_j
-      const float* b = s_bones + (int) indices[(size_t) n * K + k] * BONE_F;
+      const int j    = (int) indices[(size_t) n * K + k];
+      const float* b = s_bones + j * BONE_F;
       float y[3];
       se3_act(b, p, y);
       float gw = g_dx[0] * y[0] + g_dx[1] * y[1] + g_dx[2] * y[2];
@@ -321,7 +329,22 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_moments_kernel
       for (int c = 0; c < 4; ++c) gw += g_v[c] * b[7 + c];
 #pragma unroll
       for (int c = 0; c < 3; ++c) gw += g_ds[c] * b[11 + c];
-      g_weights[(size_t) n * K + k] = gw;
+      if (g_weights) g_weights[(size_t) n * K + k] = gw;
+      if (want_logits) {  // softmax backward of the sp_W branch (lbs_weights_backward_kernel): same order of operations
+        const float w = weights[(size_t) n * K + k];
+#pragma unroll
+        for (int q = 0; q < PREF_K; ++q)
+          if (q == k) lw[q] = w, lg[q] = gw, lj[q] = j;
+        dot += w * gw;
+      }
+    }
+    if (want_logits) {
+#pragma unroll
+      for (int q = 0; q < PREF_K; ++q) lg[q] = q < K ? lw[q] * (lg[q] - dot) : 0.f;
+      if (g_logits)
+#pragma unroll
+        for (int q = 0; q < PREF_K; ++q)
+          if (q < K) g_logits[(size_t) n * K + q] = lg[q];
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -351,6 +374,21 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_moments_kernel
   __syncthreads();
   for (int o = threadIdx.x; o < n_out; o += DEFORM_THREADS)
     partials[(size_t) blockIdx.x * n_out + o] = (s_part[o] + s_part[n_out + o]) + (s_part[2 * n_out + o] + s_part[3 * n_out + o]);
+  // ---- dense logit-gradient rows (lbs_weights_backward_kernel folded in): the weight rows in LDS are no longer needed,
+  // each lane rebuilds its row there as the gradient row, the workgroup stores its 256 rows as one contiguous span
+  if (g_sp_W) {
+    for (int i = 0; i < Mp; i += 4) *reinterpret_cast<float4*>(my_w + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < P) {
+#pragma unroll
+      for (int q = 0; q < PREF_K; ++q)
+        if (q < K) my_w[lj[q]] += lg[q];  // KNN ids are distinct; += keeps the gather-backward semantics if they are not
+    }
+    __syncthreads();
+    const int p0   = blockIdx.x * DEFORM_THREADS;
+    const int rows = min(DEFORM_THREADS, P - p0);
+    float* dst     = g_sp_W + (size_t) p0 * M;
+    for (int i = threadIdx.x; i < rows * M; i += DEFORM_THREADS) dst[i] = s_w[(i / M) * Mp + (i % M)];
+  }
 }
 
 // one workgroup per bone: fixed-order reduction of the per-workgroup partial moments, then the per-bone linear maps.
@@ -701,7 +739,10 @@ size_t deform_backward_workspace_bytes(int P, int M) {
 int launch_deform_backward(const skgs_deform_inputs& in, const float* g_means, const float* g_scales,
     const float* g_rotations, const float* g_opacity, float* g_weights, float* g_bone_T, float* g_bone_drot,
     float* g_bone_dscale, float* g_xyz, float* g_log_scale, float* g_rot, float* g_opacity_logit, void* workspace,
-    hipStream_t s) {
+    hipStream_t s, float* g_sp_W, float* g_logits) {
+  if ((g_sp_W || g_logits) && (in.M > MOM_MAX_BONES || in.K > PREF_K))
+    return set_error("deform backward with the logit gradient folded in needs M <= %d and K <= %d (got %d, %d)",
+        MOM_MAX_BONES, PREF_K, in.M, in.K);
   if (in.P == 0) {  // outputs are always written completely
     if (fill_u32(g_bone_T, 0u, (size_t) in.M * 7, s) || fill_u32(g_bone_drot, 0u, (size_t) in.M * 4, s) ||
         fill_u32(g_bone_dscale, 0u, (size_t) in.M * 3, s))
@@ -717,7 +758,7 @@ int launch_deform_backward(const skgs_deform_inputs& in, const float* g_means, c
       ProfScope prof(K_DEFORM_BWD, s);
       hipLaunchKernelGGL(deform_backward_moments_kernel, grid, block, lds, s, in.P, in.K, in.M, in.points, in.weights,
           in.indices, in.bone_T, in.bone_drot, in.bone_dscale, in.log_scale, in.rot, in.opacity_logit, g_means, g_scales,
-          g_rotations, g_opacity, g_weights, g_xyz, g_log_scale, g_rot, g_opacity_logit, partials);
+          g_rotations, g_opacity, g_weights, g_xyz, g_log_scale, g_rot, g_opacity_logit, partials, g_sp_W, g_logits);
     }
     SKGS_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(deform_backward_finalize_kernel, dim3(in.M), dim3(256), 0, s, in.M, (int) grid.x, partials, in.bone_T,

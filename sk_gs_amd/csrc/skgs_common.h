@@ -288,7 +288,7 @@ size_t deform_backward_workspace_bytes(int P, int M);
 int launch_deform_backward(const skgs_deform_inputs& in, const float* g_means, const float* g_scales,
     const float* g_rotations, const float* g_opacity, float* g_weights, float* g_bone_T, float* g_bone_drot,
     float* g_bone_dscale, float* g_xyz, float* g_log_scale, float* g_rot, float* g_opacity_logit, void* workspace,
-    hipStream_t s);
+    hipStream_t s, float* g_sp_W = nullptr, float* g_logits = nullptr);
 int launch_knn_bones(int P, int M, int K, int dim, const float* points, const float* joints, float* out_dist,
     int64_t* out_idx, hipStream_t s);
 int launch_knn_lbs_weights(int P, int M, int K, const float* points, const float* joints, const float* sp_W, int64_t* out_idx,

@@ -261,17 +261,23 @@ class FusedViewStep:
             g_drot, g_dscale = m.sk_d_rot.grad[time_id], m.sk_d_scale.grad[time_id]
         else:  # the three heads of the producer network: their gradients feed its backward below
             sk_r_raw, (g_raw, g_drot, g_dscale) = self._sk_r_raw, self._g_heads
-        chk(lib.skgs_lbs_deform_backward(
-            C.byref(d), _p(self.g_means), _p(self.g_scales), _p(self.g_rotations), _p(self.g_opacity),
-            _p(self.g_weights), _p(self.g_bone_T), _p(g_drot), _p(g_dscale),
-            _p(m._xyz.grad), _p(m._scaling.grad), _p(m._rotation.grad), _p(m._opacity.grad), _p(self.deform_ws),
-            C.c_size_t(self.deform_ws.numel()), st))
-        if self.spw_logit_grad is None:
-            chk(lib.skgs_lbs_weights_backward(C.c_int32(P), C.c_int32(M), C.c_int32(K), _p(self.weights),
-                                              _p(self.indices), _p(self.g_weights), _p(m.sp_W.grad), st))
+        if M <= 64 and K <= 8:
+            # skinning backward with the softmax backward of the LBS logits folded in: dense rows straight into sp_W.grad,
+            # or the compact [P,K] gradient for the all-reduce
+            dense = self.spw_logit_grad is None
+            chk(lib.skgs_lbs_deform_backward_logits(
+                C.byref(d), _p(self.g_means), _p(self.g_scales), _p(self.g_rotations), _p(self.g_opacity),
+                None, _p(self.g_bone_T), _p(g_drot), _p(g_dscale),
+                _p(m._xyz.grad), _p(m._scaling.grad), _p(m._rotation.grad), _p(m._opacity.grad),
+                _p(m.sp_W.grad) if dense else None, None if dense else _p(self.spw_logit_grad), _p(self.deform_ws),
+                C.c_size_t(self.deform_ws.numel()), st))
         else:
-            chk(lib.skgs_lbs_weights_backward_compact(C.c_int32(P), C.c_int32(K), _p(self.weights), _p(self.g_weights),
-                                                      _p(self.spw_logit_grad), st))
+            chk(lib.skgs_lbs_deform_backward(
+                C.byref(d), _p(self.g_means), _p(self.g_scales), _p(self.g_rotations), _p(self.g_opacity),
+                _p(self.g_weights), _p(self.g_bone_T), _p(g_drot), _p(g_dscale),
+                _p(m._xyz.grad), _p(m._scaling.grad), _p(m._rotation.grad), _p(m._opacity.grad), _p(self.deform_ws),
+                C.c_size_t(self.deform_ws.numel()), st))
+            self._lbs_logits_backward()
         chk(lib.skgs_bone_chain_backward(
             C.c_int32(M), C.c_int32(t['root']), _p(t['parents']), _p(t['level_nodes']), _p(t['level_start']),
             C.c_int32(t['num_levels']), _p(sk_r_raw), _p(m.joints), _p(m.global_tr[time_id]), _p(self.chain_A),
@@ -280,6 +286,17 @@ class FusedViewStep:
             self._deform_net_backward()
         if self.densify_stats:
             self.add_densification_stats()
+
+    def _lbs_logits_backward(self):
+        """softmax backward of the LBS logits as its own launch (many bones / neighbours: M > 64 or K > 8)"""
+        lib, m, st, chk = self.lib, self.model, _C._stream(), _C._check
+        P, M, K = self.P, self.M, self.K
+        if self.spw_logit_grad is None:
+            chk(lib.skgs_lbs_weights_backward(C.c_int32(P), C.c_int32(M), C.c_int32(K), _p(self.weights),
+                                              _p(self.indices), _p(self.g_weights), _p(m.sp_W.grad), st))
+        else:
+            chk(lib.skgs_lbs_weights_backward_compact(C.c_int32(P), C.c_int32(K), _p(self.weights), _p(self.g_weights),
+                                                      _p(self.spw_logit_grad), st))
 
     def _joint_rotations(self, time_id: int) -> Tensor:
         """raw joint rotations of the frame: a row of the per-frame table, or the producer network's first head (the

@@ -237,3 +237,58 @@ def test_knn_weights_deform_in_one_launch_is_bit_identical_to_the_separate_calls
     assert np.array_equal(n(idx2), idx_ref)
     for name, a in zip(['means', 'scales', 'rotations', 'opacity'], outs):
         assert rel_err(a, ref[name]) <= 3e-6, name
+
+
+@pytest.mark.parametrize('P,M,K', [(5000, 20, 5), (3001, 7, 4), (700, 60, 8), (300, 3, 1)])
+def test_deform_backward_with_logit_gradient_folded_in(P, M, K):
+    """skgs_lbs_deform_backward_logits == skgs_lbs_deform_backward + skgs_lbs_weights_backward(_compact), bit for bit"""
+    import ctypes as C
+    from sk_gs_amd import _C
+    g, b, bone_T, w, idx = _inputs(P, M, K, seed=P + 2)
+    gen = torch.Generator().manual_seed(P)
+    up = [torch.randn(P, c, generator=gen).cuda() for c in (3, 3, 4, 1)]
+    t = {k: v.cuda().contiguous() for k, v in dict(xyz=g['xyz'], ls=g['log_scale'], rot=g['rot'], op=g['opacity_logit'],
+                                                   w=w, idx=idx, bone_T=bone_T, drot=b['d_rot'], dscale=b['d_scale']).items()}
+    lib, st, p = _C.load_library(), _C._stream(), (lambda x: None if x is None else C.c_void_p(x.data_ptr()))
+    d = _C._DeformInputs()
+    d.P, d.K, d.M = P, K, M
+    d.points = d.xyz = t['xyz'].data_ptr()
+    d.weights, d.indices, d.bone_T = t['w'].data_ptr(), t['idx'].data_ptr(), t['bone_T'].data_ptr()
+    d.bone_drot, d.bone_dscale = t['drot'].data_ptr(), t['dscale'].data_ptr()
+    d.log_scale, d.rot, d.opacity_logit = t['ls'].data_ptr(), t['rot'].data_ptr(), t['op'].data_ptr()
+    ws = torch.empty((lib.skgs_lbs_deform_backward_workspace_bytes(C.c_int32(P), C.c_int32(M)),), dtype=torch.uint8, device='cuda')
+
+    def outs():
+        return dict(gw=torch.empty((P, K), device='cuda'), gT=torch.empty((M, 7), device='cuda'),
+                    gdr=torch.empty((M, 4), device='cuda'), gds=torch.empty((M, 3), device='cuda'),
+                    gx=torch.empty((P, 3), device='cuda'), gls=torch.empty((P, 3), device='cuda'),
+                    grot=torch.empty((P, 4), device='cuda'), gop=torch.empty((P, 1), device='cuda'))
+
+    a = outs()
+    _C._check(lib.skgs_lbs_deform_backward(C.byref(d), *[p(x) for x in up], p(a['gw']), p(a['gT']), p(a['gdr']), p(a['gds']),
+                                           p(a['gx']), p(a['gls']), p(a['grot']), p(a['gop']), p(ws), C.c_size_t(ws.numel()), st))
+    dense_ref = torch.empty((P, M), device='cuda')
+    compact_ref = torch.empty((P, K), device='cuda')
+    _C._check(lib.skgs_lbs_weights_backward(C.c_int32(P), C.c_int32(M), C.c_int32(K), p(t['w']), p(t['idx']), p(a['gw']),
+                                            p(dense_ref), st))
+    _C._check(lib.skgs_lbs_weights_backward_compact(C.c_int32(P), C.c_int32(K), p(t['w']), p(a['gw']), p(compact_ref), st))
+    for dense_out, compact_out, with_gw in ((True, False, False), (False, True, True), (True, True, True)):
+        o = outs()
+        dense = torch.full((P, M), float('nan'), device='cuda') if dense_out else None
+        compact = torch.full((P, K), float('nan'), device='cuda') if compact_out else None
+        _C._check(lib.skgs_lbs_deform_backward_logits(
+            C.byref(d), *[p(x) for x in up], p(o['gw']) if with_gw else None, p(o['gT']), p(o['gdr']), p(o['gds']), p(o['gx']),
+            p(o['gls']), p(o['grot']), p(o['gop']), p(dense), p(compact), p(ws), C.c_size_t(ws.numel()), st))
+        torch.cuda.synchronize()
+        for k in o:
+            if k != 'gw' or with_gw:
+                assert torch.equal(o[k], a[k]), k
+        if dense_out:
+            assert torch.equal(dense, dense_ref)
+        if compact_out:
+            assert torch.equal(compact, compact_ref)
+    # limits are reported, not silently exceeded
+    d.K = 9
+    assert lib.skgs_lbs_deform_backward_logits(C.byref(d), *[p(x) for x in up], None, p(a['gT']), p(a['gdr']), p(a['gds']),
+                                               p(a['gx']), p(a['gls']), p(a['grot']), p(a['gop']), p(dense_ref), None, p(ws),
+                                               C.c_size_t(ws.numel()), st) != 0
