@@ -187,10 +187,25 @@ __global__ void __launch_bounds__(BIN_THREADS) scatter_lds_kernel(int P, int gx,
     for (int k = (int) (tid % LPG); k < n; k += LPG) atomicAdd(&s_cnt[(mn[1] + k / w) * gx + mn[0] + k % w], 1u);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < T; i += BIN_THREADS) {
-    const uint32_t c = s_cnt[i];
-    s_base[i]        = c ? (bucket ? 0u : offsets[i]) + atomicAdd(&cursors[i], c) : 0u;  // bucket: index inside the tile
-    s_cnt[i]         = 0;
+  // slot reservation: one returning global atomic per touched tile.  Four tiles per lane and round, so that the
+  // (memory-side, ~2 us) round trips of a lane are in flight together instead of one after the other
+  for (int i0 = threadIdx.x; i0 < T; i0 += 4 * BIN_THREADS) {
+    uint32_t c[4], r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * BIN_THREADS;
+      c[u] = i < T ? s_cnt[i] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r[u] = c[u] ? atomicAdd(&cursors[i0 + u * BIN_THREADS], c[u]) : 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * BIN_THREADS;
+      if (i < T) {
+        s_base[i] = c[u] ? (bucket ? 0u : offsets[i]) + r[u] : 0u;  // bucket: index inside the tile
+        s_cnt[i]  = 0;
+      }
+    }
   }
   __syncthreads();
   for (int64_t tid = (int64_t) blockIdx.x * BIN_THREADS + threadIdx.x; tid < lanes; tid += stride) {
