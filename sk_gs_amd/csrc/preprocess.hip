@@ -530,18 +530,39 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_backward_kernel(int P,
   const bool staged = shs != nullptr && dL_dsh != nullptr;
   const int RL      = shs_rest ? (M - 1) * 3 : M * 3;
   const int base = blockIdx.x * blockDim.x, nrows = min((int) blockDim.x, P - base);
+  // Every per-Gaussian input is requested BEFORE the SH staging barrier, unconditionally: radius -> gradient row ->
+  // record -> mean / scale / rotation used to be a chain of dependent round trips behind `visible` (the kernel runs at
+  // ~1.5 waves per SIMD: its duration is the length of one lane's dependency chain).
+  int pf_radius = 0;
+  float4 pf_row[4], pf_rec[3], pf_q = make_float4(0.f, 0.f, 0.f, 1.f);
+  float pf_p[3] = {0.f, 0.f, 0.f}, pf_s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pf_row[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  pf_rec[0] = pf_rec[1] = pf_rec[2] = pf_row[0];
+  if (idx < P) {
+    pf_radius = radii[idx];
+    const float4* row = reinterpret_cast<const float4*>(gradacc + (size_t) idx * GRAD_ROW);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pf_row[i] = row[i];
+    pf_rec[0] = recs[3 * idx], pf_rec[1] = recs[3 * idx + 1], pf_rec[2] = recs[3 * idx + 2];
+    pf_p[0] = means3D[3 * idx], pf_p[1] = means3D[3 * idx + 1], pf_p[2] = means3D[3 * idx + 2];
+    if (scales) {
+      pf_s[0] = scales[3 * idx], pf_s[1] = scales[3 * idx + 1], pf_s[2] = scales[3 * idx + 2];
+      pf_q = reinterpret_cast<const float4*>(rotations)[idx];
+    }
+  }
   if (staged) stage_rows_in(s_sh, (shs_rest ? shs_rest : shs) + (size_t) base * RL, nrows, RL);
   __syncthreads();
   if (idx < P) {
 
   // gradients accumulated by the blend backward (+ the optional chained-in ones)
   float gm2[2] = {0.f, 0.f}, gcon[3] = {0.f, 0.f, 0.f}, gop = 0.f, gcol[3] = {0.f, 0.f, 0.f}, gex[4] = {0, 0, 0, 0};
-  const bool visible = radii[idx] > 0;
+  const bool visible = pf_radius > 0;
   {
     float4* row = reinterpret_cast<float4*>(gradacc + (size_t) idx * GRAD_ROW);
     float4 a = make_float4(0, 0, 0, 0), b = a, c = a, d = a;
     if (visible) {
-      a = row[0], b = row[1], c = row[2], d = row[3];
+      a = pf_row[0], b = pf_row[1], c = pf_row[2], d = pf_row[3];
       // skgs_raster_grads::workspace_is_zero: hand the scratch back all zero (rows of culled Gaussians are never touched)
       if (rezero) row[0] = row[1] = row[2] = row[3] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -550,7 +571,7 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_backward_kernel(int P,
     if (moments) {
       // fast blend build: slots 0..4 are sum w {dx, dy, dx^2, dx dy, dy^2} over all pixels (render_blend.inl);
       // dL/dmean2D = -(conic . [m1, m2]) * 0.5 * (W, H), dL/dconic = -0.5 * [m3, m4, m5]
-      const float4 q0 = recs[3 * idx], q1 = recs[3 * idx + 1];
+      const float4 q0 = pf_rec[0], q1 = pf_rec[1];
       const float cx = q0.z, cy = q0.w, cz = q1.x;
       const float m1 = a.x, m2 = a.y;
       gm2[0]  = -(cx * m1 + cy * m2) * (0.5f * W);
@@ -583,13 +604,12 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_backward_kernel(int P,
       for (int i = 3; i < M * 3; ++i) gsh_row[i] = 0.f;
     }
   } else {
-    const float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+    const float p[3] = {pf_p[0], pf_p[1], pf_p[2]};
     float c6[6];
     float s[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1};
     if (scales) {
-      s[0] = scales[3 * idx], s[1] = scales[3 * idx + 1], s[2] = scales[3 * idx + 2];
-      const float4 qv = reinterpret_cast<const float4*>(rotations)[idx];
-      q[0] = qv.x, q[1] = qv.y, q[2] = qv.z, q[3] = qv.w;
+      s[0] = pf_s[0], s[1] = pf_s[1], s[2] = pf_s[2];
+      q[0] = pf_q.x, q[1] = pf_q.y, q[2] = pf_q.z, q[3] = pf_q.w;
     }
     if (cov3D_precomp) {
 #pragma unroll
@@ -717,7 +737,7 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_backward_kernel(int P,
     }
     // ---- SH (part 3: +=) ----
     if (shs) {
-      const uint32_t clamp_bits = (__float_as_uint(recs[3 * idx + 2].z) >> 28) & 7u;
+      const uint32_t clamp_bits = (__float_as_uint(pf_rec[2].z) >> 28) & 7u;
       float dm[3];
       sh_backward(D, M, p, cam.campos, gsh_row, clamp_bits, gcol, gsh_dc, gsh_row, dm);  // coefficients and gradients share the row
       gmean[0] += dm[0], gmean[1] += dm[1], gmean[2] += dm[2];
