@@ -271,10 +271,31 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_moments_kernel
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* my_w = s_w + (size_t) (wave * 64 + lane) * Mp;
   float* my_u = s_u + (size_t) (wave * 64 + lane) * MOM_U;
+  const int n = blockIdx.x * DEFORM_THREADS + threadIdx.x;
+  // Every per-Gaussian input is requested before the bone table is staged (one round trip instead of a chain of
+  // dependent ones: the kernel runs at ~1.5 waves per SIMD, its duration is the length of a lane's dependency chain).
+  // The first PREF_K neighbour slots live in registers; a K beyond that reads the rest in place.
+  float pf_p[3] = {0, 0, 0}, pf_gdx[3] = {0, 0, 0}, pf_gds[3] = {0, 0, 0}, pf_ls[3] = {0, 0, 0}, pf_ol = 0.f, pf_go = 0.f;
+  float4 pf_r4 = make_float4(0.f, 0.f, 0.f, 0.f), pf_gr4 = pf_r4;
+  int pf_j[PREF_K];
+  float pf_w[PREF_K];
+#pragma unroll
+  for (int q = 0; q < PREF_K; ++q) pf_j[q] = 0, pf_w[q] = 0.f;
+  if (n < P) {
+#pragma unroll
+    for (int q = 0; q < PREF_K; ++q)
+      if (q < K) pf_j[q] = (int) indices[(size_t) n * K + q], pf_w[q] = weights[(size_t) n * K + q];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      pf_p[c] = points[3 * n + c], pf_gdx[c] = g_means[3 * n + c], pf_gds[c] = g_scales[3 * n + c];
+      pf_ls[c] = log_scale[3 * n + c];
+    }
+    pf_r4 = reinterpret_cast<const float4*>(rot)[n], pf_gr4 = reinterpret_cast<const float4*>(g_rotations)[n];
+    pf_ol = opacity_logit[n], pf_go = g_opacity[n];
+  }
   for (int j = threadIdx.x; j < M; j += DEFORM_THREADS) load_bone(bone_T, bone_drot, bone_dscale, j, s_bones + j * BONE_F);
   for (int i = 0; i < Mp; i += 4) *reinterpret_cast<float4*>(my_w + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
-  const int n = blockIdx.x * DEFORM_THREADS + threadIdx.x;
   const bool want_logits = g_sp_W != nullptr || g_logits != nullptr;
   float lw[PREF_K], lg[PREF_K];
   int lj[PREF_K];
@@ -284,17 +305,18 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_moments_kernel
 #pragma unroll
   for (int c = 0; c < MOM_U; ++c) u[c] = 0.f;
   if (n < P) {
-    const float p[3] = {points[3 * n], points[3 * n + 1], points[3 * n + 2]};
+    const float p[3] = {pf_p[0], pf_p[1], pf_p[2]};
     float sr[4] = {0, 0, 0, 0};
-    for (int k = 0; k < K; ++k) {
-      const int j   = (int) indices[(size_t) n * K + k];
-      const float w = weights[(size_t) n * K + k];
+    auto blend_rot = [&](int j, float w) {
       const float* b = s_bones + j * BONE_F;
       sr[0] += b[7] * w, sr[1] += b[8] * w, sr[2] += b[9] * w, sr[3] += b[10] * w;
       my_w[j] += w;  // own row: plain read-modify-write (KNN ids are distinct, += keeps it right if they are not)
-    }
-    const float4 r4  = reinterpret_cast<const float4*>(rot)[n];
-    const float4 gr4 = reinterpret_cast<const float4*>(g_rotations)[n];
+    };
+#pragma unroll
+    for (int q = 0; q < PREF_K; ++q)
+      if (q < K) blend_rot(pf_j[q], pf_w[q]);
+    for (int k = PREF_K; k < K; ++k) blend_rot((int) indices[(size_t) n * K + k], weights[(size_t) n * K + k]);
+    const float4 r4 = pf_r4, gr4 = pf_gr4;
     const float v[4] = {r4.x + sr[0], r4.y + sr[1], r4.z + sr[2], r4.w + sr[3]};
     const float gr[4] = {gr4.x, gr4.y, gr4.z, gr4.w};
     const float nv    = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
@@ -308,19 +330,19 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_moments_kernel
 #pragma unroll
       for (int c = 0; c < 4; ++c) g_v[c] = gr[c] / 1e-12f;
     }
-    const float g_dx[3] = {g_means[3 * n], g_means[3 * n + 1], g_means[3 * n + 2]};
-    const float g_ds[3] = {g_scales[3 * n], g_scales[3 * n + 1], g_scales[3 * n + 2]};
+    const float g_dx[3] = {pf_gdx[0], pf_gdx[1], pf_gdx[2]};
+    const float g_ds[3] = {pf_gds[0], pf_gds[1], pf_gds[2]};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       g_xyz[3 * n + c]       = g_dx[c];
-      g_log_scale[3 * n + c] = g_ds[c] * expf(log_scale[3 * n + c]);
+      g_log_scale[3 * n + c] = g_ds[c] * expf(pf_ls[c]);
     }
     reinterpret_cast<float4*>(g_rot)[n] = make_float4(g_v[0], g_v[1], g_v[2], g_v[3]);
-    const float sg     = 1.0f / (1.0f + expf(-opacity_logit[n]));
-    g_opacity_logit[n] = g_opacity[n] * sg * (1.0f - sg);
+    const float sg     = 1.0f / (1.0f + expf(-pf_ol));
+    g_opacity_logit[n] = pf_go * sg * (1.0f - sg);
     float dot = 0.f;
-    for (int k = 0; k < K; ++k) {  // dL/dw[p,k] = g_dx . (T_j p) + g_v . d_rot_j + g_ds . d_scale_j
-      const int j    = (int) indices[(size_t) n * K + k];
+    // dL/dw[p,k] = g_dx . (T_j p) + g_v . d_rot_j + g_ds . d_scale_j
+    auto weight_grad = [&](int j) {
       const float* b = s_bones + j * BONE_F;
       float y[3];
       se3_act(b, p, y);
@@ -329,14 +351,21 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_moments_kernel
       for (int c = 0; c < 4; ++c) gw += g_v[c] * b[7 + c];
 #pragma unroll
       for (int c = 0; c < 3; ++c) gw += g_ds[c] * b[11 + c];
-      if (g_weights) g_weights[(size_t) n * K + k] = gw;
-      if (want_logits) {  // softmax backward of the sp_W branch (lbs_weights_backward_kernel): same order of operations
-        const float w = weights[(size_t) n * K + k];
+      return gw;
+    };
 #pragma unroll
-        for (int q = 0; q < PREF_K; ++q)
-          if (q == k) lw[q] = w, lg[q] = gw, lj[q] = j;
-        dot += w * gw;
+    for (int q = 0; q < PREF_K; ++q) {
+      if (q < K) {
+        const float gw = weight_grad(pf_j[q]);
+        if (g_weights) g_weights[(size_t) n * K + q] = gw;
+        // softmax backward of the sp_W branch (lbs_weights_backward_kernel): same order of operations
+        lw[q] = pf_w[q], lg[q] = gw, lj[q] = pf_j[q];
+        dot += pf_w[q] * gw;
       }
+    }
+    for (int k = PREF_K; k < K; ++k) {  // (the logit gradient needs K <= PREF_K: enforced by the launcher)
+      const float gw = weight_grad((int) indices[(size_t) n * K + k]);
+      if (g_weights) g_weights[(size_t) n * K + k] = gw;
     }
     if (want_logits) {
 #pragma unroll
