@@ -278,6 +278,10 @@ def main():
             for v in range(args.views):
                 gA.capture(v)
                 gB.capture(v)
+            # the optimizer graphs' capture warm-up applies real updates: on reduced gradients only (see below)
+            for w in (vp.allreduce(0), vp.allreduce(1)):
+                if w is not None:
+                    w.wait()
             gC1.capture(0)
             gC2.capture(0)
     else:
@@ -331,6 +335,10 @@ def main():
             for v in range(args.views):
                 g_step.capture(v)
             if g_opt is not None:
+                # GraphedSteps.capture runs its function for real (warm-up) before recording it: the optimizer graph must
+                # see REDUCED gradients then, or every rank would apply its own view's gradient and the replicas would
+                # drift apart for good (tests/test_gpu_bench_contract.py runs two ranks and compares them)
+                reduce_grads()
                 g_opt.capture(0)
 
     train_step = eager_step if args.eager else graph_step
@@ -360,6 +368,16 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # view-parallel replicas must stay bit-identical: same reduced gradients, same Adam step on every rank
+    replicas_identical = None
+    if use_dist:
+        names = [n for n, _ in model.named_parameters()]
+        digest = torch.stack([p.detach().double().sum() for p in model.parameters()] +
+                             [p.detach().double().abs().sum() for p in model.parameters()])
+        every = [torch.empty_like(digest) for _ in range(world)]
+        dist.all_gather(every, digest)
+        differ = sorted({names[i % len(names)] for e in every for i in (every[0] != e).nonzero().flatten().tolist()})
+        replicas_identical = True if not differ else differ
     if not args.autograd:  # sticky device-side counter of forwards whose tile lists exceeded the capacity
         overflow += fstep.status()['overflow_events']
     assert int(overflow.item()) == 0, 'binning capacity overflow during the timed region: result invalid'
@@ -436,7 +454,8 @@ def main():
                        else f'buckets of {tile_bucket} slots per tile (longest list {longest})',
                        'joint_rotations': 'deform network (8x256 MLP) inside the step' if args.deform_net
                        else 'per-frame tables (the reference\'s sk_cache)',
-                       'step': 'autograd operator path' if args.autograd else 'FusedViewStep (direct C-ABI calls)'},
+                       'step': 'autograd operator path' if args.autograd else 'FusedViewStep (direct C-ABI calls)',
+                       'replicas_identical': replicas_identical},
             'roofline': {'bound': 'hbm', 'kernel': 'render_backward', 'achieved': round(achieved, 2),
                          'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 5),
                          'traffic': traffic, 'avg_us': round(rb_us, 2), 'launches': rb_n,

@@ -22,7 +22,10 @@ class GraphedSteps:
     capture starts.  A parameter's AccumulateGrad node is cached while any graph references it and remembers the
     stream it was created on; a backward captured on the side stream would then synchronise with that foreign
     (legacy default) stream, which drags it into the capture and crashes hipStreamEndCapture.  Drop such outputs
-    (or run those forwards under ``torch.no_grad()``) before capturing; ``capture`` runs ``gc.collect()`` first."""
+    (or run those forwards under ``torch.no_grad()``) before capturing; ``capture`` runs ``gc.collect()`` first.
+
+    ``capture`` EXECUTES ``fn`` ``warmup`` times before recording it.  View-parallel training must therefore capture an
+    optimizer step only where it would run anyway -- after the gradient all-reduce -- or the ranks' replicas diverge."""
 
     def __init__(self, fn: Callable[[Hashable], None], warmup: int = 2):
         self.fn = fn

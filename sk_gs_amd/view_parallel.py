@@ -26,6 +26,11 @@ def init_distributed(backend: Optional[str] = None, force: bool = False) -> tupl
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # test knobs: SKGS_SHARE_GPU=1 lets several ranks use one device (RCCL refuses that, so together with
+    # SKGS_DIST_BACKEND=gloo): a 1-GPU box can then run the real multi-rank schedule (tests/test_gpu_bench_contract.py)
+    if os.environ.get('SKGS_SHARE_GPU') and torch.cuda.device_count() > 0:
+        local_rank %= torch.cuda.device_count()
+    backend = os.environ.get('SKGS_DIST_BACKEND') or backend
     if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
