@@ -29,21 +29,21 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert abs(d['value'] - 1000.0 / d['ms_per_step']) / d['value'] < 0.01
 
 
-@pytest.mark.parametrize('extra', [[], ['--pipeline']])
-def test_two_ranks_share_the_gpu_and_stay_identical(extra):
-    """The driver's multi-GPU launch line with two ranks on this one GPU (gloo moves the gradients: RCCL refuses two ranks
+@pytest.mark.parametrize('ranks,extra', [(2, []), (2, ['--pipeline']), (2, ['--dense-spw-grad']), (2, ['--autograd']), (4, [])])
+def test_ranks_share_the_gpu_and_stay_identical(ranks, extra):
+    """The driver's multi-GPU launch line with 2 or 4 ranks on this one GPU (gloo moves the gradients: RCCL refuses two ranks
     per device): the real view-parallel schedule -- graph(fwd+bwd) | all-reduce | graph(expand + Adam) -- must keep the
     replicas bit-identical and print one line from rank 0 with whole-job throughput."""
     env = dict(os.environ, SKGS_DIST_BACKEND='gloo', SKGS_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29577', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
-           '--no-cpu-baseline'] + extra
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr',
+           '127.0.0.1', '--master-port', '29577', os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--steps', '6',
+           '--warmup', '2', '--no-cpu-baseline'] + extra
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     lines = [l for l in p.stdout.splitlines() if l.strip().startswith('{')]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['steps'] == 6 and d['scaling'] == 'weak'
+    assert d['n_gpus'] == ranks and d['steps'] == 6 and d['scaling'] == 'weak'
     assert d['config']['replicas_identical'] is True
-    assert abs(d['value'] - 2 * 1000.0 / d['ms_per_step']) / d['value'] < 0.01  # whole-job: both ranks' views per step
+    assert abs(d['value'] - ranks * 1000.0 / d['ms_per_step']) / d['value'] < 0.01  # whole-job: every rank's view per step
     assert 'cpu_baseline' not in d
