@@ -36,7 +36,7 @@ def test_ranks_share_the_gpu_and_stay_identical(ranks, extra):
     replicas bit-identical and print one line from rank 0 with whole-job throughput."""
     env = dict(os.environ, SKGS_DIST_BACKEND='gloo', SKGS_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr',
-           '127.0.0.1', '--master-port', '29577', os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--steps', '6',
+           '127.0.0.1', '--master-port', str(29577 + 7 * ranks + len(''.join(extra))), os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--steps', '6',
            '--warmup', '2', '--no-cpu-baseline'] + extra
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
