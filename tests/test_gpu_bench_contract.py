@@ -29,14 +29,15 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert abs(d['value'] - 1000.0 / d['ms_per_step']) / d['value'] < 0.01
 
 
-@pytest.mark.parametrize('ranks,extra', [(2, []), (2, ['--pipeline']), (2, ['--dense-spw-grad']), (2, ['--autograd']), (4, [])])
-def test_ranks_share_the_gpu_and_stay_identical(ranks, extra):
+@pytest.mark.parametrize('port,ranks,extra', [(29577, 2, []), (29578, 2, ['--pipeline']), (29579, 2, ['--dense-spw-grad']),
+                                              (29580, 2, ['--autograd']), (29581, 4, [])])
+def test_ranks_share_the_gpu_and_stay_identical(port, ranks, extra):
     """The driver's multi-GPU launch line with 2 or 4 ranks on this one GPU (gloo moves the gradients: RCCL refuses two ranks
     per device): the real view-parallel schedule -- graph(fwd+bwd) | all-reduce | graph(expand + Adam) -- must keep the
     replicas bit-identical and print one line from rank 0 with whole-job throughput."""
     env = dict(os.environ, SKGS_DIST_BACKEND='gloo', SKGS_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr',
-           '127.0.0.1', '--master-port', str(29577 + 7 * ranks + len(''.join(extra))), os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--steps', '6',
+           '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--steps', '6',
            '--warmup', '2', '--no-cpu-baseline'] + extra
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
