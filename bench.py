@@ -126,7 +126,10 @@ def main():
     ap.add_argument('--ppl', type=int, default=0, help='pixels per lane of the blend kernels (0 = heuristic)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
-    ap.add_argument('--ms-per-render', action='store_true', help='also time rasterizer fwd+bwd alone (fixed grads)')
+    ap.add_argument('--ms-per-render', action='store_true', default=None,
+                    help='also time rasterizer fwd+bwd alone (operator path, fixed upstream gradients, host-synchronised '
+                         'per render: median / p10 / p90 of 50); default: on for a 1-GPU run')
+    ap.add_argument('--no-ms-per-render', dest='ms_per_render', action='store_false')
     ap.add_argument('--lr', type=float, default=1e-4, help='base lr (reference 1e-3); small keeps the workload stationary')
     ap.add_argument('--torch-adam', action='store_true', help='use torch.optim.Adam(fused=True) instead of the one-launch kernel')
     ap.add_argument('--eager', action='store_true', help='issue every launch eagerly instead of replaying hipGraphs')
@@ -401,6 +404,8 @@ def main():
     _C.profile_enable([])
 
     ms_render = None
+    if args.ms_per_render is None:
+        args.ms_per_render = world == 1
     if args.ms_per_render:
         from sk_gs_amd.renderer.gaussian_render import render
         with torch.no_grad():
@@ -435,7 +440,8 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            'metric': 'train iters/sec (deform + rasterize fwd+bwd + L1/SSIM loss + Adam), 100k Gaussians @800x800',
+            'metric': 'train iters/sec (deform + rasterize fwd+bwd + L1/SSIM loss + Adam; ms/render fwd+bwd beside it), '
+                      f'{P // 1000}k Gaussians @{W}x{H}',
             'value': round(world * args.steps / elapsed, 3), 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -466,6 +472,13 @@ def main():
             'kernels': kernels,
         }
         if ms_render:
+            # the same pass as the sum of its kernels' HIP-event times inside the training step (no launch / sync overhead)
+            ras = ('preprocess_forward', 'count_tiles', 'scan_tiles', 'scatter', 'tile_sort', 'render_forward',
+                   'render_backward', 'preprocess_backward')
+            ms_render['kernel_sum'] = round(sum(kernels[k]['us'] * kernels[k]['launches_per_step']
+                                                for k in ras if k in kernels) / 1e3, 4)
+            ms_render['how'] = 'operator path render() + backward, eager, host-synchronised per render; kernel_sum: the ' \
+                               'rasterizer kernels of the fused step'
             line['ms_per_render_fwd_bwd'] = ms_render
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg, args.cpu_seconds)
