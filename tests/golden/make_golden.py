@@ -19,6 +19,9 @@ What is pinned (reference file:line of the function that produced the expected v
                   loss values and d(0.8 L1 + 0.2 SSIM)/d image
   mlp.npz         my_ext/blocks/mlp.py:43-85 MLP_with_skips (4 x 16, skip after layer 2, heads 4|4|3): parameters by their
                   state_dict names, outputs and parameter gradients for fixed cotangents
+  densify.npz     networks/gaussian_splatting.py:515-655 GaussianSplatting.change_optimizer / densify_and_clone / prune /
+                  reset_opacity / densify_and_split run on CPU with torch.optim.Adam(eps=1e-15): parameters, Adam moments
+                  and statistics after every operation, with Adam steps (recorded gradients) in between
 """
 import importlib.abc
 import importlib.machinery
@@ -202,6 +205,81 @@ def main():
     for (n, p), gr in zip(net.named_parameters(), grads):
         rec['param.' + n], rec['grad.' + n] = f32(p), f32(gr)
     np.savez(os.path.join(HERE, 'mlp.npz'), **rec)
+
+    # ---- adaptive density control: the reference's own clone / prune / reset_opacity / split on a torch Adam ---------
+    from networks.gaussian_splatting import GaussianSplatting
+    gs = GaussianSplatting(sh_degree=3, use_official_gaussians_render=False)
+    gd = torch.Generator().manual_seed(515)
+    P0, names = 60, ['_xyz', '_features_dc', '_features_rest', '_opacity', '_scaling', '_rotation']
+    shapes = {'_xyz': (3,), '_features_dc': (1, 3), '_features_rest': (15, 3), '_opacity': (1,), '_scaling': (3,),
+              '_rotation': (4,)}
+    init = {n: torch.randn(P0, *shapes[n], generator=gd) for n in names}
+    init['_scaling'] = torch.log(torch.rand(P0, 3, generator=gd) * 0.09 + 0.005)  # max scale straddles 0.01 * extent
+    init['_opacity'] = torch.randn(P0, 1, generator=gd) * 2.0
+    for n in names:
+        setattr(gs, n, torch.nn.Parameter(init[n].clone()))
+    lrs = {'xyz': 0.16e-3, 'f_dc': 2.5e-3, 'f_rest': 2.5e-3 / 20, 'opacity': 50e-3, 'scaling': 5e-3, 'rotation': 1e-3}
+    opt = torch.optim.Adam([{'params': [getattr(gs, n)], 'lr': lrs[gs.param_names_map[n]], 'name': gs.param_names_map[n]}
+                            for n in names], eps=1e-15)
+    rec = {'init.' + n: f32(init[n]) for n in names}
+    rec['lr'] = np.array([lrs[gs.param_names_map[n]] for n in names], dtype=np.float64)
+
+    def adam_step(tag):
+        for n in names:
+            p = getattr(gs, n)
+            p.grad = torch.randn(p.shape, generator=gd)
+            rec[f'{tag}.grad.{n}'] = f32(p.grad)
+        opt.step()
+
+    def snapshot(tag):
+        for n in names:
+            p = getattr(gs, n)
+            st = opt.state[p]
+            rec[f'{tag}.{n}'], rec[f'{tag}.m.{n}'], rec[f'{tag}.v.{n}'] = f32(p), f32(st['exp_avg']), f32(st['exp_avg_sq'])
+        rec[f'{tag}.accum'], rec[f'{tag}.denom'] = f32(gs.xyz_gradient_accum), f32(gs.denom)
+        rec[f'{tag}.radii'] = f32(gs.max_radii2D)
+
+    def set_stats(tag):
+        n = gs._xyz.shape[0]
+        gs.xyz_gradient_accum = torch.rand(n, 1, generator=gd) * 4e-4
+        gs.denom = torch.randint(0, 3, (n, 1), generator=gd).float()  # zeros -> nan -> 0, as in densify()
+        gs.max_radii2D = torch.rand(n, generator=gd) * 30
+        rec[f'{tag}.in_accum'], rec[f'{tag}.in_denom'] = f32(gs.xyz_gradient_accum), f32(gs.denom)
+        rec[f'{tag}.in_radii'] = f32(gs.max_radii2D)
+
+    extent, thr = 5.0, 2e-4
+    with torch.no_grad():
+        pass
+    adam_step('s0'), adam_step('s1')
+    snapshot('after_steps')
+    set_stats('clone')
+    with torch.no_grad():
+        grads = gs.xyz_gradient_accum / gs.denom
+        grads[grads.isnan()] = 0.0
+        gs.densify_and_clone(opt, grads, thr, 0.01 * extent)
+    snapshot('after_clone')
+    set_stats('prune')
+    with torch.no_grad():
+        gs.prune(opt, min_opacity=0.05, extent=extent, max_screen_size=20.0)
+    snapshot('after_prune')
+    adam_step('s2')
+    snapshot('after_step2')
+    with torch.no_grad():
+        gs.reset_opacity(opt)
+    snapshot('after_reset')
+    set_stats('split')
+    torch.manual_seed(99)
+    with torch.no_grad():
+        grads = gs.xyz_gradient_accum / gs.denom
+        grads[grads.isnan()] = 0.0
+        n_before = gs._xyz.shape[0]
+        big = (grads.squeeze() >= thr) & (torch.exp(gs._scaling).amax(1) > 0.01 * extent)
+        rec['split.selected'] = big.numpy()
+        gs.densify_and_split(opt, grads, thr, 0.01 * extent)
+    snapshot('after_split')
+    adam_step('s3')
+    snapshot('after_step3')
+    np.savez_compressed(os.path.join(HERE, 'densify.npz'), **rec)
     print('golden fixtures written to', HERE)
     for f in sorted(os.listdir(HERE)):
         print(f'  {f:<20} {os.path.getsize(os.path.join(HERE, f)):>8} B')

@@ -114,3 +114,94 @@ def test_densify_and_prune_keep_model_optimizer_and_step_consistent():
         opt.step()
         step.forward_backward(rs, 0, target)
     assert float(step.loss3[0]) < first
+
+
+def test_density_control_replays_the_reference_run():
+    """tests/golden/densify.npz: GaussianSplatting.densify_and_clone / prune / reset_opacity / densify_and_split of the
+    reference (gaussian_splatting.py:515-655) run on CPU over torch.optim.Adam, with Adam steps in between.  The same
+    sequence through sk_gs_amd.densify + FusedAdam must give the same parameters, moments and statistics."""
+    import os
+    import numpy as np
+    from sk_gs_amd import densify
+    from sk_gs_amd.optim import FusedAdam
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'densify.npz'))
+    names = ['_xyz', '_features_dc', '_features_rest', '_opacity', '_scaling', '_rotation']
+    dev = torch.device('cuda')
+
+    class Gaussians(torch.nn.Module):  # the six parameters of the reference's module, nothing else
+        def __init__(self):
+            super().__init__()
+            for n in names:
+                setattr(self, n, torch.nn.Parameter(torch.tensor(z['init.' + n], device=dev)))
+            self.P = self._xyz.shape[0]
+
+    m = Gaussians()
+    opt = FusedAdam([{'params': [getattr(m, n)], 'lr': float(lr), 'name': densify.PARAM_NAMES_MAP[n]}
+                     for n, lr in zip(names, z['lr'])], eps=1e-15)
+    stats = densify.DensifyStats(m.P, dev)
+
+    def adam_step(tag):
+        for n in names:
+            getattr(m, n).grad = torch.tensor(z[f'{tag}.grad.{n}'], device=dev)
+        opt.step()
+
+    def check(tag, skip=(), tol=2e-6):
+        for n in names:
+            p = getattr(m, n)
+            assert tuple(p.shape) == z[f'{tag}.{n}'].shape, (tag, n, tuple(p.shape))
+            if n in skip:
+                continue
+            st = opt.state[p]
+            assert rel_err(p, z[f'{tag}.{n}']) <= tol, (tag, n)
+            assert rel_err(st['exp_avg'], z[f'{tag}.m.{n}']) <= tol and rel_err(st['exp_avg_sq'], z[f'{tag}.v.{n}']) <= tol, (tag, n)
+
+    def set_stats(tag):
+        stats.xyz_gradient_accum = torch.tensor(z[f'{tag}.in_accum'], device=dev)
+        stats.denom = torch.tensor(z[f'{tag}.in_denom'], device=dev)
+        stats.max_radii2D = torch.tensor(z[f'{tag}.in_radii'], device=dev)
+
+    def grads_of_stats():
+        g = stats.xyz_gradient_accum / stats.denom
+        g[g.isnan()] = 0.0
+        return g
+
+    extent, thr = 5.0, 2e-4
+    adam_step('s0'), adam_step('s1')
+    check('after_steps')
+    set_stats('clone')
+    densify.densify_and_clone(m, opt, grads_of_stats(), thr, 0.01 * extent, stats)
+    check('after_clone')
+    assert float(stats.denom.abs().max()) == 0.0 and stats.denom.shape == z['after_clone.denom'].shape
+    set_stats('prune')
+    densify.prune(m, opt, stats, min_opacity=0.05, extent=extent, max_screen_size=20.0)
+    check('after_prune')
+    assert np.array_equal(stats.max_radii2D.cpu().numpy(), z['after_prune.radii'])
+    adam_step('s2')
+    check('after_step2')
+    densify.reset_opacity(m, opt)
+    check('after_reset')
+    set_stats('split')
+    n_sel = int(z['split.selected'].sum())
+    before = {n: getattr(m, n).detach().clone() for n in names}
+    densify.densify_and_split(m, opt, grads_of_stats(), thr, 0.01 * extent, N=2, stats=stats,
+                              generator=torch.Generator(device='cuda').manual_seed(3))
+    # the new positions are random samples (another generator than the reference's CPU one): everything else must agree
+    check('after_split', skip=('_xyz',))
+    kept = (~torch.tensor(z['split.selected'], device=dev))
+    n_kept = int(kept.sum())
+    assert torch.equal(m._xyz[:n_kept], before['_xyz'][kept])
+    assert rel_err(m._xyz[:n_kept], z['after_split._xyz'][:n_kept]) <= 2e-6
+    # a sample lies within a few standard deviations of its parent: |R^T (x_new - mu)| / sigma is a standard normal draw
+    sel = ~kept
+    mu = before['_xyz'][sel].repeat(2, 1)
+    R = densify.quaternion_to_R(before['_rotation'][sel]).repeat(2, 1, 1)
+    sig = torch.exp(before['_scaling'][sel]).repeat(2, 1)
+    zed = torch.bmm(R.transpose(1, 2), (m._xyz[n_kept:] - mu)[..., None]).squeeze(-1) / sig
+    assert zed.shape == (2 * n_sel, 3) and float(zed.abs().max()) < 6.0 and 0.5 < float(zed.std()) < 1.5
+    # the state of the appended rows starts from zero and the next step works on the new shapes
+    for n in names:
+        if n != '_xyz':
+            getattr(m, n).grad = torch.tensor(z[f's3.grad.{n}'], device=dev)
+    m._xyz.grad = torch.tensor(z['s3.grad._xyz'], device=dev)
+    opt.step()
+    check('after_step3', skip=('_xyz',))
