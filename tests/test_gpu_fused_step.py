@@ -19,14 +19,14 @@ def _setup(P, M, K, W, H, frames, seed=0):
     return model, rs, target
 
 
-@pytest.mark.parametrize('use_bg', [True, False])
-@pytest.mark.parametrize('flat', [True, False])
-def test_fused_step_matches_autograd(use_bg, flat):
+@pytest.mark.parametrize('use_bg,flat,W,H', [(True, True, 160, 120), (True, False, 160, 120), (False, True, 160, 120),
+                                              (False, False, 160, 120), (True, True, 203, 117), (False, False, 35, 19)])
+def test_fused_step_matches_autograd(use_bg, flat, W, H):
     from sk_gs_amd import _C
     from sk_gs_amd.fused_step import FusedViewStep
     from sk_gs_amd.losses import image_loss
     from sk_gs_amd.view_parallel import FlatGradBuffer
-    P, M, K, W, H, frames, tid = 4000, 12, 4, 160, 120, 3, 1
+    P, M, K, frames, tid = 4000, 12, 4, 3, 1
     model, rs, target = _setup(P, M, K, W, H, frames)
     bg = torch.tensor([1.0, 0.5, 0.25], device='cuda') if use_bg else None
     # ---- autograd operator path
@@ -49,12 +49,18 @@ def test_fused_step_matches_autograd(use_bg, flat):
     step.forward_backward(rs, tid, target)
     st = step.status()
     assert st['overflow'] == 0 and st['num_rendered'] == R
-    assert rel_err(step.image, ref_img) <= 5e-6  # C + T*bg in-kernel vs C + (1 - (1 - T))*bg in torch
-    assert abs(float(step.loss3[0]) - ref_loss) <= 5e-6 * abs(ref_loss)
+    # C + T*bg in-kernel vs C + (1 - (1 - T))*bg in torch: 5e-6.  The operator path takes the LBS weights from torch's
+    # softmax, the fused one from its own kernel (an ulp apart): a pair sitting on the alpha >= 1/255 cut may flip in a
+    # pixel or two (seen at 203 x 117), hence the robust comparison
+    assert_close_robust(step.image, ref_img, 5e-6, 1e-4, name='image')
+    assert abs(float(step.loss3[0]) - ref_loss) <= 2e-5 * abs(ref_loss)
     for n, p in model.named_parameters():
-        assert_close_robust(p.grad, ref[n], 1e-4, 1e-4, name=n)  # atomics order + in-kernel background rounding
+        if p.numel() >= 10000:  # per-Gaussian tensors: atomics order, in-kernel background rounding, a flipped pair
+            assert_close_robust(p.grad, ref[n], 1e-4, 1e-3, name=n)
+        else:                   # per-bone tables: sums over all Gaussians, a flipped pair moves them by a few 1e-4
+            assert rel_err(p.grad, ref[n]) <= 1e-3, n
     vs = out['viewspace_points'].grad
-    assert_close_robust(step.grad_means2D, vs, 1e-4, 1e-4, name='means2D')
+    assert_close_robust(step.grad_means2D, vs, 1e-4, 1e-3, name='means2D')
     # densification statistics of this view (gaussian_splatting.py:503-513, sk_gs.py:1990-1997)
     vis = step.radii > 0
     assert torch.equal(step.denom.view(-1), vis.float()) and torch.equal(step.max_radii2D, step.radii.float() * vis)
