@@ -9,6 +9,7 @@ including the Jacobian of the quaternion normalisation the SE3 constructor appli
 equals what lietorch's ``FromVec`` returns (tangent gradient times pinv of ``orthogonal_projector``, lie.h:82-90,
 303-311): both are the unique gradient of a scale-invariant function of q, orthogonal to q.
 """
+import ctypes as C
 from typing import Optional, Tuple
 
 import torch
@@ -53,6 +54,44 @@ def lbs_deform(points: Tensor, weights: Tensor, indices: Tensor, bone_T: Tensor,
                             opacity_logit)
 
 
+class _KnnSoftmaxWeights(torch.autograd.Function):
+    """``knn_points`` + ``softmax(gather(sp_W, idx))`` (the `W` method of calc_LBS_weight, sk_gs.py:757,767-768) as one
+    launch per direction: ``skgs_knn_lbs_weights`` forward, ``skgs_lbs_weights_backward`` (dense [P,M] logit gradient)
+    backward -- the kernels ``FusedViewStep`` uses, so both paths see the same weights, bit for bit."""
+
+    @staticmethod
+    def forward(ctx, points, joints, sp_W, K: int):
+        lib = _C.load_library()
+        _C._require_gpu(points, 'points')
+        dev = points.device
+        with _C._on_device(dev):
+            pts, jts, logits = _C._f32c(points, dev), _C._f32c(joints, dev), _C._f32c(sp_W, dev)
+            P, M = logits.shape
+            idx = torch.empty((P, K), dtype=torch.int64, device=dev)
+            w = torch.empty((P, K), dtype=torch.float32, device=dev)
+            _C._check(lib.skgs_knn_lbs_weights(C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_void_p(_C._ptr(pts)),
+                                               C.c_void_p(_C._ptr(jts)), C.c_void_p(_C._ptr(logits)),
+                                               C.c_void_p(_C._ptr(idx)), C.c_void_p(_C._ptr(w)), _C._stream()))
+        ctx.save_for_backward(w, idx)
+        ctx.M = M
+        ctx.mark_non_differentiable(idx)
+        return w, idx
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_w, _g_idx):
+        w, idx = ctx.saved_tensors
+        lib = _C.load_library()
+        P, K = w.shape
+        with _C._on_device(w.device):
+            g_w = _C._f32c(g_w, w.device)
+            g_sp_W = torch.empty((P, ctx.M), dtype=torch.float32, device=w.device)
+            _C._check(lib.skgs_lbs_weights_backward(C.c_int32(P), C.c_int32(ctx.M), C.c_int32(K), C.c_void_p(_C._ptr(w)),
+                                                    C.c_void_p(_C._ptr(idx)), C.c_void_p(_C._ptr(g_w)),
+                                                    C.c_void_p(_C._ptr(g_sp_W)), _C._stream()))
+        return None, None, g_sp_W, None
+
+
 def calc_lbs_weight(points: Tensor, joints: Tensor, K: int, sp_W: Optional[Tensor] = None,
                     kernel_radius: Optional[Tensor] = None, kernel_weight: Optional[Tensor] = None,
                     temperature: float = 1., feature: Optional[Tensor] = None, sp_feature: Optional[Tensor] = None
@@ -64,6 +103,9 @@ def calc_lbs_weight(points: Tensor, joints: Tensor, K: int, sp_W: Optional[Tenso
         joints_q = torch.cat([joints.detach(), sp_feature], dim=-1)
     else:
         joints_q = joints
+        # plain `W` method on xyz: search + gather + softmax in one launch (M <= 60: the dense backward's LDS rows)
+        if sp_W is not None and kernel_radius is None and points.shape[-1] == 3 and K <= 16 and K <= sp_W.shape[1] <= 60:
+            return _KnnSoftmaxWeights.apply(points.detach(), joints.detach(), sp_W, K)
     with torch.no_grad():
         _, indices = _C.knn_bones(points.detach(), joints_q.detach(), K)
     if kernel_radius is not None or (sp_W is None):

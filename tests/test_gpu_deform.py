@@ -292,3 +292,22 @@ def test_deform_backward_with_logit_gradient_folded_in(P, M, K):
     assert lib.skgs_lbs_deform_backward_logits(C.byref(d), *[p(x) for x in up], None, p(a['gT']), p(a['gdr']), p(a['gds']),
                                                p(a['gx']), p(a['gls']), p(a['grot']), p(a['gop']), p(dense_ref), None, p(ws),
                                                C.c_size_t(ws.numel()), st) != 0
+
+
+def test_calc_lbs_weight_W_method_one_launch_matches_torch():
+    """calc_lbs_weight(sp_W=...) (one launch per direction) vs knn + torch gather / softmax and its autograd"""
+    from sk_gs_amd import _C
+    from sk_gs_amd.deform import calc_lbs_weight
+    g = torch.Generator().manual_seed(11)
+    P, M, K = 4000, 20, 5
+    pts, joints = torch.randn(P, 3, generator=g).cuda(), torch.randn(M, 3, generator=g).cuda()
+    sp_W = torch.randn(P, M, generator=g).cuda().requires_grad_(True)
+    w, idx = calc_lbs_weight(pts, joints, K, sp_W=sp_W)
+    _, idx_ref = _C.knn_bones(pts, joints, K)
+    ref_W = sp_W.detach().clone().requires_grad_(True)
+    w_ref = torch.gather(ref_W, 1, idx_ref).softmax(-1)
+    assert torch.equal(idx, idx_ref) and rel_err(w, w_ref) <= 2e-6
+    cot = torch.randn(P, K, generator=g).cuda()
+    (g1,) = torch.autograd.grad(w, sp_W, cot)
+    (g2,) = torch.autograd.grad(w_ref, ref_W, cot)
+    assert rel_err(g1, g2) <= 2e-6
