@@ -33,7 +33,7 @@ def main():
     from sk_gs_amd import _C, densify, scene
     from sk_gs_amd.fused_step import FusedViewStep
     from sk_gs_amd.model import SkinnedGaussians
-    from sk_gs_amd.optim import FusedAdam
+    from sk_gs_amd.optim import FusedAdam, position_lr
     from sk_gs_amd.train_step import GraphedSteps
     from sk_gs_amd.view_parallel import ViewParallel, init_distributed
 
@@ -81,6 +81,8 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234)          # same samples on every rank
     for it in range(args.iters):
         run(vp.view_index(it, args.views))
+        if it % 100 == 0:  # update_learning_rate (gaussian_splatting.py:455-465): the captured Adam step reads the new rate
+            opt.set_lr('xyz', position_lr(it, args.lr * 0.16, args.lr * 0.0016, max_steps=30_000, delay_mult=0.01))
         if args.densify_every and it > 0 and it % args.densify_every == 0 and it < args.iters - 1:
             vp.allreduce_densify_stats(step.xyz_gradient_accum, step.denom, step.max_radii2D)
             before = model.P

@@ -16,6 +16,22 @@ import torch
 from sk_gs_amd import _C
 
 
+def position_lr(step: int, lr_init: float, lr_final: float, max_steps: int = 30_000, delay_steps: int = 0,
+                delay_mult: float = 1.0) -> float:
+    """Learning rate of the `xyz` group at ``step``: log-linear interpolation from ``lr_init`` to ``lr_final`` over
+    ``max_steps``, optionally eased in by a sine ramp from ``delay_mult`` over ``delay_steps`` -- the schedule
+    ``get_expon_lr_func`` builds for ``update_learning_rate`` (networks/gaussian_splatting.py:56-84,455-465; defaults
+    lr_position_init 0.16e-3 -> lr_position_final 0.0016e-3 over 30k steps).  Push it with ``FusedAdam.set_lr``."""
+    import math
+    if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+        return 0.0
+    ramp = 1.0
+    if delay_steps > 0:
+        ramp = delay_mult + (1.0 - delay_mult) * math.sin(0.5 * math.pi * min(max(step / delay_steps, 0.0), 1.0))
+    t = min(max(step / max_steps, 0.0), 1.0)
+    return ramp * math.exp((1.0 - t) * math.log(lr_init) + t * math.log(lr_final))
+
+
 class FusedAdam:
     def __init__(self, param_groups: Iterable[dict], betas=(0.9, 0.999), eps: float = 1e-15,
                  zero_after_step: 'torch.Tensor' = None):
@@ -118,8 +134,12 @@ class FusedAdam:
         self._upload()
         return out
 
-    def set_lr(self, group_index: int, lr: float):
-        self.param_groups[group_index]['lr'] = lr
+    def set_lr(self, group, lr: float):
+        """``group``: index or name of the parameter group.  Re-uploads the descriptor table (outside graph capture); a
+        captured ``step`` reads the table at every replay, so the new rate applies to replays too."""
+        if isinstance(group, str):
+            group = next(i for i, g in enumerate(self.param_groups) if g.get('name') == group)
+        self.param_groups[group]['lr'] = float(lr)
         self._upload()
 
     def zero_grad(self, set_to_none: bool = False):

@@ -22,6 +22,7 @@ What is pinned (reference file:line of the function that produced the expected v
   densify.npz     networks/gaussian_splatting.py:515-655 GaussianSplatting.change_optimizer / densify_and_clone / prune /
                   reset_opacity / densify_and_split run on CPU with torch.optim.Adam(eps=1e-15): parameters, Adam moments
                   and statistics after every operation, with Adam steps (recorded gradients) in between
+  lr_schedule.npz networks/gaussian_splatting.py:56-84 get_expon_lr_func at a grid of steps (three parameter sets)
 """
 import importlib.abc
 import importlib.machinery
@@ -280,6 +281,20 @@ def main():
     adam_step('s3')
     snapshot('after_step3')
     np.savez_compressed(os.path.join(HERE, 'densify.npz'), **rec)
+
+    # ---- learning-rate schedule of the xyz group (get_expon_lr_func) --------------------------------------------------
+    from networks.gaussian_splatting import get_expon_lr_func
+    steps = np.array([-1, 0, 1, 10, 99, 100, 500, 2500, 15000, 29999, 30000, 40000], dtype=np.int64)
+    cases = [dict(lr_init=0.16e-3, lr_final=0.0016e-3, lr_delay_mult=0.01, max_steps=30000),
+             dict(lr_init=1e-2, lr_final=1e-4, lr_delay_steps=200, lr_delay_mult=0.1, max_steps=5000),
+             dict(lr_init=0.0, lr_final=0.0, max_steps=100)]
+    rec = {'steps': steps}
+    for i, c in enumerate(cases):
+        f = get_expon_lr_func(**c)
+        rec[f'lr{i}'] = np.array([f(int(t)) for t in steps], dtype=np.float64)
+        rec[f'args{i}'] = np.array([c['lr_init'], c['lr_final'], c.get('lr_delay_steps', 0), c.get('lr_delay_mult', 1.0),
+                                    c['max_steps']], dtype=np.float64)
+    np.savez(os.path.join(HERE, 'lr_schedule.npz'), **rec)
     print('golden fixtures written to', HERE)
     for f in sorted(os.listdir(HERE)):
         print(f'  {f:<20} {os.path.getsize(os.path.join(HERE, f)):>8} B')

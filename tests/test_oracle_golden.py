@@ -192,3 +192,13 @@ def test_deform_mlp_matches_reference_modules():
     # and the module's own forward path in plain torch (encoder + net) runs and has the reference's output split
     outs = mlp.reference_forward(torch.randn(5, 3), torch.tensor([0.25]))
     assert [tuple(o.shape) for o in outs] == [(5, 4), (5, 4), (5, 3)] and saved is not None
+
+
+def test_position_lr_schedule_matches_reference():
+    """sk_gs_amd.optim.position_lr vs get_expon_lr_func (gaussian_splatting.py:56-84) at the recorded steps"""
+    from sk_gs_amd.optim import position_lr
+    z = np.load(os.path.join(GOLD, "lr_schedule.npz"))
+    for i in range(3):
+        lr_init, lr_final, delay_steps, delay_mult, max_steps = z[f'args{i}']
+        got = [position_lr(int(t), lr_init, lr_final, int(max_steps), int(delay_steps), delay_mult) for t in z['steps']]
+        np.testing.assert_allclose(got, z[f'lr{i}'], rtol=1e-12, atol=0)
