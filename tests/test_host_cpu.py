@@ -151,3 +151,16 @@ def test_view_parallel_allreduce_two_processes_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f'rank {r} ok' in o
+
+
+def test_every_c_abi_entry_point_is_documented():
+    """INTEGRATION.md (section 8) / DESIGN.md name every function include/skgs.h declares"""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, 'include', 'skgs.h')).read()
+    docs = open(os.path.join(root, 'INTEGRATION.md')).read() + open(os.path.join(root, 'DESIGN.md')).read()
+    declared = sorted(set(re.findall(r'^(?:int|size_t|int64_t|void|const char\*) (skgs_[a-z0-9_]+)\(', header, flags=re.M)))
+    assert len(declared) >= 40
+    missing = [name for name in declared if ('`' + name + '`') not in docs]
+    assert not missing, missing
