@@ -139,6 +139,9 @@ def main():
                          'of launch / stream-join overhead per step on one GPU, so it only pays when the all-reduce is slow)')
     ap.add_argument('--dense-spw-grad', action='store_true',
                     help='world > 1: all-reduce the dense [P,M] sp_W gradient instead of the compact [P,K] logit gradient')
+    ap.add_argument('--sh-allreduce', action='store_true',
+                    help='world > 1: all-reduce the dense SH gradient (192 B per Gaussian) instead of all-gathering its two '
+                         'factors per view (24 B per Gaussian and rank) and rebuilding the rows on every rank')
     ap.add_argument('--compact-lists', action='store_true',
                     help='count -> scan -> scatter into compact tile lists (the reference layout) instead of fixed per-tile '
                          'buckets (no counting / scan launch)')
@@ -193,6 +196,9 @@ def main():
     fused_dist = use_dist and not args.autograd and not args.torch_adam
     pipelined = fused_dist and args.pipeline
     compact = fused_dist and (pipelined or not args.dense_spw_grad)
+    # the SH gradient of one view is rank-1 per Gaussian (basis(view direction) x colour gradient): the ranks exchange the
+    # two factors and every rank rebuilds and sums the rows in rank order
+    sh_factored = compact and not pipelined and not args.sh_allreduce
     groups = model.param_groups(lr=args.lr)
     if compact:
         # the dense [P,M] sp_W gradient never goes on the wire: the ranks all-reduce the compact [P,K] logit gradient
@@ -203,11 +209,18 @@ def main():
         bucket1 += [t for t in (model.sk_r, model.sk_d_rot, model.sk_d_scale, model.global_tr) if t is not None]
         if model.sk_deform_net is not None:
             bucket1 += list(model.sk_deform_net.parameters())
+        fac_local = fac_all = None
         if pipelined:
             vp = BucketedGradReducer([bucket0, bucket1], extras=[0, P * model.K])
+        elif sh_factored:
+            vp = BucketedGradReducer([bucket1], extras=[P * model.K])
+            for p_ in bucket0:  # not on the wire: plain gradient tensors, rebuilt from the gathered factors
+                p_.grad = torch.zeros_like(p_)
+            fac_all = torch.zeros((world, P, 6), device=dev)
+            fac_local = fac_all[rank]
         else:
             vp = BucketedGradReducer([bucket0 + bucket1], extras=[P * model.K])
-        comm_bytes = vp.nbytes
+        comm_bytes = vp.nbytes + (fac_all.numel() * 4 if sh_factored else 0)
     else:
         vp = ViewParallel(model.parameters(), average=True)
         comm_bytes = vp.grads.nbytes
@@ -233,7 +246,8 @@ def main():
         from sk_gs_amd.fused_step import FusedViewStep
         fstep = FusedViewStep(model, W, H, capacity=int(R_max * 1.25 * _C.config.capacity_growth) + 1024,
                               background=background, grad_scale=1.0 / world,
-                              spw_logit_grad=vp.extra_views[-1] if compact else None, tile_bucket=tile_bucket)
+                              spw_logit_grad=vp.extra_views[-1] if compact else None, tile_bucket=tile_bucket,
+                              sh_factors=fac_local if sh_factored else None)
         # the per-frame table gradients (one row written per step) are cleared by the Adam launch itself
         table_span = None if args.torch_adam else fstep.table_grad_span()
         fstep.tables_zeroed_by_optimizer = table_span is not None
@@ -307,11 +321,20 @@ def main():
 
         def reduce_grads():
             if compact:
-                vp.allreduce(0, async_op=False)
+                w = vp.allreduce(0, async_op=sh_factored)
+                if sh_factored:  # every rank's (direction, colour gradient) pairs; own slice already in place
+                    if dist.get_backend() == 'nccl':  # in place: this rank's slice is already where it belongs
+                        dist.all_gather_into_tensor(fac_all.view(-1), fac_local.view(-1))
+                    else:
+                        dist.all_gather(list(fac_all.unbind(0)), fac_local)
+                    if w is not None:
+                        w.wait()
             else:
                 vp.allreduce_grads(prescaled=prescaled)
 
         def update(_=0):
+            if sh_factored:
+                fstep.sh_grads_from_factors(fac_all, 3)
             if compact:
                 fstep.scatter_spw_grad()
             opt.step()
@@ -454,7 +477,9 @@ def main():
                            f'2-bucket grad all-reduce ({comm_bytes / 1e6:.1f} MB, SH bucket overlapped with the skinning '
                            f'backward, second bucket with Adam)' if pipelined else
                            f'flat-buffer grad all-reduce ({comm_bytes / 1e6:.1f} MB'
-                           + (', compact LBS-logit gradient' if compact else '') + ')'),
+                           + (', compact LBS-logit gradient' if compact else '')
+                           + (f', SH gradient as all-gathered factors ({world} x {P * 24 / 1e6:.1f} MB)' if sh_factored else '')
+                           + ')'),
                        'launch': 'eager' if args.eager else 'one hipGraph replay per view step',
                        'tile_lists': 'compact (count, scan, scatter)' if (args.autograd or args.compact_lists)
                        else f'buckets of {tile_bucket} slots per tile (longest list {longest})',

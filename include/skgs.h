@@ -142,6 +142,11 @@ typedef struct skgs_raster_grads {
   /* ... unless workspace_is_zero != 0: the caller guarantees the scratch is all zero on entry and the library leaves
    * it all zero on exit (saves the clearing launch when the same scratch serves every step) */
   int32_t workspace_is_zero;
+  /* Optional, instead of dL_dsh / dL_dsh_rest (which are then not written and may be NULL): [P,6] floats per Gaussian,
+   * the unit view direction (x, y, z) and the clamp-masked colour gradient (r, g, b) -- the SH gradient of ONE view is
+   * their outer product basis(dir) x g (gaussian_rasterizer_backwrad.cu:26-127).  View-parallel training all-gathers these
+   * 24 bytes per Gaussian and view instead of all-reducing 192, and rebuilds the rows with skgs_sh_grad_from_factors. */
+  float* dL_dsh_factors;
 } skgs_raster_grads;
 size_t skgs_backward_workspace_bytes(int32_t P);
 
@@ -163,6 +168,12 @@ int skgs_topk_weights(int32_t topk, int32_t W, int32_t H, int32_t P, const skgs_
 /* present [P] bytes (0/1): near-plane test of in_frustum{,_colmap} */
 int skgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, int32_t colmap, uint8_t* present,
     skgs_stream_t stream);
+
+/* dL/dsh rows from the factors of n_views views ([n_views][P][6], see skgs_raster_grads::dL_dsh_factors), views summed in
+ * index order: dL_dsh [P,M,3], or the DC part [P,1,3] with dL_dsh_rest [P,M-1,3].  One view reproduces the rows
+ * skgs_rasterize_backward writes, bit for bit. */
+int skgs_sh_grad_from_factors(int32_t P, int32_t n_views, int32_t sh_degree, int32_t sh_coeffs, const float* factors,
+    float* dL_dsh, float* dL_dsh_rest, skgs_stream_t stream);
 
 /* ---- LBS deform + activation epilogue (networks/sk_gs.py:1143-1150,1162,1192-1203) ---- */
 typedef struct skgs_deform_inputs {

@@ -61,7 +61,7 @@ class _RasterGrads(C.Structure):
         ('dL_dopacity', C.c_void_p), ('dL_dmeans3D', C.c_void_p), ('dL_dcov3D', C.c_void_p), ('dL_dsh', C.c_void_p),
         ('dL_dscales', C.c_void_p), ('dL_drotations', C.c_void_p), ('dL_dextras', C.c_void_p),
         ('dL_dsh_rest', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t),
-        ('workspace_is_zero', C.c_int32),
+        ('workspace_is_zero', C.c_int32), ('dL_dsh_factors', C.c_void_p),
     ]
 
 

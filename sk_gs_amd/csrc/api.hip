@@ -196,8 +196,11 @@ int skgs_rasterize_backward(const skgs_raster_inputs* in, const skgs_raster_buff
   SKGS_REQUIRE(gr->dL_dmeans2D && gr->dL_dcolors && gr->dL_dopacity && gr->dL_dmeans3D && gr->dL_dcov3D &&
                    gr->dL_dscales && gr->dL_drotations,
       "gradient outputs are required");
-  SKGS_REQUIRE(!(in->sh && in->sh_coeffs > 0) || gr->dL_dsh, "dL_dsh is required when sh is given");
-  SKGS_REQUIRE((in->sh_rest != nullptr) == (gr->dL_dsh_rest != nullptr), "dL_dsh_rest goes with sh_rest (split SH storage)");
+  SKGS_REQUIRE(!(in->sh && in->sh_coeffs > 0) || gr->dL_dsh || gr->dL_dsh_factors,
+      "dL_dsh (or dL_dsh_factors) is required when sh is given");
+  SKGS_REQUIRE(gr->dL_dsh_factors || (in->sh_rest != nullptr) == (gr->dL_dsh_rest != nullptr),
+      "dL_dsh_rest goes with sh_rest (split SH storage)");
+  SKGS_REQUIRE(!gr->dL_dsh_factors || (!gr->dL_dsh && !gr->dL_dsh_rest), "dL_dsh_factors replaces dL_dsh / dL_dsh_rest");
   SKGS_REQUIRE(gr->workspace && gr->workspace_bytes >= skgs_backward_workspace_bytes(in->P), "workspace too small");
   hipStream_t s = (hipStream_t) stream;
   GeomView g    = geom_view(buf->geom);
@@ -308,6 +311,13 @@ int skgs_lbs_deform_backward_logits(const skgs_deform_inputs* in, const float* g
       "deform backward: workspace too small (skgs_lbs_deform_backward_workspace_bytes)");
   return launch_deform_backward(*in, g_means, g_scales, g_rotations, g_opacity, g_weights, g_bone_T, g_bone_drot,
       g_bone_dscale, g_xyz, g_log_scale, g_rot, g_opacity_logit, workspace, (hipStream_t) stream, g_sp_W, g_logits);
+}
+
+int skgs_sh_grad_from_factors(int32_t P, int32_t n_views, int32_t sh_degree, int32_t sh_coeffs, const float* factors,
+    float* dL_dsh, float* dL_dsh_rest, skgs_stream_t stream) {
+  SKGS_REQUIRE(P >= 0 && n_views >= 1, "sh_grad_from_factors: bad sizes");
+  SKGS_REQUIRE(P == 0 || (factors && dL_dsh), "sh_grad_from_factors: NULL argument");
+  return launch_sh_grad_from_factors(P, n_views, sh_degree, sh_coeffs, factors, dL_dsh, dL_dsh_rest, (hipStream_t) stream);
 }
 
 int skgs_knn_bones(int32_t P, int32_t M, int32_t K, int32_t dim, const float* points, const float* joints,

@@ -424,8 +424,10 @@ __device__ __forceinline__ void dnormvdv3(const float* v, const float* dv, float
 // follow the convention of sh_to_rgb (coefficient 0 through the first pointer; only coefficients >= 1 of sh are read).
 // Every read of `sh` happens before the first write to dL_dsh, so the two may be the SAME row (the kernel keeps the
 // coefficients and their gradients in one LDS row per lane).
+// `factors` (6 floats, or NULL): instead of the M x 3 gradient row, emit what it is the outer product of -- the unit
+// direction (x, y, z) and the clamp-masked colour gradient g -- for skgs_sh_grad_from_factors (view-parallel training).
 __device__ __forceinline__ void sh_backward(int deg, int M, const float* mean, const float* campos, const float* sh,
-    uint32_t clamp_bits, const float* dL_dcolor, float* dL_ddc, float* dL_dsh, float* dL_dmean_out) {
+    uint32_t clamp_bits, const float* dL_dcolor, float* dL_ddc, float* dL_dsh, float* dL_dmean_out, float* factors) {
   const float dir_orig[3] = {mean[0] - campos[0], mean[1] - campos[1], mean[2] - campos[2]};
   const float len = sqrtf(dir_orig[0] * dir_orig[0] + dir_orig[1] * dir_orig[1] + dir_orig[2] * dir_orig[2]);
   const float x = dir_orig[0] / len, y = dir_orig[1] / len, z = dir_orig[2] / len;
@@ -470,7 +472,11 @@ __device__ __forceinline__ void sh_backward(int deg, int M, const float* mean, c
   const float dL_ddir[3] = {dx[0] * g[0] + dx[1] * g[1] + dx[2] * g[2], dy[0] * g[0] + dy[1] * g[1] + dy[2] * g[2],
       dz[0] * g[0] + dz[1] * g[1] + dz[2] * g[2]};
   dnormvdv3(dir_orig, dL_ddir, dL_dmean_out);
-  // ---- writes: d(colour)/d(coefficient i) = basis_i(direction)
+  if (factors) {
+    factors[0] = x, factors[1] = y, factors[2] = z, factors[3] = g[0], factors[4] = g[1], factors[5] = g[2];
+    return;
+  }
+  // ---- writes: d(colour)/d(coefficient i) = basis_i(direction)   (sh_basis_row below restates these coefficients)
 #define SETSH(i, coef)                                             \
   {                                                                \
     const float _k = (coef);                                       \
@@ -516,7 +522,8 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_backward_kernel(int P,
     float* __restrict__ dL_dconic_out, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dsh_rest,
-    float* __restrict__ dL_dscales, float* __restrict__ dL_drot, float* __restrict__ dL_dextras) {
+    float* __restrict__ dL_dscales, float* __restrict__ dL_drot, float* __restrict__ dL_dextras,
+    float* __restrict__ sh_factors /* [P,6] or NULL: see sh_backward */) {
   __shared__ Cam cam;
   if (threadIdx.x < 16) {
     cam.view[threadIdx.x] = viewmatrix[threadIdx.x];
@@ -527,7 +534,7 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_backward_kernel(int P,
   // SH rows of this workgroup -> LDS; the gradient rows are built in the same LDS rows (sh_backward reads before it
   // writes) and leave as one contiguous span at the end.  The DC term is not read by the backward.
   extern __shared__ float s_sh[];
-  const bool staged = shs != nullptr && dL_dsh != nullptr;
+  const bool staged = shs != nullptr && (dL_dsh != nullptr || sh_factors != nullptr);
   const int RL      = shs_rest ? (M - 1) * 3 : M * 3;
   const int base = blockIdx.x * blockDim.x, nrows = min((int) blockDim.x, P - base);
   // Every per-Gaussian input is requested BEFORE the SH staging barrier, unconditionally: radius -> gradient row ->
@@ -597,9 +604,13 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_backward_kernel(int P,
   // gradient rows of the SH coefficients: one [M][3] row, or split DC [1][3] / rest [M-1][3] rows (rest biased by -3)
   float* my_row  = s_sh + threadIdx.x * sh_pitch(RL);
   float* gsh_dc  = !dL_dsh ? nullptr : (dL_dsh_rest ? dL_dsh + (size_t) idx * 3 : my_row);
-  float* gsh_row = dL_dsh_rest ? my_row - 3 : gsh_dc;
+  float* gsh_row = shs_rest ? my_row - 3 : my_row;  // the staged coefficients; the gradient row replaces them in place
+  float* fac     = sh_factors ? sh_factors + (size_t) idx * 6 : nullptr;
   if (!visible) {
-    if (gsh_dc) {
+    if (fac) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) fac[i] = 0.f;
+    } else if (gsh_dc) {
       for (int i = 0; i < 3; ++i) gsh_dc[i] = 0.f;
       for (int i = 3; i < M * 3; ++i) gsh_row[i] = 0.f;
     }
@@ -739,7 +750,7 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_backward_kernel(int P,
     if (shs) {
       const uint32_t clamp_bits = (__float_as_uint(pf_rec[2].z) >> 28) & 7u;
       float dm[3];
-      sh_backward(D, M, p, cam.campos, gsh_row, clamp_bits, gcol, gsh_dc, gsh_row, dm);  // coefficients and gradients share the row
+      sh_backward(D, M, p, cam.campos, gsh_row, clamp_bits, gcol, gsh_dc, gsh_row, dm, fac);  // coefficients and gradients share the row
       gmean[0] += dm[0], gmean[1] += dm[1], gmean[2] += dm[2];
     }
     // ---- Sigma3D -> scale, rotation ----
@@ -806,10 +817,76 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_backward_kernel(int P,
   dL_dscales[3 * idx] = gscale[0], dL_dscales[3 * idx + 1] = gscale[1], dL_dscales[3 * idx + 2] = gscale[2];
   reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(grot[0], grot[1], grot[2], grot[3]);
   }  // idx < P
-  if (staged) {
+  if (staged && dL_dsh) {
     __syncthreads();
     stage_rows_out((dL_dsh_rest ? dL_dsh_rest : dL_dsh) + (size_t) base * RL, s_sh, nrows, RL);
   }
+}
+
+// dL/dsh of `n_views` views from their factors (sh_backward): row i of Gaussian p = sum_v basis_i(dir_v) * g_v, views
+// added in index order (every rank of a view-parallel job holds the same [n_views][P][6] array after the all-gather and
+// gets the same bits).  The coefficients are those of sh_backward's SETSH lines, evaluated the same way, so one view
+// reproduces the dense row exactly.  Rows leave through LDS as one contiguous span per workgroup.
+__device__ __forceinline__ void sh_basis_row(int deg, float x, float y, float z, float* k /*[16]*/) {
+  const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) k[i] = 0.f;
+  k[0] = SH_C0;
+  if (deg > 0) {
+    k[1] = -SH_C1 * y, k[2] = SH_C1 * z, k[3] = -SH_C1 * x;
+    if (deg > 1) {
+      k[4] = SH_C2[0] * xy, k[5] = SH_C2[1] * yz, k[6] = SH_C2[2] * (2.f * zz - xx - yy), k[7] = SH_C2[3] * xz;
+      k[8] = SH_C2[4] * (xx - yy);
+      if (deg > 2) {
+        k[9]  = SH_C3[0] * y * (3.f * xx - yy);
+        k[10] = SH_C3[1] * xy * z;
+        k[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
+        k[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+        k[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
+        k[14] = SH_C3[5] * z * (xx - yy);
+        k[15] = SH_C3[6] * x * (xx - 3.f * yy);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(PRE_THREADS) sh_grad_from_factors_kernel(int P, int n_views, int D, int M,
+    const float* __restrict__ factors /*[n_views][P][6]*/, float* __restrict__ dL_dsh /*[P,M,3] or the DC part [P,1,3]*/,
+    float* __restrict__ dL_dsh_rest /*[P,M-1,3] or NULL*/) {
+  extern __shared__ float s_rows[];
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int RL  = dL_dsh_rest ? (M - 1) * 3 : M * 3;
+  const int base = blockIdx.x * blockDim.x, nrows = min((int) blockDim.x, P - base);
+  float* my_row = s_rows + threadIdx.x * sh_pitch(RL);
+  if (idx < P) {
+    float acc[16][3];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i][0] = acc[i][1] = acc[i][2] = 0.f;
+    for (int v = 0; v < n_views; ++v) {
+      const float* f = factors + ((size_t) v * P + idx) * 6;
+      const float g[3] = {f[3], f[4], f[5]};
+      float k[16];
+      sh_basis_row(D, f[0], f[1], f[2], k);
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[i][c] = n_views == 1 ? k[i] * g[c] : acc[i][c] + k[i] * g[c];
+    }
+    const int used = (D + 1) * (D + 1);
+    float* dc  = dL_dsh_rest ? dL_dsh + (size_t) idx * 3 : my_row;
+    float* row = dL_dsh_rest ? my_row - 3 : my_row;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i < M) {
+        float* dst = i == 0 ? dc : row + i * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dst[c] = i < used ? acc[i][c] : 0.f;
+      }
+    }
+    for (int i = 16; i < M; ++i) row[i * 3] = row[i * 3 + 1] = row[i * 3 + 2] = 0.f;
+  }
+  __syncthreads();
+  stage_rows_out((dL_dsh_rest ? dL_dsh_rest : dL_dsh) + (size_t) base * RL, s_rows, nrows, RL);
 }
 
 __global__ void mark_visible_kernel(int P, const float* means, const float* view, int colmap, uint8_t* present) {
@@ -864,7 +941,7 @@ int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const i
   const float focal_x = in.image_width / (2.0f * in.tanfovx);
   ProfScope prof(K_PREPROCESS_BWD, s);
   dim3 grid((P + PRE_THREADS - 1) / PRE_THREADS), block(PRE_THREADS);
-  const size_t lds = (in.sh && gr.dL_dsh) ? (size_t) PRE_THREADS * (((in.sh_rest ? in.sh_coeffs - 1 : in.sh_coeffs) * 3) | 1) * 4 : 0;
+  const size_t lds = (in.sh && (gr.dL_dsh || gr.dL_dsh_factors)) ? (size_t) PRE_THREADS * (((in.sh_rest ? in.sh_coeffs - 1 : in.sh_coeffs) * 3) | 1) * 4 : 0;
   const int E = (in.extras && gr.dL_dout_extra && gr.dL_dextras) ? in.E : 0;
 #define SKGS_PB_ARGS                                                                                                     \
   P, in.sh_degree, in.sh_coeffs, in.means3D, radii, in.sh, in.sh_rest, in.scales, in.rotations, in.scale_modifier,        \
@@ -872,12 +949,24 @@ int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const i
       focal_x, focal_y, g.recs, gr.workspace, (int) gradacc_rows_hold_moments(), (int) (gr.workspace_is_zero != 0),       \
       gr.grad_means2D_in, gr.grad_conic_in, gr.grad_opacity_in, E, gr.dL_dmeans2D, gr.dL_dconic, gr.dL_dcolors,           \
       gr.dL_dopacity, gr.dL_dmeans3D, gr.dL_dcov3D, gr.dL_dsh, gr.dL_dsh_rest, gr.dL_dscales, gr.dL_drotations,           \
-      gr.dL_dextras
+      gr.dL_dextras, gr.dL_dsh_factors
   if (in.colmap)
     hipLaunchKernelGGL(preprocess_backward_kernel<true>, grid, block, lds, s, SKGS_PB_ARGS);
   else
     hipLaunchKernelGGL(preprocess_backward_kernel<false>, grid, block, lds, s, SKGS_PB_ARGS);
 #undef SKGS_PB_ARGS
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_sh_grad_from_factors(int P, int n_views, int D, int M, const float* factors, float* dL_dsh, float* dL_dsh_rest,
+    hipStream_t s) {
+  if (P == 0) return 0;
+  if (M < 1 || M > 16 || D < 0 || (D + 1) * (D + 1) > M) return set_error("sh_grad_from_factors: bad degree %d / coefficient count %d", D, M);
+  const int RL     = dL_dsh_rest ? (M - 1) * 3 : M * 3;
+  const size_t lds = (size_t) PRE_THREADS * (RL | 1) * 4;
+  hipLaunchKernelGGL(sh_grad_from_factors_kernel, dim3((P + PRE_THREADS - 1) / PRE_THREADS), dim3(PRE_THREADS), lds, s, P,
+      n_views, D, M, factors, dL_dsh, dL_dsh_rest);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -264,6 +264,8 @@ int fill_u32(void* p, uint32_t v, size_t n_words, hipStream_t s);
 int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, int32_t* radii, hipStream_t s);
 int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const int32_t* radii,
     const skgs_raster_grads& gr, hipStream_t s);
+int launch_sh_grad_from_factors(int P, int n_views, int D, int M, const float* factors, float* dL_dsh, float* dL_dsh_rest,
+    hipStream_t s);
 int launch_mark_visible(int P, const float* means, const float* view, int colmap, uint8_t* present, hipStream_t s);
 // binning.hip
 int launch_scan_tiles(GeomView g, ImgView im, int64_t P, hipStream_t s);  // count tiles (16 lanes / Gaussian) + scan

@@ -48,7 +48,7 @@ class FusedViewStep:
     def __init__(self, model: SkinnedGaussians, W: int, H: int, capacity: int, lambda_dssim: float = 0.2,
                  background: Optional[Tensor] = None, grad_scale: float = 1.0, densify_stats: bool = False,
                  spw_logit_grad: Optional[Tensor] = None, tables_zeroed_by_optimizer: bool = False,
-                 tile_bucket: int = 0):
+                 tile_bucket: int = 0, sh_factors: Optional[Tensor] = None):
         assert not model.static, 'FusedViewStep covers the skinned stage (M >= 1)'
         self.model, self.W, self.H = model, int(W), int(H)
         self.lambda_l1, self.lambda_ssim = 1.0 - lambda_dssim, lambda_dssim
@@ -58,6 +58,12 @@ class FusedViewStep:
             raise _C.SkgsError('FusedViewStep needs the model on a HIP device; sk_gs_amd has no CPU path')
         P, M, K = model.P, model.M, model.K
         self.P, self.M, self.K = P, M, K
+        # view-parallel training: instead of the [P,16,3] SH gradient of this view, write its two factors here ([P,6]:
+        # unit view direction, clamp-masked colour gradient); ``sh_grads_from_factors`` rebuilds the rows of ALL views
+        # from the all-gathered factors (24 bytes per Gaussian and view on the wire instead of 192 all-reduced)
+        self.sh_factors = sh_factors
+        assert sh_factors is None or (sh_factors.is_cuda and sh_factors.dtype == torch.float32 and
+                                      sh_factors.is_contiguous() and sh_factors.numel() == P * 6)
         f32 = dict(dtype=torch.float32, device=dev)
         u8 = dict(dtype=torch.uint8, device=dev)
         self.background = None if background is None else background.to(**f32).contiguous()
@@ -240,12 +246,26 @@ class FusedViewStep:
         g.dL_dmeans2D, g.dL_dcolors, g.dL_dopacity = (self.grad_means2D.data_ptr(), self.g_colors.data_ptr(),
                                                       self.g_opacity.data_ptr())
         g.dL_dmeans3D, g.dL_dcov3D = self.g_means.data_ptr(), self.g_cov3D.data_ptr()
-        g.dL_dsh, g.dL_dsh_rest = m._features_dc.grad.data_ptr(), m._features_rest.grad.data_ptr()
+        if self.sh_factors is None:
+            g.dL_dsh, g.dL_dsh_rest = m._features_dc.grad.data_ptr(), m._features_rest.grad.data_ptr()
+        else:  # view-parallel: (direction, colour gradient) per Gaussian now, the SH rows after the all-gather
+            g.dL_dsh_factors = self.sh_factors.data_ptr()
         g.dL_dscales, g.dL_drotations = self.g_scales.data_ptr(), self.g_rotations.data_ptr()
         g.workspace, g.workspace_bytes = self.bwd_ws.data_ptr(), self.bwd_ws.numel()
         g.workspace_is_zero = 1
         chk(lib.skgs_rasterize_backward(C.byref(a), C.byref(self._bufs), _p(self.radii), _p(self.out_opacity),
                                         C.byref(g), st))
+
+    @torch.no_grad()
+    def sh_grads_from_factors(self, all_factors: Tensor, sh_degree: int):
+        """``all_factors`` [n_views, P, 6] (this rank's ``sh_factors`` and everybody else's, in rank order) ->
+        ``_features_dc.grad`` / ``_features_rest.grad``, the views summed in index order"""
+        m = self.model
+        n_views = all_factors.numel() // (self.P * 6)
+        assert all_factors.is_contiguous() and all_factors.numel() == n_views * self.P * 6
+        _C._check(self.lib.skgs_sh_grad_from_factors(
+            C.c_int32(self.P), C.c_int32(n_views), C.c_int32(sh_degree), C.c_int32(1 + m._features_rest.shape[1]),
+            _p(all_factors), _p(m._features_dc.grad), _p(m._features_rest.grad), _C._stream()))
 
     @torch.no_grad()
     def backward_skinning(self, time_id: int):

@@ -191,3 +191,38 @@ def test_bucket_tile_layout_matches_compact_lists_and_flags_overflow():
     small = FusedViewStep(model, W, H, capacity=0, tile_bucket=max(longest // 2, 1))
     small.forward_backward(rs, tid, target)
     assert small.status()['overflow'] == 1 and small.status()['overflow_events'] >= 1
+
+
+@pytest.mark.parametrize('sh_degree', [3, 1])
+def test_sh_gradient_from_factors_reproduces_the_dense_rows(sh_degree):
+    """skgs_raster_grads.dL_dsh_factors + skgs_sh_grad_from_factors: one view gives the bits of the dense SH gradient;
+    two views give their sum"""
+    from sk_gs_amd import _C, scene
+    from sk_gs_amd.fused_step import FusedViewStep
+    P, M, K, W, H, frames = 5000, 10, 4, 144, 112, 3
+    model, rs, target = _setup(P, M, K, W, H, frames)
+    cam = scene.make_camera(W, H, seed=0)
+    rs = scene.raster_settings_from_camera(cam, sh_degree=sh_degree, colmap=True, device='cuda')
+    _C.config.sync_num_rendered = True
+    with torch.no_grad():
+        R = model.render(rs, time_id=0)['buffer'].R
+    dense = FusedViewStep(model, W, H, capacity=int(R * 1.5) + 1024)
+    grads = []
+    for tid in (0, 2):
+        dense.forward_backward(rs, tid, target)
+        grads.append((model._features_dc.grad.clone(), model._features_rest.grad.clone(), model._xyz.grad.clone()))
+    fac = torch.full((2, P, 6), float('nan'), device='cuda')
+    for i, tid in enumerate((0, 2)):
+        step = FusedViewStep(model, W, H, capacity=int(R * 1.5) + 1024, sh_factors=fac[i])
+        model._features_dc.grad.fill_(7.0), model._features_rest.grad.fill_(7.0)
+        step.forward_backward(rs, tid, target)
+        assert float(model._features_dc.grad.min()) == 7.0  # not written in this mode
+        assert_close_robust(model._xyz.grad, grads[i][2], 1e-5, 1e-4, name='xyz')  # (blend atomics order only)
+        step.sh_grads_from_factors(fac[i:i + 1], sh_degree)
+        # the factors come from a second backward pass: its blend atomics may round differently -> compare closely, and
+        assert rel_err(model._features_dc.grad, grads[i][0]) <= 2e-6 and rel_err(model._features_rest.grad, grads[i][1]) <= 2e-6
+    step.sh_grads_from_factors(fac, sh_degree)
+    assert rel_err(model._features_dc.grad, grads[0][0] + grads[1][0]) <= 2e-6
+    assert rel_err(model._features_rest.grad, grads[0][1] + grads[1][1]) <= 2e-6
+    if sh_degree < 3:  # coefficients above the active degree get exactly zero
+        assert float(model._features_rest.grad[:, (sh_degree + 1) ** 2 - 1:].abs().max()) == 0.0
