@@ -216,8 +216,9 @@ def main():
             vp = BucketedGradReducer([bucket1], extras=[P * model.K])
             for p_ in bucket0:  # not on the wire: plain gradient tensors, rebuilt from the gathered factors
                 p_.grad = torch.zeros_like(p_)
-            fac_all = torch.zeros((world, P, 6), device=dev)
-            fac_local = fac_all[rank]
+            from sk_gs_amd.view_parallel import ShFactorExchange
+            sh_ex = ShFactorExchange(P, dev)
+            fac_all, fac_local = sh_ex.all, sh_ex.local
         else:
             vp = BucketedGradReducer([bucket0 + bucket1], extras=[P * model.K])
         comm_bytes = vp.nbytes + (fac_all.numel() * 4 if sh_factored else 0)
@@ -323,10 +324,7 @@ def main():
             if compact:
                 w = vp.allreduce(0, async_op=sh_factored)
                 if sh_factored:  # every rank's (direction, colour gradient) pairs; own slice already in place
-                    if dist.get_backend() == 'nccl':  # in place: this rank's slice is already where it belongs
-                        dist.all_gather_into_tensor(fac_all.view(-1), fac_local.view(-1))
-                    else:
-                        dist.all_gather(list(fac_all.unbind(0)), fac_local)
+                    sh_ex.gather()
                     if w is not None:
                         w.wait()
             else:

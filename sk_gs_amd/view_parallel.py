@@ -156,3 +156,31 @@ class BucketedGradReducer:
     @property
     def nbytes(self) -> int:
         return self.flat.numel() * 4
+
+
+class ShFactorExchange:
+    """The SH gradient of a view-parallel step without the 192-byte-per-Gaussian all-reduce.
+
+    The SH gradient of ONE view is rank-1 per Gaussian: basis(view direction) x (clamp-masked colour gradient)
+    (gaussian_rasterizer_backwrad.cu:26-127).  ``FusedViewStep(sh_factors=ex.local)`` makes the rasterizer backward write
+    those 6 floats per Gaussian instead of the [P,16,3] rows; ``gather()`` all-gathers them in place (24 B per Gaussian
+    and rank on the wire) and ``FusedViewStep.sh_grads_from_factors(ex.all, sh_degree)`` rebuilds and sums the rows of every
+    view, in rank order, identically on every rank."""
+
+    def __init__(self, P: int, device):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.all = torch.zeros((self.world, P, 6), dtype=torch.float32, device=device)
+        self.local = self.all[self.rank]
+
+    @property
+    def nbytes(self) -> int:
+        return self.all.numel() * 4
+
+    def gather(self):
+        if not dist.is_initialized():
+            return
+        if dist.get_backend() == 'nccl':  # in place: this rank's slice is already where it belongs
+            dist.all_gather_into_tensor(self.all.view(-1), self.local.view(-1))
+        else:
+            dist.all_gather(list(self.all.unbind(0)), self.local)

@@ -125,6 +125,13 @@ w1 = red.allreduce(1)
 w0.wait(), w1.wait()
 assert torch.allclose(q1.grad, torch.full((5,), 3.0)) and torch.allclose(q2.grad, torch.full((3,), 30.0))
 assert torch.allclose(q3.grad, torch.full((4,), -2.0)) and torch.allclose(red.extra_views[1], torch.full((6,), 1.0))
+# factor exchange of the SH gradient: every rank ends with every rank's [P,6] block, its own slice in place
+from sk_gs_amd.view_parallel import ShFactorExchange
+ex = ShFactorExchange(4, 'cpu')
+assert ex.world == 2 and ex.local.data_ptr() == ex.all[rank].data_ptr() and ex.nbytes == 2 * 4 * 6 * 4
+ex.local.fill_(float(rank + 1))
+ex.gather()
+assert torch.equal(ex.all[0], torch.full((4, 6), 1.0)) and torch.equal(ex.all[1], torch.full((4, 6), 2.0))
 w = torch.nn.Parameter(torch.full((3,), float(rank)))
 vp.broadcast_params([w], src=1)
 assert torch.allclose(w.data, torch.ones(3))
