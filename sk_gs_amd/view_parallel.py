@@ -38,7 +38,10 @@ def init_distributed(backend: Optional[str] = None, force: bool = False) -> tupl
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local_rank))  # barrier() knows its device
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
 
