@@ -175,6 +175,7 @@ class ShFactorExchange:
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.all = torch.zeros((self.world, P, 6), dtype=torch.float32, device=device)
         self.local = self.all[self.rank]
+        self._in_place = True
 
     @property
     def nbytes(self) -> int:
@@ -183,7 +184,10 @@ class ShFactorExchange:
     def gather(self):
         if not dist.is_initialized():
             return
-        if dist.get_backend() == 'nccl':  # in place: this rank's slice is already where it belongs
-            dist.all_gather_into_tensor(self.all.view(-1), self.local.view(-1))
-        else:
-            dist.all_gather(list(self.all.unbind(0)), self.local)
+        if self._in_place and dist.get_backend() == 'nccl':  # this rank's slice is already where it belongs
+            try:
+                dist.all_gather_into_tensor(self.all.view(-1), self.local.view(-1))
+                return
+            except (RuntimeError, ValueError):  # an argument check of this torch build (same on every rank): list form
+                self._in_place = False
+        dist.all_gather(list(self.all.unbind(0)), self.local)
