@@ -7,7 +7,7 @@ single process.
                       all as direct calls into libskgs_hip.so, gradients written into the parameters' .grad
     FusedAdam       : every parameter group in one launch (eps = 1e-15, the reference's learning-rate ratios)
     GraphedSteps    : the whole step replayed as one hipGraph per training view (two per view with > 1 rank)
-    ViewParallel    : one flat gradient buffer, one RCCL all-reduce per step
+    ViewParallel / BucketedGradReducer / ShFactorExchange : one RCCL all-reduce (+ one small all-gather) per step
 """
 import argparse
 import os
@@ -35,7 +35,7 @@ def main():
     from sk_gs_amd.model import SkinnedGaussians
     from sk_gs_amd.optim import FusedAdam, position_lr
     from sk_gs_amd.train_step import GraphedSteps
-    from sk_gs_amd.view_parallel import ViewParallel, init_distributed
+    from sk_gs_amd.view_parallel import BucketedGradReducer, ShFactorExchange, ViewParallel, init_distributed
 
     rank, world, local_rank = init_distributed()
     torch.cuda.set_device(local_rank)
@@ -59,21 +59,36 @@ def main():
     opt = FusedAdam(model.param_groups(lr=args.lr), eps=1e-15)
 
     def build_runtime():
-        """everything sized by the number of Gaussians: flat gradient buffer, step workspaces, captured graphs"""
-        vp = ViewParallel(model.parameters())                   # p.grad -> views of one flat buffer
-        step = FusedViewStep(model, W, W, capacity=capacity * model.P // P + 4096, background=bg, grad_scale=1.0 / world, densify_stats=True)
-        step.forward_backward(views[0], 0, targets[0])            # warm-up outside any capture
-        opt.rebind()                                              # the .grad tensors moved
+        """everything sized by the number of Gaussians: gradient buffers, step workspaces, captured graphs"""
+        cap = capacity * model.P // P + 4096
         if world == 1:
+            vp = ViewParallel(model.parameters())               # p.grad -> views of one flat buffer
+            step = FusedViewStep(model, W, W, capacity=cap, background=bg, densify_stats=True)
+            step.forward_backward(views[0], 0, targets[0])        # warm-up outside any capture
+            opt.rebind()                                          # the .grad tensors moved
             run = GraphedSteps(lambda v: (step.forward_backward(views[v], v, targets[v]), opt.step()))
         else:
+            # what crosses the wire per step: one all-reduce of everything except the SH coefficients and the dense LBS
+            # logits (those two travel as 6 + K floats per Gaussian: factors all-gathered, compact logit gradient reduced)
+            vp = ViewParallel([])                                 # view schedule + densification statistics only
+            wire = [p for n, p in model.named_parameters() if n not in ('_features_dc', '_features_rest', 'sp_W')]
+            red = BucketedGradReducer([wire], extras=[model.P * model.K])
+            for p in (model._features_dc, model._features_rest, model.sp_W):
+                p.grad = torch.zeros_like(p)
+            ex = ShFactorExchange(model.P, dev)
+            step = FusedViewStep(model, W, W, capacity=cap, background=bg, grad_scale=1.0 / world, densify_stats=True,
+                                 spw_logit_grad=red.extra_views[0], sh_factors=ex.local)
+            step.forward_backward(views[0], 0, targets[0])
+            opt.rebind()
             g_fb = GraphedSteps(lambda v: step.forward_backward(views[v], v, targets[v]))
-            g_opt = GraphedSteps(lambda _: opt.step())
+            g_opt = GraphedSteps(lambda _: (step.sh_grads_from_factors(ex.all, 3), step.scatter_spw_grad(), opt.step()))
 
             def run(v):
                 g_fb(v)
-                vp.allreduce_grads(prescaled=True)
-                g_opt(0)
+                w = red.allreduce(0)
+                ex.gather()
+                w.wait()
+                g_opt(0)     # captured at its first call, i.e. on reduced gradients (its warm-up applies real updates)
         step.xyz_gradient_accum.zero_(), step.denom.zero_(), step.max_radii2D.zero_()
         return vp, step, run
 
