@@ -393,7 +393,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # view-parallel replicas must stay bit-identical: same reduced gradients, same Adam step on every rank
-    replicas_identical = None
+    replicas_identical, param_digest = None, None
     if use_dist:
         names = [n for n, _ in model.named_parameters()]
         digest = torch.stack([p.detach().double().sum() for p in model.parameters()] +
@@ -402,6 +402,7 @@ def main():
         dist.all_gather(every, digest)
         differ = sorted({names[i % len(names)] for e in every for i in (every[0] != e).nonzero().flatten().tolist()})
         replicas_identical = True if not differ else differ
+        param_digest = float(digest[len(names):].sum())  # sum |p| over all parameters (rank 0): compares exchange modes
     if not args.autograd:  # sticky device-side counter of forwards whose tile lists exceeded the capacity
         overflow += fstep.status()['overflow_events']
     assert int(overflow.item()) == 0, 'binning capacity overflow during the timed region: result invalid'
@@ -484,7 +485,7 @@ def main():
                        'joint_rotations': 'deform network (8x256 MLP) inside the step' if args.deform_net
                        else 'per-frame tables (the reference\'s sk_cache)',
                        'step': 'autograd operator path' if args.autograd else 'FusedViewStep (direct C-ABI calls)',
-                       'replicas_identical': replicas_identical},
+                       'replicas_identical': replicas_identical, 'param_digest': param_digest},
             'roofline': {'bound': 'hbm', 'kernel': 'render_backward', 'achieved': round(achieved, 2),
                          'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 5),
                          'traffic': traffic, 'avg_us': round(rb_us, 2), 'launches': rb_n,

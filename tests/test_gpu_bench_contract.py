@@ -48,3 +48,20 @@ def test_ranks_share_the_gpu_and_stay_identical(port, ranks, extra):
     assert d['config']['replicas_identical'] is True
     assert abs(d['value'] - ranks * 1000.0 / d['ms_per_step']) / d['value'] < 0.01  # whole-job: every rank's view per step
     assert 'cpu_baseline' not in d
+
+
+def test_factor_exchange_and_dense_exchange_train_the_same_parameters():
+    """two ranks, eight optimizer steps: the SH gradient exchanged as factors (default) or all-reduced densely
+    (--sh-allreduce) must leave the same parameters up to summation order"""
+    env = dict(os.environ, SKGS_DIST_BACKEND='gloo', SKGS_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    digests = []
+    for port, extra in ((29585, []), (29586, ['--sh-allreduce'])):
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+               '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6',
+               '--warmup', '2', '--no-cpu-baseline', '--eager'] + extra
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert p.returncode == 0, p.stderr[-3000:]
+        d = json.loads([l for l in p.stdout.splitlines() if l.strip().startswith('{')][0])
+        assert d['config']['replicas_identical'] is True
+        digests.append(d['config']['param_digest'])
+    assert abs(digests[0] - digests[1]) <= 1e-7 * abs(digests[1]), digests
