@@ -139,6 +139,9 @@ def main():
                          'of launch / stream-join overhead per step on one GPU, so it only pays when the all-reduce is slow)')
     ap.add_argument('--dense-spw-grad', action='store_true',
                     help='world > 1: all-reduce the dense [P,M] sp_W gradient instead of the compact [P,K] logit gradient')
+    ap.add_argument('--overlap-gather', action='store_true',
+                    help='world > 1, factor exchange: split the backward graph after the rasterizer backward and run the '
+                         'all-gather of the SH factors beside the skinning backward (one more graph launch per step)')
     ap.add_argument('--sh-allreduce', action='store_true',
                     help='world > 1: all-reduce the dense SH gradient (192 B per Gaussian) instead of all-gathering its two '
                          'factors per view (24 B per Gaussian and rank) and rebuilding the rows on every rank')
@@ -342,28 +345,59 @@ def main():
             reduce_grads()
             update()
 
-        if not use_dist:  # whole step (fwd + bwd + Adam) is one graph per view
+        overlap_gather = sh_factored and args.overlap_gather
+        if overlap_gather:
+            # graph(forward, loss, rasterizer backward) | all-gather of the factors beside graph(skinning backward) |
+            # all-reduce of the rest | graph(SH rows, logit scatter, Adam)
+            def split_step(v, fa, fb, fc):
+                fa(v)
+                wg = sh_ex.gather(async_op=True)
+                fb(v)
+                w = vp.allreduce(0, async_op=True)
+                for h in (wg, w):
+                    if h is not None:
+                        h.wait()
+                fc(0)
+
+            part_a = lambda v: fstep.backward_raster(settings[v], v % frames, targets[v])  # noqa: E731
+            part_b = lambda v: fstep.backward_skinning(v % frames)                          # noqa: E731
+            gA, gB, gC = GraphedSteps(part_a), GraphedSteps(part_b), GraphedSteps(update)
+
+            def eager_step(i):  # noqa: F811
+                split_step(vp.view_index(i, args.views), part_a, part_b, update)
+
+            def graph_step(i):
+                split_step(vp.view_index(i, args.views), gA, gB, gC)
+
+            def capture_all():
+                for v in range(args.views):
+                    gA.capture(v)
+                    gB.capture(v)
+                reduce_grads()  # the optimizer graph's capture warm-up applies real updates: reduced gradients only
+                gC.capture(0)
+        elif not use_dist:  # whole step (fwd + bwd + Adam) is one graph per view
             g_step = GraphedSteps(lambda v: (fwd_bwd(v), opt.step()))
             g_opt = None
         else:           # the RCCL all-reduce stays between two graphs
             g_step = GraphedSteps(fwd_bwd)
             g_opt = GraphedSteps(update)
 
-        def graph_step(i):
-            g_step(vp.view_index(i, args.views))
-            if g_opt is not None:
-                reduce_grads()
-                g_opt(0)
+        if not overlap_gather:
+            def graph_step(i):
+                g_step(vp.view_index(i, args.views))
+                if g_opt is not None:
+                    reduce_grads()
+                    g_opt(0)
 
-        def capture_all():
-            for v in range(args.views):
-                g_step.capture(v)
-            if g_opt is not None:
-                # GraphedSteps.capture runs its function for real (warm-up) before recording it: the optimizer graph must
-                # see REDUCED gradients then, or every rank would apply its own view's gradient and the replicas would
-                # drift apart for good (tests/test_gpu_bench_contract.py runs two ranks and compares them)
-                reduce_grads()
-                g_opt.capture(0)
+            def capture_all():
+                for v in range(args.views):
+                    g_step.capture(v)
+                if g_opt is not None:
+                    # GraphedSteps.capture runs its function for real (warm-up) before recording it: the optimizer graph
+                    # must see REDUCED gradients then, or every rank would apply its own view's gradient and the replicas
+                    # would drift apart for good (tests/test_gpu_bench_contract.py runs two ranks and compares them)
+                    reduce_grads()
+                    g_opt.capture(0)
 
     train_step = eager_step if args.eager else graph_step
 

@@ -181,13 +181,14 @@ class ShFactorExchange:
     def nbytes(self) -> int:
         return self.all.numel() * 4
 
-    def gather(self):
+    def gather(self, async_op: bool = False):
+        """all-gather the factor blocks; with ``async_op`` returns the work handle (``.wait()`` before the rows are
+        rebuilt) so that the exchange can run beside the skinning backward"""
         if not dist.is_initialized():
-            return
+            return None
         if self._in_place and dist.get_backend() == 'nccl':  # this rank's slice is already where it belongs
             try:
-                dist.all_gather_into_tensor(self.all.view(-1), self.local.view(-1))
-                return
+                return dist.all_gather_into_tensor(self.all.view(-1), self.local.view(-1), async_op=async_op)
             except (RuntimeError, ValueError):  # an argument check of this torch build (same on every rank): list form
                 self._in_place = False
-        dist.all_gather(list(self.all.unbind(0)), self.local)
+        return dist.all_gather(list(self.all.unbind(0)), self.local, async_op=async_op)
