@@ -30,7 +30,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
 
 
 @pytest.mark.parametrize('port,ranks,extra', [(29577, 2, []), (29578, 2, ['--pipeline']), (29579, 2, ['--dense-spw-grad']),
-                                              (29580, 2, ['--autograd']), (29581, 4, []), (29582, 2, ['--sh-allreduce']), (29583, 2, ['--overlap-gather'])])
+                                              (29580, 2, ['--autograd']), (29581, 4, []), (29582, 2, ['--sh-allreduce']), (29583, 2, ['--overlap-gather']), (29584, 2, ['--deform-net'])])
 def test_ranks_share_the_gpu_and_stay_identical(port, ranks, extra):
     """The driver's multi-GPU launch line with 2 or 4 ranks on this one GPU (gloo moves the gradients: RCCL refuses two ranks
     per device): the real view-parallel schedule -- graph(fwd+bwd) | all-reduce | graph(expand + Adam) -- must keep the
