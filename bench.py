@@ -148,9 +148,14 @@ def main():
     ap.add_argument('--compact-lists', action='store_true',
                     help='count -> scan -> scatter into compact tile lists (the reference layout) instead of fixed per-tile '
                          'buckets (no counting / scan launch)')
-    ap.add_argument('--deform-net', action='store_true',
-                    help='produce the joint rotations / d_rot / d_scale with the 8x256 deform network inside every step '
-                         '(scope row (f)-3: +24 launches, +0.5M parameters in Adam) instead of the per-frame tables')
+    ap.add_argument('--bone-tables', dest='deform_net', action='store_false', default=True,
+                    help='read the joint rotations / d_rot / d_scale from per-frame tables (the test-time cache of '
+                         'networks/sk_gs.py:1080-1085) instead of running the 8x256 deform network inside every step.  The '
+                         'reference runs the network in every TRAINING step (sk_gs.py:1073-1074): that is the default here')
+    ap.add_argument('--deform-net', dest='deform_net', action='store_true', help='(default) the deform network inside the step')
+    ap.add_argument('--layered-mlp', action='store_true',
+                    help='run the deform network as one launch per layer (csrc/mlp.hip) instead of the one-launch-per-direction '
+                         'kernels (csrc/mlp_fused.hip)')
     ap.add_argument('--autograd', action='store_true',
                     help='run the step through the torch-autograd operator path (model.render + image_loss + backward) '
                          'instead of sk_gs_amd.fused_step.FusedViewStep (same kernels, no autograd glue)')
@@ -251,7 +256,7 @@ def main():
         fstep = FusedViewStep(model, W, H, capacity=int(R_max * 1.25 * _C.config.capacity_growth) + 1024,
                               background=background, grad_scale=1.0 / world,
                               spw_logit_grad=vp.extra_views[-1] if compact else None, tile_bucket=tile_bucket,
-                              sh_factors=fac_local if sh_factored else None)
+                              sh_factors=fac_local if sh_factored else None, fused_deform_net=not args.layered_mlp)
         # the per-frame table gradients (one row written per step) are cleared by the Adam launch itself
         table_span = None if args.torch_adam else fstep.table_grad_span()
         fstep.tables_zeroed_by_optimizer = table_span is not None
@@ -438,7 +443,9 @@ def main():
         replicas_identical = True if not differ else differ
         param_digest = float(digest[len(names):].sum())  # sum |p| over all parameters (rank 0): compares exchange modes
     if not args.autograd:  # sticky device-side counter of forwards whose tile lists exceeded the capacity
-        overflow += fstep.status()['overflow_events']
+        st = fstep.status()
+        overflow += st['overflow_events']
+        assert st.get('mlp_failed', 0) == 0, 'a fused deform-network launch gave up waiting for a workgroup: result invalid'
     assert int(overflow.item()) == 0, 'binning capacity overflow during the timed region: result invalid'
 
     # ------------------------------------------------ per-kernel HIP-event timing: eager pass over the same steps
@@ -516,8 +523,10 @@ def main():
                        'launch': 'eager' if args.eager else 'one hipGraph replay per view step',
                        'tile_lists': 'compact (count, scan, scatter)' if (args.autograd or args.compact_lists)
                        else f'buckets of {tile_bucket} slots per tile (longest list {longest})',
-                       'joint_rotations': 'deform network (8x256 MLP) inside the step' if args.deform_net
-                       else 'per-frame tables (the reference\'s sk_cache)',
+                       'joint_rotations': ('deform network (freq-encode + 8x256 MLP + heads) inside the step, '
+                                           + ('one launch per layer' if args.layered_mlp else 'one persistent launch per direction'))
+                       if args.deform_net and M > 0 else 'per-frame tables (test-time cache, sk_gs.py:1080-1085): NOT the '
+                                                         'reference\'s training step',
                        'step': 'autograd operator path' if args.autograd else 'FusedViewStep (direct C-ABI calls)',
                        'replicas_identical': replicas_identical, 'param_digest': param_digest},
             'roofline': {'bound': 'hbm', 'kernel': 'render_backward', 'achieved': round(achieved, 2),

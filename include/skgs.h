@@ -297,6 +297,52 @@ int skgs_linear_backward(int32_t B, int32_t in1, int32_t in2, int32_t out, const
     int32_t ldx2, const float* W, const float* Y, const float* gY, int32_t ldy, int32_t relu, float* gW, float* gb,
     float* gX1, int32_t ldg1, float* gX2, int32_t ldg2, int32_t accumulate_gx, skgs_stream_t stream);
 
+/* ---- the same network as ONE persistent launch per direction (csrc/mlp_fused.hip) ----
+ * Replaces the whole SimpleDeformationNetwork.forward call of kinematic() (networks/sk_gs.py:1073-1074; module :134-164,
+ * MLP_with_skips my_ext/blocks/mlp.py:43-85, FreqEncoder my_ext/_C/src/nerf/freqencoder.cu:7-60) and its autograd
+ * backward, for B <= 48 rows (one per bone), hidden width 64..256 (multiple of 64), encoded input <= 128 wide.
+ * Layer l computes act([a_{l-1} | x0] W_l^T + b_l): in_hidden = 0 for the first layer and `hidden` afterwards, in_x0 = the
+ * encoded width where the layer reads the encoded input (first layer, layers behind a skip) else 0; the last entry is the
+ * heads stored as one matrix (relu = 0).  W is [out, in_hidden + in_x0] (torch.nn.Linear layout).
+ *   forward : x0 [B, IN] (optional copy of the encoded input), acts [n_layers-1][B][hidden] (saved for the backward),
+ *             out [B, out_last]
+ *   backward: writes layer[l].gW / gb (gb may be NULL) and, if g_x0 != NULL, dL/dx0 [B, IN]
+ * `t` is a DEVICE pointer to t_dim floats (the same time for every row).  The workspace
+ * (skgs_deform_mlp_workspace_bytes, 256-byte aligned) must be prepared ONCE with skgs_deform_mlp_workspace_init before its
+ * first use and then belongs to the library: it holds the in-launch exchange images and the launch counters, so consecutive
+ * (also hipGraph-replayed) launches need no clearing.  skgs_deform_mlp_status copies four words: {forward launches, launches
+ * that gave up waiting for another workgroup (must stay 0), diagnostics switch, backward launches}.  B <= 48 rows. */
+#define SKGS_MLP_MAX_LAYERS 12
+typedef struct skgs_mlp_layer {
+  const float* W;
+  const float* bias; /* may be NULL */
+  float* gW;         /* backward only */
+  float* gb;         /* backward only, may be NULL */
+  int32_t in_hidden, in_x0, out, relu;
+} skgs_mlp_layer;
+typedef struct skgs_mlp_desc {
+  int32_t B;                                 /* rows */
+  int32_t p_dim, p_degree, t_dim, t_degree;  /* FreqEncoder(points) | FreqEncoder(t) */
+  int32_t hidden, n_layers;                  /* n_layers counts the heads */
+  skgs_mlp_layer layer[SKGS_MLP_MAX_LAYERS];
+  /* optional: the last layer's columns as separate tensors (the reference's `last` ModuleList, mlp.py:76-83: sk_r |
+   * d_rot | d_scale).  n_heads = 0: one [B, out] tensor (`out` / `g_out` arguments); else head j is [B, head_dim[j]] at
+   * head_out[j] (forward) / head_gout[j] (backward) and the `out` / `g_out` arguments may be NULL. */
+  int32_t n_heads, head_dim[4];
+  float* head_out[4];
+  const float* head_gout[4];
+} skgs_mlp_desc;
+size_t skgs_deform_mlp_workspace_bytes(const skgs_mlp_desc* d);
+int skgs_deform_mlp_workspace_init(void* workspace, size_t workspace_bytes, skgs_stream_t stream);
+int skgs_deform_mlp_forward(const skgs_mlp_desc* d, const float* points, const float* t, float* x0, float* acts, float* out,
+    void* workspace, size_t workspace_bytes, skgs_stream_t stream);
+int skgs_deform_mlp_backward(const skgs_mlp_desc* d, const float* points, const float* t, const float* acts,
+    const float* g_out, float* g_x0, void* workspace, size_t workspace_bytes, skgs_stream_t stream);
+int skgs_deform_mlp_status(const void* workspace, uint32_t* host_words4, skgs_stream_t stream);
+/* Tuning knob: output features per workgroup of the fused network kernels: 8 (default: 32 workgroups of 512 threads at
+ * hidden = 256) or 4 (64 workgroups of 256 threads, <= 32 rows). */
+void skgs_set_mlp_columns(int ncol);
+
 /* ---- densification statistics of one training view (scope row (f)-4) ----
  * networks/sk_gs.py:1990-1997 + networks/gaussian_splatting.py:503-513: for every Gaussian with radii > 0
  *   max_radii2D = max(max_radii2D, radii); xyz_gradient_accum += |grad_means2D[:, :2]|; denom += 1.

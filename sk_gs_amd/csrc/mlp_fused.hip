@@ -1,0 +1,788 @@
+// mlp_fused.hip -- the bone-transform producer (scope row (f)-3) as ONE persistent launch per direction.
+//
+// Reference: SimpleDeformationNetwork (networks/sk_gs.py:134-164) = FreqEncoder(joints, degree 10) | FreqEncoder(t,
+// degree 6) -> MLP_with_skips (my_ext/blocks/mlp.py:43-85: 8 x 256, ReLU, the encoded input concatenated again after
+// layer 4) -> heads 4 | 4 | 3, evaluated on ONE ROW PER BONE (B = M ~ 20..32) in every training step
+// (networks/sk_gs.py:1073-1079).  torch runs it as ~65 launches; mlp.hip as one launch per layer and direction (24
+// launches, 8.6 / 13.5 us each: each launch pays a boundary, a global -> LDS staging round trip and a serial dot
+// product).  The arithmetic is nothing (20 x 256 x 256 FMAs per layer); the 2.1 MB of weights and the NINE DEPENDENT
+// LAYERS are the cost.  So:
+//
+//   * G = H / NC workgroups (NC = 4 GROUPS output features each: 32 workgroups of 512 threads, or 64 of 256, at H = 256),
+//     one per CU, all resident.  Workgroup g owns output features [g NC, (g+1) NC) of EVERY layer: its rows of every
+//     weight matrix are fetched ONCE, up front, with all loads in flight, into LDS -- the 2.1 MB stream is spread over the
+//     workgroups instead of 9 dependent staging round trips.
+//   * between layers the [B, H] activations are exchanged IN-LAUNCH.  Every workgroup owns one contiguous slab
+//     [Bp][NC] of the exchange image of a layer and publishes it with ONE wave-wide 16-byte write-through (sc1) store
+//     instruction; every workgroup reads all slabs with 16-byte agent-scope (sc1) loads.  Each 4-byte word validates
+//     itself: the image is pre-filled with a sentinel (0xFFFFFFFF, a NaN pattern no arithmetic produces) and a reader
+//     re-reads until none of its words is the sentinel -- no flag, no fence, no release (the data-tagged-granule
+//     hand-off of MI355X_MICROARCH.md "visibility", with the tag folded into the value: half the bytes on the wire).
+//     Two images per layer alternate with the launch parity; a launch re-fills its slabs of the OTHER image (read by
+//     nobody in this launch) with the sentinel, the kernel boundary publishes that.  The launch counters live in the
+//     workspace header, so a hipGraph replay needs no memset node and no per-launch argument.
+//   * every spin is bounded (s_memrealtime, 50 ms): a launch that cannot complete sets a sticky failure word instead of
+//     hanging the device.
+//   * backward: workgroup g owns INPUT features [g NC, ..) of every layer (= the output features it owned one layer
+//     earlier): gA_{l-1}[:, slab] = gZ_l W_l[:, slab] is the only thing on the dependent chain; the weight gradient of
+//     its own rows, gW_l[slab, :] = gZ_l[:, slab]^T [a_{l-1} | x0], needs nothing from other workgroups but the saved
+//     activations and runs while the other workgroups' slabs are in flight.
+//
+// Thread map of a product: a group of 256 threads = 16 row groups x 16 k-lanes handles 4 features; a lane accumulates 4
+// dot products over every 16th float4 of its row (16 lanes read 64 consecutive LDS dwords: conflict-free for
+// ds_read_b128 with a row pitch that is a multiple of 64 dwords), the 16 lanes are one DPP row and are summed with four
+// row_shr adds.
+#include <algorithm>
+
+#include "skgs_common.h"
+
+namespace skgs {
+namespace {
+
+constexpr int MAXL = SKGS_MLP_MAX_LAYERS;
+constexpr unsigned SENTINEL = 0xffffffffu;
+
+using gu32 = __attribute__((address_space(1))) unsigned int;
+typedef float f4 __attribute__((ext_vector_type(4)));  // a VGPR quad as an asm operand
+
+struct FusedLayer {
+  const float* W;     // [out, in_h + in_x]
+  const float* bias;  // [out]
+  float* gW;
+  float* gb;
+  int in_h, in_x, out, relu;
+};
+struct FusedArgs {
+  int B, p_dim, p_deg, t_dim, t_deg, IN, INP, H, n_layers, lds_floats;
+  const float* points;
+  const float* t;
+  float* x0;          // forward: [B, IN] or NULL
+  float* acts;        // forward: written; backward: read.  [n_layers - 1][B][H]
+  float* out;         // forward: [B, out_last]
+  const float* g_out; // backward: [B, out_last]
+  float* g_x0;        // backward: [B, IN] or NULL
+  unsigned* hdr;      // workspace header: [0] forward launches, [1] failed launches (sticky), [2] stamps wanted,
+                      // [3] backward launches, [16..63] stamps
+  float* exch;        // this direction's exchange images [2][n_layers - 1][G][Bp][NC]
+  int n_heads, head_dim[4];  // the last layer's columns split over separate [B, head_dim[j]] tensors (n_heads = 0: one tensor)
+  float* head_out[4];        // forward
+  const float* head_gout[4]; // backward
+  FusedLayer layer[MAXL];
+};
+
+__device__ __forceinline__ int pad64(int x) { return (x + 63) & ~63; }
+
+// element (row, col) of the last layer's output / incoming gradient: one [B, out] tensor or one tensor per head
+__device__ __forceinline__ float* head_elem(const FusedArgs& a, float* const* heads, float* single, int row, int col, int out) {
+  if (a.n_heads == 0) return single + (size_t) row * out + col;
+  int j = 0, off = 0;
+  while (j < a.n_heads - 1 && col >= off + a.head_dim[j]) off += a.head_dim[j++];
+  return heads[j] + (size_t) row * a.head_dim[j] + (col - off);
+}
+
+__device__ __forceinline__ float row_sum_to_lane15(float v) {
+  v += dpp_mov<0x111, 0xf, 0xf, true>(v);  // row_shr:1
+  v += dpp_mov<0x112, 0xf, 0xf, true>(v);  // row_shr:2
+  v += dpp_mov<0x114, 0xf, 0xf, true>(v);  // row_shr:4
+  v += dpp_mov<0x118, 0xf, 0xf, true>(v);  // row_shr:8 -> lane 15 of each 16-lane row = row sum
+  return v;
+}
+
+// the frequency encoding of freqencoder.cu:7-33 (same expression as mlp.hip::freq_encode_forward_kernel)
+__device__ __forceinline__ float freq_value(const float* __restrict__ x, int D, int c) {
+  if (c < D) return x[c];
+  const int col = c / D - 1, d = c % D;
+  return sinf(scalbnf(x[d], col / 2) + (float) (col % 2) * (3.141592653589793f / 2));
+}
+
+// s_x0[b][c] (pitch INP), zero outside [B) x [IN).  The caller synchronises before reading.
+template <int NT>
+__device__ __forceinline__ void encode_inputs(const FusedArgs& a, float* s_x0, int Bp) {
+  const int pe = a.p_dim * (1 + 2 * a.p_deg), INP = a.INP, IN = a.IN;
+  for (int i = threadIdx.x; i < a.B * IN; i += NT) {
+    const int b = i / IN, c = i - b * IN;
+    s_x0[b * INP + c] = c < pe ? freq_value(a.points + (size_t) b * a.p_dim, a.p_dim, c) : freq_value(a.t, a.t_dim, c - pe);
+  }
+  for (int i = threadIdx.x; i < Bp * INP; i += NT) {  // the padding (disjoint from the entries above)
+    const int b = i / INP, c = i - b * INP;
+    if (b >= a.B || c >= IN) s_x0[i] = 0.f;
+  }
+}
+
+// diagnostics (header word 2 != 0): workgroup 0 records {100 MHz real-time counter, shader clock counter} at successive
+// points of the launch into header words 16.. (two words per stamp, 24 stamps)
+__device__ __forceinline__ void stamp(const FusedArgs& a, const unsigned* s_misc, int& si) {
+  if (s_misc[2] && blockIdx.x == 0 && threadIdx.x == 0 && si < 24) {
+    a.hdr[16 + 2 * si]     = (unsigned) __builtin_amdgcn_s_memrealtime();
+    a.hdr[16 + 2 * si + 1] = (unsigned) __builtin_amdgcn_s_memtime();
+    ++si;
+  }
+}
+
+// a produced value must never look like the "not written yet" pattern
+__device__ __forceinline__ float not_sentinel(float v) { return f2u(v) == SENTINEL ? u2f(0x7fc00000u) : v; }
+
+// 16-byte write-through store (global_store_dwordx4 ... sc1); the trailing s_nop keeps hipcc's next instruction from
+// overwriting the data registers before the store has read them (cdna_hip_programming.md 5.7)
+__device__ __forceinline__ void store16_sc1(float* p, float4 v) {
+  const f4 q = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(q) : "memory");
+}
+
+// Read every workgroup's slab of one exchange image into the [Bp][H] LDS image (row pitch H), re-reading until no word
+// is the sentinel.  Unit u = 16 bytes: slab g = u / (B NC/4), then row-major inside the slab (rows < B only).  All of a
+// thread's loads are in flight together (one asm statement with its own wait: hipcc does not track asm loads).
+// Returns false on time-out.
+template <int NT, int NC, int U>
+__device__ __forceinline__ bool gather_slabs(const float* img, float* s_dst, int B, int Bp, int H, int n_units) {
+  constexpr int Q = NC / 4;  // 16-byte units per slab row
+  const float* ptr[U];
+  int dst[U];
+  bool live[U];
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    int u   = j * NT + (int) threadIdx.x;
+    live[j] = u < n_units;
+    if (!live[j]) u = 0;
+    const int g = u / (B * Q), rem = u - g * (B * Q), row = rem / Q, part = rem - row * Q;
+    ptr[j] = img + ((size_t) g * Bp + row) * NC + 4 * part;
+    dst[j] = row * H + g * NC + 4 * part;
+  }
+  f4 v[U];
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  bool good = true;
+  for (;;) {
+    if constexpr (U == 4) {
+      asm volatile(
+          "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+          "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+          : "v"(ptr[0]), "v"(ptr[1]), "v"(ptr[2]), "v"(ptr[3])
+          : "memory");
+    } else {
+      static_assert(U == 4 || U == 8, "gather_slabs: 4 or 8 units per thread");
+      asm volatile(
+          "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
+          "global_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
+          "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+          "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4 % U]), "=&v"(v[5 % U]), "=&v"(v[6 % U]), "=&v"(v[7 % U])
+          : "v"(ptr[0]), "v"(ptr[1]), "v"(ptr[2]), "v"(ptr[3]), "v"(ptr[4 % U]), "v"(ptr[5 % U]), "v"(ptr[6 % U]), "v"(ptr[7 % U])
+          : "memory");
+    }
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < U; ++j)
+      if (live[j])
+        ok &= f2u(v[j].x) != SENTINEL && f2u(v[j].y) != SENTINEL && f2u(v[j].z) != SENTINEL && f2u(v[j].w) != SENTINEL;
+    if (ok) break;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 5000000ull) {
+      good = false;
+      break;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < U; ++j)
+    if (live[j]) *reinterpret_cast<float4*>(s_dst + dst[j]) = make_float4(v[j].x, v[j].y, v[j].z, v[j].w);
+  return good;
+}
+
+// four floats of a weight row (zero past n); 16-byte load when the source allows it
+__device__ __forceinline__ float4 load_unit(const float* __restrict__ row, int k, int n, bool vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (k + 3 < n && vec) {
+    v = *reinterpret_cast<const float4*>(row + k);
+  } else {
+    if (k < n) v.x = row[k];
+    if (k + 1 < n) v.y = row[k + 1];
+    if (k + 2 < n) v.z = row[k + 2];
+    if (k + 3 < n) v.w = row[k + 3];
+  }
+  return v;
+}
+
+// acc[p][c] += sum_k src[r + 16 p][k] w[c][k] over this lane's float4 columns k = 4 kq, 4 kq + 64, ... < klen (klen a
+// multiple of 64).  The trip count is written as a wave-uniform number (a loop bounded by the per-lane k made hipcc emit
+// exec-masked loops plus an SLP-"vectorised" body full of v_pk_mul / v_mov shuffles: 1770 cycles for 4 steps); the
+// products are explicit fma chains, 8 independent ones per lane.
+template <int PASSES>
+__device__ __forceinline__ void dot_step(float (&acc)[PASSES][4], const float* __restrict__ xs, int pitch,
+    const float* __restrict__ ws, int wpitch) {
+  float4 w[4], x[PASSES];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) w[c] = *reinterpret_cast<const float4*>(ws + c * wpitch);
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) x[p] = *reinterpret_cast<const float4*>(xs + 16 * p * pitch);
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float t = acc[p][c];
+      t = __builtin_fmaf(x[p].x, w[c].x, t);
+      t = __builtin_fmaf(x[p].y, w[c].y, t);
+      t = __builtin_fmaf(x[p].z, w[c].z, t);
+      t = __builtin_fmaf(x[p].w, w[c].w, t);
+      acc[p][c] = t;
+    }
+}
+template <int PASSES>
+__device__ __forceinline__ void dot_rows(float (&acc)[PASSES][4], const float* __restrict__ s_src, int pitch,
+    const float* __restrict__ s_wr, int wpitch, int klen, int r, int kq) {
+  const float* xs = s_src + r * pitch + 4 * kq;
+  const float* ws = s_wr + 4 * kq;
+  const int n = __builtin_amdgcn_readfirstlane(klen >> 6);
+  if (n == 4) {  // the hidden width 256: every LDS read of the product can be in flight at once
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dot_step<PASSES>(acc, xs + 64 * i, pitch, ws + 64 * i, wpitch);
+  } else {
+    for (int i = 0; i < n; ++i) dot_step<PASSES>(acc, xs + 64 * i, pitch, ws + 64 * i, wpitch);
+  }
+}
+
+// fill this workgroup's slabs of the image the launch does NOT use with the sentinel
+template <int NT, int NC>
+__device__ __forceinline__ void repoison(float* img_other, int nX, int G, int Bp) {
+  const int slab4 = Bp * NC / 4;
+  const float4 s  = make_float4(u2f(SENTINEL), u2f(SENTINEL), u2f(SENTINEL), u2f(SENTINEL));
+  for (int i = threadIdx.x; i < nX * slab4; i += NT) {
+    const int l = i / slab4, q = i - l * slab4;
+    reinterpret_cast<float4*>(img_other + ((size_t) l * G + blockIdx.x) * Bp * NC)[q] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------- forward
+// LDS (floats): s_x0 [Bp][INP] | s_act [Bp][H] | s_out [Bp][NC] | slabs: layer l -> [NC][Kp_l], Kp_l = pad64(in_h) + (in_x ?
+//               INP : 0) | bias [n_layers][NC] | misc (launch count, fail, stamps)
+template <int GROUPS, int PASSES>
+__global__ void __launch_bounds__(256 * GROUPS) fused_mlp_forward_kernel(const FusedArgs a) {
+  constexpr int NT = 256 * GROUPS, NC = 4 * GROUPS, Bp = 16 * PASSES;
+  constexpr int U = (Bp * 64 + NT - 1) / NT <= 4 ? 4 : 8;  // 16-byte units per thread of one gather at H = 256
+  static_assert((Bp * 64 + NT - 1) / NT <= 8, "gather_slabs covers at most 8 units per thread");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, grp = tid >> 8, lt = tid & 255, kq = lt & 15, r = lt >> 4;
+  const int G = gridDim.x, g = blockIdx.x, col0 = g * NC;
+  const int H = a.H, INP = a.INP, B = a.B, nL = a.n_layers, nX = nL - 1;
+  float* s_x0  = smem;
+  float* s_act = s_x0 + Bp * INP;
+  float* s_out = s_act + Bp * H;
+  float* s_w   = s_out + Bp * NC;
+  int w_total = 0;
+  for (int l = 0; l < nL; ++l) w_total += NC * (pad64(a.layer[l].in_h) + (a.layer[l].in_x ? INP : 0));
+  float* s_bias = s_w + w_total;
+  unsigned* s_misc = reinterpret_cast<unsigned*>(smem + a.lds_floats - 4);
+
+  if (tid == 0) {
+    const gu32* h = reinterpret_cast<const gu32*>((unsigned long long) a.hdr);
+    s_misc[0] = __hip_atomic_load(h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_misc[1] = 0;
+    s_misc[2] = __hip_atomic_load(h + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- every weight row this workgroup will ever need, ALL loads in flight before the first LDS store.  The layer
+  // loop is unrolled over the compile-time layer index (descriptor reads stay scalar kernarg loads; a per-thread search
+  // for "which layer does unit u belong to" was a chain of dependent vector loads: ~5 us of prologue).
+  {
+    constexpr int UPT = (NC * (256 + 128) / 4 + NT - 1) / NT;  // 16-byte units per thread and layer, worst case
+    float4 v[MAXL][UPT];
+    int woffs = 0;
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l) {
+      if (l < nL) {
+        const FusedLayer L = a.layer[l];
+        const int hp = pad64(L.in_h), Kp = hp + (L.in_x ? INP : 0), K = L.in_h + L.in_x;
+        const bool vec = (K & 3) == 0 && (L.in_h & 3) == 0 && (reinterpret_cast<uintptr_t>(L.W) & 15) == 0;
+#pragma unroll
+        for (int q = 0; q < UPT; ++q) {
+          const int e = 4 * (tid + q * NT);
+          v[l][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (e < NC * Kp) {
+            const int c = e / Kp, k = e - c * Kp;
+            const float* row = L.W + (size_t) (col0 + c) * K;
+            if (col0 + c < L.out) v[l][q] = k < hp ? load_unit(row, k, L.in_h, vec) : load_unit(row + L.in_h, k - hp, L.in_x, vec);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l) {
+      if (l < nL) {
+        const int Kp = pad64(a.layer[l].in_h) + (a.layer[l].in_x ? INP : 0);
+#pragma unroll
+        for (int q = 0; q < UPT; ++q) {
+          const int e = 4 * (tid + q * NT);
+          if (e < NC * Kp) *reinterpret_cast<float4*>(s_w + woffs + e) = v[l][q];
+        }
+        woffs += NC * Kp;
+      }
+    }
+    for (int i = tid; i < nL * NC; i += NT) {
+      const int l = i / NC, c = i - l * NC;
+      s_bias[i] = (a.layer[l].bias && col0 + c < a.layer[l].out) ? a.layer[l].bias[col0 + c] : 0.f;
+    }
+  }
+  encode_inputs<NT>(a, s_x0, Bp);
+  for (int i = tid; i < Bp * H / 4; i += NT) reinterpret_cast<float4*>(s_act)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const unsigned count = s_misc[0];
+  const size_t img_floats = (size_t) nX * G * Bp * NC;
+  float* img = a.exch + (count & 1u) * img_floats;
+  repoison<NT, NC>(a.exch + ((count & 1u) ^ 1u) * img_floats, nX, G, Bp);
+  int si = 0;
+  stamp(a, s_misc, si);
+  if (a.x0 && g == 0)
+    for (int i = tid; i < B * a.IN; i += NT) a.x0[i] = s_x0[(i / a.IN) * INP + (i % a.IN)];
+
+  int woff = 0;
+  for (int l = 0; l < nL; ++l) {
+    const FusedLayer L = a.layer[l];
+    const int hp = pad64(L.in_h), Kp = hp + (L.in_x ? INP : 0);
+    const bool last = l == nL - 1;
+    if (l > 0) {
+      const bool ok = gather_slabs<NT, NC, U>(img + (size_t) (l - 1) * G * Bp * NC, s_act, B, Bp, H, B * H / 4);
+      if (!ok) s_misc[1] = 1;
+      __syncthreads();
+      if (s_misc[1]) break;
+      stamp(a, s_misc, si);
+    }
+    if (last && col0 >= L.out) break;
+    const float* wl = s_w + woff + 4 * grp * Kp;  // this group's four rows
+    float acc[PASSES][4];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[p][c] = 0.f;
+    dot_rows<PASSES>(acc, s_act, H, wl, Kp, hp, r, kq);
+    if (L.in_x) dot_rows<PASSES>(acc, s_x0, INP, wl + hp, Kp, INP, r, kq);
+    const float4 bz = *reinterpret_cast<const float4*>(s_bias + l * NC + 4 * grp);
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[p][c] = row_sum_to_lane15(acc[p][c]);
+    if (kq == 15) {  // bias, activation and the "never the sentinel" rule in the lane that holds the sums
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        float4 y = make_float4(acc[p][0] + bz.x, acc[p][1] + bz.y, acc[p][2] + bz.z, acc[p][3] + bz.w);
+        if (L.relu) y.x = fmaxf(y.x, 0.f), y.y = fmaxf(y.y, 0.f), y.z = fmaxf(y.z, 0.f), y.w = fmaxf(y.w, 0.f);
+        y.x = not_sentinel(y.x), y.y = not_sentinel(y.y), y.z = not_sentinel(y.z), y.w = not_sentinel(y.w);
+        *reinterpret_cast<float4*>(s_out + (r + 16 * p) * NC + 4 * grp) = y;
+      }
+    }
+    __syncthreads();  // s_out complete; s_act / s_x0 reads of this layer done
+    if (tid < Bp * GROUPS) {  // one 16-byte unit per thread: the slab leaves as whole lines
+      const int row = tid / GROUPS, part = tid - row * GROUPS;
+      const float4 y = *reinterpret_cast<const float4*>(s_out + 4 * tid);
+      if (row < B) {
+        if (last) {
+          const int c = col0 + 4 * part;
+          if (c < L.out) *head_elem(a, a.head_out, a.out, row, c, L.out) = y.x;
+          if (c + 1 < L.out) *head_elem(a, a.head_out, a.out, row, c + 1, L.out) = y.y;
+          if (c + 2 < L.out) *head_elem(a, a.head_out, a.out, row, c + 2, L.out) = y.z;
+          if (c + 3 < L.out) *head_elem(a, a.head_out, a.out, row, c + 3, L.out) = y.w;
+        } else {
+          store16_sc1(img + ((size_t) l * G + g) * Bp * NC + 4 * tid, y);
+          *reinterpret_cast<float4*>(a.acts + ((size_t) l * B + row) * H + col0 + 4 * part) = y;
+        }
+      }
+    }
+    woff += NC * Kp;
+    stamp(a, s_misc, si);
+  }
+  if (g == 0 && tid == 0) {
+    gu32* h = reinterpret_cast<gu32*>((unsigned long long) a.hdr);
+    if (s_misc[1]) __hip_atomic_fetch_add(h + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(h, count + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------- backward
+// LDS (floats): s_x0 [Bp][INP] | s_gz [Bp][H] | s_own [Bp][NC] | s_out [Bp][NC] | transposed slabs: layer l >= 1 -> T_l [NC]
+//               [pad64(out_l)] = W_l[o][col0 + c]; with g_x0 and col0 < IN also X_l [NC][pad64(out_l)] = W_l[o][in_h + col0 + c]
+//               for every layer with in_x > 0 | misc
+template <int GROUPS, int PASSES>
+__global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const FusedArgs a) {
+  constexpr int NT = 256 * GROUPS, NC = 4 * GROUPS, Bp = 16 * PASSES;
+  constexpr int U = (Bp * 64 + NT - 1) / NT <= 4 ? 4 : 8;
+  static_assert((Bp * 64 + NT - 1) / NT <= 8, "gather_slabs covers at most 8 units per thread");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, grp = tid >> 8, lt = tid & 255, kq = lt & 15, r = lt >> 4;
+  const int G = gridDim.x, g = blockIdx.x, col0 = g * NC;
+  const int H = a.H, INP = a.INP, B = a.B, nL = a.n_layers, IN = a.IN, nX = nL - 1;
+  const bool want_gx = a.g_x0 != nullptr && col0 < IN;
+  float* s_x0  = smem;
+  float* s_gz  = s_x0 + Bp * INP;
+  float* s_own = s_gz + Bp * H;
+  float* s_out = s_own + Bp * NC;
+  float* s_wT  = s_out + Bp * NC;
+  int t_total = 0;  // floats of the T slabs; the X slabs follow
+  for (int l = 1; l < nL; ++l) t_total += NC * pad64(a.layer[l].out);
+  int x_total = 0;
+  if (want_gx)
+    for (int l = 0; l < nL; ++l)
+      if (a.layer[l].in_x) x_total += NC * pad64(a.layer[l].out);
+  unsigned* s_misc = reinterpret_cast<unsigned*>(smem + a.lds_floats - 4);
+
+  if (tid == 0) {
+    const gu32* h = reinterpret_cast<const gu32*>((unsigned long long) a.hdr);
+    s_misc[0] = __hip_atomic_load(h + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_misc[1] = 0;
+    s_misc[2] = __hip_atomic_load(h + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- transposed weight slabs: unit = (slab, o, group of four columns): four consecutive floats of one weight row.
+  // Same shape as the forward prologue: compile-time layer index, every load in flight before the first LDS store.
+  {
+    constexpr int UPT = (256 * GROUPS + NT - 1) / NT;  // = 1: one unit per thread and slab
+    float4 vt[MAXL][UPT], vx[MAXL][UPT];
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l) {
+      if (l < nL) {
+        const FusedLayer L = a.layer[l];
+        const int op = pad64(L.out), K = L.in_h + L.in_x;
+        const bool vecw = (K & 3) == 0 && (reinterpret_cast<uintptr_t>(L.W) & 15) == 0;
+#pragma unroll
+        for (int q = 0; q < UPT; ++q) {
+          const int u = tid + q * NT, o = u / GROUPS, c4 = 4 * (u - o * GROUPS);
+          vt[l][q] = vx[l][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (o < op && o < L.out) {
+            if (l >= 1)  // T_l: W_l[o][col0 + c4 ..], inside the hidden segment
+              vt[l][q] = load_unit(L.W + (size_t) o * K, col0 + c4, L.in_h, vecw && ((col0 + c4) & 3) == 0);
+            if (want_gx && L.in_x)  // X_l: W_l[o][in_h + col0 + c4 ..], inside the x0 segment
+              vx[l][q] = load_unit(L.W + (size_t) o * K + L.in_h, col0 + c4, L.in_x, vecw && ((L.in_h + col0 + c4) & 3) == 0);
+          }
+        }
+      }
+    }
+    int toff = 0, xoff = t_total;
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l) {
+      if (l < nL) {
+        const int op = pad64(a.layer[l].out);
+#pragma unroll
+        for (int q = 0; q < UPT; ++q) {
+          const int u = tid + q * NT, o = u / GROUPS, c4 = 4 * (u - o * GROUPS);
+          if (o < op) {
+            if (l >= 1) {
+              float* d = s_wT + toff + c4 * op + o;
+              d[0] = vt[l][q].x, d[op] = vt[l][q].y, d[2 * op] = vt[l][q].z, d[3 * op] = vt[l][q].w;
+            }
+            if (want_gx && a.layer[l].in_x) {
+              float* d = s_wT + xoff + c4 * op + o;
+              d[0] = vx[l][q].x, d[op] = vx[l][q].y, d[2 * op] = vx[l][q].z, d[3 * op] = vx[l][q].w;
+            }
+          }
+        }
+        if (l >= 1) toff += NC * op;
+        if (want_gx && a.layer[l].in_x) xoff += NC * op;
+      }
+    }
+  }
+  encode_inputs<NT>(a, s_x0, Bp);
+  {  // gZ of the last layer = the incoming gradient (zero-padded); this workgroup's slab of it
+    const int oL = a.layer[nL - 1].out;
+    for (int i = tid; i < Bp * H; i += NT) {
+      const int b = i / H, c = i - b * H;
+      s_gz[i] = (b < B && c < oL) ? *head_elem(a, const_cast<float* const*>(a.head_gout), const_cast<float*>(a.g_out), b, c, oL) : 0.f;
+    }
+    for (int i = tid; i < Bp * NC; i += NT) {
+      const int b = i / NC, c = i - b * NC;
+      s_own[i] = (b < B && col0 + c < oL)
+                     ? *head_elem(a, const_cast<float* const*>(a.head_gout), const_cast<float*>(a.g_out), b, col0 + c, oL) : 0.f;
+    }
+  }
+  __syncthreads();
+  const unsigned count = s_misc[0];
+  const size_t img_floats = (size_t) nX * G * Bp * NC;
+  float* img = a.exch + (count & 1u) * img_floats;
+  repoison<NT, NC>(a.exch + ((count & 1u) ^ 1u) * img_floats, nX, G, Bp);
+
+  float gx0[PASSES][4];
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) gx0[p][c] = 0.f;
+
+  // the slabs were laid out by increasing layer: walk their offsets backwards with the layer loop
+  int tcur = t_total, xcur = t_total + x_total;
+
+  for (int l = nL - 1; l >= 0; --l) {
+    const FusedLayer L = a.layer[l];
+    const int op = pad64(L.out), K = L.in_h + L.in_x;
+    const bool own_rows = col0 < L.out;  // this workgroup owns rows of gW_l
+    const bool publish  = l >= 1 && (l - 1 >= 1 || a.g_x0 != nullptr);  // gZ_0 is only exchanged for the input gradient
+    // ---- (A) the dependent chain: gA_{l-1}[:, slab] = gZ_l W_l[:, slab], masked by the ReLU of layer l-1
+    if (l >= 1) {
+      const bool do_x = want_gx && L.in_x;
+      tcur -= NC * op;
+      if (do_x) xcur -= NC * op;
+      float acc[PASSES][4];
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[p][c] = 0.f;
+      dot_rows<PASSES>(acc, s_gz, H, s_wT + tcur + 4 * grp * op, op, op, r, kq);
+      if (do_x) {
+        float accx[PASSES][4];
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) accx[p][c] = 0.f;
+        dot_rows<PASSES>(accx, s_gz, H, s_wT + xcur + 4 * grp * op, op, op, r, kq);
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) gx0[p][c] += row_sum_to_lane15(accx[p][c]);
+      }
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[p][c] = row_sum_to_lane15(acc[p][c]);
+      if (kq == 15) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p)
+          *reinterpret_cast<float4*>(s_out + (r + 16 * p) * NC + 4 * grp) = make_float4(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
+      }
+    }
+    __syncthreads();  // s_out complete
+    float4 newown = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (l >= 1 && tid < Bp * GROUPS) {
+      const int row = tid / GROUPS, part = tid - row * GROUPS;
+      float4 y = *reinterpret_cast<const float4*>(s_out + 4 * tid);
+      if (row < B) {
+        if (a.layer[l - 1].relu) {  // the pre-activation sign, from the saved activation
+          const float4 am = *reinterpret_cast<const float4*>(a.acts + ((size_t) (l - 1) * B + row) * H + col0 + 4 * part);
+          y.x = am.x > 0.f ? y.x : 0.f, y.y = am.y > 0.f ? y.y : 0.f, y.z = am.z > 0.f ? y.z : 0.f, y.w = am.w > 0.f ? y.w : 0.f;
+        }
+        y.x = not_sentinel(y.x), y.y = not_sentinel(y.y), y.z = not_sentinel(y.z), y.w = not_sentinel(y.w);
+        if (publish) store16_sc1(img + ((size_t) (l - 1) * G + g) * Bp * NC + 4 * tid, y);
+        newown = y;
+      }
+    }
+    // ---- (B) off the chain: weight / bias gradients of this workgroup's rows of layer l (from s_own = gZ_l[:, slab])
+    if (own_rows) {
+      const int kw = L.in_h + L.in_x;  // columns of gW_l: thread <-> (column, group of four rows)
+      for (int i = tid; i < kw * GROUPS; i += NT) {
+        const int k = i % kw, q = i / kw;
+        float gacc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (k < L.in_h) {
+          const float* ap = a.acts + (size_t) (l - 1) * B * H + k;
+#pragma unroll 4
+          for (int b = 0; b < B; ++b) {
+            const float av = ap[(size_t) b * H];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gacc[c] += s_own[b * NC + 4 * q + c] * av;
+          }
+        } else {
+          for (int b = 0; b < B; ++b) {
+            const float av = s_x0[b * INP + (k - L.in_h)];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gacc[c] += s_own[b * NC + 4 * q + c] * av;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (col0 + 4 * q + c < L.out) L.gW[(size_t) (col0 + 4 * q + c) * K + k] = gacc[c];
+      }
+      if (L.gb && tid < NC && col0 + tid < L.out) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += s_own[b * NC + tid];
+        L.gb[col0 + tid] = s;
+      }
+    }
+    if (l == 0) break;
+    __syncthreads();  // s_own and s_gz have been read
+    if (tid < Bp * GROUPS) *reinterpret_cast<float4*>(s_own + 4 * tid) = newown;
+    if (publish) {
+      const bool ok = gather_slabs<NT, NC, U>(img + (size_t) (l - 1) * G * Bp * NC, s_gz, B, Bp, H, B * H / 4);
+      if (!ok) s_misc[1] = 1;
+    }
+    __syncthreads();
+    if (s_misc[1]) break;
+  }
+  // ---- input gradient: the layers that read x0 (layer 0 included) contribute gZ_l W_l[:, x0 part]
+  if (want_gx && !s_misc[1]) {
+    const int op = pad64(a.layer[0].out);
+    float accx[PASSES][4];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) accx[p][c] = 0.f;
+    dot_rows<PASSES>(accx, s_gz, H, s_wT + t_total + 4 * grp * op, op, op, r, kq);  // X_0 is the first of the x0 slabs
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) accx[p][c] = row_sum_to_lane15(accx[p][c]);
+    if (kq == 15) {
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        const int row = r + 16 * p;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (row < B && col0 + 4 * grp + c < IN) a.g_x0[(size_t) row * IN + col0 + 4 * grp + c] = gx0[p][c] + accx[p][c];
+      }
+    }
+  }
+  if (g == 0 && tid == 0) {
+    gu32* h = reinterpret_cast<gu32*>((unsigned long long) a.hdr);
+    if (s_misc[1]) __hip_atomic_fetch_add(h + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(h + 3, count + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------ host
+constexpr int HDR_BYTES = 256;
+int g_groups = 2;  // 256-thread groups per workgroup (2 -> 32 workgroups of 512 threads at H = 256); skgs_set_mlp_columns
+
+struct Plan {
+  int Bp, passes, IN, INP, G, NC;
+  size_t exch_bytes;  // one direction: both parities
+};
+int make_plan(const skgs_mlp_desc* d, Plan* p) {
+  SKGS_REQUIRE(d, "deform_mlp: NULL descriptor");
+  SKGS_REQUIRE(d->B >= 1 && d->B <= 48, "deform_mlp: the fused kernels handle 1..48 rows (B = %d): use the per-layer path", d->B);
+  SKGS_REQUIRE(d->hidden >= 64 && d->hidden <= 256 && d->hidden % 64 == 0, "deform_mlp: hidden width must be 64, 128, 192 or 256");
+  SKGS_REQUIRE(d->n_layers >= 2 && d->n_layers <= MAXL, "deform_mlp: 2..%d layers (heads included)", MAXL);
+  SKGS_REQUIRE(d->p_dim >= 1 && d->t_dim >= 0 && d->p_degree >= 0 && d->t_degree >= 0, "deform_mlp: bad encoder sizes");
+  p->IN  = d->p_dim * (1 + 2 * d->p_degree) + d->t_dim * (1 + 2 * d->t_degree);
+  p->INP = (p->IN + 63) & ~63;
+  SKGS_REQUIRE(p->IN <= 128, "deform_mlp: encoded input wider than 128 (%d)", p->IN);
+  for (int l = 0; l < d->n_layers; ++l) {
+    const skgs_mlp_layer& L = d->layer[l];
+    SKGS_REQUIRE(L.W, "deform_mlp: layer %d has no weights", l);
+    SKGS_REQUIRE(L.in_hidden == (l == 0 ? 0 : d->hidden), "deform_mlp: layer %d: in_hidden must be %d", l, l == 0 ? 0 : d->hidden);
+    SKGS_REQUIRE(L.in_x0 == 0 || L.in_x0 == p->IN, "deform_mlp: layer %d: in_x0 must be 0 or the encoded width %d", l, p->IN);
+    SKGS_REQUIRE(l > 0 || L.in_x0 == p->IN, "deform_mlp: the first layer reads the encoded input");
+    SKGS_REQUIRE(l == d->n_layers - 1 ? (L.out >= 1 && L.out <= d->hidden) : L.out == d->hidden,
+        "deform_mlp: layer %d: out = %d", l, L.out);
+  }
+  SKGS_REQUIRE(d->n_heads >= 0 && d->n_heads <= 4, "deform_mlp: 0..4 heads");
+  if (d->n_heads) {
+    int sum = 0;
+    for (int j = 0; j < d->n_heads; ++j) sum += d->head_dim[j];
+    SKGS_REQUIRE(sum == d->layer[d->n_layers - 1].out, "deform_mlp: the head widths must add up to the last layer's out");
+  }
+  p->passes = (d->B + 15) / 16;
+  p->Bp     = p->passes * 16;
+  p->NC     = 4 * g_groups;
+  p->G      = d->hidden / p->NC;
+  p->exch_bytes = (size_t) 2 * (d->n_layers - 1) * p->Bp * d->hidden * 4;
+  return 0;
+}
+
+void fill_args(const skgs_mlp_desc* d, const Plan& p, FusedArgs* a) {
+  a->B = d->B, a->p_dim = d->p_dim, a->p_deg = d->p_degree, a->t_dim = d->t_dim, a->t_deg = d->t_degree;
+  a->IN = p.IN, a->INP = p.INP, a->H = d->hidden, a->n_layers = d->n_layers;
+  for (int l = 0; l < d->n_layers; ++l) {
+    const skgs_mlp_layer& L = d->layer[l];
+    a->layer[l] = FusedLayer{L.W, L.bias, L.gW, L.gb, L.in_hidden, L.in_x0, L.out, L.relu};
+  }
+  a->n_heads = d->n_heads;
+  for (int j = 0; j < 4; ++j) a->head_dim[j] = d->head_dim[j], a->head_out[j] = d->head_out[j], a->head_gout[j] = d->head_gout[j];
+}
+
+template <typename KernelT>
+int launch(KernelT k, const Plan& p, int groups, const FusedArgs& a, size_t lds, hipStream_t s) {
+  if (lds > 64 * 1024)
+    SKGS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipLaunchKernelGGL(k, dim3(p.G), dim3(256 * groups), lds, s, a);
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+#define SKGS_MLP_DISPATCH(KERNEL)                                                              \
+  if (g_groups == 2) {                                                                         \
+    if (p.passes == 1) return launch(KERNEL<2, 1>, p, 2, a, lds, (hipStream_t) stream);        \
+    if (p.passes == 2) return launch(KERNEL<2, 2>, p, 2, a, lds, (hipStream_t) stream);        \
+    return launch(KERNEL<2, 3>, p, 2, a, lds, (hipStream_t) stream);                           \
+  }                                                                                            \
+  SKGS_REQUIRE(p.passes <= 2, "deform_mlp: 4 columns per workgroup handle at most 32 rows");  \
+  if (p.passes == 1) return launch(KERNEL<1, 1>, p, 1, a, lds, (hipStream_t) stream);          \
+  return launch(KERNEL<1, 2>, p, 1, a, lds, (hipStream_t) stream);
+
+__global__ void init_workspace_kernel(uint32_t* w, size_t n_words) {
+  const size_t stride = (size_t) gridDim.x * blockDim.x;
+  for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride)
+    w[i] = i < HDR_BYTES / 4 ? 0u : SENTINEL;
+}
+
+}  // namespace
+}  // namespace skgs
+
+using namespace skgs;
+
+extern "C" {
+
+void skgs_set_mlp_columns(int ncol) { g_groups = (ncol == 4) ? 1 : 2; }
+
+size_t skgs_deform_mlp_workspace_bytes(const skgs_mlp_desc* d) {
+  Plan p;
+  if (make_plan(d, &p)) return 0;
+  return HDR_BYTES + 2 * p.exch_bytes;
+}
+
+int skgs_deform_mlp_workspace_init(void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
+  SKGS_REQUIRE(workspace && workspace_bytes >= HDR_BYTES && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0,
+      "deform_mlp_workspace_init: NULL, short or unaligned workspace");
+  const size_t n = workspace_bytes / 4;
+  hipLaunchKernelGGL(init_workspace_kernel, dim3((unsigned) std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0,
+      (hipStream_t) stream, reinterpret_cast<uint32_t*>(workspace), n);
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int skgs_deform_mlp_forward(const skgs_mlp_desc* d, const float* points, const float* t, float* x0, float* acts, float* out,
+    void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
+  Plan p;
+  if (make_plan(d, &p)) return 1;
+  SKGS_REQUIRE(points && (t || d->t_dim == 0) && acts && workspace, "deform_mlp_forward: NULL argument");
+  for (int j = 0; j < d->n_heads; ++j) SKGS_REQUIRE(d->head_out[j], "deform_mlp_forward: head_out[%d] is NULL", j);
+  SKGS_REQUIRE(out || d->n_heads, "deform_mlp_forward: no output tensor");
+  SKGS_REQUIRE(workspace_bytes >= HDR_BYTES + 2 * p.exch_bytes, "deform_mlp_forward: workspace too small");
+  SKGS_REQUIRE((reinterpret_cast<uintptr_t>(acts) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0,
+      "deform_mlp_forward: acts must be 16-byte, the workspace 256-byte aligned");
+  FusedArgs a{};
+  fill_args(d, p, &a);
+  a.points = points, a.t = t, a.x0 = x0, a.acts = acts, a.out = out;
+  a.hdr  = reinterpret_cast<unsigned*>(workspace);
+  a.exch = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + HDR_BYTES);
+  size_t fl = (size_t) p.Bp * p.INP + (size_t) p.Bp * d->hidden + (size_t) p.Bp * p.NC + (size_t) d->n_layers * p.NC + 4;
+  for (int l = 0; l < d->n_layers; ++l)
+    fl += (size_t) p.NC * (((d->layer[l].in_hidden + 63) & ~63) + (d->layer[l].in_x0 ? p.INP : 0));
+  a.lds_floats = (int) fl;
+  const size_t lds = fl * 4;
+  SKGS_REQUIRE(lds <= 160 * 1024, "deform_mlp_forward: %zu bytes of LDS needed", lds);
+  SKGS_MLP_DISPATCH(fused_mlp_forward_kernel)
+}
+
+int skgs_deform_mlp_backward(const skgs_mlp_desc* d, const float* points, const float* t, const float* acts,
+    const float* g_out, float* g_x0, void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
+  Plan p;
+  if (make_plan(d, &p)) return 1;
+  SKGS_REQUIRE(points && (t || d->t_dim == 0) && acts && workspace, "deform_mlp_backward: NULL argument");
+  for (int j = 0; j < d->n_heads; ++j) SKGS_REQUIRE(d->head_gout[j], "deform_mlp_backward: head_gout[%d] is NULL", j);
+  SKGS_REQUIRE(g_out || d->n_heads, "deform_mlp_backward: no incoming gradient");
+  SKGS_REQUIRE(workspace_bytes >= HDR_BYTES + 2 * p.exch_bytes, "deform_mlp_backward: workspace too small");
+  SKGS_REQUIRE((reinterpret_cast<uintptr_t>(acts) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0,
+      "deform_mlp_backward: acts must be 16-byte, the workspace 256-byte aligned");
+  for (int l = 0; l < d->n_layers; ++l) SKGS_REQUIRE(d->layer[l].gW, "deform_mlp_backward: layer %d has no gW", l);
+  SKGS_REQUIRE(!g_x0 || p.IN <= d->hidden, "deform_mlp_backward: the input gradient needs hidden >= encoded width (%d < %d)",
+      d->hidden, p.IN);
+  FusedArgs a{};
+  fill_args(d, p, &a);
+  a.points = points, a.t = t, a.acts = const_cast<float*>(acts), a.g_out = g_out, a.g_x0 = g_x0;
+  a.hdr  = reinterpret_cast<unsigned*>(workspace);
+  a.exch = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + HDR_BYTES + p.exch_bytes);
+  size_t fl = (size_t) p.Bp * p.INP + (size_t) p.Bp * d->hidden + (size_t) 2 * p.Bp * p.NC + 4;
+  for (int l = 1; l < d->n_layers; ++l) fl += (size_t) p.NC * ((d->layer[l].out + 63) & ~63);
+  if (g_x0)
+    for (int l = 0; l < d->n_layers; ++l)
+      if (d->layer[l].in_x0) fl += (size_t) p.NC * ((d->layer[l].out + 63) & ~63);
+  a.lds_floats = (int) fl;
+  const size_t lds = fl * 4;
+  SKGS_REQUIRE(lds <= 160 * 1024, "deform_mlp_backward: %zu bytes of LDS needed", lds);
+  SKGS_MLP_DISPATCH(fused_mlp_backward_kernel)
+}
+
+int skgs_deform_mlp_status(const void* workspace, uint32_t* host_words4, skgs_stream_t stream) {
+  SKGS_REQUIRE(workspace && host_words4, "deform_mlp_status: NULL argument");
+  SKGS_CHECK_HIP(hipMemcpyAsync(host_words4, workspace, 16, hipMemcpyDeviceToHost, (hipStream_t) stream));
+  return 0;
+}
+
+}  // extern "C"

@@ -9,6 +9,10 @@ pass is one launch per layer (csrc/mlp.hip) instead of ~65 torch launches for 20
 
 ``forward`` runs the HIP kernels (device tensors only, no fallback); ``reference_forward`` is the same network in
 plain torch ops -- the numerics reference of the kernels and the CPU restatement used by the host tests.
+
+Two kernel paths, same results up to summation order: ``FusedDeformMLP`` -- the whole network as ONE persistent launch per
+direction (csrc/mlp_fused.hip; <= 48 rows, the skeleton stage's one row per bone), the default wherever it applies -- and
+``DeformMLPRunner`` -- one launch per layer (csrc/mlp.hip; any row count, e.g. the 512 superpoints of the sp stage).
 """
 import ctypes as C
 from typing import List, Optional, Sequence, Tuple
@@ -182,6 +186,116 @@ class DeformMLPRunner:
         self.backward_hidden(x0, acts, grads[:-2], g_act)
 
 
+class _MlpLayer(C.Structure):
+    _fields_ = [('W', C.c_void_p), ('bias', C.c_void_p), ('gW', C.c_void_p), ('gb', C.c_void_p),
+                ('in_hidden', C.c_int32), ('in_x0', C.c_int32), ('out', C.c_int32), ('relu', C.c_int32)]
+
+
+MLP_MAX_LAYERS = 12
+
+
+class _MlpDesc(C.Structure):
+    _fields_ = [('B', C.c_int32), ('p_dim', C.c_int32), ('p_degree', C.c_int32), ('t_dim', C.c_int32),
+                ('t_degree', C.c_int32), ('hidden', C.c_int32), ('n_layers', C.c_int32),
+                ('layer', _MlpLayer * MLP_MAX_LAYERS), ('n_heads', C.c_int32), ('head_dim', C.c_int32 * 4),
+                ('head_out', C.c_void_p * 4), ('head_gout', C.c_void_p * 4)]
+
+
+def fused_supported(mlp: 'DeformMLP', B: int) -> bool:
+    """the one-launch kernels cover the skeleton stage's shapes: <= 48 rows, hidden width 64..256 in steps of 64, encoded
+    input <= 128 wide (skgs.h: skgs_deform_mlp_forward)"""
+    net = mlp.dynamic_net
+    return (1 <= B <= 48 and net.dim_hidden % 64 == 0 and 64 <= net.dim_hidden <= 256 and net.in_channels <= 128
+            and net.num_layers + 1 <= MLP_MAX_LAYERS and sum(net.out_channels) <= net.dim_hidden)
+
+
+class FusedDeformMLP:
+    """``SimpleDeformationNetwork.forward`` / its backward as one persistent launch each (csrc/mlp_fused.hip) on persistent
+    buffers: ``x0`` [B, IN], ``acts`` [L, B, H], ``out`` [B, OUT]; the backward WRITES the weight gradients into the
+    tensors given to ``backward`` (normally the parameters' ``.grad``) and optionally dL/dx0."""
+
+    def __init__(self, mlp: DeformMLP, B: int):
+        if not fused_supported(mlp, B):
+            raise _C.SkgsError(f'fused deform MLP: unsupported shape (rows {B}, hidden {mlp.dynamic_net.dim_hidden}, '
+                               f'input {mlp.dynamic_net.in_channels}); use DeformMLPRunner')
+        self.mlp, self.lib, self.B = mlp, _C.load_library(), int(B)
+        net = mlp.dynamic_net
+        dev = net.last_weight.device
+        if dev.type != 'cuda':
+            raise _C.SkgsError('fused deform MLP needs the network on a HIP device; sk_gs_amd has no CPU path')
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.x0 = torch.empty((B, net.in_channels), **f32)
+        self.acts = torch.empty((net.num_layers, B, net.dim_hidden), **f32)
+        self.out = torch.empty((B, sum(net.out_channels)), **f32)
+        self.lib.skgs_deform_mlp_workspace_bytes.restype = C.c_size_t
+        d = self._desc(None)
+        nbytes = self.lib.skgs_deform_mlp_workspace_bytes(C.byref(d))
+        if nbytes == 0:
+            _C._check(1)
+        self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=dev)  # exchange images + launch counters
+        _C._check(self.lib.skgs_deform_mlp_workspace_init(C.c_void_p(self.workspace.data_ptr()), C.c_size_t(nbytes),
+                                                          _C._stream()))
+
+    def _desc(self, grads: Optional[Sequence[Tensor]], head_out: Optional[Sequence[Tensor]] = None,
+              head_gout: Optional[Sequence[Tensor]] = None) -> _MlpDesc:
+        m, net = self.mlp, self.mlp.dynamic_net
+        d = _MlpDesc()
+        d.B, d.p_dim, d.p_degree, d.t_dim, d.t_degree = self.B, m.p_in, m.p_degree, m.t_in, m.t_degree
+        d.hidden, d.n_layers = net.dim_hidden, net.num_layers + 1
+        dims = net.layer_dims()
+        params = [(l.weight, l.bias) for l in net.net] + [(net.last_weight, net.last_bias)]
+        for i, ((w, b), (in1, in2)) in enumerate(zip(params, dims)):
+            assert w.is_contiguous() and b.is_contiguous() and w.dtype == torch.float32
+            L = d.layer[i]
+            L.W, L.bias = w.data_ptr(), b.data_ptr()
+            L.in_hidden, L.in_x0 = (0, in1) if i == 0 else (in1, in2)
+            L.out, L.relu = w.shape[0], int(i < net.num_layers)
+            if grads is not None:
+                gw, gb = grads[2 * i], grads[2 * i + 1]
+                assert gw.is_contiguous() and gb.is_contiguous() and gw.shape == w.shape and gb.shape == b.shape
+                L.gW, L.gb = gw.data_ptr(), gb.data_ptr()
+        heads = head_out if head_out is not None else head_gout
+        if heads is not None:  # the heads as separate [B, dim] tensors (sk_r | d_rot | d_scale)
+            assert len(heads) == len(net.out_channels) <= 4
+            d.n_heads = len(heads)
+            for j, (h, oc) in enumerate(zip(heads, net.out_channels)):
+                assert h.is_cuda and h.is_contiguous() and h.dtype == torch.float32 and tuple(h.shape) == (self.B, oc)
+                d.head_dim[j] = oc
+                (d.head_out if head_out is not None else d.head_gout)[j] = h.data_ptr()
+        return d
+
+    def forward(self, points: Tensor, t: Tensor, head_out: Optional[Sequence[Tensor]] = None) -> Tensor:
+        """points [B, p_in], t: device tensor with t_in floats -> ``self.out`` [B, OUT], or the heads written to the
+        separate tensors ``head_out`` (also fills x0 / acts)"""
+        assert points.is_cuda and points.is_contiguous() and points.dtype == torch.float32 and points.shape[0] == self.B
+        assert t.is_cuda and t.dtype == torch.float32 and t.numel() == self.mlp.t_in
+        d = self._desc(None, head_out=head_out)
+        _C._check(self.lib.skgs_deform_mlp_forward(
+            C.byref(d), C.c_void_p(points.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(self.x0.data_ptr()),
+            C.c_void_p(self.acts.data_ptr()), C.c_void_p(self.out.data_ptr()), C.c_void_p(self.workspace.data_ptr()),
+            C.c_size_t(self.workspace.numel()), _C._stream()))
+        return self.out
+
+    def backward(self, points: Tensor, t: Tensor, g_out, grads: Sequence[Tensor], g_x0: Optional[Tensor] = None):
+        """``g_out``: [B, OUT] or one tensor per head; ``grads``: [gW0, gb0, ..., gW_heads, gb_heads] (written); ``g_x0``
+        [B, IN] (written) or None"""
+        if isinstance(g_out, Tensor):
+            assert g_out.is_cuda and g_out.is_contiguous() and g_out.shape == self.out.shape
+            d = self._desc(grads)
+        else:
+            d, g_out = self._desc(grads, head_gout=g_out), None
+        _C._check(self.lib.skgs_deform_mlp_backward(
+            C.byref(d), C.c_void_p(points.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(self.acts.data_ptr()),
+            C.c_void_p(None if g_out is None else g_out.data_ptr()), C.c_void_p(None if g_x0 is None else g_x0.data_ptr()),
+            C.c_void_p(self.workspace.data_ptr()), C.c_size_t(self.workspace.numel()), _C._stream()))
+
+    def status(self) -> dict:
+        """(synchronising) forward / backward launches so far and 'failed': launches whose in-kernel exchange timed out
+        (must be 0)"""
+        w = self.workspace[:16].view(torch.int32).cpu()
+        return dict(forward=int(w[0]), backward=int(w[3]), failed=int(w[1]))
+
+
 class _DeformMLPFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mlp: DeformMLP, points: Tensor, t: Tensor, *params):
@@ -191,6 +305,12 @@ class _DeformMLPFn(torch.autograd.Function):
         t = t.detach().float().reshape(-1).contiguous().to(points.device)
         B = points.shape[0]
         f32 = dict(dtype=torch.float32, device=points.device)
+        if fused_supported(mlp, B) and not getattr(mlp, 'force_layered', False):
+            run = FusedDeformMLP(mlp, B)  # (allocates its exchange workspace: the training step keeps one instead)
+            out = run.forward(points, t)
+            ctx.mlp, ctx.fused, ctx.pt = mlp, run, (points, t)
+            return out
+        ctx.fused = None
         x0 = torch.empty((B, net.in_channels), **f32)
         acts = torch.empty((net.num_layers, B, net.dim_hidden), **f32)
         out = torch.empty((B, sum(net.out_channels)), **f32)
@@ -204,11 +324,14 @@ class _DeformMLPFn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_out):
-        x0, acts, out = ctx.saved_tensors
         mlp = ctx.mlp
         net = mlp.dynamic_net
         params = [p for l in net.net for p in (l.weight, l.bias)] + [net.last_weight, net.last_bias]
         grads = [torch.empty_like(p) for p in params]
+        if ctx.fused is not None:
+            ctx.fused.backward(ctx.pt[0], ctx.pt[1], g_out.contiguous(), grads)
+            return (None, None, None) + tuple(grads)
+        x0, acts, out = ctx.saved_tensors
         g_act = torch.empty((2,) + tuple(acts.shape[1:]), dtype=torch.float32, device=acts.device)
         DeformMLPRunner(mlp).backward(x0, acts, out, g_out.contiguous(), grads, g_act)
         return (None, None, None) + tuple(grads)  # joints / time are inputs of the skeleton stage, not learned here

@@ -48,7 +48,7 @@ class FusedViewStep:
     def __init__(self, model: SkinnedGaussians, W: int, H: int, capacity: int, lambda_dssim: float = 0.2,
                  background: Optional[Tensor] = None, grad_scale: float = 1.0, densify_stats: bool = False,
                  spw_logit_grad: Optional[Tensor] = None, tables_zeroed_by_optimizer: bool = False,
-                 tile_bucket: int = 0, sh_factors: Optional[Tensor] = None):
+                 tile_bucket: int = 0, sh_factors: Optional[Tensor] = None, fused_deform_net: bool = True):
         assert not model.static, 'FusedViewStep covers the skinned stage (M >= 1)'
         self.model, self.W, self.H = model, int(W), int(H)
         self.lambda_l1, self.lambda_ssim = 1.0 - lambda_dssim, lambda_dssim
@@ -115,12 +115,15 @@ class FusedViewStep:
         # bone-transform producer (scope row (f)-3): the MLP runs inside the step, its weight gradients are written in place
         self.deform_net = model.sk_deform_net
         if self.deform_net is not None:
-            from sk_gs_amd.deform_net import DeformMLPRunner
+            from sk_gs_amd.deform_net import DeformMLPRunner, FusedDeformMLP, fused_supported
             net = self.deform_net.dynamic_net
+            # one persistent launch per direction (csrc/mlp_fused.hip) where the shape allows, else one launch per layer
+            self._mlp_fused = FusedDeformMLP(self.deform_net, M) if (fused_deform_net and fused_supported(self.deform_net, M)) else None
             self._mlp = DeformMLPRunner(self.deform_net)
-            self._x0 = torch.empty((M, net.in_channels), **f32)
-            self._acts = torch.empty((net.num_layers, M, net.dim_hidden), **f32)
-            self._g_act = torch.empty((2, M, net.dim_hidden), **f32)
+            if self._mlp_fused is None:
+                self._x0 = torch.empty((M, net.in_channels), **f32)
+                self._acts = torch.empty((net.num_layers, M, net.dim_hidden), **f32)
+                self._g_act = torch.empty((2, M, net.dim_hidden), **f32)
             self._sk_r_raw, self._d_rot, self._d_scale = (torch.empty((M, 4), **f32), torch.empty((M, 4), **f32),
                                                           torch.empty((M, 3), **f32))
             self._g_heads = [torch.empty((M, 4), **f32), torch.empty((M, 4), **f32), torch.empty((M, 3), **f32)]
@@ -276,6 +279,7 @@ class FusedViewStep:
         t = self._topo
         P, M, K = self.P, self.M, self.K
         d = self._deform_inputs(time_id)
+        self._time_id = time_id
         if self.deform_net is None:
             sk_r_raw, g_raw = m.sk_r[time_id], m.sk_r.grad[time_id]
             g_drot, g_dscale = m.sk_d_rot.grad[time_id], m.sk_d_scale.grad[time_id]
@@ -324,6 +328,9 @@ class FusedViewStep:
         m = self.model
         if self.deform_net is None:
             return m.sk_r[time_id]
+        if self._mlp_fused is not None:  # the whole network: one launch
+            self._mlp_fused.forward(m.joints, m.frame_times[time_id], head_out=(self._sk_r_raw, self._d_rot, self._d_scale))
+            return self._sk_r_raw
         from sk_gs_amd.deform_net import _lin_fwd
         net, run = self.deform_net.dynamic_net, self._mlp
         run.encode(m.joints, m.frame_times[time_id], self._x0)
@@ -338,7 +345,13 @@ class FusedViewStep:
         return self._sk_r_raw
 
     def _deform_net_backward(self):
-        """weight gradients of the producer network, written into the parameters' .grad: 3 head + 8 layer launches"""
+        """weight gradients of the producer network, written into the parameters' .grad: one launch (fused kernels) or
+        3 head + 8 layer launches"""
+        if self._mlp_fused is not None:
+            net = self.deform_net.dynamic_net
+            grads = [g for l in net.net for g in (l.weight.grad, l.bias.grad)] + [net.last_weight.grad, net.last_bias.grad]
+            self._mlp_fused.backward(self.model.joints, self.model.frame_times[self._time_id], self._g_heads, grads)
+            return
         from sk_gs_amd.deform_net import _lin_bwd
         net, run = self.deform_net.dynamic_net, self._mlp
         M, H, IN = self.M, net.dim_hidden, net.in_channels
@@ -368,5 +381,9 @@ class FusedViewStep:
 
     def status(self) -> dict:
         """(synchronising) num_rendered / overflow / longest tile list of the last forward, and the number of
-        forwards since construction whose tile lists did not fit ``capacity`` (``overflow_events``)"""
-        return _C.read_status(self.geom)
+        forwards since construction whose tile lists did not fit ``capacity`` (``overflow_events``); with the fused
+        deform network also ``mlp_failed`` (launches whose in-kernel exchange gave up: must be 0)"""
+        st = _C.read_status(self.geom)
+        if self.deform_net is not None and self._mlp_fused is not None:
+            st['mlp_failed'] = self._mlp_fused.status()['failed']
+        return st

@@ -90,3 +90,138 @@ def test_deform_mlp_forward_backward_matches_reference_forward():
     out.backward(g)
     for (n, p), gr in zip(mlp.named_parameters(), gref):
         assert rel_err(p.grad, gr) <= 5e-5, n
+
+
+def _ref_with_input_grad(mlp, joints, t, g):
+    """torch reference of forward + backward, including dL/dx0 (the encoded input as a leaf)"""
+    from sk_gs_amd.deform_net import freq_encode_torch
+    net = mlp.dynamic_net
+    x0 = torch.cat([freq_encode_torch(joints, mlp.p_degree),
+                    freq_encode_torch(t.view(-1, mlp.t_in), mlp.t_degree).expand(joints.shape[0], -1)], -1)
+    x0 = x0.detach().requires_grad_(True)
+    x, acts = x0, []
+    for i in range(net.num_layers):
+        x = F.relu(net.net[i](x))
+        acts.append(x)
+        if i in net.skips:
+            x = torch.cat([x, x0], dim=-1)
+    out = F.linear(x, net.last_weight, net.last_bias)
+    for p in mlp.parameters():
+        p.grad = None
+    out.backward(g)
+    params = [p for l in net.net for p in (l.weight, l.bias)] + [net.last_weight, net.last_bias]
+    return out.detach(), torch.stack([a.detach() for a in acts]), [p.grad.clone() for p in params], x0.grad.clone(), x0.detach()
+
+
+@pytest.mark.parametrize('ncol', [4, 8])
+def test_fused_deform_mlp_matches_torch(ncol):  # noqa: C901
+    """the one-launch-per-direction network (csrc/mlp_fused.hip) against torch autograd of the restated module: outputs,
+    saved activations, every weight / bias gradient and the input gradient, for row counts on both sides of the 16-row
+    passes, repeated launches on one workspace (launch epochs) and a hipGraph replay"""
+    from sk_gs_amd import _C
+    from sk_gs_amd.deform_net import DeformMLP, FusedDeformMLP
+    _C.load_library().skgs_set_mlp_columns(ncol)
+    try:
+        torch.manual_seed(0)
+        mlp = DeformMLP().cuda()
+        with torch.no_grad():  # the reference initialises the heads with std 1e-6 (sk_gs.py:542-545): use O(1) heads here
+            mlp.dynamic_net.last_weight.normal_(0, 0.1)
+        for B in (1, 16, 20, 32) if ncol == 4 else (1, 16, 20, 32, 33, 48):  # 4 columns per workgroup: <= 32 rows
+            joints = (torch.rand(B, 3, device='cuda') - 0.5)
+            t = torch.tensor([0.41], device='cuda')
+            g = torch.randn(B, 11, device='cuda')
+            ref_out, ref_acts, ref_grads, ref_gx0, ref_x0 = _ref_with_input_grad(mlp, joints, t, g)
+            run = FusedDeformMLP(mlp, B)
+            grads = [torch.full_like(r, 7.0) for r in ref_grads]
+            g_x0 = torch.full_like(ref_gx0, 7.0)
+            for rep in range(3):  # same workspace: the launch epoch distinguishes the exchanges
+                out = run.forward(joints, t)
+                run.backward(joints, t, g, grads, g_x0)
+            assert run.status() == dict(forward=3, backward=3, failed=0)
+            assert (run.x0 - ref_x0).abs().max() <= 3e-4  # sin of arguments up to 2^9 x: argument rounding
+            assert rel_err(out, ref_out) <= 2e-5, B
+            assert rel_err(run.acts, ref_acts) <= 2e-5, B
+            for i, (a, r) in enumerate(zip(grads, ref_grads)):
+                assert rel_err(a, r) <= 5e-5, (B, i)
+            assert rel_err(g_x0, ref_gx0) <= 5e-5, B
+            # without the input gradient nothing else changes
+            grads2 = [torch.zeros_like(r) for r in ref_grads]
+            run.forward(joints, t)
+            run.backward(joints, t, g, grads2, None)
+            for a, b in zip(grads, grads2):
+                assert torch.equal(a, b)
+        # hipGraph replay of forward + backward (what the training step does)
+        B = 20
+        joints, t, g = torch.rand(B, 3, device='cuda') - 0.5, torch.tensor([0.7], device='cuda'), torch.randn(B, 11, device='cuda')
+        ref_out, _, ref_grads, _, _ = _ref_with_input_grad(mlp, joints, t, g)
+        run = FusedDeformMLP(mlp, B)
+        grads = [torch.zeros_like(r) for r in ref_grads]
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            run.forward(joints, t)
+            run.backward(joints, t, g, grads)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=s):
+                run.forward(joints, t)
+                run.backward(joints, t, g, grads)
+            for _ in range(5):
+                for gr in grads:
+                    gr.zero_()
+                run.out.zero_()
+                graph.replay()
+        torch.cuda.synchronize()
+        assert run.status()['failed'] == 0
+        assert rel_err(run.out, ref_out) <= 2e-5
+        for a, r in zip(grads, ref_grads):
+            assert rel_err(a, r) <= 5e-5
+    finally:
+        _C.load_library().skgs_set_mlp_columns(8)
+
+
+def test_fused_deform_mlp_other_shapes():
+    """hidden widths 64 / 128, one skip right before the heads, no skip, wider encoded input"""
+    from sk_gs_amd.deform_net import DeformMLP, FusedDeformMLP
+    torch.manual_seed(1)
+    for kw in (dict(width=64, depth=3, skips=()), dict(width=128, depth=4, skips=(1, 3)),
+               dict(width=256, depth=2, skips=(1,), p_in_channels=5, p_degree=6, t_degree=3)):
+        mlp = DeformMLP(**kw).cuda()
+        B = 24
+        joints = torch.rand(B, mlp.p_in, device='cuda') - 0.5
+        t = torch.tensor([0.2], device='cuda')
+        g = torch.randn(B, 11, device='cuda')
+        ref_out, ref_acts, ref_grads, ref_gx0, _ = _ref_with_input_grad(mlp, joints, t, g)
+        run = FusedDeformMLP(mlp, B)
+        grads = [torch.zeros_like(r) for r in ref_grads]
+        # (the input gradient is distributed over the workgroups by hidden column: it needs hidden >= encoded width)
+        g_x0 = torch.zeros_like(ref_gx0) if mlp.dynamic_net.dim_hidden >= mlp.dynamic_net.in_channels else None
+        out = run.forward(joints, t)
+        run.backward(joints, t, g, grads, g_x0)
+        assert run.status()['failed'] == 0
+        assert rel_err(out, ref_out) <= 2e-5, kw
+        for i, (a, r) in enumerate(zip(grads, ref_grads)):
+            assert rel_err(a, r) <= 5e-5, (kw, i)
+        assert g_x0 is None or rel_err(g_x0, ref_gx0) <= 5e-5, kw
+
+
+def test_fused_deform_mlp_separate_heads():
+    """the heads written to / read from separate tensors (sk_r | d_rot | d_scale, as the training step keeps them)"""
+    from sk_gs_amd.deform_net import DeformMLP, FusedDeformMLP
+    torch.manual_seed(3)
+    mlp = DeformMLP().cuda()
+    with torch.no_grad():
+        mlp.dynamic_net.last_weight.normal_(0, 0.1)
+    B = 20
+    joints, t, g = torch.rand(B, 3, device='cuda') - 0.5, torch.tensor([0.9], device='cuda'), torch.randn(B, 11, device='cuda')
+    run = FusedDeformMLP(mlp, B)
+    ref_grads = [torch.zeros_like(p) for l in mlp.dynamic_net.net for p in (l.weight, l.bias)] + \
+                [torch.zeros_like(mlp.dynamic_net.last_weight), torch.zeros_like(mlp.dynamic_net.last_bias)]
+    out = run.forward(joints, t).clone()
+    run.backward(joints, t, g, ref_grads)
+    heads = [torch.zeros(B, 4, device='cuda'), torch.zeros(B, 4, device='cuda'), torch.zeros(B, 3, device='cuda')]
+    run.forward(joints, t, head_out=heads)
+    assert torch.equal(torch.cat(heads, dim=1), out)
+    grads = [torch.zeros_like(r) for r in ref_grads]
+    run.backward(joints, t, [h.contiguous() for h in g.split((4, 4, 3), dim=1)], grads)
+    for a, r in zip(grads, ref_grads):
+        assert torch.equal(a, r)
