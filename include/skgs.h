@@ -300,7 +300,8 @@ int skgs_linear_backward(int32_t B, int32_t in1, int32_t in2, int32_t out, const
 /* ---- the same network as ONE persistent launch per direction (csrc/mlp_fused.hip) ----
  * Replaces the whole SimpleDeformationNetwork.forward call of kinematic() (networks/sk_gs.py:1073-1074; module :134-164,
  * MLP_with_skips my_ext/blocks/mlp.py:43-85, FreqEncoder my_ext/_C/src/nerf/freqencoder.cu:7-60) and its autograd
- * backward, for B <= 48 rows (one per bone), hidden width 64..256 (multiple of 64), encoded input <= 128 wide.
+ * backward, for B <= 48 rows (one per bone), hidden width 256 (every reference config), encoded input a multiple of 4 and
+ * <= 128 wide, at most 10 layers with the heads; 16-byte aligned weights.  Other shapes: the per-layer entry points above.
  * Layer l computes act([a_{l-1} | x0] W_l^T + b_l): in_hidden = 0 for the first layer and `hidden` afterwards, in_x0 = the
  * encoded width where the layer reads the encoded input (first layer, layers behind a skip) else 0; the last entry is the
  * heads stored as one matrix (relu = 0).  W is [out, in_hidden + in_x0] (torch.nn.Linear layout).

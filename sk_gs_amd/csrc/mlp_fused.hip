@@ -88,31 +88,14 @@ __device__ __forceinline__ float row_sum_to_lane15(float v) {
   return v;
 }
 
-// the frequency encoding of freqencoder.cu:7-33 (same expression as mlp.hip::freq_encode_forward_kernel)
-__device__ __forceinline__ float freq_value(const float* __restrict__ x, int D, int c) {
-  if (c < D) return x[c];
-  const int col = c / D - 1, d = c % D;
-  return sinf(scalbnf(x[d], col / 2) + (float) (col % 2) * (3.141592653589793f / 2));
-}
-
-// s_x0[b][c] (pitch INP), zero outside [B) x [IN).  The caller synchronises before reading.
-template <int NT>
-__device__ __forceinline__ void encode_inputs(const FusedArgs& a, float* s_x0, int Bp) {
-  const int pe = a.p_dim * (1 + 2 * a.p_deg), INP = a.INP, IN = a.IN;
-  for (int i = threadIdx.x; i < a.B * IN; i += NT) {
-    const int b = i / IN, c = i - b * IN;
-    s_x0[b * INP + c] = c < pe ? freq_value(a.points + (size_t) b * a.p_dim, a.p_dim, c) : freq_value(a.t, a.t_dim, c - pe);
-  }
-  for (int i = threadIdx.x; i < Bp * INP; i += NT) {  // the padding (disjoint from the entries above)
-    const int b = i / INP, c = i - b * INP;
-    if (b >= a.B || c >= IN) s_x0[i] = 0.f;
-  }
-}
+// (the frequency encoding of freqencoder.cu:7-33 is inlined in the prologues: raw inputs are loaded first, the sines are
+// taken while the weight loads are in flight; same expression as mlp.hip::freq_encode_forward_kernel)
 
 // diagnostics (header word 2 != 0): workgroup 0 records {100 MHz real-time counter, shader clock counter} at successive
 // points of the launch into header words 16.. (two words per stamp, 24 stamps)
-__device__ __forceinline__ void stamp(const FusedArgs& a, const unsigned* s_misc, int& si) {
-  if (s_misc[2] && blockIdx.x == 0 && threadIdx.x == 0 && si < 24) {
+__device__ __forceinline__ void stamp(const FusedArgs& a, const unsigned* s_misc, int& si, unsigned long long t_entry = 0) {
+  if (s_misc[2] && blockIdx.x == 0 && threadIdx.x == 0 && si < 23) {
+    if (t_entry) a.hdr[16 + 46] = (unsigned) t_entry;
     a.hdr[16 + 2 * si]     = (unsigned) __builtin_amdgcn_s_memrealtime();
     a.hdr[16 + 2 * si + 1] = (unsigned) __builtin_amdgcn_s_memtime();
     ++si;
@@ -187,20 +170,6 @@ __device__ __forceinline__ bool gather_slabs(const float* img, float* s_dst, int
   return good;
 }
 
-// four floats of a weight row (zero past n); 16-byte load when the source allows it
-__device__ __forceinline__ float4 load_unit(const float* __restrict__ row, int k, int n, bool vec) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (k + 3 < n && vec) {
-    v = *reinterpret_cast<const float4*>(row + k);
-  } else {
-    if (k < n) v.x = row[k];
-    if (k + 1 < n) v.y = row[k + 1];
-    if (k + 2 < n) v.z = row[k + 2];
-    if (k + 3 < n) v.w = row[k + 3];
-  }
-  return v;
-}
-
 // acc[p][c] += sum_k src[r + 16 p][k] w[c][k] over this lane's float4 columns k = 4 kq, 4 kq + 64, ... < klen (klen a
 // multiple of 64).  The trip count is written as a wave-uniform number (a loop bounded by the per-lane k made hipcc emit
 // exec-masked loops plus an SLP-"vectorised" body full of v_pk_mul / v_mov shuffles: 1770 cycles for 4 steps); the
@@ -225,18 +194,13 @@ __device__ __forceinline__ void dot_step(float (&acc)[PASSES][4], const float* _
       acc[p][c] = t;
     }
 }
-template <int PASSES>
+template <int PASSES, int STEPS>
 __device__ __forceinline__ void dot_rows(float (&acc)[PASSES][4], const float* __restrict__ s_src, int pitch,
-    const float* __restrict__ s_wr, int wpitch, int klen, int r, int kq) {
+    const float* __restrict__ s_wr, int wpitch, int r, int kq) {
   const float* xs = s_src + r * pitch + 4 * kq;
   const float* ws = s_wr + 4 * kq;
-  const int n = __builtin_amdgcn_readfirstlane(klen >> 6);
-  if (n == 4) {  // the hidden width 256: every LDS read of the product can be in flight at once
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dot_step<PASSES>(acc, xs + 64 * i, pitch, ws + 64 * i, wpitch);
-  } else {
-    for (int i = 0; i < n; ++i) dot_step<PASSES>(acc, xs + 64 * i, pitch, ws + 64 * i, wpitch);
-  }
+  for (int i = 0; i < STEPS; ++i) dot_step<PASSES>(acc, xs + 64 * i, pitch, ws + 64 * i, wpitch);
 }
 
 // fill this workgroup's slabs of the image the launch does NOT use with the sentinel
@@ -251,90 +215,112 @@ __device__ __forceinline__ void repoison(float* img_other, int nX, int G, int Bp
 }
 
 // ---------------------------------------------------------------------------------------------------------- forward
-// LDS (floats): s_x0 [Bp][INP] | s_act [Bp][H] | s_out [Bp][NC] | slabs: layer l -> [NC][Kp_l], Kp_l = pad64(in_h) + (in_x ?
+// Shapes fixed at compile time: hidden width H = 256, encoded input padded to INP = 128, at most KL layers.
+constexpr int H = 256, INP = 128, KL = 10;
+
+// LDS (floats): s_x0 [Bp][INP] | s_act [Bp][H] | s_out [Bp][NC] | slabs: layer l -> [NC][Kp_l], Kp_l = (l ? H : 0) + (in_x ?
 //               INP : 0) | bias [n_layers][NC] | misc (launch count, fail, stamps)
 template <int GROUPS, int PASSES>
 __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_forward_kernel(const FusedArgs a) {
   constexpr int NT = 256 * GROUPS, NC = 4 * GROUPS, Bp = 16 * PASSES;
-  constexpr int U = (Bp * 64 + NT - 1) / NT <= 4 ? 4 : 8;  // 16-byte units per thread of one gather at H = 256
+  constexpr int U = (Bp * 64 + NT - 1) / NT <= 4 ? 4 : 8;  // 16-byte units per thread of one gather
+  constexpr int EQ = (Bp * INP + NT - 1) / NT;             // encoded-input entries per thread, worst case
   static_assert((Bp * 64 + NT - 1) / NT <= 8, "gather_slabs covers at most 8 units per thread");
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
   const int tid = threadIdx.x, grp = tid >> 8, lt = tid & 255, kq = lt & 15, r = lt >> 4;
   const int G = gridDim.x, g = blockIdx.x, col0 = g * NC;
-  const int H = a.H, INP = a.INP, B = a.B, nL = a.n_layers, nX = nL - 1;
+  const int B = a.B, nL = a.n_layers, nX = nL - 1, IN = a.IN;
   float* s_x0  = smem;
   float* s_act = s_x0 + Bp * INP;
   float* s_out = s_act + Bp * H;
   float* s_w   = s_out + Bp * NC;
-  int w_total = 0;
-  for (int l = 0; l < nL; ++l) w_total += NC * (pad64(a.layer[l].in_h) + (a.layer[l].in_x ? INP : 0));
-  float* s_bias = s_w + w_total;
   unsigned* s_misc = reinterpret_cast<unsigned*>(smem + a.lds_floats - 4);
+  float* s_bias    = smem + a.lds_floats - 4 - KL * NC;
 
+  // ---- prologue: ONE memory round trip.  Issue order: launch counter, raw encoder inputs, biases, every weight row this
+  // workgroup will ever need (compile-time layer index: the descriptor reads stay scalar kernarg loads); then the sines,
+  // then the LDS stores.
+  unsigned cnt = 0, stamps_on = 0;
   if (tid == 0) {
     const gu32* h = reinterpret_cast<const gu32*>((unsigned long long) a.hdr);
-    s_misc[0] = __hip_atomic_load(h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_misc[1] = 0;
-    s_misc[2] = __hip_atomic_load(h + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    cnt       = __hip_atomic_load(h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stamps_on = __hip_atomic_load(h + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // ---- every weight row this workgroup will ever need, ALL loads in flight before the first LDS store.  The layer
-  // loop is unrolled over the compile-time layer index (descriptor reads stay scalar kernarg loads; a per-thread search
-  // for "which layer does unit u belong to" was a chain of dependent vector loads: ~5 us of prologue).
-  {
-    constexpr int UPT = (NC * (256 + 128) / 4 + NT - 1) / NT;  // 16-byte units per thread and layer, worst case
-    float4 v[MAXL][UPT];
-    int woffs = 0;
+  const int pe = a.p_dim * (1 + 2 * a.p_deg);
+  float xin[EQ];
 #pragma unroll
-    for (int l = 0; l < MAXL; ++l) {
+  for (int q = 0; q < EQ; ++q) {  // entry i = (b, c): the raw coordinate it is a function of
+    const int i = tid + q * NT, b = i / IN, c = i - b * IN;
+    xin[q] = 0.f;
+    if (i < B * IN) xin[q] = c < pe ? a.points[(size_t) b * a.p_dim + (c < a.p_dim ? c : c % a.p_dim)]
+                                    : a.t[(c - pe) < a.t_dim ? (c - pe) : (c - pe) % a.t_dim];
+  }
+  float bv[KL];
+  float4 vh[KL], vx[KL];
+  {
+    const int ch = tid >> 6, kh = 4 * (tid & 63);  // hidden part: NC rows x 64 units = NT units
+    const int cx = tid >> 5, kx = 4 * (tid & 31);  // x0 part: NC rows x 32 units = NT / 2 units
+#pragma unroll
+    for (int l = 0; l < KL; ++l) {
+      bv[l] = 0.f;
+      vh[l] = vx[l] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (l < nL) {
         const FusedLayer L = a.layer[l];
-        const int hp = pad64(L.in_h), Kp = hp + (L.in_x ? INP : 0), K = L.in_h + L.in_x;
-        const bool vec = (K & 3) == 0 && (L.in_h & 3) == 0 && (reinterpret_cast<uintptr_t>(L.W) & 15) == 0;
-#pragma unroll
-        for (int q = 0; q < UPT; ++q) {
-          const int e = 4 * (tid + q * NT);
-          v[l][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (e < NC * Kp) {
-            const int c = e / Kp, k = e - c * Kp;
-            const float* row = L.W + (size_t) (col0 + c) * K;
-            if (col0 + c < L.out) v[l][q] = k < hp ? load_unit(row, k, L.in_h, vec) : load_unit(row + L.in_h, k - hp, L.in_x, vec);
-          }
-        }
+        const int K = L.in_h + L.in_x;
+        if (tid < NC && L.bias && col0 + tid < L.out) bv[l] = L.bias[col0 + tid];
+        if (l > 0 && col0 + ch < L.out) vh[l] = *reinterpret_cast<const float4*>(L.W + (size_t) (col0 + ch) * K + kh);
+        if (L.in_x && tid < NT / 2 && col0 + cx < L.out && kx < L.in_x)
+          vx[l] = *reinterpret_cast<const float4*>(L.W + (size_t) (col0 + cx) * K + L.in_h + kx);
       }
     }
+  }
+  // the encoded input (the loads above are still in flight behind these)
 #pragma unroll
-    for (int l = 0; l < MAXL; ++l) {
+  for (int q = 0; q < EQ; ++q) {
+    const int i = tid + q * NT, b = i / IN, c = i - b * IN;
+    if (i < B * IN) {
+      const int cc = c < pe ? c : c - pe, D = c < pe ? a.p_dim : a.t_dim;
+      float v = xin[q];
+      if (cc >= D) {
+        const int col = cc / D - 1;
+        v = sinf(scalbnf(v, col / 2) + (float) (col % 2) * (3.141592653589793f / 2));
+      }
+      s_x0[b * INP + c] = v;
+    }
+  }
+  for (int i = tid; i < Bp * INP; i += NT) {  // padding (disjoint from the entries above)
+    const int b = i / INP, c = i - b * INP;
+    if (b >= B || c >= IN) s_x0[i] = 0.f;
+  }
+  for (int i = tid; i < Bp * H / 4; i += NT) reinterpret_cast<float4*>(s_act)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const int ch = tid >> 6, kh = 4 * (tid & 63), cx = tid >> 5, kx = 4 * (tid & 31);
+    int woffs = 0;
+#pragma unroll
+    for (int l = 0; l < KL; ++l) {
       if (l < nL) {
-        const int Kp = pad64(a.layer[l].in_h) + (a.layer[l].in_x ? INP : 0);
-#pragma unroll
-        for (int q = 0; q < UPT; ++q) {
-          const int e = 4 * (tid + q * NT);
-          if (e < NC * Kp) *reinterpret_cast<float4*>(s_w + woffs + e) = v[l][q];
-        }
+        const int hp = l ? H : 0, Kp = hp + (a.layer[l].in_x ? INP : 0);
+        if (tid < NC) s_bias[l * NC + tid] = bv[l];
+        if (l > 0) *reinterpret_cast<float4*>(s_w + woffs + ch * Kp + kh) = vh[l];
+        if (a.layer[l].in_x && tid < NT / 2) *reinterpret_cast<float4*>(s_w + woffs + cx * Kp + hp + kx) = vx[l];
         woffs += NC * Kp;
       }
     }
-    for (int i = tid; i < nL * NC; i += NT) {
-      const int l = i / NC, c = i - l * NC;
-      s_bias[i] = (a.layer[l].bias && col0 + c < a.layer[l].out) ? a.layer[l].bias[col0 + c] : 0.f;
-    }
   }
-  encode_inputs<NT>(a, s_x0, Bp);
-  for (int i = tid; i < Bp * H / 4; i += NT) reinterpret_cast<float4*>(s_act)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid == 0) s_misc[0] = cnt, s_misc[1] = 0, s_misc[2] = stamps_on;
   __syncthreads();
   const unsigned count = s_misc[0];
   const size_t img_floats = (size_t) nX * G * Bp * NC;
   float* img = a.exch + (count & 1u) * img_floats;
   repoison<NT, NC>(a.exch + ((count & 1u) ^ 1u) * img_floats, nX, G, Bp);
   int si = 0;
-  stamp(a, s_misc, si);
-  if (a.x0 && g == 0)
-    for (int i = tid; i < B * a.IN; i += NT) a.x0[i] = s_x0[(i / a.IN) * INP + (i % a.IN)];
+  stamp(a, s_misc, si, t_entry);
 
   int woff = 0;
   for (int l = 0; l < nL; ++l) {
     const FusedLayer L = a.layer[l];
-    const int hp = pad64(L.in_h), Kp = hp + (L.in_x ? INP : 0);
+    const int hp = l ? H : 0, Kp = hp + (L.in_x ? INP : 0);
     const bool last = l == nL - 1;
     if (l > 0) {
       const bool ok = gather_slabs<NT, NC, U>(img + (size_t) (l - 1) * G * Bp * NC, s_act, B, Bp, H, B * H / 4);
@@ -350,8 +336,8 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_forward_kernel(const F
     for (int p = 0; p < PASSES; ++p)
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[p][c] = 0.f;
-    dot_rows<PASSES>(acc, s_act, H, wl, Kp, hp, r, kq);
-    if (L.in_x) dot_rows<PASSES>(acc, s_x0, INP, wl + hp, Kp, INP, r, kq);
+    if (l > 0) dot_rows<PASSES, 4>(acc, s_act, H, wl, Kp, r, kq);
+    if (L.in_x) dot_rows<PASSES, 2>(acc, s_x0, INP, wl + hp, Kp, r, kq);
     const float4 bz = *reinterpret_cast<const float4*>(s_bias + l * NC + 4 * grp);
 #pragma unroll
     for (int p = 0; p < PASSES; ++p)
@@ -386,6 +372,9 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_forward_kernel(const F
     woff += NC * Kp;
     stamp(a, s_misc, si);
   }
+  // the optional copy of the encoded input leaves from the last workgroup, after its part of the chain
+  if (a.x0 && g == G - 1)
+    for (int i = tid; i < B * IN; i += NT) a.x0[i] = s_x0[(i / IN) * INP + (i % IN)];
   if (g == 0 && tid == 0) {
     gu32* h = reinterpret_cast<gu32*>((unsigned long long) a.hdr);
     if (s_misc[1]) __hip_atomic_fetch_add(h + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -394,9 +383,10 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_forward_kernel(const F
 }
 
 // --------------------------------------------------------------------------------------------------------- backward
-// LDS (floats): s_x0 [Bp][INP] | s_gz [Bp][H] | s_own [Bp][NC] | s_out [Bp][NC] | transposed slabs: layer l >= 1 -> T_l [NC]
-//               [pad64(out_l)] = W_l[o][col0 + c]; with g_x0 and col0 < IN also X_l [NC][pad64(out_l)] = W_l[o][in_h + col0 + c]
-//               for every layer with in_x > 0 | misc
+// LDS (floats): s_gz [Bp][H] (later reused for the encoded input) | s_own [n_layers][Bp][NC] (this workgroup's slab of every gZ_l, kept for the
+//               weight gradients) | s_out [Bp][NC] | transposed slabs: layer l >= 1 -> T_l [NC][pad64(out_l)] = W_l[o][col0 +
+//               c]; with g_x0 and col0 < IN also X_l [NC][pad64(out_l)] = W_l[o][in_h + col0 + c] for every layer with
+//               in_x > 0 | misc
 template <int GROUPS, int PASSES>
 __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const FusedArgs a) {
   constexpr int NT = 256 * GROUPS, NC = 4 * GROUPS, Bp = 16 * PASSES;
@@ -405,12 +395,12 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, grp = tid >> 8, lt = tid & 255, kq = lt & 15, r = lt >> 4;
   const int G = gridDim.x, g = blockIdx.x, col0 = g * NC;
-  const int H = a.H, INP = a.INP, B = a.B, nL = a.n_layers, IN = a.IN, nX = nL - 1;
+  const int B = a.B, nL = a.n_layers, IN = a.IN, nX = nL - 1;
   const bool want_gx = a.g_x0 != nullptr && col0 < IN;
-  float* s_x0  = smem;
-  float* s_gz  = s_x0 + Bp * INP;
+  float* s_gz  = smem;
+  float* s_x0  = s_gz;  // the encoded input is only needed by the weight gradients: built after the chain, over s_gz
   float* s_own = s_gz + Bp * H;
-  float* s_out = s_own + Bp * NC;
+  float* s_out = s_own + nL * Bp * NC;
   float* s_wT  = s_out + Bp * NC;
   int t_total = 0;  // floats of the T slabs; the X slabs follow
   for (int l = 1; l < nL; ++l) t_total += NC * pad64(a.layer[l].out);
@@ -420,53 +410,50 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const 
       if (a.layer[l].in_x) x_total += NC * pad64(a.layer[l].out);
   unsigned* s_misc = reinterpret_cast<unsigned*>(smem + a.lds_floats - 4);
 
+  // ---- prologue: one memory round trip (see the forward kernel)
+  unsigned cnt = 0, stamps_on = 0;
   if (tid == 0) {
     const gu32* h = reinterpret_cast<const gu32*>((unsigned long long) a.hdr);
-    s_misc[0] = __hip_atomic_load(h + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_misc[1] = 0;
-    s_misc[2] = __hip_atomic_load(h + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    cnt       = __hip_atomic_load(h + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stamps_on = __hip_atomic_load(h + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // ---- transposed weight slabs: unit = (slab, o, group of four columns): four consecutive floats of one weight row.
-  // Same shape as the forward prologue: compile-time layer index, every load in flight before the first LDS store.
+  // the ReLU masks of this workgroup's slab, one 16-byte unit per thread and layer (threads < Bp GROUPS)
+  const int mrow = tid / GROUPS, mpart = tid - mrow * GROUPS;
+  const bool mlive = tid < Bp * GROUPS && mrow < B;
+  float4 am[KL], vt[KL], vx[KL];
   {
-    constexpr int UPT = (256 * GROUPS + NT - 1) / NT;  // = 1: one unit per thread and slab
-    float4 vt[MAXL][UPT], vx[MAXL][UPT];
+    const int o = tid / GROUPS, c4 = 4 * (tid - o * GROUPS);  // (weight row, group of four columns): NT = 256 GROUPS units
 #pragma unroll
-    for (int l = 0; l < MAXL; ++l) {
+    for (int l = 0; l < KL; ++l) {
+      am[l] = make_float4(1.f, 1.f, 1.f, 1.f);
+      vt[l] = vx[l] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (l < nL) {
         const FusedLayer L = a.layer[l];
-        const int op = pad64(L.out), K = L.in_h + L.in_x;
-        const bool vecw = (K & 3) == 0 && (reinterpret_cast<uintptr_t>(L.W) & 15) == 0;
-#pragma unroll
-        for (int q = 0; q < UPT; ++q) {
-          const int u = tid + q * NT, o = u / GROUPS, c4 = 4 * (u - o * GROUPS);
-          vt[l][q] = vx[l][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (o < op && o < L.out) {
-            if (l >= 1)  // T_l: W_l[o][col0 + c4 ..], inside the hidden segment
-              vt[l][q] = load_unit(L.W + (size_t) o * K, col0 + c4, L.in_h, vecw && ((col0 + c4) & 3) == 0);
-            if (want_gx && L.in_x)  // X_l: W_l[o][in_h + col0 + c4 ..], inside the x0 segment
-              vx[l][q] = load_unit(L.W + (size_t) o * K + L.in_h, col0 + c4, L.in_x, vecw && ((L.in_h + col0 + c4) & 3) == 0);
-          }
+        const int K = L.in_h + L.in_x;
+        if (l < nL - 1 && L.relu && mlive)
+          am[l] = *reinterpret_cast<const float4*>(a.acts + ((size_t) l * B + mrow) * H + col0 + 4 * mpart);
+        if (o < L.out) {
+          if (l >= 1) vt[l] = *reinterpret_cast<const float4*>(L.W + (size_t) o * K + col0 + c4);
+          if (want_gx && L.in_x && col0 + c4 < L.in_x) vx[l] = *reinterpret_cast<const float4*>(L.W + (size_t) o * K + L.in_h + col0 + c4);
         }
       }
     }
+  }
+  {
+    const int o = tid / GROUPS, c4 = 4 * (tid - o * GROUPS);
     int toff = 0, xoff = t_total;
 #pragma unroll
-    for (int l = 0; l < MAXL; ++l) {
+    for (int l = 0; l < KL; ++l) {
       if (l < nL) {
         const int op = pad64(a.layer[l].out);
-#pragma unroll
-        for (int q = 0; q < UPT; ++q) {
-          const int u = tid + q * NT, o = u / GROUPS, c4 = 4 * (u - o * GROUPS);
-          if (o < op) {
-            if (l >= 1) {
-              float* d = s_wT + toff + c4 * op + o;
-              d[0] = vt[l][q].x, d[op] = vt[l][q].y, d[2 * op] = vt[l][q].z, d[3 * op] = vt[l][q].w;
-            }
-            if (want_gx && a.layer[l].in_x) {
-              float* d = s_wT + xoff + c4 * op + o;
-              d[0] = vx[l][q].x, d[op] = vx[l][q].y, d[2 * op] = vx[l][q].z, d[3 * op] = vx[l][q].w;
-            }
+        if (o < op) {
+          if (l >= 1) {
+            float* d = s_wT + toff + c4 * op + o;
+            d[0] = vt[l].x, d[op] = vt[l].y, d[2 * op] = vt[l].z, d[3 * op] = vt[l].w;
+          }
+          if (want_gx && a.layer[l].in_x) {
+            float* d = s_wT + xoff + c4 * op + o;
+            d[0] = vx[l].x, d[op] = vx[l].y, d[2 * op] = vx[l].z, d[3 * op] = vx[l].w;
           }
         }
         if (l >= 1) toff += NC * op;
@@ -474,19 +461,19 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const 
       }
     }
   }
-  encode_inputs<NT>(a, s_x0, Bp);
-  {  // gZ of the last layer = the incoming gradient (zero-padded); this workgroup's slab of it
+  {  // gZ of the last layer = the incoming gradient (zero-padded to 64 columns); this workgroup's slab of it
     const int oL = a.layer[nL - 1].out;
-    for (int i = tid; i < Bp * H; i += NT) {
-      const int b = i / H, c = i - b * H;
-      s_gz[i] = (b < B && c < oL) ? *head_elem(a, const_cast<float* const*>(a.head_gout), const_cast<float*>(a.g_out), b, c, oL) : 0.f;
+    for (int i = tid; i < Bp * 64; i += NT) {
+      const int b = i >> 6, c = i & 63;
+      s_gz[b * H + c] = (b < B && c < oL) ? *head_elem(a, const_cast<float* const*>(a.head_gout), const_cast<float*>(a.g_out), b, c, oL) : 0.f;
     }
     for (int i = tid; i < Bp * NC; i += NT) {
       const int b = i / NC, c = i - b * NC;
-      s_own[i] = (b < B && col0 + c < oL)
-                     ? *head_elem(a, const_cast<float* const*>(a.head_gout), const_cast<float*>(a.g_out), b, col0 + c, oL) : 0.f;
+      s_own[(nL - 1) * Bp * NC + i] =
+          (b < B && col0 + c < oL) ? *head_elem(a, const_cast<float* const*>(a.head_gout), const_cast<float*>(a.g_out), b, col0 + c, oL) : 0.f;
     }
   }
+  if (tid == 0) s_misc[0] = cnt, s_misc[1] = 0, s_misc[2] = stamps_on;
   __syncthreads();
   const unsigned count = s_misc[0];
   const size_t img_floats = (size_t) nX * G * Bp * NC;
@@ -499,16 +486,16 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const 
 #pragma unroll
     for (int c = 0; c < 4; ++c) gx0[p][c] = 0.f;
 
-  // the slabs were laid out by increasing layer: walk their offsets backwards with the layer loop
+  // ---- (A) the dependent chain: gA_{l-1}[:, slab] = gZ_l W_l[:, slab], masked by the ReLU of layer l-1.  The slabs were
+  // laid out by increasing layer: walk their offsets backwards.
   int tcur = t_total, xcur = t_total + x_total;
-
-  for (int l = nL - 1; l >= 0; --l) {
-    const FusedLayer L = a.layer[l];
-    const int op = pad64(L.out), K = L.in_h + L.in_x;
-    const bool own_rows = col0 < L.out;  // this workgroup owns rows of gW_l
-    const bool publish  = l >= 1 && (l - 1 >= 1 || a.g_x0 != nullptr);  // gZ_0 is only exchanged for the input gradient
-    // ---- (A) the dependent chain: gA_{l-1}[:, slab] = gZ_l W_l[:, slab], masked by the ReLU of layer l-1
-    if (l >= 1) {
+#pragma unroll
+  for (int lu = KL - 1; lu >= 1; --lu) {  // compile-time index: am[] stays in registers
+    if (lu < nL) {
+      const int l = lu;
+      const FusedLayer L = a.layer[l];
+      const int op = pad64(L.out);
+      const bool publish = l - 1 >= 1 || a.g_x0 != nullptr;  // gZ_0 is only exchanged for the input gradient
       const bool do_x = want_gx && L.in_x;
       tcur -= NC * op;
       if (do_x) xcur -= NC * op;
@@ -517,14 +504,16 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const 
       for (int p = 0; p < PASSES; ++p)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[p][c] = 0.f;
-      dot_rows<PASSES>(acc, s_gz, H, s_wT + tcur + 4 * grp * op, op, op, r, kq);
+      if (op == H) dot_rows<PASSES, 4>(acc, s_gz, H, s_wT + tcur + 4 * grp * op, op, r, kq);
+      else dot_rows<PASSES, 1>(acc, s_gz, H, s_wT + tcur + 4 * grp * op, op, r, kq);
       if (do_x) {
         float accx[PASSES][4];
 #pragma unroll
         for (int p = 0; p < PASSES; ++p)
 #pragma unroll
           for (int c = 0; c < 4; ++c) accx[p][c] = 0.f;
-        dot_rows<PASSES>(accx, s_gz, H, s_wT + xcur + 4 * grp * op, op, op, r, kq);
+        if (op == H) dot_rows<PASSES, 4>(accx, s_gz, H, s_wT + xcur + 4 * grp * op, op, r, kq);
+        else dot_rows<PASSES, 1>(accx, s_gz, H, s_wT + xcur + 4 * grp * op, op, r, kq);
 #pragma unroll
         for (int p = 0; p < PASSES; ++p)
 #pragma unroll
@@ -539,72 +528,31 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const 
         for (int p = 0; p < PASSES; ++p)
           *reinterpret_cast<float4*>(s_out + (r + 16 * p) * NC + 4 * grp) = make_float4(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
       }
-    }
-    __syncthreads();  // s_out complete
-    float4 newown = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (l >= 1 && tid < Bp * GROUPS) {
-      const int row = tid / GROUPS, part = tid - row * GROUPS;
-      float4 y = *reinterpret_cast<const float4*>(s_out + 4 * tid);
-      if (row < B) {
-        if (a.layer[l - 1].relu) {  // the pre-activation sign, from the saved activation
-          const float4 am = *reinterpret_cast<const float4*>(a.acts + ((size_t) (l - 1) * B + row) * H + col0 + 4 * part);
-          y.x = am.x > 0.f ? y.x : 0.f, y.y = am.y > 0.f ? y.y : 0.f, y.z = am.z > 0.f ? y.z : 0.f, y.w = am.w > 0.f ? y.w : 0.f;
-        }
-        y.x = not_sentinel(y.x), y.y = not_sentinel(y.y), y.z = not_sentinel(y.z), y.w = not_sentinel(y.w);
-        if (publish) store16_sc1(img + ((size_t) (l - 1) * G + g) * Bp * NC + 4 * tid, y);
-        newown = y;
+      __syncthreads();  // s_out complete; s_gz has been read
+      if (tid < Bp * GROUPS) {
+        float4 y = *reinterpret_cast<const float4*>(s_out + 4 * tid);
+        const float4 m = am[lu - 1];
+        y.x = (mlive && m.x > 0.f) ? not_sentinel(y.x) : 0.f, y.y = (mlive && m.y > 0.f) ? not_sentinel(y.y) : 0.f;
+        y.z = (mlive && m.z > 0.f) ? not_sentinel(y.z) : 0.f, y.w = (mlive && m.w > 0.f) ? not_sentinel(y.w) : 0.f;
+        if (publish && mlive) store16_sc1(img + ((size_t) (l - 1) * G + g) * Bp * NC + 4 * tid, y);
+        *reinterpret_cast<float4*>(s_own + (l - 1) * Bp * NC + 4 * tid) = y;  // kept for the weight gradients
       }
-    }
-    // ---- (B) off the chain: weight / bias gradients of this workgroup's rows of layer l (from s_own = gZ_l[:, slab])
-    if (own_rows) {
-      const int kw = L.in_h + L.in_x;  // columns of gW_l: thread <-> (column, group of four rows)
-      for (int i = tid; i < kw * GROUPS; i += NT) {
-        const int k = i % kw, q = i / kw;
-        float gacc[4] = {0.f, 0.f, 0.f, 0.f};
-        if (k < L.in_h) {
-          const float* ap = a.acts + (size_t) (l - 1) * B * H + k;
-#pragma unroll 4
-          for (int b = 0; b < B; ++b) {
-            const float av = ap[(size_t) b * H];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) gacc[c] += s_own[b * NC + 4 * q + c] * av;
-          }
-        } else {
-          for (int b = 0; b < B; ++b) {
-            const float av = s_x0[b * INP + (k - L.in_h)];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) gacc[c] += s_own[b * NC + 4 * q + c] * av;
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (col0 + 4 * q + c < L.out) L.gW[(size_t) (col0 + 4 * q + c) * K + k] = gacc[c];
+      if (publish) {
+        const bool ok = gather_slabs<NT, NC, U>(img + (size_t) (l - 1) * G * Bp * NC, s_gz, B, Bp, H, B * H / 4);
+        if (!ok) s_misc[1] = 1;
       }
-      if (L.gb && tid < NC && col0 + tid < L.out) {
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) s += s_own[b * NC + tid];
-        L.gb[col0 + tid] = s;
-      }
+      __syncthreads();
+      if (s_misc[1]) break;
     }
-    if (l == 0) break;
-    __syncthreads();  // s_own and s_gz have been read
-    if (tid < Bp * GROUPS) *reinterpret_cast<float4*>(s_own + 4 * tid) = newown;
-    if (publish) {
-      const bool ok = gather_slabs<NT, NC, U>(img + (size_t) (l - 1) * G * Bp * NC, s_gz, B, Bp, H, B * H / 4);
-      if (!ok) s_misc[1] = 1;
-    }
-    __syncthreads();
-    if (s_misc[1]) break;
   }
   // ---- input gradient: the layers that read x0 (layer 0 included) contribute gZ_l W_l[:, x0 part]
   if (want_gx && !s_misc[1]) {
-    const int op = pad64(a.layer[0].out);
     float accx[PASSES][4];
 #pragma unroll
     for (int p = 0; p < PASSES; ++p)
 #pragma unroll
       for (int c = 0; c < 4; ++c) accx[p][c] = 0.f;
-    dot_rows<PASSES>(accx, s_gz, H, s_wT + t_total + 4 * grp * op, op, op, r, kq);  // X_0 is the first of the x0 slabs
+    dot_rows<PASSES, 4>(accx, s_gz, H, s_wT + t_total + 4 * grp * H, H, r, kq);  // X_0 is the first of the x0 slabs
 #pragma unroll
     for (int p = 0; p < PASSES; ++p)
 #pragma unroll
@@ -616,6 +564,61 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const 
 #pragma unroll
         for (int c = 0; c < 4; ++c)
           if (row < B && col0 + 4 * grp + c < IN) a.g_x0[(size_t) row * IN + col0 + 4 * grp + c] = gx0[p][c] + accx[p][c];
+      }
+    }
+  }
+  // ---- (B) off the chain, after it: weight / bias gradients of this workgroup's rows of every layer, from the kept
+  // slabs gZ_l[:, slab] and the saved activations.  Nothing waits on this any more; all layers' loads overlap.
+  if (!s_misc[1]) {
+    __syncthreads();  // the last readers of s_gz are done: it becomes the encoded input
+    {
+      const int pe = a.p_dim * (1 + 2 * a.p_deg);
+      for (int i = tid; i < Bp * INP; i += NT) {
+        const int b = i / INP, c = i - b * INP;
+        float v = 0.f;
+        if (b < B && c < IN) {
+          const int cc = c < pe ? c : c - pe, D = c < pe ? a.p_dim : a.t_dim;
+          v = c < pe ? a.points[(size_t) b * a.p_dim + cc % D] : a.t[cc % D];
+          if (cc >= D) {
+            const int col = cc / D - 1;
+            v = sinf(scalbnf(v, col / 2) + (float) (col % 2) * (3.141592653589793f / 2));
+          }
+        }
+        s_x0[i] = v;
+      }
+    }
+    __syncthreads();
+    for (int l = nL - 1; l >= 0; --l) {
+      const FusedLayer L = a.layer[l];
+      if (col0 >= L.out) continue;
+      const int K = L.in_h + L.in_x;
+      const float* own = s_own + l * Bp * NC;
+      for (int i = tid; i < K * GROUPS; i += NT) {  // thread <-> (column of gW_l, group of four rows)
+        const int k = i % K, q = i / K;
+        float gacc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (k < L.in_h) {
+          const float* ap = a.acts + (size_t) (l - 1) * B * H + k;
+#pragma unroll 4
+          for (int b = 0; b < B; ++b) {
+            const float av = ap[(size_t) b * H];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gacc[c] += own[b * NC + 4 * q + c] * av;
+          }
+        } else {
+          for (int b = 0; b < B; ++b) {
+            const float av = s_x0[b * INP + (k - L.in_h)];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gacc[c] += own[b * NC + 4 * q + c] * av;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (col0 + 4 * q + c < L.out) L.gW[(size_t) (col0 + 4 * q + c) * K + k] = gacc[c];
+      }
+      if (L.gb && tid < NC && col0 + tid < L.out) {
+        float sum = 0.f;
+        for (int b = 0; b < B; ++b) sum += own[b * NC + tid];
+        L.gb[col0 + tid] = sum;
       }
     }
   }
@@ -637,15 +640,15 @@ struct Plan {
 int make_plan(const skgs_mlp_desc* d, Plan* p) {
   SKGS_REQUIRE(d, "deform_mlp: NULL descriptor");
   SKGS_REQUIRE(d->B >= 1 && d->B <= 48, "deform_mlp: the fused kernels handle 1..48 rows (B = %d): use the per-layer path", d->B);
-  SKGS_REQUIRE(d->hidden >= 64 && d->hidden <= 256 && d->hidden % 64 == 0, "deform_mlp: hidden width must be 64, 128, 192 or 256");
-  SKGS_REQUIRE(d->n_layers >= 2 && d->n_layers <= MAXL, "deform_mlp: 2..%d layers (heads included)", MAXL);
+  SKGS_REQUIRE(d->hidden == H, "deform_mlp: the fused kernels are built for hidden width %d (got %d): use the per-layer path", H, d->hidden);
+  SKGS_REQUIRE(d->n_layers >= 2 && d->n_layers <= KL, "deform_mlp: 2..%d layers (heads included)", KL);
   SKGS_REQUIRE(d->p_dim >= 1 && d->t_dim >= 0 && d->p_degree >= 0 && d->t_degree >= 0, "deform_mlp: bad encoder sizes");
   p->IN  = d->p_dim * (1 + 2 * d->p_degree) + d->t_dim * (1 + 2 * d->t_degree);
   p->INP = (p->IN + 63) & ~63;
-  SKGS_REQUIRE(p->IN <= 128, "deform_mlp: encoded input wider than 128 (%d)", p->IN);
+  SKGS_REQUIRE(p->IN <= INP && p->IN % 4 == 0, "deform_mlp: encoded input must be a multiple of 4 and <= %d wide (%d)", INP, p->IN);
   for (int l = 0; l < d->n_layers; ++l) {
     const skgs_mlp_layer& L = d->layer[l];
-    SKGS_REQUIRE(L.W, "deform_mlp: layer %d has no weights", l);
+    SKGS_REQUIRE(L.W && (reinterpret_cast<uintptr_t>(L.W) & 15) == 0, "deform_mlp: layer %d: weights missing or not 16-byte aligned", l);
     SKGS_REQUIRE(L.in_hidden == (l == 0 ? 0 : d->hidden), "deform_mlp: layer %d: in_hidden must be %d", l, l == 0 ? 0 : d->hidden);
     SKGS_REQUIRE(L.in_x0 == 0 || L.in_x0 == p->IN, "deform_mlp: layer %d: in_x0 must be 0 or the encoded width %d", l, p->IN);
     SKGS_REQUIRE(l > 0 || L.in_x0 == p->IN, "deform_mlp: the first layer reads the encoded input");
@@ -741,9 +744,8 @@ int skgs_deform_mlp_forward(const skgs_mlp_desc* d, const float* points, const f
   a.points = points, a.t = t, a.x0 = x0, a.acts = acts, a.out = out;
   a.hdr  = reinterpret_cast<unsigned*>(workspace);
   a.exch = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + HDR_BYTES);
-  size_t fl = (size_t) p.Bp * p.INP + (size_t) p.Bp * d->hidden + (size_t) p.Bp * p.NC + (size_t) d->n_layers * p.NC + 4;
-  for (int l = 0; l < d->n_layers; ++l)
-    fl += (size_t) p.NC * (((d->layer[l].in_hidden + 63) & ~63) + (d->layer[l].in_x0 ? p.INP : 0));
+  size_t fl = (size_t) p.Bp * INP + (size_t) p.Bp * H + (size_t) p.Bp * p.NC + (size_t) KL * p.NC + 4;
+  for (int l = 0; l < d->n_layers; ++l) fl += (size_t) p.NC * ((l ? H : 0) + (d->layer[l].in_x0 ? INP : 0));
   a.lds_floats = (int) fl;
   const size_t lds = fl * 4;
   SKGS_REQUIRE(lds <= 160 * 1024, "deform_mlp_forward: %zu bytes of LDS needed", lds);
@@ -768,7 +770,7 @@ int skgs_deform_mlp_backward(const skgs_mlp_desc* d, const float* points, const 
   a.points = points, a.t = t, a.acts = const_cast<float*>(acts), a.g_out = g_out, a.g_x0 = g_x0;
   a.hdr  = reinterpret_cast<unsigned*>(workspace);
   a.exch = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + HDR_BYTES + p.exch_bytes);
-  size_t fl = (size_t) p.Bp * p.INP + (size_t) p.Bp * d->hidden + (size_t) 2 * p.Bp * p.NC + 4;
+  size_t fl = (size_t) p.Bp * H + (size_t) (d->n_layers + 1) * p.Bp * p.NC + 4;
   for (int l = 1; l < d->n_layers; ++l) fl += (size_t) p.NC * ((d->layer[l].out + 63) & ~63);
   if (g_x0)
     for (int l = 0; l < d->n_layers; ++l)

@@ -202,11 +202,11 @@ class _MlpDesc(C.Structure):
 
 
 def fused_supported(mlp: 'DeformMLP', B: int) -> bool:
-    """the one-launch kernels cover the skeleton stage's shapes: <= 48 rows, hidden width 64..256 in steps of 64, encoded
-    input <= 128 wide (skgs.h: skgs_deform_mlp_forward)"""
+    """the one-launch kernels are built for the skeleton stage's shapes: <= 48 rows, hidden width 256, encoded input a
+    multiple of 4 and <= 128 wide, <= 10 layers with the heads (skgs.h: skgs_deform_mlp_forward)"""
     net = mlp.dynamic_net
-    return (1 <= B <= 48 and net.dim_hidden % 64 == 0 and 64 <= net.dim_hidden <= 256 and net.in_channels <= 128
-            and net.num_layers + 1 <= MLP_MAX_LAYERS and sum(net.out_channels) <= net.dim_hidden)
+    return (1 <= B <= 48 and net.dim_hidden == 256 and net.in_channels <= 128 and net.in_channels % 4 == 0
+            and net.num_layers + 1 <= 10 and sum(net.out_channels) <= net.dim_hidden)
 
 
 class FusedDeformMLP:

@@ -180,11 +180,15 @@ def test_fused_deform_mlp_matches_torch(ncol):  # noqa: C901
 
 
 def test_fused_deform_mlp_other_shapes():
-    """hidden widths 64 / 128, one skip right before the heads, no skip, wider encoded input"""
+    """no skip, two skips, a skip right before the heads with another encoder; shapes outside the fused kernels' range
+    are reported as unsupported (the per-layer path takes them)"""
     from sk_gs_amd.deform_net import DeformMLP, FusedDeformMLP
     torch.manual_seed(1)
-    for kw in (dict(width=64, depth=3, skips=()), dict(width=128, depth=4, skips=(1, 3)),
-               dict(width=256, depth=2, skips=(1,), p_in_channels=5, p_degree=6, t_degree=3)):
+    from sk_gs_amd.deform_net import fused_supported
+    assert not fused_supported(DeformMLP(width=128), 20) and not fused_supported(DeformMLP(), 49)
+    assert not fused_supported(DeformMLP(p_in_channels=4), 20)  # encoded width 97: not a multiple of 4
+    for kw in (dict(depth=3, skips=()), dict(depth=4, skips=(1, 3)),
+               dict(depth=2, skips=(1,), p_in_channels=5, p_degree=6, t_degree=3)):
         mlp = DeformMLP(**kw).cuda()
         B = 24
         joints = torch.rand(B, mlp.p_in, device='cuda') - 0.5
