@@ -153,6 +153,9 @@ def main():
                          'networks/sk_gs.py:1080-1085) instead of running the 8x256 deform network inside every step.  The '
                          'reference runs the network in every TRAINING step (sk_gs.py:1073-1074): that is the default here')
     ap.add_argument('--deform-net', dest='deform_net', action='store_true', help='(default) the deform network inside the step')
+    ap.add_argument('--graph-per-view', action='store_true',
+                    help='capture one hipGraph per view (camera, time and target baked into each) instead of ONE graph that '
+                         'reads them from a device-resident view slot')
     ap.add_argument('--layered-mlp', action='store_true',
                     help='run the deform network as one launch per layer (csrc/mlp.hip) instead of the one-launch-per-direction '
                          'kernels (csrc/mlp_fused.hip)')
@@ -201,6 +204,12 @@ def main():
         for v in range(args.views):
             img = model.render(settings[v], time_id=v % frames, background=background)['images']
             targets.append((img + 0.05 * torch.randn(3, H, W, generator=gen).to(dev)).clamp(0, 1).contiguous())
+    # every per-view input of the step as a device load: one captured graph serves all views (sk_gs_amd/view_slot.py)
+    view_table = None
+    if args.deform_net and M > 0 and not args.autograd and not args.graph_per_view:
+        from sk_gs_amd.view_slot import ViewTable
+        view_table = ViewTable(settings, [float(model.frame_times[v % frames]) for v in range(args.views)],
+                               [v % frames for v in range(args.views)], torch.stack(targets), dev)
     fused_dist = use_dist and not args.autograd and not args.torch_adam
     pipelined = fused_dist and args.pipeline
     compact = fused_dist and (pipelined or not args.dense_spw_grad)
@@ -251,12 +260,29 @@ def main():
 
     overflow = torch.zeros(1, dtype=torch.int32, device=dev)
     from sk_gs_amd.train_step import GraphedSteps
+
+    # per-view arguments of the step calls: none when the view is read from the device-resident slot
+    def fb_args(v):
+        return () if view_table is not None else (settings[v], v % frames, targets[v])
+
+    def sk_args(v):
+        return () if view_table is not None else (v % frames,)
+
+    def select(v):  # slot mode: one 256-byte device-to-device copy before the launches / the replay
+        if view_table is not None:
+            view_table.select(v)
+
+    def gkey(v):  # graphs are keyed by view only when the view is baked into them
+        return 0 if view_table is not None else v
+
+    capture_views = [0] if view_table is not None else list(range(args.views))
     if not args.autograd:
         from sk_gs_amd.fused_step import FusedViewStep
         fstep = FusedViewStep(model, W, H, capacity=int(R_max * 1.25 * _C.config.capacity_growth) + 1024,
                               background=background, grad_scale=1.0 / world,
                               spw_logit_grad=vp.extra_views[-1] if compact else None, tile_bucket=tile_bucket,
-                              sh_factors=fac_local if sh_factored else None, fused_deform_net=not args.layered_mlp)
+                              sh_factors=fac_local if sh_factored else None, fused_deform_net=not args.layered_mlp,
+                              view_table=view_table)
         # the per-frame table gradients (one row written per step) are cleared by the Adam launch itself
         table_span = None if args.torch_adam else fstep.table_grad_span()
         fstep.tables_zeroed_by_optimizer = table_span is not None
@@ -271,10 +297,10 @@ def main():
                          zero_after_step=table_span)
 
         def part_a(v):
-            fstep.backward_raster(settings[v], v % frames, targets[v])
+            fstep.backward_raster(*fb_args(v))
 
         def part_b(v):
-            fstep.backward_skinning(v % frames)
+            fstep.backward_skinning(*sk_args(v))
 
         def part_c2(_):
             fstep.scatter_spw_grad()
@@ -283,11 +309,12 @@ def main():
         gA, gB = GraphedSteps(part_a), GraphedSteps(part_b)
         gC1, gC2 = GraphedSteps(lambda _: optA.step()), GraphedSteps(part_c2)
 
-        def run_step(i, fa, fb, fc1, fc2):
+        def run_step(i, fa, fb, fc1, fc2, key=lambda v: v):
             v = vp.view_index(i, args.views)
-            fa(v)
+            select(v)
+            fa(key(v))
             w0 = vp.allreduce(0)
-            fb(v)
+            fb(key(v))
             w1 = vp.allreduce(1)
             w0.wait()
             fc1(0)
@@ -298,12 +325,13 @@ def main():
             run_step(i, part_a, part_b, lambda _: optA.step(), part_c2)
 
         def graph_step(i):
-            run_step(i, gA, gB, gC1, gC2)
+            run_step(i, gA, gB, gC1, gC2, key=gkey)
 
         def capture_all():
-            for v in range(args.views):
-                gA.capture(v)
-                gB.capture(v)
+            for v in capture_views:
+                select(v)
+                gA.capture(gkey(v))
+                gB.capture(gkey(v))
             # the optimizer graphs' capture warm-up applies real updates: on reduced gradients only (see below)
             for w in (vp.allreduce(0), vp.allreduce(1)):
                 if w is not None:
@@ -325,7 +353,7 @@ def main():
                 overflow.add_(out['buffer'].geomBuffer[4:8].view(torch.int32))
         else:
             def fwd_bwd(v):  # every gradient is overwritten in place: no zero fill of the flat buffer
-                fstep.forward_backward(settings[v], v % frames, targets[v])
+                fstep.forward_backward(*fb_args(v))
         prescaled = not args.autograd  # FusedViewStep seeds the backward with 1/world
 
         def reduce_grads():
@@ -346,7 +374,9 @@ def main():
             opt.step()
 
         def eager_step(i):
-            fwd_bwd(vp.view_index(i, args.views))
+            v = vp.view_index(i, args.views)
+            select(v)
+            fwd_bwd(v)
             reduce_grads()
             update()
 
@@ -354,30 +384,32 @@ def main():
         if overlap_gather:
             # graph(forward, loss, rasterizer backward) | all-gather of the factors beside graph(skinning backward) |
             # all-reduce of the rest | graph(SH rows, logit scatter, Adam)
-            def split_step(v, fa, fb, fc):
-                fa(v)
+            def split_step(v, fa, fb, fc, key=lambda v: v):
+                select(v)
+                fa(key(v))
                 wg = sh_ex.gather(async_op=True)
-                fb(v)
+                fb(key(v))
                 w = vp.allreduce(0, async_op=True)
                 for h in (wg, w):
                     if h is not None:
                         h.wait()
                 fc(0)
 
-            part_a = lambda v: fstep.backward_raster(settings[v], v % frames, targets[v])  # noqa: E731
-            part_b = lambda v: fstep.backward_skinning(v % frames)                          # noqa: E731
+            part_a = lambda v: fstep.backward_raster(*fb_args(v))   # noqa: E731
+            part_b = lambda v: fstep.backward_skinning(*sk_args(v))  # noqa: E731
             gA, gB, gC = GraphedSteps(part_a), GraphedSteps(part_b), GraphedSteps(update)
 
             def eager_step(i):  # noqa: F811
                 split_step(vp.view_index(i, args.views), part_a, part_b, update)
 
             def graph_step(i):
-                split_step(vp.view_index(i, args.views), gA, gB, gC)
+                split_step(vp.view_index(i, args.views), gA, gB, gC, key=gkey)
 
             def capture_all():
-                for v in range(args.views):
-                    gA.capture(v)
-                    gB.capture(v)
+                for v in capture_views:
+                    select(v)
+                    gA.capture(gkey(v))
+                    gB.capture(gkey(v))
                 reduce_grads()  # the optimizer graph's capture warm-up applies real updates: reduced gradients only
                 gC.capture(0)
         elif not use_dist:  # whole step (fwd + bwd + Adam) is one graph per view
@@ -389,14 +421,17 @@ def main():
 
         if not overlap_gather:
             def graph_step(i):
-                g_step(vp.view_index(i, args.views))
+                v = vp.view_index(i, args.views)
+                select(v)
+                g_step(gkey(v))
                 if g_opt is not None:
                     reduce_grads()
                     g_opt(0)
 
             def capture_all():
-                for v in range(args.views):
-                    g_step.capture(v)
+                for v in capture_views:
+                    select(v)
+                    g_step.capture(gkey(v))
                 if g_opt is not None:
                     # GraphedSteps.capture runs its function for real (warm-up) before recording it: the optimizer graph
                     # must see REDUCED gradients then, or every rank would apply its own view's gradient and the replicas
@@ -520,7 +555,9 @@ def main():
                            + (', compact LBS-logit gradient' if compact else '')
                            + (f', SH gradient as all-gathered factors ({world} x {P * 24 / 1e6:.1f} MB)' if sh_factored else '')
                            + ')'),
-                       'launch': 'eager' if args.eager else 'one hipGraph replay per view step',
+                       'launch': 'eager' if args.eager else (
+                           f'ONE captured hipGraph for all {args.views} views (camera, time and target read from a device view slot)'
+                           if view_table is not None else f'one captured hipGraph per view ({args.views})'),
                        'tile_lists': 'compact (count, scan, scatter)' if (args.autograd or args.compact_lists)
                        else f'buckets of {tile_bucket} slots per tile (longest list {longest})',
                        'joint_rotations': ('deform network (freq-encode + 8x256 MLP + heads) inside the step, '

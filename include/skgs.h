@@ -79,6 +79,12 @@ typedef struct skgs_raster_inputs {
                               binning buffer of T * Lcap instances, so the counting and scan launches disappear; a tile
                               with more than Lcap instances drops the excess and sets the overflow flag; num_rendered
                               and max_tile_count of skgs_status read -1. */
+  const float* tanfov_device; /* NULL, or a DEVICE pointer to {tanfovx, tanfovy}: the kernels read the field of view there
+                              instead of the two floats above.  With viewmatrix / projmatrix / campos (device pointers
+                              already) this makes every camera parameter of a launch a device load, so ONE captured
+                              hipGraph serves every training view: the caller rewrites a small "view slot" before each
+                              replay (sk_gs_amd/view_slot.py; the reference builds its settings per view on the host,
+                              networks/gaussian_splatting.py:271-284, train.py:179-250). */
 } skgs_raster_inputs;
 
 typedef struct skgs_raster_buffers {
@@ -241,29 +247,32 @@ int skgs_knn_lbs_deform_forward(int32_t P, int32_t M, int32_t K, const float* po
  *   global_T [7] or NULL (identity)                                                     bone_T  [M,7] out
  * Skeleton topology as three int32 device arrays: parents[M] (direct parent; parents[root] = root), the bones sorted
  * by depth (level_nodes[M]) and level_start[num_levels+1] (level 0 = {root}).  chain_A [M,7] is written by the forward
- * (may be NULL for inference) and consumed by the backward.  g_joints / g_global_T may be NULL. */
+ * (may be NULL for inference) and consumed by the backward.  g_joints / g_global_T may be NULL.
+ * frame_index: NULL, or a DEVICE int32: global_T (and g_global_T) are then the base of a [frames, 7] table and the kernels
+ * use row *frame_index (the frame is chosen without a host-side pointer: one captured graph for all frames). */
 int skgs_bone_chain_forward(int32_t M, int32_t root, const int32_t* parents, const int32_t* level_nodes,
     const int32_t* level_start, int32_t num_levels, const float* sk_r_raw, const float* joints, const float* global_T,
-    float* bone_T, float* chain_A, skgs_stream_t stream);
+    float* bone_T, float* chain_A, const int32_t* frame_index, skgs_stream_t stream);
 int skgs_bone_chain_backward(int32_t M, int32_t root, const int32_t* parents, const int32_t* level_nodes,
     const int32_t* level_start, int32_t num_levels, const float* sk_r_raw, const float* joints, const float* global_T,
     const float* chain_A, const float* g_bone_T, float* g_sk_r_raw, float* g_joints, float* g_global_T,
-    skgs_stream_t stream);
+    const int32_t* frame_index, skgs_stream_t stream);
 
 /* ---- fused training-image loss (scope row (f)-1): lambda_l1 * mean|x-y| + lambda_ssim * (1 - mean SSIM(x,y)) ----
  * Replaces networks/losses/ssim.py:20-62 + image_loss.py:6-32 as composed at networks/sk_gs.py:1524-1529 (11x11
  * Gaussian window, sigma 1.5, zero padding).  pred, gt: [C,H,W].  loss3 (device, 3 floats) = {total, L1 mean, SSIM
  * mean}.  The workspace (skgs_image_loss_workspace_bytes) carries the SSIM derivative maps from forward to
- * backward.  grad_loss: device scalar dL/dloss, or NULL for 1. */
+ * backward.  grad_loss: device scalar dL/dloss, or NULL for 1.  gt_index: NULL, or a DEVICE int32: gt is then a stack
+ * [views, C, H, W] and the kernels compare with image *gt_index (target chosen on the device). */
 size_t skgs_image_loss_workspace_bytes(int32_t C, int32_t H, int32_t W);
-int skgs_image_loss_forward(int32_t C, int32_t H, int32_t W, const float* pred, const float* gt, float lambda_l1,
-    float lambda_ssim, float* loss3 /* may be NULL: see the backward */, void* workspace, size_t workspace_bytes,
-    skgs_stream_t stream);
+int skgs_image_loss_forward(int32_t C, int32_t H, int32_t W, const float* pred, const float* gt, const int32_t* gt_index,
+    float lambda_l1, float lambda_ssim, float* loss3 /* may be NULL: see the backward */, void* workspace,
+    size_t workspace_bytes, skgs_stream_t stream);
 /* loss3: NULL, or where this call puts {total, L1 mean, SSIM mean} of the forward that filled `workspace` (a forward
  * called with loss3 = NULL skips its one-workgroup summation launch; one workgroup of the backward does it instead). */
-int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred, const float* gt, float lambda_l1,
-    float lambda_ssim, const float* grad_loss, const void* workspace, size_t workspace_bytes, float* dL_dpred,
-    float* loss3, skgs_stream_t stream);
+int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred, const float* gt, const int32_t* gt_index,
+    float lambda_l1, float lambda_ssim, const float* grad_loss, const void* workspace, size_t workspace_bytes,
+    float* dL_dpred, float* loss3, skgs_stream_t stream);
 
 /* ---- multi-tensor Adam step in one launch (scope row (f)-2) ----
  * Replaces torch.optim.Adam(eps=1e-15) as configured by exps/default.yaml:122-125 over the parameter groups of

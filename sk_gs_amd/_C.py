@@ -39,7 +39,7 @@ class _RasterInputs(C.Structure):
         ('means3D', C.c_void_p), ('opacity', C.c_void_p), ('sh', C.c_void_p), ('scales', C.c_void_p),
         ('rotations', C.c_void_p), ('extras', C.c_void_p), ('colors_precomp', C.c_void_p),
         ('cov3D_precomp', C.c_void_p), ('sh_rest', C.c_void_p), ('background', C.c_void_p),
-        ('tile_bucket_capacity', C.c_int32),
+        ('tile_bucket_capacity', C.c_int32), ('tanfov_device', C.c_void_p),
     ]
 
 
@@ -614,7 +614,7 @@ def bone_chain_forward(sk_r_raw: Tensor, joints: Tensor, global_T: Optional[Tens
             C.c_int32(M), C.c_int32(topo['root']), C.c_void_p(topo['parents'].data_ptr()),
             C.c_void_p(topo['level_nodes'].data_ptr()), C.c_void_p(topo['level_start'].data_ptr()),
             C.c_int32(topo['num_levels']), C.c_void_p(sk_r_raw.data_ptr()), C.c_void_p(joints.data_ptr()),
-            C.c_void_p(_ptr(global_T)), C.c_void_p(bone_T.data_ptr()), C.c_void_p(_ptr(chain)), _stream()))
+            C.c_void_p(_ptr(global_T)), C.c_void_p(bone_T.data_ptr()), C.c_void_p(_ptr(chain)), None, _stream()))
     return bone_T, chain
 
 
@@ -635,7 +635,7 @@ def bone_chain_backward(sk_r_raw: Tensor, joints: Tensor, global_T: Optional[Ten
             C.c_void_p(topo['level_nodes'].data_ptr()), C.c_void_p(topo['level_start'].data_ptr()),
             C.c_int32(topo['num_levels']), C.c_void_p(sk_r_raw.data_ptr()), C.c_void_p(joints.data_ptr()),
             C.c_void_p(_ptr(global_T)), C.c_void_p(chain_A.data_ptr()), C.c_void_p(g_bone_T.data_ptr()),
-            C.c_void_p(g_raw.data_ptr()), C.c_void_p(_ptr(g_j)), C.c_void_p(_ptr(g_g)), _stream()))
+            C.c_void_p(g_raw.data_ptr()), C.c_void_p(_ptr(g_j)), C.c_void_p(_ptr(g_g)), None, _stream()))
     return g_raw, g_j, g_g
 
 
@@ -652,7 +652,7 @@ def image_loss_forward(pred: Tensor, gt: Tensor, lambda_l1: float, lambda_ssim: 
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         loss3 = torch.empty((3,), dtype=torch.float32, device=dev)
         _check(lib.skgs_image_loss_forward(C.c_int32(Cc), C.c_int32(H), C.c_int32(W), C.c_void_p(pred.data_ptr()),
-                                           C.c_void_p(gt.data_ptr()), C.c_float(lambda_l1), C.c_float(lambda_ssim),
+                                           C.c_void_p(gt.data_ptr()), None, C.c_float(lambda_l1), C.c_float(lambda_ssim),
                                            C.c_void_p(loss3.data_ptr()), C.c_void_p(ws.data_ptr()),
                                            C.c_size_t(nbytes), _stream()))
     return loss3, ws
@@ -668,7 +668,7 @@ def image_loss_backward(pred: Tensor, gt: Tensor, lambda_l1: float, lambda_ssim:
         out = torch.empty_like(pred)
         gl = _f32c(grad_loss, dev) if grad_loss is not None else None
         _check(lib.skgs_image_loss_backward(C.c_int32(Cc), C.c_int32(H), C.c_int32(W), C.c_void_p(pred.data_ptr()),
-                                            C.c_void_p(gt.data_ptr()), C.c_float(lambda_l1), C.c_float(lambda_ssim),
+                                            C.c_void_p(gt.data_ptr()), None, C.c_float(lambda_l1), C.c_float(lambda_ssim),
                                             C.c_void_p(_ptr(gl)), C.c_void_p(workspace.data_ptr()),
                                             C.c_size_t(workspace.numel()), C.c_void_p(out.data_ptr()), None, _stream()))
     return out

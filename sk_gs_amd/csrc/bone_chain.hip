@@ -96,8 +96,10 @@ inline size_t staged_bytes(int M, int num_levels) { return ((size_t) M * LOC_F +
 __global__ void __launch_bounds__(CHAIN_THREADS) bone_chain_forward_kernel(int M, int root, const int32_t* __restrict__ parents,
     const int32_t* __restrict__ level_nodes, const int32_t* __restrict__ level_start, int num_levels,
     const float* __restrict__ sk_r_raw, const float* __restrict__ joints, const float* __restrict__ global_T,
-    float* __restrict__ bone_T, float* __restrict__ chain_A /*[M,7] saved for backward*/) {
+    float* __restrict__ bone_T, float* __restrict__ chain_A /*[M,7] saved for backward*/,
+    const int32_t* __restrict__ frame_index) {
   extern __shared__ float s_A[];  // [M][7] | staged skeleton
+  if (global_T && frame_index) global_T += 7 * (size_t) frame_index[0];  // row of a [frames, 7] table, chosen on the device
   const int tid = threadIdx.x;
   const Staged sk = stage_skeleton(s_A + 7 * (size_t) M, M, num_levels, parents, level_nodes, level_start, sk_r_raw, joints);
   if (tid == 0) {
@@ -150,8 +152,12 @@ __global__ void __launch_bounds__(CHAIN_THREADS) bone_chain_backward_kernel(int 
     const int32_t* __restrict__ level_nodes, const int32_t* __restrict__ level_start, int num_levels,
     const float* __restrict__ sk_r_raw, const float* __restrict__ joints, const float* __restrict__ global_T,
     const float* __restrict__ chain_A, const float* __restrict__ g_bone_T, float* __restrict__ g_sk_r_raw,
-    float* __restrict__ g_joints, float* __restrict__ g_global_T) {
+    float* __restrict__ g_joints, float* __restrict__ g_global_T, const int32_t* __restrict__ frame_index) {
   extern __shared__ float s_mem[];
+  if (frame_index) {
+    if (global_T) global_T += 7 * (size_t) frame_index[0];
+    if (g_global_T) g_global_T += 7 * (size_t) frame_index[0];
+  }
   float* s_A  = s_mem;          // [M][7]
   float* s_gA = s_mem + 7 * M;  // [M][7]
   __shared__ float s_gG[7];
@@ -254,13 +260,13 @@ extern "C" {
 
 int skgs_bone_chain_forward(int32_t M, int32_t root, const int32_t* parents, const int32_t* level_nodes,
     const int32_t* level_start, int32_t num_levels, const float* sk_r_raw, const float* joints, const float* global_T,
-    float* bone_T, float* chain_A, skgs_stream_t stream) {
+    float* bone_T, float* chain_A, const int32_t* frame_index, skgs_stream_t stream) {
   SKGS_REQUIRE(M >= 1 && root >= 0 && root < M && num_levels >= 1, "bone_chain: bad skeleton sizes");
   SKGS_REQUIRE(parents && level_nodes && level_start && sk_r_raw && joints && bone_T, "bone_chain: NULL argument");
   const size_t lds = (size_t) M * 7 * 4 + staged_bytes(M, num_levels);
   SKGS_REQUIRE(lds <= 64 * 1024, "bone_chain: skeleton too large for the LDS staging (about 740 bones)");
   hipLaunchKernelGGL(bone_chain_forward_kernel, dim3(1), dim3(CHAIN_THREADS), lds, (hipStream_t) stream, M, root,
-      parents, level_nodes, level_start, num_levels, sk_r_raw, joints, global_T, bone_T, chain_A);
+      parents, level_nodes, level_start, num_levels, sk_r_raw, joints, global_T, bone_T, chain_A, frame_index);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -268,7 +274,7 @@ int skgs_bone_chain_forward(int32_t M, int32_t root, const int32_t* parents, con
 int skgs_bone_chain_backward(int32_t M, int32_t root, const int32_t* parents, const int32_t* level_nodes,
     const int32_t* level_start, int32_t num_levels, const float* sk_r_raw, const float* joints, const float* global_T,
     const float* chain_A, const float* g_bone_T, float* g_sk_r_raw, float* g_joints, float* g_global_T,
-    skgs_stream_t stream) {
+    const int32_t* frame_index, skgs_stream_t stream) {
   SKGS_REQUIRE(M >= 1 && root >= 0 && root < M && num_levels >= 1, "bone_chain: bad skeleton sizes");
   SKGS_REQUIRE(parents && level_nodes && level_start && sk_r_raw && joints && chain_A && g_bone_T && g_sk_r_raw,
       "bone_chain: NULL argument");
@@ -276,7 +282,7 @@ int skgs_bone_chain_backward(int32_t M, int32_t root, const int32_t* parents, co
   SKGS_REQUIRE(lds <= 64 * 1024, "bone_chain backward: skeleton too large for the LDS staging (about 560 bones)");
   hipLaunchKernelGGL(bone_chain_backward_kernel, dim3(1), dim3(CHAIN_THREADS), lds, (hipStream_t) stream, M,
       root, parents, level_nodes, level_start, num_levels, sk_r_raw, joints, global_T, chain_A, g_bone_T, g_sk_r_raw,
-      g_joints, g_global_T);
+      g_joints, g_global_T, frame_index);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -96,9 +96,11 @@ inline dim3 tile_grid(int C, int H, int W) {
 }
 
 __global__ void __launch_bounds__(256) image_loss_forward_kernel(int C, int H, int W, const float* __restrict__ pred,
-    const float* __restrict__ gt, Win win, float* __restrict__ dmaps /*[3][C][H][W]*/, float* __restrict__ partials) {
+    const float* __restrict__ gt, const int32_t* __restrict__ gt_index, Win win, float* __restrict__ dmaps /*[3][C][H][W]*/,
+    float* __restrict__ partials) {
   __shared__ float s_h[5][IH][HP];
   __shared__ float s_red[4];
+  if (gt_index) gt += (size_t) gt_index[0] * C * H * W;  // image of a [views, C, H, W] stack, chosen on the device
   TileId tile;
   if (!tile_of_block((W + TW - 1) / TW, (H + TH - 1) / TH, C, tile)) return;
   const int c  = tile.c;
@@ -215,11 +217,13 @@ __global__ void __launch_bounds__(256) image_loss_finalize_kernel(int nblocks, d
 }
 
 __global__ void __launch_bounds__(256) image_loss_backward_kernel(int C, int H, int W, const float* __restrict__ pred,
-    const float* __restrict__ gt, Win win, const float* __restrict__ dmaps, const float* __restrict__ grad_loss,
-    float scale_l1, float scale_ssim, float* __restrict__ dL_dpred, const float* __restrict__ partials, int nblocks,
-    double inv_n, float lambda_l1, float lambda_ssim, float* __restrict__ loss3) {
+    const float* __restrict__ gt, const int32_t* __restrict__ gt_index, Win win, const float* __restrict__ dmaps,
+    const float* __restrict__ grad_loss, float scale_l1, float scale_ssim, float* __restrict__ dL_dpred,
+    const float* __restrict__ partials, int nblocks, double inv_n, float lambda_l1, float lambda_ssim,
+    float* __restrict__ loss3) {
   __shared__ float s_m[3][IH][IP];
   __shared__ float s_h[3][IH][HP];
+  if (gt_index) gt += (size_t) gt_index[0] * C * H * W;
   TileId tile;
   if (!tile_of_block((W + TW - 1) / TW, (H + TH - 1) / TH, C, tile)) return;
   const int c  = tile.c;
@@ -318,14 +322,14 @@ size_t skgs_image_loss_workspace_bytes(int32_t C, int32_t H, int32_t W) {
   return (size_t) 3 * C * H * W * 4 + align256(tiles * 2 * 4) + 256;
 }
 
-int skgs_image_loss_forward(int32_t C, int32_t H, int32_t W, const float* pred, const float* gt, float lambda_l1,
-    float lambda_ssim, float* loss3, void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
+int skgs_image_loss_forward(int32_t C, int32_t H, int32_t W, const float* pred, const float* gt, const int32_t* gt_index,
+    float lambda_l1, float lambda_ssim, float* loss3, void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
   SKGS_REQUIRE(C > 0 && H > 0 && W > 0 && pred && gt && workspace, "image_loss_forward: bad argument");
   SKGS_REQUIRE(workspace_bytes >= skgs_image_loss_workspace_bytes(C, H, W), "image_loss_forward: workspace too small");
   hipStream_t s   = (hipStream_t) stream;
   float* dmaps    = reinterpret_cast<float*>(workspace);
   float* partials = dmaps + (size_t) 3 * C * H * W;
-  hipLaunchKernelGGL(image_loss_forward_kernel, tile_grid(C, H, W), dim3(256), 0, s, C, H, W, pred, gt, make_window(), dmaps,
+  hipLaunchKernelGGL(image_loss_forward_kernel, tile_grid(C, H, W), dim3(256), 0, s, C, H, W, pred, gt, gt_index, make_window(), dmaps,
       partials);
   SKGS_CHECK_HIP(hipGetLastError());
   if (loss3) {  // NULL: the caller asks skgs_image_loss_backward for the value (saves this launch)
@@ -337,8 +341,8 @@ int skgs_image_loss_forward(int32_t C, int32_t H, int32_t W, const float* pred, 
   return 0;
 }
 
-int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred, const float* gt, float lambda_l1,
-    float lambda_ssim, const float* grad_loss /*device scalar or NULL (=1)*/, const void* workspace,
+int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred, const float* gt, const int32_t* gt_index,
+    float lambda_l1, float lambda_ssim, const float* grad_loss /*device scalar or NULL (=1)*/, const void* workspace,
     size_t workspace_bytes, float* dL_dpred, float* loss3 /*NULL, or where to put the forward's loss values*/,
     skgs_stream_t stream) {
   SKGS_REQUIRE(C > 0 && H > 0 && W > 0 && pred && gt && workspace && dL_dpred, "image_loss_backward: bad argument");
@@ -348,7 +352,7 @@ int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred,
   const float* partials = dmaps + (size_t) 3 * C * H * W;
   const int nblocks     = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * C;
   hipLaunchKernelGGL(image_loss_backward_kernel, tile_grid(C, H, W), dim3(256), 0, (hipStream_t) stream, C, H, W, pred, gt,
-      make_window(), dmaps, grad_loss, lambda_l1 / n, -lambda_ssim / n, dL_dpred, partials, nblocks,
+      gt_index, make_window(), dmaps, grad_loss, lambda_l1 / n, -lambda_ssim / n, dL_dpred, partials, nblocks,
       1.0 / ((double) C * H * W), lambda_l1, lambda_ssim, loss3);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;

@@ -264,17 +264,20 @@ class FusedDeformMLP:
                 (d.head_out if head_out is not None else d.head_gout)[j] = h.data_ptr()
         return d
 
-    def forward(self, points: Tensor, t: Tensor, head_out: Optional[Sequence[Tensor]] = None) -> Tensor:
-        """points [B, p_in], t: device tensor with t_in floats -> ``self.out`` [B, OUT], or the heads written to the
-        separate tensors ``head_out`` (also fills x0 / acts)"""
+    def forward(self, points: Tensor, t: Tensor, head_out: Optional[Sequence[Tensor]] = None,
+                out: Optional[Tensor] = None) -> Tensor:
+        """points [B, p_in], t: device tensor with t_in floats -> ``out`` (default ``self.out``) [B, OUT], or the heads
+        written to the separate tensors ``head_out`` (also fills x0 / acts)"""
         assert points.is_cuda and points.is_contiguous() and points.dtype == torch.float32 and points.shape[0] == self.B
         assert t.is_cuda and t.dtype == torch.float32 and t.numel() == self.mlp.t_in
+        out = self.out if out is None else out
+        assert out.is_cuda and out.is_contiguous() and out.shape == self.out.shape and out.dtype == torch.float32
         d = self._desc(None, head_out=head_out)
         _C._check(self.lib.skgs_deform_mlp_forward(
             C.byref(d), C.c_void_p(points.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(self.x0.data_ptr()),
-            C.c_void_p(self.acts.data_ptr()), C.c_void_p(self.out.data_ptr()), C.c_void_p(self.workspace.data_ptr()),
+            C.c_void_p(self.acts.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(self.workspace.data_ptr()),
             C.c_size_t(self.workspace.numel()), _C._stream()))
-        return self.out
+        return out
 
     def backward(self, points: Tensor, t: Tensor, g_out, grads: Sequence[Tensor], g_x0: Optional[Tensor] = None):
         """``g_out``: [B, OUT] or one tensor per head; ``grads``: [gW0, gb0, ..., gW_heads, gb_heads] (written); ``g_x0``
@@ -307,7 +310,10 @@ class _DeformMLPFn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=points.device)
         if fused_supported(mlp, B) and not getattr(mlp, 'force_layered', False):
             run = FusedDeformMLP(mlp, B)  # (allocates its exchange workspace: the training step keeps one instead)
-            out = run.forward(points, t)
+            # the returned tensor must not be owned by anything the context references: ctx -> run -> out -> grad_fn -> ctx
+            # would be a reference cycle that keeps the whole autograd graph (and its AccumulateGrad nodes, bound to the
+            # stream of THIS call) alive until the next gc -- which breaks a later hipGraph capture of the step
+            out = run.forward(points, t, out=torch.empty_like(run.out))
             ctx.mlp, ctx.fused, ctx.pt = mlp, run, (points, t)
             return out
         ctx.fused = None

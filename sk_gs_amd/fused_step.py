@@ -48,7 +48,8 @@ class FusedViewStep:
     def __init__(self, model: SkinnedGaussians, W: int, H: int, capacity: int, lambda_dssim: float = 0.2,
                  background: Optional[Tensor] = None, grad_scale: float = 1.0, densify_stats: bool = False,
                  spw_logit_grad: Optional[Tensor] = None, tables_zeroed_by_optimizer: bool = False,
-                 tile_bucket: int = 0, sh_factors: Optional[Tensor] = None, fused_deform_net: bool = True):
+                 tile_bucket: int = 0, sh_factors: Optional[Tensor] = None, fused_deform_net: bool = True,
+                 view_table=None):
         assert not model.static, 'FusedViewStep covers the skinned stage (M >= 1)'
         self.model, self.W, self.H = model, int(W), int(H)
         self.lambda_l1, self.lambda_ssim = 1.0 - lambda_dssim, lambda_dssim
@@ -127,6 +128,13 @@ class FusedViewStep:
             self._sk_r_raw, self._d_rot, self._d_scale = (torch.empty((M, 4), **f32), torch.empty((M, 4), **f32),
                                                           torch.empty((M, 3), **f32))
             self._g_heads = [torch.empty((M, 4), **f32), torch.empty((M, 4), **f32), torch.empty((M, 3), **f32)]
+        # per-view inputs as device loads (sk_gs_amd/view_slot.py): forward_backward() without arguments then trains the
+        # view selected in the table, and ONE captured graph serves all of them
+        self.view_table = view_table
+        if view_table is not None:
+            assert self.deform_net is not None, 'the view slot drives the deform network\'s time input: tables mode keeps one graph per view'
+            vs = view_table.settings
+            assert (vs.image_height, vs.image_width) == (self.H, self.W)
         topo = model.topology()
         self._topo = topo
         self._bufs = _C._buffers(self.geom, self.binning, self.img)
@@ -164,17 +172,25 @@ class FusedViewStep:
             for t in tabs:
                 t.zero_()
 
-    def _raster_inputs(self, rs: GaussianRasterizationSettings) -> '_C._RasterInputs':
+    def _raster_inputs(self, rs: Optional[GaussianRasterizationSettings]) -> '_C._RasterInputs':
         m = self.model
         a = _C._RasterInputs()
+        vt = self.view_table if rs is None else None
+        if vt is not None:
+            rs = vt.settings  # the launch arguments common to all views; the camera itself is read from the slot
         a.P, a.sh_degree, a.sh_coeffs, a.E = self.P, int(rs.sh_degree), (m.max_sh_degree + 1) ** 2, 0
         a.image_height, a.image_width = self.H, self.W
         a.tanfovx, a.tanfovy, a.scale_modifier = float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier)
         a.prefiltered, a.debug, a.colmap = int(bool(rs.prefiltered)), int(bool(rs.debug)), int(bool(rs.colmap))
-        for name in ('viewmatrix', 'projmatrix', 'campos'):
-            t = getattr(rs, name)
-            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), name
-            setattr(a, name, t.data_ptr())
+        if vt is not None:
+            from sk_gs_amd import view_slot as vsl
+            a.viewmatrix, a.projmatrix, a.campos = vt.ptr(vsl.W_VIEW), vt.ptr(vsl.W_PROJ), vt.ptr(vsl.W_CAMPOS)
+            a.tanfov_device = vt.ptr(vsl.W_TANFOV)
+        else:
+            for name in ('viewmatrix', 'projmatrix', 'campos'):
+                t = getattr(rs, name)
+                assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), name
+                setattr(a, name, t.data_ptr())
         a.means3D, a.opacity = self.means.data_ptr(), self.opacity.data_ptr()
         a.scales, a.rotations = self.scales.data_ptr(), self.rotations.data_ptr()
         a.sh, a.sh_rest = m._features_dc.data_ptr(), m._features_rest.data_ptr()
@@ -189,6 +205,7 @@ class FusedViewStep:
         a.points = a.xyz = m._xyz.data_ptr()  # points = xyz.detach() (sk_gs.py:1113): same storage
         a.weights, a.indices, a.bone_T = self.weights.data_ptr(), self.indices.data_ptr(), self.bone_T.data_ptr()
         if self.deform_net is None:
+            assert time_id is not None
             a.bone_drot, a.bone_dscale = m.sk_d_rot[time_id].data_ptr(), m.sk_d_scale[time_id].data_ptr()
         else:
             a.bone_drot, a.bone_dscale = self._d_rot.data_ptr(), self._d_scale.data_ptr()
@@ -197,18 +214,30 @@ class FusedViewStep:
 
     # ------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def forward(self, rs: GaussianRasterizationSettings, time_id: int):
-        """bone chain -> KNN + LBS weights -> skin + activations -> rasterize.  Fills ``image`` / ``out_opacity``."""
+    def _frame(self, time_id: Optional[int]):
+        """(global_T pointer, its gradient's pointer, device frame-index pointer or None) of the frame: a row of the tables,
+        or the tables' base + the slot's frame index"""
+        m = self.model
+        if time_id is None:
+            from sk_gs_amd import view_slot as vsl
+            return m.global_tr.data_ptr(), m.global_tr.grad.data_ptr(), C.c_void_p(self.view_table.ptr(vsl.W_FRAME))
+        return m.global_tr[time_id].data_ptr(), m.global_tr.grad[time_id].data_ptr(), None
+
+    def forward(self, rs: Optional[GaussianRasterizationSettings] = None, time_id: Optional[int] = None):
+        """bone chain -> KNN + LBS weights -> skin + activations -> rasterize.  Fills ``image`` / ``out_opacity``.
+        Without arguments: the view selected in ``view_table``."""
         lib, m, st, chk = self.lib, self.model, _C._stream(), _C._check
         t = self._topo
         P, M, K = self.P, self.M, self.K
+        assert (rs is None) == (time_id is None) and (rs is not None or self.view_table is not None)
         sk_r_raw = self._joint_rotations(time_id)
+        gT, _, fidx = self._frame(time_id)
         # (running the single-workgroup bone-chain kernels on a forked stream beside the wide kernels was measured:
         # the fork/join edges of the captured graph cost more (+12 us per step) than the ~10 us of overlap)
         chk(lib.skgs_bone_chain_forward(
             C.c_int32(M), C.c_int32(t['root']), _p(t['parents']), _p(t['level_nodes']), _p(t['level_start']),
-            C.c_int32(t['num_levels']), _p(sk_r_raw), _p(m.joints), _p(m.global_tr[time_id]), _p(self.bone_T),
-            _p(self.chain_A), st))
+            C.c_int32(t['num_levels']), _p(sk_r_raw), _p(m.joints), C.c_void_p(gT), _p(self.bone_T),
+            _p(self.chain_A), fidx, st))
         d = self._deform_inputs(time_id)
         # K nearest bones + softmax weights + skinning + activations: one launch (weights / indices kept for the backward)
         chk(lib.skgs_knn_lbs_deform_forward(
@@ -222,24 +251,33 @@ class FusedViewStep:
         return a, d
 
     @torch.no_grad()
-    def forward_backward(self, rs: GaussianRasterizationSettings, time_id: int, target: Tensor):
+    def forward_backward(self, rs: Optional[GaussianRasterizationSettings] = None, time_id: Optional[int] = None,
+                         target: Optional[Tensor] = None):
+        """one training view: (rs, time_id, target), or no arguments = the view selected in ``view_table``"""
         self.backward_raster(rs, time_id, target)
         self.backward_skinning(time_id)
 
     @torch.no_grad()
-    def backward_raster(self, rs: GaussianRasterizationSettings, time_id: int, target: Tensor):
+    def backward_raster(self, rs: Optional[GaussianRasterizationSettings] = None, time_id: Optional[int] = None,
+                        target: Optional[Tensor] = None):
         """first half of the step: forward, loss, rasterizer backward.  On return the SH gradients
         (``_features_dc.grad``, ``_features_rest.grad``) are final; the skinning backward has not run yet."""
         lib, m, st, chk = self.lib, self.model, _C._stream(), _C._check
         P, M, K, W, H = self.P, self.M, self.K, self.W, self.H
+        if rs is None:  # the target is an image of the table's stack, chosen by the slot
+            from sk_gs_amd import view_slot as vsl
+            assert target is None and self.view_table.targets is not None
+            target, gt_index = self.view_table.targets, C.c_void_p(self.view_table.ptr(vsl.W_TARGET))
+        else:
+            gt_index = None
         assert target.is_cuda and target.dtype == torch.float32 and target.is_contiguous()
         self._zero_table_grads()
         a, d = self.forward(rs, time_id)
         # ---- loss and dL/dimage
-        chk(lib.skgs_image_loss_forward(C.c_int32(3), C.c_int32(H), C.c_int32(W), _p(self.image), _p(target),
+        chk(lib.skgs_image_loss_forward(C.c_int32(3), C.c_int32(H), C.c_int32(W), _p(self.image), _p(target), gt_index,
                                         C.c_float(self.lambda_l1), C.c_float(self.lambda_ssim), None,  # value: backward
                                         _p(self.loss_ws), C.c_size_t(self.loss_ws.numel()), st))
-        chk(lib.skgs_image_loss_backward(C.c_int32(3), C.c_int32(H), C.c_int32(W), _p(self.image), _p(target),
+        chk(lib.skgs_image_loss_backward(C.c_int32(3), C.c_int32(H), C.c_int32(W), _p(self.image), _p(target), gt_index,
                                          C.c_float(self.lambda_l1), C.c_float(self.lambda_ssim), _p(self.grad_scale),
                                          _p(self.loss_ws), C.c_size_t(self.loss_ws.numel()), _p(self.dL_dimage),
                                          _p(self.loss3), st))
@@ -271,7 +309,7 @@ class FusedViewStep:
             _p(all_factors), _p(m._features_dc.grad), _p(m._features_rest.grad), _C._stream()))
 
     @torch.no_grad()
-    def backward_skinning(self, time_id: int):
+    def backward_skinning(self, time_id: Optional[int] = None):
         """second half: skinning backward (Gaussian parameters' gradients written in place), LBS logits, bone chain.
         With ``spw_logit_grad`` set, the logit gradient is left compact ([P,K], for the all-reduce) and
         ``scatter_spw_grad`` expands it into ``sp_W.grad`` later."""
@@ -280,6 +318,7 @@ class FusedViewStep:
         P, M, K = self.P, self.M, self.K
         d = self._deform_inputs(time_id)
         self._time_id = time_id
+        gT, g_gT, fidx = self._frame(time_id)
         if self.deform_net is None:
             sk_r_raw, g_raw = m.sk_r[time_id], m.sk_r.grad[time_id]
             g_drot, g_dscale = m.sk_d_rot.grad[time_id], m.sk_d_scale.grad[time_id]
@@ -304,8 +343,8 @@ class FusedViewStep:
             self._lbs_logits_backward()
         chk(lib.skgs_bone_chain_backward(
             C.c_int32(M), C.c_int32(t['root']), _p(t['parents']), _p(t['level_nodes']), _p(t['level_start']),
-            C.c_int32(t['num_levels']), _p(sk_r_raw), _p(m.joints), _p(m.global_tr[time_id]), _p(self.chain_A),
-            _p(self.g_bone_T), _p(g_raw), None, _p(m.global_tr.grad[time_id]), st))
+            C.c_int32(t['num_levels']), _p(sk_r_raw), _p(m.joints), C.c_void_p(gT), _p(self.chain_A),
+            _p(self.g_bone_T), _p(g_raw), None, C.c_void_p(g_gT), fidx, st))
         if self.deform_net is not None:
             self._deform_net_backward()
         if self.densify_stats:
@@ -322,18 +361,26 @@ class FusedViewStep:
             chk(lib.skgs_lbs_weights_backward_compact(C.c_int32(P), C.c_int32(K), _p(self.weights), _p(self.g_weights),
                                                       _p(self.spw_logit_grad), st))
 
-    def _joint_rotations(self, time_id: int) -> Tensor:
+    def _time_tensor(self, time_id: Optional[int]) -> Tensor:
+        """the frame's time as a 1-element device tensor: a row of ``frame_times`` or the slot's time word"""
+        if time_id is not None:
+            return self.model.frame_times[time_id]
+        from sk_gs_amd import view_slot as vsl
+        return self.view_table.slot[vsl.W_TIME:vsl.W_TIME + 1]
+
+    def _joint_rotations(self, time_id: Optional[int]) -> Tensor:
         """raw joint rotations of the frame: a row of the per-frame table, or the producer network's first head (the
         network also fills d_rot / d_scale): 2 encode + 8 layer + 3 head launches (csrc/mlp.hip)"""
         m = self.model
         if self.deform_net is None:
             return m.sk_r[time_id]
+        tt = self._time_tensor(time_id)
         if self._mlp_fused is not None:  # the whole network: one launch
-            self._mlp_fused.forward(m.joints, m.frame_times[time_id], head_out=(self._sk_r_raw, self._d_rot, self._d_scale))
+            self._mlp_fused.forward(m.joints, tt, head_out=(self._sk_r_raw, self._d_rot, self._d_scale))
             return self._sk_r_raw
         from sk_gs_amd.deform_net import _lin_fwd
         net, run = self.deform_net.dynamic_net, self._mlp
-        run.encode(m.joints, m.frame_times[time_id], self._x0)
+        run.encode(m.joints, tt, self._x0)
         run.forward_hidden(self._x0, self._acts)
         M, H, IN = self.M, net.dim_hidden, net.in_channels
         in1, in2 = net.layer_dims()[-1]
@@ -350,7 +397,7 @@ class FusedViewStep:
         if self._mlp_fused is not None:
             net = self.deform_net.dynamic_net
             grads = [g for l in net.net for g in (l.weight.grad, l.bias.grad)] + [net.last_weight.grad, net.last_bias.grad]
-            self._mlp_fused.backward(self.model.joints, self.model.frame_times[self._time_id], self._g_heads, grads)
+            self._mlp_fused.backward(self.model.joints, self._time_tensor(self._time_id), self._g_heads, grads)
             return
         from sk_gs_amd.deform_net import _lin_bwd
         net, run = self.deform_net.dynamic_net, self._mlp

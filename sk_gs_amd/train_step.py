@@ -24,10 +24,13 @@ class GraphedSteps:
     (legacy default) stream, which drags it into the capture and crashes hipStreamEndCapture.  Drop such outputs
     (or run those forwards under ``torch.no_grad()``) before capturing; ``capture`` runs ``gc.collect()`` first.
 
-    ``capture`` EXECUTES ``fn`` ``warmup`` times before recording it.  View-parallel training must therefore capture an
-    optimizer step only where it would run anyway -- after the gradient all-reduce -- or the ranks' replicas diverge."""
+    ``capture`` EXECUTES ``fn`` ``warmup`` times (default: once) before recording it: lazily initialised library state
+    must exist before a capture starts.  View-parallel training must therefore capture an optimizer step only where it
+    would run anyway -- after the gradient all-reduce -- or the ranks' replicas diverge.  Calling the object with a key
+    that has no graph yet captures it and does NOT replay on top: the warm-up execution already was that call's one
+    execution (an optimizer step or a statistics update must not run two or three times on the first call)."""
 
-    def __init__(self, fn: Callable[[Hashable], None], warmup: int = 2):
+    def __init__(self, fn: Callable[[Hashable], None], warmup: int = 1):
         self.fn = fn
         self.warmup = warmup
         self.graphs: Dict[Hashable, torch.cuda.CUDAGraph] = {}
@@ -53,5 +56,15 @@ class GraphedSteps:
     def __call__(self, key: Hashable):
         g = self.graphs.get(key)
         if g is None:
+            if self.warmup >= 1:
+                if self.warmup > 1:  # exactly one real execution on this call
+                    saved, self.warmup = self.warmup, 1
+                    try:
+                        self.capture(key)
+                    finally:
+                        self.warmup = saved
+                else:
+                    self.capture(key)
+                return
             g = self.capture(key)
         g.replay()

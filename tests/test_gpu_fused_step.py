@@ -226,3 +226,87 @@ def test_sh_gradient_from_factors_reproduces_the_dense_rows(sh_degree):
     assert rel_err(model._features_rest.grad, grads[0][1] + grads[1][1]) <= 2e-6
     if sh_degree < 3:  # coefficients above the active degree get exactly zero
         assert float(model._features_rest.grad[:, (sh_degree + 1) ** 2 - 1:].abs().max()) == 0.0
+
+
+def test_one_graph_serves_every_view_through_the_device_view_slot():
+    """sk_gs_amd/view_slot.py: camera matrices, field of view, frame time, frame index (row of global_tr) and the target
+    image are device loads of the kernels, so ONE captured hipGraph trains any of 200 views.  The slot path must give the
+    bits of the per-view-argument path (same kernels, same inputs), eagerly and replayed."""
+    import math
+    from sk_gs_amd import _C, scene
+    from sk_gs_amd.fused_step import FusedViewStep
+    from sk_gs_amd.model import SkinnedGaussians
+    from sk_gs_amd.train_step import GraphedSteps
+    from sk_gs_amd.view_slot import ViewTable
+    P, M, K, W, H, frames, V = 3000, 10, 4, 96, 64, 7, 200
+    dev = torch.device('cuda')
+    model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=4, scale_mult=2.0, deform_net=True).to(dev)
+    with torch.no_grad():
+        model.global_tr[:, :3] += 0.02 * torch.randn(frames, 3, device=dev)  # the frame's row must matter
+    cams = [scene.make_camera(W, H, seed=100 + v) for v in range(V)]
+    settings = [scene.raster_settings_from_camera(c, sh_degree=3, colmap=True, device=dev) for c in cams]
+    for v, rs in enumerate(settings):  # different fields of view too: tanfov is read from the slot
+        f = 1.0 + 0.2 * math.sin(v)
+        settings[v] = rs._replace(tanfovx=rs.tanfovx * f, tanfovy=rs.tanfovy * f)
+    n_targets = 5
+    targets = torch.rand(n_targets, 3, H, W, generator=torch.Generator().manual_seed(9)).to(dev)
+    tix = [(3 * v) % n_targets for v in range(V)]
+    fix = [v % frames for v in range(V)]
+    table = ViewTable(settings, [float(model.frame_times[f]) for f in fix], fix, targets, dev, target_indices=tix)
+    assert table.settings_of(17)['frame_index'] == fix[17] and table.settings_of(17)['target_index'] == tix[17]
+    _C.config.sync_num_rendered = True
+    with torch.no_grad():
+        R = max(model.render(settings[v], time_id=fix[v])['buffer'].R for v in range(0, V, 7))
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    classic = FusedViewStep(model, W, H, capacity=2 * R + 4096)
+    slot = FusedViewStep(model, W, H, capacity=2 * R + 4096, view_table=table)
+
+    def reference(v):
+        classic.forward_backward(settings[v], fix[v], targets[tix[v]])
+        assert classic.status()['overflow'] == 0
+        return classic.image.clone(), {n: p.grad.clone() for n, p in model.named_parameters()}, classic.loss3.clone()
+
+    def same_as_reference(v, what):
+        img, grads, loss3 = reference(v)
+        table.select(v)
+        what()
+        torch.cuda.synchronize()
+        assert torch.equal(slot.image, img), v
+        assert torch.equal(slot.loss3, loss3), v
+        for n, p in model.named_parameters():
+            # identical kernels on identical inputs; only the float atomics of the blend backward may reorder
+            assert_close_robust(p.grad, grads[n], 1e-4, 1e-3, name=f'{n} view {v}')
+        assert float(model.global_tr.grad[fix[v]].abs().sum()) > 0
+        others = [f for f in range(frames) if f != fix[v]]
+        assert float(model.global_tr.grad[others].abs().sum()) == 0 or not slot.tables_zeroed_by_optimizer
+
+    for v in (0, 17, 123):
+        model.global_tr.grad.zero_()
+        same_as_reference(v, lambda: slot.forward_backward())
+    graphs = GraphedSteps(lambda _: slot.forward_backward())
+    table.select(0)
+    graphs.capture(0)
+    assert len(graphs.graphs) == 1
+    for v in (1, 5, 64, 199, 0):
+        model.global_tr.grad.zero_()
+        same_as_reference(v, lambda: graphs(0))
+    assert len(graphs.graphs) == 1 and slot.status()['overflow_events'] == 0 and slot.status()['mlp_failed'] == 0
+
+
+def test_graphed_steps_first_call_runs_the_function_once():
+    """GraphedSteps.__call__ on a new key captures (one real warm-up execution) and must not replay on top of it: an
+    optimizer step or a statistics update would otherwise run two or three times on the first call"""
+    from sk_gs_amd.train_step import GraphedSteps
+    counter = torch.zeros(1, device='cuda')
+    g = GraphedSteps(lambda _: counter.add_(1))
+    g(0)
+    assert float(counter) == 1
+    g(0)
+    g(0)
+    assert float(counter) == 3
+    g3 = GraphedSteps(lambda _: counter.add_(10), warmup=3)
+    g3('a')
+    assert float(counter) == 13
+    g3.capture('b')  # an explicit capture runs all its warm-up executions
+    assert float(counter) == 43
