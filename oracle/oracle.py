@@ -359,6 +359,54 @@ class Oracle:
         den.reshape(-1)[mask] += 1
         return acc, den, mr
 
+    def lbs_weights_kernel(self, nn_dist, indices, kernel_radius, kernel_weight=None, g_weights=None):
+        """the `weighted_kernel` / `kernel` branch of calc_LBS_weight (networks/sk_gs.py:759-766):
+        ``u = exp(-d / (2 r[idx]^2)) [* s[idx]] + 1e-7;  w = u / sum_k u`` with r = kernel_radius (= exp(_sp_radius),
+        sk_gs.py:547-549) and s = kernel_weight (= sigmoid(_sp_weight)).  With ``g_weights`` also the analytic gradients
+        (what autograd gives the reference): dict(g_dist [P,K], g_radius [M], g_weight [M])."""
+        d, idx = self.r(nn_dist).astype(np.float64), np.asarray(indices)
+        r, M = self.r(kernel_radius).astype(np.float64), len(kernel_radius)
+        e = np.exp(-d / (2 * r[idx] ** 2))
+        sk = self.r(kernel_weight).astype(np.float64)[idx] if kernel_weight is not None else np.ones_like(e)
+        u = e * sk + 1e-7
+        ssum = u.sum(axis=1, keepdims=True)
+        w = u / ssum
+        if g_weights is None:
+            return w.astype(self.dtype)
+        g = self.r(g_weights).astype(np.float64)
+        g_u = (g - (g * w).sum(axis=1, keepdims=True)) / ssum
+        g_e, g_sk = g_u * sk, g_u * e
+        g_d = g_e * e * (-1.0 / (2 * r[idx] ** 2))
+        g_r_pk = g_e * e * (d / r[idx] ** 3)
+        g_radius, g_weight = np.zeros(M), np.zeros(M)
+        np.add.at(g_radius, idx.reshape(-1), g_r_pk.reshape(-1))
+        np.add.at(g_weight, idx.reshape(-1), g_sk.reshape(-1))
+        return w.astype(self.dtype), dict(g_dist=g_d.astype(self.dtype), g_radius=g_radius.astype(self.dtype),
+                                          g_weight=g_weight.astype(self.dtype) if kernel_weight is not None else None)
+
+    def lbs_weights_dist(self, nn_dist, temperature=1.0, g_weights=None):
+        """the `dist` branch (networks/sk_gs.py:769-770): ``w = softmax_k(-d / temperature)``; with ``g_weights`` also
+        g_dist [P,K]"""
+        d = self.r(nn_dist).astype(np.float64)
+        l = -d / temperature
+        e = np.exp(l - l.max(axis=1, keepdims=True))
+        w = e / e.sum(axis=1, keepdims=True)
+        if g_weights is None:
+            return w.astype(self.dtype)
+        g = self.r(g_weights).astype(np.float64)
+        g_l = w * (g - (g * w).sum(axis=1, keepdims=True))
+        return w.astype(self.dtype), (-g_l / temperature).astype(self.dtype)
+
+    def knn_dist_backward(self, points, joints, indices, g_dist):
+        """gradient of the squared distances d[n,k] = |p_n - j_idx[n,k]|^2 (pytorch3d.knn_points backward, sk_gs.py:757)
+        w.r.t. points [P,dim] and joints [M,dim]"""
+        p, j, idx = self.r(points).astype(np.float64), self.r(joints).astype(np.float64), np.asarray(indices)
+        diff = p[:, None, :] - j[idx]
+        gd = self.r(g_dist).astype(np.float64)[..., None] * 2.0 * diff
+        g_j = np.zeros_like(j)
+        np.add.at(g_j, idx.reshape(-1), -gd.reshape(-1, j.shape[1]))
+        return gd.sum(axis=1).astype(self.dtype), g_j.astype(self.dtype)
+
     def lbs_weights(self, sp_W, indices):
         """``torch.gather(sp_W, 1, indices).softmax(-1)`` (networks/sk_gs.py:769-770) in numpy"""
         l = np.take_along_axis(self.r(sp_W), np.asarray(indices), axis=1)

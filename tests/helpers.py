@@ -27,6 +27,9 @@ def frac_outliers(a, b, rtol, atol) -> float:
     return float((np.abs(a - b) > atol + rtol * np.abs(b)).mean())
 
 
+OBSERVED = []  # (name, elements, fraction over tol, tol, max error): what the comparisons actually saw (conftest dumps it)
+
+
 def assert_close_robust(a, b, tol=1e-4, outlier_frac=1e-4, hard=3e-2, name=''):
     """max-norm-relative comparison that tolerates threshold flips.
 
@@ -40,6 +43,9 @@ def assert_close_robust(a, b, tol=1e-4, outlier_frac=1e-4, hard=3e-2, name=''):
     scale = max(np.abs(b).max(), 1e-30)
     d = np.abs(a - b) / scale
     frac = float((d > tol).mean())
+    OBSERVED.append(dict(name=name, elements=int(d.size), tol=tol, frac_over_tol=frac, allowed_frac=outlier_frac,
+                         max_err=float(d.max()), hard=hard))
+    print(f'[parity] {name}: {frac:.3e} of {d.size} elements over {tol:g} (allowed {outlier_frac:g}), max {d.max():.3e}')
     assert frac <= outlier_frac, f'{name}: {frac:.2e} of the elements exceed {tol} (max {d.max():.2e})'
     assert d.max() <= hard, f'{name}: max rel err {d.max():.2e} > {hard}'
 

@@ -311,3 +311,97 @@ def test_calc_lbs_weight_W_method_one_launch_matches_torch():
     (g1,) = torch.autograd.grad(w, sp_W, cot)
     (g2,) = torch.autograd.grad(w_ref, ref_W, cot)
     assert rel_err(g1, g2) <= 2e-6
+
+
+@pytest.mark.parametrize('P,M,K,dim', [(4000, 20, 5, 3), (1500, 512, 5, 11)])
+def test_kernel_and_dist_lbs_weightings_match_oracle(oracle32, P, M, K, dim):
+    """the two distance-based branches of calc_LBS_weight (networks/sk_gs.py:759-766 `weighted_kernel` / `kernel`,
+    :769-770 `dist`), on xyz and on the 11-dimensional [xyz | hyper feature] space of the sp stage (:753-755): HIP KNN +
+    torch glue against the oracle's restatement, forward and the gradients autograd hands to the joints, radii and
+    weights"""
+    from sk_gs_amd.deform import calc_lbs_weight
+    gen = torch.Generator().manual_seed(P + M)
+    pts3, jts3 = torch.randn(P, 3, generator=gen), torch.randn(M, 3, generator=gen)
+    feat, jfeat = (torch.randn(P, dim - 3, generator=gen), torch.randn(M, dim - 3, generator=gen)) if dim > 3 else (None, None)
+    radius = torch.exp(0.3 * torch.randn(M, generator=gen))
+    kweight = torch.sigmoid(torch.randn(M, generator=gen))
+    g_w = torch.randn(P, K, generator=gen)
+    c = lambda t: None if t is None else t.cuda()  # noqa: E731
+    full_p = pts3 if dim == 3 else torch.cat([pts3, feat], -1)
+    full_j = jts3 if dim == 3 else torch.cat([jts3, jfeat], -1)
+    d_ref, i_ref = oracle32.knn_bones(to_np(full_p), to_np(full_j), K)
+    for method in ('weighted_kernel', 'kernel', 'dist'):
+        jt = c(jts3).requires_grad_(True)
+        ft, jft = (c(feat).requires_grad_(True), c(jfeat).requires_grad_(True)) if dim > 3 else (None, None)
+        rad, kw = c(radius).requires_grad_(True), c(kweight).requires_grad_(True)
+        kwargs = dict(kernel_radius=rad, kernel_weight=kw if method == 'weighted_kernel' else None) if method != 'dist' \
+            else dict(temperature=0.7)
+        w, idx = calc_lbs_weight(c(pts3), jt, K, feature=ft, sp_feature=jft, **kwargs)
+        np.testing.assert_array_equal(to_np(idx), i_ref)
+        (w * c(g_w)).sum().backward()
+        if method == 'dist':
+            w_ref, g_dist = oracle32.lbs_weights_dist(d_ref, 0.7, to_np(g_w))
+        else:
+            w_ref, gr = oracle32.lbs_weights_kernel(d_ref, i_ref, to_np(radius), to_np(kweight) if method == 'weighted_kernel'
+                                                    else None, to_np(g_w))
+            g_dist = gr['g_dist']
+            assert rel_err(rad.grad, gr['g_radius']) <= 2e-5, method
+            if method == 'weighted_kernel':
+                assert rel_err(kw.grad, gr['g_weight']) <= 2e-5, method
+        assert rel_err(w, w_ref) <= 2e-6, method
+        g_p, g_j = oracle32.knn_dist_backward(to_np(full_p), to_np(full_j), i_ref, g_dist)
+        if dim == 3:
+            assert rel_err(jt.grad, g_j) <= 2e-5, method
+        else:  # the xyz parts are detached when features are concatenated (sk_gs.py:754-755): only the features learn
+            assert jt.grad is None
+            assert rel_err(jft.grad, g_j[:, 3:]) <= 2e-5, method
+            assert rel_err(ft.grad, g_p[:, 3:]) <= 2e-5, method
+
+
+@pytest.mark.parametrize('cfg,P,M', [(1, 100_000, 20), (2, 200_000, 32), (4, 500_000, 24)])
+def test_deform_and_knn_at_full_size(oracle32, cfg, P, M):
+    """the deform / KNN / LBS-weight kernels at BASELINE.json's full Gaussian and bone counts against the oracle (seconds
+    of CPU): KNN indices and softmax weights, the fused KNN + weights + skinning launch, and the skinning backward"""
+    from sk_gs_amd import _C, scene
+    K = 5
+    g = scene.make_gaussians(P, seed=cfg)
+    b = scene.make_bones(M, seed=cfg)
+    gen = torch.Generator().manual_seed(cfg + 100)
+    bone_T = torch.cat([0.3 * torch.randn(M, 3, generator=gen), torch.randn(M, 4, generator=gen)], -1)
+    sp_W = torch.randn(P, M, generator=gen)
+    n, c = to_np, (lambda t: t.cuda())
+    d_ref, i_ref = oracle32.knn_bones(n(g['xyz']), n(b['joints']), K)
+    w_ref = oracle32.lbs_weights(n(sp_W), i_ref)
+    dist, idx = _C.knn_bones(c(g['xyz']), c(b['joints']), K)
+    np.testing.assert_array_equal(n(idx), i_ref)
+    assert rel_err(dist, d_ref) <= 1e-6
+    ref = oracle32.lbs_deform_forward(n(g['xyz']), w_ref, i_ref, n(bone_T), n(b['d_rot']), n(b['d_scale']), n(g['xyz']),
+                                      n(g['log_scale']), n(g['rot']), n(g['opacity_logit']))
+    # the one-launch path of the training step: search + softmax + skinning
+    lib = _C.load_library()
+    import ctypes as C
+    f32 = dict(dtype=torch.float32, device='cuda')
+    o_idx, o_w = torch.empty((P, K), dtype=torch.int64, device='cuda'), torch.empty((P, K), **f32)
+    means, scales, rots, opac = (torch.empty((P, 3), **f32), torch.empty((P, 3), **f32), torch.empty((P, 4), **f32),
+                                 torch.empty((P, 1), **f32))
+    dev = {k: c(v) for k, v in dict(xyz=g['xyz'], ls=g['log_scale'], rot=g['rot'], op=g['opacity_logit'], j=b['joints'],
+                                    spw=sp_W, bT=bone_T, dr=b['d_rot'], ds=b['d_scale']).items()}
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    _C._check(lib.skgs_knn_lbs_deform_forward(
+        C.c_int32(P), C.c_int32(M), C.c_int32(K), p(dev['xyz']), p(dev['j']), p(dev['spw']), p(dev['bT']), p(dev['dr']),
+        p(dev['ds']), p(dev['xyz']), p(dev['ls']), p(dev['rot']), p(dev['op']), p(o_idx), p(o_w), p(means), p(scales),
+        p(rots), p(opac), _C._stream()))
+    np.testing.assert_array_equal(n(o_idx), i_ref)
+    assert rel_err(o_w, w_ref) <= 2e-6
+    for name, t in zip(['means', 'scales', 'rotations', 'opacity'], (means, scales, rots, opac)):
+        assert rel_err(t, ref[name]) <= 2e-6, name
+    gm, gs, gr, go = (torch.randn(P, 3, generator=gen), torch.randn(P, 3, generator=gen),
+                      torch.randn(P, 4, generator=gen), torch.randn(P, 1, generator=gen))
+    gref = oracle32.lbs_deform_backward(n(g['xyz']), w_ref, i_ref, n(bone_T), n(b['d_rot']), n(b['d_scale']),
+                                        n(g['log_scale']), n(g['rot']), n(g['opacity_logit']), n(gm), n(gs), n(gr), n(go))
+    got = _C.lbs_deform_backward(dev['xyz'], o_w, o_idx, dev['bT'], dev['dr'], dev['ds'], dev['ls'], dev['rot'], dev['op'],
+                                 c(gm), c(gs), c(gr), c(go))
+    names = ['g_weights', 'g_bone_T', 'g_bone_drot', 'g_bone_dscale', 'g_xyz', 'g_log_scale', 'g_rot', 'g_opacity_logit']
+    for name, t in zip(names, got):
+        # per-bone gradients sum 10^5..10^6 terms in fp32 in two different orders: 1e-4; per-Gaussian ones 1e-5
+        assert rel_err(t, gref[name]) <= (1e-4 if 'bone' in name else 1e-5), (name, rel_err(t, gref[name]))

@@ -133,3 +133,41 @@ def test_oracle_is_deterministic_and_threads_agree(oracle32, colmap):
         ids = a['binning']['point_list'][rg[t, 0]:rg[t, 1]].astype(np.int64)
         k = depth_bits[ids].astype(np.int64) * (1 << 32) + ids
         assert np.all(np.diff(k) > 0)
+
+
+def test_distance_based_lbs_weightings_match_torch_autograd():
+    """oracle.lbs_weights_kernel / lbs_weights_dist / knn_dist_backward (restating networks/sk_gs.py:757-770) against
+    torch autograd of the reference's own expressions, fp64 on CPU"""
+    import numpy as np
+    import torch
+    from oracle.oracle import Oracle, build
+    build()
+    o = Oracle('f64')
+    gen = torch.Generator().manual_seed(0)
+    P, M, K, dim = 300, 12, 5, 11
+    pts = torch.randn(P, dim, generator=gen, dtype=torch.float64)
+    jts = torch.randn(M, dim, generator=gen, dtype=torch.float64).requires_grad_(True)
+    radius = torch.exp(0.3 * torch.randn(M, generator=gen, dtype=torch.float64)).requires_grad_(True)
+    kweight = torch.sigmoid(torch.randn(M, generator=gen, dtype=torch.float64)).requires_grad_(True)
+    g_w = torch.randn(P, K, generator=gen, dtype=torch.float64)
+    d_ref, idx = o.knn_bones(pts.numpy(), jts.detach().numpy(), K)
+    idx_t = torch.from_numpy(idx)
+    nn_dist = (pts[:, None, :] - jts[idx_t]).square().sum(-1)
+    assert np.allclose(nn_dist.detach().numpy(), d_ref, rtol=1e-12)
+    # weighted kernel (sk_gs.py:759-766)
+    w = torch.exp(-nn_dist / (2 * radius[idx_t] ** 2)) * kweight[idx_t] + 1e-7
+    w = w / w.sum(dim=-1, keepdim=True)
+    gj, gr, gk = torch.autograd.grad((w * g_w).sum(), [jts, radius, kweight])
+    w_o, g = o.lbs_weights_kernel(d_ref, idx, radius.detach().numpy(), kweight.detach().numpy(), g_w.numpy())
+    assert np.allclose(w_o, w.detach().numpy(), rtol=1e-12, atol=1e-15)
+    assert np.allclose(g['g_radius'], gr.numpy(), rtol=1e-9, atol=1e-12) and np.allclose(g['g_weight'], gk.numpy(), rtol=1e-9, atol=1e-12)
+    _, g_j = o.knn_dist_backward(pts.numpy(), jts.detach().numpy(), idx, g['g_dist'])
+    assert np.allclose(g_j, gj.numpy(), rtol=1e-9, atol=1e-12)
+    # dist (sk_gs.py:769-770)
+    nn_dist = (pts[:, None, :] - jts[idx_t]).square().sum(-1)
+    w = torch.softmax(-nn_dist / 0.7, dim=-1)
+    gj, = torch.autograd.grad((w * g_w).sum(), [jts])
+    w_o, g_d = o.lbs_weights_dist(d_ref, 0.7, g_w.numpy())
+    assert np.allclose(w_o, w.detach().numpy(), rtol=1e-12, atol=1e-15)
+    _, g_j = o.knn_dist_backward(pts.numpy(), jts.detach().numpy(), idx, g_d)
+    assert np.allclose(g_j, gj.numpy(), rtol=1e-9, atol=1e-12)
