@@ -54,12 +54,9 @@ def alg_bytes(name, P, M, K, W, H, R):
     }.get(name)
 
 
-def cpu_baseline(cfg, seconds_budget=20.0):
-    """time the CPU oracle on the same workload (bounded sample); returns the cpu_baseline object"""
-    import numpy as np
+def _cpu_oracle():
     import tempfile
     from oracle import oracle as om
-    from sk_gs_amd import scene, skeleton
     lib = None
     try:
         out = om.build(tempfile.mkdtemp(prefix='skgs_oracle_native_'), native=True)
@@ -68,7 +65,12 @@ def cpu_baseline(cfg, seconds_budget=20.0):
             lib = None
     except Exception:
         lib = None
-    o = om.Oracle('f32', lib_path=lib)
+    return om.Oracle('f32', lib_path=lib), lib
+
+
+def _cpu_time(o, cfg, seconds_budget, max_iters=50):
+    """(iterations, seconds) of deform + rasterize forward + backward of the oracle on the workload `cfg`"""
+    from sk_gs_amd import scene, skeleton
     P, M, K, W, H = cfg['P'], cfg['M'], cfg['K'], cfg['W'], cfg['H']
     g = scene.make_gaussians(P, seed=0)
     cam = scene.make_camera(W, H, seed=0)
@@ -100,7 +102,6 @@ def cpu_baseline(cfg, seconds_budget=20.0):
             o.lbs_deform_backward(n(g['xyz']), n(w), idx, n(sk_T), n(b['d_rot']), n(b['d_scale']), n(g['log_scale']),
                                   n(g['rot']), n(g['opacity_logit']), gr['dL_dmeans3D'], gr['dL_dscales'],
                                   gr['dL_drotations'], gr['dL_dopacity'])
-        return fwd['num_rendered']
 
     one_iter()  # warm-up
     t0 = time.perf_counter()
@@ -109,11 +110,33 @@ def cpu_baseline(cfg, seconds_budget=20.0):
         one_iter()
         iters += 1
         el = time.perf_counter() - t0
-        if el > seconds_budget or iters >= 50:
+        if el > seconds_budget or iters >= max_iters:
             break
-    return dict(value=round(iters / el, 4), unit='iters/s', cores=o.num_threads(), kind='port',
-                sample=f'{iters} iterations of deform+rasterize forward+backward (no loss/Adam) of the same workload, '
-                       f'{el:.1f} s, oracle built {"-march=native" if lib else "portable"}, OpenMP')
+    return iters, el
+
+
+def cpu_baseline(cfg, seconds_budget=20.0, single_thread_workload=False):
+    """time the CPU oracle (bounded samples); returns the cpu_baseline object.  The headline value is the bench workload on
+    all host cores; beside it BASELINE config #0 (the reference's CPU-sized case) on all cores and on ONE thread, and --
+    opt-in, it takes about a minute per iteration -- the bench workload on one thread."""
+    o, lib = _cpu_oracle()
+    cores = o.num_threads()
+    iters, el = _cpu_time(o, cfg, 0.6 * seconds_budget)
+    out = dict(value=round(iters / el, 4), unit='iters/s', cores=cores, kind='port',
+               sample=f'{iters} iterations of deform+rasterize forward+backward (no loss/Adam) of the same workload, '
+                      f'{el:.1f} s, oracle built {"-march=native" if lib else "portable"}, OpenMP')
+    c0 = CONFIGS[0]
+    i0, e0 = _cpu_time(o, c0, 0.15 * seconds_budget, max_iters=200)
+    o.set_num_threads(1)
+    i1, e1 = _cpu_time(o, c0, 0.25 * seconds_budget, max_iters=50)
+    out['config0'] = dict(workload=f'{c0["name"]}: {c0["P"]} static Gaussians, {c0["W"]}x{c0["H"]}, rasterize forward+backward',
+                          all_cores=dict(value=round(i0 / e0, 3), cores=cores, iterations=i0),
+                          single_thread=dict(value=round(i1 / e1, 3), cores=1, iterations=i1), unit='iters/s')
+    if single_thread_workload:
+        i2, e2 = _cpu_time(o, cfg, 1.0, max_iters=1)
+        out['single_thread'] = dict(value=round(i2 / e2, 5), cores=1, iterations=i2, unit='iters/s')
+    o.set_num_threads(cores)
+    return out
 
 
 def main():
@@ -126,6 +149,8 @@ def main():
     ap.add_argument('--ppl', type=int, default=0, help='pixels per lane of the blend kernels (0 = heuristic)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--cpu-single-thread', action='store_true',
+                    help='also time the oracle on the bench workload with ONE thread (about a minute per iteration at config #1)')
     ap.add_argument('--ms-per-render', action='store_true', default=None,
                     help='also time rasterizer fwd+bwd alone (operator path, fixed upstream gradients, host-synchronised '
                          'per render: median / p10 / p90 of 50); default: on for a 1-GPU run')
@@ -501,42 +526,79 @@ def main():
                              GBps=round(b / (us * 1e-6) / 1e9, 1) if b else None)
     _C.profile_enable([])
 
-    ms_render = None
+    # ---- BASELINE's second metric and the reference's FPS protocol (test.py:56-81,102-123: warm-up, then N renders between
+    # two events): 20 warm-up + 200 timed iterations, HIP events on the launch stream
+    ms_render, fps = None, None
     if args.ms_per_render is None:
         args.ms_per_render = world == 1
     if args.ms_per_render:
         from sk_gs_amd.renderer.gaussian_render import render
+        NW, NT = 20, 200
         with torch.no_grad():
             net = {k: v.detach() for k, v in model(0).items()}
         gcol, gop = torch.randn(3, H, W, device=dev), torch.randn(H, W, device=dev)
         ins = {k: v.clone().requires_grad_(True) for k, v in net.items()}
-        times = []
-        for i in range(60):
-            torch.cuda.synchronize()
-            s = time.perf_counter()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(NT)]
+        for i in range(NW + NT):  # rasterizer forward + backward with fixed upstream gradients, operator path, no host sync
+            if i >= NW:
+                ev[i - NW][0].record()
             o = render(**ins, raster_settings=settings[0])
             torch.autograd.backward([o['images'], o['opacity']], [gcol, gop])
+            if i >= NW:
+                ev[i - NW][1].record()
+        torch.cuda.synchronize()
+        times = sorted(a.elapsed_time(b_) for a, b_ in ev)
+        ms_render = dict(median=round(times[NT // 2], 4), p10=round(times[NT // 10], 4), p90=round(times[9 * NT // 10], 4),
+                         protocol=f'{NW} warm-up + {NT} timed iterations, one HIP event pair per iteration')
+        # forward-only render rate, the reference's FPS (deform network + skinning + rasterize + background, no_grad)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.no_grad():
+            for i in range(NW + NT):
+                if i == NW:
+                    e0.record()
+                model.render(settings[i % args.views], time_id=i % frames, background=background)
+            e1.record()
+        torch.cuda.synchronize()
+        fps = dict(operator_path=round(NT * 1000.0 / e0.elapsed_time(e1), 1),
+                   protocol=f'test.py:102-123: {NW} warm-up + {NT} renders between two events, views cycled')
+        if not args.autograd:  # the same forward through the fused step (direct C-ABI calls), one graph replay per render
+            g_fwd = GraphedSteps(lambda v: fstep.forward(*(fb_args(v)[:2])))
+            for v in capture_views:
+                select(v)
+                g_fwd.capture(gkey(v))
+            for i in range(NW + NT):
+                if i == NW:
+                    e0.record()
+                select(i % args.views)
+                g_fwd(gkey(i % args.views))
+            e1.record()
             torch.cuda.synchronize()
-            times.append((time.perf_counter() - s) * 1e3)
-        times = sorted(times[10:])
-        ms_render = dict(median=round(times[len(times) // 2], 4), p10=round(times[len(times) // 10], 4),
-                         p90=round(times[9 * len(times) // 10], 4))
+            fps['fused_step_graph'] = round(NT * 1000.0 / e0.elapsed_time(e1), 1)
 
     if rank == 0:
         rb_ms, rb_n = prof.get('render_backward', (0.0, 0))
         rb_us = rb_ms / max(rb_n, 1) * 1e3
         rb_bytes = alg_bytes('render_backward', P, M, K, W, H, R_mean)
         achieved = rb_bytes / (rb_us * 1e-6) / 1e9 if rb_us > 0 else 0.0
-        traffic, valu_busy = None, None
+        # counters are not collected in this run: what the last committed PMC profile of this kernel says goes under
+        # `from_profile`, with the file and the commit it was taken at (tools/pmc_summary.py writes both)
+        from_profile = None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_render_backward.json')
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
                 if rec.get('config') == cfg['name']:
-                    traffic = rec.get('hbm_bytes_per_launch')
-                    valu_busy = rec.get('valubusy')
+                    from_profile = {k: rec.get(k) for k in ('file', 'commit', 'hbm_bytes_per_launch', 'valubusy',
+                                                            'valuutilization', 'valu_insts_per_launch', 'avg_us') if k in rec}
+                    if rec.get('valu_insts_per_launch') and rec.get('avg_us'):
+                        # VALU issue roofline: wave-instructions per second against 256 CUs x 4 SIMDs x one wave64
+                        # instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles on a SIMD-32)
+                        peak = 256 * 4 * 2.4e9 / 2
+                        ach = rec['valu_insts_per_launch'] / (rec['avg_us'] * 1e-6)
+                        from_profile['valu'] = dict(bound='valu', achieved=round(ach / 1e9, 1), peak=round(peak / 1e9, 1),
+                                                    unit='G wave-instructions/s', frac=round(ach / peak, 4))
             except Exception:
-                traffic = None
+                from_profile = None
         line = {
             'metric': 'train iters/sec (deform + rasterize fwd+bwd + L1/SSIM loss + Adam; ms/render fwd+bwd beside it), '
                       f'{P // 1000}k Gaussians @{W}x{H}',
@@ -568,11 +630,13 @@ def main():
                        'replicas_identical': replicas_identical, 'param_digest': param_digest},
             'roofline': {'bound': 'hbm', 'kernel': 'render_backward', 'achieved': round(achieved, 2),
                          'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 5),
-                         'traffic': traffic, 'avg_us': round(rb_us, 2), 'launches': rb_n,
-                         'alg_bytes_per_launch': int(rb_bytes),
-                         'valu_busy_pct': round(valu_busy, 1) if valu_busy else None,
-                         'note': 'blend kernels are VALU/LDS/atomic-bound, not HBM-bound (SURVEY 8d caveat); '
-                                 'streaming kernels are listed under "kernels"'},
+                         'traffic': None, 'avg_us': round(rb_us, 2), 'launches': rb_n,
+                         'alg_bytes_per_launch': int(rb_bytes), 'limiter': 'valu',
+                         'from_profile': from_profile,
+                         'note': 'the dominant kernel is VALU-issue bound, not HBM-bound (SURVEY 8d caveat): the HBM '
+                                 'fraction above is the contract figure, from_profile.valu the one that bounds it; '
+                                 'streaming kernels are listed under "kernels" with their GB/s; traffic is null because no '
+                                 'counter is collected in this run (see from_profile)'},
             'kernels': kernels,
         }
         if ms_render:
@@ -581,11 +645,12 @@ def main():
                    'render_backward', 'preprocess_backward')
             ms_render['kernel_sum'] = round(sum(kernels[k]['us'] * kernels[k]['launches_per_step']
                                                 for k in ras if k in kernels) / 1e3, 4)
-            ms_render['how'] = 'operator path render() + backward, eager, host-synchronised per render; kernel_sum: the ' \
-                               'rasterizer kernels of the fused step'
+            ms_render['how'] = 'operator path render() + backward, eager launches, no host synchronisation; kernel_sum: ' \
+                               'the rasterizer kernels of the fused step'
             line['ms_per_render_fwd_bwd'] = ms_render
+            line['fps_forward_render'] = fps
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(cfg, args.cpu_seconds)
+            line['cpu_baseline'] = cpu_baseline(cfg, args.cpu_seconds, args.cpu_single_thread)
         os.write(json_fd, (json.dumps(line) + '\n').encode())
     if use_dist:
         dist.barrier()

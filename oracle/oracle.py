@@ -75,6 +75,10 @@ class Oracle:
     def num_threads(self) -> int:
         return int(self._fn('num_threads')())
 
+    def set_num_threads(self, n: int):
+        """OpenMP threads of the following calls (bench.py times the oracle on all cores and on one)"""
+        self._fn('set_num_threads')(C.c_int(int(n)))
+
     def set_exp_mode(self, mode: int):
         """0: libm exp (literal restatement); 1: reproducible double-arithmetic exp shared with the strict HIP build"""
         self._fn('set_exp_mode')(C.c_int(mode))

@@ -1454,6 +1454,15 @@ void ORACLE(exp_array)(int n, const REAL* x, REAL* out) {
   for (int i = 0; i < n; ++i) out[i] = oexp(x[i]);
 }
 
+/* test / bench hook: number of OpenMP threads of the following calls (the single-thread CPU baseline) */
+void ORACLE(set_num_threads)(int n) {
+#ifdef _OPENMP
+  if (n >= 1) omp_set_num_threads(n);
+#else
+  (void) n;
+#endif
+}
+
 int ORACLE(num_threads)(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

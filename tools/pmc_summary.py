@@ -47,7 +47,7 @@ def main():
         rows.append((k, max(len(f), len(w)), fm, wm, (2 * fm + wm) * 1024 / 1e6, extra))
     rows.sort(key=lambda r: -r[4])
     cols = sorted({c for r in rows for c in r[5]})
-    md = [f'# HBM traffic per launch from PMC counters ({tag}, config #1: 100k Gaussians, 20 bones, 800x800)', '',
+    md = [f'# HBM traffic per launch from PMC counters ({tag}, ' + os.environ.get('SKGS_PROFILE_CONFIG', 'config #1: 100k Gaussians, 20 bones, 800x800') + ')', '',
           'Separate passes (MI355X_MICROARCH.md): `rocprofv3 --pmc FETCH_SIZE --kernel-trace ...`, `--pmc WRITE_SIZE ...`'
           + (', `--pmc ' + ' '.join(cols) + ' ...`' if cols else '') + ' on `python bench.py --steps 10 --warmup 2 --no-cpu-baseline`.',
           'Counters are in KB; gfx950 correction from the guide: `traffic = 2 * FETCH_SIZE + WRITE_SIZE`.', '',
@@ -59,10 +59,23 @@ def main():
     rb = [r for r in rows if r[0].startswith('render_backward_kernel')]
     if rb:
         k, n, fm, wm, t, extra = rb[0]
-        rec = {'config': 'hook-like-100k-800', 'kernel': 'render_backward', 'fetch_size_kb': fm, 'write_size_kb': wm,
+        import subprocess
+        try:
+            commit = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+        except Exception:
+            commit = None
+        rec = {'config': os.environ.get('SKGS_PROFILE_CONFIG', 'hook-like-100k-800'), 'kernel': 'render_backward',
+               'file': f'profiles/{tag}_pmc_hbm_traffic.md', 'commit': commit, 'fetch_size_kb': fm, 'write_size_kb': wm,
                'hbm_bytes_per_launch': int((2 * fm + wm) * 1024),
                'method': f'2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes, see {tag}_pmc_hbm_traffic.md'}
         rec.update({c.lower(): v for c, v in extra.items()})
+        if 'sq_insts_valu' in rec:
+            rec['valu_insts_per_launch'] = rec['sq_insts_valu']
+        # average kernel duration from the --stats pass of the same profile (profiles/<tag>_kernel_stats_*.csv)
+        for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', f'{tag}_kernel_stats*.csv'))):
+            for r in csv.DictReader(open(f)):
+                if 'render_backward_kernel' in r.get('Name', ''):
+                    rec['avg_us'] = float(r['AverageNs']) / 1e3
         json.dump(rec, open(os.path.join(ROOT, 'profiles', 'pmc_render_backward.json'), 'w'), indent=1)
     print('\n'.join(md[:14]))
 
