@@ -3,10 +3,13 @@
 sk_gs_amd.  One process per GPU (`python -m torch.distributed.run --nproc-per-node N examples/train_views.py`) or a
 single process.
 
-    FusedViewStep   : bone chain -> KNN / LBS weights -> skinning -> rasterize -> 0.8 L1 + 0.2 (1 - SSIM) -> backward,
-                      all as direct calls into libskgs_hip.so, gradients written into the parameters' .grad
+    FusedViewStep   : deform network -> bone chain -> KNN / LBS weights -> skinning -> rasterize -> 0.8 L1 + 0.2 (1 - SSIM)
+                      -> backward, all as direct calls into libskgs_hip.so, gradients written into the parameters' .grad
     FusedAdam       : every parameter group in one launch (eps = 1e-15, the reference's learning-rate ratios)
-    GraphedSteps    : the whole step replayed as one hipGraph per training view (two per view with > 1 rank)
+    ViewTable       : camera, time and target of every view as a device record; `select(v)` + ONE captured hipGraph
+                      (two with > 1 rank: the all-reduce sits between them) serve all views
+    OverflowGuard   : a forward whose tile lists outgrew the binning capacity is detected, the state rolled back to the
+                      last snapshot, the capacity grown and the iterations redone
     ViewParallel / BucketedGradReducer / ShFactorExchange : one RCCL all-reduce (+ one small all-gather) per step
 """
 import argparse
@@ -34,7 +37,9 @@ def main():
     from sk_gs_amd.fused_step import FusedViewStep
     from sk_gs_amd.model import SkinnedGaussians
     from sk_gs_amd.optim import FusedAdam, position_lr
+    from sk_gs_amd.overflow import OverflowGuard
     from sk_gs_amd.train_step import GraphedSteps
+    from sk_gs_amd.view_slot import ViewTable
     from sk_gs_amd.view_parallel import BucketedGradReducer, ShFactorExchange, ViewParallel, init_distributed
 
     rank, world, local_rank = init_distributed()
@@ -42,8 +47,8 @@ def main():
     dev = torch.device('cuda', local_rank)
     P, M, W = args.gaussians, args.bones, args.size
     # "ground truth": a scene rendered from a second, perturbed set of parameters
-    teacher = SkinnedGaussians(P, M, 4, num_frames=args.views, seed=1).to(dev)
-    model = SkinnedGaussians(P, M, 4, num_frames=args.views, seed=1).to(dev)
+    teacher = SkinnedGaussians(P, M, 4, num_frames=args.views, seed=1, deform_net=True).to(dev)
+    model = SkinnedGaussians(P, M, 4, num_frames=args.views, seed=1, deform_net=True).to(dev)
     with torch.no_grad():
         model._features_dc.mul_(0.5)
         model._opacity.sub_(0.5)
@@ -53,20 +58,24 @@ def main():
     _C.config.sync_num_rendered = True
     with torch.no_grad():
         outs = [teacher.render(views[v], time_id=v, background=bg) for v in range(args.views)]
-    targets = [o['images'].contiguous() for o in outs]
-    capacity = int(max(o['buffer'].R for o in outs) * 2.5) + 4096
+    table = ViewTable(views, [float(model.frame_times[v]) for v in range(args.views)], list(range(args.views)),
+                      torch.stack([o['images'] for o in outs]).contiguous(), dev)
+    capacity = [int(max(o['buffer'].R for o in outs) * 1.5) + 4096]  # grown by the overflow guard when it stops fitting
 
     opt = FusedAdam(model.param_groups(lr=args.lr), eps=1e-15)
 
     def build_runtime():
         """everything sized by the number of Gaussians: gradient buffers, step workspaces, captured graphs"""
-        cap = capacity * model.P // P + 4096
+        cap = capacity[0] * model.P // P + 4096
         if world == 1:
             vp = ViewParallel(model.parameters())               # p.grad -> views of one flat buffer
-            step = FusedViewStep(model, W, W, capacity=cap, background=bg, densify_stats=True)
-            step.forward_backward(views[0], 0, targets[0])        # warm-up outside any capture
+            step = FusedViewStep(model, W, W, capacity=cap, background=bg, densify_stats=True, view_table=table)
             opt.rebind()                                          # the .grad tensors moved
-            run = GraphedSteps(lambda v: (step.forward_backward(views[v], v, targets[v]), opt.step()))
+            g_all = GraphedSteps(lambda _: (step.forward_backward(), opt.step()))
+
+            def run(v):                                           # ONE graph: the view is a device record
+                table.select(v)
+                g_all(0)
         else:
             # what crosses the wire per step: one all-reduce of everything except the SH coefficients and the dense LBS
             # logits (those two travel as 6 + K floats per Gaussian: factors all-gathered, compact logit gradient reduced)
@@ -77,14 +86,14 @@ def main():
                 p.grad = torch.zeros_like(p)
             ex = ShFactorExchange(model.P, dev)
             step = FusedViewStep(model, W, W, capacity=cap, background=bg, grad_scale=1.0 / world, densify_stats=True,
-                                 spw_logit_grad=red.extra_views[0], sh_factors=ex.local)
-            step.forward_backward(views[0], 0, targets[0])
+                                 spw_logit_grad=red.extra_views[0], sh_factors=ex.local, view_table=table)
             opt.rebind()
-            g_fb = GraphedSteps(lambda v: step.forward_backward(views[v], v, targets[v]))
+            g_fb = GraphedSteps(lambda _: step.forward_backward())
             g_opt = GraphedSteps(lambda _: (step.sh_grads_from_factors(ex.all, 3), step.scatter_spw_grad(), opt.step()))
 
             def run(v):
-                g_fb(v)
+                table.select(v)
+                g_fb(0)
                 w = red.allreduce(0)
                 ex.gather()
                 w.wait()
@@ -93,22 +102,36 @@ def main():
         return vp, step, run
 
     vp, step, run = build_runtime()
+    guard = OverflowGuard(step, opt, every=50)
     gen = torch.Generator(device=dev).manual_seed(1234)          # same samples on every rank
-    for it in range(args.iters):
+    it = 0
+    while it < args.iters:
         run(vp.view_index(it, args.views))
+        act = guard.after_step(it)
+        if act is not None:   # some forward since the last snapshot dropped splats: state is rolled back, redo from there
+            capacity[0] *= 2
+            vp, step, run = build_runtime()
+            guard.rebind(step)
+            if rank == 0:
+                print(f'iter {it:5d}  binning capacity overflow: redoing from iteration {act[1]} with capacity x2')
+            it = act[1]
+            continue
         if it % 100 == 0:  # update_learning_rate (gaussian_splatting.py:455-465): the captured Adam step reads the new rate
             opt.set_lr('xyz', position_lr(it, args.lr * 0.16, args.lr * 0.0016, max_steps=30_000, delay_mult=0.01))
+        if rank == 0 and (it % 100 == 0 or it == args.iters - 1):
+            l = step.loss3.tolist()                               # synchronises
+            print(f'iter {it:5d}  loss {l[0]:.5f}  (L1 {l[1]:.5f}, SSIM {l[2]:.4f})  {step.status()}')
         if args.densify_every and it > 0 and it % args.densify_every == 0 and it < args.iters - 1:
             vp.allreduce_densify_stats(step.xyz_gradient_accum, step.denom, step.max_radii2D)
             before = model.P
             densify.densify(model, opt, step, max_grad=2e-4, extent=4.0, generator=gen)
             densify.prune(model, opt, step, min_opacity=0.005, extent=4.0, max_screen_size=0.25 * W)
             vp, step, run = build_runtime()                      # P changed
+            guard = OverflowGuard(step, opt, every=50)
+            guard.checkpoint(it + 1)
             if rank == 0:
                 print(f'iter {it:5d}  densify: {before} -> {model.P} Gaussians')
-        if rank == 0 and (it % 100 == 0 or it == args.iters - 1):
-            l = step.loss3.tolist()                               # synchronises
-            print(f'iter {it:5d}  loss {l[0]:.5f}  (L1 {l[1]:.5f}, SSIM {l[2]:.4f})  {step.status()}')
+        it += 1
     if rank == 0:
         print('visible at least once:', int((step.denom > 0).sum()), 'of', model.P, 'Gaussians; max screen radius',
               float(step.max_radii2D.max()))

@@ -45,6 +45,11 @@ extern "C" {
 #define SKGS_VERSION 1
 #define SKGS_TILE 16             /* BLOCK_X = BLOCK_Y, gaussian_render.h:29-30 */
 #define SKGS_MAX_RENDER_EXTRA 4  /* E <= 4 in renderCUDA_{forward,backward}, gaussian_render.cu:117-139 */
+/* Bone count up to which the one-launch skinning paths apply (skgs_knn_lbs_deform_forward, skgs_lbs_deform_backward_logits and
+ * the LDS-staged dense logit gradient): they keep per-workgroup bone tables / gradient rows in LDS.  Beyond it (the 512
+ * superpoints of the sp stage) callers use the separate entry points, which have no bone limit. */
+#define SKGS_FUSED_LBS_MAX_BONES 60
+#define SKGS_FUSED_LBS_MAX_K 8
 
 typedef void* skgs_stream_t; /* hipStream_t */
 
@@ -356,9 +361,11 @@ void skgs_set_mlp_columns(int ncol);
 /* ---- densification statistics of one training view (scope row (f)-4) ----
  * networks/sk_gs.py:1990-1997 + networks/gaussian_splatting.py:503-513: for every Gaussian with radii > 0
  *   max_radii2D = max(max_radii2D, radii); xyz_gradient_accum += |grad_means2D[:, :2]|; denom += 1.
- * grad_means2D [P,3] is dL_dmeans2D of skgs_rasterize_backward (`viewspace_points.grad`); accum, denom [P,1]. */
-int skgs_densify_stats(int32_t P, const int32_t* radii, const float* grad_means2D, float* xyz_gradient_accum, float* denom,
-    float* max_radii2D, skgs_stream_t stream);
+ * grad_means2D [P,3] is dL_dmeans2D of skgs_rasterize_backward (`viewspace_points.grad`); accum, denom [P,1].
+ * grad_multiplier scales the norm before it is accumulated: view-parallel training seeds its backward with 1 / world (so
+ * that the gradients arrive pre-averaged), the statistic must see the UNSCALED gradient -- pass world there, 1 otherwise. */
+int skgs_densify_stats(int32_t P, const int32_t* radii, const float* grad_means2D, float grad_multiplier,
+    float* xyz_gradient_accum, float* denom, float* max_radii2D, skgs_stream_t stream);
 
 /* Tuning knob of the blend kernels: pixels handled per lane (1, 2 or 4); 0 = heuristic on the tile count. */
 void skgs_set_pixels_per_lane(int ppl);
@@ -373,6 +380,7 @@ int skgs_profile_kernel_count(void);
 const char* skgs_profile_kernel_name(int kernel_id);
 int skgs_profile_collect(int kernel_id, double* total_ms, int32_t* launches);
 
+int skgs_fused_lbs_max_bones(void); /* = SKGS_FUSED_LBS_MAX_BONES of the loaded library */
 const char* skgs_last_error(void);
 int skgs_version(void);
 

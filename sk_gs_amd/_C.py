@@ -213,9 +213,12 @@ def profile_collect() -> dict:
     return out
 
 
-def densify_stats(radii: Tensor, grad_means2D: Tensor, xyz_gradient_accum: Tensor, denom: Tensor, max_radii2D: Tensor):
+def densify_stats(radii: Tensor, grad_means2D: Tensor, xyz_gradient_accum: Tensor, denom: Tensor, max_radii2D: Tensor,
+                  grad_multiplier: float = 1.0):
     """In-place densification statistics of one view (``add_densification_stats`` + the ``max_radii2D`` update,
-    networks/gaussian_splatting.py:503-513, networks/sk_gs.py:1990-1997) in one launch."""
+    networks/gaussian_splatting.py:503-513, networks/sk_gs.py:1990-1997) in one launch.  ``grad_multiplier`` undoes a
+    pre-scaled backward (view-parallel training seeds it with 1 / world): the statistic is defined on the unscaled
+    screen-space gradient."""
     lib = load_library()
     _require_gpu(radii, 'radii')
     P = radii.shape[0]
@@ -225,7 +228,7 @@ def densify_stats(radii: Tensor, grad_means2D: Tensor, xyz_gradient_accum: Tenso
     if radii.dtype != torch.int32 or any(t.dtype != torch.float32 for t in (grad_means2D, xyz_gradient_accum, denom, max_radii2D)):
         raise SkgsError('densify_stats: radii int32, the others float32')
     _check(lib.skgs_densify_stats(C.c_int32(P), C.c_void_p(_ptr(radii)), C.c_void_p(_ptr(grad_means2D)),
-                                  C.c_void_p(_ptr(xyz_gradient_accum)), C.c_void_p(_ptr(denom)),
+                                  C.c_float(float(grad_multiplier)), C.c_void_p(_ptr(xyz_gradient_accum)), C.c_void_p(_ptr(denom)),
                                   C.c_void_p(_ptr(max_radii2D)), _stream()))
 
 

@@ -119,6 +119,7 @@ int skgs_profile_collect(int kid, double* total_ms, int32_t* launches) {
   return 0;
 }
 
+int skgs_fused_lbs_max_bones(void) { return SKGS_FUSED_LBS_MAX_BONES; }
 const char* skgs_last_error(void) { return g_err; }
 int skgs_version(void) { return SKGS_VERSION; }
 

@@ -578,6 +578,37 @@ __global__ void __launch_bounds__(256) lbs_weights_backward_kernel(int P, int M,
   for (size_t i = threadIdx.x; i < n; i += 256) dst[i] = s_rows[i];
 }
 
+// Many bones (the 512 superpoints of the sp stage, networks/sk_gs.py:830-856; exps/default.yaml num_superpoints): a [256][M]
+// row staging does not fit LDS.  One thread per four consecutive columns of a row: it writes the sum of the (at most K)
+// logit gradients whose bone id falls on its columns, zeros otherwise -- the [P,M] gradient leaves as whole 16-byte
+// stores, the K ids / gradients of a row are re-read from L1 by the M/4 threads that share it.
+template <bool SOFTMAX_BACKWARD>
+__global__ void __launch_bounds__(256) lbs_logits_dense_wide_kernel(int P, int M, int K, const float* __restrict__ weights,
+    const int64_t* __restrict__ indices, const float* __restrict__ g_in /* g_weights, or g_logits */,
+    float* __restrict__ g_sp_W) {
+  const int M4       = (M + 3) >> 2;
+  const long long t  = (long long) blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long) P * M4) return;
+  const int p = (int) (t / M4), m0 = 4 * (int) (t - (long long) p * M4);
+  float dot = 0.f;
+  if (SOFTMAX_BACKWARD)
+    for (int k = 0; k < K; ++k) dot += weights[(size_t) p * K + k] * g_in[(size_t) p * K + k];
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < K; ++k) {
+    const int j = (int) indices[(size_t) p * K + k] - m0;
+    if (j >= 0 && j < 4) {
+      const float g = SOFTMAX_BACKWARD ? weights[(size_t) p * K + k] * (g_in[(size_t) p * K + k] - dot) : g_in[(size_t) p * K + k];
+      v[j] += g;
+    }
+  }
+  float* dst = g_sp_W + (size_t) p * M + m0;
+  if ((M & 3) == 0) {
+    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    for (int c = 0; c < 4 && m0 + c < M; ++c) dst[c] = v[c];
+  }
+}
+
 // The same backward in two halves, for view-parallel training: g_logits [P,K] (compact: what the ranks all-reduce,
 // K/M of the dense size -- the KNN indices are identical on every rank) and its expansion into the dense [P,M] rows.
 __global__ void __launch_bounds__(256) lbs_weights_backward_compact_kernel(int P, int K, const float* __restrict__ weights,
@@ -850,7 +881,13 @@ int launch_lbs_weights_forward(int P, int M, int K, const float* sp_W, const int
 int launch_lbs_weights_backward(int P, int M, int K, const float* weights, const int64_t* indices, const float* g_weights,
     float* g_sp_W, hipStream_t s) {
   if (P == 0 || M == 0) return 0;
-  if ((size_t) M * 256 * 4 > 60 * 1024) return set_error("lbs_weights_backward: M = %d too large (<= 60)", M);
+  if (M > SKGS_FUSED_LBS_MAX_BONES) {  // superpoint-sized M: no LDS row staging
+    const long long n = (long long) P * ((M + 3) / 4);
+    hipLaunchKernelGGL(lbs_logits_dense_wide_kernel<true>, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, P, M, K, weights,
+        indices, g_weights, g_sp_W);
+    SKGS_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(lbs_weights_backward_kernel, dim3((P + 255) / 256), dim3(256), (size_t) M * 256 * 4, s, P, M, K, weights,
       indices, g_weights, g_sp_W);
   SKGS_CHECK_HIP(hipGetLastError());
@@ -918,7 +955,13 @@ int launch_lbs_weights_backward_compact(int P, int K, const float* weights, cons
 int launch_lbs_logits_scatter(int P, int M, int K, const int64_t* indices, const float* g_logits, float* g_sp_W,
     hipStream_t s) {
   if (P == 0 || M == 0) return 0;
-  if ((size_t) M * 256 * 4 > 60 * 1024) return set_error("lbs_logits_scatter: M = %d too large (<= 60)", M);
+  if (M > SKGS_FUSED_LBS_MAX_BONES) {
+    const long long n = (long long) P * ((M + 3) / 4);
+    hipLaunchKernelGGL(lbs_logits_dense_wide_kernel<false>, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, P, M, K, nullptr,
+        indices, g_logits, g_sp_W);
+    SKGS_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(lbs_logits_scatter_kernel, dim3((P + 255) / 256), dim3(256), (size_t) M * 256 * 4, s, P, M, K, indices,
       g_logits, g_sp_W);
   SKGS_CHECK_HIP(hipGetLastError());

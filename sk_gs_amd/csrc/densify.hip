@@ -16,15 +16,16 @@ namespace skgs {
 namespace {
 
 __global__ void __launch_bounds__(256) densify_stats_kernel(int P, const int32_t* __restrict__ radii,
-    const float* __restrict__ grad_means2D /*[P,3]*/, float* __restrict__ xyz_gradient_accum, float* __restrict__ denom,
-    float* __restrict__ max_radii2D) {
+    const float* __restrict__ grad_means2D /*[P,3]*/, float mult, float* __restrict__ xyz_gradient_accum,
+    float* __restrict__ denom, float* __restrict__ max_radii2D) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= P) return;
   const int r = radii[i];
   if (r <= 0) return;
   const float gx = grad_means2D[3 * i], gy = grad_means2D[3 * i + 1];
   max_radii2D[i]        = fmaxf(max_radii2D[i], (float) r);
-  xyz_gradient_accum[i] = xyz_gradient_accum[i] + sqrtf(gx * gx + gy * gy);
+  const float nrm       = sqrtf(gx * gx + gy * gy);
+  xyz_gradient_accum[i] = xyz_gradient_accum[i] + (mult == 1.0f ? nrm : mult * nrm);
   denom[i]              = denom[i] + 1.0f;
 }
 
@@ -33,13 +34,13 @@ __global__ void __launch_bounds__(256) densify_stats_kernel(int P, const int32_t
 
 using namespace skgs;
 
-extern "C" int skgs_densify_stats(int32_t P, const int32_t* radii, const float* grad_means2D, float* xyz_gradient_accum,
-    float* denom, float* max_radii2D, skgs_stream_t stream) {
+extern "C" int skgs_densify_stats(int32_t P, const int32_t* radii, const float* grad_means2D, float grad_multiplier,
+    float* xyz_gradient_accum, float* denom, float* max_radii2D, skgs_stream_t stream) {
   SKGS_REQUIRE(P >= 0, "densify_stats: P must be >= 0");
   if (P == 0) return 0;
   SKGS_REQUIRE(radii && grad_means2D && xyz_gradient_accum && denom && max_radii2D, "densify_stats: NULL argument");
   hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t) stream, P, radii, grad_means2D,
-      xyz_gradient_accum, denom, max_radii2D);
+      grad_multiplier, xyz_gradient_accum, denom, max_radii2D);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -103,8 +103,8 @@ def calc_lbs_weight(points: Tensor, joints: Tensor, K: int, sp_W: Optional[Tenso
         joints_q = torch.cat([joints.detach(), sp_feature], dim=-1)
     else:
         joints_q = joints
-        # plain `W` method on xyz: search + gather + softmax in one launch (M <= 60: the dense backward's LDS rows)
-        if sp_W is not None and kernel_radius is None and points.shape[-1] == 3 and K <= 16 and K <= sp_W.shape[1] <= 60:
+        # plain `W` method on xyz: search + gather + softmax in one launch (joint table in LDS: a few thousand bones at most)
+        if sp_W is not None and kernel_radius is None and points.shape[-1] == 3 and K <= 16 and K <= sp_W.shape[1] <= 2048:
             return _KnnSoftmaxWeights.apply(points.detach(), joints.detach(), sp_W, K)
     with torch.no_grad():
         _, indices = _C.knn_bones(points.detach(), joints_q.detach(), K)

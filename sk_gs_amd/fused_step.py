@@ -59,6 +59,13 @@ class FusedViewStep:
             raise _C.SkgsError('FusedViewStep needs the model on a HIP device; sk_gs_amd has no CPU path')
         P, M, K = model.P, model.M, model.K
         self.P, self.M, self.K = P, M, K
+        # one limit for every one-launch skinning path (the library's): beyond it -- the 512 superpoints of the sp stage --
+        # the step uses the separate KNN / weights / skinning launches, which have no bone limit
+        lib.skgs_fused_lbs_max_bones.restype = C.c_int
+        self.max_fused_bones = int(lib.skgs_fused_lbs_max_bones())
+        self.wide = M > self.max_fused_bones or K > 8
+        if K > 16 or K > M:
+            raise _C.SkgsError(f'FusedViewStep: K = {K} neighbours: the KNN kernels keep at most 16 (and K <= M = {M})')
         # view-parallel training: instead of the [P,16,3] SH gradient of this view, write its two factors here ([P,6]:
         # unit view direction, clamp-masked colour gradient); ``sh_grads_from_factors`` rebuilds the rows of ALL views
         # from the all-gathered factors (24 bytes per Gaussian and view on the wire instead of 192 all-reduced)
@@ -71,6 +78,7 @@ class FusedViewStep:
         # dL/dloss seed: 1/world_size makes the gradients arrive pre-averaged for a SUM all-reduce (view-parallel
         # training), instead of a separate division pass over the whole flat gradient buffer
         self.grad_scale = None if grad_scale == 1.0 else torch.full((1,), float(grad_scale), **f32)
+        self._grad_scale_value = float(grad_scale)
         for p in model.parameters():
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
@@ -239,6 +247,15 @@ class FusedViewStep:
             C.c_int32(t['num_levels']), _p(sk_r_raw), _p(m.joints), C.c_void_p(gT), _p(self.bone_T),
             _p(self.chain_A), fidx, st))
         d = self._deform_inputs(time_id)
+        if self.wide:  # many bones: search + softmax, then the skinning, as two launches (bone tables stay in global memory)
+            chk(lib.skgs_knn_lbs_weights(C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_void_p(d.points), _p(m.joints),
+                                         _p(m.sp_W), _p(self.indices), _p(self.weights), st))
+            chk(lib.skgs_lbs_deform_forward(C.byref(d), _p(self.means), _p(self.scales), _p(self.rotations), _p(self.opacity),
+                                            None, None, None, st))
+            a = self._raster_inputs(rs)
+            chk(lib.skgs_rasterize_forward(C.byref(a), C.byref(self._bufs), _p(self.radii), _p(self.image),
+                                           _p(self.out_opacity), None, None, st))
+            return a, d
         # K nearest bones + softmax weights + skinning + activations: one launch (weights / indices kept for the backward)
         chk(lib.skgs_knn_lbs_deform_forward(
             C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_void_p(d.points), _p(m.joints), _p(m.sp_W), C.c_void_p(d.bone_T),
@@ -324,7 +341,7 @@ class FusedViewStep:
             g_drot, g_dscale = m.sk_d_rot.grad[time_id], m.sk_d_scale.grad[time_id]
         else:  # the three heads of the producer network: their gradients feed its backward below
             sk_r_raw, (g_raw, g_drot, g_dscale) = self._sk_r_raw, self._g_heads
-        if M <= 64 and K <= 8:
+        if not self.wide:
             # skinning backward with the softmax backward of the LBS logits folded in: dense rows straight into sp_W.grad,
             # or the compact [P,K] gradient for the all-reduce
             dense = self.spw_logit_grad is None
@@ -422,9 +439,27 @@ class FusedViewStep:
     @torch.no_grad()
     def add_densification_stats(self):
         """accumulate this view's statistics (one launch); ``forward_backward`` calls it when ``densify_stats`` is set"""
+        # the backward may be pre-scaled (grad_scale = 1 / world): the statistic is the norm of the UNSCALED screen-space
+        # gradient (gaussian_splatting.py:503-513), or N ranks would densify as if max_grad were N times larger
         _C._check(self.lib.skgs_densify_stats(C.c_int32(self.P), _p(self.radii), _p(self.grad_means2D),
-                                             _p(self.xyz_gradient_accum), _p(self.denom), _p(self.max_radii2D),
-                                             _C._stream()))
+                                             C.c_float(1.0 / self._grad_scale_value), _p(self.xyz_gradient_accum),
+                                             _p(self.denom), _p(self.max_radii2D), _C._stream()))
+
+    @torch.no_grad()
+    def grow_capacity(self, factor: float = 2.0):
+        """re-allocate the binning buffer with ``factor`` times the tile-instance capacity (or slots per tile bucket).  Every
+        graph captured with the old buffer is invalid afterwards: re-capture.  The sticky overflow counter restarts at 0."""
+        lib = self.lib
+        if self.tile_bucket > 0:
+            self.tile_bucket = ((int(self.tile_bucket * factor) + 63) // 64) * 64
+            capacity = ((self.W + 15) // 16) * ((self.H + 15) // 16) * self.tile_bucket
+        else:
+            capacity = int(int(lib.skgs_binning_capacity(C.c_size_t(self.binning.numel()))) * factor) + 1024
+        self.binning = torch.empty((lib.skgs_binning_buffer_bytes(C.c_int64(int(capacity))),), dtype=torch.uint8,
+                                   device=self.binning.device)
+        self.geom[:256].zero_()
+        self._bufs = _C._buffers(self.geom, self.binning, self.img)
+        return capacity
 
     def status(self) -> dict:
         """(synchronising) num_rendered / overflow / longest tile list of the last forward, and the number of

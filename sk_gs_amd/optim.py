@@ -142,6 +142,49 @@ class FusedAdam:
         self.param_groups[group]['lr'] = float(lr)
         self._upload()
 
+    # ---------------------------------------------------------------------------------------------------------
+    def state_dict(self) -> dict:
+        """``torch.optim.Adam.state_dict()`` layout: ``state`` = {param index: {step, exp_avg, exp_avg_sq}} and
+        ``param_groups`` with ``params`` as index lists (+ ``lr``, ``name``, ``betas``, ``eps``): what the reference's
+        framework saves next to the model (my_ext/framework.py checkpointing) -- moments AND the step counter, so that a
+        resumed run continues the bias correction instead of restarting it.  (Synchronises: reads the device counter.)"""
+        index = {p: i for i, p in enumerate(self.params)}
+        step = float(self.step_count.item())
+        state = {i: dict(step=torch.tensor(step), exp_avg=self.state[p]['exp_avg'].detach().clone(),
+                         exp_avg_sq=self.state[p]['exp_avg_sq'].detach().clone()) for p, i in index.items()}
+        groups = []
+        for g in self.param_groups:
+            d = {k: v for k, v in g.items() if k != 'params'}
+            d.update(betas=tuple(self.betas), eps=self.eps, amsgrad=False, weight_decay=0)
+            d['params'] = [index[p] for p in g['params'] if p in index]
+            groups.append(d)
+        return dict(state=state, param_groups=groups)
+
+    def load_state_dict(self, sd: dict):
+        """inverse of ``state_dict`` (also accepts one saved by ``torch.optim.Adam`` over the same groups): moments by
+        parameter index, learning rates by group, the step counter from the entries' ``step`` (they must agree)"""
+        groups = sd['param_groups']
+        assert len(groups) == len(self.param_groups), 'load_state_dict: different number of parameter groups'
+        for g, saved in zip(self.param_groups, groups):
+            assert len(saved['params']) == len([p for p in g['params'] if p.requires_grad]), 'group sizes differ'
+            if 'lr' in saved:
+                g['lr'] = float(saved['lr'])
+        steps = set()
+        with torch.no_grad():
+            for i, p in enumerate(self.params):
+                st = sd['state'].get(i, sd['state'].get(str(i)))
+                if st is None:  # torch omits parameters that never received a gradient
+                    self.state[p]['exp_avg'].zero_(), self.state[p]['exp_avg_sq'].zero_()
+                    continue
+                assert tuple(st['exp_avg'].shape) == tuple(p.shape), f'parameter {i}: shape differs'
+                self.state[p]['exp_avg'].copy_(st['exp_avg'])
+                self.state[p]['exp_avg_sq'].copy_(st['exp_avg_sq'])
+                steps.add(float(st['step']))
+            assert len(steps) <= 1, f'load_state_dict: the parameters disagree on the step count {sorted(steps)} ' \
+                                    '(the fused kernel keeps ONE counter)'
+            self.step_count.fill_(steps.pop() if steps else 0.0)
+        self._upload()
+
     def zero_grad(self, set_to_none: bool = False):
         for p in self.params:
             if p.grad is not None:

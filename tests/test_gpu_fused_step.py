@@ -310,3 +310,68 @@ def test_graphed_steps_first_call_runs_the_function_once():
     assert float(counter) == 13
     g3.capture('b')  # an explicit capture runs all its warm-up executions
     assert float(counter) == 43
+
+
+def test_densification_statistics_are_those_of_the_unscaled_gradient():
+    """view-parallel training seeds the backward with 1 / world (pre-averaged gradients for the SUM all-reduce); the
+    densification statistic (gaussian_splatting.py:503-513) must still be the norm of the UNSCALED screen-space gradient:
+    two 'ranks' with grad_scale 1/2, their statistics summed as allreduce_densify_stats does, equal one rank that sees
+    both views -- accum / denom is what densify() compares with max_grad (:659-703)"""
+    from sk_gs_amd import _C, scene
+    from sk_gs_amd.fused_step import FusedViewStep
+    P, M, K, W, H, frames = 4000, 12, 4, 160, 120, 3
+    model, rs0, target = _setup(P, M, K, W, H, frames)
+    rs1 = scene.raster_settings_from_camera(scene.make_camera(W, H, seed=7), sh_degree=3, colmap=True, device='cuda')
+    _C.config.sync_num_rendered = True
+    with torch.no_grad():
+        R = max(model.render(rs, time_id=t)['buffer'].R for rs, t in ((rs0, 0), (rs1, 1)))
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    one = FusedViewStep(model, W, H, capacity=2 * R, densify_stats=True)
+    one.forward_backward(rs0, 0, target)
+    one.forward_backward(rs1, 1, target)
+    ranks = [FusedViewStep(model, W, H, capacity=2 * R, densify_stats=True, grad_scale=0.5) for _ in range(2)]
+    ranks[0].forward_backward(rs0, 0, target)
+    ranks[1].forward_backward(rs1, 1, target)
+    acc = ranks[0].xyz_gradient_accum + ranks[1].xyz_gradient_accum       # SUM
+    den = ranks[0].denom + ranks[1].denom                                 # SUM
+    rad = torch.maximum(ranks[0].max_radii2D, ranks[1].max_radii2D)       # MAX
+    assert torch.equal(den, one.denom) and torch.equal(rad, one.max_radii2D)
+    assert float(one.xyz_gradient_accum.max()) > 0
+    assert rel_err(acc, one.xyz_gradient_accum) <= 1e-5
+    # and the gradients themselves ARE pre-scaled
+    assert rel_err(ranks[1].grad_means2D * 2, one.grad_means2D) <= 1e-5
+
+
+def test_fused_step_with_superpoint_sized_bone_count_matches_autograd():
+    """M = 512 (the sp stage's num_superpoints, exps/default.yaml; calc_LBS_weight + warp over 512 nodes, sk_gs.py:830-856):
+    beyond the one-launch skinning paths' bone limit FusedViewStep uses the separate KNN / weights / skinning launches and
+    the wide dense logit gradient; results against the autograd operator path"""
+    from sk_gs_amd import _C
+    from sk_gs_amd.fused_step import FusedViewStep
+    from sk_gs_amd.losses import image_loss
+    P, M, K, W, H, frames, tid = 4000, 512, 5, 160, 120, 2, 1
+    model, rs, target = _setup(P, M, K, W, H, frames)
+    _C.config.sync_num_rendered = True
+    out = model.render(rs, time_id=tid)
+    loss = image_loss(out['images'], target)
+    loss.backward()
+    ref = {n: p.grad.clone() for n, p in model.named_parameters()}
+    R = out['buffer'].R
+    for p in model.parameters():
+        p.grad = torch.full_like(p, 9.0)
+    step = FusedViewStep(model, W, H, capacity=int(R * 1.2) + 1024)
+    assert step.wide and step.max_fused_bones == 60
+    step.forward_backward(rs, tid, target)
+    assert step.status()['overflow'] == 0
+    assert_close_robust(step.image, out['images'].detach(), 5e-6, 1e-4, name='image M=512')
+    for n, p in model.named_parameters():
+        assert_close_robust(p.grad, ref[n], 2e-4, 1e-3, name=n + ' M=512')
+    # the compact logit gradient expanded by the wide scatter kernel gives the same dense rows
+    spw = torch.zeros(P * K, device='cuda')
+    step2 = FusedViewStep(model, W, H, capacity=int(R * 1.2) + 1024, spw_logit_grad=spw)
+    dense = model.sp_W.grad.clone()
+    model.sp_W.grad.fill_(3.0)
+    step2.forward_backward(rs, tid, target)
+    step2.scatter_spw_grad()
+    assert_close_robust(model.sp_W.grad, dense, 1e-5, 1e-4, name='sp_W from compact logits, M=512')

@@ -49,3 +49,54 @@ def test_fused_adam_clears_the_requested_gradient_span_after_the_update():
     torch.cuda.synchronize()
     assert float(a.grad.min()) == 1.0 and float(b.grad.abs().max()) == 0.0
     assert float(b.data.max()) < 0.0 and float(opt.step_count.item()) == 1.0  # b was updated with the gradient first
+
+
+def test_fused_adam_state_dict_round_trip_and_torch_layout():
+    """FusedAdam.state_dict / load_state_dict in torch.optim.Adam's layout: a reloaded optimizer continues exactly where
+    the saved one stood (moments AND step counter: the bias correction goes on), and a state saved by torch.optim.Adam over
+    the same groups loads too"""
+    import copy
+    from sk_gs_amd.optim import FusedAdam
+    torch.manual_seed(0)
+
+    def make():
+        a = torch.nn.Parameter(torch.randn(1000, 3, device='cuda'))
+        b = torch.nn.Parameter(torch.randn(77, device='cuda'))
+        return a, b, [dict(params=[a], lr=1e-2, name='a'), dict(params=[b], lr=3e-3, name='b')]
+
+    a, b, groups = make()
+    opt = FusedAdam(groups, eps=1e-15)
+    ref = torch.optim.Adam([dict(params=[a.detach().clone().requires_grad_(True)], lr=1e-2),
+                            dict(params=[b.detach().clone().requires_grad_(True)], lr=3e-3)], eps=1e-15)
+    grads = [(torch.randn_like(a), torch.randn_like(b)) for _ in range(5)]
+    for ga, gb in grads[:3]:
+        a.grad, b.grad = ga.clone(), gb.clone()
+        opt.step()
+        for p, g in zip([q for grp in ref.param_groups for q in grp['params']], (ga, gb)):
+            p.grad = g.clone()
+        ref.step()
+    sd = opt.state_dict()
+    tsd = ref.state_dict()
+    assert sorted(sd['state'].keys()) == sorted(tsd['state'].keys()) == [0, 1]
+    for i in (0, 1):
+        assert float(sd['state'][i]['step']) == float(tsd['state'][i]['step']) == 3
+        assert rel_err(sd['state'][i]['exp_avg'], tsd['state'][i]['exp_avg']) <= 1e-6     # (torch's lerp vs an fma: an ulp)
+        assert rel_err(sd['state'][i]['exp_avg_sq'], tsd['state'][i]['exp_avg_sq']) <= 1e-6
+    assert [g['params'] for g in sd['param_groups']] == [[0], [1]] and sd['param_groups'][0]['name'] == 'a'
+    # fresh optimizer over copies of the current parameters + the saved state = the original, step for step
+    a2 = torch.nn.Parameter(a.detach().clone())
+    b2 = torch.nn.Parameter(b.detach().clone())
+    opt2 = FusedAdam([dict(params=[a2], lr=5.0, name='a'), dict(params=[b2], lr=5.0, name='b')], eps=1e-15)
+    opt2.load_state_dict(copy.deepcopy(sd))
+    assert float(opt2.step_count) == 3 and opt2.param_groups[0]['lr'] == 1e-2
+    for ga, gb in grads[3:]:
+        a.grad, b.grad, a2.grad, b2.grad = ga.clone(), gb.clone(), ga.clone(), gb.clone()
+        opt.step(), opt2.step()
+    assert torch.equal(a, a2) and torch.equal(b, b2)
+    # a torch.optim.Adam state loads into the fused optimizer
+    a3 = torch.nn.Parameter(a.detach().clone())
+    b3 = torch.nn.Parameter(b.detach().clone())
+    opt3 = FusedAdam([dict(params=[a3], lr=1.0, name='a'), dict(params=[b3], lr=1.0, name='b')], eps=1e-15)
+    opt3.load_state_dict(tsd)
+    assert float(opt3.step_count) == 3
+    assert torch.allclose(opt3.state[a3]['exp_avg'], tsd['state'][0]['exp_avg'].cuda())
