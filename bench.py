@@ -162,14 +162,18 @@ def main():
                     help='world > 1: two gradient buckets, the SH bucket on the wire during the skinning backward and the '
                          'second one during the Adam update of the first (4 graphs per step instead of 2: measured +58 us '
                          'of launch / stream-join overhead per step on one GPU, so it only pays when the all-reduce is slow)')
-    ap.add_argument('--dense-spw-grad', action='store_true',
-                    help='world > 1: all-reduce the dense [P,M] sp_W gradient instead of the compact [P,K] logit gradient')
+    ap.add_argument('--compact-logits', action='store_true',
+                    help='world > 1: all-reduce the compact [P,K] LBS-logit gradient and expand it afterwards instead of '
+                         'all-reducing the dense [P,M] sp_W gradient (the KNN indices are identical on every rank)')
+    ap.add_argument('--sh-factors', action='store_true',
+                    help='world > 1 (implies --compact-logits): all-gather the two factors of the SH gradient per view (24 B '
+                         'per Gaussian and rank) and rebuild the rows on every rank instead of all-reducing the dense SH '
+                         'gradient (192 B per Gaussian)')
+    ap.add_argument('--dense-spw-grad', action='store_true', help='(default since round 2; kept for old command lines)')
     ap.add_argument('--overlap-gather', action='store_true',
                     help='world > 1, factor exchange: split the backward graph after the rasterizer backward and run the '
                          'all-gather of the SH factors beside the skinning backward (one more graph launch per step)')
-    ap.add_argument('--sh-allreduce', action='store_true',
-                    help='world > 1: all-reduce the dense SH gradient (192 B per Gaussian) instead of all-gathering its two '
-                         'factors per view (24 B per Gaussian and rank) and rebuilding the rows on every rank')
+    ap.add_argument('--sh-allreduce', action='store_true', help='(default since round 2; kept for old command lines)')
     ap.add_argument('--compact-lists', action='store_true',
                     help='count -> scan -> scatter into compact tile lists (the reference layout) instead of fixed per-tile '
                          'buckets (no counting / scan launch)')
@@ -237,10 +241,13 @@ def main():
                                [v % frames for v in range(args.views)], torch.stack(targets), dev)
     fused_dist = use_dist and not args.autograd and not args.torch_adam
     pipelined = fused_dist and args.pipeline
-    compact = fused_dist and (pipelined or not args.dense_spw_grad)
-    # the SH gradient of one view is rank-1 per Gaussian (basis(view direction) x colour gradient): the ranks exchange the
-    # two factors and every rank rebuilds and sums the rows in rank order
-    sh_factored = compact and not pipelined and not args.sh_allreduce
+    # default exchange: ONE plain SUM all-reduce of the flat gradient buffer -- what the north star names and the easiest
+    # to trust on first contact with RCCL.  The byte-saving exchanges are opt-in until a multi-GPU measurement ranks them:
+    # --compact-logits, --sh-factors (the SH gradient of one view is rank-1 per Gaussian, basis(view direction) x colour
+    # gradient: the ranks exchange the two factors and every rank rebuilds and sums the rows in rank order), --pipeline
+    args.overlap_gather = args.overlap_gather and args.sh_factors
+    compact = fused_dist and (pipelined or args.compact_logits or args.sh_factors)
+    sh_factored = compact and not pipelined and args.sh_factors
     groups = model.param_groups(lr=args.lr)
     if compact:
         # the dense [P,M] sp_W gradient never goes on the wire: the ranks all-reduce the compact [P,K] logit gradient

@@ -135,7 +135,13 @@ def main():
     if rank == 0:
         print('visible at least once:', int((step.denom > 0).sum()), 'of', model.P, 'Gaussians; max screen radius',
               float(step.max_radii2D.max()))
-    if dist.is_initialized():
+    if dist.is_initialized():  # every rank applied the same reduced gradients and took the same densification decisions
+        digest = torch.stack([p.detach().double().sum() for p in model.parameters()] +
+                             [torch.tensor(float(model.P), dtype=torch.float64, device=dev)])
+        every = [torch.empty_like(digest) for _ in range(world)]
+        dist.all_gather(every, digest)
+        if rank == 0:
+            print('replicas identical:', all(torch.equal(every[0], e) for e in every))
         dist.barrier()
         dist.destroy_process_group()
 

@@ -175,7 +175,28 @@ class ShFactorExchange:
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.all = torch.zeros((self.world, P, 6), dtype=torch.float32, device=device)
         self.local = self.all[self.rank]
-        self._in_place = True
+        self._in_place = self._probe_in_place(device)
+
+    def _probe_in_place(self, device) -> bool:
+        """decide ONCE, at construction (outside any timed region), whether the in-place tensor form of the all-gather
+        works with this backend / torch build: a small collective is run to completion on every rank and the verdict is
+        all-reduced (MIN), so the ranks agree -- an asynchronous RCCL failure inside the training loop cannot be caught by
+        an ``except`` around the enqueue, and ranks taking different paths would deadlock"""
+        if not dist.is_initialized() or dist.get_backend() != 'nccl':
+            return False
+        ok = 1
+        try:
+            buf = torch.zeros((self.world, 8), dtype=torch.float32, device=device)
+            buf[self.rank] = float(self.rank + 1)
+            dist.all_gather_into_tensor(buf.view(-1), buf[self.rank].view(-1))
+            torch.cuda.synchronize(device)
+            want = torch.arange(1, self.world + 1, dtype=torch.float32, device=device)[:, None].expand(-1, 8)
+            ok = int(torch.equal(buf, want))
+        except Exception:  # noqa: BLE001 -- any failure means: use the list form
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
 
     @property
     def nbytes(self) -> int:
@@ -186,9 +207,6 @@ class ShFactorExchange:
         rebuilt) so that the exchange can run beside the skinning backward"""
         if not dist.is_initialized():
             return None
-        if self._in_place and dist.get_backend() == 'nccl':  # this rank's slice is already where it belongs
-            try:
-                return dist.all_gather_into_tensor(self.all.view(-1), self.local.view(-1), async_op=async_op)
-            except (RuntimeError, ValueError):  # an argument check of this torch build (same on every rank): list form
-                self._in_place = False
+        if self._in_place:  # this rank's slice is already where it belongs (form probed at construction)
+            return dist.all_gather_into_tensor(self.all.view(-1), self.local.view(-1), async_op=async_op)
         return dist.all_gather(list(self.all.unbind(0)), self.local, async_op=async_op)

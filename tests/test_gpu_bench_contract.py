@@ -29,12 +29,15 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert abs(d['value'] - 1000.0 / d['ms_per_step']) / d['value'] < 0.01
 
 
-@pytest.mark.parametrize('port,ranks,extra', [(29577, 2, []), (29578, 2, ['--pipeline']), (29579, 2, ['--dense-spw-grad']),
-                                              (29580, 2, ['--autograd']), (29581, 4, []), (29582, 2, ['--sh-allreduce']), (29583, 2, ['--overlap-gather']), (29584, 2, ['--deform-net'])])
+@pytest.mark.parametrize('port,ranks,extra', [(29577, 2, []), (29578, 2, ['--pipeline']), (29579, 2, ['--compact-logits']),
+                                              (29580, 2, ['--autograd']), (29581, 4, []), (29582, 2, ['--sh-factors']),
+                                              (29583, 2, ['--sh-factors', '--overlap-gather']), (29584, 2, ['--bone-tables']),
+                                              (29587, 2, ['--graph-per-view'])])
 def test_ranks_share_the_gpu_and_stay_identical(port, ranks, extra):
     """The driver's multi-GPU launch line with 2 or 4 ranks on this one GPU (gloo moves the gradients: RCCL refuses two ranks
-    per device): the real view-parallel schedule -- graph(fwd+bwd) | all-reduce | graph(expand + Adam) -- must keep the
-    replicas bit-identical and print one line from rank 0 with whole-job throughput."""
+    per device): the real view-parallel schedule -- graph(fwd+bwd) | all-reduce | graph(Adam) -- must keep the replicas
+    bit-identical and print one line from rank 0 with whole-job throughput.  Default exchange: ONE plain all-reduce of the
+    flat gradient buffer; the byte-saving exchanges are flags."""
     env = dict(os.environ, SKGS_DIST_BACKEND='gloo', SKGS_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr',
            '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--steps', '6',
@@ -46,16 +49,19 @@ def test_ranks_share_the_gpu_and_stay_identical(port, ranks, extra):
     d = json.loads(lines[0])
     assert d['n_gpus'] == ranks and d['steps'] == 6 and d['scaling'] == 'weak'
     assert d['config']['replicas_identical'] is True
+    par = d['config']['parallelism']
+    if not extra:
+        assert 'flat-buffer grad all-reduce' in par and 'compact' not in par and 'factors' not in par, par
     assert abs(d['value'] - ranks * 1000.0 / d['ms_per_step']) / d['value'] < 0.01  # whole-job: every rank's view per step
     assert 'cpu_baseline' not in d
 
 
 def test_factor_exchange_and_dense_exchange_train_the_same_parameters():
-    """two ranks, eight optimizer steps: the SH gradient exchanged as factors (default) or all-reduced densely
-    (--sh-allreduce) must leave the same parameters up to summation order"""
+    """two ranks, eight optimizer steps: the SH gradient exchanged as factors (--sh-factors) or all-reduced densely
+    (default) must leave the same parameters up to summation order"""
     env = dict(os.environ, SKGS_DIST_BACKEND='gloo', SKGS_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     digests = []
-    for port, extra in ((29585, []), (29586, ['--sh-allreduce'])):
+    for port, extra in ((29585, ['--sh-factors']), (29586, [])):
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
                '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6',
                '--warmup', '2', '--no-cpu-baseline', '--eager'] + extra
@@ -65,3 +71,17 @@ def test_factor_exchange_and_dense_exchange_train_the_same_parameters():
         assert d['config']['replicas_identical'] is True
         digests.append(d['config']['param_digest'])
     assert abs(digests[0] - digests[1]) <= 1e-7 * abs(digests[1]), digests
+
+
+def test_two_rank_training_with_densification_keeps_the_replicas_identical():
+    """examples/train_views.py on two ranks (gloo, one GPU): view-parallel steps, densification statistics all-reduced
+    (SUM, SUM, MAX) before every clone / split / prune so the ranks take identical decisions, the overflow guard in the
+    loop; at the end the ranks compare a digest of every parameter"""
+    env = dict(os.environ, SKGS_DIST_BACKEND='gloo', SKGS_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29588', os.path.join(ROOT, 'examples', 'train_views.py'), '--iters', '130', '--densify-every', '50',
+           '--gaussians', '8000', '--size', '160']
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    assert p.stdout.count('densify:') == 2, p.stdout[-1500:]
+    assert 'replicas identical: True' in p.stdout, p.stdout[-1500:]
