@@ -15,6 +15,7 @@ single process.
 import argparse
 import os
 import sys
+import time
 
 import torch
 import torch.distributed as dist
@@ -71,7 +72,7 @@ def main():
             vp = ViewParallel(model.parameters())               # p.grad -> views of one flat buffer
             step = FusedViewStep(model, W, W, capacity=cap, background=bg, densify_stats=True, view_table=table)
             opt.rebind()                                          # the .grad tensors moved
-            g_all = GraphedSteps(lambda _: (step.forward_backward(), opt.step()))
+            g_all = GraphedSteps(lambda _: (step.forward_backward(), opt.step()), collect_garbage=False)
 
             def run(v):                                           # ONE graph: the view is a device record
                 table.select(v)
@@ -88,8 +89,9 @@ def main():
             step = FusedViewStep(model, W, W, capacity=cap, background=bg, grad_scale=1.0 / world, densify_stats=True,
                                  spw_logit_grad=red.extra_views[0], sh_factors=ex.local, view_table=table)
             opt.rebind()
-            g_fb = GraphedSteps(lambda _: step.forward_backward())
-            g_opt = GraphedSteps(lambda _: (step.sh_grads_from_factors(ex.all, 3), step.scatter_spw_grad(), opt.step()))
+            g_fb = GraphedSteps(lambda _: step.forward_backward(), collect_garbage=False)
+            g_opt = GraphedSteps(lambda _: (step.sh_grads_from_factors(ex.all, 3), step.scatter_spw_grad(), opt.step()),
+                                 collect_garbage=False)
 
             def run(v):
                 table.select(v)
@@ -122,15 +124,23 @@ def main():
             l = step.loss3.tolist()                               # synchronises
             print(f'iter {it:5d}  loss {l[0]:.5f}  (L1 {l[1]:.5f}, SSIM {l[2]:.4f})  {step.status()}')
         if args.densify_every and it > 0 and it % args.densify_every == 0 and it < args.iters - 1:
+            torch.cuda.synchronize()
+            t_ev = time.perf_counter()
             vp.allreduce_densify_stats(step.xyz_gradient_accum, step.denom, step.max_radii2D)
             before = model.P
             densify.densify(model, opt, step, max_grad=2e-4, extent=4.0, generator=gen)
             densify.prune(model, opt, step, min_opacity=0.005, extent=4.0, max_screen_size=0.25 * W)
+            torch.cuda.synchronize(); t_a = time.perf_counter()
             vp, step, run = build_runtime()                      # P changed
+            torch.cuda.synchronize(); t_b = time.perf_counter()
             guard = OverflowGuard(step, opt, every=50)
             guard.checkpoint(it + 1)
+            run(vp.view_index(it, args.views))                    # (extra step: includes the one graph capture)
+            torch.cuda.synchronize()
             if rank == 0:
-                print(f'iter {it:5d}  densify: {before} -> {model.P} Gaussians')
+                print(f'iter {it:5d}  densify: {before} -> {model.P} Gaussians  (clone/split/prune + runtime rebuild + '
+                      f'graph capture: {1e3 * (time.perf_counter() - t_ev):.1f} ms; surgery {1e3 * (t_a - t_ev):.1f}, '
+                      f'rebuild {1e3 * (t_b - t_a):.1f}, capture {1e3 * (time.perf_counter() - t_b):.1f})')
         it += 1
     if rank == 0:
         print('visible at least once:', int((step.denom > 0).sum()), 'of', model.P, 'Gaussians; max screen radius',

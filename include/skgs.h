@@ -367,6 +367,19 @@ void skgs_set_mlp_columns(int ncol);
 int skgs_densify_stats(int32_t P, const int32_t* radii, const float* grad_means2D, float grad_multiplier,
     float* xyz_gradient_accum, float* denom, float* max_radii2D, skgs_stream_t stream);
 
+/* ---- densification surgery in one launch (scope row (f)-4) ----
+ * Replaces the per-tensor indexing / concatenation of change_optimizer, prune_points and densification_postfix
+ * (networks/gaussian_splatting.py:515-587) over the per-Gaussian parameters and their Adam moments: for every tensor t of
+ * the DEVICE descriptor array `tensors` (struct { const float* src; float* dst; int32 row_floats; int32 fresh_is_zero; },
+ * skgs_row_tensor_bytes() = 24)
+ *     dst_t[i, :] = src_t[rows[i], :]                          i <  n_keep   (survivors)
+ *     dst_t[i, :] = fresh_is_zero ? 0 : src_t[rows[i], :]      i >= n_keep   (new Gaussians: parameters copied from their
+ *                                                                             parent, moments zero)
+ * rows: device int64 [n_out]; max_row_floats: the largest row_floats of the table (sizes the grid). */
+size_t skgs_row_tensor_bytes(void);
+int skgs_gather_rows(int32_t n_tensors, const void* tensors, int64_t n_out, int64_t n_keep, const int64_t* rows,
+    int32_t max_row_floats, skgs_stream_t stream);
+
 /* Tuning knob of the blend kernels: pixels handled per lane (1, 2 or 4); 0 = heuristic on the tile count. */
 void skgs_set_pixels_per_lane(int ppl);
 /* Parity-test switch: blend kernels without FMA contraction, in the oracle's operation order, reproducible exp. */

@@ -128,6 +128,8 @@ def _ptr(t: Optional[Tensor]):
 def _f32c(t: Optional[Tensor], device=None) -> Optional[Tensor]:
     if t is None:
         return None
+    if t.dtype is torch.float32 and t.is_contiguous() and (device is None or t.device == device):
+        return t  # the common case on the operator path: nothing to convert
     if t.numel() == 0:
         return t
     if device is not None and t.device != device:
@@ -154,7 +156,9 @@ def _on_device(dev):
 
 
 def _stream() -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """the current HIP stream of the current device as a raw handle (torch.cuda.current_stream() builds a Stream object:
+    ~7 us per call, twice per render on the operator path)"""
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 # ----------------------------------------------------------------------------------------------- configuration
@@ -238,6 +242,26 @@ def set_strict_math(on: bool):
     load_library().skgs_set_strict_math(C.c_int(int(bool(on))))
 
 
+_size_cache = {}
+
+
+def _buffer_bytes(lib, kind: str, *dims) -> int:
+    """skgs_*_buffer_bytes, memoised (three ctypes calls per forward otherwise)"""
+    key = (kind,) + dims
+    v = _size_cache.get(key)
+    if v is None:
+        if kind == 'geom':
+            v = lib.skgs_geom_buffer_bytes(C.c_int32(dims[0]))
+        elif kind == 'img':
+            v = lib.skgs_img_buffer_bytes(C.c_int32(dims[0]), C.c_int32(dims[1]))
+        elif kind == 'bwd_ws':
+            v = lib.skgs_backward_workspace_bytes(C.c_int32(dims[0]))
+        else:
+            v = lib.skgs_binning_buffer_bytes(C.c_int64(dims[0]))
+        _size_cache[key] = v = int(v)
+    return v
+
+
 def _make_inputs(H, W, tanfovx, tanfovy, degree, scale_modifier, prefiltered, debug, colmap, viewmatrix, projmatrix,
                  campos, means3D, opacity, sh, scales, rotations, extras, colors, cov3D_precomp):
     dev = means3D.device
@@ -300,8 +324,8 @@ def rasterize_gaussians(image_height: int, image_width: int, tanfovx: float, tan
         out_opacity = torch.empty((H, W), **f32)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
         out_extras = torch.empty((E, H, W), **f32) if extras is not None and E > 0 else None
-        geom = torch.empty((lib.skgs_geom_buffer_bytes(C.c_int32(P)),), dtype=torch.uint8, device=dev)
-        img = torch.empty((lib.skgs_img_buffer_bytes(C.c_int32(W), C.c_int32(H)),), dtype=torch.uint8, device=dev)
+        geom = torch.empty((_buffer_bytes(lib, 'geom', P),), dtype=torch.uint8, device=dev)
+        img = torch.empty((_buffer_bytes(lib, 'img', W, H),), dtype=torch.uint8, device=dev)
         if P == 0:
             out_color.zero_(), out_opacity.zero_()
             if out_extras is not None:
@@ -326,7 +350,7 @@ def rasterize_gaussians(image_height: int, image_width: int, tanfovx: float, tan
         else:
             key = (P, W, H)
             cap = _capacity_hint.get(key, max(config.min_capacity, 8 * P))
-            binning = torch.empty((lib.skgs_binning_buffer_bytes(C.c_int64(cap)),), dtype=torch.uint8, device=dev)
+            binning = torch.empty((_buffer_bytes(lib, 'binning', int(cap)),), dtype=torch.uint8, device=dev)
             bufs = _buffers(geom, binning, img)
             _check(lib.skgs_rasterize_forward(C.byref(a), C.byref(bufs), C.c_void_p(radii.data_ptr()),
                                               C.c_void_p(out_color.data_ptr()), C.c_void_p(out_opacity.data_ptr()),
@@ -412,7 +436,7 @@ def rasterize_gaussians_backward(scale_modifier: float, tanfovx: float, tanfovy:
         if P == 0:
             return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drot,
                     dL_dextras)
-        ws_bytes = lib.skgs_backward_workspace_bytes(C.c_int32(P))
+        ws_bytes = _buffer_bytes(lib, 'bwd_ws', P)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         g.dL_dout_color, g.dL_dout_opacity, g.dL_dout_extra = _ptr(dL_dout_color), _ptr(dL_dout_opacity), _ptr(dL_dout_extra)
         g.grad_means2D_in, g.grad_conic_in, g.grad_opacity_in = _ptr(gm_in), _ptr(gc_in), _ptr(go_in)

@@ -3,9 +3,11 @@ optimizer-state surgery of ``change_optimizer`` and the clone / split / prune op
 
 Restated from ``GaussianSplatting`` (networks/gaussian_splatting.py): ``prune_points`` :565-576, ``densification_postfix``
 :578-587, ``densify_and_split`` :589-620, ``densify_and_clone`` :622-634, ``densify`` :636-641, ``prune`` :643-650,
-``reset_opacity`` :652-655.  Plain torch: these run every ~100 iterations, not per step.  Every per-Gaussian parameter
-of the model -- the reference's ``param_names_map`` plus the LBS logits ``sp_W`` -- is pruned / extended together with
-its Adam moments.  After any of them the number of Gaussians has changed: rebuild ``FusedViewStep`` / flat gradient
+``reset_opacity`` :652-655.  The decisions (masks, samples) are a handful of torch ops; the surgery itself -- every
+per-Gaussian parameter of the model (the reference's ``param_names_map`` plus the LBS logits ``sp_W``) pruned / extended
+together with its two Adam moments -- is ONE row-gather launch per operation (``FusedAdam.gather_rows``,
+csrc/densify.hip) instead of ~100 indexing / concatenation launches: clone + split + prune of 300k Gaussians take
+well under a millisecond of device time.  After any of them the number of Gaussians has changed: rebuild ``FusedViewStep`` / flat gradient
 buffers / captured graphs (their buffers are sized by P), as the reference re-creates its tensors.
 """
 from typing import Dict, Optional
@@ -43,6 +45,12 @@ def quaternion_to_R(q: Tensor) -> Tensor:
                        dim=-1).reshape(*x.shape, 3, 3)
 
 
+def _rotate(R: Tensor, v: Tensor) -> Tensor:
+    """``torch.bmm(R, v[..., None]).squeeze(-1)`` (gaussian_splatting.py:606) as three fused multiply-adds per row: the
+    first bmm of a process initialises the BLAS library (~0.9 s on ROCm) for 3 x 3 products"""
+    return (R * v[:, None, :]).sum(-1)
+
+
 def _rebind(model, new: Dict[str, torch.nn.Parameter]):
     for attr, name in _names(model).items():
         if name in new:
@@ -54,7 +62,8 @@ def _rebind(model, new: Dict[str, torch.nn.Parameter]):
 def prune_points(model, opt: FusedAdam, mask: Tensor, stats=None):
     """remove the Gaussians where ``mask`` is True (gaussian_splatting.py:565-576)"""
     keep = ~mask
-    _rebind(model, opt.change_optimizer(keep, list(_names(model).values()), op='prune'))
+    rows = torch.nonzero(keep).squeeze(1)
+    _rebind(model, opt.gather_rows(list(_names(model).values()), rows, rows.numel()))
     if stats is not None:
         stats.xyz_gradient_accum = stats.xyz_gradient_accum[keep]
         stats.denom = stats.denom[keep]
@@ -65,6 +74,10 @@ def prune_points(model, opt: FusedAdam, mask: Tensor, stats=None):
 def densification_postfix(model, opt: FusedAdam, new_params: Dict[str, Tensor], stats=None):
     """append rows (by optimizer group name) and restart the statistics (gaussian_splatting.py:578-587)"""
     _rebind(model, opt.change_optimizer(new_params, op='concat'))
+    _reset_stats(model, stats)
+
+
+def _reset_stats(model, stats):
     if stats is not None:
         P, dev = model._xyz.shape[0], model._xyz.device
         stats.xyz_gradient_accum = torch.zeros((P, 1), device=dev)
@@ -84,35 +97,58 @@ def densify_and_split(model, opt: FusedAdam, grads: Tensor, grad_threshold: floa
     stds = scaling[sel].repeat(N, 1)
     samples = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=generator)
     rots = quaternion_to_R(model._rotation[sel]).repeat(N, 1, 1)
-    new = {}
-    for attr, name in _names(model).items():
-        p = getattr(model, attr)
-        if attr == '_xyz':
-            new[name] = torch.bmm(rots, samples[..., None]).squeeze(-1) + p[sel].repeat(N, 1)
-        elif attr == '_scaling':
-            new[name] = torch.log(scaling[sel].repeat(N, 1) / (0.8 * N))
-        else:
-            new[name] = p[sel].repeat(N, *[1] * (p.ndim - 1))
-    densification_postfix(model, opt, new, stats)
-    prune_points(model, opt, torch.cat((sel, sel.new_zeros(N * int(sel.sum())))), stats)
+    new_xyz = _rotate(rots, samples) + model._xyz[sel].repeat(N, 1)
+    new_scaling = torch.log(scaling[sel].repeat(N, 1) / (0.8 * N))
+    # densification_postfix (append N copies of the selected rows) followed by prune_points (drop the selected originals,
+    # :619-620) as ONE gather: the unselected rows keep parameters and moments, the N x S new rows follow with zero moments
+    keep_rows, sel_rows = torch.nonzero(~sel).squeeze(1), torch.nonzero(sel).squeeze(1)
+    n_keep = keep_rows.numel()
+    _rebind(model, opt.gather_rows(list(_names(model).values()), torch.cat([keep_rows, sel_rows.repeat(N)]), n_keep))
+    model._xyz.data[n_keep:] = new_xyz
+    model._scaling.data[n_keep:] = new_scaling
+    _reset_stats(model, stats)
 
 
 @torch.no_grad()
 def densify_and_clone(model, opt: FusedAdam, grads: Tensor, grad_threshold: float, scene_extent: float, stats=None):
     """small Gaussians with a large screen-space gradient are duplicated (:622-634)"""
     sel = (torch.norm(grads, dim=-1) >= grad_threshold) & (torch.exp(model._scaling).amax(dim=1) <= scene_extent)
-    new = {name: getattr(model, attr)[sel] for attr, name in _names(model).items()}
-    densification_postfix(model, opt, new, stats)
+    P = model._xyz.shape[0]
+    rows = torch.cat([torch.arange(P, device=sel.device), torch.nonzero(sel).squeeze(1)])
+    _rebind(model, opt.gather_rows(list(_names(model).values()), rows, P))
+    _reset_stats(model, stats)
 
 
 @torch.no_grad()
 def densify(model, opt: FusedAdam, stats, max_grad: float, extent: float, densify_percent_dense: float = 0.01,
-            generator: Optional[torch.Generator] = None):
-    """clone, then split, by the mean screen-space gradient accumulated in ``stats`` (:636-641)"""
+            generator: Optional[torch.Generator] = None, N: int = 2):
+    """clone, then split, by the mean screen-space gradient accumulated in ``stats`` (:636-641) -- as ONE row gather.
+    The two selections are disjoint (clone: max scale <= percent_dense * extent, split: > it) and a fresh clone carries a
+    zero gradient (the padded ``grads`` of :591-593), so ``densify_and_clone`` followed by ``densify_and_split`` leaves
+        [originals not selected for splitting] + [clones] + [N samples of every split Gaussian]
+    with the moments of the first group kept and the others zero: exactly one gather (same rows, same order, same random
+    samples as the two calls)."""
     grads = stats.xyz_gradient_accum / stats.denom
     grads[grads.isnan()] = 0.0
-    densify_and_clone(model, opt, grads, max_grad, densify_percent_dense * extent, stats)
-    densify_and_split(model, opt, grads, max_grad, densify_percent_dense * extent, stats=stats, generator=generator)
+    scene_extent = densify_percent_dense * extent
+    scaling = torch.exp(model._scaling)
+    big = scaling.amax(dim=1) > scene_extent
+    hot_clone = torch.norm(grads, dim=-1) >= max_grad          # densify_and_clone's test (:624)
+    hot_split = grads.squeeze(-1) >= max_grad                  # densify_and_split's test on the padded gradients (:595)
+    clone_sel, split_sel = hot_clone & ~big, hot_split & big
+    stds = scaling[split_sel].repeat(N, 1)
+    samples = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=generator)
+    rots = quaternion_to_R(model._rotation[split_sel]).repeat(N, 1, 1)
+    new_xyz = _rotate(rots, samples) + model._xyz[split_sel].repeat(N, 1)
+    new_scaling = torch.log(scaling[split_sel].repeat(N, 1) / (0.8 * N))
+    keep_rows = torch.nonzero(~split_sel).squeeze(1)
+    rows = torch.cat([keep_rows, torch.nonzero(clone_sel).squeeze(1), torch.nonzero(split_sel).squeeze(1).repeat(N)])
+    n_new = new_xyz.shape[0]
+    _rebind(model, opt.gather_rows(list(_names(model).values()), rows, keep_rows.numel()))
+    if n_new:
+        model._xyz.data[-n_new:] = new_xyz
+        model._scaling.data[-n_new:] = new_scaling
+    _reset_stats(model, stats)
 
 
 @torch.no_grad()

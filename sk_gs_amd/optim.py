@@ -77,7 +77,22 @@ class FusedAdam:
             grads.append(p.grad.data_ptr())
         self._total_chunks = chunk0
         self._bound_grads = grads
-        self._table.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        self._h2d(self._table, blob)
+
+    def _h2d(self, dst: 'torch.Tensor', blob) -> None:
+        """small host table -> device through a pinned staging tensor, asynchronously on the current stream (a pageable
+        source makes every such copy a host synchronisation: three of them per densification)"""
+        n = len(blob)
+        pin = getattr(self, '_pin', None)
+        if pin is None or pin.numel() < n:
+            self._pin = pin = torch.empty(max(n, 4096), dtype=torch.uint8, pin_memory=True)
+            self._pin_event = None
+        if self._pin_event is not None:
+            self._pin_event.synchronize()  # the previous copy out of the staging tensor has been issued AND has run
+        pin[:n].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        dst[:n].copy_(pin[:n], non_blocking=True)
+        self._pin_event = torch.cuda.Event()
+        self._pin_event.record()
 
     def rebind(self):
         """re-read every parameter's / gradient's address (after ``ViewParallel`` moved the ``.grad`` tensors into a flat
@@ -133,6 +148,56 @@ class FusedAdam:
             self._table = torch.zeros(len(self.params) * 56, dtype=torch.uint8, device=self._table.device)
         self._upload()
         return out
+
+    @torch.no_grad()
+    def gather_rows(self, names, rows: 'torch.Tensor', n_keep: int) -> dict:
+        """Rebuild the parameters of the named groups and their Adam moments as row gathers, ALL in one launch
+        (csrc/densify.hip::skgs_gather_rows): row i of every new tensor is row ``rows[i]`` of the old one; rows
+        ``i >= n_keep`` are new Gaussians -- parameters copied from their parent, moments zero (gaussian_splatting.py:
+        531-545).  Prune = the kept rows, clone = all rows + the selected ones, split = the unselected rows + N copies of
+        the selected ones (:565-634).  Returns name -> new ``nn.Parameter`` like ``change_optimizer``."""
+        from torch import nn
+        lib = _C.load_library()
+        lib.skgs_row_tensor_bytes.restype = C.c_size_t
+        assert int(lib.skgs_row_tensor_bytes()) == 24
+        rows = rows.to(torch.int64).contiguous()
+        n_out, dev = int(rows.numel()), rows.device
+        blob, new, max_rf, keepalive = bytearray(), {}, 1, []
+        for g in self.param_groups:
+            if g.get('name') not in names:
+                continue
+            assert len(g['params']) == 1, f"group {g['name']!r}: one parameter per group"
+            old = g['params'][0]
+            st = self.state.pop(old)
+            rf = old.numel() // max(old.shape[0], 1)
+            max_rf = max(max_rf, rf)
+            shape = (n_out,) + tuple(old.shape[1:])
+            p = nn.Parameter(torch.empty(shape, dtype=torch.float32, device=dev), requires_grad=True)
+            m, v = torch.empty(shape, dtype=torch.float32, device=dev), torch.empty(shape, dtype=torch.float32, device=dev)
+            for src, dst, fresh_zero in ((old.data, p.data, 0), (st['exp_avg'], m, 1), (st['exp_avg_sq'], v, 1)):
+                assert src.is_contiguous()
+                blob += struct.pack('<QQii', src.data_ptr(), dst.data_ptr(), rf, fresh_zero)
+            keepalive += [old, st]
+            g['params'][0] = p
+            self.state[p] = dict(exp_avg=m, exp_avg_sq=v)
+            new[g['name']] = p
+        if new:
+            table = torch.empty(len(blob), dtype=torch.uint8, device=dev)
+            self._h2d(table, blob)
+            _C._check(lib.skgs_gather_rows(C.c_int32(3 * len(new)), C.c_void_p(table.data_ptr()), C.c_int64(n_out),
+                                           C.c_int64(int(n_keep)), C.c_void_p(rows.data_ptr()), C.c_int32(max_rf),
+                                           _C._stream()))
+        self.params, self._lr_index = [], []
+        for gi, g in enumerate(self.param_groups):
+            for q in g['params']:
+                if q.requires_grad:
+                    self.params.append(q)
+                    self._lr_index.append(gi)
+        if self._table.numel() != len(self.params) * 56:
+            self._table = torch.zeros(len(self.params) * 56, dtype=torch.uint8, device=self._table.device)
+        self._upload()
+        del keepalive  # (the old tensors lived until the launch was enqueued: same stream, the allocator orders reuse)
+        return new
 
     def set_lr(self, group, lr: float):
         """``group``: index or name of the parameter group.  Re-uploads the descriptor table (outside graph capture); a

@@ -183,8 +183,10 @@ def render(points: Tensor, opacity: Tensor, raster_settings: GaussianRasterizati
            rotations: Tensor = None, covariance: Tensor = None, sh_features: Tensor = None, colors=None, extras=None,
            **kwargs):
     """Render the scene; same dict as the reference's ``render`` (gaussian_render.py:285-340)."""
-    # zero tensor through which autograd hands back the gradient of the 2D (screen-space) means
-    screenspace_points = torch.zeros_like(points, requires_grad=True) + 0
+    # zero tensor through which autograd hands back the gradient of the 2D (screen-space) means: a NON-LEAF of zeros with
+    # retain_grad() (gaussian_render.py:304-308).  A view of a fresh leaf is such a tensor for one fill launch (the
+    # reference's "+ 0" costs a second elementwise launch per render)
+    screenspace_points = torch.zeros_like(points, requires_grad=True).view(points.shape)
     try:
         screenspace_points.retain_grad()
     except Exception:  # noqa
