@@ -182,6 +182,9 @@ def main():
                          'networks/sk_gs.py:1080-1085) instead of running the 8x256 deform network inside every step.  The '
                          'reference runs the network in every TRAINING step (sk_gs.py:1073-1074): that is the default here')
     ap.add_argument('--deform-net', dest='deform_net', action='store_true', help='(default) the deform network inside the step')
+    ap.add_argument('--scale-mult', type=float, default=1.0,
+                    help='multiply every Gaussian\'s scale: 2.5 gives a DENSE scene (R of several million tile instances, tile '
+                         'lists beyond 1024 entries: the LDS / global sort paths and long blend walks are timed); 1 = SURVEY 8d')
     ap.add_argument('--graph-per-view', action='store_true',
                     help='capture one hipGraph per view (camera, time and target baked into each) instead of ONE graph that '
                          'reads them from a device-resident view slot')
@@ -221,7 +224,8 @@ def main():
 
     # ---------------------------------------------------------------- synthetic scene, resident in HBM
     frames = args.views
-    model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=0, deform_net=args.deform_net).to(dev)
+    model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=0, deform_net=args.deform_net,
+                             scale_mult=args.scale_mult).to(dev)
     cams = [scene.make_camera(W, H, seed=i) for i in range(args.views)]
     settings = [scene.raster_settings_from_camera(c, sh_degree=3, colmap=True, device=dev) for c in cams]
     background = torch.ones(3, device=dev)
@@ -613,7 +617,8 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{cfg["name"]}: {P} Gaussians, {M} bones, K={K}, SH degree 3, {W}x{H}, '
-                                   f'{args.views} synthetic views, colmap=True, 1 view per rank per step',
+                                   f'{args.views} synthetic views, colmap=True, 1 view per rank per step'
+                                   + (f', DENSE variant: scales x{args.scale_mult}' if args.scale_mult != 1.0 else ''),
                        'num_rendered_mean': round(R_mean), 'num_rendered_max': R_max,
                        'tile_list_mean': round(R_mean / (((W + 15) // 16) * ((H + 15) // 16)), 1), 'tile_list_max': longest,
                        'walked_pairs_mean': round(sum(walked) / len(walked)),

@@ -228,11 +228,12 @@ __global__ void __launch_bounds__(BIN_THREADS) scatter_lds_kernel(int P, int gx,
 
 // Per-tile sort. Ascending-only bitonic network with virtual +inf padding (works for any length).
 constexpr int SORT_THREADS = 256;
-constexpr int SORT_LDS_MAX = 4096;  // 32 KB of u64
+constexpr int SORT_LDS_MAX = 8192;  // 64 KB of u64
 
+// `first_size`: the blocks of first_size / 2 keys are already sorted ascending (2 = nothing is)
 template <typename KeyPtr>
-__device__ __forceinline__ void bitonic_any(KeyPtr k, int L, int n /*pow2 >= L*/, int tid) {
-  for (int size = 2; size <= n; size <<= 1) {
+__device__ __forceinline__ void bitonic_any(KeyPtr k, int L, int n /*pow2 >= L*/, int tid, int first_size = 2) {
+  for (int size = first_size; size <= n; size <<= 1) {
     // mirror step: a in lower half of each block, partner = block end - offset
     const int half = size >> 1;
     for (int t = tid; t < (n >> 1); t += SORT_THREADS) {
@@ -257,39 +258,6 @@ __device__ __forceinline__ void bitonic_any(KeyPtr k, int L, int n /*pow2 >= L*/
   }
 }
 
-// Lists longer than the register sort below handles (> 1024 keys, rare): that kernel queues them in `worklist`.
-__global__ void __launch_bounds__(SORT_THREADS) tile_sort_kernel(const GeomHeader* __restrict__ hdr,
-    const uint32_t* __restrict__ worklist, const uint32_t* __restrict__ tile_begin, const uint32_t* __restrict__ tile_end,
-    uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list, int64_t capacity) {
-  __shared__ uint64_t sk[SORT_LDS_MAX];
-  const int tid = threadIdx.x;
-  const int nbig = hdr->big_tiles;  // the usual case: 0
-  for (int w = blockIdx.x; w < nbig; w += gridDim.x) {
-    const int tile    = (int) worklist[w];
-    const int64_t s64 = tile_begin[tile], e64 = min<int64_t>((int64_t) tile_end[tile], capacity);
-    const int L = (int) (e64 - s64);
-    if (L <= 1) continue;
-    uint64_t* gk = keys + s64;
-    int n = 1;
-    while (n < L) n <<= 1;
-    if (L <= SORT_LDS_MAX) {
-      for (int i = tid; i < L; i += SORT_THREADS) sk[i] = gk[i];
-      __syncthreads();
-      bitonic_any(sk, L, n, tid);
-      for (int i = tid; i < L; i += SORT_THREADS) {
-        const uint64_t v    = sk[i];
-        gk[i]               = v;
-        point_list[s64 + i] = (uint32_t) v;
-      }
-      __syncthreads();
-    } else {
-      // list longer than the LDS window -> same network on global memory (one workgroup, L1/L2 resident)
-      bitonic_any(gk, L, n, tid);
-      for (int i = tid; i < L; i += SORT_THREADS) point_list[s64 + i] = (uint32_t) gk[i];
-    }
-  }
-}
-
 // Lists of up to 64 * E keys (E <= 8: 512 keys, nearly every tile): ONE wave sorts the list entirely in
 // registers.  Blocked layout -- lane l holds keys l*E .. l*E+E-1 -- so a bitonic compare-exchange at distance j < E is
 // a swap between two registers of the same lane and only distances j >= E need one cross-lane read (lane ^ (j/E),
@@ -297,7 +265,6 @@ __global__ void __launch_bounds__(SORT_THREADS) tile_sort_kernel(const GeomHeade
 // workgroup barrier per step and 32 KB of LDS per tile.  Padding keys are ~0 (above every real key: the low word is a
 // Gaussian id < 2^31).
 constexpr int WSORT_WAVE_MAX = 512;   // longest list one wave sorts on its own (E = 8)
-constexpr int WSORT_TEAM_MAX = 1024;  // longest list the four waves of a workgroup sort together (E = 4 each)
 
 // Value of lane ^ J for J in {1, 2, 4, 8, 16, 32} without the LDS crossbar (ds_bpermute: ~100 cycles of latency per step,
 // and the sort is a chain of dependent steps at ~2.5 waves per SIMD): DPP quad_perm (1, 2), two bank-masked row shifts
@@ -413,20 +380,115 @@ __device__ __forceinline__ void sort_tile_blocked(uint64_t* __restrict__ gk, uin
   }
 }
 
-// One workgroup = 4 waves = 4 consecutive tiles.  Each wave first sorts its own list if that is at most 512 keys (the
-// steps are latency-bound: four waves side by side beat four team sorts in a row); lists of 513..1024 keys are then sorted one after the other by all four waves together; longer ones go to the worklist.
+// Lists longer than one wave sorts on its own (> 512 keys): queued in `worklist` by the kernel below, one workgroup per
+// list here.  In a dense scene (trained models at 800 x 800 reach several million tile instances) MOST tiles are such
+// lists, so this path matters.  Sort = the four waves sort one chunk of 64 E keys each in registers (the network of the
+// short lists, no LDS, no barrier), then log2(chunks) MERGE rounds through LDS: every thread finds the start of its E
+// consecutive outputs with a merge-path binary search and merges them sequentially -- O(n log n) compare work and two
+// barriers per round instead of the O(n log^2 n) bitonic steps with a barrier (or a cross-wave exchange) each.
+// History at R = 3.8 M (2500 lists of ~1500 keys): whole network in LDS drained by 128 workgroups 1017 us; 1024-key
+// register chunks + LDS bitonic merge levels 231 us; 2048 / 4096-key register networks over four waves 400 us.
+// One merge round over the LDS image `src` (sorted runs of `len` keys, pairs of runs merged): thread t produces outputs
+// [t E, t E + E) (E = outputs per thread).  LAST: they go to the tile's key list / point list in global memory instead of
+// `dst`.  (Merging in place -- outputs staged in registers, written back after a barrier -- halves the LDS but the staging
+// array went to scratch: 894 us instead of 135 at R = 3.8 M.)
+template <int E, bool LAST>
+__device__ __forceinline__ void merge_round(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst,
+    uint64_t* __restrict__ gk, uint32_t* __restrict__ pl, int len, int L, int tid) {
+  const int o0   = tid * E;
+  const int pair = o0 / (2 * len), d = o0 - pair * 2 * len;
+  const uint64_t* A = src + pair * 2 * len;
+  const uint64_t* B = A + len;
+  int lo = max(0, d - len), hi = min(d, len);
+  while (lo < hi) {  // merge path: a tile's keys are distinct (depth bits << 32 | Gaussian id); paddings tie freely
+    const int mid = (lo + hi) >> 1;
+    if (A[mid] < B[d - 1 - mid]) lo = mid + 1; else hi = mid;
+  }
+  int i = lo, j = d - lo;
+  uint64_t ka = i < len ? A[i] : ~0ull, kb = j < len ? B[j] : ~0ull;
+#pragma unroll
+  for (int q = 0; q < E; ++q) {
+    const bool ta    = (i < len) && (j >= len || ka <= kb);
+    const uint64_t v = ta ? ka : kb;
+    if (ta) {
+      ++i;
+      ka = i < len ? A[i] : ~0ull;
+    } else {
+      ++j;
+      kb = j < len ? B[j] : ~0ull;
+    }
+    if (LAST) {
+      if (o0 + q < L) gk[o0 + q] = v, pl[o0 + q] = (uint32_t) v;
+    } else {
+      dst[o0 + q] = v;
+    }
+  }
+}
+
+// CPW chunks of 512 keys per wave: lists of up to 2048 (CPW = 1, 32 KB of LDS) or 4096 keys (CPW = 2, 64 KB).
+template <int CPW>
+__global__ void __launch_bounds__(SORT_THREADS) tile_sort_merge_kernel(const GeomHeader* __restrict__ hdr,
+    const uint32_t* __restrict__ worklist, const uint32_t* __restrict__ tile_begin, const uint32_t* __restrict__ tile_end,
+    uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list, int64_t capacity, int len_lo, int len_hi) {
+  constexpr int E = 8, CH = 64 * E, NMAX = 4 * CPW * CH, OPT = NMAX / SORT_THREADS;  // OPT outputs per thread and round
+  __shared__ uint64_t s_a[NMAX];
+  __shared__ uint64_t s_b[NMAX];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nbig = hdr->big_tiles;  // sparse scenes: 0
+  for (int w = blockIdx.x; w < nbig; w += gridDim.x) {
+    const int tile    = (int) worklist[w];
+    const int64_t s64 = tile_begin[tile], e64 = min<int64_t>((int64_t) tile_end[tile], capacity);
+    const int L = (int) (e64 - s64);
+    if (L <= len_lo || L > len_hi) continue;  // another instantiation's list (workgroup-uniform)
+    uint64_t* gk = keys + s64;
+    uint32_t* pl = point_list + s64;
+    if (L > NMAX) {  // beyond the LDS window (only the widest instantiation gets here): the network on global memory
+      int n = 1;
+      while (n < L) n <<= 1;
+      bitonic_any(gk, L, n, tid);
+      for (int i = tid; i < L; i += SORT_THREADS) pl[i] = (uint32_t) gk[i];
+      __syncthreads();
+      continue;
+    }
+    // ---- phase 1: every wave sorts its chunk(s) of 512 keys in registers (all-padding chunks skip the network)
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+      uint64_t k[E];
+      const int base = (c * 4 + wave) * CH + lane * E;
+#pragma unroll
+      for (int e = 0; e < E; ++e) k[e] = (base + e) < L ? gk[base + e] : ~0ull;
+      if ((c * 4 + wave) * CH < L) bitonic_blocked<E, 1>(k, lane, 0, nullptr);
+#pragma unroll
+      for (int e = 0; e < E; ++e) s_a[base + e] = k[e];
+    }
+    __syncthreads();
+    // ---- phase 2: merge rounds, run length 512 -> NMAX / 2; the last one writes the list and the point list
+    if (CPW == 1) {
+      merge_round<OPT, false>(s_a, s_b, nullptr, nullptr, CH, L, tid);
+      __syncthreads();
+      merge_round<OPT, true>(s_b, nullptr, gk, pl, 2 * CH, L, tid);
+    } else {
+      merge_round<OPT, false>(s_a, s_b, nullptr, nullptr, CH, L, tid);
+      __syncthreads();
+      merge_round<OPT, false>(s_b, s_a, nullptr, nullptr, 2 * CH, L, tid);
+      __syncthreads();
+      merge_round<OPT, true>(s_a, nullptr, gk, pl, 4 * CH, L, tid);
+    }
+    __syncthreads();
+  }
+}
+
+// One workgroup = 4 waves = 4 consecutive tiles: each wave sorts its own list of at most 512 keys in registers (the steps
+// are latency-bound: four waves side by side); longer lists go to the worklist of the merge kernel above.
 __global__ void __launch_bounds__(256) tile_sort_wave_kernel(int T, int bucket, const uint32_t* __restrict__ cursors,
     uint32_t* __restrict__ tile_begin, uint32_t* __restrict__ tile_end, uint32_t* __restrict__ worklist, GeomHeader* hdr,
     uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list, int64_t capacity) {
-  __shared__ uint64_t s_x[4 * 4 * 64];
-  __shared__ int s_len[4];
-  __shared__ long long s_beg[4];
+  __shared__ int s_big[4];
+  __shared__ int s_base;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + wave;
-  int64_t s64 = 0;
-  int L       = 0;
+  int64_t s64 = 0, e64 = 0;
   if (tile < T) {
-    int64_t e64;
     if (bucket) {  // bucket layout: the per-tile cursor is the count; this kernel publishes the tile's range
       const uint32_t cnt = cursors[tile];
       s64 = (int64_t) tile * bucket, e64 = s64 + min(cnt, (uint32_t) bucket);
@@ -437,35 +499,37 @@ __global__ void __launch_bounds__(256) tile_sort_wave_kernel(int T, int bucket, 
     } else {
       s64 = tile_begin[tile], e64 = min<int64_t>((int64_t) tile_end[tile], capacity);
     }
-    L = max((int) (e64 - s64), 0);
-    if (L > WSORT_TEAM_MAX) {  // tile_sort_kernel
-      if (lane == 0) worklist[atomicAdd(&hdr->big_tiles, 1)] = (uint32_t) tile;
-      L = 0;
-    }
   }
-  if (lane == 0) s_len[wave] = L > WSORT_WAVE_MAX ? L : 0, s_beg[wave] = s64;
-  if (L > 1 && L <= WSORT_WAVE_MAX) {
-    uint64_t* gk = keys + s64;
-    uint32_t* pl = point_list + s64;
-    if (L <= 64)
-      sort_tile_blocked<1, 1>(gk, pl, L, lane, 0, nullptr);
-    else if (L <= 128)
-      sort_tile_blocked<2, 1>(gk, pl, L, lane, 0, nullptr);
-    else if (L <= 256)
-      sort_tile_blocked<4, 1>(gk, pl, L, lane, 0, nullptr);
-    else
-      sort_tile_blocked<8, 1>(gk, pl, L, lane, 0, nullptr);
-  } else if (L == 1 && lane == 0) {
-    point_list[s64] = (uint32_t) keys[s64];
+  const int L = max((int) (e64 - s64), 0);
+  // lists beyond a wave's reach go to the worklist of tile_sort_merge_kernel: ONE global atomic per workgroup (in a dense
+  // scene nearly every tile is such a list: 2500 same-address atomics serialise at the memory side)
+  const bool big = L > WSORT_WAVE_MAX;
+  if (lane == 0) s_big[wave] = big ? 1 : 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int n = s_big[0] + s_big[1] + s_big[2] + s_big[3];
+    s_base = n ? atomicAdd(&hdr->big_tiles, n) : 0;
   }
   __syncthreads();
-#pragma unroll 1
-  for (int w = 0; w < 4; ++w) {
-    const int Lw = s_len[w];  // workgroup-uniform
-    if (Lw == 0) continue;
-    uint64_t* gk = keys + s_beg[w];
-    uint32_t* pl = point_list + s_beg[w];
-    sort_tile_blocked<4, 4>(gk, pl, Lw, lane, wave, s_x);
+  if (big) {
+    int slot = s_base;
+    for (int q = 0; q < wave; ++q) slot += s_big[q];
+    if (lane == 0) worklist[slot] = (uint32_t) tile;
+    return;
+  }
+  if (tile >= T) return;
+  uint64_t* gk = keys + s64;
+  uint32_t* pl = point_list + s64;
+  if (L <= 1) {
+    if (L == 1 && lane == 0) pl[0] = (uint32_t) gk[0];
+  } else if (L <= 64) {
+    sort_tile_blocked<1, 1>(gk, pl, L, lane, 0, nullptr);
+  } else if (L <= 128) {
+    sort_tile_blocked<2, 1>(gk, pl, L, lane, 0, nullptr);
+  } else if (L <= 256) {
+    sort_tile_blocked<4, 1>(gk, pl, L, lane, 0, nullptr);
+  } else {
+    sort_tile_blocked<8, 1>(gk, pl, L, lane, 0, nullptr);
   }
 }
 
@@ -508,11 +572,15 @@ int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, Bi
     ProfScope prof(K_SORT, s);
     hipLaunchKernelGGL(tile_sort_wave_kernel, dim3((im.T + 3) / 4), dim3(256), 0, s, im.T, bucket, im.cursors, im.tile_begin,
         im.tile_end, im.worklist, g.hdr, b.keys, b.point_list, b.capacity);
-    // lists longer than 1024 keys (rare): a few workgroups drain the worklist, sorting in LDS / global memory.  A bucket
-    // layout whose buckets hold no more than the register sort takes cannot produce one: no launch
-    if (bucket == 0 || bucket > WSORT_TEAM_MAX)
-      hipLaunchKernelGGL(tile_sort_kernel, dim3(std::min(im.T, 128)), dim3(SORT_THREADS), 0, s, g.hdr, im.worklist,
-        im.tile_begin, im.tile_end, b.keys, b.point_list, b.capacity);
+    // lists longer than 512 keys: one workgroup per list drains the worklist (chunk sorts in registers + merge rounds in
+    // LDS).  A bucket layout whose buckets hold no more than a wave sorts cannot produce one: no launch.  Lists of up to
+    // 2048 keys take the one-chunk-per-wave instantiation (32 KB of LDS), longer ones the two-chunk one (64 KB).
+    if (bucket == 0 || bucket > WSORT_WAVE_MAX)
+      hipLaunchKernelGGL(tile_sort_merge_kernel<1>, dim3(std::min(im.T, 2048)), dim3(SORT_THREADS), 0, s, g.hdr, im.worklist,
+          im.tile_begin, im.tile_end, b.keys, b.point_list, b.capacity, WSORT_WAVE_MAX, 2048);
+    if (bucket == 0 || bucket > 2048)
+      hipLaunchKernelGGL(tile_sort_merge_kernel<2>, dim3(std::min(im.T, 1024)), dim3(SORT_THREADS), 0, s, g.hdr, im.worklist,
+          im.tile_begin, im.tile_end, b.keys, b.point_list, b.capacity, 2048, 0x7fffffff);
   }
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
