@@ -41,6 +41,8 @@ namespace {
 
 constexpr int MAXL = SKGS_MLP_MAX_LAYERS;
 constexpr unsigned SENTINEL = 0xffffffffu;
+// Shapes fixed at compile time: hidden width H = 256, encoded input padded to INP = 128, at most KL layers.
+constexpr int H = 256, INP = 128, KL = 10;
 
 using gu32 = __attribute__((address_space(1))) unsigned int;
 typedef float f4 __attribute__((ext_vector_type(4)));  // a VGPR quad as an asm operand
@@ -53,7 +55,7 @@ struct FusedLayer {
   int in_h, in_x, out, relu;
 };
 struct FusedArgs {
-  int B, p_dim, p_deg, t_dim, t_deg, IN, INP, H, n_layers, lds_floats;
+  int B, p_dim, p_deg, t_dim, t_deg, IN, n_layers, lds_floats;
   const float* points;
   const float* t;
   float* x0;          // forward: [B, IN] or NULL
@@ -67,8 +69,21 @@ struct FusedArgs {
   int n_heads, head_dim[4];  // the last layer's columns split over separate [B, head_dim[j]] tensors (n_heads = 0: one tensor)
   float* head_out[4];        // forward
   const float* head_gout[4]; // backward
-  FusedLayer layer[MAXL];
+  // per-layer data as parallel arrays, not an array of structs: the prologue needs every W / bias pointer at once, and ten
+  // 48-byte descriptors exceed the SGPR file -- hipcc then serialises one scalar load + wait per layer, each a round trip to
+  // the (host-visible) kernarg segment: 2.9 us before the first weight load was issued
+  const float* W[KL];
+  const float* bias[KL];
+  float* gW[KL];
+  float* gb[KL];
+  unsigned xmask, relu_mask;  // bit l: layer l reads the encoded input / applies ReLU
+  int out_last;
 };
+
+__device__ __forceinline__ FusedLayer get_layer(const FusedArgs& a, int l) {
+  return FusedLayer{a.W[l], a.bias[l], a.gW[l], a.gb[l], l ? H : 0, ((a.xmask >> l) & 1u) ? a.IN : 0,
+      l == a.n_layers - 1 ? a.out_last : H, (int) ((a.relu_mask >> l) & 1u)};
+}
 
 __device__ __forceinline__ int pad64(int x) { return (x + 63) & ~63; }
 
@@ -215,16 +230,13 @@ __device__ __forceinline__ void repoison(float* img_other, int nX, int G, int Bp
 }
 
 // ---------------------------------------------------------------------------------------------------------- forward
-// Shapes fixed at compile time: hidden width H = 256, encoded input padded to INP = 128, at most KL layers.
-constexpr int H = 256, INP = 128, KL = 10;
-
 // LDS (floats): s_x0 [Bp][INP] | s_act [Bp][H] | s_out [Bp][NC] | slabs: layer l -> [NC][Kp_l], Kp_l = (l ? H : 0) + (in_x ?
 //               INP : 0) | bias [n_layers][NC] | misc (launch count, fail, stamps)
 template <int GROUPS, int PASSES>
 __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_forward_kernel(const FusedArgs a) {
   constexpr int NT = 256 * GROUPS, NC = 4 * GROUPS, Bp = 16 * PASSES;
   constexpr int U = (Bp * 64 + NT - 1) / NT <= 4 ? 4 : 8;  // 16-byte units per thread of one gather
-  constexpr int EQ = (Bp * INP + NT - 1) / NT;             // encoded-input entries per thread, worst case
+  constexpr int EQ = (Bp * INP + NT - 1) / NT;             // encoded-input entries per thread (padding included)
   static_assert((Bp * 64 + NT - 1) / NT <= 8, "gather_slabs covers at most 8 units per thread");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
@@ -247,18 +259,34 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_forward_kernel(const F
     cnt       = __hip_atomic_load(h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     stamps_on = __hip_atomic_load(h + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  // encoded input entry (b, c): c = tid & 127 is the same for all of a thread's entries (INP = 128), so everything that
+  // depends on the column -- which raw coordinate, which frequency, sine or cosine -- is computed once, without divisions
+  // in the per-entry loop; b = tid / 128 + q NT / 128
   const int pe = a.p_dim * (1 + 2 * a.p_deg);
+  const int ec = tid & (INP - 1), eb0 = tid >> 7;
+  const bool e_live = ec < IN;
+  const bool e_pt   = ec < pe;
+  const int e_cc = e_pt ? ec : ec - pe, e_D = e_pt ? a.p_dim : a.t_dim;
+  const int e_col = e_cc / e_D - 1, e_d = e_cc - (e_col + 1) * e_D;  // column group (-1: the raw value), coordinate
+  const float e_phase = (float) (e_col & 1) * (3.141592653589793f / 2);
   float xin[EQ];
 #pragma unroll
-  for (int q = 0; q < EQ; ++q) {  // entry i = (b, c): the raw coordinate it is a function of
-    const int i = tid + q * NT, b = i / IN, c = i - b * IN;
+  for (int q = 0; q < EQ; ++q) {
+    const int b = eb0 + q * (NT / INP);
     xin[q] = 0.f;
-    if (i < B * IN) xin[q] = c < pe ? a.points[(size_t) b * a.p_dim + (c < a.p_dim ? c : c % a.p_dim)]
-                                    : a.t[(c - pe) < a.t_dim ? (c - pe) : (c - pe) % a.t_dim];
+    if (e_live && b < B) xin[q] = e_pt ? a.points[(size_t) b * a.p_dim + e_d] : a.t[e_d];
   }
   float bv[KL];
   float4 vh[KL], vx[KL];
   {
+    // every layer's pointers are fetched from the kernarg segment up front, in a few wide scalar loads and ONE wait (left
+    // inside the per-layer branches they were ten dependent round trips to host-visible memory: 2.8 us)
+    const float* wp[KL];
+    const float* bp[KL];
+#pragma unroll
+    for (int l = 0; l < KL; ++l) wp[l] = a.W[l], bp[l] = a.bias[l];
+#pragma unroll
+    for (int l = 0; l < KL; ++l) asm volatile("" : "+s"(wp[l]), "+s"(bp[l]));
     const int ch = tid >> 6, kh = 4 * (tid & 63);  // hidden part: NC rows x 64 units = NT units
     const int cx = tid >> 5, kx = 4 * (tid & 31);  // x0 part: NC rows x 32 units = NT / 2 units
 #pragma unroll
@@ -266,7 +294,8 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_forward_kernel(const F
       bv[l] = 0.f;
       vh[l] = vx[l] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (l < nL) {
-        const FusedLayer L = a.layer[l];
+        FusedLayer L = get_layer(a, l);
+        L.W = wp[l], L.bias = bp[l];
         const int K = L.in_h + L.in_x;
         if (tid < NC && L.bias && col0 + tid < L.out) bv[l] = L.bias[col0 + tid];
         if (l > 0 && col0 + ch < L.out) vh[l] = *reinterpret_cast<const float4*>(L.W + (size_t) (col0 + ch) * K + kh);
@@ -275,23 +304,18 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_forward_kernel(const F
       }
     }
   }
-  // the encoded input (the loads above are still in flight behind these)
+#ifdef SKGS_MLP_DIAG
+  const unsigned long long t_d1 = __builtin_amdgcn_s_memrealtime();
+#endif
+  // the encoded input (the loads above are still in flight behind these); padding entries are written as zeros
 #pragma unroll
   for (int q = 0; q < EQ; ++q) {
-    const int i = tid + q * NT, b = i / IN, c = i - b * IN;
-    if (i < B * IN) {
-      const int cc = c < pe ? c : c - pe, D = c < pe ? a.p_dim : a.t_dim;
+    const int b = eb0 + q * (NT / INP);
+    if (b < Bp) {
       float v = xin[q];
-      if (cc >= D) {
-        const int col = cc / D - 1;
-        v = sinf(scalbnf(v, col / 2) + (float) (col % 2) * (3.141592653589793f / 2));
-      }
-      s_x0[b * INP + c] = v;
+      if (e_live && b < B && e_col >= 0) v = sinf(scalbnf(v, e_col >> 1) + e_phase);
+      s_x0[b * INP + ec] = v;
     }
-  }
-  for (int i = tid; i < Bp * INP; i += NT) {  // padding (disjoint from the entries above)
-    const int b = i / INP, c = i - b * INP;
-    if (b >= B || c >= IN) s_x0[i] = 0.f;
   }
   for (int i = tid; i < Bp * H / 4; i += NT) reinterpret_cast<float4*>(s_act)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   {
@@ -300,14 +324,17 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_forward_kernel(const F
 #pragma unroll
     for (int l = 0; l < KL; ++l) {
       if (l < nL) {
-        const int hp = l ? H : 0, Kp = hp + (a.layer[l].in_x ? INP : 0);
+        const int hp = l ? H : 0, Kp = hp + (get_layer(a, l).in_x ? INP : 0);
         if (tid < NC) s_bias[l * NC + tid] = bv[l];
         if (l > 0) *reinterpret_cast<float4*>(s_w + woffs + ch * Kp + kh) = vh[l];
-        if (a.layer[l].in_x && tid < NT / 2) *reinterpret_cast<float4*>(s_w + woffs + cx * Kp + hp + kx) = vx[l];
+        if (get_layer(a, l).in_x && tid < NT / 2) *reinterpret_cast<float4*>(s_w + woffs + cx * Kp + hp + kx) = vx[l];
         woffs += NC * Kp;
       }
     }
   }
+#ifdef SKGS_MLP_DIAG
+  const unsigned long long t_d3 = __builtin_amdgcn_s_memrealtime();
+#endif
   if (tid == 0) s_misc[0] = cnt, s_misc[1] = 0, s_misc[2] = stamps_on;
   __syncthreads();
   const unsigned count = s_misc[0];
@@ -316,10 +343,13 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_forward_kernel(const F
   repoison<NT, NC>(a.exch + ((count & 1u) ^ 1u) * img_floats, nX, G, Bp);
   int si = 0;
   stamp(a, s_misc, si, t_entry);
+#ifdef SKGS_MLP_DIAG
+  if (s_misc[2] && g == 0 && tid == 0) a.hdr[16 + 40] = (unsigned) t_d1, a.hdr[16 + 42] = (unsigned) t_d1, a.hdr[16 + 44] = (unsigned) t_d3;
+#endif
 
   int woff = 0;
   for (int l = 0; l < nL; ++l) {
-    const FusedLayer L = a.layer[l];
+    const FusedLayer L = get_layer(a, l);
     const int hp = l ? H : 0, Kp = hp + (L.in_x ? INP : 0);
     const bool last = l == nL - 1;
     if (l > 0) {
@@ -403,11 +433,11 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const 
   float* s_out = s_own + nL * Bp * NC;
   float* s_wT  = s_out + Bp * NC;
   int t_total = 0;  // floats of the T slabs; the X slabs follow
-  for (int l = 1; l < nL; ++l) t_total += NC * pad64(a.layer[l].out);
+  for (int l = 1; l < nL; ++l) t_total += NC * pad64(get_layer(a, l).out);
   int x_total = 0;
   if (want_gx)
     for (int l = 0; l < nL; ++l)
-      if (a.layer[l].in_x) x_total += NC * pad64(a.layer[l].out);
+      if (get_layer(a, l).in_x) x_total += NC * pad64(get_layer(a, l).out);
   unsigned* s_misc = reinterpret_cast<unsigned*>(smem + a.lds_floats - 4);
 
   // ---- prologue: one memory round trip (see the forward kernel)
@@ -422,13 +452,19 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const 
   const bool mlive = tid < Bp * GROUPS && mrow < B;
   float4 am[KL], vt[KL], vx[KL];
   {
+    const float* wp[KL];  // (see the forward prologue: all pointer loads up front, one wait)
+#pragma unroll
+    for (int l = 0; l < KL; ++l) wp[l] = a.W[l];
+#pragma unroll
+    for (int l = 0; l < KL; ++l) asm volatile("" : "+s"(wp[l]));
     const int o = tid / GROUPS, c4 = 4 * (tid - o * GROUPS);  // (weight row, group of four columns): NT = 256 GROUPS units
 #pragma unroll
     for (int l = 0; l < KL; ++l) {
       am[l] = make_float4(1.f, 1.f, 1.f, 1.f);
       vt[l] = vx[l] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (l < nL) {
-        const FusedLayer L = a.layer[l];
+        FusedLayer L = get_layer(a, l);
+        L.W = wp[l];
         const int K = L.in_h + L.in_x;
         if (l < nL - 1 && L.relu && mlive)
           am[l] = *reinterpret_cast<const float4*>(a.acts + ((size_t) l * B + mrow) * H + col0 + 4 * mpart);
@@ -445,24 +481,24 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const 
 #pragma unroll
     for (int l = 0; l < KL; ++l) {
       if (l < nL) {
-        const int op = pad64(a.layer[l].out);
+        const int op = pad64(get_layer(a, l).out);
         if (o < op) {
           if (l >= 1) {
             float* d = s_wT + toff + c4 * op + o;
             d[0] = vt[l].x, d[op] = vt[l].y, d[2 * op] = vt[l].z, d[3 * op] = vt[l].w;
           }
-          if (want_gx && a.layer[l].in_x) {
+          if (want_gx && get_layer(a, l).in_x) {
             float* d = s_wT + xoff + c4 * op + o;
             d[0] = vx[l].x, d[op] = vx[l].y, d[2 * op] = vx[l].z, d[3 * op] = vx[l].w;
           }
         }
         if (l >= 1) toff += NC * op;
-        if (want_gx && a.layer[l].in_x) xoff += NC * op;
+        if (want_gx && get_layer(a, l).in_x) xoff += NC * op;
       }
     }
   }
   {  // gZ of the last layer = the incoming gradient (zero-padded to 64 columns); this workgroup's slab of it
-    const int oL = a.layer[nL - 1].out;
+    const int oL = get_layer(a, nL - 1).out;
     for (int i = tid; i < Bp * 64; i += NT) {
       const int b = i >> 6, c = i & 63;
       s_gz[b * H + c] = (b < B && c < oL) ? *head_elem(a, const_cast<float* const*>(a.head_gout), const_cast<float*>(a.g_out), b, c, oL) : 0.f;
@@ -493,7 +529,7 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const 
   for (int lu = KL - 1; lu >= 1; --lu) {  // compile-time index: am[] stays in registers
     if (lu < nL) {
       const int l = lu;
-      const FusedLayer L = a.layer[l];
+      const FusedLayer L = get_layer(a, l);
       const int op = pad64(L.out);
       const bool publish = l - 1 >= 1 || a.g_x0 != nullptr;  // gZ_0 is only exchanged for the input gradient
       const bool do_x = want_gx && L.in_x;
@@ -589,7 +625,7 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const 
     }
     __syncthreads();
     for (int l = nL - 1; l >= 0; --l) {
-      const FusedLayer L = a.layer[l];
+      const FusedLayer L = get_layer(a, l);
       if (col0 >= L.out) continue;
       const int K = L.in_h + L.in_x;
       const float* own = s_own + l * Bp * NC;
@@ -671,11 +707,15 @@ int make_plan(const skgs_mlp_desc* d, Plan* p) {
 
 void fill_args(const skgs_mlp_desc* d, const Plan& p, FusedArgs* a) {
   a->B = d->B, a->p_dim = d->p_dim, a->p_deg = d->p_degree, a->t_dim = d->t_dim, a->t_deg = d->t_degree;
-  a->IN = p.IN, a->INP = p.INP, a->H = d->hidden, a->n_layers = d->n_layers;
+  a->IN = p.IN, a->n_layers = d->n_layers;
+  a->xmask = a->relu_mask = 0;
   for (int l = 0; l < d->n_layers; ++l) {
     const skgs_mlp_layer& L = d->layer[l];
-    a->layer[l] = FusedLayer{L.W, L.bias, L.gW, L.gb, L.in_hidden, L.in_x0, L.out, L.relu};
+    a->W[l] = L.W, a->bias[l] = L.bias, a->gW[l] = L.gW, a->gb[l] = L.gb;
+    if (L.in_x0) a->xmask |= 1u << l;
+    if (L.relu) a->relu_mask |= 1u << l;
   }
+  a->out_last = d->layer[d->n_layers - 1].out;
   a->n_heads = d->n_heads;
   for (int j = 0; j < 4; ++j) a->head_dim[j] = d->head_dim[j], a->head_out[j] = d->head_out[j], a->head_gout[j] = d->head_gout[j];
 }

@@ -53,6 +53,8 @@ torch.cuda.synchronize()
 st = run.workspace[64:256].view(torch.int32).cpu().tolist()
 names = ['prologue', 'layer0'] + [n for l in range(1, 9) for n in (f'gather{l}', f'layer{l}')]
 print(f'entry -> first stamp (prologue): {((st[0] - st[46]) & 0xffffffff) * 10} ns')
+if st[40]:
+    print(f'  entry -> loads issued {((st[40] - st[46]) & 0xffffffff) * 10} ns, -> sines done {((st[42] - st[46]) & 0xffffffff) * 10} ns, -> LDS filled {((st[44] - st[46]) & 0xffffffff) * 10} ns')
 for i in range(1, len(names)):
     dt, dc = (st[2 * i] - st[2 * i - 2]) & 0xffffffff, (st[2 * i + 1] - st[2 * i - 1]) & 0xffffffff
     print(f'{names[i]:>10}: +{dt * 10} ns  {dc} clk  ({dc / max(dt, 1) * 100:.0f} MHz)')
