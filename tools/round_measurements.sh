@@ -1,0 +1,28 @@
+#!/bin/bash
+# One gpurun call at a milestone: GPU tests (+ observed parity statistics), the default bench line, one bench line per BASELINE
+# config, the dense variants, the forced 1-rank RCCL run, the comparison variants, kernel stats + PMC passes (config #1 and #4).
+# usage (on the GPU box, from the repo root): bash tools/round_measurements.sh <tag>      e.g. r02_a
+tag=${1:-rXX}
+out=gpurun_out/$tag
+rm -rf "$out"; mkdir -p "$out"
+python -m pytest tests -m gpu -q 2>&1 | tail -3 > $out/gpu_tests.txt; cat $out/gpu_tests.txt
+cp gpurun_out/parity_observed.json $out/parity_observed.json 2>/dev/null
+python bench.py > $out/bench_default.json 2> $out/bench_default.err; cut -c1-200 $out/bench_default.json
+for c in 0 1 2 3 4; do
+  python bench.py --config $c --steps 100 --warmup 10 --no-cpu-baseline > $out/bench_config$c.json 2>/dev/null
+  python -c "import json; d=json.load(open('$out/bench_config$c.json')); print('config $c', d['value'], d['ms_per_step'])"
+done
+for sm in 2.5 4; do
+  python bench.py --scale-mult $sm --steps 100 --warmup 10 --no-cpu-baseline --no-ms-per-render > $out/bench_dense_x$sm.json 2>/dev/null
+  python -c "import json; d=json.load(open('$out/bench_dense_x$sm.json')); print('dense x$sm', d['value'], d['ms_per_step'], d['config']['num_rendered_mean'])"
+done
+SKGS_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_rccl_1rank.json
+python -c "import json; d=json.load(open('$out/bench_rccl_1rank.json')); print('1-rank RCCL group', d['value'], d['ms_per_step'], d['config']['parallelism'])"
+for v in "--bone-tables" "--layered-mlp" "--graph-per-view" "--autograd" "--compact-lists"; do
+  python bench.py $v --no-cpu-baseline --no-ms-per-render 2>/dev/null | tail -1 > "$out/bench_variant${v}.json"
+  python -c "import json; d=json.load(open('$out/bench_variant${v}.json')); print('variant $v', d['value'], d['ms_per_step'])"
+done
+python tools/time_mlp.py 2>/dev/null | grep "fused" > $out/time_mlp.txt; cat $out/time_mlp.txt
+python tools/time_densify.py 2>/dev/null | tail -2 > $out/time_densify.txt; cat $out/time_densify.txt
+bash tools/profile_round.sh ${tag}_c1 > /dev/null 2>&1; ls gpurun_out/${tag}_c1 | head
+bash tools/profile_round.sh ${tag}_c4 --config 4 > /dev/null 2>&1; ls gpurun_out/${tag}_c4 | head
