@@ -182,6 +182,9 @@ def main():
                          'networks/sk_gs.py:1080-1085) instead of running the 8x256 deform network inside every step.  The '
                          'reference runs the network in every TRAINING step (sk_gs.py:1073-1074): that is the default here')
     ap.add_argument('--deform-net', dest='deform_net', action='store_true', help='(default) the deform network inside the step')
+    ap.add_argument('--fixed-joints', dest='learn_joints', action='store_false', default=True,
+                    help='keep the joint positions constant; by default they are trained at 0.1 x lr as in stage sk '
+                         '(networks/sk_gs.py:379,607): gradient through the kinematic chain and the network input')
     ap.add_argument('--scale-mult', type=float, default=1.0,
                     help='multiply every Gaussian\'s scale: 2.5 gives a DENSE scene (R of several million tile instances, tile '
                          'lists beyond 1024 entries: the LDS / global sort paths and long blend walks are timed); 1 = SURVEY 8d')
@@ -225,7 +228,7 @@ def main():
     # ---------------------------------------------------------------- synthetic scene, resident in HBM
     frames = args.views
     model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=0, deform_net=args.deform_net,
-                             scale_mult=args.scale_mult).to(dev)
+                             scale_mult=args.scale_mult, learn_joints=args.learn_joints).to(dev)
     cams = [scene.make_camera(W, H, seed=i) for i in range(args.views)]
     settings = [scene.raster_settings_from_camera(c, sh_degree=3, colmap=True, device=dev) for c in cams]
     background = torch.ones(3, device=dev)
@@ -262,6 +265,8 @@ def main():
         bucket1 += [t for t in (model.sk_r, model.sk_d_rot, model.sk_d_scale, model.global_tr) if t is not None]
         if model.sk_deform_net is not None:
             bucket1 += list(model.sk_deform_net.parameters())
+        if model.learn_joints:
+            bucket1.append(model.joints)
         fac_local = fac_all = None
         if pipelined:
             vp = BucketedGradReducer([bucket0, bucket1], extras=[0, P * model.K])
@@ -638,6 +643,7 @@ def main():
                                            + ('one launch per layer' if args.layered_mlp else 'one persistent launch per direction'))
                        if args.deform_net and M > 0 else 'per-frame tables (test-time cache, sk_gs.py:1080-1085): NOT the '
                                                          'reference\'s training step',
+                       'joints': 'trained, lr x 0.1 (sk_gs.py:607)' if model.learn_joints else 'fixed',
                        'step': 'autograd operator path' if args.autograd else 'FusedViewStep (direct C-ABI calls)',
                        'replicas_identical': replicas_identical, 'param_digest': param_digest},
             'roofline': {'bound': 'hbm', 'kernel': 'render_backward', 'achieved': round(achieved, 2),

@@ -49,7 +49,7 @@ def main():
     P, M, W = args.gaussians, args.bones, args.size
     # "ground truth": a scene rendered from a second, perturbed set of parameters
     teacher = SkinnedGaussians(P, M, 4, num_frames=args.views, seed=1, deform_net=True).to(dev)
-    model = SkinnedGaussians(P, M, 4, num_frames=args.views, seed=1, deform_net=True).to(dev)
+    model = SkinnedGaussians(P, M, 4, num_frames=args.views, seed=1, deform_net=True, learn_joints=True).to(dev)
     with torch.no_grad():
         model._features_dc.mul_(0.5)
         model._opacity.sub_(0.5)

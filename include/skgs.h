@@ -304,7 +304,7 @@ int skgs_adam_step(int32_t n_tensors, const void* tensors, int64_t total_chunks,
 int skgs_freq_encode_forward(int32_t B, int32_t D, int32_t degree, const float* x, int32_t ld_x /* 0: one input row
     for all B output rows */, float* out, int32_t ld_out, skgs_stream_t stream);
 int skgs_freq_encode_backward(int32_t B, int32_t D, int32_t degree, const float* grad_out, const float* out, int32_t ld_out,
-    float* grad_x, skgs_stream_t stream);
+    float* grad_x, int32_t accumulate /* 0: grad_x is written, 1: added to */, skgs_stream_t stream);
 int skgs_linear_forward(int32_t B, int32_t in1, int32_t in2, int32_t out, const float* X1, int32_t ldx1, const float* X2,
     int32_t ldx2, const float* W, const float* bias, float* Y, int32_t ldy, int32_t relu, skgs_stream_t stream);
 int skgs_linear_backward(int32_t B, int32_t in1, int32_t in2, int32_t out, const float* X1, int32_t ldx1, const float* X2,

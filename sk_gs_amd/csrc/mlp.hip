@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) freq_encode_forward_kernel(int B, int D, 
 
 // grad_x[b, d] = g[b, d] + sum_f 2^f (g[b, D + 2 f D + d] * out[.. + D + d] - g[.. + D + d] * out[..])   (cos = next slot)
 __global__ void __launch_bounds__(256) freq_encode_backward_kernel(int B, int D, int deg, const float* __restrict__ g,
-    const float* __restrict__ out, int ldo, float* __restrict__ gx) {
+    const float* __restrict__ out, int ldo, float* __restrict__ gx, int accumulate) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= B * D) return;
   const int b = t / D, d = t - b * D;
@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) freq_encode_backward_kernel(int B, int D,
     const int s = D + 2 * f * D;
     r += scalbnf(1.0f, f) * (gr[s + d] * o[s + D + d] - gr[s + D + d] * o[s + d]);
   }
-  gx[t] = r;
+  gx[t] = accumulate ? gx[t] + r : r;
 }
 
 // Copy nrows x ncols floats (row stride ld) into LDS rows of pitch `pitch` starting at column col0, four 16-byte loads
@@ -258,12 +258,12 @@ int skgs_freq_encode_forward(int32_t B, int32_t D, int32_t degree, const float* 
 }
 
 int skgs_freq_encode_backward(int32_t B, int32_t D, int32_t degree, const float* grad_out, const float* out, int32_t ld_out,
-    float* grad_x, skgs_stream_t stream) {
+    float* grad_x, int32_t accumulate, skgs_stream_t stream) {
   SKGS_REQUIRE(B >= 0 && D >= 1 && degree >= 0, "freq_encode: bad sizes");
   if (B == 0) return 0;
   SKGS_REQUIRE(grad_out && out && grad_x, "freq_encode_backward: NULL argument");
   hipLaunchKernelGGL(freq_encode_backward_kernel, dim3((B * D + 255) / 256), dim3(256), 0, (hipStream_t) stream, B, D, degree,
-      grad_out, out, ld_out, grad_x);
+      grad_out, out, ld_out, grad_x, accumulate);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

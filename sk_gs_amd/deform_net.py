@@ -158,32 +158,56 @@ class DeformMLPRunner:
                  x0.data_ptr() if in2 else None, net.in_channels, net.last_weight.data_ptr(), net.last_bias.data_ptr(),
                  out.data_ptr(), out.shape[1], 0)
 
-    def backward_hidden(self, x0: Tensor, acts: Tensor, grads: List[Tensor], g_act: Tensor):
+    def backward_hidden(self, x0: Tensor, acts: Tensor, grads: List[Tensor], g_act: Tensor, g_x0: Optional[Tensor] = None,
+                        g_x0_started: bool = False):
         """hidden layers, last to first; ``g_act[0]`` holds dL/d(last activation) on entry.  ``grads``: [gW0, gb0, ...]
-        (written).  The encoded input gets no gradient: joints and time are inputs of the skeleton stage."""
+        (written).  ``g_x0`` [B, IN]: if given, receives dL/d(encoded input) -- the first layer's and every skip layer's
+        contribution (joints trained through the network's input, networks/sk_gs.py:604-607,1073); ``g_x0_started``: the
+        heads already wrote into it."""
         net, lib = self.mlp.dynamic_net, self.lib
         B, IN, H, L = x0.shape[0], net.in_channels, net.dim_hidden, net.num_layers
         dims = net.layer_dims()
         x0p = x0.data_ptr()
+        gx0p = None if g_x0 is None else g_x0.data_ptr()
+        started = g_x0_started
         cur = 0
         for i in range(L - 1, -1, -1):
             in1, in2 = dims[i]
             layer = net.net[i]
             x1, ld1 = (acts[i - 1].data_ptr(), H) if i > 0 else (x0p, IN)
-            gx1 = g_act[1 - cur].data_ptr() if i > 0 else None
+            if i > 0:
+                gx1, ldg1, gx2 = g_act[1 - cur].data_ptr(), H, (gx0p if in2 else None)
+                acc = 2 if (gx2 is not None and started) else 0
+                started = started or gx2 is not None
+            else:  # the first layer's input IS the encoded input
+                gx1, ldg1, gx2 = gx0p, IN, None
+                acc = 1 if (gx1 is not None and started) else 0
             _lin_bwd(lib, B, in1, in2, H, x1, ld1, x0p if in2 else None, IN, layer.weight.data_ptr(), acts[i].data_ptr(),
-                     g_act[cur].data_ptr(), H, 1, grads[2 * i].data_ptr(), grads[2 * i + 1].data_ptr(), gx1, H, None, IN, 0)
+                     g_act[cur].data_ptr(), H, 1, grads[2 * i].data_ptr(), grads[2 * i + 1].data_ptr(), gx1, ldg1, gx2, IN,
+                     acc)
             cur = 1 - cur
 
-    def backward(self, x0: Tensor, acts: Tensor, out: Tensor, g_out: Tensor, grads: List[Tensor], g_act: Tensor):
-        """``grads``: [gW0, gb0, ..., gW_last, gb_last] (written); ``g_act`` [2, B, H] ping-pong scratch"""
+    def backward(self, x0: Tensor, acts: Tensor, out: Tensor, g_out: Tensor, grads: List[Tensor], g_act: Tensor,
+                 g_x0: Optional[Tensor] = None):
+        """``grads``: [gW0, gb0, ..., gW_last, gb_last] (written); ``g_act`` [2, B, H] ping-pong scratch; ``g_x0`` [B, IN]
+        (written) or None"""
         net, lib = self.mlp.dynamic_net, self.lib
         B, IN, H, L = x0.shape[0], net.in_channels, net.dim_hidden, net.num_layers
         in1, in2 = net.layer_dims()[-1]
+        gx2 = g_x0.data_ptr() if (g_x0 is not None and in2) else None
         _lin_bwd(lib, B, in1, in2, out.shape[1], acts[L - 1].data_ptr(), H, x0.data_ptr() if in2 else None, IN,
                  net.last_weight.data_ptr(), None, g_out.data_ptr(), out.shape[1], 0, grads[-2].data_ptr(),
-                 grads[-1].data_ptr(), g_act[0].data_ptr(), H, None, IN, 0)
-        self.backward_hidden(x0, acts, grads[:-2], g_act)
+                 grads[-1].data_ptr(), g_act[0].data_ptr(), H, gx2, IN, 0)
+        self.backward_hidden(x0, acts, grads[:-2], g_act, g_x0, g_x0_started=gx2 is not None)
+
+    def input_grad(self, g_x0: Tensor, x0: Tensor, g_points: Tensor, accumulate: bool = False):
+        """dL/d(points) [B, p_in] from dL/d(encoded input): the frequency-encoding backward (freqencoder.cu:36-60) over the
+        point part of the encoding (the time part belongs to no parameter)"""
+        m = self.mlp
+        _C._check(self.lib.skgs_freq_encode_backward(
+            C.c_int32(x0.shape[0]), C.c_int32(m.p_in), C.c_int32(m.p_degree), C.c_void_p(g_x0.data_ptr()),
+            C.c_void_p(x0.data_ptr()), C.c_int32(x0.shape[1]), C.c_void_p(g_points.data_ptr()), C.c_int32(int(accumulate)),
+            _C._stream()))
 
 
 class _MlpLayer(C.Structure):
@@ -304,6 +328,7 @@ class _DeformMLPFn(torch.autograd.Function):
     def forward(ctx, mlp: DeformMLP, points: Tensor, t: Tensor, *params):
         _C._require_gpu(points, 'points')
         net = mlp.dynamic_net
+        ctx.need_points = points.requires_grad  # joints trained through the network input (sk_gs.py:604-607)
         points = points.detach().float().contiguous()
         t = t.detach().float().reshape(-1).contiguous().to(points.device)
         B = points.shape[0]
@@ -334,10 +359,21 @@ class _DeformMLPFn(torch.autograd.Function):
         net = mlp.dynamic_net
         params = [p for l in net.net for p in (l.weight, l.bias)] + [net.last_weight, net.last_bias]
         grads = [torch.empty_like(p) for p in params]
+        g_points = None
         if ctx.fused is not None:
-            ctx.fused.backward(ctx.pt[0], ctx.pt[1], g_out.contiguous(), grads)
-            return (None, None, None) + tuple(grads)
+            run = ctx.fused
+            g_x0 = torch.empty_like(run.x0) if ctx.need_points else None
+            run.backward(ctx.pt[0], ctx.pt[1], g_out.contiguous(), grads, g_x0)
+            if g_x0 is not None:
+                g_points = torch.empty_like(ctx.pt[0])
+                DeformMLPRunner(mlp).input_grad(g_x0, run.x0, g_points)
+            return (None, g_points, None) + tuple(grads)
         x0, acts, out = ctx.saved_tensors
         g_act = torch.empty((2,) + tuple(acts.shape[1:]), dtype=torch.float32, device=acts.device)
-        DeformMLPRunner(mlp).backward(x0, acts, out, g_out.contiguous(), grads, g_act)
-        return (None, None, None) + tuple(grads)  # joints / time are inputs of the skeleton stage, not learned here
+        g_x0 = torch.empty_like(x0) if ctx.need_points else None
+        run = DeformMLPRunner(mlp)
+        run.backward(x0, acts, out, g_out.contiguous(), grads, g_act, g_x0)
+        if g_x0 is not None:
+            g_points = torch.empty((x0.shape[0], mlp.p_in), dtype=torch.float32, device=x0.device)
+            run.input_grad(g_x0, x0, g_points)
+        return (None, g_points, None) + tuple(grads)  # the time is an input, not a parameter

@@ -136,6 +136,7 @@ class FusedViewStep:
             self._sk_r_raw, self._d_rot, self._d_scale = (torch.empty((M, 4), **f32), torch.empty((M, 4), **f32),
                                                           torch.empty((M, 3), **f32))
             self._g_heads = [torch.empty((M, 4), **f32), torch.empty((M, 4), **f32), torch.empty((M, 3), **f32)]
+            self._g_x0 = torch.empty((M, net.in_channels), **f32) if getattr(model, 'learn_joints', False) else None
         # per-view inputs as device loads (sk_gs_amd/view_slot.py): forward_backward() without arguments then trains the
         # view selected in the table, and ONE captured graph serves all of them
         self.view_table = view_table
@@ -361,7 +362,8 @@ class FusedViewStep:
         chk(lib.skgs_bone_chain_backward(
             C.c_int32(M), C.c_int32(t['root']), _p(t['parents']), _p(t['level_nodes']), _p(t['level_start']),
             C.c_int32(t['num_levels']), _p(sk_r_raw), _p(m.joints), C.c_void_p(gT), _p(self.chain_A),
-            _p(self.g_bone_T), _p(g_raw), None, C.c_void_p(g_gT), fidx, st))
+            _p(self.g_bone_T), _p(g_raw), _p(m.joints.grad) if getattr(m, 'learn_joints', False) else None, C.c_void_p(g_gT),
+            fidx, st))
         if self.deform_net is not None:
             self._deform_net_backward()
         if self.densify_stats:
@@ -414,7 +416,9 @@ class FusedViewStep:
         if self._mlp_fused is not None:
             net = self.deform_net.dynamic_net
             grads = [g for l in net.net for g in (l.weight.grad, l.bias.grad)] + [net.last_weight.grad, net.last_bias.grad]
-            self._mlp_fused.backward(self.model.joints, self._time_tensor(self._time_id), self._g_heads, grads)
+            self._mlp_fused.backward(self.model.joints, self._time_tensor(self._time_id), self._g_heads, grads, self._g_x0)
+            if self._g_x0 is not None:  # joints.grad (written by the bone-chain backward) += the network-input path
+                self._mlp.input_grad(self._g_x0, self._mlp_fused.x0, self.model.joints.grad, accumulate=True)
             return
         from sk_gs_amd.deform_net import _lin_bwd
         net, run = self.deform_net.dynamic_net, self._mlp
@@ -427,7 +431,9 @@ class FusedViewStep:
                      net.last_bias.grad[o:].data_ptr(), self._g_act[0].data_ptr(), H, None, IN, 1 if j > 0 else 0)
             o += oc
         grads = [g for l in net.net for g in (l.weight.grad, l.bias.grad)]
-        run.backward_hidden(self._x0, self._acts, grads, self._g_act)
+        run.backward_hidden(self._x0, self._acts, grads, self._g_act, self._g_x0)
+        if self._g_x0 is not None:
+            run.input_grad(self._g_x0, self._x0, self.model.joints.grad, accumulate=True)
 
     @torch.no_grad()
     def scatter_spw_grad(self):

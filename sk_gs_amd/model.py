@@ -22,7 +22,7 @@ from sk_gs_amd.renderer.gaussian_render import GaussianRasterizationSettings, re
 
 class SkinnedGaussians(nn.Module):
     def __init__(self, P: int, M: int, K: int = 5, sh_degree: int = 3, num_frames: int = 8, seed: int = 0,
-                 scale_mult: float = 1.0, deform_net: bool = False):
+                 scale_mult: float = 1.0, deform_net: bool = False, learn_joints: bool = False):
         super().__init__()
         g = scene.make_gaussians(P, seed=seed, sh_degree=sh_degree, scale_mult=scale_mult)
         b = scene.make_bones(max(M, 1), seed=seed)
@@ -37,7 +37,13 @@ class SkinnedGaussians(nn.Module):
         self._opacity = nn.Parameter(g['opacity_logit'])
         gen = torch.Generator().manual_seed(3000 + seed)
         self.sp_W = nn.Parameter(torch.randn(P, max(M, 1), generator=gen))
-        self.register_buffer('joints', b['joints'])
+        # stage sk trains the joint positions at 0.1 x the base rate (sk_gs.py:379,607): through the kinematic chain and,
+        # with the deform network, through the network's input
+        self.learn_joints = bool(learn_joints) and M > 0
+        if self.learn_joints:
+            self.joints = nn.Parameter(b['joints'])
+        else:
+            self.register_buffer('joints', b['joints'])
         table, depth = skeleton.build_ancestor_table(b['parents'], 0)
         self.register_buffer('joint_parents', table)
         self.joint_root = 0
@@ -90,6 +96,8 @@ class SkinnedGaussians(nn.Module):
             else:
                 groups.append({'params': [self.global_tr], 'lr': lr, 'name': 'skinning'})
                 groups.append({'params': list(self.sk_deform_net.parameters()), 'lr': lr, 'name': 'deform_net'})
+            if self.learn_joints:
+                groups.append({'params': [self.joints], 'lr': lr * 0.1, 'name': 'joints'})  # lr_joints = 0.1
         return groups
 
     # --------------------------------------------------------------------------------------------------- forward

@@ -63,8 +63,12 @@ def test_freq_encode_kernels():
     gx = torch.empty_like(x)
     _C._check(lib.skgs_freq_encode_backward(C.c_int32(B), C.c_int32(D), C.c_int32(deg), C.c_void_p(gy.data_ptr()),
                                             C.c_void_p(out.data_ptr()), C.c_int32(Cdim + 5), C.c_void_p(gx.data_ptr()),
-                                            _C._stream()))
+                                            C.c_int32(0), _C._stream()))
     assert rel_err(gx, xr.grad) <= 1e-4
+    _C._check(lib.skgs_freq_encode_backward(C.c_int32(B), C.c_int32(D), C.c_int32(deg), C.c_void_p(gy.data_ptr()),
+                                            C.c_void_p(out.data_ptr()), C.c_int32(Cdim + 5), C.c_void_p(gx.data_ptr()),
+                                            C.c_int32(1), _C._stream()))  # accumulate: twice the gradient
+    assert rel_err(gx, 2 * xr.grad) <= 1e-4
     # one time value broadcast to all rows (ld_x = 0)
     t = torch.tensor([0.37], device='cuda')
     out_t = torch.empty(B, 13, device='cuda')
@@ -88,6 +92,32 @@ def test_deform_mlp_forward_backward_matches_reference_forward():
     out = torch.cat(mlp(joints, t), dim=-1)
     assert rel_err(out, ref) <= 2e-5
     out.backward(g)
+    for (n, p), gr in zip(mlp.named_parameters(), gref):
+        assert rel_err(p.grad, gr) <= 5e-5, n
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_deform_mlp_gradient_reaches_the_joint_positions(fused):
+    """joints are a trained parameter in stage sk (networks/sk_gs.py:507,607) and enter the network through the frequency
+    encoding (sk_gs.py:1073): dL/d(joints) of both GPU paths equals torch autograd through reference_forward"""
+    from sk_gs_amd.deform_net import DeformMLP
+    torch.manual_seed(3)
+    mlp = DeformMLP().cuda()
+    joints = (torch.rand(20, 3, device='cuda') - 0.5).requires_grad_(True)
+    t = torch.tensor([0.63], device='cuda')
+    ref = torch.cat(mlp.reference_forward(joints, t), dim=-1)
+    g = torch.randn_like(ref)
+    ref.backward(g)
+    g_joints, joints.grad = joints.grad.clone(), None
+    gref = [p.grad.clone() for p in mlp.parameters()]
+    for p in mlp.parameters():
+        p.grad = None
+    mlp.force_layered = not fused
+    out = torch.cat(mlp(joints, t), dim=-1)
+    out.backward(g)
+    assert float(g_joints.abs().max()) > 0
+    # d(sin(2^9 x))/dx multiplies rounding of the argument by 512: looser than the weight gradients
+    assert rel_err(joints.grad, g_joints) <= 2e-4
     for (n, p), gr in zip(mlp.named_parameters(), gref):
         assert rel_err(p.grad, gr) <= 5e-5, n
 

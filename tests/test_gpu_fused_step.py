@@ -134,17 +134,21 @@ def test_split_step_with_compact_logit_gradient_matches_the_single_call():
     assert red.allreduce(0) is None  # no process group: nothing to do
 
 
-def test_fused_step_with_the_deform_network_matches_autograd():
+@pytest.mark.parametrize('learn_joints,fused_net', [(False, True), (True, True), (True, False)])
+def test_fused_step_with_the_deform_network_matches_autograd(learn_joints, fused_net):
     """stage sk with the bone-transform producer network inside the step (scope row (f)-3): its weight gradients from
-    FusedViewStep equal those of the autograd path (DeformMLP -> bone_chain -> lbs_deform -> render -> loss)"""
+    FusedViewStep equal those of the autograd path (DeformMLP -> bone_chain -> lbs_deform -> render -> loss); with
+    ``learn_joints`` so does the gradient of the joint positions (chain + network-input paths, sk_gs.py:607,1073,1090)"""
     from sk_gs_amd import _C, scene
     from sk_gs_amd.fused_step import FusedViewStep
     from sk_gs_amd.losses import image_loss
     from sk_gs_amd.model import SkinnedGaussians
     P, M, K, W, H, frames, tid = 3000, 10, 4, 128, 96, 3, 2
     dev = torch.device('cuda')
-    model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=2, scale_mult=2.0, deform_net=True).to(dev)
+    model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=2, scale_mult=2.0, deform_net=True,
+                             learn_joints=learn_joints).to(dev)
     assert model.sk_r is None and any(n.startswith('sk_deform_net.') for n, _ in model.named_parameters())
+    assert ('joints' in dict(model.named_parameters())) == learn_joints
     cam = scene.make_camera(W, H, seed=2)
     rs = scene.raster_settings_from_camera(cam, sh_degree=3, colmap=True, device=dev)
     target = torch.rand(3, H, W, generator=torch.Generator().manual_seed(3)).to(dev)
@@ -157,7 +161,9 @@ def test_fused_step_with_the_deform_network_matches_autograd():
     R = out['buffer'].R
     for p in model.parameters():
         p.grad = torch.full_like(p, 5.0)
-    step = FusedViewStep(model, W, H, capacity=int(R * 1.2) + 1024)
+    if learn_joints:
+        assert float(ref['joints'].abs().max()) > 0
+    step = FusedViewStep(model, W, H, capacity=int(R * 1.2) + 1024, fused_deform_net=fused_net)
     step.forward_backward(rs, tid, target)
     assert rel_err(step.image, out['images'].detach()) <= 5e-6
     for n, p in model.named_parameters():
