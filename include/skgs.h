@@ -291,6 +291,13 @@ int64_t skgs_adam_chunk_elems(void);
 int skgs_adam_step(int32_t n_tensors, const void* tensors, int64_t total_chunks, double beta1, double beta2, double eps,
     float* step_count, float* zero_after /* NULL, or zero_n floats cleared after the update (with the counter bump) */,
     int64_t zero_n, skgs_stream_t stream);
+/* The same step taken in pieces: chunks [chunk_begin, chunk_end) of the table (whole tensors) get the update of step
+ * *step_count + 1; only a piece with advance = 1 moves the counter and clears zero_after, and it must be ordered after
+ * every other piece of that step.  Pieces may run on different streams beside backward kernels that do not touch their
+ * tensors (the SH rows are final after the rasterizer backward, the Gaussian rows after the skinning backward: their
+ * Adam runs beside the bone-chain / deform-network backward).  chunk_begin == chunk_end, advance = 1: counter only. */
+int skgs_adam_step_range(int32_t n_tensors, const void* tensors, int64_t chunk_begin, int64_t chunk_end, double beta1,
+    double beta2, double eps, float* step_count, int32_t advance, float* zero_after, int64_t zero_n, skgs_stream_t stream);
 
 /* ---- bone-transform producer of the skeleton stage (scope row (f)-3) ----
  * SimpleDeformationNetwork (networks/sk_gs.py:134-164): FreqEncoder (my_ext/_C/src/nerf/freqencoder.cu:7-60) +

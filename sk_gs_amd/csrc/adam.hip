@@ -31,14 +31,15 @@ constexpr int ADAM_THREADS = 256;
 constexpr int ADAM_CHUNK   = ADAM_THREADS * 4 * 4;  // elements per workgroup iteration (4 float4 per lane)
 
 __global__ void __launch_bounds__(ADAM_THREADS) adam_step_kernel(int n_tensors, const AdamTensor* __restrict__ tensors,
-    int64_t total_chunks, double beta1d, double beta2d, float eps, const float* __restrict__ step_count) {
+    int64_t chunk_begin, int64_t total_chunks, double beta1d, double beta2d, float eps,
+    const float* __restrict__ step_count) {
   // hyper-parameters arrive as doubles and (1 - beta) is formed in double, as torch does: 1.0f - 0.999f is off by 1.3e-5
   const double t   = (double) step_count[0] + 1.0;
   const float bc1  = (float) (1.0 - pow(beta1d, t));
   const float inv_sqrt_bc2 = (float) (1.0 / sqrt(1.0 - pow(beta2d, t)));
   const float beta1 = (float) beta1d, beta2 = (float) beta2d;
   const float omb1 = (float) (1.0 - beta1d), omb2 = (float) (1.0 - beta2d);
-  for (int64_t chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
+  for (int64_t chunk = chunk_begin + blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
     int ti = 0;
     while (ti + 1 < n_tensors && tensors[ti + 1].chunk0 <= chunk) ++ti;
     const AdamTensor T = tensors[ti];
@@ -101,17 +102,33 @@ int64_t skgs_adam_chunk_elems(void) { return ADAM_CHUNK; }
  * number of steps taken so far; incremented by the call. */
 int skgs_adam_step(int32_t n_tensors, const void* tensors, int64_t total_chunks, double beta1, double beta2, double eps,
     float* step_count, float* zero_after, int64_t zero_n, skgs_stream_t stream) {
-  SKGS_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || (tensors && step_count)), "adam_step: NULL argument");
   if (n_tensors == 0 || total_chunks == 0) return 0;
-  hipStream_t s   = (hipStream_t) stream;
-  const int grid  = (int) std::min<int64_t>(total_chunks, 256 * 16);
-  hipLaunchKernelGGL(adam_step_kernel, dim3(grid), dim3(ADAM_THREADS), 0, s, n_tensors,
-      reinterpret_cast<const AdamTensor*>(tensors), total_chunks, beta1, beta2, (float) eps, step_count);
-  SKGS_CHECK_HIP(hipGetLastError());
-  const int64_t zn = zero_after ? std::max<int64_t>(zero_n, 0) : 0;
-  hipLaunchKernelGGL(adam_bump_kernel, dim3((unsigned) std::max<int64_t>(1, (zn + 255) / 256)), dim3(256), 0, s, step_count,
-      zero_after, zn);
-  SKGS_CHECK_HIP(hipGetLastError());
+  return skgs_adam_step_range(n_tensors, tensors, 0, total_chunks, beta1, beta2, eps, step_count, 1, zero_after, zero_n,
+      stream);
+}
+
+/* One step taken in pieces: the chunks [chunk_begin, chunk_end) of the table (whole tensors: the chunk0 of a tensor and of
+ * the one after it) are updated with the bias correction of step *step_count + 1; the counter moves (and zero_after is
+ * cleared) only where `advance` is set -- in the LAST piece, ordered after all the others.  Pieces of one step may run on
+ * different streams, beside the backward kernels that do not touch their tensors.  chunk_begin == chunk_end with
+ * advance = 1 only moves the counter. */
+int skgs_adam_step_range(int32_t n_tensors, const void* tensors, int64_t chunk_begin, int64_t chunk_end, double beta1,
+    double beta2, double eps, float* step_count, int32_t advance, float* zero_after, int64_t zero_n, skgs_stream_t stream) {
+  SKGS_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || tensors) && step_count, "adam_step: NULL argument");
+  SKGS_REQUIRE(chunk_begin >= 0 && chunk_end >= chunk_begin, "adam_step: bad chunk range");
+  hipStream_t s = (hipStream_t) stream;
+  if (n_tensors > 0 && chunk_end > chunk_begin) {
+    const int grid = (int) std::min<int64_t>(chunk_end - chunk_begin, 256 * 16);
+    hipLaunchKernelGGL(adam_step_kernel, dim3(grid), dim3(ADAM_THREADS), 0, s, n_tensors,
+        reinterpret_cast<const AdamTensor*>(tensors), chunk_begin, chunk_end, beta1, beta2, (float) eps, step_count);
+    SKGS_CHECK_HIP(hipGetLastError());
+  }
+  if (advance) {
+    const int64_t zn = zero_after ? std::max<int64_t>(zero_n, 0) : 0;
+    hipLaunchKernelGGL(adam_bump_kernel, dim3((unsigned) std::max<int64_t>(1, (zn + 255) / 256)), dim3(256), 0, s,
+        step_count, zero_after, zn);
+    SKGS_CHECK_HIP(hipGetLastError());
+  }
   return 0;
 }
 

@@ -66,7 +66,9 @@ class FusedAdam:
         """(re)build the device descriptor table; must run outside graph capture (H2D copy)"""
         blob, chunk0 = bytearray(), 0
         grads = []
+        self._chunk0 = []  # first chunk of every parameter (+ the total at the end): ranges for partial steps
         for p, gi in zip(self.params, self._lr_index):
+            self._chunk0.append(chunk0)
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
             st = self.state[p]
@@ -75,6 +77,7 @@ class FusedAdam:
                                 st['exp_avg_sq'].data_ptr(), n, chunk0, float(self.param_groups[gi]['lr']), 0.0)
             chunk0 += (n + self._chunk - 1) // self._chunk
             grads.append(p.grad.data_ptr())
+        self._chunk0.append(chunk0)
         self._total_chunks = chunk0
         self._bound_grads = grads
         self._h2d(self._table, blob)
@@ -255,15 +258,50 @@ class FusedAdam:
             if p.grad is not None:
                 p.grad.zero_()
 
-    def step(self):
+    def _chunk_ranges(self, groups):
+        """chunk ranges of the named groups' parameters: one per run of neighbours in the table"""
+        groups = set(groups)
+        known = {g.get('name') for g in self.param_groups}
+        assert groups <= known, f'unknown parameter groups {sorted(groups - known)}'
+        idx = [i for i, gi in enumerate(self._lr_index) if self.param_groups[gi].get('name') in groups]
+        runs = []
+        for i in idx:
+            if runs and runs[-1][1] == self._chunk0[i]:
+                runs[-1][1] = self._chunk0[i + 1]
+            else:
+                runs.append([self._chunk0[i], self._chunk0[i + 1]])
+        return [tuple(r) for r in runs if r[1] > r[0]]
+
+    def step(self, groups=None, advance: bool = True):
+        """One Adam step over every parameter, or -- ``groups`` = names of parameter groups -- the piece of it that
+        updates those groups (one launch per run of groups that are neighbours in the table).  A step taken in pieces lets each piece start as soon as ITS gradients are final, on a
+        side stream beside the rest of the backward (``OverlappedStep``): every piece uses the bias correction of the
+        same step; pass ``advance=False`` to all of them and call ``advance_step()`` once, after they have all been
+        ordered before it (the counter every piece reads must not move under them)."""
         if not torch.cuda.is_current_stream_capturing():
             # the table holds raw gradient pointers: refresh it if autograd replaced a .grad tensor
             if any(p.grad is None or p.grad.data_ptr() != g for p, g in zip(self.params, self._bound_grads)):
                 self._upload()
         lib = _C.load_library()
+        z = self.zero_after_step if advance else None
+        ranges = [(0, self._total_chunks)] if groups is None else self._chunk_ranges(groups)
+        if advance and not ranges:
+            ranges = [(0, 0)]
+        for k, (c0, c1) in enumerate(ranges):
+            last = advance and k == len(ranges) - 1
+            _C._check(lib.skgs_adam_step_range(
+                C.c_int32(len(self.params)), C.c_void_p(self._table.data_ptr()), C.c_int64(c0), C.c_int64(c1),
+                C.c_double(self.betas[0]), C.c_double(self.betas[1]), C.c_double(self.eps),
+                C.c_void_p(self.step_count.data_ptr()), C.c_int32(1 if last else 0),
+                C.c_void_p(z.data_ptr() if (z is not None and last) else None),
+                C.c_int64(z.numel() if (z is not None and last) else 0), _C._stream()))
+
+    def advance_step(self):
+        """close a step taken in pieces: the counter moves, ``zero_after_step`` is cleared"""
+        lib = _C.load_library()
         z = self.zero_after_step
-        _C._check(lib.skgs_adam_step(C.c_int32(len(self.params)), C.c_void_p(self._table.data_ptr()),
-                                     C.c_int64(self._total_chunks), C.c_double(self.betas[0]), C.c_double(self.betas[1]),
-                                     C.c_double(self.eps), C.c_void_p(self.step_count.data_ptr()),
-                                     C.c_void_p(z.data_ptr() if z is not None else None),
-                                     C.c_int64(z.numel() if z is not None else 0), _C._stream()))
+        _C._check(lib.skgs_adam_step_range(C.c_int32(0), None, C.c_int64(0), C.c_int64(0), C.c_double(self.betas[0]),
+                                           C.c_double(self.betas[1]), C.c_double(self.eps),
+                                           C.c_void_p(self.step_count.data_ptr()), C.c_int32(1),
+                                           C.c_void_p(z.data_ptr() if z is not None else None),
+                                           C.c_int64(z.numel() if z is not None else 0), _C._stream()))

@@ -100,3 +100,36 @@ def test_fused_adam_state_dict_round_trip_and_torch_layout():
     opt3.load_state_dict(tsd)
     assert float(opt3.step_count) == 3
     assert torch.allclose(opt3.state[a3]['exp_avg'], tsd['state'][0]['exp_avg'].cuda())
+
+
+def test_a_step_taken_in_pieces_equals_the_whole_step():
+    """``step(groups, advance=False)`` pieces + ``advance_step()`` (skgs_adam_step_range): every piece uses the bias
+    correction of the same step, the counter moves once -- bit-identical to one launch over all groups"""
+    from sk_gs_amd.optim import FusedAdam
+    gen = torch.Generator().manual_seed(1)
+    names = ['xyz', 'f_dc', 'f_rest', 'opacity', 'net']
+    shapes = [(3000, 3), (3000, 1, 3), (3000, 15, 3), (3000, 1), (257, 33)]
+
+    def make():
+        g = torch.Generator().manual_seed(2)
+        ps = [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in shapes]
+        return ps, FusedAdam([{'params': [p], 'lr': 1e-2 * (i + 1), 'name': n} for i, (p, n) in enumerate(zip(ps, names))])
+    (a, whole), (b, pieces) = make(), make()
+    span = torch.ones(64, device='cuda')
+    pieces.zero_after_step = span
+    for _ in range(4):
+        for p, q in zip(a, b):
+            g = torch.randn(p.shape, generator=gen).cuda()
+            p.grad.copy_(g), q.grad.copy_(g)
+        whole.step()
+        pieces.step(['f_dc', 'f_rest'], advance=False)
+        pieces.step(['xyz', 'opacity'], advance=False)  # not neighbours in the table: two launches
+        assert float(span.sum()) == 64.0 or _ > 0          # a piece does not clear the span ...
+        pieces.step(['net'], advance=False)
+        pieces.advance_step()
+    assert float(pieces.step_count.item()) == 4.0 and float(span.abs().sum()) == 0.0  # ... the closing call does
+    for p, q in zip(a, b):
+        assert torch.equal(p, q)
+        assert torch.equal(whole.state[p]['exp_avg_sq'], pieces.state[q]['exp_avg_sq'])
+    with pytest.raises(AssertionError):
+        pieces.step(['no_such_group'])
