@@ -73,9 +73,9 @@ static int check_inputs(const skgs_raster_inputs* in) {
   SKGS_REQUIRE(in->opacity != nullptr, "opacity is required");
   SKGS_REQUIRE(in->viewmatrix && in->projmatrix && in->campos, "viewmatrix / projmatrix / campos are required");
   SKGS_REQUIRE((in->sh != nullptr) != (in->colors_precomp != nullptr),
-      "Please provide excatly one of either SHs or precomputed colors!");
+      "colour input: pass either SH coefficients or precomputed colours, not both and not neither");
   SKGS_REQUIRE(((in->scales != nullptr) && (in->rotations != nullptr)) != (in->cov3D_precomp != nullptr),
-      "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+      "shape input: pass either (scales, rotations) or a precomputed 3D covariance, not both and not neither");
   if (in->sh) {
     SKGS_REQUIRE(in->sh_degree >= 0 && in->sh_degree <= 3, "sh_degree must be in [0,3]");
     SKGS_REQUIRE(in->sh_coeffs >= (in->sh_degree + 1) * (in->sh_degree + 1), "sh has too few coefficients for sh_degree");

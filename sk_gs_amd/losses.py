@@ -1,8 +1,9 @@
 """Image loss of the training step: ``0.8 * L1 + 0.2 * (1 - SSIM)`` (exps/default.yaml:83-84,
 networks/sk_gs.py:1524-1529, networks/losses/image_loss.py:6-32, networks/losses/ssim.py:20-62).
 
-Plain torch restatement (11x11 Gaussian window, sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2). This is the
-"next" row (f)-1 of the scope table: a fused HIP version replaces it once the hot path meets its bar.
+``image_loss`` is the fused HIP kernel pair of scope row (f)-1 (csrc/image_loss.hip); ``image_loss_torch`` is the plain
+torch restatement (11x11 Gaussian window, sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2) kept as the fp32 numerics
+reference of its tests.
 """
 import math
 

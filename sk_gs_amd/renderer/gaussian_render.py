@@ -165,10 +165,10 @@ class GaussianRasterizer(nn.Module):
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None, extras=None, **kwargs):
         if (shs is None) == (colors_precomp is None):
-            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+            raise Exception('colour input: pass either shs or colors_precomp, not both and not neither')
         if ((scales is None or rotations is None) and cov3D_precomp is None) or (
                 (scales is not None or rotations is not None) and cov3D_precomp is not None):
-            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+            raise Exception('shape input: pass either (scales, rotations) or cov3D_precomp, not both and not neither')
         empty = torch.Tensor([])
         shs = empty if shs is None else shs
         colors_precomp = empty if colors_precomp is None else colors_precomp
