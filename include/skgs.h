@@ -358,12 +358,11 @@ size_t skgs_deform_mlp_workspace_bytes(const skgs_mlp_desc* d);
 int skgs_deform_mlp_workspace_init(void* workspace, size_t workspace_bytes, skgs_stream_t stream);
 int skgs_deform_mlp_forward(const skgs_mlp_desc* d, const float* points, const float* t, float* x0, float* acts, float* out,
     void* workspace, size_t workspace_bytes, skgs_stream_t stream);
-int skgs_deform_mlp_backward(const skgs_mlp_desc* d, const float* points, const float* t, const float* acts,
+/* x0: the [B, IN] encoded input the forward call wrote (its `x0` argument), or NULL: it is re-encoded from points / t
+ * (B x IN sines per workgroup, ~3 us). */
+int skgs_deform_mlp_backward(const skgs_mlp_desc* d, const float* points, const float* t, const float* x0, const float* acts,
     const float* g_out, float* g_x0, void* workspace, size_t workspace_bytes, skgs_stream_t stream);
 int skgs_deform_mlp_status(const void* workspace, uint32_t* host_words4, skgs_stream_t stream);
-/* Tuning knob: output features per workgroup of the fused network kernels: 8 (default: 32 workgroups of 512 threads at
- * hidden = 256) or 4 (64 workgroups of 256 threads, <= 32 rows). */
-void skgs_set_mlp_columns(int ncol);
 
 /* ---- densification statistics of one training view (scope row (f)-4) ----
  * networks/sk_gs.py:1990-1997 + networks/gaussian_splatting.py:503-513: for every Gaussian with radii > 0

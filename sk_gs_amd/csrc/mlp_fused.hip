@@ -8,8 +8,7 @@
 // product).  The arithmetic is nothing (20 x 256 x 256 FMAs per layer); the 2.1 MB of weights and the NINE DEPENDENT
 // LAYERS are the cost.  So:
 //
-//   * G = H / NC workgroups (NC = 4 GROUPS output features each: 32 workgroups of 512 threads, or 64 of 256, at H = 256),
-//     one per CU, all resident.  Workgroup g owns output features [g NC, (g+1) NC) of EVERY layer: its rows of every
+//   * G = H / NC = 32 workgroups of 512 threads (NC = 8 output features each), one per CU, all resident.  Workgroup g owns output features [g NC, (g+1) NC) of EVERY layer: its rows of every
 //     weight matrix are fetched ONCE, up front, with all loads in flight, into LDS -- the 2.1 MB stream is spread over the
 //     workgroups instead of 9 dependent staging round trips.
 //   * between layers the [B, H] activations are exchanged IN-LAUNCH.  Every workgroup owns one contiguous slab
@@ -28,10 +27,13 @@
 //     its own rows, gW_l[slab, :] = gZ_l[:, slab]^T [a_{l-1} | x0], needs nothing from other workgroups but the saved
 //     activations and runs while the other workgroups' slabs are in flight.
 //
-// Thread map of a product: a group of 256 threads = 16 row groups x 16 k-lanes handles 4 features; a lane accumulates 4
-// dot products over every 16th float4 of its row (16 lanes read 64 consecutive LDS dwords: conflict-free for
-// ds_read_b128 with a row pitch that is a multiple of 64 dwords), the 16 lanes are one DPP row and are summed with four
-// row_shr adds.
+// A layer's product [B rows] x [NC = 8 columns] x [K = 256 (+ encoded input)] runs on the matrix cores as outer products:
+// v_mfma_f32_4x4x1_16B_f32 holds 16 independent 4 x 4 blocks per wave = 8 row groups x 2 column groups, one k per
+// instruction; the 8 waves of the workgroup split K (32 consecutive k each: four ds_read_b128 per operand and row), their
+// partial blocks are summed through LDS in a fixed order by the threads that publish the slab.  (The first version did
+// this on the VALU -- a lane per (row, 4 columns, 16 k), DPP row sums: 24 ds_read_b128 + 160 VALU instructions per lane and
+// layer, 3000 clocks at two waves per SIMD; the MFMA form issues 32 matrix + 16 LDS instructions.)  Row pitches in LDS are
+// padded by 4 floats so that the 16 rows a ds_read_b128 touches start in different banks.
 #include <algorithm>
 
 #include "skgs_common.h"
@@ -43,6 +45,8 @@ constexpr int MAXL = SKGS_MLP_MAX_LAYERS;
 constexpr unsigned SENTINEL = 0xffffffffu;
 // Shapes fixed at compile time: hidden width H = 256, encoded input padded to INP = 128, at most KL layers.
 constexpr int H = 256, INP = 128, KL = 10;
+constexpr int NT = 512, NW = NT / 64, NC = 8;  // threads, waves and output features per workgroup
+constexpr int HP = H + 4;                       // LDS row pitch of a [rows][H] image (see the thread map above)
 
 using gu32 = __attribute__((address_space(1))) unsigned int;
 typedef float f4 __attribute__((ext_vector_type(4)));  // a VGPR quad as an asm operand
@@ -58,7 +62,7 @@ struct FusedArgs {
   int B, p_dim, p_deg, t_dim, t_deg, IN, n_layers, lds_floats;
   const float* points;
   const float* t;
-  float* x0;          // forward: [B, IN] or NULL
+  float* x0;          // forward: [B, IN] (written) or NULL; backward: the forward's copy (read) or NULL (re-encoded)
   float* acts;        // forward: written; backward: read.  [n_layers - 1][B][H]
   float* out;         // forward: [B, out_last]
   const float* g_out; // backward: [B, out_last]
@@ -85,7 +89,7 @@ __device__ __forceinline__ FusedLayer get_layer(const FusedArgs& a, int l) {
       l == a.n_layers - 1 ? a.out_last : H, (int) ((a.relu_mask >> l) & 1u)};
 }
 
-__device__ __forceinline__ int pad64(int x) { return (x + 63) & ~63; }
+__device__ __host__ __forceinline__ int pad32(int x) { return (x + 31) & ~31; }
 
 // element (row, col) of the last layer's output / incoming gradient: one [B, out] tensor or one tensor per head
 __device__ __forceinline__ float* head_elem(const FusedArgs& a, float* const* heads, float* single, int row, int col, int out) {
@@ -109,7 +113,7 @@ __device__ __forceinline__ float row_sum_to_lane15(float v) {
 // diagnostics (header word 2 != 0): workgroup 0 records {100 MHz real-time counter, shader clock counter} at successive
 // points of the launch into header words 16.. (two words per stamp, 24 stamps)
 __device__ __forceinline__ void stamp(const FusedArgs& a, const unsigned* s_misc, int& si, unsigned long long t_entry = 0) {
-  if (s_misc[2] && blockIdx.x == 0 && threadIdx.x == 0 && si < 23) {
+  if (s_misc[2] && blockIdx.x == 0 && threadIdx.x == 0 && si < 20) {
     if (t_entry) a.hdr[16 + 46] = (unsigned) t_entry;
     a.hdr[16 + 2 * si]     = (unsigned) __builtin_amdgcn_s_memrealtime();
     a.hdr[16 + 2 * si + 1] = (unsigned) __builtin_amdgcn_s_memtime();
@@ -131,8 +135,8 @@ __device__ __forceinline__ void store16_sc1(float* p, float4 v) {
 // is the sentinel.  Unit u = 16 bytes: slab g = u / (B NC/4), then row-major inside the slab (rows < B only).  All of a
 // thread's loads are in flight together (one asm statement with its own wait: hipcc does not track asm loads).
 // Returns false on time-out.
-template <int NT, int NC, int U>
-__device__ __forceinline__ bool gather_slabs(const float* img, float* s_dst, int B, int Bp, int H, int n_units) {
+template <int U>
+__device__ __forceinline__ bool gather_slabs(const float* img, float* s_dst, int B, int Bp, int pitch, int n_units) {
   constexpr int Q = NC / 4;  // 16-byte units per slab row
   const float* ptr[U];
   int dst[U];
@@ -144,7 +148,7 @@ __device__ __forceinline__ bool gather_slabs(const float* img, float* s_dst, int
     if (!live[j]) u = 0;
     const int g = u / (B * Q), rem = u - g * (B * Q), row = rem / Q, part = rem - row * Q;
     ptr[j] = img + ((size_t) g * Bp + row) * NC + 4 * part;
-    dst[j] = row * H + g * NC + 4 * part;
+    dst[j] = row * pitch + g * NC + 4 * part;
   }
   f4 v[U];
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -185,41 +189,88 @@ __device__ __forceinline__ bool gather_slabs(const float* img, float* s_dst, int
   return good;
 }
 
-// acc[p][c] += sum_k src[r + 16 p][k] w[c][k] over this lane's float4 columns k = 4 kq, 4 kq + 64, ... < klen (klen a
-// multiple of 64).  The trip count is written as a wave-uniform number (a loop bounded by the per-lane k made hipcc emit
-// exec-masked loops plus an SLP-"vectorised" body full of v_pk_mul / v_mov shuffles: 1770 cycles for 4 steps); the
-// products are explicit fma chains, 8 independent ones per lane.
-template <int PASSES>
-__device__ __forceinline__ void dot_step(float (&acc)[PASSES][4], const float* __restrict__ xs, int pitch,
-    const float* __restrict__ ws, int wpitch) {
-  float4 w[4], x[PASSES];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) w[c] = *reinterpret_cast<const float4*>(ws + c * wpitch);
-#pragma unroll
-  for (int p = 0; p < PASSES; ++p) x[p] = *reinterpret_cast<const float4*>(xs + 16 * p * pitch);
-#pragma unroll
-  for (int p = 0; p < PASSES; ++p)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float t = acc[p][c];
-      t = __builtin_fmaf(x[p].x, w[c].x, t);
-      t = __builtin_fmaf(x[p].y, w[c].y, t);
-      t = __builtin_fmaf(x[p].z, w[c].z, t);
-      t = __builtin_fmaf(x[p].w, w[c].w, t);
-      acc[p][c] = t;
-    }
+// Lane map of the 4x4x1 MFMA (checked on gfx950): lane = 4 b + j holds A[4 b + i = j] and B[4 b + j] of block b; VGPR i of the
+// result holds D_b[i][j].  Block b = 2 rgl + cg: row group rgl (rows 4 rg .. 4 rg + 3, rg = 8 round + rgl), column group cg.
+struct LaneMap {
+  int j, cg, rgl, colw;  // colw = 4 cg + j: the weight row this lane feeds as B operand
+};
+__device__ __forceinline__ LaneMap lane_map() {
+  const int l = threadIdx.x & 63;
+  return LaneMap{l & 3, (l >> 2) & 1, l >> 3, 4 * ((l >> 2) & 1) + (l & 3)};
 }
-template <int PASSES, int STEPS>
-__device__ __forceinline__ void dot_rows(float (&acc)[PASSES][4], const float* __restrict__ s_src, int pitch,
-    const float* __restrict__ s_wr, int wpitch, int r, int kq) {
-  const float* xs = s_src + r * pitch + 4 * kq;
-  const float* ws = s_wr + 4 * kq;
+
+// acc[rd] += sum over k in [k0, k0 + 4 nk4) of src[row][k] w[col][k] for this lane's blocks (two accumulators per round: the
+// chain of dependent MFMAs is half as long).  rowc[rd]: the LDS row this lane reads as A operand in round rd.
+template <int ROUNDS>
+__device__ __forceinline__ void mfma_step(f4 (&acc)[ROUNDS][2], const float* __restrict__ xs, int pitch, const int (&rowc)[ROUNDS],
+    const float* __restrict__ ws) {
+  const float4 wv = *reinterpret_cast<const float4*>(ws);
 #pragma unroll
-  for (int i = 0; i < STEPS; ++i) dot_step<PASSES>(acc, xs + 64 * i, pitch, ws + 64 * i, wpitch);
+  for (int rd = 0; rd < ROUNDS; ++rd) {
+    const float4 xv = *reinterpret_cast<const float4*>(xs + rowc[rd] * pitch);
+    acc[rd][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.x, wv.x, acc[rd][0], 0, 0, 0);
+    acc[rd][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.y, wv.y, acc[rd][1], 0, 0, 0);
+    acc[rd][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.z, wv.z, acc[rd][0], 0, 0, 0);
+    acc[rd][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.w, wv.w, acc[rd][1], 0, 0, 0);
+  }
+}
+// NK4 > 0: that many float4 steps, unrolled (all LDS reads in flight together); NK4 = 0: nk4 steps, rolled
+template <int ROUNDS, int NK4 = 0>
+__device__ __forceinline__ void mfma_dot(f4 (&acc)[ROUNDS][2], const float* __restrict__ s_src, int pitch, const int (&rowc)[ROUNDS],
+    const float* __restrict__ s_w, int wpitch, int colw, int k0, int nk4 = NK4) {
+  const float* ws = s_w + colw * wpitch + k0;
+  const float* xs = s_src + k0;
+  if constexpr (NK4 > 0) {
+#pragma unroll
+    for (int q = 0; q < NK4; ++q) mfma_step<ROUNDS>(acc, xs + 4 * q, pitch, rowc, ws + 4 * q);
+  } else {
+#pragma unroll 1
+    for (int q = 0; q < nk4; ++q) mfma_step<ROUNDS>(acc, xs + 4 * q, pitch, rowc, ws + 4 * q);
+  }
+}
+template <int ROUNDS>
+__device__ __forceinline__ void zero_acc(f4 (&acc)[ROUNDS][2]) {
+#pragma unroll
+  for (int rd = 0; rd < ROUNDS; ++rd) acc[rd][0] = acc[rd][1] = f4{0.f, 0.f, 0.f, 0.f};
+}
+// one column of a saved activation matrix [B][H]: rows in groups of four under one wave-uniform test; rows >= B re-read row
+// B - 1 (their gZ rows are zeros)
+template <int Bp>
+__device__ __forceinline__ void load_act_column(float (&av)[Bp], const float* __restrict__ ap, int B) {
+#pragma unroll
+  for (int b4 = 0; b4 < Bp; b4 += 4) {
+    if (b4 < B) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) av[b4 + u] = ap[min(b4 + u, B - 1) * H];
+    }
+  }
+}
+// this wave's partial blocks -> s_part [NW][Bp][NC]
+template <int ROUNDS>
+__device__ __forceinline__ void write_partials(float* s_part, const f4 (&acc)[ROUNDS][2], const LaneMap& m, int wave, int Bp,
+    int n_rg) {
+#pragma unroll
+  for (int rd = 0; rd < ROUNDS; ++rd) {
+    const int rg = 8 * rd + m.rgl;
+    if (rg < n_rg) {
+      const f4 v = acc[rd][0] + acc[rd][1];
+      float* d   = s_part + ((size_t) (wave * Bp + 4 * rg)) * NC + m.colw;
+      d[0] = v[0], d[NC] = v[1], d[2 * NC] = v[2], d[3 * NC] = v[3];
+    }
+  }
+}
+// columns 4 part .. 4 part + 3 of row `row`: the waves' partials added in wave order
+__device__ __forceinline__ float4 sum_partials(const float* s_part, int Bp, int row, int part) {
+  float4 y = *reinterpret_cast<const float4*>(s_part + (size_t) row * NC + 4 * part);
+#pragma unroll
+  for (int w = 1; w < NW; ++w) {
+    const float4 p = *reinterpret_cast<const float4*>(s_part + ((size_t) (w * Bp + row)) * NC + 4 * part);
+    y.x += p.x, y.y += p.y, y.z += p.z, y.w += p.w;
+  }
+  return y;
 }
 
 // fill this workgroup's slabs of the image the launch does NOT use with the sentinel
-template <int NT, int NC>
 __device__ __forceinline__ void repoison(float* img_other, int nX, int G, int Bp) {
   const int slab4 = Bp * NC / 4;
   const float4 s  = make_float4(u2f(SENTINEL), u2f(SENTINEL), u2f(SENTINEL), u2f(SENTINEL));
@@ -230,25 +281,31 @@ __device__ __forceinline__ void repoison(float* img_other, int nX, int G, int Bp
 }
 
 // ---------------------------------------------------------------------------------------------------------- forward
-// LDS (floats): s_x0 [Bp][INP] | s_act [Bp][H] | s_out [Bp][NC] | slabs: layer l -> [NC][Kp_l], Kp_l = (l ? H : 0) + (in_x ?
-//               INP : 0) | bias [n_layers][NC] | misc (launch count, fail, stamps)
-template <int GROUPS, int PASSES>
-__global__ void __launch_bounds__(256 * GROUPS) fused_mlp_forward_kernel(const FusedArgs a) {
-  constexpr int NT = 256 * GROUPS, NC = 4 * GROUPS, Bp = 16 * PASSES;
+// LDS (floats): s_x0 [Bp][XP] | s_act [Bp][HP] | s_part [NW][Bp][NC] | slabs: layer l -> [NC][Kp_l + 4], Kp_l = (l ? H : 0) +
+//               (in_x ? XW : 0) | bias [KL][NC] | misc (launch count, fail, stamps).  XW = the encoded width rounded up to
+//               32 (every wave takes XW / 8 of its k), XP = XW + 4.
+template <int PASSES>
+__global__ void __launch_bounds__(NT) fused_mlp_forward_kernel(const FusedArgs a) {
+  constexpr int Bp = 16 * PASSES, ROUNDS = (4 * PASSES + 7) / 8;
   constexpr int U = (Bp * 64 + NT - 1) / NT <= 4 ? 4 : 8;  // 16-byte units per thread of one gather
   constexpr int EQ = (Bp * INP + NT - 1) / NT;             // encoded-input entries per thread (padding included)
   static_assert((Bp * 64 + NT - 1) / NT <= 8, "gather_slabs covers at most 8 units per thread");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
-  const int tid = threadIdx.x, grp = tid >> 8, lt = tid & 255, kq = lt & 15, r = lt >> 4;
+  const int tid = threadIdx.x, wave = tid >> 6;
   const int G = gridDim.x, g = blockIdx.x, col0 = g * NC;
   const int B = a.B, nL = a.n_layers, nX = nL - 1, IN = a.IN;
-  float* s_x0  = smem;
-  float* s_act = s_x0 + Bp * INP;
-  float* s_out = s_act + Bp * H;
-  float* s_w   = s_out + Bp * NC;
+  const int XW = pad32(IN), XP = XW + 4;
+  float* s_x0   = smem;
+  float* s_act  = s_x0 + Bp * XP;
+  float* s_part = s_act + Bp * HP;
+  float* s_w    = s_part + NW * Bp * NC;
   unsigned* s_misc = reinterpret_cast<unsigned*>(smem + a.lds_floats - 4);
   float* s_bias    = smem + a.lds_floats - 4 - KL * NC;
+  const LaneMap lm = lane_map();
+  int rowc[ROUNDS];
+#pragma unroll
+  for (int rd = 0; rd < ROUNDS; ++rd) rowc[rd] = (8 * rd + lm.rgl < 4 * PASSES) ? 4 * (8 * rd + lm.rgl) + lm.j : lm.j;
 
   // ---- prologue: ONE memory round trip.  Issue order: launch counter, raw encoder inputs, biases, every weight row this
   // workgroup will ever need (compile-time layer index: the descriptor reads stay scalar kernarg loads); then the sines,
@@ -278,6 +335,8 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_forward_kernel(const F
   }
   float bv[KL];
   float4 vh[KL], vx[KL];
+  const int ch = tid >> 6, kh = 4 * (tid & 63);  // hidden part: NC rows x 64 units = NT units
+  const int cx = tid >> 5, kx = 4 * (tid & 31);  // x0 part: NC rows x 32 units = NT / 2 units
   {
     // every layer's pointers are fetched from the kernarg segment up front, in a few wide scalar loads and ONE wait (left
     // inside the per-layer branches they were ten dependent round trips to host-visible memory: 2.8 us)
@@ -287,8 +346,6 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_forward_kernel(const F
     for (int l = 0; l < KL; ++l) wp[l] = a.W[l], bp[l] = a.bias[l];
 #pragma unroll
     for (int l = 0; l < KL; ++l) asm volatile("" : "+s"(wp[l]), "+s"(bp[l]));
-    const int ch = tid >> 6, kh = 4 * (tid & 63);  // hidden part: NC rows x 64 units = NT units
-    const int cx = tid >> 5, kx = 4 * (tid & 31);  // x0 part: NC rows x 32 units = NT / 2 units
 #pragma unroll
     for (int l = 0; l < KL; ++l) {
       bv[l] = 0.f;
@@ -304,88 +361,66 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_forward_kernel(const F
       }
     }
   }
-#ifdef SKGS_MLP_DIAG
-  const unsigned long long t_d1 = __builtin_amdgcn_s_memrealtime();
-#endif
   // the encoded input (the loads above are still in flight behind these); padding entries are written as zeros
 #pragma unroll
   for (int q = 0; q < EQ; ++q) {
     const int b = eb0 + q * (NT / INP);
-    if (b < Bp) {
+    if (b < Bp && ec < XW) {
       float v = xin[q];
       if (e_live && b < B && e_col >= 0) v = sinf(scalbnf(v, e_col >> 1) + e_phase);
-      s_x0[b * INP + ec] = v;
+      s_x0[b * XP + ec] = v;
     }
   }
-  for (int i = tid; i < Bp * H / 4; i += NT) reinterpret_cast<float4*>(s_act)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < Bp * HP / 4; i += NT) reinterpret_cast<float4*>(s_act)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   {
-    const int ch = tid >> 6, kh = 4 * (tid & 63), cx = tid >> 5, kx = 4 * (tid & 31);
     int woffs = 0;
 #pragma unroll
     for (int l = 0; l < KL; ++l) {
       if (l < nL) {
-        const int hp = l ? H : 0, Kp = hp + (get_layer(a, l).in_x ? INP : 0);
+        const bool in_x = get_layer(a, l).in_x != 0;
+        const int hp = l ? H : 0, WP = hp + (in_x ? XW : 0) + 4;
         if (tid < NC) s_bias[l * NC + tid] = bv[l];
-        if (l > 0) *reinterpret_cast<float4*>(s_w + woffs + ch * Kp + kh) = vh[l];
-        if (get_layer(a, l).in_x && tid < NT / 2) *reinterpret_cast<float4*>(s_w + woffs + cx * Kp + hp + kx) = vx[l];
-        woffs += NC * Kp;
+        if (l > 0) *reinterpret_cast<float4*>(s_w + woffs + ch * WP + kh) = vh[l];
+        if (in_x && tid < NT / 2 && kx < XW) *reinterpret_cast<float4*>(s_w + woffs + cx * WP + hp + kx) = vx[l];
+        woffs += NC * WP;
       }
     }
   }
-#ifdef SKGS_MLP_DIAG
-  const unsigned long long t_d3 = __builtin_amdgcn_s_memrealtime();
-#endif
   if (tid == 0) s_misc[0] = cnt, s_misc[1] = 0, s_misc[2] = stamps_on;
   __syncthreads();
   const unsigned count = s_misc[0];
   const size_t img_floats = (size_t) nX * G * Bp * NC;
   float* img = a.exch + (count & 1u) * img_floats;
-  repoison<NT, NC>(a.exch + ((count & 1u) ^ 1u) * img_floats, nX, G, Bp);
+  repoison(a.exch + ((count & 1u) ^ 1u) * img_floats, nX, G, Bp);
   int si = 0;
   stamp(a, s_misc, si, t_entry);
-#ifdef SKGS_MLP_DIAG
-  if (s_misc[2] && g == 0 && tid == 0) a.hdr[16 + 40] = (unsigned) t_d1, a.hdr[16 + 42] = (unsigned) t_d1, a.hdr[16 + 44] = (unsigned) t_d3;
-#endif
 
   int woff = 0;
   for (int l = 0; l < nL; ++l) {
     const FusedLayer L = get_layer(a, l);
-    const int hp = l ? H : 0, Kp = hp + (L.in_x ? INP : 0);
+    const int hp = l ? H : 0, WP = hp + (L.in_x ? XW : 0) + 4;
     const bool last = l == nL - 1;
     if (l > 0) {
-      const bool ok = gather_slabs<NT, NC, U>(img + (size_t) (l - 1) * G * Bp * NC, s_act, B, Bp, H, B * H / 4);
+      const bool ok = gather_slabs<U>(img + (size_t) (l - 1) * G * Bp * NC, s_act, B, Bp, HP, B * H / 4);
       if (!ok) s_misc[1] = 1;
       __syncthreads();
       if (s_misc[1]) break;
       stamp(a, s_misc, si);
     }
     if (last && col0 >= L.out) break;
-    const float* wl = s_w + woff + 4 * grp * Kp;  // this group's four rows
-    float acc[PASSES][4];
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc[p][c] = 0.f;
-    if (l > 0) dot_rows<PASSES, 4>(acc, s_act, H, wl, Kp, r, kq);
-    if (L.in_x) dot_rows<PASSES, 2>(acc, s_x0, INP, wl + hp, Kp, r, kq);
-    const float4 bz = *reinterpret_cast<const float4*>(s_bias + l * NC + 4 * grp);
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc[p][c] = row_sum_to_lane15(acc[p][c]);
-    if (kq == 15) {  // bias, activation and the "never the sentinel" rule in the lane that holds the sums
-#pragma unroll
-      for (int p = 0; p < PASSES; ++p) {
-        float4 y = make_float4(acc[p][0] + bz.x, acc[p][1] + bz.y, acc[p][2] + bz.z, acc[p][3] + bz.w);
-        if (L.relu) y.x = fmaxf(y.x, 0.f), y.y = fmaxf(y.y, 0.f), y.z = fmaxf(y.z, 0.f), y.w = fmaxf(y.w, 0.f);
-        y.x = not_sentinel(y.x), y.y = not_sentinel(y.y), y.z = not_sentinel(y.z), y.w = not_sentinel(y.w);
-        *reinterpret_cast<float4*>(s_out + (r + 16 * p) * NC + 4 * grp) = y;
-      }
-    }
-    __syncthreads();  // s_out complete; s_act / s_x0 reads of this layer done
-    if (tid < Bp * GROUPS) {  // one 16-byte unit per thread: the slab leaves as whole lines
-      const int row = tid / GROUPS, part = tid - row * GROUPS;
-      const float4 y = *reinterpret_cast<const float4*>(s_out + 4 * tid);
+    f4 acc[ROUNDS][2];
+    zero_acc<ROUNDS>(acc);
+    if (l > 0) mfma_dot<ROUNDS, H / NW / 4>(acc, s_act, HP, rowc, s_w + woff, WP, lm.colw, (H / NW) * wave);
+    if (L.in_x) mfma_dot<ROUNDS>(acc, s_x0, XP, rowc, s_w + woff + hp, WP, lm.colw, (XW / NW) * wave, XW / NW / 4);
+    write_partials<ROUNDS>(s_part, acc, lm, wave, Bp, 4 * PASSES);
+    __syncthreads();  // partials complete; s_act / s_x0 reads of this layer done
+    if (tid < Bp * 2) {  // one 16-byte unit per thread: bias, activation, the "never the sentinel" rule; the slab leaves as whole lines
+      const int row = tid >> 1, part = tid & 1;
+      float4 y = sum_partials(s_part, Bp, row, part);
+      const float4 bz = *reinterpret_cast<const float4*>(s_bias + l * NC + 4 * part);
+      y.x += bz.x, y.y += bz.y, y.z += bz.z, y.w += bz.w;
+      if (L.relu) y.x = fmaxf(y.x, 0.f), y.y = fmaxf(y.y, 0.f), y.z = fmaxf(y.z, 0.f), y.w = fmaxf(y.w, 0.f);
+      y.x = not_sentinel(y.x), y.y = not_sentinel(y.y), y.z = not_sentinel(y.z), y.w = not_sentinel(y.w);
       if (row < B) {
         if (last) {
           const int c = col0 + 4 * part;
@@ -399,12 +434,12 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_forward_kernel(const F
         }
       }
     }
-    woff += NC * Kp;
+    woff += NC * WP;
     stamp(a, s_misc, si);
   }
   // the optional copy of the encoded input leaves from the last workgroup, after its part of the chain
   if (a.x0 && g == G - 1)
-    for (int i = tid; i < B * IN; i += NT) a.x0[i] = s_x0[(i / IN) * INP + (i % IN)];
+    for (int i = tid; i < B * IN; i += NT) a.x0[i] = s_x0[(i / IN) * XP + (i % IN)];
   if (g == 0 && tid == 0) {
     gu32* h = reinterpret_cast<gu32*>((unsigned long long) a.hdr);
     if (s_misc[1]) __hip_atomic_fetch_add(h + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -413,32 +448,36 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_forward_kernel(const F
 }
 
 // --------------------------------------------------------------------------------------------------------- backward
-// LDS (floats): s_gz [Bp][H] (later reused for the encoded input) | s_own [n_layers][Bp][NC] (this workgroup's slab of every gZ_l, kept for the
-//               weight gradients) | s_out [Bp][NC] | transposed slabs: layer l >= 1 -> T_l [NC][pad64(out_l)] = W_l[o][col0 +
-//               c]; with g_x0 and col0 < IN also X_l [NC][pad64(out_l)] = W_l[o][in_h + col0 + c] for every layer with
-//               in_x > 0 | misc
-template <int GROUPS, int PASSES>
-__global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const FusedArgs a) {
-  constexpr int NT = 256 * GROUPS, NC = 4 * GROUPS, Bp = 16 * PASSES;
+// LDS (floats): s_gz [Bp][HP] (later reused for the encoded input, pitch INP) | s_own [n_layers][Bp][NC] (this workgroup's
+//               slab of every gZ_l, kept for the weight gradients) | s_part [NW][Bp][NC] | transposed slabs: layer l >= 1 ->
+//               T_l [NC][op_l + 4] = W_l[o][col0 + c], op_l = out_l rounded up to 32; with g_x0 and col0 < IN also X_l
+//               [NC][op_l + 4] = W_l[o][in_h + col0 + c] for every layer with in_x > 0 | misc
+template <int PASSES>
+__global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs a) {
+  constexpr int Bp = 16 * PASSES, ROUNDS = (4 * PASSES + 7) / 8;
   constexpr int U = (Bp * 64 + NT - 1) / NT <= 4 ? 4 : 8;
   static_assert((Bp * 64 + NT - 1) / NT <= 8, "gather_slabs covers at most 8 units per thread");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, grp = tid >> 8, lt = tid & 255, kq = lt & 15, r = lt >> 4;
+  const int tid = threadIdx.x, wave = tid >> 6;
   const int G = gridDim.x, g = blockIdx.x, col0 = g * NC;
   const int B = a.B, nL = a.n_layers, IN = a.IN, nX = nL - 1;
   const bool want_gx = a.g_x0 != nullptr && col0 < IN;
-  float* s_gz  = smem;
-  float* s_x0  = s_gz;  // the encoded input is only needed by the weight gradients: built after the chain, over s_gz
-  float* s_own = s_gz + Bp * H;
-  float* s_out = s_own + nL * Bp * NC;
-  float* s_wT  = s_out + Bp * NC;
+  float* s_gz   = smem;
+  float* s_x0   = s_gz;  // the encoded input is only needed by the weight gradients: built after the chain, over s_gz
+  float* s_own  = s_gz + Bp * HP;
+  float* s_part = s_own + nL * Bp * NC;
+  float* s_wT   = s_part + NW * Bp * NC;
   int t_total = 0;  // floats of the T slabs; the X slabs follow
-  for (int l = 1; l < nL; ++l) t_total += NC * pad64(get_layer(a, l).out);
+  for (int l = 1; l < nL; ++l) t_total += NC * (pad32(get_layer(a, l).out) + 4);
   int x_total = 0;
   if (want_gx)
     for (int l = 0; l < nL; ++l)
-      if (get_layer(a, l).in_x) x_total += NC * pad64(get_layer(a, l).out);
+      if (get_layer(a, l).in_x) x_total += NC * (pad32(get_layer(a, l).out) + 4);
   unsigned* s_misc = reinterpret_cast<unsigned*>(smem + a.lds_floats - 4);
+  const LaneMap lm = lane_map();
+  int rowc[ROUNDS];
+#pragma unroll
+  for (int rd = 0; rd < ROUNDS; ++rd) rowc[rd] = (8 * rd + lm.rgl < 4 * PASSES) ? 4 * (8 * rd + lm.rgl) + lm.j : lm.j;
 
   // ---- prologue: one memory round trip (see the forward kernel)
   unsigned cnt = 0, stamps_on = 0;
@@ -447,17 +486,28 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const 
     cnt       = __hip_atomic_load(h + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     stamps_on = __hip_atomic_load(h + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // the ReLU masks of this workgroup's slab, one 16-byte unit per thread and layer (threads < Bp GROUPS)
-  const int mrow = tid / GROUPS, mpart = tid - mrow * GROUPS;
-  const bool mlive = tid < Bp * GROUPS && mrow < B;
+  // the ReLU masks of this workgroup's slab, one 16-byte unit per thread and layer (threads < 2 Bp)
+  const int mrow = tid >> 1, mpart = tid & 1;
+  const bool mlive = tid < Bp * 2 && mrow < B;
   float4 am[KL], vt[KL], vx[KL];
+  // the encoded input (needed after the chain, by the weight gradients of the layers that read it): the forward's copy,
+  // every load unconditional (clamped index) and in flight with the rest of the prologue
+  constexpr int XQ = Bp * INP / NT;
+  float xv[XQ];
+  if (a.x0) {
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) {
+      const int i = tid + q * NT, b = i / INP, c = i - b * INP;
+      xv[q] = a.x0[(size_t) min(b, B - 1) * IN + min(c, IN - 1)];
+    }
+  }
+  const int wo = tid >> 1, wc4 = 4 * (tid & 1);  // (weight row o, group of four columns): NT units
   {
     const float* wp[KL];  // (see the forward prologue: all pointer loads up front, one wait)
 #pragma unroll
     for (int l = 0; l < KL; ++l) wp[l] = a.W[l];
 #pragma unroll
     for (int l = 0; l < KL; ++l) asm volatile("" : "+s"(wp[l]));
-    const int o = tid / GROUPS, c4 = 4 * (tid - o * GROUPS);  // (weight row, group of four columns): NT = 256 GROUPS units
 #pragma unroll
     for (int l = 0; l < KL; ++l) {
       am[l] = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -468,32 +518,31 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const 
         const int K = L.in_h + L.in_x;
         if (l < nL - 1 && L.relu && mlive)
           am[l] = *reinterpret_cast<const float4*>(a.acts + ((size_t) l * B + mrow) * H + col0 + 4 * mpart);
-        if (o < L.out) {
-          if (l >= 1) vt[l] = *reinterpret_cast<const float4*>(L.W + (size_t) o * K + col0 + c4);
-          if (want_gx && L.in_x && col0 + c4 < L.in_x) vx[l] = *reinterpret_cast<const float4*>(L.W + (size_t) o * K + L.in_h + col0 + c4);
+        if (wo < L.out) {
+          if (l >= 1) vt[l] = *reinterpret_cast<const float4*>(L.W + (size_t) wo * K + col0 + wc4);
+          if (want_gx && L.in_x && col0 + wc4 < L.in_x) vx[l] = *reinterpret_cast<const float4*>(L.W + (size_t) wo * K + L.in_h + col0 + wc4);
         }
       }
     }
   }
   {
-    const int o = tid / GROUPS, c4 = 4 * (tid - o * GROUPS);
     int toff = 0, xoff = t_total;
 #pragma unroll
     for (int l = 0; l < KL; ++l) {
       if (l < nL) {
-        const int op = pad64(get_layer(a, l).out);
-        if (o < op) {
+        const int op = pad32(get_layer(a, l).out), OP = op + 4;
+        if (wo < op) {  // rows out_l .. op_l - 1 are written as zeros
           if (l >= 1) {
-            float* d = s_wT + toff + c4 * op + o;
-            d[0] = vt[l].x, d[op] = vt[l].y, d[2 * op] = vt[l].z, d[3 * op] = vt[l].w;
+            float* d = s_wT + toff + wc4 * OP + wo;
+            d[0] = vt[l].x, d[OP] = vt[l].y, d[2 * OP] = vt[l].z, d[3 * OP] = vt[l].w;
           }
           if (want_gx && get_layer(a, l).in_x) {
-            float* d = s_wT + xoff + c4 * op + o;
-            d[0] = vx[l].x, d[op] = vx[l].y, d[2 * op] = vx[l].z, d[3 * op] = vx[l].w;
+            float* d = s_wT + xoff + wc4 * OP + wo;
+            d[0] = vx[l].x, d[OP] = vx[l].y, d[2 * OP] = vx[l].z, d[3 * OP] = vx[l].w;
           }
         }
-        if (l >= 1) toff += NC * op;
-        if (want_gx && get_layer(a, l).in_x) xoff += NC * op;
+        if (l >= 1) toff += NC * OP;
+        if (want_gx && get_layer(a, l).in_x) xoff += NC * OP;
       }
     }
   }
@@ -501,7 +550,7 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const 
     const int oL = get_layer(a, nL - 1).out;
     for (int i = tid; i < Bp * 64; i += NT) {
       const int b = i >> 6, c = i & 63;
-      s_gz[b * H + c] = (b < B && c < oL) ? *head_elem(a, const_cast<float* const*>(a.head_gout), const_cast<float*>(a.g_out), b, c, oL) : 0.f;
+      s_gz[b * HP + c] = (b < B && c < oL) ? *head_elem(a, const_cast<float* const*>(a.head_gout), const_cast<float*>(a.g_out), b, c, oL) : 0.f;
     }
     for (int i = tid; i < Bp * NC; i += NT) {
       const int b = i / NC, c = i - b * NC;
@@ -514,13 +563,16 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const 
   const unsigned count = s_misc[0];
   const size_t img_floats = (size_t) nX * G * Bp * NC;
   float* img = a.exch + (count & 1u) * img_floats;
-  repoison<NT, NC>(a.exch + ((count & 1u) ^ 1u) * img_floats, nX, G, Bp);
+  repoison(a.exch + ((count & 1u) ^ 1u) * img_floats, nX, G, Bp);
+  int si = 12;  // diagnostics: stamps 12.. = prologue done, chain done, input gradient done, weight gradients done
+  stamp(a, s_misc, si);
 
-  float gx0[PASSES][4];
-#pragma unroll
-  for (int p = 0; p < PASSES; ++p)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) gx0[p][c] = 0.f;
+  const int kcol = (H / NW) * wave + 4 * lm.rgl + lm.j;  // weight-gradient column of this lane (block = 2 k-group + cg)
+  f4 gw = {0.f, 0.f, 0.f, 0.f};  // weight-gradient block of the layer in flight, its destination, row pitch and live rows
+  float* gw_dst = nullptr;
+  int gw_ld = 0, gw_rows = 0;
+  f4 accx[ROUNDS][2];  // the input gradient of this workgroup's columns accumulates over the layers that read x0
+  zero_acc<ROUNDS>(accx);
 
   // ---- (A) the dependent chain: gA_{l-1}[:, slab] = gZ_l W_l[:, slab], masked by the ReLU of layer l-1.  The slabs were
   // laid out by increasing layer: walk their offsets backwards.
@@ -530,84 +582,99 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const 
     if (lu < nL) {
       const int l = lu;
       const FusedLayer L = get_layer(a, l);
-      const int op = pad64(L.out);
+      const int op = pad32(L.out), OP = op + 4;
       const bool publish = l - 1 >= 1 || a.g_x0 != nullptr;  // gZ_0 is only exchanged for the input gradient
       const bool do_x = want_gx && L.in_x;
-      tcur -= NC * op;
-      if (do_x) xcur -= NC * op;
-      float acc[PASSES][4];
+      tcur -= NC * OP;
+      if (do_x) xcur -= NC * OP;
+      if (gw_dst) {  // the previous iteration's weight-gradient block
 #pragma unroll
-      for (int p = 0; p < PASSES; ++p)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[p][c] = 0.f;
-      if (op == H) dot_rows<PASSES, 4>(acc, s_gz, H, s_wT + tcur + 4 * grp * op, op, r, kq);
-      else dot_rows<PASSES, 1>(acc, s_gz, H, s_wT + tcur + 4 * grp * op, op, r, kq);
-      if (do_x) {
-        float accx[PASSES][4];
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) accx[p][c] = 0.f;
-        if (op == H) dot_rows<PASSES, 4>(accx, s_gz, H, s_wT + xcur + 4 * grp * op, op, r, kq);
-        else dot_rows<PASSES, 1>(accx, s_gz, H, s_wT + xcur + 4 * grp * op, op, r, kq);
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) gx0[p][c] += row_sum_to_lane15(accx[p][c]);
+        for (int i = 0; i < 4; ++i)
+          if (i < gw_rows) gw_dst[(size_t) i * gw_ld] = gw[i];
+        gw_dst = nullptr;
       }
-#pragma unroll
-      for (int p = 0; p < PASSES; ++p)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[p][c] = row_sum_to_lane15(acc[p][c]);
-      if (kq == 15) {
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p)
-          *reinterpret_cast<float4*>(s_out + (r + 16 * p) * NC + 4 * grp) = make_float4(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
+      // (B, hidden part) this workgroup's rows of gW_l = gZ_l[:, slab]^T a_{l-1}: the activation column of this lane, one
+      // load per row, all in flight behind the chain product below; the outer products run after the publish, while the
+      // other workgroups' slabs are on their way (nothing on the chain waits for them).  (Loading them one iteration
+      // ahead, into a second register set, was slower: 30.6 -> 32.2 us.)
+      const bool wg_rows = col0 < L.out;
+      float av[Bp];
+      if (wg_rows) load_act_column<Bp>(av, a.acts + (size_t) (l - 1) * B * H + kcol, B);
+      f4 acc[ROUNDS][2];
+      zero_acc<ROUNDS>(acc);
+      if (op == H) {
+        mfma_dot<ROUNDS, H / NW / 4>(acc, s_gz, HP, rowc, s_wT + tcur, OP, lm.colw, (H / NW) * wave);
+        if (do_x) mfma_dot<ROUNDS, H / NW / 4>(accx, s_gz, HP, rowc, s_wT + xcur, OP, lm.colw, (H / NW) * wave);
+      } else {
+        mfma_dot<ROUNDS>(acc, s_gz, HP, rowc, s_wT + tcur, OP, lm.colw, (op / NW) * wave, op / NW / 4);
+        if (do_x) mfma_dot<ROUNDS>(accx, s_gz, HP, rowc, s_wT + xcur, OP, lm.colw, (op / NW) * wave, op / NW / 4);
       }
-      __syncthreads();  // s_out complete; s_gz has been read
-      if (tid < Bp * GROUPS) {
-        float4 y = *reinterpret_cast<const float4*>(s_out + 4 * tid);
+      write_partials<ROUNDS>(s_part, acc, lm, wave, Bp, 4 * PASSES);
+      __syncthreads();  // partials complete; s_gz has been read
+      if (tid < Bp * 2) {
+        float4 y = sum_partials(s_part, Bp, mrow, mpart);
         const float4 m = am[lu - 1];
         y.x = (mlive && m.x > 0.f) ? not_sentinel(y.x) : 0.f, y.y = (mlive && m.y > 0.f) ? not_sentinel(y.y) : 0.f;
         y.z = (mlive && m.z > 0.f) ? not_sentinel(y.z) : 0.f, y.w = (mlive && m.w > 0.f) ? not_sentinel(y.w) : 0.f;
         if (publish && mlive) store16_sc1(img + ((size_t) (l - 1) * G + g) * Bp * NC + 4 * tid, y);
         *reinterpret_cast<float4*>(s_own + (l - 1) * Bp * NC + 4 * tid) = y;  // kept for the weight gradients
       }
+      if (wg_rows) {
+        const float* own = s_own + l * Bp * NC + lm.colw;  // A operand: gZ_l[b][4 cg + j]; B operand: a_{l-1}[b][kcol]
+        gw = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b4 = 0; b4 < Bp; b4 += 4) {
+          if (b4 < B) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) gw = __builtin_amdgcn_mfma_f32_4x4x1f32(own[(b4 + u) * NC], av[b4 + u], gw, 0, 0, 0);
+          }
+        }
+        // (stored at the top of the next iteration: stores still in flight here would be waited for by the gather's
+        // s_waitcnt vmcnt(0) together with its loads)
+        gw_dst = L.gW + (size_t) (col0 + 4 * lm.cg) * (L.in_h + L.in_x) + kcol;  // D: VGPR i = row 4 cg + i of the slab
+        gw_ld = L.in_h + L.in_x, gw_rows = L.out - (col0 + 4 * lm.cg);
+      }
       if (publish) {
-        const bool ok = gather_slabs<NT, NC, U>(img + (size_t) (l - 1) * G * Bp * NC, s_gz, B, Bp, H, B * H / 4);
+        const bool ok = gather_slabs<U>(img + (size_t) (l - 1) * G * Bp * NC, s_gz, B, Bp, HP, B * H / 4);
         if (!ok) s_misc[1] = 1;
       }
       __syncthreads();
       if (s_misc[1]) break;
     }
   }
+  if (gw_dst) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < gw_rows) gw_dst[(size_t) i * gw_ld] = gw[i];
+  }
+  stamp(a, s_misc, si);
   // ---- input gradient: the layers that read x0 (layer 0 included) contribute gZ_l W_l[:, x0 part]
   if (want_gx && !s_misc[1]) {
-    float accx[PASSES][4];
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) accx[p][c] = 0.f;
-    dot_rows<PASSES, 4>(accx, s_gz, H, s_wT + t_total + 4 * grp * H, H, r, kq);  // X_0 is the first of the x0 slabs
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) accx[p][c] = row_sum_to_lane15(accx[p][c]);
-    if (kq == 15) {
-#pragma unroll
-      for (int p = 0; p < PASSES; ++p) {
-        const int row = r + 16 * p;
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (row < B && col0 + 4 * grp + c < IN) a.g_x0[(size_t) row * IN + col0 + 4 * grp + c] = gx0[p][c] + accx[p][c];
-      }
+    mfma_dot<ROUNDS, H / NW / 4>(accx, s_gz, HP, rowc, s_wT + t_total, H + 4, lm.colw, (H / NW) * wave);  // X_0 (out = H): the first x0 slab
+    write_partials<ROUNDS>(s_part, accx, lm, wave, Bp, 4 * PASSES);
+    __syncthreads();
+    if (tid < Bp * 2 && mrow < B) {
+      const float4 y = sum_partials(s_part, Bp, mrow, mpart);
+      const int c = col0 + 4 * mpart;
+      float* d = a.g_x0 + (size_t) mrow * IN + c;
+      if (c < IN) d[0] = y.x;
+      if (c + 1 < IN) d[1] = y.y;
+      if (c + 2 < IN) d[2] = y.z;
+      if (c + 3 < IN) d[3] = y.w;
     }
   }
-  // ---- (B) off the chain, after it: weight / bias gradients of this workgroup's rows of every layer, from the kept
-  // slabs gZ_l[:, slab] and the saved activations.  Nothing waits on this any more; all layers' loads overlap.
+  stamp(a, s_misc, si);
+  // ---- (B, the rest) after the chain: the encoded-input columns of the weight gradients (layer 0 and the skip layers) and
+  // the bias gradients, from the kept slabs gZ_l[:, slab]
   if (!s_misc[1]) {
     __syncthreads();  // the last readers of s_gz are done: it becomes the encoded input
-    {
+    if (a.x0) {  // the forward's copy, fetched in the prologue
+#pragma unroll
+      for (int q = 0; q < XQ; ++q) {
+        const int i = tid + q * NT, b = i / INP, c = i - b * INP;
+        s_x0[i] = (b < B && c < IN) ? xv[q] : 0.f;
+      }
+    } else {
       const int pe = a.p_dim * (1 + 2 * a.p_deg);
       for (int i = tid; i < Bp * INP; i += NT) {
         const int b = i / INP, c = i - b * INP;
@@ -626,38 +693,38 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const 
     __syncthreads();
     for (int l = nL - 1; l >= 0; --l) {
       const FusedLayer L = get_layer(a, l);
-      if (col0 >= L.out) continue;
+      if (col0 >= L.out || !L.in_x) continue;
       const int K = L.in_h + L.in_x;
       const float* own = s_own + l * Bp * NC;
-      for (int i = tid; i < K * GROUPS; i += NT) {  // thread <-> (column of gW_l, group of four rows)
-        const int k = i % K, q = i / K;
+      for (int i = tid; i < L.in_x * (NC / 4); i += NT) {  // thread <-> (x0 column of gW_l, group of four rows)
+        const int kx = i % L.in_x, q = i / L.in_x, k = L.in_h + kx;
         float gacc[4] = {0.f, 0.f, 0.f, 0.f};
-        if (k < L.in_h) {
-          const float* ap = a.acts + (size_t) (l - 1) * B * H + k;
 #pragma unroll 4
-          for (int b = 0; b < B; ++b) {
-            const float av = ap[(size_t) b * H];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) gacc[c] += own[b * NC + 4 * q + c] * av;
-          }
-        } else {
-          for (int b = 0; b < B; ++b) {
-            const float av = s_x0[b * INP + (k - L.in_h)];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) gacc[c] += own[b * NC + 4 * q + c] * av;
-          }
+        for (int b = 0; b < B; ++b) {
+          const float av = s_x0[b * INP + kx];
+          const float4 o = *reinterpret_cast<const float4*>(own + b * NC + 4 * q);
+          gacc[0] += o.x * av, gacc[1] += o.y * av, gacc[2] += o.z * av, gacc[3] += o.w * av;
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c)
           if (col0 + 4 * q + c < L.out) L.gW[(size_t) (col0 + 4 * q + c) * K + k] = gacc[c];
       }
-      if (L.gb && tid < NC && col0 + tid < L.out) {
+    }
+    // bias gradients: one thread per (layer, column) -- as a loop over the layers in eight lanes this was nine serial
+    // chains of B dependent LDS reads, 5 us at the end of the launch
+    for (int i = tid; i < nL * NC; i += NT) {
+      const int l = i / NC, c = i - l * NC;
+      const FusedLayer L = get_layer(a, l);
+      if (L.gb && col0 + c < L.out) {
+        const float* own = s_own + l * Bp * NC + c;
         float sum = 0.f;
-        for (int b = 0; b < B; ++b) sum += own[b * NC + tid];
-        L.gb[col0 + tid] = sum;
+#pragma unroll 4
+        for (int b = 0; b < B; ++b) sum += own[b * NC];
+        L.gb[col0 + c] = sum;
       }
     }
   }
+  stamp(a, s_misc, si);
   if (g == 0 && tid == 0) {
     gu32* h = reinterpret_cast<gu32*>((unsigned long long) a.hdr);
     if (s_misc[1]) __hip_atomic_fetch_add(h + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -667,7 +734,6 @@ __global__ void __launch_bounds__(256 * GROUPS) fused_mlp_backward_kernel(const 
 
 // ------------------------------------------------------------------------------------------------------------ host
 constexpr int HDR_BYTES = 256;
-int g_groups = 2;  // 256-thread groups per workgroup (2 -> 32 workgroups of 512 threads at H = 256); skgs_set_mlp_columns
 
 struct Plan {
   int Bp, passes, IN, INP, G, NC;
@@ -699,8 +765,8 @@ int make_plan(const skgs_mlp_desc* d, Plan* p) {
   }
   p->passes = (d->B + 15) / 16;
   p->Bp     = p->passes * 16;
-  p->NC     = 4 * g_groups;
-  p->G      = d->hidden / p->NC;
+  p->NC     = NC;
+  p->G      = d->hidden / NC;
   p->exch_bytes = (size_t) 2 * (d->n_layers - 1) * p->Bp * d->hidden * 4;
   return 0;
 }
@@ -721,22 +787,17 @@ void fill_args(const skgs_mlp_desc* d, const Plan& p, FusedArgs* a) {
 }
 
 template <typename KernelT>
-int launch(KernelT k, const Plan& p, int groups, const FusedArgs& a, size_t lds, hipStream_t s) {
+int launch(KernelT k, const Plan& p, const FusedArgs& a, size_t lds, hipStream_t s) {
   if (lds > 64 * 1024)
     SKGS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  hipLaunchKernelGGL(k, dim3(p.G), dim3(256 * groups), lds, s, a);
+  hipLaunchKernelGGL(k, dim3(p.G), dim3(NT), lds, s, a);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }
-#define SKGS_MLP_DISPATCH(KERNEL)                                                              \
-  if (g_groups == 2) {                                                                         \
-    if (p.passes == 1) return launch(KERNEL<2, 1>, p, 2, a, lds, (hipStream_t) stream);        \
-    if (p.passes == 2) return launch(KERNEL<2, 2>, p, 2, a, lds, (hipStream_t) stream);        \
-    return launch(KERNEL<2, 3>, p, 2, a, lds, (hipStream_t) stream);                           \
-  }                                                                                            \
-  SKGS_REQUIRE(p.passes <= 2, "deform_mlp: 4 columns per workgroup handle at most 32 rows");  \
-  if (p.passes == 1) return launch(KERNEL<1, 1>, p, 1, a, lds, (hipStream_t) stream);          \
-  return launch(KERNEL<1, 2>, p, 1, a, lds, (hipStream_t) stream);
+#define SKGS_MLP_DISPATCH(KERNEL)                                                    \
+  if (p.passes == 1) return launch(KERNEL<1>, p, a, lds, (hipStream_t) stream);      \
+  if (p.passes == 2) return launch(KERNEL<2>, p, a, lds, (hipStream_t) stream);      \
+  return launch(KERNEL<3>, p, a, lds, (hipStream_t) stream);
 
 __global__ void init_workspace_kernel(uint32_t* w, size_t n_words) {
   const size_t stride = (size_t) gridDim.x * blockDim.x;
@@ -750,8 +811,6 @@ __global__ void init_workspace_kernel(uint32_t* w, size_t n_words) {
 using namespace skgs;
 
 extern "C" {
-
-void skgs_set_mlp_columns(int ncol) { g_groups = (ncol == 4) ? 1 : 2; }
 
 size_t skgs_deform_mlp_workspace_bytes(const skgs_mlp_desc* d) {
   Plan p;
@@ -784,15 +843,16 @@ int skgs_deform_mlp_forward(const skgs_mlp_desc* d, const float* points, const f
   a.points = points, a.t = t, a.x0 = x0, a.acts = acts, a.out = out;
   a.hdr  = reinterpret_cast<unsigned*>(workspace);
   a.exch = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + HDR_BYTES);
-  size_t fl = (size_t) p.Bp * INP + (size_t) p.Bp * H + (size_t) p.Bp * p.NC + (size_t) KL * p.NC + 4;
-  for (int l = 0; l < d->n_layers; ++l) fl += (size_t) p.NC * ((l ? H : 0) + (d->layer[l].in_x0 ? INP : 0));
+  const int XW = pad32(p.IN);
+  size_t fl = (size_t) p.Bp * (XW + 4) + (size_t) p.Bp * HP + (size_t) NW * p.Bp * NC + (size_t) KL * NC + 4;
+  for (int l = 0; l < d->n_layers; ++l) fl += (size_t) NC * ((l ? H : 0) + (d->layer[l].in_x0 ? XW : 0) + 4);
   a.lds_floats = (int) fl;
   const size_t lds = fl * 4;
   SKGS_REQUIRE(lds <= 160 * 1024, "deform_mlp_forward: %zu bytes of LDS needed", lds);
   SKGS_MLP_DISPATCH(fused_mlp_forward_kernel)
 }
 
-int skgs_deform_mlp_backward(const skgs_mlp_desc* d, const float* points, const float* t, const float* acts,
+int skgs_deform_mlp_backward(const skgs_mlp_desc* d, const float* points, const float* t, const float* x0, const float* acts,
     const float* g_out, float* g_x0, void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
   Plan p;
   if (make_plan(d, &p)) return 1;
@@ -807,14 +867,14 @@ int skgs_deform_mlp_backward(const skgs_mlp_desc* d, const float* points, const 
       d->hidden, p.IN);
   FusedArgs a{};
   fill_args(d, p, &a);
-  a.points = points, a.t = t, a.acts = const_cast<float*>(acts), a.g_out = g_out, a.g_x0 = g_x0;
+  a.points = points, a.t = t, a.x0 = const_cast<float*>(x0), a.acts = const_cast<float*>(acts), a.g_out = g_out, a.g_x0 = g_x0;
   a.hdr  = reinterpret_cast<unsigned*>(workspace);
   a.exch = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + HDR_BYTES + p.exch_bytes);
-  size_t fl = (size_t) p.Bp * H + (size_t) (d->n_layers + 1) * p.Bp * p.NC + 4;
-  for (int l = 1; l < d->n_layers; ++l) fl += (size_t) p.NC * ((d->layer[l].out + 63) & ~63);
+  size_t fl = (size_t) p.Bp * HP + (size_t) (d->n_layers + NW) * p.Bp * NC + 4;
+  for (int l = 1; l < d->n_layers; ++l) fl += (size_t) NC * (pad32(d->layer[l].out) + 4);
   if (g_x0)
     for (int l = 0; l < d->n_layers; ++l)
-      if (d->layer[l].in_x0) fl += (size_t) p.NC * ((d->layer[l].out + 63) & ~63);
+      if (d->layer[l].in_x0) fl += (size_t) NC * (pad32(d->layer[l].out) + 4);
   a.lds_floats = (int) fl;
   const size_t lds = fl * 4;
   SKGS_REQUIRE(lds <= 160 * 1024, "deform_mlp_backward: %zu bytes of LDS needed", lds);

@@ -303,16 +303,19 @@ class FusedDeformMLP:
             C.c_size_t(self.workspace.numel()), _C._stream()))
         return out
 
-    def backward(self, points: Tensor, t: Tensor, g_out, grads: Sequence[Tensor], g_x0: Optional[Tensor] = None):
+    def backward(self, points: Tensor, t: Tensor, g_out, grads: Sequence[Tensor], g_x0: Optional[Tensor] = None,
+                 reencode: bool = False):
         """``g_out``: [B, OUT] or one tensor per head; ``grads``: [gW0, gb0, ..., gW_heads, gb_heads] (written); ``g_x0``
-        [B, IN] (written) or None"""
+        [B, IN] (written) or None.  The encoded input is the copy the last ``forward`` left in ``self.x0`` (same points and
+        time!); ``reencode``: let the kernel rebuild it from ``points`` / ``t`` instead."""
         if isinstance(g_out, Tensor):
             assert g_out.is_cuda and g_out.is_contiguous() and g_out.shape == self.out.shape
             d = self._desc(grads)
         else:
             d, g_out = self._desc(grads, head_gout=g_out), None
         _C._check(self.lib.skgs_deform_mlp_backward(
-            C.byref(d), C.c_void_p(points.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(self.acts.data_ptr()),
+            C.byref(d), C.c_void_p(points.data_ptr()), C.c_void_p(t.data_ptr()),
+            C.c_void_p(None if reencode else self.x0.data_ptr()), C.c_void_p(self.acts.data_ptr()),
             C.c_void_p(None if g_out is None else g_out.data_ptr()), C.c_void_p(None if g_x0 is None else g_x0.data_ptr()),
             C.c_void_p(self.workspace.data_ptr()), C.c_size_t(self.workspace.numel()), _C._stream()))
 

@@ -143,70 +143,68 @@ def _ref_with_input_grad(mlp, joints, t, g):
     return out.detach(), torch.stack([a.detach() for a in acts]), [p.grad.clone() for p in params], x0.grad.clone(), x0.detach()
 
 
-@pytest.mark.parametrize('ncol', [4, 8])
-def test_fused_deform_mlp_matches_torch(ncol):  # noqa: C901
+def test_fused_deform_mlp_matches_torch():
     """the one-launch-per-direction network (csrc/mlp_fused.hip) against torch autograd of the restated module: outputs,
     saved activations, every weight / bias gradient and the input gradient, for row counts on both sides of the 16-row
     passes, repeated launches on one workspace (launch epochs) and a hipGraph replay"""
-    from sk_gs_amd import _C
     from sk_gs_amd.deform_net import DeformMLP, FusedDeformMLP
-    _C.load_library().skgs_set_mlp_columns(ncol)
-    try:
-        torch.manual_seed(0)
-        mlp = DeformMLP().cuda()
-        with torch.no_grad():  # the reference initialises the heads with std 1e-6 (sk_gs.py:542-545): use O(1) heads here
-            mlp.dynamic_net.last_weight.normal_(0, 0.1)
-        for B in (1, 16, 20, 32) if ncol == 4 else (1, 16, 20, 32, 33, 48):  # 4 columns per workgroup: <= 32 rows
-            joints = (torch.rand(B, 3, device='cuda') - 0.5)
-            t = torch.tensor([0.41], device='cuda')
-            g = torch.randn(B, 11, device='cuda')
-            ref_out, ref_acts, ref_grads, ref_gx0, ref_x0 = _ref_with_input_grad(mlp, joints, t, g)
-            run = FusedDeformMLP(mlp, B)
-            grads = [torch.full_like(r, 7.0) for r in ref_grads]
-            g_x0 = torch.full_like(ref_gx0, 7.0)
-            for rep in range(3):  # same workspace: the launch epoch distinguishes the exchanges
-                out = run.forward(joints, t)
-                run.backward(joints, t, g, grads, g_x0)
-            assert run.status() == dict(forward=3, backward=3, failed=0)
-            assert (run.x0 - ref_x0).abs().max() <= 3e-4  # sin of arguments up to 2^9 x: argument rounding
-            assert rel_err(out, ref_out) <= 2e-5, B
-            assert rel_err(run.acts, ref_acts) <= 2e-5, B
-            for i, (a, r) in enumerate(zip(grads, ref_grads)):
-                assert rel_err(a, r) <= 5e-5, (B, i)
-            assert rel_err(g_x0, ref_gx0) <= 5e-5, B
-            # without the input gradient nothing else changes
+    torch.manual_seed(0)
+    mlp = DeformMLP().cuda()
+    with torch.no_grad():  # the reference initialises the heads with std 1e-6 (sk_gs.py:542-545): use O(1) heads here
+        mlp.dynamic_net.last_weight.normal_(0, 0.1)
+    for B in (1, 3, 16, 20, 32, 33, 48):
+        joints = (torch.rand(B, 3, device='cuda') - 0.5)
+        t = torch.tensor([0.41], device='cuda')
+        g = torch.randn(B, 11, device='cuda')
+        ref_out, ref_acts, ref_grads, ref_gx0, ref_x0 = _ref_with_input_grad(mlp, joints, t, g)
+        run = FusedDeformMLP(mlp, B)
+        grads = [torch.full_like(r, 7.0) for r in ref_grads]
+        g_x0 = torch.full_like(ref_gx0, 7.0)
+        for rep in range(3):  # same workspace: the launch epoch distinguishes the exchanges
+            out = run.forward(joints, t)
+            run.backward(joints, t, g, grads, g_x0)
+        assert run.status() == dict(forward=3, backward=3, failed=0)
+        assert (run.x0 - ref_x0).abs().max() <= 3e-4  # sin of arguments up to 2^9 x: argument rounding
+        assert rel_err(out, ref_out) <= 2e-5, B
+        assert rel_err(run.acts, ref_acts) <= 2e-5, B
+        for i, (a, r) in enumerate(zip(grads, ref_grads)):
+            assert rel_err(a, r) <= 5e-5, (B, i)
+        assert rel_err(g_x0, ref_gx0) <= 5e-5, B
+        # without the input gradient nothing else changes; nor with the encoded input rebuilt inside the kernel
+        for kw in (dict(), dict(reencode=True)):
             grads2 = [torch.zeros_like(r) for r in ref_grads]
             run.forward(joints, t)
-            run.backward(joints, t, g, grads2, None)
-            for a, b in zip(grads, grads2):
-                assert torch.equal(a, b)
-        # hipGraph replay of forward + backward (what the training step does)
-        B = 20
-        joints, t, g = torch.rand(B, 3, device='cuda') - 0.5, torch.tensor([0.7], device='cuda'), torch.randn(B, 11, device='cuda')
-        ref_out, _, ref_grads, _, _ = _ref_with_input_grad(mlp, joints, t, g)
-        run = FusedDeformMLP(mlp, B)
-        grads = [torch.zeros_like(r) for r in ref_grads]
-        s = torch.cuda.Stream()
-        with torch.cuda.stream(s):
+            run.backward(joints, t, g, grads2, None, **kw)
+            for i, (a, b) in enumerate(zip(grads, grads2)):
+                if kw:  # sinf in the backward kernel vs the forward's: same code, same values
+                    assert rel_err(a, b) <= 1e-6, (B, i)
+                else:
+                    assert torch.equal(a, b)
+    # hipGraph replay of forward + backward (what the training step does)
+    B = 20
+    joints, t, g = torch.rand(B, 3, device='cuda') - 0.5, torch.tensor([0.7], device='cuda'), torch.randn(B, 11, device='cuda')
+    ref_out, _, ref_grads, _, _ = _ref_with_input_grad(mlp, joints, t, g)
+    run = FusedDeformMLP(mlp, B)
+    grads = [torch.zeros_like(r) for r in ref_grads]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        run.forward(joints, t)
+        run.backward(joints, t, g, grads)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
             run.forward(joints, t)
             run.backward(joints, t, g, grads)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=s):
-                run.forward(joints, t)
-                run.backward(joints, t, g, grads)
-            for _ in range(5):
-                for gr in grads:
-                    gr.zero_()
-                run.out.zero_()
-                graph.replay()
-        torch.cuda.synchronize()
-        assert run.status()['failed'] == 0
-        assert rel_err(run.out, ref_out) <= 2e-5
-        for a, r in zip(grads, ref_grads):
-            assert rel_err(a, r) <= 5e-5
-    finally:
-        _C.load_library().skgs_set_mlp_columns(8)
+        for _ in range(5):
+            for gr in grads:
+                gr.zero_()
+            run.out.zero_()
+            graph.replay()
+    torch.cuda.synchronize()
+    assert run.status()['failed'] == 0
+    assert rel_err(run.out, ref_out) <= 2e-5
+    for a, r in zip(grads, ref_grads):
+        assert rel_err(a, r) <= 5e-5
 
 
 def test_fused_deform_mlp_other_shapes():

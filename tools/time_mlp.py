@@ -13,8 +13,7 @@ for B in (20, 32):
     joints, t, g = torch.rand(B, 3, device='cuda') - 0.5, torch.tensor([0.3], device='cuda'), torch.randn(B, 11, device='cuda')
     params = [p for l in mlp.dynamic_net.net for p in (l.weight, l.bias)] + [mlp.dynamic_net.last_weight, mlp.dynamic_net.last_bias]
     grads = [torch.zeros_like(p) for p in params]
-    for ncol in (8, 4):
-        lib.skgs_set_mlp_columns(ncol)
+    for ncol in (8,):
         run = FusedDeformMLP(mlp, B)
         for what in ('fwd', 'bwd', 'both'):
             def body():
@@ -39,7 +38,6 @@ for B in (20, 32):
                 torch.cuda.synchronize()
                 us = (time.perf_counter() - t0) / 400 * 1e6
             print(f'B={B} ncol={ncol} fused {what}: {us:.1f} us per pass (graph of 20), status {run.status()}')
-    lib.skgs_set_mlp_columns(8)
 
 # ---- in-kernel phase stamps of workgroup 0 (forward): {100 MHz real-time counter, shader clock}
 B = 20
@@ -53,8 +51,18 @@ torch.cuda.synchronize()
 st = run.workspace[64:256].view(torch.int32).cpu().tolist()
 names = ['prologue', 'layer0'] + [n for l in range(1, 9) for n in (f'gather{l}', f'layer{l}')]
 print(f'entry -> first stamp (prologue): {((st[0] - st[46]) & 0xffffffff) * 10} ns')
-if st[40]:
-    print(f'  entry -> loads issued {((st[40] - st[46]) & 0xffffffff) * 10} ns, -> sines done {((st[42] - st[46]) & 0xffffffff) * 10} ns, -> LDS filled {((st[44] - st[46]) & 0xffffffff) * 10} ns')
 for i in range(1, len(names)):
     dt, dc = (st[2 * i] - st[2 * i - 2]) & 0xffffffff, (st[2 * i + 1] - st[2 * i - 1]) & 0xffffffff
     print(f'{names[i]:>10}: +{dt * 10} ns  {dc} clk  ({dc / max(dt, 1) * 100:.0f} MHz)')
+
+# ---- backward: stamps 12..15 of workgroup 0 = prologue done, chain done, input gradient done, weight gradients done
+g = torch.randn(B, 11, device='cuda')
+params = [p for l in mlp.dynamic_net.net for p in (l.weight, l.bias)] + [mlp.dynamic_net.last_weight, mlp.dynamic_net.last_bias]
+grads = [torch.zeros_like(p) for p in params]
+g_x0 = torch.zeros(B, mlp.dynamic_net.in_channels, device='cuda')
+for _ in range(3):
+    run.backward(joints, t, g, grads, g_x0)
+torch.cuda.synchronize()
+st = run.workspace[64:256].view(torch.int32).cpu().tolist()
+for i, name in zip(range(13, 16), ('chain (8 hops)', 'input gradient', 'weight gradients')):
+    print(f'backward {name:>18}: +{((st[2 * i] - st[2 * i - 2]) & 0xffffffff) * 10} ns')
