@@ -182,6 +182,9 @@ def main():
                          'networks/sk_gs.py:1080-1085) instead of running the 8x256 deform network inside every step.  The '
                          'reference runs the network in every TRAINING step (sk_gs.py:1073-1074): that is the default here')
     ap.add_argument('--deform-net', dest='deform_net', action='store_true', help='(default) the deform network inside the step')
+    ap.add_argument('--serial-adam', action='store_true',
+                    help='one rank: the whole Adam update as its own launch after the backward, instead of the per-Gaussian '
+                         'rows\' update running inside the deform network\'s backward launch (on the 224 CUs it leaves idle)')
     ap.add_argument('--fixed-joints', dest='learn_joints', action='store_false', default=True,
                     help='keep the joint positions constant; by default they are trained at 0.1 x lr as in stage sk '
                          '(networks/sk_gs.py:379,607): gradient through the kinematic chain and the network input')
@@ -414,9 +417,18 @@ def main():
                 fstep.scatter_spw_grad()
             opt.step()
 
+        fused_update = False
+        if not use_dist and not args.autograd and not args.torch_adam and not args.serial_adam:
+            from sk_gs_amd.train_step import FusedTrainStep
+            train1 = FusedTrainStep(fstep, opt)
+            fused_update = train1.fused
+
         def eager_step(i):
             v = vp.view_index(i, args.views)
             select(v)
+            if fused_update:
+                train1(*fb_args(v))
+                return
             fwd_bwd(v)
             reduce_grads()
             update()
@@ -454,7 +466,10 @@ def main():
                 reduce_grads()  # the optimizer graph's capture warm-up applies real updates: reduced gradients only
                 gC.capture(0)
         elif not use_dist:  # whole step (fwd + bwd + Adam) is one graph per view
-            g_step = GraphedSteps(lambda v: (fwd_bwd(v), opt.step()))
+            if fused_update:
+                g_step = GraphedSteps(lambda v: train1(*fb_args(v)))
+            else:
+                g_step = GraphedSteps(lambda v: (fwd_bwd(v), opt.step()))
             g_opt = None
         else:           # the RCCL all-reduce stays between two graphs
             g_step = GraphedSteps(fwd_bwd)
@@ -644,6 +659,9 @@ def main():
                        if args.deform_net and M > 0 else 'per-frame tables (test-time cache, sk_gs.py:1080-1085): NOT the '
                                                          'reference\'s training step',
                        'joints': 'trained, lr x 0.1 (sk_gs.py:607)' if model.learn_joints else 'fixed',
+                       'adam': ('per-Gaussian rows inside the deform network\'s backward launch (224 idle CUs), the rest after'
+                                if (not pipelined and fused_update) else 'one launch after the backward') if not pipelined
+                       else 'one launch per bucket',
                        'step': 'autograd operator path' if args.autograd else 'FusedViewStep (direct C-ABI calls)',
                        'replicas_identical': replicas_identical, 'param_digest': param_digest},
             'roofline': {'bound': 'hbm', 'kernel': 'render_backward', 'achieved': round(achieved, 2),

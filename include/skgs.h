@@ -362,6 +362,21 @@ int skgs_deform_mlp_forward(const skgs_mlp_desc* d, const float* points, const f
  * (B x IN sines per workgroup, ~3 us). */
 int skgs_deform_mlp_backward(const skgs_mlp_desc* d, const float* points, const float* t, const float* x0, const float* acts,
     const float* g_out, float* g_x0, void* workspace, size_t workspace_bytes, skgs_stream_t stream);
+/* The same launch with a side job: the network occupies 32 of the 256 CUs for ~30 us; the workgroups added for the other
+ * CUs apply the Adam update (skgs_adam_step_range with advance = 0) of chunks [chunk_begin, chunk_end) of an optimizer
+ * table -- parameters whose gradients are final before this call (the per-Gaussian rows, after the skinning backward) and
+ * which this call neither reads nor writes.  side = NULL: skgs_deform_mlp_backward.  Close the step with the remaining
+ * pieces and one advance (skgs_adam_step_range). */
+typedef struct skgs_adam_range {
+  int32_t n_tensors;
+  const void* tensors;               /* device descriptor table, see skgs_adam_step */
+  int64_t chunk_begin, chunk_end;
+  double beta1, beta2, eps;
+  const float* step_count;           /* device float: steps taken so far (read, not advanced) */
+} skgs_adam_range;
+int skgs_deform_mlp_backward_adam(const skgs_mlp_desc* d, const float* points, const float* t, const float* x0,
+    const float* acts, const float* g_out, float* g_x0, void* workspace, size_t workspace_bytes, const skgs_adam_range* side,
+    skgs_stream_t stream);
 int skgs_deform_mlp_status(const void* workspace, uint32_t* host_words4, skgs_stream_t stream);
 
 /* ---- densification statistics of one training view (scope row (f)-4) ----

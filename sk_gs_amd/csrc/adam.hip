@@ -12,79 +12,23 @@
 #include <algorithm>
 #include <cstdint>
 
+#include "adam_update.h"
 #include "skgs_common.h"
 
 namespace skgs {
 namespace {
 
-struct AdamTensor {
-  float* param;
-  const float* grad;
-  float* exp_avg;
-  float* exp_avg_sq;
-  int64_t n;        // elements
-  int64_t chunk0;   // first chunk index of this tensor in the flattened chunk space
-  float lr;
-  float pad;
-};
-static_assert(sizeof(AdamTensor) == 56, "layout shared with the host binding");
-constexpr int ADAM_THREADS = 256;
-constexpr int ADAM_CHUNK   = ADAM_THREADS * 4 * 4;  // elements per workgroup iteration (4 float4 per lane)
-
 __global__ void __launch_bounds__(ADAM_THREADS) adam_step_kernel(int n_tensors, const AdamTensor* __restrict__ tensors,
     int64_t chunk_begin, int64_t total_chunks, double beta1d, double beta2d, float eps,
     const float* __restrict__ step_count) {
-  // hyper-parameters arrive as doubles and (1 - beta) is formed in double, as torch does: 1.0f - 0.999f is off by 1.3e-5
-  const double t   = (double) step_count[0] + 1.0;
-  const float bc1  = (float) (1.0 - pow(beta1d, t));
-  const float inv_sqrt_bc2 = (float) (1.0 / sqrt(1.0 - pow(beta2d, t)));
-  const float beta1 = (float) beta1d, beta2 = (float) beta2d;
-  const float omb1 = (float) (1.0 - beta1d), omb2 = (float) (1.0 - beta2d);
-  // which tensor owns a chunk: lane i keeps the first chunk of tensors i, i + 64, ... (loaded once); the owner is the
-  // number of tensors whose first chunk is <= chunk, minus one.  (A linear walk over the descriptors was a chain of
-  // dependent global loads per chunk -- ~30 of them for the tensors at the end of the table, the deform network's: +10 us
-  // of tail on a 37 us launch.)
+  const AdamCoef k = adam_coefficients(beta1d, beta2d, eps, step_count);
   const int lane = threadIdx.x & 63;
-  int64_t first0 = lane < n_tensors ? tensors[lane].chunk0 : INT64_MAX;
+  const int64_t first0 = lane < n_tensors ? tensors[lane].chunk0 : INT64_MAX;
   for (int64_t chunk = chunk_begin + blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
-    int ti = __popcll(__ballot(first0 <= chunk)) - 1;
-    for (int base = 64; base < n_tensors; base += 64)  // (more than 64 tensors: rare)
-      ti += __popcll(__ballot(base + lane < n_tensors && tensors[base + lane].chunk0 <= chunk));
-    ti = __builtin_amdgcn_readfirstlane(ti);
-    const AdamTensor T = tensors[ti];
-    const float step_size = T.lr / bc1;
-    const int64_t base = (chunk - T.chunk0) * ADAM_CHUNK;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(T.param) | reinterpret_cast<uintptr_t>(T.grad) |
-                           reinterpret_cast<uintptr_t>(T.exp_avg) | reinterpret_cast<uintptr_t>(T.exp_avg_sq)) & 15) == 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t i = base + ((int64_t) r * ADAM_THREADS + threadIdx.x) * 4;
-      if (aligned && i + 3 < T.n) {
-        const float4 g = *reinterpret_cast<const float4*>(T.grad + i);
-        float4 m = *reinterpret_cast<float4*>(T.exp_avg + i);
-        float4 v = *reinterpret_cast<float4*>(T.exp_avg_sq + i);
-        float4 p = *reinterpret_cast<float4*>(T.param + i);
-#define SKGS_ADAM1(c)                                         \
-  m.c = beta1 * m.c + omb1 * g.c;                             \
-  v.c = beta2 * v.c + omb2 * g.c * g.c;                       \
-  p.c -= step_size * m.c / (sqrtf(v.c) * inv_sqrt_bc2 + eps);
-        SKGS_ADAM1(x) SKGS_ADAM1(y) SKGS_ADAM1(z) SKGS_ADAM1(w)
-        *reinterpret_cast<float4*>(T.exp_avg + i)    = m;
-        *reinterpret_cast<float4*>(T.exp_avg_sq + i) = v;
-        *reinterpret_cast<float4*>(T.param + i)      = p;
-      } else {
-        for (int64_t k = i; k < T.n && k < i + 4; ++k) {
-          const float g = T.grad[k];
-          const float m = beta1 * T.exp_avg[k] + omb1 * g;
-          const float v = beta2 * T.exp_avg_sq[k] + omb2 * g * g;
-          T.exp_avg[k] = m, T.exp_avg_sq[k] = v;
-          T.param[k] -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
-        }
-      }
-    }
+    const AdamTensor T = tensors[adam_owner(tensors, n_tensors, first0, lane, chunk)];
+    adam_update_chunk(T, (chunk - T.chunk0) * ADAM_CHUNK, threadIdx.x, k);
   }
 }
-#undef SKGS_ADAM1
 
 // (A last-workgroup-out ticket inside adam_step_kernel was tried instead of this launch: 4096 same-address atomics
 // next to the counter every workgroup reads cost 70 us.)

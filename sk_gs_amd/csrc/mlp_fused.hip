@@ -36,6 +36,7 @@
 // padded by 4 floats so that the 16 rows a ds_read_b128 touches start in different banks.
 #include <algorithm>
 
+#include "adam_update.h"
 #include "skgs_common.h"
 
 namespace skgs {
@@ -82,6 +83,14 @@ struct FusedArgs {
   float* gb[KL];
   unsigned xmask, relu_mask;  // bit l: layer l reads the encoded input / applies ReLU
   int out_last;
+  // side job of the backward launch: its workgroups beyond the network's G apply the Adam update of the chunks
+  // [adam_c0, adam_c1) of an optimizer table (adam.hip) -- see adam_side_job
+  const AdamTensor* adam_tensors;
+  int adam_n;
+  long long adam_c0, adam_c1;
+  double adam_beta1, adam_beta2;
+  float adam_eps;
+  const float* adam_step;
 };
 
 __device__ __forceinline__ FusedLayer get_layer(const FusedArgs& a, int l) {
@@ -280,6 +289,26 @@ __device__ __forceinline__ void repoison(float* img_other, int nX, int G, int Bp
   }
 }
 
+// The backward launch needs 32 CUs for ~30 us and leaves 224 idle; the optimizer update of the per-Gaussian parameters (a
+// pure stream: 28 B per element, 40 us at 100k Gaussians on the whole chip) does not depend on it.  Workgroups G.. of the
+// SAME launch therefore walk the chunks of that update (two 256-thread halves per workgroup, one chunk each per
+// iteration): a branch of a captured graph or a second stream would cost more in fork / join edges than it hides (DESIGN
+// section 7), workgroups of one launch cost nothing.  The network's workgroups have the lowest ids and are dispatched first,
+// so all of them are resident before the first side workgroup is placed; the LDS request of the launch keeps it at one
+// workgroup per CU.
+constexpr int G_NET = H / NC;
+constexpr int NUM_CUS = 256;  // MI355X: the side job gets one workgroup per CU the network does not occupy
+__device__ __forceinline__ void adam_side_job(const FusedArgs& a) {
+  const int n_side = (int) gridDim.x - G_NET, wg = (int) blockIdx.x - G_NET;
+  const int half = threadIdx.x >> 8, t256 = threadIdx.x & 255, lane = threadIdx.x & 63;
+  const AdamCoef k = adam_coefficients(a.adam_beta1, a.adam_beta2, a.adam_eps, a.adam_step);
+  const int64_t first0 = lane < a.adam_n ? a.adam_tensors[lane].chunk0 : INT64_MAX;
+  for (int64_t chunk = a.adam_c0 + 2 * wg + half; chunk < a.adam_c1; chunk += 2 * n_side) {
+    const AdamTensor T = a.adam_tensors[adam_owner(a.adam_tensors, a.adam_n, first0, lane, chunk)];
+    adam_update_chunk(T, (chunk - T.chunk0) * ADAM_CHUNK, t256, k);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------- forward
 // LDS (floats): s_x0 [Bp][XP] | s_act [Bp][HP] | s_part [NW][Bp][NC] | slabs: layer l -> [NC][Kp_l + 4], Kp_l = (l ? H : 0) +
 //               (in_x ? XW : 0) | bias [KL][NC] | misc (launch count, fail, stamps).  XW = the encoded width rounded up to
@@ -293,7 +322,7 @@ __global__ void __launch_bounds__(NT) fused_mlp_forward_kernel(const FusedArgs a
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
   const int tid = threadIdx.x, wave = tid >> 6;
-  const int G = gridDim.x, g = blockIdx.x, col0 = g * NC;
+  const int G = G_NET, g = blockIdx.x, col0 = g * NC;
   const int B = a.B, nL = a.n_layers, nX = nL - 1, IN = a.IN;
   const int XW = pad32(IN), XP = XW + 4;
   float* s_x0   = smem;
@@ -458,8 +487,12 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
   constexpr int U = (Bp * 64 + NT - 1) / NT <= 4 ? 4 : 8;
   static_assert((Bp * 64 + NT - 1) / NT <= 8, "gather_slabs covers at most 8 units per thread");
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (blockIdx.x >= G_NET) {
+    adam_side_job(a);
+    return;
+  }
   const int tid = threadIdx.x, wave = tid >> 6;
-  const int G = gridDim.x, g = blockIdx.x, col0 = g * NC;
+  const int G = G_NET, g = blockIdx.x, col0 = g * NC;
   const int B = a.B, nL = a.n_layers, IN = a.IN, nX = nL - 1;
   const bool want_gx = a.g_x0 != nullptr && col0 < IN;
   float* s_gz   = smem;
@@ -790,7 +823,11 @@ template <typename KernelT>
 int launch(KernelT k, const Plan& p, const FusedArgs& a, size_t lds, hipStream_t s) {
   if (lds > 64 * 1024)
     SKGS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  hipLaunchKernelGGL(k, dim3(p.G), dim3(NT), lds, s, a);
+  // side job: one workgroup per CU the network leaves idle (each takes two chunks per iteration)
+  int side = 0;
+  if (a.adam_tensors && a.adam_c1 > a.adam_c0)
+    side = (int) std::min<long long>((a.adam_c1 - a.adam_c0 + 1) / 2, NUM_CUS - p.G);
+  hipLaunchKernelGGL(k, dim3(p.G + side), dim3(NT), lds, s, a);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -854,6 +891,12 @@ int skgs_deform_mlp_forward(const skgs_mlp_desc* d, const float* points, const f
 
 int skgs_deform_mlp_backward(const skgs_mlp_desc* d, const float* points, const float* t, const float* x0, const float* acts,
     const float* g_out, float* g_x0, void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
+  return skgs_deform_mlp_backward_adam(d, points, t, x0, acts, g_out, g_x0, workspace, workspace_bytes, nullptr, stream);
+}
+
+int skgs_deform_mlp_backward_adam(const skgs_mlp_desc* d, const float* points, const float* t, const float* x0,
+    const float* acts, const float* g_out, float* g_x0, void* workspace, size_t workspace_bytes, const skgs_adam_range* side,
+    skgs_stream_t stream) {
   Plan p;
   if (make_plan(d, &p)) return 1;
   SKGS_REQUIRE(points && (t || d->t_dim == 0) && acts && workspace, "deform_mlp_backward: NULL argument");
@@ -868,6 +911,13 @@ int skgs_deform_mlp_backward(const skgs_mlp_desc* d, const float* points, const 
   FusedArgs a{};
   fill_args(d, p, &a);
   a.points = points, a.t = t, a.x0 = const_cast<float*>(x0), a.acts = const_cast<float*>(acts), a.g_out = g_out, a.g_x0 = g_x0;
+  if (side && side->n_tensors > 0) {
+    SKGS_REQUIRE(side->tensors && side->step_count && side->chunk_begin >= 0 && side->chunk_end >= side->chunk_begin,
+        "deform_mlp_backward_adam: bad side range");
+    a.adam_tensors = reinterpret_cast<const AdamTensor*>(side->tensors), a.adam_n = side->n_tensors;
+    a.adam_c0 = side->chunk_begin, a.adam_c1 = side->chunk_end;
+    a.adam_beta1 = side->beta1, a.adam_beta2 = side->beta2, a.adam_eps = (float) side->eps, a.adam_step = side->step_count;
+  }
   a.hdr  = reinterpret_cast<unsigned*>(workspace);
   a.exch = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + HDR_BYTES + p.exch_bytes);
   size_t fl = (size_t) p.Bp * HP + (size_t) (d->n_layers + NW) * p.Bp * NC + 4;

@@ -304,20 +304,23 @@ class FusedDeformMLP:
         return out
 
     def backward(self, points: Tensor, t: Tensor, g_out, grads: Sequence[Tensor], g_x0: Optional[Tensor] = None,
-                 reencode: bool = False):
+                 reencode: bool = False, side_adam=None):
         """``g_out``: [B, OUT] or one tensor per head; ``grads``: [gW0, gb0, ..., gW_heads, gb_heads] (written); ``g_x0``
         [B, IN] (written) or None.  The encoded input is the copy the last ``forward`` left in ``self.x0`` (same points and
-        time!); ``reencode``: let the kernel rebuild it from ``points`` / ``t`` instead."""
+        time!); ``reencode``: let the kernel rebuild it from ``points`` / ``t`` instead.  ``side_adam``
+        (``optim.AdamRange``): an optimizer piece that runs on the CUs this launch leaves idle -- parameters whose
+        gradients are final and that the network does not touch."""
         if isinstance(g_out, Tensor):
             assert g_out.is_cuda and g_out.is_contiguous() and g_out.shape == self.out.shape
             d = self._desc(grads)
         else:
             d, g_out = self._desc(grads, head_gout=g_out), None
-        _C._check(self.lib.skgs_deform_mlp_backward(
+        _C._check(self.lib.skgs_deform_mlp_backward_adam(
             C.byref(d), C.c_void_p(points.data_ptr()), C.c_void_p(t.data_ptr()),
             C.c_void_p(None if reencode else self.x0.data_ptr()), C.c_void_p(self.acts.data_ptr()),
             C.c_void_p(None if g_out is None else g_out.data_ptr()), C.c_void_p(None if g_x0 is None else g_x0.data_ptr()),
-            C.c_void_p(self.workspace.data_ptr()), C.c_size_t(self.workspace.numel()), _C._stream()))
+            C.c_void_p(self.workspace.data_ptr()), C.c_size_t(self.workspace.numel()),
+            None if side_adam is None else C.byref(side_adam), _C._stream()))
 
     def status(self) -> dict:
         """(synchronising) forward / backward launches so far and 'failed': launches whose in-kernel exchange timed out

@@ -114,6 +114,9 @@ class FusedViewStep:
         # the optimizer clears the per-frame table gradients after its update (FusedAdam(zero_after_step=
         # step.table_grad_span())): no fill launch at the start of the step
         self.tables_zeroed_by_optimizer = bool(tables_zeroed_by_optimizer)
+        # (FusedAdam, group names) or None: that piece of the optimizer step runs inside the deform network's backward
+        # launch (train_step.FusedTrainStep sets it; one rank, no gradient exchange between backward and update)
+        self.side_optimizer = None
         # view-parallel training: [P*K] float32 view that receives the compact LBS-logit gradient (see backward_skinning)
         self.spw_logit_grad = spw_logit_grad
         assert spw_logit_grad is None or (spw_logit_grad.numel() == P * K and spw_logit_grad.is_contiguous())
@@ -416,7 +419,11 @@ class FusedViewStep:
         if self._mlp_fused is not None:
             net = self.deform_net.dynamic_net
             grads = [g for l in net.net for g in (l.weight.grad, l.bias.grad)] + [net.last_weight.grad, net.last_bias.grad]
-            self._mlp_fused.backward(self.model.joints, self._time_tensor(self._time_id), self._g_heads, grads, self._g_x0)
+            side = None
+            if self.side_optimizer is not None:  # the per-Gaussian rows' Adam update on the CUs this launch leaves idle
+                side = self.side_optimizer[0].side_range(self.side_optimizer[1])
+            self._mlp_fused.backward(self.model.joints, self._time_tensor(self._time_id), self._g_heads, grads, self._g_x0,
+                                     side_adam=side)
             if self._g_x0 is not None:  # joints.grad (written by the bone-chain backward) += the network-input path
                 self._mlp.input_grad(self._g_x0, self._mlp_fused.x0, self.model.joints.grad, accumulate=True)
             return

@@ -32,6 +32,12 @@ def position_lr(step: int, lr_init: float, lr_final: float, max_steps: int = 30_
     return ramp * math.exp((1.0 - t) * math.log(lr_init) + t * math.log(lr_final))
 
 
+class AdamRange(C.Structure):
+    """include/skgs.h::skgs_adam_range: a run of chunks of an optimizer table, updated as the side job of another launch"""
+    _fields_ = [('n_tensors', C.c_int32), ('tensors', C.c_void_p), ('chunk_begin', C.c_int64), ('chunk_end', C.c_int64),
+                ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double), ('step_count', C.c_void_p)]
+
+
 class FusedAdam:
     def __init__(self, param_groups: Iterable[dict], betas=(0.9, 0.999), eps: float = 1e-15,
                  zero_after_step: 'torch.Tensor' = None):
@@ -295,6 +301,15 @@ class FusedAdam:
                 C.c_void_p(self.step_count.data_ptr()), C.c_int32(1 if last else 0),
                 C.c_void_p(z.data_ptr() if (z is not None and last) else None),
                 C.c_int64(z.numel() if (z is not None and last) else 0), _C._stream()))
+
+    def side_range(self, groups) -> AdamRange:
+        """the piece of a step that updates ``groups`` (neighbours in the table) as a ``skgs_adam_range``: handed to
+        ``skgs_deform_mlp_backward_adam`` it runs on the CUs that launch leaves idle -- same arithmetic as
+        ``step(groups, advance=False)``"""
+        ranges = self._chunk_ranges(groups)
+        assert len(ranges) == 1, f'groups {list(groups)} are not one run of neighbours in the table'
+        return AdamRange(len(self.params), self._table.data_ptr(), ranges[0][0], ranges[0][1], self.betas[0], self.betas[1],
+                         self.eps, self.step_count.data_ptr())
 
     def advance_step(self):
         """close a step taken in pieces: the counter moves, ``zero_after_step`` is cleared"""

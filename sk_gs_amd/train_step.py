@@ -73,3 +73,33 @@ class GraphedSteps:
                 return
             g = self.capture(key)
         g.replay()
+
+
+class FusedTrainStep:
+    """One training step of one rank: ``FusedViewStep.forward_backward`` + ``FusedAdam.step`` with the update of the
+    per-Gaussian parameters (xyz, SH, opacity, scaling, rotation, LBS logits: 95 % of the optimizer's bytes) moved INTO the
+    deform network's backward launch.  That launch is a dependent chain on 32 workgroups (~30 us) that leaves 224 CUs idle;
+    the rows' gradients are final before it starts (the skinning backward wrote them) and it does not touch them, so
+    workgroups 32.. of the same launch stream the Adam update (``skgs_deform_mlp_backward_adam``).  The optimizer pieces
+    that DO depend on it (network, joints, per-frame tables) follow as a short launch that also advances the step counter.
+    Same arithmetic as ``step.forward_backward(); optimizer.step()`` (tests/test_gpu_optim.py: bit-identical update).
+    Falls back to exactly that when the step has no fused network."""
+
+    ROW_GROUPS = ('xyz', 'f_dc', 'f_rest', 'opacity', 'scaling', 'rotation', 'sp_W')
+
+    def __init__(self, step, optimizer, enable: bool = True):
+        self.step, self.optimizer = step, optimizer
+        names = [g.get('name') for g in optimizer.param_groups]
+        self.rows = [n for n in names if n in self.ROW_GROUPS]
+        self.rest = [n for n in names if n not in self.ROW_GROUPS]
+        self.fused = bool(enable and self.rows and getattr(step, '_mlp_fused', None) is not None
+                          and step.spw_logit_grad is None and step.sh_factors is None
+                          and len(optimizer._chunk_ranges(self.rows)) == 1)
+        step.side_optimizer = (optimizer, self.rows) if self.fused else None
+
+    def __call__(self, rs=None, time_id=None, target=None):
+        self.step.forward_backward(rs, time_id, target)
+        if self.fused:
+            self.optimizer.step(self.rest, advance=True)
+        else:
+            self.optimizer.step()

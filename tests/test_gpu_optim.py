@@ -133,3 +133,49 @@ def test_a_step_taken_in_pieces_equals_the_whole_step():
         assert torch.equal(whole.state[p]['exp_avg_sq'], pieces.state[q]['exp_avg_sq'])
     with pytest.raises(AssertionError):
         pieces.step(['no_such_group'])
+
+
+def test_adam_rows_as_the_side_job_of_the_network_backward_launch():
+    """``skgs_deform_mlp_backward_adam``: the update of a run of parameter groups applied by the extra workgroups of the deform
+    network's backward launch is bit-identical to ``step(groups, advance=False)``, the network's own gradients are unchanged,
+    and the counter does not move until the closing piece"""
+    from sk_gs_amd.deform_net import DeformMLP, FusedDeformMLP
+    from sk_gs_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    mlp = DeformMLP().cuda()
+    B = 20
+    joints, t, g = torch.rand(B, 3, device='cuda') - 0.5, torch.tensor([0.3], device='cuda'), torch.randn(B, 11, device='cuda')
+    net = mlp.dynamic_net
+    params = [p for l in net.net for p in (l.weight, l.bias)] + [net.last_weight, net.last_bias]
+    names = ['xyz', 'f_dc', 'f_rest', 'opacity', 'sp_W', 'net']
+    shapes = [(30011, 3), (30011, 1, 3), (30011, 15, 3), (30011, 1), (30011, 20), (129, 7)]  # odd sizes: ragged last chunks
+
+    def make():
+        gen = torch.Generator().manual_seed(2)
+        ps = [torch.nn.Parameter(torch.randn(*s, generator=gen).cuda()) for s in shapes]
+        opt = FusedAdam([{'params': [p], 'lr': 1e-2 * (i + 1), 'name': n} for i, (p, n) in enumerate(zip(ps, names))])
+        return ps, opt
+    (a, ref), (b, side) = make(), make()
+    rows = names[:5]
+    run = FusedDeformMLP(mlp, B)
+    gen = torch.Generator().manual_seed(3)
+    for it in range(3):
+        for p, q in zip(a, b):
+            gr = torch.randn(p.shape, generator=gen).cuda()
+            p.grad.copy_(gr), q.grad.copy_(gr)
+        run.forward(joints, t)
+        g1 = [torch.zeros_like(p) for p in params]
+        run.backward(joints, t, g, g1)                                  # the launch alone
+        ref.step(rows, advance=False)
+        ref.step(['net'])
+        g2 = [torch.zeros_like(p) for p in params]
+        run.backward(joints, t, g, g2, side_adam=side.side_range(rows))  # the launch with the rows' update on board
+        assert float(side.step_count.item()) == float(it)
+        side.step(['net'])
+        for x, y in zip(g1, g2):
+            assert torch.equal(x, y)
+    assert run.status()['failed'] == 0 and float(side.step_count.item()) == 3.0
+    for p, q in zip(a, b):
+        assert torch.equal(p, q)
+        assert torch.equal(ref.state[p]['exp_avg'], side.state[q]['exp_avg'])
+        assert torch.equal(ref.state[p]['exp_avg_sq'], side.state[q]['exp_avg_sq'])
