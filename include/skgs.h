@@ -377,6 +377,31 @@ typedef struct skgs_adam_range {
 int skgs_deform_mlp_backward_adam(const skgs_mlp_desc* d, const float* points, const float* t, const float* x0,
     const float* acts, const float* g_out, float* g_x0, void* workspace, size_t workspace_bytes, const skgs_adam_range* side,
     skgs_stream_t stream);
+/* ---- the skeleton stage as ONE launch per direction: network + kinematic chain ----
+ * kinematic() (networks/sk_gs.py:1069-1107) = sk_deform_net -> normalised joint rotations -> chain of SE3 products.  The
+ * network's rows are the bones (d->B == M) and its first head the raw rotations (d->head_dim[0] == 4): the workgroup
+ * that owns those columns runs skgs_bone_chain_forward's body right after the heads (one launch and ~4 us less than the two
+ * calls); in the backward every workgroup runs skgs_bone_chain_backward's body in its prologue, behind its weight loads --
+ * the gradient of the raw rotations never goes through memory (d->head_gout[0], if not NULL, still receives a copy; the
+ * other heads' gradients are read as usual). */
+typedef struct skgs_bone_chain_desc {
+  int32_t M, root, num_levels;
+  const int32_t *parents, *level_nodes, *level_start;   /* as for skgs_bone_chain_forward */
+  const float* joints;                                  /* [M,3] */
+  const float* global_T;                                /* [7], or [frames,7] with frame_index; may be NULL */
+  const int32_t* frame_index;                           /* DEVICE int32 or NULL */
+  float* bone_T;                                        /* forward: [M,7] written */
+  float* chain_A;                                       /* forward: [M,7] written (may be NULL); backward: read */
+  const float* sk_r_raw;                                /* backward: the forward's head 0, [M,4] */
+  const float* g_bone_T;                                /* backward: [M,7] */
+  float* g_joints;                                      /* backward: [M,3] chain part, written; may be NULL */
+  float* g_global_T;                                    /* backward: [7] (row frame_index), written; may be NULL */
+} skgs_bone_chain_desc;
+int skgs_skeleton_forward(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, const float* points, const float* t,
+    float* x0, float* acts, void* workspace, size_t workspace_bytes, skgs_stream_t stream);
+int skgs_skeleton_backward(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, const float* points, const float* t,
+    const float* x0, const float* acts, float* g_x0, void* workspace, size_t workspace_bytes, const skgs_adam_range* side,
+    skgs_stream_t stream);
 int skgs_deform_mlp_status(const void* workspace, uint32_t* host_words4, skgs_stream_t stream);
 
 /* ---- densification statistics of one training view (scope row (f)-4) ----

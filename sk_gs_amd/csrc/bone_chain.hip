@@ -12,243 +12,22 @@
 // Gradients are plain Euclidean gradients w.r.t. the stored numbers.  Quaternions are unit by construction inside the
 // chain, multiplication by a unit quaternion is an isometry of R^4, so the radial part of any incoming gradient stays
 // radial and is removed where a real normalisation happens: at raw -> sk_r and at G's quaternion.
+#include "bone_chain.inl"
 #include "skgs_common.h"
-
-#pragma clang fp contract(off)
 
 namespace skgs {
 namespace {
 
-struct Q4 {
-  float x, y, z, w;
-};
-struct V3 {
-  float x, y, z;
-};
-__device__ __forceinline__ Q4 qmul(const Q4& a, const Q4& b) {  // Hamilton product, xyzw
-  return {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
-      a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
-}
-__device__ __forceinline__ Q4 qconj(const Q4& a) { return {-a.x, -a.y, -a.z, a.w}; }
-__device__ __forceinline__ Q4 qnormalize(const Q4& a) {
-  const float n = fmaxf(sqrtf(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w), 1e-12f);
-  return {a.x / n, a.y / n, a.z / n, a.w / n};
-}
-__device__ __forceinline__ V3 cross(const V3& a, const V3& b) {
-  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
-}
-__device__ __forceinline__ float dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-// p + w*uv + v x uv, uv = 2 v x p  (lie.h:59-64)
-__device__ __forceinline__ V3 qrot(const Q4& q, const V3& p) {
-  const V3 v  = {q.x, q.y, q.z};
-  V3 uv       = cross(v, p);
-  uv          = {uv.x + uv.x, uv.y + uv.y, uv.z + uv.z};
-  const V3 c  = cross(v, uv);
-  return {p.x + q.w * uv.x + c.x, p.y + q.w * uv.y + c.y, p.z + q.w * uv.z + c.z};
-}
-// gradient of (R(q) p) . g  w.r.t. q (as a polynomial in q) and w.r.t. p (= R(q)^T g)
-__device__ __forceinline__ Q4 qrot_grad_q(const Q4& q, const V3& p, const V3& g) {
-  const V3 v   = {q.x, q.y, q.z};
-  const V3 pxg = cross(p, g), vxp = cross(v, p);
-  const float vdp = dot(v, p), gdv = dot(g, v), gdp = dot(g, p);
-  return {2.f * q.w * pxg.x + 2.f * (vdp * g.x + gdv * p.x - 2.f * gdp * v.x),
-      2.f * q.w * pxg.y + 2.f * (vdp * g.y + gdv * p.y - 2.f * gdp * v.y),
-      2.f * q.w * pxg.z + 2.f * (vdp * g.z + gdv * p.z - 2.f * gdp * v.z), 2.f * dot(g, vxp)};
-}
-__device__ __forceinline__ V3 qrot_T(const Q4& q, const V3& g) { return qrot(qconj(q), g); }
-
 constexpr int CHAIN_THREADS = 256;
-constexpr int LOC_F         = 12;  // staged per-bone local data: q[4] (unit), tL[3], j[3], |raw|, pad
 
-// Per-bone local transform L_i = (j + R(q)(-j), q) and the topology, staged in LDS by all threads at once: the
-// level loops then touch LDS only.  (Reading parents / level_nodes / raw / joints from global memory inside the loop
-// made every tree level a chain of three dependent global loads: 13 us for a 20-bone skeleton.)
-struct Staged {
-  const float* loc;  // [M][LOC_F]
-  const int* par;    // [M]
-  const int* ln;     // [M]
-  const int* ls;     // [num_levels + 1]
-};
-__device__ __forceinline__ Staged stage_skeleton(float* s_base, int M, int num_levels, const int32_t* parents,
-    const int32_t* level_nodes, const int32_t* level_start, const float* sk_r_raw, const float* joints) {
-  float* loc = s_base;
-  int* par   = reinterpret_cast<int*>(s_base + (size_t) M * LOC_F);
-  int* ln    = par + M;
-  int* ls    = ln + M;
-  for (int i = threadIdx.x; i < M; i += CHAIN_THREADS) {
-    const float raw[4] = {sk_r_raw[4 * i], sk_r_raw[4 * i + 1], sk_r_raw[4 * i + 2], sk_r_raw[4 * i + 3] + 1.0f};
-    const float nraw   = fmaxf(sqrtf(raw[0] * raw[0] + raw[1] * raw[1] + raw[2] * raw[2] + raw[3] * raw[3]), 1e-12f);
-    const Q4 q  = {raw[0] / nraw, raw[1] / nraw, raw[2] / nraw, raw[3] / nraw};
-    const V3 j  = {joints[3 * i], joints[3 * i + 1], joints[3 * i + 2]};
-    const V3 rj = qrot(q, {-j.x, -j.y, -j.z});
-    float* o    = loc + (size_t) i * LOC_F;
-    o[0] = q.x, o[1] = q.y, o[2] = q.z, o[3] = q.w;
-    o[4] = j.x + rj.x, o[5] = j.y + rj.y, o[6] = j.z + rj.z;
-    o[7] = j.x, o[8] = j.y, o[9] = j.z, o[10] = nraw, o[11] = 0.f;
-    par[i] = parents[i], ln[i] = level_nodes[i];
-  }
-  for (int l = threadIdx.x; l <= num_levels; l += CHAIN_THREADS) ls[l] = level_start[l];
-  return {loc, par, ln, ls};
-}
-inline size_t staged_bytes(int M, int num_levels) { return ((size_t) M * LOC_F + 2 * (size_t) M + num_levels + 2) * 4; }
-// LDS layout per bone: A = (t[3], q[4]) -> 7 floats (forward) + gA 7 floats (backward)
-
-__global__ void __launch_bounds__(CHAIN_THREADS) bone_chain_forward_kernel(int M, int root, const int32_t* __restrict__ parents,
-    const int32_t* __restrict__ level_nodes, const int32_t* __restrict__ level_start, int num_levels,
-    const float* __restrict__ sk_r_raw, const float* __restrict__ joints, const float* __restrict__ global_T,
-    float* __restrict__ bone_T, float* __restrict__ chain_A /*[M,7] saved for backward*/,
-    const int32_t* __restrict__ frame_index) {
-  extern __shared__ float s_A[];  // [M][7] | staged skeleton
-  if (global_T && frame_index) global_T += 7 * (size_t) frame_index[0];  // row of a [frames, 7] table, chosen on the device
-  const int tid = threadIdx.x;
-  const Staged sk = stage_skeleton(s_A + 7 * (size_t) M, M, num_levels, parents, level_nodes, level_start, sk_r_raw, joints);
-  if (tid == 0) {
-    float* a = s_A + 7 * root;
-    a[0] = a[1] = a[2] = a[3] = a[4] = a[5] = 0.f, a[6] = 1.f;
-  }
-  __syncthreads();
-  for (int lv = 1; lv < num_levels; ++lv) {
-    for (int k = sk.ls[lv] + tid; k < sk.ls[lv + 1]; k += CHAIN_THREADS) {
-      const int i = sk.ln[k], p = sk.par[i];
-      const float* lo = sk.loc + (size_t) i * LOC_F;
-      const Q4 q  = {lo[0], lo[1], lo[2], lo[3]};
-      const V3 tL = {lo[4], lo[5], lo[6]};
-      const float* ap = s_A + 7 * p;
-      const Q4 qp = {ap[3], ap[4], ap[5], ap[6]};
-      const V3 rt = qrot(qp, tL);
-      const Q4 qa = qnormalize(qmul(qp, q));
-      float* a    = s_A + 7 * i;
-      a[0] = ap[0] + rt.x, a[1] = ap[1] + rt.y, a[2] = ap[2] + rt.z;
-      a[3] = qa.x, a[4] = qa.y, a[5] = qa.z, a[6] = qa.w;
-    }
-    __syncthreads();
-  }
-  Q4 qg = {0.f, 0.f, 0.f, 1.f};
-  V3 tg = {0.f, 0.f, 0.f};
-  if (global_T) {
-    qg = qnormalize({global_T[3], global_T[4], global_T[5], global_T[6]});
-    tg = {global_T[0], global_T[1], global_T[2]};
-  }
-  for (int i = tid; i < M; i += CHAIN_THREADS) {
-    const float* a = s_A + 7 * i;
-    const Q4 qa    = {a[3], a[4], a[5], a[6]};
-    float* o       = bone_T + 7 * i;
-    if (global_T) {
-      const V3 rt = qrot(qg, {a[0], a[1], a[2]});
-      const Q4 qt = qnormalize(qmul(qg, qa));
-      o[0] = tg.x + rt.x, o[1] = tg.y + rt.y, o[2] = tg.z + rt.z, o[3] = qt.x, o[4] = qt.y, o[5] = qt.z, o[6] = qt.w;
-    } else {
-#pragma unroll
-      for (int c = 0; c < 7; ++c) o[c] = a[c];
-    }
-    if (chain_A) {
-#pragma unroll
-      for (int c = 0; c < 7; ++c) chain_A[7 * i + c] = a[c];
-    }
-  }
-}
-
-__global__ void __launch_bounds__(CHAIN_THREADS) bone_chain_backward_kernel(int M, int root, const int32_t* __restrict__ parents,
-    const int32_t* __restrict__ level_nodes, const int32_t* __restrict__ level_start, int num_levels,
-    const float* __restrict__ sk_r_raw, const float* __restrict__ joints, const float* __restrict__ global_T,
-    const float* __restrict__ chain_A, const float* __restrict__ g_bone_T, float* __restrict__ g_sk_r_raw,
-    float* __restrict__ g_joints, float* __restrict__ g_global_T, const int32_t* __restrict__ frame_index) {
+// (the bodies live in bone_chain.inl: the deform network's launches run them too)
+__global__ void __launch_bounds__(CHAIN_THREADS) bone_chain_forward_kernel(const chain::ChainArgs c) {
   extern __shared__ float s_mem[];
-  if (frame_index) {
-    if (global_T) global_T += 7 * (size_t) frame_index[0];
-    if (g_global_T) g_global_T += 7 * (size_t) frame_index[0];
-  }
-  float* s_A  = s_mem;          // [M][7]
-  float* s_gA = s_mem + 7 * M;  // [M][7]
-  __shared__ float s_gG[7];
-  const int tid = threadIdx.x;
-  const Staged sk = stage_skeleton(s_mem + 14 * (size_t) M, M, num_levels, parents, level_nodes, level_start, sk_r_raw, joints);
-  for (int i = tid; i < 7 * M; i += CHAIN_THREADS) s_A[i] = chain_A[i];
-  if (tid < 7) s_gG[tid] = 0.f;
-  __syncthreads();
-  Q4 qg = {0.f, 0.f, 0.f, 1.f};
-  if (global_T) qg = qnormalize({global_T[3], global_T[4], global_T[5], global_T[6]});
-  // T_i = G o A_i
-  for (int i = tid; i < M; i += CHAIN_THREADS) {
-    const float* g = g_bone_T + 7 * i;
-    const V3 gt    = {g[0], g[1], g[2]};
-    const Q4 gq    = {g[3], g[4], g[5], g[6]};
-    float* ga      = s_gA + 7 * i;
-    if (global_T) {
-      const float* a = s_A + 7 * i;
-      const V3 tA    = {a[0], a[1], a[2]};
-      const Q4 qA    = {a[3], a[4], a[5], a[6]};
-      const V3 gtA   = qrot_T(qg, gt);
-      const Q4 gqA   = qmul(qconj(qg), gq);          // d(qg * qA)/dqA ^T
-      const Q4 gqG1  = qrot_grad_q(qg, tA, gt);      // through R(qg) tA
-      const Q4 gqG2  = qmul(gq, qconj(qA));          // d(qg * qA)/dqg ^T
-      ga[0] = gtA.x, ga[1] = gtA.y, ga[2] = gtA.z, ga[3] = gqA.x, ga[4] = gqA.y, ga[5] = gqA.z, ga[6] = gqA.w;
-      atomicAdd(&s_gG[0], gt.x), atomicAdd(&s_gG[1], gt.y), atomicAdd(&s_gG[2], gt.z);
-      atomicAdd(&s_gG[3], gqG1.x + gqG2.x), atomicAdd(&s_gG[4], gqG1.y + gqG2.y);
-      atomicAdd(&s_gG[5], gqG1.z + gqG2.z), atomicAdd(&s_gG[6], gqG1.w + gqG2.w);
-    } else {
-#pragma unroll
-      for (int c = 0; c < 7; ++c) ga[c] = g[c];
-    }
-  }
-  __syncthreads();
-  // A_i = A_p o L_i, deepest level first
-  for (int lv = num_levels - 1; lv >= 1; --lv) {
-    for (int k = sk.ls[lv] + tid; k < sk.ls[lv + 1]; k += CHAIN_THREADS) {
-      const int i = sk.ln[k], p = sk.par[i];
-      const float* lo  = sk.loc + (size_t) i * LOC_F;
-      const Q4 q       = {lo[0], lo[1], lo[2], lo[3]};
-      const V3 tL      = {lo[4], lo[5], lo[6]};
-      const V3 mj      = {-lo[7], -lo[8], -lo[9]};
-      const float nraw = lo[10];
-      const float* ap = s_A + 7 * p;
-      const Q4 qp = {ap[3], ap[4], ap[5], ap[6]};
-      const float* ga = s_gA + 7 * i;
-      const V3 gtA = {ga[0], ga[1], ga[2]};
-      const Q4 gqA = {ga[3], ga[4], ga[5], ga[6]};
-      // parent
-      const Q4 gqp1 = qrot_grad_q(qp, tL, gtA);
-      const Q4 gqp2 = qmul(gqA, qconj(q));
-      float* gp     = s_gA + 7 * p;
-      atomicAdd(&gp[0], gtA.x), atomicAdd(&gp[1], gtA.y), atomicAdd(&gp[2], gtA.z);
-      atomicAdd(&gp[3], gqp1.x + gqp2.x), atomicAdd(&gp[4], gqp1.y + gqp2.y);
-      atomicAdd(&gp[5], gqp1.z + gqp2.z), atomicAdd(&gp[6], gqp1.w + gqp2.w);
-      // local transform L_i = (j + R(q)(-j), q)
-      const V3 gtL = qrot_T(qp, gtA);
-      Q4 gq        = qmul(qconj(qp), gqA);
-      const Q4 gq2 = qrot_grad_q(q, mj, gtL);
-      gq           = {gq.x + gq2.x, gq.y + gq2.y, gq.z + gq2.z, gq.w + gq2.w};
-      if (g_joints) {
-        const V3 rtg = qrot_T(q, gtL);  // d(R(q)(-j))/dj = -R(q)
-        g_joints[3 * i] = gtL.x - rtg.x, g_joints[3 * i + 1] = gtL.y - rtg.y, g_joints[3 * i + 2] = gtL.z - rtg.z;
-      }
-      // raw -> unit quaternion
-      const float d = q.x * gq.x + q.y * gq.y + q.z * gq.z + q.w * gq.w;
-      g_sk_r_raw[4 * i]     = (gq.x - q.x * d) / nraw;
-      g_sk_r_raw[4 * i + 1] = (gq.y - q.y * d) / nraw;
-      g_sk_r_raw[4 * i + 2] = (gq.z - q.z * d) / nraw;
-      g_sk_r_raw[4 * i + 3] = (gq.w - q.w * d) / nraw;
-    }
-    __syncthreads();
-  }
-  if (tid == 0) {
-    // the root's own rotation is replaced by the identity: no gradient
-    g_sk_r_raw[4 * root] = g_sk_r_raw[4 * root + 1] = g_sk_r_raw[4 * root + 2] = g_sk_r_raw[4 * root + 3] = 0.f;
-    if (g_joints) g_joints[3 * root] = g_joints[3 * root + 1] = g_joints[3 * root + 2] = 0.f;
-    if (g_global_T) {
-      if (global_T) {
-        const float n = fmaxf(sqrtf(global_T[3] * global_T[3] + global_T[4] * global_T[4] + global_T[5] * global_T[5] +
-                                    global_T[6] * global_T[6]), 1e-12f);
-        const float d = qg.x * s_gG[3] + qg.y * s_gG[4] + qg.z * s_gG[5] + qg.w * s_gG[6];
-        g_global_T[0] = s_gG[0], g_global_T[1] = s_gG[1], g_global_T[2] = s_gG[2];
-        g_global_T[3] = (s_gG[3] - qg.x * d) / n, g_global_T[4] = (s_gG[4] - qg.y * d) / n;
-        g_global_T[5] = (s_gG[5] - qg.z * d) / n, g_global_T[6] = (s_gG[6] - qg.w * d) / n;
-      } else {
-#pragma unroll
-        for (int c = 0; c < 7; ++c) g_global_T[c] = 0.f;
-      }
-    }
-  }
+  chain::forward_body(s_mem, c);
+}
+__global__ void __launch_bounds__(CHAIN_THREADS) bone_chain_backward_kernel(const chain::ChainArgs c) {
+  extern __shared__ float s_mem[];
+  chain::backward_body(s_mem, c, c.g_sk_r_raw, true);
 }
 
 }  // namespace
@@ -263,10 +42,13 @@ int skgs_bone_chain_forward(int32_t M, int32_t root, const int32_t* parents, con
     float* bone_T, float* chain_A, const int32_t* frame_index, skgs_stream_t stream) {
   SKGS_REQUIRE(M >= 1 && root >= 0 && root < M && num_levels >= 1, "bone_chain: bad skeleton sizes");
   SKGS_REQUIRE(parents && level_nodes && level_start && sk_r_raw && joints && bone_T, "bone_chain: NULL argument");
-  const size_t lds = (size_t) M * 7 * 4 + staged_bytes(M, num_levels);
+  const size_t lds = chain::forward_scratch_floats(M, num_levels) * 4;
   SKGS_REQUIRE(lds <= 64 * 1024, "bone_chain: skeleton too large for the LDS staging (about 740 bones)");
-  hipLaunchKernelGGL(bone_chain_forward_kernel, dim3(1), dim3(CHAIN_THREADS), lds, (hipStream_t) stream, M, root,
-      parents, level_nodes, level_start, num_levels, sk_r_raw, joints, global_T, bone_T, chain_A, frame_index);
+  chain::ChainArgs c{};
+  c.M = M, c.root = root, c.num_levels = num_levels, c.parents = parents, c.level_nodes = level_nodes;
+  c.level_start = level_start, c.sk_r_raw = sk_r_raw, c.joints = joints, c.global_T = global_T, c.frame_index = frame_index;
+  c.bone_T = bone_T, c.chain_A = chain_A;
+  hipLaunchKernelGGL(bone_chain_forward_kernel, dim3(1), dim3(CHAIN_THREADS), lds, (hipStream_t) stream, c);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -278,11 +60,14 @@ int skgs_bone_chain_backward(int32_t M, int32_t root, const int32_t* parents, co
   SKGS_REQUIRE(M >= 1 && root >= 0 && root < M && num_levels >= 1, "bone_chain: bad skeleton sizes");
   SKGS_REQUIRE(parents && level_nodes && level_start && sk_r_raw && joints && chain_A && g_bone_T && g_sk_r_raw,
       "bone_chain: NULL argument");
-  const size_t lds = (size_t) M * 14 * 4 + staged_bytes(M, num_levels);
+  const size_t lds = chain::backward_scratch_floats(M, num_levels) * 4;
   SKGS_REQUIRE(lds <= 64 * 1024, "bone_chain backward: skeleton too large for the LDS staging (about 560 bones)");
-  hipLaunchKernelGGL(bone_chain_backward_kernel, dim3(1), dim3(CHAIN_THREADS), lds, (hipStream_t) stream, M,
-      root, parents, level_nodes, level_start, num_levels, sk_r_raw, joints, global_T, chain_A, g_bone_T, g_sk_r_raw,
-      g_joints, g_global_T, frame_index);
+  chain::ChainArgs c{};
+  c.M = M, c.root = root, c.num_levels = num_levels, c.parents = parents, c.level_nodes = level_nodes;
+  c.level_start = level_start, c.sk_r_raw = sk_r_raw, c.joints = joints, c.global_T = global_T, c.frame_index = frame_index;
+  c.chain_A = const_cast<float*>(chain_A), c.g_bone_T = g_bone_T, c.g_sk_r_raw = g_sk_r_raw, c.g_joints = g_joints;
+  c.g_global_T = g_global_T;
+  hipLaunchKernelGGL(bone_chain_backward_kernel, dim3(1), dim3(CHAIN_THREADS), lds, (hipStream_t) stream, c);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

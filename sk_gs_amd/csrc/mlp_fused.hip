@@ -37,6 +37,7 @@
 #include <algorithm>
 
 #include "adam_update.h"
+#include "bone_chain.inl"
 #include "skgs_common.h"
 
 namespace skgs {
@@ -91,6 +92,12 @@ struct FusedArgs {
   double adam_beta1, adam_beta2;
   float adam_eps;
   const float* adam_step;
+  // the kinematic chain riding on the launches (skgs_skeleton_forward / _backward): forward -- workgroup 0, which owns
+  // the raw joint rotations (head 0 = the last layer's columns 0..3), runs it after the heads; backward -- every workgroup
+  // runs its backward in the prologue (the gradient of head 0 is the one input of the network's backward no other kernel
+  // has produced yet)
+  int has_chain;
+  chain::ChainArgs chain;
 };
 
 __device__ __forceinline__ FusedLayer get_layer(const FusedArgs& a, int l) {
@@ -328,7 +335,8 @@ __global__ void __launch_bounds__(NT) fused_mlp_forward_kernel(const FusedArgs a
   float* s_x0   = smem;
   float* s_act  = s_x0 + Bp * XP;
   float* s_part = s_act + Bp * HP;
-  float* s_w    = s_part + NW * Bp * NC;
+  float* s_raw  = s_part + NW * Bp * NC;  // [Bp][4]: the raw joint rotations (head 0), kept for the kinematic chain
+  float* s_w    = s_raw + Bp * 4;
   unsigned* s_misc = reinterpret_cast<unsigned*>(smem + a.lds_floats - 4);
   float* s_bias    = smem + a.lds_floats - 4 - KL * NC;
   const LaneMap lm = lane_map();
@@ -453,6 +461,7 @@ __global__ void __launch_bounds__(NT) fused_mlp_forward_kernel(const FusedArgs a
       if (row < B) {
         if (last) {
           const int c = col0 + 4 * part;
+          if (c == 0) *reinterpret_cast<float4*>(s_raw + 4 * row) = y;
           if (c < L.out) *head_elem(a, a.head_out, a.out, row, c, L.out) = y.x;
           if (c + 1 < L.out) *head_elem(a, a.head_out, a.out, row, c + 1, L.out) = y.y;
           if (c + 2 < L.out) *head_elem(a, a.head_out, a.out, row, c + 2, L.out) = y.z;
@@ -465,6 +474,12 @@ __global__ void __launch_bounds__(NT) fused_mlp_forward_kernel(const FusedArgs a
     }
     woff += NC * WP;
     stamp(a, s_misc, si);
+  }
+  if (a.has_chain && g == 0 && !s_misc[1]) {  // joint rotations -> bone transforms (bone_chain.inl), s_part as scratch
+    __syncthreads();
+    chain::ChainArgs c = a.chain;
+    c.sk_r_raw = s_raw;
+    chain::forward_body(s_part, c);
   }
   // the optional copy of the encoded input leaves from the last workgroup, after its part of the chain
   if (a.x0 && g == G - 1)
@@ -499,7 +514,8 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
   float* s_x0   = s_gz;  // the encoded input is only needed by the weight gradients: built after the chain, over s_gz
   float* s_own  = s_gz + Bp * HP;
   float* s_part = s_own + nL * Bp * NC;
-  float* s_wT   = s_part + NW * Bp * NC;
+  float* s_graw = s_part + NW * Bp * NC;  // [Bp][4]: gradient of the raw joint rotations (head 0) from the chain backward
+  float* s_wT   = s_graw + Bp * 4;
   int t_total = 0;  // floats of the T slabs; the X slabs follow
   for (int l = 1; l < nL; ++l) t_total += NC * (pad32(get_layer(a, l).out) + 4);
   int x_total = 0;
@@ -579,16 +595,23 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
       }
     }
   }
+  if (a.has_chain) {  // (the loads above stay in flight behind this)
+    chain::backward_body(s_part, a.chain, s_graw, g == 0);
+    __syncthreads();
+  }
   {  // gZ of the last layer = the incoming gradient (zero-padded to 64 columns); this workgroup's slab of it
     const int oL = get_layer(a, nL - 1).out;
+    auto g_in = [&](int b, int c) -> float {
+      if (a.has_chain && c < 4) return s_graw[4 * b + c];
+      return *head_elem(a, const_cast<float* const*>(a.head_gout), const_cast<float*>(a.g_out), b, c, oL);
+    };
     for (int i = tid; i < Bp * 64; i += NT) {
       const int b = i >> 6, c = i & 63;
-      s_gz[b * HP + c] = (b < B && c < oL) ? *head_elem(a, const_cast<float* const*>(a.head_gout), const_cast<float*>(a.g_out), b, c, oL) : 0.f;
+      s_gz[b * HP + c] = (b < B && c < oL) ? g_in(b, c) : 0.f;
     }
     for (int i = tid; i < Bp * NC; i += NT) {
       const int b = i / NC, c = i - b * NC;
-      s_own[(nL - 1) * Bp * NC + i] =
-          (b < B && col0 + c < oL) ? *head_elem(a, const_cast<float* const*>(a.head_gout), const_cast<float*>(a.g_out), b, col0 + c, oL) : 0.f;
+      s_own[(nL - 1) * Bp * NC + i] = (b < B && col0 + c < oL) ? g_in(b, col0 + c) : 0.f;
     }
   }
   if (tid == 0) s_misc[0] = cnt, s_misc[1] = 0, s_misc[2] = stamps_on;
@@ -819,6 +842,25 @@ void fill_args(const skgs_mlp_desc* d, const Plan& p, FusedArgs* a) {
   for (int j = 0; j < 4; ++j) a->head_dim[j] = d->head_dim[j], a->head_out[j] = d->head_out[j], a->head_gout[j] = d->head_gout[j];
 }
 
+// the kinematic chain riding on a launch: the network's rows are the bones, its first head their raw rotations
+int fill_chain(const skgs_mlp_desc* d, const Plan& p, const skgs_bone_chain_desc* b, FusedArgs* a) {
+  SKGS_REQUIRE(d->n_heads >= 1 && d->head_dim[0] == 4, "skeleton: the network's first head must be the [M,4] raw joint rotations");
+  SKGS_REQUIRE(b->M == d->B, "skeleton: %d bones but %d network rows", b->M, d->B);
+  SKGS_REQUIRE(b->root >= 0 && b->root < b->M && b->num_levels >= 1, "skeleton: bad skeleton sizes");
+  SKGS_REQUIRE(b->parents && b->level_nodes && b->level_start && b->joints, "skeleton: NULL topology / joints");
+  a->has_chain = 1;
+  chain::ChainArgs& c = a->chain;
+  c.M = b->M, c.root = b->root, c.num_levels = b->num_levels, c.parents = b->parents, c.level_nodes = b->level_nodes;
+  c.level_start = b->level_start, c.joints = b->joints, c.global_T = b->global_T, c.frame_index = b->frame_index;
+  c.bone_T = b->bone_T, c.chain_A = b->chain_A;
+  return 0;
+}
+int forward_impl(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, const float* points, const float* t, float* x0,
+    float* acts, float* out, void* workspace, size_t workspace_bytes, skgs_stream_t stream);
+int backward_impl(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, const float* points, const float* t,
+    const float* x0, const float* acts, const float* g_out, float* g_x0, void* workspace, size_t workspace_bytes,
+    const skgs_adam_range* side, skgs_stream_t stream);
+
 template <typename KernelT>
 int launch(KernelT k, const Plan& p, const FusedArgs& a, size_t lds, hipStream_t s) {
   if (lds > 64 * 1024)
@@ -867,6 +909,21 @@ int skgs_deform_mlp_workspace_init(void* workspace, size_t workspace_bytes, skgs
 
 int skgs_deform_mlp_forward(const skgs_mlp_desc* d, const float* points, const float* t, float* x0, float* acts, float* out,
     void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
+  return forward_impl(d, nullptr, points, t, x0, acts, out, workspace, workspace_bytes, stream);
+}
+
+int skgs_skeleton_forward(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, const float* points, const float* t,
+    float* x0, float* acts, void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
+  SKGS_REQUIRE(bones, "skeleton_forward: NULL bone chain");
+  return forward_impl(d, bones, points, t, x0, acts, nullptr, workspace, workspace_bytes, stream);
+}
+
+}  // extern "C"
+
+namespace skgs {
+namespace {
+int forward_impl(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, const float* points, const float* t, float* x0,
+    float* acts, float* out, void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
   Plan p;
   if (make_plan(d, &p)) return 1;
   SKGS_REQUIRE(points && (t || d->t_dim == 0) && acts && workspace, "deform_mlp_forward: NULL argument");
@@ -880,27 +937,55 @@ int skgs_deform_mlp_forward(const skgs_mlp_desc* d, const float* points, const f
   a.points = points, a.t = t, a.x0 = x0, a.acts = acts, a.out = out;
   a.hdr  = reinterpret_cast<unsigned*>(workspace);
   a.exch = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + HDR_BYTES);
+  if (bones) {
+    if (fill_chain(d, p, bones, &a)) return 1;
+    SKGS_REQUIRE(bones->bone_T, "skeleton_forward: bone_T is NULL");
+    SKGS_REQUIRE(chain::forward_scratch_floats(bones->M, bones->num_levels) <= (size_t) NW * p.Bp * NC,
+        "skeleton_forward: %d tree levels do not fit the scratch", bones->num_levels);
+  }
   const int XW = pad32(p.IN);
-  size_t fl = (size_t) p.Bp * (XW + 4) + (size_t) p.Bp * HP + (size_t) NW * p.Bp * NC + (size_t) KL * NC + 4;
+  size_t fl = (size_t) p.Bp * (XW + 4) + (size_t) p.Bp * HP + (size_t) NW * p.Bp * NC + (size_t) p.Bp * 4 + (size_t) KL * NC + 4;
   for (int l = 0; l < d->n_layers; ++l) fl += (size_t) NC * ((l ? H : 0) + (d->layer[l].in_x0 ? XW : 0) + 4);
   a.lds_floats = (int) fl;
   const size_t lds = fl * 4;
   SKGS_REQUIRE(lds <= 160 * 1024, "deform_mlp_forward: %zu bytes of LDS needed", lds);
   SKGS_MLP_DISPATCH(fused_mlp_forward_kernel)
 }
+}  // namespace
+}  // namespace skgs
+
+extern "C" {
 
 int skgs_deform_mlp_backward(const skgs_mlp_desc* d, const float* points, const float* t, const float* x0, const float* acts,
     const float* g_out, float* g_x0, void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
-  return skgs_deform_mlp_backward_adam(d, points, t, x0, acts, g_out, g_x0, workspace, workspace_bytes, nullptr, stream);
+  return backward_impl(d, nullptr, points, t, x0, acts, g_out, g_x0, workspace, workspace_bytes, nullptr, stream);
 }
 
 int skgs_deform_mlp_backward_adam(const skgs_mlp_desc* d, const float* points, const float* t, const float* x0,
     const float* acts, const float* g_out, float* g_x0, void* workspace, size_t workspace_bytes, const skgs_adam_range* side,
     skgs_stream_t stream) {
+  return backward_impl(d, nullptr, points, t, x0, acts, g_out, g_x0, workspace, workspace_bytes, side, stream);
+}
+
+int skgs_skeleton_backward(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, const float* points, const float* t,
+    const float* x0, const float* acts, float* g_x0, void* workspace, size_t workspace_bytes, const skgs_adam_range* side,
+    skgs_stream_t stream) {
+  SKGS_REQUIRE(bones, "skeleton_backward: NULL bone chain");
+  return backward_impl(d, bones, points, t, x0, acts, nullptr, g_x0, workspace, workspace_bytes, side, stream);
+}
+
+}  // extern "C"
+
+namespace skgs {
+namespace {
+int backward_impl(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, const float* points, const float* t,
+    const float* x0, const float* acts, const float* g_out, float* g_x0, void* workspace, size_t workspace_bytes,
+    const skgs_adam_range* side, skgs_stream_t stream) {
   Plan p;
   if (make_plan(d, &p)) return 1;
   SKGS_REQUIRE(points && (t || d->t_dim == 0) && acts && workspace, "deform_mlp_backward: NULL argument");
-  for (int j = 0; j < d->n_heads; ++j) SKGS_REQUIRE(d->head_gout[j], "deform_mlp_backward: head_gout[%d] is NULL", j);
+  for (int j = bones ? 1 : 0; j < d->n_heads; ++j)
+    SKGS_REQUIRE(d->head_gout[j], "deform_mlp_backward: head_gout[%d] is NULL", j);
   SKGS_REQUIRE(g_out || d->n_heads, "deform_mlp_backward: no incoming gradient");
   SKGS_REQUIRE(workspace_bytes >= HDR_BYTES + 2 * p.exch_bytes, "deform_mlp_backward: workspace too small");
   SKGS_REQUIRE((reinterpret_cast<uintptr_t>(acts) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0,
@@ -911,6 +996,14 @@ int skgs_deform_mlp_backward_adam(const skgs_mlp_desc* d, const float* points, c
   FusedArgs a{};
   fill_args(d, p, &a);
   a.points = points, a.t = t, a.x0 = const_cast<float*>(x0), a.acts = const_cast<float*>(acts), a.g_out = g_out, a.g_x0 = g_x0;
+  if (bones) {
+    if (fill_chain(d, p, bones, &a)) return 1;
+    SKGS_REQUIRE(bones->sk_r_raw && bones->chain_A && bones->g_bone_T, "skeleton_backward: sk_r_raw / chain_A / g_bone_T is NULL");
+    SKGS_REQUIRE(chain::backward_scratch_floats(bones->M, bones->num_levels) <= (size_t) NW * p.Bp * NC,
+        "skeleton_backward: %d tree levels do not fit the scratch", bones->num_levels);
+    a.chain.sk_r_raw = bones->sk_r_raw, a.chain.g_bone_T = bones->g_bone_T, a.chain.g_joints = bones->g_joints;
+    a.chain.g_global_T = bones->g_global_T, a.chain.g_sk_r_raw = const_cast<float*>(d->head_gout[0]);
+  }
   if (side && side->n_tensors > 0) {
     SKGS_REQUIRE(side->tensors && side->step_count && side->chunk_begin >= 0 && side->chunk_end >= side->chunk_begin,
         "deform_mlp_backward_adam: bad side range");
@@ -920,7 +1013,7 @@ int skgs_deform_mlp_backward_adam(const skgs_mlp_desc* d, const float* points, c
   }
   a.hdr  = reinterpret_cast<unsigned*>(workspace);
   a.exch = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + HDR_BYTES + p.exch_bytes);
-  size_t fl = (size_t) p.Bp * HP + (size_t) (d->n_layers + NW) * p.Bp * NC + 4;
+  size_t fl = (size_t) p.Bp * HP + (size_t) (d->n_layers + NW) * p.Bp * NC + (size_t) p.Bp * 4 + 4;
   for (int l = 1; l < d->n_layers; ++l) fl += (size_t) NC * (pad32(d->layer[l].out) + 4);
   if (g_x0)
     for (int l = 0; l < d->n_layers; ++l)
@@ -930,6 +1023,10 @@ int skgs_deform_mlp_backward_adam(const skgs_mlp_desc* d, const float* points, c
   SKGS_REQUIRE(lds <= 160 * 1024, "deform_mlp_backward: %zu bytes of LDS needed", lds);
   SKGS_MLP_DISPATCH(fused_mlp_backward_kernel)
 }
+}  // namespace
+}  // namespace skgs
+
+extern "C" {
 
 int skgs_deform_mlp_status(const void* workspace, uint32_t* host_words4, skgs_stream_t stream) {
   SKGS_REQUIRE(workspace && host_words4, "deform_mlp_status: NULL argument");

@@ -225,6 +225,15 @@ class _MlpDesc(C.Structure):
                 ('head_out', C.c_void_p * 4), ('head_gout', C.c_void_p * 4)]
 
 
+class BoneChainDesc(C.Structure):
+    """include/skgs.h::skgs_bone_chain_desc: the kinematic chain riding on the fused network launches"""
+    _fields_ = [('M', C.c_int32), ('root', C.c_int32), ('num_levels', C.c_int32),
+                ('parents', C.c_void_p), ('level_nodes', C.c_void_p), ('level_start', C.c_void_p),
+                ('joints', C.c_void_p), ('global_T', C.c_void_p), ('frame_index', C.c_void_p),
+                ('bone_T', C.c_void_p), ('chain_A', C.c_void_p), ('sk_r_raw', C.c_void_p), ('g_bone_T', C.c_void_p),
+                ('g_joints', C.c_void_p), ('g_global_T', C.c_void_p)]
+
+
 def fused_supported(mlp: 'DeformMLP', B: int) -> bool:
     """the one-launch kernels are built for the skeleton stage's shapes: <= 48 rows, hidden width 256, encoded input a
     multiple of 4 and <= 128 wide, <= 10 layers with the heads (skgs.h: skgs_deform_mlp_forward)"""
@@ -289,14 +298,23 @@ class FusedDeformMLP:
         return d
 
     def forward(self, points: Tensor, t: Tensor, head_out: Optional[Sequence[Tensor]] = None,
-                out: Optional[Tensor] = None) -> Tensor:
+                out: Optional[Tensor] = None, bones: Optional[BoneChainDesc] = None) -> Tensor:
         """points [B, p_in], t: device tensor with t_in floats -> ``out`` (default ``self.out``) [B, OUT], or the heads
-        written to the separate tensors ``head_out`` (also fills x0 / acts)"""
+        written to the separate tensors ``head_out`` (also fills x0 / acts).  ``bones`` (needs ``head_out``): the kinematic
+        chain runs in the same launch (``skgs_skeleton_forward``: rows = bones, head 0 = raw joint rotations) and fills
+        ``bones.bone_T`` / ``bones.chain_A``."""
         assert points.is_cuda and points.is_contiguous() and points.dtype == torch.float32 and points.shape[0] == self.B
         assert t.is_cuda and t.dtype == torch.float32 and t.numel() == self.mlp.t_in
         out = self.out if out is None else out
         assert out.is_cuda and out.is_contiguous() and out.shape == self.out.shape and out.dtype == torch.float32
         d = self._desc(None, head_out=head_out)
+        if bones is not None:
+            assert head_out is not None
+            _C._check(self.lib.skgs_skeleton_forward(
+                C.byref(d), C.byref(bones), C.c_void_p(points.data_ptr()), C.c_void_p(t.data_ptr()),
+                C.c_void_p(self.x0.data_ptr()), C.c_void_p(self.acts.data_ptr()), C.c_void_p(self.workspace.data_ptr()),
+                C.c_size_t(self.workspace.numel()), _C._stream()))
+            return out
         _C._check(self.lib.skgs_deform_mlp_forward(
             C.byref(d), C.c_void_p(points.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(self.x0.data_ptr()),
             C.c_void_p(self.acts.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(self.workspace.data_ptr()),
@@ -304,17 +322,27 @@ class FusedDeformMLP:
         return out
 
     def backward(self, points: Tensor, t: Tensor, g_out, grads: Sequence[Tensor], g_x0: Optional[Tensor] = None,
-                 reencode: bool = False, side_adam=None):
+                 reencode: bool = False, side_adam=None, bones: Optional[BoneChainDesc] = None):
         """``g_out``: [B, OUT] or one tensor per head; ``grads``: [gW0, gb0, ..., gW_heads, gb_heads] (written); ``g_x0``
         [B, IN] (written) or None.  The encoded input is the copy the last ``forward`` left in ``self.x0`` (same points and
         time!); ``reencode``: let the kernel rebuild it from ``points`` / ``t`` instead.  ``side_adam``
         (``optim.AdamRange``): an optimizer piece that runs on the CUs this launch leaves idle -- parameters whose
-        gradients are final and that the network does not touch."""
+        gradients are final and that the network does not touch.  ``bones`` (with ``g_out`` = the heads' gradient
+        tensors): the kinematic chain's backward runs inside the launch (``skgs_skeleton_backward``) -- the gradient of head
+        0 (raw joint rotations) is then an OUTPUT (``g_out[0]`` receives a copy), computed from ``bones.g_bone_T``."""
         if isinstance(g_out, Tensor):
             assert g_out.is_cuda and g_out.is_contiguous() and g_out.shape == self.out.shape
             d = self._desc(grads)
         else:
             d, g_out = self._desc(grads, head_gout=g_out), None
+        if bones is not None:
+            assert g_out is None, 'skeleton backward: pass the heads\' gradients as separate tensors'
+            _C._check(self.lib.skgs_skeleton_backward(
+                C.byref(d), C.byref(bones), C.c_void_p(points.data_ptr()), C.c_void_p(t.data_ptr()),
+                C.c_void_p(None if reencode else self.x0.data_ptr()), C.c_void_p(self.acts.data_ptr()),
+                C.c_void_p(None if g_x0 is None else g_x0.data_ptr()), C.c_void_p(self.workspace.data_ptr()),
+                C.c_size_t(self.workspace.numel()), None if side_adam is None else C.byref(side_adam), _C._stream()))
+            return
         _C._check(self.lib.skgs_deform_mlp_backward_adam(
             C.byref(d), C.c_void_p(points.data_ptr()), C.c_void_p(t.data_ptr()),
             C.c_void_p(None if reencode else self.x0.data_ptr()), C.c_void_p(self.acts.data_ptr()),

@@ -126,6 +126,7 @@ class FusedViewStep:
         self.max_radii2D = torch.zeros((P,), **f32)
         # bone-transform producer (scope row (f)-3): the MLP runs inside the step, its weight gradients are written in place
         self.deform_net = model.sk_deform_net
+        self._mlp_fused = None
         if self.deform_net is not None:
             from sk_gs_amd.deform_net import DeformMLPRunner, FusedDeformMLP, fused_supported
             net = self.deform_net.dynamic_net
@@ -242,14 +243,15 @@ class FusedViewStep:
         t = self._topo
         P, M, K = self.P, self.M, self.K
         assert (rs is None) == (time_id is None) and (rs is not None or self.view_table is not None)
-        sk_r_raw = self._joint_rotations(time_id)
+        sk_r_raw = self._joint_rotations(time_id)  # (fused network: the kinematic chain ran in the same launch)
         gT, _, fidx = self._frame(time_id)
         # (running the single-workgroup bone-chain kernels on a forked stream beside the wide kernels was measured:
         # the fork/join edges of the captured graph cost more (+12 us per step) than the ~10 us of overlap)
-        chk(lib.skgs_bone_chain_forward(
-            C.c_int32(M), C.c_int32(t['root']), _p(t['parents']), _p(t['level_nodes']), _p(t['level_start']),
-            C.c_int32(t['num_levels']), _p(sk_r_raw), _p(m.joints), C.c_void_p(gT), _p(self.bone_T),
-            _p(self.chain_A), fidx, st))
+        if self._mlp_fused is None:
+            chk(lib.skgs_bone_chain_forward(
+                C.c_int32(M), C.c_int32(t['root']), _p(t['parents']), _p(t['level_nodes']), _p(t['level_start']),
+                C.c_int32(t['num_levels']), _p(sk_r_raw), _p(m.joints), C.c_void_p(gT), _p(self.bone_T),
+                _p(self.chain_A), fidx, st))
         d = self._deform_inputs(time_id)
         if self.wide:  # many bones: search + softmax, then the skinning, as two launches (bone tables stay in global memory)
             chk(lib.skgs_knn_lbs_weights(C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_void_p(d.points), _p(m.joints),
@@ -362,11 +364,12 @@ class FusedViewStep:
                 _p(m._xyz.grad), _p(m._scaling.grad), _p(m._rotation.grad), _p(m._opacity.grad), _p(self.deform_ws),
                 C.c_size_t(self.deform_ws.numel()), st))
             self._lbs_logits_backward()
-        chk(lib.skgs_bone_chain_backward(
-            C.c_int32(M), C.c_int32(t['root']), _p(t['parents']), _p(t['level_nodes']), _p(t['level_start']),
-            C.c_int32(t['num_levels']), _p(sk_r_raw), _p(m.joints), C.c_void_p(gT), _p(self.chain_A),
-            _p(self.g_bone_T), _p(g_raw), _p(m.joints.grad) if getattr(m, 'learn_joints', False) else None, C.c_void_p(g_gT),
-            fidx, st))
+        if self._mlp_fused is None:  # (fused network: the chain's backward runs inside its backward launch)
+            chk(lib.skgs_bone_chain_backward(
+                C.c_int32(M), C.c_int32(t['root']), _p(t['parents']), _p(t['level_nodes']), _p(t['level_start']),
+                C.c_int32(t['num_levels']), _p(sk_r_raw), _p(m.joints), C.c_void_p(gT), _p(self.chain_A),
+                _p(self.g_bone_T), _p(g_raw), _p(m.joints.grad) if getattr(m, 'learn_joints', False) else None,
+                C.c_void_p(g_gT), fidx, st))
         if self.deform_net is not None:
             self._deform_net_backward()
         if self.densify_stats:
@@ -390,6 +393,22 @@ class FusedViewStep:
         from sk_gs_amd import view_slot as vsl
         return self.view_table.slot[vsl.W_TIME:vsl.W_TIME + 1]
 
+    def _bones_desc(self, time_id: Optional[int]):
+        """the kinematic chain as a rider of the fused network launches (include/skgs.h::skgs_bone_chain_desc)"""
+        from sk_gs_amd.deform_net import BoneChainDesc
+        m, t = self.model, self._topo
+        gT, g_gT, fidx = self._frame(time_id)
+        b = BoneChainDesc()
+        b.M, b.root, b.num_levels = self.M, t['root'], t['num_levels']
+        b.parents, b.level_nodes, b.level_start = t['parents'].data_ptr(), t['level_nodes'].data_ptr(), t['level_start'].data_ptr()
+        b.joints, b.global_T = m.joints.data_ptr(), gT
+        b.frame_index = fidx.value if isinstance(fidx, C.c_void_p) else fidx
+        b.bone_T, b.chain_A = self.bone_T.data_ptr(), self.chain_A.data_ptr()
+        b.sk_r_raw, b.g_bone_T = self._sk_r_raw.data_ptr(), self.g_bone_T.data_ptr()
+        b.g_joints = m.joints.grad.data_ptr() if getattr(m, 'learn_joints', False) else None
+        b.g_global_T = g_gT
+        return b
+
     def _joint_rotations(self, time_id: Optional[int]) -> Tensor:
         """raw joint rotations of the frame: a row of the per-frame table, or the producer network's first head (the
         network also fills d_rot / d_scale): 2 encode + 8 layer + 3 head launches (csrc/mlp.hip)"""
@@ -397,8 +416,9 @@ class FusedViewStep:
         if self.deform_net is None:
             return m.sk_r[time_id]
         tt = self._time_tensor(time_id)
-        if self._mlp_fused is not None:  # the whole network: one launch
-            self._mlp_fused.forward(m.joints, tt, head_out=(self._sk_r_raw, self._d_rot, self._d_scale))
+        if self._mlp_fused is not None:  # the whole skeleton stage -- network and kinematic chain -- in one launch
+            self._mlp_fused.forward(m.joints, tt, head_out=(self._sk_r_raw, self._d_rot, self._d_scale),
+                                    bones=self._bones_desc(time_id))
             return self._sk_r_raw
         from sk_gs_amd.deform_net import _lin_fwd
         net, run = self.deform_net.dynamic_net, self._mlp
@@ -423,7 +443,7 @@ class FusedViewStep:
             if self.side_optimizer is not None:  # the per-Gaussian rows' Adam update on the CUs this launch leaves idle
                 side = self.side_optimizer[0].side_range(self.side_optimizer[1])
             self._mlp_fused.backward(self.model.joints, self._time_tensor(self._time_id), self._g_heads, grads, self._g_x0,
-                                     side_adam=side)
+                                     side_adam=side, bones=self._bones_desc(self._time_id))
             if self._g_x0 is not None:  # joints.grad (written by the bone-chain backward) += the network-input path
                 self._mlp.input_grad(self._g_x0, self._mlp_fused.x0, self.model.joints.grad, accumulate=True)
             return

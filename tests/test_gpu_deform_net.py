@@ -257,3 +257,61 @@ def test_fused_deform_mlp_separate_heads():
     run.backward(joints, t, [h.contiguous() for h in g.split((4, 4, 3), dim=1)], grads)
     for a, r in zip(grads, ref_grads):
         assert torch.equal(a, r)
+
+
+def test_skeleton_stage_in_one_launch_per_direction():
+    """``skgs_skeleton_forward`` / ``skgs_skeleton_backward`` (network + kinematic chain in one launch) against the separate
+    calls ``skgs_deform_mlp_*`` + ``skgs_bone_chain_*``: same bone transforms bit for bit (the same chain code on the same
+    rotations); same gradients up to the order of the chain backward's LDS atomics"""
+    from sk_gs_amd import _C
+    from sk_gs_amd.deform_net import BoneChainDesc, FusedDeformMLP
+    from sk_gs_amd.model import SkinnedGaussians
+    torch.manual_seed(0)
+    M = 24
+    model = SkinnedGaussians(500, M, 4, sh_degree=0, num_frames=3, seed=5, deform_net=True, learn_joints=True).cuda()
+    mlp, topo = model.sk_deform_net, model.topology()
+    with torch.no_grad():
+        mlp.dynamic_net.last_weight.normal_(0, 0.3)
+        model.global_tr[1] = torch.tensor([0.1, -0.2, 0.05, 0.1, 0.2, -0.1, 0.9])
+    joints, t = model.joints.detach().contiguous(), torch.tensor([0.37], device='cuda')
+    gT = model.global_tr.detach()[1].contiguous()
+    f32 = dict(dtype=torch.float32, device='cuda')
+    net = mlp.dynamic_net
+    params = [p for l in net.net for p in (l.weight, l.bias)] + [net.last_weight, net.last_bias]
+
+    def heads():
+        return [torch.empty((M, 4), **f32), torch.empty((M, 4), **f32), torch.empty((M, 3), **f32)]
+    # ---- separate calls
+    run = FusedDeformMLP(mlp, M)
+    h1 = heads()
+    run.forward(joints, t, head_out=h1)
+    bone_T1, chain_A1 = _C.bone_chain_forward(h1[0], joints, gT, topo, save_chain=True)
+    g_bone_T = torch.randn(M, 7, **f32)
+    g_raw1, g_j1, g_g1 = _C.bone_chain_backward(h1[0], joints, gT, topo, chain_A1, g_bone_T, need_joints=True)
+    gh = [g_raw1.contiguous(), torch.randn(M, 4, **f32), torch.randn(M, 3, **f32)]
+    grads1, gx1 = [torch.zeros_like(p) for p in params], torch.zeros(M, net.in_channels, **f32)
+    run.backward(joints, t, gh, grads1, gx1)
+    # ---- one launch per direction
+    b = BoneChainDesc()
+    b.M, b.root, b.num_levels = M, topo['root'], topo['num_levels']
+    b.parents, b.level_nodes, b.level_start = (topo['parents'].data_ptr(), topo['level_nodes'].data_ptr(),
+                                                topo['level_start'].data_ptr())
+    bone_T2, chain_A2 = torch.zeros(M, 7, **f32), torch.zeros(M, 7, **f32)
+    g_j2, g_g2 = torch.zeros(M, 3, **f32), torch.zeros(7, **f32)
+    h2 = heads()
+    b.joints, b.global_T, b.bone_T, b.chain_A = joints.data_ptr(), gT.data_ptr(), bone_T2.data_ptr(), chain_A2.data_ptr()
+    run2 = FusedDeformMLP(mlp, M)
+    run2.forward(joints, t, head_out=h2, bones=b)
+    for x, y in zip(h1, h2):
+        assert torch.equal(x, y)
+    assert torch.equal(bone_T1, bone_T2) and torch.equal(chain_A1, chain_A2)
+    b.sk_r_raw, b.g_bone_T, b.g_joints, b.g_global_T = h2[0].data_ptr(), g_bone_T.data_ptr(), g_j2.data_ptr(), g_g2.data_ptr()
+    gh2 = [torch.full((M, 4), 9.0, **f32), gh[1], gh[2]]  # head 0's gradient is an output here
+    grads2, gx2 = [torch.zeros_like(p) for p in params], torch.zeros(M, net.in_channels, **f32)
+    run2.backward(joints, t, gh2, grads2, gx2, bones=b)
+    torch.cuda.synchronize()
+    assert run2.status()['failed'] == 0
+    assert rel_err(gh2[0], g_raw1) <= 1e-5 and rel_err(g_j2, g_j1) <= 1e-5 and rel_err(g_g2, g_g1) <= 1e-5
+    assert rel_err(gx2, gx1) <= 1e-5
+    for i, (x, y) in enumerate(zip(grads2, grads1)):
+        assert rel_err(x, y) <= 1e-5, i
