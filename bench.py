@@ -659,7 +659,8 @@ def main():
                        if args.deform_net and M > 0 else 'per-frame tables (test-time cache, sk_gs.py:1080-1085): NOT the '
                                                          'reference\'s training step',
                        'joints': 'trained, lr x 0.1 (sk_gs.py:607)' if model.learn_joints else 'fixed',
-                       'adam': ('per-Gaussian rows inside the deform network\'s backward launch (224 idle CUs), the rest after'
+                       'adam': ('per-Gaussian rows inside the skeleton stage\'s backward launch (its 224 idle CUs); network, joints, tables '
+                                '+ counter (+ the encoder backward of the joints) in one closing launch'
                                 if (not pipelined and fused_update) else 'one launch after the backward') if not pipelined
                        else 'one launch per bucket',
                        'step': 'autograd operator path' if args.autograd else 'FusedViewStep (direct C-ABI calls)',

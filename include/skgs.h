@@ -284,12 +284,15 @@ int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred,
  * networks/gaussian_splatting.py:443-453 (amsgrad off, no weight decay).  `tensors` is a DEVICE array of descriptors
  *   struct { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; int64_t n; int64_t chunk0; float lr;
  *            float pad; }   (skgs_adam_tensor_bytes() = 56)
- * with chunk0 = running sum of ceil(n / skgs_adam_chunk_elems()) and total_chunks the final sum.  step_count is a
- * device float holding the number of steps taken so far; the call increments it (hipGraph-capturable). */
+ * with chunk0 = running sum of ceil(n / skgs_adam_chunk_elems()) and total_chunks the final sum.  step_state is the
+ * optimizer's DEVICE state: skgs_adam_state_bytes() (256) bytes, 8-byte aligned, zero-initialised = no step taken.  Word
+ * 0 is the number of steps taken so far as a float; doubles at bytes 8 and 16 hold 1 - beta1^steps and 1 - beta2^steps
+ * (set them too when restoring a count: load_state_dict); the call advances all of it (hipGraph-capturable). */
 size_t skgs_adam_tensor_bytes(void);
+size_t skgs_adam_state_bytes(void);
 int64_t skgs_adam_chunk_elems(void);
 int skgs_adam_step(int32_t n_tensors, const void* tensors, int64_t total_chunks, double beta1, double beta2, double eps,
-    float* step_count, float* zero_after /* NULL, or zero_n floats cleared after the update (with the counter bump) */,
+    float* step_state, float* zero_after /* NULL, or zero_n floats cleared after the update (with the counter bump) */,
     int64_t zero_n, skgs_stream_t stream);
 /* The same step taken in pieces: chunks [chunk_begin, chunk_end) of the table (whole tensors) get the update of step
  * *step_count + 1; only a piece with advance = 1 moves the counter and clears zero_after, and it must be ordered after
@@ -297,7 +300,16 @@ int skgs_adam_step(int32_t n_tensors, const void* tensors, int64_t total_chunks,
  * tensors (the SH rows are final after the rasterizer backward, the Gaussian rows after the skinning backward: their
  * Adam runs beside the bone-chain / deform-network backward).  chunk_begin == chunk_end, advance = 1: counter only. */
 int skgs_adam_step_range(int32_t n_tensors, const void* tensors, int64_t chunk_begin, int64_t chunk_end, double beta1,
-    double beta2, double eps, float* step_count, int32_t advance, float* zero_after, int64_t zero_n, skgs_stream_t stream);
+    double beta2, double eps, float* step_state, int32_t advance, float* zero_after, int64_t zero_n, skgs_stream_t stream);
+/* The closing piece of a step (it advances the counter) whose range holds a tensor with an unfinished gradient: the
+ * workgroup that owns chunk freq_chunk (the single chunk of that small tensor: the joint positions) first runs
+ * skgs_freq_encode_backward(freq_B, freq_D, freq_degree, freq_grad_out, freq_out, freq_ld_out, freq_grad_x,
+ * freq_accumulate) itself -- the gradient is completed and consumed without a launch in between.  freq_grad_x = NULL:
+ * skgs_adam_step_range(..., advance = 1). */
+int skgs_adam_step_tail(int32_t n_tensors, const void* tensors, int64_t chunk_begin, int64_t chunk_end, double beta1,
+    double beta2, double eps, float* step_state, float* zero_after, int64_t zero_n, int64_t freq_chunk, int32_t freq_B,
+    int32_t freq_D, int32_t freq_degree, const float* freq_grad_out, const float* freq_out, int32_t freq_ld_out,
+    float* freq_grad_x, int32_t freq_accumulate, skgs_stream_t stream);
 
 /* ---- bone-transform producer of the skeleton stage (scope row (f)-3) ----
  * SimpleDeformationNetwork (networks/sk_gs.py:134-164): FreqEncoder (my_ext/_C/src/nerf/freqencoder.cu:7-60) +
@@ -372,7 +384,7 @@ typedef struct skgs_adam_range {
   const void* tensors;               /* device descriptor table, see skgs_adam_step */
   int64_t chunk_begin, chunk_end;
   double beta1, beta2, eps;
-  const float* step_count;           /* device float: steps taken so far (read, not advanced) */
+  const float* step_count;           /* the optimizer's device state (skgs_adam_state_bytes()): read, not advanced */
 } skgs_adam_range;
 int skgs_deform_mlp_backward_adam(const skgs_mlp_desc* d, const float* points, const float* t, const float* x0,
     const float* acts, const float* g_out, float* g_x0, void* workspace, size_t workspace_bytes, const skgs_adam_range* side,

@@ -18,25 +18,69 @@
 namespace skgs {
 namespace {
 
+// Optional first phase of ONE workgroup: the frequency-encoding backward (mlp.hip::freq_encode_backward_kernel,
+// freqencoder.cu:36-60) that completes the gradient of the tensor whose (single) chunk is `chunk` -- the joint positions,
+// whose gradient through the network input would otherwise need a launch of its own between backward and update.
+struct FreqJob {
+  int B, D, deg, ldo, accumulate;
+  const float* g;
+  const float* out;
+  float* gx;
+  int64_t chunk;  // the chunk whose workgroup runs the job first (-1: no job)
+};
+__device__ __forceinline__ void run_freq_job(const FreqJob& job) {
+  for (int t = threadIdx.x; t < job.B * job.D; t += ADAM_THREADS) {
+    const int b = t / job.D, d = t - b * job.D;
+    const float* gr = job.g + (size_t) b * job.ldo;
+    const float* o  = job.out + (size_t) b * job.ldo;
+    float r = gr[d];
+    for (int f = 0; f < job.deg; ++f) {
+      const int s = job.D + 2 * f * job.D;
+      r += scalbnf(1.0f, f) * (gr[s + d] * o[s + job.D + d] - gr[s + job.D + d] * o[s + d]);
+    }
+    job.gx[t] = job.accumulate ? job.gx[t] + r : r;
+  }
+  __syncthreads();  // (workgroup scope: the update below reads what this workgroup just wrote)
+}
+
+// advance = 1 (small grids only): the last workgroup out moves the counter and clears `zero_after` itself
 __global__ void __launch_bounds__(ADAM_THREADS) adam_step_kernel(int n_tensors, const AdamTensor* __restrict__ tensors,
-    int64_t chunk_begin, int64_t total_chunks, double beta1d, double beta2d, float eps,
-    const float* __restrict__ step_count) {
-  const AdamCoef k = adam_coefficients(beta1d, beta2d, eps, step_count);
+    int64_t chunk_begin, int64_t total_chunks, double beta1d, double beta2d, float eps, AdamState* __restrict__ state,
+    int advance, float* __restrict__ zero_after, int64_t zero_n, FreqJob job) {
   const int lane = threadIdx.x & 63;
+  // one round trip: state, first chunks and descriptors are independent loads
+  const AdamTensorLanes desc = adam_load_descriptors(tensors, n_tensors, lane);
   const int64_t first0 = lane < n_tensors ? tensors[lane].chunk0 : INT64_MAX;
+  const AdamCoef k = adam_coefficients(beta1d, beta2d, eps, state);
   for (int64_t chunk = chunk_begin + blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
-    const AdamTensor T = tensors[adam_owner(tensors, n_tensors, first0, lane, chunk)];
+    if (chunk == job.chunk) run_freq_job(job);
+    const int ti = adam_owner(tensors, n_tensors, first0, lane, chunk);
+    const AdamTensor T = ti < 64 ? adam_descriptor_of(desc, ti) : tensors[ti];
     adam_update_chunk(T, (chunk - T.chunk0) * ADAM_CHUNK, threadIdx.x, k);
+  }
+  if (advance) {
+    __shared__ unsigned s_last;
+    __syncthreads();  // every thread's reads of the state and of its gradients are done
+    if (threadIdx.x == 0) s_last = atomicAdd(&state->ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_last) {
+      for (int64_t i = threadIdx.x; i < zero_n; i += ADAM_THREADS) zero_after[i] = 0.f;
+      if (threadIdx.x == 0) {
+        adam_advance(state, beta1d, beta2d);
+        state->ticket = 0u;
+      }
+    }
   }
 }
 
-// (A last-workgroup-out ticket inside adam_step_kernel was tried instead of this launch: 4096 same-address atomics
-// next to the counter every workgroup reads cost 70 us.)
+// (For large grids a last-workgroup-out ticket was measured instead of this launch: 4096 same-address atomics next to
+// the counter every workgroup reads cost 70 us.)
 // ... and, in the same launch, clears `zero_after` (gradient storage that must read zero when the next backward starts:
 // the per-frame tables of which a step writes one row -- instead of a fill launch at the start of every step)
-__global__ void __launch_bounds__(256) adam_bump_kernel(float* step_count, float* __restrict__ zero_after, int64_t zero_n) {
+__global__ void __launch_bounds__(256) adam_bump_kernel(AdamState* state, double beta1d, double beta2d,
+    float* __restrict__ zero_after, int64_t zero_n) {
   const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) step_count[0] += 1.0f;
+  if (i == 0) adam_advance(state, beta1d, beta2d);
   if (i < zero_n) zero_after[i] = 0.f;
 }
 
@@ -49,40 +93,77 @@ extern "C" {
 
 size_t skgs_adam_tensor_bytes(void) { return sizeof(AdamTensor); }
 int64_t skgs_adam_chunk_elems(void) { return ADAM_CHUNK; }
+size_t skgs_adam_state_bytes(void) { return sizeof(AdamState); }
 
 /* tensors: DEVICE array of n_tensors descriptors {param, grad, exp_avg, exp_avg_sq, n, chunk0, lr} (56 B each, every
- * pointer 16-B aligned; chunk0 = running sum of ceil(n / skgs_adam_chunk_elems())). step_count: device float, the
- * number of steps taken so far; incremented by the call. */
+ * pointer 16-B aligned; chunk0 = running sum of ceil(n / skgs_adam_chunk_elems())). step_state: the optimizer's device
+ * state (skgs_adam_state_bytes(), zero-initialised; word 0 = the number of steps taken as a float); advanced by the call. */
 int skgs_adam_step(int32_t n_tensors, const void* tensors, int64_t total_chunks, double beta1, double beta2, double eps,
-    float* step_count, float* zero_after, int64_t zero_n, skgs_stream_t stream) {
+    float* step_state, float* zero_after, int64_t zero_n, skgs_stream_t stream) {
   if (n_tensors == 0 || total_chunks == 0) return 0;
-  return skgs_adam_step_range(n_tensors, tensors, 0, total_chunks, beta1, beta2, eps, step_count, 1, zero_after, zero_n,
+  return skgs_adam_step_range(n_tensors, tensors, 0, total_chunks, beta1, beta2, eps, step_state, 1, zero_after, zero_n,
       stream);
 }
 
-/* One step taken in pieces: the chunks [chunk_begin, chunk_end) of the table (whole tensors: the chunk0 of a tensor and of
- * the one after it) are updated with the bias correction of step *step_count + 1; the counter moves (and zero_after is
- * cleared) only where `advance` is set -- in the LAST piece, ordered after all the others.  Pieces of one step may run on
- * different streams, beside the backward kernels that do not touch their tensors.  chunk_begin == chunk_end with
- * advance = 1 only moves the counter. */
-int skgs_adam_step_range(int32_t n_tensors, const void* tensors, int64_t chunk_begin, int64_t chunk_end, double beta1,
-    double beta2, double eps, float* step_count, int32_t advance, float* zero_after, int64_t zero_n, skgs_stream_t stream) {
-  SKGS_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || tensors) && step_count, "adam_step: NULL argument");
+namespace {
+int step_range_impl(int32_t n_tensors, const void* tensors, int64_t chunk_begin, int64_t chunk_end, double beta1, double beta2,
+    double eps, float* step_state, int32_t advance, float* zero_after, int64_t zero_n, const FreqJob& job, skgs_stream_t stream) {
+  SKGS_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || tensors) && step_state, "adam_step: NULL argument");
   SKGS_REQUIRE(chunk_begin >= 0 && chunk_end >= chunk_begin, "adam_step: bad chunk range");
-  hipStream_t s = (hipStream_t) stream;
-  if (n_tensors > 0 && chunk_end > chunk_begin) {
-    const int grid = (int) std::min<int64_t>(chunk_end - chunk_begin, 256 * 16);
+  SKGS_REQUIRE((reinterpret_cast<uintptr_t>(step_state) & 7) == 0, "adam_step: the state must be 8-byte aligned");
+  hipStream_t s    = (hipStream_t) stream;
+  AdamState* state = reinterpret_cast<AdamState*>(step_state);
+  const int64_t zn = zero_after ? std::max<int64_t>(zero_n, 0) : 0;
+  const int64_t nc = n_tensors > 0 ? chunk_end - chunk_begin : 0;
+  const bool self_advance = advance && nc > 0 && nc <= 256 && zn <= 65536;
+  if (nc > 0) {
+    const int grid = (int) std::min<int64_t>(nc, 256 * 16);
     hipLaunchKernelGGL(adam_step_kernel, dim3(grid), dim3(ADAM_THREADS), 0, s, n_tensors,
-        reinterpret_cast<const AdamTensor*>(tensors), chunk_begin, chunk_end, beta1, beta2, (float) eps, step_count);
+        reinterpret_cast<const AdamTensor*>(tensors), chunk_begin, chunk_end, beta1, beta2, (float) eps, state,
+        self_advance ? 1 : 0, zero_after, zn, job);
     SKGS_CHECK_HIP(hipGetLastError());
   }
-  if (advance) {
-    const int64_t zn = zero_after ? std::max<int64_t>(zero_n, 0) : 0;
-    hipLaunchKernelGGL(adam_bump_kernel, dim3((unsigned) std::max<int64_t>(1, (zn + 255) / 256)), dim3(256), 0, s,
-        step_count, zero_after, zn);
+  if (advance && !self_advance) {
+    hipLaunchKernelGGL(adam_bump_kernel, dim3((unsigned) std::max<int64_t>(1, (zn + 255) / 256)), dim3(256), 0, s, state,
+        beta1, beta2, zero_after, zn);
     SKGS_CHECK_HIP(hipGetLastError());
   }
   return 0;
+}
+}  // namespace
+
+/* One step taken in pieces: the chunks [chunk_begin, chunk_end) of the table (whole tensors: the chunk0 of a tensor and of
+ * the one after it) are updated with the bias correction of step count + 1; the counter moves (and zero_after is
+ * cleared) only where `advance` is set -- in the LAST piece, ordered after all the others.  Pieces of one step may run on
+ * different streams, beside the backward kernels that do not touch their tensors.  chunk_begin == chunk_end with
+ * advance = 1 only moves the counter.  (A short advancing piece does so itself, last workgroup out; a long one is followed
+ * by a one-workgroup launch.) */
+int skgs_adam_step_range(int32_t n_tensors, const void* tensors, int64_t chunk_begin, int64_t chunk_end, double beta1,
+    double beta2, double eps, float* step_state, int32_t advance, float* zero_after, int64_t zero_n, skgs_stream_t stream) {
+  FreqJob job{};
+  job.chunk = -1;
+  return step_range_impl(n_tensors, tensors, chunk_begin, chunk_end, beta1, beta2, eps, step_state, advance, zero_after, zero_n,
+      job, stream);
+}
+
+/* The closing piece of a step (advance = 1) whose range holds a tensor with an unfinished gradient: the workgroup that
+ * owns chunk `freq_chunk` (the single chunk of that small tensor: the joint positions) first runs
+ * skgs_freq_encode_backward(freq_B, freq_D, freq_degree, freq_grad_out, freq_out, freq_ld_out, freq_grad_x,
+ * freq_accumulate) itself -- gradient completed and consumed without a launch in between. */
+int skgs_adam_step_tail(int32_t n_tensors, const void* tensors, int64_t chunk_begin, int64_t chunk_end, double beta1,
+    double beta2, double eps, float* step_state, float* zero_after, int64_t zero_n, int64_t freq_chunk, int32_t freq_B,
+    int32_t freq_D, int32_t freq_degree, const float* freq_grad_out, const float* freq_out, int32_t freq_ld_out,
+    float* freq_grad_x, int32_t freq_accumulate, skgs_stream_t stream) {
+  FreqJob job{};
+  job.chunk = -1;
+  if (freq_grad_x) {
+    SKGS_REQUIRE(freq_B >= 0 && freq_D >= 1 && freq_degree >= 0 && freq_grad_out && freq_out, "adam_step_tail: bad encoder job");
+    SKGS_REQUIRE(freq_chunk >= chunk_begin && freq_chunk < chunk_end, "adam_step_tail: the job's chunk is outside the range");
+    SKGS_REQUIRE((int64_t) freq_B * freq_D <= skgs_adam_chunk_elems(), "adam_step_tail: the job's tensor must be one chunk");
+    job = FreqJob{freq_B, freq_D, freq_degree, freq_ld_out, freq_accumulate, freq_grad_out, freq_out, freq_grad_x, freq_chunk};
+  }
+  return step_range_impl(n_tensors, tensors, chunk_begin, chunk_end, beta1, beta2, eps, step_state, 1, zero_after, zero_n, job,
+      stream);
 }
 
 }  // extern "C"

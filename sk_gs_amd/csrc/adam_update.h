@@ -22,14 +22,34 @@ static_assert(sizeof(AdamTensor) == 56, "layout shared with the host binding");
 constexpr int ADAM_THREADS = 256;
 constexpr int ADAM_CHUNK   = ADAM_THREADS * 4 * 4;  // elements per 256-thread group and iteration (4 float4 per lane)
 
+// The optimizer's device state (skgs_adam_state_bytes() = 256, zero-initialised = "no step taken"): the step count and
+// q_k = 1 - beta_k^count as doubles, advanced by recurrence (q' = (1 - beta) + beta q) -- a double pow() per launch was
+// 2-3 us in front of every update; and, in its own 128-byte line, the ticket of the launches that advance the count
+// themselves (last workgroup out).
+struct AdamState {
+  float count;       // steps taken so far
+  float pad0;
+  double q1, q2;     // 1 - beta1^count, 1 - beta2^count
+  float pad1[26];
+  unsigned ticket;   // word 32
+  unsigned pad2[31];
+};
+static_assert(sizeof(AdamState) == 256, "layout shared with the host binding");
+
 struct AdamCoef {
   float bc1, inv_sqrt_bc2, beta1, beta2, omb1, omb2, eps;
 };
-// hyper-parameters arrive as doubles and (1 - beta) is formed in double, as torch does: 1.0f - 0.999f is off by 1.3e-5
-__device__ __forceinline__ AdamCoef adam_coefficients(double beta1d, double beta2d, float eps, const float* step_count) {
-  const double t = (double) step_count[0] + 1.0;
-  return AdamCoef{(float) (1.0 - pow(beta1d, t)), (float) (1.0 / sqrt(1.0 - pow(beta2d, t))), (float) beta1d, (float) beta2d,
-      (float) (1.0 - beta1d), (float) (1.0 - beta2d), eps};
+// bias corrections of step count + 1.  Hyper-parameters arrive as doubles and (1 - beta) is formed in double, as torch
+// does: 1.0f - 0.999f is off by 1.3e-5
+__device__ __forceinline__ AdamCoef adam_coefficients(double beta1d, double beta2d, float eps, const AdamState* st) {
+  const double bc1 = (1.0 - beta1d) + beta1d * st->q1, bc2 = (1.0 - beta2d) + beta2d * st->q2;
+  return AdamCoef{(float) bc1, (float) (1.0 / sqrt(bc2)), (float) beta1d, (float) beta2d, (float) (1.0 - beta1d),
+      (float) (1.0 - beta2d), eps};
+}
+__device__ __forceinline__ void adam_advance(AdamState* st, double beta1d, double beta2d) {
+  st->count += 1.0f;
+  st->q1 = (1.0 - beta1d) + beta1d * st->q1;
+  st->q2 = (1.0 - beta2d) + beta2d * st->q2;
 }
 
 // which tensor owns a chunk: lane i keeps the first chunk of tensor i (loaded once by the caller into `first0`, INT64_MAX
@@ -41,6 +61,33 @@ __device__ __forceinline__ int adam_owner(const AdamTensor* __restrict__ tensors
   for (int base = 64; base < n_tensors; base += 64)  // (more than 64 tensors: rare)
     ti += __popcll(__ballot(base + lane < n_tensors && tensors[base + lane].chunk0 <= chunk));
   return __builtin_amdgcn_readfirstlane(ti);
+}
+
+// The descriptors of tensors 0..63, one per lane (13 dwords), loaded up front beside the state: the owner's descriptor is
+// then read out of the lanes (v_readlane with the wave-uniform owner) instead of by a second dependent global load.
+struct AdamTensorLanes {
+  uint32_t w[14];
+};
+__device__ __forceinline__ AdamTensorLanes adam_load_descriptors(const AdamTensor* __restrict__ tensors, int n_tensors, int lane) {
+  AdamTensorLanes d;
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(tensors + (lane < n_tensors ? lane : 0));
+#pragma unroll
+  for (int i = 0; i < 14; ++i) d.w[i] = p[i];
+  return d;
+}
+__device__ __forceinline__ AdamTensor adam_descriptor_of(const AdamTensorLanes& d, int ti) {
+  uint32_t w[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) w[i] = (uint32_t) __builtin_amdgcn_readlane((int) d.w[i], ti);
+  AdamTensor T;
+  __builtin_memcpy(&T, w, sizeof(T));
+  return T;
+}
+
+__device__ __forceinline__ void adam_update_element(float& p, float& m, float& v, float g, float step_size, const AdamCoef& k) {
+  m = k.beta1 * m + k.omb1 * g;
+  v = k.beta2 * v + k.omb2 * g * g;
+  p -= step_size * m / (sqrtf(v) * k.inv_sqrt_bc2 + k.eps);
 }
 
 // one chunk (ADAM_CHUNK elements from `base`) of tensor T, by 256 threads; t256 = this thread's index among them
@@ -56,23 +103,64 @@ __device__ __forceinline__ void adam_update_chunk(const AdamTensor& T, int64_t b
       float4 m = *reinterpret_cast<float4*>(T.exp_avg + i);
       float4 v = *reinterpret_cast<float4*>(T.exp_avg_sq + i);
       float4 p = *reinterpret_cast<float4*>(T.param + i);
-#define SKGS_ADAM1(c)                                           \
-  m.c = k.beta1 * m.c + k.omb1 * g.c;                           \
-  v.c = k.beta2 * v.c + k.omb2 * g.c * g.c;                     \
-  p.c -= step_size * m.c / (sqrtf(v.c) * k.inv_sqrt_bc2 + k.eps);
-      SKGS_ADAM1(x) SKGS_ADAM1(y) SKGS_ADAM1(z) SKGS_ADAM1(w)
-#undef SKGS_ADAM1
+      adam_update_element(p.x, m.x, v.x, g.x, step_size, k);
+      adam_update_element(p.y, m.y, v.y, g.y, step_size, k);
+      adam_update_element(p.z, m.z, v.z, g.z, step_size, k);
+      adam_update_element(p.w, m.w, v.w, g.w, step_size, k);
       *reinterpret_cast<float4*>(T.exp_avg + i)    = m;
       *reinterpret_cast<float4*>(T.exp_avg_sq + i) = v;
       *reinterpret_cast<float4*>(T.param + i)      = p;
     } else {
       for (int64_t e = i; e < T.n && e < i + 4; ++e) {
-        const float g = T.grad[e];
-        const float m = k.beta1 * T.exp_avg[e] + k.omb1 * g;
-        const float v = k.beta2 * T.exp_avg_sq[e] + k.omb2 * g * g;
-        T.exp_avg[e] = m, T.exp_avg_sq[e] = v;
-        T.param[e] -= step_size * m / (sqrtf(v) * k.inv_sqrt_bc2 + k.eps);
+        float p = T.param[e], m = T.exp_avg[e], v = T.exp_avg_sq[e];
+        adam_update_element(p, m, v, T.grad[e], step_size, k);
+        T.exp_avg[e] = m, T.exp_avg_sq[e] = v, T.param[e] = p;
       }
+    }
+  }
+}
+
+// two chunks at once (any two tensors): all 32 loads of a thread are issued before the first update
+__device__ __forceinline__ void adam_update_chunk2(const AdamTensor& A, int64_t baseA, const AdamTensor& Bt, int64_t baseB, int t256,
+    const AdamCoef& k) {
+  const bool al = ((reinterpret_cast<uintptr_t>(A.param) | reinterpret_cast<uintptr_t>(A.grad) | reinterpret_cast<uintptr_t>(A.exp_avg) |
+                    reinterpret_cast<uintptr_t>(A.exp_avg_sq) | reinterpret_cast<uintptr_t>(Bt.param) | reinterpret_cast<uintptr_t>(Bt.grad) |
+                    reinterpret_cast<uintptr_t>(Bt.exp_avg) | reinterpret_cast<uintptr_t>(Bt.exp_avg_sq)) & 15) == 0;
+  const bool full = baseA + ADAM_CHUNK <= A.n && baseB + ADAM_CHUNK <= Bt.n;
+  if (!(al && full)) {
+    adam_update_chunk(A, baseA, t256, k);
+    adam_update_chunk(Bt, baseB, t256, k);
+    return;
+  }
+  float4 g[2][4], m[2][4], v[2][4], p[2][4];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const AdamTensor& T = c ? Bt : A;
+    const int64_t base  = c ? baseB : baseA;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t i = base + ((int64_t) r * ADAM_THREADS + t256) * 4;
+      g[c][r] = *reinterpret_cast<const float4*>(T.grad + i);
+      m[c][r] = *reinterpret_cast<const float4*>(T.exp_avg + i);
+      v[c][r] = *reinterpret_cast<const float4*>(T.exp_avg_sq + i);
+      p[c][r] = *reinterpret_cast<const float4*>(T.param + i);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const AdamTensor& T = c ? Bt : A;
+    const int64_t base  = c ? baseB : baseA;
+    const float ss      = T.lr / k.bc1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t i = base + ((int64_t) r * ADAM_THREADS + t256) * 4;
+      adam_update_element(p[c][r].x, m[c][r].x, v[c][r].x, g[c][r].x, ss, k);
+      adam_update_element(p[c][r].y, m[c][r].y, v[c][r].y, g[c][r].y, ss, k);
+      adam_update_element(p[c][r].z, m[c][r].z, v[c][r].z, g[c][r].z, ss, k);
+      adam_update_element(p[c][r].w, m[c][r].w, v[c][r].w, g[c][r].w, ss, k);
+      *reinterpret_cast<float4*>(T.exp_avg + i)    = m[c][r];
+      *reinterpret_cast<float4*>(T.exp_avg_sq + i) = v[c][r];
+      *reinterpret_cast<float4*>(T.param + i)      = p[c][r];
     }
   }
 }

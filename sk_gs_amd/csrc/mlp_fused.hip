@@ -91,7 +91,7 @@ struct FusedArgs {
   long long adam_c0, adam_c1;
   double adam_beta1, adam_beta2;
   float adam_eps;
-  const float* adam_step;
+  const AdamState* adam_step;
   // the kinematic chain riding on the launches (skgs_skeleton_forward / _backward): forward -- workgroup 0, which owns
   // the raw joint rotations (head 0 = the last layer's columns 0..3), runs it after the heads; backward -- every workgroup
   // runs its backward in the prologue (the gradient of head 0 is the one input of the network's backward no other kernel
@@ -298,7 +298,7 @@ __device__ __forceinline__ void repoison(float* img_other, int nX, int G, int Bp
 
 // The backward launch needs 32 CUs for ~30 us and leaves 224 idle; the optimizer update of the per-Gaussian parameters (a
 // pure stream: 28 B per element, 40 us at 100k Gaussians on the whole chip) does not depend on it.  Workgroups G.. of the
-// SAME launch therefore walk the chunks of that update (two 256-thread halves per workgroup, one chunk each per
+// SAME launch therefore walk the chunks of that update (two 256-thread halves per workgroup, two chunks each per
 // iteration): a branch of a captured graph or a second stream would cost more in fork / join edges than it hides (DESIGN
 // section 7), workgroups of one launch cost nothing.  The network's workgroups have the lowest ids and are dispatched first,
 // so all of them are resident before the first side workgroup is placed; the LDS request of the launch keeps it at one
@@ -309,10 +309,20 @@ __device__ __forceinline__ void adam_side_job(const FusedArgs& a) {
   const int n_side = (int) gridDim.x - G_NET, wg = (int) blockIdx.x - G_NET;
   const int half = threadIdx.x >> 8, t256 = threadIdx.x & 255, lane = threadIdx.x & 63;
   const AdamCoef k = adam_coefficients(a.adam_beta1, a.adam_beta2, a.adam_eps, a.adam_step);
+  const AdamTensorLanes desc = adam_load_descriptors(a.adam_tensors, a.adam_n, lane);
   const int64_t first0 = lane < a.adam_n ? a.adam_tensors[lane].chunk0 : INT64_MAX;
-  for (int64_t chunk = a.adam_c0 + 2 * wg + half; chunk < a.adam_c1; chunk += 2 * n_side) {
-    const AdamTensor T = a.adam_tensors[adam_owner(a.adam_tensors, a.adam_n, first0, lane, chunk)];
-    adam_update_chunk(T, (chunk - T.chunk0) * ADAM_CHUNK, t256, k);
+  // two chunks per 256-thread half and iteration: with one workgroup per CU (the launch's LDS request) the bytes in
+  // flight per CU are what bounds the stream
+  for (int64_t chunk = a.adam_c0 + 4 * wg + 2 * half; chunk < a.adam_c1; chunk += 4 * n_side) {
+    const int ti0 = adam_owner(a.adam_tensors, a.adam_n, first0, lane, chunk);
+    const AdamTensor T0 = ti0 < 64 ? adam_descriptor_of(desc, ti0) : a.adam_tensors[ti0];
+    if (chunk + 1 < a.adam_c1) {
+      const int ti1 = adam_owner(a.adam_tensors, a.adam_n, first0, lane, chunk + 1);
+      const AdamTensor T1 = ti1 < 64 ? adam_descriptor_of(desc, ti1) : a.adam_tensors[ti1];
+      adam_update_chunk2(T0, (chunk - T0.chunk0) * ADAM_CHUNK, T1, (chunk + 1 - T1.chunk0) * ADAM_CHUNK, t256, k);
+    } else {
+      adam_update_chunk(T0, (chunk - T0.chunk0) * ADAM_CHUNK, t256, k);
+    }
   }
 }
 
@@ -868,7 +878,7 @@ int launch(KernelT k, const Plan& p, const FusedArgs& a, size_t lds, hipStream_t
   // side job: one workgroup per CU the network leaves idle (each takes two chunks per iteration)
   int side = 0;
   if (a.adam_tensors && a.adam_c1 > a.adam_c0)
-    side = (int) std::min<long long>((a.adam_c1 - a.adam_c0 + 1) / 2, NUM_CUS - p.G);
+    side = (int) std::min<long long>((a.adam_c1 - a.adam_c0 + 3) / 4, NUM_CUS - p.G);
   hipLaunchKernelGGL(k, dim3(p.G + side), dim3(NT), lds, s, a);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
@@ -1009,7 +1019,8 @@ int backward_impl(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, con
         "deform_mlp_backward_adam: bad side range");
     a.adam_tensors = reinterpret_cast<const AdamTensor*>(side->tensors), a.adam_n = side->n_tensors;
     a.adam_c0 = side->chunk_begin, a.adam_c1 = side->chunk_end;
-    a.adam_beta1 = side->beta1, a.adam_beta2 = side->beta2, a.adam_eps = (float) side->eps, a.adam_step = side->step_count;
+    a.adam_beta1 = side->beta1, a.adam_beta2 = side->beta2, a.adam_eps = (float) side->eps;
+    a.adam_step  = reinterpret_cast<const AdamState*>(side->step_count);
   }
   a.hdr  = reinterpret_cast<unsigned*>(workspace);
   a.exch = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + HDR_BYTES + p.exch_bytes);

@@ -117,6 +117,7 @@ class FusedViewStep:
         # (FusedAdam, group names) or None: that piece of the optimizer step runs inside the deform network's backward
         # launch (train_step.FusedTrainStep sets it; one rank, no gradient exchange between backward and update)
         self.side_optimizer = None
+        self.defer_input_grad = False
         # view-parallel training: [P*K] float32 view that receives the compact LBS-logit gradient (see backward_skinning)
         self.spw_logit_grad = spw_logit_grad
         assert spw_logit_grad is None or (spw_logit_grad.numel() == P * K and spw_logit_grad.is_contiguous())
@@ -393,6 +394,15 @@ class FusedViewStep:
         from sk_gs_amd import view_slot as vsl
         return self.view_table.slot[vsl.W_TIME:vsl.W_TIME + 1]
 
+    def input_grad_job(self):
+        """the frequency-encoding backward that adds the network-input path to ``joints.grad``, as the argument tuple of
+        ``FusedAdam.step_tail(freq_job=...)`` (None: joints are not trained)"""
+        if self._g_x0 is None or self._mlp_fused is None:
+            return None
+        mlp = self.deform_net
+        return (self.M, mlp.p_in, mlp.p_degree, self._g_x0, self._mlp_fused.x0, self._mlp_fused.x0.shape[1],
+                self.model.joints.grad, True)
+
     def _bones_desc(self, time_id: Optional[int]):
         """the kinematic chain as a rider of the fused network launches (include/skgs.h::skgs_bone_chain_desc)"""
         from sk_gs_amd.deform_net import BoneChainDesc
@@ -444,7 +454,9 @@ class FusedViewStep:
                 side = self.side_optimizer[0].side_range(self.side_optimizer[1])
             self._mlp_fused.backward(self.model.joints, self._time_tensor(self._time_id), self._g_heads, grads, self._g_x0,
                                      side_adam=side, bones=self._bones_desc(self._time_id))
-            if self._g_x0 is not None:  # joints.grad (written by the bone-chain backward) += the network-input path
+            # joints.grad (written by the bone-chain backward) += the network-input path; with ``defer_input_grad`` the
+            # optimizer's closing launch does it (``input_grad_job``)
+            if self._g_x0 is not None and not self.defer_input_grad:
                 self._mlp.input_grad(self._g_x0, self._mlp_fused.x0, self.model.joints.grad, accumulate=True)
             return
         from sk_gs_amd.deform_net import _lin_bwd

@@ -61,7 +61,11 @@ class FusedAdam:
                     self._lr_index.append(gi)
         dev = self.params[0].device
         self.state = {p: dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p)) for p in self.params}
-        self.step_count = torch.zeros(1, dtype=torch.float32, device=dev)
+        # the optimizer's device state (include/skgs.h::skgs_adam_step): word 0 = steps taken (float), doubles at bytes 8 /
+        # 16 = 1 - beta^steps, maintained by the kernels; all zeros = no step taken
+        lib.skgs_adam_state_bytes.restype = C.c_size_t
+        self.step_state = torch.zeros(int(lib.skgs_adam_state_bytes()) // 4, dtype=torch.float32, device=dev)
+        self.step_count = self.step_state[:1]  # (a view: ``float(opt.step_count)`` reads the count)
         self._table = torch.zeros(len(self.params) * 56, dtype=torch.uint8, device=dev)
         self._total_chunks = 0
         self._bound_grads = None
@@ -256,8 +260,15 @@ class FusedAdam:
                 steps.add(float(st['step']))
             assert len(steps) <= 1, f'load_state_dict: the parameters disagree on the step count {sorted(steps)} ' \
                                     '(the fused kernel keeps ONE counter)'
-            self.step_count.fill_(steps.pop() if steps else 0.0)
+            self._set_step_count(steps.pop() if steps else 0.0)
         self._upload()
+
+    def _set_step_count(self, count: float):
+        """restore a step count: the counter and the two bias-correction terms 1 - beta^count the kernels advance by
+        recurrence (doubles, as torch forms them)"""
+        blob = struct.pack('<ffdd', float(count), 0.0, 1.0 - self.betas[0] ** count, 1.0 - self.betas[1] ** count)
+        self.step_state.zero_()
+        self._h2d(self.step_state.view(torch.uint8), blob)
 
     def zero_grad(self, set_to_none: bool = False):
         for p in self.params:
@@ -298,18 +309,42 @@ class FusedAdam:
             _C._check(lib.skgs_adam_step_range(
                 C.c_int32(len(self.params)), C.c_void_p(self._table.data_ptr()), C.c_int64(c0), C.c_int64(c1),
                 C.c_double(self.betas[0]), C.c_double(self.betas[1]), C.c_double(self.eps),
-                C.c_void_p(self.step_count.data_ptr()), C.c_int32(1 if last else 0),
+                C.c_void_p(self.step_state.data_ptr()), C.c_int32(1 if last else 0),
                 C.c_void_p(z.data_ptr() if (z is not None and last) else None),
                 C.c_int64(z.numel() if (z is not None and last) else 0), _C._stream()))
 
     def side_range(self, groups) -> AdamRange:
         """the piece of a step that updates ``groups`` (neighbours in the table) as a ``skgs_adam_range``: handed to
-        ``skgs_deform_mlp_backward_adam`` it runs on the CUs that launch leaves idle -- same arithmetic as
-        ``step(groups, advance=False)``"""
+        ``skgs_deform_mlp_backward_adam`` / ``skgs_skeleton_backward`` it runs on the CUs that launch leaves idle -- same
+        arithmetic as ``step(groups, advance=False)``"""
         ranges = self._chunk_ranges(groups)
         assert len(ranges) == 1, f'groups {list(groups)} are not one run of neighbours in the table'
         return AdamRange(len(self.params), self._table.data_ptr(), ranges[0][0], ranges[0][1], self.betas[0], self.betas[1],
-                         self.eps, self.step_count.data_ptr())
+                         self.eps, self.step_state.data_ptr())
+
+    def step_tail(self, groups, freq_job=None, freq_param=None):
+        """the closing piece of a step: ``groups`` (neighbours in the table) are updated, the counter advances,
+        ``zero_after_step`` is cleared -- ``skgs_adam_step_tail``.  ``freq_job`` = (B, D, degree, grad_out, out, ld_out,
+        grad_x, accumulate) with device tensors: the frequency-encoding backward that completes ``freq_param``'s gradient
+        (the joints': their gradient through the network input) runs first, inside the workgroup that updates that
+        (one-chunk) tensor -- no launch between the backward and the update."""
+        lib = _C.load_library()
+        ranges = self._chunk_ranges(groups)
+        assert len(ranges) == 1, f'groups {list(groups)} are not one run of neighbours in the table'
+        z = self.zero_after_step
+        if freq_job is None:
+            chunk, fj = -1, (0, 1, 0, None, None, 0, None, 0)
+        else:
+            B, D, deg, g, out, ld, gx, acc = freq_job
+            i = next(k for k, q in enumerate(self.params) if q is freq_param)
+            assert self._chunk0[i + 1] - self._chunk0[i] == 1 and gx.data_ptr() == freq_param.grad.data_ptr()
+            chunk, fj = self._chunk0[i], (B, D, deg, g.data_ptr(), out.data_ptr(), ld, gx.data_ptr(), int(acc))
+        _C._check(lib.skgs_adam_step_tail(
+            C.c_int32(len(self.params)), C.c_void_p(self._table.data_ptr()), C.c_int64(ranges[0][0]), C.c_int64(ranges[0][1]),
+            C.c_double(self.betas[0]), C.c_double(self.betas[1]), C.c_double(self.eps), C.c_void_p(self.step_state.data_ptr()),
+            C.c_void_p(z.data_ptr() if z is not None else None), C.c_int64(z.numel() if z is not None else 0),
+            C.c_int64(chunk), C.c_int32(fj[0]), C.c_int32(fj[1]), C.c_int32(fj[2]), C.c_void_p(fj[3]), C.c_void_p(fj[4]),
+            C.c_int32(fj[5]), C.c_void_p(fj[6]), C.c_int32(fj[7]), _C._stream()))
 
     def advance_step(self):
         """close a step taken in pieces: the counter moves, ``zero_after_step`` is cleared"""
@@ -317,6 +352,6 @@ class FusedAdam:
         z = self.zero_after_step
         _C._check(lib.skgs_adam_step_range(C.c_int32(0), None, C.c_int64(0), C.c_int64(0), C.c_double(self.betas[0]),
                                            C.c_double(self.betas[1]), C.c_double(self.eps),
-                                           C.c_void_p(self.step_count.data_ptr()), C.c_int32(1),
+                                           C.c_void_p(self.step_state.data_ptr()), C.c_int32(1),
                                            C.c_void_p(z.data_ptr() if z is not None else None),
                                            C.c_int64(z.numel() if z is not None else 0), _C._stream()))

@@ -40,7 +40,7 @@ class OverflowGuard:
         ts = []
         for p in self.opt.params:
             ts += [p.data, self.opt.state[p]['exp_avg'], self.opt.state[p]['exp_avg_sq']]
-        ts.append(self.opt.step_count)
+        ts.append(self.opt.step_state)
         ts += [self.step.xyz_gradient_accum, self.step.denom, self.step.max_radii2D]
         return ts + self.extra
 

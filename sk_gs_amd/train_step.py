@@ -76,14 +76,21 @@ class GraphedSteps:
 
 
 class FusedTrainStep:
-    """One training step of one rank: ``FusedViewStep.forward_backward`` + ``FusedAdam.step`` with the update of the
-    per-Gaussian parameters (xyz, SH, opacity, scaling, rotation, LBS logits: 95 % of the optimizer's bytes) moved INTO the
-    deform network's backward launch.  That launch is a dependent chain on 32 workgroups (~30 us) that leaves 224 CUs idle;
-    the rows' gradients are final before it starts (the skinning backward wrote them) and it does not touch them, so
-    workgroups 32.. of the same launch stream the Adam update (``skgs_deform_mlp_backward_adam``).  The optimizer pieces
-    that DO depend on it (network, joints, per-frame tables) follow as a short launch that also advances the step counter.
-    Same arithmetic as ``step.forward_backward(); optimizer.step()`` (tests/test_gpu_optim.py: bit-identical update).
-    Falls back to exactly that when the step has no fused network."""
+    """One training step of one rank: ``FusedViewStep.forward_backward`` + ``FusedAdam.step`` with the optimizer taken
+    apart along the data dependencies of the skeleton stage's backward launch (``skgs_skeleton_backward``), a dependent chain
+    on 32 workgroups (~45 us with the kinematic chain) that leaves 224 CUs idle:
+
+      * the per-Gaussian parameters (xyz, SH, opacity, scaling, rotation, LBS logits: 95 % of the optimizer's bytes) have
+        final gradients before it starts and are not touched by it: workgroups 32.. of the SAME launch stream their update;
+      * network, joint positions and per-frame tables follow in one short launch that advances the step counter itself
+        (last workgroup out) and whose workgroup for the joints first completes their gradient (the frequency-encoding
+        backward of the network-input path) -- no launch between backward and update.
+
+    As separate launches (Adam, counter, encoder backward) the tail of the step was 50 + 38 + 4 + 5 us; it is 57 + 8.
+    (Updating the network's weights inside the backward launch as well, by the workgroups that own their rows, was built
+    and measured: the launch grows by 15 us, more than the short launch costs.)  Same arithmetic as
+    ``step.forward_backward(); optimizer.step()`` (tests/test_gpu_optim.py: bit-identical updates).  Falls back to exactly
+    that when the step has no fused network (or ``enable=False``)."""
 
     ROW_GROUPS = ('xyz', 'f_dc', 'f_rest', 'opacity', 'scaling', 'rotation', 'sp_W')
 
@@ -92,14 +99,18 @@ class FusedTrainStep:
         names = [g.get('name') for g in optimizer.param_groups]
         self.rows = [n for n in names if n in self.ROW_GROUPS]
         self.rest = [n for n in names if n not in self.ROW_GROUPS]
-        self.fused = bool(enable and self.rows and getattr(step, '_mlp_fused', None) is not None
+        self.fused = bool(enable and self.rows and self.rest and getattr(step, '_mlp_fused', None) is not None
                           and step.spw_logit_grad is None and step.sh_factors is None
-                          and len(optimizer._chunk_ranges(self.rows)) == 1)
+                          and len(optimizer._chunk_ranges(self.rows)) == 1 and len(optimizer._chunk_ranges(self.rest)) == 1)
         step.side_optimizer = (optimizer, self.rows) if self.fused else None
+        # the joints' gradient through the network input is completed by the optimizer's closing launch
+        self.joints = step.model.joints if (self.fused and step.input_grad_job() is not None) else None
+        step.defer_input_grad = self.joints is not None
 
     def __call__(self, rs=None, time_id=None, target=None):
         self.step.forward_backward(rs, time_id, target)
         if self.fused:
-            self.optimizer.step(self.rest, advance=True)
+            job = self.step.input_grad_job() if self.joints is not None else None
+            self.optimizer.step_tail(self.rest, freq_job=job, freq_param=self.joints)
         else:
             self.optimizer.step()

@@ -46,30 +46,37 @@ def init_distributed(backend: Optional[str] = None, force: bool = False) -> tupl
 
 
 class FlatGradBuffer:
-    """All gradients of ``params`` as views of one contiguous buffer."""
+    """All gradients of ``params`` as views of one contiguous buffer.  Every view starts on a 16-byte boundary (an 11-float
+    bias in the middle would otherwise leave every later tensor off the float4 grid: the Adam kernel then takes its scalar
+    path for them, 13 us instead of 4 for the deform network's weights); the padding words stay zero."""
+
+    ALIGN = 4  # floats
+
+    @classmethod
+    def _offsets(cls, params):
+        offs, off = [], 0
+        for p in params:
+            offs.append(off)
+            off += (p.numel() + cls.ALIGN - 1) // cls.ALIGN * cls.ALIGN
+        return offs, off
 
     def __init__(self, params: Iterable[Tensor]):
         self.params: List[Tensor] = [p for p in params if p.requires_grad]
-        total = sum(p.numel() for p in self.params)
+        self._offs, total = self._offsets(self.params)
         dev = self.params[0].device if self.params else 'cpu'
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
-            off += n
+        for p, off in zip(self.params, self._offs):
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
 
     def zero_(self):
         self.flat.zero_()
 
     def rebind(self):
         """re-attach the views (needed if something replaced p.grad, e.g. zero_grad(set_to_none=True))"""
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self._offs):
             n = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.flat[off:off + n].data_ptr():
                 p.grad = self.flat[off:off + n].view_as(p)
-            off += n
 
     @property
     def nbytes(self) -> int:
@@ -132,7 +139,8 @@ class BucketedGradReducer:
         self.rank = dist.get_rank() if self.active else 0
         extras = list(extras) if extras is not None else [0] * len(buckets)
         assert len(extras) == len(buckets)
-        sizes = [sum(p.numel() for p in b) + e for b, e in zip(buckets, extras)]
+        pad4 = lambda n: (n + 3) // 4 * 4  # noqa: E731  (every view on a 16-byte boundary, see FlatGradBuffer)
+        sizes = [sum(pad4(p.numel()) for p in b) + pad4(e) for b, e in zip(buckets, extras)]
         dev = buckets[0][0].device
         self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
         self.bucket_views: List[Tensor] = []
@@ -143,7 +151,7 @@ class BucketedGradReducer:
             o = off
             for p in b:
                 p.grad = self.flat[o:o + p.numel()].view_as(p)
-                o += p.numel()
+                o += pad4(p.numel())
             self.extra_views.append(self.flat[o:o + e] if e else None)
             off += n
 

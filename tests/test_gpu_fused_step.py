@@ -121,7 +121,8 @@ def test_split_step_with_compact_logit_gradient_matches_the_single_call():
           model.global_tr]
     red = BucketedGradReducer([b0, b1], extras=[0, P * K])
     red.flat.fill_(7.0)
-    assert red.nbytes == 4 * (sum(p.numel() for p in b0 + b1) + P * K) and model.sp_W.grad is None
+    pad4 = lambda n: (n + 3) // 4 * 4  # noqa: E731  (every view of the flat buffer starts on a 16-byte boundary)
+    assert red.nbytes == 4 * (sum(pad4(p.numel()) for p in b0 + b1) + P * K) and model.sp_W.grad is None
     step = FusedViewStep(model, W, H, capacity=int(R * 1.2) + 1024, spw_logit_grad=red.extra_views[1])
     model.sp_W.grad.fill_(7.0)
     step.backward_raster(rs, tid, target)

@@ -179,3 +179,61 @@ def test_adam_rows_as_the_side_job_of_the_network_backward_launch():
         assert torch.equal(p, q)
         assert torch.equal(ref.state[p]['exp_avg'], side.state[q]['exp_avg'])
         assert torch.equal(ref.state[p]['exp_avg_sq'], side.state[q]['exp_avg_sq'])
+
+
+def test_closing_piece_with_the_encoder_backward_in_the_joints_workgroup():
+    """the tail of a fused step: rows as the side job of the network's backward launch, then ``skgs_adam_step_tail`` over
+    tables + network + joints with the frequency-encoding backward run by the workgroup that updates the joints -- against
+    backward, ``skgs_freq_encode_backward`` and ONE ``FusedAdam.step`` as separate launches: bit-identical"""
+    import copy
+    from sk_gs_amd.deform_net import DeformMLP, DeformMLPRunner, FusedDeformMLP
+    from sk_gs_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    B = 20
+    mlps = [DeformMLP().cuda()]
+    with torch.no_grad():
+        mlps[0].dynamic_net.last_weight.normal_(0, 0.1)
+    mlps.append(copy.deepcopy(mlps[0]))
+    joints0 = torch.rand(B, 3, device='cuda') - 0.5
+    t, g = torch.tensor([0.3], device='cuda'), torch.randn(B, 11, device='cuda')
+    gen = torch.Generator().manual_seed(2)
+    rows0 = [torch.randn(20011, 3, generator=gen).cuda(), torch.randn(20011, 15, 3, generator=gen).cuda()]
+    tab0 = torch.randn(6, 7, generator=gen).cuda()
+    sides = []
+    for mlp in mlps:
+        net = mlp.dynamic_net
+        layers = [(l.weight, l.bias) for l in net.net] + [(net.last_weight, net.last_bias)]
+        rows = [torch.nn.Parameter(r.clone()) for r in rows0]
+        joints, tab = torch.nn.Parameter(joints0.clone()), torch.nn.Parameter(tab0.clone())
+        opt = FusedAdam([{'params': [rows[0]], 'lr': 1e-3, 'name': 'xyz'}, {'params': [rows[1]], 'lr': 2e-3, 'name': 'f_rest'},
+                         {'params': [tab], 'lr': 1e-3, 'name': 'skinning'},
+                         {'params': list(mlp.parameters()), 'lr': 1e-3, 'name': 'deform_net'},
+                         {'params': [joints], 'lr': 1e-4, 'name': 'joints'}])
+        opt.zero_after_step = tab.grad.view(-1)
+        sides.append(dict(mlp=mlp, layers=layers, rows=rows, joints=joints, tab=tab, opt=opt, run=FusedDeformMLP(mlp, B),
+                          gx=torch.zeros(B, net.in_channels, device='cuda')))
+    ref, fus = sides
+    for it in range(3):
+        gr = [torch.randn(r.shape, generator=gen).cuda() for r in rows0]
+        gt, gj = torch.randn(tab0.shape, generator=gen).cuda(), torch.randn(joints0.shape, generator=gen).cuda()
+        for sd in sides:
+            for p, x in zip(sd['rows'], gr):
+                p.grad.copy_(x)
+            sd['tab'].grad.copy_(gt), sd['joints'].grad.copy_(gj)
+            sd['run'].forward(sd['joints'].detach(), t)
+            sd['grads'] = [x.grad for l in sd['layers'] for x in l]
+        # separate launches
+        ref['run'].backward(ref['joints'].detach(), t, g, ref['grads'], ref['gx'])
+        DeformMLPRunner(ref['mlp']).input_grad(ref['gx'], ref['run'].x0, ref['joints'].grad, accumulate=True)
+        ref['opt'].step()
+        # rows inside the backward launch + the closing launch
+        o, m = fus['opt'], fus['mlp']
+        fus['run'].backward(fus['joints'].detach(), t, g, fus['grads'], fus['gx'], side_adam=o.side_range(['xyz', 'f_rest']))
+        o.step_tail(['skinning', 'deform_net', 'joints'], freq_param=fus['joints'],
+                    freq_job=(B, m.p_in, m.p_degree, fus['gx'], fus['run'].x0, fus['run'].x0.shape[1], fus['joints'].grad, True))
+        assert float(o.step_count.item()) == it + 1 and float(fus['tab'].grad.abs().sum()) == 0.0
+    assert fus['run'].status()['failed'] == 0
+    for a, b in zip(ref['opt'].params, fus['opt'].params):
+        assert torch.equal(a, b)
+        assert torch.equal(fus['opt'].state[b]['exp_avg'], ref['opt'].state[a]['exp_avg'])
+        assert torch.equal(fus['opt'].state[b]['exp_avg_sq'], ref['opt'].state[a]['exp_avg_sq'])

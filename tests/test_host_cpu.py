@@ -85,7 +85,9 @@ def test_topology_and_flat_grad_buffer():
     a, b = torch.nn.Parameter(torch.zeros(3, 2)), torch.nn.Parameter(torch.zeros(5))
     fb = FlatGradBuffer([a, b])
     (a.sum() * 2 + (b * torch.arange(5.)).sum()).backward()
-    assert fb.flat.tolist() == [2.] * 6 + [0., 1., 2., 3., 4.]
+    # every view starts on a 16-byte boundary: 6 floats + 2 of padding, 5 floats + 3 of padding
+    assert fb.flat.tolist() == [2.] * 6 + [0., 0.] + [0., 1., 2., 3., 4.] + [0., 0., 0.]
+    assert a.grad.data_ptr() % 16 == 0 and b.grad.data_ptr() % 16 == 0
     fb.zero_()
     assert a.grad.abs().sum() == 0 and a.grad.data_ptr() == fb.flat.data_ptr()
 
@@ -117,8 +119,9 @@ assert torch.allclose(rad, torch.tensor([2., 10., 4., 0., 6.]))
 from sk_gs_amd.view_parallel import BucketedGradReducer
 q1, q2, q3 = (torch.nn.Parameter(torch.ones(n)) for n in (5, 3, 4))
 red = BucketedGradReducer([[q1], [q2, q3]], extras=[0, 6])
-assert red.flat.numel() == 5 + 3 + 4 + 6 and red.extra_views[0] is None and red.extra_views[1].numel() == 6
-assert q1.grad.data_ptr() == red.flat.data_ptr() and red.bucket_views[1].numel() == 13
+# (every view on a 16-byte boundary: 5 -> 8, 3 -> 4, 4, 6 -> 8 floats)
+assert red.flat.numel() == 8 + 4 + 4 + 8 and red.extra_views[0] is None and red.extra_views[1].numel() == 6
+assert q1.grad.data_ptr() == red.flat.data_ptr() and red.bucket_views[1].numel() == 16
 q1.grad.fill_(rank + 1.0), q2.grad.fill_(10.0 * (rank + 1)), q3.grad.fill_(-1.0), red.extra_views[1].fill_(rank)
 w0 = red.allreduce(0)
 w1 = red.allreduce(1)
