@@ -39,7 +39,7 @@ def main():
     from sk_gs_amd.model import SkinnedGaussians
     from sk_gs_amd.optim import FusedAdam, position_lr
     from sk_gs_amd.overflow import OverflowGuard
-    from sk_gs_amd.train_step import GraphedSteps
+    from sk_gs_amd.train_step import FusedTrainStep, GraphedSteps
     from sk_gs_amd.view_slot import ViewTable
     from sk_gs_amd.view_parallel import BucketedGradReducer, ShFactorExchange, ViewParallel, init_distributed
 
@@ -72,7 +72,9 @@ def main():
             vp = ViewParallel(model.parameters())               # p.grad -> views of one flat buffer
             step = FusedViewStep(model, W, W, capacity=cap, background=bg, densify_stats=True, view_table=table)
             opt.rebind()                                          # the .grad tensors moved
-            g_all = GraphedSteps(lambda _: (step.forward_backward(), opt.step()), collect_garbage=False)
+            # forward + backward + Adam: the per-Gaussian rows' update rides on the skeleton stage's backward launch
+            train = FusedTrainStep(step, opt)
+            g_all = GraphedSteps(lambda _: train(), collect_garbage=False)
 
             def run(v):                                           # ONE graph: the view is a device record
                 table.select(v)

@@ -18,11 +18,11 @@ for sm in 2.5 4; do
 done
 SKGS_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_rccl_1rank.json
 python -c "import json; d=json.load(open('$out/bench_rccl_1rank.json')); print('1-rank RCCL group', d['value'], d['ms_per_step'], d['config']['parallelism'])"
-for v in "--bone-tables" "--layered-mlp" "--graph-per-view" "--autograd" "--compact-lists"; do
+for v in "--bone-tables" "--layered-mlp" "--graph-per-view" "--autograd" "--compact-lists" "--serial-adam" "--fixed-joints"; do
   python bench.py $v --no-cpu-baseline --no-ms-per-render 2>/dev/null | tail -1 > "$out/bench_variant${v}.json"
   python -c "import json; d=json.load(open('$out/bench_variant${v}.json')); print('variant $v', d['value'], d['ms_per_step'])"
 done
-python tools/time_mlp.py 2>/dev/null | grep "fused" > $out/time_mlp.txt; cat $out/time_mlp.txt
+python tools/time_mlp.py 2>/dev/null | grep "fused\|backward\|prologue" > $out/time_mlp.txt; cat $out/time_mlp.txt
 python tools/time_densify.py 2>/dev/null | tail -2 > $out/time_densify.txt; cat $out/time_densify.txt
 bash tools/profile_round.sh ${tag}_c1 > /dev/null 2>&1; ls gpurun_out/${tag}_c1 | head
 bash tools/profile_round.sh ${tag}_c4 --config 4 > /dev/null 2>&1; ls gpurun_out/${tag}_c4 | head
