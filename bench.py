@@ -297,8 +297,11 @@ def main():
             # n_contrib[H, W] heads the image buffer: per pixel, how far down its tile's list the blend walked
             walked.append(int(buf.imgBuffer[:W * H * 4].view(torch.int32).sum(dtype=torch.int64)))
     R_mean, R_max = sum(Rs) / len(Rs), max(Rs)
-    # fixed slots per tile for the bucket layout: 1.5x the longest list seen, rounded up to 64
+    # fixed slots per tile for the bucket layout: 1.5x the longest list seen, rounded up to 64 (overflow is counted on the
+    # device and asserted to be zero below; a training loop recovers with OverflowGuard)
     tile_bucket = 0 if args.compact_lists else ((int(longest * 1.5) + 63) // 64) * 64
+    if 512 < tile_bucket and longest * 1.2 <= 512:
+        tile_bucket = 512  # a bucket one wave sorts needs no merge-sort launch behind it (20 % head room instead of 50)
     _C.config.sync_num_rendered = False
     _C.update_capacity_hint(P, W, H, int(R_max * 1.25))
 

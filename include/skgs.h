@@ -90,6 +90,11 @@ typedef struct skgs_raster_inputs {
                               hipGraph serves every training view: the caller rewrites a small "view slot" before each
                               replay (sk_gs_amd/view_slot.py; the reference builds its settings per view on the host,
                               networks/gaussian_splatting.py:271-284, train.py:179-250). */
+  int32_t host_status_words;  /* stage 1: 0 / 1 -> host_num_rendered receives R (one int32, the reference's read-back); 3 ->
+                              it receives {R, overflow flag, longest tile list} (three int32, the head of skgs_status) */
+  int32_t longest_list_hint;  /* stage 2 / forward: 0 = unknown; > 0 = an upper bound of the longest tile list (what stage 1
+                              just reported): the sort launches for longer lists, which would find nothing to do, are
+                              skipped (~4.5 us each) */
 } skgs_raster_inputs;
 
 typedef struct skgs_raster_buffers {

@@ -40,6 +40,7 @@ class _RasterInputs(C.Structure):
         ('rotations', C.c_void_p), ('extras', C.c_void_p), ('colors_precomp', C.c_void_p),
         ('cov3D_precomp', C.c_void_p), ('sh_rest', C.c_void_p), ('background', C.c_void_p),
         ('tile_bucket_capacity', C.c_int32), ('tanfov_device', C.c_void_p),
+        ('host_status_words', C.c_int32), ('longest_list_hint', C.c_int32),
     ]
 
 
@@ -337,10 +338,12 @@ def rasterize_gaussians(image_height: int, image_width: int, tanfovx: float, tan
         if config.sync_num_rendered:
             host_r = _pinned_i32(dev)
             bufs = _buffers(geom, torch.empty((0,), dtype=torch.uint8, device=dev), img)
+            a.host_status_words = 3  # R, overflow flag, longest tile list: stage 2 skips the sort launches no list needs
             _check(lib.skgs_rasterize_forward_stage1(C.byref(a), C.byref(bufs), C.c_void_p(radii.data_ptr()),
                                                      C.c_void_p(host_r.data_ptr()), stream))
             torch.cuda.current_stream().synchronize()
             num_rendered = int(host_r[0])
+            a.longest_list_hint = max(int(host_r[2]), 1)
             binning = torch.empty((lib.skgs_binning_buffer_bytes(C.c_int64(num_rendered)),), dtype=torch.uint8,
                                   device=dev)
             bufs = _buffers(geom, binning, img)

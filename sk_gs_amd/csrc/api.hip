@@ -140,7 +140,8 @@ int skgs_rasterize_forward_stage1(const skgs_raster_inputs* in, const skgs_raste
   if (launch_preprocess_forward(*in, g, im, radii, s)) return 1;
   if (launch_scan_tiles(g, im, in->P, s)) return 1;
   if (host_num_rendered)
-    SKGS_CHECK_HIP(hipMemcpyAsync(host_num_rendered, &g.hdr->num_rendered, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    SKGS_CHECK_HIP(hipMemcpyAsync(host_num_rendered, &g.hdr->num_rendered,
+        sizeof(int32_t) * (in->host_status_words == 3 ? 3 : 1), hipMemcpyDeviceToHost, s));
   return 0;
 }
 

@@ -425,14 +425,16 @@ __device__ __forceinline__ void merge_round(const uint64_t* __restrict__ src, ui
   }
 }
 
-// CPW chunks of 512 keys per wave: lists of up to 2048 (CPW = 1, 32 KB of LDS) or 4096 keys (CPW = 2, 64 KB).
+// CPW chunks of 512 keys per wave: lists of up to 2048 (CPW = 1, 32 KB of LDS), 4096 (CPW = 2, 64 KB) or 8192 keys (CPW = 4,
+// 128 KB: one workgroup per CU).  Dynamic LDS: two images of NMAX keys.
 template <int CPW>
 __global__ void __launch_bounds__(SORT_THREADS) tile_sort_merge_kernel(const GeomHeader* __restrict__ hdr,
     const uint32_t* __restrict__ worklist, const uint32_t* __restrict__ tile_begin, const uint32_t* __restrict__ tile_end,
     uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list, int64_t capacity, int len_lo, int len_hi) {
   constexpr int E = 8, CH = 64 * E, NMAX = 4 * CPW * CH, OPT = NMAX / SORT_THREADS;  // OPT outputs per thread and round
-  __shared__ uint64_t s_a[NMAX];
-  __shared__ uint64_t s_b[NMAX];
+  extern __shared__ __attribute__((aligned(16))) uint64_t s_sort[];
+  uint64_t* s_a = s_sort;
+  uint64_t* s_b = s_sort + NMAX;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nbig = hdr->big_tiles;  // sparse scenes: 0
   for (int w = blockIdx.x; w < nbig; w += gridDim.x) {
@@ -463,17 +465,16 @@ __global__ void __launch_bounds__(SORT_THREADS) tile_sort_merge_kernel(const Geo
     }
     __syncthreads();
     // ---- phase 2: merge rounds, run length 512 -> NMAX / 2; the last one writes the list and the point list
-    if (CPW == 1) {
-      merge_round<OPT, false>(s_a, s_b, nullptr, nullptr, CH, L, tid);
+    uint64_t* src = s_a;
+    uint64_t* dst = s_b;
+#pragma unroll
+    for (int len = CH; len < NMAX / 2; len *= 2) {
+      merge_round<OPT, false>(src, dst, nullptr, nullptr, len, L, tid);
       __syncthreads();
-      merge_round<OPT, true>(s_b, nullptr, gk, pl, 2 * CH, L, tid);
-    } else {
-      merge_round<OPT, false>(s_a, s_b, nullptr, nullptr, CH, L, tid);
-      __syncthreads();
-      merge_round<OPT, false>(s_b, s_a, nullptr, nullptr, 2 * CH, L, tid);
-      __syncthreads();
-      merge_round<OPT, true>(s_a, nullptr, gk, pl, 4 * CH, L, tid);
+      uint64_t* t = src;
+      src = dst, dst = t;
     }
+    merge_round<OPT, true>(src, nullptr, gk, pl, NMAX / 2, L, tid);
     __syncthreads();
   }
 }
@@ -574,13 +575,25 @@ int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, Bi
         im.tile_end, im.worklist, g.hdr, b.keys, b.point_list, b.capacity);
     // lists longer than 512 keys: one workgroup per list drains the worklist (chunk sorts in registers + merge rounds in
     // LDS).  A bucket layout whose buckets hold no more than a wave sorts cannot produce one: no launch.  Lists of up to
-    // 2048 keys take the one-chunk-per-wave instantiation (32 KB of LDS), longer ones the two-chunk one (64 KB).
-    if (bucket == 0 || bucket > WSORT_WAVE_MAX)
-      hipLaunchKernelGGL(tile_sort_merge_kernel<1>, dim3(std::min(im.T, 2048)), dim3(SORT_THREADS), 0, s, g.hdr, im.worklist,
-          im.tile_begin, im.tile_end, b.keys, b.point_list, b.capacity, WSORT_WAVE_MAX, 2048);
-    if (bucket == 0 || bucket > 2048)
-      hipLaunchKernelGGL(tile_sort_merge_kernel<2>, dim3(std::min(im.T, 1024)), dim3(SORT_THREADS), 0, s, g.hdr, im.worklist,
-          im.tile_begin, im.tile_end, b.keys, b.point_list, b.capacity, 2048, 0x7fffffff);
+    // 2048 keys take the one-chunk-per-wave instantiation (32 KB of LDS), up to 4096 the two-chunk one (64 KB), up to 8192
+    // the four-chunk one (128 KB); beyond that the network on global memory inside the widest instantiation.
+    const int longest = in.longest_list_hint > 0 ? in.longest_list_hint : 0x7fffffff;  // (an upper bound, if the caller has one)
+    if ((bucket == 0 || bucket > WSORT_WAVE_MAX) && longest > WSORT_WAVE_MAX)
+      hipLaunchKernelGGL(tile_sort_merge_kernel<1>, dim3(std::min(im.T, 2048)), dim3(SORT_THREADS), 2 * 2048 * 8, s, g.hdr,
+          im.worklist, im.tile_begin, im.tile_end, b.keys, b.point_list, b.capacity, WSORT_WAVE_MAX, 2048);
+    if ((bucket == 0 || bucket > 2048) && longest > 2048)
+      hipLaunchKernelGGL(tile_sort_merge_kernel<2>, dim3(std::min(im.T, 1024)), dim3(SORT_THREADS), 2 * 4096 * 8, s, g.hdr,
+          im.worklist, im.tile_begin, im.tile_end, b.keys, b.point_list, b.capacity, 2048, 4096);
+    if ((bucket == 0 || bucket > 4096) && longest > 4096) {
+      static bool once = false;
+      if (!once) {
+        SKGS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_sort_merge_kernel<4>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8192 * 8));
+        once = true;
+      }
+      hipLaunchKernelGGL(tile_sort_merge_kernel<4>, dim3(std::min(im.T, 512)), dim3(SORT_THREADS), 2 * 8192 * 8, s, g.hdr,
+          im.worklist, im.tile_begin, im.tile_end, b.keys, b.point_list, b.capacity, 4096, 0x7fffffff);
+    }
   }
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;

@@ -228,17 +228,18 @@ def test_empty_and_culled(oracle32):
         assert float(t.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('P,W,H,scale_mult', [(6000, 64, 64, 6.0), (20000, 96, 96, 5.0)])
-def test_long_tile_lists_all_sort_paths(oracle32, P, W, H, scale_mult):
-    """tile lists of 1k..4.5k entries: the LDS bitonic (> 1024 keys) and the global-memory network (> 4096 keys)
-    behind the one-wave register sort; sorted lists and the strict image stay bit-exact"""
+@pytest.mark.parametrize('P,W,H,scale_mult,longest', [(6000, 64, 64, 6.0, 1024), (20000, 96, 96, 5.0, 4096),
+                                                      (48000, 64, 64, 6.0, 8192)])
+def test_long_tile_lists_all_sort_paths(oracle32, P, W, H, scale_mult, longest):
+    """tile lists of 1k..10k entries: the merge-path instantiations (<= 2048 / 4096 / 8192 keys in LDS) and the
+    global-memory network (> 8192 keys) behind the one-wave register sort; sorted lists and the strict image stay bit-exact"""
     _C().set_strict_math(True)
     oracle32.set_exp_mode(1)
     try:
         act, rs, cam = scene_inputs(P, W, H, seed=3, colmap=True, scale_mult=scale_mult, device='cuda')
         ref, fwd = check_forward(oracle32, act, rs, strict=True)
         r = ref['binning']['ranges'].astype(np.int64)
-        assert (r[:, 1] - r[:, 0]).max() > 1024
+        assert (r[:, 1] - r[:, 0]).max() > longest
     finally:
         _C().set_strict_math(False)
         oracle32.set_exp_mode(0)
