@@ -419,20 +419,18 @@ __global__ void __launch_bounds__(NT) fused_mlp_forward_kernel(const FusedArgs a
     }
   }
   for (int i = tid; i < Bp * HP / 4; i += NT) reinterpret_cast<float4*>(s_act)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  {
-    int woffs = 0;
-#pragma unroll
-    for (int l = 0; l < KL; ++l) {
-      if (l < nL) {
-        const bool in_x = get_layer(a, l).in_x != 0;
-        const int hp = l ? H : 0, WP = hp + (in_x ? XW : 0) + 4;
-        if (tid < NC) s_bias[l * NC + tid] = bv[l];
-        if (l > 0) *reinterpret_cast<float4*>(s_w + woffs + ch * WP + kh) = vh[l];
-        if (in_x && tid < NT / 2 && kx < XW) *reinterpret_cast<float4*>(s_w + woffs + cx * WP + hp + kx) = vx[l];
-        woffs += NC * WP;
-      }
-    }
-  }
+  // LDS stores of the weights: layer 0 now (its loads were issued first and return first); the other layers after layer
+  // 0 has been published, inside the wait for the first exchange -- the prologue ends when the FIRST loads are back, not
+  // the last (the compiler's vmcnt waits follow the issue order)
+  auto store_layer = [&](int l, int woffs) {
+    const bool in_x = get_layer(a, l).in_x != 0;
+    const int hp = l ? H : 0, WP = hp + (in_x ? XW : 0) + 4;
+    if (tid < NC) s_bias[l * NC + tid] = bv[l];
+    if (l > 0) *reinterpret_cast<float4*>(s_w + woffs + ch * WP + kh) = vh[l];
+    if (in_x && tid < NT / 2 && kx < XW) *reinterpret_cast<float4*>(s_w + woffs + cx * WP + hp + kx) = vx[l];
+    return NC * WP;
+  };
+  const int w_after0 = store_layer(0, 0);
   if (tid == 0) s_misc[0] = cnt, s_misc[1] = 0, s_misc[2] = stamps_on;
   __syncthreads();
   const unsigned count = s_misc[0];
@@ -483,6 +481,12 @@ __global__ void __launch_bounds__(NT) fused_mlp_forward_kernel(const FusedArgs a
       }
     }
     woff += NC * WP;
+    if (l == 0) {  // (made visible by the barrier behind the next gather)
+      int woffs = w_after0;
+#pragma unroll
+      for (int l2 = 1; l2 < KL; ++l2)
+        if (l2 < nL) woffs += store_layer(l2, woffs);
+    }
     stamp(a, s_misc, si);
   }
   if (a.has_chain && g == 0 && !s_misc[1]) {  // joint rotations -> bone transforms (bone_chain.inl), s_part as scratch
