@@ -443,6 +443,26 @@ size_t skgs_row_tensor_bytes(void);
 int skgs_gather_rows(int32_t n_tensors, const void* tensors, int64_t n_out, int64_t n_keep, const int64_t* rows,
     int32_t max_row_floats, skgs_stream_t stream);
 
+/* ---- the decisions of adaptive density control on the device (networks/gaussian_splatting.py:589-650) ----
+ * skgs_densify_select: clone / split masks (mean screen-space gradient accum / denom against max_grad, largest scale
+ * against scene_extent) and the row list of the ONE gather that realises clone + split: rows = [not split] ++ [clone] ++
+ * [split] x N; counts (DEVICE int32[3]) = the group sizes -- read them back to size the new tensors (n_keep = counts[0],
+ * n_out = counts[0] + counts[1] + N counts[2]).  rows: capacity (2 + N) P int64; flags_ws: skgs_select_workspace_bytes(P)
+ * bytes of scratch (16-byte aligned).
+ * skgs_prune_select: rows = the survivors of prune() (opacity below min_opacity; with max_radii2D != NULL also screen radius
+ * above max_screen_size or largest scale above world_size_limit), counts (DEVICE int32[1]) their number.
+ * skgs_split_children: the n gathered children of split Gaussians (copies of their parents), in place: position +=
+ * R(rot) (normals * scale), scale /= 0.8 N. */
+size_t skgs_select_workspace_bytes(int32_t P);
+int skgs_densify_select(int32_t P, const float* xyz_gradient_accum, const float* denom, const float* log_scale, float max_grad,
+    float scene_extent, int32_t N, int64_t* rows, int32_t* counts, uint8_t* flags_ws, skgs_stream_t stream);
+int skgs_prune_select(int32_t P, const float* opacity_logit, const float* max_radii2D, const float* log_scale,
+    float min_opacity, float max_screen_size, float world_size_limit, int64_t* rows, int32_t* counts, uint8_t* flags_ws,
+    skgs_stream_t stream);
+int skgs_split_children(int32_t n, int32_t N, const float* normals, float* xyz, float* log_scale, const float* rot,
+    skgs_stream_t stream);
+
+
 /* Tuning knob of the blend kernels: pixels handled per lane (1, 2 or 4); 0 = heuristic on the tile count. */
 void skgs_set_pixels_per_lane(int ppl);
 /* Parity-test switch: blend kernels without FMA contraction, in the oracle's operation order, reproducible exp. */

@@ -15,6 +15,9 @@ from typing import Dict, Optional
 import torch
 from torch import Tensor
 
+import ctypes as C
+
+from sk_gs_amd import _C
 from sk_gs_amd.optim import FusedAdam
 
 # module attribute -> optimizer group name (gaussian_splatting.py:89-96 + the per-Gaussian LBS logits)
@@ -128,26 +131,33 @@ def densify(model, opt: FusedAdam, stats, max_grad: float, extent: float, densif
         [originals not selected for splitting] + [clones] + [N samples of every split Gaussian]
     with the moments of the first group kept and the others zero: exactly one gather (same rows, same order, same random
     samples as the two calls)."""
-    grads = stats.xyz_gradient_accum / stats.denom
-    grads[grads.isnan()] = 0.0
-    scene_extent = densify_percent_dense * extent
-    scaling = torch.exp(model._scaling)
-    big = scaling.amax(dim=1) > scene_extent
-    hot_clone = torch.norm(grads, dim=-1) >= max_grad          # densify_and_clone's test (:624)
-    hot_split = grads.squeeze(-1) >= max_grad                  # densify_and_split's test on the padded gradients (:595)
-    clone_sel, split_sel = hot_clone & ~big, hot_split & big
-    stds = scaling[split_sel].repeat(N, 1)
-    samples = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=generator)
-    rots = quaternion_to_R(model._rotation[split_sel]).repeat(N, 1, 1)
-    new_xyz = _rotate(rots, samples) + model._xyz[split_sel].repeat(N, 1)
-    new_scaling = torch.log(scaling[split_sel].repeat(N, 1) / (0.8 * N))
-    keep_rows = torch.nonzero(~split_sel).squeeze(1)
-    rows = torch.cat([keep_rows, torch.nonzero(clone_sel).squeeze(1), torch.nonzero(split_sel).squeeze(1).repeat(N)])
-    n_new = new_xyz.shape[0]
-    _rebind(model, opt.gather_rows(list(_names(model).values()), rows, keep_rows.numel()))
-    if n_new:
-        model._xyz.data[-n_new:] = new_xyz
-        model._scaling.data[-n_new:] = new_scaling
+    if not model._xyz.is_cuda:
+        raise _C.SkgsError('densify needs the model on a HIP device')
+    # decisions and row list on the device (csrc/densify.hip): one flag launch, one compaction launch, ONE read-back of the
+    # three group sizes (the ~25 torch kernels and three boolean-index synchronisations of the torch formulation were
+    # most of a densification: 1.6 ms at 300k Gaussians, 0.4 now)
+    lib = _C.load_library()
+    P, dev = model._xyz.shape[0], model._xyz.device
+    rows = torch.empty(((2 + N) * P,), dtype=torch.int64, device=dev)
+    counts = torch.empty((3,), dtype=torch.int32, device=dev)
+    lib.skgs_select_workspace_bytes.restype = C.c_size_t
+    flags = torch.empty((int(lib.skgs_select_workspace_bytes(C.c_int32(P))),), dtype=torch.uint8, device=dev)
+    acc, den = stats.xyz_gradient_accum, stats.denom
+    assert acc.is_contiguous() and den.is_contiguous() and acc.numel() == P and model._scaling.is_contiguous()
+    _C._check(lib.skgs_densify_select(
+        C.c_int32(P), C.c_void_p(acc.data_ptr()), C.c_void_p(den.data_ptr()), C.c_void_p(model._scaling.data_ptr()),
+        C.c_float(max_grad), C.c_float(densify_percent_dense * extent), C.c_int32(N), C.c_void_p(rows.data_ptr()),
+        C.c_void_p(counts.data_ptr()), C.c_void_p(flags.data_ptr()), _C._stream()))
+    n_keep, n_clone, n_split = counts.tolist()  # (synchronises)
+    n_new = N * n_split
+    _rebind(model, opt.gather_rows(list(_names(model).values()), rows[:n_keep + n_clone + n_new], n_keep))
+    if n_new:  # the children are copies of their parents: sample position and shrink scale in place
+        gdev = generator.device if generator is not None else dev  # (a CPU generator draws on the host)
+        normals = torch.randn((n_new, 3), device=gdev, generator=generator).to(dev)
+        _C._check(lib.skgs_split_children(
+            C.c_int32(n_new), C.c_int32(N), C.c_void_p(normals.data_ptr()), C.c_void_p(model._xyz.data[-n_new:].data_ptr()),
+            C.c_void_p(model._scaling.data[-n_new:].data_ptr()), C.c_void_p(model._rotation.data[-n_new:].data_ptr()),
+            _C._stream()))
     _reset_stats(model, stats)
 
 
@@ -155,12 +165,26 @@ def densify(model, opt: FusedAdam, stats, max_grad: float, extent: float, densif
 def prune(model, opt: FusedAdam, stats, min_opacity: float, extent: float, max_screen_size: float,
           prune_percent_dense: float = 0.1):
     """drop transparent, screen-filling and world-size outliers (:643-650)"""
-    mask = (torch.sigmoid(model._opacity) < min_opacity).squeeze(-1)
-    if max_screen_size:
-        big_vs = stats.max_radii2D > max_screen_size
-        big_ws = torch.exp(model._scaling).amax(dim=1) > prune_percent_dense * extent
-        mask = mask | big_vs | big_ws
-    prune_points(model, opt, mask, stats)
+    lib = _C.load_library()
+    P, dev = model._xyz.shape[0], model._xyz.device
+    rows = torch.empty((P,), dtype=torch.int64, device=dev)
+    counts = torch.empty((1,), dtype=torch.int32, device=dev)
+    lib.skgs_select_workspace_bytes.restype = C.c_size_t
+    flags = torch.empty((int(lib.skgs_select_workspace_bytes(C.c_int32(P))),), dtype=torch.uint8, device=dev)
+    radii = stats.max_radii2D if max_screen_size else None
+    assert model._opacity.is_contiguous() and model._scaling.is_contiguous() and (radii is None or radii.is_contiguous())
+    _C._check(lib.skgs_prune_select(
+        C.c_int32(P), C.c_void_p(model._opacity.data_ptr()), C.c_void_p(None if radii is None else radii.data_ptr()),
+        C.c_void_p(model._scaling.data_ptr()), C.c_float(min_opacity), C.c_float(max_screen_size or 0.0),
+        C.c_float(prune_percent_dense * extent), C.c_void_p(rows.data_ptr()), C.c_void_p(counts.data_ptr()),
+        C.c_void_p(flags.data_ptr()), _C._stream()))
+    n_keep = int(counts.item())  # (synchronises)
+    rows = rows[:n_keep]
+    _rebind(model, opt.gather_rows(list(_names(model).values()), rows, n_keep))
+    if stats is not None:
+        stats.xyz_gradient_accum = stats.xyz_gradient_accum.index_select(0, rows)
+        stats.denom = stats.denom.index_select(0, rows)
+        stats.max_radii2D = stats.max_radii2D.index_select(0, rows)
 
 
 @torch.no_grad()
