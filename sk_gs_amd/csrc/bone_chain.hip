@@ -23,11 +23,13 @@ constexpr int CHAIN_THREADS = 256;
 // (the bodies live in bone_chain.inl: the deform network's launches run them too)
 __global__ void __launch_bounds__(CHAIN_THREADS) bone_chain_forward_kernel(const chain::ChainArgs c) {
   extern __shared__ float s_mem[];
-  chain::forward_body(s_mem, c);
+  const chain::Prefetch pf = chain::prefetch(c, true, false);  // every global load of the pass in one round trip
+  chain::forward_body(s_mem, c, pf);
 }
 __global__ void __launch_bounds__(CHAIN_THREADS) bone_chain_backward_kernel(const chain::ChainArgs c) {
   extern __shared__ float s_mem[];
-  chain::backward_body(s_mem, c, c.g_sk_r_raw, true);
+  const chain::Prefetch pf = chain::prefetch(c, true, true);
+  chain::backward_body(s_mem, c, c.g_sk_r_raw, true, pf);
 }
 
 }  // namespace

@@ -311,12 +311,17 @@ __device__ __forceinline__ void adam_side_job(const FusedArgs& a) {
   const AdamCoef k = adam_coefficients(a.adam_beta1, a.adam_beta2, a.adam_eps, a.adam_step);
   const AdamTensorLanes desc = adam_load_descriptors(a.adam_tensors, a.adam_n, lane);
   const int64_t first0 = lane < a.adam_n ? a.adam_tensors[lane].chunk0 : INT64_MAX;
-  // two chunks per 256-thread half and iteration: with one workgroup per CU (the launch's LDS request) the bytes in
-  // flight per CU are what bounds the stream
-  for (int64_t chunk = a.adam_c0 + 4 * wg + 2 * half; chunk < a.adam_c1; chunk += 4 * n_side) {
+  // Every workgroup gets an equal, contiguous share of the chunks (+-1): with a grid-stride loop of 4 chunks per
+  // workgroup and iteration, 1890 chunks over 224 workgroups were 2 iterations for some and 3 for others -- the launch
+  // ended with the stragglers (57 us; the network alone: 45).  Inside its share a 256-thread half takes two chunks at a time
+  // (all 32 loads of a thread in flight: with one workgroup per CU -- the launch's LDS request -- the bytes in flight per
+  // CU are what bounds the stream).
+  const int64_t n_chunks = a.adam_c1 - a.adam_c0;
+  const int64_t begin = a.adam_c0 + n_chunks * wg / n_side, end = a.adam_c0 + n_chunks * (wg + 1) / n_side;
+  for (int64_t chunk = begin + 2 * half; chunk < end; chunk += 4) {
     const int ti0 = adam_owner(a.adam_tensors, a.adam_n, first0, lane, chunk);
     const AdamTensor T0 = ti0 < 64 ? adam_descriptor_of(desc, ti0) : a.adam_tensors[ti0];
-    if (chunk + 1 < a.adam_c1) {
+    if (chunk + 1 < end) {
       const int ti1 = adam_owner(a.adam_tensors, a.adam_n, first0, lane, chunk + 1);
       const AdamTensor T1 = ti1 < 64 ? adam_descriptor_of(desc, ti1) : a.adam_tensors[ti1];
       adam_update_chunk2(T0, (chunk - T0.chunk0) * ADAM_CHUNK, T1, (chunk + 1 - T1.chunk0) * ADAM_CHUNK, t256, k);
@@ -363,6 +368,9 @@ __global__ void __launch_bounds__(NT) fused_mlp_forward_kernel(const FusedArgs a
     cnt       = __hip_atomic_load(h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     stamps_on = __hip_atomic_load(h + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  chain::Prefetch cpf;  // the kinematic chain's inputs (workgroup 0 runs it after the heads): loaded with everything else
+  cpf.valid = false;
+  if (a.has_chain && g == 0) cpf = chain::prefetch(a.chain, false, false);
   // encoded input entry (b, c): c = tid & 127 is the same for all of a thread's entries (INP = 128), so everything that
   // depends on the column -- which raw coordinate, which frequency, sine or cosine -- is computed once, without divisions
   // in the per-entry loop; b = tid / 128 + q NT / 128
@@ -493,7 +501,7 @@ __global__ void __launch_bounds__(NT) fused_mlp_forward_kernel(const FusedArgs a
     __syncthreads();
     chain::ChainArgs c = a.chain;
     c.sk_r_raw = s_raw;
-    chain::forward_body(s_part, c);
+    chain::forward_body(s_part, c, cpf);
   }
   // the optional copy of the encoded input leaves from the last workgroup, after its part of the chain
   if (a.x0 && g == G - 1)
@@ -548,6 +556,13 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
     const gu32* h = reinterpret_cast<const gu32*>((unsigned long long) a.hdr);
     cnt       = __hip_atomic_load(h + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     stamps_on = __hip_atomic_load(h + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (a.has_chain) {
+    // the chain backward's inputs first: one round trip into registers and from there into LDS, BEFORE the weight loads
+    // are issued (loads return in order: behind them this would wait for all of them; held in registers across them it
+    // spilled).  The tree walk itself runs below, on LDS only, while the weights are in flight.
+    const chain::Prefetch cpf = chain::prefetch(a.chain, true, true);
+    chain::backward_stage(s_part, a.chain, cpf);
   }
   // the ReLU masks of this workgroup's slab, one 16-byte unit per thread and layer (threads < 2 Bp)
   const int mrow = tid >> 1, mpart = tid & 1;
@@ -610,7 +625,7 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
     }
   }
   if (a.has_chain) {  // (the loads above stay in flight behind this)
-    chain::backward_body(s_part, a.chain, s_graw, g == 0);
+    chain::backward_levels(s_part, a.chain, s_graw, g == 0);
     __syncthreads();
   }
   {  // gZ of the last layer = the incoming gradient (zero-padded to 64 columns); this workgroup's slab of it
@@ -882,7 +897,7 @@ int launch(KernelT k, const Plan& p, const FusedArgs& a, size_t lds, hipStream_t
   // side job: one workgroup per CU the network leaves idle (each takes two chunks per iteration)
   int side = 0;
   if (a.adam_tensors && a.adam_c1 > a.adam_c0)
-    side = (int) std::min<long long>((a.adam_c1 - a.adam_c0 + 3) / 4, NUM_CUS - p.G);
+    side = (int) std::min<long long>((a.adam_c1 - a.adam_c0 + 1) / 2, NUM_CUS - p.G);
   hipLaunchKernelGGL(k, dim3(p.G + side), dim3(NT), lds, s, a);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
