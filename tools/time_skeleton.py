@@ -58,3 +58,34 @@ torch.cuda.synchronize()
 st = run.workspace[64:256].view(torch.int32).cpu().tolist()
 for i, name in zip(range(13, 16), ('chain (8 hops)', 'input gradient', 'weight gradients')):
     print(f'backward {name:>18}: +{((st[2 * i] - st[2 * i - 2]) & 0xffffffff) * 10} ns')
+
+# ---- the backward launch with the per-Gaussian rows' Adam update (221 MB) as its side job: launch time and the
+# network's phases while the stream runs beside it
+from sk_gs_amd.optim import FusedAdam
+rows = [torch.nn.Parameter(torch.randn(100_000, n, **f32)) for n in (3, 3, 45, 1, 3, 4, 20)]
+names = ['xyz', 'f_dc', 'f_rest', 'opacity', 'scaling', 'rotation', 'sp_W']
+opt = FusedAdam([{'params': [p], 'lr': 1e-5, 'name': n} for p, n in zip(rows, names)])
+side = opt.side_range(names)
+run.workspace[8:12].view(torch.int32).fill_(0)
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    run.backward(joints, t, gh, grads, gx, bones=b, side_adam=side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        for _ in range(20):
+            run.backward(joints, t, gh, grads, gx, bones=b, side_adam=side)
+    graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        graph.replay()
+    torch.cuda.synchronize()
+    print(f'with chain + side job (221 MB Adam), bwd: {(time.perf_counter() - t0) / 400 * 1e6:.1f} us  {run.status()}')
+run.workspace[8:12].view(torch.int32).fill_(1)
+for _ in range(3):
+    run.backward(joints, t, gh, grads, gx, bones=b, side_adam=side)
+torch.cuda.synchronize()
+st = run.workspace[64:256].view(torch.int32).cpu().tolist()
+for i, name in zip(range(13, 16), ('chain (8 hops)', 'input gradient', 'weight gradients')):
+    print(f'  with side job, backward {name:>18}: +{((st[2 * i] - st[2 * i - 2]) & 0xffffffff) * 10} ns')
