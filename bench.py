@@ -185,6 +185,9 @@ def main():
     ap.add_argument('--serial-adam', action='store_true',
                     help='one rank: the whole Adam update as its own launch after the backward, instead of the per-Gaussian '
                          'rows\' update running inside the deform network\'s backward launch (on the 224 CUs it leaves idle)')
+    ap.add_argument('--select-per-step', action='store_true',
+                    help='one rank: copy the view\'s record into the slot before every replay instead of letting the closing '
+                         'launch of the previous step do it')
     ap.add_argument('--fixed-joints', dest='learn_joints', action='store_false', default=True,
                     help='keep the joint positions constant; by default they are trained at 0.1 x lr as in stage sk '
                          '(networks/sk_gs.py:379,607): gradient through the kinematic chain and the network input')
@@ -316,7 +319,7 @@ def main():
         return () if view_table is not None else (v % frames,)
 
     def select(v):  # slot mode: one 256-byte device-to-device copy before the launches / the replay
-        if view_table is not None:
+        if view_table is not None and getattr(view_table, 'order', None) is None:  # (an ordered table advances by itself)
             view_table.select(v)
 
     def gkey(v):  # graphs are keyed by view only when the view is baked into them
@@ -425,6 +428,10 @@ def main():
             from sk_gs_amd.train_step import FusedTrainStep
             train1 = FusedTrainStep(fstep, opt)
             fused_update = train1.fused
+            if fused_update and view_table is not None and not args.select_per_step:
+                # the closing launch of a step selects the next view: the views are walked in the loop's order without a
+                # device-to-device copy in front of every replay
+                view_table.set_order([vp.view_index(i, args.views) for i in range(args.views)])
 
         def eager_step(i):
             v = vp.view_index(i, args.views)
@@ -519,6 +526,9 @@ def main():
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    ordered_views = view_table is not None and getattr(view_table, 'order', None) is not None
+    if ordered_views:
+        view_table.clear_order()  # the measurements below select their views explicitly
     prof = _C.profile_collect()
     _C.profile_enable([])
     if use_dist:
@@ -655,6 +665,8 @@ def main():
                        'launch': 'eager' if args.eager else (
                            f'ONE captured hipGraph for all {args.views} views (camera, time and target read from a device view slot)'
                            if view_table is not None else f'one captured hipGraph per view ({args.views})'),
+                       'view_select': ('by the closing launch of the previous step (ordered view table)' if ordered_views else
+                                       'one 256-byte device-to-device copy per step') if view_table is not None else 'baked into the graphs',
                        'tile_lists': 'compact (count, scan, scatter)' if (args.autograd or args.compact_lists)
                        else f'buckets of {tile_bucket} slots per tile (longest list {longest})',
                        'joint_rotations': ('deform network (freq-encode + 8x256 MLP + heads) inside the step, '

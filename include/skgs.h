@@ -310,11 +310,22 @@ int skgs_adam_step_range(int32_t n_tensors, const void* tensors, int64_t chunk_b
  * workgroup that owns chunk freq_chunk (the single chunk of that small tensor: the joint positions) first runs
  * skgs_freq_encode_backward(freq_B, freq_D, freq_degree, freq_grad_out, freq_out, freq_ld_out, freq_grad_x,
  * freq_accumulate) itself -- the gradient is completed and consumed without a launch in between.  freq_grad_x = NULL:
- * skgs_adam_step_range(..., advance = 1). */
+ * skgs_adam_step_range(..., advance = 1).
+ * next_view (may be NULL): the last act of the launch puts the NEXT training view's record into the live view slot the
+ * kernels read their camera / time / target index from (skgs_raster_inputs.tanfov_device, frame_index, gt_index):
+ * slot[0..words) = table[order[*cursor % n_order]], *cursor += 1 -- a loop that walks its views in a known order then needs
+ * no copy between two replays of its captured step. */
+typedef struct skgs_view_advance {
+  const void* table;       /* DEVICE [views][words] 32-bit words */
+  const int32_t* order;    /* DEVICE [n_order] view indices */
+  int32_t* cursor;         /* DEVICE counter */
+  void* slot;              /* DEVICE [words] */
+  int32_t n_order, words;
+} skgs_view_advance;
 int skgs_adam_step_tail(int32_t n_tensors, const void* tensors, int64_t chunk_begin, int64_t chunk_end, double beta1,
     double beta2, double eps, float* step_state, float* zero_after, int64_t zero_n, int64_t freq_chunk, int32_t freq_B,
     int32_t freq_D, int32_t freq_degree, const float* freq_grad_out, const float* freq_out, int32_t freq_ld_out,
-    float* freq_grad_x, int32_t freq_accumulate, skgs_stream_t stream);
+    float* freq_grad_x, int32_t freq_accumulate, const skgs_view_advance* next_view, skgs_stream_t stream);
 
 /* ---- bone-transform producer of the skeleton stage (scope row (f)-3) ----
  * SimpleDeformationNetwork (networks/sk_gs.py:134-164): FreqEncoder (my_ext/_C/src/nerf/freqencoder.cu:7-60) +

@@ -43,10 +43,20 @@ __device__ __forceinline__ void run_freq_job(const FreqJob& job) {
   __syncthreads();  // (workgroup scope: the update below reads what this workgroup just wrote)
 }
 
+// Optional last act of the launch that closes a step: the NEXT view's record into the live view slot (sk_gs_amd/
+// view_slot.py) -- slot[0..words) = table[order[cursor % n]], cursor += 1 -- so that a training loop that walks its views in
+// a known order needs no copy between two replays of its graph (4.5 us per step as a device-to-device copy).
+struct ViewAdvance {
+  const uint32_t* table;  // [views][words]
+  const int32_t* order;   // [n]
+  int32_t* cursor;        // device counter
+  uint32_t* slot;
+  int n, words;
+};
 // advance = 1 (small grids only): the last workgroup out moves the counter and clears `zero_after` itself
 __global__ void __launch_bounds__(ADAM_THREADS) adam_step_kernel(int n_tensors, const AdamTensor* __restrict__ tensors,
     int64_t chunk_begin, int64_t total_chunks, double beta1d, double beta2d, float eps, AdamState* __restrict__ state,
-    int advance, float* __restrict__ zero_after, int64_t zero_n, FreqJob job) {
+    int advance, float* __restrict__ zero_after, int64_t zero_n, FreqJob job, ViewAdvance va) {
   const int lane = threadIdx.x & 63;
   // one round trip: state, first chunks and descriptors are independent loads
   const AdamTensorLanes desc = adam_load_descriptors(tensors, n_tensors, lane);
@@ -65,6 +75,13 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_step_kernel(int n_tensors, 
     __syncthreads();
     if (s_last) {
       for (int64_t i = threadIdx.x; i < zero_n; i += ADAM_THREADS) zero_after[i] = 0.f;
+      if (va.slot) {
+        const int c = va.cursor[0];
+        const uint32_t* rec = va.table + (size_t) va.order[c % va.n] * va.words;
+        for (int i = threadIdx.x; i < va.words; i += ADAM_THREADS) va.slot[i] = rec[i];
+        __syncthreads();  // every thread has read the cursor
+        if (threadIdx.x == 0) va.cursor[0] = c + 1;
+      }
       if (threadIdx.x == 0) {
         adam_advance(state, beta1d, beta2d);
         state->ticket = 0u;
@@ -107,7 +124,8 @@ int skgs_adam_step(int32_t n_tensors, const void* tensors, int64_t total_chunks,
 
 namespace {
 int step_range_impl(int32_t n_tensors, const void* tensors, int64_t chunk_begin, int64_t chunk_end, double beta1, double beta2,
-    double eps, float* step_state, int32_t advance, float* zero_after, int64_t zero_n, const FreqJob& job, skgs_stream_t stream) {
+    double eps, float* step_state, int32_t advance, float* zero_after, int64_t zero_n, const FreqJob& job,
+    const ViewAdvance& va, skgs_stream_t stream) {
   SKGS_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || tensors) && step_state, "adam_step: NULL argument");
   SKGS_REQUIRE(chunk_begin >= 0 && chunk_end >= chunk_begin, "adam_step: bad chunk range");
   SKGS_REQUIRE((reinterpret_cast<uintptr_t>(step_state) & 7) == 0, "adam_step: the state must be 8-byte aligned");
@@ -116,11 +134,12 @@ int step_range_impl(int32_t n_tensors, const void* tensors, int64_t chunk_begin,
   const int64_t zn = zero_after ? std::max<int64_t>(zero_n, 0) : 0;
   const int64_t nc = n_tensors > 0 ? chunk_end - chunk_begin : 0;
   const bool self_advance = advance && nc > 0 && nc <= 256 && zn <= 65536;
+  SKGS_REQUIRE(!va.slot || self_advance, "adam_step_tail: the view advance rides on a short closing piece (<= 256 chunks)");
   if (nc > 0) {
     const int grid = (int) std::min<int64_t>(nc, 256 * 16);
     hipLaunchKernelGGL(adam_step_kernel, dim3(grid), dim3(ADAM_THREADS), 0, s, n_tensors,
         reinterpret_cast<const AdamTensor*>(tensors), chunk_begin, chunk_end, beta1, beta2, (float) eps, state,
-        self_advance ? 1 : 0, zero_after, zn, job);
+        self_advance ? 1 : 0, zero_after, zn, job, va);
     SKGS_CHECK_HIP(hipGetLastError());
   }
   if (advance && !self_advance) {
@@ -143,7 +162,7 @@ int skgs_adam_step_range(int32_t n_tensors, const void* tensors, int64_t chunk_b
   FreqJob job{};
   job.chunk = -1;
   return step_range_impl(n_tensors, tensors, chunk_begin, chunk_end, beta1, beta2, eps, step_state, advance, zero_after, zero_n,
-      job, stream);
+      job, ViewAdvance{}, stream);
 }
 
 /* The closing piece of a step (advance = 1) whose range holds a tensor with an unfinished gradient: the workgroup that
@@ -153,9 +172,16 @@ int skgs_adam_step_range(int32_t n_tensors, const void* tensors, int64_t chunk_b
 int skgs_adam_step_tail(int32_t n_tensors, const void* tensors, int64_t chunk_begin, int64_t chunk_end, double beta1,
     double beta2, double eps, float* step_state, float* zero_after, int64_t zero_n, int64_t freq_chunk, int32_t freq_B,
     int32_t freq_D, int32_t freq_degree, const float* freq_grad_out, const float* freq_out, int32_t freq_ld_out,
-    float* freq_grad_x, int32_t freq_accumulate, skgs_stream_t stream) {
+    float* freq_grad_x, int32_t freq_accumulate, const skgs_view_advance* next_view, skgs_stream_t stream) {
   FreqJob job{};
   job.chunk = -1;
+  ViewAdvance va{};
+  if (next_view && next_view->slot) {
+    SKGS_REQUIRE(next_view->table && next_view->order && next_view->cursor && next_view->n_order >= 1 && next_view->words >= 1,
+        "adam_step_tail: bad view advance");
+    va = ViewAdvance{reinterpret_cast<const uint32_t*>(next_view->table), next_view->order, next_view->cursor,
+        reinterpret_cast<uint32_t*>(next_view->slot), next_view->n_order, next_view->words};
+  }
   if (freq_grad_x) {
     SKGS_REQUIRE(freq_B >= 0 && freq_D >= 1 && freq_degree >= 0 && freq_grad_out && freq_out, "adam_step_tail: bad encoder job");
     SKGS_REQUIRE(freq_chunk >= chunk_begin && freq_chunk < chunk_end, "adam_step_tail: the job's chunk is outside the range");
@@ -163,7 +189,7 @@ int skgs_adam_step_tail(int32_t n_tensors, const void* tensors, int64_t chunk_be
     job = FreqJob{freq_B, freq_D, freq_degree, freq_ld_out, freq_accumulate, freq_grad_out, freq_out, freq_grad_x, freq_chunk};
   }
   return step_range_impl(n_tensors, tensors, chunk_begin, chunk_end, beta1, beta2, eps, step_state, 1, zero_after, zero_n, job,
-      stream);
+      va, stream);
 }
 
 }  // extern "C"

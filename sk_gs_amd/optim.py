@@ -322,12 +322,13 @@ class FusedAdam:
         return AdamRange(len(self.params), self._table.data_ptr(), ranges[0][0], ranges[0][1], self.betas[0], self.betas[1],
                          self.eps, self.step_state.data_ptr())
 
-    def step_tail(self, groups, freq_job=None, freq_param=None):
+    def step_tail(self, groups, freq_job=None, freq_param=None, next_view=None):
         """the closing piece of a step: ``groups`` (neighbours in the table) are updated, the counter advances,
         ``zero_after_step`` is cleared -- ``skgs_adam_step_tail``.  ``freq_job`` = (B, D, degree, grad_out, out, ld_out,
         grad_x, accumulate) with device tensors: the frequency-encoding backward that completes ``freq_param``'s gradient
         (the joints': their gradient through the network input) runs first, inside the workgroup that updates that
-        (one-chunk) tensor -- no launch between the backward and the update."""
+        (one-chunk) tensor -- no launch between the backward and the update.  ``next_view`` (``ViewTable.advance()``): the
+        launch ends by putting the next training view's record into the view slot."""
         lib = _C.load_library()
         ranges = self._chunk_ranges(groups)
         assert len(ranges) == 1, f'groups {list(groups)} are not one run of neighbours in the table'
@@ -344,7 +345,8 @@ class FusedAdam:
             C.c_double(self.betas[0]), C.c_double(self.betas[1]), C.c_double(self.eps), C.c_void_p(self.step_state.data_ptr()),
             C.c_void_p(z.data_ptr() if z is not None else None), C.c_int64(z.numel() if z is not None else 0),
             C.c_int64(chunk), C.c_int32(fj[0]), C.c_int32(fj[1]), C.c_int32(fj[2]), C.c_void_p(fj[3]), C.c_void_p(fj[4]),
-            C.c_int32(fj[5]), C.c_void_p(fj[6]), C.c_int32(fj[7]), _C._stream()))
+            C.c_int32(fj[5]), C.c_void_p(fj[6]), C.c_int32(fj[7]), None if next_view is None else C.byref(next_view),
+            _C._stream()))
 
     def advance_step(self):
         """close a step taken in pieces: the counter moves, ``zero_after_step`` is cleared"""

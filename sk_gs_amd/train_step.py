@@ -90,7 +90,8 @@ class FusedTrainStep:
     (Updating the network's weights inside the backward launch as well, by the workgroups that own their rows, was built
     and measured: the launch grows by 15 us, more than the short launch costs.)  Same arithmetic as
     ``step.forward_backward(); optimizer.step()`` (tests/test_gpu_optim.py: bit-identical updates).  Falls back to exactly
-    that when the step has no fused network (or ``enable=False``)."""
+    that when the step has no fused network (or ``enable=False``).  With a ``ViewTable`` whose order was set
+    (``set_order``) the closing launch also selects the next view: no per-step ``select``."""
 
     ROW_GROUPS = ('xyz', 'f_dc', 'f_rest', 'opacity', 'scaling', 'rotation', 'sp_W')
 
@@ -111,6 +112,8 @@ class FusedTrainStep:
         self.step.forward_backward(rs, time_id, target)
         if self.fused:
             job = self.step.input_grad_job() if self.joints is not None else None
-            self.optimizer.step_tail(self.rest, freq_job=job, freq_param=self.joints)
+            vt  = self.step.view_table
+            self.optimizer.step_tail(self.rest, freq_job=job, freq_param=self.joints,
+                                     next_view=vt.advance() if (vt is not None and rs is None) else None)
         else:
             self.optimizer.step()

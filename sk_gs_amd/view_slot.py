@@ -21,6 +21,7 @@ with ONE small device-to-device copy on the current stream (no host synchronisat
 graph renders / trains view v.  Image size, SH degree, ``colmap`` and the other settings are common to all views of a
 table (they stay launch arguments).
 """
+import ctypes as C
 from typing import Optional, Sequence
 
 import torch
@@ -43,6 +44,12 @@ def view_record(rs: GaussianRasterizationSettings, time: float, frame_index: int
     rec.view(torch.int32)[W_FRAME] = int(frame_index)
     rec.view(torch.int32)[W_TARGET] = int(target_index)
     return rec
+
+
+class ViewAdvance(C.Structure):
+    """include/skgs.h::skgs_view_advance: the next view's record is put into the slot by the launch that closes a step"""
+    _fields_ = [('table', C.c_void_p), ('order', C.c_void_p), ('cursor', C.c_void_p), ('slot', C.c_void_p),
+                ('n_order', C.c_int32), ('words', C.c_int32)]
 
 
 class ViewTable:
@@ -76,6 +83,28 @@ class ViewTable:
         """make view ``v`` the one the next launches (or graph replays) see: one 256-byte device-to-device copy"""
         self.slot.copy_(self.records[v], non_blocking=True)
         self.current = v
+
+    def set_order(self, order: Sequence[int]):
+        """Walk the views in ``order`` (cyclically) WITHOUT a per-step ``select``: view ``order[0]`` is selected now; the
+        launch that closes a step (``FusedAdam.step_tail(next_view=table.advance())``, what ``FusedTrainStep`` issues) then
+        puts ``order[1]``, ``order[2]``, ... into the slot, one per step -- the device-to-device copy of ``select`` (4.5 us
+        in front of every replay) disappears.  Upload a new order (a new epoch's permutation) at any step boundary."""
+        assert len(order) >= 1 and all(0 <= int(v) < self.n_views for v in order)
+        dev = self.records.device
+        self.order = torch.tensor([int(v) for v in order], dtype=torch.int32, device=dev)
+        self.cursor = torch.ones(1, dtype=torch.int32, device=dev)  # the next view to load is order[1]
+        self.select(int(order[0]))
+
+    def clear_order(self):
+        """back to explicit ``select`` calls"""
+        self.order = None
+
+    def advance(self) -> Optional[ViewAdvance]:
+        """the ``skgs_view_advance`` job of the closing launch (None until ``set_order`` was called)"""
+        if getattr(self, 'order', None) is None:
+            return None
+        return ViewAdvance(self.records.data_ptr(), self.order.data_ptr(), self.cursor.data_ptr(), self.slot.data_ptr(),
+                           int(self.order.numel()), SLOT_WORDS)
 
     # ---- device addresses of the live slot's fields
     def ptr(self, word: int) -> int:

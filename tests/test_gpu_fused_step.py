@@ -382,3 +382,46 @@ def test_fused_step_with_superpoint_sized_bone_count_matches_autograd():
     step2.forward_backward(rs, tid, target)
     step2.scatter_spw_grad()
     assert_close_robust(model.sp_W.grad, dense, 1e-5, 1e-4, name='sp_W from compact logits, M=512')
+
+
+def test_ordered_view_table_is_advanced_by_the_closing_launch():
+    """``ViewTable.set_order`` + ``FusedTrainStep``: the launch that closes step i leaves view order[i + 1] in the slot
+    (``skgs_view_advance``), so a replayed graph walks the views without a per-step ``select``: same slot contents, same
+    images as explicit selection, cyclically"""
+    from sk_gs_amd import _C, scene
+    from sk_gs_amd.fused_step import FusedViewStep
+    from sk_gs_amd.model import SkinnedGaussians
+    from sk_gs_amd.optim import FusedAdam
+    from sk_gs_amd.train_step import FusedTrainStep, GraphedSteps
+    from sk_gs_amd.view_slot import ViewTable
+    P, M, K, W, H, V = 2000, 10, 4, 96, 64, 5
+    dev = torch.device('cuda')
+    model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=V, seed=4, scale_mult=2.0, deform_net=True,
+                             learn_joints=True).to(dev)
+    cams = [scene.make_camera(W, H, seed=50 + v) for v in range(V)]
+    settings = [scene.raster_settings_from_camera(c, sh_degree=3, colmap=True, device=dev) for c in cams]
+    targets = torch.rand(V, 3, H, W, generator=torch.Generator().manual_seed(9)).to(dev)
+    table = ViewTable(settings, [float(model.frame_times[v]) for v in range(V)], list(range(V)), targets, dev)
+    step = FusedViewStep(model, W, H, capacity=400_000, view_table=table)
+    opt = FusedAdam(model.param_groups(lr=0.0))  # lr 0: the parameters stay put, every view renders the same scene
+    train = FusedTrainStep(step, opt)
+    assert train.fused
+    order = [3, 0, 4, 4, 1]
+    # reference images by explicit selection
+    ref = {}
+    for v in set(order):
+        table.select(v)
+        step.forward()
+        ref[v] = step.image.clone()
+    table.set_order(order)
+    graphs = GraphedSteps(lambda _: train(), collect_garbage=False)
+    for i in range(2 * len(order) + 1):
+        v = order[i % len(order)]
+        assert torch.equal(table.slot, table.records[v]), i          # what this step is about to read
+        graphs(0)
+        torch.cuda.synchronize()
+        assert torch.equal(step.image, ref[v]), i
+        assert int(table.cursor.item()) == i + 2 and float(opt.step_count.item()) == i + 1
+    assert len(graphs.graphs) == 1 and step.status()['overflow_events'] == 0
+    table.clear_order()
+    assert table.advance() is None
