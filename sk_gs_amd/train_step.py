@@ -1,10 +1,13 @@
-"""hipGraph capture of the per-view training step.
+"""hipGraph capture of the training step, and the one-rank step with its optimizer folded into the backward.
 
-One training iteration is ~15 of our kernels plus the torch glue around them (bone chain, softmax of the LBS logits,
-concatenations, Adam) -- a few hundred short launches, i.e. launch-bound when issued eagerly.  The step has static
-shapes and, with the capacity-based binning (``_C.config.sync_num_rendered = False``), no host synchronisation, so
-the whole thing replays as ONE hipGraph per training view.  (The reference cannot do this: its forward blocks on a
-D2H copy of ``num_rendered``, gaussian_rasterizer_forward.cu:209.)
+``GraphedSteps``: the step has static shapes and, with the capacity-based binning (``_C.config.sync_num_rendered =
+False``) or the bucket layout, no host synchronisation: it replays as ONE hipGraph -- for all training views when the
+per-view inputs live in a ``ViewTable`` slot.  (The reference cannot do this: its forward blocks on a D2H copy of
+``num_rendered``, gaussian_rasterizer_forward.cu:209.)  Through the autograd operator path a step is ~15 of our kernels plus
+the torch glue around them; ``FusedViewStep`` issues 14 launches and no glue.
+
+``FusedTrainStep``: ``FusedViewStep.forward_backward`` + ``FusedAdam.step`` for one rank, with the update taken apart along
+the data dependencies of the skeleton stage's backward launch.
 """
 import gc
 from typing import Callable, Dict, Hashable
