@@ -15,6 +15,7 @@ direction (csrc/mlp_fused.hip; <= 48 rows, the skeleton stage's one row per bone
 ``DeformMLPRunner`` -- one launch per layer (csrc/mlp.hip; any row count, e.g. the 512 superpoints of the sp stage).
 """
 import ctypes as C
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -357,6 +358,9 @@ class FusedDeformMLP:
         return dict(forward=int(w[0]), backward=int(w[3]), failed=int(w[1]))
 
 
+_FUSED_POOLS = weakref.WeakKeyDictionary()  # DeformMLP -> {(rows, device, stream): [free FusedDeformMLP runners]}
+
+
 class _DeformMLPFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mlp: DeformMLP, points: Tensor, t: Tensor, *params):
@@ -368,7 +372,12 @@ class _DeformMLPFn(torch.autograd.Function):
         B = points.shape[0]
         f32 = dict(dtype=torch.float32, device=points.device)
         if fused_supported(mlp, B) and not getattr(mlp, 'force_layered', False):
-            run = FusedDeformMLP(mlp, B)  # (allocates its exchange workspace: the training step keeps one instead)
+            # a runner (exchange workspace, saved activations) is busy from a forward until its backward has run: free
+            # ones are kept on the module, per row count and stream, instead of being allocated and initialised per call
+            key = (B, points.device.index, torch.cuda.current_stream().cuda_stream)
+            pool = _FUSED_POOLS.setdefault(mlp, {}).setdefault(key, [])
+            run = pool.pop() if pool else FusedDeformMLP(mlp, B)
+            ctx.pool = pool
             # the returned tensor must not be owned by anything the context references: ctx -> run -> out -> grad_fn -> ctx
             # would be a reference cycle that keeps the whole autograd graph (and its AccumulateGrad nodes, bound to the
             # stream of THIS call) alive until the next gc -- which breaks a later hipGraph capture of the step
@@ -401,6 +410,9 @@ class _DeformMLPFn(torch.autograd.Function):
             if g_x0 is not None:
                 g_points = torch.empty_like(ctx.pt[0])
                 DeformMLPRunner(mlp).input_grad(g_x0, run.x0, g_points)
+            ctx.fused = None
+            if len(ctx.pool) < 4:
+                ctx.pool.append(run)  # (same stream: the next forward's launches are ordered behind this backward's)
             return (None, g_points, None) + tuple(grads)
         x0, acts, out = ctx.saved_tensors
         g_act = torch.empty((2,) + tuple(acts.shape[1:]), dtype=torch.float32, device=acts.device)
