@@ -388,17 +388,40 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_moments_kernel
 #pragma unroll
   for (int c = 0; c < MOM_U; c += 4) *reinterpret_cast<float4*>(my_u + c) = make_float4(u[c], u[c + 1], u[c + 2], u[c + 3]);
   __syncthreads();  // (only the own wave's rows are read below; the barrier also orders the LDS traffic)
-  // ---- each lane owns outputs o = (bone, component): Mom_wave[o] = sum over the wave's 64 Gaussians
+  // ---- Mom_wave[bone][component] = sum over the wave's 64 Gaussians of w[q][bone] u[q][component]: outer products on the
+  // matrix cores.  v_mfma_f32_4x4x1 holds 16 independent 4 x 4 blocks = (4 bones) x (4 components) each; one Gaussian per
+  // instruction; lane 4 b + i feeds bone 4 bg + i as A and component 4 cg + i as B of block b and receives row i' of the
+  // block in VGPR i'.  (On the VALU every lane owned ~6 outputs and read 2 x 64 LDS words for each: 768 ds_read_b32 and 384
+  // FMAs per lane; now 256 reads and 128 MFMAs for M = 20.)
   const int n_out   = M * MOM_F;
   const float* w0   = s_w + (size_t) wave * 64 * Mp;
   const float* u0   = s_u + (size_t) wave * 64 * MOM_U;
   float* part       = s_part + (size_t) wave * n_out;
-  for (int o = lane; o < n_out; o += 64) {
-    const int b = o / MOM_F, c = o - b * MOM_F;
-    float acc = 0.f;
+  {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    constexpr int NCG = MOM_U / 4;
+    const int nblk = (Mp / 4) * NCG, li = lane & 3, lb = lane >> 2;
+    for (int r0 = 0; r0 < nblk; r0 += 16) {
+      const int blk   = r0 + lb;
+      const bool live = blk < nblk;
+      const int bg = live ? blk / NCG : 0, cg = live ? blk - (blk / NCG) * NCG : 0;
+      const float* wa = w0 + 4 * bg + li;
+      const float* ub = u0 + 4 * cg + li;
+      f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
-    for (int q = 0; q < 64; ++q) acc += w0[q * Mp + b] * u0[q * MOM_U + c];
-    part[o] = acc;
+      for (int q = 0; q < 64; q += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[q * Mp], ub[q * MOM_U], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[(q + 1) * Mp], ub[(q + 1) * MOM_U], acc1, 0, 0, 0);
+      }
+      if (live) {
+        const int comp = 4 * cg + li;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int bone = 4 * bg + i;
+          if (bone < M && comp < MOM_F) part[bone * MOM_F + comp] = acc0[i] + acc1[i];
+        }
+      }
+    }
   }
   __syncthreads();
   for (int o = threadIdx.x; o < n_out; o += DEFORM_THREADS)
