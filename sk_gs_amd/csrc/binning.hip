@@ -465,16 +465,22 @@ __global__ void __launch_bounds__(SORT_THREADS) tile_sort_merge_kernel(const Geo
     }
     __syncthreads();
     // ---- phase 2: merge rounds, run length 512 -> NMAX / 2; the last one writes the list and the point list
-    uint64_t* src = s_a;
-    uint64_t* dst = s_b;
+    if (L <= 2 * CH) {
+      // two real chunks: their one merge is already the last round (the generic rounds below would go on merging the result
+      // with all-padding runs: at 500k Gaussians @1024^2 every long list is one of these, 36.0 -> 33.7 us)
+      merge_round<OPT, true>(s_a, nullptr, gk, pl, CH, L, tid);
+    } else {
+      uint64_t* src = s_a;
+      uint64_t* dst = s_b;
 #pragma unroll
-    for (int len = CH; len < NMAX / 2; len *= 2) {
-      merge_round<OPT, false>(src, dst, nullptr, nullptr, len, L, tid);
-      __syncthreads();
-      uint64_t* t = src;
-      src = dst, dst = t;
+      for (int len = CH; len < NMAX / 2; len *= 2) {
+        merge_round<OPT, false>(src, dst, nullptr, nullptr, len, L, tid);
+        __syncthreads();
+        uint64_t* t = src;
+        src = dst, dst = t;
+      }
+      merge_round<OPT, true>(src, nullptr, gk, pl, NMAX / 2, L, tid);
     }
-    merge_round<OPT, true>(src, nullptr, gk, pl, NMAX / 2, L, tid);
     __syncthreads();
   }
 }
