@@ -594,6 +594,28 @@ def main():
         times = sorted(a.elapsed_time(b_) for a, b_ in ev)
         ms_render = dict(median=round(times[NT // 2], 4), p10=round(times[NT // 10], 4), p90=round(times[9 * NT // 10], 4),
                          protocol=f'{NW} warm-up + {NT} timed iterations, one HIP event pair per iteration')
+        # the same operator-path calls captured once and replayed (config.sync_num_rendered is off: nothing in them touches
+        # the host): what the drop-in boundary costs without the Python / launch latency of the eager loop above
+        try:
+            def op_fwd_bwd(_):
+                o_ = render(**ins, raster_settings=settings[0])
+                torch.autograd.backward([o_['images'], o_['opacity']], [gcol, gop])
+            del o
+            g_op = GraphedSteps(op_fwd_bwd)
+            g_op.capture(0)
+            for i in range(NW + NT):
+                if i >= NW:
+                    ev[i - NW][0].record()
+                g_op(0)
+                if i >= NW:
+                    ev[i - NW][1].record()
+            torch.cuda.synchronize()
+            times = sorted(a.elapsed_time(b_) for a, b_ in ev)
+            ms_render['graph_replay_median'] = round(times[NT // 2], 4)
+            del g_op
+        except Exception as e:  # noqa  (a capture problem must not cost the headline line)
+            ms_render['graph_replay_median'] = None
+            ms_render['graph_replay_error'] = str(e)[:200]
         # forward-only render rate, the reference's FPS (deform network + skinning + rasterize + background, no_grad)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.no_grad():
