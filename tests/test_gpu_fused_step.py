@@ -425,3 +425,31 @@ def test_ordered_view_table_is_advanced_by_the_closing_launch():
     assert len(graphs.graphs) == 1 and step.status()['overflow_events'] == 0
     table.clear_order()
     assert table.advance() is None
+
+
+@pytest.mark.parametrize('M,K', [(1, 1), (3, 2)])
+def test_fused_step_with_one_or_few_bones_matches_autograd(M, K):
+    """M = 1 (a single bone: root only, one tree level) up to a handful -- the network's row count, the chain's
+    level loop and the KNN kernels all see degenerate sizes"""
+    from sk_gs_amd import _C, scene
+    from sk_gs_amd.fused_step import FusedViewStep
+    from sk_gs_amd.losses import image_loss
+    from sk_gs_amd.model import SkinnedGaussians
+    P, W, H, frames, tid = 3000, 128, 96, 3, 2
+    dev = torch.device('cuda')
+    model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=2, scale_mult=2.0, deform_net=True,
+                             learn_joints=True).to(dev)
+    cam = scene.make_camera(W, H, seed=2)
+    rs = scene.raster_settings_from_camera(cam, sh_degree=3, colmap=True, device=dev)
+    target = torch.rand(3, H, W, generator=torch.Generator().manual_seed(3)).to(dev)
+    _C.config.sync_num_rendered = True
+    out = model.render(rs, time_id=tid)
+    image_loss(out['images'], target).backward()
+    ref = {n: p.grad.clone() for n, p in model.named_parameters()}
+    for p in model.parameters():
+        p.grad = torch.full_like(p, 5.0)
+    step = FusedViewStep(model, W, H, capacity=int(out['buffer'].R * 1.2) + 1024)
+    step.forward_backward(rs, tid, target)
+    assert rel_err(step.image, out['images'].detach()) <= 5e-6 and step.status()['mlp_failed'] == 0
+    for n, p in model.named_parameters():
+        assert_close_robust(p.grad, ref[n], 2e-4, 1e-3, name=n)
