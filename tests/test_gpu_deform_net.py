@@ -259,7 +259,8 @@ def test_fused_deform_mlp_separate_heads():
         assert torch.equal(a, r)
 
 
-def test_skeleton_stage_in_one_launch_per_direction():
+@pytest.mark.parametrize('M', [24, 40])
+def test_skeleton_stage_in_one_launch_per_direction(M):
     """``skgs_skeleton_forward`` / ``skgs_skeleton_backward`` (network + kinematic chain in one launch) against the separate
     calls ``skgs_deform_mlp_*`` + ``skgs_bone_chain_*``: same bone transforms bit for bit (the same chain code on the same
     rotations); same gradients up to the order of the chain backward's LDS atomics"""
@@ -267,7 +268,6 @@ def test_skeleton_stage_in_one_launch_per_direction():
     from sk_gs_amd.deform_net import BoneChainDesc, FusedDeformMLP
     from sk_gs_amd.model import SkinnedGaussians
     torch.manual_seed(0)
-    M = 24
     model = SkinnedGaussians(500, M, 4, sh_degree=0, num_frames=3, seed=5, deform_net=True, learn_joints=True).cuda()
     mlp, topo = model.sk_deform_net, model.topology()
     with torch.no_grad():
