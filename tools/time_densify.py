@@ -9,7 +9,8 @@ from sk_gs_amd.optim import FusedAdam
 
 dev = torch.device('cuda')
 for P, M in ((100_000, 20), (300_000, 20)):
-    for rep in range(3):
+    td, tp = [], []
+    for rep in range(5):
         model = SkinnedGaussians(P, M, 5, sh_degree=3, num_frames=2, seed=0, deform_net=True).to(dev)
         for p in model.parameters():
             p.grad = torch.zeros_like(p)
@@ -27,4 +28,5 @@ for P, M in ((100_000, 20), (300_000, 20)):
         densify.prune(model, opt, stats, min_opacity=0.005, extent=4.0, max_screen_size=20.0)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-    print(f'P={P}: densify (clone + split) {1e3 * (t1 - t0):.2f} ms, prune {1e3 * (t2 - t1):.2f} ms -> {model.P} Gaussians')
+        td.append(t1 - t0), tp.append(t2 - t1)
+    print(f'P={P}: densify (clone + split) {1e3 * sorted(td)[2]:.2f} ms, prune {1e3 * sorted(tp)[2]:.2f} ms (medians of 5) -> {model.P} Gaussians')
