@@ -182,6 +182,9 @@ def main():
                          'networks/sk_gs.py:1080-1085) instead of running the 8x256 deform network inside every step.  The '
                          'reference runs the network in every TRAINING step (sk_gs.py:1073-1074): that is the default here')
     ap.add_argument('--deform-net', dest='deform_net', action='store_true', help='(default) the deform network inside the step')
+    ap.add_argument('--pre-forward', choices=('auto', 'on', 'off'), default='auto',
+                    help='one rank, ordered views: end a step with the next view\'s skeleton-forward launch, which carries 40 %% of '
+                         'the rows\' Adam update (auto: when that update is too large to hide beside the backward launch alone)')
     ap.add_argument('--serial-adam', action='store_true',
                     help='one rank: the whole Adam update as its own launch after the backward, instead of the per-Gaussian '
                          'rows\' update running inside the deform network\'s backward launch (on the 224 CUs it leaves idle)')
@@ -432,6 +435,10 @@ def main():
                 # the closing launch of a step selects the next view: the views are walked in the loop's order without a
                 # device-to-device copy in front of every replay
                 view_table.set_order([vp.view_index(i, args.views) for i in range(args.views)])
+                if args.pre_forward != 'off':
+                    # ... and ends with the next view's skeleton-forward launch, which carries the rest of the rows' update
+                    train1.set_pre_forward('auto' if args.pre_forward == 'auto' else True)
+                    train1.prime()
 
         def eager_step(i):
             v = vp.view_index(i, args.views)
@@ -527,8 +534,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ordered_views = view_table is not None and getattr(view_table, 'order', None) is not None
-    if ordered_views:
-        view_table.clear_order()  # the measurements below select their views explicitly
+    pre_forward_used = bool(not pipelined and fused_update and train1.pre_forward)
     prof = _C.profile_collect()
     _C.profile_enable([])
     if use_dist:
@@ -569,6 +575,9 @@ def main():
                              alg_MB=round(b / 1e6, 2) if b else None,
                              GBps=round(b / (us * 1e-6) / 1e9, 1) if b else None)
     _C.profile_enable([])
+    if ordered_views:
+        view_table.clear_order()  # the measurements below select their views explicitly
+        train1.set_pre_forward(False)
 
     # ---- BASELINE's second metric and the reference's FPS protocol (test.py:56-81,102-123: warm-up, then N renders between
     # two events): 20 warm-up + 200 timed iterations, HIP events on the launch stream
@@ -696,8 +705,10 @@ def main():
                        if args.deform_net and M > 0 else 'per-frame tables (test-time cache, sk_gs.py:1080-1085): NOT the '
                                                          'reference\'s training step',
                        'joints': 'trained, lr x 0.1 (sk_gs.py:607)' if model.learn_joints else 'fixed',
-                       'adam': ('per-Gaussian rows inside the skeleton stage\'s backward launch (its 224 idle CUs); network, joints, tables '
-                                '+ counter (+ the encoder backward of the joints) in one closing launch'
+                       'adam': ((('per-Gaussian rows on the idle CUs of the two skeleton-stage launches (60 % beside the backward, 40 % '
+                                  'beside the NEXT view\'s forward, which closes the step)' if pre_forward_used else
+                                  'per-Gaussian rows inside the skeleton stage\'s backward launch (its 224 idle CUs)')
+                                 + '; network, joints, tables + counter (+ the encoder backward of the joints) in one closing launch')
                                 if (not pipelined and fused_update) else 'one launch after the backward') if not pipelined
                        else 'one launch per bucket',
                        'step': 'autograd operator path' if args.autograd else 'FusedViewStep (direct C-ABI calls)',

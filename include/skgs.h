@@ -401,6 +401,9 @@ typedef struct skgs_adam_range {
   int64_t chunk_begin, chunk_end;
   double beta1, beta2, eps;
   const float* step_count;           /* the optimizer's device state (skgs_adam_state_bytes()): read, not advanced */
+  int32_t after_advance;             /* 0: the piece precedes the launch that advances the counter (bias correction of step
+                                        count + 1); 1: it follows it but belongs to that step (correction of step count):
+                                        the piece that rides on the NEXT skeleton-forward launch */
 } skgs_adam_range;
 int skgs_deform_mlp_backward_adam(const skgs_mlp_desc* d, const float* points, const float* t, const float* x0,
     const float* acts, const float* g_out, float* g_x0, void* workspace, size_t workspace_bytes, const skgs_adam_range* side,
@@ -426,7 +429,8 @@ typedef struct skgs_bone_chain_desc {
   float* g_global_T;                                    /* backward: [7] (row frame_index), written; may be NULL */
 } skgs_bone_chain_desc;
 int skgs_skeleton_forward(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, const float* points, const float* t,
-    float* x0, float* acts, void* workspace, size_t workspace_bytes, skgs_stream_t stream);
+    float* x0, float* acts, void* workspace, size_t workspace_bytes, const skgs_adam_range* side /* may be NULL */,
+    skgs_stream_t stream);
 int skgs_skeleton_backward(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, const float* points, const float* t,
     const float* x0, const float* acts, float* g_x0, void* workspace, size_t workspace_bytes, const skgs_adam_range* side,
     skgs_stream_t stream);

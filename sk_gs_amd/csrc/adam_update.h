@@ -41,8 +41,12 @@ struct AdamCoef {
 };
 // bias corrections of step count + 1.  Hyper-parameters arrive as doubles and (1 - beta) is formed in double, as torch
 // does: 1.0f - 0.999f is off by 1.3e-5
-__device__ __forceinline__ AdamCoef adam_coefficients(double beta1d, double beta2d, float eps, const AdamState* st) {
-  const double bc1 = (1.0 - beta1d) + beta1d * st->q1, bc2 = (1.0 - beta2d) + beta2d * st->q2;
+// after_advance: the piece runs AFTER the launch that advanced the counter but belongs to that step (a side job of the next
+// skeleton-forward launch): its bias corrections are the state's own 1 - beta^count.
+__device__ __forceinline__ AdamCoef adam_coefficients(double beta1d, double beta2d, float eps, const AdamState* st,
+    bool after_advance = false) {
+  const double bc1 = after_advance ? st->q1 : (1.0 - beta1d) + beta1d * st->q1;
+  const double bc2 = after_advance ? st->q2 : (1.0 - beta2d) + beta2d * st->q2;
   return AdamCoef{(float) bc1, (float) (1.0 / sqrt(bc2)), (float) beta1d, (float) beta2d, (float) (1.0 - beta1d),
       (float) (1.0 - beta2d), eps};
 }

@@ -92,6 +92,7 @@ struct FusedArgs {
   double adam_beta1, adam_beta2;
   float adam_eps;
   const AdamState* adam_step;
+  int adam_after_advance;  // the side piece follows the launch that advanced the counter (see adam_coefficients)
   // the kinematic chain riding on the launches (skgs_skeleton_forward / _backward): forward -- workgroup 0, which owns
   // the raw joint rotations (head 0 = the last layer's columns 0..3), runs it after the heads; backward -- every workgroup
   // runs its backward in the prologue (the gradient of head 0 is the one input of the network's backward no other kernel
@@ -308,7 +309,7 @@ constexpr int NUM_CUS = 256;  // MI355X: the side job gets one workgroup per CU 
 __device__ __forceinline__ void adam_side_job(const FusedArgs& a) {
   const int n_side = (int) gridDim.x - G_NET, wg = (int) blockIdx.x - G_NET;
   const int half = threadIdx.x >> 8, t256 = threadIdx.x & 255, lane = threadIdx.x & 63;
-  const AdamCoef k = adam_coefficients(a.adam_beta1, a.adam_beta2, a.adam_eps, a.adam_step);
+  const AdamCoef k = adam_coefficients(a.adam_beta1, a.adam_beta2, a.adam_eps, a.adam_step, a.adam_after_advance != 0);
   const AdamTensorLanes desc = adam_load_descriptors(a.adam_tensors, a.adam_n, lane);
   const int64_t first0 = lane < a.adam_n ? a.adam_tensors[lane].chunk0 : INT64_MAX;
   // Every workgroup gets an equal, contiguous share of the chunks (+-1): with a grid-stride loop of 4 chunks per
@@ -342,6 +343,10 @@ __global__ void __launch_bounds__(NT) fused_mlp_forward_kernel(const FusedArgs a
   constexpr int EQ = (Bp * INP + NT - 1) / NT;             // encoded-input entries per thread (padding included)
   static_assert((Bp * 64 + NT - 1) / NT <= 8, "gather_slabs covers at most 8 units per thread");
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (blockIdx.x >= G_NET) {  // (the forward launch can host an optimizer piece on its idle CUs too: see adam_side_job)
+    adam_side_job(a);
+    return;
+  }
   const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
   const int tid = threadIdx.x, wave = tid >> 6;
   const int G = G_NET, g = blockIdx.x, col0 = g * NC;
@@ -884,8 +889,19 @@ int fill_chain(const skgs_mlp_desc* d, const Plan& p, const skgs_bone_chain_desc
   c.bone_T = b->bone_T, c.chain_A = b->chain_A;
   return 0;
 }
+int fill_side(const skgs_adam_range* side, FusedArgs* a) {
+  if (!side || side->n_tensors <= 0) return 0;
+  SKGS_REQUIRE(side->tensors && side->step_count && side->chunk_begin >= 0 && side->chunk_end >= side->chunk_begin,
+      "deform_mlp: bad side range");
+  a->adam_tensors = reinterpret_cast<const AdamTensor*>(side->tensors), a->adam_n = side->n_tensors;
+  a->adam_c0 = side->chunk_begin, a->adam_c1 = side->chunk_end;
+  a->adam_beta1 = side->beta1, a->adam_beta2 = side->beta2, a->adam_eps = (float) side->eps;
+  a->adam_step  = reinterpret_cast<const AdamState*>(side->step_count);
+  a->adam_after_advance = side->after_advance ? 1 : 0;
+  return 0;
+}
 int forward_impl(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, const float* points, const float* t, float* x0,
-    float* acts, float* out, void* workspace, size_t workspace_bytes, skgs_stream_t stream);
+    float* acts, float* out, void* workspace, size_t workspace_bytes, const skgs_adam_range* side, skgs_stream_t stream);
 int backward_impl(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, const float* points, const float* t,
     const float* x0, const float* acts, const float* g_out, float* g_x0, void* workspace, size_t workspace_bytes,
     const skgs_adam_range* side, skgs_stream_t stream);
@@ -938,13 +954,13 @@ int skgs_deform_mlp_workspace_init(void* workspace, size_t workspace_bytes, skgs
 
 int skgs_deform_mlp_forward(const skgs_mlp_desc* d, const float* points, const float* t, float* x0, float* acts, float* out,
     void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
-  return forward_impl(d, nullptr, points, t, x0, acts, out, workspace, workspace_bytes, stream);
+  return forward_impl(d, nullptr, points, t, x0, acts, out, workspace, workspace_bytes, nullptr, stream);
 }
 
 int skgs_skeleton_forward(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, const float* points, const float* t,
-    float* x0, float* acts, void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
+    float* x0, float* acts, void* workspace, size_t workspace_bytes, const skgs_adam_range* side, skgs_stream_t stream) {
   SKGS_REQUIRE(bones, "skeleton_forward: NULL bone chain");
-  return forward_impl(d, bones, points, t, x0, acts, nullptr, workspace, workspace_bytes, stream);
+  return forward_impl(d, bones, points, t, x0, acts, nullptr, workspace, workspace_bytes, side, stream);
 }
 
 }  // extern "C"
@@ -952,7 +968,7 @@ int skgs_skeleton_forward(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bo
 namespace skgs {
 namespace {
 int forward_impl(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, const float* points, const float* t, float* x0,
-    float* acts, float* out, void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
+    float* acts, float* out, void* workspace, size_t workspace_bytes, const skgs_adam_range* side, skgs_stream_t stream) {
   Plan p;
   if (make_plan(d, &p)) return 1;
   SKGS_REQUIRE(points && (t || d->t_dim == 0) && acts && workspace, "deform_mlp_forward: NULL argument");
@@ -972,6 +988,7 @@ int forward_impl(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, cons
     SKGS_REQUIRE(chain::forward_scratch_floats(bones->M, bones->num_levels) <= (size_t) NW * p.Bp * NC,
         "skeleton_forward: %d tree levels do not fit the scratch", bones->num_levels);
   }
+  if (fill_side(side, &a)) return 1;
   const int XW = pad32(p.IN);
   size_t fl = (size_t) p.Bp * (XW + 4) + (size_t) p.Bp * HP + (size_t) NW * p.Bp * NC + (size_t) p.Bp * 4 + (size_t) KL * NC + 4;
   for (int l = 0; l < d->n_layers; ++l) fl += (size_t) NC * ((l ? H : 0) + (d->layer[l].in_x0 ? XW : 0) + 4);
@@ -1033,14 +1050,7 @@ int backward_impl(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, con
     a.chain.sk_r_raw = bones->sk_r_raw, a.chain.g_bone_T = bones->g_bone_T, a.chain.g_joints = bones->g_joints;
     a.chain.g_global_T = bones->g_global_T, a.chain.g_sk_r_raw = const_cast<float*>(d->head_gout[0]);
   }
-  if (side && side->n_tensors > 0) {
-    SKGS_REQUIRE(side->tensors && side->step_count && side->chunk_begin >= 0 && side->chunk_end >= side->chunk_begin,
-        "deform_mlp_backward_adam: bad side range");
-    a.adam_tensors = reinterpret_cast<const AdamTensor*>(side->tensors), a.adam_n = side->n_tensors;
-    a.adam_c0 = side->chunk_begin, a.adam_c1 = side->chunk_end;
-    a.adam_beta1 = side->beta1, a.adam_beta2 = side->beta2, a.adam_eps = (float) side->eps;
-    a.adam_step  = reinterpret_cast<const AdamState*>(side->step_count);
-  }
+  if (fill_side(side, &a)) return 1;
   a.hdr  = reinterpret_cast<unsigned*>(workspace);
   a.exch = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + HDR_BYTES + p.exch_bytes);
   size_t fl = (size_t) p.Bp * HP + (size_t) (d->n_layers + NW) * p.Bp * NC + (size_t) p.Bp * 4 + 4;

@@ -299,11 +299,12 @@ class FusedDeformMLP:
         return d
 
     def forward(self, points: Tensor, t: Tensor, head_out: Optional[Sequence[Tensor]] = None,
-                out: Optional[Tensor] = None, bones: Optional[BoneChainDesc] = None) -> Tensor:
+                out: Optional[Tensor] = None, bones: Optional[BoneChainDesc] = None, side_adam=None) -> Tensor:
         """points [B, p_in], t: device tensor with t_in floats -> ``out`` (default ``self.out``) [B, OUT], or the heads
         written to the separate tensors ``head_out`` (also fills x0 / acts).  ``bones`` (needs ``head_out``): the kinematic
         chain runs in the same launch (``skgs_skeleton_forward``: rows = bones, head 0 = raw joint rotations) and fills
-        ``bones.bone_T`` / ``bones.chain_A``."""
+        ``bones.bone_T`` / ``bones.chain_A``; ``side_adam`` (``FusedAdam.side_range``): an optimizer piece for the CUs that
+        launch leaves idle."""
         assert points.is_cuda and points.is_contiguous() and points.dtype == torch.float32 and points.shape[0] == self.B
         assert t.is_cuda and t.dtype == torch.float32 and t.numel() == self.mlp.t_in
         out = self.out if out is None else out
@@ -314,8 +315,9 @@ class FusedDeformMLP:
             _C._check(self.lib.skgs_skeleton_forward(
                 C.byref(d), C.byref(bones), C.c_void_p(points.data_ptr()), C.c_void_p(t.data_ptr()),
                 C.c_void_p(self.x0.data_ptr()), C.c_void_p(self.acts.data_ptr()), C.c_void_p(self.workspace.data_ptr()),
-                C.c_size_t(self.workspace.numel()), _C._stream()))
+                C.c_size_t(self.workspace.numel()), None if side_adam is None else C.byref(side_adam), _C._stream()))
             return out
+        assert side_adam is None
         _C._check(self.lib.skgs_deform_mlp_forward(
             C.byref(d), C.c_void_p(points.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(self.x0.data_ptr()),
             C.c_void_p(self.acts.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(self.workspace.data_ptr()),

@@ -117,6 +117,9 @@ class FusedViewStep:
         # (FusedAdam, group names) or None: that piece of the optimizer step runs inside the deform network's backward
         # launch (train_step.FusedTrainStep sets it; one rank, no gradient exchange between backward and update)
         self.side_optimizer = None
+        # the skeleton stage of the view in the slot already ran (``skeleton_forward``: FusedTrainStep(pre_forward=True)
+        # issues it for the NEXT view behind the optimizer's closing launch): ``forward`` starts at the skinning
+        self.skeleton_ahead = False
         self.defer_input_grad = False
         # view-parallel training: [P*K] float32 view that receives the compact LBS-logit gradient (see backward_skinning)
         self.spw_logit_grad = spw_logit_grad
@@ -427,8 +430,8 @@ class FusedViewStep:
             return m.sk_r[time_id]
         tt = self._time_tensor(time_id)
         if self._mlp_fused is not None:  # the whole skeleton stage -- network and kinematic chain -- in one launch
-            self._mlp_fused.forward(m.joints, tt, head_out=(self._sk_r_raw, self._d_rot, self._d_scale),
-                                    bones=self._bones_desc(time_id))
+            if not self.skeleton_ahead:
+                self.skeleton_forward(time_id)
             return self._sk_r_raw
         from sk_gs_amd.deform_net import _lin_fwd
         net, run = self.deform_net.dynamic_net, self._mlp
@@ -443,6 +446,14 @@ class FusedViewStep:
             o += oc
         return self._sk_r_raw
 
+    def skeleton_forward(self, time_id: Optional[int] = None, side_adam=None):
+        """the skeleton stage of a view (network heads + kinematic chain, one launch) on its own; ``side_adam``
+        (``FusedAdam.side_range``): an optimizer piece for the CUs the launch leaves idle"""
+        assert self._mlp_fused is not None
+        self._mlp_fused.forward(self.model.joints, self._time_tensor(time_id),
+                                head_out=(self._sk_r_raw, self._d_rot, self._d_scale), bones=self._bones_desc(time_id),
+                                side_adam=side_adam)
+
     def _deform_net_backward(self):
         """weight gradients of the producer network, written into the parameters' .grad: one launch (fused kernels) or
         3 head + 8 layer launches"""
@@ -451,7 +462,7 @@ class FusedViewStep:
             grads = [g for l in net.net for g in (l.weight.grad, l.bias.grad)] + [net.last_weight.grad, net.last_bias.grad]
             side = None
             if self.side_optimizer is not None:  # the per-Gaussian rows' Adam update on the CUs this launch leaves idle
-                side = self.side_optimizer[0].side_range(self.side_optimizer[1])
+                side = self.side_optimizer[0].side_range(*self.side_optimizer[1:])
             self._mlp_fused.backward(self.model.joints, self._time_tensor(self._time_id), self._g_heads, grads, self._g_x0,
                                      side_adam=side, bones=self._bones_desc(self._time_id))
             # joints.grad (written by the bone-chain backward) += the network-input path; with ``defer_input_grad`` the

@@ -35,7 +35,8 @@ def position_lr(step: int, lr_init: float, lr_final: float, max_steps: int = 30_
 class AdamRange(C.Structure):
     """include/skgs.h::skgs_adam_range: a run of chunks of an optimizer table, updated as the side job of another launch"""
     _fields_ = [('n_tensors', C.c_int32), ('tensors', C.c_void_p), ('chunk_begin', C.c_int64), ('chunk_end', C.c_int64),
-                ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double), ('step_count', C.c_void_p)]
+                ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double), ('step_count', C.c_void_p),
+                ('after_advance', C.c_int32)]
 
 
 class FusedAdam:
@@ -313,14 +314,20 @@ class FusedAdam:
                 C.c_void_p(z.data_ptr() if (z is not None and last) else None),
                 C.c_int64(z.numel() if (z is not None and last) else 0), _C._stream()))
 
-    def side_range(self, groups) -> AdamRange:
+    def side_range(self, groups, part=None, after_advance: bool = False) -> AdamRange:
         """the piece of a step that updates ``groups`` (neighbours in the table) as a ``skgs_adam_range``: handed to
-        ``skgs_deform_mlp_backward_adam`` / ``skgs_skeleton_backward`` it runs on the CUs that launch leaves idle -- same
-        arithmetic as ``step(groups, advance=False)``"""
+        ``skgs_deform_mlp_backward_adam`` / ``skgs_skeleton_backward`` / ``skgs_skeleton_forward`` it runs on the CUs that
+        launch leaves idle -- same arithmetic as ``step(groups, advance=False)``.  ``part`` = (lo, hi) fractions: only that
+        share of the chunks (two launches can split one run); ``after_advance``: the piece is issued after the launch that
+        advanced the counter but belongs to the step that launch closed."""
         ranges = self._chunk_ranges(groups)
         assert len(ranges) == 1, f'groups {list(groups)} are not one run of neighbours in the table'
-        return AdamRange(len(self.params), self._table.data_ptr(), ranges[0][0], ranges[0][1], self.betas[0], self.betas[1],
-                         self.eps, self.step_state.data_ptr())
+        c0, c1 = ranges[0]
+        if part is not None:
+            n = c1 - c0
+            c0, c1 = c0 + int(round(n * part[0])), c0 + int(round(n * part[1]))
+        return AdamRange(len(self.params), self._table.data_ptr(), c0, c1, self.betas[0], self.betas[1],
+                         self.eps, self.step_state.data_ptr(), int(after_advance))
 
     def step_tail(self, groups, freq_job=None, freq_param=None, next_view=None):
         """the closing piece of a step: ``groups`` (neighbours in the table) are updated, the counter advances,

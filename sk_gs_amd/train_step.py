@@ -94,11 +94,23 @@ class FusedTrainStep:
     and measured: the launch grows by 15 us, more than the short launch costs.)  Same arithmetic as
     ``step.forward_backward(); optimizer.step()`` (tests/test_gpu_optim.py: bit-identical updates).  Falls back to exactly
     that when the step has no fused network (or ``enable=False``).  With a ``ViewTable`` whose order was set
-    (``set_order``) the closing launch also selects the next view: no per-step ``select``."""
+    (``set_order``) the closing launch also selects the next view: no per-step ``select``.
+
+    ``pre_forward`` (needs that ordered table): the step ENDS with the skeleton-forward launch of the NEXT view -- the slot
+    already names it, network and joints already carry this step's update -- and the rows' update is split between the
+    two 32-workgroup launches, ``ROWS_IN_BACKWARD`` of the chunks beside the skeleton backward, the rest beside that forward
+    (after the counter moved: ``skgs_adam_range.after_advance``).  Every parameter is final when the step returns; the next
+    step starts at the skinning.  Call ``prime()`` once before the first step (and after anything that changes network,
+    joints or the slot from outside: a restore, a ``select``).  Measured (tools/time_skeleton.py, the two launches alone):
+    100k Gaussians 90 -> 90 us (the whole update already hides beside the backward, and the stream slows the network's
+    hand-offs wherever it runs), 200k 125 -> 100, 500k 251 -> 227.  ``pre_forward='auto'`` therefore switches it on only
+    when the rows' update moves more than ``AUTO_BYTES``."""
 
     ROW_GROUPS = ('xyz', 'f_dc', 'f_rest', 'opacity', 'scaling', 'rotation', 'sp_W')
+    ROWS_IN_BACKWARD = 0.6   # ~ backward launch time / (backward + forward launch time) of the bare skeleton stage
+    AUTO_BYTES = 330e6       # 28 B per element: ~150k Gaussians with degree-3 SH and 20 bones
 
-    def __init__(self, step, optimizer, enable: bool = True):
+    def __init__(self, step, optimizer, enable: bool = True, pre_forward: bool = False):
         self.step, self.optimizer = step, optimizer
         names = [g.get('name') for g in optimizer.param_groups]
         self.rows = [n for n in names if n in self.ROW_GROUPS]
@@ -106,10 +118,21 @@ class FusedTrainStep:
         self.fused = bool(enable and self.rows and self.rest and getattr(step, '_mlp_fused', None) is not None
                           and step.spw_logit_grad is None and step.sh_factors is None
                           and len(optimizer._chunk_ranges(self.rows)) == 1 and len(optimizer._chunk_ranges(self.rest)) == 1)
-        step.side_optimizer = (optimizer, self.rows) if self.fused else None
+        self.set_pre_forward(pre_forward)
         # the joints' gradient through the network input is completed by the optimizer's closing launch
         self.joints = step.model.joints if (self.fused and step.input_grad_job() is not None) else None
         step.defer_input_grad = self.joints is not None
+
+    def set_pre_forward(self, on: bool):
+        """switch the mode (off: before anything else uses the step's ``forward`` or selects views by hand)"""
+        step = self.step
+        if on == 'auto':
+            on = self.fused and 28 * sum(p.numel() for g in self.optimizer.param_groups if g.get('name') in self.rows
+                                         for p in g['params']) > self.AUTO_BYTES
+        self.pre_forward = bool(on and self.fused and step.view_table is not None)
+        part = (0.0, self.ROWS_IN_BACKWARD) if self.pre_forward else None
+        step.side_optimizer = (self.optimizer, self.rows, part) if self.fused else None
+        step.skeleton_ahead = self.pre_forward
 
     def __call__(self, rs=None, time_id=None, target=None):
         self.step.forward_backward(rs, time_id, target)
@@ -118,5 +141,14 @@ class FusedTrainStep:
             vt  = self.step.view_table
             self.optimizer.step_tail(self.rest, freq_job=job, freq_param=self.joints,
                                      next_view=vt.advance() if (vt is not None and rs is None) else None)
+            if self.pre_forward:
+                assert rs is None and vt.advance() is not None, 'pre_forward steps take their views from the ordered table'
+                self.step.skeleton_forward(None, side_adam=self.optimizer.side_range(
+                    self.rows, (self.ROWS_IN_BACKWARD, 1.0), after_advance=True))
         else:
             self.optimizer.step()
+
+    def prime(self):
+        """pre_forward: the skeleton stage of the view in the slot, before the first step"""
+        if self.pre_forward:
+            self.step.skeleton_forward(None)

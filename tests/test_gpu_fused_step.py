@@ -427,6 +427,51 @@ def test_ordered_view_table_is_advanced_by_the_closing_launch():
     assert table.advance() is None
 
 
+@pytest.mark.parametrize('graphed', [False, True])
+def test_pre_forward_steps_render_from_the_skeleton_state_of_the_current_parameters(graphed):
+    """``FusedTrainStep(pre_forward=True)``: the step ends with the NEXT view's skeleton-forward launch (which also carries
+    the tail of the rows' Adam update, tests/test_gpu_optim.py).  With a real learning rate: the image every step renders
+    from that carried-over skeleton state is bit-identical to a fresh forward of the slot's view with the parameters as they
+    are, the views follow the order, and the last rows of the optimizer table (the forward launch's share) do move"""
+    from sk_gs_amd import scene
+    from sk_gs_amd.fused_step import FusedViewStep
+    from sk_gs_amd.model import SkinnedGaussians
+    from sk_gs_amd.optim import FusedAdam
+    from sk_gs_amd.train_step import FusedTrainStep, GraphedSteps
+    from sk_gs_amd.view_slot import ViewTable
+    P, M, K, W, H, V = 6000, 12, 4, 96, 64, 4
+    dev = torch.device('cuda')
+    cams = [scene.make_camera(W, H, seed=70 + v) for v in range(V)]
+    settings = [scene.raster_settings_from_camera(c, sh_degree=3, colmap=True, device=dev) for c in cams]
+    targets = torch.rand(V, 3, H, W, generator=torch.Generator().manual_seed(3)).to(dev)
+    order = [2, 0, 3, 1]
+    model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=V, seed=6, scale_mult=2.0, deform_net=True,
+                             learn_joints=True).to(dev)
+    table = ViewTable(settings, [float(model.frame_times[v]) for v in range(V)], list(range(V)), targets, dev)
+    step = FusedViewStep(model, W, H, capacity=600_000, view_table=table)
+    opt = FusedAdam(model.param_groups(lr=2e-3))
+    train = FusedTrainStep(step, opt, pre_forward=True)
+    assert train.fused and train.pre_forward and step.skeleton_ahead
+    table.set_order(order)
+    train.prime()
+    run = GraphedSteps(lambda _: train(), collect_garbage=False) if graphed else (lambda _: train())
+    for i in range(9):
+        v = order[i % len(order)]
+        assert torch.equal(table.slot, table.records[v]), i
+        step.skeleton_ahead = False          # reference: the whole forward, skeleton stage included, from scratch
+        step.forward()
+        ref = step.image.clone()
+        step.skeleton_ahead = True
+        before = [p.detach().clone() for p in (model.sp_W, model._xyz, model.joints)]
+        run(0)
+        torch.cuda.synchronize()
+        assert torch.equal(step.image, ref), i
+        assert all(not torch.equal(a, b) for a, b in zip(before, (model.sp_W, model._xyz, model.joints))), i
+        assert float(opt.step_count.item()) == i + 1 and step.status()['mlp_failed'] == 0
+    train.set_pre_forward(False)
+    assert not step.skeleton_ahead and step.side_optimizer[2] is None
+
+
 @pytest.mark.parametrize('M,K', [(1, 1), (3, 2)])
 def test_fused_step_with_one_or_few_bones_matches_autograd(M, K):
     """M = 1 (a single bone: root only, one tree level) up to a handful -- the network's row count, the chain's

@@ -181,6 +181,70 @@ def test_adam_rows_as_the_side_job_of_the_network_backward_launch():
         assert torch.equal(ref.state[p]['exp_avg_sq'], side.state[q]['exp_avg_sq'])
 
 
+def test_rows_split_between_the_backward_launch_and_the_next_forward_launch():
+    """the pre-forward schedule of ``FusedTrainStep``: 60 % of the rows' chunks beside the skeleton backward, the closing piece
+    (counter moves), the other 40 % beside the NEXT skeleton-forward launch with ``after_advance`` -- bit-identical to one
+    ``step()``, and the forward launch's own outputs (heads, bone transforms) are those of the launch alone"""
+    from sk_gs_amd.deform_net import BoneChainDesc, FusedDeformMLP
+    from sk_gs_amd.model import SkinnedGaussians
+    from sk_gs_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    M = 20
+    model = SkinnedGaussians(500, M, 4, sh_degree=0, num_frames=3, seed=5, deform_net=True, learn_joints=True).cuda()
+    mlp, topo = model.sk_deform_net, model.topology()
+    joints, t = model.joints.detach().contiguous(), torch.tensor([0.37], device='cuda')
+    gT = model.global_tr.detach()[1].contiguous()
+    f32 = dict(dtype=torch.float32, device='cuda')
+    net = mlp.dynamic_net
+    params = [p for l in net.net for p in (l.weight, l.bias)] + [net.last_weight, net.last_bias]
+    gh = [torch.randn((M, 4), **f32), torch.randn((M, 4), **f32), torch.randn((M, 3), **f32)]
+    grads, gx = [torch.zeros_like(p) for p in params], torch.zeros(M, net.in_channels, **f32)
+    g_bone_T, g_j, g_g = torch.randn(M, 7, **f32), torch.zeros(M, 3, **f32), torch.zeros(7, **f32)
+
+    def outputs():
+        heads = [torch.empty((M, 4), **f32), torch.empty((M, 4), **f32), torch.empty((M, 3), **f32)]
+        bone_T, chain_A = torch.zeros(M, 7, **f32), torch.zeros(M, 7, **f32)
+        b = BoneChainDesc()
+        b.M, b.root, b.num_levels = M, topo['root'], topo['num_levels']
+        b.parents, b.level_nodes, b.level_start = (topo[k].data_ptr() for k in ('parents', 'level_nodes', 'level_start'))
+        b.joints, b.global_T, b.bone_T, b.chain_A = joints.data_ptr(), gT.data_ptr(), bone_T.data_ptr(), chain_A.data_ptr()
+        b.sk_r_raw, b.g_bone_T, b.g_joints, b.g_global_T = heads[0].data_ptr(), g_bone_T.data_ptr(), g_j.data_ptr(), g_g.data_ptr()
+        return heads, bone_T, chain_A, b
+    names = ['xyz', 'f_dc', 'f_rest', 'opacity', 'sp_W', 'net']
+    shapes = [(30011, 3), (30011, 1, 3), (30011, 15, 3), (30011, 1), (30011, 20), (129, 7)]
+
+    def make():
+        gen = torch.Generator().manual_seed(2)
+        ps = [torch.nn.Parameter(torch.randn(*s, generator=gen).cuda()) for s in shapes]
+        opt = FusedAdam([{'params': [p], 'lr': 1e-2 * (i + 1), 'name': n} for i, (p, n) in enumerate(zip(ps, names))])
+        return ps, opt
+    (a, ref), (b_, split) = make(), make()
+    rows = names[:5]
+    run = FusedDeformMLP(mlp, M)
+    alone, riding = outputs(), outputs()
+    run.forward(joints, t, head_out=alone[0], bones=alone[3])
+    gen = torch.Generator().manual_seed(3)
+    for it in range(3):
+        for p, q in zip(a, b_):
+            gr = torch.randn(p.shape, generator=gen).cuda()
+            p.grad.copy_(gr), q.grad.copy_(gr)
+        ref.step()
+        head = split.side_range(rows, (0.0, 0.6))
+        tail = split.side_range(rows, (0.6, 1.0), after_advance=True)
+        assert head.chunk_end == tail.chunk_begin and tail.chunk_end == split._chunk_ranges(rows)[0][1]
+        run.backward(joints, t, gh, grads, gx, bones=riding[3], side_adam=head)
+        split.step_tail(['net'])
+        assert float(split.step_count.item()) == it + 1.0
+        run.forward(joints, t, head_out=riding[0], bones=riding[3], side_adam=tail)
+        for x, y in zip(alone[0] + list(alone[1:3]), riding[0] + list(riding[1:3])):
+            assert torch.equal(x, y)
+        for p, q in zip(a, b_):
+            assert torch.equal(p, q), it
+            assert torch.equal(ref.state[p]['exp_avg'], split.state[q]['exp_avg'])
+            assert torch.equal(ref.state[p]['exp_avg_sq'], split.state[q]['exp_avg_sq'])
+    assert run.status()['failed'] == 0
+
+
 def test_closing_piece_with_the_encoder_backward_in_the_joints_workgroup():
     """the tail of a fused step: rows as the side job of the network's backward launch, then ``skgs_adam_step_tail`` over
     tables + network + joints with the frequency-encoding backward run by the workgroup that updates the joints -- against

@@ -89,3 +89,34 @@ torch.cuda.synchronize()
 st = run.workspace[64:256].view(torch.int32).cpu().tolist()
 for i, name in zip(range(13, 16), ('chain (8 hops)', 'input gradient', 'weight gradients')):
     print(f'  with side job, backward {name:>18}: +{((st[2 * i] - st[2 * i - 2]) & 0xffffffff) * 10} ns')
+
+# ---- the rows' update split between the backward launch and the (next view's) forward launch: time of the pair
+def pair_time(frac, P):
+    rows = [torch.nn.Parameter(torch.randn(P, n, **f32)) for n in (3, 3, 45, 1, 3, 4, 20)]
+    for p in rows:
+        p.grad = torch.randn_like(p)
+    opt = FusedAdam([{'params': [p], 'lr': 1e-5, 'name': n} for p, n in zip(rows, names)])
+    head = opt.side_range(names, (0.0, frac)) if frac > 0 else None
+    tail = opt.side_range(names, (frac, 1.0), after_advance=True) if frac < 1 else None
+    def pair():
+        run.backward(joints, t, gh, grads, gx, bones=b, side_adam=head)
+        run.forward(joints, t, head_out=heads, bones=b, side_adam=tail)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        pair()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            for _ in range(20):
+                pair()
+        graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            graph.replay()
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / 400 * 1e6
+run.workspace[8:12].view(torch.int32).fill_(0)
+for P in (100_000, 200_000, 500_000):
+    print(f'P={P}: backward + forward launch pair, rows split:',
+          ', '.join(f'{f:.2f}: {pair_time(f, P):.1f} us' for f in (1.0, 0.7, 0.6, 0.5)), run.status())
