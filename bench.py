@@ -426,7 +426,27 @@ def main():
                 fstep.scatter_spw_grad()
             opt.step()
 
-        fused_update = False
+        fused_update, train_n = False, None
+        if (use_dist and not args.autograd and not args.torch_adam and not args.serial_adam and view_table is not None
+                and not args.select_per_step and args.pre_forward != 'off'):
+            # view-parallel ranks: the update is the closing launch + the NEXT view's skeleton forward with the rows' Adam on
+            # its idle CUs (instead of a full Adam launch now and a bare skeleton forward in the next step); every rank
+            # walks its own views in the loop's order
+            from sk_gs_amd.train_step import FusedTrainStep
+            train_n = FusedTrainStep(fstep, opt, pre_forward=True, reduce_between=True)
+            if train_n.pre_forward:
+                view_table.set_order([vp.view_index(i, args.views) for i in range(args.views)])
+                train_n.prime()
+                plain_update = update
+
+                def update(_=0):  # noqa: F811
+                    if sh_factored:
+                        fstep.sh_grads_from_factors(fac_all, 3)
+                    if compact:
+                        fstep.scatter_spw_grad()
+                    train_n.update()
+            else:
+                train_n = None
         if not use_dist and not args.autograd and not args.torch_adam and not args.serial_adam:
             from sk_gs_amd.train_step import FusedTrainStep
             train1 = FusedTrainStep(fstep, opt)
@@ -534,7 +554,19 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ordered_views = view_table is not None and getattr(view_table, 'order', None) is not None
-    pre_forward_used = bool(not pipelined and fused_update and train1.pre_forward)
+    closing = '; network, joints, tables + counter (+ the encoder backward of the joints) in one closing launch'
+    if pipelined:
+        adam_desc = 'one launch per bucket'
+    elif train_n is not None:
+        adam_desc = ('after the all-reduce: closing launch (network, joints, tables, counter, next view), then the NEXT view\'s '
+                     'skeleton-forward launch with the per-Gaussian rows on its 224 idle CUs')
+    elif fused_update and train1.pre_forward:
+        adam_desc = ('per-Gaussian rows on the idle CUs of the two skeleton-stage launches (60 % beside the backward, 40 % beside '
+                     'the NEXT view\'s forward, which closes the step)' + closing)
+    elif fused_update:
+        adam_desc = 'per-Gaussian rows inside the skeleton stage\'s backward launch (its 224 idle CUs)' + closing
+    else:
+        adam_desc = 'one launch after the backward'
     prof = _C.profile_collect()
     _C.profile_enable([])
     if use_dist:
@@ -577,7 +609,7 @@ def main():
     _C.profile_enable([])
     if ordered_views:
         view_table.clear_order()  # the measurements below select their views explicitly
-        train1.set_pre_forward(False)
+        (train1 if fused_update else train_n).set_pre_forward(False)
 
     # ---- BASELINE's second metric and the reference's FPS protocol (test.py:56-81,102-123: warm-up, then N renders between
     # two events): 20 warm-up + 200 timed iterations, HIP events on the launch stream
@@ -705,12 +737,7 @@ def main():
                        if args.deform_net and M > 0 else 'per-frame tables (test-time cache, sk_gs.py:1080-1085): NOT the '
                                                          'reference\'s training step',
                        'joints': 'trained, lr x 0.1 (sk_gs.py:607)' if model.learn_joints else 'fixed',
-                       'adam': ((('per-Gaussian rows on the idle CUs of the two skeleton-stage launches (60 % beside the backward, 40 % '
-                                  'beside the NEXT view\'s forward, which closes the step)' if pre_forward_used else
-                                  'per-Gaussian rows inside the skeleton stage\'s backward launch (its 224 idle CUs)')
-                                 + '; network, joints, tables + counter (+ the encoder backward of the joints) in one closing launch')
-                                if (not pipelined and fused_update) else 'one launch after the backward') if not pipelined
-                       else 'one launch per bucket',
+                       'adam': adam_desc,
                        'step': 'autograd operator path' if args.autograd else 'FusedViewStep (direct C-ABI calls)',
                        'replicas_identical': replicas_identical, 'param_digest': param_digest},
             'roofline': {'bound': 'hbm', 'kernel': 'render_backward', 'achieved': round(achieved, 2),

@@ -104,23 +104,32 @@ class FusedTrainStep:
     joints or the slot from outside: a restore, a ``select``).  Measured (tools/time_skeleton.py, the two launches alone):
     100k Gaussians 90 -> 90 us (the whole update already hides beside the backward, and the stream slows the network's
     hand-offs wherever it runs), 200k 125 -> 100, 500k 251 -> 227.  ``pre_forward='auto'`` therefore switches it on only
-    when the rows' update moves more than ``AUTO_BYTES``."""
+    when the rows' update moves more than ``AUTO_BYTES``.
+
+    ``reduce_between`` (view-parallel ranks): a gradient all-reduce runs between the backward and the update, so nothing of
+    the optimizer can ride on the backward launch.  The step is then two calls, ``backward()`` -- all-reduce -- ``update()``;
+    with ``pre_forward`` the update is the closing launch (network, joints, tables, counter, next view) followed by the next
+    view's skeleton-forward launch with ALL rows as its side job: two launches (9 + ~50 us at 100k Gaussians) where a full Adam
+    launch and, in the next step, a bare skeleton forward were (41 + 32 us)."""
 
     ROW_GROUPS = ('xyz', 'f_dc', 'f_rest', 'opacity', 'scaling', 'rotation', 'sp_W')
     ROWS_IN_BACKWARD = 0.6   # ~ backward launch time / (backward + forward launch time) of the bare skeleton stage
     AUTO_BYTES = 330e6       # 28 B per element: ~150k Gaussians with degree-3 SH and 20 bones
 
-    def __init__(self, step, optimizer, enable: bool = True, pre_forward: bool = False):
+    def __init__(self, step, optimizer, enable: bool = True, pre_forward: bool = False, reduce_between: bool = False):
         self.step, self.optimizer = step, optimizer
+        self.reduce_between = bool(reduce_between)
         names = [g.get('name') for g in optimizer.param_groups]
         self.rows = [n for n in names if n in self.ROW_GROUPS]
         self.rest = [n for n in names if n not in self.ROW_GROUPS]
+        # (rows rebuilt after the backward -- compact logit gradient, SH factors -- are final only when update() starts)
         self.fused = bool(enable and self.rows and self.rest and getattr(step, '_mlp_fused', None) is not None
-                          and step.spw_logit_grad is None and step.sh_factors is None
+                          and (reduce_between or (step.spw_logit_grad is None and step.sh_factors is None))
                           and len(optimizer._chunk_ranges(self.rows)) == 1 and len(optimizer._chunk_ranges(self.rest)) == 1)
         self.set_pre_forward(pre_forward)
-        # the joints' gradient through the network input is completed by the optimizer's closing launch
-        self.joints = step.model.joints if (self.fused and step.input_grad_job() is not None) else None
+        # the joints' gradient through the network input is completed by the optimizer's closing launch (one rank; with an
+        # all-reduce in between the backward completes it itself: the exchange needs the whole gradient)
+        self.joints = step.model.joints if (self.fused and not reduce_between and step.input_grad_job() is not None) else None
         step.defer_input_grad = self.joints is not None
 
     def set_pre_forward(self, on: bool):
@@ -131,10 +140,26 @@ class FusedTrainStep:
                                          for p in g['params']) > self.AUTO_BYTES
         self.pre_forward = bool(on and self.fused and step.view_table is not None)
         part = (0.0, self.ROWS_IN_BACKWARD) if self.pre_forward else None
-        step.side_optimizer = (self.optimizer, self.rows, part) if self.fused else None
+        step.side_optimizer = (self.optimizer, self.rows, part) if (self.fused and not self.reduce_between) else None
         step.skeleton_ahead = self.pre_forward
 
+    def backward(self, rs=None, time_id=None, target=None):
+        """``reduce_between``: forward + backward of the view (the gradients then go through the all-reduce)"""
+        self.step.forward_backward(rs, time_id, target)
+
+    def update(self):
+        """``reduce_between``: the optimizer step on the reduced gradients"""
+        assert self.reduce_between
+        if not self.pre_forward:
+            self.optimizer.step()
+            return
+        vt = self.step.view_table
+        assert vt.advance() is not None, 'pre_forward steps take their views from the ordered table'
+        self.optimizer.step_tail(self.rest, next_view=vt.advance())
+        self.step.skeleton_forward(None, side_adam=self.optimizer.side_range(self.rows, after_advance=True))
+
     def __call__(self, rs=None, time_id=None, target=None):
+        assert not self.reduce_between, 'a step with an all-reduce in it is backward() ... update()'
         self.step.forward_backward(rs, time_id, target)
         if self.fused:
             job = self.step.input_grad_job() if self.joints is not None else None

@@ -427,12 +427,13 @@ def test_ordered_view_table_is_advanced_by_the_closing_launch():
     assert table.advance() is None
 
 
-@pytest.mark.parametrize('graphed', [False, True])
-def test_pre_forward_steps_render_from_the_skeleton_state_of_the_current_parameters(graphed):
+@pytest.mark.parametrize('graphed,reduce_between', [(False, False), (True, False), (True, True)])
+def test_pre_forward_steps_render_from_the_skeleton_state_of_the_current_parameters(graphed, reduce_between):
     """``FusedTrainStep(pre_forward=True)``: the step ends with the NEXT view's skeleton-forward launch (which also carries
     the tail of the rows' Adam update, tests/test_gpu_optim.py).  With a real learning rate: the image every step renders
     from that carried-over skeleton state is bit-identical to a fresh forward of the slot's view with the parameters as they
-    are, the views follow the order, and the last rows of the optimizer table (the forward launch's share) do move"""
+    are, the views follow the order, and the last rows of the optimizer table (the forward launch's share) do move.
+    ``reduce_between``: the view-parallel form, backward() | (all-reduce) | update(), as two graphs"""
     from sk_gs_amd import scene
     from sk_gs_amd.fused_step import FusedViewStep
     from sk_gs_amd.model import SkinnedGaussians
@@ -450,11 +451,17 @@ def test_pre_forward_steps_render_from_the_skeleton_state_of_the_current_paramet
     table = ViewTable(settings, [float(model.frame_times[v]) for v in range(V)], list(range(V)), targets, dev)
     step = FusedViewStep(model, W, H, capacity=600_000, view_table=table)
     opt = FusedAdam(model.param_groups(lr=2e-3))
-    train = FusedTrainStep(step, opt, pre_forward=True)
+    train = FusedTrainStep(step, opt, pre_forward=True, reduce_between=reduce_between)
     assert train.fused and train.pre_forward and step.skeleton_ahead
+    assert (step.side_optimizer is None) == reduce_between and step.defer_input_grad != reduce_between
     table.set_order(order)
     train.prime()
-    run = GraphedSteps(lambda _: train(), collect_garbage=False) if graphed else (lambda _: train())
+    if reduce_between:
+        g_bwd = GraphedSteps(lambda _: train.backward(), collect_garbage=False)
+        g_upd = GraphedSteps(lambda _: train.update(), collect_garbage=False)
+        run = lambda _: (g_bwd(0), g_upd(0))  # noqa: E731
+    else:
+        run = GraphedSteps(lambda _: train(), collect_garbage=False) if graphed else (lambda _: train())
     for i in range(9):
         v = order[i % len(order)]
         assert torch.equal(table.slot, table.records[v]), i
@@ -469,7 +476,7 @@ def test_pre_forward_steps_render_from_the_skeleton_state_of_the_current_paramet
         assert all(not torch.equal(a, b) for a, b in zip(before, (model.sp_W, model._xyz, model.joints))), i
         assert float(opt.step_count.item()) == i + 1 and step.status()['mlp_failed'] == 0
     train.set_pre_forward(False)
-    assert not step.skeleton_ahead and step.side_optimizer[2] is None
+    assert not step.skeleton_ahead and (reduce_between or step.side_optimizer[2] is None)
 
 
 @pytest.mark.parametrize('M,K', [(1, 1), (3, 2)])

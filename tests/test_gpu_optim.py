@@ -181,10 +181,12 @@ def test_adam_rows_as_the_side_job_of_the_network_backward_launch():
         assert torch.equal(ref.state[p]['exp_avg_sq'], side.state[q]['exp_avg_sq'])
 
 
-def test_rows_split_between_the_backward_launch_and_the_next_forward_launch():
+@pytest.mark.parametrize('in_backward', [0.6, 0.0])
+def test_rows_split_between_the_backward_launch_and_the_next_forward_launch(in_backward):
     """the pre-forward schedule of ``FusedTrainStep``: 60 % of the rows' chunks beside the skeleton backward, the closing piece
     (counter moves), the other 40 % beside the NEXT skeleton-forward launch with ``after_advance`` -- bit-identical to one
-    ``step()``, and the forward launch's own outputs (heads, bone transforms) are those of the launch alone"""
+    ``step()``, and the forward launch's own outputs (heads, bone transforms) are those of the launch alone.  0.0: the
+    view-parallel schedule (``reduce_between``), every row beside the forward"""
     from sk_gs_amd.deform_net import BoneChainDesc, FusedDeformMLP
     from sk_gs_amd.model import SkinnedGaussians
     from sk_gs_amd.optim import FusedAdam
@@ -229,9 +231,10 @@ def test_rows_split_between_the_backward_launch_and_the_next_forward_launch():
             gr = torch.randn(p.shape, generator=gen).cuda()
             p.grad.copy_(gr), q.grad.copy_(gr)
         ref.step()
-        head = split.side_range(rows, (0.0, 0.6))
-        tail = split.side_range(rows, (0.6, 1.0), after_advance=True)
-        assert head.chunk_end == tail.chunk_begin and tail.chunk_end == split._chunk_ranges(rows)[0][1]
+        head = split.side_range(rows, (0.0, in_backward)) if in_backward else None
+        tail = split.side_range(rows, (in_backward, 1.0), after_advance=True)
+        assert tail.chunk_end == split._chunk_ranges(rows)[0][1]
+        assert tail.chunk_begin == (head.chunk_end if head is not None else split._chunk_ranges(rows)[0][0])
         run.backward(joints, t, gh, grads, gx, bones=riding[3], side_adam=head)
         split.step_tail(['net'])
         assert float(split.step_count.item()) == it + 1.0
