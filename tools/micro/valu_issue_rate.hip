@@ -16,7 +16,7 @@ __global__ void __launch_bounds__(256) chain_kernel(float* out, float seed) {
   float2v p[UNROLL];
   for (int i = 0; i < UNROLL; ++i) a[i] = seed + i + threadIdx.x, p[i] = float2v{a[i], a[i] + 1.f};
   const float m = 1.0000001f, c = 1e-9f;
-  const unsigned long long mask = __builtin_amdgcn_ballot_w64((threadIdx.x & 1) != 0);
+  unsigned long long mask = __builtin_amdgcn_ballot_w64((threadIdx.x & 1) != 0);
   int sg = 0;
   asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a[0]), "v"(m) : "vcc");
   for (int it = 0; it < ITERS; ++it) {
@@ -40,6 +40,12 @@ __global__ void __launch_bounds__(256) chain_kernel(float* out, float seed) {
       if (KIND == 15) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
       if (KIND == 16) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
       if (KIND == 17) asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sg) : "v"(a[i]));
+      if (KIND == 19) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m));
+      if (KIND == 20) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m) : "vcc");
+      if (KIND == 21) asm volatile("v_cmp_lt_f32_e64 %1, %0, %2\n\tv_cndmask_b32_e64 %0, %0, %2, %1" : "+v"(a[i]), "+s"(mask) : "v"(m));
+      if (KIND == 22) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\ts_nop 0\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m) : "vcc");
+      if (KIND == 23 && (i & 3) == 0) asm volatile("v_cmp_lt_f32 vcc, %0, %4\n\tv_cndmask_b32 %0, %0, %4, vcc\n\tv_cndmask_b32 %1, %1, %4, vcc\n\tv_cndmask_b32 %2, %2, %4, vcc\n\tv_cndmask_b32 %3, %3, %4, vcc" : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]) : "v"(m) : "vcc");
+      if (KIND == 24 && (i & 3) == 0) asm volatile("v_cmp_lt_f32 vcc, %0, %4\n\tv_cndmask_b32_e64 %0, %0, %4, vcc\n\tv_cndmask_b32_e64 %1, %1, %4, vcc\n\tv_cndmask_b32_e64 %2, %2, %4, vcc\n\tv_cndmask_b32_e64 %3, %3, %4, vcc" : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]) : "v"(m) : "vcc");
       if (KIND == 18) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(a[i]) : "v"(a[(i + 1) % UNROLL]), "v"(m));
     }
   }
@@ -85,6 +91,12 @@ int main() {
   run<7>("v_cmp_lt_f32", d_out, cus);
   run<9>("v_cndmask_b32 (sgpr mask)", d_out, cus);
   run<18>("v_cndmask_b32 (3 registers)", d_out, cus);
+  run<19>("v_cndmask_b32_e64 vcc", d_out, cus);
+  run<20>("v_cmp vcc + v_cndmask vcc (pair)", d_out, cus);
+  run<22>("v_cmp vcc + s_nop + v_cndmask", d_out, cus);
+  run<21>("v_cmp sgpr + v_cndmask sgpr", d_out, cus);
+  run<23>("(v_cmp + 4 v_cndmask e32) / 4", d_out, cus);
+  run<24>("(v_cmp + 4 v_cndmask e64) / 4", d_out, cus);
   run<6>("v_permlane32_swap_b32", d_out, cus);
   run<12>("v_permlane16_swap_b32", d_out, cus);
   run<13>("v_mov_b32 dpp row_bcast:31", d_out, cus);

@@ -22,6 +22,14 @@ for v in "--bone-tables" "--layered-mlp" "--graph-per-view" "--autograd" "--comp
   python bench.py $v --no-cpu-baseline --no-ms-per-render 2>/dev/null | tail -1 > "$out/bench_variant${v}.json"
   python -c "import json; d=json.load(open('$out/bench_variant${v}.json')); print('variant $v', d['value'], d['ms_per_step'])"
 done
+for c in 2 3 4; do
+  python bench.py --config $c --steps 100 --warmup 10 --no-cpu-baseline --no-ms-per-render --pre-forward off 2>/dev/null | tail -1 > $out/bench_config${c}_pre-forward-off.json
+  python -c "import json; d=json.load(open('$out/bench_config${c}_pre-forward-off.json')); print('config $c --pre-forward off', d['value'], d['ms_per_step'])"
+done
+SKGS_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29542 bench.py --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline --no-ms-per-render --pre-forward off 2>/dev/null | tail -1 > $out/bench_rccl_1rank_pre-forward-off.json
+python -c "import json; d=json.load(open('$out/bench_rccl_1rank_pre-forward-off.json')); print('1-rank RCCL group --pre-forward off', d['value'], d['ms_per_step'])"
+python tools/time_skeleton.py 2>/dev/null | grep -v "^$" > $out/time_skeleton.txt; tail -4 $out/time_skeleton.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_issue_rate tools/micro/valu_issue_rate.hip 2>/dev/null && /tmp/valu_issue_rate > $out/valu_issue_rate.txt 2>&1; /tmp/valu_issue_rate >> $out/valu_issue_rate.txt 2>&1; tail -20 $out/valu_issue_rate.txt
 python tools/time_mlp.py 2>/dev/null | grep "fused\|backward\|prologue" > $out/time_mlp.txt; cat $out/time_mlp.txt
 python tools/time_densify.py 2>/dev/null | tail -2 > $out/time_densify.txt; cat $out/time_densify.txt
 bash tools/profile_round.sh ${tag}_c1 > /dev/null 2>&1; ls gpurun_out/${tag}_c1 | head
