@@ -702,8 +702,16 @@ def main():
                         # instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles on a SIMD-32)
                         peak = 256 * 4 * 2.4e9 / 2
                         ach = rec['valu_insts_per_launch'] / (rec['avg_us'] * 1e-6)
-                        from_profile['valu'] = dict(bound='valu', achieved=round(ach / 1e9, 1), peak=round(peak / 1e9, 1),
-                                                    unit='G wave-instructions/s', frac=round(ach / peak, 4))
+                        from_profile['valu'] = dict(
+                            bound='valu', achieved=round(ach / 1e9, 1), peak=round(peak / 1e9, 1),
+                            unit='G wave-instructions/s', frac=round(ach / peak, 4),
+                            # measured on this chip (tools/micro/valu_issue_rate.hip, profiles/*_valu_issue_rate.txt): plain
+                            # fp32 / integer ops ~1000 G/s, DPP / compares / selects ~570, permlane swaps, exp, rcp ~300
+                            peak_measured_plain=1000.0, frac_of_measured=round(ach / 1000.0e9, 4),
+                            busy=round(rec['valubusy'] / 100.0, 4) if rec.get('valubusy') else None,
+                            note='busy = share of the kernel\'s time its SIMDs spend issuing VALU work: the distance from the '
+                                 'ceiling of ITS OWN instruction mix (45 % of the issue clocks of a visit are the cross-lane '
+                                 'reduction: 6 permlane swaps, 11 DPP adds)')
             except Exception:
                 from_profile = None
         line = {
