@@ -57,7 +57,9 @@ class OverflowGuard:
     @torch.no_grad()
     def after_step(self, iteration: int) -> Optional[Tuple[str, int]]:
         """call after iteration ``iteration`` has been issued.  Returns None, or ('redo', first_iteration): the state has
-        been rolled back to the snapshot taken before ``first_iteration``; grow the capacity, re-capture, replay from it."""
+        been rolled back to the snapshot taken before ``first_iteration``; grow the capacity, re-capture, replay from it
+        (a ``FusedTrainStep(pre_forward=True)`` carries the NEXT view's skeleton state across steps: ``prime()`` it again
+        after the roll-back, once the view to resume from is in the slot)."""
         if (iteration + 1) % self.every:
             return None
         events = self.step.status()['overflow_events']  # synchronises: once per interval
