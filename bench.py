@@ -328,7 +328,7 @@ def main():
     def gkey(v):  # graphs are keyed by view only when the view is baked into them
         return 0 if view_table is not None else v
 
-    capture_views = [0] if view_table is not None else list(range(args.views))
+    capture_views = [vp.view_index(0, args.views)] if view_table is not None else list(range(args.views))
     if not args.autograd:
         from sk_gs_amd.fused_step import FusedViewStep
         fstep = FusedViewStep(model, W, H, capacity=int(R_max * 1.25 * _C.config.capacity_growth) + 1024,
@@ -534,9 +534,18 @@ def main():
 
     train_step = eager_step if args.eager else graph_step
 
+    def rewind_views():
+        """ordered view table: the set-up steps below consumed views; step i of the loops renders view_index(i) again, as
+        with explicit selection (and the carried-over skeleton state is rebuilt for that view)"""
+        if view_table is not None and getattr(view_table, 'order', None) is not None:
+            view_table.rewind()
+            (train1 if fused_update else train_n).prime()
+
     eager_step(0)  # initialises optimizer state before any capture
+    rewind_views()
     if not args.eager:  # every graph exists before the timed region, whatever --warmup is
         capture_all()
+        rewind_views()
     for i in range(args.warmup):
         train_step(i)
     torch.cuda.synchronize()

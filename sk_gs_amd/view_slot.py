@@ -95,6 +95,12 @@ class ViewTable:
         self.cursor = torch.ones(1, dtype=torch.int32, device=dev)  # the next view to load is order[1]
         self.select(int(order[0]))
 
+    def rewind(self):
+        """back to ``order[0]``, in place (captured graphs keep pointing at the same order / cursor storage)"""
+        assert getattr(self, 'order', None) is not None
+        self.cursor.fill_(1)
+        self.select(int(self.order[0].item()))
+
     def clear_order(self):
         """back to explicit ``select`` calls"""
         self.order = None

@@ -32,7 +32,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
 @pytest.mark.parametrize('port,ranks,extra', [(29577, 2, []), (29578, 2, ['--pipeline']), (29579, 2, ['--compact-logits']),
                                               (29580, 2, ['--autograd']), (29581, 4, []), (29582, 2, ['--sh-factors']),
                                               (29583, 2, ['--sh-factors', '--overlap-gather']), (29584, 2, ['--bone-tables']),
-                                              (29587, 2, ['--graph-per-view'])])
+                                              (29587, 2, ['--graph-per-view']), (29588, 2, ['--pre-forward', 'off'])])
 def test_ranks_share_the_gpu_and_stay_identical(port, ranks, extra):
     """The driver's multi-GPU launch line with 2 or 4 ranks on this one GPU (gloo moves the gradients: RCCL refuses two ranks
     per device): the real view-parallel schedule -- graph(fwd+bwd) | all-reduce | graph(Adam) -- must keep the replicas
@@ -52,6 +52,9 @@ def test_ranks_share_the_gpu_and_stay_identical(port, ranks, extra):
     par = d['config']['parallelism']
     if not extra:
         assert 'flat-buffer grad all-reduce' in par and 'compact' not in par and 'factors' not in par, par
+        assert 'closing launch' in d['config']['adam'] and 'skeleton-forward' in d['config']['adam'], d['config']['adam']
+    if extra == ['--pre-forward', 'off']:
+        assert d['config']['adam'] == 'one launch after the backward', d['config']['adam']
     assert abs(d['value'] - ranks * 1000.0 / d['ms_per_step']) / d['value'] < 0.01  # whole-job: every rank's view per step
     assert 'cpu_baseline' not in d
 
@@ -65,6 +68,24 @@ def test_factor_exchange_and_dense_exchange_train_the_same_parameters():
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
                '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6',
                '--warmup', '2', '--no-cpu-baseline', '--eager'] + extra
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert p.returncode == 0, p.stderr[-3000:]
+        d = json.loads([l for l in p.stdout.splitlines() if l.strip().startswith('{')][0])
+        assert d['config']['replicas_identical'] is True
+        digests.append(d['config']['param_digest'])
+    assert abs(digests[0] - digests[1]) <= 1e-7 * abs(digests[1]), digests
+
+
+def test_riding_update_and_plain_update_train_the_same_parameters():
+    """two ranks, eight optimizer steps: the update as closing launch + next view's skeleton forward with the rows' Adam on
+    board (default) or as one Adam launch (--pre-forward off) must leave the same parameters (same arithmetic per element;
+    the blend backward's atomics do not order their additions, hence a tolerance)"""
+    env = dict(os.environ, SKGS_DIST_BACKEND='gloo', SKGS_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    digests = []
+    for port, extra in ((29589, []), (29590, ['--pre-forward', 'off'])):
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+               '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6',
+               '--warmup', '2', '--no-cpu-baseline'] + extra
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
         assert p.returncode == 0, p.stderr[-3000:]
         d = json.loads([l for l in p.stdout.splitlines() if l.strip().startswith('{')][0])
