@@ -47,11 +47,18 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
     for (int e = 0; e < E; ++e) Ex[i][e] = 0.f;
   }
 
+  // fast build, one pixel per lane: the finished pixels as a lane mask (the loop below keeps its decisions in SGPRs)
+  constexpr bool LANE_MASKS = PPL == 1 && !SKGS_STRICT;
+  unsigned long long done_m = __builtin_amdgcn_ballot_w64(done[0]);
   for (int64_t base = start; base < end; base += WAVE) {
-    bool all_done = true;
+    if (LANE_MASKS) {
+      if (done_m == ~0ull) break;
+    } else {
+      bool all_done = true;
 #pragma unroll
-    for (int i = 0; i < PPL; ++i) all_done = all_done && done[i];
-    if (__all(all_done)) break;
+      for (int i = 0; i < PPL; ++i) all_done = all_done && done[i];
+      if (__all(all_done)) break;
+    }
     const int n = (int) min<int64_t>(WAVE, end - base);
     __syncthreads();  // single-wave workgroup: orders the LDS reads of the previous batch before these writes
     bool relevant = false;
@@ -124,6 +131,39 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
       // nested exec-mask regions only cost SALU work and serialise the LDS reads.  Lanes that do not contribute
       // carry weight 0 (adds an exact +0).
       const float cb = s_c[j];
+      if constexpr (LANE_MASKS) {
+        // one pixel per lane: the decisions live as lane masks in SGPRs -- `stop` and `hit` are the two halves of `valid`
+        // under ONE compare (from the bool form below the compiler emits the compare and its complement), and the index of
+        // the last contributing splat is moved under the hit mask instead of through a VGPR copy and a select: 24 VALU
+        // instructions per visit instead of 26, 54.9 -> 51.8 us at config #1
+        const float dx = a.x - pix.x[0], dy = a.y - pix.y[0];
+        const float power  = dx * (a.z * dx + a.w * dy) + (b.x * dy) * dy;
+        const float alpha  = fminf(0.99f, b.y * blend_exp(power));
+        const float test_T = Tr[0] * (1.f - alpha);
+        const unsigned long long m_valid = ~done_m & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
+                                           __builtin_amdgcn_ballot_w64(alpha >= ALPHA_MIN);
+        const unsigned long long m_lt  = __builtin_amdgcn_ballot_w64(test_T < T_MIN);
+        const unsigned long long m_hit = m_valid & ~m_lt, m_stop = m_valid & m_lt;
+        const float aT = alpha * Tr[0];
+        float wgt;
+        const uint32_t idx1 = contrib0 + j + 1;
+        asm("v_cndmask_b32_e64 %0, 0, %3, %5\n\t"
+            "v_cndmask_b32_e64 %1, %1, %4, %5\n\t"
+            "s_mov_b64 s[2:3], exec\n\t"
+            "s_and_b64 exec, exec, %5\n\t"
+            "v_mov_b32_e32 %2, %6\n\t"
+            "s_mov_b64 exec, s[2:3]"
+            : "=&v"(wgt), "+v"(Tr[0]), "+v"(last[0])
+            : "v"(aT), "v"(test_T), "s"(m_hit), "s"(idx1)
+            : "s2", "s3");
+        done_m |= m_stop;
+        C[0][0] += b.z * wgt;
+        C[0][1] += b.w * wgt;
+        C[0][2] += cb * wgt;
+#pragma unroll
+        for (int e = 0; e < E; ++e) Ex[0][e] += s_e[j * (E > 0 ? E : 1) + e] * wgt;
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < PPL; ++i) {
         const float dx = a.x - pix.x[i], dy = a.y - pix.y[i];
