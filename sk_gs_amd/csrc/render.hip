@@ -340,6 +340,7 @@ int launch_render_backward(const skgs_raster_inputs& in, GeomView g, ImgView im,
   // config #1: 0.67x the visits but ~1.5x the instructions per visit once the compiler's register shuffling for the
   // v_pk_* operands is counted.)
   const int ppl = g_ppl_override ? g_ppl_override : choose_ppl(im.T);
+  SKGS_REQUIRE(in.P <= (1 << 26), "rasterize_backward: the gradient rows are addressed with 32-bit byte offsets (P <= 2^26)");
   ProfScope prof(K_RENDER_BWD, s);
 #define BWD(E_, PPL_)                                                                                                  \
   {                                                                                                                    \

@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
 
   __shared__ float4 s_a[WAVE];  // x, y, conic a, conic b
   __shared__ float4 s_b[WAVE];  // conic c, opacity, r, g
-  __shared__ float s_c[WAVE];   // b
+  __shared__ float4 s_c[WAVE];  // b (.x): a 16-byte stride like s_a / s_b, so ONE address register serves the three reads
   __shared__ float s_e[E > 0 ? WAVE * E : 1];
 
   const int64_t start = ranges.begin[tile];
@@ -66,10 +66,10 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
       const uint32_t id = point_list[base + lane];
       const float4 a = recs[3 * id], b = recs[3 * id + 1], c = recs[3 * id + 2];
 #if SKGS_STRICT
-      s_a[lane] = a, s_b[lane] = b, s_c[lane] = c.x;
+      s_a[lane] = a, s_b[lane] = b, s_c[lane].x = c.x;
 #else
       // the staged record carries the conic pre-scaled: power = dx (p dx + q dy) + (r dy) dy with p = -A/2, q = -B, r = -C/2
-      s_a[lane] = make_float4(a.x, a.y, -0.5f * a.z, -a.w), s_b[lane] = make_float4(-0.5f * b.x, b.y, b.z, b.w), s_c[lane] = c.x;
+      s_a[lane] = make_float4(a.x, a.y, -0.5f * a.z, -a.w), s_b[lane] = make_float4(-0.5f * b.x, b.y, b.z, b.w), s_c[lane].x = c.x;
 #endif
 #pragma unroll
       for (int e = 0; e < E; ++e) s_e[lane * (E > 0 ? E : 1) + e] = extra[(size_t) id * E + e];
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
         any = any || hit[i];
       }
       if (__ballot(any) != 0) {
-        const float cb = s_c[j];
+        const float cb = s_c[j].x;
 #pragma unroll
         for (int i = 0; i < PPL; ++i) {
           // reference order: features * alpha * T, left to right (gaussian_render.cu:93-95)
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
       // Same decisions, branch-free: after the wave-level cull nearly every visit has a contributing lane, so the
       // nested exec-mask regions only cost SALU work and serialise the LDS reads.  Lanes that do not contribute
       // carry weight 0 (adds an exact +0).
-      const float cb = s_c[j];
+      const float cb = s_c[j].x;
       if constexpr (LANE_MASKS) {
         // one pixel per lane: the decisions live as lane masks in SGPRs -- `stop` and `hit` are the two halves of `valid`
         // under ONE compare (from the bool form below the compiler emits the compare and its complement), and the index of
@@ -223,8 +223,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
 
   __shared__ float4 s_a[WAVE];
   __shared__ float4 s_b[WAVE];
-  __shared__ float s_c[WAVE];
-  __shared__ uint32_t s_id[WAVE];
+  __shared__ float2 s_cid[2 * WAVE];  // [2 j]: (b, Gaussian id bits): 16-byte stride, one address register for the record
   __shared__ float s_e[E > 0 ? WAVE * E : 1];
 
   const int64_t start = ranges.begin[tile];
@@ -281,10 +280,10 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
       const uint32_t id = point_list[hi - 1 - lane];
       const float4 a = recs[3 * id], b = recs[3 * id + 1], c = recs[3 * id + 2];
 #if SKGS_STRICT
-      s_a[lane] = a, s_b[lane] = b, s_c[lane] = c.x, s_id[lane] = id;
+      s_a[lane] = a, s_b[lane] = b, s_cid[2 * lane] = make_float2(c.x, __uint_as_float(id));
 #else
       s_a[lane] = make_float4(a.x, a.y, -0.5f * a.z, -a.w), s_b[lane] = make_float4(-0.5f * b.x, b.y, b.z, b.w);
-      s_c[lane] = c.x, s_id[lane] = id;
+      s_cid[2 * lane] = make_float2(c.x, __uint_as_float(id));
 #endif
 #pragma unroll
       for (int e = 0; e < E; ++e) s_e[lane * (E > 0 ? E : 1) + e] = extra[(size_t) id * E + e];
@@ -314,7 +313,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
             const float alpha = fminf(0.99f, b.y * G);
             if (alpha >= ALPHA_MIN) {
               any = true;
-              if (!col_loaded) col[2] = s_c[j], col_loaded = true;
+              if (!col_loaded) col[2] = s_cid[2 * j].x, col_loaded = true;
               const float Tn = Tr[i] / (1.f - alpha);
               const float tf_over = -T_final[i] / (1.f - alpha);
               Tr[i]          = Tn;
@@ -363,8 +362,9 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
       // to which preprocess_backward applies the conic coefficients once per Gaussian.
       float gA[PPL], dch[PPL], dxs[PPL], dys[PPL];
       unsigned long long any_mask = 0ull;
-      col[2] = s_c[j];
-      uint32_t gid = s_id[j];  // (read here, with the record, not after the reduction where its latency is exposed)
+      const float2 cid = s_cid[2 * j];
+      col[2] = cid.x;
+      uint32_t gid = __float_as_uint(cid.y);  // (read here, with the record, not after the reduction where its latency is exposed)
       asm volatile("" : "+v"(gid));  // all three LDS reads of the record are issued together, none inside the divergent region
 #pragma unroll
       for (int i = 0; i < PPL; ++i) {
@@ -418,10 +418,19 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
 #pragma unroll
         for (int q = 9; q < NV; ++q) g[q] = wave_sum_to_lane63(g[q]);
 #if SKGS_STRICT
-        const uint32_t gid = s_id[j];
+        const uint32_t gid = __float_as_uint(s_cid[2 * j].y);
 #endif
         float* row = gradacc + (size_t) gid * GRAD_ROW;
+#if SKGS_STRICT
         if (holder) atomicAdd(row + holder_q, lane == 63 ? g[8] : g[1]);
+#else
+        // 32-bit byte offset from the (wave-uniform) table base: one v_lshl_add_u32 instead of a 64-bit shift and add per
+        // visit (rows are 64 B: good for 2^26 Gaussians, checked by the host)
+        if (holder) {
+          const uint32_t off = (gid << 6) + (uint32_t) holder_q * 4u;
+          atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(gradacc) + off), lane == 63 ? g[8] : g[1]);
+        }
+#endif
         if (lane == 63) {
 #pragma unroll
           for (int q = 9; q < NV; ++q) atomicAdd(row + q, g[q]);
