@@ -268,8 +268,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
   maxk = (uint32_t) __builtin_amdgcn_readfirstlane((int) maxk);  // wave-uniform: the walk's bounds and k live in SGPRs
   if (maxk == 0) return;
   const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-  const bool holder  = (lane & 7) == 0 || lane == 63;
-  const int holder_q = lane == 63 ? 8 : transposed_holder_value(lane >> 3);
+  const bool holder  = banked_holder(lane);
+  const int holder_q = banked_holder_value(lane);
 
   // walk the list back to front: entry at list position k (0-based) has "contributor" index k
   for (int64_t hi = start + (int64_t) min<int64_t>(maxk, end - start); hi > start; hi -= WAVE) {
@@ -412,9 +412,9 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
           for (int e = 0; e < E; ++e) g[9 + e] = i == 0 ? dch[i] * dex[i][e] : g[9 + e] + dch[i] * dex[i][e];
         }
 #endif
-        // 8 sums land one per lane in lanes 0, 8, .., 56, the ninth in lane 63: ONE atomic instruction adds the nine
-        // values into the Gaussian's 64-B gradient row (a single memory-side request)
-        wave_sum9_transposed(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], 0xff00ff00ff00ff00ull);
+        // the nine sums land in nine lanes of ONE register (banked_holder): ONE atomic instruction adds them into the
+        // Gaussian's 64-B gradient row (a single memory-side request)
+        wave_sum9_banked(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8]);
 #pragma unroll
         for (int q = 9; q < NV; ++q) g[q] = wave_sum_to_lane63(g[q]);
 #if SKGS_STRICT
@@ -422,13 +422,13 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
 #endif
         float* row = gradacc + (size_t) gid * GRAD_ROW;
 #if SKGS_STRICT
-        if (holder) atomicAdd(row + holder_q, lane == 63 ? g[8] : g[1]);
+        if (holder) atomicAdd(row + holder_q, g[0]);
 #else
         // 32-bit byte offset from the (wave-uniform) table base: one v_lshl_add_u32 instead of a 64-bit shift and add per
         // visit (rows are 64 B: good for 2^26 Gaussians, checked by the host)
         if (holder) {
           const uint32_t off = (gid << 6) + (uint32_t) holder_q * 4u;
-          atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(gradacc) + off), lane == 63 ? g[8] : g[1]);
+          atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(gradacc) + off), g[0]);
         }
 #endif
         if (lane == 63) {

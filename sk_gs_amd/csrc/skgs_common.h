@@ -164,55 +164,55 @@ __device__ __forceinline__ void wave_sum3_to_lane63(float& a, float& b, float& c
       : "+v"(a), "+v"(b), "+v"(c));
 }
 
-// Nine wave sums at once by "transposing" the reduction (gfx950: v_permlane32_swap / v_permlane16_swap).
-// Each swap+add halves the lane span of TWO values and packs them into one register, so eight values need
-// 4+2 swap/add pairs, one select pair and four DPP adds (~20 VALU) instead of 8 x 6 DPP adds.  The ninth value runs
-// the ordinary DPP chain, interleaved so that it fills the wait states the other chain needs (a VALU write followed
-// by a DPP / permlane read of the same VGPR needs 2 wait states; the compiler cannot see inside the statement).
-// All 64 lanes must be active.  On return
-//     lane 8*m (m = 0..7) of `v1` holds the total of value bitrev3(m)  (m: 0 1 2 3 4 5 6 7 -> v0 v4 v2 v6 v1 v5 v3 v7)
-//     lane 63 of `v8` holds the total of v8;  v0, v2..v7 are clobbered.
-// `m8` is the lane mask of lanes with bit 3 set (0xff00ff00ff00ff00), passed in so it lives in SGPRs across calls.
-#define SKGS_DPP_ALL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-__device__ __forceinline__ void wave_sum9_transposed(float& v0, float& v1, float& v2, float& v3, float& v4, float& v5,
-                                                     float& v6, float& v7, float& v8, unsigned long long m8) {
+// Nine wave sums at once by "transposing" the reduction: every halving step packs two values into one register, so the work
+// shrinks with the lane span instead of being 9 x 6 DPP adds.  The steps that stay inside a row of 16 lanes are DPP adds
+// under a BANK mask:
+//   v_add_f32_dpp r, a, a row_mirror      bank_mask:0x3   lanes 0-7  of every row: a[l] + a[15 - l]
+//   v_add_f32_dpp r, b, b row_mirror      bank_mask:0xc   lanes 8-15 of every row: b[l] + b[15 - l]
+// = two values in one register for two instructions of 4.2 issue clocks each (tools/micro/valu_issue_rate.hip), where a
+// v_permlane swap + add is 8.2 + 2.6; row_half_mirror with banks 0x5 / 0xa does the next halving.  Eight values are then in
+// two registers (8 + 4 DPP adds), one v_permlane32_swap + add joins those, the ninth value (two full-row mirror adds) is
+// joined by ONE v_permlane16_swap + add, two quad_perm adds finish the rows and a row_bcast:31 add the ninth:
+// 17 DPP adds, 2 swaps, 2 adds.  (Round 1-2 version: both wide halvings as v_permlane32/16_swap + add, the ninth value as a
+// separate 6-step DPP chain: 11 DPP adds, 6 swaps, 8 adds, 3 selects -- blend backward 121 -> 112 us at config #1.)
+// A VALU write followed by a DPP / permlane read of the same VGPR needs 2 wait states and the compiler cannot see inside
+// the statement: the independent chains are interleaved and s_nop covers the rest.
+// All 64 lanes must be active.  On return `v0` holds every total: lane 4 m + 32 h (m = 0..3, h = 0..1) that of value
+// banked_holder_value(lane), lanes 48-63 that of v8; v1..v8 are clobbered.
+__device__ __forceinline__ void wave_sum9_banked(float& v0, float& v1, float& v2, float& v3, float& v4, float& v5, float& v6,
+                                                 float& v7, float& v8) {
+#define SKGS_MIRROR(dst, src, banks) "v_add_f32_dpp " dst ", " src ", " src " row_mirror row_mask:0xf bank_mask:" banks "\n\t"
+#define SKGS_HALF(dst, src, banks) "v_add_f32_dpp " dst ", " src ", " src " row_half_mirror row_mask:0xf bank_mask:" banks "\n\t"
   asm volatile(
       "s_nop 1\n\t"
-      "v_permlane32_swap_b32 %0, %1\n\t"
-      "v_permlane32_swap_b32 %2, %3\n\t"
-      "v_permlane32_swap_b32 %4, %5\n\t"
-      "v_permlane32_swap_b32 %6, %7\n\t"
-      "v_add_f32_dpp %8, %8, %8 row_shr:1" SKGS_DPP_ALL
-      "v_add_f32 %0, %0, %1\n\t"
-      "v_add_f32 %2, %2, %3\n\t"
-      "v_add_f32_dpp %8, %8, %8 row_shr:2" SKGS_DPP_ALL
-      "v_add_f32 %4, %4, %5\n\t"
-      "v_add_f32 %6, %6, %7\n\t"
-      "v_permlane16_swap_b32 %0, %2\n\t"
-      "v_add_f32_dpp %8, %8, %8 row_shr:4" SKGS_DPP_ALL
-      "v_permlane16_swap_b32 %4, %6\n\t"
-      "v_add_f32 %0, %0, %2\n\t"
-      "v_add_f32 %4, %4, %6\n\t"
-      "v_add_f32_dpp %8, %8, %8 row_shr:8" SKGS_DPP_ALL
-      "s_nop 0\n\t"
-      "v_cndmask_b32_e64 %1, %0, %4, %9\n\t"
-      "v_cndmask_b32_e64 %3, %4, %0, %9\n\t"
-      "v_add_f32_dpp %8, %8, %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "s_nop 0\n\t"
-      "v_add_f32_dpp %1, %3, %1 row_ror:8" SKGS_DPP_ALL
-      "v_add_f32_dpp %8, %8, %8 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "s_nop 0\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_shl:4" SKGS_DPP_ALL
+      SKGS_MIRROR("%0", "%0", "0x3") SKGS_MIRROR("%2", "%2", "0x3") SKGS_MIRROR("%4", "%4", "0x3") SKGS_MIRROR("%6", "%6", "0x3")
+      SKGS_MIRROR("%0", "%1", "0xc") SKGS_MIRROR("%2", "%3", "0xc") SKGS_MIRROR("%4", "%5", "0xc") SKGS_MIRROR("%6", "%7", "0xc")
+      SKGS_MIRROR("%8", "%8", "0xf")
+      SKGS_HALF("%0", "%0", "0x5") SKGS_HALF("%4", "%4", "0x5")
+      SKGS_HALF("%8", "%8", "0xf")
+      SKGS_HALF("%0", "%2", "0xa") SKGS_HALF("%4", "%6", "0xa")
       "s_nop 1\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_shl:2" SKGS_DPP_ALL
+      "v_permlane32_swap_b32 %0, %4\n\t"
+      "v_add_f32 %0, %0, %4\n\t"
       "s_nop 1\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_shl:1" SKGS_DPP_ALL
+      "v_permlane16_swap_b32 %0, %8\n\t"
+      "v_add_f32 %0, %0, %8\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0x8 bank_mask:0xf\n\t"
       "s_nop 0"
-      : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8)
-      : "s"(m8));
+      : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8));
+#undef SKGS_MIRROR
+#undef SKGS_HALF
 }
-// value index held by lane 8*m after wave_sum9_transposed
-__device__ __forceinline__ int transposed_holder_value(int m) { return ((m & 1) << 2) | (m & 2) | ((m >> 2) & 1); }
+// lanes of `v0` that hold a total after wave_sum9_banked, and which one
+__device__ __forceinline__ bool banked_holder(int lane) { return (lane & 0x13) == 0 || lane == 48; }
+__device__ __forceinline__ int banked_holder_value(int lane) {
+  return lane == 48 ? 8 : ((lane >> 5) << 2) | (((lane >> 2) & 1) << 1) | ((lane >> 3) & 1);
+}
 
 // Tile rectangle of a splat (reference getRect, gaussian_render.h:42-47). Used by the preprocess AND the scatter
 // kernel: both must produce the identical rectangle.  No multiply feeds an add here, so FMA contraction settings
