@@ -13,6 +13,12 @@ __device__ __forceinline__ float blend_exp(float x) {
   return __expf(x);
 #endif
 }
+#if !SKGS_STRICT
+// product build: the staged conic is pre-scaled by log2(e) as well, so the exponent goes straight into v_exp_f32 (2^x): one
+// multiply less per visit in both kernels
+constexpr float BLEND_LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ float blend_exp2(float x_log2) { return __builtin_amdgcn_exp2f(x_log2); }
+#endif
 
 // ====================================================================================================== forward
 template <int PPL, int E>
@@ -68,8 +74,10 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
 #if SKGS_STRICT
       s_a[lane] = a, s_b[lane] = b, s_c[lane].x = c.x;
 #else
-      // the staged record carries the conic pre-scaled: power = dx (p dx + q dy) + (r dy) dy with p = -A/2, q = -B, r = -C/2
-      s_a[lane] = make_float4(a.x, a.y, -0.5f * a.z, -a.w), s_b[lane] = make_float4(-0.5f * b.x, b.y, b.z, b.w), s_c[lane].x = c.x;
+      // the staged record carries the conic pre-scaled: power log2(e) = dx (p dx + q dy) + (r dy) dy with p = -A/2 log2(e),
+      // q = -B log2(e), r = -C/2 log2(e)
+      s_a[lane] = make_float4(a.x, a.y, (-0.5f * BLEND_LOG2E) * a.z, -BLEND_LOG2E * a.w);
+      s_b[lane] = make_float4((-0.5f * BLEND_LOG2E) * b.x, b.y, b.z, b.w), s_c[lane].x = c.x;
 #endif
 #pragma unroll
       for (int e = 0; e < E; ++e) s_e[lane * (E > 0 ? E : 1) + e] = extra[(size_t) id * E + e];
@@ -138,7 +146,7 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
         // instructions per visit instead of 26, 54.9 -> 51.8 us at config #1
         const float dx = a.x - pix.x[0], dy = a.y - pix.y[0];
         const float power  = dx * (a.z * dx + a.w * dy) + (b.x * dy) * dy;
-        const float alpha  = fminf(0.99f, b.y * blend_exp(power));
+        const float alpha  = fminf(0.99f, b.y * blend_exp2(power));
         const float test_T = Tr[0] * (1.f - alpha);
         const unsigned long long m_valid = ~done_m & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
                                            __builtin_amdgcn_ballot_w64(alpha >= ALPHA_MIN);
@@ -168,7 +176,7 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
       for (int i = 0; i < PPL; ++i) {
         const float dx = a.x - pix.x[i], dy = a.y - pix.y[i];
         const float power  = dx * (a.z * dx + a.w * dy) + (b.x * dy) * dy;  // pre-scaled conic, see the staging
-        const float alpha  = fminf(0.99f, b.y * blend_exp(power));
+        const float alpha  = fminf(0.99f, b.y * blend_exp2(power));
         const float test_T = Tr[i] * (1.f - alpha);
         const bool valid   = !done[i] && power <= 0.0f && alpha >= ALPHA_MIN;
         const bool stop    = valid && test_T < T_MIN;
@@ -282,7 +290,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
 #if SKGS_STRICT
       s_a[lane] = a, s_b[lane] = b, s_cid[2 * lane] = make_float2(c.x, __uint_as_float(id));
 #else
-      s_a[lane] = make_float4(a.x, a.y, -0.5f * a.z, -a.w), s_b[lane] = make_float4(-0.5f * b.x, b.y, b.z, b.w);
+      s_a[lane] = make_float4(a.x, a.y, (-0.5f * BLEND_LOG2E) * a.z, -BLEND_LOG2E * a.w);
+      s_b[lane] = make_float4((-0.5f * BLEND_LOG2E) * b.x, b.y, b.z, b.w);
       s_cid[2 * lane] = make_float2(c.x, __uint_as_float(id));
 #endif
 #pragma unroll
@@ -376,7 +385,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
         asm volatile("" : "+v"(D));  // keep D (and the LDS reads behind it) in front of the branch
         // the three tests as one lane mask (the region below is entered by exactly the lanes the reference blends)
         const float power = dx * (a.z * dx + a.w * dy) + (b.x * dy) * dy;  // pre-scaled conic, see the staging
-        const float G     = blend_exp(power);
+        const float G     = blend_exp2(power);
         const float alpha = fminf(0.99f, b.y * G);
         const bool valid  = (k < lastk[i]) & (power <= 0.0f) & (alpha >= ALPHA_MIN);
         // wave-level "does any lane blend this splat": the AND of the three compare masks, kept in SGPRs (a ballot of
