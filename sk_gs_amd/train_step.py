@@ -103,8 +103,9 @@ class FusedTrainStep:
     step starts at the skinning.  Call ``prime()`` once before the first step (and after anything that changes network,
     joints or the slot from outside: a restore, a ``select``).  Measured (tools/time_skeleton.py, the two launches alone):
     100k Gaussians 90 -> 90 us (the whole update already hides beside the backward, and the stream slows the network's
-    hand-offs wherever it runs), 200k 125 -> 100, 500k 251 -> 227.  ``pre_forward='auto'`` therefore switches it on only
-    when the rows' update moves more than ``AUTO_BYTES``.
+    hand-offs wherever it runs), 200k 125 -> 100 on one box and 112 -> 114 on another, 500k 251 -> 227 / 233 -> 204.
+    ``pre_forward='auto'`` therefore switches it on only when the rows' update moves more than ``AUTO_BYTES`` (BASELINE
+    configs #3 and #4: +2.8 % and +1..2 % of the step).
 
     ``reduce_between`` (view-parallel ranks): a gradient all-reduce runs between the backward and the update, so nothing of
     the optimizer can ride on the backward launch.  The step is then two calls, ``backward()`` -- all-reduce -- ``update()``;
@@ -114,7 +115,7 @@ class FusedTrainStep:
 
     ROW_GROUPS = ('xyz', 'f_dc', 'f_rest', 'opacity', 'scaling', 'rotation', 'sp_W')
     ROWS_IN_BACKWARD = 0.6   # ~ backward launch time / (backward + forward launch time) of the bare skeleton stage
-    AUTO_BYTES = 330e6       # 28 B per element: ~150k Gaussians with degree-3 SH and 20 bones
+    AUTO_BYTES = 600e6       # 28 B per element: ~270k Gaussians with degree-3 SH and 20 bones
 
     def __init__(self, step, optimizer, enable: bool = True, pre_forward: bool = False, reduce_between: bool = False):
         self.step, self.optimizer = step, optimizer
