@@ -585,14 +585,15 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_backward_kernel(int P,
     gm2[0] = a.x, gm2[1] = a.y, gcon[0] = a.z, gcon[1] = a.w, gcon[2] = b.x, gop = b.y, gcol[0] = b.z, gcol[1] = b.w;
     gcol[2] = c.x, gex[0] = c.y, gex[1] = c.z, gex[2] = c.w, gex[3] = d.x;
     if (moments) {
-      // fast blend build: slots 0..4 are sum w {dx, dy, dx^2, dx dy, dy^2} over all pixels (render_blend.inl);
+      // fast blend build: slots 0..4 are sum gA {dx, dy, dx^2, dx dy, dy^2} over all pixels (render_blend.inl);
       // dL/dmean2D = -(conic . [m1, m2]) * 0.5 * (W, H), dL/dconic = -0.5 * [m3, m4, m5]
+      // (the rows hold the moments of gA = G dL/dalpha; the opacity factor of w = o gA is applied here, once)
       const float4 q0 = pf_rec[0], q1 = pf_rec[1];
-      const float cx = q0.z, cy = q0.w, cz = q1.x;
-      const float m1 = a.x, m2 = a.y;
+      const float cx = q0.z, cy = q0.w, cz = q1.x, o = q1.y;
+      const float m1 = o * a.x, m2 = o * a.y;
       gm2[0]  = -(cx * m1 + cy * m2) * (0.5f * W);
       gm2[1]  = -(cz * m2 + cy * m1) * (0.5f * H);
-      gcon[0] = -0.5f * a.z, gcon[1] = -0.5f * a.w, gcon[2] = -0.5f * b.x;
+      gcon[0] = -0.5f * (o * a.z), gcon[1] = -0.5f * (o * a.w), gcon[2] = -0.5f * (o * b.x);
     }
   }
   if (gin_means2D) gm2[0] += gin_means2D[3 * idx], gm2[1] += gin_means2D[3 * idx + 1];

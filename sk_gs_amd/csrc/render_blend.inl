@@ -366,9 +366,10 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
       // of the behind-colour: one state register instead of 3 + E)  and
       //   (D - S) T_next - T_final / (1 - alpha) dL/dT = ((D - S) T_prev + K) / (1 - alpha),  K = -T_final dL/dT.
       // The nine partials are plain products of gA / dch formed by ALL lanes afterwards (no zero-initialisation of
-      // nine registers per visit): the five geometric ones are the moments of w = o gA = G dL/dG,
-      //   sum w {dx, dy, dx^2, dx dy, dy^2}
-      // to which preprocess_backward applies the conic coefficients once per Gaussian.
+      // nine registers per visit): the five geometric ones are the moments of gA (w = o gA = G dL/dG without the
+      // wave-uniform opacity o),
+      //   sum gA {dx, dy, dx^2, dx dy, dy^2}
+      // to which preprocess_backward applies the opacity and the conic coefficients once per Gaussian.
       float gA[PPL], dch[PPL], dxs[PPL], dys[PPL];
       unsigned long long any_mask = 0ull;
       const float2 cid = s_cid[2 * j];
@@ -411,7 +412,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
 #if !SKGS_STRICT
 #pragma unroll
         for (int i = 0; i < PPL; ++i) {
-          const float w  = b.y * gA[i];
+          const float w  = gA[i];  // (x opacity = G dL/dG: applied once per Gaussian by preprocess_backward)
           const float m1 = w * dxs[i], m2 = w * dys[i];
           const float v[9] = {m1, m2, m1 * dxs[i], m1 * dys[i], m2 * dys[i], gA[i], dch[i] * dpix[i][0], dch[i] * dpix[i][1],
               dch[i] * dpix[i][2]};
