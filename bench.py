@@ -719,8 +719,8 @@ def main():
                             peak_measured_plain=1000.0, frac_of_measured=round(ach / 1000.0e9, 4),
                             busy=round(rec['valubusy'] / 100.0, 4) if rec.get('valubusy') else None,
                             note='busy = share of the kernel\'s time its SIMDs spend issuing VALU work: the distance from the '
-                                 'ceiling of ITS OWN instruction mix (45 % of the issue clocks of a visit are the cross-lane '
-                                 'reduction: 6 permlane swaps, 11 DPP adds)')
+                                 'ceiling of ITS OWN instruction mix (40 % of the issue clocks of a visit are the cross-lane '
+                                 'reduction: 17 DPP adds, 2 permlane swaps)')
             except Exception:
                 from_profile = None
         line = {
