@@ -65,8 +65,10 @@ def main():
 
     opt = FusedAdam(model.param_groups(lr=args.lr), eps=1e-15)
 
-    def build_runtime():
-        """everything sized by the number of Gaussians: gradient buffers, step workspaces, captured graphs"""
+    def build_runtime(stats_from=None):
+        """everything sized by the number of Gaussians: gradient buffers, step workspaces, captured graphs.  `stats_from`: the
+        step whose densification statistics the new one continues (a rebuild for capacity only; after a densification they
+        start from zero)"""
         cap = capacity[0] * model.P // P + 4096
         if world == 1:
             vp = ViewParallel(model.parameters())               # p.grad -> views of one flat buffer
@@ -102,7 +104,11 @@ def main():
                 ex.gather()
                 w.wait()
                 g_opt(0)     # captured at its first call, i.e. on reduced gradients (its warm-up applies real updates)
-        step.xyz_gradient_accum.zero_(), step.denom.zero_(), step.max_radii2D.zero_()
+        if stats_from is not None:
+            step.xyz_gradient_accum.copy_(stats_from.xyz_gradient_accum), step.denom.copy_(stats_from.denom)
+            step.max_radii2D.copy_(stats_from.max_radii2D)
+        else:
+            step.xyz_gradient_accum.zero_(), step.denom.zero_(), step.max_radii2D.zero_()
         return vp, step, run
 
     vp, step, run = build_runtime()
@@ -111,10 +117,12 @@ def main():
     it = 0
     while it < args.iters:
         run(vp.view_index(it, args.views))
-        act = guard.after_step(it)
+        densify_now = bool(args.densify_every) and it > 0 and it % args.densify_every == 0 and it < args.iters - 1
+        # (the counter is also read right before a densification: nothing may be cloned / pruned on truncated statistics)
+        act = guard.check_now(it) if densify_now else guard.after_step(it)
         if act is not None:   # some forward since the last snapshot dropped splats: state is rolled back, redo from there
             capacity[0] *= 2
-            vp, step, run = build_runtime()
+            vp, step, run = build_runtime(stats_from=step)  # the guard restored the statistics into the old step's tensors
             guard.rebind(step)
             if rank == 0:
                 print(f'iter {it:5d}  binning capacity overflow: redoing from iteration {act[1]} with capacity x2')
@@ -125,7 +133,7 @@ def main():
         if rank == 0 and (it % 100 == 0 or it == args.iters - 1):
             l = step.loss3.tolist()                               # synchronises
             print(f'iter {it:5d}  loss {l[0]:.5f}  (L1 {l[1]:.5f}, SSIM {l[2]:.4f})  {step.status()}')
-        if args.densify_every and it > 0 and it % args.densify_every == 0 and it < args.iters - 1:
+        if densify_now:
             torch.cuda.synchronize()
             t_ev = time.perf_counter()
             vp.allreduce_densify_stats(step.xyz_gradient_accum, step.denom, step.max_radii2D)
@@ -135,14 +143,11 @@ def main():
             torch.cuda.synchronize(); t_a = time.perf_counter()
             vp, step, run = build_runtime()                      # P changed
             torch.cuda.synchronize(); t_b = time.perf_counter()
-            guard = OverflowGuard(step, opt, every=50)
-            guard.checkpoint(it + 1)
-            run(vp.view_index(it, args.views))                    # (extra step: includes the one graph capture)
-            torch.cuda.synchronize()
-            if rank == 0:
-                print(f'iter {it:5d}  densify: {before} -> {model.P} Gaussians  (clone/split/prune + runtime rebuild + '
-                      f'graph capture: {1e3 * (time.perf_counter() - t_ev):.1f} ms; surgery {1e3 * (t_a - t_ev):.1f}, '
-                      f'rebuild {1e3 * (t_b - t_a):.1f}, capture {1e3 * (time.perf_counter() - t_b):.1f})')
+            guard.rebind(step)
+            guard.checkpoint(it + 1)                              # new shapes: the snapshot is taken afresh
+            if rank == 0:                                         # (the graph is captured by the next iteration's run())
+                print(f'iter {it:5d}  densify: {before} -> {model.P} Gaussians  (clone/split/prune {1e3 * (t_a - t_ev):.1f} ms, '
+                      f'runtime rebuild {1e3 * (t_b - t_a):.1f} ms; the next step re-captures the graph)')
         it += 1
     if rank == 0:
         print('visible at least once:', int((step.denom > 0).sum()), 'of', model.P, 'Gaussians; max screen radius',

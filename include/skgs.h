@@ -181,6 +181,14 @@ int skgs_rasterize_extra_backward(int32_t W, int32_t H, int32_t P, int32_t E, co
 /* top_indices [H,W,k] int32 (-1 fill), top_weights [H,W,k] */
 int skgs_topk_weights(int32_t topk, int32_t W, int32_t H, int32_t P, const skgs_raster_buffers* buf,
     int32_t* top_indices, float* top_weights, skgs_stream_t stream);
+/* Parity-test hook (no reference counterpart): re-run the blend forward (renderCUDA_forward, gaussian_render.cu:16-112)
+ * over the buffers of a finished forward and ALSO write, per pixel, a fingerprint of the list entries it blended --
+ * census [H*W][2] = {number of entries blended, sum over them of mix(1-based list position)}, mix(k) =
+ * (k * 2654435761) ^ (k >> 5) in uint32 -- so that a test can find exactly the pixels whose branch decisions (power > 0,
+ * alpha < 1/255, T < 1e-4) differ from the CPU oracle's.  out_color [3,H,W] / out_opacity [H,W] are the same walk's
+ * image (no background); n_contrib in the img buffer is rewritten with identical values. */
+int skgs_render_census(int32_t W, int32_t H, const skgs_raster_buffers* buf, float* out_color, float* out_opacity,
+    uint32_t* census, skgs_stream_t stream);
 /* present [P] bytes (0/1): near-plane test of in_frustum{,_colmap} */
 int skgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, int32_t colmap, uint8_t* present,
     skgs_stream_t stream);
@@ -318,9 +326,10 @@ int skgs_adam_step_range(int32_t n_tensors, const void* tensors, int64_t chunk_b
 typedef struct skgs_view_advance {
   const void* table;       /* DEVICE [views][words] 32-bit words */
   const int32_t* order;    /* DEVICE [n_order] view indices */
-  int32_t* cursor;         /* DEVICE counter */
+  int32_t* cursor;         /* DEVICE counter; with n_order = 0 a pair {counter, length of order}: a captured graph then
+                            * follows a new order of any length uploaded IN PLACE (same storage) between replays */
   void* slot;              /* DEVICE [words] */
-  int32_t n_order, words;
+  int32_t n_order, words;  /* n_order = 0: read the length from cursor[1] */
 } skgs_view_advance;
 int skgs_adam_step_tail(int32_t n_tensors, const void* tensors, int64_t chunk_begin, int64_t chunk_end, double beta1,
     double beta2, double eps, float* step_state, float* zero_after, int64_t zero_n, int64_t freq_chunk, int32_t freq_B,

@@ -179,6 +179,36 @@ class Oracle:
             _p(out['color']), _p(out['opacity']), _p(out['out_extra']))
         return out
 
+    def render_margins(self, W, H, fwd, with_cause=False):
+        """flip census of the forward walk (test infrastructure, see the C source): per-pixel distance [H,W] to the
+        nearest data-dependent branch of renderCUDA_forward, in units of the local rounding error"""
+        geom, binning = fwd['geom'], fwd['binning']
+        margin = np.zeros((H, W), self.dtype)
+        cause = np.zeros((H, W), np.uint8) if with_cause else None  # 0: power > 0, 1: alpha < 1/255, 2: T stop
+        self._fn('render_margins')(
+            C.c_int(W), C.c_int(H), _p(binning['ranges']), _p(binning['point_list']), _p(geom['means2D']),
+            _p(geom['conic_opacity']), _p(margin), _p(cause))
+        return (margin, cause) if with_cause else margin
+
+    def render_census(self, W, H, fwd):
+        """uint32 [H,W,2]: per pixel the number of list entries the reference walk blends and the fingerprint of their
+        list positions -- the counterpart of the HIP library's ``skgs_render_census``"""
+        geom, binning = fwd['geom'], fwd['binning']
+        out = np.zeros((H, W, 2), np.uint32)
+        self._fn('render_census')(C.c_int(W), C.c_int(H), _p(binning['ranges']), _p(binning['point_list']),
+                                  _p(geom['means2D']), _p(geom['conic_opacity']), _p(out))
+        return out
+
+    def render_touching(self, W, H, fwd, pix_mask):
+        """bool [P]: the Gaussians that (nearly) contribute to a pixel of `pix_mask` [H,W]"""
+        geom, binning = fwd['geom'], fwd['binning']
+        flag = np.zeros(geom['radii'].shape[0], np.uint8)
+        mask = np.ascontiguousarray(np.asarray(pix_mask).reshape(H, W), dtype=np.uint8)
+        self._fn('render_touching')(
+            C.c_int(W), C.c_int(H), _p(binning['ranges']), _p(binning['point_list']), _p(geom['means2D']),
+            _p(geom['conic_opacity']), _p(mask), _p(flag))
+        return flag.astype(bool)
+
     def render_backward(self, W, H, geom, binning, img, dL_dcolor, dL_dopacity, colors=None, extra=None,
                         dL_dextra=None, grad_means2D=None, grad_conic=None, grad_opacity=None):
         """renderCUDA_backward: gaussian_render.cu:182-341 (accumulates into the optional grad_* inputs)"""

@@ -571,11 +571,30 @@ int64_t ORACLE(bin_and_sort)(int P, int W, int H, const REAL* means2D, const REA
       }
     }
   }
-  /* SortPairs over bits [0, 32+getHigherMsb(tiles)): tile ids are < 2^msb, so this is a full-key stable sort */
-  qsort(kv, (size_t) R, sizeof(kv_t), kv_cmp);
-  for (int64_t i = 0; i < R; ++i) {
-    point_list_keys[i] = kv[i].key;
-    point_list[i]      = kv[i].val;
+  /* SortPairs over bits [0, 32+getHigherMsb(tiles)): tile ids are < 2^msb, so this is a full-key stable sort.
+   * The same order -- (tile, depth bits, emission order) -- is produced in two stable steps: a counting sort by the
+   * tile id (the key's high word), then every tile's span sorted by (key, emission order) on its own, the spans in
+   * parallel (the CPU baseline of bench.py times this oracle: one serial qsort of R entries would be most of it) */
+  {
+    const int T    = gx * gy;
+    uint32_t* head = (uint32_t*) calloc((size_t) T + 1, sizeof(uint32_t));
+    for (int64_t i = 0; i < R; ++i) head[(kv[i].key >> 32) + 1]++;
+    for (int t = 0; t < T; ++t) head[t + 1] += head[t];
+    kv_t* by_tile   = (kv_t*) malloc(sizeof(kv_t) * (size_t) R);
+    uint32_t* fill = (uint32_t*) malloc(sizeof(uint32_t) * (size_t) T);
+    memcpy(fill, head, sizeof(uint32_t) * (size_t) T);
+    for (int64_t i = 0; i < R; ++i) by_tile[fill[kv[i].key >> 32]++] = kv[i];
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int t = 0; t < T; ++t)
+      if (head[t + 1] - head[t] > 1) qsort(by_tile + head[t], head[t + 1] - head[t], sizeof(kv_t), kv_cmp);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < R; ++i) {
+      point_list_keys[i] = by_tile[i].key;
+      point_list[i]      = by_tile[i].val;
+    }
+    free(fill);
+    free(by_tile);
+    free(head);
   }
   free(kv);
   for (int64_t idx = 0; idx < R; ++idx) { /* identifyTileRanges :77-94 */
@@ -641,9 +660,138 @@ void ORACLE(render_forward)(int W, int H, int E, const uint32_t* ranges, const u
 }
 
 /* ================================================================================================
+ * Flip census (test infrastructure of the parity tests, no reference counterpart): how close does each pixel's walk
+ * of renderCUDA_forward (gaussian_render.cu:78-100) come to one of its three data-dependent branches, in units of
+ * the rounding error an implementation can have there?  With t = |A dx^2|/2 + |C dy^2|/2 + |B dx dy| (the magnitude
+ * of the terms `power` is summed from: its absolute rounding error is a few ulp OF t, and that is also the relative
+ * error of exp(power)):
+ *   power > 0            margin |power| / t
+ *   alpha < 1/255        margin |255 o exp(power) - 1| / (1 + t)
+ *   T (1 - alpha) < 1e-4 margin |T (1 - alpha) / 1e-4 - 1| / sum over the splats blended so far of
+ *                        (1 + (1 + t_j) alpha_j / (1 - alpha_j))   (T carries the error of every alpha before it)
+ * Two implementations that round exp / the quadratic form differently (CUDA expf with FMA contraction, libm expf
+ * without, v_exp_f32 on a pre-scaled conic) take different branches exactly at pairs whose margin is a small
+ * multiple of 2^-24 = 6e-8.  pix_margin[H*W] = the smallest margin of the pixel's walk.
+ * ============================================================================================== */
+void ORACLE(render_margins)(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const REAL* means2D,
+    const REAL* conic_opacity, REAL* pix_margin, uint8_t* pix_cause /* optional: 0 power, 1 alpha, 2 T */) {
+  const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int tile = 0; tile < gx * gy; ++tile) {
+    const int tx = tile % gx, ty = tile / gx;
+    const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+    for (int ly = 0; ly < BLOCK_Y; ++ly)
+      for (int lx = 0; lx < BLOCK_X; ++lx) {
+        const int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+        if (!(px < W && py < H)) continue;
+        const uint32_t pix_id = (uint32_t) W * py + px;
+        const REAL pixf[2]    = {(REAL) px, (REAL) py};
+        REAL T = RC(1.0), margin = RC(1e30);
+        double t_err = 0.0; /* relative error of T in units of the rounding */
+        uint8_t cause = 255;
+        for (uint32_t k = r0; k < r1; ++k) {
+          const uint32_t id = point_list[k];
+          const REAL dx = means2D[2 * id] - pixf[0], dy = means2D[2 * id + 1] - pixf[1];
+          const REAL* con_o = conic_opacity + 4 * id;
+          const REAL power  = RC(-0.5) * (con_o[0] * dx * dx + con_o[2] * dy * dy) - con_o[1] * dx * dy;
+          const REAL terms  = RC(0.5) * (REAL) (fabs((double) (con_o[0] * dx * dx)) + fabs((double) (con_o[2] * dy * dy))) +
+                             (REAL) fabs((double) (con_o[1] * dx * dy));
+          if (terms > 0) {
+            const REAL m = (REAL) fabs((double) power) / terms;
+            if (m < margin) margin = m, cause = 0;
+          }
+          if (power > RC(0.0)) continue;
+          const REAL araw = con_o[3] * oexp(power);
+          {
+            const REAL m = (REAL) fabs((double) (araw * RC(255.0) - RC(1.0))) / (RC(1.0) + terms);
+            if (m < margin) margin = m, cause = 1;
+          }
+          const REAL alpha = r_min(RC(0.99f), araw);
+          if (alpha < RC(1.0f / 255.0f)) continue;
+          const REAL test_T = T * (1 - alpha);
+          t_err += 1.0 + (1.0 + (double) terms) * (double) alpha / (1.0 - (double) alpha);
+          {
+            const REAL m = (REAL) (fabs((double) (test_T / RC(0.0001f) - RC(1.0))) / t_err);
+            if (m < margin) margin = m, cause = 2;
+          }
+          if (test_T < RC(0.0001f)) break;
+          T = test_T;
+        }
+        pix_margin[pix_id] = margin;
+        if (pix_cause) pix_cause[pix_id] = cause;
+      }
+  }
+}
+
+/* The fingerprint the HIP census kernel writes (include/skgs.h, skgs_render_census), from the reference walk:
+ * census[pix][0] = number of list entries blended, [1] = sum of mix(1-based list position), mix(k) =
+ * (k * 2654435761) ^ (k >> 5) mod 2^32.  Two walks with equal fingerprints took the same branch at every entry (up to
+ * a hash collision of 2^-32). */
+void ORACLE(render_census)(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const REAL* means2D,
+    const REAL* conic_opacity, uint32_t* census) {
+  const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int tile = 0; tile < gx * gy; ++tile) {
+    const int tx = tile % gx, ty = tile / gx;
+    const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+    for (int ly = 0; ly < BLOCK_Y; ++ly)
+      for (int lx = 0; lx < BLOCK_X; ++lx) {
+        const int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+        if (!(px < W && py < H)) continue;
+        const uint32_t pix_id = (uint32_t) W * py + px;
+        const REAL pixf[2]    = {(REAL) px, (REAL) py};
+        REAL T                = RC(1.0);
+        uint32_t contributor = 0, n = 0, h = 0;
+        for (uint32_t k = r0; k < r1; ++k) {
+          contributor++;
+          const uint32_t id = point_list[k];
+          const REAL dx = means2D[2 * id] - pixf[0], dy = means2D[2 * id + 1] - pixf[1];
+          const REAL* con_o = conic_opacity + 4 * id;
+          const REAL power  = RC(-0.5) * (con_o[0] * dx * dx + con_o[2] * dy * dy) - con_o[1] * dx * dy;
+          if (power > RC(0.0)) continue;
+          const REAL alpha = r_min(RC(0.99f), con_o[3] * oexp(power));
+          if (alpha < RC(1.0f / 255.0f)) continue;
+          const REAL test_T = T * (1 - alpha);
+          if (test_T < RC(0.0001f)) break;
+          T = test_T;
+          n += 1;
+          h += (contributor * 2654435761u) ^ (contributor >> 5);
+        }
+        census[2 * (size_t) pix_id]     = n;
+        census[2 * (size_t) pix_id + 1] = h;
+      }
+  }
+}
+
+/* gauss_flag[id] = 1 for every Gaussian that (nearly: alpha >= 0.99/255) contributes to a pixel of pix_mask -- the
+ * rows of the per-Gaussian gradients a branch flip at one of those pixels can change (a flip moves T for everything
+ * behind it and the behind-colour for everything in front) */
+void ORACLE(render_touching)(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const REAL* means2D,
+    const REAL* conic_opacity, const uint8_t* pix_mask, uint8_t* gauss_flag) {
+  const int gx = (W + BLOCK_X - 1) / BLOCK_X;
+  for (int py = 0; py < H; ++py)
+    for (int px = 0; px < W; ++px) {
+      if (!pix_mask[(size_t) W * py + px]) continue;
+      const int tile    = (py / BLOCK_Y) * gx + px / BLOCK_X;
+      const REAL pixf[2] = {(REAL) px, (REAL) py};
+      for (uint32_t k = ranges[2 * tile]; k < ranges[2 * tile + 1]; ++k) {
+        const uint32_t id = point_list[k];
+        const REAL dx = means2D[2 * id] - pixf[0], dy = means2D[2 * id + 1] - pixf[1];
+        const REAL* con_o = conic_opacity + 4 * id;
+        const REAL power  = RC(-0.5) * (con_o[0] * dx * dx + con_o[2] * dy * dy) - con_o[1] * dx * dy;
+        if (power > RC(1e-3)) continue;
+        if (con_o[3] * oexp(r_min(power, RC(0.0))) * RC(255.0) < RC(0.99)) continue;
+        gauss_flag[id] = 1;
+      }
+    }
+}
+
+/* ================================================================================================
  * renderCUDA_backward<3,E>: gaussian_render.cu:182-341.  The CUDA kernel scatters with atomicAdd (order
- * undefined); here tiles are walked in parallel into per-thread accumulators that are then summed in thread
- * order, so the oracle is deterministic.  dL_dmean2D is [P,3], dL_dconic2D is [P,4] (x,y,_,w), accumulated INTO.
+ * undefined); here tiles are walked in parallel, every tile INSTANCE (entry k of the sorted list) owns one private
+ * accumulator row filled by its tile's pixels in pixel order, and the rows are then added to their Gaussians in
+ * list order k = 0..R-1: deterministic for any thread count, and no per-thread [P] image to allocate and reduce
+ * (what made 128 cores slower than one).  dL_dmean2D is [P,3], dL_dconic2D is [P,4] (x,y,_,w), accumulated INTO.
  * ============================================================================================== */
 #ifdef _OPENMP
 #include <omp.h>
@@ -654,22 +802,15 @@ void ORACLE(render_backward)(int P, int W, int H, int E, const uint32_t* ranges,
     REAL* dL_dmean2D, REAL* dL_dconic2D, REAL* dL_dopacity, REAL* dL_dcolors, REAL* dL_dextras) {
   const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
   const int C  = NUM_CHANNELS;
-  int nthreads = 1;
-#ifdef _OPENMP
-  nthreads = omp_get_max_threads();
-#endif
   const int NV    = 9 + E; /* mean2D.x,.y conic.x,.y,.w opacity color[3] extra[E] */
-  REAL* scratch   = (REAL*) calloc((size_t) nthreads * P * NV, sizeof(REAL));
+  uint32_t R      = 0;
+  for (int tile = 0; tile < gx * gy; ++tile)
+    if (ranges[2 * tile + 1] > R) R = ranges[2 * tile + 1];
+  REAL* scratch   = (REAL*) calloc((size_t) (R > 0 ? R : 1) * NV, sizeof(REAL));
   const REAL ddelx_dx = (REAL) (0.5 * W);
   const REAL ddely_dy = (REAL) (0.5 * H);
-#pragma omp parallel
   {
-    int tid = 0;
-#ifdef _OPENMP
-    tid = omp_get_thread_num();
-#endif
-    REAL* acc = scratch + (size_t) tid * P * NV;
-#pragma omp for schedule(dynamic, 4)
+#pragma omp parallel for schedule(dynamic, 1)
     for (int tile = 0; tile < gx * gy; ++tile) {
       const int tx = tile % gx, ty = tile / gx;
       const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
@@ -704,7 +845,7 @@ void ORACLE(render_backward)(int P, int W, int H, int E, const uint32_t* ranges,
             T                          = T / (RC(1.) - alpha);
             const REAL dchannel_dcolor = alpha * T;
             REAL dL_dalpha             = RC(0.0);
-            REAL* a                    = acc + (size_t) id * NV;
+            REAL* a                    = scratch + (size_t) k * NV;
             for (int ch = 0; ch < C; ch++) {
               const REAL c  = colors[id * C + ch];
               accum_rec[ch] = last_alpha * last_color[ch] + (RC(1.) - last_alpha) * accum_rec[ch];
@@ -739,11 +880,11 @@ void ORACLE(render_backward)(int P, int W, int H, int E, const uint32_t* ranges,
         }
     }
   }
-  for (int t = 0; t < nthreads; ++t) {
-    const REAL* acc = scratch + (size_t) t * P * NV;
-#pragma omp parallel for schedule(static)
-    for (int id = 0; id < P; ++id) {
-      const REAL* a = acc + (size_t) id * NV;
+  (void) P;
+  {
+    for (uint32_t k = 0; k < R; ++k) {
+      const uint32_t id = point_list[k];
+      const REAL* a     = scratch + (size_t) k * NV;
       dL_dmean2D[3 * id + 0] += a[0];
       dL_dmean2D[3 * id + 1] += a[1];
       dL_dconic2D[4 * id + 0] += a[2];

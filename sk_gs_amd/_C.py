@@ -79,7 +79,7 @@ EXPORTED_SYMBOLS = [
     'skgs_geom_buffer_bytes', 'skgs_img_buffer_bytes', 'skgs_binning_buffer_bytes', 'skgs_binning_capacity',
     'skgs_rasterize_forward_stage1', 'skgs_rasterize_forward_stage2', 'skgs_rasterize_forward', 'skgs_read_status',
     'skgs_backward_workspace_bytes', 'skgs_rasterize_backward', 'skgs_rasterize_extra_forward',
-    'skgs_rasterize_extra_backward', 'skgs_topk_weights', 'skgs_mark_visible', 'skgs_lbs_deform_forward',
+    'skgs_rasterize_extra_backward', 'skgs_topk_weights', 'skgs_render_census', 'skgs_mark_visible', 'skgs_lbs_deform_forward',
     'skgs_lbs_deform_backward', 'skgs_lbs_deform_backward_workspace_bytes', 'skgs_knn_bones',
     'skgs_lbs_weights_forward', 'skgs_lbs_weights_backward', 'skgs_last_error', 'skgs_version',
 ]
@@ -523,6 +523,22 @@ def gaussian_topk_weights(topk: int, W: int, H: int, P: int, R: int, geomBuffer:
         _check(lib.skgs_topk_weights(C.c_int32(topk), C.c_int32(W), C.c_int32(H), C.c_int32(P), C.byref(bufs),
                                      C.c_void_p(idx.data_ptr()), C.c_void_p(w.data_ptr()), _stream()))
     return idx, w
+
+
+def render_census(W: int, H: int, geomBuffer: Tensor, binningBuffer: Tensor, imgBuffer: Tensor):
+    """Parity-test hook (``skgs_render_census``): the blend forward over the buffers of a finished forward, plus a
+    fingerprint of the list entries every pixel blended.  Returns ``(color[3,H,W], opacity[H,W], census[H,W,2] int32)``."""
+    lib = load_library()
+    _require_gpu(geomBuffer, 'geomBuffer')
+    dev = geomBuffer.device
+    with _on_device(dev):
+        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        opacity = torch.empty((H, W), dtype=torch.float32, device=dev)
+        census = torch.zeros((H, W, 2), dtype=torch.int32, device=dev)
+        bufs = _buffers(geomBuffer, binningBuffer, imgBuffer)
+        _check(lib.skgs_render_census(C.c_int32(W), C.c_int32(H), C.byref(bufs), C.c_void_p(color.data_ptr()),
+                                      C.c_void_p(opacity.data_ptr()), C.c_void_p(census.data_ptr()), _stream()))
+    return color, opacity, census
 
 
 def mark_visible(positions: Tensor, viewmatrix: Tensor, projmatrix: Tensor, colmap: bool = False) -> Tensor:

@@ -77,7 +77,8 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_step_kernel(int n_tensors, 
       for (int64_t i = threadIdx.x; i < zero_n; i += ADAM_THREADS) zero_after[i] = 0.f;
       if (va.slot) {
         const int c = va.cursor[0];
-        const uint32_t* rec = va.table + (size_t) va.order[c % va.n] * va.words;
+        const int n = va.n > 0 ? va.n : max(va.cursor[1], 1);  // n_order = 0: the order's length is a device word too
+        const uint32_t* rec = va.table + (size_t) va.order[c % n] * va.words;
         for (int i = threadIdx.x; i < va.words; i += ADAM_THREADS) va.slot[i] = rec[i];
         __syncthreads();  // every thread has read the cursor
         if (threadIdx.x == 0) va.cursor[0] = c + 1;
@@ -177,7 +178,7 @@ int skgs_adam_step_tail(int32_t n_tensors, const void* tensors, int64_t chunk_be
   job.chunk = -1;
   ViewAdvance va{};
   if (next_view && next_view->slot) {
-    SKGS_REQUIRE(next_view->table && next_view->order && next_view->cursor && next_view->n_order >= 1 && next_view->words >= 1,
+    SKGS_REQUIRE(next_view->table && next_view->order && next_view->cursor && next_view->n_order >= 0 && next_view->words >= 1,
         "adam_step_tail: bad view advance");
     va = ViewAdvance{reinterpret_cast<const uint32_t*>(next_view->table), next_view->order, next_view->cursor,
         reinterpret_cast<uint32_t*>(next_view->slot), next_view->n_order, next_view->words};

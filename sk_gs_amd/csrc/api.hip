@@ -258,6 +258,16 @@ int skgs_topk_weights(int32_t topk, int32_t W, int32_t H, int32_t P, const skgs_
   return launch_topk(topk, W, H, g, im, b, top_indices, top_weights, s);
 }
 
+int skgs_render_census(int32_t W, int32_t H, const skgs_raster_buffers* buf, float* out_color, float* out_opacity,
+    uint32_t* census, skgs_stream_t stream) {
+  SKGS_REQUIRE(buf && buf->geom && buf->img && buf->binning, "buffers of a finished forward are required");
+  SKGS_REQUIRE(out_color && out_opacity && census, "census outputs are required");
+  GeomView g = geom_view(buf->geom);
+  ImgView im = img_view(buf->img, W, H);
+  BinView b  = bin_view(buf->binning, buf->binning_bytes);
+  return launch_render_census(W, H, g, im, b, out_color, out_opacity, census, (hipStream_t) stream);
+}
+
 int skgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, int32_t colmap, uint8_t* present,
     skgs_stream_t stream) {
   SKGS_REQUIRE(P == 0 || (means3D && viewmatrix && present), "mark_visible: NULL argument");

@@ -591,12 +591,9 @@ int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, Bi
       hipLaunchKernelGGL(tile_sort_merge_kernel<2>, dim3(std::min(im.T, 1024)), dim3(SORT_THREADS), 2 * 4096 * 8, s, g.hdr,
           im.worklist, im.tile_begin, im.tile_end, b.keys, b.point_list, b.capacity, 2048, 4096);
     if ((bucket == 0 || bucket > 4096) && longest > 4096) {
-      static bool once = false;
-      if (!once) {
-        SKGS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_sort_merge_kernel<4>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8192 * 8));
-        once = true;
-      }
+      // per launch, not once per process: the attribute is per DEVICE (and a static flag is not thread-safe)
+      SKGS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_sort_merge_kernel<4>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8192 * 8));
       hipLaunchKernelGGL(tile_sort_merge_kernel<4>, dim3(std::min(im.T, 512)), dim3(SORT_THREADS), 2 * 8192 * 8, s, g.hdr,
           im.worklist, im.tile_begin, im.tile_end, b.keys, b.point_list, b.capacity, 4096, 0x7fffffff);
     }

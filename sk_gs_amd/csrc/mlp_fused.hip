@@ -305,7 +305,19 @@ __device__ __forceinline__ void repoison(float* img_other, int nX, int G, int Bp
 // so all of them are resident before the first side workgroup is placed; the LDS request of the launch keeps it at one
 // workgroup per CU.
 constexpr int G_NET = H / NC;
-constexpr int NUM_CUS = 256;  // MI355X: the side job gets one workgroup per CU the network does not occupy
+// the side job gets one workgroup per CU the network does not occupy: the device's CU count, asked once per device (256 on
+// a whole MI355X; a partitioned / shared GPU reports what this process can use)
+inline int num_cus() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;  // (a racing thread writes the same value)
+  }
+  return cached[dev];
+}
 __device__ __forceinline__ void adam_side_job(const FusedArgs& a) {
   const int n_side = (int) gridDim.x - G_NET, wg = (int) blockIdx.x - G_NET;
   const int half = threadIdx.x >> 8, t256 = threadIdx.x & 255, lane = threadIdx.x & 63;
@@ -913,7 +925,7 @@ int launch(KernelT k, const Plan& p, const FusedArgs& a, size_t lds, hipStream_t
   // side job: one workgroup per CU the network leaves idle (each takes two chunks per iteration)
   int side = 0;
   if (a.adam_tensors && a.adam_c1 > a.adam_c0)
-    side = (int) std::min<long long>((a.adam_c1 - a.adam_c0 + 1) / 2, NUM_CUS - p.G);
+    side = (int) std::max<long long>(1, std::min<long long>((a.adam_c1 - a.adam_c0 + 1) / 2, num_cus() - p.G));  // never 0: the rows MUST be updated
   hipLaunchKernelGGL(k, dim3(p.G + side), dim3(NT), lds, s, a);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;

@@ -314,11 +314,11 @@ int launch_render_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, 
     if (g_strict)                                                                                                       \
       hipLaunchKernelGGL((blend_strict::render_forward_kernel<PPL_, E_>), dim3(nblk), dim3(64), 0, s, W, H, im.tiles_x, \
           im.T, TileRanges{im.tile_begin, im.tile_end}, b.capacity, b.point_list, g.recs, in.extras, in.background, im.n_contrib, out_color,   \
-          out_opacity, out_extra);                                                                                      \
+          out_opacity, out_extra, (uint32_t*) nullptr);                                                                 \
     else                                                                                                                \
       hipLaunchKernelGGL((blend_fast::render_forward_kernel<PPL_, E_>), dim3(nblk), dim3(64), 0, s, W, H, im.tiles_x,   \
           im.T, TileRanges{im.tile_begin, im.tile_end}, b.capacity, b.point_list, g.recs, in.extras, in.background, im.n_contrib, out_color,   \
-          out_opacity, out_extra);                                                                                      \
+          out_opacity, out_extra, (uint32_t*) nullptr);                                                                 \
   }
   if (ppl == 4) {
     SKGS_DISPATCH_E(E, FWD, 4)
@@ -328,6 +328,23 @@ int launch_render_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, 
     SKGS_DISPATCH_E(E, FWD, 1)
   }
 #undef FWD
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// parity tests only: the product forward walk (one pixel per lane, no extras; strict or fast as set) with the census
+// fingerprint of every pixel's blended list entries
+int launch_render_census(int W, int H, GeomView g, ImgView im, BinView b, float* out_color, float* out_opacity,
+    uint32_t* census, hipStream_t s) {
+  const int nblk = xcd_grid(im.T * 4);
+  if (g_strict)
+    hipLaunchKernelGGL((blend_strict::render_forward_kernel<1, 0, true>), dim3(nblk), dim3(64), 0, s, W, H, im.tiles_x, im.T,
+        TileRanges{im.tile_begin, im.tile_end}, b.capacity, b.point_list, g.recs, (const float*) nullptr,
+        (const float*) nullptr, im.n_contrib, out_color, out_opacity, (float*) nullptr, census);
+  else
+    hipLaunchKernelGGL((blend_fast::render_forward_kernel<1, 0, true>), dim3(nblk), dim3(64), 0, s, W, H, im.tiles_x, im.T,
+        TileRanges{im.tile_begin, im.tile_end}, b.capacity, b.point_list, g.recs, (const float*) nullptr,
+        (const float*) nullptr, im.n_contrib, out_color, out_opacity, (float*) nullptr, census);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -15,17 +15,32 @@ __device__ __forceinline__ float blend_exp(float x) {
 }
 #if !SKGS_STRICT
 // product build: the staged conic is pre-scaled by log2(e) as well, so the exponent goes straight into v_exp_f32 (2^x): one
-// multiply less per visit in both kernels
+// multiply less per visit in both kernels.  -DSKGS_BLEND_LOG2E_PRESCALE=0 builds the round-2 "e" form (conic scaled by
+// -1/2 only, exp as v_mul + v_exp_f32) for A/B flip censuses (tools/flip_census_ab.sh).
+#ifndef SKGS_BLEND_LOG2E_PRESCALE
+#define SKGS_BLEND_LOG2E_PRESCALE 1
+#endif
+#if SKGS_BLEND_LOG2E_PRESCALE
 constexpr float BLEND_LOG2E = 1.4426950408889634f;
 __device__ __forceinline__ float blend_exp2(float x_log2) { return __builtin_amdgcn_exp2f(x_log2); }
+#else
+constexpr float BLEND_LOG2E = 1.0f;
+__device__ __forceinline__ float blend_exp2(float x) { return __expf(x); }
+#endif
 #endif
 
 // ====================================================================================================== forward
-template <int PPL, int E>
+// CENSUS (parity tests only, skgs_render_census): the same walk also leaves a fingerprint of WHICH list entries each pixel
+// blended -- their number and the sum of census_mix(list position) -- so that a test can find exactly the pixels whose
+// branch decisions differ from the oracle's.  The arithmetic is untouched (the census image is compared bit for bit with
+// the product kernel's).
+__device__ __forceinline__ uint32_t census_mix(uint32_t k) { return (k * 2654435761u) ^ (k >> 5); }
+template <int PPL, int E, bool CENSUS = false>
 __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx, int T, TileRanges ranges,
     int64_t capacity, const uint32_t* __restrict__ point_list, const float4* __restrict__ recs,
     const float* __restrict__ extra, const float* __restrict__ bg, uint32_t* __restrict__ n_contrib,
-    float* __restrict__ out_color, float* __restrict__ out_opacity, float* __restrict__ out_extra) {
+    float* __restrict__ out_color, float* __restrict__ out_opacity, float* __restrict__ out_extra,
+    uint32_t* __restrict__ census = nullptr /* [H*W][2]: blended entries, sum of census_mix(position) */) {
   constexpr int SUBS = 4 / PPL;
   const int v        = xcd_remap(blockIdx.x, T * SUBS);
   if (v >= T * SUBS) return;
@@ -44,9 +59,11 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
 
   float Tr[PPL], C[PPL][3], Ex[PPL][E > 0 ? E : 1];
   uint32_t last[PPL];
+  uint32_t cen_n[PPL], cen_h[PPL];
   bool done[PPL];
 #pragma unroll
   for (int i = 0; i < PPL; ++i) {
+    cen_n[i] = 0, cen_h[i] = 0;
     Tr[i] = 1.0f, last[i] = 0, done[i] = !pix.inside[i];
     C[i][0] = C[i][1] = C[i][2] = 0.f;
 #pragma unroll
@@ -114,6 +131,7 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
                 Tp[i]   = Tr[i];
                 Tr[i]   = test_T;
                 last[i] = contrib0 + j + 1;
+                if constexpr (CENSUS) cen_n[i] += 1, cen_h[i] += census_mix(contrib0 + j + 1);
               }
             }
           }
@@ -165,6 +183,10 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
             : "v"(aT), "v"(test_T), "s"(m_hit), "s"(idx1)
             : "s2", "s3");
         done_m |= m_stop;
+        if constexpr (CENSUS) {
+          const bool h = (m_hit >> lane) & 1ull;
+          cen_n[0] += h ? 1u : 0u, cen_h[0] += h ? census_mix(idx1) : 0u;
+        }
         C[0][0] += b.z * wgt;
         C[0][1] += b.w * wgt;
         C[0][2] += cb * wgt;
@@ -185,6 +207,7 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
         done[i]            = done[i] || stop;
         Tr[i]              = hit ? test_T : Tr[i];
         last[i]            = hit ? contrib0 + j + 1 : last[i];
+        if constexpr (CENSUS) cen_n[i] += hit ? 1u : 0u, cen_h[i] += hit ? census_mix(contrib0 + j + 1) : 0u;
         C[i][0] += b.z * wgt;
         C[i][1] += b.w * wgt;
         C[i][2] += cb * wgt;
@@ -200,6 +223,7 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
     if (pix.inside[i]) {
       out_opacity[pix.id[i]] = 1.f - Tr[i];
       n_contrib[pix.id[i]]   = last[i];
+      if constexpr (CENSUS) census[2 * (size_t) pix.id[i]] = cen_n[i], census[2 * (size_t) pix.id[i] + 1] = cen_h[i];
       // optional background: C + T * bg (upstream diff_gaussian_rasterization epilogue; NULL = in-tree variant)
       out_color[pix.id[i]]          = bg ? C[i][0] + Tr[i] * bg[0] : C[i][0];
       out_color[HW + pix.id[i]]     = bg ? C[i][1] + Tr[i] * bg[1] : C[i][1];

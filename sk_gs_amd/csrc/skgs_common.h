@@ -274,6 +274,8 @@ int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, Bi
 bool gradacc_rows_hold_moments();
 int launch_render_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, BinView b, float* out_color,
     float* out_opacity, float* out_extra, hipStream_t s);
+int launch_render_census(int W, int H, GeomView g, ImgView im, BinView b, float* out_color, float* out_opacity,
+    uint32_t* census, hipStream_t s);
 int launch_render_backward(const skgs_raster_inputs& in, GeomView g, ImgView im, BinView b, const float* out_opacity,
     const float* dL_dcolor, const float* dL_dopacity, const float* dL_dextra, float* gradacc, hipStream_t s);
 int launch_extra_forward(int W, int H, int P, int E, const float* extra, GeomView g, ImgView im, BinView b,

@@ -15,7 +15,11 @@ dropped splats has a truncated render and truncated gradients.  Nothing may be b
     grows the capacity (``FusedViewStep.grow_capacity``), re-captures its graphs and replays those iterations.  The redone
     steps see complete tile lists, so the run continues as if the capacity had always been large enough.
 
-The view order of the redone iterations must be reproducible (the loop's own schedule; a seeded sampler).
+The view order of the redone iterations must be reproducible (the loop's own schedule; a seeded sampler).  A loop that lets
+the closing launch walk an ordered ``ViewTable`` hands the table to the guard (``view_table=``): its cursor and live slot are
+then part of the snapshot, so the redone iterations see the same views.  The snapshot is tied to the number of Gaussians:
+call ``checkpoint()`` after every densification / pruning.  A fused deform network whose in-launch exchange timed out
+(``status()['mlp_failed']``) left partial gradients behind: the guard treats that like an overflow (roll back, redo).
 """
 from typing import Iterable, List, Optional, Tuple
 
@@ -24,17 +28,22 @@ from torch import Tensor
 
 
 class OverflowGuard:
-    def __init__(self, step, optimizer, every: int = 50, extra_state: Iterable[Tensor] = ()):
+    def __init__(self, step, optimizer, every: int = 50, extra_state: Iterable[Tensor] = (), view_table=None):
         """``step``: the FusedViewStep whose status words are watched; ``optimizer``: FusedAdam (parameters + moments +
         counter are snapshotted); ``extra_state``: further tensors that training mutates (e.g. a sampler's device state)"""
         assert every >= 1
         self.step, self.opt, self.every = step, optimizer, int(every)
-        self.extra = list(extra_state)
+        self.extra = list(extra_state) + (view_table.state_tensors() if view_table is not None else [])
         self._snap: Optional[List[Tensor]] = None
         self._snap_iter = 0
-        self._seen_events = step.status()['overflow_events']
+        self._seen_events = self._events(step)
         self.redos = 0
         self.checkpoint(0)  # the state before the first guarded iteration
+
+    @staticmethod
+    def _events(step) -> Tuple[int, int]:
+        st = step.status()
+        return st['overflow_events'], st.get('mlp_failed', 0)
 
     def _live_tensors(self) -> List[Tensor]:
         ts = []
@@ -62,10 +71,20 @@ class OverflowGuard:
         after the roll-back, once the view to resume from is in the slot)."""
         if (iteration + 1) % self.every:
             return None
-        events = self.step.status()['overflow_events']  # synchronises: once per interval
+        return self.check_now(iteration)
+
+    @torch.no_grad()
+    def check_now(self, iteration: int) -> Optional[Tuple[str, int]]:
+        """the check of ``after_step`` regardless of the interval (e.g. right before a densification, which must not be
+        decided on statistics a truncated step contributed to)"""
+        events = self._events(self.step)  # synchronises: once per interval
         if events != self._seen_events:
             self._seen_events = events
-            torch._foreach_copy_(self._live_tensors(), self._snap)
+            live = self._live_tensors()
+            if len(live) != len(self._snap) or any(a.shape != b.shape for a, b in zip(live, self._snap)):
+                raise RuntimeError('OverflowGuard: the training state changed shape since the last snapshot (densification / '
+                                   'pruning?): call checkpoint(iteration) right after such an operation')
+            torch._foreach_copy_(live, self._snap)
             self.redos += 1
             return 'redo', self._snap_iter
         self.checkpoint(iteration + 1)
@@ -74,4 +93,4 @@ class OverflowGuard:
     def rebind(self, step):
         """after the caller rebuilt its FusedViewStep (bigger capacity): watch the new one"""
         self.step = step
-        self._seen_events = step.status()['overflow_events']
+        self._seen_events = self._events(step)

@@ -84,33 +84,59 @@ class ViewTable:
         self.slot.copy_(self.records[v], non_blocking=True)
         self.current = v
 
-    def set_order(self, order: Sequence[int]):
+    def set_order(self, order: Sequence[int], capacity: Optional[int] = None):
         """Walk the views in ``order`` (cyclically) WITHOUT a per-step ``select``: view ``order[0]`` is selected now; the
         launch that closes a step (``FusedAdam.step_tail(next_view=table.advance())``, what ``FusedTrainStep`` issues) then
         puts ``order[1]``, ``order[2]``, ... into the slot, one per step -- the device-to-device copy of ``select`` (4.5 us
-        in front of every replay) disappears.  Upload a new order (a new epoch's permutation) at any step boundary."""
+        in front of every replay) disappears.  Upload a new order (a new epoch's permutation) at any step boundary.
+
+        The order, its length and the cursor live in storage allocated ONCE (the first call; ``capacity`` entries, default
+        4 x the number of views): captured graphs hold these addresses as kernel arguments, so every later call copies IN
+        PLACE.  An order longer than the capacity cannot be served by graphs captured before it: that raises."""
         assert len(order) >= 1 and all(0 <= int(v) < self.n_views for v in order)
         dev = self.records.device
-        self.order = torch.tensor([int(v) for v in order], dtype=torch.int32, device=dev)
-        self.cursor = torch.ones(1, dtype=torch.int32, device=dev)  # the next view to load is order[1]
+        if getattr(self, '_order_store', None) is None:
+            cap = max(int(capacity or 0), 4 * self.n_views, len(order))
+            self._order_store = torch.zeros(cap, dtype=torch.int32, device=dev)
+            self.cursor = torch.zeros(2, dtype=torch.int32, device=dev)  # {next position, length of the order}
+        if len(order) > self._order_store.numel():
+            raise ValueError(f'an order of {len(order)} views does not fit the {self._order_store.numel()} entries allocated by '
+                             f'the first set_order (captured graphs point at that storage): pass capacity= to the first call')
+        host = torch.tensor([int(v) for v in order], dtype=torch.int32)
+        self._order_store[:len(order)].copy_(host, non_blocking=False)
+        self.order = self._order_store[:len(order)]  # a view: same storage, the current length
+        self.cursor.copy_(torch.tensor([1, len(order)], dtype=torch.int32))  # the next view to load is order[1]
+        self._order_host = [int(v) for v in order]
         self.select(int(order[0]))
+
+    def seek(self, i: int):
+        """position the walk so that the next step trains view ``order[i % len(order)]`` (roll-back of an OverflowGuard:
+        redo from iteration i of a loop that follows the order), in place"""
+        assert getattr(self, 'order', None) is not None
+        n = len(self._order_host)
+        self.cursor[0:1].fill_(int(i) + 1)
+        self.select(self._order_host[int(i) % n])
 
     def rewind(self):
         """back to ``order[0]``, in place (captured graphs keep pointing at the same order / cursor storage)"""
-        assert getattr(self, 'order', None) is not None
-        self.cursor.fill_(1)
-        self.select(int(self.order[0].item()))
+        self.seek(0)
 
     def clear_order(self):
-        """back to explicit ``select`` calls"""
+        """back to explicit ``select`` calls (graphs captured with the self-advancing closing launch keep advancing the
+        cursor: capture again without ``next_view`` to stop that)"""
         self.order = None
+
+    def state_tensors(self):
+        """the device tensors a training loop mutates through this table (cursor + live slot): hand them to
+        ``OverflowGuard(extra_state=...)`` so that a roll-back also restores the position in the view order"""
+        return [t for t in (getattr(self, 'cursor', None), self.slot) if t is not None]
 
     def advance(self) -> Optional[ViewAdvance]:
         """the ``skgs_view_advance`` job of the closing launch (None until ``set_order`` was called)"""
         if getattr(self, 'order', None) is None:
             return None
-        return ViewAdvance(self.records.data_ptr(), self.order.data_ptr(), self.cursor.data_ptr(), self.slot.data_ptr(),
-                           int(self.order.numel()), SLOT_WORDS)
+        return ViewAdvance(self.records.data_ptr(), self._order_store.data_ptr(), self.cursor.data_ptr(), self.slot.data_ptr(),
+                           0, SLOT_WORDS)  # n_order = 0: the length is the device word cursor[1]
 
     # ---- device addresses of the live slot's fields
     def ptr(self, word: int) -> int:

@@ -421,8 +421,30 @@ def test_ordered_view_table_is_advanced_by_the_closing_launch():
         graphs(0)
         torch.cuda.synchronize()
         assert torch.equal(step.image, ref[v]), i
-        assert int(table.cursor.item()) == i + 2 and float(opt.step_count.item()) == i + 1
+        assert int(table.cursor[0].item()) == i + 2 and float(opt.step_count.item()) == i + 1
     assert len(graphs.graphs) == 1 and step.status()['overflow_events'] == 0
+    # a NEW order (another epoch's permutation, another length) is uploaded in place: the captured graph -- which holds the
+    # addresses of the order / cursor storage as kernel arguments -- follows it (the round-2 set_order
+    # re-allocated both, and the graph kept walking freed memory)
+    store, cur = table._order_store.data_ptr(), table.cursor.data_ptr()
+    order2 = [1, 1, 2, 0, 3, 4, 2]
+    table.set_order(order2)
+    assert table._order_store.data_ptr() == store and table.cursor.data_ptr() == cur
+    junk = [torch.full((64,), 7, dtype=torch.int32, device=dev) for _ in range(32)]  # what a freed block would be reused for
+    for i in range(len(order2) + 3):
+        v = order2[i % len(order2)]
+        assert torch.equal(table.slot, table.records[v]), i
+        graphs(0)
+        torch.cuda.synchronize()
+        assert torch.equal(step.image, ref[v]), i
+    assert all(int(j.sum()) == 7 * 64 for j in junk) and len(graphs.graphs) == 1
+    table.seek(4)  # (the roll-back of an OverflowGuard: redo from iteration 4)
+    for i in range(4, 9):
+        assert torch.equal(table.slot, table.records[order2[i % len(order2)]]), i
+        graphs(0)
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError):
+        table.set_order(list(range(V)) * 5)  # longer than the storage the graph points at
     table.clear_order()
     assert table.advance() is None
 

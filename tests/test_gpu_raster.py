@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_close_robust, oracle_backward, oracle_forward, rel_err, scene_inputs, to_np
+from helpers import FlipCensus, assert_close_robust, oracle_backward, oracle_forward, rel_err, scene_inputs, to_np
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -85,9 +85,15 @@ def check_forward(o, act, rs, extras=None, colors=None, cov3D=None, strict=False
         if extras is not None:
             np.testing.assert_array_equal(to_np(out_extra), ref['out_extra'])
     else:
-        assert_close_robust(color, ref['color'], TOL, name='color')
-        assert_close_robust(opacity, ref['opacity'], TOL, name='opacity')
-        assert (nc != ref['img']['n_contrib'].astype(np.int64)).mean() <= 1e-4
+        # every pixel over the tolerance must sit within 2e-6 of a branch of the reference walk (helpers.FlipCensus)
+        # (exact census when the census walk -- one pixel per lane -- reproduces this image bit for bit, else every pixel
+        # within rounding distance of a branch counts as possibly flipped)
+        ccol, cop, cen = _C().render_census(W, H, geom, binning, img)
+        exact = torch.equal(ccol, color) and torch.equal(cop, opacity)
+        census = FlipCensus(o, ref, W, H, tol=TOL, name=f'P={P} {W}x{H}')
+        census.check_image(color, opacity, cen if exact else None)
+        ref['census'] = census
+        assert (nc != ref['img']['n_contrib'].astype(np.int64)).mean() <= 2e-5
         if extras is not None:
             assert_close_robust(out_extra, ref['out_extra'], TOL, name='out_extra')
     return ref, fwd
@@ -118,7 +124,7 @@ def test_forward_backward_parity(oracle32, colmap, P, W, H, seed, scale_mult, pp
                 err = rel_err(t, gref[name].reshape(to_np(t).shape))
                 assert err <= 1e-5, (name, err)
             else:
-                assert_close_robust(t, gref[name], TOL, outlier_frac=1e-3, name=name)
+                ref['census'].check_rows(t, gref[name], name)
         assert got[8] is None
     finally:
         _C().set_pixels_per_lane(0)
