@@ -17,6 +17,7 @@
  *   skgs_mark_visible            <- mark_visible (commented out)      my_ext/_C/src/nerf/gaussian_rasterizer_imp.cu:75-103
  *   skgs_lbs_deform_forward/backward <- networks/sk_gs.py:1143-1150,1162,1192-1203 (+ lietorch SE3.act, lie.h:59-64,246)
  *   skgs_knn_bones               <- pytorch3d.ops.knn_points call     networks/sk_gs.py:757
+ *   skgs_knn_dist_weights_*      <- calc_LBS_weight, `weighted_kernel` / `kernel` / `dist` branches  networks/sk_gs.py:757-766,770
  *
  * Opaque buffers (the reference's geomBuffer / binningBuffer / imgBuffer uint8 tensors, gaussian_render.h:118-158):
  * the caller allocates them with the sizes returned by skgs_*_buffer_bytes() and hands the same bytes back to the
@@ -234,6 +235,23 @@ int skgs_lbs_deform_backward_logits(const skgs_deform_inputs* in, const float* g
 /* K (<= 16) nearest bones by squared L2 in `dim` dimensions, ascending, ties to the lower index. */
 int skgs_knn_bones(int32_t P, int32_t M, int32_t K, int32_t dim, const float* points, const float* joints,
     float* out_dist, int64_t* out_idx, skgs_stream_t stream);
+/* The two distance-based branches of calc_LBS_weight fused with the search (networks/sk_gs.py:757-766,770): K nearest bones in
+ * `dim` (<= 16) dimensions as skgs_knn_bones, then
+ *   kernel_radius != NULL:  w = (exp(-d / (2 r_i^2)) [* kernel_weight_i] + 1e-7) / sum_k(...)   (`kernel` / `weighted_kernel`;
+ *                           r = exp(_sp_radius), kernel_weight = sigmoid(_sp_weight): the [M] activations stay with the caller)
+ *   kernel_radius == NULL:  w = softmax_k(-d / temperature)                                    (`dist`)
+ * out_idx [P,K] int64, out_weights [P,K], out_dist [P,K] (kept for the backward).
+ * Backward: g_weights [P,K] -> g_points [P,dim] (optional), g_joints [M,dim], g_kernel_radius [M], g_kernel_weight [M]
+ * (optional ones may be NULL): what autograd returns through knn_points' distances and the [indices] gathers.  The
+ * workspace holds per-workgroup partial sums (skgs_knn_dist_weights_workspace_bytes). */
+int skgs_knn_dist_weights_forward(int32_t P, int32_t M, int32_t K, int32_t dim, const float* points, const float* joints,
+    const float* kernel_radius, const float* kernel_weight, float temperature, int64_t* out_idx, float* out_weights,
+    float* out_dist, skgs_stream_t stream);
+size_t skgs_knn_dist_weights_workspace_bytes(int32_t P, int32_t M, int32_t dim);
+int skgs_knn_dist_weights_backward(int32_t P, int32_t M, int32_t K, int32_t dim, const float* points, const float* joints,
+    const float* kernel_radius, const float* kernel_weight, float temperature, const float* weights, const int64_t* indices,
+    const float* nn_dist, const float* g_weights, float* g_points, float* g_joints, float* g_kernel_radius,
+    float* g_kernel_weight, void* workspace, size_t workspace_bytes, skgs_stream_t stream);
 /* LBS weights from the per-Gaussian logits, the `sp_W` branch of calc_LBS_weight (networks/sk_gs.py:769-770):
  * weights[P,K] = softmax_k(sp_W[p, indices[p,k]]).  The backward writes the DENSE gradient g_sp_W[P,M] (zeros for the
  * bones outside the K nearest), i.e. what autograd's gather backward accumulates into a zero tensor. */

@@ -79,7 +79,8 @@ EXPORTED_SYMBOLS = [
     'skgs_geom_buffer_bytes', 'skgs_img_buffer_bytes', 'skgs_binning_buffer_bytes', 'skgs_binning_capacity',
     'skgs_rasterize_forward_stage1', 'skgs_rasterize_forward_stage2', 'skgs_rasterize_forward', 'skgs_read_status',
     'skgs_backward_workspace_bytes', 'skgs_rasterize_backward', 'skgs_rasterize_extra_forward',
-    'skgs_rasterize_extra_backward', 'skgs_topk_weights', 'skgs_render_census', 'skgs_mark_visible', 'skgs_lbs_deform_forward',
+    'skgs_rasterize_extra_backward', 'skgs_topk_weights', 'skgs_render_census', 'skgs_knn_dist_weights_forward', 'skgs_knn_dist_weights_backward',
+    'skgs_knn_dist_weights_workspace_bytes', 'skgs_mark_visible', 'skgs_lbs_deform_forward',
     'skgs_lbs_deform_backward', 'skgs_lbs_deform_backward_workspace_bytes', 'skgs_knn_bones',
     'skgs_lbs_weights_forward', 'skgs_lbs_weights_backward', 'skgs_last_error', 'skgs_version',
 ]

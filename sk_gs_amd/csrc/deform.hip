@@ -656,6 +656,168 @@ __global__ void __launch_bounds__(256) lbs_logits_scatter_kernel(int P, int M, i
   for (size_t i = threadIdx.x; i < n; i += 256) dst[i] = s_rows[i];
 }
 
+// ------------------------------------------------------------- distance-based LBS weightings, fused with the search
+// The two other branches of calc_LBS_weight (networks/sk_gs.py:757-770; `LBS_method` weighted_kernel is the class default,
+// sk_gs.py:364, exps/d_nerf_sc_gs.yaml:31):
+//   kernel / weighted_kernel   w = (exp(-d / (2 r_i^2)) [* s_i] + 1e-7) / sum_k (...)      r = kernel_radius, s = kernel_weight
+//   dist                       w = softmax_k(-d / temperature)
+// with d, i the squared distances / ids of the K nearest bones in `dim` dimensions (3 in stage sk; 3 + 8 hyper-feature
+// dimensions in stage sp, sk_gs.py:753-755).  Round 2 ran these as ~8 element-wise torch launches + autograd on top of the
+// KNN kernel; here one launch per direction.  The forward keeps the distances for the backward.
+template <int KCAP>
+__global__ void __launch_bounds__(256) knn_dist_weights_kernel(int P, int M, int K, int dim, const float* __restrict__ points,
+    const float* __restrict__ joints, const float* __restrict__ radius, const float* __restrict__ kweight, float temperature,
+    int64_t* __restrict__ out_idx, float* __restrict__ out_weights, float* __restrict__ out_dist, int lds_joints) {
+  extern __shared__ float s_j[];
+  if (lds_joints) {
+    for (int i = threadIdx.x; i < M * dim; i += blockDim.x) s_j[i] = joints[i];
+    __syncthreads();
+  }
+  const float* jt = lds_joints ? s_j : joints;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= P) return;
+  float bd[KCAP];
+  int bi[KCAP];
+#pragma unroll
+  for (int k = 0; k < KCAP; ++k) bd[k] = __builtin_inff(), bi[k] = 0;
+  const float* pn = points + (size_t) n * dim;
+  const float p0 = pn[0], p1 = dim > 1 ? pn[1] : 0.f, p2 = dim > 2 ? pn[2] : 0.f;
+  for (int j = 0; j < M; ++j) {  // the search of knn_bones_kernel: same sums, same order, same ties
+    float d = 0.f;
+    if (dim == 3) {
+      const float d0 = p0 - jt[3 * j], d1 = p1 - jt[3 * j + 1], d2 = p2 - jt[3 * j + 2];
+      d += d0 * d0;
+      d += d1 * d1;
+      d += d2 * d2;
+    } else {
+      for (int c = 0; c < dim; ++c) {
+        const float df = pn[c] - jt[(size_t) j * dim + c];
+        d += df * df;
+      }
+    }
+    topk_insert<KCAP>(bd, bi, d, j);
+  }
+  float v[KCAP];
+  float sum = 0.f;
+  if (radius) {  // sk_gs.py:760-766, in its order: exp(-d / (2 r^2)), * s, + 1e-7, / sum
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) {
+      v[k] = 0.f;
+      if (k < K) {
+        const float r = radius[bi[k]];
+        float e = expf(-bd[k] / (2.f * (r * r)));
+        if (kweight) e = e * kweight[bi[k]];
+        v[k] = e + 1e-7f;
+        sum += v[k];
+      }
+    }
+  } else {  // sk_gs.py:770: softmax(-d / temperature)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) {
+      v[k] = k < K ? -bd[k] / temperature : -INFINITY;
+      mx   = fmaxf(mx, v[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) {
+      v[k] = k < K ? expf(v[k] - mx) : 0.f;
+      sum += v[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KCAP; ++k)
+    if (k < K) {
+      out_weights[(size_t) n * K + k] = v[k] / sum;
+      out_idx[(size_t) n * K + k]     = bi[k];
+      out_dist[(size_t) n * K + k]    = bd[k];
+    }
+}
+
+// Backward of the above: g_w [P,K] -> g_d [P,K] (per method) -> g_points [P,dim] = sum_k 2 g_d (p - j_k) (optional), and per
+// bone the sums  g_joints[j] = -sum 2 g_d (p - j),  g_radius[j] = sum g_e e d / r^3,  g_kweight[j] = sum g_v e  over the
+// (Gaussian, neighbour) pairs that picked bone j (what autograd's index / gather backward scatter-add in the reference).
+// A fixed grid of workgroups walks the Gaussians; each keeps [M][dim + 2] accumulators in LDS (ds_add_f32), writes them as
+// one partial, and `dist_weights_finalize_kernel` adds the partials in workgroup order.
+constexpr int DW_MAX_BLOCKS = 512;
+__global__ void __launch_bounds__(256) dist_weights_backward_kernel(int P, int M, int K, int dim,
+    const float* __restrict__ points, const float* __restrict__ joints, const float* __restrict__ radius,
+    const float* __restrict__ kweight, float temperature, const float* __restrict__ weights,
+    const int64_t* __restrict__ indices, const float* __restrict__ nn_dist, const float* __restrict__ g_weights,
+    float* __restrict__ g_points, float* __restrict__ partials) {
+  extern __shared__ float s_acc[];  // [M][V]
+  const int V = dim + 2;
+  for (int i = threadIdx.x; i < M * V; i += 256) s_acc[i] = 0.f;
+  __syncthreads();
+  for (int n = blockIdx.x * 256 + threadIdx.x; n < P; n += gridDim.x * 256) {
+    const float* w  = weights + (size_t) n * K;
+    const float* gw = g_weights + (size_t) n * K;
+    const float* dd = nn_dist + (size_t) n * K;
+    const int64_t* ix = indices + (size_t) n * K;
+    float dot = 0.f;
+    for (int k = 0; k < K; ++k) dot += w[k] * gw[k];
+    float sum = 0.f;
+    if (radius)  // S = sum_k v_k is not stored: recompute it with the forward's arithmetic
+      for (int k = 0; k < K; ++k) {
+        const float r = radius[(int) ix[k]];
+        float e = expf(-dd[k] / (2.f * (r * r)));
+        if (kweight) e = e * kweight[(int) ix[k]];
+        sum += e + 1e-7f;
+      }
+    float g_d[KNN_MAXK];  // (compile-time indexed: stays in registers)
+    int jj[KNN_MAXK];
+#pragma unroll
+    for (int k = 0; k < KNN_MAXK; ++k) {
+      g_d[k] = 0.f, jj[k] = 0;
+      if (k < K) {
+        const int j = (int) ix[k];
+        jj[k]       = j;
+        if (radius) {
+          const float r   = radius[j];
+          const float e   = expf(-dd[k] / (2.f * (r * r)));
+          const float sk  = kweight ? kweight[j] : 1.f;
+          const float g_v = (gw[k] - dot) / sum;
+          const float g_e = g_v * sk;
+          g_d[k]          = g_e * e * (-1.f / (2.f * (r * r)));
+          atomicAdd(s_acc + (size_t) j * V + dim, g_e * e * (dd[k] / (r * r * r)));
+          if (kweight) atomicAdd(s_acc + (size_t) j * V + dim + 1, g_v * e);
+        } else {
+          g_d[k] = -(w[k] * (gw[k] - dot)) / temperature;
+        }
+      }
+    }
+    for (int c = 0; c < dim; ++c) {
+      const float pc = points[(size_t) n * dim + c];
+      float gp = 0.f;
+#pragma unroll
+      for (int k = 0; k < KNN_MAXK; ++k)
+        if (k < K) {
+          const float t = g_d[k] * 2.f * (pc - joints[(size_t) jj[k] * dim + c]);
+          gp += t;
+          atomicAdd(s_acc + (size_t) jj[k] * V + c, -t);
+        }
+      if (g_points) g_points[(size_t) n * dim + c] = gp;
+    }
+  }
+  __syncthreads();
+  float* dst = partials + (size_t) blockIdx.x * M * V;
+  for (int i = threadIdx.x; i < M * V; i += 256) dst[i] = s_acc[i];
+}
+__global__ void __launch_bounds__(256) dist_weights_finalize_kernel(int M, int dim, int nblk, const float* __restrict__ partials,
+    float* __restrict__ g_joints, float* __restrict__ g_radius, float* __restrict__ g_kweight) {
+  const int V = dim + 2, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * V) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partials[(size_t) b * M * V + i];
+  const int j = i / V, c = i % V;
+  if (c < dim) {
+    if (g_joints) g_joints[(size_t) j * dim + c] = s;
+  } else if (c == dim) {
+    if (g_radius) g_radius[j] = s;
+  } else if (g_kweight) {
+    g_kweight[j] = s;
+  }
+}
+
 // K nearest bones + LBS weights in one pass (the two calls of calc_LBS_weight, sk_gs.py:757,769-770): top-K as
 // knn_bones_kernel (dim = 3), then softmax of the gathered logits; indices and weights leave through LDS so that a
 // workgroup stores contiguous spans instead of K strided 8-byte pieces per lane.
@@ -936,6 +1098,54 @@ int launch_knn_lbs_weights(int P, int M, int K, const float* points, const float
   else
     SKGS_KNNW(KNN_MAXK);
 #undef SKGS_KNNW
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_knn_dist_weights_forward(int P, int M, int K, int dim, const float* points, const float* joints, const float* radius,
+    const float* kweight, float temperature, int64_t* out_idx, float* out_weights, float* out_dist, hipStream_t s) {
+  if (P == 0) return 0;
+  if (K > KNN_MAXK || K < 1 || K > M) return set_error("knn_dist_weights: K must be in [1,min(%d,M)] (got %d)", KNN_MAXK, K);
+  if (dim < 1 || dim > 16) return set_error("knn_dist_weights: dim must be in [1,16] (got %d)", dim);
+  const size_t lds = (size_t) M * dim * 4;
+  const int use_lds = lds <= 48 * 1024;
+  ProfScope prof(K_KNN, s);
+#define SKGS_KNND(KCAP_)                                                                                                     \
+  hipLaunchKernelGGL(knn_dist_weights_kernel<KCAP_>, dim3((P + 255) / 256), dim3(256), use_lds ? lds : 0, s, P, M, K, dim, points, \
+      joints, radius, kweight, temperature, out_idx, out_weights, out_dist, use_lds)
+  if (K <= 4)
+    SKGS_KNND(4);
+  else if (K <= 5)
+    SKGS_KNND(5);
+  else if (K <= 8)
+    SKGS_KNND(8);
+  else
+    SKGS_KNND(KNN_MAXK);
+#undef SKGS_KNND
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+static int dist_weights_blocks(int P) { return std::max(1, std::min((P + 255) / 256, DW_MAX_BLOCKS)); }
+size_t knn_dist_weights_workspace_bytes(int P, int M, int dim) {
+  return (size_t) dist_weights_blocks(P) * M * (dim + 2) * sizeof(float);
+}
+int launch_knn_dist_weights_backward(int P, int M, int K, int dim, const float* points, const float* joints, const float* radius,
+    const float* kweight, float temperature, const float* weights, const int64_t* indices, const float* nn_dist,
+    const float* g_weights, float* g_points, float* g_joints, float* g_radius, float* g_kweight, void* workspace,
+    size_t workspace_bytes, hipStream_t s) {
+  if (K > KNN_MAXK || K < 1) return set_error("knn_dist_weights_backward: K must be in [1,%d] (got %d)", KNN_MAXK, K);
+  if (dim < 1 || dim > 16) return set_error("knn_dist_weights_backward: dim must be in [1,16] (got %d)", dim);
+  const int V = dim + 2, nblk = dist_weights_blocks(P);
+  const size_t lds = (size_t) M * V * 4;
+  if (lds > 60 * 1024) return set_error("knn_dist_weights_backward: %d bones x %d values do not fit the LDS accumulators", M, V);
+  if (workspace_bytes < knn_dist_weights_workspace_bytes(P, M, dim) || !workspace)
+    return set_error("knn_dist_weights_backward: workspace too small (%zu bytes)", workspace_bytes);
+  float* partials = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(dist_weights_backward_kernel, dim3(nblk), dim3(256), lds, s, P, M, K, dim, points, joints, radius, kweight,
+      temperature, weights, indices, nn_dist, g_weights, g_points, partials);
+  hipLaunchKernelGGL(dist_weights_finalize_kernel, dim3((M * V + 255) / 256), dim3(256), 0, s, M, dim, nblk, partials, g_joints,
+      g_radius, g_kweight);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

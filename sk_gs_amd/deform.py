@@ -92,12 +92,68 @@ class _KnnSoftmaxWeights(torch.autograd.Function):
         return None, None, g_sp_W, None
 
 
+class _KnnDistWeights(torch.autograd.Function):
+    """``knn_points`` + the `weighted_kernel` / `kernel` / `dist` weighting of calc_LBS_weight (sk_gs.py:757-766,770) as ONE
+    launch per direction (``skgs_knn_dist_weights_forward/backward``): search, weights, and in the backward the gradients
+    autograd hands to the points / joints (through the distances), ``kernel_radius`` and ``kernel_weight``."""
+
+    @staticmethod
+    def forward(ctx, points, joints, kernel_radius, kernel_weight, temperature: float, K: int):
+        lib = _C.load_library()
+        _C._require_gpu(points, 'points')
+        dev = points.device
+        with _C._on_device(dev):
+            pts, jts = _C._f32c(points, dev), _C._f32c(joints, dev)
+            rad = None if kernel_radius is None else _C._f32c(kernel_radius, dev)
+            kw = None if kernel_weight is None else _C._f32c(kernel_weight, dev)
+            P, dim = pts.shape
+            M = jts.shape[0]
+            idx = torch.empty((P, K), dtype=torch.int64, device=dev)
+            w = torch.empty((P, K), dtype=torch.float32, device=dev)
+            dist = torch.empty((P, K), dtype=torch.float32, device=dev)
+            _C._check(lib.skgs_knn_dist_weights_forward(
+                C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(dim), C.c_void_p(_C._ptr(pts)), C.c_void_p(_C._ptr(jts)),
+                C.c_void_p(_C._ptr(rad)), C.c_void_p(_C._ptr(kw)), C.c_float(float(temperature)), C.c_void_p(_C._ptr(idx)),
+                C.c_void_p(_C._ptr(w)), C.c_void_p(_C._ptr(dist)), _C._stream()))
+        ctx.save_for_backward(pts, jts, rad, kw, w, idx, dist)
+        ctx.temperature = float(temperature)
+        ctx.mark_non_differentiable(idx)
+        return w, idx
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_w, _g_idx):
+        pts, jts, rad, kw, w, idx, dist = ctx.saved_tensors
+        lib = _C.load_library()
+        dev = w.device
+        P, K = w.shape
+        M, dim = jts.shape
+        need_p, need_j, need_r, need_k = ctx.needs_input_grad[:4]
+        with _C._on_device(dev):
+            g_w = _C._f32c(g_w, dev)
+            g_p = torch.empty((P, dim), dtype=torch.float32, device=dev) if need_p else None
+            g_j = torch.empty((M, dim), dtype=torch.float32, device=dev) if need_j else None
+            g_r = torch.empty((M,), dtype=torch.float32, device=dev) if (need_r and rad is not None) else None
+            g_k = torch.empty((M,), dtype=torch.float32, device=dev) if (need_k and kw is not None) else None
+            lib.skgs_knn_dist_weights_workspace_bytes.restype = C.c_size_t
+            nbytes = int(lib.skgs_knn_dist_weights_workspace_bytes(C.c_int32(P), C.c_int32(M), C.c_int32(dim)))
+            ws = torch.empty((max(nbytes, 16) + 3) // 4, dtype=torch.float32, device=dev)
+            _C._check(lib.skgs_knn_dist_weights_backward(
+                C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(dim), C.c_void_p(_C._ptr(pts)), C.c_void_p(_C._ptr(jts)),
+                C.c_void_p(_C._ptr(rad)), C.c_void_p(_C._ptr(kw)), C.c_float(ctx.temperature), C.c_void_p(_C._ptr(w)),
+                C.c_void_p(_C._ptr(idx)), C.c_void_p(_C._ptr(dist)), C.c_void_p(_C._ptr(g_w)), C.c_void_p(_C._ptr(g_p)),
+                C.c_void_p(_C._ptr(g_j)), C.c_void_p(_C._ptr(g_r)), C.c_void_p(_C._ptr(g_k)), C.c_void_p(ws.data_ptr()),
+                C.c_size_t(ws.numel() * 4), _C._stream()))
+        return g_p, g_j, g_r, g_k, None, None
+
+
 def calc_lbs_weight(points: Tensor, joints: Tensor, K: int, sp_W: Optional[Tensor] = None,
                     kernel_radius: Optional[Tensor] = None, kernel_weight: Optional[Tensor] = None,
                     temperature: float = 1., feature: Optional[Tensor] = None, sp_feature: Optional[Tensor] = None
                     ) -> Tuple[Tensor, Tensor]:
     """``calc_LBS_weight`` of the reference (networks/sk_gs.py:751-774): K nearest bones + one of three weightings.
-    The P x M nearest-neighbour search runs in the HIP ``knn_bones`` kernel (pytorch3d.knn_points semantics)."""
+    Every branch is one HIP launch per direction (pytorch3d.knn_points semantics for the search): `W` on xyz through
+    ``skgs_knn_lbs_weights``, the distance-based ones -- in 3 or 3 + 8 dimensions -- through ``skgs_knn_dist_weights_*``."""
     if feature is not None and sp_feature is not None:
         points = torch.cat([points.detach(), feature], dim=-1)
         joints_q = torch.cat([joints.detach(), sp_feature], dim=-1)
@@ -106,10 +162,15 @@ def calc_lbs_weight(points: Tensor, joints: Tensor, K: int, sp_W: Optional[Tenso
         # plain `W` method on xyz: search + gather + softmax in one launch (joint table in LDS: a few thousand bones at most)
         if sp_W is not None and kernel_radius is None and points.shape[-1] == 3 and K <= 16 and K <= sp_W.shape[1] <= 2048:
             return _KnnSoftmaxWeights.apply(points.detach(), joints.detach(), sp_W, K)
+    if sp_W is None or kernel_radius is not None:
+        # `weighted_kernel` / `kernel` / `dist` (sk_gs.py:759-766,770): search + weighting in one launch, and one launch
+        # (+ a reduction of per-workgroup partials) for the gradients to the joints / features, radii and kernel weights
+        if K <= 16 and points.shape[-1] <= 16:
+            return _KnnDistWeights.apply(points, joints_q, kernel_radius, kernel_weight, float(temperature), K)
     with torch.no_grad():
         _, indices = _C.knn_bones(points.detach(), joints_q.detach(), K)
     if kernel_radius is not None or (sp_W is None):
-        # distances must carry gradients to the joints for these two methods: recompute them in torch on [P,K]
+        # (K > 16 or more than 16 dimensions: torch glue on [P,K]) distances must carry gradients to the joints
         nn_dist = (points[:, None, :] - joints_q[indices]).square().sum(-1)
     if kernel_radius is not None:
         radius = kernel_radius[indices]
