@@ -509,6 +509,10 @@ int skgs_split_children(int32_t n, int32_t N, const float* normals, float* xyz, 
 void skgs_set_pixels_per_lane(int ppl);
 /* Parity-test switch: blend kernels without FMA contraction, in the oracle's operation order, reproducible exp. */
 void skgs_set_strict_math(int on);
+/* Order in which the blend kernels' workgroups walk the tiles: 1 (default) groups of 8 tiles heaviest first (ranked inside
+ * the sort launch from the per-tile counts), 0 raster order.  Results do not depend on it; for A/B timing (set it before
+ * a hipGraph capture: the mode is a launch argument). */
+void skgs_set_tile_order(int mode);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (bit k of the mask enables kernel id k; ids are
  * 0..skgs_profile_kernel_count()-1, names via skgs_profile_kernel_name). skgs_profile_collect waits for the events

@@ -79,7 +79,7 @@ EXPORTED_SYMBOLS = [
     'skgs_geom_buffer_bytes', 'skgs_img_buffer_bytes', 'skgs_binning_buffer_bytes', 'skgs_binning_capacity',
     'skgs_rasterize_forward_stage1', 'skgs_rasterize_forward_stage2', 'skgs_rasterize_forward', 'skgs_read_status',
     'skgs_backward_workspace_bytes', 'skgs_rasterize_backward', 'skgs_rasterize_extra_forward',
-    'skgs_rasterize_extra_backward', 'skgs_topk_weights', 'skgs_render_census', 'skgs_knn_dist_weights_forward', 'skgs_knn_dist_weights_backward',
+    'skgs_rasterize_extra_backward', 'skgs_topk_weights', 'skgs_render_census', 'skgs_set_tile_order', 'skgs_knn_dist_weights_forward', 'skgs_knn_dist_weights_backward',
     'skgs_knn_dist_weights_workspace_bytes', 'skgs_mark_visible', 'skgs_lbs_deform_forward',
     'skgs_lbs_deform_backward', 'skgs_lbs_deform_backward_workspace_bytes', 'skgs_knn_bones',
     'skgs_lbs_weights_forward', 'skgs_lbs_weights_backward', 'skgs_last_error', 'skgs_version',
@@ -111,6 +111,8 @@ def load_library():
         lib.skgs_binning_capacity.argtypes = [C.c_size_t]
         lib.skgs_binning_buffer_bytes.argtypes = [C.c_int64]
         lib.skgs_last_error.restype = C.c_char_p
+        if os.environ.get('SKGS_TILE_ORDER') is not None:  # A/B timing of the blend kernels' tile order (0: raster order)
+            lib.skgs_set_tile_order(C.c_int(int(os.environ['SKGS_TILE_ORDER'])))
         _lib = lib
     return _lib
 
@@ -236,6 +238,11 @@ def densify_stats(radii: Tensor, grad_means2D: Tensor, xyz_gradient_accum: Tenso
     _check(lib.skgs_densify_stats(C.c_int32(P), C.c_void_p(_ptr(radii)), C.c_void_p(_ptr(grad_means2D)),
                                   C.c_float(float(grad_multiplier)), C.c_void_p(_ptr(xyz_gradient_accum)), C.c_void_p(_ptr(denom)),
                                   C.c_void_p(_ptr(max_radii2D)), _stream()))
+
+
+def set_tile_order(mode: int):
+    """1 (default): the blend kernels walk groups of 8 tiles heaviest first; 0: raster order (``skgs_set_tile_order``)"""
+    load_library().skgs_set_tile_order(C.c_int(int(mode)))
 
 
 def set_strict_math(on: bool):
@@ -383,12 +390,16 @@ def unpack_buffers(W: int, H: int, P: int, geomBuffer: Tensor, binningBuffer: Te
     tile_counts = imgBuffer[o:o + T * 4].view(torch.int32)
     o += a256(T * 4)
     tile_offsets = imgBuffer[o:o + (T + 1) * 4].view(torch.int32)
+    o += a256((T + 1) * 4) + 4 * a256(T * 4)  # cursors, tile_begin, tile_end, worklist
+    G = (T + 7) // 8
+    group_order = imgBuffer[o:o + G * 4].view(torch.int32)
     cap = int(load_library().skgs_binning_capacity(C.c_size_t(binningBuffer.numel())))
     keys = binningBuffer[:cap * 8].view(torch.int64)
     plo = a256(cap * 8)
     point_list = binningBuffer[plo:plo + cap * 4].view(torch.int32)
     return dict(num_rendered=hdr[0], overflow=hdr[1], max_tile_count=hdr[2], recs=recs, n_contrib=n_contrib,
-                tile_counts=tile_counts, tile_offsets=tile_offsets, keys=keys, point_list=point_list, capacity=cap)
+                tile_counts=tile_counts, tile_offsets=tile_offsets, group_order=group_order, keys=keys, point_list=point_list,
+                capacity=cap)
 
 
 def update_capacity_hint(P: int, W: int, H: int, num_rendered: int):

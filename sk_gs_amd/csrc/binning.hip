@@ -485,15 +485,54 @@ __global__ void __launch_bounds__(SORT_THREADS) tile_sort_merge_kernel(const Geo
   }
 }
 
+// The order the blend kernels walk the tiles in (VALUBusy 71 % forward / 84 % backward at config #1 against
+// 94 % at #4 -- 10 000 single-wave workgroups over 8192 wave slots with list lengths 207 mean / 424 max is a 1.2-round
+// grid whose tail is whatever long tile happens to be dispatched last).  Groups of 8 consecutive tiles (the unit that
+// xcd_remap keeps on one XCD / in one L2) are ranked by their total list length, heaviest first: the hardware dispatches
+// workgroups in blockIdx order, so the long lists start first and the short ones fill the tail (longest-processing-
+// time-first).  Ranking = one comparison pass over the group weights in LDS (rank = number of heavier groups; ties by
+// id): 313 groups at 800 x 800, no barrier ladder.  Runs as workgroup 0 of the sort launch -- the counts are final since the
+// scatter, nothing here depends on the sorting -- so it costs no launch and hides behind the sort.
+constexpr int ORDER_MAX_GROUPS = 4096;  // 32768 tiles (e.g. 2896 x 2896); beyond: identity order
+int g_tile_order_mode = 1;
+__device__ void tile_order_job(int T, int bucket, int mode, const uint32_t* __restrict__ cursors,
+    const uint32_t* __restrict__ tile_begin, const uint32_t* __restrict__ tile_end, uint32_t* __restrict__ group_order) {
+  __shared__ uint32_t s_key[ORDER_MAX_GROUPS];
+  const int G = tile_groups(T);
+  if (G > ORDER_MAX_GROUPS || mode == 0) {
+    for (int g = threadIdx.x; g < G; g += blockDim.x) group_order[g] = (uint32_t) g;
+    return;
+  }
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    uint32_t w = 0;
+    for (int t = g * TILE_GROUP; t < min(T, (g + 1) * TILE_GROUP); ++t)
+      w += bucket ? min(cursors[t], (uint32_t) bucket) : tile_end[t] - tile_begin[t];
+    s_key[g] = (min(w, 0xfffffu) << 12) | (uint32_t) (ORDER_MAX_GROUPS - 1 - g);  // unique: heavier first, then lower id
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    const uint32_t k = s_key[g];
+    int rank = 0;
+    for (int h = 0; h < G; ++h) rank += s_key[h] > k ? 1 : 0;  // uniform LDS address per iteration: broadcast reads
+    group_order[rank] = (uint32_t) g;
+  }
+}
+
 // One workgroup = 4 waves = 4 consecutive tiles: each wave sorts its own list of at most 512 keys in registers (the steps
-// are latency-bound: four waves side by side); longer lists go to the worklist of the merge kernel above.
+// are latency-bound: four waves side by side); longer lists go to the worklist of the merge kernel above.  Workgroup 0 is
+// the tile-order job above.
 __global__ void __launch_bounds__(256) tile_sort_wave_kernel(int T, int bucket, const uint32_t* __restrict__ cursors,
     uint32_t* __restrict__ tile_begin, uint32_t* __restrict__ tile_end, uint32_t* __restrict__ worklist, GeomHeader* hdr,
-    uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list, int64_t capacity) {
+    uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list, int64_t capacity, uint32_t* __restrict__ group_order,
+    int order_mode) {
+  if (blockIdx.x == 0) {
+    tile_order_job(T, bucket, order_mode, cursors, tile_begin, tile_end, group_order);
+    return;
+  }
   __shared__ int s_big[4];
   __shared__ int s_base;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * 4 + wave;
+  const int tile = (blockIdx.x - 1) * 4 + wave;
   int64_t s64 = 0, e64 = 0;
   if (tile < T) {
     if (bucket) {  // bucket layout: the per-tile cursor is the count; this kernel publishes the tile's range
@@ -542,6 +581,9 @@ __global__ void __launch_bounds__(256) tile_sort_wave_kernel(int T, int bucket, 
 
 }  // namespace
 
+// 1 (default): the blend kernels walk the tile groups heaviest first; 0: in raster order (A/B measurements)
+extern "C" void skgs_set_tile_order(int mode) { g_tile_order_mode = mode ? 1 : 0; }
+
 int launch_scan_tiles(GeomView g, ImgView im, int64_t P, hipStream_t s) {
   ProfScope prof(K_SCAN, s);
   if (P > 0) {
@@ -577,8 +619,8 @@ int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, Bi
   SKGS_CHECK_HIP(hipGetLastError());
   {
     ProfScope prof(K_SORT, s);
-    hipLaunchKernelGGL(tile_sort_wave_kernel, dim3((im.T + 3) / 4), dim3(256), 0, s, im.T, bucket, im.cursors, im.tile_begin,
-        im.tile_end, im.worklist, g.hdr, b.keys, b.point_list, b.capacity);
+    hipLaunchKernelGGL(tile_sort_wave_kernel, dim3((im.T + 3) / 4 + 1), dim3(256), 0, s, im.T, bucket, im.cursors, im.tile_begin,
+        im.tile_end, im.worklist, g.hdr, b.keys, b.point_list, b.capacity, im.group_order, g_tile_order_mode);
     // lists longer than 512 keys: one workgroup per list drains the worklist (chunk sorts in registers + merge rounds in
     // LDS).  A bucket layout whose buckets hold no more than a wave sorts cannot produce one: no launch.  Lists of up to
     // 2048 keys take the one-chunk-per-wave instantiation (32 KB of LDS), up to 4096 the two-chunk one (64 KB), up to 8192

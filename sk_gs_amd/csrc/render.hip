@@ -313,11 +313,11 @@ int launch_render_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, 
     const int nblk = xcd_grid(im.T * (4 / PPL_));                                                                       \
     if (g_strict)                                                                                                       \
       hipLaunchKernelGGL((blend_strict::render_forward_kernel<PPL_, E_>), dim3(nblk), dim3(64), 0, s, W, H, im.tiles_x, \
-          im.T, TileRanges{im.tile_begin, im.tile_end}, b.capacity, b.point_list, g.recs, in.extras, in.background, im.n_contrib, out_color,   \
+          im.T, TileRanges{im.tile_begin, im.tile_end, im.group_order}, b.capacity, b.point_list, g.recs, in.extras, in.background, im.n_contrib, out_color,   \
           out_opacity, out_extra, (uint32_t*) nullptr);                                                                 \
     else                                                                                                                \
       hipLaunchKernelGGL((blend_fast::render_forward_kernel<PPL_, E_>), dim3(nblk), dim3(64), 0, s, W, H, im.tiles_x,   \
-          im.T, TileRanges{im.tile_begin, im.tile_end}, b.capacity, b.point_list, g.recs, in.extras, in.background, im.n_contrib, out_color,   \
+          im.T, TileRanges{im.tile_begin, im.tile_end, im.group_order}, b.capacity, b.point_list, g.recs, in.extras, in.background, im.n_contrib, out_color,   \
           out_opacity, out_extra, (uint32_t*) nullptr);                                                                 \
   }
   if (ppl == 4) {
@@ -339,11 +339,11 @@ int launch_render_census(int W, int H, GeomView g, ImgView im, BinView b, float*
   const int nblk = xcd_grid(im.T * 4);
   if (g_strict)
     hipLaunchKernelGGL((blend_strict::render_forward_kernel<1, 0, true>), dim3(nblk), dim3(64), 0, s, W, H, im.tiles_x, im.T,
-        TileRanges{im.tile_begin, im.tile_end}, b.capacity, b.point_list, g.recs, (const float*) nullptr,
+        TileRanges{im.tile_begin, im.tile_end, im.group_order}, b.capacity, b.point_list, g.recs, (const float*) nullptr,
         (const float*) nullptr, im.n_contrib, out_color, out_opacity, (float*) nullptr, census);
   else
     hipLaunchKernelGGL((blend_fast::render_forward_kernel<1, 0, true>), dim3(nblk), dim3(64), 0, s, W, H, im.tiles_x, im.T,
-        TileRanges{im.tile_begin, im.tile_end}, b.capacity, b.point_list, g.recs, (const float*) nullptr,
+        TileRanges{im.tile_begin, im.tile_end, im.group_order}, b.capacity, b.point_list, g.recs, (const float*) nullptr,
         (const float*) nullptr, im.n_contrib, out_color, out_opacity, (float*) nullptr, census);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
@@ -364,11 +364,11 @@ int launch_render_backward(const skgs_raster_inputs& in, GeomView g, ImgView im,
     const int nblk = xcd_grid(im.T * (4 / PPL_));                                                                      \
     if (g_strict)                                                                                                      \
       hipLaunchKernelGGL((blend_strict::render_backward_kernel<PPL_, E_>), dim3(nblk), dim3(64), 0, s, W, H,           \
- im.tiles_x, im.T, TileRanges{im.tile_begin, im.tile_end}, b.capacity, b.point_list, g.recs, in.extras, in.background, out_opacity,       \
+ im.tiles_x, im.T, TileRanges{im.tile_begin, im.tile_end, im.group_order}, b.capacity, b.point_list, g.recs, in.extras, in.background, out_opacity,       \
           im.n_contrib, dL_dcolor, dL_dextra, dL_dopacity, gradacc);                                                               \
     else                                                                                                               \
       hipLaunchKernelGGL((blend_fast::render_backward_kernel<PPL_, E_>), dim3(nblk), dim3(64), 0, s, W, H, im.tiles_x, \
-          im.T, TileRanges{im.tile_begin, im.tile_end}, b.capacity, b.point_list, g.recs, in.extras, in.background, out_opacity, im.n_contrib,   \
+          im.T, TileRanges{im.tile_begin, im.tile_end, im.group_order}, b.capacity, b.point_list, g.recs, in.extras, in.background, out_opacity, im.n_contrib,   \
           dL_dcolor, dL_dextra, dL_dopacity, gradacc);                                                                           \
   }
   if (ppl == 4) {

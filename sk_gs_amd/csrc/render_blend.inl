@@ -42,9 +42,9 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
     float* __restrict__ out_color, float* __restrict__ out_opacity, float* __restrict__ out_extra,
     uint32_t* __restrict__ census = nullptr /* [H*W][2]: blended entries, sum of census_mix(position) */) {
   constexpr int SUBS = 4 / PPL;
-  const int v        = xcd_remap(blockIdx.x, T * SUBS);
-  if (v >= T * SUBS) return;
-  const int tile = v / SUBS, sub = v % SUBS;
+  static_assert(XCD_GROUP == TILE_GROUP * 4, "one xcd_remap group = one group of tiles at one pixel per lane");
+  int tile, sub;
+  if (!blend_work_item<SUBS>(xcd_remap(blockIdx.x, T * SUBS), T, ranges.group_order, tile, sub)) return;
   const int lane = threadIdx.x;
   const Pix<PPL> pix = pixel_setup<PPL>(tile, sub, lane, gx, W, H);
 
@@ -247,9 +247,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
     float* __restrict__ gradacc) {
   constexpr int SUBS = 4 / PPL;
   constexpr int NV   = 9 + E;
-  const int v        = xcd_remap(blockIdx.x, T * SUBS);
-  if (v >= T * SUBS) return;
-  const int tile = v / SUBS, sub = v % SUBS;
+  int tile, sub;
+  if (!blend_work_item<SUBS>(xcd_remap(blockIdx.x, T * SUBS), T, ranges.group_order, tile, sub)) return;
   const int lane = threadIdx.x;
   const Pix<PPL> pix = pixel_setup<PPL>(tile, sub, lane, gx, W, H);
 

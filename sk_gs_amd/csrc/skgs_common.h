@@ -41,7 +41,8 @@ __host__ __device__ inline GeomView geom_view(void* base) {
 inline size_t geom_bytes(int32_t P) { return 256 + (size_t) P * 48 + 256; }
 
 // ---- img buffer ----------------------------------------------------------------------------------------
-// n_contrib[H*W] u32 | tile_counts[T] | tile_offsets[T+1] | cursors[T] | tile_begin[T] | tile_end[T] | worklist[T]
+// n_contrib[H*W] u32 | tile_counts[T] | tile_offsets[T+1] | cursors[T] | tile_begin[T] | tile_end[T] | worklist[T] |
+// group_order[ceil(T/8)] (groups of 8 consecutive tiles, longest first: the order the blend kernels walk them in)
 // (each 256-B aligned).  tile_begin / tile_end are what every consumer of the lists reads: the compact layout fills
 // them from the scan (begin = offsets[t], end = offsets[t+1]), the bucket layout (skgs_raster_inputs::
 // tile_bucket_capacity) from the per-tile cursors (begin = t * Lcap).
@@ -53,12 +54,26 @@ struct ImgView {
   uint32_t* tile_begin;
   uint32_t* tile_end;
   uint32_t* worklist;
+  uint32_t* group_order;
   int tiles_x, tiles_y, T;
 };
+constexpr int TILE_GROUP = 8;  // consecutive tiles that travel together through xcd_remap (one XCD, one L2)
+__host__ __device__ inline int tile_groups(int T) { return (T + TILE_GROUP - 1) / TILE_GROUP; }
 struct TileRanges {
   const uint32_t* begin;
   const uint32_t* end;
+  const uint32_t* group_order;  // [ceil(T/8)]: permutation of the tile groups, heaviest first (binning.hip::tile_order_job)
 };
+// work item v (after xcd_remap) of a blend launch -> (tile, sub): the groups of 8 tiles are walked in `group_order`
+template <int SUBS>
+__device__ __forceinline__ bool blend_work_item(int v, int T, const uint32_t* __restrict__ group_order, int& tile, int& sub) {
+  constexpr int PER_GROUP = TILE_GROUP * SUBS;
+  const int g = v / PER_GROUP, j = v % PER_GROUP;
+  if (g >= tile_groups(T)) return false;
+  tile = (int) group_order[g] * TILE_GROUP + j / SUBS;
+  sub  = j % SUBS;
+  return tile < T;
+}
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 __host__ __device__ inline size_t align256_hd(size_t x) { return (x + 255) & ~size_t(255); }
 inline ImgView img_view(void* base, int W, int H) {
@@ -80,12 +95,14 @@ inline ImgView img_view(void* base, int W, int H) {
   v.tile_end = reinterpret_cast<uint32_t*>(p);
   p += align256((size_t) v.T * 4);
   v.worklist = reinterpret_cast<uint32_t*>(p);
+  p += align256((size_t) v.T * 4);
+  v.group_order = reinterpret_cast<uint32_t*>(p);
   return v;
 }
 inline size_t img_bytes(int W, int H) {
   int T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
   return align256((size_t) W * H * 4) + align256((size_t) T * 4) + align256((size_t) (T + 1) * 4) +
-         4 * align256((size_t) T * 4) + 256;
+         4 * align256((size_t) T * 4) + align256((size_t) tile_groups(T) * 4) + 256;
 }
 
 // ---- binning buffer ------------------------------------------------------------------------------------

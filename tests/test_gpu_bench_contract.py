@@ -27,17 +27,23 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert r['bound'] in ('hbm', 'mfma') and r['unit'] == 'GB/s' and r['peak'] == 8000.0
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-4 and r['achieved'] > 0
     assert abs(d['value'] - 1000.0 / d['ms_per_step']) / d['value'] < 0.01
+    b = d['ms_per_step_blocks']  # the spread of the timed region: 8 steps -> 8 blocks
+    assert b['blocks'] == 8 and b['min'] <= b['p10'] <= b['median'] <= b['p90'] <= b['max']
+    assert abs(b['median'] - d['ms_per_step']) / d['ms_per_step'] < 0.25
 
 
-@pytest.mark.parametrize('port,ranks,extra', [(29577, 2, []), (29578, 2, ['--pipeline']), (29579, 2, ['--compact-logits']),
-                                              (29580, 2, ['--autograd']), (29581, 4, []), (29582, 2, ['--sh-factors']),
-                                              (29583, 2, ['--sh-factors', '--overlap-gather']), (29584, 2, ['--bone-tables']),
-                                              (29587, 2, ['--graph-per-view']), (29588, 2, ['--pre-forward', 'off'])])
+PLAIN = ['--exchange', 'allreduce']
+
+
+@pytest.mark.parametrize('port,ranks,extra', [(29577, 2, PLAIN), (29578, 2, ['--pipeline']), (29579, 2, ['--compact-logits']),
+                                              (29580, 2, ['--autograd']), (29581, 4, PLAIN), (29582, 2, ['--sh-factors']),
+                                              (29583, 2, ['--sh-factors', '--overlap-gather']), (29584, 2, PLAIN + ['--bone-tables']),
+                                              (29587, 2, PLAIN + ['--graph-per-view']), (29588, 2, PLAIN + ['--pre-forward', 'off'])])
 def test_ranks_share_the_gpu_and_stay_identical(port, ranks, extra):
     """The driver's multi-GPU launch line with 2 or 4 ranks on this one GPU (gloo moves the gradients: RCCL refuses two ranks
     per device): the real view-parallel schedule -- graph(fwd+bwd) | all-reduce | graph(Adam) -- must keep the replicas
-    bit-identical and print one line from rank 0 with whole-job throughput.  Default exchange: ONE plain all-reduce of the
-    flat gradient buffer; the byte-saving exchanges are flags."""
+    bit-identical and print one line from rank 0 with whole-job throughput.  `--exchange allreduce`: ONE plain all-reduce of
+    the flat gradient buffer; the byte-saving / overlapping exchanges are flags (the default, `auto`, ranks them: next test)."""
     env = dict(os.environ, SKGS_DIST_BACKEND='gloo', SKGS_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr',
            '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--steps', '6',
@@ -50,13 +56,41 @@ def test_ranks_share_the_gpu_and_stay_identical(port, ranks, extra):
     assert d['n_gpus'] == ranks and d['steps'] == 6 and d['scaling'] == 'weak'
     assert d['config']['replicas_identical'] is True
     par = d['config']['parallelism']
-    if not extra:
+    if extra == PLAIN:
+        assert d['config']['exchange'] == 'allreduce'
         assert 'flat-buffer grad all-reduce' in par and 'compact' not in par and 'factors' not in par, par
         assert 'closing launch' in d['config']['adam'] and 'skeleton-forward' in d['config']['adam'], d['config']['adam']
-    if extra == ['--pre-forward', 'off']:
+    if extra == PLAIN + ['--pre-forward', 'off']:
         assert d['config']['adam'] == 'one launch after the backward', d['config']['adam']
     assert abs(d['value'] - ranks * 1000.0 / d['ms_per_step']) / d['value'] < 0.01  # whole-job: every rank's view per step
     assert 'cpu_baseline' not in d
+
+
+@pytest.mark.parametrize('port,ranks', [(29591, 2), (29592, 4)])
+def test_default_multi_rank_run_ranks_every_exchange_variant(port, ranks):
+    """`bench.py --gpus N` with NO exchange flag (what the driver's scaling run issues): every exchange variant is timed in
+    the same processes, each must keep the replicas bit-identical, the reported value is the fastest variant's, and all
+    variants trained the same parameters up to summation order"""
+    env = dict(os.environ, SKGS_DIST_BACKEND='gloo', SKGS_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--steps', '6',
+           '--warmup', '2']
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    ev = d['exchange_variants']
+    assert set(ev) == {'allreduce', 'factors', 'factors-overlap', 'pipeline'}, ev
+    for name, r in ev.items():
+        assert 'error' not in r and r['replicas_identical'] is True, (name, r)
+    best = d['config']['exchange']
+    assert best == max(ev, key=lambda n: ev[n]['value']) and d['value'] == ev[best]['value']
+    assert d['n_gpus'] == ranks and d['steps'] == 6 and d['config']['replicas_identical'] is True
+    assert abs(d['value'] - ranks * 1000.0 / d['ms_per_step']) / d['value'] < 0.01
+    digests = [r['param_digest'] for r in ev.values()]
+    assert max(digests) - min(digests) <= 1e-6 * abs(digests[0]), digests
+    assert d['ms_per_step_blocks']['blocks'] == 6 and 'cpu_baseline' not in d
 
 
 def test_factor_exchange_and_dense_exchange_train_the_same_parameters():
@@ -64,7 +98,7 @@ def test_factor_exchange_and_dense_exchange_train_the_same_parameters():
     (default) must leave the same parameters up to summation order"""
     env = dict(os.environ, SKGS_DIST_BACKEND='gloo', SKGS_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     digests = []
-    for port, extra in ((29585, ['--sh-factors']), (29586, [])):
+    for port, extra in ((29585, ['--sh-factors']), (29586, PLAIN)):
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
                '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6',
                '--warmup', '2', '--no-cpu-baseline', '--eager'] + extra
@@ -82,7 +116,7 @@ def test_riding_update_and_plain_update_train_the_same_parameters():
     the blend backward's atomics do not order their additions, hence a tolerance)"""
     env = dict(os.environ, SKGS_DIST_BACKEND='gloo', SKGS_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     digests = []
-    for port, extra in ((29589, []), (29590, ['--pre-forward', 'off'])):
+    for port, extra in ((29589, PLAIN), (29590, PLAIN + ['--pre-forward', 'off'])):
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
                '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6',
                '--warmup', '2', '--no-cpu-baseline'] + extra

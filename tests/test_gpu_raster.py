@@ -273,6 +273,40 @@ def test_async_capacity_overflow_flag():
         C._capacity_hint.clear()
 
 
+def test_blend_kernels_walk_the_tile_groups_heaviest_first_and_the_order_changes_nothing():
+    """the group order written by the sort launch (binning.hip::tile_order_job) is a permutation of the groups of 8 tiles,
+    by total list length descending (ties: lower id first); with the order switched off (raster order) the forward is
+    bit-identical and the backward differs only by the order of its atomic additions"""
+    C = _C()
+    P, W, H = 30000, 400, 304
+    act, rs, cam = scene_inputs(P, W, H, seed=9, colmap=True, scale_mult=1.5, device='cuda')
+    g = torch.Generator().manual_seed(2)
+    gc, go = torch.randn(3, H, W, generator=g).cuda(), torch.randn(H, W, generator=g).cuda()
+    try:
+        C.set_tile_order(1)
+        fwd = hip_forward(act, rs)
+        bufs = C.unpack_buffers(W, H, P, fwd[4], fwd[5], fwd[6])
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        G = (T + 7) // 8
+        counts = torch.zeros(G * 8, dtype=torch.long, device='cuda')
+        counts[:T] = bufs['tile_counts'].long()
+        weight = counts.view(G, 8).sum(1)
+        order = bufs['group_order'].long()
+        assert sorted(order.tolist()) == list(range(G))
+        want = sorted(range(G), key=lambda i: (-int(weight[i]), i))
+        assert order.tolist() == want
+        grads = hip_backward(fwd, act, rs, gc, go)
+        C.set_tile_order(0)
+        fwd0 = hip_forward(act, rs)
+        assert C.unpack_buffers(W, H, P, fwd0[4], fwd0[5], fwd0[6])['group_order'].tolist() == list(range(G))
+        assert torch.equal(fwd0[1], fwd[1]) and torch.equal(fwd0[2], fwd[2]) and torch.equal(fwd0[3], fwd[3])
+        grads0 = hip_backward(fwd0, act, rs, gc, go)
+        for name, a, b in zip(GRAD_NAMES, grads, grads0):
+            assert rel_err(a, b) <= 2e-5, name
+    finally:
+        C.set_tile_order(1)
+
+
 def test_single_gaussian_closed_form():
     """one isotropic Gaussian at the image centre: alpha(x) = o * exp(-r^2 / (2 s^2)) with s^2 = (f*sigma/z)^2 + 0.3"""
     import math
