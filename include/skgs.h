@@ -454,6 +454,11 @@ typedef struct skgs_bone_chain_desc {
   const float* g_bone_T;                                /* backward: [M,7] */
   float* g_joints;                                      /* backward: [M,3] chain part, written; may be NULL */
   float* g_global_T;                                    /* backward: [7] (row frame_index), written; may be NULL */
+  float* sk_cache;                                      /* skgs_skeleton_forward only, may be NULL: [frames, M, 11] -- row
+                                                         * frame_index receives [normalised joint rotation | d_rot | d_scale],
+                                                         * the reference's `self.sk_cache[time_id] = ...` under no_grad in
+                                                         * every training step (networks/sk_gs.py:1077-1079), which the
+                                                         * test-time path interpolates (:1080-1085) */
 } skgs_bone_chain_desc;
 int skgs_skeleton_forward(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, const float* points, const float* t,
     float* x0, float* acts, void* workspace, size_t workspace_bytes, const skgs_adam_range* side /* may be NULL */,

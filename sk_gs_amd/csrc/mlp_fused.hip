@@ -99,6 +99,9 @@ struct FusedArgs {
   // has produced yet)
   int has_chain;
   chain::ChainArgs chain;
+  // skeleton forward in training: the frame's row of the test-time cache, sk_cache[frame_index] = [normalised joint
+  // rotation | d_rot | d_scale] (networks/sk_gs.py:1077-1079), written by the workgroups that own the heads' columns
+  float* sk_cache;  // [frames][B][out_last] or NULL
 };
 
 __device__ __forceinline__ FusedLayer get_layer(const FusedArgs& a, int l) {
@@ -499,6 +502,19 @@ __global__ void __launch_bounds__(NT) fused_mlp_forward_kernel(const FusedArgs a
           if (c + 1 < L.out) *head_elem(a, a.head_out, a.out, row, c + 1, L.out) = y.y;
           if (c + 2 < L.out) *head_elem(a, a.head_out, a.out, row, c + 2, L.out) = y.z;
           if (c + 3 < L.out) *head_elem(a, a.head_out, a.out, row, c + 3, L.out) = y.w;
+          if (a.sk_cache) {  // (no_grad copy for test-time interpolation, sk_gs.py:1077-1085)
+            const int frame = a.chain.frame_index ? a.chain.frame_index[0] : 0;
+            float* cr = a.sk_cache + ((size_t) frame * B + row) * L.out;
+            if (c == 0) {  // F.normalize(raw + [0, 0, 0, 1]): the expression of chain::stage_skeleton
+              const chain::Q4 q = chain::qnormalize({y.x, y.y, y.z, y.w + 1.0f});
+              cr[0] = q.x, cr[1] = q.y, cr[2] = q.z, cr[3] = q.w;
+            } else {
+              if (c < L.out) cr[c] = y.x;
+              if (c + 1 < L.out) cr[c + 1] = y.y;
+              if (c + 2 < L.out) cr[c + 2] = y.z;
+              if (c + 3 < L.out) cr[c + 3] = y.w;
+            }
+          }
         } else {
           store16_sc1(img + ((size_t) l * G + g) * Bp * NC + 4 * tid, y);
           *reinterpret_cast<float4*>(a.acts + ((size_t) l * B + row) * H + col0 + 4 * part) = y;
@@ -899,6 +915,7 @@ int fill_chain(const skgs_mlp_desc* d, const Plan& p, const skgs_bone_chain_desc
   c.M = b->M, c.root = b->root, c.num_levels = b->num_levels, c.parents = b->parents, c.level_nodes = b->level_nodes;
   c.level_start = b->level_start, c.joints = b->joints, c.global_T = b->global_T, c.frame_index = b->frame_index;
   c.bone_T = b->bone_T, c.chain_A = b->chain_A;
+  a->sk_cache = b->sk_cache;
   return 0;
 }
 int fill_side(const skgs_adam_range* side, FusedArgs* a) {

@@ -232,7 +232,7 @@ class BoneChainDesc(C.Structure):
                 ('parents', C.c_void_p), ('level_nodes', C.c_void_p), ('level_start', C.c_void_p),
                 ('joints', C.c_void_p), ('global_T', C.c_void_p), ('frame_index', C.c_void_p),
                 ('bone_T', C.c_void_p), ('chain_A', C.c_void_p), ('sk_r_raw', C.c_void_p), ('g_bone_T', C.c_void_p),
-                ('g_joints', C.c_void_p), ('g_global_T', C.c_void_p)]
+                ('g_joints', C.c_void_p), ('g_global_T', C.c_void_p), ('sk_cache', C.c_void_p)]
 
 
 def fused_supported(mlp: 'DeformMLP', B: int) -> bool:

@@ -420,6 +420,9 @@ class FusedViewStep:
         b.sk_r_raw, b.g_bone_T = self._sk_r_raw.data_ptr(), self.g_bone_T.data_ptr()
         b.g_joints = m.joints.grad.data_ptr() if getattr(m, 'learn_joints', False) else None
         b.g_global_T = g_gT
+        # every training step refreshes the frame's row of the test-time cache (sk_gs.py:1077-1079); written by the launch
+        cache = getattr(m, 'sk_cache', None)
+        b.sk_cache = cache.data_ptr() if (cache is not None and cache.is_cuda and cache.shape[1] == self.M) else None
         return b
 
     def _joint_rotations(self, time_id: Optional[int]) -> Tensor:

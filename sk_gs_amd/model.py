@@ -69,6 +69,9 @@ class SkinnedGaussians(nn.Module):
                 self.sk_deform_net.dynamic_net.last_weight.mul_(0.01)
                 self.sk_deform_net.dynamic_net.last_bias.zero_()
             self.register_buffer('frame_times', torch.linspace(0., 1., frames).view(frames, 1))
+            # [normalised joint rotation | d_rot | d_scale] of every frame as of its last training step: what the reference
+            # keeps for test-time interpolation (register_buffer('sk_cache'), sk_gs.py:526,1077-1085)
+            self.register_buffer('sk_cache', torch.zeros(frames, max(M, 1), 11))
             self.sk_r = self.sk_d_rot = self.sk_d_scale = None
         else:
             self.sk_r = nn.Parameter(rot0 - rot0.new_tensor([0, 0, 0, 1.]))
@@ -113,8 +116,24 @@ class SkinnedGaussians(nn.Module):
             return self.sk_r[time_id], self.sk_d_rot[time_id], self.sk_d_scale[time_id]
         t = self.frame_times[time_id]
         if self.joints.is_cuda:
-            return tuple(self.sk_deform_net(self.joints, t))
-        return tuple(self.sk_deform_net.reference_forward(self.joints, t))
+            outs = tuple(self.sk_deform_net(self.joints, t))
+        else:
+            outs = tuple(self.sk_deform_net.reference_forward(self.joints, t))
+        if self.training and torch.is_grad_enabled():  # sk_gs.py:1077-1079 (the fused step's launch writes the same row)
+            with torch.no_grad():
+                self.sk_cache[time_id] = torch.cat([F.normalize(outs[0] + self._rot_bias, dim=-1), outs[1], outs[2]], dim=-1)
+        return outs
+
+    def cached_joint_outputs(self, t: float):
+        """test-time path of kinematic() (sk_gs.py:1080-1085): the cache rows of the two training frames around time `t`,
+        linearly interpolated; returns (normalised joint rotations [M,4], d_rot [M,4], d_scale [M,3])"""
+        times = self.frame_times.view(-1)
+        i2 = int(torch.searchsorted(times, torch.as_tensor(float(t), device=times.device)).clamp(1, len(times) - 1)) \
+            if len(times) > 1 else 0
+        i1 = max(i2 - 1, 0)
+        w = 0.0 if i1 == i2 else float((t - times[i1]) / (times[i2] - times[i1]))
+        row = torch.lerp(self.sk_cache[i1], self.sk_cache[i2], w)
+        return F.normalize(row[:, :4], dim=-1), row[:, 4:8], row[:, 8:11]
 
     def bone_transforms(self, time_id: int):
         sk_r_raw, d_rot, d_scale = self.joint_outputs(time_id)

@@ -1,0 +1,133 @@
+"""The step bench.py times, at BASELINE sizes, against the drop-in operator path + torch.optim.Adam (VERDICT r2 #1d).
+
+bench.py's one-rank step is NOT the configuration the small fused-step tests run: fixed per-tile buckets instead of compact
+tile lists, one captured graph for all views with camera / time / target read from the device view slot, the views walked
+by the closing launch (`ViewTable.set_order`), `FusedTrainStep` (the rows' Adam riding on the skeleton stage's backward
+launch, the closing piece with the encoder backward), and above ~270k Gaussians `pre_forward` (the step ends with the NEXT
+view's skeleton forward, which carries 40 % of the rows' update).  Here exactly that composition trains two steps at config
+#1 (100k Gaussians, 800x800) and #4 (500k, 1024x1024), pre_forward off and on, and every parameter is compared with a
+replica trained by `model.render()` (the reference-named operator surface) + `image_loss` + autograd backward +
+`torch.optim.Adam(eps=1e-15)`.
+
+What "equal" means after Adam: the first updates are lr * g / (|g| + 1e-15) -- the SIGN of the gradient wherever it is not
+exactly zero -- so the two paths' summation-order noise (1e-7 relative) flips the update of elements whose gradient is
+noise around zero by up to 2 lr, however small the gradient.  The comparison is therefore in units of the group's learning
+rate: |p_fused - p_ref| / lr  <= 0.02 for all but 1e-3 of a tensor's elements, and never more than 2 steps x 2 lr; the
+rendered image of the second step (parameters after one update, the next view) must agree to 1e-4.
+"""
+import copy
+
+import pytest
+import torch
+
+from helpers import assert_close_robust
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {1: dict(P=100_000, M=20, K=5, W=800, H=800), 4: dict(P=500_000, M=24, K=5, W=1024, H=1024)}
+VIEWS, STEPS, LR = 3, 2, 1e-4
+
+
+def _bench_runtime(model, settings, targets, background, pre_forward):
+    """the composition of bench.py's default one-rank step (bench.py: ViewTable / FusedViewStep(tile_bucket) / FusedAdam /
+    FusedTrainStep / set_order / pre_forward / GraphedSteps)"""
+    from sk_gs_amd import _C
+    from sk_gs_amd.fused_step import FusedViewStep
+    from sk_gs_amd.optim import FusedAdam
+    from sk_gs_amd.train_step import FusedTrainStep, GraphedSteps
+    from sk_gs_amd.view_parallel import ViewParallel
+    from sk_gs_amd.view_slot import ViewTable
+    dev = targets.device
+    W, H = settings[0].image_width, settings[0].image_height
+    table = ViewTable(settings, [float(model.frame_times[v]) for v in range(VIEWS)], list(range(VIEWS)), targets, dev)
+    ViewParallel(model.parameters(), average=True)  # the flat gradient buffer, 16-byte aligned views
+    _C.config.sync_num_rendered = True
+    Rs, longest = [], 0
+    with torch.no_grad():
+        for v in range(VIEWS):
+            buf = model.render(settings[v], time_id=v, background=background)['buffer']
+            Rs.append(buf.R)
+            longest = max(longest, _C.read_status(buf.geomBuffer)['max_tile_count'])
+    tile_bucket = ((int(longest * 1.5) + 63) // 64) * 64
+    if 512 < tile_bucket and longest * 1.2 <= 512:
+        tile_bucket = 512
+    _C.config.sync_num_rendered = False
+    fstep = FusedViewStep(model, W, H, capacity=int(max(Rs) * 1.25 * _C.config.capacity_growth) + 1024,
+                          background=background, tile_bucket=tile_bucket, view_table=table)
+    span = fstep.table_grad_span()
+    fstep.tables_zeroed_by_optimizer = span is not None
+    opt = FusedAdam(model.param_groups(lr=LR), eps=1e-15, betas=(0.9, 0.999), zero_after_step=span)
+    train = FusedTrainStep(fstep, opt)
+    assert train.fused
+    table.set_order(list(range(VIEWS)))
+    train.set_pre_forward(pre_forward)
+    assert train.pre_forward == pre_forward
+    train.prime()
+    return fstep, opt, train, GraphedSteps(lambda _: train()), table
+
+
+@pytest.mark.parametrize('cfg,pre_forward', [(1, False), (1, True), (4, False), (4, True)])
+def test_bench_step_trains_the_same_parameters_as_operator_path_plus_torch_adam(cfg, pre_forward):
+    from sk_gs_amd import _C, scene
+    from sk_gs_amd.losses import image_loss
+    from sk_gs_amd.model import SkinnedGaussians
+    c = CONFIGS[cfg]
+    P, M, K, W, H = c['P'], c['M'], c['K'], c['W'], c['H']
+    dev = torch.device('cuda')
+    model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=VIEWS, seed=0, deform_net=True, learn_joints=True).to(dev)
+    ref_model = copy.deepcopy(model)
+    settings = [scene.raster_settings_from_camera(scene.make_camera(W, H, seed=i), sh_degree=3, colmap=True, device=dev)
+                for i in range(VIEWS)]
+    background = torch.ones(3, device=dev)
+    gen = torch.Generator().manual_seed(77)
+    _C.config.sync_num_rendered = True
+    with torch.no_grad():  # bench.py's targets: the model's own renders + noise
+        targets = torch.stack([(model.render(settings[v], time_id=v, background=background)['images']
+                                + 0.05 * torch.randn(3, H, W, generator=gen).to(dev)).clamp(0, 1) for v in range(VIEWS)]).contiguous()
+    try:
+        # ---- reference: operator path + torch Adam, views 0, 1
+        ref_opt = torch.optim.Adam(ref_model.param_groups(lr=LR), eps=1e-15, betas=(0.9, 0.999))
+        ref_images = []
+        for i in range(STEPS):
+            ref_opt.zero_grad(set_to_none=True)
+            out = ref_model.render(settings[i], time_id=i, background=background)
+            ref_images.append(out['images'].detach().clone())
+            image_loss(out['images'], targets[i]).backward()
+            ref_opt.step()
+        # ---- the bench's step, replayed as ONE graph
+        fstep, opt, train, graph, table = _bench_runtime(model, settings, targets, background, pre_forward)
+        images = []
+        for i in range(STEPS):
+            assert torch.equal(table.slot, table.records[i]), i
+            graph(0)
+            images.append(fstep.image.clone())
+        torch.cuda.synchronize()
+        st = fstep.status()
+        assert st['overflow_events'] == 0 and st.get('mlp_failed', 0) == 0 and float(opt.step_count.item()) == STEPS
+        for i in range(STEPS):
+            assert_close_robust(images[i], ref_images[i], 1e-4, name=f'config{cfg} pre_forward={pre_forward} image of step {i}')
+        # ---- every parameter, in units of its group's learning rate
+        lrs = {id(p): g['lr'] for g in opt.param_groups for p in g['params']}
+        ref_params = dict(ref_model.named_parameters())
+        checked = 0
+        for n, p in model.named_parameters():
+            lr = lrs.get(id(p))
+            if lr is None or lr == 0.0:
+                assert torch.equal(p, ref_params[n]), n
+                continue
+            d = (p.detach() - ref_params[n].detach()).abs() / lr
+            frac = float((d > 0.02).float().mean())
+            print(f'[bench step] config{cfg} pre_forward={pre_forward} {n}: {p.numel()} elements, {frac:.2e} differ by more than '
+                  f'0.02 lr, max {float(d.max()):.3f} lr')
+            assert frac <= max(1e-3, 1.5 / p.numel()), (n, frac)
+            assert float(d.max()) <= 2.0 * STEPS * 1.01, (n, float(d.max()))
+            checked += 1
+        assert checked >= 8
+        # the parameters did move (a step that silently skipped its update would also "agree" with nothing)
+        fresh = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=VIEWS, seed=0, deform_net=True, learn_joints=True).to(dev)
+        for n, p0 in fresh.named_parameters():
+            if n in ('_xyz', '_features_dc', '_opacity', 'sp_W', 'joints'):
+                assert not torch.equal(p0, dict(model.named_parameters())[n]), n
+    finally:
+        _C.config.sync_num_rendered = True
+        _C._capacity_hint.clear()

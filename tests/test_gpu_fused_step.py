@@ -527,3 +527,52 @@ def test_fused_step_with_one_or_few_bones_matches_autograd(M, K):
     assert rel_err(step.image, out['images'].detach()) <= 5e-6 and step.status()['mlp_failed'] == 0
     for n, p in model.named_parameters():
         assert_close_robust(p.grad, ref[n], 2e-4, 1e-3, name=n)
+
+
+def test_training_steps_refresh_the_frames_row_of_sk_cache():
+    """every training step stores [normalised joint rotation | d_rot | d_scale] of its frame in ``sk_cache`` under no_grad
+    (networks/sk_gs.py:1077-1079) for the test-time interpolation (:1080-1085): the fused skeleton-forward launch writes
+    the row itself, the operator path does it in torch -- same row; other frames' rows stay as they were"""
+    import torch.nn.functional as F
+    from sk_gs_amd import _C, scene
+    from sk_gs_amd.fused_step import FusedViewStep
+    from sk_gs_amd.model import SkinnedGaussians
+    P, M, K, W, H, frames = 3000, 14, 4, 96, 64, 4
+    dev = torch.device('cuda')
+    model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=3, scale_mult=2.0, deform_net=True,
+                             learn_joints=True).to(dev)
+    with torch.no_grad():  # make the heads non-trivial
+        model.sk_deform_net.dynamic_net.last_weight.mul_(30.0)
+        model.sk_deform_net.dynamic_net.last_bias.normal_(0, 0.1)
+    rs = scene.raster_settings_from_camera(scene.make_camera(W, H, seed=1), sh_degree=3, colmap=True, device=dev)
+    target = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    assert tuple(model.sk_cache.shape) == (frames, M, 11) and float(model.sk_cache.abs().max()) == 0.0
+    _C.config.sync_num_rendered = True
+    with torch.no_grad():
+        R = model.render(rs, time_id=2)['buffer'].R
+        assert float(model.sk_cache.abs().max()) == 0.0  # no_grad render (test.py's path): the cache is not touched
+        raw, d_rot, d_scale = model.joint_outputs(2)
+    want = torch.cat([F.normalize(raw + raw.new_tensor([0, 0, 0, 1.]), dim=-1), d_rot, d_scale], -1)
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    step = FusedViewStep(model, W, H, capacity=int(R * 1.3) + 1024)
+    assert step._mlp_fused is not None
+    step.forward_backward(rs, 2, target)
+    torch.cuda.synchronize()
+    assert rel_err(model.sk_cache[2], want) <= 2e-6
+    assert float(model.sk_cache[[0, 1, 3]].abs().max()) == 0.0
+    # the operator path (autograd on) writes the same row
+    model.sk_cache.zero_()
+    model.render(rs, time_id=1)
+    raw1, d_rot1, d_scale1 = [t.detach() for t in model.joint_outputs(1)]
+    want1 = torch.cat([F.normalize(raw1 + raw1.new_tensor([0, 0, 0, 1.]), dim=-1), d_rot1, d_scale1], -1)
+    assert rel_err(model.sk_cache[1], want1) <= 2e-6 and float(model.sk_cache[2].abs().max()) == 0.0
+    # test-time read: at a training frame's time the interpolation returns its row, between two frames their blend
+    step.forward_backward(rs, 2, target)
+    torch.cuda.synchronize()
+    q, dr, ds = model.cached_joint_outputs(float(model.frame_times[2]))
+    assert rel_err(torch.cat([q, dr, ds], -1), model.sk_cache[2]) <= 1e-6
+    mid = 0.5 * float(model.frame_times[1] + model.frame_times[2])
+    q, dr, ds = model.cached_joint_outputs(mid)
+    blend = 0.5 * (model.sk_cache[1] + model.sk_cache[2])
+    assert rel_err(dr, blend[:, 4:8]) <= 1e-5 and rel_err(q, F.normalize(blend[:, :4], dim=-1)) <= 1e-5
