@@ -96,6 +96,11 @@ typedef struct skgs_raster_inputs {
   int32_t longest_list_hint;  /* stage 2 / forward: 0 = unknown; > 0 = an upper bound of the longest tile list (what stage 1
                               just reported): the sort launches for longer lists, which would find nothing to do, are
                               skipped (~4.5 us each) */
+  const int32_t* live_count;  /* NULL, or a DEVICE int32 n <= P: only Gaussians 0..n-1 exist.  P is then the CAPACITY the
+                               * launches are sized for; rows n..P-1 get radius 0 and an all-zero record (what a culled
+                               * Gaussian gets) and no gradient is written for them.  Densification (clone / split / prune,
+                               * networks/gaussian_splatting.py:565-636) changes n in place: a captured hipGraph of the step
+                               * stays valid -- nothing it baked in (pointers, grids, P) moved */
 } skgs_raster_inputs;
 
 typedef struct skgs_raster_buffers {
@@ -213,6 +218,8 @@ typedef struct skgs_deform_inputs {
   const float* log_scale;     /* [P,3] */
   const float* rot;           /* [P,4] */
   const float* opacity_logit; /* [P,1] */
+  const int32_t* live_count;  /* NULL, or a DEVICE int32 n <= P (see skgs_raster_inputs.live_count): the fused forward /
+                               * backward (skgs_knn_lbs_deform_forward, skgs_lbs_deform_backward_logits) skip rows >= n */
 } skgs_deform_inputs;
 /* means [P,3], scales [P,3], rotations [P,4] (normalised), opacity [P,1]; d_xyz/d_rot/d_scale optional (NULL) */
 int skgs_lbs_deform_forward(const skgs_deform_inputs* in, float* means, float* scales, float* rotations,
@@ -275,7 +282,8 @@ int skgs_lbs_weights_backward(int32_t P, int32_t M, int32_t K, const float* weig
 int skgs_knn_lbs_deform_forward(int32_t P, int32_t M, int32_t K, const float* points, const float* joints, const float* sp_W,
     const float* bone_T, const float* bone_drot, const float* bone_dscale, const float* xyz, const float* log_scale,
     const float* rot, const float* opacity_logit, int64_t* out_idx, float* out_weights, float* means, float* scales,
-    float* rotations, float* opacity, skgs_stream_t stream);
+    float* rotations, float* opacity, const int32_t* live_count /* may be NULL */,
+    skgs_stream_t stream);
 
 /* ---- bone chain (scope row a-3): joint rotations -> global bone transforms, one launch per direction ----
  * Replaces kinematic() + skeleton_warp_SE3() (networks/sk_gs.py:1069-1107,193-206; lietorch SE3 product lie.h:242-246).

@@ -40,7 +40,7 @@ class _RasterInputs(C.Structure):
         ('rotations', C.c_void_p), ('extras', C.c_void_p), ('colors_precomp', C.c_void_p),
         ('cov3D_precomp', C.c_void_p), ('sh_rest', C.c_void_p), ('background', C.c_void_p),
         ('tile_bucket_capacity', C.c_int32), ('tanfov_device', C.c_void_p),
-        ('host_status_words', C.c_int32), ('longest_list_hint', C.c_int32),
+        ('host_status_words', C.c_int32), ('longest_list_hint', C.c_int32), ('live_count', C.c_void_p),
     ]
 
 
@@ -71,7 +71,7 @@ class _DeformInputs(C.Structure):
         ('P', C.c_int32), ('K', C.c_int32), ('M', C.c_int32),
         ('points', C.c_void_p), ('weights', C.c_void_p), ('indices', C.c_void_p), ('bone_T', C.c_void_p),
         ('bone_drot', C.c_void_p), ('bone_dscale', C.c_void_p), ('xyz', C.c_void_p), ('log_scale', C.c_void_p),
-        ('rot', C.c_void_p), ('opacity_logit', C.c_void_p),
+        ('rot', C.c_void_p), ('opacity_logit', C.c_void_p), ('live_count', C.c_void_p),
     ]
 
 

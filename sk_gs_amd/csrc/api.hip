@@ -388,13 +388,13 @@ int skgs_knn_lbs_weights(int32_t P, int32_t M, int32_t K, const float* points, c
 int skgs_knn_lbs_deform_forward(int32_t P, int32_t M, int32_t K, const float* points, const float* joints, const float* sp_W,
     const float* bone_T, const float* bone_drot, const float* bone_dscale, const float* xyz, const float* log_scale,
     const float* rot, const float* opacity_logit, int64_t* out_idx, float* out_weights, float* means, float* scales,
-    float* rotations, float* opacity, skgs_stream_t stream) {
+    float* rotations, float* opacity, const int32_t* live_count, skgs_stream_t stream) {
   SKGS_REQUIRE(P == 0 || (points && joints && sp_W && bone_T && bone_drot && bone_dscale && xyz && log_scale && rot &&
                    opacity_logit && out_idx && out_weights && means && scales && rotations && opacity),
       "knn_lbs_deform_forward: NULL argument");
   SKGS_REQUIRE(M >= 1, "knn_lbs_deform_forward: M must be >= 1");
   return launch_knn_deform_forward(P, M, K, points, joints, sp_W, bone_T, bone_drot, bone_dscale, xyz, log_scale, rot,
-      opacity_logit, out_idx, out_weights, means, scales, rotations, opacity, (hipStream_t) stream);
+      opacity_logit, out_idx, out_weights, means, scales, rotations, opacity, live_count, (hipStream_t) stream);
 }
 
 int skgs_lbs_weights_forward(int32_t P, int32_t M, int32_t K, const float* sp_W, const int64_t* indices, float* weights,

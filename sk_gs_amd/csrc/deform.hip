@@ -261,7 +261,9 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_moments_kernel
     const float* __restrict__ g_opacity, float* __restrict__ g_weights, float* __restrict__ g_xyz,
     float* __restrict__ g_log_scale, float* __restrict__ g_rot, float* __restrict__ g_opacity_logit,
     float* __restrict__ partials /* [gridDim.x][M][19] */,
-    float* __restrict__ g_sp_W /* [P,M] or NULL */, float* __restrict__ g_logits /* [P,K] or NULL; both need K <= PREF_K */) {
+    float* __restrict__ g_sp_W /* [P,M] or NULL */, float* __restrict__ g_logits /* [P,K] or NULL; both need K <= PREF_K */,
+    const int32_t* __restrict__ live /* NULL, or the live Gaussian count (<= P) */) {
+  if (live) P = min(P, live[0]);  // the number of Gaussians is a device word: one captured graph survives densification
   extern __shared__ float s_mem[];
   const int Mp    = (M + 3) & ~3;                 // weight rows padded to float4
   float* s_bones  = s_mem;                        // [M][14]
@@ -884,7 +886,8 @@ __global__ void __launch_bounds__(256) knn_deform_forward_kernel(int P, int M, i
     const float* __restrict__ bone_drot, const float* __restrict__ bone_dscale, const float* __restrict__ xyz,
     const float* __restrict__ log_scale, const float* __restrict__ rot, const float* __restrict__ opacity_logit,
     int64_t* __restrict__ out_idx, float* __restrict__ out_weights, float* __restrict__ means, float* __restrict__ scales,
-    float* __restrict__ rotations, float* __restrict__ opacity) {
+    float* __restrict__ rotations, float* __restrict__ opacity, const int32_t* __restrict__ live) {
+  if (live) P = min(P, live[0]);  // the number of Gaussians is a device word: one captured graph survives densification
   extern __shared__ float s_dyn[];
   float* s_j       = s_dyn;                                                  // [M][3]
   float* s_bones   = s_dyn + ((M * 3 + 3) & ~3);                             // [M][14]
@@ -1003,7 +1006,8 @@ int launch_deform_backward(const skgs_deform_inputs& in, const float* g_means, c
       ProfScope prof(K_DEFORM_BWD, s);
       hipLaunchKernelGGL(deform_backward_moments_kernel, grid, block, lds, s, in.P, in.K, in.M, in.points, in.weights,
           in.indices, in.bone_T, in.bone_drot, in.bone_dscale, in.log_scale, in.rot, in.opacity_logit, g_means, g_scales,
-          g_rotations, g_opacity, g_weights, g_xyz, g_log_scale, g_rot, g_opacity_logit, partials, g_sp_W, g_logits);
+          g_rotations, g_opacity, g_weights, g_xyz, g_log_scale, g_rot, g_opacity_logit, partials, g_sp_W, g_logits,
+          in.live_count);
     }
     SKGS_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(deform_backward_finalize_kernel, dim3(in.M), dim3(256), 0, s, in.M, (int) grid.x, partials, in.bone_T,
@@ -1153,7 +1157,7 @@ int launch_knn_dist_weights_backward(int P, int M, int K, int dim, const float* 
 int launch_knn_deform_forward(int P, int M, int K, const float* points, const float* joints, const float* sp_W,
     const float* bone_T, const float* bone_drot, const float* bone_dscale, const float* xyz, const float* log_scale,
     const float* rot, const float* opacity_logit, int64_t* out_idx, float* out_weights, float* means, float* scales,
-    float* rotations, float* opacity, hipStream_t s) {
+    float* rotations, float* opacity, const int32_t* live_count, hipStream_t s) {
   if (P == 0) return 0;
   if (K > KNN_MAXK || K < 1 || K > M) return set_error("knn_deform_forward: K must be in [1,min(%d,M)] (got %d)", KNN_MAXK, K);
   const size_t lds = ((size_t) ((M * 3 + 3) & ~3) + ((M * BONE_F + 3) & ~3) + ((256 * K + 3) & ~3)) * 4 + (size_t) 256 * K * 8;
@@ -1162,7 +1166,7 @@ int launch_knn_deform_forward(int P, int M, int K, const float* points, const fl
 #define SKGS_KNND(KCAP_)                                                                                                 \
   hipLaunchKernelGGL(knn_deform_forward_kernel<KCAP_>, dim3((P + 255) / 256), dim3(256), lds, s, P, M, K, points, joints, \
       sp_W, bone_T, bone_drot, bone_dscale, xyz, log_scale, rot, opacity_logit, out_idx, out_weights, means, scales,      \
-      rotations, opacity)
+      rotations, opacity, live_count)
   if (K <= 4)
     SKGS_KNND(4);
   else if (K <= 5)

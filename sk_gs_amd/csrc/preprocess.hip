@@ -297,7 +297,12 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
     const float* __restrict__ campos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
     int gx, int gy, int32_t* __restrict__ radii, float4* __restrict__ recs, uint32_t* __restrict__ tile_counts,
     GeomHeader* hdr_bucket /* bucket layout: tile_counts are the per-tile cursors and the status words start here */,
-    const float* __restrict__ tanfov_dev /* NULL, or {tanfovx, tanfovy} read here instead of the launch arguments */) {
+    const float* __restrict__ tanfov_dev /* NULL, or {tanfovx, tanfovy} read here instead of the launch arguments */,
+    const int32_t* __restrict__ live /* NULL, or the live Gaussian count (<= P, the capacity the grid was sized for) */) {
+  // the number of Gaussians as a device word (one captured graph survives densification): rows [live, P) of the capacity
+  // get an all-zero record and radius 0 -- what a culled Gaussian gets -- so nothing downstream needs to know
+  const int P_cap = P;
+  if (live) P = min(P, live[0]);
   if (tanfov_dev) {  // same expressions as the host launcher: identical bits
     tan_fovx = tanfov_dev[0], tan_fovy = tanfov_dev[1];
     focal_x = W / (2.0f * tan_fovx), focal_y = H / (2.0f * tan_fovy);
@@ -333,7 +338,14 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
     }
     __syncthreads();
   }
-  if (idx >= P) return;
+  if (idx >= P) {
+    if (idx < P_cap) {
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      radii[idx] = 0;
+      recs[3 * idx + 0] = z, recs[3 * idx + 1] = z, recs[3 * idx + 2] = z;
+    }
+    return;
+  }
 
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;  // culled Gaussians get an all-zero record
   int radius = 0;
@@ -528,7 +540,9 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_backward_kernel(int P,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dsh_rest,
     float* __restrict__ dL_dscales, float* __restrict__ dL_drot, float* __restrict__ dL_dextras,
-    float* __restrict__ sh_factors /* [P,6] or NULL: see sh_backward */, const float* __restrict__ tanfov_dev) {
+    float* __restrict__ sh_factors /* [P,6] or NULL: see sh_backward */, const float* __restrict__ tanfov_dev,
+    const int32_t* __restrict__ live) {
+  if (live) P = min(P, live[0]);  // the number of Gaussians is a device word: one captured graph survives densification
   if (tanfov_dev) {
     tan_fovx = tanfov_dev[0], tan_fovy = tanfov_dev[1];
     focal_x = W / (2.0f * tan_fovx), focal_y = H / (2.0f * tan_fovy);
@@ -933,12 +947,14 @@ int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView 
     hipLaunchKernelGGL(preprocess_forward_kernel<true>, grid, block, lds, s, P, in.sh_degree, in.sh_coeffs, in.means3D,
         in.scales, in.scale_modifier, in.rotations, in.opacity, in.sh, in.sh_rest, in.cov3D_precomp, in.colors_precomp,
         in.viewmatrix, in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y,
-        im.tiles_x, im.tiles_y, radii, g.recs, bucket ? im.cursors : im.tile_counts, bucket ? g.hdr : nullptr, in.tanfov_device);
+        im.tiles_x, im.tiles_y, radii, g.recs, bucket ? im.cursors : im.tile_counts, bucket ? g.hdr : nullptr, in.tanfov_device,
+        in.live_count);
   else
     hipLaunchKernelGGL(preprocess_forward_kernel<false>, grid, block, lds, s, P, in.sh_degree, in.sh_coeffs, in.means3D,
         in.scales, in.scale_modifier, in.rotations, in.opacity, in.sh, in.sh_rest, in.cov3D_precomp, in.colors_precomp,
         in.viewmatrix, in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y,
-        im.tiles_x, im.tiles_y, radii, g.recs, bucket ? im.cursors : im.tile_counts, bucket ? g.hdr : nullptr, in.tanfov_device);
+        im.tiles_x, im.tiles_y, radii, g.recs, bucket ? im.cursors : im.tile_counts, bucket ? g.hdr : nullptr, in.tanfov_device,
+        in.live_count);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -959,7 +975,7 @@ int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const i
       focal_x, focal_y, g.recs, gr.workspace, (int) gradacc_rows_hold_moments(), (int) (gr.workspace_is_zero != 0),       \
       gr.grad_means2D_in, gr.grad_conic_in, gr.grad_opacity_in, E, gr.dL_dmeans2D, gr.dL_dconic, gr.dL_dcolors,           \
       gr.dL_dopacity, gr.dL_dmeans3D, gr.dL_dcov3D, gr.dL_dsh, gr.dL_dsh_rest, gr.dL_dscales, gr.dL_drotations,           \
-      gr.dL_dextras, gr.dL_dsh_factors, in.tanfov_device
+      gr.dL_dextras, gr.dL_dsh_factors, in.tanfov_device, in.live_count
   if (in.colmap)
     hipLaunchKernelGGL(preprocess_backward_kernel<true>, grid, block, lds, s, SKGS_PB_ARGS);
   else

@@ -324,7 +324,7 @@ int launch_knn_lbs_weights(int P, int M, int K, const float* points, const float
 int launch_knn_deform_forward(int P, int M, int K, const float* points, const float* joints, const float* sp_W,
     const float* bone_T, const float* bone_drot, const float* bone_dscale, const float* xyz, const float* log_scale,
     const float* rot, const float* opacity_logit, int64_t* out_idx, float* out_weights, float* means, float* scales,
-    float* rotations, float* opacity, hipStream_t s);
+    float* rotations, float* opacity, const int32_t* live_count, hipStream_t s);
 int launch_lbs_weights_backward_compact(int P, int K, const float* weights, const float* g_weights, float* g_logits,
     hipStream_t s);
 int launch_lbs_logits_scatter(int P, int M, int K, const int64_t* indices, const float* g_logits, float* g_sp_W,

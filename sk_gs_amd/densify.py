@@ -56,9 +56,11 @@ def _rotate(R: Tensor, v: Tensor) -> Tensor:
 
 def _rebind(model, new: Dict[str, torch.nn.Parameter]):
     for attr, name in _names(model).items():
-        if name in new:
+        if name in new and getattr(model, attr) is not new[name]:
             setattr(model, attr, new[name])
     model.P = model._xyz.shape[0]
+    if getattr(model, 'capacity', None) is not None:  # in-place surgery: the kernels read the live count from this word
+        model.capacity.set_live(model.P)
 
 
 @torch.no_grad()
@@ -68,9 +70,12 @@ def prune_points(model, opt: FusedAdam, mask: Tensor, stats=None):
     rows = torch.nonzero(keep).squeeze(1)
     _rebind(model, opt.gather_rows(list(_names(model).values()), rows, rows.numel()))
     if stats is not None:
-        stats.xyz_gradient_accum = stats.xyz_gradient_accum[keep]
-        stats.denom = stats.denom[keep]
-        stats.max_radii2D = stats.max_radii2D[keep]
+        if hasattr(stats, 'gather_densify_stats'):
+            stats.gather_densify_stats(rows)
+        else:
+            stats.xyz_gradient_accum = stats.xyz_gradient_accum[keep]
+            stats.denom = stats.denom[keep]
+            stats.max_radii2D = stats.max_radii2D[keep]
 
 
 @torch.no_grad()
@@ -81,7 +86,9 @@ def densification_postfix(model, opt: FusedAdam, new_params: Dict[str, Tensor], 
 
 
 def _reset_stats(model, stats):
-    if stats is not None:
+    if stats is not None and hasattr(stats, 'reset_densify_stats'):
+        stats.reset_densify_stats()  # (FusedViewStep: in place -- a captured graph holds the addresses)
+    elif stats is not None:
         P, dev = model._xyz.shape[0], model._xyz.device
         stats.xyz_gradient_accum = torch.zeros((P, 1), device=dev)
         stats.denom = torch.zeros((P, 1), device=dev)
@@ -181,7 +188,9 @@ def prune(model, opt: FusedAdam, stats, min_opacity: float, extent: float, max_s
     n_keep = int(counts.item())  # (synchronises)
     rows = rows[:n_keep]
     _rebind(model, opt.gather_rows(list(_names(model).values()), rows, n_keep))
-    if stats is not None:
+    if stats is not None and hasattr(stats, 'gather_densify_stats'):
+        stats.gather_densify_stats(rows)
+    elif stats is not None:
         stats.xyz_gradient_accum = stats.xyz_gradient_accum.index_select(0, rows)
         stats.denom = stats.denom.index_select(0, rows)
         stats.max_radii2D = stats.max_radii2D.index_select(0, rows)

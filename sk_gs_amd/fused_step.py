@@ -57,8 +57,15 @@ class FusedViewStep:
         dev = model._xyz.device
         if not model._xyz.is_cuda:
             raise _C.SkgsError('FusedViewStep needs the model on a HIP device; sk_gs_amd has no CPU path')
-        P, M, K = model.P, model.M, model.K
+        # With a row capacity (model.enable_capacity, sk_gs_amd/capacity.py) every per-Gaussian buffer and launch is sized for
+        # the CAPACITY and the kernels read the live count from a device word: the step -- and a hipGraph of it -- survives
+        # clone / split / prune.  `self.P` is what the launches are sized for; `model.P` is the live count.
+        cap = getattr(model, 'capacity', None)
+        P, M, K = (cap.P_cap if cap is not None else model.P), model.M, model.K
         self.P, self.M, self.K = P, M, K
+        self._live = cap.live if cap is not None else None
+        assert cap is None or (sh_factors is None and spw_logit_grad is None), \
+            'row capacity: one-rank step (the factor / compact-logit exchanges are sized by the live count)'
         # one limit for every one-launch skinning path (the library's): beyond it -- the 512 superpoints of the sp stage --
         # the step uses the separate KNN / weights / skinning launches, which have no bone limit
         lib.skgs_fused_lbs_max_bones.restype = C.c_int
@@ -79,9 +86,16 @@ class FusedViewStep:
         # training), instead of a separate division pass over the whole flat gradient buffer
         self.grad_scale = None if grad_scale == 1.0 else torch.full((1,), float(grad_scale), **f32)
         self._grad_scale_value = float(grad_scale)
+        from sk_gs_amd.capacity import cap_store
         for p in model.parameters():
             if p.grad is None:
-                p.grad = torch.zeros_like(p)
+                store = cap_store(p)
+                if store is None:
+                    p.grad = torch.zeros_like(p)
+                else:  # room for the whole capacity behind the live rows
+                    p.grad, p._grad_slot = torch.zeros_like(store)[:p.shape[0]], store.numel()
+            assert cap_store(p) is None or getattr(p, '_grad_slot', 0) >= cap_store(p).numel(), \
+                'row capacity: build the gradient buffers AFTER model.enable_capacity()'
             assert p.is_contiguous() and p.grad.is_contiguous() and p.dtype == torch.float32
         # ---- persistent intermediates -------------------------------------------------------------------------
         self.bone_T, self.chain_A = torch.empty((M, 7), **f32), torch.empty((M, 7), **f32)
@@ -126,8 +140,8 @@ class FusedViewStep:
         assert spw_logit_grad is None or (spw_logit_grad.numel() == P * K and spw_logit_grad.is_contiguous())
         # densification statistics (gaussian_splatting.py:503-513, sk_gs.py:1990-1997), updated by every step if asked
         self.densify_stats = bool(densify_stats)
-        self.xyz_gradient_accum, self.denom = torch.zeros((P, 1), **f32), torch.zeros((P, 1), **f32)
-        self.max_radii2D = torch.zeros((P,), **f32)
+        self._acc_store, self._den_store = torch.zeros((P, 1), **f32), torch.zeros((P, 1), **f32)
+        self._rad_store = torch.zeros((P,), **f32)
         # bone-transform producer (scope row (f)-3): the MLP runs inside the step, its weight gradients are written in place
         self.deform_net = model.sk_deform_net
         self._mlp_fused = None
@@ -155,6 +169,48 @@ class FusedViewStep:
         topo = model.topology()
         self._topo = topo
         self._bufs = _C._buffers(self.geom, self.binning, self.img)
+
+    # ---- densification statistics: [P,1], [P,1], [P] over the live rows (storage of capacity rows behind them) ---------
+    def _live_rows(self) -> int:
+        return int(self.model.P) if self._live is not None else int(self._acc_store.shape[0])
+
+    def _stat_get(self, store):
+        return store[:self._live_rows()]
+
+    def _stat_set(self, name, value):
+        store = getattr(self, name)
+        if self._live is None:  # no capacity: re-bind, as the reference re-creates its tensors
+            setattr(self, name, value)
+            return
+        store[:value.shape[0]].copy_(value)  # capacity: the kernels (and a captured graph) keep the address
+
+    xyz_gradient_accum = property(lambda self: self._stat_get(self._acc_store),
+                                  lambda self, v: self._stat_set('_acc_store', v))
+    denom = property(lambda self: self._stat_get(self._den_store), lambda self, v: self._stat_set('_den_store', v))
+    max_radii2D = property(lambda self: self._stat_get(self._rad_store), lambda self, v: self._stat_set('_rad_store', v))
+
+    @torch.no_grad()
+    def reset_densify_stats(self):
+        """zero the three statistics (after a densification, gaussian_splatting.py:584-587) without moving them"""
+        if self._live is None:  # no capacity: new tensors of the model's new size, as the reference re-creates them
+            n, dev = int(self.model.P), self._acc_store.device
+            self._acc_store, self._den_store = torch.zeros((n, 1), device=dev), torch.zeros((n, 1), device=dev)
+            self._rad_store = torch.zeros((n,), device=dev)
+            return
+        self._acc_store.zero_(), self._den_store.zero_(), self._rad_store.zero_()
+
+    @torch.no_grad()
+    def gather_densify_stats(self, rows: Tensor):
+        """keep the statistics of the rows a prune keeps (gaussian_splatting.py:573-575), in place"""
+        n = int(rows.numel())
+        if self._live is None:
+            self._acc_store, self._den_store = self._acc_store.index_select(0, rows), self._den_store.index_select(0, rows)
+            self._rad_store = self._rad_store.index_select(0, rows)
+            return
+        for store in (self._acc_store, self._den_store, self._rad_store):
+            kept = store.index_select(0, rows)
+            store.zero_()
+            store[:n].copy_(kept)
 
     # ------------------------------------------------------------------------------------------------------------
     def table_grad_span(self) -> Optional[Tensor]:
@@ -213,6 +269,7 @@ class FusedViewStep:
         a.sh, a.sh_rest = m._features_dc.data_ptr(), m._features_rest.data_ptr()
         a.background = None if self.background is None else self.background.data_ptr()
         a.tile_bucket_capacity = self.tile_bucket
+        a.live_count = None if self._live is None else self._live.data_ptr()
         return a
 
     def _deform_inputs(self, time_id: int) -> '_C._DeformInputs':
@@ -227,6 +284,7 @@ class FusedViewStep:
         else:
             a.bone_drot, a.bone_dscale = self._d_rot.data_ptr(), self._d_scale.data_ptr()
         a.log_scale, a.rot, a.opacity_logit = m._scaling.data_ptr(), m._rotation.data_ptr(), m._opacity.data_ptr()
+        a.live_count = None if self._live is None else self._live.data_ptr()
         return a
 
     # ------------------------------------------------------------------------------------------------------------
@@ -257,6 +315,7 @@ class FusedViewStep:
                 C.c_int32(t['num_levels']), _p(sk_r_raw), _p(m.joints), C.c_void_p(gT), _p(self.bone_T),
                 _p(self.chain_A), fidx, st))
         d = self._deform_inputs(time_id)
+        assert not (self.wide and self._live is not None), 'row capacity: the one-launch skinning path (M <= 60, K <= 8)'
         if self.wide:  # many bones: search + softmax, then the skinning, as two launches (bone tables stay in global memory)
             chk(lib.skgs_knn_lbs_weights(C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_void_p(d.points), _p(m.joints),
                                          _p(m.sp_W), _p(self.indices), _p(self.weights), st))
@@ -271,7 +330,7 @@ class FusedViewStep:
             C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_void_p(d.points), _p(m.joints), _p(m.sp_W), C.c_void_p(d.bone_T),
             C.c_void_p(d.bone_drot), C.c_void_p(d.bone_dscale), C.c_void_p(d.xyz), C.c_void_p(d.log_scale), C.c_void_p(d.rot),
             C.c_void_p(d.opacity_logit), _p(self.indices), _p(self.weights), _p(self.means), _p(self.scales),
-            _p(self.rotations), _p(self.opacity), st))
+            _p(self.rotations), _p(self.opacity), _p(self._live), st))
         a = self._raster_inputs(rs)
         chk(lib.skgs_rasterize_forward(C.byref(a), C.byref(self._bufs), _p(self.radii), _p(self.image),
                                        _p(self.out_opacity), None, None, st))
@@ -500,9 +559,10 @@ class FusedViewStep:
         """accumulate this view's statistics (one launch); ``forward_backward`` calls it when ``densify_stats`` is set"""
         # the backward may be pre-scaled (grad_scale = 1 / world): the statistic is the norm of the UNSCALED screen-space
         # gradient (gaussian_splatting.py:503-513), or N ranks would densify as if max_grad were N times larger
+        # (rows beyond the live count carry radius 0 -- skgs_raster_inputs.live_count -- and are skipped like culled ones)
         _C._check(self.lib.skgs_densify_stats(C.c_int32(self.P), _p(self.radii), _p(self.grad_means2D),
-                                             C.c_float(1.0 / self._grad_scale_value), _p(self.xyz_gradient_accum),
-                                             _p(self.denom), _p(self.max_radii2D), _C._stream()))
+                                             C.c_float(1.0 / self._grad_scale_value), _p(self._acc_store),
+                                             _p(self._den_store), _p(self._rad_store), _C._stream()))
 
     @torch.no_grad()
     def grow_capacity(self, factor: float = 2.0):

@@ -27,6 +27,7 @@ class SkinnedGaussians(nn.Module):
         g = scene.make_gaussians(P, seed=seed, sh_degree=sh_degree, scale_mult=scale_mult)
         b = scene.make_bones(max(M, 1), seed=seed)
         self.P, self.M, self.K = P, M, min(K, max(M, 1))
+        self.capacity = None  # RowCapacity: see enable_capacity
         self.max_sh_degree = sh_degree
         self.active_sh_degree = sh_degree
         self._xyz = nn.Parameter(g['xyz'])
@@ -81,6 +82,14 @@ class SkinnedGaussians(nn.Module):
         self.static = M == 0
 
     # ------------------------------------------------------------------------------------------------ parameters
+    def enable_capacity(self, P_cap: int):
+        """re-home the per-Gaussian parameters into storage of ``P_cap`` rows (the first ``P`` live): densification within
+        the capacity then happens in place and a captured training step survives it (sk_gs_amd/capacity.py).  Call before
+        building gradient buffers, optimizer and step."""
+        from sk_gs_amd.capacity import RowCapacity
+        self.capacity = RowCapacity(self, P_cap)
+        return self.capacity
+
     def param_groups(self, lr: float = 1e-3, spatial_scale: float = 1.0):
         """the six Gaussian groups of ``get_params`` (gaussian_splatting.py:443-453) + the skinning parameters"""
         groups = [

@@ -14,6 +14,7 @@ from typing import Iterable, List
 import torch
 
 from sk_gs_amd import _C
+from sk_gs_amd.capacity import cap_store, regrad, slot_numel
 
 
 def position_lr(step: int, lr_init: float, lr_final: float, max_steps: int = 30_000, delay_steps: int = 0,
@@ -39,6 +40,11 @@ class AdamRange(C.Structure):
                 ('after_advance', C.c_int32)]
 
 
+class CapacityExceeded(RuntimeError):
+    """an in-place densification needs more rows than the row capacity holds: re-home the model (enable_capacity with a
+    larger P_cap), rebuild gradient buffers / optimizer state / step and re-capture"""
+
+
 class FusedAdam:
     def __init__(self, param_groups: Iterable[dict], betas=(0.9, 0.999), eps: float = 1e-15,
                  zero_after_step: 'torch.Tensor' = None):
@@ -61,7 +67,17 @@ class FusedAdam:
                     self.params.append(p)
                     self._lr_index.append(gi)
         dev = self.params[0].device
-        self.state = {p: dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p)) for p in self.params}
+        # (a per-Gaussian parameter with a row capacity -- sk_gs_amd/capacity.py -- gets moments of the same capacity)
+        self._cap_state = {}
+        self.state = {}
+        for p in self.params:
+            store = cap_store(p)
+            if store is None:
+                self.state[p] = dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
+            else:
+                m, v = torch.zeros_like(store), torch.zeros_like(store)
+                self._cap_state[p] = (m, v)
+                self.state[p] = dict(exp_avg=m[:p.shape[0]], exp_avg_sq=v[:p.shape[0]])
         # the optimizer's device state (include/skgs.h::skgs_adam_step): word 0 = steps taken (float), doubles at bytes 8 /
         # 16 = 1 - beta^steps, maintained by the kernels; all zeros = no step taken
         lib.skgs_adam_state_bytes.restype = C.c_size_t
@@ -81,12 +97,18 @@ class FusedAdam:
         for p, gi in zip(self.params, self._lr_index):
             self._chunk0.append(chunk0)
             if p.grad is None:
-                p.grad = torch.zeros_like(p)
+                store = cap_store(p)
+                if store is None:
+                    p.grad = torch.zeros_like(p)
+                else:
+                    p.grad, p._grad_slot = torch.zeros_like(store)[:p.shape[0]], store.numel()
             st = self.state[p]
             n = p.numel()
             blob += struct.pack('<QQQQqqff', p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(),
                                 st['exp_avg_sq'].data_ptr(), n, chunk0, float(self.param_groups[gi]['lr']), 0.0)
-            chunk0 += (n + self._chunk - 1) // self._chunk
+            # chunk space by CAPACITY: ranges handed to captured launches stay valid when the live row count changes (the
+            # kernels read n from this table and skip the rest of a slot)
+            chunk0 += (slot_numel(p) + self._chunk - 1) // self._chunk
             grads.append(p.grad.data_ptr())
         self._chunk0.append(chunk0)
         self._total_chunks = chunk0
@@ -135,6 +157,9 @@ class FusedAdam:
             assert len(g['params']) == 1, f"group {g['name']!r}: change_optimizer handles one parameter per group"
             old = g['params'][0]
             new_t = tensor[g['name']] if isinstance(tensor, dict) else tensor
+            if cap_store(old) is not None:  # row capacity: the same Parameter object, the same storage
+                out[g['name']] = self._change_in_place(old, new_t, op, dim)
+                continue
             st = self.state.pop(old)
             with torch.no_grad():
                 if op == 'concat':
@@ -176,6 +201,11 @@ class FusedAdam:
         assert int(lib.skgs_row_tensor_bytes()) == 24
         rows = rows.to(torch.int64).contiguous()
         n_out, dev = int(rows.numel()), rows.device
+        named = [g for g in self.param_groups if g.get('name') in names]
+        if named and all(cap_store(g['params'][0]) is not None for g in named):
+            if all(n_out <= cap_store(g['params'][0]).shape[0] for g in named):
+                return self._gather_rows_in_place(named, rows, n_out, int(n_keep))
+            raise CapacityExceeded(f'{n_out} rows do not fit the row capacity {cap_store(named[0]["params"][0]).shape[0]}')
         blob, new, max_rf, keepalive = bytearray(), {}, 1, []
         for g in self.param_groups:
             if g.get('name') not in names:
@@ -212,6 +242,71 @@ class FusedAdam:
         self._upload()
         del keepalive  # (the old tensors lived until the launch was enqueued: same stream, the allocator orders reuse)
         return new
+
+    @torch.no_grad()
+    def _change_in_place(self, p, new_t, op: str, dim: int):
+        """``change_optimizer`` for a parameter with a row capacity (rows are dimension 0)"""
+        assert dim == 0, 'a row capacity grows along dimension 0'
+        store, (m_store, v_store) = cap_store(p), self._cap_state[p]
+        n0 = p.shape[0]
+        if op == 'replace':
+            new_t = new_t.detach().to(p.device, torch.float32)
+            n1 = new_t.shape[0]
+            if n1 > store.shape[0]:
+                raise CapacityExceeded(f'{n1} rows do not fit the row capacity {store.shape[0]}')
+            store[:n1].copy_(new_t)
+            m_store[:n1].zero_(), v_store[:n1].zero_()
+        elif op == 'concat':
+            new_t = new_t.detach().to(p.device, torch.float32)
+            n1 = n0 + new_t.shape[0]
+            if n1 > store.shape[0]:
+                raise CapacityExceeded(f'{n1} rows do not fit the row capacity {store.shape[0]}')
+            store[n0:n1].copy_(new_t)
+            m_store[n0:n1].zero_(), v_store[n0:n1].zero_()
+        else:  # prune: a keep-mask over the rows
+            rows = torch.nonzero(new_t).squeeze(1)
+            n1 = int(rows.numel())
+            for home in (store, m_store, v_store):
+                home[:n1].copy_(home.index_select(0, rows))
+        p.data = store[:n1]
+        self.state[p] = dict(exp_avg=m_store[:n1], exp_avg_sq=v_store[:n1])
+        regrad(p)
+        return p
+
+    @torch.no_grad()
+    def _gather_rows_in_place(self, named, rows, n_out: int, n_keep: int) -> dict:
+        """``gather_rows`` for parameters with a row capacity: the same ONE gather launch, into scratch tensors, then the rows
+        go back into the SAME storage (parameters and both moments) and every view -- ``p.data``, the moments, ``p.grad`` --
+        is re-shaped over it.  No address changes: a captured step keeps replaying (sk_gs_amd/capacity.py)."""
+        lib = _C.load_library()
+        dev = rows.device
+        blob, max_rf, scratch, homes = bytearray(), 1, [], []
+        for g in named:
+            p = g['params'][0]
+            st, (m_store, v_store) = self.state[p], self._cap_state[p]
+            rf = p.numel() // max(p.shape[0], 1)
+            max_rf = max(max_rf, rf)
+            shape = (n_out,) + tuple(p.shape[1:])
+            for src, home, fresh_zero in ((p.data, cap_store(p), 0), (st['exp_avg'], m_store, 1), (st['exp_avg_sq'], v_store, 1)):
+                tmp = torch.empty(shape, dtype=torch.float32, device=dev)
+                blob += struct.pack('<QQii', src.data_ptr(), tmp.data_ptr(), rf, fresh_zero)
+                scratch.append(tmp)
+                homes.append(home[:n_out])
+        table = torch.empty(len(blob), dtype=torch.uint8, device=dev)
+        self._h2d(table, blob)
+        _C._check(lib.skgs_gather_rows(C.c_int32(len(scratch)), C.c_void_p(table.data_ptr()), C.c_int64(n_out),
+                                       C.c_int64(n_keep), C.c_void_p(rows.data_ptr()), C.c_int32(max_rf), _C._stream()))
+        torch._foreach_copy_(homes, scratch)
+        out = {}
+        for g in named:
+            p = g['params'][0]
+            m_store, v_store = self._cap_state[p]
+            p.data = cap_store(p)[:n_out]
+            self.state[p] = dict(exp_avg=m_store[:n_out], exp_avg_sq=v_store[:n_out])
+            regrad(p)
+            out[g['name']] = p
+        self._upload()  # the live element counts of the descriptor table (same pointers, same chunk ranges)
+        return out
 
     def set_lr(self, group, lr: float):
         """``group``: index or name of the parameter group.  Re-uploads the descriptor table (outside graph capture); a

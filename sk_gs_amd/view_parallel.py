@@ -19,6 +19,8 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
+from sk_gs_amd.capacity import slot_numel
+
 
 def init_distributed(backend: Optional[str] = None, force: bool = False) -> tuple:
     """(rank, world, local_rank) from the torchrun environment; initialises the default group when world > 1
@@ -57,7 +59,7 @@ class FlatGradBuffer:
         offs, off = [], 0
         for p in params:
             offs.append(off)
-            off += (p.numel() + cls.ALIGN - 1) // cls.ALIGN * cls.ALIGN
+            off += (slot_numel(p) + cls.ALIGN - 1) // cls.ALIGN * cls.ALIGN  # (a row capacity reserves the whole capacity)
         return offs, off
 
     def __init__(self, params: Iterable[Tensor]):
@@ -67,6 +69,7 @@ class FlatGradBuffer:
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         for p, off in zip(self.params, self._offs):
             p.grad = self.flat[off:off + p.numel()].view_as(p)
+            p._grad_slot = slot_numel(p)
 
     def zero_(self):
         self.flat.zero_()
@@ -75,7 +78,7 @@ class FlatGradBuffer:
         """re-attach the views (needed if something replaced p.grad, e.g. zero_grad(set_to_none=True))"""
         for p, off in zip(self.params, self._offs):
             n = p.numel()
-            if p.grad is None or p.grad.data_ptr() != self.flat[off:off + n].data_ptr():
+            if p.grad is None or p.grad.data_ptr() != self.flat[off:off + n].data_ptr() or p.grad.shape != p.shape:
                 p.grad = self.flat[off:off + n].view_as(p)
 
     @property

@@ -13,7 +13,8 @@ What "equal" means after Adam: the first updates are lr * g / (|g| + 1e-15) -- t
 exactly zero -- so the two paths' summation-order noise (1e-7 relative) flips the update of elements whose gradient is
 noise around zero by up to 2 lr, however small the gradient.  The comparison is therefore in units of the group's learning
 rate: |p_fused - p_ref| / lr  <= 0.02 for all but 1e-3 of a tensor's elements, and never more than 2 steps x 2 lr; the
-rendered image of the second step (parameters after one update, the next view) must agree to 1e-4.
+rendered image of the first step must agree to 1e-4, the second step's (parameters after one update, the next view) on all
+but 5e-4 of its pixels.
 """
 import copy
 
@@ -104,8 +105,17 @@ def test_bench_step_trains_the_same_parameters_as_operator_path_plus_torch_adam(
         torch.cuda.synchronize()
         st = fstep.status()
         assert st['overflow_events'] == 0 and st.get('mlp_failed', 0) == 0 and float(opt.step_count.item()) == STEPS
-        for i in range(STEPS):
-            assert_close_robust(images[i], ref_images[i], 1e-4, name=f'config{cfg} pre_forward={pre_forward} image of step {i}')
+        # step 0 renders identical parameters: the usual gate.  Later steps render parameters that already differ where
+        # Adam turned a noise-level gradient's sign into a full +-lr move (opacity logits: lr = 5e-3): a handful of splats
+        # per million is a little brighter in one replica -- bounded statistically (observed at config #4: 6.7e-5 of the
+        # pixels over 1e-4, worst 2.3e-3)
+        assert_close_robust(images[0], ref_images[0], 1e-4, name=f'config{cfg} pre_forward={pre_forward} image of step 0')
+        for i in range(1, STEPS):
+            d = (images[i] - ref_images[i]).abs() / ref_images[i].abs().max()
+            frac = float((d > 1e-4).float().mean())
+            print(f'[bench step] config{cfg} pre_forward={pre_forward} image of step {i}: {frac:.2e} of the elements over 1e-4, '
+                  f'max {float(d.max()):.2e}')
+            assert frac <= 5e-4 and float(d.max()) <= 1e-2, (i, frac, float(d.max()))
         # ---- every parameter, in units of its group's learning rate
         lrs = {id(p): g['lr'] for g in opt.param_groups for p in g['params']}
         ref_params = dict(ref_model.named_parameters())

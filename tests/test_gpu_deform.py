@@ -224,7 +224,7 @@ def test_knn_weights_deform_in_one_launch_is_bit_identical_to_the_separate_calls
     outs = [torch.empty((P, c), device='cuda') for c in (3, 3, 4, 1)]
     _C._check(lib.skgs_knn_lbs_deform_forward(
         C.c_int32(P), C.c_int32(M), C.c_int32(K), p(d['xyz']), p(d['joints']), p(d['sp_W']), p(d['bone_T']), p(d['drot']),
-        p(d['dscale']), p(d['xyz']), p(d['ls']), p(d['rot']), p(d['op']), p(idx2), p(w2), *[p(o) for o in outs], st))
+        p(d['dscale']), p(d['xyz']), p(d['ls']), p(d['rot']), p(d['op']), p(idx2), p(w2), *[p(o) for o in outs], None, st))
     torch.cuda.synchronize()
     assert torch.equal(idx1, idx2) and torch.equal(w1, w2)
     for name, a, r in zip(['means', 'scales', 'rotations', 'opacity'], outs, sep):
@@ -390,7 +390,7 @@ def test_deform_and_knn_at_full_size(oracle32, cfg, P, M):
     _C._check(lib.skgs_knn_lbs_deform_forward(
         C.c_int32(P), C.c_int32(M), C.c_int32(K), p(dev['xyz']), p(dev['j']), p(dev['spw']), p(dev['bT']), p(dev['dr']),
         p(dev['ds']), p(dev['xyz']), p(dev['ls']), p(dev['rot']), p(dev['op']), p(o_idx), p(o_w), p(means), p(scales),
-        p(rots), p(opac), _C._stream()))
+        p(rots), p(opac), None, _C._stream()))
     np.testing.assert_array_equal(n(o_idx), i_ref)
     assert rel_err(o_w, w_ref) <= 2e-6
     for name, t in zip(['means', 'scales', 'rotations', 'opacity'], (means, scales, rots, opac)):
