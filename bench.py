@@ -206,6 +206,11 @@ def main():
     ap.add_argument('--layered-mlp', action='store_true',
                     help='run the deform network as one launch per layer (csrc/mlp.hip) instead of the one-launch-per-direction '
                          'kernels (csrc/mlp_fused.hip)')
+    ap.add_argument('--densify-every', type=int, default=0,
+                    help='one rank, fused step: run a densification event (clone + split + prune, networks/gaussian_splatting.py:'
+                         '565-650, thresholds calibrated so that ~2 %% of the Gaussians are cloned / split and ~2 %% pruned) every N '
+                         'steps INSIDE the timed region.  The model gets a row capacity of 1.5 x P (sk_gs_amd/capacity.py): the '
+                         'surgery happens in place and the ONE captured graph keeps replaying -- the reported it/s is end-to-end')
     ap.add_argument('--autograd', action='store_true',
                     help='run the step through the torch-autograd operator path (model.render + image_loss + backward) '
                          'instead of sk_gs_amd.fused_step.FusedViewStep (same kernels, no autograd glue)')
@@ -246,6 +251,9 @@ def main():
         frames = args.views
         model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=0, deform_net=args.deform_net,
                                  scale_mult=args.scale_mult, learn_joints=args.learn_joints).to(dev)
+        densify_every = args.densify_every if (world == 1 and not args.autograd and M > 0) else 0
+        if densify_every:  # room to grow BEFORE anything mirrors the parameters (gradient slots, moments, workspaces)
+            model.enable_capacity(int(P * 1.5))
         cams = [scene.make_camera(W, H, seed=i) for i in range(args.views)]
         settings = [scene.raster_settings_from_camera(c, sh_degree=3, colmap=True, device=dev) for c in cams]
         background = torch.ones(3, device=dev)
@@ -343,7 +351,7 @@ def main():
                                   background=background, grad_scale=1.0 / world,
                                   spw_logit_grad=vp.extra_views[-1] if compact else None, tile_bucket=tile_bucket,
                                   sh_factors=fac_local if sh_factored else None, fused_deform_net=not args.layered_mlp,
-                                  view_table=view_table)
+                                  view_table=view_table, densify_stats=bool(densify_every))
             # the per-frame table gradients (one row written per step) are cleared by the Adam launch itself
             table_span = None if args.torch_adam else fstep.table_grad_span()
             fstep.tables_zeroed_by_optimizer = table_span is not None
@@ -563,6 +571,30 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+        # --densify-every: thresholds from the statistics the warm-up accumulated -- the 98th percentile of the mean
+        # screen-space gradient (clone / split ~2 % of the Gaussians per event) and the 2nd percentile of the opacity (prune
+        # ~2 %) -- fixed before the timed region; an event = densify + prune + statistics restart, in place
+        densify_log = None
+        if densify_every:
+            from sk_gs_amd import densify as dn
+            assert fused_update and len(g_step.graphs) == 1
+            acc, den = fstep.xyz_gradient_accum.view(-1), fstep.denom.view(-1).clamp_min(1)
+            seen = fstep.denom.view(-1) > 0
+            thr_grad = float(torch.quantile((acc / den)[seen][:1_000_000], 0.98)) if bool(seen.any()) else 1e9
+            thr_op = float(torch.quantile(torch.sigmoid(model._opacity.detach().view(-1))[:1_000_000], 0.02))
+            extent = 1.3 * 3 ** 0.5
+            dgen = torch.Generator(device=dev).manual_seed(1234)
+            fstep.reset_densify_stats()
+            densify_log = dict(every=densify_every, events=0, P=[model.P], ms=[], max_grad=thr_grad, min_opacity=thr_op)
+
+            def densify_event():
+                t_ev = time.perf_counter()
+                dn.densify(model, opt, fstep, max_grad=thr_grad, extent=extent, generator=dgen)
+                dn.prune(model, opt, fstep, min_opacity=thr_op, extent=extent, max_screen_size=None)
+                fstep.reset_densify_stats()
+                densify_log['events'] += 1
+                densify_log['P'].append(model.P)
+                densify_log['ms'].append(round((time.perf_counter() - t_ev) * 1e3, 3))  # host time of the event (2 syncs inside)
         # the timed region: exactly args.steps steps between barriers; an event every steps/10 steps splits it into >= 10 blocks
         # (when steps >= 10) whose per-step times give the spread of `ms_per_step` (median / p10 / p90)
         n_blocks = min(args.steps, 10)
@@ -573,6 +605,8 @@ def main():
         nxt = 1
         for i in range(args.steps):
             train_step(args.warmup + i)
+            if densify_every and (i + 1) % densify_every == 0 and i + 1 < args.steps:
+                densify_event()
             if i + 1 == edges[nxt]:
                 marks[nxt].record()
                 nxt += 1
@@ -802,6 +836,12 @@ def main():
                                    'the rasterizer kernels of the fused step'
                 line['ms_per_render_fwd_bwd'] = ms_render
                 line['fps_forward_render'] = fps
+            if densify_log is not None:
+                densify_log['graphs_captured'] = len(g_step.graphs)
+                densify_log['row_capacity'] = model.capacity.P_cap
+                densify_log['how'] = ('clone + split + prune in place inside the timed region; the step is ONE hipGraph captured '
+                                      'before the first event and never re-captured; `value` is end-to-end')
+                line['densify'] = densify_log
             if world == 1 and not args.no_cpu_baseline:
                 line['cpu_baseline'] = cpu_baseline(cfg, args.cpu_seconds, args.cpu_single_thread)
             return line

@@ -32,12 +32,15 @@ def main():
     ap.add_argument('--iters', type=int, default=400)
     ap.add_argument('--lr', type=float, default=1e-3)
     ap.add_argument('--densify-every', type=int, default=0, help='clone / split / prune every N iterations (0: never)')
+    ap.add_argument('--capacity', type=float, default=2.5,
+                    help='one rank: row capacity as a multiple of --gaussians (sk_gs_amd/capacity.py): densification within it '
+                         'happens in place and the captured step is never rebuilt or re-captured; 0 = rebuild after every event')
     args = ap.parse_args()
 
     from sk_gs_amd import _C, densify, scene
     from sk_gs_amd.fused_step import FusedViewStep
     from sk_gs_amd.model import SkinnedGaussians
-    from sk_gs_amd.optim import FusedAdam, position_lr
+    from sk_gs_amd.optim import CapacityExceeded, FusedAdam, position_lr
     from sk_gs_amd.overflow import OverflowGuard
     from sk_gs_amd.train_step import FusedTrainStep, GraphedSteps
     from sk_gs_amd.view_slot import ViewTable
@@ -63,13 +66,16 @@ def main():
                       torch.stack([o['images'] for o in outs]).contiguous(), dev)
     capacity = [int(max(o['buffer'].R for o in outs) * 1.5) + 4096]  # grown by the overflow guard when it stops fitting
 
+    if world == 1 and args.capacity and args.densify_every:  # BEFORE anything mirrors the parameters
+        model.enable_capacity(int(P * args.capacity))
     opt = FusedAdam(model.param_groups(lr=args.lr), eps=1e-15)
 
     def build_runtime(stats_from=None):
         """everything sized by the number of Gaussians: gradient buffers, step workspaces, captured graphs.  `stats_from`: the
         step whose densification statistics the new one continues (a rebuild for capacity only; after a densification they
         start from zero)"""
-        cap = capacity[0] * model.P // P + 4096
+        rows = model.capacity.P_cap if model.capacity is not None else model.P  # (room for the lists of a grown model)
+        cap = capacity[0] * rows // P + 4096
         if world == 1:
             vp = ViewParallel(model.parameters())               # p.grad -> views of one flat buffer
             step = FusedViewStep(model, W, W, capacity=cap, background=bg, densify_stats=True, view_table=table)
@@ -138,16 +144,23 @@ def main():
             t_ev = time.perf_counter()
             vp.allreduce_densify_stats(step.xyz_gradient_accum, step.denom, step.max_radii2D)
             before = model.P
-            densify.densify(model, opt, step, max_grad=2e-4, extent=4.0, generator=gen)
-            densify.prune(model, opt, step, min_opacity=0.005, extent=4.0, max_screen_size=0.25 * W)
+            try:
+                densify.densify(model, opt, step, max_grad=2e-4, extent=4.0, generator=gen)
+                densify.prune(model, opt, step, min_opacity=0.005, extent=4.0, max_screen_size=0.25 * W)
+            except CapacityExceeded as e:  # (a real loop would re-home the model with a larger capacity and rebuild)
+                print(f'iter {it:5d}  densification skipped: {e}')
             torch.cuda.synchronize(); t_a = time.perf_counter()
-            vp, step, run = build_runtime()                      # P changed
+            if model.capacity is None:
+                vp, step, run = build_runtime()                  # P changed: new buffers, the next step re-captures
+                guard.rebind(step)
+            else:
+                step.reset_densify_stats()                        # in place: same buffers, same graph, it keeps replaying
             torch.cuda.synchronize(); t_b = time.perf_counter()
-            guard.rebind(step)
             guard.checkpoint(it + 1)                              # new shapes: the snapshot is taken afresh
-            if rank == 0:                                         # (the graph is captured by the next iteration's run())
-                print(f'iter {it:5d}  densify: {before} -> {model.P} Gaussians  (clone/split/prune {1e3 * (t_a - t_ev):.1f} ms, '
-                      f'runtime rebuild {1e3 * (t_b - t_a):.1f} ms; the next step re-captures the graph)')
+            if rank == 0:
+                how = (f'runtime rebuild {1e3 * (t_b - t_a):.1f} ms; the next step re-captures the graph' if model.capacity is None
+                       else f'in place within the row capacity {model.capacity.P_cap}: no rebuild, no re-capture')
+                print(f'iter {it:5d}  densify: {before} -> {model.P} Gaussians  (clone/split/prune {1e3 * (t_a - t_ev):.1f} ms; {how})')
         it += 1
     if rank == 0:
         print('visible at least once:', int((step.denom > 0).sum()), 'of', model.P, 'Gaussians; max screen radius',

@@ -480,8 +480,12 @@ class FusedViewStep:
         b.g_joints = m.joints.grad.data_ptr() if getattr(m, 'learn_joints', False) else None
         b.g_global_T = g_gT
         # every training step refreshes the frame's row of the test-time cache (sk_gs.py:1077-1079); written by the launch
+        # (the frame's row: by pointer for an explicit time_id, base + the slot's frame index otherwise -- like global_T)
         cache = getattr(m, 'sk_cache', None)
-        b.sk_cache = cache.data_ptr() if (cache is not None and cache.is_cuda and cache.shape[1] == self.M) else None
+        if cache is not None and cache.is_cuda and cache.shape[1] == self.M:
+            b.sk_cache = cache.data_ptr() if time_id is None else cache[time_id].data_ptr()
+        else:
+            b.sk_cache = None
         return b
 
     def _joint_rotations(self, time_id: Optional[int]) -> Tensor:
