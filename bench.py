@@ -587,14 +587,28 @@ def main():
             fstep.reset_densify_stats()
             densify_log = dict(every=densify_every, events=0, P=[model.P], ms=[], max_grad=thr_grad, min_opacity=thr_op)
 
-            def densify_event():
-                t_ev = time.perf_counter()
-                dn.densify(model, opt, fstep, max_grad=thr_grad, extent=extent, generator=dgen)
-                dn.prune(model, opt, fstep, min_opacity=thr_op, extent=extent, max_screen_size=None)
+            ev_marks = []
+
+            def densify_event(timed=True):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()  # (behind the steps already queued: e1 - e0 is what the event costs on the GPU's time line --
+                dn.densify(model, opt, fstep, max_grad=thr_grad, extent=extent, generator=dgen)  # surgery + the idle gaps of
+                dn.prune(model, opt, fstep, min_opacity=thr_op, extent=extent, max_screen_size=None)  # its two read-backs)
                 fstep.reset_densify_stats()
-                densify_log['events'] += 1
-                densify_log['P'].append(model.P)
-                densify_log['ms'].append(round((time.perf_counter() - t_ev) * 1e3, 3))  # host time of the event (2 syncs inside)
+                e1.record()
+                if timed:
+                    densify_log['events'] += 1
+                    densify_log['P'].append(model.P)
+                    ev_marks.append((e0, e1))
+
+            # one untimed event: first-use initialisation (random generator, index kernels) is not a per-event cost
+            for i in range(8):
+                train_step(args.warmup + i)
+            densify_event(timed=False)
+            densify_log['P'] = [model.P]
+            for i in range(8):
+                train_step(args.warmup + i)
+            torch.cuda.synchronize()
         # the timed region: exactly args.steps steps between barriers; an event every steps/10 steps splits it into >= 10 blocks
         # (when steps >= 10) whose per-step times give the spread of `ms_per_step` (median / p10 / p90)
         n_blocks = min(args.steps, 10)
@@ -837,6 +851,7 @@ def main():
                 line['ms_per_render_fwd_bwd'] = ms_render
                 line['fps_forward_render'] = fps
             if densify_log is not None:
+                densify_log['ms'] = [round(a_.elapsed_time(b_), 3) for a_, b_ in ev_marks]
                 densify_log['graphs_captured'] = len(g_step.graphs)
                 densify_log['row_capacity'] = model.capacity.P_cap
                 densify_log['how'] = ('clone + split + prune in place inside the timed region; the step is ONE hipGraph captured '

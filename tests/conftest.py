@@ -30,8 +30,11 @@ BASELINE = os.path.join(ROOT, 'tests', 'golden', 'parity_observed_baseline.json'
 
 
 def _regressions(observed):
-    """entries whose worst case grew more than 2x over the committed baseline (and is not negligible): the gate that
-    would have caught round 2's 7.6e-5 -> 7.1e-4 jump, which the per-test allowances let through"""
+    """Census entries (tests/helpers.FlipCensus: deterministic comparisons against the oracle) whose worst case over the
+    elements NO flip explains grew more than 2x over the committed baseline, or whose number of flipped pixels more than
+    doubled: the gate that would have caught a real 7.6e-5 -> 7.1e-4 jump (round 2's turned out to be one more flipped
+    pixel, which the census now reports as such).  Comparisons of trained parameters (atomics' order, Adam's sign steps)
+    vary run to run and are held by their own assertions only."""
     import json
     if not os.path.exists(BASELINE):
         return []
@@ -40,10 +43,12 @@ def _regressions(observed):
     bad = []
     for r in observed:
         b = base.get((r.get('test', ''), r['name']))
-        if b is None:
+        if b is None or 'untraced_max' not in r or 'untraced_max' not in b:
             continue
-        if r['max_err'] > 2.0 * b['max_err'] and r['max_err'] > 0.5 * r['tol']:
-            bad.append(f"{r['test']} [{r['name']}]: max error {r['max_err']:.2e}, baseline {b['max_err']:.2e}")
+        if r['untraced_max'] > 2.0 * b['untraced_max'] and r['untraced_max'] > 2e-5:
+            bad.append(f"{r['test']} [{r['name']}]: max error outside flips {r['untraced_max']:.2e}, baseline {b['untraced_max']:.2e}")
+        if 'flipped_pixels' in r and r['flipped_pixels'] > 2 * b.get('flipped_pixels', 0) + 3:
+            bad.append(f"{r['test']} [{r['name']}]: {r['flipped_pixels']} flipped pixels, baseline {b.get('flipped_pixels', 0)}")
     return bad
 
 
