@@ -325,7 +325,7 @@ def main():
         if 512 < tile_bucket and longest * 1.2 <= 512:
             tile_bucket = 512  # a bucket one wave sorts needs no merge-sort launch behind it (20 % head room instead of 50)
         _C.config.sync_num_rendered = False
-        _C.update_capacity_hint(P, W, H, int(R_max * 1.25))
+        _C.update_capacity_hint(P, W, H, int(R_max * 1.25), 0 if args.compact_lists else longest)  # (operator path too)
 
         overflow = torch.zeros(1, dtype=torch.int32, device=dev)
         from sk_gs_amd.train_step import GraphedSteps
@@ -819,7 +819,7 @@ def main():
                                if view_table is not None else f'one captured hipGraph per view ({args.views})'),
                            'view_select': ('by the closing launch of the previous step (ordered view table)' if ordered_views else
                                            'one 256-byte device-to-device copy per step') if view_table is not None else 'baked into the graphs',
-                           'tile_lists': 'compact (count, scan, scatter)' if (args.autograd or args.compact_lists)
+                           'tile_lists': 'compact (count, scan, scatter)' if args.compact_lists
                            else f'buckets of {tile_bucket} slots per tile (longest list {longest})',
                            'joint_rotations': ('deform network (freq-encode + 8x256 MLP + heads) inside the step, '
                                                + ('one launch per layer' if args.layered_mlp else 'one persistent launch per direction'))

@@ -169,6 +169,14 @@ typedef struct skgs_raster_grads {
    * their outer product basis(dir) x g (gaussian_rasterizer_backwrad.cu:26-127).  View-parallel training all-gathers these
    * 24 bytes per Gaussian and view instead of all-reducing 192, and rebuilds the rows with skgs_sh_grad_from_factors. */
   float* dL_dsh_factors;
+  /* densification statistics of this view, updated by the same launch that writes dL_dmeans2D (NULL: not updated) -- the
+   * arithmetic of skgs_densify_stats (add_densification_stats, gaussian_splatting.py:503-513 + the max_radii2D update,
+   * sk_gs.py:1990-1997) without its launch: for radii > 0: max_radii2D = max(., radii), accum += |dL_dmeans2D.xy| *
+   * stat_grad_multiplier, denom += 1 */
+  float* stat_xyz_gradient_accum; /* [P,1] */
+  float* stat_denom;              /* [P,1] */
+  float* stat_max_radii2D;        /* [P] */
+  float stat_grad_multiplier;     /* 1 / (the scale the backward was seeded with); 0 is read as 1 */
 } skgs_raster_grads;
 size_t skgs_backward_workspace_bytes(int32_t P);
 

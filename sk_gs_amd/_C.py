@@ -63,6 +63,8 @@ class _RasterGrads(C.Structure):
         ('dL_dscales', C.c_void_p), ('dL_drotations', C.c_void_p), ('dL_dextras', C.c_void_p),
         ('dL_dsh_rest', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t),
         ('workspace_is_zero', C.c_int32), ('dL_dsh_factors', C.c_void_p),
+        ('stat_xyz_gradient_accum', C.c_void_p), ('stat_denom', C.c_void_p), ('stat_max_radii2D', C.c_void_p),
+        ('stat_grad_multiplier', C.c_float),
     ]
 
 
@@ -176,6 +178,8 @@ class _Config:
 
 config = _Config()
 _capacity_hint = {}  # (P, W, H) -> last capacity
+_bucket_hint = {}    # (P, W, H) -> slots per tile for the bucket layout of the tile lists (sync-free forward only)
+_zero_ws = {}        # (device index, P) -> backward scratch that every backward hands back all zero
 _pinned = {}
 
 
@@ -361,6 +365,10 @@ def rasterize_gaussians(image_height: int, image_width: int, tanfovx: float, tan
         else:
             key = (P, W, H)
             cap = _capacity_hint.get(key, max(config.min_capacity, 8 * P))
+            bucket = _bucket_hint.get(key, 0)
+            if bucket:  # fixed slots per tile: preprocess -> scatter -> sort -> blend, four launches
+                a.tile_bucket_capacity = bucket
+                cap = ((W + 15) // 16) * ((H + 15) // 16) * bucket
             binning = torch.empty((_buffer_bytes(lib, 'binning', int(cap)),), dtype=torch.uint8, device=dev)
             bufs = _buffers(geom, binning, img)
             _check(lib.skgs_rasterize_forward(C.byref(a), C.byref(bufs), C.c_void_p(radii.data_ptr()),
@@ -402,8 +410,20 @@ def unpack_buffers(W: int, H: int, P: int, geomBuffer: Tensor, binningBuffer: Te
                 capacity=cap)
 
 
-def update_capacity_hint(P: int, W: int, H: int, num_rendered: int):
+def update_capacity_hint(P: int, W: int, H: int, num_rendered: int, longest_list: int = 0):
+    """sync-free forwards (``config.sync_num_rendered = False``) of this shape get a binning buffer for ``num_rendered`` x
+    growth tile instances.  With ``longest_list`` (the longest tile list seen, ``read_status()['max_tile_count']``) they use
+    the BUCKET layout instead -- every tile owns 1.5 x that many fixed slots, rounded up to 64: no counting and no scan
+    launch, and no merge-sort launch when a wave sorts every bucket (what ``FusedViewStep(tile_bucket=...)`` does); a tile
+    that outgrows its bucket raises the same device-side overflow flag as a binning buffer that is too small."""
     _capacity_hint[(P, W, H)] = max(config.min_capacity, int(num_rendered * config.capacity_growth) + 1024)
+    if longest_list > 0:
+        bucket = ((int(longest_list * 1.5) + 63) // 64) * 64
+        if 512 < bucket and longest_list * 1.2 <= 512:
+            bucket = 512
+        _bucket_hint[(P, W, H)] = bucket
+    else:
+        _bucket_hint.pop((P, W, H), None)
 
 
 # ====================================================================================== rasterize_gaussians_backward
@@ -451,8 +471,14 @@ def rasterize_gaussians_backward(scale_modifier: float, tanfovx: float, tanfovy:
         if P == 0:
             return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drot,
                     dL_dextras)
+        # the scratch rows of the blend backward: pooled per (device, P) and handed back all zero by every backward
+        # (skgs_raster_grads.workspace_is_zero) -- no 64-byte-per-Gaussian fill launch in front of each call
         ws_bytes = _buffer_bytes(lib, 'bwd_ws', P)
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        ws_key = (dev.index, P, _stream().value)  # (per stream: nothing orders two streams' use of one scratch)
+        ws = _zero_ws.pop(ws_key, None)  # (popped: a call that fails half-way must not leave a dirty scratch behind)
+        if ws is None or torch.cuda.is_current_stream_capturing():
+            ws = torch.zeros((ws_bytes,), dtype=torch.uint8, device=dev)
+        g.workspace_is_zero = 1
         g.dL_dout_color, g.dL_dout_opacity, g.dL_dout_extra = _ptr(dL_dout_color), _ptr(dL_dout_opacity), _ptr(dL_dout_extra)
         g.grad_means2D_in, g.grad_conic_in, g.grad_opacity_in = _ptr(gm_in), _ptr(gc_in), _ptr(go_in)
         g.dL_dmeans2D, g.dL_dconic, g.dL_dcolors, g.dL_dopacity = _ptr(dL_dmeans2D), None, _ptr(dL_dcolors), _ptr(dL_dopacity)
@@ -464,6 +490,8 @@ def rasterize_gaussians_backward(scale_modifier: float, tanfovx: float, tanfovy:
         bufs = _buffers(geomBuffer, binningBuffer, imgBuffer)
         _check(lib.skgs_rasterize_backward(C.byref(a), C.byref(bufs), C.c_void_p(radii.data_ptr()),
                                            C.c_void_p(out_opacity.data_ptr()), C.byref(g), _stream()))
+        if not torch.cuda.is_current_stream_capturing() and len(_zero_ws) < 8:
+            _zero_ws[ws_key] = ws
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drot, dL_dextras
 
 

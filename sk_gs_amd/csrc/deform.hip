@@ -262,8 +262,12 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_moments_kernel
     float* __restrict__ g_log_scale, float* __restrict__ g_rot, float* __restrict__ g_opacity_logit,
     float* __restrict__ partials /* [gridDim.x][M][19] */,
     float* __restrict__ g_sp_W /* [P,M] or NULL */, float* __restrict__ g_logits /* [P,K] or NULL; both need K <= PREF_K */,
-    const int32_t* __restrict__ live /* NULL, or the live Gaussian count (<= P) */) {
-  if (live) P = min(P, live[0]);  // the number of Gaussians is a device word: one captured graph survives densification
+    const int32_t* __restrict__ live_count /* NULL, or the live Gaussian count (<= P) */) {
+  if (live_count) P = min(P, live_count[0]);  // the number of Gaussians is a device word: one captured graph survives densification
+  if ((int) (blockIdx.x * DEFORM_THREADS) >= P) {  // a workgroup of the capacity's slack rows: its partial is zero
+    for (int o = threadIdx.x; o < M * MOM_F; o += DEFORM_THREADS) partials[(size_t) blockIdx.x * M * MOM_F + o] = 0.f;
+    return;
+  }
   extern __shared__ float s_mem[];
   const int Mp    = (M + 3) & ~3;                 // weight rows padded to float4
   float* s_bones  = s_mem;                        // [M][14]
@@ -888,6 +892,7 @@ __global__ void __launch_bounds__(256) knn_deform_forward_kernel(int P, int M, i
     int64_t* __restrict__ out_idx, float* __restrict__ out_weights, float* __restrict__ means, float* __restrict__ scales,
     float* __restrict__ rotations, float* __restrict__ opacity, const int32_t* __restrict__ live) {
   if (live) P = min(P, live[0]);  // the number of Gaussians is a device word: one captured graph survives densification
+  if ((int) (blockIdx.x * 256) >= P) return;  // slack rows of the capacity
   extern __shared__ float s_dyn[];
   float* s_j       = s_dyn;                                                  // [M][3]
   float* s_bones   = s_dyn + ((M * 3 + 3) & ~3);                             // [M][14]

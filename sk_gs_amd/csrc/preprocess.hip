@@ -320,6 +320,14 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
   if (hdr_bucket && idx == 0) {  // no scan kernel in the bucket layout: R and the longest list are not computed
     hdr_bucket->num_rendered = -1, hdr_bucket->max_tile_count = -1, hdr_bucket->overflow = 0, hdr_bucket->big_tiles = 0;
   }
+  if ((int) (blockIdx.x * blockDim.x) >= P) {  // a workgroup of the capacity's slack rows: culled-Gaussian outputs, no staging
+    if (idx < P_cap) {
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      radii[idx] = 0;
+      recs[3 * idx + 0] = z, recs[3 * idx + 1] = z, recs[3 * idx + 2] = z;
+    }
+    return;
+  }
   // this workgroup's SH rows -> LDS (coefficient 0 through my_dc, coefficients >= 1 through my_sh, see sh_to_rgb)
   extern __shared__ float s_sh[];
   const float *my_dc = nullptr, *my_sh = nullptr;
@@ -541,8 +549,10 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_backward_kernel(int P,
     float* __restrict__ dL_dsh_rest,
     float* __restrict__ dL_dscales, float* __restrict__ dL_drot, float* __restrict__ dL_dextras,
     float* __restrict__ sh_factors /* [P,6] or NULL: see sh_backward */, const float* __restrict__ tanfov_dev,
-    const int32_t* __restrict__ live) {
+    const int32_t* __restrict__ live, float* __restrict__ stat_accum, float* __restrict__ stat_denom,
+    float* __restrict__ stat_max_radii, float stat_mult) {
   if (live) P = min(P, live[0]);  // the number of Gaussians is a device word: one captured graph survives densification
+  if ((int) (blockIdx.x * blockDim.x) >= P) return;  // a workgroup of the capacity's slack rows (before any barrier)
   if (tanfov_dev) {
     tan_fovx = tanfov_dev[0], tan_fovy = tanfov_dev[1];
     focal_x = W / (2.0f * tan_fovx), focal_y = H / (2.0f * tan_fovy);
@@ -615,6 +625,14 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_backward_kernel(int P,
   if (gin_opacity) gop += gin_opacity[idx];
   dL_dmeans2D[3 * idx] = gm2[0], dL_dmeans2D[3 * idx + 1] = gm2[1];
   dL_dmeans2D[3 * idx + 2] = gin_means2D ? gin_means2D[3 * idx + 2] : 0.f;
+  // densification statistics of this view (skgs_densify_stats folded in: the arithmetic of densify.hip::densify_stats_kernel
+  // on the values just written -- one launch less per training step)
+  if (stat_accum && pf_radius > 0) {
+    stat_max_radii[idx] = fmaxf(stat_max_radii[idx], (float) pf_radius);
+    const float nrm     = sqrtf(gm2[0] * gm2[0] + gm2[1] * gm2[1]);
+    stat_accum[idx]     = stat_accum[idx] + (stat_mult == 1.0f ? nrm : stat_mult * nrm);
+    stat_denom[idx]     = stat_denom[idx] + 1.0f;
+  }
   if (dL_dconic_out) {
     dL_dconic_out[4 * idx] = gcon[0], dL_dconic_out[4 * idx + 1] = gcon[1];
     dL_dconic_out[4 * idx + 2] = gin_conic ? gin_conic[4 * idx + 2] : 0.f;
@@ -975,7 +993,8 @@ int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const i
       focal_x, focal_y, g.recs, gr.workspace, (int) gradacc_rows_hold_moments(), (int) (gr.workspace_is_zero != 0),       \
       gr.grad_means2D_in, gr.grad_conic_in, gr.grad_opacity_in, E, gr.dL_dmeans2D, gr.dL_dconic, gr.dL_dcolors,           \
       gr.dL_dopacity, gr.dL_dmeans3D, gr.dL_dcov3D, gr.dL_dsh, gr.dL_dsh_rest, gr.dL_dscales, gr.dL_drotations,           \
-      gr.dL_dextras, gr.dL_dsh_factors, in.tanfov_device, in.live_count
+      gr.dL_dextras, gr.dL_dsh_factors, in.tanfov_device, in.live_count, gr.stat_xyz_gradient_accum, gr.stat_denom,        \
+      gr.stat_max_radii2D, (gr.stat_grad_multiplier != 0.f ? gr.stat_grad_multiplier : 1.0f)
   if (in.colmap)
     hipLaunchKernelGGL(preprocess_backward_kernel<true>, grid, block, lds, s, SKGS_PB_ARGS);
   else

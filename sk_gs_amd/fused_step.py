@@ -380,6 +380,9 @@ class FusedViewStep:
         g.dL_dscales, g.dL_drotations = self.g_scales.data_ptr(), self.g_rotations.data_ptr()
         g.workspace, g.workspace_bytes = self.bwd_ws.data_ptr(), self.bwd_ws.numel()
         g.workspace_is_zero = 1
+        if self.densify_stats:  # this view's statistics, by the launch that writes the screen-space gradient
+            g.stat_xyz_gradient_accum, g.stat_denom = self._acc_store.data_ptr(), self._den_store.data_ptr()
+            g.stat_max_radii2D, g.stat_grad_multiplier = self._rad_store.data_ptr(), 1.0 / self._grad_scale_value
         chk(lib.skgs_rasterize_backward(C.byref(a), C.byref(self._bufs), _p(self.radii), _p(self.out_opacity),
                                         C.byref(g), st))
 
@@ -435,8 +438,7 @@ class FusedViewStep:
                 C.c_void_p(g_gT), fidx, st))
         if self.deform_net is not None:
             self._deform_net_backward()
-        if self.densify_stats:
-            self.add_densification_stats()
+        # (densify_stats: folded into the rasterizer backward's per-Gaussian launch, see backward_raster)
 
     def _lbs_logits_backward(self):
         """softmax backward of the LBS logits as its own launch (many bones / neighbours: M > 64 or K > 8)"""

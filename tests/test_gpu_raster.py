@@ -273,6 +273,41 @@ def test_async_capacity_overflow_flag():
         C._capacity_hint.clear()
 
 
+def test_sync_free_operator_path_with_tile_buckets_matches_the_compact_lists():
+    """``update_capacity_hint(..., longest_list)``: the sync-free operator path takes the bucket layout of the tile lists
+    (four launches instead of seven to nine) -- same image bit for bit, same gradients up to the atomics' order, the pooled
+    all-zero backward scratch is handed back clean, and a bucket that is too small raises the overflow flag"""
+    C = _C()
+    P, W, H = 20000, 320, 240
+    act, rs, cam = scene_inputs(P, W, H, seed=6, colmap=True, scale_mult=2.0, device='cuda')
+    g = torch.Generator().manual_seed(8)
+    gc, go = torch.randn(3, H, W, generator=g).cuda(), torch.randn(H, W, generator=g).cuda()
+    C.config.sync_num_rendered = True
+    ref = hip_forward(act, rs)
+    gref = hip_backward(ref, act, rs, gc, go)
+    R, longest = ref[0], C.read_status(ref[4])['max_tile_count']
+    try:
+        C.config.sync_num_rendered = False
+        C.update_capacity_hint(P, W, H, R, longest)
+        assert C._bucket_hint[(P, W, H)] >= longest
+        for _ in range(3):  # repeated calls: the pooled scratch must come back all zero every time
+            out = hip_forward(act, rs)
+            st = C.read_status(out[4])
+            assert st['overflow'] == 0
+            assert torch.equal(out[1], ref[1]) and torch.equal(out[2], ref[2]) and torch.equal(out[3], ref[3])
+            grads = hip_backward(out, act, rs, gc, go)
+            for name, a, b in zip(GRAD_NAMES, grads, gref):
+                assert rel_err(a, b) <= 2e-5, name
+        for ws in C._zero_ws.values():
+            assert int(ws.view(torch.int32).abs().max()) == 0
+        C._bucket_hint[(P, W, H)] = 64 * max(1, longest // 128)  # too small for the longest list
+        out = hip_forward(act, rs)
+        assert C.read_status(out[4])['overflow'] == 1
+    finally:
+        C.config.sync_num_rendered = True
+        C._capacity_hint.clear(), C._bucket_hint.clear()
+
+
 def test_blend_kernels_walk_the_tile_groups_heaviest_first_and_the_order_changes_nothing():
     """the group order written by the sort launch (binning.hip::tile_order_job) is a permutation of the groups of 8 tiles,
     by total list length descending (ties: lower id first); with the order switched off (raster order) the forward is

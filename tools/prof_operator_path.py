@@ -14,9 +14,10 @@ rs = scene.raster_settings_from_camera(scene.make_camera(W, H, seed=0), sh_degre
 with torch.no_grad():
     net = {k: v.detach() for k, v in model(0).items()}
     _C.config.sync_num_rendered = True
-    R = render(**net, raster_settings=rs)['buffer'].R
+    buf = render(**net, raster_settings=rs)['buffer']
+    R, longest = buf.R, _C.read_status(buf.geomBuffer)['max_tile_count']
 _C.config.sync_num_rendered = False
-_C.update_capacity_hint(P, W, H, int(R * 1.25))
+_C.update_capacity_hint(P, W, H, int(R * 1.25), 0 if os.environ.get('SKGS_COMPACT') else longest)
 gcol, gop = torch.randn(3, H, W, device=dev), torch.randn(H, W, device=dev)
 ins = {k: v.clone().requires_grad_(True) for k, v in net.items()}
 
