@@ -209,7 +209,7 @@ def main():
     ap.add_argument('--densify-every', type=int, default=0,
                     help='one rank, fused step: run a densification event (clone + split + prune, networks/gaussian_splatting.py:'
                          '565-650, thresholds calibrated so that ~2 %% of the Gaussians are cloned / split and ~2 %% pruned) every N '
-                         'steps INSIDE the timed region.  The model gets a row capacity of 1.5 x P (sk_gs_amd/capacity.py): the '
+                         'steps INSIDE the timed region.  The model gets a row capacity of 1.25 x P (sk_gs_amd/capacity.py): the '
                          'surgery happens in place and the ONE captured graph keeps replaying -- the reported it/s is end-to-end')
     ap.add_argument('--autograd', action='store_true',
                     help='run the step through the torch-autograd operator path (model.render + image_loss + backward) '
@@ -253,7 +253,7 @@ def main():
                                  scale_mult=args.scale_mult, learn_joints=args.learn_joints).to(dev)
         densify_every = args.densify_every if (world == 1 and not args.autograd and M > 0) else 0
         if densify_every:  # room to grow BEFORE anything mirrors the parameters (gradient slots, moments, workspaces)
-            model.enable_capacity(int(P * 1.5))
+            model.enable_capacity(int(P * 1.25))
         cams = [scene.make_camera(W, H, seed=i) for i in range(args.views)]
         settings = [scene.raster_settings_from_camera(c, sh_degree=3, colmap=True, device=dev) for c in cams]
         background = torch.ones(3, device=dev)
@@ -704,11 +704,14 @@ def main():
             gcol, gop = torch.randn(3, H, W, device=dev), torch.randn(H, W, device=dev)
             ins = {k: v.clone().requires_grad_(True) for k, v in net.items()}
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(NT)]
+            leaves = list(ins.values())
             for i in range(NW + NT):  # rasterizer forward + backward with fixed upstream gradients, operator path, no host sync
                 if i >= NW:
                     ev[i - NW][0].record()
                 o = render(**ins, raster_settings=settings[0])
-                torch.autograd.backward([o['images'], o['opacity']], [gcol, gop])
+                # (autograd.grad: the operator's gradients are RETURNED, not accumulated into leaf .grad tensors -- five
+                # AccumulateGrad add kernels per iteration, 19 MB of them the SH gradient, are not the rasterizer)
+                torch.autograd.grad([o['images'], o['opacity']], leaves, [gcol, gop], allow_unused=True)
                 if i >= NW:
                     ev[i - NW][1].record()
             torch.cuda.synchronize()
@@ -720,7 +723,7 @@ def main():
             try:
                 def op_fwd_bwd(_):
                     o_ = render(**ins, raster_settings=settings[0])
-                    torch.autograd.backward([o_['images'], o_['opacity']], [gcol, gop])
+                    torch.autograd.grad([o_['images'], o_['opacity']], leaves, [gcol, gop], allow_unused=True)
                 del o
                 g_op = GraphedSteps(op_fwd_bwd)
                 g_op.capture(0)
@@ -846,8 +849,9 @@ def main():
                        'render_backward', 'preprocess_backward')
                 ms_render['kernel_sum'] = round(sum(kernels[k]['us'] * kernels[k]['launches_per_step']
                                                     for k in ras if k in kernels) / 1e3, 4)
-                ms_render['how'] = 'operator path render() + backward, eager launches, no host synchronisation; kernel_sum: ' \
-                                   'the rasterizer kernels of the fused step'
+                ms_render['how'] = 'operator path render() + torch.autograd.grad of (images, opacity) w.r.t. its five inputs, eager ' \
+                                   'launches, bucket tile lists, no host synchronisation; kernel_sum: the rasterizer kernels of ' \
+                                   'the fused step'
                 line['ms_per_render_fwd_bwd'] = ms_render
                 line['fps_forward_render'] = fps
             if densify_log is not None:
