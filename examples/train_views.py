@@ -32,7 +32,7 @@ def main():
     ap.add_argument('--iters', type=int, default=400)
     ap.add_argument('--lr', type=float, default=1e-3)
     ap.add_argument('--densify-every', type=int, default=0, help='clone / split / prune every N iterations (0: never)')
-    ap.add_argument('--capacity', type=float, default=2.5,
+    ap.add_argument('--capacity', type=float, default=1.5,
                     help='one rank: row capacity as a multiple of --gaussians (sk_gs_amd/capacity.py): densification within it '
                          'happens in place and the captured step is never rebuilt or re-captured; 0 = rebuild after every event')
     args = ap.parse_args()
@@ -146,9 +146,14 @@ def main():
             before = model.P
             try:
                 densify.densify(model, opt, step, max_grad=2e-4, extent=4.0, generator=gen)
-                densify.prune(model, opt, step, min_opacity=0.005, extent=4.0, max_screen_size=0.25 * W)
-            except CapacityExceeded as e:  # (a real loop would re-home the model with a larger capacity and rebuild)
-                print(f'iter {it:5d}  densification skipped: {e}')
+            except CapacityExceeded:  # re-home into twice the rows, rebuild, capture again: once per capacity doubling
+                model.capacity.grow(model, 2 * model.capacity.P_cap, optimizer=opt)
+                vp, step, run = build_runtime(stats_from=step)
+                guard.rebind(step)
+                if rank == 0:
+                    print(f'iter {it:5d}  row capacity grown to {model.capacity.P_cap}: runtime rebuilt, the next step re-captures')
+                densify.densify(model, opt, step, max_grad=2e-4, extent=4.0, generator=gen)
+            densify.prune(model, opt, step, min_opacity=0.005, extent=4.0, max_screen_size=0.25 * W)
             torch.cuda.synchronize(); t_a = time.perf_counter()
             if model.capacity is None:
                 vp, step, run = build_runtime()                  # P changed: new buffers, the next step re-captures

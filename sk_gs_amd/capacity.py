@@ -69,6 +69,32 @@ class RowCapacity:
                 if p.grad is not None:  # a gradient allocated for P rows has no room: start over
                     p.grad = None
 
+    @torch.no_grad()
+    def grow(self, model, P_cap: int, optimizer=None):
+        """Re-home the per-Gaussian parameters (and, with ``optimizer``, their Adam moments) into storage of ``P_cap`` rows --
+        what to do on ``CapacityExceeded``.  Every address changes: afterwards rebuild the gradient buffer (``FlatGradBuffer``)
+        and the step (``FusedViewStep``), ``optimizer.rebind()``, and let the graphs be captured again -- the cost of ONE
+        round-2 densification, paid once per capacity doubling instead of at every event."""
+        assert P_cap >= self.P_cap
+        P = int(model.P)
+        for attr in PER_GAUSSIAN:
+            p = getattr(model, attr, None)
+            if p is None:
+                continue
+            store = torch.zeros((int(P_cap),) + tuple(p.shape[1:]), dtype=p.dtype, device=p.device)
+            store[:P].copy_(p.data)
+            p.data = store[:P]
+            p._cap_store = store
+            p.grad = None  # (its slot was sized for the old capacity)
+            if optimizer is not None and p in optimizer.state:
+                st = optimizer.state[p]
+                m, v = torch.zeros_like(store), torch.zeros_like(store)
+                m[:P].copy_(st['exp_avg']), v[:P].copy_(st['exp_avg_sq'])
+                optimizer._cap_state[p] = (m, v)
+                optimizer.state[p] = dict(exp_avg=m[:P], exp_avg_sq=v[:P])
+        self.P_cap = int(P_cap)
+        self.live.fill_(P)  # (the same device word: a NEW step picks it up again)
+
     def set_live(self, n: int):
         assert 0 <= n <= self.P_cap
         self.live.fill_(int(n))

@@ -186,3 +186,56 @@ def test_one_captured_graph_keeps_training_through_clone_split_and_prune():
     assert float(opt.step_count.item()) == 4 + 2 * 4 and len(graph.graphs) == 1
     # the model kept learning: the loss of the last step is finite and the parameters are finite
     assert torch.isfinite(step.loss3).all() and all(torch.isfinite(p).all() for p in model.parameters())
+
+
+def test_growing_the_capacity_keeps_parameters_and_moments():
+    """``CapacityExceeded`` -> ``RowCapacity.grow``: parameters and Adam moments move into larger storage unchanged, the
+    densification that did not fit then does, and a rebuilt runtime trains on (one rebuild + re-capture per capacity
+    doubling instead of one per event)"""
+    from sk_gs_amd import densify
+    from sk_gs_amd.optim import CapacityExceeded
+    dev = torch.device('cuda')
+    settings, targets = _scene(dev)
+    model = _model(dev)
+    model.enable_capacity(int(P * 1.1))
+    table, buf, step, opt, train, graph = _runtime(model, settings, targets, lr=2e-3)
+    for _ in range(3):
+        graph(0)
+    torch.cuda.synchronize()
+    snap = {n: (p.detach().clone(), opt.state[p]['exp_avg'].clone(), opt.state[p]['exp_avg_sq'].clone())
+            for n, p in model.named_parameters()}
+    _fill_stats(step, model.P, seed=3)
+    with pytest.raises(CapacityExceeded):
+        densify.densify(model, opt, step, max_grad=2e-4, extent=4.0, generator=torch.Generator(device='cuda').manual_seed(1))
+    assert model.P == P and all(torch.equal(p, snap[n][0]) for n, p in model.named_parameters())
+    stats = (step.xyz_gradient_accum.clone(), step.denom.clone(), step.max_radii2D.clone())
+    model.capacity.grow(model, 2 * P, optimizer=opt)
+    for n, p in model.named_parameters():
+        assert torch.equal(p, snap[n][0]) and torch.equal(opt.state[p]['exp_avg'], snap[n][1]), n
+        assert torch.equal(opt.state[p]['exp_avg_sq'], snap[n][2]), n
+    table, buf, step, _, train, graph = _runtime_with(model, opt, settings, targets)
+    step.xyz_gradient_accum, step.denom, step.max_radii2D = stats
+    densify.densify(model, opt, step, max_grad=2e-4, extent=4.0, generator=torch.Generator(device='cuda').manual_seed(1))
+    assert model.P > P and int(model.capacity.live.item()) == model.P
+    step.reset_densify_stats()
+    for _ in range(3):
+        graph(0)
+    torch.cuda.synchronize()
+    assert step.status()['overflow_events'] == 0 and float(opt.step_count.item()) == 6
+    assert torch.isfinite(step.loss3).all() and int(step.radii[model.P:].abs().max()) == 0
+
+
+def _runtime_with(model, opt, settings, targets):
+    """a rebuilt runtime around an EXISTING optimizer (after RowCapacity.grow)"""
+    from sk_gs_amd.fused_step import FusedViewStep
+    from sk_gs_amd.train_step import FusedTrainStep, GraphedSteps
+    from sk_gs_amd.view_parallel import FlatGradBuffer
+    from sk_gs_amd.view_slot import ViewTable
+    dev = targets.device
+    table = ViewTable(settings, [float(model.frame_times[v]) for v in range(V)], list(range(V)), targets, dev)
+    buf = FlatGradBuffer(model.parameters())
+    step = FusedViewStep(model, W, H, capacity=2_000_000, densify_stats=True, view_table=table)
+    opt.rebind()
+    train = FusedTrainStep(step, opt)
+    table.set_order(list(range(V)))
+    return table, buf, step, opt, train, GraphedSteps(lambda _: train(), collect_garbage=False)
