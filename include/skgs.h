@@ -258,15 +258,20 @@ int skgs_knn_bones(int32_t P, int32_t M, int32_t K, int32_t dim, const float* po
  * out_idx [P,K] int64, out_weights [P,K], out_dist [P,K] (kept for the backward).
  * Backward: g_weights [P,K] -> g_points [P,dim] (optional), g_joints [M,dim], g_kernel_radius [M], g_kernel_weight [M]
  * (optional ones may be NULL): what autograd returns through knn_points' distances and the [indices] gathers.  The
- * workspace holds per-workgroup partial sums (skgs_knn_dist_weights_workspace_bytes). */
+ * workspace holds per-workgroup partial sums (skgs_knn_dist_weights_workspace_bytes).
+ * raw_parameters != 0: kernel_radius / kernel_weight point at the RAW parameters `_sp_radius` / `_sp_weight` and the kernels
+ * apply exp / sigmoid themselves (sk_gs.py:547-553), the backward returning the gradients w.r.t. the raw parameters: a step
+ * without autograd then needs no launch for M values.  accumulate_joints != 0: g_joints += instead of = (the joints also get a
+ * gradient through the kinematic chain). */
 int skgs_knn_dist_weights_forward(int32_t P, int32_t M, int32_t K, int32_t dim, const float* points, const float* joints,
-    const float* kernel_radius, const float* kernel_weight, float temperature, int64_t* out_idx, float* out_weights,
-    float* out_dist, skgs_stream_t stream);
+    const float* kernel_radius, const float* kernel_weight, float temperature, int32_t raw_parameters, int64_t* out_idx,
+    float* out_weights, float* out_dist, skgs_stream_t stream);
 size_t skgs_knn_dist_weights_workspace_bytes(int32_t P, int32_t M, int32_t dim);
 int skgs_knn_dist_weights_backward(int32_t P, int32_t M, int32_t K, int32_t dim, const float* points, const float* joints,
-    const float* kernel_radius, const float* kernel_weight, float temperature, const float* weights, const int64_t* indices,
-    const float* nn_dist, const float* g_weights, float* g_points, float* g_joints, float* g_kernel_radius,
-    float* g_kernel_weight, void* workspace, size_t workspace_bytes, skgs_stream_t stream);
+    const float* kernel_radius, const float* kernel_weight, float temperature, int32_t raw_parameters,
+    int32_t accumulate_joints, const float* weights, const int64_t* indices, const float* nn_dist, const float* g_weights,
+    float* g_points, float* g_joints, float* g_kernel_radius, float* g_kernel_weight, void* workspace, size_t workspace_bytes,
+    skgs_stream_t stream);
 /* LBS weights from the per-Gaussian logits, the `sp_W` branch of calc_LBS_weight (networks/sk_gs.py:769-770):
  * weights[P,K] = softmax_k(sp_W[p, indices[p,k]]).  The backward writes the DENSE gradient g_sp_W[P,M] (zeros for the
  * bones outside the K nearest), i.e. what autograd's gather backward accumulates into a zero tensor. */

@@ -340,28 +340,29 @@ int skgs_knn_bones(int32_t P, int32_t M, int32_t K, int32_t dim, const float* po
 }
 
 int skgs_knn_dist_weights_forward(int32_t P, int32_t M, int32_t K, int32_t dim, const float* points, const float* joints,
-    const float* kernel_radius, const float* kernel_weight, float temperature, int64_t* out_idx, float* out_weights,
-    float* out_dist, skgs_stream_t stream) {
+    const float* kernel_radius, const float* kernel_weight, float temperature, int32_t raw_parameters, int64_t* out_idx,
+    float* out_weights, float* out_dist, skgs_stream_t stream) {
   SKGS_REQUIRE(P == 0 || (points && joints && out_idx && out_weights && out_dist), "knn_dist_weights_forward: NULL argument");
   SKGS_REQUIRE(M >= 1, "knn_dist_weights_forward: M must be >= 1");
   SKGS_REQUIRE(kernel_radius || !kernel_weight, "knn_dist_weights_forward: kernel_weight needs kernel_radius");
   SKGS_REQUIRE(kernel_radius || temperature != 0.f, "knn_dist_weights_forward: the dist method needs a temperature != 0");
-  return launch_knn_dist_weights_forward(P, M, K, dim, points, joints, kernel_radius, kernel_weight, temperature, out_idx,
-      out_weights, out_dist, (hipStream_t) stream);
+  return launch_knn_dist_weights_forward(P, M, K, dim, points, joints, kernel_radius, kernel_weight, temperature,
+      raw_parameters ? 1 : 0, out_idx, out_weights, out_dist, (hipStream_t) stream);
 }
 size_t skgs_knn_dist_weights_workspace_bytes(int32_t P, int32_t M, int32_t dim) {
   return knn_dist_weights_workspace_bytes(P, M, dim);
 }
 int skgs_knn_dist_weights_backward(int32_t P, int32_t M, int32_t K, int32_t dim, const float* points, const float* joints,
-    const float* kernel_radius, const float* kernel_weight, float temperature, const float* weights, const int64_t* indices,
-    const float* nn_dist, const float* g_weights, float* g_points, float* g_joints, float* g_kernel_radius,
-    float* g_kernel_weight, void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
+    const float* kernel_radius, const float* kernel_weight, float temperature, int32_t raw_parameters,
+    int32_t accumulate_joints, const float* weights, const int64_t* indices, const float* nn_dist, const float* g_weights,
+    float* g_points, float* g_joints, float* g_kernel_radius, float* g_kernel_weight, void* workspace, size_t workspace_bytes,
+    skgs_stream_t stream) {
   SKGS_REQUIRE(points && joints && (P == 0 || (weights && indices && nn_dist && g_weights)), "knn_dist_weights_backward: NULL argument");
   SKGS_REQUIRE(M >= 1, "knn_dist_weights_backward: M must be >= 1");
   SKGS_REQUIRE(kernel_radius || !kernel_weight, "knn_dist_weights_backward: kernel_weight needs kernel_radius");
-  return launch_knn_dist_weights_backward(P, M, K, dim, points, joints, kernel_radius, kernel_weight, temperature, weights,
-      indices, nn_dist, g_weights, g_points, g_joints, g_kernel_radius, g_kernel_weight, workspace, workspace_bytes,
-      (hipStream_t) stream);
+  return launch_knn_dist_weights_backward(P, M, K, dim, points, joints, kernel_radius, kernel_weight, temperature,
+      raw_parameters ? 1 : 0, accumulate_joints ? 1 : 0, weights, indices, nn_dist, g_weights, g_points, g_joints,
+      g_kernel_radius, g_kernel_weight, workspace, workspace_bytes, (hipStream_t) stream);
 }
 
 int skgs_lbs_weights_backward_compact(int32_t P, int32_t K, const float* weights, const float* g_weights, float* g_logits,

@@ -670,10 +670,19 @@ __global__ void __launch_bounds__(256) lbs_logits_scatter_kernel(int P, int M, i
 // with d, i the squared distances / ids of the K nearest bones in `dim` dimensions (3 in stage sk; 3 + 8 hyper-feature
 // dimensions in stage sp, sk_gs.py:753-755).  Round 2 ran these as ~8 element-wise torch launches + autograd on top of the
 // KNN kernel; here one launch per direction.  The forward keeps the distances for the backward.
+// kernel_radius / kernel_weight of bone j: the activated values, or (activate != 0) the raw parameters `_sp_radius` /
+// `_sp_weight` run through their activations here -- exp and sigmoid, the properties of sk_gs.py:547-553 -- so that a step
+// without autograd needs no launch for M values
+__device__ __forceinline__ float dw_radius(const float* __restrict__ radius, int j, int activate) {
+  return activate ? expf(radius[j]) : radius[j];
+}
+__device__ __forceinline__ float dw_kweight(const float* __restrict__ kweight, int j, int activate) {
+  return activate ? 1.0f / (1.0f + expf(-kweight[j])) : kweight[j];
+}
 template <int KCAP>
 __global__ void __launch_bounds__(256) knn_dist_weights_kernel(int P, int M, int K, int dim, const float* __restrict__ points,
     const float* __restrict__ joints, const float* __restrict__ radius, const float* __restrict__ kweight, float temperature,
-    int64_t* __restrict__ out_idx, float* __restrict__ out_weights, float* __restrict__ out_dist, int lds_joints) {
+    int64_t* __restrict__ out_idx, float* __restrict__ out_weights, float* __restrict__ out_dist, int lds_joints, int activate) {
   extern __shared__ float s_j[];
   if (lds_joints) {
     for (int i = threadIdx.x; i < M * dim; i += blockDim.x) s_j[i] = joints[i];
@@ -710,9 +719,9 @@ __global__ void __launch_bounds__(256) knn_dist_weights_kernel(int P, int M, int
     for (int k = 0; k < KCAP; ++k) {
       v[k] = 0.f;
       if (k < K) {
-        const float r = radius[bi[k]];
+        const float r = dw_radius(radius, bi[k], activate);
         float e = expf(-bd[k] / (2.f * (r * r)));
-        if (kweight) e = e * kweight[bi[k]];
+        if (kweight) e = e * dw_kweight(kweight, bi[k], activate);
         v[k] = e + 1e-7f;
         sum += v[k];
       }
@@ -749,7 +758,7 @@ __global__ void __launch_bounds__(256) dist_weights_backward_kernel(int P, int M
     const float* __restrict__ points, const float* __restrict__ joints, const float* __restrict__ radius,
     const float* __restrict__ kweight, float temperature, const float* __restrict__ weights,
     const int64_t* __restrict__ indices, const float* __restrict__ nn_dist, const float* __restrict__ g_weights,
-    float* __restrict__ g_points, float* __restrict__ partials) {
+    float* __restrict__ g_points, float* __restrict__ partials, int activate) {
   extern __shared__ float s_acc[];  // [M][V]
   const int V = dim + 2;
   for (int i = threadIdx.x; i < M * V; i += 256) s_acc[i] = 0.f;
@@ -764,9 +773,9 @@ __global__ void __launch_bounds__(256) dist_weights_backward_kernel(int P, int M
     float sum = 0.f;
     if (radius)  // S = sum_k v_k is not stored: recompute it with the forward's arithmetic
       for (int k = 0; k < K; ++k) {
-        const float r = radius[(int) ix[k]];
+        const float r = dw_radius(radius, (int) ix[k], activate);
         float e = expf(-dd[k] / (2.f * (r * r)));
-        if (kweight) e = e * kweight[(int) ix[k]];
+        if (kweight) e = e * dw_kweight(kweight, (int) ix[k], activate);
         sum += e + 1e-7f;
       }
     float g_d[KNN_MAXK];  // (compile-time indexed: stays in registers)
@@ -778,9 +787,9 @@ __global__ void __launch_bounds__(256) dist_weights_backward_kernel(int P, int M
         const int j = (int) ix[k];
         jj[k]       = j;
         if (radius) {
-          const float r   = radius[j];
+          const float r   = dw_radius(radius, j, activate);
           const float e   = expf(-dd[k] / (2.f * (r * r)));
-          const float sk  = kweight ? kweight[j] : 1.f;
+          const float sk  = kweight ? dw_kweight(kweight, j, activate) : 1.f;
           const float g_v = (gw[k] - dot) / sum;
           const float g_e = g_v * sk;
           g_d[k]          = g_e * e * (-1.f / (2.f * (r * r)));
@@ -809,18 +818,25 @@ __global__ void __launch_bounds__(256) dist_weights_backward_kernel(int P, int M
   for (int i = threadIdx.x; i < M * V; i += 256) dst[i] = s_acc[i];
 }
 __global__ void __launch_bounds__(256) dist_weights_finalize_kernel(int M, int dim, int nblk, const float* __restrict__ partials,
-    float* __restrict__ g_joints, float* __restrict__ g_radius, float* __restrict__ g_kweight) {
+    float* __restrict__ g_joints, float* __restrict__ g_radius, float* __restrict__ g_kweight,
+    const float* __restrict__ radius, const float* __restrict__ kweight, int activate, int accumulate_joints) {
   const int V = dim + 2, i = blockIdx.x * 256 + threadIdx.x;
   if (i >= M * V) return;
   float s = 0.f;
   for (int b = 0; b < nblk; ++b) s += partials[(size_t) b * M * V + i];
   const int j = i / V, c = i % V;
   if (c < dim) {
-    if (g_joints) g_joints[(size_t) j * dim + c] = s;
+    if (g_joints) g_joints[(size_t) j * dim + c] = accumulate_joints ? g_joints[(size_t) j * dim + c] + s : s;
   } else if (c == dim) {
-    if (g_radius) g_radius[j] = s;
+    // activate: the gradient w.r.t. the RAW parameter: d exp(x) = exp(x), d sigmoid(x) = s (1 - s)
+    if (g_radius) g_radius[j] = (activate && radius) ? s * expf(radius[j]) : s;
   } else if (g_kweight) {
-    g_kweight[j] = s;
+    float d = 1.f;
+    if (activate && kweight) {
+      const float sg = 1.0f / (1.0f + expf(-kweight[j]));
+      d = sg * (1.f - sg);
+    }
+    g_kweight[j] = s * d;
   }
 }
 
@@ -1112,7 +1128,7 @@ int launch_knn_lbs_weights(int P, int M, int K, const float* points, const float
 }
 
 int launch_knn_dist_weights_forward(int P, int M, int K, int dim, const float* points, const float* joints, const float* radius,
-    const float* kweight, float temperature, int64_t* out_idx, float* out_weights, float* out_dist, hipStream_t s) {
+    const float* kweight, float temperature, int activate, int64_t* out_idx, float* out_weights, float* out_dist, hipStream_t s) {
   if (P == 0) return 0;
   if (K > KNN_MAXK || K < 1 || K > M) return set_error("knn_dist_weights: K must be in [1,min(%d,M)] (got %d)", KNN_MAXK, K);
   if (dim < 1 || dim > 16) return set_error("knn_dist_weights: dim must be in [1,16] (got %d)", dim);
@@ -1121,7 +1137,7 @@ int launch_knn_dist_weights_forward(int P, int M, int K, int dim, const float* p
   ProfScope prof(K_KNN, s);
 #define SKGS_KNND(KCAP_)                                                                                                     \
   hipLaunchKernelGGL(knn_dist_weights_kernel<KCAP_>, dim3((P + 255) / 256), dim3(256), use_lds ? lds : 0, s, P, M, K, dim, points, \
-      joints, radius, kweight, temperature, out_idx, out_weights, out_dist, use_lds)
+      joints, radius, kweight, temperature, out_idx, out_weights, out_dist, use_lds, activate)
   if (K <= 4)
     SKGS_KNND(4);
   else if (K <= 5)
@@ -1140,9 +1156,9 @@ size_t knn_dist_weights_workspace_bytes(int P, int M, int dim) {
   return (size_t) dist_weights_blocks(P) * M * (dim + 2) * sizeof(float);
 }
 int launch_knn_dist_weights_backward(int P, int M, int K, int dim, const float* points, const float* joints, const float* radius,
-    const float* kweight, float temperature, const float* weights, const int64_t* indices, const float* nn_dist,
-    const float* g_weights, float* g_points, float* g_joints, float* g_radius, float* g_kweight, void* workspace,
-    size_t workspace_bytes, hipStream_t s) {
+    const float* kweight, float temperature, int activate, int accumulate_joints, const float* weights, const int64_t* indices,
+    const float* nn_dist, const float* g_weights, float* g_points, float* g_joints, float* g_radius, float* g_kweight,
+    void* workspace, size_t workspace_bytes, hipStream_t s) {
   if (K > KNN_MAXK || K < 1) return set_error("knn_dist_weights_backward: K must be in [1,%d] (got %d)", KNN_MAXK, K);
   if (dim < 1 || dim > 16) return set_error("knn_dist_weights_backward: dim must be in [1,16] (got %d)", dim);
   const int V = dim + 2, nblk = dist_weights_blocks(P);
@@ -1152,9 +1168,9 @@ int launch_knn_dist_weights_backward(int P, int M, int K, int dim, const float* 
     return set_error("knn_dist_weights_backward: workspace too small (%zu bytes)", workspace_bytes);
   float* partials = reinterpret_cast<float*>(workspace);
   hipLaunchKernelGGL(dist_weights_backward_kernel, dim3(nblk), dim3(256), lds, s, P, M, K, dim, points, joints, radius, kweight,
-      temperature, weights, indices, nn_dist, g_weights, g_points, partials);
+      temperature, weights, indices, nn_dist, g_weights, g_points, partials, activate);
   hipLaunchKernelGGL(dist_weights_finalize_kernel, dim3((M * V + 255) / 256), dim3(256), 0, s, M, dim, nblk, partials, g_joints,
-      g_radius, g_kweight);
+      g_radius, g_kweight, radius, kweight, activate, accumulate_joints);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -313,12 +313,12 @@ int launch_deform_backward(const skgs_deform_inputs& in, const float* g_means, c
 int launch_knn_bones(int P, int M, int K, int dim, const float* points, const float* joints, float* out_dist,
     int64_t* out_idx, hipStream_t s);
 int launch_knn_dist_weights_forward(int P, int M, int K, int dim, const float* points, const float* joints, const float* radius,
-    const float* kweight, float temperature, int64_t* out_idx, float* out_weights, float* out_dist, hipStream_t s);
+    const float* kweight, float temperature, int activate, int64_t* out_idx, float* out_weights, float* out_dist, hipStream_t s);
 size_t knn_dist_weights_workspace_bytes(int P, int M, int dim);
 int launch_knn_dist_weights_backward(int P, int M, int K, int dim, const float* points, const float* joints, const float* radius,
-    const float* kweight, float temperature, const float* weights, const int64_t* indices, const float* nn_dist,
-    const float* g_weights, float* g_points, float* g_joints, float* g_radius, float* g_kweight, void* workspace,
-    size_t workspace_bytes, hipStream_t s);
+    const float* kweight, float temperature, int activate, int accumulate_joints, const float* weights, const int64_t* indices,
+    const float* nn_dist, const float* g_weights, float* g_points, float* g_joints, float* g_radius, float* g_kweight,
+    void* workspace, size_t workspace_bytes, hipStream_t s);
 int launch_knn_lbs_weights(int P, int M, int K, const float* points, const float* joints, const float* sp_W, int64_t* out_idx,
     float* out_weights, hipStream_t s);
 int launch_knn_deform_forward(int P, int M, int K, const float* points, const float* joints, const float* sp_W,

@@ -113,8 +113,8 @@ class _KnnDistWeights(torch.autograd.Function):
             dist = torch.empty((P, K), dtype=torch.float32, device=dev)
             _C._check(lib.skgs_knn_dist_weights_forward(
                 C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(dim), C.c_void_p(_C._ptr(pts)), C.c_void_p(_C._ptr(jts)),
-                C.c_void_p(_C._ptr(rad)), C.c_void_p(_C._ptr(kw)), C.c_float(float(temperature)), C.c_void_p(_C._ptr(idx)),
-                C.c_void_p(_C._ptr(w)), C.c_void_p(_C._ptr(dist)), _C._stream()))
+                C.c_void_p(_C._ptr(rad)), C.c_void_p(_C._ptr(kw)), C.c_float(float(temperature)), C.c_int32(0),
+                C.c_void_p(_C._ptr(idx)), C.c_void_p(_C._ptr(w)), C.c_void_p(_C._ptr(dist)), _C._stream()))
         ctx.save_for_backward(pts, jts, rad, kw, w, idx, dist)
         ctx.temperature = float(temperature)
         ctx.mark_non_differentiable(idx)
@@ -140,7 +140,8 @@ class _KnnDistWeights(torch.autograd.Function):
             ws = torch.empty((max(nbytes, 16) + 3) // 4, dtype=torch.float32, device=dev)
             _C._check(lib.skgs_knn_dist_weights_backward(
                 C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(dim), C.c_void_p(_C._ptr(pts)), C.c_void_p(_C._ptr(jts)),
-                C.c_void_p(_C._ptr(rad)), C.c_void_p(_C._ptr(kw)), C.c_float(ctx.temperature), C.c_void_p(_C._ptr(w)),
+                C.c_void_p(_C._ptr(rad)), C.c_void_p(_C._ptr(kw)), C.c_float(ctx.temperature), C.c_int32(0), C.c_int32(0),
+                C.c_void_p(_C._ptr(w)),
                 C.c_void_p(_C._ptr(idx)), C.c_void_p(_C._ptr(dist)), C.c_void_p(_C._ptr(g_w)), C.c_void_p(_C._ptr(g_p)),
                 C.c_void_p(_C._ptr(g_j)), C.c_void_p(_C._ptr(g_r)), C.c_void_p(_C._ptr(g_k)), C.c_void_p(ws.data_ptr()),
                 C.c_size_t(ws.numel() * 4), _C._stream()))

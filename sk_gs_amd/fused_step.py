@@ -71,6 +71,11 @@ class FusedViewStep:
         lib.skgs_fused_lbs_max_bones.restype = C.c_int
         self.max_fused_bones = int(lib.skgs_fused_lbs_max_bones())
         self.wide = M > self.max_fused_bones or K > 8
+        # the weighting of calc_LBS_weight: `W` (logits per Gaussian) runs inside the one-launch skinning kernels; the three
+        # distance-based ones (sk_gs.py:757-766,770) as search + weighting in one launch, then the skinning
+        self.lbs_method = getattr(model, 'lbs_method', 'W')
+        assert self.lbs_method == 'W' or (cap is None and spw_logit_grad is None), \
+            'the distance-based LBS weightings run without a row capacity / compact-logit exchange'
         if K > 16 or K > M:
             raise _C.SkgsError(f'FusedViewStep: K = {K} neighbours: the KNN kernels keep at most 16 (and K <= M = {M})')
         # view-parallel training: instead of the [P,16,3] SH gradient of this view, write its two factors here ([P,6]:
@@ -123,6 +128,11 @@ class FusedViewStep:
         self.g_rotations, self.g_opacity = torch.empty((P, 4), **f32), torch.empty((P, 1), **f32)
         self.g_weights = torch.empty((P, K), **f32)
         self.g_bone_T = torch.empty((M, 7), **f32)
+        if self.lbs_method != 'W':
+            self.nn_dist = torch.empty((P, K), **f32)
+            lib.skgs_knn_dist_weights_workspace_bytes.restype = C.c_size_t
+            self.dist_ws = torch.empty((max(int(lib.skgs_knn_dist_weights_workspace_bytes(C.c_int32(P), C.c_int32(M), C.c_int32(3))),
+                                            16),), **u8)
         self.deform_ws = torch.empty((lib.skgs_lbs_deform_backward_workspace_bytes(C.c_int32(P), C.c_int32(M)),), **u8)
         self.bwd_ws = torch.zeros((lib.skgs_backward_workspace_bytes(C.c_int32(P)),), **u8)  # kept zero between steps
         # the optimizer clears the per-frame table gradients after its update (FusedAdam(zero_after_step=
@@ -316,6 +326,17 @@ class FusedViewStep:
                 _p(self.chain_A), fidx, st))
         d = self._deform_inputs(time_id)
         assert not (self.wide and self._live is not None), 'row capacity: the one-launch skinning path (M <= 60, K <= 8)'
+        if self.lbs_method != 'W':  # K nearest bones + kernel / dist weighting (raw radius / weight parameters: the kernel
+            chk(lib.skgs_knn_dist_weights_forward(  # applies exp / sigmoid itself), then the skinning
+                C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(3), C.c_void_p(d.points), _p(m.joints),
+                _p(m._sp_radius), _p(m._sp_weight), C.c_float(m.lbs_temperature), C.c_int32(1), _p(self.indices),
+                _p(self.weights), _p(self.nn_dist), st))
+            chk(lib.skgs_lbs_deform_forward(C.byref(d), _p(self.means), _p(self.scales), _p(self.rotations), _p(self.opacity),
+                                            None, None, None, st))
+            a = self._raster_inputs(rs)
+            chk(lib.skgs_rasterize_forward(C.byref(a), C.byref(self._bufs), _p(self.radii), _p(self.image),
+                                           _p(self.out_opacity), None, None, st))
+            return a, d
         if self.wide:  # many bones: search + softmax, then the skinning, as two launches (bone tables stay in global memory)
             chk(lib.skgs_knn_lbs_weights(C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_void_p(d.points), _p(m.joints),
                                          _p(m.sp_W), _p(self.indices), _p(self.weights), st))
@@ -413,7 +434,13 @@ class FusedViewStep:
             g_drot, g_dscale = m.sk_d_rot.grad[time_id], m.sk_d_scale.grad[time_id]
         else:  # the three heads of the producer network: their gradients feed its backward below
             sk_r_raw, (g_raw, g_drot, g_dscale) = self._sk_r_raw, self._g_heads
-        if not self.wide:
+        if self.lbs_method != 'W':
+            chk(lib.skgs_lbs_deform_backward(
+                C.byref(d), _p(self.g_means), _p(self.g_scales), _p(self.g_rotations), _p(self.g_opacity),
+                _p(self.g_weights), _p(self.g_bone_T), _p(g_drot), _p(g_dscale),
+                _p(m._xyz.grad), _p(m._scaling.grad), _p(m._rotation.grad), _p(m._opacity.grad), _p(self.deform_ws),
+                C.c_size_t(self.deform_ws.numel()), st))
+        elif not self.wide:
             # skinning backward with the softmax backward of the LBS logits folded in: dense rows straight into sp_W.grad,
             # or the compact [P,K] gradient for the all-reduce
             dense = self.spw_logit_grad is None
@@ -438,6 +465,16 @@ class FusedViewStep:
                 C.c_void_p(g_gT), fidx, st))
         if self.deform_net is not None:
             self._deform_net_backward()
+        if self.lbs_method != 'W':
+            # weights -> distances -> joints / radii / kernel weights.  AFTER the chain backward, which WRITES joints.grad:
+            # this adds to it (the optimizer's closing launch adds the network-input part the same way)
+            learn = getattr(m, 'learn_joints', False)
+            chk(lib.skgs_knn_dist_weights_backward(
+                C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(3), C.c_void_p(d.points), _p(m.joints), _p(m._sp_radius),
+                _p(m._sp_weight), C.c_float(m.lbs_temperature), C.c_int32(1), C.c_int32(1), _p(self.weights), _p(self.indices),
+                _p(self.nn_dist), _p(self.g_weights), None, _p(m.joints.grad) if learn else None,
+                None if m._sp_radius is None else _p(m._sp_radius.grad), None if m._sp_weight is None else _p(m._sp_weight.grad),
+                _p(self.dist_ws), C.c_size_t(self.dist_ws.numel()), st))
         # (densify_stats: folded into the rasterizer backward's per-Gaussian launch, see backward_raster)
 
     def _lbs_logits_backward(self):

@@ -11,6 +11,8 @@ Used by tests, bench.py and smoke(); it is NOT a re-implementation of the refere
 """
 from typing import Dict, Optional
 
+import math
+
 import torch
 from torch import Tensor, nn
 import torch.nn.functional as F
@@ -22,7 +24,8 @@ from sk_gs_amd.renderer.gaussian_render import GaussianRasterizationSettings, re
 
 class SkinnedGaussians(nn.Module):
     def __init__(self, P: int, M: int, K: int = 5, sh_degree: int = 3, num_frames: int = 8, seed: int = 0,
-                 scale_mult: float = 1.0, deform_net: bool = False, learn_joints: bool = False):
+                 scale_mult: float = 1.0, deform_net: bool = False, learn_joints: bool = False, lbs_method: str = 'W',
+                 lbs_temperature: float = 1.0):
         super().__init__()
         g = scene.make_gaussians(P, seed=seed, sh_degree=sh_degree, scale_mult=scale_mult)
         b = scene.make_bones(max(M, 1), seed=seed)
@@ -37,7 +40,17 @@ class SkinnedGaussians(nn.Module):
         self._rotation = nn.Parameter(g['rot'])
         self._opacity = nn.Parameter(g['opacity_logit'])
         gen = torch.Generator().manual_seed(3000 + seed)
-        self.sp_W = nn.Parameter(torch.randn(P, max(M, 1), generator=gen))
+        # the four weightings of calc_LBS_weight (sk_gs.py:464-475,751-774): `W` = per-Gaussian logits over the bones (yaml
+        # default, exps/default.yaml:35), `weighted_kernel` (class default; exps/d_nerf_sc_gs.yaml:31) / `kernel` = a radial
+        # kernel per bone with learnt radius exp(_sp_radius) (and weight sigmoid(_sp_weight)), `dist` = softmax(-d / T)
+        assert lbs_method in ('W', 'dist', 'kernel', 'weighted_kernel')
+        self.lbs_method, self.lbs_temperature = lbs_method, float(lbs_temperature)
+        self.sp_W = nn.Parameter(torch.randn(P, max(M, 1), generator=gen)) if lbs_method == 'W' else None
+        self._sp_radius = self._sp_weight = None
+        if lbs_method in ('kernel', 'weighted_kernel'):  # init_superpoints: log(0.1 * scene range + 1e-7) (sk_gs.py:698-701)
+            self._sp_radius = nn.Parameter(torch.full((max(M, 1),), math.log(0.1 * 2.6 + 1e-7)))
+        if lbs_method == 'weighted_kernel':
+            self._sp_weight = nn.Parameter(torch.zeros(max(M, 1)))
         # stage sk trains the joint positions at 0.1 x the base rate (sk_gs.py:379,607): through the kinematic chain and,
         # with the deform network, through the network's input
         self.learn_joints = bool(learn_joints) and M > 0
@@ -101,7 +114,12 @@ class SkinnedGaussians(nn.Module):
             {'params': [self._rotation], 'lr': lr * 1.0, 'name': 'rotation'},
         ]
         if not self.static:
-            groups.append({'params': [self.sp_W], 'lr': lr, 'name': 'sp_W'})  # per Gaussian: pruned / extended with them
+            if self.sp_W is not None:
+                groups.append({'params': [self.sp_W], 'lr': lr, 'name': 'sp_W'})  # per Gaussian: pruned / extended with them
+            if self._sp_radius is not None:  # (sk_gs.py:590-593)
+                groups.append({'params': [self._sp_radius], 'lr': lr, 'name': 'sp_radius'})
+            if self._sp_weight is not None:
+                groups.append({'params': [self._sp_weight], 'lr': lr, 'name': 'sp_weight'})
             if self.sk_deform_net is None:
                 groups.append({'params': [self.sk_r, self.sk_d_rot, self.sk_d_scale, self.global_tr],
                                'lr': lr, 'name': 'skinning'})
@@ -161,7 +179,11 @@ class SkinnedGaussians(nn.Module):
                         rotations=F.normalize(self._rotation, dim=-1), sh_features=sh_features)
         points = self._xyz.detach()
         sk_T, sk_d_rot, sk_d_scale = self.bone_transforms(time_id)
-        weights, indices = calc_lbs_weight(points, self.joints, self.K, sp_W=self.sp_W)
+        weights, indices = calc_lbs_weight(
+            points, self.joints, self.K, sp_W=self.sp_W,
+            kernel_radius=None if self._sp_radius is None else torch.exp(self._sp_radius),
+            kernel_weight=None if self._sp_weight is None else torch.sigmoid(self._sp_weight),
+            temperature=self.lbs_temperature)
         means, scales, rotations, opacity = lbs_deform(points, weights, indices, sk_T, sk_d_rot, sk_d_scale,
                                                        self._xyz, self._scaling, self._rotation, self._opacity)
         return dict(points=means, opacity=opacity, scales=scales, rotations=rotations, sh_features=sh_features)

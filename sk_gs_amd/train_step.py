@@ -124,7 +124,10 @@ class FusedTrainStep:
         self.rows = [n for n in names if n in self.ROW_GROUPS]
         self.rest = [n for n in names if n not in self.ROW_GROUPS]
         # (rows rebuilt after the backward -- compact logit gradient, SH factors -- are final only when update() starts)
+        # (distance-based LBS weightings: their backward re-reads xyz AFTER the skeleton backward launch, which must therefore
+        # not carry the rows' update -- the plain sequence forward_backward(); optimizer.step() serves them)
         self.fused = bool(enable and self.rows and self.rest and getattr(step, '_mlp_fused', None) is not None
+                          and getattr(step, 'lbs_method', 'W') == 'W'
                           and (reduce_between or (step.spw_logit_grad is None and step.sh_factors is None))
                           and len(optimizer._chunk_ranges(self.rows)) == 1 and len(optimizer._chunk_ranges(self.rest)) == 1)
         self.set_pre_forward(pre_forward)

@@ -576,3 +576,53 @@ def test_training_steps_refresh_the_frames_row_of_sk_cache():
     q, dr, ds = model.cached_joint_outputs(mid)
     blend = 0.5 * (model.sk_cache[1] + model.sk_cache[2])
     assert rel_err(dr, blend[:, 4:8]) <= 1e-5 and rel_err(q, F.normalize(blend[:, :4], dim=-1)) <= 1e-5
+
+
+@pytest.mark.parametrize('method', ['weighted_kernel', 'kernel', 'dist'])
+def test_fused_step_with_the_distance_based_lbs_weightings_matches_autograd(method):
+    """the other three branches of calc_LBS_weight (sk_gs.py:757-766,770; `weighted_kernel` is the class default,
+    exps/d_nerf_sc_gs.yaml:31) inside the fused step: search + weighting in one launch on the RAW `_sp_radius` /
+    `_sp_weight` parameters, its backward behind the chain backward (adds to joints.grad) -- against the operator path
+    (torch.exp / torch.sigmoid + the autograd Function of the same kernels), every gradient"""
+    from sk_gs_amd import _C, scene
+    from sk_gs_amd.fused_step import FusedViewStep
+    from sk_gs_amd.losses import image_loss
+    from sk_gs_amd.model import SkinnedGaussians
+    from sk_gs_amd.optim import FusedAdam
+    from sk_gs_amd.train_step import FusedTrainStep
+    P, M, K, W, H, frames, tid = 5000, 16, 5, 128, 96, 3, 1
+    dev = torch.device('cuda')
+    model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=7, scale_mult=2.0, deform_net=True,
+                             learn_joints=True, lbs_method=method, lbs_temperature=0.7).to(dev)
+    assert model.sp_W is None and (model._sp_radius is not None) == (method != 'dist')
+    with torch.no_grad():
+        if model._sp_radius is not None:
+            model._sp_radius.add_(0.3 * torch.randn(M, generator=torch.Generator().manual_seed(1)).to(dev))
+        if model._sp_weight is not None:
+            model._sp_weight.add_(torch.randn(M, generator=torch.Generator().manual_seed(2)).to(dev))
+    rs = scene.raster_settings_from_camera(scene.make_camera(W, H, seed=3), sh_degree=3, colmap=True, device=dev)
+    target = torch.rand(3, H, W, generator=torch.Generator().manual_seed(5)).to(dev)
+    _C.config.sync_num_rendered = True
+    out = model.render(rs, time_id=tid)
+    image_loss(out['images'], target).backward()
+    ref = {n: p.grad.clone() for n, p in model.named_parameters()}
+    assert all(float(ref[n].abs().max()) > 0 for n in ref if n in ('_sp_radius', '_sp_weight', 'joints'))
+    for p in model.parameters():
+        p.grad = torch.full_like(p, 3.0)
+    step = FusedViewStep(model, W, H, capacity=int(out['buffer'].R * 1.2) + 1024)
+    step.forward_backward(rs, tid, target)
+    assert rel_err(step.image, out['images'].detach()) <= 5e-6 and step.status()['mlp_failed'] == 0
+    for n, p in model.named_parameters():
+        if p.numel() >= 10000:
+            assert_close_robust(p.grad, ref[n], 2e-4, name=f'{method} {n}')
+        else:
+            assert rel_err(p.grad, ref[n]) <= 1e-3, (method, n, rel_err(p.grad, ref[n]))
+    # the plain sequence trains (the rows' update does not ride on the skeleton backward here)
+    opt = FusedAdam(model.param_groups(lr=1e-3), eps=1e-15)
+    train = FusedTrainStep(step, opt)
+    assert not train.fused
+    before = model.joints.detach().clone(), (model._sp_radius if model._sp_radius is not None else model._xyz).detach().clone()
+    train(rs, tid, target)
+    torch.cuda.synchronize()
+    assert not torch.equal(before[0], model.joints)
+    assert not torch.equal(before[1], model._sp_radius if model._sp_radius is not None else model._xyz)
