@@ -28,6 +28,10 @@ for c in 2 3 4; do
 done
 SKGS_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29542 bench.py --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline --no-ms-per-render --pre-forward off 2>/dev/null | tail -1 > $out/bench_rccl_1rank_pre-forward-off.json
 python -c "import json; d=json.load(open('$out/bench_rccl_1rank_pre-forward-off.json')); print('1-rank RCCL group --pre-forward off', d['value'], d['ms_per_step'])"
+for c in 1 3; do
+  python bench.py --config $c --steps 400 --warmup 50 --no-cpu-baseline --no-ms-per-render --densify-every 100 2>/dev/null | tail -1 > $out/bench_config${c}_densify-every-100.json
+  python -c "import json; d=json.load(open('$out/bench_config${c}_densify-every-100.json')); print('config $c --densify-every 100', d['value'], d['ms_per_step'], d['densify']['ms'], d['densify']['P'], 'graphs', d['densify']['graphs_captured'])"
+done
 python tools/time_skeleton.py 2>/dev/null | grep -v "^$" > $out/time_skeleton.txt; tail -4 $out/time_skeleton.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_issue_rate tools/micro/valu_issue_rate.hip 2>/dev/null && /tmp/valu_issue_rate > $out/valu_issue_rate.txt 2>&1; /tmp/valu_issue_rate >> $out/valu_issue_rate.txt 2>&1; tail -20 $out/valu_issue_rate.txt
 python tools/time_mlp.py 2>/dev/null | grep "fused\|backward\|prologue" > $out/time_mlp.txt; cat $out/time_mlp.txt
