@@ -88,15 +88,6 @@ __device__ __forceinline__ AdamTensor adam_descriptor_of(const AdamTensorLanes& 
   return T;
 }
 
-// An element whose gradient is zero and whose two moments are still zero stays exactly as it is (m = v = 0, the update is
-// lr * 0 / (0 + eps) = 0): its three stores are skipped.  Bit-identical to writing the same values back, and not rare: of a
-// Gaussian's M LBS logits only its K nearest bones' ever receive a gradient (15 of 20 at config #1: a fifth of the
-// optimizer's elements), and a Gaussian no view has seen yet is idle in every tensor -- 12 of 28 bytes less for them.
-__device__ __forceinline__ bool adam_idle(const float4& g, const float4& m, const float4& v) {
-  return (g.x == 0.f) & (g.y == 0.f) & (g.z == 0.f) & (g.w == 0.f) & (m.x == 0.f) & (m.y == 0.f) & (m.z == 0.f) & (m.w == 0.f) &
-         (v.x == 0.f) & (v.y == 0.f) & (v.z == 0.f) & (v.w == 0.f);
-}
-
 __device__ __forceinline__ void adam_update_element(float& p, float& m, float& v, float g, float step_size, const AdamCoef& k) {
   m = k.beta1 * m + k.omb1 * g;
   v = k.beta2 * v + k.omb2 * g * g;
@@ -116,7 +107,6 @@ __device__ __forceinline__ void adam_update_chunk(const AdamTensor& T, int64_t b
       float4 m = *reinterpret_cast<float4*>(T.exp_avg + i);
       float4 v = *reinterpret_cast<float4*>(T.exp_avg_sq + i);
       float4 p = *reinterpret_cast<float4*>(T.param + i);
-      if (adam_idle(g, m, v)) continue;
       adam_update_element(p.x, m.x, v.x, g.x, step_size, k);
       adam_update_element(p.y, m.y, v.y, g.y, step_size, k);
       adam_update_element(p.z, m.z, v.z, g.z, step_size, k);
@@ -168,7 +158,6 @@ __device__ __forceinline__ void adam_update_chunk2(const AdamTensor& A, int64_t 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t i = base + ((int64_t) r * ADAM_THREADS + t256) * 4;
-      if (adam_idle(g[c][r], m[c][r], v[c][r])) continue;
       adam_update_element(p[c][r].x, m[c][r].x, v[c][r].x, g[c][r].x, ss, k);
       adam_update_element(p[c][r].y, m[c][r].y, v[c][r].y, g[c][r].y, ss, k);
       adam_update_element(p[c][r].z, m[c][r].z, v[c][r].z, g[c][r].z, ss, k);
