@@ -884,31 +884,19 @@ def main():
         for k_, v_ in variants[args.exchange].items():
             setattr(args, k_, v_)
     if world > 1 and not explicit and not args.autograd and not args.torch_adam:
+        import threading
         lines, errors = {}, {}
-        for name, flags in variants.items():
-            a = copy.copy(args)
-            for k_, v_ in flags.items():
-                setattr(a, k_, v_)
-            a.ms_per_render, a.no_cpu_baseline = False, True
-            try:
-                lines[name] = run_workload(a)
-            except Exception as e:  # noqa  (a variant that cannot run here must not cost the record)
-                errors[name] = f'{type(e).__name__}: {e}'[:300]
-                lines[name] = None
-            # every rank must agree on whether the variant ran (an exception on one rank only would desynchronise the next)
-            ok = torch.tensor([0 if name in errors else 1], dtype=torch.int32, device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0 and name not in errors:
-                errors[name], lines[name] = 'failed on another rank', None
-            gc.collect()
-            torch.cuda.empty_cache()
-            dist.barrier()
-        if rank == 0:
+
+        def emit(aborted=None):
+            """rank 0: the fastest variant whose replicas stayed identical, all of them under `exchange_variants`"""
+            if rank != 0:
+                return
             summary = {}
             for name in variants:
                 ln = lines.get(name)
                 if ln is None:
-                    summary[name] = dict(error=errors.get(name, 'no result'))
+                    summary[name] = dict(error=errors.get(name, 'abandoned: it did not finish in time' if name == aborted
+                                                          else 'not run'))
                 else:
                     summary[name] = dict(value=ln['value'], ms_per_step=ln['ms_per_step'],
                                          ms_per_step_blocks=ln.get('ms_per_step_blocks'),
@@ -922,6 +910,55 @@ def main():
             line['config']['exchange'] = best
             line['exchange_variants'] = summary
             os.write(json_fd, (json.dumps(line) + '\n').encode())
+
+        def bail(name):
+            # a later variant hangs (a collective that never completes on this fabric) or dies: the record must not die with
+            # it.  Every rank's own timer ends its process; rank 0 first prints what the finished variants measured.
+            try:
+                emit(aborted=name)
+            finally:
+                os._exit(0)
+
+        t_first = None
+        for name, flags in variants.items():
+            a = copy.copy(args)
+            for k_, v_ in flags.items():
+                setattr(a, k_, v_)
+            a.ms_per_render, a.no_cpu_baseline = False, True
+            have_one = any(v is not None for v in lines.values())
+            timer = None
+            if have_one:  # (the first variant -- the plain all-reduce -- runs unguarded: without it there is no record)
+                timer = threading.Timer(max(240.0, 8.0 * (t_first or 30.0)), bail, args=(name,))
+                timer.daemon = True
+                timer.start()
+            t_v = time.perf_counter()
+            try:
+                try:
+                    lines[name] = run_workload(a)
+                except Exception as e:  # noqa  (a variant that cannot run here must not cost the record)
+                    errors[name] = f'{type(e).__name__}: {e}'[:300]
+                    lines[name] = None
+                # every rank must agree on whether the variant ran (an exception on one rank only would desynchronise the next)
+                ok = torch.tensor([0 if name in errors else 1], dtype=torch.int32, device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0 and name not in errors:
+                    errors[name], lines[name] = 'failed on another rank', None
+                gc.collect()
+                torch.cuda.empty_cache()
+                dist.barrier()
+            except Exception as e:  # noqa  (the process group itself is broken: report what is there and stop)
+                errors.setdefault(name, f'{type(e).__name__}: {e}'[:300])
+                if timer is not None:
+                    timer.cancel()
+                if any(v is not None for v in lines.values()):
+                    bail(name)
+                raise
+            finally:
+                if timer is not None:
+                    timer.cancel()
+            if t_first is None:
+                t_first = time.perf_counter() - t_v
+        emit()
     else:
         line = run_workload(args)
         if rank == 0:
