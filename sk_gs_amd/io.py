@@ -143,3 +143,7 @@ def load_gaussians_state_dict(module: nn.Module, state: Mapping[str, Tensor]):
         setattr(module, k, nn.Parameter(state[k].detach().to(device=ref.device, dtype=torch.float32).contiguous().clone()))
     if hasattr(module, 'P'):
         module.P = P
+    if getattr(module, 'capacity', None) is not None:
+        # the new parameters are plain tensors: the row capacity (sk_gs_amd/capacity.py) no longer describes them.  Re-home
+        # with module.enable_capacity(...) before rebuilding gradient buffers / optimizer / step
+        module.capacity = None
