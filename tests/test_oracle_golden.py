@@ -4,6 +4,8 @@ import inspect
 import json
 import os
 
+import math
+
 import numpy as np
 import torch
 
@@ -23,6 +25,38 @@ def test_sh_basis_matches_reference_eval_sh(oracle32):
         want = g[f'deg{deg}'] + 0.5
         np.testing.assert_allclose(rgb, np.maximum(want, 0), rtol=0, atol=2e-6)
         np.testing.assert_array_equal(clamped.astype(bool), want < 0)
+
+
+def test_sh_basis_is_the_real_spherical_harmonics_of_scipy(oracle64):
+    """independent pin of row a-6 (computeColorFromSH, gaussian_rasterizer_forward.cu:97-137; constants gaussian_render.h:
+    35-40) by the reference's own test strategy -- its `test_SH` checks its harmonics against scipy to 1e-6
+    (my_ext/ops_3d/spherical_harmonics.py:370-416): coefficient l^2 + l + m of the rasterizer's basis is the real spherical
+    harmonic Y_lm WITH the Condon-Shortley phase -- sqrt(2) Im Y_l^|m| for m < 0, Y_l^0, sqrt(2) Re Y_l^m for m > 0 -- which
+    is where the signs -C1 y, +C1 z, -C1 x come from"""
+    import warnings
+    from scipy import special
+    o = oracle64
+    rng = np.random.RandomState(0)
+    d = rng.randn(200, 3)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    theta, phi = np.arccos(d[:, 2]), np.arctan2(d[:, 1], d[:, 0])
+    sph = getattr(special, 'sph_harm_y', None)
+    for l in range(4):
+        for m in range(-l, l + 1):
+            sh = np.zeros((len(d), 16, 3))
+            sh[:, l * l + l + m, :] = 0.1  # small: 0.1 Y + 0.5 stays clear of the clamp at 0
+            rgb, clamped = o.sh_array(3, d, np.zeros(3), sh)
+            basis = (rgb[:, 0] - 0.5) / 0.1
+            if sph is not None:
+                Y = sph(l, abs(m), theta, phi)
+            else:
+                with warnings.catch_warnings():
+                    warnings.simplefilter('ignore')
+                    Y = special.sph_harm(abs(m), l, phi, theta)
+            want = Y.real if m == 0 else (math.sqrt(2) * Y.imag if m < 0 else math.sqrt(2) * Y.real)
+            assert np.abs(basis - want).max() < 1e-6, (l, m)  # (the kernel's constants are float literals: 3e-8)
+            assert not clamped.any()
+            assert np.array_equal(rgb[:, 0], rgb[:, 1]) and np.array_equal(rgb[:, 0], rgb[:, 2])
 
 
 def test_quaternion_conventions(oracle64):
