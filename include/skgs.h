@@ -96,9 +96,6 @@ typedef struct skgs_raster_inputs {
   int32_t longest_list_hint;  /* stage 2 / forward: 0 = unknown; > 0 = an upper bound of the longest tile list (what stage 1
                               just reported): the sort launches for longer lists, which would find nothing to do, are
                               skipped (~4.5 us each) */
-  int32_t fused_binning;      /* bucket layout only: the preprocess launch's workgroups also reserve the slots and emit the
-                               * keys of their Gaussians (no scatter launch).  The caller GUARANTEES the per-tile cursors of
-                               * the img buffer zero on entry (zero the buffer once); every forward leaves them zero */
   const int32_t* live_count;  /* NULL, or a DEVICE int32 n <= P: only Gaussians 0..n-1 exist.  P is then the CAPACITY the
                                * launches are sized for; rows n..P-1 get radius 0 and an all-zero record (what a culled
                                * Gaussian gets) and no gradient is written for them.  Densification (clone / split / prune,

@@ -40,8 +40,7 @@ class _RasterInputs(C.Structure):
         ('rotations', C.c_void_p), ('extras', C.c_void_p), ('colors_precomp', C.c_void_p),
         ('cov3D_precomp', C.c_void_p), ('sh_rest', C.c_void_p), ('background', C.c_void_p),
         ('tile_bucket_capacity', C.c_int32), ('tanfov_device', C.c_void_p),
-        ('host_status_words', C.c_int32), ('longest_list_hint', C.c_int32), ('fused_binning', C.c_int32),
-        ('live_count', C.c_void_p),
+        ('host_status_words', C.c_int32), ('longest_list_hint', C.c_int32), ('live_count', C.c_void_p),
     ]
 
 

@@ -174,7 +174,7 @@ int skgs_rasterize_forward(const skgs_raster_inputs* in, const skgs_raster_buffe
     SKGS_REQUIRE(b.capacity >= (int64_t) im.T * in->tile_bucket_capacity,
         "binning buffer too small for tiles x tile_bucket_capacity instances");
     SKGS_REQUIRE((int64_t) im.T * in->tile_bucket_capacity < (int64_t) 1 << 32, "tiles x tile_bucket_capacity must fit 32 bits");
-    if (launch_preprocess_forward(*in, g, im, radii, s, &b)) return 1;
+    if (launch_preprocess_forward(*in, g, im, radii, s)) return 1;
     if (launch_scatter_sort(*in, g, im, b, s)) return 1;
     return launch_render_forward(*in, g, im, b, out_color, out_opacity, out_extra, s);
   }

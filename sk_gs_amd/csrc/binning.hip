@@ -606,7 +606,7 @@ int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, Bi
   const int P = in.P;
   if (P == 0) return 0;
   const int bucket = in.tile_bucket_capacity > 0 ? in.tile_bucket_capacity : 0;
-  if (!fused_binning(in, im.T)) {  // (fused: the preprocess launch reserved the slots and emitted the keys itself)
+  {
     ProfScope prof(K_SCATTER, s);
     const int64_t lanes = (int64_t) P * LPG;
     if (im.T <= BIN_LDS_TILES)

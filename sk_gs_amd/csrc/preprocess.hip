@@ -288,12 +288,7 @@ __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, const fl
   for (int e = 4 * n4 + threadIdx.x; e < n; e += PRE_THREADS) dst[e] = s_src[stage_lds_index(e, RL, pitch)];
 }
 
-// FUSED_BIN (bucket layout, skgs_raster_inputs.fused_binning): the workgroup also does what the scatter launch does for its
-// 256 Gaussians -- count their (Gaussian, tile) pairs per tile in LDS, reserve the slots with ONE returning global atomic
-// per touched tile, emit the keys -- in the LDS its SH rows no longer need.  The per-tile cursors are NOT cleared here (a
-// workgroup would clear what another has already added to): the caller guarantees them zero on entry, the blend forward
-// zeroes them again for the next forward.
-template <bool COLMAP, bool FUSED_BIN>
+template <bool COLMAP>
 __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, int D, int M, const float* __restrict__ means3D,
     const float* __restrict__ scales, float scale_modifier, const float* __restrict__ rotations,
     const float* __restrict__ opacities, const float* __restrict__ shs, const float* __restrict__ shs_rest,
@@ -303,8 +298,7 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
     int gx, int gy, int32_t* __restrict__ radii, float4* __restrict__ recs, uint32_t* __restrict__ tile_counts,
     GeomHeader* hdr_bucket /* bucket layout: tile_counts are the per-tile cursors and the status words start here */,
     const float* __restrict__ tanfov_dev /* NULL, or {tanfovx, tanfovy} read here instead of the launch arguments */,
-    const int32_t* __restrict__ live /* NULL, or the live Gaussian count (<= P, the capacity the grid was sized for) */,
-    uint64_t* __restrict__ keys /* FUSED_BIN: the binning buffer's keys */, int bucket /* FUSED_BIN: slots per tile */) {
+    const int32_t* __restrict__ live /* NULL, or the live Gaussian count (<= P, the capacity the grid was sized for) */) {
   // the number of Gaussians as a device word (one captured graph survives densification): rows [live, P) of the capacity
   // get an all-zero record and radius 0 -- what a culled Gaussian gets -- so nothing downstream needs to know
   const int P_cap = P;
@@ -322,8 +316,7 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
   __syncthreads();
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   // the per-tile counters of the next kernel (binning.hip: count_tiles) start from zero: cleared here, not by a fill launch
-  if constexpr (!FUSED_BIN)
-    for (int t = idx; t < gx * gy; t += gridDim.x * blockDim.x) tile_counts[t] = 0u;
+  for (int t = idx; t < gx * gy; t += gridDim.x * blockDim.x) tile_counts[t] = 0u;
   if (hdr_bucket && idx == 0) {  // no scan kernel in the bucket layout: R and the longest list are not computed
     hdr_bucket->num_rendered = -1, hdr_bucket->max_tile_count = -1, hdr_bucket->overflow = 0, hdr_bucket->big_tiles = 0;
   }
@@ -353,32 +346,28 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
     }
     __syncthreads();
   }
-  const bool exists = idx < P;  // (lanes behind the last Gaussian: no record of their own, but FUSED_BIN's barriers need them)
-  if (!exists) {
+  if (idx >= P) {
     if (idx < P_cap) {
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       radii[idx] = 0;
       recs[3 * idx + 0] = z, recs[3 * idx + 1] = z, recs[3 * idx + 2] = z;
     }
-    if constexpr (!FUSED_BIN) return;
+    return;
   }
 
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;  // culled Gaussians get an all-zero record
   int radius = 0;
   uint32_t clamp_bits = 0;
   int mn[2] = {0, 0}, mx[2] = {0, 0};
-  const int ld = exists ? idx : 0;  // (a valid row to read for the lanes that do not exist)
-  const float p[3] = {means3D[3 * ld], means3D[3 * ld + 1], means3D[3 * ld + 2]};
-  float pv[3] = {0.f, 0.f, 0.f}, ph[4];
-  bool ok = false;
-  if (exists) {
-    if (COLMAP) {
-      xf3_cm(p, cam.view, pv);
-      ok = !(pv[2] <= 0.2f);
-    } else {
-      xf3_rm(p, cam.view, pv);
-      ok = !(pv[2] <= -1.0f);
-    }
+  const float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+  float pv[3], ph[4];
+  bool ok;
+  if (COLMAP) {
+    xf3_cm(p, cam.view, pv);
+    ok = !(pv[2] <= 0.2f);
+  } else {
+    xf3_rm(p, cam.view, pv);
+    ok = !(pv[2] <= -1.0f);
   }
   if (ok) {
     if (COLMAP)
@@ -439,62 +428,11 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
       }
     }
   }
-  if (exists) {
-    radii[idx]        = radius;
-    recs[3 * idx + 0] = r0;
-    recs[3 * idx + 1] = r1;
-    recs[3 * idx + 2] = r2;
-  }
+  radii[idx]        = radius;
+  recs[3 * idx + 0] = r0;
+  recs[3 * idx + 1] = r1;
+  recs[3 * idx + 2] = r2;
   // (per-tile instance counts are accumulated by binning.hip::count_tiles_kernel, 16 lanes per Gaussian)
-  if constexpr (FUSED_BIN) {
-    // ---- the scatter launch's three phases (binning.hip::scatter_lds_kernel) for this workgroup's Gaussians
-    constexpr int LPG = 16;  // lanes per Gaussian of the tile walks: a splat covers ~5 tiles, a few cover hundreds
-    const int T       = gx * gy;
-    __syncthreads();  // every lane is done with its SH rows: the LDS is free
-    uint32_t* s_cnt  = reinterpret_cast<uint32_t*>(s_sh);      // [T] pairs of this workgroup per tile, then the running rank
-    uint32_t* s_base = s_cnt + T;                              // [T] first slot reserved for this workgroup
-    int4* s_rect     = reinterpret_cast<int4*>(s_cnt + ((2 * T + 3) & ~3));  // [PRE_THREADS] {mn.x | mn.y << 16, width, pairs, depth bits}
-    for (int i = threadIdx.x; i < T; i += PRE_THREADS) s_cnt[i] = 0u;
-    const int rw = mx[0] - mn[0], rn = radius > 0 ? rw * (mx[1] - mn[1]) : 0;
-    s_rect[threadIdx.x] = make_int4(mn[0] | (mn[1] << 16), rw, rn, (int) __float_as_uint(pv[2]));
-    __syncthreads();
-    for (int q = threadIdx.x; q < PRE_THREADS * LPG; q += PRE_THREADS) {
-      const int4 rc = s_rect[q / LPG];
-      const int x0 = rc.x & 0xffff, y0 = rc.x >> 16;
-      for (int k = q % LPG; k < rc.z; k += LPG) atomicAdd(&s_cnt[(y0 + k / rc.y) * gx + x0 + k % rc.y], 1u);
-    }
-    __syncthreads();
-    // slot reservation: one returning global atomic per touched tile, four tiles per lane and round in flight together
-    for (int i0 = threadIdx.x; i0 < T; i0 += 4 * PRE_THREADS) {
-      uint32_t c[4], r[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * PRE_THREADS;
-        c[u] = i < T ? s_cnt[i] : 0u;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) r[u] = c[u] ? atomicAdd(&tile_counts[i0 + u * PRE_THREADS], c[u]) : 0u;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * PRE_THREADS;
-        if (i < T) s_base[i] = r[u], s_cnt[i] = 0u;
-      }
-    }
-    __syncthreads();
-    const int base0 = blockIdx.x * PRE_THREADS;
-    for (int q = threadIdx.x; q < PRE_THREADS * LPG; q += PRE_THREADS) {
-      const int gl = q / LPG;
-      const int4 rc = s_rect[gl];
-      if (rc.z <= 0) continue;
-      const int x0 = rc.x & 0xffff, y0 = rc.x >> 16;
-      const uint64_t key = ((uint64_t) (uint32_t) rc.w << 32) | (uint32_t) (base0 + gl);  // depth bits << 32 | Gaussian id
-      for (int k = q % LPG; k < rc.z; k += LPG) {
-        const int t        = (y0 + k / rc.y) * gx + x0 + k % rc.y;
-        const uint32_t pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
-        if (pos < (uint32_t) bucket) keys[(size_t) t * bucket + pos] = key;  // beyond the bucket: dropped (the sort flags it)
-      }
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -1009,41 +947,32 @@ __global__ void mark_visible_kernel(int P, const float* means, const float* view
 
 }  // namespace
 
-int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, int32_t* radii, hipStream_t s,
-    const BinView* bins) {
+int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, int32_t* radii, hipStream_t s) {
   const int P = in.P;
   const float focal_y = in.image_height / (2.0f * in.tanfovy);
   const float focal_x = in.image_width / (2.0f * in.tanfovx);
   if (P == 0) return fill_u32(im.tile_counts, 0u, (size_t) im.T, s) || fill_u32(im.cursors, 0u, (size_t) im.T, s);
   ProfScope prof(K_PREPROCESS_FWD, s);
   const bool bucket = in.tile_bucket_capacity > 0;
-  const bool fused  = bins != nullptr && fused_binning(in, im.T);
   dim3 grid((P + PRE_THREADS - 1) / PRE_THREADS), block(PRE_THREADS);
-  static_assert(PRE_THREADS == FUSED_BIN_THREADS, "fused binning lays its LDS out for the preprocess workgroup");
   size_t lds = 0;
   if (in.sh && !in.colors_precomp) {
     const int M = in.sh_coeffs;
     lds = in.sh_rest ? ((size_t) PRE_THREADS * (((M - 1) * 3) | 1) + (size_t) PRE_THREADS * 3) * 4
                      : (size_t) PRE_THREADS * ((M * 3) | 1) * 4;
   }
-  if (fused) lds = std::max(lds, fused_binning_lds_bytes(im.T));
-#define SKGS_PF_ARGS                                                                                                       \
-  P, in.sh_degree, in.sh_coeffs, in.means3D, in.scales, in.scale_modifier, in.rotations, in.opacity, in.sh, in.sh_rest,    \
-      in.cov3D_precomp, in.colors_precomp, in.viewmatrix, in.projmatrix, in.campos, in.image_width, in.image_height,       \
-      in.tanfovx, in.tanfovy, focal_x, focal_y, im.tiles_x, im.tiles_y, radii, g.recs, bucket ? im.cursors : im.tile_counts, \
-      bucket ? g.hdr : nullptr, in.tanfov_device, in.live_count, fused ? bins->keys : nullptr, in.tile_bucket_capacity
-  if (in.colmap) {
-    if (fused)
-      hipLaunchKernelGGL((preprocess_forward_kernel<true, true>), grid, block, lds, s, SKGS_PF_ARGS);
-    else
-      hipLaunchKernelGGL((preprocess_forward_kernel<true, false>), grid, block, lds, s, SKGS_PF_ARGS);
-  } else {
-    if (fused)
-      hipLaunchKernelGGL((preprocess_forward_kernel<false, true>), grid, block, lds, s, SKGS_PF_ARGS);
-    else
-      hipLaunchKernelGGL((preprocess_forward_kernel<false, false>), grid, block, lds, s, SKGS_PF_ARGS);
-  }
-#undef SKGS_PF_ARGS
+  if (in.colmap)
+    hipLaunchKernelGGL(preprocess_forward_kernel<true>, grid, block, lds, s, P, in.sh_degree, in.sh_coeffs, in.means3D,
+        in.scales, in.scale_modifier, in.rotations, in.opacity, in.sh, in.sh_rest, in.cov3D_precomp, in.colors_precomp,
+        in.viewmatrix, in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y,
+        im.tiles_x, im.tiles_y, radii, g.recs, bucket ? im.cursors : im.tile_counts, bucket ? g.hdr : nullptr, in.tanfov_device,
+        in.live_count);
+  else
+    hipLaunchKernelGGL(preprocess_forward_kernel<false>, grid, block, lds, s, P, in.sh_degree, in.sh_coeffs, in.means3D,
+        in.scales, in.scale_modifier, in.rotations, in.opacity, in.sh, in.sh_rest, in.cov3D_precomp, in.colors_precomp,
+        in.viewmatrix, in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y,
+        im.tiles_x, im.tiles_y, radii, g.recs, bucket ? im.cursors : im.tile_counts, bucket ? g.hdr : nullptr, in.tanfov_device,
+        in.live_count);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

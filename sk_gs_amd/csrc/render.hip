@@ -307,7 +307,6 @@ int launch_render_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, 
   const int W = in.image_width, H = in.image_height;
   const int E = in.extras ? in.E : 0;
   const int ppl = g_ppl_override ? g_ppl_override : choose_ppl(im.T);
-  uint32_t* zero_cursors = fused_binning(in, im.T) ? im.cursors : nullptr;
   ProfScope prof(K_RENDER_FWD, s);
 #define FWD(E_, PPL_)                                                                                                   \
   {                                                                                                                     \
@@ -315,11 +314,11 @@ int launch_render_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, 
     if (g_strict)                                                                                                       \
       hipLaunchKernelGGL((blend_strict::render_forward_kernel<PPL_, E_>), dim3(nblk), dim3(64), 0, s, W, H, im.tiles_x, \
           im.T, TileRanges{im.tile_begin, im.tile_end, im.group_order}, b.capacity, b.point_list, g.recs, in.extras, in.background, im.n_contrib, out_color,   \
-          out_opacity, out_extra, (uint32_t*) nullptr, zero_cursors);                                                   \
+          out_opacity, out_extra, (uint32_t*) nullptr);                                                                 \
     else                                                                                                                \
       hipLaunchKernelGGL((blend_fast::render_forward_kernel<PPL_, E_>), dim3(nblk), dim3(64), 0, s, W, H, im.tiles_x,   \
           im.T, TileRanges{im.tile_begin, im.tile_end, im.group_order}, b.capacity, b.point_list, g.recs, in.extras, in.background, im.n_contrib, out_color,   \
-          out_opacity, out_extra, (uint32_t*) nullptr, zero_cursors);                                                   \
+          out_opacity, out_extra, (uint32_t*) nullptr);                                                                 \
   }
   if (ppl == 4) {
     SKGS_DISPATCH_E(E, FWD, 4)

@@ -40,13 +40,7 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
     int64_t capacity, const uint32_t* __restrict__ point_list, const float4* __restrict__ recs,
     const float* __restrict__ extra, const float* __restrict__ bg, uint32_t* __restrict__ n_contrib,
     float* __restrict__ out_color, float* __restrict__ out_opacity, float* __restrict__ out_extra,
-    uint32_t* __restrict__ census = nullptr /* [H*W][2]: blended entries, sum of census_mix(position) */,
-    uint32_t* __restrict__ zero_cursors = nullptr /* skgs_raster_inputs.fused_binning: the T per-tile cursors, dead since the
-                                                     sort published the ranges, are handed back zero for the next forward */) {
-  if (zero_cursors) {
-    const int i = blockIdx.x * WAVE + threadIdx.x;
-    if (i < T) zero_cursors[i] = 0u;
-  }
+    uint32_t* __restrict__ census = nullptr /* [H*W][2]: blended entries, sum of census_mix(position) */) {
   constexpr int SUBS = 4 / PPL;
   static_assert(XCD_GROUP == TILE_GROUP * 4, "one xcd_remap group = one group of tiles at one pixel per lane");
   int tile, sub;

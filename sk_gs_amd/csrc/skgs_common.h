@@ -278,15 +278,7 @@ struct ProfScope {
 int fill_u32(void* p, uint32_t v, size_t n_words, hipStream_t s);
 
 // preprocess.hip
-int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, int32_t* radii, hipStream_t s,
-    const BinView* bins = nullptr);
-// bucket layout with the slot reservation and key emission of the scatter launch done by the preprocess launch's own
-// workgroups (skgs_raster_inputs.fused_binning): T counters + T slot bases + one rectangle per thread must fit its LDS
-constexpr int FUSED_BIN_THREADS = 128;  // = PRE_THREADS of preprocess.hip
-inline size_t fused_binning_lds_bytes(int T) { return ((size_t) ((2 * T + 3) & ~3) + 4 * FUSED_BIN_THREADS) * 4; }
-inline bool fused_binning(const skgs_raster_inputs& in, int T) {
-  return in.fused_binning && in.tile_bucket_capacity > 0 && in.P > 0 && fused_binning_lds_bytes(T) <= 60 * 1024;
-}
+int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView im, int32_t* radii, hipStream_t s);
 int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const int32_t* radii,
     const skgs_raster_grads& gr, hipStream_t s);
 int launch_sh_grad_from_factors(int P, int n_views, int D, int M, const float* factors, float* dL_dsh, float* dL_dsh_rest,

@@ -19,7 +19,6 @@ surface.
 Reference call sequence: networks/sk_gs.py:1160-1242 (forward / render), :1524-1529 (loss), train.py:179-250.
 """
 import ctypes as C
-import os
 from typing import Optional
 
 import torch
@@ -113,10 +112,7 @@ class FusedViewStep:
         self.radii = torch.empty((P,), dtype=torch.int32, device=dev)
         self.geom = torch.empty((lib.skgs_geom_buffer_bytes(C.c_int32(P)),), **u8)
         self.geom[:256].zero_()  # status words; `overflow_events` counts overflowing forwards from here on
-        # zeros: with `fused_binning` (bucket layout: the preprocess launch also reserves slots and emits keys, no scatter
-        # launch) the per-tile cursors must read zero on entry; every forward leaves them zero
-        self.img = torch.zeros((lib.skgs_img_buffer_bytes(C.c_int32(W), C.c_int32(H)),), **u8)
-        self.fused_binning = os.environ.get('SKGS_FUSED_BINNING', '1') != '0'
+        self.img = torch.empty((lib.skgs_img_buffer_bytes(C.c_int32(W), C.c_int32(H)),), **u8)
         # tile_bucket = Lcap > 0: every tile owns Lcap fixed slots (skgs_raster_inputs.tile_bucket_capacity): no counting
         # and no scan launch; `capacity` is then ignored
         self.tile_bucket = int(tile_bucket)
@@ -283,7 +279,6 @@ class FusedViewStep:
         a.sh, a.sh_rest = m._features_dc.data_ptr(), m._features_rest.data_ptr()
         a.background = None if self.background is None else self.background.data_ptr()
         a.tile_bucket_capacity = self.tile_bucket
-        a.fused_binning = int(self.fused_binning and self.tile_bucket > 0)
         a.live_count = None if self._live is None else self._live.data_ptr()
         return a
 

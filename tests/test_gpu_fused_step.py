@@ -626,50 +626,3 @@ def test_fused_step_with_the_distance_based_lbs_weightings_matches_autograd(meth
     torch.cuda.synchronize()
     assert not torch.equal(before[0], model.joints)
     assert not torch.equal(before[1], model._sp_radius if model._sp_radius is not None else model._xyz)
-
-
-@pytest.mark.parametrize('W,H', [(160, 120), (403, 299)])
-def test_fused_binning_gives_the_same_lists_as_the_scatter_launch(W, H):
-    """bucket layout with `fused_binning` (the preprocess launch's workgroups reserve the slots and emit the keys of their own
-    Gaussians; no scatter launch) against the same step with the scatter launch: identical image, radii and gradients up
-    to the atomics' order, over several forwards in a row (the per-tile cursors must come back zero every time), and with
-    Gaussians whose rectangles cover many tiles"""
-    from sk_gs_amd import _C, scene
-    from sk_gs_amd.fused_step import FusedViewStep
-    from sk_gs_amd.model import SkinnedGaussians
-    P, M, K, frames = 9000, 10, 4, 3
-    dev = torch.device('cuda')
-    model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=8, scale_mult=3.0, deform_net=True,
-                             learn_joints=True).to(dev)
-    with torch.no_grad():
-        model._scaling[:40] += 2.5  # a few splats that cover hundreds of tiles
-    rs = [scene.raster_settings_from_camera(scene.make_camera(W, H, seed=60 + v), sh_degree=3, colmap=True, device=dev)
-          for v in range(frames)]
-    target = torch.rand(3, H, W, generator=torch.Generator().manual_seed(2)).to(dev)
-    _C.config.sync_num_rendered = True
-    with torch.no_grad():
-        longest = max(_C.read_status(model.render(r, time_id=v)['buffer'].geomBuffer)['max_tile_count'] for v, r in enumerate(rs))
-    for p in model.parameters():
-        p.grad = torch.zeros_like(p)
-    bucket = ((int(longest * 1.5) + 63) // 64) * 64
-    results = {}
-    for fused in (False, True):
-        step = FusedViewStep(model, W, H, capacity=0, tile_bucket=bucket)
-        step.fused_binning = fused
-        out = []
-        for v in (0, 1, 2, 0):
-            step.forward_backward(rs[v], v, target)
-            torch.cuda.synchronize()
-            st = step.status()
-            assert st['overflow'] == 0 and st['mlp_failed'] == 0
-            T = ((W + 15) // 16) * ((H + 15) // 16)
-            off = (W * H * 4 + 255) // 256 * 256 + (T * 4 + 255) // 256 * 256 + ((T + 1) * 4 + 255) // 256 * 256
-            cursors = step.img[off:off + T * 4].view(torch.int32)
-            if fused:
-                assert int(cursors.abs().max()) == 0, 'the forward must hand the per-tile cursors back zero'
-            out.append((step.image.clone(), step.radii.clone(), {n: p.grad.clone() for n, p in model.named_parameters()}))
-        results[fused] = out
-    for a, b in zip(results[False], results[True]):
-        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-        for n in a[2]:
-            assert rel_err(b[2][n], a[2][n]) <= 2e-5, n
