@@ -119,6 +119,26 @@ def load_library():
     return _lib
 
 
+_ops = None
+
+
+def _torch_ops():
+    """the C++ tensor-level entry points (csrc/torch_ops.cpp -> _skgs_torch.so): the same marshalling as the ctypes code
+    below, compiled.  None when the module is not built, when SKGS_TORCH_OPS=0, or when SKGS_HIP_LIB points at another
+    build of the kernels (the module is linked against the in-tree libskgs_hip.so)."""
+    global _ops
+    if _ops is None:
+        _ops = False
+        if os.environ.get('SKGS_TORCH_OPS', '1') != '0' and not os.environ.get('SKGS_HIP_LIB'):
+            load_library()  # the kernels' library first: the module resolves its symbols against the loaded instance
+            try:
+                from sk_gs_amd import _skgs_torch
+                _ops = _skgs_torch
+            except ImportError:
+                pass
+    return _ops or None
+
+
 def _check(rc: int):
     if rc != 0:
         raise SkgsError(load_library().skgs_last_error().decode())
@@ -328,6 +348,25 @@ def rasterize_gaussians(image_height: int, image_width: int, tanfovx: float, tan
     _require_gpu(means3D, 'means3D')
     dev = means3D.device
     H, W = int(image_height), int(image_width)
+    ops = None if config.sync_num_rendered else _torch_ops()
+    if ops is not None and means3D.ndim == 2 and means3D.shape[0] > 0 and not (
+            sh is None or scales is None or rotations is None or colors is None or cov3D_precomp is None):
+        P = means3D.shape[0]
+        key = (P, W, H)
+        bucket = _bucket_hint.get(key, 0)
+        cap = ((W + 15) // 16) * ((H + 15) // 16) * bucket if bucket else _capacity_hint.get(
+            key, max(config.min_capacity, 8 * P))
+        with _on_device(dev):
+            try:
+                out_color, out_opacity, radii, geom, binning, img, out_extras = ops.rasterize_forward(
+                    H, W, float(tanfovx), float(tanfovy), int(degree), float(scale_modifier), bool(prefiltered), bool(debug),
+                    bool(colmap), viewmatrix, projmatrix, campos, means3D, opacity, sh, scales, rotations, extras, colors,
+                    cov3D_precomp, _buffer_bytes(lib, 'geom', P), _buffer_bytes(lib, 'img', W, H),
+                    _buffer_bytes(lib, 'binning', int(cap)), bucket,
+                    torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+            except RuntimeError as e:
+                raise SkgsError(str(e)) from None
+        return -1, out_color, out_opacity, radii, geom, binning, img, out_extras  # R unknown without a sync: read_status()
     with _on_device(dev):
         a, keep, P, M, E = _make_inputs(H, W, tanfovx, tanfovy, degree, scale_modifier, prefiltered, debug, colmap,
                                         viewmatrix, projmatrix, campos, means3D, opacity, sh, scales, rotations,
@@ -444,6 +483,28 @@ def rasterize_gaussians_backward(scale_modifier: float, tanfovx: float, tanfovy:
     _require_gpu(means3D, 'means3D')
     dev = means3D.device
     H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])
+    ops = _torch_ops()
+    if ops is not None and means3D.ndim == 2 and means3D.shape[0] > 0 and dL_dout_opacity is not None and not (
+            sh is None or scales is None or rotations is None or colors is None or cov3D_precomp is None):
+        P = means3D.shape[0]
+        with _on_device(dev):
+            stream = torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+            capturing = torch.cuda.is_current_stream_capturing()
+            ws_key = (dev.index, P, stream)  # (the same pool of all-zero scratch rows as the ctypes path below)
+            ws = _zero_ws.pop(ws_key, None)
+            if ws is None or capturing:
+                ws = torch.zeros((_buffer_bytes(lib, 'bwd_ws', P),), dtype=torch.uint8, device=dev)
+            try:
+                out = ops.rasterize_backward(
+                    float(scale_modifier), float(tanfovx), float(tanfovy), int(degree), bool(debug), bool(colmap), viewmatrix,
+                    projmatrix, campos, means3D, colors, extras, scales, rotations, cov3D_precomp, sh, radii, out_opacity,
+                    dL_dout_color, dL_dout_opacity, dL_dout_extra, grad_means2D, grad_conic, grad_opacity, geomBuffer,
+                    binningBuffer, imgBuffer, ws, stream)
+            except RuntimeError as e:
+                raise SkgsError(str(e)) from None
+            if not capturing and len(_zero_ws) < 8:
+                _zero_ws[ws_key] = ws
+        return out
     with _on_device(dev):
         # opacity is not an input of the backward: the blend kernels read it from the saved records
         dummy_op = means3D  # any non-null pointer satisfies the input check; never dereferenced in the backward

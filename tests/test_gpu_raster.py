@@ -308,6 +308,46 @@ def test_sync_free_operator_path_with_tile_buckets_matches_the_compact_lists():
         C._capacity_hint.clear(), C._bucket_hint.clear()
 
 
+@pytest.mark.parametrize('bucket', [False, True])
+def test_compiled_marshalling_of_the_operator_path_equals_the_ctypes_one(bucket):
+    """`_skgs_torch.so` (csrc/torch_ops.cpp) and the ctypes code of `_C.py` fill the same structs and make the same C-ABI
+    calls: sync-free forward bit-identical (image, opacity, radii, status words), backward identical up to the atomics'
+    order; extras and a non-contiguous / double input take the same conversions"""
+    C = _C()
+    assert C._torch_ops() is not None, 'sk_gs_amd/_skgs_torch.so is not built'
+    P, W, H = 12000, 200, 152
+    act, rs, cam = scene_inputs(P, W, H, seed=12, colmap=True, scale_mult=2.0, device='cuda')
+    g = torch.Generator().manual_seed(4)
+    gc, go = torch.randn(3, H, W, generator=g).cuda(), torch.randn(H, W, generator=g).cuda()
+    C.config.sync_num_rendered = True
+    ref = hip_forward(act, rs)
+    R, longest = ref[0], C.read_status(ref[4])['max_tile_count']
+    act2 = dict(act)
+    act2['means3D'] = act['means3D'].double()                    # converted to float32
+    act2['scales'] = act['scales'].t().contiguous().t()        # made contiguous
+    try:
+        C.config.sync_num_rendered = False
+        C.update_capacity_hint(P, W, H, R, longest if bucket else 0)
+        results = {}
+        for compiled in (False, True):
+            C._ops = None if compiled else False
+            out = hip_forward(act2, rs)
+            assert out[0] == -1
+            st = C.read_status(out[4])
+            assert st['overflow'] == 0 and (bucket or st['num_rendered'] == R)
+            results[compiled] = (out, hip_backward(out, act2, rs, gc, go))
+        (fa, ga), (fb, gb) = results[False], results[True]
+        for i in (1, 2, 3):
+            assert torch.equal(fa[i], fb[i])
+        assert torch.equal(fb[1], ref[1])
+        for name, a, b in zip(GRAD_NAMES, ga, gb):
+            assert a.shape == b.shape and rel_err(b, a) <= 2e-5, name
+    finally:
+        C._ops = None
+        C.config.sync_num_rendered = True
+        C._capacity_hint.clear(), C._bucket_hint.clear()
+
+
 def test_blend_kernels_walk_the_tile_groups_heaviest_first_and_the_order_changes_nothing():
     """the group order written by the sort launch (binning.hip::tile_order_job) is a permutation of the groups of 8 tiles,
     by total list length descending (ties: lower id first); with the order switched off (raster order) the forward is

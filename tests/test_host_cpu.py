@@ -65,6 +65,28 @@ def test_product_path_refuses_cpu_tensors():
         _C.knn_bones(torch.zeros(4, 3), torch.zeros(2, 3), 1)
 
 
+def test_tensor_level_entry_points_are_built_and_refuse_cpu_tensors():
+    """sk_gs_amd/_skgs_torch.so (csrc/torch_ops.cpp: the operator path's marshalling in C++) imports without a GPU, exposes
+    the two entry points `_C.py` dispatches to, and has no CPU path either"""
+    from sk_gs_amd import _C
+    ops = _C._torch_ops()
+    assert ops is not None, 'build it: make -C sk_gs_amd/csrc torch (or __graft_entry__.build())'
+    assert callable(ops.rasterize_forward) and callable(ops.rasterize_backward)
+    e = torch.Tensor([])
+    with pytest.raises(RuntimeError, match='HIP device'):
+        ops.rasterize_forward(32, 32, 0.5, 0.5, 0, 1.0, False, False, True, torch.eye(4), torch.eye(4), torch.zeros(3),
+                              torch.zeros(4, 3), torch.ones(4, 1), torch.zeros(4, 1, 3), torch.ones(4, 3),
+                              torch.tensor([[0, 0, 0, 1.]]).repeat(4, 1), None, e, e, 1024, 1024, 1024, 0, 0)
+    try:  # the dispatching wrapper turns it into the package's error type, sync-free or not
+        _C.config.sync_num_rendered = False
+        with pytest.raises(_C.SkgsError):
+            _C.rasterize_gaussians(32, 32, 0.5, 0.5, 0, 1.0, False, False, True, torch.eye(4), torch.eye(4), torch.zeros(3),
+                                   torch.zeros(4, 3), torch.ones(4, 1), torch.zeros(4, 1, 3), torch.ones(4, 3),
+                                   torch.tensor([[0, 0, 0, 1.]]).repeat(4, 1), None, e, e)
+    finally:
+        _C.config.sync_num_rendered = True
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, 'sk_gs_amd')
     for dirpath, _, files in os.walk(pkg):
