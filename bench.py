@@ -214,7 +214,13 @@ def main():
     ap.add_argument('--autograd', action='store_true',
                     help='run the step through the torch-autograd operator path (model.render + image_loss + backward) '
                          'instead of sk_gs_amd.fused_step.FusedViewStep (same kernels, no autograd glue)')
+    ap.add_argument('--backward-thread', choices=('caller', 'worker'), default='caller',
+                    help="where torch autograd runs a backward (operator path only: ms/render and --autograd; the fused step "
+                         "has no autograd in it).  'caller': sk_gs_amd.single_thread_backward(), what the install_as_* hooks "
+                         "set; 'worker': torch's default per-device worker thread")
     args = ap.parse_args()
+    import sk_gs_amd
+    sk_gs_amd.single_thread_backward(args.backward_thread == 'caller')
 
     # stdout carries exactly ONE JSON line: everything else that any library prints to fd 1 (RCCL's version banner,
     # MIOpen notes) is diverted to stderr for the whole run
@@ -831,6 +837,7 @@ def main():
                            'joints': 'trained, lr x 0.1 (sk_gs.py:607)' if model.learn_joints else 'fixed',
                            'adam': adam_desc,
                            'step': 'autograd operator path' if args.autograd else 'FusedViewStep (direct C-ABI calls)',
+                           'operator_path_backward_thread': args.backward_thread,
                            'replicas_identical': replicas_identical, 'param_digest': param_digest},
                 'roofline': {'bound': 'hbm', 'kernel': 'render_backward', 'achieved': round(achieved, 2),
                              'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 5),
@@ -849,6 +856,7 @@ def main():
                        'render_backward', 'preprocess_backward')
                 ms_render['kernel_sum'] = round(sum(kernels[k]['us'] * kernels[k]['launches_per_step']
                                                     for k in ras if k in kernels) / 1e3, 4)
+                ms_render['backward_thread'] = args.backward_thread
                 ms_render['how'] = 'operator path render() + torch.autograd.grad of (images, opacity) w.r.t. its five inputs, eager ' \
                                    'launches, bucket tile lists, no host synchronisation; kernel_sum: the rasterizer kernels of ' \
                                    'the fused step'

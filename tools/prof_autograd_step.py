@@ -11,6 +11,8 @@ from sk_gs_amd.optim import FusedAdam
 from sk_gs_amd.renderer.gaussian_render import render
 
 dev = torch.device('cuda')
+if os.environ.get('SINGLE_THREAD_BACKWARD'):
+    torch.autograd.set_multithreading_enabled(False)
 P, W, H, V = 100_000, 800, 800, 4
 model = SkinnedGaussians(P, 20, 5, sh_degree=3, num_frames=V, seed=0).to(dev)
 rs = [scene.raster_settings_from_camera(scene.make_camera(W, H, seed=v), sh_degree=3, colmap=True, device=dev) for v in range(V)]
