@@ -87,6 +87,29 @@ def test_tensor_level_entry_points_are_built_and_refuse_cpu_tensors():
         _C.config.sync_num_rendered = True
 
 
+def test_install_hook_moves_the_backward_to_the_calling_thread_and_back():
+    import sys
+    import sk_gs_amd
+    was = torch.autograd.is_multithreading_enabled()
+    saved = {k: sys.modules.get(k) for k in ('my_ext', 'my_ext._C')}
+    try:
+        sk_gs_amd.install_as_my_ext_C()
+        assert not torch.autograd.is_multithreading_enabled()
+        from my_ext._C import get_C_function  # what networks/renderer/gaussian_render.py:12 does
+        assert callable(get_C_function('rasterize_gaussians'))
+        sk_gs_amd.single_thread_backward(False)
+        assert torch.autograd.is_multithreading_enabled()
+        sk_gs_amd.install_as_my_ext_C(single_thread=False)
+        assert torch.autograd.is_multithreading_enabled()
+    finally:
+        torch.autograd.set_multithreading_enabled(was)
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, 'sk_gs_amd')
     for dirpath, _, files in os.walk(pkg):
