@@ -36,5 +36,11 @@ python tools/time_skeleton.py 2>/dev/null | grep -v "^$" > $out/time_skeleton.tx
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_issue_rate tools/micro/valu_issue_rate.hip 2>/dev/null && /tmp/valu_issue_rate > $out/valu_issue_rate.txt 2>&1; /tmp/valu_issue_rate >> $out/valu_issue_rate.txt 2>&1; tail -20 $out/valu_issue_rate.txt
 python tools/time_mlp.py 2>/dev/null | grep "fused\|backward\|prologue" > $out/time_mlp.txt; cat $out/time_mlp.txt
 python tools/time_densify.py 2>/dev/null | tail -2 > $out/time_densify.txt; cat $out/time_densify.txt
+python tools/time_loss.py 2>/dev/null | tail -1 > $out/time_loss.txt; python tools/time_loss.py 1024 1024 2>/dev/null | tail -1 >> $out/time_loss.txt; cat $out/time_loss.txt
+# operator path: compiled vs ctypes marshalling, backward on the calling thread vs torch's worker thread
+for v in "1 caller" "1 worker" "0 caller" "0 worker"; do set -- $v
+  SKGS_TORCH_OPS=$1 python bench.py --no-cpu-baseline --backward-thread $2 --steps 50 --warmup 10 2>/dev/null | tail -1 > $out/bench_oppath_ops$1_$2.json
+  python -c "import json; d=json.load(open('$out/bench_oppath_ops$1_$2.json')); r=d['ms_per_render_fwd_bwd']; print('operator path: compiled marshalling $1, backward thread $2: ms/render', r['median'], 'replay', r['graph_replay_median'], 'kernels', r['kernel_sum'])"
+done
 bash tools/profile_round.sh ${tag}_c1 > /dev/null 2>&1; ls gpurun_out/${tag}_c1 | head
 bash tools/profile_round.sh ${tag}_c4 --config 4 > /dev/null 2>&1; ls gpurun_out/${tag}_c4 | head
