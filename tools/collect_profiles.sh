@@ -1,0 +1,23 @@
+#!/bin/bash
+# Copy the summaries of one tools/round_measurements.sh run (gpurun_out/<tag>, gpurun_out/<tag>_c1, gpurun_out/<tag>_c4) into
+# profiles/ under the round's naming; the PMC tables are rebuilt (config #4 first: pmc_render_backward.json is config #1's).
+# usage (here, after the gpurun call has merged its output): bash tools/collect_profiles.sh r03_i
+tag=$1
+src=gpurun_out/$tag
+[ -d "$src" ] || { echo "no $src"; exit 1; }
+for f in $src/bench_*.json; do
+  b=$(basename "$f" .json); b=${b//--/_}; b=${b// /_}
+  [ -s "$f" ] && cp "$f" "profiles/${tag}_${b}.json"
+done
+for f in gpu_tests.txt parity_observed.json time_densify.txt time_mlp.txt time_skeleton.txt time_loss.txt valu_issue_rate.txt; do
+  [ -s "$src/$f" ] && cp "$src/$f" "profiles/${tag}_$f"
+done
+for c in c4 c1; do
+  d=gpurun_out/${tag}_$c
+  [ -d "$d" ] || continue
+  cp $d/bench_steps100.json profiles/${tag}_${c}_bench_steps100.json
+  cp $(ls -t $d/stats/*/*kernel_stats.csv | head -1) profiles/${tag}_${c}_kernel_stats_bench_steps100.csv
+  python tools/pmc_summary.py ${tag}_$c $d/fetch $d/write $d/valu > /dev/null
+  [ $c = c4 ] && cp profiles/pmc_render_backward.json profiles/${tag}_c4_pmc_render_backward.json
+done
+ls profiles | grep "^$tag" | wc -l
