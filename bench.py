@@ -51,6 +51,8 @@ def alg_bytes(name, P, M, K, W, H, R):
         'render_forward': 40 * R + 20 * W * H,
         'render_backward': 40 * R + 24 * W * H + 44 * P,
         'preprocess_backward': 627 * P,
+        'image_loss_forward': 20 * 3 * W * H,    # reads x and y, writes the three derivative maps
+        'image_loss_backward': 24 * 3 * W * H,   # reads the maps, x and y, writes dL/dx
     }.get(name)
 
 
@@ -689,6 +691,23 @@ def main():
         for name, (ms, n) in prof_all.items():
             us = ms / n * 1e3
             b = alg_bytes(name, P, M, K, W, H, R_mean)
+            if name in ('skeleton_forward', 'skeleton_backward', 'adam') and not args.autograd:
+                # the optimizer's stream (28 B per element: gradient, parameter and both moments read, the last three
+                # written) rides on these launches; the network itself is 2.1 MB of weights (+ as much of gradients)
+                rows_b = 28 * sum(p.numel() for n_, p in model.named_parameters() if n_.lstrip('_') in
+                                  ('xyz', 'features_dc', 'features_rest', 'opacity', 'scaling', 'rotation', 'sp_W'))
+                rest_b = 28 * sum(p.numel() for p in model.parameters()) - rows_b
+                net_b = 4 * sum(p.numel() for n_, p in model.named_parameters() if 'deform_net' in n_)
+                from sk_gs_amd.train_step import FusedTrainStep as _FTS
+                fu, tn = bool(locals().get('fused_update')), locals().get('train_n')
+                if fu:    # one rank: the rows beside the skeleton backward (and, with pre_forward, partly beside the next forward)
+                    share = _FTS.ROWS_IN_BACKWARD if train1.pre_forward else 1.0
+                    b = {'skeleton_forward': net_b + (1.0 - share) * rows_b, 'skeleton_backward': 2 * net_b + share * rows_b,
+                         'adam': rest_b}[name]
+                elif tn is not None:  # view-parallel ranks: all rows beside the next view's skeleton forward
+                    b = {'skeleton_forward': net_b + rows_b, 'skeleton_backward': 2 * net_b, 'adam': rest_b}[name]
+                else:
+                    b = {'skeleton_forward': net_b, 'skeleton_backward': 2 * net_b, 'adam': rows_b + rest_b}[name]
             kernels[name] = dict(us=round(us, 2), launches_per_step=round(n / min(args.steps, 20), 2),
                                  alg_MB=round(b / 1e6, 2) if b else None,
                                  GBps=round(b / (us * 1e-6) / 1e9, 1) if b else None)

@@ -136,6 +136,7 @@ int step_range_impl(int32_t n_tensors, const void* tensors, int64_t chunk_begin,
   const int64_t nc = n_tensors > 0 ? chunk_end - chunk_begin : 0;
   const bool self_advance = advance && nc > 0 && nc <= 256 && zn <= 65536;
   SKGS_REQUIRE(!va.slot || self_advance, "adam_step_tail: the view advance rides on a short closing piece (<= 256 chunks)");
+  ProfScope prof(K_ADAM, s);
   if (nc > 0) {
     const int grid = (int) std::min<int64_t>(nc, 256 * 16);
     hipLaunchKernelGGL(adam_step_kernel, dim3(grid), dim3(ADAM_THREADS), 0, s, n_tensors,

@@ -387,6 +387,7 @@ int skgs_image_loss_forward(int32_t C, int32_t H, int32_t W, const float* pred, 
   hipStream_t s   = (hipStream_t) stream;
   float* dmaps    = reinterpret_cast<float*>(workspace);
   float* partials = dmaps + (size_t) 3 * C * H * W;
+  ProfScope prof(K_LOSS_FWD, s);
   hipLaunchKernelGGL(image_loss_forward_kernel, tile_grid(C, H, W), dim3(NT), 0, s, C, H, W, pred, gt, gt_index, make_window(), dmaps,
       partials);
   SKGS_CHECK_HIP(hipGetLastError());
@@ -409,6 +410,7 @@ int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred,
   const float n      = (float) ((double) C * H * W);
   const float* partials = dmaps + (size_t) 3 * C * H * W;
   const int nblocks     = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * C;
+  ProfScope prof(K_LOSS_BWD, (hipStream_t) stream);
   hipLaunchKernelGGL(image_loss_backward_kernel, tile_grid(C, H, W), dim3(NT), 0, (hipStream_t) stream, C, H, W, pred, gt,
       gt_index, make_window(), dmaps, grad_loss, lambda_l1 / n, -lambda_ssim / n, dL_dpred, partials, nblocks,
       1.0 / ((double) C * H * W), lambda_l1, lambda_ssim, loss3);

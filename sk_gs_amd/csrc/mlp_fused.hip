@@ -936,7 +936,8 @@ int backward_impl(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, con
     const skgs_adam_range* side, skgs_stream_t stream);
 
 template <typename KernelT>
-int launch(KernelT k, const Plan& p, const FusedArgs& a, size_t lds, hipStream_t s) {
+int launch(KernelT k, const Plan& p, const FusedArgs& a, size_t lds, hipStream_t s, int prof_id) {
+  ProfScope prof(prof_id, s);
   if (lds > 64 * 1024)
     SKGS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   // side job: one workgroup per CU the network leaves idle (each takes two chunks per iteration)
@@ -947,10 +948,10 @@ int launch(KernelT k, const Plan& p, const FusedArgs& a, size_t lds, hipStream_t
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }
-#define SKGS_MLP_DISPATCH(KERNEL)                                                    \
-  if (p.passes == 1) return launch(KERNEL<1>, p, a, lds, (hipStream_t) stream);      \
-  if (p.passes == 2) return launch(KERNEL<2>, p, a, lds, (hipStream_t) stream);      \
-  return launch(KERNEL<3>, p, a, lds, (hipStream_t) stream);
+#define SKGS_MLP_DISPATCH(KERNEL, PROF_ID)                                                    \
+  if (p.passes == 1) return launch(KERNEL<1>, p, a, lds, (hipStream_t) stream, PROF_ID);      \
+  if (p.passes == 2) return launch(KERNEL<2>, p, a, lds, (hipStream_t) stream, PROF_ID);      \
+  return launch(KERNEL<3>, p, a, lds, (hipStream_t) stream, PROF_ID);
 
 __global__ void init_workspace_kernel(uint32_t* w, size_t n_words) {
   const size_t stride = (size_t) gridDim.x * blockDim.x;
@@ -1024,7 +1025,7 @@ int forward_impl(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, cons
   a.lds_floats = (int) fl;
   const size_t lds = fl * 4;
   SKGS_REQUIRE(lds <= 160 * 1024, "deform_mlp_forward: %zu bytes of LDS needed", lds);
-  SKGS_MLP_DISPATCH(fused_mlp_forward_kernel)
+  SKGS_MLP_DISPATCH(fused_mlp_forward_kernel, K_SKELETON_FWD)
 }
 }  // namespace
 }  // namespace skgs
@@ -1090,7 +1091,7 @@ int backward_impl(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, con
   a.lds_floats = (int) fl;
   const size_t lds = fl * 4;
   SKGS_REQUIRE(lds <= 160 * 1024, "deform_mlp_backward: %zu bytes of LDS needed", lds);
-  SKGS_MLP_DISPATCH(fused_mlp_backward_kernel)
+  SKGS_MLP_DISPATCH(fused_mlp_backward_kernel, K_SKELETON_BWD)
 }
 }  // namespace
 }  // namespace skgs

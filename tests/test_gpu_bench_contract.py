@@ -30,6 +30,14 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     b = d['ms_per_step_blocks']  # the spread of the timed region: 8 steps -> 8 blocks
     assert b['blocks'] == 8 and b['min'] <= b['p10'] <= b['median'] <= b['p90'] <= b['max']
     assert abs(b['median'] - d['ms_per_step']) / d['ms_per_step'] < 0.25
+    # every launch of the step is timed and priced (algorithmic bytes next to the 8 TB/s roofline); together they are the step
+    k = d['kernels']
+    for name in ('preprocess_forward', 'scatter', 'tile_sort', 'render_forward', 'render_backward', 'preprocess_backward',
+                 'deform_forward', 'deform_backward', 'image_loss_forward', 'image_loss_backward', 'skeleton_forward',
+                 'skeleton_backward', 'adam'):
+        assert k[name]['us'] > 0 and k[name]['alg_MB'] > 0 and 0 < k[name]['GBps'] < 8000.0, (name, k[name])
+    total = sum(v['us'] * v['launches_per_step'] for v in k.values())
+    assert 0.8 * d['ms_per_step'] * 1e3 < total < 1.6 * d['ms_per_step'] * 1e3  # (eager, event-bracketed: a little over)
 
 
 PLAIN = ['--exchange', 'allreduce']
