@@ -93,7 +93,10 @@ def check_forward(o, act, rs, extras=None, colors=None, cov3D=None, strict=False
         census = FlipCensus(o, ref, W, H, tol=TOL, name=f'P={P} {W}x{H}')
         census.check_image(color, opacity, cen if exact else None)
         ref['census'] = census
-        assert (nc != ref['img']['n_contrib'].astype(np.int64)).mean() <= 2e-5
+        # the last contributor differs only where the walk itself took a different branch
+        nc_bad = nc != ref['img']['n_contrib'].astype(np.int64)
+        assert not (nc_bad & ~np.asarray(census.flipped, dtype=bool).reshape(nc_bad.shape)).any()
+        assert nc_bad.mean() <= max(2e-5, 1.5 / nc_bad.size)
         if extras is not None:
             assert_close_robust(out_extra, ref['out_extra'], TOL, name='out_extra')
     return ref, fwd
