@@ -422,8 +422,17 @@ def main():
                 from sk_gs_amd.optim import FusedAdam
                 opt = FusedAdam(groups, eps=1e-15, betas=(0.9, 0.999), zero_after_step=table_span)
             if args.autograd:
+                grad_params = [p for p in model.parameters() if p.requires_grad]
+
                 def fwd_bwd(v):
-                    vp.grads.zero_()
+                    if world == 1 and not args.torch_adam:
+                        # what optimizer.zero_grad() does (set_to_none): autograd then hands every gradient over as it is --
+                        # no zero fill of the flat buffer and no "+=" launch per parameter; FusedAdam gives each captured
+                        # step a descriptor table with that capture's gradient addresses
+                        for p in grad_params:
+                            p.grad = None
+                    else:  # the all-reduce (and torch's captured Adam) need the gradients in place in the flat buffer
+                        vp.grads.zero_()
                     out = model.render(settings[v], time_id=v % frames, background=background)
                     loss = image_loss(out['images'], targets[v])
                     loss.backward()

@@ -46,6 +46,8 @@ class CapacityExceeded(RuntimeError):
 
 
 class FusedAdam:
+    MAX_CAPTURED_TABLES = 64  # captured steps with gradients of their own (one per graph: e.g. one graph per training view)
+
     def __init__(self, param_groups: Iterable[dict], betas=(0.9, 0.999), eps: float = 1e-15,
                  zero_after_step: 'torch.Tensor' = None):
         lib = _C.load_library()
@@ -84,6 +86,10 @@ class FusedAdam:
         self.step_state = torch.zeros(int(lib.skgs_adam_state_bytes()) // 4, dtype=torch.float32, device=dev)
         self.step_count = self.step_state[:1]  # (a view: ``float(opt.step_count)`` reads the count)
         self._table = torch.zeros(len(self.params) * 56, dtype=torch.uint8, device=dev)
+        # descriptor tables of captured steps whose gradients autograd handed over (_table_of_this_capture)
+        self._pin_arena = torch.empty(self.MAX_CAPTURED_TABLES * len(self.params) * 56, dtype=torch.uint8, pin_memory=True)
+        self._table_arena = torch.zeros(self.MAX_CAPTURED_TABLES * len(self.params) * 56, dtype=torch.uint8, device=dev)
+        self._capture_tables = []
         self._total_chunks = 0
         self._bound_grads = None
         self._upload()
@@ -114,6 +120,31 @@ class FusedAdam:
         self._total_chunks = chunk0
         self._bound_grads = grads
         self._h2d(self._table, blob)
+
+    def _table_of_this_capture(self) -> 'torch.Tensor':
+        """A step captured into a graph whose backward handed over FRESH gradient tensors (``p.grad = None`` before the
+        backward, what ``zero_grad(set_to_none=True)`` does: autograd then stores each gradient as it is -- no zero fill and
+        no "+=" launch per parameter): the tensors live in the graph's private pool, at addresses that are the same in every
+        replay of THIS graph and differ from graph to graph.  The capture therefore gets a descriptor table of its own --
+        same layout and chunk space as the bound one, these gradient addresses -- uploaded by a copy node from a pinned
+        host blob that the optimizer keeps alive (2 KB per replay)."""
+        blob = bytearray()
+        for k, (p, gi) in enumerate(zip(self.params, self._lr_index)):
+            if p.grad is None:  # no gradient reached it in this backward: a zero one from the graph's pool
+                p.grad = torch.zeros_like(p)
+            assert p.grad.is_contiguous() and p.grad.dtype == torch.float32 and cap_store(p) is None, \
+                'captured steps with fresh gradients: contiguous float32 gradients, no row capacity'
+            st = self.state[p]
+            blob += struct.pack('<QQQQqqff', p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(),
+                                st['exp_avg_sq'].data_ptr(), p.numel(), self._chunk0[k], float(self.param_groups[gi]['lr']), 0.0)
+        # (pinned memory cannot be allocated while a stream captures: both arenas exist since __init__)
+        n, used = len(blob), len(self._capture_tables)
+        assert used < self.MAX_CAPTURED_TABLES, 'FusedAdam: more captured steps with fresh gradients than MAX_CAPTURED_TABLES'
+        pin, table = self._pin_arena[used * n:(used + 1) * n], self._table_arena[used * n:(used + 1) * n]
+        pin.copy_(torch.frombuffer(blob, dtype=torch.uint8))
+        table.copy_(pin, non_blocking=True)
+        self._capture_tables.append((pin, table))
+        return table
 
     def _h2d(self, dst: 'torch.Tensor', blob) -> None:
         """small host table -> device through a pinned staging tensor, asynchronously on the current stream (a pageable
@@ -315,6 +346,12 @@ class FusedAdam:
             group = next(i for i, g in enumerate(self.param_groups) if g.get('name') == group)
         self.param_groups[group]['lr'] = float(lr)
         self._upload()
+        # tables of captured steps (_table_of_this_capture): their copy nodes read the pinned host blobs at every replay
+        for pin, _ in self._capture_tables:
+            view = pin.view(torch.float32)  # 56-byte descriptors = 14 floats; the rate is float 12
+            for k, gi in enumerate(self._lr_index):
+                if gi == group:
+                    view[14 * k + 12] = float(lr)
 
     # ---------------------------------------------------------------------------------------------------------
     def state_dict(self) -> dict:
@@ -391,9 +428,12 @@ class FusedAdam:
         side stream beside the rest of the backward (``OverlappedStep``): every piece uses the bias correction of the
         same step; pass ``advance=False`` to all of them and call ``advance_step()`` once, after they have all been
         ordered before it (the counter every piece reads must not move under them)."""
-        if not torch.cuda.is_current_stream_capturing():
-            # the table holds raw gradient pointers: refresh it if autograd replaced a .grad tensor
-            if any(p.grad is None or p.grad.data_ptr() != g for p, g in zip(self.params, self._bound_grads)):
+        table = self._table
+        # the table holds raw gradient pointers: autograd may have replaced a .grad tensor (zero_grad(set_to_none=True))
+        if any(p.grad is None or p.grad.data_ptr() != g for p, g in zip(self.params, self._bound_grads)):
+            if torch.cuda.is_current_stream_capturing():
+                table = self._table_of_this_capture()
+            else:
                 self._upload()
         lib = _C.load_library()
         z = self.zero_after_step if advance else None
@@ -403,7 +443,7 @@ class FusedAdam:
         for k, (c0, c1) in enumerate(ranges):
             last = advance and k == len(ranges) - 1
             _C._check(lib.skgs_adam_step_range(
-                C.c_int32(len(self.params)), C.c_void_p(self._table.data_ptr()), C.c_int64(c0), C.c_int64(c1),
+                C.c_int32(len(self.params)), C.c_void_p(table.data_ptr()), C.c_int64(c0), C.c_int64(c1),
                 C.c_double(self.betas[0]), C.c_double(self.betas[1]), C.c_double(self.eps),
                 C.c_void_p(self.step_state.data_ptr()), C.c_int32(1 if last else 0),
                 C.c_void_p(z.data_ptr() if (z is not None and last) else None),

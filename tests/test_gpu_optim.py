@@ -304,3 +304,62 @@ def test_closing_piece_with_the_encoder_backward_in_the_joints_workgroup():
         assert torch.equal(a, b)
         assert torch.equal(fus['opt'].state[b]['exp_avg'], ref['opt'].state[a]['exp_avg'])
         assert torch.equal(fus['opt'].state[b]['exp_avg_sq'], ref['opt'].state[a]['exp_avg_sq'])
+
+
+def test_captured_steps_with_gradients_handed_over_by_autograd():
+    """``p.grad = None`` in front of a CAPTURED backward (zero_grad(set_to_none=True) semantics: autograd stores each gradient
+    as it is, no zero fill and no "+=" launch): the gradients live in the graph's pool, at other addresses in every graph.
+    ``FusedAdam.step`` gives each capture a descriptor table of its own; two graphs replayed alternately, a learning-rate
+    change between replays and an eager step in between all follow torch.optim.Adam on a replica."""
+    from sk_gs_amd.optim import FusedAdam
+    gen = torch.Generator().manual_seed(3)
+    shapes, lrs = [(1000, 3), (257,), (33, 15, 3)], [1e-2, 3e-3, 1e-3]
+    a = [torch.nn.Parameter(torch.randn(*s, generator=gen).cuda()) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    coef = [[torch.randn(*s, generator=gen).cuda() for s in shapes] for _ in range(2)]  # two "views"
+    ref = torch.optim.Adam([{'params': [p], 'lr': lr} for p, lr in zip(a, lrs)], eps=1e-15)
+    opt = FusedAdam([{'params': [p], 'lr': lr, 'name': f'g{i}'} for i, (p, lr) in enumerate(zip(b, lrs))], eps=1e-15)
+
+    def loss(params, v):
+        return sum(((p * p) * c).sum() + (p * c).sum() for p, c in zip(params, coef[v])) + (params[1][:5] ** 3).sum()
+
+    def one(v):  # the captured body
+        for p in b:
+            p.grad = None
+        loss(b, v).backward()
+        opt.step()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graphs = []
+    with torch.cuda.stream(side):
+        pool = None
+        for v in range(2):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, stream=side):
+                one(v)
+            pool = g.pool()
+            graphs.append(g)
+    torch.cuda.current_stream().wait_stream(side)
+    assert float(opt.step_count.item()) == 0.0 and len(opt._capture_tables) == 2  # capturing runs nothing
+
+    def ref_step(v):
+        ref.zero_grad(set_to_none=True)
+        loss(a, v).backward()
+        ref.step()
+
+    order = [0, 1, 1, 0, 1, 0]
+    for i, v in enumerate(order):
+        if i == 3:
+            opt.set_lr('g0', 5e-2)
+            ref.param_groups[0]['lr'] = 5e-2
+        if i == 4:  # an eager step between replays (fresh gradients outside a capture: the bound table is refreshed)
+            one(0)
+            ref_step(0)
+        graphs[v].replay()
+        ref_step(v)
+    torch.cuda.synchronize()
+    assert float(opt.step_count.item()) == len(order) + 1
+    for p, q in zip(a, b):
+        assert rel_err(q, p) <= 2e-6
+        assert rel_err(opt.state[q]['exp_avg'], ref.state[p]['exp_avg']) <= 2e-6

@@ -14,7 +14,7 @@ dev = torch.device('cuda')
 if os.environ.get('SINGLE_THREAD_BACKWARD'):
     torch.autograd.set_multithreading_enabled(False)
 P, W, H, V = 100_000, 800, 800, 4
-model = SkinnedGaussians(P, 20, 5, sh_degree=3, num_frames=V, seed=0).to(dev)
+model = SkinnedGaussians(P, 20, 5, sh_degree=3, num_frames=V, seed=0, deform_net=True, learn_joints=True).to(dev)  # bench.py's model
 rs = [scene.raster_settings_from_camera(scene.make_camera(W, H, seed=v), sh_degree=3, colmap=True, device=dev) for v in range(V)]
 targets = [torch.rand(3, H, W, device=dev) for _ in range(V)]
 background = torch.ones(3, device=dev)
@@ -26,8 +26,7 @@ with torch.no_grad():
         R, longest = max(R, buf.R), max(longest, _C.read_status(buf.geomBuffer)['max_tile_count'])
 _C.config.sync_num_rendered = False
 _C.update_capacity_hint(P, W, H, int(R * 1.25), longest)
-opt = FusedAdam(model.param_groups() if hasattr(model, 'param_groups') else [{'params': list(model.parameters()), 'lr': 1e-3}],
-                eps=1e-15, betas=(0.9, 0.999))
+opt = FusedAdam(model.param_groups(lr=float(os.environ.get('LR', '1e-4'))), eps=1e-15, betas=(0.9, 0.999))
 
 
 def one(i):
@@ -103,3 +102,25 @@ torch.cuda.synchronize()
 print(f'with timers: host {1e3 * (t1 - t0) / 200:.3f} ms / step')
 for k in sorted(acc, key=lambda k: -acc[k]):
     print(f'  {k:45s} {1e6 * acc[k] / 200:8.1f} us / step  ({cnt[k] // 200} calls)')
+
+if os.environ.get('TORCH_PROFILE'):
+    # which torch operators (and so which launches) does one step contain, with gradients handed over (p.grad = None)?
+    from torch.profiler import profile, ProfilerActivity
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def one_none(i):
+        for p in params:
+            p.grad = None
+        v = i % V
+        out = model.render(rs[v], time_id=v, background=background)
+        image_loss(out['images'], targets[v]).backward()
+        opt.step()
+
+    for i in range(5):
+        one_none(i)
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for i in range(10):
+            one_none(i)
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=45, max_name_column_width=70))
