@@ -425,3 +425,94 @@ class _DeformMLPFn(torch.autograd.Function):
             g_points = torch.empty((x0.shape[0], mlp.p_in), dtype=torch.float32, device=x0.device)
             run.input_grad(g_x0, x0, g_points)
         return (None, g_points, None) + tuple(grads)  # the time is an input, not a parameter
+
+
+class _SkeletonStageFn(torch.autograd.Function):
+    """The whole skeleton stage of a frame on the operator path -- deform network over the joints, ``normalize(raw + [0, 0, 0,
+    1])``, the kinematic chain (sk_gs.py:1069-1107) and the frame's row of the test-time cache (:1077-1079) -- as ONE launch
+    per direction (``skgs_skeleton_forward`` / ``skgs_skeleton_backward``: what ``FusedViewStep`` runs), instead of
+    ``_DeformMLPFn`` + three copies of its strided heads + ``skeleton._BoneChain`` + seven small torch launches for the cache
+    row + a ``select`` of the global transform and its backward.  Returns (bone_T [M,7], d_rot [M,4], d_scale [M,3])."""
+
+    @staticmethod
+    def forward(ctx, mlp: DeformMLP, joints: Tensor, t: Tensor, global_tr: Optional[Tensor], time_id: int, topo: dict,
+                cache_row: Optional[Tensor], *params):
+        _C._require_gpu(joints, 'joints')
+        net = mlp.dynamic_net
+        M = joints.shape[0]
+        ctx.need_points = joints.requires_grad
+        pts = joints.detach().float().contiguous()
+        tt = t.detach().float().reshape(-1).contiguous().to(pts.device)
+        f32 = dict(dtype=torch.float32, device=pts.device)
+        key = (M, pts.device.index, torch.cuda.current_stream().cuda_stream)
+        pool = _FUSED_POOLS.setdefault(mlp, {}).setdefault(key, [])
+        run = pool.pop() if pool else FusedDeformMLP(mlp, M)
+        heads = [torch.empty((M, oc), **f32) for oc in net.out_channels]
+        bone_T, chain_A = torch.empty((M, 7), **f32), torch.empty((M, 7), **f32)
+        b = _SkeletonStageFn._desc(pts, global_tr, time_id, topo)
+        b.bone_T, b.chain_A = bone_T.data_ptr(), chain_A.data_ptr()
+        b.sk_cache = cache_row.data_ptr() if cache_row is not None else None
+        run.forward(pts, tt, head_out=heads, bones=b)
+        ctx.mlp, ctx.run, ctx.pool, ctx.topo, ctx.time_id = mlp, run, pool, topo, time_id
+        ctx.pt = (pts, tt, global_tr.detach() if global_tr is not None else None, heads[0], chain_A)
+        return bone_T, heads[1], heads[2]
+
+    @staticmethod
+    def _desc(pts: Tensor, global_tr: Optional[Tensor], time_id: int, topo: dict) -> BoneChainDesc:
+        b = BoneChainDesc()
+        b.M, b.root, b.num_levels = pts.shape[0], topo['root'], topo['num_levels']
+        b.parents, b.level_nodes, b.level_start = (topo['parents'].data_ptr(), topo['level_nodes'].data_ptr(),
+                                                   topo['level_start'].data_ptr())
+        b.joints = pts.data_ptr()
+        b.global_T = global_tr[time_id].data_ptr() if global_tr is not None else None
+        b.frame_index = None
+        return b
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_bone_T, g_d_rot, g_d_scale):
+        mlp, run = ctx.mlp, ctx.run
+        net = mlp.dynamic_net
+        pts, tt, global_tr, sk_r_raw, chain_A = ctx.pt
+        M = pts.shape[0]
+        f32 = dict(dtype=torch.float32, device=pts.device)
+        params = [p for l in net.net for p in (l.weight, l.bias)] + [net.last_weight, net.last_bias]
+        grads = [torch.empty_like(p) for p in params]
+
+        def dense(g, oc):
+            return torch.zeros((M, oc), **f32) if g is None else g.float().contiguous()
+
+        g_heads = [torch.empty((M, net.out_channels[0]), **f32), dense(g_d_rot, net.out_channels[1]),
+                   dense(g_d_scale, net.out_channels[2])]  # (head 0's gradient is produced by the chain's backward)
+        g_x0 = torch.empty_like(run.x0) if ctx.need_points else None
+        g_joints = torch.empty((M, 3), **f32) if ctx.need_points else None
+        g_global = torch.zeros_like(global_tr) if (global_tr is not None and ctx.needs_input_grad[3]) else None
+        b = _SkeletonStageFn._desc(pts, global_tr, ctx.time_id, ctx.topo)
+        b.chain_A, b.sk_r_raw = chain_A.data_ptr(), sk_r_raw.data_ptr()
+        g_bT = dense(g_bone_T, 7)
+        b.g_bone_T = g_bT.data_ptr()
+        b.g_joints = g_joints.data_ptr() if g_joints is not None else None
+        b.g_global_T = g_global[ctx.time_id].data_ptr() if g_global is not None else None
+        run.backward(pts, tt, g_heads, grads, g_x0, bones=b)
+        if g_x0 is not None:  # joints also feed the network: + the frequency encoding's backward
+            DeformMLPRunner(mlp).input_grad(g_x0, run.x0, g_joints, accumulate=True)
+        ctx.run = None
+        if len(ctx.pool) < 4:
+            ctx.pool.append(run)
+        return (None, g_joints, None, g_global, None, None, None) + tuple(grads)
+
+
+def skeleton_stage(mlp: DeformMLP, joints: Tensor, t: Tensor, global_tr: Optional[Tensor], time_id: int, topo: dict,
+                   cache_row: Optional[Tensor] = None):
+    """(bone_T [M,7], d_rot [M,4], d_scale [M,3]) of a frame: deform network + kinematic chain in one launch per direction
+    (``_SkeletonStageFn``).  ``global_tr``: the [frames, 7] table (row ``time_id`` is used; its gradient comes back as a
+    table with that row filled) or None; ``cache_row``: where the launch writes [normalised joint rotation | d_rot |
+    d_scale] (the reference's ``sk_cache[time_id]``), or None."""
+    net = mlp.dynamic_net
+    params = [p for l in net.net for p in (l.weight, l.bias)] + [net.last_weight, net.last_bias]
+    return _SkeletonStageFn.apply(mlp, joints, t, global_tr, time_id, topo, cache_row, *params)
+
+
+def skeleton_stage_supported(mlp: 'DeformMLP', M: int) -> bool:
+    net = mlp.dynamic_net
+    return fused_supported(mlp, M) and tuple(net.out_channels) == (4, 4, 3) and not getattr(mlp, 'force_layered', False)

@@ -163,6 +163,13 @@ class SkinnedGaussians(nn.Module):
         return F.normalize(row[:, :4], dim=-1), row[:, 4:8], row[:, 8:11]
 
     def bone_transforms(self, time_id: int):
+        if self.sk_deform_net is not None and self.fused_bone_chain and self.joints.is_cuda:
+            from sk_gs_amd.deform_net import skeleton_stage, skeleton_stage_supported
+            if skeleton_stage_supported(self.sk_deform_net, self.joints.shape[0]):
+                # network + kinematic chain + the frame's cache row (sk_gs.py:1069-1107) in one launch per direction
+                refresh = self.training and torch.is_grad_enabled()
+                return skeleton_stage(self.sk_deform_net, self.joints, self.frame_times[time_id], self.global_tr, time_id,
+                                      self.topology(), self.sk_cache[time_id] if refresh else None)
         sk_r_raw, d_rot, d_scale = self.joint_outputs(time_id)
         if self.fused_bone_chain and self.joints.is_cuda:
             sk_T = skeleton.bone_chain(sk_r_raw, self.joints, self.global_tr[time_id], self.topology())

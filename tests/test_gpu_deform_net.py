@@ -315,3 +315,66 @@ def test_skeleton_stage_in_one_launch_per_direction(M):
     assert rel_err(gx2, gx1) <= 1e-5
     for i, (x, y) in enumerate(zip(grads2, grads1)):
         assert rel_err(x, y) <= 1e-5, i
+
+
+@pytest.mark.parametrize('M,learn_joints', [(20, True), (33, False)])
+def test_operator_path_skeleton_stage_function(M, learn_joints):
+    """``deform_net.skeleton_stage`` (what ``SkinnedGaussians.bone_transforms`` calls on the GPU: network + chain + cache row,
+    one launch per direction under one autograd node) against (a) the composed operator path it replaces -- ``DeformMLP``'s
+    Function, ``skeleton.bone_chain``, the torch expression of the cache row -- and (b) the plain-torch restatement
+    (``reference_forward`` + ``skeleton.kinematic``): outputs, the cache row, and every gradient (network, joints through the
+    chain AND through the network input, the frame's global transform; other frames' rows exactly zero)"""
+    from sk_gs_amd import skeleton
+    from sk_gs_amd.deform_net import skeleton_stage, skeleton_stage_supported
+    from sk_gs_amd.model import SkinnedGaussians
+    torch.manual_seed(1)
+    frames, tid = 3, 1
+    model = SkinnedGaussians(300, M, 4, sh_degree=0, num_frames=frames, seed=6, deform_net=True, learn_joints=learn_joints).cuda()
+    mlp = model.sk_deform_net
+    assert skeleton_stage_supported(mlp, M)
+    with torch.no_grad():
+        mlp.dynamic_net.last_weight.normal_(0, 0.3)
+        model.global_tr[tid] = torch.tensor([0.1, -0.2, 0.05, 0.1, 0.2, -0.1, 0.9])
+    g = torch.Generator().manual_seed(2)
+    gT, gr, gs = (torch.randn(M, n, generator=g).cuda() for n in (7, 4, 3))
+    params = dict(model.named_parameters())
+    names = [n for n in params if n.startswith('sk_deform_net')] + ['global_tr'] + (['joints'] if learn_joints else [])
+
+    def grads_of(fn):
+        for p in model.parameters():
+            p.grad = None
+        model.sk_cache.zero_()
+        bone_T, d_rot, d_scale = fn()
+        ((bone_T * gT).sum() + (d_rot * gr).sum() + (d_scale * gs).sum()).backward()
+        return (bone_T.detach(), d_rot.detach(), d_scale.detach(), model.sk_cache.clone(),
+                {n: params[n].grad.clone() for n in names})
+
+    def stage():
+        return skeleton_stage(mlp, model.joints, model.frame_times[tid], model.global_tr, tid, model.topology(), model.sk_cache[tid])
+
+    def composed():  # the operator path before: separate Functions + torch glue
+        r, d_rot, d_scale = model.joint_outputs(tid)
+        return skeleton.bone_chain(r, model.joints, model.global_tr[tid], model.topology()), d_rot, d_scale
+
+    def plain_torch():
+        r, d_rot, d_scale = mlp.reference_forward(model.joints, model.frame_times[tid])
+        with torch.no_grad():
+            model.sk_cache[tid] = torch.cat([F.normalize(r + model._rot_bias, dim=-1), d_rot, d_scale], dim=-1)
+        sk_r = F.normalize(r + model._rot_bias, dim=-1)
+        return skeleton.kinematic(model.joints, sk_r, model.global_tr[tid], model.joint_parents, model.joint_root,
+                                  (model._ident7, model._root_mask)), d_rot, d_scale
+
+    model.train()
+    a, b, c = grads_of(stage), grads_of(composed), grads_of(plain_torch)
+    for other, tol in ((b, 1e-5), (c, 2e-4)):
+        for i in range(3):
+            assert rel_err(a[i], other[i]) <= tol, i
+        assert rel_err(a[3][tid], other[3][tid]) <= tol and float(a[3][[0, 2]].abs().max()) == 0.0
+        for n in names:
+            assert rel_err(a[4][n], other[4][n]) <= tol, n
+    assert float(a[4]['global_tr'][[0, 2]].abs().max()) == 0.0
+    # model.bone_transforms takes this path, and leaves the cache alone outside training
+    model.sk_cache.zero_()
+    with torch.no_grad():
+        out = model.bone_transforms(tid)
+    assert rel_err(out[0], a[0]) <= 1e-6 and float(model.sk_cache.abs().max()) == 0.0
