@@ -171,7 +171,8 @@ def main():
                     help='world > 1 (implies --compact-logits): all-gather the two factors of the SH gradient per view (24 B '
                          'per Gaussian and rank) and rebuild the rows on every rank instead of all-reducing the dense SH '
                          'gradient (192 B per Gaussian)')
-    ap.add_argument('--exchange', choices=('auto', 'allreduce', 'factors', 'factors-overlap', 'pipeline'), default='auto',
+    ap.add_argument('--exchange', choices=('auto', 'allreduce', 'factors', 'factors-overlap', 'pipeline', 'allreduce-graph',
+                                           'factors-graph'), default='auto',
                     help='world > 1: how the gradients cross the wire.  auto (default, no other exchange flag given): time EVERY '
                          'variant in this process and report the fastest one whose replicas stayed bit-identical')
     ap.add_argument('--dense-spw-grad', action='store_true', help='(default since round 2; kept for old command lines)')
@@ -216,6 +217,10 @@ def main():
     ap.add_argument('--autograd', action='store_true',
                     help='run the step through the torch-autograd operator path (model.render + image_loss + backward) '
                          'instead of sk_gs_amd.fused_step.FusedViewStep (same kernels, no autograd glue)')
+    ap.add_argument('--graph-collectives', action='store_true',
+                    help='world > 1, RCCL backend: the exchange is captured INSIDE the step graph (one graph launch per step: '
+                         'forward + backward, the collectives on the comm stream as a branch of the graph, update) instead of '
+                         'two or three graphs with eagerly issued collectives between them')
     ap.add_argument('--backward-thread', choices=('caller', 'worker'), default='caller',
                     help="where torch autograd runs a backward (operator path only: ms/render and --autograd; the fused step "
                          "has no autograd in it).  'caller': sk_gs_amd.single_thread_backward(), what the install_as_* hooks "
@@ -565,6 +570,39 @@ def main():
                         reduce_grads()
                         g_opt.capture(0)
 
+        if use_dist and args.graph_collectives and not args.eager:
+            # ---- the collectives as nodes of the step graph (RCCL enqueues are capturable: probed with a 1-rank group on the
+            # build box).  ONE graph launch per step; with the factor exchange the all-gather is a branch that runs beside the
+            # skinning backward.  GraphedSteps.capture first RUNS the step for real (RCCL's lazy set-up happens there).
+            assert not pipelined, '--graph-collectives: not with --pipeline'
+            assert dist.get_backend() == 'nccl', '--graph-collectives needs the RCCL backend (a gloo collective synchronises the host)'
+            if overlap_gather:
+                def whole_step(v):
+                    fstep.backward_raster(*fb_args(v))
+                    wg = sh_ex.gather(async_op=True)
+                    fstep.backward_skinning(*sk_args(v))
+                    w = vp.allreduce(0, async_op=True)
+                    for h in (wg, w):
+                        if h is not None:
+                            h.wait()
+                    update()
+            else:
+                def whole_step(v):
+                    fwd_bwd(v)
+                    reduce_grads()
+                    update()
+            g_whole = GraphedSteps(whole_step)
+
+            def graph_step(i):  # noqa: F811
+                v = vp.view_index(i, args.views)
+                select(v)
+                g_whole(gkey(v))
+
+            def capture_all():  # noqa: F811
+                for v in capture_views:
+                    select(v)
+                    g_whole.capture(gkey(v))
+
         train_step = eager_step if args.eager else graph_step
 
         def rewind_views():
@@ -909,12 +947,17 @@ def main():
     # done where the xGMI links are (DESIGN.md section 6 holds the predicted table to read the record against).
     import copy
     import gc
-    explicit = args.pipeline or args.compact_logits or args.sh_factors or args.overlap_gather or args.exchange != 'auto'
+    explicit = (args.pipeline or args.compact_logits or args.sh_factors or args.overlap_gather or args.graph_collectives
+                or args.exchange != 'auto')
     variants = {
         'allreduce': dict(),
         'factors': dict(sh_factors=True, compact_logits=True),
         'factors-overlap': dict(sh_factors=True, compact_logits=True, overlap_gather=True),
         'pipeline': dict(pipeline=True),
+        # the same two exchanges with the collectives captured inside ONE step graph (last: a fabric on which a captured
+        # collective never completes costs only these two entries, see bail())
+        'allreduce-graph': dict(graph_collectives=True),
+        'factors-graph': dict(sh_factors=True, compact_logits=True, overlap_gather=True, graph_collectives=True),
     }
     if args.exchange != 'auto':
         for k_, v_ in variants[args.exchange].items():
@@ -964,7 +1007,7 @@ def main():
             have_one = any(v is not None for v in lines.values())
             timer = None
             if have_one:  # (the first variant -- the plain all-reduce -- runs unguarded: without it there is no record)
-                timer = threading.Timer(max(240.0, 8.0 * (t_first or 30.0)), bail, args=(name,))
+                timer = threading.Timer(max(180.0, 6.0 * (t_first or 30.0)), bail, args=(name,))
                 timer.daemon = True
                 timer.start()
             t_v = time.perf_counter()
@@ -998,9 +1041,9 @@ def main():
     else:
         line = run_workload(args)
         if rank == 0:
-            line['config']['exchange'] = ('pipeline' if args.pipeline else 'factors-overlap' if args.overlap_gather else
-                                          'factors' if args.sh_factors else 'compact-logits' if args.compact_logits else
-                                          'allreduce') if world > 1 else None
+            line['config']['exchange'] = (('pipeline' if args.pipeline else 'factors-overlap' if args.overlap_gather else
+                                           'factors' if args.sh_factors else 'compact-logits' if args.compact_logits else
+                                           'allreduce') + ('-graph' if args.graph_collectives else '')) if world > 1 else None
             os.write(json_fd, (json.dumps(line) + '\n').encode())
     if use_dist:
         dist.barrier()
