@@ -28,6 +28,13 @@ for c in 2 3 4; do
 done
 SKGS_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29542 bench.py --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline --no-ms-per-render --pre-forward off 2>/dev/null | tail -1 > $out/bench_rccl_1rank_pre-forward-off.json
 python -c "import json; d=json.load(open('$out/bench_rccl_1rank_pre-forward-off.json')); print('1-rank RCCL group --pre-forward off', d['value'], d['ms_per_step'])"
+# per-rank cost of every exchange variant of the multi-rank step: the real RCCL backend with a 1-rank group (one GPU here)
+port=29560
+for x in allreduce factors factors-overlap pipeline allreduce-graph factors-graph; do
+  port=$((port+1))
+  SKGS_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port $port bench.py --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline --no-ms-per-render --exchange $x 2>/dev/null | tail -1 > $out/bench_rccl_1rank_exchange_$x.json
+  python -c "import json; d=json.load(open('$out/bench_rccl_1rank_exchange_$x.json')); print('1-rank RCCL group --exchange $x', d['value'], d['ms_per_step'])"
+done
 for c in 1 3; do
   python bench.py --config $c --steps 400 --warmup 50 --no-cpu-baseline --no-ms-per-render --densify-every 100 2>/dev/null | tail -1 > $out/bench_config${c}_densify-every-100.json
   python -c "import json; d=json.load(open('$out/bench_config${c}_densify-every-100.json')); print('config $c --densify-every 100', d['value'], d['ms_per_step'], d['densify']['ms'], d['densify']['P'], 'graphs', d['densify']['graphs_captured'])"
