@@ -104,7 +104,7 @@ class DeformMLP(nn.Module):
     def forward(self, points: Tensor, t: Tensor) -> List[Tensor]:
         net = self.dynamic_net
         params = [p for l in net.net for p in (l.weight, l.bias)] + [net.last_weight, net.last_bias]
-        out = _DeformMLPFn.apply(self, points, t, *params)
+        out = _DeformMLPFn.apply(self, torch.is_grad_enabled(), points, t, *params)
         return list(out.split(net.out_channels, dim=-1))
 
 
@@ -365,7 +365,7 @@ _FUSED_POOLS = weakref.WeakKeyDictionary()  # DeformMLP -> {(rows, device, strea
 
 class _DeformMLPFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mlp: DeformMLP, points: Tensor, t: Tensor, *params):
+    def forward(ctx, mlp: DeformMLP, track: bool, points: Tensor, t: Tensor, *params):
         _C._require_gpu(points, 'points')
         net = mlp.dynamic_net
         ctx.need_points = points.requires_grad  # joints trained through the network input (sk_gs.py:604-607)
@@ -384,6 +384,11 @@ class _DeformMLPFn(torch.autograd.Function):
             # would be a reference cycle that keeps the whole autograd graph (and its AccumulateGrad nodes, bound to the
             # stream of THIS call) alive until the next gc -- which breaks a later hipGraph capture of the step
             out = run.forward(points, t, out=torch.empty_like(run.out))
+            if not (track and any(ctx.needs_input_grad)):  # inference (no_grad): no backward will hand the runner back
+                ctx.fused = None
+                if len(pool) < 4:
+                    pool.append(run)
+                return out
             ctx.mlp, ctx.fused, ctx.pt = mlp, run, (points, t)
             return out
         ctx.fused = None
@@ -415,7 +420,7 @@ class _DeformMLPFn(torch.autograd.Function):
             ctx.fused = None
             if len(ctx.pool) < 4:
                 ctx.pool.append(run)  # (same stream: the next forward's launches are ordered behind this backward's)
-            return (None, g_points, None) + tuple(grads)
+            return (None, None, g_points, None) + tuple(grads)
         x0, acts, out = ctx.saved_tensors
         g_act = torch.empty((2,) + tuple(acts.shape[1:]), dtype=torch.float32, device=acts.device)
         g_x0 = torch.empty_like(x0) if ctx.need_points else None
@@ -424,7 +429,7 @@ class _DeformMLPFn(torch.autograd.Function):
         if g_x0 is not None:
             g_points = torch.empty((x0.shape[0], mlp.p_in), dtype=torch.float32, device=x0.device)
             run.input_grad(g_x0, x0, g_points)
-        return (None, g_points, None) + tuple(grads)  # the time is an input, not a parameter
+        return (None, None, g_points, None) + tuple(grads)  # the time is an input, not a parameter
 
 
 class _SkeletonStageFn(torch.autograd.Function):
@@ -435,8 +440,8 @@ class _SkeletonStageFn(torch.autograd.Function):
     row + a ``select`` of the global transform and its backward.  Returns (bone_T [M,7], d_rot [M,4], d_scale [M,3])."""
 
     @staticmethod
-    def forward(ctx, mlp: DeformMLP, joints: Tensor, t: Tensor, global_tr: Optional[Tensor], time_id: int, topo: dict,
-                cache_row: Optional[Tensor], *params):
+    def forward(ctx, mlp: DeformMLP, track: bool, joints: Tensor, t: Tensor, global_tr: Optional[Tensor], time_id: int,
+                topo: dict, cache_row: Optional[Tensor], *params):
         _C._require_gpu(joints, 'joints')
         net = mlp.dynamic_net
         M = joints.shape[0]
@@ -453,6 +458,10 @@ class _SkeletonStageFn(torch.autograd.Function):
         b.bone_T, b.chain_A = bone_T.data_ptr(), chain_A.data_ptr()
         b.sk_cache = cache_row.data_ptr() if cache_row is not None else None
         run.forward(pts, tt, head_out=heads, bones=b)
+        if not (track and any(ctx.needs_input_grad)):  # inference (no_grad): no backward will hand the runner back
+            if len(pool) < 4:
+                pool.append(run)
+            return bone_T, heads[1], heads[2]
         ctx.mlp, ctx.run, ctx.pool, ctx.topo, ctx.time_id = mlp, run, pool, topo, time_id
         ctx.pt = (pts, tt, global_tr.detach() if global_tr is not None else None, heads[0], chain_A)
         return bone_T, heads[1], heads[2]
@@ -486,7 +495,7 @@ class _SkeletonStageFn(torch.autograd.Function):
                    dense(g_d_scale, net.out_channels[2])]  # (head 0's gradient is produced by the chain's backward)
         g_x0 = torch.empty_like(run.x0) if ctx.need_points else None
         g_joints = torch.empty((M, 3), **f32) if ctx.need_points else None
-        g_global = torch.zeros_like(global_tr) if (global_tr is not None and ctx.needs_input_grad[3]) else None
+        g_global = torch.zeros_like(global_tr) if (global_tr is not None and ctx.needs_input_grad[4]) else None
         b = _SkeletonStageFn._desc(pts, global_tr, ctx.time_id, ctx.topo)
         b.chain_A, b.sk_r_raw = chain_A.data_ptr(), sk_r_raw.data_ptr()
         g_bT = dense(g_bone_T, 7)
@@ -499,7 +508,7 @@ class _SkeletonStageFn(torch.autograd.Function):
         ctx.run = None
         if len(ctx.pool) < 4:
             ctx.pool.append(run)
-        return (None, g_joints, None, g_global, None, None, None) + tuple(grads)
+        return (None, None, g_joints, None, g_global, None, None, None) + tuple(grads)
 
 
 def skeleton_stage(mlp: DeformMLP, joints: Tensor, t: Tensor, global_tr: Optional[Tensor], time_id: int, topo: dict,
@@ -510,7 +519,7 @@ def skeleton_stage(mlp: DeformMLP, joints: Tensor, t: Tensor, global_tr: Optiona
     d_scale] (the reference's ``sk_cache[time_id]``), or None."""
     net = mlp.dynamic_net
     params = [p for l in net.net for p in (l.weight, l.bias)] + [net.last_weight, net.last_bias]
-    return _SkeletonStageFn.apply(mlp, joints, t, global_tr, time_id, topo, cache_row, *params)
+    return _SkeletonStageFn.apply(mlp, torch.is_grad_enabled(), joints, t, global_tr, time_id, topo, cache_row, *params)
 
 
 def skeleton_stage_supported(mlp: 'DeformMLP', M: int) -> bool:

@@ -378,3 +378,36 @@ def test_operator_path_skeleton_stage_function(M, learn_joints):
     with torch.no_grad():
         out = model.bone_transforms(tid)
     assert rel_err(out[0], a[0]) <= 1e-6 and float(model.sk_cache.abs().max()) == 0.0
+
+
+def test_inference_forwards_reuse_one_fused_runner():
+    """under no_grad no backward ever hands a runner (exchange workspace, activations) back: the forward returns it itself,
+    so an inference loop (the FPS protocol) does not build and initialise a new one per call"""
+    from sk_gs_amd import deform_net
+    from sk_gs_amd.model import SkinnedGaussians
+    model = SkinnedGaussians(200, 20, 4, sh_degree=0, num_frames=2, seed=2, deform_net=True, learn_joints=True).cuda()
+    built = []
+    orig = deform_net.FusedDeformMLP.__init__
+
+    def counting(self, *a, **k):
+        built.append(1)
+        orig(self, *a, **k)
+    deform_net.FusedDeformMLP.__init__ = counting
+    try:
+        with torch.no_grad():
+            ref = model.bone_transforms(1)[0].clone()
+            for _ in range(5):
+                out = model.bone_transforms(1)[0]
+                heads = model.sk_deform_net(model.joints, model.frame_times[1])
+        assert len(built) == 1, built
+        assert torch.equal(out, ref) and len(heads) == 3
+        # with gradients on, a runner stays out until its backward has run
+        a = model.bone_transforms(1)[0]
+        b = model.bone_transforms(0)[0]
+        (a.sum() + b.sum()).backward()
+        assert len(built) == 2
+        c = model.bone_transforms(1)[0]
+        c.sum().backward()
+        assert len(built) == 2
+    finally:
+        deform_net.FusedDeformMLP.__init__ = orig
