@@ -272,23 +272,35 @@ class FusedDeformMLP:
 
     def _desc(self, grads: Optional[Sequence[Tensor]], head_out: Optional[Sequence[Tensor]] = None,
               head_gout: Optional[Sequence[Tensor]] = None) -> _MlpDesc:
+        """the launch descriptor.  Its static part (shapes, weight and bias addresses) is built once and kept for as long as
+        the parameters stay where they are (filling ~100 ctypes fields per call was a third of the operator path's skeleton
+        stage); gradient and head addresses are patched in per call"""
         m, net = self.mlp, self.mlp.dynamic_net
-        d = _MlpDesc()
-        d.B, d.p_dim, d.p_degree, d.t_dim, d.t_degree = self.B, m.p_in, m.p_degree, m.t_in, m.t_degree
-        d.hidden, d.n_layers = net.dim_hidden, net.num_layers + 1
-        dims = net.layer_dims()
-        params = [(l.weight, l.bias) for l in net.net] + [(net.last_weight, net.last_bias)]
-        for i, ((w, b), (in1, in2)) in enumerate(zip(params, dims)):
-            assert w.is_contiguous() and b.is_contiguous() and w.dtype == torch.float32
-            L = d.layer[i]
-            L.W, L.bias = w.data_ptr(), b.data_ptr()
-            L.in_hidden, L.in_x0 = (0, in1) if i == 0 else (in1, in2)
-            L.out, L.relu = w.shape[0], int(i < net.num_layers)
-            if grads is not None:
-                gw, gb = grads[2 * i], grads[2 * i + 1]
+        flat = getattr(self, '_flat_params', None)
+        if flat is None:
+            flat = self._flat_params = [p for l in net.net for p in (l.weight, l.bias)] + [net.last_weight, net.last_bias]
+        key = tuple(p.data_ptr() for p in flat)
+        d = getattr(self, '_desc_cache', None)
+        if d is None or self._desc_key != key:
+            d = _MlpDesc()
+            d.B, d.p_dim, d.p_degree, d.t_dim, d.t_degree = self.B, m.p_in, m.p_degree, m.t_in, m.t_degree
+            d.hidden, d.n_layers = net.dim_hidden, net.num_layers + 1
+            dims = net.layer_dims()
+            for i, (in1, in2) in enumerate(dims):
+                w, b = flat[2 * i], flat[2 * i + 1]
+                assert w.is_contiguous() and b.is_contiguous() and w.dtype == torch.float32
+                L = d.layer[i]
+                L.W, L.bias = w.data_ptr(), b.data_ptr()
+                L.in_hidden, L.in_x0 = (0, in1) if i == 0 else (in1, in2)
+                L.out, L.relu = w.shape[0], int(i < net.num_layers)
+            self._desc_cache, self._desc_key = d, key
+        if grads is not None:
+            for i in range(d.n_layers):
+                gw, gb, w, b = grads[2 * i], grads[2 * i + 1], flat[2 * i], flat[2 * i + 1]
                 assert gw.is_contiguous() and gb.is_contiguous() and gw.shape == w.shape and gb.shape == b.shape
-                L.gW, L.gb = gw.data_ptr(), gb.data_ptr()
+                d.layer[i].gW, d.layer[i].gb = gw.data_ptr(), gb.data_ptr()
         heads = head_out if head_out is not None else head_gout
+        d.n_heads = 0
         if heads is not None:  # the heads as separate [B, dim] tensors (sk_r | d_rot | d_scale)
             assert len(heads) == len(net.out_channels) <= 4
             d.n_heads = len(heads)
@@ -296,6 +308,7 @@ class FusedDeformMLP:
                 assert h.is_cuda and h.is_contiguous() and h.dtype == torch.float32 and tuple(h.shape) == (self.B, oc)
                 d.head_dim[j] = oc
                 (d.head_out if head_out is not None else d.head_gout)[j] = h.data_ptr()
+                (d.head_gout if head_out is not None else d.head_out)[j] = None  # (nothing of an earlier call stays behind)
         return d
 
     def forward(self, points: Tensor, t: Tensor, head_out: Optional[Sequence[Tensor]] = None,
