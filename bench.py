@@ -172,7 +172,7 @@ def main():
                          'per Gaussian and rank) and rebuild the rows on every rank instead of all-reducing the dense SH '
                          'gradient (192 B per Gaussian)')
     ap.add_argument('--exchange', choices=('auto', 'allreduce', 'factors', 'factors-overlap', 'pipeline', 'allreduce-graph',
-                                           'factors-graph'), default='auto',
+                                           'factors-graph', 'factors-graph-split'), default='auto',
                     help='world > 1: how the gradients cross the wire.  auto (default, no other exchange flag given): time EVERY '
                          'variant in this process and report the fastest one whose replicas stayed bit-identical')
     ap.add_argument('--dense-spw-grad', action='store_true', help='(default since round 2; kept for old command lines)')
@@ -217,6 +217,10 @@ def main():
     ap.add_argument('--autograd', action='store_true',
                     help='run the step through the torch-autograd operator path (model.render + image_loss + backward) '
                          'instead of sk_gs_amd.fused_step.FusedViewStep (same kernels, no autograd glue)')
+    ap.add_argument('--split-rest', action='store_true',
+                    help='with --sh-factors --overlap-gather --graph-collectives: the all-reduce of everything but the SH factors in '
+                         'two pieces -- the per-Gaussian rows (final after the skinning backward launch) go on the wire beside the '
+                         'skeleton backward, the network / joints / tables after it')
     ap.add_argument('--graph-collectives', action='store_true',
                     help='world > 1, RCCL backend: the exchange is captured INSIDE the step graph (one graph launch per step: '
                          'forward + backward, the collectives on the comm stream as a branch of the graph, update) instead of '
@@ -294,6 +298,7 @@ def main():
         compact = fused_dist and (pipelined or args.compact_logits or args.sh_factors)
         sh_factored = compact and not pipelined and args.sh_factors
         groups = model.param_groups(lr=args.lr)
+        split_rest = bool(sh_factored and args.split_rest)
         if compact:
             # the dense [P,M] sp_W gradient never goes on the wire: the ranks all-reduce the compact [P,K] logit gradient
             # (their KNN indices are identical) and expand it afterwards
@@ -308,15 +313,19 @@ def main():
             fac_local = fac_all = None
             if pipelined:
                 vp = BucketedGradReducer([bucket0, bucket1], extras=[0, P * model.K])
+            elif split_rest:
+                rows_b = [model._xyz, model._scaling, model._rotation, model._opacity]
+                vp = BucketedGradReducer([rows_b, [t for t in bucket1 if all(t is not r for r in rows_b)]], extras=[P * model.K, 0])
             elif sh_factored:
                 vp = BucketedGradReducer([bucket1], extras=[P * model.K])
+            else:
+                vp = BucketedGradReducer([bucket0 + bucket1], extras=[P * model.K])
+            if sh_factored:
                 for p_ in bucket0:  # not on the wire: plain gradient tensors, rebuilt from the gathered factors
                     p_.grad = torch.zeros_like(p_)
                 from sk_gs_amd.view_parallel import ShFactorExchange
                 sh_ex = ShFactorExchange(P, dev)
                 fac_all, fac_local = sh_ex.all, sh_ex.local
-            else:
-                vp = BucketedGradReducer([bucket0 + bucket1], extras=[P * model.K])
             comm_bytes = vp.nbytes + (fac_all.numel() * 4 if sh_factored else 0)
         else:
             vp = ViewParallel(model.parameters(), average=True)
@@ -362,7 +371,8 @@ def main():
             from sk_gs_amd.fused_step import FusedViewStep
             fstep = FusedViewStep(model, W, H, capacity=int(R_max * 1.25 * _C.config.capacity_growth) + 1024,
                                   background=background, grad_scale=1.0 / world,
-                                  spw_logit_grad=vp.extra_views[-1] if compact else None, tile_bucket=tile_bucket,
+                                  spw_logit_grad=next(e for e in vp.extra_views if e is not None) if compact else None,
+                                  tile_bucket=tile_bucket,
                                   sh_factors=fac_local if sh_factored else None, fused_deform_net=not args.layered_mlp,
                                   view_table=view_table, densify_stats=bool(densify_every))
             # the per-frame table gradients (one row written per step) are cleared by the Adam launch itself
@@ -449,11 +459,12 @@ def main():
 
             def reduce_grads():
                 if compact:
-                    w = vp.allreduce(0, async_op=sh_factored)
+                    ws = [vp.allreduce(i, async_op=sh_factored) for i in range(len(vp.bucket_views))]
                     if sh_factored:  # every rank's (direction, colour gradient) pairs; own slice already in place
                         sh_ex.gather()
-                        if w is not None:
-                            w.wait()
+                        for w in ws:
+                            if w is not None:
+                                w.wait()
                 else:
                     vp.allreduce_grads(prescaled=prescaled)
 
@@ -576,7 +587,19 @@ def main():
             # skinning backward.  GraphedSteps.capture first RUNS the step for real (RCCL's lazy set-up happens there).
             assert not pipelined, '--graph-collectives: not with --pipeline'
             assert dist.get_backend() == 'nccl', '--graph-collectives needs the RCCL backend (a gloo collective synchronises the host)'
-            if overlap_gather:
+            if overlap_gather and split_rest:
+                def whole_step(v):
+                    fstep.backward_raster(*fb_args(v))
+                    wg = sh_ex.gather(async_op=True)                  # | beside everything up to the update
+                    fstep.backward_skinning(*sk_args(v), part='rows')
+                    w0 = vp.allreduce(0, async_op=True)               # | rows + compact logits: beside the skeleton backward
+                    fstep.backward_skinning(*sk_args(v), part='skeleton')
+                    w1 = vp.allreduce(1, async_op=True)               # network, joints, tables: the exposed piece
+                    for h in (wg, w0, w1):
+                        if h is not None:
+                            h.wait()
+                    update()
+            elif overlap_gather:
                 def whole_step(v):
                     fstep.backward_raster(*fb_args(v))
                     wg = sh_ex.gather(async_op=True)
@@ -947,7 +970,7 @@ def main():
     # done where the xGMI links are (DESIGN.md section 6 holds the predicted table to read the record against).
     import copy
     import gc
-    explicit = (args.pipeline or args.compact_logits or args.sh_factors or args.overlap_gather or args.graph_collectives
+    explicit = (args.pipeline or args.compact_logits or args.sh_factors or args.overlap_gather or args.graph_collectives or args.split_rest
                 or args.exchange != 'auto')
     variants = {
         'allreduce': dict(),
@@ -958,6 +981,8 @@ def main():
         # collective never completes costs only these two entries, see bail())
         'allreduce-graph': dict(graph_collectives=True),
         'factors-graph': dict(sh_factors=True, compact_logits=True, overlap_gather=True, graph_collectives=True),
+        'factors-graph-split': dict(sh_factors=True, compact_logits=True, overlap_gather=True, graph_collectives=True,
+                                    split_rest=True),
     }
     if args.exchange != 'auto':
         for k_, v_ in variants[args.exchange].items():
@@ -1043,7 +1068,7 @@ def main():
         if rank == 0:
             line['config']['exchange'] = (('pipeline' if args.pipeline else 'factors-overlap' if args.overlap_gather else
                                            'factors' if args.sh_factors else 'compact-logits' if args.compact_logits else
-                                           'allreduce') + ('-graph' if args.graph_collectives else '')) if world > 1 else None
+                                           'allreduce') + ('-graph' if args.graph_collectives else '') + ('-split' if args.split_rest else '')) if world > 1 else None
             os.write(json_fd, (json.dumps(line) + '\n').encode())
     if use_dist:
         dist.barrier()

@@ -419,11 +419,22 @@ class FusedViewStep:
             _p(all_factors), _p(m._features_dc.grad), _p(m._features_rest.grad), _C._stream()))
 
     @torch.no_grad()
-    def backward_skinning(self, time_id: Optional[int] = None):
+    def backward_skinning(self, time_id: Optional[int] = None, part: Optional[str] = None):
         """second half: skinning backward (Gaussian parameters' gradients written in place), LBS logits, bone chain.
         With ``spw_logit_grad`` set, the logit gradient is left compact ([P,K], for the all-reduce) and
-        ``scatter_spw_grad`` expands it into ``sp_W.grad`` later."""
+        ``scatter_spw_grad`` expands it into ``sp_W.grad`` later.  ``part`` (fused network, ``lbs_method='W'``, K <= the fused
+        limit): ``'rows'`` runs only the per-Gaussian launch -- on return the gradients of xyz / scaling / rotation / opacity and
+        the LBS logits are final, a view-parallel step can put them on the wire -- and ``'skeleton'`` the rest (network,
+        kinematic chain, joints, per-frame tables)."""
         lib, m, st, chk = self.lib, self.model, _C._stream(), _C._check
+        assert part in (None, 'rows', 'skeleton')
+        if part is not None:
+            assert self.lbs_method == 'W' and not self.wide and self._mlp_fused is not None, \
+                'backward_skinning(part=...): the one-launch skinning backward and the fused skeleton stage'
+        if part == 'skeleton':
+            self._time_id = time_id
+            self._deform_net_backward()
+            return
         t = self._topo
         P, M, K = self.P, self.M, self.K
         d = self._deform_inputs(time_id)
@@ -450,6 +461,8 @@ class FusedViewStep:
                 _p(m._xyz.grad), _p(m._scaling.grad), _p(m._rotation.grad), _p(m._opacity.grad),
                 _p(m.sp_W.grad) if dense else None, None if dense else _p(self.spw_logit_grad), _p(self.deform_ws),
                 C.c_size_t(self.deform_ws.numel()), st))
+            if part == 'rows':
+                return
         else:
             chk(lib.skgs_lbs_deform_backward(
                 C.byref(d), _p(self.g_means), _p(self.g_scales), _p(self.g_rotations), _p(self.g_opacity),

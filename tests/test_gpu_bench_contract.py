@@ -89,10 +89,11 @@ def test_default_multi_rank_run_ranks_every_exchange_variant(port, ranks):
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     ev = d['exchange_variants']
-    assert set(ev) == {'allreduce', 'factors', 'factors-overlap', 'pipeline', 'allreduce-graph', 'factors-graph'}, ev
+    assert set(ev) == {'allreduce', 'factors', 'factors-overlap', 'pipeline', 'allreduce-graph', 'factors-graph',
+                       'factors-graph-split'}, ev
     # the two variants with the collectives captured inside the step graph need RCCL: over gloo (this test shares one GPU
     # between the ranks) they must fail cleanly on every rank and cost nothing but their entry
-    for name in ('allreduce-graph', 'factors-graph'):
+    for name in ('allreduce-graph', 'factors-graph', 'factors-graph-split'):
         assert 'RCCL backend' in ev.pop(name)['error']
     for name, r in ev.items():
         assert 'error' not in r and r['replicas_identical'] is True, (name, r)
@@ -154,15 +155,16 @@ def test_two_rank_training_with_densification_keeps_the_replicas_identical():
     assert 'replicas identical: True' in p.stdout, p.stdout[-1500:]
 
 
-@pytest.mark.parametrize('port,exchange', [(29597, 'allreduce-graph'), (29598, 'factors-graph')])
+@pytest.mark.parametrize('port,exchange', [(29597, 'allreduce-graph'), (29598, 'factors-graph'), (29599, 'factors-graph-split')])
 def test_collectives_captured_inside_the_step_graph_one_rank_rccl(port, exchange):
     """`--exchange allreduce-graph / factors-graph`: the RCCL collectives are nodes of the ONE step graph (the factor
-    all-gather as a branch beside the skinning backward).  One GPU holds one RCCL rank, so this runs the real backend with a
+    all-gather as a branch beside the skinning backward; `-split`: the rows' all-reduce beside the skeleton backward).  One GPU holds one RCCL rank, so this runs the real backend with a
     1-rank group: capture, replays, the update path of the multi-rank step; the result must train like the eager-collective
     form of the same exchange"""
     env = dict(os.environ, SKGS_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     out = {}
-    for k, x in enumerate((exchange, exchange.replace('-graph', '') if exchange != 'factors-graph' else 'factors-overlap')):
+    eager_form = {'allreduce-graph': 'allreduce', 'factors-graph': 'factors-overlap', 'factors-graph-split': 'factors-overlap'}
+    for k, x in enumerate((exchange, eager_form[exchange])):
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
                '--master-port', str(port + 10 * k), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '12', '--warmup', '3',
                '--no-cpu-baseline', '--no-ms-per-render', '--exchange', x]

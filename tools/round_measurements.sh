@@ -30,7 +30,7 @@ SKGS_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 
 python -c "import json; d=json.load(open('$out/bench_rccl_1rank_pre-forward-off.json')); print('1-rank RCCL group --pre-forward off', d['value'], d['ms_per_step'])"
 # per-rank cost of every exchange variant of the multi-rank step: the real RCCL backend with a 1-rank group (one GPU here)
 port=29560
-for x in allreduce factors factors-overlap pipeline allreduce-graph factors-graph; do
+for x in allreduce factors factors-overlap pipeline allreduce-graph factors-graph factors-graph-split; do
   port=$((port+1))
   SKGS_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port $port bench.py --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline --no-ms-per-render --exchange $x 2>/dev/null | tail -1 > $out/bench_rccl_1rank_exchange_$x.json
   python -c "import json; d=json.load(open('$out/bench_rccl_1rank_exchange_$x.json')); print('1-rank RCCL group --exchange $x', d['value'], d['ms_per_step'])"
