@@ -168,6 +168,7 @@ __global__ void __launch_bounds__(BIN_THREADS) count_tiles_lds_kernel(int P, int
   }
 }
 
+template <int LPG>  // lanes per Gaussian of the two tile walks
 __global__ void __launch_bounds__(BIN_THREADS) scatter_lds_kernel(int P, int gx, int gy, int T, const float4* __restrict__ recs,
     const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursors, uint64_t* __restrict__ keys, int64_t capacity,
     GeomHeader* hdr, int bucket /* 0: compact lists at offsets[]; > 0: tile t owns slots [t * bucket, (t + 1) * bucket) */) {
@@ -602,6 +603,23 @@ int launch_scan_tiles(GeomView g, ImgView im, int64_t P, hipStream_t s) {
   return 0;
 }
 
+// Lanes per Gaussian of the scatter launch.  The kernel is a chain of dependent memory round trips -- 73 % of its wave time is
+// spent in s_waitcnt (tools/pmc_kernel.sh) -- and every grid-stride iteration of its two passes is one of them: P * LPG lanes
+// over 256 x 1024 threads are 6 iterations per pass at 100k Gaussians with 16 lanes each, 1.5 with 4.  Sixteen lanes pay only
+// when splats cover many tiles (the inner walk of a splat is LPG-strided); the capacity of the tile lists per Gaussian bounds
+// the average number of tiles a Gaussian touches.  Measured (scatter launch, config #1 / #3 / #4): 21.7 / 42.0 / 65.1 us with 16
+// lanes, 16.1 / 27.2 / 42.7 with 4 (2: the same, 1: 20.2 at #1); dense scenes (x4 scales, 38 tiles per Gaussian) do not care.
+// SKGS_SCATTER_LPG overrides (4 / 8 / 16).
+static int scatter_lanes(int P, int T, int bucket, int64_t capacity) {
+  static const int forced = [] {
+    const char* e = getenv("SKGS_SCATTER_LPG");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 4 || forced == 8 || forced == 16) return forced;
+  const double slots_per_gaussian = (bucket > 0 ? (double) T * bucket : (double) capacity) / (double) (P > 0 ? P : 1);
+  return slots_per_gaussian <= 24.0 ? 4 : slots_per_gaussian <= 64.0 ? 8 : 16;
+}
+
 int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, BinView b, hipStream_t s) {
   const int P = in.P;
   if (P == 0) return 0;
@@ -609,10 +627,17 @@ int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, Bi
   {
     ProfScope prof(K_SCATTER, s);
     const int64_t lanes = (int64_t) P * LPG;
-    if (im.T <= BIN_LDS_TILES)
-      hipLaunchKernelGGL(scatter_lds_kernel, dim3(bin_groups()), dim3(BIN_THREADS), (size_t) im.T * 8, s, P, im.tiles_x,
-          im.tiles_y, im.T, g.recs, im.tile_offsets, im.cursors, b.keys, b.capacity, g.hdr, bucket);
-    else
+    if (im.T <= BIN_LDS_TILES) {
+#define SKGS_SCATTER(L)                                                                                                   \
+  hipLaunchKernelGGL(scatter_lds_kernel<L>, dim3(bin_groups()), dim3(BIN_THREADS), (size_t) im.T * 8, s, P, im.tiles_x, \
+      im.tiles_y, im.T, g.recs, im.tile_offsets, im.cursors, b.keys, b.capacity, g.hdr, bucket)
+      switch (scatter_lanes(P, im.T, bucket, b.capacity)) {
+        case 4: SKGS_SCATTER(4); break;
+        case 8: SKGS_SCATTER(8); break;
+        default: SKGS_SCATTER(16); break;
+      }
+#undef SKGS_SCATTER
+    } else
       hipLaunchKernelGGL(scatter_kernel, dim3((unsigned) ((lanes + 255) / 256)), dim3(256), 0, s, P, im.tiles_x, im.tiles_y,
           g.recs, im.tile_offsets, im.cursors, b.keys, b.capacity, g.hdr, bucket);
   }

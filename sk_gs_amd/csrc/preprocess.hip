@@ -307,14 +307,28 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
     tan_fovx = tanfov_dev[0], tan_fovy = tanfov_dev[1];
     focal_x = W / (2.0f * tan_fovx), focal_y = H / (2.0f * tan_fovy);
   }
-  __shared__ Cam cam;
-  if (threadIdx.x < 16) {
-    cam.view[threadIdx.x] = viewmatrix[threadIdx.x];
-    cam.proj[threadIdx.x] = projmatrix[threadIdx.x];
-  }
-  if (threadIdx.x < 3) cam.campos[threadIdx.x] = campos[threadIdx.x];
-  __syncthreads();
+  // Every per-Gaussian input of the lane is requested HERE, before the camera and the SH rows are staged: the kernel runs at
+  // 1.5 waves per SIMD and 64 % of its wave time was spent in s_waitcnt (tools/pmc_kernel.sh) on a chain of four dependent
+  // round trips -- camera, SH staging, mean, then scale / rotation / opacity behind the cull test.  Now they are one.  (Rows up
+  // to the capacity exist; a lane behind it reads row 0 and uses nothing.)
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ld  = idx < P_cap ? idx : 0;
+  const float pf_p[3] = {means3D[3 * ld], means3D[3 * ld + 1], means3D[3 * ld + 2]};
+  const float pf_op   = opacities[ld];
+  float pf_s[3] = {0.f, 0.f, 0.f}, pf_c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pf_col[3] = {0.f, 0.f, 0.f};
+  float4 pf_q = make_float4(0.f, 0.f, 0.f, 1.f);
+  if (cov3D_precomp != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pf_c6[i] = cov3D_precomp[6 * ld + i];
+  } else {
+    pf_s[0] = scales[3 * ld], pf_s[1] = scales[3 * ld + 1], pf_s[2] = scales[3 * ld + 2];
+    pf_q    = reinterpret_cast<const float4*>(rotations)[ld];
+  }
+  if (colors_precomp != nullptr)
+    pf_col[0] = colors_precomp[3 * ld], pf_col[1] = colors_precomp[3 * ld + 1], pf_col[2] = colors_precomp[3 * ld + 2];
+  __shared__ Cam cam;  // (its three loads ride in the same round trip; stored to LDS behind the SH rows, ONE barrier for both)
+  const float cam_v = threadIdx.x < 16 ? viewmatrix[threadIdx.x] : 0.f, cam_p = threadIdx.x < 16 ? projmatrix[threadIdx.x] : 0.f;
+  const float cam_c = threadIdx.x < 3 ? campos[threadIdx.x] : 0.f;
   // the per-tile counters of the next kernel (binning.hip: count_tiles) start from zero: cleared here, not by a fill launch
   for (int t = idx; t < gx * gy; t += gridDim.x * blockDim.x) tile_counts[t] = 0u;
   if (hdr_bucket && idx == 0) {  // no scan kernel in the bucket layout: R and the longest list are not computed
@@ -344,8 +358,10 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
       stage_rows_in(s_sh, shs + (size_t) base * RL, nrows, RL);
       my_dc = my_sh = s_sh + threadIdx.x * sh_pitch(RL);
     }
-    __syncthreads();
   }
+  if (threadIdx.x < 16) cam.view[threadIdx.x] = cam_v, cam.proj[threadIdx.x] = cam_p;
+  if (threadIdx.x < 3) cam.campos[threadIdx.x] = cam_c;
+  __syncthreads();
   if (idx >= P) {
     if (idx < P_cap) {
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -359,7 +375,7 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
   int radius = 0;
   uint32_t clamp_bits = 0;
   int mn[2] = {0, 0}, mx[2] = {0, 0};
-  const float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+  const float p[3] = {pf_p[0], pf_p[1], pf_p[2]};
   float pv[3], ph[4];
   bool ok;
   if (COLMAP) {
@@ -379,10 +395,10 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
     float c6[6];
     if (cov3D_precomp != nullptr) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) c6[i] = cov3D_precomp[6 * idx + i];
+      for (int i = 0; i < 6; ++i) c6[i] = pf_c6[i];
     } else {
-      const float s[3] = {scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]};
-      const float4 qv  = reinterpret_cast<const float4*>(rotations)[idx];
+      const float s[3] = {pf_s[0], pf_s[1], pf_s[2]};
+      const float4 qv  = pf_q;
       const float q[4] = {qv.x, qv.y, qv.z, qv.w};
       if (COLMAP)
         cov3d_cm(s, scale_modifier, q, c6);
@@ -414,15 +430,15 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
         if (colors_precomp == nullptr) {
           sh_to_rgb(D, p, cam.campos, my_dc, my_sh, rgb, &clamp_bits);
         } else {
-          rgb[0] = colors_precomp[3 * idx], rgb[1] = colors_precomp[3 * idx + 1], rgb[2] = colors_precomp[3 * idx + 2];
+          rgb[0] = pf_col[0], rgb[1] = pf_col[1], rgb[2] = pf_col[2];
         }
         radius = (int) my_radius;
         r0     = make_float4(pix[0], pix[1], conic[0], conic[1]);
-        r1     = make_float4(conic[2], opacities[idx], rgb[0], rgb[1]);
+        r1     = make_float4(conic[2], pf_op, rgb[0], rgb[1]);
         // qmax = 2 ln(255 o): a pixel can reach alpha = min(0.99, o * exp(-q/2)) >= 1/255 only where the conic form
         // q(d) <= qmax.  The blend kernels skip a splat for a whole wave when the minimum of q over the wave's pixel
         // rectangle exceeds it (render.hip: splat_reaches_rect); +0.01 absorbs logf / exp rounding.
-        const float o255 = 255.0f * opacities[idx];
+        const float o255 = 255.0f * pf_op;
         const float qmax = o255 > 1.0f ? 2.0f * logf(o255) + 0.01f : -1.0f;
         r2 = make_float4(rgb[2], pv[2], __int_as_float(radius | (int) (clamp_bits << 28)), qmax);
       }
