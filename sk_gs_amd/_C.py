@@ -696,6 +696,42 @@ def lbs_deform_forward(points, weights, indices, bone_T, bone_drot, bone_dscale,
     return means, scales, rotations, opacity, d_xyz, d_rot, d_scale
 
 
+_max_fused_bones = None
+
+
+def fused_lbs_max_bones() -> int:
+    """most bones the one-launch KNN + weights (+ skinning) kernels stage in LDS (``skgs_fused_lbs_max_bones``)"""
+    global _max_fused_bones
+    if _max_fused_bones is None:
+        lib = load_library()
+        lib.skgs_fused_lbs_max_bones.restype = C.c_int
+        _max_fused_bones = int(lib.skgs_fused_lbs_max_bones())
+    return _max_fused_bones
+
+
+def knn_lbs_deform_forward(points, joints, sp_W, K: int, bone_T, bone_drot, bone_dscale, xyz, log_scale, rot, opacity_logit):
+    """KNN + softmax of the gathered LBS logits + skinning + activation epilogue in ONE launch
+    (``skgs_knn_lbs_deform_forward``: what the fused step runs; bit-identical to ``skgs_knn_lbs_weights`` followed by
+    ``skgs_lbs_deform_forward``).  The inference path of the `W` weighting (calc_LBS_weight, sk_gs.py:757,767-768, then
+    :1143-1150,1162,1192-1203).  Returns ``(means[P,3], scales[P,3], rotations[P,4], opacity[P,1], weights[P,K],
+    indices[P,K] int64)``."""
+    lib = load_library()
+    _require_gpu(points, 'points')
+    dev = points.device
+    with _on_device(dev):
+        ts = [_f32c(t, dev) for t in (points, joints, sp_W, bone_T, bone_drot, bone_dscale, xyz, log_scale, rot, opacity_logit)]
+        P, M = ts[2].shape
+        f32 = dict(dtype=torch.float32, device=dev)
+        means, scales = torch.empty((P, 3), **f32), torch.empty((P, 3), **f32)
+        rotations, opacity = torch.empty((P, 4), **f32), torch.empty((P, 1), **f32)
+        weights, indices = torch.empty((P, K), **f32), torch.empty((P, K), dtype=torch.int64, device=dev)
+        _check(lib.skgs_knn_lbs_deform_forward(
+            C.c_int32(P), C.c_int32(M), C.c_int32(int(K)), *[C.c_void_p(_ptr(t)) for t in ts], C.c_void_p(_ptr(indices)),
+            C.c_void_p(_ptr(weights)), C.c_void_p(_ptr(means)), C.c_void_p(_ptr(scales)), C.c_void_p(_ptr(rotations)),
+            C.c_void_p(_ptr(opacity)), None, _stream()))
+    return means, scales, rotations, opacity, weights, indices
+
+
 def lbs_deform_backward(points, weights, indices, bone_T, bone_drot, bone_dscale, log_scale, rot, opacity_logit,
                         g_means, g_scales, g_rotations, g_opacity):
     """Returns ``(g_weights[P,K], g_bone_T[M,7], g_bone_drot[M,4], g_bone_dscale[M,3], g_xyz, g_log_scale, g_rot,
@@ -829,6 +865,7 @@ _FUNCTIONS = {
     'gaussian_topk_weights': gaussian_topk_weights,
     'mark_visible': mark_visible,
     'lbs_deform_forward': lbs_deform_forward,
+    'knn_lbs_deform_forward': knn_lbs_deform_forward,
     'lbs_deform_backward': lbs_deform_backward,
     'knn_bones': knn_bones,
 }

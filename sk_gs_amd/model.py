@@ -17,7 +17,7 @@ import torch
 from torch import Tensor, nn
 import torch.nn.functional as F
 
-from sk_gs_amd import scene, skeleton
+from sk_gs_amd import _C, scene, skeleton
 from sk_gs_amd.deform import calc_lbs_weight, lbs_deform
 from sk_gs_amd.renderer.gaussian_render import GaussianRasterizationSettings, render
 
@@ -186,6 +186,13 @@ class SkinnedGaussians(nn.Module):
                         rotations=F.normalize(self._rotation, dim=-1), sh_features=sh_features)
         points = self._xyz.detach()
         sk_T, sk_d_rot, sk_d_scale = self.bone_transforms(time_id)
+        if (not torch.is_grad_enabled() and self.lbs_method == 'W' and points.is_cuda
+                and self.joints.shape[0] <= _C.fused_lbs_max_bones() and self.K <= 16):
+            # inference (the FPS protocol, test.py:102-123): search, weights and skinning in the fused step's one launch
+            means, scales, rotations, opacity, _, _ = _C.knn_lbs_deform_forward(
+                points, self.joints, self.sp_W, self.K, sk_T, sk_d_rot, sk_d_scale, self._xyz, self._scaling, self._rotation,
+                self._opacity)
+            return dict(points=means, opacity=opacity, scales=scales, rotations=rotations, sh_features=sh_features)
         weights, indices = calc_lbs_weight(
             points, self.joints, self.K, sp_W=self.sp_W,
             kernel_radius=None if self._sp_radius is None else torch.exp(self._sp_radius),

@@ -405,3 +405,16 @@ def test_deform_and_knn_at_full_size(oracle32, cfg, P, M):
     for name, t in zip(names, got):
         # per-bone gradients sum 10^5..10^6 terms in fp32 in two different orders: 1e-4; per-Gaussian ones 1e-5
         assert rel_err(t, gref[name]) <= (1e-4 if 'bone' in name else 1e-5), (name, rel_err(t, gref[name]))
+
+
+def test_inference_forward_takes_the_one_launch_skinning_and_matches_the_training_forward():
+    """under no_grad ``SkinnedGaussians.forward`` runs search + weights + skinning as the fused step's ONE launch
+    (``_C.knn_lbs_deform_forward``); with gradients on, the two autograd Functions: same outputs bit for bit"""
+    from sk_gs_amd.model import SkinnedGaussians
+    model = SkinnedGaussians(5000, 20, 5, sh_degree=1, num_frames=2, seed=4, deform_net=True).cuda()
+    with torch.no_grad():
+        a = model(1)
+    b = model(1)
+    assert b['points'].requires_grad and not a['points'].requires_grad
+    for k in ('points', 'scales', 'rotations', 'opacity'):
+        assert torch.equal(a[k], b[k].detach()), k
