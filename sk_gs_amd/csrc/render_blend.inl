@@ -421,8 +421,9 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
           const float Tprev = Tr[i];
           const float Tn    = Tprev * rinv;
           Tr[i]             = Tn;
-          const float dL_dalpha = ((D - accum[i][0]) * Tprev + dL_dT[i]) * rinv;
-          accum[i][0] = alpha * D + (1.f - alpha) * accum[i][0];
+          const float t     = D - accum[i][0];
+          const float dL_dalpha = (t * Tprev + dL_dT[i]) * rinv;
+          accum[i][0] = fmaf(alpha, t, accum[i][0]);  // = alpha D + (1 - alpha) S, updated in place (one instruction, no copy)
           gA[i]  = G * dL_dalpha;
           dch[i] = alpha * Tn;
         }
