@@ -217,6 +217,9 @@ def main():
     ap.add_argument('--autograd', action='store_true',
                     help='run the step through the torch-autograd operator path (model.render + image_loss + backward) '
                          'instead of sk_gs_amd.fused_step.FusedViewStep (same kernels, no autograd glue)')
+    ap.add_argument('--auto-budget', type=float, default=420.0,
+                    help='world > 1, --exchange auto: seconds after which no further exchange variant is started (the ones that '
+                         'finished are ranked and reported)')
     ap.add_argument('--split-rest', action='store_true',
                     help='with --sh-factors --overlap-gather --graph-collectives: the all-reduce of everything but the SH factors in '
                          'two pieces -- the per-Gaussian rows (final after the skinning backward launch) go on the wire beside the '
@@ -1024,7 +1027,16 @@ def main():
                 os._exit(0)
 
         t_first = None
+        t_auto0 = time.perf_counter()
         for name, flags in variants.items():
+            # a wall-clock budget for the whole ranking: the record is ONE line at the very end, so a caller's time limit that
+            # fell in the middle of a late variant would cost all of it.  Every rank takes the same decision (MAX of the clocks).
+            if any(n_ not in errors for n_ in lines):  # (the same on every rank: errors are agreed on below; lines are rank 0's)
+                el = torch.tensor([time.perf_counter() - t_auto0], dtype=torch.float64, device=dev)
+                dist.all_reduce(el, op=dist.ReduceOp.MAX)
+                if float(el.item()) > args.auto_budget:
+                    errors[name], lines[name] = f'not run: the ranking had used {float(el.item()):.0f} s of its {args.auto_budget:.0f} s budget', None
+                    continue
             a = copy.copy(args)
             for k_, v_ in flags.items():
                 setattr(a, k_, v_)

@@ -175,3 +175,20 @@ def test_collectives_captured_inside_the_step_graph_one_rank_rccl(port, exchange
     assert a['config']['replicas_identical'] is True and b['config']['replicas_identical'] is True
     assert abs(a['config']['param_digest'] - b['config']['param_digest']) <= 1e-6 * abs(b['config']['param_digest'])
     assert 'ONE captured hipGraph' in a['config']['launch']
+
+
+def test_auto_ranking_stops_starting_variants_when_its_time_budget_is_spent():
+    """`--auto-budget` (seconds): the record is one line at the very end, so the ranking must end by itself before a caller's
+    limit could cut it off -- with a budget of zero only the first variant runs, the others are listed as not run"""
+    env = dict(os.environ, SKGS_DIST_BACKEND='gloo', SKGS_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29641', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
+           '--auto-budget', '0']
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip().startswith('{')][-1])
+    ev = d['exchange_variants']
+    assert d['config']['exchange'] == 'allreduce' and 'value' in ev['allreduce']
+    for name, r in ev.items():
+        if name != 'allreduce':
+            assert 'budget' in r['error'], (name, r)
