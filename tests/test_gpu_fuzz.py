@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_close_robust, oracle_backward
+from helpers import assert_close_robust, oracle_backward, oracle_forward
 from test_gpu_raster import GRAD_NAMES, TOL, check_forward, hip_backward
 
 pytestmark = pytest.mark.gpu
@@ -42,8 +42,10 @@ def _case(seed):
                 colors=use_colors), act, rs, extras, colors
 
 
-@pytest.mark.parametrize('seed', list(range(64)))
-def test_random_scene_against_the_oracle(oracle32, seed):
+# beyond the first 64: the scenes a 1000-seed sweep singled out -- 240: a flipped pixel worth 2.2e-3; 762: a flipped pixel under
+# extras; 394, 474, 570, 640, 753, 1008: ill-conditioned in fp32 (the fp32 oracle itself is 1e-4 ... 0.45 from the fp64 one)
+@pytest.mark.parametrize('seed', list(range(64)) + [240, 394, 474, 570, 640, 753, 762, 1008])
+def test_random_scene_against_the_oracle(oracle32, oracle64, seed):
     desc, act, rs, extras, colors = _case(seed)
     W, H, P, E = desc['W'], desc['H'], desc['P'], desc['E']
     ref, fwd = check_forward(oracle32, act, rs, extras=extras, colors=colors)
@@ -53,6 +55,9 @@ def test_random_scene_against_the_oracle(oracle32, seed):
     dL_dopacity = torch.randn(H, W, generator=tg).cuda()
     dL_dextra = torch.randn(E, H, W, generator=tg).cuda() if E else None
     gref = oracle_backward(oracle32, ref, act, rs, dL_dcolor, dL_dopacity, extras, dL_dextra, colors=colors)
+    # the same gradients in fp64: how far the reference arithmetic itself is from the true value on this scene
+    g64 = oracle_backward(oracle64, oracle_forward(oracle64, act, rs, extras, colors), act, rs, dL_dcolor, dL_dopacity, extras,
+                          dL_dextra, colors=colors)
     got = hip_backward(fwd, act, rs, dL_dcolor, dL_dopacity, extras, dL_dextra, colors=colors)
     for name, t in zip(GRAD_NAMES, got[:8]):
         assert bool(torch.isfinite(t).all()), (desc, name)
@@ -61,9 +66,9 @@ def test_random_scene_against_the_oracle(oracle32, seed):
         want = gref[name]
         if name == 'dL_dcolors' and colors is None:
             continue  # (colours come from the SH: the oracle reports their gradient under dL_dsh)
-        ref['census'].check_rows(t, want, f'{name} {desc}')
+        ref['census'].check_rows(t, want, f'{name} {desc}', exact=g64[name])
     if E:
-        assert_close_robust(got[8], gref['dL_dextras'], TOL, 2e-3, name=f'dL_dextras {desc}')
+        ref['census'].check_rows(got[8], gref['dL_dextras'], f'dL_dextras {desc}', exact=g64['dL_dextras'])
     else:
         assert got[8] is None
     # nothing rendered: every gradient is exactly zero

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import FlipCensus, assert_close_robust, oracle_backward, oracle_forward, rel_err, scene_inputs, to_np
+from helpers import FLIP_HARD, FlipCensus, assert_close_robust, oracle_backward, oracle_forward, rel_err, scene_inputs, to_np
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -98,7 +98,11 @@ def check_forward(o, act, rs, extras=None, colors=None, cov3D=None, strict=False
         assert not (nc_bad & ~np.asarray(census.flipped, dtype=bool).reshape(nc_bad.shape)).any()
         assert nc_bad.mean() <= max(2e-5, 1.5 / nc_bad.size)
         if extras is not None:
-            assert_close_robust(out_extra, ref['out_extra'], TOL, name='out_extra')
+            # (extras blend like colours: a pixel over the tolerance must be one the census names)
+            de = np.abs(to_np(out_extra).astype(np.float64) - np.asarray(ref['out_extra'], np.float64))
+            de = (de / max(np.abs(ref['out_extra']).max(), 1e-30)).max(0)
+            assert not ((de > TOL) & ~np.asarray(census.flipped, dtype=bool)).any(), f'out_extra: max {de.max():.2e}'
+            assert de.max() <= FLIP_HARD
     return ref, fwd
 
 
