@@ -67,7 +67,10 @@ def pytest_sessionfinish(session, exitstatus):
     try:
         out = os.path.join(ROOT, 'gpurun_out')
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, 'parity_observed.json'), 'w') as f:
+        # (a session without a GPU -- the oracle's own census tests -- must not overwrite the file of the last GPU session)
+        import torch
+        name = 'parity_observed.json' if torch.cuda.is_available() else 'parity_observed_cpu.json'
+        with open(os.path.join(out, name), 'w') as f:
             json.dump(helpers.OBSERVED, f, indent=1)
     except OSError:
         pass
