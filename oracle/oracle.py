@@ -43,6 +43,38 @@ def _p(a: Optional[np.ndarray]):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def freq_encode_forward(inputs: np.ndarray, degree: int) -> np.ndarray:
+    """``kernel_freq`` (my_ext/_C/src/nerf/freqencoder.cu:7-31), element by element: column c < D copies the input,
+    otherwise ``col = c / D - 1, d = c % D, freq = col / 2`` and the value is ``sin(scalbn(x[d], freq) + (col % 2) pi/2)``
+    in fp32 (the CUDA kernel uses the ``__sinf`` intrinsic: bit-level behaviour of the compiled reference is unpinned).
+    Test infrastructure only."""
+    x = np.ascontiguousarray(inputs, dtype=np.float32)
+    B, D = x.shape
+    Cn = D + 2 * D * degree
+    out = np.empty((B, Cn), np.float32)
+    half_pi = np.float32(3.141592653589793 / 2)
+    for c in range(Cn):
+        if c < D:
+            out[:, c] = x[:, c]
+        else:
+            col, d = c // D - 1, c % D
+            arg = np.ldexp(x[:, d], col // 2).astype(np.float32) + np.float32(col % 2) * half_pi
+            out[:, c] = np.sin(arg.astype(np.float32)).astype(np.float32)
+    return out
+
+
+def freq_encode_backward(grad: np.ndarray, outputs: np.ndarray, D: int, degree: int) -> np.ndarray:
+    """``kernel_freq_backward`` (freqencoder.cu:36-60): ``g_x[d] = g[d] + sum_f 2^f (g[s + d] out[s + D + d] -
+    g[s + D + d] out[s + d])`` with ``s = D + 2 f D`` (the saved cos / sin are read back from ``outputs``)."""
+    g = np.ascontiguousarray(grad, dtype=np.float32)
+    o = np.ascontiguousarray(outputs, dtype=np.float32)
+    r = g[:, :D].copy()
+    for f in range(degree):
+        s = D + 2 * f * D
+        r = r + np.float32(2.0 ** f) * (g[:, s:s + D] * o[:, s + D:s + 2 * D] - g[:, s + D:s + 2 * D] * o[:, s:s + D])
+    return r.astype(np.float32)
+
+
 class Oracle:
     """fp32 oracle (``dtype='f32'``) or its fp64 twin (``dtype='f64'``)."""
 

@@ -857,6 +857,51 @@ def image_loss_backward(pred: Tensor, gt: Tensor, lambda_l1: float, lambda_ssim:
     return out
 
 
+def freq_encode_forward(inputs: Tensor, B: int, D: int, deg: int, C_out: int, outputs: Tensor) -> None:
+    """``freq_encode_forward`` of the reference's extension (my_ext/_C/src/nerf/freqencoder.cu:66-85), same positional
+    arguments: ``outputs[B, C] = [x | sin(2^f x), cos(2^f x) for f < deg]`` written in place, ``C = D + 2 D deg``.  What
+    ``networks/encoders/freq_encoder.py:13,33`` resolves at import time and calls from ``_freq_encoder.forward``."""
+    lib = load_library()
+    _require_gpu(inputs, 'inputs')
+    _require_gpu(outputs, 'outputs')
+    _check_freq_args('freq_encode_forward', B, D, deg, C_out, (inputs, B * D, 'inputs'), (outputs, B * C_out, 'outputs'))
+    with _on_device(inputs.device):
+        _check(lib.skgs_freq_encode_forward(C.c_int32(B), C.c_int32(D), C.c_int32(deg), C.c_void_p(_ptr(inputs)),
+                                            C.c_int32(D), C.c_void_p(_ptr(outputs)), C.c_int32(C_out), _stream()))
+
+
+def freq_encode_backward(grad: Tensor, outputs: Tensor, B: int, D: int, deg: int, C_out: int, grad_inputs: Tensor) -> None:
+    """``freq_encode_backward`` (freqencoder.cu:87-105): ``grad_inputs[B, D]`` is WRITTEN (the reference's kernel assigns,
+    `:59`) from the cotangent ``grad[B, C]`` and the saved ``outputs[B, C]`` (cos / sin are read back from them)."""
+    lib = load_library()
+    for t, n in ((grad, 'grad'), (outputs, 'outputs'), (grad_inputs, 'grad_inputs')):
+        _require_gpu(t, n)
+    _check_freq_args('freq_encode_backward', B, D, deg, C_out, (grad, B * C_out, 'grad'), (outputs, B * C_out, 'outputs'),
+                     (grad_inputs, B * D, 'grad_inputs'))
+    with _on_device(grad.device):
+        _check(lib.skgs_freq_encode_backward(C.c_int32(B), C.c_int32(D), C.c_int32(deg), C.c_void_p(_ptr(grad)),
+                                             C.c_void_p(_ptr(outputs)), C.c_int32(C_out), C.c_void_p(_ptr(grad_inputs)),
+                                             C.c_int32(0), _stream()))
+
+
+def _check_freq_args(who, B, D, deg, C_out, *tensors):
+    # the reference's CHECK_CONTIGUOUS / CHECK_IS_FLOATING (freqencoder.cu:68-75), plus the sizes its kernels assume
+    if C_out != D + 2 * D * deg:
+        raise SkgsError(f'{who}: C = {C_out} is not D + 2 D deg = {D + 2 * D * deg}')
+    for t, n, name in tensors:
+        if t.dtype is not torch.float32 or not t.is_contiguous():
+            raise SkgsError(f'{who}: {name} must be a contiguous float32 tensor')
+        if t.numel() != n:
+            raise SkgsError(f'{who}: {name} has {t.numel()} elements, expected {n}')
+
+
+#: the names the reference's compiled module ``my_ext._C._C`` defines for THIS path (pybind ``m.def`` names:
+#: gaussian_rasterizer_forward.cu:314, gaussian_rasterizer_backwrad.cu:260, gaussian_rasterizer_extra.cu:279-283,
+#: gaussian_topk.cu:121, freqencoder.cu:107-110; ``mark_visible`` is commented out there, gaussian_rasterizer_imp.cu:75-103)
+PYBIND_NAMES = ('rasterize_gaussians', 'rasterize_gaussians_backward', 'gaussian_rasterize_extra_forward',
+                'gaussian_rasterize_extra_backward', 'gaussian_topk_weights', 'mark_visible', 'freq_encode_forward',
+                'freq_encode_backward')
+
 _FUNCTIONS = {
     'rasterize_gaussians': rasterize_gaussians,
     'rasterize_gaussians_backward': rasterize_gaussians_backward,
@@ -864,18 +909,47 @@ _FUNCTIONS = {
     'gaussian_rasterize_extra_backward': gaussian_rasterize_extra_backward,
     'gaussian_topk_weights': gaussian_topk_weights,
     'mark_visible': mark_visible,
+    'freq_encode_forward': freq_encode_forward,
+    'freq_encode_backward': freq_encode_backward,
     'lbs_deform_forward': lbs_deform_forward,
     'knn_lbs_deform_forward': knn_lbs_deform_forward,
     'lbs_deform_backward': lbs_deform_backward,
     'knn_bones': knn_bones,
 }
+assert all(n in _FUNCTIONS for n in PYBIND_NAMES)
 
 
-def get_C_function(name: str):
-    """Same contract as ``my_ext._C.get_C_function`` (my_ext/_C/__init__.py:39-48) except that an unknown name or a
-    missing library raises instead of silently returning None."""
+def get_C_function(name):
+    """Same contract as ``my_ext._C.get_C_function`` (my_ext/_C/__init__.py:39-40): ``getattr(_C, name, None)`` for a
+    string -- an unknown name yields ``None`` -- and a callable is handed back as it is.  A missing library still raises:
+    there is nothing behind the names without it."""
     load_library()
-    try:
-        return _FUNCTIONS[name]
-    except KeyError:
-        raise SkgsError(f'sk_gs_amd._C has no function named {name!r}') from None
+    if not isinstance(name, str):
+        return name
+    return _FUNCTIONS.get(name)
+
+
+def have_C_functions(*names) -> bool:
+    """``my_ext._C.have_C_functions`` (my_ext/_C/__init__.py:43-47)"""
+    return all(n in _FUNCTIONS for n in names)
+
+
+_pybind_module = None
+
+
+def pybind_module():
+    """A module object shaped like the reference's COMPILED extension ``my_ext._C._C`` (the inner module that
+    ``my_ext/_C/__init__.py:14`` imports with ``from . import _C``): its only public attributes are the ops of this path
+    under their pybind names, so the reference's own ``hasattr(_C, name)`` / ``getattr(_C, name, None)`` probes
+    (my_ext/_C/__init__.py:20,29,40,45) see exactly what a build of the extension with these translation units would
+    define and fall back to their Python twins for everything else, as they do for any op a build lacks.  Made once;
+    ``sk_gs_amd.install_as_my_ext_C`` registers it as ``sys.modules['my_ext._C._C']``."""
+    global _pybind_module
+    if _pybind_module is None:
+        import types
+        m = types.ModuleType('my_ext._C._C', 'sk_gs_amd (MI355X / HIP) ops under the pybind names of my_ext._C._C')
+        for n in PYBIND_NAMES:
+            setattr(m, n, _FUNCTIONS[n])
+        m.__file__ = _LIB_PATH
+        _pybind_module = m
+    return _pybind_module

@@ -24,20 +24,72 @@ def single_thread_backward(on: bool = True):
 
 
 def install_as_my_ext_C(single_thread: bool = True):
-    """Make ``from my_ext._C import get_C_function`` (networks/renderer/gaussian_render.py:12) resolve to this package's
-    binding, so the reference's own renderer module runs unchanged on top of libskgs_hip.so."""
+    """Put this package's ops behind the reference's extension lookup, so that the reference's own modules --
+    ``networks/renderer/gaussian_render.py`` (``get_C_function('rasterize_gaussians')`` ...), ``networks/encoders/
+    freq_encoder.py:13-14`` (``freq_encode_forward/backward``) -- run unmodified on top of libskgs_hip.so.
+
+    In the reference ``my_ext._C`` is a Python PACKAGE (my_ext/_C/__init__.py) that defines ``get_C_function``,
+    ``try_use_C_extension``, ``have_C_functions``, ``check_C_runtime`` and ``get_python_function`` over the compiled
+    module it imports with ``from . import _C`` (:14) -- the INNER module ``my_ext._C._C``.  That inner module is the one
+    thing replaced: ``sys.modules['my_ext._C._C'] = sk_gs_amd._C.pybind_module()``.  The reference's package, its helper
+    functions and every Python twin stay the reference's own; ops this library does not define (``xfm_fwd``,
+    ``quaternion_to_R_forward``, ...) are reported missing by the reference's own probes and fall back to their Python
+    implementations exactly as with a partial build of its extension.
+
+    Call it BEFORE the first ``import my_ext`` / ``import networks``: the reference resolves ops at import time
+    (freq_encoder.py:13-14, cdist_top.py:42-44) and, once its ``my_ext._C`` has been imported without a compiled module,
+    has already taken the "Please Compile" branch (my_ext/_C/__init__.py:104-130) -- that is refused here with an error.
+
+    Where the reference's ``my_ext`` cannot be found at all (a machine that only has this repository: the GPU box's
+    tests, a stand-alone copy of the renderer module), a minimal stand-in for the two outer packages is planted so that
+    ``from my_ext._C import get_C_function`` still resolves (``sk_gs_amd._C`` offers the same helper names)."""
+    import importlib.util
     import sys
     import types
     from sk_gs_amd import _C
+    inner = _C.pybind_module()
+    outer = sys.modules.get('my_ext._C')
+    if outer is not None and getattr(outer, '_sk_gs_amd_stand_in', False):
+        pass  # our own stand-in from an earlier call
+    elif outer is not None and getattr(outer, '_C', None) is not inner:
+        raise RuntimeError(
+            "sk_gs_amd.install_as_my_ext_C(): the reference's my_ext._C is already imported without these ops (its modules "
+            "resolved their C functions at import time) -- call install_as_my_ext_C() before importing my_ext / networks")
     if single_thread:
         single_thread_backward(True)
-    pkg = sys.modules.get('my_ext')
-    if pkg is None:
-        pkg = types.ModuleType('my_ext')
-        pkg.__path__ = []
-        sys.modules['my_ext'] = pkg
-    sys.modules['my_ext._C'] = _C
-    pkg._C = _C
+    sys.modules['my_ext._C._C'] = inner
+    if outer is not None:
+        return
+    try:
+        found = 'my_ext' in sys.modules or importlib.util.find_spec('my_ext') is not None
+    except (ImportError, ValueError):
+        found = False
+    if found:
+        return  # the reference is importable: its own my_ext/_C/__init__.py will pick the inner module up
+    pkg = types.ModuleType('my_ext')
+    pkg.__path__ = []
+    pkg._sk_gs_amd_stand_in = True
+    mid = types.ModuleType('my_ext._C')
+    mid.__path__ = []
+    mid._sk_gs_amd_stand_in = True
+    mid._C = inner
+    # the helper names of my_ext/_C/__init__.py:9-48 over the inner module, with the reference's semantics
+    mid.get_C_function = lambda func: getattr(inner, func, None) if isinstance(func, str) else func
+    mid.have_C_functions = lambda *names: all(hasattr(inner, n) for n in names)
+    pkg._C = mid
+    pkg.get_C_function, pkg.have_C_functions = mid.get_C_function, mid.have_C_functions
+    sys.modules['my_ext'] = pkg
+    sys.modules['my_ext._C'] = mid
+
+
+def uninstall_my_ext_C():
+    """Undo ``install_as_my_ext_C`` for modules not imported yet (tests): drops the inner module and any stand-in."""
+    import sys
+    sys.modules.pop('my_ext._C._C', None)
+    for name in ('my_ext._C', 'my_ext'):
+        m = sys.modules.get(name)
+        if m is not None and getattr(m, '_sk_gs_amd_stand_in', False):
+            del sys.modules[name]
 
 
 def install_as_diff_gaussian_rasterization(single_thread: bool = True):

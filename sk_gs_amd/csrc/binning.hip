@@ -622,9 +622,11 @@ static int scatter_lanes(int P, int T, int bucket, int64_t capacity) {
 
 int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, BinView b, hipStream_t s) {
   const int P = in.P;
-  if (P == 0) return 0;
   const int bucket = in.tile_bucket_capacity > 0 ? in.tile_bucket_capacity : 0;
-  {
+  // P == 0 (an empty scene through the C ABI): nothing to scatter, but the sort launch still runs over the T empty lists --
+  // it is the launch that publishes tile_begin / tile_end in the bucket layout and the blend kernels' group order
+  // (tile_order_job); skipping it left the blend launch indexing tiles through uninitialised words.
+  if (P > 0) {
     ProfScope prof(K_SCATTER, s);
     const int64_t lanes = (int64_t) P * LPG;
     if (im.T <= BIN_LDS_TILES) {
@@ -650,7 +652,7 @@ int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, Bi
     // LDS).  A bucket layout whose buckets hold no more than a wave sorts cannot produce one: no launch.  Lists of up to
     // 2048 keys take the one-chunk-per-wave instantiation (32 KB of LDS), up to 4096 the two-chunk one (64 KB), up to 8192
     // the four-chunk one (128 KB); beyond that the network on global memory inside the widest instantiation.
-    const int longest = in.longest_list_hint > 0 ? in.longest_list_hint : 0x7fffffff;  // (an upper bound, if the caller has one)
+    const int longest = P == 0 ? 0 : in.longest_list_hint > 0 ? in.longest_list_hint : 0x7fffffff;  // (an upper bound, if the caller has one)
     if ((bucket == 0 || bucket > WSORT_WAVE_MAX) && longest > WSORT_WAVE_MAX)
       hipLaunchKernelGGL(tile_sort_merge_kernel<1>, dim3(std::min(im.T, 2048)), dim3(SORT_THREADS), 2 * 2048 * 8, s, g.hdr,
           im.worklist, im.tile_begin, im.tile_end, b.keys, b.point_list, b.capacity, WSORT_WAVE_MAX, 2048);

@@ -87,9 +87,9 @@ class FusedAdam:
         self.step_count = self.step_state[:1]  # (a view: ``float(opt.step_count)`` reads the count)
         self._table = torch.zeros(len(self.params) * 56, dtype=torch.uint8, device=dev)
         # descriptor tables of captured steps whose gradients autograd handed over (_table_of_this_capture)
-        self._pin_arena = torch.empty(self.MAX_CAPTURED_TABLES * len(self.params) * 56, dtype=torch.uint8, pin_memory=True)
-        self._table_arena = torch.zeros(self.MAX_CAPTURED_TABLES * len(self.params) * 56, dtype=torch.uint8, device=dev)
         self._capture_tables = []
+        self._retired_arenas = []
+        self._new_capture_arenas()
         self._total_chunks = 0
         self._bound_grads = None
         self._upload()
@@ -121,30 +121,109 @@ class FusedAdam:
         self._bound_grads = grads
         self._h2d(self._table, blob)
 
+    def _new_capture_arenas(self, slots: int = None):
+        """(re)create the arenas the per-capture descriptor tables are carved from: a pinned host blob and a device table per
+        slot, sized for the CURRENT number of parameters.  Outside graph capture only (pinned memory cannot be allocated while
+        a stream captures).  The previous arenas are kept alive -- graphs captured earlier may still replay copy nodes that
+        read them -- until ``release_captured_tables(drop_retired=True)``."""
+        slots = max(int(slots or 0), self.MAX_CAPTURED_TABLES)
+        if getattr(self, '_pin_arena', None) is not None and self._capture_tables:
+            self._retired_arenas.append((self._pin_arena, self._table_arena))
+        n = slots * len(self.params) * 56
+        self._capture_slots = slots
+        self._pin_arena = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+        self._table_arena = torch.zeros(n, dtype=torch.uint8, device=self.params[0].device)
+        self._capture_tables = []
+
+    def release_captured_tables(self, drop_retired: bool = True, slots: int = None):
+        """Forget the descriptor tables of captured steps (``_table_of_this_capture``): call it when the graphs that own them
+        are discarded -- e.g. before re-capturing after a densification -- so their slots are used again.  The optimizer does
+        this by itself whenever parameter or moment ADDRESSES change (``change_optimizer`` / ``gather_rows`` without a row
+        capacity: every graph captured before is invalid then anyway).  ``slots``: reserve room for that many captured steps
+        (default ``MAX_CAPTURED_TABLES``); ``drop_retired``: also free arenas retired earlier (no old graph replays again)."""
+        assert not torch.cuda.is_current_stream_capturing(), 'release_captured_tables: outside graph capture'
+        self._capture_tables = []
+        if drop_retired:
+            self._retired_arenas = []
+        target = max(int(slots or 0), self.MAX_CAPTURED_TABLES)
+        if target != self._capture_slots or self._pin_arena.numel() != target * len(self.params) * 56:
+            if not drop_retired:
+                self._retired_arenas.append((self._pin_arena, self._table_arena))
+            self._new_capture_arenas(target)
+
+    def _addresses_changed(self):
+        """parameter / moment tensors were re-created (densification without a row capacity): every graph captured before is
+        invalid, so are the descriptor tables made for them -- their slots are free again; the arenas are re-made when the
+        number of parameters changed (a slot is n_params x 56 bytes).  The old arenas stay alive until released: a copy node
+        of a stale graph must never read freed pinned memory."""
+        if self._pin_arena.numel() != self._capture_slots * len(self.params) * 56:
+            self._new_capture_arenas(self._capture_slots)
+        else:
+            self._capture_tables = []
+
+    def _capture_blob(self) -> bytearray:
+        blob = bytearray()
+        for k, (p, gi) in enumerate(zip(self.params, self._lr_index)):
+            st = self.state[p]
+            blob += struct.pack('<QQQQqqff', p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(),
+                                st['exp_avg_sq'].data_ptr(), p.numel(), self._chunk0[k], float(self.param_groups[gi]['lr']), 0.0)
+        return blob
+
     def _table_of_this_capture(self) -> 'torch.Tensor':
         """A step captured into a graph whose backward handed over FRESH gradient tensors (``p.grad = None`` before the
         backward, what ``zero_grad(set_to_none=True)`` does: autograd then stores each gradient as it is -- no zero fill and
         no "+=" launch per parameter): the tensors live in the graph's private pool, at addresses that are the same in every
         replay of THIS graph and differ from graph to graph.  The capture therefore gets a descriptor table of its own --
         same layout and chunk space as the bound one, these gradient addresses -- uploaded by a copy node from a pinned
-        host blob that the optimizer keeps alive (2 KB per replay)."""
-        blob = bytearray()
-        for k, (p, gi) in enumerate(zip(self.params, self._lr_index)):
+        host blob that the optimizer keeps alive (2 KB per replay).
+
+        Slots: a table is keyed by its CONTENT minus the learning rates (the addresses): the pieces of a step taken in pieces
+        (``step(groups=...)`` several times in one capture) and a re-capture that lands on the same addresses share one slot.
+        Slots are recycled when the addresses they describe die (``release_captured_tables``; automatic on optimizer
+        surgery that re-creates tensors), and the arenas are re-made when the number of parameters changes."""
+        for p in self.params:
             if p.grad is None:  # no gradient reached it in this backward: a zero one from the graph's pool
                 p.grad = torch.zeros_like(p)
             assert p.grad.is_contiguous() and p.grad.dtype == torch.float32 and cap_store(p) is None, \
                 'captured steps with fresh gradients: contiguous float32 gradients, no row capacity'
-            st = self.state[p]
-            blob += struct.pack('<QQQQqqff', p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(),
-                                st['exp_avg_sq'].data_ptr(), p.numel(), self._chunk0[k], float(self.param_groups[gi]['lr']), 0.0)
-        # (pinned memory cannot be allocated while a stream captures: both arenas exist since __init__)
-        n, used = len(blob), len(self._capture_tables)
-        assert used < self.MAX_CAPTURED_TABLES, 'FusedAdam: more captured steps with fresh gradients than MAX_CAPTURED_TABLES'
+        blob = self._capture_blob()
+        n = len(blob)
+        assert self._pin_arena.numel() == self._capture_slots * n, \
+            'FusedAdam: the parameter list changed since the capture arenas were made; call release_captured_tables() ' \
+            'outside graph capture first'
+        key = bytes(b for k in range(len(self.params)) for b in blob[56 * k:56 * k + 48])  # everything but (lr, pad)
+        for ent in self._capture_tables:
+            if ent['key'] == key:
+                return ent['table']
+        used = len(self._capture_tables)
+        if used >= self._capture_slots:
+            raise RuntimeError(
+                f'FusedAdam: {used} captured steps with gradients of their own are alive and the arenas hold '
+                f'{self._capture_slots}; discard the graphs you no longer replay and call release_captured_tables() (outside '
+                f'capture), or reserve more with release_captured_tables(slots=N)')
         pin, table = self._pin_arena[used * n:(used + 1) * n], self._table_arena[used * n:(used + 1) * n]
         pin.copy_(torch.frombuffer(blob, dtype=torch.uint8))
         table.copy_(pin, non_blocking=True)
-        self._capture_tables.append((pin, table))
+        self._capture_tables.append(dict(key=key, pin=pin, table=table))
         return table
+
+    def _refresh_captured_rates(self):
+        """push the current learning rates into the tables of captured steps, ORDERED on the current stream: the copy nodes
+        of a replay read the pinned blob when they execute, so a plain host store could reach replays that are queued but
+        have not run yet (their result would depend on how far the device lags).  The new descriptors therefore travel
+        host -> device scratch (``_h2d``: staged, event-guarded) -> pinned blob (a device-to-host copy ON the stream):
+        replays enqueued before this call see the old rates, replays after it the new ones."""
+        if not self._capture_tables:
+            return
+        n = len(self.params) * 56
+        scratch = torch.empty(n, dtype=torch.uint8, device=self._table.device)
+        for ent in self._capture_tables:
+            blob = bytearray(ent['pin'].numpy().tobytes())  # addresses as captured; only the rates are rewritten
+            for k, gi in enumerate(self._lr_index):
+                struct.pack_into('<f', blob, 56 * k + 48, float(self.param_groups[gi]['lr']))
+            self._h2d(scratch, blob)
+            ent['pin'].copy_(scratch, non_blocking=True)
+            ent['table'].copy_(scratch, non_blocking=True)
 
     def _h2d(self, dst: 'torch.Tensor', blob) -> None:
         """small host table -> device through a pinned staging tensor, asynchronously on the current stream (a pageable
@@ -217,6 +296,7 @@ class FusedAdam:
         if self._table.numel() != len(self.params) * 56:
             self._table = torch.zeros(len(self.params) * 56, dtype=torch.uint8, device=self._table.device)
         self._upload()
+        self._addresses_changed()
         return out
 
     @torch.no_grad()
@@ -271,6 +351,7 @@ class FusedAdam:
         if self._table.numel() != len(self.params) * 56:
             self._table = torch.zeros(len(self.params) * 56, dtype=torch.uint8, device=self._table.device)
         self._upload()
+        self._addresses_changed()
         del keepalive  # (the old tensors lived until the launch was enqueued: same stream, the allocator orders reuse)
         return new
 
@@ -346,12 +427,7 @@ class FusedAdam:
             group = next(i for i, g in enumerate(self.param_groups) if g.get('name') == group)
         self.param_groups[group]['lr'] = float(lr)
         self._upload()
-        # tables of captured steps (_table_of_this_capture): their copy nodes read the pinned host blobs at every replay
-        for pin, _ in self._capture_tables:
-            view = pin.view(torch.float32)  # 56-byte descriptors = 14 floats; the rate is float 12
-            for k, gi in enumerate(self._lr_index):
-                if gi == group:
-                    view[14 * k + 12] = float(lr)
+        self._refresh_captured_rates()  # tables of captured steps (_table_of_this_capture), stream-ordered
 
     # ---------------------------------------------------------------------------------------------------------
     def state_dict(self) -> dict:
@@ -395,6 +471,7 @@ class FusedAdam:
                                     '(the fused kernel keeps ONE counter)'
             self._set_step_count(steps.pop() if steps else 0.0)
         self._upload()
+        self._refresh_captured_rates()  # captured steps keep their addresses; the restored rates reach them too
 
     def _set_step_count(self, count: float):
         """restore a step count: the counter and the two bias-correction terms 1 - beta^count the kernels advance by

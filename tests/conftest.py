@@ -52,6 +52,25 @@ def _regressions(observed):
     return bad
 
 
+def _print_baseline_log(last=3):
+    """the tail of tests/golden/parity_baseline_log.json: every refresh of the baseline the 2x gate compares against (the one
+    way to loosen it) with its stated reason and the entries that got looser -- printed by every session that gates"""
+    import json
+    path = os.path.join(ROOT, 'tests', 'golden', 'parity_baseline_log.json')
+    if not os.path.exists(path):
+        return
+    try:
+        log = json.load(open(path))
+    except (OSError, ValueError):
+        return
+    print(f'\n[parity] baseline refreshes on record: {len(log)}; latest:')
+    for e in log[-last:]:
+        print(f"  {e.get('date')} ({e.get('commit') or 'no commit given'}): {e.get('reason')} -- {e.get('refreshed')} entries, "
+              f"{e.get('looser_count', 0)} looser, {e.get('tighter', 0)} tighter")
+        for l in e.get('looser', [])[:3]:
+            print(f"      looser: {l['test']} [{l['name']}] {l['field']}: {l['old']:.3g} -> {l['new']:.3g}")
+
+
 def pytest_sessionfinish(session, exitstatus):
     """what the comparisons observed (outlier fraction, max error, flips per tensor) -> gpurun_out/parity_observed.json, so
     the numbers behind the tolerances of tests/helpers are kept, not only asserted; and the session FAILS if a worst case
@@ -74,6 +93,7 @@ def pytest_sessionfinish(session, exitstatus):
             json.dump(helpers.OBSERVED, f, indent=1)
     except OSError:
         pass
+    _print_baseline_log()
     bad = _regressions(helpers.OBSERVED)
     if bad:
         print('\n[parity] worst cases grew > 2x over the committed baseline:\n  ' + '\n  '.join(bad))

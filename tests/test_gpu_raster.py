@@ -223,6 +223,42 @@ def test_other_extras_and_topk(oracle32):
     np.testing.assert_array_equal(to_np(vis), oracle32.mark_visible(to_np(act['means3D']), to_np(rs.viewmatrix), True))
 
 
+@pytest.mark.parametrize('bucket', [0, 64])
+def test_empty_scene_through_the_raw_c_abi(bucket):
+    """P == 0 straight through skgs_rasterize_forward (the Python wrappers short-circuit an empty scene, the C ABI
+    did not -- the sort launch that publishes the tile ranges / the blend kernels' group order was skipped and the blend
+    launch indexed tiles through uninitialised words).  Poisoned buffers in, an all-zero image (plus background) out."""
+    import ctypes as ct
+    C = _C()
+    lib = C.load_library()
+    W, H = 200, 136
+    act, rs, cam = scene_inputs(16, W, H, seed=0, colmap=True, device='cuda')
+    e = torch.Tensor([]).cuda()
+    a, keep, P, M, E = C._make_inputs(H, W, rs.tanfovx, rs.tanfovy, 3, 1.0, False, False, True, rs.viewmatrix, rs.projmatrix,
+                                      rs.campos, act['means3D'][:0], act['opacity'][:0], act['sh'][:0], act['scales'][:0],
+                                      act['rotations'][:0], None, e, e)
+    assert P == 0
+    bg = torch.tensor([0.25, 0.5, 0.75], device='cuda')
+    a.background = bg.data_ptr()
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    a.tile_bucket_capacity = bucket
+    cap = T * bucket if bucket else 1024
+    poison = dict(dtype=torch.uint8, device='cuda')
+    geom = torch.full((C._buffer_bytes(lib, 'geom', 0),), 0xCD, **poison)
+    geom[:256].zero_()
+    img = torch.full((C._buffer_bytes(lib, 'img', W, H),), 0xCD, **poison)
+    binning = torch.full((C._buffer_bytes(lib, 'binning', cap),), 0xCD, **poison)
+    color = torch.full((3, H, W), float('nan'), device='cuda')
+    opac = torch.full((H, W), float('nan'), device='cuda')
+    bufs = C._buffers(geom, binning, img)
+    for _ in range(2):
+        C._check(lib.skgs_rasterize_forward(ct.byref(a), ct.byref(bufs), None, ct.c_void_p(color.data_ptr()),
+                                            ct.c_void_p(opac.data_ptr()), None, None, C._stream()))
+    torch.cuda.synchronize()
+    assert float(opac.abs().max()) == 0.0
+    assert torch.equal(color, bg.view(3, 1, 1).expand(3, H, W))
+
+
 def test_empty_and_culled(oracle32):
     C = _C()
     W, H = 64, 48

@@ -49,8 +49,10 @@ def test_argument_errors_are_reported_not_crashed():
     lib = _C.load_library()
     rc = lib.skgs_rasterize_forward_stage1(None, None, None, None, None)
     assert rc != 0 and b'NULL' in lib.skgs_last_error()
-    with pytest.raises(_C.SkgsError):
-        _C.get_C_function('no_such_function')
+    # the reference's contract (my_ext/_C/__init__.py:39-40): an unknown name yields None, a callable passes through
+    assert _C.get_C_function('no_such_function') is None
+    assert _C.get_C_function(len) is len
+    assert _C.have_C_functions('rasterize_gaussians', 'freq_encode_backward') and not _C.have_C_functions('xfm_fwd')
 
 
 def test_product_path_refuses_cpu_tensors():
@@ -88,26 +90,91 @@ def test_tensor_level_entry_points_are_built_and_refuse_cpu_tensors():
 
 
 def test_install_hook_moves_the_backward_to_the_calling_thread_and_back():
-    import sys
     import sk_gs_amd
     was = torch.autograd.is_multithreading_enabled()
-    saved = {k: sys.modules.get(k) for k in ('my_ext', 'my_ext._C')}
+    saved = {k: sys.modules.get(k) for k in ('my_ext', 'my_ext._C', 'my_ext._C._C')}
     try:
         sk_gs_amd.install_as_my_ext_C()
         assert not torch.autograd.is_multithreading_enabled()
-        from my_ext._C import get_C_function  # what networks/renderer/gaussian_render.py:12 does
-        assert callable(get_C_function('rasterize_gaussians'))
+        from sk_gs_amd import _C
+        # the compiled INNER module is what gets replaced (my_ext/_C/__init__.py:14: `from . import _C`)
+        inner = sys.modules['my_ext._C._C']
+        assert inner is _C.pybind_module()
+        assert sorted(n for n in vars(inner) if not n.startswith('__')) == sorted(_C.PYBIND_NAMES)
+        assert getattr(inner, 'xfm_fwd', None) is None and not hasattr(inner, 'config')
+        from my_ext._C import get_C_function  # what networks/renderer/gaussian_render.py:12 does (stand-in without the reference)
+        assert get_C_function('rasterize_gaussians') is _C.rasterize_gaussians
+        assert get_C_function('freq_encode_forward') is _C.freq_encode_forward
+        assert get_C_function('no_such_op') is None
         sk_gs_amd.single_thread_backward(False)
         assert torch.autograd.is_multithreading_enabled()
         sk_gs_amd.install_as_my_ext_C(single_thread=False)
         assert torch.autograd.is_multithreading_enabled()
     finally:
         torch.autograd.set_multithreading_enabled(was)
+        sk_gs_amd.uninstall_my_ext_C()
         for k, v in saved.items():
             if v is None:
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+_REFERENCE = '/root/reference'
+_HOOK_SCRIPT = r"""
+import sys, warnings
+sys.dont_write_bytecode = True
+sys.path[:0] = [{root!r}, {golden!r}, {ref!r}]
+import make_golden                                  # only for its stub finder: lietorch, pytorch3d, cv2 ... are not in this image
+sys.meta_path.insert(0, make_golden._Finder())
+import sk_gs_amd
+sk_gs_amd.install_as_my_ext_C()                     # INTEGRATION.md section 2, verbatim
+with warnings.catch_warnings(record=True) as caught:
+    warnings.simplefilter('always')
+    import my_ext                                   # the reference's packages, unmodified, from {ref!r}
+    from networks.renderer import gaussian_render
+    from networks.encoders import freq_encoder
+    import networks.sk_gs, networks.gaussian_splatting
+assert my_ext.__file__.startswith({ref!r}) and my_ext._C.__file__.startswith({ref!r}), (my_ext.__file__, my_ext._C.__file__)
+from sk_gs_amd import _C
+assert my_ext._C._C is _C.pybind_module()
+for name in _C.PYBIND_NAMES:                        # every op of the path resolves to this package through THEIR lookup
+    assert my_ext.get_C_function(name) is getattr(_C, name), name
+    assert gaussian_render.get_C_function(name) is getattr(_C, name), name
+assert my_ext.have_C_functions(*_C.PYBIND_NAMES)
+assert freq_encoder.freq_encode_forward is _C.freq_encode_forward      # bound at import time, freq_encoder.py:13-14
+assert freq_encoder.freq_encode_backward is _C.freq_encode_backward
+# ops this library does not define: the reference's own probes report them and keep the Python twins
+assert my_ext.get_C_function('xfm_fwd') is None and not my_ext.have_C_functions('cdist_top')
+told = [str(w.message) for w in caught if 'No such function' in str(w.message)]
+assert any('xfm_fwd' in t for t in told), told
+assert not any('Please Compile' in str(w.message) for w in caught)     # the "no extension" branch was NOT taken
+# the surface the reference module builds on top of those ops
+assert gaussian_render.GaussianRasterizationSettings._fields[:4] == ('image_height', 'image_width', 'tanfovx', 'tanfovy')
+try:                                                # wrong order is refused, not silently half-wired
+    import subprocess
+    r = subprocess.run([sys.executable, '-c', 'import sys; sys.dont_write_bytecode = True; sys.path[:0] = [%r, %r, %r]; '
+                        'import make_golden; sys.meta_path.insert(0, make_golden._Finder()); import warnings; '
+                        'warnings.simplefilter("ignore"); import my_ext, sk_gs_amd; sk_gs_amd.install_as_my_ext_C()'
+                        % ({root!r}, {golden!r}, {ref!r})], capture_output=True, text=True)
+    assert r.returncode != 0 and 'before importing my_ext' in r.stderr, r.stderr[-400:]
+finally:
+    pass
+print('HOOK-OK')
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir(_REFERENCE), reason='the reference is only mounted in the build container')
+def test_unmodified_reference_imports_through_the_hook():
+    """INTEGRATION.md section 2 run for real: the reference's my_ext, its renderer module, its frequency encoder,
+    networks/sk_gs.py and networks/gaussian_splatting.py are imported UNMODIFIED after install_as_my_ext_C(), and every
+    one of the path's eight op names resolves, through the reference's own get_C_function, to this package.  Runs in a
+    child process (the reference's packages stay out of this session); third-party modules the image lacks are the
+    inert stubs of tests/golden/make_golden.py.  Nothing here computes: no GPU."""
+    code = _HOOK_SCRIPT.format(root=ROOT, golden=os.path.join(ROOT, 'tests', 'golden'), ref=_REFERENCE)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd='/tmp', env=env, timeout=600)
+    assert r.returncode == 0 and 'HOOK-OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
 def test_product_package_never_imports_the_oracle():

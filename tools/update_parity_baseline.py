@@ -1,30 +1,77 @@
 """Refresh tests/golden/parity_observed_baseline.json from the last GPU test run (gpurun_out/parity_observed.json).
 
-tests/conftest.py fails a session whose worst observed error grew more than 2x over this baseline; run this after a
-DELIBERATE numerics change and state the reason in the commit message.  Keeps, per (test, tensor), the largest error of
-the run; entries of tests that did not run keep their old value."""
+    python tools/update_parity_baseline.py --reason "why the numerics changed" [observed.json]
+
+tests/conftest.py fails a session whose worst observed error grew more than 2x over this baseline, so a refresh is the
+one way to loosen that gate: it therefore REQUIRES a reason, appends it (date, reason, every entry that got looser, by how
+much) to tests/golden/parity_baseline_log.json, and the test session prints that log's tail -- a silent loosening shows up in
+every run's output.
+
+Per (test, tensor) the baseline keeps the MAXIMUM over the run's observations of each gated quantity separately
+(`untraced_max`, `flipped_pixels`: what tests/conftest.py::_regressions compares) and of the informational ones; entries of
+tests that did not run keep their old value.  (Round 3 kept the whole record with the largest `max_err`: its `untraced_max`
+could be smaller than another observation's with the same key -- spurious failures -- or larger.)"""
+import argparse
+import datetime
 import json
 import os
-import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'gpurun_out', 'parity_observed.json')
-dst = os.path.join(ROOT, 'tests', 'golden', 'parity_observed_baseline.json')
-old = {}
-if os.path.exists(dst):
-    old = {(r['test'], r['name']): r for r in json.load(open(dst)) if 'untraced_max' in r}
-new = {}
-for r in json.load(open(src)):
-    if 'untraced_max' not in r:  # only the deterministic census comparisons are gated (tests/conftest.py::_regressions)
-        continue
-    k = (r.get('test', ''), r['name'])
-    keep = {f: r[f] for f in ('test', 'name', 'elements', 'tol', 'max_err', 'frac_over_tol') if f in r}
-    for f in ('flipped_pixels', 'flipped_max_margin', 'traced_pixels', 'traced_rows', 'rows_touching_a_flip', 'untraced_max'):
-        if f in r:
-            keep[f] = r[f]
-    if k not in new or keep['max_err'] > new[k]['max_err']:
-        new[k] = keep
-old.update(new)
-rows = sorted(old.values(), key=lambda r: (r['test'], r['name']))
-json.dump(rows, open(dst, 'w'), indent=0)
-print(f'{len(new)} entries refreshed, {len(rows)} in {dst}')
+DST = os.path.join(ROOT, 'tests', 'golden', 'parity_observed_baseline.json')
+LOG = os.path.join(ROOT, 'tests', 'golden', 'parity_baseline_log.json')
+MAX_FIELDS = ('max_err', 'frac_over_tol', 'flipped_pixels', 'flipped_max_margin', 'traced_pixels', 'traced_rows',
+              'rows_touching_a_flip', 'untraced_max')
+GATED = ('untraced_max', 'flipped_pixels')
+
+
+def aggregate(records):
+    """(test, name) -> record with every MAX_FIELDS entry the maximum over the observations sharing the key"""
+    out = {}
+    for r in records:
+        if 'untraced_max' not in r:  # only the deterministic census comparisons are gated
+            continue
+        k = (r.get('test', ''), r['name'])
+        cur = out.get(k)
+        if cur is None:
+            cur = out[k] = {f: r[f] for f in ('test', 'name', 'elements', 'tol') if f in r}
+        for f in MAX_FIELDS:
+            if f in r:
+                cur[f] = max(cur.get(f, r[f]), r[f])
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument('src', nargs='?', default=os.path.join(ROOT, 'gpurun_out', 'parity_observed.json'))
+    ap.add_argument('--reason', required=True, help='why the observed numbers changed (kept in parity_baseline_log.json)')
+    ap.add_argument('--commit', default='', help='commit the observations were taken at')
+    args = ap.parse_args()
+    old = {}
+    if os.path.exists(DST):
+        old = {(r['test'], r['name']): r for r in json.load(open(DST)) if 'untraced_max' in r}
+    new = aggregate(json.load(open(args.src)))
+    looser, tighter = [], 0
+    for k, r in new.items():
+        b = old.get(k)
+        if b is None:
+            continue
+        for f in GATED:
+            if f in r and r[f] > b.get(f, 0):
+                looser.append(dict(test=k[0], name=k[1], field=f, old=b.get(f, 0), new=r[f]))
+            elif f in r and r[f] < b.get(f, 0):
+                tighter += 1
+    old.update(new)
+    rows = sorted(old.values(), key=lambda r: (r['test'], r['name']))
+    json.dump(rows, open(DST, 'w'), indent=0)
+    log = json.load(open(LOG)) if os.path.exists(LOG) else []
+    log.append(dict(date=datetime.date.today().isoformat(), reason=args.reason, commit=args.commit, source=os.path.relpath(args.src, ROOT),
+                    refreshed=len(new), tighter=tighter,
+                    looser=sorted(looser, key=lambda e: -e['new'] / max(e['old'], 1e-30))[:40], looser_count=len(looser)))
+    json.dump(log, open(LOG, 'w'), indent=1)
+    print(f'{len(new)} entries refreshed ({len(looser)} looser, {tighter} tighter), {len(rows)} in {DST}')
+    for e in log[-1]['looser'][:10]:
+        print(f"  looser: {e['test']} [{e['name']}] {e['field']}: {e['old']:.3g} -> {e['new']:.3g}")
+
+
+if __name__ == '__main__':
+    main()
