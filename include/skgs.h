@@ -489,6 +489,41 @@ int skgs_skeleton_backward(const skgs_mlp_desc* d, const skgs_bone_chain_desc* b
     skgs_stream_t stream);
 int skgs_deform_mlp_status(const void* workspace, uint32_t* host_words4, skgs_stream_t stream);
 
+/* ---- the deform network of the SUPERPOINT stage (stage `sp`, networks/sk_gs.py:830-856) ----
+ * sp_deform_net = DeformNetwork (networks/sk_gs.py:209-315) as the shipped configs build it (exps/default.yaml:4-11,31:
+ * is_blender, D = 8, W = 256, skips = [4], position degree 10, time degree 6), evaluated on the M superpoints (512,
+ * exps/default.yaml:25) every step:
+ *   t_emb = time_w2 relu(time_w1 freq(t, 6) + time_b1) + time_b2          (timenet: Linear(13,256) ReLU Linear(256,30), :250-253)
+ *   h = [freq(x, 10) | t_emb] (93);  8 x  h = relu(W[i] h + b[i]);  after layer 4  h = [freq(x) | t_emb | h]      (:300-306)
+ *   raw = [warp(h) 3 | rotation(h) 4 | scaling(h) 3]                                                              (:308-310)
+ * and the stage's epilogue (sk_gs.py:847, warp() :796-821): bone_T [M,7] = [d_xyz | u], d_rot [M,4] = u, d_scale [M,3] =
+ * scaling, u = normalize(rotation + [0,0,0,1]) -- the three inputs of skgs_lbs_deform_forward.  All matrices in
+ * torch.nn.Linear layout [out, in], contiguous: W[0] [256,93], W[5] [256,349] (input columns first), the others [256,256].
+ * One launch forward (MFMA row blocks: 16 superpoints per workgroup through the whole network); two backward (row blocks,
+ * then all weight gradients on the whole chip).  The backward WRITES the gradient of every parameter into the matching
+ * pointer of `grads` (same struct; points / time ignored).  Cotangents: either g_raw [M,10] (w.r.t. the raw row above) or
+ * g_bone_T [M,7] / g_d_rot [M,4] / g_d_scale [M,3] (any may be NULL; the normalisation's backward runs in the launch).
+ * No gradient w.r.t. points or time (the reference detaches the positions, sk_gs.py:746-748,845).
+ * saved: skgs_sp_net_saved_bytes(M), written by the forward, read by the backward.  workspace:
+ * skgs_sp_net_workspace_bytes(M), ZERO before the first call (the library keeps its first 256 bytes zero between calls).
+ * side (may be NULL): an optimizer piece for the CUs the row-block launch leaves idle, as skgs_skeleton_backward. */
+typedef struct skgs_sp_net {
+  int32_t M, reserved;
+  const float* points;                                   /* [M,3] */
+  const float* time;                                     /* DEVICE scalar */
+  const float *time_w1, *time_b1, *time_w2, *time_b2;    /* [256,13], [256], [30,256], [30] */
+  const float* W[8];
+  const float* b[8];
+  const float *warp_w, *warp_b, *scaling_w, *scaling_b, *rotation_w, *rotation_b;   /* [3,256] [3] [3,256] [3] [4,256] [4] */
+} skgs_sp_net;
+size_t skgs_sp_net_saved_bytes(int32_t M);
+size_t skgs_sp_net_workspace_bytes(int32_t M);
+int skgs_sp_net_forward(const skgs_sp_net* net, float* raw /* [M,10] or NULL */, float* bone_T, float* d_rot, float* d_scale,
+    void* saved, size_t saved_bytes, skgs_stream_t stream);
+int skgs_sp_net_backward(const skgs_sp_net* net, const skgs_sp_net* grads, const float* g_bone_T, const float* g_d_rot,
+    const float* g_d_scale, const float* g_raw, const void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes,
+    const skgs_adam_range* side, skgs_stream_t stream);
+
 /* ---- densification statistics of one training view (scope row (f)-4) ----
  * networks/sk_gs.py:1990-1997 + networks/gaussian_splatting.py:503-513: for every Gaussian with radii > 0
  *   max_radii2D = max(max_radii2D, radii); xyz_gradient_accum += |grad_means2D[:, :2]|; denom += 1.

@@ -42,7 +42,8 @@ ProfSlot g_prof[K_COUNT];
 uint32_t g_prof_mask = 0;
 const char* const g_prof_names[K_COUNT] = {"preprocess_forward", "scan_tiles", "scatter", "tile_sort", "render_forward",
     "render_backward", "preprocess_backward", "deform_forward", "deform_backward", "knn_bones", "image_loss_forward",
-    "image_loss_backward", "skeleton_forward", "skeleton_backward", "adam"};
+    "image_loss_backward", "skeleton_forward", "skeleton_backward", "adam", "sp_net_forward", "sp_net_backward",
+    "sp_knn_weights", "sp_knn_weights_backward"};
 }  // namespace
 
 void prof_begin(int kid, hipStream_t s) {

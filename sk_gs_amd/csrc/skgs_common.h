@@ -263,7 +263,8 @@ int set_error(const char* fmt, ...);
 // reports.  Events are recorded on the stream the kernel is launched on.
 enum KernelId {
   K_PREPROCESS_FWD = 0, K_SCAN, K_SCATTER, K_SORT, K_RENDER_FWD, K_RENDER_BWD, K_PREPROCESS_BWD, K_DEFORM_FWD,
-  K_DEFORM_BWD, K_KNN, K_LOSS_FWD, K_LOSS_BWD, K_SKELETON_FWD, K_SKELETON_BWD, K_ADAM, K_COUNT
+  K_DEFORM_BWD, K_KNN, K_LOSS_FWD, K_LOSS_BWD, K_SKELETON_FWD, K_SKELETON_BWD, K_ADAM, K_SP_NET_FWD, K_SP_NET_BWD, K_SP_KNN,
+  K_SP_KNN_BWD, K_COUNT
 };
 void prof_begin(int kid, hipStream_t s);
 void prof_end(int kid, hipStream_t s);

@@ -1,0 +1,323 @@
+"""Stage ``sp`` of the hot path: the SUPERPOINT LBS deform (networks/sk_gs.py:830-856).
+
+In stage ``sp`` (30 k of the reference's 80 k default steps: ``sp_fix`` 3 000 + ``sp`` 27 000, exps/default.yaml:12-19) the
+"bones" are M = 512 superpoints (exps/default.yaml:25) without a kinematic chain:
+
+    calc_LBS_weight(points, sp_points, hyper_feature, sp_hyper_feature)   K nearest superpoints in 3 + 8 dimensions
+                                                                          (sk_gs.py:751-774) + one of the four weightings
+    sp_deform_net(sp_points.detach(), t)                                  DeformNetwork (sk_gs.py:209-315) on 512 rows
+    d_rot = normalize(d_rotation + [0,0,0,1])                             sk_gs.py:847
+    warp(..., method 'LBS'):  spT = SE3(d_xyz, d_rot);  d_points = sum_k w (spT[i_k].act(p)) - p;
+                              d_rotation = sum_k w d_rot[i_k];  d_scales = sum_k w d_scaling[i_k]      (sk_gs.py:776-828)
+
+followed by the same activation epilogue and rasterizer as stage ``sk``.  This module holds
+
+  * ``SpDeformNet``           the reference's ``DeformNetwork`` with ``is_blender=True`` (the D-NeRF default,
+                              exps/default.yaml:31): parameters under the reference's state_dict names, ``reference_forward``
+                              in plain torch ops (the numerics reference of the kernels, pinned by tests/golden/
+                              sp_deformnet.npz), ``forward`` on the HIP kernels of csrc/sp_mlp.hip (MFMA row-block kernels);
+  * ``SuperpointGaussians``   the minimal model of the stage (parameters with the reference's names and learning-rate groups,
+                              sk_gs.py:583-602) used by tests and ``bench.py --stage sp``;
+  * ``FusedSuperpointStep``   the per-view training step as a straight line of C-ABI calls (the sibling of
+                              ``fused_step.FusedViewStep``).
+
+There is no CPU path: the kernels raise on host tensors; ``reference_forward`` exists for tests.
+"""
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import torch
+from torch import Tensor, nn
+import torch.nn.functional as F
+
+from sk_gs_amd import _C
+from sk_gs_amd.deform_net import freq_encode_torch
+
+
+class SpDeformNet(nn.Module):
+    """``DeformNetwork(D, W, is_blender=True, sep_rot=False)`` (networks/sk_gs.py:209-315).
+
+    ``x_emb = freq(x, 10)`` [.,63]; ``t_emb = timenet(freq(t, 6))`` [30] with ``timenet = Linear(13,256) ReLU Linear(256,30)``
+    (:250-253); ``h = [x_emb | t_emb]``; D layers ``h = relu(linear[i](h))``, after layer ``D // 2`` the input is put IN FRONT:
+    ``h = [x_emb | t_emb | h]`` (:303-306); heads ``gaussian_warp`` (3), ``gaussian_scaling`` (3), ``gaussian_rotation`` (4)."""
+
+    def __init__(self, D: int = 8, W: int = 256, p_degree: int = 10, t_degree: int = 6, time_hidden: int = 256,
+                 time_out: int = 30):
+        super().__init__()
+        self.D, self.W, self.p_degree, self.t_degree = D, W, p_degree, t_degree
+        self.skips = [D // 2]
+        self.p_dim, self.t_dim = 3 * (1 + 2 * p_degree), 1 + 2 * t_degree
+        self.time_hidden, self.time_out = time_hidden, time_out
+        self.in_dim = self.p_dim + time_out
+        self.timenet = nn.Sequential(nn.Linear(self.t_dim, time_hidden), nn.ReLU(inplace=True), nn.Linear(time_hidden, time_out))
+        self.linear = nn.ModuleList([nn.Linear(self.in_dim, W)] + [
+            nn.Linear(W, W) if i not in self.skips else nn.Linear(W + self.in_dim, W) for i in range(D - 1)])
+        self.gaussian_warp, self.gaussian_scaling, self.gaussian_rotation = nn.Linear(W, 3), nn.Linear(W, 3), nn.Linear(W, 4)
+        self.reset_parameters()
+        self._runner = None
+
+    def reset_parameters(self):
+        """sk_gs.py:280-293"""
+        for layer in self.linear:
+            nn.init.kaiming_uniform_(layer.weight, mode='fan_in', nonlinearity='relu')
+            nn.init.zeros_(layer.bias)
+        nn.init.normal_(self.gaussian_warp.weight, mean=0, std=1e-5)
+        nn.init.normal_(self.gaussian_scaling.weight, mean=0, std=1e-8)
+        nn.init.normal_(self.gaussian_rotation.weight, mean=0, std=1e-5)
+        for head in (self.gaussian_warp, self.gaussian_scaling, self.gaussian_rotation):
+            nn.init.zeros_(head.bias)
+
+    # ------------------------------------------------------------------------------------------------ plain torch
+    def reference_forward(self, x: Tensor, t: Tensor) -> Dict[str, Tensor]:
+        t_emb = freq_encode_torch(t.view(-1, 1), self.t_degree).expand(x.shape[0], self.t_dim)
+        t_emb = self.timenet(t_emb)
+        x_emb = freq_encode_torch(x, self.p_degree)
+        h = torch.cat([x_emb, t_emb], dim=-1)
+        for i, layer in enumerate(self.linear):
+            h = F.relu(layer(h))
+            if i in self.skips:
+                h = torch.cat([x_emb, t_emb, h], -1)
+        return dict(d_xyz=self.gaussian_warp(h), d_rotation=self.gaussian_rotation(h), d_scaling=self.gaussian_scaling(h),
+                    hidden=h)
+
+    # ------------------------------------------------------------------------------------------------ HIP kernels
+    def kernel_supported(self) -> bool:
+        """csrc/sp_mlp.hip is written for the shipped configuration: 8 x 256, skip after layer 4, degrees 10 / 6, 13 -> 256 ->
+        30 time network (exps/default.yaml:4-11,31)"""
+        return (self.D == 8 and self.W == 256 and self.p_degree == 10 and self.t_degree == 6 and self.time_hidden == 256
+                and self.time_out == 30)
+
+    def runner(self, M: int) -> 'SpNetRunner':
+        if self._runner is None or self._runner.M != M:
+            self._runner = SpNetRunner(self, M)
+        return self._runner
+
+    def forward(self, x: Tensor, t: Tensor) -> Dict[str, Tensor]:
+        """the reference's call ``sp_deform_net(sp_points.detach(), t)``: d_xyz, d_rotation (raw), d_scaling; autograd reaches
+        the network's parameters (``x`` is detached by the caller in every stage, sk_gs.py:746-748,845)"""
+        params = list(self.parameters())
+        out = _SpNetFn.apply(self, x, t, *params)
+        return dict(d_xyz=out[0], d_rotation=out[1], d_scaling=out[2])
+
+
+class _SpNetDesc(C.Structure):
+    """include/skgs.h::skgs_sp_net"""
+    _fields_ = [('M', C.c_int32), ('reserved', C.c_int32), ('points', C.c_void_p), ('time', C.c_void_p),
+                ('time_w1', C.c_void_p), ('time_b1', C.c_void_p), ('time_w2', C.c_void_p), ('time_b2', C.c_void_p),
+                ('W', C.c_void_p * 8), ('b', C.c_void_p * 8),
+                ('warp_w', C.c_void_p), ('warp_b', C.c_void_p), ('scaling_w', C.c_void_p), ('scaling_b', C.c_void_p),
+                ('rotation_w', C.c_void_p), ('rotation_b', C.c_void_p)]
+
+
+def _net_desc(net: SpDeformNet, M: int, points, time, grads: bool = False) -> _SpNetDesc:
+    """pointers of the parameters (or of their .grad tensors) in the layout of include/skgs.h::skgs_sp_net"""
+    def ptr(p):
+        t = p.grad if grads else p
+        assert t is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        return t.data_ptr()
+    d = _SpNetDesc()
+    d.M = M
+    d.points = None if points is None else points.data_ptr()
+    d.time = None if time is None else time.data_ptr()
+    d.time_w1, d.time_b1 = ptr(net.timenet[0].weight), ptr(net.timenet[0].bias)
+    d.time_w2, d.time_b2 = ptr(net.timenet[2].weight), ptr(net.timenet[2].bias)
+    for i, layer in enumerate(net.linear):
+        d.W[i], d.b[i] = ptr(layer.weight), ptr(layer.bias)
+    d.warp_w, d.warp_b = ptr(net.gaussian_warp.weight), ptr(net.gaussian_warp.bias)
+    d.scaling_w, d.scaling_b = ptr(net.gaussian_scaling.weight), ptr(net.gaussian_scaling.bias)
+    d.rotation_w, d.rotation_b = ptr(net.gaussian_rotation.weight), ptr(net.gaussian_rotation.bias)
+    return d
+
+
+class SpNetRunner:
+    """The launches of one forward / backward of ``SpDeformNet`` on persistent buffers (csrc/sp_mlp.hip):
+
+      forward   ONE launch, a workgroup per block of 16 superpoints runs the whole network for its rows on MFMA tiles
+                (rows are independent: no exchange between workgroups), saves the activations, and ends in the stage's
+                epilogue: ``bone_T = [d_xyz | normalize(d_rotation + [0,0,0,1])]`` (sk_gs.py:847), ``d_rot`` (the same unit
+                quaternion, what ``warp`` blends, sk_gs.py:818-821), ``d_scale``;
+      backward  launch A: the same row blocks walk the layers backwards (gZ = gY * relu', gX = gZ W) and save every gZ;
+                launch B: all weight / bias gradients gW_l = gZ_l^T X_l as 64 x 64 output tiles over all 512 rows on the
+                whole chip, the time network's backward in the workgroup that finishes last.
+    """
+
+    def __init__(self, net: SpDeformNet, M: int):
+        assert net.kernel_supported(), 'csrc/sp_mlp.hip: 8 x 256 layers, skip after layer 4, degrees 10 / 6, time net 13-256-30'
+        self.net, self.M = net, int(M)
+        self.lib = lib = _C.load_library()
+        dev = next(net.parameters()).device
+        if dev.type != 'cuda':
+            raise _C.SkgsError('SpDeformNet kernels need the parameters on a HIP device; sk_gs_amd has no CPU path')
+        lib.skgs_sp_net_saved_bytes.restype = C.c_size_t
+        lib.skgs_sp_net_workspace_bytes.restype = C.c_size_t
+        self.saved = torch.empty((int(lib.skgs_sp_net_saved_bytes(C.c_int32(M))),), dtype=torch.uint8, device=dev)
+        self.ws = torch.zeros((int(lib.skgs_sp_net_workspace_bytes(C.c_int32(M))),), dtype=torch.uint8, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.bone_T, self.d_rot, self.d_scale = torch.empty((M, 7), **f32), torch.empty((M, 4), **f32), torch.empty((M, 3), **f32)
+        self.raw = torch.empty((M, 10), **f32)  # d_xyz | d_rotation (raw) | d_scaling: the reference's three outputs
+
+    def forward(self, points: Tensor, time: Tensor):
+        """fills ``bone_T`` / ``d_rot`` / ``d_scale`` (and ``raw``); ``time``: 1-element device tensor"""
+        d = _net_desc(self.net, self.M, points, time)
+        _C._check(self.lib.skgs_sp_net_forward(
+            C.byref(d), C.c_void_p(self.raw.data_ptr()), C.c_void_p(self.bone_T.data_ptr()), C.c_void_p(self.d_rot.data_ptr()),
+            C.c_void_p(self.d_scale.data_ptr()), C.c_void_p(self.saved.data_ptr()), C.c_size_t(self.saved.numel()), _C._stream()))
+
+    def backward(self, g_bone_T: Optional[Tensor], g_d_rot: Optional[Tensor], g_d_scale: Optional[Tensor],
+                 g_raw: Optional[Tensor] = None, side_adam=None):
+        """parameter gradients WRITTEN into the parameters' ``.grad``.  Either the stage's gradients (``g_bone_T`` [M,7],
+        ``g_d_rot`` [M,4], ``g_d_scale`` [M,3]: the quaternion normalisation's backward runs in the launch) or ``g_raw`` [M,10]
+        w.r.t. the three raw outputs.  ``side_adam`` (``FusedAdam.side_range``): an optimizer piece for the CUs launch A
+        leaves idle."""
+        dg = _net_desc(self.net, self.M, None, None, grads=True)
+        d = _net_desc(self.net, self.M, None, None)
+        p = lambda t: C.c_void_p(None if t is None else t.data_ptr())  # noqa: E731
+        _C._check(self.lib.skgs_sp_net_backward(
+            C.byref(d), C.byref(dg), p(g_bone_T), p(g_d_rot), p(g_d_scale), p(g_raw), C.c_void_p(self.saved.data_ptr()),
+            C.c_size_t(self.saved.numel()), C.c_void_p(self.ws.data_ptr()), C.c_size_t(self.ws.numel()),
+            None if side_adam is None else C.byref(side_adam), _C._stream()))
+
+
+class _SpNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net: SpDeformNet, x: Tensor, t: Tensor, *params):
+        _C._require_gpu(x, 'x')
+        M = x.shape[0]
+        run = net.runner(M)
+        x = _C._f32c(x.detach(), x.device)
+        tt = _C._f32c(t.detach().reshape(-1)[:1], x.device)
+        run.forward(x, tt)
+        ctx.net, ctx.M = net, M
+        raw = run.raw.clone()
+        return raw[:, 0:3], raw[:, 3:7], raw[:, 7:10]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_xyz, g_rot, g_scale):
+        net, M = ctx.net, ctx.M
+        run = net.runner(M)
+        dev = run.raw.device
+        z = lambda g, n: torch.zeros((M, n), device=dev) if g is None else g  # noqa: E731
+        g_raw = torch.cat([z(g_xyz, 3), z(g_rot, 4), z(g_scale, 3)], dim=1).contiguous()
+        params = list(net.parameters())
+        keep = [p.grad for p in params]
+        for p in params:  # the kernels WRITE into .grad: hand autograd fresh tensors and restore what was there
+            p.grad = torch.empty_like(p)
+        run.backward(None, None, None, g_raw=g_raw)
+        grads = [p.grad for p in params]
+        for p, k in zip(params, keep):
+            p.grad = k
+        return (None, None, None, *grads)
+
+
+class SuperpointGaussians(nn.Module):
+    """The part of ``SkeletonGaussianSplatting`` that stage ``sp`` touches per frame: the six Gaussian parameter tensors
+    (gaussian_splatting.py:134-139), ``hyper_feature`` [P,8] (sk_gs.py:428,644), the superpoints ``sp_points`` [M,3] with
+    ``sp_hyper_feature`` [M,8] (:458-462), the weighting's parameters (``_sp_radius`` / ``_sp_weight`` [M] or ``sp_W`` [P,M],
+    :464-475) and ``sp_deform_net``.  ``forward`` reproduces the stage's call sequence on the operator path (autograd);
+    ``FusedSuperpointStep`` runs the same C-ABI calls in a straight line."""
+
+    def __init__(self, P: int, M: int = 512, K: int = 5, sh_degree: int = 3, num_frames: int = 8, seed: int = 0,
+                 scale_mult: float = 1.0, lbs_method: str = 'weighted_kernel', hyper_dim: int = 8, lbs_temperature: float = 1.0):
+        super().__init__()
+        from sk_gs_amd import scene
+        g = scene.make_gaussians(P, seed=seed, sh_degree=sh_degree, scale_mult=scale_mult)
+        self.P, self.M, self.K, self.hyper_dim = P, M, min(K, M), hyper_dim
+        self.static, self.capacity = False, None
+        self.max_sh_degree = self.active_sh_degree = sh_degree
+        self._xyz = nn.Parameter(g['xyz'])
+        self._features_dc = nn.Parameter(g['sh'][:, :1].contiguous())
+        self._features_rest = nn.Parameter(g['sh'][:, 1:].contiguous())
+        self._scaling = nn.Parameter(g['log_scale'])
+        self._rotation = nn.Parameter(g['rot'])
+        self._opacity = nn.Parameter(g['opacity_logit'])
+        gen = torch.Generator().manual_seed(5000 + seed)
+        assert lbs_method in ('W', 'dist', 'kernel', 'weighted_kernel')
+        self.lbs_method, self.lbs_temperature = lbs_method, float(lbs_temperature)
+        # superpoints: sampled from the Gaussians (init_sp_from: sampled, exps/default.yaml:33; sk_gs.py:679-701)
+        pick = torch.randperm(P, generator=gen)[:M]
+        self.sp_points = nn.Parameter(g['xyz'][pick].clone())
+        # hyper coordinates: the reference starts them at -1e-2 / +1e-2 (sk_gs.py:644,696); a little noise keeps the 3+8-d
+        # search from degenerating into the 3-d one in tests
+        self.hyper_feature = nn.Parameter(torch.full((P, hyper_dim), -1e-2) + 0.02 * torch.randn(P, hyper_dim, generator=gen)) \
+            if hyper_dim else None
+        self.sp_hyper_feature = nn.Parameter(torch.full((M, hyper_dim), 1e-2) + 0.02 * torch.randn(M, hyper_dim, generator=gen)) \
+            if hyper_dim else None
+        self.sp_W = nn.Parameter(torch.randn(P, M, generator=gen)) if lbs_method == 'W' else None
+        self._sp_radius = self._sp_weight = None
+        if lbs_method in ('kernel', 'weighted_kernel'):  # log(0.1 * scene range + 1e-7) (sk_gs.py:698-701)
+            self._sp_radius = nn.Parameter(torch.full((M,), math.log(0.1 * 2.6 + 1e-7)))
+        if lbs_method == 'weighted_kernel':
+            self._sp_weight = nn.Parameter(torch.zeros(M))
+        torch.manual_seed(6000 + seed)
+        self.sp_deform_net = SpDeformNet()
+        with torch.no_grad():  # a trained network's output sizes instead of the 1e-5 / 1e-8 heads of reset_parameters
+            self.sp_deform_net.gaussian_warp.weight.normal_(0, 2e-3, generator=gen)
+            self.sp_deform_net.gaussian_rotation.weight.normal_(0, 2e-3, generator=gen)
+            self.sp_deform_net.gaussian_scaling.weight.normal_(0, 2e-5, generator=gen)
+        frames = max(num_frames, 1)
+        self.register_buffer('frame_times', torch.linspace(0., 1., frames).view(frames, 1))
+        self.register_buffer('_rot_bias', torch.tensor([0., 0., 0., 1.]))
+
+    def param_groups(self, lr: float = 1e-3, spatial_scale: float = 1.0, lr_feature_scale: float = 2.5):
+        """``get_params`` (gaussian_splatting.py:443-453 + sk_gs.py:583-602): the six Gaussian groups, then ``sp_deform``,
+        ``sp_points``, the weighting's parameters, and the two hyper features at ``lr * lr_feature_scale``"""
+        groups = [
+            {'params': [self._xyz], 'lr': lr * 0.16 * spatial_scale, 'name': 'xyz'},
+            {'params': [self._features_dc], 'lr': lr * 2.5, 'name': 'f_dc'},
+            {'params': [self._features_rest], 'lr': lr * 2.5 / 20, 'name': 'f_rest'},
+            {'params': [self._opacity], 'lr': lr * 50., 'name': 'opacity'},
+            {'params': [self._scaling], 'lr': lr * 5.0, 'name': 'scaling'},
+            {'params': [self._rotation], 'lr': lr * 1.0, 'name': 'rotation'},
+        ]
+        lr_d = lr * 0.16 * spatial_scale
+        if self.hyper_feature is not None:
+            groups.append({'params': [self.hyper_feature], 'lr': lr * lr_feature_scale, 'name': 'hyper'})
+        if self.sp_W is not None:
+            groups.append({'params': [self.sp_W], 'lr': lr_d, 'name': 'sp_W'})
+        groups.append({'params': list(self.sp_deform_net.parameters()), 'lr': lr_d, 'name': 'sp_deform'})
+        groups.append({'params': [self.sp_points], 'lr': lr_d, 'name': 'sp_points'})
+        if self._sp_radius is not None:
+            groups.append({'params': [self._sp_radius], 'lr': lr_d, 'name': 'sp_radius'})
+        if self._sp_weight is not None:
+            groups.append({'params': [self._sp_weight], 'lr': lr_d, 'name': 'sp_weight'})
+        if self.sp_hyper_feature is not None:
+            groups.append({'params': [self.sp_hyper_feature], 'lr': lr * lr_feature_scale, 'name': 'sp_hyper'})
+        return groups
+
+    # --------------------------------------------------------------------------------------------------- forward
+    def superpoint_transforms(self, time_id: int, reference: bool = False):
+        """``sp_deform_net(sp_points.detach(), t)`` + the normalisation of sk_gs.py:847: (spT [M,7] = (t, unit q), d_rot [M,4],
+        d_scale [M,3])"""
+        t = self.frame_times[time_id]
+        net = self.sp_deform_net
+        out = net.reference_forward(self.sp_points.detach(), t) if (reference or not self.sp_points.is_cuda) \
+            else net(self.sp_points.detach(), t)
+        d_rot = F.normalize(out['d_rotation'] + self._rot_bias, dim=-1)
+        return torch.cat([out['d_xyz'], d_rot], dim=-1), d_rot, out['d_scaling']
+
+    def lbs_weights(self):
+        """``calc_LBS_weight(points, sp_points, hyper_feature, sp_hyper_feature)`` (sk_gs.py:844): weights, indices"""
+        from sk_gs_amd.deform import calc_lbs_weight
+        return calc_lbs_weight(
+            self._xyz.detach(), self.sp_points.detach(), self.K, sp_W=self.sp_W,
+            kernel_radius=None if self._sp_radius is None else torch.exp(self._sp_radius),
+            kernel_weight=None if self._sp_weight is None else torch.sigmoid(self._sp_weight),
+            temperature=self.lbs_temperature, feature=self.hyper_feature, sp_feature=self.sp_hyper_feature)
+
+    def forward(self, time_id: int = 0) -> Dict[str, Tensor]:
+        from sk_gs_amd.deform import lbs_deform
+        sh_features = torch.cat((self._features_dc, self._features_rest), dim=1)
+        spT, d_rot, d_scale = self.superpoint_transforms(time_id)
+        weights, indices = self.lbs_weights()
+        means, scales, rotations, opacity = lbs_deform(self._xyz.detach(), weights, indices, spT, d_rot, d_scale,
+                                                       self._xyz, self._scaling, self._rotation, self._opacity)
+        return dict(points=means, opacity=opacity, scales=scales, rotations=rotations, sh_features=sh_features)
+
+    def render(self, raster_settings, time_id: int = 0, background: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        from sk_gs_amd.renderer.gaussian_render import render
+        out = render(**self(time_id), raster_settings=raster_settings)
+        if background is not None:
+            out['images'] = out['images'] + (1 - out['opacity'][None]) * background.view(3, 1, 1)
+        return out

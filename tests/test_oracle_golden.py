@@ -236,3 +236,95 @@ def test_position_lr_schedule_matches_reference():
         lr_init, lr_final, delay_steps, delay_mult, max_steps = z[f'args{i}']
         got = [position_lr(int(t), lr_init, lr_final, int(max_steps), int(delay_steps), delay_mult) for t in z['steps']]
         np.testing.assert_allclose(got, z[f'lr{i}'], rtol=1e-12, atol=0)
+
+
+def _lbs_cases():
+    g = np.load(os.path.join(GOLD, 'lbs_weights.npz'))
+    for ci, spec in enumerate(g['cases']):
+        method, hyper, P, M, K = str(spec).split('|')
+        yield g, f'c{ci}.', method, int(hyper), int(P), int(M), int(K)
+
+
+def test_lbs_weightings_match_the_reference_calc_LBS_weight(oracle32, oracle64):
+    """``lbs_weights.npz`` holds what the reference's OWN ``calc_LBS_weight`` lines (sk_gs.py:751-774)
+    return -- called unbound on a stand-in self, pytorch3d's ``knn_points`` replaced by brute force with its documented
+    semantics (tests/golden/make_golden_sp.py) -- for the four LBS methods with a 3-d and a 3+8-d search, and the autograd
+    gradients of sum(weights * G).  The oracle's search, its weightings and their analytic backward must reproduce them:
+    indices exactly, weights / distances to fp32 rounding, gradients to 1e-5 of their scale."""
+    n_cases = 0
+    for g, pre, method, hyper, P, M, K in _lbs_cases():
+        n_cases += 1
+        points, sp_points = g[pre + 'points'], g[pre + 'sp_points']
+        if hyper:
+            feat, sp_feat = g[pre + 'in.feature'], g[pre + 'in.sp_feature']
+            pts, sps = np.concatenate([points, feat], 1), np.concatenate([sp_points, sp_feat], 1)
+        else:
+            pts, sps = points, sp_points
+        want_idx, want_w, want_d, G = g[pre + 'indices'], g[pre + 'weights'], g[pre + 'nn_dist'], g[pre + 'G']
+        dist, idx = oracle32.knn_bones(pts, sps, K)
+        np.testing.assert_array_equal(idx, want_idx, err_msg=f'{pre}{method} dim={3 + hyper}: neighbour indices')
+        np.testing.assert_allclose(dist, want_d, rtol=2e-6, atol=1e-7)
+        scale = lambda a: max(float(np.abs(a).max()), 1e-30)  # noqa: E731
+        if method in ('weighted_kernel', 'kernel'):
+            radius = np.exp(g[pre + 'in._sp_radius'].astype(np.float64))
+            kw = 1.0 / (1.0 + np.exp(-g[pre + 'in._sp_weight'].astype(np.float64))) if method == 'weighted_kernel' else None
+            for o, tol in ((oracle32, 2e-6), (oracle64, 2e-6)):
+                w, gr = o.lbs_weights_kernel(dist, idx, radius, kw, g_weights=G)
+                assert np.abs(w - want_w).max() <= tol, (pre, method)
+            # raw-parameter gradients (chain rule through exp / sigmoid, sk_gs.py:547-553)
+            w, gr = oracle64.lbs_weights_kernel(dist, idx, radius, kw, g_weights=G)
+            g_raw_radius = gr['g_radius'] * radius
+            assert np.abs(g_raw_radius - g[pre + 'grad._sp_radius']).max() / scale(g[pre + 'grad._sp_radius']) < 1e-5
+            if kw is not None:
+                g_raw_w = gr['g_weight'] * kw * (1 - kw)
+                assert np.abs(g_raw_w - g[pre + 'grad._sp_weight']).max() / scale(g[pre + 'grad._sp_weight']) < 1e-5
+            g_dist = gr['g_dist']
+        elif method == 'dist':
+            T = float(g[pre + 'temperature'])
+            w = oracle32.lbs_weights_dist(dist, T)
+            assert np.abs(w - want_w).max() <= 2e-6
+            _, g_dist = oracle64.lbs_weights_dist(dist, T, g_weights=G)
+        else:  # W: softmax of the gathered logits
+            w = oracle32.lbs_weights(g[pre + 'in.sp_W'], idx)
+            assert np.abs(w - want_w).max() <= 2e-6
+            # dense gradient = scatter of w * (G - sum w G): what skgs_lbs_weights_backward writes
+            w64 = want_w.astype(np.float64)
+            gl = w64 * (G - (G * w64).sum(1, keepdims=True))
+            dense = np.zeros((P, M))
+            np.put_along_axis(dense, idx, gl, axis=1)
+            assert np.abs(dense - g[pre + 'grad.sp_W']).max() / scale(g[pre + 'grad.sp_W']) < 1e-5
+            g_dist = None
+        if hyper and g_dist is not None:  # the distances' gradient reaches the two hyper features (points are detached)
+            g_p, g_j = oracle64.knn_dist_backward(pts, sps, idx, g_dist)
+            assert np.abs(g_p[:, 3:] - g[pre + 'grad.feature']).max() / scale(g[pre + 'grad.feature']) < 1e-5
+            assert np.abs(g_j[:, 3:] - g[pre + 'grad.sp_feature']).max() / scale(g[pre + 'grad.sp_feature']) < 1e-5
+        elif hyper and method == 'W':
+            assert float(np.abs(g[pre + 'grad.feature']).max()) == 0.0  # logits do not depend on the distances
+    assert n_cases == 24
+
+
+def test_sp_deform_net_restatement_matches_reference_DeformNetwork():
+    """``SpDeformNet.reference_forward`` (the torch restatement the sp-stage kernels are checked against at full size) against
+    the reference's own ``DeformNetwork(is_blender=True)`` (sk_gs.py:209-315) on the fixture of make_golden_sp.py: outputs,
+    the hidden state, every parameter gradient, and the quaternion normalisation of sk_gs.py:847.  The state_dict loads by
+    the reference's parameter names."""
+    from sk_gs_amd.superpoint import SpDeformNet
+    g = load('sp_deformnet.npz')
+    net = SpDeformNet(D=8, W=32, time_out=int(g['w32.time_out']))
+    assert net.skips == list(g['w32.skips'])
+    sd = {k[len('w32.param.'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith('w32.param.')}
+    assert set(sd) == set(dict(net.named_parameters()))  # same names as the reference's state_dict
+    net.load_state_dict(sd)
+    x, t = torch.from_numpy(g['w32.x']), torch.from_numpy(g['w32.t'])
+    out = net.reference_forward(x, t)
+    for n in ('d_xyz', 'd_rotation', 'd_scaling'):
+        np.testing.assert_allclose(out[n].detach().numpy(), g[f'w32.out.{n}'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out['hidden'].detach().numpy(), g['w32.hidden'], rtol=1e-5, atol=1e-6)
+    names = ('d_xyz', 'd_rotation', 'd_scaling')
+    params = dict(net.named_parameters())
+    grads = torch.autograd.grad([out[n] for n in names], list(params.values()), [torch.from_numpy(g[f'w32.gy.{n}']) for n in names])
+    for (n, _), gr in zip(params.items(), grads):
+        want = g[f'w32.grad.{n}']
+        assert np.abs(gr.numpy() - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-30) + 1e-7, n
+    q = torch.nn.functional.normalize(out['d_rotation'] + torch.tensor([0, 0, 0, 1.]), dim=-1)
+    np.testing.assert_allclose(q.detach().numpy(), g['w32.d_rot_normalized'], rtol=1e-6, atol=1e-7)
