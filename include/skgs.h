@@ -489,6 +489,29 @@ int skgs_skeleton_backward(const skgs_mlp_desc* d, const skgs_bone_chain_desc* b
     skgs_stream_t stream);
 int skgs_deform_mlp_status(const void* workspace, uint32_t* host_words4, skgs_stream_t stream);
 
+/* ---- calc_LBS_weight of the SUPERPOINT stage (networks/sk_gs.py:751-774 as sp_stage calls it, :844) ----
+ * K (<= 16) nearest of the M superpoints by squared L2 over [xyz | hyper_feature] (F = 8 hyper dimensions, or F = 0: xyz only;
+ * pytorch3d.knn_points semantics: ascending, ties to the lower index; the positions carry no gradient, :753-755), then one of
+ *   sp_W != NULL          : w = softmax_k(sp_W[p, idx])                                   (`W`, sk_gs.py:767-768)
+ *   sp_radius_raw != NULL : w = (exp(-d / (2 r^2)) [* s] + 1e-7) / sum_k(...),  r = exp(_sp_radius), s = sigmoid(_sp_weight)
+ *                                                                                         (`kernel` / `weighted_kernel`, :760-766)
+ *   neither               : w = softmax_k(-d / temperature)                               (`dist`, :770)
+ * in ONE launch.  points [P,3], feature [P,F], sp_points [M,3], sp_feature [M,F], sp_radius_raw / sp_weight_raw [M] (the RAW
+ * parameters: the kernels apply exp / sigmoid, sk_gs.py:547-553), sp_W [P,M].  out_idx [P,K] int64, out_weights [P,K],
+ * out_dist [P,K] (may be NULL for `W`).  Same arithmetic as skgs_knn_dist_weights_forward / skgs_lbs_weights_forward on the
+ * concatenated rows (bit-identical weights).
+ * Backward of the two distance-based weightings: g_weights [P,K] -> g_feature [P,F] (written), g_sp_feature [M,F],
+ * g_sp_radius [M], g_sp_weight [M] w.r.t. the raw parameters (written; any may be NULL).  workspace:
+ * skgs_sp_lbs_weights_workspace_bytes(P, M, F).  (`W`: skgs_lbs_weights_backward.) */
+int skgs_sp_lbs_weights_forward(int32_t P, int32_t M, int32_t K, int32_t F, const float* points, const float* feature,
+    const float* sp_points, const float* sp_feature, const float* sp_radius_raw, const float* sp_weight_raw, float temperature,
+    const float* sp_W, int64_t* out_idx, float* out_weights, float* out_dist, skgs_stream_t stream);
+size_t skgs_sp_lbs_weights_workspace_bytes(int32_t P, int32_t M, int32_t F);
+int skgs_sp_lbs_weights_backward(int32_t P, int32_t M, int32_t K, int32_t F, const float* feature, const float* sp_feature,
+    const float* sp_radius_raw, const float* sp_weight_raw, float temperature, const float* weights, const int64_t* indices,
+    const float* nn_dist, const float* g_weights, float* g_feature, float* g_sp_feature, float* g_sp_radius, float* g_sp_weight,
+    void* workspace, size_t workspace_bytes, skgs_stream_t stream);
+
 /* ---- the deform network of the SUPERPOINT stage (stage `sp`, networks/sk_gs.py:830-856) ----
  * sp_deform_net = DeformNetwork (networks/sk_gs.py:209-315) as the shipped configs build it (exps/default.yaml:4-11,31:
  * is_blender, D = 8, W = 256, skips = [4], position degree 10, time degree 6), evaluated on the M superpoints (512,

@@ -1,0 +1,315 @@
+// sp_knn.hip -- calc_LBS_weight of the SUPERPOINT stage (networks/sk_gs.py:751-774 as sp_stage calls it, :844): the K nearest of
+// M = 512 superpoints in 3 + 8 dimensions ([xyz | hyper_feature], the positions detached, :753-755) and one of the four
+// weightings, in ONE launch; and its backward.
+//
+// The search is P x M x 11 subtract / multiply / add triples with a 5-slot insertion behind each: 100k x 512 candidates are
+// 2.8 G lane-operations if done blindly.  Exact arithmetic (the distance is the oracle's left-to-right sum of squares, no
+// contraction: indices must be BIT-exact, ties to the lower id as pytorch3d) leaves two exact savings, both wave-wide:
+//   * a candidate whose xyz part alone is already no better than the last entry of the lane's list cannot enter the list
+//     (adding non-negative terms never decreases an fp32 sum): when that holds for ALL 64 lanes the eight hyper dimensions are
+//     skipped;
+//   * when no lane's full distance beats its K-th, the insertion network is skipped.
+// Superpoints live in LDS as 12-float rows (three broadcast ds_read_b128 per candidate).  The list is kept sorted with
+// v_min / v_med3 on the distances (slot k becomes med3(d[k-1], d[k], cand)) and two selects per slot on the ids: 4 K
+// operations instead of the 5 K of a compare-and-swap bubble.
+// Weightings exactly as csrc/deform.hip::knn_dist_weights_kernel / lbs_weights_forward_kernel evaluate them (the operator
+// path), so the fused step and the autograd path see the same weights bit for bit.
+//
+// Backward (distance-based weightings): g_weights [P,K] -> g_dist -> hyper_feature.grad [P,F] (per Gaussian) and, summed over
+// the (Gaussian, neighbour) pairs that picked superpoint j, sp_hyper_feature.grad [M,F], _sp_radius.grad, _sp_weight.grad:
+// LDS accumulators per workgroup, partials, fixed-order reduction (as dist_weights_backward_kernel).  The `W` weighting's
+// dense [P,M] logit gradient is skgs_lbs_weights_backward.
+#pragma clang fp contract(off)
+#include <algorithm>
+#include <cstdint>
+
+#include "skgs_common.h"
+
+namespace skgs {
+namespace {
+
+constexpr int SPK_THREADS = 256;
+constexpr int CROW        = 12;  // LDS row of a superpoint: xyz, 8 hyper coordinates, pad
+constexpr int MAXF        = 8;
+
+template <int KCAP>
+__device__ __forceinline__ void topk_insert_sorted(float (&bd)[KCAP], int (&bi)[KCAP], float d, int id) {
+  bool lt[KCAP];
+#pragma unroll
+  for (int k = 0; k < KCAP; ++k) lt[k] = d < bd[k];
+#pragma unroll
+  for (int k = KCAP - 1; k >= 1; --k) {
+    bi[k] = lt[k - 1] ? bi[k - 1] : (lt[k] ? id : bi[k]);
+    bd[k] = __builtin_amdgcn_fmed3f(bd[k - 1], bd[k], d);  // bd[k-1] <= bd[k]: clamps d into the slot's interval
+  }
+  bi[0] = lt[0] ? id : bi[0];
+  bd[0] = fminf(bd[0], d);
+}
+
+__device__ __forceinline__ float act_radius(const float* __restrict__ r, int j) { return expf(r[j]); }
+__device__ __forceinline__ float act_kweight(const float* __restrict__ w, int j) { return 1.0f / (1.0f + expf(-w[j])); }
+
+// F = number of hyper dimensions (0 or 8)
+template <int KCAP, int F>
+__global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int M, int K, const float* __restrict__ points,
+    const float* __restrict__ feature, const float* __restrict__ sp_points, const float* __restrict__ sp_feature,
+    const float* __restrict__ radius_raw, const float* __restrict__ kweight_raw, float temperature, const float* __restrict__ sp_W,
+    int64_t* __restrict__ out_idx, float* __restrict__ out_weights, float* __restrict__ out_dist) {
+  extern __shared__ __attribute__((aligned(16))) float s_c[];  // [M][CROW]
+  for (int i = threadIdx.x; i < M * CROW; i += SPK_THREADS) {
+    const int j = i / CROW, c = i - j * CROW;
+    float v = 0.f;
+    if (c < 3)
+      v = sp_points[3 * j + c];
+    else if (c < 3 + F)
+      v = sp_feature[(size_t) j * F + c - 3];
+    s_c[i] = v;
+  }
+  __syncthreads();
+  const int n  = blockIdx.x * SPK_THREADS + threadIdx.x;
+  const int nn = min(n, P - 1);  // (lanes beyond P follow the last Gaussian: the wave-wide tests stay well defined)
+  const float p0 = points[3 * nn], p1 = points[3 * nn + 1], p2 = points[3 * nn + 2];
+  float f[MAXF];
+#pragma unroll
+  for (int c = 0; c < MAXF; ++c) f[c] = (F > 0 && c < F) ? feature[(size_t) nn * F + c] : 0.f;
+  float bd[KCAP];
+  int bi[KCAP];
+#pragma unroll
+  for (int k = 0; k < KCAP; ++k) bd[k] = __builtin_inff(), bi[k] = 0;
+  for (int j = 0; j < M; ++j) {
+    const float4 c0 = *reinterpret_cast<const float4*>(s_c + j * CROW);
+    const float d0 = p0 - c0.x, d1 = p1 - c0.y, d2 = p2 - c0.z;
+    float d = d0 * d0;  // (0 + t = t: the oracle's `d = 0; d += df * df` starts here)
+    d += d1 * d1;
+    d += d2 * d2;
+    if (F > 0) {
+      if (__builtin_amdgcn_ballot_w64(d < bd[KCAP - 1]) == 0) continue;  // exact: the sum only grows
+      const float4 c1 = *reinterpret_cast<const float4*>(s_c + j * CROW + 4);
+      const float4 c2 = *reinterpret_cast<const float4*>(s_c + j * CROW + 8);
+      const float e3 = f[0] - c0.w, e4 = f[1] - c1.x, e5 = f[2] - c1.y, e6 = f[3] - c1.z, e7 = f[4] - c1.w;
+      const float e8 = f[5] - c2.x, e9 = f[6] - c2.y, e10 = f[7] - c2.z;
+      d += e3 * e3;
+      d += e4 * e4;
+      d += e5 * e5;
+      d += e6 * e6;
+      d += e7 * e7;
+      d += e8 * e8;
+      d += e9 * e9;
+      d += e10 * e10;
+    }
+    if (__builtin_amdgcn_ballot_w64(d < bd[KCAP - 1]) == 0) continue;
+    topk_insert_sorted<KCAP>(bd, bi, d, j);
+  }
+  if (n >= P) return;
+  // ---- weighting (sk_gs.py:759-770), the arithmetic of deform.hip::knn_dist_weights_kernel / lbs_weights_forward_kernel
+  float v[KCAP];
+  float sum = 0.f;
+  if (sp_W) {  // softmax of the gathered logits
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) {
+      v[k] = k < K ? sp_W[(size_t) n * M + bi[k]] : -INFINITY;
+      mx   = fmaxf(mx, v[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) {
+      v[k] = k < K ? expf(v[k] - mx) : 0.f;
+      sum += v[k];
+    }
+  } else if (radius_raw) {  // exp(-d / (2 r^2)) [* s] + 1e-7, / sum
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) {
+      v[k] = 0.f;
+      if (k < K) {
+        const float r = act_radius(radius_raw, bi[k]);
+        float e = expf(-bd[k] / (2.f * (r * r)));
+        if (kweight_raw) e = e * act_kweight(kweight_raw, bi[k]);
+        v[k] = e + 1e-7f;
+        sum += v[k];
+      }
+    }
+  } else {  // softmax(-d / temperature)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) {
+      v[k] = k < K ? -bd[k] / temperature : -INFINITY;
+      mx   = fmaxf(mx, v[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) {
+      v[k] = k < K ? expf(v[k] - mx) : 0.f;
+      sum += v[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KCAP; ++k)
+    if (k < K) {
+      out_weights[(size_t) n * K + k] = v[k] / sum;
+      out_idx[(size_t) n * K + k]     = bi[k];
+      if (out_dist) out_dist[(size_t) n * K + k] = bd[k];
+    }
+}
+
+// ---- backward of the distance-based weightings -----------------------------------------------------------------------------
+// accumulators per superpoint: [F] hyper-feature gradient, radius, kernel weight
+constexpr int SPB_MAX_BLOCKS = 256;
+template <int F>
+__global__ void __launch_bounds__(SPK_THREADS) sp_weights_backward_kernel(int P, int M, int K, const float* __restrict__ feature,
+    const float* __restrict__ sp_feature, const float* __restrict__ radius_raw, const float* __restrict__ kweight_raw,
+    float temperature, const float* __restrict__ weights, const int64_t* __restrict__ indices, const float* __restrict__ nn_dist,
+    const float* __restrict__ g_weights, float* __restrict__ g_feature, float* __restrict__ partials) {
+  extern __shared__ float s_acc[];  // [M][V]
+  constexpr int V = F + 2;
+  for (int i = threadIdx.x; i < M * V; i += SPK_THREADS) s_acc[i] = 0.f;
+  __syncthreads();
+  for (int n = blockIdx.x * SPK_THREADS + threadIdx.x; n < P; n += gridDim.x * SPK_THREADS) {
+    const float* w  = weights + (size_t) n * K;
+    const float* gw = g_weights + (size_t) n * K;
+    const float* dd = nn_dist + (size_t) n * K;
+    const int64_t* ix = indices + (size_t) n * K;
+    float dot = 0.f;
+    for (int k = 0; k < K; ++k) dot += w[k] * gw[k];
+    float sum = 0.f;
+    if (radius_raw)  // S = sum_k v_k is not stored: recomputed with the forward's arithmetic
+      for (int k = 0; k < K; ++k) {
+        const float r = act_radius(radius_raw, (int) ix[k]);
+        float e = expf(-dd[k] / (2.f * (r * r)));
+        if (kweight_raw) e = e * act_kweight(kweight_raw, (int) ix[k]);
+        sum += e + 1e-7f;
+      }
+    float gf[MAXF];
+#pragma unroll
+    for (int c = 0; c < MAXF; ++c) gf[c] = 0.f;
+    float fc[MAXF];
+#pragma unroll
+    for (int c = 0; c < MAXF; ++c) fc[c] = (F > 0 && c < F) ? feature[(size_t) n * F + c] : 0.f;
+    for (int k = 0; k < K; ++k) {
+      const int j = (int) ix[k];
+      float g_d;
+      if (radius_raw) {
+        const float r   = act_radius(radius_raw, j);
+        const float e   = expf(-dd[k] / (2.f * (r * r)));
+        const float sk  = kweight_raw ? act_kweight(kweight_raw, j) : 1.f;
+        const float g_v = (gw[k] - dot) / sum;
+        const float g_e = g_v * sk;
+        g_d             = g_e * e * (-1.f / (2.f * (r * r)));
+        atomicAdd(s_acc + (size_t) j * V + F, g_e * e * (dd[k] / (r * r * r)));
+        if (kweight_raw) atomicAdd(s_acc + (size_t) j * V + F + 1, g_v * e);
+      } else {
+        g_d = -(w[k] * (gw[k] - dot)) / temperature;
+      }
+#pragma unroll
+      for (int c = 0; c < MAXF; ++c)
+        if (F > 0 && c < F) {
+          const float t = g_d * 2.f * (fc[c] - sp_feature[(size_t) j * F + c]);
+          gf[c] += t;
+          atomicAdd(s_acc + (size_t) j * V + c, -t);
+        }
+    }
+    if (g_feature)
+#pragma unroll
+      for (int c = 0; c < MAXF; ++c)
+        if (F > 0 && c < F) g_feature[(size_t) n * F + c] = gf[c];
+  }
+  __syncthreads();
+  float* dst = partials + (size_t) blockIdx.x * M * V;
+  for (int i = threadIdx.x; i < M * V; i += SPK_THREADS) dst[i] = s_acc[i];
+}
+
+__global__ void __launch_bounds__(256) sp_weights_finalize_kernel(int M, int F, int nblk, const float* __restrict__ partials,
+    float* __restrict__ g_sp_feature, float* __restrict__ g_radius, float* __restrict__ g_kweight,
+    const float* __restrict__ radius_raw, const float* __restrict__ kweight_raw) {
+  const int V = F + 2, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * V) return;
+  float s = 0.f;
+  for (int b0 = 0; b0 < nblk; b0 += 16) {  // 16 loads in flight per round, summed in block order
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = partials[(size_t) min(b0 + u, nblk - 1) * M * V + i];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (b0 + u < nblk) s += v[u];
+  }
+  const int j = i / V, c = i % V;
+  if (c < F) {
+    if (g_sp_feature) g_sp_feature[(size_t) j * F + c] = s;
+  } else if (c == F) {  // w.r.t. the RAW parameter: d exp(x) = exp(x)
+    if (g_radius) g_radius[j] = radius_raw ? s * expf(radius_raw[j]) : 0.f;
+  } else if (g_kweight) {  // d sigmoid(x) = s (1 - s)
+    float d = 0.f;
+    if (kweight_raw) {
+      const float sg = 1.0f / (1.0f + expf(-kweight_raw[j]));
+      d = sg * (1.f - sg);
+    }
+    g_kweight[j] = s * d;
+  }
+}
+
+int backward_blocks(int P) { return std::max(1, std::min((P + SPK_THREADS - 1) / SPK_THREADS, SPB_MAX_BLOCKS)); }
+
+}  // namespace
+}  // namespace skgs
+
+using namespace skgs;
+
+extern "C" {
+
+size_t skgs_sp_lbs_weights_workspace_bytes(int32_t P, int32_t M, int32_t F) {
+  return (size_t) backward_blocks(P) * M * (F + 2) * sizeof(float);
+}
+
+int skgs_sp_lbs_weights_forward(int32_t P, int32_t M, int32_t K, int32_t F, const float* points, const float* feature,
+    const float* sp_points, const float* sp_feature, const float* sp_radius_raw, const float* sp_weight_raw, float temperature,
+    const float* sp_W, int64_t* out_idx, float* out_weights, float* out_dist, skgs_stream_t stream) {
+  SKGS_REQUIRE(P >= 0 && M >= 1 && K >= 1 && K <= 16 && K <= M, "sp_lbs_weights_forward: need P >= 0, 1 <= K <= min(16, M)");
+  SKGS_REQUIRE(F == 0 || F == 8, "sp_lbs_weights_forward: F (hyper dimensions) must be 0 or 8");
+  if (P == 0) return 0;
+  SKGS_REQUIRE(points && sp_points && out_idx && out_weights && (F == 0 || (feature && sp_feature)),
+      "sp_lbs_weights_forward: NULL argument");
+  SKGS_REQUIRE(!(sp_weight_raw && !sp_radius_raw), "sp_lbs_weights_forward: a kernel weight needs a kernel radius");
+  const size_t lds = (size_t) M * CROW * 4;
+  SKGS_REQUIRE(lds <= 64 * 1024, "sp_lbs_weights_forward: too many superpoints for the LDS table (<= 1365)");
+  hipStream_t s = (hipStream_t) stream;
+  ProfScope prof(K_SP_KNN, s);
+  const dim3 grid((P + SPK_THREADS - 1) / SPK_THREADS), block(SPK_THREADS);
+#define SKGS_SPK(KCAP_, F_)                                                                                              \
+  hipLaunchKernelGGL((sp_knn_weights_kernel<KCAP_, F_>), grid, block, lds, s, P, M, K, points, feature, sp_points, sp_feature, \
+      sp_radius_raw, sp_weight_raw, temperature, sp_W, out_idx, out_weights, out_dist)
+  if (F == 8) {
+    if (K <= 5) SKGS_SPK(5, 8); else if (K <= 8) SKGS_SPK(8, 8); else SKGS_SPK(16, 8);
+  } else {
+    if (K <= 5) SKGS_SPK(5, 0); else if (K <= 8) SKGS_SPK(8, 0); else SKGS_SPK(16, 0);
+  }
+#undef SKGS_SPK
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int skgs_sp_lbs_weights_backward(int32_t P, int32_t M, int32_t K, int32_t F, const float* feature, const float* sp_feature,
+    const float* sp_radius_raw, const float* sp_weight_raw, float temperature, const float* weights, const int64_t* indices,
+    const float* nn_dist, const float* g_weights, float* g_feature, float* g_sp_feature, float* g_sp_radius, float* g_sp_weight,
+    void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
+  SKGS_REQUIRE(P >= 0 && M >= 1 && K >= 1 && K <= 16, "sp_lbs_weights_backward: need P >= 0, 1 <= K <= 16");
+  SKGS_REQUIRE(F == 0 || F == 8, "sp_lbs_weights_backward: F (hyper dimensions) must be 0 or 8");
+  SKGS_REQUIRE(P == 0 || (weights && indices && nn_dist && g_weights && (F == 0 || (feature && sp_feature))),
+      "sp_lbs_weights_backward: NULL argument");
+  SKGS_REQUIRE(workspace && workspace_bytes >= skgs_sp_lbs_weights_workspace_bytes(P, M, F), "sp_lbs_weights_backward: workspace too small");
+  const int V = F + 2, nblk = backward_blocks(P);
+  const size_t lds = (size_t) M * V * 4;
+  SKGS_REQUIRE(lds <= 64 * 1024, "sp_lbs_weights_backward: too many superpoints for the LDS accumulators");
+  hipStream_t s = (hipStream_t) stream;
+  ProfScope prof(K_SP_KNN_BWD, s);
+  float* partials = reinterpret_cast<float*>(workspace);
+  if (F == 8)
+    hipLaunchKernelGGL((sp_weights_backward_kernel<8>), dim3(nblk), dim3(SPK_THREADS), lds, s, P, M, K, feature, sp_feature,
+        sp_radius_raw, sp_weight_raw, temperature, weights, indices, nn_dist, g_weights, g_feature, partials);
+  else
+    hipLaunchKernelGGL((sp_weights_backward_kernel<0>), dim3(nblk), dim3(SPK_THREADS), lds, s, P, M, K, feature, sp_feature,
+        sp_radius_raw, sp_weight_raw, temperature, weights, indices, nn_dist, g_weights, g_feature, partials);
+  hipLaunchKernelGGL(sp_weights_finalize_kernel, dim3((M * V + 255) / 256), dim3(256), 0, s, M, F, nblk, partials, g_sp_feature,
+      g_sp_radius, g_sp_weight, sp_radius_raw, sp_weight_raw);
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

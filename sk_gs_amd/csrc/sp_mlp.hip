@@ -50,7 +50,10 @@ constexpr int THID   = 256, TOUT = 30;
 constexpr int IN0    = PDIM + TOUT;          // 93
 constexpr int IN0P   = 96;                   // padded row of the saved encoded input
 constexpr int ROWS   = 16;                   // superpoints per workgroup = the MFMA tile's rows
-constexpr int NT     = 256;                  // 4 waves
+constexpr int NT     = 512;                  // 8 waves: two per SIMD, each owns 32 features (two 16x16 tiles) of every layer
+constexpr int NTB    = 256;                  // the weight-gradient launch: 4 waves
+constexpr int NWAVE  = NT / 64;
+constexpr int FPW    = SPW / NWAVE;          // features per wave (32)
 constexpr int PITCH  = SPW + 4;              // LDS row pitch of an activation block (floats)
 constexpr int XPITCH = IN0P + 4;
 constexpr int NOUT   = 10;                   // d_xyz 3 | d_rotation 4 | d_scaling 3
@@ -59,8 +62,13 @@ struct __attribute__((packed, aligned(4))) f4u {  // a float4 at 4-byte alignmen
   float x, y, z, w;
 };
 __device__ __forceinline__ float4 ldg4(const float* p) {
+#ifdef SPX_NO_LOAD  // timing experiment: no weight traffic
+  const float f = __builtin_bit_cast(float, (uint32_t) (uintptr_t) p);
+  return make_float4(f, f, f, f);
+#else
   const f4u v = *reinterpret_cast<const f4u*>(p);
   return make_float4(v.x, v.y, v.z, v.w);
+#endif
 }
 __device__ __forceinline__ float4 ldg4_guard(const float* p, int valid) {  // elements [0, valid) exist
   float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -70,7 +78,11 @@ __device__ __forceinline__ float4 ldg4_guard(const float* p, int valid) {  // el
   if (valid > 2) r.z = p[2];
   return r;
 }
+#ifndef SPX_NO_MFMA
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+#else  // timing experiment: the operands are consumed, the matrix pipe is not used
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { c[0] += a * b; return c; }
+#endif
 
 // saved by the forward for the backward (floats), Mp = rows rounded up to 16
 struct SavedView {
@@ -98,15 +110,17 @@ __host__ __device__ inline SavedView saved_view(void* base, int M) {
   v.tout = p;
   return v;
 }
-// backward workspace: ticket (256 B) | GH [Mp][16] head cotangents (10 used) | GZ [SPD][Mp][SPW]
+// backward workspace: (256 B reserved) | GH [Mp][16] head cotangents (10 used) | GZ [SPD][Mp][SPW] | GBP [2][Mp / 16][SPW]: the
+// row blocks' column sums of gZ_0 and gZ_5 (the time network's backward needs the bias gradients of those two layers)
 struct WorkView {
   unsigned* ticket;
   float* GH;
   float* GZ;
+  float* GBP;
 };
 __host__ __device__ inline size_t work_bytes(int M) {
   const size_t Mp = pad_rows(M);
-  return 256 + (Mp * 16 + (size_t) SPD * Mp * SPW) * 4;
+  return 256 + (Mp * 16 + (size_t) SPD * Mp * SPW + 2 * (Mp / ROWS) * SPW) * 4;
 }
 __host__ __device__ inline WorkView work_view(void* base, int M) {
   const size_t Mp = pad_rows(M);
@@ -114,6 +128,7 @@ __host__ __device__ inline WorkView work_view(void* base, int M) {
   v.ticket = reinterpret_cast<unsigned*>(base);
   v.GH     = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + 256);
   v.GZ     = v.GH + Mp * 16;
+  v.GBP    = v.GZ + (size_t) SPD * Mp * SPW;
   return v;
 }
 
@@ -131,88 +146,101 @@ struct SideAdam {
 __host__ __device__ inline int layer_ld(int l) { return l == 0 ? IN0 : (l == SKIP + 1 ? IN0 + SPW : SPW); }
 __host__ __device__ inline int layer_hofs(int l) { return l == SKIP + 1 ? IN0 : 0; }
 
-// acc[c] (tile c = output features 64 wave + 16 c + j) += A[16 x 16 nsteps] W^T, A from LDS (row pitch pa), W rows at stride ldw
-// starting at column kofs; `kvalid` = number of valid weight columns from kofs (the tail of the 93-wide input is guarded).
-template <bool GUARD>
-__device__ __forceinline__ void gemm_fwd(f32x4 (&acc)[4], const float* sA, int pa, const float* __restrict__ W, int ldw, int kofs,
-    int nsteps, int kvalid, int wave, int lane) {
+// ---- weight operands go through a per-wave LDS staging area ---------------------------------------------------------------
+// A 16x16 MFMA tile wants lane (j, q) to hold row j of the weight matrix: a wave instruction that loads the operand straight
+// from global memory touches 16 rows x 64 B -- HALF cache lines -- and one workgroup then pulls its 2.3 MB of weights at
+// 37 GB/s (56 us for the eight layers; 8 rows x 128 B or 1 row x 1 KB per instruction: 135 GB/s = the L1's 64 B/clk, 15.5 us;
+// tools/micro/weight_stream_patterns.hip, MI355X).  So every wave loads its slab of the weights with full-line instructions
+// (4 rows x 256 B forward, 8 rows x 128 B backward), parks it in a PRIVATE LDS region (no barrier: LDS instructions of one
+// wave execute in order) and reads the MFMA operand back from there.  The next chunk's global loads are in flight while the
+// current chunk's MFMAs run; the other wave of the SIMD covers the write -> read turn-around.
+constexpr int FST_P       = 68;              // forward stage: [32 features][64 k + 4]
+constexpr int BST_P       = 36;              // backward stage: [64 outputs][32 inputs + 4]
+constexpr int STAGE_F     = 64 * BST_P;      // floats per wave (>= 32 * FST_P)
+static_assert(STAGE_F >= 32 * FST_P, "stage");
+constexpr size_t STAGE_BYTES = (size_t) NWAVE * STAGE_F * 4;
+
+// Forward product of one layer part.  Tile c (c = 0, 1) of a wave holds output features f0 + 2 j + c (f0 = 32 wave): a lane
+// ends with two CONSECUTIVE features per row.  acc[c] += A[16 x 16 NSTEPS] W^T with A from LDS (row pitch pa) and W rows at
+// stride ldw from column kofs, in chunks of 64 k.  `kvalid` = valid weight columns from kofs (the 93-wide part is guarded).
+template <int NSTEPS, bool GUARD>
+__device__ __forceinline__ void gemm_fwd(f32x4 (&acc)[2], const float* sA, int pa, const float* __restrict__ W, int ldw, int kofs,
+    int kvalid, int wave, int lane, float* sw) {
+  constexpr int NCH = (NSTEPS + 3) / 4;
   const int j = lane & 15, q = lane >> 4;
   const float* arow = sA + j * pa + 4 * q;
-  const float* wrow[4];
+  const float* wb   = W + (size_t) (FPW * wave + q) * ldw + kofs + 4 * j;  // chunk loads: lane -> row q + 4 i, 16 B at column 4 j
+  float* wr         = sw + q * FST_P + 4 * j;
+  const float* rd0  = sw + (2 * j) * FST_P + 4 * q;
+  float4 g[2][8];
+  auto fetch = [&](int ck, float4 (&dst)[8]) {
 #pragma unroll
-  for (int c = 0; c < 4; ++c) wrow[c] = W + (size_t) (64 * wave + 16 * c + j) * ldw + kofs + 4 * q;
-  float4 b[2][4];
-  auto fetch = [&](int s, float4 (&dst)[4]) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dst[c] = GUARD ? ldg4_guard(wrow[c] + 16 * s, kvalid - (16 * s + 4 * q)) : ldg4(wrow[c] + 16 * s);
+    for (int i = 0; i < 8; ++i) {
+      const float* p = wb + (size_t) (4 * i) * ldw + 64 * ck;
+      dst[i] = GUARD ? ldg4_guard(p, kvalid - (64 * ck + 4 * j)) : ldg4(p);
+    }
   };
-  fetch(0, b[0]);
-  for (int s = 0; s < nsteps; s += 2) {
-    if (s + 1 < nsteps) fetch(s + 1, b[1]);
-    {
-      const float4 a = *reinterpret_cast<const float4*>(arow + 16 * s);
+  fetch(0, g[0]);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        acc[c] = mfma4(a.x, b[0][c].x, acc[c]);
-        acc[c] = mfma4(a.y, b[0][c].y, acc[c]);
-        acc[c] = mfma4(a.z, b[0][c].z, acc[c]);
-        acc[c] = mfma4(a.w, b[0][c].w, acc[c]);
-      }
-    }
-    if (s + 2 < nsteps) fetch(s + 2, b[0]);
-    if (s + 1 < nsteps) {
-      const float4 a = *reinterpret_cast<const float4*>(arow + 16 * (s + 1));
+  for (int ck = 0; ck < NCH; ++ck) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        acc[c] = mfma4(a.x, b[1][c].x, acc[c]);
-        acc[c] = mfma4(a.y, b[1][c].y, acc[c]);
-        acc[c] = mfma4(a.z, b[1][c].z, acc[c]);
-        acc[c] = mfma4(a.w, b[1][c].w, acc[c]);
-      }
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(wr + (4 * i) * FST_P) = g[ck & 1][i];
+    if (ck + 1 < NCH) fetch(ck + 1, g[(ck + 1) & 1]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (4 * ck + s >= NSTEPS) break;
+      const float4 a  = *reinterpret_cast<const float4*>(arow + 16 * (4 * ck + s));
+      const float4 b0 = *reinterpret_cast<const float4*>(rd0 + 16 * s);
+      const float4 b1 = *reinterpret_cast<const float4*>(rd0 + FST_P + 16 * s);
+      acc[0] = mfma4(a.x, b0.x, acc[0]);
+      acc[1] = mfma4(a.x, b1.x, acc[1]);
+      acc[0] = mfma4(a.y, b0.y, acc[0]);
+      acc[1] = mfma4(a.y, b1.y, acc[1]);
+      acc[0] = mfma4(a.z, b0.z, acc[0]);
+      acc[1] = mfma4(a.z, b1.z, acc[1]);
+      acc[0] = mfma4(a.w, b0.w, acc[0]);
+      acc[1] = mfma4(a.w, b1.w, acc[1]);
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
-// acc[c] (tile c = INPUT features n0 + 4 j + c of a wave's 64: n0 = 64 wave) += gZ[16 x 256] W[:, kofs + n0 ...]: the contraction
-// runs over the layer's 256 output features o = 16 s + 4 q + t, one float4 of weight row o per (s, t)
-__device__ __forceinline__ void gemm_bwd(f32x4 (&acc)[4], const float* sA, int pa, const float* __restrict__ W, int ldw, int kofs,
-    int wave, int lane) {
+// Backward product: tile c holds INPUT features n0 + 2 j + c (n0 = 32 wave); acc[c] += gZ[16 x 256] W[:, kofs + n0 ...], the
+// contraction over the layer's 256 output features in chunks of 64: the wave's [64 outputs][32 inputs] block of W is loaded
+// as 8 rows x 128 B per instruction, staged, and read back as one float2 per (output o = 16 s + 4 q + t, lane).
+__device__ __forceinline__ void gemm_bwd(f32x4 (&acc)[2], const float* sA, int pa, const float* __restrict__ W, int ldw, int kofs,
+    int wave, int lane, float* sw) {
   const int j = lane & 15, q = lane >> 4;
   const float* arow = sA + j * pa + 4 * q;
-  const float* wcol = W + (size_t) (4 * q) * ldw + kofs + 64 * wave + 4 * j;
-  float4 b[2][4];
-  auto fetch = [&](int s, float4 (&dst)[4]) {
+  const float* wb   = W + (size_t) (lane >> 3) * ldw + kofs + FPW * wave + 4 * (lane & 7);  // row L / 8 + 8 i, 16 B at 4 (L % 8)
+  float* wr         = sw + (lane >> 3) * BST_P + 4 * (lane & 7);
+  const float* rd   = sw + (4 * q) * BST_P + 2 * j;
+  constexpr int NCH = SPW / 64;
+  float4 g[2][8];
+  auto fetch = [&](int ck, float4 (&dst)[8]) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) dst[t] = ldg4(wcol + (size_t) (16 * s + t) * ldw);
+    for (int i = 0; i < 8; ++i) dst[i] = ldg4(wb + (size_t) (64 * ck + 8 * i) * ldw);
   };
-  fetch(0, b[0]);
-  constexpr int nsteps = SPW / 16;
-#pragma unroll 1
-  for (int s = 0; s < nsteps; s += 2) {
-    fetch(s + 1, b[1]);
-    {
-      const float4 a = *reinterpret_cast<const float4*>(arow + 16 * s);
+  fetch(0, g[0]);
+#pragma unroll
+  for (int ck = 0; ck < NCH; ++ck) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(wr + (8 * i) * BST_P) = g[ck & 1][i];
+    if (ck + 1 < NCH) fetch(ck + 1, g[(ck + 1) & 1]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float4 a    = *reinterpret_cast<const float4*>(arow + 16 * (4 * ck + s));
       const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        acc[0] = mfma4(av[t], b[0][t].x, acc[0]);
-        acc[1] = mfma4(av[t], b[0][t].y, acc[1]);
-        acc[2] = mfma4(av[t], b[0][t].z, acc[2]);
-        acc[3] = mfma4(av[t], b[0][t].w, acc[3]);
+        const float2 b = *reinterpret_cast<const float2*>(rd + (16 * s + t) * BST_P);
+        acc[0] = mfma4(av[t], b.x, acc[0]);
+        acc[1] = mfma4(av[t], b.y, acc[1]);
       }
     }
-    if (s + 2 < nsteps) fetch(s + 2, b[0]);
-    {
-      const float4 a = *reinterpret_cast<const float4*>(arow + 16 * (s + 1));
-      const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        acc[0] = mfma4(av[t], b[1][t].x, acc[0]);
-        acc[1] = mfma4(av[t], b[1][t].y, acc[1]);
-        acc[2] = mfma4(av[t], b[1][t].z, acc[2]);
-        acc[3] = mfma4(av[t], b[1][t].w, acc[3]);
-      }
-    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -244,8 +272,10 @@ __global__ void __launch_bounds__(NT) sp_net_forward_kernel(int M, NetPtrs n, fl
   __shared__ __attribute__((aligned(16))) float s_x0[ROWS * XPITCH];
   __shared__ __attribute__((aligned(16))) float s_act[2][ROWS * PITCH];
   __shared__ float s_temb[16], s_thid[THID], s_tout[32];
-  __shared__ __attribute__((aligned(16))) float s_head[4][ROWS][16];
+  __shared__ __attribute__((aligned(16))) float s_head[NWAVE][ROWS][16];
+  extern __shared__ __attribute__((aligned(16))) float s_stage[];  // [NWAVE][STAGE_F]: the waves' private weight staging
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float* sw = s_stage + wave * STAGE_F;
   const int r0 = blockIdx.x * ROWS, Mp = pad_rows(M);
   // ---- time network (every workgroup: 13 -> 256 -> 30 is ~11 k multiply-adds)
   if (tid < TDIM) {
@@ -258,7 +288,7 @@ __global__ void __launch_bounds__(NT) sp_net_forward_kernel(int M, NetPtrs n, fl
     s_temb[tid] = v;
   }
   __syncthreads();
-  {
+  if (tid < THID) {
     float h = n.tb1[tid];
 #pragma unroll
     for (int k = 0; k < TDIM; ++k) h += n.tw1[tid * TDIM + k] * s_temb[k];
@@ -277,7 +307,7 @@ __global__ void __launch_bounds__(NT) sp_net_forward_kernel(int M, NetPtrs n, fl
   __syncthreads();
   if (blockIdx.x == 0) {
     if (tid < 16) sv.temb[tid] = tid < TDIM ? s_temb[tid] : 0.f;
-    sv.thid[tid] = s_thid[tid];
+    if (tid < THID) sv.thid[tid] = s_thid[tid];
     if (tid < 32) sv.tout[tid] = tid < TOUT ? s_tout[tid] : 0.f;
   }
   // ---- encoded input of the 16 rows: [x | sin / cos(2^f x) ...] (freqencoder.cu:7-31) | t_emb | 0 0 0
@@ -301,40 +331,34 @@ __global__ void __launch_bounds__(NT) sp_net_forward_kernel(int M, NetPtrs n, fl
   const int j = lane & 15, q = lane >> 4;
   int cur = 0;
   for (int l = 0; l < SPD; ++l) {
-    f32x4 acc[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     const float* W = n.W[l];
     const int ldw  = layer_ld(l);
-    if (l == 0 || l == SKIP + 1) gemm_fwd<true>(acc, s_x0, XPITCH, W, ldw, 0, IN0P / 16, IN0, wave, lane);
-    if (l > 0) gemm_fwd<false>(acc, s_act[cur], PITCH, W, ldw, layer_hofs(l), SPW / 16, SPW, wave, lane);
-    float* out  = s_act[cur ^ 1];
-    float* Yl   = sv.Y + ((size_t) l * Mp + r0) * SPW;
+    if (l == 0 || l == SKIP + 1) gemm_fwd<IN0P / 16, true>(acc, s_x0, XPITCH, W, ldw, 0, IN0, wave, lane, sw);
+    if (l > 0) gemm_fwd<SPW / 16, false>(acc, s_act[cur], PITCH, W, ldw, layer_hofs(l), SPW, wave, lane, sw);
+    float* out      = s_act[cur ^ 1] + FPW * wave + 2 * j;
+    float* Yl       = sv.Y + ((size_t) l * Mp + r0) * SPW + FPW * wave + 2 * j;
+    const float2 bb = *reinterpret_cast<const float2*>(n.b[l] + FPW * wave + 2 * j);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int f    = 64 * wave + 16 * c + j;
-      const float bb = n.b[l][f];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 4 * q + r;
-        const float v = fmaxf(acc[c][r] + bb, 0.f);
-        out[row * PITCH + f]       = v;
-        Yl[(size_t) row * SPW + f] = v;
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int row  = 4 * q + r;
+      const float2 v = make_float2(fmaxf(acc[0][r] + bb.x, 0.f), fmaxf(acc[1][r] + bb.y, 0.f));
+      *reinterpret_cast<float2*>(out + row * PITCH)          = v;
+      *reinterpret_cast<float2*>(Yl + (size_t) row * SPW) = v;
     }
     cur ^= 1;
     __syncthreads();
   }
-  // ---- heads: raw[16 x 10] = h W_heads^T + b; the contraction split over the 4 waves (64 k each), summed through LDS
+  // ---- heads: raw[16 x 10] = h W_heads^T + b; the contraction split over the 8 waves (32 k each), summed through LDS
   {
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     int hrow;
     const int hd        = head_of(min(j, NOUT - 1), hrow);
-    const float* wr     = n.head_w[hd] + (size_t) hrow * SPW + 64 * wave + 4 * q;
-    const float* arow   = s_act[cur] + j * PITCH + 64 * wave + 4 * q;
+    const float* wr     = n.head_w[hd] + (size_t) hrow * SPW + FPW * wave + 4 * q;
+    const float* arow   = s_act[cur] + j * PITCH + FPW * wave + 4 * q;
     const bool real_col = j < NOUT;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < FPW / 16; ++s) {
       const float4 a = *reinterpret_cast<const float4*>(arow + 16 * s);
       float4 b       = *reinterpret_cast<const float4*>(wr + 16 * s);
       if (!real_col) b = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -354,7 +378,10 @@ __global__ void __launch_bounds__(NT) sp_net_forward_kernel(int M, NetPtrs n, fl
     for (int c = 0; c < NOUT; ++c) {
       int hrow;
       const int hd = head_of(c, hrow);
-      o[c] = ((s_head[0][tid][c] + s_head[1][tid][c]) + (s_head[2][tid][c] + s_head[3][tid][c])) + n.head_b[hd][hrow];
+      float acc = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWAVE; ++w) acc += s_head[w][tid][c];
+      o[c] = acc + n.head_b[hd][hrow];
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) sv.rawq[(size_t) gr * 4 + c] = o[3 + c];
@@ -382,13 +409,13 @@ __global__ void __launch_bounds__(NT) sp_net_forward_kernel(int M, NetPtrs n, fl
 
 // ================================================================================================ backward, launch A
 __device__ __forceinline__ void side_adam_walk(const SideAdam& a, int wg, int n_side) {
-  const int t256 = threadIdx.x, lane = threadIdx.x & 63;
+  const int half = threadIdx.x >> 8, t256 = threadIdx.x & 255, lane = threadIdx.x & 63;
   const AdamCoef k            = adam_coefficients(a.beta1, a.beta2, a.eps, a.state, a.after_advance != 0);
   const AdamTensorLanes desc  = adam_load_descriptors(a.tensors, a.n, lane);
   const int64_t first0        = lane < a.n ? a.tensors[lane].chunk0 : INT64_MAX;
   const int64_t n_chunks      = a.c1 - a.c0;
   const int64_t begin = a.c0 + n_chunks * wg / n_side, end = a.c0 + n_chunks * (wg + 1) / n_side;
-  for (int64_t chunk = begin; chunk < end; chunk += 2) {
+  for (int64_t chunk = begin + 2 * half; chunk < end; chunk += 4) {
     const int ti0      = adam_owner(a.tensors, a.n, first0, lane, chunk);
     const AdamTensor T0 = ti0 < 64 ? adam_descriptor_of(desc, ti0) : a.tensors[ti0];
     if (chunk + 1 < end) {
@@ -410,7 +437,9 @@ __global__ void __launch_bounds__(NT) sp_net_backward_rows_kernel(int M, int nbl
   }
   __shared__ __attribute__((aligned(16))) float s_gz[2][ROWS * PITCH];
   __shared__ __attribute__((aligned(16))) float s_gh[ROWS][16];
+  extern __shared__ __attribute__((aligned(16))) float s_stage[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float* sw = s_stage + wave * STAGE_F;
   const int j = lane & 15, q = lane >> 4;
   const int r0 = blockIdx.x * ROWS, Mp = pad_rows(M);
   // ---- cotangent of the raw output row [d_xyz 3 | rotation 4 | scaling 3]
@@ -459,50 +488,115 @@ __global__ void __launch_bounds__(NT) sp_net_backward_rows_kernel(int M, int nbl
     }
   }
   __syncthreads();
-  // ---- gY_7 = gH W_heads: K = 10 (three 4-steps), tile c = features {64 wave + 4 j + c}
-  f32x4 acc[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // ---- gY_7 = gH W_heads: K = 10 (three 4-steps), tile c = features {32 wave + 2 j + c}
+  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     const int o   = 4 * s + q;
     const float a = s_gh[j][o];  // A[i = j][kk = q]
-    float4 b      = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 b      = make_float2(0.f, 0.f);
     if (o < NOUT) {
       int hrow;
       const int hd = head_of(o, hrow);
-      b = *reinterpret_cast<const float4*>(n.head_w[hd] + (size_t) hrow * SPW + 64 * wave + 4 * j);
+      b = *reinterpret_cast<const float2*>(n.head_w[hd] + (size_t) hrow * SPW + FPW * wave + 2 * j);
     }
     acc[0] = mfma4(a, b.x, acc[0]);
     acc[1] = mfma4(a, b.y, acc[1]);
-    acc[2] = mfma4(a, b.z, acc[2]);
-    acc[3] = mfma4(a, b.w, acc[3]);
   }
   int cur = 0;
   for (int l = SPD - 1; l >= 0; --l) {
-    // gZ_l = gY_l * (Y_l > 0): lane holds rows 4 q + r, features 64 wave + 4 j + {0..3}
-    const float* Yl = sv.Y + ((size_t) l * Mp + r0) * SPW + 64 * wave + 4 * j;
-    float* GZl      = wk.GZ + ((size_t) l * Mp + r0) * SPW + 64 * wave + 4 * j;
-    float* sz       = s_gz[cur] + 64 * wave + 4 * j;
+    // gZ_l = gY_l * (Y_l > 0): lane holds rows 4 q + r, features 32 wave + 2 j + {0, 1}
+    const float* Yl = sv.Y + ((size_t) l * Mp + r0) * SPW + FPW * wave + 2 * j;
+    float* GZl      = wk.GZ + ((size_t) l * Mp + r0) * SPW + FPW * wave + 2 * j;
+    float* sz       = s_gz[cur] + FPW * wave + 2 * j;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row  = 4 * q + r;
-      const float4 y = *reinterpret_cast<const float4*>(Yl + (size_t) row * SPW);
+      const int row   = 4 * q + r;
+      const float2 y  = *reinterpret_cast<const float2*>(Yl + (size_t) row * SPW);
       const bool live = r0 + row < M;  // rows beyond M carry no gradient (their activations are copies of the last row's)
-      float4 g;
+      float2 g;
       g.x = (live && y.x > 0.f) ? acc[0][r] : 0.f;
       g.y = (live && y.y > 0.f) ? acc[1][r] : 0.f;
-      g.z = (live && y.z > 0.f) ? acc[2][r] : 0.f;
-      g.w = (live && y.w > 0.f) ? acc[3][r] : 0.f;
-      *reinterpret_cast<float4*>(sz + row * PITCH)           = g;
-      *reinterpret_cast<float4*>(GZl + (size_t) row * SPW) = g;
+      *reinterpret_cast<float2*>(sz + row * PITCH)           = g;
+      *reinterpret_cast<float2*>(GZl + (size_t) row * SPW) = g;
+    }
+    __syncthreads();
+    if ((l == 0 || l == SKIP + 1) && tid < SPW) {  // this block's column sums of gZ_l (for the time network, launch B)
+      float cs = 0.f;
+#pragma unroll
+      for (int row = 0; row < ROWS; ++row) cs += s_gz[cur][row * PITCH + tid];
+      wk.GBP[((size_t) (l == 0 ? 0 : 1) * nblk + blockIdx.x) * SPW + tid] = cs;
     }
     if (l == 0) break;  // no gradient to the encoded input (the superpoint positions are detached)
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    gemm_bwd(acc, s_gz[cur], PITCH, n.W[l], layer_ld(l), layer_hofs(l), wave, lane);
+    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}, acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gemm_bwd(acc, s_gz[cur], PITCH, n.W[l], layer_ld(l), layer_hofs(l), wave, lane, sw);
     cur ^= 1;
+  }
+}
+
+// The time network's backward (one workgroup of launch B).  t_emb is the same for every row, so
+//   d loss / d t_emb [30] = gb_0 W_0[:, 63:93] + gb_5 W_5[:, 63:93]
+// needs only the bias gradients of layers 0 and 5 -- summed here from the row blocks' partial column sums (launch A), so the
+// job depends on no other workgroup of its launch (a last-workgroup-out ticket needed a device-scope fence per workgroup:
+// an L2 write-back each, 30 us of the launch).
+__device__ void timenet_backward(int M, const NetPtrs& n, const GradPtrs& g, const SavedView& sv, const WorkView& wk, float* s_buf) {
+  const int tid = threadIdx.x, Mp = pad_rows(M);
+  // d loss / d t_emb [30] = gb_0 W_0[:, 63:93] + gb_5 W_5[:, 63:93]: thread o forms its 30 products from ONE round of loads
+  // (a loop over o per output was 32 dependent round trips: 40 us of this launch), parked [c][o] in LDS, 8 lanes sum a column
+  float* s_prod = s_buf;              // [TOUT][256]  (30 KB of the 49 KB partial-tile area)
+  float* s_gt   = s_buf + TOUT * SPW; // [32]
+  float* s_ghid = s_gt + 64;              // [256]
+  {
+    const int nblk = Mp / ROWS;
+    float gb0 = 0.f, gb5 = 0.f;  // bias gradients of layers 0 and 5, from the row blocks' partial sums (launch A)
+    for (int b0 = 0; b0 < nblk; b0 += 16) {  // 32 loads in flight per round (a plain loop was one round trip per block)
+      float v0[16], v5[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int b = min(b0 + u, nblk - 1);
+        v0[u] = wk.GBP[(size_t) b * SPW + tid], v5[u] = wk.GBP[((size_t) nblk + b) * SPW + tid];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (b0 + u < nblk) gb0 += v0[u], gb5 += v5[u];
+    }
+    const float* w0 = n.W[0] + (size_t) tid * IN0 + PDIM;
+    const float* w5 = n.W[SKIP + 1] + (size_t) tid * (IN0 + SPW) + PDIM;
+    float pr[TOUT];
+#pragma unroll
+    for (int c = 0; c < TOUT; ++c) pr[c] = gb0 * w0[c] + gb5 * w5[c];
+#pragma unroll
+    for (int c = 0; c < TOUT; ++c) s_prod[c * SPW + tid] = pr[c];
+  }
+  __syncthreads();
+  if (tid < TOUT * 8) {
+    const int c = tid >> 3, part = tid & 7;
+    float v = 0.f;
+    for (int o = part; o < SPW; o += 8) v += s_prod[c * SPW + o];
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    if (part == 0) s_gt[c] = v;
+  }
+  __syncthreads();
+  {  // second linear: gW2 [30][256] = g_t (x) hid, gb2 = g_t;  g_hid = W2^T g_t * (hid > 0)
+    const float hid = sv.thid[tid];
+    float gh = 0.f;
+    float w2[TOUT];
+#pragma unroll
+    for (int c = 0; c < TOUT; ++c) w2[c] = n.tw2[c * THID + tid];  // (one round of loads)
+#pragma unroll
+    for (int c = 0; c < TOUT; ++c) {
+      g.tw2[c * THID + tid] = s_gt[c] * hid;
+      gh += s_gt[c] * w2[c];
+    }
+    gh = hid > 0.f ? gh : 0.f;
+    s_ghid[tid] = gh;
+    if (tid < TOUT) g.tb2[tid] = s_gt[tid];
+    // first linear: gW1 [256][13] = g_hid (x) freq(t), gb1 = g_hid
+    g.tb1[tid] = gh;
+#pragma unroll
+    for (int k = 0; k < TDIM; ++k) g.tw1[tid * TDIM + k] = gh * sv.temb[k];
   }
 }
 
@@ -512,14 +606,17 @@ __global__ void __launch_bounds__(NT) sp_net_backward_rows_kernel(int M, int nbl
 // 16 x 64).  Rows (the contraction) split over the 4 waves, partial tiles summed through LDS.
 constexpr int JOBS_HH = 7 * 16, JOBS_X0 = 8, JOBS_HEAD = 4, N_JOBS = JOBS_HH + 2 * JOBS_X0 + JOBS_HEAD;
 
-__global__ void __launch_bounds__(NT) sp_net_backward_weights_kernel(int M, NetPtrs n, GradPtrs g, SavedView sv, WorkView wk) {
+__global__ void __launch_bounds__(NTB) sp_net_backward_weights_kernel(int M, NetPtrs n, GradPtrs g, SavedView sv, WorkView wk) {
   __shared__ __attribute__((aligned(16))) float s_part[3][64 * 65];
   __shared__ float s_gb[4][64];
-  __shared__ int s_last;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int j = lane & 15, q = lane >> 4;
   const int Mp  = pad_rows(M);
   const int job = blockIdx.x;
+  if (job == N_JOBS) {  // one more workgroup: the time network's backward (needs nothing from the other jobs)
+    timenet_backward(M, n, g, sv, wk, &s_part[0][0]);
+    return;
+  }
   // ---- decode
   int layer, o0, k0, kvalid, xld, gofs, gld;
   const float* X;     // right operand rows: [Mp][xld], columns k0 ...
@@ -558,29 +655,76 @@ __global__ void __launch_bounds__(NT) sp_net_backward_weights_kernel(int M, NetP
     for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);
   const int kcol = k0 + 4 * j;
+  // the loads of BATCH steps (4 rows each) are in flight before their MFMAs, the next batch's behind them (a load -> use chain
+  // per step was 32 dependent L2 round trips: 50 us for this launch)
+  constexpr int BATCH = 8;
   if (!heads) {
-    for (int r = rb; r < re; r += 4) {
-      const float4 av = *reinterpret_cast<const float4*>(A + (size_t) (r + q) * SPW + o0 + 4 * j);   // lane (i = j, kk = q)
-      const float4 bv = kcol < xld ? *reinterpret_cast<const float4*>(X + (size_t) (r + q) * xld + kcol) : make_float4(0, 0, 0, 0);
-      colsum.x += av.x, colsum.y += av.y, colsum.z += av.z, colsum.w += av.w;
-      const float a4[4] = {av.x, av.y, av.z, av.w};
+    const float* ap = A + (size_t) q * SPW + o0 + 4 * j;   // lane (i = j, kk = q)
+    const float* xp = X + (size_t) q * xld + kcol;
+    const bool xin  = kcol < xld;
+    float4 av[2][BATCH], bv[2][BATCH];
+    auto fetch = [&](int r, float4 (&a)[BATCH], float4 (&b)[BATCH]) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        acc[a][0] = mfma4(a4[a], bv.x, acc[a][0]);
-        acc[a][1] = mfma4(a4[a], bv.y, acc[a][1]);
-        acc[a][2] = mfma4(a4[a], bv.z, acc[a][2]);
-        acc[a][3] = mfma4(a4[a], bv.w, acc[a][3]);
+      for (int u = 0; u < BATCH; ++u) {
+        const int rr  = r + 4 * u;
+        const bool in = rr < re;
+        const int rc  = in ? rr : rb;  // (clamped address, value masked: a select between POINTERS put the zero in scratch)
+        a[u] = *reinterpret_cast<const float4*>(ap + (size_t) rc * SPW);
+        b[u] = *reinterpret_cast<const float4*>(xin ? xp + (size_t) rc * xld : ap + (size_t) rc * SPW);
+        if (!in) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(in && xin)) b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    auto consume = [&](const float4 (&aa)[BATCH], const float4 (&bb)[BATCH]) {
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const float4 a = aa[u], b = bb[u];
+        colsum.x += a.x, colsum.y += a.y, colsum.z += a.z, colsum.w += a.w;
+        acc[0][0] = mfma4(a.x, b.x, acc[0][0]), acc[0][1] = mfma4(a.x, b.y, acc[0][1]);
+        acc[0][2] = mfma4(a.x, b.z, acc[0][2]), acc[0][3] = mfma4(a.x, b.w, acc[0][3]);
+        acc[1][0] = mfma4(a.y, b.x, acc[1][0]), acc[1][1] = mfma4(a.y, b.y, acc[1][1]);
+        acc[1][2] = mfma4(a.y, b.z, acc[1][2]), acc[1][3] = mfma4(a.y, b.w, acc[1][3]);
+        acc[2][0] = mfma4(a.z, b.x, acc[2][0]), acc[2][1] = mfma4(a.z, b.y, acc[2][1]);
+        acc[2][2] = mfma4(a.z, b.z, acc[2][2]), acc[2][3] = mfma4(a.z, b.w, acc[2][3]);
+        acc[3][0] = mfma4(a.w, b.x, acc[3][0]), acc[3][1] = mfma4(a.w, b.y, acc[3][1]);
+        acc[3][2] = mfma4(a.w, b.z, acc[3][2]), acc[3][3] = mfma4(a.w, b.w, acc[3][3]);
+      }
+    };
+    fetch(rb, av[0], bv[0]);
+    for (int r = rb; r < re; r += 8 * BATCH) {
+      if (r + 4 * BATCH < re) fetch(r + 4 * BATCH, av[1], bv[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(av[0], bv[0]);
+      if (r + 4 * BATCH < re) {
+        if (r + 8 * BATCH < re) fetch(r + 8 * BATCH, av[0], bv[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(av[1], bv[1]);
       }
     }
   } else {
-    for (int r = rb; r < re; r += 4) {
-      const float av  = A[(size_t) (r + q) * 16 + j];  // GH row r + q, output column j (>= 10: zero)
-      const float4 bv = *reinterpret_cast<const float4*>(X + (size_t) (r + q) * xld + kcol);
-      colsum.x += av;
-      acc[0][0] = mfma4(av, bv.x, acc[0][0]);
-      acc[0][1] = mfma4(av, bv.y, acc[0][1]);
-      acc[0][2] = mfma4(av, bv.z, acc[0][2]);
-      acc[0][3] = mfma4(av, bv.w, acc[0][3]);
+    const float* ap = A + (size_t) q * 16 + j;  // GH row r + q, output column j (>= 10: zero)
+    const float* xp = X + (size_t) q * xld + kcol;
+    for (int r = rb; r < re; r += 4 * BATCH) {
+      float av[BATCH];
+      float4 bv[BATCH];
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int rr  = r + 4 * u;
+        const bool in = rr < re;
+        const int rc  = in ? rr : rb;
+        av[u] = ap[(size_t) rc * 16];
+        bv[u] = *reinterpret_cast<const float4*>(xp + (size_t) rc * xld);
+        if (!in) av[u] = 0.f, bv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        colsum.x += av[u];
+        acc[0][0] = mfma4(av[u], bv[u].x, acc[0][0]);
+        acc[0][1] = mfma4(av[u], bv[u].y, acc[0][1]);
+        acc[0][2] = mfma4(av[u], bv[u].z, acc[0][2]);
+        acc[0][3] = mfma4(av[u], bv[u].w, acc[0][3]);
+      }
     }
   }
   // ---- waves 1..3 park their partial tiles in LDS ([o local (64)][k local (64)], pitch 65); wave 0 adds them to its own and
@@ -651,46 +795,6 @@ __global__ void __launch_bounds__(NT) sp_net_backward_weights_kernel(int M, NetP
       g.b[layer][o0 + tid] = v;
     }
   }
-  // ---- the workgroup that finishes last: the time network's backward
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned t = atomicAdd(wk.ticket, 1u);
-    s_last = (t == (unsigned) gridDim.x - 1) ? 1 : 0;
-    if (s_last) *wk.ticket = 0u;  // ready for the next launch
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  float* s_gt   = s_part[0];        // [32] d loss / d t_emb
-  float* s_ghid = s_part[0] + 64;   // [256]
-  if (tid < TOUT * 8) {
-    const int c = tid >> 3, part = tid & 7;
-    float v = 0.f;
-    for (int o = part; o < SPW; o += 8)
-      v += __builtin_nontemporal_load(&g.b[0][o]) * n.W[0][(size_t) o * IN0 + PDIM + c] +
-           __builtin_nontemporal_load(&g.b[SKIP + 1][o]) * n.W[SKIP + 1][(size_t) o * (IN0 + SPW) + PDIM + c];
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    if (part == 0) s_gt[c] = v;
-  }
-  __syncthreads();
-  {  // second linear: gW2 [30][256] = g_t (x) hid, gb2 = g_t;  g_hid = W2^T g_t * (hid > 0)
-    const float hid = sv.thid[tid];
-    float gh = 0.f;
-    for (int c = 0; c < TOUT; ++c) {
-      g.tw2[c * THID + tid] = s_gt[c] * hid;
-      gh += s_gt[c] * n.tw2[c * THID + tid];
-    }
-    gh = hid > 0.f ? gh : 0.f;
-    s_ghid[tid] = gh;
-    if (tid < TOUT) g.tb2[tid] = s_gt[tid];
-    // first linear: gW1 [256][13] = g_hid (x) freq(t), gb1 = g_hid
-    g.tb1[tid] = gh;
-#pragma unroll
-    for (int k = 0; k < TDIM; ++k) g.tw1[tid * TDIM + k] = gh * sv.temb[k];
-  }
 }
 
 NetPtrs net_ptrs(const skgs_sp_net* d) {
@@ -708,6 +812,17 @@ bool net_complete(const skgs_sp_net* d) {
             d->rotation_w && d->rotation_b;
   for (int l = 0; l < SPD; ++l) ok = ok && d->W[l] && d->b[l];
   return ok;
+}
+int allow_stage_lds() {  // static + dynamic LDS of the two row-block kernels exceed the default 64 KB
+  static int rc = [] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_net_forward_kernel),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int) STAGE_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_net_backward_rows_kernel),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int) STAGE_BYTES);
+    return e == hipSuccess ? 0 : 1;
+  }();
+  return rc;
 }
 int cu_count() {
   static int cached[64] = {0};
@@ -740,7 +855,8 @@ int skgs_sp_net_forward(const skgs_sp_net* net, float* raw, float* bone_T, float
   SKGS_REQUIRE(raw || bone_T, "sp_net_forward: no output requested");
   hipStream_t s = (hipStream_t) stream;
   ProfScope prof(K_SP_NET_FWD, s);
-  hipLaunchKernelGGL(sp_net_forward_kernel, dim3(pad_rows(net->M) / ROWS), dim3(NT), 0, s, net->M, net_ptrs(net), raw, bone_T, d_rot,
+  SKGS_REQUIRE(allow_stage_lds() == 0, "sp_net_forward: cannot raise the dynamic LDS limit");
+  hipLaunchKernelGGL(sp_net_forward_kernel, dim3(pad_rows(net->M) / ROWS), dim3(NT), STAGE_BYTES, s, net->M, net_ptrs(net), raw, bone_T, d_rot,
       d_scale, saved_view(saved, net->M));
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
@@ -766,8 +882,8 @@ int skgs_sp_net_backward(const skgs_sp_net* net, const skgs_sp_net* grads, const
     sd.c0 = side->chunk_begin, sd.c1 = side->chunk_end;
     sd.beta1 = side->beta1, sd.beta2 = side->beta2, sd.eps = (float) side->eps;
     sd.state = reinterpret_cast<const AdamState*>(side->step_count), sd.after_advance = side->after_advance ? 1 : 0;
-    if (sd.c1 > sd.c0)  // two workgroups per idle CU (256 threads each): the stream needs the bytes in flight
-      n_side = (int) std::max<long long>(1, std::min<long long>((sd.c1 - sd.c0 + 1) / 2, 2LL * std::max(cu_count() - nblk, 1)));
+    if (sd.c1 > sd.c0)  // one workgroup (two 256-thread halves, two chunks each per iteration) per idle CU
+      n_side = (int) std::max<long long>(1, std::min<long long>((sd.c1 - sd.c0 + 3) / 4, (long long) std::max(cu_count() - nblk, 1)));
   }
   SavedView sv = saved_view(const_cast<void*>(saved), M);
   WorkView wk  = work_view(workspace, M);
@@ -780,10 +896,11 @@ int skgs_sp_net_backward(const skgs_sp_net* net, const skgs_sp_net* grads, const
   g.head_w[1] = const_cast<float*>(grads->rotation_w), g.head_b[1] = const_cast<float*>(grads->rotation_b);
   g.head_w[2] = const_cast<float*>(grads->scaling_w), g.head_b[2] = const_cast<float*>(grads->scaling_b);
   ProfScope prof(K_SP_NET_BWD, s);
-  hipLaunchKernelGGL(sp_net_backward_rows_kernel, dim3(nblk + n_side), dim3(NT), 0, s, M, nblk, n, g_bone_T, g_d_rot, g_d_scale,
+  SKGS_REQUIRE(allow_stage_lds() == 0, "sp_net_backward: cannot raise the dynamic LDS limit");
+  hipLaunchKernelGGL(sp_net_backward_rows_kernel, dim3(nblk + n_side), dim3(NT), STAGE_BYTES, s, M, nblk, n, g_bone_T, g_d_rot, g_d_scale,
       g_raw, sv, wk, sd);
   SKGS_CHECK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(sp_net_backward_weights_kernel, dim3(N_JOBS), dim3(NT), 0, s, M, n, g, sv, wk);
+  hipLaunchKernelGGL(sp_net_backward_weights_kernel, dim3(N_JOBS + 1), dim3(NTB), 0, s, M, n, g, sv, wk);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -321,3 +321,150 @@ class SuperpointGaussians(nn.Module):
         if background is not None:
             out['images'] = out['images'] + (1 - out['opacity'][None]) * background.view(3, 1, 1)
         return out
+
+    def topology(self) -> dict:
+        return {}  # (no kinematic chain in stage sp; FusedViewStep's constructor asks every model)
+
+
+from sk_gs_amd.fused_step import FusedViewStep, _p  # noqa: E402  (after the model classes: fused_step imports model.py only)
+
+
+class FusedSuperpointStep(FusedViewStep):
+    """forward + loss + backward of one view in stage ``sp`` as a straight line of C-ABI calls on persistent buffers: the
+    sibling of ``FusedViewStep`` (which covers stage ``sk``), sharing its rasterizer / loss half.
+
+        skgs_sp_net_forward            sp_deform_net on the M superpoints + normalisation   (1 launch, MFMA row blocks)
+        skgs_sp_lbs_weights_forward    K nearest superpoints in 3 + 8 dimensions + weighting (1 launch)
+        skgs_lbs_deform_forward        skinning + activations                                (1 launch)
+        rasterize forward, loss forward / backward, rasterize backward                       (as stage sk)
+        skgs_lbs_deform_backward       -> g_weights, g_spT, g_d_rot, g_d_scale, the Gaussians' parameter gradients
+        skgs_sp_lbs_weights_backward   -> hyper_feature.grad, sp_hyper_feature.grad, _sp_radius.grad, _sp_weight.grad
+                                          (`W`: skgs_lbs_weights_backward -> the dense sp_W.grad)
+        skgs_sp_net_backward           -> the network's parameter gradients (2 launches; the per-Gaussian rows' Adam update
+                                          rides on the first one's idle CUs: ``side_optimizer``)
+
+    Every gradient is WRITTEN into the parameter's ``.grad`` storage.  ``sp_points`` receives no gradient in this stage (the
+    reference detaches it everywhere on this path, sk_gs.py:753-755,845; ``warp`` method 'LBS' does not read it): its
+    ``.grad`` stays zero."""
+
+    def __init__(self, model: SuperpointGaussians, W: int, H: int, capacity: int, lambda_dssim: float = 0.2,
+                 background: Optional[Tensor] = None, grad_scale: float = 1.0, densify_stats: bool = False,
+                 tile_bucket: int = 0, view_table=None):
+        assert isinstance(model.sp_deform_net, SpDeformNet) and model.sp_deform_net.kernel_supported()
+        model.sk_deform_net = None  # (what FusedViewStep's constructor probes for the stage-sk network)
+        super().__init__(model, W, H, capacity, lambda_dssim=lambda_dssim, background=background, grad_scale=grad_scale,
+                         densify_stats=densify_stats, tile_bucket=tile_bucket, view_table=None)
+        lib, dev = self.lib, model._xyz.device
+        P, M, K = self.P, self.M, self.K
+        self.F = int(model.hyper_dim) if model.hyper_feature is not None else 0
+        assert self.F in (0, 8), 'csrc/sp_knn.hip: 0 or 8 hyper dimensions'
+        self.net = model.sp_deform_net.runner(M)
+        self.nn_dist = torch.empty((P, K), dtype=torch.float32, device=dev)
+        lib.skgs_sp_lbs_weights_workspace_bytes.restype = C.c_size_t
+        self.spw_ws = torch.empty((max(int(lib.skgs_sp_lbs_weights_workspace_bytes(C.c_int32(P), C.c_int32(M), C.c_int32(self.F))),
+                                       16),), dtype=torch.uint8, device=dev)
+        self.g_d_rot = torch.empty((M, 4), dtype=torch.float32, device=dev)
+        self.g_d_scale = torch.empty((M, 3), dtype=torch.float32, device=dev)
+        self.view_table = view_table
+        if view_table is not None:
+            vs = view_table.settings
+            assert (vs.image_height, vs.image_width) == (self.H, self.W)
+        self.wide = True
+
+    # ---- the pieces FusedViewStep asks its subclass for --------------------------------------------------------------
+    def table_grad_span(self):
+        return None
+
+    def _zero_table_grads(self):
+        pass  # no per-frame tables in stage sp
+
+    def _deform_inputs(self, time_id):
+        m = self.model
+        a = _C._DeformInputs()
+        a.P, a.K, a.M = self.P, self.K, self.M
+        a.points = a.xyz = m._xyz.data_ptr()  # points = xyz.detach() (sk_gs.py:833)
+        a.weights, a.indices = self.weights.data_ptr(), self.indices.data_ptr()
+        a.bone_T, a.bone_drot, a.bone_dscale = self.net.bone_T.data_ptr(), self.net.d_rot.data_ptr(), self.net.d_scale.data_ptr()
+        a.log_scale, a.rot, a.opacity_logit = m._scaling.data_ptr(), m._rotation.data_ptr(), m._opacity.data_ptr()
+        a.live_count = None
+        return a
+
+    def _time(self, time_id) -> Tensor:
+        if time_id is not None:
+            return self.model.frame_times[time_id]
+        from sk_gs_amd import view_slot as vsl
+        return self.view_table.slot[vsl.W_TIME:vsl.W_TIME + 1]
+
+    @torch.no_grad()
+    def forward(self, rs=None, time_id=None):
+        lib, m, st, chk = self.lib, self.model, _C._stream(), _C._check
+        P, M, K = self.P, self.M, self.K
+        assert (rs is None) == (time_id is None) and (rs is not None or self.view_table is not None)
+        self.net.forward(m.sp_points, self._time(time_id))
+        chk(lib.skgs_sp_lbs_weights_forward(
+            C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(self.F), _p(m._xyz), _p(m.hyper_feature), _p(m.sp_points),
+            _p(m.sp_hyper_feature), _p(m._sp_radius), _p(m._sp_weight), C.c_float(m.lbs_temperature), _p(m.sp_W),
+            _p(self.indices), _p(self.weights), _p(self.nn_dist), st))
+        d = self._deform_inputs(time_id)
+        chk(lib.skgs_lbs_deform_forward(C.byref(d), _p(self.means), _p(self.scales), _p(self.rotations), _p(self.opacity),
+                                        None, None, None, st))
+        a = self._raster_inputs(rs)
+        chk(lib.skgs_rasterize_forward(C.byref(a), C.byref(self._bufs), _p(self.radii), _p(self.image),
+                                       _p(self.out_opacity), None, None, st))
+        return a, d
+
+    @torch.no_grad()
+    def backward_skinning(self, time_id=None, part=None):
+        assert part is None
+        lib, m, st, chk = self.lib, self.model, _C._stream(), _C._check
+        P, M, K = self.P, self.M, self.K
+        d = self._deform_inputs(time_id)
+        chk(lib.skgs_lbs_deform_backward(
+            C.byref(d), _p(self.g_means), _p(self.g_scales), _p(self.g_rotations), _p(self.g_opacity),
+            _p(self.g_weights), _p(self.g_bone_T), _p(self.g_d_rot), _p(self.g_d_scale),
+            _p(m._xyz.grad), _p(m._scaling.grad), _p(m._rotation.grad), _p(m._opacity.grad), _p(self.deform_ws),
+            C.c_size_t(self.deform_ws.numel()), st))
+        if m.sp_W is not None:  # `W`: the dense [P,M] logit gradient (what autograd's gather backward builds)
+            chk(lib.skgs_lbs_weights_backward(C.c_int32(P), C.c_int32(M), C.c_int32(K), _p(self.weights), _p(self.indices),
+                                              _p(self.g_weights), _p(m.sp_W.grad), st))
+        else:
+            g = lambda t: None if t is None else _p(t.grad)  # noqa: E731
+            chk(lib.skgs_sp_lbs_weights_backward(
+                C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(self.F), _p(m.hyper_feature), _p(m.sp_hyper_feature),
+                _p(m._sp_radius), _p(m._sp_weight), C.c_float(m.lbs_temperature), _p(self.weights), _p(self.indices),
+                _p(self.nn_dist), _p(self.g_weights), g(m.hyper_feature), g(m.sp_hyper_feature), g(m._sp_radius),
+                g(m._sp_weight), _p(self.spw_ws), C.c_size_t(self.spw_ws.numel()), st))
+        side = None
+        if self.side_optimizer is not None:  # the per-Gaussian rows' Adam update on the CUs the row-block launch leaves idle
+            side = self.side_optimizer[0].side_range(*self.side_optimizer[1:])
+        self.net.backward(self.g_bone_T, self.g_d_rot, self.g_d_scale, side_adam=side)
+
+    def status(self) -> dict:
+        return _C.read_status(self.geom)
+
+
+class FusedSuperpointTrainStep:
+    """One training step of one rank in stage ``sp``: ``FusedSuperpointStep.forward_backward`` + ``FusedAdam.step`` with the
+    per-Gaussian rows' update (xyz, SH, opacity, scaling, rotation, hyper features, LBS logits: > 95 % of the optimizer's
+    bytes) as the side job of the network's row-block backward launch, and one closing launch for the rest (network,
+    superpoint tables) that advances the counter and, with an ordered ``ViewTable``, selects the next view.  Same arithmetic
+    as ``step.forward_backward(); optimizer.step()``."""
+
+    ROW_GROUPS = ('xyz', 'f_dc', 'f_rest', 'opacity', 'scaling', 'rotation', 'hyper', 'sp_W')
+
+    def __init__(self, step: FusedSuperpointStep, optimizer, enable: bool = True):
+        self.step, self.optimizer = step, optimizer
+        names = [g.get('name') for g in optimizer.param_groups]
+        self.rows = [n for n in names if n in self.ROW_GROUPS]
+        self.rest = [n for n in names if n not in self.ROW_GROUPS]
+        self.fused = bool(enable and self.rows and self.rest and len(optimizer._chunk_ranges(self.rows)) == 1
+                          and len(optimizer._chunk_ranges(self.rest)) == 1)
+        step.side_optimizer = (optimizer, self.rows, None) if self.fused else None
+
+    def __call__(self, rs=None, time_id=None, target=None):
+        self.step.forward_backward(rs, time_id, target)
+        if self.fused:
+            vt = self.step.view_table
+            self.optimizer.step_tail(self.rest, next_view=vt.advance() if (vt is not None and rs is None) else None)
+        else:
+            self.optimizer.step()

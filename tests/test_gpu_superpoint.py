@@ -118,3 +118,202 @@ def test_sp_net_autograd_function_and_state_dict():
         assert rel_err(a, b) <= 5e-5, n
     with pytest.raises(Exception):
         net(x.cpu(), t)
+
+
+# ------------------------------------------------------------------------------------------- search + weightings
+def _sp_scene(P, M, seed, F=8):
+    g = torch.Generator().manual_seed(seed)
+    pts = torch.rand(P, 3, generator=g) * 2.6 - 1.3
+    sp = pts[torch.randperm(P, generator=g)[:M]].clone() + 0.01 * torch.randn(M, 3, generator=g)
+    feat = torch.full((P, F), -1e-2) + 0.03 * torch.randn(P, F, generator=g) if F else None
+    sfeat = torch.full((M, F), 1e-2) + 0.03 * torch.randn(M, F, generator=g) if F else None
+    radius_raw = torch.randn(M, generator=g) * 0.3 + float(np.log(0.25))
+    kweight_raw = torch.randn(M, generator=g)
+    return pts, sp, feat, sfeat, radius_raw, kweight_raw
+
+
+def _sp_forward(P, M, K, F, pts, sp, feat, sfeat, radius_raw=None, kweight_raw=None, T=1.0, sp_W=None):
+    import ctypes as C
+    from sk_gs_amd import _C
+    lib = _C.load_library()
+    dev = 'cuda'
+    idx = torch.empty((P, K), dtype=torch.int64, device=dev)
+    w, d = torch.empty((P, K), device=dev), torch.empty((P, K), device=dev)
+    p = lambda t: C.c_void_p(None if t is None else t.data_ptr())  # noqa: E731
+    _C._check(lib.skgs_sp_lbs_weights_forward(C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(F), p(pts), p(feat), p(sp),
+                                              p(sfeat), p(radius_raw), p(kweight_raw), C.c_float(T), p(sp_W), p(idx), p(w), p(d),
+                                              _C._stream()))
+    return idx, w, d
+
+
+@pytest.mark.parametrize('P,M,K,F', [(100_000, 512, 5, 8), (100_000, 512, 5, 0), (30_000, 512, 8, 8), (5_001, 100, 12, 8),
+                                     (777, 7, 3, 8)])
+def test_sp_search_and_weightings_match_the_oracle_at_full_size(oracle32, oracle64, P, M, K, F):
+    """the 3 + 8-dimensional search over 512 superpoints at P = 100k (BASELINE config #1's Gaussians, the
+    reference's num_superpoints) -- indices BIT-exact against the oracle (pytorch3d order: ascending, ties to the lower id),
+    distances bit-exact, the four weightings <= 1e-6, and the backward of the distance-based ones (hyper features, superpoint
+    hyper features, radii, kernel weights) <= 1e-4 of each tensor's scale against the oracle's analytic gradients."""
+    import ctypes as C
+    from sk_gs_amd import _C
+    pts, sp, feat, sfeat, radius_raw, kweight_raw = _sp_scene(P, M, 7 * P + M, F)
+    cat = lambda a, b: a if b is None else torch.cat([a, b], 1)  # noqa: E731
+    want_d, want_i = oracle32.knn_bones(to_np(cat(pts, feat)), to_np(cat(sp, sfeat)), K)
+    dev = 'cuda'
+    d_pts, d_sp = pts.to(dev), sp.to(dev)
+    d_feat, d_sfeat = (feat.to(dev), sfeat.to(dev)) if F else (None, None)
+    d_rad, d_kw = radius_raw.to(dev), kweight_raw.to(dev)
+    g = torch.Generator().manual_seed(P)
+    G = torch.randn(P, K, generator=g)
+    lib = _C.load_library()
+    lib.skgs_sp_lbs_weights_workspace_bytes.restype = C.c_size_t
+    ws = torch.empty((int(lib.skgs_sp_lbs_weights_workspace_bytes(C.c_int32(P), C.c_int32(M), C.c_int32(F))) + 16,),
+                     dtype=torch.uint8, device=dev)
+    p = lambda t: C.c_void_p(None if t is None else t.data_ptr())  # noqa: E731
+    radius = np.exp(to_np(radius_raw).astype(np.float64))
+    kw = 1.0 / (1.0 + np.exp(-to_np(kweight_raw).astype(np.float64)))
+    for method in ('weighted_kernel', 'kernel', 'dist', 'W'):
+        sp_W = torch.randn(P, M, generator=g).to(dev) if (method == 'W' and P * M <= 20_000_000) else None
+        if method == 'W' and sp_W is None:
+            continue
+        rr = d_rad if method in ('weighted_kernel', 'kernel') else None
+        kk = d_kw if method == 'weighted_kernel' else None
+        T = 0.05
+        idx, w, d = _sp_forward(P, M, K, F, d_pts, d_sp, d_feat, d_sfeat, rr, kk, T, sp_W)
+        np.testing.assert_array_equal(to_np(idx), want_i, err_msg=method)
+        np.testing.assert_array_equal(to_np(d), want_d, err_msg=method)
+        if method == 'W':
+            want_w = oracle32.lbs_weights(to_np(sp_W), want_i)
+            assert np.abs(to_np(w) - want_w).max() <= 2e-6
+            continue
+        if method == 'dist':
+            want_w, g_dist = oracle64.lbs_weights_dist(want_d, T, g_weights=to_np(G))
+            g_rad = g_kw = None
+        else:
+            want_w, gr = oracle64.lbs_weights_kernel(want_d, want_i, radius, kw if method == 'weighted_kernel' else None,
+                                                     g_weights=to_np(G))
+            g_dist, g_rad, g_kw = gr['g_dist'], gr['g_radius'] * radius, gr['g_weight']
+            if g_kw is not None:
+                g_kw = g_kw * kw * (1 - kw)
+        assert np.abs(to_np(w) - want_w).max() <= 2e-6, method
+        # ---- backward
+        g_feat = torch.full((P, max(F, 1)), float('nan'), device=dev)
+        g_sfeat = torch.full((M, max(F, 1)), float('nan'), device=dev)
+        g_r, g_k = torch.full((M,), float('nan'), device=dev), torch.full((M,), float('nan'), device=dev)
+        _C._check(lib.skgs_sp_lbs_weights_backward(
+            C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(F), p(d_feat), p(d_sfeat), p(rr), p(kk), C.c_float(T), p(w), p(idx),
+            p(d), p(G.to(dev)), p(g_feat) if F else None, p(g_sfeat) if F else None, p(g_r), p(g_k), p(ws),
+            C.c_size_t(ws.numel()), _C._stream()))
+        if F:
+            want_gp, want_gj = oracle64.knn_dist_backward(to_np(cat(pts, feat)), to_np(cat(sp, sfeat)), want_i, g_dist)
+            assert rel_err(g_feat, want_gp[:, 3:]) <= 1e-4, method
+            assert rel_err(g_sfeat, want_gj[:, 3:]) <= 1e-4, method
+        if g_rad is not None:
+            assert rel_err(g_r, g_rad) <= 1e-4, method
+        if g_kw is not None:
+            assert rel_err(g_k, g_kw) <= 1e-4, method
+
+
+def test_sp_search_agrees_bit_for_bit_with_the_operator_path():
+    """the fused step's one-launch search + weighting (split pointers) and the operator path (`calc_lbs_weight` on the
+    concatenated rows -> skgs_knn_dist_weights_forward) return identical indices and weights"""
+    from sk_gs_amd.deform import calc_lbs_weight
+    P, M, K, F = 20_000, 512, 5, 8
+    pts, sp, feat, sfeat, radius_raw, kweight_raw = [t.cuda() for t in _sp_scene(P, M, 3, F)]
+    idx, w, d = _sp_forward(P, M, K, F, pts, sp, feat, sfeat, radius_raw, kweight_raw)
+    w2, idx2 = calc_lbs_weight(pts, sp, K, kernel_radius=torch.exp(radius_raw), kernel_weight=torch.sigmoid(kweight_raw),
+                               feature=feat, sp_feature=sfeat)
+    assert torch.equal(idx, idx2)
+    assert float((w - w2).abs().max()) <= 1e-6  # (exp / sigmoid of the raw parameters: in the kernel vs torch)
+
+
+# ---------------------------------------------------------------------------------------------------- the fused step
+def _sp_model(P, M, K, W, H, frames, method, seed=0):
+    from sk_gs_amd import scene
+    from sk_gs_amd.superpoint import SuperpointGaussians
+    dev = torch.device('cuda')
+    model = SuperpointGaussians(P, M, K, num_frames=frames, seed=seed, scale_mult=3.0, lbs_method=method).to(dev)
+    with torch.no_grad():  # deformations large enough to matter in the image
+        model.sp_deform_net.gaussian_warp.weight.mul_(20.0)
+        model.sp_deform_net.gaussian_rotation.weight.mul_(20.0)
+        model.sp_deform_net.gaussian_scaling.weight.mul_(100.0)
+    cam = scene.make_camera(W, H, seed=seed)
+    rs = scene.raster_settings_from_camera(cam, sh_degree=3, colmap=True, device=dev)
+    target = torch.rand(3, H, W, generator=torch.Generator().manual_seed(seed + 1)).to(dev)
+    return model, rs, target
+
+
+@pytest.mark.parametrize('method', ['weighted_kernel', 'W', 'dist'])
+def test_fused_superpoint_step_matches_the_operator_path(method):
+    """stage sp end to end: FusedSuperpointStep (straight C-ABI calls, MFMA network, one-launch 3+8-d search) against the
+    autograd operator path of SuperpointGaussians.render + image_loss -- the image and EVERY parameter gradient (Gaussians,
+    hyper features, superpoint tables, the network's 26 tensors)"""
+    from sk_gs_amd import _C
+    from sk_gs_amd.losses import image_loss
+    from sk_gs_amd.superpoint import FusedSuperpointStep
+    from helpers import assert_close_robust
+    P, M, K, W, H, frames, tid = 6000, 512, 5, 160, 120, 3, 1
+    model, rs, target = _sp_model(P, M, K, W, H, frames, method)
+    _C.config.sync_num_rendered = True
+    out = model.render(rs, time_id=tid)
+    loss = image_loss(out['images'], target)
+    loss.backward()
+    ref = {n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()}
+    R = out['buffer'].R
+    for p in model.parameters():
+        p.grad = None
+    step = FusedSuperpointStep(model, W, H, capacity=int(R * 1.2) + 1024)
+    # parameters this stage / weighting gives no gradient keep their zero .grad (never written): sp_points (detached
+    # everywhere on this path) and, under `W`, the hyper features (the logits do not depend on the distances)
+    silent = {'sp_points'} | ({'hyper_feature', 'sp_hyper_feature'} if method == 'W' else set())
+    for n, p in model.named_parameters():
+        if n not in silent:
+            p.grad.fill_(7.0)
+    step.forward_backward(rs, tid, target)
+    assert step.status()['overflow'] == 0
+    assert_close_robust(step.image, out['images'].detach(), 5e-6, 1e-4, name=f'image sp {method}')
+    for n, p in model.named_parameters():
+        if n in silent:
+            assert float(p.grad.abs().max()) == 0.0 and float(ref[n].abs().max()) == 0.0, n
+            continue
+        assert float(ref[n].abs().max()) > 0, n
+        assert_close_robust(p.grad, ref[n], 3e-4, 1e-3, name=f'{n} sp {method}')
+
+
+def test_superpoint_train_step_graph_replay_equals_eager_steps():
+    """FusedSuperpointTrainStep (rows' Adam on the idle CUs of the network's backward launch, closing launch for the rest)
+    captured as ONE hipGraph and replayed = the same steps issued eagerly with a plain optimizer.step(); and it trains"""
+    from sk_gs_amd import _C
+    from sk_gs_amd.optim import FusedAdam
+    from sk_gs_amd.superpoint import FusedSuperpointStep, FusedSuperpointTrainStep
+    from sk_gs_amd.train_step import GraphedSteps
+    P, M, K, W, H, frames = 5000, 512, 5, 128, 96, 2
+    runs = []
+    for fused in (True, False):
+        model, rs, _ = _sp_model(P, M, K, W, H, frames, 'weighted_kernel', seed=5)
+        _C.config.sync_num_rendered = True
+        with torch.no_grad():  # a fitting problem with a known answer: the model's own render, then perturbed colours
+            first = model.render(rs, time_id=0)
+            R, target = first['buffer'].R, first['images'].clamp(0, 1).contiguous()
+            model._features_dc.add_(0.3 * torch.randn(model._features_dc.shape, generator=torch.Generator().manual_seed(8)).cuda())
+        step = FusedSuperpointStep(model, W, H, capacity=int(R * 1.5) + 1024)
+        opt = FusedAdam(model.param_groups(lr=1e-4))
+        train = FusedSuperpointTrainStep(step, opt, enable=fused)
+        assert train.fused == fused
+        losses = []
+        if fused:
+            graphs = GraphedSteps(lambda _: train(rs, 0, target), collect_garbage=False)
+            for i in range(6):
+                graphs(0)
+                losses.append(float(step.loss3[0]))
+        else:
+            for i in range(6):
+                train(rs, 0, target)
+                losses.append(float(step.loss3[0]))
+        assert float(opt.step_count.item()) == 6
+        runs.append((losses, {n: p.detach().clone() for n, p in model.named_parameters()}))
+    (la, pa), (lb, pb) = runs
+    assert all(np.isfinite(la)) and la[0] > 0  # (Adam with eps 1e-15 random-walks the parameters whose gradient is noise: no monotone claim)
+    for a, b in zip(la, lb):
+        assert abs(a - b) <= 2e-5 * max(abs(b), 1e-6)
+    for n in pa:
+        assert rel_err(pa[n], pb[n]) <= 2e-5, n
