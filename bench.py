@@ -232,6 +232,17 @@ def main():
                     help="where torch autograd runs a backward (operator path only: ms/render and --autograd; the fused step "
                          "has no autograd in it).  'caller': sk_gs_amd.single_thread_backward(), what the install_as_* hooks "
                          "set; 'worker': torch's default per-device worker thread")
+    ap.add_argument('--stage', choices=('sk', 'sp'), default='sk',
+                    help="'sk' (default): the skeleton stage, BASELINE's headline workload.  'sp': the SUPERPOINT stage at the same "
+                         "size -- 512 superpoints, 3+8-d search, sp_deform_net on 512 rows (30 k of the reference's 80 k default "
+                         "steps, exps/default.yaml:12-26; benchlib/sp_stage.py)")
+    ap.add_argument('--keep-order', action='store_true',
+                    help='--stage sp: leave the synthetic Gaussians in their random order (default: sorted along a Z-order curve, '
+                         'densify.sort_spatially, as after a densification event)')
+    ap.add_argument('--superpoints', type=int, default=512, help='--stage sp: num_superpoints (exps/default.yaml:25)')
+    ap.add_argument('--lbs-method', choices=('weighted_kernel', 'kernel', 'dist', 'W'), default='weighted_kernel',
+                    help="--stage sp: the weighting of calc_LBS_weight (class default 'weighted_kernel', sk_gs.py:364; "
+                         "exps/default.yaml:35 sets 'W': a dense [P,512] logit table)")
     args = ap.parse_args()
     import sk_gs_amd
     sk_gs_amd.single_thread_backward(args.backward_thread == 'caller')
@@ -248,6 +259,16 @@ def main():
     from sk_gs_amd.view_parallel import ViewParallel, init_distributed
 
     # SKGS_FORCE_DIST=1: create a (1-rank) RCCL group so a single GPU exercises the multi-GPU code path
+    if args.stage == 'sp':
+        assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
+        from benchlib import sp_stage
+        line = sp_stage.run(args, alg_bytes, CONFIGS)
+        if line is not None:
+            os.write(json_fd, (json.dumps(line) + '\n').encode())
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     rank, world, local_rank = init_distributed(force=bool(os.environ.get('SKGS_FORCE_DIST')))
     use_dist = dist.is_initialized()
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'

@@ -1,0 +1,216 @@
+"""bench.py --stage sp: the SUPERPOINT stage of the hot path at BASELINE config #1's size.
+
+Stage `sp` is 30 k of the reference's 80 k default steps (exps/default.yaml:12-19: sp_fix 3 000 + sp 27 000): 100k Gaussians
+skinned by M = 512 superpoints (num_superpoints, :25) found by a K = 5 nearest search over [xyz | 8 hyper coordinates]
+(hyper_dim 8, :26; sk_gs.py:751-757), `sp_deform_net` (DeformNetwork, 8 x 256, on the 512 superpoints; sk_gs.py:209-315) producing
+their transforms every step, then the same rasterizer, loss and Adam as the skeleton stage.  One step =
+
+    sp net forward (1 launch, MFMA) | search + weighting (1) | skinning (1) | preprocess | scatter | sort | blend forward |
+    loss forward | loss backward | blend backward | preprocess backward | skinning backward | weighting backward (2) |
+    sp net backward (2; the per-Gaussian rows' Adam on the first one's idle CUs) | closing optimizer launch
+
+as ONE captured hipGraph for all views (camera, time, target from the device view slot).  Returns the JSON line as a dict.
+"""
+import time
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBPS = 8000.0
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+
+
+def net_flops(M: int):
+    fwd = 2 * M * (93 * 256 + 6 * 256 * 256 + 349 * 256 + 256 * 10) + 2 * (13 * 256 + 256 * 30)
+    return fwd, 2 * fwd
+
+
+def alg_bytes_sp(name, P, M, K, F, W, H, R, rows_adam_bytes=0):
+    """algorithmic bytes per launch of the stage's own kernels (the rasterizer's are bench.alg_bytes)"""
+    net_w = 4 * (13 * 256 + 256 + 256 * 30 + 30 + 93 * 256 + 6 * 256 * 256 + 349 * 256 + 8 * 256 + 10 * 256 + 10)
+    acts = 4 * M * (96 + 8 * 256)
+    return {
+        # positions + hyper row in, K (index 8 B, weight 4 B, distance 4 B) out; the superpoint table is LDS-resident
+        'sp_knn_weights': P * (12 + 4 * F + 16 * K) + M * (12 + 4 * F + 8),
+        # K (weight, index, distance, cotangent) in, hyper gradient row out + per-workgroup partial tables
+        'sp_knn_weights_backward': P * (20 * K + 8 * F),
+        'sp_net_forward': net_w + acts + M * (12 + 4 * (10 + 7 + 4 + 3)),       # weights once, saved activations out
+        'sp_net_backward': 3 * net_w + 3 * acts + rows_adam_bytes,               # weights, activations, gZ out + in, gradients out
+        'deform_forward': P * (88 + 12 * K),
+        'deform_backward': P * (40 + 16 * K),
+    }.get(name)
+
+
+def run(args, base_alg_bytes, configs):
+    """`args`: bench.py's namespace (config, views, steps, warmup, lr, lbs_method ...)"""
+    from sk_gs_amd import _C, scene
+    from sk_gs_amd.optim import FusedAdam
+    from sk_gs_amd.superpoint import FusedSuperpointStep, FusedSuperpointTrainStep, SuperpointGaussians
+    from sk_gs_amd.train_step import GraphedSteps
+    from sk_gs_amd.view_parallel import ViewParallel, init_distributed
+    from sk_gs_amd.view_slot import ViewTable
+
+    rank, world, local_rank = init_distributed()
+    use_dist = dist.is_initialized()
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(local_rank)
+    cfg = configs[args.config]
+    P, W, H = cfg['P'], cfg['W'], cfg['H']
+    M, K, F = args.superpoints, 5, 8
+    frames = args.views
+    model = SuperpointGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=0, scale_mult=args.scale_mult,
+                                lbs_method=args.lbs_method, hyper_dim=F).to(dev)
+    if not args.keep_order:  # Gaussians along a Z-order curve (sk_gs_amd/densify.py::sort_spatially): what a training loop
+        from sk_gs_amd.densify import sort_spatially  # does after every densification event
+        sort_spatially(model)
+    cams = [scene.make_camera(W, H, seed=i) for i in range(args.views)]
+    settings = [scene.raster_settings_from_camera(c, sh_degree=3, colmap=True, device=dev) for c in cams]
+    background = torch.ones(3, device=dev)
+    gen = torch.Generator().manual_seed(77)
+    _C.config.sync_num_rendered = True
+    targets, Rs, longest, walked = [], [], 0, []
+    with torch.no_grad():
+        for v in range(args.views):
+            out = model.render(settings[v], time_id=v % frames, background=background)
+            targets.append((out['images'] + 0.05 * torch.randn(3, H, W, generator=gen).to(dev)).clamp(0, 1).contiguous())
+            buf = out['buffer']
+            Rs.append(buf.R)
+            longest = max(longest, _C.read_status(buf.geomBuffer)['max_tile_count'])
+            walked.append(int(buf.imgBuffer[:W * H * 4].view(torch.int32).sum(dtype=torch.int64)))
+    R_mean, R_max = sum(Rs) / len(Rs), max(Rs)
+    tile_bucket = ((int(longest * 1.5) + 63) // 64) * 64
+    if 512 < tile_bucket and longest * 1.2 <= 512:
+        tile_bucket = 512
+    _C.config.sync_num_rendered = False
+    view_table = ViewTable(settings, [float(model.frame_times[v % frames]) for v in range(args.views)],
+                           [v % frames for v in range(args.views)], torch.stack(targets), dev)
+    vp = ViewParallel(model.parameters(), average=True)  # the parameters' gradients as views of ONE flat buffer
+    step = FusedSuperpointStep(model, W, H, capacity=int(R_max * 1.25 * _C.config.capacity_growth) + 1024,
+                               background=background, grad_scale=1.0 / world, tile_bucket=tile_bucket, view_table=view_table)
+    opt = FusedAdam(model.param_groups(lr=args.lr), eps=1e-15, betas=(0.9, 0.999))
+    train = FusedSuperpointTrainStep(step, opt, enable=not use_dist)
+    order = [vp.view_index(i, args.views) for i in range(args.views)]
+    if not use_dist:
+        view_table.set_order(order)
+        g_step = GraphedSteps(lambda _: train(), collect_garbage=False)
+
+        def train_step(i):
+            g_step(0)
+    else:  # view-parallel ranks: backward | ONE all-reduce of the flat gradient buffer | Adam
+        g_bwd = GraphedSteps(lambda _: step.forward_backward(), collect_garbage=False)
+        g_opt = GraphedSteps(lambda _: opt.step(), collect_garbage=False)
+
+        def train_step(i):
+            view_table.select(vp.view_index(i, args.views))
+            g_bwd(0)
+            vp.allreduce_grads(prescaled=True)
+            g_opt(0)
+
+    def eager_step(i):
+        if not use_dist:
+            train()
+        else:
+            view_table.select(vp.view_index(i, args.views))
+            step.forward_backward()
+            vp.allreduce_grads(prescaled=True)
+            opt.step()
+
+    eager_step(0)
+    if not use_dist:
+        view_table.rewind()
+    for i in range(max(args.warmup, 2)):
+        train_step(i)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    n_blocks = min(args.steps, 10)
+    edges = [round(b * args.steps / n_blocks) for b in range(n_blocks + 1)]
+    marks = [torch.cuda.Event(enable_timing=True) for _ in edges]
+    t0 = time.perf_counter()
+    marks[0].record()
+    nxt = 1
+    for i in range(args.steps):
+        train_step(args.warmup + i)
+        if i + 1 == edges[nxt]:
+            marks[nxt].record()
+            nxt += 1
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[b].elapsed_time(marks[b + 1]) / (edges[b + 1] - edges[b]) for b in range(n_blocks))
+    block_stats = dict(blocks=n_blocks, median=round(per_step[n_blocks // 2], 4), p10=round(per_step[n_blocks // 10], 4),
+                       p90=round(per_step[min(n_blocks - 1, (9 * n_blocks) // 10)], 4), min=round(per_step[0], 4),
+                       max=round(per_step[-1], 4),
+                       how='HIP events on the launch stream every steps/blocks steps inside the timed region (rank 0)')
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = step.status()
+    assert st['overflow_events'] == 0, 'binning capacity overflow during the timed region: result invalid'
+    # ---- per-kernel HIP-event timing: an eager pass over the same steps
+    _C.profile_enable(None)
+    n_prof = min(args.steps, 20)
+    for i in range(n_prof):
+        eager_step(args.warmup + args.steps + i)
+    torch.cuda.synchronize()
+    prof = _C.profile_collect()
+    _C.profile_enable([])
+    rows_b = 28 * sum(p.numel() for g in opt.param_groups if g.get('name') in train.rows for p in g['params'])
+    rest_b = 28 * sum(p.numel() for g in opt.param_groups if g.get('name') in train.rest for p in g['params'])
+    kernels = {}
+    for name, (ms, n) in prof.items():
+        us = ms / n * 1e3
+        b = alg_bytes_sp(name, P, M, K, F, W, H, R_mean, rows_adam_bytes=rows_b if train.fused else 0)
+        if b is None:
+            b = base_alg_bytes(name, P, M, K, W, H, R_mean)
+        if name == 'adam':
+            b = rest_b if train.fused else rows_b + rest_b
+        rec = dict(us=round(us, 2), launches_per_step=round(n / n_prof, 2), alg_MB=round(b / 1e6, 2) if b else None,
+                   GBps=round(b / (us * 1e-6) / 1e9, 1) if b else None,
+                   frac_of_hbm_peak=round(b / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if b else None)
+        if name in ('sp_net_forward', 'sp_net_backward'):
+            fl = net_flops(M)[0 if name == 'sp_net_forward' else 1]
+            rec['TFLOPs'] = round(fl / (us * 1e-6) / 1e12, 2)
+            rec['frac_of_mfma_f32_peak'] = round(fl / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
+        kernels[name] = rec
+    if rank != 0:
+        return None
+    rb = kernels.get('render_backward', {})
+    rb_us, rb_bytes = rb.get('us', 0.0), base_alg_bytes('render_backward', P, M, K, W, H, R_mean)
+    achieved = rb_bytes / (rb_us * 1e-6) / 1e9 if rb_us else 0.0
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    step_bytes = (P * (1138 + 4 * K) + 116 * R_mean + 44 * W * H + 8 * T  # SURVEY 8d without the 4 M logit row (kernel weighting)
+                  + alg_bytes_sp('sp_knn_weights', P, M, K, F, W, H, R_mean) + alg_bytes_sp('sp_knn_weights_backward', P, M, K, F, W, H, R_mean)
+                  + alg_bytes_sp('sp_net_forward', P, M, K, F, W, H, R_mean) + alg_bytes_sp('sp_net_backward', P, M, K, F, W, H, R_mean))
+    ms_step = elapsed / args.steps * 1e3
+    return {
+        'metric': f'train iters/sec, SUPERPOINT stage (sp net + 3+8-d search + skinning + rasterize fwd+bwd + L1/SSIM loss + Adam), '
+                  f'{P // 1000}k Gaussians @{W}x{H}',
+        'value': round(world * args.steps / elapsed, 3), 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(ms_step, 4), 'ms_per_step_blocks': block_stats, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'{cfg["name"]} in stage sp: {P} Gaussians, {M} superpoints, K={K}, search over xyz + {F} hyper '
+                               f'dimensions, LBS_method {args.lbs_method}, sp_deform_net 8x256 on {M} rows, SH degree 3, {W}x{H}, '
+                               f'{args.views} synthetic views, 1 view per rank per step',
+                   'stage': 'sp', 'num_rendered_mean': round(R_mean), 'num_rendered_max': R_max,
+                   'tile_list_mean': round(R_mean / T, 1), 'tile_list_max': longest,
+                   'walked_pairs_mean': round(sum(walked) / len(walked)),
+                   'parallelism': f'view-parallel x{world}, flat-buffer grad all-reduce ({vp.grads.nbytes / 1e6:.1f} MB)',
+                   'launch': 'ONE captured hipGraph for all views (camera, time and target read from a device view slot)'
+                   if not use_dist else 'two hipGraphs per step with the all-reduce between them',
+                   'tile_lists': f'buckets of {tile_bucket} slots per tile (longest list {longest})',
+                   'adam': ('per-Gaussian rows on the idle CUs of the sp net\'s row-block backward launch; network + superpoint '
+                            'tables + counter + next view in one closing launch') if train.fused else 'one launch after the all-reduce',
+                   'step': 'FusedSuperpointStep (direct C-ABI calls)'},
+        'roofline': {'bound': 'hbm', 'kernel': 'render_backward', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBPS,
+                     'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 5), 'traffic': None, 'avg_us': rb_us,
+                     'alg_bytes_per_launch': int(rb_bytes), 'limiter': 'valu',
+                     'whole_step': {'alg_bytes': int(step_bytes), 'ms': round(ms_step, 4),
+                                    'frac': round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},
+                     'note': 'same dominant kernel as stage sk (VALU-issue bound); the stage\'s own kernels are under "kernels": '
+                             'the sp net against the fp32 MFMA peak, the search against its algorithmic bytes'},
+        'kernels': kernels,
+    }

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_kernel(int P, 
     const float* __restrict__ g_scales, const float* __restrict__ g_rotations, const float* __restrict__ g_opacity,
     float* __restrict__ g_weights, float* __restrict__ g_bone_T, float* __restrict__ g_bone_drot,
     float* __restrict__ g_bone_dscale, float* __restrict__ g_xyz, float* __restrict__ g_log_scale,
-    float* __restrict__ g_rot, float* __restrict__ g_opacity_logit, int ncopy) {
+    float* __restrict__ g_rot, float* __restrict__ g_opacity_logit, int ncopy, float* __restrict__ partials) {
   extern __shared__ float s_mem[];
   float* s_bones = s_mem;                                   // [M][14] (LDS_BONES only)
   float* s_grad  = s_mem + (LDS_BONES ? M * BONE_F : 0);    // [ncopy][M][14] (LDS_BONES only)
@@ -113,7 +113,10 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_kernel(int P, 
     for (int i = threadIdx.x; i < ncopy * M * BONE_F; i += DEFORM_THREADS) s_grad[i] = 0.f;
     __syncthreads();
   }
-  for (int n = blockIdx.x * DEFORM_THREADS + threadIdx.x; n < P; n += gridDim.x * DEFORM_THREADS) {
+  // (whole waves stay in the loop: the merged accumulation below needs all 64 lanes; `live` masks a wave's tail)
+  for (int base = blockIdx.x * DEFORM_THREADS; base < P; base += gridDim.x * DEFORM_THREADS) {
+    const bool live = base + (int) threadIdx.x < P;
+    const int n     = live ? base + (int) threadIdx.x : P - 1;
     const float p[3] = {points[3 * n], points[3 * n + 1], points[3 * n + 2]};
     // All neighbour ids / weights are fetched up front (static registers, loads in flight together): with ~1.5 waves
     // per SIMD at P = 1e5 a load-use chain per k was pure HBM latency (measured 30 us for this loop alone).
@@ -155,14 +158,16 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_kernel(int P, 
     }
     const float g_dx[3] = {g_means[3 * n], g_means[3 * n + 1], g_means[3 * n + 2]};
     const float g_ds[3] = {g_scales[3 * n], g_scales[3 * n + 1], g_scales[3 * n + 2]};
+    if (live) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      g_xyz[3 * n + c]       = g_dx[c];
-      g_log_scale[3 * n + c] = g_ds[c] * expf(log_scale[3 * n + c]);
+      for (int c = 0; c < 3; ++c) {
+        g_xyz[3 * n + c]       = g_dx[c];
+        g_log_scale[3 * n + c] = g_ds[c] * expf(log_scale[3 * n + c]);
+      }
+      reinterpret_cast<float4*>(g_rot)[n] = make_float4(g_v[0], g_v[1], g_v[2], g_v[3]);
+      const float sg     = 1.0f / (1.0f + expf(-opacity_logit[n]));
+      g_opacity_logit[n] = g_opacity[n] * sg * (1.0f - sg);
     }
-    reinterpret_cast<float4*>(g_rot)[n] = make_float4(g_v[0], g_v[1], g_v[2], g_v[3]);
-    const float sg     = 1.0f / (1.0f + expf(-opacity_logit[n]));
-    g_opacity_logit[n] = g_opacity[n] * sg * (1.0f - sg);
     auto bone_body = [&](int k, int j, float w) {
       float bl[BONE_F];
       const float* b;
@@ -179,7 +184,7 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_kernel(int P, 
       for (int c = 0; c < 4; ++c) gw += g_v[c] * b[7 + c];
 #pragma unroll
       for (int c = 0; c < 3; ++c) gw += g_ds[c] * b[11 + c];
-      g_weights[(size_t) n * K + k] = gw;
+      if (live) g_weights[(size_t) n * K + k] = gw;
       float out[BONE_F];
       const float g[3] = {w * g_dx[0], w * g_dx[1], w * g_dx[2]};
       out[0] = g[0], out[1] = g[1], out[2] = g[2];
@@ -204,9 +209,13 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_kernel(int P, 
 #pragma unroll
       for (int c = 0; c < 3; ++c) out[11 + c] = w * g_ds[c];
       if (LDS_BONES) {
+        if (ncopy == 1) {  // many bones: merge the wave's lanes that name the same bone, then one 14-lane ds_add per bone
+          wave_group_add<BONE_F>(s_grad, BONE_F, j, out, live);
+        } else if (live) {
 #pragma unroll
-        for (int c = 0; c < BONE_F; ++c) atomicAdd(&s_my[j * BONE_F + c], out[c]);
-      } else {
+          for (int c = 0; c < BONE_F; ++c) atomicAdd(&s_my[j * BONE_F + c], out[c]);
+        }
+      } else if (live) {
 #pragma unroll
         for (int c = 0; c < 7; ++c) atomicAdd(&g_bone_T[7 * j + c], out[c]);
 #pragma unroll
@@ -225,7 +234,9 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_kernel(int P, 
     for (int i = threadIdx.x; i < M * BONE_F; i += DEFORM_THREADS) {
       float val = 0.f;
       for (int cpy = 0; cpy < ncopy; ++cpy) val += s_grad[(size_t) cpy * M * BONE_F + i];
-      if (val != 0.f) {
+      if (partials) {  // this workgroup's table as one contiguous partial: summed in workgroup order by the finalize launch
+        partials[(size_t) blockIdx.x * M * BONE_F + i] = val;
+      } else if (val != 0.f) {
         const int j = i / BONE_F, c = i % BONE_F;
         if (c < 7)
           atomicAdd(&g_bone_T[7 * j + c], val);
@@ -236,6 +247,31 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_kernel(int P, 
       }
     }
   }
+}
+
+// Many bones (the 512 superpoints of stage sp): every workgroup's [M][14] table used to be flushed with one global atomic per
+// non-zero entry -- 391 workgroups x 7168 atomics onto the same 7168 addresses: 71 us at P = 1e5.  Now a fixed grid of
+// workgroups walks the Gaussians, writes its table as a partial, and this launch sums the partials in workgroup order.
+__global__ void __launch_bounds__(256) deform_backward_wide_finalize_kernel(int M, int nblk, const float* __restrict__ partials,
+    float* __restrict__ g_bone_T, float* __restrict__ g_bone_drot, float* __restrict__ g_bone_dscale) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * BONE_F) return;
+  float sum = 0.f;
+  for (int b0 = 0; b0 < nblk; b0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = partials[(size_t) min(b0 + u, nblk - 1) * M * BONE_F + i];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (b0 + u < nblk) sum += v[u];
+  }
+  const int j = i / BONE_F, c = i % BONE_F;
+  if (c < 7)
+    g_bone_T[7 * j + c] = sum;
+  else if (c < 11)
+    g_bone_drot[4 * j + c - 7] = sum;
+  else
+    g_bone_dscale[3 * j + c - 11] = sum;
 }
 
 // ------------------------------------------------------------------------------ bone gradients by moments
@@ -999,8 +1035,10 @@ int launch_deform_forward(const skgs_deform_inputs& in, float* means, float* sca
   return 0;
 }
 
+constexpr int WIDE_MAX_BLOCKS = 512;
+static int wide_blocks(int P) { return std::max(1, std::min((P + DEFORM_THREADS - 1) / DEFORM_THREADS, WIDE_MAX_BLOCKS)); }
 size_t deform_backward_workspace_bytes(int P, int M) {
-  if (M > MOM_MAX_BONES) return 256;
+  if (M > MOM_MAX_BONES) return M <= MAX_LDS_BONES / 2 ? align256((size_t) wide_blocks(P) * M * BONE_F * 4) + 256 : 256;
   const size_t nblk = (size_t) (P + DEFORM_THREADS - 1) / DEFORM_THREADS;
   return align256(nblk * (size_t) M * MOM_F * 4) + 256;
 }
@@ -1036,25 +1074,35 @@ int launch_deform_backward(const skgs_deform_inputs& in, const float* g_means, c
     SKGS_CHECK_HIP(hipGetLastError());
     return 0;
   }
-  // many bones (superpoint stage): scatter with atomics into zeroed outputs
+  // many bones (superpoint stage)
+  if (in.M <= MAX_LDS_BONES / 2) {  // LDS tables per workgroup -> partials -> fixed-order sum (no memset, no global atomics)
+    const size_t table = (size_t) in.M * BONE_F * 4;
+    int ncopy = 1;
+    while (ncopy < 16 && table * (1 + 2 * ncopy) <= 56 * 1024) ncopy *= 2;
+    const int nblk  = wide_blocks(in.P);
+    float* partials = reinterpret_cast<float*>(workspace);
+    {
+      ProfScope prof(K_DEFORM_BWD, s);
+      hipLaunchKernelGGL(deform_backward_kernel<true>, dim3(nblk), block, table * (1 + ncopy), s, in.P, in.K, in.M, in.points,
+          in.weights, in.indices, in.bone_T, in.bone_drot, in.bone_dscale, in.log_scale, in.rot, in.opacity_logit, g_means,
+          g_scales, g_rotations, g_opacity, g_weights, g_bone_T, g_bone_drot, g_bone_dscale, g_xyz, g_log_scale, g_rot,
+          g_opacity_logit, ncopy, partials);
+    }
+    SKGS_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(deform_backward_wide_finalize_kernel, dim3((in.M * BONE_F + 255) / 256), dim3(256), 0, s, in.M, nblk,
+        partials, g_bone_T, g_bone_drot, g_bone_dscale);
+    SKGS_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
+  // more bones than the LDS tables hold: scatter with global atomics into zeroed outputs
   if (fill_u32(g_bone_T, 0u, (size_t) in.M * 7, s) || fill_u32(g_bone_drot, 0u, (size_t) in.M * 4, s) ||
       fill_u32(g_bone_dscale, 0u, (size_t) in.M * 3, s))
     return 1;
   ProfScope prof(K_DEFORM_BWD, s);
-  if (in.M <= MAX_LDS_BONES / 2) {
-    const size_t table = (size_t) in.M * BONE_F * 4;
-    int ncopy = 1;
-    while (ncopy < 16 && table * (1 + 2 * ncopy) <= 56 * 1024) ncopy *= 2;
-    hipLaunchKernelGGL(deform_backward_kernel<true>, grid, block, table * (1 + ncopy), s, in.P, in.K, in.M, in.points,
-        in.weights, in.indices, in.bone_T, in.bone_drot, in.bone_dscale, in.log_scale, in.rot, in.opacity_logit, g_means,
-        g_scales, g_rotations, g_opacity, g_weights, g_bone_T, g_bone_drot, g_bone_dscale, g_xyz, g_log_scale, g_rot,
-        g_opacity_logit, ncopy);
-  } else {
-    hipLaunchKernelGGL(deform_backward_kernel<false>, grid, block, 0, s, in.P, in.K, in.M, in.points, in.weights,
-        in.indices, in.bone_T, in.bone_drot, in.bone_dscale, in.log_scale, in.rot, in.opacity_logit, g_means, g_scales,
-        g_rotations, g_opacity, g_weights, g_bone_T, g_bone_drot, g_bone_dscale, g_xyz, g_log_scale, g_rot,
-        g_opacity_logit, 1);
-  }
+  hipLaunchKernelGGL(deform_backward_kernel<false>, grid, block, 0, s, in.P, in.K, in.M, in.points, in.weights,
+      in.indices, in.bone_T, in.bone_drot, in.bone_dscale, in.log_scale, in.rot, in.opacity_logit, g_means, g_scales,
+      g_rotations, g_opacity, g_weights, g_bone_T, g_bone_drot, g_bone_dscale, g_xyz, g_log_scale, g_rot,
+      g_opacity_logit, 1, (float*) nullptr);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -160,6 +160,41 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   return v;
 }
 
+// Per-row accumulation into an LDS table with the wave's duplicates merged first.
+// Every lane holds N values for table row `row`; LDS float atomics retire about one LANE per 2-3 clocks (deform backward at
+// M = 512: 7 M lane-atomics = 37 us of LDS time per CU, tools/pmc_kernel.sh), and lanes that share a row serialise on top.
+// With the Gaussians in spatial order (sk_gs_amd/densify.py::sort_spatially) the 64 lanes of a wave name only a handful of
+// distinct rows: for each of the first WAVE_GROUPS_MAX distinct rows the group's N sums are formed by masked DPP wave
+// reductions and added by ONE ds_add_f32 with N active lanes (distinct addresses); lanes of any further row fall back to
+// their own atomics.  ALL 64 lanes must be active (`valid` masks the ones without work).  Sum order inside a group is the DPP
+// tree's: deterministic for a given lane assignment.
+constexpr int WAVE_GROUPS_MAX = 6;
+template <int N>
+__device__ __forceinline__ void wave_group_add(float* __restrict__ table, int stride, int row, const float (&v)[N], bool valid) {
+  const int lane = threadIdx.x & 63;
+  uint64_t todo = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll 1
+  for (int it = 0; todo != 0 && it < WAVE_GROUPS_MAX; ++it) {
+    const int leader    = __builtin_ctzll(todo);
+    const int r         = __builtin_amdgcn_readlane(row, leader);
+    const uint64_t same = __builtin_amdgcn_ballot_w64(valid && row == r) & todo;
+    const bool mine     = (same >> lane) & 1;
+    float tot = 0.f;
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+      const float x = wave_sum_to_lane63(mine ? v[c] : 0.f);
+      const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+      tot = lane == c ? t : tot;
+    }
+    if (lane < N) atomicAdd(table + (size_t) r * stride + lane, tot);
+    todo &= ~same;
+  }
+  if ((todo >> lane) & 1) {
+#pragma unroll
+    for (int c = 0; c < N; ++c) atomicAdd(table + (size_t) row * stride + c, v[c]);
+  }
+}
+
 // Three independent wave sums at once, as hand-placed v_add_f32_dpp (one instruction per step and value: hipcc's
 // DPP-combine leaves most update_dpp + add pairs un-fused, doubling the instruction count of the reduction).
 // A VALU write -> DPP read of the same VGPR needs 2 wait states on gfx9-family parts: inside the statement the

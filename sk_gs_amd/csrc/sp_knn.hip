@@ -22,6 +22,7 @@
 #pragma clang fp contract(off)
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 #include "skgs_common.h"
 
@@ -49,7 +50,27 @@ __device__ __forceinline__ void topk_insert_sorted(float (&bd)[KCAP], int (&bi)[
 __device__ __forceinline__ float act_radius(const float* __restrict__ r, int j) { return expf(r[j]); }
 __device__ __forceinline__ float act_kweight(const float* __restrict__ w, int j) { return 1.0f / (1.0f + expf(-w[j])); }
 
-// F = number of hyper dimensions (0 or 8)
+// insertion by (distance, id) lexicographically: the merge of the four partial lists of a Gaussian (ties to the lower id, the
+// order the serial scan produces)
+template <int KCAP>
+__device__ __forceinline__ void topk_insert_lex(float (&bd)[KCAP], int (&bi)[KCAP], float d, int id) {
+  bool lt[KCAP];
+#pragma unroll
+  for (int k = 0; k < KCAP; ++k) lt[k] = (d < bd[k]) | ((d == bd[k]) & (id < bi[k]));
+#pragma unroll
+  for (int k = KCAP - 1; k >= 1; --k) {
+    bi[k] = lt[k - 1] ? bi[k - 1] : (lt[k] ? id : bi[k]);
+    bd[k] = lt[k - 1] ? bd[k - 1] : (lt[k] ? d : bd[k]);
+  }
+  bi[0] = lt[0] ? id : bi[0];
+  bd[0] = lt[0] ? d : bd[0];
+}
+
+// F = number of hyper dimensions (0 or 8).  FOUR lanes per Gaussian: lane `part` scans the superpoints j = part (mod 4) --
+// a quad reads four consecutive 48-byte table rows, conflict-free -- and the four sorted lists are merged by (distance, id)
+// over two quad shuffles.  One lane per Gaussian left the chip with 1.5 waves per SIMD on a chain of dependent LDS reads
+// (154 us at P = 1e5, M = 512); four give 6 waves per SIMD and a quarter of the chain each.
+constexpr int LPG = 4;
 template <int KCAP, int F>
 __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int M, int K, const float* __restrict__ points,
     const float* __restrict__ feature, const float* __restrict__ sp_points, const float* __restrict__ sp_feature,
@@ -66,8 +87,9 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
     s_c[i] = v;
   }
   __syncthreads();
-  const int n  = blockIdx.x * SPK_THREADS + threadIdx.x;
-  const int nn = min(n, P - 1);  // (lanes beyond P follow the last Gaussian: the wave-wide tests stay well defined)
+  const int part = threadIdx.x & (LPG - 1);
+  const int n    = blockIdx.x * (SPK_THREADS / LPG) + (threadIdx.x >> 2);
+  const int nn   = min(n, P - 1);  // (lanes beyond P follow the last Gaussian: the wave-wide tests stay well defined)
   const float p0 = points[3 * nn], p1 = points[3 * nn + 1], p2 = points[3 * nn + 2];
   float f[MAXF];
 #pragma unroll
@@ -76,7 +98,7 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
   int bi[KCAP];
 #pragma unroll
   for (int k = 0; k < KCAP; ++k) bd[k] = __builtin_inff(), bi[k] = 0;
-  for (int j = 0; j < M; ++j) {
+  for (int j = part; j < M; j += LPG) {  // (the ballots below see the lanes still in the loop: the skips stay wave-uniform)
     const float4 c0 = *reinterpret_cast<const float4*>(s_c + j * CROW);
     const float d0 = p0 - c0.x, d1 = p1 - c0.y, d2 = p2 - c0.z;
     float d = d0 * d0;  // (0 + t = t: the oracle's `d = 0; d += df * df` starts here)
@@ -100,6 +122,17 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
     if (__builtin_amdgcn_ballot_w64(d < bd[KCAP - 1]) == 0) continue;
     topk_insert_sorted<KCAP>(bd, bi, d, j);
   }
+  // ---- merge the quad's four lists: after xor 1 lanes (0,1) and (2,3) agree, after xor 2 all four
+#pragma unroll
+  for (int step = 1; step <= 2; step <<= 1) {
+    float od[KCAP];
+    int oi[KCAP];
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) od[k] = __shfl_xor(bd[k], step), oi[k] = __shfl_xor(bi[k], step);
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) topk_insert_lex<KCAP>(bd, bi, od[k], oi[k]);
+  }
+  if (part != 0) return;
   if (n >= P) return;
   // ---- weighting (sk_gs.py:759-770), the arithmetic of deform.hip::knn_dist_weights_kernel / lbs_weights_forward_kernel
   float v[KCAP];
@@ -162,7 +195,10 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_weights_backward_kernel(int P,
   constexpr int V = F + 2;
   for (int i = threadIdx.x; i < M * V; i += SPK_THREADS) s_acc[i] = 0.f;
   __syncthreads();
-  for (int n = blockIdx.x * SPK_THREADS + threadIdx.x; n < P; n += gridDim.x * SPK_THREADS) {
+  // (whole waves stay in the loop: wave_group_add merges the lanes that picked the same superpoint and needs all 64 lanes)
+  for (int base = blockIdx.x * SPK_THREADS; base < P; base += gridDim.x * SPK_THREADS) {
+    const bool live = base + (int) threadIdx.x < P;
+    const int n     = live ? base + (int) threadIdx.x : P - 1;
     const float* w  = weights + (size_t) n * K;
     const float* gw = g_weights + (size_t) n * K;
     const float* dd = nn_dist + (size_t) n * K;
@@ -185,6 +221,9 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_weights_backward_kernel(int P,
     for (int c = 0; c < MAXF; ++c) fc[c] = (F > 0 && c < F) ? feature[(size_t) n * F + c] : 0.f;
     for (int k = 0; k < K; ++k) {
       const int j = (int) ix[k];
+      float acc[V];  // this pair's contribution to superpoint j: [-2 g_d (f - sf)] (F), radius, kernel weight
+#pragma unroll
+      for (int c = 0; c < V; ++c) acc[c] = 0.f;
       float g_d;
       if (radius_raw) {
         const float r   = act_radius(radius_raw, j);
@@ -193,8 +232,8 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_weights_backward_kernel(int P,
         const float g_v = (gw[k] - dot) / sum;
         const float g_e = g_v * sk;
         g_d             = g_e * e * (-1.f / (2.f * (r * r)));
-        atomicAdd(s_acc + (size_t) j * V + F, g_e * e * (dd[k] / (r * r * r)));
-        if (kweight_raw) atomicAdd(s_acc + (size_t) j * V + F + 1, g_v * e);
+        acc[F]          = g_e * e * (dd[k] / (r * r * r));
+        if (kweight_raw) acc[F + 1] = g_v * e;
       } else {
         g_d = -(w[k] * (gw[k] - dot)) / temperature;
       }
@@ -203,10 +242,12 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_weights_backward_kernel(int P,
         if (F > 0 && c < F) {
           const float t = g_d * 2.f * (fc[c] - sp_feature[(size_t) j * F + c]);
           gf[c] += t;
-          atomicAdd(s_acc + (size_t) j * V + c, -t);
+          acc[c] = -t;
         }
+      // (global atomics straight into one [M][V] table were measured: 534 us -- 5 M atomics on 5 k hot addresses)
+      wave_group_add<V>(s_acc, V, j, acc, live);
     }
-    if (g_feature)
+    if (g_feature && live)
 #pragma unroll
       for (int c = 0; c < MAXF; ++c)
         if (F > 0 && c < F) g_feature[(size_t) n * F + c] = gf[c];
@@ -271,7 +312,8 @@ int skgs_sp_lbs_weights_forward(int32_t P, int32_t M, int32_t K, int32_t F, cons
   SKGS_REQUIRE(lds <= 64 * 1024, "sp_lbs_weights_forward: too many superpoints for the LDS table (<= 1365)");
   hipStream_t s = (hipStream_t) stream;
   ProfScope prof(K_SP_KNN, s);
-  const dim3 grid((P + SPK_THREADS - 1) / SPK_THREADS), block(SPK_THREADS);
+  const int per_wg = SPK_THREADS / LPG;  // four lanes per Gaussian
+  const dim3 grid((P + per_wg - 1) / per_wg), block(SPK_THREADS);
 #define SKGS_SPK(KCAP_, F_)                                                                                              \
   hipLaunchKernelGGL((sp_knn_weights_kernel<KCAP_, F_>), grid, block, lds, s, P, M, K, points, feature, sp_points, sp_feature, \
       sp_radius_raw, sp_weight_raw, temperature, sp_W, out_idx, out_weights, out_dist)

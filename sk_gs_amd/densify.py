@@ -22,7 +22,7 @@ from sk_gs_amd.optim import FusedAdam
 
 # module attribute -> optimizer group name (gaussian_splatting.py:89-96 + the per-Gaussian LBS logits)
 PARAM_NAMES_MAP = {'_xyz': 'xyz', '_features_dc': 'f_dc', '_features_rest': 'f_rest', '_opacity': 'opacity',
-                   '_scaling': 'scaling', '_rotation': 'rotation', 'sp_W': 'sp_W'}
+                   '_scaling': 'scaling', '_rotation': 'rotation', 'sp_W': 'sp_W', 'hyper_feature': 'hyper'}  # (sk_gs.py:429)
 
 
 class DensifyStats:
@@ -201,3 +201,41 @@ def reset_opacity(model, opt: FusedAdam):
     """opacity <- min(opacity, 0.01) in logit space, with fresh Adam moments (:652-655)"""
     o = torch.minimum(torch.sigmoid(model._opacity), torch.full_like(model._opacity, 0.01))
     _rebind(model, opt.change_optimizer(torch.log(o / (1 - o)), name='opacity', op='replace'))
+
+
+# ------------------------------------------------------------------------------------------------ spatial order
+def morton_order(xyz: Tensor, bits: int = 10) -> Tensor:
+    """row permutation that sorts the positions along a Z-order curve (``bits`` per axis over their bounding box): Gaussians
+    that are neighbours in space become neighbours in memory -- and in a wavefront"""
+    lo, hi = xyz.min(0).values, xyz.max(0).values
+    q = ((xyz - lo) / (hi - lo).clamp_min(1e-12) * ((1 << bits) - 1)).long().clamp_(0, (1 << bits) - 1)
+    code = torch.zeros(xyz.shape[0], dtype=torch.int64, device=xyz.device)
+    for b in range(bits):
+        for a in range(3):
+            code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+    return torch.argsort(code, stable=True)
+
+
+@torch.no_grad()
+def sort_spatially(model, opt: Optional[FusedAdam] = None, stats=None) -> Tensor:
+    """Re-order the Gaussians along a Z-order curve: every per-Gaussian parameter, its Adam moments (ONE row-gather launch,
+    ``FusedAdam.gather_rows``) and the densification statistics move together, so training is unaffected -- the order of the
+    Gaussians carries no meaning (the reference appends clones and split children at the end, gaussian_splatting.py:577-587).
+    What it buys: the lanes of a wavefront then hold spatial neighbours, which share their nearest bones / superpoints and
+    their screen tiles -- the wave-wide early-outs of the superpoint search (csrc/sp_knn.hip) skip most candidates, and the
+    bone-gradient accumulation of the skinning backward merges a wave's contributions before it touches LDS.  Call it after
+    a densification event (the same cadence as the reference's surgery); returns the permutation applied."""
+    rows = morton_order(model._xyz.detach())
+    if opt is None:
+        for attr in _names(model):
+            p = getattr(model, attr)
+            p.data = p.data.index_select(0, rows).contiguous()
+    else:
+        _rebind(model, opt.gather_rows(list(_names(model).values()), rows, rows.numel()))
+    if stats is not None:
+        if hasattr(stats, 'gather_densify_stats'):
+            stats.gather_densify_stats(rows)
+        else:
+            stats.xyz_gradient_accum = stats.xyz_gradient_accum[rows]
+            stats.denom, stats.max_radii2D = stats.denom[rows], stats.max_radii2D[rows]
+    return rows
