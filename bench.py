@@ -56,89 +56,7 @@ def alg_bytes(name, P, M, K, W, H, R):
     }.get(name)
 
 
-def _cpu_oracle():
-    import tempfile
-    from oracle import oracle as om
-    lib = None
-    try:
-        out = om.build(tempfile.mkdtemp(prefix='skgs_oracle_native_'), native=True)
-        lib = os.path.join(out, 'libskgs_oracle_native.so')
-        if not os.path.exists(lib):
-            lib = None
-    except Exception:
-        lib = None
-    return om.Oracle('f32', lib_path=lib), lib
-
-
-def _cpu_time(o, cfg, seconds_budget, max_iters=50):
-    """(iterations, seconds) of deform + rasterize forward + backward of the oracle on the workload `cfg`"""
-    from sk_gs_amd import scene, skeleton
-    P, M, K, W, H = cfg['P'], cfg['M'], cfg['K'], cfg['W'], cfg['H']
-    g = scene.make_gaussians(P, seed=0)
-    cam = scene.make_camera(W, H, seed=0)
-    rs = scene.raster_settings_from_camera(cam, colmap=True)
-    n = lambda t: t.numpy()  # noqa: E731
-    gen = torch.Generator().manual_seed(5)
-    if M > 0:
-        b = scene.make_bones(M, seed=0)
-        table, _ = skeleton.build_ancestor_table(b['parents'], 0)
-        sk_T = skeleton.kinematic(b['joints'], skeleton.axis_angle_to_quat(b['axis_angle']), None, table, 0)
-        w = torch.softmax(torch.randn(P, K, generator=gen), -1)
-    gcol = torch.randn(3, H, W, generator=gen).numpy()
-    gop = torch.randn(H, W, generator=gen).numpy()
-
-    def one_iter():
-        if M > 0:
-            _, idx = o.knn_bones(n(g['xyz']), n(b['joints']), K)
-            d = o.lbs_deform_forward(n(g['xyz']), n(w), idx, n(sk_T), n(b['d_rot']), n(b['d_scale']), n(g['xyz']),
-                                     n(g['log_scale']), n(g['rot']), n(g['opacity_logit']))
-        else:
-            act = scene.activate(g)
-            d = dict(means=n(act['means3D']), scales=n(act['scales']), rotations=n(act['rotations']),
-                     opacity=n(act['opacity']))
-        fwd = o.rasterize_forward(H, W, rs.tanfovx, rs.tanfovy, 3, 1.0, True, n(rs.viewmatrix), n(rs.projmatrix),
-                                  n(rs.campos), d['means'], d['opacity'], n(g['sh']), d['scales'], d['rotations'])
-        gr = o.rasterize_backward(fwd, H, W, rs.tanfovx, rs.tanfovy, 3, 1.0, True, n(rs.viewmatrix), n(rs.projmatrix),
-                                  n(rs.campos), d['means'], n(g['sh']), d['scales'], d['rotations'], gcol, gop)
-        if M > 0:
-            o.lbs_deform_backward(n(g['xyz']), n(w), idx, n(sk_T), n(b['d_rot']), n(b['d_scale']), n(g['log_scale']),
-                                  n(g['rot']), n(g['opacity_logit']), gr['dL_dmeans3D'], gr['dL_dscales'],
-                                  gr['dL_drotations'], gr['dL_dopacity'])
-
-    one_iter()  # warm-up
-    t0 = time.perf_counter()
-    iters = 0
-    while True:
-        one_iter()
-        iters += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget or iters >= max_iters:
-            break
-    return iters, el
-
-
-def cpu_baseline(cfg, seconds_budget=20.0, single_thread_workload=False):
-    """time the CPU oracle (bounded samples); returns the cpu_baseline object.  The headline value is the bench workload on
-    all host cores; beside it BASELINE config #0 (the reference's CPU-sized case) on all cores and on ONE thread, and --
-    opt-in, it takes about a minute per iteration -- the bench workload on one thread."""
-    o, lib = _cpu_oracle()
-    cores = o.num_threads()
-    iters, el = _cpu_time(o, cfg, 0.6 * seconds_budget)
-    out = dict(value=round(iters / el, 4), unit='iters/s', cores=cores, kind='port',
-               sample=f'{iters} iterations of deform+rasterize forward+backward (no loss/Adam) of the same workload, '
-                      f'{el:.1f} s, oracle built {"-march=native" if lib else "portable"}, OpenMP')
-    c0 = CONFIGS[0]
-    i0, e0 = _cpu_time(o, c0, 0.15 * seconds_budget, max_iters=200)
-    o.set_num_threads(1)
-    i1, e1 = _cpu_time(o, c0, 0.25 * seconds_budget, max_iters=50)
-    out['config0'] = dict(workload=f'{c0["name"]}: {c0["P"]} static Gaussians, {c0["W"]}x{c0["H"]}, rasterize forward+backward',
-                          all_cores=dict(value=round(i0 / e0, 3), cores=cores, iterations=i0),
-                          single_thread=dict(value=round(i1 / e1, 3), cores=1, iterations=i1), unit='iters/s')
-    if single_thread_workload:
-        i2, e2 = _cpu_time(o, cfg, 1.0, max_iters=1)
-        out['single_thread'] = dict(value=round(i2 / e2, 5), cores=1, iterations=i2, unit='iters/s')
-    o.set_num_threads(cores)
-    return out
+from benchlib.cpu_baseline import cpu_baseline  # noqa: E402  (the CPU oracle timed on the host cores)
 
 
 def main():
@@ -217,7 +135,7 @@ def main():
     ap.add_argument('--autograd', action='store_true',
                     help='run the step through the torch-autograd operator path (model.render + image_loss + backward) '
                          'instead of sk_gs_amd.fused_step.FusedViewStep (same kernels, no autograd glue)')
-    ap.add_argument('--auto-budget', type=float, default=420.0,
+    ap.add_argument('--auto-budget', type=float, default=240.0,
                     help='world > 1, --exchange auto: seconds after which no further exchange variant is started (the ones that '
                          'finished are ranked and reported)')
     ap.add_argument('--split-rest', action='store_true',
@@ -244,6 +162,9 @@ def main():
                     help="--stage sp: the weighting of calc_LBS_weight (class default 'weighted_kernel', sk_gs.py:364; "
                          "exps/default.yaml:35 sets 'W': a dense [P,512] logit table)")
     args = ap.parse_args()
+    from benchlib import launch
+    if launch.needs_spawn(args.gpus):  # `python bench.py --gpus N` without a launcher: start the N ranks (or refuse), never run 1
+        sys.exit(launch.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
     import sk_gs_amd
     sk_gs_amd.single_thread_backward(args.backward_thread == 'caller')
 
@@ -271,7 +192,7 @@ def main():
         return
     rank, world, local_rank = init_distributed(force=bool(os.environ.get('SKGS_FORCE_DIST')))
     use_dist = dist.is_initialized()
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree'
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -804,7 +725,8 @@ def main():
                     b = {'skeleton_forward': net_b, 'skeleton_backward': 2 * net_b, 'adam': rows_b + rest_b}[name]
             kernels[name] = dict(us=round(us, 2), launches_per_step=round(n / min(args.steps, 20), 2),
                                  alg_MB=round(b / 1e6, 2) if b else None,
-                                 GBps=round(b / (us * 1e-6) / 1e9, 1) if b else None)
+                                 GBps=round(b / (us * 1e-6) / 1e9, 1) if b else None,
+                                 frac=round(b / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if b else None)
         _C.profile_enable([])
         if ordered_views:
             view_table.clear_order()  # the measurements below select their views explicitly
@@ -884,6 +806,8 @@ def main():
                 torch.cuda.synchronize()
                 fps['fused_step_graph'] = round(NT * 1000.0 / e0.elapsed_time(e1), 1)
 
+        from benchlib import launch as _launch
+        cluster = _launch.cluster_info(dist, torch, local_rank)  # (a collective: every rank)
         if rank == 0:
             rb_ms, rb_n = prof.get('render_backward', (0.0, 0))
             rb_us = rb_ms / max(rb_n, 1) * 1e3
@@ -916,6 +840,16 @@ def main():
                                      'reduction: 17 DPP adds, 2 permlane swaps)')
                 except Exception:
                     from_profile = None
+            # the whole step against the HBM roofline: SURVEY 8(d)'s B_alg (one render's algorithmic bytes) + the optimizer's
+            # 28 B per parameter element, over the measured step
+            T_ = ((W + 15) // 16) * ((H + 15) // 16)
+            b_alg = P * (1138 + 4 * M + 4 * K) + 116 * R_mean + 44 * W * H + 8 * T_
+            b_adam = 28 * sum(p_.numel() for p_ in model.parameters())
+            ms_step_ = elapsed / args.steps * 1e3
+            whole_step = dict(alg_bytes_render=int(b_alg), alg_bytes_adam=int(b_adam), ms=round(ms_step_, 4),
+                              frac=round((b_alg + b_adam) / (ms_step_ * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                              frac_render_only=round(b_alg / (ms_step_ * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                              note='B_alg of SURVEY 8(d) (+ 28 B per optimizer element) / ms_per_step / 8 TB/s')
             line = {
                 'metric': 'train iters/sec (deform + rasterize fwd+bwd + L1/SSIM loss + Adam; ms/render fwd+bwd beside it), '
                           f'{P // 1000}k Gaussians @{W}x{H}',
@@ -951,10 +885,17 @@ def main():
                            'adam': adam_desc,
                            'step': 'autograd operator path' if args.autograd else 'FusedViewStep (direct C-ABI calls)',
                            'operator_path_backward_thread': args.backward_thread,
-                           'replicas_identical': replicas_identical, 'param_digest': param_digest},
+                           'replicas_identical': replicas_identical, 'param_digest': param_digest,
+                           'cluster': cluster},
                 'roofline': {'bound': 'hbm', 'kernel': 'render_backward', 'achieved': round(achieved, 2),
                              'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 5),
-                             'traffic': None, 'avg_us': round(rb_us, 2), 'launches': rb_n,
+                             # HBM bytes per launch from the PMC counters (2 x FETCH_SIZE + WRITE_SIZE, separate passes): not
+                             # collected in this run -- the figure of the last committed counter profile of this kernel on this
+                             # workload, with the file and commit it comes from (null when there is none for this workload)
+                             'traffic': (from_profile or {}).get('hbm_bytes_per_launch'),
+                             'traffic_source': ({k_: from_profile.get(k_) for k_ in ('file', 'commit')} if from_profile else None),
+                             'whole_step': whole_step,
+                             'avg_us': round(rb_us, 2), 'launches': rb_n,
                              'alg_bytes_per_launch': int(rb_bytes), 'limiter': 'valu',
                              'from_profile': from_profile,
                              'note': 'the dominant kernel is VALU-issue bound, not HBM-bound (SURVEY 8d caveat): the HBM '
@@ -983,7 +924,7 @@ def main():
                                       'before the first event and never re-captured; `value` is end-to-end')
                 line['densify'] = densify_log
             if world == 1 and not args.no_cpu_baseline:
-                line['cpu_baseline'] = cpu_baseline(cfg, args.cpu_seconds, args.cpu_single_thread)
+                line['cpu_baseline'] = cpu_baseline(cfg, args.cpu_seconds, args.cpu_single_thread, configs=CONFIGS)
             return line
         return None
 
@@ -996,9 +937,12 @@ def main():
     import gc
     explicit = (args.pipeline or args.compact_logits or args.sh_factors or args.overlap_gather or args.graph_collectives or args.split_rest
                 or args.exchange != 'auto')
+    # order = the order they are timed in: the predicted-best variant with EAGER collectives first (`factors`
+    # 5.9x, `factors-overlap` 6.0x against 4.7x for the plain all-reduce), so a caller's time limit that cuts the ranking
+    # short still records it; the plain all-reduce second; the captured-collective variants last, each under the watchdog
     variants = {
-        'allreduce': dict(),
         'factors': dict(sh_factors=True, compact_logits=True),
+        'allreduce': dict(),
         'factors-overlap': dict(sh_factors=True, compact_logits=True, overlap_gather=True),
         'pipeline': dict(pipeline=True),
         # the same two exchanges with the collectives captured inside ONE step graph (last: a fabric on which a captured

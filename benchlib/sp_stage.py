@@ -41,6 +41,62 @@ def alg_bytes_sp(name, P, M, K, F, W, H, R, rows_adam_bytes=0):
     }.get(name)
 
 
+def cpu_baseline_sp(cfg, M, K, F, seconds_budget=12.0):
+    """the stage on the host cores: the oracle's search (3 + F dimensions over M superpoints), weighting, skinning and
+    rasterizer forward + backward (OpenMP), and the torch CPU restatement of sp_deform_net forward + backward; bounded sample"""
+    import time as _t
+    import numpy as np
+    from benchlib.cpu_baseline import _cpu_oracle
+    from sk_gs_amd import scene
+    from sk_gs_amd.superpoint import SpDeformNet
+    o, lib = _cpu_oracle()
+    P, W, H = cfg['P'], cfg['W'], cfg['H']
+    g = scene.make_gaussians(P, seed=0)
+    cam = scene.make_camera(W, H, seed=0)
+    rs = scene.raster_settings_from_camera(cam, colmap=True)
+    n = lambda t: t.numpy()  # noqa: E731
+    gen = torch.Generator().manual_seed(5)
+    sp = g['xyz'][torch.randperm(P, generator=gen)[:M]].clone()
+    feat, sfeat = 0.02 * torch.randn(P, F, generator=gen), 0.02 * torch.randn(M, F, generator=gen)
+    pts, sps = np.concatenate([n(g['xyz']), n(feat)], 1), np.concatenate([n(sp), n(sfeat)], 1)
+    radius, kw = np.full(M, 0.26), np.full(M, 0.5)
+    torch.manual_seed(0)
+    net = SpDeformNet()
+    t = torch.tensor([0.3])
+    gcol, gop = torch.randn(3, H, W, generator=gen).numpy(), torch.randn(H, W, generator=gen).numpy()
+
+    def one():
+        out = net.reference_forward(sp, t)
+        q = torch.nn.functional.normalize(out['d_rotation'] + torch.tensor([0, 0, 0, 1.]), dim=-1)
+        spT = torch.cat([out['d_xyz'], q], 1)
+        dist, idx = o.knn_bones(pts, sps, K)
+        w = o.lbs_weights_kernel(dist, idx, radius, kw)
+        d = o.lbs_deform_forward(n(g['xyz']), w, idx, n(spT.detach()), n(q.detach()), n(out['d_scaling'].detach()), n(g['xyz']),
+                                 n(g['log_scale']), n(g['rot']), n(g['opacity_logit']))
+        fwd = o.rasterize_forward(H, W, rs.tanfovx, rs.tanfovy, 3, 1.0, True, n(rs.viewmatrix), n(rs.projmatrix),
+                                  n(rs.campos), d['means'], d['opacity'], n(g['sh']), d['scales'], d['rotations'])
+        gr = o.rasterize_backward(fwd, H, W, rs.tanfovx, rs.tanfovy, 3, 1.0, True, n(rs.viewmatrix), n(rs.projmatrix),
+                                  n(rs.campos), d['means'], n(g['sh']), d['scales'], d['rotations'], gcol, gop)
+        gb = o.lbs_deform_backward(n(g['xyz']), w, idx, n(spT.detach()), n(q.detach()), n(out['d_scaling'].detach()),
+                                   n(g['log_scale']), n(g['rot']), n(g['opacity_logit']), gr['dL_dmeans3D'], gr['dL_dscales'],
+                                   gr['dL_drotations'], gr['dL_dopacity'])
+        (spT * torch.from_numpy(np.asarray(gb['g_bone_T']))).sum().backward()
+        net.zero_grad()
+
+    one()
+    t0, it = _t.perf_counter(), 0
+    while True:
+        one()
+        it += 1
+        if _t.perf_counter() - t0 > seconds_budget or it >= 30:
+            break
+    el = _t.perf_counter() - t0
+    return dict(value=round(it / el, 4), unit='iters/s', cores=o.num_threads(), kind='port',
+                sample=f'{it} iterations of stage sp on the host: sp_deform_net (torch CPU) + the oracle\'s 3+{F}-d search over {M} '
+                       f'superpoints, weighting, skinning, rasterize forward + backward, skinning backward (no loss / Adam), '
+                       f'{el:.1f} s, oracle built {"-march=native" if lib else "portable"}, OpenMP')
+
+
 def run(args, base_alg_bytes, configs):
     """`args`: bench.py's namespace (config, views, steps, warmup, lr, lbs_method ...)"""
     from sk_gs_amd import _C, scene
@@ -176,8 +232,16 @@ def run(args, base_alg_bytes, configs):
             rec['TFLOPs'] = round(fl / (us * 1e-6) / 1e12, 2)
             rec['frac_of_mfma_f32_peak'] = round(fl / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
         kernels[name] = rec
+    from benchlib import launch as _launch
+    cluster = _launch.cluster_info(dist, torch, local_rank)  # (a collective: every rank)
     if rank != 0:
         return None
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline_sp(cfg, M, K, F, min(args.cpu_seconds, 12.0))
+        except Exception as e:  # noqa
+            cpu = dict(error=f'{type(e).__name__}: {e}'[:300])
     rb = kernels.get('render_backward', {})
     rb_us, rb_bytes = rb.get('us', 0.0), base_alg_bytes('render_backward', P, M, K, W, H, R_mean)
     achieved = rb_bytes / (rb_us * 1e-6) / 1e9 if rb_us else 0.0
@@ -204,7 +268,10 @@ def run(args, base_alg_bytes, configs):
                    'tile_lists': f'buckets of {tile_bucket} slots per tile (longest list {longest})',
                    'adam': ('per-Gaussian rows on the idle CUs of the sp net\'s row-block backward launch; network + superpoint '
                             'tables + counter + next view in one closing launch') if train.fused else 'one launch after the all-reduce',
-                   'step': 'FusedSuperpointStep (direct C-ABI calls)'},
+                   'step': 'FusedSuperpointStep (direct C-ABI calls)', 'cluster': cluster,
+                   'gaussian_order': 'as generated (random)' if args.keep_order else
+                   'sorted along a Z-order curve (densify.sort_spatially: what a training loop does after each densification event)'},
+        'cpu_baseline': cpu,
         'roofline': {'bound': 'hbm', 'kernel': 'render_backward', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBPS,
                      'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 5), 'traffic': None, 'avg_us': rb_us,
                      'alg_bytes_per_launch': int(rb_bytes), 'limiter': 'valu',

@@ -98,29 +98,47 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
   int bi[KCAP];
 #pragma unroll
   for (int k = 0; k < KCAP; ++k) bd[k] = __builtin_inff(), bi[k] = 0;
-  for (int j = part; j < M; j += LPG) {  // (the ballots below see the lanes still in the loop: the skips stay wave-uniform)
-    const float4 c0 = *reinterpret_cast<const float4*>(s_c + j * CROW);
-    const float d0 = p0 - c0.x, d1 = p1 - c0.y, d2 = p2 - c0.z;
-    float d = d0 * d0;  // (0 + t = t: the oracle's `d = 0; d += df * df` starts here)
-    d += d1 * d1;
-    d += d2 * d2;
+  // two candidates (j, j + 4) per iteration: both first rows are requested together, ONE wave-wide test skips the pair when
+  // neither xyz part can enter any lane's list (the common case once the lists have filled)
+  auto tail = [&](float d, const float4& c0, int j) {
+    const float4 c1 = *reinterpret_cast<const float4*>(s_c + j * CROW + 4);
+    const float4 c2 = *reinterpret_cast<const float4*>(s_c + j * CROW + 8);
+    const float e3 = f[0] - c0.w, e4 = f[1] - c1.x, e5 = f[2] - c1.y, e6 = f[3] - c1.z, e7 = f[4] - c1.w;
+    const float e8 = f[5] - c2.x, e9 = f[6] - c2.y, e10 = f[7] - c2.z;
+    d += e3 * e3;
+    d += e4 * e4;
+    d += e5 * e5;
+    d += e6 * e6;
+    d += e7 * e7;
+    d += e8 * e8;
+    d += e9 * e9;
+    d += e10 * e10;
+    return d;
+  };
+  const int Mq = (M + LPG - 1) / LPG;  // candidates per lane (the last ones may fall beyond M: masked by `in`)
+  for (int i = 0; i < Mq; i += 2) {
+    const int ja = part + LPG * i, jb = ja + LPG;
+    const bool ina = ja < M, inb = (i + 1 < Mq) && jb < M;
+    const float4 ca = *reinterpret_cast<const float4*>(s_c + (ina ? ja : 0) * CROW);
+    const float4 cb = *reinterpret_cast<const float4*>(s_c + (inb ? jb : 0) * CROW);
+    const float a0 = p0 - ca.x, a1 = p1 - ca.y, a2 = p2 - ca.z;
+    const float b0 = p0 - cb.x, b1 = p1 - cb.y, b2 = p2 - cb.z;
+    float da = a0 * a0;  // (0 + t = t: the oracle's `d = 0; d += df * df` starts here)
+    da += a1 * a1;
+    da += a2 * a2;
+    float db = b0 * b0;
+    db += b1 * b1;
+    db += b2 * b2;
+    da = ina ? da : __builtin_inff();
+    db = inb ? db : __builtin_inff();
+    // exact: the sums only grow, so a pair whose xyz parts already lose cannot enter
+    if (__builtin_amdgcn_ballot_w64((da < bd[KCAP - 1]) | (db < bd[KCAP - 1])) == 0) continue;
     if (F > 0) {
-      if (__builtin_amdgcn_ballot_w64(d < bd[KCAP - 1]) == 0) continue;  // exact: the sum only grows
-      const float4 c1 = *reinterpret_cast<const float4*>(s_c + j * CROW + 4);
-      const float4 c2 = *reinterpret_cast<const float4*>(s_c + j * CROW + 8);
-      const float e3 = f[0] - c0.w, e4 = f[1] - c1.x, e5 = f[2] - c1.y, e6 = f[3] - c1.z, e7 = f[4] - c1.w;
-      const float e8 = f[5] - c2.x, e9 = f[6] - c2.y, e10 = f[7] - c2.z;
-      d += e3 * e3;
-      d += e4 * e4;
-      d += e5 * e5;
-      d += e6 * e6;
-      d += e7 * e7;
-      d += e8 * e8;
-      d += e9 * e9;
-      d += e10 * e10;
+      if (ina) da = tail(da, ca, ja);
+      if (inb) db = tail(db, cb, jb);
     }
-    if (__builtin_amdgcn_ballot_w64(d < bd[KCAP - 1]) == 0) continue;
-    topk_insert_sorted<KCAP>(bd, bi, d, j);
+    if (__builtin_amdgcn_ballot_w64(da < bd[KCAP - 1]) != 0) topk_insert_sorted<KCAP>(bd, bi, da, ja);
+    if (__builtin_amdgcn_ballot_w64(db < bd[KCAP - 1]) != 0) topk_insert_sorted<KCAP>(bd, bi, db, jb);
   }
   // ---- merge the quad's four lists: after xor 1 lanes (0,1) and (2,3) agree, after xor 2 all four
 #pragma unroll

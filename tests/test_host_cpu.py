@@ -286,3 +286,20 @@ def test_every_c_abi_entry_point_is_documented():
     assert len(declared) >= 40
     missing = [name for name in declared if ('`' + name + '`') not in docs]
     assert not missing, missing
+
+
+def test_bench_gpus_flag_without_a_launcher_spawns_or_refuses():
+    """VERDICT r3 #5a: `python bench.py --gpus N` (N > 1) with no launcher in the environment must not silently run ONE rank.
+    benchlib.launch decides before anything touches a GPU: under a launcher (RANK / WORLD_SIZE set) nothing is spawned; without
+    one the ranks are started as a child `torch.distributed.run`; with fewer visible devices than ranks it exits non-zero."""
+    from benchlib import launch
+    assert not launch.needs_spawn(1, {})
+    assert launch.needs_spawn(2, {}) and launch.needs_spawn(8, {'PATH': '/bin'})
+    assert not launch.needs_spawn(8, {'WORLD_SIZE': '8', 'RANK': '3'})
+    # this container has no GPU: asking for 2 ranks is refused with a message, exit code 2, and NO JSON line
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'SKGS_SHARE_GPU')}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    if not torch.cuda.is_available():
+        assert p.returncode == 2 and 'only 0 device(s) visible' in p.stderr and p.stdout.strip() == '', (p.returncode, p.stderr[-500:])
+    assert isinstance(launch.free_port(), int)
