@@ -206,6 +206,7 @@ def run(args, base_alg_bytes, configs):
         elapsed = float(t.item())
     st = step.status()
     assert st['overflow_events'] == 0, 'binning capacity overflow during the timed region: result invalid'
+    assert st['pairs_overflow'] == 0, 'a superpoint\'s inverse neighbour list overflowed: result invalid'
     # ---- per-kernel HIP-event timing: an eager pass over the same steps
     _C.profile_enable(None)
     n_prof = min(args.steps, 20)

@@ -502,14 +502,38 @@ int skgs_deform_mlp_status(const void* workspace, uint32_t* host_words4, skgs_st
  * concatenated rows (bit-identical weights).
  * Backward of the two distance-based weightings: g_weights [P,K] -> g_feature [P,F] (written), g_sp_feature [M,F],
  * g_sp_radius [M], g_sp_weight [M] w.r.t. the raw parameters (written; any may be NULL).  workspace:
- * skgs_sp_lbs_weights_workspace_bytes(P, M, F).  (`W`: skgs_lbs_weights_backward.) */
+ * skgs_sp_lbs_weights_workspace_bytes(P, M, F).  (`W`: skgs_lbs_weights_backward.)
+ * pairs (skgs_sp_pairs_bytes(P, M, K) bytes, may be NULL): the forward also files every (Gaussian, neighbour) pair under its
+ * superpoint -- inverse lists that skgs_sp_skinning_backward walks; the call clears them first.  A superpoint whose list
+ * outgrows its capacity (16 x the mean list, >= 4096 entries) sets the overflow word (byte 4 of the buffer). */
 int skgs_sp_lbs_weights_forward(int32_t P, int32_t M, int32_t K, int32_t F, const float* points, const float* feature,
     const float* sp_points, const float* sp_feature, const float* sp_radius_raw, const float* sp_weight_raw, float temperature,
-    const float* sp_W, int64_t* out_idx, float* out_weights, float* out_dist, skgs_stream_t stream);
+    const float* sp_W, int64_t* out_idx, float* out_weights, float* out_dist, void* pairs /* or NULL */, size_t pairs_bytes,
+    skgs_stream_t stream);
 size_t skgs_sp_lbs_weights_workspace_bytes(int32_t P, int32_t M, int32_t F);
 int skgs_sp_lbs_weights_backward(int32_t P, int32_t M, int32_t K, int32_t F, const float* feature, const float* sp_feature,
     const float* sp_radius_raw, const float* sp_weight_raw, float temperature, const float* weights, const int64_t* indices,
     const float* nn_dist, const float* g_weights, float* g_feature, float* g_sp_feature, float* g_sp_radius, float* g_sp_weight,
+    void* workspace, size_t workspace_bytes, skgs_stream_t stream);
+
+/* ---- skinning + weighting backward of the SUPERPOINT stage in one call, no atomics on the superpoint tables ----
+ * = skgs_lbs_deform_backward + skgs_sp_lbs_weights_backward for M in the hundreds (their LDS float atomics are LDS-bound there:
+ * 58 + 68 us at P = 1e5, M = 512).  Three launches: rows (one lane per Gaussian: its parameter gradients, g_weights, the
+ * weighting's chain rule, hyper_feature.grad, and a compact payload), bones (4 workgroups per superpoint walk the inverse list
+ * the forward filed and tree-reduce the 24 per-superpoint sums), finalize (adds the slices, d exp / d sigmoid of the raw
+ * radius / weight parameters).  `in`: as skgs_lbs_deform_backward (bone_T = spT [M,7], bone_drot = the unit quaternion,
+ * bone_dscale = d_scaling; weights / indices of the forward).  logit_weighting != 0: the `W` weighting (the weights do not
+ * depend on the distances: only g_weights [P,K] leaves, feed it to skgs_lbs_weights_backward); otherwise nn_dist [P,K] and the
+ * weighting's parameters as given to the forward.  Outputs are WRITTEN: g_xyz, g_log_scale, g_rot, g_opacity_logit [P,.],
+ * g_feature [P,F], g_weights [P,K] (may be NULL), g_bone_T [M,7], g_bone_drot [M,4], g_bone_dscale [M,3], g_sp_feature [M,F],
+ * g_sp_radius [M], g_sp_weight [M] (the last four may be NULL).  workspace: skgs_sp_skinning_backward_workspace_bytes. */
+size_t skgs_sp_pairs_bytes(int32_t P, int32_t M, int32_t K);
+size_t skgs_sp_skinning_backward_workspace_bytes(int32_t P, int32_t M, int32_t K);
+int skgs_sp_skinning_backward(const skgs_deform_inputs* in, int32_t F, const float* feature, const float* sp_feature,
+    const float* sp_radius_raw, const float* sp_weight_raw, float temperature, int32_t logit_weighting, const float* nn_dist,
+    const float* g_means, const float* g_scales, const float* g_rotations, const float* g_opacity, float* g_weights, float* g_xyz,
+    float* g_log_scale, float* g_rot, float* g_opacity_logit, float* g_feature, float* g_bone_T, float* g_bone_drot,
+    float* g_bone_dscale, float* g_sp_feature, float* g_sp_radius, float* g_sp_weight, void* pairs, size_t pairs_bytes,
     void* workspace, size_t workspace_bytes, skgs_stream_t stream);
 
 /* ---- the deform network of the SUPERPOINT stage (stage `sp`, networks/sk_gs.py:830-856) ----

@@ -20,7 +20,7 @@ import torch
 from torch import Tensor
 
 # module attributes of SkinnedGaussians with one row per Gaussian (sk_gs_amd.densify.PARAM_NAMES_MAP)
-PER_GAUSSIAN = ('_xyz', '_features_dc', '_features_rest', '_opacity', '_scaling', '_rotation', 'sp_W')
+PER_GAUSSIAN = ('_xyz', '_features_dc', '_features_rest', '_opacity', '_scaling', '_rotation', 'sp_W', 'hyper_feature')
 
 
 def cap_store(p: Tensor) -> Optional[Tensor]:

@@ -1,6 +1,7 @@
 // skgs_common.h -- private layouts and device helpers shared by the gfx950 kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 
 #include "../../include/skgs.h"
@@ -309,6 +310,29 @@ struct ProfScope {
   ProfScope(int k, hipStream_t st) : kid(k), s(st) { prof_begin(kid, s); }
   ~ProfScope() { prof_end(kid, s); }
 };
+
+// ---- inverse neighbour lists of the superpoint stage (sp_knn.hip files them, sp_backward.hip walks them) ------------------
+// [0,256) header {cap, overflow flag}, counts[M] (256-B aligned), lists[M][cap] of pair ids (n << 4 | k).  Capacity per
+// superpoint: 16 x the mean list (P K / M), at least 4096, at most P: a list that outgrows it raises the overflow flag.
+struct SpPairsView {
+  uint32_t* header;  // [0] cap, [1] overflow
+  uint32_t* counts;
+  uint32_t* lists;
+  int cap;
+};
+inline size_t sp_pairs_capacity(int P, int M, int K) {
+  const size_t mean = ((size_t) P * K + M - 1) / M;
+  return std::min<size_t>((size_t) std::max(P, 1), std::max<size_t>(4096, 16 * mean));
+}
+inline SpPairsView sp_pairs_view(void* base, int P, int M, int K) {
+  SpPairsView v;
+  v.header = reinterpret_cast<uint32_t*>(base);
+  v.counts = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + 256);
+  v.lists  = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + 256 + align256((size_t) M * 4));
+  v.cap    = (int) sp_pairs_capacity(P, M, K);
+  return v;
+}
+size_t sp_pairs_bytes(int P, int M, int K);  // sp_backward.hip
 
 // api.hip: p[0..n_words) = v  (kernel, not hipMemsetAsync: keeps captured graphs to kernel nodes only)
 int fill_u32(void* p, uint32_t v, size_t n_words, hipStream_t s);

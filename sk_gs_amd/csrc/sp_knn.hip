@@ -75,8 +75,13 @@ template <int KCAP, int F>
 __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int M, int K, const float* __restrict__ points,
     const float* __restrict__ feature, const float* __restrict__ sp_points, const float* __restrict__ sp_feature,
     const float* __restrict__ radius_raw, const float* __restrict__ kweight_raw, float temperature, const float* __restrict__ sp_W,
-    int64_t* __restrict__ out_idx, float* __restrict__ out_weights, float* __restrict__ out_dist) {
-  extern __shared__ __attribute__((aligned(16))) float s_c[];  // [M][CROW]
+    int64_t* __restrict__ out_idx, float* __restrict__ out_weights, float* __restrict__ out_dist, uint32_t* __restrict__ pair_counts,
+    uint32_t* __restrict__ pair_lists, int pair_cap, uint32_t* __restrict__ pair_header) {
+  extern __shared__ __attribute__((aligned(16))) float s_c[];  // [M][CROW] | pair filing: cnt[M], base[M]
+  uint32_t* s_cnt  = reinterpret_cast<uint32_t*>(s_c + (size_t) M * CROW);
+  uint32_t* s_base = s_cnt + M;
+  if (pair_counts)
+    for (int i = threadIdx.x; i < M; i += SPK_THREADS) s_cnt[i] = 0u;
   for (int i = threadIdx.x; i < M * CROW; i += SPK_THREADS) {
     const int j = i / CROW, c = i - j * CROW;
     float v = 0.f;
@@ -150,55 +155,80 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
 #pragma unroll
     for (int k = 0; k < KCAP; ++k) topk_insert_lex<KCAP>(bd, bi, od[k], oi[k]);
   }
-  if (part != 0) return;
-  if (n >= P) return;
-  // ---- weighting (sk_gs.py:759-770), the arithmetic of deform.hip::knn_dist_weights_kernel / lbs_weights_forward_kernel
-  float v[KCAP];
-  float sum = 0.f;
-  if (sp_W) {  // softmax of the gathered logits
-    float mx = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < KCAP; ++k) {
-      v[k] = k < K ? sp_W[(size_t) n * M + bi[k]] : -INFINITY;
-      mx   = fmaxf(mx, v[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < KCAP; ++k) {
-      v[k] = k < K ? expf(v[k] - mx) : 0.f;
-      sum += v[k];
-    }
-  } else if (radius_raw) {  // exp(-d / (2 r^2)) [* s] + 1e-7, / sum
-#pragma unroll
-    for (int k = 0; k < KCAP; ++k) {
-      v[k] = 0.f;
-      if (k < K) {
-        const float r = act_radius(radius_raw, bi[k]);
-        float e = expf(-bd[k] / (2.f * (r * r)));
-        if (kweight_raw) e = e * act_kweight(kweight_raw, bi[k]);
-        v[k] = e + 1e-7f;
+  const bool owner = part == 0 && n < P;  // one lane per Gaussian holds the merged list from here on
+  uint32_t rank[KCAP];
+  if (owner) {
+    // ---- weighting (sk_gs.py:759-770), the arithmetic of deform.hip::knn_dist_weights_kernel / lbs_weights_forward_kernel
+    float v[KCAP];
+    float sum = 0.f;
+    if (sp_W) {  // softmax of the gathered logits
+      float mx = -INFINITY;
+  #pragma unroll
+      for (int k = 0; k < KCAP; ++k) {
+        v[k] = k < K ? sp_W[(size_t) n * M + bi[k]] : -INFINITY;
+        mx   = fmaxf(mx, v[k]);
+      }
+  #pragma unroll
+      for (int k = 0; k < KCAP; ++k) {
+        v[k] = k < K ? expf(v[k] - mx) : 0.f;
+        sum += v[k];
+      }
+    } else if (radius_raw) {  // exp(-d / (2 r^2)) [* s] + 1e-7, / sum
+  #pragma unroll
+      for (int k = 0; k < KCAP; ++k) {
+        v[k] = 0.f;
+        if (k < K) {
+          const float r = act_radius(radius_raw, bi[k]);
+          float e = expf(-bd[k] / (2.f * (r * r)));
+          if (kweight_raw) e = e * act_kweight(kweight_raw, bi[k]);
+          v[k] = e + 1e-7f;
+          sum += v[k];
+        }
+      }
+    } else {  // softmax(-d / temperature)
+      float mx = -INFINITY;
+  #pragma unroll
+      for (int k = 0; k < KCAP; ++k) {
+        v[k] = k < K ? -bd[k] / temperature : -INFINITY;
+        mx   = fmaxf(mx, v[k]);
+      }
+  #pragma unroll
+      for (int k = 0; k < KCAP; ++k) {
+        v[k] = k < K ? expf(v[k] - mx) : 0.f;
         sum += v[k];
       }
     }
-  } else {  // softmax(-d / temperature)
-    float mx = -INFINITY;
+  #pragma unroll
+    for (int k = 0; k < KCAP; ++k)
+      if (k < K) {
+        out_weights[(size_t) n * K + k] = v[k] / sum;
+        out_idx[(size_t) n * K + k]     = bi[k];
+        if (out_dist) out_dist[(size_t) n * K + k] = bd[k];
+      }
+    if (pair_counts)  // file the K pairs under their superpoints: local rank now, global slots below
 #pragma unroll
-    for (int k = 0; k < KCAP; ++k) {
-      v[k] = k < K ? -bd[k] / temperature : -INFINITY;
-      mx   = fmaxf(mx, v[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < KCAP; ++k) {
-      v[k] = k < K ? expf(v[k] - mx) : 0.f;
-      sum += v[k];
-    }
+      for (int k = 0; k < KCAP; ++k)
+        if (k < K) rank[k] = atomicAdd(&s_cnt[bi[k]], 1u);
   }
+  if (!pair_counts) return;
+  // ---- inverse lists (sp_backward.hip walks them): ONE global atomic per superpoint this workgroup touched reserves its slots
+  __syncthreads();
+  for (int j = threadIdx.x; j < M; j += SPK_THREADS) {
+    const uint32_t c = s_cnt[j];
+    s_base[j] = c ? atomicAdd(&pair_counts[j], c) : 0u;
+  }
+  __syncthreads();
+  if (owner) {
 #pragma unroll
-  for (int k = 0; k < KCAP; ++k)
-    if (k < K) {
-      out_weights[(size_t) n * K + k] = v[k] / sum;
-      out_idx[(size_t) n * K + k]     = bi[k];
-      if (out_dist) out_dist[(size_t) n * K + k] = bd[k];
-    }
+    for (int k = 0; k < KCAP; ++k)
+      if (k < K) {
+        const uint32_t slot = s_base[bi[k]] + rank[k];
+        if (slot < (uint32_t) pair_cap)
+          pair_lists[(size_t) bi[k] * pair_cap + slot] = ((uint32_t) n << 4) | (uint32_t) k;
+        else
+          pair_header[1] = 1u;  // overflow: a superpoint with more than cap Gaussians (skgs_sp_pairs_bytes)
+      }
+  }
 }
 
 // ---- backward of the distance-based weightings -----------------------------------------------------------------------------
@@ -319,22 +349,28 @@ size_t skgs_sp_lbs_weights_workspace_bytes(int32_t P, int32_t M, int32_t F) {
 
 int skgs_sp_lbs_weights_forward(int32_t P, int32_t M, int32_t K, int32_t F, const float* points, const float* feature,
     const float* sp_points, const float* sp_feature, const float* sp_radius_raw, const float* sp_weight_raw, float temperature,
-    const float* sp_W, int64_t* out_idx, float* out_weights, float* out_dist, skgs_stream_t stream) {
+    const float* sp_W, int64_t* out_idx, float* out_weights, float* out_dist, void* pairs, size_t pairs_bytes, skgs_stream_t stream) {
   SKGS_REQUIRE(P >= 0 && M >= 1 && K >= 1 && K <= 16 && K <= M, "sp_lbs_weights_forward: need P >= 0, 1 <= K <= min(16, M)");
+  SKGS_REQUIRE(!pairs || pairs_bytes >= sp_pairs_bytes(P > 0 ? P : 1, M, K), "sp_lbs_weights_forward: pair-list buffer too small (skgs_sp_pairs_bytes)");
   SKGS_REQUIRE(F == 0 || F == 8, "sp_lbs_weights_forward: F (hyper dimensions) must be 0 or 8");
   if (P == 0) return 0;
   SKGS_REQUIRE(points && sp_points && out_idx && out_weights && (F == 0 || (feature && sp_feature)),
       "sp_lbs_weights_forward: NULL argument");
   SKGS_REQUIRE(!(sp_weight_raw && !sp_radius_raw), "sp_lbs_weights_forward: a kernel weight needs a kernel radius");
-  const size_t lds = (size_t) M * CROW * 4;
-  SKGS_REQUIRE(lds <= 64 * 1024, "sp_lbs_weights_forward: too many superpoints for the LDS table (<= 1365)");
+  const size_t lds = (size_t) M * CROW * 4 + (pairs ? (size_t) M * 8 : 0);
+  SKGS_REQUIRE(lds <= 64 * 1024, "sp_lbs_weights_forward: too many superpoints for the LDS table (<= 1170)");
   hipStream_t s = (hipStream_t) stream;
+  SpPairsView pv{};
+  if (pairs) {  // the lists start empty: whatever an earlier forward filed (with or without a backward) is dropped
+    pv = sp_pairs_view(pairs, P, M, K);
+    if (fill_u32(pv.header, 0u, 64 + ((size_t) M + 63) / 64 * 64, s)) return 1;  // header + counts (contiguous: counts start at byte 256)
+  }
   ProfScope prof(K_SP_KNN, s);
   const int per_wg = SPK_THREADS / LPG;  // four lanes per Gaussian
   const dim3 grid((P + per_wg - 1) / per_wg), block(SPK_THREADS);
 #define SKGS_SPK(KCAP_, F_)                                                                                              \
   hipLaunchKernelGGL((sp_knn_weights_kernel<KCAP_, F_>), grid, block, lds, s, P, M, K, points, feature, sp_points, sp_feature, \
-      sp_radius_raw, sp_weight_raw, temperature, sp_W, out_idx, out_weights, out_dist)
+      sp_radius_raw, sp_weight_raw, temperature, sp_W, out_idx, out_weights, out_dist, pv.counts, pv.lists, pv.cap, pv.header)
   if (F == 8) {
     if (K <= 5) SKGS_SPK(5, 8); else if (K <= 8) SKGS_SPK(8, 8); else SKGS_SPK(16, 8);
   } else {

@@ -363,6 +363,12 @@ class FusedSuperpointStep(FusedViewStep):
         lib.skgs_sp_lbs_weights_workspace_bytes.restype = C.c_size_t
         self.spw_ws = torch.empty((max(int(lib.skgs_sp_lbs_weights_workspace_bytes(C.c_int32(P), C.c_int32(M), C.c_int32(self.F))),
                                        16),), dtype=torch.uint8, device=dev)
+        # inverse neighbour lists (filed by the search, walked by the backward) and the backward's payload / partial buffers
+        for fn in (lib.skgs_sp_pairs_bytes, lib.skgs_sp_skinning_backward_workspace_bytes):
+            fn.restype = C.c_size_t
+        self.pairs = torch.zeros((int(lib.skgs_sp_pairs_bytes(C.c_int32(P), C.c_int32(M), C.c_int32(K))),), dtype=torch.uint8, device=dev)
+        self.sb_ws = torch.empty((int(lib.skgs_sp_skinning_backward_workspace_bytes(C.c_int32(P), C.c_int32(M), C.c_int32(K))),),
+                                 dtype=torch.uint8, device=dev)
         self.g_d_rot = torch.empty((M, 4), dtype=torch.float32, device=dev)
         self.g_d_scale = torch.empty((M, 3), dtype=torch.float32, device=dev)
         self.view_table = view_table
@@ -404,7 +410,7 @@ class FusedSuperpointStep(FusedViewStep):
         chk(lib.skgs_sp_lbs_weights_forward(
             C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(self.F), _p(m._xyz), _p(m.hyper_feature), _p(m.sp_points),
             _p(m.sp_hyper_feature), _p(m._sp_radius), _p(m._sp_weight), C.c_float(m.lbs_temperature), _p(m.sp_W),
-            _p(self.indices), _p(self.weights), _p(self.nn_dist), st))
+            _p(self.indices), _p(self.weights), _p(self.nn_dist), _p(self.pairs), C.c_size_t(self.pairs.numel()), st))
         d = self._deform_inputs(time_id)
         chk(lib.skgs_lbs_deform_forward(C.byref(d), _p(self.means), _p(self.scales), _p(self.rotations), _p(self.opacity),
                                         None, None, None, st))
@@ -419,28 +425,29 @@ class FusedSuperpointStep(FusedViewStep):
         lib, m, st, chk = self.lib, self.model, _C._stream(), _C._check
         P, M, K = self.P, self.M, self.K
         d = self._deform_inputs(time_id)
-        chk(lib.skgs_lbs_deform_backward(
-            C.byref(d), _p(self.g_means), _p(self.g_scales), _p(self.g_rotations), _p(self.g_opacity),
-            _p(self.g_weights), _p(self.g_bone_T), _p(self.g_d_rot), _p(self.g_d_scale),
-            _p(m._xyz.grad), _p(m._scaling.grad), _p(m._rotation.grad), _p(m._opacity.grad), _p(self.deform_ws),
-            C.c_size_t(self.deform_ws.numel()), st))
-        if m.sp_W is not None:  # `W`: the dense [P,M] logit gradient (what autograd's gather backward builds)
+        g = lambda t: None if t is None else _p(t.grad)  # noqa: E731
+        logits = m.sp_W is not None
+        # skinning + weighting backward: rows | bones (the inverse lists of the forward) | finalize -- no atomics
+        chk(lib.skgs_sp_skinning_backward(
+            C.byref(d), C.c_int32(self.F), _p(m.hyper_feature), _p(m.sp_hyper_feature), _p(m._sp_radius), _p(m._sp_weight),
+            C.c_float(m.lbs_temperature), C.c_int32(1 if logits else 0), _p(self.nn_dist), _p(self.g_means), _p(self.g_scales),
+            _p(self.g_rotations), _p(self.g_opacity), _p(self.g_weights) if logits else None, _p(m._xyz.grad), _p(m._scaling.grad),
+            _p(m._rotation.grad), _p(m._opacity.grad), None if logits else g(m.hyper_feature), _p(self.g_bone_T), _p(self.g_d_rot),
+            _p(self.g_d_scale), None if logits else g(m.sp_hyper_feature), g(m._sp_radius), g(m._sp_weight), _p(self.pairs),
+            C.c_size_t(self.pairs.numel()), _p(self.sb_ws), C.c_size_t(self.sb_ws.numel()), st))
+        if logits:  # `W`: the dense [P,M] logit gradient (what autograd's gather backward builds)
             chk(lib.skgs_lbs_weights_backward(C.c_int32(P), C.c_int32(M), C.c_int32(K), _p(self.weights), _p(self.indices),
                                               _p(self.g_weights), _p(m.sp_W.grad), st))
-        else:
-            g = lambda t: None if t is None else _p(t.grad)  # noqa: E731
-            chk(lib.skgs_sp_lbs_weights_backward(
-                C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(self.F), _p(m.hyper_feature), _p(m.sp_hyper_feature),
-                _p(m._sp_radius), _p(m._sp_weight), C.c_float(m.lbs_temperature), _p(self.weights), _p(self.indices),
-                _p(self.nn_dist), _p(self.g_weights), g(m.hyper_feature), g(m.sp_hyper_feature), g(m._sp_radius),
-                g(m._sp_weight), _p(self.spw_ws), C.c_size_t(self.spw_ws.numel()), st))
         side = None
         if self.side_optimizer is not None:  # the per-Gaussian rows' Adam update on the CUs the row-block launch leaves idle
             side = self.side_optimizer[0].side_range(*self.side_optimizer[1:])
         self.net.backward(self.g_bone_T, self.g_d_rot, self.g_d_scale, side_adam=side)
 
     def status(self) -> dict:
-        return _C.read_status(self.geom)
+        """(synchronising) the rasterizer's status words + ``pairs_overflow``: a superpoint's inverse list outgrew its capacity"""
+        st = _C.read_status(self.geom)
+        st['pairs_overflow'] = int(self.pairs[:8].view(torch.int32)[1])
+        return st
 
 
 class FusedSuperpointTrainStep:

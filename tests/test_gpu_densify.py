@@ -88,7 +88,7 @@ def test_densify_and_prune_keep_model_optimizer_and_step_consistent():
     densify.densify(model, opt, stats, max_grad=2e-4, extent=extent, generator=gen)
     # clone adds n_small; split (on the grown set, gradients zero-padded) adds 2 * n_big and removes n_big
     assert model.P == P + n_small + n_big
-    for attr, name in densify.PARAM_NAMES_MAP.items():
+    for attr, name in densify._names(model).items():  # (the per-Gaussian tensors this model has: no hyper features in stage sk)
         p = getattr(model, attr)
         assert p.shape[0] == model.P and isinstance(p, torch.nn.Parameter)
         st = opt.state[p]

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
+import torch.nn.functional as F_
 
 from helpers import rel_err, to_np
 
@@ -142,7 +143,7 @@ def _sp_forward(P, M, K, F, pts, sp, feat, sfeat, radius_raw=None, kweight_raw=N
     p = lambda t: C.c_void_p(None if t is None else t.data_ptr())  # noqa: E731
     _C._check(lib.skgs_sp_lbs_weights_forward(C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(F), p(pts), p(feat), p(sp),
                                               p(sfeat), p(radius_raw), p(kweight_raw), C.c_float(T), p(sp_W), p(idx), p(w), p(d),
-                                              _C._stream()))
+                                              None, C.c_size_t(0), _C._stream()))
     return idx, w, d
 
 
@@ -325,3 +326,91 @@ def test_superpoint_train_step_graph_replay_equals_eager_steps():
             scale = float(pb[n].abs().max().clamp_min(1e-30))
             off = ((pa[n] - pb[n]).abs() > 2e-5 * scale).float().mean()
             assert float(off) <= 5e-3, (n, float(off))
+
+
+@pytest.mark.parametrize('P,M,K,F,method', [(100_000, 512, 5, 8, 'weighted_kernel'), (20_000, 512, 5, 8, 'dist'),
+                                            (20_000, 512, 5, 8, 'W'), (3_000, 100, 7, 0, 'kernel'), (257, 9, 3, 8, 'weighted_kernel')])
+def test_sp_skinning_backward_by_inverse_lists_matches_the_two_call_sequence_and_the_oracle(oracle32, P, M, K, F, method):
+    """skgs_sp_skinning_backward (rows | bones over the inverse neighbour lists | finalize: no atomics) against the sequence it
+    replaces (skgs_lbs_deform_backward + skgs_sp_lbs_weights_backward, LDS atomics) on every output, and its skinning part
+    against the oracle (lbs_deform_backward) at P = 100k, M = 512"""
+    import ctypes as C
+    from sk_gs_amd import _C, scene
+    lib = _C.load_library()
+    dev = 'cuda'
+    pts, sp, feat, sfeat, radius_raw, kweight_raw = _sp_scene(P, M, P + 3 * M, F)
+    gs = scene.make_gaussians(P, seed=2)
+    gen = torch.Generator().manual_seed(P + 1)
+    spT = torch.cat([0.05 * torch.randn(M, 3, generator=gen),
+                     F_.normalize(0.2 * torch.randn(M, 4, generator=gen) + torch.tensor([0, 0, 0, 1.]), dim=-1)], 1)
+    d_rot, d_scale = spT[:, 3:].clone(), 0.01 * torch.randn(M, 3, generator=gen)
+    cu = lambda t: None if t is None else t.to(dev).contiguous()  # noqa: E731
+    d_pts, d_sp, d_feat, d_sfeat = cu(pts), cu(sp), cu(feat), cu(sfeat)
+    rr = cu(radius_raw) if method in ('weighted_kernel', 'kernel') else None
+    kk = cu(kweight_raw) if method == 'weighted_kernel' else None
+    sp_W = torch.randn(P, M, generator=gen).to(dev) if method == 'W' else None
+    T = 0.07
+    p = lambda t: C.c_void_p(None if t is None else t.data_ptr())  # noqa: E731
+    for fn in (lib.skgs_sp_pairs_bytes, lib.skgs_sp_skinning_backward_workspace_bytes, lib.skgs_sp_lbs_weights_workspace_bytes,
+               lib.skgs_lbs_deform_backward_workspace_bytes):
+        fn.restype = C.c_size_t
+    pairs = torch.zeros((int(lib.skgs_sp_pairs_bytes(C.c_int32(P), C.c_int32(M), C.c_int32(K))),), dtype=torch.uint8, device=dev)
+    idx = torch.empty((P, K), dtype=torch.int64, device=dev)
+    w, dist = torch.empty((P, K), device=dev), torch.empty((P, K), device=dev)
+    for rep in range(2):  # (twice: the forward clears the lists it filed before)
+        _C._check(lib.skgs_sp_lbs_weights_forward(C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(F), p(d_pts), p(d_feat), p(d_sp),
+                                                  p(d_sfeat), p(rr), p(kk), C.c_float(T), p(sp_W), p(idx), p(w), p(dist), p(pairs),
+                                                  C.c_size_t(pairs.numel()), _C._stream()))
+    torch.cuda.synchronize()
+    hdr = pairs[:8].view(torch.int32)
+    counts = pairs[256:256 + 4 * M].view(torch.int32)
+    assert int(hdr[1]) == 0 and int(counts.sum()) == P * K
+    assert torch.equal(counts.long(), torch.bincount(idx.view(-1), minlength=M))
+    xyz, ls, rot, op = cu(gs['xyz']), cu(gs['log_scale']), cu(gs['rot']), cu(gs['opacity_logit'])
+    d = _C._DeformInputs()
+    d.P, d.K, d.M = P, K, M
+    d.points = d.xyz = d_pts.data_ptr()
+    c_T, c_rot, c_scale = cu(spT), cu(d_rot), cu(d_scale)
+    d.weights, d.indices, d.bone_T, d.bone_drot, d.bone_dscale = w.data_ptr(), idx.data_ptr(), c_T.data_ptr(), c_rot.data_ptr(), c_scale.data_ptr()
+    d.log_scale, d.rot, d.opacity_logit = ls.data_ptr(), rot.data_ptr(), op.data_ptr()
+    g_means, g_scales = torch.randn(P, 3, generator=gen).to(dev), torch.randn(P, 3, generator=gen).to(dev)
+    g_rots, g_op = torch.randn(P, 4, generator=gen).to(dev), torch.randn(P, 1, generator=gen).to(dev)
+    nan = lambda *s_: torch.full(s_, float('nan'), device=dev)  # noqa: E731
+
+    def outs():
+        return dict(g_w=nan(P, K), g_xyz=nan(P, 3), g_ls=nan(P, 3), g_rot=nan(P, 4), g_op=nan(P, 1), g_feat=nan(P, max(F, 1)),
+                    g_T=nan(M, 7), g_dr=nan(M, 4), g_ds=nan(M, 3), g_sf=nan(M, max(F, 1)), g_r=nan(M), g_k=nan(M))
+    a, b = outs(), outs()
+    ws = torch.empty((int(lib.skgs_sp_skinning_backward_workspace_bytes(C.c_int32(P), C.c_int32(M), C.c_int32(K))),), dtype=torch.uint8, device=dev)
+    logits = method == 'W'
+    _C._check(lib.skgs_sp_skinning_backward(
+        C.byref(d), C.c_int32(F), p(d_feat), p(d_sfeat), p(rr), p(kk), C.c_float(T), C.c_int32(int(logits)), p(dist), p(g_means),
+        p(g_scales), p(g_rots), p(g_op), p(a['g_w']), p(a['g_xyz']), p(a['g_ls']), p(a['g_rot']), p(a['g_op']),
+        p(a['g_feat']) if F and not logits else None, p(a['g_T']), p(a['g_dr']), p(a['g_ds']), p(a['g_sf']) if F and not logits else None,
+        p(a['g_r']) if rr is not None else None, p(a['g_k']) if kk is not None else None, p(pairs), C.c_size_t(pairs.numel()), p(ws),
+        C.c_size_t(ws.numel()), _C._stream()))
+    # ---- the two-call sequence it replaces
+    dws = torch.empty((int(lib.skgs_lbs_deform_backward_workspace_bytes(C.c_int32(P), C.c_int32(M))),), dtype=torch.uint8, device=dev)
+    _C._check(lib.skgs_lbs_deform_backward(C.byref(d), p(g_means), p(g_scales), p(g_rots), p(g_op), p(b['g_w']), p(b['g_T']), p(b['g_dr']),
+                                           p(b['g_ds']), p(b['g_xyz']), p(b['g_ls']), p(b['g_rot']), p(b['g_op']), p(dws),
+                                           C.c_size_t(dws.numel()), _C._stream()))
+    names = ['g_w', 'g_xyz', 'g_ls', 'g_rot', 'g_op', 'g_T', 'g_dr', 'g_ds']
+    if not logits:
+        sws = torch.empty((int(lib.skgs_sp_lbs_weights_workspace_bytes(C.c_int32(P), C.c_int32(M), C.c_int32(F))) + 16,), dtype=torch.uint8, device=dev)
+        _C._check(lib.skgs_sp_lbs_weights_backward(
+            C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(F), p(d_feat), p(d_sfeat), p(rr), p(kk), C.c_float(T), p(w), p(idx),
+            p(dist), p(b['g_w']), p(b['g_feat']) if F else None, p(b['g_sf']) if F else None, p(b['g_r']), p(b['g_k']), p(sws),
+            C.c_size_t(sws.numel()), _C._stream()))
+        names += (['g_feat', 'g_sf'] if F else []) + (['g_r'] if rr is not None else []) + (['g_k'] if kk is not None else [])
+    torch.cuda.synchronize()
+    for nme in names:
+        assert torch.isfinite(a[nme]).all(), nme
+        assert rel_err(a[nme], b[nme]) <= 2e-5, (nme, rel_err(a[nme], b[nme]))
+    # the skinning part against the oracle
+    want = oracle32.lbs_deform_backward(to_np(pts), to_np(w), to_np(idx), to_np(spT), to_np(d_rot), to_np(d_scale), to_np(gs['log_scale']),
+                                        to_np(gs['rot']), to_np(gs['opacity_logit']), to_np(g_means), to_np(g_scales), to_np(g_rots),
+                                        to_np(g_op))
+    for nme, key in (('g_w', 'g_weights'), ('g_T', 'g_bone_T'), ('g_dr', 'g_bone_drot'), ('g_ds', 'g_bone_dscale'), ('g_xyz', 'g_xyz'),
+                     ('g_rot', 'g_rot')):
+        assert rel_err(a[nme], want[key]) <= 1e-4, (nme, rel_err(a[nme], want[key]))
+    assert int(counts.sum()) == 0  # consumed: the finalize launch cleared the lists
