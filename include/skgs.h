@@ -503,13 +503,19 @@ int skgs_deform_mlp_status(const void* workspace, uint32_t* host_words4, skgs_st
  * Backward of the two distance-based weightings: g_weights [P,K] -> g_feature [P,F] (written), g_sp_feature [M,F],
  * g_sp_radius [M], g_sp_weight [M] w.r.t. the raw parameters (written; any may be NULL).  workspace:
  * skgs_sp_lbs_weights_workspace_bytes(P, M, F).  (`W`: skgs_lbs_weights_backward.)
+ * sp_order (may be NULL): a permutation of 0..M-1, the order the superpoints are SCANNED in.  It cannot change the result (the
+ * list is kept by (distance, id)); a spatial order (Z-order of sp_points) makes the candidates a wave looks at together
+ * neighbours, so its wave-wide early-outs skip most of them.  sp_rank (may be NULL; with sp_order): its inverse, rank[id] = the
+ * scan position of superpoint id.  With it every wave starts its scan at the superpoint that was nearest to its first Gaussian
+ * in the PREVIOUS call with the same out_idx buffer (read before it is overwritten; any content is a valid hint) and walks
+ * outwards: the lists fill with near neighbours first and the rest of the scan is skipped wave-wide.
  * pairs (skgs_sp_pairs_bytes(P, M, K) bytes, may be NULL): the forward also files every (Gaussian, neighbour) pair under its
  * superpoint -- inverse lists that skgs_sp_skinning_backward walks; the call clears them first.  A superpoint whose list
  * outgrows its capacity (16 x the mean list, >= 4096 entries) sets the overflow word (byte 4 of the buffer). */
 int skgs_sp_lbs_weights_forward(int32_t P, int32_t M, int32_t K, int32_t F, const float* points, const float* feature,
     const float* sp_points, const float* sp_feature, const float* sp_radius_raw, const float* sp_weight_raw, float temperature,
-    const float* sp_W, int64_t* out_idx, float* out_weights, float* out_dist, void* pairs /* or NULL */, size_t pairs_bytes,
-    skgs_stream_t stream);
+    const float* sp_W, const int32_t* sp_order /* or NULL */, const int32_t* sp_rank /* or NULL */, int64_t* out_idx,
+    float* out_weights, float* out_dist, void* pairs /* or NULL */, size_t pairs_bytes, skgs_stream_t stream);
 size_t skgs_sp_lbs_weights_workspace_bytes(int32_t P, int32_t M, int32_t F);
 int skgs_sp_lbs_weights_backward(int32_t P, int32_t M, int32_t K, int32_t F, const float* feature, const float* sp_feature,
     const float* sp_radius_raw, const float* sp_weight_raw, float temperature, const float* weights, const int64_t* indices,

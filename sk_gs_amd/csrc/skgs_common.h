@@ -318,6 +318,7 @@ struct SpPairsView {
   uint32_t* header;  // [0] cap, [1] overflow
   uint32_t* counts;
   uint32_t* lists;
+  float* table;      // [M][12]: the superpoints as the search's LDS rows (xyz | 8 hyper | id), in scan order
   int cap;
 };
 inline size_t sp_pairs_capacity(int P, int M, int K) {
@@ -330,6 +331,7 @@ inline SpPairsView sp_pairs_view(void* base, int P, int M, int K) {
   v.counts = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + 256);
   v.lists  = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + 256 + align256((size_t) M * 4));
   v.cap    = (int) sp_pairs_capacity(P, M, K);
+  v.table  = reinterpret_cast<float*>(v.lists + (size_t) M * v.cap);
   return v;
 }
 size_t sp_pairs_bytes(int P, int M, int K);  // sp_backward.hip

@@ -301,10 +301,10 @@ __global__ void __launch_bounds__(256) sp_backward_finalize_kernel(int M, int F,
 
 }  // namespace
 
-// the inverse lists: [0,256) header {cap, overflow}, counts[M] (256-B aligned), lists[M][cap]
+// the inverse lists: [0,256) header {cap, overflow}, counts[M] (256-B aligned), lists[M][cap], the search's packed table [M][12]
 size_t sp_pairs_bytes(int P, int M, int K) {
   const size_t cap = sp_pairs_capacity(P, M, K);
-  return 256 + align256((size_t) M * 4) + (size_t) M * cap * 4;
+  return 256 + align256((size_t) M * 4) + (size_t) M * cap * 4 + align256((size_t) M * 48);
 }
 
 }  // namespace skgs

@@ -66,6 +66,27 @@ __device__ __forceinline__ void topk_insert_lex(float (&bd)[KCAP], int (&bi)[KCA
   bd[0] = lt[0] ? d : bd[0];
 }
 
+// One small launch in front of the search (when the caller gave the pair buffer): the list header and counters are cleared and
+// the superpoint table is packed ONCE -- rows [xyz | hyper | id] in scan order -- so that each of the search's ~1500 workgroups
+// fills its LDS copy with six coalesced 16-byte loads per thread instead of 24 dependent gathers (order -> position / feature).
+__global__ void __launch_bounds__(256) sp_prepare_kernel(int M, int F, const float* __restrict__ sp_points,
+    const float* __restrict__ sp_feature, const int32_t* __restrict__ sp_order, uint32_t* __restrict__ header_and_counts,
+    int n_clear, float* __restrict__ table) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_clear) header_and_counts[i] = 0u;
+  if (i >= M * CROW) return;
+  const int r = i / CROW, c = i - r * CROW;
+  const int j = sp_order ? sp_order[r] : r;
+  float v = 0.f;
+  if (c < 3)
+    v = sp_points[3 * j + c];
+  else if (c < 3 + F)
+    v = sp_feature[(size_t) j * F + c - 3];
+  else if (c == CROW - 1)
+    v = __builtin_bit_cast(float, j);
+  table[i] = v;
+}
+
 // F = number of hyper dimensions (0 or 8).  FOUR lanes per Gaussian: lane `part` scans the superpoints j = part (mod 4) --
 // a quad reads four consecutive 48-byte table rows, conflict-free -- and the four sorted lists are merged by (distance, id)
 // over two quad shuffles.  One lane per Gaussian left the chip with 1.5 waves per SIMD on a chain of dependent LDS reads
@@ -76,19 +97,29 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
     const float* __restrict__ feature, const float* __restrict__ sp_points, const float* __restrict__ sp_feature,
     const float* __restrict__ radius_raw, const float* __restrict__ kweight_raw, float temperature, const float* __restrict__ sp_W,
     int64_t* __restrict__ out_idx, float* __restrict__ out_weights, float* __restrict__ out_dist, uint32_t* __restrict__ pair_counts,
-    uint32_t* __restrict__ pair_lists, int pair_cap, uint32_t* __restrict__ pair_header) {
+    uint32_t* __restrict__ pair_lists, int pair_cap, uint32_t* __restrict__ pair_header, const int32_t* __restrict__ sp_order,
+    const int32_t* __restrict__ sp_rank, const float* __restrict__ packed) {
   extern __shared__ __attribute__((aligned(16))) float s_c[];  // [M][CROW] | pair filing: cnt[M], base[M]
   uint32_t* s_cnt  = reinterpret_cast<uint32_t*>(s_c + (size_t) M * CROW);
   uint32_t* s_base = s_cnt + M;
   if (pair_counts)
     for (int i = threadIdx.x; i < M; i += SPK_THREADS) s_cnt[i] = 0u;
+  // table row r = superpoint sp_order[r] (any permutation: the list is kept by (distance, id), so the scan order cannot change
+  // the result); its id rides in the row's last word.  A spatial order makes the 8 candidates of a wave iteration neighbours.
+  if (packed) {  // (sp_prepare_kernel built the rows)
+    for (int i = threadIdx.x; i < M * CROW / 4; i += SPK_THREADS)
+      reinterpret_cast<float4*>(s_c)[i] = reinterpret_cast<const float4*>(packed)[i];
+  } else
   for (int i = threadIdx.x; i < M * CROW; i += SPK_THREADS) {
-    const int j = i / CROW, c = i - j * CROW;
+    const int r = i / CROW, c = i - r * CROW;
+    const int j = sp_order ? sp_order[r] : r;
     float v = 0.f;
     if (c < 3)
       v = sp_points[3 * j + c];
     else if (c < 3 + F)
       v = sp_feature[(size_t) j * F + c - 3];
+    else if (c == CROW - 1)
+      v = __builtin_bit_cast(float, j);
     s_c[i] = v;
   }
   __syncthreads();
@@ -102,7 +133,7 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
   float bd[KCAP];
   int bi[KCAP];
 #pragma unroll
-  for (int k = 0; k < KCAP; ++k) bd[k] = __builtin_inff(), bi[k] = 0;
+  for (int k = 0; k < KCAP; ++k) bd[k] = __builtin_inff(), bi[k] = 0x7fffffff;  // (loses every (distance, id) comparison)
   // two candidates (j, j + 4) per iteration: both first rows are requested together, ONE wave-wide test skips the pair when
   // neither xyz part can enter any lane's list (the common case once the lists have filled)
   auto tail = [&](float d, const float4& c0, int j) {
@@ -120,12 +151,37 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
     d += e10 * e10;
     return d;
   };
+  // Where to start: a scan that walks a spatial order from its beginning APPROACHES the Gaussians -- every candidate beats the
+  // last one and is inserted.  With `sp_rank` (the inverse of sp_order) the wave starts at the table row of the superpoint that
+  // was nearest to its first Gaussian in the PREVIOUS call (out_idx still holds it; any value is a valid hint -- the result does
+  // not depend on the order) and walks outwards, row s0, s0 + 1, s0 - 1, s0 + 2 ...: the lists fill with near neighbours in the
+  // first iterations and the wave-wide tests skip the rest.
+  int s0 = 0;
+  if (sp_rank) {
+    const uint32_t prev = (uint32_t) out_idx[(size_t) nn * K];
+    s0 = __builtin_amdgcn_readfirstlane(sp_rank[prev % (uint32_t) M]);
+  }
+  // scan position pos -> table row: alternately right and left of s0 (pos even: s0 + pos / 2, odd: s0 - (pos + 1) / 2).  Lane
+  // `part` takes positions part + 8 t and part + 4 + 8 t: both on its own side of s0, 4 t and 4 t + 2 rows out.
+  const int dir  = (part & 1) ? -1 : 1;
+  const int base = (part & 1) ? -((part + 1) >> 1) : (part >> 1);
+  auto wrap = [&](int r) {  // into [0, M): r is at most M away
+    r += r < 0 ? M : 0;
+    r -= r >= M ? M : 0;
+    return r;
+  };
+  // `wq`: the tightest bound any lane of the quad has on the Gaussian's K-th distance -- a part whose own list is still loose
+  // (it has seen a quarter of the candidates) prunes with its partners' (the merged top-K can only be tighter than each part's)
+  float wq = __builtin_inff();
   const int Mq = (M + LPG - 1) / LPG;  // candidates per lane (the last ones may fall beyond M: masked by `in`)
+  const int full = (M / (2 * LPG)) * 2;  // iterations-of-one (i) that need no bounds check: i + 1 < full
   for (int i = 0; i < Mq; i += 2) {
-    const int ja = part + LPG * i, jb = ja + LPG;
-    const bool ina = ja < M, inb = (i + 1 < Mq) && jb < M;
-    const float4 ca = *reinterpret_cast<const float4*>(s_c + (ina ? ja : 0) * CROW);
-    const float4 cb = *reinterpret_cast<const float4*>(s_c + (inb ? jb : 0) * CROW);
+    const bool checked = i + 1 >= full;
+    const int pa = part + LPG * i, pb = pa + LPG;
+    const bool ina = !checked || pa < M, inb = !checked || ((i + 1 < Mq) && pb < M);
+    const int ja = wrap(s0 + base + dir * (2 * i)), jb = wrap(s0 + base + dir * (2 * i + 2));
+    const float4 ca = *reinterpret_cast<const float4*>(s_c + ja * CROW);
+    const float4 cb = *reinterpret_cast<const float4*>(s_c + jb * CROW);
     const float a0 = p0 - ca.x, a1 = p1 - ca.y, a2 = p2 - ca.z;
     const float b0 = p0 - cb.x, b1 = p1 - cb.y, b2 = p2 - cb.z;
     float da = a0 * a0;  // (0 + t = t: the oracle's `d = 0; d += df * df` starts here)
@@ -134,16 +190,31 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
     float db = b0 * b0;
     db += b1 * b1;
     db += b2 * b2;
-    da = ina ? da : __builtin_inff();
-    db = inb ? db : __builtin_inff();
-    // exact: the sums only grow, so a pair whose xyz parts already lose cannot enter
-    if (__builtin_amdgcn_ballot_w64((da < bd[KCAP - 1]) | (db < bd[KCAP - 1])) == 0) continue;
+    if (checked) {
+      da = ina ? da : __builtin_inff();
+      db = inb ? db : __builtin_inff();
+    }
+    // exact: the sums only grow, so a pair whose xyz parts already lose cannot enter ("<=": an equal distance with a lower id
+    // still displaces the list's last entry)
+    if (__builtin_amdgcn_ballot_w64((da <= wq) | (db <= wq)) == 0) continue;
     if (F > 0) {
       if (ina) da = tail(da, ca, ja);
       if (inb) db = tail(db, cb, jb);
     }
-    if (__builtin_amdgcn_ballot_w64(da < bd[KCAP - 1]) != 0) topk_insert_sorted<KCAP>(bd, bi, da, ja);
-    if (__builtin_amdgcn_ballot_w64(db < bd[KCAP - 1]) != 0) topk_insert_sorted<KCAP>(bd, bi, db, jb);
+    bool any = false;
+    if (__builtin_amdgcn_ballot_w64(da <= wq) != 0) {
+      if (da <= wq) topk_insert_lex<KCAP>(bd, bi, da, __builtin_bit_cast(int, s_c[ja * CROW + CROW - 1]));
+      any = true;
+    }
+    if (__builtin_amdgcn_ballot_w64(db <= wq) != 0) {
+      if (db <= wq) topk_insert_lex<KCAP>(bd, bi, db, __builtin_bit_cast(int, s_c[jb * CROW + CROW - 1]));
+      any = true;
+    }
+    if (any) {  // (wave-uniform) refresh the quad's bound: min over the four parts' last entries
+      float w = bd[KCAP - 1];
+      w  = fminf(w, dpp_mov<0xb1>(w));  // quad_perm:[1,0,3,2]
+      wq = fminf(w, dpp_mov<0x4e>(w));  // quad_perm:[2,3,0,1]
+    }
   }
   // ---- merge the quad's four lists: after xor 1 lanes (0,1) and (2,3) agree, after xor 2 all four
 #pragma unroll
@@ -349,7 +420,9 @@ size_t skgs_sp_lbs_weights_workspace_bytes(int32_t P, int32_t M, int32_t F) {
 
 int skgs_sp_lbs_weights_forward(int32_t P, int32_t M, int32_t K, int32_t F, const float* points, const float* feature,
     const float* sp_points, const float* sp_feature, const float* sp_radius_raw, const float* sp_weight_raw, float temperature,
-    const float* sp_W, int64_t* out_idx, float* out_weights, float* out_dist, void* pairs, size_t pairs_bytes, skgs_stream_t stream) {
+    const float* sp_W, const int32_t* sp_order, const int32_t* sp_rank, int64_t* out_idx, float* out_weights, float* out_dist,
+    void* pairs, size_t pairs_bytes, skgs_stream_t stream) {
+  SKGS_REQUIRE(!sp_rank || sp_order, "sp_lbs_weights_forward: sp_rank is the inverse of sp_order: give both");
   SKGS_REQUIRE(P >= 0 && M >= 1 && K >= 1 && K <= 16 && K <= M, "sp_lbs_weights_forward: need P >= 0, 1 <= K <= min(16, M)");
   SKGS_REQUIRE(!pairs || pairs_bytes >= sp_pairs_bytes(P > 0 ? P : 1, M, K), "sp_lbs_weights_forward: pair-list buffer too small (skgs_sp_pairs_bytes)");
   SKGS_REQUIRE(F == 0 || F == 8, "sp_lbs_weights_forward: F (hyper dimensions) must be 0 or 8");
@@ -363,14 +436,17 @@ int skgs_sp_lbs_weights_forward(int32_t P, int32_t M, int32_t K, int32_t F, cons
   SpPairsView pv{};
   if (pairs) {  // the lists start empty: whatever an earlier forward filed (with or without a backward) is dropped
     pv = sp_pairs_view(pairs, P, M, K);
-    if (fill_u32(pv.header, 0u, 64 + ((size_t) M + 63) / 64 * 64, s)) return 1;  // header + counts (contiguous: counts start at byte 256)
+    const int n_clear = 64 + (M + 63) / 64 * 64;  // header + counts (contiguous: the counts start at byte 256)
+    hipLaunchKernelGGL(sp_prepare_kernel, dim3((std::max(n_clear, M * CROW) + 255) / 256), dim3(256), 0, s, M, F, sp_points, sp_feature,
+        sp_order, pv.header, n_clear, pv.table);
+    SKGS_CHECK_HIP(hipGetLastError());
   }
   ProfScope prof(K_SP_KNN, s);
   const int per_wg = SPK_THREADS / LPG;  // four lanes per Gaussian
   const dim3 grid((P + per_wg - 1) / per_wg), block(SPK_THREADS);
 #define SKGS_SPK(KCAP_, F_)                                                                                              \
   hipLaunchKernelGGL((sp_knn_weights_kernel<KCAP_, F_>), grid, block, lds, s, P, M, K, points, feature, sp_points, sp_feature, \
-      sp_radius_raw, sp_weight_raw, temperature, sp_W, out_idx, out_weights, out_dist, pv.counts, pv.lists, pv.cap, pv.header)
+      sp_radius_raw, sp_weight_raw, temperature, sp_W, out_idx, out_weights, out_dist, pv.counts, pv.lists, pv.cap, pv.header, sp_order, sp_rank, (const float*) pv.table)
   if (F == 8) {
     if (K <= 5) SKGS_SPK(5, 8); else if (K <= 8) SKGS_SPK(8, 8); else SKGS_SPK(16, 8);
   } else {

@@ -376,6 +376,20 @@ class FusedSuperpointStep(FusedViewStep):
             vs = view_table.settings
             assert (vs.image_height, vs.image_width) == (self.H, self.W)
         self.wide = True
+        self.sp_order = torch.empty((M,), dtype=torch.int32, device=dev)
+        self.sp_rank = torch.empty((M,), dtype=torch.int32, device=dev)
+        self.indices.zero_()  # (the search reads the previous call's nearest superpoint as its starting hint)
+        self.refresh_scan_order()
+
+    @torch.no_grad()
+    def refresh_scan_order(self):
+        """the order the search scans the superpoints in: along a Z-order curve of their positions (any order gives the same
+        result; this one lets a wave skip most candidates together).  In place -- a captured step keeps the pointer; call it
+        when the superpoints have moved far (e.g. with the densification cadence)."""
+        from sk_gs_amd.densify import morton_order
+        order = morton_order(self.model.sp_points.detach())
+        self.sp_order.copy_(order.to(torch.int32))
+        self.sp_rank[order] = torch.arange(order.numel(), dtype=torch.int32, device=order.device)  # the inverse permutation
 
     # ---- the pieces FusedViewStep asks its subclass for --------------------------------------------------------------
     def table_grad_span(self):
@@ -410,7 +424,7 @@ class FusedSuperpointStep(FusedViewStep):
         chk(lib.skgs_sp_lbs_weights_forward(
             C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(self.F), _p(m._xyz), _p(m.hyper_feature), _p(m.sp_points),
             _p(m.sp_hyper_feature), _p(m._sp_radius), _p(m._sp_weight), C.c_float(m.lbs_temperature), _p(m.sp_W),
-            _p(self.indices), _p(self.weights), _p(self.nn_dist), _p(self.pairs), C.c_size_t(self.pairs.numel()), st))
+            _p(self.sp_order), _p(self.sp_rank), _p(self.indices), _p(self.weights), _p(self.nn_dist), _p(self.pairs), C.c_size_t(self.pairs.numel()), st))
         d = self._deform_inputs(time_id)
         chk(lib.skgs_lbs_deform_forward(C.byref(d), _p(self.means), _p(self.scales), _p(self.rotations), _p(self.opacity),
                                         None, None, None, st))

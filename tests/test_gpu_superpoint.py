@@ -133,16 +133,21 @@ def _sp_scene(P, M, seed, F=8):
     return pts, sp, feat, sfeat, radius_raw, kweight_raw
 
 
-def _sp_forward(P, M, K, F, pts, sp, feat, sfeat, radius_raw=None, kweight_raw=None, T=1.0, sp_W=None):
+def _sp_forward(P, M, K, F, pts, sp, feat, sfeat, radius_raw=None, kweight_raw=None, T=1.0, sp_W=None, order=None, hint=False,
+                prev=None):
     import ctypes as C
     from sk_gs_amd import _C
     lib = _C.load_library()
     dev = 'cuda'
-    idx = torch.empty((P, K), dtype=torch.int64, device=dev)
+    idx = prev if prev is not None else torch.randint(-2 ** 40, 2 ** 40, (P, K), dtype=torch.int64, device=dev)  # (any hint is valid)
     w, d = torch.empty((P, K), device=dev), torch.empty((P, K), device=dev)
     p = lambda t: C.c_void_p(None if t is None else t.data_ptr())  # noqa: E731
+    rank = None
+    if order is not None and hint:
+        rank = torch.empty_like(order)
+        rank[order.long()] = torch.arange(M, dtype=order.dtype, device=order.device)
     _C._check(lib.skgs_sp_lbs_weights_forward(C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(F), p(pts), p(feat), p(sp),
-                                              p(sfeat), p(radius_raw), p(kweight_raw), C.c_float(T), p(sp_W), p(idx), p(w), p(d),
+                                              p(sfeat), p(radius_raw), p(kweight_raw), C.c_float(T), p(sp_W), p(order), p(rank), p(idx), p(w), p(d),
                                               None, C.c_size_t(0), _C._stream()))
     return idx, w, d
 
@@ -182,6 +187,16 @@ def test_sp_search_and_weightings_match_the_oracle_at_full_size(oracle32, oracle
         idx, w, d = _sp_forward(P, M, K, F, d_pts, d_sp, d_feat, d_sfeat, rr, kk, T, sp_W)
         np.testing.assert_array_equal(to_np(idx), want_i, err_msg=method)
         np.testing.assert_array_equal(to_np(d), want_d, err_msg=method)
+        # any scan order of the superpoints gives the same lists, bit for bit (a spatial one, a random one)
+        from sk_gs_amd.densify import morton_order
+        for order in (morton_order(d_sp).int().contiguous(), torch.randperm(M, generator=g).int().cuda()):
+            idx2, w2, d2 = _sp_forward(P, M, K, F, d_pts, d_sp, d_feat, d_sfeat, rr, kk, T, sp_W, order=order)
+            assert torch.equal(idx2, idx) and torch.equal(d2, d) and torch.equal(w2, w), method
+            # ... and so does any starting point: a garbage hint (first call) and the previous call's own result
+            idx3, w3, d3 = _sp_forward(P, M, K, F, d_pts, d_sp, d_feat, d_sfeat, rr, kk, T, sp_W, order=order, hint=True)
+            assert torch.equal(idx3, idx) and torch.equal(d3, d) and torch.equal(w3, w), method
+            idx4, w4, d4 = _sp_forward(P, M, K, F, d_pts, d_sp, d_feat, d_sfeat, rr, kk, T, sp_W, order=order, hint=True, prev=idx3.clone())
+            assert torch.equal(idx4, idx) and torch.equal(d4, d) and torch.equal(w4, w), method
         if method == 'W':
             want_w = oracle32.lbs_weights(to_np(sp_W), want_i)
             assert np.abs(to_np(w) - want_w).max() <= 2e-6
@@ -359,7 +374,7 @@ def test_sp_skinning_backward_by_inverse_lists_matches_the_two_call_sequence_and
     w, dist = torch.empty((P, K), device=dev), torch.empty((P, K), device=dev)
     for rep in range(2):  # (twice: the forward clears the lists it filed before)
         _C._check(lib.skgs_sp_lbs_weights_forward(C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(F), p(d_pts), p(d_feat), p(d_sp),
-                                                  p(d_sfeat), p(rr), p(kk), C.c_float(T), p(sp_W), p(idx), p(w), p(dist), p(pairs),
+                                                  p(d_sfeat), p(rr), p(kk), C.c_float(T), p(sp_W), None, None, p(idx), p(w), p(dist), p(pairs),
                                                   C.c_size_t(pairs.numel()), _C._stream()))
     torch.cuda.synchronize()
     hdr = pairs[:8].view(torch.int32)
