@@ -29,7 +29,7 @@
 namespace skgs {
 namespace {
 
-constexpr int SPK_THREADS = 256;
+constexpr int SPK_THREADS = 512;
 constexpr int CROW        = 12;  // LDS row of a superpoint: xyz, 8 hyper coordinates, pad
 constexpr int MAXF        = 8;
 
