@@ -155,7 +155,7 @@ def main():
                          "size -- 512 superpoints, 3+8-d search, sp_deform_net on 512 rows (30 k of the reference's 80 k default "
                          "steps, exps/default.yaml:12-26; benchlib/sp_stage.py)")
     ap.add_argument('--keep-order', action='store_true',
-                    help='--stage sp: leave the synthetic Gaussians in their random order (default: sorted along a Z-order curve, '
+                    help='leave the synthetic Gaussians in their random order (default: sorted along a Z-order curve, '
                          'densify.sort_spatially, as after a densification event)')
     ap.add_argument('--superpoints', type=int, default=512, help='--stage sp: num_superpoints (exps/default.yaml:25)')
     ap.add_argument('--lbs-method', choices=('weighted_kernel', 'kernel', 'dist', 'W'), default='weighted_kernel',
@@ -213,6 +213,12 @@ def main():
         frames = args.views
         model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=0, deform_net=args.deform_net,
                                  scale_mult=args.scale_mult, learn_joints=args.learn_joints).to(dev)
+        if not args.keep_order and M > 0:
+            # Gaussians along a Z-order curve (sk_gs_amd/densify.py::sort_spatially): neighbours in space become neighbours in
+            # memory and in a wavefront -- what a training loop does after a densification event (the reference's order carries no
+            # meaning: clones and split children are appended, gaussian_splatting.py:577-587)
+            from sk_gs_amd.densify import sort_spatially
+            sort_spatially(model)
         densify_every = args.densify_every if (world == 1 and not args.autograd and M > 0) else 0
         if densify_every:  # room to grow BEFORE anything mirrors the parameters (gradient slots, moments, workspaces)
             model.enable_capacity(int(P * 1.25))

@@ -31,6 +31,7 @@
 // No gradient w.r.t. the superpoint positions: every caller detaches them (sk_gs.py:746-748,845).
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 #include "adam_update.h"
 #include "skgs_common.h"
@@ -51,7 +52,8 @@ constexpr int IN0    = PDIM + TOUT;          // 93
 constexpr int IN0P   = 96;                   // padded row of the saved encoded input
 constexpr int ROWS   = 16;                   // superpoints per workgroup = the MFMA tile's rows
 constexpr int NT     = 512;                  // 8 waves: two per SIMD, each owns 32 features (two 16x16 tiles) of every layer
-constexpr int NTB    = 256;                  // the weight-gradient launch: 4 waves
+constexpr int NTB    = 512;                  // the weight-gradient launch: 8 waves, the rows (the contraction) split over them
+constexpr int NWB    = NTB / 64;
 constexpr int NWAVE  = NT / 64;
 constexpr int FPW    = SPW / NWAVE;          // features per wave (32)
 constexpr int PITCH  = SPW + 4;              // LDS row pitch of an activation block (floats)
@@ -154,68 +156,90 @@ __host__ __device__ inline int layer_hofs(int l) { return l == SKIP + 1 ? IN0 : 
 // (4 rows x 256 B forward, 8 rows x 128 B backward), parks it in a PRIVATE LDS region (no barrier: LDS instructions of one
 // wave execute in order) and reads the MFMA operand back from there.  The next chunk's global loads are in flight while the
 // current chunk's MFMAs run; the other wave of the SIMD covers the write -> read turn-around.
-constexpr int FST_P       = 68;              // forward stage: [32 features][64 k + 4]
-constexpr int BST_P       = 36;              // backward stage: [64 outputs][32 inputs + 4]
-constexpr int STAGE_F     = 64 * BST_P;      // floats per wave (>= 32 * FST_P)
-static_assert(STAGE_F >= 32 * FST_P, "stage");
+constexpr int ST_P        = 36;              // stage row pitch: 32 values + 4 (both directions)
+constexpr int ST_BUF      = 32 * ST_P;       // one buffer: forward [32 features][32 k], backward [32 outputs][32 inputs]
+constexpr int STAGE_F     = 2 * ST_BUF;      // floats per wave: two buffers
 constexpr size_t STAGE_BYTES = (size_t) NWAVE * STAGE_F * 4;
 
+// The pipeline of one wave (both directions), chunks of 32 along the contraction, TWO stage buffers: in program order
+//     ds_read  operands of chunk c        (buffer c & 1)
+//     ds_write chunk c + 1                (the other buffer; its global loads were issued two chunks ago)
+//     global loads of chunk c + 3
+//     16 MFMAs of chunk c
+// so the LDS write of the next chunk and the loads behind it are in flight while the matrix pipe works (LDS instructions of one
+// wave execute in order: the MFMAs wait with lgkmcnt(4), not 0).  With ONE buffer the write had to follow the reads' MFMAs: LDS
+// time (2.1 us per layer and CU) and MFMA time (3.4 us) added up -- 54 us for the eight layers against 38 without staging.
+
 // Forward product of one layer part.  Tile c (c = 0, 1) of a wave holds output features f0 + 2 j + c (f0 = 32 wave): a lane
-// ends with two CONSECUTIVE features per row.  acc[c] += A[16 x 16 NSTEPS] W^T with A from LDS (row pitch pa) and W rows at
-// stride ldw from column kofs, in chunks of 64 k.  `kvalid` = valid weight columns from kofs (the 93-wide part is guarded).
-template <int NSTEPS, bool GUARD>
+// ends with two CONSECUTIVE features per row.  acc[c] += A[16 x 32 NCH] W^T with A from LDS (row pitch pa) and W rows at stride
+// ldw from column kofs.  `kvalid` = valid weight columns from kofs (the 93-wide input part is guarded).  Global pattern of a
+// chunk: lane -> row L / 8 + 8 i, 16 B at column 4 (L % 8): 8 rows x 128 B per instruction.
+template <int NCH, bool GUARD>
 __device__ __forceinline__ void gemm_fwd(f32x4 (&acc)[2], const float* sA, int pa, const float* __restrict__ W, int ldw, int kofs,
     int kvalid, int wave, int lane, float* sw) {
-  constexpr int NCH = (NSTEPS + 3) / 4;
   const int j = lane & 15, q = lane >> 4;
   const float* arow = sA + j * pa + 4 * q;
-  const float* wb   = W + (size_t) (FPW * wave + q) * ldw + kofs + 4 * j;  // chunk loads: lane -> row q + 4 i, 16 B at column 4 j
-  float* wr         = sw + q * FST_P + 4 * j;
-  const float* rd0  = sw + (2 * j) * FST_P + 4 * q;
-  float4 g[2][8];
-  auto fetch = [&](int ck, float4 (&dst)[8]) {
+  const int lr = lane >> 3, lc = 4 * (lane & 7);
+  const float* wb = W + (size_t) (FPW * wave + lr) * ldw + kofs + lc;
+  float* wr       = sw + lr * ST_P + lc;
+  const float* rd = sw + (2 * j) * ST_P + 4 * q;
+  float4 g[3][4];
+  auto fetch = [&](int ck, float4 (&dst)[4]) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float* p = wb + (size_t) (4 * i) * ldw + 64 * ck;
-      dst[i] = GUARD ? ldg4_guard(p, kvalid - (64 * ck + 4 * j)) : ldg4(p);
+    for (int i = 0; i < 4; ++i) {
+      const float* p = wb + (size_t) (8 * i) * ldw + 32 * ck;
+      dst[i] = GUARD ? ldg4_guard(p, kvalid - (32 * ck + lc)) : ldg4(p);
     }
   };
+  auto park = [&](int ck, const float4 (&src)[4]) {
+    float* d = wr + (ck & 1) * ST_BUF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(d + (8 * i) * ST_P) = src[i];
+  };
   fetch(0, g[0]);
+  if (NCH > 1) fetch(1, g[1]);
+  if (NCH > 2) fetch(2, g[2]);
+  park(0, g[0]);
 #pragma unroll
   for (int ck = 0; ck < NCH; ++ck) {
+    const float* r = rd + (ck & 1) * ST_BUF;
+    float4 a[2], b0[2], b1[2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(wr + (4 * i) * FST_P) = g[ck & 1][i];
-    if (ck + 1 < NCH) fetch(ck + 1, g[(ck + 1) & 1]);
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (4 * ck + s >= NSTEPS) break;
-      const float4 a  = *reinterpret_cast<const float4*>(arow + 16 * (4 * ck + s));
-      const float4 b0 = *reinterpret_cast<const float4*>(rd0 + 16 * s);
-      const float4 b1 = *reinterpret_cast<const float4*>(rd0 + FST_P + 16 * s);
-      acc[0] = mfma4(a.x, b0.x, acc[0]);
-      acc[1] = mfma4(a.x, b1.x, acc[1]);
-      acc[0] = mfma4(a.y, b0.y, acc[0]);
-      acc[1] = mfma4(a.y, b1.y, acc[1]);
-      acc[0] = mfma4(a.z, b0.z, acc[0]);
-      acc[1] = mfma4(a.z, b1.z, acc[1]);
-      acc[0] = mfma4(a.w, b0.w, acc[0]);
-      acc[1] = mfma4(a.w, b1.w, acc[1]);
+    for (int s = 0; s < 2; ++s) {
+      a[s]  = *reinterpret_cast<const float4*>(arow + 32 * ck + 16 * s);
+      b0[s] = *reinterpret_cast<const float4*>(r + 16 * s);
+      b1[s] = *reinterpret_cast<const float4*>(r + ST_P + 16 * s);
     }
-    __builtin_amdgcn_wave_barrier();
+    if (ck + 1 < NCH) park(ck + 1, g[(ck + 1) % 3]);
+    if (ck + 3 < NCH) fetch(ck + 3, g[ck % 3]);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      acc[0] = mfma4(a[s].x, b0[s].x, acc[0]);
+      acc[1] = mfma4(a[s].x, b1[s].x, acc[1]);
+      acc[0] = mfma4(a[s].y, b0[s].y, acc[0]);
+      acc[1] = mfma4(a[s].y, b1[s].y, acc[1]);
+      acc[0] = mfma4(a[s].z, b0[s].z, acc[0]);
+      acc[1] = mfma4(a[s].z, b1[s].z, acc[1]);
+      acc[0] = mfma4(a[s].w, b0[s].w, acc[0]);
+      acc[1] = mfma4(a[s].w, b1[s].w, acc[1]);
+    }
   }
+  __builtin_amdgcn_wave_barrier();
 }
 
 // Backward product: tile c holds INPUT features n0 + 2 j + c (n0 = 32 wave); acc[c] += gZ[16 x 256] W[:, kofs + n0 ...], the
 // contraction over the layer's 256 output features in chunks of 64: the wave's [64 outputs][32 inputs] block of W is loaded
-// as 8 rows x 128 B per instruction, staged, and read back as one float2 per (output o = 16 s + 4 q + t, lane).
+// as 8 rows x 128 B per instruction, staged in ONE buffer (the whole stage area), and read back as one float2 per (output
+// o = 16 s + 4 q + t, lane).  (The double-buffered 32-chunk pipeline of the forward was measured here too: 59.7 against 55.6 us --
+// the operand reads are 8-byte ones, twice the LDS instructions per MFMA of the forward, and the shorter chunks only add
+// overhead.)
 __device__ __forceinline__ void gemm_bwd(f32x4 (&acc)[2], const float* sA, int pa, const float* __restrict__ W, int ldw, int kofs,
     int wave, int lane, float* sw) {
   const int j = lane & 15, q = lane >> 4;
   const float* arow = sA + j * pa + 4 * q;
   const float* wb   = W + (size_t) (lane >> 3) * ldw + kofs + FPW * wave + 4 * (lane & 7);  // row L / 8 + 8 i, 16 B at 4 (L % 8)
-  float* wr         = sw + (lane >> 3) * BST_P + 4 * (lane & 7);
-  const float* rd   = sw + (4 * q) * BST_P + 2 * j;
+  float* wr         = sw + (lane >> 3) * ST_P + 4 * (lane & 7);
+  const float* rd   = sw + (4 * q) * ST_P + 2 * j;
   constexpr int NCH = SPW / 64;
   float4 g[2][8];
   auto fetch = [&](int ck, float4 (&dst)[8]) {
@@ -226,7 +250,7 @@ __device__ __forceinline__ void gemm_bwd(f32x4 (&acc)[2], const float* sA, int p
 #pragma unroll
   for (int ck = 0; ck < NCH; ++ck) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(wr + (8 * i) * BST_P) = g[ck & 1][i];
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(wr + (8 * i) * ST_P) = g[ck & 1][i];
     if (ck + 1 < NCH) fetch(ck + 1, g[(ck + 1) & 1]);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -235,7 +259,7 @@ __device__ __forceinline__ void gemm_bwd(f32x4 (&acc)[2], const float* sA, int p
       const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const float2 b = *reinterpret_cast<const float2*>(rd + (16 * s + t) * BST_P);
+        const float2 b = *reinterpret_cast<const float2*>(rd + (16 * s + t) * ST_P);
         acc[0] = mfma4(av[t], b.x, acc[0]);
         acc[1] = mfma4(av[t], b.y, acc[1]);
       }
@@ -334,8 +358,8 @@ __global__ void __launch_bounds__(NT) sp_net_forward_kernel(int M, NetPtrs n, fl
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     const float* W = n.W[l];
     const int ldw  = layer_ld(l);
-    if (l == 0 || l == SKIP + 1) gemm_fwd<IN0P / 16, true>(acc, s_x0, XPITCH, W, ldw, 0, IN0, wave, lane, sw);
-    if (l > 0) gemm_fwd<SPW / 16, false>(acc, s_act[cur], PITCH, W, ldw, layer_hofs(l), SPW, wave, lane, sw);
+    if (l == 0 || l == SKIP + 1) gemm_fwd<IN0P / 32, true>(acc, s_x0, XPITCH, W, ldw, 0, IN0, wave, lane, sw);
+    if (l > 0) gemm_fwd<SPW / 32, false>(acc, s_act[cur], PITCH, W, ldw, layer_hofs(l), SPW, wave, lane, sw);
     float* out      = s_act[cur ^ 1] + FPW * wave + 2 * j;
     float* Yl       = sv.Y + ((size_t) l * Mp + r0) * SPW + FPW * wave + 2 * j;
     const float2 bb = *reinterpret_cast<const float2*>(n.b[l] + FPW * wave + 2 * j);
@@ -546,7 +570,8 @@ __device__ void timenet_backward(int M, const NetPtrs& n, const GradPtrs& g, con
   float* s_prod = s_buf;              // [TOUT][256]  (30 KB of the 49 KB partial-tile area)
   float* s_gt   = s_buf + TOUT * SPW; // [32]
   float* s_ghid = s_gt + 64;              // [256]
-  {
+  const bool act = tid < SPW;             // (the launch has 512 threads; one per feature works here, all reach the barriers)
+  if (act) {
     const int nblk = Mp / ROWS;
     float gb0 = 0.f, gb5 = 0.f;  // bias gradients of layers 0 and 5, from the row blocks' partial sums (launch A)
     for (int b0 = 0; b0 < nblk; b0 += 16) {  // 32 loads in flight per round (a plain loop was one round trip per block)
@@ -579,7 +604,7 @@ __device__ void timenet_backward(int M, const NetPtrs& n, const GradPtrs& g, con
     if (part == 0) s_gt[c] = v;
   }
   __syncthreads();
-  {  // second linear: gW2 [30][256] = g_t (x) hid, gb2 = g_t;  g_hid = W2^T g_t * (hid > 0)
+  if (act) {  // second linear: gW2 [30][256] = g_t (x) hid, gb2 = g_t;  g_hid = W2^T g_t * (hid > 0)
     const float hid = sv.thid[tid];
     float gh = 0.f;
     float w2[TOUT];
@@ -604,11 +629,13 @@ __device__ void timenet_backward(int M, const NetPtrs& n, const GradPtrs& g, con
 // job table: [0,112) hidden x hidden products of layers 1..7 (16 tiles of 64 x 64 each; layer 5 writes at column 93),
 // [112,120) layer 0 (256 x 93: 4 x 2 tiles), [120,128) layer 5's input part (256 x 93), [128,132) heads (10 x 256: 4 tiles of
 // 16 x 64).  Rows (the contraction) split over the 4 waves, partial tiles summed through LDS.
+constexpr size_t WEIGHTS_LDS_BYTES = ((size_t) NWB * 64 * 65 + NWB * 64) * 4;
 constexpr int JOBS_HH = 7 * 16, JOBS_X0 = 8, JOBS_HEAD = 4, N_JOBS = JOBS_HH + 2 * JOBS_X0 + JOBS_HEAD;
 
 __global__ void __launch_bounds__(NTB) sp_net_backward_weights_kernel(int M, NetPtrs n, GradPtrs g, SavedView sv, WorkView wk) {
-  __shared__ __attribute__((aligned(16))) float s_part[3][64 * 65];
-  __shared__ float s_gb[4][64];
+  extern __shared__ __attribute__((aligned(16))) float s_dynb[];  // [NWB][64 * 65] partial tiles | [NWB][64] column sums
+  float (*s_part)[64 * 65] = reinterpret_cast<float (*)[64 * 65]>(s_dynb);
+  float (*s_gb)[64]        = reinterpret_cast<float (*)[64]>(s_dynb + NWB * 64 * 65);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int j = lane & 15, q = lane >> 4;
   const int Mp  = pad_rows(M);
@@ -646,8 +673,8 @@ __global__ void __launch_bounds__(NTB) sp_net_backward_weights_kernel(int M, Net
     bias = k0 == 0;
   }
   // ---- the wave's share of the rows: rows [rb, re), 4 per step
-  const int per = (Mp / 4 + 3) / 4 * 4;  // Mp is a multiple of 16: per = Mp / 4
-  const int rb = wave * per, re = min(rb + per, Mp);
+  const int per = ((Mp + NWB - 1) / NWB + 3) / 4 * 4;
+  const int rb = min(wave * per, Mp), re = min(rb + per, Mp);
   f32x4 acc[4][4];  // [o tile a][k tile c]: outputs o0 + 4 i + a (heads: o = i), k0 + 4 j + c
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -669,8 +696,12 @@ __global__ void __launch_bounds__(NTB) sp_net_backward_weights_kernel(int M, Net
         const int rr  = r + 4 * u;
         const bool in = rr < re;
         const int rc  = in ? rr : rb;  // (clamped address, value masked: a select between POINTERS put the zero in scratch)
+#ifdef SPX_B_NOLOAD  // timing experiment
+        a[u] = make_float4((float) rc, 1.f, 2.f, 3.f), b[u] = make_float4(1.f, (float) rc, 2.f, 3.f);
+#else
         a[u] = *reinterpret_cast<const float4*>(ap + (size_t) rc * SPW);
         b[u] = *reinterpret_cast<const float4*>(xin ? xp + (size_t) rc * xld : ap + (size_t) rc * SPW);
+#endif
         if (!in) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!(in && xin)) b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -727,8 +758,9 @@ __global__ void __launch_bounds__(NTB) sp_net_backward_weights_kernel(int M, Net
       }
     }
   }
-  // ---- waves 1..3 park their partial tiles in LDS ([o local (64)][k local (64)], pitch 65); wave 0 adds them to its own and
-  // stores.  D layout: row 4 q + r of tile a <-> o local 4 (4 q + r) + a (heads: 4 q + r), column j of tile c <-> k local 4 j + c
+  // ---- every wave parks its partial tile in LDS ([o local (64)][k local (64)], pitch 65); then ALL threads add the NWB partials,
+  // 8 outputs each, and store rows of 64 consecutive columns.  D layout: row 4 q + r of tile a <-> o local 4 (4 q + r) + a
+  // (heads: 4 q + r), column j of tile c <-> k local 4 j + c
   const int na = heads ? 1 : 4;
   {
     // column sums of the left operand over this wave's rows: lanes (j, q) hold features o0 + 4 j + {x,y,z,w} (heads: j)
@@ -743,8 +775,11 @@ __global__ void __launch_bounds__(NTB) sp_net_backward_weights_kernel(int M, Net
       }
     }
   }
-  if (wave > 0) {
-    float* sp = s_part[wave - 1];
+#ifdef SPX_B_NOEPI  // timing experiment
+  if (acc[0][0][0] != 12345.f) return;
+#endif
+  {
+    float* sp = s_part[wave];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       if (a >= na) break;
@@ -757,34 +792,27 @@ __global__ void __launch_bounds__(NTB) sp_net_backward_weights_kernel(int M, Net
     }
   }
   __syncthreads();
-  if (wave == 0) {
+  const int no = heads ? 16 : 64;
+  for (int e = tid; e < no * 64; e += NTB) {
+    const int ol = e >> 6, kl = e & 63;
+    float v = 0.f;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      if (a >= na) break;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ol = heads ? 4 * q + r : 4 * (4 * q + r) + a;
-        float* dst   = nullptr;
-        if (heads) {
-          if (ol < NOUT) {
-            int hrow;
-            const int hd = head_of(ol, hrow);
-            dst = g.head_w[hd] + (size_t) hrow * SPW;
-          }
-        } else {
-          dst = G + (size_t) (o0 + ol) * gld + gofs;
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int kl  = 4 * j + c;
-          const float v = (acc[a][c][r] + s_part[0][ol * 65 + kl]) + (s_part[1][ol * 65 + kl] + s_part[2][ol * 65 + kl]);
-          if (dst && k0 + kl < kvalid) dst[k0 + kl] = v;
-        }
+    for (int w = 0; w < NWB; ++w) v += s_part[w][ol * 65 + kl];
+    if (k0 + kl >= kvalid) continue;
+    if (heads) {
+      if (ol < NOUT) {
+        int hrow;
+        const int hd = head_of(ol, hrow);
+        g.head_w[hd][(size_t) hrow * SPW + k0 + kl] = v;
       }
+    } else {
+      G[(size_t) (o0 + ol) * gld + gofs + k0 + kl] = v;
     }
   }
-  if (bias && tid < (heads ? 16 : 64)) {
-    const float v = (s_gb[0][tid] + s_gb[1][tid]) + (s_gb[2][tid] + s_gb[3][tid]);
+  if (bias && tid < no) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWB; ++w) v += s_gb[w][tid];
     if (heads) {
       if (tid < NOUT) {
         int hrow;
@@ -820,6 +848,9 @@ int allow_stage_lds() {  // static + dynamic LDS of the two row-block kernels ex
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_net_backward_rows_kernel),
           hipFuncAttributeMaxDynamicSharedMemorySize, (int) STAGE_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_net_backward_weights_kernel),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int) WEIGHTS_LDS_BYTES);
     return e == hipSuccess ? 0 : 1;
   }();
   return rc;
@@ -900,7 +931,8 @@ int skgs_sp_net_backward(const skgs_sp_net* net, const skgs_sp_net* grads, const
   hipLaunchKernelGGL(sp_net_backward_rows_kernel, dim3(nblk + n_side), dim3(NT), STAGE_BYTES, s, M, nblk, n, g_bone_T, g_d_rot, g_d_scale,
       g_raw, sv, wk, sd);
   SKGS_CHECK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(sp_net_backward_weights_kernel, dim3(N_JOBS + 1), dim3(NTB), 0, s, M, n, g, sv, wk);
+  static const int skip_time = getenv("SPX_SKIP_TIMENET") ? 1 : 0;  // (timing experiment)
+  hipLaunchKernelGGL(sp_net_backward_weights_kernel, dim3(N_JOBS + 1 - skip_time), dim3(NTB), WEIGHTS_LDS_BYTES, s, M, n, g, sv, wk);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }
