@@ -33,38 +33,39 @@ constexpr int SPK_THREADS = 512;
 constexpr int CROW        = 12;  // LDS row of a superpoint: xyz, 8 hyper coordinates, pad
 constexpr int MAXF        = 8;
 
+// Per-lane select on an explicit lane mask: v_cndmask_b32 in its VOP3 form with an SGPR-pair mask.  hipcc picks the VOP2 form
+// (implicit VCC) for about a third of the selects of an insertion network, and that encoding issues in 22.6 clocks per wave
+// instruction on gfx950 against 4.4 for this one (tools/micro/valu_issue_rate.hip, profiles/r03_l_valu_issue_rate.txt).
+__device__ __forceinline__ float sel(uint64_t m, float t, float f) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
+  return r;
+}
+__device__ __forceinline__ int sel(uint64_t m, int t, int f) {
+  int r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
+  return r;
+}
+
+// insertion by (distance, id) lexicographically: ties to the lower id -- the order a serial scan in id order produces, whatever
+// order the candidates arrive in (the scan order, the merge of the four partial lists of a Gaussian)
 template <int KCAP>
-__device__ __forceinline__ void topk_insert_sorted(float (&bd)[KCAP], int (&bi)[KCAP], float d, int id) {
-  bool lt[KCAP];
+__device__ __forceinline__ void topk_insert_lex(float (&bd)[KCAP], int (&bi)[KCAP], float d, int id) {
+  uint64_t lt[KCAP];
 #pragma unroll
-  for (int k = 0; k < KCAP; ++k) lt[k] = d < bd[k];
+  for (int k = 0; k < KCAP; ++k)
+    lt[k] = __builtin_amdgcn_ballot_w64(d < bd[k]) | (__builtin_amdgcn_ballot_w64(d == bd[k]) & __builtin_amdgcn_ballot_w64(id < bi[k]));
 #pragma unroll
   for (int k = KCAP - 1; k >= 1; --k) {
-    bi[k] = lt[k - 1] ? bi[k - 1] : (lt[k] ? id : bi[k]);
-    bd[k] = __builtin_amdgcn_fmed3f(bd[k - 1], bd[k], d);  // bd[k-1] <= bd[k]: clamps d into the slot's interval
+    bi[k] = sel(lt[k - 1], bi[k - 1], sel(lt[k], id, bi[k]));
+    bd[k] = sel(lt[k - 1], bd[k - 1], sel(lt[k], d, bd[k]));
   }
-  bi[0] = lt[0] ? id : bi[0];
-  bd[0] = fminf(bd[0], d);
+  bi[0] = sel(lt[0], id, bi[0]);
+  bd[0] = sel(lt[0], d, bd[0]);
 }
 
 __device__ __forceinline__ float act_radius(const float* __restrict__ r, int j) { return expf(r[j]); }
 __device__ __forceinline__ float act_kweight(const float* __restrict__ w, int j) { return 1.0f / (1.0f + expf(-w[j])); }
-
-// insertion by (distance, id) lexicographically: the merge of the four partial lists of a Gaussian (ties to the lower id, the
-// order the serial scan produces)
-template <int KCAP>
-__device__ __forceinline__ void topk_insert_lex(float (&bd)[KCAP], int (&bi)[KCAP], float d, int id) {
-  bool lt[KCAP];
-#pragma unroll
-  for (int k = 0; k < KCAP; ++k) lt[k] = (d < bd[k]) | ((d == bd[k]) & (id < bi[k]));
-#pragma unroll
-  for (int k = KCAP - 1; k >= 1; --k) {
-    bi[k] = lt[k - 1] ? bi[k - 1] : (lt[k] ? id : bi[k]);
-    bd[k] = lt[k - 1] ? bd[k - 1] : (lt[k] ? d : bd[k]);
-  }
-  bi[0] = lt[0] ? id : bi[0];
-  bd[0] = lt[0] ? d : bd[0];
-}
 
 // One small launch in front of the search (when the caller gave the pair buffer): the list header and counters are cleared and
 // the superpoint table is packed ONCE -- rows [xyz | hyper | id] in scan order -- so that each of the search's ~1500 workgroups
@@ -165,10 +166,9 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
   // `part` takes positions part + 8 t and part + 4 + 8 t: both on its own side of s0, 4 t and 4 t + 2 rows out.
   const int dir  = (part & 1) ? -1 : 1;
   const int base = (part & 1) ? -((part + 1) >> 1) : (part >> 1);
-  auto wrap = [&](int r) {  // into [0, M): r is at most M away
-    r += r < 0 ? M : 0;
-    r -= r >= M ? M : 0;
-    return r;
+  auto wrap = [&](int r) {  // into [0, M): r is at most M away.  Integer arithmetic only (no compare + select pairs)
+    r += (r >> 31) & M;
+    return (int) min((unsigned) r, (unsigned) (r - M));
   };
   // `wq`: the tightest bound any lane of the quad has on the Gaussian's K-th distance -- a part whose own list is still loose
   // (it has seen a quarter of the candidates) prunes with its partners' (the merged top-K can only be tighter than each part's)
@@ -201,13 +201,16 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
       if (ina) da = tail(da, ca, ja);
       if (inb) db = tail(db, cb, jb);
     }
+    // (a lane whose candidate cannot enter inserts a NaN: every comparison fails, nothing moves -- no divergent branch)
     bool any = false;
-    if (__builtin_amdgcn_ballot_w64(da <= wq) != 0) {
-      if (da <= wq) topk_insert_lex<KCAP>(bd, bi, da, __builtin_bit_cast(int, s_c[ja * CROW + CROW - 1]));
+    const uint64_t ma = __builtin_amdgcn_ballot_w64(da <= wq);
+    if (ma != 0) {
+      topk_insert_lex<KCAP>(bd, bi, sel(ma, da, __builtin_nanf("")), __builtin_bit_cast(int, s_c[ja * CROW + CROW - 1]));
       any = true;
     }
-    if (__builtin_amdgcn_ballot_w64(db <= wq) != 0) {
-      if (db <= wq) topk_insert_lex<KCAP>(bd, bi, db, __builtin_bit_cast(int, s_c[jb * CROW + CROW - 1]));
+    const uint64_t mb = __builtin_amdgcn_ballot_w64(db <= wq);
+    if (mb != 0) {
+      topk_insert_lex<KCAP>(bd, bi, sel(mb, db, __builtin_nanf("")), __builtin_bit_cast(int, s_c[jb * CROW + CROW - 1]));
       any = true;
     }
     if (any) {  // (wave-uniform) refresh the quad's bound: min over the four parts' last entries
