@@ -586,6 +586,11 @@ int skgs_sp_net_backward(const skgs_sp_net* net, const skgs_sp_net* grads, const
 int skgs_densify_stats(int32_t P, const int32_t* radii, const float* grad_means2D, float grad_multiplier,
     float* xyz_gradient_accum, float* denom, float* max_radii2D, skgs_stream_t stream);
 
+/* ---- simple_knn (initialisation, not on the per-frame path): networks/gaussian_splatting.py:211-213 resolves `simple_knn` from the
+ * extension for create_from_pcd (my_ext/_C/src/other/knn.cu:192-205): mean_dist2[p] = mean of the squared distances from point p
+ * to its three nearest other points.  points [P,3], mean_dist2 [P]. */
+int skgs_simple_knn(int32_t P, const float* points, float* mean_dist2, skgs_stream_t stream);
+
 /* ---- densification surgery in one launch (scope row (f)-4) ----
  * Replaces the per-tensor indexing / concatenation of change_optimizer, prune_points and densification_postfix
  * (networks/gaussian_splatting.py:515-587) over the per-Gaussian parameters and their Adam moments: for every tensor t of

@@ -884,6 +884,20 @@ def freq_encode_backward(grad: Tensor, outputs: Tensor, B: int, D: int, deg: int
                                              C.c_int32(0), _stream()))
 
 
+def simple_knn(points: Tensor) -> Tensor:
+    """``simple_knn`` of the reference's extension (my_ext/_C/src/other/knn.cu:192-205; called once by ``create_from_pcd``,
+    networks/gaussian_splatting.py:211-213): the mean squared distance of every point to its three nearest other points."""
+    lib = load_library()
+    _require_gpu(points, 'points')
+    if points.ndim != 2 or points.shape[-1] != 3 or points.dtype is not torch.float32:
+        raise SkgsError('simple_knn: points must be a float32 tensor of shape (P, 3)')  # the reference's CHECK_TYPE / BCNN_ASSERT
+    with _on_device(points.device):
+        pts = points.contiguous()
+        out = torch.empty((pts.shape[0],), dtype=torch.float32, device=pts.device)
+        _check(lib.skgs_simple_knn(C.c_int32(pts.shape[0]), C.c_void_p(_ptr(pts)), C.c_void_p(_ptr(out)), _stream()))
+    return out
+
+
 def _check_freq_args(who, B, D, deg, C_out, *tensors):
     # the reference's CHECK_CONTIGUOUS / CHECK_IS_FLOATING (freqencoder.cu:68-75), plus the sizes its kernels assume
     if C_out != D + 2 * D * deg:
@@ -897,10 +911,10 @@ def _check_freq_args(who, B, D, deg, C_out, *tensors):
 
 #: the names the reference's compiled module ``my_ext._C._C`` defines for THIS path (pybind ``m.def`` names:
 #: gaussian_rasterizer_forward.cu:314, gaussian_rasterizer_backwrad.cu:260, gaussian_rasterizer_extra.cu:279-283,
-#: gaussian_topk.cu:121, freqencoder.cu:107-110; ``mark_visible`` is commented out there, gaussian_rasterizer_imp.cu:75-103)
+#: gaussian_topk.cu:121, freqencoder.cu:107-110, other/knn.cu:205; ``mark_visible`` is commented out there, gaussian_rasterizer_imp.cu:75-103)
 PYBIND_NAMES = ('rasterize_gaussians', 'rasterize_gaussians_backward', 'gaussian_rasterize_extra_forward',
                 'gaussian_rasterize_extra_backward', 'gaussian_topk_weights', 'mark_visible', 'freq_encode_forward',
-                'freq_encode_backward')
+                'freq_encode_backward', 'simple_knn')
 
 _FUNCTIONS = {
     'rasterize_gaussians': rasterize_gaussians,
@@ -911,6 +925,7 @@ _FUNCTIONS = {
     'mark_visible': mark_visible,
     'freq_encode_forward': freq_encode_forward,
     'freq_encode_backward': freq_encode_backward,
+    'simple_knn': simple_knn,
     'lbs_deform_forward': lbs_deform_forward,
     'knn_lbs_deform_forward': knn_lbs_deform_forward,
     'lbs_deform_backward': lbs_deform_backward,

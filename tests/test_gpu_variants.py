@@ -184,3 +184,32 @@ def test_render_dict_other_extras_and_detach(oracle32):
     assert float(pts2.grad.abs().max()) == 0.0
     idx, w = topk_weights(2, out['buffer'])
     assert tuple(idx.shape) == (H, W, 2) and tuple(w.shape) == (H, W, 2)
+
+
+@pytest.mark.parametrize('P', [2000, 3, 1, 50_001])
+def test_simple_knn_under_its_pybind_name(P):
+    """``simple_knn`` (my_ext/_C/src/other/knn.cu:192-205; what create_from_pcd resolves, gaussian_splatting.py:211-213): the mean
+    squared distance to the three nearest OTHER points, against a brute-force restatement (exact three smallest of the same
+    fp32 distances; fewer than four points: missing neighbours count as FLT_MAX, as upstream)"""
+    from sk_gs_amd import _C
+    m = _C.pybind_module()
+    g = torch.Generator().manual_seed(P)
+    pts = (torch.rand(P, 3, generator=g) * 2.6 - 1.3).cuda()
+    got = getattr(m, 'simple_knn')(pts)
+    assert tuple(got.shape) == (P,) and got.dtype == torch.float32
+    n = min(P, 4000)  # (the check is O(n P) on the host)
+    d = ((pts[:n, None, :] - pts[None, :, :]) ** 2).sum(-1)
+    d[torch.arange(n), torch.arange(n)] = float('inf')
+    best = torch.sort(d, dim=1).values[:, :3]
+    best = torch.where(torch.isinf(best), torch.full_like(best, 3.402823466e+38), best)
+    if best.shape[1] < 3:
+        best = torch.cat([best, torch.full((n, 3 - best.shape[1]), 3.402823466e+38, device='cuda')], 1)
+    want = (best[:, 0] + best[:, 1] + best[:, 2]) / 3.0
+    finite = torch.isfinite(want) & (want < 1e30)
+    assert rel_err_t(got[:n][finite], want[finite]) <= 1e-5
+    with pytest.raises(_C.SkgsError):
+        m.simple_knn(pts.cpu())
+
+
+def rel_err_t(a, b):
+    return float(((a - b).abs() / b.abs().clamp_min(1e-30)).max()) if b.numel() else 0.0

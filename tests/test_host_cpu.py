@@ -105,6 +105,7 @@ def test_install_hook_moves_the_backward_to_the_calling_thread_and_back():
         from my_ext._C import get_C_function  # what networks/renderer/gaussian_render.py:12 does (stand-in without the reference)
         assert get_C_function('rasterize_gaussians') is _C.rasterize_gaussians
         assert get_C_function('freq_encode_forward') is _C.freq_encode_forward
+        assert get_C_function('simple_knn') is _C.simple_knn
         assert get_C_function('no_such_op') is None
         sk_gs_amd.single_thread_backward(False)
         assert torch.autograd.is_multithreading_enabled()
