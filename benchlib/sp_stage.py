@@ -11,12 +11,12 @@ their transforms every step, then the same rasterizer, loss and Adam as the skel
 
 as ONE captured hipGraph for all views (camera, time, target from the device view slot).  Returns the JSON line as a dict.
 """
-import time
-
 import torch
 import torch.distributed as dist
 
-HBM_PEAK_GBPS = 8000.0
+from benchlib import timing
+from benchlib.options import HBM_PEAK_GBPS
+
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 
 
@@ -107,6 +107,7 @@ def run(args, base_alg_bytes, configs):
     from sk_gs_amd.view_slot import ViewTable
 
     rank, world, local_rank = init_distributed()
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree'
     use_dist = dist.is_initialized()
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(local_rank)
@@ -176,45 +177,13 @@ def run(args, base_alg_bytes, configs):
         view_table.rewind()
     for i in range(max(args.warmup, 2)):
         train_step(i)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    n_blocks = min(args.steps, 10)
-    edges = [round(b * args.steps / n_blocks) for b in range(n_blocks + 1)]
-    marks = [torch.cuda.Event(enable_timing=True) for _ in edges]
-    t0 = time.perf_counter()
-    marks[0].record()
-    nxt = 1
-    for i in range(args.steps):
-        train_step(args.warmup + i)
-        if i + 1 == edges[nxt]:
-            marks[nxt].record()
-            nxt += 1
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    per_step = sorted(marks[b].elapsed_time(marks[b + 1]) / (edges[b + 1] - edges[b]) for b in range(n_blocks))
-    block_stats = dict(blocks=n_blocks, median=round(per_step[n_blocks // 2], 4), p10=round(per_step[n_blocks // 10], 4),
-                       p90=round(per_step[min(n_blocks - 1, (9 * n_blocks) // 10)], 4), min=round(per_step[0], 4),
-                       max=round(per_step[-1], 4),
-                       how='HIP events on the launch stream every steps/blocks steps inside the timed region (rank 0)')
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, block_stats = timing.timed_steps(train_step, args.steps, args.warmup, dev)
     st = step.status()
     assert st['overflow_events'] == 0, 'binning capacity overflow during the timed region: result invalid'
     assert st['pairs_overflow'] == 0, 'a superpoint\'s inverse neighbour list overflowed: result invalid'
     # ---- per-kernel HIP-event timing: an eager pass over the same steps
-    _C.profile_enable(None)
     n_prof = min(args.steps, 20)
-    for i in range(n_prof):
-        eager_step(args.warmup + args.steps + i)
-    torch.cuda.synchronize()
-    prof = _C.profile_collect()
-    _C.profile_enable([])
+    prof = timing.profiled_eager_pass(_C, eager_step, args.warmup + args.steps, n_prof)
     rows_b = 28 * sum(p.numel() for g in opt.param_groups if g.get('name') in train.rows for p in g['params'])
     rest_b = 28 * sum(p.numel() for g in opt.param_groups if g.get('name') in train.rest for p in g['params'])
     kernels = {}
@@ -225,9 +194,7 @@ def run(args, base_alg_bytes, configs):
             b = base_alg_bytes(name, P, M, K, W, H, R_mean)
         if name == 'adam':
             b = rest_b if train.fused else rows_b + rest_b
-        rec = dict(us=round(us, 2), launches_per_step=round(n / n_prof, 2), alg_MB=round(b / 1e6, 2) if b else None,
-                   GBps=round(b / (us * 1e-6) / 1e9, 1) if b else None,
-                   frac_of_hbm_peak=round(b / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if b else None)
+        rec = timing.kernel_record(us, n / n_prof, b)
         if name in ('sp_net_forward', 'sp_net_backward'):
             fl = net_flops(M)[0 if name == 'sp_net_forward' else 1]
             rec['TFLOPs'] = round(fl / (us * 1e-6) / 1e12, 2)

@@ -304,3 +304,46 @@ def test_bench_gpus_flag_without_a_launcher_spawns_or_refuses():
     if not torch.cuda.is_available():
         assert p.returncode == 2 and 'only 0 device(s) visible' in p.stderr and p.stdout.strip() == '', (p.returncode, p.stderr[-500:])
     assert isinstance(launch.free_port(), int)
+
+
+def test_bench_pieces_are_importable_without_a_gpu():
+    """bench.py is a dispatcher over importable pieces (benchlib/): the tables and the command line, the exchange
+    ranking's summary, the per-kernel record and the roofline object can be used (and are checked here) without a GPU."""
+    import bench
+    from benchlib import exchange_rank, options, roofline, timing
+    assert bench.CONFIGS is options.CONFIGS and bench.alg_bytes is options.alg_bytes
+    a = options.build_parser().parse_args([])
+    assert (a.gpus, a.config, a.stage, a.exchange) == (1, 1, 'sk', 'auto') and not options.exchange_flags_given(a)
+    assert options.exchange_name(a, 1) is None and options.exchange_name(a, 2) == 'allreduce'
+    # the predicted-best eager variant is timed first, the captured-collective ones last (VERDICT r3 #5d)
+    order = list(options.EXCHANGE_VARIANTS)
+    assert order[0] == 'factors' and order[1] == 'allreduce' and all(n.endswith(('-graph', '-graph-split')) for n in order[-3:])
+    for name, flags in options.EXCHANGE_VARIANTS.items():
+        b = options.build_parser().parse_args(['--exchange', name])
+        assert options.exchange_flags_given(b)
+        options.apply_exchange(b, name)
+        assert all(getattr(b, k) == v for k, v in flags.items())
+    # SURVEY 8(d): the per-kernel figures add up to less than the whole-step figure (which also counts the skinning and the loss)
+    c = options.CONFIGS[1]
+    dims = (c['P'], c['M'], c['K'], c['W'], c['H'], 1_000_000)
+    assert options.alg_bytes('render_backward', *dims) == 40 * 1_000_000 + 24 * 800 * 800 + 44 * 100_000
+    assert options.alg_bytes('no_such_kernel', *dims) is None
+    assert options.whole_step_bytes(*dims) > sum(options.alg_bytes(k, *dims) for k in ('render_forward', 'render_backward'))
+    rec = timing.kernel_record(10.0, 1.0, 40_000_000)
+    assert rec == dict(us=10.0, launches_per_step=1.0, alg_MB=40.0, GBps=4000.0, frac=0.5)
+    assert timing.kernel_record(10.0, 1.0, None)['GBps'] is None
+    # ranking: the fastest variant whose replicas stayed identical; a faster one that drifted is listed, not chosen
+    mk = lambda v, same: dict(value=v, ms_per_step=1.0 / v, config=dict(parallelism='x', replicas_identical=same, param_digest=1.0))  # noqa: E731
+    best, summary = exchange_rank.summarise({'factors': mk(10.0, True), 'allreduce': mk(8.0, True), 'pipeline': mk(12.0, ['_xyz'])},
+                                            {'factors-graph': 'needs the RCCL backend'}, aborted='allreduce-graph')
+    assert best == 'factors' and summary['pipeline']['replicas_identical'] == ['_xyz']
+    assert summary['factors-graph']['error'] == 'needs the RCCL backend' and 'abandoned' in summary['allreduce-graph']['error']
+    assert summary['factors-overlap']['error'] == 'not run'
+    # the roofline object: contract keys, the committed counter profile as the traffic source when it is of this workload
+    r = roofline.render_backward_roofline({'render_backward': (2.0, 20)}, c, 1_000_000, 8_000_000, 0.37)
+    assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'whole_step', 'traffic_source'} <= set(r)
+    assert abs(r['achieved'] - options.alg_bytes('render_backward', *dims) / 100e-6 / 1e9) < 0.01 and r['peak'] == 8000.0
+    assert abs(r['frac'] - r['achieved'] / 8000.0) < 1e-4 and 0 < r['whole_step']['frac'] < 1
+    prof = roofline.committed_counter_profile(c['name'])
+    assert (r['traffic'] is None) == (prof is None or prof.get('hbm_bytes_per_launch') is None)
+    assert roofline.committed_counter_profile('no-such-workload') is None
