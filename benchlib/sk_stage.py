@@ -545,18 +545,6 @@ def kernel_table(args, s, t, prof_all, passes):
 
 
 # ------------------------------------------------------------------------------------------------ one measurement
-def replicas_digest(model, world):
-    """view-parallel replicas must stay bit-identical: same reduced gradients, same Adam step on every rank.  Returns
-    (True | names of the parameters that differ, sum |p| over all parameters on this rank: compares exchange modes)"""
-    names = [n for n, _ in model.named_parameters()]
-    digest = torch.stack([p.detach().double().sum() for p in model.parameters()] +
-                         [p.detach().double().abs().sum() for p in model.parameters()])
-    every = [torch.empty_like(digest) for _ in range(world)]
-    dist.all_gather(every, digest)
-    differ = sorted({names[i % len(names)] for e in every for i in (every[0] != e).nonzero().flatten().tolist()})
-    return (True if not differ else differ), float(digest[len(names):].sum())
-
-
 def run(args, env):
     """one complete measurement of the workload with the exchange / step options in `args`: builds the scene and the runtime from
     scratch (seed 0), captures, warms up, times exactly args.steps steps between barriers.  Returns the JSON line as a dict on
@@ -594,7 +582,7 @@ def run(args, env):
     adam_desc = describe_adam(x, t)
     prof = _C.profile_collect()
     _C.profile_enable([])
-    replicas_identical, param_digest = replicas_digest(model, world) if env.use_dist else (None, None)
+    replicas_identical, param_digest = timing.replicas_digest(model, world) if env.use_dist else (None, None)
     if fstep is not None:  # sticky device-side counter of forwards whose tile lists exceeded the capacity
         st = fstep.status()
         t.overflow += st['overflow_events']

@@ -178,6 +178,7 @@ def run(args, base_alg_bytes, configs):
     for i in range(max(args.warmup, 2)):
         train_step(i)
     elapsed, block_stats = timing.timed_steps(train_step, args.steps, args.warmup, dev)
+    replicas_identical, param_digest = timing.replicas_digest(model, world) if use_dist else (None, None)
     st = step.status()
     assert st['overflow_events'] == 0, 'binning capacity overflow during the timed region: result invalid'
     assert st['pairs_overflow'] == 0, 'a superpoint\'s inverse neighbour list overflowed: result invalid'
@@ -237,6 +238,7 @@ def run(args, base_alg_bytes, configs):
                    'adam': ('per-Gaussian rows on the idle CUs of the sp net\'s row-block backward launch; network + superpoint '
                             'tables + counter + next view in one closing launch') if train.fused else 'one launch after the all-reduce',
                    'step': 'FusedSuperpointStep (direct C-ABI calls)', 'cluster': cluster,
+                   'exchange': 'allreduce' if world > 1 else None, 'replicas_identical': replicas_identical, 'param_digest': param_digest,
                    'gaussian_order': 'as generated (random)' if args.keep_order else
                    'sorted along a Z-order curve (densify.sort_spatially: what a training loop does after each densification event)'},
         'cpu_baseline': cpu,

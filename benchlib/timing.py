@@ -64,3 +64,15 @@ def profiled_eager_pass(_C, eager_step, first, count):
     prof = _C.profile_collect()
     _C.profile_enable([])
     return prof
+
+
+def replicas_digest(model, world):
+    """view-parallel replicas must stay bit-identical: same reduced gradients, same Adam step on every rank.  Returns
+    (True | names of the parameters that differ, sum |p| over all parameters on this rank: compares exchange modes)"""
+    names = [n for n, _ in model.named_parameters()]
+    digest = torch.stack([p.detach().double().sum() for p in model.parameters()] +
+                         [p.detach().double().abs().sum() for p in model.parameters()])
+    every = [torch.empty_like(digest) for _ in range(world)]
+    dist.all_gather(every, digest)
+    differ = sorted({names[i % len(names)] for e in every for i in (every[0] != e).nonzero().flatten().tolist()})
+    return (True if not differ else differ), float(digest[len(names):].sum())

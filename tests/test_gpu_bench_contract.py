@@ -213,3 +213,44 @@ def test_gpus_flag_without_launcher_starts_the_ranks_itself():
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     d = json.loads([l for l in p.stdout.splitlines() if l.strip().startswith('{')][-1])
     assert d['n_gpus'] == 2 and d['config']['cluster']['world'] == 2 and d['config']['replicas_identical'] is True
+
+
+def test_stage_sp_prints_the_contract_line():
+    """`bench.py --stage sp`: the superpoint stage at config #1's size -- the same contract fields, the stage's own
+    kernels in the table (the MFMA network against the fp32 matrix peak, the search against its algorithmic bytes)"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--stage', 'sp', '--steps', '8', '--warmup', '2',
+                        '--no-cpu-baseline'], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'kernels'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['config']['stage'] == 'sp' and '512 superpoints' in d['config']['workload']
+    assert abs(d['value'] - 1000.0 / d['ms_per_step']) / d['value'] < 0.01
+    k = d['kernels']
+    for name in ('sp_net_forward', 'sp_net_backward', 'sp_knn_weights', 'deform_forward', 'deform_backward', 'render_forward',
+                 'render_backward', 'adam'):
+        assert k[name]['us'] > 0 and 0 < k[name]['frac'] < 1, (name, k[name])
+    assert 0 < k['sp_net_forward']['frac_of_mfma_f32_peak'] < 1 and k['sp_net_forward']['TFLOPs'] > 1
+    total = sum(v['us'] * v['launches_per_step'] for v in k.values())
+    assert 0.8 * d['ms_per_step'] * 1e3 < total < 1.6 * d['ms_per_step'] * 1e3
+    assert d['ms_per_step'] < 1.0  # (0.49 ms when written: within 1.5x of the skeleton stage's step)
+
+
+def test_stage_sp_two_ranks_share_the_gpu_and_stay_identical():
+    """the superpoint stage view-parallel: graph(forward + backward) | ONE all-reduce of the flat gradient buffer | graph(Adam);
+    two ranks on this one GPU over gloo must end with bit-identical replicas"""
+    env = dict(os.environ, SKGS_DIST_BACKEND='gloo', SKGS_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29597', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--stage', 'sp', '--steps', '6', '--warmup', '2',
+           '--no-cpu-baseline']
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['replicas_identical'] is True and d['config']['exchange'] == 'allreduce'
+    assert d['config']['cluster']['world'] == 2
+    assert abs(d['value'] - 2 * 1000.0 / d['ms_per_step']) / d['value'] < 0.01
