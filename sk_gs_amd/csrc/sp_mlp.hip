@@ -12,18 +12,15 @@
 // 512 rows x 256 x 256 per layer is where the matrix cores pay: 0.5 GFLOP forward, 1 GFLOP backward, all
 // fp32 (v_mfma_f32_16x16x4_f32: exact f32, one rounding per product -- MI355X_MICROARCH "FP32-input MFMA").
 //
-//   forward    ONE launch.  The ROWS are independent, so a workgroup takes 16 superpoints through the WHOLE network: no
-//              exchange between workgroups, no barrier across the grid.  4 waves; wave w owns output features [64w, 64w+64) of
-//              every layer as four 16x16 tiles.  The 16 x 256 activation block lives in LDS (two buffers), the weights
-//              stream from L2 (2.3 MB for all layers: every XCD's 4 MB L2 holds them after the first touch).
-//              K-permutation: lane (j, q) loads ONE float4 of weight row j -- columns 16s + 4q .. +3 -- per tile and step and
-//              feeds component t to MFMA t, so MFMA t contracts k in {16s + 4q + t}; the activation operand is the matching
-//              float4 from LDS.  1 ds_read_b128 + 4 global_load_dwordx4 per 16 MFMAs.
-//   backward A the same row blocks walk back: gZ = gY * (Y > 0), gX = gZ W.  Column interleave: lane (j, q) loads one float4 of
-//              weight row o = 16s + 4q + t at input columns n0 + 4j .. +3 and component c goes to tile c, so tile c holds
-//              input features {n0 + 4j + c}: again 4 x dwordx4 per 16 MFMAs, and every lane ends with float4s of consecutive
-//              features (16-byte stores).  Every layer's gZ is saved for launch B.  The launch occupies M / 16 = 32 CUs; its
-//              other workgroups run an optimizer piece (skgs_adam_range, as skgs_skeleton_backward does).
+//   forward    The ROWS are independent, so a workgroup takes FOUR superpoints through the WHOLE network: 128 workgroups, no
+//              exchange between them, no barrier across the grid.  The weights stream from L2 (2 MB for all layers: every
+//              XCD's 4 MB L2 holds them after the first touch) as rows of a TRANSPOSED copy ([contraction index][256 outputs],
+//              written by a small launch in front: nn.Linear stores [out][in]) straight into the B operands of
+//              v_mfma_f32_4x4x1_16B_f32; the 8 waves split the contraction, their partial tiles meet in LDS (`stream_rows`).
+//   backward A the same row blocks walk back: gZ = gY * (Y > 0), gX = gZ W -- here the contraction index IS the row of nn.Linear's
+//              matrix, so the stream reads the parameters themselves.  Every layer's gZ is saved for launch B.  The launch
+//              occupies M / 4 = 128 CUs; its other workgroups run an optimizer piece (skgs_adam_range, as skgs_skeleton_backward
+//              does).
 //   backward B all weight gradients gW_l = gZ_l^T X_l (K = the 512 rows) as 64 x 64 output tiles on the whole chip: 132
 //              workgroups, the rows split over the 4 waves and summed through LDS; bias gradients = column sums of gZ_l; the
 //              time network's backward in the workgroup that finishes last (d loss / d t_emb = gb_0 W_0[:, 63:93] + gb_5
@@ -50,41 +47,40 @@ constexpr int TDIM   = 1 + 2 * TDEG;         // 13
 constexpr int THID   = 256, TOUT = 30;
 constexpr int IN0    = PDIM + TOUT;          // 93
 constexpr int IN0P   = 96;                   // padded row of the saved encoded input
-constexpr int ROWS   = 16;                   // superpoints per workgroup = the MFMA tile's rows
-constexpr int NT     = 512;                  // 8 waves: two per SIMD, each owns 32 features (two 16x16 tiles) of every layer
+constexpr int ROWS   = 16;                   // row padding of the saved activations (the weight-gradient launch walks 16-row steps)
+constexpr int RB     = 4;                    // superpoints per workgroup of the row-block launches = one 4 x 4 MFMA row group
+constexpr int NT     = 512;                  // 8 waves: two per SIMD; wave w takes every 8th contraction row of every layer
 constexpr int NTB    = 512;                  // the weight-gradient launch: 8 waves, the rows (the contraction) split over them
 constexpr int NWB    = NTB / 64;
 constexpr int NWAVE  = NT / 64;
-constexpr int FPW    = SPW / NWAVE;          // features per wave (32)
-constexpr int PITCH  = SPW + 4;              // LDS row pitch of an activation block (floats)
-constexpr int XPITCH = IN0P + 4;
+constexpr int RING_F = 32, RING_B = 32;      // weight rows (1 KB each) a wave keeps in flight, forward / backward
+constexpr int HT     = 36;                   // LDS pitch of a transposed activation row [r & 7][r >> 3]: 32 + 4
+constexpr int XT     = 16;                   // ... of the encoded input: 12 + 4
 constexpr int NOUT   = 10;                   // d_xyz 3 | d_rotation 4 | d_scaling 3
 
 struct __attribute__((packed, aligned(4))) f4u {  // a float4 at 4-byte alignment (weight rows of 93 / 349 floats)
   float x, y, z, w;
 };
 __device__ __forceinline__ float4 ldg4(const float* p) {
-#ifdef SPX_NO_LOAD  // timing experiment: no weight traffic
-  const float f = __builtin_bit_cast(float, (uint32_t) (uintptr_t) p);
-  return make_float4(f, f, f, f);
-#else
   const f4u v = *reinterpret_cast<const f4u*>(p);
   return make_float4(v.x, v.y, v.z, v.w);
-#endif
 }
-__device__ __forceinline__ float4 ldg4_guard(const float* p, int valid) {  // elements [0, valid) exist
-  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (valid >= 4) return ldg4(p);
-  if (valid > 0) r.x = p[0];
-  if (valid > 1) r.y = p[1];
-  if (valid > 2) r.z = p[2];
-  return r;
-}
-#ifndef SPX_NO_MFMA
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-#else  // timing experiment: the operands are consumed, the matrix pipe is not used
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { c[0] += a * b; return c; }
-#endif
+// v_mfma_f32_4x4x1_16B_f32: 16 independent 4 x 4 outer products, D_b[i][j] += A_b[i] B_b[j]; lane 4 b + i holds A_b[i], lane
+// 4 b + j holds B_b[j], register i of lane 4 b + j holds D_b[i][j] (checked on the chip: tools/micro/mfma4x4_layer.hip)
+__device__ __forceinline__ f32x4 mfma1(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
+// forward stream of a wave: contraction rows per layer / 8 (the encoded input is padded to 96 columns; layer 5 contracts
+// [input 96 | hidden 256]) and where a layer starts in the flattened sequence
+__host__ __device__ constexpr int fwd_items(int l) { return l == 0 ? IN0P / 8 : (l == SKIP + 1 ? (IN0P + SPW) / 8 : SPW / 8); }
+__host__ __device__ constexpr int fwd_start(int l) {
+  int t = 0;
+  for (int i = 0; i < l; ++i) t += fwd_items(i);
+  return t;
+}
+constexpr int FWD_TOTAL = fwd_start(SPD);   // 248 items per wave
+constexpr int WT_ROWS   = 8 * FWD_TOTAL;    // 1984 rows of 256 floats (2.03 MB)
+constexpr int BWD_TOTAL = (SPD - 1) * SPW / 8;  // 224: layers 7 .. 1, 32 rows each per wave
 
 // saved by the forward for the backward (floats), Mp = rows rounded up to 16
 struct SavedView {
@@ -94,11 +90,12 @@ struct SavedView {
   float* temb;  // [16]         freq(t) (13 used)
   float* thid;  // [THID]       hidden layer of the time network (post-ReLU)
   float* tout;  // [32]         its output (30 used)
+  float* wt;    // [WT_ROWS][SPW] the hidden layers' weights with the CONTRACTION index as the row (written by every forward)
 };
 __host__ __device__ inline int pad_rows(int M) { return (M + ROWS - 1) / ROWS * ROWS; }
 __host__ __device__ inline size_t saved_floats(int M) {
   const size_t Mp = pad_rows(M);
-  return Mp * IN0P + (size_t) SPD * Mp * SPW + Mp * 4 + 16 + THID + 32;
+  return Mp * IN0P + (size_t) SPD * Mp * SPW + Mp * 4 + 16 + THID + 32 + (size_t) WT_ROWS * SPW;
 }
 __host__ __device__ inline SavedView saved_view(void* base, int M) {
   const size_t Mp = pad_rows(M);
@@ -109,10 +106,11 @@ __host__ __device__ inline SavedView saved_view(void* base, int M) {
   v.rawq = p, p += Mp * 4;
   v.temb = p, p += 16;
   v.thid = p, p += THID;
-  v.tout = p;
+  v.tout = p, p += 32;
+  v.wt = p;
   return v;
 }
-// backward workspace: (256 B reserved) | GH [Mp][16] head cotangents (10 used) | GZ [SPD][Mp][SPW] | GBP [2][Mp / 16][SPW]: the
+// backward workspace: (256 B reserved) | GH [Mp][16] head cotangents (10 used) | GZ [SPD][Mp][SPW] | GBP [2][Mp / 4][SPW]: the
 // row blocks' column sums of gZ_0 and gZ_5 (the time network's backward needs the bias gradients of those two layers)
 struct WorkView {
   unsigned* ticket;
@@ -122,7 +120,7 @@ struct WorkView {
 };
 __host__ __device__ inline size_t work_bytes(int M) {
   const size_t Mp = pad_rows(M);
-  return 256 + (Mp * 16 + (size_t) SPD * Mp * SPW + 2 * (Mp / ROWS) * SPW) * 4;
+  return 256 + (Mp * 16 + (size_t) SPD * Mp * SPW + 2 * (Mp / RB) * SPW) * 4;
 }
 __host__ __device__ inline WorkView work_view(void* base, int M) {
   const size_t Mp = pad_rows(M);
@@ -148,124 +146,61 @@ struct SideAdam {
 __host__ __device__ inline int layer_ld(int l) { return l == 0 ? IN0 : (l == SKIP + 1 ? IN0 + SPW : SPW); }
 __host__ __device__ inline int layer_hofs(int l) { return l == SKIP + 1 ? IN0 : 0; }
 
-// ---- weight operands go through a per-wave LDS staging area ---------------------------------------------------------------
-// A 16x16 MFMA tile wants lane (j, q) to hold row j of the weight matrix: a wave instruction that loads the operand straight
-// from global memory touches 16 rows x 64 B -- HALF cache lines -- and one workgroup then pulls its 2.3 MB of weights at
-// 37 GB/s (56 us for the eight layers; 8 rows x 128 B or 1 row x 1 KB per instruction: 135 GB/s = the L1's 64 B/clk, 15.5 us;
-// tools/micro/weight_stream_patterns.hip, MI355X).  So every wave loads its slab of the weights with full-line instructions
-// (4 rows x 256 B forward, 8 rows x 128 B backward), parks it in a PRIVATE LDS region (no barrier: LDS instructions of one
-// wave execute in order) and reads the MFMA operand back from there.  The next chunk's global loads are in flight while the
-// current chunk's MFMAs run; the other wave of the SIMD covers the write -> read turn-around.
-constexpr int ST_P        = 36;              // stage row pitch: 32 values + 4 (both directions)
-constexpr int ST_BUF      = 32 * ST_P;       // one buffer: forward [32 features][32 k], backward [32 outputs][32 inputs]
-constexpr int STAGE_F     = 2 * ST_BUF;      // floats per wave: two buffers
-constexpr size_t STAGE_BYTES = (size_t) NWAVE * STAGE_F * 4;
-
-// The pipeline of one wave (both directions), chunks of 32 along the contraction, TWO stage buffers: in program order
-//     ds_read  operands of chunk c        (buffer c & 1)
-//     ds_write chunk c + 1                (the other buffer; its global loads were issued two chunks ago)
-//     global loads of chunk c + 3
-//     16 MFMAs of chunk c
-// so the LDS write of the next chunk and the loads behind it are in flight while the matrix pipe works (LDS instructions of one
-// wave execute in order: the MFMAs wait with lgkmcnt(4), not 0).  With ONE buffer the write had to follow the reads' MFMAs: LDS
-// time (2.1 us per layer and CU) and MFMA time (3.4 us) added up -- 54 us for the eight layers against 38 without staging.
-
-// Forward product of one layer part.  Tile c (c = 0, 1) of a wave holds output features f0 + 2 j + c (f0 = 32 wave): a lane
-// ends with two CONSECUTIVE features per row.  acc[c] += A[16 x 32 NCH] W^T with A from LDS (row pitch pa) and W rows at stride
-// ldw from column kofs.  `kvalid` = valid weight columns from kofs (the 93-wide input part is guarded).  Global pattern of a
-// chunk: lane -> row L / 8 + 8 i, 16 B at column 4 (L % 8): 8 rows x 128 B per instruction.
-template <int NCH, bool GUARD>
-__device__ __forceinline__ void gemm_fwd(f32x4 (&acc)[2], const float* sA, int pa, const float* __restrict__ W, int ldw, int kofs,
-    int kvalid, int wave, int lane, float* sw) {
-  const int j = lane & 15, q = lane >> 4;
-  const float* arow = sA + j * pa + 4 * q;
-  const int lr = lane >> 3, lc = 4 * (lane & 7);
-  const float* wb = W + (size_t) (FPW * wave + lr) * ldw + kofs + lc;
-  float* wr       = sw + lr * ST_P + lc;
-  const float* rd = sw + (2 * j) * ST_P + 4 * q;
-  float4 g[3][4];
-  auto fetch = [&](int ck, float4 (&dst)[4]) {
+// ---- the product of a row block with a weight matrix, streamed -----------------------------------------------------------
+// Found with tools/micro/mfma4x4_layer.hip (MI355X).  A CU pulls weights out of L2 at most at its L1's 64 B/clk (~1.7 us for a
+// 256 x 256 fp32 layer), and only with wave instructions whose consecutive lanes read consecutive addresses; the fp32 matrix
+// pipe does 128 multiply-adds per clock and CU.  Round 4 first ran 16-row blocks on v_mfma_f32_16x16x4_f32: 32 workgroups,
+// 3.4 us of MFMA issue per layer each and the operand re-shaped through LDS -- 5.7 us per layer.  Here a workgroup takes FOUR
+// rows (128 workgroups for 512 superpoints) on v_mfma_f32_4x4x1_16B_f32 with the weights stored with the CONTRACTION index as
+// the row ([r][256 outputs]: nn.Linear's own layout for the backward, a transposed copy for the forward):
+//   * lane l loads outputs 4 l .. 4 l + 3 of row r -- one row x 1 KB per wave instruction, straight into the B operands of four
+//     MFMAs (register q: block b, column j <-> output 16 b + 4 j + q); the A operand x[i][r] is the same in all 16 blocks;
+//   * the 8 waves split the contraction: wave w takes rows r = 8 t + w.  32 rows per wave (256 KB per CU: a whole
+//     layer) are in flight at any time, each register refilled with the row 32 steps ahead right after its MFMAs -- across
+//     layer boundaries, the sequence of a wave is one flat list (everything below is unrolled: the waits are exact vmcnt);
+//   * the waves' partial [4 x 256] tiles meet in LDS (32 KB), two barriers per layer.
+// 2.5 us per layer instead of 5.7 (the micro: 4 rows / 8 waves; 8 rows per workgroup 3.5, no split 2.6).
+// Activations live in LDS transposed, [row][r & 7][r >> 3], so that the A operands of four steps are one ds_read_b128.
+template <int T0, int NR, int TOTAL, int RING, class RowPtr>
+__device__ __forceinline__ void stream_rows(f32x4 (&acc)[4], float4 (&ring)[RING], const float* ap, const RowPtr& row_ptr) {
+  static_assert(NR % 4 == 0, "four steps per operand read");
+  float4 a = *reinterpret_cast<const float4*>(ap);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float* p = wb + (size_t) (8 * i) * ldw + 32 * ck;
-      dst[i] = GUARD ? ldg4_guard(p, kvalid - (32 * ck + lc)) : ldg4(p);
-    }
-  };
-  auto park = [&](int ck, const float4 (&src)[4]) {
-    float* d = wr + (ck & 1) * ST_BUF;
+  for (int t4 = 0; t4 < NR / 4; ++t4) {
+    const float4 ac = a;
+    if (t4 + 1 < NR / 4) a = *reinterpret_cast<const float4*>(ap + 4 * (t4 + 1));
+    const float av[4] = {ac.x, ac.y, ac.z, ac.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(d + (8 * i) * ST_P) = src[i];
-  };
-  fetch(0, g[0]);
-  if (NCH > 1) fetch(1, g[1]);
-  if (NCH > 2) fetch(2, g[2]);
-  park(0, g[0]);
-#pragma unroll
-  for (int ck = 0; ck < NCH; ++ck) {
-    const float* r = rd + (ck & 1) * ST_BUF;
-    float4 a[2], b0[2], b1[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      a[s]  = *reinterpret_cast<const float4*>(arow + 32 * ck + 16 * s);
-      b0[s] = *reinterpret_cast<const float4*>(r + 16 * s);
-      b1[s] = *reinterpret_cast<const float4*>(r + ST_P + 16 * s);
-    }
-    if (ck + 1 < NCH) park(ck + 1, g[(ck + 1) % 3]);
-    if (ck + 3 < NCH) fetch(ck + 3, g[ck % 3]);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      acc[0] = mfma4(a[s].x, b0[s].x, acc[0]);
-      acc[1] = mfma4(a[s].x, b1[s].x, acc[1]);
-      acc[0] = mfma4(a[s].y, b0[s].y, acc[0]);
-      acc[1] = mfma4(a[s].y, b1[s].y, acc[1]);
-      acc[0] = mfma4(a[s].z, b0[s].z, acc[0]);
-      acc[1] = mfma4(a[s].z, b1[s].z, acc[1]);
-      acc[0] = mfma4(a[s].w, b0[s].w, acc[0]);
-      acc[1] = mfma4(a[s].w, b1[s].w, acc[1]);
+    for (int e = 0; e < 4; ++e) {
+      const int t = T0 + 4 * t4 + e, slot = t % RING;
+      acc[0] = mfma1(av[e], ring[slot].x, acc[0]);
+      acc[1] = mfma1(av[e], ring[slot].y, acc[1]);
+      acc[2] = mfma1(av[e], ring[slot].z, acc[2]);
+      acc[3] = mfma1(av[e], ring[slot].w, acc[3]);
+      __builtin_amdgcn_sched_barrier(0);  // (left alone the compiler sinks every refill to the end of the layer: load phase,
+      if (t + RING < TOTAL) ring[slot] = ldg4(row_ptr(t + RING));  // then MFMA phase, 3.3 us per layer)
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-  __builtin_amdgcn_wave_barrier();
 }
-
-// Backward product: tile c holds INPUT features n0 + 2 j + c (n0 = 32 wave); acc[c] += gZ[16 x 256] W[:, kofs + n0 ...], the
-// contraction over the layer's 256 output features in chunks of 64: the wave's [64 outputs][32 inputs] block of W is loaded
-// as 8 rows x 128 B per instruction, staged in ONE buffer (the whole stage area), and read back as one float2 per (output
-// o = 16 s + 4 q + t, lane).  (The double-buffered 32-chunk pipeline of the forward was measured here too: 59.7 against 55.6 us --
-// the operand reads are 8-byte ones, twice the LDS instructions per MFMA of the forward, and the shorter chunks only add
-// overhead.)
-__device__ __forceinline__ void gemm_bwd(f32x4 (&acc)[2], const float* sA, int pa, const float* __restrict__ W, int ldw, int kofs,
-    int wave, int lane, float* sw) {
-  const int j = lane & 15, q = lane >> 4;
-  const float* arow = sA + j * pa + 4 * q;
-  const float* wb   = W + (size_t) (lane >> 3) * ldw + kofs + FPW * wave + 4 * (lane & 7);  // row L / 8 + 8 i, 16 B at 4 (L % 8)
-  float* wr         = sw + (lane >> 3) * ST_P + 4 * (lane & 7);
-  const float* rd   = sw + (4 * q) * ST_P + 2 * j;
-  constexpr int NCH = SPW / 64;
-  float4 g[2][8];
-  auto fetch = [&](int ck, float4 (&dst)[8]) {
+// the wave's partial tile -> LDS.  Register i of acc[q] in lane l = row i, output 4 l + q
+__device__ __forceinline__ void park_partial(const f32x4 (&acc)[4], float (*part)[SPW], int lane) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dst[i] = ldg4(wb + (size_t) (64 * ck + 8 * i) * ldw);
-  };
-  fetch(0, g[0]);
+  for (int i = 0; i < RB; ++i)
+    *reinterpret_cast<float4*>(&part[i][4 * lane]) = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+}
+// thread (i = tid >> 7, o = 2 (tid & 127)): the 8 partials of two neighbouring outputs
+__device__ __forceinline__ float2 sum_partials(const float (*part)[RB][SPW], int i, int o, float2 v) {
 #pragma unroll
-  for (int ck = 0; ck < NCH; ++ck) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(wr + (8 * i) * ST_P) = g[ck & 1][i];
-    if (ck + 1 < NCH) fetch(ck + 1, g[(ck + 1) & 1]);
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const float4 a    = *reinterpret_cast<const float4*>(arow + 16 * (4 * ck + s));
-      const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float2 b = *reinterpret_cast<const float2*>(rd + (16 * s + t) * ST_P);
-        acc[0] = mfma4(av[t], b.x, acc[0]);
-        acc[1] = mfma4(av[t], b.y, acc[1]);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
+  for (int w = 0; w < NWAVE; ++w) {
+    const float2 p = *reinterpret_cast<const float2*>(&part[w][i][o]);
+    v.x += p.x, v.y += p.y;
   }
+  return v;
+}
+__device__ __forceinline__ void zero4(f32x4 (&acc)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
 struct NetPtrs {  // device copy of skgs_sp_net's pointers
@@ -291,16 +226,58 @@ __device__ __forceinline__ int head_of(int o, int& row) {  // raw output column 
 }
 
 // =================================================================================================== forward
+// The hidden layers' weights with the contraction index as the row, for the forward's stream: layer 0 [96][256] (rows 93..95
+// zero), layers 1-4, 6, 7 [256][256], layer 5 [96 | 256][256] (its input part padded like layer 0, then the hidden part) --
+// WT_ROWS = 1984 rows.  32 x 32 tiles through LDS; a tile never straddles two layers (96, 256, 352 are multiples of 32).
+__global__ void __launch_bounds__(256) sp_net_transpose_kernel(NetPtrs n, float* __restrict__ wt) {
+  __shared__ float tile[32][33];
+  const int rb = blockIdx.x >> 3, nb = blockIdx.x & 7, R0 = 32 * rb;
+  int l = 0, base = 0;
+  for (; l < SPD - 1; ++l) {
+    if (R0 < base + 8 * fwd_items(l)) break;
+    base += 8 * fwd_items(l);
+  }
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, rl = R0 - base + tx;  // rl: the row inside the layer
+  int k = rl;
+  bool valid = true;
+  if (l == 0) valid = rl < IN0;
+  if (l == SKIP + 1) {
+    if (rl < IN0P) valid = rl < IN0;
+    else k = IN0 + rl - IN0P;
+  }
+  const float* W = n.W[l];
+  const int ld   = layer_ld(l);
+#pragma unroll
+  for (int yy = ty; yy < 32; yy += 8) tile[yy][tx] = valid ? W[(size_t) (32 * nb + yy) * ld + k] : 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int yy = ty; yy < 32; yy += 8) wt[(size_t) (R0 + yy) * SPW + 32 * nb + tx] = tile[tx][yy];
+}
+
+struct FwdRows {  // item t of wave w = row 8 t + w of the transposed weights
+  const float* wt;
+  int at;  // wave * SPW + 4 * lane
+  __device__ __forceinline__ const float* operator()(int t) const { return wt + (uint32_t) (t * (8 * SPW) + at); }
+};
+
 __global__ void __launch_bounds__(NT) sp_net_forward_kernel(int M, NetPtrs n, float* __restrict__ raw, float* __restrict__ bone_T,
     float* __restrict__ d_rot, float* __restrict__ d_scale, SavedView sv) {
-  __shared__ __attribute__((aligned(16))) float s_x0[ROWS * XPITCH];
-  __shared__ __attribute__((aligned(16))) float s_act[2][ROWS * PITCH];
+  __shared__ __attribute__((aligned(16))) float s_x0t[RB][8][XT];     // encoded input, transposed: [row][c & 7][c >> 3]
+  __shared__ __attribute__((aligned(16))) float s_ht[2][RB][8][HT];   // activations, two buffers, transposed likewise
+  __shared__ __attribute__((aligned(16))) float s_part[NWAVE][RB][SPW];
   __shared__ float s_temb[16], s_thid[THID], s_tout[32];
-  __shared__ __attribute__((aligned(16))) float s_head[NWAVE][ROWS][16];
-  extern __shared__ __attribute__((aligned(16))) float s_stage[];  // [NWAVE][STAGE_F]: the waves' private weight staging
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  float* sw = s_stage + wave * STAGE_F;
-  const int r0 = blockIdx.x * ROWS, Mp = pad_rows(M);
+  __shared__ float s_raw[RB][16];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i_ = lane & 3;
+  const int r0 = blockIdx.x * RB, Mp = pad_rows(M);
+  // ---- the first 32 weight rows of this wave are on their way while the time network runs
+  const int ei = tid >> 7, eo = 2 * (tid & 127);  // the thread's share of a layer's epilogue: row ei, outputs eo, eo + 1
+  float2 bias[SPD];  // (loaded FIRST: vmcnt counts in order -- a load issued at a layer's end would wait for the whole ring)
+#pragma unroll
+  for (int l = 0; l < SPD; ++l) bias[l] = *reinterpret_cast<const float2*>(n.b[l] + eo);
+  const FwdRows rows{sv.wt, wave * SPW + 4 * lane};
+  float4 ring[RING_F];
+#pragma unroll
+  for (int t = 0; t < RING_F; ++t) ring[t] = ldg4(rows(t));
   // ---- time network (every workgroup: 13 -> 256 -> 30 is ~11 k multiply-adds)
   if (tid < TDIM) {
     const float t = n.time[0];
@@ -334,9 +311,9 @@ __global__ void __launch_bounds__(NT) sp_net_forward_kernel(int M, NetPtrs n, fl
     if (tid < THID) sv.thid[tid] = s_thid[tid];
     if (tid < 32) sv.tout[tid] = tid < TOUT ? s_tout[tid] : 0.f;
   }
-  // ---- encoded input of the 16 rows: [x | sin / cos(2^f x) ...] (freqencoder.cu:7-31) | t_emb | 0 0 0
-  for (int e = tid; e < ROWS * IN0P; e += NT) {
-    const int row = e / IN0P, c = e - row * IN0P;
+  // ---- encoded input of the 4 rows: [x | sin / cos(2^f x) ...] (freqencoder.cu:7-31) | t_emb | 0 0 0
+  if (tid < RB * IN0P) {
+    const int row = tid / IN0P, c = tid - row * IN0P;
     const int gr = min(r0 + row, M - 1);  // (rows beyond M repeat the last one: computed, never stored outside `saved`)
     float v = 0.f;
     if (c < 3) {
@@ -347,66 +324,61 @@ __global__ void __launch_bounds__(NT) sp_net_forward_kernel(int M, NetPtrs n, fl
     } else if (c < IN0) {
       v = s_tout[c - PDIM];
     }
-    s_x0[row * XPITCH + c]                 = v;
+    s_x0t[row][c & 7][c >> 3]              = v;
     sv.x0[(size_t) (r0 + row) * IN0P + c] = v;
   }
   __syncthreads();
-  // ---- the eight layers
-  const int j = lane & 15, q = lane >> 4;
+  // ---- the eight layers: one flat stream of FWD_TOTAL items per wave
+  f32x4 acc[4];
   int cur = 0;
-  for (int l = 0; l < SPD; ++l) {
-    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    const float* W = n.W[l];
-    const int ldw  = layer_ld(l);
-    if (l == 0 || l == SKIP + 1) gemm_fwd<IN0P / 32, true>(acc, s_x0, XPITCH, W, ldw, 0, IN0, wave, lane, sw);
-    if (l > 0) gemm_fwd<SPW / 32, false>(acc, s_act[cur], PITCH, W, ldw, layer_hofs(l), SPW, wave, lane, sw);
-    float* out      = s_act[cur ^ 1] + FPW * wave + 2 * j;
-    float* Yl       = sv.Y + ((size_t) l * Mp + r0) * SPW + FPW * wave + 2 * j;
-    const float2 bb = *reinterpret_cast<const float2*>(n.b[l] + FPW * wave + 2 * j);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row  = 4 * q + r;
-      const float2 v = make_float2(fmaxf(acc[0][r] + bb.x, 0.f), fmaxf(acc[1][r] + bb.y, 0.f));
-      *reinterpret_cast<float2*>(out + row * PITCH)          = v;
-      *reinterpret_cast<float2*>(Yl + (size_t) row * SPW) = v;
-    }
+  auto close_layer = [&](int l) {  // partial tiles -> bias, ReLU -> the next layer's operand (LDS, transposed) and `saved`
+    park_partial(acc, s_part[wave], lane);
+    __syncthreads();
+    float2 v = sum_partials(s_part, ei, eo, bias[l]);
+    v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f);
+    *reinterpret_cast<float2*>(sv.Y + ((size_t) l * Mp + r0 + ei) * SPW + eo) = v;
+    s_ht[cur ^ 1][ei][eo & 7][eo >> 3]       = v.x;
+    s_ht[cur ^ 1][ei][(eo & 7) + 1][eo >> 3] = v.y;
     cur ^= 1;
     __syncthreads();
-  }
-  // ---- heads: raw[16 x 10] = h W_heads^T + b; the contraction split over the 8 waves (32 k each), summed through LDS
+  };
+  const float* ax = &s_x0t[i_][wave][0];
+#define SP_HID(T0)  stream_rows<T0, SPW / 8, FWD_TOTAL, RING_F>(acc, ring, &s_ht[cur][i_][wave][0], rows)
+#define SP_X0(T0)   stream_rows<T0, IN0P / 8, FWD_TOTAL, RING_F>(acc, ring, ax, rows)
+  zero4(acc), SP_X0(fwd_start(0)), close_layer(0);
+  zero4(acc), SP_HID(fwd_start(1)), close_layer(1);
+  zero4(acc), SP_HID(fwd_start(2)), close_layer(2);
+  zero4(acc), SP_HID(fwd_start(3)), close_layer(3);
+  zero4(acc), SP_HID(fwd_start(4)), close_layer(4);
+  zero4(acc), SP_X0(fwd_start(5)), SP_HID(fwd_start(5) + IN0P / 8), close_layer(5);
+  zero4(acc), SP_HID(fwd_start(6)), close_layer(6);
+  zero4(acc), SP_HID(fwd_start(7)), close_layer(7);
+#undef SP_HID
+#undef SP_X0
+  // ---- heads: raw[4 x 10] = h W_heads^T + b.  Thread (row i, output o, part p): the contraction indices k = 8 kk + p
   {
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int pp = tid & 7, o = (tid >> 3) & 15, i = tid >> 7;
     int hrow;
-    const int hd        = head_of(min(j, NOUT - 1), hrow);
-    const float* wr     = n.head_w[hd] + (size_t) hrow * SPW + FPW * wave + 4 * q;
-    const float* arow   = s_act[cur] + j * PITCH + FPW * wave + 4 * q;
-    const bool real_col = j < NOUT;
+    const int hd    = head_of(min(o, NOUT - 1), hrow);
+    const float* wr = n.head_w[hd] + (size_t) hrow * SPW + pp;
+    const float* hp = &s_ht[cur][i][pp][0];
+    float w[SPW / 8];
 #pragma unroll
-    for (int s = 0; s < FPW / 16; ++s) {
-      const float4 a = *reinterpret_cast<const float4*>(arow + 16 * s);
-      float4 b       = *reinterpret_cast<const float4*>(wr + 16 * s);
-      if (!real_col) b = make_float4(0.f, 0.f, 0.f, 0.f);
-      acc = mfma4(a.x, b.x, acc);
-      acc = mfma4(a.y, b.y, acc);
-      acc = mfma4(a.z, b.z, acc);
-      acc = mfma4(a.w, b.w, acc);
-    }
+    for (int kk = 0; kk < SPW / 8; ++kk) w[kk] = wr[8 * kk];  // (one round of loads)
+    float v = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s_head[wave][4 * q + r][j] = acc[r];
+    for (int kk = 0; kk < SPW / 8; ++kk) v += hp[kk] * w[kk];
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    if (pp == 0 && o < NOUT) s_raw[i][o] = v + n.head_b[hd][hrow];
   }
   __syncthreads();
-  if (tid < ROWS) {  // one thread per superpoint: the three raw outputs and the stage's epilogue (sk_gs.py:847)
+  if (tid < RB) {  // one thread per superpoint: the three raw outputs and the stage's epilogue (sk_gs.py:847)
     const int gr = r0 + tid;
     float o[NOUT];
 #pragma unroll
-    for (int c = 0; c < NOUT; ++c) {
-      int hrow;
-      const int hd = head_of(c, hrow);
-      float acc = 0.f;
-#pragma unroll
-      for (int w = 0; w < NWAVE; ++w) acc += s_head[w][tid][c];
-      o[c] = acc + n.head_b[hd][hrow];
-    }
+    for (int c = 0; c < NOUT; ++c) o[c] = s_raw[tid][c];
 #pragma unroll
     for (int c = 0; c < 4; ++c) sv.rawq[(size_t) gr * 4 + c] = o[3 + c];
     if (gr < M) {
@@ -452,22 +424,36 @@ __device__ __forceinline__ void side_adam_walk(const SideAdam& a, int wg, int n_
   }
 }
 
+struct BwdRows {  // item t of wave w: layer 7 - t / 32, row (output feature) 8 (t % 32) + w of that layer's weight matrix,
+  const float* W[SPD];  // the 256 columns of its hidden part
+  int wave, lane;
+  __device__ __forceinline__ const float* operator()(int t) const {
+    const int l = SPD - 1 - t / (SPW / 8), o = 8 * (t % (SPW / 8)) + wave;
+    return W[l] + (uint32_t) (o * layer_ld(l) + layer_hofs(l) + 4 * lane);  // (uniform base + 32-bit lane offset: one VGPR per address)
+  }
+};
+
 __global__ void __launch_bounds__(NT) sp_net_backward_rows_kernel(int M, int nblk, NetPtrs n, const float* __restrict__ g_bone_T,
     const float* __restrict__ g_d_rot, const float* __restrict__ g_d_scale, const float* __restrict__ g_raw, SavedView sv,
     WorkView wk, SideAdam side) {
-  if ((int) blockIdx.x >= nblk) {  // the CUs the 32 row blocks leave idle: an optimizer piece
+  if ((int) blockIdx.x >= nblk) {  // the CUs the row blocks leave idle: an optimizer piece
     side_adam_walk(side, (int) blockIdx.x - nblk, (int) gridDim.x - nblk);
     return;
   }
-  __shared__ __attribute__((aligned(16))) float s_gz[2][ROWS * PITCH];
-  __shared__ __attribute__((aligned(16))) float s_gh[ROWS][16];
-  extern __shared__ __attribute__((aligned(16))) float s_stage[];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  float* sw = s_stage + wave * STAGE_F;
-  const int j = lane & 15, q = lane >> 4;
-  const int r0 = blockIdx.x * ROWS, Mp = pad_rows(M);
+  __shared__ __attribute__((aligned(16))) float s_gzt[2][RB][8][HT];  // gZ of the current layer, transposed [row][o & 7][o >> 3]
+  __shared__ __attribute__((aligned(16))) float s_part[NWAVE][RB][SPW];
+  __shared__ float s_gh[RB][16];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i_ = lane & 3;
+  const int r0 = blockIdx.x * RB, Mp = pad_rows(M);
+  BwdRows rows;
+#pragma unroll
+  for (int l = 0; l < SPD; ++l) rows.W[l] = n.W[l];
+  rows.wave = wave, rows.lane = lane;
+  float4 ring[RING_B];
+#pragma unroll
+  for (int t = 0; t < RING_B; ++t) ring[t] = ldg4(rows(t));
   // ---- cotangent of the raw output row [d_xyz 3 | rotation 4 | scaling 3]
-  if (tid < ROWS) {
+  if (tid < RB) {
     const int gr = r0 + tid;
     float g[16];
 #pragma unroll
@@ -507,55 +493,60 @@ __global__ void __launch_bounds__(NT) sp_net_backward_rows_kernel(int M, int nbl
     }
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-      s_gh[tid][c]                     = g[c];
+      s_gh[tid][c]                        = g[c];
       wk.GH[(size_t) (r0 + tid) * 16 + c] = g[c];
     }
   }
   __syncthreads();
-  // ---- gY_7 = gH W_heads: K = 10 (three 4-steps), tile c = features {32 wave + 2 j + c}
-  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    const int o   = 4 * s + q;
-    const float a = s_gh[j][o];  // A[i = j][kk = q]
-    float2 b      = make_float2(0.f, 0.f);
-    if (o < NOUT) {
-      int hrow;
-      const int hd = head_of(o, hrow);
-      b = *reinterpret_cast<const float2*>(n.head_w[hd] + (size_t) hrow * SPW + FPW * wave + 2 * j);
-    }
-    acc[0] = mfma4(a, b.x, acc[0]);
-    acc[1] = mfma4(a, b.y, acc[1]);
-  }
+  // ---- thread (row ei, features eo, eo + 1) closes every layer: gZ_l = gY_l * (Y_l > 0) -> `GZ` (for launch B), the next
+  // product's operand (LDS, transposed), and this block's column sums of gZ_0 / gZ_5 (for the time network, launch B)
+  const int ei = tid >> 7, eo = 2 * (tid & 127);
+  const bool live = r0 + ei < M;  // rows beyond M carry no gradient (their activations are copies of the last row's)
   int cur = 0;
-  for (int l = SPD - 1; l >= 0; --l) {
-    // gZ_l = gY_l * (Y_l > 0): lane holds rows 4 q + r, features 32 wave + 2 j + {0, 1}
-    const float* Yl = sv.Y + ((size_t) l * Mp + r0) * SPW + FPW * wave + 2 * j;
-    float* GZl      = wk.GZ + ((size_t) l * Mp + r0) * SPW + FPW * wave + 2 * j;
-    float* sz       = s_gz[cur] + FPW * wave + 2 * j;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row   = 4 * q + r;
-      const float2 y  = *reinterpret_cast<const float2*>(Yl + (size_t) row * SPW);
-      const bool live = r0 + row < M;  // rows beyond M carry no gradient (their activations are copies of the last row's)
-      float2 g;
-      g.x = (live && y.x > 0.f) ? acc[0][r] : 0.f;
-      g.y = (live && y.y > 0.f) ? acc[1][r] : 0.f;
-      *reinterpret_cast<float2*>(sz + row * PITCH)           = g;
-      *reinterpret_cast<float2*>(GZl + (size_t) row * SPW) = g;
-    }
+  auto y_of = [&](int l) { return *reinterpret_cast<const float2*>(sv.Y + ((size_t) l * Mp + r0 + ei) * SPW + eo); };
+  auto close_layer = [&](int l, float2 gy, float2 y) {
+    const size_t at = ((size_t) l * Mp + r0 + ei) * SPW + eo;
+    float2 g;
+    g.x = (live && y.x > 0.f) ? gy.x : 0.f;
+    g.y = (live && y.y > 0.f) ? gy.y : 0.f;
+    *reinterpret_cast<float2*>(wk.GZ + at) = g;
+    s_gzt[cur][ei][eo & 7][eo >> 3]       = g.x;
+    s_gzt[cur][ei][(eo & 7) + 1][eo >> 3] = g.y;
     __syncthreads();
-    if ((l == 0 || l == SKIP + 1) && tid < SPW) {  // this block's column sums of gZ_l (for the time network, launch B)
+    if ((l == 0 || l == SKIP + 1) && tid < SPW) {
       float cs = 0.f;
 #pragma unroll
-      for (int row = 0; row < ROWS; ++row) cs += s_gz[cur][row * PITCH + tid];
+      for (int row = 0; row < RB; ++row) cs += s_gzt[cur][row][tid & 7][tid >> 3];
       wk.GBP[((size_t) (l == 0 ? 0 : 1) * nblk + blockIdx.x) * SPW + tid] = cs;
     }
-    if (l == 0) break;  // no gradient to the encoded input (the superpoint positions are detached)
-    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}, acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    gemm_bwd(acc, s_gz[cur], PITCH, n.W[l], layer_ld(l), layer_hofs(l), wave, lane, sw);
-    cur ^= 1;
+  };
+  {  // gY_7 = gH W_heads (K = 10)
+    float2 gy = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < NOUT; ++c) {
+      int hrow;
+      const int hd   = head_of(c, hrow);
+      const float2 w = *reinterpret_cast<const float2*>(n.head_w[hd] + (size_t) hrow * SPW + eo);
+      const float gc = s_gh[ei][c];
+      gy.x += gc * w.x, gy.y += gc * w.y;
+    }
+    close_layer(SPD - 1, gy, y_of(SPD - 1));
   }
+  // ---- gY_{l-1} = gZ_l W_l[:, hidden part], l = 7 .. 1: one flat stream of BWD_TOTAL items per wave.  (No gradient to the
+  // encoded input: the superpoint positions are detached.)
+  f32x4 acc[4];
+  float2 y_in;  // Y_{l-1} of this thread's two features, requested BEFORE the stream of layer l (vmcnt counts in order: a load
+                // issued at the layer's end would wait for the whole ring)
+#define SP_BACK(L)                                                                                              \
+  y_in = y_of((L) - 1);                                                                                         \
+  zero4(acc);                                                                                                   \
+  stream_rows<(SPD - 1 - (L)) * (SPW / 8), SPW / 8, BWD_TOTAL, RING_B>(acc, ring, &s_gzt[cur][i_][wave][0], rows);      \
+  park_partial(acc, s_part[wave], lane);                                                                        \
+  __syncthreads();                                                                                              \
+  cur ^= 1;                                                                                                     \
+  close_layer((L) - 1, sum_partials(s_part, ei, eo, make_float2(0.f, 0.f)), y_in);
+  SP_BACK(7) SP_BACK(6) SP_BACK(5) SP_BACK(4) SP_BACK(3) SP_BACK(2) SP_BACK(1)
+#undef SP_BACK
 }
 
 // The time network's backward (one workgroup of launch B).  t_emb is the same for every row, so
@@ -572,7 +563,7 @@ __device__ void timenet_backward(int M, const NetPtrs& n, const GradPtrs& g, con
   float* s_ghid = s_gt + 64;              // [256]
   const bool act = tid < SPW;             // (the launch has 512 threads; one per feature works here, all reach the barriers)
   if (act) {
-    const int nblk = Mp / ROWS;
+    const int nblk = Mp / RB;
     float gb0 = 0.f, gb5 = 0.f;  // bias gradients of layers 0 and 5, from the row blocks' partial sums (launch A)
     for (int b0 = 0; b0 < nblk; b0 += 16) {  // 32 loads in flight per round (a plain loop was one round trip per block)
       float v0[16], v5[16];
@@ -629,10 +620,16 @@ __device__ void timenet_backward(int M, const NetPtrs& n, const GradPtrs& g, con
 // job table: [0,112) hidden x hidden products of layers 1..7 (16 tiles of 64 x 64 each; layer 5 writes at column 93),
 // [112,120) layer 0 (256 x 93: 4 x 2 tiles), [120,128) layer 5's input part (256 x 93), [128,132) heads (10 x 256: 4 tiles of
 // 16 x 64).  Rows (the contraction) split over the 4 waves, partial tiles summed through LDS.
+constexpr double ROWS_LAUNCH_SHARE = 0.56;  // of the optimizer's side range: beside launch A; the rest beside launch B
 constexpr size_t WEIGHTS_LDS_BYTES = ((size_t) NWB * 64 * 65 + NWB * 64) * 4;
 constexpr int JOBS_HH = 7 * 16, JOBS_X0 = 8, JOBS_HEAD = 4, N_JOBS = JOBS_HH + 2 * JOBS_X0 + JOBS_HEAD;
 
-__global__ void __launch_bounds__(NTB) sp_net_backward_weights_kernel(int M, NetPtrs n, GradPtrs g, SavedView sv, WorkView wk) {
+__global__ void __launch_bounds__(NTB) sp_net_backward_weights_kernel(int M, int n_jobs, NetPtrs n, GradPtrs g, SavedView sv,
+    WorkView wk, SideAdam side) {
+  if ((int) blockIdx.x >= n_jobs) {  // the CUs the 133 jobs leave idle: the second piece of the optimizer's side range
+    side_adam_walk(side, (int) blockIdx.x - n_jobs, (int) gridDim.x - n_jobs);
+    return;
+  }
   extern __shared__ __attribute__((aligned(16))) float s_dynb[];  // [NWB][64 * 65] partial tiles | [NWB][64] column sums
   float (*s_part)[64 * 65] = reinterpret_cast<float (*)[64 * 65]>(s_dynb);
   float (*s_gb)[64]        = reinterpret_cast<float (*)[64]>(s_dynb + NWB * 64 * 65);
@@ -841,17 +838,10 @@ bool net_complete(const skgs_sp_net* d) {
   for (int l = 0; l < SPD; ++l) ok = ok && d->W[l] && d->b[l];
   return ok;
 }
-int allow_stage_lds() {  // static + dynamic LDS of the two row-block kernels exceed the default 64 KB
+int allow_weights_lds() {  // the weight-gradient launch parks 8 partial 64 x 64 tiles: more than the default 64 KB of LDS
   static int rc = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_net_forward_kernel),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int) STAGE_BYTES);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_net_backward_rows_kernel),
-          hipFuncAttributeMaxDynamicSharedMemorySize, (int) STAGE_BYTES);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_net_backward_weights_kernel),
-          hipFuncAttributeMaxDynamicSharedMemorySize, (int) WEIGHTS_LDS_BYTES);
-    return e == hipSuccess ? 0 : 1;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(sp_net_backward_weights_kernel),
+               hipFuncAttributeMaxDynamicSharedMemorySize, (int) WEIGHTS_LDS_BYTES) == hipSuccess ? 0 : 1;
   }();
   return rc;
 }
@@ -886,9 +876,11 @@ int skgs_sp_net_forward(const skgs_sp_net* net, float* raw, float* bone_T, float
   SKGS_REQUIRE(raw || bone_T, "sp_net_forward: no output requested");
   hipStream_t s = (hipStream_t) stream;
   ProfScope prof(K_SP_NET_FWD, s);
-  SKGS_REQUIRE(allow_stage_lds() == 0, "sp_net_forward: cannot raise the dynamic LDS limit");
-  hipLaunchKernelGGL(sp_net_forward_kernel, dim3(pad_rows(net->M) / ROWS), dim3(NT), STAGE_BYTES, s, net->M, net_ptrs(net), raw, bone_T, d_rot,
-      d_scale, saved_view(saved, net->M));
+  const SavedView sv = saved_view(saved, net->M);
+  const NetPtrs n    = net_ptrs(net);
+  hipLaunchKernelGGL(sp_net_transpose_kernel, dim3(WT_ROWS / 32 * (SPW / 32)), dim3(256), 0, s, n, sv.wt);
+  SKGS_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(sp_net_forward_kernel, dim3(pad_rows(net->M) / RB), dim3(NT), 0, s, net->M, n, raw, bone_T, d_rot, d_scale, sv);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -903,9 +895,13 @@ int skgs_sp_net_backward(const skgs_sp_net* net, const skgs_sp_net* grads, const
   SKGS_REQUIRE(saved && saved_bytes >= skgs_sp_net_saved_bytes(net->M), "sp_net_backward: saved buffer too small");
   SKGS_REQUIRE(workspace && workspace_bytes >= skgs_sp_net_workspace_bytes(net->M), "sp_net_backward: workspace too small");
   hipStream_t s = (hipStream_t) stream;
-  const int M = net->M, nblk = pad_rows(M) / ROWS;
-  SideAdam sd{};
-  int n_side = 0;
+  const int M = net->M, nblk = pad_rows(M) / RB;
+  // The optimizer piece rides on BOTH launches, split like their durations (the row blocks' walk ~24 us on 128 CUs, the weight
+  // gradients ~19 us on 133): alone beside the first it took 47 us and made that launch the step's long pole.
+  SideAdam sd{}, sd2{};
+  int n_side = 0, n_side2 = 0;
+  static const int skip_time = getenv("SPX_SKIP_TIMENET") ? 1 : 0;  // (timing experiment)
+  const int n_jobs = N_JOBS + 1 - skip_time;
   if (side && side->n_tensors > 0) {
     SKGS_REQUIRE(side->tensors && side->step_count && side->chunk_begin >= 0 && side->chunk_end >= side->chunk_begin,
         "sp_net_backward: bad side range");
@@ -913,8 +909,13 @@ int skgs_sp_net_backward(const skgs_sp_net* net, const skgs_sp_net* grads, const
     sd.c0 = side->chunk_begin, sd.c1 = side->chunk_end;
     sd.beta1 = side->beta1, sd.beta2 = side->beta2, sd.eps = (float) side->eps;
     sd.state = reinterpret_cast<const AdamState*>(side->step_count), sd.after_advance = side->after_advance ? 1 : 0;
-    if (sd.c1 > sd.c0)  // one workgroup (two 256-thread halves, two chunks each per iteration) per idle CU
-      n_side = (int) std::max<long long>(1, std::min<long long>((sd.c1 - sd.c0 + 3) / 4, (long long) std::max(cu_count() - nblk, 1)));
+    sd2 = sd;
+    const int64_t cut = sd.c0 + (int64_t) ((sd.c1 - sd.c0) * ROWS_LAUNCH_SHARE);
+    sd.c1 = cut, sd2.c0 = cut;
+    auto side_groups = [](const SideAdam& a, int busy) {  // one workgroup (two 256-thread halves, two chunks each per iteration) per idle CU
+      return a.c1 > a.c0 ? (int) std::max<long long>(1, std::min<long long>((a.c1 - a.c0 + 3) / 4, (long long) std::max(cu_count() - busy, 1))) : 0;
+    };
+    n_side = side_groups(sd, nblk), n_side2 = side_groups(sd2, n_jobs);
   }
   SavedView sv = saved_view(const_cast<void*>(saved), M);
   WorkView wk  = work_view(workspace, M);
@@ -927,12 +928,11 @@ int skgs_sp_net_backward(const skgs_sp_net* net, const skgs_sp_net* grads, const
   g.head_w[1] = const_cast<float*>(grads->rotation_w), g.head_b[1] = const_cast<float*>(grads->rotation_b);
   g.head_w[2] = const_cast<float*>(grads->scaling_w), g.head_b[2] = const_cast<float*>(grads->scaling_b);
   ProfScope prof(K_SP_NET_BWD, s);
-  SKGS_REQUIRE(allow_stage_lds() == 0, "sp_net_backward: cannot raise the dynamic LDS limit");
-  hipLaunchKernelGGL(sp_net_backward_rows_kernel, dim3(nblk + n_side), dim3(NT), STAGE_BYTES, s, M, nblk, n, g_bone_T, g_d_rot, g_d_scale,
-      g_raw, sv, wk, sd);
+  SKGS_REQUIRE(allow_weights_lds() == 0, "sp_net_backward: cannot raise the dynamic LDS limit");
+  hipLaunchKernelGGL(sp_net_backward_rows_kernel, dim3(nblk + n_side), dim3(NT), 0, s, M, nblk, n, g_bone_T, g_d_rot, g_d_scale, g_raw, sv,
+      wk, sd);
   SKGS_CHECK_HIP(hipGetLastError());
-  static const int skip_time = getenv("SPX_SKIP_TIMENET") ? 1 : 0;  // (timing experiment)
-  hipLaunchKernelGGL(sp_net_backward_weights_kernel, dim3(N_JOBS + 1 - skip_time), dim3(NTB), WEIGHTS_LDS_BYTES, s, M, n, g, sv, wk);
+  hipLaunchKernelGGL(sp_net_backward_weights_kernel, dim3(n_jobs + n_side2), dim3(NTB), WEIGHTS_LDS_BYTES, s, M, n_jobs, n, g, sv, wk, sd2);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }
