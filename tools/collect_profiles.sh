@@ -9,9 +9,17 @@ for f in $src/bench_*.json; do
   b=$(basename "$f" .json); b=${b//--/_}; b=${b// /_}
   [ -s "$f" ] && cp "$f" "profiles/${tag}_${b}.json"
 done
-for f in gpu_tests.txt parity_observed.json time_densify.txt time_mlp.txt time_skeleton.txt time_loss.txt valu_issue_rate.txt; do
+for f in gpu_tests.txt parity_observed.json time_densify.txt time_mlp.txt time_skeleton.txt time_loss.txt valu_issue_rate.txt time_sp_net.txt mfma4x4_layer.txt; do
   [ -s "$src/$f" ] && cp "$src/$f" "profiles/${tag}_$f"
 done
+d=gpurun_out/${tag}_sp   # stage sp: kernel stats + the counters' table (its own file: pmc_render_backward.json stays config #1 / stage sk)
+if [ -d "$d" ]; then
+  cp $d/bench_steps100.json profiles/${tag}_sp_bench_steps100.json
+  cp $(ls -t $d/stats/*/*kernel_stats.csv | head -1) profiles/${tag}_sp_kernel_stats_bench_steps100.csv
+  cp profiles/pmc_render_backward.json /tmp/pmc_keep.json 2>/dev/null
+  python tools/pmc_summary.py ${tag}_sp $d/fetch $d/write $d/valu > /dev/null
+  cp /tmp/pmc_keep.json profiles/pmc_render_backward.json 2>/dev/null
+fi
 for c in c4 c1; do
   d=gpurun_out/${tag}_$c
   [ -d "$d" ] || continue

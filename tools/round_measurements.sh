@@ -8,6 +8,17 @@ rm -rf "$out"; mkdir -p "$out"
 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $out/gpu_tests.txt; cat $out/gpu_tests.txt
 cp gpurun_out/parity_observed.json $out/parity_observed.json 2>/dev/null
 python bench.py > $out/bench_default.json 2> $out/bench_default.err; cut -c1-200 $out/bench_default.json
+# stage sp (512 superpoints, 3+8-d search, sp_deform_net on 512 rows) at config #1's size, every weighting; with the CPU leg once
+python bench.py --stage sp > $out/bench_stage_sp.json 2> $out/bench_stage_sp.err; cut -c1-200 $out/bench_stage_sp.json
+for m in kernel dist W; do
+  python bench.py --stage sp --lbs-method $m --steps 100 --warmup 10 --no-cpu-baseline > $out/bench_stage_sp_$m.json 2>/dev/null
+  python -c "import json; d=json.load(open('$out/bench_stage_sp_$m.json')); print('stage sp, $m', d['value'], d['ms_per_step'])"
+done
+python bench.py --stage sp --keep-order --steps 100 --warmup 10 --no-cpu-baseline > $out/bench_stage_sp_keep-order.json 2>/dev/null
+python bench.py --keep-order --steps 100 --warmup 10 --no-cpu-baseline --no-ms-per-render > $out/bench_keep-order.json 2>/dev/null
+python -c "import json; a=json.load(open('$out/bench_stage_sp_keep-order.json')); b=json.load(open('$out/bench_keep-order.json')); print('unsorted Gaussians: stage sp', a['value'], ' stage sk', b['value'])"
+python tools/time_sp_net.py 512 2>/dev/null > $out/time_sp_net.txt; cat $out/time_sp_net.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma4x4_layer tools/micro/mfma4x4_layer.hip 2>/dev/null && /tmp/mfma4x4_layer 128 x | grep -v "    lane" > $out/mfma4x4_layer.txt 2>&1; tail -12 $out/mfma4x4_layer.txt
 for c in 0 1 2 3 4; do
   python bench.py --config $c --steps 100 --warmup 10 --no-cpu-baseline > $out/bench_config$c.json 2>/dev/null
   python -c "import json; d=json.load(open('$out/bench_config$c.json')); print('config $c', d['value'], d['ms_per_step'])"
@@ -51,3 +62,4 @@ for v in "1 caller" "1 worker" "0 caller" "0 worker"; do set -- $v
 done
 bash tools/profile_round.sh ${tag}_c1 > /dev/null 2>&1; ls gpurun_out/${tag}_c1 | head
 bash tools/profile_round.sh ${tag}_c4 --config 4 > /dev/null 2>&1; ls gpurun_out/${tag}_c4 | head
+bash tools/profile_round.sh ${tag}_sp --stage sp > /dev/null 2>&1; ls gpurun_out/${tag}_sp | head
