@@ -552,14 +552,16 @@ int skgs_sp_skinning_backward(const skgs_deform_inputs* in, int32_t F, const flo
  * and the stage's epilogue (sk_gs.py:847, warp() :796-821): bone_T [M,7] = [d_xyz | u], d_rot [M,4] = u, d_scale [M,3] =
  * scaling, u = normalize(rotation + [0,0,0,1]) -- the three inputs of skgs_lbs_deform_forward.  All matrices in
  * torch.nn.Linear layout [out, in], contiguous: W[0] [256,93], W[5] [256,349] (input columns first), the others [256,256].
- * One launch forward (MFMA row blocks: 16 superpoints per workgroup through the whole network); two backward (row blocks,
- * then all weight gradients on the whole chip).  The backward WRITES the gradient of every parameter into the matching
+ * Two launches forward (a transposed copy of the hidden layers' weights into `saved`, then MFMA row blocks: 4 superpoints per
+ * workgroup through the whole network, the weights streamed from that copy); two backward (row blocks, then all weight
+ * gradients on the whole chip).  The backward WRITES the gradient of every parameter into the matching
  * pointer of `grads` (same struct; points / time ignored).  Cotangents: either g_raw [M,10] (w.r.t. the raw row above) or
  * g_bone_T [M,7] / g_d_rot [M,4] / g_d_scale [M,3] (any may be NULL; the normalisation's backward runs in the launch).
  * No gradient w.r.t. points or time (the reference detaches the positions, sk_gs.py:746-748,845).
  * saved: skgs_sp_net_saved_bytes(M), written by the forward, read by the backward.  workspace:
  * skgs_sp_net_workspace_bytes(M), ZERO before the first call (the library keeps its first 256 bytes zero between calls).
- * side (may be NULL): an optimizer piece for the CUs the row-block launch leaves idle, as skgs_skeleton_backward. */
+ * side (may be NULL): an optimizer piece for the CUs the two backward launches leave idle (split between them), as
+ * skgs_skeleton_backward. */
 typedef struct skgs_sp_net {
   int32_t M, reserved;
   const float* points;                                   /* [M,3] */
