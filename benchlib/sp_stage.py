@@ -186,7 +186,7 @@ def run(args, base_alg_bytes, configs):
     n_prof = min(args.steps, 20)
     prof = timing.profiled_eager_pass(_C, eager_step, args.warmup + args.steps, n_prof)
     rows_b = 28 * sum(p.numel() for g in opt.param_groups if g.get('name') in train.rows for p in g['params'])
-    rest_b = 28 * sum(p.numel() for g in opt.param_groups if g.get('name') in train.rest for p in g['params'])
+    rest_b = 28 * sum(p.numel() for g in opt.param_groups if g.get('name') in train.rest + train.wide for p in g['params'])
     kernels = {}
     for name, (ms, n) in prof.items():
         us = ms / n * 1e3
@@ -235,8 +235,10 @@ def run(args, base_alg_bytes, configs):
                    'launch': 'ONE captured hipGraph for all views (camera, time and target read from a device view slot)'
                    if not use_dist else 'two hipGraphs per step with the all-reduce between them',
                    'tile_lists': f'buckets of {tile_bucket} slots per tile (longest list {longest})',
-                   'adam': ('per-Gaussian rows on the idle CUs of the sp net\'s row-block backward launch; network + superpoint '
-                            'tables + counter + next view in one closing launch') if train.fused else 'one launch after the all-reduce',
+                   'adam': ('per-Gaussian rows on the idle CUs of the sp net\'s two backward launches; '
+                            + ('the dense [P, M] logit table as a launch of its own; ' if train.wide else '')
+                            + 'network + superpoint tables + counter + next view in one closing launch') if train.fused
+                   else 'one launch after the all-reduce',
                    'step': 'FusedSuperpointStep (direct C-ABI calls)', 'cluster': cluster,
                    'exchange': 'allreduce' if world > 1 else None, 'replicas_identical': replicas_identical, 'param_digest': param_digest,
                    'gaussian_order': 'as generated (random)' if args.keep_order else

@@ -466,18 +466,23 @@ class FusedSuperpointStep(FusedViewStep):
 
 class FusedSuperpointTrainStep:
     """One training step of one rank in stage ``sp``: ``FusedSuperpointStep.forward_backward`` + ``FusedAdam.step`` with the
-    per-Gaussian rows' update (xyz, SH, opacity, scaling, rotation, hyper features, LBS logits: > 95 % of the optimizer's
-    bytes) as the side job of the network's row-block backward launch, and one closing launch for the rest (network,
+    per-Gaussian rows' update (xyz, SH, opacity, scaling, rotation, hyper features: > 95 % of the optimizer's bytes without
+    a dense logit table) as the side job of the network's two backward launches, and one closing launch for the rest (network,
     superpoint tables) that advances the counter and, with an ordered ``ViewTable``, selects the next view.  Same arithmetic
     as ``step.forward_backward(); optimizer.step()``."""
 
-    ROW_GROUPS = ('xyz', 'f_dc', 'f_rest', 'opacity', 'scaling', 'rotation', 'hyper', 'sp_W')
+    ROW_GROUPS = ('xyz', 'f_dc', 'f_rest', 'opacity', 'scaling', 'rotation', 'hyper')
+    # LBS_method 'W' (exps/default.yaml:35): the dense [P, M] logit table is 7.5 x the other rows together (1.4 GB of optimizer
+    # traffic per step at P = 100k, M = 512).  Beside the network's launches it would stream at 4.4 TB/s on the CUs they leave;
+    # as a launch of its own on the whole chip it runs at the Adam kernel's 5.9 TB/s: 373 -> ~290 us for the backward + update
+    WIDE_GROUPS = ('sp_W',)
 
     def __init__(self, step: FusedSuperpointStep, optimizer, enable: bool = True):
         self.step, self.optimizer = step, optimizer
         names = [g.get('name') for g in optimizer.param_groups]
         self.rows = [n for n in names if n in self.ROW_GROUPS]
-        self.rest = [n for n in names if n not in self.ROW_GROUPS]
+        self.wide = [n for n in names if n in self.WIDE_GROUPS]
+        self.rest = [n for n in names if n not in self.ROW_GROUPS and n not in self.WIDE_GROUPS]
         self.fused = bool(enable and self.rows and self.rest and len(optimizer._chunk_ranges(self.rows)) == 1
                           and len(optimizer._chunk_ranges(self.rest)) == 1)
         step.side_optimizer = (optimizer, self.rows, None) if self.fused else None
@@ -486,6 +491,8 @@ class FusedSuperpointTrainStep:
         self.step.forward_backward(rs, time_id, target)
         if self.fused:
             vt = self.step.view_table
+            if self.wide:
+                self.optimizer.step(self.wide, advance=False)
             self.optimizer.step_tail(self.rest, next_view=vt.advance() if (vt is not None and rs is None) else None)
         else:
             self.optimizer.step()
