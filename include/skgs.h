@@ -353,6 +353,18 @@ int skgs_adam_step(int32_t n_tensors, const void* tensors, int64_t total_chunks,
  * Adam runs beside the bone-chain / deform-network backward).  chunk_begin == chunk_end, advance = 1: counter only. */
 int skgs_adam_step_range(int32_t n_tensors, const void* tensors, int64_t chunk_begin, int64_t chunk_end, double beta1,
     double beta2, double eps, float* step_state, int32_t advance, float* zero_after, int64_t zero_n, skgs_stream_t stream);
+/* LBS_method 'W' (networks/sk_gs.py:469-471, exps/default.yaml:35): the Adam update of the dense [P, M] logit table WITHOUT the
+ * dense gradient -- skgs_adam_step_range(advance = 0) for that one tensor, restricted to the 32-column tiles of a row that have
+ * ever received a gradient (every other entry has g = m = v = 0: its update is exactly zero).  Bit-identical parameters and
+ * moments to skgs_lbs_weights_backward + the dense step.  weights / indices / g_weights [P,K]: this step's softmax weights,
+ * neighbours and the weights' cotangent; tensor: the table's descriptor in the optimizer's DEVICE table (skgs_adam_step:
+ * param, exp_avg, exp_avg_sq, lr are read from it); tile_mask [P] uint32, persistent: zero at the start of training, else
+ * skgs_adam_logit_mask_rebuild (a tile is live when any of its moments is non-zero).  M <= 1024, K <= 16. */
+int skgs_adam_logit_rows(int32_t P, int32_t M, int32_t K, const float* weights, const int64_t* indices, const float* g_weights,
+    const void* tensor, uint32_t* tile_mask, double beta1, double beta2, double eps, const float* step_state, int32_t after_advance,
+    skgs_stream_t stream);
+int skgs_adam_logit_mask_rebuild(int32_t P, int32_t M, const float* exp_avg, const float* exp_avg_sq, uint32_t* tile_mask,
+    skgs_stream_t stream);
 /* The closing piece of a step (it advances the counter) whose range holds a tensor with an unfinished gradient: the
  * workgroup that owns chunk freq_chunk (the single chunk of that small tensor: the joint positions) first runs
  * skgs_freq_encode_backward(freq_B, freq_D, freq_degree, freq_grad_out, freq_out, freq_ld_out, freq_grad_x,

@@ -102,6 +102,83 @@ __global__ void __launch_bounds__(256) adam_bump_kernel(AdamState* state, double
   if (i < zero_n) zero_after[i] = 0.f;
 }
 
+
+// ---- LBS_method 'W' (networks/sk_gs.py:469-471, exps/default.yaml:35): Adam on the dense [P, M] logit table, sparsely ----------
+// A row of the table receives a gradient at its K nearest superpoints only (the gather of sk_gs.py:769): every other entry has
+// g = 0, and as long as its moments are zero too its update is EXACTLY zero (m' = v' = 0, p' = p - lr/bc1 * 0 / (0 + eps)).
+// So the dense update (1.4 GB of traffic per step at P = 100k, M = 512: 245 us, after a 200 MB dense gradient was written)
+// only has to visit the 32-column tiles of a row that have EVER been touched: `tile_mask[row]`, one bit per tile, grows by the
+// tiles of this step's neighbours and can be rebuilt from the moments at any time (skgs_adam_logit_mask_rebuild).  Inside a
+// visited tile every element takes the full update (stale moments keep decaying, as in the dense launch): bit-identical
+// parameters and moments.  The dense gradient is never formed: g = w_k (g_w_k - sum_j w_j g_w_j) at column indices[k]
+// (the arithmetic of deform.hip::lbs_logits_dense_wide_kernel), zero elsewhere.
+constexpr int LOGIT_TILE = 32;
+__global__ void __launch_bounds__(256) adam_logit_rows_kernel(int P, int M, int K, const float* __restrict__ weights,
+    const int64_t* __restrict__ indices, const float* __restrict__ g_weights, const AdamTensor* __restrict__ desc,
+    uint32_t* __restrict__ tile_mask, double beta1d, double beta2d, float eps, const AdamState* __restrict__ state, int after_advance) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, e = lane & 31;
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = gridDim.x * 4;
+  const AdamCoef k = adam_coefficients(beta1d, beta2d, eps, state, after_advance != 0);
+  const AdamTensor T    = desc[0];
+  const float step_size = T.lr / k.bc1;
+  for (int n = wave; n < P; n += n_waves) {
+    // (n is wave-uniform: the K triples are scalar loads)
+    float gl[16];
+    int id[16];
+    float dot = 0.f;
+    for (int q = 0; q < K; ++q) dot = __builtin_fmaf(weights[(size_t) n * K + q], g_weights[(size_t) n * K + q], dot);
+    uint32_t touched = 0u;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      if (q < K) {
+        id[q] = (int) indices[(size_t) n * K + q];
+        gl[q] = __fmul_rn(weights[(size_t) n * K + q], __fsub_rn(g_weights[(size_t) n * K + q], dot));
+        touched |= 1u << (id[q] / LOGIT_TILE);
+      } else {
+        id[q] = -1, gl[q] = 0.f;
+      }
+    }
+    const uint32_t before = tile_mask[n];
+    uint32_t todo = __builtin_amdgcn_readfirstlane(before | touched);
+    if (lane == 0 && todo != before) tile_mask[n] = todo;
+    while (todo) {  // two tiles per pass: lanes 0-31 the lowest set bit, lanes 32-63 the next one
+      const int ta = __builtin_ctz(todo);
+      todo &= todo - 1;
+      const int tb = todo ? __builtin_ctz(todo) : -1;
+      if (todo) todo &= todo - 1;
+      const int t = half ? tb : ta;
+      const int j = t * LOGIT_TILE + e;
+      if (t >= 0 && j < M) {
+        float g = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (id[q] == j) g += gl[q];
+        const size_t at = (size_t) n * M + j;
+        float p = T.param[at], m = T.exp_avg[at], v = T.exp_avg_sq[at];
+        adam_update_element(p, m, v, g, step_size, k);
+        T.exp_avg[at] = m, T.exp_avg_sq[at] = v, T.param[at] = p;
+      }
+    }
+  }
+}
+// a tile is live when any of its moments is non-zero (after a restore, a re-ordering or a change of the row count)
+__global__ void __launch_bounds__(256) adam_logit_mask_kernel(int P, int M, const float* __restrict__ exp_avg,
+    const float* __restrict__ exp_avg_sq, uint32_t* __restrict__ tile_mask) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = gridDim.x * 4;
+  for (int n = wave; n < P; n += n_waves) {
+    uint32_t mask = 0u;
+    for (int j0 = 0; j0 < M; j0 += 64) {
+      const int j = j0 + lane;
+      const bool live = j < M && (exp_avg[(size_t) n * M + j] != 0.f || exp_avg_sq[(size_t) n * M + j] != 0.f);
+      const unsigned long long b = __ballot(live);
+      if (b & 0xffffffffull) mask |= 1u << (j0 / LOGIT_TILE);
+      if (b >> 32) mask |= 1u << (j0 / LOGIT_TILE + 1);
+    }
+    if (lane == 0) tile_mask[n] = mask;
+  }
+}
+
 }  // namespace
 }  // namespace skgs
 
@@ -192,6 +269,38 @@ int skgs_adam_step_tail(int32_t n_tensors, const void* tensors, int64_t chunk_be
   }
   return step_range_impl(n_tensors, tensors, chunk_begin, chunk_end, beta1, beta2, eps, step_state, 1, zero_after, zero_n, job,
       va, stream);
+}
+
+/* Adam on the dense [P, M] LBS-logit table of LBS_method 'W' without the dense gradient (see adam_logit_rows_kernel): the update
+ * of skgs_adam_step_range(advance = 0) for that ONE tensor -- `tensor` = its descriptor in the optimizer's DEVICE table
+ * (param, exp_avg, exp_avg_sq, lr, n = P * M are read from it; its grad pointer is not) -- given the step's K neighbours per row
+ * and the cotangent of their softmax weights; bit-identical parameters and moments.  tile_mask [P] uint32: persistent, zero at
+ * the start of training (all moments zero), else skgs_adam_logit_mask_rebuild.  M <= 1024, K <= 16. */
+int skgs_adam_logit_rows(int32_t P, int32_t M, int32_t K, const float* weights, const int64_t* indices, const float* g_weights,
+    const void* tensor, uint32_t* tile_mask, double beta1, double beta2, double eps, const float* step_state, int32_t after_advance,
+    skgs_stream_t stream) {
+  SKGS_REQUIRE(P >= 0 && M >= 1 && M <= 32 * LOGIT_TILE && K >= 1 && K <= 16 && K <= M, "adam_logit_rows: need M <= 1024, 1 <= K <= min(16, M)");
+  if (P == 0) return 0;
+  SKGS_REQUIRE(weights && indices && g_weights && tensor && tile_mask && step_state, "adam_logit_rows: NULL argument");
+  hipStream_t s = (hipStream_t) stream;
+  ProfScope prof(K_ADAM, s);
+  const int grid = (int) std::min<int64_t>(((int64_t) P + 3) / 4, 256 * 8);
+  hipLaunchKernelGGL(adam_logit_rows_kernel, dim3(grid), dim3(256), 0, s, P, M, K, weights, indices, g_weights,
+      reinterpret_cast<const AdamTensor*>(tensor), tile_mask, beta1, beta2, (float) eps, reinterpret_cast<const AdamState*>(step_state),
+      after_advance ? 1 : 0);
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+int skgs_adam_logit_mask_rebuild(int32_t P, int32_t M, const float* exp_avg, const float* exp_avg_sq, uint32_t* tile_mask,
+    skgs_stream_t stream) {
+  SKGS_REQUIRE(P >= 0 && M >= 1 && M <= 32 * LOGIT_TILE, "adam_logit_mask_rebuild: need M <= 1024");
+  if (P == 0) return 0;
+  SKGS_REQUIRE(exp_avg && exp_avg_sq && tile_mask, "adam_logit_mask_rebuild: NULL argument");
+  hipStream_t s = (hipStream_t) stream;
+  const int grid = (int) std::min<int64_t>(((int64_t) P + 3) / 4, 256 * 8);
+  hipLaunchKernelGGL(adam_logit_mask_kernel, dim3(grid), dim3(256), 0, s, P, M, exp_avg, exp_avg_sq, tile_mask);
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 
 }  // extern "C"

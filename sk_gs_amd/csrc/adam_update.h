@@ -88,10 +88,15 @@ __device__ __forceinline__ AdamTensor adam_descriptor_of(const AdamTensorLanes& 
   return T;
 }
 
+// Every rounding is spelled out (no a * b + c left for the compiler to contract one way here and another way there): the
+// update runs in several kernels -- the optimizer's own launch, the side jobs of the network launches, the sparse logit-table
+// update -- and they must agree to the bit (a step taken in pieces, a sparse step against a dense one).  The form is the one
+// the optimizer's launch had been compiled to: m' = fma(beta1, m, (1 - beta1) g), v' = fma(beta2, v, ((1 - beta2) g) g),
+// p' = p - (lr / bc1 m') / fma(sqrt(v'), 1 / sqrt(bc2), eps).
 __device__ __forceinline__ void adam_update_element(float& p, float& m, float& v, float g, float step_size, const AdamCoef& k) {
-  m = k.beta1 * m + k.omb1 * g;
-  v = k.beta2 * v + k.omb2 * g * g;
-  p -= step_size * m / (sqrtf(v) * k.inv_sqrt_bc2 + k.eps);
+  m = __builtin_fmaf(k.beta1, m, __fmul_rn(k.omb1, g));
+  v = __builtin_fmaf(k.beta2, v, __fmul_rn(__fmul_rn(k.omb2, g), g));
+  p = __fsub_rn(p, __fdiv_rn(__fmul_rn(step_size, m), __builtin_fmaf(sqrtf(v), k.inv_sqrt_bc2, k.eps)));
 }
 
 // one chunk (ADAM_CHUNK elements from `base`) of tensor T, by 256 threads; t256 = this thread's index among them

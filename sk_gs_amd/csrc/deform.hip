@@ -655,14 +655,16 @@ __global__ void __launch_bounds__(256) lbs_logits_dense_wide_kernel(int P, int M
   const long long t  = (long long) blockIdx.x * 256 + threadIdx.x;
   if (t >= (long long) P * M4) return;
   const int p = (int) (t / M4), m0 = 4 * (int) (t - (long long) p * M4);
+  // (every rounding spelled out: adam.hip::adam_logit_rows_kernel forms the same gradient on the fly and must agree to the bit)
   float dot = 0.f;
   if (SOFTMAX_BACKWARD)
-    for (int k = 0; k < K; ++k) dot += weights[(size_t) p * K + k] * g_in[(size_t) p * K + k];
+    for (int k = 0; k < K; ++k) dot = __builtin_fmaf(weights[(size_t) p * K + k], g_in[(size_t) p * K + k], dot);
   float v[4] = {0.f, 0.f, 0.f, 0.f};
   for (int k = 0; k < K; ++k) {
     const int j = (int) indices[(size_t) p * K + k] - m0;
     if (j >= 0 && j < 4) {
-      const float g = SOFTMAX_BACKWARD ? weights[(size_t) p * K + k] * (g_in[(size_t) p * K + k] - dot) : g_in[(size_t) p * K + k];
+      const float g = SOFTMAX_BACKWARD ? __fmul_rn(weights[(size_t) p * K + k], __fsub_rn(g_in[(size_t) p * K + k], dot))
+                                       : g_in[(size_t) p * K + k];
       v[j] += g;
     }
   }

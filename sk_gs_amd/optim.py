@@ -541,6 +541,13 @@ class FusedAdam:
         return AdamRange(len(self.params), self._table.data_ptr(), c0, c1, self.betas[0], self.betas[1],
                          self.eps, self.step_state.data_ptr(), int(after_advance))
 
+    def table_entry(self, param) -> int:
+        """device address of ``param``'s descriptor in the optimizer's table (param, grad, exp_avg, exp_avg_sq, n, chunk0, lr):
+        what the special-purpose update launches read their tensor from (``skgs_adam_logit_rows``), so that ``set_lr`` and
+        re-homed storage reach them like every other piece of the step"""
+        i = next(k for k, q in enumerate(self.params) if q is param)
+        return self._table.data_ptr() + 56 * i
+
     def step_tail(self, groups, freq_job=None, freq_param=None, next_view=None):
         """the closing piece of a step: ``groups`` (neighbours in the table) are updated, the counter advances,
         ``zero_after_step`` is cleared -- ``skgs_adam_step_tail``.  ``freq_job`` = (B, D, degree, grad_out, out, ld_out,

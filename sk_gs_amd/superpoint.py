@@ -237,6 +237,10 @@ class SuperpointGaussians(nn.Module):
         self.lbs_method, self.lbs_temperature = lbs_method, float(lbs_temperature)
         # superpoints: sampled from the Gaussians (init_sp_from: sampled, exps/default.yaml:33; sk_gs.py:679-701)
         pick = torch.randperm(P, generator=gen)[:M]
+        # ... numbered along a Z-order curve: the numbering of the superpoints carries no meaning, and a Gaussian's neighbours
+        # then share few 32-column tiles of the `W` logit table (the sparse update visits tiles, csrc/adam.hip)
+        from sk_gs_amd.densify import morton_order
+        pick = pick[morton_order(g['xyz'][pick])]
         self.sp_points = nn.Parameter(g['xyz'][pick].clone())
         # hyper coordinates: the reference starts them at -1e-2 / +1e-2 (sk_gs.py:644,696); a little noise keeps the 3+8-d
         # search from degenerating into the 3-d one in tests
@@ -376,6 +380,10 @@ class FusedSuperpointStep(FusedViewStep):
             vs = view_table.settings
             assert (vs.image_height, vs.image_width) == (self.H, self.W)
         self.wide = True
+        # LBS_method 'W': with ``sparse_logits`` (FusedSuperpointTrainStep) the dense [P, M] logit gradient is never written -- the
+        # table's Adam update visits only the 32-column tiles a row has ever been touched in (skgs_adam_logit_rows)
+        self.sparse_logits = False
+        self.logit_mask = torch.zeros((P,), dtype=torch.int32, device=dev) if model.sp_W is not None else None
         self.sp_order = torch.empty((M,), dtype=torch.int32, device=dev)
         self.sp_rank = torch.empty((M,), dtype=torch.int32, device=dev)
         self.indices.zero_()  # (the search reads the previous call's nearest superpoint as its starting hint)
@@ -449,13 +457,33 @@ class FusedSuperpointStep(FusedViewStep):
             _p(m._rotation.grad), _p(m._opacity.grad), None if logits else g(m.hyper_feature), _p(self.g_bone_T), _p(self.g_d_rot),
             _p(self.g_d_scale), None if logits else g(m.sp_hyper_feature), g(m._sp_radius), g(m._sp_weight), _p(self.pairs),
             C.c_size_t(self.pairs.numel()), _p(self.sb_ws), C.c_size_t(self.sb_ws.numel()), st))
-        if logits:  # `W`: the dense [P,M] logit gradient (what autograd's gather backward builds)
+        if logits and not self.sparse_logits:  # `W`: the dense [P,M] logit gradient (what autograd's gather backward builds)
             chk(lib.skgs_lbs_weights_backward(C.c_int32(P), C.c_int32(M), C.c_int32(K), _p(self.weights), _p(self.indices),
                                               _p(self.g_weights), _p(m.sp_W.grad), st))
         side = None
         if self.side_optimizer is not None:  # the per-Gaussian rows' Adam update on the CUs the row-block launch leaves idle
             side = self.side_optimizer[0].side_range(*self.side_optimizer[1:])
         self.net.backward(self.g_bone_T, self.g_d_rot, self.g_d_scale, side_adam=side)
+
+    @torch.no_grad()
+    def refresh_logit_mask(self, optimizer):
+        """``sparse_logits``: rebuild the live-tile mask of the logit table from its Adam moments -- after a restored state, a
+        re-ordering of the Gaussians or any other change of the table's rows from outside the step"""
+        m = self.model
+        st = optimizer.state[m.sp_W]
+        _C._check(self.lib.skgs_adam_logit_mask_rebuild(C.c_int32(self.P), C.c_int32(self.M), _p(st['exp_avg']), _p(st['exp_avg_sq']),
+                                                        _p(self.logit_mask), _C._stream()))
+
+    @torch.no_grad()
+    def sparse_logit_adam(self, optimizer):
+        """the logit table's piece of the Adam step (``optimizer.step(['sp_W'], advance=False)``), from this step's neighbours,
+        weights and their cotangent; ``sp_W.grad`` is neither read nor written"""
+        m = self.model
+        _C._check(self.lib.skgs_adam_logit_rows(
+            C.c_int32(self.P), C.c_int32(self.M), C.c_int32(self.K), _p(self.weights), _p(self.indices), _p(self.g_weights),
+            C.c_void_p(optimizer.table_entry(m.sp_W)), _p(self.logit_mask), C.c_double(optimizer.betas[0]),
+            C.c_double(optimizer.betas[1]), C.c_double(optimizer.eps), C.c_void_p(optimizer.step_state.data_ptr()), C.c_int32(0),
+            _C._stream()))
 
     def status(self) -> dict:
         """(synchronising) the rasterizer's status words + ``pairs_overflow``: a superpoint's inverse list outgrew its capacity"""
@@ -473,11 +501,13 @@ class FusedSuperpointTrainStep:
 
     ROW_GROUPS = ('xyz', 'f_dc', 'f_rest', 'opacity', 'scaling', 'rotation', 'hyper')
     # LBS_method 'W' (exps/default.yaml:35): the dense [P, M] logit table is 7.5 x the other rows together (1.4 GB of optimizer
-    # traffic per step at P = 100k, M = 512).  Beside the network's launches it would stream at 4.4 TB/s on the CUs they leave;
-    # as a launch of its own on the whole chip it runs at the Adam kernel's 5.9 TB/s: 373 -> ~290 us for the backward + update
+    # traffic per step at P = 100k, M = 512; beside the network's launches it streamed at 4.4 TB/s on the CUs they leave, as a
+    # launch of its own at the Adam kernel's 5.9 TB/s).  Its update is its own piece of the step: sparse (the tiles a row has
+    # ever been touched in, no dense gradient: csrc/adam.hip::adam_logit_rows_kernel) where the table fits the kernel, dense
+    # otherwise (``sparse_logits=False``)
     WIDE_GROUPS = ('sp_W',)
 
-    def __init__(self, step: FusedSuperpointStep, optimizer, enable: bool = True):
+    def __init__(self, step: FusedSuperpointStep, optimizer, enable: bool = True, sparse_logits: bool = True):
         self.step, self.optimizer = step, optimizer
         names = [g.get('name') for g in optimizer.param_groups]
         self.rows = [n for n in names if n in self.ROW_GROUPS]
@@ -486,12 +516,17 @@ class FusedSuperpointTrainStep:
         self.fused = bool(enable and self.rows and self.rest and len(optimizer._chunk_ranges(self.rows)) == 1
                           and len(optimizer._chunk_ranges(self.rest)) == 1)
         step.side_optimizer = (optimizer, self.rows, None) if self.fused else None
+        step.sparse_logits = bool(self.fused and self.wide and sparse_logits and step.M <= 1024 and step.K <= 16)
+        if step.sparse_logits:
+            step.refresh_logit_mask(optimizer)
 
     def __call__(self, rs=None, time_id=None, target=None):
         self.step.forward_backward(rs, time_id, target)
         if self.fused:
             vt = self.step.view_table
-            if self.wide:
+            if self.step.sparse_logits:
+                self.step.sparse_logit_adam(self.optimizer)
+            elif self.wide:
                 self.optimizer.step(self.wide, advance=False)
             self.optimizer.step_tail(self.rest, next_view=vt.advance() if (vt is not None and rs is None) else None)
         else:

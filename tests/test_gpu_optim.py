@@ -454,3 +454,61 @@ def test_captured_tables_are_recycled_across_recaptures_and_optimizer_surgery():
     g = capture(False)
     g.replay()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('P,M,K', [(3000, 512, 5), (257, 100, 7), (64, 1024, 16)])
+def test_sparse_logit_table_adam_is_bit_identical_to_the_dense_step(P, M, K):
+    """LBS_method 'W' (sk_gs.py:469-471, exps/default.yaml:35): skgs_adam_logit_rows -- the Adam update of the dense [P, M] logit
+    table restricted to the 32-column tiles a row has ever received a gradient in, the gradient formed on the fly from the
+    step's neighbours -- against the dense path (skgs_lbs_weights_backward writes the [P, M] gradient, FusedAdam steps over all
+    of it): parameters and both moments BIT-identical over steps whose neighbour sets drift; the tile mask rebuilt from the
+    moments continues identically."""
+    import ctypes as C
+    from sk_gs_amd import _C
+    from sk_gs_amd.optim import FusedAdam
+    lib = _C.load_library()
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(P + M)
+    w0 = torch.randn(P, M, generator=g)
+    other0 = torch.randn(1000, generator=g)
+
+    def make():
+        spw, other = torch.nn.Parameter(w0.clone().to(dev)), torch.nn.Parameter(other0.clone().to(dev))
+        opt = FusedAdam([{'params': [other], 'lr': 1e-2, 'name': 'other'}, {'params': [spw], 'lr': 3e-3, 'name': 'sp_W'}], eps=1e-15)
+        other.grad.normal_(generator=torch.Generator(device=dev).manual_seed(1))
+        return spw, other, opt
+
+    spw_a, other_a, opt_a = make()   # dense
+    spw_b, other_b, opt_b = make()   # sparse
+    mask = torch.zeros(P, dtype=torch.int32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    score = torch.rand(P, M, generator=g)
+    for step in range(7):
+        score = score + 0.35 * torch.rand(P, M, generator=g)   # the neighbour sets drift
+        idx = score.topk(K, dim=1).indices.to(dev).contiguous()
+        w = torch.softmax(torch.randn(P, K, generator=g), -1).to(dev)
+        gw = torch.randn(P, K, generator=g).to(dev)
+        if step == 3:
+            gw[::3] = 0.0   # rows whose gradient is exactly zero: their moments only decay
+        _C._check(lib.skgs_lbs_weights_backward(C.c_int32(P), C.c_int32(M), C.c_int32(K), p(w), p(idx), p(gw), p(spw_a.grad), _C._stream()))
+        opt_a.step()
+        opt_b.step(['other'], advance=False)
+        _C._check(lib.skgs_adam_logit_rows(C.c_int32(P), C.c_int32(M), C.c_int32(K), p(w), p(idx), p(gw),
+                                           C.c_void_p(opt_b.table_entry(spw_b)), p(mask), C.c_double(0.9), C.c_double(0.999),
+                                           C.c_double(1e-15), C.c_void_p(opt_b.step_state.data_ptr()), C.c_int32(0), _C._stream()))
+        opt_b.advance_step()
+        if step == 4:  # the mask is a cache of "a moment of this tile is non-zero": rebuilt, the run continues identically
+            rebuilt = torch.zeros_like(mask)
+            st = opt_b.state[spw_b]
+            _C._check(lib.skgs_adam_logit_mask_rebuild(C.c_int32(P), C.c_int32(M), p(st['exp_avg']), p(st['exp_avg_sq']), p(rebuilt), _C._stream()))
+            assert bool(((rebuilt & ~mask) == 0).all())   # nothing live outside the accumulated mask
+            mask.copy_(rebuilt)
+        for name, a, b in (('param', spw_a, spw_b), ('exp_avg', opt_a.state[spw_a]['exp_avg'], opt_b.state[spw_b]['exp_avg']),
+                           ('exp_avg_sq', opt_a.state[spw_a]['exp_avg_sq'], opt_b.state[spw_b]['exp_avg_sq']), ('other', other_a, other_b)):
+            same = torch.equal(a.detach(), b.detach())
+            assert same, f'step {step} {name}: max diff {float((a.detach() - b.detach()).abs().max()):.3e}, ' \
+                         f'{int((a.detach() != b.detach()).sum())} elements differ'
+        assert float(opt_a.step_count) == float(opt_b.step_count) == step + 1
+    tiles = (M + 31) // 32
+    live = sum(int(((mask >> t) & 1).sum()) for t in range(tiles)) / (P * tiles)
+    assert live < 1.0 or K * 7 >= tiles  # (the point of the kernel: most tiles are never visited)

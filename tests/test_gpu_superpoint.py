@@ -295,9 +295,11 @@ def test_fused_superpoint_step_matches_the_operator_path(method):
         assert_close_robust(p.grad, ref[n], 3e-4, 1e-3, name=f'{n} sp {method}')
 
 
-def test_superpoint_train_step_graph_replay_equals_eager_steps():
-    """FusedSuperpointTrainStep (rows' Adam on the idle CUs of the network's backward launch, closing launch for the rest)
-    captured as ONE hipGraph and replayed = the same steps issued eagerly with a plain optimizer.step(); and it trains"""
+@pytest.mark.parametrize('method', ['weighted_kernel', 'W'])
+def test_superpoint_train_step_graph_replay_equals_eager_steps(method):
+    """FusedSuperpointTrainStep (rows' Adam on the idle CUs of the network's backward launches, closing launch for the rest; `W`:
+    the dense logit table updated sparsely from the step's neighbours, no dense gradient) captured as ONE hipGraph and
+    replayed = the same steps issued eagerly with a plain optimizer.step() over the dense gradients; and it trains"""
     from sk_gs_amd import _C
     from sk_gs_amd.optim import FusedAdam
     from sk_gs_amd.superpoint import FusedSuperpointStep, FusedSuperpointTrainStep
@@ -305,7 +307,7 @@ def test_superpoint_train_step_graph_replay_equals_eager_steps():
     P, M, K, W, H, frames = 5000, 512, 5, 128, 96, 2
     runs = []
     for fused in (True, False):
-        model, rs, _ = _sp_model(P, M, K, W, H, frames, 'weighted_kernel', seed=5)
+        model, rs, _ = _sp_model(P, M, K, W, H, frames, method, seed=5)
         _C.config.sync_num_rendered = True
         with torch.no_grad():  # a fitting problem with a known answer: the model's own render, then perturbed colours
             first = model.render(rs, time_id=0)
@@ -314,7 +316,7 @@ def test_superpoint_train_step_graph_replay_equals_eager_steps():
         step = FusedSuperpointStep(model, W, H, capacity=int(R * 1.5) + 1024)
         opt = FusedAdam(model.param_groups(lr=1e-4))
         train = FusedSuperpointTrainStep(step, opt, enable=fused)
-        assert train.fused == fused
+        assert train.fused == fused and step.sparse_logits == (fused and method == 'W')
         losses = []
         if fused:
             graphs = GraphedSteps(lambda _: train(rs, 0, target), collect_garbage=False)
