@@ -512,6 +512,9 @@ int skgs_deform_mlp_status(const void* workspace, uint32_t* host_words4, skgs_st
  * parameters: the kernels apply exp / sigmoid, sk_gs.py:547-553), sp_W [P,M].  out_idx [P,K] int64, out_weights [P,K],
  * out_dist [P,K] (may be NULL for `W`).  Same arithmetic as skgs_knn_dist_weights_forward / skgs_lbs_weights_forward on the
  * concatenated rows (bit-identical weights).
+ * params_activated != 0: sp_radius_raw / sp_weight_raw hold the ACTIVATED values r = exp(_sp_radius), s = sigmoid(_sp_weight) --
+ * what the reference's calc_LBS_weight receives (sk_gs.py:759-766), the operator path (sk_gs_amd.deform.calc_lbs_weight) --
+ * and the backward returns the gradients w.r.t. those.
  * Backward of the two distance-based weightings: g_weights [P,K] -> g_feature [P,F] (written), g_sp_feature [M,F],
  * g_sp_radius [M], g_sp_weight [M] w.r.t. the raw parameters (written; any may be NULL).  workspace:
  * skgs_sp_lbs_weights_workspace_bytes(P, M, F).  (`W`: skgs_lbs_weights_backward.)
@@ -527,12 +530,12 @@ int skgs_deform_mlp_status(const void* workspace, uint32_t* host_words4, skgs_st
 int skgs_sp_lbs_weights_forward(int32_t P, int32_t M, int32_t K, int32_t F, const float* points, const float* feature,
     const float* sp_points, const float* sp_feature, const float* sp_radius_raw, const float* sp_weight_raw, float temperature,
     const float* sp_W, const int32_t* sp_order /* or NULL */, const int32_t* sp_rank /* or NULL */, int64_t* out_idx,
-    float* out_weights, float* out_dist, void* pairs /* or NULL */, size_t pairs_bytes, skgs_stream_t stream);
+    float* out_weights, float* out_dist, void* pairs /* or NULL */, size_t pairs_bytes, int32_t params_activated, skgs_stream_t stream);
 size_t skgs_sp_lbs_weights_workspace_bytes(int32_t P, int32_t M, int32_t F);
 int skgs_sp_lbs_weights_backward(int32_t P, int32_t M, int32_t K, int32_t F, const float* feature, const float* sp_feature,
     const float* sp_radius_raw, const float* sp_weight_raw, float temperature, const float* weights, const int64_t* indices,
     const float* nn_dist, const float* g_weights, float* g_feature, float* g_sp_feature, float* g_sp_radius, float* g_sp_weight,
-    void* workspace, size_t workspace_bytes, skgs_stream_t stream);
+    void* workspace, size_t workspace_bytes, int32_t params_activated, skgs_stream_t stream);
 
 /* ---- skinning + weighting backward of the SUPERPOINT stage in one call, no atomics on the superpoint tables ----
  * = skgs_lbs_deform_backward + skgs_sp_lbs_weights_backward for M in the hundreds (their LDS float atomics are LDS-bound there:

@@ -64,8 +64,13 @@ __device__ __forceinline__ void topk_insert_lex(float (&bd)[KCAP], int (&bi)[KCA
   bd[0] = sel(lt[0], d, bd[0]);
 }
 
-__device__ __forceinline__ float act_radius(const float* __restrict__ r, int j) { return expf(r[j]); }
-__device__ __forceinline__ float act_kweight(const float* __restrict__ w, int j) { return 1.0f / (1.0f + expf(-w[j])); }
+// the weighting's per-superpoint parameters arrive RAW (`_sp_radius`, `_sp_weight`: exp / sigmoid of sk_gs.py:547-553 applied
+// here, the backward returns the raw parameters' gradients -- what the fused step hands over) or ACTIVATED (what the reference's
+// calc_LBS_weight receives, sk_gs.py:759-766: the operator path)
+__device__ __forceinline__ float act_radius(const float* __restrict__ r, int j, int activated) { return activated ? r[j] : expf(r[j]); }
+__device__ __forceinline__ float act_kweight(const float* __restrict__ w, int j, int activated) {
+  return activated ? w[j] : 1.0f / (1.0f + expf(-w[j]));
+}
 
 // One small launch in front of the search (when the caller gave the pair buffer): the list header and counters are cleared and
 // the superpoint table is packed ONCE -- rows [xyz | hyper | id] in scan order -- so that each of the search's ~1500 workgroups
@@ -99,7 +104,7 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
     const float* __restrict__ radius_raw, const float* __restrict__ kweight_raw, float temperature, const float* __restrict__ sp_W,
     int64_t* __restrict__ out_idx, float* __restrict__ out_weights, float* __restrict__ out_dist, uint32_t* __restrict__ pair_counts,
     uint32_t* __restrict__ pair_lists, int pair_cap, uint32_t* __restrict__ pair_header, const int32_t* __restrict__ sp_order,
-    const int32_t* __restrict__ sp_rank, const float* __restrict__ packed) {
+    const int32_t* __restrict__ sp_rank, const float* __restrict__ packed, int activated) {
   extern __shared__ __attribute__((aligned(16))) float s_c[];  // [M][CROW] | pair filing: cnt[M], base[M]
   uint32_t* s_cnt  = reinterpret_cast<uint32_t*>(s_c + (size_t) M * CROW);
   uint32_t* s_base = s_cnt + M;
@@ -252,9 +257,9 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
       for (int k = 0; k < KCAP; ++k) {
         v[k] = 0.f;
         if (k < K) {
-          const float r = act_radius(radius_raw, bi[k]);
+          const float r = act_radius(radius_raw, bi[k], activated);
           float e = expf(-bd[k] / (2.f * (r * r)));
-          if (kweight_raw) e = e * act_kweight(kweight_raw, bi[k]);
+          if (kweight_raw) e = e * act_kweight(kweight_raw, bi[k], activated);
           v[k] = e + 1e-7f;
           sum += v[k];
         }
@@ -312,7 +317,7 @@ template <int F>
 __global__ void __launch_bounds__(SPK_THREADS) sp_weights_backward_kernel(int P, int M, int K, const float* __restrict__ feature,
     const float* __restrict__ sp_feature, const float* __restrict__ radius_raw, const float* __restrict__ kweight_raw,
     float temperature, const float* __restrict__ weights, const int64_t* __restrict__ indices, const float* __restrict__ nn_dist,
-    const float* __restrict__ g_weights, float* __restrict__ g_feature, float* __restrict__ partials) {
+    const float* __restrict__ g_weights, float* __restrict__ g_feature, float* __restrict__ partials, int activated) {
   extern __shared__ float s_acc[];  // [M][V]
   constexpr int V = F + 2;
   for (int i = threadIdx.x; i < M * V; i += SPK_THREADS) s_acc[i] = 0.f;
@@ -330,9 +335,9 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_weights_backward_kernel(int P,
     float sum = 0.f;
     if (radius_raw)  // S = sum_k v_k is not stored: recomputed with the forward's arithmetic
       for (int k = 0; k < K; ++k) {
-        const float r = act_radius(radius_raw, (int) ix[k]);
+        const float r = act_radius(radius_raw, (int) ix[k], activated);
         float e = expf(-dd[k] / (2.f * (r * r)));
-        if (kweight_raw) e = e * act_kweight(kweight_raw, (int) ix[k]);
+        if (kweight_raw) e = e * act_kweight(kweight_raw, (int) ix[k], activated);
         sum += e + 1e-7f;
       }
     float gf[MAXF];
@@ -348,9 +353,9 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_weights_backward_kernel(int P,
       for (int c = 0; c < V; ++c) acc[c] = 0.f;
       float g_d;
       if (radius_raw) {
-        const float r   = act_radius(radius_raw, j);
+        const float r   = act_radius(radius_raw, j, activated);
         const float e   = expf(-dd[k] / (2.f * (r * r)));
-        const float sk  = kweight_raw ? act_kweight(kweight_raw, j) : 1.f;
+        const float sk  = kweight_raw ? act_kweight(kweight_raw, j, activated) : 1.f;
         const float g_v = (gw[k] - dot) / sum;
         const float g_e = g_v * sk;
         g_d             = g_e * e * (-1.f / (2.f * (r * r)));
@@ -381,7 +386,7 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_weights_backward_kernel(int P,
 
 __global__ void __launch_bounds__(256) sp_weights_finalize_kernel(int M, int F, int nblk, const float* __restrict__ partials,
     float* __restrict__ g_sp_feature, float* __restrict__ g_radius, float* __restrict__ g_kweight,
-    const float* __restrict__ radius_raw, const float* __restrict__ kweight_raw) {
+    const float* __restrict__ radius_raw, const float* __restrict__ kweight_raw, int activated) {
   const int V = F + 2, i = blockIdx.x * 256 + threadIdx.x;
   if (i >= M * V) return;
   float s = 0.f;
@@ -397,10 +402,11 @@ __global__ void __launch_bounds__(256) sp_weights_finalize_kernel(int M, int F, 
   if (c < F) {
     if (g_sp_feature) g_sp_feature[(size_t) j * F + c] = s;
   } else if (c == F) {  // w.r.t. the RAW parameter: d exp(x) = exp(x)
-    if (g_radius) g_radius[j] = radius_raw ? s * expf(radius_raw[j]) : 0.f;
+    if (g_radius) g_radius[j] = radius_raw ? (activated ? s : s * expf(radius_raw[j])) : 0.f;
   } else if (g_kweight) {  // d sigmoid(x) = s (1 - s)
     float d = 0.f;
-    if (kweight_raw) {
+    if (kweight_raw && activated) d = 1.f;
+    else if (kweight_raw) {
       const float sg = 1.0f / (1.0f + expf(-kweight_raw[j]));
       d = sg * (1.f - sg);
     }
@@ -424,7 +430,7 @@ size_t skgs_sp_lbs_weights_workspace_bytes(int32_t P, int32_t M, int32_t F) {
 int skgs_sp_lbs_weights_forward(int32_t P, int32_t M, int32_t K, int32_t F, const float* points, const float* feature,
     const float* sp_points, const float* sp_feature, const float* sp_radius_raw, const float* sp_weight_raw, float temperature,
     const float* sp_W, const int32_t* sp_order, const int32_t* sp_rank, int64_t* out_idx, float* out_weights, float* out_dist,
-    void* pairs, size_t pairs_bytes, skgs_stream_t stream) {
+    void* pairs, size_t pairs_bytes, int32_t params_activated, skgs_stream_t stream) {
   SKGS_REQUIRE(!sp_rank || sp_order, "sp_lbs_weights_forward: sp_rank is the inverse of sp_order: give both");
   SKGS_REQUIRE(P >= 0 && M >= 1 && K >= 1 && K <= 16 && K <= M, "sp_lbs_weights_forward: need P >= 0, 1 <= K <= min(16, M)");
   SKGS_REQUIRE(!pairs || pairs_bytes >= sp_pairs_bytes(P > 0 ? P : 1, M, K), "sp_lbs_weights_forward: pair-list buffer too small (skgs_sp_pairs_bytes)");
@@ -449,7 +455,7 @@ int skgs_sp_lbs_weights_forward(int32_t P, int32_t M, int32_t K, int32_t F, cons
   const dim3 grid((P + per_wg - 1) / per_wg), block(SPK_THREADS);
 #define SKGS_SPK(KCAP_, F_)                                                                                              \
   hipLaunchKernelGGL((sp_knn_weights_kernel<KCAP_, F_>), grid, block, lds, s, P, M, K, points, feature, sp_points, sp_feature, \
-      sp_radius_raw, sp_weight_raw, temperature, sp_W, out_idx, out_weights, out_dist, pv.counts, pv.lists, pv.cap, pv.header, sp_order, sp_rank, (const float*) pv.table)
+      sp_radius_raw, sp_weight_raw, temperature, sp_W, out_idx, out_weights, out_dist, pv.counts, pv.lists, pv.cap, pv.header, sp_order, sp_rank, (const float*) pv.table, params_activated ? 1 : 0)
   if (F == 8) {
     if (K <= 5) SKGS_SPK(5, 8); else if (K <= 8) SKGS_SPK(8, 8); else SKGS_SPK(16, 8);
   } else {
@@ -463,7 +469,7 @@ int skgs_sp_lbs_weights_forward(int32_t P, int32_t M, int32_t K, int32_t F, cons
 int skgs_sp_lbs_weights_backward(int32_t P, int32_t M, int32_t K, int32_t F, const float* feature, const float* sp_feature,
     const float* sp_radius_raw, const float* sp_weight_raw, float temperature, const float* weights, const int64_t* indices,
     const float* nn_dist, const float* g_weights, float* g_feature, float* g_sp_feature, float* g_sp_radius, float* g_sp_weight,
-    void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
+    void* workspace, size_t workspace_bytes, int32_t params_activated, skgs_stream_t stream) {
   SKGS_REQUIRE(P >= 0 && M >= 1 && K >= 1 && K <= 16, "sp_lbs_weights_backward: need P >= 0, 1 <= K <= 16");
   SKGS_REQUIRE(F == 0 || F == 8, "sp_lbs_weights_backward: F (hyper dimensions) must be 0 or 8");
   SKGS_REQUIRE(P == 0 || (weights && indices && nn_dist && g_weights && (F == 0 || (feature && sp_feature))),
@@ -477,12 +483,12 @@ int skgs_sp_lbs_weights_backward(int32_t P, int32_t M, int32_t K, int32_t F, con
   float* partials = reinterpret_cast<float*>(workspace);
   if (F == 8)
     hipLaunchKernelGGL((sp_weights_backward_kernel<8>), dim3(nblk), dim3(SPK_THREADS), lds, s, P, M, K, feature, sp_feature,
-        sp_radius_raw, sp_weight_raw, temperature, weights, indices, nn_dist, g_weights, g_feature, partials);
+        sp_radius_raw, sp_weight_raw, temperature, weights, indices, nn_dist, g_weights, g_feature, partials, params_activated ? 1 : 0);
   else
     hipLaunchKernelGGL((sp_weights_backward_kernel<0>), dim3(nblk), dim3(SPK_THREADS), lds, s, P, M, K, feature, sp_feature,
-        sp_radius_raw, sp_weight_raw, temperature, weights, indices, nn_dist, g_weights, g_feature, partials);
+        sp_radius_raw, sp_weight_raw, temperature, weights, indices, nn_dist, g_weights, g_feature, partials, params_activated ? 1 : 0);
   hipLaunchKernelGGL(sp_weights_finalize_kernel, dim3((M * V + 255) / 256), dim3(256), 0, s, M, F, nblk, partials, g_sp_feature,
-      g_sp_radius, g_sp_weight, sp_radius_raw, sp_weight_raw);
+      g_sp_radius, g_sp_weight, sp_radius_raw, sp_weight_raw, params_activated ? 1 : 0);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -148,6 +148,69 @@ class _KnnDistWeights(torch.autograd.Function):
         return g_p, g_j, g_r, g_k, None, None
 
 
+class _SpKnnWeights(torch.autograd.Function):
+    """calc_LBS_weight over SUPERPOINT-sized tables (hundreds of bones; sk_gs.py:751-774 as stage ``sp`` calls it, :844) as the
+    launches of ``FusedSuperpointStep``: ``skgs_sp_lbs_weights_forward`` (csrc/sp_knn.hip: 4 lanes per Gaussian, exact
+    wave-wide prunes; 57 us at P = 100k, M = 512, 3 + 8 dimensions, where ``skgs_knn_dist_weights_forward`` -- built for the
+    <= 60 bones of stage ``sk`` -- takes 705) with the weighting's parameters ACTIVATED as the reference passes them, and
+    ``skgs_sp_lbs_weights_backward`` / ``skgs_lbs_weights_backward``.  The positions carry no gradient here (the caller
+    detaches them, :753-755): gradients go to the hyper features, the radii / kernel weights, or the logit table."""
+
+    @staticmethod
+    def forward(ctx, xyz, feature, sp_xyz, sp_feature, kernel_radius, kernel_weight, sp_W, temperature: float, K: int):
+        lib = _C.load_library()
+        _C._require_gpu(xyz, 'points')
+        dev = xyz.device
+        f32 = lambda t: None if t is None else _C._f32c(t, dev)  # noqa: E731
+        with _C._on_device(dev):
+            pts, feat, sp, sfeat, rad, kw, spw = (f32(t) for t in (xyz, feature, sp_xyz, sp_feature, kernel_radius, kernel_weight, sp_W))
+            P, M, F = pts.shape[0], sp.shape[0], 0 if feat is None else feat.shape[1]
+            idx = torch.zeros((P, K), dtype=torch.int64, device=dev)
+            w = torch.empty((P, K), dtype=torch.float32, device=dev)
+            dist = torch.empty((P, K), dtype=torch.float32, device=dev)
+            ptr = lambda t: C.c_void_p(_C._ptr(t))  # noqa: E731
+            _C._check(lib.skgs_sp_lbs_weights_forward(
+                C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(F), ptr(pts), ptr(feat), ptr(sp), ptr(sfeat), ptr(rad), ptr(kw),
+                C.c_float(float(temperature)), ptr(spw), None, None, ptr(idx), ptr(w), ptr(dist), None, C.c_size_t(0), C.c_int32(1),
+                _C._stream()))
+        ctx.save_for_backward(feat, sfeat, rad, kw, w, idx, dist)
+        ctx.temperature, ctx.logits, ctx.M = float(temperature), spw is not None, M
+        ctx.mark_non_differentiable(idx)
+        return w, idx
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_w, _g_idx):
+        feat, sfeat, rad, kw, w, idx, dist = ctx.saved_tensors
+        lib = _C.load_library()
+        dev = w.device
+        (P, K), M = w.shape, ctx.M
+        F = 0 if feat is None else feat.shape[1]
+        need_f, need_sf, need_r, need_k, need_W = ctx.needs_input_grad[1], *ctx.needs_input_grad[3:7]
+        ptr = lambda t: C.c_void_p(_C._ptr(t))  # noqa: E731
+        g_f = g_sf = g_r = g_k = g_W = None
+        with _C._on_device(dev):
+            g_w = _C._f32c(g_w, dev)
+            if ctx.logits:  # `W`: the weights do not depend on the distances
+                if need_W:
+                    g_W = torch.empty((P, M), dtype=torch.float32, device=dev)
+                    _C._check(lib.skgs_lbs_weights_backward(C.c_int32(P), C.c_int32(M), C.c_int32(K), ptr(w), ptr(idx), ptr(g_w), ptr(g_W),
+                                                            _C._stream()))
+            else:
+                g_f = torch.empty((P, F), dtype=torch.float32, device=dev) if (need_f and F) else None
+                g_sf = torch.empty((M, F), dtype=torch.float32, device=dev) if (need_sf and F) else None
+                g_r = torch.empty((M,), dtype=torch.float32, device=dev) if (need_r and rad is not None) else None
+                g_k = torch.empty((M,), dtype=torch.float32, device=dev) if (need_k and kw is not None) else None
+                lib.skgs_sp_lbs_weights_workspace_bytes.restype = C.c_size_t
+                ws = torch.empty((int(lib.skgs_sp_lbs_weights_workspace_bytes(C.c_int32(P), C.c_int32(M), C.c_int32(F))) + 16,),
+                                 dtype=torch.uint8, device=dev)
+                _C._check(lib.skgs_sp_lbs_weights_backward(
+                    C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(F), ptr(feat), ptr(sfeat), ptr(rad), ptr(kw),
+                    C.c_float(ctx.temperature), ptr(w), ptr(idx), ptr(dist), ptr(g_w), ptr(g_f), ptr(g_sf), ptr(g_r), ptr(g_k),
+                    C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()), C.c_int32(1), _C._stream()))
+        return None, g_f, None, g_sf, g_r, g_k, g_W, None, None
+
+
 def calc_lbs_weight(points: Tensor, joints: Tensor, K: int, sp_W: Optional[Tensor] = None,
                     kernel_radius: Optional[Tensor] = None, kernel_weight: Optional[Tensor] = None,
                     temperature: float = 1., feature: Optional[Tensor] = None, sp_feature: Optional[Tensor] = None
@@ -155,6 +218,15 @@ def calc_lbs_weight(points: Tensor, joints: Tensor, K: int, sp_W: Optional[Tenso
     """``calc_LBS_weight`` of the reference (networks/sk_gs.py:751-774): K nearest bones + one of three weightings.
     Every branch is one HIP launch per direction (pytorch3d.knn_points semantics for the search): `W` on xyz through
     ``skgs_knn_lbs_weights``, the distance-based ones -- in 3 or 3 + 8 dimensions -- through ``skgs_knn_dist_weights_*``."""
+    # superpoint-sized tables (stage sp): the search built for them -- when the positions carry no gradient (with hyper features
+    # the reference detaches them, sk_gs.py:753-755), 0 or 8 hyper dimensions, and the table fits its LDS copy
+    M = joints.shape[0]
+    with_f = feature is not None and sp_feature is not None
+    if (points.is_cuda and 60 < M <= 1024 and K <= 16 and K <= M and not (sp_W is not None and kernel_radius is not None)
+            and (kernel_weight is None or kernel_radius is not None)
+            and ((with_f and feature.shape[-1] == 8) or (not with_f and not points.requires_grad and not joints.requires_grad))):
+        return _SpKnnWeights.apply(points.detach(), feature if with_f else None, joints.detach(), sp_feature if with_f else None,
+                                   kernel_radius, kernel_weight, sp_W, float(temperature), K)
     if feature is not None and sp_feature is not None:
         points = torch.cat([points.detach(), feature], dim=-1)
         joints_q = torch.cat([joints.detach(), sp_feature], dim=-1)

@@ -432,7 +432,8 @@ class FusedSuperpointStep(FusedViewStep):
         chk(lib.skgs_sp_lbs_weights_forward(
             C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(self.F), _p(m._xyz), _p(m.hyper_feature), _p(m.sp_points),
             _p(m.sp_hyper_feature), _p(m._sp_radius), _p(m._sp_weight), C.c_float(m.lbs_temperature), _p(m.sp_W),
-            _p(self.sp_order), _p(self.sp_rank), _p(self.indices), _p(self.weights), _p(self.nn_dist), _p(self.pairs), C.c_size_t(self.pairs.numel()), st))
+            _p(self.sp_order), _p(self.sp_rank), _p(self.indices), _p(self.weights), _p(self.nn_dist), _p(self.pairs), C.c_size_t(self.pairs.numel()),
+            C.c_int32(0), st))
         d = self._deform_inputs(time_id)
         chk(lib.skgs_lbs_deform_forward(C.byref(d), _p(self.means), _p(self.scales), _p(self.rotations), _p(self.opacity),
                                         None, None, None, st))

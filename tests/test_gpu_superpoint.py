@@ -148,7 +148,7 @@ def _sp_forward(P, M, K, F, pts, sp, feat, sfeat, radius_raw=None, kweight_raw=N
         rank[order.long()] = torch.arange(M, dtype=order.dtype, device=order.device)
     _C._check(lib.skgs_sp_lbs_weights_forward(C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(F), p(pts), p(feat), p(sp),
                                               p(sfeat), p(radius_raw), p(kweight_raw), C.c_float(T), p(sp_W), p(order), p(rank), p(idx), p(w), p(d),
-                                              None, C.c_size_t(0), _C._stream()))
+                                              None, C.c_size_t(0), C.c_int32(0), _C._stream()))
     return idx, w, d
 
 
@@ -218,7 +218,7 @@ def test_sp_search_and_weightings_match_the_oracle_at_full_size(oracle32, oracle
         _C._check(lib.skgs_sp_lbs_weights_backward(
             C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(F), p(d_feat), p(d_sfeat), p(rr), p(kk), C.c_float(T), p(w), p(idx),
             p(d), p(G.to(dev)), p(g_feat) if F else None, p(g_sfeat) if F else None, p(g_r), p(g_k), p(ws),
-            C.c_size_t(ws.numel()), _C._stream()))
+            C.c_size_t(ws.numel()), C.c_int32(0), _C._stream()))
         if F:
             want_gp, want_gj = oracle64.knn_dist_backward(to_np(cat(pts, feat)), to_np(cat(sp, sfeat)), want_i, g_dist)
             assert rel_err(g_feat, want_gp[:, 3:]) <= 1e-4, method
@@ -229,17 +229,56 @@ def test_sp_search_and_weightings_match_the_oracle_at_full_size(oracle32, oracle
             assert rel_err(g_k, g_kw) <= 1e-4, method
 
 
-def test_sp_search_agrees_bit_for_bit_with_the_operator_path():
-    """the fused step's one-launch search + weighting (split pointers) and the operator path (`calc_lbs_weight` on the
-    concatenated rows -> skgs_knn_dist_weights_forward) return identical indices and weights"""
+@pytest.mark.parametrize('method', ['weighted_kernel', 'kernel', 'dist', 'W'])
+def test_operator_path_at_superpoint_size_runs_the_sp_search_and_matches_the_oracle(oracle32, oracle64, method):
+    """`sk_gs_amd.deform.calc_lbs_weight` -- the reference's calc_LBS_weight surface, ACTIVATED radii / kernel weights -- with a
+    superpoint-sized table routes to the launches of the fused step (csrc/sp_knn.hip; 57 us where the search built for <= 60 bones
+    takes 705): indices identical to the fused step's, weights <= 2e-6 of the oracle, and autograd's gradients w.r.t. the hyper
+    features, the ACTIVATED radii / kernel weights and the logit table <= 1e-4 of the oracle's analytic ones."""
+    from sk_gs_amd import deform
     from sk_gs_amd.deform import calc_lbs_weight
-    P, M, K, F = 20_000, 512, 5, 8
+    P, M, K, F, T = 20_000, 512, 5, 8, 0.05
     pts, sp, feat, sfeat, radius_raw, kweight_raw = [t.cuda() for t in _sp_scene(P, M, 3, F)]
-    idx, w, d = _sp_forward(P, M, K, F, pts, sp, feat, sfeat, radius_raw, kweight_raw)
-    w2, idx2 = calc_lbs_weight(pts, sp, K, kernel_radius=torch.exp(radius_raw), kernel_weight=torch.sigmoid(kweight_raw),
-                               feature=feat, sp_feature=sfeat)
-    assert torch.equal(idx, idx2)
-    assert float((w - w2).abs().max()) <= 1e-6  # (exp / sigmoid of the raw parameters: in the kernel vs torch)
+    g = torch.Generator().manual_seed(11)
+    G = torch.randn(P, K, generator=g)
+    radius, kw = torch.exp(radius_raw).requires_grad_(True), torch.sigmoid(kweight_raw).requires_grad_(True)
+    feat, sfeat = feat.requires_grad_(True), sfeat.requires_grad_(True)
+    sp_W = torch.randn(P, M, generator=g).cuda().requires_grad_(True) if method == 'W' else None
+    calls = []
+    orig = deform._SpKnnWeights.apply
+    deform._SpKnnWeights.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+    try:
+        w, idx = calc_lbs_weight(pts, sp, K, sp_W=sp_W, kernel_radius=radius if method in ('weighted_kernel', 'kernel') else None,
+                                 kernel_weight=kw if method == 'weighted_kernel' else None, temperature=T, feature=feat, sp_feature=sfeat)
+    finally:
+        deform._SpKnnWeights.apply = orig
+    assert calls, 'the superpoint-sized route was not taken'
+    (w * G.cuda()).sum().backward()
+    cat = lambda a, b: torch.cat([a, b], 1)  # noqa: E731
+    want_d, want_i = oracle32.knn_bones(to_np(cat(pts, feat)), to_np(cat(sp, sfeat)), K)
+    np.testing.assert_array_equal(to_np(idx), want_i)
+    idx_f, _, _ = _sp_forward(P, M, K, F, pts, sp, feat.detach(), sfeat.detach(), radius_raw, kweight_raw)
+    assert torch.equal(idx, idx_f)  # (and the fused step's call of the same launch)
+    if method == 'W':
+        want_w = oracle32.lbs_weights(to_np(sp_W), want_i)
+        assert np.abs(to_np(w) - want_w).max() <= 2e-6
+        dot = (w.detach() * G.cuda()).sum(1, keepdim=True)
+        want = torch.zeros(P, M, device='cuda').scatter_(1, idx, w.detach() * (G.cuda() - dot))
+        assert rel_err(sp_W.grad, want) <= 1e-5
+        assert feat.grad is None and sfeat.grad is None  # (the logits do not depend on the distances)
+        return
+    if method == 'dist':
+        want_w, g_dist = oracle64.lbs_weights_dist(want_d, T, g_weights=to_np(G))
+    else:
+        want_w, gr = oracle64.lbs_weights_kernel(want_d, want_i, to_np(radius).astype(np.float64),
+                                                 to_np(kw).astype(np.float64) if method == 'weighted_kernel' else None, g_weights=to_np(G))
+        g_dist = gr['g_dist']
+        assert rel_err(radius.grad, gr['g_radius']) <= 1e-4       # (w.r.t. the ACTIVATED radius: no d exp)
+        if method == 'weighted_kernel':
+            assert rel_err(kw.grad, gr['g_weight']) <= 1e-4
+    assert np.abs(to_np(w) - want_w).max() <= 2e-6
+    want_gp, want_gj = oracle64.knn_dist_backward(to_np(cat(pts, feat)), to_np(cat(sp, sfeat)), want_i, g_dist)
+    assert rel_err(feat.grad, want_gp[:, 3:]) <= 1e-4 and rel_err(sfeat.grad, want_gj[:, 3:]) <= 1e-4
 
 
 # ---------------------------------------------------------------------------------------------------- the fused step
@@ -378,7 +417,7 @@ def test_sp_skinning_backward_by_inverse_lists_matches_the_two_call_sequence_and
     for rep in range(2):  # (twice: the forward clears the lists it filed before)
         _C._check(lib.skgs_sp_lbs_weights_forward(C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(F), p(d_pts), p(d_feat), p(d_sp),
                                                   p(d_sfeat), p(rr), p(kk), C.c_float(T), p(sp_W), None, None, p(idx), p(w), p(dist), p(pairs),
-                                                  C.c_size_t(pairs.numel()), _C._stream()))
+                                                  C.c_size_t(pairs.numel()), C.c_int32(0), _C._stream()))
     torch.cuda.synchronize()
     hdr = pairs[:8].view(torch.int32)
     counts = pairs[256:256 + 4 * M].view(torch.int32)
@@ -418,7 +457,7 @@ def test_sp_skinning_backward_by_inverse_lists_matches_the_two_call_sequence_and
         _C._check(lib.skgs_sp_lbs_weights_backward(
             C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(F), p(d_feat), p(d_sfeat), p(rr), p(kk), C.c_float(T), p(w), p(idx),
             p(dist), p(b['g_w']), p(b['g_feat']) if F else None, p(b['g_sf']) if F else None, p(b['g_r']), p(b['g_k']), p(sws),
-            C.c_size_t(sws.numel()), _C._stream()))
+            C.c_size_t(sws.numel()), C.c_int32(0), _C._stream()))
         names += (['g_feat', 'g_sf'] if F else []) + (['g_r'] if rr is not None else []) + (['g_k'] if kk is not None else [])
     torch.cuda.synchronize()
     for nme in names:
