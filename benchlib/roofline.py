@@ -9,10 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VALU_PEAK = 256 * 4 * 2.4e9 / 2  # wave-instructions / s: 256 CUs x 4 SIMDs x one wave64 instruction per 2 cycles at 2.4 GHz
 
 
-def committed_counter_profile(cfg_name):
+def committed_counter_profile(cfg_name, file='pmc_render_backward.json'):
     """counters are not collected in a bench run: what the last committed PMC profile of render_backward on this workload says,
     with the file and the commit it was taken at (tools/pmc_summary.py writes both); None when there is none"""
-    pmc = os.path.join(ROOT, 'profiles', 'pmc_render_backward.json')
+    pmc = os.path.join(ROOT, 'profiles', file)
     if not os.path.exists(pmc):
         return None
     try:

@@ -219,6 +219,8 @@ def run(args, base_alg_bytes, configs):
                   + alg_bytes_sp('sp_knn_weights', P, M, K, F, W, H, R_mean) + alg_bytes_sp('sp_knn_weights_backward', P, M, K, F, W, H, R_mean)
                   + alg_bytes_sp('sp_net_forward', P, M, K, F, W, H, R_mean) + alg_bytes_sp('sp_net_backward', P, M, K, F, W, H, R_mean))
     ms_step = elapsed / args.steps * 1e3
+    from benchlib.roofline import committed_counter_profile
+    from_profile = committed_counter_profile(cfg['name'] + ', stage sp', 'pmc_render_backward_sp.json')
     return {
         'metric': f'train iters/sec, SUPERPOINT stage (sp net + 3+8-d search + skinning + rasterize fwd+bwd + L1/SSIM loss + Adam), '
                   f'{P // 1000}k Gaussians @{W}x{H}',
@@ -245,7 +247,9 @@ def run(args, base_alg_bytes, configs):
                    'sorted along a Z-order curve (densify.sort_spatially: what a training loop does after each densification event)'},
         'cpu_baseline': cpu,
         'roofline': {'bound': 'hbm', 'kernel': 'render_backward', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBPS,
-                     'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 5), 'traffic': None, 'avg_us': rb_us,
+                     'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 5),
+                     'traffic': (from_profile or {}).get('hbm_bytes_per_launch'),
+                     'traffic_source': ({k: from_profile.get(k) for k in ('file', 'commit')} if from_profile else None), 'avg_us': rb_us,
                      'alg_bytes_per_launch': int(rb_bytes), 'limiter': 'valu',
                      'whole_step': {'alg_bytes': int(step_bytes), 'ms': round(ms_step, 4),
                                     'frac': round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},

@@ -16,9 +16,7 @@ d=gpurun_out/${tag}_sp   # stage sp: kernel stats + the counters' table (its own
 if [ -d "$d" ]; then
   cp $d/bench_steps100.json profiles/${tag}_sp_bench_steps100.json
   cp $(ls -t $d/stats/*/*kernel_stats.csv | head -1) profiles/${tag}_sp_kernel_stats_bench_steps100.csv
-  cp profiles/pmc_render_backward.json /tmp/pmc_keep.json 2>/dev/null
-  python tools/pmc_summary.py ${tag}_sp $d/fetch $d/write $d/valu > /dev/null
-  cp /tmp/pmc_keep.json profiles/pmc_render_backward.json 2>/dev/null
+  SKGS_PMC_JSON=pmc_render_backward_sp.json SKGS_PROFILE_CONFIG="hook-like-100k-800, stage sp" python tools/pmc_summary.py ${tag}_sp $d/fetch $d/write $d/valu > /dev/null
 fi
 for c in c4 c1; do
   d=gpurun_out/${tag}_$c

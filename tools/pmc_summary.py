@@ -60,8 +60,9 @@ def main():
     if rb:
         k, n, fm, wm, t, extra = rb[0]
         import subprocess
+        # the commit the counters were taken at: SKGS_PROFILE_COMMIT when the summary is made later than the run, else HEAD
         try:
-            commit = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+            commit = os.environ.get('SKGS_PROFILE_COMMIT') or subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
         except Exception:
             commit = None
         rec = {'config': os.environ.get('SKGS_PROFILE_CONFIG', 'hook-like-100k-800'), 'kernel': 'render_backward',
@@ -76,7 +77,8 @@ def main():
             for r in csv.DictReader(open(f)):
                 if 'render_backward_kernel' in r.get('Name', ''):
                     rec['avg_us'] = float(r['AverageNs']) / 1e3
-        json.dump(rec, open(os.path.join(ROOT, 'profiles', 'pmc_render_backward.json'), 'w'), indent=1)
+        # (SKGS_PMC_JSON: another file name, e.g. pmc_render_backward_sp.json for the stage-sp profile)
+        json.dump(rec, open(os.path.join(ROOT, 'profiles', os.environ.get('SKGS_PMC_JSON', 'pmc_render_backward.json')), 'w'), indent=1)
     print('\n'.join(md[:14]))
 
 
