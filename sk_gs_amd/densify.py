@@ -238,4 +238,6 @@ def sort_spatially(model, opt: Optional[FusedAdam] = None, stats=None) -> Tensor
         else:
             stats.xyz_gradient_accum = stats.xyz_gradient_accum[rows]
             stats.denom, stats.max_radii2D = stats.denom[rows], stats.max_radii2D[rows]
+        if getattr(stats, 'sparse_logits', False) and opt is not None:  # stage sp, `W`: the logit table's rows moved with the rest
+            stats.refresh_logit_mask(opt)
     return rows
