@@ -177,7 +177,45 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
   };
   // `wq`: the tightest bound any lane of the quad has on the Gaussian's K-th distance -- a part whose own list is still loose
   // (it has seen a quarter of the candidates) prunes with its partners' (the merged top-K can only be tighter than each part's)
-  float wq = __builtin_inff();
+  // `seed`: with the hint, the K neighbours of the PREVIOUS call (out_idx still holds them) give a bound before the scan starts:
+  // when the K ids are distinct, K superpoints lie within the largest of their CURRENT distances (the scan's own arithmetic), so
+  // the K-th distance cannot exceed it -- whatever the ids are (garbage before the first call: any K distinct rows bound it).
+  // The lists then only ever see candidates within that bound: the insertion network (45 instructions, run by the whole wave
+  // whenever ONE lane has a candidate) fires for the few true members instead of for everything the scan meets while the lists
+  // fill.
+  float seed = __builtin_inff();
+  if (sp_rank && K <= 8) {
+    int pid[8];
+    bool distinct = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pid[k] = k < K ? (int) ((uint32_t) out_idx[(size_t) nn * K + k] % (uint32_t) M) : -1 - k;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = a + 1; b < 8; ++b) distinct = distinct && pid[a] != pid[b];
+    float far = 0.f;
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0 += LPG) {  // lane `part` takes neighbours part, part + 4
+      const int k = k0 + part;
+      if (k < K) {
+        int id = pid[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) id = q == k ? pid[q] : id;
+        const int row  = sp_rank[id];
+        const float4 c = *reinterpret_cast<const float4*>(s_c + row * CROW);
+        const float a0 = p0 - c.x, a1 = p1 - c.y, a2 = p2 - c.z;
+        float d = a0 * a0;
+        d += a1 * a1;
+        d += a2 * a2;
+        if (F > 0) d = tail(d, c, row);
+        far = fmaxf(far, d);
+      }
+    }
+    far = fmaxf(far, dpp_mov<0xb1>(far));
+    far = fmaxf(far, dpp_mov<0x4e>(far));
+    seed = distinct ? far : __builtin_inff();
+  }
+  float wq = seed;
   const int Mq = (M + LPG - 1) / LPG;  // candidates per lane (the last ones may fall beyond M: masked by `in`)
   const int full = (M / (2 * LPG)) * 2;  // iterations-of-one (i) that need no bounds check: i + 1 < full
   for (int i = 0; i < Mq; i += 2) {
@@ -221,7 +259,7 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
     if (any) {  // (wave-uniform) refresh the quad's bound: min over the four parts' last entries
       float w = bd[KCAP - 1];
       w  = fminf(w, dpp_mov<0xb1>(w));  // quad_perm:[1,0,3,2]
-      wq = fminf(w, dpp_mov<0x4e>(w));  // quad_perm:[2,3,0,1]
+      wq = fminf(seed, fminf(w, dpp_mov<0x4e>(w)));  // quad_perm:[2,3,0,1]
     }
   }
   // ---- merge the quad's four lists: after xor 1 lanes (0,1) and (2,3) agree, after xor 2 all four
