@@ -47,6 +47,19 @@ __global__ void __launch_bounds__(256) chain_kernel(float* out, float seed) {
       if (KIND == 23 && (i & 3) == 0) asm volatile("v_cmp_lt_f32 vcc, %0, %4\n\tv_cndmask_b32 %0, %0, %4, vcc\n\tv_cndmask_b32 %1, %1, %4, vcc\n\tv_cndmask_b32 %2, %2, %4, vcc\n\tv_cndmask_b32 %3, %3, %4, vcc" : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]) : "v"(m) : "vcc");
       if (KIND == 24 && (i & 3) == 0) asm volatile("v_cmp_lt_f32 vcc, %0, %4\n\tv_cndmask_b32_e64 %0, %0, %4, vcc\n\tv_cndmask_b32_e64 %1, %1, %4, vcc\n\tv_cndmask_b32_e64 %2, %2, %4, vcc\n\tv_cndmask_b32_e64 %3, %3, %4, vcc" : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]) : "v"(m) : "vcc");
       if (KIND == 18) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(a[i]) : "v"(a[(i + 1) % UNROLL]), "v"(m));
+      // encodings: the same operation as VOP2 / VOPC (32-bit) and as VOP3 (64-bit)
+      if (KIND == 30) asm volatile("v_max_f32_e64 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+      if (KIND == 31) asm volatile("v_min_f32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+      if (KIND == 32) asm volatile("v_add_f32_e64 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+      if (KIND == 33) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+      if (KIND == 34) asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(mask) : "v"(a[i]), "v"(m));
+      if (KIND == 35) asm volatile("v_sub_f32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+      if (KIND == 36) asm volatile("v_and_b32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+      if (KIND == 37) asm volatile("v_lshlrev_b32_e32 %0, 1, %0" : "+v"(a[i]));
+      if (KIND == 38) asm volatile("v_mul_f32_e64 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+      if (KIND == 39) asm volatile("v_max_f32_e32 %0, %0, %0" : "+v"(a[i]));
+      if (KIND == 40) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+      if (KIND == 41) asm volatile("v_max_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(m));
     }
   }
   float s = 0;
@@ -106,5 +119,17 @@ int main() {
   run<15>("v_add_u32", d_out, cus);
   run<14>("v_rcp_f32", d_out, cus);
   run<17>("v_readlane_b32", d_out, cus);
+  run<30>("v_max_f32_e64", d_out, cus);
+  run<41>("v_max_f32_e32 (operands swapped)", d_out, cus);
+  run<39>("v_max_f32_e32 v, v, v (same reg)", d_out, cus);
+  run<31>("v_min_f32_e32", d_out, cus);
+  run<40>("v_med3_f32", d_out, cus);
+  run<32>("v_add_f32_e64", d_out, cus);
+  run<38>("v_mul_f32_e64", d_out, cus);
+  run<35>("v_sub_f32_e32", d_out, cus);
+  run<33>("v_fmac_f32_e32", d_out, cus);
+  run<34>("v_cmp_lt_f32_e64 -> sgpr", d_out, cus);
+  run<36>("v_and_b32_e32", d_out, cus);
+  run<37>("v_lshlrev_b32_e32", d_out, cus);
   return 0;
 }
