@@ -1,6 +1,8 @@
 """GPU tests of the superpoint stage (stage `sp`, networks/sk_gs.py:830-856): the MFMA deform network (csrc/sp_mlp.hip) against
 its torch restatement (itself pinned to the reference's DeformNetwork by tests/golden/sp_deformnet.npz), the 3+8-d search and
 weightings against the oracle, and the fused step against the operator path."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -471,3 +473,19 @@ def test_sp_skinning_backward_by_inverse_lists_matches_the_two_call_sequence_and
                      ('g_rot', 'g_rot')):
         assert rel_err(a[nme], want[key]) <= 1e-4, (nme, rel_err(a[nme], want[key]))
     assert int(counts.sum()) == 0  # consumed: the finalize launch cleared the lists
+
+
+@pytest.mark.parametrize('method', ['weighted_kernel', 'W'])
+def test_superpoint_training_example_runs_and_fits(method):
+    """examples/train_superpoints.py: the stage-sp loop a user would write (one captured graph for all views, fused optimizer,
+    `W`: the sparse logit-table update) runs, stays finite, overflows nothing and lowers the loss"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, 'examples', 'train_superpoints.py'), '--gaussians', '6000', '--size', '128',
+                        '--iters', '120', '--views', '4', '--lbs-method', method], capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    last = p.stdout.strip().splitlines()[-1]
+    assert f'LBS_method {method}' in last and f'sparse logit update: {method == "W"}' in last, last
+    first, final = [float(x) for x in last.split('loss ')[1].split(',')[0].split(' -> ')]
+    assert final < 0.8 * first, last
