@@ -201,6 +201,25 @@ def run(args, base_alg_bytes, configs):
             rec['TFLOPs'] = round(fl / (us * 1e-6) / 1e12, 2)
             rec['frac_of_mfma_f32_peak'] = round(fl / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
         kernels[name] = rec
+    # forward-only render rate of the stage (the reference's FPS protocol, test.py:102-123: warm-up, then N renders between two
+    # events, views cycled): sp net + search + skinning + rasterize as one graph replay per render
+    fps = None
+    if world == 1:
+        if not use_dist:
+            view_table.clear_order()
+        g_fwd = GraphedSteps(lambda _: step.forward(), collect_garbage=False)
+        view_table.select(0)
+        g_fwd.capture(0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for i in range(220):
+            if i == 20:
+                e0.record()
+            view_table.select(i % args.views)
+            g_fwd(0)
+        e1.record()
+        torch.cuda.synchronize()
+        fps = dict(fused_step_graph=round(200 * 1000.0 / e0.elapsed_time(e1), 1),
+                   protocol='test.py:102-123: 20 warm-up + 200 renders between two events, views cycled')
     from benchlib import launch as _launch
     cluster = _launch.cluster_info(dist, torch, local_rank)  # (a collective: every rank)
     if rank != 0:
@@ -245,7 +264,7 @@ def run(args, base_alg_bytes, configs):
                    'exchange': 'allreduce' if world > 1 else None, 'replicas_identical': replicas_identical, 'param_digest': param_digest,
                    'gaussian_order': 'as generated (random)' if args.keep_order else
                    'sorted along a Z-order curve (densify.sort_spatially: what a training loop does after each densification event)'},
-        'cpu_baseline': cpu,
+        'cpu_baseline': cpu, 'fps_forward_render': fps,
         'roofline': {'bound': 'hbm', 'kernel': 'render_backward', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBPS,
                      'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 5),
                      'traffic': (from_profile or {}).get('hbm_bytes_per_launch'),

@@ -237,6 +237,7 @@ def test_stage_sp_prints_the_contract_line():
     total = sum(v['us'] * v['launches_per_step'] for v in k.values())
     assert 0.8 * d['ms_per_step'] * 1e3 < total < 1.6 * d['ms_per_step'] * 1e3
     assert d['ms_per_step'] < 1.0  # (0.49 ms when written: within 1.5x of the skeleton stage's step)
+    assert d['fps_forward_render']['fused_step_graph'] > 500  # (the reference's FPS protocol on the stage's forward: ~5500)
 
 
 def test_stage_sp_two_ranks_share_the_gpu_and_stay_identical():
