@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 #include "skgs_common.h"
 
@@ -142,9 +143,9 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
   for (int k = 0; k < KCAP; ++k) bd[k] = __builtin_inff(), bi[k] = 0x7fffffff;  // (loses every (distance, id) comparison)
   // two candidates (j, j + 4) per iteration: both first rows are requested together, ONE wave-wide test skips the pair when
   // neither xyz part can enter any lane's list (the common case once the lists have filled)
-  auto tail = [&](float d, const float4& c0, int j) {
-    const float4 c1 = *reinterpret_cast<const float4*>(s_c + j * CROW + 4);
-    const float4 c2 = *reinterpret_cast<const float4*>(s_c + j * CROW + 8);
+  auto tail = [&](float d, const float4& c0, const float* rowp) {
+    const float4 c1 = *reinterpret_cast<const float4*>(rowp + 4);
+    const float4 c2 = *reinterpret_cast<const float4*>(rowp + 8);
     const float e3 = f[0] - c0.w, e4 = f[1] - c1.x, e5 = f[2] - c1.y, e6 = f[3] - c1.z, e7 = f[4] - c1.w;
     const float e8 = f[5] - c2.x, e9 = f[6] - c2.y, e10 = f[7] - c2.z;
     d += e3 * e3;
@@ -207,7 +208,7 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
         float d = a0 * a0;
         d += a1 * a1;
         d += a2 * a2;
-        if (F > 0) d = tail(d, c, row);
+        if (F > 0) d = tail(d, c, s_c + row * CROW);
         far = fmaxf(far, d);
       }
     }
@@ -218,13 +219,21 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
   float wq = seed;
   const int Mq = (M + LPG - 1) / LPG;  // candidates per lane (the last ones may fall beyond M: masked by `in`)
   const int full = (M / (2 * LPG)) * 2;  // iterations-of-one (i) that need no bounds check: i + 1 < full
-  for (int i = 0; i < Mq; i += 2) {
-    const bool checked = i + 1 >= full;
-    const int pa = part + LPG * i, pb = pa + LPG;
-    const bool ina = !checked || pa < M, inb = !checked || ((i + 1 < Mq) && pb < M);
-    const int ja = wrap(s0 + base + dir * (2 * i)), jb = wrap(s0 + base + dir * (2 * i + 2));
-    const float4 ca = *reinterpret_cast<const float4*>(s_c + ja * CROW);
-    const float4 cb = *reinterpret_cast<const float4*>(s_c + jb * CROW);
+  // The lane's two rows as BYTE offsets into the table, advanced by 4 rows per iteration on the lane's own side of s0 and folded
+  // back into [0, 48 M) with one three-way minimum (x, x - 48 M, x + 48 M as unsigned: exactly one of them is in range) -- the
+  // row index arithmetic (two wraps, two 32-bit multiplies by the row size) was 19 of the ~45 instructions of a skipped iteration
+  const uint32_t M48 = (uint32_t) M * (CROW * 4);
+  auto fold = [&](uint32_t x) { return min(min(x, x - M48), x + M48); };
+  uint32_t oa = (uint32_t) wrap(s0 + base) * (CROW * 4), ob = (uint32_t) wrap(s0 + base + 2 * dir) * (CROW * 4);
+  const uint32_t ostep = (uint32_t) (dir * 4 * CROW * 4);
+  const char* tbl = reinterpret_cast<const char*>(s_c);
+  auto visit = [&](int i, auto checked_c) {
+    constexpr bool checked = decltype(checked_c)::value;
+    const float* pa_row = reinterpret_cast<const float*>(tbl + oa);
+    const float* pb_row = reinterpret_cast<const float*>(tbl + ob);
+    oa = fold(oa + ostep), ob = fold(ob + ostep);
+    const float4 ca = *reinterpret_cast<const float4*>(pa_row);
+    const float4 cb = *reinterpret_cast<const float4*>(pb_row);
     const float a0 = p0 - ca.x, a1 = p1 - ca.y, a2 = p2 - ca.z;
     const float b0 = p0 - cb.x, b1 = p1 - cb.y, b2 = p2 - cb.z;
     float da = a0 * a0;  // (0 + t = t: the oracle's `d = 0; d += df * df` starts here)
@@ -233,27 +242,30 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
     float db = b0 * b0;
     db += b1 * b1;
     db += b2 * b2;
-    if (checked) {
+    bool ina = true, inb = true;
+    if (checked) {  // the last iterations of a table whose size is not a multiple of 8: positions beyond M are masked
+      const int pa = part + LPG * i, pb = pa + LPG;
+      ina = pa < M, inb = (i + 1 < Mq) && pb < M;
       da = ina ? da : __builtin_inff();
       db = inb ? db : __builtin_inff();
     }
     // exact: the sums only grow, so a pair whose xyz parts already lose cannot enter ("<=": an equal distance with a lower id
     // still displaces the list's last entry)
-    if (__builtin_amdgcn_ballot_w64((da <= wq) | (db <= wq)) == 0) continue;
+    if (__builtin_amdgcn_ballot_w64((da <= wq) | (db <= wq)) == 0) return;
     if (F > 0) {
-      if (ina) da = tail(da, ca, ja);
-      if (inb) db = tail(db, cb, jb);
+      if (ina) da = tail(da, ca, pa_row);
+      if (inb) db = tail(db, cb, pb_row);
     }
     // (a lane whose candidate cannot enter inserts a NaN: every comparison fails, nothing moves -- no divergent branch)
     bool any = false;
     const uint64_t ma = __builtin_amdgcn_ballot_w64(da <= wq);
     if (ma != 0) {
-      topk_insert_lex<KCAP>(bd, bi, sel(ma, da, __builtin_nanf("")), __builtin_bit_cast(int, s_c[ja * CROW + CROW - 1]));
+      topk_insert_lex<KCAP>(bd, bi, sel(ma, da, __builtin_nanf("")), __builtin_bit_cast(int, pa_row[CROW - 1]));
       any = true;
     }
     const uint64_t mb = __builtin_amdgcn_ballot_w64(db <= wq);
     if (mb != 0) {
-      topk_insert_lex<KCAP>(bd, bi, sel(mb, db, __builtin_nanf("")), __builtin_bit_cast(int, s_c[jb * CROW + CROW - 1]));
+      topk_insert_lex<KCAP>(bd, bi, sel(mb, db, __builtin_nanf("")), __builtin_bit_cast(int, pb_row[CROW - 1]));
       any = true;
     }
     if (any) {  // (wave-uniform) refresh the quad's bound: min over the four parts' last entries
@@ -261,7 +273,10 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
       w  = fminf(w, dpp_mov<0xb1>(w));  // quad_perm:[1,0,3,2]
       wq = fminf(seed, fminf(w, dpp_mov<0x4e>(w)));  // quad_perm:[2,3,0,1]
     }
-  }
+  };
+  int it = 0;
+  for (; it + 1 < full; it += 2) visit(it, std::false_type{});
+  for (; it < Mq; it += 2) visit(it, std::true_type{});
   // ---- merge the quad's four lists: after xor 1 lanes (0,1) and (2,3) agree, after xor 2 all four
 #pragma unroll
   for (int step = 1; step <= 2; step <<= 1) {
