@@ -530,7 +530,9 @@ int skgs_deform_mlp_status(const void* workspace, uint32_t* host_words4, skgs_st
 int skgs_sp_lbs_weights_forward(int32_t P, int32_t M, int32_t K, int32_t F, const float* points, const float* feature,
     const float* sp_points, const float* sp_feature, const float* sp_radius_raw, const float* sp_weight_raw, float temperature,
     const float* sp_W, const int32_t* sp_order /* or NULL */, const int32_t* sp_rank /* or NULL */, int64_t* out_idx,
-    float* out_weights, float* out_dist, void* pairs /* or NULL */, size_t pairs_bytes, int32_t params_activated, skgs_stream_t stream);
+    float* out_weights, float* out_dist, void* pairs /* or NULL */, size_t pairs_bytes, int32_t params_activated,
+    int32_t pairs_prepared /* the table and counters of `pairs` were prepared by skgs_sp_net_forward's launch (skgs_sp_prepare) */,
+    skgs_stream_t stream);
 size_t skgs_sp_lbs_weights_workspace_bytes(int32_t P, int32_t M, int32_t F);
 int skgs_sp_lbs_weights_backward(int32_t P, int32_t M, int32_t K, int32_t F, const float* feature, const float* sp_feature,
     const float* sp_radius_raw, const float* sp_weight_raw, float temperature, const float* weights, const int64_t* indices,
@@ -588,8 +590,21 @@ typedef struct skgs_sp_net {
 } skgs_sp_net;
 size_t skgs_sp_net_saved_bytes(int32_t M);
 size_t skgs_sp_net_workspace_bytes(int32_t M);
+/* prepare (may be NULL): the per-step preparation of the stage's SEARCH -- its superpoint table packed in scan order, the
+ * inverse lists' header and counters cleared (what skgs_sp_lbs_weights_forward otherwise does in a small launch of its own) --
+ * done by extra workgroups of this call's weight-transposition launch: the two are independent preparations of parameters.
+ * Give the SAME pairs buffer / sp_order / sp_points / sp_feature to the skgs_sp_lbs_weights_forward call that follows, with
+ * pairs_prepared = 1. */
+typedef struct skgs_sp_prepare {
+  int32_t P, M, K, F;
+  const float* sp_points;
+  const float* sp_feature;   /* [M,F] or NULL (F = 0) */
+  const int32_t* sp_order;   /* or NULL */
+  void* pairs;
+  size_t pairs_bytes;
+} skgs_sp_prepare;
 int skgs_sp_net_forward(const skgs_sp_net* net, float* raw /* [M,10] or NULL */, float* bone_T, float* d_rot, float* d_scale,
-    void* saved, size_t saved_bytes, skgs_stream_t stream);
+    void* saved, size_t saved_bytes, const skgs_sp_prepare* prepare, skgs_stream_t stream);
 int skgs_sp_net_backward(const skgs_sp_net* net, const skgs_sp_net* grads, const float* g_bone_T, const float* g_d_rot,
     const float* g_d_scale, const float* g_raw, const void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes,
     const skgs_adam_range* side, skgs_stream_t stream);

@@ -321,6 +321,35 @@ struct SpPairsView {
   float* table;      // [M][12]: the superpoints as the search's LDS rows (xyz | 8 hyper | id), in scan order
   int cap;
 };
+// The superpoint table of the search packed once per step -- rows [xyz | hyper | id] in scan order, 12 floats each -- and the
+// inverse lists' header and counters cleared: the job of sp_knn.hip::sp_prepare_kernel, or of extra workgroups of the network's
+// weight-transposition launch in front of it (sp_mlp.hip: both are per-step preparations of parameters, neither needs the other)
+struct SpPrepareJob {
+  int M, F;
+  const float* sp_points;
+  const float* sp_feature;
+  const int32_t* sp_order;
+  uint32_t* header_and_counts;
+  int n_clear;
+  float* table;
+};
+#if defined(__HIPCC__)
+__device__ __forceinline__ void sp_prepare_element(const SpPrepareJob& j, int i) {
+  constexpr int ROW = 12;
+  if (i < j.n_clear) j.header_and_counts[i] = 0u;
+  if (i >= j.M * ROW) return;
+  const int r = i / ROW, c = i - r * ROW;
+  const int id = j.sp_order ? j.sp_order[r] : r;
+  float v = 0.f;
+  if (c < 3)
+    v = j.sp_points[3 * id + c];
+  else if (c < 3 + j.F)
+    v = j.sp_feature[(size_t) id * j.F + c - 3];
+  else if (c == ROW - 1)
+    v = __builtin_bit_cast(float, id);
+  j.table[i] = v;
+}
+#endif
 inline size_t sp_pairs_capacity(int P, int M, int K) {
   const size_t mean = ((size_t) P * K + M - 1) / M;
   return std::min<size_t>((size_t) std::max(P, 1), std::max<size_t>(4096, 16 * mean));

@@ -76,22 +76,8 @@ __device__ __forceinline__ float act_kweight(const float* __restrict__ w, int j,
 // One small launch in front of the search (when the caller gave the pair buffer): the list header and counters are cleared and
 // the superpoint table is packed ONCE -- rows [xyz | hyper | id] in scan order -- so that each of the search's ~1500 workgroups
 // fills its LDS copy with six coalesced 16-byte loads per thread instead of 24 dependent gathers (order -> position / feature).
-__global__ void __launch_bounds__(256) sp_prepare_kernel(int M, int F, const float* __restrict__ sp_points,
-    const float* __restrict__ sp_feature, const int32_t* __restrict__ sp_order, uint32_t* __restrict__ header_and_counts,
-    int n_clear, float* __restrict__ table) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n_clear) header_and_counts[i] = 0u;
-  if (i >= M * CROW) return;
-  const int r = i / CROW, c = i - r * CROW;
-  const int j = sp_order ? sp_order[r] : r;
-  float v = 0.f;
-  if (c < 3)
-    v = sp_points[3 * j + c];
-  else if (c < 3 + F)
-    v = sp_feature[(size_t) j * F + c - 3];
-  else if (c == CROW - 1)
-    v = __builtin_bit_cast(float, j);
-  table[i] = v;
+__global__ void __launch_bounds__(256) sp_prepare_kernel(SpPrepareJob job) {
+  sp_prepare_element(job, blockIdx.x * 256 + threadIdx.x);
 }
 
 // F = number of hyper dimensions (0 or 8).  FOUR lanes per Gaussian: lane `part` scans the superpoints j = part (mod 4) --
@@ -483,7 +469,7 @@ size_t skgs_sp_lbs_weights_workspace_bytes(int32_t P, int32_t M, int32_t F) {
 int skgs_sp_lbs_weights_forward(int32_t P, int32_t M, int32_t K, int32_t F, const float* points, const float* feature,
     const float* sp_points, const float* sp_feature, const float* sp_radius_raw, const float* sp_weight_raw, float temperature,
     const float* sp_W, const int32_t* sp_order, const int32_t* sp_rank, int64_t* out_idx, float* out_weights, float* out_dist,
-    void* pairs, size_t pairs_bytes, int32_t params_activated, skgs_stream_t stream) {
+    void* pairs, size_t pairs_bytes, int32_t params_activated, int32_t pairs_prepared, skgs_stream_t stream) {
   SKGS_REQUIRE(!sp_rank || sp_order, "sp_lbs_weights_forward: sp_rank is the inverse of sp_order: give both");
   SKGS_REQUIRE(P >= 0 && M >= 1 && K >= 1 && K <= 16 && K <= M, "sp_lbs_weights_forward: need P >= 0, 1 <= K <= min(16, M)");
   SKGS_REQUIRE(!pairs || pairs_bytes >= sp_pairs_bytes(P > 0 ? P : 1, M, K), "sp_lbs_weights_forward: pair-list buffer too small (skgs_sp_pairs_bytes)");
@@ -498,10 +484,12 @@ int skgs_sp_lbs_weights_forward(int32_t P, int32_t M, int32_t K, int32_t F, cons
   SpPairsView pv{};
   if (pairs) {  // the lists start empty: whatever an earlier forward filed (with or without a backward) is dropped
     pv = sp_pairs_view(pairs, P, M, K);
-    const int n_clear = 64 + (M + 63) / 64 * 64;  // header + counts (contiguous: the counts start at byte 256)
-    hipLaunchKernelGGL(sp_prepare_kernel, dim3((std::max(n_clear, M * CROW) + 255) / 256), dim3(256), 0, s, M, F, sp_points, sp_feature,
-        sp_order, pv.header, n_clear, pv.table);
-    SKGS_CHECK_HIP(hipGetLastError());
+    if (!pairs_prepared) {  // (else: skgs_sp_net_forward's launch did it, see skgs_sp_prepare)
+      const int n_clear = 64 + (M + 63) / 64 * 64;  // header + counts (contiguous: the counts start at byte 256)
+      const SpPrepareJob job{M, F, sp_points, sp_feature, sp_order, pv.header, n_clear, pv.table};
+      hipLaunchKernelGGL(sp_prepare_kernel, dim3((std::max(n_clear, M * CROW) + 255) / 256), dim3(256), 0, s, job);
+      SKGS_CHECK_HIP(hipGetLastError());
+    }
   }
   ProfScope prof(K_SP_KNN, s);
   const int per_wg = SPK_THREADS / LPG;  // four lanes per Gaussian

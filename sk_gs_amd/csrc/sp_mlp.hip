@@ -229,7 +229,12 @@ __device__ __forceinline__ int head_of(int o, int& row) {  // raw output column 
 // The hidden layers' weights with the contraction index as the row, for the forward's stream: layer 0 [96][256] (rows 93..95
 // zero), layers 1-4, 6, 7 [256][256], layer 5 [96 | 256][256] (its input part padded like layer 0, then the hidden part) --
 // WT_ROWS = 1984 rows.  32 x 32 tiles through LDS; a tile never straddles two layers (96, 256, 352 are multiples of 32).
-__global__ void __launch_bounds__(256) sp_net_transpose_kernel(NetPtrs n, float* __restrict__ wt) {
+constexpr int TRANSPOSE_GROUPS = WT_ROWS / 32 * (SPW / 32);
+__global__ void __launch_bounds__(256) sp_net_transpose_kernel(NetPtrs n, float* __restrict__ wt, SpPrepareJob prep) {
+  if ((int) blockIdx.x >= TRANSPOSE_GROUPS) {  // the search's table and list counters for this step (skgs_sp_prepare)
+    sp_prepare_element(prep, ((int) blockIdx.x - TRANSPOSE_GROUPS) * 256 + (int) threadIdx.x);
+    return;
+  }
   __shared__ float tile[32][33];
   const int rb = blockIdx.x >> 3, nb = blockIdx.x & 7, R0 = 32 * rb;
   int l = 0, base = 0;
@@ -868,7 +873,7 @@ size_t skgs_sp_net_saved_bytes(int32_t M) { return M > 0 ? saved_floats(M) * 4 :
 size_t skgs_sp_net_workspace_bytes(int32_t M) { return M > 0 ? work_bytes(M) : 0; }
 
 int skgs_sp_net_forward(const skgs_sp_net* net, float* raw, float* bone_T, float* d_rot, float* d_scale, void* saved,
-    size_t saved_bytes, skgs_stream_t stream) {
+    size_t saved_bytes, const skgs_sp_prepare* prepare, skgs_stream_t stream) {
   SKGS_REQUIRE(net && net->M >= 0, "sp_net_forward: NULL descriptor or M < 0");
   if (net->M == 0) return 0;
   SKGS_REQUIRE(net->points && net->time && net_complete(net), "sp_net_forward: NULL points / time / parameter");
@@ -878,7 +883,20 @@ int skgs_sp_net_forward(const skgs_sp_net* net, float* raw, float* bone_T, float
   ProfScope prof(K_SP_NET_FWD, s);
   const SavedView sv = saved_view(saved, net->M);
   const NetPtrs n    = net_ptrs(net);
-  hipLaunchKernelGGL(sp_net_transpose_kernel, dim3(WT_ROWS / 32 * (SPW / 32)), dim3(256), 0, s, n, sv.wt);
+  SpPrepareJob prep{};
+  int prep_groups = 0;
+  if (prepare && prepare->pairs) {
+    SKGS_REQUIRE(prepare->M >= 1 && prepare->K >= 1 && (prepare->F == 0 || prepare->F == 8) && prepare->sp_points &&
+                     (prepare->F == 0 || prepare->sp_feature),
+        "sp_net_forward: bad prepare job");
+    SKGS_REQUIRE(prepare->pairs_bytes >= skgs_sp_pairs_bytes(prepare->P > 0 ? prepare->P : 1, prepare->M, prepare->K),
+        "sp_net_forward: pair-list buffer too small (skgs_sp_pairs_bytes)");
+    const SpPairsView pv = sp_pairs_view(prepare->pairs, prepare->P > 0 ? prepare->P : 1, prepare->M, prepare->K);
+    const int n_clear = 64 + (prepare->M + 63) / 64 * 64;
+    prep = SpPrepareJob{prepare->M, prepare->F, prepare->sp_points, prepare->sp_feature, prepare->sp_order, pv.header, n_clear, pv.table};
+    prep_groups = (std::max(n_clear, prepare->M * 12) + 255) / 256;
+  }
+  hipLaunchKernelGGL(sp_net_transpose_kernel, dim3(TRANSPOSE_GROUPS + prep_groups), dim3(256), 0, s, n, sv.wt, prep);
   SKGS_CHECK_HIP(hipGetLastError());
   hipLaunchKernelGGL(sp_net_forward_kernel, dim3(pad_rows(net->M) / RB), dim3(NT), 0, s, net->M, n, raw, bone_T, d_rot, d_scale, sv);
   SKGS_CHECK_HIP(hipGetLastError());

@@ -172,7 +172,7 @@ class _SpKnnWeights(torch.autograd.Function):
             _C._check(lib.skgs_sp_lbs_weights_forward(
                 C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(F), ptr(pts), ptr(feat), ptr(sp), ptr(sfeat), ptr(rad), ptr(kw),
                 C.c_float(float(temperature)), ptr(spw), None, None, ptr(idx), ptr(w), ptr(dist), None, C.c_size_t(0), C.c_int32(1),
-                _C._stream()))
+                C.c_int32(0), _C._stream()))
         ctx.save_for_backward(feat, sfeat, rad, kw, w, idx, dist)
         ctx.temperature, ctx.logits, ctx.M = float(temperature), spw is not None, M
         ctx.mark_non_differentiable(idx)

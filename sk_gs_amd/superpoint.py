@@ -24,6 +24,7 @@ followed by the same activation epilogue and rasterizer as stage ``sk``.  This m
 There is no CPU path: the kernels raise on host tensors; ``reference_forward`` exists for tests.
 """
 import ctypes as C
+import os
 import math
 from typing import Dict, List, Optional
 
@@ -130,6 +131,12 @@ def _net_desc(net: SpDeformNet, M: int, points, time, grads: bool = False) -> _S
     return d
 
 
+class _SpPrepare(C.Structure):
+    """include/skgs.h::skgs_sp_prepare"""
+    _fields_ = [('P', C.c_int32), ('M', C.c_int32), ('K', C.c_int32), ('F', C.c_int32), ('sp_points', C.c_void_p),
+                ('sp_feature', C.c_void_p), ('sp_order', C.c_void_p), ('pairs', C.c_void_p), ('pairs_bytes', C.c_size_t)]
+
+
 class SpNetRunner:
     """The launches of one forward / backward of ``SpDeformNet`` on persistent buffers (csrc/sp_mlp.hip):
 
@@ -157,12 +164,14 @@ class SpNetRunner:
         self.bone_T, self.d_rot, self.d_scale = torch.empty((M, 7), **f32), torch.empty((M, 4), **f32), torch.empty((M, 3), **f32)
         self.raw = torch.empty((M, 10), **f32)  # d_xyz | d_rotation (raw) | d_scaling: the reference's three outputs
 
-    def forward(self, points: Tensor, time: Tensor):
-        """fills ``bone_T`` / ``d_rot`` / ``d_scale`` (and ``raw``); ``time``: 1-element device tensor"""
+    def forward(self, points: Tensor, time: Tensor, prepare: Optional[_SpPrepare] = None):
+        """fills ``bone_T`` / ``d_rot`` / ``d_scale`` (and ``raw``); ``time``: 1-element device tensor.  ``prepare``: the search's
+        per-step table / list preparation rides on this call's first launch (``skgs_sp_prepare``)"""
         d = _net_desc(self.net, self.M, points, time)
         _C._check(self.lib.skgs_sp_net_forward(
             C.byref(d), C.c_void_p(self.raw.data_ptr()), C.c_void_p(self.bone_T.data_ptr()), C.c_void_p(self.d_rot.data_ptr()),
-            C.c_void_p(self.d_scale.data_ptr()), C.c_void_p(self.saved.data_ptr()), C.c_size_t(self.saved.numel()), _C._stream()))
+            C.c_void_p(self.d_scale.data_ptr()), C.c_void_p(self.saved.data_ptr()), C.c_size_t(self.saved.numel()),
+            None if prepare is None else C.byref(prepare), _C._stream()))
 
     def backward(self, g_bone_T: Optional[Tensor], g_d_rot: Optional[Tensor], g_d_scale: Optional[Tensor],
                  g_raw: Optional[Tensor] = None, side_adam=None):
@@ -428,12 +437,17 @@ class FusedSuperpointStep(FusedViewStep):
         lib, m, st, chk = self.lib, self.model, _C._stream(), _C._check
         P, M, K = self.P, self.M, self.K
         assert (rs is None) == (time_id is None) and (rs is not None or self.view_table is not None)
-        self.net.forward(m.sp_points, self._time(time_id))
+        # (the search's table and list counters are prepared by extra workgroups of the network's first launch)
+        prep = _SpPrepare(P, M, K, self.F, m.sp_points.data_ptr(), None if m.sp_hyper_feature is None else m.sp_hyper_feature.data_ptr(),
+                          self.sp_order.data_ptr(), self.pairs.data_ptr(), self.pairs.numel())
+        if os.environ.get('SKGS_SP_SEPARATE_PREPARE'):  # (A/B measurements: the search prepares its table in a launch of its own)
+            prep = None
+        self.net.forward(m.sp_points, self._time(time_id), prepare=prep)
         chk(lib.skgs_sp_lbs_weights_forward(
             C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(self.F), _p(m._xyz), _p(m.hyper_feature), _p(m.sp_points),
             _p(m.sp_hyper_feature), _p(m._sp_radius), _p(m._sp_weight), C.c_float(m.lbs_temperature), _p(m.sp_W),
             _p(self.sp_order), _p(self.sp_rank), _p(self.indices), _p(self.weights), _p(self.nn_dist), _p(self.pairs), C.c_size_t(self.pairs.numel()),
-            C.c_int32(0), st))
+            C.c_int32(0), C.c_int32(0 if prep is None else 1), st))
         d = self._deform_inputs(time_id)
         chk(lib.skgs_lbs_deform_forward(C.byref(d), _p(self.means), _p(self.scales), _p(self.rotations), _p(self.opacity),
                                         None, None, None, st))

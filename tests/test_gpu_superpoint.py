@@ -150,7 +150,7 @@ def _sp_forward(P, M, K, F, pts, sp, feat, sfeat, radius_raw=None, kweight_raw=N
         rank[order.long()] = torch.arange(M, dtype=order.dtype, device=order.device)
     _C._check(lib.skgs_sp_lbs_weights_forward(C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(F), p(pts), p(feat), p(sp),
                                               p(sfeat), p(radius_raw), p(kweight_raw), C.c_float(T), p(sp_W), p(order), p(rank), p(idx), p(w), p(d),
-                                              None, C.c_size_t(0), C.c_int32(0), _C._stream()))
+                                              None, C.c_size_t(0), C.c_int32(0), C.c_int32(0), _C._stream()))
     return idx, w, d
 
 
@@ -419,7 +419,7 @@ def test_sp_skinning_backward_by_inverse_lists_matches_the_two_call_sequence_and
     for rep in range(2):  # (twice: the forward clears the lists it filed before)
         _C._check(lib.skgs_sp_lbs_weights_forward(C.c_int32(P), C.c_int32(M), C.c_int32(K), C.c_int32(F), p(d_pts), p(d_feat), p(d_sp),
                                                   p(d_sfeat), p(rr), p(kk), C.c_float(T), p(sp_W), None, None, p(idx), p(w), p(dist), p(pairs),
-                                                  C.c_size_t(pairs.numel()), C.c_int32(0), _C._stream()))
+                                                  C.c_size_t(pairs.numel()), C.c_int32(0), C.c_int32(0), _C._stream()))
     torch.cuda.synchronize()
     hdr = pairs[:8].view(torch.int32)
     counts = pairs[256:256 + 4 * M].view(torch.int32)
