@@ -29,7 +29,7 @@ def _net(seed=0, heads=0.05):
     return net.cuda()
 
 
-@pytest.mark.parametrize('M', [512, 20, 100, 1000])
+@pytest.mark.parametrize('M', [512, 20, 100, 1000, 1, 3])
 def test_sp_net_forward_matches_the_torch_restatement(M):
     net = _net(M)
     g = torch.Generator().manual_seed(M)
@@ -52,7 +52,7 @@ def test_sp_net_forward_matches_the_torch_restatement(M):
     assert rel_err(Y7, ref['hidden']) <= 2e-5
 
 
-@pytest.mark.parametrize('M,stage', [(512, False), (512, True), (37, True), (1000, False)])
+@pytest.mark.parametrize('M,stage', [(512, False), (512, True), (37, True), (1000, False), (3, True)])
 def test_sp_net_backward_matches_torch_autograd(M, stage):
     """every parameter gradient (8 layers, the time network, the three heads) of ONE row-block launch + ONE weight-gradient
     launch against torch autograd of the restatement; `stage`: cotangents w.r.t. (bone_T, d_rot, d_scale), the quaternion
