@@ -698,12 +698,8 @@ __global__ void __launch_bounds__(NTB) sp_net_backward_weights_kernel(int M, int
         const int rr  = r + 4 * u;
         const bool in = rr < re;
         const int rc  = in ? rr : rb;  // (clamped address, value masked: a select between POINTERS put the zero in scratch)
-#ifdef SPX_B_NOLOAD  // timing experiment
-        a[u] = make_float4((float) rc, 1.f, 2.f, 3.f), b[u] = make_float4(1.f, (float) rc, 2.f, 3.f);
-#else
         a[u] = *reinterpret_cast<const float4*>(ap + (size_t) rc * SPW);
         b[u] = *reinterpret_cast<const float4*>(xin ? xp + (size_t) rc * xld : ap + (size_t) rc * SPW);
-#endif
         if (!in) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!(in && xin)) b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -777,9 +773,6 @@ __global__ void __launch_bounds__(NTB) sp_net_backward_weights_kernel(int M, int
       }
     }
   }
-#ifdef SPX_B_NOEPI  // timing experiment
-  if (acc[0][0][0] != 12345.f) return;
-#endif
   {
     float* sp = s_part[wave];
 #pragma unroll
@@ -918,8 +911,7 @@ int skgs_sp_net_backward(const skgs_sp_net* net, const skgs_sp_net* grads, const
   // gradients ~19 us on 133): alone beside the first it took 47 us and made that launch the step's long pole.
   SideAdam sd{}, sd2{};
   int n_side = 0, n_side2 = 0;
-  static const int skip_time = getenv("SPX_SKIP_TIMENET") ? 1 : 0;  // (timing experiment)
-  const int n_jobs = N_JOBS + 1 - skip_time;
+  const int n_jobs = N_JOBS + 1;
   if (side && side->n_tensors > 0) {
     SKGS_REQUIRE(side->tensors && side->step_count && side->chunk_begin >= 0 && side->chunk_end >= side->chunk_begin,
         "sp_net_backward: bad side range");
