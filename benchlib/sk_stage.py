@@ -540,7 +540,13 @@ def kernel_table(args, s, t, prof_all, passes):
                 b = {'skeleton_forward': net_b + rows_b, 'skeleton_backward': 2 * net_b, 'adam': rest_b}[name]
             else:
                 b = {'skeleton_forward': net_b, 'skeleton_backward': 2 * net_b, 'adam': rows_b + rest_b}[name]
+        if name == 'preprocess_forward' and 'deform_forward' not in prof_all and getattr(t.fstep, 'deform_in_preprocess', False):
+            # the skinning runs as a job of this launch (skgs_raster_inputs.deform_job): its bytes, minus the 44 B per Gaussian
+            # of means / scales / rotations / opacity that are no longer re-read
+            b += alg_bytes('deform_forward', s.P, s.M, s.K, s.W, s.H, s.R_mean) - 44 * s.P
         kernels[name] = timing.kernel_record(ms / n * 1e3, n / passes, b)
+    if 'deform_forward' not in prof_all and getattr(t.fstep, 'deform_in_preprocess', False) and 'preprocess_forward' in kernels:
+        kernels['preprocess_forward']['includes'] = 'deform_forward (K nearest bones + softmax weights + skinning + activations)'
     return kernels
 
 

@@ -54,6 +54,31 @@ extern "C" {
 
 typedef void* skgs_stream_t; /* hipStream_t */
 
+/* The skeleton stage's deform as a job of the rasterizer's per-Gaussian launch (skgs_raster_inputs.deform_job): the arguments of
+ * skgs_knn_lbs_deform_forward below (sk_gs.py:757-770 K nearest joints + softmax of the gathered sp_W logits, :1143-1150 linear
+ * blend skinning, :1162,1192-1203 activations).  The Gaussian's mean / scale / rotation / opacity are computed in the lane that
+ * projects them: written (with weights / indices) for the backward, never re-read by the forward.  Same arithmetic, same bits as
+ * the separate launch.  Needs K <= min(8, M), M <= SKGS_FUSED_LBS_MAX_BONES, scales + rotations (no cov3D_precomp). */
+typedef struct skgs_knn_deform_job {
+  int32_t M, K;
+  const float* points;  /* [P,3] the positions the bones are searched from (xyz.detach(), sk_gs.py:1113) */
+  const float* joints;  /* [M,3] */
+  const float* sp_W;    /* [P,M] logits */
+  const float* bone_T;  /* [M,7] */
+  const float* bone_drot;   /* [M,4] */
+  const float* bone_dscale; /* [M,3] */
+  const float* xyz;         /* [P,3] */
+  const float* log_scale;   /* [P,3] */
+  const float* rot;         /* [P,4] */
+  const float* opacity_logit; /* [P] */
+  int64_t* out_idx;     /* [P,K] */
+  float* out_weights;   /* [P,K] */
+  float* means;         /* [P,3]  == skgs_raster_inputs.means3D   */
+  float* scales;        /* [P,3]  == skgs_raster_inputs.scales    */
+  float* rotations;     /* [P,4]  == skgs_raster_inputs.rotations */
+  float* opacity;       /* [P]    == skgs_raster_inputs.opacity   */
+} skgs_knn_deform_job;
+
 /* Inputs of rasterize_gaussians / rasterize_gaussians_backward (same meaning, same order as the pybind args). */
 typedef struct skgs_raster_inputs {
   int32_t P;          /* number of Gaussians */
@@ -101,6 +126,8 @@ typedef struct skgs_raster_inputs {
                                * Gaussian gets) and no gradient is written for them.  Densification (clone / split / prune,
                                * networks/gaussian_splatting.py:565-636) changes n in place: a captured hipGraph of the step
                                * stays valid -- nothing it baked in (pointers, grids, P) moved */
+  const skgs_knn_deform_job* deform_job; /* NULL, or (forward only): means3D / scales / rotations / opacity are not read but
+                               * COMPUTED by the per-Gaussian launch from this job and written there (see the struct) */
 } skgs_raster_inputs;
 
 typedef struct skgs_raster_buffers {

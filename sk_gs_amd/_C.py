@@ -29,6 +29,13 @@ class SkgsError(RuntimeError):
     pass
 
 
+class _KnnDeformJob(C.Structure):
+    """include/skgs.h: skgs_knn_deform_job"""
+    _fields_ = [('M', C.c_int32), ('K', C.c_int32)] + [(n, C.c_void_p) for n in (
+        'points', 'joints', 'sp_W', 'bone_T', 'bone_drot', 'bone_dscale', 'xyz', 'log_scale', 'rot', 'opacity_logit', 'out_idx',
+        'out_weights', 'means', 'scales', 'rotations', 'opacity')]
+
+
 class _RasterInputs(C.Structure):
     _fields_ = [
         ('P', C.c_int32), ('sh_degree', C.c_int32), ('sh_coeffs', C.c_int32), ('E', C.c_int32),
@@ -41,6 +48,7 @@ class _RasterInputs(C.Structure):
         ('cov3D_precomp', C.c_void_p), ('sh_rest', C.c_void_p), ('background', C.c_void_p),
         ('tile_bucket_capacity', C.c_int32), ('tanfov_device', C.c_void_p),
         ('host_status_words', C.c_int32), ('longest_list_hint', C.c_int32), ('live_count', C.c_void_p),
+        ('deform_job', C.POINTER(_KnnDeformJob)),
     ]
 
 

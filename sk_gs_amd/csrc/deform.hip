@@ -10,6 +10,7 @@
 #include <algorithm>
 
 #include "skgs_common.h"
+#include "deform_lane.h"
 
 #pragma clang fp contract(off)
 
@@ -17,28 +18,8 @@ namespace skgs {
 namespace {
 
 constexpr int DEFORM_THREADS = 256;
-constexpr int BONE_F         = 14;    // qx qy qz qw tx ty tz | drot[4] | dscale[3]
 constexpr int PREF_K         = 8;     // neighbour slots prefetched into registers (K is 5 in every shipped config)
 constexpr int MAX_LDS_BONES  = 1024;  // 56 KB of dynamic LDS (backward keeps a gradient copy too: 512 bones)
-
-__device__ __forceinline__ void load_bone(const float* T7, const float* drot, const float* dscale, int j, float* b) {
-  const float q0 = T7[7 * j + 3], q1 = T7[7 * j + 4], q2 = T7[7 * j + 5], q3 = T7[7 * j + 6];
-  const float n  = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
-  b[0] = q0 / n, b[1] = q1 / n, b[2] = q2 / n, b[3] = q3 / n;
-  b[4] = T7[7 * j], b[5] = T7[7 * j + 1], b[6] = T7[7 * j + 2];
-  b[7] = drot[4 * j], b[8] = drot[4 * j + 1], b[9] = drot[4 * j + 2], b[10] = drot[4 * j + 3];
-  b[11] = dscale[3 * j], b[12] = dscale[3 * j + 1], b[13] = dscale[3 * j + 2];
-}
-
-// y = p + w*uv + q x uv + t, uv = 2 q x p   (lie.h:59-64,246)
-__device__ __forceinline__ void se3_act(const float* b, const float* p, float* y) {
-  float uv[3] = {b[1] * p[2] - b[2] * p[1], b[2] * p[0] - b[0] * p[2], b[0] * p[1] - b[1] * p[0]};
-  uv[0] += uv[0], uv[1] += uv[1], uv[2] += uv[2];
-  const float c[3] = {b[1] * uv[2] - b[2] * uv[1], b[2] * uv[0] - b[0] * uv[2], b[0] * uv[1] - b[1] * uv[0]};
-  y[0] = p[0] + b[3] * uv[0] + c[0] + b[4];
-  y[1] = p[1] + b[3] * uv[1] + c[1] + b[5];
-  y[2] = p[2] + b[3] * uv[2] + c[2] + b[6];
-}
 
 template <bool LDS_BONES>
 __global__ void __launch_bounds__(DEFORM_THREADS) deform_forward_kernel(int P, int K, int M, const float* __restrict__ points,
@@ -539,23 +520,6 @@ __global__ void __launch_bounds__(256) deform_backward_finalize_kernel(int M, in
 
 // K nearest bones (squared L2, ascending, ties -> lower index). joints staged in LDS.
 constexpr int KNN_MAXK = 16;
-// KCAP = compile-time capacity of the per-lane top-K list (>= K): the insertion network is KCAP steps per bone.
-// One bubble step per slot as selects (v_cndmask), no branches and no array copies: a candidate displaces the first entry it
-// is strictly smaller than and the displaced entry moves on, so equal distances stay behind earlier (lower) indices.  Slots
-// beyond K just collect the overflow; the first K are the top-K.
-template <int KCAP>
-__device__ __forceinline__ void topk_insert(float (&bd)[KCAP], int (&bi)[KCAP], float cd, int ci) {
-#pragma unroll
-  for (int k = 0; k < KCAP; ++k) {
-    const bool lt  = cd < bd[k];
-    const float td = bd[k];
-    const int ti   = bi[k];
-    bd[k] = lt ? cd : td;
-    bi[k] = lt ? ci : ti;
-    cd    = lt ? td : cd;
-    ci    = lt ? ti : ci;
-  }
-}
 template <int KCAP>
 __global__ void __launch_bounds__(256) knn_bones_kernel(int P, int M, int K, int dim, const float* __restrict__ points,
     const float* __restrict__ joints, float* __restrict__ out_dist, int64_t* __restrict__ out_idx, int lds_joints) {
@@ -957,58 +921,22 @@ __global__ void __launch_bounds__(256) knn_deform_forward_kernel(int P, int M, i
   __syncthreads();
   const int p0 = blockIdx.x * 256, n = p0 + threadIdx.x;
   if (n < P) {
-    float bd[KCAP];
-    int bi[KCAP];
-#pragma unroll
-    for (int k = 0; k < KCAP; ++k) bd[k] = __builtin_inff(), bi[k] = 0;
     const float p[3] = {points[3 * (size_t) n], points[3 * (size_t) n + 1], points[3 * (size_t) n + 2]};
-    for (int j = 0; j < M; ++j) {
-      const float d0 = p[0] - s_j[3 * j], d1 = p[1] - s_j[3 * j + 1], d2 = p[2] - s_j[3 * j + 2];
-      float d = 0.f;
-      d += d0 * d0;
-      d += d1 * d1;
-      d += d2 * d2;
-      topk_insert<KCAP>(bd, bi, d, j);
-    }
-    float l[KCAP];
-    float mx = -INFINITY;
+    float w[KCAP], sx[3], sr[4], ss[3];
+    int bi[KCAP];
+    knn_softmax_skin_lane<KCAP>(M, K, s_j, s_bones, p, [&](int j) { return sp_W[(size_t) n * M + j]; }, w, bi, sx, sr, ss);
 #pragma unroll
-    for (int k = 0; k < KCAP; ++k) {
-      l[k] = k < K ? sp_W[(size_t) n * M + bi[k]] : -INFINITY;
-      mx   = fmaxf(mx, l[k]);
-    }
-    float sum = 0.f;
+    for (int k = 0; k < KCAP; ++k)
+      if (k < K) s_w[threadIdx.x * K + k] = w[k], s_idx[threadIdx.x * K + k] = bi[k];
+    const float x3[3] = {xyz[3 * n], xyz[3 * n + 1], xyz[3 * n + 2]};
+    const float ls[3] = {log_scale[3 * n], log_scale[3 * n + 1], log_scale[3 * n + 2]};
+    float mo[3], so[3], oo;
+    float4 ro;
+    deform_activate_lane(p, sx, sr, ss, x3, ls, reinterpret_cast<const float4*>(rot)[n], opacity_logit[n], mo, so, ro, oo);
 #pragma unroll
-    for (int k = 0; k < KCAP; ++k) {
-      l[k] = k < K ? expf(l[k] - mx) : 0.f;
-      sum += l[k];
-    }
-    float sx[3] = {0, 0, 0}, sr[4] = {0, 0, 0, 0}, ss[3] = {0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < KCAP; ++k) {
-      if (k < K) {
-        const float w = l[k] / sum;
-        s_w[threadIdx.x * K + k] = w, s_idx[threadIdx.x * K + k] = bi[k];
-        const float* b = s_bones + bi[k] * BONE_F;
-        float y[3];
-        se3_act(b, p, y);
-        sx[0] += y[0] * w, sx[1] += y[1] * w, sx[2] += y[2] * w;
-        sr[0] += b[7] * w, sr[1] += b[8] * w, sr[2] += b[9] * w, sr[3] += b[10] * w;
-        ss[0] += b[11] * w, ss[1] += b[12] * w, ss[2] += b[13] * w;
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float dx = sx[c] - p[c];
-      means[3 * n + c]  = xyz[3 * n + c] + dx;
-      scales[3 * n + c] = expf(log_scale[3 * n + c]) + ss[c];
-    }
-    const float4 r4 = reinterpret_cast<const float4*>(rot)[n];
-    const float v[4] = {r4.x + sr[0], r4.y + sr[1], r4.z + sr[2], r4.w + sr[3]};
-    float nv = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
-    nv       = fmaxf(nv, 1e-12f);
-    reinterpret_cast<float4*>(rotations)[n] = make_float4(v[0] / nv, v[1] / nv, v[2] / nv, v[3] / nv);
-    opacity[n] = 1.0f / (1.0f + expf(-opacity_logit[n]));
+    for (int c = 0; c < 3; ++c) means[3 * n + c] = mo[c], scales[3 * n + c] = so[c];
+    reinterpret_cast<float4*>(rotations)[n] = ro;
+    opacity[n]                              = oo;
   }
   __syncthreads();
   const int cnt = min(256, P - p0) * K;

@@ -13,6 +13,7 @@
 // rectangle, SH clamp) is bit-identical to the CPU oracle; these kernels move ~0.3 KB per Gaussian, the extra
 // VALU work is free.
 #include "skgs_common.h"
+#include "deform_lane.h"
 
 #pragma clang fp contract(off)
 
@@ -239,16 +240,21 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const float* mean, const floa
 // hold the workgroup's span, so each 64-B line is fetched from L2 many times.  Here the waves copy whole rows with
 // consecutive lanes on consecutive floats (the span of a workgroup is contiguous in memory); rows get an odd pitch so
 // that the per-lane reads afterwards are bank-conflict free.
-constexpr int PRE_THREADS = 128;
+constexpr int PRE_THREADS     = 128;
+// the backward in workgroups of 256 (50 KB of staged SH rows each, three per CU): 20.9 us against 22.1 at 100k Gaussians; the
+// forward is slower that way and with 64 (A/B on one box, 300 steps each)
+constexpr int PRE_BWD_THREADS = 256;
 __device__ __forceinline__ int sh_pitch(int RL) { return RL | 1; }
+inline int sh_pitch_host(int RL) { return RL | 1; }
 // Both copies keep all of a thread's global accesses in flight at once (up to STAGE_V float4 per thread): a loop of
 // load -> LDS store per row serialised on the load latency and was slower than no staging at all.
-constexpr int STAGE_V = 12;  // PRE_THREADS rows x 48 floats / 4 / PRE_THREADS
+constexpr int STAGE_V = 12;  // NT rows x 48 floats / 4 / NT threads
 __device__ __forceinline__ int stage_lds_index(int e, int RL, int pitch) {  // float index e of the span -> LDS index
   if (pitch == RL) return e;
   const int r = e / RL;
   return r * pitch + (e - r * RL);
 }
+template <int NT = PRE_THREADS>
 __device__ __forceinline__ void stage_rows_in(float* s_dst, const float* __restrict__ src, int nrows, int RL) {
   const int pitch = sh_pitch(RL), n = nrows * RL;
   const bool vec  = (RL % 4 == 0 || pitch == RL) && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
@@ -256,12 +262,12 @@ __device__ __forceinline__ void stage_rows_in(float* s_dst, const float* __restr
   float4 v[STAGE_V];
 #pragma unroll
   for (int k = 0; k < STAGE_V; ++k) {
-    const int i = threadIdx.x + k * PRE_THREADS;
+    const int i = threadIdx.x + k * NT;
     if (i < n4) v[k] = reinterpret_cast<const float4*>(src)[i];
   }
 #pragma unroll
   for (int k = 0; k < STAGE_V; ++k) {
-    const int i = threadIdx.x + k * PRE_THREADS;
+    const int i = threadIdx.x + k * NT;
     if (i < n4) {
       if (pitch == RL) {
         s_dst[4 * i] = v[k].x, s_dst[4 * i + 1] = v[k].y, s_dst[4 * i + 2] = v[k].z, s_dst[4 * i + 3] = v[k].w;
@@ -271,24 +277,36 @@ __device__ __forceinline__ void stage_rows_in(float* s_dst, const float* __restr
       }
     }
   }
-  for (int e = 4 * n4 + threadIdx.x; e < n; e += PRE_THREADS) s_dst[stage_lds_index(e, RL, pitch)] = src[e];
+  for (int e = 4 * n4 + threadIdx.x; e < n; e += NT) s_dst[stage_lds_index(e, RL, pitch)] = src[e];
 }
+template <int NT = PRE_THREADS>
 __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, const float* s_src, int nrows, int RL) {
   const int pitch = sh_pitch(RL), n = nrows * RL;
   const bool vec  = (RL % 4 == 0 || pitch == RL) && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
   const int n4    = vec ? n >> 2 : 0;
 #pragma unroll
   for (int k = 0; k < STAGE_V; ++k) {
-    const int i = threadIdx.x + k * PRE_THREADS;
+    const int i = threadIdx.x + k * NT;
     if (i < n4) {
       const int o = pitch == RL ? 4 * i : stage_lds_index(4 * i, RL, pitch);
       reinterpret_cast<float4*>(dst)[i] = make_float4(s_src[o], s_src[o + 1], s_src[o + 2], s_src[o + 3]);
     }
   }
-  for (int e = 4 * n4 + threadIdx.x; e < n; e += PRE_THREADS) dst[e] = s_src[stage_lds_index(e, RL, pitch)];
+  for (int e = 4 * n4 + threadIdx.x; e < n; e += NT) dst[e] = s_src[stage_lds_index(e, RL, pitch)];
 }
 
-template <bool COLMAP>
+// The skeleton stage's deform in front of this pass (template DK > 0: the capacity of the per-lane top-K list): the lane first
+// computes its Gaussian's mean / scale / rotation / opacity -- K nearest bones, softmax weights, skinning, activations,
+// knn_deform_forward_kernel's arithmetic through the same deform_lane.h functions -- writes them (and the weights / indices) for
+// the backward, and projects them from registers: one launch and one round trip through HBM less per step.
+struct KnnDeformJob {
+  int M, K, lds_offset /* floats: where the deform's tables start in the dynamic LDS (behind the SH rows) */, stage_logits;
+  const float *points, *joints, *sp_W, *bone_T, *bone_drot, *bone_dscale, *xyz, *log_scale, *rot, *opacity_logit;
+  int64_t* out_idx;
+  float *out_weights, *means, *scales, *rotations, *opacity;
+};
+
+template <bool COLMAP, int DK>
 __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, int D, int M, const float* __restrict__ means3D,
     const float* __restrict__ scales, float scale_modifier, const float* __restrict__ rotations,
     const float* __restrict__ opacities, const float* __restrict__ shs, const float* __restrict__ shs_rest,
@@ -298,7 +316,8 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
     int gx, int gy, int32_t* __restrict__ radii, float4* __restrict__ recs, uint32_t* __restrict__ tile_counts,
     GeomHeader* hdr_bucket /* bucket layout: tile_counts are the per-tile cursors and the status words start here */,
     const float* __restrict__ tanfov_dev /* NULL, or {tanfovx, tanfovy} read here instead of the launch arguments */,
-    const int32_t* __restrict__ live /* NULL, or the live Gaussian count (<= P, the capacity the grid was sized for) */) {
+    const int32_t* __restrict__ live /* NULL, or the live Gaussian count (<= P, the capacity the grid was sized for) */,
+    KnnDeformJob dj) {
   // the number of Gaussians as a device word (one captured graph survives densification): rows [live, P) of the capacity
   // get an all-zero record and radius 0 -- what a culled Gaussian gets -- so nothing downstream needs to know
   const int P_cap = P;
@@ -313,16 +332,26 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
   // to the capacity exist; a lane behind it reads row 0 and uses nothing.)
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int ld  = idx < P_cap ? idx : 0;
-  const float pf_p[3] = {means3D[3 * ld], means3D[3 * ld + 1], means3D[3 * ld + 2]};
-  const float pf_op   = opacities[ld];
+  float pf_p[3] = {0.f, 0.f, 0.f}, pf_op = 0.f;
   float pf_s[3] = {0.f, 0.f, 0.f}, pf_c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pf_col[3] = {0.f, 0.f, 0.f};
   float4 pf_q = make_float4(0.f, 0.f, 0.f, 1.f);
-  if (cov3D_precomp != nullptr) {
+  // (DK > 0) the deform's per-Gaussian inputs instead: the point the bones are searched from, and the four raw parameters
+  float dj_p[3] = {0.f, 0.f, 0.f}, dj_x[3] = {0.f, 0.f, 0.f}, dj_ls[3] = {0.f, 0.f, 0.f}, dj_ol = 0.f;
+  float4 dj_r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (DK > 0) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) pf_c6[i] = cov3D_precomp[6 * ld + i];
+    for (int c = 0; c < 3; ++c) dj_p[c] = dj.points[3 * ld + c], dj_x[c] = dj.xyz[3 * ld + c], dj_ls[c] = dj.log_scale[3 * ld + c];
+    dj_r4 = reinterpret_cast<const float4*>(dj.rot)[ld], dj_ol = dj.opacity_logit[ld];
   } else {
-    pf_s[0] = scales[3 * ld], pf_s[1] = scales[3 * ld + 1], pf_s[2] = scales[3 * ld + 2];
-    pf_q    = reinterpret_cast<const float4*>(rotations)[ld];
+    pf_p[0] = means3D[3 * ld], pf_p[1] = means3D[3 * ld + 1], pf_p[2] = means3D[3 * ld + 2];
+    pf_op   = opacities[ld];
+    if (cov3D_precomp != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) pf_c6[i] = cov3D_precomp[6 * ld + i];
+    } else {
+      pf_s[0] = scales[3 * ld], pf_s[1] = scales[3 * ld + 1], pf_s[2] = scales[3 * ld + 2];
+      pf_q    = reinterpret_cast<const float4*>(rotations)[ld];
+    }
   }
   if (colors_precomp != nullptr)
     pf_col[0] = colors_precomp[3 * ld], pf_col[1] = colors_precomp[3 * ld + 1], pf_col[2] = colors_precomp[3 * ld + 2];
@@ -359,9 +388,43 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
       my_dc = my_sh = s_sh + threadIdx.x * sh_pitch(RL);
     }
   }
+  // (DK > 0) the deform's tables behind the SH rows: joints, bones, this workgroup's rows of the logit table (a lane gathers K
+  // of its row's M logits AFTER the search: from LDS that is no second round trip, and the rows' lines are fetched whole anyway)
+  float *s_j = nullptr, *s_bones = nullptr, *s_logit = nullptr;
+  if constexpr (DK > 0) {
+    const int base = blockIdx.x * blockDim.x, nrows = min((int) blockDim.x, P - base);
+    s_j     = s_sh + dj.lds_offset;
+    s_bones = s_j + ((dj.M * 3 + 3) & ~3);
+    s_logit = s_bones + ((dj.M * BONE_F + 3) & ~3);
+    if (dj.stage_logits) stage_rows_in(s_logit, dj.sp_W + (size_t) base * dj.M, nrows, dj.M);
+    for (int i = threadIdx.x; i < dj.M * 3; i += PRE_THREADS) s_j[i] = dj.joints[i];
+    for (int j = threadIdx.x; j < dj.M; j += PRE_THREADS) load_bone(dj.bone_T, dj.bone_drot, dj.bone_dscale, j, s_bones + j * BONE_F);
+  }
   if (threadIdx.x < 16) cam.view[threadIdx.x] = cam_v, cam.proj[threadIdx.x] = cam_p;
   if (threadIdx.x < 3) cam.campos[threadIdx.x] = cam_c;
   __syncthreads();
+  if constexpr (DK > 0) {
+    if (idx < P) {
+      float w[DK], sx[3], sr[4], ss[3];
+      int bi[DK];
+      if (dj.stage_logits) {
+        const float* row = s_logit + threadIdx.x * sh_pitch(dj.M);
+        knn_softmax_skin_lane<DK>(dj.M, dj.K, s_j, s_bones, dj_p, [&](int j) { return row[j]; }, w, bi, sx, sr, ss);
+      } else {
+        const float* row = dj.sp_W + (size_t) idx * dj.M;
+        knn_softmax_skin_lane<DK>(dj.M, dj.K, s_j, s_bones, dj_p, [&](int j) { return row[j]; }, w, bi, sx, sr, ss);
+      }
+      // (straight from the lane: rows through LDS would cost this launch a quarter of its resident workgroups)
+#pragma unroll
+      for (int k = 0; k < DK; ++k)
+        if (k < dj.K) dj.out_weights[(size_t) idx * dj.K + k] = w[k], dj.out_idx[(size_t) idx * dj.K + k] = bi[k];
+      deform_activate_lane(dj_p, sx, sr, ss, dj_x, dj_ls, dj_r4, dj_ol, pf_p, pf_s, pf_q, pf_op);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dj.means[3 * idx + c] = pf_p[c], dj.scales[3 * idx + c] = pf_s[c];
+      reinterpret_cast<float4*>(dj.rotations)[idx] = pf_q;
+      dj.opacity[idx]                              = pf_op;
+    }
+  }
   if (idx >= P) {
     if (idx < P_cap) {
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -552,7 +615,7 @@ __device__ __forceinline__ void sh_backward(int deg, int M, const float* mean, c
 }
 
 template <bool COLMAP>
-__global__ void __launch_bounds__(PRE_THREADS) preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3D,
+__global__ void __launch_bounds__(PRE_BWD_THREADS) preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3D,
     const int32_t* __restrict__ radii, const float* __restrict__ shs, const float* __restrict__ shs_rest,
     const float* __restrict__ scales,
     const float* __restrict__ rotations, float scale_modifier, const float* __restrict__ cov3D_precomp,
@@ -607,7 +670,7 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_backward_kernel(int P,
       pf_q = reinterpret_cast<const float4*>(rotations)[idx];
     }
   }
-  if (staged) stage_rows_in(s_sh, (shs_rest ? shs_rest : shs) + (size_t) base * RL, nrows, RL);
+  if (staged) stage_rows_in<PRE_BWD_THREADS>(s_sh, (shs_rest ? shs_rest : shs) + (size_t) base * RL, nrows, RL);
   __syncthreads();
   if (idx < P) {
 
@@ -877,7 +940,7 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_backward_kernel(int P,
   }  // idx < P
   if (staged && dL_dsh) {
     __syncthreads();
-    stage_rows_out((dL_dsh_rest ? dL_dsh_rest : dL_dsh) + (size_t) base * RL, s_sh, nrows, RL);
+    stage_rows_out<PRE_BWD_THREADS>((dL_dsh_rest ? dL_dsh_rest : dL_dsh) + (size_t) base * RL, s_sh, nrows, RL);
   }
 }
 
@@ -977,18 +1040,54 @@ int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView 
     lds = in.sh_rest ? ((size_t) PRE_THREADS * (((M - 1) * 3) | 1) + (size_t) PRE_THREADS * 3) * 4
                      : (size_t) PRE_THREADS * ((M * 3) | 1) * 4;
   }
-  if (in.colmap)
-    hipLaunchKernelGGL(preprocess_forward_kernel<true>, grid, block, lds, s, P, in.sh_degree, in.sh_coeffs, in.means3D,
-        in.scales, in.scale_modifier, in.rotations, in.opacity, in.sh, in.sh_rest, in.cov3D_precomp, in.colors_precomp,
-        in.viewmatrix, in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y,
-        im.tiles_x, im.tiles_y, radii, g.recs, bucket ? im.cursors : im.tile_counts, bucket ? g.hdr : nullptr, in.tanfov_device,
-        in.live_count);
-  else
-    hipLaunchKernelGGL(preprocess_forward_kernel<false>, grid, block, lds, s, P, in.sh_degree, in.sh_coeffs, in.means3D,
-        in.scales, in.scale_modifier, in.rotations, in.opacity, in.sh, in.sh_rest, in.cov3D_precomp, in.colors_precomp,
-        in.viewmatrix, in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y,
-        im.tiles_x, im.tiles_y, radii, g.recs, bucket ? im.cursors : im.tile_counts, bucket ? g.hdr : nullptr, in.tanfov_device,
-        in.live_count);
+  KnnDeformJob dj{};
+  int dk = 0;
+  if (const skgs_knn_deform_job* j = in.deform_job) {
+    // the deform in front of the pass: its outputs ARE this pass's per-Gaussian inputs
+    if (!(j->points && j->joints && j->sp_W && j->bone_T && j->bone_drot && j->bone_dscale && j->xyz && j->log_scale && j->rot &&
+            j->opacity_logit && j->out_idx && j->out_weights && j->means && j->scales && j->rotations && j->opacity))
+      return set_error("deform_job: NULL pointer");
+    if (j->means != in.means3D || j->scales != in.scales || j->rotations != in.rotations || j->opacity != in.opacity)
+      return set_error("deform_job: means / scales / rotations / opacity must be the rasterizer's means3D / scales / rotations / opacity");
+    if (in.cov3D_precomp) return set_error("deform_job: not with cov3D_precomp");
+    if (j->K < 1 || j->K > 8 || j->K > j->M || j->M > SKGS_FUSED_LBS_MAX_BONES)
+      return set_error("deform_job: needs 1 <= K <= min(8, M), M <= %d (got K = %d, M = %d)", SKGS_FUSED_LBS_MAX_BONES, j->K, j->M);
+    dk = j->K <= 5 ? 5 : 8;
+    dj.M = j->M, dj.K = j->K;
+    dj.lds_offset = (int) ((lds / 4 + 3) & ~(size_t) 3);
+    dj.points = j->points, dj.joints = j->joints, dj.sp_W = j->sp_W, dj.bone_T = j->bone_T, dj.bone_drot = j->bone_drot;
+    dj.bone_dscale = j->bone_dscale, dj.xyz = j->xyz, dj.log_scale = j->log_scale, dj.rot = j->rot;
+    dj.opacity_logit = j->opacity_logit, dj.out_idx = j->out_idx, dj.out_weights = j->out_weights, dj.means = j->means;
+    dj.scales = j->scales, dj.rotations = j->rotations, dj.opacity = j->opacity;
+    // the workgroup's logit rows through LDS while FOUR workgroups still share a CU's 160 KB (at 100k Gaussians the launch is
+    // 782 workgroups: with three per CU the last 14 run alone behind the rest, 32 us instead of 22)
+    const size_t tables = (size_t) ((j->M * 3 + 3) & ~3) + ((j->M * BONE_F + 3) & ~3);
+    const size_t rows   = (size_t) (PRE_THREADS * sh_pitch_host(j->M) + 3) & ~(size_t) 3;
+    dj.stage_logits     = j->M <= 4 * STAGE_V && ((size_t) dj.lds_offset + tables + rows) * 4 + sizeof(Cam) <= 40 * 1024;
+    lds                 = ((size_t) dj.lds_offset + tables + (dj.stage_logits ? rows : 0)) * 4;
+  }
+#define SKGS_PRE_FWD(COLMAP_, DK_)                                                                                          \
+  hipLaunchKernelGGL((preprocess_forward_kernel<COLMAP_, DK_>), grid, block, lds, s, P, in.sh_degree, in.sh_coeffs, in.means3D, \
+      in.scales, in.scale_modifier, in.rotations, in.opacity, in.sh, in.sh_rest, in.cov3D_precomp, in.colors_precomp,        \
+      in.viewmatrix, in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, focal_x, focal_y,    \
+      im.tiles_x, im.tiles_y, radii, g.recs, bucket ? im.cursors : im.tile_counts, bucket ? g.hdr : nullptr,                 \
+      in.tanfov_device, in.live_count, dj)
+  if (in.colmap) {
+    if (dk == 0)
+      SKGS_PRE_FWD(true, 0);
+    else if (dk == 5)
+      SKGS_PRE_FWD(true, 5);
+    else
+      SKGS_PRE_FWD(true, 8);
+  } else {
+    if (dk == 0)
+      SKGS_PRE_FWD(false, 0);
+    else if (dk == 5)
+      SKGS_PRE_FWD(false, 5);
+    else
+      SKGS_PRE_FWD(false, 8);
+  }
+#undef SKGS_PRE_FWD
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1000,8 +1099,8 @@ int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const i
   const float focal_y = in.image_height / (2.0f * in.tanfovy);
   const float focal_x = in.image_width / (2.0f * in.tanfovx);
   ProfScope prof(K_PREPROCESS_BWD, s);
-  dim3 grid((P + PRE_THREADS - 1) / PRE_THREADS), block(PRE_THREADS);
-  const size_t lds = (in.sh && (gr.dL_dsh || gr.dL_dsh_factors)) ? (size_t) PRE_THREADS * (((in.sh_rest ? in.sh_coeffs - 1 : in.sh_coeffs) * 3) | 1) * 4 : 0;
+  dim3 grid((P + PRE_BWD_THREADS - 1) / PRE_BWD_THREADS), block(PRE_BWD_THREADS);
+  const size_t lds = (in.sh && (gr.dL_dsh || gr.dL_dsh_factors)) ? (size_t) PRE_BWD_THREADS * (((in.sh_rest ? in.sh_coeffs - 1 : in.sh_coeffs) * 3) | 1) * 4 : 0;
   const int E = (in.extras && gr.dL_dout_extra && gr.dL_dextras) ? in.E : 0;
 #define SKGS_PB_ARGS                                                                                                     \
   P, in.sh_degree, in.sh_coeffs, in.means3D, radii, in.sh, in.sh_rest, in.scales, in.rotations, in.scale_modifier,        \

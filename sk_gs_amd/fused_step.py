@@ -19,6 +19,7 @@ surface.
 Reference call sequence: networks/sk_gs.py:1160-1242 (forward / render), :1524-1529 (loss), train.py:179-250.
 """
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -71,6 +72,9 @@ class FusedViewStep:
         lib.skgs_fused_lbs_max_bones.restype = C.c_int
         self.max_fused_bones = int(lib.skgs_fused_lbs_max_bones())
         self.wide = M > self.max_fused_bones or K > 8
+        # the one-launch skinning as a job of the rasterizer's per-Gaussian launch (skgs_raster_inputs.deform_job): the same
+        # bits one launch earlier; SKGS_SEPARATE_DEFORM=1 keeps the two launches (A/B measurements)
+        self.deform_in_preprocess = os.environ.get('SKGS_SEPARATE_DEFORM', '0') != '1'
         # the weighting of calc_LBS_weight: `W` (logits per Gaussian) runs inside the one-launch skinning kernels; the three
         # distance-based ones (sk_gs.py:757-766,770) as search + weighting in one launch, then the skinning
         self.lbs_method = getattr(model, 'lbs_method', 'W')
@@ -345,6 +349,22 @@ class FusedViewStep:
             a = self._raster_inputs(rs)
             chk(lib.skgs_rasterize_forward(C.byref(a), C.byref(self._bufs), _p(self.radii), _p(self.image),
                                            _p(self.out_opacity), None, None, st))
+            return a, d
+        if self.deform_in_preprocess and K <= 8:
+            # K nearest bones + softmax weights + skinning + activations as a job of the rasterizer's per-Gaussian launch: the
+            # lane that projects a Gaussian computes its mean / scale / rotation / opacity first (written for the backward)
+            j = _C._KnnDeformJob()
+            j.M, j.K = M, K
+            j.points, j.joints, j.sp_W, j.bone_T = d.points, m.joints.data_ptr(), m.sp_W.data_ptr(), d.bone_T
+            j.bone_drot, j.bone_dscale, j.xyz, j.log_scale = d.bone_drot, d.bone_dscale, d.xyz, d.log_scale
+            j.rot, j.opacity_logit, j.out_idx, j.out_weights = d.rot, d.opacity_logit, self.indices.data_ptr(), self.weights.data_ptr()
+            j.means, j.scales = self.means.data_ptr(), self.scales.data_ptr()
+            j.rotations, j.opacity = self.rotations.data_ptr(), self.opacity.data_ptr()
+            a = self._raster_inputs(rs)
+            a.deform_job = C.pointer(j)
+            chk(lib.skgs_rasterize_forward(C.byref(a), C.byref(self._bufs), _p(self.radii), _p(self.image),
+                                           _p(self.out_opacity), None, None, st))
+            a.deform_job = None  # (the backward's copy of the inputs: the job was the forward's)
             return a, d
         # K nearest bones + softmax weights + skinning + activations: one launch (weights / indices kept for the backward)
         chk(lib.skgs_knn_lbs_deform_forward(

@@ -629,3 +629,40 @@ def test_fused_step_with_the_distance_based_lbs_weightings_matches_autograd(meth
     torch.cuda.synchronize()
     assert not torch.equal(before[0], model.joints)
     assert not torch.equal(before[1], model._sp_radius if model._sp_radius is not None else model._xyz)
+
+
+@pytest.mark.parametrize('P,M,K,W,H,capacity_rows', [(4000, 12, 4, 160, 120, False), (5003, 20, 5, 203, 117, False), (3000, 50, 8, 96, 64, False),
+                                                     (2100, 60, 3, 96, 64, False), (4000, 20, 5, 160, 120, True)])
+def test_deform_as_a_job_of_the_per_gaussian_launch_is_bit_identical(P, M, K, W, H, capacity_rows):
+    """skgs_raster_inputs.deform_job: the skinning inside the rasterizer's per-Gaussian launch against the two launches --
+    every output of both halves bit for bit, then the whole step's gradients"""
+    from sk_gs_amd import _C
+    from sk_gs_amd.fused_step import FusedViewStep
+    model, rs, target = _setup(P, M, K, W, H, 3)
+    _C.config.sync_num_rendered = True
+    R = model.render(rs, time_id=1)['buffer'].R
+    if capacity_rows:
+        model.enable_capacity(int(P * 1.3))
+    got = {}
+    for job in (False, True):
+        for p in model.parameters():
+            p.grad = None  # (the step builds zeroed gradient buffers: behind a row capacity they have its size)
+        step = FusedViewStep(model, W, H, capacity=int(R * 1.2) + 1024, tile_bucket=0)
+        step.deform_in_preprocess = job
+        for buf in (step.means, step.scales, step.rotations, step.opacity, step.weights):
+            buf.fill_(-7.0)
+        step.indices.fill_(-7)
+        step.forward_backward(rs, 1, target)
+        torch.cuda.synchronize()
+        n = int(model.P)
+        got[job] = {k: getattr(step, k)[:n].clone() for k in ('means', 'scales', 'rotations', 'opacity', 'weights', 'indices', 'radii')}
+        got[job].update(image=step.image.clone(), **{'g_' + k: p.grad.clone() for k, p in model.named_parameters()})
+        if capacity_rows:  # rows behind the live count: not touched
+            assert bool((step.means[n:] == -7.0).all()) and bool((step.indices[n:] == -7).all())
+    for k, v in got[False].items():
+        if k.startswith('g_') and v.numel() < 10000:  # per-bone sums are atomics: order, not bits
+            assert rel_err(got[True][k], v) < 1e-5, k
+        elif k.startswith('g_'):
+            assert_close_robust(got[True][k], v, 1e-6, 1e-5, name=k)
+        else:
+            assert torch.equal(got[True][k], v), k
