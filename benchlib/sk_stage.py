@@ -544,7 +544,12 @@ def kernel_table(args, s, t, prof_all, passes):
             # the skinning runs as a job of this launch (skgs_raster_inputs.deform_job): its bytes, minus the 44 B per Gaussian
             # of means / scales / rotations / opacity that are no longer re-read
             b += alg_bytes('deform_forward', s.P, s.M, s.K, s.W, s.H, s.R_mean) - 44 * s.P
+        if name == 'preprocess_backward' and 'deform_backward' not in prof_all and getattr(t.fstep, 'deform_backward_in_preprocess', False):
+            # likewise the skinning backward (skgs_raster_grads.deform_backward_job): minus the 44 B per Gaussian it no longer reads
+            b += alg_bytes('deform_backward', s.P, s.M, s.K, s.W, s.H, s.R_mean) - 44 * s.P
         kernels[name] = timing.kernel_record(ms / n * 1e3, n / passes, b)
+    if 'deform_backward' not in prof_all and getattr(t.fstep, 'deform_backward_in_preprocess', False) and 'preprocess_backward' in kernels:
+        kernels['preprocess_backward']['includes'] = 'deform_backward (skinning + softmax backward, partial bone moments)'
     if 'deform_forward' not in prof_all and getattr(t.fstep, 'deform_in_preprocess', False) and 'preprocess_forward' in kernels:
         kernels['preprocess_forward']['includes'] = 'deform_forward (K nearest bones + softmax weights + skinning + activations)'
     return kernels

@@ -204,6 +204,7 @@ typedef struct skgs_raster_grads {
   float* stat_denom;              /* [P,1] */
   float* stat_max_radii2D;        /* [P] */
   float stat_grad_multiplier;     /* 1 / (the scale the backward was seeded with); 0 is read as 1 */
+  const struct skgs_deform_backward_job* deform_backward_job; /* NULL, or: see the struct (below skgs_deform_inputs) */
 } skgs_raster_grads;
 size_t skgs_backward_workspace_bytes(int32_t P);
 
@@ -256,6 +257,26 @@ typedef struct skgs_deform_inputs {
   const int32_t* live_count;  /* NULL, or a DEVICE int32 n <= P (see skgs_raster_inputs.live_count): the fused forward /
                                * backward (skgs_knn_lbs_deform_forward, skgs_lbs_deform_backward_logits) skip rows >= n */
 } skgs_deform_inputs;
+/* skgs_lbs_deform_backward_logits (below) as a job of skgs_rasterize_backward (skgs_raster_grads.deform_backward_job): the
+ * per-Gaussian launch that produces dL/d(means3D, scales, rotations, opacity) hands them to the skinning backward in registers
+ * (they are still written to the skgs_raster_grads outputs) -- the Gaussian's parameter gradients, its logit gradient and the
+ * bone gradients come out of skgs_rasterize_backward, one launch less, the same arithmetic on the same values.  Needs
+ * M <= 64, K <= 8, in->P / in->live_count equal to the rasterizer's, and means3D / scales / rotations / opacity of the
+ * rasterizer being what skgs_lbs_deform_forward (or the deform_job of the forward) produced from `in`. */
+typedef struct skgs_deform_backward_job {
+  const skgs_deform_inputs* in;
+  float* g_bone_T;        /* [M,7] */
+  float* g_bone_drot;     /* [M,4] */
+  float* g_bone_dscale;   /* [M,3] */
+  float* g_xyz;           /* [P,3] */
+  float* g_log_scale;     /* [P,3] */
+  float* g_rot;           /* [P,4] */
+  float* g_opacity_logit; /* [P,1] */
+  float* g_sp_W;          /* [P,M] dense logit gradient, or NULL */
+  float* g_logits;        /* [P,K] compact logit gradient, or NULL (one of the two is required) */
+  void* workspace;        /* skgs_lbs_deform_backward_workspace_bytes(P, M) */
+  size_t workspace_bytes;
+} skgs_deform_backward_job;
 /* means [P,3], scales [P,3], rotations [P,4] (normalised), opacity [P,1]; d_xyz/d_rot/d_scale optional (NULL) */
 int skgs_lbs_deform_forward(const skgs_deform_inputs* in, float* means, float* scales, float* rotations,
     float* opacity, float* d_xyz, float* d_rot, float* d_scale, skgs_stream_t stream);

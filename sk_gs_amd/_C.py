@@ -72,7 +72,7 @@ class _RasterGrads(C.Structure):
         ('dL_dsh_rest', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t),
         ('workspace_is_zero', C.c_int32), ('dL_dsh_factors', C.c_void_p),
         ('stat_xyz_gradient_accum', C.c_void_p), ('stat_denom', C.c_void_p), ('stat_max_radii2D', C.c_void_p),
-        ('stat_grad_multiplier', C.c_float),
+        ('stat_grad_multiplier', C.c_float), ('deform_backward_job', C.c_void_p),
     ]
 
 
@@ -83,6 +83,13 @@ class _DeformInputs(C.Structure):
         ('bone_drot', C.c_void_p), ('bone_dscale', C.c_void_p), ('xyz', C.c_void_p), ('log_scale', C.c_void_p),
         ('rot', C.c_void_p), ('opacity_logit', C.c_void_p), ('live_count', C.c_void_p),
     ]
+
+
+class _DeformBackwardJob(C.Structure):
+    """include/skgs.h: skgs_deform_backward_job"""
+    _fields_ = [('in_', C.POINTER(_DeformInputs))] + [(n, C.c_void_p) for n in (
+        'g_bone_T', 'g_bone_drot', 'g_bone_dscale', 'g_xyz', 'g_log_scale', 'g_rot', 'g_opacity_logit', 'g_sp_W', 'g_logits',
+        'workspace')] + [('workspace_bytes', C.c_size_t)]
 
 
 EXPORTED_SYMBOLS = [

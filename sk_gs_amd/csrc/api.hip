@@ -190,11 +190,22 @@ int skgs_read_status(const skgs_raster_buffers* buf, skgs_status* host_status, s
   return 0;
 }
 
+static int check_deform(const skgs_deform_inputs* in);
+
 int skgs_rasterize_backward(const skgs_raster_inputs* in, const skgs_raster_buffers* buf, const int32_t* radii,
     const float* out_opacity, const skgs_raster_grads* gr, skgs_stream_t stream) {
   if (check_inputs(in) || check_buffers(in, buf, true)) return 1;
   SKGS_REQUIRE(gr != nullptr, "grads struct is NULL");
-  if (in->P == 0) return 0;
+  if (in->P == 0) {  // (the deform backward job's bone gradients are always written completely)
+    if (const skgs_deform_backward_job* dj0 = gr->deform_backward_job) {
+      SKGS_REQUIRE(dj0->in && dj0->g_bone_T && dj0->g_bone_drot && dj0->g_bone_dscale, "deform_backward_job: NULL argument");
+      hipStream_t s0 = (hipStream_t) stream;
+      if (fill_u32(dj0->g_bone_T, 0u, (size_t) dj0->in->M * 7, s0) || fill_u32(dj0->g_bone_drot, 0u, (size_t) dj0->in->M * 4, s0) ||
+          fill_u32(dj0->g_bone_dscale, 0u, (size_t) dj0->in->M * 3, s0))
+        return 1;
+    }
+    return 0;
+  }
   SKGS_REQUIRE(radii && out_opacity, "radii / out_opacity are required");
   SKGS_REQUIRE(gr->dL_dout_color, "dL_dout_color is required");
   SKGS_REQUIRE(gr->dL_dmeans2D && gr->dL_dcolors && gr->dL_dopacity && gr->dL_dmeans3D && gr->dL_dcov3D &&
@@ -210,11 +221,27 @@ int skgs_rasterize_backward(const skgs_raster_inputs* in, const skgs_raster_buff
   GeomView g    = geom_view(buf->geom);
   ImgView im    = img_view(buf->img, in->image_width, in->image_height);
   BinView b     = bin_view(buf->binning, buf->binning_bytes);
+  const skgs_deform_backward_job* dj = gr->deform_backward_job;
+  if (dj) {  // the skinning backward rides on the per-Gaussian launch (same checks as skgs_lbs_deform_backward_logits)
+    SKGS_REQUIRE(dj->in != nullptr, "deform_backward_job: in is NULL");
+    if (check_deform(dj->in)) return 1;
+    SKGS_REQUIRE(dj->in->P == in->P && dj->in->live_count == in->live_count, "deform_backward_job: P / live_count differ from the rasterizer's");
+    SKGS_REQUIRE(dj->in->M <= deform_backward_job_max_bones() && dj->in->K <= deform_backward_job_max_k(),
+        "deform_backward_job: needs M <= %d, K <= %d (got %d, %d)", deform_backward_job_max_bones(), deform_backward_job_max_k(),
+        dj->in->M, dj->in->K);
+    SKGS_REQUIRE(dj->g_bone_T && dj->g_bone_drot && dj->g_bone_dscale, "deform_backward_job: bone gradient outputs are required");
+    SKGS_REQUIRE(dj->g_xyz && dj->g_log_scale && dj->g_rot && dj->g_opacity_logit, "deform_backward_job: gradient outputs are required");
+    SKGS_REQUIRE(dj->g_sp_W || dj->g_logits, "deform_backward_job: one of g_sp_W / g_logits is required");
+    SKGS_REQUIRE(dj->workspace && dj->workspace_bytes >= deform_backward_workspace_bytes(in->P, dj->in->M),
+        "deform_backward_job: workspace too small (skgs_lbs_deform_backward_workspace_bytes)");
+    SKGS_REQUIRE(in->scales && in->rotations, "deform_backward_job: not with cov3D_precomp");
+  }
   if (!gr->workspace_is_zero && fill_u32(gr->workspace, 0u, (size_t) in->P * GRAD_ROW, s)) return 1;
   if (launch_render_backward(*in, g, im, b, out_opacity, gr->dL_dout_color, gr->dL_dout_opacity, gr->dL_dout_extra,
           gr->workspace, s))
     return 1;
-  return launch_preprocess_backward(*in, g, radii, *gr, s);
+  if (launch_preprocess_backward(*in, g, radii, *gr, s)) return 1;
+  return dj ? launch_deform_backward_finalize(*dj->in, dj->workspace, dj->g_bone_T, dj->g_bone_drot, dj->g_bone_dscale, s) : 0;
 }
 
 int skgs_rasterize_extra_forward(int32_t W, int32_t H, int32_t P, int32_t E, const float* extra,

@@ -18,7 +18,6 @@ namespace skgs {
 namespace {
 
 constexpr int DEFORM_THREADS = 256;
-constexpr int PREF_K         = 8;     // neighbour slots prefetched into registers (K is 5 in every shipped config)
 constexpr int MAX_LDS_BONES  = 1024;  // 56 KB of dynamic LDS (backward keeps a gradient copy too: 512 bones)
 
 template <bool LDS_BONES>
@@ -266,204 +265,26 @@ __global__ void __launch_bounds__(256) deform_backward_wide_finalize_kernel(int 
 // every lane owns (bone, component) outputs, summing over the wave's Gaussians with conflict-free broadcast reads.
 // Per-workgroup partial moments go to a workspace; a second tiny kernel reduces them in a fixed order and applies
 // the per-bone linear maps.  No atomics: the bone gradients are deterministic.
-constexpr int MOM_F         = 19;
-constexpr int MOM_U         = 20;  // padded row of U
-constexpr int MOM_MAX_BONES = 64;
-
-__global__ void __launch_bounds__(DEFORM_THREADS) deform_backward_moments_kernel(int P, int K, int M,
-    const float* __restrict__ points, const float* __restrict__ weights, const int64_t* __restrict__ indices,
-    const float* __restrict__ bone_T, const float* __restrict__ bone_drot, const float* __restrict__ bone_dscale,
-    const float* __restrict__ log_scale, const float* __restrict__ rot, const float* __restrict__ opacity_logit,
+__global__ void __launch_bounds__(DEFORM_BWD_THREADS) deform_backward_moments_kernel(int P, DeformBwdArgs a,
     const float* __restrict__ g_means, const float* __restrict__ g_scales, const float* __restrict__ g_rotations,
-    const float* __restrict__ g_opacity, float* __restrict__ g_weights, float* __restrict__ g_xyz,
-    float* __restrict__ g_log_scale, float* __restrict__ g_rot, float* __restrict__ g_opacity_logit,
-    float* __restrict__ partials /* [gridDim.x][M][19] */,
-    float* __restrict__ g_sp_W /* [P,M] or NULL */, float* __restrict__ g_logits /* [P,K] or NULL; both need K <= PREF_K */,
-    const int32_t* __restrict__ live_count /* NULL, or the live Gaussian count (<= P) */) {
+    const float* __restrict__ g_opacity, const int32_t* __restrict__ live_count /* NULL, or the live Gaussian count (<= P) */) {
   if (live_count) P = min(P, live_count[0]);  // the number of Gaussians is a device word: one captured graph survives densification
-  if ((int) (blockIdx.x * DEFORM_THREADS) >= P) {  // a workgroup of the capacity's slack rows: its partial is zero
-    for (int o = threadIdx.x; o < M * MOM_F; o += DEFORM_THREADS) partials[(size_t) blockIdx.x * M * MOM_F + o] = 0.f;
+  if ((int) (blockIdx.x * DEFORM_BWD_THREADS) >= P) {
+    deform_bwd_zero_partials(a);
     return;
   }
   extern __shared__ float s_mem[];
-  const int Mp    = (M + 3) & ~3;                 // weight rows padded to float4
-  float* s_bones  = s_mem;                        // [M][14]
-  float* s_w      = s_bones + M * BONE_F;         // [4 waves][64][Mp]
-  float* s_u      = s_w + 4 * 64 * Mp;            // [4 waves][64][20]
-  float* s_part   = s_u + 4 * 64 * MOM_U;         // [4 waves][M*19]
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float* my_w = s_w + (size_t) (wave * 64 + lane) * Mp;
-  float* my_u = s_u + (size_t) (wave * 64 + lane) * MOM_U;
-  const int n = blockIdx.x * DEFORM_THREADS + threadIdx.x;
-  // Every per-Gaussian input is requested before the bone table is staged (one round trip instead of a chain of
-  // dependent ones: the kernel runs at ~1.5 waves per SIMD, its duration is the length of a lane's dependency chain).
-  // The first PREF_K neighbour slots live in registers; a K beyond that reads the rest in place.
-  float pf_p[3] = {0, 0, 0}, pf_gdx[3] = {0, 0, 0}, pf_gds[3] = {0, 0, 0}, pf_ls[3] = {0, 0, 0}, pf_ol = 0.f, pf_go = 0.f;
-  float4 pf_r4 = make_float4(0.f, 0.f, 0.f, 0.f), pf_gr4 = pf_r4;
-  int pf_j[PREF_K];
-  float pf_w[PREF_K];
-#pragma unroll
-  for (int q = 0; q < PREF_K; ++q) pf_j[q] = 0, pf_w[q] = 0.f;
+  const int n = blockIdx.x * DEFORM_BWD_THREADS + threadIdx.x;
+  DeformBwdLane L;
+  deform_bwd_prefetch(a, n, n < P, L);
+  float g_dx[3] = {0, 0, 0}, g_ds[3] = {0, 0, 0}, go = 0.f;
+  float4 gr4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (n < P) {
 #pragma unroll
-    for (int q = 0; q < PREF_K; ++q)
-      if (q < K) pf_j[q] = (int) indices[(size_t) n * K + q], pf_w[q] = weights[(size_t) n * K + q];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      pf_p[c] = points[3 * n + c], pf_gdx[c] = g_means[3 * n + c], pf_gds[c] = g_scales[3 * n + c];
-      pf_ls[c] = log_scale[3 * n + c];
-    }
-    pf_r4 = reinterpret_cast<const float4*>(rot)[n], pf_gr4 = reinterpret_cast<const float4*>(g_rotations)[n];
-    pf_ol = opacity_logit[n], pf_go = g_opacity[n];
+    for (int c = 0; c < 3; ++c) g_dx[c] = g_means[3 * n + c], g_ds[c] = g_scales[3 * n + c];
+    gr4 = reinterpret_cast<const float4*>(g_rotations)[n], go = g_opacity[n];
   }
-  for (int j = threadIdx.x; j < M; j += DEFORM_THREADS) load_bone(bone_T, bone_drot, bone_dscale, j, s_bones + j * BONE_F);
-  for (int i = 0; i < Mp; i += 4) *reinterpret_cast<float4*>(my_w + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
-  const bool want_logits = g_sp_W != nullptr || g_logits != nullptr;
-  float lw[PREF_K], lg[PREF_K];
-  int lj[PREF_K];
-#pragma unroll
-  for (int q = 0; q < PREF_K; ++q) lw[q] = 0.f, lg[q] = 0.f, lj[q] = 0;
-  float u[MOM_U];
-#pragma unroll
-  for (int c = 0; c < MOM_U; ++c) u[c] = 0.f;
-  if (n < P) {
-    const float p[3] = {pf_p[0], pf_p[1], pf_p[2]};
-    float sr[4] = {0, 0, 0, 0};
-    auto blend_rot = [&](int j, float w) {
-      const float* b = s_bones + j * BONE_F;
-      sr[0] += b[7] * w, sr[1] += b[8] * w, sr[2] += b[9] * w, sr[3] += b[10] * w;
-      my_w[j] += w;  // own row: plain read-modify-write (KNN ids are distinct, += keeps it right if they are not)
-    };
-#pragma unroll
-    for (int q = 0; q < PREF_K; ++q)
-      if (q < K) blend_rot(pf_j[q], pf_w[q]);
-    for (int k = PREF_K; k < K; ++k) blend_rot((int) indices[(size_t) n * K + k], weights[(size_t) n * K + k]);
-    const float4 r4 = pf_r4, gr4 = pf_gr4;
-    const float v[4] = {r4.x + sr[0], r4.y + sr[1], r4.z + sr[2], r4.w + sr[3]};
-    const float gr[4] = {gr4.x, gr4.y, gr4.z, gr4.w};
-    const float nv    = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
-    float g_v[4];
-    if (nv > 1e-12f) {
-      const float uq[4] = {v[0] / nv, v[1] / nv, v[2] / nv, v[3] / nv};
-      const float dot   = uq[0] * gr[0] + uq[1] * gr[1] + uq[2] * gr[2] + uq[3] * gr[3];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) g_v[c] = (gr[c] - uq[c] * dot) / nv;
-    } else {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) g_v[c] = gr[c] / 1e-12f;
-    }
-    const float g_dx[3] = {pf_gdx[0], pf_gdx[1], pf_gdx[2]};
-    const float g_ds[3] = {pf_gds[0], pf_gds[1], pf_gds[2]};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      g_xyz[3 * n + c]       = g_dx[c];
-      g_log_scale[3 * n + c] = g_ds[c] * expf(pf_ls[c]);
-    }
-    reinterpret_cast<float4*>(g_rot)[n] = make_float4(g_v[0], g_v[1], g_v[2], g_v[3]);
-    const float sg     = 1.0f / (1.0f + expf(-pf_ol));
-    g_opacity_logit[n] = pf_go * sg * (1.0f - sg);
-    float dot = 0.f;
-    // dL/dw[p,k] = g_dx . (T_j p) + g_v . d_rot_j + g_ds . d_scale_j
-    auto weight_grad = [&](int j) {
-      const float* b = s_bones + j * BONE_F;
-      float y[3];
-      se3_act(b, p, y);
-      float gw = g_dx[0] * y[0] + g_dx[1] * y[1] + g_dx[2] * y[2];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) gw += g_v[c] * b[7 + c];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) gw += g_ds[c] * b[11 + c];
-      return gw;
-    };
-#pragma unroll
-    for (int q = 0; q < PREF_K; ++q) {
-      if (q < K) {
-        const float gw = weight_grad(pf_j[q]);
-        if (g_weights) g_weights[(size_t) n * K + q] = gw;
-        // softmax backward of the sp_W branch (lbs_weights_backward_kernel): same order of operations
-        lw[q] = pf_w[q], lg[q] = gw, lj[q] = pf_j[q];
-        dot += pf_w[q] * gw;
-      }
-    }
-    for (int k = PREF_K; k < K; ++k) {  // (the logit gradient needs K <= PREF_K: enforced by the launcher)
-      const float gw = weight_grad((int) indices[(size_t) n * K + k]);
-      if (g_weights) g_weights[(size_t) n * K + k] = gw;
-    }
-    if (want_logits) {
-#pragma unroll
-      for (int q = 0; q < PREF_K; ++q) lg[q] = q < K ? lw[q] * (lg[q] - dot) : 0.f;
-      if (g_logits)
-#pragma unroll
-        for (int q = 0; q < PREF_K; ++q)
-          if (q < K) g_logits[(size_t) n * K + q] = lg[q];
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      u[a] = g_dx[a];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) u[3 + 3 * a + c] = g_dx[a] * p[c];
-      u[16 + a] = g_ds[a];
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) u[12 + c] = g_v[c];
-  }
-#pragma unroll
-  for (int c = 0; c < MOM_U; c += 4) *reinterpret_cast<float4*>(my_u + c) = make_float4(u[c], u[c + 1], u[c + 2], u[c + 3]);
-  __syncthreads();  // (only the own wave's rows are read below; the barrier also orders the LDS traffic)
-  // ---- Mom_wave[bone][component] = sum over the wave's 64 Gaussians of w[q][bone] u[q][component]: outer products on the
-  // matrix cores.  v_mfma_f32_4x4x1 holds 16 independent 4 x 4 blocks = (4 bones) x (4 components) each; one Gaussian per
-  // instruction; lane 4 b + i feeds bone 4 bg + i as A and component 4 cg + i as B of block b and receives row i' of the
-  // block in VGPR i'.  (On the VALU every lane owned ~6 outputs and read 2 x 64 LDS words for each: 768 ds_read_b32 and 384
-  // FMAs per lane; now 256 reads and 128 MFMAs for M = 20.)
-  const int n_out   = M * MOM_F;
-  const float* w0   = s_w + (size_t) wave * 64 * Mp;
-  const float* u0   = s_u + (size_t) wave * 64 * MOM_U;
-  float* part       = s_part + (size_t) wave * n_out;
-  {
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    constexpr int NCG = MOM_U / 4;
-    const int nblk = (Mp / 4) * NCG, li = lane & 3, lb = lane >> 2;
-    for (int r0 = 0; r0 < nblk; r0 += 16) {
-      const int blk   = r0 + lb;
-      const bool live = blk < nblk;
-      const int bg = live ? blk / NCG : 0, cg = live ? blk - (blk / NCG) * NCG : 0;
-      const float* wa = w0 + 4 * bg + li;
-      const float* ub = u0 + 4 * cg + li;
-      f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-      for (int q = 0; q < 64; q += 2) {
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[q * Mp], ub[q * MOM_U], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[(q + 1) * Mp], ub[(q + 1) * MOM_U], acc1, 0, 0, 0);
-      }
-      if (live) {
-        const int comp = 4 * cg + li;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int bone = 4 * bg + i;
-          if (bone < M && comp < MOM_F) part[bone * MOM_F + comp] = acc0[i] + acc1[i];
-        }
-      }
-    }
-  }
-  __syncthreads();
-  for (int o = threadIdx.x; o < n_out; o += DEFORM_THREADS)
-    partials[(size_t) blockIdx.x * n_out + o] = (s_part[o] + s_part[n_out + o]) + (s_part[2 * n_out + o] + s_part[3 * n_out + o]);
-  // ---- dense logit-gradient rows (lbs_weights_backward_kernel folded in): the weight rows in LDS are no longer needed,
-  // each lane rebuilds its row there as the gradient row, the workgroup stores its 256 rows as one contiguous span
-  if (g_sp_W) {
-    for (int i = 0; i < Mp; i += 4) *reinterpret_cast<float4*>(my_w + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n < P) {
-#pragma unroll
-      for (int q = 0; q < PREF_K; ++q)
-        if (q < K) my_w[lj[q]] += lg[q];  // KNN ids are distinct; += keeps the gather-backward semantics if they are not
-    }
-    __syncthreads();
-    const int p0   = blockIdx.x * DEFORM_THREADS;
-    const int rows = min(DEFORM_THREADS, P - p0);
-    float* dst     = g_sp_W + (size_t) p0 * M;
-    for (int i = threadIdx.x; i < rows * M; i += DEFORM_THREADS) dst[i] = s_w[(i / M) * Mp + (i % M)];
-  }
+  deform_bwd_moments(a, P, s_mem, L, g_dx, g_ds, gr4, go);
 }
 
 // one workgroup per bone: fixed-order reduction of the per-workgroup partial moments, then the per-bone linear maps.
@@ -988,14 +809,13 @@ int launch_deform_backward(const skgs_deform_inputs& in, const float* g_means, c
   }
   dim3 grid((in.P + DEFORM_THREADS - 1) / DEFORM_THREADS), block(DEFORM_THREADS);
   if (in.M <= MOM_MAX_BONES) {
-    const int Mp     = (in.M + 3) & ~3;
-    const size_t lds = ((size_t) in.M * BONE_F + 4 * 64 * (size_t) Mp + 4 * 64 * MOM_U + 4 * (size_t) in.M * MOM_F) * 4;
+    const size_t lds = deform_bwd_lds_bytes(in.M);
     float* partials  = reinterpret_cast<float*>(workspace);
+    DeformBwdArgs a{in.K, in.M, in.points, in.weights, in.indices, in.bone_T, in.bone_drot, in.bone_dscale, in.log_scale, in.rot,
+        in.opacity_logit, g_weights, g_xyz, g_log_scale, g_rot, g_opacity_logit, partials, g_sp_W, g_logits};
     {
       ProfScope prof(K_DEFORM_BWD, s);
-      hipLaunchKernelGGL(deform_backward_moments_kernel, grid, block, lds, s, in.P, in.K, in.M, in.points, in.weights,
-          in.indices, in.bone_T, in.bone_drot, in.bone_dscale, in.log_scale, in.rot, in.opacity_logit, g_means, g_scales,
-          g_rotations, g_opacity, g_weights, g_xyz, g_log_scale, g_rot, g_opacity_logit, partials, g_sp_W, g_logits,
+      hipLaunchKernelGGL(deform_backward_moments_kernel, grid, block, lds, s, in.P, a, g_means, g_scales, g_rotations, g_opacity,
           in.live_count);
     }
     SKGS_CHECK_HIP(hipGetLastError());
@@ -1036,6 +856,19 @@ int launch_deform_backward(const skgs_deform_inputs& in, const float* g_means, c
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }
+
+// the second launch of the moments path alone: the first ran as a job of the rasterizer's per-Gaussian backward launch
+// (preprocess.hip, skgs_raster_grads.deform_backward_job), grid = ceil(P / DEFORM_BWD_THREADS) workgroups
+int launch_deform_backward_finalize(const skgs_deform_inputs& in, void* workspace, float* g_bone_T, float* g_bone_drot,
+    float* g_bone_dscale, hipStream_t s) {
+  const int nblk = (in.P + DEFORM_BWD_THREADS - 1) / DEFORM_BWD_THREADS;
+  hipLaunchKernelGGL(deform_backward_finalize_kernel, dim3(in.M), dim3(256), 0, s, in.M, nblk, reinterpret_cast<float*>(workspace),
+      in.bone_T, g_bone_T, g_bone_drot, g_bone_dscale);
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+int deform_backward_job_max_bones() { return MOM_MAX_BONES; }
+int deform_backward_job_max_k() { return PREF_K; }
 
 int launch_knn_bones(int P, int M, int K, int dim, const float* points, const float* joints, float* out_dist,
     int64_t* out_idx, hipStream_t s) {

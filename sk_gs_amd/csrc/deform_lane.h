@@ -113,5 +113,220 @@ __device__ __forceinline__ void deform_activate_lane(const float (&p)[3], const 
   opacity  = 1.0f / (1.0f + expf(-opacity_logit));
 }
 
+// ------------------------------------------------------------------------------ deform backward: bone gradients by moments
+// (the algorithm: deform.hip, above deform_backward_moments_kernel.)  The body is shared by that kernel and by the rasterizer's
+// per-Gaussian backward launch (preprocess.hip), which runs it on the gradients it has just produced, from registers.
+constexpr int PREF_K             = 8;  // neighbour slots prefetched into registers (K is 5 in every shipped config)
+constexpr int MOM_F              = 19;
+constexpr int MOM_U              = 20;  // padded row of U
+constexpr int MOM_MAX_BONES      = 64;
+constexpr int DEFORM_BWD_THREADS = 256;  // 4 waves: the LDS carving below and the partial sums assume it
+
+struct DeformBwdArgs {
+  int K, M;
+  const float *points, *weights;
+  const int64_t* indices;
+  const float *bone_T, *bone_drot, *bone_dscale, *log_scale, *rot, *opacity_logit;
+  float *g_weights, *g_xyz, *g_log_scale, *g_rot, *g_opacity_logit;
+  float* partials;  // [gridDim.x][M][19]
+  float* g_sp_W;    // [P,M] or NULL
+  float* g_logits;  // [P,K] or NULL; both need K <= PREF_K
+};
+// what a lane requests up front (one round trip instead of a chain of dependent ones: these launches run at ~1.5 waves per
+// SIMD, their duration is the length of a lane's dependency chain).  The first PREF_K neighbour slots live in registers; a K
+// beyond that reads the rest in place.
+struct DeformBwdLane {
+  float p[3], ls[3], ol;
+  float4 r4;
+  int j[PREF_K];
+  float w[PREF_K];
+};
+inline size_t deform_bwd_lds_bytes(int M) {
+  const int Mp = (M + 3) & ~3;
+  return ((size_t) M * BONE_F + 4 * 64 * (size_t) Mp + 4 * 64 * MOM_U + 4 * (size_t) M * MOM_F) * 4;
+}
+__device__ __forceinline__ void deform_bwd_prefetch(const DeformBwdArgs& a, int n, bool valid, DeformBwdLane& L) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) L.p[c] = 0.f, L.ls[c] = 0.f;
+  L.ol = 0.f, L.r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int q = 0; q < PREF_K; ++q) L.j[q] = 0, L.w[q] = 0.f;
+  if (valid) {
+#pragma unroll
+    for (int q = 0; q < PREF_K; ++q)
+      if (q < a.K) L.j[q] = (int) a.indices[(size_t) n * a.K + q], L.w[q] = a.weights[(size_t) n * a.K + q];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) L.p[c] = a.points[3 * n + c], L.ls[c] = a.log_scale[3 * n + c];
+    L.r4 = reinterpret_cast<const float4*>(a.rot)[n], L.ol = a.opacity_logit[n];
+  }
+}
+// a workgroup of the capacity's slack rows: its partial is zero
+__device__ __forceinline__ void deform_bwd_zero_partials(const DeformBwdArgs& a) {
+  for (int o = threadIdx.x; o < a.M * MOM_F; o += DEFORM_BWD_THREADS) a.partials[(size_t) blockIdx.x * a.M * MOM_F + o] = 0.f;
+}
+// The whole workgroup (DEFORM_BWD_THREADS threads, Gaussian n = blockIdx.x * DEFORM_BWD_THREADS + threadIdx.x, P the live
+// count) with the upstream gradients of its Gaussian in registers; s_mem: deform_bwd_lds_bytes(M) of LDS nobody else uses
+// from here on.  Contains workgroup barriers.
+__device__ __forceinline__ void deform_bwd_moments(const DeformBwdArgs& a, int P, float* s_mem, const DeformBwdLane& L,
+    const float (&g_dx_in)[3], const float (&g_ds_in)[3], float4 gr4_in, float go_in) {
+  const int Mp    = (a.M + 3) & ~3;                 // weight rows padded to float4
+  float* s_bones  = s_mem;                        // [a.M][14]
+  float* s_w      = s_bones + a.M * BONE_F;         // [4 waves][64][Mp]
+  float* s_u      = s_w + 4 * 64 * Mp;            // [4 waves][64][20]
+  float* s_part   = s_u + 4 * 64 * MOM_U;         // [4 waves][a.M*19]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* my_w = s_w + (size_t) (wave * 64 + lane) * Mp;
+  float* my_u = s_u + (size_t) (wave * 64 + lane) * MOM_U;
+  const int n = blockIdx.x * DEFORM_BWD_THREADS + threadIdx.x;
+  for (int j = threadIdx.x; j < a.M; j += DEFORM_BWD_THREADS) load_bone(a.bone_T, a.bone_drot, a.bone_dscale, j, s_bones + j * BONE_F);
+  for (int i = 0; i < Mp; i += 4) *reinterpret_cast<float4*>(my_w + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const bool want_logits = a.g_sp_W != nullptr || a.g_logits != nullptr;
+  float lw[PREF_K], lg[PREF_K];
+  int lj[PREF_K];
+#pragma unroll
+  for (int q = 0; q < PREF_K; ++q) lw[q] = 0.f, lg[q] = 0.f, lj[q] = 0;
+  float u[MOM_U];
+#pragma unroll
+  for (int c = 0; c < MOM_U; ++c) u[c] = 0.f;
+  if (n < P) {
+    const float p[3] = {L.p[0], L.p[1], L.p[2]};
+    float sr[4] = {0, 0, 0, 0};
+    auto blend_rot = [&](int j, float w) {
+      const float* b = s_bones + j * BONE_F;
+      sr[0] += b[7] * w, sr[1] += b[8] * w, sr[2] += b[9] * w, sr[3] += b[10] * w;
+      my_w[j] += w;  // own row: plain read-modify-write (KNN ids are distinct, += keeps it right if they are not)
+    };
+#pragma unroll
+    for (int q = 0; q < PREF_K; ++q)
+      if (q < a.K) blend_rot(L.j[q], L.w[q]);
+    for (int k = PREF_K; k < a.K; ++k) blend_rot((int) a.indices[(size_t) n * a.K + k], a.weights[(size_t) n * a.K + k]);
+    const float4 r4 = L.r4, gr4 = gr4_in;
+    const float v[4] = {r4.x + sr[0], r4.y + sr[1], r4.z + sr[2], r4.w + sr[3]};
+    const float gr[4] = {gr4.x, gr4.y, gr4.z, gr4.w};
+    const float nv    = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+    float g_v[4];
+    if (nv > 1e-12f) {
+      const float uq[4] = {v[0] / nv, v[1] / nv, v[2] / nv, v[3] / nv};
+      const float dot   = uq[0] * gr[0] + uq[1] * gr[1] + uq[2] * gr[2] + uq[3] * gr[3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) g_v[c] = (gr[c] - uq[c] * dot) / nv;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) g_v[c] = gr[c] / 1e-12f;
+    }
+    const float g_dx[3] = {g_dx_in[0], g_dx_in[1], g_dx_in[2]};
+    const float g_ds[3] = {g_ds_in[0], g_ds_in[1], g_ds_in[2]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      a.g_xyz[3 * n + c]       = g_dx[c];
+      a.g_log_scale[3 * n + c] = g_ds[c] * expf(L.ls[c]);
+    }
+    reinterpret_cast<float4*>(a.g_rot)[n] = make_float4(g_v[0], g_v[1], g_v[2], g_v[3]);
+    const float sg     = 1.0f / (1.0f + expf(-L.ol));
+    a.g_opacity_logit[n] = go_in * sg * (1.0f - sg);
+    float dot = 0.f;
+    // dL/dw[p,k] = g_dx . (T_j p) + g_v . d_rot_j + g_ds . d_scale_j
+    auto weight_grad = [&](int j) {
+      const float* b = s_bones + j * BONE_F;
+      float y[3];
+      se3_act(b, p, y);
+      float gw = g_dx[0] * y[0] + g_dx[1] * y[1] + g_dx[2] * y[2];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) gw += g_v[c] * b[7 + c];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gw += g_ds[c] * b[11 + c];
+      return gw;
+    };
+#pragma unroll
+    for (int q = 0; q < PREF_K; ++q) {
+      if (q < a.K) {
+        const float gw = weight_grad(L.j[q]);
+        if (a.g_weights) a.g_weights[(size_t) n * a.K + q] = gw;
+        // softmax backward of the sp_W branch (lbs_weights_backward_kernel): same order of operations
+        lw[q] = L.w[q], lg[q] = gw, lj[q] = L.j[q];
+        dot += L.w[q] * gw;
+      }
+    }
+    for (int k = PREF_K; k < a.K; ++k) {  // (the logit gradient needs a.K <= PREF_K: enforced by the launcher)
+      const float gw = weight_grad((int) a.indices[(size_t) n * a.K + k]);
+      if (a.g_weights) a.g_weights[(size_t) n * a.K + k] = gw;
+    }
+    if (want_logits) {
+#pragma unroll
+      for (int q = 0; q < PREF_K; ++q) lg[q] = q < a.K ? lw[q] * (lg[q] - dot) : 0.f;
+      if (a.g_logits)
+#pragma unroll
+        for (int q = 0; q < PREF_K; ++q)
+          if (q < a.K) a.g_logits[(size_t) n * a.K + q] = lg[q];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      u[a] = g_dx[a];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) u[3 + 3 * a + c] = g_dx[a] * p[c];
+      u[16 + a] = g_ds[a];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) u[12 + c] = g_v[c];
+  }
+#pragma unroll
+  for (int c = 0; c < MOM_U; c += 4) *reinterpret_cast<float4*>(my_u + c) = make_float4(u[c], u[c + 1], u[c + 2], u[c + 3]);
+  __syncthreads();  // (only the own wave's rows are read below; the barrier also orders the LDS traffic)
+  // ---- Mom_wave[bone][component] = sum over the wave's 64 Gaussians of w[q][bone] u[q][component]: outer products on the
+  // matrix cores.  v_mfma_f32_4x4x1 holds 16 independent 4 x 4 blocks = (4 bones) x (4 components) each; one Gaussian per
+  // instruction; lane 4 b + i feeds bone 4 bg + i as A and component 4 cg + i as B of block b and receives row i' of the
+  // block in VGPR i'.  (On the VALU every lane owned ~6 outputs and read 2 x 64 LDS words for each: 768 ds_read_b32 and 384
+  // FMAs per lane; now 256 reads and 128 MFMAs for a.M = 20.)
+  const int n_out   = a.M * MOM_F;
+  const float* w0   = s_w + (size_t) wave * 64 * Mp;
+  const float* u0   = s_u + (size_t) wave * 64 * MOM_U;
+  float* part       = s_part + (size_t) wave * n_out;
+  {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    constexpr int NCG = MOM_U / 4;
+    const int nblk = (Mp / 4) * NCG, li = lane & 3, lb = lane >> 2;
+    for (int r0 = 0; r0 < nblk; r0 += 16) {
+      const int blk   = r0 + lb;
+      const bool live = blk < nblk;
+      const int bg = live ? blk / NCG : 0, cg = live ? blk - (blk / NCG) * NCG : 0;
+      const float* wa = w0 + 4 * bg + li;
+      const float* ub = u0 + 4 * cg + li;
+      f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+      for (int q = 0; q < 64; q += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[q * Mp], ub[q * MOM_U], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[(q + 1) * Mp], ub[(q + 1) * MOM_U], acc1, 0, 0, 0);
+      }
+      if (live) {
+        const int comp = 4 * cg + li;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int bone = 4 * bg + i;
+          if (bone < a.M && comp < MOM_F) part[bone * MOM_F + comp] = acc0[i] + acc1[i];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < n_out; o += DEFORM_BWD_THREADS)
+    a.partials[(size_t) blockIdx.x * n_out + o] = (s_part[o] + s_part[n_out + o]) + (s_part[2 * n_out + o] + s_part[3 * n_out + o]);
+  // ---- dense logit-gradient rows (lbs_weights_backward_kernel folded in): the weight rows in LDS are no longer needed,
+  // each lane rebuilds its row there as the gradient row, the workgroup stores its 256 rows as one contiguous span
+  if (a.g_sp_W) {
+    for (int i = 0; i < Mp; i += 4) *reinterpret_cast<float4*>(my_w + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < P) {
+#pragma unroll
+      for (int q = 0; q < PREF_K; ++q)
+        if (q < a.K) my_w[lj[q]] += lg[q];  // KNN ids are distinct; += keeps the gather-backward semantics if they are not
+    }
+    __syncthreads();
+    const int p0   = blockIdx.x * DEFORM_BWD_THREADS;
+    const int rows = min(DEFORM_BWD_THREADS, P - p0);
+    float* dst     = a.g_sp_W + (size_t) p0 * a.M;
+    for (int i = threadIdx.x; i < rows * a.M; i += DEFORM_BWD_THREADS) dst[i] = s_w[(i / a.M) * Mp + (i % a.M)];
+  }
+}
+
 }  // namespace
 }  // namespace skgs

@@ -12,6 +12,8 @@
 // order and compiled without FMA contraction so that every discrete decision (cull, radius = ceil(..), tile
 // rectangle, SH clamp) is bit-identical to the CPU oracle; these kernels move ~0.3 KB per Gaussian, the extra
 // VALU work is free.
+#include <algorithm>
+
 #include "skgs_common.h"
 #include "deform_lane.h"
 
@@ -245,7 +247,6 @@ constexpr int PRE_THREADS     = 128;
 // forward is slower that way and with 64 (A/B on one box, 300 steps each)
 constexpr int PRE_BWD_THREADS = 256;
 __device__ __forceinline__ int sh_pitch(int RL) { return RL | 1; }
-inline int sh_pitch_host(int RL) { return RL | 1; }
 // Both copies keep all of a thread's global accesses in flight at once (up to STAGE_V float4 per thread): a loop of
 // load -> LDS store per row serialised on the load latency and was slower than no staging at all.
 constexpr int STAGE_V = 12;  // NT rows x 48 floats / 4 / NT threads
@@ -300,7 +301,7 @@ __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, const fl
 // knn_deform_forward_kernel's arithmetic through the same deform_lane.h functions -- writes them (and the weights / indices) for
 // the backward, and projects them from registers: one launch and one round trip through HBM less per step.
 struct KnnDeformJob {
-  int M, K, lds_offset /* floats: where the deform's tables start in the dynamic LDS (behind the SH rows) */, stage_logits;
+  int M, K, lds_offset /* floats: where the deform's tables start in the dynamic LDS (behind the SH rows) */;
   const float *points, *joints, *sp_W, *bone_T, *bone_drot, *bone_dscale, *xyz, *log_scale, *rot, *opacity_logit;
   int64_t* out_idx;
   float *out_weights, *means, *scales, *rotations, *opacity;
@@ -388,15 +389,13 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
       my_dc = my_sh = s_sh + threadIdx.x * sh_pitch(RL);
     }
   }
-  // (DK > 0) the deform's tables behind the SH rows: joints, bones, this workgroup's rows of the logit table (a lane gathers K
-  // of its row's M logits AFTER the search: from LDS that is no second round trip, and the rows' lines are fetched whole anyway)
-  float *s_j = nullptr, *s_bones = nullptr, *s_logit = nullptr;
+  // (DK > 0) the deform's tables behind the SH rows: joints and bones.  (Staging the workgroup's logit rows there as well -- a
+  // lane gathers K of its row's M logits AFTER the search -- saved nothing at 100k Gaussians and cost the launch a third of
+  // its resident waves at 300k and 500k: 11 KB more LDS per workgroup.)
+  float *s_j = nullptr, *s_bones = nullptr;
   if constexpr (DK > 0) {
-    const int base = blockIdx.x * blockDim.x, nrows = min((int) blockDim.x, P - base);
     s_j     = s_sh + dj.lds_offset;
     s_bones = s_j + ((dj.M * 3 + 3) & ~3);
-    s_logit = s_bones + ((dj.M * BONE_F + 3) & ~3);
-    if (dj.stage_logits) stage_rows_in(s_logit, dj.sp_W + (size_t) base * dj.M, nrows, dj.M);
     for (int i = threadIdx.x; i < dj.M * 3; i += PRE_THREADS) s_j[i] = dj.joints[i];
     for (int j = threadIdx.x; j < dj.M; j += PRE_THREADS) load_bone(dj.bone_T, dj.bone_drot, dj.bone_dscale, j, s_bones + j * BONE_F);
   }
@@ -407,14 +406,9 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
     if (idx < P) {
       float w[DK], sx[3], sr[4], ss[3];
       int bi[DK];
-      if (dj.stage_logits) {
-        const float* row = s_logit + threadIdx.x * sh_pitch(dj.M);
-        knn_softmax_skin_lane<DK>(dj.M, dj.K, s_j, s_bones, dj_p, [&](int j) { return row[j]; }, w, bi, sx, sr, ss);
-      } else {
-        const float* row = dj.sp_W + (size_t) idx * dj.M;
-        knn_softmax_skin_lane<DK>(dj.M, dj.K, s_j, s_bones, dj_p, [&](int j) { return row[j]; }, w, bi, sx, sr, ss);
-      }
-      // (straight from the lane: rows through LDS would cost this launch a quarter of its resident workgroups)
+      const float* row = dj.sp_W + (size_t) idx * dj.M;
+      knn_softmax_skin_lane<DK>(dj.M, dj.K, s_j, s_bones, dj_p, [&](int j) { return row[j]; }, w, bi, sx, sr, ss);
+      // (straight from the lane: rows through LDS would cost this launch resident workgroups)
 #pragma unroll
       for (int k = 0; k < DK; ++k)
         if (k < dj.K) dj.out_weights[(size_t) idx * dj.K + k] = w[k], dj.out_idx[(size_t) idx * dj.K + k] = bi[k];
@@ -614,7 +608,12 @@ __device__ __forceinline__ void sh_backward(int deg, int M, const float* mean, c
   for (int i = used; i < M; ++i) dL_dsh[i * 3] = 0.f, dL_dsh[i * 3 + 1] = 0.f, dL_dsh[i * 3 + 2] = 0.f;
 }
 
-template <bool COLMAP>
+// DBJ: the skeleton stage's deform backward as a job of this launch (skgs_raster_grads.deform_backward_job): the lane that has
+// just produced dL/d(mean, scale, rotation, opacity) of its Gaussian hands them, in registers, to deform_bwd_moments
+// (deform_lane.h: the body of deform_backward_moments_kernel) -- the Gaussian's parameter gradients, its logit gradients and
+// the workgroup's partial bone moments, in the LDS the SH rows have just left.
+static_assert(PRE_BWD_THREADS == DEFORM_BWD_THREADS, "the deform backward job runs in this launch's workgroups");
+template <bool COLMAP, bool DBJ>
 __global__ void __launch_bounds__(PRE_BWD_THREADS) preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3D,
     const int32_t* __restrict__ radii, const float* __restrict__ shs, const float* __restrict__ shs_rest,
     const float* __restrict__ scales,
@@ -629,9 +628,12 @@ __global__ void __launch_bounds__(PRE_BWD_THREADS) preprocess_backward_kernel(in
     float* __restrict__ dL_dscales, float* __restrict__ dL_drot, float* __restrict__ dL_dextras,
     float* __restrict__ sh_factors /* [P,6] or NULL: see sh_backward */, const float* __restrict__ tanfov_dev,
     const int32_t* __restrict__ live, float* __restrict__ stat_accum, float* __restrict__ stat_denom,
-    float* __restrict__ stat_max_radii, float stat_mult) {
+    float* __restrict__ stat_max_radii, float stat_mult, DeformBwdArgs dbj) {
   if (live) P = min(P, live[0]);  // the number of Gaussians is a device word: one captured graph survives densification
-  if ((int) (blockIdx.x * blockDim.x) >= P) return;  // a workgroup of the capacity's slack rows (before any barrier)
+  if ((int) (blockIdx.x * blockDim.x) >= P) {  // a workgroup of the capacity's slack rows (before any barrier)
+    if constexpr (DBJ) deform_bwd_zero_partials(dbj);
+    return;
+  }
   if (tanfov_dev) {
     tan_fovx = tanfov_dev[0], tan_fovy = tanfov_dev[1];
     focal_x = W / (2.0f * tan_fovx), focal_y = H / (2.0f * tan_fovy);
@@ -670,6 +672,10 @@ __global__ void __launch_bounds__(PRE_BWD_THREADS) preprocess_backward_kernel(in
       pf_q = reinterpret_cast<const float4*>(rotations)[idx];
     }
   }
+  DeformBwdLane dbl;  // (DBJ) the deform backward's own per-Gaussian inputs ride in the same round trip
+  if constexpr (DBJ) deform_bwd_prefetch(dbj, idx, idx < P, dbl);
+  float dj_gm[3] = {0.f, 0.f, 0.f}, dj_gs[3] = {0.f, 0.f, 0.f}, dj_go = 0.f;
+  float4 dj_gr = make_float4(0.f, 0.f, 0.f, 0.f);
   if (staged) stage_rows_in<PRE_BWD_THREADS>(s_sh, (shs_rest ? shs_rest : shs) + (size_t) base * RL, nrows, RL);
   __syncthreads();
   if (idx < P) {
@@ -937,10 +943,19 @@ __global__ void __launch_bounds__(PRE_BWD_THREADS) preprocess_backward_kernel(in
   for (int i = 0; i < 6; ++i) dL_dcov3D[6 * idx + i] = gcov[i];
   dL_dscales[3 * idx] = gscale[0], dL_dscales[3 * idx + 1] = gscale[1], dL_dscales[3 * idx + 2] = gscale[2];
   reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(grot[0], grot[1], grot[2], grot[3]);
+  if constexpr (DBJ) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dj_gm[c] = gmean[c], dj_gs[c] = gscale[c];
+    dj_gr = make_float4(grot[0], grot[1], grot[2], grot[3]), dj_go = gop;
+  }
   }  // idx < P
   if (staged && dL_dsh) {
     __syncthreads();
     stage_rows_out<PRE_BWD_THREADS>((dL_dsh_rest ? dL_dsh_rest : dL_dsh) + (size_t) base * RL, s_sh, nrows, RL);
+  }
+  if constexpr (DBJ) {
+    __syncthreads();  // the SH rows have left the LDS: it is the deform backward's now
+    deform_bwd_moments(dbj, P, s_sh, dbl, dj_gm, dj_gs, dj_gr, dj_go);
   }
 }
 
@@ -1059,12 +1074,10 @@ int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView 
     dj.bone_dscale = j->bone_dscale, dj.xyz = j->xyz, dj.log_scale = j->log_scale, dj.rot = j->rot;
     dj.opacity_logit = j->opacity_logit, dj.out_idx = j->out_idx, dj.out_weights = j->out_weights, dj.means = j->means;
     dj.scales = j->scales, dj.rotations = j->rotations, dj.opacity = j->opacity;
-    // the workgroup's logit rows through LDS while FOUR workgroups still share a CU's 160 KB (at 100k Gaussians the launch is
-    // 782 workgroups: with three per CU the last 14 run alone behind the rest, 32 us instead of 22)
-    const size_t tables = (size_t) ((j->M * 3 + 3) & ~3) + ((j->M * BONE_F + 3) & ~3);
-    const size_t rows   = (size_t) (PRE_THREADS * sh_pitch_host(j->M) + 3) & ~(size_t) 3;
-    dj.stage_logits     = j->M <= 4 * STAGE_V && ((size_t) dj.lds_offset + tables + rows) * 4 + sizeof(Cam) <= 40 * 1024;
-    lds                 = ((size_t) dj.lds_offset + tables + (dj.stage_logits ? rows : 0)) * 4;
+    // (26 KB per workgroup with degree-3 SH rows: six workgroups per CU, as without the job.  The first version kept 44 KB --
+    // three per CU = 768 resident workgroups for a grid of 782 at 100k Gaussians: the last 14 ran alone behind the rest,
+    // 32 us instead of 22)
+    lds = ((size_t) dj.lds_offset + (size_t) ((j->M * 3 + 3) & ~3) + ((j->M * BONE_F + 3) & ~3)) * 4;
   }
 #define SKGS_PRE_FWD(COLMAP_, DK_)                                                                                          \
   hipLaunchKernelGGL((preprocess_forward_kernel<COLMAP_, DK_>), grid, block, lds, s, P, in.sh_degree, in.sh_coeffs, in.means3D, \
@@ -1100,8 +1113,16 @@ int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const i
   const float focal_x = in.image_width / (2.0f * in.tanfovx);
   ProfScope prof(K_PREPROCESS_BWD, s);
   dim3 grid((P + PRE_BWD_THREADS - 1) / PRE_BWD_THREADS), block(PRE_BWD_THREADS);
-  const size_t lds = (in.sh && (gr.dL_dsh || gr.dL_dsh_factors)) ? (size_t) PRE_BWD_THREADS * (((in.sh_rest ? in.sh_coeffs - 1 : in.sh_coeffs) * 3) | 1) * 4 : 0;
+  size_t lds = (in.sh && (gr.dL_dsh || gr.dL_dsh_factors)) ? (size_t) PRE_BWD_THREADS * (((in.sh_rest ? in.sh_coeffs - 1 : in.sh_coeffs) * 3) | 1) * 4 : 0;
   const int E = (in.extras && gr.dL_dout_extra && gr.dL_dextras) ? in.E : 0;
+  DeformBwdArgs dbj{};
+  if (const skgs_deform_backward_job* j = gr.deform_backward_job) {  // (arguments checked by skgs_rasterize_backward)
+    const skgs_deform_inputs& d = *j->in;
+    dbj = DeformBwdArgs{d.K, d.M, d.points, d.weights, d.indices, d.bone_T, d.bone_drot, d.bone_dscale, d.log_scale, d.rot,
+        d.opacity_logit, nullptr, j->g_xyz, j->g_log_scale, j->g_rot, j->g_opacity_logit, reinterpret_cast<float*>(j->workspace),
+        j->g_sp_W, j->g_logits};
+    lds = std::max(lds, deform_bwd_lds_bytes(d.M));
+  }
 #define SKGS_PB_ARGS                                                                                                     \
   P, in.sh_degree, in.sh_coeffs, in.means3D, radii, in.sh, in.sh_rest, in.scales, in.rotations, in.scale_modifier,        \
       in.cov3D_precomp, in.viewmatrix, in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, \
@@ -1109,11 +1130,17 @@ int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const i
       gr.grad_means2D_in, gr.grad_conic_in, gr.grad_opacity_in, E, gr.dL_dmeans2D, gr.dL_dconic, gr.dL_dcolors,           \
       gr.dL_dopacity, gr.dL_dmeans3D, gr.dL_dcov3D, gr.dL_dsh, gr.dL_dsh_rest, gr.dL_dscales, gr.dL_drotations,           \
       gr.dL_dextras, gr.dL_dsh_factors, in.tanfov_device, in.live_count, gr.stat_xyz_gradient_accum, gr.stat_denom,        \
-      gr.stat_max_radii2D, (gr.stat_grad_multiplier != 0.f ? gr.stat_grad_multiplier : 1.0f)
-  if (in.colmap)
-    hipLaunchKernelGGL(preprocess_backward_kernel<true>, grid, block, lds, s, SKGS_PB_ARGS);
-  else
-    hipLaunchKernelGGL(preprocess_backward_kernel<false>, grid, block, lds, s, SKGS_PB_ARGS);
+      gr.stat_max_radii2D, (gr.stat_grad_multiplier != 0.f ? gr.stat_grad_multiplier : 1.0f), dbj
+  if (gr.deform_backward_job) {
+    if (in.colmap)
+      hipLaunchKernelGGL((preprocess_backward_kernel<true, true>), grid, block, lds, s, SKGS_PB_ARGS);
+    else
+      hipLaunchKernelGGL((preprocess_backward_kernel<false, true>), grid, block, lds, s, SKGS_PB_ARGS);
+  } else if (in.colmap) {
+    hipLaunchKernelGGL((preprocess_backward_kernel<true, false>), grid, block, lds, s, SKGS_PB_ARGS);
+  } else {
+    hipLaunchKernelGGL((preprocess_backward_kernel<false, false>), grid, block, lds, s, SKGS_PB_ARGS);
+  }
 #undef SKGS_PB_ARGS
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;

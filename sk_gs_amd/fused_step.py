@@ -75,6 +75,10 @@ class FusedViewStep:
         # the one-launch skinning as a job of the rasterizer's per-Gaussian launch (skgs_raster_inputs.deform_job): the same
         # bits one launch earlier; SKGS_SEPARATE_DEFORM=1 keeps the two launches (A/B measurements)
         self.deform_in_preprocess = os.environ.get('SKGS_SEPARATE_DEFORM', '0') != '1'
+        # likewise the skinning backward (moments path: M <= 64, K <= 8) as a job of the rasterizer's per-Gaussian backward
+        # launch (skgs_raster_grads.deform_backward_job); SKGS_SEPARATE_DEFORM_BACKWARD=1 keeps the launch of its own
+        self.deform_backward_in_preprocess = os.environ.get('SKGS_SEPARATE_DEFORM_BACKWARD', '0') != '1'
+        self._rows_backward_done = False
         # the weighting of calc_LBS_weight: `W` (logits per Gaussian) runs inside the one-launch skinning kernels; the three
         # distance-based ones (sk_gs.py:757-766,770) as search + weighting in one launch, then the skinning
         self.lbs_method = getattr(model, 'lbs_method', 'W')
@@ -424,6 +428,25 @@ class FusedViewStep:
         if self.densify_stats:  # this view's statistics, by the launch that writes the screen-space gradient
             g.stat_xyz_gradient_accum, g.stat_denom = self._acc_store.data_ptr(), self._den_store.data_ptr()
             g.stat_max_radii2D, g.stat_grad_multiplier = self._rad_store.data_ptr(), 1.0 / self._grad_scale_value
+        self._rows_backward_done = False
+        if self.deform_backward_in_preprocess and self.lbs_method == 'W' and not self.wide and self.M <= 64 and self.K <= 8:
+            # the skinning backward (with the softmax backward of the LBS logits) rides on the per-Gaussian launch: what
+            # backward_skinning would launch next, on the same values, handed over in registers
+            if self.deform_net is None:
+                g_drot, g_dscale = m.sk_d_rot.grad[time_id], m.sk_d_scale.grad[time_id]
+            else:
+                _, g_drot, g_dscale = self._g_heads
+            dense = self.spw_logit_grad is None
+            j = _C._DeformBackwardJob()
+            j.in_ = C.pointer(d)
+            j.g_bone_T, j.g_bone_drot, j.g_bone_dscale = self.g_bone_T.data_ptr(), g_drot.data_ptr(), g_dscale.data_ptr()
+            j.g_xyz, j.g_log_scale = m._xyz.grad.data_ptr(), m._scaling.grad.data_ptr()
+            j.g_rot, j.g_opacity_logit = m._rotation.grad.data_ptr(), m._opacity.grad.data_ptr()
+            j.g_sp_W = m.sp_W.grad.data_ptr() if dense else None
+            j.g_logits = None if dense else self.spw_logit_grad.data_ptr()
+            j.workspace, j.workspace_bytes = self.deform_ws.data_ptr(), self.deform_ws.numel()
+            g.deform_backward_job = C.cast(C.pointer(j), C.c_void_p)
+            self._rows_backward_done = True
         chk(lib.skgs_rasterize_backward(C.byref(a), C.byref(self._bufs), _p(self.radii), _p(self.out_opacity),
                                         C.byref(g), st))
 
@@ -471,6 +494,10 @@ class FusedViewStep:
                 _p(self.g_weights), _p(self.g_bone_T), _p(g_drot), _p(g_dscale),
                 _p(m._xyz.grad), _p(m._scaling.grad), _p(m._rotation.grad), _p(m._opacity.grad), _p(self.deform_ws),
                 C.c_size_t(self.deform_ws.numel()), st))
+        elif self._rows_backward_done:  # (ran as a job of the rasterizer's backward, forward_backward above)
+            self._rows_backward_done = False
+            if part == 'rows':
+                return
         elif not self.wide:
             # skinning backward with the softmax backward of the LBS logits folded in: dense rows straight into sp_W.grad,
             # or the compact [P,K] gradient for the all-reduce

@@ -54,7 +54,13 @@ class GraphedSteps:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self.pool):
+        # With a process group alive its watchdog thread polls the events of earlier (eager) collectives every 100 ms:
+        # hipEventQuery from ANOTHER thread is an error while a capture in the default "global" mode is open, the watchdog
+        # rethrows it and the rank aborts (seen once in ~100 one-rank RCCL runs of bench.py).  "thread_local" restricts the
+        # check to this thread, which is the one that captures.
+        import torch.distributed as dist
+        mode = 'thread_local' if (dist.is_available() and dist.is_initialized()) else 'global'
+        with torch.cuda.graph(g, pool=self.pool, capture_error_mode=mode):
             self.fn(key)
         if self.pool is None:
             self.pool = g.pool()

@@ -36,10 +36,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert abs(b['median'] - d['ms_per_step']) / d['ms_per_step'] < 0.25
     # every launch of the step is timed and priced (algorithmic bytes next to the 8 TB/s roofline); together they are the step
     k = d['kernels']
-    assert 'deform_forward' in k['preprocess_forward']['includes']  # (the skinning is a job of the per-Gaussian launch)
+    # (the skinning and its backward are jobs of the rasterizer's per-Gaussian launches)
+    assert 'deform_forward' in k['preprocess_forward']['includes'] and 'deform_backward' in k['preprocess_backward']['includes']
     for name in ('preprocess_forward', 'scatter', 'tile_sort', 'render_forward', 'render_backward', 'preprocess_backward',
-                 'deform_backward', 'image_loss_forward', 'image_loss_backward', 'skeleton_forward',
-                 'skeleton_backward', 'adam'):
+                 'image_loss_forward', 'image_loss_backward', 'skeleton_forward', 'skeleton_backward', 'adam'):
         assert k[name]['us'] > 0 and k[name]['alg_MB'] > 0 and 0 < k[name]['GBps'] < 8000.0, (name, k[name])
         assert abs(k[name]['frac'] - k[name]['GBps'] / 8000.0) < 1e-3
     total = sum(v['us'] * v['launches_per_step'] for v in k.values())

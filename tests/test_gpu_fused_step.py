@@ -634,8 +634,9 @@ def test_fused_step_with_the_distance_based_lbs_weightings_matches_autograd(meth
 @pytest.mark.parametrize('P,M,K,W,H,capacity_rows', [(4000, 12, 4, 160, 120, False), (5003, 20, 5, 203, 117, False), (3000, 50, 8, 96, 64, False),
                                                      (2100, 60, 3, 96, 64, False), (4000, 20, 5, 160, 120, True)])
 def test_deform_as_a_job_of_the_per_gaussian_launch_is_bit_identical(P, M, K, W, H, capacity_rows):
-    """skgs_raster_inputs.deform_job: the skinning inside the rasterizer's per-Gaussian launch against the two launches --
-    every output of both halves bit for bit, then the whole step's gradients"""
+    """skgs_raster_inputs.deform_job / skgs_raster_grads.deform_backward_job: the skinning and its backward inside the
+    rasterizer's per-Gaussian launches against launches of their own -- every output of both forward halves bit for bit, then
+    the whole step's gradients (their upstream is summed by atomics: order, not bits)"""
     from sk_gs_amd import _C
     from sk_gs_amd.fused_step import FusedViewStep
     model, rs, target = _setup(P, M, K, W, H, 3)
@@ -648,11 +649,13 @@ def test_deform_as_a_job_of_the_per_gaussian_launch_is_bit_identical(P, M, K, W,
         for p in model.parameters():
             p.grad = None  # (the step builds zeroed gradient buffers: behind a row capacity they have its size)
         step = FusedViewStep(model, W, H, capacity=int(R * 1.2) + 1024, tile_bucket=0)
-        step.deform_in_preprocess = job
+        step.deform_in_preprocess = step.deform_backward_in_preprocess = job
         for buf in (step.means, step.scales, step.rotations, step.opacity, step.weights):
             buf.fill_(-7.0)
         step.indices.fill_(-7)
-        step.forward_backward(rs, 1, target)
+        step.backward_raster(rs, 1, target)
+        assert step._rows_backward_done == job
+        step.backward_skinning(1)
         torch.cuda.synchronize()
         n = int(model.P)
         got[job] = {k: getattr(step, k)[:n].clone() for k in ('means', 'scales', 'rotations', 'opacity', 'weights', 'indices', 'radii')}
