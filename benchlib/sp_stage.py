@@ -195,7 +195,21 @@ def run(args, base_alg_bytes, configs):
             b = base_alg_bytes(name, P, M, K, W, H, R_mean)
         if name == 'adam':
             b = rest_b if train.fused else rows_b + rest_b
+        # the skinning and the rows pass of its backward run as jobs of the rasterizer's per-Gaussian launches
+        # (skgs_raster_inputs.deform_job / skgs_raster_grads.sp_skinning_job): their bytes, minus the 44 B per Gaussian of
+        # means / scales / rotations / opacity (and their gradients) that are no longer re-read
+        includes = None
+        if name == 'preprocess_forward' and 'deform_forward' not in prof and step.deform_in_preprocess:
+            b += alg_bytes_sp('deform_forward', P, M, K, F, W, H, R_mean) - 44 * P
+            includes = 'deform_forward (skinning + activations)'
+        if name == 'preprocess_backward' and step.deform_backward_in_preprocess:
+            b += P * (40 + 16 * K) - 44 * P
+            includes = 'the rows pass of deform_backward (the row of that name: its bones + finalize launches)'
+        if name == 'deform_backward' and step.deform_backward_in_preprocess:
+            b = P * 16 * K + M * 24 * 4  # the bones pass gathers the pairs' payload; per-superpoint sums out
         rec = timing.kernel_record(us, n / n_prof, b)
+        if includes:
+            rec['includes'] = includes
         if name in ('sp_net_forward', 'sp_net_backward'):
             fl = net_flops(M)[0 if name == 'sp_net_forward' else 1]
             rec['TFLOPs'] = round(fl / (us * 1e-6) / 1e12, 2)

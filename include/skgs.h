@@ -58,7 +58,9 @@ typedef void* skgs_stream_t; /* hipStream_t */
  * skgs_knn_lbs_deform_forward below (sk_gs.py:757-770 K nearest joints + softmax of the gathered sp_W logits, :1143-1150 linear
  * blend skinning, :1162,1192-1203 activations).  The Gaussian's mean / scale / rotation / opacity are computed in the lane that
  * projects them: written (with weights / indices) for the backward, never re-read by the forward.  Same arithmetic, same bits as
- * the separate launch.  Needs K <= min(8, M), M <= SKGS_FUSED_LBS_MAX_BONES, scales + rotations (no cov3D_precomp). */
+ * the separate launch.  Needs K <= min(8, M), M <= SKGS_FUSED_LBS_MAX_BONES, scales + rotations (no cov3D_precomp).
+ * joints == NULL: the skinning ALONE (skgs_lbs_deform_forward's arithmetic) -- out_idx / out_weights are then INPUTS (the
+ * superpoint stage's search has written them), sp_W is not read, any M, K <= 16, no row capacity. */
 typedef struct skgs_knn_deform_job {
   int32_t M, K;
   const float* points;  /* [P,3] the positions the bones are searched from (xyz.detach(), sk_gs.py:1113) */
@@ -205,6 +207,8 @@ typedef struct skgs_raster_grads {
   float* stat_max_radii2D;        /* [P] */
   float stat_grad_multiplier;     /* 1 / (the scale the backward was seeded with); 0 is read as 1 */
   const struct skgs_deform_backward_job* deform_backward_job; /* NULL, or: see the struct (below skgs_deform_inputs) */
+  const struct skgs_sp_skinning_job* sp_skinning_job;         /* NULL, or: see the struct (beside skgs_sp_skinning_backward);
+                                                                 not together with deform_backward_job */
 } skgs_raster_grads;
 size_t skgs_backward_workspace_bytes(int32_t P);
 
@@ -600,6 +604,24 @@ int skgs_sp_lbs_weights_backward(int32_t P, int32_t M, int32_t K, int32_t F, con
  * g_sp_radius [M], g_sp_weight [M] (the last four may be NULL).  workspace: skgs_sp_skinning_backward_workspace_bytes. */
 size_t skgs_sp_pairs_bytes(int32_t P, int32_t M, int32_t K);
 size_t skgs_sp_skinning_backward_workspace_bytes(int32_t P, int32_t M, int32_t K);
+/* The call below as a job of skgs_rasterize_backward (skgs_raster_grads.sp_skinning_job): its arguments without the four upstream
+ * gradients -- the per-Gaussian launch that produces dL/d(means3D, scales, rotations, opacity) runs the ROWS pass on them in
+ * registers (they are still written to the skgs_raster_grads outputs), the bones and finalize launches follow inside
+ * skgs_rasterize_backward.  One launch less, the same arithmetic on the same values. */
+typedef struct skgs_sp_skinning_job {
+  const skgs_deform_inputs* in;
+  int32_t F;
+  const float *feature, *sp_feature, *sp_radius_raw, *sp_weight_raw;
+  float temperature;
+  int32_t logit_weighting;
+  const float* nn_dist;
+  float *g_weights, *g_xyz, *g_log_scale, *g_rot, *g_opacity_logit, *g_feature, *g_bone_T, *g_bone_drot, *g_bone_dscale, *g_sp_feature,
+      *g_sp_radius, *g_sp_weight;
+  void* pairs;
+  size_t pairs_bytes;
+  void* workspace;
+  size_t workspace_bytes;
+} skgs_sp_skinning_job;
 int skgs_sp_skinning_backward(const skgs_deform_inputs* in, int32_t F, const float* feature, const float* sp_feature,
     const float* sp_radius_raw, const float* sp_weight_raw, float temperature, int32_t logit_weighting, const float* nn_dist,
     const float* g_means, const float* g_scales, const float* g_rotations, const float* g_opacity, float* g_weights, float* g_xyz,

@@ -72,7 +72,7 @@ class _RasterGrads(C.Structure):
         ('dL_dsh_rest', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t),
         ('workspace_is_zero', C.c_int32), ('dL_dsh_factors', C.c_void_p),
         ('stat_xyz_gradient_accum', C.c_void_p), ('stat_denom', C.c_void_p), ('stat_max_radii2D', C.c_void_p),
-        ('stat_grad_multiplier', C.c_float), ('deform_backward_job', C.c_void_p),
+        ('stat_grad_multiplier', C.c_float), ('deform_backward_job', C.c_void_p), ('sp_skinning_job', C.c_void_p),
     ]
 
 
@@ -90,6 +90,16 @@ class _DeformBackwardJob(C.Structure):
     _fields_ = [('in_', C.POINTER(_DeformInputs))] + [(n, C.c_void_p) for n in (
         'g_bone_T', 'g_bone_drot', 'g_bone_dscale', 'g_xyz', 'g_log_scale', 'g_rot', 'g_opacity_logit', 'g_sp_W', 'g_logits',
         'workspace')] + [('workspace_bytes', C.c_size_t)]
+
+
+class _SpSkinningJob(C.Structure):
+    """include/skgs.h: skgs_sp_skinning_job"""
+    _fields_ = ([('in_', C.POINTER(_DeformInputs)), ('F', C.c_int32)] +
+                [(n, C.c_void_p) for n in ('feature', 'sp_feature', 'sp_radius_raw', 'sp_weight_raw')] +
+                [('temperature', C.c_float), ('logit_weighting', C.c_int32), ('nn_dist', C.c_void_p)] +
+                [(n, C.c_void_p) for n in ('g_weights', 'g_xyz', 'g_log_scale', 'g_rot', 'g_opacity_logit', 'g_feature', 'g_bone_T',
+                                           'g_bone_drot', 'g_bone_dscale', 'g_sp_feature', 'g_sp_radius', 'g_sp_weight', 'pairs')] +
+                [('pairs_bytes', C.c_size_t), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)])
 
 
 EXPORTED_SYMBOLS = [

@@ -204,6 +204,8 @@ int skgs_rasterize_backward(const skgs_raster_inputs* in, const skgs_raster_buff
           fill_u32(dj0->g_bone_dscale, 0u, (size_t) dj0->in->M * 3, s0))
         return 1;
     }
+    if (const skgs_sp_skinning_job* sj0 = gr->sp_skinning_job)  // (empty lists: the superpoint gradients come out zero)
+      return sp_skinning_check(*sj0) || launch_sp_skinning_rest(*sj0, (hipStream_t) stream);
     return 0;
   }
   SKGS_REQUIRE(radii && out_opacity, "radii / out_opacity are required");
@@ -236,11 +238,19 @@ int skgs_rasterize_backward(const skgs_raster_inputs* in, const skgs_raster_buff
         "deform_backward_job: workspace too small (skgs_lbs_deform_backward_workspace_bytes)");
     SKGS_REQUIRE(in->scales && in->rotations, "deform_backward_job: not with cov3D_precomp");
   }
+  const skgs_sp_skinning_job* sj = gr->sp_skinning_job;
+  if (sj) {  // the superpoint stage's rows pass rides on the per-Gaussian launch (checks of skgs_sp_skinning_backward)
+    SKGS_REQUIRE(!dj, "sp_skinning_job: not together with deform_backward_job");
+    if (sp_skinning_check(*sj)) return 1;
+    SKGS_REQUIRE(sj->in->P == in->P && in->live_count == nullptr, "sp_skinning_job: P differs from the rasterizer's / no row capacity");
+    SKGS_REQUIRE(in->scales && in->rotations, "sp_skinning_job: not with cov3D_precomp");
+  }
   if (!gr->workspace_is_zero && fill_u32(gr->workspace, 0u, (size_t) in->P * GRAD_ROW, s)) return 1;
   if (launch_render_backward(*in, g, im, b, out_opacity, gr->dL_dout_color, gr->dL_dout_opacity, gr->dL_dout_extra,
           gr->workspace, s))
     return 1;
   if (launch_preprocess_backward(*in, g, radii, *gr, s)) return 1;
+  if (sj) return launch_sp_skinning_rest(*sj, s);
   return dj ? launch_deform_backward_finalize(*dj->in, dj->workspace, dj->g_bone_T, dj->g_bone_drot, dj->g_bone_dscale, s) : 0;
 }
 

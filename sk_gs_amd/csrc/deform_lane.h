@@ -328,5 +328,157 @@ __device__ __forceinline__ void deform_bwd_moments(const DeformBwdArgs& a, int P
   }
 }
 
+// ------------------------------------------------------------------------------ superpoint stage: the rows pass of the backward
+// (sp_backward.hip: one lane per Gaussian -- its four parameter gradients, g_weights, the weighting's chain rule,
+// hyper_feature.grad and the compact payload U / V of the bones pass).  Shared by sp_backward_rows_kernel and by the rasterizer's
+// per-Gaussian backward launch (preprocess.hip), which runs it on the gradients it has just produced.
+constexpr int SP_MAXK = 16;
+constexpr int SP_MAXF = 8;
+constexpr int SP_UROW = 12;  // per-Gaussian payload row: g_dx 3 | g_v 4 | g_ds 3 | pad 2
+struct SpRowsArgs {
+  int K, M;
+  const float *points, *weights;
+  const int64_t* indices;
+  const float *nn_dist, *bone_T, *bone_drot, *bone_dscale, *log_scale, *rot, *opacity_logit, *feature, *sp_feature, *radius_raw,
+      *kweight_raw;
+  float temperature;
+  int logits;
+  float *g_weights, *g_xyz, *g_log_scale, *g_rot, *g_opacity_logit, *g_feature, *U, *V;
+};
+// the arguments from the public job (U and V are the first two pieces of its workspace: sp_backward.hip carves the same way)
+inline SpRowsArgs sp_rows_args(const skgs_sp_skinning_job& j) {
+  const skgs_deform_inputs* in = j.in;
+  const size_t P = (size_t) (in->P > 1 ? in->P : 1);
+  char* wsp      = reinterpret_cast<char*>(j.workspace);
+  float* U       = reinterpret_cast<float*>(wsp);
+  float* V       = reinterpret_cast<float*>(wsp + align256(P * SP_UROW * 4));
+  return SpRowsArgs{in->K, in->M, in->points, in->weights, in->indices, j.nn_dist, in->bone_T, in->bone_drot, in->bone_dscale,
+      in->log_scale, in->rot, in->opacity_logit, j.feature, j.sp_feature, j.sp_radius_raw, j.sp_weight_raw, j.temperature,
+      (int) j.logit_weighting, j.g_weights, j.g_xyz, j.g_log_scale, j.g_rot, j.g_opacity_logit, j.g_feature, U, V};
+}
+inline size_t sp_rows_lds_bytes(int M) { return (size_t) M * BONE_F * 4; }
+// s_bones: [M][BONE_F] staged by the caller (load_bone), n: the lane's Gaussian (< P)
+template <int F>
+__device__ __forceinline__ void sp_rows_lane(const SpRowsArgs& ja, const float* s_bones, int n, const float (&g_dx_in)[3],
+    const float (&g_ds_in)[3], float4 gr4_in, float go_in) {
+  const float p[3] = {ja.points[3 * n], ja.points[3 * n + 1], ja.points[3 * n + 2]};
+  int jj[SP_MAXK];
+  float ww[SP_MAXK];
+#pragma unroll
+  for (int k = 0; k < SP_MAXK; ++k) {
+    jj[k] = k < ja.K ? (int) ja.indices[(size_t) n * ja.K + k] : 0;
+    ww[k] = k < ja.K ? ja.weights[(size_t) n * ja.K + k] : 0.f;
+  }
+  // ---- the Gaussian's own gradients (deform.hip::deform_backward_kernel, same expressions)
+  float sr[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < SP_MAXK; ++k)
+    if (k < ja.K) {
+      const float* b = s_bones + jj[k] * BONE_F;
+      sr[0] += b[7] * ww[k], sr[1] += b[8] * ww[k], sr[2] += b[9] * ww[k], sr[3] += b[10] * ww[k];
+    }
+  const float4 r4  = reinterpret_cast<const float4*>(ja.rot)[n];
+  const float4 gr4 = gr4_in;
+  const float v[4]  = {r4.x + sr[0], r4.y + sr[1], r4.z + sr[2], r4.w + sr[3]};
+  const float gr[4] = {gr4.x, gr4.y, gr4.z, gr4.w};
+  const float nv    = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+  float g_v[4];
+  if (nv > 1e-12f) {
+    const float u[4] = {v[0] / nv, v[1] / nv, v[2] / nv, v[3] / nv};
+    const float dot  = u[0] * gr[0] + u[1] * gr[1] + u[2] * gr[2] + u[3] * gr[3];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) g_v[c] = (gr[c] - u[c] * dot) / nv;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) g_v[c] = gr[c] / 1e-12f;
+  }
+  const float g_dx[3] = {g_dx_in[0], g_dx_in[1], g_dx_in[2]};
+  const float g_ds[3] = {g_ds_in[0], g_ds_in[1], g_ds_in[2]};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    ja.g_xyz[3 * n + c]       = g_dx[c];
+    ja.g_log_scale[3 * n + c] = g_ds[c] * expf(ja.log_scale[3 * n + c]);
+  }
+  reinterpret_cast<float4*>(ja.g_rot)[n] = make_float4(g_v[0], g_v[1], g_v[2], g_v[3]);
+  const float sg     = 1.0f / (1.0f + expf(-ja.opacity_logit[n]));
+  ja.g_opacity_logit[n] = go_in * sg * (1.0f - sg);
+  float* un = ja.U + (size_t) n * SP_UROW;
+  reinterpret_cast<float4*>(un)[0] = make_float4(g_dx[0], g_dx[1], g_dx[2], g_v[0]);
+  reinterpret_cast<float4*>(un)[1] = make_float4(g_v[1], g_v[2], g_v[3], g_ds[0]);
+  reinterpret_cast<float4*>(un)[2] = make_float4(g_ds[1], g_ds[2], 0.f, 0.f);
+  // ---- g_weights[k] = g_dx . (T_j p) + g_v . d_rot_j + g_ds . d_scale_j
+  float gw[SP_MAXK];
+#pragma unroll
+  for (int k = 0; k < SP_MAXK; ++k) {
+    gw[k] = 0.f;
+    if (k < ja.K) {
+      const float* b = s_bones + jj[k] * BONE_F;
+      float y[3];
+      se3_act(b, p, y);
+      float a = g_dx[0] * y[0] + g_dx[1] * y[1] + g_dx[2] * y[2];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a += g_v[c] * b[7 + c];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a += g_ds[c] * b[11 + c];
+      gw[k] = a;
+      if (ja.g_weights) ja.g_weights[(size_t) n * ja.K + k] = a;
+    }
+  }
+  // ---- the weighting's backward (sp_knn.hip::sp_weights_backward_kernel, same expressions); `ja.logits`: the W weighting --
+  // the ja.weights do not depend on the distances, its dense logit gradient is skgs_lbs_weights_backward
+  float gf[SP_MAXF];
+#pragma unroll
+  for (int c = 0; c < SP_MAXF; ++c) gf[c] = 0.f;
+  if (!ja.logits) {
+    float dd[SP_MAXK];
+#pragma unroll
+    for (int k = 0; k < SP_MAXK; ++k) dd[k] = k < ja.K ? ja.nn_dist[(size_t) n * ja.K + k] : 0.f;
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < SP_MAXK; ++k)
+      if (k < ja.K) dot += ww[k] * gw[k];
+    float sum = 0.f;
+    if (ja.radius_raw)
+#pragma unroll
+      for (int k = 0; k < SP_MAXK; ++k)
+        if (k < ja.K) {
+          const float r = expf(ja.radius_raw[jj[k]]);
+          float e = expf(-dd[k] / (2.f * (r * r)));
+          if (ja.kweight_raw) e = e * (1.0f / (1.0f + expf(-ja.kweight_raw[jj[k]])));
+          sum += e + 1e-7f;
+        }
+    float fc[SP_MAXF];
+#pragma unroll
+    for (int c = 0; c < SP_MAXF; ++c) fc[c] = (F > 0 && c < F) ? ja.feature[(size_t) n * F + c] : 0.f;
+#pragma unroll
+    for (int k = 0; k < SP_MAXK; ++k)
+      if (k < ja.K) {
+        const int j = jj[k];
+        float g_d, rterm = 0.f, kterm = 0.f;
+        if (ja.radius_raw) {
+          const float r   = expf(ja.radius_raw[j]);
+          const float e   = expf(-dd[k] / (2.f * (r * r)));
+          const float sk  = ja.kweight_raw ? 1.0f / (1.0f + expf(-ja.kweight_raw[j])) : 1.f;
+          const float g_u = (gw[k] - dot) / sum;
+          const float g_e = g_u * sk;
+          g_d   = g_e * e * (-1.f / (2.f * (r * r)));
+          rterm = g_e * e * (dd[k] / (r * r * r));
+          if (ja.kweight_raw) kterm = g_u * e;
+        } else {
+          g_d = -(ww[k] * (gw[k] - dot)) / ja.temperature;
+        }
+#pragma unroll
+        for (int c = 0; c < SP_MAXF; ++c)
+          if (F > 0 && c < F) gf[c] += g_d * 2.f * (fc[c] - ja.sp_feature[(size_t) j * F + c]);
+        float* vp = ja.V + ((size_t) n * ja.K + k) * 4;
+        *reinterpret_cast<float4*>(vp) = make_float4(g_d, rterm, kterm, 0.f);
+      }
+  }
+  if (ja.g_feature)
+#pragma unroll
+    for (int c = 0; c < SP_MAXF; ++c)
+      if (F > 0 && c < F) ja.g_feature[(size_t) n * F + c] = gf[c];
+}
+
 }  // namespace
 }  // namespace skgs

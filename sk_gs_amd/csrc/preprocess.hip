@@ -300,6 +300,8 @@ __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, const fl
 // computes its Gaussian's mean / scale / rotation / opacity -- K nearest bones, softmax weights, skinning, activations,
 // knn_deform_forward_kernel's arithmetic through the same deform_lane.h functions -- writes them (and the weights / indices) for
 // the backward, and projects them from registers: one launch and one round trip through HBM less per step.
+// DK == -1: the skinning alone -- weights / indices are INPUTS (joints == NULL in the public job: the superpoint stage's search has
+// produced them), any number of bones, their rows gathered from global memory (deform_forward_kernel<false>'s arithmetic).
 struct KnnDeformJob {
   int M, K, lds_offset /* floats: where the deform's tables start in the dynamic LDS (behind the SH rows) */;
   const float *points, *joints, *sp_W, *bone_T, *bone_drot, *bone_dscale, *xyz, *log_scale, *rot, *opacity_logit;
@@ -339,7 +341,16 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
   // (DK > 0) the deform's per-Gaussian inputs instead: the point the bones are searched from, and the four raw parameters
   float dj_p[3] = {0.f, 0.f, 0.f}, dj_x[3] = {0.f, 0.f, 0.f}, dj_ls[3] = {0.f, 0.f, 0.f}, dj_ol = 0.f;
   float4 dj_r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (DK > 0) {
+  int sk_j[PREF_K];  // (DK == -1) the first PREF_K (index, weight) pairs of the lane
+  float sk_w[PREF_K];
+  if constexpr (DK != 0) {
+    if constexpr (DK == -1) {
+#pragma unroll
+      for (int q = 0; q < PREF_K; ++q) {
+        sk_j[q] = q < dj.K ? (int) dj.out_idx[(size_t) ld * dj.K + q] : 0;
+        sk_w[q] = q < dj.K ? dj.out_weights[(size_t) ld * dj.K + q] : 0.f;
+      }
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) dj_p[c] = dj.points[3 * ld + c], dj_x[c] = dj.xyz[3 * ld + c], dj_ls[c] = dj.log_scale[3 * ld + c];
     dj_r4 = reinterpret_cast<const float4*>(dj.rot)[ld], dj_ol = dj.opacity_logit[ld];
@@ -412,6 +423,29 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
 #pragma unroll
       for (int k = 0; k < DK; ++k)
         if (k < dj.K) dj.out_weights[(size_t) idx * dj.K + k] = w[k], dj.out_idx[(size_t) idx * dj.K + k] = bi[k];
+      deform_activate_lane(dj_p, sx, sr, ss, dj_x, dj_ls, dj_r4, dj_ol, pf_p, pf_s, pf_q, pf_op);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dj.means[3 * idx + c] = pf_p[c], dj.scales[3 * idx + c] = pf_s[c];
+      reinterpret_cast<float4*>(dj.rotations)[idx] = pf_q;
+      dj.opacity[idx]                              = pf_op;
+    }
+  }
+  if constexpr (DK == -1) {
+    if (idx < P) {  // deform_forward_kernel<false>: the bones' rows from global memory, in the neighbours' order
+      float sx[3] = {0, 0, 0}, sr[4] = {0, 0, 0, 0}, ss[3] = {0, 0, 0};
+      auto skin = [&](int j, float w) {
+        float b[BONE_F];
+        load_bone(dj.bone_T, dj.bone_drot, dj.bone_dscale, j, b);
+        float y[3];
+        se3_act(b, dj_p, y);
+        sx[0] += y[0] * w, sx[1] += y[1] * w, sx[2] += y[2] * w;
+        sr[0] += b[7] * w, sr[1] += b[8] * w, sr[2] += b[9] * w, sr[3] += b[10] * w;
+        ss[0] += b[11] * w, ss[1] += b[12] * w, ss[2] += b[13] * w;
+      };
+#pragma unroll
+      for (int q = 0; q < PREF_K; ++q)
+        if (q < dj.K) skin(sk_j[q], sk_w[q]);
+      for (int k = PREF_K; k < dj.K; ++k) skin((int) dj.out_idx[(size_t) idx * dj.K + k], dj.out_weights[(size_t) idx * dj.K + k]);
       deform_activate_lane(dj_p, sx, sr, ss, dj_x, dj_ls, dj_r4, dj_ol, pf_p, pf_s, pf_q, pf_op);
 #pragma unroll
       for (int c = 0; c < 3; ++c) dj.means[3 * idx + c] = pf_p[c], dj.scales[3 * idx + c] = pf_s[c];
@@ -613,7 +647,9 @@ __device__ __forceinline__ void sh_backward(int deg, int M, const float* mean, c
 // (deform_lane.h: the body of deform_backward_moments_kernel) -- the Gaussian's parameter gradients, its logit gradients and
 // the workgroup's partial bone moments, in the LDS the SH rows have just left.
 static_assert(PRE_BWD_THREADS == DEFORM_BWD_THREADS, "the deform backward job runs in this launch's workgroups");
-template <bool COLMAP, bool DBJ>
+// JOB 0: none; 1 (DBJ): that; 2 / 3: the superpoint stage's ROWS pass (skgs_raster_grads.sp_skinning_job, sp_rows_lane<8 / 0>
+// of deform_lane.h = the body of sp_backward_rows_kernel) with its bone table in the same LDS.
+template <bool COLMAP, int JOB>
 __global__ void __launch_bounds__(PRE_BWD_THREADS) preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means3D,
     const int32_t* __restrict__ radii, const float* __restrict__ shs, const float* __restrict__ shs_rest,
     const float* __restrict__ scales,
@@ -628,7 +664,8 @@ __global__ void __launch_bounds__(PRE_BWD_THREADS) preprocess_backward_kernel(in
     float* __restrict__ dL_dscales, float* __restrict__ dL_drot, float* __restrict__ dL_dextras,
     float* __restrict__ sh_factors /* [P,6] or NULL: see sh_backward */, const float* __restrict__ tanfov_dev,
     const int32_t* __restrict__ live, float* __restrict__ stat_accum, float* __restrict__ stat_denom,
-    float* __restrict__ stat_max_radii, float stat_mult, DeformBwdArgs dbj) {
+    float* __restrict__ stat_max_radii, float stat_mult, DeformBwdArgs dbj, SpRowsArgs srj) {
+  constexpr bool DBJ = JOB == 1;
   if (live) P = min(P, live[0]);  // the number of Gaussians is a device word: one captured graph survives densification
   if ((int) (blockIdx.x * blockDim.x) >= P) {  // a workgroup of the capacity's slack rows (before any barrier)
     if constexpr (DBJ) deform_bwd_zero_partials(dbj);
@@ -943,7 +980,7 @@ __global__ void __launch_bounds__(PRE_BWD_THREADS) preprocess_backward_kernel(in
   for (int i = 0; i < 6; ++i) dL_dcov3D[6 * idx + i] = gcov[i];
   dL_dscales[3 * idx] = gscale[0], dL_dscales[3 * idx + 1] = gscale[1], dL_dscales[3 * idx + 2] = gscale[2];
   reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(grot[0], grot[1], grot[2], grot[3]);
-  if constexpr (DBJ) {
+  if constexpr (JOB != 0) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) dj_gm[c] = gmean[c], dj_gs[c] = gscale[c];
     dj_gr = make_float4(grot[0], grot[1], grot[2], grot[3]), dj_go = gop;
@@ -956,6 +993,12 @@ __global__ void __launch_bounds__(PRE_BWD_THREADS) preprocess_backward_kernel(in
   if constexpr (DBJ) {
     __syncthreads();  // the SH rows have left the LDS: it is the deform backward's now
     deform_bwd_moments(dbj, P, s_sh, dbl, dj_gm, dj_gs, dj_gr, dj_go);
+  }
+  if constexpr (JOB >= 2) {
+    __syncthreads();
+    for (int j = threadIdx.x; j < srj.M; j += PRE_BWD_THREADS) load_bone(srj.bone_T, srj.bone_drot, srj.bone_dscale, j, s_sh + j * BONE_F);
+    __syncthreads();
+    if (idx < P) sp_rows_lane<(JOB == 2 ? 8 : 0)>(srj, s_sh, idx, dj_gm, dj_gs, dj_gr, dj_go);
   }
 }
 
@@ -1059,15 +1102,18 @@ int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView 
   int dk = 0;
   if (const skgs_knn_deform_job* j = in.deform_job) {
     // the deform in front of the pass: its outputs ARE this pass's per-Gaussian inputs
-    if (!(j->points && j->joints && j->sp_W && j->bone_T && j->bone_drot && j->bone_dscale && j->xyz && j->log_scale && j->rot &&
+    const bool search = j->joints != nullptr;  // (joints == NULL: weights / indices are inputs, the skinning alone)
+    if (!(j->points && (!search || j->sp_W) && j->bone_T && j->bone_drot && j->bone_dscale && j->xyz && j->log_scale && j->rot &&
             j->opacity_logit && j->out_idx && j->out_weights && j->means && j->scales && j->rotations && j->opacity))
       return set_error("deform_job: NULL pointer");
     if (j->means != in.means3D || j->scales != in.scales || j->rotations != in.rotations || j->opacity != in.opacity)
       return set_error("deform_job: means / scales / rotations / opacity must be the rasterizer's means3D / scales / rotations / opacity");
     if (in.cov3D_precomp) return set_error("deform_job: not with cov3D_precomp");
-    if (j->K < 1 || j->K > 8 || j->K > j->M || j->M > SKGS_FUSED_LBS_MAX_BONES)
+    if (search && (j->K < 1 || j->K > 8 || j->K > j->M || j->M > SKGS_FUSED_LBS_MAX_BONES))
       return set_error("deform_job: needs 1 <= K <= min(8, M), M <= %d (got K = %d, M = %d)", SKGS_FUSED_LBS_MAX_BONES, j->K, j->M);
-    dk = j->K <= 5 ? 5 : 8;
+    if (!search && (j->K < 1 || j->K > 16 || j->M < 1 || in.live_count))
+      return set_error("deform_job (skinning alone): needs 1 <= K <= 16, M >= 1, no row capacity (got K = %d, M = %d)", j->K, j->M);
+    dk = !search ? -1 : j->K <= 5 ? 5 : 8;
     dj.M = j->M, dj.K = j->K;
     dj.lds_offset = (int) ((lds / 4 + 3) & ~(size_t) 3);
     dj.points = j->points, dj.joints = j->joints, dj.sp_W = j->sp_W, dj.bone_T = j->bone_T, dj.bone_drot = j->bone_drot;
@@ -1077,7 +1123,7 @@ int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView 
     // (26 KB per workgroup with degree-3 SH rows: six workgroups per CU, as without the job.  The first version kept 44 KB --
     // three per CU = 768 resident workgroups for a grid of 782 at 100k Gaussians: the last 14 ran alone behind the rest,
     // 32 us instead of 22)
-    lds = ((size_t) dj.lds_offset + (size_t) ((j->M * 3 + 3) & ~3) + ((j->M * BONE_F + 3) & ~3)) * 4;
+    if (search) lds = ((size_t) dj.lds_offset + (size_t) ((j->M * 3 + 3) & ~3) + ((j->M * BONE_F + 3) & ~3)) * 4;
   }
 #define SKGS_PRE_FWD(COLMAP_, DK_)                                                                                          \
   hipLaunchKernelGGL((preprocess_forward_kernel<COLMAP_, DK_>), grid, block, lds, s, P, in.sh_degree, in.sh_coeffs, in.means3D, \
@@ -1088,6 +1134,8 @@ int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView 
   if (in.colmap) {
     if (dk == 0)
       SKGS_PRE_FWD(true, 0);
+    else if (dk == -1)
+      SKGS_PRE_FWD(true, -1);
     else if (dk == 5)
       SKGS_PRE_FWD(true, 5);
     else
@@ -1095,6 +1143,8 @@ int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView 
   } else {
     if (dk == 0)
       SKGS_PRE_FWD(false, 0);
+    else if (dk == -1)
+      SKGS_PRE_FWD(false, -1);
     else if (dk == 5)
       SKGS_PRE_FWD(false, 5);
     else
@@ -1123,6 +1173,11 @@ int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const i
         j->g_sp_W, j->g_logits};
     lds = std::max(lds, deform_bwd_lds_bytes(d.M));
   }
+  SpRowsArgs srj{};
+  if (const skgs_sp_skinning_job* j = gr.sp_skinning_job) {  // (checked by skgs_rasterize_backward)
+    srj = sp_rows_args(*j);
+    lds = std::max(lds, sp_rows_lds_bytes(j->in->M));
+  }
 #define SKGS_PB_ARGS                                                                                                     \
   P, in.sh_degree, in.sh_coeffs, in.means3D, radii, in.sh, in.sh_rest, in.scales, in.rotations, in.scale_modifier,        \
       in.cov3D_precomp, in.viewmatrix, in.projmatrix, in.campos, in.image_width, in.image_height, in.tanfovx, in.tanfovy, \
@@ -1130,17 +1185,20 @@ int launch_preprocess_backward(const skgs_raster_inputs& in, GeomView g, const i
       gr.grad_means2D_in, gr.grad_conic_in, gr.grad_opacity_in, E, gr.dL_dmeans2D, gr.dL_dconic, gr.dL_dcolors,           \
       gr.dL_dopacity, gr.dL_dmeans3D, gr.dL_dcov3D, gr.dL_dsh, gr.dL_dsh_rest, gr.dL_dscales, gr.dL_drotations,           \
       gr.dL_dextras, gr.dL_dsh_factors, in.tanfov_device, in.live_count, gr.stat_xyz_gradient_accum, gr.stat_denom,        \
-      gr.stat_max_radii2D, (gr.stat_grad_multiplier != 0.f ? gr.stat_grad_multiplier : 1.0f), dbj
-  if (gr.deform_backward_job) {
-    if (in.colmap)
-      hipLaunchKernelGGL((preprocess_backward_kernel<true, true>), grid, block, lds, s, SKGS_PB_ARGS);
-    else
-      hipLaunchKernelGGL((preprocess_backward_kernel<false, true>), grid, block, lds, s, SKGS_PB_ARGS);
-  } else if (in.colmap) {
-    hipLaunchKernelGGL((preprocess_backward_kernel<true, false>), grid, block, lds, s, SKGS_PB_ARGS);
-  } else {
-    hipLaunchKernelGGL((preprocess_backward_kernel<false, false>), grid, block, lds, s, SKGS_PB_ARGS);
+      gr.stat_max_radii2D, (gr.stat_grad_multiplier != 0.f ? gr.stat_grad_multiplier : 1.0f), dbj, srj
+  const int job = gr.deform_backward_job ? 1 : gr.sp_skinning_job ? (gr.sp_skinning_job->F == 8 ? 2 : 3) : 0;
+#define SKGS_PB(JOB_)                                                                                  \
+  if (in.colmap)                                                                                       \
+    hipLaunchKernelGGL((preprocess_backward_kernel<true, JOB_>), grid, block, lds, s, SKGS_PB_ARGS);   \
+  else                                                                                                 \
+    hipLaunchKernelGGL((preprocess_backward_kernel<false, JOB_>), grid, block, lds, s, SKGS_PB_ARGS)
+  switch (job) {
+    case 1: SKGS_PB(1); break;
+    case 2: SKGS_PB(2); break;
+    case 3: SKGS_PB(3); break;
+    default: SKGS_PB(0); break;
   }
+#undef SKGS_PB
 #undef SKGS_PB_ARGS
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;

@@ -412,6 +412,8 @@ int launch_knn_dist_weights_backward(int P, int M, int K, int dim, const float* 
     void* workspace, size_t workspace_bytes, hipStream_t s);
 int launch_knn_lbs_weights(int P, int M, int K, const float* points, const float* joints, const float* sp_W, int64_t* out_idx,
     float* out_weights, hipStream_t s);
+int sp_skinning_check(const skgs_sp_skinning_job& j);                       // sp_backward.hip
+int launch_sp_skinning_rest(const skgs_sp_skinning_job& j, hipStream_t s);  // bones + finalize
 int launch_deform_backward_finalize(const skgs_deform_inputs& in, void* workspace, float* g_bone_T, float* g_bone_drot,
     float* g_bone_dscale, hipStream_t s);
 int deform_backward_job_max_bones();

@@ -22,6 +22,7 @@
 #include <cstdint>
 
 #include "skgs_common.h"
+#include "deform_lane.h"
 
 #pragma clang fp contract(off)
 
@@ -29,164 +30,24 @@ namespace skgs {
 namespace {
 
 constexpr int SB_THREADS = 256;
-constexpr int BONE_F     = 14;   // unit q (4) | t (3) | d_rot (4) | d_scale (3): the LDS bone row of deform.hip
-constexpr int MAXK       = 16;
-constexpr int MAXF       = 8;
-constexpr int UROW       = 12;   // per-Gaussian payload row: g_dx 3 | g_v 4 | g_ds 3 | pad 2
+constexpr int MAXK       = SP_MAXK;
+constexpr int MAXF       = SP_MAXF;
+constexpr int UROW       = SP_UROW;  // per-Gaussian payload row (deform_lane.h)
 constexpr int NV         = 24;   // per-superpoint sums: spT 7 | d_rot 4 | d_scale 3 | sp_hyper 8 | radius | kernel weight
 constexpr int SLICES     = 4;    // workgroups per superpoint list
 
-__device__ __forceinline__ void load_bone(const float* T7, const float* drot, const float* dscale, int j, float* b) {
-  const float q0 = T7[7 * j + 3], q1 = T7[7 * j + 4], q2 = T7[7 * j + 5], q3 = T7[7 * j + 6];
-  const float n  = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
-  b[0] = q0 / n, b[1] = q1 / n, b[2] = q2 / n, b[3] = q3 / n;
-  b[4] = T7[7 * j], b[5] = T7[7 * j + 1], b[6] = T7[7 * j + 2];
-  b[7] = drot[4 * j], b[8] = drot[4 * j + 1], b[9] = drot[4 * j + 2], b[10] = drot[4 * j + 3];
-  b[11] = dscale[3 * j], b[12] = dscale[3 * j + 1], b[13] = dscale[3 * j + 2];
-}
-// y = p + w*uv + q x uv + t, uv = 2 q x p   (lie.h:59-64,246)
-__device__ __forceinline__ void se3_act(const float* b, const float* p, float* y) {
-  float uv[3] = {b[1] * p[2] - b[2] * p[1], b[2] * p[0] - b[0] * p[2], b[0] * p[1] - b[1] * p[0]};
-  uv[0] += uv[0], uv[1] += uv[1], uv[2] += uv[2];
-  const float c[3] = {b[1] * uv[2] - b[2] * uv[1], b[2] * uv[0] - b[0] * uv[2], b[0] * uv[1] - b[1] * uv[0]};
-  y[0] = p[0] + b[3] * uv[0] + c[0] + b[4];
-  y[1] = p[1] + b[3] * uv[1] + c[1] + b[5];
-  y[2] = p[2] + b[3] * uv[2] + c[2] + b[6];
-}
-
 // ------------------------------------------------------------------------------------------------------------ rows
 template <int F>
-__global__ void __launch_bounds__(SB_THREADS) sp_backward_rows_kernel(int P, int K, int M, const float* __restrict__ points,
-    const float* __restrict__ weights, const int64_t* __restrict__ indices, const float* __restrict__ nn_dist,
-    const float* __restrict__ bone_T, const float* __restrict__ bone_drot, const float* __restrict__ bone_dscale,
-    const float* __restrict__ log_scale, const float* __restrict__ rot, const float* __restrict__ opacity_logit,
-    const float* __restrict__ feature, const float* __restrict__ sp_feature, const float* __restrict__ radius_raw,
-    const float* __restrict__ kweight_raw, float temperature, int logits, const float* __restrict__ g_means,
-    const float* __restrict__ g_scales, const float* __restrict__ g_rotations, const float* __restrict__ g_opacity,
-    float* __restrict__ g_weights, float* __restrict__ g_xyz, float* __restrict__ g_log_scale, float* __restrict__ g_rot,
-    float* __restrict__ g_opacity_logit, float* __restrict__ g_feature, float* __restrict__ U, float* __restrict__ V) {
+__global__ void __launch_bounds__(SB_THREADS) sp_backward_rows_kernel(int P, SpRowsArgs ja, const float* __restrict__ g_means,
+    const float* __restrict__ g_scales, const float* __restrict__ g_rotations, const float* __restrict__ g_opacity) {
   extern __shared__ float s_bones[];  // [M][14]
-  for (int j = threadIdx.x; j < M; j += SB_THREADS) load_bone(bone_T, bone_drot, bone_dscale, j, s_bones + j * BONE_F);
+  for (int j = threadIdx.x; j < ja.M; j += SB_THREADS) load_bone(ja.bone_T, ja.bone_drot, ja.bone_dscale, j, s_bones + j * BONE_F);
   __syncthreads();
   const int n = blockIdx.x * SB_THREADS + threadIdx.x;
   if (n >= P) return;
-  const float p[3] = {points[3 * n], points[3 * n + 1], points[3 * n + 2]};
-  int jj[MAXK];
-  float ww[MAXK];
-#pragma unroll
-  for (int k = 0; k < MAXK; ++k) {
-    jj[k] = k < K ? (int) indices[(size_t) n * K + k] : 0;
-    ww[k] = k < K ? weights[(size_t) n * K + k] : 0.f;
-  }
-  // ---- the Gaussian's own gradients (deform.hip::deform_backward_kernel, same expressions)
-  float sr[4] = {0, 0, 0, 0};
-#pragma unroll
-  for (int k = 0; k < MAXK; ++k)
-    if (k < K) {
-      const float* b = s_bones + jj[k] * BONE_F;
-      sr[0] += b[7] * ww[k], sr[1] += b[8] * ww[k], sr[2] += b[9] * ww[k], sr[3] += b[10] * ww[k];
-    }
-  const float4 r4  = reinterpret_cast<const float4*>(rot)[n];
-  const float4 gr4 = reinterpret_cast<const float4*>(g_rotations)[n];
-  const float v[4]  = {r4.x + sr[0], r4.y + sr[1], r4.z + sr[2], r4.w + sr[3]};
-  const float gr[4] = {gr4.x, gr4.y, gr4.z, gr4.w};
-  const float nv    = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
-  float g_v[4];
-  if (nv > 1e-12f) {
-    const float u[4] = {v[0] / nv, v[1] / nv, v[2] / nv, v[3] / nv};
-    const float dot  = u[0] * gr[0] + u[1] * gr[1] + u[2] * gr[2] + u[3] * gr[3];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) g_v[c] = (gr[c] - u[c] * dot) / nv;
-  } else {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) g_v[c] = gr[c] / 1e-12f;
-  }
   const float g_dx[3] = {g_means[3 * n], g_means[3 * n + 1], g_means[3 * n + 2]};
   const float g_ds[3] = {g_scales[3 * n], g_scales[3 * n + 1], g_scales[3 * n + 2]};
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    g_xyz[3 * n + c]       = g_dx[c];
-    g_log_scale[3 * n + c] = g_ds[c] * expf(log_scale[3 * n + c]);
-  }
-  reinterpret_cast<float4*>(g_rot)[n] = make_float4(g_v[0], g_v[1], g_v[2], g_v[3]);
-  const float sg     = 1.0f / (1.0f + expf(-opacity_logit[n]));
-  g_opacity_logit[n] = g_opacity[n] * sg * (1.0f - sg);
-  float* un = U + (size_t) n * UROW;
-  reinterpret_cast<float4*>(un)[0] = make_float4(g_dx[0], g_dx[1], g_dx[2], g_v[0]);
-  reinterpret_cast<float4*>(un)[1] = make_float4(g_v[1], g_v[2], g_v[3], g_ds[0]);
-  reinterpret_cast<float4*>(un)[2] = make_float4(g_ds[1], g_ds[2], 0.f, 0.f);
-  // ---- g_weights[k] = g_dx . (T_j p) + g_v . d_rot_j + g_ds . d_scale_j
-  float gw[MAXK];
-#pragma unroll
-  for (int k = 0; k < MAXK; ++k) {
-    gw[k] = 0.f;
-    if (k < K) {
-      const float* b = s_bones + jj[k] * BONE_F;
-      float y[3];
-      se3_act(b, p, y);
-      float a = g_dx[0] * y[0] + g_dx[1] * y[1] + g_dx[2] * y[2];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) a += g_v[c] * b[7 + c];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) a += g_ds[c] * b[11 + c];
-      gw[k] = a;
-      if (g_weights) g_weights[(size_t) n * K + k] = a;
-    }
-  }
-  // ---- the weighting's backward (sp_knn.hip::sp_weights_backward_kernel, same expressions); `logits`: the W weighting --
-  // the weights do not depend on the distances, its dense logit gradient is skgs_lbs_weights_backward
-  float gf[MAXF];
-#pragma unroll
-  for (int c = 0; c < MAXF; ++c) gf[c] = 0.f;
-  if (!logits) {
-    float dd[MAXK];
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k) dd[k] = k < K ? nn_dist[(size_t) n * K + k] : 0.f;
-    float dot = 0.f;
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k)
-      if (k < K) dot += ww[k] * gw[k];
-    float sum = 0.f;
-    if (radius_raw)
-#pragma unroll
-      for (int k = 0; k < MAXK; ++k)
-        if (k < K) {
-          const float r = expf(radius_raw[jj[k]]);
-          float e = expf(-dd[k] / (2.f * (r * r)));
-          if (kweight_raw) e = e * (1.0f / (1.0f + expf(-kweight_raw[jj[k]])));
-          sum += e + 1e-7f;
-        }
-    float fc[MAXF];
-#pragma unroll
-    for (int c = 0; c < MAXF; ++c) fc[c] = (F > 0 && c < F) ? feature[(size_t) n * F + c] : 0.f;
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k)
-      if (k < K) {
-        const int j = jj[k];
-        float g_d, rterm = 0.f, kterm = 0.f;
-        if (radius_raw) {
-          const float r   = expf(radius_raw[j]);
-          const float e   = expf(-dd[k] / (2.f * (r * r)));
-          const float sk  = kweight_raw ? 1.0f / (1.0f + expf(-kweight_raw[j])) : 1.f;
-          const float g_u = (gw[k] - dot) / sum;
-          const float g_e = g_u * sk;
-          g_d   = g_e * e * (-1.f / (2.f * (r * r)));
-          rterm = g_e * e * (dd[k] / (r * r * r));
-          if (kweight_raw) kterm = g_u * e;
-        } else {
-          g_d = -(ww[k] * (gw[k] - dot)) / temperature;
-        }
-#pragma unroll
-        for (int c = 0; c < MAXF; ++c)
-          if (F > 0 && c < F) gf[c] += g_d * 2.f * (fc[c] - sp_feature[(size_t) j * F + c]);
-        float* vp = V + ((size_t) n * K + k) * 4;
-        *reinterpret_cast<float4*>(vp) = make_float4(g_d, rterm, kterm, 0.f);
-      }
-  }
-  if (g_feature)
-#pragma unroll
-    for (int c = 0; c < MAXF; ++c)
-      if (F > 0 && c < F) g_feature[(size_t) n * F + c] = gf[c];
+  sp_rows_lane<F>(ja, s_bones, n, g_dx, g_ds, reinterpret_cast<const float4*>(g_rotations)[n], g_opacity[n]);
 }
 
 // ------------------------------------------------------------------------------------------------------------ bones
@@ -307,6 +168,63 @@ size_t sp_pairs_bytes(int P, int M, int K) {
   return 256 + align256((size_t) M * 4) + (size_t) M * cap * 4 + align256((size_t) M * 48);
 }
 
+// ---- the call in pieces: argument checks, the rows launch (or the arguments of the rows job of the rasterizer's per-Gaussian
+// backward launch, preprocess.hip), the bones + finalize launches
+static size_t sp_skinning_workspace_bytes(int P, int M, int K) {
+  if (P <= 0 || M <= 0 || K <= 0) return 0;
+  return align256((size_t) P * UROW * 4) + align256((size_t) P * K * 16) + align256((size_t) M * SLICES * NV * 4) + 256;
+}
+struct SpSkinningScratch {
+  float *U, *V, *partials;
+};
+static SpSkinningScratch sp_skinning_scratch(const skgs_sp_skinning_job& j) {
+  const int P = std::max(j.in->P, 1), K = j.in->K;
+  char* wsp = reinterpret_cast<char*>(j.workspace);
+  return SpSkinningScratch{reinterpret_cast<float*>(wsp), reinterpret_cast<float*>(wsp + align256((size_t) P * UROW * 4)),
+      reinterpret_cast<float*>(wsp + align256((size_t) P * UROW * 4) + align256((size_t) P * K * 16))};
+}
+int sp_skinning_check(const skgs_sp_skinning_job& j) {
+  const skgs_deform_inputs* in = j.in;
+  SKGS_REQUIRE(in && in->P >= 0 && in->K >= 1 && in->K <= MAXK && in->M >= 1, "sp_skinning_backward: need P >= 0, 1 <= K <= 16, M >= 1");
+  SKGS_REQUIRE(j.F == 0 || j.F == 8, "sp_skinning_backward: F (hyper dimensions) must be 0 or 8");
+  const int P = in->P, K = in->K, M = in->M;
+  SKGS_REQUIRE(in->live_count == nullptr, "sp_skinning_backward: no row capacity in stage sp");
+  SKGS_REQUIRE(j.pairs && j.pairs_bytes >= sp_pairs_bytes(std::max(P, 1), M, K), "sp_skinning_backward: pair lists missing or too small");
+  SKGS_REQUIRE(j.workspace && j.workspace_bytes >= sp_skinning_workspace_bytes(std::max(P, 1), M, K),
+      "sp_skinning_backward: workspace too small");
+  SKGS_REQUIRE(j.g_bone_T && j.g_bone_drot && j.g_bone_dscale, "sp_skinning_backward: superpoint gradient outputs are required");
+  SKGS_REQUIRE(P == 0 || (in->points && in->weights && in->indices && in->bone_T && in->bone_drot && in->bone_dscale &&
+                             in->log_scale && in->rot && in->opacity_logit && j.g_xyz && j.g_log_scale && j.g_rot && j.g_opacity_logit),
+      "sp_skinning_backward: NULL argument");
+  SKGS_REQUIRE(j.logit_weighting || P == 0 || (j.nn_dist && (j.F == 0 || (j.feature && j.sp_feature))),
+      "sp_skinning_backward: the weighting's inputs are required");
+  SKGS_REQUIRE((size_t) M * BONE_F * 4 <= 64 * 1024, "sp_skinning_backward: too many superpoints for the LDS table");
+  return 0;
+}
+static int sp_skinning_rest_launches(const skgs_sp_skinning_job& j, hipStream_t s) {
+  const skgs_deform_inputs* in = j.in;
+  const int P = in->P, K = in->K, M = in->M, F = j.F;
+  const SpSkinningScratch w = sp_skinning_scratch(j);
+  SpPairsView pv            = sp_pairs_view(j.pairs, std::max(P, 1), M, K);
+#define SKGS_BONES(F_)                                                                                                          \
+  hipLaunchKernelGGL((sp_backward_bones_kernel<F_>), dim3(M * SLICES), dim3(SB_THREADS), 0, s, K, M, pv.cap, pv.counts, pv.lists, \
+      in->points, in->weights, in->bone_T, in->bone_drot, in->bone_dscale, j.feature, j.sp_feature, (int) j.logit_weighting, w.U, w.V, \
+      w.partials)
+  if (F == 8) SKGS_BONES(8); else SKGS_BONES(0);
+#undef SKGS_BONES
+  SKGS_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(sp_backward_finalize_kernel, dim3((M * NV + 255) / 256), dim3(256), 0, s, M, F, (int) j.logit_weighting, w.partials,
+      j.sp_radius_raw, j.sp_weight_raw, j.g_bone_T, j.g_bone_drot, j.g_bone_dscale, j.g_sp_feature, j.g_sp_radius, j.g_sp_weight,
+      pv.counts);
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_sp_skinning_rest(const skgs_sp_skinning_job& j, hipStream_t s) {  // (the rows pass ran as the rasterizer's job)
+  ProfScope prof(K_DEFORM_BWD, s);
+  return sp_skinning_rest_launches(j, s);
+}
+
 }  // namespace skgs
 
 using namespace skgs;
@@ -314,10 +232,7 @@ using namespace skgs;
 extern "C" {
 
 size_t skgs_sp_pairs_bytes(int32_t P, int32_t M, int32_t K) { return (P > 0 && M > 0 && K > 0) ? sp_pairs_bytes(P, M, K) : 0; }
-size_t skgs_sp_skinning_backward_workspace_bytes(int32_t P, int32_t M, int32_t K) {
-  if (P <= 0 || M <= 0 || K <= 0) return 0;
-  return align256((size_t) P * UROW * 4) + align256((size_t) P * K * 16) + align256((size_t) M * SLICES * NV * 4) + 256;
-}
+size_t skgs_sp_skinning_backward_workspace_bytes(int32_t P, int32_t M, int32_t K) { return sp_skinning_workspace_bytes(P, M, K); }
 
 int skgs_sp_skinning_backward(const skgs_deform_inputs* in, int32_t F, const float* feature, const float* sp_feature,
     const float* sp_radius_raw, const float* sp_weight_raw, float temperature, int32_t logit_weighting, const float* nn_dist,
@@ -325,49 +240,26 @@ int skgs_sp_skinning_backward(const skgs_deform_inputs* in, int32_t F, const flo
     float* g_log_scale, float* g_rot, float* g_opacity_logit, float* g_feature, float* g_bone_T, float* g_bone_drot,
     float* g_bone_dscale, float* g_sp_feature, float* g_sp_radius, float* g_sp_weight, void* pairs, size_t pairs_bytes,
     void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
-  SKGS_REQUIRE(in && in->P >= 0 && in->K >= 1 && in->K <= MAXK && in->M >= 1, "sp_skinning_backward: need P >= 0, 1 <= K <= 16, M >= 1");
-  SKGS_REQUIRE(F == 0 || F == 8, "sp_skinning_backward: F (hyper dimensions) must be 0 or 8");
-  const int P = in->P, K = in->K, M = in->M;
-  SKGS_REQUIRE(in->live_count == nullptr, "sp_skinning_backward: no row capacity in stage sp");
-  SKGS_REQUIRE(pairs && pairs_bytes >= skgs_sp_pairs_bytes(std::max(P, 1), M, K), "sp_skinning_backward: pair lists missing or too small");
-  SKGS_REQUIRE(workspace && workspace_bytes >= skgs_sp_skinning_backward_workspace_bytes(std::max(P, 1), M, K),
-      "sp_skinning_backward: workspace too small");
-  SKGS_REQUIRE(g_bone_T && g_bone_drot && g_bone_dscale, "sp_skinning_backward: superpoint gradient outputs are required");
-  SKGS_REQUIRE(P == 0 || (in->points && in->weights && in->indices && in->bone_T && in->bone_drot && in->bone_dscale &&
-                             in->log_scale && in->rot && in->opacity_logit && g_means && g_scales && g_rotations && g_opacity &&
-                             g_xyz && g_log_scale && g_rot && g_opacity_logit),
-      "sp_skinning_backward: NULL argument");
-  SKGS_REQUIRE(logit_weighting || P == 0 || (nn_dist && (F == 0 || (feature && sp_feature))), "sp_skinning_backward: the weighting's inputs are required");
-  SKGS_REQUIRE((size_t) M * BONE_F * 4 <= 64 * 1024, "sp_skinning_backward: too many superpoints for the LDS table");
+  const skgs_sp_skinning_job j{in, F, feature, sp_feature, sp_radius_raw, sp_weight_raw, temperature, logit_weighting, nn_dist,
+      g_weights, g_xyz, g_log_scale, g_rot, g_opacity_logit, g_feature, g_bone_T, g_bone_drot, g_bone_dscale, g_sp_feature, g_sp_radius,
+      g_sp_weight, pairs, pairs_bytes, workspace, workspace_bytes};
+  if (sp_skinning_check(j)) return 1;
+  const int P = in->P;
+  SKGS_REQUIRE(P == 0 || (g_means && g_scales && g_rotations && g_opacity), "sp_skinning_backward: NULL argument");
   hipStream_t s = (hipStream_t) stream;
-  char* wsp = reinterpret_cast<char*>(workspace);
-  float* U  = reinterpret_cast<float*>(wsp);
-  float* V  = reinterpret_cast<float*>(wsp + align256((size_t) std::max(P, 1) * UROW * 4));
-  float* partials = reinterpret_cast<float*>(wsp + align256((size_t) std::max(P, 1) * UROW * 4) + align256((size_t) std::max(P, 1) * K * 16));
-  SpPairsView pv = sp_pairs_view(pairs, std::max(P, 1), M, K);
   ProfScope prof(K_DEFORM_BWD, s);
   if (P > 0) {
-    const size_t lds = (size_t) M * BONE_F * 4;
+    const SpRowsArgs ra = sp_rows_args(j);
     const dim3 grid((P + SB_THREADS - 1) / SB_THREADS), block(SB_THREADS);
-#define SKGS_ROWS(F_)                                                                                                            \
-  hipLaunchKernelGGL((sp_backward_rows_kernel<F_>), grid, block, lds, s, P, K, M, in->points, in->weights, in->indices, nn_dist, \
-      in->bone_T, in->bone_drot, in->bone_dscale, in->log_scale, in->rot, in->opacity_logit, feature, sp_feature, sp_radius_raw, \
-      sp_weight_raw, temperature, (int) logit_weighting, g_means, g_scales, g_rotations, g_opacity, g_weights, g_xyz, g_log_scale,     \
-      g_rot, g_opacity_logit, g_feature, U, V)
-    if (F == 8) SKGS_ROWS(8); else SKGS_ROWS(0);
-#undef SKGS_ROWS
+    if (F == 8)
+      hipLaunchKernelGGL((sp_backward_rows_kernel<8>), grid, block, sp_rows_lds_bytes(in->M), s, P, ra, g_means, g_scales,
+          g_rotations, g_opacity);
+    else
+      hipLaunchKernelGGL((sp_backward_rows_kernel<0>), grid, block, sp_rows_lds_bytes(in->M), s, P, ra, g_means, g_scales,
+          g_rotations, g_opacity);
     SKGS_CHECK_HIP(hipGetLastError());
   }
-#define SKGS_BONES(F_)                                                                                                          \
-  hipLaunchKernelGGL((sp_backward_bones_kernel<F_>), dim3(M * SLICES), dim3(SB_THREADS), 0, s, K, M, pv.cap, pv.counts, pv.lists, \
-      in->points, in->weights, in->bone_T, in->bone_drot, in->bone_dscale, feature, sp_feature, (int) logit_weighting, U, V, partials)
-  if (F == 8) SKGS_BONES(8); else SKGS_BONES(0);
-#undef SKGS_BONES
-  SKGS_CHECK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(sp_backward_finalize_kernel, dim3((M * NV + 255) / 256), dim3(256), 0, s, M, F, (int) logit_weighting, partials,
-      sp_radius_raw, sp_weight_raw, g_bone_T, g_bone_drot, g_bone_dscale, g_sp_feature, g_sp_radius, g_sp_weight, pv.counts);
-  SKGS_CHECK_HIP(hipGetLastError());
-  return 0;
+  return sp_skinning_rest_launches(j, s);
 }
 
 }  // extern "C"

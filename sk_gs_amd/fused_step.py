@@ -429,26 +429,34 @@ class FusedViewStep:
             g.stat_xyz_gradient_accum, g.stat_denom = self._acc_store.data_ptr(), self._den_store.data_ptr()
             g.stat_max_radii2D, g.stat_grad_multiplier = self._rad_store.data_ptr(), 1.0 / self._grad_scale_value
         self._rows_backward_done = False
-        if self.deform_backward_in_preprocess and self.lbs_method == 'W' and not self.wide and self.M <= 64 and self.K <= 8:
-            # the skinning backward (with the softmax backward of the LBS logits) rides on the per-Gaussian launch: what
-            # backward_skinning would launch next, on the same values, handed over in registers
-            if self.deform_net is None:
-                g_drot, g_dscale = m.sk_d_rot.grad[time_id], m.sk_d_scale.grad[time_id]
-            else:
-                _, g_drot, g_dscale = self._g_heads
-            dense = self.spw_logit_grad is None
-            j = _C._DeformBackwardJob()
-            j.in_ = C.pointer(d)
-            j.g_bone_T, j.g_bone_drot, j.g_bone_dscale = self.g_bone_T.data_ptr(), g_drot.data_ptr(), g_dscale.data_ptr()
-            j.g_xyz, j.g_log_scale = m._xyz.grad.data_ptr(), m._scaling.grad.data_ptr()
-            j.g_rot, j.g_opacity_logit = m._rotation.grad.data_ptr(), m._opacity.grad.data_ptr()
-            j.g_sp_W = m.sp_W.grad.data_ptr() if dense else None
-            j.g_logits = None if dense else self.spw_logit_grad.data_ptr()
-            j.workspace, j.workspace_bytes = self.deform_ws.data_ptr(), self.deform_ws.numel()
-            g.deform_backward_job = C.cast(C.pointer(j), C.c_void_p)
-            self._rows_backward_done = True
+        job = self._attach_backward_job(g, d, time_id)  # (kept alive until the call has read it)
         chk(lib.skgs_rasterize_backward(C.byref(a), C.byref(self._bufs), _p(self.radii), _p(self.out_opacity),
                                         C.byref(g), st))
+
+    def _attach_backward_job(self, g, d, time_id):
+        """the skinning backward as a job of the rasterizer's per-Gaussian backward launch: fills the job pointer of ``g`` and
+        sets ``_rows_backward_done`` (``backward_skinning`` then skips its launch); returns the struct to keep alive"""
+        m = self.model
+        if not (self.deform_backward_in_preprocess and self.lbs_method == 'W' and not self.wide and self.M <= 64 and self.K <= 8):
+            return None
+        # the skinning backward (with the softmax backward of the LBS logits) rides on the per-Gaussian launch: what
+        # backward_skinning would launch next, on the same values, handed over in registers
+        if self.deform_net is None:
+            g_drot, g_dscale = m.sk_d_rot.grad[time_id], m.sk_d_scale.grad[time_id]
+        else:
+            _, g_drot, g_dscale = self._g_heads
+        dense = self.spw_logit_grad is None
+        j = _C._DeformBackwardJob()
+        j.in_ = C.pointer(d)
+        j.g_bone_T, j.g_bone_drot, j.g_bone_dscale = self.g_bone_T.data_ptr(), g_drot.data_ptr(), g_dscale.data_ptr()
+        j.g_xyz, j.g_log_scale = m._xyz.grad.data_ptr(), m._scaling.grad.data_ptr()
+        j.g_rot, j.g_opacity_logit = m._rotation.grad.data_ptr(), m._opacity.grad.data_ptr()
+        j.g_sp_W = m.sp_W.grad.data_ptr() if dense else None
+        j.g_logits = None if dense else self.spw_logit_grad.data_ptr()
+        j.workspace, j.workspace_bytes = self.deform_ws.data_ptr(), self.deform_ws.numel()
+        g.deform_backward_job = C.cast(C.pointer(j), C.c_void_p)
+        self._rows_backward_done = True
+        return j
 
     @torch.no_grad()
     def sh_grads_from_factors(self, all_factors: Tensor, sh_degree: int):

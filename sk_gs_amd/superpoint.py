@@ -449,12 +449,48 @@ class FusedSuperpointStep(FusedViewStep):
             _p(self.sp_order), _p(self.sp_rank), _p(self.indices), _p(self.weights), _p(self.nn_dist), _p(self.pairs), C.c_size_t(self.pairs.numel()),
             C.c_int32(0), C.c_int32(0 if prep is None else 1), st))
         d = self._deform_inputs(time_id)
-        chk(lib.skgs_lbs_deform_forward(C.byref(d), _p(self.means), _p(self.scales), _p(self.rotations), _p(self.opacity),
-                                        None, None, None, st))
         a = self._raster_inputs(rs)
+        if self.deform_in_preprocess:  # the skinning as a job of the rasterizer's per-Gaussian launch (joints = NULL: no search)
+            j = _C._KnnDeformJob()
+            j.M, j.K = M, K
+            j.points, j.bone_T, j.bone_drot, j.bone_dscale = d.points, d.bone_T, d.bone_drot, d.bone_dscale
+            j.xyz, j.log_scale, j.rot, j.opacity_logit = d.xyz, d.log_scale, d.rot, d.opacity_logit
+            j.out_idx, j.out_weights = self.indices.data_ptr(), self.weights.data_ptr()
+            j.means, j.scales = self.means.data_ptr(), self.scales.data_ptr()
+            j.rotations, j.opacity = self.rotations.data_ptr(), self.opacity.data_ptr()
+            a.deform_job = C.pointer(j)
+        else:
+            chk(lib.skgs_lbs_deform_forward(C.byref(d), _p(self.means), _p(self.scales), _p(self.rotations), _p(self.opacity),
+                                            None, None, None, st))
         chk(lib.skgs_rasterize_forward(C.byref(a), C.byref(self._bufs), _p(self.radii), _p(self.image),
                                        _p(self.out_opacity), None, None, st))
+        a.deform_job = None  # (the backward's copy of the inputs: the job was the forward's)
         return a, d
+
+    def _attach_backward_job(self, g, d, time_id):
+        """the ROWS pass of the skinning + weighting backward as a job of the rasterizer's per-Gaussian backward launch
+        (skgs_raster_grads.sp_skinning_job: the arguments of skgs_sp_skinning_backward below without the upstream gradients);
+        the bones and finalize launches follow inside skgs_rasterize_backward.  SKGS_SEPARATE_DEFORM_BACKWARD=1: off"""
+        if not self.deform_backward_in_preprocess:
+            return None
+        m = self.model
+        gp = lambda t: None if t is None or t.grad is None else t.grad.data_ptr()  # noqa: E731
+        pp = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        logits = m.sp_W is not None
+        j = _C._SpSkinningJob()
+        j.in_, j.F = C.pointer(d), self.F
+        j.feature, j.sp_feature, j.sp_radius_raw, j.sp_weight_raw = pp(m.hyper_feature), pp(m.sp_hyper_feature), pp(m._sp_radius), pp(m._sp_weight)
+        j.temperature, j.logit_weighting, j.nn_dist = float(m.lbs_temperature), 1 if logits else 0, self.nn_dist.data_ptr()
+        j.g_weights = self.g_weights.data_ptr() if logits else None
+        j.g_xyz, j.g_log_scale, j.g_rot = m._xyz.grad.data_ptr(), m._scaling.grad.data_ptr(), m._rotation.grad.data_ptr()
+        j.g_opacity_logit, j.g_feature = m._opacity.grad.data_ptr(), None if logits else gp(m.hyper_feature)
+        j.g_bone_T, j.g_bone_drot, j.g_bone_dscale = self.g_bone_T.data_ptr(), self.g_d_rot.data_ptr(), self.g_d_scale.data_ptr()
+        j.g_sp_feature, j.g_sp_radius, j.g_sp_weight = None if logits else gp(m.sp_hyper_feature), gp(m._sp_radius), gp(m._sp_weight)
+        j.pairs, j.pairs_bytes = self.pairs.data_ptr(), self.pairs.numel()
+        j.workspace, j.workspace_bytes = self.sb_ws.data_ptr(), self.sb_ws.numel()
+        g.sp_skinning_job = C.cast(C.pointer(j), C.c_void_p)
+        self._rows_backward_done = True
+        return j
 
     @torch.no_grad()
     def backward_skinning(self, time_id=None, part=None):
@@ -465,13 +501,16 @@ class FusedSuperpointStep(FusedViewStep):
         g = lambda t: None if t is None else _p(t.grad)  # noqa: E731
         logits = m.sp_W is not None
         # skinning + weighting backward: rows | bones (the inverse lists of the forward) | finalize -- no atomics
-        chk(lib.skgs_sp_skinning_backward(
-            C.byref(d), C.c_int32(self.F), _p(m.hyper_feature), _p(m.sp_hyper_feature), _p(m._sp_radius), _p(m._sp_weight),
-            C.c_float(m.lbs_temperature), C.c_int32(1 if logits else 0), _p(self.nn_dist), _p(self.g_means), _p(self.g_scales),
-            _p(self.g_rotations), _p(self.g_opacity), _p(self.g_weights) if logits else None, _p(m._xyz.grad), _p(m._scaling.grad),
-            _p(m._rotation.grad), _p(m._opacity.grad), None if logits else g(m.hyper_feature), _p(self.g_bone_T), _p(self.g_d_rot),
-            _p(self.g_d_scale), None if logits else g(m.sp_hyper_feature), g(m._sp_radius), g(m._sp_weight), _p(self.pairs),
-            C.c_size_t(self.pairs.numel()), _p(self.sb_ws), C.c_size_t(self.sb_ws.numel()), st))
+        if self._rows_backward_done:  # (ran with the rasterizer's backward: _attach_backward_job)
+            self._rows_backward_done = False
+        else:
+            chk(lib.skgs_sp_skinning_backward(
+                C.byref(d), C.c_int32(self.F), _p(m.hyper_feature), _p(m.sp_hyper_feature), _p(m._sp_radius), _p(m._sp_weight),
+                C.c_float(m.lbs_temperature), C.c_int32(1 if logits else 0), _p(self.nn_dist), _p(self.g_means), _p(self.g_scales),
+                _p(self.g_rotations), _p(self.g_opacity), _p(self.g_weights) if logits else None, _p(m._xyz.grad), _p(m._scaling.grad),
+                _p(m._rotation.grad), _p(m._opacity.grad), None if logits else g(m.hyper_feature), _p(self.g_bone_T), _p(self.g_d_rot),
+                _p(self.g_d_scale), None if logits else g(m.sp_hyper_feature), g(m._sp_radius), g(m._sp_weight), _p(self.pairs),
+                C.c_size_t(self.pairs.numel()), _p(self.sb_ws), C.c_size_t(self.sb_ws.numel()), st))
         if logits and not self.sparse_logits:  # `W`: the dense [P,M] logit gradient (what autograd's gather backward builds)
             chk(lib.skgs_lbs_weights_backward(C.c_int32(P), C.c_int32(M), C.c_int32(K), _p(self.weights), _p(self.indices),
                                               _p(self.g_weights), _p(m.sp_W.grad), st))

@@ -231,8 +231,10 @@ def test_stage_sp_prints_the_contract_line():
     assert d['n_gpus'] == 1 and d['config']['stage'] == 'sp' and '512 superpoints' in d['config']['workload']
     assert abs(d['value'] - 1000.0 / d['ms_per_step']) / d['value'] < 0.01
     k = d['kernels']
-    for name in ('sp_net_forward', 'sp_net_backward', 'sp_knn_weights', 'deform_forward', 'deform_backward', 'render_forward',
-                 'render_backward', 'adam'):
+    # (the skinning and the rows pass of its backward are jobs of the rasterizer's per-Gaussian launches)
+    assert 'deform_forward' in k['preprocess_forward']['includes'] and 'rows pass' in k['preprocess_backward']['includes']
+    for name in ('sp_net_forward', 'sp_net_backward', 'sp_knn_weights', 'preprocess_forward', 'preprocess_backward', 'deform_backward',
+                 'render_forward', 'render_backward', 'adam'):
         assert k[name]['us'] > 0 and 0 < k[name]['frac'] < 1, (name, k[name])
     assert 0 < k['sp_net_forward']['frac_of_mfma_f32_peak'] < 1 and k['sp_net_forward']['TFLOPs'] > 1
     total = sum(v['us'] * v['launches_per_step'] for v in k.values())

@@ -337,6 +337,43 @@ def test_fused_superpoint_step_matches_the_operator_path(method):
         assert_close_robust(p.grad, ref[n], 3e-4, 1e-3, name=f'{n} sp {method}')
 
 
+@pytest.mark.parametrize('method', ['weighted_kernel', 'kernel', 'dist', 'W'])
+def test_sp_rows_pass_as_a_job_of_the_rasterizer_backward_equals_the_separate_launch(method):
+    """skgs_raster_grads.sp_skinning_job: the rows pass of the skinning + weighting backward inside the rasterizer's per-Gaussian
+    backward launch (+ bones and finalize behind it) against skgs_sp_skinning_backward as a call of its own -- every gradient
+    (their upstream is summed by atomics: order, not bits)"""
+    from sk_gs_amd import _C
+    from sk_gs_amd.superpoint import FusedSuperpointStep
+    from helpers import assert_close_robust
+    P, M, K, W, H, frames, tid = 6000, 512, 5, 160, 120, 3, 1
+    model, rs, target = _sp_model(P, M, K, W, H, frames, method)
+    _C.config.sync_num_rendered = True
+    R = model.render(rs, time_id=tid)['buffer'].R
+    got = {}
+    for job in (False, True):
+        for p in model.parameters():
+            p.grad = None
+        step = FusedSuperpointStep(model, W, H, capacity=int(R * 1.2) + 1024)
+        step.deform_in_preprocess = step.deform_backward_in_preprocess = job  # (the forward's skinning likewise: deform_job)
+        for p in model.parameters():
+            p.grad.zero_()
+        for buf in (step.means, step.scales, step.rotations, step.opacity):
+            buf.fill_(-7.0)
+        step.backward_raster(rs, tid, target)
+        assert step._rows_backward_done == job
+        step.backward_skinning(tid)
+        torch.cuda.synchronize()
+        got[job] = {n: p.grad.clone() for n, p in model.named_parameters()}
+        got[job].update({'fwd_' + k: getattr(step, k).clone() for k in ('means', 'scales', 'rotations', 'opacity', 'radii', 'image')})
+    for n, v in got[False].items():
+        if n.startswith('fwd_'):  # the forward halves: the same arithmetic on the same values -- the same bits
+            assert torch.equal(got[True][n], v), n
+        elif float(v.abs().max()) == 0.0:
+            assert float(got[True][n].abs().max()) == 0.0, n
+        else:
+            assert_close_robust(got[True][n], v, 2e-5, 1e-4, name=f'{n} sp {method}')
+
+
 @pytest.mark.parametrize('method', ['weighted_kernel', 'W'])
 def test_superpoint_train_step_graph_replay_equals_eager_steps(method):
     """FusedSuperpointTrainStep (rows' Adam on the idle CUs of the network's backward launches, closing launch for the rest; `W`:
