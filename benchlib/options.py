@@ -57,6 +57,11 @@ def build_parser():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--prime-steps', type=int, default=100,
+                    help='untimed steps run as part of the SETUP (after the graph capture, before the --warmup steps): a fresh '
+                         'process reaches the steady state of a training run -- clocks, TLBs, the views\' first touches -- only '
+                         'after some tens of ms of work; with the driver\'s 5 warm-up steps (1.9 ms) a 20-step region measured '
+                         '0.375 ms per step, 0.358 behind 50 and the long-run 0.354 behind 200.  Reported as `prime_steps`; 0 = off')
     ap.add_argument('--config', type=int, default=1)
     ap.add_argument('--views', type=int, default=8)
     ap.add_argument('--ppl', type=int, default=0, help='pixels per lane of the blend kernels (0 = heuristic)')

@@ -577,6 +577,11 @@ def run(args, env):
     if not args.eager:  # every graph exists before the timed region, whatever --warmup is
         t.capture_all()
         t.rewind_views()
+    if args.prime_steps > 0:  # setup: bring the fresh process to the steady state of a training run (see --prime-steps)
+        for i in range(args.prime_steps):
+            t.train_step(i)
+        torch.cuda.synchronize()
+        t.rewind_views()
     for i in range(args.warmup):
         t.train_step(i)
     torch.cuda.synchronize()
@@ -637,7 +642,8 @@ def run(args, env):
         'metric': 'train iters/sec (deform + rasterize fwd+bwd + L1/SSIM loss + Adam; ms/render fwd+bwd beside it), '
                   f'{P // 1000}k Gaussians @{W}x{H}',
         'value': round(world * args.steps / elapsed, 3), 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': round(ms_step, 4), 'ms_per_step_blocks': block_stats, 'higher_is_better': True,
+        'warmup': args.warmup, 'prime_steps': args.prime_steps, 'ms_per_step': round(ms_step, 4), 'ms_per_step_blocks': block_stats,
+        'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'{cfg["name"]}: {P} Gaussians, {M} bones, K={K}, SH degree 3, {W}x{H}, '
                                f'{args.views} synthetic views, colmap=True, 1 view per rank per step'
