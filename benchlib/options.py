@@ -57,6 +57,10 @@ def build_parser():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--steps-per-graph', type=int, default=4,
+                    help='consecutive training steps recorded in ONE hipGraph (one-rank fused step with an ordered view table, whose '
+                         'closing launch selects the next view; the one-step graph serves the remainder): between two replays '
+                         'the device idles ~8 us.  1 = one step per replay')
     ap.add_argument('--prime-steps', type=int, default=100,
                     help='untimed steps run as part of the SETUP (after the graph capture, before the --warmup steps): a fresh '
                          'process reaches the steady state of a training run -- clocks, TLBs, the views\' first touches -- only '

@@ -141,7 +141,8 @@ def build_steps(args, env, s, x):
     settings, targets, frames, background = s.settings, s.targets, s.frames, s.background
     compact, sh_factored, pipelined, sh_ex = x.compact, x.sh_factored, x.pipelined, x.sh_ex
     groups = model.param_groups(lr=args.lr)
-    t = SimpleNamespace(fstep=None, opt=None, g_step=None, fused_update=False, train1=None, train_n=None)
+    t = SimpleNamespace(fstep=None, opt=None, g_step=None, fused_update=False, train1=None, train_n=None, steps_per_graph=1,
+                        train_chunk=None)
     t.overflow = torch.zeros(1, dtype=torch.int32, device=env.dev)
 
     # per-view arguments of the step calls: none when the view is read from the device-resident slot
@@ -359,10 +360,25 @@ def build_steps(args, env, s, x):
                     reduce_grads()
                     g_opt(0)
 
+            # several steps per graph replay: the one-rank fused step whose closing launch selects the next view (every piece of
+            # state between two steps lives on the device; a densification only ever happens between two replays)
+            n_multi = max(1, int(args.steps_per_graph))
+            if (n_multi > 1 and not env.use_dist and t.fused_update and view_table is not None
+                    and getattr(view_table, 'order', None) is not None and len(capture_views) == 1
+                    and (not s.densify_every or s.densify_every % n_multi == 0)):
+                t.steps_per_graph = n_multi
+
+                def graph_chunk(i, n):
+                    assert n == n_multi
+                    t.g_step.replay(gkey(capture_views[0]), n)
+                t.train_chunk = graph_chunk
+
             def capture_all():
                 for v in capture_views:
                     select(v)
                     t.g_step.capture(gkey(v))
+                if t.steps_per_graph > 1:
+                    t.g_step.capture(gkey(capture_views[0]), repeat=t.steps_per_graph)
                 if g_opt is not None:
                     # GraphedSteps.capture runs its function for real (warm-up) before recording it: the optimizer graph must see
                     # REDUCED gradients then, or every rank would apply its own view's gradient and the replicas would drift
@@ -453,7 +469,7 @@ class DensifyEvents:
 
     def __init__(self, s, t, dev):
         from sk_gs_amd import densify as dn
-        assert t.fused_update and len(t.g_step.graphs) == 1
+        assert t.fused_update and len(t.g_step.graphs) == (2 if t.steps_per_graph > 1 else 1)  # (one step, N steps)
         self.dn, self.s, self.t = dn, s, t
         fstep, model = t.fstep, s.model
         acc, den = fstep.xyz_gradient_accum.view(-1), fstep.denom.view(-1).clamp_min(1)
@@ -512,8 +528,9 @@ class DensifyEvents:
         self.log['ms'] = [round(a.elapsed_time(b), 3) for a, b in self.marks]
         self.log['graphs_captured'] = len(self.t.g_step.graphs)
         self.log['row_capacity'] = self.s.model.capacity.P_cap
-        self.log['how'] = ('clone + split + prune in place inside the timed region; the step is ONE hipGraph captured before the '
-                           'first event and never re-captured; `value` is end-to-end')
+        self.log['how'] = ('clone + split + prune in place inside the timed region; the step is ONE hipGraph (and its '
+                           f'{self.t.steps_per_graph}-step form) captured before the first event and never re-captured; `value` is '
+                           'end-to-end')
         return self.log
 
 
@@ -578,8 +595,14 @@ def run(args, env):
         t.capture_all()
         t.rewind_views()
     if args.prime_steps > 0:  # setup: bring the fresh process to the steady state of a training run (see --prime-steps)
-        for i in range(args.prime_steps):
-            t.train_step(i)
+        i = 0
+        while i < args.prime_steps:
+            if t.train_chunk is not None and not args.eager and args.prime_steps - i >= t.steps_per_graph:
+                t.train_chunk(i, t.steps_per_graph)
+                i += t.steps_per_graph
+            else:
+                t.train_step(i)
+                i += 1
         torch.cuda.synchronize()
         t.rewind_views()
     for i in range(args.warmup):
@@ -593,7 +616,8 @@ def run(args, env):
         events = DensifyEvents(s, t, dev)
         events.settle(t.train_step, args.warmup)
     elapsed, block_stats = timing.timed_steps(t.train_step, args.steps, args.warmup, dev,
-                                              after_step=events.after_step(args.steps) if events else None)
+                                              after_step=events.after_step(args.steps) if events else None,
+                                              chunk=1 if args.eager else t.steps_per_graph, train_chunk=None if args.eager else t.train_chunk)
     ordered_views = view_table is not None and getattr(view_table, 'order', None) is not None
     adam_desc = describe_adam(x, t)
     prof = _C.profile_collect()
@@ -642,8 +666,8 @@ def run(args, env):
         'metric': 'train iters/sec (deform + rasterize fwd+bwd + L1/SSIM loss + Adam; ms/render fwd+bwd beside it), '
                   f'{P // 1000}k Gaussians @{W}x{H}',
         'value': round(world * args.steps / elapsed, 3), 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'prime_steps': args.prime_steps, 'ms_per_step': round(ms_step, 4), 'ms_per_step_blocks': block_stats,
-        'higher_is_better': True,
+        'warmup': args.warmup, 'prime_steps': args.prime_steps, 'steps_per_graph': 1 if args.eager else t.steps_per_graph,
+        'ms_per_step': round(ms_step, 4), 'ms_per_step_blocks': block_stats, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'{cfg["name"]}: {P} Gaussians, {M} bones, K={K}, SH degree 3, {W}x{H}, '
                                f'{args.views} synthetic views, colmap=True, 1 view per rank per step'
@@ -660,6 +684,7 @@ def run(args, env):
                        + ')'),
                    'launch': 'eager' if args.eager else (
                        f'ONE captured hipGraph for all {args.views} views (camera, time and target read from a device view slot)'
+                       + (f', {t.steps_per_graph} consecutive steps per replay' if t.steps_per_graph > 1 else '')
                        if view_table is not None else f'one captured hipGraph per view ({args.views})'),
                    'view_select': ('by the closing launch of the previous step (ordered view table)' if ordered_views else
                                    'one 256-byte device-to-device copy per step') if view_table is not None else 'baked into the graphs',

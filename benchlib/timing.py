@@ -7,36 +7,49 @@ import torch.distributed as dist
 from benchlib.options import HBM_PEAK_GBPS
 
 
-def timed_steps(train_step, steps, warmup, dev, after_step=None):
-    """exactly `steps` calls of train_step(warmup + i) between a barrier + synchronize on both sides.  Returns (seconds: MAX over
-    the ranks, block statistics of rank 0's launch stream).  An event every steps/10 steps splits the region into >= 10 blocks
-    (when steps >= 10) whose per-step times give the spread of `ms_per_step` (median / p10 / p90); `after_step(i)` runs
-    inside the region (the densification events of --densify-every)."""
+def timed_steps(train_step, steps, warmup, dev, after_step=None, chunk=1, train_chunk=None):
+    """exactly `steps` training steps -- train_step(warmup + i), or `train_chunk(warmup + i, chunk)` = `chunk` consecutive steps in
+    one graph replay while that many are left -- between a barrier + synchronize on both sides.  Returns (seconds: MAX over
+    the ranks, block statistics of rank 0's launch stream).  Events split the region into ~10 blocks (when steps >= 10) whose
+    per-step times give the spread of `ms_per_step` (median / p10 / p90); `after_step(i)` runs inside the region behind step i
+    (the densification events of --densify-every; the caller keeps `chunk` a divisor of their period)."""
     use_dist = dist.is_initialized()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    n_blocks = min(steps, 10)
-    edges = [round(b * steps / n_blocks) for b in range(n_blocks + 1)]
-    marks = [torch.cuda.Event(enable_timing=True) for _ in edges]
+    if train_chunk is None:
+        chunk = 1
+    n_blocks = max(1, min(steps, 10))
+    edges = [round(b * steps / n_blocks) for b in range(1, n_blocks + 1)]
+    marks = [(torch.cuda.Event(enable_timing=True), 0)]
     t0 = time.perf_counter()
-    marks[0].record()
-    nxt = 1
-    for i in range(steps):
-        train_step(warmup + i)
+    marks[0][0].record()
+    i = 0
+    while i < steps:
+        n = chunk if steps - i >= chunk else 1
+        if n > 1:
+            train_chunk(warmup + i, n)
+        else:
+            train_step(warmup + i)
         if after_step is not None:
-            after_step(i)
-        if i + 1 == edges[nxt]:
-            marks[nxt].record()
-            nxt += 1
+            for j in range(i, i + n):
+                after_step(j)
+        i += n
+        if edges and i >= edges[0]:
+            while edges and i >= edges[0]:
+                edges.pop(0)
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append((e, i))
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    per_step = sorted(marks[b].elapsed_time(marks[b + 1]) / (edges[b + 1] - edges[b]) for b in range(n_blocks))
-    block_stats = dict(blocks=n_blocks, median=round(per_step[n_blocks // 2], 4), p10=round(per_step[n_blocks // 10], 4),
-                       p90=round(per_step[min(n_blocks - 1, (9 * n_blocks) // 10)], 4),
+    per_step = sorted(marks[b][0].elapsed_time(marks[b + 1][0]) / (marks[b + 1][1] - marks[b][1]) for b in range(len(marks) - 1))
+    nb = len(per_step)
+    block_stats = dict(blocks=nb, median=round(per_step[nb // 2], 4), p10=round(per_step[nb // 10], 4),
+                       p90=round(per_step[min(nb - 1, (9 * nb) // 10)], 4),
                        min=round(per_step[0], 4), max=round(per_step[-1], 4),
                        how='HIP events on the launch stream every steps/blocks steps inside the timed region (rank 0)')
     if use_dist:

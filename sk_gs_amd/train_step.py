@@ -43,7 +43,12 @@ class GraphedSteps:
         self.graphs: Dict[Hashable, torch.cuda.CUDAGraph] = {}
         self.pool = None
 
-    def capture(self, key: Hashable):
+    def capture(self, key: Hashable, repeat: int = 1):
+        """``repeat`` > 1: ``fn(key)`` recorded ``repeat`` times in ONE graph (stored beside the one-step graph of the key) --
+        for a step whose state lives on the device (an ordered ``ViewTable``: the closing launch selects the next view) this is
+        ``repeat`` consecutive training steps per replay.  Between two replays on a stream the device idles for ~8 us
+        (rocprofv3: tools/step_timeline.py); four steps per graph took 4 us off each 0.35 ms step of bench.py.  The warm-up
+        executions before the recording run ``fn`` once each, whatever ``repeat`` is."""
         if self.collect_garbage:
             gc.collect()
         side = torch.cuda.Stream()
@@ -61,11 +66,16 @@ class GraphedSteps:
         import torch.distributed as dist
         mode = 'thread_local' if (dist.is_available() and dist.is_initialized()) else 'global'
         with torch.cuda.graph(g, pool=self.pool, capture_error_mode=mode):
-            self.fn(key)
+            for _ in range(repeat):
+                self.fn(key)
         if self.pool is None:
             self.pool = g.pool()
-        self.graphs[key] = g
+        self.graphs[key if repeat == 1 else (key, '*', repeat)] = g
         return g
+
+    def replay(self, key: Hashable, repeat: int):
+        """replay the ``repeat``-step graph of ``key`` (captured with ``capture(key, repeat)``)"""
+        self.graphs[(key, '*', repeat)].replay()
 
     def __call__(self, key: Hashable):
         g = self.graphs.get(key)

@@ -31,8 +31,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert 'traffic' in r and 'traffic_source' in r
     assert d['config']['cluster']['world'] == 1 and d['config']['cluster']['devices'][0]['name']
     assert abs(d['value'] - 1000.0 / d['ms_per_step']) / d['value'] < 0.01
-    b = d['ms_per_step_blocks']  # the spread of the timed region: 8 steps -> 8 blocks
-    assert b['blocks'] == 8 and b['min'] <= b['p10'] <= b['median'] <= b['p90'] <= b['max']
+    b = d['ms_per_step_blocks']  # the spread of the timed region: 8 steps = 2 replays of the 4-step graph -> 2 blocks
+    assert d['steps_per_graph'] == 4 and d['prime_steps'] == 100 and '4 consecutive steps per replay' in d['config']['launch']
+    assert b['blocks'] == 2 and b['min'] <= b['p10'] <= b['median'] <= b['p90'] <= b['max']
     assert abs(b['median'] - d['ms_per_step']) / d['ms_per_step'] < 0.25
     # every launch of the step is timed and priced (algorithmic bytes next to the 8 TB/s roofline); together they are the step
     k = d['kernels']

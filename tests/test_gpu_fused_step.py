@@ -669,3 +669,51 @@ def test_deform_as_a_job_of_the_per_gaussian_launch_is_bit_identical(P, M, K, W,
             assert_close_robust(got[True][k], v, 1e-6, 1e-5, name=k)
         else:
             assert torch.equal(got[True][k], v), k
+
+
+def test_several_steps_per_graph_replay_walk_the_views_like_single_replays():
+    """``GraphedSteps.capture(key, repeat=n)``: n consecutive training steps in ONE graph (the closing launch of a step selects
+    the next view, every piece of state between two steps lives on the device) -- the same views in the same order and the same
+    step count as n replays of the one-step graph (learning rate 0: every view keeps rendering the same image, bit for bit)"""
+    from sk_gs_amd import scene
+    from sk_gs_amd.fused_step import FusedViewStep
+    from sk_gs_amd.model import SkinnedGaussians
+    from sk_gs_amd.optim import FusedAdam
+    from sk_gs_amd.train_step import FusedTrainStep, GraphedSteps
+    from sk_gs_amd.view_slot import ViewTable
+    P, M, K, W, H, V, N = 2000, 10, 4, 96, 64, 5, 4
+    dev = torch.device('cuda')
+    cams = [scene.make_camera(W, H, seed=50 + v) for v in range(V)]
+    settings = [scene.raster_settings_from_camera(c, sh_degree=3, colmap=True, device=dev) for c in cams]
+    targets = torch.rand(V, 3, H, W, generator=torch.Generator().manual_seed(9)).to(dev)
+    order = [3, 0, 4, 4, 1]
+    model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=V, seed=4, scale_mult=2.0, deform_net=True,
+                             learn_joints=True).to(dev)
+    table = ViewTable(settings, [float(model.frame_times[v]) for v in range(V)], list(range(V)), targets, dev)
+    step = FusedViewStep(model, W, H, capacity=400_000, view_table=table)
+    opt = FusedAdam(model.param_groups(lr=0.0))
+    train = FusedTrainStep(step, opt)
+    assert train.fused
+    ref = {}
+    for v in range(V):
+        table.select(v)
+        step.forward()
+        ref[v] = step.image.clone()
+    table.set_order(order)
+    graphs = GraphedSteps(lambda _: train(), collect_garbage=False)
+    graphs(0)                        # step 1: captures the one-step graph (its warm-up execution is the step)
+    graphs.capture(0, repeat=N)      # (the warm-up execution of this capture is step 2)
+    done = 2
+    for _ in range(3):
+        graphs.replay(0, N)          # N steps per replay
+        done += N
+        torch.cuda.synchronize()
+        assert float(opt.step_count.item()) == done and int(table.cursor[0].item()) == done + 1
+        assert torch.equal(step.image, ref[order[(done - 1) % len(order)]])       # the last step's view
+        assert torch.equal(table.slot, table.records[order[done % len(order)]])   # the view the NEXT step reads
+    graphs(0)                        # the one-step graph serves a remainder
+    torch.cuda.synchronize()
+    assert torch.equal(step.image, ref[order[done % len(order)]]) and float(opt.step_count.item()) == done + 1
+    assert len(graphs.graphs) == 2 and step.status()['overflow_events'] == 0
+    st = opt.state[model._features_dc]
+    assert float(st['exp_avg'].abs().max()) > 0  # (the steps did run their backward and their optimizer launch)
