@@ -378,7 +378,7 @@ def build_steps(args, env, s, x):
                     select(v)
                     t.g_step.capture(gkey(v))
                 if t.steps_per_graph > 1:
-                    t.g_step.capture(gkey(capture_views[0]), repeat=t.steps_per_graph)
+                    t.g_step.capture(gkey(capture_views[0]), repeat=t.steps_per_graph, warmup=0)
                 if g_opt is not None:
                     # GraphedSteps.capture runs its function for real (warm-up) before recording it: the optimizer graph must see
                     # REDUCED gradients then, or every rank would apply its own view's gradient and the replicas would drift
@@ -428,10 +428,24 @@ def build_steps(args, env, s, x):
             select(v)
             g_whole(gkey(v))
 
+        # several steps per replay here too when the table is ordered (every rank walks its own views by itself): the collectives
+        # are nodes of the graph like the kernels
+        n_multi = max(1, int(args.steps_per_graph))
+        if (n_multi > 1 and view_table is not None and getattr(view_table, 'order', None) is not None and len(capture_views) == 1
+                and not s.densify_every):
+            t.steps_per_graph = n_multi
+
+            def graph_chunk(i, n):  # noqa: F811
+                assert n == n_multi
+                g_whole.replay(gkey(capture_views[0]), n)
+            t.train_chunk = graph_chunk
+
         def capture_all():  # noqa: F811
             for v in capture_views:
                 select(v)
                 g_whole.capture(gkey(v))
+            if t.steps_per_graph > 1:
+                g_whole.capture(gkey(capture_views[0]), repeat=t.steps_per_graph, warmup=0)
 
     def rewind_views():
         """ordered view table: the set-up steps consumed views; step i of the loops renders view_index(i) again, as with explicit

@@ -183,7 +183,7 @@ def run(args, base_alg_bytes, configs):
         view_table.rewind()
     if train_chunk is not None:  # (the one-step graph first: a first call captures)
         train_step(0)
-        g_step.capture(0, repeat=n_multi)
+        g_step.capture(0, repeat=n_multi, warmup=0)
         view_table.rewind()
     if args.prime_steps > 0:  # setup: the steady state of a training run before anything is timed (see --prime-steps)
         i = 0

@@ -10,7 +10,7 @@ the torch glue around them; ``FusedViewStep`` issues 14 launches and no glue.
 the data dependencies of the skeleton stage's backward launch.
 """
 import gc
-from typing import Callable, Dict, Hashable
+from typing import Callable, Dict, Hashable, Optional
 
 import torch
 
@@ -43,18 +43,19 @@ class GraphedSteps:
         self.graphs: Dict[Hashable, torch.cuda.CUDAGraph] = {}
         self.pool = None
 
-    def capture(self, key: Hashable, repeat: int = 1):
+    def capture(self, key: Hashable, repeat: int = 1, warmup: Optional[int] = None):
         """``repeat`` > 1: ``fn(key)`` recorded ``repeat`` times in ONE graph (stored beside the one-step graph of the key) --
         for a step whose state lives on the device (an ordered ``ViewTable``: the closing launch selects the next view) this is
         ``repeat`` consecutive training steps per replay.  Between two replays on a stream the device idles for ~8 us
         (rocprofv3: tools/step_timeline.py); four steps per graph took 4 us off each 0.35 ms step of bench.py.  The warm-up
-        executions before the recording run ``fn`` once each, whatever ``repeat`` is."""
+        executions before the recording run ``fn`` once each, whatever ``repeat`` is; ``warmup=0`` skips them (the one-step
+        graph of the key exists: everything lazy has been initialised, and no extra training step is executed)."""
         if self.collect_garbage:
             gc.collect()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(self.warmup):
+            for _ in range(self.warmup if warmup is None else warmup):
                 self.fn(key)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
