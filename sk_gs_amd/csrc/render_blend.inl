@@ -102,9 +102,13 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
     }
     __syncthreads();
     const uint32_t contrib0 = (uint32_t) (base - start);
+    [[maybe_unused]] uint32_t lastj = 0xffffffffu;  // LANE_MASKS: slot of the lane's last contributing splat in THIS batch
     // only the splats whose 1/255 iso-contour can reach this wave's pixel rectangle are visited (wave-uniform list)
-    for (unsigned long long todo = __ballot(relevant); todo; todo &= todo - 1) {
+    // (the visited bit is cleared by ONE s_bitset0_b64 -- `todo &= todo - 1` is s_add_u32 / s_addc_u32 / s_and_b64: a wave issues
+    // one instruction of any kind per turn of its SIMD, and the visit is a chain)
+    for (unsigned long long todo = __ballot(relevant); todo;) {
       const int j    = __builtin_ctzll(todo);
+      asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(j));
       const float4 a = s_a[j];
       const float4 b = s_b[j];
 #if SKGS_STRICT
@@ -161,7 +165,11 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
         // one pixel per lane: the decisions live as lane masks in SGPRs -- `stop` and `hit` are the two halves of `valid`
         // under ONE compare (from the bool form below the compiler emits the compare and its complement), and the index of
         // the last contributing splat is moved under the hit mask instead of through a VGPR copy and a select: 24 VALU
-        // instructions per visit instead of 26, 54.9 -> 51.8 us at config #1
+        // instructions per visit instead of 26, 54.9 -> 51.8 us at config #1.  Round 4: a wave issues ONE instruction of any kind
+        // per turn of its SIMD and the visit is a dependent chain, so its twenty scalar instructions count at low residency (the
+        // launch's last third): the batch slot j itself is what moves (contrib0 + j + 1 is formed once per batch, behind the walk),
+        // exec is saved and narrowed by one s_and_saveexec_b64, the visited bit cleared by one s_bitset0_b64: 46 -> 42
+        // instructions per visit, 47.9 -> 46.0 us with the bit clear alone
         const float dx = a.x - pix.x[0], dy = a.y - pix.y[0];
         const float power  = dx * (a.z * dx + a.w * dy) + (b.x * dy) * dy;
         const float alpha  = fminf(0.99f, b.y * blend_exp2(power));
@@ -172,20 +180,18 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
         const unsigned long long m_hit = m_valid & ~m_lt, m_stop = m_valid & m_lt;
         const float aT = alpha * Tr[0];
         float wgt;
-        const uint32_t idx1 = contrib0 + j + 1;
         asm("v_cndmask_b32_e64 %0, 0, %3, %5\n\t"
             "v_cndmask_b32_e64 %1, %1, %4, %5\n\t"
-            "s_mov_b64 s[2:3], exec\n\t"
-            "s_and_b64 exec, exec, %5\n\t"
+            "s_and_saveexec_b64 s[2:3], %5\n\t"
             "v_mov_b32_e32 %2, %6\n\t"
             "s_mov_b64 exec, s[2:3]"
-            : "=&v"(wgt), "+v"(Tr[0]), "+v"(last[0])
-            : "v"(aT), "v"(test_T), "s"(m_hit), "s"(idx1)
-            : "s2", "s3");
+            : "=&v"(wgt), "+v"(Tr[0]), "+v"(lastj)
+            : "v"(aT), "v"(test_T), "s"(m_hit), "s"(j)
+            : "s2", "s3", "scc");
         done_m |= m_stop;
         if constexpr (CENSUS) {
           const bool h = (m_hit >> lane) & 1ull;
-          cen_n[0] += h ? 1u : 0u, cen_h[0] += h ? census_mix(idx1) : 0u;
+          cen_n[0] += h ? 1u : 0u, cen_h[0] += h ? census_mix(contrib0 + j + 1) : 0u;
         }
         C[0][0] += b.z * wgt;
         C[0][1] += b.w * wgt;
@@ -216,6 +222,9 @@ __global__ void __launch_bounds__(64) render_forward_kernel(int W, int H, int gx
       }
 #endif
     }
+#if !SKGS_STRICT
+    if constexpr (LANE_MASKS) last[0] = lastj != 0xffffffffu ? contrib0 + lastj + 1 : last[0];
+#endif
   }
   const size_t HW = (size_t) H * W;
 #pragma unroll
@@ -322,6 +331,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(int W, int H, int g
       relevant = splat_reaches_rect(a.x, a.y, a.z, a.w, b.x, c.w, rect);
     }
     __syncthreads();
+    // (the forward's walk clears the bit with s_bitset0_b64; here, at eight waves per SIMD throughout and VALU-bound, that form
+    // measured 1 us SLOWER)
     for (unsigned long long todo = __ballot(relevant); todo; todo &= todo - 1) {
       const int j      = __builtin_ctzll(todo);
       const uint32_t k = (uint32_t) (hi - 1 - j - start);
