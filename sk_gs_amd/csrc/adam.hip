@@ -53,7 +53,10 @@ struct ViewAdvance {
   uint32_t* slot;
   int n, words;
 };
-// advance = 1 (small grids only): the last workgroup out moves the counter and clears `zero_after` itself
+// advance = 1 (small grids only): the last workgroup out moves the counter and clears `zero_after` itself.  What it does there is
+// stores only: the state's words were read with the coefficients at the start, and the view advance -- which depends on nothing
+// this launch computes -- is the job of ONE EXTRA workgroup (the grid's last, no chunk of its own) that walks its chain of three
+// dependent loads (cursor -> order -> record) beside the others' update instead of behind the ticket: 10.1 -> ~7 us.
 __global__ void __launch_bounds__(ADAM_THREADS) adam_step_kernel(int n_tensors, const AdamTensor* __restrict__ tensors,
     int64_t chunk_begin, int64_t total_chunks, double beta1d, double beta2d, float eps, AdamState* __restrict__ state,
     int advance, float* __restrict__ zero_after, int64_t zero_n, FreqJob job, ViewAdvance va) {
@@ -62,6 +65,17 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_step_kernel(int n_tensors, 
   const AdamTensorLanes desc = adam_load_descriptors(tensors, n_tensors, lane);
   const int64_t first0 = lane < n_tensors ? tensors[lane].chunk0 : INT64_MAX;
   const AdamCoef k = adam_coefficients(beta1d, beta2d, eps, state);
+  double pf_q1 = 0.0, pf_q2 = 0.0;
+  float pf_count = 0.f;
+  if (advance) pf_q1 = state->q1, pf_q2 = state->q2, pf_count = state->count;
+  if (advance && va.slot && blockIdx.x == gridDim.x - 1) {  // the extra workgroup: next view's record -> the live slot
+    const int c = va.cursor[0];
+    const int n = va.n > 0 ? va.n : max(va.cursor[1], 1);  // n_order = 0: the order's length is a device word too
+    const uint32_t* rec = va.table + (size_t) va.order[c % n] * va.words;
+    for (int i = threadIdx.x; i < va.words; i += ADAM_THREADS) va.slot[i] = rec[i];
+    __syncthreads();  // every thread has read the cursor
+    if (threadIdx.x == 0) va.cursor[0] = c + 1;
+  }
   for (int64_t chunk = chunk_begin + blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
     if (chunk == job.chunk) run_freq_job(job);
     const int ti = adam_owner(tensors, n_tensors, first0, lane, chunk);
@@ -75,16 +89,10 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_step_kernel(int n_tensors, 
     __syncthreads();
     if (s_last) {
       for (int64_t i = threadIdx.x; i < zero_n; i += ADAM_THREADS) zero_after[i] = 0.f;
-      if (va.slot) {
-        const int c = va.cursor[0];
-        const int n = va.n > 0 ? va.n : max(va.cursor[1], 1);  // n_order = 0: the order's length is a device word too
-        const uint32_t* rec = va.table + (size_t) va.order[c % n] * va.words;
-        for (int i = threadIdx.x; i < va.words; i += ADAM_THREADS) va.slot[i] = rec[i];
-        __syncthreads();  // every thread has read the cursor
-        if (threadIdx.x == 0) va.cursor[0] = c + 1;
-      }
-      if (threadIdx.x == 0) {
-        adam_advance(state, beta1d, beta2d);
+      if (threadIdx.x == 0) {  // adam_advance's expressions on the words read at the start (nobody has written them since)
+        state->count  = pf_count + 1.0f;
+        state->q1     = (1.0 - beta1d) + beta1d * pf_q1;
+        state->q2     = (1.0 - beta2d) + beta2d * pf_q2;
         state->ticket = 0u;
       }
     }
@@ -215,7 +223,8 @@ int step_range_impl(int32_t n_tensors, const void* tensors, int64_t chunk_begin,
   SKGS_REQUIRE(!va.slot || self_advance, "adam_step_tail: the view advance rides on a short closing piece (<= 256 chunks)");
   ProfScope prof(K_ADAM, s);
   if (nc > 0) {
-    const int grid = (int) std::min<int64_t>(nc, 256 * 16);
+    // (+ 1: the view advance's own workgroup; self_advance grids are one chunk per workgroup, so it finds no chunk)
+    const int grid = (int) std::min<int64_t>(nc, 256 * 16) + ((self_advance && va.slot) ? 1 : 0);
     hipLaunchKernelGGL(adam_step_kernel, dim3(grid), dim3(ADAM_THREADS), 0, s, n_tensors,
         reinterpret_cast<const AdamTensor*>(tensors), chunk_begin, chunk_end, beta1, beta2, (float) eps, state,
         self_advance ? 1 : 0, zero_after, zn, job, va);
