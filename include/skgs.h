@@ -17,6 +17,8 @@
  *   skgs_mark_visible            <- mark_visible (commented out)      my_ext/_C/src/nerf/gaussian_rasterizer_imp.cu:75-103
  *   skgs_lbs_deform_forward/backward <- networks/sk_gs.py:1143-1150,1162,1192-1203 (+ lietorch SE3.act, lie.h:59-64,246)
  *   skgs_knn_bones               <- pytorch3d.ops.knn_points call     networks/sk_gs.py:757
+ *   skgs_se3_blend_forward/backward <- (sk_T[indices].act(points[:, None]) * weights[..., None]).sum(1)  networks/sk_gs.py:1147,814
+ *                                   as lietorch executes it (gather + act + mul + sum), tangent-space gradients (lie_cpu.cpp:217-236)
  *   skgs_knn_dist_weights_*      <- calc_LBS_weight, `weighted_kernel` / `kernel` / `dist` branches  networks/sk_gs.py:757-766,770
  *
  * Opaque buffers (the reference's geomBuffer / binningBuffer / imgBuffer uint8 tensors, gaussian_render.h:118-158):
@@ -349,6 +351,23 @@ int skgs_knn_lbs_deform_forward(int32_t P, int32_t M, int32_t K, const float* po
     const float* rot, const float* opacity_logit, int64_t* out_idx, float* out_weights, float* means, float* scales,
     float* rotations, float* opacity, const int32_t* live_count /* may be NULL */,
     skgs_stream_t stream);
+
+/* ---- the reference's own skinning expression, for the lietorch stand-in (sk_gs_amd/lietorch.py) ----
+ *   out[n] = sum_k weights[n,k] * SE3(T[indices[n,k]]).act(points[n])        networks/sk_gs.py:1147,814,1478  (weights NULL: 1;
+ *                                                                             K = 1, no weights: :816,1481 `spT[p2sp].act(points)`)
+ * which lietorch executes as gather [P,K,7] + act (lie.h:59-64,246; the SE3 constructor normalises q, lie.h:45-47) + mul + sum.
+ * Backward in lietorch's convention (my_ext/_C/src/ops_3d/lie_cpu.cpp:217-236): g_T [M,7] holds the LEFT-TANGENT gradient
+ * (tau, phi) = sum over the gathering rows of c [I | -hat(X p)], c = weights * g_out, in slots 0..5 and 0 in slot 6 -- what the
+ * reference's chain of lietorch ops above `sk_T` expects; g_weights [P,K] = g_out . X p (NULL to skip, required NULL without
+ * weights); g_points [P,3] = sum_k c R (NULL to skip: the reference detaches the points, sk_gs.py:833,1113).  Any M: tables of
+ * up to 1024 bones are staged (and their gradient rows summed) in LDS, one partial per workgroup added in a fixed order by a
+ * second launch (the order INSIDE a workgroup is the LDS atomics'); larger ones use global atomics. */
+int skgs_se3_blend_forward(int32_t P, int32_t K, int32_t M, const float* T, const int64_t* indices, const float* points,
+    const float* weights, float* out, skgs_stream_t stream);
+size_t skgs_se3_blend_backward_workspace_bytes(int32_t P, int32_t M);
+int skgs_se3_blend_backward(int32_t P, int32_t K, int32_t M, const float* T, const int64_t* indices, const float* points,
+    const float* weights, const float* g_out, float* g_T, float* g_weights, float* g_points, void* workspace,
+    size_t workspace_bytes, skgs_stream_t stream);
 
 /* ---- bone chain (scope row a-3): joint rotations -> global bone transforms, one launch per direction ----
  * Replaces kinematic() + skeleton_warp_SE3() (networks/sk_gs.py:1069-1107,193-206; lietorch SE3 product lie.h:242-246).

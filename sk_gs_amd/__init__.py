@@ -7,6 +7,8 @@ Layout (only what the path needs):
   renderer/gaussian_render  mirror of networks/renderer/gaussian_render.py
   diff_gaussian_rasterization  upstream-compatible front end (variant A of the boundary)
   deform.py / skeleton.py   lbs_deform autograd op, bone chain
+  lietorch.py / pytorch3d_ops.py  stand-ins for the two CUDA-only packages networks/sk_gs.py imports (SE3 / SO3, knn_points): the
+                            reference's deform runs UNMODIFIED on them, its skinning expression and search as launches of the library
   scene.py / model.py       synthetic scenes and the minimal skinned-Gaussian module used by tests and bench
   view_parallel.py          one-process-per-GPU view-parallel gradient all-reduce (RCCL)
 """
@@ -90,6 +92,53 @@ def uninstall_my_ext_C():
         m = sys.modules.get(name)
         if m is not None and getattr(m, '_sk_gs_amd_stand_in', False):
             del sys.modules[name]
+
+
+def install_as_lietorch():
+    """``from lietorch import SE3, SO3`` (networks/sk_gs.py:12, networks/gaussian_splatting.py:27, networks/GS_utils.py:7) resolves to
+    ``sk_gs_amd.lietorch``: the reference's deform -- ``skeleton_warp_SE3``, ``kinematic``, ``warp``, ``sk_stage``, ``sp_stage``, its
+    Lie-group losses -- runs unmodified, pure torch on any device, with the per-Gaussian skinning expression
+    ``(sk_T[indices].act(points[:, None]) * weights[..., None]).sum(dim=1)`` as one launch of libskgs_hip.so on a HIP device.  Refuses
+    to shadow a real lietorch that is already imported."""
+    import sys
+    from sk_gs_amd import lietorch as m
+    have = sys.modules.get('lietorch')
+    if have is not None and have is not m:
+        raise RuntimeError('sk_gs_amd.install_as_lietorch(): a different `lietorch` module is already imported')
+    sys.modules['lietorch'] = m
+    return m
+
+
+def install_as_pytorch3d():
+    """``from pytorch3d.ops import knn_points`` (networks/sk_gs.py:11; ``import pytorch3d.ops`` / ``ball_query`` in
+    networks/losses/SC_GS_arap_loss.py:5-7) resolves to ``sk_gs_amd.pytorch3d_ops``: ``knn_points`` of calc_LBS_weight
+    (sk_gs.py:757) is one launch of libskgs_hip.so on a HIP device.  Refuses to shadow a real pytorch3d that is already imported."""
+    import sys
+    import types
+    from sk_gs_amd import pytorch3d_ops as ops
+    have = sys.modules.get('pytorch3d')
+    if have is not None and not getattr(have, '_sk_gs_amd_stand_in', False):
+        raise RuntimeError('sk_gs_amd.install_as_pytorch3d(): a different `pytorch3d` package is already imported')
+    if have is None:
+        pkg = types.ModuleType('pytorch3d')
+        pkg.__path__ = []
+        pkg._sk_gs_amd_stand_in = True
+        pkg.__version__ = '0.0.0+sk_gs_amd'
+        pkg.ops = ops
+        sys.modules['pytorch3d'] = pkg
+    sys.modules['pytorch3d.ops'] = ops
+    return ops
+
+
+def install_reference_hooks(single_thread: bool = True):
+    """Everything an unmodified checkout of the reference needs from this package on an MI355X machine, in one call made BEFORE
+    ``import my_ext`` / ``import networks`` / ``import train``: the compiled ops behind ``my_ext._C`` (``install_as_my_ext_C``), the
+    shipped configs' rasterizer package (``install_as_diff_gaussian_rasterization``), and the two CUDA-only third-party packages of
+    the deform (``install_as_lietorch``, ``install_as_pytorch3d``).  INTEGRATION.md section 1."""
+    install_as_my_ext_C(single_thread=single_thread)
+    install_as_diff_gaussian_rasterization(single_thread=single_thread)
+    install_as_lietorch()
+    install_as_pytorch3d()
 
 
 def install_as_diff_gaussian_rasterization(single_thread: bool = True):

@@ -126,10 +126,12 @@ _HOOK_SCRIPT = r"""
 import sys, warnings
 sys.dont_write_bytecode = True
 sys.path[:0] = [{root!r}, {golden!r}, {ref!r}]
-import make_golden                                  # only for its stub finder: lietorch, pytorch3d, cv2 ... are not in this image
+import make_golden                                  # only for its stub finder: cv2, imageio, plyfile ... are not in this image
+make_golden.STUBS = make_golden.STUBS - {{'lietorch', 'pytorch3d', 'diff_gaussian_rasterization'}}   # NOT stubbed: served by this package
 sys.meta_path.insert(0, make_golden._Finder())
 import sk_gs_amd
-sk_gs_amd.install_as_my_ext_C()                     # INTEGRATION.md section 2, verbatim
+sk_gs_amd.install_reference_hooks()                 # INTEGRATION.md sections 2-4, verbatim: my_ext._C._C, diff_gaussian_rasterization,
+                                                    # lietorch, pytorch3d.ops
 with warnings.catch_warnings(record=True) as caught:
     warnings.simplefilter('always')
     import my_ext                                   # the reference's packages, unmodified, from {ref!r}
@@ -137,6 +139,12 @@ with warnings.catch_warnings(record=True) as caught:
     from networks.encoders import freq_encoder
     import networks.sk_gs, networks.gaussian_splatting
 assert my_ext.__file__.startswith({ref!r}) and my_ext._C.__file__.startswith({ref!r}), (my_ext.__file__, my_ext._C.__file__)
+# the deform's two third-party imports (networks/sk_gs.py:11-12) are this package's stand-ins, the shipped configs' rasterizer its shim
+from sk_gs_amd import lietorch as _lt, pytorch3d_ops as _p3d
+assert networks.sk_gs.SE3 is _lt.SE3 and networks.sk_gs.SO3 is _lt.SO3 and networks.sk_gs.knn_points is _p3d.knn_points
+assert networks.gaussian_splatting.SO3 is _lt.SO3
+import networks.renderer.gaussian_render_origin as _gro, sk_gs_amd.diff_gaussian_rasterization as _dgr
+assert _gro.GaussianRasterizer is _dgr.GaussianRasterizer
 from sk_gs_amd import _C
 assert my_ext._C._C is _C.pybind_module()
 for name in _C.PYBIND_NAMES:                        # every op of the path resolves to this package through THEIR lookup
@@ -171,7 +179,8 @@ def test_unmodified_reference_imports_through_the_hook():
     networks/sk_gs.py and networks/gaussian_splatting.py are imported UNMODIFIED after install_as_my_ext_C(), and every
     one of the path's eight op names resolves, through the reference's own get_C_function, to this package.  Runs in a
     child process (the reference's packages stay out of this session); third-party modules the image lacks are the
-    inert stubs of tests/golden/make_golden.py.  Nothing here computes: no GPU."""
+    inert stubs of tests/golden/make_golden.py -- except lietorch, pytorch3d and diff_gaussian_rasterization, which resolve to
+    this package (install_reference_hooks).  Nothing here computes: no GPU (tests/test_lietorch_standin.py runs the deform)."""
     code = _HOOK_SCRIPT.format(root=ROOT, golden=os.path.join(ROOT, 'tests', 'golden'), ref=_REFERENCE)
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd='/tmp', env=env, timeout=600)
