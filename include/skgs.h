@@ -19,6 +19,7 @@
  *   skgs_knn_bones               <- pytorch3d.ops.knn_points call     networks/sk_gs.py:757
  *   skgs_se3_blend_forward/backward <- (sk_T[indices].act(points[:, None]) * weights[..., None]).sum(1)  networks/sk_gs.py:1147,814
  *                                   as lietorch executes it (gather + act + mul + sum), tangent-space gradients (lie_cpu.cpp:217-236)
+ *   skgs_lie_forward/backward    <- lietorch's backend ops (lie_expm ... lie_act4 and their backward)  my_ext/_C/src/ops_3d/lie_torch.cpp:357-385
  *   skgs_knn_dist_weights_*      <- calc_LBS_weight, `weighted_kernel` / `kernel` / `dist` branches  networks/sk_gs.py:757-766,770
  *
  * Opaque buffers (the reference's geomBuffer / binningBuffer / imgBuffer uint8 tensors, gaussian_render.h:118-158):
@@ -368,6 +369,28 @@ size_t skgs_se3_blend_backward_workspace_bytes(int32_t P, int32_t M);
 int skgs_se3_blend_backward(int32_t P, int32_t K, int32_t M, const float* T, const int64_t* indices, const float* points,
     const float* weights, const float* g_out, float* g_T, float* g_weights, float* g_points, void* workspace,
     size_t workspace_bytes, skgs_stream_t stream);
+
+/* ---- Lie-group operators for the lietorch stand-in (sk_gs_amd/lietorch.py): lietorch's backend, one launch per operator ----
+ * What `lietorch_backends` is to upstream lietorch and my_ext/_C/src/ops_3d/lie_{cpu.cpp,gpu.cu,torch.cpp} (pybind `lie_expm`,
+ * `lie_logm`, `lie_inv`, `lie_mul`, `lie_adj`, `lie_adjT`, `lie_act`, `lie_act4` + `_backward`, `lie_projector`;
+ * lie_torch.cpp:357-385) restate in the reference tree.  group: lietorch's id, 1 = SO3 (K = 3 tangent, N = 4 embedding, q_xyzw),
+ * 3 = SE3 (K = 6 = (tau, phi), N = 7 = (t, q)).  Rows are contiguous [B, width]; one lane per row.
+ *   op  forward                         X      Y      out   | backward: grad (out's width) -> dX, dY (either may be NULL)
+ *   0   exp   a -> X                    [K]    -      [N]   | da = dX[:K] J_l(a)                                  lie_cpu.cpp:25-38
+ *   1   log   X -> a                    [N]    -      [K]   | dX = da J_l^-1(log X)                               :54-67
+ *   2   inv                             [N]    -      [N]   | dX = -dY Adj(X^-1)                                  :84-97
+ *   3   mul   X * Y                     [N]    [N]    [N]   | dX = dZ, dY = dZ Adj(X)                             :111-126
+ *   4   adj   Adj(X) a                  [N]    [K]    [K]   | dX = -db adj(Adj(X) a), da = db Adj(X)              :143-162
+ *   5   adjT  Adj(X)^T a                [N]    [K]    [K]   | dX = -a adj(Adj(X) db), da = Adj(X) db              :179-198
+ *   6   act   X p                       [N]    [3]    [3]   | dX = dq [I | -hat(X p)], dp = dq R                  :217-236
+ *   7   act4  X p (homogeneous)         [N]    [4]    [4]   | dX = dq act4_jacobian(X p), dp = dq Matrix4x4       :288-309
+ *   8   vec()        (backward only: the forward is the identity)   dX = grad J,  J = orthogonal_projector(X)     lie.h:82-90,303-311
+ *   9   InitFromVec  (backward only)                                dX = grad pinv(J) = (tau, 4 J_q (phi - t x tau))
+ * Gradients of group elements are LEFT-TANGENT row vectors in the first K of their N slots, the remaining slots written 0.  Every
+ * constructor normalises the quaternion (lie.h:45-47); small-angle series below 1e-6 (lie.h:23). */
+int skgs_lie_forward(int32_t group, int32_t op, int64_t B, const float* X, const float* Y, float* out, skgs_stream_t stream);
+int skgs_lie_backward(int32_t group, int32_t op, int64_t B, const float* grad, const float* X, const float* Y, float* dX, float* dY,
+    skgs_stream_t stream);
 
 /* ---- bone chain (scope row a-3): joint rotations -> global bone transforms, one launch per direction ----
  * Replaces kinematic() + skeleton_warp_SE3() (networks/sk_gs.py:1069-1107,193-206; lietorch SE3 product lie.h:242-246).

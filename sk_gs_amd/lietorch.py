@@ -24,8 +24,10 @@ Semantics follow the vendored copy of lietorch's C++ core in the reference (the 
   (J_q^T J_q = I/4 for the unit quaternion the constructor produces): pinv = [[I, -4 hat(-t) J_q^T], [0, 4 J_q^T]] -- checked
   against ``torch.linalg.pinv`` in tests/test_lietorch_standin.py.
 
-Every op is a pure-torch ``autograd.Function`` on any device (this is what runs on CPU, and for the M-row chains -- skeleton_warp_SE3
-over 20 bones -- on the GPU).  The one P-sized pattern of the per-frame path,
+Every op is an ``autograd.Function`` with a pure-torch body (any device and dtype: what runs on CPU) and, for fp32 rows on a HIP
+device, ONE launch of libskgs_hip.so per direction (``skgs_lie_forward`` / ``skgs_lie_backward``, csrc/lie_ops.hip -- lietorch's
+backend; the torch bodies are ~40-60 small kernels per operator, which made the 20-bone chain of stage `sk` 30 ms of launches per
+step).  ``SKGS_LIE_HIP_OPS=0`` keeps the torch bodies.  The one P-sized pattern of the per-frame path,
 
     (sk_T[indices].act(points[:, None]) * weights[..., None]).sum(dim=1)          sk_gs.py:1147, 814, 1478
     spT[self.p2sp].act(points)                                                     sk_gs.py:816, 1481
@@ -384,23 +386,77 @@ _MATH = {_SO3Math.group_id: _SO3Math, _SE3Math.group_id: _SE3Math}
 
 
 # ------------------------------------------------------------------------------------------------ group ops (autograd)
+def _on_hip(*ts) -> bool:
+    """the operator's rows live on a HIP device in fp32: libskgs_hip.so's launch (skgs_lie_forward / _backward, csrc/lie_ops.hip)
+    serves it; anything else (CPU tensors, fp64 -- the tests' finite differences) takes the pure-torch body below"""
+    return _HIP_OPS and all(t.is_cuda and t.dtype == torch.float32 for t in ts)
+
+
+_HIP_OPS = os.environ.get('SKGS_LIE_HIP_OPS', '1') != '0'
+hip_op_calls = {'forward': 0, 'backward': 0}  # counters (tests)
+
+
+def _hip_forward(G, op: int, out_width: int, X: Tensor, Y: Optional[Tensor] = None) -> Tensor:
+    from sk_gs_amd import _C
+    lib = _C.load_library()
+    with _C._on_device(X.device):
+        X = X.contiguous()
+        Y = None if Y is None else Y.contiguous()
+        out = torch.empty((X.shape[0], out_width), dtype=torch.float32, device=X.device)
+        _C._check(lib.skgs_lie_forward(C.c_int32(G.group_id), C.c_int32(op), C.c_int64(X.shape[0]), C.c_void_p(_C._ptr(X)), C.c_void_p(_C._ptr(Y)),
+                                       C.c_void_p(_C._ptr(out)), _C._stream()))
+    hip_op_calls['forward'] += 1
+    return out
+
+
+def _hip_backward(G, op: int, grad: Tensor, X: Tensor, Y: Optional[Tensor] = None, need=(True, True)):
+    from sk_gs_amd import _C
+    lib = _C.load_library()
+    with _C._on_device(X.device):
+        grad, X = grad.contiguous(), X.contiguous()
+        Y = None if Y is None else Y.contiguous()
+        dX = torch.empty_like(X) if need[0] else None
+        dY = torch.empty_like(Y) if (Y is not None and need[1]) else None
+        if dX is not None or dY is not None:
+            _C._check(lib.skgs_lie_backward(C.c_int32(G.group_id), C.c_int32(op), C.c_int64(X.shape[0]), C.c_void_p(_C._ptr(grad)),
+                                            C.c_void_p(_C._ptr(X)), C.c_void_p(_C._ptr(Y)), C.c_void_p(_C._ptr(dX)), C.c_void_p(_C._ptr(dY)),
+                                            _C._stream()))
+    hip_op_calls['backward'] += 1
+    return (dX,) if Y is None else (dX, dY)
+
+
 class _GroupOp(torch.autograd.Function):
     """lietorch/group_ops.py GroupOp: forward(group_id, *inputs) on [B, dim] rows; backward hands the row-vector gradients of
-    lie_cpu.cpp back (N wide for group elements)."""
+    lie_cpu.cpp back (N wide for group elements).  Rows on a HIP device: one launch of csrc/lie_ops.hip per direction (`hip_op`:
+    the operator's number there); otherwise the pure-torch ``forward_op`` / ``backward_op``."""
+    hip_op = None
+
+    @classmethod
+    def out_width(cls, G):
+        return G.N
 
     @classmethod
     def forward(cls, ctx, group_id, *inputs):
         ctx.group_id = group_id
         ctx.save_for_backward(*inputs)
-        return cls.forward_op(_MATH[group_id], *inputs)
+        G = _MATH[group_id]
+        if cls.hip_op is not None and _on_hip(*inputs) and inputs[0].shape[0] > 0:
+            return _hip_forward(G, cls.hip_op, cls.out_width(G), *inputs)
+        return cls.forward_op(G, *inputs)
 
     @classmethod
     @torch.autograd.function.once_differentiable
     def backward(cls, ctx, grad):
-        return (None,) + tuple(cls.backward_op(_MATH[ctx.group_id], grad.contiguous(), *ctx.saved_tensors))
+        G = _MATH[ctx.group_id]
+        inputs = ctx.saved_tensors
+        if cls.hip_op is not None and _on_hip(grad, *inputs) and inputs[0].shape[0] > 0:
+            return (None,) + tuple(_hip_backward(G, cls.hip_op, grad, *inputs, need=ctx.needs_input_grad[1:] + (True,)))
+        return (None,) + tuple(cls.backward_op(G, grad.contiguous(), *inputs))
 
 
 class Exp(_GroupOp):
+    hip_op = 0
+
     @staticmethod
     def forward_op(G, a):
         return G.exp(a)
@@ -411,6 +467,12 @@ class Exp(_GroupOp):
 
 
 class Log(_GroupOp):
+    hip_op = 1
+
+    @classmethod
+    def out_width(cls, G):
+        return G.K
+
     @staticmethod
     def forward_op(G, X):
         return G.log(X)
@@ -421,6 +483,8 @@ class Log(_GroupOp):
 
 
 class Inv(_GroupOp):
+    hip_op = 2
+
     @staticmethod
     def forward_op(G, X):
         return G.inv(X)
@@ -431,6 +495,8 @@ class Inv(_GroupOp):
 
 
 class Mul(_GroupOp):
+    hip_op = 3
+
     @staticmethod
     def forward_op(G, X, Y):
         return G.mul(X, Y)
@@ -442,6 +508,12 @@ class Mul(_GroupOp):
 
 
 class Adj(_GroupOp):
+    hip_op = 4
+
+    @classmethod
+    def out_width(cls, G):
+        return G.K
+
     @staticmethod
     def forward_op(G, X, a):
         return (G.Adj(X) @ a.unsqueeze(-1)).squeeze(-1)
@@ -454,6 +526,12 @@ class Adj(_GroupOp):
 
 
 class AdjT(_GroupOp):
+    hip_op = 5
+
+    @classmethod
+    def out_width(cls, G):
+        return G.K
+
     @staticmethod
     def forward_op(G, X, a):
         return (G.Adj(X).transpose(-1, -2) @ a.unsqueeze(-1)).squeeze(-1)
@@ -465,6 +543,12 @@ class AdjT(_GroupOp):
 
 
 class Act3(_GroupOp):
+    hip_op = 6
+
+    @classmethod
+    def out_width(cls, G):
+        return 3
+
     @staticmethod
     def forward_op(G, X, p):
         return G.act(X, p)
@@ -476,6 +560,12 @@ class Act3(_GroupOp):
 
 
 class Act4(_GroupOp):
+    hip_op = 7
+
+    @classmethod
+    def out_width(cls, G):
+        return 4
+
     @staticmethod
     def forward_op(G, X, p):
         return G.act4(X, p)
@@ -523,6 +613,8 @@ class FromVec(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad):
         (a,) = ctx.saved_tensors
+        if _on_hip(grad, a) and a.shape[0] > 0:
+            return None, _hip_backward(_MATH[ctx.group_id], 9, grad, a)[0]
         return None, _MATH[ctx.group_id].from_tangent(a, grad)
 
 
@@ -539,6 +631,8 @@ class ToVec(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad):
         (X,) = ctx.saved_tensors
+        if _on_hip(grad, X) and X.shape[0] > 0:
+            return None, _hip_backward(_MATH[ctx.group_id], 8, grad, X)[0]
         return None, _MATH[ctx.group_id].to_tangent(X, grad)
 
 
@@ -716,6 +810,10 @@ class LieGroup:
     def __init__(self, data: Tensor):
         self.data = data
 
+    def _new(self, data: Tensor):
+        """a group of this element's kind around `data` (upstream: ``self.__class__(data)``)"""
+        return type(self)(data)
+
     def __repr__(self):
         return '{}: size={}, device={}, dtype={}'.format(self.group_name, self.shape, self.device, self.dtype)
 
@@ -798,15 +896,15 @@ class LieGroup:
         return self.apply_op(Log, self.data)
 
     def inv(self):
-        return self.__class__(self.apply_op(Inv, self.data))
+        return self._new(self.apply_op(Inv, self.data))
 
     def mul(self, other):
-        return self.__class__(self.apply_op(Mul, self.data, other.data))
+        return self._new(self.apply_op(Mul, self.data, other.data))
 
     def retr(self, a: Tensor):
         """retraction: Exp(a) * X"""
         dX = self.__class__.apply_op(Exp, a)
-        return self.__class__(self.apply_op(Mul, dX, self.data))
+        return self._new(self.apply_op(Mul, dX, self.data))
 
     def adj(self, a: Tensor) -> Tensor:
         return self.apply_op(Adj, self.data, a)
@@ -828,7 +926,7 @@ class LieGroup:
         """[..., 4, 4]; differentiable (the action on the identity's columns, as upstream)"""
         I = torch.eye(4, dtype=self.dtype, device=self.device)
         I = I.view([1] * (len(self.data.shape) - 1) + [4, 4])
-        return self.__class__(self.data[..., None, :]).act(I).transpose(-1, -2)
+        return self._new(self.data[..., None, :]).act(I).transpose(-1, -2)
 
     def translation(self) -> Tensor:
         p = torch.as_tensor([0.0, 0.0, 0.0, 1.0], dtype=self.dtype, device=self.device)
@@ -837,10 +935,10 @@ class LieGroup:
 
     # -- tensor-like plumbing
     def detach(self):
-        return self.__class__(self.data.detach())
+        return self._new(self.data.detach())
 
     def view(self, dims):
-        return self.__class__(self.data.view(tuple(dims) + (self.embedded_dim,)))
+        return self._new(self.data.view(tuple(dims) + (self.embedded_dim,)))
 
     def __mul__(self, other):
         if isinstance(other, LieGroup):
@@ -850,7 +948,7 @@ class LieGroup:
         return NotImplemented
 
     def __getitem__(self, index):
-        return self.__class__(self.data[index])
+        return self._new(self.data[index])
 
     def __setitem__(self, index, item):
         self.data[index] = item.data
@@ -859,22 +957,22 @@ class LieGroup:
         return self.data.shape[0]
 
     def to(self, *args, **kwargs):
-        return self.__class__(self.data.to(*args, **kwargs))
+        return self._new(self.data.to(*args, **kwargs))
 
     def cpu(self):
-        return self.__class__(self.data.cpu())
+        return self._new(self.data.cpu())
 
     def cuda(self):
-        return self.__class__(self.data.cuda())
+        return self._new(self.data.cuda())
 
     def float(self, device=None):
-        return self.__class__(self.data.float())
+        return self._new(self.data.float())
 
     def double(self, device=None):
-        return self.__class__(self.data.double())
+        return self._new(self.data.double())
 
     def unbind(self, dim=0):
-        return [self.__class__(x) for x in self.data.unbind(dim=dim)]
+        return [self._new(x) for x in self.data.unbind(dim=dim)]
 
 
 class SO3(LieGroup):
@@ -915,6 +1013,9 @@ class _GatheredSE3Proxy(SE3):
 
     def __init__(self, base: Tensor, index: Tensor):
         self._base, self._index, self._rows = base, index, None
+
+    def _new(self, data: Tensor):
+        return SE3(data)
 
     @property
     def data(self):

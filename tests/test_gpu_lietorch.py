@@ -151,3 +151,56 @@ def test_reference_sequence_equals_the_fused_operators():
         assert rel_err(res[k], got) <= 2e-6, k
     for k in ('_xyz', '_scaling', '_rotation', '_opacity', 'sp_W', 'net_d_rot', 'net_d_scale', 'net_sk_r', 'joints', 'global_tr'):
         assert rel_err(a[k].grad, b[k].grad) <= 5e-5, (k, rel_err(a[k].grad, b[k].grad))
+
+
+@pytest.mark.parametrize('group', ['SO3', 'SE3'])
+def test_hip_group_operators_against_the_torch_bodies(group):
+    """csrc/lie_ops.hip (one launch per operator and direction) against the pure-torch bodies evaluated in fp64 on the CPU: every
+    operator of both groups, values and gradients (tangent rows for group arguments), incl. the small-angle series"""
+    L, _ = _mods()
+    G = {'SO3': L.SO3, 'SE3': L.SE3}[group]
+    K, N = G._math.K, G._math.N
+    g = torch.Generator().manual_seed(17)
+    B = 3000
+    a = torch.randn(B, K, generator=g, dtype=torch.float64) * 0.8
+    a[:40, -3:] *= 1e-8                                                   # theta < 1e-6: the series branches
+    X = G.exp(a).data
+    Y = G.exp(torch.randn(B, K, generator=g, dtype=torch.float64)).data
+    X[:, -4:] *= 1.0 + 0.3 * torch.rand(B, 1, generator=g, dtype=torch.float64)   # un-normalised on purpose: the constructors normalise
+    tang = torch.randn(B, K, generator=g, dtype=torch.float64)
+    p3, p4 = torch.randn(B, 3, generator=g, dtype=torch.float64), torch.randn(B, 4, generator=g, dtype=torch.float64)
+    cases = {
+        'exp': (lambda x, y: G.exp(x).data, a, None),
+        'log': (lambda x, y: G(x).log(), X, None),
+        'inv': (lambda x, y: G(x).inv().data, X, None),
+        'mul': (lambda x, y: (G(x) * G(y)).data, X, Y),
+        'adj': (lambda x, y: G(x).adj(y), X, tang),
+        'adjT': (lambda x, y: G(x).adjT(y), X, tang),
+        'act': (lambda x, y: G(x).act(y), X, p3),
+        'act4': (lambda x, y: G(x).act(y), X, p4),
+        'vec': (lambda x, y: G(x).vec(), X, None),
+        'InitFromVec.act': (lambda x, y: G.InitFromVec(x).act(y), X, p3),
+    }
+    for name, (f, x0, y0) in cases.items():
+        res = {}
+        for where in ('hip', 'ref'):
+            conv = (lambda t: t.float().cuda()) if where == 'hip' else (lambda t: t.clone())
+            x = conv(x0).requires_grad_()
+            y = None if y0 is None else conv(y0).requires_grad_()
+            before = dict(L.hip_op_calls)
+            out = f(x, y)
+            c = torch.randn(out.shape, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+            (out * conv(c)).sum().backward()
+            if where == 'hip':
+                assert L.hip_op_calls['forward'] > before['forward'] or name == 'vec', name
+                assert L.hip_op_calls['backward'] > before['backward'], name
+            res[where] = (out.detach().cpu().double(), x.grad.cpu().double(), None if y is None else y.grad.cpu().double())
+        (o1, gx1, gy1), (o0, gx0, gy0) = res['hip'], res['ref']
+        if name in ('exp', 'inv', 'mul'):                                  # q and -q are the same rotation
+            s = torch.sign((o1[:, -4:] * o0[:, -4:]).sum(-1, keepdim=True))
+            o1 = torch.cat([o1[:, :-4], o1[:, -4:] * s], -1)
+        if name != 'vec':
+            assert rel_err(o1, o0) <= 3e-6, (group, name, rel_err(o1, o0))
+        assert rel_err(gx1, gx0) <= 2e-5, (group, name, 'dX', rel_err(gx1, gx0))
+        if gy0 is not None:
+            assert rel_err(gy1, gy0) <= 2e-5, (group, name, 'dY', rel_err(gy1, gy0))

@@ -245,10 +245,15 @@ def fixture():
     return np.load(os.path.join(GOLDEN, 'sk_stage.npz'))
 
 
+@pytest.mark.parametrize('recognise', [False, True])
 @pytest.mark.parametrize('name', sorted(rs.SCENARIOS))
-def test_replay_of_the_reference_run(fixture, name):
-    """the restated call sequence (tests/ref_sequence.py) on the stand-ins reproduces what the reference's own forward + backward gave"""
+def test_replay_of_the_reference_run(fixture, name, recognise, monkeypatch):
+    """the restated call sequence (tests/ref_sequence.py) on the stand-ins reproduces what the reference's own forward + backward gave;
+    `recognise`: with the deferred gather / skinning expression machinery of the HIP route switched on (evaluated by the generic ops here)"""
+    monkeypatch.setattr(L, '_FUSED_ON_CPU', recognise)
+    before = dict(L.fused_calls)
     res, out, got_grad, grad = rs.run_scenario(L, p3d.knn_points, fixture, name)
+    assert L.fused_calls['forward'] - before['forward'] == int(recognise) and L.fused_calls['materialised'] == before['materialised']
     assert torch.equal(res['_knn_i'], out['_knn_i'])
     for k, want in out.items():
         if k != '_knn_i':
