@@ -370,6 +370,15 @@ int skgs_se3_blend_backward(int32_t P, int32_t K, int32_t M, const float* T, con
     const float* weights, const float* g_out, float* g_T, float* g_weights, float* g_points, void* workspace,
     size_t workspace_bytes, skgs_stream_t stream);
 
+/* out [M,C] = sum over the R rows r of rows[r, :] filed under indices[r] (int64 in [0, M)): the backward of the reference's
+ * `table[indices]` gathers of per-bone rows (networks/sk_gs.py:1148-1149 `sk_d_rot[indices]`, `sk_d_scale[indices]`, :760-763
+ * `kernel_radius[indices]`, `kernel_weight[indices]`), R = P * K.  torch's index backward sorts the indices and walks every bone's
+ * duplicates serially (7.5 ms per gather at 100k x 5 rows into 20 bones on an MI355X); here: LDS rows per workgroup, one partial
+ * per workgroup, added in workgroup order by a second launch (tables beyond 48 KB: global atomics).  `out` is written completely. */
+size_t skgs_index_add_rows_workspace_bytes(int64_t R, int32_t C, int32_t M);
+int skgs_index_add_rows(int64_t R, int32_t C, int32_t M, const int64_t* indices, const float* rows, float* out, void* workspace,
+    size_t workspace_bytes, skgs_stream_t stream);
+
 /* ---- Lie-group operators for the lietorch stand-in (sk_gs_amd/lietorch.py): lietorch's backend, one launch per operator ----
  * What `lietorch_backends` is to upstream lietorch and my_ext/_C/src/ops_3d/lie_{cpu.cpp,gpu.cu,torch.cpp} (pybind `lie_expm`,
  * `lie_logm`, `lie_inv`, `lie_mul`, `lie_adj`, `lie_adjT`, `lie_act`, `lie_act4` + `_backward`, `lie_projector`;

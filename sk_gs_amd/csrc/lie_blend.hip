@@ -137,16 +137,60 @@ __global__ void __launch_bounds__(BLEND_THREADS) se3_blend_backward_kernel(const
   }
 }
 
+// one WAVE per output element: its lanes take the partials 64 apart, then a fixed-order butterfly (G is up to 512 partials: a lane
+// summing them alone is a chain of 512 dependent loads -- 94 us for 140 elements)
+__device__ __forceinline__ float wave_sum_partials(const float* __restrict__ partials, size_t stride, size_t offset, int G) {
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int g = lane; g < G; g += 64) s += partials[(size_t) g * stride + offset];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  return s;
+}
 __global__ void __launch_bounds__(BLEND_THREADS) se3_blend_reduce_kernel(int M, int G, const float* __restrict__ partials,
     float* __restrict__ g_T) {
-  const int i = blockIdx.x * BLEND_THREADS + threadIdx.x;  // (bone, slot) over [M,7]
+  const int i = (blockIdx.x * BLEND_THREADS + threadIdx.x) >> 6;  // (bone, slot) over [M,7]
   if (i >= 7 * M) return;
   const int j = i / 7, e = i % 7;
-  float s = 0.f;
-  if (e < 6)
-    for (int g = 0; g < G; ++g) s += partials[(size_t) g * 6 * M + 6 * j + e];
-  g_T[i] = s;  // slot 6: lietorch's gradient buffers are 7 wide with the tangent in the first 6 (lie_cpu.cpp:489)
+  const float s = e < 6 ? wave_sum_partials(partials, (size_t) 6 * M, (size_t) 6 * j + e, G) : 0.f;
+  if ((threadIdx.x & 63) == 0) g_T[i] = s;  // slot 6: lietorch's gradient buffers are 7 wide with the tangent in the first 6 (lie_cpu.cpp:489)
 }
+
+// out[idx[r], :] += g[r, :] over R rows of C floats: the backward of the reference's `table[indices]` gathers of per-bone rows
+// (sk_gs.py:1148-1149 `sk_d_rot[indices]`, `sk_d_scale[indices]`, :760-763 `kernel_radius[indices]`): torch's index backward sorts
+// the R = P * K indices and walks each bone's ~P * K / M duplicates serially -- 7.5 ms per gather at 100k x 5 into 20 rows on this
+// GPU.  Same scheme as the blend backward: LDS rows per workgroup, one partial per workgroup, a second launch adds them in order.
+template <bool IN_LDS>
+__global__ void __launch_bounds__(BLEND_THREADS) index_add_rows_kernel(long long R, int C, int M, const int64_t* __restrict__ idx,
+    const float* __restrict__ g, float* __restrict__ out, float* __restrict__ partials) {
+  extern __shared__ float s_acc[];
+  if (IN_LDS) {
+    for (int i = threadIdx.x; i < M * C; i += BLEND_THREADS) s_acc[i] = 0.f;
+    __syncthreads();
+  }
+  const long long n = R * C;
+  for (long long e = (long long) blockIdx.x * BLEND_THREADS + threadIdx.x; e < n; e += (long long) gridDim.x * BLEND_THREADS) {
+    const long long r = e / C;
+    const int c = (int) (e - r * C);
+    const int j = (int) idx[r];
+    if (IN_LDS)
+      atomicAdd(s_acc + j * C + c, g[e]);
+    else
+      atomicAdd(out + (size_t) j * C + c, g[e]);
+  }
+  if (IN_LDS) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < M * C; i += BLEND_THREADS) partials[(size_t) blockIdx.x * M * C + i] = s_acc[i];
+  }
+}
+__global__ void __launch_bounds__(BLEND_THREADS) index_add_reduce_kernel(int n, int G, const float* __restrict__ partials, float* __restrict__ out) {
+  const int i = (blockIdx.x * BLEND_THREADS + threadIdx.x) >> 6;
+  if (i >= n) return;
+  const float s = wave_sum_partials(partials, (size_t) n, (size_t) i, G);
+  if ((threadIdx.x & 63) == 0) out[i] = s;
+}
+constexpr int INDEX_ADD_LDS_FLOATS = 12 * 1024;  // 48 KB of rows per workgroup
+inline int index_add_grid(long long n) { return (int) std::max<long long>(1, std::min<long long>((n + BLEND_THREADS - 1) / BLEND_THREADS, BLEND_MAX_WG)); }
 
 inline int blend_grid(int P) { return std::max(1, std::min((P + BLEND_THREADS - 1) / BLEND_THREADS, BLEND_MAX_WG)); }
 
@@ -198,11 +242,42 @@ int skgs_se3_blend_backward(int32_t P, int32_t K, int32_t M, const float* T, con
     a.partials = reinterpret_cast<float*>(workspace);
     hipLaunchKernelGGL(se3_blend_backward_kernel<true>, dim3(grid), dim3(BLEND_THREADS), (size_t) M * 13 * 4, (hipStream_t) stream, a);
     SKGS_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(se3_blend_reduce_kernel, dim3((7 * M + BLEND_THREADS - 1) / BLEND_THREADS), dim3(BLEND_THREADS), 0,
+    hipLaunchKernelGGL(se3_blend_reduce_kernel, dim3((7 * M * 64 + BLEND_THREADS - 1) / BLEND_THREADS), dim3(BLEND_THREADS), 0,
         (hipStream_t) stream, M, grid, a.partials, g_T);
   } else {
     SKGS_CHECK_HIP(hipMemsetAsync(g_T, 0, (size_t) M * 7 * 4, (hipStream_t) stream));
     hipLaunchKernelGGL(se3_blend_backward_kernel<false>, dim3(grid), dim3(BLEND_THREADS), 0, (hipStream_t) stream, a);
+  }
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+size_t skgs_index_add_rows_workspace_bytes(int64_t R, int32_t C, int32_t M) {
+  if (R <= 0 || (long long) M * C > INDEX_ADD_LDS_FLOATS) return 16;
+  return (size_t) index_add_grid(R * C) * (size_t) M * C * 4 + 16;
+}
+
+int skgs_index_add_rows(int64_t R, int32_t C, int32_t M, const int64_t* indices, const float* rows, float* out, void* workspace,
+    size_t workspace_bytes, skgs_stream_t stream) {
+  SKGS_REQUIRE(R >= 0 && C >= 1 && M >= 1 && out, "index_add_rows: bad arguments");
+  if (R == 0) {
+    SKGS_CHECK_HIP(hipMemsetAsync(out, 0, (size_t) M * C * 4, (hipStream_t) stream));
+    return 0;
+  }
+  SKGS_REQUIRE(indices && rows, "index_add_rows: NULL argument");
+  const int grid = index_add_grid(R * C);
+  if ((long long) M * C <= INDEX_ADD_LDS_FLOATS) {
+    SKGS_REQUIRE(workspace && workspace_bytes >= skgs_index_add_rows_workspace_bytes(R, C, M), "index_add_rows: workspace too small");
+    float* partials = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(index_add_rows_kernel<true>, dim3(grid), dim3(BLEND_THREADS), (size_t) M * C * 4, (hipStream_t) stream, (long long) R, C, M,
+        indices, rows, out, partials);
+    SKGS_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(index_add_reduce_kernel, dim3((M * C * 64 + BLEND_THREADS - 1) / BLEND_THREADS), dim3(BLEND_THREADS), 0, (hipStream_t) stream,
+        M * C, grid, partials, out);
+  } else {
+    SKGS_CHECK_HIP(hipMemsetAsync(out, 0, (size_t) M * C * 4, (hipStream_t) stream));
+    hipLaunchKernelGGL(index_add_rows_kernel<false>, dim3(grid), dim3(BLEND_THREADS), 0, (hipStream_t) stream, (long long) R, C, M, indices, rows, out,
+        (float*) nullptr);
   }
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;

@@ -17,11 +17,15 @@ same as csrc/deform.hip and the oracle); ``dists`` is differentiable w.r.t. p1 a
 On a HIP device the per-frame call shape (one cloud, no lengths, squared L2, K <= 16, D <= 16, fp32) is ONE launch of
 libskgs_hip.so: ``skgs_sp_lbs_weights_forward`` for superpoint-sized tables (60 < M <= 1024 in 3 or 3 + 8 dimensions: the
 wave-cooperative pruned scan of csrc/sp_knn.hip) and ``skgs_knn_bones`` otherwise -- no fallback when the library is missing.
-Everything else (CPU tensors, batches, lengths, L1, large K) runs as chunked pure torch.
+Everything else (CPU tensors, batches, lengths, L1, large K) runs as chunked pure torch.  The indices that call returns are typed
+(``NeighbourIndex``, a ``torch.Tensor`` subclass over the same int64 storage) so that the reference's own gathers of per-bone rows by
+them -- ``sk_d_rot[indices]``, ``kernel_radius[indices]`` ... -- get a backward (``skgs_index_add_rows``) that does not walk
+duplicates serially: torch's index backward is 7.5 ms per gather at 100k x 5 indices into 20 rows (``SKGS_KNN_TYPED_INDEX=0``: plain).
 """
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections import namedtuple
 from typing import Optional, Union
 
@@ -31,7 +35,78 @@ from torch import Tensor
 __all__ = ['knn_points', 'knn_gather', 'ball_query']
 
 _KNN = namedtuple('KNN', 'dists idx knn')
-hip_calls = {'knn_bones': 0, 'sp_search': 0}  # counters (tests)
+_TYPED_INDEX = os.environ.get('SKGS_KNN_TYPED_INDEX', '1') != '0'
+hip_calls = {'knn_bones': 0, 'sp_search': 0, 'gather_backward': 0}  # counters (tests)
+
+
+def _index_add_rows(index: Tensor, rows: Tensor, shape) -> Tensor:
+    """``zeros(shape).index_add_(0, index.flatten(), rows.reshape(-1, *shape[1:]))`` on a HIP device: skgs_index_add_rows"""
+    from sk_gs_amd import _C
+    M, Cn = shape[0], 1
+    for d in shape[1:]:
+        Cn *= d
+    lib = _C.load_library()
+    dev = rows.device
+    with _C._on_device(dev):
+        g = _C._f32c(rows, dev)
+        idx = index.contiguous()
+        R = idx.numel()
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=dev)
+        lib.skgs_index_add_rows_workspace_bytes.restype = C.c_size_t
+        nbytes = int(lib.skgs_index_add_rows_workspace_bytes(C.c_int64(R), C.c_int32(Cn), C.c_int32(M)))
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+        _C._check(lib.skgs_index_add_rows(C.c_int64(R), C.c_int32(Cn), C.c_int32(M), C.c_void_p(_C._ptr(idx)), C.c_void_p(_C._ptr(g)),
+                                          C.c_void_p(_C._ptr(out)), C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel() * 4), _C._stream()))
+    hip_calls['gather_backward'] += 1
+    return out
+
+
+class _GatherRows(torch.autograd.Function):
+    """``table[index]`` for a per-bone table [M, ...] and neighbour indices [P, K]: torch's gather forward; backward = the rows summed
+    per bone by ``skgs_index_add_rows`` (csrc/lie_blend.hip) instead of torch's sort-and-walk index backward, whose cost grows with the
+    number of DUPLICATES per row -- 100k x 5 indices into 20 bones: 7.5 ms per gather on an MI355X, four of them per step of the
+    reference's stage `sk` (sk_gs.py:1148-1149 `sk_d_rot[indices]`, `sk_d_scale[indices]`; :760-763 `kernel_radius[indices]`)."""
+
+    @staticmethod
+    def forward(ctx, table, index):
+        ctx.save_for_backward(index)
+        ctx.table_shape = table.shape
+        return table[index]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad):
+        (index,) = ctx.saved_tensors
+        return _index_add_rows(index, grad, ctx.table_shape), None
+
+
+class NeighbourIndex(torch.Tensor):
+    """What ``knn_points`` returns as ``idx`` on a HIP device: the int64 indices (a real tensor, same storage) typed so that the
+    reference's ``table[indices]`` gathers of per-bone rows (see ``_GatherRows``) get a backward that does not degrade with duplicates.
+    Only that one expression is changed; slicing / reshaping the indices keeps the type, every other use -- ``torch.gather(sp_W, 1,
+    indices)``, ``SE3[indices]``, ``indices.detach()`` (what the reference stores in its buffers, sk_gs.py:772-773), comparisons,
+    arithmetic -- sees and returns plain tensors."""
+    _KEEP = None
+
+    @classmethod
+    def wrap(cls, idx: Tensor) -> Tensor:
+        return torch.Tensor._make_subclass(cls, idx)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if cls._KEEP is None:
+            T = torch.Tensor
+            cls._KEEP = {T.__getitem__, T.select, T.view, T.reshape, T.contiguous, T.squeeze, T.unsqueeze, T.expand, T.flatten, T.clone}
+        with torch._C.DisableTorchFunctionSubclass():
+            if (func is torch.Tensor.__getitem__ and len(args) == 2 and isinstance(args[1], cls) and not isinstance(args[0], cls)
+                    and isinstance(args[0], Tensor) and args[0].dtype == torch.float32 and args[0].is_cuda and args[0].requires_grad
+                    and torch.is_grad_enabled() and args[0].dim() >= 1 and args[0].shape[0] <= (1 << 20)):
+                return _GatherRows.apply(args[0], args[1].as_subclass(Tensor))
+            out = func(*args, **kwargs)
+            if func in cls._KEEP and len(args) and isinstance(args[0], cls) and isinstance(out, Tensor) and out.dtype == torch.int64:
+                return out.as_subclass(cls)
+            return out
 
 
 def _pairwise(p1: Tensor, p2: Tensor, norm: int) -> Tensor:
@@ -103,7 +178,7 @@ class _KnnHip(torch.autograd.Function):
             if need_a:
                 g_a = t.sum(dim=1)
             if need_b:
-                g_b = torch.zeros_like(b).index_add_(0, idx.reshape(-1), -t.reshape(-1, t.shape[-1]))
+                g_b = _index_add_rows(idx, -t, b.shape)
         return g_a, g_b, None
 
 
@@ -121,7 +196,7 @@ def knn_points(p1: Tensor, p2: Tensor, lengths1: Optional[Tensor] = None, length
     if (p1.is_cuda and N == 1 and lengths1 is None and lengths2 is None and norm == 2 and 1 <= K <= min(16, P2) and D <= 16
             and p1.dtype == torch.float32 and p2.dtype == torch.float32 and P1 > 0):
         dists, idx = _KnnHip.apply(p1[0], p2[0], K)
-        dists, idx = dists[None], idx[None]
+        dists, idx = dists[None], (NeighbourIndex.wrap(idx[None]) if _TYPED_INDEX else idx[None])
     else:
         p1c, p2c = p1.contiguous(), p2.contiguous()
         idx_rows, dist_rows = [], []

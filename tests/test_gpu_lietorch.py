@@ -204,3 +204,29 @@ def test_hip_group_operators_against_the_torch_bodies(group):
         assert rel_err(gx1, gx0) <= 2e-5, (group, name, 'dX', rel_err(gx1, gx0))
         if gy0 is not None:
             assert rel_err(gy1, gy0) <= 2e-5, (group, name, 'dY', rel_err(gy1, gy0))
+
+
+@pytest.mark.parametrize('R,C,M', [(500_000, 4, 20), (500_000, 1, 512), (300_000, 3, 1), (1000, 14, 5000), (0, 4, 7), (100_000, 40, 512)])
+def test_typed_neighbour_indices_give_the_same_gather_gradients(R, C, M):
+    """knn_points' typed indices: `table[indices]` forward is torch's gather, backward skgs_index_add_rows (LDS partials; global atomics
+    beyond 48 KB of rows) -- against torch's own index backward"""
+    _, p3d = _mods()
+    g = torch.Generator().manual_seed(R + C + M)
+    idx = torch.randint(0, M, (max(R // 5, 0), 5) if R % 5 == 0 else (R, 1), generator=g).cuda()
+    table0 = torch.randn((M, C) if C > 1 else (M,), generator=g)
+    cot = torch.randn(tuple(idx.shape) + ((C,) if C > 1 else ()), generator=g).cuda()
+    res = []
+    for typed in (True, False):
+        t = table0.cuda().requires_grad_()
+        i = p3d.NeighbourIndex.wrap(idx) if typed else idx
+        before = p3d.hip_calls['gather_backward']
+        out = t[i]
+        assert type(out) is torch.Tensor
+        (out * cot).sum().backward()
+        assert p3d.hip_calls['gather_backward'] == before + int(typed)
+        res.append((out.detach(), t.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    assert rel_err(res[0][1], res[1][1]) <= 2e-5, rel_err(res[0][1], res[1][1])
+    i = p3d.NeighbourIndex.wrap(idx)
+    assert type(i.detach()) is torch.Tensor and type(i + 1) is torch.Tensor and (R == 0 or type(i[0]) is p3d.NeighbourIndex)
+    assert type(table0.cuda()[i]) is torch.Tensor                       # no gradient asked for: torch's own gather
