@@ -203,7 +203,7 @@ def run(args, base_alg_bytes, configs):
     replicas_identical, param_digest = timing.replicas_digest(model, world) if use_dist else (None, None)
     st = step.status()
     assert st['overflow_events'] == 0, 'binning capacity overflow during the timed region: result invalid'
-    assert st['pairs_overflow'] == 0, 'a superpoint\'s inverse neighbour list overflowed: result invalid'
+    assert st['pairs_overflow_events'] == 0, 'a superpoint\'s inverse neighbour list overflowed in some step: result invalid'
     # ---- per-kernel HIP-event timing: an eager pass over the same steps
     n_prof = min(args.steps, 20)
     prof = timing.profiled_eager_pass(_C, eager_step, args.warmup + args.steps, n_prof)

@@ -87,7 +87,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     st = step.status()
-    assert st['overflow_events'] == 0 and st['pairs_overflow'] == 0, st
+    assert st['overflow_events'] == 0 and st['pairs_overflow_events'] == 0, st
     assert all(l == l for l in losses), 'NaN loss'
     print(f'{args.iters} iterations in {dt:.2f} s ({args.iters / dt:.0f} it/s), loss {losses[0]:.5f} -> {losses[-1]:.5f}, '
           f'stage sp, LBS_method {args.lbs_method}, sparse logit update: {step.sparse_logits}')

@@ -629,7 +629,9 @@ int skgs_deform_mlp_status(const void* workspace, uint32_t* host_words4, skgs_st
  * outwards: the lists fill with near neighbours first and the rest of the scan is skipped wave-wide.
  * pairs (skgs_sp_pairs_bytes(P, M, K) bytes, may be NULL): the forward also files every (Gaussian, neighbour) pair under its
  * superpoint -- inverse lists that skgs_sp_skinning_backward walks; the call clears them first.  A superpoint whose list
- * outgrows its capacity (16 x the mean list, >= 4096 entries) sets the overflow word (byte 4 of the buffer). */
+ * outgrows its capacity (16 x the mean list, >= 4096 entries) sets the overflow word (byte 4 of the buffer; cleared by the next
+ * forward's preparation) and counts the forward in the overflow-EVENT word (byte 8), which the library never clears: the pairs
+ * beyond the capacity are missing from the backward's sums, and a caller that looks only every N steps must still learn of it. */
 int skgs_sp_lbs_weights_forward(int32_t P, int32_t M, int32_t K, int32_t F, const float* points, const float* feature,
     const float* sp_points, const float* sp_feature, const float* sp_radius_raw, const float* sp_weight_raw, float temperature,
     const float* sp_W, const int32_t* sp_order /* or NULL */, const int32_t* sp_rank /* or NULL */, int64_t* out_idx,

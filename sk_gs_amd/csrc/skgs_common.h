@@ -312,10 +312,12 @@ struct ProfScope {
 };
 
 // ---- inverse neighbour lists of the superpoint stage (sp_knn.hip files them, sp_backward.hip walks them) ------------------
-// [0,256) header {cap, overflow flag}, counts[M] (256-B aligned), lists[M][cap] of pair ids (n << 4 | k).  Capacity per
-// superpoint: 16 x the mean list (P K / M), at least 4096, at most P: a list that outgrows it raises the overflow flag.
+// [0,256) header {cap, overflow flag of the last forward, overflow EVENTS}, counts[M] (256-B aligned), lists[M][cap] of pair ids
+// (n << 4 | k).  Capacity per superpoint: 16 x the mean list (P K / M), at least 4096, at most P: a list that outgrows it raises the
+// overflow flag (cleared by every forward's preparation) and, once per forward, bumps the event counter in word 2, which the
+// library never clears (as GeomHeader::overflow_events): a training loop that looks every N steps still sees a dropped pair.
 struct SpPairsView {
-  uint32_t* header;  // [0] cap, [1] overflow
+  uint32_t* header;  // [0] cap, [1] overflow (this forward), [2] forwards that overflowed since the caller zeroed the buffer
   uint32_t* counts;
   uint32_t* lists;
   float* table;      // [M][12]: the superpoints as the search's LDS rows (xyz | 8 hyper | id), in scan order
@@ -336,7 +338,7 @@ struct SpPrepareJob {
 #if defined(__HIPCC__)
 __device__ __forceinline__ void sp_prepare_element(const SpPrepareJob& j, int i) {
   constexpr int ROW = 12;
-  if (i < j.n_clear) j.header_and_counts[i] = 0u;
+  if (i < j.n_clear && i != 2) j.header_and_counts[i] = 0u;  // (word 2: the sticky overflow-event counter)
   if (i >= j.M * ROW) return;
   const int r = i / ROW, c = i - r * ROW;
   const int id = j.sp_order ? j.sp_order[r] : r;

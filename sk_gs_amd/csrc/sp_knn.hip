@@ -343,8 +343,8 @@ __global__ void __launch_bounds__(SPK_THREADS) sp_knn_weights_kernel(int P, int 
         const uint32_t slot = s_base[bi[k]] + rank[k];
         if (slot < (uint32_t) pair_cap)
           pair_lists[(size_t) bi[k] * pair_cap + slot] = ((uint32_t) n << 4) | (uint32_t) k;
-        else
-          pair_header[1] = 1u;  // overflow: a superpoint with more than cap Gaussians (skgs_sp_pairs_bytes)
+        else if (atomicExch(&pair_header[1], 1u) == 0u)  // overflow: a superpoint with more than cap Gaussians (skgs_sp_pairs_bytes);
+          atomicAdd(&pair_header[2], 1u);                // the first lane to see it in this forward counts the event (never cleared here)
       }
   }
 }

@@ -60,6 +60,7 @@ class FusedAdam:
         assert zero_after_step is None or (zero_after_step.is_contiguous() and zero_after_step.dtype == torch.float32)
         self._chunk = int(lib.skgs_adam_chunk_elems())
         assert int(lib.skgs_adam_tensor_bytes()) == 56
+        self._state_listeners = []  # callables run after the moments changed from outside a step (see add_state_listener)
         self.params, self._lr_index = [], []
         for gi, g in enumerate(self.param_groups):
             g['params'] = [p for p in g['params']]
@@ -246,6 +247,17 @@ class FusedAdam:
         self._upload()
 
     # ---------------------------------------------------------------------------------------------------------
+    def add_state_listener(self, fn):
+        """``fn()`` is called after every change of the Adam moments that does not come from a step: ``load_state_dict``,
+        ``change_optimizer``, ``gather_rows``.  What depends on the moments registers here -- the live-tile mask of the sparse
+        logit-table update (``FusedSuperpointStep.refresh_logit_mask``): a restored checkpoint whose live tiles the current
+        neighbours do not touch would otherwise stop being updated, silently diverging from dense Adam.  A listener that returns
+        False is dropped (its owner is gone)."""
+        self._state_listeners.append(fn)
+
+    def _notify_state_changed(self):
+        self._state_listeners = [fn for fn in self._state_listeners if fn() is not False]
+
     def change_optimizer(self, tensor, name=None, op: str = 'replace', dim: int = 0) -> dict:
         """Replace, prune or extend the parameter of the named group(s) together with its Adam state -- the optimizer
         surgery of densification, ``GaussianSplatting.change_optimizer`` (networks/gaussian_splatting.py:515-563):
@@ -297,6 +309,7 @@ class FusedAdam:
             self._table = torch.zeros(len(self.params) * 56, dtype=torch.uint8, device=self._table.device)
         self._upload()
         self._addresses_changed()
+        self._notify_state_changed()
         return out
 
     @torch.no_grad()
@@ -315,7 +328,9 @@ class FusedAdam:
         named = [g for g in self.param_groups if g.get('name') in names]
         if named and all(cap_store(g['params'][0]) is not None for g in named):
             if all(n_out <= cap_store(g['params'][0]).shape[0] for g in named):
-                return self._gather_rows_in_place(named, rows, n_out, int(n_keep))
+                out = self._gather_rows_in_place(named, rows, n_out, int(n_keep))
+                self._notify_state_changed()
+                return out
             raise CapacityExceeded(f'{n_out} rows do not fit the row capacity {cap_store(named[0]["params"][0]).shape[0]}')
         blob, new, max_rf, keepalive = bytearray(), {}, 1, []
         for g in self.param_groups:
@@ -353,6 +368,7 @@ class FusedAdam:
         self._upload()
         self._addresses_changed()
         del keepalive  # (the old tensors lived until the launch was enqueued: same stream, the allocator orders reuse)
+        self._notify_state_changed()
         return new
 
     @torch.no_grad()
@@ -472,6 +488,7 @@ class FusedAdam:
             self._set_step_count(steps.pop() if steps else 0.0)
         self._upload()
         self._refresh_captured_rates()  # captured steps keep their addresses; the restored rates reach them too
+        self._notify_state_changed()
 
     def _set_step_count(self, count: float):
         """restore a step count: the counter and the two bias-correction terms 1 - beta^count the kernels advance by

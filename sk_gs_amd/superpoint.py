@@ -56,7 +56,7 @@ class SpDeformNet(nn.Module):
             nn.Linear(W, W) if i not in self.skips else nn.Linear(W + self.in_dim, W) for i in range(D - 1)])
         self.gaussian_warp, self.gaussian_scaling, self.gaussian_rotation = nn.Linear(W, 3), nn.Linear(W, 3), nn.Linear(W, 4)
         self.reset_parameters()
-        self._runner = None
+        self._runners = {}
 
     def reset_parameters(self):
         """sk_gs.py:280-293"""
@@ -90,13 +90,22 @@ class SpDeformNet(nn.Module):
                 and self.time_out == 30)
 
     def runner(self, M: int) -> 'SpNetRunner':
-        if self._runner is None or self._runner.M != M:
-            self._runner = SpNetRunner(self, M)
-        return self._runner
+        """the launches' persistent buffers for M rows: one runner per M, kept (a network is called with 512 superpoints by the stage
+        and with M * T rows by the reference's regularisers, sk_gs.py:1383-1395: replacing the runner would hand the first call's
+        backward uninitialised buffers)"""
+        run = self._runners.get(M)
+        if run is None:
+            run = self._runners[M] = SpNetRunner(self, M)
+        return run
 
     def forward(self, x: Tensor, t: Tensor) -> Dict[str, Tensor]:
         """the reference's call ``sp_deform_net(sp_points.detach(), t)``: d_xyz, d_rotation (raw), d_scaling; autograd reaches
         the network's parameters (``x`` is detached by the caller in every stage, sk_gs.py:746-748,845)"""
+        if t.numel() > 1:
+            # one time PER ROW (loss_arap / loss_elastic call sp_deform_net(x [M*T,3], t [M*T,1]), sk_gs.py:1383-1395): the kernels take
+            # one time for all rows -- the plain-torch body computes exactly what the reference does
+            out = self.reference_forward(x, t)
+            return dict(d_xyz=out['d_xyz'], d_rotation=out['d_rotation'], d_scaling=out['d_scaling'])
         params = list(self.parameters())
         out = _SpNetFn.apply(self, x, t, *params)
         return dict(d_xyz=out[0], d_rotation=out[1], d_scaling=out[2])
@@ -174,17 +183,19 @@ class SpNetRunner:
             None if prepare is None else C.byref(prepare), _C._stream()))
 
     def backward(self, g_bone_T: Optional[Tensor], g_d_rot: Optional[Tensor], g_d_scale: Optional[Tensor],
-                 g_raw: Optional[Tensor] = None, side_adam=None):
+                 g_raw: Optional[Tensor] = None, side_adam=None, saved: Optional[Tensor] = None):
         """parameter gradients WRITTEN into the parameters' ``.grad``.  Either the stage's gradients (``g_bone_T`` [M,7],
         ``g_d_rot`` [M,4], ``g_d_scale`` [M,3]: the quaternion normalisation's backward runs in the launch) or ``g_raw`` [M,10]
         w.r.t. the three raw outputs.  ``side_adam`` (``FusedAdam.side_range``): an optimizer piece for the CUs launch A
-        leaves idle."""
+        leaves idle.  ``saved``: the activations of the forward this backward belongs to, when that is not the runner's last one (the
+        autograd operator keeps a copy per call)."""
+        saved = self.saved if saved is None else saved
         dg = _net_desc(self.net, self.M, None, None, grads=True)
         d = _net_desc(self.net, self.M, None, None)
         p = lambda t: C.c_void_p(None if t is None else t.data_ptr())  # noqa: E731
         _C._check(self.lib.skgs_sp_net_backward(
-            C.byref(d), C.byref(dg), p(g_bone_T), p(g_d_rot), p(g_d_scale), p(g_raw), C.c_void_p(self.saved.data_ptr()),
-            C.c_size_t(self.saved.numel()), C.c_void_p(self.ws.data_ptr()), C.c_size_t(self.ws.numel()),
+            C.byref(d), C.byref(dg), p(g_bone_T), p(g_d_rot), p(g_d_scale), p(g_raw), C.c_void_p(saved.data_ptr()),
+            C.c_size_t(saved.numel()), C.c_void_p(self.ws.data_ptr()), C.c_size_t(self.ws.numel()),
             None if side_adam is None else C.byref(side_adam), _C._stream()))
 
 
@@ -197,15 +208,17 @@ class _SpNetFn(torch.autograd.Function):
         x = _C._f32c(x.detach(), x.device)
         tt = _C._f32c(t.detach().reshape(-1)[:1], x.device)
         run.forward(x, tt)
-        ctx.net, ctx.M = net, M
+        # this call's activations and its runner stay with the autograd node: a second forward before this one's backward (another
+        # M, another time) overwrites the runner's buffer
+        ctx.net, ctx.M, ctx.run = net, M, run
+        ctx.saved_acts = run.saved.clone() if any(p.requires_grad for p in params) else None
         raw = run.raw.clone()
         return raw[:, 0:3], raw[:, 3:7], raw[:, 7:10]
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_xyz, g_rot, g_scale):
-        net, M = ctx.net, ctx.M
-        run = net.runner(M)
+        net, M, run = ctx.net, ctx.M, ctx.run
         dev = run.raw.device
         z = lambda g, n: torch.zeros((M, n), device=dev) if g is None else g  # noqa: E731
         g_raw = torch.cat([z(g_xyz, 3), z(g_rot, 4), z(g_scale, 3)], dim=1).contiguous()
@@ -213,7 +226,7 @@ class _SpNetFn(torch.autograd.Function):
         keep = [p.grad for p in params]
         for p in params:  # the kernels WRITE into .grad: hand autograd fresh tensors and restore what was there
             p.grad = torch.empty_like(p)
-        run.backward(None, None, None, g_raw=g_raw)
+        run.backward(None, None, None, g_raw=g_raw, saved=ctx.saved_acts)
         grads = [p.grad for p in params]
         for p, k in zip(params, keep):
             p.grad = k
@@ -540,9 +553,12 @@ class FusedSuperpointStep(FusedViewStep):
             _C._stream()))
 
     def status(self) -> dict:
-        """(synchronising) the rasterizer's status words + ``pairs_overflow``: a superpoint's inverse list outgrew its capacity"""
+        """(synchronising) the rasterizer's status words + ``pairs_overflow``: a superpoint's inverse list outgrew its capacity in the
+        LAST step (its pairs beyond the capacity were dropped from the backward's sums), and ``pairs_overflow_events``: the number of
+        steps in which that happened since this object was built (sticky: a loop that asks every N steps still sees it)"""
         st = _C.read_status(self.geom)
-        st['pairs_overflow'] = int(self.pairs[:8].view(torch.int32)[1])
+        words = self.pairs[:12].view(torch.int32).tolist()
+        st['pairs_overflow'], st['pairs_overflow_events'] = words[1], words[2]
         return st
 
 
@@ -573,6 +589,19 @@ class FusedSuperpointTrainStep:
         step.sparse_logits = bool(self.fused and self.wide and sparse_logits and step.M <= 1024 and step.K <= 16)
         if step.sparse_logits:
             step.refresh_logit_mask(optimizer)
+            # ... and again whenever the table's moments change from outside a step (a restored checkpoint, optimizer surgery): the
+            # sparse update is bit-identical to the dense one only while the mask covers every tile with a non-zero moment
+            import weakref
+            ref_step, ref_opt = weakref.ref(step), weakref.ref(optimizer)
+
+            def _refresh():
+                st, op = ref_step(), ref_opt()
+                if st is None or op is None or not st.sparse_logits:
+                    return False
+                if st.model.sp_W in op.state and st.P == st.model.sp_W.shape[0]:
+                    st.refresh_logit_mask(op)
+                return True
+            optimizer.add_state_listener(_refresh)
 
     def __call__(self, rs=None, time_id=None, target=None):
         self.step.forward_backward(rs, time_id, target)

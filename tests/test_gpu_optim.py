@@ -512,3 +512,24 @@ def test_sparse_logit_table_adam_is_bit_identical_to_the_dense_step(P, M, K):
     tiles = (M + 31) // 32
     live = sum(int(((mask >> t) & 1).sum()) for t in range(tiles)) / (P * tiles)
     assert live < 1.0 or K * 7 >= tiles  # (the point of the kernel: most tiles are never visited)
+
+
+def test_state_listeners_hear_every_change_of_the_moments_from_outside_a_step():
+    from sk_gs_amd.optim import FusedAdam
+    a, b = torch.nn.Parameter(torch.randn(50, 3, device='cuda')), torch.nn.Parameter(torch.randn(7, device='cuda'))
+    opt = FusedAdam([{'params': [a], 'lr': 1e-2, 'name': 'xyz'}, {'params': [b], 'lr': 1e-2, 'name': 'b'}], eps=1e-15)
+    heard, once = [], []
+    opt.add_state_listener(lambda: heard.append(1) or True)
+    opt.add_state_listener(lambda: once.append(1) or False)       # returns False: dropped after its first call
+    a.grad.normal_(), b.grad.normal_()
+    opt.step()
+    assert not heard
+    opt.load_state_dict(opt.state_dict())
+    assert len(heard) == 1 and len(once) == 1
+    keep = torch.ones(50, dtype=torch.bool, device='cuda')
+    keep[::5] = False
+    opt.change_optimizer(keep, 'xyz', op='prune')
+    assert len(heard) == 2 and len(once) == 1
+    rows = torch.arange(40, device='cuda', dtype=torch.int32)
+    opt.gather_rows(['xyz'], rows, 40)
+    assert len(heard) == 3

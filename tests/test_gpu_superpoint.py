@@ -78,9 +78,9 @@ def test_sp_net_backward_matches_torch_autograd(M, stage):
     # the same gradients in fp64: a pre-activation within rounding distance of 0 takes the other side of the ReLU in ANY
     # two fp32 evaluations (torch's included) -- a parameter is held to max(5e-5, 3 x torch-fp32's own distance from fp64)
     import copy
-    keep, net._runner = net._runner, None
+    keep, net._runners = net._runners, {}
     net64 = copy.deepcopy(net).double()
-    net._runner = keep
+    net._runners = keep
     ref64 = net64.reference_forward(x.double(), t.double())
     if stage:
         u64 = F.normalize(ref64['d_rotation'] + torch.tensor([0, 0, 0, 1.], device='cuda', dtype=torch.float64), dim=-1)
@@ -121,6 +121,38 @@ def test_sp_net_autograd_function_and_state_dict():
         assert rel_err(a, b) <= 5e-5, n
     with pytest.raises(Exception):
         net(x.cpu(), t)
+
+
+def test_sp_net_called_more_than_once_per_graph():
+    """two forwards (another row count, another time) before one backward -- each autograd node keeps its own activations and
+    its runner; a time PER ROW (the reference's regularisers call sp_deform_net(x [M*T,3], t [M*T,1]), sk_gs.py:1383-1395) takes the
+    plain-torch body, which honours it"""
+    net = _net(11)
+    g = torch.Generator().manual_seed(11)
+    xa, xb = (torch.rand(512, 3, generator=g) * 2 - 1).cuda(), (torch.rand(96, 3, generator=g) * 2 - 1).cuda()
+    ta, tb = torch.tensor([0.2], device='cuda'), torch.tensor([[0.9]], device='cuda')
+    keys = ('d_xyz', 'd_rotation', 'd_scaling')
+    ca = [torch.randn(512, n, generator=g).cuda() for n in (3, 4, 3)]
+    cb = [torch.randn(96, n, generator=g).cuda() for n in (3, 4, 3)]
+    params = list(net.parameters())
+
+    def loss(fn):
+        oa, ob = fn(xa, ta), fn(xb, tb)                       # second forward BEFORE the first backward
+        oc = fn(xa, ta * 2)                                   # ... and a third one on the first runner's buffers
+        return (sum((oa[k] * c).sum() for k, c in zip(keys, ca)) + sum((ob[k] * c).sum() for k, c in zip(keys, cb))
+                + 0.5 * sum((oc[k] * c).sum() for k, c in zip(keys, ca)))
+    got = torch.autograd.grad(loss(net), params)
+    want = torch.autograd.grad(loss(net.reference_forward), params)
+    for (n, _), a, b in zip(net.named_parameters(), got, want):
+        assert rel_err(a, b) <= 5e-5, (n, rel_err(a, b))
+    assert set(net._runners) == {512, 96}
+    # one time per row
+    T = 4
+    x = xb[:, None, :].repeat(1, T, 1).reshape(-1, 3)
+    t_rows = torch.rand(96 * T, 1, generator=g).cuda()
+    out, ref = net(x, t_rows), net.reference_forward(x, t_rows)
+    assert all(torch.equal(out[k], ref[k]) for k in keys)
+    assert not torch.allclose(out['d_xyz'], net(x, t_rows[:1])['d_xyz'])       # the rows' own times matter
 
 
 # ------------------------------------------------------------------------------------------- search + weightings
@@ -526,3 +558,83 @@ def test_superpoint_training_example_runs_and_fits(method):
     assert f'LBS_method {method}' in last and f'sparse logit update: {method == "W"}' in last, last
     first, final = [float(x) for x in last.split('loss ')[1].split(',')[0].split(' -> ')]
     assert final < 0.8 * first, last
+
+
+def test_inverse_list_overflow_is_reported_and_sticky():
+    """a superpoint whose inverse list outgrows its capacity (16 x the mean list) loses pairs in the backward's sums; the
+    per-step flag is cleared by the next forward's preparation, the EVENT counter is not -- a loop that asks every N steps sees it"""
+    from sk_gs_amd import _C
+    from sk_gs_amd.superpoint import FusedSuperpointStep
+    P, M, K, W, H = 40_000, 64, 2, 96, 64        # mean list 1250 -> capacity 20 000 < P
+    model, rs, target = _sp_model(P, M, K, W, H, 2, 'dist')
+    _C.config.sync_num_rendered = True
+    R = model.render(rs, time_id=0)['buffer'].R
+    for p in model.parameters():
+        p.grad = None
+    step = FusedSuperpointStep(model, W, H, capacity=int(R * 3) + 4096)
+    step.forward_backward(rs, 0, target)
+    st = step.status()
+    assert st['pairs_overflow'] == 0 and st['pairs_overflow_events'] == 0
+    keep = model._xyz.detach().clone()
+    with torch.no_grad():  # every Gaussian next to superpoint 0: its list would hold all P of them
+        model._xyz.copy_(model.sp_points[0] + 1e-3 * torch.randn(P, 3, device='cuda'))
+        if model.hyper_feature is not None:
+            model.hyper_feature.copy_(model.sp_hyper_feature[0].expand(P, -1))
+    step.forward_backward(rs, 0, target)
+    st = step.status()
+    assert st['pairs_overflow'] == 1 and st['pairs_overflow_events'] == 1
+    step.forward_backward(rs, 1, target)
+    assert step.status()['pairs_overflow_events'] == 2
+    with torch.no_grad():
+        model._xyz.copy_(keep)
+    step.forward_backward(rs, 0, target)          # a clean step: the flag of the last step is clear, the events remain
+    st = step.status()
+    assert st['pairs_overflow'] == 0 and st['pairs_overflow_events'] == 2
+
+
+def test_restored_checkpoint_keeps_the_sparse_logit_update_equal_to_the_dense_one():
+    """the sparse `W` logit update visits only tiles whose moments are live according to its mask; a checkpoint restored into an
+    existing train step (FusedAdam.load_state_dict) brings live moments in tiles the CURRENT neighbours do not touch -- the optimizer now
+    tells the step (add_state_listener) and the mask is rebuilt, so those rows keep decaying exactly as under dense Adam"""
+    from sk_gs_amd import _C
+    from sk_gs_amd.optim import FusedAdam
+    from sk_gs_amd.superpoint import FusedSuperpointStep, FusedSuperpointTrainStep
+    P, M, K, W, H, frames = 4000, 512, 5, 96, 64, 2
+
+    def build(sparse):
+        model, rs, target = _sp_model(P, M, K, W, H, frames, 'W', seed=9)
+        _C.config.sync_num_rendered = True
+        with torch.no_grad():
+            R = model.render(rs, time_id=0)['buffer'].R
+        step = FusedSuperpointStep(model, W, H, capacity=int(R * 3) + 4096)
+        opt = FusedAdam(model.param_groups(lr=1e-3))
+        train = FusedSuperpointTrainStep(step, opt, sparse_logits=sparse)
+        assert step.sparse_logits == sparse
+        return model, rs, target, step, opt, train
+
+    model, rs, target, step, opt, train = build(False)          # the donor: three dense steps
+    for _ in range(3):
+        train(rs, 0, target)
+    sd = opt.state_dict()
+    params = {n: p.detach().clone() for n, p in model.named_parameters()}
+    got = {}
+    for sparse in (True, False):
+        model, rs, target, step, opt, train = build(sparse)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                p.copy_(params[n])
+            model._xyz.add_(0.6)                                 # other neighbours than the donor's: its live tiles are not visited now
+        opt.load_state_dict(sd)
+        if sparse:
+            st = opt.state[model.sp_W]
+            live = (st['exp_avg'].view(P, M // 32, 32) != 0).any(-1)
+            mask_bits = torch.stack([(step.logit_mask >> t) & 1 for t in range(M // 32)], 1).bool()
+            assert bool((mask_bits | ~live).all()), 'the mask must cover every tile with a live moment after the restore'
+        for _ in range(2):
+            train(rs, 1, target)
+        torch.cuda.synchronize()
+        got[sparse] = (model.sp_W.detach().clone(), opt.state[model.sp_W]['exp_avg'].clone(), opt.state[model.sp_W]['exp_avg_sq'].clone())
+    for a, b, name in zip(got[True], got[False], ('sp_W', 'exp_avg', 'exp_avg_sq')):
+        # (two runs differ where the blend backward's atomics decide a rounding; a tile that stopped being updated differs by whole steps)
+        far = ((a - b).abs() > 1e-5 * float(b.abs().max())).float().mean()
+        assert float(far) <= 1e-3, (name, float(far))
