@@ -70,6 +70,9 @@ def build_parser():
     ap.add_argument('--views', type=int, default=8)
     ap.add_argument('--ppl', type=int, default=0, help='pixels per lane of the blend kernels (0 = heuristic)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-survey-recipe', action='store_true',
+                    help="skip the second short run the default one-GPU line carries under `survey_recipe`: SURVEY.md 8(d)'s recipe "
+                         "to the letter (U(0,1) targets, Gaussians in generation order) in a child process")
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--cpu-single-thread', action='store_true',
                     help='also time the oracle on the bench workload with ONE thread (about a minute per iteration at config #1)')
@@ -78,6 +81,14 @@ def build_parser():
                          'per render: median / p10 / p90 of 50); default: on for a 1-GPU run')
     ap.add_argument('--no-ms-per-render', dest='ms_per_render', action='store_false')
     ap.add_argument('--lr', type=float, default=1e-4, help='base lr (reference 1e-3); small keeps the workload stationary')
+    ap.add_argument('--lr-schedule', choices=('device', 'off'), default='device',
+                    help="the reference's per-iteration update_learning_rate (train.py:140-141): `xyz` follows get_expon_lr_func from "
+                         "0.16 lr to 0.0016 lr over 30 000 steps (gaussian_splatting.py:455-470), the deform network's group its own "
+                         "schedule over 40 000 (sk_gs.py:611-632) -- evaluated ON THE DEVICE by the step's closing Adam launch "
+                         "(FusedAdam.set_lr_schedule), so every step of a multi-step graph replay applies its own rate.  off: constant rates")
+    ap.add_argument('--targets', choices=('own-render', 'uniform'), default='own-render',
+                    help="training targets: the model's own initial renders + N(0, 0.05^2) noise (default: gradients stay small, the "
+                         "workload -- num_rendered, tile lists -- is stationary over the run) or U(0,1) images, SURVEY.md 8(d)'s recipe")
     ap.add_argument('--torch-adam', action='store_true', help='use torch.optim.Adam(fused=True) instead of the one-launch kernel')
     ap.add_argument('--eager', action='store_true', help='issue every launch eagerly instead of replaying hipGraphs')
     ap.add_argument('--pipeline', action='store_true',

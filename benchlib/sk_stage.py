@@ -6,6 +6,7 @@ as captured hipGraphs (`build_steps`), warm-up, exactly args.steps timed steps b
 per-kernel pass, BASELINE's second metric (benchlib/render_protocol.py) and the JSON line.  A multi-rank run with no exchange
 flag calls `run` once per exchange variant (benchlib/exchange_rank.py).
 """
+import os
 from types import SimpleNamespace
 
 import torch
@@ -46,6 +47,9 @@ def build_scene(args, env):
     targets = []
     with torch.no_grad():
         for v in range(args.views):
+            if args.targets == 'uniform':  # target image U(0,1)
+                targets.append(torch.rand(3, H, W, generator=gen).to(dev).contiguous())
+                continue
             img = model.render(settings[v], time_id=v % frames, background=background)['images']
             targets.append((img + 0.05 * torch.randn(3, H, W, generator=gen).to(dev)).clamp(0, 1).contiguous())
     # every per-view input of the step as a device load: one captured graph serves all views (sk_gs_amd/view_slot.py)
@@ -56,6 +60,24 @@ def build_scene(args, env):
                                [v % frames for v in range(args.views)], torch.stack(targets), dev)
     return SimpleNamespace(cfg=cfg, P=P, M=M, K=K, W=W, H=H, frames=frames, model=model, settings=settings, targets=targets,
                            background=background, view_table=view_table, densify_every=densify_every)
+
+
+def lr_schedules(args, opt) -> str:
+    """the reference's update_learning_rate on the device (FusedAdam.set_lr_schedule): `xyz` and the deform network's group, when
+    `opt` holds them.  Returns what the bench line says about it."""
+    names = {g.get('name') for g in opt.param_groups}
+    if args.lr_schedule != 'device' or not hasattr(opt, 'set_lr_schedule'):
+        return 'off: constant rates'
+    said = []
+    if 'xyz' in names:  # gaussian_splatting.py:455-470 (lr_position_init 0.16 -> lr_position_final 0.0016, 30k steps)
+        opt.set_lr_schedule('xyz', lr_init=args.lr * 0.16, lr_final=args.lr * 0.0016, max_steps=30_000, lr_delay_mult=0.01)
+        said.append('xyz 0.16 lr -> 0.0016 lr over 30000 steps')
+    net = [n for n in ('deform_net', 'sp_deform') if n in names]
+    if net:  # sk_gs.py:611-614 (lr_deform_max_steps 40k; final / initial = 0.0016 / (0.16 x 5))
+        opt.set_lr_schedule(net, lr_init=args.lr, lr_final=args.lr * 0.002, max_steps=40_000, lr_delay_mult=0.01)
+        said.append(f'{net[0]} lr -> 0.002 lr over 40000 steps')
+    return ('get_expon_lr_func evaluated per step by the closing Adam launch (update_learning_rate, train.py:140-141): '
+            + '; '.join(said)) if said else 'off: no scheduled group in this optimizer'
 
 
 # ------------------------------------------------------------------------------------------------ exchange (world > 1)
@@ -180,6 +202,7 @@ def build_steps(args, env, s, x):
         optA = FusedAdam([g for g in groups if g['name'] in ('f_dc', 'f_rest')], eps=1e-15, betas=(0.9, 0.999))
         optB = FusedAdam([g for g in groups if g['name'] not in ('f_dc', 'f_rest')], eps=1e-15, betas=(0.9, 0.999),
                          zero_after_step=table_span)
+        t.lr_schedule = lr_schedules(args, optB)
 
         def part_a(v):
             fstep.backward_raster(*fb_args(v))
@@ -230,6 +253,7 @@ def build_steps(args, env, s, x):
             from sk_gs_amd.optim import FusedAdam
             opt = FusedAdam(groups, eps=1e-15, betas=(0.9, 0.999), zero_after_step=table_span)
         t.opt = opt
+        t.lr_schedule = lr_schedules(args, opt)
         if args.autograd:
             grad_params = [p for p in model.parameters() if p.requires_grad]
 
@@ -712,6 +736,11 @@ def run(args, env):
                    'gaussian_order': 'as generated (random)' if (args.keep_order or M == 0) else
                    'sorted along a Z-order curve (densify.sort_spatially: what a training loop does after each densification event)',
                    'adam': adam_desc,
+                   'lr': args.lr, 'lr_schedule': getattr(t, 'lr_schedule', 'off'),
+                   'targets': ("the model's own initial renders + N(0, 0.05^2) noise, clamped (SURVEY.md 8(d) says U(0,1): `survey_recipe` "
+                               "below is that run)" if args.targets == 'own-render' else 'U(0,1) images (SURVEY.md 8(d))'),
+                   'prime_steps_why': 'untimed steps after the capture: a fresh process reaches a training run\'s steady state only after '
+                                      'tens of ms of work (0.375 -> 0.358 ms per step in a 20-step region)',
                    'step': 'autograd operator path' if args.autograd else 'FusedViewStep (direct C-ABI calls)',
                    'operator_path_backward_thread': args.backward_thread,
                    'replicas_identical': replicas_identical, 'param_digest': param_digest,
@@ -735,4 +764,27 @@ def run(args, env):
     if world == 1 and not args.no_cpu_baseline:
         from benchlib.cpu_baseline import cpu_baseline
         line['cpu_baseline'] = cpu_baseline(cfg, args.cpu_seconds, args.cpu_single_thread, configs=CONFIGS)
+    if (world == 1 and not args.no_cpu_baseline and not args.no_survey_recipe and args.targets == 'own-render' and not args.keep_order
+            and not args.autograd and not args.eager and args.scale_mult == 1.0):
+        line['survey_recipe'] = survey_recipe_run(args)
     return line
+
+
+def survey_recipe_run(args) -> dict:
+    """SURVEY.md 8(d)'s recipe to the letter, as a number of its own beside the headline: the same step and configuration with U(0,1)
+    target images and the Gaussians left in generation order (no Z-order sort) -- a short run of bench.py in a child process (this
+    process keeps its GPU memory; nothing of it runs meanwhile)"""
+    import json
+    import subprocess
+    import sys
+    cmd = [sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'), '--config', str(args.config),
+           '--targets', 'uniform', '--keep-order', '--steps', '200', '--warmup', '20', '--no-cpu-baseline', '--no-ms-per-render',
+           '--no-survey-recipe', '--lr', str(args.lr), '--lr-schedule', args.lr_schedule, '--views', str(args.views)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'],
+                'targets': d['config']['targets'], 'gaussian_order': d['config']['gaussian_order'], 'lr_schedule': d['config']['lr_schedule'],
+                'num_rendered_mean': d['config']['num_rendered_mean'], 'how': 'python bench.py ' + ' '.join(cmd[2:])}
+    except Exception as e:  # noqa: BLE001  (the headline does not depend on it)
+        return {'error': f'{type(e).__name__}: {e}'}

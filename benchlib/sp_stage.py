@@ -145,6 +145,8 @@ def run(args, base_alg_bytes, configs):
     step = FusedSuperpointStep(model, W, H, capacity=int(R_max * 1.25 * _C.config.capacity_growth) + 1024,
                                background=background, grad_scale=1.0 / world, tile_bucket=tile_bucket, view_table=view_table)
     opt = FusedAdam(model.param_groups(lr=args.lr), eps=1e-15, betas=(0.9, 0.999))
+    from benchlib.sk_stage import lr_schedules
+    lr_schedule_desc = lr_schedules(args, opt)  # update_learning_rate on the device: xyz and sp_deform (sk_gs.py:627-631)
     train = FusedSuperpointTrainStep(step, opt, enable=not use_dist)
     order = [vp.view_index(i, args.views) for i in range(args.views)]
     train_chunk, n_multi = None, 1
@@ -293,6 +295,7 @@ def run(args, base_alg_bytes, configs):
                    'launch': 'ONE captured hipGraph for all views (camera, time and target read from a device view slot)'
                    if not use_dist else 'two hipGraphs per step with the all-reduce between them',
                    'tile_lists': f'buckets of {tile_bucket} slots per tile (longest list {longest})',
+                   'lr': args.lr, 'lr_schedule': lr_schedule_desc,
                    'adam': ('per-Gaussian rows on the idle CUs of the sp net\'s two backward launches; '
                             + ('the dense [P, M] logit table as a launch of its own; ' if train.wide else '')
                             + 'network + superpoint tables + counter + next view in one closing launch') if train.fused

@@ -40,7 +40,7 @@ def main():
     from sk_gs_amd import _C, densify, scene
     from sk_gs_amd.fused_step import FusedViewStep
     from sk_gs_amd.model import SkinnedGaussians
-    from sk_gs_amd.optim import CapacityExceeded, FusedAdam, position_lr
+    from sk_gs_amd.optim import CapacityExceeded, FusedAdam
     from sk_gs_amd.overflow import OverflowGuard
     from sk_gs_amd.train_step import FusedTrainStep, GraphedSteps
     from sk_gs_amd.view_slot import ViewTable
@@ -69,6 +69,11 @@ def main():
     if world == 1 and args.capacity and args.densify_every:  # BEFORE anything mirrors the parameters
         model.enable_capacity(int(P * args.capacity))
     opt = FusedAdam(model.param_groups(lr=args.lr), eps=1e-15)
+    # update_learning_rate (train.py:140-141, gaussian_splatting.py:455-470, sk_gs.py:611-632) EVERY step, on the device: the closing
+    # Adam launch of a step evaluates the schedules for the next one, captured graphs included
+    opt.set_lr_schedule('xyz', lr_init=args.lr * 0.16, lr_final=args.lr * 0.0016, max_steps=30_000, lr_delay_mult=0.01)
+    if any(g.get('name') == 'deform_net' for g in opt.param_groups):
+        opt.set_lr_schedule('deform_net', lr_init=args.lr, lr_final=args.lr * 0.002, max_steps=40_000, lr_delay_mult=0.01)
 
     def build_runtime(stats_from=None):
         """everything sized by the number of Gaussians: gradient buffers, step workspaces, captured graphs.  `stats_from`: the
@@ -134,8 +139,6 @@ def main():
                 print(f'iter {it:5d}  binning capacity overflow: redoing from iteration {act[1]} with capacity x2')
             it = act[1]
             continue
-        if it % 100 == 0:  # update_learning_rate (gaussian_splatting.py:455-465): the captured Adam step reads the new rate
-            opt.set_lr('xyz', position_lr(it, args.lr * 0.16, args.lr * 0.0016, max_steps=30_000, delay_mult=0.01))
         if rank == 0 and (it % 100 == 0 or it == args.iters - 1):
             l = step.loss3.tolist()                               # synchronises
             print(f'iter {it:5d}  loss {l[0]:.5f}  (L1 {l[1]:.5f}, SSIM {l[2]:.4f})  {step.status()}')

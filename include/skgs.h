@@ -438,11 +438,32 @@ int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred,
  * Replaces torch.optim.Adam(eps=1e-15) as configured by exps/default.yaml:122-125 over the parameter groups of
  * networks/gaussian_splatting.py:443-453 (amsgrad off, no weight decay).  `tensors` is a DEVICE array of descriptors
  *   struct { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; int64_t n; int64_t chunk0; float lr;
- *            float pad; }   (skgs_adam_tensor_bytes() = 56)
+ *            int32_t sched; }   (skgs_adam_tensor_bytes() = 56; sched: 0, or k > 0 = learning-rate schedule k - 1, see above)
  * with chunk0 = running sum of ceil(n / skgs_adam_chunk_elems()) and total_chunks the final sum.  step_state is the
  * optimizer's DEVICE state: skgs_adam_state_bytes() (256) bytes, 8-byte aligned, zero-initialised = no step taken.  Word
  * 0 is the number of steps taken so far as a float; doubles at bytes 8 and 16 hold 1 - beta1^steps and 1 - beta2^steps
  * (set them too when restoring a count: load_state_dict); the call advances all of it (hipGraph-capturable). */
+/* ---- learning-rate schedules on the device ----
+ * The reference calls update_learning_rate before EVERY training step (train.py:140-141): the `xyz` group follows
+ * get_expon_lr_func (networks/gaussian_splatting.py:56-84,455-470: log-linear from lr_init to lr_final over max_steps, eased in by
+ * lr_delay_mult + (1 - lr_delay_mult) sin(pi/2 clip(step / lr_delay_steps))), the deform networks' groups a second such schedule
+ * with a stage offset (networks/sk_gs.py:611-632).  Up to 8 schedules live in the optimizer's device state: a tensor descriptor
+ * whose `sched` word (the int32 after `lr`, 0 = none) is k > 0 takes schedule k - 1's rate instead of its own `lr`; the launch that
+ * ADVANCES the step counter (skgs_adam_step, skgs_adam_step_range(advance = 1), skgs_adam_step_tail) evaluates every schedule for
+ * the training step that follows -- in the double arithmetic numpy gives the reference, rounded to the float the update uses --
+ * and keeps the closed step's rates for pieces that run after the advance but belong to it (after_advance).  No host in the loop:
+ * a step replayed inside a hipGraph, several steps per replay, follows the reference's rate step for step.
+ * Training step numbers are 1-based (the reference passes global_step + 1 / self._step); a schedule sees step - step_offset. */
+typedef struct skgs_lr_schedule {
+  double lr_init, lr_final, lr_delay_mult;
+  int32_t lr_delay_steps; /* 0: no ease-in */
+  int32_t max_steps;
+  int32_t step_offset;    /* sk_gs.py:621-626: the stage's first step */
+  int32_t reserved;
+} skgs_lr_schedule;
+/* schedules: DEVICE array of n <= 8 entries, alive and unchanged while the optimizer steps.  Evaluates them for the state's current
+ * count (call it again after restoring a step count).  n = 0 removes them. */
+int skgs_adam_set_lr_schedules(float* step_state, const skgs_lr_schedule* schedules, int32_t n, skgs_stream_t stream);
 size_t skgs_adam_tensor_bytes(void);
 size_t skgs_adam_state_bytes(void);
 int64_t skgs_adam_chunk_elems(void);

@@ -95,6 +95,7 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_step_kernel(int n_tensors, 
         state->q2     = (1.0 - beta2d) + beta2d * pf_q2;
         state->ticket = 0u;
       }
+      lr_schedules_advance(state, threadIdx.x, pf_count + 1.0f);  // the scheduled rates of the step that follows (lanes 0..n-1)
     }
   }
 }
@@ -106,10 +107,22 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_step_kernel(int n_tensors, 
 __global__ void __launch_bounds__(256) adam_bump_kernel(AdamState* state, double beta1d, double beta2d,
     float* __restrict__ zero_after, int64_t zero_n) {
   const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) adam_advance(state, beta1d, beta2d);
+  if (blockIdx.x == 0 && threadIdx.x < 64) adam_advance(state, beta1d, beta2d, threadIdx.x);
   if (i < zero_n) zero_after[i] = 0.f;
 }
 
+
+// installs the schedules in the optimizer's state and evaluates them for the state's CURRENT count: lr_now = the rates of training
+// step count + 1, lr_prev = those of step count (also the way to re-derive them after a restored step count)
+__global__ void __launch_bounds__(64) adam_set_schedules_kernel(AdamState* state, const LrSchedule* sched, int n) {
+  const int lane = threadIdx.x;
+  if (lane == 0) state->n_sched = (unsigned) n, state->sched = n > 0 ? sched : nullptr;
+  if (lane < ADAM_MAX_SCHEDULES) {
+    const int count = (int) state->count;
+    state->lr_now[lane]  = lane < n ? lr_schedule_eval(sched[lane], count + 1) : 0.f;
+    state->lr_prev[lane] = lane < n ? lr_schedule_eval(sched[lane], count) : 0.f;
+  }
+}
 
 // ---- LBS_method 'W' (networks/sk_gs.py:469-471, exps/default.yaml:35): Adam on the dense [P, M] logit table, sparsely ----------
 // A row of the table receives a gradient at its K nearest superpoints only (the gather of sk_gs.py:769): every other entry has
@@ -128,7 +141,7 @@ __global__ void __launch_bounds__(256) adam_logit_rows_kernel(int P, int M, int 
   const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = gridDim.x * 4;
   const AdamCoef k = adam_coefficients(beta1d, beta2d, eps, state, after_advance != 0);
   const AdamTensor T    = desc[0];
-  const float step_size = T.lr / k.bc1;
+  const float step_size = adam_lr(T, k) / k.bc1;
   for (int n = wave; n < P; n += n_waves) {
     // (n is wave-uniform: the K triples are scalar loads)
     float gl[16];
@@ -206,6 +219,19 @@ int skgs_adam_step(int32_t n_tensors, const void* tensors, int64_t total_chunks,
   if (n_tensors == 0 || total_chunks == 0) return 0;
   return skgs_adam_step_range(n_tensors, tensors, 0, total_chunks, beta1, beta2, eps, step_state, 1, zero_after, zero_n,
       stream);
+}
+
+/* Learning-rate schedules evaluated on the device (the reference's per-iteration update_learning_rate: train.py:140-141,
+ * gaussian_splatting.py:56-84,455-470, sk_gs.py:611-632).  schedules: DEVICE array of n <= 8 skgs_lr_schedule (it must stay alive and
+ * unchanged while the optimizer steps); tensors whose descriptor carries slot k (the int32 after `lr`) take schedule k - 1's rate. */
+int skgs_adam_set_lr_schedules(float* step_state, const skgs_lr_schedule* schedules, int32_t n, skgs_stream_t stream) {
+  SKGS_REQUIRE(step_state && n >= 0 && n <= ADAM_MAX_SCHEDULES && (n == 0 || schedules), "adam_set_lr_schedules: 0 <= n <= 8 schedules");
+  SKGS_REQUIRE((reinterpret_cast<uintptr_t>(step_state) & 7) == 0, "adam_set_lr_schedules: the state must be 8-byte aligned");
+  static_assert(sizeof(skgs_lr_schedule) == sizeof(LrSchedule), "skgs_lr_schedule");
+  hipLaunchKernelGGL(adam_set_schedules_kernel, dim3(1), dim3(64), 0, (hipStream_t) stream, reinterpret_cast<AdamState*>(step_state),
+      reinterpret_cast<const LrSchedule*>(schedules), n);
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 
 namespace {

@@ -2,6 +2,7 @@
 // side job of the deform network's backward launch (mlp_fused.hip: the Gaussian rows' update runs on the CUs that launch
 // leaves idle).  Math: see adam.hip.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 
 #include "skgs_common.h"
@@ -16,7 +17,7 @@ struct AdamTensor {
   int64_t n;        // elements
   int64_t chunk0;   // first chunk index of this tensor in the flattened chunk space
   float lr;
-  float pad;
+  int32_t sched;    // 0: the rate is `lr`; k > 0: slot k - 1 of the optimizer state's scheduled rates (skgs_adam_set_lr_schedules)
 };
 static_assert(sizeof(AdamTensor) == 56, "layout shared with the host binding");
 constexpr int ADAM_THREADS = 256;
@@ -26,19 +27,58 @@ constexpr int ADAM_CHUNK   = ADAM_THREADS * 4 * 4;  // elements per 256-thread g
 // q_k = 1 - beta_k^count as doubles, advanced by recurrence (q' = (1 - beta) + beta q) -- a double pow() per launch was
 // 2-3 us in front of every update; and, in its own 128-byte line, the ticket of the launches that advance the count
 // themselves (last workgroup out).
+// Learning-rate schedules on the device (the reference calls update_learning_rate before EVERY train step: train.py:140-141,
+// networks/gaussian_splatting.py:56-84,455-470, networks/sk_gs.py:611-632): up to 8 schedules, each `get_expon_lr_func`'s
+// parameters; the launch that advances the step counter evaluates them for the step that follows and keeps the closed step's
+// rates for the pieces that still belong to it (after_advance).  A step replayed inside a hipGraph -- four steps per replay in
+// bench.py -- therefore follows the reference's rate step for step, with no host in the loop.
+constexpr int ADAM_MAX_SCHEDULES = 8;
+struct LrSchedule {  // include/skgs.h::skgs_lr_schedule
+  double lr_init, lr_final, lr_delay_mult;
+  int32_t lr_delay_steps, max_steps, step_offset, reserved;
+};
+static_assert(sizeof(LrSchedule) == 40, "layout shared with the host binding");
 struct AdamState {
   float count;       // steps taken so far
   float pad0;
   double q1, q2;     // 1 - beta1^count, 1 - beta2^count
-  float pad1[26];
+  unsigned n_sched;  // byte 24
+  unsigned pad_a;
+  float lr_now[ADAM_MAX_SCHEDULES];   // byte 32: the scheduled rates of training step count + 1 (the step in progress)
+  float lr_prev[ADAM_MAX_SCHEDULES];  // byte 64: ... of step `count` (pieces that run after the advance but belong to it)
+  const LrSchedule* sched;            // byte 96
+  float pad1[6];
   unsigned ticket;   // word 32
   unsigned pad2[31];
 };
 static_assert(sizeof(AdamState) == 256, "layout shared with the host binding");
+static_assert(offsetof(AdamState, lr_now) == 32 && offsetof(AdamState, sched) == 96 && offsetof(AdamState, ticket) == 128, "layout");
 
 struct AdamCoef {
   float bc1, inv_sqrt_bc2, beta1, beta2, omb1, omb2, eps;
+  float lr_sched[ADAM_MAX_SCHEDULES];
 };
+// get_expon_lr_func's helper (gaussian_splatting.py:69-82) in the double arithmetic numpy gives it, for training step `step`
+// (1-based: the reference passes global_step + 1 / self._step); the float the optimizer applies is its rounding
+__device__ __forceinline__ float lr_schedule_eval(const LrSchedule& s, int step) {
+  step -= s.step_offset;
+  if (step < 0 || (s.lr_init == 0.0 && s.lr_final == 0.0)) return 0.f;
+  double delay_rate = 1.0;
+  if (s.lr_delay_steps > 0) {
+    const double u = fmin(fmax((double) step / (double) s.lr_delay_steps, 0.0), 1.0);
+    delay_rate = s.lr_delay_mult + (1.0 - s.lr_delay_mult) * sin(0.5 * 3.14159265358979323846 * u);
+  }
+  const double t = fmin(fmax((double) step / (double) s.max_steps, 0.0), 1.0);
+  return (float) (delay_rate * exp(log(s.lr_init) * (1.0 - t) + log(s.lr_final) * t));
+}
+// after the counter moved to `count`: slot i's rate for step count + 1, the old one kept for the closed step (lanes 0..n-1)
+__device__ __forceinline__ void lr_schedules_advance(AdamState* st, int lane, float count) {
+  const int n = (int) st->n_sched;
+  if (lane < n && lane < ADAM_MAX_SCHEDULES) {
+    st->lr_prev[lane] = st->lr_now[lane];
+    st->lr_now[lane]  = lr_schedule_eval(st->sched[lane], (int) count + 1);
+  }
+}
 // bias corrections of step count + 1.  Hyper-parameters arrive as doubles and (1 - beta) is formed in double, as torch
 // does: 1.0f - 0.999f is off by 1.3e-5
 // after_advance: the piece runs AFTER the launch that advanced the counter but belongs to that step (a side job of the next
@@ -47,13 +87,28 @@ __device__ __forceinline__ AdamCoef adam_coefficients(double beta1d, double beta
     bool after_advance = false) {
   const double bc1 = after_advance ? st->q1 : (1.0 - beta1d) + beta1d * st->q1;
   const double bc2 = after_advance ? st->q2 : (1.0 - beta2d) + beta2d * st->q2;
-  return AdamCoef{(float) bc1, (float) (1.0 / sqrt(bc2)), (float) beta1d, (float) beta2d, (float) (1.0 - beta1d),
-      (float) (1.0 - beta2d), eps};
+  AdamCoef k{(float) bc1, (float) (1.0 / sqrt(bc2)), (float) beta1d, (float) beta2d, (float) (1.0 - beta1d),
+      (float) (1.0 - beta2d), eps, {}};
+#pragma unroll
+  for (int i = 0; i < ADAM_MAX_SCHEDULES; ++i) k.lr_sched[i] = after_advance ? st->lr_prev[i] : st->lr_now[i];
+  return k;
 }
-__device__ __forceinline__ void adam_advance(AdamState* st, double beta1d, double beta2d) {
-  st->count += 1.0f;
-  st->q1 = (1.0 - beta1d) + beta1d * st->q1;
-  st->q2 = (1.0 - beta2d) + beta2d * st->q2;
+// the rate a tensor's update uses in this launch: its own, or its schedule slot's
+__device__ __forceinline__ float adam_lr(const AdamTensor& T, const AdamCoef& k) {
+  float lr = T.lr;
+#pragma unroll
+  for (int i = 0; i < ADAM_MAX_SCHEDULES; ++i) lr = T.sched == i + 1 ? k.lr_sched[i] : lr;
+  return lr;
+}
+// (one thread: the counter; then the schedules, one lane each -- call with the lanes of one wave)
+__device__ __forceinline__ void adam_advance(AdamState* st, double beta1d, double beta2d, int lane = 0) {
+  float count = st->count + 1.0f;
+  if (lane == 0) {
+    st->count = count;
+    st->q1 = (1.0 - beta1d) + beta1d * st->q1;
+    st->q2 = (1.0 - beta2d) + beta2d * st->q2;
+  }
+  lr_schedules_advance(st, lane, count);
 }
 
 // which tensor owns a chunk: lane i keeps the first chunk of tensor i (loaded once by the caller into `first0`, INT64_MAX
@@ -101,7 +156,7 @@ __device__ __forceinline__ void adam_update_element(float& p, float& m, float& v
 
 // one chunk (ADAM_CHUNK elements from `base`) of tensor T, by 256 threads; t256 = this thread's index among them
 __device__ __forceinline__ void adam_update_chunk(const AdamTensor& T, int64_t base, int t256, const AdamCoef& k) {
-  const float step_size = T.lr / k.bc1;
+  const float step_size = adam_lr(T, k) / k.bc1;
   const bool aligned = ((reinterpret_cast<uintptr_t>(T.param) | reinterpret_cast<uintptr_t>(T.grad) |
                          reinterpret_cast<uintptr_t>(T.exp_avg) | reinterpret_cast<uintptr_t>(T.exp_avg_sq)) & 15) == 0;
 #pragma unroll
@@ -159,7 +214,7 @@ __device__ __forceinline__ void adam_update_chunk2(const AdamTensor& A, int64_t 
   for (int c = 0; c < 2; ++c) {
     const AdamTensor& T = c ? Bt : A;
     const int64_t base  = c ? baseB : baseA;
-    const float ss      = T.lr / k.bc1;
+    const float ss      = adam_lr(T, k) / k.bc1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t i = base + ((int64_t) r * ADAM_THREADS + t256) * 4;

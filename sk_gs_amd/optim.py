@@ -61,6 +61,7 @@ class FusedAdam:
         self._chunk = int(lib.skgs_adam_chunk_elems())
         assert int(lib.skgs_adam_tensor_bytes()) == 56
         self._state_listeners = []  # callables run after the moments changed from outside a step (see add_state_listener)
+        self._schedules, self._sched_of_group, self._sched_dev = [], {}, None  # device learning-rate schedules (set_lr_schedule)
         self.params, self._lr_index = [], []
         for gi, g in enumerate(self.param_groups):
             g['params'] = [p for p in g['params']]
@@ -111,8 +112,8 @@ class FusedAdam:
                     p.grad, p._grad_slot = torch.zeros_like(store)[:p.shape[0]], store.numel()
             st = self.state[p]
             n = p.numel()
-            blob += struct.pack('<QQQQqqff', p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(),
-                                st['exp_avg_sq'].data_ptr(), n, chunk0, float(self.param_groups[gi]['lr']), 0.0)
+            blob += struct.pack('<QQQQqqfi', p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(),
+                                st['exp_avg_sq'].data_ptr(), n, chunk0, float(self.param_groups[gi]['lr']), self._sched_slot(gi))
             # chunk space by CAPACITY: ranges handed to captured launches stay valid when the live row count changes (the
             # kernels read n from this table and skip the rest of a slot)
             chunk0 += (slot_numel(p) + self._chunk - 1) // self._chunk
@@ -166,8 +167,9 @@ class FusedAdam:
         blob = bytearray()
         for k, (p, gi) in enumerate(zip(self.params, self._lr_index)):
             st = self.state[p]
-            blob += struct.pack('<QQQQqqff', p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(),
-                                st['exp_avg_sq'].data_ptr(), p.numel(), self._chunk0[k], float(self.param_groups[gi]['lr']), 0.0)
+            blob += struct.pack('<QQQQqqfi', p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(),
+                                st['exp_avg_sq'].data_ptr(), p.numel(), self._chunk0[k], float(self.param_groups[gi]['lr']),
+                                self._sched_slot(gi))
         return blob
 
     def _table_of_this_capture(self) -> 'torch.Tensor':
@@ -221,7 +223,7 @@ class FusedAdam:
         for ent in self._capture_tables:
             blob = bytearray(ent['pin'].numpy().tobytes())  # addresses as captured; only the rates are rewritten
             for k, gi in enumerate(self._lr_index):
-                struct.pack_into('<f', blob, 56 * k + 48, float(self.param_groups[gi]['lr']))
+                struct.pack_into('<fi', blob, 56 * k + 48, float(self.param_groups[gi]['lr']), self._sched_slot(gi))
             self._h2d(scratch, blob)
             ent['pin'].copy_(scratch, non_blocking=True)
             ent['table'].copy_(scratch, non_blocking=True)
@@ -445,6 +447,56 @@ class FusedAdam:
         self._upload()
         self._refresh_captured_rates()  # tables of captured steps (_table_of_this_capture), stream-ordered
 
+    # ------------------------------------------------------------------------------------------ device learning-rate schedules
+    def _sched_slot(self, gi: int) -> int:
+        """the `sched` word of a descriptor: 0, or 1 + the schedule of the parameter's group"""
+        return self._sched_of_group.get(gi, -1) + 1
+
+    def set_lr_schedule(self, groups, lr_init: float, lr_final: float, max_steps: int, lr_delay_steps: int = 0, lr_delay_mult: float = 1.0,
+                        step_offset: int = 0):
+        """The named group(s) follow ``get_expon_lr_func(lr_init, lr_final, lr_delay_steps, lr_delay_mult, max_steps)`` (networks/
+        gaussian_splatting.py:56-84) of the 1-based training step minus ``step_offset`` -- evaluated ON THE DEVICE by the launch that
+        advances the step counter (``skgs_adam_set_lr_schedules``, csrc/adam_update.h): what the reference's ``update_learning_rate``
+        does from a before-train-step hook (train.py:140-141; `xyz`: gaussian_splatting.py:455-470; the deform networks' groups with
+        the stage's first step as offset: sk_gs.py:611-632), without the host -- a step replayed in a hipGraph, several steps per
+        replay, follows it step for step.  Up to 8 schedules; outside graph capture.  ``clear_lr_schedules()`` returns to ``set_lr``."""
+        names = [groups] if isinstance(groups, (str, int)) else list(groups)
+        idx = [n if isinstance(n, int) else next(i for i, g in enumerate(self.param_groups) if g.get('name') == n) for n in names]
+        entry = (float(lr_init), float(lr_final), float(lr_delay_mult), int(lr_delay_steps), int(max_steps), int(step_offset))
+        if entry in self._schedules:
+            slot = self._schedules.index(entry)
+        else:
+            assert len(self._schedules) < 8, 'FusedAdam: at most 8 device learning-rate schedules'
+            self._schedules.append(entry)
+            slot = len(self._schedules) - 1
+        for gi in idx:
+            self._sched_of_group[gi] = slot
+        self._upload_schedules()
+
+    def clear_lr_schedules(self):
+        self._schedules, self._sched_of_group = [], {}
+        self._upload_schedules()
+
+    def _upload_schedules(self):
+        lib = _C.load_library()
+        blob = b''.join(struct.pack('<dddiiii', a, b, c, d, e, f, 0) for a, b, c, d, e, f in self._schedules)
+        n = len(self._schedules)
+        if n:  # (a new tensor per upload: launches already queued keep reading the old array)
+            self._sched_dev = torch.empty(max(len(blob), 64), dtype=torch.uint8, device=self._table.device)
+            self._h2d(self._sched_dev, blob)
+        _C._check(lib.skgs_adam_set_lr_schedules(C.c_void_p(self.step_state.data_ptr()), C.c_void_p(self._sched_dev.data_ptr() if n else None),
+                                                 C.c_int32(n), _C._stream()))
+        self._upload()
+        self._refresh_captured_rates()
+
+    def scheduled_lr(self, group) -> float:
+        """(synchronising) the rate the next step applies to ``group``: its schedule's current value on the device, or its ``lr``"""
+        gi = group if isinstance(group, int) else next(i for i, g in enumerate(self.param_groups) if g.get('name') == group)
+        slot = self._sched_of_group.get(gi)
+        if slot is None:
+            return float(self.param_groups[gi]['lr'])
+        return float(self.step_state[8 + slot].item())   # AdamState.lr_now (byte 32)
+
     # ---------------------------------------------------------------------------------------------------------
     def state_dict(self) -> dict:
         """``torch.optim.Adam.state_dict()`` layout: ``state`` = {param index: {step, exp_avg, exp_avg_sq}} and
@@ -496,6 +548,10 @@ class FusedAdam:
         blob = struct.pack('<ffdd', float(count), 0.0, 1.0 - self.betas[0] ** count, 1.0 - self.betas[1] ** count)
         self.step_state.zero_()
         self._h2d(self.step_state.view(torch.uint8), blob)
+        if self._schedules:  # (the state also holds the schedules' pointer and current rates: re-derived for the restored count)
+            lib = _C.load_library()
+            _C._check(lib.skgs_adam_set_lr_schedules(C.c_void_p(self.step_state.data_ptr()), C.c_void_p(self._sched_dev.data_ptr()),
+                                                     C.c_int32(len(self._schedules)), _C._stream()))
 
     def zero_grad(self, set_to_none: bool = False):
         for p in self.params:

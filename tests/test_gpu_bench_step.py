@@ -27,6 +27,10 @@ pytestmark = pytest.mark.gpu
 
 CONFIGS = {1: dict(P=100_000, M=20, K=5, W=800, H=800), 4: dict(P=500_000, M=24, K=5, W=1024, H=1024)}
 VIEWS, STEPS, LR = 3, 2, 1e-4
+# the reference's per-step learning-rate schedules (update_learning_rate before every train step: train.py:140-141,
+# gaussian_splatting.py:455-470, sk_gs.py:611-632), steep enough for two steps to tell a wrong rate: `xyz` and the deform network
+SCHEDULES = {'xyz': dict(lr_init=LR * 0.16, lr_final=LR * 0.0016, max_steps=3, lr_delay_steps=2, lr_delay_mult=0.3),
+             'deform_net': dict(lr_init=LR, lr_final=LR * 0.01, max_steps=4)}
 
 
 def _bench_runtime(model, settings, targets, background, pre_forward):
@@ -58,6 +62,8 @@ def _bench_runtime(model, settings, targets, background, pre_forward):
     span = fstep.table_grad_span()
     fstep.tables_zeroed_by_optimizer = span is not None
     opt = FusedAdam(model.param_groups(lr=LR), eps=1e-15, betas=(0.9, 0.999), zero_after_step=span)
+    for name, kw in SCHEDULES.items():  # evaluated on the device by the step's closing launch
+        opt.set_lr_schedule(name, **kw)
     train = FusedTrainStep(fstep, opt)
     assert train.fused
     table.set_order(list(range(VIEWS)))
@@ -89,7 +95,12 @@ def test_bench_step_trains_the_same_parameters_as_operator_path_plus_torch_adam(
         # ---- reference: operator path + torch Adam, views 0, 1
         ref_opt = torch.optim.Adam(ref_model.param_groups(lr=LR), eps=1e-15, betas=(0.9, 0.999))
         ref_images = []
+        from sk_gs_amd.optim import position_lr
         for i in range(STEPS):
+            for grp in ref_opt.param_groups:  # what the reference's hook does before the step (1-based step numbers)
+                if grp.get('name') in SCHEDULES:
+                    kw = SCHEDULES[grp['name']]
+                    grp['lr'] = position_lr(i + 1, kw['lr_init'], kw['lr_final'], kw['max_steps'], kw.get('lr_delay_steps', 0), kw.get('lr_delay_mult', 1.0))
             ref_opt.zero_grad(set_to_none=True)
             out = ref_model.render(settings[i], time_id=i, background=background)
             ref_images.append(out['images'].detach().clone())

@@ -533,3 +533,119 @@ def test_state_listeners_hear_every_change_of_the_moments_from_outside_a_step():
     rows = torch.arange(40, device='cuda', dtype=torch.int32)
     opt.gather_rows(['xyz'], rows, 40)
     assert len(heard) == 3
+
+
+def test_device_lr_schedules_follow_the_reference_step_for_step_inside_multi_step_graphs():
+    """update_learning_rate runs before every train step in the reference (train.py:140-141); here the launch that
+    advances the step counter evaluates get_expon_lr_func on the device.  Four optimizer steps per hipGraph replay over 40 steps: the
+    rate of EVERY step equals float32 of the reference's value (tests/golden/lr_schedule_dense.npz, written by the reference's own
+    get_expon_lr_func) bit for bit, and it is the rate the update applies; restored step counts (a resumed run) and the schedules'
+    stage offset land on the right values too."""
+    import os
+    from sk_gs_amd.optim import FusedAdam, position_lr
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'lr_schedule_dense.npz'))
+    steps = z['steps'].tolist()
+    want = {name: {s: np.float32(v) for s, v in zip(steps, z[name])} for name in ('xyz', 'deform', 'eased')}
+    args = {name: z[name + '_args'] for name in want}
+    dev = 'cuda'
+    xyz, net, other = (torch.nn.Parameter(torch.zeros(n, device=dev)) for n in (3000, 700, 50))
+    opt = FusedAdam([{'params': [xyz], 'lr': 123.0, 'name': 'xyz'}, {'params': [other], 'lr': 1e-2, 'name': 'other'},
+                     {'params': [net], 'lr': 456.0, 'name': 'sk_deform'}], eps=1e-15)
+
+    def sched(name, group, offset=0):
+        a = args[name]
+        opt.set_lr_schedule(group, lr_init=a[0], lr_final=a[1], lr_delay_steps=int(a[2]), lr_delay_mult=a[3], max_steps=int(a[4]), step_offset=offset)
+    sched('xyz', 'xyz')
+    sched('eased', 'sk_deform')
+    for p in (xyz, net, other):
+        p.grad.fill_(0.5)                                  # constant gradient: m_hat / sqrt(v_hat) = 1, every step moves by its rate
+    assert np.float32(opt.scheduled_lr('xyz')) == want['xyz'][1] and np.float32(opt.scheduled_lr('sk_deform')) == want['eased'][1]
+    assert opt.scheduled_lr('other') == 1e-2
+    # four steps per replay; after each step the state's rates (of the NEXT step) and the parameters are logged by the graph itself
+    log_lr, log_p = torch.zeros(4, 8, device=dev), torch.zeros(4, 3, device=dev)
+    g = torch.cuda.CUDAGraph()
+    opt.rebind()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            pass
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        for i in range(4):
+            opt.step()
+            log_lr[i].copy_(opt.step_state[8:16])
+            log_p[i].copy_(torch.stack([xyz[0], net[0], other[0]]))
+    # (the capture itself does not execute: the counter is still 0)
+    assert float(opt.step_count) == 0
+    prev = np.zeros(3, np.float64)
+    for r in range(10):
+        g.replay()
+        torch.cuda.synchronize()
+        lr_next, p_now = log_lr.cpu().numpy(), log_p.cpu().numpy().astype(np.float64)
+        for i in range(4):
+            step = 4 * r + i + 1                              # the 1-based training step just taken
+            assert np.float32(lr_next[i, 0]) == want['xyz'][step + 1], (step, lr_next[i, 0], want['xyz'][step + 1])
+            assert np.float32(lr_next[i, 1]) == want['eased'][step + 1], (step, lr_next[i, 1], want['eased'][step + 1])
+            moved = prev - p_now[i]
+            for j, rate in enumerate((want['xyz'][step], want['eased'][step], np.float32(1e-2))):
+                assert abs(moved[j] - float(rate)) <= 3e-6 * float(rate) + 1e-9, (step, j, moved[j], rate)
+            prev = p_now[i]
+    assert float(opt.step_count) == 40
+    # a restored step count: the rates are re-derived for it (float32 of the reference's double, every sampled step up to 45 000)
+    bad = 0
+    for name, group in (('xyz', 'xyz'), ('eased', 'sk_deform')):
+        for st in steps[65::7]:
+            opt._set_step_count(float(st - 1))               # st - 1 steps taken: the next one is training step st
+            got = np.float32(opt.scheduled_lr(group))
+            bad += int(got != want[name][st])
+            assert abs(float(got) - float(want[name][st])) <= 1.2e-7 * float(want[name][st]), (name, st)
+    assert bad == 0, f'{bad} sampled steps differ from float32(reference) in the last bit'
+    # the stage offset of sk_gs.py:621-626, and the host twin used with set_lr
+    opt._set_step_count(0.0)
+    sched('deform', 'sk_deform', offset=10_000)
+    opt._set_step_count(10_088.0)
+    assert np.float32(opt.scheduled_lr('sk_deform')) == want['deform'][89]
+    a = args['deform']
+    assert np.float32(position_lr(89, a[0], a[1], int(a[4]), int(a[2]), a[3])) == want['deform'][89]
+    opt.clear_lr_schedules()
+    assert opt.scheduled_lr('xyz') == 123.0
+
+
+def test_device_lr_schedule_reaches_every_kind_of_update_piece():
+    """a scheduled group's rate is the same in the one-launch step and in a step taken in pieces -- against torch.optim.Adam fed the
+    reference schedule by hand (pieces that run AFTER the counter advanced, FusedTrainStep's pre-forward, use the closed step's rates:
+    tests/test_gpu_bench_step.py trains with the schedule on, pre-forward on and off)"""
+    from sk_gs_amd.optim import FusedAdam, position_lr
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(3)
+    a0, b0 = torch.randn(5000, generator=g), torch.randn(9000, generator=g)
+    grads = [(torch.randn(5000, generator=g), torch.randn(9000, generator=g)) for _ in range(6)]
+    kw = dict(lr_init=2e-2, lr_final=1e-4, max_steps=5, lr_delay_steps=3, lr_delay_mult=0.2)
+
+    def run(mode):
+        a, b = torch.nn.Parameter(a0.clone().to(dev)), torch.nn.Parameter(b0.clone().to(dev))
+        if mode == 'torch':
+            opt = torch.optim.Adam([{'params': [a], 'lr': 1.0}, {'params': [b], 'lr': 3e-3}], eps=1e-15)
+        else:
+            opt = FusedAdam([{'params': [a], 'lr': 1.0, 'name': 'xyz'}, {'params': [b], 'lr': 3e-3, 'name': 'rest'}], eps=1e-15)
+            opt.set_lr_schedule('xyz', **kw)
+        for i, (ga, gb) in enumerate(grads):
+            if mode == 'torch':
+                opt.param_groups[0]['lr'] = position_lr(i + 1, kw['lr_init'], kw['lr_final'], kw['max_steps'], kw['lr_delay_steps'], kw['lr_delay_mult'])
+                a.grad, b.grad = ga.to(dev), gb.to(dev)
+                opt.step()
+            else:
+                a.grad.copy_(ga), b.grad.copy_(gb)
+                if mode == 'one':
+                    opt.step()
+                else:
+                    opt.step(['rest'], advance=False)
+                    opt.step(['xyz'], advance=True)
+        torch.cuda.synchronize()
+        return a.detach().cpu(), b.detach().cpu()
+    ref = run('torch')
+    for mode in ('one', 'pieces'):
+        got = run(mode)
+        assert rel_err(got[0], ref[0]) <= 5e-6 and rel_err(got[1], ref[1]) <= 5e-6, (mode, rel_err(got[0], ref[0]))
+    assert torch.equal(run('one')[0], run('pieces')[0])
