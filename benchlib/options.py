@@ -70,6 +70,9 @@ def build_parser():
     ap.add_argument('--views', type=int, default=8)
     ap.add_argument('--ppl', type=int, default=0, help='pixels per lane of the blend kernels (0 = heuristic)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--list-headroom', type=float, default=1.0,
+                    help='multiplies the room the tile lists and the binning capacity get over what the first renders needed (a drifting '
+                         'workload -- U(0,1) targets -- outgrows the default 1.2-1.5x; overflow inside the timed region fails the run)')
     ap.add_argument('--no-survey-recipe', action='store_true',
                     help="skip the second short run the default one-GPU line carries under `survey_recipe`: SURVEY.md 8(d)'s recipe "
                          "to the letter (U(0,1) targets, Gaussians in generation order) in a child process")

@@ -447,7 +447,7 @@ int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred,
  * The reference calls update_learning_rate before EVERY training step (train.py:140-141): the `xyz` group follows
  * get_expon_lr_func (networks/gaussian_splatting.py:56-84,455-470: log-linear from lr_init to lr_final over max_steps, eased in by
  * lr_delay_mult + (1 - lr_delay_mult) sin(pi/2 clip(step / lr_delay_steps))), the deform networks' groups a second such schedule
- * with a stage offset (networks/sk_gs.py:611-632).  Up to 8 schedules live in the optimizer's device state: a tensor descriptor
+ * with a stage offset (networks/sk_gs.py:611-632).  Up to 4 schedules live in the optimizer's device state: a tensor descriptor
  * whose `sched` word (the int32 after `lr`, 0 = none) is k > 0 takes schedule k - 1's rate instead of its own `lr`; the launch that
  * ADVANCES the step counter (skgs_adam_step, skgs_adam_step_range(advance = 1), skgs_adam_step_tail) evaluates every schedule for
  * the training step that follows -- in the double arithmetic numpy gives the reference, rounded to the float the update uses --
@@ -456,12 +456,13 @@ int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred,
  * Training step numbers are 1-based (the reference passes global_step + 1 / self._step); a schedule sees step - step_offset. */
 typedef struct skgs_lr_schedule {
   double lr_init, lr_final, lr_delay_mult;
+  double log_lr_init, log_lr_final; /* np.log of the two rates, formed by the host: the reference's own arithmetic (0 if the rate is 0) */
   int32_t lr_delay_steps; /* 0: no ease-in */
   int32_t max_steps;
   int32_t step_offset;    /* sk_gs.py:621-626: the stage's first step */
   int32_t reserved;
 } skgs_lr_schedule;
-/* schedules: DEVICE array of n <= 8 entries, alive and unchanged while the optimizer steps.  Evaluates them for the state's current
+/* schedules: DEVICE array of n <= 4 entries, alive and unchanged while the optimizer steps.  Evaluates them for the state's current
  * count (call it again after restoring a step count).  n = 0 removes them. */
 int skgs_adam_set_lr_schedules(float* step_state, const skgs_lr_schedule* schedules, int32_t n, skgs_stream_t stream);
 size_t skgs_adam_tensor_bytes(void);

@@ -68,6 +68,9 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_step_kernel(int n_tensors, 
   double pf_q1 = 0.0, pf_q2 = 0.0;
   float pf_count = 0.f;
   if (advance) pf_q1 = state->q1, pf_q2 = state->q2, pf_count = state->count;
+  // the scheduled rates of the step after next, staged by the first wave of workgroup 0 while the update streams (nobody reads the
+  // staging slots in this launch; its ticket below publishes them to the workgroup that commits)
+  if (advance && blockIdx.x == 0 && threadIdx.x < 64) lr_schedules_stage(state, threadIdx.x, pf_count);
   if (advance && va.slot && blockIdx.x == gridDim.x - 1) {  // the extra workgroup: next view's record -> the live slot
     const int c = va.cursor[0];
     const int n = va.n > 0 ? va.n : max(va.cursor[1], 1);  // n_order = 0: the order's length is a device word too
@@ -85,7 +88,10 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_step_kernel(int n_tensors, 
   if (advance) {
     __shared__ unsigned s_last;
     __syncthreads();  // every thread's reads of the state and of its gradients are done
-    if (threadIdx.x == 0) s_last = atomicAdd(&state->ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    if (threadIdx.x == 0) {
+      __threadfence();  // (workgroup 0's staged rates before its ticket)
+      s_last = atomicAdd(&state->ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
     __syncthreads();
     if (s_last) {
       for (int64_t i = threadIdx.x; i < zero_n; i += ADAM_THREADS) zero_after[i] = 0.f;
@@ -95,7 +101,8 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_step_kernel(int n_tensors, 
         state->q2     = (1.0 - beta2d) + beta2d * pf_q2;
         state->ticket = 0u;
       }
-      lr_schedules_advance(state, threadIdx.x, pf_count + 1.0f);  // the scheduled rates of the step that follows (lanes 0..n-1)
+      __threadfence();
+      lr_schedules_commit(state, threadIdx.x);  // now -> prev, staged -> now (lanes 0..3)
     }
   }
 }
@@ -121,6 +128,7 @@ __global__ void __launch_bounds__(64) adam_set_schedules_kernel(AdamState* state
     const int count = (int) state->count;
     state->lr_now[lane]  = lane < n ? lr_schedule_eval(sched[lane], count + 1) : 0.f;
     state->lr_prev[lane] = lane < n ? lr_schedule_eval(sched[lane], count) : 0.f;
+    state->lr_next[lane] = lane < n ? lr_schedule_eval(sched[lane], count + 2) : 0.f;
   }
 }
 
@@ -223,9 +231,9 @@ int skgs_adam_step(int32_t n_tensors, const void* tensors, int64_t total_chunks,
 
 /* Learning-rate schedules evaluated on the device (the reference's per-iteration update_learning_rate: train.py:140-141,
  * gaussian_splatting.py:56-84,455-470, sk_gs.py:611-632).  schedules: DEVICE array of n <= 8 skgs_lr_schedule (it must stay alive and
- * unchanged while the optimizer steps); tensors whose descriptor carries slot k (the int32 after `lr`) take schedule k - 1's rate. */
+ * unchanged while the optimizer steps; n <= 4); tensors whose descriptor carries slot k (the int32 after `lr`) take schedule k - 1's rate. */
 int skgs_adam_set_lr_schedules(float* step_state, const skgs_lr_schedule* schedules, int32_t n, skgs_stream_t stream) {
-  SKGS_REQUIRE(step_state && n >= 0 && n <= ADAM_MAX_SCHEDULES && (n == 0 || schedules), "adam_set_lr_schedules: 0 <= n <= 8 schedules");
+  SKGS_REQUIRE(step_state && n >= 0 && n <= ADAM_MAX_SCHEDULES && (n == 0 || schedules), "adam_set_lr_schedules: 0 <= n <= 4 schedules");
   SKGS_REQUIRE((reinterpret_cast<uintptr_t>(step_state) & 7) == 0, "adam_set_lr_schedules: the state must be 8-byte aligned");
   static_assert(sizeof(skgs_lr_schedule) == sizeof(LrSchedule), "skgs_lr_schedule");
   hipLaunchKernelGGL(adam_set_schedules_kernel, dim3(1), dim3(64), 0, (hipStream_t) stream, reinterpret_cast<AdamState*>(step_state),

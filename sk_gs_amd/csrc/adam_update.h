@@ -32,12 +32,13 @@ constexpr int ADAM_CHUNK   = ADAM_THREADS * 4 * 4;  // elements per 256-thread g
 // parameters; the launch that advances the step counter evaluates them for the step that follows and keeps the closed step's
 // rates for the pieces that still belong to it (after_advance).  A step replayed inside a hipGraph -- four steps per replay in
 // bench.py -- therefore follows the reference's rate step for step, with no host in the loop.
-constexpr int ADAM_MAX_SCHEDULES = 8;
+constexpr int ADAM_MAX_SCHEDULES = 4;
 struct LrSchedule {  // include/skgs.h::skgs_lr_schedule
   double lr_init, lr_final, lr_delay_mult;
+  double log_lr_init, log_lr_final;  // numpy's np.log of the two rates, formed by the HOST (the reference's own arithmetic)
   int32_t lr_delay_steps, max_steps, step_offset, reserved;
 };
-static_assert(sizeof(LrSchedule) == 40, "layout shared with the host binding");
+static_assert(sizeof(LrSchedule) == 56, "layout shared with the host binding");
 struct AdamState {
   float count;       // steps taken so far
   float pad0;
@@ -45,14 +46,15 @@ struct AdamState {
   unsigned n_sched;  // byte 24
   unsigned pad_a;
   float lr_now[ADAM_MAX_SCHEDULES];   // byte 32: the scheduled rates of training step count + 1 (the step in progress)
-  float lr_prev[ADAM_MAX_SCHEDULES];  // byte 64: ... of step `count` (pieces that run after the advance but belong to it)
-  const LrSchedule* sched;            // byte 96
-  float pad1[6];
+  float lr_prev[ADAM_MAX_SCHEDULES];  // byte 48: ... of step `count` (pieces that run after the advance but belong to it)
+  float lr_next[ADAM_MAX_SCHEDULES];  // byte 64: ... of step count + 2, staged early by the advancing launch (off its tail)
+  const LrSchedule* sched;            // byte 80
+  float pad1[10];
   unsigned ticket;   // word 32
   unsigned pad2[31];
 };
 static_assert(sizeof(AdamState) == 256, "layout shared with the host binding");
-static_assert(offsetof(AdamState, lr_now) == 32 && offsetof(AdamState, sched) == 96 && offsetof(AdamState, ticket) == 128, "layout");
+static_assert(offsetof(AdamState, lr_now) == 32 && offsetof(AdamState, sched) == 80 && offsetof(AdamState, ticket) == 128, "layout");
 
 struct AdamCoef {
   float bc1, inv_sqrt_bc2, beta1, beta2, omb1, omb2, eps;
@@ -69,14 +71,19 @@ __device__ __forceinline__ float lr_schedule_eval(const LrSchedule& s, int step)
     delay_rate = s.lr_delay_mult + (1.0 - s.lr_delay_mult) * sin(0.5 * 3.14159265358979323846 * u);
   }
   const double t = fmin(fmax((double) step / (double) s.max_steps, 0.0), 1.0);
-  return (float) (delay_rate * exp(log(s.lr_init) * (1.0 - t) + log(s.lr_final) * t));
+  return (float) (delay_rate * exp(s.log_lr_init * (1.0 - t) + s.log_lr_final * t));
 }
-// after the counter moved to `count`: slot i's rate for step count + 1, the old one kept for the closed step (lanes 0..n-1)
-__device__ __forceinline__ void lr_schedules_advance(AdamState* st, int lane, float count) {
+// The advancing launch, in two parts.  EARLY (any one wave, before its own work; `count` = the counter as the launch found it): the
+// rates of the step after next into the staging slots -- nobody reads those during the launch, and the double exp / sin are off the
+// launch's tail.  LATE (the thread(s) that move the counter, after every reader of lr_now is done): now -> prev, staged -> now.
+__device__ __forceinline__ void lr_schedules_stage(AdamState* st, int lane, float count) {
   const int n = (int) st->n_sched;
-  if (lane < n && lane < ADAM_MAX_SCHEDULES) {
+  if (lane < n && lane < ADAM_MAX_SCHEDULES) st->lr_next[lane] = lr_schedule_eval(st->sched[lane], (int) count + 2);
+}
+__device__ __forceinline__ void lr_schedules_commit(AdamState* st, int lane) {
+  if (lane < ADAM_MAX_SCHEDULES) {
     st->lr_prev[lane] = st->lr_now[lane];
-    st->lr_now[lane]  = lr_schedule_eval(st->sched[lane], (int) count + 1);
+    st->lr_now[lane]  = st->lr_next[lane];
   }
 }
 // bias corrections of step count + 1.  Hyper-parameters arrive as doubles and (1 - beta) is formed in double, as torch
@@ -100,15 +107,16 @@ __device__ __forceinline__ float adam_lr(const AdamTensor& T, const AdamCoef& k)
   for (int i = 0; i < ADAM_MAX_SCHEDULES; ++i) lr = T.sched == i + 1 ? k.lr_sched[i] : lr;
   return lr;
 }
-// (one thread: the counter; then the schedules, one lane each -- call with the lanes of one wave)
+// (lanes of ONE wave: lane 0 moves the counter, the schedules advance one lane each)
 __device__ __forceinline__ void adam_advance(AdamState* st, double beta1d, double beta2d, int lane = 0) {
-  float count = st->count + 1.0f;
+  const float count = st->count;
+  lr_schedules_stage(st, lane, count);
   if (lane == 0) {
-    st->count = count;
+    st->count = count + 1.0f;
     st->q1 = (1.0 - beta1d) + beta1d * st->q1;
     st->q2 = (1.0 - beta2d) + beta2d * st->q2;
   }
-  lr_schedules_advance(st, lane, count);
+  lr_schedules_commit(st, lane);  // (same lane wrote the staging slot it reads)
 }
 
 // which tensor owns a chunk: lane i keeps the first chunk of tensor i (loaded once by the caller into `first0`, INT64_MAX

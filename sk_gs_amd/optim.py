@@ -459,14 +459,14 @@ class FusedAdam:
         advances the step counter (``skgs_adam_set_lr_schedules``, csrc/adam_update.h): what the reference's ``update_learning_rate``
         does from a before-train-step hook (train.py:140-141; `xyz`: gaussian_splatting.py:455-470; the deform networks' groups with
         the stage's first step as offset: sk_gs.py:611-632), without the host -- a step replayed in a hipGraph, several steps per
-        replay, follows it step for step.  Up to 8 schedules; outside graph capture.  ``clear_lr_schedules()`` returns to ``set_lr``."""
+        replay, follows it step for step.  Up to 4 schedules; outside graph capture.  ``clear_lr_schedules()`` returns to ``set_lr``."""
         names = [groups] if isinstance(groups, (str, int)) else list(groups)
         idx = [n if isinstance(n, int) else next(i for i, g in enumerate(self.param_groups) if g.get('name') == n) for n in names]
         entry = (float(lr_init), float(lr_final), float(lr_delay_mult), int(lr_delay_steps), int(max_steps), int(step_offset))
         if entry in self._schedules:
             slot = self._schedules.index(entry)
         else:
-            assert len(self._schedules) < 8, 'FusedAdam: at most 8 device learning-rate schedules'
+            assert len(self._schedules) < 4, 'FusedAdam: at most 4 device learning-rate schedules'
             self._schedules.append(entry)
             slot = len(self._schedules) - 1
         for gi in idx:
@@ -479,7 +479,9 @@ class FusedAdam:
 
     def _upload_schedules(self):
         lib = _C.load_library()
-        blob = b''.join(struct.pack('<dddiiii', a, b, c, d, e, f, 0) for a, b, c, d, e, f in self._schedules)
+        import numpy as np
+        lg = lambda v: float(np.log(v)) if v > 0 else 0.0  # noqa: E731  (np.log: what get_expon_lr_func itself evaluates)
+        blob = b''.join(struct.pack('<dddddiiii', a, b, c, lg(a), lg(b), d, e, f, 0) for a, b, c, d, e, f in self._schedules)
         n = len(self._schedules)
         if n:  # (a new tensor per upload: launches already queued keep reading the old array)
             self._sched_dev = torch.empty(max(len(blob), 64), dtype=torch.uint8, device=self._table.device)

@@ -535,13 +535,16 @@ def test_state_listeners_hear_every_change_of_the_moments_from_outside_a_step():
     assert len(heard) == 3
 
 
-def test_device_lr_schedules_follow_the_reference_step_for_step_inside_multi_step_graphs():
+@pytest.mark.parametrize('n_big', [0, 3_000_000])
+def test_device_lr_schedules_follow_the_reference_step_for_step_inside_multi_step_graphs(n_big):
     """update_learning_rate runs before every train step in the reference (train.py:140-141); here the launch that
     advances the step counter evaluates get_expon_lr_func on the device.  Four optimizer steps per hipGraph replay over 40 steps: the
     rate of EVERY step equals float32 of the reference's value (tests/golden/lr_schedule_dense.npz, written by the reference's own
     get_expon_lr_func) bit for bit, and it is the rate the update applies; restored step counts (a resumed run) and the schedules'
-    stage offset land on the right values too."""
+    stage offset land on the right values too.  n_big: a large tensor beside them -- the step then has more than 256 chunks and the
+    counter is advanced by the separate bump launch instead of the update launch's last workgroup."""
     import os
+    import numpy as np
     from sk_gs_amd.optim import FusedAdam, position_lr
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'lr_schedule_dense.npz'))
     steps = z['steps'].tolist()
@@ -549,8 +552,11 @@ def test_device_lr_schedules_follow_the_reference_step_for_step_inside_multi_ste
     args = {name: z[name + '_args'] for name in want}
     dev = 'cuda'
     xyz, net, other = (torch.nn.Parameter(torch.zeros(n, device=dev)) for n in (3000, 700, 50))
-    opt = FusedAdam([{'params': [xyz], 'lr': 123.0, 'name': 'xyz'}, {'params': [other], 'lr': 1e-2, 'name': 'other'},
-                     {'params': [net], 'lr': 456.0, 'name': 'sk_deform'}], eps=1e-15)
+    groups = [{'params': [xyz], 'lr': 123.0, 'name': 'xyz'}, {'params': [other], 'lr': 1e-2, 'name': 'other'},
+              {'params': [net], 'lr': 456.0, 'name': 'sk_deform'}]
+    if n_big:
+        groups.insert(1, {'params': [torch.nn.Parameter(torch.zeros(n_big, device=dev))], 'lr': 1e-3, 'name': 'big'})
+    opt = FusedAdam(groups, eps=1e-15)
 
     def sched(name, group, offset=0):
         a = args[name]
@@ -575,7 +581,7 @@ def test_device_lr_schedules_follow_the_reference_step_for_step_inside_multi_ste
         for i in range(4):
             opt.step()
             log_lr[i].copy_(opt.step_state[8:16])
-            log_p[i].copy_(torch.stack([xyz[0], net[0], other[0]]))
+            log_p[i].copy_(torch.stack([xyz.detach()[0], net.detach()[0], other.detach()[0]]))
     # (the capture itself does not execute: the counter is still 0)
     assert float(opt.step_count) == 0
     prev = np.zeros(3, np.float64)
