@@ -53,9 +53,11 @@ PLAIN = ['--exchange', 'allreduce']
 @pytest.mark.parametrize('port,ranks,extra', [(29577, 2, PLAIN), (29578, 2, ['--pipeline']), (29579, 2, ['--compact-logits']),
                                               (29580, 2, ['--autograd']), (29581, 4, PLAIN), (29582, 2, ['--sh-factors']),
                                               (29583, 2, ['--sh-factors', '--overlap-gather']), (29584, 2, PLAIN + ['--bone-tables']),
-                                              (29587, 2, PLAIN + ['--graph-per-view']), (29588, 2, PLAIN + ['--pre-forward', 'off'])])
+                                              (29587, 2, PLAIN + ['--graph-per-view']), (29588, 2, PLAIN + ['--pre-forward', 'off']),
+                                              (29589, 8, PLAIN), (29590, 8, ['--sh-factors'])])
 def test_ranks_share_the_gpu_and_stay_identical(port, ranks, extra):
-    """The driver's multi-GPU launch line with 2 or 4 ranks on this one GPU (gloo moves the gradients: RCCL refuses two ranks
+    """The driver's multi-GPU launch line with 2, 4 or 8 ranks (the driver's largest run: no rank-count assumption may surface on
+    the first real 8-GPU lease) on this one GPU (gloo moves the gradients: RCCL refuses two ranks
     per device): the real view-parallel schedule -- graph(fwd+bwd) | all-reduce | graph(Adam) -- must keep the replicas
     bit-identical and print one line from rank 0 with whole-job throughput.  `--exchange allreduce`: ONE plain all-reduce of
     the flat gradient buffer; the byte-saving / overlapping exchanges are flags (the default, `auto`, ranks them: next test)."""
