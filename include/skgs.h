@@ -717,21 +717,30 @@ int skgs_sp_skinning_backward(const skgs_deform_inputs* in, int32_t F, const flo
  * Two launches forward (a transposed copy of the hidden layers' weights into `saved`, then MFMA row blocks: 4 superpoints per
  * workgroup through the whole network, the weights streamed from that copy); two backward (row blocks, then all weight
  * gradients on the whole chip).  The backward WRITES the gradient of every parameter into the matching
- * pointer of `grads` (same struct; points / time ignored).  Cotangents: either g_raw [M,10] (w.r.t. the raw row above) or
+ * pointer of `grads` (same struct; time ignored, points: see SKGS_SP_NET_LBS_C).  Cotangents: either g_raw [M,10] ([M,14] with the
+ * local-rotation head; w.r.t. the raw row above) or
  * g_bone_T [M,7] / g_d_rot [M,4] / g_d_scale [M,3] (any may be NULL; the normalisation's backward runs in the launch).
  * No gradient w.r.t. points or time (the reference detaches the positions, sk_gs.py:746-748,845).
  * saved: skgs_sp_net_saved_bytes(M), written by the forward, read by the backward.  workspace:
  * skgs_sp_net_workspace_bytes(M), ZERO before the first call (the library keeps its first 256 bytes zero between calls).
  * side (may be NULL): an optimizer piece for the CUs the two backward launches leave idle (split between them), as
  * skgs_skeleton_backward. */
+#define SKGS_SP_NET_LBS_C 1 /* skgs_sp_net.flags: warp_method LBS_c (exps/d_nerf_sc_gs.yaml:32, sk_gs.py:803-804, 1121-1122): the
+                             * superpoint's translation is re-centred on the superpoint, bone_T = [d_xyz + x + R(u)(-x) | u]; the
+                             * backward then also returns d loss / d sp_points through `grads->points` [M,3] (written; may be NULL) */
 typedef struct skgs_sp_net {
-  int32_t M, reserved;
+  int32_t M, flags;
   const float* points;                                   /* [M,3] */
   const float* time;                                     /* DEVICE scalar */
   const float *time_w1, *time_b1, *time_w2, *time_b2;    /* [256,13], [256], [30,256], [30] */
   const float* W[8];
   const float* b[8];
   const float *warp_w, *warp_b, *scaling_w, *scaling_b, *rotation_w, *rotation_b;   /* [3,256] [3] [3,256] [3] [4,256] [4] */
+  /* sep_rot (DeformNetwork.local_rotation, sk_gs.py:275-282,315; both NULL: off): a fourth head [4,256] [4] whose output
+   * g_rotation is what `warp` blends per Gaussian instead of d_rotation (sk_gs.py:848,818-821): d_rot = normalize(g_rotation +
+   * [0,0,0,1]) while bone_T keeps normalize(d_rotation + [0,0,0,1]); the raw row is then [M,14] = [d_xyz | d_rotation | d_scaling |
+   * g_rotation] */
+  const float *local_w, *local_b;
 } skgs_sp_net;
 size_t skgs_sp_net_saved_bytes(int32_t M);
 size_t skgs_sp_net_workspace_bytes(int32_t M);
@@ -748,7 +757,7 @@ typedef struct skgs_sp_prepare {
   void* pairs;
   size_t pairs_bytes;
 } skgs_sp_prepare;
-int skgs_sp_net_forward(const skgs_sp_net* net, float* raw /* [M,10] or NULL */, float* bone_T, float* d_rot, float* d_scale,
+int skgs_sp_net_forward(const skgs_sp_net* net, float* raw /* [M,10] ([M,14] with local_w) or NULL */, float* bone_T, float* d_rot, float* d_scale,
     void* saved, size_t saved_bytes, const skgs_sp_prepare* prepare, skgs_stream_t stream);
 int skgs_sp_net_backward(const skgs_sp_net* net, const skgs_sp_net* grads, const float* g_bone_T, const float* g_d_rot,
     const float* g_d_scale, const float* g_raw, const void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes,

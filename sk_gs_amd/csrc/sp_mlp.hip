@@ -57,6 +57,7 @@ constexpr int RING_F = 32, RING_B = 32;      // weight rows (1 KB each) a wave k
 constexpr int HT     = 36;                   // LDS pitch of a transposed activation row [r & 7][r >> 3]: 32 + 4
 constexpr int XT     = 16;                   // ... of the encoded input: 12 + 4
 constexpr int NOUT   = 10;                   // d_xyz 3 | d_rotation 4 | d_scaling 3
+constexpr int NOUT_MAX = 14;                // ... | g_rotation 4 (sep_rot: the `local_rotation` head, sk_gs.py:275-282,315)
 
 struct __attribute__((packed, aligned(4))) f4u {  // a float4 at 4-byte alignment (weight rows of 93 / 349 floats)
   float x, y, z, w;
@@ -87,6 +88,7 @@ struct SavedView {
   float* x0;    // [Mp][IN0P]   encoded input (columns 93..95 zero)
   float* Y;     // [SPD][Mp][SPW] post-ReLU activations
   float* rawq;  // [Mp][4]      raw rotation head (before + [0,0,0,1] and the normalisation)
+  float* rawl;  // [Mp][4]      raw local-rotation head (sep_rot), likewise
   float* temb;  // [16]         freq(t) (13 used)
   float* thid;  // [THID]       hidden layer of the time network (post-ReLU)
   float* tout;  // [32]         its output (30 used)
@@ -95,7 +97,7 @@ struct SavedView {
 __host__ __device__ inline int pad_rows(int M) { return (M + ROWS - 1) / ROWS * ROWS; }
 __host__ __device__ inline size_t saved_floats(int M) {
   const size_t Mp = pad_rows(M);
-  return Mp * IN0P + (size_t) SPD * Mp * SPW + Mp * 4 + 16 + THID + 32 + (size_t) WT_ROWS * SPW;
+  return Mp * IN0P + (size_t) SPD * Mp * SPW + Mp * 8 + 16 + THID + 32 + (size_t) WT_ROWS * SPW;
 }
 __host__ __device__ inline SavedView saved_view(void* base, int M) {
   const size_t Mp = pad_rows(M);
@@ -104,6 +106,7 @@ __host__ __device__ inline SavedView saved_view(void* base, int M) {
   v.x0 = p, p += Mp * IN0P;
   v.Y = p, p += (size_t) SPD * Mp * SPW;
   v.rawq = p, p += Mp * 4;
+  v.rawl = p, p += Mp * 4;
   v.temb = p, p += 16;
   v.thid = p, p += THID;
   v.tout = p, p += 32;
@@ -209,20 +212,44 @@ struct NetPtrs {  // device copy of skgs_sp_net's pointers
   const float *tw1, *tb1, *tw2, *tb2;
   const float* W[SPD];
   const float* b[SPD];
-  const float* head_w[3];  // warp (3), rotation (4), scaling (3): the order of the raw output row
-  const float* head_b[3];
+  const float* head_w[4];  // warp (3), rotation (4), scaling (3), local rotation (4, sep_rot only): the order of the raw output row
+  const float* head_b[4];
+  int nout;                // 10, or 14 with the local-rotation head
+  int lbs_c;               // warp_method LBS_c: bone_T's translation is d_xyz + x + R(u)(-x) (sk_gs.py:803-804)
 };
 struct GradPtrs {
   float *tw1, *tb1, *tw2, *tb2;
   float* W[SPD];
   float* b[SPD];
-  float* head_w[3];
-  float* head_b[3];
+  float* head_w[4];
+  float* head_b[4];
+  float* points;  // LBS_c: d loss / d sp_points [M,3] (written), or NULL
 };
 __device__ __forceinline__ int head_of(int o, int& row) {  // raw output column -> (head, row of that head's matrix)
   if (o < 3) return row = o, 0;
   if (o < 7) return row = o - 3, 1;
-  return row = o - 7, 2;
+  if (o < 10) return row = o - 7, 2;
+  return row = o - 10, 3;
+}
+// y = R(q) v for a unit quaternion q = (a, w): v + 2 w (a x v) + 2 a x (a x v)   (lie.h:59-64)
+__device__ __forceinline__ void quat_rotate(const float* q, const float* v, float* y) {
+  float uv[3] = {q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0]};
+  uv[0] += uv[0], uv[1] += uv[1], uv[2] += uv[2];
+  y[0] = v[0] + q[3] * uv[0] + (q[1] * uv[2] - q[2] * uv[1]);
+  y[1] = v[1] + q[3] * uv[1] + (q[2] * uv[0] - q[0] * uv[2]);
+  y[2] = v[2] + q[3] * uv[2] + (q[0] * uv[1] - q[1] * uv[0]);
+}
+// d (g . R(q) v) / d q for the four stored numbers of a unit q (the normalisation's Jacobian is applied by the caller):
+//   d/dw = 2 g . (a x v);   d/da = 2 w (v x g) + 2 [g (a . v) + v (g . a) - 2 a (g . v)]
+__device__ __forceinline__ void quat_rotate_grad_q(const float* q, const float* v, const float* g, float* gq) {
+  const float a[3] = {q[0], q[1], q[2]}, w = q[3];
+  const float axv[3] = {a[1] * v[2] - a[2] * v[1], a[2] * v[0] - a[0] * v[2], a[0] * v[1] - a[1] * v[0]};
+  const float vxg[3] = {v[1] * g[2] - v[2] * g[1], v[2] * g[0] - v[0] * g[2], v[0] * g[1] - v[1] * g[0]};
+  const float av = a[0] * v[0] + a[1] * v[1] + a[2] * v[2], ga = g[0] * a[0] + g[1] * a[1] + g[2] * a[2];
+  const float gv = g[0] * v[0] + g[1] * v[1] + g[2] * v[2];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) gq[c] = 2.f * w * vxg[c] + 2.f * (g[c] * av + v[c] * ga - 2.f * a[c] * gv);
+  gq[3] = 2.f * (g[0] * axv[0] + g[1] * axv[1] + g[2] * axv[2]);
 }
 
 // =================================================================================================== forward
@@ -360,11 +387,11 @@ __global__ void __launch_bounds__(NT) sp_net_forward_kernel(int M, NetPtrs n, fl
   zero4(acc), SP_HID(fwd_start(7)), close_layer(7);
 #undef SP_HID
 #undef SP_X0
-  // ---- heads: raw[4 x 10] = h W_heads^T + b.  Thread (row i, output o, part p): the contraction indices k = 8 kk + p
+  // ---- heads: raw[4 x nout] = h W_heads^T + b.  Thread (row i, output o, part p): the contraction indices k = 8 kk + p
   {
     const int pp = tid & 7, o = (tid >> 3) & 15, i = tid >> 7;
     int hrow;
-    const int hd    = head_of(min(o, NOUT - 1), hrow);
+    const int hd    = head_of(min(o, n.nout - 1), hrow);
     const float* wr = n.head_w[hd] + (size_t) hrow * SPW + pp;
     const float* hp = &s_ht[cur][i][pp][0];
     float w[SPW / 8];
@@ -376,31 +403,50 @@ __global__ void __launch_bounds__(NT) sp_net_forward_kernel(int M, NetPtrs n, fl
     v += __shfl_xor(v, 1);
     v += __shfl_xor(v, 2);
     v += __shfl_xor(v, 4);
-    if (pp == 0 && o < NOUT) s_raw[i][o] = v + n.head_b[hd][hrow];
+    if (pp == 0 && o < n.nout) s_raw[i][o] = v + n.head_b[hd][hrow];
   }
   __syncthreads();
   if (tid < RB) {  // one thread per superpoint: the three raw outputs and the stage's epilogue (sk_gs.py:847)
     const int gr = r0 + tid;
-    float o[NOUT];
+    float o[NOUT_MAX];
 #pragma unroll
-    for (int c = 0; c < NOUT; ++c) o[c] = s_raw[tid][c];
+    for (int c = 0; c < NOUT_MAX; ++c) o[c] = c < n.nout ? s_raw[tid][c] : 0.f;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) sv.rawq[(size_t) gr * 4 + c] = o[3 + c];
+    for (int c = 0; c < 4; ++c) sv.rawq[(size_t) gr * 4 + c] = o[3 + c], sv.rawl[(size_t) gr * 4 + c] = o[10 + c];
     if (gr < M) {
       if (raw)
 #pragma unroll
-        for (int c = 0; c < NOUT; ++c) raw[(size_t) gr * NOUT + c] = o[c];
+        for (int c = 0; c < NOUT_MAX; ++c)
+          if (c < n.nout) raw[(size_t) gr * n.nout + c] = o[c];
       const float v[4] = {o[3], o[4], o[5], o[6] + 1.0f};
       const float nv   = fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]), 1e-12f);  // F.normalize eps
+      const float u[4] = {v[0] / nv, v[1] / nv, v[2] / nv, v[3] / nv};
       if (bone_T) {
+        float t[3] = {o[0], o[1], o[2]};
+        if (n.lbs_c) {  // sp_t = d_xyz + sp_points + SO3(d_rot).act(-sp_points)   (sk_gs.py:803-804)
+          const float x[3] = {n.points[(size_t) gr * 3], n.points[(size_t) gr * 3 + 1], n.points[(size_t) gr * 3 + 2]};
+          const float mx[3] = {-x[0], -x[1], -x[2]};
+          float y[3];
+          quat_rotate(u, mx, y);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) bone_T[(size_t) gr * 7 + c] = o[c];
+          for (int c = 0; c < 3; ++c) t[c] = (o[c] + x[c]) + y[c];
+        }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) bone_T[(size_t) gr * 7 + 3 + c] = v[c] / nv;
+        for (int c = 0; c < 3; ++c) bone_T[(size_t) gr * 7 + c] = t[c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bone_T[(size_t) gr * 7 + 3 + c] = u[c];
       }
-      if (d_rot)
+      if (d_rot) {  // what warp blends: the unit d_rot, or with sep_rot the unit g_rot (sk_gs.py:848,818-821)
+        if (n.nout == NOUT_MAX) {
+          const float l[4] = {o[10], o[11], o[12], o[13] + 1.0f};
+          const float nl   = fmaxf(sqrtf(l[0] * l[0] + l[1] * l[1] + l[2] * l[2] + l[3] * l[3]), 1e-12f);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) d_rot[(size_t) gr * 4 + c] = v[c] / nv;
+          for (int c = 0; c < 4; ++c) d_rot[(size_t) gr * 4 + c] = l[c] / nl;
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) d_rot[(size_t) gr * 4 + c] = u[c];
+        }
+      }
       if (d_scale)
 #pragma unroll
         for (int c = 0; c < 3; ++c) d_scale[(size_t) gr * 3 + c] = o[7 + c];
@@ -439,8 +485,8 @@ struct BwdRows {  // item t of wave w: layer 7 - t / 32, row (output feature) 8 
 };
 
 __global__ void __launch_bounds__(NT) sp_net_backward_rows_kernel(int M, int nblk, NetPtrs n, const float* __restrict__ g_bone_T,
-    const float* __restrict__ g_d_rot, const float* __restrict__ g_d_scale, const float* __restrict__ g_raw, SavedView sv,
-    WorkView wk, SideAdam side) {
+    const float* __restrict__ g_d_rot, const float* __restrict__ g_d_scale, const float* __restrict__ g_raw,
+    float* __restrict__ g_points, SavedView sv, WorkView wk, SideAdam side) {
   if ((int) blockIdx.x >= nblk) {  // the CUs the row blocks leave idle: an optimizer piece
     side_adam_walk(side, (int) blockIdx.x - nblk, (int) gridDim.x - nblk);
     return;
@@ -466,30 +512,65 @@ __global__ void __launch_bounds__(NT) sp_net_backward_rows_kernel(int M, int nbl
     if (gr < M) {
       if (g_raw) {
 #pragma unroll
-        for (int c = 0; c < NOUT; ++c) g[c] = g_raw[(size_t) gr * NOUT + c];
+        for (int c = 0; c < NOUT_MAX; ++c)
+          if (c < n.nout) g[c] = g_raw[(size_t) gr * n.nout + c];
       } else {
-        // bone_T = [d_xyz | u], d_rot = u, u = v / |v|, v = rotation + [0,0,0,1]:  g_v = (g_u - u (u . g_u)) / |v|
-        float gu[4] = {0.f, 0.f, 0.f, 0.f};
+        // bone_T = [t | u], u = v / |v|, v = rotation + [0,0,0,1]:  g_v = (g_u - u (u . g_u)) / |v|;  t = d_xyz, or with LBS_c
+        // d_xyz + x + R(u)(-x).  d_rot (the blended rotation) = u, or with the local-rotation head normalize(local + [0,0,0,1])
+        const bool sep = n.nout == NOUT_MAX;
+        float gu[4] = {0.f, 0.f, 0.f, 0.f}, gl[4] = {0.f, 0.f, 0.f, 0.f};
+        const float v[4] = {sv.rawq[(size_t) gr * 4], sv.rawq[(size_t) gr * 4 + 1], sv.rawq[(size_t) gr * 4 + 2],
+            sv.rawq[(size_t) gr * 4 + 3] + 1.0f};
+        const float nv = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+        const float nvc = fmaxf(nv, 1e-12f);
+        const float u[4] = {v[0] / nvc, v[1] / nvc, v[2] / nvc, v[3] / nvc};
         if (g_bone_T) {
 #pragma unroll
           for (int c = 0; c < 3; ++c) g[c] = g_bone_T[(size_t) gr * 7 + c];
 #pragma unroll
           for (int c = 0; c < 4; ++c) gu[c] = g_bone_T[(size_t) gr * 7 + 3 + c];
+          if (n.lbs_c) {  // t = d_xyz + x + R(u)(-x):  g_x = g_t - R(u)^T g_t,  g_u += d (g_t . R(u)(-x)) / d u
+            const float x[3] = {n.points[(size_t) gr * 3], n.points[(size_t) gr * 3 + 1], n.points[(size_t) gr * 3 + 2]};
+            const float mx[3] = {-x[0], -x[1], -x[2]}, gt[3] = {g[0], g[1], g[2]};
+            float gq[4], rt[3];
+            quat_rotate_grad_q(u, mx, gt, gq);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gu[c] += gq[c];
+            if (g_points) {
+              const float uc[4] = {-u[0], -u[1], -u[2], u[3]};
+              quat_rotate(uc, gt, rt);
+#pragma unroll
+              for (int c = 0; c < 3; ++c) g_points[(size_t) gr * 3 + c] = gt[c] - rt[c];
+            }
+          }
+        } else if (n.lbs_c && g_points) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) g_points[(size_t) gr * 3 + c] = 0.f;
         }
         if (g_d_rot)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) gu[c] += g_d_rot[(size_t) gr * 4 + c];
-        const float v[4] = {sv.rawq[(size_t) gr * 4], sv.rawq[(size_t) gr * 4 + 1], sv.rawq[(size_t) gr * 4 + 2],
-            sv.rawq[(size_t) gr * 4 + 3] + 1.0f};
-        const float nv = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+          for (int c = 0; c < 4; ++c) (sep ? gl[c] : gu[c]) += g_d_rot[(size_t) gr * 4 + c];
         if (nv > 1e-12f) {
-          const float u[4] = {v[0] / nv, v[1] / nv, v[2] / nv, v[3] / nv};
           const float dot  = u[0] * gu[0] + u[1] * gu[1] + u[2] * gu[2] + u[3] * gu[3];
 #pragma unroll
           for (int c = 0; c < 4; ++c) g[3 + c] = (gu[c] - u[c] * dot) / nv;
         } else {
 #pragma unroll
           for (int c = 0; c < 4; ++c) g[3 + c] = gu[c] / 1e-12f;
+        }
+        if (sep) {
+          const float l[4] = {sv.rawl[(size_t) gr * 4], sv.rawl[(size_t) gr * 4 + 1], sv.rawl[(size_t) gr * 4 + 2],
+              sv.rawl[(size_t) gr * 4 + 3] + 1.0f};
+          const float nl = sqrtf(l[0] * l[0] + l[1] * l[1] + l[2] * l[2] + l[3] * l[3]);
+          if (nl > 1e-12f) {
+            const float ul[4] = {l[0] / nl, l[1] / nl, l[2] / nl, l[3] / nl};
+            const float dot   = ul[0] * gl[0] + ul[1] * gl[1] + ul[2] * gl[2] + ul[3] * gl[3];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) g[10 + c] = (gl[c] - ul[c] * dot) / nl;
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) g[10 + c] = gl[c] / 1e-12f;
+          }
         }
         if (g_d_scale)
 #pragma unroll
@@ -525,10 +606,11 @@ __global__ void __launch_bounds__(NT) sp_net_backward_rows_kernel(int M, int nbl
       wk.GBP[((size_t) (l == 0 ? 0 : 1) * nblk + blockIdx.x) * SPW + tid] = cs;
     }
   };
-  {  // gY_7 = gH W_heads (K = 10)
+  {  // gY_7 = gH W_heads (K = 10, or 14 with the local-rotation head)
     float2 gy = make_float2(0.f, 0.f);
 #pragma unroll
-    for (int c = 0; c < NOUT; ++c) {
+    for (int c = 0; c < NOUT_MAX; ++c) {
+      if (c >= n.nout) break;
       int hrow;
       const int hd   = head_of(c, hrow);
       const float2 w = *reinterpret_cast<const float2*>(n.head_w[hd] + (size_t) hrow * SPW + eo);
@@ -795,7 +877,7 @@ __global__ void __launch_bounds__(NTB) sp_net_backward_weights_kernel(int M, int
     for (int w = 0; w < NWB; ++w) v += s_part[w][ol * 65 + kl];
     if (k0 + kl >= kvalid) continue;
     if (heads) {
-      if (ol < NOUT) {
+      if (ol < n.nout) {
         int hrow;
         const int hd = head_of(ol, hrow);
         g.head_w[hd][(size_t) hrow * SPW + k0 + kl] = v;
@@ -809,7 +891,7 @@ __global__ void __launch_bounds__(NTB) sp_net_backward_weights_kernel(int M, int
 #pragma unroll
     for (int w = 0; w < NWB; ++w) v += s_gb[w][tid];
     if (heads) {
-      if (tid < NOUT) {
+      if (tid < n.nout) {
         int hrow;
         const int hd = head_of(tid, hrow);
         g.head_b[hd][hrow] = v;
@@ -828,6 +910,9 @@ NetPtrs net_ptrs(const skgs_sp_net* d) {
   n.head_w[0] = d->warp_w, n.head_b[0] = d->warp_b;
   n.head_w[1] = d->rotation_w, n.head_b[1] = d->rotation_b;
   n.head_w[2] = d->scaling_w, n.head_b[2] = d->scaling_b;
+  n.head_w[3] = d->local_w, n.head_b[3] = d->local_b;
+  n.nout  = (d->local_w && d->local_b) ? NOUT_MAX : NOUT;
+  n.lbs_c = (d->flags & SKGS_SP_NET_LBS_C) ? 1 : 0;
   return n;
 }
 bool net_complete(const skgs_sp_net* d) {
@@ -937,10 +1022,14 @@ int skgs_sp_net_backward(const skgs_sp_net* net, const skgs_sp_net* grads, const
   g.head_w[0] = const_cast<float*>(grads->warp_w), g.head_b[0] = const_cast<float*>(grads->warp_b);
   g.head_w[1] = const_cast<float*>(grads->rotation_w), g.head_b[1] = const_cast<float*>(grads->rotation_b);
   g.head_w[2] = const_cast<float*>(grads->scaling_w), g.head_b[2] = const_cast<float*>(grads->scaling_b);
+  g.head_w[3] = const_cast<float*>(grads->local_w), g.head_b[3] = const_cast<float*>(grads->local_b);
+  g.points = const_cast<float*>(grads->points);
+  SKGS_REQUIRE(n.nout == NOUT || (g.head_w[3] && g.head_b[3]), "sp_net_backward: the local-rotation head needs gradient pointers too");
+  SKGS_REQUIRE(!n.lbs_c || net->points, "sp_net_backward: LBS_c needs the superpoint positions");
   ProfScope prof(K_SP_NET_BWD, s);
   SKGS_REQUIRE(allow_weights_lds() == 0, "sp_net_backward: cannot raise the dynamic LDS limit");
-  hipLaunchKernelGGL(sp_net_backward_rows_kernel, dim3(nblk + n_side), dim3(NT), 0, s, M, nblk, n, g_bone_T, g_d_rot, g_d_scale, g_raw, sv,
-      wk, sd);
+  hipLaunchKernelGGL(sp_net_backward_rows_kernel, dim3(nblk + n_side), dim3(NT), 0, s, M, nblk, n, g_bone_T, g_d_rot, g_d_scale, g_raw,
+      n.lbs_c ? g.points : nullptr, sv, wk, sd);
   SKGS_CHECK_HIP(hipGetLastError());
   hipLaunchKernelGGL(sp_net_backward_weights_kernel, dim3(n_jobs + n_side2), dim3(NTB), WEIGHTS_LDS_BYTES, s, M, n_jobs, n, g, sv, wk, sd2);
   SKGS_CHECK_HIP(hipGetLastError());

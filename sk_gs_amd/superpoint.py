@@ -37,16 +37,18 @@ from sk_gs_amd.deform_net import freq_encode_torch
 
 
 class SpDeformNet(nn.Module):
-    """``DeformNetwork(D, W, is_blender=True, sep_rot=False)`` (networks/sk_gs.py:209-315).
+    """``DeformNetwork(D, W, is_blender=True, sep_rot=...)`` (networks/sk_gs.py:209-315).  ``sep_rot`` (the class default of the
+    reference's model, `sep_rot: false` in exps/default.yaml:37): a fourth head ``local_rotation`` (:275-282,315) whose output
+    ``g_rotation`` is what the skinning blends per Gaussian instead of ``d_rotation``.
 
     ``x_emb = freq(x, 10)`` [.,63]; ``t_emb = timenet(freq(t, 6))`` [30] with ``timenet = Linear(13,256) ReLU Linear(256,30)``
     (:250-253); ``h = [x_emb | t_emb]``; D layers ``h = relu(linear[i](h))``, after layer ``D // 2`` the input is put IN FRONT:
     ``h = [x_emb | t_emb | h]`` (:303-306); heads ``gaussian_warp`` (3), ``gaussian_scaling`` (3), ``gaussian_rotation`` (4)."""
 
     def __init__(self, D: int = 8, W: int = 256, p_degree: int = 10, t_degree: int = 6, time_hidden: int = 256,
-                 time_out: int = 30):
+                 time_out: int = 30, sep_rot: bool = False):
         super().__init__()
-        self.D, self.W, self.p_degree, self.t_degree = D, W, p_degree, t_degree
+        self.D, self.W, self.p_degree, self.t_degree, self.sep_rot = D, W, p_degree, t_degree, bool(sep_rot)
         self.skips = [D // 2]
         self.p_dim, self.t_dim = 3 * (1 + 2 * p_degree), 1 + 2 * t_degree
         self.time_hidden, self.time_out = time_hidden, time_out
@@ -55,11 +57,16 @@ class SpDeformNet(nn.Module):
         self.linear = nn.ModuleList([nn.Linear(self.in_dim, W)] + [
             nn.Linear(W, W) if i not in self.skips else nn.Linear(W + self.in_dim, W) for i in range(D - 1)])
         self.gaussian_warp, self.gaussian_scaling, self.gaussian_rotation = nn.Linear(W, 3), nn.Linear(W, 3), nn.Linear(W, 4)
+        if self.sep_rot:
+            self.local_rotation = nn.Linear(W, 4)
         self.reset_parameters()
         self._runners = {}
 
     def reset_parameters(self):
         """sk_gs.py:280-293"""
+        if self.sep_rot:
+            nn.init.normal_(self.local_rotation.weight, mean=0, std=1e-4)
+            nn.init.zeros_(self.local_rotation.bias)
         for layer in self.linear:
             nn.init.kaiming_uniform_(layer.weight, mode='fan_in', nonlinearity='relu')
             nn.init.zeros_(layer.bias)
@@ -79,8 +86,10 @@ class SpDeformNet(nn.Module):
             h = F.relu(layer(h))
             if i in self.skips:
                 h = torch.cat([x_emb, t_emb, h], -1)
-        return dict(d_xyz=self.gaussian_warp(h), d_rotation=self.gaussian_rotation(h), d_scaling=self.gaussian_scaling(h),
-                    hidden=h)
+        out = dict(d_xyz=self.gaussian_warp(h), d_rotation=self.gaussian_rotation(h), d_scaling=self.gaussian_scaling(h), hidden=h)
+        if self.sep_rot:
+            out['g_rotation'] = self.local_rotation(h)
+        return out
 
     # ------------------------------------------------------------------------------------------------ HIP kernels
     def kernel_supported(self) -> bool:
@@ -89,13 +98,14 @@ class SpDeformNet(nn.Module):
         return (self.D == 8 and self.W == 256 and self.p_degree == 10 and self.t_degree == 6 and self.time_hidden == 256
                 and self.time_out == 30)
 
-    def runner(self, M: int) -> 'SpNetRunner':
+    def runner(self, M: int, lbs_c: bool = False) -> 'SpNetRunner':
         """the launches' persistent buffers for M rows: one runner per M, kept (a network is called with 512 superpoints by the stage
         and with M * T rows by the reference's regularisers, sk_gs.py:1383-1395: replacing the runner would hand the first call's
         backward uninitialised buffers)"""
-        run = self._runners.get(M)
+        key = M if not lbs_c else (M, 'LBS_c')
+        run = self._runners.get(key)
         if run is None:
-            run = self._runners[M] = SpNetRunner(self, M)
+            run = self._runners[key] = SpNetRunner(self, M, lbs_c=lbs_c)
         return run
 
     def forward(self, x: Tensor, t: Tensor) -> Dict[str, Tensor]:
@@ -105,19 +115,23 @@ class SpDeformNet(nn.Module):
             # one time PER ROW (loss_arap / loss_elastic call sp_deform_net(x [M*T,3], t [M*T,1]), sk_gs.py:1383-1395): the kernels take
             # one time for all rows -- the plain-torch body computes exactly what the reference does
             out = self.reference_forward(x, t)
-            return dict(d_xyz=out['d_xyz'], d_rotation=out['d_rotation'], d_scaling=out['d_scaling'])
+            out.pop('hidden')
+            return out
         params = list(self.parameters())
         out = _SpNetFn.apply(self, x, t, *params)
-        return dict(d_xyz=out[0], d_rotation=out[1], d_scaling=out[2])
+        res = dict(d_xyz=out[0], d_rotation=out[1], d_scaling=out[2])
+        if self.sep_rot:
+            res['g_rotation'] = out[3]
+        return res
 
 
 class _SpNetDesc(C.Structure):
     """include/skgs.h::skgs_sp_net"""
-    _fields_ = [('M', C.c_int32), ('reserved', C.c_int32), ('points', C.c_void_p), ('time', C.c_void_p),
+    _fields_ = [('M', C.c_int32), ('flags', C.c_int32), ('points', C.c_void_p), ('time', C.c_void_p),
                 ('time_w1', C.c_void_p), ('time_b1', C.c_void_p), ('time_w2', C.c_void_p), ('time_b2', C.c_void_p),
                 ('W', C.c_void_p * 8), ('b', C.c_void_p * 8),
                 ('warp_w', C.c_void_p), ('warp_b', C.c_void_p), ('scaling_w', C.c_void_p), ('scaling_b', C.c_void_p),
-                ('rotation_w', C.c_void_p), ('rotation_b', C.c_void_p)]
+                ('rotation_w', C.c_void_p), ('rotation_b', C.c_void_p), ('local_w', C.c_void_p), ('local_b', C.c_void_p)]
 
 
 def _net_desc(net: SpDeformNet, M: int, points, time, grads: bool = False) -> _SpNetDesc:
@@ -127,7 +141,9 @@ def _net_desc(net: SpDeformNet, M: int, points, time, grads: bool = False) -> _S
         assert t is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
         return t.data_ptr()
     d = _SpNetDesc()
-    d.M = M
+    d.M, d.flags = M, 0
+    if net.sep_rot:
+        d.local_w, d.local_b = ptr(net.local_rotation.weight), ptr(net.local_rotation.bias)
     d.points = None if points is None else points.data_ptr()
     d.time = None if time is None else time.data_ptr()
     d.time_w1, d.time_b1 = ptr(net.timenet[0].weight), ptr(net.timenet[0].bias)
@@ -158,9 +174,10 @@ class SpNetRunner:
                 whole chip, the time network's backward in the workgroup that finishes last.
     """
 
-    def __init__(self, net: SpDeformNet, M: int):
+    def __init__(self, net: SpDeformNet, M: int, lbs_c: bool = False):
         assert net.kernel_supported(), 'csrc/sp_mlp.hip: 8 x 256 layers, skip after layer 4, degrees 10 / 6, time net 13-256-30'
-        self.net, self.M = net, int(M)
+        self.net, self.M, self.lbs_c = net, int(M), bool(lbs_c)  # lbs_c: warp_method LBS_c, bone_T re-centred on the superpoints
+        self.nout = 14 if net.sep_rot else 10
         self.lib = lib = _C.load_library()
         dev = next(net.parameters()).device
         if dev.type != 'cuda':
@@ -171,19 +188,21 @@ class SpNetRunner:
         self.ws = torch.zeros((int(lib.skgs_sp_net_workspace_bytes(C.c_int32(M))),), dtype=torch.uint8, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
         self.bone_T, self.d_rot, self.d_scale = torch.empty((M, 7), **f32), torch.empty((M, 4), **f32), torch.empty((M, 3), **f32)
-        self.raw = torch.empty((M, 10), **f32)  # d_xyz | d_rotation (raw) | d_scaling: the reference's three outputs
+        self.raw = torch.empty((M, self.nout), **f32)  # d_xyz | d_rotation (raw) | d_scaling [| g_rotation (raw)]: the reference's outputs
 
     def forward(self, points: Tensor, time: Tensor, prepare: Optional[_SpPrepare] = None):
         """fills ``bone_T`` / ``d_rot`` / ``d_scale`` (and ``raw``); ``time``: 1-element device tensor.  ``prepare``: the search's
         per-step table / list preparation rides on this call's first launch (``skgs_sp_prepare``)"""
         d = _net_desc(self.net, self.M, points, time)
+        d.flags = 1 if self.lbs_c else 0  # SKGS_SP_NET_LBS_C
+        self._points = points
         _C._check(self.lib.skgs_sp_net_forward(
             C.byref(d), C.c_void_p(self.raw.data_ptr()), C.c_void_p(self.bone_T.data_ptr()), C.c_void_p(self.d_rot.data_ptr()),
             C.c_void_p(self.d_scale.data_ptr()), C.c_void_p(self.saved.data_ptr()), C.c_size_t(self.saved.numel()),
             None if prepare is None else C.byref(prepare), _C._stream()))
 
     def backward(self, g_bone_T: Optional[Tensor], g_d_rot: Optional[Tensor], g_d_scale: Optional[Tensor],
-                 g_raw: Optional[Tensor] = None, side_adam=None, saved: Optional[Tensor] = None):
+                 g_raw: Optional[Tensor] = None, side_adam=None, saved: Optional[Tensor] = None, g_points: Optional[Tensor] = None):
         """parameter gradients WRITTEN into the parameters' ``.grad``.  Either the stage's gradients (``g_bone_T`` [M,7],
         ``g_d_rot`` [M,4], ``g_d_scale`` [M,3]: the quaternion normalisation's backward runs in the launch) or ``g_raw`` [M,10]
         w.r.t. the three raw outputs.  ``side_adam`` (``FusedAdam.side_range``): an optimizer piece for the CUs launch A
@@ -191,7 +210,10 @@ class SpNetRunner:
         autograd operator keeps a copy per call)."""
         saved = self.saved if saved is None else saved
         dg = _net_desc(self.net, self.M, None, None, grads=True)
-        d = _net_desc(self.net, self.M, None, None)
+        d = _net_desc(self.net, self.M, self._points if self.lbs_c else None, None)
+        if self.lbs_c:  # the re-centring's backward needs the superpoint positions and returns their gradient [M,3] (written)
+            d.flags = 1
+            dg.points = None if g_points is None else g_points.data_ptr()
         p = lambda t: C.c_void_p(None if t is None else t.data_ptr())  # noqa: E731
         _C._check(self.lib.skgs_sp_net_backward(
             C.byref(d), C.byref(dg), p(g_bone_T), p(g_d_rot), p(g_d_scale), p(g_raw), C.c_void_p(saved.data_ptr()),
@@ -213,15 +235,17 @@ class _SpNetFn(torch.autograd.Function):
         ctx.net, ctx.M, ctx.run = net, M, run
         ctx.saved_acts = run.saved.clone() if any(p.requires_grad for p in params) else None
         raw = run.raw.clone()
+        if net.sep_rot:
+            return raw[:, 0:3], raw[:, 3:7], raw[:, 7:10], raw[:, 10:14]
         return raw[:, 0:3], raw[:, 3:7], raw[:, 7:10]
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g_xyz, g_rot, g_scale):
+    def backward(ctx, g_xyz, g_rot, g_scale, g_loc=None):
         net, M, run = ctx.net, ctx.M, ctx.run
         dev = run.raw.device
         z = lambda g, n: torch.zeros((M, n), device=dev) if g is None else g  # noqa: E731
-        g_raw = torch.cat([z(g_xyz, 3), z(g_rot, 4), z(g_scale, 3)], dim=1).contiguous()
+        g_raw = torch.cat([z(g_xyz, 3), z(g_rot, 4), z(g_scale, 3)] + ([z(g_loc, 4)] if net.sep_rot else []), dim=1).contiguous()
         params = list(net.parameters())
         keep = [p.grad for p in params]
         for p in params:  # the kernels WRITE into .grad: hand autograd fresh tensors and restore what was there
@@ -241,8 +265,15 @@ class SuperpointGaussians(nn.Module):
     ``FusedSuperpointStep`` runs the same C-ABI calls in a straight line."""
 
     def __init__(self, P: int, M: int = 512, K: int = 5, sh_degree: int = 3, num_frames: int = 8, seed: int = 0,
-                 scale_mult: float = 1.0, lbs_method: str = 'weighted_kernel', hyper_dim: int = 8, lbs_temperature: float = 1.0):
+                 scale_mult: float = 1.0, lbs_method: str = 'weighted_kernel', hyper_dim: int = 8, lbs_temperature: float = 1.0,
+                 warp_method: str = 'LBS', sep_rot: bool = False):
         super().__init__()
+        # warp_method (sk_gs.py:776-828): 'LBS' (exps/default.yaml:36), 'LBS_c' (d_nerf_sc_gs.yaml:32: the superpoint's transform
+        # re-centred on the superpoint, :803-804), 'largest' (d_nerf_sp_gs.yaml:32: each Gaussian follows the ONE superpoint with the
+        # largest weight, :811-816,849-850; rotation / scale offsets stay blended).  sep_rot: the network's `g_rotation` head is what the
+        # rotation blend uses (:848,818-821)
+        assert warp_method in ('LBS', 'LBS_c', 'largest')
+        self.warp_method, self.sep_rot = warp_method, bool(sep_rot)
         from sk_gs_amd import scene
         g = scene.make_gaussians(P, seed=seed, sh_degree=sh_degree, scale_mult=scale_mult)
         self.P, self.M, self.K, self.hyper_dim = P, M, min(K, M), hyper_dim
@@ -277,8 +308,10 @@ class SuperpointGaussians(nn.Module):
         if lbs_method == 'weighted_kernel':
             self._sp_weight = nn.Parameter(torch.zeros(M))
         torch.manual_seed(6000 + seed)
-        self.sp_deform_net = SpDeformNet()
+        self.sp_deform_net = SpDeformNet(sep_rot=self.sep_rot)
         with torch.no_grad():  # a trained network's output sizes instead of the 1e-5 / 1e-8 heads of reset_parameters
+            if self.sep_rot:
+                self.sp_deform_net.local_rotation.weight.normal_(0, 2e-3, generator=gen)
             self.sp_deform_net.gaussian_warp.weight.normal_(0, 2e-3, generator=gen)
             self.sp_deform_net.gaussian_rotation.weight.normal_(0, 2e-3, generator=gen)
             self.sp_deform_net.gaussian_scaling.weight.normal_(0, 2e-5, generator=gen)
@@ -314,14 +347,19 @@ class SuperpointGaussians(nn.Module):
 
     # --------------------------------------------------------------------------------------------------- forward
     def superpoint_transforms(self, time_id: int, reference: bool = False):
-        """``sp_deform_net(sp_points.detach(), t)`` + the normalisation of sk_gs.py:847: (spT [M,7] = (t, unit q), d_rot [M,4],
-        d_scale [M,3])"""
+        """``sp_deform_net(sp_points.detach(), t)`` + the normalisations of sk_gs.py:847-848 + the re-centring of `LBS_c` (:803-804):
+        (spT [M,7] = (t, unit q), the rotation offsets the skinning blends [M,4] -- d_rot, or g_rot with ``sep_rot`` --, d_scale [M,3])"""
+        from sk_gs_amd.skeleton import quat_act
         t = self.frame_times[time_id]
         net = self.sp_deform_net
         out = net.reference_forward(self.sp_points.detach(), t) if (reference or not self.sp_points.is_cuda) \
             else net(self.sp_points.detach(), t)
         d_rot = F.normalize(out['d_rotation'] + self._rot_bias, dim=-1)
-        return torch.cat([out['d_xyz'], d_rot], dim=-1), d_rot, out['d_scaling']
+        blend_rot = F.normalize(out['g_rotation'] + self._rot_bias, dim=-1) if self.sep_rot else d_rot
+        sp_t = out['d_xyz']
+        if self.warp_method == 'LBS_c':  # (the superpoints are NOT detached here: they receive a gradient, as in the reference)
+            sp_t = sp_t + self.sp_points + quat_act(d_rot, -self.sp_points)
+        return torch.cat([sp_t, d_rot], dim=-1), blend_rot, out['d_scaling']
 
     def lbs_weights(self):
         """``calc_LBS_weight(points, sp_points, hyper_feature, sp_hyper_feature)`` (sk_gs.py:844): weights, indices"""
@@ -339,6 +377,11 @@ class SuperpointGaussians(nn.Module):
         weights, indices = self.lbs_weights()
         means, scales, rotations, opacity = lbs_deform(self._xyz.detach(), weights, indices, spT, d_rot, d_scale,
                                                        self._xyz, self._scaling, self._rotation, self._opacity)
+        if self.warp_method == 'largest':  # the position follows the superpoint of the largest weight alone (sk_gs.py:811-816,849-850)
+            from sk_gs_amd.skeleton import se3_act
+            pts = self._xyz.detach()
+            self.p2sp = torch.gather(indices, -1, weights.argmax(dim=-1, keepdim=True))[:, 0]
+            means = self._xyz + (se3_act(spT[self.p2sp], pts) - pts)
         return dict(points=means, opacity=opacity, scales=scales, rotations=rotations, sh_features=sh_features)
 
     def render(self, raster_settings, time_id: int = 0, background: Optional[Tensor] = None) -> Dict[str, Tensor]:
@@ -384,7 +427,9 @@ class FusedSuperpointStep(FusedViewStep):
         P, M, K = self.P, self.M, self.K
         self.F = int(model.hyper_dim) if model.hyper_feature is not None else 0
         assert self.F in (0, 8), 'csrc/sp_knn.hip: 0 or 8 hyper dimensions'
-        self.net = model.sp_deform_net.runner(M)
+        assert model.warp_method in ('LBS', 'LBS_c'), \
+            "FusedSuperpointStep: warp_method 'largest' runs on the operator path only (SuperpointGaussians.forward) this round"
+        self.net = model.sp_deform_net.runner(M, lbs_c=model.warp_method == 'LBS_c')
         self.nn_dist = torch.empty((P, K), dtype=torch.float32, device=dev)
         lib.skgs_sp_lbs_weights_workspace_bytes.restype = C.c_size_t
         self.spw_ws = torch.empty((max(int(lib.skgs_sp_lbs_weights_workspace_bytes(C.c_int32(P), C.c_int32(M), C.c_int32(self.F))),
@@ -530,7 +575,9 @@ class FusedSuperpointStep(FusedViewStep):
         side = None
         if self.side_optimizer is not None:  # the per-Gaussian rows' Adam update on the CUs the row-block launch leaves idle
             side = self.side_optimizer[0].side_range(*self.side_optimizer[1:])
-        self.net.backward(self.g_bone_T, self.g_d_rot, self.g_d_scale, side_adam=side)
+        # (LBS_c: the re-centring's backward writes d loss / d sp_points; nothing else on this path reaches the superpoints' positions)
+        self.net.backward(self.g_bone_T, self.g_d_rot, self.g_d_scale, side_adam=side,
+                          g_points=self.model.sp_points.grad if self.net.lbs_c else None)
 
     @torch.no_grad()
     def refresh_logit_mask(self, optimizer):

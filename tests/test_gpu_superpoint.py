@@ -316,32 +316,38 @@ def test_operator_path_at_superpoint_size_runs_the_sp_search_and_matches_the_ora
 
 
 # ---------------------------------------------------------------------------------------------------- the fused step
-def _sp_model(P, M, K, W, H, frames, method, seed=0):
+def _sp_model(P, M, K, W, H, frames, method, seed=0, warp_method='LBS', sep_rot=False):
     from sk_gs_amd import scene
     from sk_gs_amd.superpoint import SuperpointGaussians
     dev = torch.device('cuda')
-    model = SuperpointGaussians(P, M, K, num_frames=frames, seed=seed, scale_mult=3.0, lbs_method=method).to(dev)
+    model = SuperpointGaussians(P, M, K, num_frames=frames, seed=seed, scale_mult=3.0, lbs_method=method, warp_method=warp_method,
+                                sep_rot=sep_rot).to(dev)
     with torch.no_grad():  # deformations large enough to matter in the image
         model.sp_deform_net.gaussian_warp.weight.mul_(20.0)
         model.sp_deform_net.gaussian_rotation.weight.mul_(20.0)
         model.sp_deform_net.gaussian_scaling.weight.mul_(100.0)
+        if sep_rot:
+            model.sp_deform_net.local_rotation.weight.mul_(20.0)
     cam = scene.make_camera(W, H, seed=seed)
     rs = scene.raster_settings_from_camera(cam, sh_degree=3, colmap=True, device=dev)
     target = torch.rand(3, H, W, generator=torch.Generator().manual_seed(seed + 1)).to(dev)
     return model, rs, target
 
 
-@pytest.mark.parametrize('method', ['weighted_kernel', 'W', 'dist'])
-def test_fused_superpoint_step_matches_the_operator_path(method):
+@pytest.mark.parametrize('method,warp_method,sep_rot', [('weighted_kernel', 'LBS', False), ('W', 'LBS', False), ('dist', 'LBS', False),
+                                                        ('weighted_kernel', 'LBS_c', True), ('kernel', 'LBS_c', False), ('W', 'LBS', True)])
+def test_fused_superpoint_step_matches_the_operator_path(method, warp_method, sep_rot):
     """stage sp end to end: FusedSuperpointStep (straight C-ABI calls, MFMA network, one-launch 3+8-d search) against the
     autograd operator path of SuperpointGaussians.render + image_loss -- the image and EVERY parameter gradient (Gaussians,
-    hyper features, superpoint tables, the network's 26 tensors)"""
+    hyper features, superpoint tables, the network's 26 tensors; + the `local_rotation` head with sep_rot, + the superpoints' positions
+    with warp_method LBS_c: the shipped SC-GS configuration is (weighted_kernel, LBS_c, sep_rot), exps/d_nerf_sc_gs.yaml:31-32)"""
     from sk_gs_amd import _C
     from sk_gs_amd.losses import image_loss
     from sk_gs_amd.superpoint import FusedSuperpointStep
     from helpers import assert_close_robust
     P, M, K, W, H, frames, tid = 6000, 512, 5, 160, 120, 3, 1
-    model, rs, target = _sp_model(P, M, K, W, H, frames, method)
+    model, rs, target = _sp_model(P, M, K, W, H, frames, method, warp_method=warp_method, sep_rot=sep_rot)
+    assert ('local_rotation.weight' in dict(model.sp_deform_net.named_parameters())) == sep_rot
     _C.config.sync_num_rendered = True
     out = model.render(rs, time_id=tid)
     loss = image_loss(out['images'], target)
@@ -353,7 +359,7 @@ def test_fused_superpoint_step_matches_the_operator_path(method):
     step = FusedSuperpointStep(model, W, H, capacity=int(R * 1.2) + 1024)
     # parameters this stage / weighting gives no gradient keep their zero .grad (never written): sp_points (detached
     # everywhere on this path) and, under `W`, the hyper features (the logits do not depend on the distances)
-    silent = {'sp_points'} | ({'hyper_feature', 'sp_hyper_feature'} if method == 'W' else set())
+    silent = (set() if warp_method == 'LBS_c' else {'sp_points'}) | ({'hyper_feature', 'sp_hyper_feature'} if method == 'W' else set())
     for n, p in model.named_parameters():
         if n not in silent:
             p.grad.fill_(7.0)
@@ -366,7 +372,7 @@ def test_fused_superpoint_step_matches_the_operator_path(method):
             assert float(p.grad.abs().max()) == 0.0 and float(ref[n].abs().max()) == 0.0, n
             continue
         assert float(ref[n].abs().max()) > 0, n
-        assert_close_robust(p.grad, ref[n], 3e-4, 1e-3, name=f'{n} sp {method}')
+        assert_close_robust(p.grad, ref[n], 3e-4, 1e-3, name=f'{n} sp {method} {warp_method} sep_rot={sep_rot}')
 
 
 @pytest.mark.parametrize('method', ['weighted_kernel', 'kernel', 'dist', 'W'])
@@ -638,3 +644,118 @@ def test_restored_checkpoint_keeps_the_sparse_logit_update_equal_to_the_dense_on
         # (two runs differ where the blend backward's atomics decide a rounding; a tile that stopped being updated differs by whole steps)
         far = ((a - b).abs() > 1e-5 * float(b.abs().max())).float().mean()
         assert float(far) <= 1e-3, (name, float(far))
+
+
+@pytest.mark.parametrize('M,sep_rot,lbs_c', [(512, True, False), (512, False, True), (100, True, True), (37, True, True)])
+def test_sp_net_local_rotation_head_and_recentring(M, sep_rot, lbs_c):
+    """the network kernels with the `local_rotation` head (sep_rot, sk_gs.py:275-282,315,848: a raw row of 14) and with the
+    re-centring of warp_method LBS_c in the epilogue (bone_T.t = d_xyz + x + R(u)(-x), sk_gs.py:803-804) against torch autograd of the
+    restatement: raw outputs, bone_T / d_rot / d_scale, every parameter gradient and d loss / d sp_points"""
+    import copy
+    from sk_gs_amd.skeleton import quat_act
+    from sk_gs_amd.superpoint import SpDeformNet
+    torch.manual_seed(M)
+    net = SpDeformNet(sep_rot=sep_rot)
+    g = torch.Generator().manual_seed(M + 1)
+    with torch.no_grad():
+        heads = [net.gaussian_warp, net.gaussian_scaling, net.gaussian_rotation] + ([net.local_rotation] if sep_rot else [])
+        for head in heads:
+            head.weight.normal_(0, 0.05, generator=g)
+            head.bias.normal_(0, 0.1, generator=g)
+    net = net.cuda()
+    x = (torch.rand(M, 3, generator=g) * 2 - 1).cuda().requires_grad_()
+    t = torch.tensor([0.4], device='cuda')
+    bias = torch.tensor([0, 0, 0, 1.], device='cuda')
+    run = net.runner(M, lbs_c=lbs_c)
+    run.forward(x.detach(), t)
+    net64 = copy.deepcopy(net)
+    net64._runners = {}
+    net64 = net64.double()
+    x64 = x.detach().double().requires_grad_()
+
+    def stage(n_, xx):
+        ref = n_.reference_forward(xx.detach(), t.to(xx.dtype))
+        u = F.normalize(ref['d_rotation'] + bias.to(xx.dtype), dim=-1)
+        blend = F.normalize(ref['g_rotation'] + bias.to(xx.dtype), dim=-1) if sep_rot else u
+        tt = ref['d_xyz'] + xx + quat_act(u, -xx) if lbs_c else ref['d_xyz']
+        return ref, torch.cat([tt, u], 1), blend, ref['d_scaling']
+    ref, bone_T, blend, d_scale = stage(net, x)
+    raw = torch.cat([ref['d_xyz'], ref['d_rotation'], ref['d_scaling']] + ([ref['g_rotation']] if sep_rot else []), 1)
+    assert run.raw.shape == (M, 14 if sep_rot else 10) and rel_err(run.raw, raw) <= 2e-5
+    assert rel_err(run.bone_T, bone_T) <= 2e-5 and rel_err(run.d_rot, blend) <= 2e-5 and rel_err(run.d_scale, d_scale) <= 2e-5
+    g_T, g_r, g_s = torch.randn(M, 7, generator=g).cuda(), torch.randn(M, 4, generator=g).cuda(), torch.randn(M, 3, generator=g).cuda()
+    _, bT64, bl64, ds64 = stage(net64, x64)
+    loss64 = (bT64 * g_T.double()).sum() + (bl64 * g_r.double()).sum() + (ds64 * g_s.double()).sum()
+    params64 = list(net64.parameters())
+    want64 = torch.autograd.grad(loss64, params64 + ([x64] if lbs_c else []))
+    loss32 = (bone_T * g_T).sum() + (blend * g_r).sum() + (d_scale * g_s).sum()
+    params = list(net.parameters())
+    want32 = torch.autograd.grad(loss32, params + ([x] if lbs_c else []))
+    for p in params:
+        p.grad = torch.full_like(p, float('nan'))
+    g_x = torch.full((M, 3), float('nan'), device='cuda')
+    run.backward(g_T, g_r, g_s, g_points=g_x if lbs_c else None)
+    torch.cuda.synchronize()
+    names = [n for n, _ in net.named_parameters()]
+    for n, p, w, w64 in zip(names, params, want32, want64):
+        assert torch.isfinite(p.grad).all(), n
+        tol = max(5e-5, 3.0 * rel_err(w.double(), w64))     # (ReLU pre-activations within rounding of 0: see the test above)
+        assert rel_err(p.grad.double(), w64) <= tol, (n, rel_err(p.grad.double(), w64), tol)
+    if lbs_c:
+        assert rel_err(g_x.double(), want64[-1]) <= 5e-5, rel_err(g_x.double(), want64[-1])
+    # the autograd operator returns the fourth output and routes its cotangent
+    if sep_rot:
+        out = net(x.detach(), t)
+        assert set(out) == {'d_xyz', 'd_rotation', 'd_scaling', 'g_rotation'} and rel_err(out['g_rotation'], ref['g_rotation']) <= 2e-5
+        c = torch.randn(M, 4, generator=g).cuda()
+        got = torch.autograd.grad((out['g_rotation'] * c).sum(), params, allow_unused=True)
+        want = torch.autograd.grad((ref['g_rotation'] * c).sum(), params, allow_unused=True, retain_graph=True)
+        for n, a, b in zip(names, got, want):
+            if b is not None and float(b.abs().max()) > 0:
+                assert rel_err(a, b) <= 5e-5, n
+
+
+@pytest.mark.parametrize('method,warp_method,sep_rot,K', [('weighted_kernel', 'LBS_c', True, 3), ('W', 'largest', False, 3), ('dist', 'LBS', True, 5),
+                                                          ('kernel', 'LBS_c', False, 4)])
+def test_operator_path_variants_equal_the_reference_sequence(method, warp_method, sep_rot, K):
+    """SuperpointGaussians.forward with the warp / network variants of the shipped configs (exps/d_nerf_sc_gs.yaml, d_nerf_sp_gs.yaml)
+    against the reference's call sequence on the stand-ins (tests/ref_sequence.py, itself pinned by the reference's own run in
+    tests/golden/sk_stage.npz): the deformed Gaussians and every gradient that reaches a parameter of the stage"""
+    import ref_sequence as rs
+    from sk_gs_amd import lietorch as L, pytorch3d_ops as p3d
+    P, M = 20_000, 512
+    model, _, _ = _sp_model(P, M, K, 64, 64, 2, method, seed=3, warp_method=warp_method, sep_rot=sep_rot)
+    tid = 1
+    g = torch.Generator().manual_seed(5)
+    cot = {k: torch.randn(P, n, generator=g).cuda() for k, n in (('points', 3), ('scales', 3), ('rotations', 4), ('opacity', 1))}
+    out = model(tid)
+    sum((out[k] * cot[k]).sum() for k in cot).backward()
+    got = {n: (p.grad.clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+    for p in model.parameters():
+        p.grad = None
+    net = model.sp_deform_net
+    ref = net.reference_forward(model.sp_points.detach(), model.frame_times[tid])
+    a = {'_xyz': model._xyz, '_scaling': model._scaling, '_rotation': model._rotation, '_opacity': model._opacity, 'sp_points': model.sp_points,
+         'hyper_feature': model.hyper_feature, 'sp_hyper_feature': model.sp_hyper_feature, 'net_d_xyz': ref['d_xyz'],
+         'net_d_rotation': ref['d_rotation'], 'net_d_scaling': ref['d_scaling']}
+    if sep_rot:
+        a['net_g_rotation'] = ref['g_rotation']
+    for k in ('_sp_radius', '_sp_weight', 'sp_W'):
+        if getattr(model, k) is not None:
+            a[k] = getattr(model, k)
+    res = rs.sp_stage(L, p3d.knn_points, a, K, warp_method, sep_rot)
+    sum((res[k] * cot[k]).sum() for k in cot).backward()
+    for k in cot:
+        assert rel_err(out[k], res[k]) <= 5e-6, k
+    if warp_method == 'largest':
+        assert torch.equal(model.p2sp, res['p2sp'])
+    checked = 0
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            assert got[n] is None or float(got[n].abs().max()) == 0.0, n
+            continue
+        assert got[n] is not None, n
+        tol = 2e-4 if n.startswith('sp_deform_net') else 3e-5      # (the network's kernels against its torch body: ReLU flips)
+        assert rel_err(got[n], p.grad) <= tol, (n, rel_err(got[n], p.grad))
+        checked += 1
+    assert checked >= 8 + (1 if warp_method == 'LBS_c' else 0)
