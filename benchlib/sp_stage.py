@@ -113,10 +113,12 @@ def run(args, base_alg_bytes, configs):
     torch.cuda.set_device(local_rank)
     cfg = configs[args.config]
     P, W, H = cfg['P'], cfg['W'], cfg['H']
-    M, K, F = args.superpoints, 5, 8
+    if args.preset == 'sc_gs':  # exps/d_nerf_sc_gs.yaml:18,31-32 (sep_rot: the class default, not overridden there)
+        args.lbs_method, args.warp_method, args.sep_rot, args.knn = 'weighted_kernel', 'LBS_c', True, 3
+    M, K, F = args.superpoints, args.knn, 8
     frames = args.views
     model = SuperpointGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=0, scale_mult=args.scale_mult,
-                                lbs_method=args.lbs_method, hyper_dim=F).to(dev)
+                                lbs_method=args.lbs_method, hyper_dim=F, warp_method=args.warp_method, sep_rot=args.sep_rot).to(dev)
     if not args.keep_order:  # Gaussians along a Z-order curve (sk_gs_amd/densify.py::sort_spatially): what a training loop
         from sk_gs_amd.densify import sort_spatially  # does after every densification event
         sort_spatially(model)
@@ -286,7 +288,8 @@ def run(args, base_alg_bytes, configs):
         'ms_per_step': round(ms_step, 4), 'ms_per_step_blocks': block_stats, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'{cfg["name"]} in stage sp: {P} Gaussians, {M} superpoints, K={K}, search over xyz + {F} hyper '
-                               f'dimensions, LBS_method {args.lbs_method}, sp_deform_net 8x256 on {M} rows, SH degree 3, {W}x{H}, '
+                               f'dimensions, LBS_method {args.lbs_method}, warp_method {args.warp_method}, sep_rot {bool(args.sep_rot)}, '
+                               f'sp_deform_net 8x256 on {M} rows, SH degree 3, {W}x{H}, '
                                f'{args.views} synthetic views, 1 view per rank per step',
                    'stage': 'sp', 'num_rendered_mean': round(R_mean), 'num_rendered_max': R_max,
                    'tile_list_mean': round(R_mean / T, 1), 'tile_list_max': longest,
