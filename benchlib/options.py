@@ -150,6 +150,9 @@ def build_parser():
     ap.add_argument('--autograd', action='store_true',
                     help='run the step through the torch-autograd operator path (model.render + image_loss + backward) '
                          'instead of sk_gs_amd.fused_step.FusedViewStep (same kernels, no autograd glue)')
+    ap.add_argument('--autograd-fused', action='store_true',
+                    help="the reference's loop shape over the FUSED launches: `loss = step.loss(...); loss.backward(); optimizer.step()` "
+                         "(FusedViewStep.loss: one autograd node; the optimizer step a launch of its own behind it, no riding update)")
     ap.add_argument('--auto-budget', type=float, default=240.0,
                     help='world > 1, --exchange auto: seconds after which no further exchange variant is started (the ones that '
                          'finished are ranked and reported)')

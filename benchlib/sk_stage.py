@@ -273,6 +273,9 @@ def build_steps(args, env, s, x):
                 loss = image_loss(out['images'], targets[v])
                 loss.backward()
                 t.overflow.add_(out['buffer'].geomBuffer[4:8].view(torch.int32))
+        elif args.autograd_fused:
+            def fwd_bwd(v):  # the fused launches as ONE autograd node: forward half now, backward half when autograd reaches it
+                fstep.loss(*fb_args(v)).backward()
         else:
             def fwd_bwd(v):  # every gradient is overwritten in place: no zero fill of the flat buffer
                 fstep.forward_backward(*fb_args(v))
@@ -299,7 +302,7 @@ def build_steps(args, env, s, x):
             rebuild_exchanged_grads()
             opt.step()
 
-        fused_path = not args.autograd and not args.torch_adam and not args.serial_adam
+        fused_path = not args.autograd and not args.torch_adam and not args.serial_adam and not args.autograd_fused
         if (env.use_dist and fused_path and view_table is not None and not args.select_per_step and args.pre_forward != 'off'):
             # view-parallel ranks: the update is the closing launch + the NEXT view's skeleton forward with the rows' Adam on its
             # idle CUs (instead of a full Adam launch now and a bare skeleton forward in the next step); every rank walks its
@@ -746,7 +749,9 @@ def run(args, env):
                                "below is that run)" if args.targets == 'own-render' else 'U(0,1) images (SURVEY.md 8(d))'),
                    'prime_steps_why': 'untimed steps after the capture: a fresh process reaches a training run\'s steady state only after '
                                       'tens of ms of work (0.375 -> 0.358 ms per step in a 20-step region)',
-                   'step': 'autograd operator path' if args.autograd else 'FusedViewStep (direct C-ABI calls)',
+                   'step': 'autograd operator path' if args.autograd else (
+                       'FusedViewStep behind the autograd API: loss = step.loss(...); loss.backward(); optimizer.step()'
+                       if args.autograd_fused else 'FusedViewStep (direct C-ABI calls)'),
                    'operator_path_backward_thread': args.backward_thread,
                    'replicas_identical': replicas_identical, 'param_digest': param_digest,
                    'cluster': cluster},

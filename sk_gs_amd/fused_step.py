@@ -408,8 +408,14 @@ class FusedViewStep:
         chk(lib.skgs_image_loss_forward(C.c_int32(3), C.c_int32(H), C.c_int32(W), _p(self.image), _p(target), gt_index,
                                         C.c_float(self.lambda_l1), C.c_float(self.lambda_ssim), None,  # value: backward
                                         _p(self.loss_ws), C.c_size_t(self.loss_ws.numel()), st))
+        self._loss_backward_and_raster(a, d, target, gt_index, time_id, self.grad_scale)
+
+    def _loss_backward_and_raster(self, a, d, target, gt_index, time_id, grad_loss: Tensor):
+        """dL/dimage from the loss workspace (seeded with the device scalar ``grad_loss``), then the rasterizer backward"""
+        lib, m, st, chk = self.lib, self.model, _C._stream(), _C._check
+        W, H = self.W, self.H
         chk(lib.skgs_image_loss_backward(C.c_int32(3), C.c_int32(H), C.c_int32(W), _p(self.image), _p(target), gt_index,
-                                         C.c_float(self.lambda_l1), C.c_float(self.lambda_ssim), _p(self.grad_scale),
+                                         C.c_float(self.lambda_l1), C.c_float(self.lambda_ssim), _p(grad_loss),
                                          _p(self.loss_ws), C.c_size_t(self.loss_ws.numel()), _p(self.dL_dimage),
                                          _p(self.loss3), st))
         # ---- rasterize backward: SH gradients land in the parameters' .grad, the rest feeds the skinning backward
@@ -457,6 +463,55 @@ class FusedViewStep:
         g.deform_backward_job = C.cast(C.pointer(j), C.c_void_p)
         self._rows_backward_done = True
         return j
+
+    # ---- the same launches behind torch's autograd API ------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_loss(self, rs: Optional[GaussianRasterizationSettings] = None, time_id: Optional[int] = None,
+                     target: Optional[Tensor] = None) -> Tensor:
+        """the forward half of a training view alone: deform, rasterize, ``0.8 L1 + 0.2 (1 - SSIM)`` -- ``loss3`` holds {total, L1,
+        SSIM}; ``backward_pending`` runs the backward half later.  What ``loss()`` calls from an autograd node."""
+        lib, st, chk = self.lib, _C._stream(), _C._check
+        if rs is None:
+            from sk_gs_amd import view_slot as vsl
+            assert target is None and self.view_table.targets is not None
+            target, gt_index = self.view_table.targets, C.c_void_p(self.view_table.ptr(vsl.W_TARGET))
+        else:
+            gt_index = None
+        assert target.is_cuda and target.dtype == torch.float32 and target.is_contiguous()
+        self._zero_table_grads()
+        a, d = self.forward(rs, time_id)
+        chk(lib.skgs_image_loss_forward(C.c_int32(3), C.c_int32(self.H), C.c_int32(self.W), _p(self.image), _p(target), gt_index,
+                                        C.c_float(self.lambda_l1), C.c_float(self.lambda_ssim), _p(self.loss3),
+                                        _p(self.loss_ws), C.c_size_t(self.loss_ws.numel()), st))
+        self._pending = (a, d, target, gt_index, time_id)
+        return self.loss3[0]
+
+    @torch.no_grad()
+    def backward_pending(self, grad_loss: Optional[Tensor] = None):
+        """the backward half of the view ``forward_loss`` ran: every parameter's gradient is WRITTEN into its ``.grad`` storage
+        (the fused kernels overwrite, they do not accumulate).  ``grad_loss``: d(objective) / d(loss) as a device scalar tensor
+        (multiplied by the step's own ``grad_scale``)."""
+        a, d, target, gt_index, time_id = self._pending
+        self._pending = None
+        seed = self.grad_scale  # (None: 1)
+        if grad_loss is not None:
+            seed = grad_loss.detach().reshape(1).to(torch.float32)
+            if self.grad_scale is not None:
+                seed = seed * self.grad_scale
+            seed = seed.contiguous()
+        self._loss_backward_and_raster(a, d, target, gt_index, time_id, seed)
+        self.backward_skinning(time_id)
+
+    def loss(self, rs: Optional[GaussianRasterizationSettings] = None, time_id: Optional[int] = None,
+             target: Optional[Tensor] = None) -> Tensor:
+        """One training view as an AUTOGRAD node over the fused launches: ``loss = step.loss(rs, time_id, target);
+        loss.backward(); optimizer.step()`` -- the reference's loop shape (train.py:179-250) with this package's 11 launches per
+        view instead of the operator path's ~30.  The forward half runs now, the backward half when autograd reaches the node
+        (seeded with the incoming d/dloss, so ``(2 * loss).backward()`` or a sum with other terms behave); the parameters'
+        gradients are WRITTEN into their existing ``.grad`` tensors -- call ``optimizer.zero_grad()`` (which keeps the tensors)
+        before the forward, not between forward and backward, and do not expect accumulation over several views."""
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        return _FusedViewLoss.apply(self, rs, time_id, target, *params)
 
     @torch.no_grad()
     def sh_grads_from_factors(self, all_factors: Tensor, sh_degree: int):
@@ -699,3 +754,20 @@ class FusedViewStep:
         if self.deform_net is not None and self._mlp_fused is not None:
             st['mlp_failed'] = self._mlp_fused.status()['failed']
         return st
+
+
+class _FusedViewLoss(torch.autograd.Function):
+    """``FusedViewStep.loss``: forward = ``forward_loss``, backward = ``backward_pending`` (side effect: the parameters' ``.grad``
+    storage is overwritten; the node itself hands autograd no gradient tensors -- returning them would make autograd add them on
+    top of what the kernels wrote)."""
+
+    @staticmethod
+    def forward(ctx, step, rs, time_id, target, *params):
+        ctx.step = step
+        return step.forward_loss(rs, time_id, target).clone()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        ctx.step.backward_pending(g)
+        return (None,) * (4 + len([p for p in ctx.step.model.parameters() if p.requires_grad]))

@@ -717,3 +717,61 @@ def test_several_steps_per_graph_replay_walk_the_views_like_single_replays():
     assert len(graphs.graphs) == 2 and step.status()['overflow_events'] == 0
     st = opt.state[model._features_dc]
     assert float(st['exp_avg'].abs().max()) > 0  # (the steps did run their backward and their optimizer launch)
+
+
+def test_fused_step_behind_the_autograd_api():
+    """``loss = step.loss(rs, time_id, target); loss.backward(); optimizer.step()`` -- the fused launches as ONE autograd
+    node (forward half at the call, backward half when autograd reaches it, seeded with the incoming d/dloss): loss value and every
+    gradient equal ``forward_backward``'s bit for bit, a scaled objective scales them, and two optimizer steps of the loop train what
+    ``FusedTrainStep``-less ``forward_backward + FusedAdam.step`` trains"""
+    from sk_gs_amd import _C, scene
+    from sk_gs_amd.fused_step import FusedViewStep
+    from sk_gs_amd.model import SkinnedGaussians
+    from sk_gs_amd.optim import FusedAdam
+    P, M, K, W, H, frames = 3000, 10, 4, 128, 96, 3
+    dev = torch.device('cuda')
+
+    def build():
+        model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=2, scale_mult=2.0, deform_net=True, learn_joints=True).to(dev)
+        rs = [scene.raster_settings_from_camera(scene.make_camera(W, H, seed=v), sh_degree=3, colmap=True, device=dev) for v in range(frames)]
+        targets = [torch.rand(3, H, W, generator=torch.Generator().manual_seed(3 + v)).to(dev) for v in range(frames)]
+        _C.config.sync_num_rendered = True
+        with torch.no_grad():
+            R = max(model.render(rs[v], time_id=v)['buffer'].R for v in range(frames))
+        for p in model.parameters():
+            p.grad = None
+        step = FusedViewStep(model, W, H, capacity=int(R * 1.5) + 1024)
+        return model, rs, targets, step
+    model, rs, targets, step = build()
+    step.forward_backward(rs[1], 1, targets[1])
+    want = {n: p.grad.clone() for n, p in model.named_parameters()}
+    want_loss = step.loss3.clone()
+    for p in model.parameters():
+        p.grad.fill_(3.0)
+    loss = step.loss(rs[1], 1, targets[1])
+    assert loss.requires_grad and loss.shape == () and float(loss) == float(want_loss[0])
+    assert all(float(p.grad.flatten()[0]) == 3.0 for p in model.parameters() if p.numel() > 0 and p is not model.global_tr)   # forward half only
+    loss.backward()
+    for n, p in model.named_parameters():
+        assert torch.equal(p.grad, want[n]), n
+    (2.5 * step.loss(rs[1], 1, targets[1]) + 7.0).backward()           # the incoming cotangent seeds the backward half
+    for n, p in model.named_parameters():
+        if float(want[n].abs().max()) > 0:
+            assert rel_err(p.grad, 2.5 * want[n]) <= 2e-6, n
+    # the loop of the reference's train step, against the same launches called directly
+    runs = []
+    for api in (True, False):
+        model, rs, targets, step = build()
+        opt = FusedAdam(model.param_groups(lr=1e-3), eps=1e-15)
+        for it in range(3):
+            v = it % frames
+            opt.zero_grad()
+            if api:
+                step.loss(rs[v], v, targets[v]).backward()
+            else:
+                step.forward_backward(rs[v], v, targets[v])
+            opt.step()
+        torch.cuda.synchronize()
+        runs.append({n: p.detach().clone() for n, p in model.named_parameters()})
+    for n in runs[0]:
+        assert_close_robust(runs[0][n], runs[1][n], 1e-5, 2e-3, name=f'loop {n}')
