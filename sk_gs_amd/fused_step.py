@@ -764,7 +764,7 @@ class _FusedViewLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, step, rs, time_id, target, *params):
         ctx.step = step
-        return step.forward_loss(rs, time_id, target).clone()
+        return step.forward_loss(rs, time_id, target).clone()  # (a copy: `loss3` is rewritten by the next view)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
