@@ -103,6 +103,22 @@ def sp_stage(lie, knn_points, a, K, warp_method='LBS', sep_rot=False):
     return res
 
 
+def loss_sp_arap(lie, spT, sp_points, sk_knn_num):
+    """the reference's Lie-group regulariser on the superpoint transforms (loss_sp_arap, sk_gs.py:1371-1381): inverse, product, log
+    and action of SE3 elements -- (mean geodesic distance to the neighbours' transforms, change of neighbour distances)"""
+    se3 = lie.SE3.InitFromVec(spT)
+    c = sp_points[..., :3]
+    moved = se3.act(c)
+    with torch.no_grad():
+        dist = torch.cdist(c, c)
+        _, knn = torch.topk(dist, dim=1, k=min(c.shape[0], sk_knn_num + 1), largest=False)
+        knn = knn[:, 1:]
+    loss = (se3[:, None].inv() * se3[knn]).log().norm(dim=-1).mean()
+    dist_c = (c[:, None] - c[knn]).square().sum(dim=-1)
+    dist_t = (moved[:, None] - moved[knn]).square().sum(dim=-1)
+    return loss, (dist_c - dist_t).abs().mean()
+
+
 SCENARIOS = {  # name -> (stage, K, warp_method, sep_rot): tests/golden/make_golden_sk_stage.py
     'sk_W': ('sk', 5, 'LBS', False), 'sk_lie': ('sk', 5, 'LBS', False), 'sk_kernel': ('sk', 3, 'LBS', False),
     'sp_W_LBS': ('sp', 5, 'LBS', False), 'sp_wk_LBSc_sep': ('sp', 3, 'LBS_c', True), 'sp_W_largest': ('sp', 3, 'largest', False),

@@ -230,3 +230,16 @@ def test_typed_neighbour_indices_give_the_same_gather_gradients(R, C, M):
     i = p3d.NeighbourIndex.wrap(idx)
     assert type(i.detach()) is torch.Tensor and type(i + 1) is torch.Tensor and (R == 0 or type(i[0]) is p3d.NeighbourIndex)
     assert type(table0.cuda()[i]) is torch.Tensor                       # no gradient asked for: torch's own gather
+
+
+def test_reference_arap_loss_on_the_gpu():
+    """loss_sp_arap (sk_gs.py:1371-1381; inv, product, log, act through csrc/lie_ops.hip) against the reference's own CPU run"""
+    L, _ = _mods()
+    z = np.load(os.path.join(GOLDEN, 'sk_stage.npz'))
+    before = dict(L.hip_op_calls)
+    spT = torch.from_numpy(z['arap/spT']).cuda().requires_grad_()
+    loss, loss_ct = rs.loss_sp_arap(L, spT, torch.from_numpy(z['arap/sp_points']).cuda(), int(z['arap/sk_knn_num']))
+    (loss + 0.5 * loss_ct).backward()
+    assert L.hip_op_calls['forward'] >= before['forward'] + 4 and L.hip_op_calls['backward'] >= before['backward'] + 4
+    assert abs(float(loss) - float(z['arap/loss'])) < 5e-6 and abs(float(loss_ct) - float(z['arap/loss_ct'])) < 5e-6
+    assert rel_err(spT.grad.cpu(), z['arap/g_spT']) <= 5e-5

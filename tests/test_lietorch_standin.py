@@ -263,6 +263,15 @@ def test_replay_of_the_reference_run(fixture, name, recognise, monkeypatch):
         assert _rel(got_grad[k], want) < 2e-5, (name, k, _rel(got_grad[k], want))
 
 
+def test_replay_of_the_reference_arap_loss(fixture):
+    """loss_sp_arap (sk_gs.py:1371-1381) as the reference itself ran it on the stand-ins: inv, product, log, act and their gradient"""
+    spT = torch.from_numpy(fixture['arap/spT']).requires_grad_()
+    loss, loss_ct = rs.loss_sp_arap(L, spT, torch.from_numpy(fixture['arap/sp_points']), int(fixture['arap/sk_knn_num']))
+    (loss + 0.5 * loss_ct).backward()
+    assert abs(float(loss) - float(fixture['arap/loss'])) < 2e-6 and abs(float(loss_ct) - float(fixture['arap/loss_ct'])) < 2e-6
+    assert _rel(spT.grad, fixture['arap/g_spT']) < 2e-5
+
+
 def test_fixture_against_the_oracle(fixture, oracle32):
     """sk_W: the C oracle's bone chain, search and skinning (forward and backward) on the reference run's inputs"""
     a, out, cot, grad = rs.load_scenario(fixture, 'sk_W')

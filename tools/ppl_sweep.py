@@ -4,7 +4,7 @@ import torch
 from helpers import scene_inputs
 from test_gpu_raster import hip_forward, hip_backward
 from sk_gs_amd import _C
-for (P, W, H) in [(500000, 1024, 1024), (200000, 512, 512), (300000, 1600, 1200)]:
+for (P, W, H) in [(100000, 800, 800), (500000, 1024, 1024), (200000, 512, 512), (300000, 800, 800)]:
     act, rs, cam = scene_inputs(P, W, H, seed=0, device='cuda')
     g = torch.Generator().manual_seed(1)
     gc, go = torch.randn(3, H, W, generator=g).cuda(), torch.randn(H, W, generator=g).cuda()
