@@ -159,10 +159,10 @@ def main():
             # and act of the stand-in under the reference's own code -- values and the gradient that reaches the transforms
             spT_leaf = outputs['_spT'].detach().clone().requires_grad_()
             arap, arap_ct = model.loss_sp_arap(SE3.InitFromVec(spT_leaf))
-            (arap + 0.5 * arap_ct).backward()
+            (g_spT,) = torch.autograd.grad(arap + 0.5 * arap_ct, spT_leaf)   # (not .backward(): the scenario's own gradients follow)
             rec['arap/spT'], rec['arap/sp_points'] = f32(spT_leaf), f32(model.sp_points)
             rec['arap/sk_knn_num'] = np.int64(model.sk_knn_num)
-            rec['arap/loss'], rec['arap/loss_ct'], rec['arap/g_spT'] = f32(arap), f32(arap_ct), f32(spT_leaf.grad)
+            rec['arap/loss'], rec['arap/loss_ct'], rec['arap/g_spT'] = f32(arap), f32(arap_ct), f32(g_spT)
             print(f'   loss_sp_arap {float(arap):.6f} {float(arap_ct):.6f}')
         for k, v in ins.items():
             rec[f'{name}/in/{k}'] = v.numpy()
