@@ -179,14 +179,14 @@ def build_parser():
     ap.add_argument('--lbs-method', choices=('weighted_kernel', 'kernel', 'dist', 'W'), default='weighted_kernel',
                     help="--stage sp: the weighting of calc_LBS_weight (class default 'weighted_kernel', sk_gs.py:364; "
                          "exps/default.yaml:35 sets 'W': a dense [P,512] logit table)")
-    ap.add_argument('--warp-method', choices=('LBS', 'LBS_c'), default='LBS',
+    ap.add_argument('--warp-method', choices=('LBS', 'LBS_c', 'largest'), default='LBS',
                     help="--stage sp: warp_method (exps/default.yaml:36 LBS; exps/d_nerf_sc_gs.yaml:32 LBS_c: the superpoint's transform "
                          "re-centred on the superpoint, sk_gs.py:803-804)")
     ap.add_argument('--sep-rot', action='store_true',
                     help="--stage sp: the deform network's local_rotation head feeds the rotation blend (sep_rot, the class default "
                          "sk_gs.py:357 and what exps/d_nerf_sc_gs.yaml runs with)")
     ap.add_argument('--knn', type=int, default=5, help='--stage sp: num_knn (exps/default.yaml:20: 5; the SC-GS / SP-GS configs: 3)')
-    ap.add_argument('--preset', choices=('sc_gs',), default=None,
+    ap.add_argument('--preset', choices=('sc_gs', 'sp_gs'), default=None,
                     help="--stage sp: sc_gs = exps/d_nerf_sc_gs.yaml's combination: LBS_method weighted_kernel, warp_method LBS_c, "
                          "sep_rot, num_knn 3")
     return ap

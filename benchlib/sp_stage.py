@@ -115,6 +115,8 @@ def run(args, base_alg_bytes, configs):
     P, W, H = cfg['P'], cfg['W'], cfg['H']
     if args.preset == 'sc_gs':  # exps/d_nerf_sc_gs.yaml:18,31-32 (sep_rot: the class default, not overridden there)
         args.lbs_method, args.warp_method, args.sep_rot, args.knn = 'weighted_kernel', 'LBS_c', True, 3
+    if args.preset == 'sp_gs':  # exps/d_nerf_sp_gs.yaml:18,30-32
+        args.lbs_method, args.warp_method, args.sep_rot, args.knn = 'W', 'largest', False, 3
     M, K, F = args.superpoints, args.knn, 8
     frames = args.views
     model = SuperpointGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=0, scale_mult=args.scale_mult,

@@ -82,6 +82,7 @@ typedef struct skgs_knn_deform_job {
   float* scales;        /* [P,3]  == skgs_raster_inputs.scales    */
   float* rotations;     /* [P,4]  == skgs_raster_inputs.rotations */
   float* opacity;       /* [P]    == skgs_raster_inputs.opacity   */
+  int32_t largest;      /* skinning alone (joints == NULL) only: see skgs_deform_inputs.largest */
 } skgs_knn_deform_job;
 
 /* Inputs of rasterize_gaussians / rasterize_gaussians_backward (same meaning, same order as the pybind args). */
@@ -263,6 +264,12 @@ typedef struct skgs_deform_inputs {
   const float* opacity_logit; /* [P,1] */
   const int32_t* live_count;  /* NULL, or a DEVICE int32 n <= P (see skgs_raster_inputs.live_count): the fused forward /
                                * backward (skgs_knn_lbs_deform_forward, skgs_lbs_deform_backward_logits) skip rows >= n */
+  int32_t largest;            /* warp_method `largest` (exps/d_nerf_sp_gs.yaml:32, networks/sk_gs.py:811-816,849-850): the POSITION of a
+                               * Gaussian follows the one bone with its largest weight (the first of equal ones, torch.argmax) --
+                               * d_xyz = T[indices[n, argmax_k weights[n,k]]](p) - p -- while the rotation / scale offsets stay blended
+                               * with the K weights; the weights then receive no gradient through the position.  Honoured by
+                               * skgs_lbs_deform_forward, the skinning-alone deform_job of skgs_rasterize_forward, and
+                               * skgs_sp_skinning_backward / skgs_raster_grads.sp_skinning_job; every other entry point refuses it */
 } skgs_deform_inputs;
 /* skgs_lbs_deform_backward_logits (below) as a job of skgs_rasterize_backward (skgs_raster_grads.deform_backward_job): the
  * per-Gaussian launch that produces dL/d(means3D, scales, rotations, opacity) hands them to the skinning backward in registers

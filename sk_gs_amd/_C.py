@@ -33,7 +33,7 @@ class _KnnDeformJob(C.Structure):
     """include/skgs.h: skgs_knn_deform_job"""
     _fields_ = [('M', C.c_int32), ('K', C.c_int32)] + [(n, C.c_void_p) for n in (
         'points', 'joints', 'sp_W', 'bone_T', 'bone_drot', 'bone_dscale', 'xyz', 'log_scale', 'rot', 'opacity_logit', 'out_idx',
-        'out_weights', 'means', 'scales', 'rotations', 'opacity')]
+        'out_weights', 'means', 'scales', 'rotations', 'opacity')] + [('largest', C.c_int32)]
 
 
 class _RasterInputs(C.Structure):
@@ -81,7 +81,7 @@ class _DeformInputs(C.Structure):
         ('P', C.c_int32), ('K', C.c_int32), ('M', C.c_int32),
         ('points', C.c_void_p), ('weights', C.c_void_p), ('indices', C.c_void_p), ('bone_T', C.c_void_p),
         ('bone_drot', C.c_void_p), ('bone_dscale', C.c_void_p), ('xyz', C.c_void_p), ('log_scale', C.c_void_p),
-        ('rot', C.c_void_p), ('opacity_logit', C.c_void_p), ('live_count', C.c_void_p),
+        ('rot', C.c_void_p), ('opacity_logit', C.c_void_p), ('live_count', C.c_void_p), ('largest', C.c_int32),
     ]
 
 

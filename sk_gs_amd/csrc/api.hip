@@ -228,6 +228,7 @@ int skgs_rasterize_backward(const skgs_raster_inputs* in, const skgs_raster_buff
     SKGS_REQUIRE(dj->in != nullptr, "deform_backward_job: in is NULL");
     if (check_deform(dj->in)) return 1;
     SKGS_REQUIRE(dj->in->P == in->P && dj->in->live_count == in->live_count, "deform_backward_job: P / live_count differ from the rasterizer's");
+    SKGS_REQUIRE(!dj->in->largest, "deform_backward_job: warp_method `largest` is served by the sp_skinning_job only");
     SKGS_REQUIRE(dj->in->M <= deform_backward_job_max_bones() && dj->in->K <= deform_backward_job_max_k(),
         "deform_backward_job: needs M <= %d, K <= %d (got %d, %d)", deform_backward_job_max_bones(), deform_backward_job_max_k(),
         dj->in->M, dj->in->K);
@@ -339,6 +340,7 @@ int skgs_lbs_deform_backward(const skgs_deform_inputs* in, const float* g_means,
     float* g_bone_dscale, float* g_xyz, float* g_log_scale, float* g_rot, float* g_opacity_logit, void* workspace,
     size_t workspace_bytes, skgs_stream_t stream) {
   if (check_deform(in)) return 1;
+  SKGS_REQUIRE(!in->largest, "deform backward: warp_method `largest` is served by skgs_sp_skinning_backward / sp_skinning_job only");
   SKGS_REQUIRE(in->P == 0 || (g_means && g_scales && g_rotations && g_opacity), "deform: upstream gradients are required");
   SKGS_REQUIRE(g_bone_T && g_bone_drot && g_bone_dscale, "deform: bone gradient outputs are required");
   SKGS_REQUIRE(in->P == 0 || (g_weights && g_xyz && g_log_scale && g_rot && g_opacity_logit),
@@ -354,6 +356,7 @@ int skgs_lbs_deform_backward_logits(const skgs_deform_inputs* in, const float* g
     float* g_bone_dscale, float* g_xyz, float* g_log_scale, float* g_rot, float* g_opacity_logit, float* g_sp_W,
     float* g_logits, void* workspace, size_t workspace_bytes, skgs_stream_t stream) {
   if (check_deform(in)) return 1;
+  SKGS_REQUIRE(!in->largest, "deform backward: warp_method `largest` is served by skgs_sp_skinning_backward / sp_skinning_job only");
   SKGS_REQUIRE(in->P == 0 || (g_means && g_scales && g_rotations && g_opacity), "deform: upstream gradients are required");
   SKGS_REQUIRE(g_bone_T && g_bone_drot && g_bone_dscale, "deform: bone gradient outputs are required");
   SKGS_REQUIRE(in->P == 0 || (g_xyz && g_log_scale && g_rot && g_opacity_logit), "deform: gradient outputs are required");

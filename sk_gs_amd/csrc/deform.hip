@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_forward_kernel(int P, i
     const float* __restrict__ bone_drot, const float* __restrict__ bone_dscale, const float* __restrict__ xyz,
     const float* __restrict__ log_scale, const float* __restrict__ rot, const float* __restrict__ opacity_logit,
     float* __restrict__ means, float* __restrict__ scales, float* __restrict__ rotations, float* __restrict__ opacity,
-    float* __restrict__ d_xyz, float* __restrict__ d_rot, float* __restrict__ d_scale) {
+    float* __restrict__ d_xyz, float* __restrict__ d_rot, float* __restrict__ d_scale, int largest) {
   extern __shared__ float s_bones[];
   if (LDS_BONES) {
     for (int j = threadIdx.x; j < M; j += DEFORM_THREADS) load_bone(bone_T, bone_drot, bone_dscale, j, s_bones + j * BONE_F);
@@ -36,6 +36,7 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_forward_kernel(int P, i
   if (n >= P) return;
   const float p[3] = {points[3 * n], points[3 * n + 1], points[3 * n + 2]};
   float sx[3] = {0, 0, 0}, sr[4] = {0, 0, 0, 0}, ss[3] = {0, 0, 0};
+  const int kmax = largest ? argmax_slot(weights + (size_t) n * K, K) : -1;  // warp_method `largest` (skgs_deform_inputs.largest)
   for (int k = 0; k < K; ++k) {
     const int j   = (int) indices[(size_t) n * K + k];
     const float w = weights[(size_t) n * K + k];
@@ -49,7 +50,8 @@ __global__ void __launch_bounds__(DEFORM_THREADS) deform_forward_kernel(int P, i
     }
     float y[3];
     se3_act(b, p, y);
-    sx[0] += y[0] * w, sx[1] += y[1] * w, sx[2] += y[2] * w;
+    const float wx = kmax < 0 ? w : (k == kmax ? 1.f : 0.f);
+    sx[0] += y[0] * wx, sx[1] += y[1] * wx, sx[2] += y[2] * wx;
     sr[0] += b[7] * w, sr[1] += b[8] * w, sr[2] += b[9] * w, sr[3] += b[10] * w;
     ss[0] += b[11] * w, ss[1] += b[12] * w, ss[2] += b[13] * w;
   }
@@ -777,11 +779,11 @@ int launch_deform_forward(const skgs_deform_inputs& in, float* means, float* sca
   if (in.M <= MAX_LDS_BONES)
     hipLaunchKernelGGL(deform_forward_kernel<true>, grid, block, (size_t) in.M * BONE_F * 4, s, in.P, in.K, in.M, in.points,
         in.weights, in.indices, in.bone_T, in.bone_drot, in.bone_dscale, in.xyz, in.log_scale, in.rot, in.opacity_logit,
-        means, scales, rotations, opacity, d_xyz, d_rot, d_scale);
+        means, scales, rotations, opacity, d_xyz, d_rot, d_scale, in.largest ? 1 : 0);
   else
     hipLaunchKernelGGL(deform_forward_kernel<false>, grid, block, 0, s, in.P, in.K, in.M, in.points, in.weights,
         in.indices, in.bone_T, in.bone_drot, in.bone_dscale, in.xyz, in.log_scale, in.rot, in.opacity_logit, means, scales,
-        rotations, opacity, d_xyz, d_rot, d_scale);
+        rotations, opacity, d_xyz, d_rot, d_scale, in.largest ? 1 : 0);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

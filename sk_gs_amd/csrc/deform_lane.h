@@ -335,8 +335,18 @@ __device__ __forceinline__ void deform_bwd_moments(const DeformBwdArgs& a, int P
 constexpr int SP_MAXK = 16;
 constexpr int SP_MAXF = 8;
 constexpr int SP_UROW = 12;  // per-Gaussian payload row: g_dx 3 | g_v 4 | g_ds 3 | pad 2
+// warp_method `largest` (sk_gs.py:811-816,849-850): the slot of a row's largest weight, the first of equal ones (torch.argmax)
+__device__ __forceinline__ int argmax_slot(const float* __restrict__ w, int K) {
+  int best = 0;
+  float wb = w[0];
+  for (int k = 1; k < K; ++k) {
+    const float wk = w[k];
+    if (wk > wb) wb = wk, best = k;
+  }
+  return best;
+}
 struct SpRowsArgs {
-  int K, M;
+  int K, M, largest;
   const float *points, *weights;
   const int64_t* indices;
   const float *nn_dist, *bone_T, *bone_drot, *bone_dscale, *log_scale, *rot, *opacity_logit, *feature, *sp_feature, *radius_raw,
@@ -352,7 +362,7 @@ inline SpRowsArgs sp_rows_args(const skgs_sp_skinning_job& j) {
   char* wsp      = reinterpret_cast<char*>(j.workspace);
   float* U       = reinterpret_cast<float*>(wsp);
   float* V       = reinterpret_cast<float*>(wsp + align256(P * SP_UROW * 4));
-  return SpRowsArgs{in->K, in->M, in->points, in->weights, in->indices, j.nn_dist, in->bone_T, in->bone_drot, in->bone_dscale,
+  return SpRowsArgs{in->K, in->M, (int) in->largest, in->points, in->weights, in->indices, j.nn_dist, in->bone_T, in->bone_drot, in->bone_dscale,
       in->log_scale, in->rot, in->opacity_logit, j.feature, j.sp_feature, j.sp_radius_raw, j.sp_weight_raw, j.temperature,
       (int) j.logit_weighting, j.g_weights, j.g_xyz, j.g_log_scale, j.g_rot, j.g_opacity_logit, j.g_feature, U, V};
 }
@@ -416,6 +426,7 @@ __device__ __forceinline__ void sp_rows_lane(const SpRowsArgs& ja, const float* 
       float y[3];
       se3_act(b, p, y);
       float a = g_dx[0] * y[0] + g_dx[1] * y[1] + g_dx[2] * y[2];
+      if (ja.largest) a = 0.f;  // the position follows ONE bone: the weights reach the loss through the rotation / scale blend only
 #pragma unroll
       for (int c = 0; c < 4; ++c) a += g_v[c] * b[7 + c];
 #pragma unroll

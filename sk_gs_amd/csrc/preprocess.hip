@@ -304,6 +304,7 @@ __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, const fl
 // produced them), any number of bones, their rows gathered from global memory (deform_forward_kernel<false>'s arithmetic).
 struct KnnDeformJob {
   int M, K, lds_offset /* floats: where the deform's tables start in the dynamic LDS (behind the SH rows) */;
+  int largest;         /* (DK == -1) warp_method `largest`: the position follows the bone of the largest weight alone */
   const float *points, *joints, *sp_W, *bone_T, *bone_drot, *bone_dscale, *xyz, *log_scale, *rot, *opacity_logit;
   int64_t* out_idx;
   float *out_weights, *means, *scales, *rotations, *opacity;
@@ -433,19 +434,21 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
   if constexpr (DK == -1) {
     if (idx < P) {  // deform_forward_kernel<false>: the bones' rows from global memory, in the neighbours' order
       float sx[3] = {0, 0, 0}, sr[4] = {0, 0, 0, 0}, ss[3] = {0, 0, 0};
-      auto skin = [&](int j, float w) {
+      const int kmax = dj.largest ? argmax_slot(dj.out_weights + (size_t) idx * dj.K, dj.K) : -1;  // (the row is in cache: just read)
+      auto skin = [&](int k, int j, float w) {
         float b[BONE_F];
         load_bone(dj.bone_T, dj.bone_drot, dj.bone_dscale, j, b);
         float y[3];
         se3_act(b, dj_p, y);
-        sx[0] += y[0] * w, sx[1] += y[1] * w, sx[2] += y[2] * w;
+        const float wx = kmax < 0 ? w : (k == kmax ? 1.f : 0.f);  // `largest`: the position follows that one bone
+        sx[0] += y[0] * wx, sx[1] += y[1] * wx, sx[2] += y[2] * wx;
         sr[0] += b[7] * w, sr[1] += b[8] * w, sr[2] += b[9] * w, sr[3] += b[10] * w;
         ss[0] += b[11] * w, ss[1] += b[12] * w, ss[2] += b[13] * w;
       };
 #pragma unroll
       for (int q = 0; q < PREF_K; ++q)
-        if (q < dj.K) skin(sk_j[q], sk_w[q]);
-      for (int k = PREF_K; k < dj.K; ++k) skin((int) dj.out_idx[(size_t) idx * dj.K + k], dj.out_weights[(size_t) idx * dj.K + k]);
+        if (q < dj.K) skin(q, sk_j[q], sk_w[q]);
+      for (int k = PREF_K; k < dj.K; ++k) skin(k, (int) dj.out_idx[(size_t) idx * dj.K + k], dj.out_weights[(size_t) idx * dj.K + k]);
       deform_activate_lane(dj_p, sx, sr, ss, dj_x, dj_ls, dj_r4, dj_ol, pf_p, pf_s, pf_q, pf_op);
 #pragma unroll
       for (int c = 0; c < 3; ++c) dj.means[3 * idx + c] = pf_p[c], dj.scales[3 * idx + c] = pf_s[c];
@@ -1113,8 +1116,9 @@ int launch_preprocess_forward(const skgs_raster_inputs& in, GeomView g, ImgView 
       return set_error("deform_job: needs 1 <= K <= min(8, M), M <= %d (got K = %d, M = %d)", SKGS_FUSED_LBS_MAX_BONES, j->K, j->M);
     if (!search && (j->K < 1 || j->K > 16 || j->M < 1 || in.live_count))
       return set_error("deform_job (skinning alone): needs 1 <= K <= 16, M >= 1, no row capacity (got K = %d, M = %d)", j->K, j->M);
+    if (search && j->largest) return set_error("deform_job: `largest` applies to the skinning alone (joints == NULL)");
     dk = !search ? -1 : j->K <= 5 ? 5 : 8;
-    dj.M = j->M, dj.K = j->K;
+    dj.M = j->M, dj.K = j->K, dj.largest = j->largest ? 1 : 0;
     dj.lds_offset = (int) ((lds / 4 + 3) & ~(size_t) 3);
     dj.points = j->points, dj.joints = j->joints, dj.sp_W = j->sp_W, dj.bone_T = j->bone_T, dj.bone_drot = j->bone_drot;
     dj.bone_dscale = j->bone_dscale, dj.xyz = j->xyz, dj.log_scale = j->log_scale, dj.rot = j->rot;

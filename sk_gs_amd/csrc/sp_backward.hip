@@ -55,7 +55,7 @@ template <int F>
 __global__ void __launch_bounds__(SB_THREADS) sp_backward_bones_kernel(int K, int M, int cap, const uint32_t* __restrict__ counts,
     const uint32_t* __restrict__ lists, const float* __restrict__ points, const float* __restrict__ weights,
     const float* __restrict__ bone_T, const float* __restrict__ bone_drot, const float* __restrict__ bone_dscale,
-    const float* __restrict__ feature, const float* __restrict__ sp_feature, int logits, const float* __restrict__ U,
+    const float* __restrict__ feature, const float* __restrict__ sp_feature, int logits, int largest, const float* __restrict__ U,
     const float* __restrict__ V, float* __restrict__ partials) {
   __shared__ float s_red[SB_THREADS / 64][NV];
   const int j = blockIdx.x / SLICES, slice = blockIdx.x % SLICES;
@@ -76,13 +76,15 @@ __global__ void __launch_bounds__(SB_THREADS) sp_backward_bones_kernel(int K, in
     const int n = (int) (pid >> 4), k = (int) (pid & 15u);
     const float p[3] = {points[3 * n], points[3 * n + 1], points[3 * n + 2]};
     const float w    = weights[(size_t) n * K + k];
+    // warp_method `largest`: the position's gradient reaches only the bone of the Gaussian's largest weight, unweighted
+    const float wx   = largest ? (argmax_slot(weights + (size_t) n * K, K) == k ? 1.f : 0.f) : w;
     const float4 u0 = reinterpret_cast<const float4*>(U + (size_t) n * UROW)[0];
     const float4 u1 = reinterpret_cast<const float4*>(U + (size_t) n * UROW)[1];
     const float4 u2 = reinterpret_cast<const float4*>(U + (size_t) n * UROW)[2];
     const float g_v[4]  = {u0.w, u1.x, u1.y, u1.z};
     const float g_ds[3] = {u1.w, u2.x, u2.y};
     // d spT: translation = w g_dx; quaternion through R(q) p and the normalisation (deform.hip::deform_backward_kernel)
-    const float g[3] = {w * u0.x, w * u0.y, w * u0.z};
+    const float g[3] = {wx * u0.x, wx * u0.y, wx * u0.z};
     const float* vq  = b;
     const float vxp[3] = {vq[1] * p[2] - vq[2] * p[1], vq[2] * p[0] - vq[0] * p[2], vq[0] * p[1] - vq[1] * p[0]};
     const float pxg[3] = {p[1] * g[2] - p[2] * g[1], p[2] * g[0] - p[0] * g[2], p[0] * g[1] - p[1] * g[0]};
@@ -208,8 +210,8 @@ static int sp_skinning_rest_launches(const skgs_sp_skinning_job& j, hipStream_t 
   SpPairsView pv            = sp_pairs_view(j.pairs, std::max(P, 1), M, K);
 #define SKGS_BONES(F_)                                                                                                          \
   hipLaunchKernelGGL((sp_backward_bones_kernel<F_>), dim3(M * SLICES), dim3(SB_THREADS), 0, s, K, M, pv.cap, pv.counts, pv.lists, \
-      in->points, in->weights, in->bone_T, in->bone_drot, in->bone_dscale, j.feature, j.sp_feature, (int) j.logit_weighting, w.U, w.V, \
-      w.partials)
+      in->points, in->weights, in->bone_T, in->bone_drot, in->bone_dscale, j.feature, j.sp_feature, (int) j.logit_weighting, \
+      in->largest ? 1 : 0, w.U, w.V, w.partials)
   if (F == 8) SKGS_BONES(8); else SKGS_BONES(0);
 #undef SKGS_BONES
   SKGS_CHECK_HIP(hipGetLastError());

@@ -427,8 +427,9 @@ class FusedSuperpointStep(FusedViewStep):
         P, M, K = self.P, self.M, self.K
         self.F = int(model.hyper_dim) if model.hyper_feature is not None else 0
         assert self.F in (0, 8), 'csrc/sp_knn.hip: 0 or 8 hyper dimensions'
-        assert model.warp_method in ('LBS', 'LBS_c'), \
-            "FusedSuperpointStep: warp_method 'largest' runs on the operator path only (SuperpointGaussians.forward) this round"
+        # warp_method: LBS_c is the network launches' business (bone_T re-centred in their epilogue), `largest` the skinning's (the
+        # position follows the bone of the largest weight: skgs_deform_inputs.largest)
+        self.largest = model.warp_method == 'largest'
         self.net = model.sp_deform_net.runner(M, lbs_c=model.warp_method == 'LBS_c')
         self.nn_dist = torch.empty((P, K), dtype=torch.float32, device=dev)
         lib.skgs_sp_lbs_weights_workspace_bytes.restype = C.c_size_t
@@ -482,6 +483,7 @@ class FusedSuperpointStep(FusedViewStep):
         a.bone_T, a.bone_drot, a.bone_dscale = self.net.bone_T.data_ptr(), self.net.d_rot.data_ptr(), self.net.d_scale.data_ptr()
         a.log_scale, a.rot, a.opacity_logit = m._scaling.data_ptr(), m._rotation.data_ptr(), m._opacity.data_ptr()
         a.live_count = None
+        a.largest = 1 if self.largest else 0
         return a
 
     def _time(self, time_id) -> Tensor:
@@ -510,7 +512,7 @@ class FusedSuperpointStep(FusedViewStep):
         a = self._raster_inputs(rs)
         if self.deform_in_preprocess:  # the skinning as a job of the rasterizer's per-Gaussian launch (joints = NULL: no search)
             j = _C._KnnDeformJob()
-            j.M, j.K = M, K
+            j.M, j.K, j.largest = M, K, d.largest
             j.points, j.bone_T, j.bone_drot, j.bone_dscale = d.points, d.bone_T, d.bone_drot, d.bone_dscale
             j.xyz, j.log_scale, j.rot, j.opacity_logit = d.xyz, d.log_scale, d.rot, d.opacity_logit
             j.out_idx, j.out_weights = self.indices.data_ptr(), self.weights.data_ptr()

@@ -335,7 +335,8 @@ def _sp_model(P, M, K, W, H, frames, method, seed=0, warp_method='LBS', sep_rot=
 
 
 @pytest.mark.parametrize('method,warp_method,sep_rot', [('weighted_kernel', 'LBS', False), ('W', 'LBS', False), ('dist', 'LBS', False),
-                                                        ('weighted_kernel', 'LBS_c', True), ('kernel', 'LBS_c', False), ('W', 'LBS', True)])
+                                                        ('weighted_kernel', 'LBS_c', True), ('kernel', 'LBS_c', False), ('W', 'LBS', True),
+                                                        ('W', 'largest', False), ('weighted_kernel', 'largest', True)])
 def test_fused_superpoint_step_matches_the_operator_path(method, warp_method, sep_rot):
     """stage sp end to end: FusedSuperpointStep (straight C-ABI calls, MFMA network, one-launch 3+8-d search) against the
     autograd operator path of SuperpointGaussians.render + image_loss -- the image and EVERY parameter gradient (Gaussians,
@@ -375,8 +376,9 @@ def test_fused_superpoint_step_matches_the_operator_path(method, warp_method, se
         assert_close_robust(p.grad, ref[n], 3e-4, 1e-3, name=f'{n} sp {method} {warp_method} sep_rot={sep_rot}')
 
 
-@pytest.mark.parametrize('method', ['weighted_kernel', 'kernel', 'dist', 'W'])
-def test_sp_rows_pass_as_a_job_of_the_rasterizer_backward_equals_the_separate_launch(method):
+@pytest.mark.parametrize('method,warp_method', [('weighted_kernel', 'LBS'), ('kernel', 'LBS'), ('dist', 'LBS'), ('W', 'LBS'), ('W', 'largest'),
+                                                ('dist', 'largest')])
+def test_sp_rows_pass_as_a_job_of_the_rasterizer_backward_equals_the_separate_launch(method, warp_method):
     """skgs_raster_grads.sp_skinning_job: the rows pass of the skinning + weighting backward inside the rasterizer's per-Gaussian
     backward launch (+ bones and finalize behind it) against skgs_sp_skinning_backward as a call of its own -- every gradient
     (their upstream is summed by atomics: order, not bits)"""
@@ -384,7 +386,7 @@ def test_sp_rows_pass_as_a_job_of_the_rasterizer_backward_equals_the_separate_la
     from sk_gs_amd.superpoint import FusedSuperpointStep
     from helpers import assert_close_robust
     P, M, K, W, H, frames, tid = 6000, 512, 5, 160, 120, 3, 1
-    model, rs, target = _sp_model(P, M, K, W, H, frames, method)
+    model, rs, target = _sp_model(P, M, K, W, H, frames, method, warp_method=warp_method)
     _C.config.sync_num_rendered = True
     R = model.render(rs, time_id=tid)['buffer'].R
     got = {}
