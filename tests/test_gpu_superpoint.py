@@ -367,7 +367,9 @@ def test_fused_superpoint_step_matches_the_operator_path(method, warp_method, se
     step.forward_backward(rs, tid, target)
     assert step.status()['overflow'] == 0
     # (the two paths bin with different tile-list layouts; 2 of 57 600 values were 1.7e-5 apart in one of the synthetic scenes)
-    assert_close_robust(step.image, out['images'].detach(), 2e-5, 1e-4, name=f'image sp {method}')
+    # (`largest`: the operator path forms the position from torch ops -- normalize, cross products -- the step from the kernel's
+    # arithmetic: the means differ in the last bits and a handful of pixels by up to 5e-5)
+    assert_close_robust(step.image, out['images'].detach(), 1e-4 if warp_method == 'largest' else 2e-5, 1e-4, name=f'image sp {method} {warp_method}')
     for n, p in model.named_parameters():
         if n in silent:
             assert float(p.grad.abs().max()) == 0.0 and float(ref[n].abs().max()) == 0.0, n
