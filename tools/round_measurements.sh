@@ -3,6 +3,7 @@
 # config, the dense variants, the forced 1-rank RCCL run, the comparison variants, kernel stats + PMC passes (config #1 and #4).
 # usage (on the GPU box, from the repo root): bash tools/round_measurements.sh <tag>      e.g. r02_a
 tag=${1:-rXX}
+exec < /dev/null   # (nothing here reads stdin; a tool that does must not wait on the terminal of a batch run)
 out=gpurun_out/$tag
 rm -rf "$out"; mkdir -p "$out"
 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $out/gpu_tests.txt; cat $out/gpu_tests.txt
@@ -60,6 +61,18 @@ for v in "1 caller" "1 worker" "0 caller" "0 worker"; do set -- $v
   SKGS_TORCH_OPS=$1 python bench.py --no-cpu-baseline --backward-thread $2 --steps 50 --warmup 10 2>/dev/null | tail -1 > $out/bench_oppath_ops$1_$2.json
   python -c "import json; d=json.load(open('$out/bench_oppath_ops$1_$2.json')); r=d['ms_per_render_fwd_bwd']; print('operator path: compiled marshalling $1, backward thread $2: ms/render', r['median'], 'replay', r['graph_replay_median'], 'kernels', r['kernel_sum'])"
 done
+# round 5: the schedule off, the fused step behind the autograd API, the shipped SC-GS / SP-GS combinations of stage sp, the unmodified
+# reference's deform sequence through the lietorch / pytorch3d stand-ins, the one-round-latency sweep, pixels per lane
+python bench.py --lr-schedule off --steps 200 --warmup 20 --no-cpu-baseline --no-ms-per-render --no-survey-recipe 2>/dev/null | tail -1 > $out/bench_lr-schedule-off.json
+python bench.py --autograd-fused --steps 200 --warmup 20 --no-cpu-baseline --no-ms-per-render --no-survey-recipe 2>/dev/null | tail -1 > $out/bench_variant--autograd-fused.json
+python -c "import json; a=json.load(open('$out/bench_lr-schedule-off.json')); b=json.load(open('$out/bench_variant--autograd-fused.json')); print('lr schedule off', a['value'], ' autograd-fused', b['value'])"
+for p in sc_gs sp_gs; do
+  python bench.py --stage sp --preset $p --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_stage_sp_preset_$p.json
+  python -c "import json; d=json.load(open('$out/bench_stage_sp_preset_$p.json')); print('stage sp preset $p', d['value'], d['ms_per_step'])"
+done
+timeout -k 5 200 python tools/time_reference_sequence.py 2>/dev/null | grep -v "not capturable" > $out/time_reference_sequence.txt; cat $out/time_reference_sequence.txt
+timeout -k 5 300 python tools/round_latency_sweep.py 2>/dev/null | grep -v amdgpu > $out/round_latency_sweep.txt; cat $out/round_latency_sweep.txt
+timeout -k 5 300 python tools/ppl_sweep.py 2>/dev/null | grep ppl > $out/ppl_sweep.txt; cat $out/ppl_sweep.txt
 bash tools/profile_round.sh ${tag}_c1 > /dev/null 2>&1; ls gpurun_out/${tag}_c1 | head
 bash tools/profile_round.sh ${tag}_c4 --config 4 > /dev/null 2>&1; ls gpurun_out/${tag}_c4 | head
 bash tools/profile_round.sh ${tag}_sp --stage sp > /dev/null 2>&1; ls gpurun_out/${tag}_sp | head
