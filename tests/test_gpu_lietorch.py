@@ -243,3 +243,82 @@ def test_reference_arap_loss_on_the_gpu():
     assert L.hip_op_calls['forward'] >= before['forward'] + 4 and L.hip_op_calls['backward'] >= before['backward'] + 4
     assert abs(float(loss) - float(z['arap/loss'])) < 5e-6 and abs(float(loss_ct) - float(z['arap/loss_ct'])) < 5e-6
     assert rel_err(spT.grad.cpu(), z['arap/g_spT']) <= 5e-5
+
+
+def test_accelerated_kinematic_equals_the_reference_chain():
+    """sk_gs_amd.accelerate_reference()'s replacement of SkeletonGaussianSplatting.kinematic (one bone-chain launch per direction,
+    handed back as SE3.InitFromVec) on a stand-in `self` with the reference run's inputs (sk_stage.npz, scenario sk_W): the bone
+    transforms, the cache row and -- through the rest of the reference's sequence -- every gradient of the reference's own run"""
+    import sys
+    import types
+    L, p3d = _mods()
+    from sk_gs_amd import reference_accel as ra
+    z = np.load(os.path.join(GOLDEN, 'sk_stage.npz'))
+    a, out, cot, grad = rs.load_scenario(z, 'sk_W', 'cuda')
+    saved = sys.modules.get('lietorch')
+    sys.modules['lietorch'] = L
+    try:
+        me = types.SimpleNamespace(training=True, test_time_interpolate=False, sk_feature=None, _R_dim=4, joint_parents=a['parents_table'].int(),
+                                   joint_root=a['root'].int().cuda(), sk_cache=torch.zeros(3, 20, 11, device='cuda'),
+                                   sk_deform_net=lambda x, t: (a['net_sk_r'], a['net_d_rot'], a['net_d_scale']))
+        tid = int(a['time_id'])
+        before = dict(ra.calls)
+        sk_T, d_rot, d_scale = ra.kinematic(me, a['joints'], a['t'].cuda(), a['global_tr'][tid].view(-1), tid, None)
+        assert ra.calls['kinematic_fused'] == before['kinematic_fused'] + 1 and isinstance(sk_T, L.SE3)
+        got = sk_T.vec()
+        sign = torch.sign((got[:, 3:] * out['_skT'].cuda()[:, 3:]).sum(-1, keepdim=True))
+        assert rel_err(got[:, :3], out['_skT'][:, :3]) <= 2e-6 and rel_err(got[:, 3:] * sign, out['_skT'][:, 3:]) <= 2e-6
+        want_cache = torch.cat([F.normalize(a['net_sk_r'].detach() + torch.tensor([0, 0, 0, 1.], device='cuda'), dim=-1), a['net_d_rot'].detach(),
+                                a['net_d_scale'].detach()], -1)
+        assert torch.equal(me.sk_cache[tid], want_cache) and float(me.sk_cache[0].abs().max()) == 0
+        # the rest of sk_stage on top of it (the reference's own lines, restated): the skinning and the activations
+        points = a['_xyz'].detach()
+        w, idx = rs._lbs_weights(p3d.knn_points, a, points, a['joints'], 5)
+        d_xyz = (sk_T[idx].act(points[:, None]) * w[..., None]).sum(dim=1) - points
+        res = rs._activate(a, d_xyz, (d_rot[idx] * w[..., None]).sum(dim=1), (d_scale[idx] * w[..., None]).sum(dim=1))
+        res.update(_skT=sk_T.vec(), _knn_w=w, _sk_rot=d_rot, _sk_scale=d_scale, _d_xyz=d_xyz, _d_rot=(d_rot[idx] * w[..., None]).sum(dim=1),
+                   _d_scale=(d_scale[idx] * w[..., None]).sum(dim=1))
+        loss = sum((res[k] * G.cuda()).sum() for k, G in cot.items() if k in res and res[k].requires_grad and k != '_skT')
+        loss = loss + (res['_skT'] * (cot['_skT'].cuda() * torch.cat([torch.ones_like(sign).expand(-1, 3), sign.expand(-1, 4)], 1))).sum()
+        loss.backward()
+        for k, want in grad.items():
+            assert a[k].grad is not None and rel_err(a[k].grad.cpu(), want) <= 3e-5, (k, rel_err(a[k].grad.cpu(), want))
+        # outside the fast path's conditions the reference's own method is called
+        ra._originals['kinematic'] = lambda *args: 'reference'
+        assert ra.kinematic(me, a['joints'], a['t'].cuda(), None, tid, torch.zeros(20, 3, device='cuda')) == 'reference'
+    finally:
+        ra._originals.pop('kinematic', None)
+        if saved is None:
+            sys.modules.pop('lietorch', None)
+        else:
+            sys.modules['lietorch'] = saved
+
+
+def test_accelerated_ssim_loss_equals_the_reference_loss():
+    """accelerate_reference()'s SSIM_Loss.forward: one HWC image pair as sk_gs.loss hands it over (sk_gs.py:1527-1529) through the
+    fused kernels, against the values and gradients the reference's own SSIM_Loss produced (tests/golden/ssim.npz)"""
+    import types
+    from sk_gs_amd import reference_accel as ra
+    g = np.load(os.path.join(GOLDEN, 'ssim.npz'))
+    me = types.SimpleNamespace(window_size=11, reduction='mean')
+    from sk_gs_amd.losses import ssim_loss as ssim_loss_torch      # the torch restatement of ssim.py:20-62 (pinned by the same fixture)
+    k = 0
+    while f'x{k}' in g.files:
+        x, y = torch.from_numpy(g[f'x{k}']).cuda(), torch.from_numpy(g[f'y{k}']).cuda()          # [1,H,W,3] as sk_gs.loss hands them over
+        xh = x.clone().requires_grad_()
+        before = ra.calls['ssim_fused']
+        loss = ra.ssim_loss_forward(me, xh, y)
+        assert ra.calls['ssim_fused'] == before + 1
+        assert abs(float(loss) - float(g[f'ssim{k}'])) <= 2e-6, (float(loss), float(g[f'ssim{k}']))
+        loss.backward()
+        xt = x.clone().requires_grad_()
+        ssim_loss_torch(xt[0].permute(2, 0, 1), y[0].permute(2, 0, 1)).backward()
+        assert rel_err(xh.grad, xt.grad) <= 2e-5
+        k += 1
+    assert k >= 1
+    ra._originals['ssim'] = lambda self, a, b: 'reference'
+    try:
+        assert ra.ssim_loss_forward(me, torch.rand(1, 8, 8, 3), torch.rand(1, 8, 8, 3)) == 'reference'      # CPU tensors
+        assert ra.ssim_loss_forward(types.SimpleNamespace(window_size=7, reduction='mean'), x, y) == 'reference'
+    finally:
+        ra._originals.pop('ssim', None)

@@ -169,6 +169,20 @@ try:                                                # wrong order is refused, no
     assert r.returncode != 0 and 'before importing my_ext' in r.stderr, r.stderr[-400:]
 finally:
     pass
+# the optional accelerators (sk_gs_amd.accelerate_reference): two methods patched on the reference's classes; on CPU tensors every call
+# is outside the fast path and reaches the reference's own method
+import torch
+from networks.losses import ssim as _ssim_mod
+from sk_gs_amd import reference_accel as _ra
+orig_ssim, orig_kin = _ssim_mod.SSIM_Loss.forward, networks.sk_gs.SkeletonGaussianSplatting.kinematic
+assert sorted(sk_gs_amd.accelerate_reference()) == ['networks.losses.ssim.SSIM_Loss.forward', 'networks.sk_gs.SkeletonGaussianSplatting.kinematic']
+assert _ssim_mod.SSIM_Loss.forward is _ra.ssim_loss_forward and networks.sk_gs.SkeletonGaussianSplatting.kinematic is _ra.kinematic
+g = torch.Generator().manual_seed(0)
+x, y = torch.rand(1, 40, 48, 3, generator=g), torch.rand(1, 40, 48, 3, generator=g)
+crit = _ssim_mod.SSIM_Loss()
+assert torch.equal(crit(x, y), orig_ssim(crit, x, y)) and _ra.calls['ssim_reference'] >= 1 and _ra.calls['ssim_fused'] == 0
+_ra.restore_reference()
+assert _ssim_mod.SSIM_Loss.forward is orig_ssim and networks.sk_gs.SkeletonGaussianSplatting.kinematic is orig_kin
 print('HOOK-OK')
 """
 
