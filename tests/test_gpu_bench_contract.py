@@ -54,7 +54,7 @@ PLAIN = ['--exchange', 'allreduce']
                                               (29580, 2, ['--autograd']), (29581, 4, PLAIN), (29582, 2, ['--sh-factors']),
                                               (29583, 2, ['--sh-factors', '--overlap-gather']), (29584, 2, PLAIN + ['--bone-tables']),
                                               (29587, 2, PLAIN + ['--graph-per-view']), (29588, 2, PLAIN + ['--pre-forward', 'off']),
-                                              (29589, 8, PLAIN), (29590, 8, ['--sh-factors'])])
+                                              (29589, 8, PLAIN)])
 def test_ranks_share_the_gpu_and_stay_identical(port, ranks, extra):
     """The driver's multi-GPU launch line with 2, 4 or 8 ranks (the driver's largest run: no rank-count assumption may surface on
     the first real 8-GPU lease) on this one GPU (gloo moves the gradients: RCCL refuses two ranks
