@@ -185,6 +185,9 @@ def build_parser():
     ap.add_argument('--sep-rot', action='store_true',
                     help="--stage sp: the deform network's local_rotation head feeds the rotation blend (sep_rot, the class default "
                          "sk_gs.py:357 and what exps/d_nerf_sc_gs.yaml runs with)")
+    ap.add_argument('--raw-time', action='store_true',
+                    help="--stage sp: DeformNetwork(is_blender=False) (sk_gs.py:220,255-261; no shipped YAML): no time network, time "
+                         "degree 10, and the stage's time noise (sk_gs.py:837-839) drawn on the device inside the captured step")
     ap.add_argument('--knn', type=int, default=5, help='--stage sp: num_knn (exps/default.yaml:20: 5; the SC-GS / SP-GS configs: 3)')
     ap.add_argument('--preset', choices=('sc_gs', 'sp_gs'), default=None,
                     help="--stage sp: sc_gs = exps/d_nerf_sc_gs.yaml's combination: LBS_method weighted_kernel, warp_method LBS_c, "

@@ -120,7 +120,9 @@ def run(args, base_alg_bytes, configs):
     M, K, F = args.superpoints, args.knn, 8
     frames = args.views
     model = SuperpointGaussians(P, M, K, sh_degree=3, num_frames=frames, seed=0, scale_mult=args.scale_mult,
-                                lbs_method=args.lbs_method, hyper_dim=F, warp_method=args.warp_method, sep_rot=args.sep_rot).to(dev)
+                                lbs_method=args.lbs_method, hyper_dim=F, warp_method=args.warp_method, sep_rot=args.sep_rot,
+                                is_blender=not args.raw_time, t_degree=10 if args.raw_time else 6).to(dev)
+    model.time_noise = 0.01 if args.raw_time else 0.0  # (time_interval 1/100 x smooth scale 1: the start of the annealing)
     if not args.keep_order:  # Gaussians along a Z-order curve (sk_gs_amd/densify.py::sort_spatially): what a training loop
         from sk_gs_amd.densify import sort_spatially  # does after every densification event
         sort_spatially(model)
@@ -291,7 +293,7 @@ def run(args, base_alg_bytes, configs):
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'{cfg["name"]} in stage sp: {P} Gaussians, {M} superpoints, K={K}, search over xyz + {F} hyper '
                                f'dimensions, LBS_method {args.lbs_method}, warp_method {args.warp_method}, sep_rot {bool(args.sep_rot)}, '
-                               f'sp_deform_net 8x256 on {M} rows, SH degree 3, {W}x{H}, '
+                               f'sp_deform_net 8x256 on {M} rows' + (' (is_blender=False: raw time encoding of degree 10, time noise 0.01)' if args.raw_time else '') + f', SH degree 3, {W}x{H}, '
                                f'{args.views} synthetic views, 1 view per rank per step',
                    'stage': 'sp', 'num_rendered_mean': round(R_mean), 'num_rendered_max': R_max,
                    'tile_list_mean': round(R_mean / T, 1), 'tile_list_max': longest,

@@ -735,6 +735,13 @@ int skgs_sp_skinning_backward(const skgs_deform_inputs* in, int32_t F, const flo
 #define SKGS_SP_NET_LBS_C 1 /* skgs_sp_net.flags: warp_method LBS_c (exps/d_nerf_sc_gs.yaml:32, sk_gs.py:803-804, 1121-1122): the
                              * superpoint's translation is re-centred on the superpoint, bone_T = [d_xyz + x + R(u)(-x) | u]; the
                              * backward then also returns d loss / d sp_points through `grads->points` [M,3] (written; may be NULL) */
+/* skgs_sp_net.flags: DeformNetwork(is_blender=False) (the class default, sk_gs.py:220; the HyperNeRF-style variant: no shipped
+ * YAML selects it): NO time network -- t_emb = freq(t, degree) itself (sk_gs.py:297-301 without :299), so the encoded input has
+ * 63 + 1 + 2 degree columns: W[0] [256, 64 + 2 degree], W[5] [256, 64 + 2 degree + 256]; time_w1 .. time_b2 are ignored (NULL).
+ * degree <= 15.  The caller adds the stage's time noise (sk_gs.py:837-839) to `time` before the call. */
+#define SKGS_SP_NET_RAW_TIME_FLAG 2
+#define SKGS_SP_NET_RAW_TIME SKGS_SP_NET_RAW_TIME_FLAG
+#define SKGS_SP_NET_RAW_TIME_DEGREE(degree) (SKGS_SP_NET_RAW_TIME_FLAG | ((degree) << 8))
 typedef struct skgs_sp_net {
   int32_t M, flags;
   const float* points;                                   /* [M,3] */

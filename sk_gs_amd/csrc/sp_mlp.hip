@@ -146,8 +146,9 @@ struct SideAdam {
 };
 
 // input width / weight row stride / column offset of the hidden part of layer l
-__host__ __device__ inline int layer_ld(int l) { return l == 0 ? IN0 : (l == SKIP + 1 ? IN0 + SPW : SPW); }
-__host__ __device__ inline int layer_hofs(int l) { return l == SKIP + 1 ? IN0 : 0; }
+// (in0: 93 with the time network; 63 + 1 + 2 deg with the raw time encoding of is_blender = False, sk_gs.py:255-261)
+__host__ __device__ inline int layer_ld(int l, int in0) { return l == 0 ? in0 : (l == SKIP + 1 ? in0 + SPW : SPW); }
+__host__ __device__ inline int layer_hofs(int l, int in0) { return l == SKIP + 1 ? in0 : 0; }
 
 // ---- the product of a row block with a weight matrix, streamed -----------------------------------------------------------
 // Found with tools/micro/mfma4x4_layer.hip (MI355X).  A CU pulls weights out of L2 at most at its L1's 64 B/clk (~1.7 us for a
@@ -216,6 +217,8 @@ struct NetPtrs {  // device copy of skgs_sp_net's pointers
   const float* head_b[4];
   int nout;                // 10, or 14 with the local-rotation head
   int lbs_c;               // warp_method LBS_c: bone_T's translation is d_xyz + x + R(u)(-x) (sk_gs.py:803-804)
+  int in0;                 // columns of the encoded input: 93 = 63 + 30 (time network), or 63 + tdim (raw time encoding)
+  int tdim;                // raw time encoding (is_blender = False: no time network, tw1 == NULL): 1 + 2 * degree columns
 };
 struct GradPtrs {
   float *tw1, *tb1, *tw2, *tb2;
@@ -272,13 +275,13 @@ __global__ void __launch_bounds__(256) sp_net_transpose_kernel(NetPtrs n, float*
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, rl = R0 - base + tx;  // rl: the row inside the layer
   int k = rl;
   bool valid = true;
-  if (l == 0) valid = rl < IN0;
+  if (l == 0) valid = rl < n.in0;
   if (l == SKIP + 1) {
-    if (rl < IN0P) valid = rl < IN0;
-    else k = IN0 + rl - IN0P;
+    if (rl < IN0P) valid = rl < n.in0;
+    else k = n.in0 + rl - IN0P;
   }
   const float* W = n.W[l];
-  const int ld   = layer_ld(l);
+  const int ld   = layer_ld(l, n.in0);
 #pragma unroll
   for (int yy = ty; yy < 32; yy += 8) tile[yy][tx] = valid ? W[(size_t) (32 * nb + yy) * ld + k] : 0.f;
   __syncthreads();
@@ -297,7 +300,7 @@ __global__ void __launch_bounds__(NT) sp_net_forward_kernel(int M, NetPtrs n, fl
   __shared__ __attribute__((aligned(16))) float s_x0t[RB][8][XT];     // encoded input, transposed: [row][c & 7][c >> 3]
   __shared__ __attribute__((aligned(16))) float s_ht[2][RB][8][HT];   // activations, two buffers, transposed likewise
   __shared__ __attribute__((aligned(16))) float s_part[NWAVE][RB][SPW];
-  __shared__ float s_temb[16], s_thid[THID], s_tout[32];
+  __shared__ float s_temb[32], s_thid[THID], s_tout[32];
   __shared__ float s_raw[RB][16];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i_ = lane & 3;
   const int r0 = blockIdx.x * RB, Mp = pad_rows(M);
@@ -311,7 +314,8 @@ __global__ void __launch_bounds__(NT) sp_net_forward_kernel(int M, NetPtrs n, fl
 #pragma unroll
   for (int t = 0; t < RING_F; ++t) ring[t] = ldg4(rows(t));
   // ---- time network (every workgroup: 13 -> 256 -> 30 is ~11 k multiply-adds)
-  if (tid < TDIM) {
+  const bool timenet = n.tw1 != nullptr;  // (uniform)
+  if (tid < (timenet ? TDIM : n.tdim)) {
     const float t = n.time[0];
     float v = t;
     if (tid >= 1) {
@@ -319,8 +323,10 @@ __global__ void __launch_bounds__(NT) sp_net_forward_kernel(int M, NetPtrs n, fl
       v = sinf(scalbnf(t, col / 2) + (float) (col % 2) * (3.141592653589793f / 2));
     }
     s_temb[tid] = v;
+    if (!timenet) s_tout[tid] = v;  // is_blender = False: t_emb IS freq(t) (sk_gs.py:297-299 without the timenet line)
   }
   __syncthreads();
+  if (timenet) {
   if (tid < THID) {
     float h = n.tb1[tid];
 #pragma unroll
@@ -338,7 +344,8 @@ __global__ void __launch_bounds__(NT) sp_net_forward_kernel(int M, NetPtrs n, fl
     if (part == 0) s_tout[o] = v + n.tb2[o];
   }
   __syncthreads();
-  if (blockIdx.x == 0) {
+  }
+  if (blockIdx.x == 0 && timenet) {
     if (tid < 16) sv.temb[tid] = tid < TDIM ? s_temb[tid] : 0.f;
     if (tid < THID) sv.thid[tid] = s_thid[tid];
     if (tid < 32) sv.tout[tid] = tid < TOUT ? s_tout[tid] : 0.f;
@@ -353,7 +360,7 @@ __global__ void __launch_bounds__(NT) sp_net_forward_kernel(int M, NetPtrs n, fl
     } else if (c < PDIM) {
       const int col = c / 3 - 1, d = c % 3;
       v = sinf(scalbnf(n.points[3 * gr + d], col / 2) + (float) (col % 2) * (3.141592653589793f / 2));
-    } else if (c < IN0) {
+    } else if (c < n.in0) {
       v = s_tout[c - PDIM];
     }
     s_x0t[row][c & 7][c >> 3]              = v;
@@ -477,10 +484,10 @@ __device__ __forceinline__ void side_adam_walk(const SideAdam& a, int wg, int n_
 
 struct BwdRows {  // item t of wave w: layer 7 - t / 32, row (output feature) 8 (t % 32) + w of that layer's weight matrix,
   const float* W[SPD];  // the 256 columns of its hidden part
-  int wave, lane;
+  int wave, lane, in0;
   __device__ __forceinline__ const float* operator()(int t) const {
     const int l = SPD - 1 - t / (SPW / 8), o = 8 * (t % (SPW / 8)) + wave;
-    return W[l] + (uint32_t) (o * layer_ld(l) + layer_hofs(l) + 4 * lane);  // (uniform base + 32-bit lane offset: one VGPR per address)
+    return W[l] + (uint32_t) (o * layer_ld(l, in0) + layer_hofs(l, in0) + 4 * lane);  // (uniform base + 32-bit lane offset: one VGPR per address)
   }
 };
 
@@ -499,7 +506,7 @@ __global__ void __launch_bounds__(NT) sp_net_backward_rows_kernel(int M, int nbl
   BwdRows rows;
 #pragma unroll
   for (int l = 0; l < SPD; ++l) rows.W[l] = n.W[l];
-  rows.wave = wave, rows.lane = lane;
+  rows.wave = wave, rows.lane = lane, rows.in0 = n.in0;
   float4 ring[RING_B];
 #pragma unroll
   for (int t = 0; t < RING_B; ++t) ring[t] = ldg4(rows(t));
@@ -725,7 +732,7 @@ __global__ void __launch_bounds__(NTB) sp_net_backward_weights_kernel(int M, int
   const int Mp  = pad_rows(M);
   const int job = blockIdx.x;
   if (job == N_JOBS) {  // one more workgroup: the time network's backward (needs nothing from the other jobs)
-    timenet_backward(M, n, g, sv, wk, &s_part[0][0]);
+    if (n.tw1) timenet_backward(M, n, g, sv, wk, &s_part[0][0]);  // (raw time encoding: the time is data, nothing to do)
     return;
   }
   // ---- decode
@@ -739,15 +746,15 @@ __global__ void __launch_bounds__(NTB) sp_net_backward_weights_kernel(int M, int
     layer = li + 1, o0 = 64 * (t / 4), k0 = 64 * (t % 4), kvalid = SPW;
     X = sv.Y + (size_t) (layer - 1) * Mp * SPW, xld = SPW;
     A = wk.GZ + (size_t) layer * Mp * SPW;
-    G = g.W[layer], gld = layer_ld(layer), gofs = layer_hofs(layer);
+    G = g.W[layer], gld = layer_ld(layer, n.in0), gofs = layer_hofs(layer, n.in0);
     bias = (t % 4) == 0;
   } else if (job < JOBS_HH + 2 * JOBS_X0) {
     const int t = (job - JOBS_HH) % JOBS_X0;
     layer = job < JOBS_HH + JOBS_X0 ? 0 : SKIP + 1;
-    o0 = 64 * (t / 2), k0 = 64 * (t % 2), kvalid = IN0;
+    o0 = 64 * (t / 2), k0 = 64 * (t % 2), kvalid = n.in0;
     X = sv.x0, xld = IN0P;
     A = wk.GZ + (size_t) layer * Mp * SPW;
-    G = g.W[layer], gld = layer_ld(layer), gofs = 0;
+    G = g.W[layer], gld = layer_ld(layer, n.in0), gofs = 0;
     bias = layer == 0 && (t % 2) == 0;
   } else {
     heads = true, layer = SPD, o0 = 0, k0 = 64 * (job - JOBS_HH - 2 * JOBS_X0), kvalid = SPW;
@@ -913,11 +920,15 @@ NetPtrs net_ptrs(const skgs_sp_net* d) {
   n.head_w[3] = d->local_w, n.head_b[3] = d->local_b;
   n.nout  = (d->local_w && d->local_b) ? NOUT_MAX : NOUT;
   n.lbs_c = (d->flags & SKGS_SP_NET_LBS_C) ? 1 : 0;
+  n.tdim  = (d->flags & SKGS_SP_NET_RAW_TIME) ? 1 + 2 * ((d->flags >> 8) & 0xff) : 0;
+  n.in0   = n.tdim ? PDIM + n.tdim : IN0;
+  if (n.tdim) n.tw1 = n.tb1 = n.tw2 = n.tb2 = nullptr;
   return n;
 }
 bool net_complete(const skgs_sp_net* d) {
-  bool ok = d->time_w1 && d->time_b1 && d->time_w2 && d->time_b2 && d->warp_w && d->warp_b && d->scaling_w && d->scaling_b &&
-            d->rotation_w && d->rotation_b;
+  bool ok = d->warp_w && d->warp_b && d->scaling_w && d->scaling_b && d->rotation_w && d->rotation_b;
+  if (d->flags & SKGS_SP_NET_RAW_TIME) ok = ok && ((d->flags >> 8) & 0xff) <= 15;  // 63 + 1 + 2 * 15 = 94 <= 96 padded columns
+  else ok = ok && d->time_w1 && d->time_b1 && d->time_w2 && d->time_b2;
   for (int l = 0; l < SPD; ++l) ok = ok && d->W[l] && d->b[l];
   return ok;
 }

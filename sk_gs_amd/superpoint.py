@@ -43,17 +43,23 @@ class SpDeformNet(nn.Module):
 
     ``x_emb = freq(x, 10)`` [.,63]; ``t_emb = timenet(freq(t, 6))`` [30] with ``timenet = Linear(13,256) ReLU Linear(256,30)``
     (:250-253); ``h = [x_emb | t_emb]``; D layers ``h = relu(linear[i](h))``, after layer ``D // 2`` the input is put IN FRONT:
-    ``h = [x_emb | t_emb | h]`` (:303-306); heads ``gaussian_warp`` (3), ``gaussian_scaling`` (3), ``gaussian_rotation`` (4)."""
+    ``h = [x_emb | t_emb | h]`` (:303-306); heads ``gaussian_warp`` (3), ``gaussian_scaling`` (3), ``gaussian_rotation`` (4).
+
+    ``is_blender=False`` (the reference class's own default, :220; every shipped YAML sets true): no time network --
+    ``t_emb = freq(t, t_degree)`` itself, ``1 + 2 t_degree`` columns (:255-261, :297-301 without :299); the stage then adds noise to
+    the time before the call (``SuperpointGaussians.time_noise``, sk_gs.py:837-839)."""
 
     def __init__(self, D: int = 8, W: int = 256, p_degree: int = 10, t_degree: int = 6, time_hidden: int = 256,
-                 time_out: int = 30, sep_rot: bool = False):
+                 time_out: int = 30, sep_rot: bool = False, is_blender: bool = True):
         super().__init__()
         self.D, self.W, self.p_degree, self.t_degree, self.sep_rot = D, W, p_degree, t_degree, bool(sep_rot)
+        self.is_blender = bool(is_blender)
         self.skips = [D // 2]
         self.p_dim, self.t_dim = 3 * (1 + 2 * p_degree), 1 + 2 * t_degree
         self.time_hidden, self.time_out = time_hidden, time_out
-        self.in_dim = self.p_dim + time_out
-        self.timenet = nn.Sequential(nn.Linear(self.t_dim, time_hidden), nn.ReLU(inplace=True), nn.Linear(time_hidden, time_out))
+        self.in_dim = self.p_dim + (time_out if self.is_blender else self.t_dim)
+        if self.is_blender:
+            self.timenet = nn.Sequential(nn.Linear(self.t_dim, time_hidden), nn.ReLU(inplace=True), nn.Linear(time_hidden, time_out))
         self.linear = nn.ModuleList([nn.Linear(self.in_dim, W)] + [
             nn.Linear(W, W) if i not in self.skips else nn.Linear(W + self.in_dim, W) for i in range(D - 1)])
         self.gaussian_warp, self.gaussian_scaling, self.gaussian_rotation = nn.Linear(W, 3), nn.Linear(W, 3), nn.Linear(W, 4)
@@ -79,7 +85,8 @@ class SpDeformNet(nn.Module):
     # ------------------------------------------------------------------------------------------------ plain torch
     def reference_forward(self, x: Tensor, t: Tensor) -> Dict[str, Tensor]:
         t_emb = freq_encode_torch(t.view(-1, 1), self.t_degree).expand(x.shape[0], self.t_dim)
-        t_emb = self.timenet(t_emb)
+        if self.is_blender:
+            t_emb = self.timenet(t_emb)
         x_emb = freq_encode_torch(x, self.p_degree)
         h = torch.cat([x_emb, t_emb], dim=-1)
         for i, layer in enumerate(self.linear):
@@ -95,6 +102,8 @@ class SpDeformNet(nn.Module):
     def kernel_supported(self) -> bool:
         """csrc/sp_mlp.hip is written for the shipped configuration: 8 x 256, skip after layer 4, degrees 10 / 6, 13 -> 256 ->
         30 time network (exps/default.yaml:4-11,31)"""
+        if not self.is_blender:  # raw time encoding: any degree whose columns fit the 96-column padded input
+            return self.D == 8 and self.W == 256 and self.p_degree == 10 and 0 <= self.t_degree <= 15
         return (self.D == 8 and self.W == 256 and self.p_degree == 10 and self.t_degree == 6 and self.time_hidden == 256
                 and self.time_out == 30)
 
@@ -141,13 +150,14 @@ def _net_desc(net: SpDeformNet, M: int, points, time, grads: bool = False) -> _S
         assert t is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
         return t.data_ptr()
     d = _SpNetDesc()
-    d.M, d.flags = M, 0
+    d.M, d.flags = M, 0 if net.is_blender else (2 | (net.t_degree << 8))  # SKGS_SP_NET_RAW_TIME_DEGREE(t_degree)
     if net.sep_rot:
         d.local_w, d.local_b = ptr(net.local_rotation.weight), ptr(net.local_rotation.bias)
     d.points = None if points is None else points.data_ptr()
     d.time = None if time is None else time.data_ptr()
-    d.time_w1, d.time_b1 = ptr(net.timenet[0].weight), ptr(net.timenet[0].bias)
-    d.time_w2, d.time_b2 = ptr(net.timenet[2].weight), ptr(net.timenet[2].bias)
+    if net.is_blender:
+        d.time_w1, d.time_b1 = ptr(net.timenet[0].weight), ptr(net.timenet[0].bias)
+        d.time_w2, d.time_b2 = ptr(net.timenet[2].weight), ptr(net.timenet[2].bias)
     for i, layer in enumerate(net.linear):
         d.W[i], d.b[i] = ptr(layer.weight), ptr(layer.bias)
     d.warp_w, d.warp_b = ptr(net.gaussian_warp.weight), ptr(net.gaussian_warp.bias)
@@ -194,7 +204,7 @@ class SpNetRunner:
         """fills ``bone_T`` / ``d_rot`` / ``d_scale`` (and ``raw``); ``time``: 1-element device tensor.  ``prepare``: the search's
         per-step table / list preparation rides on this call's first launch (``skgs_sp_prepare``)"""
         d = _net_desc(self.net, self.M, points, time)
-        d.flags = 1 if self.lbs_c else 0  # SKGS_SP_NET_LBS_C
+        d.flags |= 1 if self.lbs_c else 0  # SKGS_SP_NET_LBS_C
         self._points = points
         _C._check(self.lib.skgs_sp_net_forward(
             C.byref(d), C.c_void_p(self.raw.data_ptr()), C.c_void_p(self.bone_T.data_ptr()), C.c_void_p(self.d_rot.data_ptr()),
@@ -212,7 +222,7 @@ class SpNetRunner:
         dg = _net_desc(self.net, self.M, None, None, grads=True)
         d = _net_desc(self.net, self.M, self._points if self.lbs_c else None, None)
         if self.lbs_c:  # the re-centring's backward needs the superpoint positions and returns their gradient [M,3] (written)
-            d.flags = 1
+            d.flags |= 1
             dg.points = None if g_points is None else g_points.data_ptr()
         p = lambda t: C.c_void_p(None if t is None else t.data_ptr())  # noqa: E731
         _C._check(self.lib.skgs_sp_net_backward(
@@ -266,14 +276,18 @@ class SuperpointGaussians(nn.Module):
 
     def __init__(self, P: int, M: int = 512, K: int = 5, sh_degree: int = 3, num_frames: int = 8, seed: int = 0,
                  scale_mult: float = 1.0, lbs_method: str = 'weighted_kernel', hyper_dim: int = 8, lbs_temperature: float = 1.0,
-                 warp_method: str = 'LBS', sep_rot: bool = False):
+                 warp_method: str = 'LBS', sep_rot: bool = False, is_blender: bool = True, t_degree: int = 6):
         super().__init__()
         # warp_method (sk_gs.py:776-828): 'LBS' (exps/default.yaml:36), 'LBS_c' (d_nerf_sc_gs.yaml:32: the superpoint's transform
         # re-centred on the superpoint, :803-804), 'largest' (d_nerf_sp_gs.yaml:32: each Gaussian follows the ONE superpoint with the
         # largest weight, :811-816,849-850; rotation / scale offsets stay blended).  sep_rot: the network's `g_rotation` head is what the
         # rotation blend uses (:848,818-821)
+        # is_blender=False (sk_gs.py:220,255-261): the network without its time branch, and NOISE on the time of every call of the stage
+        # (sk_gs.py:837-839: t + randn * time_interval * get_smooth_scale()); the caller keeps ``time_noise`` = that product current
+        # (``smooth_scale`` below restates the annealing)
         assert warp_method in ('LBS', 'LBS_c', 'largest')
         self.warp_method, self.sep_rot = warp_method, bool(sep_rot)
+        self.time_noise = 0.0
         from sk_gs_amd import scene
         g = scene.make_gaussians(P, seed=seed, sh_degree=sh_degree, scale_mult=scale_mult)
         self.P, self.M, self.K, self.hyper_dim = P, M, min(K, M), hyper_dim
@@ -308,7 +322,7 @@ class SuperpointGaussians(nn.Module):
         if lbs_method == 'weighted_kernel':
             self._sp_weight = nn.Parameter(torch.zeros(M))
         torch.manual_seed(6000 + seed)
-        self.sp_deform_net = SpDeformNet(sep_rot=self.sep_rot)
+        self.sp_deform_net = SpDeformNet(sep_rot=self.sep_rot, is_blender=is_blender, t_degree=t_degree)
         with torch.no_grad():  # a trained network's output sizes instead of the 1e-5 / 1e-8 heads of reset_parameters
             if self.sep_rot:
                 self.sp_deform_net.local_rotation.weight.normal_(0, 2e-3, generator=gen)
@@ -350,7 +364,7 @@ class SuperpointGaussians(nn.Module):
         """``sp_deform_net(sp_points.detach(), t)`` + the normalisations of sk_gs.py:847-848 + the re-centring of `LBS_c` (:803-804):
         (spT [M,7] = (t, unit q), the rotation offsets the skinning blends [M,4] -- d_rot, or g_rot with ``sep_rot`` --, d_scale [M,3])"""
         from sk_gs_amd.skeleton import quat_act
-        t = self.frame_times[time_id]
+        t = self.noisy_time(self.frame_times[time_id])
         net = self.sp_deform_net
         out = net.reference_forward(self.sp_points.detach(), t) if (reference or not self.sp_points.is_cuda) \
             else net(self.sp_points.detach(), t)
@@ -360,6 +374,26 @@ class SuperpointGaussians(nn.Module):
         if self.warp_method == 'LBS_c':  # (the superpoints are NOT detached here: they receive a gradient, as in the reference)
             sp_t = sp_t + self.sp_points + quat_act(d_rot, -self.sp_points)
         return torch.cat([sp_t, d_rot], dim=-1), blend_rot, out['d_scaling']
+
+    def noisy_time(self, t: Tensor) -> Tensor:
+        """sk_gs.py:837-839 (and :742-744): a network without the time branch sees ``t + randn * time_interval * smooth_scale``"""
+        if self.sp_deform_net.is_blender or self.time_noise == 0.0:
+            return t
+        return t + torch.randn_like(t) * self.time_noise
+
+    @staticmethod
+    def smooth_scale(step: int, f_s: float, annealing_steps: int, lr_final: float = 1e-15, lr_delay_steps: float = 0.01,
+                     lr_delay_mult: float = 1.0) -> float:
+        """``get_smooth_scale`` (sk_gs.py:723-740) for ``step`` counted from the stage's start: a LINEAR ramp from ``f_s`` to
+        ``lr_final`` over ``annealing_steps`` (the reference's variable is called log_lerp; it interpolates the values themselves),
+        times the sine delay; 0 when disabled.  ``time_noise = time_interval * smooth_scale(...)``"""
+        if step < 0 or (f_s == 0.0 and lr_final == 0.0):
+            return 0.0
+        delay = 1.0
+        if lr_delay_steps > 0:
+            delay = lr_delay_mult + (1 - lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / lr_delay_steps, 0.0), 1.0))
+        u = min(max(step / annealing_steps, 0.0), 1.0)
+        return delay * (f_s * (1 - u) + lr_final * u)
 
     def lbs_weights(self):
         """``calc_LBS_weight(points, sp_points, hyper_feature, sp_hyper_feature)`` (sk_gs.py:844): weights, indices"""
@@ -430,6 +464,7 @@ class FusedSuperpointStep(FusedViewStep):
         # warp_method: LBS_c is the network launches' business (bone_T re-centred in their epilogue), `largest` the skinning's (the
         # position follows the bone of the largest weight: skgs_deform_inputs.largest)
         self.largest = model.warp_method == 'largest'
+        self.time_noise = torch.full((1,), float(model.time_noise), dtype=torch.float32, device=dev)
         self.net = model.sp_deform_net.runner(M, lbs_c=model.warp_method == 'LBS_c')
         self.nn_dist = torch.empty((P, K), dtype=torch.float32, device=dev)
         lib.skgs_sp_lbs_weights_workspace_bytes.restype = C.c_size_t
@@ -488,9 +523,19 @@ class FusedSuperpointStep(FusedViewStep):
 
     def _time(self, time_id) -> Tensor:
         if time_id is not None:
-            return self.model.frame_times[time_id]
-        from sk_gs_amd import view_slot as vsl
-        return self.view_table.slot[vsl.W_TIME:vsl.W_TIME + 1]
+            t = self.model.frame_times[time_id]
+        else:
+            from sk_gs_amd import view_slot as vsl
+            t = self.view_table.slot[vsl.W_TIME:vsl.W_TIME + 1]
+        if not self.model.sp_deform_net.is_blender:
+            # the stage's time noise (sk_gs.py:837-839), drawn on the device so that a captured step draws a fresh one per replay
+            # (torch's generator is graph-safe); its scale is a device scalar the loop updates with set_time_noise()
+            t = (t.reshape(1) + torch.randn(1, device=t.device) * self.time_noise).contiguous()
+        return t
+
+    def set_time_noise(self, scale: float):
+        """``time_interval * get_smooth_scale()`` of the current iteration (is_blender=False only; a 4-byte fill, legal between replays)"""
+        self.time_noise.fill_(float(scale))
 
     @torch.no_grad()
     def forward(self, rs=None, time_id=None):

@@ -316,12 +316,12 @@ def test_operator_path_at_superpoint_size_runs_the_sp_search_and_matches_the_ora
 
 
 # ---------------------------------------------------------------------------------------------------- the fused step
-def _sp_model(P, M, K, W, H, frames, method, seed=0, warp_method='LBS', sep_rot=False):
+def _sp_model(P, M, K, W, H, frames, method, seed=0, warp_method='LBS', sep_rot=False, is_blender=True, t_degree=6):
     from sk_gs_amd import scene
     from sk_gs_amd.superpoint import SuperpointGaussians
     dev = torch.device('cuda')
     model = SuperpointGaussians(P, M, K, num_frames=frames, seed=seed, scale_mult=3.0, lbs_method=method, warp_method=warp_method,
-                                sep_rot=sep_rot).to(dev)
+                                sep_rot=sep_rot, is_blender=is_blender, t_degree=t_degree).to(dev)
     with torch.no_grad():  # deformations large enough to matter in the image
         model.sp_deform_net.gaussian_warp.weight.mul_(20.0)
         model.sp_deform_net.gaussian_rotation.weight.mul_(20.0)
@@ -761,3 +761,157 @@ def test_operator_path_variants_equal_the_reference_sequence(method, warp_method
         assert rel_err(got[n], p.grad) <= tol, (n, rel_err(got[n], p.grad))
         checked += 1
     assert checked >= 8 + (1 if warp_method == 'LBS_c' else 0)
+
+
+def _relu_masks_agree(net, run, x, t):
+    """True when the kernel's saved activations and the torch body took the same side of every ReLU.  A pre-activation within rounding
+    of 0 may land on either side in two fp32 evaluations; ONE such flip moves a weight gradient by a row's whole contribution (~1e-2
+    of its largest element), which says nothing about either evaluation"""
+    from sk_gs_amd.deform_net import freq_encode_torch
+    M = x.shape[0]
+    Mp = (M + 15) // 16 * 16
+    saved = run.saved.view(torch.float32)
+    with torch.no_grad():
+        t_emb = freq_encode_torch(t.view(-1, 1), net.t_degree).expand(M, net.t_dim)
+        if net.is_blender:
+            t_emb = net.timenet(t_emb)
+        x_emb = freq_encode_torch(x, net.p_degree)
+        h = torch.cat([x_emb, t_emb], -1)
+        for i, layer in enumerate(net.linear):
+            h = F.relu(layer(h))
+            Y = saved[Mp * 96 + i * Mp * 256: Mp * 96 + (i + 1) * Mp * 256].view(Mp, 256)[:M]
+            if bool(((Y > 0) != (h > 0)).any()):
+                return False
+            if i in net.skips:
+                h = torch.cat([x_emb, t_emb, h], -1)
+    return True
+
+
+@pytest.mark.parametrize('M,t_degree,sep_rot,lbs_c', [(512, 10, False, False), (512, 6, True, True), (37, 10, True, False), (100, 15, False, True),
+                                                      (3, 0, False, False)])
+def test_sp_net_without_the_time_branch(M, t_degree, sep_rot, lbs_c):
+    """VERDICT r4 #3, last variant: ``DeformNetwork(is_blender=False)`` (sk_gs.py:220,255-261: no time network, ``t_emb = freq(t)``,
+    84 input columns at the degree 10 its comment names) through the SAME kernels (``SKGS_SP_NET_RAW_TIME_DEGREE``): raw outputs, the
+    stage's epilogue and every parameter gradient against torch autograd of the restatement (pinned to the reference's class by
+    tests/golden/sp_deformnet.npz ``raw32``).  Gradients are compared on a draw in which both evaluations took the same side of every
+    ReLU (``_relu_masks_agree``; at most a few seeds are needed)"""
+    from sk_gs_amd.skeleton import quat_act
+    from sk_gs_amd.superpoint import SpDeformNet
+    bias = torch.tensor([0, 0, 0, 1.], device='cuda')
+    compared = False
+    for seed in range(4):
+        torch.manual_seed(1000 * seed + M + t_degree)
+        net = SpDeformNet(sep_rot=sep_rot, is_blender=False, t_degree=t_degree)
+        assert net.in_dim == 64 + 2 * t_degree and tuple(net.linear[5].weight.shape) == (256, 256 + net.in_dim) and not hasattr(net, 'timenet')
+        assert net.kernel_supported()
+        g = torch.Generator().manual_seed(1000 * seed + M + 1)
+        with torch.no_grad():
+            heads = [net.gaussian_warp, net.gaussian_scaling, net.gaussian_rotation] + ([net.local_rotation] if sep_rot else [])
+            for head in heads:
+                head.weight.normal_(0, 0.05, generator=g)
+                head.bias.normal_(0, 0.1, generator=g)
+            for layer in net.linear:
+                layer.bias.normal_(0, 0.05, generator=g)
+        net = net.cuda()
+        x = (torch.rand(M, 3, generator=g) * 2 - 1).cuda().requires_grad_()
+        t = torch.tensor([0.4375], device='cuda')
+        run = net.runner(M, lbs_c=lbs_c)
+        run.forward(x.detach(), t)
+
+        ref = net.reference_forward(x.detach(), t)
+        u = F.normalize(ref['d_rotation'] + bias, dim=-1)
+        blend = F.normalize(ref['g_rotation'] + bias, dim=-1) if sep_rot else u
+        bone_T = torch.cat([ref['d_xyz'] + x + quat_act(u, -x) if lbs_c else ref['d_xyz'], u], 1)
+        d_scale = ref['d_scaling']
+        raw = torch.cat([ref['d_xyz'], ref['d_rotation'], ref['d_scaling']] + ([ref['g_rotation']] if sep_rot else []), 1)
+        assert rel_err(run.raw, raw) <= 2e-5, rel_err(run.raw, raw)
+        assert rel_err(run.bone_T, bone_T) <= 2e-5 and rel_err(run.d_rot, blend) <= 2e-5 and rel_err(run.d_scale, d_scale) <= 2e-5
+        if not _relu_masks_agree(net, run, x.detach(), t):
+            continue
+        g_T, g_r, g_s = torch.randn(M, 7, generator=g).cuda(), torch.randn(M, 4, generator=g).cuda(), torch.randn(M, 3, generator=g).cuda()
+        loss = (bone_T * g_T).sum() + (blend * g_r).sum() + (d_scale * g_s).sum()
+        params = list(net.parameters())
+        want = torch.autograd.grad(loss, params + ([x] if lbs_c else []), retain_graph=True)
+        for p in params:
+            p.grad = torch.full_like(p, float('nan'))
+        g_x = torch.full((M, 3), float('nan'), device='cuda')
+        for _ in range(2):
+            run.backward(g_T, g_r, g_s, g_points=g_x if lbs_c else None)
+        torch.cuda.synchronize()
+        names = [n for n, _ in net.named_parameters()]
+        for n, p, w in zip(names, params, want):
+            assert torch.isfinite(p.grad).all(), n
+            assert rel_err(p.grad, w) <= 5e-5, (n, rel_err(p.grad, w))
+        if lbs_c:
+            assert rel_err(g_x, want[-1]) <= 5e-5
+        # the autograd operator
+        out = net(x.detach(), t)
+        keys = ('d_xyz', 'd_rotation', 'd_scaling') + (('g_rotation',) if sep_rot else ())
+        gs = [torch.randn(M, out[k].shape[1], generator=g).cuda() for k in keys]
+        got = torch.autograd.grad([out[k] for k in keys], params, gs)
+        want = torch.autograd.grad([ref[k] for k in keys], params, gs)
+        for n, a, b in zip(names, got, want):
+            assert rel_err(a, b) <= 5e-5, (n, rel_err(a, b))
+        compared = True
+        break
+    assert compared, 'four draws in a row with a ReLU flip between the two fp32 evaluations'
+
+
+def test_fused_superpoint_step_without_the_time_branch_and_its_time_noise():
+    """is_blender=False end to end: with the noise off the fused step equals the operator path (image, every gradient); with it on
+    (sk_gs.py:837-839: t + randn * time_interval * get_smooth_scale()) a captured step draws a FRESH time per replay and the spread of
+    the network's outputs follows the scale; ``smooth_scale`` restates sk_gs.py:723-740"""
+    from sk_gs_amd import _C
+    from sk_gs_amd.losses import image_loss
+    from sk_gs_amd.superpoint import FusedSuperpointStep, SuperpointGaussians
+    from helpers import assert_close_robust
+    P, M, K, W, H, frames, tid = 6000, 512, 5, 160, 120, 3, 1
+    model, rs, target = _sp_model(P, M, K, W, H, frames, 'weighted_kernel', warp_method='LBS_c', sep_rot=True, is_blender=False, t_degree=10)
+    _C.config.sync_num_rendered = True
+    out = model.render(rs, time_id=tid)
+    image_loss(out['images'], target).backward()
+    ref = {n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()}
+    R = out['buffer'].R
+    for p in model.parameters():
+        p.grad = None
+    step = FusedSuperpointStep(model, W, H, capacity=int(R * 1.2) + 1024)
+    step.forward_backward(rs, tid, target)
+    assert step.status()['overflow'] == 0
+    # (the network's kernels against its torch body differ by ~1e-6 in the superpoint transforms; the high time frequencies make that
+    # visible in a couple of pixels: 2 of 57 600 at 7.5e-5 -- the north-star tolerance applies)
+    assert_close_robust(step.image, out['images'].detach(), 1e-4, 1e-4, name='image sp raw time')
+    for n, p in model.named_parameters():
+        if n in ('hyper_feature', 'sp_hyper_feature') and float(ref[n].abs().max()) == 0:
+            continue
+        assert_close_robust(p.grad, ref[n], 3e-4, 1e-3, name=f'{n} sp raw time')
+    # ---- the noise: a captured forward draws a new time per replay
+    quiet = step.net.bone_T.clone()
+    step.set_time_noise(0.05)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step.forward(rs, tid)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            step.forward(rs, tid)
+    draws = []
+    for _ in range(6):
+        graph.replay()
+        torch.cuda.synchronize()
+        draws.append(step.net.bone_T.clone())
+    d = torch.stack(draws)
+    assert float((d[1:] - d[:-1]).abs().amax(dim=(1, 2)).min()) > 0, 'every replay must see another time'
+    assert bool(torch.isfinite(d).all())
+    step.set_time_noise(0.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(step.net.bone_T, quiet)
+    # ---- the annealing (sk_gs.py:723-740)
+    f = SuperpointGaussians.smooth_scale
+    assert f(-1, 0.1, 1000) == 0.0 and f(5, 0.0, 1000, lr_final=0.0) == 0.0
+    assert abs(f(0, 0.1, 1000) - 0.1) < 1e-12 and abs(f(500, 0.1, 1000) - (0.05 + 0.5e-15)) < 1e-12 and abs(f(2000, 0.1, 1000) - 1e-15) < 1e-20
+    # the operator path draws its noise with torch.randn_like
+    model.time_noise = 0.05
+    a, b = model.superpoint_transforms(tid)[0], model.superpoint_transforms(tid)[0]
+    assert float((a - b).detach().abs().max()) > 0

@@ -7,6 +7,7 @@ import os
 import math
 
 import numpy as np
+import pytest
 import torch
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
@@ -303,28 +304,32 @@ def test_lbs_weightings_match_the_reference_calc_LBS_weight(oracle32, oracle64):
     assert n_cases == 24
 
 
-def test_sp_deform_net_restatement_matches_reference_DeformNetwork():
+@pytest.mark.parametrize('tag', ['w32', 'raw32'])
+def test_sp_deform_net_restatement_matches_reference_DeformNetwork(tag):
     """``SpDeformNet.reference_forward`` (the torch restatement the sp-stage kernels are checked against at full size) against
-    the reference's own ``DeformNetwork(is_blender=True)`` (sk_gs.py:209-315) on the fixture of make_golden_sp.py: outputs,
+    the reference's own ``DeformNetwork`` (sk_gs.py:209-315) on the fixtures of make_golden_sp.py -- ``w32``: is_blender=True as
+    the shipped configs; ``raw32``: is_blender=False (no time network), time degree 10, with the local-rotation head --: outputs,
     the hidden state, every parameter gradient, and the quaternion normalisation of sk_gs.py:847.  The state_dict loads by
     the reference's parameter names."""
     from sk_gs_amd.superpoint import SpDeformNet
     g = load('sp_deformnet.npz')
-    net = SpDeformNet(D=8, W=32, time_out=int(g['w32.time_out']))
-    assert net.skips == list(g['w32.skips'])
-    sd = {k[len('w32.param.'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith('w32.param.')}
+    raw = tag == 'raw32'
+    net = SpDeformNet(D=8, W=32, time_out=30, is_blender=False, t_degree=10, sep_rot=True) if raw else \
+        SpDeformNet(D=8, W=32, time_out=int(g['w32.time_out']))
+    assert net.skips == list(g[f'{tag}.skips']) and net.in_dim == int(g[f'{tag}.in_dim']) if raw else net.skips == list(g['w32.skips'])
+    sd = {k[len(f'{tag}.param.'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f'{tag}.param.')}
     assert set(sd) == set(dict(net.named_parameters()))  # same names as the reference's state_dict
     net.load_state_dict(sd)
-    x, t = torch.from_numpy(g['w32.x']), torch.from_numpy(g['w32.t'])
+    x, t = torch.from_numpy(g[f'{tag}.x']), torch.from_numpy(g[f'{tag}.t'])
     out = net.reference_forward(x, t)
-    for n in ('d_xyz', 'd_rotation', 'd_scaling'):
-        np.testing.assert_allclose(out[n].detach().numpy(), g[f'w32.out.{n}'], rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(out['hidden'].detach().numpy(), g['w32.hidden'], rtol=1e-5, atol=1e-6)
-    names = ('d_xyz', 'd_rotation', 'd_scaling')
+    names = ('d_xyz', 'd_rotation', 'd_scaling') + (('g_rotation',) if raw else ())
+    for n in names:
+        np.testing.assert_allclose(out[n].detach().numpy(), g[f'{tag}.out.{n}'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out['hidden'].detach().numpy(), g[f'{tag}.hidden'], rtol=1e-5, atol=1e-6)
     params = dict(net.named_parameters())
-    grads = torch.autograd.grad([out[n] for n in names], list(params.values()), [torch.from_numpy(g[f'w32.gy.{n}']) for n in names])
+    grads = torch.autograd.grad([out[n] for n in names], list(params.values()), [torch.from_numpy(g[f'{tag}.gy.{n}']) for n in names])
     for (n, _), gr in zip(params.items(), grads):
-        want = g[f'w32.grad.{n}']
+        want = g[f'{tag}.grad.{n}']
         assert np.abs(gr.numpy() - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-30) + 1e-7, n
     q = torch.nn.functional.normalize(out['d_rotation'] + torch.tensor([0, 0, 0, 1.]), dim=-1)
-    np.testing.assert_allclose(q.detach().numpy(), g['w32.d_rot_normalized'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(q.detach().numpy(), g[f'{tag}.d_rot_normalized'], rtol=1e-6, atol=1e-7)
