@@ -152,7 +152,8 @@ def build_parser():
                          'instead of sk_gs_amd.fused_step.FusedViewStep (same kernels, no autograd glue)')
     ap.add_argument('--autograd-fused', action='store_true',
                     help="the reference's loop shape over the FUSED launches: `loss = step.loss(...); loss.backward(); optimizer.step()` "
-                         "(FusedViewStep.loss: one autograd node; the optimizer step a launch of its own behind it, no riding update)")
+                         "(FusedTrainStep.loss: one autograd node whose backward carries the per-Gaussian rows' update on its skeleton launch; "
+                         "optimizer.step() is then the closing launch.  With --serial-adam: FusedViewStep.loss and a full optimizer launch)")
     ap.add_argument('--auto-budget', type=float, default=240.0,
                     help='world > 1, --exchange auto: seconds after which no further exchange variant is started (the ones that '
                          'finished are ranked and reported)')

@@ -275,7 +275,7 @@ def build_steps(args, env, s, x):
                 t.overflow.add_(out['buffer'].geomBuffer[4:8].view(torch.int32))
         elif args.autograd_fused:
             def fwd_bwd(v):  # the fused launches as ONE autograd node: forward half now, backward half when autograd reaches it
-                fstep.loss(*fb_args(v)).backward()
+                (t.train1.loss if t.train1 is not None else fstep.loss)(*fb_args(v)).backward()
         else:
             def fwd_bwd(v):  # every gradient is overwritten in place: no zero fill of the flat buffer
                 fstep.forward_backward(*fb_args(v))
@@ -317,7 +317,8 @@ def build_steps(args, env, s, x):
                 def update(_=0):  # noqa: F811
                     rebuild_exchanged_grads()
                     train_n.update()
-        if not env.use_dist and fused_path:
+        t.train1 = None
+        if not env.use_dist and (fused_path or (args.autograd_fused and not args.torch_adam and not args.serial_adam)):
             from sk_gs_amd.train_step import FusedTrainStep
             t.train1 = train1 = FusedTrainStep(fstep, opt)
             t.fused_update = train1.fused
@@ -333,7 +334,7 @@ def build_steps(args, env, s, x):
         def eager_step(i):
             v = vp.view_index(i, args.views)
             select(v)
-            if t.fused_update:
+            if t.fused_update and not args.autograd_fused:
                 t.train1(*fb_args(v))
                 return
             fwd_bwd(v)
@@ -374,7 +375,10 @@ def build_steps(args, env, s, x):
                 gC.capture(0)
         else:
             if not env.use_dist:  # whole step (fwd + bwd + Adam) is one graph per view
-                if t.fused_update:
+                if t.fused_update and args.autograd_fused:
+                    # loss = train.loss(...); loss.backward(); optimizer.step() -- the step's launches behind the autograd API
+                    t.g_step = GraphedSteps(lambda v: (fwd_bwd(v), opt.step()))
+                elif t.fused_update:
                     t.g_step = GraphedSteps(lambda v: t.train1(*fb_args(v)))
                 else:
                     t.g_step = GraphedSteps(lambda v: (fwd_bwd(v), opt.step()))
@@ -750,7 +754,7 @@ def run(args, env):
                    'prime_steps_why': 'untimed steps after the capture: a fresh process reaches a training run\'s steady state only after '
                                       'tens of ms of work (0.375 -> 0.358 ms per step in a 20-step region)',
                    'step': 'autograd operator path' if args.autograd else (
-                       'FusedViewStep behind the autograd API: loss = step.loss(...); loss.backward(); optimizer.step()'
+                       ('FusedTrainStep behind the autograd API: loss = train.loss(...); loss.backward() [rows\' update on board]; optimizer.step() [closing launch]' if t.fused_update else 'FusedViewStep behind the autograd API: loss = step.loss(...); loss.backward(); optimizer.step()')
                        if args.autograd_fused else 'FusedViewStep (direct C-ABI calls)'),
                    'operator_path_backward_thread': args.backward_thread,
                    'replicas_identical': replicas_identical, 'param_digest': param_digest,

@@ -86,6 +86,7 @@ class FusedAdam:
         # 16 = 1 - beta^steps, maintained by the kernels; all zeros = no step taken
         lib.skgs_adam_state_bytes.restype = C.c_size_t
         self.step_state = torch.zeros(int(lib.skgs_adam_state_bytes()) // 4, dtype=torch.float32, device=dev)
+        self._pending_tail = None  # (FusedTrainStep.loss: the next step() is that training step's closing launch)
         self.step_count = self.step_state[:1]  # (a view: ``float(opt.step_count)`` reads the count)
         self._table = torch.zeros(len(self.params) * 56, dtype=torch.uint8, device=dev)
         # descriptor tables of captured steps whose gradients autograd handed over (_table_of_this_capture)
@@ -579,7 +580,15 @@ class FusedAdam:
         updates those groups (one launch per run of groups that are neighbours in the table).  A step taken in pieces lets each piece start as soon as ITS gradients are final, on a
         side stream beside the rest of the backward (``OverlappedStep``): every piece uses the bias correction of the
         same step; pass ``advance=False`` to all of them and call ``advance_step()`` once, after they have all been
-        ordered before it (the counter every piece reads must not move under them)."""
+        ordered before it (the counter every piece reads must not move under them).
+
+        After ``FusedTrainStep.loss(...).backward()`` the call is that step's TAIL: the per-Gaussian rows were updated by the
+        backward's skeleton launch, what is left is the closing launch."""
+        pending = self._pending_tail
+        if pending is not None and groups is None and advance:
+            self._pending_tail = None
+            pending[0]._tail(pending[1])
+            return
         table = self._table
         # the table holds raw gradient pointers: autograd may have replaced a .grad tensor (zero_grad(set_to_none=True))
         if any(p.grad is None or p.grad.data_ptr() != g for p, g in zip(self.params, self._bound_grads)):

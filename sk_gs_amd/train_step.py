@@ -182,6 +182,24 @@ class FusedTrainStep:
     def __call__(self, rs=None, time_id=None, target=None):
         assert not self.reduce_between, 'a step with an all-reduce in it is backward() ... update()'
         self.step.forward_backward(rs, time_id, target)
+        self._tail(rs)
+
+    def loss(self, rs=None, time_id=None, target=None):
+        """The same step behind torch's autograd API (the reference's loop shape, train.py:179-250)::
+
+            loss = train.loss(rs, time_id, target)     # the forward half runs now
+            loss.backward()                            # the backward half; the per-Gaussian rows' Adam update rides on its skeleton launch
+            optimizer.step()                           # = the closing launch (network, joints, tables, counter, next view)
+
+        Same launches and the same arithmetic as ``train(rs, time_id, target)``.  What differs from a plain optimizer: the rows are
+        already updated when ``backward()`` returns (their gradients are final before the skeleton launch starts), so nothing may
+        read or change those gradients between ``backward()`` and ``optimizer.step()`` -- the next ``optimizer.step()`` call is
+        consumed by this step's tail."""
+        assert not self.reduce_between, 'a step with an all-reduce in it is backward() ... update()'
+        self.optimizer._pending_tail = (self, rs)
+        return self.step.loss(rs, time_id, target)
+
+    def _tail(self, rs):
         if self.fused:
             job = self.step.input_grad_job() if self.joints is not None else None
             vt  = self.step.view_table
