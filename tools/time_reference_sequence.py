@@ -92,6 +92,31 @@ def sp_inputs(P=100_000, M=512, seed=0):
     return a, cot
 
 
+def sk_stage_accelerated(a):
+    """rs.sk_stage with the reference's ``kinematic`` as sk_gs_amd.accelerate_reference() replaces it (reference_accel.kinematic on a
+    stand-in `self`); the rest of the sequence -- search, weights, the skinning expression, the activations -- unchanged"""
+    import types
+    from sk_gs_amd import reference_accel as ra
+    sys.modules.setdefault('lietorch', L)
+    me = types.SimpleNamespace(training=True, test_time_interpolate=False, sk_feature=None, _R_dim=4, joint_parents=a['parents_table'].int(),
+                               joint_root=a['root'], sk_cache=_cache(a), sk_deform_net=lambda x, t: (a['net_sk_r'], a['net_d_rot'], a['net_d_scale']))
+    points = a['_xyz'].detach()
+    sk_T, d_rot, d_scale = ra.kinematic(me, a['joints'], None, a['global_tr'][int(a['time_id'])].view(-1), int(a['time_id']), None)
+    w, idx = rs._lbs_weights(p3d.knn_points, a, points, a['joints'], 5)
+    d_xyz = (sk_T[idx].act(points[:, None]) * w[..., None]).sum(dim=1) - points
+    return rs._activate(a, d_xyz, (d_rot[idx] * w[..., None]).sum(dim=1), (d_scale[idx] * w[..., None]).sum(dim=1))
+
+
+_CACHE = {}
+
+
+def _cache(a):
+    M = a['joints'].shape[0]
+    if M not in _CACHE:
+        _CACHE[M] = torch.zeros(1, M, 11, device=dev)
+    return _CACHE[M]
+
+
 def main():
     rows = []
     a, cot, bones = sk_inputs()
@@ -104,7 +129,10 @@ def main():
         sum((res[k] * cot[k]).sum() for k in cot).backward()
 
     sk = lambda: rs.sk_stage(L, p3d.knn_points, a, 5)  # noqa: E731
+    timed(lambda: ref_step(sk), n=30, warm=30)  # (a fresh process: the first timed region ran 1.5 x slower than every later one)
     rows.append(('sk 100k x 20: reference sequence on the stand-ins, eager', *timed(lambda: ref_step(sk))))
+    rows.append(('sk 100k x 20: ... with accelerate_reference()\'s kinematic (the chain as one launch per direction)',
+                 *timed(lambda: ref_step(lambda: sk_stage_accelerated(a)))))
     L._FUSED = False
     rows.append(('sk 100k x 20: ... skinning expression NOT recognised (generic torch ops)', *timed(lambda: ref_step(sk))))
     L._FUSED = True
