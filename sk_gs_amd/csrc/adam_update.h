@@ -171,17 +171,17 @@ __device__ __forceinline__ void adam_update_chunk(const AdamTensor& T, int64_t b
   for (int r = 0; r < 4; ++r) {
     const int64_t i = base + ((int64_t) r * ADAM_THREADS + t256) * 4;
     if (aligned && i + 3 < T.n) {
-      const float4 g = *reinterpret_cast<const float4*>(T.grad + i);
-      float4 m = *reinterpret_cast<float4*>(T.exp_avg + i);
-      float4 v = *reinterpret_cast<float4*>(T.exp_avg_sq + i);
-      float4 p = *reinterpret_cast<float4*>(T.param + i);
+      const float4 g = stream_load4<NT_ADAM_LOAD>(T.grad + i);
+      float4 m = stream_load4<NT_ADAM_LOAD>(T.exp_avg + i);
+      float4 v = stream_load4<NT_ADAM_LOAD>(T.exp_avg_sq + i);
+      float4 p = stream_load4<NT_ADAM_LOAD>(T.param + i);
       adam_update_element(p.x, m.x, v.x, g.x, step_size, k);
       adam_update_element(p.y, m.y, v.y, g.y, step_size, k);
       adam_update_element(p.z, m.z, v.z, g.z, step_size, k);
       adam_update_element(p.w, m.w, v.w, g.w, step_size, k);
-      *reinterpret_cast<float4*>(T.exp_avg + i)    = m;
-      *reinterpret_cast<float4*>(T.exp_avg_sq + i) = v;
-      *reinterpret_cast<float4*>(T.param + i)      = p;
+      stream_store4<NT_ADAM>(T.exp_avg + i, m);
+      stream_store4<NT_ADAM>(T.exp_avg_sq + i, v);
+      stream_store4<NT_ADAM>(T.param + i, p);
     } else {
       for (int64_t e = i; e < T.n && e < i + 4; ++e) {
         float p = T.param[e], m = T.exp_avg[e], v = T.exp_avg_sq[e];
@@ -212,10 +212,10 @@ __device__ __forceinline__ void adam_update_chunk2(const AdamTensor& A, int64_t 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t i = base + ((int64_t) r * ADAM_THREADS + t256) * 4;
-      g[c][r] = *reinterpret_cast<const float4*>(T.grad + i);
-      m[c][r] = *reinterpret_cast<const float4*>(T.exp_avg + i);
-      v[c][r] = *reinterpret_cast<const float4*>(T.exp_avg_sq + i);
-      p[c][r] = *reinterpret_cast<const float4*>(T.param + i);
+      g[c][r] = stream_load4<NT_ADAM_LOAD>(T.grad + i);
+      m[c][r] = stream_load4<NT_ADAM_LOAD>(T.exp_avg + i);
+      v[c][r] = stream_load4<NT_ADAM_LOAD>(T.exp_avg_sq + i);
+      p[c][r] = stream_load4<NT_ADAM_LOAD>(T.param + i);
     }
   }
 #pragma unroll
@@ -230,9 +230,9 @@ __device__ __forceinline__ void adam_update_chunk2(const AdamTensor& A, int64_t 
       adam_update_element(p[c][r].y, m[c][r].y, v[c][r].y, g[c][r].y, ss, k);
       adam_update_element(p[c][r].z, m[c][r].z, v[c][r].z, g[c][r].z, ss, k);
       adam_update_element(p[c][r].w, m[c][r].w, v[c][r].w, g[c][r].w, ss, k);
-      *reinterpret_cast<float4*>(T.exp_avg + i)    = m[c][r];
-      *reinterpret_cast<float4*>(T.exp_avg_sq + i) = v[c][r];
-      *reinterpret_cast<float4*>(T.param + i)      = p[c][r];
+      stream_store4<NT_ADAM>(T.exp_avg + i, m[c][r]);
+      stream_store4<NT_ADAM>(T.exp_avg_sq + i, v[c][r]);
+      stream_store4<NT_ADAM>(T.param + i, p[c][r]);
     }
   }
 }

@@ -324,7 +324,7 @@ __device__ __forceinline__ void deform_bwd_moments(const DeformBwdArgs& a, int P
     const int p0   = blockIdx.x * DEFORM_BWD_THREADS;
     const int rows = min(DEFORM_BWD_THREADS, P - p0);
     float* dst     = a.g_sp_W + (size_t) p0 * a.M;
-    for (int i = threadIdx.x; i < rows * a.M; i += DEFORM_BWD_THREADS) dst[i] = s_w[(i / a.M) * Mp + (i % a.M)];
+    for (int i = threadIdx.x; i < rows * a.M; i += DEFORM_BWD_THREADS) stream_store<NT_DEFORM_BWD>(dst + i, s_w[(i / a.M) * Mp + (i % a.M)]);
   }
 }
 

@@ -209,7 +209,8 @@ __global__ void __launch_bounds__(NT) image_loss_forward_kernel(int C, int H, in
       const float d_exy = 2.f * A1 * inv;
       const size_t oo  = (size_t) c * plane + (size_t) gy * W + gx;
       const size_t CHW = (size_t) C * plane;
-      dmaps[oo] = d_mu1, dmaps[CHW + oo] = d_exx, dmaps[2 * CHW + oo] = d_exy;
+      stream_store<NT_LOSS_FWD>(dmaps + oo, d_mu1), stream_store<NT_LOSS_FWD>(dmaps + CHW + oo, d_exx);
+      stream_store<NT_LOSS_FWD>(dmaps + 2 * CHW + oo, d_exy);
       ssim_sum += ssim;
     }
   }
@@ -345,7 +346,7 @@ __global__ void __launch_bounds__(NT) image_loss_backward_kernel(int C, int H, i
       const float x = xs[o], y = ys[o];
       const float d = x - y;
       const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-      dL_dpred[oo] = g * (scale_ssim * (v[o][0] + 2.f * x * v[o][1] + y * v[o][2]) + scale_l1 * sgn);
+      stream_store<NT_LOSS_BWD>(dL_dpred + oo, g * (scale_ssim * (v[o][0] + 2.f * x * v[o][1] + y * v[o][2]) + scale_l1 * sgn));
     }
   }
   // the loss value itself, when the forward left it to this launch (one workgroup, off everybody else's critical path)

@@ -255,7 +255,7 @@ __device__ __forceinline__ int stage_lds_index(int e, int RL, int pitch) {  // f
   const int r = e / RL;
   return r * pitch + (e - r * RL);
 }
-template <int NT = PRE_THREADS>
+template <int NT = PRE_THREADS, int SITE = 31 /* StreamSite of the loads (31: plain) */>
 __device__ __forceinline__ void stage_rows_in(float* s_dst, const float* __restrict__ src, int nrows, int RL) {
   const int pitch = sh_pitch(RL), n = nrows * RL;
   const bool vec  = (RL % 4 == 0 || pitch == RL) && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
@@ -264,7 +264,7 @@ __device__ __forceinline__ void stage_rows_in(float* s_dst, const float* __restr
 #pragma unroll
   for (int k = 0; k < STAGE_V; ++k) {
     const int i = threadIdx.x + k * NT;
-    if (i < n4) v[k] = reinterpret_cast<const float4*>(src)[i];
+    if (i < n4) v[k] = stream_load4<SITE>(src + 4 * (size_t) i);
   }
 #pragma unroll
   for (int k = 0; k < STAGE_V; ++k) {
@@ -280,7 +280,7 @@ __device__ __forceinline__ void stage_rows_in(float* s_dst, const float* __restr
   }
   for (int e = 4 * n4 + threadIdx.x; e < n; e += NT) s_dst[stage_lds_index(e, RL, pitch)] = src[e];
 }
-template <int NT = PRE_THREADS>
+template <int NT = PRE_THREADS, int SITE = 31 /* StreamSite of the stores (31: plain) */>
 __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, const float* s_src, int nrows, int RL) {
   const int pitch = sh_pitch(RL), n = nrows * RL;
   const bool vec  = (RL % 4 == 0 || pitch == RL) && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
@@ -290,10 +290,10 @@ __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, const fl
     const int i = threadIdx.x + k * NT;
     if (i < n4) {
       const int o = pitch == RL ? 4 * i : stage_lds_index(4 * i, RL, pitch);
-      reinterpret_cast<float4*>(dst)[i] = make_float4(s_src[o], s_src[o + 1], s_src[o + 2], s_src[o + 3]);
+      stream_store4<SITE>(dst + 4 * (size_t) i, make_float4(s_src[o], s_src[o + 1], s_src[o + 2], s_src[o + 3]));
     }
   }
-  for (int e = 4 * n4 + threadIdx.x; e < n; e += NT) dst[e] = s_src[stage_lds_index(e, RL, pitch)];
+  for (int e = 4 * n4 + threadIdx.x; e < n; e += NT) stream_store<SITE>(dst + e, s_src[stage_lds_index(e, RL, pitch)]);
 }
 
 // The skeleton stage's deform in front of this pass (template DK > 0: the capacity of the per-lane top-K list): the lane first
@@ -392,12 +392,12 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
     if (shs_rest) {
       const int RL = (M - 1) * 3;
       float* s_dc  = s_sh + blockDim.x * sh_pitch(RL);
-      stage_rows_in(s_sh, shs_rest + (size_t) base * RL, nrows, RL);
+      stage_rows_in<PRE_THREADS, NT_SH_LOAD_FWD>(s_sh, shs_rest + (size_t) base * RL, nrows, RL);
       for (int i = threadIdx.x; i < nrows * 3; i += blockDim.x) s_dc[i] = shs[(size_t) base * 3 + i];
       my_dc = s_dc + threadIdx.x * 3, my_sh = s_sh + threadIdx.x * sh_pitch(RL) - 3;
     } else {
       const int RL = M * 3;
-      stage_rows_in(s_sh, shs + (size_t) base * RL, nrows, RL);
+      stage_rows_in<PRE_THREADS, NT_SH_LOAD_FWD>(s_sh, shs + (size_t) base * RL, nrows, RL);
       my_dc = my_sh = s_sh + threadIdx.x * sh_pitch(RL);
     }
   }
@@ -702,9 +702,9 @@ __global__ void __launch_bounds__(PRE_BWD_THREADS) preprocess_backward_kernel(in
   pf_rec[0] = pf_rec[1] = pf_rec[2] = pf_row[0];
   if (idx < P) {
     pf_radius = radii[idx];
-    const float4* row = reinterpret_cast<const float4*>(gradacc + (size_t) idx * GRAD_ROW);
+    const float* row = gradacc + (size_t) idx * GRAD_ROW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pf_row[i] = row[i];
+    for (int i = 0; i < 4; ++i) pf_row[i] = stream_load4<NT_GRADROW_LOAD>(row + 4 * i);
     pf_rec[0] = recs[3 * idx], pf_rec[1] = recs[3 * idx + 1], pf_rec[2] = recs[3 * idx + 2];
     pf_p[0] = means3D[3 * idx], pf_p[1] = means3D[3 * idx + 1], pf_p[2] = means3D[3 * idx + 2];
     if (scales) {
@@ -716,7 +716,7 @@ __global__ void __launch_bounds__(PRE_BWD_THREADS) preprocess_backward_kernel(in
   if constexpr (DBJ) deform_bwd_prefetch(dbj, idx, idx < P, dbl);
   float dj_gm[3] = {0.f, 0.f, 0.f}, dj_gs[3] = {0.f, 0.f, 0.f}, dj_go = 0.f;
   float4 dj_gr = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (staged) stage_rows_in<PRE_BWD_THREADS>(s_sh, (shs_rest ? shs_rest : shs) + (size_t) base * RL, nrows, RL);
+  if (staged) stage_rows_in<PRE_BWD_THREADS, NT_SH_LOAD_BWD>(s_sh, (shs_rest ? shs_rest : shs) + (size_t) base * RL, nrows, RL);
   __syncthreads();
   if (idx < P) {
 
@@ -991,7 +991,7 @@ __global__ void __launch_bounds__(PRE_BWD_THREADS) preprocess_backward_kernel(in
   }  // idx < P
   if (staged && dL_dsh) {
     __syncthreads();
-    stage_rows_out<PRE_BWD_THREADS>((dL_dsh_rest ? dL_dsh_rest : dL_dsh) + (size_t) base * RL, s_sh, nrows, RL);
+    stage_rows_out<PRE_BWD_THREADS, NT_PRE_BWD>((dL_dsh_rest ? dL_dsh_rest : dL_dsh) + (size_t) base * RL, s_sh, nrows, RL);
   }
   if constexpr (DBJ) {
     __syncthreads();  // the SH rows have left the LDS: it is the deform backward's now

@@ -277,6 +277,45 @@ __device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int
   mx[1] = min(gy, max(0, (int) ((py + r + TILE - 1) / TILE)));
 }
 
+// Streaming accesses.  A plain store leaves its line dirty in the XCD's L2 until it is evicted or the launch's closing write-back
+// flushes it, and a plain load allocates its line there; for arrays that are touched once per step and not again before tens of MB
+// have passed, the non-temporal hint (`global_load / global_store ... nt`) keeps them out of the way.  Measured on one box with
+// alternating builds (SKGS_NT_MASK, one bit per site; 10-12 default bench runs each; ms per step, config #1):
+//   no site 0.3511 | the optimizer's stores 0.3496 | + the dense logit-gradient rows 0.3481 | + the optimizer's loads 0.3474
+// and neutral or worse: the SH gradient rows, the loss maps (read back by the very next launch: image_loss_backward 19.2 -> 21.7 us),
+// dL/dimage (the loss backward -0.5 us, the blend backward +1), the SH rows' and the gradient rows' loads.  Default 0x61 = the three
+// sites that paid; make CXXFLAGS="... -DSKGS_NT_MASK=0" builds every access plain.
+#ifndef SKGS_NT_MASK
+#define SKGS_NT_MASK 0x61
+#endif
+enum StreamSite { NT_ADAM = 0, NT_PRE_BWD = 1, NT_LOSS_FWD = 2, NT_LOSS_BWD = 3, NT_PRE_FWD = 4, NT_DEFORM_BWD = 5, NT_ADAM_LOAD = 6,
+  NT_SH_LOAD_FWD = 7, NT_SH_LOAD_BWD = 8, NT_GRADROW_LOAD = 9 };
+template <int SITE>
+__device__ __forceinline__ void stream_store(float* p, float v) {
+  if constexpr (SITE < 31 && ((SKGS_NT_MASK >> SITE) & 1)) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+template <int SITE>
+__device__ __forceinline__ float4 stream_load4(const float* p) {
+  if constexpr (SITE < 31 && ((SKGS_NT_MASK >> SITE) & 1)) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v q = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+    return make_float4(q.x, q.y, q.z, q.w);
+  } else {
+    return *reinterpret_cast<const float4*>(p);
+  }
+}
+template <int SITE>
+__device__ __forceinline__ void stream_store4(float* p, float4 v) {
+  if constexpr (SITE < 31 && ((SKGS_NT_MASK >> SITE) & 1)) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v q = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(q, reinterpret_cast<f4v*>(p));
+  } else {
+    *reinterpret_cast<float4*>(p) = v;
+  }
+}
+
 __device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 __device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 
