@@ -190,6 +190,114 @@ __global__ void __launch_bounds__(256) adam_logit_rows_kernel(int P, int M, int 
     }
   }
 }
+// The same update with R rows of a wave in flight at once (K <= KM): the triples and masks of R rows are requested together (scalar
+// loads: the row numbers are made wave-uniform for the compiler), then the first tile pair of every row, and only a row with more than
+// two live tiles takes further passes.  Same arithmetic per element.  Measured in the superpoint stage's step with LBS_method W
+// (three alternating runs each): one row at a time 0.4668 ms, R = 2 0.4635, R = 4 0.4733 (91 registers: 5 waves per SIMD) -- the launch
+// is close to what its 128-byte accesses stream at (~270 MB in 62 us), not a chain of round trips.
+template <int KM, int R>
+__global__ void __launch_bounds__(256) adam_logit_rows_batched_kernel(int P, int M, int K, const float* __restrict__ weights,
+    const int64_t* __restrict__ indices, const float* __restrict__ g_weights, const AdamTensor* __restrict__ desc,
+    uint32_t* __restrict__ tile_mask, double beta1d, double beta2d, float eps, const AdamState* __restrict__ state, int after_advance) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, e = lane & 31;
+  // (readfirstlane: the row numbers are wave-uniform, which the compiler cannot see through threadIdx.x >> 6 -- the triples become
+  // scalar loads into SGPRs instead of 64 copies in vector registers)
+  const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), n_waves = gridDim.x * 4;
+  const AdamCoef k = adam_coefficients(beta1d, beta2d, eps, state, after_advance != 0);
+  const AdamTensor T    = desc[0];
+  const float step_size = adam_lr(T, k) / k.bc1;
+  for (int n0 = wave * R; n0 < P; n0 += n_waves * R) {
+    // ---- every row's triples and mask (wave-uniform addresses; rows beyond P repeat the last one and do nothing)
+    float w[R][KM], gw[R][KM];
+    int id[R][KM];
+    uint32_t before[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const size_t row = (size_t) min(n0 + r, P - 1) * K;
+#pragma unroll
+      for (int q = 0; q < KM; ++q) {
+        const int qc = min(q, K - 1);
+        w[r][q] = weights[row + qc], gw[r][q] = g_weights[row + qc], id[r][q] = (int) indices[row + qc];
+      }
+      before[r] = tile_mask[min(n0 + r, P - 1)];
+    }
+    float gl[R][KM];
+    uint32_t todo[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float dot = 0.f;
+#pragma unroll
+      for (int q = 0; q < KM; ++q)
+        if (q < K) dot = __builtin_fmaf(w[r][q], gw[r][q], dot);
+      uint32_t touched = 0u;
+#pragma unroll
+      for (int q = 0; q < KM; ++q) {
+        if (q < K) {
+          gl[r][q] = __fmul_rn(w[r][q], __fsub_rn(gw[r][q], dot));
+          touched |= 1u << (id[r][q] / LOGIT_TILE);
+        } else {
+          id[r][q] = -1, gl[r][q] = 0.f;
+        }
+      }
+      const bool valid = n0 + r < P;
+      todo[r] = valid ? __builtin_amdgcn_readfirstlane(before[r] | touched) : 0u;
+      if (lane == 0 && valid && todo[r] != before[r]) tile_mask[n0 + r] = todo[r];
+    }
+    // ---- the first tile pair of every row: all loads, then all updates
+    float pp[R], mm[R], vv[R];
+    size_t at[R];
+    int jj[R];
+    bool act[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      uint32_t td = todo[r];
+      const int ta = td ? __builtin_ctz(td) : -1;
+      if (td) td &= td - 1;
+      const int tb = td ? __builtin_ctz(td) : -1;
+      if (td) td &= td - 1;
+      todo[r] = td;
+      const int t = half ? tb : ta;
+      jj[r]  = t * LOGIT_TILE + e;
+      act[r] = t >= 0 && jj[r] < M;
+      at[r]  = act[r] ? (size_t) (n0 + r) * M + jj[r] : 0;
+      pp[r] = T.param[at[r]], mm[r] = T.exp_avg[at[r]], vv[r] = T.exp_avg_sq[at[r]];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (act[r]) {
+        float g = 0.f;
+#pragma unroll
+        for (int q = 0; q < KM; ++q)
+          if (id[r][q] == jj[r]) g += gl[r][q];
+        adam_update_element(pp[r], mm[r], vv[r], g, step_size, k);
+        T.exp_avg[at[r]] = mm[r], T.exp_avg_sq[at[r]] = vv[r], T.param[at[r]] = pp[r];
+      }
+    }
+    // ---- rows with more than two live tiles
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      uint32_t td = todo[r];
+      while (td) {
+        const int ta = __builtin_ctz(td);
+        td &= td - 1;
+        const int tb = td ? __builtin_ctz(td) : -1;
+        if (td) td &= td - 1;
+        const int t = half ? tb : ta;
+        const int j = t * LOGIT_TILE + e;
+        if (t >= 0 && j < M) {
+          float g = 0.f;
+#pragma unroll
+          for (int q = 0; q < KM; ++q)
+            if (id[r][q] == j) g += gl[r][q];
+          const size_t a = (size_t) (n0 + r) * M + j;
+          float p = T.param[a], m = T.exp_avg[a], v = T.exp_avg_sq[a];
+          adam_update_element(p, m, v, g, step_size, k);
+          T.exp_avg[a] = m, T.exp_avg_sq[a] = v, T.param[a] = p;
+        }
+      }
+    }
+  }
+}
 // a tile is live when any of its moments is non-zero (after a restore, a re-ordering or a change of the row count)
 __global__ void __launch_bounds__(256) adam_logit_mask_kernel(int P, int M, const float* __restrict__ exp_avg,
     const float* __restrict__ exp_avg_sq, uint32_t* __restrict__ tile_mask) {
@@ -327,10 +435,21 @@ int skgs_adam_logit_rows(int32_t P, int32_t M, int32_t K, const float* weights, 
   SKGS_REQUIRE(weights && indices && g_weights && tensor && tile_mask && step_state, "adam_logit_rows: NULL argument");
   hipStream_t s = (hipStream_t) stream;
   ProfScope prof(K_ADAM, s);
-  const int grid = (int) std::min<int64_t>(((int64_t) P + 3) / 4, 256 * 8);
-  hipLaunchKernelGGL(adam_logit_rows_kernel, dim3(grid), dim3(256), 0, s, P, M, K, weights, indices, g_weights,
-      reinterpret_cast<const AdamTensor*>(tensor), tile_mask, beta1, beta2, (float) eps, reinterpret_cast<const AdamState*>(step_state),
-      after_advance ? 1 : 0);
+  static const int rows_in_flight = [] {  // SKGS_LOGIT_ROWS=1: the one-row-at-a-time kernel (A/B measurements)
+    const char* e_ = getenv("SKGS_LOGIT_ROWS");
+    return e_ ? atoi(e_) : 2;
+  }();
+  if (K <= 8 && rows_in_flight == 2) {
+    const int grid = (int) std::min<int64_t>(((int64_t) P + 7) / 8, 256 * 8);
+    hipLaunchKernelGGL((adam_logit_rows_batched_kernel<8, 2>), dim3(grid), dim3(256), 0, s, P, M, K, weights, indices, g_weights,
+        reinterpret_cast<const AdamTensor*>(tensor), tile_mask, beta1, beta2, (float) eps, reinterpret_cast<const AdamState*>(step_state),
+        after_advance ? 1 : 0);
+  } else {
+    const int grid = (int) std::min<int64_t>(((int64_t) P + 3) / 4, 256 * 8);
+    hipLaunchKernelGGL(adam_logit_rows_kernel, dim3(grid), dim3(256), 0, s, P, M, K, weights, indices, g_weights,
+        reinterpret_cast<const AdamTensor*>(tensor), tile_mask, beta1, beta2, (float) eps, reinterpret_cast<const AdamState*>(step_state),
+        after_advance ? 1 : 0);
+  }
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

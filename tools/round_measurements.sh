@@ -66,6 +66,9 @@ done
 python bench.py --lr-schedule off --steps 200 --warmup 20 --no-cpu-baseline --no-ms-per-render --no-survey-recipe 2>/dev/null | tail -1 > $out/bench_lr-schedule-off.json
 python bench.py --autograd-fused --steps 200 --warmup 20 --no-cpu-baseline --no-ms-per-render --no-survey-recipe 2>/dev/null | tail -1 > $out/bench_variant--autograd-fused.json
 python -c "import json; a=json.load(open('$out/bench_lr-schedule-off.json')); b=json.load(open('$out/bench_variant--autograd-fused.json')); print('lr schedule off', a['value'], ' autograd-fused', b['value'])"
+python bench.py --autograd-fused --serial-adam --steps 200 --warmup 20 --no-cpu-baseline --no-ms-per-render --no-survey-recipe 2>/dev/null | tail -1 > $out/bench_variant--autograd-fused_serial-adam.json
+python bench.py --stage sp --raw-time --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_stage_sp_raw-time.json
+python -c "import json; a=json.load(open('$out/bench_variant--autograd-fused_serial-adam.json')); b=json.load(open('$out/bench_stage_sp_raw-time.json')); print('autograd-fused + serial adam', a['value'], ' stage sp raw time', b['value'])"
 for p in sc_gs sp_gs; do
   python bench.py --stage sp --preset $p --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_stage_sp_preset_$p.json
   python -c "import json; d=json.load(open('$out/bench_stage_sp_preset_$p.json')); print('stage sp preset $p', d['value'], d['ms_per_step'])"
