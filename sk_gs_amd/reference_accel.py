@@ -3,10 +3,10 @@
     import sk_gs_amd
     sk_gs_amd.install_reference_hooks()          # before `import networks`: the compiled ops and the two third-party stand-ins
     import networks, train
-    sk_gs_amd.accelerate_reference()             # after: two methods of the reference's classes get a fast path
+    sk_gs_amd.accelerate_reference()             # after: five methods of the reference's classes get a fast path
 
-``install_reference_hooks`` makes the reference RUN on an MI355X; with it alone two pieces of its training step are still long chains
-of small torch launches.  ``accelerate_reference`` replaces exactly those two methods -- same arguments, same returned objects, and a
+``install_reference_hooks`` makes the reference RUN on an MI355X; with it alone five pieces of its training step are still long chains
+of small torch launches.  ``accelerate_reference`` replaces exactly those methods -- same arguments, same returned objects, and a
 call that does not match the fast path's conditions is handed to the reference's own method:
 
 * ``networks.losses.ssim.SSIM_Loss.forward`` (ssim.py:26-43: five depth-wise 11x11 convolutions + ~30 element-wise kernels, 3.5 ms per
@@ -20,17 +20,33 @@ call that does not match the fast path's conditions is handed to the reference's
   everything the reference does with ``sk_T`` afterwards -- ``sk_T[indices].act(...)``, ``sk_T.vec()`` -- is unchanged; the train-time
   cache write ``self.sk_cache[time_id] = ...`` (:1077-1079) is kept.
 
+* ``networks.sk_gs.SimpleDeformationNetwork.forward`` (sk_gs.py:158-164: two frequency encoders + ``MLP_with_skips``, ~65 torch launches
+  forward and ~130 backward for the 20 joint rows of stage `sk`) -> the persistent one-launch-per-direction network kernels
+  (``skgs_deform_mlp_forward / _backward``, ``sk_gs_amd.deform_net``) on a SHADOW module whose hidden-layer parameters ARE the
+  reference module's ``nn.Parameter`` objects (the heads are concatenated into one persistent matrix per call; autograd routes their
+  gradient back through that concatenation) -- for <= 48 rows, one time for all rows, width 256;
+* ``networks.sk_gs.DeformNetwork.forward`` (sk_gs.py:295-317: the superpoint stage's network on the 512 superpoints) -> the MFMA
+  row-block kernels (``skgs_sp_net_forward / _backward``, ``sk_gs_amd.superpoint.SpDeformNet``) on a shadow that shares EVERY
+  parameter object (the two classes have the same parameter names), ``is_blender`` either way, with or without the ``local_rotation``
+  head; the returned dict has ``d_xyz / d_rotation / d_scaling (/ g_rotation)`` -- not ``hidden``, which nothing in the reference reads.
+
+* ``networks.sk_gs.SkeletonGaussianSplatting.calc_LBS_weight`` (sk_gs.py:751-774) -> ``sk_gs_amd.deform.calc_lbs_weight``: the search
+  and the weighting (kernel / weighted kernel / `W` logits / distance softmax, 3 or 3 + 8 search dimensions) as one launch per direction.
+
 The reference's files are not touched; ``restore_reference()`` puts the original methods back.
 """
 from __future__ import annotations
 
 import sys
+import weakref
 
 import torch
+import torch.nn as nn
 import torch.nn.functional as F
 
 _originals = {}
-calls = {'ssim_fused': 0, 'ssim_reference': 0, 'kinematic_fused': 0, 'kinematic_reference': 0}  # counters (tests)
+calls = {'ssim_fused': 0, 'ssim_reference': 0, 'kinematic_fused': 0, 'kinematic_reference': 0, 'sk_net_fused': 0, 'sk_net_reference': 0,
+         'sp_net_fused': 0, 'sp_net_reference': 0, 'lbs_weight_fused': 0, 'lbs_weight_reference': 0}  # counters (tests)
 
 
 # ------------------------------------------------------------------------------------------------ SSIM_Loss.forward
@@ -78,6 +94,18 @@ def _topology(parents_table: torch.Tensor, root) -> dict:
     return hit
 
 
+_bias_cache = {}
+
+
+def _quat_bias(like: torch.Tensor) -> torch.Tensor:
+    """[0, 0, 0, 1] on ``like``'s device, built once (``x.new_tensor([...])`` is a blocking host-to-device copy per call)"""
+    key = (like.device, like.dtype)
+    b = _bias_cache.get(key)
+    if b is None:
+        b = _bias_cache[key] = torch.tensor([0., 0., 0., 1.], dtype=like.dtype, device=like.device)
+    return b
+
+
 def kinematic(self, joints, t, g_tr=None, time_id=None, sk_r_delta=None):
     """``SkeletonGaussianSplatting.kinematic`` (networks/sk_gs.py:1069-1107) with the Lie-group chain as one launch per direction"""
     lie = sys.modules.get('lietorch')
@@ -96,7 +124,7 @@ def kinematic(self, joints, t, g_tr=None, time_id=None, sk_r_delta=None):
         return _originals['kinematic'](self, joints, t, g_tr, time_id, sk_r_delta)
     if self.training and time_id is not None:                                  # the train-time cache (:1077-1079)
         with torch.no_grad():
-            sk_r = F.normalize(sk_r_raw + sk_r_raw.new_tensor([0., 0., 0., 1.]), dim=-1)
+            sk_r = F.normalize(sk_r_raw + _quat_bias(sk_r_raw), dim=-1)
             self.sk_cache[time_id] = torch.cat([sk_r, d_rot, d_scale], dim=-1)
     topo = _topology(self.joint_parents, self.joint_root)
     T = bone_chain(sk_r_raw, joints, g_tr, topo)                               # [M,7] = (t, q_xyzw): kinematic + skeleton_warp_SE3
@@ -104,10 +132,163 @@ def kinematic(self, joints, t, g_tr=None, time_id=None, sk_r_delta=None):
     return lie.SE3.InitFromVec(T), d_rot, d_scale
 
 
+# ------------------------------------------------------------------------------------------------ SimpleDeformationNetwork.forward
+_shadows = weakref.WeakKeyDictionary()   # reference module -> shadow module of this package (parameters shared)
+
+
+def _freq_degree(enc, input_dim):
+    """degree of a reference FreqEncoder (networks/encoders/freq_encoder.py:61-75), or None for any other encoder"""
+    d = getattr(enc, 'degree', None)
+    if not isinstance(d, int) or getattr(enc, 'input_dim', None) != input_dim:
+        return None
+    return d if getattr(enc, 'output_dim', None) == input_dim * (1 + 2 * d) else None
+
+
+def sk_net_shadow(ref):
+    """``sk_gs_amd.deform_net.DeformMLP`` over the parameters of a reference ``SimpleDeformationNetwork``, or None when the module is
+    not the shape the kernels are written for (the caller then uses the reference's own forward)"""
+    hit = _shadows.get(ref)
+    net = getattr(ref, 'dynamic_net', None)
+    if hit is not None and hit.dynamic_net.last_weight.device == net.net[0].weight.device:
+        return hit
+    from sk_gs_amd.deform_net import DeformMLP
+    p_deg, t_deg = _freq_degree(getattr(ref, 'pos_enc_p', None), 3), _freq_degree(getattr(ref, 'pos_enc_t', None), 1)
+    last = getattr(net, 'last', None)
+    if (p_deg is None or t_deg is None or net is None or not isinstance(last, nn.ModuleList) or getattr(net, 'weight_norm', False)
+            or not getattr(net, 'bias', True) or net.dim_hidden != 256 or not (1 <= len(last) <= 4)):
+        return None
+    out_channels = tuple(int(l.out_features) for l in last)
+    sh = DeformMLP(3, 1, out_channels, width=net.dim_hidden, depth=net.num_layers, skips=tuple(net.skips), p_degree=p_deg, t_degree=t_deg)
+    if sh.dynamic_net.in_channels != net.in_channels or any(a.weight.shape != b.weight.shape for a, b in zip(sh.dynamic_net.net, net.net)):
+        return None
+    for mine, theirs in zip(sh.dynamic_net.net, net.net):   # the SAME Parameter objects: updates, .grad and device moves are shared
+        mine.weight, mine.bias = theirs.weight, theirs.bias
+    dev = net.net[0].weight.device
+    sh.dynamic_net.last_weight = nn.Parameter(torch.cat([l.weight.detach() for l in last]).to(dev), requires_grad=False)
+    sh.dynamic_net.last_bias = nn.Parameter(torch.cat([l.bias.detach() for l in last]).to(dev), requires_grad=False)
+    _shadows[ref] = sh
+    return sh
+
+
+def simple_deform_forward(self, points, t):
+    """``SimpleDeformationNetwork.forward`` (networks/sk_gs.py:158-164) as one launch per direction"""
+    from sk_gs_amd.deform_net import _DeformMLPFn, fused_supported
+    sh = None
+    if (torch.is_tensor(points) and points.is_cuda and points.dtype == torch.float32 and points.dim() == 2 and points.shape[1] == 3
+            and torch.is_tensor(t) and t.numel() == 1):
+        sh = sk_net_shadow(self)
+    if sh is None or not fused_supported(sh, points.shape[0]):
+        calls['sk_net_reference'] += 1
+        return _originals['sk_net'](self, points, t)
+    net, heads = sh.dynamic_net, self.dynamic_net.last
+    with torch.no_grad():  # the kernels read ONE head matrix: the current values of the reference's heads, in their order
+        torch.cat([h.weight for h in heads], out=net.last_weight.data)
+        torch.cat([h.bias for h in heads], out=net.last_bias.data)
+    # (what autograd differentiates: the same concatenations -- the gradient of the fused head matrix is split back onto the heads)
+    params = [p for l in net.net for p in (l.weight, l.bias)] + [torch.cat([h.weight for h in heads]), torch.cat([h.bias for h in heads])]
+    out = _DeformMLPFn.apply(sh, torch.is_grad_enabled(), points, t.to(points.device), *params)
+    calls['sk_net_fused'] += 1
+    return list(out.split(net.out_channels, dim=-1))
+
+
+# ------------------------------------------------------------------------------------------------ DeformNetwork.forward
+def sp_net_shadow(ref):
+    """``sk_gs_amd.superpoint.SpDeformNet`` sharing every parameter of a reference ``DeformNetwork``, or None"""
+    hit = _shadows.get(ref)
+    if hit is not None:
+        return hit
+    from sk_gs_amd.superpoint import SpDeformNet
+    p_deg, t_deg = _freq_degree(getattr(ref, 'pos_enc_p', None), 3), _freq_degree(getattr(ref, 'pos_enc_t', None), 1)
+    if (p_deg != 10 or t_deg is None or getattr(ref, 'D', 0) != 8 or getattr(ref, 'W', 0) != 256 or list(getattr(ref, 'skips', [])) != [4]
+            or getattr(ref, 'max_d_scale', -1) > 0):
+        return None
+    blender = bool(getattr(ref, 'is_blender', False))
+    if blender and (getattr(ref, 'time_out', 0) != 30 or tuple(ref.timenet[0].weight.shape) != (256, 1 + 2 * t_deg)):
+        return None
+    sh = SpDeformNet(t_degree=t_deg, sep_rot=bool(getattr(ref, 'sep_rot', False)), is_blender=blender)
+    theirs = dict(ref.named_parameters())
+    if set(theirs) != set(dict(sh.named_parameters())) or not sh.kernel_supported():
+        return None
+    for name in list(theirs):   # the SAME Parameter objects under the same names
+        mod, leaf = sh, name.split('.')
+        for part in leaf[:-1]:
+            mod = getattr(mod, part)
+        if getattr(mod, leaf[-1]).shape != theirs[name].shape:
+            return None
+        setattr(mod, leaf[-1], theirs[name])
+    _shadows[ref] = sh
+    return sh
+
+
+SP_NET_MAX_ROWS = 4096   # (a runner keeps 8.6 KB of activations per row and is kept per row count: the superpoint-sized calls only)
+
+
+def deform_network_forward(self, x, t, **kwargs):
+    """``DeformNetwork.forward`` (networks/sk_gs.py:295-317) on the MFMA row-block kernels"""
+    sh = None
+    if (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 3 and not kwargs
+            and 1 <= x.shape[0] <= SP_NET_MAX_ROWS and torch.is_tensor(t) and t.numel() == 1):
+        sh = sp_net_shadow(self)
+    if sh is None:
+        calls['sp_net_reference'] += 1
+        return _originals['sp_net'](self, x, t, **kwargs)
+    calls['sp_net_fused'] += 1
+    return sh(x, t.to(x.device))
+
+
+# ------------------------------------------------------------------------------------------------ calc_LBS_weight
+def calc_LBS_weight(self, points, sp_points, feature=None, sp_feature=None, K=None, temperature=1.):
+    """``SkeletonGaussianSplatting.calc_LBS_weight`` (networks/sk_gs.py:751-774): the search AND the weighting as one launch per
+    direction (``sk_gs_amd.deform.calc_lbs_weight``; the reference's lines are a search + ~10 element-wise / gather launches on
+    [P, K] tensors, and as many again backward).  Same priority of the weightings (:760-770), same side effect (:771-773); the
+    indices come back typed as the ``knn_points`` stand-in types them (the reference's own ``table[indices]`` gathers keep their
+    duplicate-free backward)."""
+    ok = (torch.is_tensor(points) and points.is_cuda and points.dtype == torch.float32 and points.dim() == 2 and points.shape[1] == 3
+          and torch.is_tensor(sp_points) and sp_points.is_cuda and sp_points.dim() == 2 and sp_points.shape[1] == 3
+          and (feature is None) == (sp_feature is None) and isinstance(temperature, (int, float)))
+    K = self.num_knn if K is None else K
+    if not ok or K > 16 or K > sp_points.shape[0]:
+        calls['lbs_weight_reference'] += 1
+        return _originals['lbs_weight'](self, points, sp_points, feature, sp_feature, K, temperature)
+    from sk_gs_amd import pytorch3d_ops as p3d
+    from sk_gs_amd.deform import calc_lbs_weight
+    kernel = self._sp_radius is not None
+    weights, indices = calc_lbs_weight(
+        points, sp_points, int(K), sp_W=None if kernel else self.sp_W, kernel_radius=self.kernel_radius if kernel else None,
+        kernel_weight=self.kernel_weight if (kernel and self._sp_weight is not None) else None, temperature=float(temperature),
+        feature=feature, sp_feature=sp_feature)
+    if p3d._TYPED_INDEX:
+        indices = p3d.NeighbourIndex.wrap(indices)
+    if not self.sk_is_init:
+        self.sp_weights = weights.detach()
+        self.sp_knn = indices.detach()
+    calls['lbs_weight_fused'] += 1
+    return weights, indices
+
+
 # ------------------------------------------------------------------------------------------------ install / restore
-def accelerate_reference(ssim: bool = True, kinematic_chain: bool = True) -> list:
-    """Patch the two methods on the reference's classes (the modules must be imported already).  Returns what was patched."""
+def accelerate_reference(ssim: bool = True, kinematic_chain: bool = True, networks: bool = True, lbs_weights: bool = True) -> list:
+    """Patch the methods on the reference's classes (the modules must be imported already).  Returns what was patched."""
     done = []
+    if networks:
+        mod = sys.modules.get('networks.sk_gs')
+        if mod is None:
+            raise RuntimeError("accelerate_reference(): import the reference first (networks.sk_gs is not loaded)")
+        if 'sk_net' not in _originals:
+            _originals['sk_net'] = mod.SimpleDeformationNetwork.forward
+            mod.SimpleDeformationNetwork.forward = simple_deform_forward
+        if 'sp_net' not in _originals:
+            _originals['sp_net'] = mod.DeformNetwork.forward
+            mod.DeformNetwork.forward = deform_network_forward
+        done += ['networks.sk_gs.SimpleDeformationNetwork.forward', 'networks.sk_gs.DeformNetwork.forward']
+    if lbs_weights:
+        mod = sys.modules.get('networks.sk_gs')
+        if mod is None:
+            raise RuntimeError("accelerate_reference(): import the reference first (networks.sk_gs is not loaded)")
+        if 'lbs_weight' not in _originals:
+            _originals['lbs_weight'] = mod.SkeletonGaussianSplatting.calc_LBS_weight
+            mod.SkeletonGaussianSplatting.calc_LBS_weight = calc_LBS_weight
+        done.append('networks.sk_gs.SkeletonGaussianSplatting.calc_LBS_weight')
     if ssim:
         mod = sys.modules.get('networks.losses.ssim')
         if mod is None:
@@ -133,3 +314,9 @@ def restore_reference():
         sys.modules['networks.losses.ssim'].SSIM_Loss.forward = _originals.pop('ssim')
     if 'kinematic' in _originals and 'networks.sk_gs' in sys.modules:
         sys.modules['networks.sk_gs'].SkeletonGaussianSplatting.kinematic = _originals.pop('kinematic')
+    if 'sk_net' in _originals and 'networks.sk_gs' in sys.modules:
+        sys.modules['networks.sk_gs'].SimpleDeformationNetwork.forward = _originals.pop('sk_net')
+    if 'sp_net' in _originals and 'networks.sk_gs' in sys.modules:
+        sys.modules['networks.sk_gs'].DeformNetwork.forward = _originals.pop('sp_net')
+    if 'lbs_weight' in _originals and 'networks.sk_gs' in sys.modules:
+        sys.modules['networks.sk_gs'].SkeletonGaussianSplatting.calc_LBS_weight = _originals.pop('lbs_weight')

@@ -195,3 +195,27 @@ def oracle_backward(o, fwd, act, rs, dL_dcolor, dL_dopacity, extras=None, dL_dex
         n(rs.viewmatrix), n(rs.projmatrix), n(rs.campos), n(act['means3D']), n(act['sh']) if use_sh else None,
         n(act['scales']) if cov3D is None else None, n(act['rotations']) if cov3D is None else None, n(dL_dcolor),
         n(dL_dopacity), n(extras), n(dL_dextra), n(colors), n(cov3D), n(grad_means2D), n(grad_conic), n(grad_opacity))
+
+
+def sp_net_relu_masks_agree(net, run, x, t):
+    """True when the kernel's saved activations and the torch body took the same side of every ReLU.  A pre-activation within rounding
+    of 0 may land on either side in two fp32 evaluations; ONE such flip moves a weight gradient by a row's whole contribution (~1e-2
+    of its largest element), which says nothing about either evaluation"""
+    from sk_gs_amd.deform_net import freq_encode_torch
+    M = x.shape[0]
+    Mp = (M + 15) // 16 * 16
+    saved = run.saved.view(torch.float32)
+    with torch.no_grad():
+        t_emb = freq_encode_torch(t.view(-1, 1), net.t_degree).expand(M, net.t_dim)
+        if net.is_blender:
+            t_emb = net.timenet(t_emb)
+        x_emb = freq_encode_torch(x, net.p_degree)
+        h = torch.cat([x_emb, t_emb], -1)
+        for i, layer in enumerate(net.linear):
+            h = torch.relu(layer(h))
+            Y = saved[Mp * 96 + i * Mp * 256: Mp * 96 + (i + 1) * Mp * 256].view(Mp, 256)[:M]
+            if bool(((Y > 0) != (h > 0)).any()):
+                return False
+            if i in net.skips:
+                h = torch.cat([x_emb, t_emb, h], -1)
+    return True

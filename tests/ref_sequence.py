@@ -10,6 +10,7 @@ Reference lines restated (networks/sk_gs.py): forward :1160-1204, sk_stage :1109
 :193-206, calc_LBS_weight :751-774, sp_stage :830-856, warp :776-828.  Test infrastructure only.
 """
 import torch
+import torch.nn as nn
 import torch.nn.functional as F
 
 
@@ -117,6 +118,52 @@ def loss_sp_arap(lie, spT, sp_points, sk_knn_num):
     dist_c = (c[:, None] - c[knn]).square().sum(dim=-1)
     dist_t = (moved[:, None] - moved[knn]).square().sum(dim=-1)
     return loss, (dist_c - dist_t).abs().mean()
+
+
+# ---- stand-ins with the STRUCTURE of the reference's network classes (attribute and parameter names of networks/sk_gs.py:134-164,
+# my_ext/blocks/mlp.py:43-85, networks/encoders/freq_encoder.py:61-75; tests/test_host_cpu.py runs the same accelerators' shadow
+# builders on the reference's real classes in the build container)
+class RefFreqEncoder(nn.Module):
+    def __init__(self, input_dim, degree):
+        super().__init__()
+        self.input_dim, self.degree, self.output_dim = input_dim, degree, input_dim * (1 + 2 * degree)
+
+    def forward(self, x):
+        from sk_gs_amd.deform_net import freq_encode_torch
+        return freq_encode_torch(x, self.degree)
+
+
+class RefMLPWithSkips(nn.Module):
+    def __init__(self, in_channels, dim_hidden, out_channels, num_layers, skips):
+        super().__init__()
+        self.in_channels, self.out_channels, self.dim_hidden, self.num_layers = in_channels, out_channels, dim_hidden, num_layers
+        self.skips, self.bias, self.weight_norm = tuple(skips), True, False
+        net, c = [], in_channels
+        for i in range(num_layers):
+            net.append(nn.Linear(c, dim_hidden))
+            c = dim_hidden + (in_channels if i in self.skips else 0)
+        self.net = nn.ModuleList(net)
+        self.last = nn.ModuleList(nn.Linear(c, oc) for oc in out_channels)
+
+    def forward(self, inputs):
+        x = inputs
+        for i in range(self.num_layers):
+            x = F.relu(self.net[i](x))
+            if i in self.skips:
+                x = torch.cat([x, inputs], dim=-1)
+        return [m(x) for m in self.last]
+
+
+class RefSimpleDeformationNetwork(nn.Module):
+    def __init__(self, out_channels=(4, 4, 3), p_degree=10, t_degree=6):
+        super().__init__()
+        self.pos_enc_p, self.pos_enc_t = RefFreqEncoder(3, p_degree), RefFreqEncoder(1, t_degree)
+        self.dynamic_net = RefMLPWithSkips(self.pos_enc_p.output_dim + self.pos_enc_t.output_dim, 256, list(out_channels), 8, (4,))
+
+    def forward(self, points, t):
+        p_embed = self.pos_enc_p(points)
+        t_embed = self.pos_enc_t(t.view(-1, 1)).expand(*points.shape[:-1], -1)
+        return self.dynamic_net(torch.cat([p_embed, t_embed], dim=-1))
 
 
 SCENARIOS = {  # name -> (stage, K, warp_method, sep_rot): tests/golden/make_golden_sk_stage.py

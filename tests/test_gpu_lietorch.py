@@ -322,3 +322,136 @@ def test_accelerated_ssim_loss_equals_the_reference_loss():
         assert ra.ssim_loss_forward(types.SimpleNamespace(window_size=7, reduction='mean'), x, y) == 'reference'
     finally:
         ra._originals.pop('ssim', None)
+
+
+_RefFreqEncoder, _RefSimpleDeformationNetwork = rs.RefFreqEncoder, rs.RefSimpleDeformationNetwork
+
+
+def test_accelerated_deform_networks_run_on_the_reference_modules_parameters():
+    """accelerate_reference()'s two network fast paths on modules with the reference classes' structure: the one-launch 20-row kernels
+    under ``SimpleDeformationNetwork.forward`` and the MFMA row-block kernels under ``DeformNetwork.forward`` give the modules' own
+    torch forward (values, every parameter gradient, the joints' gradient through the input) -- on the modules' OWN parameter objects:
+    an in-place update of a weight is what the next call computes with"""
+    from sk_gs_amd import reference_accel as ra
+    from sk_gs_amd.superpoint import SpDeformNet
+    g = torch.Generator().manual_seed(4)
+    before = dict(ra.calls)
+    try:
+        # ---- stage sk: 20 joints
+        torch.manual_seed(1)
+        net = _RefSimpleDeformationNetwork().cuda()
+        with torch.no_grad():
+            for h in net.dynamic_net.last:
+                h.weight.normal_(0, 0.05, generator=None)
+        ra._originals['sk_net'] = _RefSimpleDeformationNetwork.forward
+        pts = (torch.rand(20, 3, generator=g) * 2 - 1).cuda().requires_grad_()
+        t = torch.tensor([0.3125], device='cuda')
+        cots = [torch.randn(20, n, generator=g).cuda() for n in (4, 4, 3)]
+        for rep in range(2):
+            got = ra.simple_deform_forward(net, pts, t)
+            want = net(pts, t)
+            assert len(got) == 3 and all(rel_err(a, b) <= 2e-5 for a, b in zip(got, want))
+            params = list(net.parameters())
+            gg = torch.autograd.grad(sum((a * c).sum() for a, c in zip(got, cots)), params + [pts])
+            gw = torch.autograd.grad(sum((a * c).sum() for a, c in zip(want, cots)), params + [pts])
+            for (n, _), a, b in zip(list(net.named_parameters()) + [('points', None)], gg, gw):
+                assert rel_err(a, b) <= 1e-4, (rep, n, rel_err(a, b))
+            with torch.no_grad():   # an optimizer step in place: hidden layer, head, bias
+                net.dynamic_net.net[3].weight.add_(0.01 * torch.randn(256, 256, generator=g).cuda())
+                net.dynamic_net.last[1].weight.mul_(1.5)
+                net.dynamic_net.last[2].bias.add_(0.2)
+        assert ra.calls['sk_net_fused'] == before['sk_net_fused'] + 2
+        # outside the fast path: the module's own forward, counted
+        n_ref = ra.calls['sk_net_reference']
+        out2 = ra.simple_deform_forward(net, pts.detach()[None].expand(1, 20, 3).reshape(1, 20, 3), t)    # 3-d points: not the kernels' call
+        assert ra.calls['sk_net_reference'] == n_ref + 1 and out2[0].shape == (1, 20, 4)
+        # ---- stage sp: 512 superpoints, both network variants (gradients compared on draws in which the two fp32 evaluations took the
+        # same side of every ReLU: helpers.sp_net_relu_masks_agree)
+        from helpers import sp_net_relu_masks_agree
+        compared = 0
+        for blender, sep, tdeg in ((True, False, 6), (False, True, 10)):
+            for seed in range(4):
+                torch.manual_seed(2 + 100 * seed)
+                ref = SpDeformNet(t_degree=tdeg, sep_rot=sep, is_blender=blender)
+                ref.pos_enc_p, ref.pos_enc_t, ref.max_d_scale = _RefFreqEncoder(3, 10), _RefFreqEncoder(1, tdeg), -1.0
+                with torch.no_grad():
+                    for h in (ref.gaussian_warp, ref.gaussian_rotation, ref.gaussian_scaling) + ((ref.local_rotation,) if sep else ()):
+                        h.weight.normal_(0, 0.05)
+                    for layer in ref.linear:
+                        layer.bias.normal_(0, 0.05)
+                ref = ref.cuda()
+                ra._originals['sp_net'] = lambda self, x, t, **kw: self.reference_forward(x, t)
+                x = (torch.rand(512, 3, generator=g) * 2 - 1).cuda()
+                keys = ('d_xyz', 'd_rotation', 'd_scaling') + (('g_rotation',) if sep else ())
+                cot = {k: torch.randn(512, 4 if 'rot' in k else 3, generator=g).cuda() for k in keys}
+                ok = True
+                for rep in range(2):
+                    got = ra.deform_network_forward(ref, x, t)
+                    want = ref.reference_forward(x, t)
+                    assert set(got) == set(keys) and all(rel_err(got[k], want[k]) <= 2e-5 for k in keys)
+                    sh = ra.sp_net_shadow(ref)
+                    assert all(a is b for a, b in zip(sh.parameters(), ref.parameters()))
+                    if not sp_net_relu_masks_agree(ref, sh.runner(512), x, t):
+                        ok = False
+                        break
+                    params = list(ref.parameters())
+                    gg = torch.autograd.grad(sum((got[k] * cot[k]).sum() for k in keys), params)
+                    gw = torch.autograd.grad(sum((want[k] * cot[k]).sum() for k in keys), params)
+                    for (n, _), a, b in zip(ref.named_parameters(), gg, gw):
+                        assert rel_err(a, b) <= 5e-5, (blender, rep, n, rel_err(a, b))
+                    with torch.no_grad():   # an optimizer step in place
+                        ref.linear[2].weight.add_(0.01 * torch.randn(256, 256, generator=g).cuda())
+                        ref.gaussian_warp.weight.mul_(1.3)
+                if ok:
+                    compared += 1
+                    break
+        assert compared == 2, 'four draws in a row with a ReLU flip between the two fp32 evaluations'
+        assert ra.calls['sp_net_fused'] >= before['sp_net_fused'] + 4
+    finally:
+        ra._originals.pop('sk_net', None)
+        ra._originals.pop('sp_net', None)
+
+
+@pytest.mark.parametrize('name', ['sk_W', 'sk_kernel', 'sp_W_LBS', 'sp_wk_LBSc_sep', 'sp_dist_LBS', 'sp_kernel_LBSc'])
+def test_accelerated_calc_LBS_weight_equals_the_reference_lines(name):
+    """accelerate_reference()'s ``calc_LBS_weight`` (search + weighting as one launch per direction) on a stand-in `self` with the
+    inputs of the reference's own runs (sk_stage.npz): weights, indices, the side effect of sk_gs.py:771-773, and -- through a cotangent
+    on the weights -- the gradients of the weighting's parameters against torch autograd of the reference's lines restated
+    (ref_sequence._lbs_weights, itself replayed against the reference's recorded outputs by the tests above)"""
+    import types
+    L, p3d = _mods()
+    from sk_gs_amd import reference_accel as ra
+    z = np.load(os.path.join(GOLDEN, 'sk_stage.npz'))
+    stage, K, _, _ = rs.SCENARIOS[name]
+    results = []
+    for fast in (True, False):
+        a, out, cot, grad = rs.load_scenario(z, name, 'cuda')
+        points = a['_xyz'].detach()
+        bones = a['joints'] if stage == 'sk' else a['sp_points']
+        feat, sfeat = (a.get('hyper_feature'), a.get('sp_hyper_feature')) if stage == 'sp' else (None, None)
+        if fast:
+            me = types.SimpleNamespace(num_knn=K, _sp_radius=a.get('_sp_radius'), _sp_weight=a.get('_sp_weight'), sp_W=a.get('sp_W'),
+                                       sk_is_init=torch.tensor(False), sp_weights=None, sp_knn=None)
+            me.kernel_radius = torch.exp(me._sp_radius) if me._sp_radius is not None else None
+            me.kernel_weight = torch.sigmoid(me._sp_weight) if me._sp_weight is not None else None
+            n0 = ra.calls['lbs_weight_fused']
+            w, idx = ra.calc_LBS_weight(me, points, bones, feat, sfeat)
+            assert ra.calls['lbs_weight_fused'] == n0 + 1
+            assert torch.equal(me.sp_weights, w.detach()) and torch.equal(me.sp_knn.as_subclass(torch.Tensor), idx.as_subclass(torch.Tensor))
+            assert isinstance(idx, p3d.NeighbourIndex) == p3d._TYPED_INDEX
+        else:
+            w, idx = rs._lbs_weights(p3d.knn_points, a, points, bones, K, feat, sfeat)
+        leaves = [a[k] for k in ('_sp_radius', '_sp_weight', 'sp_W', 'hyper_feature', 'sp_hyper_feature') if k in a and a[k].requires_grad]
+        names = [k for k in ('_sp_radius', '_sp_weight', 'sp_W', 'hyper_feature', 'sp_hyper_feature') if k in a and a[k].requires_grad]
+        G = torch.randn(w.shape, generator=torch.Generator().manual_seed(9)).cuda()
+        gr = torch.autograd.grad((w * G).sum(), leaves, allow_unused=True) if (leaves and w.requires_grad) else []
+        results.append((w.detach(), idx.as_subclass(torch.Tensor), dict(zip(names, gr))))
+    (w1, i1, g1), (w0, i0, g0) = results
+    assert torch.equal(i1, i0) and rel_err(w1, w0) <= 2e-6
+    assert torch.equal(i0.cpu(), out['_knn_i']) and rel_err(w1.cpu(), out['_knn_w']) <= 2e-6       # the reference's own run
+    assert set(g1) == set(g0)
+    for k in g0:
+        if g0[k] is None:
+            assert g1[k] is None or float(g1[k].abs().max()) == 0.0, k
+        else:
+            assert rel_err(g1[k], g0[k]) <= 2e-5, (k, rel_err(g1[k], g0[k]))

@@ -763,28 +763,7 @@ def test_operator_path_variants_equal_the_reference_sequence(method, warp_method
     assert checked >= 8 + (1 if warp_method == 'LBS_c' else 0)
 
 
-def _relu_masks_agree(net, run, x, t):
-    """True when the kernel's saved activations and the torch body took the same side of every ReLU.  A pre-activation within rounding
-    of 0 may land on either side in two fp32 evaluations; ONE such flip moves a weight gradient by a row's whole contribution (~1e-2
-    of its largest element), which says nothing about either evaluation"""
-    from sk_gs_amd.deform_net import freq_encode_torch
-    M = x.shape[0]
-    Mp = (M + 15) // 16 * 16
-    saved = run.saved.view(torch.float32)
-    with torch.no_grad():
-        t_emb = freq_encode_torch(t.view(-1, 1), net.t_degree).expand(M, net.t_dim)
-        if net.is_blender:
-            t_emb = net.timenet(t_emb)
-        x_emb = freq_encode_torch(x, net.p_degree)
-        h = torch.cat([x_emb, t_emb], -1)
-        for i, layer in enumerate(net.linear):
-            h = F.relu(layer(h))
-            Y = saved[Mp * 96 + i * Mp * 256: Mp * 96 + (i + 1) * Mp * 256].view(Mp, 256)[:M]
-            if bool(((Y > 0) != (h > 0)).any()):
-                return False
-            if i in net.skips:
-                h = torch.cat([x_emb, t_emb, h], -1)
-    return True
+from helpers import sp_net_relu_masks_agree as _relu_masks_agree  # noqa: E402
 
 
 @pytest.mark.parametrize('M,t_degree,sep_rot,lbs_c', [(512, 10, False, False), (512, 6, True, True), (37, 10, True, False), (100, 15, False, True),

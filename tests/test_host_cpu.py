@@ -169,20 +169,51 @@ try:                                                # wrong order is refused, no
     assert r.returncode != 0 and 'before importing my_ext' in r.stderr, r.stderr[-400:]
 finally:
     pass
-# the optional accelerators (sk_gs_amd.accelerate_reference): two methods patched on the reference's classes; on CPU tensors every call
+# the optional accelerators (sk_gs_amd.accelerate_reference): five methods patched on the reference's classes; on CPU tensors every call
 # is outside the fast path and reaches the reference's own method
 import torch
 from networks.losses import ssim as _ssim_mod
 from sk_gs_amd import reference_accel as _ra
 orig_ssim, orig_kin = _ssim_mod.SSIM_Loss.forward, networks.sk_gs.SkeletonGaussianSplatting.kinematic
-assert sorted(sk_gs_amd.accelerate_reference()) == ['networks.losses.ssim.SSIM_Loss.forward', 'networks.sk_gs.SkeletonGaussianSplatting.kinematic']
+assert sorted(sk_gs_amd.accelerate_reference()) == ['networks.losses.ssim.SSIM_Loss.forward', 'networks.sk_gs.DeformNetwork.forward',
+                                                     'networks.sk_gs.SimpleDeformationNetwork.forward',
+                                                     'networks.sk_gs.SkeletonGaussianSplatting.calc_LBS_weight',
+                                                     'networks.sk_gs.SkeletonGaussianSplatting.kinematic']
+assert networks.sk_gs.SkeletonGaussianSplatting.calc_LBS_weight is _ra.calc_LBS_weight
 assert _ssim_mod.SSIM_Loss.forward is _ra.ssim_loss_forward and networks.sk_gs.SkeletonGaussianSplatting.kinematic is _ra.kinematic
 g = torch.Generator().manual_seed(0)
 x, y = torch.rand(1, 40, 48, 3, generator=g), torch.rand(1, 40, 48, 3, generator=g)
 crit = _ssim_mod.SSIM_Loss()
 assert torch.equal(crit(x, y), orig_ssim(crit, x, y)) and _ra.calls['ssim_reference'] >= 1 and _ra.calls['ssim_fused'] == 0
+# the two deform networks of the reference, built by ITS classes with the shipped settings (exps/default.yaml:4-11,31): the shadows this
+# package runs the kernels on share the reference modules' parameter OBJECTS; a call on CPU tensors takes the reference's own forward
+cfg = dict(pos_enc_p='freq', pos_enc_p_cfg={{'degree': 10}}, pos_enc_t='freq', pos_enc_t_cfg={{'degree': 6}})
+sk_net = networks.sk_gs.SimpleDeformationNetwork(out_channels=[4, 4, 3], width=256, depth=8, skips=(4,), **cfg)
+sh = _ra.sk_net_shadow(sk_net)
+assert sh is not None and all(a.weight is b.weight and a.bias is b.bias for a, b in zip(sh.dynamic_net.net, sk_net.dynamic_net.net))
+assert tuple(sh.dynamic_net.last_weight.shape) == (11, sk_net.dynamic_net.last[0].in_features) and sh.dynamic_net.out_channels == (4, 4, 3)
+assert (sh.p_degree, sh.t_degree, sh.dynamic_net.skips, sh.dynamic_net.num_layers) == (10, 6, (4,), 8)
+pts, tt = torch.rand(20, 3, generator=g), torch.tensor([0.25])
+# (the reference's own encoder moves its input to a GPU, which this container has not: the routing is checked with markers in the
+# originals' places -- a CPU call must reach the reference's method, not the kernels)
+keep_sk, keep_sp = _ra._originals['sk_net'], _ra._originals['sp_net']
+_ra._originals['sk_net'], _ra._originals['sp_net'] = (lambda *a, **k: 'reference sk'), (lambda *a, **k: 'reference sp')
+assert networks.sk_gs.SimpleDeformationNetwork.forward is _ra.simple_deform_forward and sk_net(pts, tt) == 'reference sk'
+assert _ra.calls['sk_net_reference'] >= 1 and _ra.calls['sk_net_fused'] == 0
+for blender, sep, tdeg in ((True, False, 6), (False, True, 10)):
+    c2 = dict(cfg, pos_enc_t_cfg={{'degree': tdeg}})
+    sp_net = networks.sk_gs.DeformNetwork(D=8, W=256, is_blender=blender, sep_rot=sep, max_d_scale=-1.0, **c2)
+    sh = _ra.sp_net_shadow(sp_net)
+    assert sh is not None and sh.is_blender == blender and sh.sep_rot == sep and sh.kernel_supported()
+    theirs, mine = dict(sp_net.named_parameters()), dict(sh.named_parameters())
+    assert set(theirs) == set(mine) and all(mine[k] is theirs[k] for k in theirs)
+    assert sp_net(pts, tt) == 'reference sp' and _ra.calls['sp_net_fused'] == 0
+assert _ra.sp_net_shadow(networks.sk_gs.DeformNetwork(D=6, W=256, is_blender=True, **cfg)) is None        # not the kernels' shape
+_ra._originals['sk_net'], _ra._originals['sp_net'] = keep_sk, keep_sp
 _ra.restore_reference()
 assert _ssim_mod.SSIM_Loss.forward is orig_ssim and networks.sk_gs.SkeletonGaussianSplatting.kinematic is orig_kin
+assert networks.sk_gs.DeformNetwork.forward is not _ra.deform_network_forward
+assert networks.sk_gs.SkeletonGaussianSplatting.calc_LBS_weight is not _ra.calc_LBS_weight
 print('HOOK-OK')
 """
 

@@ -157,6 +157,40 @@ def main():
     rows.append(('sp 100k x 512: ... skinning expression NOT recognised', *timed(lambda: ref_step(sp))))
     L._FUSED = True
     rows.append(('sp 100k x 512: ... as one hipGraph replay', *timed(graphed(lambda: ref_step(sp)))))
+    # ---- the two deform networks: the modules' own torch forward against accelerate_reference()'s fast paths (modules with the
+    # reference classes' structure: tests/ref_sequence.py; the kernels run on the modules' own parameters)
+    from sk_gs_amd import reference_accel as ra
+    from sk_gs_amd.superpoint import SpDeformNet
+    g = torch.Generator().manual_seed(3)
+    net = rs.RefSimpleDeformationNetwork().to(dev)
+    pts, tt = (torch.rand(20, 3, generator=g) * 2 - 1).to(dev).requires_grad_(), torch.tensor([0.3125], device=dev)
+    cots = [torch.randn(20, n, generator=g).to(dev) for n in (4, 4, 3)]
+    ra._originals['sk_net'] = rs.RefSimpleDeformationNetwork.forward
+
+    def net_step(fwd):
+        for p_ in net.parameters():
+            p_.grad = None
+        pts.grad = None
+        sum((o * c).sum() for o, c in zip(fwd(), cots)).backward()
+    rows.append(('sk_deform_net, 20 joint rows, forward + backward: the module\'s own torch forward', *timed(lambda: net_step(lambda: net(pts, tt)))))
+    rows.append(('sk_deform_net: ... through accelerate_reference() (one launch per direction)',
+                 *timed(lambda: net_step(lambda: ra.simple_deform_forward(net, pts, tt)))))
+    sp_net = SpDeformNet()
+    sp_net.pos_enc_p, sp_net.pos_enc_t, sp_net.max_d_scale = rs.RefFreqEncoder(3, 10), rs.RefFreqEncoder(1, 6), -1.0
+    sp_net = sp_net.to(dev)
+    ra._originals['sp_net'] = lambda self, x, t, **kw: self.reference_forward(x, t)
+    x512 = (torch.rand(512, 3, generator=g) * 2 - 1).to(dev)
+    cot = {k: torch.randn(512, n, generator=g).to(dev) for k, n in (('d_xyz', 3), ('d_rotation', 4), ('d_scaling', 3))}
+
+    def sp_net_step(fwd):
+        for p_ in sp_net.parameters():
+            p_.grad = None
+        out = fwd()
+        sum((out[k] * cot[k]).sum() for k in cot).backward()
+    rows.append(('sp_deform_net, 512 superpoints, forward + backward: the module\'s own torch forward',
+                 *timed(lambda: sp_net_step(lambda: sp_net.reference_forward(x512, tt)))))
+    rows.append(('sp_deform_net: ... through accelerate_reference() (MFMA row blocks)',
+                 *timed(lambda: sp_net_step(lambda: ra.deform_network_forward(sp_net, x512, tt)))))
     print(f'{"deform forward + backward":92s} {"GPU ms":>8s} {"host ms":>8s}')
     for name, gpu, host in rows:
         print(f'{name:92s} {gpu:8.3f} {host:8.3f}')
