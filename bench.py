@@ -57,7 +57,10 @@ def main(argv=None):
     write_line = claim_stdout()
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
 
-    if args.stage == 'sp':
+    if args.reference_loop:
+        from benchlib import reference_loop
+        write_line(reference_loop.run(args, CONFIGS))
+    elif args.stage == 'sp':
         from benchlib import sp_stage
         line = sp_stage.run(args, alg_bytes, CONFIGS)
         if line is not None:

@@ -1,0 +1,151 @@
+"""`bench.py --reference-loop hooks | accelerated`: one training iteration AS THE REFERENCE WRITES IT, on this package's hooks.
+
+The GPU box has no /root/reference, so the loop is the reference's call sequence restated (tests/ref_sequence.py -- replayed against
+the reference's own recorded run by tests/test_gpu_lietorch.py -- plus the lines of train.py / gaussian_splatting.py named below), written
+only against what `sk_gs_amd.install_reference_hooks()` puts under an unmodified checkout:
+
+    sk_deform_net(joints, t)                        SimpleDeformationNetwork: torch encoders + MLP_with_skips (sk_gs.py:134-164)
+    kinematic / skeleton_warp_SE3                   lietorch stand-in (sk_gs.py:1069-1107, 193-206)
+    calc_LBS_weight                                 pytorch3d.ops.knn_points stand-in + the reference's gather / softmax lines (:751-774)
+    (sk_T[indices].act(points[:, None]) * w).sum    lietorch stand-in (:1147), d_rot / d_scale blends, the activations (:1192-1203)
+    GaussianRasterizer(settings)(...)               diff_gaussian_rasterization stand-in, wxyz rotations (gaussian_render_origin.py:36-58)
+    0.8 L1 + 0.2 (1 - SSIM)                         SSIM_Loss as torch convolutions (losses/ssim.py:20-62), image_loss.py:6-32
+    loss.backward(); torch.optim.Adam(eps=1e-15).step(); zero_grad(set_to_none)            train.py:179-250, gaussian_splatting.py:443-453
+
+`hooks`: exactly that -- every launch is one the reference's own Python issues (eager, no graph: the sequence holds blocking
+host-to-device copies, `x.new_tensor([...])`).  `accelerated`: the same loop after `sk_gs_amd.accelerate_reference()` -- the five
+methods it patches (network forward, kinematic, calc_LBS_weight, SSIM_Loss.forward) and torch.optim.Adam.step run their fast paths;
+everything else unchanged.
+The number is what a user of the UNMODIFIED reference gets on one MI355X; the package's own trainer (`FusedTrainStep`, the default bench
+line) is the same arithmetic as 12 launches in a graph.
+"""
+import os
+import sys
+import time
+import types
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(args, configs):
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import ref_sequence as rs
+    from sk_gs_amd import _C, lietorch as L, pytorch3d_ops as p3d, reference_accel as ra, scene
+    from sk_gs_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from sk_gs_amd.losses import ssim_loss
+    from sk_gs_amd.skeleton import build_ancestor_table
+    sys.modules.setdefault('lietorch', L)
+    accel = args.reference_loop == 'accelerated'
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    torch.autograd.set_multithreading_enabled(False)
+    _C.load_library()
+    _C.config.sync_num_rendered = True    # the reference's forward blocks on num_rendered (gaussian_rasterizer_forward.cu:209); the hook's default
+    cfg = configs[args.config]
+    P, M, K, W, H = cfg['P'], cfg['M'], cfg['K'], cfg['W'], cfg['H']
+    assert M > 0, '--reference-loop needs a skinned config (1..4)'
+    frames = args.views
+    gs, bones = scene.make_gaussians(P, seed=0, sh_degree=3, scale_mult=args.scale_mult), scene.make_bones(M, seed=0)
+    table, _ = build_ancestor_table(bones['parents'].long(), 0)
+    g = torch.Generator().manual_seed(0)
+    par = lambda t: torch.nn.Parameter(t.clone().to(dev))  # noqa: E731
+    p = dict(_xyz=par(gs['xyz']), _features_dc=par(gs['sh'][:, :1]), _features_rest=par(gs['sh'][:, 1:]), _scaling=par(gs['log_scale']),
+             _rotation=par(gs['rot']), _opacity=par(gs['opacity_logit']), sp_W=par(torch.randn(P, M, generator=g)),
+             joints=par(bones['joints']), global_tr=par(torch.tensor([[0., 0, 0, 0, 0, 0, 1]]).repeat(frames, 1)))
+    torch.manual_seed(1)
+    net = rs.RefSimpleDeformationNetwork().to(dev)
+    with torch.no_grad():   # (a trained network's output sizes, as the default bench line's model has them)
+        for h, s in zip(net.dynamic_net.last, (0.2, 1e-2, 1e-3)):
+            h.weight.normal_(0, s / 16.)
+    if accel and 'adam' not in ra._originals:   # (what accelerate_reference(adam=True) does)
+        ra._originals['adam'] = torch.optim.Adam.step
+        torch.optim.Adam.step = ra.adam_step
+    lr = args.lr
+    opt = torch.optim.Adam([
+        {'params': [p['_xyz']], 'lr': lr * 0.16, 'name': 'xyz'}, {'params': [p['_features_dc']], 'lr': lr * 2.5, 'name': 'f_dc'},
+        {'params': [p['_features_rest']], 'lr': lr * 2.5 / 20, 'name': 'f_rest'}, {'params': [p['_opacity']], 'lr': lr * 50., 'name': 'opacity'},
+        {'params': [p['_scaling']], 'lr': lr * 5.0, 'name': 'scaling'}, {'params': [p['_rotation']], 'lr': lr, 'name': 'rotation'},
+        {'params': [p['sp_W']], 'lr': lr, 'name': 'sp_W'}, {'params': [p['global_tr']], 'lr': lr, 'name': 'skinning'},
+        {'params': list(net.parameters()), 'lr': lr, 'name': 'deform_net'}, {'params': [p['joints']], 'lr': lr * 0.1, 'name': 'joints'},
+    ], lr=0.0, eps=1e-15)
+    times = torch.linspace(0., 1., frames, device=dev).view(frames, 1)
+    bg = torch.ones(3, device=dev)
+    settings = []
+    for v in range(args.views):
+        r = scene.raster_settings_from_camera(scene.make_camera(W, H, seed=v), sh_degree=3, colmap=True, device=dev)
+        settings.append(GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=r.tanfovx, tanfovy=r.tanfovy, bg=bg, scale_modifier=1.0, viewmatrix=r.viewmatrix,
+            projmatrix=r.projmatrix, sh_degree=3, campos=r.campos, prefiltered=False, debug=False))
+    # a stand-in `self` for the two patched methods of SkeletonGaussianSplatting (what tests/test_gpu_lietorch.py uses)
+    me = types.SimpleNamespace(training=True, test_time_interpolate=False, sk_feature=None, _R_dim=4, joint_parents=table.to(dev).int(),
+                               joint_root=torch.tensor(0), sk_cache=torch.zeros(frames, M, 11, device=dev), num_knn=K, _sp_radius=None,
+                               _sp_weight=None, sp_W=p['sp_W'], sk_is_init=torch.tensor(True),
+                               sk_deform_net=lambda x, t: ra.simple_deform_forward(net, x, t))
+    if accel:
+        ra._originals.setdefault('sk_net', rs.RefSimpleDeformationNetwork.forward)
+    ssim_self = types.SimpleNamespace(window_size=11, reduction='mean')
+
+    def deform(v):
+        points = p['_xyz'].detach()
+        a = dict(p, time_id=torch.tensor(v), parents_table=table.to(dev), root=torch.tensor(0))
+        if not accel:
+            a['net_sk_r'], a['net_d_rot'], a['net_d_scale'] = net(p['joints'], times[v])
+            return rs.sk_stage(L, p3d.knn_points, a, K)
+        sk_T, sk_d_rot, sk_d_scale = ra.kinematic(me, p['joints'], times[v], p['global_tr'][v].view(-1), v, None)
+        w, idx = ra.calc_LBS_weight(me, points, p['joints'])
+        d_xyz = (sk_T[idx].act(points[:, None]) * w[..., None]).sum(dim=1) - points
+        return rs._activate(a, d_xyz, (sk_d_rot[idx] * w[..., None]).sum(dim=1), (sk_d_scale[idx] * w[..., None]).sum(dim=1))
+
+    def render(v, res):
+        means2D = torch.zeros_like(res['points'], requires_grad=True)                     # gaussian_splatting.py: screenspace_points
+        shs = torch.cat([p['_features_dc'], p['_features_rest']], dim=1)
+        img, _ = GaussianRasterizer(settings[v])(means3D=res['points'], means2D=means2D, opacities=res['opacity'], shs=shs,
+                                                 scales=res['scales'], rotations=res['rotations'][..., (3, 0, 1, 2)])
+        return img
+
+    def loss_of(img, gt):
+        l1 = (img - gt).abs().mean()
+        if accel:
+            ss = ra.ssim_loss_forward(ssim_self, img, gt)
+        else:
+            ss = ssim_loss(img, gt)
+        return 0.8 * l1 + 0.2 * ss
+
+    ra._originals.setdefault('ssim', lambda self, a, b: ssim_loss(a, b))
+    with torch.no_grad():
+        gen = torch.Generator().manual_seed(77)
+        targets = [(render(v, deform(v)) + 0.05 * torch.randn(3, H, W, generator=gen).to(dev)).clamp(0, 1) for v in range(args.views)]
+
+    def step(i):
+        v = i % args.views
+        opt.zero_grad(set_to_none=True)
+        loss = loss_of(render(v, deform(v)), targets[v])
+        loss.backward()
+        opt.step()
+        return loss
+
+    for i in range(max(args.warmup, 5)):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = step(args.warmup + i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = 1e3 * elapsed / args.steps
+    return {
+        'metric': f"train iters/sec of the REFERENCE's own call sequence on the hooks ({args.reference_loop}), {P // 1000}k Gaussians @{W}x{H}",
+        'value': round(args.steps / elapsed, 3), 'unit': 'iters/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': max(args.warmup, 5),
+        'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'{cfg["name"]}: {P} Gaussians, {M} bones, K={K}, SH degree 3, {W}x{H}, {args.views} synthetic views',
+                   'step': ("the reference's call sequence restated (tests/ref_sequence.py + train.py:179-250) on install_reference_hooks() alone: "
+                            "torch network, lietorch / pytorch3d stand-ins, diff_gaussian_rasterization stand-in, torch SSIM, torch.optim.Adam; eager"
+                            if not accel else
+                            "the same loop after accelerate_reference(): network forward, kinematic, calc_LBS_weight and SSIM_Loss.forward on "
+                            "their fast paths, torch.optim.Adam.step as one launch (sk_gs_amd.reference_accel); rasterizer stand-in unchanged; eager"),
+                   'loss_last': float(last.detach()), 'sync_num_rendered': bool(_C.config.sync_num_rendered), 'accelerators': dict(ra.calls) if accel else None,
+                   'lie_fused_calls': dict(L.fused_calls), 'knn_hip_calls': dict(p3d.hip_calls)},
+    }

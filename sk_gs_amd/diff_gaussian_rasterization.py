@@ -51,7 +51,8 @@ class GaussianRasterizer(nn.Module):
             scale_modifier=s.scale_modifier, viewmatrix=s.viewmatrix, projmatrix=s.projmatrix, sh_degree=s.sh_degree,
             campos=s.campos, prefiltered=s.prefiltered, debug=s.debug, detach_other_extra=False, colmap=True)
         if rotations is not None:
-            rotations = rotations[..., (1, 2, 3, 0)]  # (w, x, y, z) -> (x, y, z, w)
+            # (w, x, y, z) -> (x, y, z, w) as two slices: the backward of an index list is torch's sort-based index_put (0.3 ms for 100k rows)
+            rotations = torch.cat([rotations[..., 1:], rotations[..., :1]], dim=-1)
         color, opacity, _, radii, _, _ = _gr.GaussianRasterizer(inner)(
             means3D=means3D, means2D=means2D, opacities=opacities, shs=shs, colors_precomp=colors_precomp, scales=scales,
             rotations=rotations, cov3D_precomp=cov3D_precomp)

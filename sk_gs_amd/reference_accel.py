@@ -3,7 +3,7 @@
     import sk_gs_amd
     sk_gs_amd.install_reference_hooks()          # before `import networks`: the compiled ops and the two third-party stand-ins
     import networks, train
-    sk_gs_amd.accelerate_reference()             # after: five methods of the reference's classes get a fast path
+    sk_gs_amd.accelerate_reference()             # after: five methods of the reference's classes (+ torch.optim.Adam.step) get a fast path
 
 ``install_reference_hooks`` makes the reference RUN on an MI355X; with it alone five pieces of its training step are still long chains
 of small torch launches.  ``accelerate_reference`` replaces exactly those methods -- same arguments, same returned objects, and a
@@ -33,6 +33,11 @@ call that does not match the fast path's conditions is handed to the reference's
 * ``networks.sk_gs.SkeletonGaussianSplatting.calc_LBS_weight`` (sk_gs.py:751-774) -> ``sk_gs_amd.deform.calc_lbs_weight``: the search
   and the weighting (kernel / weighted kernel / `W` logits / distance softmax, 3 or 3 + 8 search dimensions) as one launch per direction.
 
+* ``torch.optim.Adam.step`` (the optimizer the reference builds, gaussian_splatting.py:443-460: ten parameter groups, ``eps=1e-15``) ->
+  ONE launch of ``skgs_adam_step_range`` over a descriptor table of the optimizer's OWN state tensors (the reference's per-parameter
+  state surgery keeps working); torch's foreach form is ~80 launches per step for those groups.  The one patch outside the reference's
+  classes: ``accelerate_reference(adam=False)`` leaves torch alone.
+
 The reference's files are not touched; ``restore_reference()`` puts the original methods back.
 """
 from __future__ import annotations
@@ -46,7 +51,7 @@ import torch.nn.functional as F
 
 _originals = {}
 calls = {'ssim_fused': 0, 'ssim_reference': 0, 'kinematic_fused': 0, 'kinematic_reference': 0, 'sk_net_fused': 0, 'sk_net_reference': 0,
-         'sp_net_fused': 0, 'sp_net_reference': 0, 'lbs_weight_fused': 0, 'lbs_weight_reference': 0}  # counters (tests)
+         'sp_net_fused': 0, 'sp_net_reference': 0, 'lbs_weight_fused': 0, 'lbs_weight_reference': 0, 'adam_fused': 0, 'adam_reference': 0}  # counters (tests)
 
 
 # ------------------------------------------------------------------------------------------------ SSIM_Loss.forward
@@ -266,8 +271,120 @@ def calc_LBS_weight(self, points, sp_points, feature=None, sp_feature=None, K=No
     return weights, indices
 
 
+# ------------------------------------------------------------------------------------------------ torch.optim.Adam.step
+class _AdamRunner:
+    """the device descriptor table of ONE torch.optim.Adam instance for ``skgs_adam_step_range`` (include/skgs.h): built from the
+    optimizer's OWN state tensors -- ``state[p]['exp_avg'] / ['exp_avg_sq']`` stay where torch keeps them, so the reference's optimizer
+    surgery (gaussian_splatting.py: replace / cat / prune the state per parameter) keeps working -- re-built when any address or size
+    changes, the learning rates refreshed (pinned staging, asynchronous copy) when a group's ``lr`` changes"""
+
+    def __init__(self, dev):
+        import ctypes as C
+        from sk_gs_amd import _C
+        self.C, self._C, self.lib = C, _C, _C.load_library()
+        self.lib.skgs_adam_state_bytes.restype = C.c_size_t
+        self.lib.skgs_adam_chunk_elems.restype = C.c_int64
+        self.chunk = int(self.lib.skgs_adam_chunk_elems())
+        self.dev = dev
+        self.state = torch.zeros(int(self.lib.skgs_adam_state_bytes()) // 4, dtype=torch.float32, device=dev)
+        self.key = self.lrs = self.table = self.pin = self.event = None
+        self.count = None
+        self.n = self.chunks = 0
+
+    def _copy(self, dst, blob):
+        n = len(blob)
+        if self.pin is None or self.pin.numel() < n:
+            self.pin, self.event = torch.empty(max(n, 4096), dtype=torch.uint8, pin_memory=True), None
+        if self.event is not None:
+            self.event.synchronize()
+        self.pin[:n].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        dst[:n].copy_(self.pin[:n], non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def step(self, entries, lrs, beta1, beta2, eps, count):
+        """entries: [(param, grad, exp_avg, exp_avg_sq)] in table order, lrs: one per entry, count: steps taken so far (all equal)"""
+        import struct
+        key = tuple((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()) for p, g, m, v in entries)
+        if key != self.key or lrs != self.lrs:
+            blob, chunk0 = bytearray(), 0
+            for (p, g, m, v), lr in zip(entries, lrs):
+                blob += struct.pack('<QQQQqqfi', p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), chunk0, float(lr), 0)
+                chunk0 += (p.numel() + self.chunk - 1) // self.chunk
+            if self.table is None or self.table.numel() < len(blob):
+                self.table = torch.zeros(len(blob), dtype=torch.uint8, device=self.dev)
+            self._copy(self.table, blob)
+            self.key, self.lrs, self.n, self.chunks = key, list(lrs), len(entries), chunk0
+        if count != self.count:   # first fused step, or torch's own step ran in between: the counter and 1 - beta^count re-derived
+            import struct as _s
+            blob = _s.pack('<ffdd', float(count), 0.0, 1.0 - beta1 ** count, 1.0 - beta2 ** count)
+            self.state.zero_()
+            self._copy(self.state.view(torch.uint8), blob)
+        C = self.C
+        self._C._check(self.lib.skgs_adam_step_range(
+            C.c_int32(self.n), C.c_void_p(self.table.data_ptr()), C.c_int64(0), C.c_int64(self.chunks), C.c_double(beta1),
+            C.c_double(beta2), C.c_double(eps), C.c_void_p(self.state.data_ptr()), C.c_int32(1), None, C.c_int64(0), self._C._stream()))
+        self.count = count + 1
+
+
+_adam_runners = weakref.WeakKeyDictionary()
+
+
+def adam_step(self, closure=None):
+    """``torch.optim.Adam.step`` as ONE launch over every parameter (torch's foreach form: ~8 launches per parameter GROUP, 80 per step
+    for the reference's ten groups: 0.84 ms of GPU time at config #1) when the optimizer is what the reference builds
+    (gaussian_splatting.py:443-460: plain Adam, ``eps=1e-15``, one ``lr`` per group): dense fp32 parameters on one HIP device, every
+    parameter with a gradient and an initialised state, every state at the same step count, no amsgrad / weight decay / maximize /
+    capturable / differentiable.  Anything else -- and the very first step, which creates the state -- is torch's own ``step``."""
+    groups = self.param_groups
+    g0 = groups[0] if groups else None
+    ok = closure is None and g0 is not None and type(self) is torch.optim.Adam
+    entries, lrs, count, dev = [], [], None, None
+    if ok:
+        for g in groups:
+            if (g.get('amsgrad') or g.get('weight_decay', 0) != 0 or g.get('maximize') or g.get('capturable') or g.get('differentiable')
+                    or g['betas'] != g0['betas'] or g['eps'] != g0['eps'] or torch.is_tensor(g['lr'])):
+                ok = False
+                break
+            for p in g['params']:
+                if not p.requires_grad:
+                    continue
+                st = self.state.get(p)
+                gr = p.grad
+                if (gr is None or not st or not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or gr.is_sparse
+                        or not gr.is_contiguous() or gr.dtype != torch.float32 or (dev is not None and p.device != dev)):
+                    ok = False
+                    break
+                c = st['step']
+                c = float(c) if not torch.is_tensor(c) else (float(c) if not c.is_cuda else None)   # (a CPU scalar tensor: torch's default)
+                if c is None or (count is not None and c != count):
+                    ok = False
+                    break
+                count, dev = c, p.device
+                entries.append((p, gr, st['exp_avg'], st['exp_avg_sq']))
+                lrs.append(float(g['lr']))
+            if not ok:
+                break
+    if not ok or not entries:
+        calls['adam_reference'] += 1
+        return _originals['adam'](self, closure)
+    run = _adam_runners.get(self)
+    if run is None or run.dev != dev:
+        run = _adam_runners[self] = _AdamRunner(dev)
+    with torch.no_grad():
+        run.step(entries, lrs, float(g0['betas'][0]), float(g0['betas'][1]), float(g0['eps']), int(count))
+        for g in groups:      # torch's bookkeeping: the per-parameter step counters (CPU scalars)
+            for p in g['params']:
+                st = self.state.get(p)
+                if st and p.requires_grad:
+                    st['step'] += 1
+    calls['adam_fused'] += 1
+    return None
+
+
 # ------------------------------------------------------------------------------------------------ install / restore
-def accelerate_reference(ssim: bool = True, kinematic_chain: bool = True, networks: bool = True, lbs_weights: bool = True) -> list:
+def accelerate_reference(ssim: bool = True, kinematic_chain: bool = True, networks: bool = True, lbs_weights: bool = True,
+                         adam: bool = True) -> list:
     """Patch the methods on the reference's classes (the modules must be imported already).  Returns what was patched."""
     done = []
     if networks:
@@ -289,6 +406,11 @@ def accelerate_reference(ssim: bool = True, kinematic_chain: bool = True, networ
             _originals['lbs_weight'] = mod.SkeletonGaussianSplatting.calc_LBS_weight
             mod.SkeletonGaussianSplatting.calc_LBS_weight = calc_LBS_weight
         done.append('networks.sk_gs.SkeletonGaussianSplatting.calc_LBS_weight')
+    if adam:
+        if 'adam' not in _originals:
+            _originals['adam'] = torch.optim.Adam.step
+            torch.optim.Adam.step = adam_step
+        done.append('torch.optim.Adam.step')
     if ssim:
         mod = sys.modules.get('networks.losses.ssim')
         if mod is None:
@@ -318,5 +440,7 @@ def restore_reference():
         sys.modules['networks.sk_gs'].SimpleDeformationNetwork.forward = _originals.pop('sk_net')
     if 'sp_net' in _originals and 'networks.sk_gs' in sys.modules:
         sys.modules['networks.sk_gs'].DeformNetwork.forward = _originals.pop('sp_net')
+    if 'adam' in _originals:
+        torch.optim.Adam.step = _originals.pop('adam')
     if 'lbs_weight' in _originals and 'networks.sk_gs' in sys.modules:
         sys.modules['networks.sk_gs'].SkeletonGaussianSplatting.calc_LBS_weight = _originals.pop('lbs_weight')

@@ -655,3 +655,59 @@ def test_device_lr_schedule_reaches_every_kind_of_update_piece():
         got = run(mode)
         assert rel_err(got[0], ref[0]) <= 5e-6 and rel_err(got[1], ref[1]) <= 5e-6, (mode, rel_err(got[0], ref[0]))
     assert torch.equal(run('one')[0], run('pieces')[0])
+
+
+def test_accelerated_torch_adam_step_equals_torch():
+    """accelerate_reference(adam=True): ``torch.optim.Adam.step`` of the optimizer the reference builds (ten groups, eps 1e-15, a rate per
+    group that changes every iteration) as ONE launch over the optimizer's own state tensors -- parameters and both moments against an
+    untouched torch.optim.Adam over six steps, with the reference's kind of state surgery in between (a parameter and its moments
+    replaced by longer tensors, gaussian_splatting.py:cat_tensors_to_optimizer); steps outside the conditions (first step, a missing
+    gradient) are torch's own"""
+    from sk_gs_amd import reference_accel as ra
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(0)
+    shapes = [(5000, 3), (5000, 1, 3), (5000, 15, 3), (5000, 1), (5000, 3), (5000, 4), (5000, 20), (8, 7), (256, 84), (256,), (20, 3)]
+
+    def build():
+        params = [torch.nn.Parameter(torch.randn(*s, generator=torch.Generator().manual_seed(i)).to(dev)) for i, s in enumerate(shapes)]
+        groups = [{'params': [p], 'lr': 1e-3 * (1 + i), 'name': f'g{i}'} for i, p in enumerate(params[:8])]
+        groups.append({'params': params[8:10], 'lr': 1e-4, 'name': 'net'})
+        groups.append({'params': params[10:], 'lr': 1e-5, 'name': 'joints'})
+        return params, torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+    pa, oa = build()
+    pb, ob = build()
+    original = torch.optim.Adam.step
+    before = dict(ra.calls)
+    try:
+        ra._originals['adam'] = original
+        for it in range(6):
+            grads = [torch.randn(p.shape, generator=g).to(dev) * (1e-3 if it % 2 else 1.0) for p in pa]
+            for p, q, gr in zip(pa, pb, grads):
+                p.grad, q.grad = gr.clone(), gr.clone()
+            if it == 4:
+                pa[3].grad = pb[3].grad = None       # a parameter without a gradient this step: torch's own step on both sides
+            for o in (oa, ob):
+                o.param_groups[0]['lr'] = 1e-3 * 0.9 ** it      # update_learning_rate (train.py:140-141)
+            ra.adam_step(oa)
+            original(ob)
+            if it == 2:   # densification: parameter 0 and its state grow (the optimizer's state dict is edited in place, as the reference does)
+                for params, o in ((pa, oa), (pb, ob)):
+                    old = params[0]
+                    st = o.state.pop(old)
+                    new = torch.nn.Parameter(torch.cat([old.detach(), torch.ones(100, 3, device=dev)]))
+                    st['exp_avg'] = torch.cat([st['exp_avg'], torch.zeros(100, 3, device=dev)])
+                    st['exp_avg_sq'] = torch.cat([st['exp_avg_sq'], torch.zeros(100, 3, device=dev)])
+                    o.param_groups[0]['params'] = [new]
+                    o.state[new] = st
+                    params[0] = new
+        torch.cuda.synchronize()
+    finally:
+        ra._originals.pop('adam', None)
+    # (step 0 creates the state; from step 4 on one parameter's counter is behind the others: torch's own step serves both)
+    assert ra.calls['adam_fused'] - before['adam_fused'] == 3 and ra.calls['adam_reference'] - before['adam_reference'] == 3
+    for i, (p, q) in enumerate(zip(pa, pb)):
+        assert p.shape == q.shape
+        assert rel_err(p, q) <= 2e-6, (i, rel_err(p, q))
+        sa, sb = oa.state[p], ob.state[q]
+        assert float(sa['step']) == float(sb['step'])
+        assert rel_err(sa['exp_avg'], sb['exp_avg']) <= 2e-6 and rel_err(sa['exp_avg_sq'], sb['exp_avg_sq']) <= 2e-6

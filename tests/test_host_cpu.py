@@ -178,7 +178,14 @@ orig_ssim, orig_kin = _ssim_mod.SSIM_Loss.forward, networks.sk_gs.SkeletonGaussi
 assert sorted(sk_gs_amd.accelerate_reference()) == ['networks.losses.ssim.SSIM_Loss.forward', 'networks.sk_gs.DeformNetwork.forward',
                                                      'networks.sk_gs.SimpleDeformationNetwork.forward',
                                                      'networks.sk_gs.SkeletonGaussianSplatting.calc_LBS_weight',
-                                                     'networks.sk_gs.SkeletonGaussianSplatting.kinematic']
+                                                     'networks.sk_gs.SkeletonGaussianSplatting.kinematic', 'torch.optim.Adam.step']
+assert torch.optim.Adam.step is _ra.adam_step
+# (the optimizer on CPU parameters: torch's own step, same numbers)
+_w = torch.nn.Parameter(torch.ones(4))
+_o = torch.optim.Adam([_w], lr=0.1, eps=1e-15)
+_w.grad = torch.full((4,), 2.0)
+_o.step(); _o.step()
+assert _ra.calls['adam_fused'] == 0 and _ra.calls['adam_reference'] == 2 and abs(float(_w[0]) - 0.8) < 1e-6
 assert networks.sk_gs.SkeletonGaussianSplatting.calc_LBS_weight is _ra.calc_LBS_weight
 assert _ssim_mod.SSIM_Loss.forward is _ra.ssim_loss_forward and networks.sk_gs.SkeletonGaussianSplatting.kinematic is _ra.kinematic
 g = torch.Generator().manual_seed(0)
@@ -214,6 +221,7 @@ _ra.restore_reference()
 assert _ssim_mod.SSIM_Loss.forward is orig_ssim and networks.sk_gs.SkeletonGaussianSplatting.kinematic is orig_kin
 assert networks.sk_gs.DeformNetwork.forward is not _ra.deform_network_forward
 assert networks.sk_gs.SkeletonGaussianSplatting.calc_LBS_weight is not _ra.calc_LBS_weight
+assert torch.optim.Adam.step is not _ra.adam_step
 print('HOOK-OK')
 """
 
