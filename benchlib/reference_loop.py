@@ -47,6 +47,9 @@ def run(args, configs):
     cfg = configs[args.config]
     P, M, K, W, H = cfg['P'], cfg['M'], cfg['K'], cfg['W'], cfg['H']
     assert M > 0, '--reference-loop needs a skinned config (1..4)'
+    sp = args.stage == 'sp'       # stage sp: 512 superpoints, search over xyz + 8 hyper dimensions, sp_deform_net (sk_gs.py:830-856)
+    if sp:
+        M, K = args.superpoints, args.knn
     frames = args.views
     gs, bones = scene.make_gaussians(P, seed=0, sh_degree=3, scale_mult=args.scale_mult), scene.make_bones(M, seed=0)
     table, _ = build_ancestor_table(bones['parents'].long(), 0)
@@ -56,21 +59,45 @@ def run(args, configs):
              _rotation=par(gs['rot']), _opacity=par(gs['opacity_logit']), sp_W=par(torch.randn(P, M, generator=g)),
              joints=par(bones['joints']), global_tr=par(torch.tensor([[0., 0, 0, 0, 0, 0, 1]]).repeat(frames, 1)))
     torch.manual_seed(1)
-    net = rs.RefSimpleDeformationNetwork().to(dev)
-    with torch.no_grad():   # (a trained network's output sizes, as the default bench line's model has them)
-        for h, s in zip(net.dynamic_net.last, (0.2, 1e-2, 1e-3)):
-            h.weight.normal_(0, s / 16.)
+    if sp:
+        from sk_gs_amd.densify import morton_order
+        from sk_gs_amd.superpoint import SpDeformNet
+        pick = torch.randperm(P, generator=g)[:M]
+        pick = pick[morton_order(gs['xyz'][pick])]
+        for k_ in ('sp_W', 'joints', 'global_tr'):
+            p.pop(k_)
+        p.update(sp_points=par(gs['xyz'][pick]), hyper_feature=par(torch.full((P, 8), -1e-2) + 0.02 * torch.randn(P, 8, generator=g)),
+                 sp_hyper_feature=par(torch.full((M, 8), 1e-2) + 0.02 * torch.randn(M, 8, generator=g)),
+                 _sp_radius=par(torch.full((M,), -1.35)), _sp_weight=par(torch.zeros(M)))
+        # DeformNetwork's structure and parameter names (sk_gs.py:209-315; pinned by tests/golden/sp_deformnet.npz) + the attributes
+        # the accelerator probes on the reference's class
+        net = SpDeformNet()
+        net.pos_enc_p, net.pos_enc_t, net.max_d_scale = rs.RefFreqEncoder(3, 10), rs.RefFreqEncoder(1, 6), -1.0
+        net = net.to(dev)
+        with torch.no_grad():
+            net.gaussian_warp.weight.normal_(0, 2e-3), net.gaussian_rotation.weight.normal_(0, 2e-3), net.gaussian_scaling.weight.normal_(0, 2e-5)
+        ra._originals.setdefault('sp_net', lambda self, x, t, **kw: dict(self.reference_forward(x, t)))
+    else:
+        net = rs.RefSimpleDeformationNetwork().to(dev)
+        with torch.no_grad():   # (a trained network's output sizes, as the default bench line's model has them)
+            for h, s in zip(net.dynamic_net.last, (0.2, 1e-2, 1e-3)):
+                h.weight.normal_(0, s / 16.)
     if accel and 'adam' not in ra._originals:   # (what accelerate_reference(adam=True) does)
         ra._originals['adam'] = torch.optim.Adam.step
         torch.optim.Adam.step = ra.adam_step
     lr = args.lr
-    opt = torch.optim.Adam([
+    groups = [
         {'params': [p['_xyz']], 'lr': lr * 0.16, 'name': 'xyz'}, {'params': [p['_features_dc']], 'lr': lr * 2.5, 'name': 'f_dc'},
         {'params': [p['_features_rest']], 'lr': lr * 2.5 / 20, 'name': 'f_rest'}, {'params': [p['_opacity']], 'lr': lr * 50., 'name': 'opacity'},
-        {'params': [p['_scaling']], 'lr': lr * 5.0, 'name': 'scaling'}, {'params': [p['_rotation']], 'lr': lr, 'name': 'rotation'},
-        {'params': [p['sp_W']], 'lr': lr, 'name': 'sp_W'}, {'params': [p['global_tr']], 'lr': lr, 'name': 'skinning'},
-        {'params': list(net.parameters()), 'lr': lr, 'name': 'deform_net'}, {'params': [p['joints']], 'lr': lr * 0.1, 'name': 'joints'},
-    ], lr=0.0, eps=1e-15)
+        {'params': [p['_scaling']], 'lr': lr * 5.0, 'name': 'scaling'}, {'params': [p['_rotation']], 'lr': lr, 'name': 'rotation'}]
+    if sp:   # get_params of stage sp (sk_gs.py:583-602)
+        groups += [{'params': [p['hyper_feature']], 'lr': lr * 2.5, 'name': 'hyper'}, {'params': list(net.parameters()), 'lr': lr * 0.16, 'name': 'sp_deform'},
+                   {'params': [p['sp_points']], 'lr': lr * 0.16, 'name': 'sp_points'}, {'params': [p['_sp_radius']], 'lr': lr * 0.16, 'name': 'sp_radius'},
+                   {'params': [p['_sp_weight']], 'lr': lr * 0.16, 'name': 'sp_weight'}, {'params': [p['sp_hyper_feature']], 'lr': lr * 2.5, 'name': 'sp_hyper'}]
+    else:
+        groups += [{'params': [p['sp_W']], 'lr': lr, 'name': 'sp_W'}, {'params': [p['global_tr']], 'lr': lr, 'name': 'skinning'},
+                   {'params': list(net.parameters()), 'lr': lr, 'name': 'deform_net'}, {'params': [p['joints']], 'lr': lr * 0.1, 'name': 'joints'}]
+    opt = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
     times = torch.linspace(0., 1., frames, device=dev).view(frames, 1)
     bg = torch.ones(3, device=dev)
     settings = []
@@ -81,14 +108,31 @@ def run(args, configs):
             projmatrix=r.projmatrix, sh_degree=3, campos=r.campos, prefiltered=False, debug=False))
     # a stand-in `self` for the two patched methods of SkeletonGaussianSplatting (what tests/test_gpu_lietorch.py uses)
     me = types.SimpleNamespace(training=True, test_time_interpolate=False, sk_feature=None, _R_dim=4, joint_parents=table.to(dev).int(),
-                               joint_root=torch.tensor(0), sk_cache=torch.zeros(frames, M, 11, device=dev), num_knn=K, _sp_radius=None,
-                               _sp_weight=None, sp_W=p['sp_W'], sk_is_init=torch.tensor(True),
+                               joint_root=torch.tensor(0), sk_cache=torch.zeros(frames, M, 11, device=dev), num_knn=K,
+                               _sp_radius=p.get('_sp_radius'), _sp_weight=p.get('_sp_weight'), sp_W=p.get('sp_W'), sk_is_init=torch.tensor(True),
                                sk_deform_net=lambda x, t: ra.simple_deform_forward(net, x, t))
     if accel:
         ra._originals.setdefault('sk_net', rs.RefSimpleDeformationNetwork.forward)
     ssim_self = types.SimpleNamespace(window_size=11, reduction='mean')
 
+    def deform_sp(v):
+        points = p['_xyz'].detach()
+        if not accel:
+            out = net.reference_forward(p['sp_points'].detach(), times[v])              # the module's own torch forward
+            a = dict(p, net_d_xyz=out['d_xyz'], net_d_rotation=out['d_rotation'], net_d_scaling=out['d_scaling'])
+            return rs.sp_stage(L, p3d.knn_points, a, K, 'LBS', False)
+        me.kernel_radius, me.kernel_weight = torch.exp(p['_sp_radius']), torch.sigmoid(p['_sp_weight'])     # the reference's properties (:548-553)
+        w, idx = ra.calc_LBS_weight(me, points, p['sp_points'], p['hyper_feature'], p['sp_hyper_feature'])
+        out = ra.deform_network_forward(net, p['sp_points'].detach(), times[v])
+        bias = points.new_tensor([0, 0, 0, 1.])                                              # (sk_gs.py:835: the reference's own line)
+        d_rot = F.normalize(out['d_rotation'] + bias, dim=-1)
+        spT = L.SE3.InitFromVec(torch.cat([out['d_xyz'], d_rot], dim=-1))
+        d_points = (spT[idx].act(points[:, None]) * w[..., None]).sum(dim=1) - points
+        return rs._activate(p, d_points, (d_rot[idx] * w[..., None]).sum(dim=1), (out['d_scaling'][idx] * w[..., None]).sum(dim=1))
+
     def deform(v):
+        if sp:
+            return deform_sp(v)
         points = p['_xyz'].detach()
         a = dict(p, time_id=torch.tensor(v), parents_table=table.to(dev), root=torch.tensor(0))
         if not accel:
@@ -140,7 +184,7 @@ def run(args, configs):
         'metric': f"train iters/sec of the REFERENCE's own call sequence on the hooks ({args.reference_loop}), {P // 1000}k Gaussians @{W}x{H}",
         'value': round(args.steps / elapsed, 3), 'unit': 'iters/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': max(args.warmup, 5),
         'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'{cfg["name"]}: {P} Gaussians, {M} bones, K={K}, SH degree 3, {W}x{H}, {args.views} synthetic views',
+        'config': {'workload': f'{cfg["name"]}' + (' in stage sp' if sp else '') + f': {P} Gaussians, {M} ' + ('superpoints (3+8-d search, weighted_kernel)' if sp else 'bones') + f', K={K}, SH degree 3, {W}x{H}, {args.views} synthetic views',
                    'step': ("the reference's call sequence restated (tests/ref_sequence.py + train.py:179-250) on install_reference_hooks() alone: "
                             "torch network, lietorch / pytorch3d stand-ins, diff_gaussian_rasterization stand-in, torch SSIM, torch.optim.Adam; eager"
                             if not accel else

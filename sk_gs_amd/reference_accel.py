@@ -334,7 +334,8 @@ def adam_step(self, closure=None):
     """``torch.optim.Adam.step`` as ONE launch over every parameter (torch's foreach form: ~8 launches per parameter GROUP, 80 per step
     for the reference's ten groups: 0.84 ms of GPU time at config #1) when the optimizer is what the reference builds
     (gaussian_splatting.py:443-460: plain Adam, ``eps=1e-15``, one ``lr`` per group): dense fp32 parameters on one HIP device, every
-    parameter with a gradient and an initialised state, every state at the same step count, no amsgrad / weight decay / maximize /
+    parameter that has a gradient with an initialised state and all of those at the same step count (one without a gradient is
+    skipped, as torch skips it), no amsgrad / weight decay / maximize /
     capturable / differentiable.  Anything else -- and the very first step, which creates the state -- is torch's own ``step``."""
     groups = self.param_groups
     g0 = groups[0] if groups else None
@@ -351,7 +352,9 @@ def adam_step(self, closure=None):
                     continue
                 st = self.state.get(p)
                 gr = p.grad
-                if (gr is None or not st or not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or gr.is_sparse
+                if gr is None:      # (torch skips it too: no update, its step counter stays)
+                    continue
+                if (not st or not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or gr.is_sparse
                         or not gr.is_contiguous() or gr.dtype != torch.float32 or (dev is not None and p.device != dev)):
                     ok = False
                     break
@@ -373,11 +376,8 @@ def adam_step(self, closure=None):
         run = _adam_runners[self] = _AdamRunner(dev)
     with torch.no_grad():
         run.step(entries, lrs, float(g0['betas'][0]), float(g0['betas'][1]), float(g0['eps']), int(count))
-        for g in groups:      # torch's bookkeeping: the per-parameter step counters (CPU scalars)
-            for p in g['params']:
-                st = self.state.get(p)
-                if st and p.requires_grad:
-                    st['step'] += 1
+        for p, _, _, _ in entries:      # torch's bookkeeping: the per-parameter step counters (CPU scalars)
+            self.state[p]['step'] += 1
     calls['adam_fused'] += 1
     return None
 

@@ -263,13 +263,14 @@ def test_stage_sp_two_ranks_share_the_gpu_and_stay_identical():
     assert abs(d['value'] - 2 * 1000.0 / d['ms_per_step']) / d['value'] < 0.01
 
 
-def test_reference_loop_runs_on_the_hooks_and_accelerated_with_the_same_training():
+@pytest.mark.parametrize('stage', ['sk', 'sp'])
+def test_reference_loop_runs_on_the_hooks_and_accelerated_with_the_same_training(stage):
     """`bench.py --reference-loop hooks | accelerated` (benchlib/reference_loop.py): the reference's whole iteration restated on the hooks
     alone and after accelerate_reference() -- one JSON line each, every accelerator used on every step of the second run, the same loss
     after the same steps (different arithmetic paths, same training), and the accelerated loop faster"""
     out = {}
     for mode in ('hooks', 'accelerated'):
-        p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--reference-loop', mode, '--steps', '12', '--warmup', '5'],
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--stage', stage, '--reference-loop', mode, '--steps', '12', '--warmup', '5'],
                            capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert p.returncode == 0, p.stderr[-2000:]
         lines = [l for l in p.stdout.splitlines() if l.strip()]
@@ -278,7 +279,7 @@ def test_reference_loop_runs_on_the_hooks_and_accelerated_with_the_same_training
     h, a = out['hooks'], out['accelerated']
     assert h['config']['accelerators'] is None and h['config']['lie_fused_calls']['forward'] >= 17     # the recognised skinning expression
     c = a['config']['accelerators']
-    for k in ('ssim', 'kinematic', 'sk_net', 'lbs_weight'):
+    for k in ('ssim', 'lbs_weight') + (('kinematic', 'sk_net') if stage == 'sk' else ('sp_net',)):
         assert c[f'{k}_fused'] >= 17 and c[f'{k}_reference'] == 0, (k, c)
     assert c['adam_fused'] >= 16 and c['adam_reference'] == 1           # (the first step creates torch's state)
     assert abs(h['config']['loss_last'] - a['config']['loss_last']) <= 2e-3 * abs(h['config']['loss_last'])

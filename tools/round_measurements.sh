@@ -77,6 +77,10 @@ for m in hooks accelerated; do
   timeout -k 5 300 python bench.py --reference-loop $m --steps 100 --warmup 10 2>/dev/null | tail -1 > $out/bench_reference-loop_$m.json
   python -c "import json; d=json.load(open('$out/bench_reference-loop_$m.json')); print('reference loop, $m', d['value'], d['ms_per_step'], d['config']['loss_last'])"
 done
+for m in hooks accelerated; do
+  timeout -k 5 300 python bench.py --stage sp --reference-loop $m --steps 100 --warmup 10 2>/dev/null | tail -1 > $out/bench_stage_sp_reference-loop_$m.json
+  python -c "import json; d=json.load(open('$out/bench_stage_sp_reference-loop_$m.json')); print('reference loop, stage sp, $m', d['value'], d['ms_per_step'], d['config']['loss_last'])"
+done
 timeout -k 5 200 python tools/time_reference_sequence.py 2>/dev/null | grep -v "not capturable" > $out/time_reference_sequence.txt; cat $out/time_reference_sequence.txt
 timeout -k 5 300 python tools/round_latency_sweep.py 2>/dev/null | grep -v amdgpu > $out/round_latency_sweep.txt; cat $out/round_latency_sweep.txt
 timeout -k 5 300 python tools/ppl_sweep.py 2>/dev/null | grep ppl > $out/ppl_sweep.txt; cat $out/ppl_sweep.txt
