@@ -147,7 +147,7 @@ def run(args, configs):
         means2D = torch.zeros_like(res['points'], requires_grad=True)                     # gaussian_splatting.py: screenspace_points
         shs = torch.cat([p['_features_dc'], p['_features_rest']], dim=1)
         img, _ = GaussianRasterizer(settings[v])(means3D=res['points'], means2D=means2D, opacities=res['opacity'], shs=shs,
-                                                 scales=res['scales'], rotations=res['rotations'][..., (3, 0, 1, 2)])
+                                                 scales=res['scales'], rotations=(ra.QuatXYZW.wrap(res['rotations']) if accel else res['rotations'])[..., (3, 0, 1, 2)])   # the adapter's swizzle (gaussian_render_origin.py:41-42)
         return img
 
     def loss_of(img, gt):

@@ -142,7 +142,7 @@ def install_reference_hooks(single_thread: bool = True):
 
 
 def accelerate_reference(ssim: bool = True, kinematic_chain: bool = True, networks: bool = True, lbs_weights: bool = True,
-                         adam: bool = True) -> list:
+                         adam: bool = True, swizzle: bool = True) -> list:
     """AFTER the reference has been imported (``install_reference_hooks()`` before it): give methods of its classes a fast path --
     ``SSIM_Loss.forward`` (3.5 ms of depth-wise convolutions per image -> the fused loss kernels),
     ``SkeletonGaussianSplatting.kinematic`` (~60 Lie-group launches -> one bone-chain launch per direction),
@@ -152,7 +152,7 @@ def accelerate_reference(ssim: bool = True, kinematic_chain: bool = True, networ
     optimizer's own state tensors instead of ~80; ``adam=False`` leaves torch alone).  Same arguments, same returned objects, the reference's
     own method for every call outside the fast path's conditions; ``sk_gs_amd.reference_accel``."""
     from sk_gs_amd import reference_accel
-    return reference_accel.accelerate_reference(ssim=ssim, kinematic_chain=kinematic_chain, networks=networks, lbs_weights=lbs_weights, adam=adam)
+    return reference_accel.accelerate_reference(ssim=ssim, kinematic_chain=kinematic_chain, networks=networks, lbs_weights=lbs_weights, adam=adam, swizzle=swizzle)
 
 
 def install_as_diff_gaussian_rasterization(single_thread: bool = True):

@@ -175,11 +175,17 @@ import torch
 from networks.losses import ssim as _ssim_mod
 from sk_gs_amd import reference_accel as _ra
 orig_ssim, orig_kin = _ssim_mod.SSIM_Loss.forward, networks.sk_gs.SkeletonGaussianSplatting.kinematic
-assert sorted(sk_gs_amd.accelerate_reference()) == ['networks.losses.ssim.SSIM_Loss.forward', 'networks.sk_gs.DeformNetwork.forward',
+assert sorted(sk_gs_amd.accelerate_reference()) == ['networks.losses.ssim.SSIM_Loss.forward', 'networks.renderer.gaussian_render_origin.render_gs_offical',
+                                                     'networks.sk_gs.DeformNetwork.forward',
                                                      'networks.sk_gs.SimpleDeformationNetwork.forward',
                                                      'networks.sk_gs.SkeletonGaussianSplatting.calc_LBS_weight',
                                                      'networks.sk_gs.SkeletonGaussianSplatting.kinematic', 'torch.optim.Adam.step']
 assert torch.optim.Adam.step is _ra.adam_step
+import networks.renderer.gaussian_render_origin as _gro
+assert _gro.render_gs_offical is _ra.render_gs_offical and networks.gaussian_splatting.render_gs_offical is _ra.render_gs_offical
+_q = torch.randn(6, 4, requires_grad=True)
+_sw = _ra.QuatXYZW.wrap(_q)[..., (3, 0, 1, 2)]          # the adapter's own expression on typed rotations: same values, slices behind it
+assert type(_sw) is torch.Tensor and torch.equal(_sw, _q[..., (3, 0, 1, 2)]) and 'Cat' in type(_sw.grad_fn).__name__
 # (the optimizer on CPU parameters: torch's own step, same numbers)
 _w = torch.nn.Parameter(torch.ones(4))
 _o = torch.optim.Adam([_w], lr=0.1, eps=1e-15)
@@ -222,6 +228,7 @@ assert _ssim_mod.SSIM_Loss.forward is orig_ssim and networks.sk_gs.SkeletonGauss
 assert networks.sk_gs.DeformNetwork.forward is not _ra.deform_network_forward
 assert networks.sk_gs.SkeletonGaussianSplatting.calc_LBS_weight is not _ra.calc_LBS_weight
 assert torch.optim.Adam.step is not _ra.adam_step
+assert _gro.render_gs_offical is not _ra.render_gs_offical and networks.gaussian_splatting.render_gs_offical is _gro.render_gs_offical
 print('HOOK-OK')
 """
 
