@@ -139,6 +139,7 @@ def install_reference_hooks(single_thread: bool = True):
     install_as_diff_gaussian_rasterization(single_thread=single_thread)
     install_as_lietorch()
     install_as_pytorch3d()
+    return ['my_ext._C._C', 'diff_gaussian_rasterization', 'lietorch', 'pytorch3d.ops']
 
 
 def accelerate_reference(ssim: bool = True, kinematic_chain: bool = True, networks: bool = True, lbs_weights: bool = True,
@@ -149,7 +150,8 @@ def accelerate_reference(ssim: bool = True, kinematic_chain: bool = True, networ
     ``SkeletonGaussianSplatting.calc_LBS_weight`` (search + weighting -> one launch per direction) and the two deform
     networks' ``forward`` (``SimpleDeformationNetwork`` -> the one-launch 20-row network kernels, ``DeformNetwork`` -> the MFMA
     row-block kernels; both on the reference modules' OWN parameter objects) -- and ``torch.optim.Adam.step`` (one launch over the
-    optimizer's own state tensors instead of ~80; ``adam=False`` leaves torch alone).  Same arguments, same returned objects, the reference's
+    optimizer's own state tensors instead of ~80; ``adam=False`` leaves torch alone) and the rasterizer adapter's quaternion swizzle (two
+    slices instead of an index list: call this BEFORE the model is built).  Same arguments, same returned objects, the reference's
     own method for every call outside the fast path's conditions; ``sk_gs_amd.reference_accel``."""
     from sk_gs_amd import reference_accel
     return reference_accel.accelerate_reference(ssim=ssim, kinematic_chain=kinematic_chain, networks=networks, lbs_weights=lbs_weights, adam=adam, swizzle=swizzle)

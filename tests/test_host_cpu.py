@@ -247,6 +247,25 @@ def test_unmodified_reference_imports_through_the_hook():
     assert r.returncode == 0 and 'HOOK-OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
+@pytest.mark.skipif(not os.path.isdir(_REFERENCE), reason='the reference is only mounted in the build container')
+def test_example_launcher_imports_the_reference_train_module_and_patches_it():
+    """examples/reference_with_hooks.py --check: the reference's own ``train.py`` -- the whole import chain of its entry point: my_ext,
+    networks, data_loader, datasets -- is imported UNMODIFIED on the hooks and the seven accelerators are applied (a child process; the
+    generic third-party packages this image lacks -- plyfile, cv2, ... -- are the inert stubs of tests/golden/make_golden.py, the four
+    packages of the hot path resolve to this package)"""
+    code = ("import sys, runpy, warnings; sys.dont_write_bytecode = True; sys.path[:0] = [%r, %r]; import make_golden; "
+            "sys.meta_path.insert(0, make_golden._Finder()); warnings.simplefilter('ignore'); "
+            "sys.argv = ['reference_with_hooks.py', %r, '--check']; "
+            "runpy.run_path(%r, run_name='__main__')" % (ROOT, os.path.join(ROOT, 'tests', 'golden'), _REFERENCE,
+                                                        os.path.join(ROOT, 'examples', 'reference_with_hooks.py')))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd='/tmp', env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'),
+                       timeout=600)
+    assert r.returncode == 0 and 'REFERENCE-READY' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    for name in ('my_ext._C._C', 'diff_gaussian_rasterization', 'lietorch', 'pytorch3d.ops', 'SSIM_Loss.forward', 'kinematic', 'calc_LBS_weight',
+                 'SimpleDeformationNetwork.forward', 'DeformNetwork.forward', 'render_gs_offical', 'torch.optim.Adam.step'):
+        assert name in r.stdout, name
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, 'sk_gs_amd')
     for dirpath, _, files in os.walk(pkg):
