@@ -125,7 +125,8 @@ __global__ void __launch_bounds__(256) scatter_kernel(int P, int gx, int gy, con
 // memory once per non-empty bin: ~BIN_GROUPS x T global atomics instead of R.
 constexpr int BIN_LDS_TILES = 8192;
 constexpr int BIN_THREADS   = 1024;
-constexpr int BIN_GROUPS    = 256;  // one per CU (measured: 48 -> 82 us, 256 -> 42 us for count + scatter); SKGS_BIN_GROUPS overrides
+constexpr int BIN_GROUPS    = 512;  // two per CU (measured: 48 -> 82 us, 256 -> 42 us for count + scatter; round 5, 8 alternating bench
+                                    // runs each: 256 0.3470 ms per step, 512 0.3461, 768 / 1024 the same); SKGS_BIN_GROUPS overrides
 static int bin_groups() {
   static int v = [] {
     const char* e = getenv("SKGS_BIN_GROUPS");
