@@ -180,7 +180,9 @@ typedef struct skgs_raster_grads {
   const float* grad_means2D_in; /* [P,3] */
   const float* grad_conic_in;   /* [P,2,2] */
   const float* grad_opacity_in; /* [P,1] */
-  /* outputs, all written completely (rows of culled Gaussians are zero) */
+  /* outputs, all written completely (rows of culled Gaussians are zero).  With deform_backward_job / sp_skinning_job attached,
+   * dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dscales and dL_drotations may each be NULL: the job takes those gradients over
+   * in registers (80 bytes per Gaussian less to write) */
   float* dL_dmeans2D;   /* [P,3]  (NDC-scaled, z = 0) */
   float* dL_dconic;     /* [P,2,2] or NULL */
   float* dL_dcolors;    /* [P,3] */

@@ -210,8 +210,10 @@ int skgs_rasterize_backward(const skgs_raster_inputs* in, const skgs_raster_buff
   }
   SKGS_REQUIRE(radii && out_opacity, "radii / out_opacity are required");
   SKGS_REQUIRE(gr->dL_dout_color, "dL_dout_color is required");
-  SKGS_REQUIRE(gr->dL_dmeans2D && gr->dL_dcolors && gr->dL_dopacity && gr->dL_dmeans3D && gr->dL_dcov3D &&
-                   gr->dL_dscales && gr->dL_drotations,
+  // (with a job attached the per-Gaussian gradients it consumes in registers need no array: any of them may be NULL)
+  SKGS_REQUIRE(gr->dL_dmeans2D && ((gr->deform_backward_job || gr->sp_skinning_job) ||
+                                      (gr->dL_dcolors && gr->dL_dopacity && gr->dL_dmeans3D && gr->dL_dcov3D && gr->dL_dscales &&
+                                          gr->dL_drotations)),
       "gradient outputs are required");
   SKGS_REQUIRE(!(in->sh && in->sh_coeffs > 0) || gr->dL_dsh || gr->dL_dsh_factors,
       "dL_dsh (or dL_dsh_factors) is required when sh is given");

@@ -763,8 +763,9 @@ __global__ void __launch_bounds__(PRE_BWD_THREADS) preprocess_backward_kernel(in
     dL_dconic_out[4 * idx + 2] = gin_conic ? gin_conic[4 * idx + 2] : 0.f;
     dL_dconic_out[4 * idx + 3] = gcon[2];
   }
-  dL_dopacity[idx] = gop;
-  dL_dcolors[3 * idx] = gcol[0], dL_dcolors[3 * idx + 1] = gcol[1], dL_dcolors[3 * idx + 2] = gcol[2];
+  // (NULL with a job attached: the job takes these per-Gaussian gradients over in registers, nobody reads the arrays)
+  if (dL_dopacity) dL_dopacity[idx] = gop;
+  if (dL_dcolors) dL_dcolors[3 * idx] = gcol[0], dL_dcolors[3 * idx + 1] = gcol[1], dL_dcolors[3 * idx + 2] = gcol[2];
   for (int e = 0; e < E; ++e) dL_dextras[(size_t) idx * E + e] = gex[e];
 
   float gmean[3] = {0.f, 0.f, 0.f}, gcov[6] = {0, 0, 0, 0, 0, 0}, gscale[3] = {0, 0, 0}, grot[4] = {0, 0, 0, 0};
@@ -978,11 +979,13 @@ __global__ void __launch_bounds__(PRE_BWD_THREADS) preprocess_backward_kernel(in
       }
     }
   }
-  dL_dmeans3D[3 * idx] = gmean[0], dL_dmeans3D[3 * idx + 1] = gmean[1], dL_dmeans3D[3 * idx + 2] = gmean[2];
+  if (dL_dmeans3D) dL_dmeans3D[3 * idx] = gmean[0], dL_dmeans3D[3 * idx + 1] = gmean[1], dL_dmeans3D[3 * idx + 2] = gmean[2];
+  if (dL_dcov3D) {
 #pragma unroll
-  for (int i = 0; i < 6; ++i) dL_dcov3D[6 * idx + i] = gcov[i];
-  dL_dscales[3 * idx] = gscale[0], dL_dscales[3 * idx + 1] = gscale[1], dL_dscales[3 * idx + 2] = gscale[2];
-  reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(grot[0], grot[1], grot[2], grot[3]);
+    for (int i = 0; i < 6; ++i) dL_dcov3D[6 * idx + i] = gcov[i];
+  }
+  if (dL_dscales) dL_dscales[3 * idx] = gscale[0], dL_dscales[3 * idx + 1] = gscale[1], dL_dscales[3 * idx + 2] = gscale[2];
+  if (dL_drot) reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(grot[0], grot[1], grot[2], grot[3]);
   if constexpr (JOB != 0) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) dj_gm[c] = gmean[c], dj_gs[c] = gscale[c];

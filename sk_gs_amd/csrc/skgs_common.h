@@ -290,9 +290,19 @@ __device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int
 #endif
 enum StreamSite { NT_ADAM = 0, NT_PRE_BWD = 1, NT_LOSS_FWD = 2, NT_LOSS_BWD = 3, NT_PRE_FWD = 4, NT_DEFORM_BWD = 5, NT_ADAM_LOAD = 6,
   NT_SH_LOAD_FWD = 7, NT_SH_LOAD_BWD = 8, NT_GRADROW_LOAD = 9 };
+// SKGS_WT_MASK: sites whose stores are WRITE-THROUGH (`sc1`: the line leaves the XCD's L2 at once and is not kept) -- what shortens a
+// launch's closing write-back: SQ_BUSY_CYCLES of preprocess_backward is 62 % of its GRBM_GUI_ACTIVE (profiles/r05_n_*): ~12 us of the
+// launch's 31.8 have no wave on the chip, the 46 MB it wrote are being flushed.
+// Measured like the mask above (8 alternating runs each, ms per step): the optimizer's stores nt 0.3460 -> sc1 0.3429; the SH gradient
+// rows sc1 0.3476 (worse: the optimizer piece of the NEXT launch reads them, out of L2 while they are there).  sc1 only pays on 16-byte
+// stores (a dword sc1 store is a fabric write of its own, MI355X_MICROARCH.md).  Default 0x1 = the optimizer's three output arrays.
+#ifndef SKGS_WT_MASK
+#define SKGS_WT_MASK 0x1
+#endif
 template <int SITE>
 __device__ __forceinline__ void stream_store(float* p, float v) {
-  if constexpr (SITE < 31 && ((SKGS_NT_MASK >> SITE) & 1)) __builtin_nontemporal_store(v, p);
+  if constexpr (SITE < 31 && ((SKGS_WT_MASK >> SITE) & 1)) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else if constexpr (SITE < 31 && ((SKGS_NT_MASK >> SITE) & 1)) __builtin_nontemporal_store(v, p);
   else *p = v;
 }
 template <int SITE>
@@ -307,7 +317,11 @@ __device__ __forceinline__ float4 stream_load4(const float* p) {
 }
 template <int SITE>
 __device__ __forceinline__ void stream_store4(float* p, float4 v) {
-  if constexpr (SITE < 31 && ((SKGS_NT_MASK >> SITE) & 1)) {
+  if constexpr (SITE < 31 && ((SKGS_WT_MASK >> SITE) & 1)) {
+    typedef float f4w __attribute__((ext_vector_type(4)));
+    const f4w q = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(q) : "memory");
+  } else if constexpr (SITE < 31 && ((SKGS_NT_MASK >> SITE) & 1)) {
     typedef float f4v __attribute__((ext_vector_type(4)));
     const f4v q = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(q, reinterpret_cast<f4v*>(p));

@@ -149,6 +149,7 @@ class FusedViewStep:
         # (FusedAdam, group names) or None: that piece of the optimizer step runs inside the deform network's backward
         # launch (train_step.FusedTrainStep sets it; one rank, no gradient exchange between backward and update)
         self.side_optimizer = None
+        self.keep_raster_grads = False  # (True: g_means / g_scales / g_rotations / g_opacity / g_colors / g_cov3D are written even when a job consumes them)
         # the skeleton stage of the view in the slot already ran (``skeleton_forward``: FusedTrainStep(pre_forward=True)
         # issues it for the NEXT view behind the optimizer's closing launch): ``forward`` starts at the skinning
         self.skeleton_ahead = False
@@ -436,6 +437,9 @@ class FusedViewStep:
             g.stat_max_radii2D, g.stat_grad_multiplier = self._rad_store.data_ptr(), 1.0 / self._grad_scale_value
         self._rows_backward_done = False
         job = self._attach_backward_job(g, d, time_id)  # (kept alive until the call has read it)
+        if job is not None and self._rows_backward_done and not self.keep_raster_grads:
+            # the job takes the per-Gaussian gradients over in registers: their arrays are not written (80 B per Gaussian)
+            g.dL_dcolors = g.dL_dopacity = g.dL_dmeans3D = g.dL_dcov3D = g.dL_dscales = g.dL_drotations = None
         chk(lib.skgs_rasterize_backward(C.byref(a), C.byref(self._bufs), _p(self.radii), _p(self.out_opacity),
                                         C.byref(g), st))
 
