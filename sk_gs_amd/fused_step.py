@@ -149,7 +149,7 @@ class FusedViewStep:
         # (FusedAdam, group names) or None: that piece of the optimizer step runs inside the deform network's backward
         # launch (train_step.FusedTrainStep sets it; one rank, no gradient exchange between backward and update)
         self.side_optimizer = None
-        self.keep_raster_grads = False  # (True: g_means / g_scales / g_rotations / g_opacity / g_colors / g_cov3D are written even when a job consumes them)
+        self.keep_raster_grads = bool(os.environ.get('SKGS_KEEP_RASTER_GRADS'))  # (True: g_means / g_scales / g_rotations / g_opacity / g_colors / g_cov3D are written even when a job consumes them)
         # the skeleton stage of the view in the slot already ran (``skeleton_forward``: FusedTrainStep(pre_forward=True)
         # issues it for the NEXT view behind the optimizer's closing launch): ``forward`` starts at the skinning
         self.skeleton_ahead = False
@@ -562,7 +562,9 @@ class FusedViewStep:
                 _p(m._xyz.grad), _p(m._scaling.grad), _p(m._rotation.grad), _p(m._opacity.grad), _p(self.deform_ws),
                 C.c_size_t(self.deform_ws.numel()), st))
         elif self._rows_backward_done:  # (ran as a job of the rasterizer's backward, forward_backward above)
-            self._rows_backward_done = False
+            # (the flag stays until the next backward_raster clears it: a GraphedSteps capture calls this function twice -- warm-up,
+            # then the recording -- behind ONE backward_raster; consumed by the first call, the recording launched the rows pass a second
+            # time, harmless only while the rasterizer still wrote the arrays that launch reads)
             if part == 'rows':
                 return
         elif not self.wide:

@@ -606,8 +606,8 @@ class FusedSuperpointStep(FusedViewStep):
         g = lambda t: None if t is None else _p(t.grad)  # noqa: E731
         logits = m.sp_W is not None
         # skinning + weighting backward: rows | bones (the inverse lists of the forward) | finalize -- no atomics
-        if self._rows_backward_done:  # (ran with the rasterizer's backward: _attach_backward_job)
-            self._rows_backward_done = False
+        if self._rows_backward_done:  # (ran with the rasterizer's backward: _attach_backward_job; the flag stays until the next
+            pass                       # backward_raster clears it -- see FusedViewStep.backward_skinning)
         else:
             chk(lib.skgs_sp_skinning_backward(
                 C.byref(d), C.c_int32(self.F), _p(m.hyper_feature), _p(m.sp_hyper_feature), _p(m._sp_radius), _p(m._sp_weight),
