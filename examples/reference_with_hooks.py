@@ -5,12 +5,12 @@
 
 What happens, in this order (INTEGRATION.md sections 1-4):
 
-  1. the checkout goes on `sys.path`, then `sk_gs_amd.install_reference_hooks()` BEFORE anything of the reference is imported: its compiled extension (`my_ext._C._C`: the
+  1. the checkout goes on `sys.path`, then `sk_gs_amd.install_reference_hooks(accelerate=True)` BEFORE anything of the reference is imported: its compiled extension (`my_ext._C._C`: the
      rasterizer, the frequency encoder, simple_knn under their pybind names) and the three packages it imports that do not exist for
      ROCm (`diff_gaussian_rasterization`, `lietorch`, `pytorch3d.ops`) resolve to this package.
   2. `import train` -- the reference's module, from the given checkout.
-  3. `sk_gs_amd.accelerate_reference()` (unless --no-accelerate) BEFORE the model is built: seven pieces of the training step that are
-     long chains of small torch launches get a fast path with the same arguments and results (loss, kinematic chain, LBS weights, both
+  3. (unless --no-accelerate) a post-import hook has applied `sk_gs_amd.accelerate_reference()` by then: seven pieces of the training
+     step that are long chains of small torch launches get a fast path with the same arguments and results (loss, kinematic chain, LBS weights, both
      deform networks, the rasterizer adapter's swizzle, `torch.optim.Adam.step`).
   4. `train.GaussianTrainTask().run()` -- the reference's own entry point (train.py:381-382) with the arguments behind `--`.
 
@@ -32,9 +32,10 @@ def main(argv):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
     sys.path.insert(0, ref)          # (before the hooks: install_as_my_ext_C plants a stand-in `my_ext` only where the reference's cannot be found)
     import sk_gs_amd
-    hooked = sk_gs_amd.install_reference_hooks()
+    fast = '--no-accelerate' not in own
+    hooked = sk_gs_amd.install_reference_hooks(accelerate=fast)   # (accelerate: the fast paths are applied as the reference's modules arrive)
     import train  # noqa: E402  (the reference's)
-    patched = [] if '--no-accelerate' in own else sk_gs_amd.accelerate_reference()
+    patched = sk_gs_amd.accelerate_reference() if fast else []    # (idempotent: here only to list what the post-import hook has patched)
     if '--check' in own:
         print('hooks    :', hooked)
         print('patched  :', patched)

@@ -130,15 +130,22 @@ def install_as_pytorch3d():
     return ops
 
 
-def install_reference_hooks(single_thread: bool = True):
+def install_reference_hooks(single_thread: bool = True, accelerate: bool = False):
     """Everything an unmodified checkout of the reference needs from this package on an MI355X machine, in one call made BEFORE
     ``import my_ext`` / ``import networks`` / ``import train``: the compiled ops behind ``my_ext._C`` (``install_as_my_ext_C``), the
     shipped configs' rasterizer package (``install_as_diff_gaussian_rasterization``), and the two CUDA-only third-party packages of
-    the deform (``install_as_lietorch``, ``install_as_pytorch3d``).  INTEGRATION.md section 1."""
+    the deform (``install_as_lietorch``, ``install_as_pytorch3d``).  ``accelerate=True``: ``accelerate_reference()``'s fast paths are
+    applied as the reference's modules arrive (no second call).  INTEGRATION.md section 1."""
     install_as_my_ext_C(single_thread=single_thread)
     install_as_diff_gaussian_rasterization(single_thread=single_thread)
     install_as_lietorch()
     install_as_pytorch3d()
+    if accelerate:
+        # ... and the fast paths of accelerate_reference() applied BY THEMSELVES as the reference's modules finish importing (a post-import
+        # hook): the two lines `import sk_gs_amd; sk_gs_amd.install_reference_hooks(accelerate=True)` in front of the reference's own
+        # imports are then everything
+        from sk_gs_amd import reference_accel
+        reference_accel.install_post_import_patcher()
     return ['my_ext._C._C', 'diff_gaussian_rasterization', 'lietorch', 'pytorch3d.ops']
 
 

@@ -418,10 +418,74 @@ def adam_step(self, closure=None):
 
 
 # ------------------------------------------------------------------------------------------------ install / restore
+def _fully_imported(name: str) -> bool:
+    """the module has finished executing (its classes exist): what a patch needs"""
+    m = sys.modules.get(name)
+    spec = getattr(m, '__spec__', None)
+    return m is not None and not getattr(spec, '_initializing', False)
+
+
+_WATCHED = ('networks.sk_gs', 'networks.losses.ssim', 'networks.renderer.gaussian_render_origin')
+
+
+class _PostImportPatcher:
+    """``install_reference_hooks(accelerate=True)``: a meta-path finder that lets the normal machinery find the reference's modules and,
+    once one of the three modules the fast paths live in has finished executing, applies the patches that have become possible
+    (``accelerate_reference(strict=False)``) -- the rasterizer adapter right after its own module, i.e. before
+    ``networks/gaussian_splatting.py`` binds its name (:34), so the model stores the typed-rotation wrapper without further ado"""
+
+    def __init__(self, **kwargs):
+        self.kwargs, self.busy = kwargs, False
+
+    def find_spec(self, name, path=None, target=None):
+        if name not in _WATCHED or self.busy:
+            return None
+        import importlib.util
+        self.busy = True
+        try:
+            spec = importlib.util.find_spec(name)
+        except (ImportError, ValueError):
+            spec = None
+        finally:
+            self.busy = False
+        if spec is None or spec.loader is None or not hasattr(spec.loader, 'exec_module'):
+            return spec
+        loader, patcher = spec.loader, self
+
+        class _Loader:
+            def create_module(self, spec_):
+                return loader.create_module(spec_) if hasattr(loader, 'create_module') else None
+
+            def exec_module(self, module):
+                loader.exec_module(module)
+                spec_ = getattr(module, '__spec__', None)
+                if spec_ is not None:
+                    spec_._initializing = False     # (finished as far as the patches are concerned)
+                accelerate_reference(strict=False, **patcher.kwargs)
+
+            def __getattr__(self, item):
+                return getattr(loader, item)
+        spec.loader = _Loader()
+        return spec
+
+
+def install_post_import_patcher(**kwargs):
+    """see ``_PostImportPatcher``; idempotent.  ``torch.optim.Adam.step`` (not part of the reference) is patched at once."""
+    if not any(isinstance(f, _PostImportPatcher) for f in sys.meta_path):
+        sys.meta_path.insert(0, _PostImportPatcher(**kwargs))
+    return accelerate_reference(strict=False, **kwargs)
+
+
+
 def accelerate_reference(ssim: bool = True, kinematic_chain: bool = True, networks: bool = True, lbs_weights: bool = True,
-                         adam: bool = True, swizzle: bool = True) -> list:
-    """Patch the methods on the reference's classes (the modules must be imported already).  Returns what was patched."""
+                         adam: bool = True, swizzle: bool = True, strict: bool = True) -> list:
+    """Patch the methods on the reference's classes (the modules must be imported already; ``strict=False``: patch what IS imported,
+    skip the rest -- what the post-import hook of ``install_reference_hooks(accelerate=True)`` calls as the modules arrive).  Returns what
+    was patched."""
     done = []
+    if not strict:
+        sk, ss = _fully_imported('networks.sk_gs'), _fully_imported('networks.losses.ssim')
+        networks, kinematic_chain, lbs_weights, ssim = networks and sk, kinematic_chain and sk, lbs_weights and sk, ssim and ss
     if networks:
         mod = sys.modules.get('networks.sk_gs')
         if mod is None:
@@ -443,7 +507,8 @@ def accelerate_reference(ssim: bool = True, kinematic_chain: bool = True, networ
         done.append('networks.sk_gs.SkeletonGaussianSplatting.calc_LBS_weight')
     if swizzle:
         mod = sys.modules.get('networks.renderer.gaussian_render_origin')
-        if mod is not None:     # (the adapter exists only where the upstream rasterizer package -- here: the stand-in -- could be imported)
+        if mod is not None and hasattr(mod, 'render_gs_offical') and (strict or _fully_imported('networks.renderer.gaussian_render_origin')):
+            # (the adapter exists only where the upstream rasterizer package -- here: the stand-in -- could be imported)
             if 'render_adapter' not in _originals:
                 _originals['render_adapter'] = mod.render_gs_offical
                 mod.render_gs_offical = render_gs_offical

@@ -266,6 +266,42 @@ def test_example_launcher_imports_the_reference_train_module_and_patches_it():
         assert name in r.stdout, name
 
 
+@pytest.mark.skipif(not os.path.isdir(_REFERENCE), reason='the reference is only mounted in the build container')
+def test_two_lines_in_front_of_the_reference_imports_are_everything():
+    """``import sk_gs_amd; sk_gs_amd.install_reference_hooks(accelerate=True)`` BEFORE the reference's imports: the hooks are planted and a
+    post-import hook applies every fast path of accelerate_reference() as the reference's modules finish importing -- the optimizer at once,
+    the rasterizer adapter right behind its own module (so that ``networks/gaussian_splatting.py`` binds the wrapped function, :34),
+    the five methods behind ``networks.sk_gs`` / ``networks.losses.ssim``.  The reference's whole ``train`` module is imported for it."""
+    code = """
+import sys, warnings
+sys.dont_write_bytecode = True
+sys.path[:0] = [%r, %r, %r]
+import make_golden
+sys.meta_path.insert(0, make_golden._Finder())
+warnings.simplefilter('ignore')
+import sk_gs_amd
+sk_gs_amd.install_reference_hooks(accelerate=True)
+import torch
+from sk_gs_amd import reference_accel as ra
+assert torch.optim.Adam.step is ra.adam_step
+import train
+import networks.sk_gs as sk, networks.gaussian_splatting as gsm, networks.renderer.gaussian_render_origin as gro
+from networks.losses import ssim
+S = sk.SkeletonGaussianSplatting
+assert S.kinematic is ra.kinematic and S.calc_LBS_weight is ra.calc_LBS_weight
+assert sk.SimpleDeformationNetwork.forward is ra.simple_deform_forward and sk.DeformNetwork.forward is ra.deform_network_forward
+assert ssim.SSIM_Loss.forward is ra.ssim_loss_forward
+assert gro.render_gs_offical is ra.render_gs_offical and gsm.render_gs_offical is ra.render_gs_offical
+assert sorted(ra._originals) == ['adam', 'kinematic', 'lbs_weight', 'render_adapter', 'sk_net', 'sp_net', 'ssim']
+ra.restore_reference()
+assert S.kinematic is not ra.kinematic and torch.optim.Adam.step is not ra.adam_step and gsm.render_gs_offical is gro.render_gs_offical
+print('TWO-LINES-OK')
+""" % (ROOT, os.path.join(ROOT, 'tests', 'golden'), _REFERENCE)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd='/tmp', env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'),
+                       timeout=600)
+    assert r.returncode == 0 and 'TWO-LINES-OK' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, 'sk_gs_amd')
     for dirpath, _, files in os.walk(pkg):
