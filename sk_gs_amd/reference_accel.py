@@ -369,13 +369,13 @@ def adam_step(self, closure=None):
     """``torch.optim.Adam.step`` as ONE launch over every parameter (torch's foreach form: ~8 launches per parameter GROUP, 80 per step
     for the reference's ten groups: 0.84 ms of GPU time at config #1) when the optimizer is what the reference builds
     (gaussian_splatting.py:443-460: plain Adam, ``eps=1e-15``, one ``lr`` per group): dense fp32 parameters on one HIP device, every
-    parameter that has a gradient with an initialised state and all of those at the same step count (one without a gradient is
-    skipped, as torch skips it), no amsgrad / weight decay / maximize /
+    parameter that has a gradient with an initialised state (one without a gradient is skipped, as torch skips it; parameters of
+    different step counts -- a later stage's groups -- take one launch per count), no amsgrad / weight decay / maximize /
     capturable / differentiable.  Anything else -- and the very first step, which creates the state -- is torch's own ``step``."""
     groups = self.param_groups
     g0 = groups[0] if groups else None
     ok = closure is None and g0 is not None and type(self) is torch.optim.Adam
-    entries, lrs, count, dev = [], [], None, None
+    buckets, dev = {}, None      # step count -> ([(param, grad, exp_avg, exp_avg_sq)], [lr])
     if ok:
         for g in groups:
             if (g.get('amsgrad') or g.get('weight_decay', 0) != 0 or g.get('maximize') or g.get('capturable') or g.get('differentiable')
@@ -395,24 +395,34 @@ def adam_step(self, closure=None):
                     break
                 c = st['step']
                 c = float(c) if not torch.is_tensor(c) else (float(c) if not c.is_cuda else None)   # (a CPU scalar tensor: torch's default)
-                if c is None or (count is not None and c != count):
+                if c is None:
                     ok = False
                     break
-                count, dev = c, p.device
-                entries.append((p, gr, st['exp_avg'], st['exp_avg_sq']))
+                dev = p.device
+                ent, lrs = buckets.setdefault(c, ([], []))
+                ent.append((p, gr, st['exp_avg'], st['exp_avg_sq']))
                 lrs.append(float(g['lr']))
             if not ok:
                 break
-    if not ok or not entries:
+    # parameters that joined later (a new stage's groups, sk_gs.py) are younger than the others: one launch per step count, with its
+    # own bias corrections; more than a few different ages is not the reference's optimizer any more
+    if not ok or not buckets or len(buckets) > 4:
         calls['adam_reference'] += 1
         return _originals['adam'](self, closure)
-    run = _adam_runners.get(self)
-    if run is None or run.dev != dev:
-        run = _adam_runners[self] = _AdamRunner(dev)
+    runners = _adam_runners.get(self)
+    if runners is None:
+        runners = _adam_runners[self] = {}
+    newest = max(buckets)
     with torch.no_grad():
-        run.step(entries, lrs, float(g0['betas'][0]), float(g0['betas'][1]), float(g0['eps']), int(count))
-        for p, _, _, _ in entries:      # torch's bookkeeping: the per-parameter step counters (CPU scalars)
-            self.state[p]['step'] += 1
+        for count in sorted(buckets, reverse=True):
+            ent, lrs = buckets[count]
+            age = newest - count          # (constant from step to step: the runner of a bucket keeps its table and its counter)
+            run = runners.get(age)
+            if run is None or run.dev != dev:
+                run = runners[age] = _AdamRunner(dev)
+            run.step(ent, lrs, float(g0['betas'][0]), float(g0['betas'][1]), float(g0['eps']), int(count))
+            for p, _, _, _ in ent:      # torch's bookkeeping: the per-parameter step counters (CPU scalars)
+                self.state[p]['step'] += 1
     calls['adam_fused'] += 1
     return None
 

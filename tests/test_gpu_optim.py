@@ -704,8 +704,8 @@ def test_accelerated_torch_adam_step_equals_torch():
     finally:
         ra._originals.pop('adam', None)
     # (step 0 creates the state; step 4 skips the parameter without a gradient as torch does; at step 5 that parameter's counter is one
-    # behind the others: torch's own step)
-    assert ra.calls['adam_fused'] - before['adam_fused'] == 4 and ra.calls['adam_reference'] - before['adam_reference'] == 2
+    # behind the others: a launch of its own with its own bias corrections)
+    assert ra.calls['adam_fused'] - before['adam_fused'] == 5 and ra.calls['adam_reference'] - before['adam_reference'] == 1
     for i, (p, q) in enumerate(zip(pa, pb)):
         assert p.shape == q.shape
         assert rel_err(p, q) <= 2e-6, (i, rel_err(p, q))
