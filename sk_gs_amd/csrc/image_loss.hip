@@ -25,17 +25,32 @@
 namespace skgs {
 namespace {
 
-constexpr int TW   = 32, TH = 32;      // output tile of one workgroup
+#ifndef SKGS_LOSS_TH
+#define SKGS_LOSS_TH 32
+#define SKGS_LOSS_VSEG 4
+#endif
+constexpr int TW   = 32, TH = SKGS_LOSS_TH;      // output tile of one workgroup
 constexpr int HALO = 5;                // window radius
 constexpr int IW   = TW + 2 * HALO;    // 42 input columns under a tile
 constexpr int IH   = TH + 2 * HALO;    // 42 input rows under a tile
 constexpr int HP   = TW + 1;           // LDS pitch of the horizontally filtered rows
 constexpr int SEG  = 8;                // horizontal pass: outputs per thread (18 inputs -> 8 outputs)
-constexpr int VSEG = 4;                // vertical pass: outputs per thread (14 inputs -> 4 outputs)
+constexpr int VSEG = SKGS_LOSS_VSEG;   // vertical pass: outputs per thread (VSEG + 10 inputs -> VSEG outputs)
 constexpr int NT   = TW * TH / VSEG;   // threads of a workgroup: one per VSEG outputs of a column
 constexpr int HTASKS = IH * (TW / SEG);  // (row, segment) tasks of the horizontal pass
 constexpr int NMOM = 4;                // window moments of the forward: E[x], E[y], E[xx + yy], E[xy]
 static_assert(TW % SEG == 0 && TH % VSEG == 0 && NT % 64 == 0 && (NT & (NT - 1)) == 0 && SEG == 8, "tile / thread mapping");
+// The BACKWARD walks tiles of its own height: 800 / 32 = 25 tile rows x 25 x 3 channels = 1875 workgroups for 7 x 256 = 1792
+// resident ones (66 registers, 21.7 KB of LDS: seven per CU) -- 83 workgroups ran a second round behind all the others.  40 rows per
+// tile (five outputs per thread, the same 256 threads) are 1500 workgroups of 25.8 KB, six per CU = 1536: ONE round.  Measured, 8
+// alternating bench runs each: image_loss_backward 19.8 -> 17.6 us, the step 0.3431 -> 0.3417 ms; the forward (69 registers, longer
+// per-tile chain) gained nothing from the same change and keeps 32.
+#ifndef SKGS_LOSS_TH_B
+#define SKGS_LOSS_TH_B 40
+#define SKGS_LOSS_VSEG_B 5
+#endif
+constexpr int TH_B = SKGS_LOSS_TH_B, VSEG_B = SKGS_LOSS_VSEG_B, IH_B = TH_B + 2 * HALO, HTASKS_B = IH_B * (TW / SEG);
+static_assert(TH_B % VSEG_B == 0 && TW * TH_B / VSEG_B == NT, "the backward's tiles: the same workgroup size");
 struct Win {
   float g[11];
 };
@@ -106,8 +121,8 @@ __device__ __forceinline__ bool tile_of_block(int tiles_x, int tiles_y, int C, T
   t.c      = w / (tiles_x * tiles_y);
   return true;
 }
-inline dim3 tile_grid(int C, int H, int W) {
-  const int n = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * C;
+inline dim3 tile_grid(int C, int H, int W, int th = TH) {
+  const int n = ((W + TW - 1) / TW) * ((H + th - 1) / th) * C;
   return dim3((unsigned) (((n + 7) / 8) * 8));
 }
 
@@ -261,32 +276,32 @@ __global__ void __launch_bounds__(NT) image_loss_backward_kernel(int C, int H, i
     float* __restrict__ loss3) {
   // the staged maps and, once every thread holds its filtered segment in registers, the filtered rows share one buffer
   // (21.7 KB: 7 workgroups per CU)
-  static_assert(HTASKS <= NT, "one (row, segment) task per thread");
+  static_assert(HTASKS_B <= NT, "one (row, segment) task per thread");
   constexpr int IP = IW + 1;  // 43: the 8 rows x 4 segments of a 32-lane group read 32 different banks
-  __shared__ float s_buf[3 * IH * IP];
-  float (&s_m)[3][IH][IP] = *reinterpret_cast<float (*)[3][IH][IP]>(s_buf);
-  float (&s_h)[3][IH][HP] = *reinterpret_cast<float (*)[3][IH][HP]>(s_buf);
+  __shared__ float s_buf[3 * IH_B * IP];
+  float (&s_m)[3][IH_B][IP] = *reinterpret_cast<float (*)[3][IH_B][IP]>(s_buf);
+  float (&s_h)[3][IH_B][HP] = *reinterpret_cast<float (*)[3][IH_B][HP]>(s_buf);
   if (gt_index) gt += (size_t) gt_index[0] * C * H * W;
   TileId tile;
-  if (!tile_of_block((W + TW - 1) / TW, (H + TH - 1) / TH, C, tile)) return;
+  if (!tile_of_block((W + TW - 1) / TW, (H + TH_B - 1) / TH_B, C, tile)) return;
   const int c  = tile.c;
-  const int x0 = tile.tx * TW, y0 = tile.ty * TH;
+  const int x0 = tile.tx * TW, y0 = tile.ty * TH_B;
   const int tid = threadIdx.x;
   const size_t plane = (size_t) H * W, CHW = (size_t) C * plane;
   const float* const maps[3] = {dmaps + c * plane, dmaps + CHW + c * plane, dmaps + 2 * CHW + c * plane};
   // the own pixels of the epilogue: requested before the filter passes, used after them
-  const int tx = tid % TW, ty0 = (tid / TW) * VSEG;
+  const int tx = tid % TW, ty0 = (tid / TW) * VSEG_B;
   const int gx = x0 + tx;
-  float xs[VSEG], ys[VSEG];
+  float xs[VSEG_B], ys[VSEG_B];
 #pragma unroll
-  for (int o = 0; o < VSEG; ++o) {
+  for (int o = 0; o < VSEG_B; ++o) {
     const int gy  = y0 + ty0 + o;
     const bool ok = gx < W && gy < H;
     const size_t oo = (size_t) c * plane + (ok ? (size_t) gy * W + gx : 0);
     xs[o] = pred[oo], ys[o] = gt[oo];
   }
   // the three derivative maps under the tile, staged once (coalesced rows), then the horizontal pass out of LDS
-  for (int i = tid; i < IH * IW; i += NT) {
+  for (int i = tid; i < IH_B * IW; i += NT) {
     const int r = i / IW, q = i - r * IW;
     const int gy = y0 + r - HALO, gxx = x0 + q - HALO;
     const bool in = gy >= 0 && gy < H && gxx >= 0 && gxx < W;
@@ -296,7 +311,7 @@ __global__ void __launch_bounds__(NT) image_loss_backward_kernel(int C, int H, i
   }
   __syncthreads();
   {
-    const bool has = tid < HTASKS;
+    const bool has = tid < HTASKS_B;
     const int r = tid / (TW / SEG), q0 = (tid % (TW / SEG)) * SEG;
     float a[SEG][3];
 #pragma unroll
@@ -322,14 +337,14 @@ __global__ void __launch_bounds__(NT) image_loss_backward_kernel(int C, int H, i
     }
   }
   __syncthreads();
-  float v[VSEG][3];
+  float v[VSEG_B][3];
 #pragma unroll
-  for (int o = 0; o < VSEG; ++o) v[o][0] = v[o][1] = v[o][2] = 0.f;
+  for (int o = 0; o < VSEG_B; ++o) v[o][0] = v[o][1] = v[o][2] = 0.f;
 #pragma unroll
-  for (int i = 0; i < VSEG + 10; ++i) {
+  for (int i = 0; i < VSEG_B + 10; ++i) {
     const float h0 = s_h[0][ty0 + i][tx], h1 = s_h[1][ty0 + i][tx], h2 = s_h[2][ty0 + i][tx];
 #pragma unroll
-    for (int o = 0; o < VSEG; ++o) {
+    for (int o = 0; o < VSEG_B; ++o) {
       const int k = i - o;
       if (k >= 0 && k < 11) {
         const float w = win.g[k];
@@ -339,7 +354,7 @@ __global__ void __launch_bounds__(NT) image_loss_backward_kernel(int C, int H, i
   }
   const float g = grad_loss ? grad_loss[0] : 1.0f;
 #pragma unroll
-  for (int o = 0; o < VSEG; ++o) {
+  for (int o = 0; o < VSEG_B; ++o) {
     const int gy = y0 + ty0 + o;
     if (gx < W && gy < H) {
       const size_t oo = (size_t) c * plane + (size_t) gy * W + gx;
@@ -412,7 +427,7 @@ int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred,
   const float* partials = dmaps + (size_t) 3 * C * H * W;
   const int nblocks     = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * C;
   ProfScope prof(K_LOSS_BWD, (hipStream_t) stream);
-  hipLaunchKernelGGL(image_loss_backward_kernel, tile_grid(C, H, W), dim3(NT), 0, (hipStream_t) stream, C, H, W, pred, gt,
+  hipLaunchKernelGGL(image_loss_backward_kernel, tile_grid(C, H, W, TH_B), dim3(NT), 0, (hipStream_t) stream, C, H, W, pred, gt,
       gt_index, make_window(), dmaps, grad_loss, lambda_l1 / n, -lambda_ssim / n, dL_dpred, partials, nblocks,
       1.0 / ((double) C * H * W), lambda_l1, lambda_ssim, loss3);
   SKGS_CHECK_HIP(hipGetLastError());
