@@ -192,6 +192,10 @@ __device__ __forceinline__ void adam_update_chunk(const AdamTensor& T, int64_t b
   }
 }
 
+// how many chunks a 256-thread half of a side-job workgroup takes per iteration (mlp_fused.hip, sp_mlp.hip)
+#ifndef SKGS_SIDE_CHUNKS
+#define SKGS_SIDE_CHUNKS 1
+#endif
 // two chunks at once (any two tensors): all 32 loads of a thread are issued before the first update
 __device__ __forceinline__ void adam_update_chunk2(const AdamTensor& A, int64_t baseA, const AdamTensor& Bt, int64_t baseB, int t256,
     const AdamCoef& k) {

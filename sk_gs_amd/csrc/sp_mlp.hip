@@ -469,6 +469,15 @@ __device__ __forceinline__ void side_adam_walk(const SideAdam& a, int wg, int n_
   const int64_t first0        = lane < a.n ? a.tensors[lane].chunk0 : INT64_MAX;
   const int64_t n_chunks      = a.c1 - a.c0;
   const int64_t begin = a.c0 + n_chunks * wg / n_side, end = a.c0 + n_chunks * (wg + 1) / n_side;
+#if defined(SKGS_SP_SIDE_CHUNKS) && SKGS_SP_SIDE_CHUNKS == 1   // (A/B: one chunk per half and iteration pays beside the 20-row network,
+                            // mlp_fused.hip::adam_side_job, not here: 0.3990 -> 0.4010 ms per step)
+  for (int64_t chunk = begin + half; chunk < end; chunk += 2) {
+    const int ti0      = adam_owner(a.tensors, a.n, first0, lane, chunk);
+    const AdamTensor T0 = ti0 < 64 ? adam_descriptor_of(desc, ti0) : a.tensors[ti0];
+    adam_update_chunk(T0, (chunk - T0.chunk0) * ADAM_CHUNK, t256, k);
+  }
+  return;
+#endif
   for (int64_t chunk = begin + 2 * half; chunk < end; chunk += 4) {
     const int ti0      = adam_owner(a.tensors, a.n, first0, lane, chunk);
     const AdamTensor T0 = ti0 < 64 ? adam_descriptor_of(desc, ti0) : a.tensors[ti0];
