@@ -486,3 +486,52 @@ def test_bench_pieces_are_importable_without_a_gpu():
     prof = roofline.committed_counter_profile(c['name'])
     assert (r['traffic'] is None) == (prof is None or prof.get('hbm_bytes_per_launch') is None)
     assert roofline.committed_counter_profile('no-such-workload') is None
+
+
+def _gate_row(test, name, v, flips=None):
+    r = dict(test=test, name=name, elements=100, tol=1e-4, max_err=v, untraced_max=v)
+    if flips is not None:
+        r['flipped_pixels'] = flips
+    return r
+
+
+def test_parity_gate_catches_a_real_jump_and_ignores_atomic_noise():
+    """the drift gate (tests/parity_gate.py) compares a session against the max / min over >= 5 sessions, not one
+    noisy sample against one noisy sample.  Fed (a) round 5's actual failure -- fuzz[13] dL_dmeans3D, an order-dependent sum of
+    atomics that read 4.2e-6 ... 2.7e-5 over 14 sessions -- it stays green; fed (b) round 2's real regression, 7e-5 -> 7e-4 on
+    a deterministic entry, it fails; (c) a 2.5x growth of a deterministic 3e-5 entry fails too; (d) anything below the 3e-5 floor
+    passes; (e) flipped pixels more than doubling (+3) fail."""
+    import parity_gate as pg
+    noisy = [4.2e-6, 7.2e-6, 2.74e-5, 1.1e-5, 2.0e-5, 5.0e-6]
+    sessions = [[_gate_row('t::fuzz[13]', 'dL_dmeans3D', v), _gate_row('t::c3', 'dL_dcolors', 7.0e-5 * (1 + 0.01 * i)),
+                 _gate_row('t::c1', 'dL_dscales', 3.0e-5), _gate_row('t::tiny', 'x', 2e-7), _gate_row('t::img', 'color', 1e-6, flips=2)]
+                for i, v in enumerate(noisy)]
+    base = list(pg.aggregate_sessions(sessions).values())
+    by = {r['test']: r for r in base}
+    assert by['t::fuzz[13]']['runs'] == 6 and by['t::fuzz[13]']['untraced_min'] == 4.2e-6 and by['t::fuzz[13]']['untraced_max'] == 2.74e-5
+    assert 9e-5 < pg.limit(by['t::fuzz[13]']) < 1e-4 and abs(pg.limit(by['t::c1']) - 6e-5) < 1e-12
+    ok = [_gate_row('t::fuzz[13]', 'dL_dmeans3D', 2.17e-5), _gate_row('t::fuzz[13]', 'dL_dmeans3D', 5.5e-5),
+          _gate_row('t::c3', 'dL_dcolors', 7.3e-5), _gate_row('t::tiny', 'x', 2.9e-5), _gate_row('t::img', 'color', 1e-6, flips=7),
+          _gate_row('t::new-test', 'y', 1.0)]
+    assert pg.regressions(ok, base) == []
+    bad = pg.regressions([_gate_row('t::c3', 'dL_dcolors', 7.0e-4)], base)
+    assert len(bad) == 1 and 't::c3' in bad[0] and '7.00e-04' in bad[0]
+    assert len(pg.regressions([_gate_row('t::c1', 'dL_dscales', 7.5e-5)], base)) == 1
+    assert len(pg.regressions([_gate_row('t::fuzz[13]', 'dL_dmeans3D', 1.2e-4)], base)) == 1
+    assert len(pg.regressions([_gate_row('t::img', 'color', 1e-6, flips=8)], base)) == 1
+    # fewer than five sessions on record: 3x instead of 2x
+    few = list(pg.aggregate_sessions(sessions[:2]).values())
+    assert abs(pg.limit({r['test']: r for r in few}['t::c1']) - 9e-5) < 1e-12
+
+
+def test_parity_gate_baseline_is_many_sessions_and_round5_failure_passes():
+    """the committed baseline holds >= 5 sessions per gated entry, and the two sessions that were red in round 5 (the driver's and
+    the builder's last: fuzz[13] dL_dmeans3D at 2.02e-5 / 2.17e-5) are inside its band"""
+    import parity_gate as pg
+    base = pg.load_baseline()
+    assert len(base) > 800 and min(r.get('runs', 1) for r in base) >= pg.MIN_RUNS, min(r.get('runs', 1) for r in base)
+    k = [r for r in base if r['test'].endswith('test_random_scene_against_the_oracle[13]') and ' dL_dmeans3D ' in r['name']]
+    assert len(k) == 1 and pg.limit(k[0]) < 1e-4
+    for v in (2.02e-5, 2.17e-5):
+        assert pg.regressions([dict(k[0], untraced_max=v)], base) == []
+    assert len(pg.regressions([dict(k[0], untraced_max=2e-4)], base)) == 1

@@ -6,8 +6,7 @@ tag=${1:-rXX}
 exec < /dev/null   # (nothing here reads stdin; a tool that does must not wait on the terminal of a batch run)
 out=gpurun_out/$tag
 rm -rf "$out"; mkdir -p "$out"
-python -m pytest tests -m gpu -q 2>&1 | tail -3 > $out/gpu_tests.txt; cat $out/gpu_tests.txt
-cp gpurun_out/parity_observed.json $out/parity_observed.json 2>/dev/null
+bash tools/gpu_tests.sh $tag ${SKGS_TEST_RUNS:-1}; echo "GPU TESTS rc=$?" | tee $out/gpu_tests_exit.txt   # whole log + rc kept
 python bench.py > $out/bench_default.json 2> $out/bench_default.err; cut -c1-200 $out/bench_default.json
 # stage sp (512 superpoints, 3+8-d search, sp_deform_net on 512 rows) at config #1's size, every weighting; with the CPU leg once
 python bench.py --stage sp > $out/bench_stage_sp.json 2> $out/bench_stage_sp.err; cut -c1-200 $out/bench_stage_sp.json
