@@ -46,6 +46,25 @@ def rank_variants(args, run_workload, rank, dev, write_line):
         line['exchange_variants'] = summary
         write_line(line)
 
+    def provisional(name):
+        # N-rank evidence must not wait for the whole ranking.  As soon as a variant has finished -- the FIRST is the
+        # plain flat-buffer all-reduce, nothing but one standard RCCL collective per step -- rank 0 writes the record as it stands to
+        # STDERR (stdout stays the contract's ONE line at the end); a lease that dies inside a later captured-collective variant
+        # still leaves the measured ones in the driver's stderr tail.
+        if rank != 0 or lines.get(name) is None:
+            return
+        import json
+        import sys
+        try:
+            best, summary = summarise(lines, errors)
+        except AssertionError:
+            return
+        line = copy.deepcopy(lines[best])
+        line['config']['exchange'] = best
+        line['exchange_variants'] = {k: v for k, v in summary.items() if 'value' in v or k in errors}
+        line['provisional'] = f'after variant {name!r}: {sum(1 for v in lines.values() if v is not None)} of {len(EXCHANGE_VARIANTS)} variants timed'
+        print('[exchange auto] provisional ' + json.dumps(line), file=sys.stderr, flush=True)
+
     def bail(name):
         # a later variant hangs (a collective that never completes on this fabric) or dies: the record must not die with it.
         # Every rank's own timer ends its process; rank 0 first prints what the finished variants measured.
@@ -103,4 +122,5 @@ def rank_variants(args, run_workload, rank, dev, write_line):
                 timer.cancel()
         if t_first is None:
             t_first = time.perf_counter() - t_v
+        provisional(name)
     emit()

@@ -17,13 +17,26 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # captured-collective variants last, each under the watchdog (a fabric on which a captured collective never completes costs
 # only those entries)
 EXCHANGE_VARIANTS = {
-    'factors': dict(sh_factors=True, compact_logits=True),
     'allreduce': dict(),
+    'factors': dict(sh_factors=True, compact_logits=True),
     'factors-overlap': dict(sh_factors=True, compact_logits=True, overlap_gather=True),
     'pipeline': dict(pipeline=True),
     'allreduce-graph': dict(graph_collectives=True),
     'factors-graph': dict(sh_factors=True, compact_logits=True, overlap_gather=True, graph_collectives=True),
     'factors-graph-split': dict(sh_factors=True, compact_logits=True, overlap_gather=True, graph_collectives=True, split_rest=True),
+}
+
+
+# the launches of ONE fused training step of stage sk on one rank, as rocprofv3 names them (regex on the kernel name, template
+# arguments included where the step's instantiation differs from the operator path's): tools/pmc_summary.py sums their average
+# durations out of the committed `--kernel-trace --stats` pass; bench.py prints that sum beside its own event-bracketed table
+STEP_KERNELS_SK = {
+    'skeleton_forward': r'fused_mlp_forward_kernel<2>', 'preprocess_forward': r'preprocess_forward_kernel<true, [1-9]\d*>',
+    'scatter': r'scatter_lds_kernel<4>', 'tile_sort': r'tile_sort_wave_kernel', 'render_forward': r'render_forward_kernel<1, 0, false>',
+    'image_loss_forward': r'image_loss_forward_kernel', 'image_loss_backward': r'image_loss_backward_kernel',
+    'render_backward': r'render_backward_kernel<1, 0>', 'preprocess_backward': r'preprocess_backward_kernel<true, [1-9]\d*>',
+    'deform_backward_finalize': r'deform_backward_finalize_kernel', 'skeleton_backward': r'fused_mlp_backward_kernel<2>',
+    'adam': r'adam_step_kernel',
 }
 
 

@@ -20,7 +20,7 @@ def committed_counter_profile(cfg_name, file='pmc_render_backward.json'):
         if rec.get('config') != cfg_name:
             return None
         out = {k: rec.get(k) for k in ('file', 'commit', 'hbm_bytes_per_launch', 'valubusy', 'valuutilization',
-                                       'valu_insts_per_launch', 'avg_us') if k in rec}
+                                       'valu_insts_per_launch', 'avg_us', 'step_kernels_rocprof') if k in rec}
         if rec.get('valu_insts_per_launch') and rec.get('avg_us'):
             # VALU issue roofline (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles on a SIMD-32)
             ach = rec['valu_insts_per_launch'] / (rec['avg_us'] * 1e-6)
@@ -65,3 +65,18 @@ def render_backward_roofline(prof, cfg, R_mean, n_params, ms_step):
                     'contract figure, from_profile.valu the one that bounds it; streaming kernels are listed under "kernels" with '
                     'their GB/s; traffic comes from the committed counter profile named in traffic_source (no counter is '
                     'collected in a bench run), null when there is none for this workload'}
+
+
+def kernels_sum(kernels, cfg_name, ms_step):
+    """the three ways the step's kernel time is stated, side by side: the sum of the `kernels` table (every entry is a
+    HIP-event bracket around ONE eager launch: ~2-4 us of bracket each, so the sum sits ABOVE the step), the step itself (graph
+    replay, the contract's number), and the sum of the same launches' rocprofv3 averages from the committed `--kernel-trace --stats`
+    profile of this workload (no brackets: equals the step when the graph has no gaps)"""
+    prof = (committed_counter_profile(cfg_name) or {}).get('step_kernels_rocprof')
+    return {'event_bracketed_us': round(sum(v['us'] * v['launches_per_step'] for v in kernels.values()), 1),
+            'graph_step_us': round(ms_step * 1e3, 1),
+            'rocprof_us': None if prof is None else prof.get('sum_us'),
+            'rocprof_source': None if prof is None else {'file': prof.get('file'), 'missing': prof.get('missing')},
+            'note': 'event_bracketed = sum of the `kernels` table, each entry timed as one eager launch between two HIP events (the '
+                    'bracket adds 2-4 us per entry); rocprof = sum of the same launches\' average durations in the committed '
+                    'rocprofv3 kernel-stats profile; graph_step = ms_per_step'}

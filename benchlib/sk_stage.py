@@ -14,7 +14,7 @@ import torch.distributed as dist
 
 from benchlib import render_protocol, timing
 from benchlib.options import CONFIGS, alg_bytes
-from benchlib.roofline import render_backward_roofline
+from benchlib.roofline import kernels_sum, render_backward_roofline
 
 
 # ------------------------------------------------------------------------------------------------ scene
@@ -761,6 +761,7 @@ def run(args, env):
                    'cluster': cluster},
         'roofline': render_backward_roofline(prof, cfg, s.R_mean, sum(p_.numel() for p_ in model.parameters()), ms_step),
         'kernels': kernels,
+        'kernels_sum': kernels_sum(kernels, cfg['name'], ms_step),
     }
     if ms_render:
         # the same pass as the sum of its kernels' HIP-event times inside the training step (no launch / sync overhead)

@@ -154,6 +154,7 @@ class FusedViewStep:
         # issues it for the NEXT view behind the optimizer's closing launch): ``forward`` starts at the skinning
         self.skeleton_ahead = False
         self.defer_input_grad = False
+        self._arm_tail = None   # (FusedTrainStep.loss: what the node's backward arms on the optimizer)
         # view-parallel training: [P*K] float32 view that receives the compact LBS-logit gradient (see backward_skinning)
         self.spw_logit_grad = spw_logit_grad
         assert spw_logit_grad is None or (spw_logit_grad.numel() == P * K and spw_logit_grad.is_contiguous())
@@ -776,4 +777,8 @@ class _FusedViewLoss(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         ctx.step.backward_pending(g)
+        arm = getattr(ctx.step, '_arm_tail', None)
+        if arm is not None:     # FusedTrainStep.loss(): the next optimizer.step() is THIS step's closing launch
+            ctx.step._arm_tail = None
+            arm[0]._pending_tail = arm[1]
         return (None,) * (4 + len([p for p in ctx.step.model.parameters() if p.requires_grad]))

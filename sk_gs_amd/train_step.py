@@ -196,7 +196,14 @@ class FusedTrainStep:
         read or change those gradients between ``backward()`` and ``optimizer.step()`` -- the next ``optimizer.step()`` call is
         consumed by this step's tail."""
         assert not self.reduce_between, 'a step with an all-reduce in it is backward() ... update()'
-        self.optimizer._pending_tail = (self, rs)
+        if self.optimizer._pending_tail is not None:
+            # the previous view's backward ran (its skeleton launch carried the rows' update) but optimizer.step() -- that step's
+            # closing launch -- was never called: network / joints / counter are one update behind the rows
+            raise RuntimeError('FusedTrainStep.loss(): the previous loss.backward() was not followed by optimizer.step()')
+        # the tail is armed by the node's BACKWARD, after the launches that carry the rows' update (ADVICE r5: armed in the forward, a
+        # loss evaluated without backward() -- logging, torch.no_grad(), an exception, a skipped NaN step -- turned a later, unrelated
+        # optimizer.step() into a closing launch on stale gradients)
+        self.step._arm_tail = (self.optimizer, (self, rs))
         return self.step.loss(rs, time_id, target)
 
     def _tail(self, rs):

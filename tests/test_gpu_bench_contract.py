@@ -113,6 +113,8 @@ def test_default_multi_rank_run_ranks_every_exchange_variant(port, ranks):
     digests = [r['param_digest'] for r in ev.values()]
     assert max(digests) - min(digests) <= 1e-6 * abs(digests[0]), digests
     assert d['ms_per_step_blocks']['blocks'] == 6 and 'cpu_baseline' not in d
+    prov = [l for l in p.stderr.splitlines() if '[exchange auto] provisional {' in l]
+    assert len(prov) == 4 and "after variant 'allreduce': 1 of 7" in prov[0], [l[:200] for l in prov]   # (one per variant that ran)
 
 
 def test_factor_exchange_and_dense_exchange_train_the_same_parameters():
@@ -188,8 +190,8 @@ def test_collectives_captured_inside_the_step_graph_one_rank_rccl(port, exchange
 
 def test_auto_ranking_stops_starting_variants_when_its_time_budget_is_spent():
     """`--auto-budget` (seconds): the record is one line at the very end, so the ranking must end by itself before a caller's
-    limit could cut it off -- with a budget of zero only the first variant runs (the predicted-best one with eager collectives,
-    `factors`: VERDICT r3 #5d), the others are listed as not run"""
+    limit could cut it off -- with a budget of zero only the first variant runs (the plain flat-buffer
+    all-reduce: one standard collective per step, VERDICT r5 #8), the others are listed as not run"""
     env = dict(os.environ, SKGS_DIST_BACKEND='gloo', SKGS_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29641', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
@@ -198,10 +200,15 @@ def test_auto_ranking_stops_starting_variants_when_its_time_budget_is_spent():
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     d = json.loads([l for l in p.stdout.splitlines() if l.strip().startswith('{')][-1])
     ev = d['exchange_variants']
-    assert list(ev)[0] == 'factors' and d['config']['exchange'] == 'factors' and 'value' in ev['factors']
+    assert list(ev)[0] == 'allreduce' and d['config']['exchange'] == 'allreduce' and 'value' in ev['allreduce']
     for name, r in ev.items():
-        if name != 'factors':
+        if name != 'allreduce':
             assert 'budget' in r['error'], (name, r)
+    # the record of the first finished variant is on stderr BEFORE the ranking ends (a lease that dies later keeps it)
+    prov = [l for l in p.stderr.splitlines() if '[exchange auto] provisional {' in l]
+    assert prov, p.stderr[-2000:]
+    pj = json.loads(prov[0].split('provisional ', 1)[1])
+    assert pj['n_gpus'] == 2 and pj['config']['exchange'] == 'allreduce' and pj['value'] == ev['allreduce']['value'] and 'provisional' in pj
     # the record proves the ranks: backend, world, one entry per rank with its device
     cl = d['config']['cluster']
     assert cl['world'] == 2 and cl['backend'] == 'gloo' and len(cl['devices']) == 2 and {x['rank'] for x in cl['devices']} == {0, 1}

@@ -358,7 +358,7 @@ def test_kernel_and_dist_lbs_weightings_match_oracle(oracle32, P, M, K, dim):
             assert rel_err(ft.grad, g_p[:, 3:]) <= 2e-5, method
 
 
-@pytest.mark.parametrize('cfg,P,M', [(1, 100_000, 20), (2, 200_000, 32), (4, 500_000, 24)])
+@pytest.mark.parametrize('cfg,P,M', [(1, 100_000, 20), (2, 200_000, 32), (3, 300_000, 20), (4, 500_000, 24)])
 def test_deform_and_knn_at_full_size(oracle32, cfg, P, M):
     """the deform / KNN / LBS-weight kernels at BASELINE.json's full Gaussian and bone counts against the oracle (seconds
     of CPU): KNN indices and softmax weights, the fused KNN + weights + skinning launch, and the skinning backward"""

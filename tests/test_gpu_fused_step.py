@@ -844,3 +844,47 @@ def test_fused_train_step_behind_the_autograd_api():
         far = ((a - b).abs() > max(1e-5 * float(b.abs().max()), 2e-6)).float().mean()
         assert float(far) <= 5e-2, (n, float(far))
     assert opt._pending_tail is None   # (consumed: the next optimizer.step() without a loss() is an ordinary full step)
+
+
+def test_a_loss_evaluated_without_backward_does_not_arm_the_optimizer_tail():
+    """``FusedTrainStep.loss()`` used to arm ``optimizer._pending_tail`` in the FORWARD; a loss evaluated for
+    logging / under ``no_grad`` / before an exception then turned a later unrelated ``optimizer.step()`` into a closing launch on stale
+    gradients.  The tail is armed by the node's backward: (a) loss without backward -> the optimizer stays un-armed (the next
+    direct step is one whole step: every group moves, counter + 1); (b) loss + backward arms it, ``step()`` consumes it;
+    (c) a second ``loss()`` while a tail is still pending is an error, not a silent skew."""
+    from sk_gs_amd import _C, scene
+    from sk_gs_amd.fused_step import FusedViewStep
+    from sk_gs_amd.model import SkinnedGaussians
+    from sk_gs_amd.optim import FusedAdam
+    from sk_gs_amd.train_step import FusedTrainStep
+    P, M, K, W, H = 2000, 8, 4, 96, 64
+    dev = torch.device('cuda')
+    model = SkinnedGaussians(P, M, K, sh_degree=3, num_frames=2, seed=5, scale_mult=2.0, deform_net=True, learn_joints=True).to(dev)
+    rs = scene.raster_settings_from_camera(scene.make_camera(W, H, seed=0), sh_degree=3, colmap=True, device=dev)
+    target = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    step = FusedViewStep(model, W, H, capacity=200_000)
+    opt = FusedAdam(model.param_groups(lr=1e-3), eps=1e-8)
+    train = FusedTrainStep(step, opt)
+    assert train.fused
+    # (a)
+    with torch.no_grad():
+        train.loss(rs, 0, target)
+    loss = train.loss(rs, 0, target)            # evaluated, never differentiated
+    del loss
+    assert opt._pending_tail is None
+    xyz0, net_p = model._xyz.detach().clone(), next(model.sk_deform_net.parameters())
+    net0, c0 = net_p.detach().clone(), int(opt.step_state[0].item())
+    train(rs, 0, target)                        # the direct call: one whole step, nothing left over from the evaluations above
+    assert not torch.equal(model._xyz.detach(), xyz0) and not torch.equal(net_p.detach(), net0)
+    assert int(opt.step_state[0].item()) == c0 + 1 and opt._pending_tail is None
+    # (b)
+    loss = train.loss(rs, 1, target)
+    assert opt._pending_tail is None
+    loss.backward()
+    assert opt._pending_tail is not None
+    # (c)
+    with pytest.raises(RuntimeError, match='not followed by optimizer.step'):
+        train.loss(rs, 0, target)
+    opt.step()
+    assert opt._pending_tail is None and int(opt.step_state[0].item()) == c0 + 2
+    torch.cuda.synchronize()

@@ -23,7 +23,8 @@ for c in c4 c1; do
   [ -d "$d" ] || continue
   cp $d/bench_steps100.json profiles/${tag}_${c}_bench_steps100.json
   cp $(ls -t $d/stats/*/*kernel_stats.csv | head -1) profiles/${tag}_${c}_kernel_stats_bench_steps100.csv
-  python tools/pmc_summary.py ${tag}_$c $d/fetch $d/write $d/valu > /dev/null
+  if [ $c = c4 ]; then title="config #4: 500k Gaussians, 24 joints, 1024x1024"; cfg=zju-like-500k-1024; else title="config #1: 100k Gaussians, 20 bones, 800x800"; cfg=hook-like-100k-800; fi
+  SKGS_PROFILE_TITLE="$title" SKGS_PROFILE_CONFIG="$cfg" python tools/pmc_summary.py ${tag}_$c $d/fetch $d/write $d/valu > /dev/null
   [ $c = c4 ] && cp profiles/pmc_render_backward.json profiles/${tag}_c4_pmc_render_backward.json
 done
 ls profiles | grep "^$tag" | wc -l

@@ -47,14 +47,24 @@ def main():
         rows.append((k, max(len(f), len(w)), fm, wm, (2 * fm + wm) * 1024 / 1e6, extra))
     rows.sort(key=lambda r: -r[4])
     cols = sorted({c for r in rows for c in r[5]})
-    md = [f'# HBM traffic per launch from PMC counters ({tag}, ' + os.environ.get('SKGS_PROFILE_CONFIG', 'config #1: 100k Gaussians, 20 bones, 800x800') + ')', '',
+    md = [f'# HBM traffic per launch from PMC counters ({tag}, ' + (os.environ.get('SKGS_PROFILE_TITLE') or os.environ.get('SKGS_PROFILE_CONFIG', 'config #1: 100k Gaussians, 20 bones, 800x800')) + ')', '',
           'Separate passes (MI355X_MICROARCH.md): `rocprofv3 --pmc FETCH_SIZE --kernel-trace ...`, `--pmc WRITE_SIZE ...`'
           + (', `--pmc ' + ' '.join(cols) + ' ...`' if cols else '') + ' on `python bench.py --steps 10 --warmup 2 --no-cpu-baseline`.',
           'Counters are in KB; gfx950 correction from the guide: `traffic = 2 * FETCH_SIZE + WRITE_SIZE`.', '',
           '| kernel | launches | FETCH_SIZE [KB] | WRITE_SIZE [KB] | traffic = 2F+W [MB] |' + ''.join(f' {c} |' for c in cols),
           '|---|---|---|---|---|' + '---|' * len(cols)]
     for k, n, fm, wm, t, extra in rows:
-        md.append(f'| {k} | {n} | {fm:.1f} | {wm:.1f} | {t:.1f} |' + ''.join(f' {extra.get(c, float("nan")):.1f} |' for c in cols))
+        def cell(c):
+            v = extra.get(c, float('nan'))
+            if c in ('VALUBusy', 'VALUUtilization') and v > 100.0:    # a derived PERCENTAGE: see the note under the table
+                return f' 100 (raw {v:.1f}) |'
+            return f' {v:.1f} |'
+        md.append(f'| {k} | {n} | {fm:.1f} | {wm:.1f} | {t:.1f} |' + ''.join(cell(c) for c in cols))
+    if any(extra.get(c, 0.0) > 100.0 for _, _, _, _, _, extra in rows for c in ('VALUBusy', 'VALUUtilization')):
+        md += ['', 'Note: `VALUBusy` is rocprofv3\'s DERIVED metric `100 * SQ_ACTIVE_INST_VALU * 4 / SIMD_NUM / GRBM_GUI_ACTIVE`; the two raw',
+               'counters are sampled by different blocks (SQ per XCD, summed; GRBM once) and on launches of several hundred microseconds',
+               'the ratio overshoots 100 % by up to ~20 % on this chip.  Values above 100 are shown clamped with the raw reading in',
+               'brackets; read them as "the SIMDs issue VALU work in (nearly) every cycle", not as a measurement above the peak.']
     open(os.path.join(ROOT, 'profiles', f'{tag}_pmc_hbm_traffic.md'), 'w').write('\n'.join(md) + '\n')
     rb = [r for r in rows if r[0].startswith('render_backward_kernel')]
     if rb:
@@ -77,6 +87,20 @@ def main():
             for r in csv.DictReader(open(f)):
                 if 'render_backward_kernel' in r.get('Name', ''):
                     rec['avg_us'] = float(r['AverageNs']) / 1e3
+        # the step's launches by rocprofv3 (average duration of each, and their sum): what bench.py prints under `kernels_sum`
+        sys.path.insert(0, ROOT)
+        from benchlib.options import STEP_KERNELS_SK
+        for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', f'{tag}_kernel_stats*.csv'))):
+            per = {}
+            for r in csv.DictReader(open(f)):
+                for nm, pat in STEP_KERNELS_SK.items():
+                    if re.search(pat + r'\(', r.get('Name', '')) and 'at::' not in r['Name'][:20]:
+                        # (several instantiations match a family only for the preprocess pair: the step's is the one with a job)
+                        if nm not in per or int(r['Calls']) < per[nm]['calls']:
+                            per[nm] = dict(us=round(float(r['AverageNs']) / 1e3, 2), calls=int(r['Calls']))
+            if per:
+                rec['step_kernels_rocprof'] = dict(file=os.path.relpath(f, ROOT), kernels=per, sum_us=round(sum(v['us'] for v in per.values()), 1),
+                                                   missing=[n for n in STEP_KERNELS_SK if n not in per])
         # (SKGS_PMC_JSON: another file name, e.g. pmc_render_backward_sp.json for the stage-sp profile)
         json.dump(rec, open(os.path.join(ROOT, 'profiles', os.environ.get('SKGS_PMC_JSON', 'pmc_render_backward.json')), 'w'), indent=1)
     print('\n'.join(md[:14]))
