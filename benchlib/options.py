@@ -199,9 +199,11 @@ def build_parser():
     ap.add_argument('--sep-rot', action='store_true',
                     help="--stage sp: the deform network's local_rotation head feeds the rotation blend (sep_rot, the class default "
                          "sk_gs.py:357 and what exps/d_nerf_sc_gs.yaml runs with)")
-    ap.add_argument('--reference-loop', choices=('hooks', 'accelerated'), default=None,
-                    help="time the REFERENCE's own call sequence (tests/ref_sequence.py + train.py's step) on install_reference_hooks() "
-                         "alone, or after accelerate_reference(): what a user of the unmodified reference gets (benchlib/reference_loop.py)")
+    ap.add_argument('--reference-loop', choices=('hooks', 'accelerated', 'fused'), default=None,
+                    help="time the REFERENCE's own call sequence (benchlib/ref_sequence.py + train.py's step) on install_reference_hooks() "
+                         "alone, after accelerate_reference(fused_render=False) (per-method fast paths), or -- fused -- with "
+                         "SkeletonGaussianSplatting.render / ImageLoss.forward / SSIM_Loss.forward routed into the fused step "
+                         "(sk_gs_amd/reference_fused.py): what a user of the unmodified reference gets (benchlib/reference_loop.py)")
     ap.add_argument('--raw-time', action='store_true',
                     help="--stage sp: DeformNetwork(is_blender=False) (sk_gs.py:220,255-261; no shipped YAML): no time network, time "
                          "degree 10, and the stage's time noise (sk_gs.py:837-839) drawn on the device inside the captured step")

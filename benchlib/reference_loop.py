@@ -1,6 +1,6 @@
-"""`bench.py --reference-loop hooks | accelerated`: one training iteration AS THE REFERENCE WRITES IT, on this package's hooks.
+"""`bench.py --reference-loop hooks | accelerated | fused`: one training iteration AS THE REFERENCE WRITES IT, on this package's hooks.
 
-The GPU box has no /root/reference, so the loop is the reference's call sequence restated (tests/ref_sequence.py -- replayed against
+The GPU box has no /root/reference, so the loop is the reference's call sequence restated (benchlib/ref_sequence.py -- replayed against
 the reference's own recorded run by tests/test_gpu_lietorch.py -- plus the lines of train.py / gaussian_splatting.py named below), written
 only against what `sk_gs_amd.install_reference_hooks()` puts under an unmodified checkout:
 
@@ -13,9 +13,14 @@ only against what `sk_gs_amd.install_reference_hooks()` puts under an unmodified
     loss.backward(); torch.optim.Adam(eps=1e-15).step(); zero_grad(set_to_none)            train.py:179-250, gaussian_splatting.py:443-453
 
 `hooks`: exactly that -- every launch is one the reference's own Python issues (eager, no graph: the sequence holds blocking
-host-to-device copies, `x.new_tensor([...])`).  `accelerated`: the same loop after `sk_gs_amd.accelerate_reference()` -- the five
-methods it patches (network forward, kinematic, calc_LBS_weight, SSIM_Loss.forward) and torch.optim.Adam.step run their fast paths;
-everything else unchanged.
+host-to-device copies, `x.new_tensor([...])`).  `accelerated`: the same loop after `sk_gs_amd.accelerate_reference(fused_render=False)`
+-- the five methods it patches (network forward, kinematic, calc_LBS_weight, SSIM_Loss.forward) and torch.optim.Adam.step run their fast
+paths; everything else unchanged.  `fused` (round 6): the loop as `train.py:179-250` + `framework.execute_backward` write it --
+`outputs = model.render(t=, info=, background=, time_id=)`, `losses = model.loss(...)` (the `rgb` / `ssim` lines, sk_gs.py:1524-1529,
+through a `LossDict`), `sum(losses.values()).backward()`, `optimizer.step()`, `zero_grad(set_to_none=True)` -- on a stand-in model with
+the reference's attribute names, with the three methods `accelerate_reference()` patches for the fused route bound to it:
+`SkeletonGaussianSplatting.render`, `ImageLoss.forward`, `SSIM_Loss.forward` (sk_gs_amd/reference_fused.py).  `info` holds DEVICE
+tensors, as after `tensor_to(data, device)` (train.py:180).
 The number is what a user of the UNMODIFIED reference gets on one MI355X; the package's own trainer (`FusedTrainStep`, the default bench
 line) is the same arithmetic as 12 launches in a graph.
 """
@@ -30,15 +35,17 @@ import torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(args, configs):
-    sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    import ref_sequence as rs
+def setup(args, configs):
+    """everything up to the timed loop: the scene, the optimizer, the targets and ``step(i)`` of the requested mode (a namespace; the
+    tests drive the pieces in-process: tests/test_gpu_reference_fused.py)"""
+    from benchlib import ref_sequence as rs
     from sk_gs_amd import _C, lietorch as L, pytorch3d_ops as p3d, reference_accel as ra, scene
     from sk_gs_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     from sk_gs_amd.losses import ssim_loss
     from sk_gs_amd.skeleton import build_ancestor_table
     sys.modules.setdefault('lietorch', L)
-    accel = args.reference_loop == 'accelerated'
+    fused = args.reference_loop == 'fused'
+    accel = args.reference_loop == 'accelerated' or fused
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
     torch.autograd.set_multithreading_enabled(False)
@@ -171,6 +178,52 @@ def run(args, configs):
         opt.step()
         return loss
 
+    rf = None
+    if fused:
+        assert not sp, '--reference-loop fused: stage sk (stage sp runs `accelerated`)'
+        from sk_gs_amd import reference_fused as rf
+        model = _RefSkeletonModel(p, net, table.to(dev).int(), frames, M, K, dev)
+        # what a call outside the fused route's conditions reaches: the reference's own render, i.e. the `accelerated` sequence above
+        ra._originals['render'] = lambda self, *a, t=None, info=None, time_id=None, **kw: {
+            'images': render(int(time_id), deform(int(time_id))).permute(1, 2, 0)[None], 'stage': 'sk'}
+        image_crit, ssim_crit = _RefImageLoss(), types.SimpleNamespace(window_size=11, reduction='mean')
+        ra._originals['image_loss'] = _RefImageLoss.reference_forward
+        cams = [scene.make_camera(W, H, seed=v) for v in range(args.views)]
+        infos = [{k: (c[k].to(dev) if torch.is_tensor(c[k]) else c[k]) for k in ('Tw2v', 'Tv2c', 'FoV', 'campos', 'size')} for c in cams]
+        time_ids = [torch.tensor([v], device=dev) for v in range(args.views)]               # int64, as the loader's `time_id`
+        targets_hwc = [tg.permute(1, 2, 0)[None].contiguous() for tg in targets]             # [1,H,W,3]: targets['images']
+        weights = {'image': 0.8, 'ssim': 0.2}                                                # exps/default.yaml:86-88
+
+        def loss_funcs(name, *inputs):                                                       # LossDict.forward (losses/build.py:55-64)
+            func = {'image': lambda a, b: rf.image_loss_forward(image_crit, a, b), 'ssim': lambda a, b: ra.ssim_loss_forward(ssim_crit, a, b)}[name]
+            return func(*inputs) * weights[name]
+
+        def model_loss(outputs, tgt):                                                        # sk_gs.py:1524-1529 (stage sk: nothing else)
+            image, gt_img = outputs['images'], tgt[..., :3]
+            Hh, Ww, Cc = image.shape[-3:]
+            image, gt_img = image.view(1, Hh, Ww, Cc), gt_img.view(1, Hh, Ww, Cc)
+            return {'rgb': loss_funcs('image', image, gt_img), 'ssim': loss_funcs('ssim', image, gt_img)}
+
+        def step(i):  # noqa: F811
+            v = i % args.views
+            outputs = rf.render(model, t=times[v], info=infos[v], background=bg, time_id=time_ids[v])      # train.py:190
+            losses = model_loss(outputs, targets_hwc[v])                                      # :194
+            loss = sum(losses.values())                                                      # framework.py:268
+            loss.backward()                                                                  # :286
+            opt.step()                                                                       # :304
+            opt.zero_grad(set_to_none=True)                                                  # :305
+            return loss
+
+    return types.SimpleNamespace(step=step, p=p, net=net, opt=opt, rf=rf, ra=ra, L=L, p3d=p3d, _C=_C, cfg=cfg, P=P, M=M, K=K, W=W, H=H, sp=sp,
+                                 accel=accel, fused=fused, targets=targets, deform=deform, render=render, loss_of=loss_of, times=times, bg=bg,
+                                 model=locals().get('model'), infos=locals().get('infos'), time_ids=locals().get('time_ids'),
+                                 targets_hwc=locals().get('targets_hwc'), model_loss=locals().get('model_loss'))
+
+
+def run(args, configs):
+    s = setup(args, configs)
+    step, rf, ra, L, p3d, _C, cfg, P, M, K, W, H, sp, accel, fused, model = (
+        s.step, s.rf, s.ra, s.L, s.p3d, s._C, s.cfg, s.P, s.M, s.K, s.W, s.H, s.sp, s.accel, s.fused, s.model)
     for i in range(max(args.warmup, 5)):
         step(i)
     torch.cuda.synchronize()
@@ -185,11 +238,54 @@ def run(args, configs):
         'value': round(args.steps / elapsed, 3), 'unit': 'iters/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': max(args.warmup, 5),
         'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'{cfg["name"]}' + (' in stage sp' if sp else '') + f': {P} Gaussians, {M} ' + ('superpoints (3+8-d search, weighted_kernel)' if sp else 'bones') + f', K={K}, SH degree 3, {W}x{H}, {args.views} synthetic views',
-                   'step': ("the reference's call sequence restated (tests/ref_sequence.py + train.py:179-250) on install_reference_hooks() alone: "
+                   'step': ("the reference's call sequence restated (benchlib/ref_sequence.py + train.py:179-250) on install_reference_hooks() alone: "
                             "torch network, lietorch / pytorch3d stand-ins, diff_gaussian_rasterization stand-in, torch SSIM, torch.optim.Adam; eager"
                             if not accel else
                             "the same loop after accelerate_reference(): network forward, kinematic, calc_LBS_weight and SSIM_Loss.forward on "
-                            "their fast paths, torch.optim.Adam.step as one launch (sk_gs_amd.reference_accel); rasterizer stand-in unchanged; eager"),
+                            "their fast paths, torch.optim.Adam.step as one launch (sk_gs_amd.reference_accel); rasterizer stand-in unchanged; eager"
+                            if not fused else
+                            "train.py:179-250 / framework.execute_backward restated -- outputs = model.render(t, info, background, time_id); "
+                            "losses = model.loss(...) [rgb, ssim through a LossDict]; sum(losses).backward(); optimizer.step(); zero_grad(set_to_none) "
+                            "-- with SkeletonGaussianSplatting.render, ImageLoss.forward and SSIM_Loss.forward as accelerate_reference() patches them "
+                            "(sk_gs_amd.reference_fused: the package's fused launches on the model's own Parameters, info on the device, "
+                            "no host read-back), torch.optim.Adam.step as one launch; eager"),
                    'loss_last': float(last.detach()), 'sync_num_rendered': bool(_C.config.sync_num_rendered), 'accelerators': dict(ra.calls) if accel else None,
-                   'lie_fused_calls': dict(L.fused_calls), 'knn_hip_calls': dict(p3d.hip_calls)},
+                   'lie_fused_calls': dict(L.fused_calls), 'knn_hip_calls': dict(p3d.hip_calls),
+                   'fused_route': None if rf is None else dict(calls=dict(rf.calls), why_not=dict(rf.why_not),
+                                                                status=_route_status(rf, model))},
     }
+
+
+def _route_status(rf, model):
+    r = rf._routes.get(model)
+    if r is None or isinstance(r, tuple):
+        return None
+    st = r.step.status()
+    return dict(tile_bucket=r._bucket, overflow_events=st['overflow_events'], mlp_failed=st.get('mlp_failed', 0))
+
+
+class _RefImageLoss:
+    """ImageLoss(method='l1') (networks/losses/image_loss.py:6-32): the attributes the patch probes + the reference's own forward"""
+    method, masked = 'l1', False
+
+    def reference_forward(self, pred_image, gt_image, mask=None):
+        return F.l1_loss(pred_image[..., :3], gt_image[..., :3])
+
+
+class _RefSkeletonModel:
+    """the attributes of ``SkeletonGaussianSplatting`` (networks/sk_gs.py:342-540, gaussian_splatting.py:101-183) the fused route reads,
+    under the reference's names, around the SAME Parameter objects the optimizer holds (tests/test_host_cpu.py runs the route's condition
+    and re-homing code on the reference's real class in the build container)"""
+    training, use_official_gaussians_render, convert_SHs_python, compute_cov3D = True, True, False, False
+    LBS_method, sk_feature, _R_dim, max_sh_degree, test_time_interpolate = 'W', None, 4, 3, False
+
+    def __init__(self, p, net, table, frames, M, K, dev):
+        for k_ in ('_xyz', '_features_dc', '_features_rest', '_scaling', '_rotation', '_opacity', 'sp_W', 'joints', 'global_tr'):
+            setattr(self, k_, p[k_])
+        self.sk_deform_net, self.joint_parents, self.joint_root, self.num_knn = net, table, torch.tensor(0), K
+        self.sk_cache = torch.zeros(frames, M, 11, device=dev)
+        self.sk_is_init = torch.tensor(True, device=dev)
+        self._active_sh_degree = torch.tensor(3, dtype=torch.int, device=dev)
+
+    def get_now_stage(self, stage=None):
+        return 'sk' if stage is None else stage

@@ -442,6 +442,25 @@ int skgs_image_loss_forward(int32_t C, int32_t H, int32_t W, const float* pred, 
 int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred, const float* gt, const int32_t* gt_index,
     float lambda_l1, float lambda_ssim, const float* grad_loss, const void* workspace, size_t workspace_bytes,
     float* dL_dpred, float* loss3, skgs_stream_t stream);
+/* The backward for a caller that holds the two terms as SEPARATE autograd outputs -- the reference's loss dict keeps
+ * losses['rgb'] = w_image * L1 and losses['ssim'] = w_ssim * (1 - SSIM) apart (networks/sk_gs.py:1527-1529, losses/build.py:55-64),
+ * so autograd hands back one cotangent per term:  dL_dpred = *grad_l1 * d(L1 mean)/dpred + *grad_ssim * d(1 - SSIM mean)/dpred.
+ * grad_l1 / grad_ssim: DEVICE scalars; one of them may be NULL (= 0).  Same workspace as skgs_image_loss_backward. */
+int skgs_image_loss_backward_terms(int32_t C, int32_t H, int32_t W, const float* pred, const float* gt,
+    const int32_t* gt_index, const float* grad_l1, const float* grad_ssim, const void* workspace, size_t workspace_bytes,
+    float* dL_dpred, skgs_stream_t stream);
+
+/* ---- the live view slot from the reference's per-view tensors (no host read-back) ----
+ * Replaces the host side of `prepare_inputs` (networks/gaussian_splatting.py:247-300) for one view: the reference builds
+ * GaussianRasterizationSettings from `info` with `math.tan(0.5 * FoV[b, 0])` and `info['Tw2v']` on the host -- a blocking
+ * device-to-host copy per iteration once `tensor_to(data, device)` (train.py:180) has put `info` on the GPU.  This launch writes
+ * the 64-word record the kernels read their camera from (skgs_raster_inputs.viewmatrix / projmatrix / campos /
+ * tanfov_device, skgs_bone_chain_*'s frame_index, the deform network's time; layout: sk_gs_amd/view_slot.py) from DEVICE
+ * inputs:  viewmatrix = Tw2v^T, projmatrix = (Tv2c Tw2v)^T (:278-279), campos, tanfov = tan(0.5 FoV) (float product,
+ * double tangent, as the host expression), time = *time, frame = *frame_index_device (int64, the data loader's `time_id`) or
+ * the host value frame_index when that pointer is NULL.  Tw2v, Tv2c: [4,4] row-major; fov: [2]. */
+int skgs_view_slot_fill(const float* Tw2v, const float* Tv2c, const float* campos, const float* fov, const float* time,
+    const int64_t* frame_index_device, int32_t frame_index, int32_t target_index, float* slot, skgs_stream_t stream);
 
 /* ---- multi-tensor Adam step in one launch (scope row (f)-2) ----
  * Replaces torch.optim.Adam(eps=1e-15) as configured by exps/default.yaml:122-125 over the parameter groups of

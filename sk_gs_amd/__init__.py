@@ -150,7 +150,7 @@ def install_reference_hooks(single_thread: bool = True, accelerate: bool = False
 
 
 def accelerate_reference(ssim: bool = True, kinematic_chain: bool = True, networks: bool = True, lbs_weights: bool = True,
-                         adam: bool = True, swizzle: bool = True) -> list:
+                         adam: bool = True, swizzle: bool = True, fused_render: bool = True) -> list:
     """AFTER the reference has been imported (``install_reference_hooks()`` before it): give methods of its classes a fast path --
     ``SSIM_Loss.forward`` (3.5 ms of depth-wise convolutions per image -> the fused loss kernels),
     ``SkeletonGaussianSplatting.kinematic`` (~60 Lie-group launches -> one bone-chain launch per direction),
@@ -159,9 +159,15 @@ def accelerate_reference(ssim: bool = True, kinematic_chain: bool = True, networ
     row-block kernels; both on the reference modules' OWN parameter objects) -- and ``torch.optim.Adam.step`` (one launch over the
     optimizer's own state tensors instead of ~80; ``adam=False`` leaves torch alone) and the rasterizer adapter's quaternion swizzle (two
     slices instead of an index list: call this BEFORE the model is built).  Same arguments, same returned objects, the reference's
-    own method for every call outside the fast path's conditions; ``sk_gs_amd.reference_accel``."""
+    own method for every call outside the fast path's conditions; ``sk_gs_amd.reference_accel``.
+
+    ``fused_render`` (round 6): ``SkeletonGaussianSplatting.render`` + ``ImageLoss.forward`` + ``SSIM_Loss.forward`` put the package's
+    WHOLE fused per-view step (11 launches forward + backward, the trainer's own) behind the reference's iteration for stage ``sk`` on
+    the model's own parameters -- ``sk_gs_amd.reference_fused``; calls outside its conditions run the reference's ``render`` and, inside
+    it, the per-method fast paths above."""
     from sk_gs_amd import reference_accel
-    return reference_accel.accelerate_reference(ssim=ssim, kinematic_chain=kinematic_chain, networks=networks, lbs_weights=lbs_weights, adam=adam, swizzle=swizzle)
+    return reference_accel.accelerate_reference(ssim=ssim, kinematic_chain=kinematic_chain, networks=networks, lbs_weights=lbs_weights, adam=adam,
+                                                swizzle=swizzle, fused_render=fused_render)
 
 
 def install_as_diff_gaussian_rasterization(single_thread: bool = True):

@@ -29,6 +29,36 @@ int fill_u32(void* p, uint32_t v, size_t n_words, hipStream_t s) {
   return 0;
 }
 
+// ---- the live view slot from the reference's per-view `info` tensors (skgs_view_slot_fill) -------------------------------
+// One thread per output word; every input is a DEVICE load: no host read-back between the data loader and the launches.
+__global__ void view_slot_fill_kernel(const float* __restrict__ Tw2v, const float* __restrict__ Tv2c,
+    const float* __restrict__ campos, const float* __restrict__ fov, const float* __restrict__ time,
+    const int64_t* __restrict__ frame64, int32_t frame_host, int32_t target_index, float* __restrict__ slot) {
+#pragma clang fp contract(off)
+  const int w = threadIdx.x;
+  if (w < 16) {  // viewmatrix = Tw2v^T, row-major: word[4 i + j] = Tw2v[j][i]   (gaussian_splatting.py:278)
+    slot[w] = Tw2v[4 * (w & 3) + (w >> 2)];
+  } else if (w < 32) {  // projmatrix = (Tv2c Tw2v)^T: word[16 + 4 i + j] = sum_k Tv2c[j][k] Tw2v[k][i]   (:279)
+    const int i = (w - 16) >> 2, j = (w - 16) & 3;
+    float acc = Tv2c[4 * j + 0] * Tw2v[0 + i];
+    acc = acc + Tv2c[4 * j + 1] * Tw2v[4 + i];
+    acc = acc + Tv2c[4 * j + 2] * Tw2v[8 + i];
+    acc = acc + Tv2c[4 * j + 3] * Tw2v[12 + i];
+    slot[w] = acc;
+  } else if (w < 35) {
+    slot[w] = campos[w - 32];
+  } else if (w == 36 || w == 37) {  // math.tan(0.5 * FoV[b, c]): the product in float32 (a tensor op), the tangent in double (:274-275)
+    const float h = 0.5f * fov[w - 36];
+    slot[w] = (float) tan((double) h);
+  } else if (w == 38) {
+    slot[w] = time ? time[0] : 0.f;
+  } else if (w == 39) {
+    reinterpret_cast<int32_t*>(slot)[w] = frame64 ? (int32_t) frame64[0] : frame_host;
+  } else if (w == 40) {
+    reinterpret_cast<int32_t*>(slot)[w] = target_index;
+  }
+}
+
 // ---- per-kernel event timing ---------------------------------------------------------------------------------
 namespace {
 constexpr int PROF_RING = 4096;
@@ -100,6 +130,15 @@ static int check_buffers(const skgs_raster_inputs* in, const skgs_raster_buffers
 using namespace skgs;
 
 extern "C" {
+
+int skgs_view_slot_fill(const float* Tw2v, const float* Tv2c, const float* campos, const float* fov, const float* time,
+    const int64_t* frame_index_device, int32_t frame_index, int32_t target_index, float* slot, skgs_stream_t stream) {
+  SKGS_REQUIRE(Tw2v && Tv2c && campos && fov && slot, "view_slot_fill: bad argument");
+  hipLaunchKernelGGL(view_slot_fill_kernel, dim3(1), dim3(64), 0, (hipStream_t) stream, Tw2v, Tv2c, campos, fov, time,
+      frame_index_device, frame_index, target_index, slot);
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 
 void skgs_profile_enable(uint32_t kernel_mask) { g_prof_mask = kernel_mask; }
 int skgs_profile_kernel_count(void) { return K_COUNT; }

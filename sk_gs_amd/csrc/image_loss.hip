@@ -271,7 +271,8 @@ __global__ void __launch_bounds__(256) image_loss_finalize_kernel(int nblocks, d
 
 __global__ void __launch_bounds__(NT) image_loss_backward_kernel(int C, int H, int W, const float* __restrict__ pred,
     const float* __restrict__ gt, const int32_t* __restrict__ gt_index, Win win, const float* __restrict__ dmaps,
-    const float* __restrict__ grad_loss, float scale_l1, float scale_ssim, float* __restrict__ dL_dpred,
+    const float* __restrict__ grad_loss, const float* __restrict__ grad_l1, const float* __restrict__ grad_ssim, float scale_l1,
+    float scale_ssim, float* __restrict__ dL_dpred,
     const float* __restrict__ partials, int nblocks, double inv_n, float lambda_l1, float lambda_ssim,
     float* __restrict__ loss3) {
   // the staged maps and, once every thread holds its filtered segment in registers, the filtered rows share one buffer
@@ -353,6 +354,12 @@ __global__ void __launch_bounds__(NT) image_loss_backward_kernel(int C, int H, i
     }
   }
   const float g = grad_loss ? grad_loss[0] : 1.0f;
+  // separate cotangents of the two terms (skgs_image_loss_backward_terms: the L1 mean and 1 - SSIM mean are two autograd outputs,
+  // each weighted by its own factor outside: networks/losses/build.py:55-64); a missing one is zero.  Wave-uniform branch: the
+  // one-cotangent form keeps its expression (and its bits).
+  const bool terms = grad_l1 != nullptr || grad_ssim != nullptr;
+  const float gs = terms ? (grad_ssim ? grad_ssim[0] : 0.f) * scale_ssim : scale_ssim;
+  const float gl = terms ? (grad_l1 ? grad_l1[0] : 0.f) * scale_l1 : scale_l1;
 #pragma unroll
   for (int o = 0; o < VSEG_B; ++o) {
     const int gy = y0 + ty0 + o;
@@ -361,7 +368,8 @@ __global__ void __launch_bounds__(NT) image_loss_backward_kernel(int C, int H, i
       const float x = xs[o], y = ys[o];
       const float d = x - y;
       const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-      stream_store<NT_LOSS_BWD>(dL_dpred + oo, g * (scale_ssim * (v[o][0] + 2.f * x * v[o][1] + y * v[o][2]) + scale_l1 * sgn));
+      const float r = gs * (v[o][0] + 2.f * x * v[o][1] + y * v[o][2]) + gl * sgn;
+      stream_store<NT_LOSS_BWD>(dL_dpred + oo, terms ? r : g * r);
     }
   }
   // the loss value itself, when the forward left it to this launch (one workgroup, off everybody else's critical path)
@@ -428,8 +436,26 @@ int skgs_image_loss_backward(int32_t C, int32_t H, int32_t W, const float* pred,
   const int nblocks     = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * C;
   ProfScope prof(K_LOSS_BWD, (hipStream_t) stream);
   hipLaunchKernelGGL(image_loss_backward_kernel, tile_grid(C, H, W, TH_B), dim3(NT), 0, (hipStream_t) stream, C, H, W, pred, gt,
-      gt_index, make_window(), dmaps, grad_loss, lambda_l1 / n, -lambda_ssim / n, dL_dpred, partials, nblocks,
-      1.0 / ((double) C * H * W), lambda_l1, lambda_ssim, loss3);
+      gt_index, make_window(), dmaps, grad_loss, (const float*) nullptr, (const float*) nullptr, lambda_l1 / n, -lambda_ssim / n,
+      dL_dpred, partials, nblocks, 1.0 / ((double) C * H * W), lambda_l1, lambda_ssim, loss3);
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int skgs_image_loss_backward_terms(int32_t C, int32_t H, int32_t W, const float* pred, const float* gt, const int32_t* gt_index,
+    const float* grad_l1 /*device scalar or NULL (= 0)*/, const float* grad_ssim /*device scalar or NULL (= 0)*/,
+    const void* workspace, size_t workspace_bytes, float* dL_dpred, skgs_stream_t stream) {
+  SKGS_REQUIRE(C > 0 && H > 0 && W > 0 && pred && gt && workspace && dL_dpred, "image_loss_backward_terms: bad argument");
+  SKGS_REQUIRE(grad_l1 || grad_ssim, "image_loss_backward_terms: at least one cotangent");
+  SKGS_REQUIRE(workspace_bytes >= skgs_image_loss_workspace_bytes(C, H, W), "image_loss_backward_terms: workspace too small");
+  const float* dmaps = reinterpret_cast<const float*>(workspace);
+  const float n      = (float) ((double) C * H * W);
+  const float* partials = dmaps + (size_t) 3 * C * H * W;
+  const int nblocks     = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * C;
+  ProfScope prof(K_LOSS_BWD, (hipStream_t) stream);
+  hipLaunchKernelGGL(image_loss_backward_kernel, tile_grid(C, H, W, TH_B), dim3(NT), 0, (hipStream_t) stream, C, H, W, pred, gt,
+      gt_index, make_window(), dmaps, (const float*) nullptr, grad_l1, grad_ssim, 1.0f / n, -1.0f / n, dL_dpred, partials, nblocks,
+      1.0 / ((double) C * H * W), 1.0f, 1.0f, (float*) nullptr);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -315,8 +315,12 @@ class FusedViewStep:
         m = self.model
         if time_id is None:
             from sk_gs_amd import view_slot as vsl
-            return m.global_tr.data_ptr(), m.global_tr.grad.data_ptr(), C.c_void_p(self.view_table.ptr(vsl.W_FRAME))
-        return m.global_tr[time_id].data_ptr(), m.global_tr.grad[time_id].data_ptr(), None
+            # (a forward may run while the gradients are detached -- zero_grad(set_to_none=True) of a foreign loop: the gradient
+            # pointers are only read by the backward launches)
+            gg = m.global_tr.grad
+            return m.global_tr.data_ptr(), (None if gg is None else gg.data_ptr()), C.c_void_p(self.view_table.ptr(vsl.W_FRAME))
+        gg = m.global_tr.grad
+        return m.global_tr[time_id].data_ptr(), (None if gg is None else gg[time_id].data_ptr()), None
 
     def forward(self, rs: Optional[GaussianRasterizationSettings] = None, time_id: Optional[int] = None):
         """bone chain -> KNN + LBS weights -> skin + activations -> rasterize.  Fills ``image`` / ``out_opacity``.
@@ -420,6 +424,12 @@ class FusedViewStep:
                                          C.c_float(self.lambda_l1), C.c_float(self.lambda_ssim), _p(grad_loss),
                                          _p(self.loss_ws), C.c_size_t(self.loss_ws.numel()), _p(self.dL_dimage),
                                          _p(self.loss3), st))
+        self._raster_backward(a, d, time_id)
+
+    def _raster_backward(self, a, d, time_id):
+        """the rasterizer backward on the cotangent in ``dL_dimage`` (written by the loss backward, or by a caller that holds
+        d objective / d image itself: sk_gs_amd/reference_fused.py)"""
+        lib, m, st, chk = self.lib, self.model, _C._stream(), _C._check
         # ---- rasterize backward: SH gradients land in the parameters' .grad, the rest feeds the skinning backward
         g = _C._RasterGrads()
         g.dL_dout_color = self.dL_dimage.data_ptr()  # dL_dout_opacity = NULL: the background term is in-kernel
@@ -646,7 +656,7 @@ class FusedViewStep:
         b.frame_index = fidx.value if isinstance(fidx, C.c_void_p) else fidx
         b.bone_T, b.chain_A = self.bone_T.data_ptr(), self.chain_A.data_ptr()
         b.sk_r_raw, b.g_bone_T = self._sk_r_raw.data_ptr(), self.g_bone_T.data_ptr()
-        b.g_joints = m.joints.grad.data_ptr() if getattr(m, 'learn_joints', False) else None
+        b.g_joints = m.joints.grad.data_ptr() if (getattr(m, 'learn_joints', False) and m.joints.grad is not None) else None
         b.g_global_T = g_gT
         # every training step refreshes the frame's row of the test-time cache (sk_gs.py:1077-1079); written by the launch
         # (the frame's row: by pointer for an explicit time_id, base + the slot's frame index otherwise -- like global_T)

@@ -76,6 +76,12 @@ def _as_chw(img: torch.Tensor):
 
 def ssim_loss_forward(self, img1, img2):
     """``SSIM_Loss.forward`` (networks/losses/ssim.py:26-43): ``1 - mean SSIM`` of one image pair through the fused kernels"""
+    if 'render' in _originals:      # an image out of the fused render node: the term comes from the one fused loss launch
+        from sk_gs_amd import reference_fused as rf
+        term = rf.ssim_terms(self, img1, img2)
+        if term is not None:
+            calls['ssim_fused'] += 1
+            return term
     if getattr(self, 'window_size', 11) == 11 and getattr(self, 'reduction', 'mean') == 'mean' and img1.shape == img2.shape:
         a, b = _as_chw(img1), _as_chw(img2)
         if a is not None and b is not None:
@@ -190,9 +196,10 @@ def simple_deform_forward(self, points, t):
         calls['sk_net_reference'] += 1
         return _originals['sk_net'](self, points, t)
     net, heads = sh.dynamic_net, self.dynamic_net.last
-    with torch.no_grad():  # the kernels read ONE head matrix: the current values of the reference's heads, in their order
-        torch.cat([h.weight for h in heads], out=net.last_weight.data)
-        torch.cat([h.bias for h in heads], out=net.last_bias.data)
+    if getattr(sh, '_heads_rehomed', None) is None:   # (re-homed by the fused route: the heads ARE rows of that matrix already)
+        with torch.no_grad():  # the kernels read ONE head matrix: the current values of the reference's heads, in their order
+            torch.cat([h.weight for h in heads], out=net.last_weight.data)
+            torch.cat([h.bias for h in heads], out=net.last_bias.data)
     # (what autograd differentiates: the same concatenations -- the gradient of the fused head matrix is split back onto the heads)
     params = [p for l in net.net for p in (l.weight, l.bias)] + [torch.cat([h.weight for h in heads]), torch.cat([h.bias for h in heads])]
     out = _DeformMLPFn.apply(sh, torch.is_grad_enabled(), points, t.to(points.device), *params)
@@ -435,7 +442,7 @@ def _fully_imported(name: str) -> bool:
     return m is not None and not getattr(spec, '_initializing', False)
 
 
-_WATCHED = ('networks.sk_gs', 'networks.losses.ssim', 'networks.renderer.gaussian_render_origin')
+_WATCHED = ('networks.sk_gs', 'networks.losses.ssim', 'networks.losses.image_loss', 'networks.renderer.gaussian_render_origin')
 
 
 class _PostImportPatcher:
@@ -488,7 +495,7 @@ def install_post_import_patcher(**kwargs):
 
 
 def accelerate_reference(ssim: bool = True, kinematic_chain: bool = True, networks: bool = True, lbs_weights: bool = True,
-                         adam: bool = True, swizzle: bool = True, strict: bool = True) -> list:
+                         adam: bool = True, swizzle: bool = True, strict: bool = True, fused_render: bool = True) -> list:
     """Patch the methods on the reference's classes (the modules must be imported already; ``strict=False``: patch what IS imported,
     skip the rest -- what the post-import hook of ``install_reference_hooks(accelerate=True)`` calls as the modules arrive).  Returns what
     was patched."""
@@ -496,6 +503,21 @@ def accelerate_reference(ssim: bool = True, kinematic_chain: bool = True, networ
     if not strict:
         sk, ss = _fully_imported('networks.sk_gs'), _fully_imported('networks.losses.ssim')
         networks, kinematic_chain, lbs_weights, ssim = networks and sk, kinematic_chain and sk, lbs_weights and sk, ssim and ss
+        fused_render = fused_render and sk and ss and _fully_imported('networks.losses.image_loss')
+    if fused_render:
+        # the whole per-view step behind SkeletonGaussianSplatting.render + the two image terms (sk_gs_amd/reference_fused.py): render
+        # falls back to the reference's own method -- and with it to the per-method fast paths below -- whenever its conditions fail
+        from sk_gs_amd import reference_fused as rf
+        mod, il = sys.modules.get('networks.sk_gs'), sys.modules.get('networks.losses.image_loss')
+        if mod is None or il is None:
+            raise RuntimeError("accelerate_reference(): import the reference first (networks.sk_gs / networks.losses.image_loss are not loaded)")
+        if 'render' not in _originals:
+            _originals['render'] = mod.SkeletonGaussianSplatting.render
+            mod.SkeletonGaussianSplatting.render = rf.render
+        if 'image_loss' not in _originals:
+            _originals['image_loss'] = il.ImageLoss.forward
+            il.ImageLoss.forward = rf.image_loss_forward
+        done += ['networks.sk_gs.SkeletonGaussianSplatting.render', 'networks.losses.image_loss.ImageLoss.forward']
     if networks:
         mod = sys.modules.get('networks.sk_gs')
         if mod is None:
@@ -552,6 +574,15 @@ def accelerate_reference(ssim: bool = True, kinematic_chain: bool = True, networ
 
 def restore_reference():
     """put the reference's own methods back"""
+    if 'render' in _originals and 'networks.sk_gs' in sys.modules:
+        sys.modules['networks.sk_gs'].SkeletonGaussianSplatting.render = _originals.pop('render')
+        from sk_gs_amd import reference_fused as rf
+        for ref in list(rf._routes.keys()):     # the heads the fused route re-homed get storage of their own again
+            if hasattr(ref, 'sk_deform_net'):
+                rf.unhome_heads(ref.sk_deform_net)
+        rf._routes.clear()
+    if 'image_loss' in _originals and 'networks.losses.image_loss' in sys.modules:
+        sys.modules['networks.losses.image_loss'].ImageLoss.forward = _originals.pop('image_loss')
     if 'ssim' in _originals and 'networks.losses.ssim' in sys.modules:
         sys.modules['networks.losses.ssim'].SSIM_Loss.forward = _originals.pop('ssim')
     if 'kinematic' in _originals and 'networks.sk_gs' in sys.modules:

@@ -1,5 +1,5 @@
 """GPU tests of the lietorch / pytorch3d stand-ins (VERDICT r4 row b''): the reference's deform call sequence -- restated in
-tests/ref_sequence.py, pinned on CPU against the reference's own run (tests/golden/sk_stage.npz) -- driven on the MI355X through
+benchlib/ref_sequence.py, pinned on CPU against the reference's own run (tests/golden/sk_stage.npz) -- driven on the MI355X through
 ``sk_gs_amd.lietorch`` / ``sk_gs_amd.pytorch3d_ops``, where the skinning expression and the search are launches of libskgs_hip.so
 (``skgs_se3_blend_forward/backward``, ``skgs_knn_bones``, ``skgs_sp_lbs_weights_forward``).
 
@@ -14,7 +14,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-import ref_sequence as rs
+from benchlib import ref_sequence as rs
 from helpers import rel_err, to_np
 
 pytestmark = pytest.mark.gpu

@@ -1,0 +1,189 @@
+"""The fused step UNDER the reference's own API (sk_gs_amd/reference_fused.py): ``SkeletonGaussianSplatting.render`` +
+``ImageLoss.forward`` + ``SSIM_Loss.forward`` as ``accelerate_reference()`` patches them, driven on a stand-in model with the reference's
+attribute names (benchlib/reference_loop.py; the real class runs the same condition / re-homing code in tests/test_host_cpu.py) against
+the reference's own call sequence on the stand-ins (benchlib/ref_sequence.py, pinned by tests/golden/sk_stage.npz)."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+SMALL = {9: dict(name='small-4k-160', P=4000, M=12, K=4, W=160, H=120)}
+
+
+def _setup(mode, extra=()):
+    from benchlib import options, reference_loop
+    from sk_gs_amd import reference_accel as ra, reference_fused as rf
+    ra.restore_reference()
+    for k in list(ra._originals):
+        ra._originals.pop(k)
+    for k in rf.calls:
+        rf.calls[k] = 0
+    args = options.build_parser().parse_args(['--reference-loop', mode, '--config', '9', '--views', '3', '--scale-mult', '2.0', *extra])
+    return reference_loop.setup(args, SMALL)
+
+
+def _teardown(s):
+    import torch.optim
+    if 'adam' in s.ra._originals:
+        torch.optim.Adam.step = s.ra._originals.pop('adam')
+    for k in list(s.ra._originals):
+        s.ra._originals.pop(k)
+
+
+def test_one_iteration_gives_the_gradients_of_the_reference_sequence():
+    """forward values and EVERY parameter's gradient of one iteration through the fused route == the reference's own sequence (stand-ins +
+    rasterizer adapter + torch L1 + fused SSIM) on the same parameters; the returned dict holds what ``loss`` / ``adaptive_control`` read"""
+    s = _setup('fused')
+    try:
+        rf, v = s.rf, 1
+        names = dict(s.p)
+        names.update({f'net.{n}': q for n, q in s.net.named_parameters()})
+        # reference sequence (the `accelerated` path of the same loop) -> autograd gradients
+        for q in names.values():
+            q.grad = None
+        img = s.render(v, s.deform(v))
+        loss_ref = s.loss_of(img, s.targets[v])
+        loss_ref.backward()
+        want = {n: (None if q.grad is None else q.grad.detach().clone()) for n, q in names.items()}
+        img_ref = img.detach().clone()
+        for q in names.values():
+            q.grad = None
+        # fused route
+        out = rf.render(s.model, t=s.times[v], info=s.infos[v], background=s.bg, time_id=s.time_ids[v])
+        assert rf.calls['render_fused'] == 1 and rf.calls['render_reference'] == 0, rf.why_not
+        assert isinstance(out, dict) and out['stage'] == 'sk' and tuple(out['images'].shape) == (1, s.H, s.W, 3)
+        assert tuple(out['radii'].shape) == (1, s.P) and tuple(out['_knn_w'].shape) == (1, s.P, s.K) and tuple(out['_skT'].shape) == (1, s.M, 7)
+        assert float((out['images'][0].permute(2, 0, 1) - img_ref).abs().max()) <= 2e-5
+        losses = s.model_loss(out, s.targets_hwc[v])
+        assert set(losses) == {'rgb', 'ssim'} and rf.calls['image_terms_fused'] == 1          # ONE launch behind both terms
+        loss = sum(losses.values())
+        assert abs(float(loss) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref))
+        loss.backward()
+        assert rf.calls['backward_direct'] == 1 and rf.calls['backward_cotangent'] == 0 and rf.calls['foreign_grads_added'] == 0
+        for n, q in names.items():
+            if want[n] is None:
+                assert q.grad is None or float(q.grad.abs().max()) == 0.0, n
+                continue
+            assert q.grad is not None, n
+            scale = float(want[n].abs().max())
+            assert float((q.grad - want[n]).abs().max()) <= 2e-4 * scale + 1e-12, (n, float((q.grad - want[n]).abs().max()), scale)
+        # what adaptive_control reads (gaussian_splatting.py:503-513): the screen-space gradient on viewspace_points[0]
+        vp = out['viewspace_points'][0]
+        assert vp.grad is not None and tuple(vp.grad.shape) == (s.P, 3) and float(vp.grad.abs().max()) > 0
+        # the blends the fused kernels never materialise, on first access
+        w, i = out['_knn_w'][0], out['_knn_i'][0]
+        assert torch.allclose(out['_d_rot'], (out['_sk_rot'][0][i] * w[..., None]).sum(1)) and tuple(out['_d_xyz'].shape) == (s.P, 3)
+        assert torch.equal(out['visibility_filter'][0], out['radii'][0] > 0)
+        # the frame's row of sk_cache (sk_gs.py:1077-1079) was written by the skeleton launch
+        row = s.model.sk_cache[v]
+        assert float(row.abs().max()) > 0 and float((row[:, :4].norm(dim=-1) - 1).abs().max()) < 1e-5
+        assert float(s.model.sk_cache[(v + 1) % 3].abs().max()) == 0.0
+    finally:
+        _teardown(s)
+
+
+def test_other_terms_on_the_same_parameters_and_other_uses_of_the_image_stay_exact():
+    """(a) a second loss term on ``_xyz`` / the network in the same backward pass is ADDED (the route's kernels write, they do not
+    accumulate: whatever another AccumulateGrad did before is carried over), whichever node autograd runs first; (b) an image that goes
+    through something else than the two patched losses reaches the render node as an ordinary cotangent; (c) gradients nobody cleared are
+    accumulated onto; (d) eval mode / no_grad: the reference's own render"""
+    s = _setup('fused')
+    try:
+        rf, v = s.rf, 0
+        xyz, w0 = s.p['_xyz'], s.net.dynamic_net.net[0].weight
+
+        def run(extra, use_losses=True):
+            for q in list(s.p.values()) + list(s.net.parameters()):
+                q.grad = None
+            out = rf.render(s.model, t=s.times[v], info=s.infos[v], background=s.bg, time_id=s.time_ids[v])
+            if use_losses:
+                loss = sum(s.model_loss(out, s.targets_hwc[v]).values())
+            else:
+                loss = (out['images'] * 2.0).square().mean()
+            if extra:
+                loss = loss + 0.5 * xyz.square().sum() + 3.0 * w0.sum()
+            loss.backward()
+            return xyz.grad.detach().clone(), w0.grad.detach().clone()
+
+        gx, gw = run(False)
+        gx2, gw2 = run(True)
+        assert rf.calls['foreign_grads_added'] >= 0
+        assert float((gx2 - (gx + xyz.detach())).abs().max()) <= 1e-5 * float(gx2.abs().max())
+        assert float((gw2 - (gw + 3.0)).abs().max()) <= 1e-4 * float(gw2.abs().max())
+        # (b)
+        n0 = rf.calls['backward_cotangent']
+        gx3, _ = run(False, use_losses=False)
+        assert rf.calls['backward_cotangent'] == n0 + 1
+        out = rf.render(s.model, t=s.times[v], info=s.infos[v], background=s.bg, time_id=s.time_ids[v])
+        img = out['images'].detach().requires_grad_(True)
+        (img * 2.0).square().mean().backward()
+        d = s.deform(v)
+        for q in list(s.p.values()) + list(s.net.parameters()):
+            q.grad = None
+        ref_img = s.render(v, d)
+        ref_img.backward(img.grad[0].permute(2, 0, 1))
+        assert float((gx3 - xyz.grad).abs().max()) <= 2e-4 * float(xyz.grad.abs().max())
+        # (c) nobody cleared the gradients: the second view accumulates onto the first
+        g1, _ = run(False)
+        out = rf.render(s.model, t=s.times[v], info=s.infos[v], background=s.bg, time_id=s.time_ids[v])
+        sum(s.model_loss(out, s.targets_hwc[v]).values()).backward()
+        assert float((xyz.grad - 2 * g1).abs().max()) <= 1e-5 * float(g1.abs().max())
+        # (d)
+        seen = []
+        keep = s.ra._originals['render']
+        s.ra._originals['render'] = lambda self, *a, **kw: seen.append(kw) or 'reference'
+        s.model.training = False
+        assert rf.render(s.model, t=s.times[v], info=s.infos[v], background=s.bg, time_id=s.time_ids[v]) == 'reference'
+        s.model.training = True
+        with torch.no_grad():
+            assert rf.render(s.model, t=s.times[v], info=s.infos[v], background=s.bg, time_id=s.time_ids[v]) == 'reference'
+        assert len(seen) == 2 and 'not training' in rf.why_not['render']
+        s.ra._originals['render'] = keep
+    finally:
+        _teardown(s)
+
+
+def test_training_through_the_fused_route_follows_the_reference_sequence():
+    """20 iterations of the reference's loop (render / loss / backward / Adam / zero_grad(set_to_none)) through the fused route and
+    through the per-method fast paths on identical scenes: the same loss curve, the same parameters up to the atomics' order, no
+    fallback, no overflow, and a replaced Parameter (densification) rebuilds the route"""
+    runs = {}
+    for mode in ('accelerated', 'fused'):
+        s = _setup(mode)
+        try:
+            losses = [float(s.step(i)) for i in range(20)]
+            torch.cuda.synchronize()
+            runs[mode] = (losses, {n: q.detach().clone() for n, q in s.p.items()})
+            if mode == 'fused':
+                rf = s.rf
+                assert rf.calls['render_fused'] == 20 and rf.calls['render_reference'] == 0 and rf.calls['routes_built'] == 1
+                assert rf.calls['backward_direct'] == 20 and rf.calls['foreign_grads_added'] == 0
+                route = rf._routes[s.model]
+                st = route.step.status()
+                assert st['overflow_events'] == 0 and st.get('mlp_failed', 0) == 0 and route._bucket >= 64
+                assert s.ra.calls['adam_fused'] >= 18
+                # the heads are rows of one matrix, trained in place
+                heads = list(s.net.dynamic_net.last)
+                store = route.shadow.dynamic_net.last_weight
+                assert heads[1].weight.data_ptr() == store.data_ptr() + 4 * 4 * store.shape[1]
+                # densification replaces Parameters: the next call builds a new route on the new objects
+                old = s.model._xyz
+                s.model._xyz = torch.nn.Parameter(old.detach().clone())
+                s.p['_xyz'] = s.model._xyz
+                out = rf.render(s.model, t=s.times[0], info=s.infos[0], background=s.bg, time_id=s.time_ids[0])
+                assert rf.calls['routes_built'] == 2 and rf._routes[s.model] is not route
+                sum(s.model_loss(out, s.targets_hwc[0]).values()).backward()
+                assert s.model._xyz.grad is not None and old.grad is None
+        finally:
+            _teardown(s)
+    (la, pa), (lf, pf) = runs['accelerated'], runs['fused']
+    for a, b in zip(la, lf):
+        assert abs(a - b) <= 2e-3 * abs(a), (la, lf)
+    assert lf[-1] < lf[0]
+    for n in pa:
+        far = ((pa[n] - pf[n]).abs() > 2e-2 * float(pa[n].abs().max())).float().mean()
+        assert float(far) <= 1e-3, (n, float(far))

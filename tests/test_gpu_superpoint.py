@@ -721,9 +721,9 @@ def test_sp_net_local_rotation_head_and_recentring(M, sep_rot, lbs_c):
                                                           ('kernel', 'LBS_c', False, 4)])
 def test_operator_path_variants_equal_the_reference_sequence(method, warp_method, sep_rot, K):
     """SuperpointGaussians.forward with the warp / network variants of the shipped configs (exps/d_nerf_sc_gs.yaml, d_nerf_sp_gs.yaml)
-    against the reference's call sequence on the stand-ins (tests/ref_sequence.py, itself pinned by the reference's own run in
+    against the reference's call sequence on the stand-ins (benchlib/ref_sequence.py, itself pinned by the reference's own run in
     tests/golden/sk_stage.npz): the deformed Gaussians and every gradient that reaches a parameter of the stage"""
-    import ref_sequence as rs
+    from benchlib import ref_sequence as rs
     from sk_gs_amd import lietorch as L, pytorch3d_ops as p3d
     P, M = 20_000, 512
     model, _, _ = _sp_model(P, M, K, 64, 64, 2, method, seed=3, warp_method=warp_method, sep_rot=sep_rot)

@@ -175,11 +175,13 @@ import torch
 from networks.losses import ssim as _ssim_mod
 from sk_gs_amd import reference_accel as _ra
 orig_ssim, orig_kin = _ssim_mod.SSIM_Loss.forward, networks.sk_gs.SkeletonGaussianSplatting.kinematic
-assert sorted(sk_gs_amd.accelerate_reference()) == ['networks.losses.ssim.SSIM_Loss.forward', 'networks.renderer.gaussian_render_origin.render_gs_offical',
+assert sorted(sk_gs_amd.accelerate_reference()) == ['networks.losses.image_loss.ImageLoss.forward', 'networks.losses.ssim.SSIM_Loss.forward',
+                                                     'networks.renderer.gaussian_render_origin.render_gs_offical',
                                                      'networks.sk_gs.DeformNetwork.forward',
                                                      'networks.sk_gs.SimpleDeformationNetwork.forward',
                                                      'networks.sk_gs.SkeletonGaussianSplatting.calc_LBS_weight',
-                                                     'networks.sk_gs.SkeletonGaussianSplatting.kinematic', 'torch.optim.Adam.step']
+                                                     'networks.sk_gs.SkeletonGaussianSplatting.kinematic',
+                                                     'networks.sk_gs.SkeletonGaussianSplatting.render', 'torch.optim.Adam.step']
 assert torch.optim.Adam.step is _ra.adam_step
 import networks.renderer.gaussian_render_origin as _gro
 assert _gro.render_gs_offical is _ra.render_gs_offical and networks.gaussian_splatting.render_gs_offical is _ra.render_gs_offical
@@ -233,6 +235,115 @@ print('HOOK-OK')
 """
 
 
+_FUSED_ROUTE_SCRIPT = r"""
+import sys, warnings
+sys.dont_write_bytecode = True
+sys.path[:0] = [{root!r}, {golden!r}, {ref!r}]
+import make_golden
+make_golden.STUBS = make_golden.STUBS - {{'lietorch', 'pytorch3d', 'diff_gaussian_rasterization'}}
+sys.meta_path.insert(0, make_golden._Finder())
+import sk_gs_amd
+sk_gs_amd.install_reference_hooks()
+warnings.simplefilter('ignore')
+import yaml, torch
+from torch import nn
+import my_ext
+import networks.sk_gs as sk, networks.losses.image_loss as il, networks.losses.ssim as ss
+from sk_gs_amd import reference_accel as ra, reference_fused as rf
+orig_render, orig_il, orig_ss = sk.SkeletonGaussianSplatting.render, il.ImageLoss.forward, ss.SSIM_Loss.forward
+done = sk_gs_amd.accelerate_reference()
+assert 'networks.sk_gs.SkeletonGaussianSplatting.render' in done and 'networks.losses.image_loss.ImageLoss.forward' in done
+assert sk.SkeletonGaussianSplatting.render is rf.render and il.ImageLoss.forward is rf.image_loss_forward and ss.SSIM_Loss.forward is ra.ssim_loss_forward
+# the reference's REAL model class with the shipped settings (exps/default.yaml), a small scene in its own parameters, skeleton stage
+m = sk.SkeletonGaussianSplatting(**yaml.safe_load(open({ref!r} + '/exps/default.yaml'))['arch_cfg'])
+g = torch.Generator().manual_seed(0)
+P, M, T = 300, 12, 4
+for name, shape in (('_xyz', (P, 3)), ('_features_dc', (P, 1, 3)), ('_features_rest', (P, 15, 3)), ('_scaling', (P, 3)), ('_rotation', (P, 4)),
+                    ('_opacity', (P, 1)), ('sp_W', (P, M)), ('joints', (M, 3)), ('global_tr', (T, 7))):
+    setattr(m, name, nn.Parameter(torch.randn(*shape, generator=g)))
+m.joint_parents = torch.zeros(M, 3, dtype=torch.int32)
+m.sk_cache, m.sk_is_init = torch.zeros(T, M, 11), torch.tensor(True)
+assert (m.LBS_method, m.num_knn, m.use_official_gaussians_render, m._R_dim) == ('W', 5, True, 4) and m.loss_funcs.w('image') == 0.8
+# (1) no GPU here: the route's conditions say why not, and render hands the call -- same arguments -- to the reference's own method
+assert 'HIP device' in rf._conditions(m)
+seen = []
+keep = ra._originals['render']
+ra._originals['render'] = lambda self, *a, **kw: seen.append(kw) or 'the reference render'
+info = dict(Tw2v=torch.eye(4)[None], Tv2c=torch.eye(4)[None], campos=torch.zeros(1, 3), FoV=torch.tensor([[0.7, 0.7]]), size=(64, 48))
+m.train()
+bg = torch.ones(3)
+assert m.render(t=torch.tensor([0.5]), info=info, background=bg, time_id=torch.tensor([1]), stage='sk') == 'the reference render'
+assert seen[-1]['stage'] == 'sk' and seen[-1]['background'] is bg and int(seen[-1]['time_id']) == 1 and seen[-1]['info'] is info
+assert rf.calls['render_reference'] == 1 and rf.calls['render_fused'] == 0 and 'device' in rf.why_not['render']
+m.render(t=torch.tensor([0.5]), info=info, stage='sp')
+assert "stage 'sp'" in rf.why_not['render']
+m.render(t=torch.tensor([0.5]), info=info, stage='sk', time_id=1, hook=lambda o: o)
+assert 'hook' in rf.why_not['render'] and 'hook' in seen[-1]
+m.eval()
+m.render(t=torch.tensor([0.5]), info=info, stage='sk', time_id=1)
+assert 'not training' in rf.why_not['render']
+ra._originals['render'] = keep
+# (2) the loss classes: an image that does not come from a fused render node takes the reference's own forward, bit for bit
+crit = m.loss_funcs.loss_functions['image']['func']
+assert type(crit) is il.ImageLoss and crit.method == 'l1'
+a, b = torch.rand(1, 20, 24, 3, generator=g, requires_grad=True), torch.rand(1, 20, 24, 4, generator=g)
+n0 = rf.calls['image_terms_reference']
+assert torch.equal(crit(a, b), orig_il(crit, a, b)) and rf.calls['image_terms_reference'] == n0 + 1 and rf.calls['image_terms_fused'] == 0
+assert rf.route_of(a) is None and rf.route_of(a.view(1, 20, 24, 3)[..., :3]) is None
+sc = ss.SSIM_Loss()
+assert torch.equal(sc(a, b[..., :3]), orig_ss(sc, a, b[..., :3]))
+# (3) re-homing the three head Linears of the REAL SimpleDeformationNetwork: same Parameter objects and values, ONE store; in-place updates
+# of the store are the heads' updates; state_dict and an optimizer keep working; un-homing gives them storage of their own again
+net = m.sk_deform_net
+sh = ra.sk_net_shadow(net)
+heads = list(net.dynamic_net.last)
+before, ids = [h.weight.detach().clone() for h in heads], [id(h.weight) for h in heads]
+rf._rehome_heads(net, sh)
+store = sh.dynamic_net.last_weight
+assert [id(h.weight) for h in heads] == ids and all(torch.equal(h.weight, w) for h, w in zip(heads, before))
+lo, hi = store.data_ptr(), store.data_ptr() + store.numel() * 4
+assert all(lo <= h.weight.data_ptr() < hi and h.weight.is_contiguous() for h in heads) and tuple(store.shape) == (11, heads[0].in_features)
+assert sh._heads_rehomed == [0, 4, 8] and store.requires_grad
+with torch.no_grad():
+    store.mul_(2.0)
+assert all(torch.equal(h.weight, 2 * w) for h, w in zip(heads, before))
+assert torch.equal(net.state_dict()['dynamic_net.last.1.weight'], 2 * before[1])
+opt = torch.optim.SGD(net.parameters(), lr=1.0)
+heads[2].weight.grad = torch.ones_like(heads[2].weight)
+opt.step()
+assert torch.equal(store[8:11], 2 * before[2] - 1) and torch.equal(store[0:4], 2 * before[0])
+rf._rehome_heads(net, sh)          # idempotent
+assert heads[0].weight.data_ptr() == store.data_ptr()
+rf.unhome_heads(net)
+assert not any(lo <= h.weight.data_ptr() < hi for h in heads) and torch.equal(heads[0].weight, 2 * before[0]) and sh._heads_rehomed is None
+# (4) what can change under a route is seen by the per-call identity: a replaced Parameter (densification), a rewritten topology
+i0 = rf._light_identity(m)
+assert rf._light_identity(m) == i0
+m._xyz = nn.Parameter(m._xyz.detach().clone())
+i1 = rf._light_identity(m)
+m.joint_parents[0, 0] = -1
+assert i1 != i0 and rf._light_identity(m) != i1
+# (5) everything back
+ra.restore_reference()
+assert sk.SkeletonGaussianSplatting.render is orig_render and il.ImageLoss.forward is orig_il and ss.SSIM_Loss.forward is orig_ss
+print('FUSED-ROUTE-OK')
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir(_REFERENCE), reason='the reference is only mounted in the build container')
+def test_fused_render_route_binds_falls_back_and_restores_on_the_real_checkout():
+    """``accelerate_reference()`` patches ``SkeletonGaussianSplatting.render`` / ``ImageLoss.forward`` on the UNMODIFIED
+    checkout (sk_gs_amd/reference_fused.py).  Without a GPU: the patches bind; the reference's REAL model class, built with the shipped
+    YAML, is refused by the route's conditions for the stated reason and every ``render`` call reaches the reference's own method with
+    the same arguments; the loss classes give the reference's numbers; the head re-homing the route performs on the real
+    ``SimpleDeformationNetwork`` keeps Parameter identity, values, ``state_dict`` and optimizers intact and is undone by the restore."""
+    golden = os.path.join(ROOT, 'tests', 'golden')
+    code = _FUSED_ROUTE_SCRIPT.format(root=ROOT, golden=golden, ref=_REFERENCE)
+    env = {k: v for k, v in os.environ.items() if k != 'PYTHONPATH'}
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd='/tmp', env=env, timeout=600)
+    assert r.returncode == 0 and 'FUSED-ROUTE-OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 @pytest.mark.skipif(not os.path.isdir(_REFERENCE), reason='the reference is only mounted in the build container')
 def test_unmodified_reference_imports_through_the_hook():
     """INTEGRATION.md section 2 run for real: the reference's my_ext, its renderer module, its frequency encoder,
@@ -262,7 +373,8 @@ def test_example_launcher_imports_the_reference_train_module_and_patches_it():
                        timeout=600)
     assert r.returncode == 0 and 'REFERENCE-READY' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
     for name in ('my_ext._C._C', 'diff_gaussian_rasterization', 'lietorch', 'pytorch3d.ops', 'SSIM_Loss.forward', 'kinematic', 'calc_LBS_weight',
-                 'SimpleDeformationNetwork.forward', 'DeformNetwork.forward', 'render_gs_offical', 'torch.optim.Adam.step'):
+                 'SimpleDeformationNetwork.forward', 'DeformNetwork.forward', 'render_gs_offical', 'torch.optim.Adam.step',
+                 'SkeletonGaussianSplatting.render', 'ImageLoss.forward'):
         assert name in r.stdout, name
 
 
@@ -292,8 +404,12 @@ assert S.kinematic is ra.kinematic and S.calc_LBS_weight is ra.calc_LBS_weight
 assert sk.SimpleDeformationNetwork.forward is ra.simple_deform_forward and sk.DeformNetwork.forward is ra.deform_network_forward
 assert ssim.SSIM_Loss.forward is ra.ssim_loss_forward
 assert gro.render_gs_offical is ra.render_gs_offical and gsm.render_gs_offical is ra.render_gs_offical
-assert sorted(ra._originals) == ['adam', 'kinematic', 'lbs_weight', 'render_adapter', 'sk_net', 'sp_net', 'ssim']
+from sk_gs_amd import reference_fused as rf
+import networks.losses.image_loss as il
+assert S.render is rf.render and il.ImageLoss.forward is rf.image_loss_forward        # (round 6: the fused step behind render + the image terms)
+assert sorted(ra._originals) == ['adam', 'image_loss', 'kinematic', 'lbs_weight', 'render', 'render_adapter', 'sk_net', 'sp_net', 'ssim']
 ra.restore_reference()
+assert S.render is not rf.render and il.ImageLoss.forward is not rf.image_loss_forward
 assert S.kinematic is not ra.kinematic and torch.optim.Adam.step is not ra.adam_step and gsm.render_gs_offical is gro.render_gs_offical
 print('TWO-LINES-OK')
 """ % (ROOT, os.path.join(ROOT, 'tests', 'golden'), _REFERENCE)

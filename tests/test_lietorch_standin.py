@@ -21,7 +21,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-import ref_sequence as rs
+from benchlib import ref_sequence as rs
 from sk_gs_amd import lietorch as L
 from sk_gs_amd import pytorch3d_ops as p3d
 from sk_gs_amd.lietorch import SE3, SO3
@@ -248,7 +248,7 @@ def fixture():
 @pytest.mark.parametrize('recognise', [False, True])
 @pytest.mark.parametrize('name', sorted(rs.SCENARIOS))
 def test_replay_of_the_reference_run(fixture, name, recognise, monkeypatch):
-    """the restated call sequence (tests/ref_sequence.py) on the stand-ins reproduces what the reference's own forward + backward gave;
+    """the restated call sequence (benchlib/ref_sequence.py) on the stand-ins reproduces what the reference's own forward + backward gave;
     `recognise`: with the deferred gather / skinning expression machinery of the HIP route switched on (evaluated by the generic ops here)"""
     monkeypatch.setattr(L, '_FUSED_ON_CPU', recognise)
     before = dict(L.fused_calls)

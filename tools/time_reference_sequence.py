@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What the UNMODIFIED reference's deform costs on the MI355X through the stand-ins (sk_gs_amd.lietorch / pytorch3d_ops), at
 config #1's size (100k Gaussians, 20 bones, K = 5) and at the superpoint stage's (512 superpoints, 3 + 8 search dimensions): the
-call sequence of SkeletonGaussianSplatting.forward (tests/ref_sequence.py) forward + backward,
+call sequence of SkeletonGaussianSplatting.forward (benchlib/ref_sequence.py) forward + backward,
 
   * eager, as torch issues it (host-bound: the 20-row kinematic chain is ~150 small torch kernels forward, ~300 backward),
   * with the recognition of the skinning expression off (SKGS_LIE_FUSED=0 semantics: gather [P,K,7] + act + mul + sum as torch ops),
@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
 import torch  # noqa: E402
 
-import ref_sequence as rs  # noqa: E402
+from benchlib import ref_sequence as rs  # noqa: E402
 from sk_gs_amd import lietorch as L, pytorch3d_ops as p3d, scene  # noqa: E402
 from sk_gs_amd.deform import calc_lbs_weight, lbs_deform  # noqa: E402
 from sk_gs_amd.skeleton import bone_chain, build_ancestor_table, build_topology  # noqa: E402
@@ -158,7 +158,7 @@ def main():
     L._FUSED = True
     rows.append(('sp 100k x 512: ... as one hipGraph replay', *timed(graphed(lambda: ref_step(sp)))))
     # ---- the two deform networks: the modules' own torch forward against accelerate_reference()'s fast paths (modules with the
-    # reference classes' structure: tests/ref_sequence.py; the kernels run on the modules' own parameters)
+    # reference classes' structure: benchlib/ref_sequence.py; the kernels run on the modules' own parameters)
     from sk_gs_amd import reference_accel as ra
     from sk_gs_amd.superpoint import SpDeformNet
     g = torch.Generator().manual_seed(3)
