@@ -224,18 +224,22 @@ def run(args, configs):
     s = setup(args, configs)
     step, rf, ra, L, p3d, _C, cfg, P, M, K, W, H, sp, accel, fused, model = (
         s.step, s.rf, s.ra, s.L, s.p3d, s._C, s.cfg, s.P, s.M, s.K, s.W, s.H, s.sp, s.accel, s.fused, s.model)
-    for i in range(max(args.warmup, 5)):
+    # untimed prime steps, as the headline run does and for its reason (--prime-steps: a fresh process and a fresh scene reach a training
+    # run's steady state only after some tens of steps -- here also the tile lists of the synthetic scene's first steps, which the route
+    # re-measures at calls 32 and 128); reported as `prime_steps`
+    prime = max(int(args.prime_steps), 0)
+    for i in range(prime + max(args.warmup, 5)):
         step(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        last = step(args.warmup + i)
+        last = step(prime + args.warmup + i)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ms = 1e3 * elapsed / args.steps
     return {
         'metric': f"train iters/sec of the REFERENCE's own call sequence on the hooks ({args.reference_loop}), {P // 1000}k Gaussians @{W}x{H}",
-        'value': round(args.steps / elapsed, 3), 'unit': 'iters/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': max(args.warmup, 5),
+        'value': round(args.steps / elapsed, 3), 'unit': 'iters/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': max(args.warmup, 5), 'prime_steps': prime,
         'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'{cfg["name"]}' + (' in stage sp' if sp else '') + f': {P} Gaussians, {M} ' + ('superpoints (3+8-d search, weighted_kernel)' if sp else 'bones') + f', K={K}, SH degree 3, {W}x{H}, {args.views} synthetic views',
                    'step': ("the reference's call sequence restated (benchlib/ref_sequence.py + train.py:179-250) on install_reference_hooks() alone: "

@@ -333,16 +333,25 @@ class _AdamRunner:
         self.count = None
         self.n = self.chunks = 0
 
+    RING = 8   # pinned staging buffers in flight: the host may run this many uploads ahead of the device before it has to wait
+
     def _copy(self, dst, blob):
+        """asynchronous upload through a RING of pinned staging buffers (one buffer + ``event.synchronize()`` blocked the
+        host on the previous step's copy every time a learning rate changed -- the reference changes two per iteration)"""
         n = len(blob)
-        if self.pin is None or self.pin.numel() < n:
-            self.pin, self.event = torch.empty(max(n, 4096), dtype=torch.uint8, pin_memory=True), None
-        if self.event is not None:
-            self.event.synchronize()
-        self.pin[:n].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
-        dst[:n].copy_(self.pin[:n], non_blocking=True)
-        self.event = torch.cuda.Event()
-        self.event.record()
+        if self.pin is None or self.pin[0].numel() < n:
+            self.pin = [torch.empty(max(n, 4096), dtype=torch.uint8, pin_memory=True) for _ in range(self.RING)]
+            self.event, self._slot = [None] * self.RING, 0
+        k = self._slot
+        self._slot = (k + 1) % self.RING
+        if self.event[k] is not None:
+            self.event[k].synchronize()      # (the upload issued RING uploads ago: long done unless the device is that far behind)
+        self.pin[k][:n].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        dst[:n].copy_(self.pin[k][:n], non_blocking=True)
+        ev = self.event[k]
+        if ev is None:
+            ev = self.event[k] = torch.cuda.Event()
+        ev.record()
 
     def step(self, entries, lrs, beta1, beta2, eps, count):
         """entries: [(param, grad, exp_avg, exp_avg_sq)] in table order, lrs: one per entry, count: steps taken so far (all equal)"""
@@ -370,6 +379,61 @@ class _AdamRunner:
 
 
 _adam_runners = weakref.WeakKeyDictionary()
+_adam_plans = weakref.WeakKeyDictionary()
+
+
+class _AdamPlan:
+    """what the last fused step of an optimizer launched, so that the next one -- same parameters in the same groups, the same gradient
+    tensors, the same learning rates, every parameter one step older -- is ONE comparison pass and the launch (the per-step walk over
+    groups, states and gradients with its ~35 table entries was 0.13 ms of host time per iteration).  Anything that differs (a
+    learning rate, a gradient tensor, a parameter list after densification, a step count somebody moved) returns False: the general
+    path rebuilds."""
+
+    def __init__(self, opt, runner, entries, count):
+        self.runner, self.count = runner, count
+        self.params = [p for p, _, _, _ in entries]
+        self.grads = [g for _, g, _, _ in entries]
+        self.moments = [(m, v) for _, _, m, v in entries]
+        self.states = [opt.state[p] for p in self.params]
+        self.steps = [st['step'] for st in self.states]
+        self.with_grad = set(map(id, self.params))
+        self.layout = [(id(g), len(g['params'])) for g in opt.param_groups]
+        self.lrs = [g['lr'] for g in opt.param_groups]
+        g0 = opt.param_groups[0]
+        self.hyper = (float(g0['betas'][0]), float(g0['betas'][1]), float(g0['eps']))
+
+    def replay(self, opt) -> bool:
+        groups = opt.param_groups
+        if len(groups) != len(self.layout) or self.runner.count != self.count:
+            return False
+        for g, (gid, n), lr in zip(groups, self.layout, self.lrs):
+            if id(g) != gid or len(g['params']) != n or g['lr'] != lr:
+                return False
+        for p, gr in zip(self.params, self.grads):
+            if p.grad is not gr:
+                return False
+        k = 0
+        for g in groups:          # a parameter that had no gradient last time must still have none (torch skips it; so does the table)
+            for p in g['params']:
+                if id(p) in self.with_grad:
+                    k += 1
+                elif p.grad is not None and p.requires_grad:
+                    return False
+        if k != len(self.params):
+            return False
+        st = opt.state
+        for p, s_, (m, v) in zip(self.params, self.states, self.moments):
+            s2 = st.get(p)
+            if s2 is not s_ or s2['exp_avg'] is not m or s2['exp_avg_sq'] is not v:
+                return False
+        run, C = self.runner, self.runner.C
+        b1, b2, eps = self.hyper
+        run._C._check(run.lib.skgs_adam_step_range(
+            C.c_int32(run.n), C.c_void_p(run.table.data_ptr()), C.c_int64(0), C.c_int64(run.chunks), C.c_double(b1),
+            C.c_double(b2), C.c_double(eps), C.c_void_p(run.state.data_ptr()), C.c_int32(1), None, C.c_int64(0), run._C._stream()))
+        run.count = self.count = self.count + 1
+        torch._foreach_add_(self.steps, 1)      # torch's bookkeeping: the per-parameter step counters
+        return True
 
 
 def adam_step(self, closure=None):
@@ -381,6 +445,10 @@ def adam_step(self, closure=None):
     capturable / differentiable.  Anything else -- and the very first step, which creates the state -- is torch's own ``step``."""
     groups = self.param_groups
     g0 = groups[0] if groups else None
+    plan = _adam_plans.get(self)
+    if plan is not None and closure is None and plan.replay(self):
+        calls['adam_fused'] += 1
+        return None
     ok = closure is None and g0 is not None and type(self) is torch.optim.Adam
     buckets, dev = {}, None      # step count -> ([(param, grad, exp_avg, exp_avg_sq)], [lr])
     if ok:
@@ -430,6 +498,11 @@ def adam_step(self, closure=None):
             run.step(ent, lrs, float(g0['betas'][0]), float(g0['betas'][1]), float(g0['eps']), int(count))
             for p, _, _, _ in ent:      # torch's bookkeeping: the per-parameter step counters (CPU scalars)
                 self.state[p]['step'] += 1
+    if len(buckets) == 1:   # the common case from the second fused step on: remember what was launched (``_AdamPlan``)
+        ent, lrs = buckets[newest]
+        _adam_plans[self] = _AdamPlan(self, runners[0], ent, int(newest) + 1)
+    else:
+        _adam_plans.pop(self, None)
     calls['adam_fused'] += 1
     return None
 
@@ -593,6 +666,7 @@ def restore_reference():
         sys.modules['networks.sk_gs'].DeformNetwork.forward = _originals.pop('sp_net')
     if 'adam' in _originals:
         torch.optim.Adam.step = _originals.pop('adam')
+        _adam_plans.clear()
     if 'render_adapter' in _originals:
         orig = _originals.pop('render_adapter')
         for name in ('networks.renderer.gaussian_render_origin', 'networks.gaussian_splatting'):

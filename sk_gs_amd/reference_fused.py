@@ -30,12 +30,16 @@ initialised; ``LBS_method == 'W'`` with ``sp_W`` [P, M] over the M <= 48 joints,
 The three head matrices of the network (``dynamic_net.last``) are RE-HOMED into one contiguous matrix (their ``.data`` become row
 views of it -- same Parameter objects, same values): the kernels read and train them in place.
 
-Nothing here blocks on the device per iteration; every ``check_every`` (64) calls the route reads the status words once (tile-list
-overflow -> the bucket capacity is doubled with a warning; the reference itself blocks on ``num_rendered`` in every forward).
+The forward half and the backward half are ONE hipGraph replay each (``SKGS_REF_FUSED_GRAPHS=0``: the same launches issued one by one);
+per call the host still issues the slot fill, the target's layout copy and the two loss launches.  Nothing blocks on the device per
+iteration: every ``CHECK_EVERY`` (64) calls the route reads the status words once (a tile-list overflow doubles the bucket capacity with
+a warning; the reference itself blocks on ``num_rendered`` in every forward), and at calls 1 / 32 / 128 / 512 / every 1024th it
+re-measures the longest tile list with one extra compact-list forward and resizes the per-tile buckets to 1.5 x that (both directions).
 """
 from __future__ import annotations
 
 import ctypes as C
+import os
 import sys
 import types
 import warnings
@@ -44,7 +48,7 @@ import weakref
 import torch
 
 calls = {'render_fused': 0, 'render_reference': 0, 'image_terms_fused': 0, 'image_terms_reference': 0, 'backward_direct': 0,
-         'backward_cotangent': 0, 'foreign_grads_added': 0, 'routes_built': 0, 'capacity_grown': 0}
+         'backward_cotangent': 0, 'foreign_grads_added': 0, 'routes_built': 0, 'capacity_grown': 0, 'capacity_retuned': 0}
 why_not = {'render': None, 'terms': None}
 _routes = weakref.WeakKeyDictionary()     # reference model -> FusedReferenceRoute | str (the reason there is none)
 CHECK_EVERY = 64
@@ -54,6 +58,25 @@ _VIEW_NODES = ('ViewBackward', 'PermuteBackward', 'UnsqueezeBackward', 'SqueezeB
 
 def _p(t):
     return C.c_void_p(None if t is None else t.data_ptr())
+
+
+_frozen = False
+
+
+def _freeze_collector_once():
+    """``gc.freeze()`` when the first route is built (``SKGS_GC_FREEZE=0``: leave the collector alone).  An eager iteration creates a few
+    hundred container objects (autograd nodes, ctypes structures, dicts), so CPython's oldest-generation collection comes round every
+    ~230 iterations -- and walks EVERYTHING the process has imported: 103 ms with torch and the reference loaded (266 k tracked objects;
+    tools/find_host_spikes.py), i.e. 0.45 ms per iteration against a 0.5 ms iteration.  Freezing moves what exists now (modules, classes,
+    the model) into the permanent generation: later collections see only what training allocates (reference counting still frees
+    everything it can; what is frozen is merely never scanned for cycles again)."""
+    global _frozen
+    if _frozen or os.environ.get('SKGS_GC_FREEZE', '1') == '0':
+        return
+    import gc
+    gc.collect()
+    gc.freeze()
+    _frozen = True
 
 
 class _LiveSlot:
@@ -178,7 +201,7 @@ class FusedReferenceRoute:
         saved = {p: p.grad for p in self.view.parameters()}
         for p in saved:
             p.grad = None
-        self.step = self._build_step(0)
+        self.step = self._build_step(64)
         self.grads = {p: p.grad for p in self.view.parameters()}            # persistent: the kernels' write targets
         net, heads = shadow.dynamic_net, ref.sk_deform_net.dynamic_net.last
         for h, o in zip(heads, shadow._heads_rehomed):                       # the heads' gradients: row views of the head matrix's
@@ -192,9 +215,14 @@ class FusedReferenceRoute:
         self.vp = torch.zeros((self.view.P, 3), dtype=torch.float32, device=dev, requires_grad=True)   # outputs['viewspace_points'][0]
         self.loss_ring = torch.zeros((64, 3), dtype=torch.float32, device=dev)
         self._ring_pos = 0
-        self.serial, self._fwd, self._terms, self._bg_key, self._probed = 0, None, None, None, False
+        self.target = torch.zeros((3, self.H, self.W), dtype=torch.float32, device=dev)    # the view's ground truth as [3,H,W]
+        self.serial, self._fwd, self._terms, self._bg_key, self._spare = 0, None, None, None, None
         self._seen_events = 0
+        self._attach = [(p, g, (p is net.last_weight or p is net.last_bias)) for p, g in self.grads.items()]
+        self.graphs, self._graph_key = None, None      # hipGraphs of the forward half / the backward half (None: eager launches)
+        self.use_graphs = os.environ.get('SKGS_REF_FUSED_GRAPHS', '1') != '0'
         calls['routes_built'] += 1
+        _freeze_collector_once()
 
     # -------------------------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -217,27 +245,92 @@ class FusedReferenceRoute:
         self._bucket = bucket
         return step
 
-    def _probe_capacity(self):
-        """first call: one forward with compact tile lists (exact counts) and ONE status read; then the bucket layout the package's
-        trainer uses (fixed slots per tile, no count / scan launch) with 50 % head room over the longest list"""
+    RETUNE_AT = (1, 32, 128, 512)      # calls at which the tile-list capacity is re-measured; afterwards every RETUNE_EVERY
+    RETUNE_EVERY = 1024
+
+    def _measure_longest(self):
+        """one extra forward of the view in the slot with COMPACT tile lists (exact counts: the bucket layout's status words do not
+        carry them) into a spare binning buffer, and one status read: (longest tile list, tile instances)"""
         from sk_gs_amd import _C
-        self.step.forward(None, None)
-        st = _C.read_status(self.step.geom)
-        longest = max(int(st['max_tile_count']), 1)
-        bucket = ((int(longest * 1.5) + 63) // 64) * 64
+        st, lib = self.step, self.lib
+        if getattr(self, '_spare', None) is None:
+            T = ((self.W + 15) // 16) * ((self.H + 15) // 16)
+            self._spare = torch.empty((lib.skgs_binning_buffer_bytes(C.c_int64(max(24 * self.view.P, 64 * T))),), dtype=torch.uint8,
+                                      device=st.binning.device)
+        keep = (st.tile_bucket, st.binning, st._bufs)
+        st.tile_bucket, st.binning = 0, self._spare
+        st._bufs = _C._buffers(st.geom, st.binning, st.img)
+        try:
+            st.forward(None, None)
+            s = _C.read_status(st.geom)
+        finally:
+            st.tile_bucket, st.binning, st._bufs = keep
+        if s['overflow']:
+            self._spare = None
+            raise RuntimeError(f"fused reference route: {s['num_rendered']} tile instances do not fit the probing buffer")
+        return max(int(s['max_tile_count']), 1), int(s['num_rendered'])
+
+    @staticmethod
+    def _bucket_for(longest):
+        bucket = ((int(longest * 1.5) + 63) // 64) * 64     # the package's own trainer: 50 % head room (benchlib/sk_stage.py)
         if 512 < bucket and longest * 1.2 <= 512:
-            bucket = 512
-        grads = {p: p.grad for p in self.view.parameters()}
-        net = self.shadow.dynamic_net
-        for p in (net.last_weight, net.last_bias):
-            p.grad = self.grads[p]
-        for p in self.view.parameters():
-            if p.grad is None:
-                p.grad = self.grads[p]
-        self.step = self._build_step(bucket)
-        for p, g in grads.items():
+            bucket = 512                                    # a list one wave sorts needs no merge launch behind it
+        return bucket
+
+    def _retune(self):
+        """measure the longest tile list and give every tile 1.5 x that many slots; training moves and resizes the Gaussians, so the
+        measurement is repeated (RETUNE_AT, then every RETUNE_EVERY calls): the capacity follows the scene in both directions before
+        a list can overflow, and a scene whose lists have shrunk below 512 entries loses its merge-sort launch again"""
+        longest, R = self._measure_longest()
+        want = self._bucket_for(longest)
+        have = self._bucket
+        self.longest, self.num_rendered = longest, R
+        if want == have or (want < have and want > 512 and want > 0.75 * have):
+            return
+        st = self.step
+        T = ((self.W + 15) // 16) * ((self.H + 15) // 16)
+        st.tile_bucket = want
+        st.binning = torch.empty((self.lib.skgs_binning_buffer_bytes(C.c_int64(T * want)),), dtype=torch.uint8, device=st.binning.device)
+        from sk_gs_amd import _C
+        st._bufs = _C._buffers(st.geom, st.binning, st.img)
+        st.geom[:256].zero_()
+        self._bucket, self._seen_events, self.graphs = want, 0, None
+        calls['capacity_retuned'] += 1
+
+    def _graph_state(self):
+        t = self.table.settings
+        return (int(t.sh_degree), float(t.scale_modifier), self._bucket, self.step.binning.data_ptr())
+
+    def _capture(self):
+        """the forward half and the backward half as ONE hipGraph each (every pointer they bake in is persistent: parameters, the
+        persistent gradients, the live slot, the background, the target and cotangent buffers); what still runs per call on the host:
+        the slot fill, two replays, the loss launches.  Re-captured when the SH degree, the scale modifier or the binning buffer change;
+        a capture that fails leaves the eager launches in place."""
+        from sk_gs_amd.train_step import GraphedSteps
+        st = self.step
+        saved = [(p, p.grad) for p, _, _ in self._attach]
+        for p, g, _ in self._attach:
             p.grad = g
-        self._probed = True
+        try:
+            def fwd(_):
+                self._fwd = st.forward(None, None)
+
+            def bwd(_):
+                with torch.no_grad():
+                    st._zero_table_grads()
+                    st._raster_backward(self._fwd[0], self._fwd[1], None)
+                    st.backward_skinning(None)
+            st.dL_dimage.zero_()      # (the warm-up execution of the backward half runs on it)
+            gs = GraphedSteps(lambda k: (fwd if k == 'f' else bwd)(k), warmup=1, collect_garbage=False, thread_local=True)
+            gs.capture('f')
+            gs.capture('b')
+            self.graphs, self._graph_key = gs, self._graph_state()
+        except Exception as e:   # noqa: BLE001  (no graph: the same launches, issued one by one)
+            warnings.warn(f'fused reference route: hipGraph capture failed ({type(e).__name__}: {e}); using eager launches')
+            self.graphs, self.use_graphs = None, False
+        finally:
+            for p, g in saved:
+                p.grad = g
 
     def check_status(self):
         st = self.step.status()
@@ -251,6 +344,7 @@ class FusedReferenceRoute:
                 p.grad = self.grads[p]
             self.step.grow_capacity(2.0)
             self._bucket = self.step.tile_bucket
+            self.graphs = None
             for p, g in grads.items():
                 p.grad = g
             self._seen_events = 0
@@ -297,9 +391,11 @@ class FusedReferenceRoute:
             self.check_status()
         self.fill_slot(info, t, time_id)
         self.set_background(background)
-        if not self._probed:
-            self._probe_capacity()
-        image = _FusedRender.apply(self, *self.params)                       # [3,H,W]
+        if self.serial in self.RETUNE_AT or self.serial % self.RETUNE_EVERY == 0:
+            self._retune()
+        if self.use_graphs and (self.graphs is None or self._graph_key != self._graph_state()):
+            self._capture()
+        image = _FusedRender.apply(self, self.view._xyz)                     # [3,H,W]
         st = self.step
         out = FusedOutputs(self)
         out['images'] = image.permute(1, 2, 0).unsqueeze(0)                  # [1,H,W,3]: torch.permute(images, (1, 2, 0)) stacked (:1229,1240)
@@ -318,15 +414,11 @@ class FusedReferenceRoute:
         my_ext/framework.py:305); returns what has to be added afterwards: gradients another term accumulated before this node ran
         (or ours from an earlier view that nobody cleared)"""
         foreign = []
-        net = self.shadow.dynamic_net
-        for p, g in self.grads.items():
-            if p is net.last_weight or p is net.last_bias:
-                p.grad = g
-                continue
+        for p, g, store in self._attach:
             cur = p.grad
-            if cur is None:
+            if cur is None or store:
                 p.grad = g
-            elif cur.data_ptr() == g.data_ptr():
+            elif cur is g or cur.data_ptr() == g.data_ptr():
                 foreign.append((g, cur.clone()))
             else:
                 foreign.append((g, cur))
@@ -346,13 +438,17 @@ class FusedReferenceRoute:
         self._dimage_ready = False
         foreign = self.attach_grads()
         with torch.no_grad():
-            st._zero_table_grads()
-            st._raster_backward(a, d, None)
-            st.backward_skinning(None)
+            if self.graphs is not None:
+                self.graphs.graphs['b'].replay()
+            else:
+                st._zero_table_grads()
+                st._raster_backward(a, d, None)
+                st.backward_skinning(None)
             self.vp.grad = st.grad_means2D
-            for ours, theirs in foreign:
-                ours.add_(theirs)
-            calls['foreign_grads_added'] += len(foreign)
+            if foreign:
+                for ours, theirs in foreign:
+                    ours.add_(theirs)
+                calls['foreign_grads_added'] += len(foreign)
         net = self.shadow.dynamic_net
         net.last_weight.grad = net.last_bias.grad = None      # (the heads own these rows as far as any optimizer is concerned)
 
@@ -365,8 +461,9 @@ class FusedReferenceRoute:
         g = gt
         while g.dim() > 3 and g.shape[0] == 1:
             g = g[0]
-        target = g[..., :3].permute(2, 0, 1).contiguous().float()          # [3,H,W] (the reference's targets are HWC)
-        out = _FusedImageTerms.apply(pred, self, target)
+        with torch.no_grad():
+            self.target.copy_(g[..., :3].permute(2, 0, 1))                 # [3,H,W] (the reference's targets are HWC): one launch
+        out = _FusedImageTerms.apply(pred, self)
         self._terms = (key, out)
         calls['image_terms_fused'] += 1
         return out
@@ -403,9 +500,13 @@ class _FusedRender(torch.autograd.Function):
     parameters' ``.grad`` (returning them would make ``AccumulateGrad`` copy ~30 tensors per step)."""
 
     @staticmethod
-    def forward(ctx, route, *params):
+    def forward(ctx, route, anchor):
+        # (`anchor`: ONE parameter, so that the image requires grad; the node writes every parameter's gradient itself)
         ctx._skgs_route, ctx.serial = route, route.serial
-        route._fwd = route.step.forward(None, None)
+        if route.graphs is not None:
+            route.graphs.graphs['f'].replay()
+        else:
+            route._fwd = route.step.forward(None, None)
         route._dimage_ready = False
         return route.step.image.detach()
 
@@ -417,15 +518,15 @@ class _FusedRender(torch.autograd.Function):
             raise RuntimeError('fused reference route: backward of a render() whose buffers a later render() has overwritten '
                                '(one view at a time: call backward before the next render)')
         route.backward(g_image)
-        return (None,) * (1 + len(route.params))
+        return None, None
 
 
 class _FusedImageTerms(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, route, target):
+    def forward(ctx, pred, route):
         from sk_gs_amd import _C
-        st = route.step
-        ctx.route, ctx.target, ctx.shape, ctx.serial = route, target, tuple(pred.shape), route.serial
+        st, target = route.step, route.target
+        ctx.route, ctx.shape, ctx.serial = route, tuple(pred.shape), route.serial
         row = route.loss_ring[route._ring_pos]
         route._ring_pos = (route._ring_pos + 1) % route.loss_ring.shape[0]
         # lambdas (0, 1): loss3 = {0 * L1 + 1 * (1 - SSIM), L1 mean, SSIM mean}
@@ -443,7 +544,7 @@ class _FusedImageTerms(torch.autograd.Function):
             raise RuntimeError('fused reference route: backward of image terms whose render() has been overwritten by a later one')
         fix = lambda g: None if g is None else g.detach().reshape(1).to(torch.float32).contiguous()  # noqa: E731
         gl, gs = fix(g_l1), fix(g_ssim)
-        _C._check(route.lib.skgs_image_loss_backward_terms(C.c_int32(3), C.c_int32(st.H), C.c_int32(st.W), _p(st.image), _p(ctx.target), None,
+        _C._check(route.lib.skgs_image_loss_backward_terms(C.c_int32(3), C.c_int32(st.H), C.c_int32(st.W), _p(st.image), _p(route.target), None,
                                                            _p(gl), _p(gs), _p(st.loss_ws), C.c_size_t(st.loss_ws.numel()), _p(st.dL_dimage),
                                                            _C._stream()))
         route._dimage_ready = True
@@ -451,7 +552,7 @@ class _FusedImageTerms(torch.autograd.Function):
         shape = ctx.shape
         if shape[-1] == 3 and shape[-3:] != (3, st.H, st.W):
             g = g.permute(1, 2, 0)
-        return g.reshape(shape), None, None
+        return g.reshape(shape), None
 
 
 # ------------------------------------------------------------------------------------------------ recognising a fused image

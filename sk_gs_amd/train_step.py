@@ -33,13 +33,16 @@ class GraphedSteps:
     that has no graph yet captures it and does NOT replay on top: the warm-up execution already was that call's one
     execution (an optimizer step or a statistics update must not run two or three times on the first call)."""
 
-    def __init__(self, fn: Callable[[Hashable], None], warmup: int = 1, collect_garbage: bool = True):
+    def __init__(self, fn: Callable[[Hashable], None], warmup: int = 1, collect_garbage: bool = True, thread_local: bool = False):
         """``collect_garbage``: run ``gc.collect()`` before a capture (see the pitfall above).  A step that builds no
         autograd graph (``FusedViewStep``) does not need it; the collection is most of the cost of re-capturing after a
         densification (~20 of ~27 ms)."""
         self.fn = fn
         self.warmup = warmup
         self.collect_garbage = collect_garbage
+        # capture_error_mode 'thread_local': other threads of the process may touch the device while a capture is open (a data
+        # loader's pin-memory thread under the reference's training loop: sk_gs_amd/reference_fused.py)
+        self.thread_local = bool(thread_local)
         self.graphs: Dict[Hashable, torch.cuda.CUDAGraph] = {}
         self.pool = None
 
@@ -65,7 +68,7 @@ class GraphedSteps:
         # rethrows it and the rank aborts (seen once in ~100 one-rank RCCL runs of bench.py).  "thread_local" restricts the
         # check to this thread, which is the one that captures.
         import torch.distributed as dist
-        mode = 'thread_local' if (dist.is_available() and dist.is_initialized()) else 'global'
+        mode = 'thread_local' if (self.thread_local or (dist.is_available() and dist.is_initialized())) else 'global'
         with torch.cuda.graph(g, pool=self.pool, capture_error_mode=mode):
             for _ in range(repeat):
                 self.fn(key)
