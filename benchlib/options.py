@@ -189,6 +189,11 @@ def build_parser():
     ap.add_argument('--keep-order', action='store_true',
                     help='leave the synthetic Gaussians in their random order (default: sorted along a Z-order curve, '
                          'densify.sort_spatially, as after a densification event)')
+    ap.add_argument('--sp-regularisers', action='store_true',
+                    help="--stage sp --reference-loop accelerated|fused: add the two per-Gaussian regularisers the shipped config runs on the "
+                         "[P,K] LBS weights in every sp iteration (`sparse`, `smooth`, weight 0.1 each: exps/default.yaml:85-86, "
+                         "sk_gs.py:1339-1359,1572-1574) as the reference writes them (torch); without the flag the loss is the image "
+                         "terms only")
     ap.add_argument('--superpoints', type=int, default=512, help='--stage sp: num_superpoints (exps/default.yaml:25)')
     ap.add_argument('--lbs-method', choices=('weighted_kernel', 'kernel', 'dist', 'W'), default='weighted_kernel',
                     help="--stage sp: the weighting of calc_LBS_weight (class default 'weighted_kernel', sk_gs.py:364; "

@@ -76,6 +76,14 @@ def setup(args, configs):
         p.update(sp_points=par(gs['xyz'][pick]), hyper_feature=par(torch.full((P, 8), -1e-2) + 0.02 * torch.randn(P, 8, generator=g)),
                  sp_hyper_feature=par(torch.full((M, 8), 1e-2) + 0.02 * torch.randn(M, 8, generator=g)),
                  _sp_radius=par(torch.full((M,), -1.35)), _sp_weight=par(torch.zeros(M)))
+        # --lbs-method: which parameters of the weighting exist decides the weighting (sk_gs.py:464-475,757-770)
+        if args.lbs_method == 'W':
+            p.pop('_sp_radius'), p.pop('_sp_weight')
+            p['sp_W'] = par(torch.randn(P, M, generator=g))
+        elif args.lbs_method == 'kernel':
+            p.pop('_sp_weight')
+        elif args.lbs_method == 'dist':
+            p.pop('_sp_radius'), p.pop('_sp_weight')
         # DeformNetwork's structure and parameter names (sk_gs.py:209-315; pinned by tests/golden/sp_deformnet.npz) + the attributes
         # the accelerator probes on the reference's class
         net = SpDeformNet()
@@ -99,8 +107,9 @@ def setup(args, configs):
         {'params': [p['_scaling']], 'lr': lr * 5.0, 'name': 'scaling'}, {'params': [p['_rotation']], 'lr': lr, 'name': 'rotation'}]
     if sp:   # get_params of stage sp (sk_gs.py:583-602)
         groups += [{'params': [p['hyper_feature']], 'lr': lr * 2.5, 'name': 'hyper'}, {'params': list(net.parameters()), 'lr': lr * 0.16, 'name': 'sp_deform'},
-                   {'params': [p['sp_points']], 'lr': lr * 0.16, 'name': 'sp_points'}, {'params': [p['_sp_radius']], 'lr': lr * 0.16, 'name': 'sp_radius'},
-                   {'params': [p['_sp_weight']], 'lr': lr * 0.16, 'name': 'sp_weight'}, {'params': [p['sp_hyper_feature']], 'lr': lr * 2.5, 'name': 'sp_hyper'}]
+                   {'params': [p['sp_points']], 'lr': lr * 0.16, 'name': 'sp_points'}] + \
+                  [{'params': [p[k_]], 'lr': lr * 0.16, 'name': n_} for k_, n_ in (('_sp_radius', 'sp_radius'), ('_sp_weight', 'sp_weight'), ('sp_W', 'sp_W')) if k_ in p] + \
+                  [{'params': [p['sp_hyper_feature']], 'lr': lr * 2.5, 'name': 'sp_hyper'}]
     else:
         groups += [{'params': [p['sp_W']], 'lr': lr, 'name': 'sp_W'}, {'params': [p['global_tr']], 'lr': lr, 'name': 'skinning'},
                    {'params': list(net.parameters()), 'lr': lr, 'name': 'deform_net'}, {'params': [p['joints']], 'lr': lr * 0.1, 'name': 'joints'}]
@@ -128,14 +137,19 @@ def setup(args, configs):
             out = net.reference_forward(p['sp_points'].detach(), times[v])              # the module's own torch forward
             a = dict(p, net_d_xyz=out['d_xyz'], net_d_rotation=out['d_rotation'], net_d_scaling=out['d_scaling'])
             return rs.sp_stage(L, p3d.knn_points, a, K, 'LBS', False)
-        me.kernel_radius, me.kernel_weight = torch.exp(p['_sp_radius']), torch.sigmoid(p['_sp_weight'])     # the reference's properties (:548-553)
+        if '_sp_radius' in p:                                                                  # the reference's properties (:548-553)
+            me.kernel_radius = torch.exp(p['_sp_radius'])
+        if '_sp_weight' in p:
+            me.kernel_weight = torch.sigmoid(p['_sp_weight'])
         w, idx = ra.calc_LBS_weight(me, points, p['sp_points'], p['hyper_feature'], p['sp_hyper_feature'])
         out = ra.deform_network_forward(net, p['sp_points'].detach(), times[v])
         bias = points.new_tensor([0, 0, 0, 1.])                                              # (sk_gs.py:835: the reference's own line)
         d_rot = F.normalize(out['d_rotation'] + bias, dim=-1)
         spT = L.SE3.InitFromVec(torch.cat([out['d_xyz'], d_rot], dim=-1))
         d_points = (spT[idx].act(points[:, None]) * w[..., None]).sum(dim=1) - points
-        return rs._activate(p, d_points, (d_rot[idx] * w[..., None]).sum(dim=1), (out['d_scaling'][idx] * w[..., None]).sum(dim=1))
+        res = rs._activate(p, d_points, (d_rot[idx] * w[..., None]).sum(dim=1), (out['d_scaling'][idx] * w[..., None]).sum(dim=1))
+        res['_knn_w'], res['_spT'] = w, spT.vec()
+        return res
 
     def deform(v):
         if sp:
@@ -178,14 +192,43 @@ def setup(args, configs):
         opt.step()
         return loss
 
+    # the two regularisers of the shipped sp configuration on the [P,K] LBS weights (--sp-regularisers), as the reference writes them:
+    # loss_weight_sparsity / loss_weight_smooth (sk_gs.py:1339-1359) over a 20-neighbour table of the Gaussians (gs_knn_num, :345)
+    gs_knn_index = None
+    if sp and args.sp_regularisers:
+        assert args.reference_loop != 'hooks', '--sp-regularisers: accelerated | fused'
+        with torch.no_grad():
+            pts = p['_xyz'].detach()
+            gs_knn_index = p3d.knn_points(pts[None], pts[None], None, None, K=21)[1][0].contiguous()      # (pykdtree in the reference, :1348-1353)
+
+    def weight_regularisers(knn_w):     # sk_gs.py:1572-1574 with the weights of exps/default.yaml:85-86
+        w = knn_w
+        sparse = -(w * torch.log(w + 1e-7) + (1 - w) * torch.log(1 - w + 1e-7)).mean()
+        smooth = (w[0][:, None] - w[0][gs_knn_index]).abs().mean()
+        return 0.1 * sparse + 0.1 * smooth
+
+    if gs_knn_index is not None and not fused:
+        base_step = step
+
+        def step(i):  # noqa: F811
+            v = i % args.views
+            opt.zero_grad(set_to_none=True)
+            res = deform(v)
+            loss = loss_of(render(v, res), targets[v]) + weight_regularisers(res['_knn_w'][None])
+            loss.backward()
+            opt.step()
+            return loss
+
     rf = None
     if fused:
-        assert not sp, '--reference-loop fused: stage sk (stage sp runs `accelerated`)'
         from sk_gs_amd import reference_fused as rf
-        model = _RefSkeletonModel(p, net, table.to(dev).int(), frames, M, K, dev)
+        if sp:
+            model = _RefSuperpointModel(p, net, K)
+        else:
+            model = _RefSkeletonModel(p, net, table.to(dev).int(), frames, M, K, dev)
         # what a call outside the fused route's conditions reaches: the reference's own render, i.e. the `accelerated` sequence above
         ra._originals['render'] = lambda self, *a, t=None, info=None, time_id=None, **kw: {
-            'images': render(int(time_id), deform(int(time_id))).permute(1, 2, 0)[None], 'stage': 'sk'}
+            'images': render(int(time_id), deform(int(time_id))).permute(1, 2, 0)[None], 'stage': args.stage}
         image_crit, ssim_crit = _RefImageLoss(), types.SimpleNamespace(window_size=11, reduction='mean')
         ra._originals['image_loss'] = _RefImageLoss.reference_forward
         cams = [scene.make_camera(W, H, seed=v) for v in range(args.views)]
@@ -202,11 +245,14 @@ def setup(args, configs):
             image, gt_img = outputs['images'], tgt[..., :3]
             Hh, Ww, Cc = image.shape[-3:]
             image, gt_img = image.view(1, Hh, Ww, Cc), gt_img.view(1, Hh, Ww, Cc)
-            return {'rgb': loss_funcs('image', image, gt_img), 'ssim': loss_funcs('ssim', image, gt_img)}
+            losses = {'rgb': loss_funcs('image', image, gt_img), 'ssim': loss_funcs('ssim', image, gt_img)}
+            if gs_knn_index is not None:                                                      # :1572-1574
+                losses['sparse+smooth'] = weight_regularisers(outputs['_knn_w'])
+            return losses
 
         def step(i):  # noqa: F811
             v = i % args.views
-            outputs = rf.render(model, t=times[v], info=infos[v], background=bg, time_id=time_ids[v])      # train.py:190
+            outputs = rf.render(model, t=times[v], info=infos[v], background=bg, time_id=time_ids[v], stage=args.stage)      # train.py:190
             losses = model_loss(outputs, targets_hwc[v])                                      # :194
             loss = sum(losses.values())                                                      # framework.py:268
             loss.backward()                                                                  # :286
@@ -217,7 +263,7 @@ def setup(args, configs):
     return types.SimpleNamespace(step=step, p=p, net=net, opt=opt, rf=rf, ra=ra, L=L, p3d=p3d, _C=_C, cfg=cfg, P=P, M=M, K=K, W=W, H=H, sp=sp,
                                  accel=accel, fused=fused, targets=targets, deform=deform, render=render, loss_of=loss_of, times=times, bg=bg,
                                  model=locals().get('model'), infos=locals().get('infos'), time_ids=locals().get('time_ids'),
-                                 targets_hwc=locals().get('targets_hwc'), model_loss=locals().get('model_loss'))
+                                 targets_hwc=locals().get('targets_hwc'), model_loss=locals().get('model_loss'), weight_regularisers=weight_regularisers)
 
 
 def run(args, configs):
@@ -261,8 +307,8 @@ def run(args, configs):
 
 
 def _route_status(rf, model):
-    r = rf._routes.get(model)
-    if r is None or isinstance(r, tuple):
+    r = rf.route_of_model(model, 'sp' if getattr(model, '_stage', 'sk') == 'sp' else 'sk')
+    if r is None:
         return None
     st = r.step.status()
     return dict(tile_bucket=r._bucket, overflow_events=st['overflow_events'], mlp_failed=st.get('mlp_failed', 0))
@@ -274,6 +320,24 @@ class _RefImageLoss:
 
     def reference_forward(self, pred_image, gt_image, mask=None):
         return F.l1_loss(pred_image[..., :3], gt_image[..., :3])
+
+
+class _RefSuperpointModel:
+    """the attributes of ``SkeletonGaussianSplatting`` the fused route reads in stage sp (networks/sk_gs.py:342-540)"""
+    training, use_official_gaussians_render, convert_SHs_python, compute_cov3D, _stage = True, True, False, False, 'sp'
+    warp_method, sep_rot, max_sh_degree, hyper_dim = 'LBS', False, 3, 8
+
+    def __init__(self, p, net, K):
+        for k_ in ('_xyz', '_features_dc', '_features_rest', '_scaling', '_rotation', '_opacity', 'sp_points', 'hyper_feature', 'sp_hyper_feature'):
+            setattr(self, k_, p[k_])
+        self.sp_W, self._sp_radius, self._sp_weight = p.get('sp_W'), p.get('_sp_radius'), p.get('_sp_weight')
+        self.LBS_method = 'W' if self.sp_W is not None else ('weighted_kernel' if self._sp_weight is not None else 'kernel')
+        self.sp_deform_net, self.num_knn = net, K
+        self._active_sh_degree = torch.tensor(3, dtype=torch.int, device=p['_xyz'].device)
+        self.sp_weights = self.sp_knn = None
+
+    def get_now_stage(self, stage=None):
+        return 'sp' if stage is None else stage
 
 
 class _RefSkeletonModel:

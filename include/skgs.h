@@ -724,6 +724,9 @@ typedef struct skgs_sp_skinning_job {
   size_t pairs_bytes;
   void* workspace;
   size_t workspace_bytes;
+  const float* g_weights_extra; /* NULL, or [P,K]: a cotangent on the LBS weights from OUTSIDE the skinning -- the reference's loss
+                                 * reads outputs['_knn_w'] in stage `sp` (`sparse`, `smooth`: networks/sk_gs.py:1339-1359,1572-1574) --
+                                 * added to the skinning's own before the weighting's chain rule (and into g_weights) */
 } skgs_sp_skinning_job;
 int skgs_sp_skinning_backward(const skgs_deform_inputs* in, int32_t F, const float* feature, const float* sp_feature,
     const float* sp_radius_raw, const float* sp_weight_raw, float temperature, int32_t logit_weighting, const float* nn_dist,

@@ -99,7 +99,7 @@ class _SpSkinningJob(C.Structure):
                 [('temperature', C.c_float), ('logit_weighting', C.c_int32), ('nn_dist', C.c_void_p)] +
                 [(n, C.c_void_p) for n in ('g_weights', 'g_xyz', 'g_log_scale', 'g_rot', 'g_opacity_logit', 'g_feature', 'g_bone_T',
                                            'g_bone_drot', 'g_bone_dscale', 'g_sp_feature', 'g_sp_radius', 'g_sp_weight', 'pairs')] +
-                [('pairs_bytes', C.c_size_t), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)])
+                [('pairs_bytes', C.c_size_t), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('g_weights_extra', C.c_void_p)])
 
 
 EXPORTED_SYMBOLS = [

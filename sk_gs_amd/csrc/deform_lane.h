@@ -354,6 +354,7 @@ struct SpRowsArgs {
   float temperature;
   int logits;
   float *g_weights, *g_xyz, *g_log_scale, *g_rot, *g_opacity_logit, *g_feature, *U, *V;
+  const float* g_weights_extra;
 };
 // the arguments from the public job (U and V are the first two pieces of its workspace: sp_backward.hip carves the same way)
 inline SpRowsArgs sp_rows_args(const skgs_sp_skinning_job& j) {
@@ -364,7 +365,7 @@ inline SpRowsArgs sp_rows_args(const skgs_sp_skinning_job& j) {
   float* V       = reinterpret_cast<float*>(wsp + align256(P * SP_UROW * 4));
   return SpRowsArgs{in->K, in->M, (int) in->largest, in->points, in->weights, in->indices, j.nn_dist, in->bone_T, in->bone_drot, in->bone_dscale,
       in->log_scale, in->rot, in->opacity_logit, j.feature, j.sp_feature, j.sp_radius_raw, j.sp_weight_raw, j.temperature,
-      (int) j.logit_weighting, j.g_weights, j.g_xyz, j.g_log_scale, j.g_rot, j.g_opacity_logit, j.g_feature, U, V};
+      (int) j.logit_weighting, j.g_weights, j.g_xyz, j.g_log_scale, j.g_rot, j.g_opacity_logit, j.g_feature, U, V, j.g_weights_extra};
 }
 inline size_t sp_rows_lds_bytes(int M) { return (size_t) M * BONE_F * 4; }
 // s_bones: [M][BONE_F] staged by the caller (load_bone), n: the lane's Gaussian (< P)
@@ -431,6 +432,7 @@ __device__ __forceinline__ void sp_rows_lane(const SpRowsArgs& ja, const float* 
       for (int c = 0; c < 4; ++c) a += g_v[c] * b[7 + c];
 #pragma unroll
       for (int c = 0; c < 3; ++c) a += g_ds[c] * b[11 + c];
+      if (ja.g_weights_extra) a += ja.g_weights_extra[(size_t) n * ja.K + k];  // (a cotangent on the weights from outside the skinning)
       gw[k] = a;
       if (ja.g_weights) ja.g_weights[(size_t) n * ja.K + k] = a;
     }

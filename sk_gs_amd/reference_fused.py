@@ -48,7 +48,7 @@ import weakref
 import torch
 
 calls = {'render_fused': 0, 'render_reference': 0, 'image_terms_fused': 0, 'image_terms_reference': 0, 'backward_direct': 0,
-         'backward_cotangent': 0, 'foreign_grads_added': 0, 'routes_built': 0, 'capacity_grown': 0, 'capacity_retuned': 0}
+         'backward_cotangent': 0, 'foreign_grads_added': 0, 'routes_built': 0, 'capacity_grown': 0, 'capacity_retuned': 0, 'backward_extras': 0}
 why_not = {'render': None, 'terms': None}
 _routes = weakref.WeakKeyDictionary()     # reference model -> FusedReferenceRoute | str (the reason there is none)
 CHECK_EVERY = 64
@@ -180,38 +180,108 @@ def _conditions(ref):
     return None
 
 
-class FusedReferenceRoute:
-    """one reference model's fused step: the adapter, the ``FusedViewStep``, the persistent gradients"""
+class _ModelViewSp:
+    """what ``FusedSuperpointStep`` asks of a model (``superpoint.SuperpointGaussians``), answered by the reference's model in stage sp"""
+    static, capacity, lbs_temperature, time_noise, sk_deform_net = False, None, 1.0, 0.0, None
 
-    def __init__(self, ref, W, H, sh_degree, scale_modifier):
+    def __init__(self, ref, shadow_net):
+        self._ref, self.sp_deform_net = ref, shadow_net
+        for name in ('_xyz', '_features_dc', '_features_rest', '_scaling', '_rotation', '_opacity', 'sp_points', 'hyper_feature',
+                     'sp_hyper_feature', 'sp_W', '_sp_radius', '_sp_weight'):
+            setattr(self, name, getattr(ref, name, None))
+        self.P, self.M, self.K = int(ref._xyz.shape[0]), int(ref.sp_points.shape[0]), int(ref.num_knn)
+        self.hyper_dim = int(ref.hyper_dim) if ref.hyper_feature is not None else 0
+        self.max_sh_degree = int(ref.max_sh_degree)
+        self.lbs_method, self.warp_method, self.sep_rot = ref.LBS_method, ref.warp_method, bool(ref.sep_rot)
+
+    def topology(self):
+        return {}
+
+    def parameters(self):
+        # (sp_points: detached everywhere on this path, sk_gs.py:753-755,845 -- except by the re-centring of LBS_c; a parameter the
+        # reference gives no gradient must not get one here: Adam would move it on its old moments)
+        ps = [self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation, self._opacity]
+        if self.sp_W is not None:
+            ps.append(self.sp_W)
+        else:
+            ps += [q for q in (self.hyper_feature, self.sp_hyper_feature, self._sp_radius, self._sp_weight) if q is not None]
+        if self.warp_method == 'LBS_c':
+            ps.append(self.sp_points)
+        return ps + list(self.sp_deform_net.parameters())
+
+
+def _conditions_sp(ref):
+    """None when ``ref`` in stage sp is what ``FusedSuperpointStep`` covers, else the reason"""
+    from sk_gs_amd import reference_accel as ra
+    if not getattr(ref, 'use_official_gaussians_render', False):
+        return 'use_official_gaussians_render is off (the in-tree rasterizer convention: operator path)'
+    if getattr(ref, 'convert_SHs_python', False) or getattr(ref, 'compute_cov3D', False):
+        return 'convert_SHs_python / compute_cov3D'
+    if getattr(ref, 'warp_method', None) not in ('LBS', 'LBS_c'):
+        return f'warp_method {getattr(ref, "warp_method", None)!r} (the fused route covers LBS and LBS_c)'
+    if getattr(ref, 'LBS_method', None) not in ('W', 'dist', 'kernel', 'weighted_kernel'):
+        return 'LBS_method'
+    ps = [ref._xyz, ref._features_dc, ref._features_rest, ref._scaling, ref._rotation, ref._opacity, ref.sp_points] + \
+         [q for q in (ref.hyper_feature, ref.sp_hyper_feature, ref.sp_W, ref._sp_radius, ref._sp_weight) if q is not None]
+    if not all(torch.is_tensor(p) and p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in ps):
+        return 'parameters are not contiguous fp32 tensors on a HIP device'
+    P, M, K = ref._xyz.shape[0], ref.sp_points.shape[0], int(ref.num_knn)
+    F_ = int(ref.hyper_dim) if ref.hyper_feature is not None else 0
+    if P == 0 or not (1 <= K <= 8 and K <= M) or not (60 < M <= 1024) or F_ not in (0, 8):
+        return f'shapes: P = {P}, {M} superpoints, K = {K}, {F_} hyper dimensions'
+    if F_ and (tuple(ref.hyper_feature.shape) != (P, F_) or tuple(ref.sp_hyper_feature.shape) != (M, F_)):
+        return 'hyper feature shapes'
+    if ref.LBS_method == 'W' and (ref.sp_W is None or tuple(ref.sp_W.shape) != (P, M)):
+        return 'sp_W shape'
+    if ref.LBS_method in ('kernel', 'weighted_kernel') and (ref._sp_radius is None or ref._sp_radius.shape[0] != M):
+        return '_sp_radius shape'
+    if not getattr(ref.sp_deform_net, 'is_blender', False):
+        return 'sp_deform_net without the time network (its per-call time noise, sk_gs.py:837-839, stays with the reference)'
+    sh = ra.sp_net_shadow(ref.sp_deform_net)
+    if sh is None or not sh.kernel_supported():
+        return 'sp_deform_net is not a network the row-block kernels cover'
+    return None
+
+
+class FusedReferenceRoute:
+    """one reference model's fused step for one stage: the adapter, the ``FusedViewStep`` / ``FusedSuperpointStep``, the persistent
+    gradients, the graphs"""
+
+    def __init__(self, ref, W, H, sh_degree, scale_modifier, stage='sk'):
         from sk_gs_amd import _C, reference_accel as ra
-        from sk_gs_amd.fused_step import FusedViewStep
         self.lib = _C.load_library()
         self.ref = weakref.ref(ref)
-        self.W, self.H = int(W), int(H)
+        self.W, self.H, self.stage = int(W), int(H), stage
         dev = ref._xyz.device
-        shadow = ra.sk_net_shadow(ref.sk_deform_net)
-        _rehome_heads(ref.sk_deform_net, shadow)
-        self.shadow = shadow
-        topo = ra._topology(ref.joint_parents, ref.joint_root)
-        self.view = _ModelView(ref, shadow, topo)
         self.table = _LiveSlot(dev, W, H, sh_degree, scale_modifier)
-        self.key = self.identity(ref)
         self._bucket = 0
+        if stage == 'sk':
+            shadow = ra.sk_net_shadow(ref.sk_deform_net)
+            _rehome_heads(ref.sk_deform_net, shadow)
+            self.shadow = shadow
+            topo = ra._topology(ref.joint_parents, ref.joint_root)
+            self.view = _ModelView(ref, shadow, topo)
+        else:
+            self.shadow = ra.sp_net_shadow(ref.sp_deform_net)
+            self.view = _ModelViewSp(ref, self.shadow)
         saved = {p: p.grad for p in self.view.parameters()}
         for p in saved:
             p.grad = None
         self.step = self._build_step(64)
         self.grads = {p: p.grad for p in self.view.parameters()}            # persistent: the kernels' write targets
-        net, heads = shadow.dynamic_net, ref.sk_deform_net.dynamic_net.last
-        for h, o in zip(heads, shadow._heads_rehomed):                       # the heads' gradients: row views of the head matrix's
-            oc = h.weight.shape[0]
-            self.grads[h.weight], self.grads[h.bias] = net.last_weight.grad[o:o + oc], net.last_bias.grad[o:o + oc]
+        stores = ()
+        if stage == 'sk':
+            net, heads = shadow.dynamic_net, ref.sk_deform_net.dynamic_net.last
+            for h, o in zip(heads, shadow._heads_rehomed):                   # the heads' gradients: row views of the head matrix's
+                oc = h.weight.shape[0]
+                self.grads[h.weight], self.grads[h.bias] = net.last_weight.grad[o:o + oc], net.last_bias.grad[o:o + oc]
+            stores = (net.last_weight, net.last_bias)
         for p, g in saved.items():
             p.grad = g
-        net.last_weight.grad = net.last_bias.grad = None
-        self.params = [p for p in self.view.parameters() if p is not net.last_weight and p is not net.last_bias] + \
-                      [q for h in heads for q in (h.weight, h.bias)]
+        for p in stores:
+            p.grad = None
+        self._stores = stores
+        net = types.SimpleNamespace(last_weight=stores[0], last_bias=stores[1]) if stores else types.SimpleNamespace(last_weight=None, last_bias=None)
         self.vp = torch.zeros((self.view.P, 3), dtype=torch.float32, device=dev, requires_grad=True)   # outputs['viewspace_points'][0]
         self.loss_ring = torch.zeros((64, 3), dtype=torch.float32, device=dev)
         self._ring_pos = 0
@@ -219,6 +289,9 @@ class FusedReferenceRoute:
         self.serial, self._fwd, self._terms, self._bg_key, self._spare = 0, None, None, None, None
         self._seen_events = 0
         self._attach = [(p, g, (p is net.last_weight or p is net.last_bias)) for p, g in self.grads.items()]
+        if stage == 'sp':   # cotangents the reference's loss puts on outputs['_knn_w'] / outputs['_spT'] (sparse, smooth, joint: sk_gs.py:1555-1574)
+            self.gw_extra = torch.zeros((self.view.P, self.view.K), dtype=torch.float32, device=dev)
+            self.gT_extra = torch.zeros((self.view.M, 7), dtype=torch.float32, device=dev)
         self.graphs, self._graph_key = None, None      # hipGraphs of the forward half / the backward half (None: eager launches)
         self.use_graphs = os.environ.get('SKGS_REF_FUSED_GRAPHS', '1') != '0'
         calls['routes_built'] += 1
@@ -240,8 +313,13 @@ class FusedReferenceRoute:
         old = getattr(self, 'step', None)
         if old is not None:
             bg = old.background
-        step = FusedViewStep(self.view, self.W, self.H, capacity=max(24 * self.view.P, 64 * T) if bucket == 0 else 0, lambda_dssim=0.2,
-                             background=bg, tile_bucket=bucket, view_table=self.table)
+        if self.stage == 'sp':
+            from sk_gs_amd.superpoint import FusedSuperpointStep
+            step = FusedSuperpointStep(self.view, self.W, self.H, capacity=max(24 * self.view.P, 64 * T) if bucket == 0 else 0,
+                                       lambda_dssim=0.2, background=bg, tile_bucket=bucket, view_table=self.table)
+        else:
+            step = FusedViewStep(self.view, self.W, self.H, capacity=max(24 * self.view.P, 64 * T) if bucket == 0 else 0, lambda_dssim=0.2,
+                                 background=bg, tile_bucket=bucket, view_table=self.table)
         self._bucket = bucket
         return step
 
@@ -315,15 +393,14 @@ class FusedReferenceRoute:
             def fwd(_):
                 self._fwd = st.forward(None, None)
 
-            def bwd(_):
-                with torch.no_grad():
-                    st._zero_table_grads()
-                    st._raster_backward(self._fwd[0], self._fwd[1], None)
-                    st.backward_skinning(None)
+            def bwd(k):
+                self._launch_backward(extras=(k == 'bx'))
             st.dL_dimage.zero_()      # (the warm-up execution of the backward half runs on it)
             gs = GraphedSteps(lambda k: (fwd if k == 'f' else bwd)(k), warmup=1, collect_garbage=False, thread_local=True)
             gs.capture('f')
             gs.capture('b')
+            if self.stage == 'sp':    # the same with the cotangents on _knn_w / _spT read from their persistent buffers
+                gs.capture('bx')
             self.graphs, self._graph_key = gs, self._graph_state()
         except Exception as e:   # noqa: BLE001  (no graph: the same launches, issued one by one)
             warnings.warn(f'fused reference route: hipGraph capture failed ({type(e).__name__}: {e}); using eager launches')
@@ -332,10 +409,21 @@ class FusedReferenceRoute:
             for p, g in saved:
                 p.grad = g
 
+    def _launch_backward(self, extras=False):
+        st = self.step
+        with torch.no_grad():
+            if self.stage == 'sp':
+                st.g_weights_extra, st.g_bone_T_extra = (self.gw_extra, self.gT_extra) if extras else (None, None)
+            st._zero_table_grads()
+            st._raster_backward(self._fwd[0], self._fwd[1], None)
+            st.backward_skinning(None)
+
     def check_status(self):
         st = self.step.status()
         if st.get('mlp_failed', 0):
             raise RuntimeError(f"fused reference route: {st['mlp_failed']} skeleton launches gave up their in-launch exchange")
+        if st.get('pairs_overflow_events', 0):
+            raise RuntimeError(f"fused reference route: a superpoint's inverse neighbour list overflowed in {st['pairs_overflow_events']} steps")
         if st['overflow_events'] > self._seen_events:
             warnings.warn(f"fused reference route: {st['overflow_events'] - self._seen_events} forward(s) of the last {CHECK_EVERY} had tile "
                           f"lists longer than the {self._bucket} slots per tile (excess splats were dropped there); capacity doubled")
@@ -395,15 +483,27 @@ class FusedReferenceRoute:
             self._retune()
         if self.use_graphs and (self.graphs is None or self._graph_key != self._graph_state()):
             self._capture()
-        image = _FusedRender.apply(self, self.view._xyz)                     # [3,H,W]
         st = self.step
         out = FusedOutputs(self)
+        if self.stage == 'sk':
+            image = _FusedRender.apply(self, self.view._xyz)                 # [3,H,W]
+            out['_knn_w'] = st.weights.unsqueeze(0)
+            out['_skT'], out['_sk_rot'], out['_sk_scale'] = st.bone_T.unsqueeze(0), st._d_rot.unsqueeze(0), st._d_scale.unsqueeze(0)
+        else:
+            # outputs['_knn_w'] and outputs['_spT'] carry gradient in the reference (the `sparse` / `smooth` regularisers and the joint
+            # losses read them, sk_gs.py:1555-1574): outputs of the node; their cotangents enter the backward half
+            image, knn_w, spT = _FusedRenderSp.apply(self, self.view._xyz)
+            out['_knn_w'], out['_spT'] = knn_w.unsqueeze(0), spT.unsqueeze(0)
+            out['_sp_scale'] = st.net.d_scale.unsqueeze(0)
+            if self.view.sep_rot:                                            # (None without sep_rot: dropped by render's stack, :1236)
+                out['_sp_rot'] = st.net.d_rot.unsqueeze(0)
+            # calc_LBS_weight's side effect while the skeleton is not initialised (sk_gs.py:771-773): the stage's latest weights
+            ref.sp_weights, ref.sp_knn = st.weights, st.indices
         out['images'] = image.permute(1, 2, 0).unsqueeze(0)                  # [1,H,W,3]: torch.permute(images, (1, 2, 0)) stacked (:1229,1240)
         out['viewspace_points'] = [self.vp]
         out['radii'] = st.radii.unsqueeze(0)
         out['points'] = st.means.unsqueeze(0)
-        out['_knn_w'], out['_knn_i'] = st.weights.unsqueeze(0), st.indices.unsqueeze(0)
-        out['_skT'], out['_sk_rot'], out['_sk_scale'] = st.bone_T.unsqueeze(0), st._d_rot.unsqueeze(0), st._d_scale.unsqueeze(0)
+        out['_knn_i'] = st.indices.unsqueeze(0)
         out['stage'] = stage
         calls['render_fused'] += 1
         return out
@@ -425,10 +525,20 @@ class FusedReferenceRoute:
                 p.grad = g
         return foreign
 
-    def backward(self, g_image):
+    def backward(self, g_image, g_w=None, g_T=None):
         from sk_gs_amd import _C
         st = self.step
         a, d = self._fwd
+        extras = g_w is not None or g_T is not None
+        if extras:
+            with torch.no_grad():
+                self.gw_extra.copy_(g_w.reshape(self.gw_extra.shape)) if g_w is not None else self.gw_extra.zero_()
+                self.gT_extra.copy_(g_T.reshape(self.gT_extra.shape)) if g_T is not None else self.gT_extra.zero_()
+            calls['backward_extras'] += 1
+        if g_image is None:          # (only the regularisers were differentiated: the image's cotangent is zero)
+            with torch.no_grad():
+                st.dL_dimage.zero_()
+            g_image, self._dimage_ready = st.dL_dimage, True
         if not (self._dimage_ready and g_image.data_ptr() == st.dL_dimage.data_ptr() and g_image.is_contiguous()):
             with torch.no_grad():
                 st.dL_dimage.copy_(g_image)
@@ -439,18 +549,16 @@ class FusedReferenceRoute:
         foreign = self.attach_grads()
         with torch.no_grad():
             if self.graphs is not None:
-                self.graphs.graphs['b'].replay()
+                self.graphs.graphs['bx' if extras else 'b'].replay()
             else:
-                st._zero_table_grads()
-                st._raster_backward(a, d, None)
-                st.backward_skinning(None)
+                self._launch_backward(extras)
             self.vp.grad = st.grad_means2D
             if foreign:
                 for ours, theirs in foreign:
                     ours.add_(theirs)
                 calls['foreign_grads_added'] += len(foreign)
-        net = self.shadow.dynamic_net
-        net.last_weight.grad = net.last_bias.grad = None      # (the heads own these rows as far as any optimizer is concerned)
+        for p in self._stores:      # (the heads own these rows as far as any optimizer is concerned)
+            p.grad = None
 
     # -------------------------------------------------------------------------------------------------------------------------
     def image_terms(self, pred, gt):
@@ -481,7 +589,7 @@ class FusedOutputs(dict):
         with torch.no_grad():
             if key == 'visibility_filter':
                 v = (st.radii > 0).unsqueeze(0)
-            elif key in ('_d_xyz', '_d_rot', '_d_scale'):
+            elif key in ('_d_xyz', '_d_rot', '_d_scale') and self._route.stage == 'sk':
                 w, i = st.weights, st.indices
                 if key == '_d_xyz':
                     v = st.means - self._route.view._xyz.detach()
@@ -503,6 +611,7 @@ class _FusedRender(torch.autograd.Function):
     def forward(ctx, route, anchor):
         # (`anchor`: ONE parameter, so that the image requires grad; the node writes every parameter's gradient itself)
         ctx._skgs_route, ctx.serial = route, route.serial
+        ctx.set_materialize_grads(False)      # (an output nobody differentiated arrives as None, not as a tensor of zeros)
         if route.graphs is not None:
             route.graphs.graphs['f'].replay()
         else:
@@ -517,7 +626,35 @@ class _FusedRender(torch.autograd.Function):
         if ctx.serial != route.serial:
             raise RuntimeError('fused reference route: backward of a render() whose buffers a later render() has overwritten '
                                '(one view at a time: call backward before the next render)')
-        route.backward(g_image)
+        if g_image is not None:
+            route.backward(g_image)
+        return None, None
+
+
+class _FusedRenderSp(torch.autograd.Function):
+    """stage sp: the image, the LBS weights [P,K] and the superpoint transforms [M,7] are the node's differentiable outputs"""
+
+    @staticmethod
+    def forward(ctx, route, anchor):
+        ctx._skgs_route, ctx.serial = route, route.serial
+        ctx.set_materialize_grads(False)      # (an output nobody differentiated arrives as None, not as a tensor of zeros)
+        if route.graphs is not None:
+            route.graphs.graphs['f'].replay()
+        else:
+            route._fwd = route.step.forward(None, None)
+        route._dimage_ready = False
+        st = route.step
+        return st.image.detach(), st.weights.detach(), st.net.bone_T.detach()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_image, g_w, g_T):
+        route = ctx._skgs_route
+        if ctx.serial != route.serial:
+            raise RuntimeError('fused reference route: backward of a render() whose buffers a later render() has overwritten '
+                               '(one view at a time: call backward before the next render)')
+        if g_image is not None or g_w is not None or g_T is not None:
+            route.backward(g_image, g_w, g_T)
         return None, None
 
 
@@ -527,6 +664,7 @@ class _FusedImageTerms(torch.autograd.Function):
         from sk_gs_amd import _C
         st, target = route.step, route.target
         ctx.route, ctx.shape, ctx.serial = route, tuple(pred.shape), route.serial
+        ctx.set_materialize_grads(False)
         row = route.loss_ring[route._ring_pos]
         route._ring_pos = (route._ring_pos + 1) % route.loss_ring.shape[0]
         # lambdas (0, 1): loss3 = {0 * L1 + 1 * (1 - SSIM), L1 mean, SSIM mean}
@@ -542,6 +680,8 @@ class _FusedImageTerms(torch.autograd.Function):
         route, st = ctx.route, ctx.route.step
         if ctx.serial != route.serial:
             raise RuntimeError('fused reference route: backward of image terms whose render() has been overwritten by a later one')
+        if g_l1 is None and g_ssim is None:
+            return None, None
         fix = lambda g: None if g is None else g.detach().reshape(1).to(torch.float32).contiguous()  # noqa: E731
         gl, gs = fix(g_l1), fix(g_ssim)
         _C._check(route.lib.skgs_image_loss_backward_terms(C.c_int32(3), C.c_int32(st.H), C.c_int32(st.W), _p(st.image), _p(route.target), None,
@@ -556,6 +696,12 @@ class _FusedImageTerms(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ recognising a fused image
+def route_of_model(model, stage='sk'):
+    """the route built for ``model`` in ``stage`` (None: none yet, or the conditions refused it -- ``why_not['render']``)"""
+    r = (_routes.get(model) or {}).get(stage)
+    return None if (r is None or isinstance(r, tuple)) else r
+
+
 def route_of(image):
     """the route whose render node produced ``image`` (through view operations only), or None"""
     fn, hops = getattr(image, 'grad_fn', None), 0
@@ -616,8 +762,8 @@ def _size_of(info, cached):
 
 
 def _route_for(self, stage, t, info, background, time_id, scale_modifier, args, kwargs):
-    if stage != 'sk':
-        return None, f'stage {stage!r} (the fused route covers sk)'
+    if stage not in ('sk', 'sp'):
+        return None, f'stage {stage!r} (the fused route covers sk and sp)'
     if not (self.training and torch.is_grad_enabled()):
         return None, 'not training / grad disabled'
     if args or kwargs:
@@ -633,36 +779,45 @@ def _route_for(self, stage, t, info, background, time_id, scale_modifier, args, 
         return None, 'more than one view per call'
     if background is not None and not (torch.is_tensor(background) and background.is_cuda and background.numel() <= 3):
         return None, 'an image-shaped background'
-    cached = _routes.get(self)
+    per_stage = _routes.get(self)
+    if per_stage is None:
+        per_stage = _routes[self] = {}
+    cached = per_stage.get(stage)
     W, H = _size_of(info, cached)
     sh = int(self.active_sh_degree) if not hasattr(self, '_active_sh_degree') else _cached_sh_degree(self)
     if isinstance(cached, tuple):          # (reason, light identity): no route for this model as it is
-        if cached[1] == _light_identity(self):
+        if cached[1] == _light_identity(self, stage):
             return None, cached[0]
         cached = None
-    if cached is not None and (cached.light != _light_identity(self) or (cached.W, cached.H) != (W, H)):
+    if cached is not None and (cached.light != _light_identity(self, stage) or (cached.W, cached.H) != (W, H)):
         cached = None
     if cached is None:
-        reason = _conditions(self)
+        reason = _conditions(self) if stage == 'sk' else _conditions_sp(self)
         if reason is not None:
-            _routes[self] = (reason, _light_identity(self))
+            per_stage[stage] = (reason, _light_identity(self, stage))
             return None, reason
-        cached = _routes[self] = FusedReferenceRoute(self, W, H, sh, scale_modifier)
-        cached.light = _light_identity(self)
+        cached = per_stage[stage] = FusedReferenceRoute(self, W, H, sh, scale_modifier, stage)
+        cached.light = _light_identity(self, stage)
     cached.table.settings.sh_degree, cached.table.settings.scale_modifier = sh, float(scale_modifier)
     return cached, None
 
 
-_LIGHT = ('_xyz', '_features_dc', '_features_rest', '_scaling', '_rotation', '_opacity', 'sp_W', 'joints', 'global_tr', 'sk_cache',
-          'joint_parents', 'sk_deform_net', 'sk_is_init')
+_LIGHT = {'sk': ('_xyz', '_features_dc', '_features_rest', '_scaling', '_rotation', '_opacity', 'sp_W', 'joints', 'global_tr', 'sk_cache',
+                 'joint_parents', 'sk_deform_net', 'sk_is_init'),
+          'sp': ('_xyz', '_features_dc', '_features_rest', '_scaling', '_rotation', '_opacity', 'sp_W', 'sp_points', 'hyper_feature',
+                 'sp_hyper_feature', '_sp_radius', '_sp_weight', 'sp_deform_net')}
 
 
-def _light_identity(ref):
+def _light_identity(ref, stage='sk'):
     """what can change under a route between two calls, cheap enough for every call: the objects behind the attributes the step reads
     (densification / re-initialisation REPLACE the Parameters, set_from_dataset the tables), the storage of the first, the topology's
     version, the skeleton flag's"""
-    obj = tuple(id(getattr(ref, n, None)) for n in _LIGHT)
-    x, jp, flag = ref._xyz, getattr(ref, 'joint_parents', None), getattr(ref, 'sk_is_init', None)
+    obj = tuple(id(getattr(ref, n, None)) for n in _LIGHT[stage])
+    x = ref._xyz
+    if stage == 'sp':
+        return obj + (x.data_ptr(), int(x.shape[0]), int(ref.sp_points.shape[0]), int(getattr(ref, 'num_knn', 0)),
+                      getattr(ref, 'LBS_method', None), getattr(ref, 'warp_method', None), bool(getattr(ref, 'sep_rot', False)))
+    jp, flag = getattr(ref, 'joint_parents', None), getattr(ref, 'sk_is_init', None)
     return obj + (x.data_ptr(), int(x.shape[0]), None if jp is None else jp._version, None if flag is None else flag._version,
                   int(getattr(ref, 'num_knn', 0)), getattr(ref, 'LBS_method', None))
 

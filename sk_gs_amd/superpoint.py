@@ -486,6 +486,9 @@ class FusedSuperpointStep(FusedViewStep):
         # LBS_method 'W': with ``sparse_logits`` (FusedSuperpointTrainStep) the dense [P, M] logit gradient is never written -- the
         # table's Adam update visits only the 32-column tiles a row has ever been touched in (skgs_adam_logit_rows)
         self.sparse_logits = False
+        # cotangents from OUTSIDE the step on the LBS weights [P,K] / the superpoint transforms [M,7] (the reference's loss reads
+        # outputs['_knn_w'] and outputs['_spT']: sk_gs_amd/reference_fused.py): added inside the rows pass / before the network's backward
+        self.g_weights_extra = self.g_bone_T_extra = None
         self.logit_mask = torch.zeros((P,), dtype=torch.int32, device=dev) if model.sp_W is not None else None
         self.sp_order = torch.empty((M,), dtype=torch.int32, device=dev)
         self.sp_rank = torch.empty((M,), dtype=torch.int32, device=dev)
@@ -593,6 +596,7 @@ class FusedSuperpointStep(FusedViewStep):
         j.g_sp_feature, j.g_sp_radius, j.g_sp_weight = None if logits else gp(m.sp_hyper_feature), gp(m._sp_radius), gp(m._sp_weight)
         j.pairs, j.pairs_bytes = self.pairs.data_ptr(), self.pairs.numel()
         j.workspace, j.workspace_bytes = self.sb_ws.data_ptr(), self.sb_ws.numel()
+        j.g_weights_extra = None if self.g_weights_extra is None else self.g_weights_extra.data_ptr()
         g.sp_skinning_job = C.cast(C.pointer(j), C.c_void_p)
         self._rows_backward_done = True
         return j
@@ -609,6 +613,7 @@ class FusedSuperpointStep(FusedViewStep):
         if self._rows_backward_done:  # (ran with the rasterizer's backward: _attach_backward_job; the flag stays until the next
             pass                       # backward_raster clears it -- see FusedViewStep.backward_skinning)
         else:
+            assert self.g_weights_extra is None, 'a cotangent on the weights rides on the rows pass of the rasterizer backward (sp_skinning_job)'
             chk(lib.skgs_sp_skinning_backward(
                 C.byref(d), C.c_int32(self.F), _p(m.hyper_feature), _p(m.sp_hyper_feature), _p(m._sp_radius), _p(m._sp_weight),
                 C.c_float(m.lbs_temperature), C.c_int32(1 if logits else 0), _p(self.nn_dist), _p(self.g_means), _p(self.g_scales),
@@ -619,6 +624,8 @@ class FusedSuperpointStep(FusedViewStep):
         if logits and not self.sparse_logits:  # `W`: the dense [P,M] logit gradient (what autograd's gather backward builds)
             chk(lib.skgs_lbs_weights_backward(C.c_int32(P), C.c_int32(M), C.c_int32(K), _p(self.weights), _p(self.indices),
                                               _p(self.g_weights), _p(m.sp_W.grad), st))
+        if self.g_bone_T_extra is not None:
+            self.g_bone_T.add_(self.g_bone_T_extra)
         side = None
         if self.side_optimizer is not None:  # the per-Gaussian rows' Adam update on the CUs the row-block launch leaves idle
             side = self.side_optimizer[0].side_range(*self.side_optimizer[1:])

@@ -272,13 +272,13 @@ def test_stage_sp_two_ranks_share_the_gpu_and_stay_identical():
 
 @pytest.mark.parametrize('stage', ['sk', 'sp'])
 def test_reference_loop_runs_on_the_hooks_and_accelerated_with_the_same_training(stage):
-    """`bench.py --reference-loop hooks | accelerated` (benchlib/reference_loop.py): the reference's whole iteration restated on the hooks
+    """`bench.py --reference-loop hooks | accelerated | fused` (benchlib/reference_loop.py): the reference's whole iteration restated on the hooks
     alone and after accelerate_reference() -- one JSON line each, every accelerator used on every step of the second run, the same loss
     after the same steps (different arithmetic paths, same training), and the accelerated loop faster"""
     out = {}
-    for mode in ('hooks', 'accelerated'):
-        p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--stage', stage, '--reference-loop', mode, '--steps', '12', '--warmup', '5'],
-                           capture_output=True, text=True, timeout=900, cwd=ROOT)
+    for mode in ('hooks', 'accelerated', 'fused'):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--stage', stage, '--reference-loop', mode, '--steps', '12', '--warmup', '5',
+                            '--prime-steps', '0'], capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert p.returncode == 0, p.stderr[-2000:]
         lines = [l for l in p.stdout.splitlines() if l.strip()]
         assert len(lines) == 1, lines
@@ -291,3 +291,13 @@ def test_reference_loop_runs_on_the_hooks_and_accelerated_with_the_same_training
     assert c['adam_fused'] >= 16 and c['adam_reference'] == 1           # (the first step creates torch's state)
     assert abs(h['config']['loss_last'] - a['config']['loss_last']) <= 2e-3 * abs(h['config']['loss_last'])
     assert a['value'] > 1.5 * h['value']
+    # the same loop with SkeletonGaussianSplatting.render + the two image-loss classes routed into the fused step
+    # (sk_gs_amd/reference_fused.py): every iteration on the route, the plain backward graph, no overflow, the same loss, and faster again
+    f = out['fused']
+    fr = f['config']['fused_route']
+    assert fr['calls']['render_fused'] == 17 and fr['calls']['render_reference'] == 0 and fr['calls']['backward_direct'] == 17, fr
+    assert fr['calls']['image_terms_fused'] == 17 and fr['calls']['foreign_grads_added'] == 0 and fr['calls']['backward_extras'] == 0
+    assert fr['status']['overflow_events'] == 0 and fr['status']['tile_bucket'] >= 64
+    assert f['config']['accelerators']['adam_fused'] >= 15
+    assert abs(f['config']['loss_last'] - a['config']['loss_last']) <= 2e-3 * abs(a['config']['loss_last'])
+    assert f['value'] > 1.5 * a['value'] and f['prime_steps'] == 0

@@ -162,7 +162,7 @@ def test_training_through_the_fused_route_follows_the_reference_sequence():
                 rf = s.rf
                 assert rf.calls['render_fused'] == 20 and rf.calls['render_reference'] == 0 and rf.calls['routes_built'] == 1
                 assert rf.calls['backward_direct'] == 20 and rf.calls['foreign_grads_added'] == 0
-                route = rf._routes[s.model]
+                route = rf.route_of_model(s.model)
                 st = route.step.status()
                 assert st['overflow_events'] == 0 and st.get('mlp_failed', 0) == 0 and route._bucket >= 64
                 assert s.ra.calls['adam_fused'] >= 18
@@ -175,7 +175,7 @@ def test_training_through_the_fused_route_follows_the_reference_sequence():
                 s.model._xyz = torch.nn.Parameter(old.detach().clone())
                 s.p['_xyz'] = s.model._xyz
                 out = rf.render(s.model, t=s.times[0], info=s.infos[0], background=s.bg, time_id=s.time_ids[0])
-                assert rf.calls['routes_built'] == 2 and rf._routes[s.model] is not route
+                assert rf.calls['routes_built'] == 2 and rf.route_of_model(s.model) is not route
                 sum(s.model_loss(out, s.targets_hwc[0]).values()).backward()
                 assert s.model._xyz.grad is not None and old.grad is None
         finally:
@@ -186,3 +186,79 @@ def test_training_through_the_fused_route_follows_the_reference_sequence():
     for n in pa:
         far = ((pa[n] - pf[n]).abs() > 2e-2 * float(pa[n].abs().max())).float().mean()
         assert float(far) <= 1e-3, (n, float(far))
+
+
+SMALL_SP = {9: dict(name='small-4k-160', P=4000, M=12, K=4, W=160, H=120)}
+
+
+def _setup_sp(mode, extra=()):
+    return _setup(mode, ('--stage', 'sp', '--superpoints', '128', '--knn', '4', *extra))
+
+
+@pytest.mark.parametrize('lbs', ['weighted_kernel', 'W'])
+def test_stage_sp_one_iteration_with_the_weight_regularisers(lbs):
+    """stage sp through the fused route (``FusedSuperpointStep`` behind ``render``): the image terms AND the two regularisers the shipped
+    configuration puts on outputs['_knn_w'] (sparse, smooth: sk_gs.py:1339-1359,1572-1574) -- their cotangent enters the rows pass of the
+    backward half (``skgs_sp_skinning_job.g_weights_extra``) -- plus a term on outputs['_spT'] (what the joint losses read, :1555-1563):
+    every parameter's gradient equals the reference sequence's on the stand-ins"""
+    s = _setup_sp('fused', ('--sp-regularisers',) + (('--lbs-method', 'W') if lbs == 'W' else ()))
+    try:
+        rf, v = s.rf, 1
+        names = dict(s.p)
+        names.update({f'net.{n}': q for n, q in s.net.named_parameters()})
+        gT = torch.randn(s.M, 7, generator=torch.Generator().manual_seed(5)).cuda() * 1e-3
+
+        def extra_terms(knn_w, spT):
+            return s.weight_regularisers(knn_w) + (spT * gT).sum()
+        for q in names.values():
+            q.grad = None
+        res = s.deform(v)
+        loss_ref = s.loss_of(s.render(v, res), s.targets[v]) + extra_terms(res['_knn_w'][None], res['_spT'])
+        loss_ref.backward()
+        want = {n: (None if q.grad is None else q.grad.detach().clone()) for n, q in names.items()}
+        for q in names.values():
+            q.grad = None
+        out = rf.render(s.model, t=s.times[v], info=s.infos[v], background=s.bg, time_id=s.time_ids[v], stage='sp')
+        assert rf.calls['render_fused'] == 1, rf.why_not
+        assert out['stage'] == 'sp' and tuple(out['_knn_w'].shape) == (1, s.P, s.K) and tuple(out['_spT'].shape) == (1, s.M, 7)
+        assert '_sp_rot' not in out and tuple(out['_sp_scale'].shape) == (1, s.M, 3)
+        assert s.model.sp_weights is not None and s.model.sp_knn is not None           # calc_LBS_weight's side effect (:771-773)
+        assert float((out['_knn_w'][0] - res['_knn_w']).abs().max()) <= 1e-6 and float((out['_spT'][0] - res['_spT']).abs().max()) <= 1e-6
+        losses = s.model_loss(out, s.targets_hwc[v])
+        loss = sum(losses.values()) + (out['_spT'][0] * gT).sum()
+        assert abs(float(loss) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref))
+        loss.backward()
+        assert rf.calls['backward_extras'] == 1
+        for n, q in names.items():
+            if want[n] is None:
+                assert q.grad is None or float(q.grad.abs().max()) == 0.0, n
+                continue
+            assert q.grad is not None, n
+            scale = float(want[n].abs().max())
+            assert float((q.grad - want[n]).abs().max()) <= 3e-4 * scale + 1e-12, (n, float((q.grad - want[n]).abs().max()), scale)
+        # without the extra terms: the plain backward graph, no cotangent buffers touched
+        for q in names.values():
+            q.grad = None
+        out = rf.render(s.model, t=s.times[v], info=s.infos[v], background=s.bg, time_id=s.time_ids[v], stage='sp')
+        sum(list(s.model_loss(out, s.targets_hwc[v]).values())[:2]).backward()
+        assert rf.calls['backward_extras'] == 1 and s.p['_xyz'].grad is not None
+    finally:
+        _teardown(s)
+
+
+def test_stage_sp_training_follows_the_reference_sequence():
+    """15 iterations of the loop in stage sp (image terms) through the fused route and through the per-method fast paths: same losses"""
+    runs = {}
+    for mode in ('accelerated', 'fused'):
+        s = _setup_sp(mode)
+        try:
+            runs[mode] = [float(s.step(i)) for i in range(15)]
+            torch.cuda.synchronize()
+            if mode == 'fused':
+                assert s.rf.calls['render_fused'] == 15 and s.rf.calls['render_reference'] == 0 and s.rf.calls['backward_extras'] == 0
+                st = s.rf.route_of_model(s.model, 'sp').step.status()
+                assert st['overflow_events'] == 0 and st['pairs_overflow_events'] == 0
+        finally:
+            _teardown(s)
+    for a, b in zip(runs['accelerated'], runs['fused']):
+        assert abs(a - b) <= 2e-3 * abs(a), runs

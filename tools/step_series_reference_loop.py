@@ -24,5 +24,5 @@ gpu = [ev[b].elapsed_time(ev[b + 1]) / B for b in range(N // B)]
 print('host ms/step per block:', ' '.join(f'{h:.2f}' for h in host))
 print('gpu  ms/step per block:', ' '.join(f'{g:.2f}' for g in gpu))
 if s.rf is not None:
-    r = s.rf._routes[s.model]
+    r = s.rf.route_of_model(s.model)
     print('bucket', r._bucket, s.rf.calls)
