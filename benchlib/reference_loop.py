@@ -274,6 +274,11 @@ def run(args, configs):
     # run's steady state only after some tens of steps -- here also the tile lists of the synthetic scene's first steps, which the route
     # re-measures at calls 32 and 128); reported as `prime_steps`
     prime = max(int(args.prime_steps), 0)
+    # every mode: CPython's oldest-generation collection walks all of torch (~100 ms, every ~200 eager iterations); the set-up's objects
+    # are frozen out of it, as the fused route does for itself (sk_gs_amd/reference_fused.py::_freeze_collector_once)
+    import gc
+    gc.collect()
+    gc.freeze()
     for i in range(prime + max(args.warmup, 5)):
         step(i)
     torch.cuda.synchronize()
