@@ -40,6 +40,10 @@ MAX_HARD = 2e-3
 # for the contributor itself plus the factor (1 - alpha) on everything behind it, another <= 1 / 255 of the pixel -- 2 / 255 of the
 # image's scale (a 400-scene sweep of tests/test_gpu_fuzz.py's generator found one such pixel at 2.2e-3, 5e-8 from its branch).
 FLIP_HARD = 2.0 / 255.0
+# FlipCensus.check_rows, second branch: a row more than 1e-4 from the fp32 oracle must be within max(1e-4, REF_ERR_FACTOR x ref_err) OF
+# THE TRUTH, ref_err = the reference arithmetic's own distance from the fp64 oracle on that tensor (see there; tests/golden/
+# fuzz_bounds.json is the table of every tensor that needs the branch)
+REF_ERR_FACTOR = 2.0
 
 
 def _record(name, d, tol, frac, allowed, hard, **kw):
@@ -134,11 +138,19 @@ class FlipCensus:
 
     def check_rows(self, got, want, name, exact=None):
         """per-Gaussian tensor [P, ...]: rows of Gaussians that touch a flipped pixel <= hard, all others <= tol.
-        ``exact`` (the same tensor from the fp64 oracle): the tolerance of an untraced row is then max(tol, 2.5 x the error the
-        REFERENCE arithmetic itself makes on this tensor, max |fp32 oracle - fp64 oracle| / scale) -- some scenes (a camera
-        inside the cloud, splats covering the image) are ill-conditioned in fp32: there the fp32 oracle is off by 1e-3 ... 0.4 of
-        the tensor's scale, the strict build reproduces it to 1e-6, and the product build's other summation order lands as
-        close to the true value as the reference does, 1e-4 ... 5e-4 away from it (1000-scene sweep, 7 such scenes)."""
+
+        ``exact`` (the same tensor from the fp64 oracle) tells how far the REFERENCE arithmetic itself is from the true value on this
+        tensor: ``ref_err = max |fp32 oracle - fp64 oracle| / scale``.  Some scenes (a camera inside the cloud, splats covering the image)
+        are ill-conditioned in fp32: there the fp32 oracle is off by 1e-4 ... 0.45 of the tensor's scale, the strict build reproduces it
+        to 1e-6, and the product build -- another summation order of the same terms -- lands elsewhere inside the same error ball.  An
+        untraced row passes when it is within ``tol`` (1e-4) of the fp32 oracle -- the north star's literal bar -- OR when it is as close
+        to the TRUE value as the reference arithmetic is:  |product - fp64 oracle| <= max(tol, REF_ERR_FACTOR x ref_err).  (Round 5
+        widened the bar AROUND THE FP32 ORACLE by 2.5 x ref_err, which let the product sit 3.5 x ref_err from the truth.)  Why the factor
+        is 2 and not 1: the product and the fp32 oracle are two fp32 evaluations of the same ill-conditioned sums in different orders --
+        two draws from one error distribution; over the 72 scenes x 9 tensors of tests/test_gpu_fuzz.py the product's distance to the
+        truth is 0.0 ... 1.74 x the oracle's (median 1.00: on 640 of 648 tensors the product follows the fp32 oracle to 1e-5 and simply
+        shares its error).  tests/golden/fuzz_bounds.json lists every tensor that needs the second branch (8 of 648) with ref_err, both
+        errors and its bound; tests/test_host_cpu.py checks the table against REF_ERR_FACTOR."""
         assert self.rows is not None, 'check_image first'
         got = to_np(got).astype(np.float64)
         want = np.asarray(want, np.float64).reshape(got.shape)
@@ -147,23 +159,33 @@ class FlipCensus:
         scale = max(np.abs(want).max(), 1e-30)
         d = np.abs(got - want) / scale
         dr = d.reshape(d.shape[0], -1).max(1)
-        tol = self.tol
+        over = dr > self.tol
+        extra = {}
+        bound = self.tol
         if exact is not None:
-            cond = float(np.abs(want - np.asarray(exact, np.float64).reshape(got.shape)).max() / scale)
-            tol = max(self.tol, 2.5 * cond)
-            if tol > self.tol:
-                print(f'[census] {self.name} {name}: the fp32 oracle is {cond:.2e} from the fp64 one: rows held to {tol:.2e}')
-        over = dr > tol
+            ex = np.asarray(exact, np.float64).reshape(got.shape)
+            ref_err = float(np.abs(want - ex).max() / scale)
+            d64 = (np.abs(got - ex) / scale).reshape(d.shape[0], -1).max(1)
+            clean64 = d64[~self.rows]
+            extra = dict(ref_err=ref_err, untraced_max_vs_fp64=float(clean64.max()) if clean64.size else 0.0)
+            bound = max(self.tol, REF_ERR_FACTOR * ref_err)
+            extra['bound_vs_fp64'] = bound
+            if over.any():
+                over = over & (d64 > bound)          # within tol of the fp32 oracle, OR as close to the truth as the reference is
+                print(f'[census] {self.name} {name}: the fp32 oracle is {ref_err:.2e} from the fp64 one: rows over {self.tol:g} of it are '
+                      f'held to {bound:.2e} of the fp64 oracle (worst untraced: {extra["untraced_max_vs_fp64"]:.2e})')
         clean = dr[~self.rows]
         _record(f'{self.name} {name}', d, self.tol, float((d > self.tol).mean()), 0.0, self.hard,
                 traced_rows=int((over & self.rows).sum()), rows_touching_a_flip=int(self.rows.sum()),
-                untraced_max=float(clean.max()) if clean.size else 0.0)
-        print(f'[census] {self.name} {name}: {int(over.sum())} rows over {self.tol:g} ({int(self.rows.sum())} of {dr.size} rows '
+                untraced_max=float(clean.max()) if clean.size else 0.0, **extra)
+        print(f'[census] {self.name} {name}: {int((dr > self.tol).sum())} rows over {self.tol:g} ({int(self.rows.sum())} of {dr.size} rows '
               f'touch a flipped pixel); max over the others {clean.max() if clean.size else 0.0:.3e}; max {d.max():.3e}')
         assert not (over & ~self.rows).any(), \
-            f'{self.name} {name}: {int((over & ~self.rows).sum())} rows over {tol:.2e} that touch no flipped pixel ' \
-            f'(max {clean.max():.2e})'
-        assert d.max() <= max(self.hard, tol), f'{self.name} {name}: max rel err {d.max():.2e} > {max(self.hard, tol):.2e}'
+            f'{self.name} {name}: {int((over & ~self.rows).sum())} rows over {self.tol:.0e} of the fp32 oracle' + \
+            (f' and over {bound:.2e} of the fp64 one' if bound != self.tol else '') + \
+            f' that touch no flipped pixel (max {clean.max():.2e})'
+        assert d.max() <= max(self.hard, bound + extra.get('ref_err', 0.0)), \
+            f'{self.name} {name}: max rel err {d.max():.2e} > {max(self.hard, bound + extra.get("ref_err", 0.0)):.2e}'
 
 
 def scene_inputs(P, W, H, seed=0, colmap=True, sh_degree=3, scale_mult=1.0, device='cpu'):

@@ -651,3 +651,21 @@ def test_parity_gate_baseline_is_many_sessions_and_round5_failure_passes():
     for v in (2.02e-5, 2.17e-5):
         assert pg.regressions([dict(k[0], untraced_max=v)], base) == []
     assert len(pg.regressions([dict(k[0], untraced_max=2e-4)], base)) == 1
+
+
+def test_fuzz_bound_table_matches_the_rule_the_tests_apply():
+    """what "within 1e-4" means where the reference's own fp32 arithmetic is not within 1e-4 of the truth.  The rule lives in
+    tests/helpers.FlipCensus.check_rows (an untraced row is within 1e-4 of the fp32 oracle, OR within max(1e-4, REF_ERR_FACTOR x ref_err) of
+    the fp64 oracle); tests/golden/fuzz_bounds.json (tools/make_fuzz_bounds.py, from a GPU session) lists every tensor of the 72-scene sweep
+    that needed the second branch: each inside its bound, the bound computed with the factor the tests use, and the factor no larger than
+    the observed worst ratio rounded up to the next integer."""
+    import json
+    import helpers
+    t = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'fuzz_bounds.json')))
+    assert t['factor'] == helpers.REF_ERR_FACTOR == 2.0 and t['tensors_checked'] >= 600
+    worst = t['ratio_product_to_reference_error']['max']
+    assert 1.0 < worst <= helpers.REF_ERR_FACTOR and 0.99 <= t['ratio_product_to_reference_error']['median'] <= 1.01
+    assert 1 <= len(t['second_branch']) <= 12
+    for e in t['second_branch']:
+        assert e['err_vs_fp32_oracle'] > 1e-4 and e['err_vs_fp64_oracle'] <= e['bound_vs_fp64']
+        assert abs(e['bound_vs_fp64'] - max(1e-4, helpers.REF_ERR_FACTOR * e['ref_err'])) <= 1e-12
