@@ -147,9 +147,9 @@ class FlipCensus:
         to the TRUE value as the reference arithmetic is:  |product - fp64 oracle| <= max(tol, REF_ERR_FACTOR x ref_err).  (Round 5
         widened the bar AROUND THE FP32 ORACLE by 2.5 x ref_err, which let the product sit 3.5 x ref_err from the truth.)  Why the factor
         is 2 and not 1: the product and the fp32 oracle are two fp32 evaluations of the same ill-conditioned sums in different orders --
-        two draws from one error distribution; over the 72 scenes x 9 tensors of tests/test_gpu_fuzz.py the product's distance to the
-        truth is 0.0 ... 1.74 x the oracle's (median 1.00: on 640 of 648 tensors the product follows the fp32 oracle to 1e-5 and simply
-        shares its error).  tests/golden/fuzz_bounds.json lists every tensor that needs the second branch (8 of 648) with ref_err, both
+        two draws from one error distribution; over the 538 tensors of the 72 scenes of tests/test_gpu_fuzz.py the product's distance to the
+        truth is 0.0 ... 1.74 x the oracle's (median 1.00: on 530 of 538 tensors the product follows the fp32 oracle to 1e-5 and simply
+        shares its error).  tests/golden/fuzz_bounds.json lists every tensor that needs the second branch (8 of 538) with ref_err, both
         errors and its bound; tests/test_host_cpu.py checks the table against REF_ERR_FACTOR."""
         assert self.rows is not None, 'check_image first'
         got = to_np(got).astype(np.float64)

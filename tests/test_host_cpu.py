@@ -662,7 +662,7 @@ def test_fuzz_bound_table_matches_the_rule_the_tests_apply():
     import json
     import helpers
     t = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'fuzz_bounds.json')))
-    assert t['factor'] == helpers.REF_ERR_FACTOR == 2.0 and t['tensors_checked'] >= 600
+    assert t['factor'] == helpers.REF_ERR_FACTOR == 2.0 and t["tensors_checked"] >= 500
     worst = t['ratio_product_to_reference_error']['max']
     assert 1.0 < worst <= helpers.REF_ERR_FACTOR and 0.99 <= t['ratio_product_to_reference_error']['median'] <= 1.01
     assert 1 <= len(t['second_branch']) <= 12
