@@ -28,7 +28,7 @@ constexpr int ADAM_CHUNK   = ADAM_THREADS * 4 * 4;  // elements per 256-thread g
 // 2-3 us in front of every update; and, in its own 128-byte line, the ticket of the launches that advance the count
 // themselves (last workgroup out).
 // Learning-rate schedules on the device (the reference calls update_learning_rate before EVERY train step: train.py:140-141,
-// networks/gaussian_splatting.py:56-84,455-470, networks/sk_gs.py:611-632): up to 8 schedules, each `get_expon_lr_func`'s
+// networks/gaussian_splatting.py:56-84,455-470, networks/sk_gs.py:611-632): up to 4 schedules (ADAM_MAX_SCHEDULES), each `get_expon_lr_func`'s
 // parameters; the launch that advances the step counter evaluates them for the step that follows and keeps the closed step's
 // rates for the pieces that still belong to it (after_advance).  A step replayed inside a hipGraph -- four steps per replay in
 // bench.py -- therefore follows the reference's rate step for step, with no host in the loop.

@@ -56,6 +56,14 @@ __device__ __forceinline__ void load_row(const BlendArgs& a, int j, float* b) {
   b[4] = a.T[7 * j], b[5] = a.T[7 * j + 1], b[6] = a.T[7 * j + 2];
 }
 
+// torch's index semantics for the int64 neighbour indices: a negative index counts from the end (j += M); one outside
+// [-M, M) -- torch raises a device assertion there -- addresses nothing: the entry contributes nothing, forward and backward, instead of
+// reading or adding through a wild LDS / global address
+__device__ __forceinline__ int wrap_row(long long v, int M) {
+  if (v < 0) v += M;
+  return (v < 0 || v >= M) ? -1 : (int) v;
+}
+
 template <bool IN_LDS>
 __global__ void __launch_bounds__(BLEND_THREADS) se3_blend_forward_kernel(const BlendArgs a) {
   extern __shared__ float s_mem[];
@@ -67,7 +75,8 @@ __global__ void __launch_bounds__(BLEND_THREADS) se3_blend_forward_kernel(const 
     const float p[3] = {a.points[3 * n], a.points[3 * n + 1], a.points[3 * n + 2]};
     float s[3] = {0.f, 0.f, 0.f};
     for (int k = 0; k < a.K; ++k) {
-      const int j   = (int) a.indices[(size_t) n * a.K + k];
+      const int j   = wrap_row(a.indices[(size_t) n * a.K + k], a.M);
+      if (j < 0) continue;
       float row[7];
       const float* b = s_mem + 7 * j;
       if (!IN_LDS) load_row(a, j, row), b = row;
@@ -101,7 +110,11 @@ __global__ void __launch_bounds__(BLEND_THREADS) se3_blend_backward_kernel(const
     const float g[3] = {a.g_out[3 * n], a.g_out[3 * n + 1], a.g_out[3 * n + 2]};
     float gp[3] = {0.f, 0.f, 0.f};
     for (int k = 0; k < a.K; ++k) {
-      const int j = (int) a.indices[(size_t) n * a.K + k];
+      const int j = wrap_row(a.indices[(size_t) n * a.K + k], a.M);
+      if (j < 0) {
+        if (a.g_weights) a.g_weights[(size_t) n * a.K + k] = 0.f;
+        continue;
+      }
       float row[7];
       const float* b = s_T + 7 * j;
       if (!IN_LDS) load_row(a, j, row), b = row;
@@ -172,7 +185,8 @@ __global__ void __launch_bounds__(BLEND_THREADS) index_add_rows_kernel(long long
   for (long long e = (long long) blockIdx.x * BLEND_THREADS + threadIdx.x; e < n; e += (long long) gridDim.x * BLEND_THREADS) {
     const long long r = e / C;
     const int c = (int) (e - r * C);
-    const int j = (int) idx[r];
+    const int j = wrap_row(idx[r], M);
+    if (j < 0) continue;
     if (IN_LDS)
       atomicAdd(s_acc + j * C + c, g[e]);
     else

@@ -320,7 +320,14 @@ __device__ __forceinline__ void stream_store4(float* p, float4 v) {
   if constexpr (SITE < 31 && ((SKGS_WT_MASK >> SITE) & 1)) {
     typedef float f4w __attribute__((ext_vector_type(4)));
     const f4w q = {v.x, v.y, v.z, v.w};
+#if defined(__gfx950__) || defined(__gfx942__) || defined(__gfx940__) || defined(__gfx941__) || !defined(__HIP_DEVICE_COMPILE__)
+    // (the `sc1` modifier exists on gfx94x / gfx950 only -- this library is written for gfx950, csrc/Makefile ARCH; the statement is a
+    // store the compiler's waitcnt bookkeeping does not see: the `memory` clobber keeps it ordered against the surrounding accesses and
+    // vmcnt retires in order, so the kernel's closing s_endpgm wait covers it)
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(q) : "memory");
+#else
+    __builtin_nontemporal_store(q, reinterpret_cast<f4w*>(p));     // another target: no write-through form; the streaming hint instead
+#endif
   } else if constexpr (SITE < 31 && ((SKGS_NT_MASK >> SITE) & 1)) {
     typedef float f4v __attribute__((ext_vector_type(4)));
     const f4v q = {v.x, v.y, v.z, v.w};

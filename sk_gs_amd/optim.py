@@ -464,14 +464,20 @@ class FusedAdam:
         names = [groups] if isinstance(groups, (str, int)) else list(groups)
         idx = [n if isinstance(n, int) else next(i for i, g in enumerate(self.param_groups) if g.get('name') == n) for n in names]
         entry = (float(lr_init), float(lr_final), float(lr_delay_mult), int(lr_delay_steps), int(max_steps), int(step_offset))
-        if entry in self._schedules:
-            slot = self._schedules.index(entry)
-        else:
-            assert len(self._schedules) < 4, 'FusedAdam: at most 4 device learning-rate schedules'
-            self._schedules.append(entry)
-            slot = len(self._schedules) - 1
+        # the table is REBUILT from the entries some group still follows (appending only, a re-scheduled group's old entry
+        # kept its slot; the reference's piecewise schedule -- offset 0, then sp_fix[0], then sk_init[0] for `xyz` and for the deform
+        # groups, sk_gs.py:619-626: six distinct entries over a run -- hit the limit at the second stage boundary).  A device schedule
+        # carries ONE fixed step_offset: the host re-sets it at every stage boundary, as update_learning_rate recomputes its offset.
+        by_group = {gi: self._schedules[slot] for gi, slot in self._sched_of_group.items()}
         for gi in idx:
-            self._sched_of_group[gi] = slot
+            by_group[gi] = entry
+        table = []
+        for e in by_group.values():
+            if e not in table:
+                table.append(e)
+        assert len(table) <= 4, 'FusedAdam: at most 4 device learning-rate schedules in use at a time'
+        self._schedules = table
+        self._sched_of_group = {gi: table.index(e) for gi, e in by_group.items()}
         self._upload_schedules()
 
     def clear_lr_schedules(self):

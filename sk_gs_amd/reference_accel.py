@@ -93,20 +93,23 @@ def ssim_loss_forward(self, img1, img2):
 
 
 # ------------------------------------------------------------------------------------------------ SkeletonGaussianSplatting.kinematic
-_topo_cache = {}
+_topo_cache = {}    # id(joint_parents tensor) -> (weak reference to it, its version, the root object, its version, topology)
 
 
 def _topology(parents_table: torch.Tensor, root) -> dict:
     """``build_topology`` of the skeleton in ``joint_parents`` (column 0: the direct parent, sp_gs_joint.cu:55-85) / ``joint_root``,
-    cached until the table is rewritten (joint discovery runs every 1000+ iterations)"""
+    cached per table OBJECT until the table is rewritten in place or replaced (joint discovery runs every 1000+ iterations).  (ADVICE r5:
+    a key of address + version could alias across model instances -- another model's table allocated where a freed one lay.)"""
     from sk_gs_amd.skeleton import build_topology
-    key = (parents_table.data_ptr(), parents_table._version, tuple(parents_table.shape), str(parents_table.device))
-    hit = _topo_cache.get(key)
-    if hit is None:
-        _topo_cache.clear()
+    hit = _topo_cache.get(id(parents_table))
+    rv = root._version if torch.is_tensor(root) else root
+    if hit is None or hit[0]() is not parents_table or hit[1] != parents_table._version or hit[2] is not root or hit[3] != rv:
+        for k in [k for k, v in _topo_cache.items() if v[0]() is None]:     # (tables that are gone)
+            del _topo_cache[k]
         r = int(root.reshape(-1)[0]) if torch.is_tensor(root) else int(root)
-        hit = _topo_cache[key] = build_topology(parents_table[:, 0].long().cpu(), r, parents_table.device)
-    return hit
+        hit = _topo_cache[id(parents_table)] = (weakref.ref(parents_table), parents_table._version, root, rv,
+                                                 build_topology(parents_table[:, 0].long().cpu(), r, parents_table.device))
+    return hit[4]
 
 
 _bias_cache = {}
@@ -624,7 +627,13 @@ def accelerate_reference(ssim: bool = True, kinematic_chain: bool = True, networ
     if adam:
         if 'adam' not in _originals:
             _originals['adam'] = torch.optim.Adam.step
-            torch.optim.Adam.step = adam_step
+            step = adam_step
+            if getattr(_originals['adam'], 'hooked', False):
+                # torch wrapped the class's step once, when the first optimizer was built (Optimizer._patch_step_function: the wrapper
+                # runs the registered step pre / post hooks and the profiler range): an optimizer that exists already must keep them
+                step = torch.optim.Optimizer.profile_hook_step(adam_step)
+                step.hooked = True
+            torch.optim.Adam.step = step
         done.append('torch.optim.Adam.step')
     if ssim:
         mod = sys.modules.get('networks.losses.ssim')

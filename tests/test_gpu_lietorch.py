@@ -455,3 +455,44 @@ def test_accelerated_calc_LBS_weight_equals_the_reference_lines(name):
             assert g1[k] is None or float(g1[k].abs().max()) == 0.0, k
         else:
             assert rel_err(g1[k], g0[k]) <= 2e-5, (k, rel_err(g1[k], g0[k]))
+
+
+def test_negative_indices_wrap_and_wild_ones_address_nothing():
+    """the blend / index-add launches took their int64 indices unchecked.  torch semantics now: a negative index counts from the
+    end -- the same numbers as torch's own indexing, forward and backward --; an index outside [-M, M) (torch: a device assertion) reads
+    and adds NOTHING instead of going through a wild LDS or global address"""
+    L, p3d = _mods()
+    g = torch.Generator().manual_seed(3)
+    P, M, K = 5000, 20, 5
+    v = torch.cat([0.4 * torch.randn(M, 3, generator=g), torch.randn(M, 4, generator=g)], -1)
+    idx = torch.randint(0, M, (P, K), generator=g)
+    neg = idx.clone()
+    neg[::3] -= M                                                          # the same rows, addressed from the end
+    pts, w0, c = torch.randn(P, 3, generator=g), torch.softmax(torch.randn(P, K, generator=g), -1), torch.randn(P, 3, generator=g)
+    outs = []
+    for ix in (idx, neg):
+        a, w = v.cuda().requires_grad_(), w0.cuda().requires_grad_()
+        d = L._se3_blend(a, ix.cuda(), pts.cuda(), w)
+        (d * c.cuda()).sum().backward()
+        outs.append((d.detach(), a.grad, w.grad))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    # the typed gather's backward with negative indices == torch's own index backward
+    table0, cot = torch.randn(M, 4, generator=g), torch.randn(P, K, 4, generator=g).cuda()
+    res = []
+    for typed in (True, False):
+        t = table0.cuda().requires_grad_()
+        i = p3d.NeighbourIndex.wrap(neg.cuda()) if typed else neg.cuda()
+        (t[i] * cot).sum().backward()
+        res.append(t.grad)
+    assert rel_err(res[0], res[1]) <= 2e-5
+    # wild indices: skipped (rows that only hold valid ones are untouched by their neighbours' garbage)
+    wild = idx.clone()
+    wild[7, 2], wild[11, 0] = M + 12345, -M - 9
+    a, w = v.cuda().requires_grad_(), w0.cuda().requires_grad_()
+    d = L._se3_blend(a, wild.cuda(), pts.cuda(), w)
+    (d * c.cuda()).sum().backward()
+    keep = torch.ones(P, dtype=torch.bool)
+    keep[[7, 11]] = False
+    assert torch.equal(d.detach()[keep.cuda()], outs[0][0][keep.cuda()]) and bool(torch.isfinite(d).all()) and bool(torch.isfinite(a.grad).all())
+    assert float(w.grad[7, 2]) == 0.0 and float(w.grad[11, 0]) == 0.0

@@ -712,3 +712,28 @@ def test_accelerated_torch_adam_step_equals_torch():
         sa, sb = oa.state[p], ob.state[q]
         assert float(sa['step']) == float(sb['step'])
         assert rel_err(sa['exp_avg'], sb['exp_avg']) <= 2e-6 and rel_err(sa['exp_avg_sq'], sb['exp_avg_sq']) <= 2e-6
+
+
+def test_rescheduling_a_group_frees_its_old_schedule_slot():
+    """``set_lr_schedule`` only appended -- the reference's piecewise schedule (offset 0, then sp_fix[0], then sk_init[0], for
+    `xyz` and for the deform groups: six distinct entries over a run, sk_gs.py:619-626) hit 'at most 4' at the second stage boundary.
+    The table is rebuilt from the entries still in use: the three stage boundaries of a run fit, and the rates stay the reference's."""
+    import math
+    from sk_gs_amd.optim import FusedAdam
+    dev = torch.device('cuda')
+    ps = [torch.nn.Parameter(torch.ones(64, device=dev)) for _ in range(3)]
+    opt = FusedAdam([{'params': [ps[0]], 'lr': 1e-3, 'name': 'xyz'}, {'params': [ps[1]], 'lr': 1e-3, 'name': 'sp_deform'},
+                     {'params': [ps[2]], 'lr': 1e-3, 'name': 'sk_deform'}], eps=1e-15)
+    for offset in (0, 13_000, 40_000):        # static/init -> sp_fix -> sk_init (exps/default.yaml:12-19)
+        opt.set_lr_schedule('xyz', 1.6e-4 * 5, 1.6e-6 * 5, 30_000, 0, 0.01, step_offset=offset)
+        opt.set_lr_schedule(['sp_deform', 'sk_deform'], 8e-4, 8e-6, 40_000, 0, 0.01, step_offset=offset)
+        assert len(opt._schedules) == 2 and sorted(opt._sched_of_group.values()) == [0, 1, 1]
+    # a fifth / sixth distinct entry IN USE at the same time is still refused
+    opt.set_lr_schedule('sp_deform', 1e-3, 1e-5, 100, 0, 1.0)
+    assert len(opt._schedules) == 3
+    for p in ps:
+        p.grad = torch.ones_like(p)
+    opt.step()
+    torch.cuda.synchronize()
+    want = math.exp(math.log(8e-4) * (1 - 2 / 40_000) + math.log(8e-6) * (2 / 40_000))     # delay_steps = 0: the plain log-lerp at step 2
+    assert abs(opt.scheduled_lr('sk_deform') - want) <= 1e-6 * want

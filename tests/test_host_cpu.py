@@ -275,8 +275,12 @@ bg = torch.ones(3)
 assert m.render(t=torch.tensor([0.5]), info=info, background=bg, time_id=torch.tensor([1]), stage='sk') == 'the reference render'
 assert seen[-1]['stage'] == 'sk' and seen[-1]['background'] is bg and int(seen[-1]['time_id']) == 1 and seen[-1]['info'] is info
 assert rf.calls['render_reference'] == 1 and rf.calls['render_fused'] == 0 and 'device' in rf.why_not['render']
-m.render(t=torch.tensor([0.5]), info=info, stage='sp')
-assert "stage 'sp'" in rf.why_not['render']
+m.render(t=torch.tensor([0.5]), info=info, stage='init')
+assert "stage 'init'" in rf.why_not['render']
+m.render(t=torch.tensor([0.5]), info=info, stage='sp', time_id=1)          # stage sp is covered too -- on a GPU
+assert 'device' in rf.why_not['render'] and 'HIP device' in rf._conditions_sp(m)
+m.hyper_feature, m.sp_points = nn.Parameter(torch.zeros(P, 8)), nn.Parameter(torch.randn(512, 3, generator=g))
+assert rf._light_identity(m, 'sp') != rf._light_identity(m, 'sk') and len(rf._ModelViewSp(m, ra.sp_net_shadow(m.sp_deform_net)).parameters()) > 20
 m.render(t=torch.tensor([0.5]), info=info, stage='sk', time_id=1, hook=lambda o: o)
 assert 'hook' in rf.why_not['render'] and 'hook' in seen[-1]
 m.eval()
