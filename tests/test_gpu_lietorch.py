@@ -475,8 +475,8 @@ def test_negative_indices_wrap_and_wild_ones_address_nothing():
         d = L._se3_blend(a, ix.cuda(), pts.cuda(), w)
         (d * c.cuda()).sum().backward()
         outs.append((d.detach(), a.grad, w.grad))
-    for x, y in zip(*outs):
-        assert torch.equal(x, y)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2])
+    assert rel_err(outs[0][1], outs[1][1]) <= 2e-5           # (the bones' rows are summed by LDS atomics: order-dependent bits)
     # the typed gather's backward with negative indices == torch's own index backward
     table0, cot = torch.randn(M, 4, generator=g), torch.randn(P, K, 4, generator=g).cuda()
     res = []

@@ -724,7 +724,7 @@ def test_rescheduling_a_group_frees_its_old_schedule_slot():
     ps = [torch.nn.Parameter(torch.ones(64, device=dev)) for _ in range(3)]
     opt = FusedAdam([{'params': [ps[0]], 'lr': 1e-3, 'name': 'xyz'}, {'params': [ps[1]], 'lr': 1e-3, 'name': 'sp_deform'},
                      {'params': [ps[2]], 'lr': 1e-3, 'name': 'sk_deform'}], eps=1e-15)
-    for offset in (0, 13_000, 40_000):        # static/init -> sp_fix -> sk_init (exps/default.yaml:12-19)
+    for offset in (40_000, 13_000, 0):        # the three offsets of a run (sk_init, sp_fix, static: exps/default.yaml:12-19), the last one checked below
         opt.set_lr_schedule('xyz', 1.6e-4 * 5, 1.6e-6 * 5, 30_000, 0, 0.01, step_offset=offset)
         opt.set_lr_schedule(['sp_deform', 'sk_deform'], 8e-4, 8e-6, 40_000, 0, 0.01, step_offset=offset)
         assert len(opt._schedules) == 2 and sorted(opt._sched_of_group.values()) == [0, 1, 1]
