@@ -189,6 +189,11 @@ def build_parser():
     ap.add_argument('--keep-order', action='store_true',
                     help='leave the synthetic Gaussians in their random order (default: sorted along a Z-order curve, '
                          'densify.sort_spatially, as after a densification event)')
+    ap.add_argument('--loop-scene', choices=('r5', 'headline'), default='r5',
+                    help="--reference-loop, stage sk: 'r5' = the synthetic scene of round 5's reference-loop lines (head weights of the "
+                         "deform network N(0, s/16): joint rotations of ~0.2 rad along the chain pile the Gaussians up -- R = 0.8 M tile "
+                         "instances, lists of up to 770); 'headline' = the default bench line's scene (heads x 0.01: rotations near identity, "
+                         "Gaussians in Z-order, R = 0.52 M)")
     ap.add_argument('--sp-regularisers', action='store_true',
                     help="--stage sp --reference-loop accelerated|fused: add the two per-Gaussian regularisers the shipped config runs on the "
                          "[P,K] LBS weights in every sp iteration (`sparse`, `smooth`, weight 0.1 each: exps/default.yaml:85-86, "

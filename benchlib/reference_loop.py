@@ -59,6 +59,10 @@ def setup(args, configs):
         M, K = args.superpoints, args.knn
     frames = args.views
     gs, bones = scene.make_gaussians(P, seed=0, sh_degree=3, scale_mult=args.scale_mult), scene.make_bones(M, seed=0)
+    if args.loop_scene == 'headline' and not sp:   # Gaussians in Z-order, as the default line keeps them (densify.sort_spatially)
+        from sk_gs_amd.densify import morton_order
+        order = morton_order(gs['xyz'])
+        gs = {k_: v_[order].contiguous() for k_, v_ in gs.items()}
     table, _ = build_ancestor_table(bones['parents'].long(), 0)
     g = torch.Generator().manual_seed(0)
     par = lambda t: torch.nn.Parameter(t.clone().to(dev))  # noqa: E731
@@ -86,17 +90,23 @@ def setup(args, configs):
             p.pop('_sp_radius'), p.pop('_sp_weight')
         # DeformNetwork's structure and parameter names (sk_gs.py:209-315; pinned by tests/golden/sp_deformnet.npz) + the attributes
         # the accelerator probes on the reference's class
-        net = SpDeformNet()
+        net = SpDeformNet(sep_rot=bool(args.sep_rot))
         net.pos_enc_p, net.pos_enc_t, net.max_d_scale = rs.RefFreqEncoder(3, 10), rs.RefFreqEncoder(1, 6), -1.0
         net = net.to(dev)
         with torch.no_grad():
             net.gaussian_warp.weight.normal_(0, 2e-3), net.gaussian_rotation.weight.normal_(0, 2e-3), net.gaussian_scaling.weight.normal_(0, 2e-5)
+            if args.sep_rot:
+                net.local_rotation.weight.normal_(0, 2e-3)
         ra._originals.setdefault('sp_net', lambda self, x, t, **kw: dict(self.reference_forward(x, t)))
     else:
         net = rs.RefSimpleDeformationNetwork().to(dev)
-        with torch.no_grad():   # (a trained network's output sizes, as the default bench line's model has them)
-            for h, s in zip(net.dynamic_net.last, (0.2, 1e-2, 1e-3)):
-                h.weight.normal_(0, s / 16.)
+        with torch.no_grad():
+            if args.loop_scene == 'headline':   # the default bench line's model: start of the skeleton stage (sk_gs_amd/model.py)
+                for h in net.dynamic_net.last:
+                    h.weight.mul_(0.01), h.bias.zero_()
+            else:                               # (round 5's loop scene: larger joint rotations)
+                for h, s in zip(net.dynamic_net.last, (0.2, 1e-2, 1e-3)):
+                    h.weight.normal_(0, s / 16.)
     if accel and 'adam' not in ra._originals:   # (what accelerate_reference(adam=True) does)
         ra._originals['adam'] = torch.optim.Adam.step
         torch.optim.Adam.step = ra.adam_step
@@ -133,10 +143,12 @@ def setup(args, configs):
 
     def deform_sp(v):
         points = p['_xyz'].detach()
-        if not accel:
+        if not accel or args.warp_method != 'LBS' or args.sep_rot:   # (the per-method fast paths below restate the LBS lines only)
             out = net.reference_forward(p['sp_points'].detach(), times[v])              # the module's own torch forward
             a = dict(p, net_d_xyz=out['d_xyz'], net_d_rotation=out['d_rotation'], net_d_scaling=out['d_scaling'])
-            return rs.sp_stage(L, p3d.knn_points, a, K, 'LBS', False)
+            if args.sep_rot:
+                a['net_g_rotation'] = out['g_rotation']
+            return rs.sp_stage(L, p3d.knn_points, a, K, args.warp_method, bool(args.sep_rot))
         if '_sp_radius' in p:                                                                  # the reference's properties (:548-553)
             me.kernel_radius = torch.exp(p['_sp_radius'])
         if '_sp_weight' in p:
@@ -224,6 +236,7 @@ def setup(args, configs):
         from sk_gs_amd import reference_fused as rf
         if sp:
             model = _RefSuperpointModel(p, net, K)
+            model.warp_method, model.sep_rot = args.warp_method, bool(args.sep_rot)
         else:
             model = _RefSkeletonModel(p, net, table.to(dev).int(), frames, M, K, dev)
         # what a call outside the fused route's conditions reaches: the reference's own render, i.e. the `accelerated` sequence above
@@ -304,7 +317,7 @@ def run(args, configs):
                             "-- with SkeletonGaussianSplatting.render, ImageLoss.forward and SSIM_Loss.forward as accelerate_reference() patches them "
                             "(sk_gs_amd.reference_fused: the package's fused launches on the model's own Parameters, info on the device, "
                             "no host read-back), torch.optim.Adam.step as one launch; eager"),
-                   'loss_last': float(last.detach()), 'sync_num_rendered': bool(_C.config.sync_num_rendered), 'accelerators': dict(ra.calls) if accel else None,
+                   'loop_scene': args.loop_scene, 'loss_last': float(last.detach()), 'sync_num_rendered': bool(_C.config.sync_num_rendered), 'accelerators': dict(ra.calls) if accel else None,
                    'lie_fused_calls': dict(L.fused_calls), 'knn_hip_calls': dict(p3d.hip_calls),
                    'fused_route': None if rf is None else dict(calls=dict(rf.calls), why_not=dict(rf.why_not),
                                                                 status=_route_status(rf, model))},
@@ -336,7 +349,8 @@ class _RefSuperpointModel:
         for k_ in ('_xyz', '_features_dc', '_features_rest', '_scaling', '_rotation', '_opacity', 'sp_points', 'hyper_feature', 'sp_hyper_feature'):
             setattr(self, k_, p[k_])
         self.sp_W, self._sp_radius, self._sp_weight = p.get('sp_W'), p.get('_sp_radius'), p.get('_sp_weight')
-        self.LBS_method = 'W' if self.sp_W is not None else ('weighted_kernel' if self._sp_weight is not None else 'kernel')
+        self.LBS_method = 'W' if self.sp_W is not None else ('weighted_kernel' if self._sp_weight is not None else
+                                                              'kernel' if self._sp_radius is not None else 'dist')
         self.sp_deform_net, self.num_knn = net, K
         self._active_sh_degree = torch.tensor(3, dtype=torch.int, device=p['_xyz'].device)
         self.sp_weights = self.sp_knn = None

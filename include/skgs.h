@@ -134,6 +134,10 @@ typedef struct skgs_raster_inputs {
                                * stays valid -- nothing it baked in (pointers, grids, P) moved */
   const skgs_knn_deform_job* deform_job; /* NULL, or (forward only): means3D / scales / rotations / opacity are not read but
                                * COMPUTED by the per-Gaussian launch from this job and written there (see the struct) */
+  int32_t tiles_per_gaussian_hint; /* 0 = unknown; > 0 = about how many tiles a Gaussian touches (R / P of a recent forward, with
+                               * head room): the scatter launch chooses its lanes per Gaussian from it instead of from the CAPACITY
+                               * of the tile lists (a bucket layout sized for one long list has many slots per Gaussian and few
+                               * tiles per Gaussian: 8 lanes cost that launch 27 us where 4 take 16) */
 } skgs_raster_inputs;
 
 typedef struct skgs_raster_buffers {

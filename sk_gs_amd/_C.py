@@ -48,7 +48,7 @@ class _RasterInputs(C.Structure):
         ('cov3D_precomp', C.c_void_p), ('sh_rest', C.c_void_p), ('background', C.c_void_p),
         ('tile_bucket_capacity', C.c_int32), ('tanfov_device', C.c_void_p),
         ('host_status_words', C.c_int32), ('longest_list_hint', C.c_int32), ('live_count', C.c_void_p),
-        ('deform_job', C.POINTER(_KnnDeformJob)),
+        ('deform_job', C.POINTER(_KnnDeformJob)), ('tiles_per_gaussian_hint', C.c_int32),
     ]
 
 

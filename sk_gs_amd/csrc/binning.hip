@@ -611,13 +611,14 @@ int launch_scan_tiles(GeomView g, ImgView im, int64_t P, hipStream_t s) {
 // the average number of tiles a Gaussian touches.  Measured (scatter launch, config #1 / #3 / #4): 21.7 / 42.0 / 65.1 us with 16
 // lanes, 16.1 / 27.2 / 42.7 with 4 (2: the same, 1: 20.2 at #1); dense scenes (x4 scales, 38 tiles per Gaussian) do not care.
 // SKGS_SCATTER_LPG overrides (4 / 8 / 16).
-static int scatter_lanes(int P, int T, int bucket, int64_t capacity) {
+static int scatter_lanes(int P, int T, int bucket, int64_t capacity, int hint) {
   static const int forced = [] {
     const char* e = getenv("SKGS_SCATTER_LPG");
     return e ? atoi(e) : 0;
   }();
   if (forced == 4 || forced == 8 || forced == 16) return forced;
-  const double slots_per_gaussian = (bucket > 0 ? (double) T * bucket : (double) capacity) / (double) (P > 0 ? P : 1);
+  // (the caller's measurement of tiles per Gaussian, if it has one: skgs_raster_inputs.tiles_per_gaussian_hint)
+  const double slots_per_gaussian = hint > 0 ? (double) hint : (bucket > 0 ? (double) T * bucket : (double) capacity) / (double) (P > 0 ? P : 1);
   return slots_per_gaussian <= 24.0 ? 4 : slots_per_gaussian <= 64.0 ? 8 : 16;
 }
 
@@ -634,7 +635,7 @@ int launch_scatter_sort(const skgs_raster_inputs& in, GeomView g, ImgView im, Bi
 #define SKGS_SCATTER(L)                                                                                                   \
   hipLaunchKernelGGL(scatter_lds_kernel<L>, dim3(bin_groups()), dim3(BIN_THREADS), (size_t) im.T * 8, s, P, im.tiles_x, \
       im.tiles_y, im.T, g.recs, im.tile_offsets, im.cursors, b.keys, b.capacity, g.hdr, bucket)
-      switch (scatter_lanes(P, im.T, bucket, b.capacity)) {
+      switch (scatter_lanes(P, im.T, bucket, b.capacity, in.tiles_per_gaussian_hint)) {
         case 4: SKGS_SCATTER(4); break;
         case 8: SKGS_SCATTER(8); break;
         default: SKGS_SCATTER(16); break;

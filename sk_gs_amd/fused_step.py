@@ -289,6 +289,7 @@ class FusedViewStep:
         a.sh, a.sh_rest = m._features_dc.data_ptr(), m._features_rest.data_ptr()
         a.background = None if self.background is None else self.background.data_ptr()
         a.tile_bucket_capacity = self.tile_bucket
+        a.tiles_per_gaussian_hint = int(getattr(self, 'tiles_per_gaussian_hint', 0))
         a.live_count = None if self._live is None else self._live.data_ptr()
         return a
 

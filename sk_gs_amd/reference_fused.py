@@ -217,8 +217,8 @@ def _conditions_sp(ref):
         return 'use_official_gaussians_render is off (the in-tree rasterizer convention: operator path)'
     if getattr(ref, 'convert_SHs_python', False) or getattr(ref, 'compute_cov3D', False):
         return 'convert_SHs_python / compute_cov3D'
-    if getattr(ref, 'warp_method', None) not in ('LBS', 'LBS_c'):
-        return f'warp_method {getattr(ref, "warp_method", None)!r} (the fused route covers LBS and LBS_c)'
+    if getattr(ref, 'warp_method', None) not in ('LBS', 'LBS_c', 'largest'):
+        return f'warp_method {getattr(ref, "warp_method", None)!r}'
     if getattr(ref, 'LBS_method', None) not in ('W', 'dist', 'kernel', 'weighted_kernel'):
         return 'LBS_method'
     ps = [ref._xyz, ref._features_dc, ref._features_rest, ref._scaling, ref._rotation, ref._opacity, ref.sp_points] + \
@@ -363,6 +363,11 @@ class FusedReferenceRoute:
         want = self._bucket_for(longest)
         have = self._bucket
         self.longest, self.num_rendered = longest, R
+        hint = max(1, int(1.5 * R / max(self.view.P, 1) + 0.999))       # tiles a Gaussian touches, with head room: the scatter launch's lanes
+        lanes = lambda h: 4 if h <= 24 else 8 if h <= 64 else 16           # noqa: E731  (csrc/binning.hip::scatter_lanes)
+        old = getattr(self.step, 'tiles_per_gaussian_hint', 0)
+        if old == 0 or lanes(old) != lanes(hint):
+            self.step.tiles_per_gaussian_hint, self.graphs = hint, None
         if want == have or (want < have and want > 512 and want > 0.75 * have):
             return
         st = self.step
@@ -499,6 +504,9 @@ class FusedReferenceRoute:
                 out['_sp_rot'] = st.net.d_rot.unsqueeze(0)
             # calc_LBS_weight's side effect while the skeleton is not initialised (sk_gs.py:771-773): the stage's latest weights
             ref.sp_weights, ref.sp_knn = st.weights, st.indices
+            if self.view.warp_method == 'largest':   # sp_stage's own side effect while training (:849-850): the superpoint each Gaussian follows
+                with torch.no_grad():
+                    ref.p2sp = torch.gather(st.indices, -1, st.weights.argmax(dim=-1, keepdim=True))[:, 0]
         out['images'] = image.permute(1, 2, 0).unsqueeze(0)                  # [1,H,W,3]: torch.permute(images, (1, 2, 0)) stacked (:1229,1240)
         out['viewspace_points'] = [self.vp]
         out['radii'] = st.radii.unsqueeze(0)

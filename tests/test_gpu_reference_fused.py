@@ -262,3 +262,45 @@ def test_stage_sp_training_follows_the_reference_sequence():
             _teardown(s)
     for a, b in zip(runs['accelerated'], runs['fused']):
         assert abs(a - b) <= 2e-3 * abs(a), runs
+
+
+@pytest.mark.parametrize('warp,sep,lbs', [('LBS_c', True, 'weighted_kernel'), ('largest', False, 'W'), ('LBS_c', False, 'dist')])
+def test_stage_sp_variants_against_the_reference_sequence(warp, sep, lbs):
+    """the shipped combinations of stage sp through the fused route -- SC-GS (`weighted_kernel`, `LBS_c`, `sep_rot`: exps/d_nerf_sc_gs.yaml)
+    and SP-GS (`W`, `largest`: d_nerf_sp_gs.yaml; the route also performs sp_stage's `p2sp` side effect, sk_gs.py:849-850) -- against the
+    reference's own sequence on the stand-ins (ref_sequence.sp_stage, pinned by tests/golden/sk_stage.npz): forward values, the loss and
+    every parameter's gradient, `sp_points` included where the re-centring of LBS_c reaches it"""
+    extra = ('--warp-method', warp, '--lbs-method', lbs) + (('--sep-rot',) if sep else ())
+    s = _setup_sp('fused', extra)
+    try:
+        rf, v = s.rf, 2
+        names = dict(s.p)
+        names.update({f'net.{n}': q for n, q in s.net.named_parameters()})
+        for q in names.values():
+            q.grad = None
+        res = s.deform(v)
+        loss_ref = s.loss_of(s.render(v, res), s.targets[v])
+        loss_ref.backward()
+        want = {n: (None if q.grad is None else q.grad.detach().clone()) for n, q in names.items()}
+        for q in names.values():
+            q.grad = None
+        out = rf.render(s.model, t=s.times[v], info=s.infos[v], background=s.bg, time_id=s.time_ids[v], stage='sp')
+        assert rf.calls['render_fused'] == 1, rf.why_not
+        assert ('_sp_rot' in out) == sep
+        if sep:
+            assert float((out['_sp_rot'][0] - res['_sp_rot']).abs().max()) <= 1e-6
+        if warp == 'largest':
+            assert torch.equal(s.model.p2sp, res['p2sp'])
+        assert float((out['_spT'][0] - res['_spT']).abs().max()) <= 2e-6 and float((out['points'][0] - res['points']).abs().max()) <= 2e-5
+        loss = sum(s.model_loss(out, s.targets_hwc[v]).values())
+        assert abs(float(loss) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref))
+        loss.backward()
+        for n, q in names.items():
+            if want[n] is None or float(want[n].abs().max()) == 0.0:
+                assert q.grad is None or float(q.grad.abs().max()) == 0.0, n
+                continue
+            assert q.grad is not None, n
+            scale = float(want[n].abs().max())
+            assert float((q.grad - want[n]).abs().max()) <= 3e-4 * scale + 1e-12, (n, float((q.grad - want[n]).abs().max()), scale)
+    finally:
+        _teardown(s)
