@@ -9,7 +9,7 @@ for f in $src/bench_*.json; do
   b=$(basename "$f" .json); b=${b//--/_}; b=${b// /_}
   [ -s "$f" ] && cp "$f" "profiles/${tag}_${b}.json"
 done
-for f in gpu_tests.txt gpu_tests_rc.txt gpu_tests_exit.txt parity_observed.json time_densify.txt time_mlp.txt time_skeleton.txt time_loss.txt valu_issue_rate.txt time_sp_net.txt mfma4x4_layer.txt time_reference_sequence.txt round_latency_sweep.txt ppl_sweep.txt; do
+for f in gpu_tests.txt gpu_tests_rc.txt gpu_tests_exit.txt parity_observed.json time_densify.txt time_mlp.txt time_skeleton.txt time_loss.txt valu_issue_rate.txt time_sp_net.txt mfma4x4_layer.txt time_reference_sequence.txt round_latency_sweep.txt ppl_sweep.txt phase_times_reference_loop.txt find_host_spikes.txt preprocess_chain_sweep.txt; do
   [ -s "$src/$f" ] && cp "$src/$f" "profiles/${tag}_$f"
 done
 d=gpurun_out/${tag}_sp   # stage sp: kernel stats + the counters' table (its own file: pmc_render_backward.json stays config #1 / stage sk)

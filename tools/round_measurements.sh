@@ -72,14 +72,29 @@ for p in sc_gs sp_gs; do
   python bench.py --stage sp --preset $p --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_stage_sp_preset_$p.json
   python -c "import json; d=json.load(open('$out/bench_stage_sp_preset_$p.json')); print('stage sp preset $p', d['value'], d['ms_per_step'])"
 done
-for m in hooks accelerated; do
-  timeout -k 5 300 python bench.py --reference-loop $m --steps 100 --warmup 10 2>/dev/null | tail -1 > $out/bench_reference-loop_$m.json
+for m in hooks accelerated fused; do
+  timeout -k 5 300 python bench.py --reference-loop $m --steps 200 --warmup 10 2>/dev/null | tail -1 > $out/bench_reference-loop_$m.json
   python -c "import json; d=json.load(open('$out/bench_reference-loop_$m.json')); print('reference loop, $m', d['value'], d['ms_per_step'], d['config']['loss_last'])"
 done
-for m in hooks accelerated; do
-  timeout -k 5 300 python bench.py --stage sp --reference-loop $m --steps 100 --warmup 10 2>/dev/null | tail -1 > $out/bench_stage_sp_reference-loop_$m.json
+for m in hooks accelerated fused; do
+  timeout -k 5 300 python bench.py --stage sp --reference-loop $m --steps 200 --warmup 10 2>/dev/null | tail -1 > $out/bench_stage_sp_reference-loop_$m.json
   python -c "import json; d=json.load(open('$out/bench_stage_sp_reference-loop_$m.json')); print('reference loop, stage sp, $m', d['value'], d['ms_per_step'], d['config']['loss_last'])"
 done
+# round 6: the fused route (sk_gs_amd/reference_fused.py) on the default line's scene, unprimed, with eager launches instead of graphs, stage sp
+# with the W weighting (dense logit table under torch's Adam) and with the shipped weight regularisers (torch ops of the reference)
+for v in "accelerated --loop-scene headline" "fused --loop-scene headline" "fused --prime-steps 0"; do set -- $v; m=$1; shift
+  timeout -k 5 300 python bench.py --reference-loop $m "$@" --steps 200 --warmup 10 2>/dev/null | tail -1 > "$out/bench_reference-loop_${m}_${2:-x}${3:-}.json"
+  python -c "import json; d=json.load(open('$out/bench_reference-loop_${m}_${2:-x}${3:-}.json')); print('reference loop, $v', d['value'], d['ms_per_step'], d['config']['loss_last'])"
+done
+SKGS_REF_FUSED_GRAPHS=0 timeout -k 5 300 python bench.py --reference-loop fused --steps 200 --warmup 10 2>/dev/null | tail -1 > $out/bench_reference-loop_fused_eager-launches.json
+python -c "import json; d=json.load(open('$out/bench_reference-loop_fused_eager-launches.json')); print('reference loop, fused, SKGS_REF_FUSED_GRAPHS=0', d['value'], d['ms_per_step'])"
+for v in "fused --lbs-method W" "accelerated --sp-regularisers" "fused --sp-regularisers"; do set -- $v; m=$1; shift
+  timeout -k 5 300 python bench.py --stage sp --reference-loop $m "$@" --steps 100 --warmup 10 2>/dev/null | tail -1 > "$out/bench_stage_sp_reference-loop_${m}_${1#--}${2:-}.json"
+  python -c "import json; d=json.load(open('$out/bench_stage_sp_reference-loop_${m}_${1#--}${2:-}.json')); print('reference loop, stage sp, $v', d['value'], d['ms_per_step'], d['config']['loss_last'])"
+done
+timeout -k 5 200 python tools/phase_times_reference_loop.py 2>/dev/null | tail -1 > $out/phase_times_reference_loop.txt; cat $out/phase_times_reference_loop.txt
+timeout -k 5 200 python tools/find_host_spikes.py 2>/dev/null | tail -4 > $out/find_host_spikes.txt; cat $out/find_host_spikes.txt
+timeout -k 5 300 python tools/preprocess_chain_sweep.py 2>/dev/null | grep -v amdgpu > $out/preprocess_chain_sweep.txt; cat $out/preprocess_chain_sweep.txt
 timeout -k 5 200 python tools/time_reference_sequence.py 2>/dev/null | grep -v "not capturable" > $out/time_reference_sequence.txt; cat $out/time_reference_sequence.txt
 timeout -k 5 300 python tools/round_latency_sweep.py 2>/dev/null | grep -v amdgpu > $out/round_latency_sweep.txt; cat $out/round_latency_sweep.txt
 timeout -k 5 300 python tools/ppl_sweep.py 2>/dev/null | grep ppl > $out/ppl_sweep.txt; cat $out/ppl_sweep.txt
