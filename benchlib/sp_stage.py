@@ -285,8 +285,8 @@ def run(args, base_alg_bytes, configs):
     from benchlib.roofline import committed_counter_profile
     from_profile = committed_counter_profile(cfg['name'] + ', stage sp', 'pmc_render_backward_sp.json')
     return {
-        'metric': f'train iters/sec, SUPERPOINT stage (sp net + 3+8-d search + skinning + rasterize fwd+bwd + L1/SSIM loss + Adam), '
-                  f'{P // 1000}k Gaussians @{W}x{H}',
+        'metric': f'train iters/sec, SUPERPOINT stage (sp net + 3+8-d search + skinning + rasterize fwd+bwd + L1/SSIM loss + Adam; image '
+                  f'loss only: the shipped `sparse` / `smooth` weight regularisers are not included), {P // 1000}k Gaussians @{W}x{H}',
         'value': round(world * args.steps / elapsed, 3), 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'prime_steps': args.prime_steps, 'steps_per_graph': n_multi if train_chunk is not None else 1,
         'ms_per_step': round(ms_step, 4), 'ms_per_step_blocks': block_stats, 'higher_is_better': True,
@@ -295,7 +295,12 @@ def run(args, base_alg_bytes, configs):
                                f'dimensions, LBS_method {args.lbs_method}, warp_method {args.warp_method}, sep_rot {bool(args.sep_rot)}, '
                                f'sp_deform_net 8x256 on {M} rows' + (' (is_blender=False: raw time encoding of degree 10, time noise 0.01)' if args.raw_time else '') + f', SH degree 3, {W}x{H}, '
                                f'{args.views} synthetic views, 1 view per rank per step',
-                   'stage': 'sp', 'num_rendered_mean': round(R_mean), 'num_rendered_max': R_max,
+                   'stage': 'sp',
+                   'loss': 'image terms only (0.8 L1 + 0.2 (1 - SSIM)): the shipped sp configuration also runs two regularisers on the [P,K] LBS '
+                           'weights in every iteration (sparse, smooth, weight 0.1 each: exps/default.yaml:85-86, sk_gs.py:1339-1359,1572-1574) '
+                           '-- the reference\'s own torch code, SURVEY 2 out of scope; `--stage sp --reference-loop fused --sp-regularisers` times '
+                           'the iteration with them',
+                   'num_rendered_mean': round(R_mean), 'num_rendered_max': R_max,
                    'tile_list_mean': round(R_mean / T, 1), 'tile_list_max': longest,
                    'walked_pairs_mean': round(sum(walked) / len(walked)),
                    'parallelism': f'view-parallel x{world}, flat-buffer grad all-reduce ({vp.grads.nbytes / 1e6:.1f} MB)',
