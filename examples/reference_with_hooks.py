@@ -11,12 +11,14 @@ What happens, in this order (INTEGRATION.md sections 1-4):
   2. `import train` -- the reference's module, from the given checkout.
   3. (unless --no-accelerate) a post-import hook has applied `sk_gs_amd.accelerate_reference()` by then: seven pieces of the training
      step that are long chains of small torch launches get a fast path with the same arguments and results (loss, kinematic chain, LBS weights, both
-     deform networks, the rasterizer adapter's swizzle, `torch.optim.Adam.step`).
+     deform networks, the rasterizer adapter's swizzle, `torch.optim.Adam.step`) -- and (round 6) `SkeletonGaussianSplatting.render` +
+     `ImageLoss.forward` + `SSIM_Loss.forward` route stages `sk` and `sp` into the package's whole fused step on the model's own parameters
+     (sk_gs_amd/reference_fused.py; every call outside its conditions runs the reference's own `render`).
   4. `train.GaussianTrainTask().run()` -- the reference's own entry point (train.py:381-382) with the arguments behind `--`.
 
 `--check`: stop after step 3 and print what was hooked and patched (no GPU needed: what tests/test_host_cpu.py runs in the build container).
-The whole iteration restated on the same hooks is timed by `bench.py --reference-loop hooks | accelerated` (129 -> 503 it/s at config #1;
-the reference's own speed note, train.py:383-389, has 1000 steps in 15-24 s).
+The whole iteration restated on the same hooks is timed by `bench.py --reference-loop hooks | accelerated | fused` (133 -> 514 -> 2 003 it/s
+at config #1; the reference's own speed note, train.py:383-389, has 1000 steps in 15-24 s).
 """
 import os
 import sys

@@ -23,12 +23,16 @@ bone-moment finalize | skeleton backward) behind those two methods, on the model
   copy slower.
 
 Conditions of the fast path (anything else runs the reference's own ``render``; ``calls`` counts both and ``why_not`` keeps the last
-reason): stage ``sk``; training with grad enabled; ONE view; ``t`` / ``time_id`` / ``info`` tensors on the HIP device; no ``hook`` and no
-extra keyword; ``use_official_gaussians_render`` (the shipped configs), no ``convert_SHs_python`` / ``compute_cov3D``; the skeleton is
-initialised; ``LBS_method == 'W'`` with ``sp_W`` [P, M] over the M <= 48 joints, ``num_knn`` <= 8; quaternion rotations, no
-``sk_feature``; a ``SimpleDeformationNetwork`` the one-launch kernels cover (width 256, frequency encoders); a background of <= 3 values.
-The three head matrices of the network (``dynamic_net.last``) are RE-HOMED into one contiguous matrix (their ``.data`` become row
-views of it -- same Parameter objects, same values): the kernels read and train them in place.
+reason): stage ``sk`` or ``sp``; training with grad enabled; ONE view; ``t`` / ``time_id`` / ``info`` tensors on the HIP device; no ``hook``
+(other keywords are ignored, as the reference's ``render`` ignores them); ``use_official_gaussians_render`` (the shipped configs), no
+``convert_SHs_python`` / ``compute_cov3D``; a background of <= 3 values.  Stage ``sk``: the skeleton is initialised; ``LBS_method == 'W'``
+with ``sp_W`` [P, M] over the M <= 48 joints, ``num_knn`` <= 8; quaternion rotations, no ``sk_feature``; a ``SimpleDeformationNetwork`` the
+one-launch kernels cover (width 256, frequency encoders) -- its three head matrices (``dynamic_net.last``) are RE-HOMED into one contiguous
+matrix (their ``.data`` become row views of it: same Parameter objects, same values; the kernels read and train them in place).  Stage
+``sp`` (``FusedSuperpointStep``): 60 < M <= 1024 superpoints, ``num_knn`` <= 8, 0 or 8 hyper dimensions, any of the four weightings,
+``warp_method`` LBS / LBS_c / largest, ``sep_rot`` either way, ``is_blender=True``; ``outputs['_knn_w']`` and ``outputs['_spT']`` are outputs
+of the node too -- the shipped ``sparse`` / ``smooth`` regularisers and the joint losses differentiate them (sk_gs.py:1555-1574) -- and their
+cotangents enter the backward half (``skgs_sp_skinning_job.g_weights_extra``; ``g_bone_T`` before the network's backward).
 
 The forward half and the backward half are ONE hipGraph replay each (``SKGS_REF_FUSED_GRAPHS=0``: the same launches issued one by one);
 per call the host still issues the slot fill, the target's layout copy and the two loss launches.  Nothing blocks on the device per
@@ -774,8 +778,9 @@ def _route_for(self, stage, t, info, background, time_id, scale_modifier, args, 
         return None, f'stage {stage!r} (the fused route covers sk and sp)'
     if not (self.training and torch.is_grad_enabled()):
         return None, 'not training / grad disabled'
-    if args or kwargs:
-        return None, f'extra arguments {list(kwargs) or "positional"}'
+    if 'hook' in kwargs:      # (the only keyword the reference's render reads besides its named ones, sk_gs.py:1222-1223: it edits the
+        return None, 'a hook on the network outputs'      # per-Gaussian tensors the fused kernels never materialise; other keywords --
+                                                           # rays_o / rays_d of a loader with rays -- are ignored there and here)
     if t is None or time_id is None or not torch.is_tensor(t) or not t.is_cuda or t.numel() != 1:
         return None, 't / time_id: one frame of the training set on the device'
     if torch.is_tensor(time_id) and time_id.numel() != 1:
