@@ -304,3 +304,27 @@ def test_stage_sp_variants_against_the_reference_sequence(warp, sep, lbs):
             assert float((q.grad - want[n]).abs().max()) <= 3e-4 * scale + 1e-12, (n, float((q.grad - want[n]).abs().max()), scale)
     finally:
         _teardown(s)
+
+
+def test_arguments_as_a_collating_loader_hands_them_over_stay_on_the_route():
+    """train.py:179-191: `inputs` / `infos` come out of a DataLoader's collation and `tensor_to(device)` -- a leading batch dimension on every
+    tensor, `info['size']` as two one-element DEVICE tensors, a one-value background, and (loaders with rays) `rays_o` / `rays_d` keywords the
+    reference's render ignores: all of that stays on the fused route and renders the same image; a `hook` keyword does not"""
+    s = _setup('fused')
+    try:
+        rf, v = s.rf, 0
+        plain = rf.render(s.model, t=s.times[v], info=s.infos[v], background=s.bg, time_id=s.time_ids[v])['images'].detach().clone()
+        info = {k: (x[None] if torch.is_tensor(x) else x) for k, x in s.infos[v].items()}
+        info['size'] = [torch.tensor([s.W]).cuda(), torch.tensor([s.H]).cuda()]
+        out = rf.render(s.model, t=s.times[v].view(1, 1), info=info, background=torch.ones(1, device='cuda'), time_id=s.time_ids[v].view(1),
+                        rays_o=torch.zeros(1, 4, 3), rays_d=torch.zeros(1, 4, 3))
+        assert rf.calls['render_fused'] == 2 and rf.calls['render_reference'] == 0, rf.why_not
+        assert torch.equal(out['images'].detach(), plain)
+        seen = []
+        keep = s.ra._originals['render']
+        s.ra._originals['render'] = lambda self, *a, **kw: seen.append(kw) or 'reference'
+        assert rf.render(s.model, t=s.times[v], info=s.infos[v], background=s.bg, time_id=s.time_ids[v], hook=lambda o: o) == 'reference'
+        assert 'hook' in seen[0] and 'hook' in rf.why_not['render']
+        s.ra._originals['render'] = keep
+    finally:
+        _teardown(s)
