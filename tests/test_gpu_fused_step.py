@@ -666,7 +666,9 @@ def test_deform_as_a_job_of_the_per_gaussian_launch_is_bit_identical(P, M, K, W,
         if k.startswith('g_') and v.numel() < 10000:  # per-bone sums are atomics: order, not bits
             assert rel_err(got[True][k], v) < 1e-5, k
         elif k.startswith('g_'):
-            assert_close_robust(got[True][k], v, 1e-6, 1e-5, name=k)
+            # (two evaluations of the same sums in two atomic orders: 5e-6, not 1e-6 -- one session in ~10 saw 1e-4 of g__rotation's
+            # elements between 1.0e-6 and 1.4e-6 apart, profiles/r06_g_gpu_tests_rc.txt run 2)
+            assert_close_robust(got[True][k], v, 5e-6, 1e-5, name=k)
         else:
             assert torch.equal(got[True][k], v), k
 
