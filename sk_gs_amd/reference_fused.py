@@ -269,21 +269,23 @@ class FusedReferenceRoute:
             self.shadow = ra.sp_net_shadow(ref.sp_deform_net)
             self.view = _ModelViewSp(ref, self.shadow)
         saved = {p: p.grad for p in self.view.parameters()}
-        for p in saved:
-            p.grad = None
-        self.step = self._build_step(64)
-        self.grads = {p: p.grad for p in self.view.parameters()}            # persistent: the kernels' write targets
         stores = ()
-        if stage == 'sk':
-            net, heads = shadow.dynamic_net, ref.sk_deform_net.dynamic_net.last
-            for h, o in zip(heads, shadow._heads_rehomed):                   # the heads' gradients: row views of the head matrix's
-                oc = h.weight.shape[0]
-                self.grads[h.weight], self.grads[h.bias] = net.last_weight.grad[o:o + oc], net.last_bias.grad[o:o + oc]
-            stores = (net.last_weight, net.last_bias)
-        for p, g in saved.items():
-            p.grad = g
-        for p in stores:
-            p.grad = None
+        try:        # (the step's constructor builds zeroed gradient tensors for parameters that have none: those become the persistent ones)
+            for p in saved:
+                p.grad = None
+            self.step = self._build_step(64)
+            self.grads = {p: p.grad for p in self.view.parameters()}        # persistent: the kernels' write targets
+            if stage == 'sk':
+                net, heads = shadow.dynamic_net, ref.sk_deform_net.dynamic_net.last
+                for h, o in zip(heads, shadow._heads_rehomed):               # the heads' gradients: row views of the head matrix's
+                    oc = h.weight.shape[0]
+                    self.grads[h.weight], self.grads[h.bias] = net.last_weight.grad[o:o + oc], net.last_bias.grad[o:o + oc]
+                stores = (net.last_weight, net.last_bias)
+        finally:    # whatever the caller's gradients were, they are back
+            for p, g in saved.items():
+                p.grad = g
+            for p in stores:
+                p.grad = None
         self._stores = stores
         net = types.SimpleNamespace(last_weight=stores[0], last_bias=stores[1]) if stores else types.SimpleNamespace(last_weight=None, last_bias=None)
         self.vp = torch.zeros((self.view.P, 3), dtype=torch.float32, device=dev, requires_grad=True)   # outputs['viewspace_points'][0]
