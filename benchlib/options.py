@@ -199,6 +199,9 @@ def build_parser():
                          "[P,K] LBS weights in every sp iteration (`sparse`, `smooth`, weight 0.1 each: exps/default.yaml:85-86, "
                          "sk_gs.py:1339-1359,1572-1574) as the reference writes them (torch); without the flag the loss is the image "
                          "terms only")
+    ap.add_argument('--reg-torch', action='store_true',
+                    help='--sp-regularisers: the two regularisers as the reference writes them in torch (a [P, 21, K] gather and its sort-based '
+                         'index backward) instead of the one-launch kernels accelerate_reference() patches in (csrc/weight_reg.hip)')
     ap.add_argument('--superpoints', type=int, default=512, help='--stage sp: num_superpoints (exps/default.yaml:25)')
     ap.add_argument('--lbs-method', choices=('weighted_kernel', 'kernel', 'dist', 'W'), default='weighted_kernel',
                     help="--stage sp: the weighting of calc_LBS_weight (class default 'weighted_kernel', sk_gs.py:364; "

@@ -213,10 +213,15 @@ def setup(args, configs):
             pts = p['_xyz'].detach()
             gs_knn_index = p3d.knn_points(pts[None], pts[None], None, None, K=21)[1][0].contiguous()      # (pykdtree in the reference, :1348-1353)
 
-    def weight_regularisers(knn_w):     # sk_gs.py:1572-1574 with the weights of exps/default.yaml:85-86
-        w = knn_w
-        sparse = -(w * torch.log(w + 1e-7) + (1 - w) * torch.log(1 - w + 1e-7)).mean()
-        smooth = (w[0][:, None] - w[0][gs_knn_index]).abs().mean()
+    reg_self = types.SimpleNamespace(gs_knn_index=gs_knn_index, update_gs_knn=lambda: None)
+    ra._originals.setdefault('w_sparse', lambda self, w, eps=1e-7: -(w * torch.log(w + eps) + (1 - w) * torch.log(1 - w + eps)).mean())   # sk_gs.py:1339-1340
+    ra._originals.setdefault('w_smooth', lambda self, w: (w[:, None] - w[self.gs_knn_index]).abs().mean())                                # :1357-1359
+
+    def weight_regularisers(knn_w, reference=False):     # sk_gs.py:1572-1574 with the weights of exps/default.yaml:85-86
+        if reference or args.reg_torch:                  # as the reference writes them (torch)
+            sparse, smooth = ra._originals['w_sparse'](reg_self, knn_w), ra._originals['w_smooth'](reg_self, knn_w[0])
+        else:                                            # as accelerate_reference() patches the two methods (one launch each)
+            sparse, smooth = ra.loss_weight_sparsity(reg_self, knn_w), ra.loss_weight_smooth(reg_self, knn_w[0])
         return 0.1 * sparse + 0.1 * smooth
 
     if gs_knn_index is not None and not fused:

@@ -454,6 +454,22 @@ int skgs_image_loss_backward_terms(int32_t C, int32_t H, int32_t W, const float*
     const int32_t* gt_index, const float* grad_l1, const float* grad_ssim, const void* workspace, size_t workspace_bytes,
     float* dL_dpred, skgs_stream_t stream);
 
+/* ---- the two regularisers of stage `sp` on the LBS weights (value + gradient in one launch each) ----
+ * Replace `loss_weight_sparsity` (networks/sk_gs.py:1339-1340: -mean(w log(w + eps) + (1 - w) log(1 - w + eps)) over the n = P K
+ * weights) and `loss_weight_smooth` (:1357-1359: mean |w[i, k] - w[neighbours[i, g], k]| over i < P, g < G, k < K; neighbours [P, G]
+ * int64 = `gs_knn_index`, the reference's 20-neighbour table of the Gaussians incl. the Gaussian itself) as the shipped configuration
+ * runs them on outputs['_knn_w'] in EVERY stage-sp iteration (exps/default.yaml:85-86, sk_gs.py:1572-1574); in torch the second is a
+ * [P, G, K] gather whose backward is a sort-based index_put (~1 ms at P = 1e5).  grad [n] / [P, K]: d value / d w (the caller multiplies
+ * by the incoming cotangent); partials: skgs_weight_reg_partials() floats whose sum is the value (fixed-order partial sums). */
+int32_t skgs_weight_reg_partials(void);
+int skgs_weight_sparsity(int64_t n, const float* weights, float eps, float* grad, float* partials, skgs_stream_t stream);
+/* inverse_offsets [P + 1] / inverse_sources [number of valid (i, g) pairs] (int32, both or neither): for every Gaussian j the Gaussians i
+ * that list it, i.e. the pairs sorted by neighbours[i, g] -- built once per neighbour table (the reference rebuilds gs_knn_index every
+ * 1000-3000 iterations).  With them the launch uses no atomics (the [P,K] table stays in L2); without them the gradient is summed by float
+ * atomics (21 M of them at P = 1e5: 1.2 ms). */
+int skgs_weight_smooth(int32_t P, int32_t K, int32_t G, const float* weights, const int64_t* neighbours, const int32_t* inverse_offsets,
+    const int32_t* inverse_sources, float* grad, float* partials, skgs_stream_t stream);
+
 /* ---- the live view slot from the reference's per-view tensors (no host read-back) ----
  * Replaces the host side of `prepare_inputs` (networks/gaussian_splatting.py:247-300) for one view: the reference builds
  * GaussianRasterizationSettings from `info` with `math.tan(0.5 * FoV[b, 0])` and `info['Tw2v']` on the host -- a blocking

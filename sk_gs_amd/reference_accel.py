@@ -55,7 +55,8 @@ import torch.nn.functional as F
 
 _originals = {}
 calls = {'ssim_fused': 0, 'ssim_reference': 0, 'kinematic_fused': 0, 'kinematic_reference': 0, 'sk_net_fused': 0, 'sk_net_reference': 0,
-         'sp_net_fused': 0, 'sp_net_reference': 0, 'lbs_weight_fused': 0, 'lbs_weight_reference': 0, 'adam_fused': 0, 'adam_reference': 0, 'swizzle_fused': 0}  # counters (tests)
+         'sp_net_fused': 0, 'sp_net_reference': 0, 'lbs_weight_fused': 0, 'lbs_weight_reference': 0, 'adam_fused': 0, 'adam_reference': 0, 'swizzle_fused': 0,
+         'weight_reg_fused': 0, 'weight_reg_reference': 0}  # counters (tests)
 
 
 # ------------------------------------------------------------------------------------------------ SSIM_Loss.forward
@@ -283,6 +284,31 @@ def calc_LBS_weight(self, points, sp_points, feature=None, sp_feature=None, K=No
         self.sp_knn = indices.detach()
     calls['lbs_weight_fused'] += 1
     return weights, indices
+
+
+# ------------------------------------------------------------------------------------------------ the weight regularisers of stage sp
+def loss_weight_sparsity(self, weight, eps=1e-7):
+    """``SkeletonGaussianSplatting.loss_weight_sparsity`` (networks/sk_gs.py:1339-1340) as one launch (``skgs_weight_sparsity``)"""
+    from sk_gs_amd import weight_reg as wr
+    if wr.sparsity_supported(weight) and isinstance(eps, float):
+        calls['weight_reg_fused'] += 1
+        return wr.weight_sparsity(weight, eps)
+    calls['weight_reg_reference'] += 1
+    return _originals['w_sparse'](self, weight, eps)
+
+
+def loss_weight_smooth(self, weight):
+    """``SkeletonGaussianSplatting.loss_weight_smooth`` (networks/sk_gs.py:1357-1359): the reference's own ``update_gs_knn()`` (the
+    neighbour table of the Gaussians, rebuilt by its own schedule), then value and gradient as one launch (``skgs_weight_smooth``)
+    instead of the [P, 21, K] gather and its sort-based index backward"""
+    from sk_gs_amd import weight_reg as wr
+    self.update_gs_knn()
+    nbr = getattr(self, 'gs_knn_index', None)
+    if wr.smooth_supported(weight, nbr):
+        calls['weight_reg_fused'] += 1
+        return wr.weight_smooth(weight, nbr)
+    calls['weight_reg_reference'] += 1
+    return _originals['w_smooth'](self, weight)
 
 
 # ------------------------------------------------------------------------------------------------ render_gs_offical
@@ -609,6 +635,11 @@ def accelerate_reference(ssim: bool = True, kinematic_chain: bool = True, networ
         mod = sys.modules.get('networks.sk_gs')
         if mod is None:
             raise RuntimeError("accelerate_reference(): import the reference first (networks.sk_gs is not loaded)")
+        if 'w_sparse' not in _originals:   # the two regularisers the shipped stage-sp configuration runs on those weights every iteration
+            _originals['w_sparse'], _originals['w_smooth'] = mod.SkeletonGaussianSplatting.loss_weight_sparsity, mod.SkeletonGaussianSplatting.loss_weight_smooth
+            mod.SkeletonGaussianSplatting.loss_weight_sparsity = loss_weight_sparsity
+            mod.SkeletonGaussianSplatting.loss_weight_smooth = loss_weight_smooth
+        done += ['networks.sk_gs.SkeletonGaussianSplatting.loss_weight_sparsity', 'networks.sk_gs.SkeletonGaussianSplatting.loss_weight_smooth']
         if 'lbs_weight' not in _originals:
             _originals['lbs_weight'] = mod.SkeletonGaussianSplatting.calc_LBS_weight
             mod.SkeletonGaussianSplatting.calc_LBS_weight = calc_LBS_weight
@@ -684,3 +715,6 @@ def restore_reference():
                 m.render_gs_offical = orig
     if 'lbs_weight' in _originals and 'networks.sk_gs' in sys.modules:
         sys.modules['networks.sk_gs'].SkeletonGaussianSplatting.calc_LBS_weight = _originals.pop('lbs_weight')
+    if 'w_sparse' in _originals and 'networks.sk_gs' in sys.modules:
+        sys.modules['networks.sk_gs'].SkeletonGaussianSplatting.loss_weight_sparsity = _originals.pop('w_sparse')
+        sys.modules['networks.sk_gs'].SkeletonGaussianSplatting.loss_weight_smooth = _originals.pop('w_smooth')

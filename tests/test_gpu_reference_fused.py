@@ -328,3 +328,30 @@ def test_arguments_as_a_collating_loader_hands_them_over_stay_on_the_route():
         s.ra._originals['render'] = keep
     finally:
         _teardown(s)
+
+
+@pytest.mark.parametrize('P,K,G', [(100_000, 5, 21), (3001, 4, 7), (64, 16, 3), (1, 1, 1)])
+def test_weight_regularisers_as_one_launch_each_equal_the_reference_lines(P, K, G):
+    """skgs_weight_sparsity / skgs_weight_smooth (csrc/weight_reg.hip; sk_gs_amd/weight_reg.py) against the reference's own expressions
+    (sk_gs.py:1339-1340, 1357-1359) in torch: value and gradient, with negative and self indices in the neighbour table"""
+    from sk_gs_amd import weight_reg as wr
+    g = torch.Generator().manual_seed(P + K)
+    w0 = torch.softmax(torch.randn(P, K, generator=g), -1).cuda()
+    nbr = torch.randint(0, P, (P, G), generator=g)
+    nbr[:, 0] = torch.arange(P)                       # the Gaussian itself, as pykdtree returns it first (sk_gs.py:1351)
+    if P > 10:
+        nbr[5, 1] -= P                                # a negative index: counted from the end, as torch does
+    nbr = nbr.cuda()
+    res = []
+    for fused in (True, False):
+        w = w0.clone().requires_grad_()
+        if fused:
+            sparse, smooth = wr.weight_sparsity(w[None], 1e-7), wr.weight_smooth(w, nbr)
+        else:
+            sparse = -(w[None] * torch.log(w[None] + 1e-7) + (1 - w[None]) * torch.log(1 - w[None] + 1e-7)).mean()
+            smooth = (w[:, None] - w[nbr]).abs().mean()
+        (0.3 * sparse + 0.7 * smooth).backward()
+        res.append((float(sparse), float(smooth), w.grad.clone()))
+    (s1, m1, g1), (s0, m0, g0) = res
+    assert abs(s1 - s0) <= 2e-6 * abs(s0) + 1e-9 and abs(m1 - m0) <= 2e-6 * abs(m0) + 1e-9, (s1, s0, m1, m0)
+    assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max()) + 1e-12
