@@ -536,6 +536,14 @@ int skgs_adam_step_range(int32_t n_tensors, const void* tensors, int64_t chunk_b
 int skgs_adam_logit_rows(int32_t P, int32_t M, int32_t K, const float* weights, const int64_t* indices, const float* g_weights,
     const void* tensor, uint32_t* tile_mask, double beta1, double beta2, double eps, const float* step_state, int32_t after_advance,
     skgs_stream_t stream);
+/* The sparse visit for an optimizer that KEEPS the dense gradient (torch.optim.Adam over the reference's own state tensors,
+ * sk_gs_amd/reference_accel.py): the update of skgs_adam_step_range(advance = 0) for the ONE [P, M] tensor `tensor` describes, reading
+ * its dense `grad`, restricted to the 32-column tiles in tile_mask [P] -- which first grows by the tiles of indices [P,K] (NULL / K = 0:
+ * none known) and, with scan_gradient != 0, by every tile that holds a non-zero gradient (one pass over the gradient).  Exact: an
+ * element whose gradient and moments are all zero does not move under Adam.  tile_mask must cover every non-zero moment
+ * (skgs_adam_logit_mask_rebuild when it is first used).  M <= 1024. */
+int skgs_adam_masked_rows(int32_t P, int32_t M, int32_t K, const int64_t* indices, int32_t scan_gradient, const void* tensor,
+    uint32_t* tile_mask, double beta1, double beta2, double eps, const float* step_state, int32_t after_advance, skgs_stream_t stream);
 int skgs_adam_logit_mask_rebuild(int32_t P, int32_t M, const float* exp_avg, const float* exp_avg_sq, uint32_t* tile_mask,
     skgs_stream_t stream);
 /* The closing piece of a step (it advances the counter) whose range holds a tensor with an unfinished gradient: the

@@ -298,6 +298,54 @@ __global__ void __launch_bounds__(256) adam_logit_rows_batched_kernel(int P, int
     }
   }
 }
+// The same sparse visit for an optimizer that is NOT this package's: the dense gradient EXISTS (torch's autograd built it, or
+// skgs_lbs_weights_backward wrote it) and is what the update reads -- the rule that makes skipping exact is the same: an element whose
+// gradient and both moments are zero does not move.  tile_mask[row] grows by the tiles of `indices` [P,K] (the caller's knowledge of where
+// this step's gradient can be non-zero; may be NULL) and, with `scan`, by every tile of the row that holds a non-zero gradient (one pass
+// over the dense gradient: for a step in which something else than the known neighbours may have written to it).  Inside a live tile every
+// element takes adam_update_element -- the dense launch's arithmetic: bit-identical parameters and moments.
+__global__ void __launch_bounds__(256) adam_masked_rows_kernel(int P, int M, int K, const int64_t* __restrict__ indices, int scan,
+    const AdamTensor* __restrict__ desc, uint32_t* __restrict__ tile_mask, double beta1d, double beta2d, float eps,
+    const AdamState* __restrict__ state, int after_advance) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, e = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), n_waves = gridDim.x * 4;
+  const AdamCoef k = adam_coefficients(beta1d, beta2d, eps, state, after_advance != 0);
+  const AdamTensor T    = desc[0];
+  const float step_size = adam_lr(T, k) / k.bc1;
+  for (int n = wave; n < P; n += n_waves) {
+    uint32_t touched = 0u;
+    if (indices)
+      for (int q = 0; q < K; ++q) {
+        const long long j = indices[(size_t) n * K + q];
+        if (j >= 0 && j < M) touched |= 1u << ((int) j / LOGIT_TILE);
+      }
+    if (scan)
+      for (int j0 = 0; j0 < M; j0 += 64) {
+        const int j = j0 + lane;
+        const unsigned long long b = __ballot(j < M && T.grad[(size_t) n * M + j] != 0.f);
+        if (b & 0xffffffffull) touched |= 1u << (j0 / LOGIT_TILE);
+        if (b >> 32) touched |= 1u << (j0 / LOGIT_TILE + 1);
+      }
+    const uint32_t before = tile_mask[n];
+    uint32_t todo = __builtin_amdgcn_readfirstlane(before | touched);
+    if (lane == 0 && todo != before) tile_mask[n] = todo;
+    while (todo) {  // two tiles per pass: lanes 0-31 the lowest set bit, lanes 32-63 the next one
+      const int ta = __builtin_ctz(todo);
+      todo &= todo - 1;
+      const int tb = todo ? __builtin_ctz(todo) : -1;
+      if (todo) todo &= todo - 1;
+      const int t = half ? tb : ta;
+      const int j = t * LOGIT_TILE + e;
+      if (t >= 0 && j < M) {
+        const size_t at = (size_t) n * M + j;
+        float p = T.param[at], m = T.exp_avg[at], v = T.exp_avg_sq[at];
+        adam_update_element(p, m, v, T.grad[at], step_size, k);
+        T.exp_avg[at] = m, T.exp_avg_sq[at] = v, T.param[at] = p;
+      }
+    }
+  }
+}
+
 // a tile is live when any of its moments is non-zero (after a restore, a re-ordering or a change of the row count)
 __global__ void __launch_bounds__(256) adam_logit_mask_kernel(int P, int M, const float* __restrict__ exp_avg,
     const float* __restrict__ exp_avg_sq, uint32_t* __restrict__ tile_mask) {
@@ -450,6 +498,20 @@ int skgs_adam_logit_rows(int32_t P, int32_t M, int32_t K, const float* weights, 
         reinterpret_cast<const AdamTensor*>(tensor), tile_mask, beta1, beta2, (float) eps, reinterpret_cast<const AdamState*>(step_state),
         after_advance ? 1 : 0);
   }
+  SKGS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+int skgs_adam_masked_rows(int32_t P, int32_t M, int32_t K, const int64_t* indices, int32_t scan_gradient, const void* tensor,
+    uint32_t* tile_mask, double beta1, double beta2, double eps, const float* step_state, int32_t after_advance, skgs_stream_t stream) {
+  SKGS_REQUIRE(P >= 0 && M >= 1 && M <= 32 * LOGIT_TILE && K >= 0 && K <= 64, "adam_masked_rows: need M <= 1024");
+  if (P == 0) return 0;
+  SKGS_REQUIRE(tensor && tile_mask && step_state && (indices || K == 0), "adam_masked_rows: NULL argument");
+  hipStream_t s = (hipStream_t) stream;
+  ProfScope prof(K_ADAM, s);
+  const int grid = (int) std::min<int64_t>(((int64_t) P + 3) / 4, 256 * 8);
+  hipLaunchKernelGGL(adam_masked_rows_kernel, dim3(grid), dim3(256), 0, s, P, M, K, indices, scan_gradient ? 1 : 0,
+      reinterpret_cast<const AdamTensor*>(tensor), tile_mask, beta1, beta2, (float) eps, reinterpret_cast<const AdamState*>(step_state),
+      after_advance ? 1 : 0);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }

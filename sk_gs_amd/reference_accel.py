@@ -56,7 +56,7 @@ import torch.nn.functional as F
 _originals = {}
 calls = {'ssim_fused': 0, 'ssim_reference': 0, 'kinematic_fused': 0, 'kinematic_reference': 0, 'sk_net_fused': 0, 'sk_net_reference': 0,
          'sp_net_fused': 0, 'sp_net_reference': 0, 'lbs_weight_fused': 0, 'lbs_weight_reference': 0, 'adam_fused': 0, 'adam_reference': 0, 'swizzle_fused': 0,
-         'weight_reg_fused': 0, 'weight_reg_reference': 0}  # counters (tests)
+         'weight_reg_fused': 0, 'weight_reg_reference': 0, 'adam_tiled': 0}  # counters (tests)
 
 
 # ------------------------------------------------------------------------------------------------ SSIM_Loss.forward
@@ -383,28 +383,80 @@ class _AdamRunner:
         ev.record()
 
     def step(self, entries, lrs, beta1, beta2, eps, count):
-        """entries: [(param, grad, exp_avg, exp_avg_sq)] in table order, lrs: one per entry, count: steps taken so far (all equal)"""
+        """entries: [(param, grad, exp_avg, exp_avg_sq)] in table order, lrs: one per entry, count: steps taken so far (all equal).
+        An entry whose parameter carries ``_skgs_logit_tiles`` (the dense [P, M] logit table of ``LBS_method: W``, flagged by the fused
+        reference route) is updated by ``skgs_adam_masked_rows`` -- the 32-column tiles that have ever held a gradient -- instead of as a
+        part of the dense launch: 1.4 GB of optimizer traffic per iteration at P = 1e5, M = 512 otherwise."""
         import struct
-        key = tuple((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()) for p, g, m, v in entries)
+        tiled = [(e, lr) for e, lr in zip(entries, lrs) if _tiles_of(e[0]) is not None]
+        if tiled:
+            dense = [(e, lr) for e, lr in zip(entries, lrs) if _tiles_of(e[0]) is None]
+            entries, lrs = [e for e, _ in dense], [lr for _, lr in dense]
+        key = (tuple((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()) for p, g, m, v in entries),
+               tuple((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr)) for (p, g, m, v), lr in tiled))
         if key != self.key or lrs != self.lrs:
             blob, chunk0 = bytearray(), 0
             for (p, g, m, v), lr in zip(entries, lrs):
                 blob += struct.pack('<QQQQqqfi', p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), chunk0, float(lr), 0)
                 chunk0 += (p.numel() + self.chunk - 1) // self.chunk
+            n_dense = len(blob)
+            for (p, g, m, v), lr in tiled:      # one descriptor each behind the dense table (its own chunk space: chunk0 = 0)
+                blob += struct.pack('<QQQQqqfi', p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 0, float(lr), 0)
             if self.table is None or self.table.numel() < len(blob):
-                self.table = torch.zeros(len(blob), dtype=torch.uint8, device=self.dev)
+                self.table = torch.zeros(max(len(blob), 56), dtype=torch.uint8, device=self.dev)
             self._copy(self.table, blob)
             self.key, self.lrs, self.n, self.chunks = key, list(lrs), len(entries), chunk0
+            self.tiled = []
+            for i, ((p, g, m, v), lr) in enumerate(tiled):
+                info = _tiles_of(p)
+                if info.mask is None or info.mask.numel() != p.shape[0] or info.mask_of is not m:
+                    # the live tiles = wherever a moment is non-zero now (an optimizer that has trained the table before)
+                    info.mask, info.mask_of = torch.zeros(p.shape[0], dtype=torch.int32, device=self.dev), m
+                    self._C._check(self.lib.skgs_adam_logit_mask_rebuild(self.C.c_int32(p.shape[0]), self.C.c_int32(p.shape[1]), self.C.c_void_p(m.data_ptr()),
+                                                                        self.C.c_void_p(v.data_ptr()), self.C.c_void_p(info.mask.data_ptr()), self._C._stream()))
+                self.tiled.append((p, info, n_dense + 56 * i))
         if count != self.count:   # first fused step, or torch's own step ran in between: the counter and 1 - beta^count re-derived
             import struct as _s
             blob = _s.pack('<ffdd', float(count), 0.0, 1.0 - beta1 ** count, 1.0 - beta2 ** count)
             self.state.zero_()
             self._copy(self.state.view(torch.uint8), blob)
+        self.launch(beta1, beta2, eps)
+        self.count = count + 1
+
+    tiled = ()
+
+    def launch(self, beta1, beta2, eps):
+        """the tiled pieces (they read the counter and the bias corrections of the step in progress), then the dense launch, which
+        advances the counter"""
         C = self.C
+        for p, info, offset in self.tiled:
+            idx = info.indices if (info.indices is not None and info.indices.shape[0] == p.shape[0]) else None
+            scan = info.scan or idx is None
+            info.scan = True      # (whoever knows that only `indices` received a gradient says so per step: reference_fused.py)
+            self._C._check(self.lib.skgs_adam_masked_rows(
+                C.c_int32(p.shape[0]), C.c_int32(p.shape[1]), C.c_int32(0 if idx is None else idx.shape[1]), C.c_void_p(None if idx is None else idx.data_ptr()),
+                C.c_int32(1 if scan else 0), C.c_void_p(self.table.data_ptr() + offset), C.c_void_p(info.mask.data_ptr()), C.c_double(beta1),
+                C.c_double(beta2), C.c_double(eps), C.c_void_p(self.state.data_ptr()), C.c_int32(0), self._C._stream()))
+            calls['adam_tiled'] += 1
         self._C._check(self.lib.skgs_adam_step_range(
             C.c_int32(self.n), C.c_void_p(self.table.data_ptr()), C.c_int64(0), C.c_int64(self.chunks), C.c_double(beta1),
             C.c_double(beta2), C.c_double(eps), C.c_void_p(self.state.data_ptr()), C.c_int32(1), None, C.c_int64(0), self._C._stream()))
-        self.count = count + 1
+
+
+class LogitTiles:
+    """what the fused reference route hangs on the dense [P, M] logit table (``param._skgs_logit_tiles``): ``indices`` [P, K] = the columns
+    this step's gradient can be non-zero in, ``scan`` = something else may have written to the gradient as well (the default: the update
+    then looks at the whole gradient row before it trusts the mask), ``mask`` [P] = the live 32-column tiles (built from the moments)"""
+
+    def __init__(self, indices):
+        self.indices, self.scan, self.mask, self.mask_of = indices, True, None, None
+
+
+def _tiles_of(p):
+    info = getattr(p, '_skgs_logit_tiles', None)
+    if info is None or p.dim() != 2 or p.shape[1] > 1024 or p.shape[0] == 0:
+        return None
+    return info
 
 
 _adam_runners = weakref.WeakKeyDictionary()
@@ -430,6 +482,8 @@ class _AdamPlan:
         self.lrs = [g['lr'] for g in opt.param_groups]
         g0 = opt.param_groups[0]
         self.hyper = (float(g0['betas'][0]), float(g0['betas'][1]), float(g0['eps']))
+        self.tiles = tuple(id(_tiles_of(p)) for p, _, _ in runner.tiled)
+        self.flagged = [(p, _tiles_of(p)) for p in self.params]
 
     def replay(self, opt) -> bool:
         groups = opt.param_groups
@@ -440,6 +494,9 @@ class _AdamPlan:
                 return False
         for p, gr in zip(self.params, self.grads):
             if p.grad is not gr:
+                return False
+        for p, info in self.flagged:
+            if _tiles_of(p) is not info:
                 return False
         k = 0
         for g in groups:          # a parameter that had no gradient last time must still have none (torch skips it; so does the table)
@@ -455,11 +512,11 @@ class _AdamPlan:
             s2 = st.get(p)
             if s2 is not s_ or s2['exp_avg'] is not m or s2['exp_avg_sq'] is not v:
                 return False
-        run, C = self.runner, self.runner.C
+        run = self.runner
+        if tuple(id(_tiles_of(p)) for p, _, _ in run.tiled) != self.tiles:      # (a flag put on / taken off a parameter since)
+            return False
         b1, b2, eps = self.hyper
-        run._C._check(run.lib.skgs_adam_step_range(
-            C.c_int32(run.n), C.c_void_p(run.table.data_ptr()), C.c_int64(0), C.c_int64(run.chunks), C.c_double(b1),
-            C.c_double(b2), C.c_double(eps), C.c_void_p(run.state.data_ptr()), C.c_int32(1), None, C.c_int64(0), run._C._stream()))
+        run.launch(b1, b2, eps)
         run.count = self.count = self.count + 1
         torch._foreach_add_(self.steps, 1)      # torch's bookkeeping: the per-parameter step counters
         return True
@@ -693,6 +750,8 @@ def restore_reference():
         for ref in list(rf._routes.keys()):     # the heads the fused route re-homed get storage of their own again
             if hasattr(ref, 'sk_deform_net'):
                 rf.unhome_heads(ref.sk_deform_net)
+            if getattr(getattr(ref, 'sp_W', None), '_skgs_logit_tiles', None) is not None:
+                del ref.sp_W._skgs_logit_tiles
         rf._routes.clear()
     if 'image_loss' in _originals and 'networks.losses.image_loss' in sys.modules:
         sys.modules['networks.losses.image_loss'].ImageLoss.forward = _originals.pop('image_loss')

@@ -295,9 +295,17 @@ class FusedReferenceRoute:
         self.serial, self._fwd, self._terms, self._bg_key, self._spare = 0, None, None, None, None
         self._seen_events = 0
         self._attach = [(p, g, (p is net.last_weight or p is net.last_bias)) for p, g in self.grads.items()]
+        self._tiles = None
         if stage == 'sp':   # cotangents the reference's loss puts on outputs['_knn_w'] / outputs['_spT'] (sparse, smooth, joint: sk_gs.py:1555-1574)
             self.gw_extra = torch.zeros((self.view.P, self.view.K), dtype=torch.float32, device=dev)
             self.gT_extra = torch.zeros((self.view.M, 7), dtype=torch.float32, device=dev)
+            if self.view.sp_W is not None and os.environ.get('SKGS_REF_TILED_ADAM', '1') != '0':
+                # LBS_method W (the shipped default): the dense [P, M] logit table receives a gradient at a row's K neighbours only.  The
+                # patched torch.optim.Adam.step (reference_accel.adam_step) updates the 32-column tiles that have ever held one instead of
+                # all P x M elements -- exact, see skgs_adam_masked_rows -- when the table carries this note; every backward says whether
+                # anything besides this step's neighbours may have written to the gradient (then the update scans the gradient rows first)
+                self._tiles = ra.LogitTiles(self.step.indices)
+                self.view.sp_W._skgs_logit_tiles = self._tiles
         self.graphs, self._graph_key = None, None      # hipGraphs of the forward half / the backward half (None: eager launches)
         self.use_graphs = os.environ.get('SKGS_REF_FUSED_GRAPHS', '1') != '0'
         calls['routes_built'] += 1
@@ -571,6 +579,9 @@ class FusedReferenceRoute:
                 for ours, theirs in foreign:
                     ours.add_(theirs)
                 calls['foreign_grads_added'] += len(foreign)
+            if self._tiles is not None:   # only this step's neighbours hold a gradient on the logit table, unless somebody else added one
+                spw = self.grads[self.view.sp_W]
+                self._tiles.scan = any(ours is spw for ours, _ in foreign)
         for p in self._stores:      # (the heads own these rows as far as any optimizer is concerned)
             p.grad = None
 

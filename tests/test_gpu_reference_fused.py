@@ -246,22 +246,34 @@ def test_stage_sp_one_iteration_with_the_weight_regularisers(lbs):
         _teardown(s)
 
 
-def test_stage_sp_training_follows_the_reference_sequence():
-    """15 iterations of the loop in stage sp (image terms) through the fused route and through the per-method fast paths: same losses"""
-    runs = {}
+@pytest.mark.parametrize('lbs', ['weighted_kernel', 'W'])
+def test_stage_sp_training_follows_the_reference_sequence(lbs):
+    """15 iterations of the loop in stage sp (image terms) through the fused route and through the per-method fast paths: same losses.
+    `W` (the shipped default): the dense [P, M] logit table is updated tile-sparsely by the patched torch.optim.Adam.step on the route
+    (skgs_adam_masked_rows, every step after the one that creates torch's state) -- and ends where the dense update ends"""
+    runs, tables = {}, {}
     for mode in ('accelerated', 'fused'):
-        s = _setup_sp(mode)
+        s = _setup_sp(mode, ('--lbs-method', lbs))
         try:
+            n0 = s.ra.calls['adam_tiled']
             runs[mode] = [float(s.step(i)) for i in range(15)]
             torch.cuda.synchronize()
+            if lbs == 'W':
+                tables[mode] = s.p['sp_W'].detach().clone()
             if mode == 'fused':
                 assert s.rf.calls['render_fused'] == 15 and s.rf.calls['render_reference'] == 0 and s.rf.calls['backward_extras'] == 0
                 st = s.rf.route_of_model(s.model, 'sp').step.status()
                 assert st['overflow_events'] == 0 and st['pairs_overflow_events'] == 0
+                assert s.ra.calls['adam_tiled'] - n0 == (14 if lbs == 'W' else 0)
         finally:
+            if 'sp_W' in s.p and hasattr(s.p['sp_W'], '_skgs_logit_tiles'):
+                del s.p['sp_W']._skgs_logit_tiles
             _teardown(s)
     for a, b in zip(runs['accelerated'], runs['fused']):
         assert abs(a - b) <= 2e-3 * abs(a), runs
+    if lbs == 'W':   # the tile-sparse update moved the table as the dense one did (Adam's sign steps: lr-sized differences where a gradient is ~0)
+        d = (tables['accelerated'] - tables['fused']).abs()
+        assert float((d > 1e-4).float().mean()) < 2e-3, float((d > 1e-4).float().mean())
 
 
 @pytest.mark.parametrize('warp,sep,lbs', [('LBS_c', True, 'weighted_kernel'), ('largest', False, 'W'), ('LBS_c', False, 'dist')])
@@ -355,3 +367,57 @@ def test_weight_regularisers_as_one_launch_each_equal_the_reference_lines(P, K, 
     (s1, m1, g1), (s0, m0, g0) = res
     assert abs(s1 - s0) <= 2e-6 * abs(s0) + 1e-9 and abs(m1 - m0) <= 2e-6 * abs(m0) + 1e-9, (s1, s0, m1, m0)
     assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max()) + 1e-12
+
+
+def test_tiled_adam_on_the_logit_table_is_bit_identical_to_the_dense_launch():
+    """``skgs_adam_masked_rows`` behind the patched ``torch.optim.Adam.step`` (reference_accel: a parameter that carries ``_skgs_logit_tiles``):
+    the [P, M] logit table updated tile-sparsely from its DENSE gradient -- parameters and both moments bit-identical to the dense one-launch
+    update over 12 steps in which the neighbour columns move, one step has a gradient OUTSIDE the known neighbours (scan), and the moments
+    are non-zero before the note is attached (the mask is rebuilt from them)"""
+    from sk_gs_amd import reference_accel as ra
+    import torch.optim
+    keep = torch.optim.Adam.step
+    ra._originals.setdefault('adam', keep)
+    torch.optim.Adam.step = ra.adam_step
+    try:
+        P, M, K = 5000, 512, 5
+        g = torch.Generator().manual_seed(11)
+        w0, small0 = torch.randn(P, M, generator=g).cuda(), torch.randn(300, generator=g).cuda()
+        idx = torch.randint(0, M, (P, K), generator=g).cuda()
+        runs = []
+        gg = torch.Generator().manual_seed(5)
+        grads = []                 # the SAME gradients for both runs (a scatter with duplicate columns in a row is not deterministic)
+        for it in range(12):
+            grad = torch.zeros(P, M, device='cuda')
+            cols = (idx + it // 4) % M                                       # the neighbours move every four steps
+            grad.scatter_(1, cols, torch.randn(P, K, generator=gg).cuda())
+            if it == 7:                                                       # a term that reaches other columns (another loss on the table)
+                grad[::17, 300] += 0.5
+            grads.append((grad, cols, torch.randn(300, generator=gg).cuda()))
+        for tiled in (False, True):
+            w, small = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(small0.clone())
+            opt = torch.optim.Adam([{'params': [w], 'lr': 1e-2}, {'params': [small], 'lr': 1e-3}], eps=1e-15)
+            n0 = ra.calls['adam_tiled']
+            for it in range(12):
+                grad, cols, gsmall = grads[it]
+                outside = it == 7
+                w.grad, small.grad = grad.clone(), gsmall.clone()
+                if tiled and it == 3:                                         # the note arrives when the moments are already non-zero
+                    w._skgs_logit_tiles = ra.LogitTiles(cols)
+                if tiled and it >= 3:
+                    w._skgs_logit_tiles.indices, w._skgs_logit_tiles.scan = cols, outside
+                opt.step()
+            torch.cuda.synchronize()
+            assert (ra.calls['adam_tiled'] - n0) == (9 if tiled else 0)
+            st = opt.state[w]
+            runs.append((w.detach().clone(), st['exp_avg'].clone(), st['exp_avg_sq'].clone(), small.detach().clone(), float(st['step'])))
+            if tiled:   # the mask is sparse: a row has touched at most 3 x K + 1 tiles of 16
+                bits = w._skgs_logit_tiles.mask.cpu().numpy()
+                assert max(bin(int(b) & 0xffffffff).count('1') for b in bits) <= 16 and sum(bin(int(b) & 0xffffffff).count('1') for b in bits) < 0.8 * 16 * P
+        for name, a, b in zip(('table', 'exp_avg', 'exp_avg_sq', 'the other parameter'), runs[0][:4], runs[1][:4]):
+            assert torch.equal(a, b), (name, int((a != b).sum()), float((a - b).abs().max()), (a != b).nonzero()[:5].tolist())
+        assert runs[0][4] == runs[1][4] == 12.0
+    finally:
+        torch.optim.Adam.step = keep
+        ra._originals.pop('adam', None)
+        ra._adam_plans.clear()
