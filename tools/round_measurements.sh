@@ -88,10 +88,13 @@ for v in "accelerated --loop-scene headline" "fused --loop-scene headline" "fuse
 done
 SKGS_REF_FUSED_GRAPHS=0 timeout -k 5 300 python bench.py --reference-loop fused --steps 200 --warmup 10 2>/dev/null | tail -1 > $out/bench_reference-loop_fused_eager-launches.json
 python -c "import json; d=json.load(open('$out/bench_reference-loop_fused_eager-launches.json')); print('reference loop, fused, SKGS_REF_FUSED_GRAPHS=0', d['value'], d['ms_per_step'])"
-for v in "fused --lbs-method W" "accelerated --sp-regularisers" "fused --sp-regularisers"; do set -- $v; m=$1; shift
-  timeout -k 5 300 python bench.py --stage sp --reference-loop $m "$@" --steps 100 --warmup 10 2>/dev/null | tail -1 > "$out/bench_stage_sp_reference-loop_${m}_${1#--}${2:-}.json"
-  python -c "import json; d=json.load(open('$out/bench_stage_sp_reference-loop_${m}_${1#--}${2:-}.json')); print('reference loop, stage sp, $v', d['value'], d['ms_per_step'], d['config']['loss_last'])"
+for v in "fused --lbs-method W" "accelerated --sp-regularisers" "fused --sp-regularisers" "fused --sp-regularisers --reg-torch" "fused --sp-regularisers --lbs-method W"; do set -- $v; m=$1; shift
+  f="$out/bench_stage_sp_reference-loop_${m}$(echo "$@" | tr -d ' ' | sed 's/--/_/g').json"
+  timeout -k 5 300 python bench.py --stage sp --reference-loop $m "$@" --steps 100 --warmup 10 2>/dev/null | tail -1 > "$f"
+  python -c "import json; d=json.load(open('$f')); print('reference loop, stage sp, $v', d['value'], d['ms_per_step'], d['config']['loss_last'])"
 done
+SKGS_REF_TILED_ADAM=0 timeout -k 5 300 python bench.py --stage sp --reference-loop fused --lbs-method W --steps 100 --warmup 10 2>/dev/null | tail -1 > $out/bench_stage_sp_reference-loop_fused_lbs-methodW_dense-adam.json
+python -c "import json; d=json.load(open('$out/bench_stage_sp_reference-loop_fused_lbs-methodW_dense-adam.json')); print('reference loop, stage sp, fused W, SKGS_REF_TILED_ADAM=0', d['value'], d['ms_per_step'])"
 timeout -k 5 200 python tools/phase_times_reference_loop.py 2>/dev/null | tail -1 > $out/phase_times_reference_loop.txt; cat $out/phase_times_reference_loop.txt
 timeout -k 5 200 python tools/find_host_spikes.py 2>/dev/null | tail -4 > $out/find_host_spikes.txt; cat $out/find_host_spikes.txt
 timeout -k 5 300 python tools/preprocess_chain_sweep.py 2>/dev/null | grep -v amdgpu > $out/preprocess_chain_sweep.txt; cat $out/preprocess_chain_sweep.txt
