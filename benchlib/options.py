@@ -189,6 +189,9 @@ def build_parser():
     ap.add_argument('--keep-order', action='store_true',
                     help='leave the synthetic Gaussians in their random order (default: sorted along a Z-order curve, '
                          'densify.sort_spatially, as after a densification event)')
+    ap.add_argument('--no-reference-route', action='store_true',
+                    help="default line: skip the three short child runs of `--reference-loop` (per-method fast paths; the fused route in stage sk and "
+                         "stage sp) reported under `reference_route`")
     ap.add_argument('--loop-scene', choices=('r5', 'headline'), default='r5',
                     help="--reference-loop, stage sk: 'r5' = the synthetic scene of round 5's reference-loop lines (head weights of the "
                          "deform network N(0, s/16): joint rotations of ~0.2 rad along the chain pile the Gaussians up -- R = 0.8 M tile "

@@ -782,7 +782,41 @@ def run(args, env):
     if (world == 1 and not args.no_cpu_baseline and not args.no_survey_recipe and args.targets == 'own-render' and not args.keep_order
             and not args.autograd and not args.eager and args.scale_mult == 1.0):
         line['survey_recipe'] = survey_recipe_run(args)
+        if args.config == 1 and not args.no_reference_route:
+            line['reference_route'] = reference_route_runs(args)
     return line
+
+
+def reference_route_runs(args) -> dict:
+    """The reference's OWN iteration restated on the hooks (`bench.py --reference-loop`, benchlib/reference_loop.py: train.py:179-250 +
+    framework.execute_backward) at this configuration, as numbers of their own beside the headline ("the driver line does not cover
+    it"): the per-method fast paths, and SkeletonGaussianSplatting.render + the image-loss classes routed into the fused step
+    (sk_gs_amd/reference_fused.py) in stage sk and stage sp.  Short child runs (this process keeps its GPU memory; nothing of it runs meanwhile)."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py')
+    out = {'what': "train iters/s of the reference's loop (outputs = model.render(t, info, background, time_id); losses = {rgb, ssim}; "
+                   "sum(losses).backward(); torch.optim.Adam.step(); zero_grad(set_to_none=True)) on install_reference_hooks(): `accelerated` = "
+                   "accelerate_reference(fused_render=False), `fused` = accelerate_reference(); eager; 100 untimed prime steps; synthetic scene of "
+                   "benchlib/reference_loop.py (--loop-scene r5: R = 0.8 M tile instances; the headline's scene: `--loop-scene headline`)"}
+    for key, extra in (('sk_accelerated', ['--reference-loop', 'accelerated', '--steps', '60']), ('sk_fused', ['--reference-loop', 'fused', '--steps', '200']),
+                       ('sp_fused', ['--stage', 'sp', '--reference-loop', 'fused', '--steps', '200'])):
+        cmd = [sys.executable, bench, '--config', str(args.config), '--warmup', '10', '--lr', str(args.lr), '--views', str(args.views)] + extra
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=200, stdin=subprocess.DEVNULL)
+            if r.returncode != 0 or not r.stdout.strip():
+                out[key] = {'error': f'child exited with {r.returncode}', 'stderr_tail': r.stderr.strip().splitlines()[-3:]}
+                continue
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            out[key] = {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'], 'prime_steps': d.get('prime_steps'),
+                        'loss_last': d['config']['loss_last'], 'how': 'python bench.py ' + ' '.join(cmd[2:])}
+            fr = d['config'].get('fused_route')
+            if fr:
+                out[key]['route'] = {'render_fused': fr['calls']['render_fused'], 'render_reference': fr['calls']['render_reference'], 'status': fr['status']}
+        except Exception as e:  # noqa: BLE001  (the headline does not depend on it)
+            out[key] = {'error': f'{type(e).__name__}: {e}'}
+    return out
 
 
 def survey_recipe_run(args) -> dict:

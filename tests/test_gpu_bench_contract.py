@@ -270,6 +270,30 @@ def test_stage_sp_two_ranks_share_the_gpu_and_stay_identical():
     assert abs(d['value'] - 2 * 1000.0 / d['ms_per_step']) / d['value'] < 0.01
 
 
+def test_the_driver_command_carries_the_baselines_and_the_reference_route():
+    """`python bench.py` with NO flags -- the driver's round-end command: one JSON line within minutes, with `cpu_baseline`, `survey_recipe` and
+    (round 6) `reference_route`: the reference's own iteration on the hooks as child runs, every iteration of the fused ones on the route"""
+    import time
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    took = time.time() - t0
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert took < 300, took
+    assert d['n_gpus'] == 1 and d['cpu_baseline']['kind'] == 'port' and d['cpu_baseline']['value'] > 0 and d['survey_recipe']['value'] > 0
+    rr = d['reference_route']
+    for k in ('sk_accelerated', 'sk_fused', 'sp_fused'):
+        assert 'error' not in rr[k], rr[k]
+        assert rr[k]['value'] > 0 and rr[k]['unit'] == 'iters/s' and rr[k]['how'].startswith('python bench.py --config 1')
+    for k in ('sk_fused', 'sp_fused'):
+        r = rr[k]['route']
+        assert r['render_reference'] == 0 and r['render_fused'] == rr[k]['steps'] + rr[k]['prime_steps'] + 10 and r['status']['overflow_events'] == 0
+    assert rr['sk_fused']['value'] > 2 * rr['sk_accelerated']['value']
+    assert d['value'] > rr['sk_fused']['value']          # (the package's own step: no Python between the launches)
+
+
 @pytest.mark.parametrize('stage', ['sk', 'sp'])
 def test_reference_loop_runs_on_the_hooks_and_accelerated_with_the_same_training(stage):
     """`bench.py --reference-loop hooks | accelerated | fused` (benchlib/reference_loop.py): the reference's whole iteration restated on the hooks
