@@ -791,7 +791,8 @@ def reference_route_runs(args) -> dict:
     """The reference's OWN iteration restated on the hooks (`bench.py --reference-loop`, benchlib/reference_loop.py: train.py:179-250 +
     framework.execute_backward) at this configuration, as numbers of their own beside the headline ("the driver line does not cover
     it"): the per-method fast paths, and SkeletonGaussianSplatting.render + the image-loss classes routed into the fused step
-    (sk_gs_amd/reference_fused.py) in stage sk and stage sp.  Short child runs (this process keeps its GPU memory; nothing of it runs meanwhile)."""
+    (sk_gs_amd/reference_fused.py) in stage sk and stage sp.  Short child runs (this process keeps its GPU memory; nothing of it runs meanwhile).
+    `sk_fused_headline_scene`: the same loop on the scene `value` is measured on (R = 0.52 M)."""
     import json
     import subprocess
     import sys
@@ -801,6 +802,7 @@ def reference_route_runs(args) -> dict:
                    "accelerate_reference(fused_render=False), `fused` = accelerate_reference(); eager; 100 untimed prime steps; synthetic scene of "
                    "benchlib/reference_loop.py (--loop-scene r5: R = 0.8 M tile instances; the headline's scene: `--loop-scene headline`)"}
     for key, extra in (('sk_accelerated', ['--reference-loop', 'accelerated', '--steps', '60']), ('sk_fused', ['--reference-loop', 'fused', '--steps', '200']),
+                       ('sk_fused_headline_scene', ['--reference-loop', 'fused', '--steps', '200', '--loop-scene', 'headline']),
                        ('sp_fused', ['--stage', 'sp', '--reference-loop', 'fused', '--steps', '200'])):
         cmd = [sys.executable, bench, '--config', str(args.config), '--warmup', '10', '--lr', str(args.lr), '--views', str(args.views)] + extra
         try:

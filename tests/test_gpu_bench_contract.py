@@ -281,17 +281,17 @@ def test_the_driver_command_carries_the_baselines_and_the_reference_route():
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
-    assert took < 300, took
+    assert took < 420, took
     assert d['n_gpus'] == 1 and d['cpu_baseline']['kind'] == 'port' and d['cpu_baseline']['value'] > 0 and d['survey_recipe']['value'] > 0
     rr = d['reference_route']
-    for k in ('sk_accelerated', 'sk_fused', 'sp_fused'):
+    for k in ('sk_accelerated', 'sk_fused', 'sk_fused_headline_scene', 'sp_fused'):
         assert 'error' not in rr[k], rr[k]
         assert rr[k]['value'] > 0 and rr[k]['unit'] == 'iters/s' and rr[k]['how'].startswith('python bench.py --config 1')
-    for k in ('sk_fused', 'sp_fused'):
+    for k in ('sk_fused', 'sk_fused_headline_scene', 'sp_fused'):
         r = rr[k]['route']
         assert r['render_reference'] == 0 and r['render_fused'] == rr[k]['steps'] + rr[k]['prime_steps'] + 10 and r['status']['overflow_events'] == 0
     assert rr['sk_fused']['value'] > 2 * rr['sk_accelerated']['value']
-    assert d['value'] > rr['sk_fused']['value']          # (the package's own step: no Python between the launches)
+    assert d['value'] > rr['sk_fused_headline_scene']['value'] > 0.6 * d['value']          # (the package's own step: no Python between the launches)
 
 
 @pytest.mark.parametrize('stage', ['sk', 'sp'])
