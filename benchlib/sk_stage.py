@@ -675,6 +675,7 @@ def run(args, env):
         st = fstep.status()
         t.overflow += st['overflow_events']
         assert st.get('mlp_failed', 0) == 0, 'a fused deform-network launch gave up waiting for a workgroup: result invalid'
+        mlp_one_xcd = st.get('mlp_one_xcd')
     assert int(t.overflow.item()) == 0, ('binning capacity overflow during the timed region: result invalid '
                                          + (f'(last step: {st}; tile bucket {s.tile_bucket} slots, R capacity for {s.R_max} x 1.25 x '
                                             f'{_C.config.capacity_growth})' if fstep is not None else ''))
@@ -744,6 +745,10 @@ def run(args, env):
                                        + ('one launch per layer' if args.layered_mlp else 'one persistent launch per direction'))
                    if args.deform_net and M > 0 else 'per-frame tables (test-time cache, sk_gs.py:1080-1085): NOT the '
                                                      'reference\'s training step',
+                   'deform_net_on_one_xcd': None if (fstep is None or mlp_one_xcd is None) else dict(
+                       mlp_one_xcd, note='[launches whose own census found the 32 network workgroups on ONE XCD (exchange kept in that L2, '
+                                         'plain stores), launches so far] per direction; skgs_deform_mlp_xcd_mode / SKGS_MLP_XCD=0: blocks 0..31, '
+                                         'write-through exchange (the layout before round 6)'),
                    'joints': 'trained, lr x 0.1 (sk_gs.py:607)' if model.learn_joints else 'fixed',
                    'gaussian_order': 'as generated (random)' if (args.keep_order or M == 0) else
                    'sorted along a Z-order curve (densify.sort_spatially: what a training loop does after each densification event)',

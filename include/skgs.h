@@ -625,6 +625,19 @@ typedef struct skgs_mlp_desc {
 } skgs_mlp_desc;
 size_t skgs_deform_mlp_workspace_bytes(const skgs_mlp_desc* d);
 int skgs_deform_mlp_workspace_init(void* workspace, size_t workspace_bytes, skgs_stream_t stream);
+/* Where the network's 32 workgroups run (process-wide; mode < 0: only ask; returns the mode in force before the call).
+ *   0: blocks 0..31 of the launch (the dispatcher deals them four to each XCD); the in-launch exchange of the [B, hidden]
+ *      activations goes through write-through (sc1) stores: every hop crosses the fabric.
+ *   1 (default on a whole MI355X, 256 CUs; environment SKGS_MLP_XCD overrides): blocks 0, 8, .. 248 -- blocks of one residue mod 8
+ *      are observed to share an XCD.  Every launch CHECKS that: each workgroup publishes the XCC_ID it runs on with its first
+ *      slab, all read all 32 with their first gather, and only a launch found on ONE XCD sends the later slabs as plain stores
+ *      (they stay in that XCD's L2: a hop is an L2 round trip, 0.76 us instead of 1.3); any other placement keeps the
+ *      write-through stores.  Words 4 / 5 of the workspace header count the forward / backward launches that ran that way.
+ *      Measured at config #1: skeleton forward 37.1 -> 34.4 us, skeleton backward (the rows' Adam on the other seven XCDs, none
+ *      beside the network) 58.6 -> 53.4 us, the step 0.3388 -> 0.3294 ms.
+ *   2: the placement of 1 with write-through stores throughout;  3: mode 1 with a falsified census (tests of the fall-back).
+ * No reference counterpart (the reference runs the network as ~65 torch launches, networks/sk_gs.py:1073-1074). */
+int32_t skgs_deform_mlp_xcd_mode(int32_t mode);
 int skgs_deform_mlp_forward(const skgs_mlp_desc* d, const float* points, const float* t, float* x0, float* acts, float* out,
     void* workspace, size_t workspace_bytes, skgs_stream_t stream);
 /* x0: the [B, IN] encoded input the forward call wrote (its `x0` argument), or NULL: it is re-encoded from points / t

@@ -35,6 +35,7 @@
 // layer, 3000 clocks at two waves per SIMD; the MFMA form issues 32 matrix + 16 LDS instructions.)  Row pitches in LDS are
 // padded by 4 floats so that the 16 rows a ds_read_b128 touches start in different banks.
 #include <algorithm>
+#include <cstdlib>
 
 #include "adam_update.h"
 #include "bone_chain.inl"
@@ -48,6 +49,7 @@ constexpr unsigned SENTINEL = 0xffffffffu;
 // Shapes fixed at compile time: hidden width H = 256, encoded input padded to INP = 128, at most KL layers.
 constexpr int H = 256, INP = 128, KL = 10;
 constexpr int NT = 512, NW = NT / 64, NC = 8;  // threads, waves and output features per workgroup
+constexpr int G_NET = H / NC;                   // the network's workgroups
 constexpr int HP = H + 4;                       // LDS row pitch of a [rows][H] image (see the thread map above)
 
 using gu32 = __attribute__((address_space(1))) unsigned int;
@@ -70,7 +72,8 @@ struct FusedArgs {
   const float* g_out; // backward: [B, out_last]
   float* g_x0;        // backward: [B, IN] or NULL
   unsigned* hdr;      // workspace header: [0] forward launches, [1] failed launches (sticky), [2] stamps wanted,
-                      // [3] backward launches, [16..63] stamps
+                      // [3] backward launches, [4] / [5] forward / backward launches whose exchange ran on plain stores
+                      // (xcd_mode 1: the census found the network on one XCD), [16..63] stamps
   float* exch;        // this direction's exchange images [2][n_layers - 1][G][Bp][NC]
   int n_heads, head_dim[4];  // the last layer's columns split over separate [B, head_dim[j]] tensors (n_heads = 0: one tensor)
   float* head_out[4];        // forward
@@ -102,6 +105,18 @@ struct FusedArgs {
   // skeleton forward in training: the frame's row of the test-time cache, sk_cache[frame_index] = [normalised joint
   // rotation | d_rot | d_scale] (networks/sk_gs.py:1077-1079), written by the workgroups that own the heads' columns
   float* sk_cache;  // [frames][B][out_last] or NULL
+  // Where the network's workgroups run.
+  // 0: blocks 0 .. G-1 (the dispatcher deals them four to each XCD); slabs leave as write-through (sc1) stores.
+  // 1: blocks 0, 8, 16 .. 8 (G - 1) -- blocks of one residue mod 8 are observed to share an XCD (MI355X_MICROARCH.md, dispatch), so the
+  //    whole exchange can stay inside ONE L2: slabs leave as PLAIN stores (the line stays in that L2; an sc1 store drops it), readers
+  //    poll with sc1 loads (L1 bypassed) as before.  Placement is no contract: every workgroup publishes the XCC_ID it runs on next to
+  //    its first slab (always write-through), every workgroup reads all of them with its first gather, and only a launch whose
+  //    network sits on ONE XCD switches to plain stores -- the same 32 words are seen by all, so all decide alike.  A launch placed
+  //    otherwise runs on write-through stores as in mode 0.
+  // 2: the placement of 1, write-through stores throughout (A/B of the placement alone).
+  // 3: mode 1 with a FALSIFIED census (tests: the fall-back path of a launch that is not on one XCD).
+  int xcd_mode;
+  unsigned* census;  // this direction's [2 parities][G][4 words]: (XCC_ID, 0, 0, 0) per network workgroup, sentinel-filled like the images
 };
 
 __device__ __forceinline__ FusedLayer get_layer(const FusedArgs& a, int l) {
@@ -151,13 +166,28 @@ __device__ __forceinline__ void store16_sc1(float* p, float4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(q) : "memory");
 }
 
+// plain 16-byte store: only for readers behind the SAME L2 (xcd_mode 1)
+__device__ __forceinline__ void store16_plain(float* p, float4 v) {
+  const f4 q = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(q) : "memory");
+}
+__device__ __forceinline__ void store16_exch(float* p, float4 v, bool plain) {
+  if (plain) store16_plain(p, v);
+  else store16_sc1(p, v);
+}
+
 // Read every workgroup's slab of one exchange image into the [Bp][H] LDS image (row pitch H), re-reading until no word
 // is the sentinel.  Unit u = 16 bytes: slab g = u / (B NC/4), then row-major inside the slab (rows < B only).  All of a
 // thread's loads are in flight together (one asm statement with its own wait: hipcc does not track asm loads).
 // Returns false on time-out.
+// `census`: this launch's [G][4] census words; lane i (mod 32) also fetches workgroup i's entry in the same batch of loads and holds
+// it back in `census_word` (valid, like the slabs, once the function returns true).
 template <int U>
-__device__ __forceinline__ bool gather_slabs(const float* img, float* s_dst, int B, int Bp, int pitch, int n_units) {
+__device__ __forceinline__ bool gather_slabs(const float* img, float* s_dst, int B, int Bp, int pitch, int n_units, const unsigned* census,
+    unsigned& census_word) {
   constexpr int Q = NC / 4;  // 16-byte units per slab row
+  const unsigned* cptr = census + 4 * (threadIdx.x & (G_NET - 1));
+  f4 cv;
   const float* ptr[U];
   int dst[U];
   bool live[U];
@@ -177,23 +207,25 @@ __device__ __forceinline__ bool gather_slabs(const float* img, float* s_dst, int
   for (;;) {
     if constexpr (U == 4) {
       asm volatile(
-          "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
-          "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
-          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-          : "v"(ptr[0]), "v"(ptr[1]), "v"(ptr[2]), "v"(ptr[3])
+          "global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %6, off sc1\n\t"
+          "global_load_dwordx4 %2, %7, off sc1\n\tglobal_load_dwordx4 %3, %8, off sc1\n\t"
+          "global_load_dwordx4 %4, %9, off sc1\n\ts_waitcnt vmcnt(0)"
+          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(cv)
+          : "v"(ptr[0]), "v"(ptr[1]), "v"(ptr[2]), "v"(ptr[3]), "v"(cptr)
           : "memory");
     } else {
       static_assert(U == 4 || U == 8, "gather_slabs: 4 or 8 units per thread");
       asm volatile(
-          "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
-          "global_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
-          "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
-          "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
-          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4 % U]), "=&v"(v[5 % U]), "=&v"(v[6 % U]), "=&v"(v[7 % U])
-          : "v"(ptr[0]), "v"(ptr[1]), "v"(ptr[2]), "v"(ptr[3]), "v"(ptr[4 % U]), "v"(ptr[5 % U]), "v"(ptr[6 % U]), "v"(ptr[7 % U])
+          "global_load_dwordx4 %0, %9, off sc1\n\tglobal_load_dwordx4 %1, %10, off sc1\n\t"
+          "global_load_dwordx4 %2, %11, off sc1\n\tglobal_load_dwordx4 %3, %12, off sc1\n\t"
+          "global_load_dwordx4 %4, %13, off sc1\n\tglobal_load_dwordx4 %5, %14, off sc1\n\t"
+          "global_load_dwordx4 %6, %15, off sc1\n\tglobal_load_dwordx4 %7, %16, off sc1\n\t"
+          "global_load_dwordx4 %8, %17, off sc1\n\ts_waitcnt vmcnt(0)"
+          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4 % U]), "=&v"(v[5 % U]), "=&v"(v[6 % U]), "=&v"(v[7 % U]), "=&v"(cv)
+          : "v"(ptr[0]), "v"(ptr[1]), "v"(ptr[2]), "v"(ptr[3]), "v"(ptr[4 % U]), "v"(ptr[5 % U]), "v"(ptr[6 % U]), "v"(ptr[7 % U]), "v"(cptr)
           : "memory");
     }
-    bool ok = true;
+    bool ok = f2u(cv.x) != SENTINEL;
 #pragma unroll
     for (int j = 0; j < U; ++j)
       if (live[j])
@@ -211,7 +243,24 @@ __device__ __forceinline__ bool gather_slabs(const float* img, float* s_dst, int
 #pragma unroll
   for (int j = 0; j < U; ++j)
     if (live[j]) *reinterpret_cast<float4*>(s_dst + dst[j]) = make_float4(v[j].x, v[j].y, v[j].z, v[j].w);
+  census_word = f2u(cv.x);
   return good;
+}
+// every lane holds one workgroup's census word (lane i mod 32: workgroup i): does the whole network run on one XCD?  Wave-uniform, and
+// the same answer in every wave of every workgroup (all of them read the same G words).
+__device__ __forceinline__ bool census_one_xcd(unsigned census_word) {
+  const unsigned first = (unsigned) __builtin_amdgcn_readfirstlane((int) census_word);
+  return __builtin_amdgcn_ballot_w64(census_word == first) == ~0ull;
+}
+// the XCD this wave runs on: HW_REG_XCC_ID (id 20), bits [3:0]
+__device__ __forceinline__ unsigned xcc_id() { return (unsigned) __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)); }
+// this workgroup's entry of the launch's census (thread 0; write-through: readers on any XCD)
+__device__ __forceinline__ void census_publish(const FusedArgs& a, unsigned parity, int g) {
+  if (threadIdx.x == 0) {
+    unsigned id = xcc_id();
+    if (a.xcd_mode == 3) id = (unsigned) (g & 1);  // (tests: a network that is NOT on one XCD)
+    store16_sc1(reinterpret_cast<float*>(a.census + ((size_t) parity * G_NET + g) * 4), make_float4(u2f(id), 0.f, 0.f, 0.f));
+  }
 }
 
 // Lane map of the 4x4x1 MFMA (checked on gfx950): lane = 4 b + j holds A[4 b + i = j] and B[4 b + j] of block b; VGPR i of the
@@ -296,12 +345,13 @@ __device__ __forceinline__ float4 sum_partials(const float* s_part, int Bp, int 
 }
 
 // fill this workgroup's slabs of the image the launch does NOT use with the sentinel
-__device__ __forceinline__ void repoison(float* img_other, int nX, int G, int Bp) {
+__device__ __forceinline__ void repoison(float* img_other, int nX, int G, int Bp, int g, unsigned* census_other) {
   const int slab4 = Bp * NC / 4;
   const float4 s  = make_float4(u2f(SENTINEL), u2f(SENTINEL), u2f(SENTINEL), u2f(SENTINEL));
+  if (threadIdx.x == 0) reinterpret_cast<float4*>(census_other)[g] = s;
   for (int i = threadIdx.x; i < nX * slab4; i += NT) {
     const int l = i / slab4, q = i - l * slab4;
-    reinterpret_cast<float4*>(img_other + ((size_t) l * G + blockIdx.x) * Bp * NC)[q] = s;
+    reinterpret_cast<float4*>(img_other + ((size_t) l * G + g) * Bp * NC)[q] = s;
   }
 }
 
@@ -312,7 +362,6 @@ __device__ __forceinline__ void repoison(float* img_other, int nX, int G, int Bp
 // section 7), workgroups of one launch cost nothing.  The network's workgroups have the lowest ids and are dispatched first,
 // so all of them are resident before the first side workgroup is placed; the LDS request of the launch keeps it at one
 // workgroup per CU.
-constexpr int G_NET = H / NC;
 // the side job gets one workgroup per CU the network does not occupy: the device's CU count, asked once per device (256 on
 // a whole MI355X; a partitioned / shared GPU reports what this process can use)
 inline int num_cus() {
@@ -326,8 +375,21 @@ inline int num_cus() {
   }
   return cached[dev];
 }
-__device__ __forceinline__ void adam_side_job(const FusedArgs& a) {
-  const int n_side = (int) gridDim.x - G_NET, wg = (int) blockIdx.x - G_NET;
+// which workgroup of the launch is what (see FusedArgs::xcd_mode)
+struct Role {
+  bool net;
+  int g, wg, n_side;  // network index, or index among the n_side others
+};
+__device__ __forceinline__ Role role_of(const FusedArgs& a) {
+  const int b = (int) blockIdx.x, n_side = (int) gridDim.x - G_NET;
+  if (!a.xcd_mode) return Role{b < G_NET, b, b - G_NET, n_side};
+  const bool low = b < 8 * G_NET;
+  const bool net = low && (b & 7) == 0;
+  const int before = low ? (b >> 3) + 1 : G_NET;  // network workgroups with a smaller block id (b itself not a network one)
+  return Role{net, b >> 3, b - before, n_side};
+}
+__device__ __forceinline__ void adam_side_job(const FusedArgs& a, int wg, int n_side) {
+  if (!a.adam_tensors || a.adam_c1 <= a.adam_c0) return;  // (xcd_mode without a side range: the blocks between the network's just leave)
   const int half = threadIdx.x >> 8, t256 = threadIdx.x & 255, lane = threadIdx.x & 63;
   const AdamCoef k = adam_coefficients(a.adam_beta1, a.adam_beta2, a.adam_eps, a.adam_step, a.adam_after_advance != 0);
   const AdamTensorLanes desc = adam_load_descriptors(a.adam_tensors, a.adam_n, lane);
@@ -372,13 +434,14 @@ __global__ void __launch_bounds__(NT) fused_mlp_forward_kernel(const FusedArgs a
   constexpr int EQ = (Bp * INP + NT - 1) / NT;             // encoded-input entries per thread (padding included)
   static_assert((Bp * 64 + NT - 1) / NT <= 8, "gather_slabs covers at most 8 units per thread");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (blockIdx.x >= G_NET) {  // (the forward launch can host an optimizer piece on its idle CUs too: see adam_side_job)
-    adam_side_job(a);
+  const Role role = role_of(a);
+  if (!role.net) {  // (the forward launch can host an optimizer piece on its idle CUs too: see adam_side_job)
+    adam_side_job(a, role.wg, role.n_side);
     return;
   }
   const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
   const int tid = threadIdx.x, wave = tid >> 6;
-  const int G = G_NET, g = blockIdx.x, col0 = g * NC;
+  const int G = G_NET, g = role.g, col0 = g * NC;
   const int B = a.B, nL = a.n_layers, nX = nL - 1, IN = a.IN;
   const int XW = pad32(IN), XP = XW + 4;
   float* s_x0   = smem;
@@ -478,7 +541,11 @@ __global__ void __launch_bounds__(NT) fused_mlp_forward_kernel(const FusedArgs a
   const unsigned count = s_misc[0];
   const size_t img_floats = (size_t) nX * G * Bp * NC;
   float* img = a.exch + (count & 1u) * img_floats;
-  repoison(a.exch + ((count & 1u) ^ 1u) * img_floats, nX, G, Bp);
+  repoison(a.exch + ((count & 1u) ^ 1u) * img_floats, nX, G, Bp, g, a.census + ((count & 1u) ^ 1u) * (G_NET * 4));
+  census_publish(a, count & 1u, g);
+  const unsigned* census = a.census + (count & 1u) * (G_NET * 4);
+  bool plain = false;  // slabs leave as plain stores once the census has shown the whole network on one XCD (xcd_mode 1 / 3)
+  unsigned census_word = 0;
   int si = 0;
   stamp(a, s_misc, si, t_entry);
 
@@ -488,10 +555,11 @@ __global__ void __launch_bounds__(NT) fused_mlp_forward_kernel(const FusedArgs a
     const int hp = l ? H : 0, WP = hp + (L.in_x ? XW : 0) + 4;
     const bool last = l == nL - 1;
     if (l > 0) {
-      const bool ok = gather_slabs<U>(img + (size_t) (l - 1) * G * Bp * NC, s_act, B, Bp, HP, B * H / 4);
+      const bool ok = gather_slabs<U>(img + (size_t) (l - 1) * G * Bp * NC, s_act, B, Bp, HP, B * H / 4, census, census_word);
       if (!ok) s_misc[1] = 1;
       __syncthreads();
       if (s_misc[1]) break;
+      if (l == 1) plain = (a.xcd_mode == 1 || a.xcd_mode == 3) && census_one_xcd(census_word);
       stamp(a, s_misc, si);
     }
     if (last && col0 >= L.out) break;
@@ -530,7 +598,7 @@ __global__ void __launch_bounds__(NT) fused_mlp_forward_kernel(const FusedArgs a
             }
           }
         } else {
-          store16_sc1(img + ((size_t) l * G + g) * Bp * NC + 4 * tid, y);
+          store16_exch(img + ((size_t) l * G + g) * Bp * NC + 4 * tid, y, plain);
           *reinterpret_cast<float4*>(a.acts + ((size_t) l * B + row) * H + col0 + 4 * part) = y;
         }
       }
@@ -556,6 +624,7 @@ __global__ void __launch_bounds__(NT) fused_mlp_forward_kernel(const FusedArgs a
   if (g == 0 && tid == 0) {
     gu32* h = reinterpret_cast<gu32*>((unsigned long long) a.hdr);
     if (s_misc[1]) __hip_atomic_fetch_add(h + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (plain) __hip_atomic_fetch_add(h + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // launches whose exchange stayed in one L2
     __hip_atomic_store(h, count + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -571,12 +640,13 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
   constexpr int U = (Bp * 64 + NT - 1) / NT <= 4 ? 4 : 8;
   static_assert((Bp * 64 + NT - 1) / NT <= 8, "gather_slabs covers at most 8 units per thread");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (blockIdx.x >= G_NET) {
-    adam_side_job(a);
+  const Role role = role_of(a);
+  if (!role.net) {
+    adam_side_job(a, role.wg, role.n_side);
     return;
   }
   const int tid = threadIdx.x, wave = tid >> 6;
-  const int G = G_NET, g = blockIdx.x, col0 = g * NC;
+  const int G = G_NET, g = role.g, col0 = g * NC;
   const int B = a.B, nL = a.n_layers, IN = a.IN, nX = nL - 1;
   const bool want_gx = a.g_x0 != nullptr && col0 < IN;
   float* s_gz   = smem;
@@ -695,7 +765,11 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
   const unsigned count = s_misc[0];
   const size_t img_floats = (size_t) nX * G * Bp * NC;
   float* img = a.exch + (count & 1u) * img_floats;
-  repoison(a.exch + ((count & 1u) ^ 1u) * img_floats, nX, G, Bp);
+  repoison(a.exch + ((count & 1u) ^ 1u) * img_floats, nX, G, Bp, g, a.census + ((count & 1u) ^ 1u) * (G_NET * 4));
+  census_publish(a, count & 1u, g);
+  const unsigned* census = a.census + (count & 1u) * (G_NET * 4);
+  bool plain = false;  // slabs leave as plain stores once the census has shown the whole network on one XCD (xcd_mode 1 / 3)
+  unsigned census_word = 0;
   int si = 12;  // diagnostics: stamps 12.. = prologue done, chain done, input gradient done, weight gradients done
   stamp(a, s_misc, si);
 
@@ -748,7 +822,7 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
         const float4 m = am[lu - 1];
         y.x = (mlive && m.x > 0.f) ? not_sentinel(y.x) : 0.f, y.y = (mlive && m.y > 0.f) ? not_sentinel(y.y) : 0.f;
         y.z = (mlive && m.z > 0.f) ? not_sentinel(y.z) : 0.f, y.w = (mlive && m.w > 0.f) ? not_sentinel(y.w) : 0.f;
-        if (publish && mlive) store16_sc1(img + ((size_t) (l - 1) * G + g) * Bp * NC + 4 * tid, y);
+        if (publish && mlive) store16_exch(img + ((size_t) (l - 1) * G + g) * Bp * NC + 4 * tid, y, plain);
         *reinterpret_cast<float4*>(s_own + (l - 1) * Bp * NC + 4 * tid) = y;  // kept for the weight gradients
       }
       if (wg_rows) {
@@ -767,11 +841,12 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
         gw_ld = L.in_h + L.in_x, gw_rows = L.out - (col0 + 4 * lm.cg);
       }
       if (publish) {
-        const bool ok = gather_slabs<U>(img + (size_t) (l - 1) * G * Bp * NC, s_gz, B, Bp, HP, B * H / 4);
+        const bool ok = gather_slabs<U>(img + (size_t) (l - 1) * G * Bp * NC, s_gz, B, Bp, HP, B * H / 4, census, census_word);
         if (!ok) s_misc[1] = 1;
       }
       __syncthreads();
       if (s_misc[1]) break;
+      if (publish && l == nL - 1) plain = (a.xcd_mode == 1 || a.xcd_mode == 3) && census_one_xcd(census_word);
     }
   }
   if (gw_dst) {
@@ -860,12 +935,14 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
   if (g == 0 && tid == 0) {
     gu32* h = reinterpret_cast<gu32*>((unsigned long long) a.hdr);
     if (s_misc[1]) __hip_atomic_fetch_add(h + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (plain) __hip_atomic_fetch_add(h + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(h + 3, count + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------ host
 constexpr int HDR_BYTES = 256;
+constexpr int CENSUS_BYTES = 2 * G_NET * 16;  // one direction: both parities of [G][4 words]
 
 struct Plan {
   int Bp, passes, IN, INP, G, NC;
@@ -899,7 +976,7 @@ int make_plan(const skgs_mlp_desc* d, Plan* p) {
   p->Bp     = p->passes * 16;
   p->NC     = NC;
   p->G      = d->hidden / NC;
-  p->exch_bytes = (size_t) 2 * (d->n_layers - 1) * p->Bp * d->hidden * 4;
+  p->exch_bytes = (size_t) 2 * (d->n_layers - 1) * p->Bp * d->hidden * 4 + CENSUS_BYTES;  // images, then the census
   return 0;
 }
 
@@ -949,6 +1026,14 @@ int backward_impl(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, con
     const float* x0, const float* acts, const float* g_out, float* g_x0, void* workspace, size_t workspace_bytes,
     const skgs_adam_range* side, skgs_stream_t stream);
 
+int g_xcd_mode = -1;  // -1: not decided yet (the environment's SKGS_MLP_XCD, default 1)
+inline int xcd_mode_wanted() {
+  if (g_xcd_mode < 0) {
+    const char* e = getenv("SKGS_MLP_XCD");
+    g_xcd_mode = e ? std::max(0, std::min(3, atoi(e))) : 1;
+  }
+  return g_xcd_mode;
+}
 template <typename KernelT>
 int launch(KernelT k, const Plan& p, const FusedArgs& a, size_t lds, hipStream_t s, int prof_id) {
   ProfScope prof(prof_id, s);
@@ -958,7 +1043,14 @@ int launch(KernelT k, const Plan& p, const FusedArgs& a, size_t lds, hipStream_t
   int side = 0;
   if (a.adam_tensors && a.adam_c1 > a.adam_c0)
     side = (int) std::max<long long>(1, std::min<long long>((a.adam_c1 - a.adam_c0 + 1) / 2, num_cus() - p.G));  // never 0: the rows MUST be updated
-  hipLaunchKernelGGL(k, dim3(p.G + side), dim3(NT), lds, s, a);
+  FusedArgs b = a;
+  int grid = p.G + side;
+  b.xcd_mode = xcd_mode_wanted();
+  if (b.xcd_mode) {  // the network on blocks 0, 8, .. 8 (G - 1): the grid must reach the last of them
+    if (num_cus() != 256 || p.G != G_NET || (side > 0 && grid < 8 * p.G - 7)) b.xcd_mode = 0;
+    else grid = std::max(grid, 8 * p.G - 7);
+  }
+  hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, s, b);
   SKGS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -979,6 +1071,12 @@ __global__ void init_workspace_kernel(uint32_t* w, size_t n_words) {
 using namespace skgs;
 
 extern "C" {
+
+int32_t skgs_deform_mlp_xcd_mode(int32_t mode) {
+  const int before = xcd_mode_wanted();
+  if (mode >= 0) g_xcd_mode = std::min(3, (int) mode);
+  return before;
+}
 
 size_t skgs_deform_mlp_workspace_bytes(const skgs_mlp_desc* d) {
   Plan p;
@@ -1026,6 +1124,7 @@ int forward_impl(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, cons
   a.points = points, a.t = t, a.x0 = x0, a.acts = acts, a.out = out;
   a.hdr  = reinterpret_cast<unsigned*>(workspace);
   a.exch = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + HDR_BYTES);
+  a.census = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(a.exch) + p.exch_bytes - CENSUS_BYTES);
   if (bones) {
     if (fill_chain(d, p, bones, &a)) return 1;
     SKGS_REQUIRE(bones->bone_T, "skeleton_forward: bone_T is NULL");
@@ -1097,6 +1196,7 @@ int backward_impl(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, con
   if (fill_side(side, &a)) return 1;
   a.hdr  = reinterpret_cast<unsigned*>(workspace);
   a.exch = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + HDR_BYTES + p.exch_bytes);
+  a.census = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(a.exch) + p.exch_bytes - CENSUS_BYTES);
   size_t fl = (size_t) p.Bp * HP + (size_t) (d->n_layers + NW) * p.Bp * NC + (size_t) p.Bp * 4 + 4;
   for (int l = 1; l < d->n_layers; ++l) fl += (size_t) NC * (pad32(d->layer[l].out) + 4);
   if (g_x0)

@@ -770,7 +770,10 @@ class FusedViewStep:
         deform network also ``mlp_failed`` (launches whose in-kernel exchange gave up: must be 0)"""
         st = _C.read_status(self.geom)
         if self.deform_net is not None and self._mlp_fused is not None:
-            st['mlp_failed'] = self._mlp_fused.status()['failed']
+            m = self._mlp_fused.status()
+            st['mlp_failed'] = m['failed']
+            # launches whose network sat on ONE XCD by their own census, the exchange kept in its L2 (skgs_deform_mlp_xcd_mode)
+            st['mlp_one_xcd'] = dict(forward=[m['one_xcd_forward'], m['forward']], backward=[m['one_xcd_backward'], m['backward']])
         return st
 
 

@@ -163,7 +163,8 @@ def test_fused_deform_mlp_matches_torch():
         for rep in range(3):  # same workspace: the launch epoch distinguishes the exchanges
             out = run.forward(joints, t)
             run.backward(joints, t, g, grads, g_x0)
-        assert run.status() == dict(forward=3, backward=3, failed=0)
+        st = run.status()
+        assert (st['forward'], st['backward'], st['failed']) == (3, 3, 0)
         assert (run.x0 - ref_x0).abs().max() <= 3e-4  # sin of arguments up to 2^9 x: argument rounding
         assert rel_err(out, ref_out) <= 2e-5, B
         assert rel_err(run.acts, ref_acts) <= 2e-5, B
@@ -205,6 +206,53 @@ def test_fused_deform_mlp_matches_torch():
     assert rel_err(run.out, ref_out) <= 2e-5
     for a, r in zip(grads, ref_grads):
         assert rel_err(a, r) <= 5e-5
+
+
+@pytest.mark.parametrize('mode', [0, 1, 2, 3])
+def test_fused_deform_mlp_where_the_network_runs(mode):
+    """``skgs_deform_mlp_xcd_mode``: the network's 32 workgroups on blocks 0..31 (four per XCD, write-through exchange: 0), on blocks
+    0, 8, .. 248 = one XCD with the exchange kept in that L2 when the launch's own census confirms the placement (1), that placement
+    with write-through stores (2), and mode 1 with a census that says "two XCDs" (3: the fall-back every launch must be able to take).
+    Same outputs and gradients in all of them (the arithmetic does not depend on the store flavour: bit-identical to mode 0), no launch
+    gives up, with and without the optimizer's side job beside the network, eager and as a graph replay."""
+    from sk_gs_amd import _C
+    from sk_gs_amd.deform_net import DeformMLP, FusedDeformMLP
+    lib = _C.load_library()
+    lib.skgs_deform_mlp_xcd_mode.restype = C.c_int32
+    before = lib.skgs_deform_mlp_xcd_mode(C.c_int32(-1))
+    torch.manual_seed(1)
+    mlp = DeformMLP().cuda()
+    with torch.no_grad():
+        mlp.dynamic_net.last_weight.normal_(0, 0.1)
+    results = {}
+    try:
+        for m in (0, mode):
+            assert lib.skgs_deform_mlp_xcd_mode(C.c_int32(m)) in (0, 1, 2, 3)
+            for B in (20, 32, 48):
+                torch.manual_seed(100 + B)
+                joints, t, g = torch.rand(B, 3, device='cuda') - 0.5, torch.tensor([0.3], device='cuda'), torch.randn(B, 11, device='cuda')
+                ref_out, _, ref_grads, ref_gx0, _ = _ref_with_input_grad(mlp, joints, t, g)
+                run = FusedDeformMLP(mlp, B)
+                grads, g_x0 = [torch.zeros_like(r) for r in ref_grads], torch.zeros_like(ref_gx0)
+                for rep in range(6):
+                    out = run.forward(joints, t)
+                    run.backward(joints, t, g, grads, g_x0)
+                st = run.status()
+                assert (st['forward'], st['backward'], st['failed']) == (6, 6, 0), (m, B, st)
+                if m in (0, 2, 3):
+                    assert st['one_xcd_forward'] == 0 and st['one_xcd_backward'] == 0, (m, st)
+                else:  # every launch or none: the placement rule holds on this device or it does not (then mode 1 IS mode 2)
+                    assert st['one_xcd_forward'] in (0, 6) and st['one_xcd_backward'] == st['one_xcd_forward'], st
+                    print(f'[xcd] mode 1, B={B}: {st["one_xcd_forward"]} of 6 launches per direction on one XCD')
+                assert rel_err(out, ref_out) <= 2e-5 and rel_err(g_x0, ref_gx0) <= 5e-5
+                for a, r in zip(grads, ref_grads):
+                    assert rel_err(a, r) <= 5e-5
+                results[(m, B)] = [out.clone(), g_x0.clone()] + [x.clone() for x in grads]
+        for B in (20, 32, 48):
+            for a, b in zip(results[(0, B)], results[(mode, B)]):
+                assert torch.equal(a, b), (mode, B)
+    finally:
+        lib.skgs_deform_mlp_xcd_mode(C.c_int32(before))
 
 
 def test_fused_deform_mlp_other_shapes():
