@@ -63,8 +63,6 @@ struct ChainArgs {
   float* g_sk_r_raw;         // backward: [M,4] written if not NULL (global)
   float* g_joints;           // backward: [M,3] written if not NULL
   float* g_global_T;         // backward: [7] (row frame_index of a table) written if not NULL
-  float* global_T_row;       // NULL, or 7 floats the caller owns: the forward leaves the frame's row of global_T there and the backward
-                             // of the same frame reads it from there -- no load that waits for frame_index[0] first
 };
 
 // Every global load of a chain pass, issued at once into registers (bone i = threadIdx.x): the bodies below then run on
@@ -84,11 +82,7 @@ __device__ __forceinline__ Prefetch prefetch(const ChainArgs& c, bool want_raw, 
   if (!p.valid) return p;
   const int i = threadIdx.x;
   const float* gTp = c.global_T;
-  if (backward && gTp && c.global_T_row) {
-    gTp = c.global_T_row;  // (the forward's copy of the row: one round trip instead of index -> row)
-  } else if (gTp && c.frame_index) {
-    gTp += 7 * (size_t) c.frame_index[0];
-  }
+  if (gTp && c.frame_index) gTp += 7 * (size_t) c.frame_index[0];
   p.gT = (gTp && i < 7) ? gTp[i] : 0.f;
   p.ls = i <= c.num_levels ? c.level_start[i] : 0;
   p.par = p.ln = 0;
@@ -174,7 +168,6 @@ __device__ __forceinline__ void forward_body_t(float* s_mem, const ChainArgs& c,
   float* s_gT = s_mem + 7 * (size_t) M;
   const float* global_T = c.global_T ? s_gT : nullptr;
   stage_global_T<PRE>(s_gT, c, pf);
-  if (c.global_T && c.global_T_row && tid < 7) c.global_T_row[tid] = s_gT[tid];  // (this thread staged that word)
   const Staged sk = stage_skeleton<PRE>(s_gT + 8, c, pf);
   if (tid == 0) {
     float* a = s_A + 7 * c.root;

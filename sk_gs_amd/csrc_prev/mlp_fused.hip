@@ -73,8 +73,7 @@ struct FusedArgs {
   float* g_x0;        // backward: [B, IN] or NULL
   unsigned* hdr;      // workspace header: [0] forward launches, [1] failed launches (sticky), [2] stamps wanted,
                       // [3] backward launches, [4] / [5] forward / backward launches whose exchange ran on plain stores
-                      // (xcd_mode 1: the census found the network on one XCD), [8..14] the frame's row of global_T (skeleton
-                      // forward -> backward), [16..63] stamps
+                      // (xcd_mode 1: the census found the network on one XCD), [16..63] stamps
   float* exch;        // this direction's exchange images [2][n_layers - 1][G][Bp][NC]
   int n_heads, head_dim[4];  // the last layer's columns split over separate [B, head_dim[j]] tensors (n_heads = 0: one tensor)
   float* head_out[4];        // forward
@@ -117,7 +116,6 @@ struct FusedArgs {
   // 2: the placement of 1, write-through stores throughout (A/B of the placement alone).
   // 3: mode 1 with a FALSIFIED census (tests: the fall-back path of a launch that is not on one XCD).
   int xcd_mode;
-  int side_delay;  // the side job's workgroups start this many x ~0.85 us late (the network's weight loads go first)
   unsigned* census;  // this direction's [2 parities][G][4 words]: (XCC_ID, 0, 0, 0) per network workgroup, sentinel-filled like the images
 };
 
@@ -157,25 +155,6 @@ __device__ __forceinline__ void stamp(const FusedArgs& a, const unsigned* s_misc
     ++si;
   }
 }
-
-// head_elem with every pointer and width read at a STATIC index (scalar kernel-argument loads that go out with the launch's first
-// batch) and selected by compares: a dynamic index into head_gout[] is a scalar load of its own from the host-visible argument
-// segment, a ~3 us round trip in front of the load it feeds
-__device__ __forceinline__ const float* head_elem_sel(const FusedArgs& a, const float* const* heads, const float* single, int row, int col,
-    int out) {
-  if (a.n_heads == 0) return single + (size_t) row * out + col;
-  const int d0 = a.head_dim[0], d1 = a.head_dim[1], d2 = a.head_dim[2], d3 = a.head_dim[3];
-  const float *h0 = heads[0], *h1 = heads[1], *h2 = heads[2], *h3 = heads[3];
-  const int n = a.n_heads;
-  const bool in0 = n == 1 || col < d0, in1 = n == 2 || col < d0 + d1, in2 = n == 3 || col < d0 + d1 + d2;
-  const float* base = in0 ? h0 : in1 ? h1 : in2 ? h2 : h3;
-  const int dim     = in0 ? d0 : in1 ? d1 : in2 ? d2 : d3;
-  const int off     = in0 ? 0 : in1 ? d0 : in2 ? d0 + d1 : d0 + d1 + d2;
-  return base + (size_t) row * dim + (col - off);
-}
-
-// diagnostics switch as every thread sees it (header word 2; a uniform load)
-__device__ __forceinline__ bool stamps_on_all(const FusedArgs& a) { return a.hdr[2] != 0; }
 
 // a produced value must never look like the "not written yet" pattern
 __device__ __forceinline__ float not_sentinel(float v) { return f2u(v) == SENTINEL ? u2f(0x7fc00000u) : v; }
@@ -411,7 +390,6 @@ __device__ __forceinline__ Role role_of(const FusedArgs& a) {
 }
 __device__ __forceinline__ void adam_side_job(const FusedArgs& a, int wg, int n_side) {
   if (!a.adam_tensors || a.adam_c1 <= a.adam_c0) return;  // (xcd_mode without a side range: the blocks between the network's just leave)
-  for (int i = 0; i < a.side_delay; ++i) __builtin_amdgcn_s_sleep(32);  // (experiment: 32 x 64 clocks ~ 0.85 us per unit)
   const int half = threadIdx.x >> 8, t256 = threadIdx.x & 255, lane = threadIdx.x & 63;
   const AdamCoef k = adam_coefficients(a.adam_beta1, a.adam_beta2, a.adam_eps, a.adam_step, a.adam_after_advance != 0);
   const AdamTensorLanes desc = adam_load_descriptors(a.adam_tensors, a.adam_n, lane);
@@ -684,41 +662,25 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
     for (int l = 0; l < nL; ++l)
       if (get_layer(a, l).in_x) x_total += NC * (pad32(get_layer(a, l).out) + 4);
   unsigned* s_misc = reinterpret_cast<unsigned*>(smem + a.lds_floats - 4);
-  // per-layer data the hop loop reads at a RUN-TIME layer index (the loop is rolled: one copy of its code, warm in the instruction
-  // cache after the first hop): the gW / gb pointers (a dynamic index into the kernel arguments is a scalar load from the
-  // host-visible argument segment); the ReLU masks of this workgroup's slab are four bits per layer in a register pair
-  float** s_ptr = reinterpret_cast<float**>(smem + a.lds_floats - 4 - 4 * KL);   // [KL][2]: gW_l, gb_l
-  static_assert(4 * (KL - 1) <= 64, "the ReLU masks of a thread's unit: four bits per layer in one 64-bit word");
-  unsigned long long relu_bits = 0;  // bit 4 l + k: element k of this thread's unit of a_l is > 0 (or layer l has no ReLU)
   const LaneMap lm = lane_map();
   int rowc[ROUNDS];
 #pragma unroll
   for (int rd = 0; rd < ROUNDS; ++rd) rowc[rd] = (8 * rd + lm.rgl < 4 * PASSES) ? 4 * (8 * rd + lm.rgl) + lm.j : lm.j;
 
   // ---- prologue: one memory round trip (see the forward kernel)
-  const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
   unsigned cnt = 0, stamps_on = 0;
   if (tid == 0) {
     const gu32* h = reinterpret_cast<const gu32*>((unsigned long long) a.hdr);
     cnt       = __hip_atomic_load(h + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     stamps_on = __hip_atomic_load(h + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // diagnostics: stamps 18.. of workgroup 0 = entry, chain inputs staged, weight slabs in LDS, chain levels walked
-  auto pstamp = [&](int slot, unsigned long long t) {
-    if (stamps_on && blockIdx.x == 0 && tid == 0) {
-      a.hdr[16 + 2 * slot]     = (unsigned) (t ? t : __builtin_amdgcn_s_memrealtime());
-      a.hdr[16 + 2 * slot + 1] = (unsigned) __builtin_amdgcn_s_memtime();
-    }
-  };
-  // EVERY global load of the prologue goes out now, in one batch: the chain backward's inputs (the frame's row of global_T from the
-  // copy the forward left in the workspace header -- read through frame_index[0] it was a second, dependent round trip), the heads'
-  // incoming gradient, the encoded input, the weights.  (Round 6, stamps of workgroup 0 beside the Adam stream: index -> row, then the
-  // weights' round trip, then the tree walk, then the head gradients' round trip, one after the other, were 15.8 us of prologue.  The
-  // walk cannot be made to overlap the weights' round trip from C++: hipcc's wait counts turn into vmcnt(0) at its first branch.)
-  chain::Prefetch cpf;
-  cpf.valid = false;
-  if (a.has_chain) cpf = chain::prefetch(a.chain, true, true);
-  pstamp(18, t_entry);
+  if (a.has_chain) {
+    // the chain backward's inputs first: one round trip into registers and from there into LDS, BEFORE the weight loads
+    // are issued (loads return in order: behind them this would wait for all of them; held in registers across them it
+    // spilled).  The tree walk itself runs below, on LDS only, while the weights are in flight.
+    const chain::Prefetch cpf = chain::prefetch(a.chain, true, true);
+    chain::backward_stage(s_part, a.chain, cpf);
+  }
   // the ReLU masks of this workgroup's slab, one 16-byte unit per thread and layer (threads < 2 Bp)
   const int mrow = tid >> 1, mpart = tid & 1;
   const bool mlive = tid < Bp * 2 && mrow < B;
@@ -737,16 +699,10 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
   const int wo = tid >> 1, wc4 = 4 * (tid & 1);  // (weight row o, group of four columns): NT units
   {
     const float* wp[KL];  // (see the forward prologue: all pointer loads up front, one wait)
-    float* gwp[KL];
-    float* gbp[KL];
 #pragma unroll
-    for (int l = 0; l < KL; ++l) wp[l] = a.W[l], gwp[l] = a.gW[l], gbp[l] = a.gb[l];
+    for (int l = 0; l < KL; ++l) wp[l] = a.W[l];
 #pragma unroll
-    for (int l = 0; l < KL; ++l) asm volatile("" : "+s"(wp[l]), "+s"(gwp[l]), "+s"(gbp[l]));
-    if (tid == 0) {
-#pragma unroll
-      for (int l = 0; l < KL; ++l) s_ptr[2 * l] = gwp[l], s_ptr[2 * l + 1] = gbp[l];
-    }
+    for (int l = 0; l < KL; ++l) asm volatile("" : "+s"(wp[l]));
 #pragma unroll
     for (int l = 0; l < KL; ++l) {
       am[l] = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -764,43 +720,11 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
       }
     }
   }
-  // the incoming gradient of the heads (gZ of the last layer) the chain does not produce: this thread's entries of the [Bp][64] image
-  // and of this workgroup's slab, fetched in the same batch, behind the weights (instead of behind the walk)
-  const int oL_pf = get_layer(a, nL - 1).out;
-  constexpr int GZQ = Bp * 64 / NT;
-  float hgz[GZQ], hown = 0.f;
-  {
-    const int c = tid & 63;
-#pragma unroll
-    for (int q = 0; q < GZQ; ++q) {
-      const int b = (tid >> 6) + q * (NT / 64);
-      hgz[q] = 0.f;
-      if (b < B && c < oL_pf && !(a.has_chain && c < 4))
-        hgz[q] = *head_elem_sel(a, a.head_gout, a.g_out, b, c, oL_pf);
-    }
-    const int bo = tid / NC, co = col0 + tid % NC;
-    if (tid < Bp * NC && bo < B && co < oL_pf && !(a.has_chain && co < 4))
-      hown = *head_elem_sel(a, a.head_gout, a.g_out, bo, co, oL_pf);
-  }
-  if (stamps_on_all(a)) {  // (diagnostics only: when every load of the batch is back)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    pstamp(22, 0);
-  }
-  if (a.has_chain) {  // (LDS only)
-    chain::backward_stage(s_part, a.chain, cpf);
-    pstamp(19, 0);
-    chain::backward_levels(s_part, a.chain, s_graw, g == 0);
-    __syncthreads();
-  }
-  pstamp(21, 0);
   {
     int toff = 0, xoff = t_total;
 #pragma unroll
     for (int l = 0; l < KL; ++l) {
       if (l < nL) {
-        if (l < nL - 1)
-          relu_bits |= (unsigned long long) ((am[l].x > 0.f ? 1u : 0u) | (am[l].y > 0.f ? 2u : 0u) | (am[l].z > 0.f ? 4u : 0u) | (am[l].w > 0.f ? 8u : 0u))
-                       << (4 * l);
         const int op = pad32(get_layer(a, l).out), OP = op + 4;
         if (wo < op) {  // rows out_l .. op_l - 1 are written as zeros
           if (l >= 1) {
@@ -817,23 +741,23 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
       }
     }
   }
-  pstamp(20, 0);
-  {  // gZ of the last layer = the incoming gradient (zero-padded to 64 columns); this workgroup's slab of it: the chain's part from
-     // LDS, the rest from the registers filled at the top
-    const int oL = oL_pf;
-    const int c = tid & 63;
-#pragma unroll
-    for (int q = 0; q < GZQ; ++q) {
-      const int b = (tid >> 6) + q * (NT / 64);
-      float v = hgz[q];
-      if (a.has_chain && c < 4 && b < B) v = s_graw[4 * b + c];
-      s_gz[b * HP + c] = (b < B && c < oL) ? v : 0.f;
+  if (a.has_chain) {  // (the loads above stay in flight behind this)
+    chain::backward_levels(s_part, a.chain, s_graw, g == 0);
+    __syncthreads();
+  }
+  {  // gZ of the last layer = the incoming gradient (zero-padded to 64 columns); this workgroup's slab of it
+    const int oL = get_layer(a, nL - 1).out;
+    auto g_in = [&](int b, int c) -> float {
+      if (a.has_chain && c < 4) return s_graw[4 * b + c];
+      return *head_elem(a, const_cast<float* const*>(a.head_gout), const_cast<float*>(a.g_out), b, c, oL);
+    };
+    for (int i = tid; i < Bp * 64; i += NT) {
+      const int b = i >> 6, c = i & 63;
+      s_gz[b * HP + c] = (b < B && c < oL) ? g_in(b, c) : 0.f;
     }
-    if (tid < Bp * NC) {
-      const int b = tid / NC, cc = col0 + tid % NC;
-      float v = hown;
-      if (a.has_chain && cc < 4 && b < B) v = s_graw[4 * b + cc];
-      s_own[(nL - 1) * Bp * NC + tid] = (b < B && cc < oL) ? v : 0.f;
+    for (int i = tid; i < Bp * NC; i += NT) {
+      const int b = i / NC, c = i - b * NC;
+      s_own[(nL - 1) * Bp * NC + i] = (b < B && col0 + c < oL) ? g_in(b, col0 + c) : 0.f;
     }
   }
   if (tid == 0) s_misc[0] = cnt, s_misc[1] = 0, s_misc[2] = stamps_on;
@@ -859,14 +783,14 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
   // ---- (A) the dependent chain: gA_{l-1}[:, slab] = gZ_l W_l[:, slab], masked by the ReLU of layer l-1.  The slabs were
   // laid out by increasing layer: walk their offsets backwards.
   int tcur = t_total, xcur = t_total + x_total;
-#pragma unroll 1
-  for (int l = nL - 1; l >= 1; --l) {  // ROLLED: every hop runs the same instructions (unrolled nine times the body was ~130 KB of code,
-    {                                   // each hop's copy fetched cold; the per-layer data comes from LDS / masks instead of kernel arguments)
-      const int L_out = l == nL - 1 ? a.out_last : H, L_in_x = ((a.xmask >> l) & 1u) ? a.IN : 0, L_in_h = H;
-      float* const L_gW = s_ptr[2 * l];
-      const int op = pad32(L_out), OP = op + 4;
+#pragma unroll
+  for (int lu = KL - 1; lu >= 1; --lu) {  // compile-time index: am[] stays in registers
+    if (lu < nL) {
+      const int l = lu;
+      const FusedLayer L = get_layer(a, l);
+      const int op = pad32(L.out), OP = op + 4;
       const bool publish = l - 1 >= 1 || a.g_x0 != nullptr;  // gZ_0 is only exchanged for the input gradient
-      const bool do_x = want_gx && L_in_x;
+      const bool do_x = want_gx && L.in_x;
       tcur -= NC * OP;
       if (do_x) xcur -= NC * OP;
       if (gw_dst) {  // the previous iteration's weight-gradient block
@@ -879,7 +803,7 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
       // load per row, all in flight behind the chain product below; the outer products run after the publish, while the
       // other workgroups' slabs are on their way (nothing on the chain waits for them).  (Loading them one iteration
       // ahead, into a second register set, was slower: 30.6 -> 32.2 us.)
-      const bool wg_rows = col0 < L_out;
+      const bool wg_rows = col0 < L.out;
       float av[Bp];
       if (wg_rows) load_act_column<Bp>(av, a.acts + (size_t) (l - 1) * B * H + kcol, B);
       f4 acc[ROUNDS][2];
@@ -895,9 +819,9 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
       __syncthreads();  // partials complete; s_gz has been read
       if (tid < Bp * 2) {
         float4 y = sum_partials(s_part, Bp, mrow, mpart);
-        const unsigned m = (unsigned) (relu_bits >> (4 * (l - 1)));
-        y.x = (mlive && (m & 1u)) ? not_sentinel(y.x) : 0.f, y.y = (mlive && (m & 2u)) ? not_sentinel(y.y) : 0.f;
-        y.z = (mlive && (m & 4u)) ? not_sentinel(y.z) : 0.f, y.w = (mlive && (m & 8u)) ? not_sentinel(y.w) : 0.f;
+        const float4 m = am[lu - 1];
+        y.x = (mlive && m.x > 0.f) ? not_sentinel(y.x) : 0.f, y.y = (mlive && m.y > 0.f) ? not_sentinel(y.y) : 0.f;
+        y.z = (mlive && m.z > 0.f) ? not_sentinel(y.z) : 0.f, y.w = (mlive && m.w > 0.f) ? not_sentinel(y.w) : 0.f;
         if (publish && mlive) store16_exch(img + ((size_t) (l - 1) * G + g) * Bp * NC + 4 * tid, y, plain);
         *reinterpret_cast<float4*>(s_own + (l - 1) * Bp * NC + 4 * tid) = y;  // kept for the weight gradients
       }
@@ -913,8 +837,8 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
         }
         // (stored at the top of the next iteration: stores still in flight here would be waited for by the gather's
         // s_waitcnt vmcnt(0) together with its loads)
-        gw_dst = L_gW + (size_t) (col0 + 4 * lm.cg) * (L_in_h + L_in_x) + kcol;  // D: VGPR i = row 4 cg + i of the slab
-        gw_ld = L_in_h + L_in_x, gw_rows = L_out - (col0 + 4 * lm.cg);
+        gw_dst = L.gW + (size_t) (col0 + 4 * lm.cg) * (L.in_h + L.in_x) + kcol;  // D: VGPR i = row 4 cg + i of the slab
+        gw_ld = L.in_h + L.in_x, gw_rows = L.out - (col0 + 4 * lm.cg);
       }
       if (publish) {
         const bool ok = gather_slabs<U>(img + (size_t) (l - 1) * G * Bp * NC, s_gz, B, Bp, HP, B * H / 4, census, census_word);
@@ -975,7 +899,7 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
     }
     __syncthreads();
     for (int l = nL - 1; l >= 0; --l) {
-      struct { int out, in_x, in_h; float* gW; } L = {l == nL - 1 ? a.out_last : H, ((a.xmask >> l) & 1u) ? a.IN : 0, l ? H : 0, s_ptr[2 * l]};
+      const FusedLayer L = get_layer(a, l);
       if (col0 >= L.out || !L.in_x) continue;
       const int K = L.in_h + L.in_x;
       const float* own = s_own + l * Bp * NC;
@@ -997,7 +921,7 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
     // chains of B dependent LDS reads, 5 us at the end of the launch
     for (int i = tid; i < nL * NC; i += NT) {
       const int l = i / NC, c = i - l * NC;
-      struct { int out; float* gb; } L = {l == nL - 1 ? a.out_last : H, s_ptr[2 * l + 1]};
+      const FusedLayer L = get_layer(a, l);
       if (L.gb && col0 + c < L.out) {
         const float* own = s_own + l * Bp * NC + c;
         float sum = 0.f;
@@ -1082,7 +1006,6 @@ int fill_chain(const skgs_mlp_desc* d, const Plan& p, const skgs_bone_chain_desc
   c.M = b->M, c.root = b->root, c.num_levels = b->num_levels, c.parents = b->parents, c.level_nodes = b->level_nodes;
   c.level_start = b->level_start, c.joints = b->joints, c.global_T = b->global_T, c.frame_index = b->frame_index;
   c.bone_T = b->bone_T, c.chain_A = b->chain_A;
-  c.global_T_row = reinterpret_cast<float*>(a->hdr + 8);  // header words 8..14: the frame's row, forward -> backward (a.hdr is set before)
   a->sk_cache = b->sk_cache;
   return 0;
 }
@@ -1122,10 +1045,6 @@ int launch(KernelT k, const Plan& p, const FusedArgs& a, size_t lds, hipStream_t
     side = (int) std::max<long long>(1, std::min<long long>((a.adam_c1 - a.adam_c0 + 1) / 2, num_cus() - p.G));  // never 0: the rows MUST be updated
   FusedArgs b = a;
   int grid = p.G + side;
-  {
-    static const int delay = [] { const char* e = getenv("SKGS_SIDE_DELAY"); return e ? std::max(0, atoi(e)) : 0; }();
-    b.side_delay = delay;
-  }
   b.xcd_mode = xcd_mode_wanted();
   if (b.xcd_mode) {  // the network on blocks 0, 8, .. 8 (G - 1): the grid must reach the last of them
     if (num_cus() != 256 || p.G != G_NET || (side > 0 && grid < 8 * p.G - 7)) b.xcd_mode = 0;
@@ -1266,7 +1185,6 @@ int backward_impl(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, con
   FusedArgs a{};
   fill_args(d, p, &a);
   a.points = points, a.t = t, a.x0 = const_cast<float*>(x0), a.acts = const_cast<float*>(acts), a.g_out = g_out, a.g_x0 = g_x0;
-  a.hdr = reinterpret_cast<unsigned*>(workspace);
   if (bones) {
     if (fill_chain(d, p, bones, &a)) return 1;
     SKGS_REQUIRE(bones->sk_r_raw && bones->chain_A && bones->g_bone_T, "skeleton_backward: sk_r_raw / chain_A / g_bone_T is NULL");
@@ -1280,7 +1198,6 @@ int backward_impl(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, con
   a.exch = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + HDR_BYTES + p.exch_bytes);
   a.census = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(a.exch) + p.exch_bytes - CENSUS_BYTES);
   size_t fl = (size_t) p.Bp * HP + (size_t) (d->n_layers + NW) * p.Bp * NC + (size_t) p.Bp * 4 + 4;
-  fl += (size_t) 4 * KL;  // the hop loop's per-layer table: gW / gb pointers
   for (int l = 1; l < d->n_layers; ++l) fl += (size_t) NC * (pad32(d->layer[l].out) + 4);
   if (g_x0)
     for (int l = 0; l < d->n_layers; ++l)

@@ -66,3 +66,9 @@ torch.cuda.synchronize()
 st = run.workspace[64:256].view(torch.int32).cpu().tolist()
 for i, name in zip(range(13, 16), ('chain (8 hops)', 'input gradient', 'weight gradients')):
     print(f'backward {name:>18}: +{((st[2 * i] - st[2 * i - 2]) & 0xffffffff) * 10} ns')
+# the backward's prologue: stamps 18, 19, 21, 20 = entry, chain inputs staged, chain levels walked, weight slabs in LDS; 12 = prologue done
+seq = [(19, 'chain inputs staged'), (21, 'chain levels walked'), (20, 'weight slabs in LDS'), (12, 'prologue done (gZ of the last layer, re-poison)')]
+prev = 18
+for i, name in seq:
+    print(f'backward prologue {name:>48}: +{((st[2 * i] - st[2 * prev]) & 0xffffffff) * 10} ns')
+    prev = i

@@ -89,6 +89,10 @@ torch.cuda.synchronize()
 st = run.workspace[64:256].view(torch.int32).cpu().tolist()
 for i, name in zip(range(13, 16), ('chain (8 hops)', 'input gradient', 'weight gradients')):
     print(f'  with side job, backward {name:>18}: +{((st[2 * i] - st[2 * i - 2]) & 0xffffffff) * 10} ns')
+prev = 18   # the backward's prologue: stamps 18, 19, 21, 20 = entry, chain inputs staged, chain levels walked, weight slabs in LDS; 12 = prologue done
+for i, name in ((22, 'every load back'), (19, 'chain inputs staged'), (21, 'chain levels walked'), (20, 'weight slabs in LDS'), (12, 'prologue done')):
+    print(f'  with side job, backward prologue {name:>22}: +{((st[2 * i] - st[2 * prev]) & 0xffffffff) * 10} ns')
+    prev = i
 
 # ---- the rows' update split between the backward launch and the (next view's) forward launch: time of the pair
 def pair_time(frac, P):
