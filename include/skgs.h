@@ -636,6 +636,10 @@ int skgs_deform_mlp_workspace_init(void* workspace, size_t workspace_bytes, skgs
  *      Measured at config #1: skeleton forward 37.1 -> 34.4 us, skeleton backward (the rows' Adam on the other seven XCDs, none
  *      beside the network) 58.6 -> 53.4 us, the step 0.3388 -> 0.3294 ms.
  *   2: the placement of 1 with write-through stores throughout;  3: mode 1 with a falsified census (tests of the fall-back).
+ * Mode 1 is for ONE fused network launch at a time per device (a training process): its 32 workgroups fill one XCD (one per CU),
+ * so two such launches dispatched in the same microsecond to the same XCD would each hold CUs the other's missing workgroups
+ * need, and both would give up after their bounded spins (status word 1; never a wrong result).  Processes that share a GPU and
+ * run in lockstep (SKGS_SHARE_GPU=1) therefore default to mode 0; callers that launch from several streams at once choose 0 too.
  * No reference counterpart (the reference runs the network as ~65 torch launches, networks/sk_gs.py:1073-1074). */
 int32_t skgs_deform_mlp_xcd_mode(int32_t mode);
 int skgs_deform_mlp_forward(const skgs_mlp_desc* d, const float* points, const float* t, float* x0, float* acts, float* out,

@@ -1103,11 +1103,18 @@ int backward_impl(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, con
     const float* x0, const float* acts, const float* g_out, float* g_x0, void* workspace, size_t workspace_bytes,
     const skgs_adam_range* side, skgs_stream_t stream);
 
-int g_xcd_mode = -1;  // -1: not decided yet (the environment's SKGS_MLP_XCD, default 1)
+// Mode 1 puts all 32 network workgroups of a launch on ONE XCD, one per CU (the launch's LDS request): TWO such launches dispatched
+// within the same microsecond to the same XCD interleave on its 32 CUs, and each then holds CUs the other's missing workgroups
+// need -- both give up after their bounded spins (a loud failure, never a wrong result).  One launch at a time per device is what a
+// training process does; ranks that SHARE a GPU (SKGS_SHARE_GPU=1: the tests' stand-in for a multi-GPU node) run in lockstep and do
+// hit that window (1 of 3 sessions, 2 ranks): they get mode 0, where the network's workgroups are the first blocks of their
+// launch, four per XCD, and eight launches fit side by side.
+int g_xcd_mode = -1;  // -1: not decided yet (the environment's SKGS_MLP_XCD; default 1, or 0 with SKGS_SHARE_GPU=1)
 inline int xcd_mode_wanted() {
   if (g_xcd_mode < 0) {
     const char* e = getenv("SKGS_MLP_XCD");
-    g_xcd_mode = e ? std::max(0, std::min(3, atoi(e))) : 1;
+    const char* shared = getenv("SKGS_SHARE_GPU");
+    g_xcd_mode = e ? std::max(0, std::min(3, atoi(e))) : ((shared && atoi(shared) != 0) ? 0 : 1);
   }
   return g_xcd_mode;
 }

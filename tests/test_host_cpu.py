@@ -682,3 +682,18 @@ def test_fuzz_bound_table_matches_the_rule_the_tests_apply():
     for e in t['second_branch']:
         assert e['err_vs_fp32_oracle'] > 1e-4 and e['err_vs_fp64_oracle'] <= e['bound_vs_fp64']
         assert abs(e['bound_vs_fp64'] - max(1e-4, helpers.REF_ERR_FACTOR * e['ref_err'])) <= 1e-12
+
+
+def test_where_the_deform_network_runs_by_default():
+    """``skgs_deform_mlp_xcd_mode`` (a host function: no GPU needed): one XCD for the network's 32 workgroups by default, blocks 0..31 for
+    ranks that share a GPU (two launches dispatched to one XCD in the same microsecond would starve each other: include/skgs.h), the
+    environment's explicit choice over both"""
+    import subprocess
+    code = ("import ctypes, os; lib = ctypes.CDLL(os.path.join(%r, 'sk_gs_amd', 'libskgs_hip.so')); "
+            "lib.skgs_deform_mlp_xcd_mode.restype = ctypes.c_int32; print(lib.skgs_deform_mlp_xcd_mode(ctypes.c_int32(-1)), "
+            "lib.skgs_deform_mlp_xcd_mode(ctypes.c_int32(2)), lib.skgs_deform_mlp_xcd_mode(ctypes.c_int32(-1)))" % ROOT)
+    base = {k: v for k, v in os.environ.items() if k not in ('SKGS_SHARE_GPU', 'SKGS_MLP_XCD')}
+    for extra, want in (({}, '1 1 2'), ({'SKGS_SHARE_GPU': '1'}, '0 0 2'), ({'SKGS_SHARE_GPU': '1', 'SKGS_MLP_XCD': '1'}, '1 1 2'),
+                        ({'SKGS_MLP_XCD': '0'}, '0 0 2')):
+        p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120, env=dict(base, **extra))
+        assert p.returncode == 0 and p.stdout.split() == want.split(), (extra, p.stdout, p.stderr[-500:])
