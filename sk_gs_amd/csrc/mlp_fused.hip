@@ -73,7 +73,8 @@ struct FusedArgs {
   float* g_x0;        // backward: [B, IN] or NULL
   unsigned* hdr;      // workspace header: [0] forward launches, [1] failed launches (sticky), [2] stamps wanted,
                       // [3] backward launches, [4] / [5] forward / backward launches whose exchange ran on plain stores
-                      // (xcd_mode 1: the census found the network on one XCD), [8..14] the frame's row of global_T (skeleton
+                      // (xcd_mode 1: the census found the network on one XCD), [6] / [7] bit x: workgroup 0 of a forward /
+                      // backward launch has run on XCD x, [8..14] the frame's row of global_T (skeleton
                       // forward -> backward), [16..63] stamps
   float* exch;        // this direction's exchange images [2][n_layers - 1][G][Bp][NC]
   int n_heads, head_dim[4];  // the last layer's columns split over separate [B, head_dim[j]] tensors (n_heads = 0: one tensor)
@@ -647,6 +648,7 @@ __global__ void __launch_bounds__(NT) fused_mlp_forward_kernel(const FusedArgs a
     gu32* h = reinterpret_cast<gu32*>((unsigned long long) a.hdr);
     if (s_misc[1]) __hip_atomic_fetch_add(h + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (plain) __hip_atomic_fetch_add(h + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // launches whose exchange stayed in one L2
+    __hip_atomic_fetch_or(h + 6, 1u << (xcc_id() & 7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the XCDs workgroup 0 has run on
     __hip_atomic_store(h, count + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -1012,6 +1014,7 @@ __global__ void __launch_bounds__(NT) fused_mlp_backward_kernel(const FusedArgs 
     gu32* h = reinterpret_cast<gu32*>((unsigned long long) a.hdr);
     if (s_misc[1]) __hip_atomic_fetch_add(h + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (plain) __hip_atomic_fetch_add(h + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_or(h + 7, 1u << (xcc_id() & 7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(h + 3, count + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }

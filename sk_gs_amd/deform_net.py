@@ -369,9 +369,10 @@ class FusedDeformMLP:
     def status(self) -> dict:
         """(synchronising) forward / backward launches so far and 'failed': launches whose in-kernel exchange timed out
         (must be 0); ``one_xcd_*``: launches whose in-launch census found all of the network's workgroups on one XCD and kept the
-        exchange inside its L2 (``skgs_deform_mlp_xcd_mode``)"""
+        exchange inside its L2 (``skgs_deform_mlp_xcd_mode``); ``xcds_*``: the XCDs workgroup 0 of a launch has run on so far"""
         w = self.workspace[:32].view(torch.int32).cpu()
-        return dict(forward=int(w[0]), backward=int(w[3]), failed=int(w[1]), one_xcd_forward=int(w[4]), one_xcd_backward=int(w[5]))
+        return dict(forward=int(w[0]), backward=int(w[3]), failed=int(w[1]), one_xcd_forward=int(w[4]), one_xcd_backward=int(w[5]),
+                    xcds_forward=[x for x in range(8) if int(w[6]) >> x & 1], xcds_backward=[x for x in range(8) if int(w[7]) >> x & 1])
 
 
 _FUSED_POOLS = weakref.WeakKeyDictionary()  # DeformMLP -> {(rows, device, stream): [free FusedDeformMLP runners]}

@@ -255,6 +255,45 @@ def test_fused_deform_mlp_where_the_network_runs(mode):
         lib.skgs_deform_mlp_xcd_mode(C.c_int32(before))
 
 
+@pytest.mark.parametrize('mode', [0, 1])
+def test_fused_deform_mlp_never_reads_an_earlier_launch(mode):
+    """The in-launch exchange validates a word by its VALUE (anything but the sentinel): a word left over from an earlier launch of the
+    same parity would pass as data.  The re-poisoning between launches and the kernel boundary's cache maintenance must therefore hold in
+    every placement -- in mode 1 the slabs stay in ONE XCD's L2 and the network's XCD may change from launch to launch.  96 launches per
+    direction on one workspace, fresh inputs AND fresh weights in every one (the working set is far too small to evict anything), each
+    checked against torch: a stale slab would show as another launch's activations."""
+    from sk_gs_amd import _C
+    from sk_gs_amd.deform_net import DeformMLP, FusedDeformMLP
+    lib = _C.load_library()
+    lib.skgs_deform_mlp_xcd_mode.restype = C.c_int32
+    before = lib.skgs_deform_mlp_xcd_mode(C.c_int32(mode))
+    try:
+        torch.manual_seed(5)
+        mlp = DeformMLP().cuda()
+        B = 20
+        run = FusedDeformMLP(mlp, B)
+        worst = 0.0
+        for it in range(96):
+            with torch.no_grad():
+                for p in mlp.parameters():
+                    p.add_(torch.randn_like(p) * 0.02)
+                mlp.dynamic_net.last_weight.normal_(0, 0.1)
+            joints, t, g = torch.rand(B, 3, device='cuda') - 0.5, torch.rand(1, device='cuda'), torch.randn(B, 11, device='cuda')
+            ref_out, ref_acts, ref_grads, ref_gx0, _ = _ref_with_input_grad(mlp, joints, t, g)
+            grads, g_x0 = [torch.zeros_like(r) for r in ref_grads], torch.zeros_like(ref_gx0)
+            out = run.forward(joints, t)
+            run.backward(joints, t, g, grads, g_x0)
+            errs = [rel_err(out, ref_out), rel_err(run.acts, ref_acts), rel_err(g_x0, ref_gx0)] + [rel_err(a, r) for a, r in zip(grads, ref_grads)]
+            worst = max(worst, max(float(e) for e in errs))
+            assert worst <= 1e-4, (mode, it, errs)
+        st = run.status()
+        assert (st['forward'], st['backward'], st['failed']) == (96, 96, 0)
+        print(f'[xcd] mode {mode}: 96 launches per direction with fresh inputs and weights, worst relative error {worst:.2e}; '
+              f'on one XCD: {st["one_xcd_forward"]} / {st["one_xcd_backward"]}; workgroup 0 ran on XCDs {st["xcds_forward"]} / {st["xcds_backward"]}')
+    finally:
+        lib.skgs_deform_mlp_xcd_mode(C.c_int32(before))
+
+
 def test_fused_deform_mlp_other_shapes():
     """no skip, two skips, a skip right before the heads with another encoder; shapes outside the fused kernels' range
     are reported as unsupported (the per-layer path takes them)"""

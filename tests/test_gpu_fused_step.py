@@ -282,8 +282,12 @@ def test_one_graph_serves_every_view_through_the_device_view_slot():
         assert torch.equal(slot.image, img), v
         assert torch.equal(slot.loss3, loss3), v
         for n, p in model.named_parameters():
-            # identical kernels on identical inputs; only the float atomics of the blend backward may reorder
-            assert_close_robust(p.grad, grads[n], 1e-4, 1e-3, name=f'{n} view {v}')
+            # identical kernels on identical inputs; only the float atomics of the blend backward may reorder.  The logit table's
+            # gradient is the softmax backward w_k (g_k - sum_j w_j g_j): a difference of nearly equal sums that turns the atomics'
+            # 1e-7 into quantised steps of 1.9e-5 .. 1.9e-4 of the tensor's largest entry (29 sessions of rounds 5-6: 1.0e-4 in every
+            # third, 1.9e-4 in two, at one or two of 30 000 elements) -- 1e-4 with ONE element allowed over it was a coin that came up
+            # red once (profiles/r06_m_gpu_tests_rc.txt); 5e-4 for that tensor, 1e-4 for every other
+            assert_close_robust(p.grad, grads[n], 5e-4 if n == 'sp_W' else 1e-4, 1e-3, name=f'{n} view {v}')
         assert float(model.global_tr.grad[fix[v]].abs().sum()) > 0
         others = [f for f in range(frames) if f != fix[v]]
         assert float(model.global_tr.grad[others].abs().sum()) == 0 or not slot.tables_zeroed_by_optimizer
@@ -835,10 +839,13 @@ def test_fused_train_step_behind_the_autograd_api():
         counts.append(int(opt.step_state[0].item()))
         runs.append(({n: p.detach().clone() for n, p in model.named_parameters()}, losses))
     assert counts[0] == counts[1] == 3
+    print('[api-vs-direct] losses, relative:', ' '.join(f'{abs(a - b) / abs(b):.1e}' for a, b in zip(runs[0][1], runs[1][1])))
     for a, b in zip(runs[0][1], runs[1][1]):
         assert abs(a - b) <= 1e-4 * abs(b)
     for n in runs[0][0]:
         a, b = runs[0][0][n], runs[1][0][n]
+        print(f'[api-vs-direct] {n}: max {float((a - b).abs().max()):.2e}, far '
+              f'{float(((a - b).abs() > max(1e-5 * float(b.abs().max()), 2e-6)).float().mean()):.2e}')
         assert float((a - b).abs().max()) <= 2 * 3 * 50 * 1e-3, n
         # (threshold: 1e-5 of the tensor's size, or 0.2 % of ONE step at lr 1e-3 for tensors as small as the network's head weights -- the
         # atomics' 1e-7..1e-6 relative noise in a gradient moves an Adam update by ~1e-4 of its size: two DIRECT runs
