@@ -489,6 +489,8 @@ __global__ void __launch_bounds__(NT) fused_mlp_forward_kernel(const FusedArgs a
     stamps_on = __hip_atomic_load(h + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   chain::Prefetch cpf;  // the kinematic chain's inputs (workgroup 0 runs it after the heads): loaded with everything else
+  int frame_pf = 0;     // the frame's row of the test-time cache (the workgroups that own the heads' columns)
+  if (a.sk_cache && a.chain.frame_index && col0 < a.out_last) frame_pf = a.chain.frame_index[0];
   cpf.valid = false;
   if (a.has_chain && g == 0) cpf = chain::prefetch(a.chain, false, false);
   // encoded input entry (b, c): c = tid & 127 is the same for all of a thread's entries (INP = 128), so everything that
@@ -603,12 +605,12 @@ __global__ void __launch_bounds__(NT) fused_mlp_forward_kernel(const FusedArgs a
         if (last) {
           const int c = col0 + 4 * part;
           if (c == 0) *reinterpret_cast<float4*>(s_raw + 4 * row) = y;
-          if (c < L.out) *head_elem(a, a.head_out, a.out, row, c, L.out) = y.x;
-          if (c + 1 < L.out) *head_elem(a, a.head_out, a.out, row, c + 1, L.out) = y.y;
-          if (c + 2 < L.out) *head_elem(a, a.head_out, a.out, row, c + 2, L.out) = y.z;
-          if (c + 3 < L.out) *head_elem(a, a.head_out, a.out, row, c + 3, L.out) = y.w;
+          if (c < L.out) *const_cast<float*>(head_elem_sel(a, a.head_out, a.out, row, c, L.out)) = y.x;
+          if (c + 1 < L.out) *const_cast<float*>(head_elem_sel(a, a.head_out, a.out, row, c + 1, L.out)) = y.y;
+          if (c + 2 < L.out) *const_cast<float*>(head_elem_sel(a, a.head_out, a.out, row, c + 2, L.out)) = y.z;
+          if (c + 3 < L.out) *const_cast<float*>(head_elem_sel(a, a.head_out, a.out, row, c + 3, L.out)) = y.w;
           if (a.sk_cache) {  // (no_grad copy for test-time interpolation, sk_gs.py:1077-1085)
-            const int frame = a.chain.frame_index ? a.chain.frame_index[0] : 0;
+            const int frame = frame_pf;  // (fetched in the prologue: here it was a round trip in front of the cache row's stores)
             float* cr = a.sk_cache + ((size_t) frame * B + row) * L.out;
             if (c == 0) {  // F.normalize(raw + [0, 0, 0, 1]): the expression of chain::stage_skeleton
               const chain::Q4 q = chain::qnormalize({y.x, y.y, y.z, y.w + 1.0f});
