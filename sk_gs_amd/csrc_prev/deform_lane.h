@@ -145,25 +145,16 @@ inline size_t deform_bwd_lds_bytes(int M) {
   const int Mp = (M + 3) & ~3;
   return ((size_t) M * BONE_F + 4 * 64 * (size_t) Mp + 4 * 64 * MOM_U + 4 * (size_t) M * MOM_F) * 4;
 }
-__device__ __forceinline__ void deform_bwd_lane_clear(DeformBwdLane& L) {
+__device__ __forceinline__ void deform_bwd_prefetch(const DeformBwdArgs& a, int n, bool valid, DeformBwdLane& L) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) L.p[c] = 0.f, L.ls[c] = 0.f;
   L.ol = 0.f, L.r4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int q = 0; q < PREF_K; ++q) L.j[q] = 0, L.w[q] = 0.f;
-}
-__device__ __forceinline__ void deform_bwd_prefetch(const DeformBwdArgs& a, int n, bool valid, DeformBwdLane& L) {
-  deform_bwd_lane_clear(L);
   if (valid) {
-    // (branch-free: a slot behind K re-reads slot 0 and is zeroed by a select -- a branch per slot made every slot a basic block of
-    // its own, and hipcc's wait counts at their heads serialised the slots' loads behind one another)
 #pragma unroll
-    for (int q = 0; q < PREF_K; ++q) {
-      const int qq  = q < a.K ? q : 0;
-      const int jv  = (int) a.indices[(size_t) n * a.K + qq];
-      const float wv = a.weights[(size_t) n * a.K + qq];
-      L.j[q] = q < a.K ? jv : 0, L.w[q] = q < a.K ? wv : 0.f;
-    }
+    for (int q = 0; q < PREF_K; ++q)
+      if (q < a.K) L.j[q] = (int) a.indices[(size_t) n * a.K + q], L.w[q] = a.weights[(size_t) n * a.K + q];
 #pragma unroll
     for (int c = 0; c < 3; ++c) L.p[c] = a.points[3 * n + c], L.ls[c] = a.log_scale[3 * n + c];
     L.r4 = reinterpret_cast<const float4*>(a.rot)[n], L.ol = a.opacity_logit[n];

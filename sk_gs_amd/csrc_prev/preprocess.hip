@@ -325,8 +325,11 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
   // the number of Gaussians as a device word (one captured graph survives densification): rows [live, P) of the capacity
   // get an all-zero record and radius 0 -- what a culled Gaussian gets -- so nothing downstream needs to know
   const int P_cap = P;
-  // (the two device words -- live count, field of view -- are read BEHIND the per-Gaussian loads below: in front of them each was a
-  // scalar round trip of its own before the first vector load went out, on a kernel whose duration is one lane's dependency chain)
+  if (live) P = min(P, live[0]);
+  if (tanfov_dev) {  // same expressions as the host launcher: identical bits
+    tan_fovx = tanfov_dev[0], tan_fovy = tanfov_dev[1];
+    focal_x = W / (2.0f * tan_fovx), focal_y = H / (2.0f * tan_fovy);
+  }
   // Every per-Gaussian input of the lane is requested HERE, before the camera and the SH rows are staged: the kernel runs at
   // 1.5 waves per SIMD and 64 % of its wave time was spent in s_waitcnt (tools/pmc_kernel.sh) on a chain of four dependent
   // round trips -- camera, SH staging, mean, then scale / rotation / opacity behind the cull test.  Now they are one.  (Rows up
@@ -368,11 +371,6 @@ __global__ void __launch_bounds__(PRE_THREADS) preprocess_forward_kernel(int P, 
   __shared__ Cam cam;  // (its three loads ride in the same round trip; stored to LDS behind the SH rows, ONE barrier for both)
   const float cam_v = threadIdx.x < 16 ? viewmatrix[threadIdx.x] : 0.f, cam_p = threadIdx.x < 16 ? projmatrix[threadIdx.x] : 0.f;
   const float cam_c = threadIdx.x < 3 ? campos[threadIdx.x] : 0.f;
-  if (live) P = min(P, live[0]);
-  if (tanfov_dev) {  // same expressions as the host launcher: identical bits
-    tan_fovx = tanfov_dev[0], tan_fovy = tanfov_dev[1];
-    focal_x = W / (2.0f * tan_fovx), focal_y = H / (2.0f * tan_fovy);
-  }
   // the per-tile counters of the next kernel (binning.hip: count_tiles) start from zero: cleared here, not by a fill launch
   for (int t = idx; t < gx * gy; t += gridDim.x * blockDim.x) tile_counts[t] = 0u;
   if (hdr_bucket && idx == 0) {  // no scan kernel in the bucket layout: R and the longest list are not computed
@@ -671,46 +669,6 @@ __global__ void __launch_bounds__(PRE_BWD_THREADS) preprocess_backward_kernel(in
     const int32_t* __restrict__ live, float* __restrict__ stat_accum, float* __restrict__ stat_denom,
     float* __restrict__ stat_max_radii, float stat_mult, DeformBwdArgs dbj, SpRowsArgs srj) {
   constexpr bool DBJ = JOB == 1;
-  // (the two device words -- live count, field of view -- and the camera are read BEHIND the per-Gaussian loads below: in front of them
-  // each was a round trip of its own before the first of those loads went out; rows up to the launch's P, the capacity, exist)
-  const int P_cap = P;
-  __shared__ Cam cam;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  // SH rows of this workgroup -> LDS; the gradient rows are built in the same LDS rows (sh_backward reads before it
-  // writes) and leave as one contiguous span at the end.  The DC term is not read by the backward.
-  extern __shared__ float s_sh[];
-  const bool staged = shs != nullptr && (dL_dsh != nullptr || sh_factors != nullptr);
-  const int RL      = shs_rest ? (M - 1) * 3 : M * 3;
-  const int base = blockIdx.x * blockDim.x;
-  // Every per-Gaussian input is requested BEFORE the SH staging barrier, unconditionally: radius -> gradient row ->
-  // record -> mean / scale / rotation used to be a chain of dependent round trips behind `visible` (the kernel runs at
-  // ~1.5 waves per SIMD: its duration is the length of one lane's dependency chain).
-  int pf_radius = 0;
-  float4 pf_row[4], pf_rec[3], pf_q = make_float4(0.f, 0.f, 0.f, 1.f);
-  float pf_p[3] = {0.f, 0.f, 0.f}, pf_s[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) pf_row[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  pf_rec[0] = pf_rec[1] = pf_rec[2] = pf_row[0];
-  {
-    // UNCONDITIONAL loads at a clamped row (a lane behind the capacity reads row 0 and uses nothing): under `if (idx < P)` hipcc
-    // gave the zero defaults of the other lanes the registers of loads still in flight -- two `s_waitcnt vmcnt(2)` in the middle
-    // of the batch, i.e. three round trips where one was meant
-    const int ld = idx < P_cap ? idx : 0;
-    pf_radius = radii[ld];
-    const float* row = gradacc + (size_t) ld * GRAD_ROW;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) pf_row[i] = stream_load4<NT_GRADROW_LOAD>(row + 4 * i);
-    pf_rec[0] = recs[3 * ld], pf_rec[1] = recs[3 * ld + 1], pf_rec[2] = recs[3 * ld + 2];
-    pf_p[0] = means3D[3 * ld], pf_p[1] = means3D[3 * ld + 1], pf_p[2] = means3D[3 * ld + 2];
-    if (scales) {
-      pf_s[0] = scales[3 * ld], pf_s[1] = scales[3 * ld + 1], pf_s[2] = scales[3 * ld + 2];
-      pf_q = reinterpret_cast<const float4*>(rotations)[ld];
-    }
-  }
-  DeformBwdLane dbl;  // (DBJ) the deform backward's own per-Gaussian inputs ride in the same round trip
-  if constexpr (DBJ) deform_bwd_prefetch(dbj, idx < P_cap ? idx : 0, true, dbl);
-  const float cam_v = threadIdx.x < 16 ? viewmatrix[threadIdx.x] : 0.f, cam_p = threadIdx.x < 16 ? projmatrix[threadIdx.x] : 0.f;
-  const float cam_c = threadIdx.x < 3 ? campos[threadIdx.x] : 0.f;
   if (live) P = min(P, live[0]);  // the number of Gaussians is a device word: one captured graph survives densification
   if ((int) (blockIdx.x * blockDim.x) >= P) {  // a workgroup of the capacity's slack rows (before any barrier)
     if constexpr (DBJ) deform_bwd_zero_partials(dbj);
@@ -720,13 +678,42 @@ __global__ void __launch_bounds__(PRE_BWD_THREADS) preprocess_backward_kernel(in
     tan_fovx = tanfov_dev[0], tan_fovy = tanfov_dev[1];
     focal_x = W / (2.0f * tan_fovx), focal_y = H / (2.0f * tan_fovy);
   }
-  if (idx >= P) {  // a row between the live count and the capacity: culled, whatever the prefetch read
-    pf_radius = 0;
-    if constexpr (DBJ) deform_bwd_lane_clear(dbl);
+  __shared__ Cam cam;
+  if (threadIdx.x < 16) {
+    cam.view[threadIdx.x] = viewmatrix[threadIdx.x];
+    cam.proj[threadIdx.x] = projmatrix[threadIdx.x];
   }
-  const int nrows = min((int) blockDim.x, P - base);
-  if (threadIdx.x < 16) cam.view[threadIdx.x] = cam_v, cam.proj[threadIdx.x] = cam_p;
-  if (threadIdx.x < 3) cam.campos[threadIdx.x] = cam_c;
+  if (threadIdx.x < 3) cam.campos[threadIdx.x] = campos[threadIdx.x];
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  // SH rows of this workgroup -> LDS; the gradient rows are built in the same LDS rows (sh_backward reads before it
+  // writes) and leave as one contiguous span at the end.  The DC term is not read by the backward.
+  extern __shared__ float s_sh[];
+  const bool staged = shs != nullptr && (dL_dsh != nullptr || sh_factors != nullptr);
+  const int RL      = shs_rest ? (M - 1) * 3 : M * 3;
+  const int base = blockIdx.x * blockDim.x, nrows = min((int) blockDim.x, P - base);
+  // Every per-Gaussian input is requested BEFORE the SH staging barrier, unconditionally: radius -> gradient row ->
+  // record -> mean / scale / rotation used to be a chain of dependent round trips behind `visible` (the kernel runs at
+  // ~1.5 waves per SIMD: its duration is the length of one lane's dependency chain).
+  int pf_radius = 0;
+  float4 pf_row[4], pf_rec[3], pf_q = make_float4(0.f, 0.f, 0.f, 1.f);
+  float pf_p[3] = {0.f, 0.f, 0.f}, pf_s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pf_row[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  pf_rec[0] = pf_rec[1] = pf_rec[2] = pf_row[0];
+  if (idx < P) {
+    pf_radius = radii[idx];
+    const float* row = gradacc + (size_t) idx * GRAD_ROW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pf_row[i] = stream_load4<NT_GRADROW_LOAD>(row + 4 * i);
+    pf_rec[0] = recs[3 * idx], pf_rec[1] = recs[3 * idx + 1], pf_rec[2] = recs[3 * idx + 2];
+    pf_p[0] = means3D[3 * idx], pf_p[1] = means3D[3 * idx + 1], pf_p[2] = means3D[3 * idx + 2];
+    if (scales) {
+      pf_s[0] = scales[3 * idx], pf_s[1] = scales[3 * idx + 1], pf_s[2] = scales[3 * idx + 2];
+      pf_q = reinterpret_cast<const float4*>(rotations)[idx];
+    }
+  }
+  DeformBwdLane dbl;  // (DBJ) the deform backward's own per-Gaussian inputs ride in the same round trip
+  if constexpr (DBJ) deform_bwd_prefetch(dbj, idx, idx < P, dbl);
   float dj_gm[3] = {0.f, 0.f, 0.f}, dj_gs[3] = {0.f, 0.f, 0.f}, dj_go = 0.f;
   float4 dj_gr = make_float4(0.f, 0.f, 0.f, 0.f);
   if (staged) stage_rows_in<PRE_BWD_THREADS, NT_SH_LOAD_BWD>(s_sh, (shs_rest ? shs_rest : shs) + (size_t) base * RL, nrows, RL);

@@ -7,6 +7,6 @@ for rep in $(seq 1 $reps); do
     python bench.py --steps 400 --no-cpu-baseline "$@" 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels']
-print('$which rep $rep', d['value'], d['ms_per_step'], {n:k[n]['us'] for n in k if 'skeleton' in n})"
+print('$which rep $rep', d['value'], d['ms_per_step'], {n:k[n]['us'] for n in k if 'skeleton' in n or 'preprocess' in n})"
   done
 done
