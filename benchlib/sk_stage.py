@@ -7,6 +7,7 @@ per-kernel pass, BASELINE's second metric (benchlib/render_protocol.py) and the 
 flag calls `run` once per exchange variant (benchlib/exchange_rank.py).
 """
 import os
+import sys
 from types import SimpleNamespace
 
 import torch
@@ -668,6 +669,18 @@ def run(args, env):
                                               chunk=1 if args.eager else t.steps_per_graph, train_chunk=None if args.eager else t.train_chunk)
     ordered_views = view_table is not None and getattr(view_table, 'order', None) is not None
     adam_desc = describe_adam(x, t)
+    if os.environ.get('SKGS_PRINT_LAYOUT'):  # (diagnostics: where the optimizer's arrays sit -- tools/run_spread.sh)
+        try:
+            opt = t.opt if hasattr(t, 'opt') else None
+            rows = []
+            for n_, p_ in model.named_parameters():
+                st_ = (opt.state.get(p_) if opt is not None else None) or {}
+                ptrs = [p_.data_ptr(), p_.grad.data_ptr() if p_.grad is not None else 0] + [v.data_ptr() for v in st_.values() if torch.is_tensor(v)]
+                if p_.numel() >= 100_000:
+                    rows.append(n_ + ':' + ','.join(f'{(a >> 12) & 0x1ff:03x}.{a & 0xfff:03x}' for a in ptrs))
+            print('[layout] (bits 12..20).(bits 0..11) of param, grad, state...: ' + ' '.join(rows), file=sys.stderr)
+        except Exception as e:  # noqa: BLE001
+            print('[layout] unavailable:', e, file=sys.stderr)
     prof = _C.profile_collect()
     _C.profile_enable([])
     replicas_identical, param_digest = timing.replicas_digest(model, world) if env.use_dist else (None, None)
