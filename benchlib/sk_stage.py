@@ -6,6 +6,7 @@ as captured hipGraphs (`build_steps`), warm-up, exactly args.steps timed steps b
 per-kernel pass, BASELINE's second metric (benchlib/render_protocol.py) and the JSON line.  A multi-rank run with no exchange
 flag calls `run` once per exchange variant (benchlib/exchange_rank.py).
 """
+import json
 import os
 import sys
 from types import SimpleNamespace
@@ -669,6 +670,10 @@ def run(args, env):
                                               chunk=1 if args.eager else t.steps_per_graph, train_chunk=None if args.eager else t.train_chunk)
     ordered_views = view_table is not None and getattr(view_table, 'order', None) is not None
     adam_desc = describe_adam(x, t)
+    if os.environ.get('SKGS_PRINT_DIGEST'):  # (diagnostics: what the timed steps trained -- tools/mode_equivalence.sh)
+        torch.cuda.synchronize()
+        dig = {n_: [float(p_.detach().double().sum()), float(p_.detach().double().norm())] for n_, p_ in model.named_parameters()}
+        print('[digest] ' + json.dumps(dig), file=sys.stderr)
     if os.environ.get('SKGS_PRINT_LAYOUT'):  # (diagnostics: where the optimizer's arrays sit -- tools/run_spread.sh)
         try:
             opt = t.opt if hasattr(t, 'opt') else None

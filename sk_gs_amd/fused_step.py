@@ -773,7 +773,8 @@ class FusedViewStep:
             m = self._mlp_fused.status()
             st['mlp_failed'] = m['failed']
             # launches whose network sat on ONE XCD by their own census, the exchange kept in its L2 (skgs_deform_mlp_xcd_mode)
-            st['mlp_one_xcd'] = dict(forward=[m['one_xcd_forward'], m['forward']], backward=[m['one_xcd_backward'], m['backward']])
+            st['mlp_one_xcd'] = dict(forward=[m['one_xcd_forward'], m['forward']], backward=[m['one_xcd_backward'], m['backward']],
+                                     xcds=[m['xcds_forward'], m['xcds_backward']])
         return st
 
 
