@@ -697,3 +697,28 @@ def test_where_the_deform_network_runs_by_default():
                         ({'SKGS_MLP_XCD': '0'}, '0 0 2')):
         p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120, env=dict(base, **extra))
         assert p.returncode == 0 and p.stdout.split() == want.split(), (extra, p.stdout, p.stderr[-500:])
+
+
+def test_one_xcd_role_map_of_the_fused_network_launch():
+    """csrc/mlp_fused.hip::role_of restated: in the one-XCD placement blocks 0, 8, .. 8 (G - 1) are the network's workgroups g = b / 8, every
+    other block is a side workgroup, and the side indices are exactly 0 .. n_side - 1 (each share of the optimizer's chunks is taken once)
+    for every grid the launcher can produce (249: no side job .. 256: a side workgroup on every other CU)"""
+    G = 32
+
+    def role(b, grid):
+        low = b < 8 * G
+        net = low and b % 8 == 0
+        before = (b >> 3) + 1 if low else G
+        return net, b >> 3, b - before, grid - G
+
+    for grid in range(8 * G - 7, 8 * G + 1):
+        nets, sides = [], []
+        for b in range(grid):
+            net, g, wg, n_side = role(b, grid)
+            (nets if net else sides).append(g if net else wg)
+            assert n_side == grid - G
+        assert nets == list(range(G)), grid
+        assert sorted(sides) == list(range(grid - G)), grid
+    src = open(os.path.join(ROOT, 'sk_gs_amd', 'csrc', 'mlp_fused.hip')).read()     # (the restated lines are the ones in the source)
+    assert 'const bool net = low && (b & 7) == 0;' in src and 'const int before = low ? (b >> 3) + 1 : G_NET;' in src
+    assert 'grid = std::max(grid, 8 * p.G - 7);' in src
