@@ -694,6 +694,9 @@ typedef struct skgs_bone_chain_desc {
 int skgs_skeleton_forward(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, const float* points, const float* t,
     float* x0, float* acts, void* workspace, size_t workspace_bytes, const skgs_adam_range* side /* may be NULL */,
     skgs_stream_t stream);
+/* skgs_skeleton_backward follows the skgs_skeleton_forward of the SAME frame on the SAME workspace (as it must for `acts` and
+ * `chain_A`): with a [frames,7] table it takes the frame's row of global_T from the copy that forward left in the workspace header
+ * (words 8..14) instead of loading it through frame_index[0] again. */
 int skgs_skeleton_backward(const skgs_mlp_desc* d, const skgs_bone_chain_desc* bones, const float* points, const float* t,
     const float* x0, const float* acts, float* g_x0, void* workspace, size_t workspace_bytes, const skgs_adam_range* side,
     skgs_stream_t stream);
